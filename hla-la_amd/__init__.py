@@ -1,0 +1,294 @@
+"""ctypes binding of libhlala_gpu.so (the C ABI in include/hlala_gpu.h).
+
+This package is plumbing for tests and bench.py: the product is the shared library built from
+csrc/ (hand-written HIP for gfx950 behind a plain C ABI).  There is NO CPU fallback here: if
+the library or a GPU is missing, loading/creating fails loudly.
+
+The directory name has a hyphen (repo layout contract), so import it through
+`importlib` -- see `tests/conftest.py` / `__graft_entry__.py` (`load_package()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhlala_gpu.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+c_u32p = C.POINTER(C.c_uint32)
+c_f64p = C.POINTER(C.c_double)
+
+CHAIN_OK, CHAIN_SKIP_STRAND, CHAIN_SKIP_DUP = 0, 1, 2
+CHAIN_ERR_COLUMNS, CHAIN_ERR_FRONTIER, CHAIN_ERR_INPUT = -1, -2, -3
+
+
+class GraphDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
+                ("node_level", c_i32p), ("edge_from", c_i32p), ("edge_to", c_i32p), ("edge_label", c_u8p)]
+
+
+class ContigsDesc(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("contig_off", c_i64p), ("contig_seq", c_u8p),
+                ("contig_level", c_i32p), ("contig_seqid", c_i32p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("insert_mean", C.c_double), ("insert_sd", C.c_double), ("rng_seed", C.c_uint32),
+                ("long_read_mode", C.c_int32), ("max_columns", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("n_nodes", C.c_int32), ("n_edges", C.c_int32), ("n_paths", C.c_int32),
+                ("n_jump_entries", C.c_int64), ("n_path_edges", C.c_int64), ("n_levelpos_entries", C.c_int64),
+                ("max_nodes_per_level", C.c_int32), ("max_out_degree", C.c_int32), ("max_in_degree", C.c_int32),
+                ("n_gap_stretch_levels", C.c_int32)]
+
+
+class BatchIn(C.Structure):
+    _fields_ = [("n_pairs", C.c_int32), ("read_off", c_i32p), ("read_bases", c_u8p), ("read_quals", c_u8p),
+                ("chain_off", c_i32p), ("read_primary", c_i32p), ("n_chains", C.c_int32),
+                ("chain_contig", c_i32p), ("chain_pos", c_i32p), ("chain_offset", c_i32p), ("chain_as", c_i32p),
+                ("chain_reverse", c_u8p), ("cigar_off", c_i32p), ("cigar", c_u32p)]
+
+
+class SeedsIn(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("read_off", c_i32p), ("read_bases", c_u8p), ("read_quals", c_u8p),
+                ("n_chains", C.c_int32), ("chain_read", c_i32p), ("chain_seq_begin", c_i32p),
+                ("chain_seq_end", c_i32p), ("chain_reverse", c_u8p), ("col_off", c_i32p), ("col_level", c_i32p),
+                ("col_edge", c_i32p), ("col_gchar", c_u8p), ("col_schar", c_u8p)]
+
+
+class ChainsOut(C.Structure):
+    _fields_ = [("status", c_i32p), ("n_cols", c_i32p), ("seq_begin", c_i32p), ("seq_end", c_i32p),
+                ("removed_cols", c_i32p), ("ll", c_f64p), ("dp_iters", c_i32p), ("dp_score", c_i32p),
+                ("col_level", c_i32p), ("col_edge", c_i32p), ("col_gchar", c_u8p), ("col_schar", c_u8p),
+                ("col_fromseed", c_u8p)]
+
+
+class PairsOut(C.Structure):
+    _fields_ = [("pair_status", c_i32p), ("best_chain", c_i32p), ("n_combinations", c_i32p),
+                ("pair_ll", c_f64p), ("pair_mapq", c_f64p), ("mate_mapq", c_f64p), ("strands_valid", c_u8p),
+                ("n_cols", c_i32p), ("col_level", c_i32p), ("col_edge", c_i32p), ("col_gchar", c_u8p),
+                ("col_schar", c_u8p), ("col_fromseed", c_u8p), ("col_mapq", c_u8p)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("ms_project", C.c_float), ("ms_extend", C.c_float), ("ms_pair", C.c_float),
+                ("n_chains_extended", C.c_int64), ("n_dp_calls", C.c_int64), ("n_dp_iterations", C.c_int64),
+                ("n_dp_cells", C.c_int64), ("n_seed_columns", C.c_int64), ("n_out_columns", C.c_int64),
+                ("n_edges_touched", C.c_int64), ("n_errors", C.c_int64)]
+
+
+_DT = {c_i32p: np.int32, c_i64p: np.int64, c_u8p: np.uint8, c_u32p: np.uint32, c_f64p: np.float64}
+
+
+def fill_struct(cls, d):
+    """Build a ctypes struct from a dict of numpy arrays / scalars.  Returns (struct, keepalive)."""
+    s = cls()
+    keep = []
+    for name, ctype in cls._fields_:
+        if name not in d or d[name] is None:
+            continue
+        if ctype in _DT:
+            a = np.ascontiguousarray(d[name], dtype=_DT[ctype])
+            keep.append(a)
+            setattr(s, name, a.ctypes.data_as(ctype))
+        else:
+            setattr(s, name, d[name])
+    return s, keep
+
+
+def alloc_chains_out(n_chains, stride):
+    d = dict(status=np.zeros(n_chains, np.int32), n_cols=np.zeros(n_chains, np.int32),
+             seq_begin=np.zeros(n_chains, np.int32), seq_end=np.zeros(n_chains, np.int32),
+             removed_cols=np.zeros(n_chains, np.int32), ll=np.zeros(n_chains, np.float64),
+             dp_iters=np.zeros(2 * n_chains, np.int32), dp_score=np.zeros(2 * n_chains, np.int32),
+             col_level=np.zeros(n_chains * stride, np.int32), col_edge=np.zeros(n_chains * stride, np.int32),
+             col_gchar=np.zeros(n_chains * stride, np.uint8), col_schar=np.zeros(n_chains * stride, np.uint8),
+             col_fromseed=np.zeros(n_chains * stride, np.uint8))
+    s, keep = fill_struct(ChainsOut, d)
+    d["_stride"] = stride
+    return s, d
+
+
+def alloc_pairs_out(n_pairs, stride):
+    n2 = 2 * n_pairs
+    d = dict(pair_status=np.zeros(n_pairs, np.int32), best_chain=np.zeros(n2, np.int32),
+             n_combinations=np.zeros(n_pairs, np.int32), pair_ll=np.zeros(n_pairs, np.float64),
+             pair_mapq=np.zeros(n_pairs, np.float64), mate_mapq=np.zeros(n2, np.float64),
+             strands_valid=np.zeros(n_pairs, np.uint8), n_cols=np.zeros(n2, np.int32),
+             col_level=np.zeros(n2 * stride, np.int32), col_edge=np.zeros(n2 * stride, np.int32),
+             col_gchar=np.zeros(n2 * stride, np.uint8), col_schar=np.zeros(n2 * stride, np.uint8),
+             col_fromseed=np.zeros(n2 * stride, np.uint8), col_mapq=np.zeros(n2 * stride, np.uint8))
+    s, keep = fill_struct(PairsOut, d)
+    d["_stride"] = stride
+    return s, d
+
+
+class HlalaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Load libhlala_gpu.so.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HlalaError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(p)
+    vp = C.c_void_p
+    lib.hlala_create.argtypes = [C.POINTER(vp), C.c_int, vp, C.POINTER(GraphDesc), C.POINTER(ContigsDesc), C.POINTER(Params)]
+    lib.hlala_create.restype = C.c_int
+    lib.hlala_destroy.argtypes = [vp]
+    lib.hlala_destroy.restype = None
+    lib.hlala_last_error.argtypes = [vp]
+    lib.hlala_last_error.restype = C.c_char_p
+    lib.hlala_graph_get_info.argtypes = [vp, C.POINTER(GraphInfo)]
+    lib.hlala_graph_get_nodes.argtypes = [vp, c_i32p, c_i32p]
+    lib.hlala_graph_get_paths.argtypes = [vp, c_i32p, c_i32p, c_i32p]
+    lib.hlala_graph_get_gap_stretch.argtypes = [vp, c_u8p]
+    lib.hlala_batch_create.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(vp)]
+    lib.hlala_batch_create_from_seeds.argtypes = [vp, C.POINTER(SeedsIn), C.POINTER(vp)]
+    lib.hlala_batch_destroy.argtypes = [vp]
+    lib.hlala_batch_destroy.restype = None
+    for f in ("hlala_project_chains", "hlala_extend_chains", "hlala_pair_chains", "hlala_align_batch"):
+        getattr(lib, f).argtypes = [vp, vp]
+        getattr(lib, f).restype = C.c_int
+    lib.hlala_batch_get_chains.argtypes = [vp, vp, C.c_int, C.POINTER(ChainsOut)]
+    lib.hlala_batch_get_pairs.argtypes = [vp, vp, C.POINTER(PairsOut)]
+    lib.hlala_batch_get_stats.argtypes = [vp, vp, C.POINTER(BatchStats)]
+    lib.hlala_kat_phred.argtypes = [vp, C.c_int, c_f64p, c_u8p, c_u8p, c_f64p]
+    lib.hlala_kat_rand_r.argtypes = [vp, C.c_int, c_u32p, c_i32p]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "hlala_create", "hlala_destroy", "hlala_last_error", "hlala_graph_get_info", "hlala_graph_get_nodes",
+    "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
+    "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
+    "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
+    "hlala_batch_get_stats", "hlala_kat_phred", "hlala_kat_rand_r",
+]
+
+
+class Context:
+    """hlala_ctx wrapper: uploads the flattened graph once (hlala_create)."""
+
+    def __init__(self, graph: dict, contigs: dict | None, insert_mean=200.0, insert_sd=35.0, rng_seed=12345,
+                 long_read_mode=0, max_columns=384, device=0, stream=None):
+        self.lib = load_library()
+        self.max_columns = max_columns
+        g, self._kg = fill_struct(GraphDesc, graph)
+        self.params = Params(insert_mean, insert_sd, rng_seed, long_read_mode, max_columns, 0)
+        h = C.c_void_p()
+        if contigs is not None:
+            c, self._kc = fill_struct(ContigsDesc, contigs)
+            cp = C.byref(c)
+        else:
+            cp = None
+        rc = self.lib.hlala_create(C.byref(h), device, C.c_void_p(stream or 0), C.byref(g), cp, C.byref(self.params))
+        if rc != 0:
+            msg = self.lib.hlala_last_error(None)
+            raise HlalaError(f"hlala_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.h = h
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.hlala_last_error(self.h)
+            raise HlalaError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def graph_info(self) -> GraphInfo:
+        gi = GraphInfo()
+        self._check(self.lib.hlala_graph_get_info(self.h, C.byref(gi)), "hlala_graph_get_info")
+        return gi
+
+    def graph_paths(self):
+        gi = self.graph_info()
+        a = [np.zeros(gi.n_paths, np.int32) for _ in range(3)]
+        self._check(self.lib.hlala_graph_get_paths(self.h, *[x.ctypes.data_as(c_i32p) for x in a]), "hlala_graph_get_paths")
+        return a
+
+    def graph_gap_stretch(self):
+        gi = self.graph_info()
+        a = np.zeros(gi.n_levels - 1, np.uint8)
+        self._check(self.lib.hlala_graph_get_gap_stretch(self.h, a.ctypes.data_as(c_u8p)), "hlala_graph_get_gap_stretch")
+        return a
+
+    def batch(self, batch_in: dict) -> "Batch":
+        s, keep = fill_struct(BatchIn, batch_in)
+        b = C.c_void_p()
+        self._check(self.lib.hlala_batch_create(self.h, C.byref(s), C.byref(b)), "hlala_batch_create")
+        return Batch(self, b, batch_in["n_chains"], batch_in["n_pairs"])
+
+    def batch_from_seeds(self, seeds_in: dict) -> "Batch":
+        s, keep = fill_struct(SeedsIn, seeds_in)
+        b = C.c_void_p()
+        self._check(self.lib.hlala_batch_create_from_seeds(self.h, C.byref(s), C.byref(b)), "hlala_batch_create_from_seeds")
+        return Batch(self, b, seeds_in["n_chains"], 0)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hlala_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    def __init__(self, ctx: Context, b, n_chains, n_pairs):
+        self.ctx, self.b, self.n_chains, self.n_pairs = ctx, b, n_chains, n_pairs
+
+    def project(self):
+        self.ctx._check(self.ctx.lib.hlala_project_chains(self.ctx.h, self.b), "hlala_project_chains")
+
+    def extend(self):
+        self.ctx._check(self.ctx.lib.hlala_extend_chains(self.ctx.h, self.b), "hlala_extend_chains")
+
+    def pair(self):
+        self.ctx._check(self.ctx.lib.hlala_pair_chains(self.ctx.h, self.b), "hlala_pair_chains")
+
+    def align(self):
+        self.ctx._check(self.ctx.lib.hlala_align_batch(self.ctx.h, self.b), "hlala_align_batch")
+
+    def chains(self, stage: int) -> dict:
+        s, d = alloc_chains_out(self.n_chains, self.ctx.max_columns)
+        self.ctx._check(self.ctx.lib.hlala_batch_get_chains(self.ctx.h, self.b, stage, C.byref(s)), "hlala_batch_get_chains")
+        return d
+
+    def pairs(self) -> dict:
+        s, d = alloc_pairs_out(self.n_pairs, self.ctx.max_columns)
+        self.ctx._check(self.ctx.lib.hlala_batch_get_pairs(self.ctx.h, self.b, C.byref(s)), "hlala_batch_get_pairs")
+        return d
+
+    def stats(self) -> BatchStats:
+        st = BatchStats()
+        self.ctx._check(self.ctx.lib.hlala_batch_get_stats(self.ctx.h, self.b, C.byref(st)), "hlala_batch_get_stats")
+        return st
+
+    def close(self):
+        if getattr(self, "b", None):
+            self.ctx.lib.hlala_batch_destroy(self.b)
+            self.b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

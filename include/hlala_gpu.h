@@ -1,0 +1,242 @@
+/*
+ * hlala_gpu.h -- C ABI of libhlala_gpu.so, the MI355X (gfx950) implementation of HLA*LA's
+ * read-to-PRG alignment hot path.
+ *
+ * The reference (DiltheyLab/HLA-LA) has no FFI seam: the path is reached through C++ member
+ * calls inside one binary.  Every entry point below therefore names the reference member
+ * function(s) it stands in for (file:line in the reference tree), so that a maintainer can
+ * swap the call (see INTEGRATION.md for the binding code).
+ *
+ * Conventions
+ *  - plain C, no exceptions cross the boundary; every function returns 0 on success and a
+ *    negative HLALA_E_* code on failure; hlala_last_error() gives the text.
+ *  - the caller owns every host buffer; the library owns device memory behind the handles.
+ *  - one hlala_ctx per GPU/process; calls on one ctx are serialised by the caller.
+ *  - all indices are 0-based; "level" is a PRG graph level as in the reference
+ *    (Graph::NodesPerLevel index); level -1 marks a read base aligned against nothing.
+ *  - node rank z within a level, edge order within a node and jump order are CANONICAL:
+ *    creation order in graph.txt (the reference uses heap-pointer order).
+ */
+#ifndef HLALA_GPU_H_
+#define HLALA_GPU_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HLALA_OK              0
+#define HLALA_E_ARG          -1   /* bad argument / inconsistent sizes              */
+#define HLALA_E_DEVICE       -2   /* HIP runtime error, no device, no kernel image  */
+#define HLALA_E_GRAPH        -3   /* graph violates the levelled-DAG invariants     */
+#define HLALA_E_CAPACITY     -4   /* a fixed device capacity was exceeded           */
+#define HLALA_E_STATE        -5   /* call sequence error (stage not run yet, ...)   */
+
+/* per-chain status (hlala_chains_out.status) */
+#define HLALA_CHAIN_OK             0  /* projected, extended and scored                             */
+#define HLALA_CHAIN_SKIP_STRAND    1  /* strand differs from the primary's (processBAM.cpp:3216)     */
+#define HLALA_CHAIN_SKIP_DUP       2  /* same start//stop id seen with >= AS (processBAM.cpp:3234)   */
+#define HLALA_CHAIN_ERR_COLUMNS   -1  /* more alignment columns than params.max_columns              */
+#define HLALA_CHAIN_ERR_FRONTIER  -2  /* DP frontier / candidate / cell capacity exceeded            */
+#define HLALA_CHAIN_ERR_INPUT     -3  /* CIGAR/coordinates the reference would assert or throw on    */
+
+/* ------------------------------------------------------------------------------------------
+ * Graph: replaces Graph::readFromFile's in-memory result (Graph/Graph.cpp:2329-2559) as input to
+ * alignerBase::alignerBase (mapper/aligner/alignerBase.cpp:16-38), Graph::computeGapEdgePaths
+ * (Graph/Graph.cpp:347-476) and the gap-stretch scan of processBAM::processBAM
+ * (mapper/processBAM.cpp:91-149).  Arrays are in graph.txt creation order.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t        n_levels;    /* number of node levels L; edges connect level l -> l+1      */
+    int32_t        n_nodes;
+    int32_t        n_edges;
+    const int32_t* node_level;  /* [n_nodes]                                                  */
+    const int32_t* edge_from;   /* [n_edges] node index                                       */
+    const int32_t* edge_to;     /* [n_edges] node index                                       */
+    const uint8_t* edge_label;  /* [n_edges] decoded emission char: 'A','C','G','T','N','_','*' */
+} hlala_graph_desc;
+
+/* Linear reference contigs the seeds were aligned to, with their position->level tables:
+ * replaces processBAM::{extendedReferenceGenomeSequences,PRGonlyReferenceGenomeSequences} and
+ * processBAM::_loadMapping (mapper/processBAM.cpp:4389-4457).  All tables are loaded up front
+ * (SURVEY.md Appendix A3 note on load order). */
+typedef struct {
+    int32_t        n_contigs;
+    const int64_t* contig_off;   /* [n_contigs+1] offsets into contig_seq / contig_level       */
+    const uint8_t* contig_seq;   /* bases                                                      */
+    const int32_t* contig_level; /* translation/<SequenceID>.txt: graph level of each position */
+    const int32_t* contig_seqid; /* [n_contigs] PRG SequenceID (key order of the insert-size scan) */
+} hlala_contigs_desc;
+
+typedef struct {
+    double   insert_mean;        /* boost::math::normal(IS_mean, IS_sd), processBAM.cpp:2342    */
+    double   insert_sd;
+    uint32_t rng_seed;           /* base of extensionAligner::rng_seeds (extensionAligner.h:38):
+                                    the DP of chain c, direction d (0 = left, 1 = right) starts
+                                    from seed rng_seed + 2*c + d, c = absolute chain index       */
+    int32_t  long_read_mode;     /* 0: indel rate 0.001; !=0: 0.075 (extensionAligner.cpp:58-64) */
+    int32_t  max_columns;        /* per-chain alignment column capacity (stride of col_* arrays) */
+    int32_t  reserved;
+} hlala_params;
+
+typedef struct hlala_ctx   hlala_ctx;
+typedef struct hlala_batch hlala_batch;
+
+/* Build the device-resident CSR (levels, per-node ordered edge lists, gap-path jump tables,
+ * gap-stretch bitmap, level->(sequence,position) table) once.  `stream` is a hipStream_t (may
+ * be NULL for the default stream); all kernels of this ctx are launched on it.              */
+int  hlala_create(hlala_ctx** out, int device, void* stream,
+                  const hlala_graph_desc* graph, const hlala_contigs_desc* contigs,
+                  const hlala_params* params);
+void hlala_destroy(hlala_ctx* ctx);
+const char* hlala_last_error(const hlala_ctx* ctx);   /* ctx may be NULL: create-time errors */
+
+/* Flattened-graph introspection (parity of the one-time host pass with the oracle).          */
+typedef struct {
+    int32_t n_levels, n_nodes, n_edges, n_paths;
+    int64_t n_jump_entries, n_path_edges, n_levelpos_entries;
+    int32_t max_nodes_per_level, max_out_degree, max_in_degree, n_gap_stretch_levels;
+} hlala_graph_info;
+int hlala_graph_get_info(const hlala_ctx* ctx, hlala_graph_info* info);
+/* node renumbering: device node id -> creation index, [n_nodes]; level offsets [n_levels+1] */
+int hlala_graph_get_nodes(const hlala_ctx* ctx, int32_t* node_orig, int32_t* level_off);
+/* completed gap-edge paths in completedGapEdgePaths order (Graph.cpp:417): first/last node
+ * (creation idx) and length, [n_paths] each; path_edges may be NULL                         */
+int hlala_graph_get_paths(const hlala_ctx* ctx, int32_t* first_node, int32_t* last_node,
+                          int32_t* length);
+int hlala_graph_get_gap_stretch(const hlala_ctx* ctx, uint8_t* in_stretch /* [n_levels-1] */);
+
+/* ------------------------------------------------------------------------------------------
+ * One batch of read pairs with their BWA alignments ("proto seeds", mapper/reads/protoSeeds.h):
+ * read 2p is mate 1 of pair p, read 2p+1 is mate 2.  Bases/qualities are those of the mate's
+ * PRIMARY alignment in alignment orientation (processBAM.cpp:3142-3145); chains of a read are
+ * its BAM records in AS-descending order (processBAM.cpp:1945).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t         n_pairs;
+    const int32_t*  read_off;      /* [2n+1] offsets into read_bases / read_quals               */
+    const uint8_t*  read_bases;    /* ASCII                                                     */
+    const uint8_t*  read_quals;    /* ASCII Phred+33                                            */
+    const int32_t*  chain_off;     /* [2n+1] chains of read r: [chain_off[r], chain_off[r+1])   */
+    const int32_t*  read_primary;  /* [2n] absolute chain index of the read's primary alignment */
+    int32_t         n_chains;
+    const int32_t*  chain_contig;  /* [n_chains] index into hlala_contigs_desc                  */
+    const int32_t*  chain_pos;     /* [n_chains] BamAlignment::Position (0-based leftmost)      */
+    const int32_t*  chain_offset;  /* [n_chains] reference2level_offset (interval start)        */
+    const int32_t*  chain_as;      /* [n_chains] AS tag                                         */
+    const uint8_t*  chain_reverse; /* [n_chains] IsReverseStrand()                              */
+    const int32_t*  cigar_off;     /* [n_chains+1]                                              */
+    const uint32_t* cigar;         /* BAM encoding: len<<4 | op, op index into "MIDNSHP=X"      */
+} hlala_batch_in;
+
+/* Seed chains handed over directly, bypassing the BAM projection: the protocol of
+ * `--action testChainExtension` (HLA-LA.cpp:1733-1861) and the input type of
+ * extensionAligner::extendSeedChain (mapper/aligner/extensionAligner.cpp:186).  Chain c
+ * belongs to read chain_read[c]; columns of chain c are [col_off[c], col_off[c+1]).          */
+typedef struct {
+    int32_t         n_reads;
+    const int32_t*  read_off;       /* [n_reads+1] */
+    const uint8_t*  read_bases;
+    const uint8_t*  read_quals;
+    int32_t         n_chains;
+    const int32_t*  chain_read;     /* [n_chains] */
+    const int32_t*  chain_seq_begin;/* verboseSeedChain::sequence_begin */
+    const int32_t*  chain_seq_end;  /* verboseSeedChain::sequence_end   */
+    const uint8_t*  chain_reverse;
+    const int32_t*  col_off;        /* [n_chains+1] */
+    const int32_t*  col_level;      /* graph_aligned_levels */
+    const int32_t*  col_edge;       /* graph_aligned_edges as edge creation index, -1 = none */
+    const uint8_t*  col_gchar;      /* graph_aligned    */
+    const uint8_t*  col_schar;      /* sequence_aligned */
+} hlala_seeds_in;
+
+/* Chain-level results (mapper::reads::verboseSeedChain, verboseSeedChain.h:22-50), fixed
+ * stride = params.max_columns columns per chain.  Any pointer may be NULL to skip it.       */
+typedef struct {
+    int32_t* status;        /* [n_chains] HLALA_CHAIN_*                                      */
+    int32_t* n_cols;        /* [n_chains]                                                    */
+    int32_t* seq_begin;     /* [n_chains]                                                    */
+    int32_t* seq_end;       /* [n_chains]                                                    */
+    int32_t* removed_cols;  /* [n_chains] removed_columns_noGap_restriction (seed stage)     */
+    double*  ll;            /* [n_chains] scoreOneAlignment (extended stage only)            */
+    int32_t* dp_iters;      /* [2*n_chains] DP iterations run, left/right (extended stage)   */
+    int32_t* dp_score;      /* [2*n_chains] score of the DP end cell, INT32_MIN = no extension */
+    int32_t* col_level;     /* [n_chains*stride]                                             */
+    int32_t* col_edge;      /* [n_chains*stride] edge creation index, -1 = none              */
+    uint8_t* col_gchar;     /* [n_chains*stride]                                             */
+    uint8_t* col_schar;     /* [n_chains*stride]                                             */
+    uint8_t* col_fromseed;  /* [n_chains*stride] is_from_BWAseed                             */
+} hlala_chains_out;
+
+/* Pair-level results (mapper::reads::verboseSeedChainPair, verboseSeedChain.h:318-346):
+ * the selected chain of each mate with mapping qualities.                                   */
+typedef struct {
+    int32_t* pair_status;   /* [n] 0 ok, <0: a chain of the pair hit an HLALA_CHAIN_ERR_*    */
+    int32_t* best_chain;    /* [2n] absolute chain index selected for each mate              */
+    int32_t* n_combinations;/* [n] read1_extendedChains.size()*read2_extendedChains.size()   */
+    double*  pair_ll;       /* [n] combinations_max.first (processBAM.cpp:3538)              */
+    double*  pair_mapq;     /* [n] verboseSeedChainPair::mapQ                                */
+    double*  mate_mapq;     /* [2n] verboseSeedChain::mapQ                                   */
+    uint8_t* strands_valid; /* [n] alignedReadPair_strandsValid of the selected pair         */
+    int32_t* n_cols;        /* [2n]                                                          */
+    int32_t* col_level;     /* [2n*stride]                                                   */
+    int32_t* col_edge;      /* [2n*stride]                                                   */
+    uint8_t* col_gchar;     /* [2n*stride]                                                   */
+    uint8_t* col_schar;     /* [2n*stride]                                                   */
+    uint8_t* col_fromseed;  /* [2n*stride]                                                   */
+    uint8_t* col_mapq;      /* [2n*stride] mapQ_perPosition (Phred char)                     */
+} hlala_pairs_out;
+
+/* Upload a batch: inputs become resident in HBM; nothing is computed.                       */
+int  hlala_batch_create(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** out);
+/* Upload seed chains directly (stage A is then not available on this batch).                */
+int  hlala_batch_create_from_seeds(hlala_ctx* ctx, const hlala_seeds_in* in, hlala_batch** out);
+void hlala_batch_destroy(hlala_batch* b);
+
+/* Stage A -- processBAM::alignment2Chain (mapper/processBAM.cpp:3019-3127) for every chain that
+ * survives the strand / duplicate-coordinate filters of alignOneReadPair (:3200-3240):
+ * transformBAMreadToInternalAlignment (:4794), PRGContigAlignment2Seed (:2491) incl.
+ * cleanInitialAlignment (:4621) and restrictInitialAlignmentToNoGapAreas (:4461).           */
+int  hlala_project_chains(hlala_ctx* ctx, hlala_batch* b);
+/* Stage B -- extensionAligner::extendSeedChain (mapper/aligner/extensionAligner.cpp:186-333)
+ * = fullNeedleman_diagonal_extension_gapJumper (:335-1556) left and right, stitching
+ * (verboseSeedChain.cpp:23-136), then extensionAligner::scoreOneAlignment (:52-182).         */
+int  hlala_extend_chains(hlala_ctx* ctx, hlala_batch* b);
+/* Stage C -- the pairing loop of processBAM::alignOneReadPair (mapper/processBAM.cpp:3408-3546)
+ * and processBAM::assignMappingQualities (:4062-4312).                                       */
+int  hlala_pair_chains(hlala_ctx* ctx, hlala_batch* b);
+/* A + B + C: processBAM::alignOneReadPair (mapper/processBAM.cpp:3129-3616) over the batch.   */
+int  hlala_align_batch(hlala_ctx* ctx, hlala_batch* b);
+
+/* Download results (synchronises the stream).  `stage` 0 = seed chains after stage A,
+ * 1 = extended chains after stage B.                                                         */
+int  hlala_batch_get_chains(hlala_ctx* ctx, hlala_batch* b, int stage, hlala_chains_out* out);
+int  hlala_batch_get_pairs(hlala_ctx* ctx, hlala_batch* b, hlala_pairs_out* out);
+
+/* Per-stage statistics of the last hlala_align_batch / stage call on this batch, measured
+ * with HIP events on the ctx stream (ms) plus work counters reduced on the device.          */
+typedef struct {
+    float   ms_project, ms_extend, ms_pair;
+    int64_t n_chains_extended;    /* chains with status OK                        */
+    int64_t n_dp_calls;           /* DP invocations (left + right)                */
+    int64_t n_dp_iterations;      /* sum of DP iterations                         */
+    int64_t n_dp_cells;           /* candidate target cells evaluated             */
+    int64_t n_seed_columns;       /* columns of all projected seed chains         */
+    int64_t n_out_columns;        /* columns of all extended chains               */
+    int64_t n_edges_touched;      /* CSR edge records read by stages A and B      */
+    int64_t n_errors;             /* chains with status < 0                       */
+} hlala_batch_stats;
+int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
+
+/* Known-answer helpers exported for the parity tests (device implementations of
+ * Utilities::PCorrectToPhred / PhredToPCorrect, Utilities.cpp:178-203, 357-377, and of glibc
+ * rand_r as used by Utilities::randomNumber_nonCritical, Utilities.cpp:922).                 */
+int  hlala_kat_phred(hlala_ctx* ctx, int n, const double* p_correct, uint8_t* phred_out,
+                     const uint8_t* phred_in, double* p_out);
+int  hlala_kat_rand_r(hlala_ctx* ctx, int n, uint32_t* seeds_inout, int32_t* values_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HLALA_GPU_H_ */

@@ -1,0 +1,1394 @@
+/*
+ * hlala_oracle.cpp -- CPU restatement of HLA*LA's read-to-PRG alignment hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product (libhlala_gpu.so) never links or calls it.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):  the reference cannot be compiled in this image
+ * (every translation unit on the path includes Boost and BamTools headers, which are absent,
+ * and stand-ins are not allowed), so there is no oracle/_ref.  The restatement is pinned on
+ * the known-answer material the reference itself carries for this path -- the
+ * intervalsOverlap asserts (HLA-LA.cpp:94-102), the Phred round-trip table
+ * (mapper/processBAM.cpp:4229-4239), the `--action testChainExtension` protocol
+ * (HLA-LA.cpp:1733-1861: extended chain must re-spell the read) and the paranoid invariants
+ * (verboseSeedChain.cpp:48-77, verboseSeedChain.h:282-315) -- and on glibc's own rand_r.
+ * The DP cell values / tie-breaks themselves have NO golden vectors in the reference:
+ * for those, parity is UNPINNED beyond the line-by-line restatement below.
+ *
+ * Every function cites the reference file:line it follows.  Data structures deliberately
+ * keep the reference's std::map / std::set iteration orders (with node/edge creation index
+ * standing in for heap-pointer order) so that tie-breaking is inherited
+ * by construction rather than re-derived.
+ */
+#include "../include/hlala_gpu.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace orc {
+
+struct oracle_error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+#define ORC_CHECK(cond, msg) do { if(!(cond)) throw oracle_error(std::string("oracle check failed: ") + msg + " [" #cond "]"); } while(0)
+
+/* ---------------------------------------------------------------- Utilities.cpp helpers */
+
+/* Utilities::intervalsOverlap, Utilities.cpp:168-176 */
+static bool intervalsOverlap(int x1, int x2, int y1, int y2)
+{
+    return (x1 >= y1 && x1 <= y2) || (x2 >= y1 && x2 <= y2) || (y1 >= x1 && y1 <= x2) || (y2 >= x1 && y2 <= x2);
+}
+
+/* Utilities::PCorrectToPhred, Utilities.cpp:178-203 */
+static unsigned char PCorrectToPhred(double PCorrect)
+{
+    double pWrong = 1 - PCorrect;
+    if(pWrong == 0) pWrong = 1e-100;
+    double phred1 = -10.0 * log10(pWrong);
+    if((phred1 + 33) > 255) phred1 = 255 - 33;
+    int r = (int)round(phred1 + 33);
+    return (unsigned char)r;
+}
+
+/* Utilities::PhredToPCorrect, Utilities.cpp:357-377 */
+static double PhredToPCorrect(unsigned char q)
+{
+    if(q == 0) return -1;
+    int illuminaPhred = (int)q - 33;
+    double log10_pWrong = (double)illuminaPhred / (double)-10;
+    double pWrong = exp(log(10) * log10_pWrong);
+    return 1 - pWrong;
+}
+
+/* Utilities::findVectorMax / findVectorMaxP_nonCritical, Utilities.cpp:309-323, 379-406:
+ * only a strictly greater element replaces the maximum, so the FIRST maximum wins and the RNG
+ * branch (iMaxs.size() > 1) is unreachable. */
+static std::pair<double, unsigned> firstMax(const std::vector<double>& v)
+{
+    double mx = 0; unsigned iMax = 0;
+    for(unsigned i = 0; i < v.size(); i++)
+        if(i == 0 || v[i] > mx) { mx = v[i]; iMax = i; }
+    return {mx, iMax};
+}
+
+/* Utilities::seq_reverse_complement's per-character map, Utilities.cpp:1170-1200 */
+static char complementChar(char c)
+{
+    switch(c) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+        default: return c;
+    }
+}
+
+/* boost::math::pdf(normal_distribution, x), boost/math/distributions/normal.hpp (Boost >= 1.59,
+ * un-vendored, README.md:42): exponent = -(x-mean)^2 / (2 sd^2); exp(exponent) / (sd*sqrt(2 pi)).
+ * Call sites processBAM.cpp:2343, 3446.  Parity with a real Boost build is unpinned. */
+static double normal_pdf(double mean, double sd, double x)
+{
+    double exponent = x - mean;
+    exponent *= -exponent;
+    exponent /= 2 * sd * sd;
+    double result = exp(exponent);
+    result /= sd * sqrt(2 * 3.141592653589793238462643383279502884);
+    return result;
+}
+
+/* --------------------------------------------------------------------------- the graph */
+
+struct Graph {
+    int L = 0;
+    std::vector<int> node_level;
+    std::vector<int> efrom, eto;
+    std::vector<unsigned char> elabel;
+    std::vector<std::vector<int>> level_nodes;   /* alignerBase::nodesPerLevel_ordered, alignerBase.cpp:27-37 */
+    std::vector<int> node_rank;                  /* nodesPerLevel_ordered_rev                                 */
+    std::vector<std::vector<int>> out_e, in_e;   /* Node::Outgoing_Edges / Incoming_Edges in set order        */
+    std::vector<std::vector<int>> paths;         /* Graph::completedGapEdgePaths                              */
+    std::map<int, std::map<int, int>> jump_fwd;  /* gapEdgePaths_connectedNodes_forwards: first -> last -> path */
+    std::map<int, std::map<int, int>> jump_bwd;  /* gapEdgePaths_connectedNodes_backwards                      */
+    std::vector<unsigned char> inGraphGapStretch;/* processBAM::inGraphGapStretch                              */
+
+    void build(const hlala_graph_desc* d)
+    {
+        L = d->n_levels;
+        ORC_CHECK(L > 1, "graph needs > 1 level");
+        node_level.assign(d->node_level, d->node_level + d->n_nodes);
+        efrom.assign(d->edge_from, d->edge_from + d->n_edges);
+        eto.assign(d->edge_to, d->edge_to + d->n_edges);
+        elabel.assign(d->edge_label, d->edge_label + d->n_edges);
+        level_nodes.assign(L, {});
+        node_rank.assign(d->n_nodes, -1);
+        for(int n = 0; n < d->n_nodes; n++) {
+            ORC_CHECK(node_level[n] >= 0 && node_level[n] < L, "node level range");
+            node_rank[n] = (int)level_nodes[node_level[n]].size();
+            level_nodes[node_level[n]].push_back(n);
+        }
+        out_e.assign(d->n_nodes, {});
+        in_e.assign(d->n_nodes, {});
+        for(int e = 0; e < d->n_edges; e++) {
+            ORC_CHECK(node_level[eto[e]] == node_level[efrom[e]] + 1, "edge must connect consecutive levels");
+            out_e[efrom[e]].push_back(e);
+            in_e[eto[e]].push_back(e);
+        }
+        computeGapEdgePaths();
+        computeGapStretches();
+    }
+
+    /* Graph::computeGapEdgePaths, Graph/Graph.cpp:347-476 */
+    void computeGapEdgePaths()
+    {
+        std::map<int, std::map<int, std::vector<int>>> runningPaths;   /* node at this level -> origin node -> edge path */
+        for(int lI = 0; lI < L; lI++) {
+            std::map<int, std::map<int, std::vector<int>>> runningPaths_nextLevel;
+            std::set<int> seen_gap_edge;
+            for(auto& nodeIt : runningPaths) {
+                int thisLevelNode = nodeIt.first;
+                int non_gap_edges = 0;
+                for(int e : out_e[thisLevelNode]) {
+                    if(elabel[e] == '_') {
+                        seen_gap_edge.insert(e);
+                        int targetNode = eto[e];
+                        for(auto& fromNodeIt : nodeIt.second) {
+                            int fromNode = fromNodeIt.first;
+                            if(runningPaths_nextLevel.count(targetNode) == 0 || runningPaths_nextLevel.at(targetNode).count(fromNode) == 0) {
+                                std::vector<int> p = fromNodeIt.second;
+                                p.push_back(e);
+                                runningPaths_nextLevel[targetNode][fromNode] = p;
+                            }
+                        }
+                    } else {
+                        non_gap_edges++;
+                    }
+                }
+                if(non_gap_edges != 0 || lI == L - 1)
+                    for(auto& fromNodeIt : nodeIt.second)
+                        paths.push_back(fromNodeIt.second);
+            }
+            /* Graph::getEdgesEmanatingFromLevel (Graph.cpp:556-565): a std::set<Edge*> = edge creation order */
+            std::set<int> edges_thisLevel;
+            for(int n : level_nodes[lI]) edges_thisLevel.insert(out_e[n].begin(), out_e[n].end());
+            for(int e : edges_thisLevel) {
+                if(elabel[e] == '_' && seen_gap_edge.count(e) == 0) {
+                    int fromNode = efrom[e], targetNode = eto[e];
+                    if(runningPaths_nextLevel.count(targetNode) == 0 || runningPaths_nextLevel.at(targetNode).count(fromNode) == 0)
+                        runningPaths_nextLevel[targetNode][fromNode] = std::vector<int>{e};
+                }
+            }
+            runningPaths = runningPaths_nextLevel;
+        }
+        for(int pathI = 0; pathI < (int)paths.size(); pathI++) {
+            int firstNode = efrom[paths[pathI].front()];
+            int lastNode = eto[paths[pathI].back()];
+            ORC_CHECK(jump_fwd.count(firstNode) == 0 || jump_fwd.at(firstNode).count(lastNode) == 0, "duplicate gap path");
+            jump_fwd[firstNode][lastNode] = pathI;
+            jump_bwd[lastNode][firstNode] = pathI;
+        }
+    }
+
+    /* processBAM::processBAM gap-stretch scan, mapper/processBAM.cpp:91-149 */
+    void computeGapStretches()
+    {
+        inGraphGapStretch.assign(L - 1, 0);
+        const int gapStretchMinimumLength = 3;
+        auto addGapStretch = [&](int a, int b) {
+            if(b - a + 1 >= gapStretchMinimumLength)
+                for(int l = a; l <= b; l++) inGraphGapStretch[l] = 1;
+        };
+        int stretchStart = -1;
+        for(int lI = 0; lI < L - 1; lI++) {
+            bool haveGapEdge = false;
+            for(int n : level_nodes[lI]) for(int e : out_e[n]) if(elabel[e] == '_') haveGapEdge = true;
+            if(haveGapEdge) { if(stretchStart == -1) stretchStart = lI; }
+            else if(stretchStart != -1) { addGapStretch(stretchStart, lI - 1); stretchStart = -1; }
+        }
+        if(stretchStart != -1) addGapStretch(stretchStart, L - 2);
+    }
+};
+
+/* mapper::reads::verboseSeedChain, mapper/reads/verboseSeedChain.h:22-50 */
+struct Chain {
+    int sequence_begin = -1, sequence_end = -1;
+    bool reverse = false;
+    int removed_columns_noGap_restriction = -1;
+    double improvement_through_bt = -1;
+    std::vector<int> levels;       /* graph_aligned_levels */
+    std::vector<int> edges;        /* graph_aligned_edges (creation index, -1 = null) */
+    std::string graph_aligned, sequence_aligned;
+    std::vector<unsigned char> is_from_BWAseed;
+    double mapQ = 0;
+    std::string mapQ_perPosition;
+    double ll = 0;
+    int dp_iters[2] = {0, 0};
+    int dp_score[2] = {INT_MIN, INT_MIN};
+
+    size_t size() const { return levels.size(); }
+    /* verboseSeedChain::alignment_firstLevel / lastLevel, verboseSeedChain.h:118-190 */
+    int firstLevel() const { for(int l : levels) if(l != -1) return l; return -1; }
+    int lastLevel() const { for(int i = (int)levels.size() - 1; i >= 0; i--) if(levels[i] != -1) return levels[i]; return -1; }
+    std::vector<int> firstLevels(int n) const { std::vector<int> r; for(int l : levels) if(l != -1) { r.push_back(l); if((int)r.size() >= n) break; } return r; }
+    std::vector<int> lastLevels(int n) const { std::vector<int> r; for(int i = (int)levels.size() - 1; i >= 0; i--) if(levels[i] != -1) { r.push_back(levels[i]); if((int)r.size() >= n) break; } return r; }
+
+    /* verboseSeedChain::checkChainConcordanceWithSequence, verboseSeedChain.cpp:48-77 */
+    void checkConcordance(const std::string& sequence) const
+    {
+        ORC_CHECK(edges.size() == levels.size() && graph_aligned.size() == levels.size() && sequence_aligned.size() == levels.size(), "chain array sizes");
+        ORC_CHECK(sequence_begin <= sequence_end && sequence_begin >= 0 && sequence_end < (int)sequence.size(), "chain sequence range");
+        std::string noGaps;
+        for(char c : sequence_aligned) if(c != '_') noGaps.push_back(c);
+        ORC_CHECK(sequence.substr(sequence_begin, sequence_end - sequence_begin + 1) == noGaps, "chain concordance with sequence");
+    }
+    /* verboseSeedChain::checkLevelContiguity, verboseSeedChain.h:282-315 */
+    void checkLevelContiguity() const
+    {
+        int last = -1;
+        for(int l : levels) if(l != -1) { ORC_CHECK(last == -1 || last + 1 == l, "level contiguity"); last = l; }
+    }
+    /* verboseSeedChain::extendWithOtherSeedChain, verboseSeedChain.cpp:23-46 */
+    void extendWith(const Chain& o, bool left)
+    {
+        if(left) {
+            ORC_CHECK(o.sequence_end + 1 == sequence_begin, "left extension adjacency");
+            sequence_begin = o.sequence_begin;
+            levels.insert(levels.begin(), o.levels.begin(), o.levels.end());
+            edges.insert(edges.begin(), o.edges.begin(), o.edges.end());
+            graph_aligned.insert(graph_aligned.begin(), o.graph_aligned.begin(), o.graph_aligned.end());
+            sequence_aligned.insert(sequence_aligned.begin(), o.sequence_aligned.begin(), o.sequence_aligned.end());
+            is_from_BWAseed.insert(is_from_BWAseed.begin(), o.is_from_BWAseed.begin(), o.is_from_BWAseed.end());
+        } else {
+            ORC_CHECK(o.sequence_begin == sequence_end + 1, "right extension adjacency");
+            sequence_end = o.sequence_end;
+            levels.insert(levels.end(), o.levels.begin(), o.levels.end());
+            edges.insert(edges.end(), o.edges.begin(), o.edges.end());
+            graph_aligned.insert(graph_aligned.end(), o.graph_aligned.begin(), o.graph_aligned.end());
+            sequence_aligned.insert(sequence_aligned.end(), o.sequence_aligned.begin(), o.sequence_aligned.end());
+            is_from_BWAseed.insert(is_from_BWAseed.end(), o.is_from_BWAseed.begin(), o.is_from_BWAseed.end());
+        }
+    }
+    /* verboseSeedChain::extendToFullSequenceLength, verboseSeedChain.cpp:79-136 */
+    void extendToFull(const std::string& sequence)
+    {
+        int missing_left = sequence_begin;
+        int missing_right = (int)sequence.size() - sequence_end - 1;
+        if(missing_left) {
+            edges.insert(edges.begin(), missing_left, -1);
+            levels.insert(levels.begin(), missing_left, -1);
+            graph_aligned.insert(graph_aligned.begin(), missing_left, '_');
+            sequence_aligned.insert(0, sequence.substr(0, missing_left));
+            is_from_BWAseed.insert(is_from_BWAseed.begin(), missing_left, 0);
+            sequence_begin = 0;
+        }
+        if(missing_right) {
+            edges.insert(edges.end(), missing_right, -1);
+            levels.insert(levels.end(), missing_right, -1);
+            graph_aligned.insert(graph_aligned.end(), missing_right, '_');
+            sequence_aligned.append(sequence.substr(sequence.size() - missing_right, missing_right));
+            is_from_BWAseed.insert(is_from_BWAseed.end(), missing_right, 0);
+            sequence_end = (int)sequence.size() - 1;
+        }
+        checkConcordance(sequence);
+    }
+};
+
+/* ------------------------------------------------------------------ extension aligner */
+
+struct Aligner {
+    const Graph* g;
+    /* alignerBase::alignerBase, mapper/aligner/alignerBase.cpp:19-25 */
+    double S_match = 2, S_mismatch = -5, S_gap = -2, S_graphGap = 0, S_openGap = -4, S_extendGap = -2;
+    long long stat_cells = 0, stat_iters = 0, stat_calls = 0, stat_edges = 0;
+    bool h4_hit = false;
+
+    explicit Aligner(const Graph* g_) : g(g_) {}
+
+    /* backtraceStep_affine, alignerBase.h:36-51.  edge >= 0: graph edge; edge == -1: none;
+     * edge <= -2: pseudo edge of gap path (-2 - edge). */
+    struct BT { int x = -1, y = -1, z = -1, src = -1, edge = -1; };
+    struct Cell { double D, GG, SG; };
+    struct CellBT { BT D, GG, SG; };
+    struct Alt { std::vector<double> D, GG, SG; std::vector<BT> bD, bGG, bSG; };
+    typedef std::tuple<int, int, int> Key;
+
+    /* alignerBase::_graph_get_{next,previous}_z_values_and_edges, alignerBase.cpp:149-195 */
+    std::vector<std::pair<int, int>> neighbours(int x, int z, bool fwd) const
+    {
+        std::vector<std::pair<int, int>> r;
+        int n = g->level_nodes.at(x).at(z);
+        if(fwd) for(int e : g->out_e[n]) r.push_back({g->node_rank[g->eto[e]], e});
+        else    for(int e : g->in_e[n])  r.push_back({g->node_rank[g->efrom[e]], e});
+        return r;
+    }
+    /* extensionAligner::_graph_get_jump{Next,Previous}_x_and_z_values_and_edges, extensionAligner.cpp:2694-2742 */
+    std::vector<std::tuple<int, int, int>> jumps(int x, int z, bool fwd) const
+    {
+        std::vector<std::tuple<int, int, int>> r;   /* (level, z, pathIdx) */
+        int n = g->level_nodes.at(x).at(z);
+        const auto& tbl = fwd ? g->jump_fwd : g->jump_bwd;
+        auto it = tbl.find(n);
+        if(it != tbl.end())
+            for(auto& t : it->second)
+                r.push_back(std::make_tuple(g->node_level[t.first], g->node_rank[t.first], t.second));
+        return r;
+    }
+
+    struct Ext { bool have = false; Chain chain; int iters = 0; int score = INT_MIN; };
+
+    /* extensionAligner::fullNeedleman_diagonal_extension_gapJumper, extensionAligner.cpp:335-1556,
+     * in the only configuration the path uses (extendSeedChain, :229-241 and :281-293):
+     * returnGlobalScore = false, preferSequenceCompleAlignments = true, empty blockedPathsTable. */
+    Ext dp(const std::string& sequence, int start_sequence, int startLevel_graph, int startZ_graph,
+           int maxLevel_graph, int maxPosition_sequence, int diagonal_stop_threshold, bool directionPositive,
+           unsigned int* rng_seed)
+    {
+        stat_calls++;
+        const double minusInfinity = -1 * DBL_MAX;                                   /* :363 */
+        std::map<Key, Cell> scores;                                                    /* :396 */
+        std::map<Key, CellBT> scores_backtrace;                                        /* :397 */
+        std::vector<Key> m1_diagonal, m2_diagonal;
+
+        int levels = g->L;
+        int sequenceLength = (int)sequence.size();
+        int diagonals = sequenceLength + levels - 1;                                  /* :431 */
+        int max_levelI = levels - 1, max_seqI = sequenceLength, min_levelI = 0, min_seqI = 0;
+        if(maxLevel_graph != -1) { if(directionPositive) max_levelI = maxLevel_graph; else min_levelI = maxLevel_graph; }
+        if(maxPosition_sequence != -1) { if(directionPositive) max_seqI = maxPosition_sequence; else min_seqI = maxPosition_sequence; }
+        ORC_CHECK(startLevel_graph >= min_levelI && startLevel_graph <= max_levelI, "DP start level");      /* :465-478 */
+        ORC_CHECK(start_sequence >= min_seqI && start_sequence <= max_seqI, "DP start seq");
+        ORC_CHECK(max_levelI > min_levelI && max_seqI > min_seqI, "DP extent");
+
+        double currentMaximum = 0;                                                    /* :480 */
+        std::vector<Key> currentMaxima_coordinates;
+        int statesPerLevel0 = (int)g->level_nodes.at(startLevel_graph).size();
+        ORC_CHECK(startZ_graph >= 0 && startZ_graph < statesPerLevel0, "DP start z");
+        const int threshold_for_filtering = 15;                                       /* :489 */
+        const int maximum_steps_nonIncrease = 40;                                     /* :490 */
+        std::set<std::string> achieved_complete_sequence_alignments;                  /* :493 */
+
+        for(int stateI = 0; stateI < statesPerLevel0; stateI++) {                     /* :495-519 */
+            Key k(startLevel_graph, start_sequence, stateI);
+            Cell c;
+            c.D = (stateI == startZ_graph) ? 0 : minusInfinity;
+            c.GG = minusInfinity; c.SG = minusInfinity;
+            scores[k] = c;
+            if(stateI == startZ_graph) {
+                scores_backtrace[k] = CellBT();
+                m1_diagonal.push_back(k);
+                currentMaxima_coordinates.push_back(k);
+            }
+        }
+
+        int lastMaximumIncrease_at_diagonalI = 0;
+        int itersRun = 0;
+        for(int diagonalI = 1; diagonalI <= diagonals; diagonalI++) {                 /* :531 */
+            if((diagonalI - lastMaximumIncrease_at_diagonalI) > maximum_steps_nonIncrease) break;   /* :553 */
+            itersRun++;
+            std::map<Key, Alt> thisDiagonal;
+
+            /* extend from m-2 diagonal, :565-607 */
+            for(const Key& p : m2_diagonal) {
+                int px = std::get<0>(p), py = std::get<1>(p), pz = std::get<2>(p);
+                int nx = px + (directionPositive ? 1 : -1), ny = py + (directionPositive ? 1 : -1);
+                if(nx > max_levelI || ny > max_seqI) continue;
+                if(nx < min_levelI || ny < min_seqI) continue;
+                char sequenceEmission = directionPositive ? sequence.at(py) : sequence.at(py - 1);
+                auto nextZs = neighbours(px, pz, directionPositive);
+                ORC_CHECK(nextZs.size() > 0, "node without neighbours");
+                for(auto& zj : nextZs) {
+                    stat_edges++;
+                    char edgeEmission = (char)g->elabel[zj.second];
+                    double s = scores.at(p).D + ((edgeEmission == sequenceEmission) ? S_match : S_mismatch);
+                    BT b; b.x = px; b.y = py; b.z = pz; b.edge = zj.second; b.src = 0;
+                    Alt& a = thisDiagonal[Key(nx, ny, zj.first)];
+                    a.D.push_back(s); a.bD.push_back(b);
+                }
+            }
+
+            /* extend from m-1 diagonal, :613-787 */
+            for(const Key& p : m1_diagonal) {
+                int px = std::get<0>(p), py = std::get<1>(p), pz = std::get<2>(p);
+                const Cell& pc = scores.at(p);
+                /* gap in graph, :621-661 */
+                {
+                    int nx = px, ny = py + (directionPositive ? 1 : -1);
+                    if((directionPositive && nx <= max_levelI && ny <= max_seqI) || (!directionPositive && nx >= min_levelI && ny >= min_seqI)) {
+                        Alt& a = thisDiagonal[Key(nx, ny, pz)];
+                        BT bo; bo.x = px; bo.y = py; bo.z = pz; bo.edge = -1; bo.src = 0;
+                        a.GG.push_back(pc.D + S_openGap + S_extendGap); a.bGG.push_back(bo);
+                        BT be = bo; be.src = 1;
+                        a.GG.push_back(pc.GG + S_extendGap); a.bGG.push_back(be);
+                    }
+                }
+                /* gap in sequence, :664-754 */
+                {
+                    int nx = px + (directionPositive ? 1 : -1), ny = py;
+                    if((directionPositive && nx <= max_levelI && ny <= max_seqI) || (!directionPositive && nx >= min_levelI && ny >= min_seqI)) {
+                        auto nextZs = neighbours(px, pz, directionPositive);
+                        ORC_CHECK(nextZs.size() > 0, "node without neighbours");
+                        for(auto& zj : nextZs) {
+                            stat_edges++;
+                            bool gapEdge = (g->elabel[zj.second] == '_');
+                            Alt& a = thisDiagonal[Key(nx, ny, zj.first)];
+                            double s_open = pc.D + S_openGap + S_extendGap;
+                            if(gapEdge) s_open = minusInfinity;
+                            BT bo; bo.x = px; bo.y = py; bo.z = pz; bo.edge = zj.second; bo.src = 0;
+                            a.SG.push_back(s_open); a.bSG.push_back(bo);
+                            double s_ext = pc.SG + S_extendGap;
+                            if(gapEdge) s_ext = (pc.SG == minusInfinity) ? minusInfinity : pc.SG + S_graphGap;
+                            BT be = bo; be.src = 2;
+                            a.SG.push_back(s_ext); a.bSG.push_back(be);
+                            if(gapEdge) {                                       /* non-affine sequence gap, :738-752 */
+                                BT bn = bo; bn.src = 0;
+                                a.D.push_back(pc.D + S_graphGap); a.bD.push_back(bn);
+                            }
+                        }
+                    }
+                }
+                /* gap in sequence, jump, :757-786 */
+                for(auto& j : jumps(px, pz, directionPositive)) {
+                    int jx = std::get<0>(j), jy = py, jz = std::get<1>(j), pathI = std::get<2>(j);
+                    if((directionPositive && jx <= max_levelI && jy <= max_seqI) || (!directionPositive && jx >= min_levelI && jy >= min_seqI)) {
+                        int jump_length = (int)g->paths.at(pathI).size();
+                        BT b; b.x = px; b.y = py; b.z = pz; b.edge = -2 - pathI; b.src = 0;
+                        Alt& a = thisDiagonal[Key(jx, jy, jz)];
+                        a.D.push_back(pc.D + (jump_length * S_graphGap)); a.bD.push_back(b);
+                    }
+                }
+            }
+
+            /* call maxima for this diagonal, :794-1073 */
+            std::vector<Key> m_thisDiagonal;
+            for(auto& diagIt : thisDiagonal) {
+                stat_cells++;
+                const Key& k = diagIt.first;
+                int levelI = std::get<0>(k), seqI = std::get<1>(k), stateI = std::get<2>(k);
+                Alt& a = diagIt.second;
+                double selGG = minusInfinity, selSG = minusInfinity;
+                BT stepGG, stepSG;
+                if(a.GG.size()) { auto m = firstMax(a.GG); selGG = m.first; stepGG = a.bGG[m.second]; }
+                if(a.SG.size()) { auto m = firstMax(a.SG); selSG = m.first; stepSG = a.bSG[m.second]; }
+                BT fromGG; fromGG.x = levelI; fromGG.y = seqI; fromGG.z = stateI; fromGG.src = 1; fromGG.edge = -1;
+                a.D.push_back(selGG); a.bD.push_back(fromGG);
+                BT fromSG = fromGG; fromSG.src = 2;
+                a.D.push_back(selSG); a.bD.push_back(fromSG);
+                auto maxD = firstMax(a.D);
+                /* blockedPathsTable is empty on this path (extensionAligner.cpp:210-218): blockOutCell never fires */
+                if(maxD.first >= diagonal_stop_threshold) {                              /* :949 */
+                    bool newEntry = (scores.count(k) == 0);
+                    bool overwrittenEntry = false;
+                    if(newEntry || scores.at(k).D < maxD.first) {
+                        overwrittenEntry = !newEntry;
+                        scores[k].D = maxD.first; scores_backtrace[k].D = a.bD[maxD.second];
+                    }
+                    if(newEntry || scores.at(k).GG < selGG) {
+                        overwrittenEntry = !newEntry;
+                        scores[k].GG = selGG; scores_backtrace[k].GG = stepGG;
+                    }
+                    if(newEntry || scores.at(k).SG < selSG) {
+                        overwrittenEntry = !newEntry;
+                        scores[k].SG = selSG; scores_backtrace[k].SG = stepSG;
+                    }
+                    if((directionPositive && seqI == max_seqI) || (!directionPositive && seqI == min_seqI))     /* :982-999 */
+                        achieved_complete_sequence_alignments.insert(std::to_string(levelI) + "/" + std::to_string(stateI));
+                    m_thisDiagonal.push_back(k);
+
+                    BT oneRealStepBackwards = scores_backtrace[k].D;                          /* :1007-1041 */
+                    while(oneRealStepBackwards.x == levelI && oneRealStepBackwards.y == seqI) {
+                        Key kk(oneRealStepBackwards.x, oneRealStepBackwards.y, oneRealStepBackwards.z);
+                        ORC_CHECK(oneRealStepBackwards.src != 0, "same-cell hop from D");
+                        if(oneRealStepBackwards.src == 1) oneRealStepBackwards = scores_backtrace[kk].GG;
+                        else oneRealStepBackwards = scores_backtrace[kk].SG;
+                    }
+                    double prevD;
+                    {
+                        Key kk(oneRealStepBackwards.x, oneRealStepBackwards.y, oneRealStepBackwards.z);
+                        const Cell& pc2 = scores[kk];
+                        prevD = (oneRealStepBackwards.src == 0) ? pc2.D : (oneRealStepBackwards.src == 1 ? pc2.GG : pc2.SG);
+                    }
+                    int previousScore;     /* `int previousScore = <double>`: x86 cvttsd2si gives INT_MIN out of range */
+                    if(prevD <= (double)INT_MIN || prevD >= (double)INT_MAX) { previousScore = INT_MIN; h4_hit = true; }
+                    else previousScore = (int)prevD;
+                    int scoreDifference = (int)(maxD.first - previousScore);
+                    if(maxD.first == currentMaximum) {
+                        if(scoreDifference != 0) {
+                            currentMaxima_coordinates.push_back(k);
+                            lastMaximumIncrease_at_diagonalI = diagonalI;
+                        }
+                    } else if(maxD.first > currentMaximum) {
+                        currentMaximum = maxD.first;
+                        currentMaxima_coordinates.clear();
+                        currentMaxima_coordinates.push_back(k);
+                        lastMaximumIncrease_at_diagonalI = diagonalI;
+                    }
+                    if(overwrittenEntry) lastMaximumIncrease_at_diagonalI = diagonalI;
+                }
+            }
+
+            /* filtering, :1076-1102 */
+            if(m_thisDiagonal.size() > 0) {
+                double mx = 0;
+                for(size_t i = 0; i < m_thisDiagonal.size(); i++) {
+                    double S = scores.at(m_thisDiagonal[i]).D;
+                    if(i == 0 || mx < S) mx = S;
+                }
+                std::vector<Key> filtered;
+                for(const Key& c : m_thisDiagonal)
+                    if((mx - scores.at(c).D) <= threshold_for_filtering) filtered.push_back(c);
+                m_thisDiagonal = filtered;
+            }
+            m2_diagonal = m1_diagonal;                                               /* :1104-1105 */
+            m1_diagonal = m_thisDiagonal;
+        }
+        stat_iters += itersRun;
+
+        /* backtraceFrom, :1109-1354 */
+        auto backtraceFrom = [&](int start_x, int start_y, int start_z, double StartScore) -> Ext {
+            int bx = start_x, by = start_y, bz = start_z, bm = 0;
+            std::string rec_graph, rec_seq;
+            std::vector<int> rec_levels, used_edges;
+            std::vector<Key> coords;
+            coords.push_back(Key(start_x, start_y, start_z));
+            while(bx != startLevel_graph || by != start_sequence) {
+                const CellBT& cb = scores_backtrace.at(Key(bx, by, bz));
+                BT step = (bm == 0) ? cb.D : (bm == 1 ? cb.GG : cb.SG);
+                char sequenceEmission = 0;
+                if(by >= 1 && directionPositive) sequenceEmission = sequence.at(by - 1);
+                if(by < max_seqI && !directionPositive) sequenceEmission = sequence.at(by);
+                int nx = step.x, ny = step.y, nz = step.z, nm = step.src;
+                bool dontAdd = false;
+                if(step.edge > -2) {                                   /* not a pseudo edge */
+                    char edgeEmission = step.edge >= 0 ? (char)g->elabel[step.edge] : 0;
+                    int dirx = directionPositive ? -1 : 1;
+                    int lvl = directionPositive ? bx - 1 : bx;
+                    if(nx == bx + dirx && ny == by + dirx) {           /* match or mismatch */
+                        ORC_CHECK(step.edge >= 0, "match step without edge");
+                        rec_graph.push_back(edgeEmission); rec_levels.push_back(lvl); rec_seq.push_back(sequenceEmission); used_edges.push_back(step.edge);
+                    } else if(nx == bx && ny == by + dirx) {           /* gap in graph */
+                        rec_graph.push_back('_'); rec_levels.push_back(-1); rec_seq.push_back(sequenceEmission); used_edges.push_back(-1);
+                    } else if(nx == bx + dirx && ny == by) {           /* gap in sequence */
+                        ORC_CHECK(step.edge >= 0, "sequence-gap step without edge");
+                        rec_graph.push_back(edgeEmission); rec_levels.push_back(lvl); rec_seq.push_back('_'); used_edges.push_back(step.edge);
+                    } else {
+                        dontAdd = true;
+                        ORC_CHECK(bx == nx && by == ny && bz == nz && nm != bm, "matrix hop");
+                    }
+                } else {                                              /* gap-path jump, :1282-1307 */
+                    std::vector<int> edgePath = g->paths.at(-2 - step.edge);
+                    std::vector<int> graph_levels;
+                    for(int e : edgePath) graph_levels.push_back(g->node_level[g->efrom[e]]);
+                    if(directionPositive) { std::reverse(graph_levels.begin(), graph_levels.end()); std::reverse(edgePath.begin(), edgePath.end()); }
+                    rec_levels.insert(rec_levels.end(), graph_levels.begin(), graph_levels.end());
+                    rec_graph.append(edgePath.size(), '_');
+                    rec_seq.append(edgePath.size(), '_');
+                    used_edges.insert(used_edges.end(), edgePath.begin(), edgePath.end());
+                }
+                bx = nx; by = ny; bz = nz; bm = nm;
+                if(!dontAdd) coords.push_back(Key(nx, ny, nz));
+            }
+            if(directionPositive) {
+                std::reverse(rec_graph.begin(), rec_graph.end()); std::reverse(rec_levels.begin(), rec_levels.end());
+                std::reverse(rec_seq.begin(), rec_seq.end()); std::reverse(used_edges.begin(), used_edges.end());
+                std::reverse(coords.begin(), coords.end());
+            }
+            /* localExtension_pathDescription::toVerboseSeedChain, VirtualNWUnique.cpp:20-40 */
+            Ext r; r.have = true;
+            r.chain.edges = used_edges; r.chain.levels = rec_levels; r.chain.graph_aligned = rec_graph; r.chain.sequence_aligned = rec_seq;
+            r.chain.sequence_begin = std::get<1>(coords.front());
+            r.chain.sequence_end = std::get<1>(coords.back()) - 1;
+            ORC_CHECK(r.chain.sequence_begin <= r.chain.sequence_end, "extension consumes no read base");
+            r.chain.reverse = false;
+            r.score = (int)StartScore;
+            return r;
+        };
+
+        /* end cell, :1381-1517 */
+        Ext result;
+        {
+            int coordinate_seqI = directionPositive ? max_seqI : min_seqI;
+            std::vector<std::string> best; double maxScore = 0; bool first = true;
+            for(const std::string& coordinates : achieved_complete_sequence_alignments) {
+                size_t sl = coordinates.find('/');
+                int cl = atoi(coordinates.substr(0, sl).c_str()), cs = atoi(coordinates.substr(sl + 1).c_str());
+                double S = scores.at(Key(cl, coordinate_seqI, cs)).D;
+                if(first || S > maxScore) { best.clear(); best.push_back(coordinates); maxScore = S; first = false; }
+                else if(S == maxScore) best.push_back(coordinates);
+            }
+            if(best.size() > 0) {
+                /* Utilities::randomNumber_nonCritical, Utilities.cpp:922-927 */
+                int selectedIndex = rand_r(rng_seed) % (int)best.size();
+                const std::string& coordinates = best.at(selectedIndex);
+                size_t sl = coordinates.find('/');
+                int cl = atoi(coordinates.substr(0, sl).c_str()), cs = atoi(coordinates.substr(sl + 1).c_str());
+                result = backtraceFrom(cl, coordinate_seqI, cs, maxScore);
+            } else if(currentMaximum > 0) {
+                /* :1481-1497 backtraces from every maximum, but :1548-1552 returns copies of forReturn.at(0) only */
+                for(const Key& c : currentMaxima_coordinates) {
+                    if(scores.at(c).D != minusInfinity) {
+                        result = backtraceFrom(std::get<0>(c), std::get<1>(c), std::get<2>(c), scores.at(c).D);
+                        break;
+                    }
+                }
+            }
+        }
+        result.iters = itersRun;
+        return result;
+    }
+
+    /* extensionAligner::extendSeedChain, extensionAligner.cpp:186-333 */
+    Chain extendSeedChain(const std::string& sequence, const Chain& seedChain, unsigned int seed_left, unsigned int seed_right)
+    {
+        ORC_CHECK(seedChain.sequence_begin <= seedChain.sequence_end && seedChain.sequence_begin >= 0, "seed range");
+        ORC_CHECK(seedChain.sequence_end < (int)sequence.size(), "seed end");
+        seedChain.checkConcordance(sequence);
+        Chain forReturn = seedChain;
+        ORC_CHECK(seedChain.edges.size() > 0, "empty seed chain");
+        if(seedChain.sequence_begin != 0) {                                            /* left, :220-268 */
+            int e0 = seedChain.edges.front();
+            ORC_CHECK(e0 >= 0, "first seed column has no edge");
+            int firstNode = g->efrom[e0];
+            if(g->node_level[firstNode] > 0) {
+                unsigned int s = seed_left;
+                Ext x = dp(sequence, seedChain.sequence_begin, g->node_level[firstNode], g->node_rank[firstNode], 0, 0, -16, false, &s);
+                forReturn.dp_iters[0] = x.iters;
+                if(x.have) {
+                    x.chain.reverse = seedChain.reverse;
+                    x.chain.checkConcordance(sequence);
+                    x.chain.is_from_BWAseed.assign(x.chain.size(), 0);
+                    forReturn.extendWith(x.chain, true);
+                    forReturn.dp_score[0] = x.score;
+                }
+            }
+        }
+        if(seedChain.sequence_end != (int)sequence.size() - 1) {                       /* right, :271-319 */
+            int e1 = seedChain.edges.back();
+            ORC_CHECK(e1 >= 0, "last seed column has no edge");
+            int lastNode = g->eto[e1];
+            if(g->node_level[lastNode] < g->L - 1) {
+                unsigned int s = seed_right;
+                Ext x = dp(sequence, seedChain.sequence_end + 1, g->node_level[lastNode], g->node_rank[lastNode], g->L - 1, (int)sequence.size(), -16, true, &s);
+                forReturn.dp_iters[1] = x.iters;
+                if(x.have) {
+                    x.chain.reverse = seedChain.reverse;
+                    x.chain.checkConcordance(sequence);
+                    x.chain.is_from_BWAseed.assign(x.chain.size(), 0);
+                    forReturn.extendWith(x.chain, false);
+                    forReturn.dp_score[1] = x.score;
+                }
+            }
+        }
+        forReturn.checkConcordance(sequence);
+        forReturn.extendToFull(sequence);
+        return forReturn;
+    }
+
+    /* extensionAligner::scoreOneAlignment, extensionAligner.cpp:52-182.  `read_seq`/`read_qual` are the
+     * oneRead in ORIGINAL orientation (processBAM.cpp:3147-3166). */
+    double scoreOneAlignment(const Chain& alignment, const std::string& read_seq, const std::string& read_qual, bool longReadMode) const
+    {
+        int indexIntoOriginalReadData = alignment.sequence_begin - 1;
+        double rate_deletions = log(0.001), rate_insertions = log(0.001);
+        if(longReadMode) { rate_deletions = log(0.075); rate_insertions = log(0.075); }
+        double rate_match_mismatch = log(1 - exp(rate_deletions) - exp(rate_insertions));
+        double combined_log_likelihood = 0;
+        for(size_t cI = 0; cI < alignment.sequence_aligned.size(); cI++) {
+            char sequenceCharacter = alignment.sequence_aligned[cI];
+            char graphCharacter = alignment.graph_aligned[cI];
+            if(sequenceCharacter != '_') {
+                indexIntoOriginalReadData++;
+                int idx = indexIntoOriginalReadData;
+                if(alignment.reverse) idx = (int)read_seq.size() - idx - 1;
+                ORC_CHECK(idx >= 0 && idx < (int)read_seq.size(), "score index");
+                if(!longReadMode) {
+                    char u = read_seq[idx];
+                    if(alignment.reverse) u = complementChar(u);
+                    ORC_CHECK(u == sequenceCharacter, "score: read character mismatch");
+                }
+                if(graphCharacter == '_') {
+                    combined_log_likelihood += (rate_insertions + log(1.0 / 4.0));
+                } else {
+                    combined_log_likelihood += rate_match_mismatch;
+                    double pCorrect = PhredToPCorrect((unsigned char)read_qual.at(idx));
+                    if(pCorrect > 0.999) pCorrect = 0.999;
+                    if(pCorrect == 0) pCorrect = 0.00001;
+                    ORC_CHECK(pCorrect > 0 && pCorrect <= 1, "pCorrect range");
+                    if(sequenceCharacter == graphCharacter) combined_log_likelihood += log(pCorrect);
+                    else { double pIncorrect = 1 - pCorrect; pIncorrect *= (1.0 / 3.0); combined_log_likelihood += log(pIncorrect); }
+                }
+            } else {
+                if(graphCharacter != '_') combined_log_likelihood += rate_deletions;
+            }
+        }
+        return combined_log_likelihood;
+    }
+};
+
+/* ------------------------------------------------------------------------ processBAM */
+
+struct Contigs {
+    int n = 0;
+    std::vector<long long> off;
+    std::vector<unsigned char> seq;
+    std::vector<int> level;
+    std::vector<int> seqid;
+    /* processBAM::graphLevel_2_underlyingSequencePositions, filled by _loadMapping (processBAM.cpp:4441-4456) */
+    std::vector<std::map<int, int>> level2pos;
+    void build(const hlala_contigs_desc* d, int L)
+    {
+        n = d->n_contigs;
+        off.assign(d->contig_off, d->contig_off + n + 1);
+        seq.assign(d->contig_seq, d->contig_seq + off[n]);
+        level.assign(d->contig_level, d->contig_level + off[n]);
+        seqid.assign(d->contig_seqid, d->contig_seqid + n);
+        level2pos.assign(L, {});
+        for(int c = 0; c < n; c++)
+            for(long long p = off[c]; p < off[c + 1]; p++) {
+                ORC_CHECK(level[p] >= 0 && level[p] < L, "translation level range");
+                level2pos[level[p]][seqid[c]] = (int)(p - off[c]);
+            }
+    }
+};
+
+/* mapper::reads::PRGContigBAMAlignment, mapper/reads/PRGContigBAMAlignment.h */
+struct ContigAlignment {
+    std::vector<int> levels; std::string graph_aligned, sequence_aligned;
+    int startInRaw = -1, stopInRaw = -1; bool reverse = false;
+};
+
+struct BamRecord { int contig, pos, offset, as; bool reverse; std::vector<uint32_t> cigar; };
+
+static const char* CIGAR_OPS = "MIDNSHP=X";
+
+struct Processor {
+    Graph g;
+    Contigs contigs;
+    hlala_params params;
+    Aligner* eA = nullptr;
+
+    /* processBAM::transformBAMreadToInternalAlignment, mapper/processBAM.cpp:4794-5337 */
+    bool transformBAMreadToInternalAlignment(const BamRecord& al, const std::string& queryBases, ContigAlignment& out) const
+    {
+        const unsigned char* referenceSequence = contigs.seq.data() + contigs.off[al.contig];
+        const int* reference2level = contigs.level.data() + contigs.off[al.contig];
+        long long refLen = contigs.off[al.contig + 1] - contigs.off[al.contig];
+        out = ContigAlignment();
+        out.reverse = al.reverse;
+        std::vector<char> CIGAR;
+        for(uint32_t c : al.cigar) {                                   /* :4814-4828, 'P' dropped */
+            unsigned op = c & 15u, len = c >> 4;
+            ORC_CHECK(op < 9, "cigar op");
+            if(CIGAR_OPS[op] != 'P') CIGAR.insert(CIGAR.end(), len, CIGAR_OPS[op]);
+        }
+        ORC_CHECK(al.cigar.size() >= 1, "empty cigar");
+        int index_along_genome_fromReadStart = 0, index_along_read = 0, index_along_unclipped_read = 0;
+        if(CIGAR_OPS[al.cigar.front() & 15u] == 'H') index_along_unclipped_read += (int)(al.cigar.front() >> 4);     /* :4868-4874 */
+        int readStart = al.pos;
+        auto qb = [&](int i) -> char { ORC_CHECK(i >= 0 && i < (int)queryBases.size(), "read index in CIGAR walk"); return queryBases[i]; };
+        auto ref = [&](int i) -> char { ORC_CHECK(i >= 0 && i < refLen, "reference index in CIGAR walk"); return (char)referenceSequence[i]; };
+        for(size_t cigarI = 0; cigarI < CIGAR.size(); cigarI++) {
+            int index_into_genome = readStart + index_along_genome_fromReadStart;
+            std::string allele, genome; std::vector<int> genome_level;
+            int allele_start = -1;
+            char op = CIGAR[cigarI];
+            switch(op) {
+            case 'M': case '=': case 'X': case 'D':
+                if(op == 'D') { allele = "_"; }
+                else { allele = std::string(1, qb(index_along_unclipped_read)); }
+                genome = std::string(1, ref(index_into_genome));
+                genome_level.push_back(index_into_genome);
+                allele_start = index_along_unclipped_read;
+                while(cigarI + 1 < CIGAR.size() && CIGAR[cigarI + 1] == 'I') {               /* :5042-5065 */
+                    int nextPositionUnclipped = (op == 'D') ? index_along_unclipped_read : index_along_unclipped_read + 1;
+                    allele.push_back(qb(nextPositionUnclipped));
+                    genome.push_back('_'); genome_level.push_back(-1);
+                    index_along_read++; index_along_unclipped_read++; cigarI++;
+                }
+                index_along_genome_fromReadStart++; index_along_read++;
+                if(op != 'D') index_along_unclipped_read++;
+                break;
+            case 'I': {                                                                      /* :5085-5166 */
+                ORC_CHECK(index_along_read == 0, "internal I not attached to a column");
+                std::string a1(1, qb(index_along_unclipped_read)); std::string g1 = "_"; std::vector<int> l1{-1};
+                ORC_CHECK(out.startInRaw == -1, "leading I after start");
+                out.startInRaw = index_along_unclipped_read;
+                while(cigarI + 1 < CIGAR.size() && CIGAR[cigarI + 1] == 'I') {
+                    a1.push_back(qb(index_along_unclipped_read + 1)); g1.push_back('_'); l1.push_back(-1);
+                    index_along_read++; index_along_unclipped_read++; cigarI++;
+                }
+                index_along_read++; index_along_unclipped_read++;
+                out.sequence_aligned.append(a1); out.graph_aligned.append(g1); out.levels.insert(out.levels.end(), l1.begin(), l1.end());
+                out.stopInRaw = index_along_unclipped_read - 1;
+                break; }
+            case 'N': throw oracle_error("N character in CIGAR");
+            case 'S': index_along_unclipped_read++; break;
+            case 'H': break;
+            default: throw oracle_error("Unknown element of CIGAR string");
+            }
+            if(allele != "") {                                                               /* :5185-5213 */
+                out.sequence_aligned.append(allele); out.graph_aligned.append(genome);
+                out.levels.insert(out.levels.end(), genome_level.begin(), genome_level.end());
+                if(out.startInRaw == -1) out.startInRaw = allele_start;
+                out.stopInRaw = index_along_unclipped_read - 1;
+            }
+        }
+        ORC_CHECK(out.startInRaw < out.stopInRaw, "sequence_aligned_startInRaw < stopInRaw");   /* :5252 */
+        bool haveNonMinusOne = false;
+        for(int l : out.levels) if(l != -1) { haveNonMinusOne = true; break; }
+        if(!haveNonMinusOne) return false;
+        size_t positions_nonGap = 0;
+        for(size_t c = 0; c < out.levels.size(); c++) {                                      /* :5290-5317 */
+            if(out.levels[c] != -1) {
+                int l = out.levels[c] - al.offset;
+                ORC_CHECK(l >= 0 && l < refLen, "translation index");
+                out.levels[c] = reference2level[l];
+            }
+            if(out.sequence_aligned[c] != '_') positions_nonGap++;
+        }
+        ORC_CHECK((long long)positions_nonGap == (out.stopInRaw - out.startInRaw + 1), "positions_nonGap");
+        return true;
+    }
+
+    /* processBAM::cleanInitialAlignment, mapper/processBAM.cpp:4621-4792 */
+    static void cleanInitialAlignment(std::vector<int>& lv, std::string& ga, std::string& sa)
+    {
+        bool inStretch = false; int stretchStart = -1; int balance = 0; bool cleaningNecessary = false;
+        for(size_t pI = 0; pI < lv.size(); pI++) {
+            if(lv[pI] == -1 || (ga[pI] == '_' && sa[pI] == '_')) {
+                if(!inStretch) { stretchStart = (int)pI; inStretch = true; }
+                if(lv[pI] == -1) balance++;
+                if(ga[pI] == '_' && sa[pI] == '_') { ORC_CHECK(lv[pI] != -1, "double gap without level"); balance--; }
+            } else if(inStretch) {
+                int stretchStop = (int)pI - 1;
+                if(balance == 0) {
+                    int Ls = stretchStop - stretchStart + 1;
+                    std::string inserted; std::vector<int> gapLevels;
+                    for(int p = stretchStart; p <= stretchStop; p++) {
+                        if(lv[p] == -1) inserted.push_back(sa[p]); else gapLevels.push_back(lv[p]);
+                    }
+                    ORC_CHECK(inserted.size() == gapLevels.size() && (int)inserted.size() == Ls / 2, "clean stretch balance");
+                    cleaningNecessary = true;
+                    for(int p = stretchStart; p <= stretchStop; p++) {
+                        int i = p - stretchStart;
+                        if(i < Ls / 2) { lv[p] = gapLevels[i]; ga[p] = '_'; sa[p] = inserted[i]; }
+                        else { lv[p] = -1; ga[p] = '_'; sa[p] = '_'; }
+                    }
+                }
+                inStretch = false; stretchStart = -1; balance = 0;
+            }
+        }
+        if(cleaningNecessary) {
+            std::vector<int> nl; std::string ng, ns;
+            for(size_t pI = 0; pI < lv.size(); pI++)
+                if(!(lv[pI] == -1 && ga[pI] == '_' && sa[pI] == '_')) { nl.push_back(lv[pI]); ng.push_back(ga[pI]); ns.push_back(sa[pI]); }
+            lv = nl; ga = ng; sa = ns;
+        }
+    }
+
+    /* processBAM::restrictInitialAlignmentToNoGapAreas, mapper/processBAM.cpp:4461-4619 */
+    void restrictInitialAlignmentToNoGapAreas(std::vector<int>& lv, std::string& ga, std::string& sa, int& startInRaw, int& stopInRaw) const
+    {
+        int runningBegin = -1; int sequenceCharacters = 0;
+        std::vector<std::pair<int, int>> pre;
+        for(size_t lI = 0; lI < lv.size(); lI++) {
+            if(sa[lI] != '_') sequenceCharacters++;
+            int graph_level = lv[lI];
+            if(graph_level != -1 && g.inGraphGapStretch.at(graph_level)) {
+                if(runningBegin != -1) { pre.push_back({runningBegin, (int)lI - 1}); runningBegin = -1; }
+            } else if(runningBegin == -1) runningBegin = (int)lI;
+        }
+        if(runningBegin != -1 && runningBegin != 0) {                               /* :4492-4502: a stretch from column 0 to the end is not recorded */
+            int e = (int)lv.size() - 1;
+            if(e >= runningBegin) pre.push_back({runningBegin, e});
+        }
+        std::vector<std::pair<int, int>> possible;
+        for(auto s : pre) {
+            while(lv.at(s.first) == -1) { s.first++; if(s.first > s.second || s.first > (int)lv.size() - 1) break; }
+            while(lv.at(s.second) == -1) { s.second--; if(s.second < s.first || s.second < 0) break; }
+            if(s.second >= s.first) possible.push_back(s);
+        }
+        /* std::sort by length ascending then .back() (:4533-4552): libstdc++ uses insertion sort below 16
+         * elements, which is stable, so among equal longest stretches the LAST one in column order is taken. */
+        std::stable_sort(possible.begin(), possible.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+            return (a.second - a.first + 1) < (b.second - b.first + 1); });
+        if(possible.size() > 0) {
+            std::pair<int, int> sel = possible.back();
+            int newStart = startInRaw, newStop = stopInRaw;
+            for(int lI = 0; lI < sel.first; lI++) if(sa[lI] != '_') newStart++;
+            for(int lI = sel.second + 1; lI < (int)lv.size(); lI++) if(sa[lI] != '_') newStop--;
+            int stretchChars = 0;
+            std::vector<int> nl; std::string ng, ns;
+            for(int lI = sel.first; lI <= sel.second; lI++) { nl.push_back(lv[lI]); ng.push_back(ga[lI]); ns.push_back(sa[lI]); if(sa[lI] != '_') stretchChars++; }
+            if(((double)stretchChars / (double)sequenceCharacters) > 0.3) { lv = nl; ga = ng; sa = ns; startInRaw = newStart; stopInRaw = newStop; }
+        }
+    }
+
+    /* processBAM::PRGContigAlignment2Seed, mapper/processBAM.cpp:2491-3017; returns the sequenceSeed
+     * (the only one alignment2Chain hands on, :3126).  `restrictGaps` = false reproduces the all-false
+     * inGraphGapStretch vector of --action testChainExtension (HLA-LA.cpp:1812-1814). */
+    Chain PRGContigAlignment2Seed(const ContigAlignment& al, bool restrictGaps) const
+    {
+        std::vector<int> lv; std::string ga, sa;
+        int startInRaw = al.startInRaw, stopInRaw = al.stopInRaw;
+        ORC_CHECK(al.levels.size() > 0, "empty contig alignment");
+        size_t firstColumn = 0;
+        while(al.levels.at(firstColumn) == -1) { firstColumn++; startInRaw++; }
+        size_t lastColumn = al.levels.size() - 1;
+        while(al.levels.at(lastColumn) == -1) { lastColumn--; stopInRaw--; }
+        ORC_CHECK(firstColumn < lastColumn, "firstColumn < lastColumn");                      /* :2535 */
+        int lastInserted = -1;
+        for(size_t c = firstColumn; c <= lastColumn; c++) {                                    /* :2540-2579 */
+            if(c == firstColumn) { lv.push_back(al.levels[c]); ga.push_back(al.graph_aligned[c]); sa.push_back(al.sequence_aligned[c]); lastInserted = al.levels[c]; }
+            else if(al.levels[c] == -1) { lv.push_back(-1); ga.push_back(al.graph_aligned[c]); sa.push_back(al.sequence_aligned[c]); }
+            else {
+                if(lastInserted + 1 != al.levels[c]) {
+                    ORC_CHECK(lastInserted + 1 < al.levels[c], "levels must increase");
+                    for(int l = lastInserted + 1; l <= al.levels[c] - 1; l++) { lv.push_back(l); ga.push_back('_'); sa.push_back('_'); }
+                }
+                lv.push_back(al.levels[c]); ga.push_back(al.graph_aligned[c]); sa.push_back(al.sequence_aligned[c]); lastInserted = al.levels[c];
+            }
+        }
+        cleanInitialAlignment(lv, ga, sa);
+        int before = (int)lv.size();
+        if(restrictGaps) restrictInitialAlignmentToNoGapAreas(lv, ga, sa, startInRaw, stopInRaw);
+        int removed = before - (int)lv.size();
+        size_t before_matches = 0;
+        for(size_t i = 0; i < ga.size(); i++) if(ga[i] == sa[i]) before_matches++;
+        ORC_CHECK(lv.front() != -1 && lv.back() != -1, "seed ends defined");
+
+        /* sequence-variant path finding, :2676-2835 */
+        struct SB { double S; std::set<int> takenEdges; };
+        std::vector<std::map<int, SB>> bt(lv.size() + 1);
+        ORC_CHECK(lv[0] < g.L, "first level range");
+        for(int n : g.level_nodes.at(lv[0])) bt[0][n].S = 0;
+        size_t lastNonGap = 0;
+        for(size_t columnI = 1; columnI <= lv.size(); columnI++) {
+            if(lv[columnI - 1] == -1) continue;
+            int graphLevel = lv[columnI - 1];
+            char sequenceCharacter = sa[columnI - 1], graphCharacter = ga[columnI - 1];
+            bool seedIsMatch = (sequenceCharacter == graphCharacter);
+            for(auto& nodeIt : bt[lastNonGap]) {
+                int fromN = nodeIt.first;
+                ORC_CHECK(g.node_level[fromN] == graphLevel, "rethreading level");
+                for(int e : g.out_e[fromN]) {
+                    eA->stat_edges++;
+                    if(seedIsMatch && (char)g.elabel[e] != sequenceCharacter) continue;
+                    double S = ((char)g.elabel[e] == sequenceCharacter) ? 1 : 0;
+                    int toN = g.eto[e];
+                    double cand = nodeIt.second.S + S;
+                    auto it = bt[columnI].find(toN);
+                    if(it == bt[columnI].end()) { bt[columnI][toN].S = cand; bt[columnI][toN].takenEdges.insert(e); }
+                    else if(it->second.S == cand) it->second.takenEdges.insert(e);
+                    else if(it->second.S < cand) { it->second.takenEdges.clear(); it->second.takenEdges.insert(e); it->second.S = cand; }
+                }
+            }
+            ORC_CHECK(bt[columnI].size() > 0, "rethreading found no edge");
+            lastNonGap = columnI;
+        }
+        /* backtrace, :2838-2970 */
+        std::vector<int> bl, be; std::string bg, bs;
+        double Smax = 0; bool first = true;
+        for(auto& n : bt[lv.size()]) if(first || n.second.S > Smax) { Smax = n.second.S; first = false; }
+        int running = -1;
+        for(auto& n : bt[lv.size()]) if(n.second.S == Smax) { running = n.first; break; }       /* *(runningN.begin()), :2867 */
+        for(int columnI = (int)lv.size(); columnI >= 1; columnI--) {
+            if(lv[columnI - 1] == -1) { bl.push_back(-1); be.push_back(-1); bg.push_back('_'); bs.push_back(sa[columnI - 1]); continue; }
+            const SB& sb = bt[columnI].at(running);
+            int e = *sb.takenEdges.begin();                                                       /* first edge in std::set<Edge*> order, :2906-2915 */
+            bl.push_back(lv[columnI - 1]); be.push_back(e); bg.push_back((char)g.elabel[e]); bs.push_back(sa[columnI - 1]);
+            running = g.efrom[e];
+        }
+        std::reverse(bl.begin(), bl.end()); std::reverse(be.begin(), be.end()); std::reverse(bg.begin(), bg.end()); std::reverse(bs.begin(), bs.end());
+        Chain r;
+        r.edges = be; r.levels = bl; r.graph_aligned = bg; r.sequence_aligned = bs;
+        r.sequence_begin = startInRaw; r.sequence_end = stopInRaw; r.reverse = al.reverse;
+        r.removed_columns_noGap_restriction = removed;
+        size_t after_matches = 0;
+        for(size_t i = 0; i < bg.size(); i++) if(bg[i] == bs[i]) after_matches++;
+        r.improvement_through_bt = (double)after_matches / (double)bg.size() - (double)before_matches / (double)ga.size();
+        r.is_from_BWAseed.assign(r.size(), 1);                                                    /* :3123-3124 */
+        return r;
+    }
+
+    /* processBAM::alignment_get_startstop_PRGcoordinates, mapper/processBAM.cpp:3840-3898; GetEndPosition(false,true)
+     * of BamTools 2.5.1 (un-vendored): Position + sum of M,=,X,D,N lengths - 1. */
+    std::pair<int, int> startstop(const BamRecord& al) const
+    {
+        const int* tr = contigs.level.data() + contigs.off[al.contig];
+        long long refLen = contigs.off[al.contig + 1] - contigs.off[al.contig];
+        int readStart = al.pos, readStop = al.pos;
+        for(uint32_t c : al.cigar) { char op = CIGAR_OPS[c & 15u]; if(op == 'M' || op == '=' || op == 'X' || op == 'D' || op == 'N') readStop += (int)(c >> 4); }
+        readStop -= 1;
+        int a = readStart - al.offset, b = readStop - al.offset;
+        ORC_CHECK(a >= 0 && a < refLen && b >= 0 && b < refLen, "start/stop translation index");
+        return {tr[a], tr[b]};
+    }
+
+    /* alignerBase::alignedReadPair_strandsValid, alignerBase.cpp:213-244 */
+    static bool strandsValid(const Chain& a1, const Chain& a2)
+    {
+        if(a1.firstLevel() != -1 && a2.firstLevel() != -1 && a1.reverse != a2.reverse) {
+            if(!a1.reverse) return a1.firstLevel() < a2.firstLevel();
+            return a1.lastLevel() > a2.lastLevel();
+        }
+        return false;
+    }
+    /* verboseSeedChain::alignment_{end,begin}_originalSequenceAnchors, verboseSeedChain.h:230-280 */
+    std::map<int, int> anchors(const std::vector<int>& levels_for_anchors) const
+    {
+        std::map<int, int> r;
+        for(int level : levels_for_anchors)
+            for(auto& it : contigs.level2pos.at(level))
+                if(r.count(it.first) == 0) r[it.first] = it.second;
+        return r;
+    }
+    /* alignerBase::alignedReadPair_pairsDistancesUnderlyingSequences, alignerBase.cpp:290-329 */
+    std::set<int> pairDistances(const Chain& a1, const Chain& a2) const
+    {
+        std::set<int> r; const int scanPositions = 2;
+        const Chain& up = (a1.firstLevel() < a2.firstLevel()) ? a1 : a2;
+        const Chain& down = (a1.firstLevel() < a2.firstLevel()) ? a2 : a1;
+        std::map<int, int> endA = anchors(up.lastLevels(scanPositions)), beginA = anchors(down.firstLevels(scanPositions));
+        for(auto& it : endA) if(beginA.count(it.first)) r.insert(beginA.at(it.first) - it.second - 1);
+        return r;
+    }
+
+    struct PairResult {
+        int status = 0; int best1 = -1, best2 = -1; int nComb = 0; double ll = 0, mapQ = 0; bool strandsOK = false;
+        Chain c1, c2;
+    };
+
+    /* processBAM::assignMappingQualities, mapper/processBAM.cpp:4062-4312 */
+    void assignMappingQualities(PairResult& R, const std::vector<std::pair<unsigned, unsigned>>& idx, const std::vector<double>& LL,
+                                std::pair<double, unsigned> mx, const std::vector<Chain>& r1, const std::vector<Chain>& r2) const
+    {
+        if(idx.size() > 1) {
+            unsigned i1m = idx.at(mx.second).first, i2m = idx.at(mx.second).second;
+            std::vector<double> PP = LL;
+            for(double& p : PP) { p = exp(p - mx.first); ORC_CHECK(p >= 0 && p <= 1, "PP range"); }
+            double S = 0; for(double p : PP) S += p;                                  /* Utilities::normalize_vector, Utilities.cpp:987-999 */
+            for(double& p : PP) p = p / S;
+            R.c1 = r1.at(i1m); R.c2 = r2.at(i2m);
+            double mapQ = PP.at(mx.second);
+            R.mapQ = mapQ;
+            double q1 = 0, q2 = 0;
+            for(size_t i = 0; i < PP.size(); i++) { if(idx[i].first == i1m) q1 += PP[i]; if(idx[i].second == i2m) q2 += PP[i]; }
+            if(q1 > 1) q1 = 1; if(q2 > 1) q2 = 1;
+            R.c1.mapQ = q1; R.c2.mapQ = q2;
+            /* key "c:level:rN:strand:idx" (:4175, 4190) as a tuple -- same key set, same accumulation order */
+            typedef std::tuple<int, char, int, int, int> PKey;    /* mate, graph char, level, strand, sequence index */
+            std::map<PKey, double> conf;
+            auto seqIndex = [](const std::string& sa, bool reverse) {               /* alignedSequence2SequenceIndex, :4117-4153 */
+                std::vector<int> r; int noGap = 0; for(char c : sa) if(c != '_') noGap++;
+                int i_noGap = -1;
+                for(char c : sa) { if(c == '_') r.push_back(-1); else { i_noGap++; r.push_back(reverse ? noGap - i_noGap - 1 : i_noGap); } }
+                return r;
+            };
+            for(size_t i = 0; i < idx.size(); i++) {
+                const Chain& a = r1.at(idx[i].first); const Chain& b = r2.at(idx[i].second);
+                std::vector<int> ia = seqIndex(a.sequence_aligned, a.reverse), ib = seqIndex(b.sequence_aligned, b.reverse);
+                for(size_t j = 0; j < a.size(); j++) conf[PKey(1, a.graph_aligned[j], a.levels[j], a.reverse, ia[j])] += PP[i];
+                for(size_t j = 0; j < b.size(); j++) conf[PKey(2, b.graph_aligned[j], b.levels[j], b.reverse, ib[j])] += PP[i];
+            }
+            auto perPos = [&](Chain& c, int mate) {
+                std::vector<int> ic = seqIndex(c.sequence_aligned, c.reverse);
+                c.mapQ_perPosition.clear();
+                for(size_t j = 0; j < c.size(); j++) {
+                    double Q = conf.at(PKey(mate, c.graph_aligned[j], c.levels[j], c.reverse, ic[j]));
+                    ORC_CHECK((Q - 1) <= 1e-5, "position confidence > 1");
+                    if(Q > 1) Q = 1;
+                    c.mapQ_perPosition.push_back((char)PCorrectToPhred(Q));
+                }
+            };
+            perPos(R.c1, 1); perPos(R.c2, 2);
+        } else {
+            R.mapQ = 1; R.c1.mapQ = 1; R.c2.mapQ = 1;
+            char Phred1 = (char)PCorrectToPhred(1);
+            R.c1.mapQ_perPosition.assign(R.c1.size(), Phred1);
+            R.c2.mapQ_perPosition.assign(R.c2.size(), Phred1);
+        }
+    }
+};
+
+static std::string invertRead(const std::string& s, bool complement)
+{
+    std::string r(s.rbegin(), s.rend());
+    if(complement) for(char& c : r) c = complementChar(c);
+    return r;
+}
+
+} /* namespace orc */
+
+/* ============================================================================ C interface */
+
+using namespace orc;
+
+struct orc_handle { Processor P; std::string err; };
+
+static thread_local std::string g_err;
+
+static void storeChain(const Chain& c, int ci, int stride, hlala_chains_out* o, int status)
+{
+    if(!o) return;
+    if(o->status) o->status[ci] = status;
+    if(status != HLALA_CHAIN_OK) { if(o->n_cols) o->n_cols[ci] = 0; return; }
+    int n = (int)c.size();
+    if(n > stride) { if(o->status) o->status[ci] = HLALA_CHAIN_ERR_COLUMNS; if(o->n_cols) o->n_cols[ci] = 0; return; }
+    if(o->n_cols) o->n_cols[ci] = n;
+    if(o->seq_begin) o->seq_begin[ci] = c.sequence_begin;
+    if(o->seq_end) o->seq_end[ci] = c.sequence_end;
+    if(o->removed_cols) o->removed_cols[ci] = c.removed_columns_noGap_restriction;
+    if(o->ll) o->ll[ci] = c.ll;
+    if(o->dp_iters) { o->dp_iters[2 * ci] = c.dp_iters[0]; o->dp_iters[2 * ci + 1] = c.dp_iters[1]; }
+    if(o->dp_score) { o->dp_score[2 * ci] = c.dp_score[0]; o->dp_score[2 * ci + 1] = c.dp_score[1]; }
+    size_t base = (size_t)ci * stride;
+    for(int j = 0; j < n; j++) {
+        if(o->col_level) o->col_level[base + j] = c.levels[j];
+        if(o->col_edge) o->col_edge[base + j] = c.edges[j];
+        if(o->col_gchar) o->col_gchar[base + j] = (uint8_t)c.graph_aligned[j];
+        if(o->col_schar) o->col_schar[base + j] = (uint8_t)c.sequence_aligned[j];
+        if(o->col_fromseed) o->col_fromseed[base + j] = c.is_from_BWAseed[j];
+    }
+}
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+orc_handle* orc_create(const hlala_graph_desc* graph, const hlala_contigs_desc* contigs, const hlala_params* params)
+{
+    try {
+        orc_handle* h = new orc_handle();
+        h->P.g.build(graph);
+        if(contigs) h->P.contigs.build(contigs, graph->n_levels);
+        h->P.params = *params;
+        h->P.eA = new Aligner(&h->P.g);
+        return h;
+    } catch(std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_destroy(orc_handle* h) { if(h) { delete h->P.eA; delete h; } }
+
+int orc_graph_info(orc_handle* h, hlala_graph_info* info)
+{
+    const Graph& g = h->P.g;
+    memset(info, 0, sizeof(*info));
+    info->n_levels = g.L; info->n_nodes = (int)g.node_level.size(); info->n_edges = (int)g.efrom.size(); info->n_paths = (int)g.paths.size();
+    for(auto& a : g.jump_fwd) info->n_jump_entries += (int64_t)a.second.size();
+    for(auto& p : g.paths) info->n_path_edges += (int64_t)p.size();
+    for(auto& m : h->P.contigs.level2pos) info->n_levelpos_entries += (int64_t)m.size();
+    for(auto& l : g.level_nodes) info->max_nodes_per_level = std::max(info->max_nodes_per_level, (int)l.size());
+    for(auto& l : g.out_e) info->max_out_degree = std::max(info->max_out_degree, (int)l.size());
+    for(auto& l : g.in_e) info->max_in_degree = std::max(info->max_in_degree, (int)l.size());
+    for(auto b : g.inGraphGapStretch) info->n_gap_stretch_levels += b;
+    return 0;
+}
+int orc_graph_get_paths(orc_handle* h, int32_t* first_node, int32_t* last_node, int32_t* length)
+{
+    const Graph& g = h->P.g;
+    for(size_t i = 0; i < g.paths.size(); i++) { first_node[i] = g.efrom[g.paths[i].front()]; last_node[i] = g.eto[g.paths[i].back()]; length[i] = (int)g.paths[i].size(); }
+    return 0;
+}
+int orc_graph_get_gap_stretch(orc_handle* h, uint8_t* out)
+{
+    memcpy(out, h->P.g.inGraphGapStretch.data(), h->P.g.inGraphGapStretch.size());
+    return 0;
+}
+
+/* known-answer helpers */
+int orc_intervals_overlap(int x1, int x2, int y1, int y2) { return intervalsOverlap(x1, x2, y1, y2) ? 1 : 0; }
+int orc_phred(int n, const double* p_correct, uint8_t* phred_out, const uint8_t* phred_in, double* p_out)
+{
+    for(int i = 0; i < n; i++) {
+        if(p_correct && phred_out) phred_out[i] = PCorrectToPhred(p_correct[i]);
+        if(phred_in && p_out) p_out[i] = PhredToPCorrect(phred_in[i]);
+    }
+    return 0;
+}
+int orc_rand_r(int n, uint32_t* seeds_inout, int32_t* values_out)
+{
+    for(int i = 0; i < n; i++) { unsigned int s = seeds_inout[i]; values_out[i] = rand_r(&s); seeds_inout[i] = s; }
+    return 0;
+}
+double orc_normal_logpdf_penalty(double mean, double sd) { return log(normal_pdf(mean, sd, mean + 8 * sd)); }
+
+/* extendSeedChain + scoreOneAlignment over seed chains handed in directly (testChainExtension protocol).
+ * Read r's bases are in alignment orientation; scoring needs the original-orientation read
+ * (processBAM.cpp:3147-3166), derived here from the chain's reverse flag. */
+int orc_extend_seeds(orc_handle* h, const hlala_seeds_in* in, hlala_chains_out* out, int64_t* stats /* [4] calls, iters, cells, edges */)
+{
+    try {
+        Processor& P = h->P;
+        Aligner& A = *P.eA;
+        A.stat_calls = A.stat_iters = A.stat_cells = A.stat_edges = 0;
+        int stride = P.params.max_columns;
+        for(int c = 0; c < in->n_chains; c++) {
+            int r = in->chain_read[c];
+            std::string seq((const char*)in->read_bases + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
+            std::string qual((const char*)in->read_quals + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
+            Chain s;
+            s.sequence_begin = in->chain_seq_begin[c]; s.sequence_end = in->chain_seq_end[c]; s.reverse = in->chain_reverse[c] != 0;
+            for(int j = in->col_off[c]; j < in->col_off[c + 1]; j++) {
+                s.levels.push_back(in->col_level[j]); s.edges.push_back(in->col_edge[j]);
+                s.graph_aligned.push_back((char)in->col_gchar[j]); s.sequence_aligned.push_back((char)in->col_schar[j]);
+            }
+            s.is_from_BWAseed.assign(s.size(), 1);
+            Chain e = A.extendSeedChain(seq, s, P.params.rng_seed + 2u * (unsigned)c, P.params.rng_seed + 2u * (unsigned)c + 1u);
+            e.checkLevelContiguity();
+            std::string oseq = s.reverse ? invertRead(seq, true) : seq;
+            std::string oqual = s.reverse ? invertRead(qual, false) : qual;
+            e.ll = A.scoreOneAlignment(e, oseq, oqual, P.params.long_read_mode != 0);
+            storeChain(e, c, stride, out, HLALA_CHAIN_OK);
+        }
+        if(stats) { stats[0] = A.stat_calls; stats[1] = A.stat_iters; stats[2] = A.stat_cells; stats[3] = A.stat_edges; }
+        return 0;
+    } catch(std::exception& e) { g_err = e.what(); return -1; }
+}
+
+/* processBAM::alignOneReadPair (mapper/processBAM.cpp:3129-3616) over a batch; optionally stops after the
+ * projection stage.  seeds_out / ext_out / pairs_out may be NULL. */
+int orc_align_batch(orc_handle* h, const hlala_batch_in* in, hlala_chains_out* seeds_out, hlala_chains_out* ext_out,
+                    hlala_pairs_out* pairs_out, int stop_after_projection, int64_t* stats)
+{
+    try {
+        Processor& P = h->P;
+        Aligner& A = *P.eA;
+        A.stat_calls = A.stat_iters = A.stat_cells = A.stat_edges = 0;
+        int stride = P.params.max_columns;
+        bool longRead = P.params.long_read_mode != 0;
+        double IS_mean = P.params.insert_mean, IS_sd = P.params.insert_sd;
+        double max_insertsize_penalty_log = log(normal_pdf(IS_mean, IS_sd, IS_mean + 8 * IS_sd));   /* processBAM.cpp:2342-2346 */
+        for(int p = 0; p < in->n_pairs; p++) {
+            std::vector<Chain> ext[2]; std::vector<double> ll[2]; std::vector<int> extIdx[2];
+            bool pairErr = false;
+            for(int m = 0; m < 2; m++) {
+                int r = 2 * p + m;
+                std::string seq((const char*)in->read_bases + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
+                std::string qual((const char*)in->read_quals + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
+                int prim = in->read_primary[r];
+                bool primReverse = in->chain_reverse[prim] != 0;
+                /* oneRead in original orientation: invert() if the primary is on the reverse strand (:3147-3166) */
+                std::string oseq = primReverse ? invertRead(seq, true) : seq;
+                std::string oqual = primReverse ? invertRead(qual, false) : qual;
+                std::map<std::string, int> alignments_scores;                                            /* :3198 */
+                for(int c = in->chain_off[r]; c < in->chain_off[r + 1]; c++) {
+                    BamRecord al; al.contig = in->chain_contig[c]; al.pos = in->chain_pos[c]; al.offset = in->chain_offset[c];
+                    al.as = in->chain_as[c]; al.reverse = in->chain_reverse[c] != 0;
+                    al.cigar.assign(in->cigar + in->cigar_off[c], in->cigar + in->cigar_off[c + 1]);
+                    std::pair<int, int> ss = P.startstop(al);
+                    std::string id = std::to_string(ss.first) + "//" + std::to_string(ss.second);
+                    int score = al.as;
+                    if(al.reverse != primReverse) {                                                     /* :3216 */
+                        storeChain(Chain(), c, stride, seeds_out, HLALA_CHAIN_SKIP_STRAND);
+                        storeChain(Chain(), c, stride, ext_out, HLALA_CHAIN_SKIP_STRAND);
+                        continue;
+                    }
+                    /* alignment2Chain (:3019-3127) is evaluated BEFORE the duplicate test in the reference (:3225 vs :3234);
+                     * its result is discarded for duplicates, so only its asserts could matter. */
+                    ContigAlignment ca;
+                    bool ok = P.transformBAMreadToInternalAlignment(al, seq, ca);
+                    ORC_CHECK(ok, "alignment consists of insertions only");
+                    Chain seed = P.PRGContigAlignment2Seed(ca, true);
+                    if(alignments_scores.count(id) && alignments_scores.at(id) >= score) {               /* :3234 */
+                        storeChain(Chain(), c, stride, seeds_out, HLALA_CHAIN_SKIP_DUP);
+                        storeChain(Chain(), c, stride, ext_out, HLALA_CHAIN_SKIP_DUP);
+                        continue;
+                    }
+                    seed.checkConcordance(seq);
+                    storeChain(seed, c, stride, seeds_out, HLALA_CHAIN_OK);
+                    if(stop_after_projection) { if(alignments_scores.count(id) == 0 || alignments_scores.at(id) < score) alignments_scores[id] = score; continue; }
+                    Chain e = A.extendSeedChain(seq, seed, P.params.rng_seed + 2u * (unsigned)c, P.params.rng_seed + 2u * (unsigned)c + 1u);
+                    e.ll = A.scoreOneAlignment(e, oseq, oqual, longRead);
+                    storeChain(e, c, stride, ext_out, HLALA_CHAIN_OK);
+                    if((int)e.size() > stride) pairErr = true;
+                    ext[m].push_back(e); ll[m].push_back(e.ll); extIdx[m].push_back(c);
+                    if(alignments_scores.count(id) == 0 || alignments_scores.at(id) < score) alignments_scores[id] = score;
+                }
+            }
+            if(stop_after_projection || !pairs_out) continue;
+            ORC_CHECK(ext[0].size() > 0 && ext[1].size() > 0, "no extended chains for a mate");           /* :3393-3394 */
+            /* pairing loop, :3408-3506 */
+            std::vector<std::pair<unsigned, unsigned>> idx; std::vector<double> LL;
+            for(unsigned i1 = 0; i1 < ext[0].size(); i1++)
+                for(unsigned i2 = 0; i2 < ext[1].size(); i2++) {
+                    double combined = ll[0][i1] + ll[1][i2];
+                    const Chain& c1 = ext[0][i1]; const Chain& c2 = ext[1][i2];
+                    double ll_IS;
+                    if(Processor::strandsValid(c1, c2)) {
+                        std::set<int> dist = P.pairDistances(c1, c2);
+                        if(dist.size()) {
+                            std::vector<double> lls;
+                            for(int d : dist) {
+                                double dP = normal_pdf(IS_mean, IS_sd, d);
+                                if(dP <= 0) lls.push_back(max_insertsize_penalty_log); else lls.push_back(log(dP));
+                            }
+                            ll_IS = firstMax(lls).first;
+                        } else ll_IS = max_insertsize_penalty_log;
+                    } else ll_IS = max_insertsize_penalty_log;
+                    combined += ll_IS;
+                    LL.push_back(combined); idx.push_back({i1, i2});
+                }
+            auto mx = firstMax(LL);                                                                    /* :3538 */
+            Processor::PairResult R;
+            R.best1 = idx[mx.second].first; R.best2 = idx[mx.second].second; R.nComb = (int)idx.size(); R.ll = mx.first;
+            R.c1 = ext[0][R.best1]; R.c2 = ext[1][R.best2];
+            P.assignMappingQualities(R, idx, LL, mx, ext[0], ext[1]);
+            R.strandsOK = Processor::strandsValid(R.c1, R.c2);
+            if(pairs_out->pair_status) pairs_out->pair_status[p] = pairErr ? -1 : 0;
+            if(pairs_out->best_chain) { pairs_out->best_chain[2 * p] = extIdx[0][R.best1]; pairs_out->best_chain[2 * p + 1] = extIdx[1][R.best2]; }
+            if(pairs_out->n_combinations) pairs_out->n_combinations[p] = R.nComb;
+            if(pairs_out->pair_ll) pairs_out->pair_ll[p] = R.ll;
+            if(pairs_out->pair_mapq) pairs_out->pair_mapq[p] = R.mapQ;
+            if(pairs_out->mate_mapq) { pairs_out->mate_mapq[2 * p] = R.c1.mapQ; pairs_out->mate_mapq[2 * p + 1] = R.c2.mapQ; }
+            if(pairs_out->strands_valid) pairs_out->strands_valid[p] = R.strandsOK ? 1 : 0;
+            for(int m = 0; m < 2; m++) {
+                const Chain& c = m ? R.c2 : R.c1;
+                int r = 2 * p + m; int n = (int)c.size();
+                if(n > stride) { if(pairs_out->n_cols) pairs_out->n_cols[r] = 0; continue; }
+                if(pairs_out->n_cols) pairs_out->n_cols[r] = n;
+                size_t base = (size_t)r * stride;
+                for(int j = 0; j < n; j++) {
+                    if(pairs_out->col_level) pairs_out->col_level[base + j] = c.levels[j];
+                    if(pairs_out->col_edge) pairs_out->col_edge[base + j] = c.edges[j];
+                    if(pairs_out->col_gchar) pairs_out->col_gchar[base + j] = (uint8_t)c.graph_aligned[j];
+                    if(pairs_out->col_schar) pairs_out->col_schar[base + j] = (uint8_t)c.sequence_aligned[j];
+                    if(pairs_out->col_fromseed) pairs_out->col_fromseed[base + j] = c.is_from_BWAseed[j];
+                    if(pairs_out->col_mapq) pairs_out->col_mapq[base + j] = (uint8_t)c.mapQ_perPosition[j];
+                }
+            }
+        }
+        if(stats) { stats[0] = A.stat_calls; stats[1] = A.stat_iters; stats[2] = A.stat_cells; stats[3] = A.stat_edges; }
+        return 0;
+    } catch(std::exception& e) { g_err = e.what(); return -1; }
+}
+
+/* PRGContigAlignment2Seed over column alignments handed in as seeds_in columns WITHOUT edges
+ * (the simulateBAMAlignments route of --action testAlignments2Chains / testChainExtension,
+ * HLA-LA.cpp:1622-1861): seq_begin/seq_end play sequence_aligned_{start,stop}InRaw. */
+int orc_rethread_columns(orc_handle* h, const hlala_seeds_in* in, int restrict_gaps, hlala_chains_out* out)
+{
+    try {
+        Processor& P = h->P;
+        int stride = P.params.max_columns;
+        for(int c = 0; c < in->n_chains; c++) {
+            ContigAlignment ca; ca.startInRaw = in->chain_seq_begin[c]; ca.stopInRaw = in->chain_seq_end[c]; ca.reverse = in->chain_reverse[c] != 0;
+            for(int j = in->col_off[c]; j < in->col_off[c + 1]; j++) {
+                ca.levels.push_back(in->col_level[j]); ca.graph_aligned.push_back((char)in->col_gchar[j]); ca.sequence_aligned.push_back((char)in->col_schar[j]);
+            }
+            Chain s = P.PRGContigAlignment2Seed(ca, restrict_gaps != 0);
+            storeChain(s, c, stride, out, HLALA_CHAIN_OK);
+        }
+        return 0;
+    } catch(std::exception& e) { g_err = e.what(); return -1; }
+}
+
+} /* extern "C" */

@@ -1,0 +1,112 @@
+"""ctypes binding of oracle/_build/liboracle.so -- the CPU checker.  Tests / smoke / bench cpu_baseline only."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from conftest import load_package  # noqa: E402
+
+P = load_package()
+_so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_so)
+        vp = C.c_void_p
+        _lib.orc_create.argtypes = [C.POINTER(P.GraphDesc), C.POINTER(P.ContigsDesc), C.POINTER(P.Params)]
+        _lib.orc_create.restype = vp
+        _lib.orc_destroy.argtypes = [vp]
+        _lib.orc_last_error.restype = C.c_char_p
+        _lib.orc_graph_info.argtypes = [vp, C.POINTER(P.GraphInfo)]
+        _lib.orc_graph_get_paths.argtypes = [vp, P.c_i32p, P.c_i32p, P.c_i32p]
+        _lib.orc_graph_get_gap_stretch.argtypes = [vp, P.c_u8p]
+        _lib.orc_extend_seeds.argtypes = [vp, C.POINTER(P.SeedsIn), C.POINTER(P.ChainsOut), P.c_i64p]
+        _lib.orc_align_batch.argtypes = [vp, C.POINTER(P.BatchIn), C.POINTER(P.ChainsOut), C.POINTER(P.ChainsOut),
+                                         C.POINTER(P.PairsOut), C.c_int, P.c_i64p]
+        _lib.orc_rethread_columns.argtypes = [vp, C.POINTER(P.SeedsIn), C.c_int, C.POINTER(P.ChainsOut)]
+        _lib.orc_intervals_overlap.argtypes = [C.c_int] * 4
+        _lib.orc_phred.argtypes = [C.c_int, P.c_f64p, P.c_u8p, P.c_u8p, P.c_f64p]
+        _lib.orc_rand_r.argtypes = [C.c_int, P.c_u32p, P.c_i32p]
+        _lib.orc_normal_logpdf_penalty.argtypes = [C.c_double, C.c_double]
+        _lib.orc_normal_logpdf_penalty.restype = C.c_double
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class Oracle:
+    def __init__(self, graph, contigs, insert_mean=200.0, insert_sd=35.0, rng_seed=12345, long_read_mode=0, max_columns=384):
+        L = lib()
+        self.max_columns = max_columns
+        g, self._kg = P.fill_struct(P.GraphDesc, graph)
+        params = P.Params(insert_mean, insert_sd, rng_seed, long_read_mode, max_columns, 0)
+        cp = None
+        if contigs is not None:
+            c, self._kc = P.fill_struct(P.ContigsDesc, contigs)
+            cp = C.byref(c)
+        self.h = L.orc_create(C.byref(g), cp, C.byref(params))
+        if not self.h:
+            raise OracleError(L.orc_last_error().decode())
+
+    def _check(self, rc):
+        if rc != 0:
+            raise OracleError(lib().orc_last_error().decode())
+
+    def graph_info(self):
+        gi = P.GraphInfo()
+        lib().orc_graph_info(self.h, C.byref(gi))
+        return gi
+
+    def graph_paths(self):
+        gi = self.graph_info()
+        a = [np.zeros(gi.n_paths, np.int32) for _ in range(3)]
+        lib().orc_graph_get_paths(self.h, *[x.ctypes.data_as(P.c_i32p) for x in a])
+        return a
+
+    def graph_gap_stretch(self):
+        gi = self.graph_info()
+        a = np.zeros(gi.n_levels - 1, np.uint8)
+        lib().orc_graph_get_gap_stretch(self.h, a.ctypes.data_as(P.c_u8p))
+        return a
+
+    def extend_seeds(self, seeds_in):
+        s, keep = P.fill_struct(P.SeedsIn, seeds_in)
+        o, d = P.alloc_chains_out(seeds_in["n_chains"], self.max_columns)
+        stats = np.zeros(4, np.int64)
+        self._check(lib().orc_extend_seeds(self.h, C.byref(s), C.byref(o), stats.ctypes.data_as(P.c_i64p)))
+        d["_stats"] = stats
+        return d
+
+    def rethread_columns(self, seeds_in, restrict_gaps=False):
+        s, keep = P.fill_struct(P.SeedsIn, seeds_in)
+        o, d = P.alloc_chains_out(seeds_in["n_chains"], self.max_columns)
+        self._check(lib().orc_rethread_columns(self.h, C.byref(s), int(restrict_gaps), C.byref(o)))
+        return d
+
+    def align_batch(self, batch_in, stop_after_projection=False):
+        s, keep = P.fill_struct(P.BatchIn, batch_in)
+        so, sd = P.alloc_chains_out(batch_in["n_chains"], self.max_columns)
+        eo, ed = P.alloc_chains_out(batch_in["n_chains"], self.max_columns)
+        po, pd = P.alloc_pairs_out(batch_in["n_pairs"], self.max_columns)
+        stats = np.zeros(4, np.int64)
+        self._check(lib().orc_align_batch(self.h, C.byref(s), C.byref(so), C.byref(eo), C.byref(po),
+                                          int(stop_after_projection), stats.ctypes.data_as(P.c_i64p)))
+        return dict(seeds=sd, ext=ed, pairs=pd, stats=stats)
+
+    def close(self):
+        if self.h:
+            lib().orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,282 @@
+"""Synthetic PRG + read-pair + BWA-like seed generator (numpy only).
+
+Test/bench infrastructure -- NOT part of the product.  Recipe follows the reference's
+`simpleGraphSimulator` (Graph/graphSimulator/simpleGraphSimulator.cpp:20-31, 142-271:
+random scaffold, haplotypes mutated at a given density of which 30 % become '_', one
+haplotype with Poisson-long gaps) and `simulateBAMAlignments` (:273-367: reads drawn
+from the haplotype contigs with their true column alignment), degraded to look like
+`bwa mem -a` output (soft-clipped ends so the extension DP has work, secondary
+alignments on other haplotypes) as laid out in SURVEY.md section 8(d).
+
+Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+OPS = "MIDNSHP=X"
+OP = {c: i for i, c in enumerate(OPS)}
+_COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[a] = b
+
+
+def revcomp(a: np.ndarray) -> np.ndarray:
+    return _COMP[a[..., ::-1]]
+
+
+# --------------------------------------------------------------------------- graph
+
+def make_haplotypes(rng, G, n_mut=2, n_largegap=1, mut_density=0.02, gap_frac=0.3,
+                    gap_start=0.01, gap_mean=10, extra_identical=0):
+    """Aligned haplotypes [H, G] over A,C,G,T,_ (uint8)."""
+    nuc = np.frombuffer(b"ACGT", dtype=np.uint8)
+    scaffold = nuc[rng.integers(0, 4, G)]
+    haps = [scaffold.copy()]
+    for _ in range(n_mut):
+        h = scaffold.copy()
+        ev = rng.random(G) <= mut_density
+        isgap = ev & (rng.random(G) < gap_frac)
+        issnp = ev & ~isgap
+        h[issnp] = nuc[rng.integers(0, 4, int(issnp.sum()))]
+        h[isgap] = ord("_")
+        haps.append(h)
+    for _ in range(n_largegap):
+        h = scaffold.copy()
+        starts = np.nonzero(rng.random(G) <= gap_start)[0]
+        lens = rng.poisson(gap_mean, len(starts))
+        last = -1
+        for s, l in zip(starts, lens):
+            if s <= last or l <= 0:
+                continue
+            e = min(G - 1, s + l - 1)
+            h[s:e + 1] = ord("_")
+            last = e
+        haps.append(h)
+    for i in range(extra_identical):
+        haps.append(haps[i % len(haps)].copy())
+    H = np.stack(haps)
+    # keep the first and last 2 columns gap-free so every contig spans the graph ends
+    H[:, :2] = scaffold[:2]
+    H[:, -2:] = scaffold[-2:]
+    return H
+
+
+def build_graph(H: np.ndarray, k: int = 1):
+    """Levelled DAG from aligned haplotypes.  Node classes at level l = haplotypes sharing the
+    next k symbols (k = 0: one node per level, parallel edges); node / edge creation order =
+    level-major, then first-haplotype order -- this IS the canonical order of the C-ABI."""
+    nh, G = H.shape
+    L = G + 1
+    # class key per (hap, level): polynomial hash of symbols [l, l+k)
+    key = np.zeros((nh, L), dtype=np.uint64)
+    if k > 0:
+        pad = np.concatenate([H, np.zeros((nh, k), dtype=np.uint8)], axis=1).astype(np.uint64)
+        for j in range(k):
+            key[:, :G] = key[:, :G] * np.uint64(257) + pad[:, j:j + G] + np.uint64(1)
+    key[:, G] = 0  # single sink class
+
+    def first_occurrence_rank(keys):
+        """keys [nh, N] -> (rank [nh, N] of each hap's class in first-hap order, n_classes [N])"""
+        n, N = keys.shape
+        rep = np.tile(np.arange(n)[:, None], (1, N))
+        for h in range(n):
+            for h2 in range(h):
+                m = (keys[h] == keys[h2]) & (rep[h] == h)
+                rep[h][m] = np.minimum(rep[h][m], rep[h2][m])
+        is_first = rep == np.arange(n)[:, None]
+        cum = np.cumsum(is_first, axis=0) - 1      # rank of a first occurrence
+        rank = np.take_along_axis(cum, rep, axis=0)
+        return rank.astype(np.int64), is_first.sum(axis=0).astype(np.int64), is_first
+
+    nrank, ncls, _ = first_occurrence_rank(key)
+    level_off = np.concatenate([[0], np.cumsum(ncls)]).astype(np.int64)
+    n_nodes = int(level_off[-1])
+    node_level = np.repeat(np.arange(L), ncls).astype(np.int32)
+    node_id = level_off[:-1][None, :] + nrank              # [nh, L]
+    # edges: unique (from, label, to) per level in first-hap order
+    ekey = (node_id[:, :G].astype(np.uint64) * np.uint64(256) + H.astype(np.uint64)) * np.uint64(1 << 20) \
+        + nrank[:, 1:].astype(np.uint64)
+    erank, ecls, efirst = first_occurrence_rank(ekey)
+    e_off = np.concatenate([[0], np.cumsum(ecls)]).astype(np.int64)
+    n_edges = int(e_off[-1])
+    edge_id = e_off[:-1][None, :] + erank                   # [nh, G]
+    edge_from = np.zeros(n_edges, dtype=np.int32)
+    edge_to = np.zeros(n_edges, dtype=np.int32)
+    edge_label = np.zeros(n_edges, dtype=np.uint8)
+    for h in range(nh):
+        m = efirst[h]
+        ids = edge_id[h][m]
+        edge_from[ids] = node_id[h, :G][m]
+        edge_to[ids] = node_id[h, 1:][m]
+        edge_label[ids] = H[h][m]
+    return dict(n_levels=L, n_nodes=n_nodes, n_edges=n_edges, node_level=node_level,
+                edge_from=edge_from, edge_to=edge_to, edge_label=edge_label,
+                hap_edge=edge_id.astype(np.int32), hap_node=node_id.astype(np.int32))
+
+
+def make_contigs(H: np.ndarray):
+    """Gap-free haplotype sequences + position->level tables (translation/<id>.txt)."""
+    seqs, levels, off = [], [], [0]
+    for h in range(H.shape[0]):
+        nz = np.nonzero(H[h] != ord("_"))[0]
+        seqs.append(H[h][nz])
+        levels.append(nz.astype(np.int32))
+        off.append(off[-1] + len(nz))
+    return dict(n_contigs=H.shape[0], contig_off=np.asarray(off, dtype=np.int64),
+                contig_seq=np.concatenate(seqs), contig_level=np.concatenate(levels),
+                contig_seqid=np.arange(1, H.shape[0] + 1, dtype=np.int32))
+
+
+def make_world(seed=1, G=25000, k=1, **kw):
+    rng = np.random.default_rng(seed)
+    H = make_haplotypes(rng, G, **kw)
+    g = build_graph(H, k)
+    c = make_contigs(H)
+    return dict(H=H, graph=g, contigs=c, G=G)
+
+
+# --------------------------------------------------------------------------- reads + seeds
+
+def _cigar(ops):
+    return [(int(l) << 4) | OP[o] for l, o in ops if l > 0]
+
+
+def make_batch(world, n_pairs, seed=3, read_len=150, ins_mean=200.0, ins_sd=35.0, clip_max=30,
+               p_secondary=0.5, max_secondary=4, p_random_secondary=0.1, indel_read_frac=0.05,
+               qual_lo=2, qual_hi=40, p_no_clip=0.15, hardclip_frac=0.0, p_flip=0.5):
+    """Read pairs with BAM-like alignment records in the hlala_batch_in layout."""
+    rng = np.random.default_rng(seed)
+    C = world["contigs"]
+    nh = C["n_contigs"]
+    off = C["contig_off"]
+    clen = np.diff(off)
+    seq = C["contig_seq"]
+    lvl = C["contig_level"]
+    nuc = np.frombuffer(b"ACGT", dtype=np.uint8)
+    G = world["G"]
+    # level -> position of the first base at or after that level, per contig
+    pos_at_level = []
+    for h in range(nh):
+        l = lvl[off[h]:off[h + 1]]
+        pos_at_level.append(np.searchsorted(l, np.arange(G + 1), side="left"))
+
+    reads_b, reads_q, read_off = [], [], [0]
+    chain_off = [0]
+    read_primary = []
+    ch = dict(contig=[], pos=[], offset=[], AS=[], rev=[], cig=[])
+    truth_level0 = []
+
+    # ins_mean/ins_sd describe the INNER distance between the mates (what the reference's pairing
+    # step measures: pos_downstream - pos_upstream - 1, alignerBase.cpp:290-329)
+    frag = np.maximum(read_len + 10, np.rint(rng.normal(ins_mean, ins_sd, n_pairs)).astype(np.int64) + 2 * read_len)
+    hap = rng.integers(0, nh, n_pairs)
+    for p in range(n_pairs):
+        h = int(hap[p])
+        F = int(min(frag[p], clen[h] - 2))
+        s = int(rng.integers(0, clen[h] - F))
+        flip = rng.random() < p_flip
+        for m in range(2):
+            upstream = (m == 0) != flip          # which physical mate this read is
+            rs = s if upstream else s + F - read_len
+            rev = not upstream                   # downstream mate aligns to the reverse strand
+            base = off[h] + rs
+            # optional indel: read consumes read_len +/- 1 reference bases
+            ops_mid = None
+            if rng.random() < indel_read_frac:
+                at = int(rng.integers(40, read_len - 40))
+                if rng.random() < 0.5:           # insertion in read
+                    ln = int(rng.integers(1, 4))
+                    ref = seq[base:base + read_len - ln]
+                    b = np.concatenate([ref[:at], nuc[rng.integers(0, 4, ln)], ref[at:]])
+                    ops_mid = ("I", at, ln)
+                else:                            # deletion from read
+                    ln = int(rng.integers(1, 4))
+                    ref = seq[base:base + read_len + ln]
+                    b = np.concatenate([ref[:at], ref[at + ln:]])
+                    ops_mid = ("D", at, ln)
+                if len(b) != read_len:
+                    ops_mid = None
+            if ops_mid is None:
+                b = seq[base:base + read_len].copy()
+            # mostly high qualities with a geometric tail and a few uniformly bad bases
+            q = np.clip(qual_hi - rng.geometric(0.25, read_len) + 1, qual_lo, qual_hi)
+            bad = rng.random(read_len) < 0.03
+            q[bad] = rng.integers(qual_lo, qual_hi + 1, int(bad.sum()))
+            q = q.astype(np.uint8)
+            err = rng.random(read_len) < 10.0 ** (-q.astype(np.float64) / 10.0)
+            b = b.copy()
+            b[err] = nuc[rng.integers(0, 4, int(err.sum()))]
+            # soft clips (Beta(1,4) * clip_max), as in SURVEY 8(d)
+            a = 0 if rng.random() < p_no_clip else int(rng.beta(1, 4) * clip_max)
+            c = 0 if rng.random() < p_no_clip else int(rng.beta(1, 4) * clip_max)
+            if ops_mid is not None:
+                a = min(a, ops_mid[1] - 5)
+                c = min(c, read_len - ops_mid[1] - ops_mid[2] - 5)
+            # primary record
+            recs = []
+            if ops_mid is None:
+                cig = [(a, "S"), (read_len - a - c, "M"), (c, "S")]
+            elif ops_mid[0] == "I":
+                _, at, ln = ops_mid
+                cig = [(a, "S"), (at - a, "M"), (ln, "I"), (read_len - at - ln - c, "M"), (c, "S")]
+            else:
+                _, at, ln = ops_mid
+                cig = [(a, "S"), (at - a, "M"), (ln, "D"), (read_len - at - c, "M"), (c, "S")]
+            use_hard = hardclip_frac > 0 and rng.random() < hardclip_frac
+            mism = int(err.sum())
+            recs.append(dict(contig=h, pos=rs + a, AS=read_len - a - c - 5 * mism, rev=rev, cig=cig, primary=True))
+            # secondary alignments: same read placed on other haplotypes at the level of the seed start
+            lv0 = int(lvl[base + a])
+            if rng.random() < p_secondary:
+                nsec = int(min(max_secondary, rng.geometric(0.5)))
+                others = rng.permutation(nh)
+                for h2 in others[:nsec]:
+                    h2 = int(h2)
+                    if h2 == h:
+                        continue
+                    if rng.random() < p_random_secondary:
+                        p2 = int(rng.integers(0, clen[h2] - read_len - 1))
+                    else:
+                        p2 = int(pos_at_level[h2][lv0])
+                    a2, c2 = a, c
+                    if use_hard:
+                        pass
+                    mlen = read_len - a2 - c2
+                    if p2 + mlen + 1 >= clen[h2]:
+                        continue
+                    refseg = seq[off[h2] + p2: off[h2] + p2 + mlen]
+                    mm = int((refseg != b[a2:a2 + mlen]).sum())
+                    recs.append(dict(contig=h2, pos=p2, AS=mlen - 5 * mm, rev=rev,
+                                     cig=[(a2, "S"), (mlen, "M"), (c2, "S")], primary=False))
+            recs.sort(key=lambda r: -r["AS"])      # AS-descending (processBAM.cpp:1945), stable
+            c0 = chain_off[-1]
+            for i, r in enumerate(recs):
+                if r["primary"]:
+                    read_primary.append(c0 + i)
+                ch["contig"].append(r["contig"]); ch["pos"].append(r["pos"]); ch["offset"].append(0)
+                ch["AS"].append(r["AS"]); ch["rev"].append(1 if r["rev"] else 0); ch["cig"].append(_cigar(r["cig"]))
+            chain_off.append(c0 + len(recs))
+            reads_b.append(b); reads_q.append(q + 33)
+            read_off.append(read_off[-1] + read_len)
+            truth_level0.append(lv0)
+
+    cigar_off = np.concatenate([[0], np.cumsum([len(c) for c in ch["cig"]])]).astype(np.int32)
+    cigar = np.asarray([x for c in ch["cig"] for x in c], dtype=np.uint32)
+    return dict(
+        n_pairs=n_pairs,
+        read_off=np.asarray(read_off, dtype=np.int32),
+        read_bases=np.concatenate(reads_b).astype(np.uint8),
+        read_quals=np.concatenate(reads_q).astype(np.uint8),
+        chain_off=np.asarray(chain_off, dtype=np.int32),
+        read_primary=np.asarray(read_primary, dtype=np.int32),
+        n_chains=len(ch["pos"]),
+        chain_contig=np.asarray(ch["contig"], dtype=np.int32),
+        chain_pos=np.asarray(ch["pos"], dtype=np.int32),
+        chain_offset=np.asarray(ch["offset"], dtype=np.int32),
+        chain_as=np.asarray(ch["AS"], dtype=np.int32),
+        chain_reverse=np.asarray(ch["rev"], dtype=np.uint8),
+        cigar_off=cigar_off, cigar=cigar,
+        truth_level0=np.asarray(truth_level0, dtype=np.int32),
+        insert_mean=float(ins_mean), insert_sd=float(ins_sd),
+    )
