@@ -1,0 +1,67 @@
+// batch.h -- device-resident batch of read pairs / chains (SoA, fixed column stride per chain).
+#pragma once
+#include "device_common.h"
+
+namespace hlala {
+
+struct DevBatch {
+    int n_pairs, n_reads, n_chains, stride;
+    int from_seeds;                 // 1: seed chains were uploaded directly (no stage A / C inputs)
+    // ---- inputs
+    const int* read_off;            // [n_reads+1]
+    const uint8_t* read_bases;      // alignment orientation of the primary
+    const uint8_t* read_quals;
+    const int* chain_off;           // [n_reads+1]
+    const int* read_primary;        // [n_reads]
+    const int* chain_read;          // [n_chains]
+    const int* chain_contig;
+    const int* chain_pos;
+    const int* chain_offset;
+    const int* chain_as;
+    const uint8_t* chain_reverse;
+    const int* cigar_off;
+    const u32* cigar;
+    // ---- stage A: seed chains (verboseSeedChain after alignment2Chain)
+    int* seed_status;               // [n_chains] HLALA_CHAIN_*
+    int* seed_ncols;
+    int* seed_begin;
+    int* seed_end;
+    int* seed_removed;
+    int* seed_level;                // [n_chains*stride]
+    int* seed_edge;
+    uint8_t* seed_g;
+    uint8_t* seed_s;
+    // ---- stage B: extended chains
+    int* ext_status;
+    int* ext_ncols;
+    int* ext_begin;
+    int* ext_end;
+    double* ext_ll;
+    int* dp_iters;                  // [2*n_chains]
+    int* dp_score;                  // [2*n_chains]
+    int* ext_level;                 // [n_chains*stride]
+    int* ext_edge;
+    uint8_t* ext_g;
+    uint8_t* ext_s;
+    uint8_t* ext_fromseed;
+    int* ext_firstlast;             // [n_chains*4]: first level, second level, last level, second-last level (-1 = none)
+    // ---- stage C: selected pair
+    int* pair_status;               // [n_pairs]
+    int* best_chain;                // [n_reads]
+    int* n_comb;                    // [n_pairs]
+    double* pair_ll;
+    double* pair_mapq;
+    double* mate_mapq;              // [n_reads]
+    uint8_t* strands_valid;
+    uint8_t* sel_mapq;              // [n_reads*stride] mapQ_perPosition of the selected chain
+    // ---- counters (device): see hlala_batch_stats
+    u64* counters;                  // [16]
+    int* work_counter;              // [4] dynamic work distribution, one per stage
+    int* dbg;                       // host-mapped progress words (HLALA_DEBUG=1), else null
+};
+
+enum {
+    CNT_CHAINS_EXT = 0, CNT_DP_CALLS, CNT_DP_ITERS, CNT_DP_CELLS, CNT_SEED_COLS, CNT_OUT_COLS, CNT_EDGES, CNT_ERRORS
+};
+
+}  // namespace hlala

@@ -1,0 +1,116 @@
+// device_common.h -- device-side data layout shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hlala {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// Flattened PRG resident in HBM (see flat_graph.hpp for the meaning of each array).
+struct DevGraph {
+    int L, N, E, P;
+    const int* level_off;      // [L+1]
+    const int* node_level;     // [N]
+    const int* node_orig;      // [N]
+    const int* out_off;        // [N+1]
+    const int* out_to;         // [E]
+    const uint8_t* out_label;  // [E]
+    const int* out_eid;        // [E]
+    const int* in_off;
+    const int* in_from;
+    const uint8_t* in_label;
+    const int* in_eid;
+    const int* edge_from_new;  // [E] by creation index
+    const int* edge_to_new;    // [E]
+    const uint8_t* edge_label; // [E] by creation index
+    const int* jf_off; const int* jf_node; const int* jf_path;
+    const int* jb_off; const int* jb_node; const int* jb_path;
+    const int* path_len;       // [P]
+    const long long* path_off; // [P+1]
+    const int* path_edges;
+    const uint8_t* gap_stretch;// [L-1]
+    const long long* lp_off;   // [L+1]
+    const int* lp_seqid;
+    const int* lp_pos;
+};
+
+// Constant tables computed once on the host with the host libm so that device results are
+// bit-identical to a CPU evaluation of the reference formulas.
+struct DevTables {
+    double ll_match[256];      // log(pCorrect(q)) with the 0.999 cap / 1e-5 floor, extensionAligner.cpp:124-141
+    double ll_mismatch[256];   // log((1 - pCorrect(q)) / 3)
+    double rate_indel;         // log(0.001) or log(0.075)
+    double rate_ins_quarter;   // rate_insertions + log(1/4)
+    double rate_match_mismatch;// log(1 - 2 * rate)
+    double is_penalty;         // log pdf(mean + 8 sd), processBAM.cpp:2343-2346
+    int    is_dmin, is_n;      // logpdf table covers integer distances [is_dmin, is_dmin + is_n)
+    const double* is_logpdf;   // device pointer; entries with pdf <= 0 hold is_penalty
+    double phred_thr[256];     // phred_thr[k] = largest pWrong for which PCorrectToPhred gives >= k
+};
+
+// capacities of the extension DP (one wavefront per chain)
+constexpr int DP_WCAP      = 128;    // frontier cells per diagonal list
+constexpr int DP_HC        = 512;    // candidate-target hash entries per iteration
+constexpr int DP_SEQCAP    = 1024;   // read length staged in LDS
+constexpr int DP_CELLS     = 16384;  // kept cells per DP call (global slab)
+constexpr int DP_EARLY     = 4096;   // hash entries for cells reached early through gap-path jumps
+constexpr int DP_STEPS     = 8192;   // backtrace steps
+constexpr int DP_COMPLETED = 2048;   // sequence-complete cells
+constexpr int DP_NEG       = -30000; // minusInfinity (-DBL_MAX in the reference, extensionAligner.cpp:363)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    for(int o = 32; o; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    for(int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v)
+{
+    for(int o = 32; o; o >>= 1) { u64 w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+}
+// exclusive prefix sum over the wave; returns the lane's offset, `total` is wave-uniform
+__device__ __forceinline__ int wave_excl_scan(int v, int& total)
+{
+    int x = v;
+    for(int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if(lane_id() >= o) x += y; }
+    total = __shfl(x, 63);
+    return x - v;
+}
+
+// glibc rand_r (stdlib/rand_r.c, glibc 2.35: three rounds of the 1103515245/12345 LCG yielding
+// 11 + 10 + 10 bits) as called by Utilities::randomNumber_nonCritical (Utilities.cpp:922-927).
+__host__ __device__ inline int glibc_rand_r(unsigned int* seed)
+{
+    unsigned int next = *seed;
+    int result;
+    next *= 1103515245u; next += 12345u;
+    result = (unsigned int)(next / 65536u) % 2048u;
+    next *= 1103515245u; next += 12345u;
+    result <<= 10; result ^= (unsigned int)(next / 65536u) % 1024u;
+    next *= 1103515245u; next += 12345u;
+    result <<= 10; result ^= (unsigned int)(next / 65536u) % 1024u;
+    *seed = next;
+    return result;
+}
+
+// Utilities::PCorrectToPhred (Utilities.cpp:178-203) through the host-computed threshold table.
+__device__ inline unsigned char phred_from_pcorrect(const DevTables& T, double pCorrect)
+{
+    double pWrong = 1 - pCorrect;
+    if(pWrong == 0) pWrong = 1e-100;
+    // result k = largest k with pWrong <= phred_thr[k]; thresholds are non-increasing in k
+    int lo = 0, hi = 255;
+    while(lo < hi) { int mid = (lo + hi + 1) >> 1; if(pWrong <= T.phred_thr[mid]) lo = mid; else hi = mid - 1; }
+    return (unsigned char)lo;
+}
+
+}  // namespace hlala

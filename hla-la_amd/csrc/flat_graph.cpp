@@ -1,0 +1,203 @@
+// flat_graph.cpp -- see flat_graph.hpp.  Host-only, runs once per graph.
+#include "flat_graph.hpp"
+
+#include <algorithm>
+#include <map>
+#include <numeric>
+
+namespace hlala {
+
+namespace {
+struct TrieEnt { int32_t parent; int32_t edge; int32_t len; };
+}
+
+std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c, FlatGraph& F)
+{
+    if(!g || g->n_levels < 2 || g->n_nodes < 2 || g->n_edges < 1) return "graph needs >= 2 levels, nodes and >= 1 edge";
+    const int32_t L = g->n_levels, N = g->n_nodes, E = g->n_edges;
+    F.L = L; F.N = N; F.E = E;
+
+    // ---- nodes: level-major renumbering, stable in creation order (rank z of alignerBase.cpp:27-37)
+    F.level_off.assign(L + 1, 0);
+    for(int32_t n = 0; n < N; n++) {
+        int32_t l = g->node_level[n];
+        if(l < 0 || l >= L) return "node level out of range";
+        F.level_off[l + 1]++;
+    }
+    for(int32_t l = 0; l < L; l++) {
+        if(F.level_off[l + 1] == 0) return "level without nodes";
+        F.max_nodes_per_level = std::max(F.max_nodes_per_level, F.level_off[l + 1]);
+        F.level_off[l + 1] += F.level_off[l];
+    }
+    F.node_orig.assign(N, 0); F.node_new.assign(N, 0); F.node_level.assign(N, 0);
+    {
+        std::vector<int32_t> cursor(F.level_off.begin(), F.level_off.end() - 1);
+        for(int32_t n = 0; n < N; n++) {
+            int32_t id = cursor[g->node_level[n]]++;
+            F.node_orig[id] = n; F.node_new[n] = id; F.node_level[id] = g->node_level[n];
+        }
+    }
+
+    // ---- edges: CSR in edge creation order (std::set<Edge*> order of Node::Outgoing_/Incoming_Edges)
+    F.out_off.assign(N + 1, 0); F.in_off.assign(N + 1, 0);
+    F.edge_from_new.assign(E, 0); F.edge_to_new.assign(E, 0);
+    for(int32_t e = 0; e < E; e++) {
+        int32_t a = g->edge_from[e], b = g->edge_to[e];
+        if(a < 0 || a >= N || b < 0 || b >= N) return "edge endpoint out of range";
+        if(g->node_level[b] != g->node_level[a] + 1) return "edge does not connect consecutive levels";
+        if(g->edge_label[e] == 0) return "edge with emission 0";
+        F.edge_from_new[e] = F.node_new[a]; F.edge_to_new[e] = F.node_new[b];
+        F.out_off[F.node_new[a] + 1]++; F.in_off[F.node_new[b] + 1]++;
+    }
+    for(int32_t n = 0; n < N; n++) {
+        F.max_out_degree = std::max(F.max_out_degree, F.out_off[n + 1]);
+        F.max_in_degree = std::max(F.max_in_degree, F.in_off[n + 1]);
+        // the reference asserts every node it touches has neighbours (alignerBase.cpp:161, 185)
+        if(F.node_level[n] < L - 1 && F.out_off[n + 1] == 0) return "non-terminal node without outgoing edge";
+        if(F.node_level[n] > 0 && F.in_off[n + 1] == 0) return "non-initial node without incoming edge";
+        F.out_off[n + 1] += F.out_off[n]; F.in_off[n + 1] += F.in_off[n];
+    }
+    F.out_to.assign(E, 0); F.out_label.assign(E, 0); F.out_eid.assign(E, 0);
+    F.in_from.assign(E, 0); F.in_label.assign(E, 0); F.in_eid.assign(E, 0);
+    {
+        std::vector<int32_t> co(F.out_off.begin(), F.out_off.end() - 1), ci(F.in_off.begin(), F.in_off.end() - 1);
+        for(int32_t e = 0; e < E; e++) {
+            int32_t a = F.edge_from_new[e], b = F.edge_to_new[e];
+            int32_t io = co[a]++, ii = ci[b]++;
+            F.out_to[io] = b; F.out_label[io] = g->edge_label[e]; F.out_eid[io] = e;
+            F.in_from[ii] = a; F.in_label[ii] = g->edge_label[e]; F.in_eid[ii] = e;
+        }
+    }
+
+    // ---- gap stretches (processBAM.cpp:91-149): runs of >= 3 levels that have a '_' edge
+    std::vector<uint8_t> levelHasGap(L, 0);
+    for(int32_t e = 0; e < E; e++) if(g->edge_label[e] == '_') levelHasGap[g->node_level[g->edge_from[e]]] = 1;
+    F.gap_stretch.assign(L - 1, 0);
+    for(int32_t l = 0; l < L - 1;) {
+        if(!levelHasGap[l]) { l++; continue; }
+        int32_t s = l;
+        while(l < L - 1 && levelHasGap[l]) l++;
+        if(l - s >= 3) std::fill(F.gap_stretch.begin() + s, F.gap_stretch.begin() + l, 1);
+    }
+
+    // ---- gap-edge paths (Graph.cpp:347-476).  Running paths live in a trie (parent entry + edge)
+    // instead of the reference's per-level vector copies; iteration orders are the reference's
+    // std::map<Node*,...> orders with creation index for the pointer.
+    std::vector<TrieEnt> trie;
+    std::vector<int32_t> completed;                       // trie entries, in completedGapEdgePaths order
+    std::map<int32_t, std::map<int32_t, int32_t>> running, next;   // node(orig) -> from(orig) -> trie entry
+    std::vector<int32_t> levelEdges;
+    for(int32_t l = 0; l < L; l++) {
+        if(running.empty() && !levelHasGap[l]) continue;
+        next.clear();
+        for(auto& nodeIt : running) {
+            int32_t n = F.node_new[nodeIt.first];
+            int nonGap = 0;
+            for(int32_t i = F.out_off[n]; i < F.out_off[n + 1]; i++) {
+                if(F.out_label[i] == '_') {
+                    int32_t t = F.node_orig[F.out_to[i]];
+                    auto& slot = next[t];
+                    for(auto& fromIt : nodeIt.second)
+                        if(slot.find(fromIt.first) == slot.end()) {
+                            trie.push_back({fromIt.second, F.out_eid[i], trie[fromIt.second].len + 1});
+                            slot[fromIt.first] = (int32_t)trie.size() - 1;
+                        }
+                } else nonGap++;
+            }
+            if(nonGap != 0 || l == L - 1)
+                for(auto& fromIt : nodeIt.second) completed.push_back(fromIt.second);
+        }
+        if(levelHasGap[l]) {
+            levelEdges.clear();
+            for(int32_t n = F.level_off[l]; n < F.level_off[l + 1]; n++)
+                for(int32_t i = F.out_off[n]; i < F.out_off[n + 1]; i++)
+                    if(F.out_label[i] == '_') levelEdges.push_back(F.out_eid[i]);
+            std::sort(levelEdges.begin(), levelEdges.end());
+            for(int32_t e : levelEdges) {
+                int32_t from = g->edge_from[e], to = g->edge_to[e];
+                if(running.find(from) != running.end()) continue;          // "seen_gap_edge"
+                auto& slot = next[to];
+                if(slot.find(from) == slot.end()) {
+                    trie.push_back({-1, e, 1});
+                    slot[from] = (int32_t)trie.size() - 1;
+                }
+            }
+        }
+        running.swap(next);
+    }
+    const int32_t P = (int32_t)completed.size();
+    F.path_first.assign(P, 0); F.path_last.assign(P, 0); F.path_len.assign(P, 0); F.path_off.assign(P + 1, 0);
+    for(int32_t p = 0; p < P; p++) F.path_off[p + 1] = F.path_off[p] + trie[completed[p]].len;
+    F.path_edges.assign(F.path_off[P], 0);
+    for(int32_t p = 0; p < P; p++) {
+        int32_t ent = completed[p], len = trie[ent].len;
+        for(int32_t k = len - 1; k >= 0; k--) { F.path_edges[F.path_off[p] + k] = trie[ent].edge; ent = trie[ent].parent; }
+        F.path_len[p] = len;
+        F.path_first[p] = F.edge_from_new[F.path_edges[F.path_off[p]]];
+        F.path_last[p] = F.edge_to_new[F.path_edges[F.path_off[p] + len - 1]];
+    }
+    // jump tables (gapEdgePaths_connectedNodes_{forwards,backwards}): per node, ordered by the
+    // creation index of the node at the other end (std::map<Node*,Edge*> order)
+    {
+        std::vector<int32_t> idx(P);
+        std::iota(idx.begin(), idx.end(), 0);
+        auto build = [&](const std::vector<int32_t>& key, const std::vector<int32_t>& other, std::vector<int32_t>& off,
+                         std::vector<int32_t>& node, std::vector<int32_t>& path) -> bool {
+            std::sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
+                if(key[a] != key[b]) return key[a] < key[b];
+                return F.node_orig[other[a]] < F.node_orig[other[b]]; });
+            off.assign(N + 1, 0); node.assign(P, 0); path.assign(P, 0);
+            for(int32_t i = 0; i < P; i++) {
+                int32_t p = idx[i];
+                if(i > 0 && key[idx[i - 1]] == key[p] && other[idx[i - 1]] == other[p]) return false;   // Graph.cpp:461-462 asserts
+                off[key[p] + 1]++; node[i] = other[p]; path[i] = p;
+            }
+            for(int32_t n = 0; n < N; n++) { F.max_jumps = std::max(F.max_jumps, off[n + 1]); off[n + 1] += off[n]; }
+            return true;
+        };
+        if(!build(F.path_first, F.path_last, F.jf_off, F.jf_node, F.jf_path)) return "duplicate gap-edge path between two nodes";
+        if(!build(F.path_last, F.path_first, F.jb_off, F.jb_node, F.jb_path)) return "duplicate gap-edge path between two nodes";
+    }
+
+    // ---- level -> (sequence id, position), last writer wins (processBAM.cpp:4455)
+    F.lp_off.assign(L + 1, 0);
+    if(c && c->n_contigs > 0) {
+        const int64_t total = c->contig_off[c->n_contigs];
+        // contigs visited in ascending sequence id so each level's entries come out sorted by id
+        std::vector<int32_t> order(c->n_contigs);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return c->contig_seqid[a] < c->contig_seqid[b]; });
+        for(int64_t p = 0; p < total; p++) {
+            int32_t l = c->contig_level[p];
+            if(l < 0 || l >= L) return "translation level out of range";
+        }
+        // pass 1: count distinct (level, contig) -- positions of one contig mapping to the same level collapse
+        std::vector<int32_t> lastContigAtLevel(L, -1);
+        for(int32_t oc : order)
+            for(int64_t p = c->contig_off[oc]; p < c->contig_off[oc + 1]; p++) {
+                int32_t l = c->contig_level[p];
+                if(lastContigAtLevel[l] != oc) { lastContigAtLevel[l] = oc; F.lp_off[l + 1]++; }
+            }
+        for(int32_t l = 0; l < L; l++) F.lp_off[l + 1] += F.lp_off[l];
+        F.lp_seqid.assign(F.lp_off[L], 0); F.lp_pos.assign(F.lp_off[L], 0);
+        std::vector<int64_t> cursor(F.lp_off.begin(), F.lp_off.end() - 1);
+        std::fill(lastContigAtLevel.begin(), lastContigAtLevel.end(), -1);
+        for(int32_t oc : order)
+            for(int64_t p = c->contig_off[oc]; p < c->contig_off[oc + 1]; p++) {
+                int32_t l = c->contig_level[p];
+                if(lastContigAtLevel[l] != oc) {
+                    lastContigAtLevel[l] = oc;
+                    // two contigs with the same sequence id overwrite each other in the reference's map
+                    if(cursor[l] > F.lp_off[l] && F.lp_seqid[cursor[l] - 1] == c->contig_seqid[oc]) cursor[l]--;
+                    F.lp_seqid[cursor[l]] = c->contig_seqid[oc];
+                    F.lp_pos[cursor[l]] = (int32_t)(p - c->contig_off[oc]);
+                    cursor[l]++;
+                } else {
+                    F.lp_pos[cursor[l] - 1] = (int32_t)(p - c->contig_off[oc]);     // later position overwrites
+                }
+            }
+    }
+    return "";
+}
+
+}  // namespace hlala

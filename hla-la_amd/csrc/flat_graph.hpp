@@ -1,0 +1,51 @@
+// flat_graph.hpp -- one-time host pass: PRG graph (graph.txt creation order) -> CSR arrays for HBM.
+//
+// Replaces, for the device path, the pointer structures the reference builds at start-up:
+//   alignerBase::nodesPerLevel_ordered{,_rev}        mapper/aligner/alignerBase.cpp:27-37
+//   Node::Outgoing_Edges / Incoming_Edges             Graph/Node.h:74-75  (std::set<Edge*> order)
+//   Graph::computeGapEdgePaths                        Graph/Graph.cpp:347-476
+//   processBAM::inGraphGapStretch                     mapper/processBAM.cpp:91-149
+//   processBAM::graphLevel_2_underlyingSequencePositions   mapper/processBAM.cpp:4441-4456
+// Canonical order everywhere = creation index.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/hlala_gpu.h"
+
+namespace hlala {
+
+struct FlatGraph {
+    int32_t L = 0, N = 0, E = 0;
+    // nodes are renumbered level-major (stable in creation index): rank z = id - level_off[level]
+    std::vector<int32_t> level_off;      // [L+1]
+    std::vector<int32_t> node_orig;      // [N] new id -> creation index
+    std::vector<int32_t> node_new;       // [N] creation index -> new id
+    std::vector<int32_t> node_level;     // [N] by new id
+    // out-/in-edge CSR by new node id, entries in edge creation order
+    std::vector<int32_t> out_off, in_off;        // [N+1]
+    std::vector<int32_t> out_to, in_from;        // [E] new node ids
+    std::vector<uint8_t> out_label, in_label;    // [E]
+    std::vector<int32_t> out_eid, in_eid;        // [E] edge creation index
+    std::vector<int32_t> edge_from_new, edge_to_new;   // [E] by creation index -> new node ids
+    // completed gap-edge paths (completedGapEdgePaths order)
+    std::vector<int32_t> path_first, path_last;  // [P] new node ids
+    std::vector<int32_t> path_len;               // [P]
+    std::vector<int64_t> path_off;               // [P+1] into path_edges
+    std::vector<int32_t> path_edges;             // edge creation indices, first -> last
+    // jump tables by new node id; entries ordered by the CREATION index of the other node
+    std::vector<int32_t> jf_off, jb_off;         // [N+1]
+    std::vector<int32_t> jf_node, jb_node;       // target node (new id)
+    std::vector<int32_t> jf_path, jb_path;       // path index
+    std::vector<uint8_t> gap_stretch;            // [L-1]
+    // level -> (sequence id, position) CSR, entries sorted by sequence id
+    std::vector<int64_t> lp_off;                 // [L+1]
+    std::vector<int32_t> lp_seqid, lp_pos;
+    int32_t max_nodes_per_level = 0, max_out_degree = 0, max_in_degree = 0, max_jumps = 0;
+};
+
+// Returns "" on success, else the error text (graph invariants the reference asserts).
+std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c, FlatGraph& out);
+
+}  // namespace hlala

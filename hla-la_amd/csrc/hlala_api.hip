@@ -1,0 +1,606 @@
+// hlala_api.hip -- the C ABI of include/hlala_gpu.h: device memory management, host tables, launches.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/hlala_gpu.h"
+#include "batch.h"
+#include "flat_graph.hpp"
+
+// unity build: the kernels live in their own files but are compiled in this translation unit
+#include "kernel_extend.hip"
+#include "kernel_project.hip"
+#include "kernel_pair.hip"
+
+namespace hlala {
+size_t ext_slab_bytes_host(int stride) { return ext_slab_bytes(stride); }
+size_t proj_slab_bytes_host(int stride, int maxNodesPerLevel) { return proj_slab_bytes(stride, maxNodesPerLevel); }
+}  // namespace hlala
+
+using namespace hlala;
+
+static thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+};
+
+struct hlala_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hlala_params params{};
+    FlatGraph F;
+    DevGraph G{};
+    DevTables* dT = nullptr;
+    double* d_islog = nullptr;
+    long long* d_contig_off = nullptr; uint8_t* d_contig_seq = nullptr; int* d_contig_level = nullptr;
+    int n_contigs = 0; std::vector<long long> contig_off;
+    std::vector<void*> allocs;
+    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0;
+    char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0;
+    hipEvent_t ev[4]{};
+    int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
+    std::string err;
+};
+
+struct hlala_batch {
+    hlala_ctx* ctx = nullptr;
+    DevBatch B{};
+    std::vector<void*> allocs;
+    int staged = 0;   // bit0 seeds available, bit1 extended, bit2 paired
+    float ms[3] = {0, 0, 0};
+};
+
+#define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HLALA_E_DEVICE; } } while(0)
+
+template <class T>
+static int dev_upload(hlala_ctx* c, std::vector<void*>& allocs, const T* host, size_t n, T** out)
+{
+    *out = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    if(n && host) HIP_TRY(c, hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *out = (T*)p;
+    return 0;
+}
+template <class T>
+static int dev_alloc(hlala_ctx* c, std::vector<void*>& allocs, size_t n, T** out, bool zero = false)
+{
+    *out = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    if(zero) HIP_TRY(c, hipMemsetAsync(p, 0, bytes, c->stream));
+    *out = (T*)p;
+    return 0;
+}
+#define UP(vec, field) do { int rc_ = dev_upload(c, c->allocs, (vec).data(), (vec).size(), &tmp_##field); if(rc_) return rc_; } while(0)
+
+// ---- host-side constant tables (host libm => bit-identical to a CPU evaluation of the reference formulas)
+
+/* Utilities::PhredToPCorrect, Utilities.cpp:357-377 */
+static double host_PhredToPCorrect(unsigned char q)
+{
+    if(q == 0) return -1;
+    int illuminaPhred = (int)q - 33;
+    double log10_pWrong = (double)illuminaPhred / (double)-10;
+    double pWrong = exp(log(10) * log10_pWrong);
+    return 1 - pWrong;
+}
+/* Utilities::PCorrectToPhred (Utilities.cpp:178-203) as a function of pWrong */
+static int host_phred_of_pwrong(double pWrong)
+{
+    if(pWrong == 0) pWrong = 1e-100;
+    double phred1 = -10.0 * log10(pWrong);
+    if((phred1 + 33) > 255) phred1 = 255 - 33;
+    return (int)round(phred1 + 33);
+}
+/* boost::math::pdf(normal) closed form, see oracle header note; processBAM.cpp:2343, 3446 */
+static double host_normal_pdf(double mean, double sd, double x)
+{
+    double exponent = x - mean;
+    exponent *= -exponent;
+    exponent /= 2 * sd * sd;
+    double result = exp(exponent);
+    result /= sd * sqrt(2 * 3.141592653589793238462643383279502884);
+    return result;
+}
+
+static int build_tables(hlala_ctx* c)
+{
+    DevTables T;
+    memset(&T, 0, sizeof(T));
+    for(int q = 0; q < 256; q++) {
+        double pCorrect = host_PhredToPCorrect((unsigned char)q);
+        if(q < 33) pCorrect = host_PhredToPCorrect(33);         // the reference asserts illuminaPhred >= 0; never indexed for valid input
+        if(pCorrect > 0.999) pCorrect = 0.999;                    // conservativeReadQualities, extensionAligner.cpp:128-131
+        if(pCorrect == 0) pCorrect = 0.00001;
+        T.ll_match[q] = log(pCorrect);
+        double pIncorrect = 1 - pCorrect; pIncorrect *= (1.0 / 3.0);
+        T.ll_mismatch[q] = log(pIncorrect);
+    }
+    double rate = c->params.long_read_mode ? log(0.075) : log(0.001);
+    T.rate_indel = rate;
+    T.rate_ins_quarter = rate + log(1.0 / 4.0);
+    T.rate_match_mismatch = log(1 - exp(rate) - exp(rate));
+    // PCorrectToPhred thresholds: phred_thr[k] = largest pWrong (as a double) that still maps to a Phred char >= k
+    for(int k = 0; k < 256; k++) {
+        if(host_phred_of_pwrong(1.0) >= k) { T.phred_thr[k] = 1.0; continue; }
+        double lo = 1e-300, hi = 1.0;      // f(lo) >= k (= 255), f(hi) < k
+        uint64_t blo, bhi; memcpy(&blo, &lo, 8); memcpy(&bhi, &hi, 8);
+        while(bhi - blo > 1) {
+            uint64_t mid = blo + (bhi - blo) / 2; double m; memcpy(&m, &mid, 8);
+            if(host_phred_of_pwrong(m) >= k) blo = mid; else bhi = mid;
+        }
+        double r; memcpy(&r, &blo, 8);
+        T.phred_thr[k] = r;
+    }
+    // insert-size log pdf over every integer distance with a positive density
+    double mean = c->params.insert_mean, sd = c->params.insert_sd;
+    std::vector<double> tbl;
+    T.is_dmin = 0; T.is_n = 0;
+    if(sd > 0) {
+        T.is_penalty = log(host_normal_pdf(mean, sd, mean + 8 * sd));
+        long long dmin = (long long)floor(mean - 40 * sd) - 2, dmax = (long long)ceil(mean + 40 * sd) + 2;
+        if(dmax - dmin > 50000000) { c->err = "insert size sd too large for the log-pdf table"; return HLALA_E_ARG; }
+        if(host_normal_pdf(mean, sd, (double)dmin) > 0 || host_normal_pdf(mean, sd, (double)dmax) > 0) { c->err = "log-pdf table does not reach zero density"; return HLALA_E_ARG; }
+        tbl.resize((size_t)(dmax - dmin + 1));
+        for(long long d = dmin; d <= dmax; d++) {
+            double p = host_normal_pdf(mean, sd, (double)d);
+            tbl[(size_t)(d - dmin)] = (p <= 0) ? T.is_penalty : log(p);             // processBAM.cpp:3447-3464
+        }
+        T.is_dmin = (int)dmin; T.is_n = (int)tbl.size();
+    }
+    int rc = dev_upload(c, c->allocs, tbl.data(), tbl.size(), &c->d_islog); if(rc) return rc;
+    T.is_logpdf = c->d_islog;
+    rc = dev_upload(c, c->allocs, &T, 1, &c->dT); if(rc) return rc;
+    return 0;
+}
+
+template <class T>
+static int dl(hlala_ctx* c, T* host, const T* dev, size_t n)
+{
+    if(!host || !n) return 0;
+    HIP_TRY(c, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+extern "C" {
+
+const char* hlala_last_error(const hlala_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_desc* graph, const hlala_contigs_desc* contigs, const hlala_params* params)
+{
+    if(!out || !graph || !params) { g_create_error = "null argument"; return HLALA_E_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if(e != hipSuccess || ndev <= 0 || device >= ndev) {
+        g_create_error = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device index out of range") + "); this library has no CPU fallback";
+        return HLALA_E_DEVICE;
+    }
+    hlala_ctx* c = new hlala_ctx();
+    c->device = device; c->stream = (hipStream_t)stream; c->params = *params;
+    auto fail = [&](int rc) { g_create_error = c->err; hlala_destroy(c); return rc; };
+    if(c->params.max_columns < 16 || c->params.max_columns > 65536) { c->err = "params.max_columns out of range"; return fail(HLALA_E_ARG); }
+    if(hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(HLALA_E_DEVICE); }
+    std::string ferr = flatten_graph(graph, contigs, c->F);
+    if(!ferr.empty()) { c->err = ferr; return fail(HLALA_E_GRAPH); }
+    FlatGraph& F = c->F;
+    if(F.max_nodes_per_level > 65535) { c->err = "more than 65535 nodes in one level"; return fail(HLALA_E_CAPACITY); }
+    DevGraph& G = c->G;
+    G.L = F.L; G.N = F.N; G.E = F.E; G.P = (int)F.path_len.size();
+    std::vector<uint8_t> edge_label(graph->edge_label, graph->edge_label + graph->n_edges);
+    int rc = 0;
+#define UPG(field, vec) do { rc = dev_upload(c, c->allocs, (vec).data(), (vec).size(), (std::remove_const<std::remove_pointer<decltype(G.field)>::type>::type**)&G.field); if(rc) return fail(rc); } while(0)
+    UPG(level_off, F.level_off); UPG(node_level, F.node_level); UPG(node_orig, F.node_orig);
+    UPG(out_off, F.out_off); UPG(out_to, F.out_to); UPG(out_label, F.out_label); UPG(out_eid, F.out_eid);
+    UPG(in_off, F.in_off); UPG(in_from, F.in_from); UPG(in_label, F.in_label); UPG(in_eid, F.in_eid);
+    UPG(edge_from_new, F.edge_from_new); UPG(edge_to_new, F.edge_to_new); UPG(edge_label, edge_label);
+    UPG(jf_off, F.jf_off); UPG(jf_node, F.jf_node); UPG(jf_path, F.jf_path);
+    UPG(jb_off, F.jb_off); UPG(jb_node, F.jb_node); UPG(jb_path, F.jb_path);
+    UPG(path_len, F.path_len); UPG(path_edges, F.path_edges);
+    {
+        std::vector<long long> po(F.path_off.begin(), F.path_off.end());
+        rc = dev_upload(c, c->allocs, po.data(), po.size(), (long long**)&G.path_off); if(rc) return fail(rc);
+        std::vector<long long> lo(F.lp_off.begin(), F.lp_off.end());
+        rc = dev_upload(c, c->allocs, lo.data(), lo.size(), (long long**)&G.lp_off); if(rc) return fail(rc);
+    }
+    UPG(gap_stretch, F.gap_stretch); UPG(lp_seqid, F.lp_seqid); UPG(lp_pos, F.lp_pos);
+#undef UPG
+    if(contigs && contigs->n_contigs > 0) {
+        c->n_contigs = contigs->n_contigs;
+        c->contig_off.assign(contigs->contig_off, contigs->contig_off + contigs->n_contigs + 1);
+        size_t total = (size_t)c->contig_off.back();
+        std::vector<long long> co(c->contig_off.begin(), c->contig_off.end());
+        rc = dev_upload(c, c->allocs, co.data(), co.size(), &c->d_contig_off); if(rc) return fail(rc);
+        rc = dev_upload(c, c->allocs, contigs->contig_seq, total, &c->d_contig_seq); if(rc) return fail(rc);
+        rc = dev_upload(c, c->allocs, contigs->contig_level, total, &c->d_contig_level); if(rc) return fail(rc);
+    }
+    rc = build_tables(c); if(rc) return fail(rc);
+    // scratch slabs: one per resident wavefront (persistent grid, dynamic work distribution)
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, device) != hipSuccess) { c->err = "hipGetDeviceProperties failed"; return fail(HLALA_E_DEVICE); }
+    int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->ext_grid = cus * 6;
+    c->ext_slab_bytes = ext_slab_bytes_host(c->params.max_columns);
+    if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
+    c->allocs.push_back(c->ext_slabs);
+    c->proj_grid = cus * 8;
+    c->proj_slab_bytes = proj_slab_bytes_host(c->params.max_columns, F.max_nodes_per_level);
+    if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
+    c->allocs.push_back(c->proj_slabs);
+    if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 64 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 64 * sizeof(int)); }
+    for(int i = 0; i < 4; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
+    *out = c;
+    return HLALA_OK;
+}
+
+void hlala_destroy(hlala_ctx* c)
+{
+    if(!c) return;
+    for(void* p : c->allocs) if(p) (void)hipFree(p);
+    for(int i = 0; i < 4; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+int hlala_graph_get_info(const hlala_ctx* c, hlala_graph_info* info)
+{
+    if(!c || !info) return HLALA_E_ARG;
+    const FlatGraph& F = c->F;
+    memset(info, 0, sizeof(*info));
+    info->n_levels = F.L; info->n_nodes = F.N; info->n_edges = F.E; info->n_paths = (int)F.path_len.size();
+    info->n_jump_entries = (int64_t)F.jf_node.size(); info->n_path_edges = (int64_t)F.path_edges.size();
+    info->n_levelpos_entries = (int64_t)F.lp_seqid.size();
+    info->max_nodes_per_level = F.max_nodes_per_level; info->max_out_degree = F.max_out_degree; info->max_in_degree = F.max_in_degree;
+    for(uint8_t b : F.gap_stretch) info->n_gap_stretch_levels += b;
+    return HLALA_OK;
+}
+int hlala_graph_get_nodes(const hlala_ctx* c, int32_t* node_orig, int32_t* level_off)
+{
+    if(!c) return HLALA_E_ARG;
+    if(node_orig) memcpy(node_orig, c->F.node_orig.data(), c->F.node_orig.size() * 4);
+    if(level_off) memcpy(level_off, c->F.level_off.data(), c->F.level_off.size() * 4);
+    return HLALA_OK;
+}
+int hlala_graph_get_paths(const hlala_ctx* c, int32_t* first_node, int32_t* last_node, int32_t* length)
+{
+    if(!c) return HLALA_E_ARG;
+    const FlatGraph& F = c->F;
+    for(size_t p = 0; p < F.path_len.size(); p++) {
+        if(first_node) first_node[p] = F.node_orig[F.path_first[p]];
+        if(last_node) last_node[p] = F.node_orig[F.path_last[p]];
+        if(length) length[p] = F.path_len[p];
+    }
+    return HLALA_OK;
+}
+int hlala_graph_get_gap_stretch(const hlala_ctx* c, uint8_t* in_stretch)
+{
+    if(!c || !in_stretch) return HLALA_E_ARG;
+    memcpy(in_stretch, c->F.gap_stretch.data(), c->F.gap_stretch.size());
+    return HLALA_OK;
+}
+
+// ------------------------------------------------------------------------------------ batches
+
+static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
+{
+    DevBatch& B = b->B;
+    size_t nc = (size_t)B.n_chains, cs = nc * (size_t)B.stride, nr = (size_t)B.n_reads, np = (size_t)B.n_pairs;
+    int rc = 0;
+#define AL(field, n, zero) do { rc = dev_alloc(c, b->allocs, (n), &B.field, zero); if(rc) return rc; } while(0)
+    AL(seed_status, nc, true); AL(seed_ncols, nc, true); AL(seed_begin, nc, true); AL(seed_end, nc, true); AL(seed_removed, nc, true);
+    AL(seed_level, cs, false); AL(seed_edge, cs, false); AL(seed_g, cs, false); AL(seed_s, cs, false);
+    AL(ext_status, nc, true); AL(ext_ncols, nc, true); AL(ext_begin, nc, true); AL(ext_end, nc, true); AL(ext_ll, nc, true);
+    AL(dp_iters, 2 * nc, true); AL(dp_score, 2 * nc, true);
+    AL(ext_level, cs, false); AL(ext_edge, cs, false); AL(ext_g, cs, false); AL(ext_s, cs, false); AL(ext_fromseed, cs, false);
+    AL(ext_firstlast, 4 * nc, true);
+    AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
+    AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, false);
+    AL(counters, 16, true); AL(work_counter, 4, true);
+    B.dbg = c->dbg_host;
+#undef AL
+    return 0;
+}
+
+int hlala_batch_create(hlala_ctx* c, const hlala_batch_in* in, hlala_batch** out)
+{
+    if(!c || !in || !out) return HLALA_E_ARG;
+    *out = nullptr;
+    if(in->n_pairs < 0 || in->n_chains < 0) { c->err = "negative batch sizes"; return HLALA_E_ARG; }
+    if(!c->d_contig_off) { c->err = "hlala_batch_create needs contigs (hlala_create was called without them)"; return HLALA_E_STATE; }
+    hlala_batch* b = new hlala_batch(); b->ctx = c;
+    DevBatch& B = b->B;
+    B.n_pairs = in->n_pairs; B.n_reads = 2 * in->n_pairs; B.n_chains = in->n_chains; B.stride = c->params.max_columns; B.from_seeds = 0;
+    int nr = B.n_reads, nc = B.n_chains;
+    auto fail = [&](int rc) { hlala_batch_destroy(b); return rc; };
+    // validation the reference would assert on
+    if(nr > 0 && (in->read_off[0] != 0 || in->chain_off[0] != 0 || in->chain_off[nr] != nc)) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
+    std::vector<int> chain_read((size_t)nc);
+    for(int r = 0; r < nr; r++) {
+        if(in->chain_off[r + 1] <= in->chain_off[r]) { c->err = "read without alignments"; return fail(HLALA_E_ARG); }
+        if(in->read_primary[r] < in->chain_off[r] || in->read_primary[r] >= in->chain_off[r + 1]) { c->err = "read_primary outside the read's chains"; return fail(HLALA_E_ARG); }
+        for(int k = in->chain_off[r]; k < in->chain_off[r + 1]; k++) chain_read[k] = r;
+    }
+    for(int k = 0; k < nc; k++) if(in->chain_contig[k] < 0 || in->chain_contig[k] >= c->n_contigs) { c->err = "chain_contig out of range"; return fail(HLALA_E_ARG); }
+    size_t nbases = nr ? (size_t)in->read_off[nr] : 0, ncig = nc ? (size_t)in->cigar_off[nc] : 0;
+    int rc = 0;
+#define UPB(field, ptr, n) do { rc = dev_upload(c, b->allocs, (ptr), (n), (std::remove_const<std::remove_pointer<decltype(B.field)>::type>::type**)&B.field); if(rc) return fail(rc); } while(0)
+    UPB(read_off, in->read_off, (size_t)nr + 1); UPB(read_bases, in->read_bases, nbases); UPB(read_quals, in->read_quals, nbases);
+    UPB(chain_off, in->chain_off, (size_t)nr + 1); UPB(read_primary, in->read_primary, (size_t)nr);
+    UPB(chain_read, chain_read.data(), (size_t)nc);
+    UPB(chain_contig, in->chain_contig, (size_t)nc); UPB(chain_pos, in->chain_pos, (size_t)nc); UPB(chain_offset, in->chain_offset, (size_t)nc);
+    UPB(chain_as, in->chain_as, (size_t)nc); UPB(chain_reverse, in->chain_reverse, (size_t)nc);
+    UPB(cigar_off, in->cigar_off, (size_t)nc + 1); UPB(cigar, in->cigar, ncig);
+#undef UPB
+    rc = batch_alloc_outputs(c, b); if(rc) return fail(rc);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *out = b;
+    return HLALA_OK;
+}
+
+int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_batch** out)
+{
+    if(!c || !in || !out) return HLALA_E_ARG;
+    *out = nullptr;
+    hlala_batch* b = new hlala_batch(); b->ctx = c;
+    DevBatch& B = b->B;
+    B.n_pairs = 0; B.n_reads = in->n_reads; B.n_chains = in->n_chains; B.stride = c->params.max_columns; B.from_seeds = 1;
+    int nr = B.n_reads, nc = B.n_chains; int stride = B.stride;
+    auto fail = [&](int rc) { hlala_batch_destroy(b); return rc; };
+    size_t nbases = nr ? (size_t)in->read_off[nr] : 0;
+    int rc = 0;
+    rc = dev_upload(c, b->allocs, in->read_off, (size_t)nr + 1, (int**)&B.read_off); if(rc) return fail(rc);
+    rc = dev_upload(c, b->allocs, in->read_bases, nbases, (uint8_t**)&B.read_bases); if(rc) return fail(rc);
+    rc = dev_upload(c, b->allocs, in->read_quals, nbases, (uint8_t**)&B.read_quals); if(rc) return fail(rc);
+    rc = dev_upload(c, b->allocs, in->chain_read, (size_t)nc, (int**)&B.chain_read); if(rc) return fail(rc);
+    rc = dev_upload(c, b->allocs, in->chain_reverse, (size_t)nc, (uint8_t**)&B.chain_reverse); if(rc) return fail(rc);
+    rc = batch_alloc_outputs(c, b); if(rc) return fail(rc);
+    // scatter the ragged seed columns into the fixed-stride layout
+    std::vector<int> st((size_t)nc, HLALA_CHAIN_OK), ncols((size_t)nc), lev((size_t)nc * stride, -1), edg((size_t)nc * stride, -1);
+    std::vector<uint8_t> g((size_t)nc * stride, 0), s((size_t)nc * stride, 0);
+    for(int k = 0; k < nc; k++) {
+        int n = in->col_off[k + 1] - in->col_off[k];
+        if(in->chain_read[k] < 0 || in->chain_read[k] >= nr) { c->err = "chain_read out of range"; return fail(HLALA_E_ARG); }
+        if(n > stride || n < 1) { st[k] = HLALA_CHAIN_ERR_COLUMNS; ncols[k] = 0; continue; }
+        ncols[k] = n;
+        for(int j = 0; j < n; j++) {
+            size_t o = (size_t)k * stride + j; int i = in->col_off[k] + j;
+            lev[o] = in->col_level[i]; edg[o] = in->col_edge[i]; g[o] = in->col_gchar[i]; s[o] = in->col_schar[i];
+        }
+    }
+    HIP_TRY(c, hipMemcpyAsync(B.seed_status, st.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(B.seed_ncols, ncols.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(B.seed_begin, in->chain_seq_begin, (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(B.seed_end, in->chain_seq_end, (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(B.seed_level, lev.data(), lev.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(B.seed_edge, edg.data(), edg.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(B.seed_g, g.data(), g.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(B.seed_s, s.data(), s.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    b->staged = 1;
+    *out = b;
+    return HLALA_OK;
+}
+
+void hlala_batch_destroy(hlala_batch* b)
+{
+    if(!b) return;
+    for(void* p : b->allocs) if(p) (void)hipFree(p);
+    delete b;
+}
+
+static int check_launch(hlala_ctx* c, const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if(e != hipSuccess) { c->err = std::string(what) + ": " + hipGetErrorString(e); return HLALA_E_DEVICE; }
+    return 0;
+}
+
+int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
+{
+    if(!c || !b) return HLALA_E_ARG;
+    if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
+    DevBatch& B = b->B;
+    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 4 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.counters, 0, 16 * sizeof(u64), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if(B.n_chains > 0) {
+        int threads = 256, blocks = (B.n_reads + threads - 1) / threads;
+        hipLaunchKernelGGL(k_filter_chains, dim3(blocks), dim3(threads), 0, c->stream, c->G, B, c->d_contig_off, c->d_contig_level);
+        int grid = B.n_chains < c->proj_grid ? B.n_chains : c->proj_grid;
+        hipLaunchKernelGGL(k_project_chains, dim3(grid), dim3(64), 0, c->stream, c->G, B, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
+                           c->proj_slabs, c->proj_slab_bytes);
+        int rc = check_launch(c, "k_project_chains"); if(rc) return rc;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    b->staged |= 1;
+    return HLALA_OK;
+}
+
+int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
+{
+    if(!c || !b) return HLALA_E_ARG;
+    if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
+    DevBatch& B = b->B;
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
+    if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 16 * sizeof(u64), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if(B.n_chains > 0) {
+        int grid = B.n_chains < c->ext_grid ? B.n_chains : c->ext_grid;
+        hipLaunchKernelGGL(k_extend_chains, dim3(grid), dim3(64), 0, c->stream, c->G, c->dT, B, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        int rc = check_launch(c, "k_extend_chains"); if(rc) return rc;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    b->staged |= 2;
+    return HLALA_OK;
+}
+
+int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
+{
+    if(!c || !b) return HLALA_E_ARG;
+    if(b->B.from_seeds) { c->err = "batch was created from seeds: stage C not available"; return HLALA_E_STATE; }
+    if(!(b->staged & 2)) { c->err = "hlala_pair_chains before hlala_extend_chains"; return HLALA_E_STATE; }
+    DevBatch& B = b->B;
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->stream));
+    if(B.n_pairs > 0) {
+        int grid = B.n_pairs < c->proj_grid ? B.n_pairs : c->proj_grid;
+        hipLaunchKernelGGL(k_pair_chains, dim3(grid), dim3(64), 0, c->stream, c->G, c->dT, B);
+        int rc = check_launch(c, "k_pair_chains"); if(rc) return rc;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    b->staged |= 4;
+    return HLALA_OK;
+}
+
+int hlala_align_batch(hlala_ctx* c, hlala_batch* b)
+{
+    int rc = hlala_project_chains(c, b); if(rc) return rc;
+    rc = hlala_extend_chains(c, b); if(rc) return rc;
+    return hlala_pair_chains(c, b);
+}
+
+int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains_out* o)
+{
+    if(!c || !b || !o) return HLALA_E_ARG;
+    DevBatch& B = b->B;
+    size_t nc = (size_t)B.n_chains, cs = nc * (size_t)B.stride;
+    int rc = 0;
+    if(stage == 0) {
+        if(!(b->staged & 1)) { c->err = "seed chains not computed"; return HLALA_E_STATE; }
+        if((rc = dl(c, o->status, B.seed_status, nc))) return rc; if((rc = dl(c, o->n_cols, B.seed_ncols, nc))) return rc;
+        if((rc = dl(c, o->seq_begin, B.seed_begin, nc))) return rc; if((rc = dl(c, o->seq_end, B.seed_end, nc))) return rc;
+        if((rc = dl(c, o->removed_cols, B.seed_removed, nc))) return rc;
+        if((rc = dl(c, o->col_level, B.seed_level, cs))) return rc; if((rc = dl(c, o->col_edge, B.seed_edge, cs))) return rc;
+        if((rc = dl(c, o->col_gchar, B.seed_g, cs))) return rc; if((rc = dl(c, o->col_schar, B.seed_s, cs))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if(o->col_fromseed) memset(o->col_fromseed, 1, cs);
+        if(o->ll) memset(o->ll, 0, nc * 8);
+        if(o->dp_iters) memset(o->dp_iters, 0, nc * 8);
+        if(o->dp_score) memset(o->dp_score, 0, nc * 8);
+    } else if(stage == 1) {
+        if(!(b->staged & 2)) { c->err = "extended chains not computed"; return HLALA_E_STATE; }
+        if((rc = dl(c, o->status, B.ext_status, nc))) return rc; if((rc = dl(c, o->n_cols, B.ext_ncols, nc))) return rc;
+        if((rc = dl(c, o->seq_begin, B.ext_begin, nc))) return rc; if((rc = dl(c, o->seq_end, B.ext_end, nc))) return rc;
+        if((rc = dl(c, o->removed_cols, B.seed_removed, nc))) return rc; if((rc = dl(c, o->ll, B.ext_ll, nc))) return rc;
+        if((rc = dl(c, o->dp_iters, B.dp_iters, 2 * nc))) return rc; if((rc = dl(c, o->dp_score, B.dp_score, 2 * nc))) return rc;
+        if((rc = dl(c, o->col_level, B.ext_level, cs))) return rc; if((rc = dl(c, o->col_edge, B.ext_edge, cs))) return rc;
+        if((rc = dl(c, o->col_gchar, B.ext_g, cs))) return rc; if((rc = dl(c, o->col_schar, B.ext_s, cs))) return rc;
+        if((rc = dl(c, o->col_fromseed, B.ext_fromseed, cs))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else { c->err = "stage must be 0 or 1"; return HLALA_E_ARG; }
+    return HLALA_OK;
+}
+
+int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
+{
+    if(!c || !b || !o) return HLALA_E_ARG;
+    if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
+    DevBatch& B = b->B;
+    size_t np = (size_t)B.n_pairs, nr = (size_t)B.n_reads, stride = (size_t)B.stride;
+    int rc = 0;
+    std::vector<int> best(nr);
+    if((rc = dl(c, best.data(), B.best_chain, nr))) return rc;
+    if((rc = dl(c, o->pair_status, B.pair_status, np))) return rc; if((rc = dl(c, o->n_combinations, B.n_comb, np))) return rc;
+    if((rc = dl(c, o->pair_ll, B.pair_ll, np))) return rc; if((rc = dl(c, o->pair_mapq, B.pair_mapq, np))) return rc;
+    if((rc = dl(c, o->mate_mapq, B.mate_mapq, nr))) return rc; if((rc = dl(c, o->strands_valid, B.strands_valid, np))) return rc;
+    if((rc = dl(c, o->col_mapq, B.sel_mapq, nr * stride))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if(o->best_chain) memcpy(o->best_chain, best.data(), nr * 4);
+    // columns of the selected chains: gathered from the chain-level arrays
+    for(size_t r = 0; r < nr; r++) {
+        int ch = best[r];
+        int n = 0;
+        if(ch >= 0 && ch < B.n_chains) HIP_TRY(c, hipMemcpy(&n, B.ext_ncols + ch, 4, hipMemcpyDeviceToHost));
+        if(o->n_cols) o->n_cols[r] = n;
+        if(n <= 0) continue;
+        size_t so = (size_t)ch * stride, dofs = r * stride;
+        if(o->col_level) HIP_TRY(c, hipMemcpy(o->col_level + dofs, B.ext_level + so, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if(o->col_edge) HIP_TRY(c, hipMemcpy(o->col_edge + dofs, B.ext_edge + so, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if(o->col_gchar) HIP_TRY(c, hipMemcpy(o->col_gchar + dofs, B.ext_g + so, (size_t)n, hipMemcpyDeviceToHost));
+        if(o->col_schar) HIP_TRY(c, hipMemcpy(o->col_schar + dofs, B.ext_s + so, (size_t)n, hipMemcpyDeviceToHost));
+        if(o->col_fromseed) HIP_TRY(c, hipMemcpy(o->col_fromseed + dofs, B.ext_fromseed + so, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    return HLALA_OK;
+}
+
+int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
+{
+    if(!c || !b || !out) return HLALA_E_ARG;
+    memset(out, 0, sizeof(*out));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    u64 cnt[16];
+    HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
+    if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
+    if(b->staged & 2) (void)hipEventElapsedTime(&out->ms_extend, c->ev[1], c->ev[2]);
+    if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[2], c->ev[3]);
+    out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
+    out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];
+    out->n_seed_columns = (int64_t)cnt[CNT_SEED_COLS]; out->n_out_columns = (int64_t)cnt[CNT_OUT_COLS];
+    out->n_edges_touched = (int64_t)cnt[CNT_EDGES]; out->n_errors = (int64_t)cnt[CNT_ERRORS];
+    return HLALA_OK;
+}
+
+}  // extern "C"
+
+// ---- known-answer kernels
+namespace hlala {
+__global__ void k_kat_phred(const DevTables* T, int n, const double* p, uint8_t* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = phred_from_pcorrect(*T, p[i]);
+}
+__global__ void k_kat_rand(int n, u32* seeds, int* vals)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) { unsigned int s = seeds[i]; vals[i] = glibc_rand_r(&s); seeds[i] = s; }
+}
+}  // namespace hlala
+
+extern "C" int hlala_debug_peek(hlala_ctx* c, int* out64)
+{
+    if(!c || !c->dbg_host) return HLALA_E_STATE;
+    for(int i = 0; i < 64; i++) out64[i] = ((volatile int*)c->dbg_host)[i];
+    return (hipStreamQuery(c->stream) == hipSuccess) ? 1 : 0;     // 1 = stream idle
+}
+
+extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uint8_t* phred_out, const uint8_t* phred_in, double* p_out)
+{
+    if(!c || n < 0) return HLALA_E_ARG;
+    if(p_correct && phred_out && n) {
+        double* dp = nullptr; uint8_t* dq = nullptr; std::vector<void*> tmp;
+        int rc = dev_upload(c, tmp, p_correct, (size_t)n, &dp); if(rc) return rc;
+        rc = dev_alloc(c, tmp, (size_t)n, &dq); if(rc) return rc;
+        hipLaunchKernelGGL(k_kat_phred, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dT, n, dp, dq);
+        HIP_TRY(c, hipMemcpyAsync(phred_out, dq, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for(void* p : tmp) (void)hipFree(p);
+    }
+    if(phred_in && p_out) {
+        // PhredToPCorrect feeds the host-built likelihood tables: report the table entries' pre-image
+        for(int i = 0; i < n; i++) p_out[i] = host_PhredToPCorrect(phred_in[i]);
+    }
+    return HLALA_OK;
+}
+
+extern "C" int hlala_kat_rand_r(hlala_ctx* c, int n, uint32_t* seeds_inout, int32_t* values_out)
+{
+    if(!c || n < 0 || !seeds_inout || !values_out) return HLALA_E_ARG;
+    if(!n) return HLALA_OK;
+    u32* ds = nullptr; int* dv = nullptr; std::vector<void*> tmp;
+    int rc = dev_upload(c, tmp, seeds_inout, (size_t)n, &ds); if(rc) return rc;
+    rc = dev_alloc(c, tmp, (size_t)n, &dv); if(rc) return rc;
+    hipLaunchKernelGGL(k_kat_rand, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, ds, dv);
+    HIP_TRY(c, hipMemcpyAsync(seeds_inout, ds, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(values_out, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for(void* p : tmp) (void)hipFree(p);
+    return HLALA_OK;
+}
