@@ -61,6 +61,20 @@ constexpr int DP_COMPLETED = 2048;   // sequence-complete cells
 constexpr int DP_NEG       = -30000; // minusInfinity (-DBL_MAX in the reference, extensionAligner.cpp:363)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// All kernels run ONE wavefront per block, so a block barrier is only a memory-ordering point between lanes of the
+// same wave.  __syncthreads() is not used: hipcc (ROCm 7.2) miscompiled persistent work loops that `continue` / `break`
+// around it (kernels never terminated); a wavefront-scope fence + scheduling barrier gives the ordering without the
+// workgroup-barrier semantics.
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while(0)
+// make a value the compiler cannot prove wave-uniform explicitly scalar (all 64 lanes hold the same value)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// dynamic work distribution for one-wave blocks: lane 0 draws the next item, every lane gets it in an SGPR
+__device__ __forceinline__ int next_work(int* counter)
+{
+    int w = 0;
+    if(lane_id() == 0) w = atomicAdd(counter, 1);
+    return __builtin_amdgcn_readfirstlane(w);
+}
 
 __device__ __forceinline__ int wave_max_i32(int v)
 {

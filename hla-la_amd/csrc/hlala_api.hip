@@ -34,6 +34,7 @@ struct hlala_ctx {
     hlala_params params{};
     FlatGraph F;
     DevGraph G{};
+    DevGraph* dG = nullptr;       // device copy of G (kernels take descriptors by pointer)
     DevTables* dT = nullptr;
     double* d_islog = nullptr;
     long long* d_contig_off = nullptr; uint8_t* d_contig_seq = nullptr; int* d_contig_level = nullptr;
@@ -41,7 +42,7 @@ struct hlala_ctx {
     std::vector<void*> allocs;
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0;
-    hipEvent_t ev[4]{};
+    hipEvent_t ev[6]{};           // start/end per stage
     int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
     std::string err;
 };
@@ -49,6 +50,7 @@ struct hlala_ctx {
 struct hlala_batch {
     hlala_ctx* ctx = nullptr;
     DevBatch B{};
+    DevBatch* dB = nullptr;       // device copy of B
     std::vector<void*> allocs;
     int staged = 0;   // bit0 seeds available, bit1 extended, bit2 paired
     float ms[3] = {0, 0, 0};
@@ -193,7 +195,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     std::string ferr = flatten_graph(graph, contigs, c->F);
     if(!ferr.empty()) { c->err = ferr; return fail(HLALA_E_GRAPH); }
     FlatGraph& F = c->F;
-    if(F.max_nodes_per_level > 65535) { c->err = "more than 65535 nodes in one level"; return fail(HLALA_E_CAPACITY); }
+    if(F.max_nodes_per_level > PROJ_NODES) { c->err = "more nodes in one level than this build holds in LDS (PROJ_NODES)"; return fail(HLALA_E_CAPACITY); }
+    if(c->params.max_columns > PROJ_CAP || c->params.max_columns > PAIR_COLS) { c->err = "params.max_columns exceeds the LDS column capacity of this build (768)"; return fail(HLALA_E_ARG); }
     DevGraph& G = c->G;
     G.L = F.L; G.N = F.N; G.E = F.E; G.P = (int)F.path_len.size();
     std::vector<uint8_t> edge_label(graph->edge_label, graph->edge_label + graph->n_edges);
@@ -224,6 +227,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
         rc = dev_upload(c, c->allocs, contigs->contig_level, total, &c->d_contig_level); if(rc) return fail(rc);
     }
     rc = build_tables(c); if(rc) return fail(rc);
+    rc = dev_upload(c, c->allocs, &c->G, 1, &c->dG); if(rc) return fail(rc);
     // scratch slabs: one per resident wavefront (persistent grid, dynamic work distribution)
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, device) != hipSuccess) { c->err = "hipGetDeviceProperties failed"; return fail(HLALA_E_DEVICE); }
@@ -236,8 +240,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->proj_slab_bytes = proj_slab_bytes_host(c->params.max_columns, F.max_nodes_per_level);
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
-    if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 64 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 64 * sizeof(int)); }
-    for(int i = 0; i < 4; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
+    for(int i = 0; i < 6; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;
@@ -247,7 +251,7 @@ void hlala_destroy(hlala_ctx* c)
 {
     if(!c) return;
     for(void* p : c->allocs) if(p) (void)hipFree(p);
-    for(int i = 0; i < 4; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for(int i = 0; i < 6; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -341,6 +345,7 @@ int hlala_batch_create(hlala_ctx* c, const hlala_batch_in* in, hlala_batch** out
     UPB(cigar_off, in->cigar_off, (size_t)nc + 1); UPB(cigar, in->cigar, ncig);
 #undef UPB
     rc = batch_alloc_outputs(c, b); if(rc) return fail(rc);
+    rc = dev_upload(c, b->allocs, &b->B, 1, &b->dB); if(rc) return fail(rc);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *out = b;
     return HLALA_OK;
@@ -363,6 +368,7 @@ int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_
     rc = dev_upload(c, b->allocs, in->chain_read, (size_t)nc, (int**)&B.chain_read); if(rc) return fail(rc);
     rc = dev_upload(c, b->allocs, in->chain_reverse, (size_t)nc, (uint8_t**)&B.chain_reverse); if(rc) return fail(rc);
     rc = batch_alloc_outputs(c, b); if(rc) return fail(rc);
+    rc = dev_upload(c, b->allocs, &b->B, 1, &b->dB); if(rc) return fail(rc);
     // scatter the ragged seed columns into the fixed-stride layout
     std::vector<int> st((size_t)nc, HLALA_CHAIN_OK), ncols((size_t)nc), lev((size_t)nc * stride, -1), edg((size_t)nc * stride, -1);
     std::vector<uint8_t> g((size_t)nc * stride, 0), s((size_t)nc * stride, 0);
@@ -414,9 +420,9 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if(B.n_chains > 0) {
         int threads = 256, blocks = (B.n_reads + threads - 1) / threads;
-        hipLaunchKernelGGL(k_filter_chains, dim3(blocks), dim3(threads), 0, c->stream, c->G, B, c->d_contig_off, c->d_contig_level);
+        hipLaunchKernelGGL(k_filter_chains, dim3(blocks), dim3(threads), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_level);
         int grid = B.n_chains < c->proj_grid ? B.n_chains : c->proj_grid;
-        hipLaunchKernelGGL(k_project_chains, dim3(grid), dim3(64), 0, c->stream, c->G, B, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
+        hipLaunchKernelGGL(k_project_chains, dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
                            c->proj_slabs, c->proj_slab_bytes);
         int rc = check_launch(c, "k_project_chains"); if(rc) return rc;
     }
@@ -432,13 +438,13 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
     if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 16 * sizeof(u64), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if(B.n_chains > 0) {
         int grid = B.n_chains < c->ext_grid ? B.n_chains : c->ext_grid;
-        hipLaunchKernelGGL(k_extend_chains, dim3(grid), dim3(64), 0, c->stream, c->G, c->dT, B, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        hipLaunchKernelGGL(k_extend_chains, dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
         int rc = check_launch(c, "k_extend_chains"); if(rc) return rc;
     }
-    HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
     b->staged |= 2;
     return HLALA_OK;
 }
@@ -450,12 +456,13 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
     if(!(b->staged & 2)) { c->err = "hlala_pair_chains before hlala_extend_chains"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
     if(B.n_pairs > 0) {
         int grid = B.n_pairs < c->proj_grid ? B.n_pairs : c->proj_grid;
-        hipLaunchKernelGGL(k_pair_chains, dim3(grid), dim3(64), 0, c->stream, c->G, c->dT, B);
+        hipLaunchKernelGGL(k_pair_chains, dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);
         int rc = check_launch(c, "k_pair_chains"); if(rc) return rc;
     }
-    HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
     b->staged |= 4;
     return HLALA_OK;
 }
@@ -539,8 +546,8 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     u64 cnt[16];
     HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
-    if(b->staged & 2) (void)hipEventElapsedTime(&out->ms_extend, c->ev[1], c->ev[2]);
-    if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[2], c->ev[3]);
+    if(b->staged & 2) (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]);
+    if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];
     out->n_seed_columns = (int64_t)cnt[CNT_SEED_COLS]; out->n_out_columns = (int64_t)cnt[CNT_OUT_COLS];
@@ -567,8 +574,12 @@ __global__ void k_kat_rand(int n, u32* seeds, int* vals)
 extern "C" int hlala_debug_peek(hlala_ctx* c, int* out64)
 {
     if(!c || !c->dbg_host) return HLALA_E_STATE;
-    for(int i = 0; i < 64; i++) out64[i] = ((volatile int*)c->dbg_host)[i];
-    return (hipStreamQuery(c->stream) == hipSuccess) ? 1 : 0;     // 1 = stream idle
+    for(int i = 0; i < 8192; i++) out64[i] = ((volatile int*)c->dbg_host)[i];
+    hipError_t q = hipStreamQuery(c->stream);
+    if(q == hipSuccess) return 1;                 // stream idle
+    if(q == hipErrorNotReady) return 0;           // still running
+    c->err = std::string("hipStreamQuery: ") + hipGetErrorString(q);
+    return -100 - (int)q;                          // device error (sticky)
 }
 
 extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uint8_t* phred_out, const uint8_t* phred_in, double* p_out)

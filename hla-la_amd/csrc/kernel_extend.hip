@@ -176,6 +176,7 @@ __device__ inline bool xz_less(int x1, int z1, int x2, int z2)
 struct DpResult { int have, ncols, seq_begin, seq_end, iters, score, err; };
 
 #define DBGW(i, v) __hip_atomic_store(&dbg[i], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define DBGB(i, v) do { if(dbg && lane == 0 && blockIdx.x < 2000) __hip_atomic_store(&dbg[64 + 4 * blockIdx.x + (i)], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while(0)
 #define DP_FAIL(code) do { if(lane == 0 && S.err == 0) S.err = (code); } while(0)
 
 // extensionAligner::fullNeedleman_diagonal_extension_gapJumper (extensionAligner.cpp:335-1556) with
@@ -201,7 +202,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
         S.fx[0][0] = startLevel; S.fyz[0][0] = ((u32)start_seq << 16) | (u32)startZ; S.fslot[0][0] = 0;
         S.fD[0][0] = 0; S.fG[0][0] = (short)DP_NEG; S.fS[0][0] = (short)DP_NEG;
     }
-    __syncthreads();
+    WSYNC();
     int b1 = 0, b2 = 1, bn = 2;
     int n1 = 1, n2 = 0;
     int nCells = 1, nCompleted = 0;
@@ -218,6 +219,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
             itersRun = last; break;
         }
         itersRun = d;
+        DBGB(0, chain); DBGB(1, (int)d); DBGB(2, 100 + side);
         if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(0, chain); DBGW(1, (int)d); DBGW(2, n1); DBGW(3, n2); DBGW(4, nCells); DBGW(5, lastInc); DBGW(6, 1); DBGW(7, side); }
         if(d > 60000) { DP_FAIL(__LINE__); break; }          // watchdog: far beyond any read length + patience
 
@@ -290,15 +292,15 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                 }
             }
         }
-        __syncthreads();
-        int nT = S.nT;
+        WSYNC();
+        int nT = uni(S.nT);
         if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 2); DBGW(8, nT); }
-        if(nT > (DP_HC * 3) / 4 || S.err) { DP_FAIL(__LINE__); break; }
+        if(nT > (DP_HC * 3) / 4 || uni(S.err)) { DP_FAIL(__LINE__); break; }
         cellsEvaluated += (u64)nT;
 
         // ================= evaluate =====================================================
         if(lane == 0) { S.nNew = 0; S.nImp = 0; S.nCompletedAdd = 0; }
-        __syncthreads();
+        WSYNC();
         int itMaxNew = DP_NEG;        // max Dv over kept targets of this iteration
         u64 itMaxKey = ~0ull;         // smallest key achieving it (= first such cell in std::map order)
         bool anyEqDiff = false, anyOw = false, anyExisting = false;
@@ -318,7 +320,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                 }
                 if(__ballot(es >= 0)) anyExisting = true;
             }
-            __syncthreads();
+            WSYNC();
         }
         const bool slow = anyExisting;
         if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 21); }
@@ -399,7 +401,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                         if(!earlyInit) {
                             for(int i = lane; i < DP_EARLY; i += 64) sl.early_key[i] = HKEY_EMPTY;
                             earlyInit = true;
-                            __syncthreads();
+                            WSYNC();
                         }
                         if(isEarly) if(!early_insert(sl, key, slot)) S.err = __LINE__;
                     }
@@ -468,20 +470,20 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                     S.hbest[2][h] = (u32)(unsigned short)(short)mS;
                 }
             }
-            __syncthreads();
+            WSYNC();
         }
         if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 27); DBGW(11, S.err); DBGW(12, S.nImp); DBGW(13, slow ? 1 : 0); }
-        nCompleted += S.nCompletedAdd;
-        if(S.err) { DP_FAIL(__LINE__); break; }
+        nCompleted += uni(S.nCompletedAdd);
+        if(uni(S.err)) { DP_FAIL(__LINE__); break; }
         // apply staged improvements of existing cells and patch cached frontier copies
         {
-            int nImp = S.nImp;
+            int nImp = uni(S.nImp);
             for(int q = lane; q < nImp; q += 64) {
                 int es = sl.imp_slot[q]; int msk = sl.imp_mask[q];
                 for(int m = 0; m < 3; m++) if(msk & (1 << m)) { sl.cell_sc[4 * es + m] = sl.imp_new[4 * q + m]; sl.cell_bt[m * DP_CELLS + es] = sl.imp_bt[3 * q + m]; }
             }
             if(nImp) {
-                __syncthreads();
+                WSYNC();
                 for(int q = 0; q < nImp; q++) {
                     int es = sl.imp_slot[q]; short v0 = sl.imp_new[4 * q + 0], v1 = sl.imp_new[4 * q + 1], v2 = sl.imp_new[4 * q + 2];
                     for(int i = lane; i < n1; i += 64) if(S.fslot[b1][i] == es) { S.fD[b1][i] = v0; S.fG[b1][i] = v1; S.fS[b1][i] = v2; }
@@ -526,16 +528,17 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
             nNew += __popcll(__ballot(pass));
         }
         if(nNew > DP_WCAP) { DP_FAIL(__LINE__); break; }
-        __syncthreads();
+        WSYNC();
         // reset the hash entries used by this iteration
         for(int t = lane; t < nT; t += 64) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
         if(lane == 0) S.nT = 0;
-        __syncthreads();
+        WSYNC();
         { int tmp = b2; b2 = b1; b1 = bn; bn = tmp; }                                        // m2 := m1; m1 := this, :1104-1105
         n2 = n1; n1 = nNew;
     }
-    __syncthreads();
+    WSYNC();
     R.iters = (int)itersRun;
+    DBGB(2, 200 + side);
     if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 30); DBGW(14, S.err); }
     if(lane == 0 && counters) {
         atomicAdd(&counters[CNT_DP_CALLS], 1ull); atomicAdd(&counters[CNT_DP_ITERS], (u64)itersRun);
@@ -548,7 +551,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
         if(lane == 0 && counters) atomicAdd(&counters[CNT_EDGES], (u64)e);
     }
     if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 31); }
-    if(S.err) { R.err = S.err; return R; }
+    if(uni(S.err)) { R.err = uni(S.err); return R; }
 
     if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 4); DBGW(9, nCompleted); }
     // ---- end cell, :1381-1517
@@ -582,6 +585,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
     if(endSlot < 0) return R;                                                                // no extension
 
     if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 5); DBGW(10, endSlot); }
+    DBGB(2, 300 + side);
     // ---- backtrace, :1109-1354: lane 0 chases the back pointers, then all lanes expand the steps into columns
     if(lane == 0) {
         int slot = endSlot, m = 0; u64 k = sl.cell_key[slot]; int x = key_x(k), y = key_y(k);
@@ -604,9 +608,9 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
         S.nNew = nSteps; S.nKeepF = nCols;
         if(nSteps >= DP_STEPS || guardSteps >= 4 * DP_STEPS) S.err = __LINE__;
     }
-    __syncthreads();
-    if(S.err) { R.err = S.err; return R; }
-    int nSteps = S.nNew, nCols = S.nKeepF;
+    WSYNC();
+    if(uni(S.err)) { R.err = uni(S.err); return R; }
+    int nSteps = uni(S.nNew), nCols = uni(S.nKeepF);
     if(nCols > outCap) { R.err = -1000000 - nCols; return R; }
     int* oL = sl.x_level[side]; int* oE = sl.x_edge[side]; uint8_t* oG = sl.x_g[side]; uint8_t* oS = sl.x_s[side];
     int base = 0;
@@ -633,7 +637,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
         }
         base += total;
     }
-    __syncthreads();
+    WSYNC();
     u64 ek = sl.cell_key[endSlot];
     int yEnd = key_y(ek);
     R.have = 1; R.ncols = nCols; R.score = endScore;
@@ -646,54 +650,50 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
 // ------------------------------------------------------------------------------------------
 // one wave per chain: left DP, right DP, stitch (extendWithOtherSeedChain / extendToFullSequenceLength,
 // verboseSeedChain.cpp:23-136), then scoreOneAlignment (extensionAligner.cpp:52-182).
-__global__ __launch_bounds__(64) void k_extend_chains(DevGraph G, const DevTables* __restrict__ Tp, DevBatch B, char* slabs, size_t slabBytes, u32 rng_seed)
+__global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp, char* slabs, size_t slabBytes, u32 rng_seed)
 {
+    // graph / batch descriptors stay in memory (scalar loads on demand): passing them by value costs ~150 SGPRs
+    const DevGraph& G = *Gp;
+    const DevBatch& B = *Bp;
     __shared__ DpLds S;
-    __shared__ int s_work;
     const int lane = lane_id();
     const DevTables& T = *Tp;
     ExtSlab sl = ext_slab_at(slabs + (size_t)blockIdx.x * slabBytes, B.stride);
     const int stride = B.stride;
 
     for(;;) {
-        if(lane == 0) s_work = atomicAdd(&B.work_counter[1], 1);
-        if(B.dbg && lane == 0 && blockIdx.x == 0) { __hip_atomic_store(&B.dbg[15], s_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-        __syncthreads();
-        const int c = s_work;
-        __syncthreads();
-        if(c >= B.n_chains) break;
-        int st = B.seed_status[c];
+        const int c = next_work(&B.work_counter[1]);
+        { int* dbg = B.dbg; DBGB(0, c); DBGB(2, 1); }
+        if(c >= B.n_chains) { int* dbg = B.dbg; DBGB(2, 999); break; }
+        int st = uni(B.seed_status[c]);
         if(st != HLALA_CHAIN_OK) {
             if(lane == 0) { B.ext_status[c] = st; B.ext_ncols[c] = 0; B.dp_iters[2 * c] = 0; B.dp_iters[2 * c + 1] = 0; B.dp_score[2 * c] = INT32_MIN; B.dp_score[2 * c + 1] = INT32_MIN;
                             if(st < 0) atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
-            continue;
-        }
-        const int r = B.chain_read[c];
-        const int rOff = B.read_off[r], seqLen = B.read_off[r + 1] - rOff;
+        } else {
+        const int r = uni(B.chain_read[c]);
+        const int rOff = uni(B.read_off[r]), seqLen = uni(B.read_off[r + 1]) - rOff;
         const size_t cb = (size_t)c * stride;
-        const int nSeed = B.seed_ncols[c], sBegin = B.seed_begin[c], sEnd = B.seed_end[c];
+        const int nSeed = uni(B.seed_ncols[c]), sBegin = uni(B.seed_begin[c]), sEnd = uni(B.seed_end[c]);
         int err = 0;
         if(seqLen > DP_SEQCAP || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;
         if(!err) for(int i = lane; i < seqLen; i += 64) S.seq[i] = B.read_bases[rOff + i];
-        __syncthreads();
+        WSYNC();
         DpResult RL, RR; RL.have = 0; RL.ncols = 0; RL.iters = 0; RL.score = INT32_MIN; RL.err = 0; RL.seq_begin = 0; RL.seq_end = -1; RR = RL;
         if(!err) {
-            int e0 = B.seed_edge[cb], e1 = B.seed_edge[cb + nSeed - 1];
+            int e0 = uni(B.seed_edge[cb]), e1 = uni(B.seed_edge[cb + nSeed - 1]);
             if(e0 < 0 || e1 < 0 || e0 >= G.E || e1 >= G.E) err = HLALA_CHAIN_ERR_INPUT;
             else {
                 if(sBegin != 0) {                                                      // left extension, extensionAligner.cpp:220-268
-                    int firstNode = G.edge_from_new[e0]; int lvl = G.node_level[firstNode];
+                    int firstNode = uni(G.edge_from_new[e0]); int lvl = uni(G.node_level[firstNode]);
                     if(lvl > 0) RL = dp_run(G, S, sl, seqLen, sBegin, lvl, firstNode - G.level_off[lvl], false, rng_seed + 2u * (u32)c, 0, stride, B.counters, B.dbg, c);
                 }
                 if(sEnd != seqLen - 1) {                                               // right extension, :271-319
-                    int lastNode = G.edge_to_new[e1]; int lvl = G.node_level[lastNode];
+                    int lastNode = uni(G.edge_to_new[e1]); int lvl = uni(G.node_level[lastNode]);
                     if(lvl < G.L - 1) RR = dp_run(G, S, sl, seqLen, sEnd + 1, lvl, lastNode - G.level_off[lvl], true, rng_seed + 2u * (u32)c + 1u, 1, stride, B.counters, B.dbg, c);
                 }
-                if(B.dbg && lane == 0 && blockIdx.x == 0) { __hip_atomic_store(&B.dbg[16], 41, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
                 if(RL.err || RR.err) err = ((RL.err <= -1000000) || (RR.err <= -1000000)) ? HLALA_CHAIN_ERR_COLUMNS : HLALA_CHAIN_ERR_FRONTIER;
             }
         }
-        if(B.dbg && lane == 0 && blockIdx.x == 0) { __hip_atomic_store(&B.dbg[16], 42, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         int nL = RL.have ? RL.ncols : 0, nR = RR.have ? RR.ncols : 0;
         int newBegin = RL.have ? RL.seq_begin : sBegin, newEnd = RR.have ? RR.seq_end : sEnd;
         int padL = newBegin, padR = seqLen - 1 - newEnd;
@@ -703,12 +703,10 @@ __global__ __launch_bounds__(64) void k_extend_chains(DevGraph G, const DevTable
             B.dp_iters[2 * c] = RL.iters; B.dp_iters[2 * c + 1] = RR.iters;
             B.dp_score[2 * c] = RL.have ? RL.score : INT32_MIN; B.dp_score[2 * c + 1] = RR.have ? RR.score : INT32_MIN;
         }
-        if(B.dbg && lane == 0 && blockIdx.x == 0) { __hip_atomic_store(&B.dbg[16], 43, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         if(err) {
             if(lane == 0) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(RL.err ? RL.err : RR.err); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
-            if(B.dbg && lane == 0 && blockIdx.x == 0) { __hip_atomic_store(&B.dbg[16], 44, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-            continue;
-        }
+        } else {
+        { int* dbg = B.dbg; DBGB(2, 400); }
         // ---- stitch
         for(int j = lane; j < total; j += 64) {
             int lvl, edge; unsigned char g, s, fs = 0;
@@ -719,7 +717,8 @@ __global__ __launch_bounds__(64) void k_extend_chains(DevGraph G, const DevTable
             else { int q = j - (padL + nL + nSeed + nR); lvl = -1; edge = -1; g = '_'; s = S.seq[newEnd + 1 + q]; }
             B.ext_level[cb + j] = lvl; B.ext_edge[cb + j] = edge; B.ext_g[cb + j] = g; B.ext_s[cb + j] = s; B.ext_fromseed[cb + j] = fs;
         }
-        __syncthreads();
+        WSYNC();
+        { int* dbg = B.dbg; DBGB(2, 500); }
         // ---- scoreOneAlignment: terms are added strictly left to right in FP64 (same order as the reference loop).
         // The read quality of alignment-orientation base i is read_quals[i] in both strands: the reference indexes the
         // ORIGINAL-orientation read with len-i-1 when the chain is reverse (extensionAligner.cpp:85-88), which is the same base.
@@ -762,7 +761,9 @@ __global__ __launch_bounds__(64) void k_extend_chains(DevGraph G, const DevTable
                 atomicAdd(&B.counters[CNT_CHAINS_EXT], 1ull); atomicAdd(&B.counters[CNT_OUT_COLS], (u64)total);
             }
         }
-        __syncthreads();
+        }   // no error
+        }   // chain to extend
+        WSYNC();
     }
 }
 

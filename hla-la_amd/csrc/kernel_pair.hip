@@ -1,5 +1,212 @@
-// kernel_pair.hip -- stage C (placeholder until the pairing kernel lands)
+// kernel_pair.hip -- stage C: pairing + mapping qualities, one wavefront per read pair.
+//   pairing loop of processBAM::alignOneReadPair          mapper/processBAM.cpp:3408-3546
+//   alignerBase::alignedReadPair_strandsValid             mapper/aligner/alignerBase.cpp:213-244
+//   alignedReadPair_pairsDistancesUnderlyingSequences     mapper/aligner/alignerBase.cpp:290-329
+//   verboseSeedChain::alignment_{begin,end}_originalSequenceAnchors   mapper/reads/verboseSeedChain.h:230-280
+//   processBAM::assignMappingQualities                    mapper/processBAM.cpp:4062-4312
+// Insert-size log densities come from a host-built table over integer distances (bit-identical to the host
+// libm evaluation); posterior sums are accumulated in the reference's combination order.
 #include "batch.h"
+#include "../../include/hlala_gpu.h"
+
 namespace hlala {
-__global__ void k_pair_chains(DevGraph G, const DevTables* Tp, DevBatch B) {}
+
+constexpr int PAIR_CHAINS = 64;     // extended chains per mate
+constexpr int PAIR_COMB   = 1024;   // chain combinations per pair
+constexpr int PAIR_COLS   = 768;    // columns per chain handled by the per-position pass
+
+struct __align__(16) PairLds {
+    double LL[PAIR_COMB];
+    int list[2][PAIR_CHAINS];
+    int nlist[2];
+    short basecol[PAIR_COLS];
+    short levcol[PAIR_COLS];
+    double red[4];
+    int ired[8];
+};
+
+// max_d log pdf(d) over the distances of every underlying sequence both chain ends map to (:3436-3495)
+__device__ inline double pair_insert_ll(const DevGraph& G, const DevTables& T, const int* fl_up, const int* fl_down)
+{
+    // upstream chain: last two defined levels (scan order: last, second last); downstream: first two
+    int upL[2] = {fl_up[2], fl_up[3]}, dnL[2] = {fl_down[0], fl_down[1]};
+    double best = 0; bool have = false;
+    for(int a = 0; a < 2; a++) {
+        if(upL[a] < 0) continue;
+        for(long long ia = G.lp_off[upL[a]]; ia < G.lp_off[upL[a] + 1]; ia++) {
+            int id = G.lp_seqid[ia]; int endPos = G.lp_pos[ia];
+            if(a == 1 && upL[0] >= 0) {                       // first found wins: skip ids already anchored by the last level
+                bool dup = false;
+                for(long long q = G.lp_off[upL[0]]; q < G.lp_off[upL[0] + 1]; q++) if(G.lp_seqid[q] == id) { dup = true; break; }
+                if(dup) continue;
+            }
+            int beginPos = -1;
+            for(int b = 0; b < 2 && beginPos < 0; b++) {
+                if(dnL[b] < 0) continue;
+                for(long long q = G.lp_off[dnL[b]]; q < G.lp_off[dnL[b] + 1]; q++) if(G.lp_seqid[q] == id) { beginPos = G.lp_pos[q]; break; }
+            }
+            if(beginPos < 0) continue;
+            long long d = (long long)beginPos - endPos - 1;
+            long long k = d - T.is_dmin;
+            double v = (k >= 0 && k < T.is_n) ? T.is_logpdf[k] : T.is_penalty;      // pdf <= 0 -> penalty (:3447-3464)
+            if(!have || v > best) { best = v; have = true; }
+        }
+    }
+    return have ? best : T.is_penalty;
 }
+
+__global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp)
+{
+    const DevGraph& G = *Gp;
+    const DevBatch& B = *Bp;
+    __shared__ PairLds P;
+    const int lane = lane_id();
+    const DevTables& T = *Tp;
+    const int stride = B.stride;
+
+    for(;;) {
+        const int p = next_work(&B.work_counter[2]);
+        if(p >= B.n_pairs) break;
+        // ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains), error propagation
+        int bad = 0;
+        for(int m = 0; m < 2; m++) {
+            int r = 2 * p + m; int c0 = B.chain_off[r], c1 = B.chain_off[r + 1];
+            int cnt = 0;
+            for(int b0 = c0; b0 < c1; b0 += 64) {
+                int c = b0 + lane; int st = c < c1 ? B.ext_status[c] : 1;
+                if(__ballot(st < 0)) bad = 1;
+                u64 okm = __ballot(st == HLALA_CHAIN_OK);
+                if(st == HLALA_CHAIN_OK) { int pos = cnt + __popcll(okm & ((1ull << lane) - 1ull)); if(pos < PAIR_CHAINS) P.list[m][pos] = c; }
+                cnt += __popcll(okm);
+            }
+            if(lane == 0) P.nlist[m] = cnt;
+            if(cnt < 1 || cnt > PAIR_CHAINS) bad = 1;
+        }
+        WSYNC();
+        const int n1 = uni(P.nlist[0]), n2 = uni(P.nlist[1]);
+        bad = uni(bad);
+        const long long nCombLL = (long long)n1 * n2;
+        if(!bad && nCombLL > PAIR_COMB) bad = 1;
+        if(bad) {
+            if(lane == 0) { B.pair_status[p] = -1; B.best_chain[2 * p] = -1; B.best_chain[2 * p + 1] = -1; B.n_comb[p] = 0; }
+        } else {
+        const int nComb = (int)nCombLL;
+        // ---- combination log likelihoods, row-major (i1, i2) (:3408-3506)
+        for(int i = lane; i < nComb; i += 64) {
+            int i1 = i / n2, i2 = i % n2;
+            int ca = P.list[0][i1], cb = P.list[1][i2];
+            const int* fa = B.ext_firstlast + 4 * ca; const int* fb = B.ext_firstlast + 4 * cb;
+            bool ra = B.chain_reverse[ca] != 0, rb = B.chain_reverse[cb] != 0;
+            bool valid = false;
+            if(fa[0] != -1 && fb[0] != -1 && ra != rb) valid = (!ra) ? (fa[0] < fb[0]) : (fa[2] > fb[2]);          // alignerBase.cpp:213-244
+            double llIS = T.is_penalty;
+            if(valid) llIS = (fa[0] < fb[0]) ? pair_insert_ll(G, T, fa, fb) : pair_insert_ll(G, T, fb, fa);        // alignerBase.cpp:294, 312
+            double combined = B.ext_ll[ca] + B.ext_ll[cb];
+            combined += llIS;
+            P.LL[i] = combined;
+        }
+        WSYNC();
+        // ---- first maximum (Utilities::findVectorMax, Utilities.cpp:309-323)
+        double mx = -1.0e300; int mi = 0x7FFFFFFF;
+        for(int i = lane; i < nComb; i += 64) { double v = P.LL[i]; if(v > mx) { mx = v; mi = i; } }
+        for(int o = 32; o; o >>= 1) { double ov = __shfl_xor(mx, o); int oi = __shfl_xor(mi, o); if(ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; } }
+        const int bestI = uni(mi), best1 = bestI / n2, best2 = bestI % n2;
+        const int selA = uni(P.list[0][best1]), selB = uni(P.list[1][best2]);
+        // ---- posterior over combinations (:4064-4085): exp(LL - max), normalised by a left-to-right sum
+        double mapQ = 1, q1 = 1, q2 = 1;
+        if(nComb > 1) {
+            for(int i = lane; i < nComb; i += 64) P.LL[i] = exp(P.LL[i] - mx);
+            WSYNC();
+            if(lane == 0) {
+                double S = 0; for(int i = 0; i < nComb; i++) S += P.LL[i];
+                P.red[0] = S;
+            }
+            WSYNC();
+            double S = P.red[0];
+            for(int i = lane; i < nComb; i += 64) P.LL[i] = P.LL[i] / S;
+            WSYNC();
+            if(lane == 0) {
+                double a = 0, b = 0;
+                for(int i = 0; i < nComb; i++) { double pp = P.LL[i]; if(i / n2 == best1) a += pp; if(i % n2 == best2) b += pp; }
+                if(a > 1) a = 1; if(b > 1) b = 1;
+                P.red[1] = a; P.red[2] = b;
+            }
+            WSYNC();
+            mapQ = P.LL[bestI]; q1 = P.red[1]; q2 = P.red[2];
+        }
+        if(lane == 0) {
+            B.pair_status[p] = 0; B.best_chain[2 * p] = selA; B.best_chain[2 * p + 1] = selB; B.n_comb[p] = nComb;
+            B.pair_ll[p] = mx; B.pair_mapq[p] = mapQ; B.mate_mapq[2 * p] = q1; B.mate_mapq[2 * p + 1] = q2;
+            const int* fa = B.ext_firstlast + 4 * selA; const int* fb = B.ext_firstlast + 4 * selB;
+            bool ra = B.chain_reverse[selA] != 0, rb = B.chain_reverse[selB] != 0; bool valid = false;
+            if(fa[0] != -1 && fb[0] != -1 && ra != rb) valid = (!ra) ? (fa[0] < fb[0]) : (fa[2] > fb[2]);
+            B.strands_valid[p] = valid ? 1 : 0;
+        }
+        // ---- per-position mapping quality of the selected chains (:4155-4311)
+        for(int m = 0; m < 2; m++) {
+            const int sel = m ? selB : selA; const int r = 2 * p + m;
+            const int nSel = uni(B.ext_ncols[sel]); const size_t sb = (size_t)sel * stride; const size_t ob = (size_t)r * stride;
+            if(nComb == 1) {
+                unsigned char ph = phred_from_pcorrect(T, 1.0);
+                for(int j = lane; j < nSel; j += 64) B.sel_mapq[ob + j] = ph;
+                continue;
+            }
+            const int nl = m ? n2 : n1;
+            // columns of the selected chain handled by this lane: j = lane + 64*t
+            constexpr int PER = PAIR_COLS / 64;
+            u64 mask[PER];
+            int myIdx[PER];
+            for(int t = 0; t < PER; t++) { mask[t] = 0; myIdx[t] = -1; }
+            // read-base ordinal of each selected column (alignment orientation; strand is shared by all chains of the mate)
+            {
+                int carry = 0;
+                for(int t = 0; t < PER; t++) {
+                    int j = t * 64 + lane; bool isBase = j < nSel && B.ext_s[sb + j] != '_';
+                    u64 bm = __ballot(isBase);
+                    if(isBase) myIdx[t] = carry + __popcll(bm & ((1ull << lane) - 1ull));
+                    carry += __popcll(bm);
+                }
+            }
+            for(int k = 0; k < nl; k++) {
+                const int ck = uni(P.list[m][k]); const int nk = uni(B.ext_ncols[ck]); const size_t kb = (size_t)ck * stride;
+                const int firstK = uni(B.ext_firstlast[4 * ck + 0]);
+                WSYNC();
+                for(int i = lane; i < PAIR_COLS; i += 64) { P.basecol[i] = -1; P.levcol[i] = -1; }
+                WSYNC();
+                int carry = 0;
+                for(int j0 = 0; j0 < nk; j0 += 64) {
+                    int j = j0 + lane; bool act = j < nk;
+                    bool isBase = act && B.ext_s[kb + j] != '_';
+                    u64 bm = __ballot(isBase);
+                    if(isBase) { int bi = carry + __popcll(bm & ((1ull << lane) - 1ull)); if(bi < PAIR_COLS) P.basecol[bi] = (short)j; }
+                    carry += __popcll(bm);
+                    if(act) { int l = B.ext_level[kb + j]; if(l != -1 && firstK >= 0) { int li = l - firstK; if(li >= 0 && li < PAIR_COLS) P.levcol[li] = (short)j; } }
+                }
+                WSYNC();
+                for(int t = 0; t < PER; t++) {
+                    int j = t * 64 + lane;
+                    if(j >= nSel) continue;
+                    int lj = B.ext_level[sb + j]; unsigned char gj = B.ext_g[sb + j];
+                    bool hit = false;
+                    if(myIdx[t] >= 0) { int col = P.basecol[myIdx[t]]; if(col >= 0) hit = (B.ext_level[kb + col] == lj) && (B.ext_g[kb + col] == gj); }
+                    else if(lj != -1 && firstK >= 0) { int li = lj - firstK; if(li >= 0 && li < PAIR_COLS) { int col = P.levcol[li]; if(col >= 0) hit = (B.ext_s[kb + col] == '_') && (B.ext_g[kb + col] == gj); } }
+                    if(hit) mask[t] |= (1ull << k);
+                }
+            }
+            WSYNC();
+            for(int t = 0; t < PER; t++) {
+                int j = t * 64 + lane;
+                if(j >= nSel) continue;
+                double Q = 0;                                   // alignmentPositionConfidences accumulated in combination order
+                if(m == 0) { for(int i1 = 0; i1 < n1; i1++) if(mask[t] & (1ull << i1)) for(int i2 = 0; i2 < n2; i2++) Q += P.LL[i1 * n2 + i2]; }
+                else       { for(int i1 = 0; i1 < n1; i1++) for(int i2 = 0; i2 < n2; i2++) if(mask[t] & (1ull << i2)) Q += P.LL[i1 * n2 + i2]; }
+                if(Q > 1) Q = 1;
+                B.sel_mapq[ob + j] = phred_from_pcorrect(T, Q);
+            }
+        }
+        }   // !bad
+        WSYNC();
+    }
+}
+
+}  // namespace hlala

@@ -1,8 +1,399 @@
-// kernel_project.hip -- stage A (placeholder until the projection kernel lands)
+// kernel_project.hip -- stage A: BAM record -> graph-space seed chain (processBAM::alignment2Chain) on gfx950.
+//
+//   k_filter_chains  : strand / duplicate-coordinate filters of alignOneReadPair (processBAM.cpp:3200-3240),
+//                      one thread per read (the filter is sequential over a read's chains by definition).
+//   k_project_chains : one wavefront per surviving chain:
+//        CIGAR walk -> columns            transformBAMreadToInternalAlignment   processBAM.cpp:4794-5337
+//        trim / pad skipped levels        PRGContigAlignment2Seed               :2518-2579
+//        cleanInitialAlignment                                                  :4621-4792
+//        restrictInitialAlignmentToNoGapAreas                                   :4461-4619
+//        re-threading DP (sequence variant) + deterministic backtrace           :2676-3007
+//      Columns live in LDS; the per-node back pointers of the re-threading DP live in LDS when the
+//      node range of the chain is small (the common case) and in the wave's HBM slab otherwise.
 #include "batch.h"
+#include "../../include/hlala_gpu.h"
+
 namespace hlala {
-__host__ __device__ inline size_t proj_slab_bytes(int stride, int maxNodesPerLevel) { return 256; }
-__global__ void k_filter_chains(DevGraph G, DevBatch B, const long long* contig_off, const int* contig_level) {}
-__global__ void k_project_chains(DevGraph G, DevBatch B, const long long* contig_off, const uint8_t* contig_seq, const int* contig_level,
-                                 char* slabs, size_t slabBytes) {}
+
+constexpr int PROJ_CAP   = 768;     // alignment columns held in LDS (>= params.max_columns)
+constexpr int PROJ_OPS   = 64;      // CIGAR operations per record
+constexpr int PROJ_NODES = 1024;    // nodes per level held in LDS score rows
+constexpr int PROJ_CHLDS = 768;     // back-pointer records kept in LDS
+
+struct ChoiceRec { int eid; short fromz; short S; };
+
+struct __align__(16) ProjLds {
+    int lvl[2][PROJ_CAP];
+    unsigned char g[2][PROJ_CAP], s[2][PROJ_CAP];
+    int opColStart[PROJ_OPS + 1], opRefStart[PROJ_OPS], opReadStart[PROJ_OPS];
+    unsigned char opType[PROJ_OPS];
+    short Srow[2][PROJ_NODES];
+    ChoiceRec ch[PROJ_CHLDS];
+    int err, n, startRaw, stopRaw, tmp0, tmp1;
+};
+
+__host__ __device__ inline size_t proj_slab_bytes(int stride, int maxNodesPerLevel)
+{
+    size_t ent = (size_t)stride * (size_t)(maxNodesPerLevel < 1 ? 1 : maxNodesPerLevel);
+    if(ent > (1u << 20)) ent = (1u << 20);
+    if(ent < 1024) ent = 1024;
+    return (ent * sizeof(ChoiceRec) + 255) & ~(size_t)255;
 }
+
+// BamAlignment::GetEndPosition(false, true) of BamTools 2.5.1 (un-vendored dependency, makefile:3-12):
+// Position + sum of M, =, X, D, N lengths - 1.  Call site processBAM.cpp:3872.
+__device__ inline int cigar_end_position(const u32* cig, int n, int pos)
+{
+    int e = pos;
+    for(int i = 0; i < n; i++) { u32 op = cig[i] & 15u; if(op == 0 || op == 7 || op == 8 || op == 2 || op == 3) e += (int)(cig[i] >> 4); }
+    return e - 1;
+}
+
+__global__ void k_filter_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const int* contig_level)
+{
+    const DevBatch& B = *Bp;
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if(r >= B.n_reads) return;
+    int c0 = B.chain_off[r], c1 = B.chain_off[r + 1];
+    bool primRev = B.chain_reverse[B.read_primary[r]] != 0;
+    for(int c = c0; c < c1; c++) {
+        int st = HLALA_CHAIN_OK;
+        int contig = B.chain_contig[c];
+        long long clen = contig_off[contig + 1] - contig_off[contig];
+        int a = B.chain_pos[c] - B.chain_offset[c];
+        int b = cigar_end_position(B.cigar + B.cigar_off[c], B.cigar_off[c + 1] - B.cigar_off[c], B.chain_pos[c]) - B.chain_offset[c];
+        int idA = -1, idB = -1;
+        if(a < 0 || a >= clen || b < 0 || b >= clen) st = HLALA_CHAIN_ERR_INPUT;          // asserts of alignment_get_startstop_PRGcoordinates, :3883-3885
+        else { idA = contig_level[contig_off[contig] + a]; idB = contig_level[contig_off[contig] + b]; }
+        if(st == HLALA_CHAIN_OK && (B.chain_reverse[c] != 0) != primRev) st = HLALA_CHAIN_SKIP_STRAND;      // :3216
+        if(st == HLALA_CHAIN_OK) {
+            // "start//stop" id already extended with >= AS (:3207, :3234); the map holds the best score per id
+            for(int p = c0; p < c; p++) {
+                if(B.seed_status[p] != HLALA_CHAIN_OK) continue;
+                int pc = B.chain_contig[p];
+                int pa = B.chain_pos[p] - B.chain_offset[p];
+                int pb = cigar_end_position(B.cigar + B.cigar_off[p], B.cigar_off[p + 1] - B.cigar_off[p], B.chain_pos[p]) - B.chain_offset[p];
+                int pidA = contig_level[contig_off[pc] + pa], pidB = contig_level[contig_off[pc] + pb];
+                if(pidA == idA && pidB == idB && B.chain_as[p] >= B.chain_as[c]) { st = HLALA_CHAIN_SKIP_DUP; break; }
+            }
+        }
+        B.seed_status[c] = st;
+        if(st != HLALA_CHAIN_OK) B.seed_ncols[c] = 0;
+    }
+}
+
+#define PJ_FAIL(code) do { if(P.err == 0) P.err = (code); } while(0)
+#define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
+
+__global__ __launch_bounds__(64) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
+                                                       const int* contig_level, char* slabs, size_t slabBytes)
+{
+    const DevGraph& G = *Gp;
+    const DevBatch& B = *Bp;
+    __shared__ ProjLds P;
+    const int lane = lane_id();
+    ChoiceRec* slabCh = (ChoiceRec*)(slabs + (size_t)blockIdx.x * slabBytes);
+    const int slabEnt = (int)(slabBytes / sizeof(ChoiceRec));
+    const int stride = B.stride;
+
+    for(;;) {
+        const int c = next_work(&B.work_counter[0]);
+        if(c >= B.n_chains) break;
+        if(uni(B.seed_status[c]) == HLALA_CHAIN_OK) {
+        const int r = uni(B.chain_read[c]);
+        const int rOff = uni(B.read_off[r]), readLen = uni(B.read_off[r + 1]) - rOff;
+        const int contig = uni(B.chain_contig[c]);
+        const long long cOff = contig_off[contig]; const long long cLen = contig_off[contig + 1] - cOff;
+        const int pos = uni(B.chain_pos[c]), tOffset = uni(B.chain_offset[c]);
+        const int cg0 = uni(B.cigar_off[c]), nOps = uni(B.cigar_off[c + 1]) - cg0;
+        if(lane == 0) { P.err = 0; }
+        WSYNC();
+
+        // ---------------- CIGAR walk (transformBAMreadToInternalAlignment, :4794-5337)
+        // Columns are the M/=/X/D/I operations in CIGAR order: M -> (ref, read), D -> (ref, '_'), I -> (-1, '_', read);
+        // S advances the read index, H only counts at the very start (:4868-4874), P is dropped (:4814-4828), N throws (:5167).
+        if(nOps < 1 || nOps > PROJ_OPS) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+        int nCols = 0;
+        if(nOps >= 1 && nOps <= PROJ_OPS) {
+            u32 cg = lane < nOps ? B.cigar[cg0 + lane] : 0;
+            int op = (int)(cg & 15u), len = (int)(cg >> 4);
+            if(lane >= nOps) { op = 6; len = 0; }                       // behaves like 'P'
+            bool isCol = (op == 0 || op == 7 || op == 8 || op == 2 || op == 1);
+            bool useRef = (op == 0 || op == 7 || op == 8 || op == 2);
+            bool useRead = (op == 0 || op == 7 || op == 8 || op == 1 || op == 4);
+            int leadH = 0;
+            if(lane == 0 && op == 5) leadH = len;                       // leading hard clip offsets the unclipped read index
+            leadH = __shfl(leadH, 0);
+            int tc, tr, tq;
+            int colStart = wave_excl_scan(isCol ? len : 0, tc);
+            int refStart = wave_excl_scan(useRef ? len : 0, tr);
+            int readStart = wave_excl_scan(useRead ? len : 0, tq) + leadH;
+            if(lane < nOps) {
+                P.opColStart[lane] = colStart; P.opRefStart[lane] = refStart; P.opReadStart[lane] = readStart; P.opType[lane] = (unsigned char)op;
+                if(op == 3 || op > 8) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
+                // an insertion must follow a column operation or open the alignment (assert(index_along_read == 0), :5086)
+                if(op == 1 && colStart > 0 && lane > 0) {
+                    int pop = (int)(B.cigar[cg0 + lane - 1] & 15u);
+                    if(!(pop == 0 || pop == 7 || pop == 8 || pop == 2 || pop == 1)) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
+                }
+            }
+            if(lane == 0) P.opColStart[nOps] = tc;
+            nCols = tc;
+            // first / last column operation give sequence_aligned_{start,stop}InRaw (:5197-5203)
+            u64 colMask = __ballot(isCol && len > 0);
+            if(colMask == 0) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+            else {
+                int firstOp = __ffsll((long long)colMask) - 1, lastOp = 63 - __clzll((long long)colMask);
+                int startRaw = __shfl(readStart, firstOp);
+                int lastRS = __shfl(readStart, lastOp), lastLen = __shfl(len, lastOp), lastUse = __shfl(useRead ? 1 : 0, lastOp);
+                if(lane == 0) { P.startRaw = startRaw; P.stopRaw = lastRS + (lastUse ? lastLen : 0) - 1; }
+            }
+            if(nCols > PROJ_CAP || nCols > stride) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); }
+        }
+        WSYNC();
+        if(PJ_OK()) {
+            for(int j = lane; j < nCols; j += 64) {
+                int o = 0;
+                while(o + 1 < nOps && P.opColStart[o + 1] <= j) o++;
+                while(P.opColStart[o + 1] == P.opColStart[o] && o + 1 < nOps) o++;       // skip non-column ops
+                int k = j - P.opColStart[o]; int op = P.opType[o];
+                int lv = -1; unsigned char gc = '_', sc = '_';
+                if(op != 1) {
+                    int refpos = pos + P.opRefStart[o] + k;
+                    int ti = refpos - tOffset;
+                    if(refpos < 0 || refpos >= cLen || ti < 0 || ti >= cLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+                    else { gc = contig_seq[cOff + refpos]; lv = contig_level[cOff + ti]; }
+                }
+                if(op != 2) {
+                    int ri = P.opReadStart[o] + k;
+                    if(ri < 0 || ri >= readLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); } else sc = B.read_bases[rOff + ri];
+                }
+                P.lvl[0][j] = lv; P.g[0][j] = gc; P.s[0][j] = sc;
+            }
+        }
+        WSYNC();
+        if(PJ_OK() && !(uni(P.startRaw) < uni(P.stopRaw))) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }        // :5252
+        WSYNC();
+
+        // ---------------- trim leading / trailing insertion columns, pad skipped levels (:2518-2579)
+        int n1 = 0;
+        if(PJ_OK()) {
+            int firstCol = nCols, lastCol = -1;
+            for(int j0 = 0; j0 < nCols; j0 += 64) {
+                int j = j0 + lane; bool def = j < nCols && P.lvl[0][j] != -1;
+                u64 m = __ballot(def);
+                if(m) { int f = j0 + __ffsll((long long)m) - 1, l = j0 + 63 - __clzll((long long)m); if(f < firstCol) firstCol = f; if(l > lastCol) lastCol = l; }
+            }
+            if(lastCol < 0 || !(firstCol < lastCol)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }       // "all insertions" :5271 / assert :2535
+            else {
+                if(lane == 0) { P.startRaw += firstCol; P.stopRaw -= (nCols - 1 - lastCol); }
+                // prefix over columns: new index = (j - firstCol) + sum of level gaps up to and including j
+                int carryGap = 0, carryPrev = -1;
+                for(int j0 = firstCol; j0 <= lastCol; j0 += 64) {
+                    int j = j0 + lane; bool act = j <= lastCol;
+                    int lv = act ? P.lvl[0][j] : -1;
+                    // last defined level strictly before j: prefix max (levels increase along the alignment)
+                    int pm = lv;
+                    for(int o = 1; o < 64; o <<= 1) { int y = __shfl_up(pm, o); if(lane >= o) pm = max(pm, y); }
+                    int prevIncl = max(pm, carryPrev);
+                    int prevExcl = __shfl_up(prevIncl, 1); if(lane == 0) prevExcl = carryPrev;
+                    int gap = 0;
+                    if(act && lv != -1 && prevExcl != -1) { gap = lv - prevExcl - 1; if(gap < 0) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); gap = 0; } }
+                    int tg; int gb = wave_excl_scan(gap, tg);
+                    int np = (j - firstCol) + carryGap + gb + gap;
+                    if(act) {
+                        if(np >= PROJ_CAP || np >= stride) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS);
+                        else {
+                            for(int q = 0; q < gap; q++) { int w = np - gap + q; P.lvl[1][w] = prevExcl + 1 + q; P.g[1][w] = '_'; P.s[1][w] = '_'; }
+                            P.lvl[1][np] = lv; P.g[1][np] = P.g[0][j]; P.s[1][np] = P.s[0][j];
+                        }
+                    }
+                    carryGap += tg; carryPrev = __shfl(prevIncl, 63);
+                }
+                n1 = (lastCol - firstCol + 1) + carryGap;
+                if(n1 > PROJ_CAP || n1 > stride) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); }
+            }
+        }
+        WSYNC();
+        int cur = 1;       // buffer holding the current columns
+
+        // ---------------- cleanInitialAlignment (:4621-4792) -- only when an insertion or a double-gap column exists
+        int removed = 0;
+        if(PJ_OK()) {
+            bool any = false;
+            for(int j0 = 0; j0 < n1; j0 += 64) { int j = j0 + lane; bool in = j < n1 && (P.lvl[cur][j] == -1 || (P.g[cur][j] == '_' && P.s[cur][j] == '_')); if(__ballot(in)) any = true; }
+            if(any) {
+                if(lane == 0) {
+                    int* lv = P.lvl[cur]; unsigned char* ga = P.g[cur]; unsigned char* sa = P.s[cur];
+                    bool inStretch = false, cleaned = false; int sStart = -1, balance = 0;
+                    for(int p = 0; p < n1; p++) {
+                        bool interesting = (lv[p] == -1) || (ga[p] == '_' && sa[p] == '_');
+                        if(interesting) {
+                            if(!inStretch) { sStart = p; inStretch = true; }
+                            if(lv[p] == -1) balance++;
+                            if(ga[p] == '_' && sa[p] == '_') balance--;
+                        } else if(inStretch) {
+                            int sStop = p - 1;
+                            if(balance == 0) {
+                                // pair the inserted bases with the skipped levels: first half = (gap level, '_', base), rest deleted
+                                int Ls = sStop - sStart + 1, half = Ls / 2;
+                                int* olv = P.lvl[1 - cur]; unsigned char* osa = P.s[1 - cur];     // scratch: gather in order
+                                int ni = 0, ng = 0;
+                                for(int q = sStart; q <= sStop; q++) { if(lv[q] == -1) osa[ni++] = sa[q]; else olv[ng++] = lv[q]; }
+                                if(ni != ng || ni != half) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+                                else {
+                                    cleaned = true;
+                                    for(int q = sStart; q <= sStop; q++) {
+                                        int i = q - sStart;
+                                        if(i < half) { lv[q] = olv[i]; ga[q] = '_'; sa[q] = osa[i]; } else { lv[q] = -1; ga[q] = '_'; sa[q] = '_'; }
+                                    }
+                                }
+                            }
+                            inStretch = false; sStart = -1; balance = 0;
+                        }
+                    }
+                    int w = n1;
+                    if(cleaned) { w = 0; for(int p = 0; p < n1; p++) if(!(lv[p] == -1 && ga[p] == '_' && sa[p] == '_')) { lv[w] = lv[p]; ga[w] = ga[p]; sa[w] = sa[p]; w++; } }
+                    P.n = w;
+                }
+                WSYNC();
+                n1 = uni(P.n);
+            }
+        }
+        WSYNC();
+
+        // ---------------- restrictInitialAlignmentToNoGapAreas (:4461-4619) -- only when a gap-stretch level is touched
+        if(PJ_OK()) {
+            bool any = false;
+            for(int j0 = 0; j0 < n1; j0 += 64) {
+                int j = j0 + lane; bool in = false;
+                if(j < n1) { int l = P.lvl[cur][j]; if(l != -1) { if(l < 0 || l >= G.L - 1) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); else in = G.gap_stretch[l] != 0; } }
+                if(__ballot(in)) any = true;
+            }
+            WSYNC();
+            if(any && PJ_OK()) {
+                if(lane == 0) {
+                    int* lv = P.lvl[cur]; unsigned char* ga = P.g[cur]; unsigned char* sa = P.s[cur];
+                    int runBegin = -1, seqChars = 0, bestA = -1, bestB = -1, bestLen = 0;
+                    auto consider = [&](int a, int b) {                                     // trim -1 ends (:4507-4531), keep the LAST longest (:4533-4552)
+                        while(lv[a] == -1) { a++; if(a > b || a > n1 - 1) break; }
+                        if(a <= b) while(lv[b] == -1) { b--; if(b < a || b < 0) break; }
+                        if(b >= a) { int len = b - a + 1; if(len >= bestLen) { bestLen = len; bestA = a; bestB = b; } }
+                    };
+                    for(int p = 0; p < n1; p++) {
+                        if(sa[p] != '_') seqChars++;
+                        int l = lv[p];
+                        if(l != -1 && G.gap_stretch[l]) { if(runBegin != -1) { consider(runBegin, p - 1); runBegin = -1; } }
+                        else if(runBegin == -1) runBegin = p;
+                    }
+                    if(runBegin != -1 && runBegin != 0) consider(runBegin, n1 - 1);          // a stretch starting at column 0 that reaches the end is not recorded (:4492-4502)
+                    int w = n1;
+                    if(bestLen > 0) {
+                        int ns = P.startRaw, ne = P.stopRaw, sc = 0;
+                        for(int p = 0; p < bestA; p++) if(sa[p] != '_') ns++;
+                        for(int p = bestB + 1; p < n1; p++) if(sa[p] != '_') ne--;
+                        for(int p = bestA; p <= bestB; p++) if(sa[p] != '_') sc++;
+                        if(((double)sc / (double)seqChars) > 0.3) {                          // :4606
+                            for(int p = bestA; p <= bestB; p++) { lv[p - bestA] = lv[p]; ga[p - bestA] = ga[p]; sa[p - bestA] = sa[p]; }
+                            w = bestLen; P.startRaw = ns; P.stopRaw = ne;
+                        }
+                    }
+                    P.tmp0 = n1 - w; P.n = w;
+                }
+                WSYNC();
+                removed = uni(P.tmp0); n1 = uni(P.n);
+            }
+        }
+        WSYNC();
+
+        // ---------------- re-threading DP, sequence variant (:2676-2835)
+        // state of column i = best number of edge labels equal to the read character over all graph paths that respect
+        // the seed's matches, per node of the column's target level; ties keep the smallest edge (std::set<Edge*> order).
+        int level0 = -1, nb = 0, chCount = 0; ChoiceRec* ch = P.ch;
+        int nDef = 0;
+        if(PJ_OK()) {
+            level0 = uni(P.lvl[cur][0]);
+            int lastLevel = uni(P.lvl[cur][n1 - 1]);
+            if(level0 < 0 || lastLevel < level0 || lastLevel + 1 >= G.L) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+            else {
+                nDef = lastLevel - level0 + 1;
+                nb = G.level_off[level0 + 1];
+                chCount = G.level_off[lastLevel + 2] - nb;
+                if(chCount > PROJ_CHLDS) { ch = slabCh; if(chCount > slabEnt) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); } }
+                int m0 = G.level_off[level0 + 1] - G.level_off[level0];
+                if(m0 > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); }
+                else for(int z = lane; z < m0; z += 64) P.Srow[0][z] = 0;                     // all nodes of the first level, S = 0 (:2694-2701)
+            }
+        }
+        WSYNC();
+        u64 edgesTouched = 0;
+        if(PJ_OK()) {
+            int rowP = 0;
+            for(int j = 0; j < n1; j++) {
+                int l = uni(P.lvl[cur][j]);
+                if(l == -1) continue;                                                         // :2710-2714
+                unsigned char sc = P.s[cur][j], gc = P.g[cur][j];
+                bool seedIsMatch = (sc == gc);
+                int tb = G.level_off[l + 1], tm = G.level_off[l + 2] - tb, fb = G.level_off[l];
+                if(tm > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); break; }
+                int anyReached = 0;
+                for(int z = lane; z < tm; z += 64) {
+                    int node = tb + z;
+                    int best = -1, bestE = -1, bestFrom = -1;
+                    int e0 = G.in_off[node], e1 = G.in_off[node + 1];
+                    for(int e = e0; e < e1; e++) {                                           // in-edges in creation order: first maximum = smallest edge
+                        int fz = G.in_from[e] - fb; int sp = P.Srow[rowP][fz];
+                        if(sp < 0) continue;
+                        unsigned char lab = G.in_label[e];
+                        if(seedIsMatch && lab != sc) continue;                                // :2803-2809
+                        int cand = sp + (lab == sc ? 1 : 0);
+                        if(cand > best) { best = cand; bestE = G.in_eid[e]; bestFrom = fz; }
+                    }
+                    edgesTouched += (u64)(e1 - e0);
+                    P.Srow[1 - rowP][z] = (short)best;
+                    ChoiceRec cr; cr.eid = bestE; cr.fromz = (short)bestFrom; cr.S = (short)best;
+                    ch[node - nb] = cr;
+                    if(best >= 0) anyReached = 1;
+                }
+                if(!__ballot(anyReached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); break; }      // assert(seedChain_backtrack_*.size() > 0)
+                rowP = 1 - rowP;
+                WSYNC();
+            }
+            WSYNC();
+            // ---------------- backtrace (:2838-3007)
+            if(PJ_OK()) {
+                int lastLevel = uni(P.lvl[cur][n1 - 1]);
+                int tb = G.level_off[lastLevel + 1], tm = G.level_off[lastLevel + 2] - tb;
+                int bestS = -1;
+                for(int z = lane; z < tm; z += 64) bestS = max(bestS, (int)P.Srow[rowP][z]);
+                bestS = wave_max_i32(bestS);
+                int zsel = 0x7FFFFFFF;
+                for(int z = lane; z < tm; z += 64) if(P.Srow[rowP][z] == bestS) { zsel = min(zsel, z); }
+                zsel = -wave_max_i32(-zsel);                                                   // *(runningN.begin()): smallest node among the maxima (:2867)
+                const size_t cb = (size_t)c * stride;
+                if(lane == 0) {
+                    int node = tb + zsel;
+                    for(int j = n1 - 1; j >= 0; j--) {
+                        int l = P.lvl[cur][j];
+                        if(l == -1) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; B.seed_s[cb + j] = P.s[cur][j]; continue; }
+                        ChoiceRec cr = ch[node - nb];
+                        B.seed_level[cb + j] = l; B.seed_edge[cb + j] = cr.eid; B.seed_g[cb + j] = G.edge_label[cr.eid]; B.seed_s[cb + j] = P.s[cur][j];
+                        node = G.level_off[l] + cr.fromz;
+                    }
+                    B.seed_ncols[c] = n1; B.seed_begin[c] = P.startRaw; B.seed_end[c] = P.stopRaw; B.seed_removed[c] = removed;
+                    atomicAdd(&B.counters[CNT_SEED_COLS], (u64)n1);
+                }
+            }
+        }
+        {
+            int e = wave_sum_i32((int)edgesTouched);
+            if(lane == 0 && e) atomicAdd(&B.counters[CNT_EDGES], (u64)e);
+        }
+        WSYNC();
+        if(!PJ_OK() && lane == 0) { B.seed_status[c] = P.err; B.seed_ncols[c] = 0; }
+        }   // chain survives the filters
+        WSYNC();
+    }
+}
+
+}  // namespace hlala
