@@ -168,6 +168,7 @@ def load_library(path: str | None = None):
     lib.hlala_batch_get_chains.argtypes = [vp, vp, C.c_int, C.POINTER(ChainsOut)]
     lib.hlala_batch_get_pairs.argtypes = [vp, vp, C.POINTER(PairsOut)]
     lib.hlala_batch_get_stats.argtypes = [vp, vp, C.POINTER(BatchStats)]
+    lib.hlala_batch_export_pair_records.argtypes = [vp, vp, vp]
     lib.hlala_kat_phred.argtypes = [vp, C.c_int, c_f64p, c_u8p, c_u8p, c_f64p]
     lib.hlala_kat_rand_r.argtypes = [vp, C.c_int, c_u32p, c_i32p]
     if path is None:
@@ -180,7 +181,7 @@ EXPORTED_SYMBOLS = [
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
     "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
-    "hlala_batch_get_stats", "hlala_kat_phred", "hlala_kat_rand_r",
+    "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_kat_phred", "hlala_kat_rand_r",
 ]
 
 
@@ -276,6 +277,11 @@ class Batch:
         s, d = alloc_pairs_out(self.n_pairs, self.ctx.max_columns)
         self.ctx._check(self.ctx.lib.hlala_batch_get_pairs(self.ctx.h, self.b, C.byref(s)), "hlala_batch_get_pairs")
         return d
+
+    def export_pair_records(self, device_ptr: int):
+        """Write 8 doubles per pair into a device buffer (e.g. a torch tensor's data_ptr())."""
+        self.ctx._check(self.ctx.lib.hlala_batch_export_pair_records(self.ctx.h, self.b, C.c_void_p(device_ptr)),
+                        "hlala_batch_export_pair_records")
 
     def stats(self) -> BatchStats:
         st = BatchStats()

@@ -40,7 +40,7 @@ struct hlala_ctx {
     long long* d_contig_off = nullptr; uint8_t* d_contig_seq = nullptr; int* d_contig_level = nullptr;
     int n_contigs = 0; std::vector<long long> contig_off;
     std::vector<void*> allocs;
-    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0;
+    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0;
     hipEvent_t ev[6]{};           // start/end per stage
     int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
@@ -233,6 +233,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(hipGetDeviceProperties(&prop, device) != hipSuccess) { c->err = "hipGetDeviceProperties failed"; return fail(HLALA_E_DEVICE); }
     int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->ext_grid = cus * 6;
+    c->retry_grid = cus;
     c->ext_slab_bytes = ext_slab_bytes_host(c->params.max_columns);
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->ext_slabs);
@@ -308,7 +309,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, false);
-    AL(counters, 16, true); AL(work_counter, 4, true);
+    AL(counters, 16, true); AL(work_counter, 8, true); AL(retry_list, nc, false);
     B.dbg = c->dbg_host;
 #undef AL
     return 0;
@@ -415,7 +416,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     if(!c || !b) return HLALA_E_ARG;
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
-    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 4 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 8 * sizeof(int), c->stream));
     HIP_TRY(c, hipMemsetAsync(B.counters, 0, 16 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if(B.n_chains > 0) {
@@ -437,12 +438,17 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 3, 0, 2 * sizeof(int), c->stream));
     if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 16 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if(B.n_chains > 0) {
         int grid = B.n_chains < c->ext_grid ? B.n_chains : c->ext_grid;
-        hipLaunchKernelGGL(k_extend_chains, dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
-        int rc = check_launch(c, "k_extend_chains"); if(rc) return rc;
+        hipLaunchKernelGGL((k_extend_chains<DpSmall, false>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        int rc = check_launch(c, "k_extend_chains<small>"); if(rc) return rc;
+        // second pass over the (usually empty) list of chains that outgrew the small capacity class: one block per CU
+        int rgrid = B.n_chains < c->retry_grid ? B.n_chains : c->retry_grid;
+        hipLaunchKernelGGL((k_extend_chains<DpLarge, true>), dim3(rgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        rc = check_launch(c, "k_extend_chains<large>"); if(rc) return rc;
     }
     HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
     b->staged |= 2;
@@ -534,6 +540,17 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
         if(o->col_gchar) HIP_TRY(c, hipMemcpy(o->col_gchar + dofs, B.ext_g + so, (size_t)n, hipMemcpyDeviceToHost));
         if(o->col_schar) HIP_TRY(c, hipMemcpy(o->col_schar + dofs, B.ext_s + so, (size_t)n, hipMemcpyDeviceToHost));
         if(o->col_fromseed) HIP_TRY(c, hipMemcpy(o->col_fromseed + dofs, B.ext_fromseed + so, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    return HLALA_OK;
+}
+
+int hlala_batch_export_pair_records(hlala_ctx* c, hlala_batch* b, double* device_out)
+{
+    if(!c || !b || !device_out) return HLALA_E_ARG;
+    if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
+    if(b->B.n_pairs > 0) {
+        hipLaunchKernelGGL(k_export_pairs, dim3((b->B.n_pairs + 255) / 256), dim3(256), 0, c->stream, b->dB, device_out);
+        int rc = check_launch(c, "k_export_pairs"); if(rc) return rc;
     }
     return HLALA_OK;
 }

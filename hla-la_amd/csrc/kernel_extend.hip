@@ -21,19 +21,25 @@ enum { K_DIAG = 0, K_GGAP = 1, K_SGAP = 2, K_HOP = 3, K_JUMP = 4 };
 enum { M_D = 0, M_GG = 1, M_SG = 2 };
 
 constexpr u64 HKEY_EMPTY = ~0ull;
-constexpr int DP_IMPCAP = DP_HC;     // staged improvements of existing cells per iteration (rare path, kept in the slab)
+constexpr int DP_IMPCAP = 2048;    // staged improvements of existing cells per iteration (rare path, kept in the slab)
 
-struct __align__(16) DpLds {
-    u64 hkey[DP_HC];
-    u32 hbest[3][DP_HC];
-    unsigned short tlist[DP_HC];
-    int fx[3][DP_WCAP];
-    u32 fyz[3][DP_WCAP];
-    int fslot[3][DP_WCAP];
-    short fD[3][DP_WCAP], fG[3][DP_WCAP], fS[3][DP_WCAP];
+// Two capacity classes: the small one serves almost every chain at 6-7 blocks per CU; chains whose frontier /
+// candidate set outgrows it (long runs of parallel gap paths) are re-run by the large one (one block per CU).
+struct DpSmall { static constexpr int WCAP = DP_WCAP, HC = DP_HC, IBITS = 7;  typedef u32 Best; };
+struct DpLarge { static constexpr int WCAP = 1024,    HC = 2048,  IBITS = 10; typedef u64 Best; };
+
+template <class C>
+struct __align__(16) DpLdsT {
+    u64 hkey[C::HC];
+    typename C::Best hbest[3][C::HC];
+    unsigned short tlist[C::HC];
+    int fx[3][C::WCAP];
+    u32 fyz[3][C::WCAP];
+    int fslot[3][C::WCAP];
+    short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
     unsigned char seq[DP_SEQCAP];
-    int tes[DP_HC];                 // per target: existing / assigned table slot
-    unsigned char timp[DP_HC];      // per target: improved-matrix mask | 0x80 = new cell
+    int tes[C::HC];                 // per target: existing / assigned table slot
+    unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     int nT, nNew, nImp, nKeepF, err, nCompletedAdd;
 };
 
@@ -104,26 +110,31 @@ __device__ __forceinline__ int bt_src(u64 b) { return (int)((b >> 24) & 3); }
 __device__ __forceinline__ int bt_kind(u64 b) { return (int)((b >> 26) & 7); }
 __device__ __forceinline__ int bt_edge(u64 b) { return (int)(b >> 32); }
 
-__device__ __forceinline__ u32 pack_best(int score, int order) { return ((u32)(score + 64) << 16) | (u32)(0xFFFF - order); }
+// candidate value: (score, reversed push index) so that an unsigned max = highest score, earliest push
+__device__ __forceinline__ void pack_best(u32& o, int score, int order) { o = ((u32)(score + 64) << 16) | (u32)(0xFFFF - order); }
+__device__ __forceinline__ void pack_best(u64& o, int score, int order) { o = ((u64)(u32)(score + 64) << 32) | (u64)(u32)(0x7FFFFFFF - order); }
 __device__ __forceinline__ int best_score(u32 b) { return b ? (int)(b >> 16) - 64 : DP_NEG; }
+__device__ __forceinline__ int best_score(u64 b) { return b ? (int)(b >> 32) - 64 : DP_NEG; }
 __device__ __forceinline__ int best_order(u32 b) { return 0xFFFF - (int)(b & 0xFFFF); }
+__device__ __forceinline__ int best_order(u64 b) { return 0x7FFFFFFF - (int)(b & 0xFFFFFFFFull); }
 
 // push one candidate (Alt::{D,GG,SG}.push_back in the reference) -- returns false on hash overflow
-__device__ inline bool dp_push(DpLds& S, u64 key, int mat, int score, int order)
+template <class C>
+__device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int order)
 {
-    u32 h = hash64(key) & (DP_HC - 1);
-    for(int probe = 0; probe < DP_HC; probe++) {
+    u32 h = hash64(key) & (C::HC - 1);
+    for(int probe = 0; probe < C::HC; probe++) {
         u64 cur = S.hkey[h];
         if(cur == HKEY_EMPTY) {
             u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
             if(old == HKEY_EMPTY) {
                 int pos = atomicAdd(&S.nT, 1);
-                if(pos < DP_HC) S.tlist[pos] = (unsigned short)h;
+                if(pos < C::HC) S.tlist[pos] = (unsigned short)h;
                 cur = key;
             } else cur = old;
         }
-        if(cur == key) { atomicMax(&S.hbest[mat][h], pack_best(score, order)); return true; }
-        h = (h + 1) & (DP_HC - 1);
+        if(cur == key) { typename C::Best v; pack_best(v, score, order); atomicMax(&S.hbest[mat][h], v); return true; }
+        h = (h + 1) & (C::HC - 1);
     }
     return false;
 }
@@ -173,7 +184,7 @@ __device__ inline bool xz_less(int x1, int z1, int x2, int z2)
     return la < lb;
 }
 
-struct DpResult { int have, ncols, seq_begin, seq_end, iters, score, err; };
+struct DpResult { int have, ncols, seq_begin, seq_end, iters, score, err; u64 cells; int edges; };
 
 #define DBGW(i, v) __hip_atomic_store(&dbg[i], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #define DBGB(i, v) do { if(dbg && lane == 0 && blockIdx.x < 2000) __hip_atomic_store(&dbg[64 + 4 * blockIdx.x + (i)], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while(0)
@@ -182,7 +193,8 @@ struct DpResult { int have, ncols, seq_begin, seq_end, iters, score, err; };
 // extensionAligner::fullNeedleman_diagonal_extension_gapJumper (extensionAligner.cpp:335-1556) with
 // returnGlobalScore = false, preferSequenceCompleAlignments = true, empty blockedPathsTable,
 // diagonal_stop_threshold = -16 (the only configuration extendSeedChain uses, :229-241, :281-293).
-__device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int seqLen, int start_seq, int startLevel,
+template <class C>
+__device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, int seqLen, int start_seq, int startLevel,
                            int startZ, bool fwd, u32 seed, int side, int outCap, u64* counters, int* dbg, int chain)
 {
     const int lane = lane_id();
@@ -190,10 +202,10 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
     const int max_levelI = G.L - 1, max_seqI = seqLen;       // :431-463 (min_* are 0 in both directions)
     const int limitY = fwd ? seqLen : 0;
     const long long diagonals = (long long)seqLen + G.L - 1;
-    DpResult R; R.have = 0; R.ncols = 0; R.seq_begin = 0; R.seq_end = -1; R.iters = 0; R.score = INT32_MIN; R.err = 0;
+    DpResult R; R.have = 0; R.ncols = 0; R.seq_begin = 0; R.seq_end = -1; R.iters = 0; R.score = INT32_MIN; R.err = 0; R.cells = 0; R.edges = 0;
 
     // ---- init, :480-519
-    for(int i = lane; i < DP_HC; i += 64) { S.hkey[i] = HKEY_EMPTY; S.hbest[0][i] = 0; S.hbest[1][i] = 0; S.hbest[2][i] = 0; }
+    for(int i = lane; i < C::HC; i += 64) { S.hkey[i] = HKEY_EMPTY; S.hbest[0][i] = 0; S.hbest[1][i] = 0; S.hbest[2][i] = 0; }
     if(lane == 0) {
         S.nT = 0; S.err = 0;
         sl.cell_key[0] = mk_key(startLevel, start_seq, startZ);
@@ -239,7 +251,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                 int tn = fwd ? G.out_to[e] : G.in_from[e];
                 unsigned char lab = fwd ? G.out_label[e] : G.in_label[e];
                 int sc = pD + (lab == rc ? 2 : -5);
-                if(!dp_push(S, mk_key(nx, ny, tn - nbase), M_D, sc, (i << 8) | (e - e0))) S.err = __LINE__;
+                if(!dp_push<C>(S, mk_key(nx, ny, tn - nbase), M_D, sc, (i << 8) | (e - e0))) S.err = __LINE__;
             }
             edgesTouched += (u64)(e1 - e0);
         }
@@ -247,13 +259,13 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
         for(int i = lane; i < n1; i += 64) {
             int px = S.fx[b1][i]; u32 pyz = S.fyz[b1][i]; int py = (int)(pyz >> 16), pz = (int)(pyz & 0xFFFF);
             int pD = S.fD[b1][i], pG = S.fG[b1][i], pS = S.fS[b1][i];
-            int ord0 = 0x8000 | (i << 8);
+            int ord0 = (1 << (C::IBITS + 8)) | (i << 8);
             {   // gap in graph, :621-661
                 int ny = py + dir;
                 if(ny >= 0 && ny <= max_seqI) {
                     u64 k = mk_key(px, ny, pz);
-                    if(!dp_push(S, k, M_GG, pD - 6, ord0 | 0)) S.err = __LINE__;
-                    if(pG != DP_NEG) if(!dp_push(S, k, M_GG, pG - 2, ord0 | 1)) S.err = __LINE__;
+                    if(!dp_push<C>(S, k, M_GG, pD - 6, ord0 | 0)) S.err = __LINE__;
+                    if(pG != DP_NEG) if(!dp_push<C>(S, k, M_GG, pG - 2, ord0 | 1)) S.err = __LINE__;
                 }
             }
             int node = G.level_off[px] + pz;
@@ -271,11 +283,11 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                         u64 k = mk_key(nx, py, tn - nbase);
                         int kk = e - e0;
                         if(lab != '_') {
-                            if(!dp_push(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
-                            if(pS != DP_NEG) if(!dp_push(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
+                            if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
+                            if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
                         } else {
-                            if(pS != DP_NEG) if(!dp_push(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
-                            if(!dp_push(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;         // non-affine sequence gap, :738-752
+                            if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
+                            if(!dp_push<C>(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;         // non-affine sequence gap, :738-752
                         }
                     }
                     edgesTouched += (u64)deg;
@@ -288,14 +300,14 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                 for(int j = j0; j < j1; j++) {
                     int tn = jnode[j]; int jx = G.node_level[tn];
                     if(jx < 0 || jx > max_levelI) continue;
-                    if(!dp_push(S, mk_key(jx, py, tn - G.level_off[jx]), M_D, pD, ord0 | (deg + (j - j0)))) S.err = __LINE__;
+                    if(!dp_push<C>(S, mk_key(jx, py, tn - G.level_off[jx]), M_D, pD, ord0 | (deg + (j - j0)))) S.err = __LINE__;
                 }
             }
         }
         WSYNC();
         int nT = uni(S.nT);
         if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 2); DBGW(8, nT); }
-        if(nT > (DP_HC * 3) / 4 || uni(S.err)) { DP_FAIL(__LINE__); break; }
+        if(nT > (C::HC * 3) / 4 || uni(S.err)) { DP_FAIL(__LINE__); break; }
         cellsEvaluated += (u64)nT;
 
         // ================= evaluate =====================================================
@@ -332,7 +344,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                 bool act = t < nT;
                 int h = act ? S.tlist[t] : 0;
                 u64 key = act ? S.hkey[h] : 0;
-                u32 bD = act ? S.hbest[M_D][h] : 0, bG = act ? S.hbest[M_GG][h] : 0, bS = act ? S.hbest[M_SG][h] : 0;
+                typename C::Best bD = act ? S.hbest[M_D][h] : 0, bG = act ? S.hbest[M_GG][h] : 0, bS = act ? S.hbest[M_SG][h] : 0;
                 int Dc = best_score(bD), GGv = best_score(bG), SGv = best_score(bS);
                 int Dv = Dc, dsel = 0;                      // D candidates first, then GG, then SG (:840-865); first maximum wins
                 if(GGv > Dv) { Dv = GGv; dsel = 1; }
@@ -356,14 +368,14 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                 u64 btD = 0, btG = 0, btS = 0;
                 int srcScore = 0;       // score the real previous step came from (fast form of the `diff` rule)
                 if(keep && S.err == 0 && slot >= 0 && slot < DP_CELLS) {
-                    if(bG) { int o = best_order(bG); int i = (o >> 8) & 127; int j = o & 255;
+                    if(bG) { int o = best_order(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                              btG = mk_bt(S.fslot[b1][i], j ? 1 : 0, K_GGAP, -1); }
-                    if(bS) { int o = best_order(bS); int i = (o >> 8) & 127; int j = o & 255; int kk = j >> 1;
+                    if(bS) { int o = best_order(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255; int kk = j >> 1;
                              int px = S.fx[b1][i]; int pz = (int)(S.fyz[b1][i] & 0xFFFF); int node = G.level_off[px] + pz;
                              int eid = fwd ? G.out_eid[G.out_off[node] + kk] : G.in_eid[G.in_off[node] + kk];
                              btS = mk_bt(S.fslot[b1][i], (j & 1) ? 2 : 0, K_SGAP, eid); }
                     if(dsel == 0) {
-                        int o = best_order(bD); int ph = o >> 15; int i = (o >> 8) & 127; int j = o & 255;
+                        int o = best_order(bD); int ph = o >> (C::IBITS + 8); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                         int sb = ph ? b1 : b2;
                         int px = S.fx[sb][i]; int pz = (int)(S.fyz[sb][i] & 0xFFFF); int node = G.level_off[px] + pz;
                         int e0 = fwd ? G.out_off[node] : G.in_off[node];
@@ -375,11 +387,11 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                                btD = mk_bt(S.fslot[sb][i], 0, K_JUMP, jpath[joff[node] + (j - deg)]); }
                     } else if(dsel == 1) {
                         btD = mk_bt(slot, 1, K_HOP, -1);
-                        int o = best_order(bG); int i = (o >> 8) & 127; int j = o & 255;
+                        int o = best_order(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                         srcScore = j ? S.fG[b1][i] : S.fD[b1][i];
                     } else {
                         btD = mk_bt(slot, 2, K_HOP, -1);
-                        int o = best_order(bS); int i = (o >> 8) & 127; int j = o & 255;
+                        int o = best_order(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                         srcScore = (j & 1) ? S.fS[b1][i] : S.fD[b1][i];
                     }
                 }
@@ -465,9 +477,9 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
                 if(mn < itMaxKey) itMaxKey = mn;
                 // stash for the filter phase: [0] = slot (or ~0 if dropped), [1] = merged D | GG<<16, [2] = merged SG
                 if(act) {
-                    S.hbest[0][h] = keep ? (u32)slot : 0xFFFFFFFFu;
-                    S.hbest[1][h] = ((u32)(unsigned short)(short)mD) | ((u32)(unsigned short)(short)mG << 16);
-                    S.hbest[2][h] = (u32)(unsigned short)(short)mS;
+                    S.hbest[0][h] = keep ? (typename C::Best)(u32)slot : (typename C::Best)0xFFFFFFFFu;
+                    S.hbest[1][h] = (typename C::Best)(((u32)(unsigned short)(short)mD) | ((u32)(unsigned short)(short)mG << 16));
+                    S.hbest[2][h] = (typename C::Best)(u32)(unsigned short)(short)mS;
                 }
             }
             WSYNC();
@@ -505,29 +517,29 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
         if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 3); }
         // ================= filter + sort, :1076-1105 ======================================
         int mx = DP_NEG;
-        for(int t = lane; t < nT; t += 64) { int h = S.tlist[t]; if(S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)(S.hbest[1][h] & 0xFFFF); mx = max(mx, v); } }
+        for(int t = lane; t < nT; t += 64) { int h = S.tlist[t]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); mx = max(mx, v); } }
         mx = wave_max_i32(mx);
         int nNew = 0;
         for(int t0 = 0; t0 < nT; t0 += 64) {
             int t = t0 + lane;
             bool pass = false; u64 key = 0; int h = 0;
-            if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if(S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)(S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
+            if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
             int rank = 0;
             if(pass) {
                 for(int u = 0; u < nT; u++) {
                     int hu = S.tlist[u];
-                    if(S.hbest[0][hu] == 0xFFFFFFFFu) continue;
-                    int vu = (short)(S.hbest[1][hu] & 0xFFFF);
+                    if((u32)S.hbest[0][hu] == 0xFFFFFFFFu) continue;
+                    int vu = (short)((u32)S.hbest[1][hu] & 0xFFFF);
                     if((mx - vu) <= 15 && S.hkey[hu] < key) rank++;
                 }
-                if(rank < DP_WCAP) {
+                if(rank < C::WCAP) {
                     S.fx[bn][rank] = key_x(key); S.fyz[bn][rank] = (u32)(key & 0xFFFFFFFFu); S.fslot[bn][rank] = (int)S.hbest[0][h];
-                    S.fD[bn][rank] = (short)(S.hbest[1][h] & 0xFFFF); S.fG[bn][rank] = (short)(S.hbest[1][h] >> 16); S.fS[bn][rank] = (short)(S.hbest[2][h] & 0xFFFF);
+                    S.fD[bn][rank] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][rank] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][rank] = (short)((u32)S.hbest[2][h] & 0xFFFF);
                 }
             }
             nNew += __popcll(__ballot(pass));
         }
-        if(nNew > DP_WCAP) { DP_FAIL(__LINE__); break; }
+        if(nNew > C::WCAP) { DP_FAIL(__LINE__); break; }
         WSYNC();
         // reset the hash entries used by this iteration
         for(int t = lane; t < nT; t += 64) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
@@ -540,16 +552,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
     R.iters = (int)itersRun;
     DBGB(2, 200 + side);
     if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 30); DBGW(14, S.err); }
-    if(lane == 0 && counters) {
-        atomicAdd(&counters[CNT_DP_CALLS], 1ull); atomicAdd(&counters[CNT_DP_ITERS], (u64)itersRun);
-    }
-    {
-        // per-lane partial counters
-        u64 c = cellsEvaluated;   // wave-uniform already
-        if(lane == 0 && counters) atomicAdd(&counters[CNT_DP_CELLS], c);
-        int e = wave_sum_i32((int)edgesTouched);
-        if(lane == 0 && counters) atomicAdd(&counters[CNT_EDGES], (u64)e);
-    }
+    R.cells = cellsEvaluated; R.edges = wave_sum_i32((int)edgesTouched);
     if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 31); }
     if(uni(S.err)) { R.err = uni(S.err); return R; }
 
@@ -650,24 +653,26 @@ __device__ DpResult dp_run(const DevGraph& G, DpLds& S, const ExtSlab& sl, int s
 // ------------------------------------------------------------------------------------------
 // one wave per chain: left DP, right DP, stitch (extendWithOtherSeedChain / extendToFullSequenceLength,
 // verboseSeedChain.cpp:23-136), then scoreOneAlignment (extensionAligner.cpp:52-182).
+template <class C, bool RETRY>
 __global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp, char* slabs, size_t slabBytes, u32 rng_seed)
 {
     // graph / batch descriptors stay in memory (scalar loads on demand): passing them by value costs ~150 SGPRs
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
-    __shared__ DpLds S;
+    __shared__ DpLdsT<C> S;
     const int lane = lane_id();
     const DevTables& T = *Tp;
     ExtSlab sl = ext_slab_at(slabs + (size_t)blockIdx.x * slabBytes, B.stride);
     const int stride = B.stride;
 
     for(;;) {
-        const int c = next_work(&B.work_counter[1]);
+        int c;
+        if(RETRY) { int i = next_work(&B.work_counter[4]); if(i >= uni(B.work_counter[3])) break; c = uni(B.retry_list[i]); }
+        else { c = next_work(&B.work_counter[1]); if(c >= B.n_chains) break; }
         { int* dbg = B.dbg; DBGB(0, c); DBGB(2, 1); }
-        if(c >= B.n_chains) { int* dbg = B.dbg; DBGB(2, 999); break; }
         int st = uni(B.seed_status[c]);
         if(st != HLALA_CHAIN_OK) {
-            if(lane == 0) { B.ext_status[c] = st; B.ext_ncols[c] = 0; B.dp_iters[2 * c] = 0; B.dp_iters[2 * c + 1] = 0; B.dp_score[2 * c] = INT32_MIN; B.dp_score[2 * c + 1] = INT32_MIN;
+            if(lane == 0 && !RETRY) { B.ext_status[c] = st; B.ext_ncols[c] = 0; B.dp_iters[2 * c] = 0; B.dp_iters[2 * c + 1] = 0; B.dp_score[2 * c] = INT32_MIN; B.dp_score[2 * c + 1] = INT32_MIN;
                             if(st < 0) atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
         } else {
         const int r = uni(B.chain_read[c]);
@@ -678,18 +683,19 @@ __global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict
         if(seqLen > DP_SEQCAP || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;
         if(!err) for(int i = lane; i < seqLen; i += 64) S.seq[i] = B.read_bases[rOff + i];
         WSYNC();
-        DpResult RL, RR; RL.have = 0; RL.ncols = 0; RL.iters = 0; RL.score = INT32_MIN; RL.err = 0; RL.seq_begin = 0; RL.seq_end = -1; RR = RL;
+        DpResult RL, RR; RL.have = 0; RL.ncols = 0; RL.iters = 0; RL.score = INT32_MIN; RL.err = 0; RL.seq_begin = 0; RL.seq_end = -1; RL.cells = 0; RL.edges = 0; RR = RL;
+        int nCalls = 0;
         if(!err) {
             int e0 = uni(B.seed_edge[cb]), e1 = uni(B.seed_edge[cb + nSeed - 1]);
             if(e0 < 0 || e1 < 0 || e0 >= G.E || e1 >= G.E) err = HLALA_CHAIN_ERR_INPUT;
             else {
                 if(sBegin != 0) {                                                      // left extension, extensionAligner.cpp:220-268
                     int firstNode = uni(G.edge_from_new[e0]); int lvl = uni(G.node_level[firstNode]);
-                    if(lvl > 0) RL = dp_run(G, S, sl, seqLen, sBegin, lvl, firstNode - G.level_off[lvl], false, rng_seed + 2u * (u32)c, 0, stride, B.counters, B.dbg, c);
+                    if(lvl > 0) { nCalls++; RL = dp_run<C>(G, S, sl, seqLen, sBegin, lvl, firstNode - G.level_off[lvl], false, rng_seed + 2u * (u32)c, 0, stride, B.counters, B.dbg, c); }
                 }
                 if(sEnd != seqLen - 1) {                                               // right extension, :271-319
                     int lastNode = uni(G.edge_to_new[e1]); int lvl = uni(G.node_level[lastNode]);
-                    if(lvl < G.L - 1) RR = dp_run(G, S, sl, seqLen, sEnd + 1, lvl, lastNode - G.level_off[lvl], true, rng_seed + 2u * (u32)c + 1u, 1, stride, B.counters, B.dbg, c);
+                    if(lvl < G.L - 1) { nCalls++; RR = dp_run<C>(G, S, sl, seqLen, sEnd + 1, lvl, lastNode - G.level_off[lvl], true, rng_seed + 2u * (u32)c + 1u, 1, stride, B.counters, B.dbg, c); }
                 }
                 if(RL.err || RR.err) err = ((RL.err <= -1000000) || (RR.err <= -1000000)) ? HLALA_CHAIN_ERR_COLUMNS : HLALA_CHAIN_ERR_FRONTIER;
             }
@@ -703,8 +709,17 @@ __global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict
             B.dp_iters[2 * c] = RL.iters; B.dp_iters[2 * c + 1] = RR.iters;
             B.dp_score[2 * c] = RL.have ? RL.score : INT32_MIN; B.dp_score[2 * c + 1] = RR.have ? RR.score : INT32_MIN;
         }
+        // a chain that outgrew the small capacity class is queued for the large-capacity pass and leaves no trace here
+        const bool requeue = !RETRY && err == HLALA_CHAIN_ERR_FRONTIER;
+        if(lane == 0 && !requeue) {
+            atomicAdd(&B.counters[CNT_DP_CALLS], (u64)nCalls); atomicAdd(&B.counters[CNT_DP_ITERS], (u64)(RL.iters + RR.iters));
+            atomicAdd(&B.counters[CNT_DP_CELLS], RL.cells + RR.cells); atomicAdd(&B.counters[CNT_EDGES], (u64)(RL.edges + RR.edges));
+        }
         if(err) {
-            if(lane == 0) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(RL.err ? RL.err : RR.err); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
+            if(lane == 0) {
+                if(requeue) { int q = atomicAdd(&B.work_counter[3], 1); B.retry_list[q] = c; }
+                else { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(RL.err ? RL.err : RR.err); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
+            }
         } else {
         { int* dbg = B.dbg; DBGB(2, 400); }
         // ---- stitch

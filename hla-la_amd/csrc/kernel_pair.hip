@@ -209,4 +209,14 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
     }
 }
 
+__global__ void k_export_pairs(const DevBatch* __restrict__ Bp, double* out)
+{
+    const DevBatch& B = *Bp;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= B.n_pairs) return;
+    double* o = out + 8 * (size_t)p;
+    o[0] = B.pair_status[p]; o[1] = B.best_chain[2 * p]; o[2] = B.best_chain[2 * p + 1]; o[3] = B.n_comb[p];
+    o[4] = B.pair_ll[p]; o[5] = B.pair_mapq[p]; o[6] = B.mate_mapq[2 * p]; o[7] = B.mate_mapq[2 * p + 1];
+}
+
 }  // namespace hlala

@@ -214,6 +214,12 @@ int  hlala_align_batch(hlala_ctx* ctx, hlala_batch* b);
 int  hlala_batch_get_chains(hlala_ctx* ctx, hlala_batch* b, int stage, hlala_chains_out* out);
 int  hlala_batch_get_pairs(hlala_ctx* ctx, hlala_batch* b, hlala_pairs_out* out);
 
+/* Device-to-device export of one fixed-size record per pair (8 doubles: pair_status, best_chain[0], best_chain[1],
+ * n_combinations, pair_ll, pair_mapq, mate_mapq[0], mate_mapq[1]) into a caller-owned DEVICE buffer of
+ * 8 * n_pairs doubles -- the payload of the multi-GPU gather of per-pair best-path records to rank 0
+ * (the host program hands the buffer to RCCL; there is no collective inside this library).        */
+int  hlala_batch_export_pair_records(hlala_ctx* ctx, hlala_batch* b, double* device_out);
+
 /* Per-stage statistics of the last hlala_align_batch / stage call on this batch, measured
  * with HIP events on the ctx stream (ms) plus work counters reduced on the device.          */
 typedef struct {

@@ -280,3 +280,88 @@ def make_batch(world, n_pairs, seed=3, read_len=150, ins_mean=200.0, ins_sd=35.0
         truth_level0=np.asarray(truth_level0, dtype=np.int32),
         insert_mean=float(ins_mean), insert_sd=float(ins_sd),
     )
+
+
+def make_batch_fast(world, n_pairs, seed=3, read_len=150, ins_mean=200.0, ins_sd=35.0, clip_max=30,
+                    p_secondary=0.5, max_secondary=4, p_random_secondary=0.1, qual_lo=2, qual_hi=40,
+                    p_no_clip=0.15, p_flip=0.5):
+    """Vectorised variant of make_batch for bench-scale inputs (no read indels: CIGARs are S/M/S).
+    Same distributions otherwise; used where a million pairs are needed in seconds."""
+    rng = np.random.default_rng(seed)
+    C = world["contigs"]
+    nh = C["n_contigs"]; off = C["contig_off"]; clen = np.diff(off); seq = C["contig_seq"]; lvl = C["contig_level"]
+    nuc = np.frombuffer(b"ACGT", dtype=np.uint8)
+    G = world["G"]; L = read_len
+    if "_pos_at_level" not in world:
+        world["_pos_at_level"] = np.stack([np.searchsorted(lvl[off[h]:off[h + 1]], np.arange(G + 1), side="left").astype(np.int32)
+                                           for h in range(nh)])
+    pal = world["_pos_at_level"]
+    hap = rng.integers(0, nh, n_pairs)
+    frag = np.maximum(L + 10, np.rint(rng.normal(ins_mean, ins_sd, n_pairs)).astype(np.int64) + 2 * L)
+    frag = np.minimum(frag, clen[hap] - 2)
+    s = (rng.random(n_pairs) * (clen[hap] - frag)).astype(np.int64)
+    flip = rng.random(n_pairs) < p_flip
+    n = 2 * n_pairs
+    # per read (2p, 2p+1)
+    mate = np.tile(np.array([0, 1]), n_pairs)
+    rhap = np.repeat(hap, 2)
+    upstream = (mate == 0) != np.repeat(flip, 2)
+    rs = np.where(upstream, np.repeat(s, 2), np.repeat(s + frag - L, 2))
+    rev = ~upstream
+    ar = np.arange(L)
+    b = seq[(off[rhap] + rs)[:, None] + ar[None, :]].copy()
+    q = np.clip(qual_hi - rng.geometric(0.25, (n, L)) + 1, qual_lo, qual_hi)
+    bad = rng.random((n, L)) < 0.03
+    q[bad] = rng.integers(qual_lo, qual_hi + 1, int(bad.sum()))
+    q = q.astype(np.uint8)
+    err = rng.random((n, L)) < 10.0 ** (-q.astype(np.float32) / 10.0)
+    b[err] = nuc[rng.integers(0, 4, int(err.sum()))]
+    a = np.where(rng.random(n) < p_no_clip, 0, (rng.beta(1, 4, n) * clip_max).astype(np.int64))
+    c = np.where(rng.random(n) < p_no_clip, 0, (rng.beta(1, 4, n) * clip_max).astype(np.int64))
+    mism = err.sum(1)
+    lv0 = lvl[off[rhap] + rs + a]
+    # ---- records: slot 0 = primary, slots 1.. = secondaries
+    rec_read = [np.arange(n)]; rec_contig = [rhap]; rec_pos = [rs + a]; rec_as = [L - a - c - 5 * mism]; rec_prim = [np.ones(n, bool)]
+    has_sec = rng.random(n) < p_secondary
+    nsec = np.where(has_sec, np.minimum(max_secondary, rng.geometric(0.5, n)), 0)
+    for k in range(max_secondary):
+        sel = np.nonzero(nsec > k)[0]
+        if len(sel) == 0:
+            break
+        h2 = (rhap[sel] + 1 + rng.integers(0, max(1, nh - 1), len(sel))) % nh
+        rnd = rng.random(len(sel)) < p_random_secondary
+        p2 = np.where(rnd, (rng.random(len(sel)) * (clen[h2] - L - 2)).astype(np.int64), pal[h2, lv0[sel]].astype(np.int64))
+        start = p2 - a[sel]
+        ok = (start >= 0) & (start + L + 1 < clen[h2])
+        sel, h2, p2, start = sel[ok], h2[ok], p2[ok], start[ok]
+        ref2 = seq[(off[h2] + start)[:, None] + ar[None, :]]
+        mask = (ar[None, :] >= a[sel][:, None]) & (ar[None, :] < (L - c[sel])[:, None])
+        mm = ((ref2 != b[sel]) & mask).sum(1)
+        rec_read.append(sel); rec_contig.append(h2); rec_pos.append(p2); rec_as.append(L - a[sel] - c[sel] - 5 * mm); rec_prim.append(np.zeros(len(sel), bool))
+    rread = np.concatenate(rec_read); rcontig = np.concatenate(rec_contig); rpos = np.concatenate(rec_pos)
+    ras = np.concatenate(rec_as); rprim = np.concatenate(rec_prim)
+    slot = np.concatenate([np.full(len(x), i) for i, x in enumerate(rec_read)])
+    order = np.lexsort((slot, -ras, rread))            # by read, AS descending, then generation order (stable)
+    rread, rcontig, rpos, ras, rprim = rread[order], rcontig[order], rpos[order], ras[order], rprim[order]
+    nchains = len(rread)
+    chain_off = np.zeros(n + 1, np.int64); np.add.at(chain_off, rread + 1, 1); chain_off = np.cumsum(chain_off)
+    read_primary = np.nonzero(rprim)[0]
+    # CIGAR: aS (L-a-c)M cS with zero-length ops dropped
+    ca, cc = a[rread], c[rread]
+    nops = 1 + (ca > 0) + (cc > 0)
+    cigar_off = np.concatenate([[0], np.cumsum(nops)])
+    cigar = np.zeros(int(cigar_off[-1]), np.uint32)
+    pos0 = cigar_off[:-1]
+    hasA = ca > 0
+    cigar[pos0[hasA]] = (ca[hasA].astype(np.uint32) << 4) | OP["S"]
+    mpos = pos0 + hasA
+    cigar[mpos] = ((L - ca - cc).astype(np.uint32) << 4) | OP["M"]
+    hasC = cc > 0
+    cigar[(mpos + 1)[hasC]] = (cc[hasC].astype(np.uint32) << 4) | OP["S"]
+    return dict(
+        n_pairs=n_pairs, read_off=(np.arange(n + 1) * L).astype(np.int32), read_bases=b.reshape(-1), read_quals=(q + 33).reshape(-1),
+        chain_off=chain_off.astype(np.int32), read_primary=read_primary.astype(np.int32), n_chains=int(nchains),
+        chain_contig=rcontig.astype(np.int32), chain_pos=rpos.astype(np.int32), chain_offset=np.zeros(nchains, np.int32),
+        chain_as=ras.astype(np.int32), chain_reverse=rev[rread].astype(np.uint8),
+        cigar_off=cigar_off.astype(np.int32), cigar=cigar, truth_level0=lv0.astype(np.int32),
+        insert_mean=float(ins_mean), insert_sd=float(ins_sd))
