@@ -308,7 +308,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_level, cs, false); AL(ext_edge, cs, false); AL(ext_g, cs, false); AL(ext_s, cs, false); AL(ext_fromseed, cs, false);
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
-    AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, false);
+    AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
     AL(counters, 16, true); AL(work_counter, 8, true); AL(retry_list, nc, false);
     B.dbg = c->dbg_host;
 #undef AL

@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: the sharding + gather plumbing of the N > 1 path reproduces the unsharded result.
+The per-rank engine here is the oracle (test infrastructure) -- on GPUs it is libhlala_gpu.so; the plumbing is identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _records(pairs):
+    n = len(pairs["pair_ll"])
+    rec = np.zeros((n, 8))
+    rec[:, 0] = pairs["pair_status"]; rec[:, 1] = pairs["best_chain"][0::2]; rec[:, 2] = pairs["best_chain"][1::2]
+    rec[:, 3] = pairs["n_combinations"]; rec[:, 4] = pairs["pair_ll"]; rec[:, 5] = pairs["pair_mapq"]
+    rec[:, 6] = pairs["mate_mapq"][0::2]; rec[:, 7] = pairs["mate_mapq"][1::2]
+    return rec
+
+
+def _worker(rank, world, port, n_pairs, tmp):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import load_package
+    from tools import synth
+    from oracle_binding import Oracle
+    P = load_package()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hla_la_amd.dist", os.path.join(ROOT, "hla-la_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec); spec.loader.exec_module(D)
+    w = synth.make_world(seed=7, G=6000, k=1)
+    b = synth.make_batch(w, n_pairs, seed=8)
+    sub, p0, c0 = D.shard_pairs(b, rank, world)
+    o = Oracle(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=(99 + 2 * c0) & 0xFFFFFFFF)
+    pr = o.align_batch(sub)["pairs"]
+    rec = _records(pr)
+    rec[:, 1:3] += c0                     # chain indices back to the global numbering
+    got = D.gather_records(torch.from_numpy(rec), dst=0)
+    if rank == 0:
+        full = _records(Oracle(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=99).align_batch(b)["pairs"])
+        cat = torch.cat(got).numpy()
+        np.save(os.path.join(tmp, "ok.npy"), np.array([int(np.array_equal(cat, full)), cat.shape[0]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [61])      # odd: ragged shards (31 + 30)
+def test_sharded_gather_equals_unsharded(tmp_path, oracle, n_pairs):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, n_pairs, str(tmp_path)), nprocs=2, join=True)
+    ok = np.load(tmp_path / "ok.npy")
+    assert ok[0] == 1 and ok[1] == n_pairs
+
+
+def test_shard_bounds_cover_everything():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("d", os.path.join(ROOT, "hla-la_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec); spec.loader.exec_module(D)
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 4, 8):
+            edges = [D.shard_bounds(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            assert max(e[1] - e[0] for e in edges) - min(e[1] - e[0] for e in edges) <= 1

