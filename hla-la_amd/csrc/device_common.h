@@ -25,8 +25,8 @@ struct DevGraph {
     const int* edge_from_new;  // [E] by creation index
     const int* edge_to_new;    // [E]
     const uint8_t* edge_label; // [E] by creation index
-    const int* jf_off; const int* jf_node; const int* jf_path;
-    const int* jb_off; const int* jb_node; const int* jb_path;
+    const int* jf_off; const int* jf_node; const int* jf_path; const int* jf_lvl;
+    const int* jb_off; const int* jb_node; const int* jb_path; const int* jb_lvl;
     const int* path_len;       // [P]
     const long long* path_off; // [P+1]
     const int* path_edges;
@@ -76,20 +76,40 @@ __device__ __forceinline__ int next_work(int* counter)
     return __builtin_amdgcn_readfirstlane(w);
 }
 
+// Wave-wide reductions on the DPP cross-lane path (row_shr 1/2/3 + row_bcast15/31): ~6 VALU ops instead of six
+// ds_bpermute round trips through the LDS crossbar.  The result is read from lane 63 into an SGPR.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int oldv, int v) { return __builtin_amdgcn_update_dpp(oldv, v, CTRL, 0xF, 0xF, false); }
+#define HLALA_DPP_REDUCE(v, IDENT, OP)                                                     \
+    do {                                                                                    \
+        int t_;                                                                             \
+        t_ = dpp_mov<0x111>(IDENT, v); v = OP(v, t_);   /* row_shr:1 */                     \
+        t_ = dpp_mov<0x112>(IDENT, v); v = OP(v, t_);   /* row_shr:2 */                     \
+        t_ = dpp_mov<0x114>(IDENT, v); v = OP(v, t_);   /* row_shr:4 */                     \
+        t_ = dpp_mov<0x118>(IDENT, v); v = OP(v, t_);   /* row_shr:8 */                     \
+        t_ = __builtin_amdgcn_update_dpp(IDENT, v, 0x142, 0xA, 0xF, false); v = OP(v, t_);  /* row_bcast:15 */ \
+        t_ = __builtin_amdgcn_update_dpp(IDENT, v, 0x143, 0xC, 0xF, false); v = OP(v, t_);  /* row_bcast:31 */ \
+    } while(0)
+__device__ __forceinline__ int op_max_(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int op_add_(int a, int b) { return a + b; }
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-    for(int o = 32; o; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
+    HLALA_DPP_REDUCE(v, (int)0x80000000, op_max_);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-    for(int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    HLALA_DPP_REDUCE(v, 0, op_add_);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ u64 wave_min_u64(u64 v)
 {
-    for(int o = 32; o; o >>= 1) { u64 w = __shfl_xor(v, o); v = w < v ? w : v; }
-    return v;
+    // two 32-bit max passes on the complemented halves: high word first, then the low word among the winners
+    int hi = (int)(~(u32)(v >> 32) ^ 0x80000000u);
+    int mh = wave_max_i32(hi);
+    int lo = (hi == mh) ? (int)(~(u32)v ^ 0x80000000u) : (int)0x80000000;
+    int ml = wave_max_i32(lo);
+    return ((u64)(~((u32)mh ^ 0x80000000u)) << 32) | (u64)(~((u32)ml ^ 0x80000000u));
 }
 // exclusive prefix sum over the wave; returns the lane's offset, `total` is wave-uniform
 __device__ __forceinline__ int wave_excl_scan(int v, int& total)

@@ -157,6 +157,8 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
         };
         if(!build(F.path_first, F.path_last, F.jf_off, F.jf_node, F.jf_path)) return "duplicate gap-edge path between two nodes";
         if(!build(F.path_last, F.path_first, F.jb_off, F.jb_node, F.jb_path)) return "duplicate gap-edge path between two nodes";
+        F.jf_lvl.resize(P); F.jb_lvl.resize(P);
+        for(int32_t i = 0; i < P; i++) { F.jf_lvl[i] = F.node_level[F.jf_node[i]]; F.jb_lvl[i] = F.node_level[F.jb_node[i]]; }
     }
 
     // ---- level -> (sequence id, position), last writer wins (processBAM.cpp:4455)

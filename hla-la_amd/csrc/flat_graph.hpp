@@ -38,6 +38,7 @@ struct FlatGraph {
     std::vector<int32_t> jf_off, jb_off;         // [N+1]
     std::vector<int32_t> jf_node, jb_node;       // target node (new id)
     std::vector<int32_t> jf_path, jb_path;       // path index
+    std::vector<int32_t> jf_lvl, jb_lvl;         // level of the target node (saves a dependent load on the device)
     std::vector<uint8_t> gap_stretch;            // [L-1]
     // level -> (sequence id, position) CSR, entries sorted by sequence id
     std::vector<int64_t> lp_off;                 // [L+1]

@@ -195,6 +195,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     std::string ferr = flatten_graph(graph, contigs, c->F);
     if(!ferr.empty()) { c->err = ferr; return fail(HLALA_E_GRAPH); }
     FlatGraph& F = c->F;
+    if(F.N >= (1 << 28) || F.L >= (1 << 24)) { c->err = "graph exceeds 2^28 nodes or 2^24 levels (DP cell key layout)"; return fail(HLALA_E_CAPACITY); }
     if(F.max_nodes_per_level > PROJ_NODES) { c->err = "more nodes in one level than this build holds in LDS (PROJ_NODES)"; return fail(HLALA_E_CAPACITY); }
     if(c->params.max_columns > PROJ_CAP || c->params.max_columns > PAIR_COLS) { c->err = "params.max_columns exceeds the LDS column capacity of this build (768)"; return fail(HLALA_E_ARG); }
     DevGraph& G = c->G;
@@ -208,6 +209,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     UPG(edge_from_new, F.edge_from_new); UPG(edge_to_new, F.edge_to_new); UPG(edge_label, edge_label);
     UPG(jf_off, F.jf_off); UPG(jf_node, F.jf_node); UPG(jf_path, F.jf_path);
     UPG(jb_off, F.jb_off); UPG(jb_node, F.jb_node); UPG(jb_path, F.jb_path);
+    UPG(jf_lvl, F.jf_lvl); UPG(jb_lvl, F.jb_lvl);
     UPG(path_len, F.path_len); UPG(path_edges, F.path_edges);
     {
         std::vector<long long> po(F.path_off.begin(), F.path_off.end());
@@ -232,7 +234,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, device) != hipSuccess) { c->err = "hipGetDeviceProperties failed"; return fail(HLALA_E_DEVICE); }
     int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->ext_grid = cus * 6;
+    c->ext_grid = cus * 14;
     c->retry_grid = cus;
     c->ext_slab_bytes = ext_slab_bytes_host(c->params.max_columns);
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
@@ -587,6 +589,14 @@ __global__ void k_kat_rand(int n, u32* seeds, int* vals)
     if(i < n) { unsigned int s = seeds[i]; vals[i] = glibc_rand_r(&s); seeds[i] = s; }
 }
 }  // namespace hlala
+
+extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long long* out16)
+{
+    if(!c || !b) return HLALA_E_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out16, b->B.counters, 16 * sizeof(u64), hipMemcpyDeviceToHost));
+    return HLALA_OK;
+}
 
 extern "C" int hlala_debug_peek(hlala_ctx* c, int* out64)
 {

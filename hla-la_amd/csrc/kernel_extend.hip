@@ -25,7 +25,7 @@ constexpr int DP_IMPCAP = 2048;    // staged improvements of existing cells per 
 
 // Two capacity classes: the small one serves almost every chain at 6-7 blocks per CU; chains whose frontier /
 // candidate set outgrows it (long runs of parallel gap paths) are re-run by the large one (one block per CU).
-struct DpSmall { static constexpr int WCAP = DP_WCAP, HC = DP_HC, IBITS = 7;  typedef u32 Best; };
+struct DpSmall { static constexpr int WCAP = 64,      HC = 256,   IBITS = 7;  typedef u32 Best; };
 struct DpLarge { static constexpr int WCAP = 1024,    HC = 2048,  IBITS = 10; typedef u64 Best; };
 
 template <class C>
@@ -33,8 +33,7 @@ struct __align__(16) DpLdsT {
     u64 hkey[C::HC];
     typename C::Best hbest[3][C::HC];
     unsigned short tlist[C::HC];
-    int fx[3][C::WCAP];
-    u32 fyz[3][C::WCAP];
+    u64 fkey[3][C::WCAP];
     int fslot[3][C::WCAP];
     short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
     unsigned char seq[DP_SEQCAP];
@@ -98,10 +97,12 @@ __device__ inline ExtSlab ext_slab_at(char* base, int stride)
     return s;
 }
 
-__device__ __forceinline__ u64 mk_key(int x, int y, int z) { return ((u64)(u32)x << 32) | ((u64)(u32)y << 16) | (u64)(u32)z; }
-__device__ __forceinline__ int key_x(u64 k) { return (int)(k >> 32); }
-__device__ __forceinline__ int key_y(u64 k) { return (int)((k >> 16) & 0xFFFF); }
-__device__ __forceinline__ int key_z(u64 k) { return (int)(k & 0xFFFF); }
+// DP cell key: level x (24 bits) | read offset y (12 bits) | node id (28 bits).  Node ids are level-major and
+// stable in creation order, so unsigned key order == the reference's std::map order (x, then y, then rank z).
+__device__ __forceinline__ u64 mk_key(int x, int y, int node) { return ((u64)(u32)x << 40) | ((u64)(u32)y << 28) | (u64)(u32)node; }
+__device__ __forceinline__ int key_x(u64 k) { return (int)(k >> 40); }
+__device__ __forceinline__ int key_y(u64 k) { return (int)((k >> 28) & 0xFFF); }
+__device__ __forceinline__ int key_node(u64 k) { return (int)(k & 0xFFFFFFF); }
 __device__ __forceinline__ u32 hash64(u64 k) { k ^= k >> 29; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 32; return (u32)k; }
 
 __device__ __forceinline__ u64 mk_bt(int prev, int src, int kind, int edge) { return ((u64)(u32)edge << 32) | (u64)((u32)prev | ((u32)src << 24) | ((u32)kind << 26)); }
@@ -195,7 +196,7 @@ struct DpResult { int have, ncols, seq_begin, seq_end, iters, score, err; u64 ce
 // diagonal_stop_threshold = -16 (the only configuration extendSeedChain uses, :229-241, :281-293).
 template <class C>
 __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, int seqLen, int start_seq, int startLevel,
-                           int startZ, bool fwd, u32 seed, int side, int outCap, u64* counters, int* dbg, int chain)
+                           int startNode, bool fwd, u32 seed, int side, int outCap, u64* counters, int* dbg, int chain)
 {
     const int lane = lane_id();
     const int dir = fwd ? 1 : -1;
@@ -208,10 +209,10 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
     for(int i = lane; i < C::HC; i += 64) { S.hkey[i] = HKEY_EMPTY; S.hbest[0][i] = 0; S.hbest[1][i] = 0; S.hbest[2][i] = 0; }
     if(lane == 0) {
         S.nT = 0; S.err = 0;
-        sl.cell_key[0] = mk_key(startLevel, start_seq, startZ);
+        sl.cell_key[0] = mk_key(startLevel, start_seq, startNode);
         sl.cell_sc[0] = 0; sl.cell_sc[1] = (short)DP_NEG; sl.cell_sc[2] = (short)DP_NEG; sl.cell_sc[3] = 0;
         sl.cell_bt[0] = 0; sl.cell_bt[DP_CELLS] = 0; sl.cell_bt[2 * DP_CELLS] = 0;
-        S.fx[0][0] = startLevel; S.fyz[0][0] = ((u32)start_seq << 16) | (u32)startZ; S.fslot[0][0] = 0;
+        S.fkey[0][0] = mk_key(startLevel, start_seq, startNode); S.fslot[0][0] = 0;
         S.fD[0][0] = 0; S.fG[0][0] = (short)DP_NEG; S.fS[0][0] = (short)DP_NEG;
     }
     WSYNC();
@@ -222,6 +223,9 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
     bool earlyInit = false;
     long long itersRun = 0;
     u64 cellsEvaluated = 0, edgesTouched = 0;
+    long long tGen = 0, tEval = 0, tFilt = 0, tMark = 0;
+    const bool timing = dbg != nullptr;
+    if(timing) tMark = clock64();
 
     for(long long d = 1; d <= diagonals; d++) {                                            // :531
         if((d - lastInc) > 40) break;                                                      // :553 maximum_steps_nonIncrease
@@ -231,56 +235,50 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
             itersRun = last; break;
         }
         itersRun = d;
-        DBGB(0, chain); DBGB(1, (int)d); DBGB(2, 100 + side);
-        if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(0, chain); DBGW(1, (int)d); DBGW(2, n1); DBGW(3, n2); DBGW(4, nCells); DBGW(5, lastInc); DBGW(6, 1); DBGW(7, side); }
         if(d > 60000) { DP_FAIL(__LINE__); break; }          // watchdog: far beyond any read length + patience
 
         // ================= generate =====================================================
         // from the m-2 diagonal: match / mismatch, :565-607
         for(int i = lane; i < n2; i += 64) {
-            int px = S.fx[b2][i]; u32 pyz = S.fyz[b2][i]; int py = (int)(pyz >> 16), pz = (int)(pyz & 0xFFFF);
+            u64 pk = S.fkey[b2][i]; int px = key_x(pk), py = key_y(pk), node = key_node(pk);
             int nx = px + dir, ny = py + dir;
             if(nx > max_levelI || ny > max_seqI || nx < 0 || ny < 0) continue;
             unsigned char rc = fwd ? S.seq[py] : S.seq[py - 1];
-            int node = G.level_off[px] + pz;
             int e0 = fwd ? G.out_off[node] : G.in_off[node], e1 = fwd ? G.out_off[node + 1] : G.in_off[node + 1];
             int pD = S.fD[b2][i];
-            int nbase = G.level_off[nx];
-            if(e1 - e0 > 250) { S.err = __LINE__; continue; }
+            if(e1 - e0 > 127) { S.err = __LINE__; continue; }
             for(int e = e0; e < e1; e++) {
                 int tn = fwd ? G.out_to[e] : G.in_from[e];
                 unsigned char lab = fwd ? G.out_label[e] : G.in_label[e];
                 int sc = pD + (lab == rc ? 2 : -5);
-                if(!dp_push<C>(S, mk_key(nx, ny, tn - nbase), M_D, sc, (i << 8) | (e - e0))) S.err = __LINE__;
+                if(!dp_push<C>(S, mk_key(nx, ny, tn), M_D, sc, (i << 8) | (e - e0))) S.err = __LINE__;
             }
             edgesTouched += (u64)(e1 - e0);
         }
         // from the m-1 diagonal: gaps and jumps, :613-787
         for(int i = lane; i < n1; i += 64) {
-            int px = S.fx[b1][i]; u32 pyz = S.fyz[b1][i]; int py = (int)(pyz >> 16), pz = (int)(pyz & 0xFFFF);
+            u64 pk = S.fkey[b1][i]; int px = key_x(pk), py = key_y(pk), node = key_node(pk);
             int pD = S.fD[b1][i], pG = S.fG[b1][i], pS = S.fS[b1][i];
             int ord0 = (1 << (C::IBITS + 8)) | (i << 8);
             {   // gap in graph, :621-661
                 int ny = py + dir;
                 if(ny >= 0 && ny <= max_seqI) {
-                    u64 k = mk_key(px, ny, pz);
+                    u64 k = mk_key(px, ny, node);
                     if(!dp_push<C>(S, k, M_GG, pD - 6, ord0 | 0)) S.err = __LINE__;
                     if(pG != DP_NEG) if(!dp_push<C>(S, k, M_GG, pG - 2, ord0 | 1)) S.err = __LINE__;
                 }
             }
-            int node = G.level_off[px] + pz;
             int deg = 0;
             {   // gap in sequence, :664-754
                 int nx = px + dir;
                 int e0 = fwd ? G.out_off[node] : G.in_off[node], e1 = fwd ? G.out_off[node + 1] : G.in_off[node + 1];
                 deg = e1 - e0;
-                if(deg > 120) { S.err = __LINE__; continue; }
+                if(deg > 127) { S.err = __LINE__; continue; }
                 if(nx >= 0 && nx <= max_levelI) {
-                    int nbase = G.level_off[nx];
                     for(int e = e0; e < e1; e++) {
                         int tn = fwd ? G.out_to[e] : G.in_from[e];
                         unsigned char lab = fwd ? G.out_label[e] : G.in_label[e];
-                        u64 k = mk_key(nx, py, tn - nbase);
+                        u64 k = mk_key(nx, py, tn);
                         int kk = e - e0;
                         if(lab != '_') {
                             if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
@@ -294,19 +292,20 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                 }
             }
             {   // gap-path jumps, :757-786 (jump_length * S_graphGap = 0)
-                const int* joff = fwd ? G.jf_off : G.jb_off; const int* jnode = fwd ? G.jf_node : G.jb_node;
+                // push index of a jump = 128 + its rank in the jump table: after every edge candidate of the same source (:757)
+                const int* joff = fwd ? G.jf_off : G.jb_off; const int* jnode = fwd ? G.jf_node : G.jb_node; const int* jlvl = fwd ? G.jf_lvl : G.jb_lvl;
                 int j0 = joff[node], j1 = joff[node + 1];
-                if(deg + (j1 - j0) > 250) { S.err = __LINE__; continue; }
+                if(j1 - j0 > 127) { S.err = __LINE__; continue; }
                 for(int j = j0; j < j1; j++) {
-                    int tn = jnode[j]; int jx = G.node_level[tn];
+                    int tn = jnode[j]; int jx = jlvl[j];
                     if(jx < 0 || jx > max_levelI) continue;
-                    if(!dp_push<C>(S, mk_key(jx, py, tn - G.level_off[jx]), M_D, pD, ord0 | (deg + (j - j0)))) S.err = __LINE__;
+                    if(!dp_push<C>(S, mk_key(jx, py, tn), M_D, pD, ord0 | (128 + (j - j0)))) S.err = __LINE__;
                 }
             }
         }
         WSYNC();
+        if(timing) { long long t = clock64(); tGen += t - tMark; tMark = t; }
         int nT = uni(S.nT);
-        if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 2); DBGW(8, nT); }
         if(nT > (C::HC * 3) / 4 || uni(S.err)) { DP_FAIL(__LINE__); break; }
         cellsEvaluated += (u64)nT;
 
@@ -335,7 +334,6 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
             WSYNC();
         }
         const bool slow = anyExisting;
-        if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 21); }
         const bool hadEarly = earlyInit;      // S.tes[] holds lookups only if the pre-pass ran
 
         for(int pass = 0; pass < (slow ? 2 : 1); pass++) {
@@ -363,28 +361,23 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                     isNew = keep && (S.timp[t] & 0x80);
                     es = isNew ? -1 : slot;
                 }
-                if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 22); }
                 // ---- back pointers of the three matrices, decoded from the winning push index
                 u64 btD = 0, btG = 0, btS = 0;
                 int srcScore = 0;       // score the real previous step came from (fast form of the `diff` rule)
                 if(keep && S.err == 0 && slot >= 0 && slot < DP_CELLS) {
+                    // back pointer = (previous cell slot, source matrix, kind, local push index j); the graph edge / gap path behind j
+                    // is resolved only for the cells on the final path, at backtrace time
                     if(bG) { int o = best_order(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                              btG = mk_bt(S.fslot[b1][i], j ? 1 : 0, K_GGAP, -1); }
-                    if(bS) { int o = best_order(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255; int kk = j >> 1;
-                             int px = S.fx[b1][i]; int pz = (int)(S.fyz[b1][i] & 0xFFFF); int node = G.level_off[px] + pz;
-                             int eid = fwd ? G.out_eid[G.out_off[node] + kk] : G.in_eid[G.in_off[node] + kk];
-                             btS = mk_bt(S.fslot[b1][i], (j & 1) ? 2 : 0, K_SGAP, eid); }
+                    if(bS) { int o = best_order(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                             btS = mk_bt(S.fslot[b1][i], (j & 1) ? 2 : 0, K_SGAP, j >> 1); }
                     if(dsel == 0) {
                         int o = best_order(bD); int ph = o >> (C::IBITS + 8); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                         int sb = ph ? b1 : b2;
-                        int px = S.fx[sb][i]; int pz = (int)(S.fyz[sb][i] & 0xFFFF); int node = G.level_off[px] + pz;
-                        int e0 = fwd ? G.out_off[node] : G.in_off[node];
-                        int deg = (fwd ? G.out_off[node + 1] : G.in_off[node + 1]) - e0;
                         srcScore = S.fD[sb][i];
-                        if(!ph) btD = mk_bt(S.fslot[sb][i], 0, K_DIAG, fwd ? G.out_eid[e0 + j] : G.in_eid[e0 + j]);
-                        else if(j < deg) btD = mk_bt(S.fslot[sb][i], 0, K_SGAP, fwd ? G.out_eid[e0 + j] : G.in_eid[e0 + j]);
-                        else { const int* joff = fwd ? G.jf_off : G.jb_off; const int* jpath = fwd ? G.jf_path : G.jb_path;
-                               btD = mk_bt(S.fslot[sb][i], 0, K_JUMP, jpath[joff[node] + (j - deg)]); }
+                        if(!ph) btD = mk_bt(S.fslot[sb][i], 0, K_DIAG, j);
+                        else if(j < 128) btD = mk_bt(S.fslot[sb][i], 0, K_SGAP, j);
+                        else btD = mk_bt(S.fslot[sb][i], 0, K_JUMP, j - 128);
                     } else if(dsel == 1) {
                         btD = mk_bt(slot, 1, K_HOP, -1);
                         int o = best_order(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
@@ -395,7 +388,6 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                         srcScore = (j & 1) ? S.fS[b1][i] : S.fD[b1][i];
                     }
                 }
-                if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 23); }
                 int impMask = 0;
                 int mD = Dv, mG = GGv, mS = SGv;          // merged values
                 u64 mbtD = btD;                            // merged D back pointer
@@ -422,7 +414,6 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                         if(nCompleted + pos < DP_COMPLETED) sl.completed[nCompleted + pos] = slot; else S.err = __LINE__;
                     }
                 }
-                if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 24); }
                 // ---- existing cells: each matrix independently overwritten iff strictly greater, :951-979 (writes are staged)
                 if(keep && !isNew && S.err == 0) {
                     int oD = sl.cell_sc[4 * es + 0], oG = sl.cell_sc[4 * es + 1], oS = sl.cell_sc[4 * es + 2];
@@ -443,7 +434,6 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                     if(act) { S.tes[t] = slot; S.timp[t] = (unsigned char)(impMask | (isNew ? 0x80 : 0)); }
                     continue;
                 }
-                if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 25); }
                 if(__ballot(impMask != 0)) anyOw = true;
                 // ---- the `diff` rule, :1007-1041: score difference to the real previous step of the MERGED D back pointer
                 int diff = 1;
@@ -467,7 +457,6 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                         diff = Dv - pv;
                     }
                 }
-                if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 26); }
                 // ---- running maximum bookkeeping, :1043-1062
                 bool eq = keep && Dv == curMax0 && diff != 0;
                 if(__ballot(eq)) anyEqDiff = true;
@@ -484,7 +473,6 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
             }
             WSYNC();
         }
-        if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 27); DBGW(11, S.err); DBGW(12, S.nImp); DBGW(13, slow ? 1 : 0); }
         nCompleted += uni(S.nCompletedAdd);
         if(uni(S.err)) { DP_FAIL(__LINE__); break; }
         // apply staged improvements of existing cells and patch cached frontier copies
@@ -503,7 +491,6 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                 }
             }
         }
-        if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 28); }
         // "== currentMaximum && diff != 0" / "> currentMaximum" / overwritten entry all set lastMaximumIncrease_at_diagonalI
         if(itMaxNew > curMax0) {
             curMax = itMaxNew; lastInc = (int)d;
@@ -511,10 +498,9 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
             for(int t = lane; t < nT; t += 64) { int h = S.tlist[t]; if(S.hkey[h] == itMaxKey) fs = (int)S.hbest[0][h]; }
             firstMaxSlot = wave_max_i32(fs);
         }
-        if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 29); }
         if(anyEqDiff || anyOw) lastInc = (int)d;
 
-        if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 3); }
+        if(timing) { long long t = clock64(); tEval += t - tMark; tMark = t; }
         // ================= filter + sort, :1076-1105 ======================================
         int mx = DP_NEG;
         for(int t = lane; t < nT; t += 64) { int h = S.tlist[t]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); mx = max(mx, v); } }
@@ -533,7 +519,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                     if((mx - vu) <= 15 && S.hkey[hu] < key) rank++;
                 }
                 if(rank < C::WCAP) {
-                    S.fx[bn][rank] = key_x(key); S.fyz[bn][rank] = (u32)(key & 0xFFFFFFFFu); S.fslot[bn][rank] = (int)S.hbest[0][h];
+                    S.fkey[bn][rank] = key; S.fslot[bn][rank] = (int)S.hbest[0][h];
                     S.fD[bn][rank] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][rank] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][rank] = (short)((u32)S.hbest[2][h] & 0xFFFF);
                 }
             }
@@ -546,17 +532,14 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
         if(lane == 0) S.nT = 0;
         WSYNC();
         { int tmp = b2; b2 = b1; b1 = bn; bn = tmp; }                                        // m2 := m1; m1 := this, :1104-1105
+        if(timing) { long long t = clock64(); tFilt += t - tMark; tMark = t; }
         n2 = n1; n1 = nNew;
     }
     WSYNC();
     R.iters = (int)itersRun;
-    DBGB(2, 200 + side);
-    if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 30); DBGW(14, S.err); }
     R.cells = cellsEvaluated; R.edges = wave_sum_i32((int)edgesTouched);
-    if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 31); }
+    if(timing && lane == 0) { atomicAdd(&counters[8], (u64)tGen); atomicAdd(&counters[9], (u64)tEval); atomicAdd(&counters[10], (u64)tFilt); atomicAdd(&counters[11], (u64)itersRun); tMark = clock64(); }
     if(uni(S.err)) { R.err = uni(S.err); return R; }
-
-    if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 4); DBGW(9, nCompleted); }
     // ---- end cell, :1381-1517
     int endSlot = -1, endScore = 0;
     if(nCompleted > 0) {
@@ -575,8 +558,11 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                 int s = sl.completed[i];
                 if(sl.cell_sc[4 * s + 0] == best) {
                     u64 k = sl.cell_key[s]; int rank = 0;
-                    if(nTies > 1)
-                        for(int u = 0; u < nCompleted; u++) { int su = sl.completed[u]; if(su != s && sl.cell_sc[4 * su + 0] == best) { u64 ku = sl.cell_key[su]; if(xz_less(key_x(ku), key_z(ku), key_x(k), key_z(k))) rank++; } }
+                    if(nTies > 1) {
+                        int kz = key_node(k) - G.level_off[key_x(k)];
+                        for(int u = 0; u < nCompleted; u++) { int su = sl.completed[u]; if(su != s && sl.cell_sc[4 * su + 0] == best) { u64 ku = sl.cell_key[su];
+                            if(xz_less(key_x(ku), key_node(ku) - G.level_off[key_x(ku)], key_x(k), kz)) rank++; } }
+                    }
                     if(rank == selectedIndex) found = s;
                 }
             }
@@ -586,9 +572,6 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
         endSlot = firstMaxSlot; endScore = sl.cell_sc[4 * firstMaxSlot + 0];
     }
     if(endSlot < 0) return R;                                                                // no extension
-
-    if(dbg && lane == 0 && blockIdx.x == 0) { DBGW(6, 5); DBGW(10, endSlot); }
-    DBGB(2, 300 + side);
     // ---- backtrace, :1109-1354: lane 0 chases the back pointers, then all lanes expand the steps into columns
     if(lane == 0) {
         int slot = endSlot, m = 0; u64 k = sl.cell_key[slot]; int x = key_x(k), y = key_y(k);
@@ -598,7 +581,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
             int kind = bt_kind(b);
             if(kind != K_HOP) {
                 int len = 1;
-                if(kind == K_JUMP) len = G.path_len[bt_edge(b)];
+                if(kind == K_JUMP) { int px = key_x(sl.cell_key[bt_prev(b)]); len = px > x ? px - x : x - px; }
                 sl.step_bt[nSteps] = b; sl.step_xy[nSteps] = ((u64)(u32)x << 32) | ((u64)(u32)y << 8) | 0; nSteps++; nCols += len;
             }
             int prev = bt_prev(b);
@@ -620,17 +603,26 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
     for(int s0 = 0; s0 < nSteps; s0 += 64) {
         int s = s0 + lane; bool act = s < nSteps;
         u64 b = act ? sl.step_bt[s] : 0; u64 xy = act ? sl.step_xy[s] : 0;
-        int kind = bt_kind(b); int len = act ? (kind == K_JUMP ? G.path_len[bt_edge(b)] : 1) : 0;
+        int kind = bt_kind(b);
+        // resolve the graph object behind the push index j: edge j of the previous cell's node, or entry j of its jump table
+        int pnode = 0, plevel = 0, robj = -1;
+        if(act && kind != K_GGAP) {
+            u64 pkey = sl.cell_key[bt_prev(b)]; pnode = key_node(pkey); plevel = key_x(pkey);
+            int j = bt_edge(b);
+            if(kind == K_JUMP) robj = (fwd ? G.jf_path : G.jb_path)[(fwd ? G.jf_off : G.jb_off)[pnode] + j];
+            else robj = fwd ? G.out_eid[G.out_off[pnode] + j] : G.in_eid[G.in_off[pnode] + j];
+        }
+        int len = act ? (kind == K_JUMP ? G.path_len[robj] : 1) : 0;
         int total; int off = wave_excl_scan(len, total);
         if(act) {
             int x = (int)(xy >> 32), y = (int)((xy >> 8) & 0xFFFFFF);
             int start = fwd ? (nCols - (base + off) - len) : (base + off);     // forward traces are reversed at the end, :1319-1326
             if(kind == K_JUMP) {                                                       // :1282-1307
-                int p = bt_edge(b); long long po = G.path_off[p];
+                int p = robj; long long po = G.path_off[p];
                 int lvl0 = G.node_level[G.edge_from_new[G.path_edges[po]]];
                 for(int j = 0; j < len; j++) { oL[start + j] = lvl0 + j; oE[start + j] = G.path_edges[po + j]; oG[start + j] = '_'; oS[start + j] = '_'; }
             } else {
-                int eid = bt_edge(b);
+                int eid = robj;
                 unsigned char sc = fwd ? (y >= 1 ? S.seq[y - 1] : 0) : (y < max_seqI ? S.seq[y] : 0);
                 int lvl = fwd ? x - 1 : x;
                 if(kind == K_DIAG) { oL[start] = lvl; oE[start] = eid; oG[start] = G.edge_label[eid]; oS[start] = sc; }
@@ -641,6 +633,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
         base += total;
     }
     WSYNC();
+    if(timing && lane == 0) { atomicAdd(&counters[12], (u64)(clock64() - tMark)); }
     u64 ek = sl.cell_key[endSlot];
     int yEnd = key_y(ek);
     R.have = 1; R.ncols = nCols; R.score = endScore;
@@ -654,7 +647,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
 // one wave per chain: left DP, right DP, stitch (extendWithOtherSeedChain / extendToFullSequenceLength,
 // verboseSeedChain.cpp:23-136), then scoreOneAlignment (extensionAligner.cpp:52-182).
 template <class C, bool RETRY>
-__global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp, char* slabs, size_t slabBytes, u32 rng_seed)
+__global__ __launch_bounds__(64, 4) void k_extend_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp, char* slabs, size_t slabBytes, u32 rng_seed)
 {
     // graph / batch descriptors stay in memory (scalar loads on demand): passing them by value costs ~150 SGPRs
     const DevGraph& G = *Gp;
@@ -669,8 +662,8 @@ __global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict
         int c;
         if(RETRY) { int i = next_work(&B.work_counter[4]); if(i >= uni(B.work_counter[3])) break; c = uni(B.retry_list[i]); }
         else { c = next_work(&B.work_counter[1]); if(c >= B.n_chains) break; }
-        { int* dbg = B.dbg; DBGB(0, c); DBGB(2, 1); }
         int st = uni(B.seed_status[c]);
+        long long tChain0 = B.dbg ? clock64() : 0;
         if(st != HLALA_CHAIN_OK) {
             if(lane == 0 && !RETRY) { B.ext_status[c] = st; B.ext_ncols[c] = 0; B.dp_iters[2 * c] = 0; B.dp_iters[2 * c + 1] = 0; B.dp_score[2 * c] = INT32_MIN; B.dp_score[2 * c + 1] = INT32_MIN;
                             if(st < 0) atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
@@ -691,11 +684,11 @@ __global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict
             else {
                 if(sBegin != 0) {                                                      // left extension, extensionAligner.cpp:220-268
                     int firstNode = uni(G.edge_from_new[e0]); int lvl = uni(G.node_level[firstNode]);
-                    if(lvl > 0) { nCalls++; RL = dp_run<C>(G, S, sl, seqLen, sBegin, lvl, firstNode - G.level_off[lvl], false, rng_seed + 2u * (u32)c, 0, stride, B.counters, B.dbg, c); }
+                    if(lvl > 0) { nCalls++; RL = dp_run<C>(G, S, sl, seqLen, sBegin, lvl, firstNode, false, rng_seed + 2u * (u32)c, 0, stride, B.counters, B.dbg, c); }
                 }
                 if(sEnd != seqLen - 1) {                                               // right extension, :271-319
                     int lastNode = uni(G.edge_to_new[e1]); int lvl = uni(G.node_level[lastNode]);
-                    if(lvl < G.L - 1) { nCalls++; RR = dp_run<C>(G, S, sl, seqLen, sEnd + 1, lvl, lastNode - G.level_off[lvl], true, rng_seed + 2u * (u32)c + 1u, 1, stride, B.counters, B.dbg, c); }
+                    if(lvl < G.L - 1) { nCalls++; RR = dp_run<C>(G, S, sl, seqLen, sEnd + 1, lvl, lastNode, true, rng_seed + 2u * (u32)c + 1u, 1, stride, B.counters, B.dbg, c); }
                 }
                 if(RL.err || RR.err) err = ((RL.err <= -1000000) || (RR.err <= -1000000)) ? HLALA_CHAIN_ERR_COLUMNS : HLALA_CHAIN_ERR_FRONTIER;
             }
@@ -721,7 +714,7 @@ __global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict
                 else { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(RL.err ? RL.err : RR.err); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
             }
         } else {
-        { int* dbg = B.dbg; DBGB(2, 400); }
+        long long tStitch0 = B.dbg ? clock64() : 0;
         // ---- stitch
         for(int j = lane; j < total; j += 64) {
             int lvl, edge; unsigned char g, s, fs = 0;
@@ -733,7 +726,6 @@ __global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict
             B.ext_level[cb + j] = lvl; B.ext_edge[cb + j] = edge; B.ext_g[cb + j] = g; B.ext_s[cb + j] = s; B.ext_fromseed[cb + j] = fs;
         }
         WSYNC();
-        { int* dbg = B.dbg; DBGB(2, 500); }
         // ---- scoreOneAlignment: terms are added strictly left to right in FP64 (same order as the reference loop).
         // The read quality of alignment-orientation base i is read_quals[i] in both strands: the reference indexes the
         // ORIGINAL-orientation read with len-i-1 when the chain is reverse (extensionAligner.cpp:85-88), which is the same base.
@@ -774,6 +766,7 @@ __global__ __launch_bounds__(64) void k_extend_chains(const DevGraph* __restrict
                 B.ext_firstlast[4 * c + 0] = f0; B.ext_firstlast[4 * c + 1] = f1; B.ext_firstlast[4 * c + 2] = l0; B.ext_firstlast[4 * c + 3] = l1;
                 B.ext_status[c] = HLALA_CHAIN_OK; B.ext_ncols[c] = total; B.ext_begin[c] = 0; B.ext_end[c] = seqLen - 1; B.ext_ll[c] = ll;
                 atomicAdd(&B.counters[CNT_CHAINS_EXT], 1ull); atomicAdd(&B.counters[CNT_OUT_COLS], (u64)total);
+                if(B.dbg) { long long t = clock64(); atomicAdd(&B.counters[13], (u64)(t - tStitch0)); atomicAdd(&B.counters[14], (u64)(t - tChain0)); atomicAdd(&B.counters[15], 1ull); }
             }
         }
         }   // no error

@@ -1,0 +1,23 @@
+import sys, time, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from tools import synth
+from conftest import load_package
+P = load_package()
+n_pairs = int(sys.argv[1]); G = int(sys.argv[2])
+w = synth.make_world(seed=2, G=G, k=1, n_mut=3)
+b = synth.make_batch_fast(w, n_pairs, seed=1000)
+ctx = P.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=12345)
+gb = ctx.batch(b)
+gb.align(); gb.stats()
+gb.align(); st = gb.stats()
+buf = (C.c_ulonglong * 16)()
+ctx.lib.hlala_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_ulonglong)]
+ctx.lib.hlala_debug_counters(ctx.h, gb.b, buf)
+d = np.array(list(buf)[8:16], dtype=np.float64)
+names = ['gen', 'eval', 'filter', 'iters', 'select+backtrace', 'stitch+LL', 'chain_total', 'chains']
+print({n: float(v) for n, v in zip(names, d)})
+it = d[3]; ch = d[7]
+print('cycles/iter: gen %.0f eval %.0f filter %.0f | per chain: select+bt %.0f stitch+LL %.0f total %.0f | iters/chain %.1f' % (d[0]/it, d[1]/it, d[2]/it, d[4]/ch, d[5]/ch, d[6]/ch, it/ch))
+print('ms', st.ms_project, st.ms_extend, st.ms_pair, 'pairs/s', n_pairs/((st.ms_project+st.ms_extend+st.ms_pair)*1e-3))
