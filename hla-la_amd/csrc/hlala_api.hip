@@ -42,7 +42,7 @@ struct hlala_ctx {
     std::vector<void*> allocs;
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0;
-    hipEvent_t ev[6]{};           // start/end per stage
+    hipEvent_t ev[7]{};           // start/end per stage, [6] = between the two extension passes
     int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
     std::string err;
 };
@@ -197,7 +197,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     FlatGraph& F = c->F;
     if(F.N >= (1 << 28) || F.L >= (1 << 24)) { c->err = "graph exceeds 2^28 nodes or 2^24 levels (DP cell key layout)"; return fail(HLALA_E_CAPACITY); }
     if(F.max_nodes_per_level > PROJ_NODES) { c->err = "more nodes in one level than this build holds in LDS (PROJ_NODES)"; return fail(HLALA_E_CAPACITY); }
-    if(c->params.max_columns > PROJ_CAP || c->params.max_columns > PAIR_COLS) { c->err = "params.max_columns exceeds the LDS column capacity of this build (768)"; return fail(HLALA_E_ARG); }
+    if(c->params.max_columns > PROJ_CAP || c->params.max_columns > PAIR_COLS) { c->err = "params.max_columns exceeds the LDS column capacity of this build (512)"; return fail(HLALA_E_ARG); }
     DevGraph& G = c->G;
     G.L = F.L; G.N = F.N; G.E = F.E; G.P = (int)F.path_len.size();
     std::vector<uint8_t> edge_label(graph->edge_label, graph->edge_label + graph->n_edges);
@@ -239,12 +239,12 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->ext_slab_bytes = ext_slab_bytes_host(c->params.max_columns);
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->ext_slabs);
-    c->proj_grid = cus * 8;
+    c->proj_grid = cus * 14;
     c->proj_slab_bytes = proj_slab_bytes_host(c->params.max_columns, F.max_nodes_per_level);
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
-    for(int i = 0; i < 6; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    for(int i = 0; i < 7; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;
@@ -254,7 +254,7 @@ void hlala_destroy(hlala_ctx* c)
 {
     if(!c) return;
     for(void* p : c->allocs) if(p) (void)hipFree(p);
-    for(int i = 0; i < 6; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for(int i = 0; i < 7; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -447,6 +447,7 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
         int grid = B.n_chains < c->ext_grid ? B.n_chains : c->ext_grid;
         hipLaunchKernelGGL((k_extend_chains<DpSmall, false>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
         int rc = check_launch(c, "k_extend_chains<small>"); if(rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
         // second pass over the (usually empty) list of chains that outgrew the small capacity class: one block per CU
         int rgrid = B.n_chains < c->retry_grid ? B.n_chains : c->retry_grid;
         hipLaunchKernelGGL((k_extend_chains<DpLarge, true>), dim3(rgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
@@ -565,7 +566,8 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     u64 cnt[16];
     HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
-    if(b->staged & 2) (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]);
+    if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[3]); }
+    { int wc[8]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[3]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

@@ -103,7 +103,8 @@ __device__ __forceinline__ u64 mk_key(int x, int y, int node) { return ((u64)(u3
 __device__ __forceinline__ int key_x(u64 k) { return (int)(k >> 40); }
 __device__ __forceinline__ int key_y(u64 k) { return (int)((k >> 28) & 0xFFF); }
 __device__ __forceinline__ int key_node(u64 k) { return (int)(k & 0xFFFFFFF); }
-__device__ __forceinline__ u32 hash64(u64 k) { k ^= k >> 29; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 32; return (u32)k; }
+// targets of one iteration differ in a few low bits of node / y / x: one 32-bit multiply spreads them
+__device__ __forceinline__ u32 hash64(u64 k) { u32 h = (u32)k ^ ((u32)(k >> 28) * 0x9E3779B1u) ^ ((u32)(k >> 40) * 0x85EBCA6Bu); h *= 0x9E3779B1u; return h ^ (h >> 15); }
 
 __device__ __forceinline__ u64 mk_bt(int prev, int src, int kind, int edge) { return ((u64)(u32)edge << 32) | (u64)((u32)prev | ((u32)src << 24) | ((u32)kind << 26)); }
 __device__ __forceinline__ int bt_prev(u64 b) { return (int)(b & 0xFFFFFF); }

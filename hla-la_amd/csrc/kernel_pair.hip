@@ -13,7 +13,7 @@ namespace hlala {
 
 constexpr int PAIR_CHAINS = 64;     // extended chains per mate
 constexpr int PAIR_COMB   = 1024;   // chain combinations per pair
-constexpr int PAIR_COLS   = 768;    // columns per chain handled by the per-position pass
+constexpr int PAIR_COLS   = 512;    // columns per chain handled by the per-position pass
 
 struct __align__(16) PairLds {
     double LL[PAIR_COMB];

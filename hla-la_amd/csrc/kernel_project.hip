@@ -15,10 +15,10 @@
 
 namespace hlala {
 
-constexpr int PROJ_CAP   = 768;     // alignment columns held in LDS (>= params.max_columns)
+constexpr int PROJ_CAP   = 512;     // alignment columns held in LDS (>= params.max_columns)
 constexpr int PROJ_OPS   = 64;      // CIGAR operations per record
-constexpr int PROJ_NODES = 1024;    // nodes per level held in LDS score rows
-constexpr int PROJ_CHLDS = 768;     // back-pointer records kept in LDS
+constexpr int PROJ_NODES = 512;     // nodes per level held in LDS score rows
+constexpr int PROJ_CHLDS = 448;     // back-pointer records kept in LDS
 
 struct ChoiceRec { int eid; short fromz; short S; };
 
@@ -85,7 +85,7 @@ __global__ void k_filter_chains(const DevGraph* __restrict__ Gp, const DevBatch*
 #define PJ_FAIL(code) do { if(P.err == 0) P.err = (code); } while(0)
 #define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
 
-__global__ __launch_bounds__(64) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
+__global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
                                                        const int* contig_level, char* slabs, size_t slabBytes)
 {
     const DevGraph& G = *Gp;
