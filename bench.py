@@ -62,9 +62,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    # one process per GPU; HLALA_BENCH_BACKEND=gloo (+ ranks sharing a device) exists only to dry-run the N > 1 plumbing on a 1-GPU box
+    backend = os.environ.get("HLALA_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     P = load_package()
@@ -86,7 +92,10 @@ def main():
         gb.align()
         gb.export_pair_records(rec.data_ptr())
         if world > 1:
-            dist.gather(rec, gathered, dst=0)
+            if backend == "nccl":
+                dist.gather(rec, gathered, dst=0)          # RCCL over xGMI: the one exchange of the path
+            else:
+                dist.gather(rec.cpu(), [g.cpu() for g in gathered] if gathered is not None else None, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -108,7 +117,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t1
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

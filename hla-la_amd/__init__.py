@@ -77,6 +77,12 @@ class PairsOut(C.Structure):
                 ("col_schar", c_u8p), ("col_fromseed", c_u8p), ("col_mapq", c_u8p)]
 
 
+class ExonIn(C.Structure):
+    _fields_ = [("n_clusters", C.c_int32), ("exon_length", C.c_int32), ("cluster_seq", c_u8p), ("n_reads", C.c_int32),
+                ("pos_off", c_i32p), ("pos_exon", c_i32p), ("pos_g0", c_u8p), ("pos_glen", c_i32p), ("pos_qual", c_u8p),
+                ("pos_use", c_u8p)]
+
+
 class BatchStats(C.Structure):
     _fields_ = [("ms_project", C.c_float), ("ms_extend", C.c_float), ("ms_pair", C.c_float),
                 ("n_chains_extended", C.c_int64), ("n_dp_calls", C.c_int64), ("n_dp_iterations", C.c_int64),
@@ -170,6 +176,8 @@ def load_library(path: str | None = None):
     lib.hlala_batch_get_pairs.argtypes = [vp, vp, C.POINTER(PairsOut)]
     lib.hlala_batch_get_stats.argtypes = [vp, vp, C.POINTER(BatchStats)]
     lib.hlala_batch_export_pair_records.argtypes = [vp, vp, vp]
+    lib.hlala_exon_loglik.argtypes = [vp, C.POINTER(ExonIn), c_f64p, c_i32p]
+    lib.hlala_pair_loglik.argtypes = [vp, c_f64p, c_i32p, C.c_int32, C.c_int32, c_f64p, c_f64p, c_f64p]
     lib.hlala_kat_phred.argtypes = [vp, C.c_int, c_f64p, c_u8p, c_u8p, c_f64p]
     lib.hlala_kat_rand_r.argtypes = [vp, C.c_int, c_u32p, c_i32p]
     if path is None:
@@ -182,7 +190,8 @@ EXPORTED_SYMBOLS = [
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
     "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
-    "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_kat_phred", "hlala_kat_rand_r",
+    "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
+    "hlala_kat_rand_r",
 ]
 
 
@@ -240,6 +249,24 @@ class Context:
         b = C.c_void_p()
         self._check(self.lib.hlala_batch_create_from_seeds(self.h, C.byref(s), C.byref(b)), "hlala_batch_create_from_seeds")
         return Batch(self, b, seeds_in["n_chains"], 0)
+
+    def exon_loglik(self, exon_in: dict):
+        """HLATyper per-cluster x per-read log-likelihoods and mismatch counts (hlala_exon_loglik)."""
+        s, keep = fill_struct(ExonIn, exon_in)
+        Cn, R = exon_in["n_clusters"], exon_in["n_reads"]
+        LL = np.zeros(Cn * R, np.float64); mism = np.zeros(Cn * R, np.int32)
+        self._check(self.lib.hlala_exon_loglik(self.h, C.byref(s), LL.ctypes.data_as(c_f64p), mism.ctypes.data_as(c_i32p)), "hlala_exon_loglik")
+        return LL.reshape(Cn, R), mism.reshape(Cn, R)
+
+    def pair_loglik(self, LL, mism):
+        """All cluster pairs c1 <= c2 in the reference's single-thread order (hlala_pair_loglik)."""
+        LL = np.ascontiguousarray(LL, np.float64); mism = np.ascontiguousarray(mism, np.int32)
+        Cn, R = LL.shape
+        n = Cn * (Cn + 1) // 2
+        out = [np.zeros(n, np.float64) for _ in range(3)]
+        self._check(self.lib.hlala_pair_loglik(self.h, LL.ctypes.data_as(c_f64p), mism.ctypes.data_as(c_i32p), Cn, R,
+                                               *[o.ctypes.data_as(c_f64p) for o in out]), "hlala_pair_loglik")
+        return out
 
     def close(self):
         if getattr(self, "h", None):

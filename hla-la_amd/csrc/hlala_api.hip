@@ -14,6 +14,7 @@
 #include "kernel_extend.hip"
 #include "kernel_project.hip"
 #include "kernel_pair.hip"
+#include "kernel_typer.hip"
 
 namespace hlala {
 size_t ext_slab_bytes_host(int stride) { return ext_slab_bytes(stride); }
@@ -577,6 +578,83 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------ HLATyper scoring
+static int typer_tables(hlala_ctx* c, std::vector<void*>& tmp, TyperTables** out)
+{
+    TyperTables T;
+    double insertionP = c->params.long_read_mode ? 0.075 : 0.001, deletionP = insertionP;          // HLATyper.cpp:935-942
+    T.ll_ins_actual = log(insertionP) + log(1.0 / 4.0);                                            // :952-954
+    T.ll_deletion = log(deletionP);                                                                // :956
+    T.ll_match_mismatch = log(1 - insertionP - deletionP);                                         // :959
+    for(int q = 0; q < 256; q++) {
+        double pCorrect = host_PhredToPCorrect((unsigned char)(q < 33 ? 33 : q));
+        if(pCorrect > 0.999) pCorrect = 0.999;                                                     // veryConservativeReadLikelihoods, :2190-2194
+        if(pCorrect == 0) pCorrect = 0.001;                                                        // :2197-2200
+        T.ll_match[q] = log(pCorrect);
+        double pIncorrect = (1 - pCorrect) * (1.0 / 3.0);
+        T.ll_mismatch[q] = log(pIncorrect);
+    }
+    return dev_upload(c, tmp, &T, 1, out);
+}
+
+extern "C" int hlala_exon_loglik(hlala_ctx* c, const hlala_exon_in* in, double* LL, int32_t* mism)
+{
+    if(!c || !in || !LL || !mism) return HLALA_E_ARG;
+    const int C = in->n_clusters, P = in->exon_length, R = in->n_reads;
+    if(C < 0 || P < 0 || R < 0) { c->err = "negative sizes"; return HLALA_E_ARG; }
+    if(C == 0 || R == 0) return HLALA_OK;
+    const size_t npos = (size_t)in->pos_off[R];
+    for(size_t i = 0; i < npos; i++) if(in->pos_exon[i] < 0 || in->pos_exon[i] >= P || in->pos_glen[i] < 1) { c->err = "exon position out of range / empty genotype"; return HLALA_E_ARG; }
+    std::vector<void*> tmp; int rc = 0;
+    auto done = [&](int r) { for(void* p : tmp) (void)hipFree(p); return r; };
+    TyperTables* dT = nullptr; if((rc = typer_tables(c, tmp, &dT))) return done(rc);
+    // cluster sequences transposed to [P][C] on the host side of the upload (one-time per locus)
+    std::vector<uint8_t> seqT((size_t)C * P);
+    for(int cc = 0; cc < C; cc++) for(int p = 0; p < P; p++) seqT[(size_t)p * C + cc] = in->cluster_seq[(size_t)cc * P + p];
+    uint8_t *dSeq, *dG0, *dQ, *dUse; int *dOff, *dExon, *dGlen, *dM; double* dLL;
+    if((rc = dev_upload(c, tmp, seqT.data(), seqT.size(), &dSeq))) return done(rc);
+    if((rc = dev_upload(c, tmp, in->pos_off, (size_t)R + 1, &dOff))) return done(rc);
+    if((rc = dev_upload(c, tmp, in->pos_exon, npos, &dExon))) return done(rc);
+    if((rc = dev_upload(c, tmp, in->pos_g0, npos, &dG0))) return done(rc);
+    if((rc = dev_upload(c, tmp, in->pos_glen, npos, &dGlen))) return done(rc);
+    if((rc = dev_upload(c, tmp, in->pos_qual, npos, &dQ))) return done(rc);
+    if((rc = dev_upload(c, tmp, in->pos_use, npos, &dUse))) return done(rc);
+    if((rc = dev_alloc(c, tmp, (size_t)C * R, &dLL))) return done(rc);
+    if((rc = dev_alloc(c, tmp, (size_t)C * R, &dM))) return done(rc);
+    hipLaunchKernelGGL(k_exon_loglik, dim3((C + 255) / 256, R), dim3(256), 0, c->stream, dT, C, P, R, dSeq, dOff, dExon, dG0, dGlen, dQ, dUse, dLL, dM);
+    if((rc = check_launch(c, "k_exon_loglik"))) return done(rc);
+    if(hipMemcpyAsync(LL, dLL, (size_t)C * R * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipMemcpyAsync(mism, dM, (size_t)C * R * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+       hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "hlala_exon_loglik: download failed"; return done(HLALA_E_DEVICE); }
+    return done(HLALA_OK);
+}
+
+extern "C" int hlala_pair_loglik(hlala_ctx* c, const double* LL, const int32_t* mism, int32_t C, int32_t R, double* pairLL, double* misAvg, double* misMin)
+{
+    if(!c || !LL || !mism || !pairLL || !misAvg || !misMin || C < 0 || R < 0) return HLALA_E_ARG;
+    if(C == 0) return HLALA_OK;
+    std::vector<void*> tmp; int rc = 0;
+    auto done = [&](int r) { for(void* p : tmp) (void)hipFree(p); return r; };
+    const size_t npairs = (size_t)C * (C + 1) / 2, nCR = (size_t)C * R;
+    double *dLL, *dLLT, *dP, *dA, *dMn; int *dM, *dMT;
+    if((rc = dev_upload(c, tmp, LL, nCR, &dLL))) return done(rc);
+    if((rc = dev_upload(c, tmp, mism, nCR, &dM))) return done(rc);
+    if((rc = dev_alloc(c, tmp, nCR, &dLLT))) return done(rc);
+    if((rc = dev_alloc(c, tmp, nCR, &dMT))) return done(rc);
+    if((rc = dev_alloc(c, tmp, npairs, &dP))) return done(rc);
+    if((rc = dev_alloc(c, tmp, npairs, &dA))) return done(rc);
+    if((rc = dev_alloc(c, tmp, npairs, &dMn))) return done(rc);
+    if(R > 0) {
+        dim3 tb(32, 32), tg((R + 31) / 32, (C + 31) / 32);
+        hipLaunchKernelGGL(k_transpose<double>, tg, tb, 0, c->stream, C, R, dLL, dLLT);
+        hipLaunchKernelGGL(k_transpose<int>, tg, tb, 0, c->stream, C, R, dM, dMT);
+    }
+    hipLaunchKernelGGL(k_pair_loglik, dim3((C + 255) / 256, C), dim3(256), 0, c->stream, C, R, dLL, dLLT, dM, dMT, dP, dA, dMn);
+    if((rc = check_launch(c, "k_pair_loglik"))) return done(rc);
+    if(hipMemcpyAsync(pairLL, dP, npairs * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipMemcpyAsync(misAvg, dA, npairs * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+       hipMemcpyAsync(misMin, dMn, npairs * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "hlala_pair_loglik: download failed"; return done(HLALA_E_DEVICE); }
+    return done(HLALA_OK);
+}
 
 // ---- known-answer kernels
 namespace hlala {

@@ -237,6 +237,32 @@ typedef struct {
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 
+/* ------------------------------------------------------------------------------------------
+ * HLATyper per-read log-likelihood scoring (hla/HLATyper.cpp).  One locus at a time.
+ * Reads are the per-read lists of hla::oneExonPosition (hla/oneExonPosition.h:16-46) that survive the
+ * HOST-side filters (mapQ_position >= 0.7, ignored alleles, ignored reads: HLATyper.cpp:2102-2121 --
+ * none of them depends on the cluster, so the host folds them into `pos_use`).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t        n_clusters;     /* C: allele clusters of the locus (HLAtype_clusters)                  */
+    int32_t        exon_length;    /* P: length of the concatenated exon string                           */
+    const uint8_t* cluster_seq;    /* [C*P] cluster_2_sequence, row-major                                 */
+    int32_t        n_reads;        /* R: exonPositions_fromReads.size()                                   */
+    const int32_t* pos_off;        /* [R+1] positions of read r: [pos_off[r], pos_off[r+1])               */
+    const int32_t* pos_exon;       /* oneExonPosition::positionInExon                                     */
+    const uint8_t* pos_g0;         /* first character of oneExonPosition::genotype                        */
+    const int32_t* pos_glen;       /* genotype.length() (>1: inserted bases appended, HLATyper.cpp:3323)  */
+    const uint8_t* pos_qual;       /* qualities.at(0)                                                     */
+    const uint8_t* pos_use;        /* 0: skipped by the host-side filters                                 */
+} hlala_exon_in;
+
+/* likelihoods_perCluster_perRead / mismatches_perCluster_perRead (hla/HLATyper.cpp:2067-2277): LL[c*R + r], mism[c*R + r] */
+int  hlala_exon_loglik(hlala_ctx* ctx, const hlala_exon_in* in, double* LL, int32_t* mism);
+/* all cluster pairs c1 <= c2 in the reference's single-thread order (hla/HLATyper.cpp:2293-2364; Utilities::logAvg,
+ * Utilities.cpp:1368-1379): pair (c1,c2) at index c1*C - c1*(c1-1)/2 + (c2-c1).  Outputs hold C*(C+1)/2 values. */
+int  hlala_pair_loglik(hlala_ctx* ctx, const double* LL, const int32_t* mism, int32_t C, int32_t R,
+                       double* pairLL, double* misAvg, double* misMin);
+
 /* Known-answer helpers exported for the parity tests (device implementations of
  * Utilities::PCorrectToPhred / PhredToPCorrect, Utilities.cpp:178-203, 357-377, and of glibc
  * rand_r as used by Utilities::randomNumber_nonCritical, Utilities.cpp:922).                 */

@@ -1371,6 +1371,78 @@ int orc_align_batch(orc_handle* h, const hlala_batch_in* in, hlala_chains_out* s
     } catch(std::exception& e) { g_err = e.what(); return -1; }
 }
 
+/* HLATyper per-cluster x per-read log-likelihood and mismatch count, hla/HLATyper.cpp:2067-2277 (parameters :935-959).
+ * The position filters of :2102-2121 are cluster-independent and arrive folded into pos_use. */
+int orc_exon_loglik(const hlala_exon_in* in, int long_read_mode, double* LL, int32_t* mism)
+{
+    double insertionP = long_read_mode ? 0.075 : 0.001, deletionP = insertionP;
+    double log_likelihood_insertion = log(insertionP);
+    double log_likelihood_insertion_actualAllele = log_likelihood_insertion + log(1.0 / 4.0);
+    double log_likelihood_deletion = log(deletionP);
+    double log_likelihood_match_mismatch = log(1 - insertionP - deletionP);
+    const int C = in->n_clusters, P = in->exon_length, R = in->n_reads;
+    for(int clusterI = 0; clusterI < C; clusterI++) {
+        const unsigned char* clusterSequence = in->cluster_seq + (size_t)clusterI * P;
+        for(int readI = 0; readI < R; readI++) {
+            double log_likelihood_read = 0; int mismatches = 0;
+            for(int i = in->pos_off[readI]; i < in->pos_off[readI + 1]; i++) {
+                if(!in->pos_use[i]) continue;
+                double log_likelihood_position = 0;
+                char exonGenotype = (char)clusterSequence[in->pos_exon[i]];
+                std::string readGenotype(1, (char)in->pos_g0[i]);
+                readGenotype.append((size_t)(in->pos_glen[i] - 1), 'N');          /* inserted bases: only their count matters */
+                unsigned int l_diff = (unsigned int)readGenotype.length() - 1;
+                if(exonGenotype == '_') {
+                    if(readGenotype == "_") { /* intrinsic graph gap, likelihood 1 */ }
+                    else log_likelihood_position += (log_likelihood_insertion_actualAllele * (1 + l_diff));
+                } else {
+                    if(readGenotype[0] == '_') log_likelihood_position += log_likelihood_deletion;
+                    else {
+                        log_likelihood_position += log_likelihood_match_mismatch;
+                        double pCorrect = PhredToPCorrect(in->pos_qual[i]);
+                        if(pCorrect > 0.999) pCorrect = 0.999;
+                        if(pCorrect == 0) pCorrect = 0.001;
+                        if(exonGenotype == readGenotype[0]) log_likelihood_position += log(pCorrect);
+                        else { double pIncorrect = (1 - pCorrect) * (1.0 / 3.0); log_likelihood_position += log(pIncorrect); }
+                    }
+                    log_likelihood_position += (log_likelihood_insertion_actualAllele * l_diff);
+                }
+                if(readGenotype != "_") if(readGenotype != std::string(1, exonGenotype)) mismatches++;
+                log_likelihood_read += log_likelihood_position;
+            }
+            LL[(size_t)clusterI * R + readI] = log_likelihood_read;
+            mism[(size_t)clusterI * R + readI] = mismatches;
+        }
+    }
+    return 0;
+}
+
+/* Utilities::logAvg, Utilities.cpp:1368-1379 */
+static double logAvg(double a, double b)
+{
+    if(a > b) return (log(0.5) + (log(1 + exp(b - a)) + a));
+    return (log(0.5) + (log(1 + exp(a - b)) + b));
+}
+
+/* all cluster pairs in single-thread order, hla/HLATyper.cpp:2293-2364 */
+int orc_pair_loglik(const double* LL, const int32_t* mism, int C, int R, double* pairLL, double* misAvg, double* misMin)
+{
+    size_t idx = 0;
+    for(int c1 = 0; c1 < C; c1++)
+        for(int c2 = c1; c2 < C; c2++) {
+            double mismatches_sum_averages = 0, mismatches_sum_min = 0, pair_log_likelihood = 0;
+            for(int readI = 0; readI < R; readI++) {
+                double a = LL[(size_t)c1 * R + readI], b = LL[(size_t)c2 * R + readI];
+                int m1 = mism[(size_t)c1 * R + readI], m2 = mism[(size_t)c2 * R + readI];
+                mismatches_sum_averages += ((double)(m1 + m2) / 2.0);
+                mismatches_sum_min += ((m1 < m2) ? m1 : m2);
+                pair_log_likelihood += logAvg(a, b);
+            }
+            pairLL[idx] = pair_log_likelihood; misAvg[idx] = mismatches_sum_averages; misMin[idx] = mismatches_sum_min; idx++;
+        }
+    return 0;
+}
+
 /* PRGContigAlignment2Seed over column alignments handed in as seeds_in columns WITHOUT edges
  * (the simulateBAMAlignments route of --action testAlignments2Chains / testChainExtension,
  * HLA-LA.cpp:1622-1861): seq_begin/seq_end play sequence_aligned_{start,stop}InRaw. */

@@ -32,6 +32,8 @@ def lib():
         _lib.orc_intervals_overlap.argtypes = [C.c_int] * 4
         _lib.orc_phred.argtypes = [C.c_int, P.c_f64p, P.c_u8p, P.c_u8p, P.c_f64p]
         _lib.orc_rand_r.argtypes = [C.c_int, P.c_u32p, P.c_i32p]
+        _lib.orc_exon_loglik.argtypes = [C.POINTER(P.ExonIn), C.c_int, P.c_f64p, P.c_i32p]
+        _lib.orc_pair_loglik.argtypes = [P.c_f64p, P.c_i32p, C.c_int, C.c_int, P.c_f64p, P.c_f64p, P.c_f64p]
         _lib.orc_normal_logpdf_penalty.argtypes = [C.c_double, C.c_double]
         _lib.orc_normal_logpdf_penalty.restype = C.c_double
     return _lib
@@ -39,6 +41,22 @@ def lib():
 
 class OracleError(RuntimeError):
     pass
+
+
+def exon_loglik(exon_in, long_read_mode=0):
+    s, keep = P.fill_struct(P.ExonIn, exon_in)
+    Cn, R = exon_in["n_clusters"], exon_in["n_reads"]
+    LL = np.zeros(Cn * R, np.float64); mism = np.zeros(Cn * R, np.int32)
+    lib().orc_exon_loglik(C.byref(s), long_read_mode, LL.ctypes.data_as(P.c_f64p), mism.ctypes.data_as(P.c_i32p))
+    return LL.reshape(Cn, R), mism.reshape(Cn, R)
+
+
+def pair_loglik(LL, mism):
+    LL = np.ascontiguousarray(LL, np.float64); mism = np.ascontiguousarray(mism, np.int32)
+    Cn, R = LL.shape
+    out = [np.zeros(Cn * (Cn + 1) // 2, np.float64) for _ in range(3)]
+    lib().orc_pair_loglik(LL.ctypes.data_as(P.c_f64p), mism.ctypes.data_as(P.c_i32p), Cn, R, *[o.ctypes.data_as(P.c_f64p) for o in out])
+    return out
 
 
 class Oracle:

@@ -365,3 +365,37 @@ def make_batch_fast(world, n_pairs, seed=3, read_len=150, ins_mean=200.0, ins_sd
         chain_as=ras.astype(np.int32), chain_reverse=rev[rread].astype(np.uint8),
         cigar_off=cigar_off.astype(np.int32), cigar=cigar, truth_level0=lv0.astype(np.int32),
         insert_mean=float(ins_mean), insert_sd=float(ins_sd))
+
+
+def make_locus(seed=5, n_clusters=200, exon_length=546, n_reads=300, snp_density=0.03, gap_frac=0.01, read_cover=140, p_unused=0.05):
+    """Synthetic HLATyper input for one locus (hlala_exon_in layout): allele clusters that differ at SNP sites from a
+    consensus exon string, reads drawn from two of the clusters with quality-dependent errors, occasional deletions
+    ('_' genotypes), insertions (genotype length > 1) and host-filtered positions (pos_use = 0)."""
+    rng = np.random.default_rng(seed)
+    nuc = np.frombuffer(b"ACGT", dtype=np.uint8)
+    cons = nuc[rng.integers(0, 4, exon_length)]
+    seqs = np.tile(cons, (n_clusters, 1))
+    snp = rng.random((n_clusters, exon_length)) < snp_density
+    seqs[snp] = nuc[rng.integers(0, 4, int(snp.sum()))]
+    gaps = rng.random((n_clusters, exon_length)) < gap_frac
+    seqs[gaps] = ord("_")
+    truth = rng.integers(0, n_clusters, 2)
+    pos_off = [0]; pe, g0, gl, q, use = [], [], [], [], []
+    for r in range(n_reads):
+        src = seqs[truth[r % 2]]
+        start = int(rng.integers(0, max(1, exon_length - read_cover)))
+        n = int(min(read_cover, exon_length - start))
+        for p in range(start, start + n):
+            base = src[p]
+            qual = int(np.clip(40 - rng.geometric(0.25) + 1, 2, 40))
+            if base != ord("_") and rng.random() < 10 ** (-qual / 10):
+                base = nuc[rng.integers(0, 4)]
+            if base != ord("_") and rng.random() < 0.002:
+                base = ord("_")                                   # deletion in the read
+            glen = 1 + (int(rng.integers(1, 4)) if (base != ord("_") and rng.random() < 0.003) else 0)
+            pe.append(p); g0.append(base); gl.append(glen); q.append(qual + 33); use.append(0 if rng.random() < p_unused else 1)
+        pos_off.append(len(pe))
+    return dict(n_clusters=n_clusters, exon_length=exon_length, cluster_seq=seqs.reshape(-1).astype(np.uint8), n_reads=n_reads,
+                pos_off=np.asarray(pos_off, np.int32), pos_exon=np.asarray(pe, np.int32), pos_g0=np.asarray(g0, np.uint8),
+                pos_glen=np.asarray(gl, np.int32), pos_qual=np.asarray(q, np.uint8), pos_use=np.asarray(use, np.uint8),
+                truth=truth)
