@@ -54,7 +54,7 @@ struct DevTables {
 constexpr int DP_WCAP      = 128;    // frontier cells per diagonal list
 constexpr int DP_HC        = 512;    // candidate-target hash entries per iteration
 constexpr int DP_SEQCAP    = 1024;   // read length staged in LDS
-constexpr int DP_CELLS     = 16384;  // kept cells per DP call (global slab)
+constexpr int DP_CELLS     = 16384;  // kept cells per DP call (global slab); < 32768 so slots fit a short
 constexpr int DP_EARLY     = 4096;   // hash entries for cells reached early through gap-path jumps
 constexpr int DP_STEPS     = 8192;   // backtrace steps
 constexpr int DP_COMPLETED = 2048;   // sequence-complete cells

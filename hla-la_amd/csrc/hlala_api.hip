@@ -235,7 +235,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, device) != hipSuccess) { c->err = "hipGetDeviceProperties failed"; return fail(HLALA_E_DEVICE); }
     int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->ext_grid = cus * 14;
+    c->ext_grid = cus * 20;
     c->retry_grid = cus;
     c->ext_slab_bytes = ext_slab_bytes_host(c->params.max_columns);
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }

@@ -25,8 +25,8 @@ constexpr int DP_IMPCAP = 2048;    // staged improvements of existing cells per 
 
 // Two capacity classes: the small one serves almost every chain at 6-7 blocks per CU; chains whose frontier /
 // candidate set outgrows it (long runs of parallel gap paths) are re-run by the large one (one block per CU).
-struct DpSmall { static constexpr int WCAP = 64,      HC = 256,   IBITS = 7;  typedef u32 Best; };
-struct DpLarge { static constexpr int WCAP = 1024,    HC = 2048,  IBITS = 10; typedef u64 Best; };
+struct DpSmall { static constexpr int WCAP = 64,      HC = 128,   IBITS = 7,  SEQCAP = 512;       typedef u32 Best; };
+struct DpLarge { static constexpr int WCAP = 1024,    HC = 2048,  IBITS = 10, SEQCAP = DP_SEQCAP; typedef u64 Best; };
 
 template <class C>
 struct __align__(16) DpLdsT {
@@ -34,10 +34,10 @@ struct __align__(16) DpLdsT {
     typename C::Best hbest[3][C::HC];
     unsigned short tlist[C::HC];
     u64 fkey[3][C::WCAP];
-    int fslot[3][C::WCAP];
+    short fslot[3][C::WCAP];        // table slot of the frontier cell
     short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
-    unsigned char seq[DP_SEQCAP];
-    int tes[C::HC];                 // per target: existing / assigned table slot
+    unsigned char seq[C::SEQCAP];
+    short tes[C::HC];               // per target: existing / assigned table slot (-1 = none; DP_CELLS <= 32767)
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     int nT, nNew, nImp, nKeepF, err, nCompletedAdd;
 };
@@ -328,7 +328,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                     int h = S.tlist[t];
                     int Dv = max(best_score(S.hbest[M_D][h]), max(best_score(S.hbest[M_GG][h]), best_score(S.hbest[M_SG][h])));
                     if(Dv >= -16) es = early_lookup(sl, S.hkey[h]);
-                    S.tes[t] = es;
+                    S.tes[t] = (short)es;
                 }
                 if(__ballot(es >= 0)) anyExisting = true;
             }
@@ -432,7 +432,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                 }
                 if(pass == 0 && slow) {
                     // exact diff needs every staged improvement of the iteration: finish in the second pass
-                    if(act) { S.tes[t] = slot; S.timp[t] = (unsigned char)(impMask | (isNew ? 0x80 : 0)); }
+                    if(act) { S.tes[t] = (short)slot; S.timp[t] = (unsigned char)(impMask | (isNew ? 0x80 : 0)); }
                     continue;
                 }
                 if(__ballot(impMask != 0)) anyOw = true;
@@ -520,7 +520,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
                     if((mx - vu) <= 15 && S.hkey[hu] < key) rank++;
                 }
                 if(rank < C::WCAP) {
-                    S.fkey[bn][rank] = key; S.fslot[bn][rank] = (int)S.hbest[0][h];
+                    S.fkey[bn][rank] = key; S.fslot[bn][rank] = (short)(int)S.hbest[0][h];
                     S.fD[bn][rank] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][rank] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][rank] = (short)((u32)S.hbest[2][h] & 0xFFFF);
                 }
             }
@@ -648,7 +648,7 @@ __device__ DpResult dp_run(const DevGraph& G, DpLdsT<C>& S, const ExtSlab& sl, i
 // one wave per chain: left DP, right DP, stitch (extendWithOtherSeedChain / extendToFullSequenceLength,
 // verboseSeedChain.cpp:23-136), then scoreOneAlignment (extensionAligner.cpp:52-182).
 template <class C, bool RETRY>
-__global__ __launch_bounds__(64, 4) void k_extend_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp, char* slabs, size_t slabBytes, u32 rng_seed)
+__global__ __launch_bounds__(64, 5) void k_extend_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp, char* slabs, size_t slabBytes, u32 rng_seed)
 {
     // graph / batch descriptors stay in memory (scalar loads on demand): passing them by value costs ~150 SGPRs
     const DevGraph& G = *Gp;
@@ -674,7 +674,8 @@ __global__ __launch_bounds__(64, 4) void k_extend_chains(const DevGraph* __restr
         const size_t cb = (size_t)c * stride;
         const int nSeed = uni(B.seed_ncols[c]), sBegin = uni(B.seed_begin[c]), sEnd = uni(B.seed_end[c]);
         int err = 0;
-        if(seqLen > DP_SEQCAP || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;
+        if(seqLen > C::SEQCAP && !RETRY && seqLen <= DP_SEQCAP && nSeed >= 1) err = HLALA_CHAIN_ERR_FRONTIER;      // long read: large class
+        else if(seqLen > C::SEQCAP || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;
         if(!err) for(int i = lane; i < seqLen; i += 64) S.seq[i] = B.read_bases[rOff + i];
         WSYNC();
         DpResult RL, RR; RL.have = 0; RL.ncols = 0; RL.iters = 0; RL.score = INT32_MIN; RL.err = 0; RL.seq_begin = 0; RL.seq_end = -1; RL.cells = 0; RL.edges = 0; RR = RL;
@@ -731,30 +732,42 @@ __global__ __launch_bounds__(64, 4) void k_extend_chains(const DevGraph* __restr
         // The read quality of alignment-orientation base i is read_quals[i] in both strands: the reference indexes the
         // ORIGINAL-orientation read with len-i-1 when the chain is reverse (extensionAligner.cpp:85-88), which is the same base.
         {
+            // phase 1 (parallel): every lane turns its <= 8 consecutive columns into two addends each (an unused addend is +0.0,
+            // an exact identity); phase 2 (serial by construction of FP addition): the running sum walks the lanes in order.
+            constexpr int LLPER = 8;                                   // 64 * 8 = 512 >= params.max_columns
             const int per = (total + 63) / 64;
             const int j0 = lane * per, j1 = min(total, j0 + per);
-            // number of read bases before column j0
+            unsigned char scv[LLPER], gcv[LLPER];
             int nb = 0;
-            for(int j = j0; j < j1; j++) if(B.ext_s[cb + j] != '_') nb++;
+#pragma unroll
+            for(int k = 0; k < LLPER; k++) {
+                int j = j0 + k; bool in = k < per && j < j1;
+                scv[k] = in ? B.ext_s[cb + j] : (unsigned char)'_'; gcv[k] = in ? B.ext_g[cb + j] : (unsigned char)'_';
+                if(in && scv[k] != '_') nb++;
+            }
             int tot; int before = wave_excl_scan(nb, tot);
+            double t1[LLPER], t2[LLPER];
+            {
+                int idx = before;
+#pragma unroll
+                for(int k = 0; k < LLPER; k++) {
+                    unsigned char sc = scv[k], gc = gcv[k];
+                    double a1 = 0.0, a2 = 0.0;
+                    if(sc != '_') {
+                        if(gc == '_') a1 = T.rate_ins_quarter;
+                        else { a1 = T.rate_match_mismatch; unsigned char q = B.read_quals[rOff + idx]; a2 = (sc == gc) ? T.ll_match[q] : T.ll_mismatch[q]; }
+                        idx++;
+                    } else if(gc != '_') a1 = T.rate_indel;
+                    t1[k] = a1; t2[k] = a2;
+                }
+            }
             double acc = 0.0;
             for(int l = 0; l < 64; l++) {
                 double in = __shfl(acc, l > 0 ? l - 1 : 0);
                 if(lane == l) {
                     double a = (l == 0) ? 0.0 : in;
-                    int idx = before;
-                    for(int j = j0; j < j1; j++) {
-                        unsigned char sc = B.ext_s[cb + j], gc = B.ext_g[cb + j];
-                        if(sc != '_') {
-                            if(gc == '_') a += T.rate_ins_quarter;
-                            else {
-                                a += T.rate_match_mismatch;
-                                unsigned char q = B.read_quals[rOff + idx];
-                                a += (sc == gc) ? T.ll_match[q] : T.ll_mismatch[q];
-                            }
-                            idx++;
-                        } else if(gc != '_') a += T.rate_indel;
-                    }
+#pragma unroll
+                    for(int k = 0; k < LLPER; k++) { a += t1[k]; a += t2[k]; }
                     acc = a;
                 }
             }

@@ -20,4 +20,4 @@ names = ['gen', 'eval', 'filter', 'iters', 'select+backtrace', 'stitch+LL', 'cha
 print({n: float(v) for n, v in zip(names, d)})
 it = d[3]; ch = d[7]
 print('cycles/iter: gen %.0f eval %.0f filter %.0f | per chain: select+bt %.0f stitch+LL %.0f total %.0f | iters/chain %.1f' % (d[0]/it, d[1]/it, d[2]/it, d[4]/ch, d[5]/ch, d[6]/ch, it/ch))
-print('ms', st.ms_project, st.ms_extend, st.ms_pair, 'pairs/s', n_pairs/((st.ms_project+st.ms_extend+st.ms_pair)*1e-3))
+print('retry ms', st.ms_extend_retry, 'retried', st.n_chains_retried, 'errors', st.n_errors); print('ms', st.ms_project, st.ms_extend, st.ms_pair, 'pairs/s', n_pairs/((st.ms_project+st.ms_extend+st.ms_pair)*1e-3))

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 make -C oracle 2>&1 | tail -1
 timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-timeout 300 python tools/dbg_timing.py 131072 2000000 2>&1 | tail -1
+timeout 300 python tools/dbg_timing.py 262144 5000000 2>&1 | tail -2
+HLALA_DEBUG=1 timeout 300 python tools/dbg_timing.py 131072 2000000 2>&1 | tail -3 | head -1
