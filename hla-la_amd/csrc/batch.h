@@ -55,7 +55,7 @@ struct DevBatch {
     uint8_t* strands_valid;
     uint8_t* sel_mapq;              // [n_reads*stride] mapQ_perPosition of the selected chain
     // ---- counters (device): see hlala_batch_stats
-    u64* counters;                  // [16]
+    u64* counters;                  // [32]
     int* work_counter;              // [8] dynamic work distribution: [0..2] stages A-C, [3] retry count, [4] retry fetch
     int* retry_list;                // [n_chains] chains whose DP outgrew the small capacity class
     int* dbg;                       // host-mapped progress words (HLALA_DEBUG=1), else null

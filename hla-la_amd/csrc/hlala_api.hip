@@ -42,7 +42,7 @@ struct hlala_ctx {
     int n_contigs = 0; std::vector<long long> contig_off;
     std::vector<void*> allocs;
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0;
-    char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0;
+    char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     hipEvent_t ev[7]{};           // start/end per stage, [6] = between the two extension passes
     int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
     std::string err;
@@ -240,7 +240,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->ext_slab_bytes = ext_slab_bytes_host(c->params.max_columns);
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->ext_slabs);
-    c->proj_grid = cus * 14;
+    c->proj_grid = cus * 9; c->pair_grid = cus * 14;
     c->proj_slab_bytes = proj_slab_bytes_host(c->params.max_columns, F.max_nodes_per_level);
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
@@ -312,7 +312,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
-    AL(counters, 16, true); AL(work_counter, 8, true); AL(retry_list, nc, false);
+    AL(counters, 32, true); AL(work_counter, 8, true); AL(retry_list, nc, false);
     B.dbg = c->dbg_host;
 #undef AL
     return 0;
@@ -420,7 +420,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 8 * sizeof(int), c->stream));
-    HIP_TRY(c, hipMemsetAsync(B.counters, 0, 16 * sizeof(u64), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if(B.n_chains > 0) {
         int threads = 256, blocks = (B.n_reads + threads - 1) / threads;
@@ -442,7 +442,7 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 3, 0, 2 * sizeof(int), c->stream));
-    if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 16 * sizeof(u64), c->stream));
+    if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if(B.n_chains > 0) {
         int grid = B.n_chains < c->ext_grid ? B.n_chains : c->ext_grid;
@@ -468,7 +468,7 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
     if(B.n_pairs > 0) {
-        int grid = B.n_pairs < c->proj_grid ? B.n_pairs : c->proj_grid;
+        int grid = B.n_pairs < c->pair_grid ? B.n_pairs : c->pair_grid;
         hipLaunchKernelGGL(k_pair_chains, dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);
         int rc = check_launch(c, "k_pair_chains"); if(rc) return rc;
     }
@@ -670,11 +670,11 @@ __global__ void k_kat_rand(int n, u32* seeds, int* vals)
 }
 }  // namespace hlala
 
-extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long long* out16)
+extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long long* out32)
 {
     if(!c || !b) return HLALA_E_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out16, b->B.counters, 16 * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out32, b->B.counters, 32 * sizeof(u64), hipMemcpyDeviceToHost));
     return HLALA_OK;
 }
 

@@ -8,8 +8,10 @@
 //        cleanInitialAlignment                                                  :4621-4792
 //        restrictInitialAlignmentToNoGapAreas                                   :4461-4619
 //        re-threading DP (sequence variant) + deterministic backtrace           :2676-3007
-//      Columns live in LDS; the per-node back pointers of the re-threading DP live in LDS when the
-//      node range of the chain is small (the common case) and in the wave's HBM slab otherwise.
+//      Columns live in LDS.  The chain's window of the in-edge CSR (level offsets, edge offsets, from-nodes,
+//      labels) is staged into LDS once and the per-node back pointers stay there too (the common case);
+//      windows that exceed PROJ_SN nodes / PROJ_SE edges run the same recurrence against HBM with the
+//      back pointers in the wave's slab.
 #include "batch.h"
 #include "../../include/hlala_gpu.h"
 
@@ -18,17 +20,25 @@ namespace hlala {
 constexpr int PROJ_CAP   = 512;     // alignment columns held in LDS (>= params.max_columns)
 constexpr int PROJ_OPS   = 64;      // CIGAR operations per record
 constexpr int PROJ_NODES = 512;     // nodes per level held in LDS score rows
-constexpr int PROJ_CHLDS = 448;     // back-pointer records kept in LDS
+constexpr int PROJ_SN    = 640;     // nodes of a chain's level window staged in LDS (CSR offsets + back pointers)
+constexpr int PROJ_SE    = 768;     // in-edges of that window staged in LDS
+constexpr int PROJ_SEGMAX = 24;     // longest run of multi-node levels one lane solves alone
 
 struct ChoiceRec { int eid; short fromz; short S; };
 
 struct __align__(16) ProjLds {
     int lvl[2][PROJ_CAP];
     unsigned char g[2][PROJ_CAP], s[2][PROJ_CAP];
-    int opColStart[PROJ_OPS + 1], opRefStart[PROJ_OPS], opReadStart[PROJ_OPS];
-    unsigned char opType[PROJ_OPS];
     short Srow[2][PROJ_NODES];
-    ChoiceRec ch[PROJ_CHLDS];
+    // the chain's window of the in-edge CSR, staged once so that the per-column recurrence never leaves LDS
+    unsigned short sLev[PROJ_CAP + 2];      // level_off[level0 + i] - nodeBase
+    unsigned short sIn[PROJ_SN + 1];        // in_off[tgtBase + i] - eBase
+    unsigned short sChoice[PROJ_SN];        // per target node: chosen in-edge (index into the window), 0xFFFF = unreachable
+    unsigned short sFrom[PROJ_SE];          // in_from[eBase + e] - nodeBase
+    unsigned char sLab[PROJ_SE];
+    u32 colInfo[PROJ_CAP];                  // per level of the window: column | read char << 16 | seed-is-match << 24
+    unsigned short segStart[PROJ_CAP + 2];  // level indices where a DP segment starts (single-node levels, see below)
+    u64 mGap[PROJ_CAP / 64], mDef[PROJ_CAP / 64], mSeq[PROJ_CAP / 64];     // column bit masks of the restrict step
     int err, n, startRaw, stopRaw, tmp0, tmp1;
 };
 
@@ -83,9 +93,10 @@ __global__ void k_filter_chains(const DevGraph* __restrict__ Gp, const DevBatch*
 }
 
 #define PJ_FAIL(code) do { if(P.err == 0) P.err = (code); } while(0)
+#define PJ_T(i) do { if(B.dbg) tPh[i] = clock64(); } while(0)      // HLALA_DEBUG phase clocks -> counters[16..23]
 #define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
 
-__global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
+__global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
                                                        const int* contig_level, char* slabs, size_t slabBytes)
 {
     const DevGraph& G = *Gp;
@@ -96,6 +107,7 @@ __global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __rest
     const int slabEnt = (int)(slabBytes / sizeof(ChoiceRec));
     const int stride = B.stride;
 
+    long long tAcc[7] = {0, 0, 0, 0, 0, 0, 0};
     for(;;) {
         const int c = next_work(&B.work_counter[0]);
         if(c >= B.n_chains) break;
@@ -108,12 +120,16 @@ __global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __rest
         const int cg0 = uni(B.cigar_off[c]), nOps = uni(B.cigar_off[c + 1]) - cg0;
         if(lane == 0) { P.err = 0; }
         WSYNC();
+        long long tPh[7] = {0, 0, 0, 0, 0, 0, 0};
 
+        PJ_T(0);
         // ---------------- CIGAR walk (transformBAMreadToInternalAlignment, :4794-5337)
         // Columns are the M/=/X/D/I operations in CIGAR order: M -> (ref, read), D -> (ref, '_'), I -> (-1, '_', read);
         // S advances the read index, H only counts at the very start (:4868-4874), P is dropped (:4814-4828), N throws (:5167).
         if(nOps < 1 || nOps > PROJ_OPS) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
         int nCols = 0;
+        // one CIGAR operation per lane; the per-operation starts stay in registers and are broadcast with readlane
+        int opK = 6, opLen = 0, opCol = 0, opRef = 0, opRead = 0;
         if(nOps >= 1 && nOps <= PROJ_OPS) {
             u32 cg = lane < nOps ? B.cigar[cg0 + lane] : 0;
             int op = (int)(cg & 15u), len = (int)(cg >> 4);
@@ -128,16 +144,15 @@ __global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __rest
             int colStart = wave_excl_scan(isCol ? len : 0, tc);
             int refStart = wave_excl_scan(useRef ? len : 0, tr);
             int readStart = wave_excl_scan(useRead ? len : 0, tq) + leadH;
+            opK = op; opLen = len; opCol = colStart; opRef = refStart; opRead = readStart;
             if(lane < nOps) {
-                P.opColStart[lane] = colStart; P.opRefStart[lane] = refStart; P.opReadStart[lane] = readStart; P.opType[lane] = (unsigned char)op;
                 if(op == 3 || op > 8) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
                 // an insertion must follow a column operation or open the alignment (assert(index_along_read == 0), :5086)
                 if(op == 1 && colStart > 0 && lane > 0) {
-                    int pop = (int)(B.cigar[cg0 + lane - 1] & 15u);
+                    int pop = __shfl_up(op, 1);
                     if(!(pop == 0 || pop == 7 || pop == 8 || pop == 2 || pop == 1)) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
                 }
             }
-            if(lane == 0) P.opColStart[nOps] = tc;
             nCols = tc;
             // first / last column operation give sequence_aligned_{start,stop}InRaw (:5197-5203)
             u64 colMask = __ballot(isCol && len > 0);
@@ -152,29 +167,32 @@ __global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __rest
         }
         WSYNC();
         if(PJ_OK()) {
-            for(int j = lane; j < nCols; j += 64) {
-                int o = 0;
-                while(o + 1 < nOps && P.opColStart[o + 1] <= j) o++;
-                while(P.opColStart[o + 1] == P.opColStart[o] && o + 1 < nOps) o++;       // skip non-column ops
-                int k = j - P.opColStart[o]; int op = P.opType[o];
-                int lv = -1; unsigned char gc = '_', sc = '_';
-                if(op != 1) {
-                    int refpos = pos + P.opRefStart[o] + k;
-                    int ti = refpos - tOffset;
-                    if(refpos < 0 || refpos >= cLen || ti < 0 || ti >= cLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
-                    else { gc = contig_seq[cOff + refpos]; lv = contig_level[cOff + ti]; }
+            for(int o = 0; o < nOps; o++) {
+                const int op = __builtin_amdgcn_readlane(opK, o), olen = __builtin_amdgcn_readlane(opLen, o);
+                if(!(op == 0 || op == 7 || op == 8 || op == 2 || op == 1)) continue;
+                const int ocs = __builtin_amdgcn_readlane(opCol, o), ors = __builtin_amdgcn_readlane(opRef, o), oqs = __builtin_amdgcn_readlane(opRead, o);
+                for(int k = lane; k < olen; k += 64) {
+                    int lv = -1; unsigned char gc = '_', sc = '_';
+                    if(op != 1) {
+                        int refpos = pos + ors + k;
+                        int ti = refpos - tOffset;
+                        if(refpos < 0 || refpos >= cLen || ti < 0 || ti >= cLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+                        else { gc = contig_seq[cOff + refpos]; lv = contig_level[cOff + ti]; }
+                    }
+                    if(op != 2) {
+                        int ri = oqs + k;
+                        if(ri < 0 || ri >= readLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); } else sc = B.read_bases[rOff + ri];
+                    }
+                    const int j = ocs + k;
+                    P.lvl[0][j] = lv; P.g[0][j] = gc; P.s[0][j] = sc;
                 }
-                if(op != 2) {
-                    int ri = P.opReadStart[o] + k;
-                    if(ri < 0 || ri >= readLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); } else sc = B.read_bases[rOff + ri];
-                }
-                P.lvl[0][j] = lv; P.g[0][j] = gc; P.s[0][j] = sc;
             }
         }
         WSYNC();
         if(PJ_OK() && !(uni(P.startRaw) < uni(P.stopRaw))) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }        // :5252
         WSYNC();
 
+        PJ_T(1);
         // ---------------- trim leading / trailing insertion columns, pad skipped levels (:2518-2579)
         int n1 = 0;
         if(PJ_OK()) {
@@ -217,6 +235,7 @@ __global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __rest
         WSYNC();
         int cur = 1;       // buffer holding the current columns
 
+        PJ_T(2);
         // ---------------- cleanInitialAlignment (:4621-4792) -- only when an insertion or a double-gap column exists
         int removed = 0;
         if(PJ_OK()) {
@@ -262,116 +281,246 @@ __global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __rest
         }
         WSYNC();
 
+        PJ_T(3);
         // ---------------- restrictInitialAlignmentToNoGapAreas (:4461-4619) -- only when a gap-stretch level is touched
         if(PJ_OK()) {
-            bool any = false;
-            for(int j0 = 0; j0 < n1; j0 += 64) {
-                int j = j0 + lane; bool in = false;
-                if(j < n1) { int l = P.lvl[cur][j]; if(l != -1) { if(l < 0 || l >= G.L - 1) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); else in = G.gap_stretch[l] != 0; } }
-                if(__ballot(in)) any = true;
+            // three bit masks per 64 columns (gap-stretch level / defined level / read character) carry all the step needs
+            bool any = false; int seqChars = 0;
+            const int nW = (n1 + 63) >> 6;
+            for(int k = 0; k < nW; k++) {
+                int j = k * 64 + lane; bool in = false, def = false, sq = false;
+                if(j < n1) {
+                    int l = P.lvl[cur][j]; def = (l != -1); sq = (P.s[cur][j] != '_');
+                    if(def) { if(l < 0 || l >= G.L - 1) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); else in = G.gap_stretch[l] != 0; }
+                }
+                u64 mg = __ballot(in), md = __ballot(def), ms = __ballot(sq);
+                if(mg) any = true;
+                seqChars += __popcll(ms);
+                if(lane == 0) { P.mGap[k] = mg; P.mDef[k] = md; P.mSeq[k] = ms; }
             }
             WSYNC();
             if(any && PJ_OK()) {
-                if(lane == 0) {
-                    int* lv = P.lvl[cur]; unsigned char* ga = P.g[cur]; unsigned char* sa = P.s[cur];
-                    int runBegin = -1, seqChars = 0, bestA = -1, bestB = -1, bestLen = 0;
-                    auto consider = [&](int a, int b) {                                     // trim -1 ends (:4507-4531), keep the LAST longest (:4533-4552)
-                        while(lv[a] == -1) { a++; if(a > b || a > n1 - 1) break; }
-                        if(a <= b) while(lv[b] == -1) { b--; if(b < a || b < 0) break; }
-                        if(b >= a) { int len = b - a + 1; if(len >= bestLen) { bestLen = len; bestA = a; bestB = b; } }
-                    };
-                    for(int p = 0; p < n1; p++) {
-                        if(sa[p] != '_') seqChars++;
-                        int l = lv[p];
-                        if(l != -1 && G.gap_stretch[l]) { if(runBegin != -1) { consider(runBegin, p - 1); runBegin = -1; } }
-                        else if(runBegin == -1) runBegin = p;
+                // every lane runs the same scalar walk over the masks (uniform control flow, no divergence)
+                auto bitOf = [&](const u64* m, int p) -> bool { return (m[p >> 6] >> (p & 63)) & 1ull; };
+                auto nextSet = [&](const u64* m, int p, int hi) -> int {                  // first set bit in [p, hi], else hi + 1
+                    while(p <= hi) { u64 w = m[p >> 6] >> (p & 63); if(w) { int q = p + __ffsll((long long)w) - 1; return q <= hi ? q : hi + 1; } p = (p | 63) + 1; }
+                    return hi + 1; };
+                auto prevSet = [&](const u64* m, int p, int lo) -> int {                  // last set bit in [lo, p], else lo - 1
+                    while(p >= lo) { u64 w = m[p >> 6] << (63 - (p & 63)); if(w) { int q = p - __clzll((long long)w); return q >= lo ? q : lo - 1; } p = (p & ~63) - 1; }
+                    return lo - 1; };
+                auto countSeq = [&](int a, int b) -> int {                                 // read characters in [a, b]
+                    int n = 0;
+                    for(int k = (a >> 6); k <= (b >> 6) && a <= b; k++) {
+                        u64 w = P.mSeq[k]; int lo = k * 64, hi = lo + 63;
+                        if(a > lo) w &= ~0ull << (a - lo);
+                        if(b < hi) w &= ~0ull >> (hi - b);
+                        n += __popcll(w);
                     }
-                    if(runBegin != -1 && runBegin != 0) consider(runBegin, n1 - 1);          // a stretch starting at column 0 that reaches the end is not recorded (:4492-4502)
-                    int w = n1;
-                    if(bestLen > 0) {
-                        int ns = P.startRaw, ne = P.stopRaw, sc = 0;
-                        for(int p = 0; p < bestA; p++) if(sa[p] != '_') ns++;
-                        for(int p = bestB + 1; p < n1; p++) if(sa[p] != '_') ne--;
-                        for(int p = bestA; p <= bestB; p++) if(sa[p] != '_') sc++;
-                        if(((double)sc / (double)seqChars) > 0.3) {                          // :4606
-                            for(int p = bestA; p <= bestB; p++) { lv[p - bestA] = lv[p]; ga[p - bestA] = ga[p]; sa[p - bestA] = sa[p]; }
-                            w = bestLen; P.startRaw = ns; P.stopRaw = ne;
-                        }
-                    }
-                    P.tmp0 = n1 - w; P.n = w;
+                    return n; };
+                int bestA = -1, bestB = -1, bestLen = 0;
+                auto consider = [&](int a, int b) {                                         // trim -1 ends (:4507-4531), keep the LAST longest (:4533-4552)
+                    int a2 = nextSet(P.mDef, a, b);
+                    if(a2 <= b) { int b2 = prevSet(P.mDef, b, a2); int len = b2 - a2 + 1; if(len >= bestLen) { bestLen = len; bestA = a2; bestB = b2; } }
+                };
+                // maximal stretches without a gap-stretch level; a gap column ends the stretch before it (:4470-4502)
+                int p = 0;
+                while(p < n1) {
+                    if(bitOf(P.mGap, p)) { p++; continue; }
+                    int q = nextSet(P.mGap, p, n1 - 1);                                      // stretch = [p, q - 1]
+                    if(!(p == 0 && q == n1)) consider(p, q - 1);                             // a stretch from column 0 to the end is not recorded (:4492-4502)
+                    p = q;
                 }
-                WSYNC();
-                removed = uni(P.tmp0); n1 = uni(P.n);
+                int w = n1;
+                if(bestLen > 0) {
+                    int ns = uni(P.startRaw) + countSeq(0, bestA - 1), ne = uni(P.stopRaw) - countSeq(bestB + 1, n1 - 1), sc = countSeq(bestA, bestB);
+                    if(((double)sc / (double)seqChars) > 0.3) {                              // :4606
+                        for(int q = bestA + lane; q <= bestB; q += 64) { P.lvl[1 - cur][q - bestA] = P.lvl[cur][q]; P.g[1 - cur][q - bestA] = P.g[cur][q]; P.s[1 - cur][q - bestA] = P.s[cur][q]; }
+                        WSYNC();
+                        cur = 1 - cur; w = bestLen;
+                        if(lane == 0) { P.startRaw = ns; P.stopRaw = ne; }
+                    }
+                }
+                removed = n1 - w; n1 = w;
             }
         }
         WSYNC();
 
+        PJ_T(4);
         // ---------------- re-threading DP, sequence variant (:2676-2835)
         // state of column i = best number of edge labels equal to the read character over all graph paths that respect
         // the seed's matches, per node of the column's target level; ties keep the smallest edge (std::set<Edge*> order).
-        int level0 = -1, nb = 0, chCount = 0; ChoiceRec* ch = P.ch;
-        int nDef = 0;
+        //
+        // Device formulation.  The chain's window of the in-edge CSR is staged into LDS.  A level that holds a single node is a
+        // cut: every path passes through it, so the recurrence to the right of it only sees the left part as an additive
+        // constant, and neither the argmax per node nor the order of the ties depends on that constant.  The window is
+        // therefore split at its single-node levels into independent segments (S = 0 at each segment start) that are solved
+        // one per lane, and the backtrace likewise restarts at every cut node.  In a PRG most levels are single-node, so
+        // segments are a few levels long.  Windows that do not fit the LDS staging, that contain a segment longer than
+        // PROJ_SEGMAX levels, or in which a segment hits the "no node reachable" assert, run the column-sequential form below.
+        int level0 = -1, nb = 0, chCount = 0; ChoiceRec* ch = slabCh;
+        int nDef = 0, nodeBase = 0, eBase = 0, nEdges = 0; bool staged = false, par = false;
         if(PJ_OK()) {
             level0 = uni(P.lvl[cur][0]);
             int lastLevel = uni(P.lvl[cur][n1 - 1]);
             if(level0 < 0 || lastLevel < level0 || lastLevel + 1 >= G.L) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
             else {
                 nDef = lastLevel - level0 + 1;
-                nb = G.level_off[level0 + 1];
-                chCount = G.level_off[lastLevel + 2] - nb;
-                if(chCount > PROJ_CHLDS) { ch = slabCh; if(chCount > slabEnt) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); } }
-                int m0 = G.level_off[level0 + 1] - G.level_off[level0];
-                if(m0 > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); }
-                else for(int z = lane; z < m0; z += 64) P.Srow[0][z] = 0;                     // all nodes of the first level, S = 0 (:2694-2701)
+                int v = 0;                                                                     // four offsets, one round trip
+                if(lane == 0) v = G.level_off[level0]; else if(lane == 1) v = G.level_off[level0 + 1]; else if(lane == 2) v = G.level_off[lastLevel + 2];
+                nodeBase = __builtin_amdgcn_readlane(v, 0); nb = __builtin_amdgcn_readlane(v, 1);
+                const int nodeEnd = __builtin_amdgcn_readlane(v, 2);
+                chCount = nodeEnd - nb;
+                int v2 = 0; if(lane == 0) v2 = G.in_off[nb]; else if(lane == 1) v2 = G.in_off[nodeEnd];
+                eBase = __builtin_amdgcn_readlane(v2, 0);
+                nEdges = __builtin_amdgcn_readlane(v2, 1) - eBase;
+                staged = (nDef <= PROJ_CAP) && (nodeEnd - nodeBase <= PROJ_SN) && (nEdges <= PROJ_SE);
+                if(staged) {
+                    for(int i = lane; i <= nDef + 1; i += 64) P.sLev[i] = (unsigned short)(G.level_off[level0 + i] - nodeBase);
+                    for(int i = lane; i <= chCount; i += 64) P.sIn[i] = (unsigned short)(G.in_off[nb + i] - eBase);
+                    for(int e = lane; e < nEdges; e += 64) { P.sFrom[e] = (unsigned short)(G.in_from[eBase + e] - nodeBase); P.sLab[e] = G.in_label[eBase + e]; }
+                }
             }
         }
         WSYNC();
         u64 edgesTouched = 0;
+        int nSeg = 0;
+        short* const Sflat = &P.Srow[0][0];                                                    // S per node of the window (parallel form)
+        if(PJ_OK() && staged) {
+            // level -> (column, read character, seed-is-match); the defined columns must cover level0..lastLevel exactly once
+            int defCount = 0;
+            for(int j0 = 0; j0 < n1; j0 += 64) {
+                int j = j0 + lane; bool d = false;
+                if(j < n1) {
+                    int l = P.lvl[cur][j];
+                    if(l != -1) {
+                        d = true; int li = l - level0;
+                        if(li >= 0 && li < nDef) { u32 sc = P.s[cur][j], gc = P.g[cur][j]; P.colInfo[li] = (u32)j | (sc << 16) | ((sc == gc ? 1u : 0u) << 24); }
+                    }
+                }
+                defCount += __popcll(__ballot(d));
+            }
+            for(int i0 = 0; i0 < nDef; i0 += 64) {
+                int i = i0 + lane;
+                bool cut = i < nDef && (i == 0 || (P.sLev[i + 1] - P.sLev[i]) == 1);
+                u64 m = __ballot(cut);
+                if(cut) P.segStart[nSeg + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+                nSeg += __popcll(m);
+            }
+            if(lane == 0) P.segStart[nSeg] = (unsigned short)nDef;
+            WSYNC();
+            int mx = 0;
+            for(int sg = lane; sg < nSeg; sg += 64) mx = max(mx, (int)P.segStart[sg + 1] - (int)P.segStart[sg]);
+            mx = wave_max_i32(mx);
+            par = (defCount == nDef) && (mx <= PROJ_SEGMAX);
+            if(par) {
+                const int nbR = nb - nodeBase;
+                int fail = 0;
+                for(int sg = lane; sg < nSeg; sg += 64) {
+                    const int a = P.segStart[sg], b = P.segStart[sg + 1];
+                    for(int i = a; i < b && !fail; i++) {
+                        const u32 ci = P.colInfo[i];
+                        const unsigned char sc = (unsigned char)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
+                        const int t0 = P.sLev[i + 1], t1 = P.sLev[i + 2];
+                        int anyReached = 0;
+                        for(int t = t0; t < t1; t++) {
+                            int best = -1, bestE = 0xFFFF;
+                            const int e0 = P.sIn[t - nbR], e1 = P.sIn[t - nbR + 1];
+                            for(int e = e0; e < e1; e++) {                                   // in-edges in creation order: first maximum = smallest edge
+                                int sp = (i == a) ? 0 : (int)Sflat[P.sFrom[e]];
+                                if(sp < 0) continue;
+                                unsigned char lab = P.sLab[e];
+                                if(seedIsMatch && lab != sc) continue;                        // :2803-2809
+                                int cand = sp + (lab == sc ? 1 : 0);
+                                if(cand > best) { best = cand; bestE = e; }
+                            }
+                            Sflat[t] = (short)best;
+                            P.sChoice[t - nbR] = (unsigned short)bestE;
+                            if(best >= 0) anyReached = 1;
+                        }
+                        if(!anyReached) fail = 1;
+                    }
+                }
+                if(__ballot(fail)) par = false;                                               // let the sequential form raise the reference's assert
+                else if(lane == 0) edgesTouched += (u64)nEdges;
+            }
+        }
+        WSYNC();
+        if(PJ_OK() && !par) {
+            if(chCount > slabEnt) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); }
+            int m0 = nb - nodeBase;
+            if(m0 > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); }
+            else for(int z = lane; z < m0; z += 64) P.Srow[0][z] = 0;                         // all nodes of the first level, S = 0 (:2694-2701)
+        }
+        WSYNC();
         if(PJ_OK()) {
             int rowP = 0;
-            for(int j = 0; j < n1; j++) {
-                int l = uni(P.lvl[cur][j]);
-                if(l == -1) continue;                                                         // :2710-2714
-                unsigned char sc = P.s[cur][j], gc = P.g[cur][j];
-                bool seedIsMatch = (sc == gc);
-                int tb = G.level_off[l + 1], tm = G.level_off[l + 2] - tb, fb = G.level_off[l];
-                if(tm > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); break; }
-                int anyReached = 0;
-                for(int z = lane; z < tm; z += 64) {
-                    int node = tb + z;
-                    int best = -1, bestE = -1, bestFrom = -1;
-                    int e0 = G.in_off[node], e1 = G.in_off[node + 1];
-                    for(int e = e0; e < e1; e++) {                                           // in-edges in creation order: first maximum = smallest edge
-                        int fz = G.in_from[e] - fb; int sp = P.Srow[rowP][fz];
-                        if(sp < 0) continue;
-                        unsigned char lab = G.in_label[e];
-                        if(seedIsMatch && lab != sc) continue;                                // :2803-2809
-                        int cand = sp + (lab == sc ? 1 : 0);
-                        if(cand > best) { best = cand; bestE = G.in_eid[e]; bestFrom = fz; }
+            if(!par) {
+                for(int j = 0; j < n1; j++) {
+                    int l = uni(P.lvl[cur][j]);
+                    if(l == -1) continue;                                                     // :2710-2714
+                    unsigned char sc = P.s[cur][j], gc = P.g[cur][j];
+                    bool seedIsMatch = (sc == gc);
+                    int tb = G.level_off[l + 1], tm = G.level_off[l + 2] - tb, fb = G.level_off[l];
+                    if(tm > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); break; }
+                    int anyReached = 0;
+                    for(int z = lane; z < tm; z += 64) {
+                        int node = tb + z;
+                        int best = -1, bestE = -1, bestFrom = -1;
+                        int e0 = G.in_off[node], e1 = G.in_off[node + 1];
+                        for(int e = e0; e < e1; e++) {
+                            int fz = G.in_from[e] - fb; int sp = P.Srow[rowP][fz];
+                            if(sp < 0) continue;
+                            unsigned char lab = G.in_label[e];
+                            if(seedIsMatch && lab != sc) continue;
+                            int cand = sp + (lab == sc ? 1 : 0);
+                            if(cand > best) { best = cand; bestE = G.in_eid[e]; bestFrom = fz; }
+                        }
+                        edgesTouched += (u64)(e1 - e0);
+                        P.Srow[1 - rowP][z] = (short)best;
+                        ChoiceRec cr; cr.eid = bestE; cr.fromz = (short)bestFrom; cr.S = (short)best;
+                        ch[node - nb] = cr;
+                        if(best >= 0) anyReached = 1;
                     }
-                    edgesTouched += (u64)(e1 - e0);
-                    P.Srow[1 - rowP][z] = (short)best;
-                    ChoiceRec cr; cr.eid = bestE; cr.fromz = (short)bestFrom; cr.S = (short)best;
-                    ch[node - nb] = cr;
-                    if(best >= 0) anyReached = 1;
+                    if(!__ballot(anyReached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); break; }  // assert(seedChain_backtrack_*.size() > 0)
+                    rowP = 1 - rowP;
+                    WSYNC();
                 }
-                if(!__ballot(anyReached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); break; }      // assert(seedChain_backtrack_*.size() > 0)
-                rowP = 1 - rowP;
-                WSYNC();
             }
             WSYNC();
+            PJ_T(5);
             // ---------------- backtrace (:2838-3007)
             if(PJ_OK()) {
                 int lastLevel = uni(P.lvl[cur][n1 - 1]);
-                int tb = G.level_off[lastLevel + 1], tm = G.level_off[lastLevel + 2] - tb;
+                int tb, tm; const short* lastS;
+                if(par) { tb = nodeBase + P.sLev[nDef]; tm = P.sLev[nDef + 1] - P.sLev[nDef]; lastS = Sflat + P.sLev[nDef]; }
+                else { tb = G.level_off[lastLevel + 1]; tm = G.level_off[lastLevel + 2] - tb; lastS = P.Srow[rowP]; }
                 int bestS = -1;
-                for(int z = lane; z < tm; z += 64) bestS = max(bestS, (int)P.Srow[rowP][z]);
+                for(int z = lane; z < tm; z += 64) bestS = max(bestS, (int)lastS[z]);
                 bestS = wave_max_i32(bestS);
                 int zsel = 0x7FFFFFFF;
-                for(int z = lane; z < tm; z += 64) if(P.Srow[rowP][z] == bestS) { zsel = min(zsel, z); }
+                for(int z = lane; z < tm; z += 64) if(lastS[z] == bestS) { zsel = min(zsel, z); }
                 zsel = -wave_max_i32(-zsel);                                                   // *(runningN.begin()): smallest node among the maxima (:2867)
                 const size_t cb = (size_t)c * stride;
-                if(lane == 0) {
+                if(par) {
+                    // every segment is traced from its right cut node (the last one from the selected node); the other column
+                    // buffer takes the chosen edge per column, then all lanes emit (edge ids are independent HBM reads)
+                    int* pick = P.lvl[1 - cur];
+                    for(int j = lane; j < n1; j += 64) pick[j] = -1;
+                    WSYNC();
+                    const int nbR = nb - nodeBase;
+                    for(int sg = lane; sg < nSeg; sg += 64) {
+                        const int a = P.segStart[sg], b = P.segStart[sg + 1];
+                        int t = (b == nDef) ? (int)P.sLev[nDef] + zsel : (int)P.sLev[b];
+                        for(int i = b - 1; i >= a; i--) { int e = P.sChoice[t - nbR]; pick[P.colInfo[i] & 0xFFFFu] = e; t = P.sFrom[e]; }
+                    }
+                    WSYNC();
+                    for(int j = lane; j < n1; j += 64) {
+                        int e = pick[j];
+                        if(e < 0) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
+                        else { B.seed_level[cb + j] = P.lvl[cur][j]; B.seed_edge[cb + j] = G.in_eid[eBase + e]; B.seed_g[cb + j] = P.sLab[e]; }
+                        B.seed_s[cb + j] = P.s[cur][j];
+                    }
+                } else if(lane == 0) {
                     int node = tb + zsel;
                     for(int j = n1 - 1; j >= 0; j--) {
                         int l = P.lvl[cur][j];
@@ -380,11 +529,15 @@ __global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __rest
                         B.seed_level[cb + j] = l; B.seed_edge[cb + j] = cr.eid; B.seed_g[cb + j] = G.edge_label[cr.eid]; B.seed_s[cb + j] = P.s[cur][j];
                         node = G.level_off[l] + cr.fromz;
                     }
+                }
+                if(lane == 0) {
                     B.seed_ncols[c] = n1; B.seed_begin[c] = P.startRaw; B.seed_end[c] = P.stopRaw; B.seed_removed[c] = removed;
                     atomicAdd(&B.counters[CNT_SEED_COLS], (u64)n1);
                 }
             }
         }
+        PJ_T(6);
+        if(B.dbg) { for(int i = 0; i < 6; i++) if(tPh[i + 1] && tPh[i]) tAcc[i] += tPh[i + 1] - tPh[i]; tAcc[6]++; }
         {
             int e = wave_sum_i32((int)edgesTouched);
             if(lane == 0 && e) atomicAdd(&B.counters[CNT_EDGES], (u64)e);
@@ -394,6 +547,7 @@ __global__ __launch_bounds__(64, 4) void k_project_chains(const DevGraph* __rest
         }   // chain survives the filters
         WSYNC();
     }
+    if(B.dbg && lane == 0) { for(int i = 0; i < 6; i++) atomicAdd(&B.counters[16 + i], (u64)tAcc[i]); atomicAdd(&B.counters[23], (u64)tAcc[6]); }
 }
 
 }  // namespace hlala

@@ -12,7 +12,7 @@ ctx = P.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_s
 gb = ctx.batch(b)
 gb.align(); gb.stats()
 gb.align(); st = gb.stats()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 ctx.lib.hlala_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_ulonglong)]
 ctx.lib.hlala_debug_counters(ctx.h, gb.b, buf)
 d = np.array(list(buf)[8:16], dtype=np.float64)
@@ -21,3 +21,7 @@ print({n: float(v) for n, v in zip(names, d)})
 it = d[3]; ch = d[7]
 print('cycles/iter: gen %.0f eval %.0f filter %.0f | per chain: select+bt %.0f stitch+LL %.0f total %.0f | iters/chain %.1f' % (d[0]/it, d[1]/it, d[2]/it, d[4]/ch, d[5]/ch, d[6]/ch, it/ch))
 print('retry ms', st.ms_extend_retry, 'retried', st.n_chains_retried, 'errors', st.n_errors); print('ms', st.ms_project, st.ms_extend, st.ms_pair, 'pairs/s', n_pairs/((st.ms_project+st.ms_extend+st.ms_pair)*1e-3))
+
+pj = np.array(list(buf)[16:24], dtype=np.float64)
+if pj[7] > 0:
+    print('project cycles/chain: walk %.0f trim+pad %.0f clean %.0f restrict %.0f stage+dp %.0f backtrace %.0f | chains %d' % tuple(list(pj[:6] / pj[7]) + [int(pj[7])]))
