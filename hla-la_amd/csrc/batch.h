@@ -39,6 +39,10 @@ struct DevBatch {
     double* ext_ll;
     int* dp_iters;                  // [2*n_chains]
     int* dp_score;                  // [2*n_chains]
+    int* dp_ncols;                  // [2*n_chains] extension columns of the DP (-1: no extension)
+    int* dp_sb;                     // [2*n_chains] read interval covered by the extension
+    int* dp_se;
+    int* dp_err;                    // [2*n_chains] 0, kernel line of a capacity failure, or -1000000 - columns
     int* ext_level;                 // [n_chains*stride]
     int* ext_edge;
     uint8_t* ext_g;
@@ -56,8 +60,11 @@ struct DevBatch {
     uint8_t* sel_mapq;              // [n_reads*stride] mapQ_perPosition of the selected chain
     // ---- counters (device): see hlala_batch_stats
     u64* counters;                  // [32]
-    int* work_counter;              // [8] dynamic work distribution: [0..2] stages A-C, [3] retry count, [4] retry fetch
-    int* retry_list;                // [n_chains] chains whose DP outgrew the small capacity class
+    int* work_counter;              // [16] dynamic work distribution: [0] stage A, [1] DP items fetched, [2] stage C, [3]/[4] retry list 1 count / fetched,
+                                    //      [5]/[6] retry list 2 count / fetched, [7] chains stitched, [8] DP items
+    int* retry_list;                // [2*n_chains] DP items that outgrew DpTiny
+    int* retry_list2;               // [2*n_chains] DP items that outgrew DpSmall
+    void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
     int* dbg;                       // host-mapped progress words (HLALA_DEBUG=1), else null
 };
 

@@ -11,13 +11,12 @@
 #include "flat_graph.hpp"
 
 // unity build: the kernels live in their own files but are compiled in this translation unit
-#include "kernel_extend.hip"
+#include "kernel_dp.hip"
 #include "kernel_project.hip"
 #include "kernel_pair.hip"
 #include "kernel_typer.hip"
 
 namespace hlala {
-size_t ext_slab_bytes_host(int stride) { return ext_slab_bytes(stride); }
 size_t proj_slab_bytes_host(int stride, int maxNodesPerLevel) { return proj_slab_bytes(stride, maxNodesPerLevel); }
 }  // namespace hlala
 
@@ -41,9 +40,11 @@ struct hlala_ctx {
     long long* d_contig_off = nullptr; uint8_t* d_contig_seq = nullptr; int* d_contig_level = nullptr;
     int n_contigs = 0; std::vector<long long> contig_off;
     std::vector<void*> allocs;
-    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0;
+    // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
+    char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
+    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0; int stitch_grid = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
-    hipEvent_t ev[7]{};           // start/end per stage, [6] = between the two extension passes
+    hipEvent_t ev[9]{};           // start/end per stage; [7] / [6] / [8] = before DpTiny / after DpTiny / after the retry classes
     int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
     std::string err;
 };
@@ -235,9 +236,14 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, device) != hipSuccess) { c->err = "hipGetDeviceProperties failed"; return fail(HLALA_E_DEVICE); }
     int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->tiny_grid = cus * 16;
+    c->tiny_slab_bytes = dp_slab_bytes<DpTiny>();
+    if(hipMalloc((void**)&c->tiny_slabs, c->tiny_slab_bytes * 4 * (size_t)c->tiny_grid) != hipSuccess) { c->err = "hipMalloc(DP slabs) failed"; return fail(HLALA_E_DEVICE); }
+    c->allocs.push_back(c->tiny_slabs);
     c->ext_grid = cus * 20;
     c->retry_grid = cus;
-    c->ext_slab_bytes = ext_slab_bytes_host(c->params.max_columns);
+    c->stitch_grid = cus * 32;
+    c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpLarge>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpLarge>();
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->ext_slabs);
     c->proj_grid = cus * 9; c->pair_grid = cus * 14;
@@ -245,7 +251,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
-    for(int i = 0; i < 7; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    for(int i = 0; i < 9; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;
@@ -255,7 +261,7 @@ void hlala_destroy(hlala_ctx* c)
 {
     if(!c) return;
     for(void* p : c->allocs) if(p) (void)hipFree(p);
-    for(int i = 0; i < 7; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for(int i = 0; i < 9; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -307,12 +313,13 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(seed_status, nc, true); AL(seed_ncols, nc, true); AL(seed_begin, nc, true); AL(seed_end, nc, true); AL(seed_removed, nc, true);
     AL(seed_level, cs, false); AL(seed_edge, cs, false); AL(seed_g, cs, false); AL(seed_s, cs, false);
     AL(ext_status, nc, true); AL(ext_ncols, nc, true); AL(ext_begin, nc, true); AL(ext_end, nc, true); AL(ext_ll, nc, true);
-    AL(dp_iters, 2 * nc, true); AL(dp_score, 2 * nc, true);
+    AL(dp_iters, 2 * nc, true); AL(dp_score, 2 * nc, true); AL(dp_ncols, 2 * nc, true); AL(dp_sb, 2 * nc, true); AL(dp_se, 2 * nc, true); AL(dp_err, 2 * nc, true);
     AL(ext_level, cs, false); AL(ext_edge, cs, false); AL(ext_g, cs, false); AL(ext_s, cs, false); AL(ext_fromseed, cs, false);
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
-    AL(counters, 32, true); AL(work_counter, 8, true); AL(retry_list, nc, false);
+    AL(counters, 32, true); AL(work_counter, 16, true); AL(retry_list, 2 * nc, false); AL(retry_list2, 2 * nc, false);
+    { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
     B.dbg = c->dbg_host;
 #undef AL
     return 0;
@@ -419,7 +426,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     if(!c || !b) return HLALA_E_ARG;
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
-    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 8 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 16 * sizeof(int), c->stream));
     HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if(B.n_chains > 0) {
@@ -441,18 +448,27 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
-    HIP_TRY(c, hipMemsetAsync(B.work_counter + 3, 0, 2 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 3, 0, 6 * sizeof(int), c->stream));
     if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if(B.n_chains > 0) {
-        int grid = B.n_chains < c->ext_grid ? B.n_chains : c->ext_grid;
-        hipLaunchKernelGGL((k_extend_chains<DpSmall, false>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
-        int rc = check_launch(c, "k_extend_chains<small>"); if(rc) return rc;
+        DpItem* items = (DpItem*)B.dp_items;
+        hipLaunchKernelGGL(k_dp_items, dim3((B.n_chains + 255) / 256), dim3(256), 0, c->stream, c->dG, b->dB, items);
+        int rc = check_launch(c, "k_dp_items"); if(rc) return rc;
+        // every DP item first runs in the 16-lane class; the item count lives on the device, idle groups leave at once
+        HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
+        hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, c->params.rng_seed);
+        rc = check_launch(c, "k_dp<tiny>"); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
-        // second pass over the (usually empty) list of chains that outgrew the small capacity class: one block per CU
-        int rgrid = B.n_chains < c->retry_grid ? B.n_chains : c->retry_grid;
-        hipLaunchKernelGGL((k_extend_chains<DpLarge, true>), dim3(rgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
-        rc = check_launch(c, "k_extend_chains<large>"); if(rc) return rc;
+        // items that outgrew it: one wave per DP, then the large-capacity class (one block per CU)
+        hipLaunchKernelGGL((k_dp<DpSmall, 1>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        rc = check_launch(c, "k_dp<small>"); if(rc) return rc;
+        hipLaunchKernelGGL((k_dp<DpLarge, 2>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        rc = check_launch(c, "k_dp<large>"); if(rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev[8], c->stream));
+        int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
+        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);
+        rc = check_launch(c, "k_stitch_chains"); if(rc) return rc;
     }
     HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
     b->staged |= 2;
@@ -567,8 +583,8 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     u64 cnt[16];
     HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
-    if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[3]); }
-    { int wc[8]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[3]; }
+    if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]); } }
+    { int wc[16]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[3]; out->n_dp_retried_large = wc[5]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

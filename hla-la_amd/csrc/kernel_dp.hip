@@ -1,0 +1,1070 @@
+// kernel_dp.hip -- stage B: extensionAligner::extendSeedChain + scoreOneAlignment on gfx950.
+//
+// The work item of the extension stage is ONE call of the affine X-drop frontier DP
+// fullNeedleman_diagonal_extension_gapJumper (mapper/aligner/extensionAligner.cpp:335-1556): the left or the
+// right extension of one seed chain (extendSeedChain, :220-319).  A frontier of this DP holds a handful of
+// cells (median 3-4 on 2x150 bp pairs), so a DP is run by a GROUP of lanes, not by a whole wavefront:
+//
+//   DpTiny   16 lanes per DP, 4 DPs per wavefront   frontier <= 16 cells, <= 48 candidate targets per iteration
+//   DpSmall  64 lanes per DP                        frontier <= 64, <= 96 targets        (DPs that outgrow DpTiny)
+//   DpLarge  64 lanes per DP                        frontier <= 1024, <= 1536 targets    (DPs that outgrow DpSmall)
+//
+// Every group is a small state machine (fetch -> iterate ... -> select end cell -> backtrace -> expand -> done);
+// the four groups of a wavefront advance independently inside one persistent loop, so a DP that ends early
+// immediately makes room for the next item and the slow serial part of one DP (the back-pointer chase) is
+// spread over the iterations of the other three.  Group collectives stay on the DPP cross-lane path: a group
+// of 16 is exactly one DPP row.
+//
+// Per iteration (identical in all classes):
+//   generate : one lane per frontier cell pushes its candidates into an LDS hash keyed by the target cell; ties
+//              are resolved with ds_max_u32 on (score, reversed push index), which is exactly the reference's
+//              "first maximum in push order" (Utilities.cpp:379-406)
+//   evaluate : one lane per target cell combines the three matrices, applies the -16 keep threshold, merges into
+//              the cell table (HBM scratch slab private to the group) and derives the running-maximum / patience
+//              bookkeeping with group reductions
+//   filter   : X-drop window of 15 below the iteration maximum, then a rank sort by (x,y,z) so the next
+//              iteration pushes in the reference's std::map order.
+// Scores are integers (the reference's doubles only ever hold integers, alignerBase.cpp:19-25).
+//
+// k_dp_items      : per chain, input checks of extendSeedChain and the list of DP items
+// k_dp<C, TIER>   : the DP classes above; extension columns go straight into the chain's output row
+// k_stitch_chains : extendWithOtherSeedChain / extendToFullSequenceLength (verboseSeedChain.cpp:23-136) and
+//                   scoreOneAlignment (extensionAligner.cpp:52-182), one wavefront per chain
+#include "batch.h"
+#include "../../include/hlala_gpu.h"
+
+namespace hlala {
+
+enum { K_DIAG = 0, K_GGAP = 1, K_SGAP = 2, K_HOP = 3, K_JUMP = 4 };
+enum { M_D = 0, M_GG = 1, M_SG = 2 };
+enum { PH_IDLE = 0, PH_RUN, PH_SELECT, PH_BT, PH_EXPAND, PH_DONE };
+
+constexpr u64 HKEY_EMPTY = ~0ull;
+constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
+constexpr int DP_BT_STEPS_PER_TRIP = 6;     // back pointers one group follows per trip of the persistent loop
+
+struct DpTiny  { static constexpr int GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 1024,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; };
+struct DpSmall { static constexpr int GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; };
+struct DpLarge { static constexpr int GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; };
+
+// State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
+// that only the phase has to stay in registers across the states of the persistent loop.
+struct DpState {
+    int itemIdx;                                          // index into the item list (kept for a requeue)
+    int item, rOff, seqLen, start_seq, startLevel, startNode;
+    int d, b1, b2, bn, n1, n2, nCells, nCompleted, curMax, firstMaxSlot, lastInc, earlyInit, itersRun, diagonals;
+    u32 cellsEvaluated;
+    int endSlot, endScore, nSteps, nCols;
+    int have, sb, se, err;
+};
+
+template <class C>
+struct __align__(16) DpLdsT {
+    u64 hkey[C::HC];
+    typename C::Best hbest[3][C::HC];
+    unsigned short tlist[C::HC];
+    u64 fkey[3][C::WCAP];
+    short fslot[3][C::WCAP];        // table slot of the frontier cell
+    short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
+    short tes[C::HC];               // per target: existing / assigned table slot (-1 = none; CELLS <= 32767)
+    unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
+    int nT, nNew, nImp, nKeepF, err, nCompletedAdd;
+    int btSlot, btM, btX, btY, btGuard, btDone;       // back-pointer chase in progress (lane 0 of the group)
+    DpState st;
+    u64 accCalls, accIters, accCells, accEdges;       // work counters of the DPs this group finished (flushed once at exit)
+};
+
+// Scratch of one DP call in HBM (private to its group).  Only the base address is held in registers; every array sits at a
+// compile-time offset, 8-byte arrays first.
+template <class C>
+struct DpSlabT {
+    char* base;
+    static constexpr size_t O_CELL_KEY  = 0;                                          // u64  [CELLS]
+    static constexpr size_t O_CELL_BT   = O_CELL_KEY + (size_t)C::CELLS * 8;          // u64  [3*CELLS]
+    static constexpr size_t O_EARLY_KEY = O_CELL_BT + (size_t)C::CELLS * 24;          // u64  [EARLY]
+    static constexpr size_t O_STEP_BT   = O_EARLY_KEY + (size_t)C::EARLY * 8;         // u64  [STEPS]
+    static constexpr size_t O_STEP_XY   = O_STEP_BT + (size_t)C::STEPS * 8;           // u64  [STEPS]
+    static constexpr size_t O_IMP_KEY   = O_STEP_XY + (size_t)C::STEPS * 8;           // u64  [IMPCAP]
+    static constexpr size_t O_IMP_BT    = O_IMP_KEY + (size_t)C::IMPCAP * 8;          // u64  [3*IMPCAP]
+    static constexpr size_t O_IMP_NEW   = O_IMP_BT + (size_t)C::IMPCAP * 24;          // short[4*IMPCAP]
+    static constexpr size_t O_CELL_SC   = O_IMP_NEW + (size_t)C::IMPCAP * 8;          // short[4*CELLS]  D, GG, SG, -
+    static constexpr size_t O_EARLY_VAL = O_CELL_SC + (size_t)C::CELLS * 8;           // int  [EARLY]
+    static constexpr size_t O_COMPLETED = O_EARLY_VAL + (size_t)C::EARLY * 4;         // int  [COMPLETED]
+    static constexpr size_t O_IMP_SLOT  = O_COMPLETED + (size_t)C::COMPLETED * 4;     // int  [IMPCAP]
+    static constexpr size_t O_IMP_MASK  = O_IMP_SLOT + (size_t)C::IMPCAP * 4;         // int  [IMPCAP]
+    static constexpr size_t BYTES       = (O_IMP_MASK + (size_t)C::IMPCAP * 4 + 255) & ~(size_t)255;
+    __device__ __forceinline__ u64* cell_key() const { return (u64*)(base + O_CELL_KEY); }
+    __device__ __forceinline__ u64* cell_bt() const { return (u64*)(base + O_CELL_BT); }
+    __device__ __forceinline__ u64* early_key() const { return (u64*)(base + O_EARLY_KEY); }
+    __device__ __forceinline__ u64* step_bt() const { return (u64*)(base + O_STEP_BT); }
+    __device__ __forceinline__ u64* step_xy() const { return (u64*)(base + O_STEP_XY); }
+    __device__ __forceinline__ u64* imp_key() const { return (u64*)(base + O_IMP_KEY); }
+    __device__ __forceinline__ u64* imp_bt() const { return (u64*)(base + O_IMP_BT); }
+    __device__ __forceinline__ short* imp_new() const { return (short*)(base + O_IMP_NEW); }
+    __device__ __forceinline__ short* cell_sc() const { return (short*)(base + O_CELL_SC); }
+    __device__ __forceinline__ int* early_val() const { return (int*)(base + O_EARLY_VAL); }
+    __device__ __forceinline__ int* completed() const { return (int*)(base + O_COMPLETED); }
+    __device__ __forceinline__ int* imp_slot() const { return (int*)(base + O_IMP_SLOT); }
+    __device__ __forceinline__ int* imp_mask() const { return (int*)(base + O_IMP_MASK); }
+};
+
+template <class C>
+__host__ __device__ inline size_t dp_slab_bytes() { return DpSlabT<C>::BYTES; }
+
+// ------------------------------------------------------------------------------------------ group collectives
+// GW = 64: the wave-wide DPP reductions of device_common.h (results are wave-uniform, in SGPRs).
+// GW = 16: one DPP row; all-reduce with quad_perm xor 1 / xor 2, row_half_mirror, row_mirror (4 VALU ops, every lane
+//          of the row ends with the result).  Rows never exchange data, so groups may sit in divergent code.
+template <int GW> __device__ __forceinline__ int grp_lane() { return (int)(threadIdx.x & (GW - 1)); }
+template <int GW> __device__ __forceinline__ int grp_base() { return (int)(threadIdx.x & 63 & ~(GW - 1)); }
+
+#define HLALA_ROW_ALLREDUCE(v, OP)                                                          \
+    do {                                                                                    \
+        int t_;                                                                             \
+        t_ = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); v = OP(v, t_);       /* quad_perm [1,0,3,2] */ \
+        t_ = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false); v = OP(v, t_);       /* quad_perm [2,3,0,1] */ \
+        t_ = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false); v = OP(v, t_);      /* row_half_mirror */     \
+        t_ = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); v = OP(v, t_);      /* row_mirror */          \
+    } while(0)
+
+template <int GW> __device__ __forceinline__ int grp_max_i32(int v)
+{
+    if(GW == 64) return wave_max_i32(v);
+    HLALA_ROW_ALLREDUCE(v, op_max_);
+    return v;
+}
+template <int GW> __device__ __forceinline__ int grp_sum_i32(int v)
+{
+    if(GW == 64) return wave_sum_i32(v);
+    HLALA_ROW_ALLREDUCE(v, op_add_);
+    return v;
+}
+template <int GW> __device__ __forceinline__ u64 grp_min_u64(u64 v)
+{
+    if(GW == 64) return wave_min_u64(v);
+    int hi = (int)(~(u32)(v >> 32) ^ 0x80000000u);
+    int mh = grp_max_i32<GW>(hi);
+    int lo = (hi == mh) ? (int)(~(u32)v ^ 0x80000000u) : (int)0x80000000;
+    int ml = grp_max_i32<GW>(lo);
+    return ((u64)(~((u32)mh ^ 0x80000000u)) << 32) | (u64)(~((u32)ml ^ 0x80000000u));
+}
+// exclusive prefix sum over the group (v >= 0); `total` is group-uniform
+template <int GW> __device__ __forceinline__ int grp_excl_scan(int v, int& total)
+{
+    if(GW == 64) return wave_excl_scan(v, total);
+    int x = v, t;
+    t = dpp_mov<0x111>(0, x); x += t;       // row_shr:1 (lanes without a source keep 0)
+    t = dpp_mov<0x112>(0, x); x += t;
+    t = dpp_mov<0x114>(0, x); x += t;
+    t = dpp_mov<0x118>(0, x); x += t;
+    int m = x; HLALA_ROW_ALLREDUCE(m, op_max_);     // inclusive sums are non-decreasing: the maximum is the total
+    total = m;
+    return x - v;
+}
+template <int GW> __device__ __forceinline__ u64 grp_ballot(bool p)
+{
+    u64 b = __ballot(p);
+    if(GW == 64) return b;
+    return (b >> grp_base<GW>()) & ((1ull << GW) - 1ull);
+}
+template <int GW> __device__ __forceinline__ int grp_bcast(int v, int srcGroupLane)
+{
+    return __shfl(v, grp_base<GW>() + srcGroupLane);
+}
+// a group-uniform value: scalar for full-wave groups, left alone otherwise
+template <int GW> __device__ __forceinline__ int guni(int v) { return GW == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }
+
+// DP cell key: level x (24 bits) | read offset y (12 bits) | node id (28 bits).  Node ids are level-major and
+// stable in creation order, so unsigned key order == the reference's std::map order (x, then y, then rank z).
+__device__ __forceinline__ u64 mk_key(int x, int y, int node) { return ((u64)(u32)x << 40) | ((u64)(u32)y << 28) | (u64)(u32)node; }
+__device__ __forceinline__ int key_x(u64 k) { return (int)(k >> 40); }
+__device__ __forceinline__ int key_y(u64 k) { return (int)((k >> 28) & 0xFFF); }
+__device__ __forceinline__ int key_node(u64 k) { return (int)(k & 0xFFFFFFF); }
+// targets of one iteration differ in a few low bits of node / y / x: one 32-bit multiply spreads them
+__device__ __forceinline__ u32 hash64(u64 k) { u32 h = (u32)k ^ ((u32)(k >> 28) * 0x9E3779B1u) ^ ((u32)(k >> 40) * 0x85EBCA6Bu); h *= 0x9E3779B1u; return h ^ (h >> 15); }
+
+__device__ __forceinline__ u64 mk_bt(int prev, int src, int kind, int edge) { return ((u64)(u32)edge << 32) | (u64)((u32)prev | ((u32)src << 24) | ((u32)kind << 26)); }
+__device__ __forceinline__ int bt_prev(u64 b) { return (int)(b & 0xFFFFFF); }
+__device__ __forceinline__ int bt_src(u64 b) { return (int)((b >> 24) & 3); }
+__device__ __forceinline__ int bt_kind(u64 b) { return (int)((b >> 26) & 7); }
+__device__ __forceinline__ int bt_edge(u64 b) { return (int)(b >> 32); }
+
+// candidate value: (score, reversed push index) so that an unsigned max = highest score, earliest push
+__device__ __forceinline__ void pack_best(u32& o, int score, int order) { o = ((u32)(score + 64) << 16) | (u32)(0xFFFF - order); }
+__device__ __forceinline__ void pack_best(u64& o, int score, int order) { o = ((u64)(u32)(score + 64) << 32) | (u64)(u32)(0x7FFFFFFF - order); }
+__device__ __forceinline__ int best_score(u32 b) { return b ? (int)(b >> 16) - 64 : DP_NEG; }
+__device__ __forceinline__ int best_score(u64 b) { return b ? (int)(b >> 32) - 64 : DP_NEG; }
+__device__ __forceinline__ int best_order(u32 b) { return 0xFFFF - (int)(b & 0xFFFF); }
+__device__ __forceinline__ int best_order(u64 b) { return 0x7FFFFFFF - (int)(b & 0xFFFFFFFFull); }
+
+// push one candidate (Alt::{D,GG,SG}.push_back in the reference) -- returns false on hash overflow
+template <class C>
+__device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int order)
+{
+    u32 h = hash64(key) & (C::HC - 1);
+#pragma nounroll
+    for(int probe = 0; probe < C::HC; probe++) {
+        u64 cur = S.hkey[h];
+        if(cur == HKEY_EMPTY) {
+            u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
+            if(old == HKEY_EMPTY) {
+                int pos = atomicAdd(&S.nT, 1);
+                if(pos < C::HC) S.tlist[pos] = (unsigned short)h;
+                cur = key;
+            } else cur = old;
+        }
+        if(cur == key) { typename C::Best v; pack_best(v, score, order); atomicMax(&S.hbest[mat][h], v); return true; }
+        h = (h + 1) & (C::HC - 1);
+    }
+    return false;
+}
+
+template <class C>
+__device__ inline int early_lookup(const DpSlabT<C>& sl, u64 key)
+{
+    u32 h = hash64(key) & (C::EARLY - 1);
+    for(int probe = 0; probe < C::EARLY; probe++) {
+        // entries are published with L2 atomics: read them past the CU's L1
+        u64 cur = __hip_atomic_load(&sl.early_key()[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if(cur == key) return __hip_atomic_load(&sl.early_val()[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if(cur == HKEY_EMPTY) return -1;
+        h = (h + 1) & (C::EARLY - 1);
+    }
+    return -1;
+}
+template <class C>
+__device__ inline bool early_insert(const DpSlabT<C>& sl, u64 key, int slot)
+{
+    u32 h = hash64(key) & (C::EARLY - 1);
+    for(int probe = 0; probe < C::EARLY; probe++) {
+        u64 old = atomicCAS(&sl.early_key()[h], HKEY_EMPTY, key);
+        if(old == HKEY_EMPTY || old == key) { __hip_atomic_store(&sl.early_val()[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
+        h = (h + 1) & (C::EARLY - 1);
+    }
+    return false;
+}
+
+// "x/z" string order of std::set<std::string> achieved_complete_sequence_alignments (extensionAligner.cpp:493, 1431)
+// (characters are produced on the fly: no per-lane buffers, no scratch memory)
+__device__ inline int dec_len(int v) { int n = 1; while(v >= 10) { v /= 10; n++; } return n; }
+__device__ inline int pow10i(int n) { int p = 1; while(n-- > 0) p *= 10; return p; }
+__device__ inline int xz_char(int x, int z, int lx, int lz, int i)
+{
+    if(i < lx) return '0' + (x / pow10i(lx - 1 - i)) % 10;
+    if(i == lx) return '/';
+    return '0' + (z / pow10i(lz - 1 - (i - lx - 1))) % 10;
+}
+__device__ inline bool xz_less(int x1, int z1, int x2, int z2)
+{
+    const int lx1 = dec_len(x1), lz1 = dec_len(z1), lx2 = dec_len(x2), lz2 = dec_len(z2);
+    const int la = lx1 + 1 + lz1, lb = lx2 + 1 + lz2;
+    const int n = la < lb ? la : lb;
+    for(int i = 0; i < n; i++) { int ca = xz_char(x1, z1, lx1, lz1, i), cb = xz_char(x2, z2, lx2, lz2, i); if(ca != cb) return ca < cb; }
+    return la < lb;
+}
+
+// one DP item as prepared by k_dp_items (32 bytes)
+struct __align__(16) DpItem { int item, rOff, seqLen, start_seq, startLevel, startNode, pad0, pad1; };
+
+#define DP_FAIL(code) do { if(gl == 0 && S.err == 0) S.err = (code); } while(0)
+
+template <class C>
+__device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, const DpItem& it, int itemIdx)
+{
+    constexpr int GW = C::GW;
+    const int gl = grp_lane<GW>();
+    // ---- init, :480-519
+    for(int i = gl; i < C::HC; i += GW) { S.hkey[i] = HKEY_EMPTY; S.hbest[0][i] = 0; S.hbest[1][i] = 0; S.hbest[2][i] = 0; }
+    if(gl == 0) {
+        DpState& st = S.st;
+        st.itemIdx = itemIdx;
+        st.item = it.item; st.rOff = it.rOff; st.seqLen = it.seqLen; st.start_seq = it.start_seq; st.startLevel = it.startLevel; st.startNode = it.startNode;
+        st.diagonals = it.seqLen + G.L - 1;
+        st.d = 1; st.b1 = 0; st.b2 = 1; st.bn = 2; st.n1 = 1; st.n2 = 0; st.nCells = 1; st.nCompleted = 0;
+        st.curMax = 0; st.firstMaxSlot = 0; st.lastInc = 0; st.earlyInit = 0; st.itersRun = 0;
+        st.cellsEvaluated = 0;
+        st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
+        st.have = 0; st.sb = 0; st.se = -1; st.err = 0;
+        S.nT = 0; S.err = 0;
+        sl.cell_key()[0] = mk_key(it.startLevel, it.start_seq, it.startNode);
+        sl.cell_sc()[0] = 0; sl.cell_sc()[1] = (short)DP_NEG; sl.cell_sc()[2] = (short)DP_NEG; sl.cell_sc()[3] = 0;
+        sl.cell_bt()[0] = 0; sl.cell_bt()[C::CELLS] = 0; sl.cell_bt()[2 * C::CELLS] = 0;
+        S.fkey[0][0] = mk_key(it.startLevel, it.start_seq, it.startNode); S.fslot[0][0] = 0;
+        S.fD[0][0] = 0; S.fG[0][0] = (short)DP_NEG; S.fS[0][0] = (short)DP_NEG;
+    }
+    WSYNC();
+    return PH_RUN;
+}
+
+// One iteration of extensionAligner::fullNeedleman_diagonal_extension_gapJumper (extensionAligner.cpp:531-1105) with
+// returnGlobalScore = false, preferSequenceCompleAlignments = true, empty blockedPathsTable,
+// diagonal_stop_threshold = -16 (the only configuration extendSeedChain uses, :229-241, :281-293).
+template <class C>
+__device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, const uint8_t* readBases, const bool fwd, int& edgesAcc)
+{
+    constexpr int GW = C::GW;
+    const int gl = grp_lane<GW>();
+    DpState& st = S.st;
+    const int dir = fwd ? 1 : -1;
+    const int seqLen = guni<GW>(st.seqLen);
+    const int max_levelI = G.L - 1, max_seqI = seqLen;       // :431-463 (min_* are 0 in both directions)
+    const int limitY = fwd ? seqLen : 0;
+    const int startLevel = guni<GW>(st.startLevel), start_seq = guni<GW>(st.start_seq);
+    const int d = guni<GW>(st.d);
+    const int n1 = guni<GW>(st.n1), n2 = guni<GW>(st.n2);
+    const int b1 = guni<GW>(st.b1), b2 = guni<GW>(st.b2), bn = guni<GW>(st.bn);
+    const int lastInc0 = guni<GW>(st.lastInc), diagonals = guni<GW>(st.diagonals);
+    const int curMax0 = guni<GW>(st.curMax);
+    const int nCompleted0 = guni<GW>(st.nCompleted);
+    int nCells = guni<GW>(st.nCells);
+    int earlyInit = guni<GW>(st.earlyInit);
+    const uint8_t* seqp = readBases + guni<GW>(st.rOff);
+
+    // ---- loop header, :531-560
+    if(d > diagonals || (d - lastInc0) > 40) return PH_SELECT;                             // :553 maximum_steps_nonIncrease
+    if(n1 == 0 && n2 == 0) {
+        // both frontiers empty: the remaining iterations of the reference loop are no-ops
+        int last = lastInc0 + 40; if(last > diagonals) last = diagonals;
+        if(gl == 0) st.itersRun = last;
+        WSYNC();
+        return PH_SELECT;
+    }
+    if(d > 60000) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }      // watchdog: far beyond any read length + patience
+
+    // ================= generate =====================================================
+    const int* eoff = fwd ? G.out_off : G.in_off; const int* eto = fwd ? G.out_to : G.in_from; const uint8_t* elab = fwd ? G.out_label : G.in_label;
+    int edges = 0;      // (the direction is wave-uniform: these are scalar selects)
+    // from the m-2 diagonal: match / mismatch, :565-607
+    for(int i = gl; i < n2; i += GW) {
+        u64 pk = S.fkey[b2][i]; int px = key_x(pk), py = key_y(pk), node = key_node(pk);
+        int nx = px + dir, ny = py + dir;
+        if(nx > max_levelI || ny > max_seqI || nx < 0 || ny < 0) continue;
+        unsigned char rc = fwd ? seqp[py] : seqp[py - 1];
+        int e0 = eoff[node], e1 = eoff[node + 1];
+        int pD = S.fD[b2][i];
+        if(e1 - e0 > 127) { S.err = __LINE__; continue; }
+        for(int e = e0; e < e1; e++) {
+            int tn = eto[e];
+            unsigned char lab = elab[e];
+            int sc = pD + (lab == rc ? 2 : -5);
+            if(!dp_push<C>(S, mk_key(nx, ny, tn), M_D, sc, (i << 8) | (e - e0))) S.err = __LINE__;
+        }
+        edges += e1 - e0;
+    }
+    // from the m-1 diagonal: gaps and jumps, :613-787
+    for(int i = gl; i < n1; i += GW) {
+        u64 pk = S.fkey[b1][i]; int px = key_x(pk), py = key_y(pk), node = key_node(pk);
+        int pD = S.fD[b1][i], pG = S.fG[b1][i], pS = S.fS[b1][i];
+        int ord0 = (1 << (C::IBITS + 8)) | (i << 8);
+        {   // gap in graph, :621-661
+            int ny = py + dir;
+            if(ny >= 0 && ny <= max_seqI) {
+                u64 k = mk_key(px, ny, node);
+                if(!dp_push<C>(S, k, M_GG, pD - 6, ord0 | 0)) S.err = __LINE__;
+                if(pG != DP_NEG) if(!dp_push<C>(S, k, M_GG, pG - 2, ord0 | 1)) S.err = __LINE__;
+            }
+        }
+        {   // gap in sequence, :664-754
+            int nx = px + dir;
+            int e0 = eoff[node], e1 = eoff[node + 1];
+            int deg = e1 - e0;
+            if(deg > 127) { S.err = __LINE__; continue; }
+            if(nx >= 0 && nx <= max_levelI) {
+                for(int e = e0; e < e1; e++) {
+                    int tn = eto[e];
+                    unsigned char lab = elab[e];
+                    u64 k = mk_key(nx, py, tn);
+                    int kk = e - e0;
+                    if(lab != '_') {
+                        if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
+                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
+                    } else {
+                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
+                        if(!dp_push<C>(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;         // non-affine sequence gap, :738-752
+                    }
+                }
+                edges += deg;
+            }
+        }
+        {   // gap-path jumps, :757-786 (jump_length * S_graphGap = 0)
+            // push index of a jump = 128 + its rank in the jump table: after every edge candidate of the same source (:757)
+            const int* joff = fwd ? G.jf_off : G.jb_off; const int* jnode = fwd ? G.jf_node : G.jb_node; const int* jlvl = fwd ? G.jf_lvl : G.jb_lvl;
+            int j0 = joff[node], j1 = joff[node + 1];
+            if(j1 - j0 > 127) { S.err = __LINE__; continue; }
+            for(int j = j0; j < j1; j++) {
+                int tn = jnode[j]; int jx = jlvl[j];
+                if(jx < 0 || jx > max_levelI) continue;
+                if(!dp_push<C>(S, mk_key(jx, py, tn), M_D, pD, ord0 | (128 + (j - j0)))) S.err = __LINE__;
+            }
+        }
+    }
+    edgesAcc += edges;
+    WSYNC();
+    const int nT = guni<GW>(S.nT);
+    if(nT > (C::HC * 3) / 4 || guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
+
+    // ================= evaluate =====================================================
+    if(gl == 0) { S.nNew = 0; S.nImp = 0; S.nCompletedAdd = 0; }
+    WSYNC();
+    int itMaxNew = DP_NEG;        // max Dv over kept targets of this iteration
+    u64 itMaxKey = ~0ull;         // smallest key achieving it (= first such cell in std::map order)
+    bool anyEqDiff = false, anyOw = false, anyExisting = false;
+
+    // Cells reached through a gap-path jump arrive EARLIER than their natural diagonal |dx|+|dy| and can be
+    // reached again later ("scores" merge, :951-979).  Only such cells are registered in the early hash, and
+    // only while it is non-empty do targets need an existence lookup.
+    if(earlyInit) {
+        for(int t0 = 0; t0 < nT; t0 += GW) {
+            int t = t0 + gl; int es = -1;
+            if(t < nT) {
+                int h = S.tlist[t];
+                int Dv = max(best_score(S.hbest[M_D][h]), max(best_score(S.hbest[M_GG][h]), best_score(S.hbest[M_SG][h])));
+                if(Dv >= -16) es = early_lookup<C>(sl, S.hkey[h]);
+                S.tes[t] = (short)es;
+            }
+            if(grp_ballot<GW>(es >= 0)) anyExisting = true;
+        }
+        WSYNC();
+    }
+    const bool slow = anyExisting;
+    const bool hadEarly = earlyInit != 0;      // S.tes[] holds lookups only if the pre-pass ran
+    bool failed = false;
+
+    for(int pass = 0; pass < (slow ? 2 : 1); pass++) {
+        for(int t0 = 0; t0 < nT; t0 += GW) {
+            int t = t0 + gl;
+            bool act = t < nT;
+            int h = act ? S.tlist[t] : 0;
+            u64 key = act ? S.hkey[h] : 0;
+            typename C::Best bD = act ? S.hbest[M_D][h] : 0, bG = act ? S.hbest[M_GG][h] : 0, bS = act ? S.hbest[M_SG][h] : 0;
+            int Dc = best_score(bD), GGv = best_score(bG), SGv = best_score(bS);
+            int Dv = Dc, dsel = 0;                      // D candidates first, then GG, then SG (:840-865); first maximum wins
+            if(GGv > Dv) { Dv = GGv; dsel = 1; }
+            if(SGv > Dv) { Dv = SGv; dsel = 2; }
+            bool keep = act && (Dv >= -16);                                               // :949
+            int es = -1; bool isNew; int slot;
+            if(pass == 0) {
+                if(hadEarly && keep) es = S.tes[t];
+                isNew = keep && es < 0;
+                int total; int off = grp_excl_scan<GW>(isNew ? 1 : 0, total);
+                slot = isNew ? nCells + off : es;
+                if(nCells + total > C::CELLS) { DP_FAIL(__LINE__); failed = true; }
+                nCells += total;
+            } else {
+                slot = keep ? S.tes[t] : -1;
+                isNew = keep && (S.timp[t] & 0x80);
+                es = isNew ? -1 : slot;
+            }
+            const bool ok = !failed && S.err == 0;
+            // ---- back pointers of the three matrices, decoded from the winning push index
+            u64 btD = 0, btG = 0, btS = 0;
+            int srcScore = 0;       // score the real previous step came from (fast form of the `diff` rule)
+            if(keep && ok && slot >= 0 && slot < C::CELLS) {
+                // back pointer = (previous cell slot, source matrix, kind, local push index j); the graph edge / gap path behind j
+                // is resolved only for the cells on the final path, at backtrace time
+                if(bG) { int o = best_order(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                         btG = mk_bt(S.fslot[b1][i], j ? 1 : 0, K_GGAP, -1); }
+                if(bS) { int o = best_order(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                         btS = mk_bt(S.fslot[b1][i], (j & 1) ? 2 : 0, K_SGAP, j >> 1); }
+                if(dsel == 0) {
+                    int o = best_order(bD); int ph = o >> (C::IBITS + 8); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                    int sb = ph ? b1 : b2;
+                    srcScore = S.fD[sb][i];
+                    if(!ph) btD = mk_bt(S.fslot[sb][i], 0, K_DIAG, j);
+                    else if(j < 128) btD = mk_bt(S.fslot[sb][i], 0, K_SGAP, j);
+                    else btD = mk_bt(S.fslot[sb][i], 0, K_JUMP, j - 128);
+                } else if(dsel == 1) {
+                    btD = mk_bt(slot, 1, K_HOP, -1);
+                    int o = best_order(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                    srcScore = j ? S.fG[b1][i] : S.fD[b1][i];
+                } else {
+                    btD = mk_bt(slot, 2, K_HOP, -1);
+                    int o = best_order(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                    srcScore = (j & 1) ? S.fS[b1][i] : S.fD[b1][i];
+                }
+            }
+            int impMask = 0;
+            int mD = Dv, mG = GGv, mS = SGv;          // merged values
+            u64 mbtD = btD;                            // merged D back pointer
+            if(pass == 0) {
+                // ---- new cells: write the table entry, register early / sequence-complete cells
+                if(isNew && ok && slot < C::CELLS) {
+                    sl.cell_key()[slot] = key;
+                    sl.cell_sc()[4 * slot + 0] = (short)Dv; sl.cell_sc()[4 * slot + 1] = (short)GGv; sl.cell_sc()[4 * slot + 2] = (short)SGv; sl.cell_sc()[4 * slot + 3] = 0;
+                    sl.cell_bt()[slot] = btD; sl.cell_bt()[C::CELLS + slot] = btG; sl.cell_bt()[2 * C::CELLS + slot] = btS;
+                }
+                int x = key_x(key), y = key_y(key);
+                int natural = (x > startLevel ? x - startLevel : startLevel - x) + (y > start_seq ? y - start_seq : start_seq - y);
+                bool isEarly = isNew && natural > d;
+                if(grp_ballot<GW>(isEarly)) {
+                    if(!earlyInit) {
+                        for(int i = gl; i < C::EARLY; i += GW) sl.early_key()[i] = HKEY_EMPTY;
+                        earlyInit = 1;
+                        WSYNC();
+                    }
+                    if(isEarly) if(!early_insert<C>(sl, key, slot)) S.err = __LINE__;
+                }
+                if(isNew && y == limitY) {                                                     // :982-999
+                    int pos = atomicAdd(&S.nCompletedAdd, 1);
+                    if(nCompleted0 + pos < C::COMPLETED) sl.completed()[nCompleted0 + pos] = slot; else S.err = __LINE__;
+                }
+            }
+            // ---- existing cells: each matrix independently overwritten iff strictly greater, :951-979 (writes are staged)
+            if(keep && !isNew && ok) {
+                int oD = sl.cell_sc()[4 * es + 0], oG = sl.cell_sc()[4 * es + 1], oS = sl.cell_sc()[4 * es + 2];
+                if(Dv > oD) impMask |= 1; else { mD = oD; mbtD = sl.cell_bt()[es]; }
+                if(GGv > oG) impMask |= 2; else mG = oG;
+                if(SGv > oS) impMask |= 4; else mS = oS;
+                if(impMask && pass == 0) {
+                    int p = atomicAdd(&S.nImp, 1);
+                    if(p < C::IMPCAP) {
+                        sl.imp_slot()[p] = es; sl.imp_key()[p] = key; sl.imp_mask()[p] = impMask;
+                        sl.imp_new()[4 * p + 0] = (short)mD; sl.imp_new()[4 * p + 1] = (short)mG; sl.imp_new()[4 * p + 2] = (short)mS;
+                        sl.imp_bt()[3 * p + 0] = btD; sl.imp_bt()[3 * p + 1] = btG; sl.imp_bt()[3 * p + 2] = btS;
+                    } else S.err = __LINE__;
+                }
+            }
+            if(pass == 0 && slow) {
+                // exact diff needs every staged improvement of the iteration: finish in the second pass
+                if(act) { S.tes[t] = (short)slot; S.timp[t] = (unsigned char)(impMask | (isNew ? 0x80 : 0)); }
+                continue;
+            }
+            if(grp_ballot<GW>(impMask != 0)) anyOw = true;
+            // ---- the `diff` rule, :1007-1041: score difference to the real previous step of the MERGED D back pointer
+            int diff = 1;
+            if(keep && ok) {
+                if(!slow) {
+                    diff = Dv - srcScore;       // no table entry changes this iteration: cached frontier values are the table values
+                } else {
+                    u64 b = mbtD;
+                    int guard = 0;
+                    while(bt_kind(b) == K_HOP && guard++ < 4) {
+                        int m = bt_src(b);
+                        bool useNew = isNew || (impMask & (1 << m));
+                        if(useNew) b = (m == 1) ? btG : btS; else b = sl.cell_bt()[m * C::CELLS + slot];
+                    }
+                    int ps = bt_prev(b), pm = bt_src(b);
+                    int pv = sl.cell_sc()[4 * ps + pm];
+                    // a predecessor improved in THIS iteration counts with its new value only if it precedes this cell in map order
+                    int nImp = S.nImp < C::IMPCAP ? S.nImp : C::IMPCAP;
+                    for(int q = 0; q < nImp; q++)
+                        if(sl.imp_slot()[q] == ps && (sl.imp_mask()[q] & (1 << pm)) && sl.imp_key()[q] < key) pv = sl.imp_new()[4 * q + pm];
+                    diff = Dv - pv;
+                }
+            }
+            // ---- running maximum bookkeeping, :1043-1062
+            bool eq = keep && Dv == curMax0 && diff != 0;
+            if(grp_ballot<GW>(eq)) anyEqDiff = true;
+            int wm = grp_max_i32<GW>(keep ? Dv : DP_NEG);
+            if(wm > itMaxNew) { itMaxNew = wm; itMaxKey = ~0ull; }
+            u64 mn = grp_min_u64<GW>((keep && Dv == itMaxNew) ? key : ~0ull);
+            if(mn < itMaxKey) itMaxKey = mn;
+            // stash for the filter phase: [0] = slot (or ~0 if dropped), [1] = merged D | GG<<16, [2] = merged SG
+            if(act) {
+                S.hbest[0][h] = keep ? (typename C::Best)(u32)slot : (typename C::Best)0xFFFFFFFFu;
+                S.hbest[1][h] = (typename C::Best)(((u32)(unsigned short)(short)mD) | ((u32)(unsigned short)(short)mG << 16));
+                S.hbest[2][h] = (typename C::Best)(u32)(unsigned short)(short)mS;
+            }
+        }
+        WSYNC();
+    }
+    if(guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
+    const int nCompletedNew = nCompleted0 + guni<GW>(S.nCompletedAdd);
+    // apply staged improvements of existing cells and patch cached frontier copies
+    {
+        int nImp = guni<GW>(S.nImp);
+        for(int q = gl; q < nImp; q += GW) {
+            int es = sl.imp_slot()[q]; int msk = sl.imp_mask()[q];
+            for(int m = 0; m < 3; m++) if(msk & (1 << m)) { sl.cell_sc()[4 * es + m] = sl.imp_new()[4 * q + m]; sl.cell_bt()[m * C::CELLS + es] = sl.imp_bt()[3 * q + m]; }
+        }
+        if(nImp) {
+            WSYNC();
+            for(int q = 0; q < nImp; q++) {
+                int es = sl.imp_slot()[q]; short v0 = sl.imp_new()[4 * q + 0], v1 = sl.imp_new()[4 * q + 1], v2 = sl.imp_new()[4 * q + 2];
+                for(int i = gl; i < n1; i += GW) if(S.fslot[b1][i] == es) { S.fD[b1][i] = v0; S.fG[b1][i] = v1; S.fS[b1][i] = v2; }
+                for(int i = gl; i < n2; i += GW) if(S.fslot[b2][i] == es) { S.fD[b2][i] = v0; S.fG[b2][i] = v1; S.fS[b2][i] = v2; }
+            }
+        }
+    }
+    // "== currentMaximum && diff != 0" / "> currentMaximum" / overwritten entry all set lastMaximumIncrease_at_diagonalI
+    int curMax = curMax0, lastInc = lastInc0, firstMaxSlot = -1;
+    if(itMaxNew > curMax0) {
+        curMax = itMaxNew; lastInc = d;
+        int fs = -1;      // slot of the first cell in map order that carries the new maximum
+        for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; if(S.hkey[h] == itMaxKey) fs = (int)S.hbest[0][h]; }
+        firstMaxSlot = grp_max_i32<GW>(fs);
+    }
+    if(anyEqDiff || anyOw) lastInc = d;
+
+    // ================= filter + sort, :1076-1105 ======================================
+    int mx = DP_NEG;
+    for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); mx = max(mx, v); } }
+    mx = grp_max_i32<GW>(mx);
+    int nNew = 0;
+    for(int t0 = 0; t0 < nT; t0 += GW) {
+        int t = t0 + gl;
+        bool pass = false; u64 key = 0; int h = 0;
+        if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
+        int rank = 0;
+        if(pass) {
+            for(int u = 0; u < nT; u++) {
+                int hu = S.tlist[u];
+                if((u32)S.hbest[0][hu] == 0xFFFFFFFFu) continue;
+                int vu = (short)((u32)S.hbest[1][hu] & 0xFFFF);
+                if((mx - vu) <= 15 && S.hkey[hu] < key) rank++;
+            }
+            if(rank < C::WCAP) {
+                S.fkey[bn][rank] = key; S.fslot[bn][rank] = (short)(int)S.hbest[0][h];
+                S.fD[bn][rank] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][rank] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][rank] = (short)((u32)S.hbest[2][h] & 0xFFFF);
+            }
+        }
+        nNew += __popcll(grp_ballot<GW>(pass));
+    }
+    if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
+    WSYNC();
+    // reset the hash entries used by this iteration
+    for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
+    if(gl == 0) {
+        S.nT = 0;
+        st.b2 = b1; st.b1 = bn; st.bn = b2;                                                   // m2 := m1; m1 := this, :1104-1105
+        st.n2 = n1; st.n1 = nNew;
+        st.d = d + 1; st.itersRun = d;
+        st.nCells = nCells; st.nCompleted = nCompletedNew; st.earlyInit = earlyInit;
+        st.curMax = curMax; st.lastInc = lastInc; if(firstMaxSlot >= 0) st.firstMaxSlot = firstMaxSlot;
+        st.cellsEvaluated += (u32)nT;
+    }
+    WSYNC();
+    return PH_RUN;
+}
+
+// ---- end cell, :1381-1517
+template <class C>
+__device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, u32 rng_seed, const bool fwd)
+{
+    constexpr int GW = C::GW;
+    const int gl = grp_lane<GW>();
+    DpState& st = S.st;
+    const int nCompleted = guni<GW>(st.nCompleted);
+    const u32 seed = rng_seed + (u32)guni<GW>(st.item);
+    const int curMax = guni<GW>(st.curMax), firstMaxSlot = guni<GW>(st.firstMaxSlot), start_seq = guni<GW>(st.start_seq);
+    int endSlot = -1, endScore = 0;
+    if(nCompleted > 0) {
+        int best = DP_NEG;
+        for(int i = gl; i < nCompleted; i += GW) best = max(best, (int)sl.cell_sc()[4 * sl.completed()[i] + 0]);
+        best = grp_max_i32<GW>(best);
+        int nTies = 0;
+        for(int i0 = 0; i0 < nCompleted; i0 += GW) { int i = i0 + gl; bool tie = i < nCompleted && sl.cell_sc()[4 * sl.completed()[i] + 0] == best; nTies += __popcll(grp_ballot<GW>(tie)); }
+        u32 sd = seed;
+        int selectedIndex = glibc_rand_r(&sd) % nTies;                                      // Utilities.cpp:922-927
+        // the tie with exactly `selectedIndex` ties before it in "x/z" string order
+        int found = -1;
+        for(int i0 = 0; i0 < nCompleted; i0 += GW) {
+            int i = i0 + gl;
+            if(i < nCompleted) {
+                int s = sl.completed()[i];
+                if(sl.cell_sc()[4 * s + 0] == best) {
+                    u64 k = sl.cell_key()[s]; int rank = 0;
+                    if(nTies > 1) {
+                        int kz = key_node(k) - G.level_off[key_x(k)];
+                        for(int u = 0; u < nCompleted; u++) { int su = sl.completed()[u]; if(su != s && sl.cell_sc()[4 * su + 0] == best) { u64 ku = sl.cell_key()[su];
+                            if(xz_less(key_x(ku), key_node(ku) - G.level_off[key_x(ku)], key_x(k), kz)) rank++; } }
+                    }
+                    if(rank == selectedIndex) found = s;
+                }
+            }
+        }
+        endSlot = grp_max_i32<GW>(found); endScore = best;
+    } else if(curMax > 0) {
+        endSlot = firstMaxSlot; endScore = sl.cell_sc()[4 * firstMaxSlot + 0];
+    }
+    if(endSlot < 0) return PH_DONE;                                                          // no extension (have = 0)
+    u64 ek = sl.cell_key()[endSlot];
+    const int yEnd = key_y(ek);
+    if(gl == 0) {
+        st.endSlot = endSlot; st.endScore = endScore;
+        if(fwd) { st.sb = start_seq; st.se = yEnd - 1; }                                     // toVerboseSeedChain, VirtualNWUnique.cpp:28-29
+        else { st.sb = yEnd; st.se = start_seq - 1; }
+        S.btSlot = endSlot; S.btM = 0; S.btX = key_x(ek); S.btY = yEnd; S.btGuard = 0; S.btDone = 0; S.nNew = 0; S.nKeepF = 0;
+    }
+    WSYNC();
+    return PH_BT;
+}
+
+// ---- backtrace, :1109-1354: lane 0 of the group chases at most `maxSteps` back pointers per call
+template <class C>
+__device__ inline int dp_backtrace(DpLdsT<C>& S, const DpSlabT<C>& sl, int maxSteps, const bool fwd)
+{
+    constexpr int GW = C::GW;
+    const int gl = grp_lane<GW>();
+    DpState& st = S.st;
+    const int dir = fwd ? 1 : -1;
+    if(gl == 0) {
+        const int startLevel = st.startLevel, start_seq = st.start_seq;
+        int slot = S.btSlot, m = S.btM, x = S.btX, y = S.btY, guardSteps = S.btGuard;
+        int nSteps = S.nNew, nCols = S.nKeepF;
+        int done = 0;
+        for(int it = 0; it < maxSteps; it++) {
+            if(!((x != startLevel || y != start_seq) && nSteps < C::STEPS && guardSteps++ < 4 * C::STEPS)) { done = 1; break; }
+            u64 b = sl.cell_bt()[m * C::CELLS + slot];
+            int kind = bt_kind(b);
+            int prev = bt_prev(b);
+            int px = 0;
+            if(kind == K_JUMP) px = key_x(sl.cell_key()[prev]);
+            if(kind != K_HOP) {
+                int len = 1;
+                if(kind == K_JUMP) len = px > x ? px - x : x - px;
+                sl.step_bt()[nSteps] = b; sl.step_xy()[nSteps] = ((u64)(u32)x << 32) | ((u64)(u32)y << 8) | 0; nSteps++; nCols += len;
+            }
+            if(kind == K_DIAG) { x -= dir; y -= dir; }
+            else if(kind == K_GGAP) { y -= dir; }
+            else if(kind == K_SGAP) { x -= dir; }
+            else if(kind == K_JUMP) { x = px; }
+            slot = prev; m = bt_src(b);
+        }
+        if(!done && !(x != startLevel || y != start_seq)) done = 1;
+        S.btSlot = slot; S.btM = m; S.btX = x; S.btY = y; S.btGuard = guardSteps; S.nNew = nSteps; S.nKeepF = nCols;
+        if(done) {
+            if(nSteps >= C::STEPS || guardSteps >= 4 * C::STEPS) st.err = __LINE__;
+            st.nSteps = nSteps; st.nCols = nCols;
+        }
+        S.btDone = done;
+    }
+    WSYNC();
+    if(guni<GW>(S.btDone)) return guni<GW>(st.err) ? PH_DONE : PH_EXPAND;
+    return PH_BT;
+}
+
+// ---- all lanes of the group expand the steps into alignment columns, written into the chain's output row:
+// the left extension at its final place [seq_begin, seq_begin + n), the right extension right-aligned in the row
+// (k_stitch_chains moves it next to the seed once the left extension's length is known)
+template <class C>
+__device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, const DevBatch& B, const bool fwd)
+{
+    constexpr int GW = C::GW;
+    const int gl = grp_lane<GW>();
+    DpState& st = S.st;
+    const int nSteps = guni<GW>(st.nSteps), nCols = guni<GW>(st.nCols);
+    const int stride = B.stride;
+    const int max_seqI = guni<GW>(st.seqLen);
+    const int sb = guni<GW>(st.sb), se = guni<GW>(st.se);
+    const uint8_t* seqp = B.read_bases + guni<GW>(st.rOff);
+    if(nCols > stride) { if(gl == 0) st.err = -1000000 - nCols; WSYNC(); return PH_DONE; }
+    if(sb > se) { if(gl == 0) { st.err = __LINE__; st.have = 0; } WSYNC(); return PH_DONE; }
+    if(gl == 0) st.have = 1;
+    WSYNC();
+    const int c = guni<GW>(st.item) >> 1;
+    const int rowOff = fwd ? stride - nCols : sb;
+    if(rowOff + nCols > stride) return PH_DONE;             // the stitched chain cannot fit the row: k_stitch_chains reports the column error
+    const size_t cb = (size_t)c * stride + rowOff;
+    int* oL = B.ext_level + cb; int* oE = B.ext_edge + cb; uint8_t* oG = B.ext_g + cb; uint8_t* oS = B.ext_s + cb;
+    int base = 0;
+    for(int s0 = 0; s0 < nSteps; s0 += GW) {
+        int s = s0 + gl; bool act = s < nSteps;
+        u64 b = act ? sl.step_bt()[s] : 0; u64 xy = act ? sl.step_xy()[s] : 0;
+        int kind = bt_kind(b);
+        // resolve the graph object behind the push index j: edge j of the previous cell's node, or entry j of its jump table
+        int pnode = 0, robj = -1;
+        if(act && kind != K_GGAP) {
+            u64 pkey = sl.cell_key()[bt_prev(b)]; pnode = key_node(pkey);
+            int j = bt_edge(b);
+            if(kind == K_JUMP) robj = (fwd ? G.jf_path : G.jb_path)[(fwd ? G.jf_off : G.jb_off)[pnode] + j];
+            else robj = fwd ? G.out_eid[G.out_off[pnode] + j] : G.in_eid[G.in_off[pnode] + j];
+        }
+        int len = act ? (kind == K_JUMP ? G.path_len[robj] : 1) : 0;
+        int total; int off = grp_excl_scan<GW>(len, total);
+        if(act) {
+            int x = (int)(xy >> 32), y = (int)((xy >> 8) & 0xFFFFFF);
+            int start = fwd ? (nCols - (base + off) - len) : (base + off);     // forward traces are reversed at the end, :1319-1326
+            if(kind == K_JUMP) {                                                       // :1282-1307
+                int p = robj; long long po = G.path_off[p];
+                int lvl0 = G.node_level[G.edge_from_new[G.path_edges[po]]];
+                for(int j = 0; j < len; j++) { oL[start + j] = lvl0 + j; oE[start + j] = G.path_edges[po + j]; oG[start + j] = '_'; oS[start + j] = '_'; }
+            } else {
+                int eid = robj;
+                unsigned char sc = fwd ? (y >= 1 ? seqp[y - 1] : 0) : (y < max_seqI ? seqp[y] : 0);
+                int lvl = fwd ? x - 1 : x;
+                if(kind == K_DIAG) { oL[start] = lvl; oE[start] = eid; oG[start] = G.edge_label[eid]; oS[start] = sc; }
+                else if(kind == K_GGAP) { oL[start] = -1; oE[start] = -1; oG[start] = '_'; oS[start] = sc; }
+                else { oL[start] = lvl; oE[start] = eid; oG[start] = G.edge_label[eid]; oS[start] = '_'; }
+            }
+        }
+        base += total;
+    }
+    return PH_DONE;
+}
+
+// ------------------------------------------------------------------------------------------
+// Input checks of extendSeedChain (extensionAligner.cpp:184-319) per chain and the list of DP items.
+// work_counter[8] / [9] count the left / right items; chains without any usable seed get their final status here.
+__global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, DpItem* items)
+{
+    const DevGraph& G = *Gp;
+    const DevBatch& B = *Bp;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    bool needL = false, needR = false;
+    DpItem itL, itR;
+    if(c < B.n_chains) {
+        const int st = B.seed_status[c];
+        B.dp_iters[2 * c] = 0; B.dp_iters[2 * c + 1] = 0; B.dp_score[2 * c] = INT32_MIN; B.dp_score[2 * c + 1] = INT32_MIN;
+        B.dp_ncols[2 * c] = -1; B.dp_ncols[2 * c + 1] = -1; B.dp_err[2 * c] = 0; B.dp_err[2 * c + 1] = 0;
+        if(st != HLALA_CHAIN_OK) {
+            B.ext_status[c] = st; B.ext_ncols[c] = 0;
+            if(st < 0) atomicAdd(&B.counters[CNT_ERRORS], 1ull);
+        } else {
+            const int stride = B.stride;
+            const int r = B.chain_read[c];
+            const int rOff = B.read_off[r], seqLen = B.read_off[r + 1] - rOff;
+            const size_t cb = (size_t)c * stride;
+            const int nSeed = B.seed_ncols[c], sBegin = B.seed_begin[c], sEnd = B.seed_end[c];
+            int err = 0;
+            if(seqLen > DP_SEQCAP || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;
+            int e0 = -1, e1 = -1;
+            if(!err) {
+                e0 = B.seed_edge[cb]; e1 = B.seed_edge[cb + nSeed - 1];
+                if(e0 < 0 || e1 < 0 || e0 >= G.E || e1 >= G.E) err = HLALA_CHAIN_ERR_INPUT;
+            }
+            if(err) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = 0.0; atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
+            else {
+                B.ext_status[c] = EXT_PENDING;
+                if(sBegin != 0) {                                                      // left extension, extensionAligner.cpp:220-268
+                    int firstNode = G.edge_from_new[e0]; int lvl = G.node_level[firstNode];
+                    if(lvl > 0) { needL = true; itL.item = 2 * c; itL.rOff = rOff; itL.seqLen = seqLen; itL.start_seq = sBegin; itL.startLevel = lvl; itL.startNode = firstNode; itL.pad0 = 0; itL.pad1 = 0; }
+                }
+                if(sEnd != seqLen - 1) {                                               // right extension, :271-319
+                    int lastNode = G.edge_to_new[e1]; int lvl = G.node_level[lastNode];
+                    if(lvl < G.L - 1) { needR = true; itR.item = 2 * c + 1; itR.rOff = rOff; itR.seqLen = seqLen; itR.start_seq = sEnd + 1; itR.startLevel = lvl; itR.startNode = lastNode; itR.pad0 = 0; itR.pad1 = 0; }
+                }
+            }
+        }
+    }
+    // wave-aggregated append: left extensions fill items[0, n_chains), right extensions items[n_chains, 2 n_chains)
+    const int lane = lane_id();
+    const u64 mL = __ballot(needL), mR = __ballot(needR);
+    const u64 below = (1ull << lane) - 1ull;
+    if(mL) {
+        int basePos = 0;
+        if(lane == 0) basePos = atomicAdd(&B.work_counter[8], __popcll(mL));
+        basePos = __shfl(basePos, 0);
+        if(needL) items[basePos + __popcll(mL & below)] = itL;
+    }
+    if(mR) {
+        int basePos = 0;
+        if(lane == 0) basePos = atomicAdd(&B.work_counter[9], __popcll(mR));
+        basePos = __shfl(basePos, 0);
+        if(needR) items[B.n_chains + basePos + __popcll(mR & below)] = itR;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TIER 0: items of k_dp_items, the left extensions first and then the right extensions, so that the direction (and with it
+//         every choice between the out- and the in-edge arrays) is uniform across the four groups of a wavefront;
+// TIER 1: items that outgrew DpTiny (retry list 1); TIER 2: items that outgrew DpSmall (retry list 2).
+template <class C, int TIER>
+__global__ __launch_bounds__(64, (C::GW == 16 ? 4 : 5)) void k_dp(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items,
+                                                                    char* slabs, size_t slabBytes, u32 rng_seed)
+{
+    constexpr int GW = C::GW;
+    constexpr int NG = 64 / GW;
+    // graph / batch descriptors stay in memory (scalar loads on demand): passing them by value costs ~150 SGPRs
+    const DevGraph& G = *Gp;
+    const DevBatch& B = *Bp;
+    __shared__ DpLdsT<C> SS[NG];
+    const int gl = grp_lane<GW>();
+    const int g = (int)((threadIdx.x & 63) / GW);
+    DpLdsT<C>& S = SS[g];
+    DpSlabT<C> sl; sl.base = slabs + ((size_t)blockIdx.x * NG + g) * slabBytes;
+    const uint8_t* readBases = B.read_bases;
+
+    if(gl == 0) { S.accCalls = 0; S.accIters = 0; S.accCells = 0; S.accEdges = 0; }
+#ifdef HLALA_DP_TIMING                                     // build-time switch: cycles per state of the persistent loop -> counters[8..15]
+    long long tAcc[6] = {0, 0, 0, 0, 0, 0}; long long trips = 0, runGroups = 0; long long tMark = clock64();
+#define DP_T(i) do { long long t_ = clock64(); tAcc[i] += t_ - tMark; tMark = t_; } while(0)
+#else
+#define DP_T(i) do { } while(0)
+#endif
+
+    for(int dirPass = 0; dirPass < (TIER == 0 ? 2 : 1); dirPass++) {
+        int* fetchCounter = &B.work_counter[TIER == 0 ? (dirPass ? 10 : 1) : (TIER == 1 ? 4 : 6)];
+        const int nItems = uni(B.work_counter[TIER == 0 ? 8 + dirPass : (TIER == 1 ? 3 : 5)]);
+        const int listBase = (TIER == 0 && dirPass) ? B.n_chains : 0;
+        const int* srcList = TIER == 1 ? B.retry_list : B.retry_list2;
+        bool fwd = dirPass != 0;                           // TIER > 0: set per item (one group per wave)
+        int phase = PH_IDLE;
+        bool more = true;
+        int edgesAcc = 0;                                  // per-lane partial sum of the edges the current DP touched
+
+        for(;;) {
+            if(phase == PH_IDLE && more) {
+                int w = 0;
+                if(gl == 0) w = atomicAdd(fetchCounter, 1);
+                w = (GW == 64) ? __builtin_amdgcn_readfirstlane(w) : grp_bcast<GW>(w, 0);
+                if(w >= nItems) more = false;
+                else {
+                    const int idx = (TIER == 0) ? listBase + w : guni<GW>(srcList[w]);
+                    const int4* ip = (const int4*)(items + idx);
+                    int4 a = ip[0], b = ip[1];
+                    DpItem it; it.item = a.x; it.rOff = a.y; it.seqLen = a.z; it.start_seq = a.w; it.startLevel = b.x; it.startNode = b.y; it.pad0 = 0; it.pad1 = 0;
+                    if(TIER > 0) fwd = (uni(it.item) & 1) != 0;
+                    phase = dp_begin<C>(S, sl, G, it, idx);
+                    edgesAcc = 0;
+                }
+            }
+            DP_T(0);
+            if(!__ballot(phase != PH_IDLE)) break;       // every group is idle and found no more work
+#ifdef HLALA_DP_TIMING
+            trips++; runGroups += __popcll(__ballot(phase == PH_RUN)) / GW;
+#endif
+            if(phase == PH_DONE) {
+                // final bookkeeping of this DP in this class; a DP that outgrew the class is queued for the next one and leaves no trace
+                const int edges = grp_sum_i32<GW>(edgesAcc);
+                if(gl == 0) {
+                    const DpState& st = S.st;
+                    const bool capacity = st.err != 0 && st.err > -1000000;
+                    if(capacity && TIER < 2) {
+                        int* cnt = &B.work_counter[TIER == 0 ? 3 : 5]; int* lst = TIER == 0 ? B.retry_list : B.retry_list2;
+                        int q = atomicAdd(cnt, 1); lst[q] = st.itemIdx;
+                    } else {
+                        const int item = st.item;
+                        B.dp_iters[item] = st.itersRun; B.dp_score[item] = st.have ? st.endScore : INT32_MIN;
+                        B.dp_ncols[item] = st.have ? st.nCols : -1; B.dp_sb[item] = st.sb; B.dp_se[item] = st.se; B.dp_err[item] = st.err;
+                        S.accCalls++; S.accIters += (u64)st.itersRun; S.accCells += (u64)st.cellsEvaluated; S.accEdges += (u64)edges;
+                    }
+                }
+                phase = PH_IDLE;
+            }
+            DP_T(1);
+            if(phase == PH_EXPAND) phase = dp_expand<C>(S, sl, G, B, fwd);
+            DP_T(2);
+            if(phase == PH_BT) phase = dp_backtrace<C>(S, sl, DP_BT_STEPS_PER_TRIP, fwd);
+            DP_T(3);
+            if(phase == PH_SELECT) phase = dp_select<C>(S, sl, G, rng_seed, fwd);
+            DP_T(4);
+            if(phase == PH_RUN) phase = dp_iterate<C>(S, sl, G, readBases, fwd, edgesAcc);
+            DP_T(5);
+        }
+    }
+    if(gl == 0 && S.accCalls) {
+        atomicAdd(&B.counters[CNT_DP_CALLS], S.accCalls); atomicAdd(&B.counters[CNT_DP_ITERS], S.accIters);
+        atomicAdd(&B.counters[CNT_DP_CELLS], S.accCells); atomicAdd(&B.counters[CNT_EDGES], S.accEdges);
+    }
+#ifdef HLALA_DP_TIMING
+    if(TIER == 0 && (threadIdx.x & 63) == 0) { for(int i = 0; i < 6; i++) atomicAdd(&B.counters[8 + i], (u64)tAcc[i]); atomicAdd(&B.counters[14], (u64)trips); atomicAdd(&B.counters[15], (u64)runGroups); }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// one wave per chain: stitch left extension + seed + right extension (extendWithOtherSeedChain /
+// extendToFullSequenceLength, verboseSeedChain.cpp:23-136), then scoreOneAlignment (extensionAligner.cpp:52-182).
+__global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp)
+{
+    const DevBatch& B = *Bp;
+    const DevTables& T = *Tp;
+    const int lane = lane_id();
+    const int stride = B.stride;
+    for(;;) {
+        const int c = next_work(&B.work_counter[7]);
+        if(c >= B.n_chains) break;
+        if(uni(B.ext_status[c]) == EXT_PENDING) {
+        const int r = uni(B.chain_read[c]);
+        const int rOff = uni(B.read_off[r]), seqLen = uni(B.read_off[r + 1]) - rOff;
+        const size_t cb = (size_t)c * stride;
+        const int nSeed = uni(B.seed_ncols[c]), sBegin = uni(B.seed_begin[c]), sEnd = uni(B.seed_end[c]);
+        const int ncL = uni(B.dp_ncols[2 * c]), ncR = uni(B.dp_ncols[2 * c + 1]);
+        const int errL = uni(B.dp_err[2 * c]), errR = uni(B.dp_err[2 * c + 1]);
+        int err = 0;
+        if(errL || errR) err = ((errL <= -1000000) || (errR <= -1000000)) ? HLALA_CHAIN_ERR_COLUMNS : HLALA_CHAIN_ERR_FRONTIER;
+        const bool haveL = ncL >= 0 && !errL, haveR = ncR >= 0 && !errR;
+        const int nL = haveL ? ncL : 0, nR = haveR ? ncR : 0;
+        const int newBegin = haveL ? uni(B.dp_sb[2 * c]) : sBegin, newEnd = haveR ? uni(B.dp_se[2 * c + 1]) : sEnd;
+        const int padL = newBegin, padR = seqLen - 1 - newEnd;
+        const int total = padL + nL + nSeed + nR + padR;
+        if(!err && total > stride) err = HLALA_CHAIN_ERR_COLUMNS;
+        if(err) {
+            if(lane == 0) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(errL ? errL : errR); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
+        } else {
+        // ---- stitch.  The left extension already sits at [padL, padL + nL).  The right extension moves from the end of the row
+        // to its place after the seed: destination <= source, so ascending 64-column chunks (read all, then write all) are safe.
+        {
+            const int src = stride - nR, dst = padL + nL + nSeed;
+            if(nR > 0 && dst != src) {
+                for(int q0 = 0; q0 < nR; q0 += 64) {
+                    int q = q0 + lane; bool in = q < nR;
+                    int lv = 0, ed = 0; unsigned char gg = 0, ss = 0;
+                    if(in) { lv = B.ext_level[cb + src + q]; ed = B.ext_edge[cb + src + q]; gg = B.ext_g[cb + src + q]; ss = B.ext_s[cb + src + q]; }
+                    WSYNC();
+                    if(in) { B.ext_level[cb + dst + q] = lv; B.ext_edge[cb + dst + q] = ed; B.ext_g[cb + dst + q] = gg; B.ext_s[cb + dst + q] = ss; }
+                    WSYNC();
+                }
+            }
+        }
+        for(int j = lane; j < total; j += 64) {
+            unsigned char fs = 0;
+            if(j < padL) { B.ext_level[cb + j] = -1; B.ext_edge[cb + j] = -1; B.ext_g[cb + j] = '_'; B.ext_s[cb + j] = B.read_bases[rOff + j]; }
+            else if(j < padL + nL) { }
+            else if(j < padL + nL + nSeed) { int q = j - padL - nL; B.ext_level[cb + j] = B.seed_level[cb + q]; B.ext_edge[cb + j] = B.seed_edge[cb + q]; B.ext_g[cb + j] = B.seed_g[cb + q]; B.ext_s[cb + j] = B.seed_s[cb + q]; fs = 1; }
+            else if(j < padL + nL + nSeed + nR) { }
+            else { int q = j - (padL + nL + nSeed + nR); B.ext_level[cb + j] = -1; B.ext_edge[cb + j] = -1; B.ext_g[cb + j] = '_'; B.ext_s[cb + j] = B.read_bases[rOff + newEnd + 1 + q]; }
+            B.ext_fromseed[cb + j] = fs;
+        }
+        WSYNC();
+        // ---- scoreOneAlignment: terms are added strictly left to right in FP64 (same order as the reference loop).
+        // The read quality of alignment-orientation base i is read_quals[i] in both strands: the reference indexes the
+        // ORIGINAL-orientation read with len-i-1 when the chain is reverse (extensionAligner.cpp:85-88), which is the same base.
+        {
+            // phase 1 (parallel): every lane turns its <= 8 consecutive columns into two addends each (an unused addend is +0.0,
+            // an exact identity); phase 2 (serial by construction of FP addition): the running sum walks the lanes in order.
+            constexpr int LLPER = 8;                                   // 64 * 8 = 512 >= params.max_columns
+            const int per = (total + 63) / 64;
+            const int j0 = lane * per, j1 = min(total, j0 + per);
+            unsigned char scv[LLPER], gcv[LLPER];
+            int nb = 0;
+#pragma unroll
+            for(int k = 0; k < LLPER; k++) {
+                int j = j0 + k; bool in = k < per && j < j1;
+                scv[k] = in ? B.ext_s[cb + j] : (unsigned char)'_'; gcv[k] = in ? B.ext_g[cb + j] : (unsigned char)'_';
+                if(in && scv[k] != '_') nb++;
+            }
+            int tot; int before = wave_excl_scan(nb, tot);
+            double t1[LLPER], t2[LLPER];
+            {
+                int idx = before;
+#pragma unroll
+                for(int k = 0; k < LLPER; k++) {
+                    unsigned char sc = scv[k], gc = gcv[k];
+                    double a1 = 0.0, a2 = 0.0;
+                    if(sc != '_') {
+                        if(gc == '_') a1 = T.rate_ins_quarter;
+                        else { a1 = T.rate_match_mismatch; unsigned char q = B.read_quals[rOff + idx]; a2 = (sc == gc) ? T.ll_match[q] : T.ll_mismatch[q]; }
+                        idx++;
+                    } else if(gc != '_') a1 = T.rate_indel;
+                    t1[k] = a1; t2[k] = a2;
+                }
+            }
+            double acc = 0.0;
+            for(int l = 0; l < 64; l++) {
+                double in = __shfl(acc, l > 0 ? l - 1 : 0);
+                if(lane == l) {
+                    double a = (l == 0) ? 0.0 : in;
+#pragma unroll
+                    for(int k = 0; k < LLPER; k++) { a += t1[k]; a += t2[k]; }
+                    acc = a;
+                }
+            }
+            double ll = __shfl(acc, 63);
+            // first / last two defined levels for the pairing stage (verboseSeedChain.h:134-228)
+            if(lane == 0) {
+                int f0 = -1, f1 = -1, l0 = -1, l1 = -1;
+                for(int j = 0; j < total && f1 < 0; j++) { int lv = B.ext_level[cb + j]; if(lv != -1) { if(f0 < 0) f0 = lv; else f1 = lv; } }
+                for(int j = total - 1; j >= 0 && l1 < 0; j--) { int lv = B.ext_level[cb + j]; if(lv != -1) { if(l0 < 0) l0 = lv; else l1 = lv; } }
+                B.ext_firstlast[4 * c + 0] = f0; B.ext_firstlast[4 * c + 1] = f1; B.ext_firstlast[4 * c + 2] = l0; B.ext_firstlast[4 * c + 3] = l1;
+                B.ext_status[c] = HLALA_CHAIN_OK; B.ext_ncols[c] = total; B.ext_begin[c] = 0; B.ext_end[c] = seqLen - 1; B.ext_ll[c] = ll;
+                atomicAdd(&B.counters[CNT_CHAINS_EXT], 1ull); atomicAdd(&B.counters[CNT_OUT_COLS], (u64)total);
+            }
+        }
+        }   // no error
+        }   // chain pending
+        WSYNC();
+    }
+}
+
+}  // namespace hlala

@@ -16,12 +16,13 @@ buf = (C.c_ulonglong * 32)()
 ctx.lib.hlala_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_ulonglong)]
 ctx.lib.hlala_debug_counters(ctx.h, gb.b, buf)
 d = np.array(list(buf)[8:16], dtype=np.float64)
-names = ['gen', 'eval', 'filter', 'iters', 'select+backtrace', 'stitch+LL', 'chain_total', 'chains']
-print({n: float(v) for n, v in zip(names, d)})
-it = d[3]; ch = d[7]
-print('cycles/iter: gen %.0f eval %.0f filter %.0f | per chain: select+bt %.0f stitch+LL %.0f total %.0f | iters/chain %.1f' % (d[0]/it, d[1]/it, d[2]/it, d[4]/ch, d[5]/ch, d[6]/ch, it/ch))
-print('retry ms', st.ms_extend_retry, 'retried', st.n_chains_retried, 'errors', st.n_errors); print('ms', st.ms_project, st.ms_extend, st.ms_pair, 'pairs/s', n_pairs/((st.ms_project+st.ms_extend+st.ms_pair)*1e-3))
+if d[6] > 0:
+    print('k_dp<tiny> cycles/trip: fetch %.0f done %.0f expand %.0f bt %.0f select %.0f run %.0f | trips %d, run groups/trip %.2f' % (d[0]/d[6], d[1]/d[6], d[2]/d[6], d[3]/d[6], d[4]/d[6], d[5]/d[6], d[6], d[7]/d[6]))
+print('retry ms', st.ms_extend_retry, 'dp main ms', st.ms_dp_main, 'retried', st.n_chains_retried, 'retried large', st.n_dp_retried_large, 'errors', st.n_errors); print('ms', st.ms_project, st.ms_extend, st.ms_pair, 'pairs/s', n_pairs/((st.ms_project+st.ms_extend+st.ms_pair)*1e-3))
 
 pj = np.array(list(buf)[16:24], dtype=np.float64)
 if pj[7] > 0:
     print('project cycles/chain: walk %.0f trim+pad %.0f clean %.0f restrict %.0f stage+dp %.0f backtrace %.0f | chains %d' % tuple(list(pj[:6] / pj[7]) + [int(pj[7])]))
+hh = np.array(list(buf)[24:32], dtype=np.float64)
+if hh[0] > 0:
+    print('DP histogram: n=%d maxN<=8 %.4f <=16 %.4f <=32 %.4f | maxT<=24 %.4f <=48 %.4f | tiny-eligible %.4f | early %.4f' % (hh[0], hh[1]/hh[0], hh[2]/hh[0], hh[3]/hh[0], hh[4]/hh[0], hh[5]/hh[0], hh[6]/hh[0], hh[7]/hh[0]))
