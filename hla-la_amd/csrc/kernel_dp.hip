@@ -58,11 +58,14 @@ struct DpState {
     int have, sb, se, err;
 };
 
+template <bool SMALL> struct TlistT { typedef unsigned short type; };
+template <> struct TlistT<true> { typedef unsigned char type; };
+
 template <class C>
 struct __align__(16) DpLdsT {
     u64 hkey[C::HC];
     typename C::Best hbest[3][C::HC];
-    unsigned short tlist[C::HC];
+    typename TlistT<(C::HC <= 256)>::type tlist[C::HC];     // hash entries in use this iteration
     u64 fkey[3][C::WCAP];
     short fslot[3][C::WCAP];        // table slot of the frontier cell
     short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
@@ -72,6 +75,9 @@ struct __align__(16) DpLdsT {
     int btSlot, btM, btX, btY, btGuard, btDone;       // back-pointer chase in progress (lane 0 of the group)
     DpState st;
     u64 accCalls, accIters, accCells, accEdges;       // work counters of the DPs this group finished (flushed once at exit)
+#ifdef HLALA_DP_TIMING
+    long long tPh[4];
+#endif
 };
 
 // Scratch of one DP call in HBM (private to its group).  Only the base address is held in registers; every array sits at a
@@ -165,7 +171,7 @@ template <int GW> __device__ __forceinline__ u64 grp_ballot(bool p)
 {
     u64 b = __ballot(p);
     if(GW == 64) return b;
-    return (b >> grp_base<GW>()) & ((1ull << GW) - 1ull);
+    return (b >> grp_base<GW>()) & ((1ull << (GW & 63)) - 1ull);
 }
 template <int GW> __device__ __forceinline__ int grp_bcast(int v, int srcGroupLane)
 {
@@ -197,23 +203,16 @@ __device__ __forceinline__ int best_score(u64 b) { return b ? (int)(b >> 32) - 6
 __device__ __forceinline__ int best_order(u32 b) { return 0xFFFF - (int)(b & 0xFFFF); }
 __device__ __forceinline__ int best_order(u64 b) { return 0x7FFFFFFF - (int)(b & 0xFFFFFFFFull); }
 
-// push one candidate (Alt::{D,GG,SG}.push_back in the reference) -- returns false on hash overflow
+// push one candidate (Alt::{D,GG,SG}.push_back in the reference) -- returns false on hash overflow.
+// One LDS round trip per probe: the compare-and-swap both claims an empty entry and reports the resident key.
 template <class C>
 __device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int order)
 {
     u32 h = hash64(key) & (C::HC - 1);
 #pragma nounroll
     for(int probe = 0; probe < C::HC; probe++) {
-        u64 cur = S.hkey[h];
-        if(cur == HKEY_EMPTY) {
-            u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
-            if(old == HKEY_EMPTY) {
-                int pos = atomicAdd(&S.nT, 1);
-                if(pos < C::HC) S.tlist[pos] = (unsigned short)h;
-                cur = key;
-            } else cur = old;
-        }
-        if(cur == key) { typename C::Best v; pack_best(v, score, order); atomicMax(&S.hbest[mat][h], v); return true; }
+        u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
+        if(old == HKEY_EMPTY || old == key) { typename C::Best v; pack_best(v, score, order); atomicMax(&S.hbest[mat][h], v); return true; }
         h = (h + 1) & (C::HC - 1);
     }
     return false;
@@ -285,7 +284,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.cellsEvaluated = 0;
         st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
         st.have = 0; st.sb = 0; st.se = -1; st.err = 0;
-        S.nT = 0; S.err = 0;
+        S.err = 0;
         sl.cell_key()[0] = mk_key(it.startLevel, it.start_seq, it.startNode);
         sl.cell_sc()[0] = 0; sl.cell_sc()[1] = (short)DP_NEG; sl.cell_sc()[2] = (short)DP_NEG; sl.cell_sc()[3] = 0;
         sl.cell_bt()[0] = 0; sl.cell_bt()[C::CELLS] = 0; sl.cell_bt()[2 * C::CELLS] = 0;
@@ -331,6 +330,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     }
     if(d > 60000) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }      // watchdog: far beyond any read length + patience
 
+#ifdef HLALA_DP_TIMING
+    long long tq0 = clock64();
+#define DP_TQ(i) do { long long t_ = clock64(); if(gl == 0) S.tPh[i] += t_ - tq0; tq0 = t_; } while(0)
+#else
+#define DP_TQ(i) do { } while(0)
+#endif
     // ================= generate =====================================================
     const int* eoff = fwd ? G.out_off : G.in_off; const int* eto = fwd ? G.out_to : G.in_from; const uint8_t* elab = fwd ? G.out_label : G.in_label;
     int edges = 0;      // (the direction is wave-uniform: these are scalar selects)
@@ -400,7 +405,17 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     }
     edgesAcc += edges;
     WSYNC();
-    const int nT = guni<GW>(S.nT);
+    // target list = occupied hash entries, compacted with a ballot per GW entries (no per-push counter, no ordering assumed)
+    int nT = 0;
+    for(int h0 = 0; h0 < C::HC; h0 += GW) {
+        const int h = h0 + gl;
+        const bool occ = S.hkey[h] != HKEY_EMPTY;
+        const u64 m = grp_ballot<GW>(occ);
+        if(occ) S.tlist[nT + __popcll(m & ((1ull << gl) - 1ull))] = (typename TlistT<(C::HC <= 256)>::type)h;
+        nT += __popcll(m);
+    }
+    WSYNC();
+    DP_TQ(0);
     if(nT > (C::HC * 3) / 4 || guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
 
     // ================= evaluate =====================================================
@@ -596,36 +611,66 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     }
     if(anyEqDiff || anyOw) lastInc = d;
 
+    DP_TQ(1);
     // ================= filter + sort, :1076-1105 ======================================
     int mx = DP_NEG;
     for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); mx = max(mx, v); } }
     mx = grp_max_i32<GW>(mx);
     int nNew = 0;
-    for(int t0 = 0; t0 < nT; t0 += GW) {
-        int t = t0 + gl;
-        bool pass = false; u64 key = 0; int h = 0;
-        if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
-        int rank = 0;
-        if(pass) {
-            for(int u = 0; u < nT; u++) {
-                int hu = S.tlist[u];
-                if((u32)S.hbest[0][hu] == 0xFFFFFFFFu) continue;
-                int vu = (short)((u32)S.hbest[1][hu] & 0xFFFF);
-                if((mx - vu) <= 15 && S.hkey[hu] < key) rank++;
+    if(C::WCAP <= GW) {
+        // survivors are first compacted into the new frontier buffer in target-list order, then every survivor counts the
+        // smaller keys among them (its rank = its place in std::map order) and the buffer is rewritten in rank order
+        for(int t0 = 0; t0 < nT; t0 += GW) {
+            int t = t0 + gl;
+            bool pass = false; u64 key = 0; int h = 0;
+            if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
+            const u64 m = grp_ballot<GW>(pass);
+            const int pos = nNew + __popcll(m & ((1ull << gl) - 1ull));
+            if(pass && pos < C::WCAP) {
+                S.fkey[bn][pos] = key; S.fslot[bn][pos] = (short)(int)S.hbest[0][h];
+                S.fD[bn][pos] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][pos] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][pos] = (short)((u32)S.hbest[2][h] & 0xFFFF);
             }
-            if(rank < C::WCAP) {
-                S.fkey[bn][rank] = key; S.fslot[bn][rank] = (short)(int)S.hbest[0][h];
-                S.fD[bn][rank] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][rank] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][rank] = (short)((u32)S.hbest[2][h] & 0xFFFF);
-            }
+            nNew += __popcll(m);
         }
-        nNew += __popcll(grp_ballot<GW>(pass));
+        if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
+        WSYNC();
+        if(nNew > 1) {
+            const bool act = gl < nNew;
+            u64 key = 0; short vs = 0, vD = 0, vG = 0, vS = 0; int rank = 0;
+            if(act) {
+                key = S.fkey[bn][gl]; vs = S.fslot[bn][gl]; vD = S.fD[bn][gl]; vG = S.fG[bn][gl]; vS = S.fS[bn][gl];
+                for(int u = 0; u < nNew; u++) rank += (S.fkey[bn][u] < key) ? 1 : 0;
+            }
+            WSYNC();
+            if(act) { S.fkey[bn][rank] = key; S.fslot[bn][rank] = vs; S.fD[bn][rank] = vD; S.fG[bn][rank] = vG; S.fS[bn][rank] = vS; }
+        }
+    } else {
+        // frontier larger than the group: rank among all surviving targets straight from the hash
+        for(int t0 = 0; t0 < nT; t0 += GW) {
+            int t = t0 + gl;
+            bool pass = false; u64 key = 0; int h = 0;
+            if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
+            int rank = 0;
+            if(pass) {
+                for(int u = 0; u < nT; u++) {
+                    int hu = S.tlist[u];
+                    if((u32)S.hbest[0][hu] == 0xFFFFFFFFu) continue;
+                    int vu = (short)((u32)S.hbest[1][hu] & 0xFFFF);
+                    if((mx - vu) <= 15 && S.hkey[hu] < key) rank++;
+                }
+                if(rank < C::WCAP) {
+                    S.fkey[bn][rank] = key; S.fslot[bn][rank] = (short)(int)S.hbest[0][h];
+                    S.fD[bn][rank] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][rank] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][rank] = (short)((u32)S.hbest[2][h] & 0xFFFF);
+                }
+            }
+            nNew += __popcll(grp_ballot<GW>(pass));
+        }
+        if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
     }
-    if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
     WSYNC();
     // reset the hash entries used by this iteration
     for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
     if(gl == 0) {
-        S.nT = 0;
         st.b2 = b1; st.b1 = bn; st.bn = b2;                                                   // m2 := m1; m1 := this, :1104-1105
         st.n2 = n1; st.n1 = nNew;
         st.d = d + 1; st.itersRun = d;
@@ -634,6 +679,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         st.cellsEvaluated += (u32)nT;
     }
     WSYNC();
+    DP_TQ(2);
     return PH_RUN;
 }
 
@@ -876,6 +922,9 @@ __global__ __launch_bounds__(64, (C::GW == 16 ? 4 : 5)) void k_dp(const DevGraph
     const uint8_t* readBases = B.read_bases;
 
     if(gl == 0) { S.accCalls = 0; S.accIters = 0; S.accCells = 0; S.accEdges = 0; }
+#ifdef HLALA_DP_TIMING
+    if(gl == 0) { S.tPh[0] = 0; S.tPh[1] = 0; S.tPh[2] = 0; S.tPh[3] = 0; }
+#endif
 #ifdef HLALA_DP_TIMING                                     // build-time switch: cycles per state of the persistent loop -> counters[8..15]
     long long tAcc[6] = {0, 0, 0, 0, 0, 0}; long long trips = 0, runGroups = 0; long long tMark = clock64();
 #define DP_T(i) do { long long t_ = clock64(); tAcc[i] += t_ - tMark; tMark = t_; } while(0)
@@ -948,7 +997,8 @@ __global__ __launch_bounds__(64, (C::GW == 16 ? 4 : 5)) void k_dp(const DevGraph
         atomicAdd(&B.counters[CNT_DP_CELLS], S.accCells); atomicAdd(&B.counters[CNT_EDGES], S.accEdges);
     }
 #ifdef HLALA_DP_TIMING
-    if(TIER == 0 && (threadIdx.x & 63) == 0) { for(int i = 0; i < 6; i++) atomicAdd(&B.counters[8 + i], (u64)tAcc[i]); atomicAdd(&B.counters[14], (u64)trips); atomicAdd(&B.counters[15], (u64)runGroups); }
+    if(TIER == 0 && (threadIdx.x & 63) == 0) { for(int i = 0; i < 3; i++) atomicAdd(&B.counters[24 + i], (u64)S.tPh[i]);
+        for(int i = 0; i < 6; i++) atomicAdd(&B.counters[8 + i], (u64)tAcc[i]); atomicAdd(&B.counters[14], (u64)trips); atomicAdd(&B.counters[15], (u64)runGroups); }
 #endif
 }
 

@@ -24,5 +24,5 @@ pj = np.array(list(buf)[16:24], dtype=np.float64)
 if pj[7] > 0:
     print('project cycles/chain: walk %.0f trim+pad %.0f clean %.0f restrict %.0f stage+dp %.0f backtrace %.0f | chains %d' % tuple(list(pj[:6] / pj[7]) + [int(pj[7])]))
 hh = np.array(list(buf)[24:32], dtype=np.float64)
-if hh[0] > 0:
-    print('DP histogram: n=%d maxN<=8 %.4f <=16 %.4f <=32 %.4f | maxT<=24 %.4f <=48 %.4f | tiny-eligible %.4f | early %.4f' % (hh[0], hh[1]/hh[0], hh[2]/hh[0], hh[3]/hh[0], hh[4]/hh[0], hh[5]/hh[0], hh[6]/hh[0], hh[7]/hh[0]))
+if hh[0] > 0 and d[6] > 0:
+    print('dp_iterate cycles/trip (group 0 of each wave): generate %.0f evaluate %.0f filter %.0f' % (hh[0]/d[6], hh[1]/d[6], hh[2]/d[6]))
