@@ -60,10 +60,9 @@ struct DevBatch {
     uint8_t* sel_mapq;              // [n_reads*stride] mapQ_perPosition of the selected chain
     // ---- counters (device): see hlala_batch_stats
     u64* counters;                  // [32]
-    int* work_counter;              // [16] dynamic work distribution: [0] stage A, [1] DP items fetched, [2] stage C, [3]/[4] retry list 1 count / fetched,
-                                    //      [5]/[6] retry list 2 count / fetched, [7] chains stitched, [8] DP items
-    int* retry_list;                // [2*n_chains] DP items that outgrew DpTiny
-    int* retry_list2;               // [2*n_chains] DP items that outgrew DpSmall
+    int* work_counter;              // [32] dynamic work distribution: [0] stage A, [2] stage C, [7] chains stitched, [8]/[9] left / right DP items,
+                                    //      [1]/[10] left / right items fetched, [12..23] retry lists (count, fetched) per tier 1..3 and direction
+    int* retry_list;                // [6*n_chains] DP items that outgrew a capacity class: (tier 1..3) x (left, right) x n_chains
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
     int* dbg;                       // host-mapped progress words (HLALA_DEBUG=1), else null
 };

@@ -42,7 +42,7 @@ struct hlala_ctx {
     std::vector<void*> allocs;
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
-    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0; int stitch_grid = 0;
+    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     hipEvent_t ev[9]{};           // start/end per stage; [7] / [6] / [8] = before DpTiny / after DpTiny / after the retry classes
     int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
@@ -241,6 +241,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(hipMalloc((void**)&c->tiny_slabs, c->tiny_slab_bytes * 4 * (size_t)c->tiny_grid) != hipSuccess) { c->err = "hipMalloc(DP slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->tiny_slabs);
     c->ext_grid = cus * 20;
+    c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();      // 2 * mid_grid mid slabs fit the pool of ext_grid small slabs
     c->retry_grid = cus;
     c->stitch_grid = cus * 32;
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpLarge>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpLarge>();
@@ -318,7 +319,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
-    AL(counters, 32, true); AL(work_counter, 16, true); AL(retry_list, 2 * nc, false); AL(retry_list2, 2 * nc, false);
+    AL(counters, 32, true); AL(work_counter, 32, true); AL(retry_list, 6 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
     B.dbg = c->dbg_host;
 #undef AL
@@ -426,7 +427,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     if(!c || !b) return HLALA_E_ARG;
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
-    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 16 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 32 * sizeof(int), c->stream));
     HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if(B.n_chains > 0) {
@@ -448,7 +449,7 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
-    HIP_TRY(c, hipMemsetAsync(B.work_counter + 3, 0, 6 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, 25 * sizeof(int), c->stream));
     if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if(B.n_chains > 0) {
@@ -460,10 +461,12 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
         hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, c->params.rng_seed);
         rc = check_launch(c, "k_dp<tiny>"); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
-        // items that outgrew it: one wave per DP, then the large-capacity class (one block per CU)
-        hipLaunchKernelGGL((k_dp<DpSmall, 1>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        // items that outgrew it: two DPs per wave, then one wave per DP, then the large-capacity class (one block per CU)
+        hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, c->params.rng_seed);
+        rc = check_launch(c, "k_dp<mid>"); if(rc) return rc;
+        hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
         rc = check_launch(c, "k_dp<small>"); if(rc) return rc;
-        hipLaunchKernelGGL((k_dp<DpLarge, 2>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
         rc = check_launch(c, "k_dp<large>"); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[8], c->stream));
         int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
@@ -584,7 +587,7 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
     if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]); } }
-    { int wc[16]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[3]; out->n_dp_retried_large = wc[5]; }
+    { int wc[32]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[12] + wc[14]; out->n_dp_retried_large = wc[20] + wc[22]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

@@ -6,7 +6,8 @@
 // cells (median 3-4 on 2x150 bp pairs), so a DP is run by a GROUP of lanes, not by a whole wavefront:
 //
 //   DpTiny   16 lanes per DP, 4 DPs per wavefront   frontier <= 16 cells, <= 48 candidate targets per iteration
-//   DpSmall  64 lanes per DP                        frontier <= 64, <= 96 targets        (DPs that outgrow DpTiny)
+//   DpMid    32 lanes per DP, 2 DPs per wavefront   frontier <= 32, <= 96 targets        (DPs that outgrow DpTiny)
+//   DpSmall  64 lanes per DP                        frontier <= 64, <= 96 targets        (DPs that outgrow DpMid)
 //   DpLarge  64 lanes per DP                        frontier <= 1024, <= 1536 targets    (DPs that outgrow DpSmall)
 //
 // Every group is a small state machine (fetch -> iterate ... -> select end cell -> backtrace -> expand -> done);
@@ -44,6 +45,7 @@ constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP it
 constexpr int DP_BT_STEPS_PER_TRIP = 6;     // back pointers one group follows per trip of the persistent loop
 
 struct DpTiny  { static constexpr int GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 1024,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; };
+struct DpMid   { static constexpr int GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 2048,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; };
 struct DpSmall { static constexpr int GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; };
 struct DpLarge { static constexpr int GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; };
 
@@ -137,12 +139,14 @@ template <int GW> __device__ __forceinline__ int grp_max_i32(int v)
 {
     if(GW == 64) return wave_max_i32(v);
     HLALA_ROW_ALLREDUCE(v, op_max_);
+    if(GW == 32) v = op_max_(v, __shfl_xor(v, 16));     // the partner row of a 32-lane group
     return v;
 }
 template <int GW> __device__ __forceinline__ int grp_sum_i32(int v)
 {
     if(GW == 64) return wave_sum_i32(v);
     HLALA_ROW_ALLREDUCE(v, op_add_);
+    if(GW == 32) v = op_add_(v, __shfl_xor(v, 16));
     return v;
 }
 template <int GW> __device__ __forceinline__ u64 grp_min_u64(u64 v)
@@ -163,7 +167,12 @@ template <int GW> __device__ __forceinline__ int grp_excl_scan(int v, int& total
     t = dpp_mov<0x112>(0, x); x += t;
     t = dpp_mov<0x114>(0, x); x += t;
     t = dpp_mov<0x118>(0, x); x += t;
-    int m = x; HLALA_ROW_ALLREDUCE(m, op_max_);     // inclusive sums are non-decreasing: the maximum is the total
+    int m = x; HLALA_ROW_ALLREDUCE(m, op_max_);     // inclusive sums are non-decreasing: the maximum is the row total
+    if(GW == 32) {
+        const int other = __shfl_xor(m, 16);
+        if(threadIdx.x & 16) x += other;             // second row of the group continues after the first
+        m += other;
+    }
     total = m;
     return x - v;
 }
@@ -441,6 +450,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         }
         WSYNC();
     }
+    DP_TQ(3);
     const bool slow = anyExisting;
     const bool hadEarly = earlyInit != 0;      // S.tes[] holds lookups only if the pre-pass ran
     bool failed = false;
@@ -904,9 +914,9 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
 // ------------------------------------------------------------------------------------------
 // TIER 0: items of k_dp_items, the left extensions first and then the right extensions, so that the direction (and with it
 //         every choice between the out- and the in-edge arrays) is uniform across the four groups of a wavefront;
-// TIER 1: items that outgrew DpTiny (retry list 1); TIER 2: items that outgrew DpSmall (retry list 2).
+// TIER k > 0: items that outgrew the class of tier k-1 (retry list k).
 template <class C, int TIER>
-__global__ __launch_bounds__(64, (C::GW == 16 ? 4 : 5)) void k_dp(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items,
+__global__ __launch_bounds__(64, (C::GW == 64 ? 5 : 4)) void k_dp(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items,
                                                                     char* slabs, size_t slabBytes, u32 rng_seed)
 {
     constexpr int GW = C::GW;
@@ -932,12 +942,14 @@ __global__ __launch_bounds__(64, (C::GW == 16 ? 4 : 5)) void k_dp(const DevGraph
 #define DP_T(i) do { } while(0)
 #endif
 
-    for(int dirPass = 0; dirPass < (TIER == 0 ? 2 : 1); dirPass++) {
-        int* fetchCounter = &B.work_counter[TIER == 0 ? (dirPass ? 10 : 1) : (TIER == 1 ? 4 : 6)];
-        const int nItems = uni(B.work_counter[TIER == 0 ? 8 + dirPass : (TIER == 1 ? 3 : 5)]);
+    for(int dirPass = 0; dirPass < 2; dirPass++) {
+        // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
+        // retry list of tier k = 1..3 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
+        int* fetchCounter = &B.work_counter[TIER == 0 ? (dirPass ? 10 : 1) : 13 + 4 * (TIER - 1) + 2 * dirPass];
+        const int nItems = uni(B.work_counter[TIER == 0 ? 8 + dirPass : 12 + 4 * (TIER - 1) + 2 * dirPass]);
         const int listBase = (TIER == 0 && dirPass) ? B.n_chains : 0;
-        const int* srcList = TIER == 1 ? B.retry_list : B.retry_list2;
-        bool fwd = dirPass != 0;                           // TIER > 0: set per item (one group per wave)
+        const int* srcList = B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains;
+        const bool fwd = dirPass != 0;                     // left extensions run backwards (alignerBase: extensionAligner.cpp:229-241)
         int phase = PH_IDLE;
         bool more = true;
         int edgesAcc = 0;                                  // per-lane partial sum of the edges the current DP touched
@@ -953,7 +965,6 @@ __global__ __launch_bounds__(64, (C::GW == 16 ? 4 : 5)) void k_dp(const DevGraph
                     const int4* ip = (const int4*)(items + idx);
                     int4 a = ip[0], b = ip[1];
                     DpItem it; it.item = a.x; it.rOff = a.y; it.seqLen = a.z; it.start_seq = a.w; it.startLevel = b.x; it.startNode = b.y; it.pad0 = 0; it.pad1 = 0;
-                    if(TIER > 0) fwd = (uni(it.item) & 1) != 0;
                     phase = dp_begin<C>(S, sl, G, it, idx);
                     edgesAcc = 0;
                 }
@@ -969,8 +980,8 @@ __global__ __launch_bounds__(64, (C::GW == 16 ? 4 : 5)) void k_dp(const DevGraph
                 if(gl == 0) {
                     const DpState& st = S.st;
                     const bool capacity = st.err != 0 && st.err > -1000000;
-                    if(capacity && TIER < 2) {
-                        int* cnt = &B.work_counter[TIER == 0 ? 3 : 5]; int* lst = TIER == 0 ? B.retry_list : B.retry_list2;
+                    if(capacity && TIER < 3) {
+                        int* cnt = &B.work_counter[12 + 4 * TIER + 2 * dirPass]; int* lst = B.retry_list + (size_t)(2 * TIER + dirPass) * (size_t)B.n_chains;
                         int q = atomicAdd(cnt, 1); lst[q] = st.itemIdx;
                     } else {
                         const int item = st.item;
@@ -997,7 +1008,7 @@ __global__ __launch_bounds__(64, (C::GW == 16 ? 4 : 5)) void k_dp(const DevGraph
         atomicAdd(&B.counters[CNT_DP_CELLS], S.accCells); atomicAdd(&B.counters[CNT_EDGES], S.accEdges);
     }
 #ifdef HLALA_DP_TIMING
-    if(TIER == 0 && (threadIdx.x & 63) == 0) { for(int i = 0; i < 3; i++) atomicAdd(&B.counters[24 + i], (u64)S.tPh[i]);
+    if(TIER == 0 && (threadIdx.x & 63) == 0) { for(int i = 0; i < 4; i++) atomicAdd(&B.counters[24 + i], (u64)S.tPh[i]);
         for(int i = 0; i < 6; i++) atomicAdd(&B.counters[8 + i], (u64)tAcc[i]); atomicAdd(&B.counters[14], (u64)trips); atomicAdd(&B.counters[15], (u64)runGroups); }
 #endif
 }
@@ -1011,9 +1022,23 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
     const DevTables& T = *Tp;
     const int lane = lane_id();
     const int stride = B.stride;
+    // chains are drawn eight at a time: one same-address atomic per chain would serialise the whole grid at the L2
+    constexpr int CHUNK = 8;
+    u64 accChains = 0, accCols = 0;          // work counters, flushed once per wave (same-address atomics serialise at the L2)
+#ifdef HLALA_DP_TIMING
+    long long tS[6] = {0, 0, 0, 0, 0, 0}, tM = clock64(); long long nCh = 0;
+#define ST_T(i) do { long long t_ = clock64(); tS[i] += t_ - tM; tM = t_; } while(0)
+#else
+#define ST_T(i) do { } while(0)
+#endif
     for(;;) {
-        const int c = next_work(&B.work_counter[7]);
-        if(c >= B.n_chains) break;
+        int c0 = 0;
+        if(lane == 0) c0 = atomicAdd(&B.work_counter[7], CHUNK);
+        c0 = __builtin_amdgcn_readfirstlane(c0);
+        if(c0 >= B.n_chains) break;
+        const int cEnd = min(c0 + CHUNK, B.n_chains);
+        for(int c = c0; c < cEnd; c++) {
+        ST_T(0);
         if(uni(B.ext_status[c]) == EXT_PENDING) {
         const int r = uni(B.chain_read[c]);
         const int rOff = uni(B.read_off[r]), seqLen = uni(B.read_off[r + 1]) - rOff;
@@ -1029,6 +1054,7 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
         const int padL = newBegin, padR = seqLen - 1 - newEnd;
         const int total = padL + nL + nSeed + nR + padR;
         if(!err && total > stride) err = HLALA_CHAIN_ERR_COLUMNS;
+        ST_T(1);
         if(err) {
             if(lane == 0) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(errL ? errL : errR); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
         } else {
@@ -1057,6 +1083,7 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
             B.ext_fromseed[cb + j] = fs;
         }
         WSYNC();
+        ST_T(2);
         // ---- scoreOneAlignment: terms are added strictly left to right in FP64 (same order as the reference loop).
         // The read quality of alignment-orientation base i is read_quals[i] in both strands: the reference indexes the
         // ORIGINAL-orientation read with len-i-1 when the chain is reverse (extensionAligner.cpp:85-88), which is the same base.
@@ -1101,6 +1128,7 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
                 }
             }
             double ll = __shfl(acc, 63);
+            ST_T(3);
             // first / last two defined levels for the pairing stage (verboseSeedChain.h:134-228)
             if(lane == 0) {
                 int f0 = -1, f1 = -1, l0 = -1, l1 = -1;
@@ -1108,13 +1136,22 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
                 for(int j = total - 1; j >= 0 && l1 < 0; j--) { int lv = B.ext_level[cb + j]; if(lv != -1) { if(l0 < 0) l0 = lv; else l1 = lv; } }
                 B.ext_firstlast[4 * c + 0] = f0; B.ext_firstlast[4 * c + 1] = f1; B.ext_firstlast[4 * c + 2] = l0; B.ext_firstlast[4 * c + 3] = l1;
                 B.ext_status[c] = HLALA_CHAIN_OK; B.ext_ncols[c] = total; B.ext_begin[c] = 0; B.ext_end[c] = seqLen - 1; B.ext_ll[c] = ll;
-                atomicAdd(&B.counters[CNT_CHAINS_EXT], 1ull); atomicAdd(&B.counters[CNT_OUT_COLS], (u64)total);
+                accChains++; accCols += (u64)total;
             }
+            ST_T(4);
+#ifdef HLALA_DP_TIMING
+            nCh++;
+#endif
         }
         }   // no error
         }   // chain pending
         WSYNC();
+        }
     }
+    if(lane == 0 && accChains) { atomicAdd(&B.counters[CNT_CHAINS_EXT], accChains); atomicAdd(&B.counters[CNT_OUT_COLS], accCols); }
+#ifdef HLALA_DP_TIMING
+    if(lane == 0) { for(int i = 0; i < 5; i++) atomicAdd(&B.counters[16 + i], (u64)tS[i]); atomicAdd(&B.counters[23], (u64)nCh); }
+#endif
 }
 
 }  // namespace hlala

@@ -108,9 +108,15 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
     const int stride = B.stride;
 
     long long tAcc[7] = {0, 0, 0, 0, 0, 0, 0};
+    u64 accCols = 0, accEdges = 0;           // work counters, flushed once per wave (same-address atomics serialise at the L2)
+    constexpr int CHUNK = 4;                 // chains drawn per atomic
     for(;;) {
-        const int c = next_work(&B.work_counter[0]);
-        if(c >= B.n_chains) break;
+        int c0 = 0;
+        if(lane == 0) c0 = atomicAdd(&B.work_counter[0], CHUNK);
+        c0 = __builtin_amdgcn_readfirstlane(c0);
+        if(c0 >= B.n_chains) break;
+        const int cEnd = min(c0 + CHUNK, B.n_chains);
+        for(int c = c0; c < cEnd; c++) {
         if(uni(B.seed_status[c]) == HLALA_CHAIN_OK) {
         const int r = uni(B.chain_read[c]);
         const int rOff = uni(B.read_off[r]), readLen = uni(B.read_off[r + 1]) - rOff;
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 }
                 if(lane == 0) {
                     B.seed_ncols[c] = n1; B.seed_begin[c] = P.startRaw; B.seed_end[c] = P.stopRaw; B.seed_removed[c] = removed;
-                    atomicAdd(&B.counters[CNT_SEED_COLS], (u64)n1);
+                    accCols += (u64)n1;
                 }
             }
         }
@@ -540,13 +546,15 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         if(B.dbg) { for(int i = 0; i < 6; i++) if(tPh[i + 1] && tPh[i]) tAcc[i] += tPh[i + 1] - tPh[i]; tAcc[6]++; }
         {
             int e = wave_sum_i32((int)edgesTouched);
-            if(lane == 0 && e) atomicAdd(&B.counters[CNT_EDGES], (u64)e);
+            accEdges += (u64)e;
         }
         WSYNC();
         if(!PJ_OK() && lane == 0) { B.seed_status[c] = P.err; B.seed_ncols[c] = 0; }
         }   // chain survives the filters
         WSYNC();
+        }
     }
+    if(lane == 0) { if(accCols) atomicAdd(&B.counters[CNT_SEED_COLS], accCols); if(accEdges) atomicAdd(&B.counters[CNT_EDGES], accEdges); }
     if(B.dbg && lane == 0) { for(int i = 0; i < 6; i++) atomicAdd(&B.counters[16 + i], (u64)tAcc[i]); atomicAdd(&B.counters[23], (u64)tAcc[6]); }
 }
 

@@ -22,7 +22,8 @@ print('retry ms', st.ms_extend_retry, 'dp main ms', st.ms_dp_main, 'retried', st
 
 pj = np.array(list(buf)[16:24], dtype=np.float64)
 if pj[7] > 0:
+    print('stitch cycles/chain (timing build): fetch+status %.0f descriptors %.0f stitch %.0f LL %.0f firstlast+out %.0f | chains %d' % tuple(list(pj[:5] / pj[7]) + [int(pj[7])]))
     print('project cycles/chain: walk %.0f trim+pad %.0f clean %.0f restrict %.0f stage+dp %.0f backtrace %.0f | chains %d' % tuple(list(pj[:6] / pj[7]) + [int(pj[7])]))
 hh = np.array(list(buf)[24:32], dtype=np.float64)
 if hh[0] > 0 and d[6] > 0:
-    print('dp_iterate cycles/trip (group 0 of each wave): generate %.0f evaluate %.0f filter %.0f' % (hh[0]/d[6], hh[1]/d[6], hh[2]/d[6]))
+    print('dp_iterate cycles/trip (group 0 of each wave): generate %.0f early-lookup %.0f evaluate %.0f filter %.0f' % (hh[0]/d[6], hh[3]/d[6], hh[1]/d[6], hh[2]/d[6]))
