@@ -346,69 +346,86 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
 #define DP_TQ(i) do { } while(0)
 #endif
     // ================= generate =====================================================
+    // Lane i serves entry i of the m-2 frontier (match / mismatch, :565-607) and entry i of the m-1 frontier (gaps and jumps,
+    // :613-787).  All graph reads of both are issued up front in two dependent rounds (offsets, then the first two edges of
+    // each node and the first jump); the pushes follow.  The push index of a candidate fixes its precedence (first maximum
+    // in push order), so the order in which lanes and loops execute the pushes is irrelevant.
     const int* eoff = fwd ? G.out_off : G.in_off; const int* eto = fwd ? G.out_to : G.in_from; const uint8_t* elab = fwd ? G.out_label : G.in_label;
+    const int* joff = fwd ? G.jf_off : G.jb_off; const int* jnode = fwd ? G.jf_node : G.jb_node; const int* jlvl = fwd ? G.jf_lvl : G.jb_lvl;
     int edges = 0;      // (the direction is wave-uniform: these are scalar selects)
-    // from the m-2 diagonal: match / mismatch, :565-607
-    for(int i = gl; i < n2; i += GW) {
-        u64 pk = S.fkey[b2][i]; int px = key_x(pk), py = key_y(pk), node = key_node(pk);
-        int nx = px + dir, ny = py + dir;
-        if(nx > max_levelI || ny > max_seqI || nx < 0 || ny < 0) continue;
-        unsigned char rc = fwd ? seqp[py] : seqp[py - 1];
-        int e0 = eoff[node], e1 = eoff[node + 1];
-        int pD = S.fD[b2][i];
-        if(e1 - e0 > 127) { S.err = __LINE__; continue; }
-        for(int e = e0; e < e1; e++) {
-            int tn = eto[e];
-            unsigned char lab = elab[e];
-            int sc = pD + (lab == rc ? 2 : -5);
-            if(!dp_push<C>(S, mk_key(nx, ny, tn), M_D, sc, (i << 8) | (e - e0))) S.err = __LINE__;
-        }
-        edges += e1 - e0;
-    }
-    // from the m-1 diagonal: gaps and jumps, :613-787
-    for(int i = gl; i < n1; i += GW) {
-        u64 pk = S.fkey[b1][i]; int px = key_x(pk), py = key_y(pk), node = key_node(pk);
-        int pD = S.fD[b1][i], pG = S.fG[b1][i], pS = S.fS[b1][i];
-        int ord0 = (1 << (C::IBITS + 8)) | (i << 8);
-        {   // gap in graph, :621-661
-            int ny = py + dir;
-            if(ny >= 0 && ny <= max_seqI) {
-                u64 k = mk_key(px, ny, node);
-                if(!dp_push<C>(S, k, M_GG, pD - 6, ord0 | 0)) S.err = __LINE__;
-                if(pG != DP_NEG) if(!dp_push<C>(S, k, M_GG, pG - 2, ord0 | 1)) S.err = __LINE__;
-            }
-        }
-        {   // gap in sequence, :664-754
-            int nx = px + dir;
-            int e0 = eoff[node], e1 = eoff[node + 1];
-            int deg = e1 - e0;
-            if(deg > 127) { S.err = __LINE__; continue; }
-            if(nx >= 0 && nx <= max_levelI) {
-                for(int e = e0; e < e1; e++) {
-                    int tn = eto[e];
-                    unsigned char lab = elab[e];
-                    u64 k = mk_key(nx, py, tn);
-                    int kk = e - e0;
-                    if(lab != '_') {
-                        if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
-                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
-                    } else {
-                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
-                        if(!dp_push<C>(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;         // non-affine sequence gap, :738-752
-                    }
+    const int nMax = n1 > n2 ? n1 : n2;
+    for(int i = gl; i < nMax; i += GW) {
+        // ---- round 0: frontier entries (LDS)
+        const bool hasA = i < n2, hasB = i < n1;
+        u64 pkA = hasA ? S.fkey[b2][i] : 0, pkB = hasB ? S.fkey[b1][i] : 0;
+        const int pxA = key_x(pkA), pyA = key_y(pkA), nodeA = key_node(pkA);
+        const int pxB = key_x(pkB), pyB = key_y(pkB), nodeB = key_node(pkB);
+        const int nxA = pxA + dir, nyA = pyA + dir;
+        const bool doA = hasA && !(nxA > max_levelI || nyA > max_seqI || nxA < 0 || nyA < 0);
+        const int pDA = hasA ? (int)S.fD[b2][i] : 0;
+        const int pD = hasB ? (int)S.fD[b1][i] : 0, pG = hasB ? (int)S.fG[b1][i] : 0, pS = hasB ? (int)S.fS[b1][i] : 0;
+        // ---- round 1: edge / jump offsets, read character
+        int a0 = 0, a1 = 0, e0 = 0, e1 = 0, j0 = 0, j1 = 0; unsigned char rc = 0;
+        if(doA) { a0 = eoff[nodeA]; a1 = eoff[nodeA + 1]; rc = fwd ? seqp[pyA] : seqp[pyA - 1]; }
+        if(hasB) { e0 = eoff[nodeB]; e1 = eoff[nodeB + 1]; j0 = joff[nodeB]; j1 = joff[nodeB + 1]; }
+        const int degA = a1 - a0, degB = e1 - e0;
+        // ---- round 2: the first two edges of each node, the first jump
+        int tnA0 = 0, tnA1 = 0, tnB0 = 0, tnB1 = 0, jn0 = 0, jx0 = 0; unsigned char labA0 = 0, labA1 = 0, labB0 = 0, labB1 = 0;
+        if(degA > 0) { tnA0 = eto[a0]; labA0 = elab[a0]; }
+        if(degA > 1) { tnA1 = eto[a0 + 1]; labA1 = elab[a0 + 1]; }
+        if(degB > 0) { tnB0 = eto[e0]; labB0 = elab[e0]; }
+        if(degB > 1) { tnB1 = eto[e0 + 1]; labB1 = elab[e0 + 1]; }
+        if(j1 > j0) { jn0 = jnode[j0]; jx0 = jlvl[j0]; }
+        // ---- pushes from the m-2 entry
+        if(doA) {
+            if(degA > 127) S.err = __LINE__;
+            else {
+                for(int k = 0; k < degA; k++) {
+                    int tn; unsigned char lab;
+                    if(k == 0) { tn = tnA0; lab = labA0; } else if(k == 1) { tn = tnA1; lab = labA1; } else { tn = eto[a0 + k]; lab = elab[a0 + k]; }
+                    int sc = pDA + (lab == rc ? 2 : -5);
+                    if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, sc, (i << 8) | k)) S.err = __LINE__;
                 }
-                edges += deg;
+                edges += degA;
             }
         }
-        {   // gap-path jumps, :757-786 (jump_length * S_graphGap = 0)
-            // push index of a jump = 128 + its rank in the jump table: after every edge candidate of the same source (:757)
-            const int* joff = fwd ? G.jf_off : G.jb_off; const int* jnode = fwd ? G.jf_node : G.jb_node; const int* jlvl = fwd ? G.jf_lvl : G.jb_lvl;
-            int j0 = joff[node], j1 = joff[node + 1];
-            if(j1 - j0 > 127) { S.err = __LINE__; continue; }
-            for(int j = j0; j < j1; j++) {
-                int tn = jnode[j]; int jx = jlvl[j];
-                if(jx < 0 || jx > max_levelI) continue;
-                if(!dp_push<C>(S, mk_key(jx, py, tn), M_D, pD, ord0 | (128 + (j - j0)))) S.err = __LINE__;
+        // ---- pushes from the m-1 entry
+        if(hasB) {
+            const int ord0 = (1 << (C::IBITS + 8)) | (i << 8);
+            {   // gap in graph, :621-661
+                int ny = pyB + dir;
+                if(ny >= 0 && ny <= max_seqI) {
+                    u64 k = mk_key(pxB, ny, nodeB);
+                    if(!dp_push<C>(S, k, M_GG, pD - 6, ord0 | 0)) S.err = __LINE__;
+                    if(pG != DP_NEG) if(!dp_push<C>(S, k, M_GG, pG - 2, ord0 | 1)) S.err = __LINE__;
+                }
+            }
+            if(degB > 127 || j1 - j0 > 127) S.err = __LINE__;
+            else {
+                const int nx = pxB + dir;
+                if(nx >= 0 && nx <= max_levelI) {                                             // gap in sequence, :664-754
+                    for(int kk = 0; kk < degB; kk++) {
+                        int tn; unsigned char lab;
+                        if(kk == 0) { tn = tnB0; lab = labB0; } else if(kk == 1) { tn = tnB1; lab = labB1; } else { tn = eto[e0 + kk]; lab = elab[e0 + kk]; }
+                        u64 k = mk_key(nx, pyB, tn);
+                        if(lab != '_') {
+                            if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
+                            if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
+                        } else {
+                            if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
+                            if(!dp_push<C>(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;         // non-affine sequence gap, :738-752
+                        }
+                    }
+                    edges += degB;
+                }
+                // gap-path jumps, :757-786 (jump_length * S_graphGap = 0); push index of a jump = 128 + its rank in the jump
+                // table: after every edge candidate of the same source (:757)
+                for(int j = j0; j < j1; j++) {
+                    int tn, jx;
+                    if(j == j0) { tn = jn0; jx = jx0; } else { tn = jnode[j]; jx = jlvl[j]; }
+                    if(jx < 0 || jx > max_levelI) continue;
+                    if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)))) S.err = __LINE__;
+                }
             }
         }
     }
