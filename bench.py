@@ -130,7 +130,7 @@ def main():
         edges_pc = st.n_edges_touched / max(1, st.n_chains_extended)
         cols_pm = st.n_out_columns / max(1, st.n_chains_extended)
         bpp = algorithmic_bytes_per_pair(150, chains_pp, edges_pc, cols_pm)
-        ext_s = (st.ms_extend - st.ms_extend_retry) * 1e-3      # the dominant kernel alone: k_extend_chains<DpSmall>
+        ext_s = st.ms_dp_main * 1e-3      # the dominant kernel alone: k_dp<DpTiny, 0> (HIP events around it on the ctx stream)
         achieved = bpp * args.pairs / ext_s / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
@@ -152,11 +152,12 @@ def main():
                        "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
                        "dp_cells_per_s": st.n_dp_cells / ext_s, "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
-                       "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "extend_retry_pass": st.ms_extend_retry, "pair": st.ms_pair},
-                       "chains_retried_large_capacity": int(st.n_chains_retried),
+                       "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "extend_dp_16lane_kernel": st.ms_dp_main,
+                                    "extend_dp_retry_classes": st.ms_extend_retry, "pair": st.ms_pair},
+                       "dp_calls_retried_wider_class": int(st.n_chains_retried), "dp_calls_retried_large_class": int(st.n_dp_retried_large),
                        "generation_s": t_gen},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "kernel": "k_extend_chains<DpSmall>", "kernel_ms": st.ms_extend - st.ms_extend_retry,
+                         "traffic": traffic, "kernel": "k_dp<DpTiny, 0>", "kernel_ms": st.ms_dp_main,
                          "algorithmic_bytes_per_pair": bpp},
         }
         if world == 1 and not args.no_cpu_baseline:
