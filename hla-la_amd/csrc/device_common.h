@@ -27,6 +27,8 @@ struct DevGraph {
     const uint8_t* edge_label; // [E] by creation index
     const int* jf_off; const int* jf_node; const int* jf_path; const int* jf_lvl;
     const int* jb_off; const int* jb_node; const int* jb_path; const int* jb_lvl;
+    const int4* nrec_out;      // [2*N] 32-byte node records of the extension DP (flat_graph.hpp)
+    const int4* nrec_in;
     const int* path_len;       // [P]
     const long long* path_off; // [P+1]
     const int* path_edges;

@@ -199,6 +199,25 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
                 }
             }
     }
+    // ---- node records: everything one DP iteration needs of a frontier node in one 32-byte read
+    {
+        auto build = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& to, const std::vector<uint8_t>& lab,
+                         const std::vector<int32_t>& joff, const std::vector<int32_t>& jnode, const std::vector<int32_t>& jlvl,
+                         std::vector<int32_t>& rec) {
+            rec.assign((size_t)8 * N, 0);
+            for(int32_t n = 0; n < N; n++) {
+                const int32_t e0 = off[n], deg = off[n + 1] - e0;
+                const int32_t j0 = joff[n], nj = joff[n + 1] - j0;
+                int32_t* r = &rec[(size_t)8 * n];
+                r[0] = e0; r[1] = (deg & 0xFFFF) | (int32_t)((uint32_t)(nj > 0x7FFF ? 0x7FFF : nj) << 16);
+                r[2] = deg > 0 ? to[e0] : 0; r[3] = deg > 1 ? to[e0 + 1] : 0;
+                r[4] = j0; r[5] = nj > 0 ? jnode[j0] : 0; r[6] = nj > 0 ? jlvl[j0] : 0;
+                r[7] = (deg > 0 ? lab[e0] : 0) | ((deg > 1 ? lab[e0 + 1] : 0) << 8);
+            }
+        };
+        build(F.out_off, F.out_to, F.out_label, F.jf_off, F.jf_node, F.jf_lvl, F.nrec_out);
+        build(F.in_off, F.in_from, F.in_label, F.jb_off, F.jb_node, F.jb_lvl, F.nrec_in);
+    }
     return "";
 }
 

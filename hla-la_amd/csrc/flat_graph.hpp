@@ -39,6 +39,9 @@ struct FlatGraph {
     std::vector<int32_t> jf_node, jb_node;       // target node (new id)
     std::vector<int32_t> jf_path, jb_path;       // path index
     std::vector<int32_t> jf_lvl, jb_lvl;         // level of the target node (saves a dependent load on the device)
+    // one 32-byte record per node and direction for the extension DP: {first CSR edge, degree | jumps << 16, target of edge 0,
+    // target of edge 1, first jump-table entry, node of jump 0, level of jump 0, label 0 | label 1 << 8}
+    std::vector<int32_t> nrec_out, nrec_in;      // [8*N]
     std::vector<uint8_t> gap_stretch;            // [L-1]
     // level -> (sequence id, position) CSR, entries sorted by sequence id
     std::vector<int64_t> lp_off;                 // [L+1]

@@ -212,6 +212,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     UPG(jf_off, F.jf_off); UPG(jf_node, F.jf_node); UPG(jf_path, F.jf_path);
     UPG(jb_off, F.jb_off); UPG(jb_node, F.jb_node); UPG(jb_path, F.jb_path);
     UPG(jf_lvl, F.jf_lvl); UPG(jb_lvl, F.jb_lvl);
+    { int* p_ = nullptr; rc = dev_upload(c, c->allocs, F.nrec_out.data(), F.nrec_out.size(), &p_); if(rc) return fail(rc); G.nrec_out = (const int4*)p_;
+      rc = dev_upload(c, c->allocs, F.nrec_in.data(), F.nrec_in.size(), &p_); if(rc) return fail(rc); G.nrec_in = (const int4*)p_; }
     UPG(path_len, F.path_len); UPG(path_edges, F.path_edges);
     {
         std::vector<long long> po(F.path_off.begin(), F.path_off.end());

@@ -347,11 +347,13 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
 #endif
     // ================= generate =====================================================
     // Lane i serves entry i of the m-2 frontier (match / mismatch, :565-607) and entry i of the m-1 frontier (gaps and jumps,
-    // :613-787).  All graph reads of both are issued up front in two dependent rounds (offsets, then the first two edges of
-    // each node and the first jump); the pushes follow.  The push index of a candidate fixes its precedence (first maximum
-    // in push order), so the order in which lanes and loops execute the pushes is irrelevant.
+    // :613-787).  Each needs ONE 32-byte node record (first CSR edge, degree, jumps, the first two edges, the first jump:
+    // flat_graph.hpp); nodes with more than two edges or more than one jump read the rest from the CSR arrays.  The push
+    // index of a candidate fixes its precedence (first maximum in push order), so the order in which lanes and loops
+    // execute the pushes is irrelevant.
     const int* eoff = fwd ? G.out_off : G.in_off; const int* eto = fwd ? G.out_to : G.in_from; const uint8_t* elab = fwd ? G.out_label : G.in_label;
     const int* joff = fwd ? G.jf_off : G.jb_off; const int* jnode = fwd ? G.jf_node : G.jb_node; const int* jlvl = fwd ? G.jf_lvl : G.jb_lvl;
+    const int4* nrec = fwd ? G.nrec_out : G.nrec_in;
     int edges = 0;      // (the direction is wave-uniform: these are scalar selects)
     const int nMax = n1 > n2 ? n1 : n2;
     for(int i = gl; i < nMax; i += GW) {
@@ -364,18 +366,15 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         const bool doA = hasA && !(nxA > max_levelI || nyA > max_seqI || nxA < 0 || nyA < 0);
         const int pDA = hasA ? (int)S.fD[b2][i] : 0;
         const int pD = hasB ? (int)S.fD[b1][i] : 0, pG = hasB ? (int)S.fG[b1][i] : 0, pS = hasB ? (int)S.fS[b1][i] : 0;
-        // ---- round 1: edge / jump offsets, read character
-        int a0 = 0, a1 = 0, e0 = 0, e1 = 0, j0 = 0, j1 = 0; unsigned char rc = 0;
-        if(doA) { a0 = eoff[nodeA]; a1 = eoff[nodeA + 1]; rc = fwd ? seqp[pyA] : seqp[pyA - 1]; }
-        if(hasB) { e0 = eoff[nodeB]; e1 = eoff[nodeB + 1]; j0 = joff[nodeB]; j1 = joff[nodeB + 1]; }
-        const int degA = a1 - a0, degB = e1 - e0;
-        // ---- round 2: the first two edges of each node, the first jump
-        int tnA0 = 0, tnA1 = 0, tnB0 = 0, tnB1 = 0, jn0 = 0, jx0 = 0; unsigned char labA0 = 0, labA1 = 0, labB0 = 0, labB1 = 0;
-        if(degA > 0) { tnA0 = eto[a0]; labA0 = elab[a0]; }
-        if(degA > 1) { tnA1 = eto[a0 + 1]; labA1 = elab[a0 + 1]; }
-        if(degB > 0) { tnB0 = eto[e0]; labB0 = elab[e0]; }
-        if(degB > 1) { tnB1 = eto[e0 + 1]; labB1 = elab[e0 + 1]; }
-        if(j1 > j0) { jn0 = jnode[j0]; jx0 = jlvl[j0]; }
+        // ---- round 1: node records, read character
+        int4 ra0 = make_int4(0, 0, 0, 0), ra1 = ra0, rb0 = ra0, rb1 = ra0; unsigned char rc = 0;
+        if(doA) { ra0 = nrec[2 * (size_t)nodeA]; ra1 = nrec[2 * (size_t)nodeA + 1]; rc = fwd ? seqp[pyA] : seqp[pyA - 1]; }
+        if(hasB) { rb0 = nrec[2 * (size_t)nodeB]; rb1 = nrec[2 * (size_t)nodeB + 1]; }
+        const int a0 = ra0.x, degA = ra0.y & 0xFFFF, tnA0 = ra0.z, tnA1 = ra0.w;
+        const unsigned char labA0 = (unsigned char)(ra1.w & 0xFF), labA1 = (unsigned char)((ra1.w >> 8) & 0xFF);
+        const int e0 = rb0.x, degB = rb0.y & 0xFFFF, tnB0 = rb0.z, tnB1 = rb0.w;
+        const int j0 = rb1.x, j1 = j0 + (int)((u32)rb0.y >> 16), jn0 = rb1.y, jx0 = rb1.z;
+        const unsigned char labB0 = (unsigned char)(rb1.w & 0xFF), labB1 = (unsigned char)((rb1.w >> 8) & 0xFF);
         // ---- pushes from the m-2 entry
         if(doA) {
             if(degA > 127) S.err = __LINE__;
