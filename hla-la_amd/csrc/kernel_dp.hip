@@ -44,10 +44,10 @@ constexpr u64 HKEY_EMPTY = ~0ull;
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 6;     // back pointers one group follows per trip of the persistent loop
 
-struct DpTiny  { static constexpr int GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 1024,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; };
-struct DpMid   { static constexpr int GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 2048,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; };
-struct DpSmall { static constexpr int GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; };
-struct DpLarge { static constexpr int GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; };
+struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 1024,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; };
+struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 2048,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; };
+struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; };
+struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; };
 
 // State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
 // that only the phase has to stay in registers across the states of the persistent loop.
@@ -78,7 +78,7 @@ struct __align__(16) DpLdsT {
     DpState st;
     u64 accCalls, accIters, accCells, accEdges;       // work counters of the DPs this group finished (flushed once at exit)
 #ifdef HLALA_DP_TIMING
-    long long tPh[4];
+    long long tPh[8];
 #endif
 };
 
@@ -195,8 +195,14 @@ __device__ __forceinline__ u64 mk_key(int x, int y, int node) { return ((u64)(u3
 __device__ __forceinline__ int key_x(u64 k) { return (int)(k >> 40); }
 __device__ __forceinline__ int key_y(u64 k) { return (int)((k >> 28) & 0xFFF); }
 __device__ __forceinline__ int key_node(u64 k) { return (int)(k & 0xFFFFFFF); }
-// targets of one iteration differ in a few low bits of node / y / x: one 32-bit multiply spreads them
-__device__ __forceinline__ u32 hash64(u64 k) { u32 h = (u32)k ^ ((u32)(k >> 28) * 0x9E3779B1u) ^ ((u32)(k >> 40) * 0x85EBCA6Bu); h *= 0x9E3779B1u; return h ^ (h >> 15); }
+// targets of one iteration differ in a few low bits of node / y / x: node + 17 y + 31 x spreads them over neighbouring
+// entries without a full-width multiply (v_mul_lo_u32 is quarter rate; shifts, adds and the 24-bit mad are full rate)
+__device__ __forceinline__ u32 hash64(u64 k)
+{
+    const u32 node = (u32)k & 0xFFFFFFFu, y = (u32)(k >> 28) & 0xFFFu, x = (u32)(k >> 40);
+    u32 h = node + __umul24(y, 17u) + __umul24(x, 31u);
+    return h ^ (h >> 6) ^ (h >> 12);
+}
 
 __device__ __forceinline__ u64 mk_bt(int prev, int src, int kind, int edge) { return ((u64)(u32)edge << 32) | (u64)((u32)prev | ((u32)src << 24) | ((u32)kind << 26)); }
 __device__ __forceinline__ int bt_prev(u64 b) { return (int)(b & 0xFFFFFF); }
@@ -225,6 +231,19 @@ __device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int or
         h = (h + 1) & (C::HC - 1);
     }
     return false;
+}
+
+// continue the probe sequence of a claim that found a different key at its home entry; returns HC when the hash is full
+template <class C>
+__device__ inline u32 dp_probe(DpLdsT<C>& S, u64 key, u32 h)
+{
+#pragma nounroll
+    for(int probe = 1; probe < C::HC; probe++) {
+        h = (h + 1) & (C::HC - 1);
+        u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
+        if(old == HKEY_EMPTY || old == key) return h;
+    }
+    return (u32)C::HC;
 }
 
 template <class C>
@@ -317,15 +336,10 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     const int seqLen = guni<GW>(st.seqLen);
     const int max_levelI = G.L - 1, max_seqI = seqLen;       // :431-463 (min_* are 0 in both directions)
     const int limitY = fwd ? seqLen : 0;
-    const int startLevel = guni<GW>(st.startLevel), start_seq = guni<GW>(st.start_seq);
     const int d = guni<GW>(st.d);
     const int n1 = guni<GW>(st.n1), n2 = guni<GW>(st.n2);
     const int b1 = guni<GW>(st.b1), b2 = guni<GW>(st.b2), bn = guni<GW>(st.bn);
     const int lastInc0 = guni<GW>(st.lastInc), diagonals = guni<GW>(st.diagonals);
-    const int curMax0 = guni<GW>(st.curMax);
-    const int nCompleted0 = guni<GW>(st.nCompleted);
-    int nCells = guni<GW>(st.nCells);
-    int earlyInit = guni<GW>(st.earlyInit);
     const uint8_t* seqp = readBases + guni<GW>(st.rOff);
 
     // ---- loop header, :531-560
@@ -341,7 +355,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
 
 #ifdef HLALA_DP_TIMING
     long long tq0 = clock64();
-#define DP_TQ(i) do { long long t_ = clock64(); if(gl == 0) S.tPh[i] += t_ - tq0; tq0 = t_; } while(0)
+#define DP_TQ(i) do { __builtin_amdgcn_s_waitcnt(0); long long t_ = clock64(); if(gl == 0) S.tPh[i] += t_ - tq0; tq0 = t_; } while(0)
 #else
 #define DP_TQ(i) do { } while(0)
 #endif
@@ -375,61 +389,85 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         const int e0 = rb0.x, degB = rb0.y & 0xFFFF, tnB0 = rb0.z, tnB1 = rb0.w;
         const int j0 = rb1.x, j1 = j0 + (int)((u32)rb0.y >> 16), jn0 = rb1.y, jx0 = rb1.z;
         const unsigned char labB0 = (unsigned char)(rb1.w & 0xFF), labB1 = (unsigned char)((rb1.w >> 8) & 0xFF);
-        // ---- pushes from the m-2 entry
-        if(doA) {
-            if(degA > 127) S.err = __LINE__;
-            else {
-                for(int k = 0; k < degA; k++) {
-                    int tn; unsigned char lab;
-                    if(k == 0) { tn = tnA0; lab = labA0; } else if(k == 1) { tn = tnA1; lab = labA1; } else { tn = eto[a0 + k]; lab = elab[a0 + k]; }
-                    int sc = pDA + (lab == rc ? 2 : -5);
-                    if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, sc, (i << 8) | k)) S.err = __LINE__;
+        DP_TQ(4);
+        // ---- six target cells per lane, claimed with six independent compare-and-swaps issued back to back (one LDS round
+        // trip for all), then the values: 0/1 = edges 0/1 of the m-2 entry (D); 2 = gap in graph (:621-661, both GG candidates);
+        // 3/4 = edges 0/1 of the m-1 entry (gap in sequence :664-754: both SG candidates, or SG + the non-affine D across a
+        // '_' edge, :738-752); 5 = first gap-path jump (:757-786, jump_length * S_graphGap = 0)
+        const int ord0 = (1 << (C::IBITS + 8)) | (i << 8);
+        const int nyG = pyB + dir, nxB = pxB + dir;
+        const bool okA = doA && degA <= 127;
+        const bool okB = hasB && degB <= 127 && (j1 - j0) <= 127;
+        const bool sgB = okB && nxB >= 0 && nxB <= max_levelI;
+        if((doA && !okA) || (hasB && !okB)) S.err = __LINE__;
+        typedef typename C::Best BestT;
+        {   // batch 1: both edges of the m-2 entry, the graph gap
+            bool cv[3]; u64 ck[3]; u32 ch[3]; u64 cold[3];
+            cv[0] = okA && degA > 0; ck[0] = mk_key(nxA, nyA, tnA0);
+            cv[1] = okA && degA > 1; ck[1] = mk_key(nxA, nyA, tnA1);
+            cv[2] = hasB && nyG >= 0 && nyG <= max_seqI; ck[2] = mk_key(pxB, nyG, nodeB);
+#pragma unroll
+            for(int q = 0; q < 3; q++) { ch[q] = hash64(ck[q]) & (C::HC - 1); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
+#pragma unroll
+            for(int q = 0; q < 3; q++)
+                if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
+            if(cv[0]) { BestT v; pack_best(v, pDA + (labA0 == rc ? 2 : -5), (i << 8) | 0); atomicMax(&S.hbest[M_D][ch[0]], v); }
+            if(cv[1]) { BestT v; pack_best(v, pDA + (labA1 == rc ? 2 : -5), (i << 8) | 1); atomicMax(&S.hbest[M_D][ch[1]], v); }
+            if(cv[2]) { BestT v, w; pack_best(v, pD - 6, ord0 | 0); if(pG != DP_NEG) { pack_best(w, pG - 2, ord0 | 1); if(w > v) v = w; } atomicMax(&S.hbest[M_GG][ch[2]], v); }
+        }
+        {   // batch 2: both edges of the m-1 entry, the first jump
+            bool cv[3]; u64 ck[3]; u32 ch[3]; u64 cold[3];
+            cv[0] = sgB && degB > 0; ck[0] = mk_key(nxB, pyB, tnB0);
+            cv[1] = sgB && degB > 1; ck[1] = mk_key(nxB, pyB, tnB1);
+            cv[2] = okB && j1 > j0 && jx0 >= 0 && jx0 <= max_levelI; ck[2] = mk_key(jx0, pyB, jn0);
+#pragma unroll
+            for(int q = 0; q < 3; q++) { ch[q] = hash64(ck[q]) & (C::HC - 1); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
+#pragma unroll
+            for(int q = 0; q < 3; q++)
+                if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
+#pragma unroll
+            for(int kk = 0; kk < 2; kk++) {
+                const unsigned char lab = kk ? labB1 : labB0;
+                if(cv[kk]) {
+                    BestT v, w;
+                    if(lab != '_') {
+                        pack_best(v, pD - 6, ord0 | (2 * kk)); if(pS != DP_NEG) { pack_best(w, pS - 2, ord0 | (2 * kk + 1)); if(w > v) v = w; }
+                        atomicMax(&S.hbest[M_SG][ch[kk]], v);
+                    } else {
+                        if(pS != DP_NEG) { pack_best(w, pS, ord0 | (2 * kk + 1)); atomicMax(&S.hbest[M_SG][ch[kk]], w); }
+                        pack_best(v, pD, ord0 | kk); atomicMax(&S.hbest[M_D][ch[kk]], v);
+                    }
                 }
-                edges += degA;
+            }
+            if(cv[2]) { BestT v; pack_best(v, pD, ord0 | 128); atomicMax(&S.hbest[M_D][ch[2]], v); }
+        }
+        if(okA) edges += degA;
+        if(sgB) edges += degB;
+        // ---- the rest of wide nodes: edges 2.. and jumps 1.., read from the CSR arrays
+        if(okA) for(int k = 2; k < degA; k++) {
+            int tn = eto[a0 + k]; unsigned char lab = elab[a0 + k];
+            if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | k)) S.err = __LINE__;
+        }
+        if(sgB) for(int kk = 2; kk < degB; kk++) {
+            int tn = eto[e0 + kk]; unsigned char lab = elab[e0 + kk];
+            u64 k = mk_key(nxB, pyB, tn);
+            if(lab != '_') {
+                if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
+                if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
+            } else {
+                if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
+                if(!dp_push<C>(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;
             }
         }
-        // ---- pushes from the m-1 entry
-        if(hasB) {
-            const int ord0 = (1 << (C::IBITS + 8)) | (i << 8);
-            {   // gap in graph, :621-661
-                int ny = pyB + dir;
-                if(ny >= 0 && ny <= max_seqI) {
-                    u64 k = mk_key(pxB, ny, nodeB);
-                    if(!dp_push<C>(S, k, M_GG, pD - 6, ord0 | 0)) S.err = __LINE__;
-                    if(pG != DP_NEG) if(!dp_push<C>(S, k, M_GG, pG - 2, ord0 | 1)) S.err = __LINE__;
-                }
-            }
-            if(degB > 127 || j1 - j0 > 127) S.err = __LINE__;
-            else {
-                const int nx = pxB + dir;
-                if(nx >= 0 && nx <= max_levelI) {                                             // gap in sequence, :664-754
-                    for(int kk = 0; kk < degB; kk++) {
-                        int tn; unsigned char lab;
-                        if(kk == 0) { tn = tnB0; lab = labB0; } else if(kk == 1) { tn = tnB1; lab = labB1; } else { tn = eto[e0 + kk]; lab = elab[e0 + kk]; }
-                        u64 k = mk_key(nx, pyB, tn);
-                        if(lab != '_') {
-                            if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
-                            if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
-                        } else {
-                            if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
-                            if(!dp_push<C>(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;         // non-affine sequence gap, :738-752
-                        }
-                    }
-                    edges += degB;
-                }
-                // gap-path jumps, :757-786 (jump_length * S_graphGap = 0); push index of a jump = 128 + its rank in the jump
-                // table: after every edge candidate of the same source (:757)
-                for(int j = j0; j < j1; j++) {
-                    int tn, jx;
-                    if(j == j0) { tn = jn0; jx = jx0; } else { tn = jnode[j]; jx = jlvl[j]; }
-                    if(jx < 0 || jx > max_levelI) continue;
-                    if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)))) S.err = __LINE__;
-                }
-            }
+        if(okB) for(int j = j0 + 1; j < j1; j++) {
+            int tn = jnode[j]; int jx = jlvl[j];
+            if(jx < 0 || jx > max_levelI) continue;
+            if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)))) S.err = __LINE__;
         }
     }
     edgesAcc += edges;
     WSYNC();
+    DP_TQ(5);
     // target list = occupied hash entries, compacted with a ballot per GW entries (no per-push counter, no ordering assumed)
     int nT = 0;
     for(int h0 = 0; h0 < C::HC; h0 += GW) {
@@ -444,6 +482,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     if(nT > (C::HC * 3) / 4 || guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
 
     // ================= evaluate =====================================================
+    // (the part of the DP state that only this phase needs is read here, not at the top: shorter live ranges)
+    const int startLevel = guni<GW>(st.startLevel), start_seq = guni<GW>(st.start_seq);
+    const int curMax0 = guni<GW>(st.curMax);
+    const int nCompleted0 = guni<GW>(st.nCompleted);
+    int nCells = guni<GW>(st.nCells);
+    int earlyInit = guni<GW>(st.earlyInit);
     if(gl == 0) { S.nNew = 0; S.nImp = 0; S.nCompletedAdd = 0; }
     WSYNC();
     int itMaxNew = DP_NEG;        // max Dv over kept targets of this iteration
@@ -609,6 +653,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         }
         WSYNC();
     }
+    DP_TQ(6);
     if(guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
     const int nCompletedNew = nCompleted0 + guni<GW>(S.nCompletedAdd);
     // apply staged improvements of existing cells and patch cached frontier copies
@@ -932,7 +977,7 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
 //         every choice between the out- and the in-edge arrays) is uniform across the four groups of a wavefront;
 // TIER k > 0: items that outgrew the class of tier k-1 (retry list k).
 template <class C, int TIER>
-__global__ __launch_bounds__(64, (C::GW == 64 ? 5 : 4)) void k_dp(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items,
+__global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items,
                                                                     char* slabs, size_t slabBytes, u32 rng_seed)
 {
     constexpr int GW = C::GW;
@@ -949,7 +994,7 @@ __global__ __launch_bounds__(64, (C::GW == 64 ? 5 : 4)) void k_dp(const DevGraph
 
     if(gl == 0) { S.accCalls = 0; S.accIters = 0; S.accCells = 0; S.accEdges = 0; }
 #ifdef HLALA_DP_TIMING
-    if(gl == 0) { S.tPh[0] = 0; S.tPh[1] = 0; S.tPh[2] = 0; S.tPh[3] = 0; }
+    if(gl == 0) { for(int i = 0; i < 8; i++) S.tPh[i] = 0; }
 #endif
 #ifdef HLALA_DP_TIMING                                     // build-time switch: cycles per state of the persistent loop -> counters[8..15]
     long long tAcc[6] = {0, 0, 0, 0, 0, 0}; long long trips = 0, runGroups = 0; long long tMark = clock64();
@@ -1024,7 +1069,7 @@ __global__ __launch_bounds__(64, (C::GW == 64 ? 5 : 4)) void k_dp(const DevGraph
         atomicAdd(&B.counters[CNT_DP_CELLS], S.accCells); atomicAdd(&B.counters[CNT_EDGES], S.accEdges);
     }
 #ifdef HLALA_DP_TIMING
-    if(TIER == 0 && (threadIdx.x & 63) == 0) { for(int i = 0; i < 4; i++) atomicAdd(&B.counters[24 + i], (u64)S.tPh[i]);
+    if(TIER == 0 && (threadIdx.x & 63) == 0) { for(int i = 0; i < 8; i++) atomicAdd(&B.counters[24 + i], (u64)S.tPh[i]);
         for(int i = 0; i < 6; i++) atomicAdd(&B.counters[8 + i], (u64)tAcc[i]); atomicAdd(&B.counters[14], (u64)trips); atomicAdd(&B.counters[15], (u64)runGroups); }
 #endif
 }

@@ -26,4 +26,4 @@ if pj[7] > 0:
     print('project cycles/chain: walk %.0f trim+pad %.0f clean %.0f restrict %.0f stage+dp %.0f backtrace %.0f | chains %d' % tuple(list(pj[:6] / pj[7]) + [int(pj[7])]))
 hh = np.array(list(buf)[24:32], dtype=np.float64)
 if hh[0] > 0 and d[6] > 0:
-    print('dp_iterate cycles/trip (group 0 of each wave): generate %.0f early-lookup %.0f evaluate %.0f filter %.0f' % (hh[0]/d[6], hh[3]/d[6], hh[1]/d[6], hh[2]/d[6]))
+    print('dp_iterate cycles/trip (group 0 of each wave; waitcnt(0) before each clock): header+records %.0f pushes %.0f tlist %.0f early-lookup %.0f evaluate-passes %.0f post-evaluate %.0f filter+writeback %.0f' % (hh[4]/d[6], hh[5]/d[6], hh[0]/d[6], hh[3]/d[6], hh[6]/d[6], hh[1]/d[6], hh[2]/d[6]))
