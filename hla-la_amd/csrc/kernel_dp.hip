@@ -44,10 +44,10 @@ constexpr u64 HKEY_EMPTY = ~0ull;
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 6;     // back pointers one group follows per trip of the persistent loop
 
-struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 1024,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; };
-struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 2048,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; };
-struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; };
-struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS, EARLY = DP_EARLY, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; };
+struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; };
+struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; };
+struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; };
+struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; };
 
 // State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
 // that only the phase has to stay in registers across the states of the persistent loop.
@@ -257,6 +257,20 @@ __device__ inline int early_lookup(const DpSlabT<C>& sl, u64 key)
         if(cur == HKEY_EMPTY) return -1;
         h = (h + 1) & (C::EARLY - 1);
     }
+    return -1;
+}
+// find-or-insert in ONE compare-and-swap round trip per probe: returns the entry (>= 0) and whether the key was already there
+template <class C>
+__device__ inline int early_claim(const DpSlabT<C>& sl, u64 key, bool& found)
+{
+    u32 h = hash64(key) & (C::EARLY - 1);
+    for(int probe = 0; probe < C::EARLY; probe++) {
+        u64 old = atomicCAS(&sl.early_key()[h], HKEY_EMPTY, key);
+        if(old == HKEY_EMPTY) { found = false; return (int)h; }
+        if(old == key) { found = true; return (int)h; }
+        h = (h + 1) & (C::EARLY - 1);
+    }
+    found = false;
     return -1;
 }
 template <class C>
@@ -495,16 +509,24 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     bool anyEqDiff = false, anyOw = false, anyExisting = false;
 
     // Cells reached through a gap-path jump arrive EARLIER than their natural diagonal |dx|+|dy| and can be
-    // reached again later ("scores" merge, :951-979).  Only such cells are registered in the early hash, and
-    // only while it is non-empty do targets need an existence lookup.
+    // reached again later ("scores" merge, :951-979).  From the first such cell on, every kept target is looked up in and, if
+    // new, registered with the DP's cell hash in the slab -- one compare-and-swap round trip does both (cells that are not
+    // early can never be reached again, registering them is merely harmless).  tes[t] = table slot of an existing cell,
+    // or -2 - (hash entry claimed for a new one), or -1.
     if(earlyInit) {
         for(int t0 = 0; t0 < nT; t0 += GW) {
             int t = t0 + gl; int es = -1;
             if(t < nT) {
                 int h = S.tlist[t];
                 int Dv = max(best_score(S.hbest[M_D][h]), max(best_score(S.hbest[M_GG][h]), best_score(S.hbest[M_SG][h])));
-                if(Dv >= -16) es = early_lookup<C>(sl, S.hkey[h]);
-                S.tes[t] = (short)es;
+                int v = -1;
+                if(Dv >= -16) {
+                    bool found; int pos = early_claim<C>(sl, S.hkey[h], found);
+                    if(pos < 0) S.err = __LINE__;
+                    else if(found) { es = __hip_atomic_load(&sl.early_val()[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = es; }
+                    else v = -2 - pos;
+                }
+                S.tes[t] = (short)v;
             }
             if(grp_ballot<GW>(es >= 0)) anyExisting = true;
         }
@@ -529,12 +551,14 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             bool keep = act && (Dv >= -16);                                               // :949
             int es = -1; bool isNew; int slot;
             if(pass == 0) {
-                if(hadEarly && keep) es = S.tes[t];
+                int claimed = -1;
+                if(hadEarly && keep) { int v = S.tes[t]; if(v >= 0) es = v; else if(v <= -2) claimed = -2 - v; }
                 isNew = keep && es < 0;
                 int total; int off = grp_excl_scan<GW>(isNew ? 1 : 0, total);
                 slot = isNew ? nCells + off : es;
                 if(nCells + total > C::CELLS) { DP_FAIL(__LINE__); failed = true; }
                 nCells += total;
+                if(isNew && claimed >= 0) __hip_atomic_store(&sl.early_val()[claimed], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 slot = keep ? S.tes[t] : -1;
                 isNew = keep && (S.timp[t] & 0x80);
@@ -581,7 +605,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 int x = key_x(key), y = key_y(key);
                 int natural = (x > startLevel ? x - startLevel : startLevel - x) + (y > start_seq ? y - start_seq : start_seq - y);
                 bool isEarly = isNew && natural > d;
-                if(grp_ballot<GW>(isEarly)) {
+                if(!hadEarly && grp_ballot<GW>(isEarly)) {       // the first early cells of this DP: start the hash with them
                     if(!earlyInit) {
                         for(int i = gl; i < C::EARLY; i += GW) sl.early_key()[i] = HKEY_EMPTY;
                         earlyInit = 1;
