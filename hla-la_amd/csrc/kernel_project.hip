@@ -243,46 +243,83 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
 
         PJ_T(2);
         // ---------------- cleanInitialAlignment (:4621-4792) -- only when an insertion or a double-gap column exists
+        // Bit-mask helpers over 64-column words in LDS; every lane runs the same scalar walk (uniform control flow).
+        auto bitOf = [&](const u64* m, int p) -> bool { return (m[p >> 6] >> (p & 63)) & 1ull; };
+        auto nextSet = [&](const u64* m, int p, int hi) -> int {                          // first set bit in [p, hi], else hi + 1
+            while(p <= hi) { u64 w = m[p >> 6] >> (p & 63); if(w) { int q = p + __ffsll((long long)w) - 1; return q <= hi ? q : hi + 1; } p = (p | 63) + 1; }
+            return hi + 1; };
+        auto nextClear = [&](const u64* m, int p, int hi) -> int {                        // first clear bit in [p, hi], else hi + 1
+            while(p <= hi) { u64 w = (~m[p >> 6]) >> (p & 63); if(w) { int q = p + __ffsll((long long)w) - 1; return q <= hi ? q : hi + 1; } p = (p | 63) + 1; }
+            return hi + 1; };
+        auto prevSet = [&](const u64* m, int p, int lo) -> int {                          // last set bit in [lo, p], else lo - 1
+            while(p >= lo) { u64 w = m[p >> 6] << (63 - (p & 63)); if(w) { int q = p - __clzll((long long)w); return q >= lo ? q : lo - 1; } p = (p & ~63) - 1; }
+            return lo - 1; };
+        auto countBits = [&](const u64* m, int a, int b) -> int {                         // set bits in [a, b]
+            int n = 0;
+            for(int k = (a >> 6); k <= (b >> 6) && a <= b; k++) {
+                u64 w = m[k]; int lo = k * 64, hi = lo + 63;
+                if(a > lo) w &= ~0ull << (a - lo);
+                if(b < hi) w &= ~0ull >> (hi - b);
+                n += __popcll(w);
+            }
+            return n; };
         int removed = 0;
         if(PJ_OK()) {
+            // masks: mGap = interesting column (insertion or double gap), mDef = insertion (level -1), mSeq = double gap
             bool any = false;
-            for(int j0 = 0; j0 < n1; j0 += 64) { int j = j0 + lane; bool in = j < n1 && (P.lvl[cur][j] == -1 || (P.g[cur][j] == '_' && P.s[cur][j] == '_')); if(__ballot(in)) any = true; }
+            const int nW = (n1 + 63) >> 6;
+            for(int k = 0; k < nW; k++) {
+                int j = k * 64 + lane; bool ins = false, dg = false;
+                if(j < n1) { ins = P.lvl[cur][j] == -1; dg = P.g[cur][j] == '_' && P.s[cur][j] == '_'; }
+                u64 mi = __ballot(ins), md = __ballot(dg);
+                if(mi | md) any = true;
+                if(lane == 0) { P.mGap[k] = mi | md; P.mDef[k] = mi; P.mSeq[k] = md; }
+            }
+            WSYNC();
             if(any) {
-                if(lane == 0) {
-                    int* lv = P.lvl[cur]; unsigned char* ga = P.g[cur]; unsigned char* sa = P.s[cur];
-                    bool inStretch = false, cleaned = false; int sStart = -1, balance = 0;
-                    for(int p = 0; p < n1; p++) {
-                        bool interesting = (lv[p] == -1) || (ga[p] == '_' && sa[p] == '_');
-                        if(interesting) {
-                            if(!inStretch) { sStart = p; inStretch = true; }
-                            if(lv[p] == -1) balance++;
-                            if(ga[p] == '_' && sa[p] == '_') balance--;
-                        } else if(inStretch) {
-                            int sStop = p - 1;
-                            if(balance == 0) {
-                                // pair the inserted bases with the skipped levels: first half = (gap level, '_', base), rest deleted
-                                int Ls = sStop - sStart + 1, half = Ls / 2;
-                                int* olv = P.lvl[1 - cur]; unsigned char* osa = P.s[1 - cur];     // scratch: gather in order
-                                int ni = 0, ng = 0;
-                                for(int q = sStart; q <= sStop; q++) { if(lv[q] == -1) osa[ni++] = sa[q]; else olv[ng++] = lv[q]; }
-                                if(ni != ng || ni != half) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
-                                else {
-                                    cleaned = true;
-                                    for(int q = sStart; q <= sStop; q++) {
-                                        int i = q - sStart;
-                                        if(i < half) { lv[q] = olv[i]; ga[q] = '_'; sa[q] = osa[i]; } else { lv[q] = -1; ga[q] = '_'; sa[q] = '_'; }
-                                    }
-                                }
+                bool cleaned = false;
+                int p = 0;
+                while(p < n1) {
+                    const int a = nextSet(P.mGap, p, n1 - 1);
+                    if(a > n1 - 1) break;
+                    const int e = nextClear(P.mGap, a, n1 - 1);
+                    if(e > n1 - 1) break;                                   // a stretch that reaches the last column is never closed (:4650-4720)
+                    const int b = e - 1;
+                    const int ni = countBits(P.mDef, a, b), nd = countBits(P.mSeq, a, b);
+                    if(ni - nd == 0) {
+                        // pair the inserted bases with the skipped levels: first half = (gap level, '_', base), rest deleted
+                        const int Ls = b - a + 1, half = Ls / 2, ng = Ls - ni;
+                        if(ni != ng || ni != half) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+                        else {
+                            cleaned = true;
+                            int* olv = P.lvl[1 - cur]; unsigned char* osa = P.s[1 - cur];      // scratch: gathered in column order
+                            for(int q = a + lane; q <= b; q += 64) {
+                                const int r = q > a ? countBits(P.mDef, a, q - 1) : 0;
+                                if(bitOf(P.mDef, q)) osa[r] = P.s[cur][q]; else olv[(q - a) - r] = P.lvl[cur][q];
                             }
-                            inStretch = false; sStart = -1; balance = 0;
+                            WSYNC();
+                            for(int q = a + lane; q <= b; q += 64) {
+                                const int i = q - a;
+                                if(i < half) { P.lvl[cur][q] = olv[i]; P.g[cur][q] = '_'; P.s[cur][q] = osa[i]; }
+                                else { P.lvl[cur][q] = -1; P.g[cur][q] = '_'; P.s[cur][q] = '_'; }
+                            }
+                            WSYNC();
                         }
                     }
-                    int w = n1;
-                    if(cleaned) { w = 0; for(int p = 0; p < n1; p++) if(!(lv[p] == -1 && ga[p] == '_' && sa[p] == '_')) { lv[w] = lv[p]; ga[w] = ga[p]; sa[w] = sa[p]; w++; } }
-                    P.n = w;
+                    p = e;
                 }
-                WSYNC();
-                n1 = uni(P.n);
+                if(cleaned) {
+                    int w = 0;
+                    for(int k = 0; k < nW; k++) {
+                        int j = k * 64 + lane; bool keep = false; int lv = 0; unsigned char gc = 0, sc = 0;
+                        if(j < n1) { lv = P.lvl[cur][j]; gc = P.g[cur][j]; sc = P.s[cur][j]; keep = !(lv == -1 && gc == '_' && sc == '_'); }
+                        const u64 m = __ballot(keep);
+                        if(keep) { const int o = w + __popcll(m & ((1ull << lane) - 1ull)); P.lvl[1 - cur][o] = lv; P.g[1 - cur][o] = gc; P.s[1 - cur][o] = sc; }
+                        w += __popcll(m);
+                    }
+                    WSYNC();
+                    cur = 1 - cur; n1 = w;
+                }
             }
         }
         WSYNC();
@@ -307,22 +344,6 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             WSYNC();
             if(any && PJ_OK()) {
                 // every lane runs the same scalar walk over the masks (uniform control flow, no divergence)
-                auto bitOf = [&](const u64* m, int p) -> bool { return (m[p >> 6] >> (p & 63)) & 1ull; };
-                auto nextSet = [&](const u64* m, int p, int hi) -> int {                  // first set bit in [p, hi], else hi + 1
-                    while(p <= hi) { u64 w = m[p >> 6] >> (p & 63); if(w) { int q = p + __ffsll((long long)w) - 1; return q <= hi ? q : hi + 1; } p = (p | 63) + 1; }
-                    return hi + 1; };
-                auto prevSet = [&](const u64* m, int p, int lo) -> int {                  // last set bit in [lo, p], else lo - 1
-                    while(p >= lo) { u64 w = m[p >> 6] << (63 - (p & 63)); if(w) { int q = p - __clzll((long long)w); return q >= lo ? q : lo - 1; } p = (p & ~63) - 1; }
-                    return lo - 1; };
-                auto countSeq = [&](int a, int b) -> int {                                 // read characters in [a, b]
-                    int n = 0;
-                    for(int k = (a >> 6); k <= (b >> 6) && a <= b; k++) {
-                        u64 w = P.mSeq[k]; int lo = k * 64, hi = lo + 63;
-                        if(a > lo) w &= ~0ull << (a - lo);
-                        if(b < hi) w &= ~0ull >> (hi - b);
-                        n += __popcll(w);
-                    }
-                    return n; };
                 int bestA = -1, bestB = -1, bestLen = 0;
                 auto consider = [&](int a, int b) {                                         // trim -1 ends (:4507-4531), keep the LAST longest (:4533-4552)
                     int a2 = nextSet(P.mDef, a, b);
@@ -338,7 +359,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 }
                 int w = n1;
                 if(bestLen > 0) {
-                    int ns = uni(P.startRaw) + countSeq(0, bestA - 1), ne = uni(P.stopRaw) - countSeq(bestB + 1, n1 - 1), sc = countSeq(bestA, bestB);
+                    int ns = uni(P.startRaw) + countBits(P.mSeq, 0, bestA - 1), ne = uni(P.stopRaw) - countBits(P.mSeq, bestB + 1, n1 - 1), sc = countBits(P.mSeq, bestA, bestB);
                     if(((double)sc / (double)seqChars) > 0.3) {                              // :4606
                         for(int q = bestA + lane; q <= bestB; q += 64) { P.lvl[1 - cur][q - bestA] = P.lvl[cur][q]; P.g[1 - cur][q - bestA] = P.g[cur][q]; P.s[1 - cur][q - bestA] = P.s[cur][q]; }
                         WSYNC();
