@@ -64,9 +64,15 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
     const DevTables& T = *Tp;
     const int stride = B.stride;
 
+    // pairs are drawn eight at a time (one same-address atomic per pair serialises the grid at the L2)
+    constexpr int CHUNK = 8;
     for(;;) {
-        const int p = next_work(&B.work_counter[2]);
-        if(p >= B.n_pairs) break;
+        int p0 = 0;
+        if(lane == 0) p0 = atomicAdd(&B.work_counter[2], CHUNK);
+        p0 = __builtin_amdgcn_readfirstlane(p0);
+        if(p0 >= B.n_pairs) break;
+        const int pEnd = min(p0 + CHUNK, B.n_pairs);
+        for(int p = p0; p < pEnd; p++) {
         // ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains), error propagation
         int bad = 0;
         for(int m = 0; m < 2; m++) {
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
         }
         }   // !bad
         WSYNC();
+        }
     }
 }
 
