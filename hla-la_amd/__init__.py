@@ -180,6 +180,8 @@ def load_library(path: str | None = None):
     lib.hlala_pair_loglik.argtypes = [vp, c_f64p, c_i32p, C.c_int32, C.c_int32, c_f64p, c_f64p, c_f64p]
     lib.hlala_kat_phred.argtypes = [vp, C.c_int, c_f64p, c_u8p, c_u8p, c_f64p]
     lib.hlala_kat_rand_r.argtypes = [vp, C.c_int, c_u32p, c_i32p]
+    lib.hlala_abi_sizeof.argtypes = [C.c_char_p]
+    lib.hlala_abi_sizeof.restype = C.c_int
     if path is None:
         _lib = lib
     return lib
@@ -191,7 +193,7 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
-    "hlala_kat_rand_r",
+    "hlala_kat_rand_r", "hlala_abi_sizeof",
 ]
 
 

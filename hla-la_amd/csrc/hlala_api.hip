@@ -729,6 +729,17 @@ extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uin
     return HLALA_OK;
 }
 
+extern "C" int hlala_abi_sizeof(const char* name)
+{
+    if(!name) return -1;
+    const std::string n(name);
+#define SZ(t) if(n == #t) return (int)sizeof(t);
+    SZ(hlala_graph_desc) SZ(hlala_contigs_desc) SZ(hlala_params) SZ(hlala_graph_info) SZ(hlala_batch_in) SZ(hlala_seeds_in)
+    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in)
+#undef SZ
+    return -1;
+}
+
 extern "C" int hlala_kat_rand_r(hlala_ctx* c, int n, uint32_t* seeds_inout, int32_t* values_out)
 {
     if(!c || n < 0 || !seeds_inout || !values_out) return HLALA_E_ARG;

@@ -272,6 +272,10 @@ int  hlala_kat_phred(hlala_ctx* ctx, int n, const double* p_correct, uint8_t* ph
                      const uint8_t* phred_in, double* p_out);
 int  hlala_kat_rand_r(hlala_ctx* ctx, int n, uint32_t* seeds_inout, int32_t* values_out);
 
+/* sizeof() of the structs of this header as the library was compiled, by struct name ("hlala_graph_desc", "hlala_params", ...);
+ * -1 for an unknown name.  Lets a foreign-function binding (ctypes, cgo, JNI) check its mirror of the layout at load time. */
+int  hlala_abi_sizeof(const char* struct_name);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,18 @@ def test_abi_exports_every_declared_symbol(pkg):
     assert declared == set(pkg.EXPORTED_SYMBOLS)
 
 
+def test_ctypes_mirror_matches_the_compiled_struct_layout(pkg):
+    lib = C.CDLL(pkg.LIB_PATH)
+    lib.hlala_abi_sizeof.argtypes = [C.c_char_p]; lib.hlala_abi_sizeof.restype = C.c_int
+    mirror = {"hlala_graph_desc": pkg.GraphDesc, "hlala_contigs_desc": pkg.ContigsDesc, "hlala_params": pkg.Params,
+              "hlala_graph_info": pkg.GraphInfo, "hlala_batch_in": pkg.BatchIn, "hlala_seeds_in": pkg.SeedsIn,
+              "hlala_chains_out": pkg.ChainsOut, "hlala_pairs_out": pkg.PairsOut, "hlala_batch_stats": pkg.BatchStats,
+              "hlala_exon_in": pkg.ExonIn}
+    for name, cls in mirror.items():
+        assert lib.hlala_abi_sizeof(name.encode()) == C.sizeof(cls), name
+    assert lib.hlala_abi_sizeof(b"no_such_struct") == -1
+
+
 def test_create_fails_loudly_without_gpu(pkg):
     import torch
     if torch.cuda.is_available():

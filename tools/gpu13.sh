@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-HLALA_DEBUG=1 timeout 300 python tools/dbg_timing.py 262144 5000000 2>&1 | tail -3
+make -C oracle 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_gpu_extend.py -x -q -m gpu -s 2>&1 | grep -E "k=|passed|failed|Error" | head
