@@ -82,34 +82,33 @@ struct __align__(16) DpLdsT {
 #endif
 };
 
+// one kept DP cell in the slab: 32 bytes, written with two 16-byte stores
+struct __align__(16) CellRec { u64 key; short sc[4]; u32 bt[3]; u32 pad; };      // sc = D, GG, SG, -; bt per matrix
+
 // Scratch of one DP call in HBM (private to its group).  Only the base address is held in registers; every array sits at a
 // compile-time offset, 8-byte arrays first.
 template <class C>
 struct DpSlabT {
     char* base;
-    static constexpr size_t O_CELL_KEY  = 0;                                          // u64  [CELLS]
-    static constexpr size_t O_CELL_BT   = O_CELL_KEY + (size_t)C::CELLS * 8;          // u64  [3*CELLS]
-    static constexpr size_t O_EARLY_KEY = O_CELL_BT + (size_t)C::CELLS * 24;          // u64  [EARLY]
-    static constexpr size_t O_STEP_BT   = O_EARLY_KEY + (size_t)C::EARLY * 8;         // u64  [STEPS]
-    static constexpr size_t O_STEP_XY   = O_STEP_BT + (size_t)C::STEPS * 8;           // u64  [STEPS]
+    static constexpr size_t O_CELL      = 0;                                          // CellRec [CELLS]
+    static constexpr size_t O_EARLY_KEY = O_CELL + (size_t)C::CELLS * 32;             // u64  [EARLY]
+    static constexpr size_t O_STEP_XY   = O_EARLY_KEY + (size_t)C::EARLY * 8;         // u64  [STEPS]
     static constexpr size_t O_IMP_KEY   = O_STEP_XY + (size_t)C::STEPS * 8;           // u64  [IMPCAP]
-    static constexpr size_t O_IMP_BT    = O_IMP_KEY + (size_t)C::IMPCAP * 8;          // u64  [3*IMPCAP]
-    static constexpr size_t O_IMP_NEW   = O_IMP_BT + (size_t)C::IMPCAP * 24;          // short[4*IMPCAP]
-    static constexpr size_t O_CELL_SC   = O_IMP_NEW + (size_t)C::IMPCAP * 8;          // short[4*CELLS]  D, GG, SG, -
-    static constexpr size_t O_EARLY_VAL = O_CELL_SC + (size_t)C::CELLS * 8;           // int  [EARLY]
+    static constexpr size_t O_IMP_NEW   = O_IMP_KEY + (size_t)C::IMPCAP * 8;          // short[4*IMPCAP]
+    static constexpr size_t O_IMP_BT    = O_IMP_NEW + (size_t)C::IMPCAP * 8;          // u32  [3*IMPCAP]
+    static constexpr size_t O_STEP_BT   = O_IMP_BT + (size_t)C::IMPCAP * 12;          // u32  [STEPS]
+    static constexpr size_t O_EARLY_VAL = O_STEP_BT + (size_t)C::STEPS * 4;           // int  [EARLY]
     static constexpr size_t O_COMPLETED = O_EARLY_VAL + (size_t)C::EARLY * 4;         // int  [COMPLETED]
     static constexpr size_t O_IMP_SLOT  = O_COMPLETED + (size_t)C::COMPLETED * 4;     // int  [IMPCAP]
     static constexpr size_t O_IMP_MASK  = O_IMP_SLOT + (size_t)C::IMPCAP * 4;         // int  [IMPCAP]
     static constexpr size_t BYTES       = (O_IMP_MASK + (size_t)C::IMPCAP * 4 + 255) & ~(size_t)255;
-    __device__ __forceinline__ u64* cell_key() const { return (u64*)(base + O_CELL_KEY); }
-    __device__ __forceinline__ u64* cell_bt() const { return (u64*)(base + O_CELL_BT); }
+    __device__ __forceinline__ CellRec* cell() const { return (CellRec*)(base + O_CELL); }
     __device__ __forceinline__ u64* early_key() const { return (u64*)(base + O_EARLY_KEY); }
-    __device__ __forceinline__ u64* step_bt() const { return (u64*)(base + O_STEP_BT); }
+    __device__ __forceinline__ u32* step_bt() const { return (u32*)(base + O_STEP_BT); }
     __device__ __forceinline__ u64* step_xy() const { return (u64*)(base + O_STEP_XY); }
     __device__ __forceinline__ u64* imp_key() const { return (u64*)(base + O_IMP_KEY); }
-    __device__ __forceinline__ u64* imp_bt() const { return (u64*)(base + O_IMP_BT); }
+    __device__ __forceinline__ u32* imp_bt() const { return (u32*)(base + O_IMP_BT); }
     __device__ __forceinline__ short* imp_new() const { return (short*)(base + O_IMP_NEW); }
-    __device__ __forceinline__ short* cell_sc() const { return (short*)(base + O_CELL_SC); }
     __device__ __forceinline__ int* early_val() const { return (int*)(base + O_EARLY_VAL); }
     __device__ __forceinline__ int* completed() const { return (int*)(base + O_COMPLETED); }
     __device__ __forceinline__ int* imp_slot() const { return (int*)(base + O_IMP_SLOT); }
@@ -204,11 +203,13 @@ __device__ __forceinline__ u32 hash64(u64 k)
     return h ^ (h >> 6) ^ (h >> 12);
 }
 
-__device__ __forceinline__ u64 mk_bt(int prev, int src, int kind, int edge) { return ((u64)(u32)edge << 32) | (u64)((u32)prev | ((u32)src << 24) | ((u32)kind << 26)); }
-__device__ __forceinline__ int bt_prev(u64 b) { return (int)(b & 0xFFFFFF); }
-__device__ __forceinline__ int bt_src(u64 b) { return (int)((b >> 24) & 3); }
-__device__ __forceinline__ int bt_kind(u64 b) { return (int)((b >> 26) & 7); }
-__device__ __forceinline__ int bt_edge(u64 b) { return (int)(b >> 32); }
+// back pointer: previous cell slot (15 bits, CELLS <= 32768) | source matrix (2) | kind (3) | local push index j (8; 0xFF = none)
+__device__ __forceinline__ u32 mk_bt(int prev, int src, int kind, int edge) { return (u32)prev | ((u32)src << 15) | ((u32)kind << 17) | (((u32)edge & 0xFFu) << 20); }
+__device__ __forceinline__ int bt_prev(u32 b) { return (int)(b & 0x7FFF); }
+__device__ __forceinline__ int bt_src(u32 b) { return (int)((b >> 15) & 3); }
+__device__ __forceinline__ int bt_kind(u32 b) { return (int)((b >> 17) & 7); }
+__device__ __forceinline__ int bt_edge(u32 b) { return (int)((b >> 20) & 0xFF); }
+
 
 // candidate value: (score, reversed push index) so that an unsigned max = highest score, earliest push
 __device__ __forceinline__ void pack_best(u32& o, int score, int order) { o = ((u32)(score + 64) << 16) | (u32)(0xFFFF - order); }
@@ -327,9 +328,9 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
         st.have = 0; st.sb = 0; st.se = -1; st.err = 0;
         S.err = 0;
-        sl.cell_key()[0] = mk_key(it.startLevel, it.start_seq, it.startNode);
-        sl.cell_sc()[0] = 0; sl.cell_sc()[1] = (short)DP_NEG; sl.cell_sc()[2] = (short)DP_NEG; sl.cell_sc()[3] = 0;
-        sl.cell_bt()[0] = 0; sl.cell_bt()[C::CELLS] = 0; sl.cell_bt()[2 * C::CELLS] = 0;
+        CellRec c0; c0.key = mk_key(it.startLevel, it.start_seq, it.startNode);
+        c0.sc[0] = 0; c0.sc[1] = (short)DP_NEG; c0.sc[2] = (short)DP_NEG; c0.sc[3] = 0; c0.bt[0] = 0; c0.bt[1] = 0; c0.bt[2] = 0; c0.pad = 0;
+        sl.cell()[0] = c0;
         S.fkey[0][0] = mk_key(it.startLevel, it.start_seq, it.startNode); S.fslot[0][0] = 0;
         S.fD[0][0] = 0; S.fG[0][0] = (short)DP_NEG; S.fS[0][0] = (short)DP_NEG;
     }
@@ -566,7 +567,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             }
             const bool ok = !failed && S.err == 0;
             // ---- back pointers of the three matrices, decoded from the winning push index
-            u64 btD = 0, btG = 0, btS = 0;
+            u32 btD = 0, btG = 0, btS = 0;
             int srcScore = 0;       // score the real previous step came from (fast form of the `diff` rule)
             if(keep && ok && slot >= 0 && slot < C::CELLS) {
                 // back pointer = (previous cell slot, source matrix, kind, local push index j); the graph edge / gap path behind j
@@ -594,13 +595,13 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             }
             int impMask = 0;
             int mD = Dv, mG = GGv, mS = SGv;          // merged values
-            u64 mbtD = btD;                            // merged D back pointer
+            u32 mbtD = btD;                            // merged D back pointer
             if(pass == 0) {
                 // ---- new cells: write the table entry, register early / sequence-complete cells
                 if(isNew && ok && slot < C::CELLS) {
-                    sl.cell_key()[slot] = key;
-                    sl.cell_sc()[4 * slot + 0] = (short)Dv; sl.cell_sc()[4 * slot + 1] = (short)GGv; sl.cell_sc()[4 * slot + 2] = (short)SGv; sl.cell_sc()[4 * slot + 3] = 0;
-                    sl.cell_bt()[slot] = btD; sl.cell_bt()[C::CELLS + slot] = btG; sl.cell_bt()[2 * C::CELLS + slot] = btS;
+                    uint4* dst = (uint4*)(sl.cell() + slot);
+                    dst[0] = make_uint4((u32)key, (u32)(key >> 32), ((u32)(unsigned short)(short)Dv) | ((u32)(unsigned short)(short)GGv << 16), (u32)(unsigned short)(short)SGv);
+                    dst[1] = make_uint4(btD, btG, btS, 0u);
                 }
                 int x = key_x(key), y = key_y(key);
                 int natural = (x > startLevel ? x - startLevel : startLevel - x) + (y > start_seq ? y - start_seq : start_seq - y);
@@ -620,8 +621,9 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             }
             // ---- existing cells: each matrix independently overwritten iff strictly greater, :951-979 (writes are staged)
             if(keep && !isNew && ok) {
-                int oD = sl.cell_sc()[4 * es + 0], oG = sl.cell_sc()[4 * es + 1], oS = sl.cell_sc()[4 * es + 2];
-                if(Dv > oD) impMask |= 1; else { mD = oD; mbtD = sl.cell_bt()[es]; }
+                const CellRec* er = sl.cell() + es;
+                int oD = er->sc[0], oG = er->sc[1], oS = er->sc[2];
+                if(Dv > oD) impMask |= 1; else { mD = oD; mbtD = er->bt[0]; }
                 if(GGv > oG) impMask |= 2; else mG = oG;
                 if(SGv > oS) impMask |= 4; else mS = oS;
                 if(impMask && pass == 0) {
@@ -645,15 +647,15 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 if(!slow) {
                     diff = Dv - srcScore;       // no table entry changes this iteration: cached frontier values are the table values
                 } else {
-                    u64 b = mbtD;
+                    u32 b = mbtD;
                     int guard = 0;
                     while(bt_kind(b) == K_HOP && guard++ < 4) {
                         int m = bt_src(b);
                         bool useNew = isNew || (impMask & (1 << m));
-                        if(useNew) b = (m == 1) ? btG : btS; else b = sl.cell_bt()[m * C::CELLS + slot];
+                        if(useNew) b = (m == 1) ? btG : btS; else b = sl.cell()[slot].bt[m];
                     }
                     int ps = bt_prev(b), pm = bt_src(b);
-                    int pv = sl.cell_sc()[4 * ps + pm];
+                    int pv = sl.cell()[ps].sc[pm];
                     // a predecessor improved in THIS iteration counts with its new value only if it precedes this cell in map order
                     int nImp = S.nImp < C::IMPCAP ? S.nImp : C::IMPCAP;
                     for(int q = 0; q < nImp; q++)
@@ -685,7 +687,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         int nImp = guni<GW>(S.nImp);
         for(int q = gl; q < nImp; q += GW) {
             int es = sl.imp_slot()[q]; int msk = sl.imp_mask()[q];
-            for(int m = 0; m < 3; m++) if(msk & (1 << m)) { sl.cell_sc()[4 * es + m] = sl.imp_new()[4 * q + m]; sl.cell_bt()[m * C::CELLS + es] = sl.imp_bt()[3 * q + m]; }
+            for(int m = 0; m < 3; m++) if(msk & (1 << m)) { sl.cell()[es].sc[m] = sl.imp_new()[4 * q + m]; sl.cell()[es].bt[m] = sl.imp_bt()[3 * q + m]; }
         }
         if(nImp) {
             WSYNC();
@@ -791,10 +793,10 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
     int endSlot = -1, endScore = 0;
     if(nCompleted > 0) {
         int best = DP_NEG;
-        for(int i = gl; i < nCompleted; i += GW) best = max(best, (int)sl.cell_sc()[4 * sl.completed()[i] + 0]);
+        for(int i = gl; i < nCompleted; i += GW) best = max(best, (int)sl.cell()[sl.completed()[i]].sc[0]);
         best = grp_max_i32<GW>(best);
         int nTies = 0;
-        for(int i0 = 0; i0 < nCompleted; i0 += GW) { int i = i0 + gl; bool tie = i < nCompleted && sl.cell_sc()[4 * sl.completed()[i] + 0] == best; nTies += __popcll(grp_ballot<GW>(tie)); }
+        for(int i0 = 0; i0 < nCompleted; i0 += GW) { int i = i0 + gl; bool tie = i < nCompleted && sl.cell()[sl.completed()[i]].sc[0] == best; nTies += __popcll(grp_ballot<GW>(tie)); }
         u32 sd = seed;
         int selectedIndex = glibc_rand_r(&sd) % nTies;                                      // Utilities.cpp:922-927
         // the tie with exactly `selectedIndex` ties before it in "x/z" string order
@@ -803,11 +805,11 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
             int i = i0 + gl;
             if(i < nCompleted) {
                 int s = sl.completed()[i];
-                if(sl.cell_sc()[4 * s + 0] == best) {
-                    u64 k = sl.cell_key()[s]; int rank = 0;
+                if(sl.cell()[s].sc[0] == best) {
+                    u64 k = sl.cell()[s].key; int rank = 0;
                     if(nTies > 1) {
                         int kz = key_node(k) - G.level_off[key_x(k)];
-                        for(int u = 0; u < nCompleted; u++) { int su = sl.completed()[u]; if(su != s && sl.cell_sc()[4 * su + 0] == best) { u64 ku = sl.cell_key()[su];
+                        for(int u = 0; u < nCompleted; u++) { int su = sl.completed()[u]; if(su != s && sl.cell()[su].sc[0] == best) { u64 ku = sl.cell()[su].key;
                             if(xz_less(key_x(ku), key_node(ku) - G.level_off[key_x(ku)], key_x(k), kz)) rank++; } }
                     }
                     if(rank == selectedIndex) found = s;
@@ -816,10 +818,10 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
         }
         endSlot = grp_max_i32<GW>(found); endScore = best;
     } else if(curMax > 0) {
-        endSlot = firstMaxSlot; endScore = sl.cell_sc()[4 * firstMaxSlot + 0];
+        endSlot = firstMaxSlot; endScore = sl.cell()[firstMaxSlot].sc[0];
     }
     if(endSlot < 0) return PH_DONE;                                                          // no extension (have = 0)
-    u64 ek = sl.cell_key()[endSlot];
+    u64 ek = sl.cell()[endSlot].key;
     const int yEnd = key_y(ek);
     if(gl == 0) {
         st.endSlot = endSlot; st.endScore = endScore;
@@ -846,11 +848,11 @@ __device__ inline int dp_backtrace(DpLdsT<C>& S, const DpSlabT<C>& sl, int maxSt
         int done = 0;
         for(int it = 0; it < maxSteps; it++) {
             if(!((x != startLevel || y != start_seq) && nSteps < C::STEPS && guardSteps++ < 4 * C::STEPS)) { done = 1; break; }
-            u64 b = sl.cell_bt()[m * C::CELLS + slot];
+            u32 b = sl.cell()[slot].bt[m];
             int kind = bt_kind(b);
             int prev = bt_prev(b);
             int px = 0;
-            if(kind == K_JUMP) px = key_x(sl.cell_key()[prev]);
+            if(kind == K_JUMP) px = key_x(sl.cell()[prev].key);
             if(kind != K_HOP) {
                 int len = 1;
                 if(kind == K_JUMP) len = px > x ? px - x : x - px;
@@ -901,12 +903,12 @@ __device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
     int base = 0;
     for(int s0 = 0; s0 < nSteps; s0 += GW) {
         int s = s0 + gl; bool act = s < nSteps;
-        u64 b = act ? sl.step_bt()[s] : 0; u64 xy = act ? sl.step_xy()[s] : 0;
+        u32 b = act ? sl.step_bt()[s] : 0; u64 xy = act ? sl.step_xy()[s] : 0;
         int kind = bt_kind(b);
         // resolve the graph object behind the push index j: edge j of the previous cell's node, or entry j of its jump table
         int pnode = 0, robj = -1;
         if(act && kind != K_GGAP) {
-            u64 pkey = sl.cell_key()[bt_prev(b)]; pnode = key_node(pkey);
+            u64 pkey = sl.cell()[bt_prev(b)].key; pnode = key_node(pkey);
             int j = bt_edge(b);
             if(kind == K_JUMP) robj = (fwd ? G.jf_path : G.jb_path)[(fwd ? G.jf_off : G.jb_off)[pnode] + j];
             else robj = fwd ? G.out_eid[G.out_off[pnode] + j] : G.in_eid[G.in_off[pnode] + j];
