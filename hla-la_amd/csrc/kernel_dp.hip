@@ -668,8 +668,10 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             if(grp_ballot<GW>(eq)) anyEqDiff = true;
             int wm = grp_max_i32<GW>(keep ? Dv : DP_NEG);
             if(wm > itMaxNew) { itMaxNew = wm; itMaxKey = ~0ull; }
-            u64 mn = grp_min_u64<GW>((keep && Dv == itMaxNew) ? key : ~0ull);
-            if(mn < itMaxKey) itMaxKey = mn;
+            if(itMaxNew > curMax0) {       // the first cell of a NEW maximum is only needed when the maximum moves (group-uniform test)
+                u64 mn = grp_min_u64<GW>((keep && Dv == itMaxNew) ? key : ~0ull);
+                if(mn < itMaxKey) itMaxKey = mn;
+            }
             // stash for the filter phase: [0] = slot (or ~0 if dropped), [1] = merged D | GG<<16, [2] = merged SG
             if(act) {
                 S.hbest[0][h] = keep ? (typename C::Best)(u32)slot : (typename C::Best)0xFFFFFFFFu;
@@ -710,9 +712,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
 
     DP_TQ(1);
     // ================= filter + sort, :1076-1105 ======================================
-    int mx = DP_NEG;
-    for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); mx = max(mx, v); } }
-    mx = grp_max_i32<GW>(mx);
+    int mx = itMaxNew;          // without merges the merged D of a kept target is its new D
+    if(slow) {
+        mx = DP_NEG;
+        for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); mx = max(mx, v); } }
+        mx = grp_max_i32<GW>(mx);
+    }
     int nNew = 0;
     if(C::WCAP <= GW) {
         // survivors are first compacted into the new frontier buffer in target-list order, then every survivor counts the
