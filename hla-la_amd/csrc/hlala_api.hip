@@ -460,15 +460,15 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
         int rc = check_launch(c, "k_dp_items"); if(rc) return rc;
         // every DP item first runs in the 16-lane class; the item count lives on the device, idle groups leave at once
         HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
-        hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, c->params.rng_seed);
+        hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
         rc = check_launch(c, "k_dp<tiny>"); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
         // items that outgrew it: two DPs per wave, then one wave per DP, then the large-capacity class (one block per CU)
-        hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, c->params.rng_seed);
+        hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
         rc = check_launch(c, "k_dp<mid>"); if(rc) return rc;
-        hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
         rc = check_launch(c, "k_dp<small>"); if(rc) return rc;
-        hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed);
+        hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
         rc = check_launch(c, "k_dp<large>"); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[8], c->stream));
         int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
@@ -589,7 +589,7 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
     if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]); } }
-    { int wc[32]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[12] + wc[14]; out->n_dp_retried_large = wc[20] + wc[22]; }
+    { int wc[32]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[12] + wc[14] + wc[16] + wc[18] + wc[20] + wc[22]; out->n_dp_retried_large = wc[20] + wc[22]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

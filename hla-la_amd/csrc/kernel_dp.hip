@@ -58,6 +58,7 @@ struct DpState {
     u32 cellsEvaluated;
     int endSlot, endScore, nSteps, nCols;
     int have, sb, se, err;
+    int needTier;                                         // capacity failure: first tier whose class can hold what overflowed (0 = the next one)
 };
 
 template <bool SMALL> struct TlistT { typedef unsigned short type; };
@@ -308,6 +309,10 @@ __device__ inline bool xz_less(int x1, int z1, int x2, int z2)
 // one DP item as prepared by k_dp_items (32 bytes)
 struct __align__(16) DpItem { int item, rOff, seqLen, start_seq, startLevel, startNode, pad0, pad1; };
 
+// first tier (1 = DpMid, 2 = DpSmall, 3 = DpLarge) whose class holds a frontier of n cells / a target set of n cells
+__device__ __forceinline__ int tier_for_frontier(int n) { return n <= DpMid::WCAP ? 1 : (n <= DpSmall::WCAP ? 2 : 3); }
+__device__ __forceinline__ int tier_for_targets(int n) { return n <= (DpMid::HC * 3) / 4 ? 1 : (n <= (DpSmall::HC * 3) / 4 ? 2 : 3); }
+
 #define DP_FAIL(code) do { if(gl == 0 && S.err == 0) S.err = (code); } while(0)
 
 template <class C>
@@ -326,7 +331,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.curMax = 0; st.firstMaxSlot = 0; st.lastInc = 0; st.earlyInit = 0; st.itersRun = 0;
         st.cellsEvaluated = 0;
         st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
-        st.have = 0; st.sb = 0; st.se = -1; st.err = 0;
+        st.have = 0; st.sb = 0; st.se = -1; st.err = 0; st.needTier = 0;
         S.err = 0;
         CellRec c0; c0.key = mk_key(it.startLevel, it.start_seq, it.startNode);
         c0.sc[0] = 0; c0.sc[1] = (short)DP_NEG; c0.sc[2] = (short)DP_NEG; c0.sc[3] = 0; c0.bt[0] = 0; c0.bt[1] = 0; c0.bt[2] = 0; c0.pad = 0;
@@ -342,7 +347,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
 // returnGlobalScore = false, preferSequenceCompleAlignments = true, empty blockedPathsTable,
 // diagonal_stop_threshold = -16 (the only configuration extendSeedChain uses, :229-241, :281-293).
 template <class C>
-__device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, const uint8_t* readBases, const bool fwd, int& edgesAcc)
+__device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, const int4* nrec, const uint8_t* readBases, const bool fwd, int& edgesAcc)
 {
     constexpr int GW = C::GW;
     const int gl = grp_lane<GW>();
@@ -382,7 +387,6 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     // execute the pushes is irrelevant.
     const int* eoff = fwd ? G.out_off : G.in_off; const int* eto = fwd ? G.out_to : G.in_from; const uint8_t* elab = fwd ? G.out_label : G.in_label;
     const int* joff = fwd ? G.jf_off : G.jb_off; const int* jnode = fwd ? G.jf_node : G.jb_node; const int* jlvl = fwd ? G.jf_lvl : G.jb_lvl;
-    const int4* nrec = fwd ? G.nrec_out : G.nrec_in;
     int edges = 0;      // (the direction is wave-uniform: these are scalar selects)
     const int nMax = n1 > n2 ? n1 : n2;
     for(int i = gl; i < nMax; i += GW) {
@@ -494,7 +498,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     }
     WSYNC();
     DP_TQ(0);
-    if(nT > (C::HC * 3) / 4 || guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
+    if(nT > (C::HC * 3) / 4 || guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; if(nT > (C::HC * 3) / 4) st.needTier = tier_for_targets(nT); } WSYNC(); return PH_DONE; }
 
     // ================= evaluate =====================================================
     // (the part of the DP state that only this phase needs is read here, not at the top: shorter live ranges)
@@ -734,7 +738,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             }
             nNew += __popcll(m);
         }
-        if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
+        if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; st.needTier = tier_for_frontier(nNew); } WSYNC(); return PH_DONE; }
         WSYNC();
         if(nNew > 1) {
             const bool act = gl < nNew;
@@ -767,7 +771,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             }
             nNew += __popcll(grp_ballot<GW>(pass));
         }
-        if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
+        if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; st.needTier = tier_for_frontier(nNew); } WSYNC(); return PH_DONE; }
     }
     WSYNC();
     // reset the hash entries used by this iteration
@@ -1009,7 +1013,10 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
 // TIER k > 0: items that outgrew the class of tier k-1 (retry list k).
 template <class C, int TIER>
 __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items,
-                                                                    char* slabs, size_t slabBytes, u32 rng_seed)
+                                                        char* slabs, size_t slabBytes, u32 rng_seed,
+                                                        // the arrays of the inner loop are passed as kernel arguments: pointers loaded from the descriptors are generic
+                                                        // (flat_load, which also ties up the LDS counter), kernel-argument pointers are known to be global
+                                                        const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBasesArg)
 {
     constexpr int GW = C::GW;
     constexpr int NG = 64 / GW;
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
     const int g = (int)((threadIdx.x & 63) / GW);
     DpLdsT<C>& S = SS[g];
     DpSlabT<C> sl; sl.base = slabs + ((size_t)blockIdx.x * NG + g) * slabBytes;
-    const uint8_t* readBases = B.read_bases;
+    const uint8_t* readBases = readBasesArg;
 
     if(gl == 0) { S.accCalls = 0; S.accIters = 0; S.accCells = 0; S.accEdges = 0; }
 #ifdef HLALA_DP_TIMING
@@ -1073,7 +1080,9 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
                     const DpState& st = S.st;
                     const bool capacity = st.err != 0 && st.err > -1000000;
                     if(capacity && TIER < 3) {
-                        int* cnt = &B.work_counter[12 + 4 * TIER + 2 * dirPass]; int* lst = B.retry_list + (size_t)(2 * TIER + dirPass) * (size_t)B.n_chains;
+                        // next tier, or straight to the first tier whose class holds what overflowed (no point in failing again on the way)
+                        int to = TIER + 1; if(st.needTier > to) to = st.needTier; if(to > 3) to = 3;
+                        int* cnt = &B.work_counter[12 + 4 * (to - 1) + 2 * dirPass]; int* lst = B.retry_list + (size_t)(2 * (to - 1) + dirPass) * (size_t)B.n_chains;
                         int q = atomicAdd(cnt, 1); lst[q] = st.itemIdx;
                     } else {
                         const int item = st.item;
@@ -1091,7 +1100,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
             DP_T(3);
             if(phase == PH_SELECT) phase = dp_select<C>(S, sl, G, rng_seed, fwd);
             DP_T(4);
-            if(phase == PH_RUN) phase = dp_iterate<C>(S, sl, G, readBases, fwd, edgesAcc);
+            if(phase == PH_RUN) phase = dp_iterate<C>(S, sl, G, fwd ? nrecOut : nrecIn, readBases, fwd, edgesAcc);
             DP_T(5);
         }
     }

@@ -233,7 +233,7 @@ typedef struct {
     int64_t n_edges_touched;      /* CSR edge records read by stages A and B      */
     int64_t n_errors;             /* chains with status < 0                       */
     float   ms_extend_retry;      /* part of ms_extend spent re-running DP calls in the 64-lane classes */
-    int32_t n_chains_retried;     /* DP calls that outgrew the 16-lane class (re-run one wave per call)  */
+    int32_t n_chains_retried;     /* re-runs of DP calls in a wider capacity class (a call can be re-run twice) */
     float   ms_dp_main;           /* part of ms_extend spent in the 16-lane DP kernel (k_dp<DpTiny>)      */
     int32_t n_dp_retried_large;   /* DP calls that also outgrew the 64-lane small class                  */
 } hlala_batch_stats;
