@@ -544,27 +544,38 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
     DevBatch& B = b->B;
     size_t np = (size_t)B.n_pairs, nr = (size_t)B.n_reads, stride = (size_t)B.stride;
     int rc = 0;
-    std::vector<int> best(nr);
-    if((rc = dl(c, best.data(), B.best_chain, nr))) return rc;
+    if((rc = dl(c, o->best_chain, B.best_chain, nr))) return rc;
     if((rc = dl(c, o->pair_status, B.pair_status, np))) return rc; if((rc = dl(c, o->n_combinations, B.n_comb, np))) return rc;
     if((rc = dl(c, o->pair_ll, B.pair_ll, np))) return rc; if((rc = dl(c, o->pair_mapq, B.pair_mapq, np))) return rc;
     if((rc = dl(c, o->mate_mapq, B.mate_mapq, nr))) return rc; if((rc = dl(c, o->strands_valid, B.strands_valid, np))) return rc;
     if((rc = dl(c, o->col_mapq, B.sel_mapq, nr * stride))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if(o->best_chain) memcpy(o->best_chain, best.data(), nr * 4);
-    // columns of the selected chains: gathered from the chain-level arrays
-    for(size_t r = 0; r < nr; r++) {
-        int ch = best[r];
-        int n = 0;
-        if(ch >= 0 && ch < B.n_chains) HIP_TRY(c, hipMemcpy(&n, B.ext_ncols + ch, 4, hipMemcpyDeviceToHost));
-        if(o->n_cols) o->n_cols[r] = n;
-        if(n <= 0) continue;
-        size_t so = (size_t)ch * stride, dofs = r * stride;
-        if(o->col_level) HIP_TRY(c, hipMemcpy(o->col_level + dofs, B.ext_level + so, (size_t)n * 4, hipMemcpyDeviceToHost));
-        if(o->col_edge) HIP_TRY(c, hipMemcpy(o->col_edge + dofs, B.ext_edge + so, (size_t)n * 4, hipMemcpyDeviceToHost));
-        if(o->col_gchar) HIP_TRY(c, hipMemcpy(o->col_gchar + dofs, B.ext_g + so, (size_t)n, hipMemcpyDeviceToHost));
-        if(o->col_schar) HIP_TRY(c, hipMemcpy(o->col_schar + dofs, B.ext_s + so, (size_t)n, hipMemcpyDeviceToHost));
-        if(o->col_fromseed) HIP_TRY(c, hipMemcpy(o->col_fromseed + dofs, B.ext_fromseed + so, (size_t)n, hipMemcpyDeviceToHost));
+    // columns of the selected chains: gathered on the device into read-major staging rows, one bulk copy per array and chunk
+    // (columns beyond n_cols come back as zero)
+    const bool wantCols = o->n_cols || o->col_level || o->col_edge || o->col_gchar || o->col_schar || o->col_fromseed;
+    if(wantCols && nr > 0) {
+        const size_t CH = nr < 65536 ? nr : 65536;
+        std::vector<void*> tmp;
+        auto done = [&](int r_) { for(void* p : tmp) if(p) (void)hipFree(p); return r_; };
+        int* dN = nullptr; int* dL = nullptr; int* dE = nullptr; uint8_t* dG = nullptr; uint8_t* dS = nullptr; uint8_t* dF = nullptr;
+        if((rc = dev_alloc(c, tmp, CH, &dN, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dL, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dE, false)) ||
+           (rc = dev_alloc(c, tmp, CH * stride, &dG, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dS, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dF, false))) return done(rc);
+        for(size_t r0 = 0; r0 < nr; r0 += CH) {
+            const size_t rows = nr - r0 < CH ? nr - r0 : CH;
+            hipLaunchKernelGGL(k_gather_selected, dim3((unsigned)rows), dim3(128), 0, c->stream, b->dB, (int)r0, (int)rows, dN, dL, dE, dG, dS, dF);
+            if((rc = check_launch(c, "k_gather_selected"))) return done(rc);
+            const size_t cols = rows * stride, o0 = r0 * stride;
+            hipError_t e = hipSuccess;
+            if(o->n_cols && e == hipSuccess) e = hipMemcpyAsync(o->n_cols + r0, dN, rows * 4, hipMemcpyDeviceToHost, c->stream);
+            if(o->col_level && e == hipSuccess) e = hipMemcpyAsync(o->col_level + o0, dL, cols * 4, hipMemcpyDeviceToHost, c->stream);
+            if(o->col_edge && e == hipSuccess) e = hipMemcpyAsync(o->col_edge + o0, dE, cols * 4, hipMemcpyDeviceToHost, c->stream);
+            if(o->col_gchar && e == hipSuccess) e = hipMemcpyAsync(o->col_gchar + o0, dG, cols, hipMemcpyDeviceToHost, c->stream);
+            if(o->col_schar && e == hipSuccess) e = hipMemcpyAsync(o->col_schar + o0, dS, cols, hipMemcpyDeviceToHost, c->stream);
+            if(o->col_fromseed && e == hipSuccess) e = hipMemcpyAsync(o->col_fromseed + o0, dF, cols, hipMemcpyDeviceToHost, c->stream);
+            if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if(e != hipSuccess) { c->err = std::string("hlala_batch_get_pairs: ") + hipGetErrorString(e); return done(HLALA_E_DEVICE); }
+        }
+        done(0);
     }
     return HLALA_OK;
 }

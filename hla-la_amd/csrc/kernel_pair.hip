@@ -216,6 +216,29 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
     }
 }
 
+// Columns of the selected chains, gathered into read-major staging rows for one bulk copy per array
+// (hlala_batch_get_pairs): read r0 + blockIdx.x -> row blockIdx.x; columns beyond n_cols are zero.
+__global__ void k_gather_selected(const DevBatch* __restrict__ Bp, int r0, int nRows, int* __restrict__ oN, int* __restrict__ oLevel, int* __restrict__ oEdge,
+                                  uint8_t* __restrict__ oG, uint8_t* __restrict__ oS, uint8_t* __restrict__ oFs)
+{
+    const DevBatch& B = *Bp;
+    const int row = blockIdx.x;
+    if(row >= nRows) return;
+    const int r = r0 + row;
+    const int stride = B.stride;
+    const int ch = B.best_chain[r];
+    int n = 0;
+    if(ch >= 0 && ch < B.n_chains) n = B.ext_ncols[ch];
+    if(n < 0) n = 0;
+    if(threadIdx.x == 0) oN[row] = n;
+    const size_t so = (size_t)(ch >= 0 ? ch : 0) * stride, dofs = (size_t)row * stride;
+    for(int j = threadIdx.x; j < stride; j += blockDim.x) {
+        const bool in = j < n;
+        oLevel[dofs + j] = in ? B.ext_level[so + j] : 0; oEdge[dofs + j] = in ? B.ext_edge[so + j] : 0;
+        oG[dofs + j] = in ? B.ext_g[so + j] : 0; oS[dofs + j] = in ? B.ext_s[so + j] : 0; oFs[dofs + j] = in ? B.ext_fromseed[so + j] : 0;
+    }
+}
+
 __global__ void k_export_pairs(const DevBatch* __restrict__ Bp, double* out)
 {
     const DevBatch& B = *Bp;

@@ -170,7 +170,8 @@ typedef struct {
 } hlala_chains_out;
 
 /* Pair-level results (mapper::reads::verboseSeedChainPair, verboseSeedChain.h:318-346):
- * the selected chain of each mate with mapping qualities.                                   */
+ * the selected chain of each mate with mapping qualities.  Any pointer may be NULL (that array is then not
+ * transferred); of the column arrays only the first n_cols entries of a row are meaningful, the rest come back zero. */
 typedef struct {
     int32_t* pair_status;   /* [n] 0 ok, <0: a chain of the pair hit an HLALA_CHAIN_ERR_*    */
     int32_t* best_chain;    /* [2n] absolute chain index selected for each mate              */
