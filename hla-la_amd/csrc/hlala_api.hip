@@ -3,7 +3,9 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hlala_gpu.h"
@@ -40,6 +42,11 @@ struct hlala_ctx {
     long long* d_contig_off = nullptr; uint8_t* d_contig_seq = nullptr; int* d_contig_level = nullptr;
     int n_contigs = 0; std::vector<long long> contig_off;
     std::vector<void*> allocs;
+    // Device buffers of destroyed batches are kept for the next batch (hipMalloc of the ~35 GB of column arrays of a 1 M-pair batch
+    // costs 0.6-1.1 s): block sizes by pointer, free blocks by size.
+    std::unordered_map<void*, size_t> block_bytes;
+    std::multimap<size_t, void*> pool;
+    size_t pool_bytes = 0;
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
@@ -60,13 +67,44 @@ struct hlala_batch {
 
 #define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HLALA_E_DEVICE; } } while(0)
 
+// hipMalloc, or a block of a destroyed batch that is large enough and wastes at most a quarter
+static int pool_malloc(hlala_ctx* c, void** out, size_t bytes)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = c->pool.lower_bound(bytes);
+    if(it != c->pool.end() && it->first <= bytes + bytes / 4 + 4096) {
+        *out = it->second; c->pool_bytes -= it->first; c->pool.erase(it);
+        return 0;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if(e != hipSuccess && !c->pool.empty()) {       // out of memory with blocks parked in the pool: release them and retry
+        for(auto& kv : c->pool) { c->block_bytes.erase(kv.second); (void)hipFree(kv.second); }
+        c->pool.clear(); c->pool_bytes = 0;
+        (void)hipGetLastError();
+        e = hipMalloc(&p, bytes);
+    }
+    if(e != hipSuccess) { c->err = std::string("hipMalloc: ") + hipGetErrorString(e); return HLALA_E_DEVICE; }
+    c->block_bytes[p] = bytes;
+    *out = p;
+    return 0;
+}
+static void pool_release(hlala_ctx* c, void* p)
+{
+    if(!p) return;
+    auto it = c->block_bytes.find(p);
+    if(it == c->block_bytes.end()) { (void)hipFree(p); return; }
+    if(c->pool_bytes + it->second > ((size_t)96 << 30)) { c->block_bytes.erase(it); (void)hipFree(p); return; }      // keep at most 96 GB parked
+    c->pool.emplace(it->second, p); c->pool_bytes += it->second;
+}
+
 template <class T>
 static int dev_upload(hlala_ctx* c, std::vector<void*>& allocs, const T* host, size_t n, T** out)
 {
     *out = nullptr;
     size_t bytes = (n ? n : 1) * sizeof(T);
     void* p = nullptr;
-    HIP_TRY(c, hipMalloc(&p, bytes));
+    { int rc_ = pool_malloc(c, &p, bytes); if(rc_) return rc_; }
     allocs.push_back(p);
     if(n && host) HIP_TRY(c, hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     *out = (T*)p;
@@ -78,7 +116,7 @@ static int dev_alloc(hlala_ctx* c, std::vector<void*>& allocs, size_t n, T** out
     *out = nullptr;
     size_t bytes = (n ? n : 1) * sizeof(T);
     void* p = nullptr;
-    HIP_TRY(c, hipMalloc(&p, bytes));
+    { int rc_ = pool_malloc(c, &p, bytes); if(rc_) return rc_; }
     allocs.push_back(p);
     if(zero) HIP_TRY(c, hipMemsetAsync(p, 0, bytes, c->stream));
     *out = (T*)p;
@@ -264,6 +302,7 @@ void hlala_destroy(hlala_ctx* c)
 {
     if(!c) return;
     for(void* p : c->allocs) if(p) (void)hipFree(p);
+    for(auto& kv : c->pool) (void)hipFree(kv.second);
     for(int i = 0; i < 9; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
@@ -413,7 +452,11 @@ int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_
 void hlala_batch_destroy(hlala_batch* b)
 {
     if(!b) return;
-    for(void* p : b->allocs) if(p) (void)hipFree(p);
+    hlala_ctx* c = b->ctx;
+    if(c) {
+        (void)hipStreamSynchronize(c->stream);       // nothing of this batch may still be running when its buffers are handed to the next one
+        for(void* p : b->allocs) pool_release(c, p);
+    } else for(void* p : b->allocs) if(p) (void)hipFree(p);
     delete b;
 }
 

@@ -193,6 +193,8 @@ typedef struct {
 int  hlala_batch_create(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** out);
 /* Upload seed chains directly (stage A is then not available on this batch).                */
 int  hlala_batch_create_from_seeds(hlala_ctx* ctx, const hlala_seeds_in* in, hlala_batch** out);
+/* Destroy batches before their context.  The device buffers are parked in the context and reused by the next batch
+ * of similar size (allocating the column arrays of a 1 M-pair batch costs about a second otherwise).                 */
 void hlala_batch_destroy(hlala_batch* b);
 
 /* Stage A -- processBAM::alignment2Chain (mapper/processBAM.cpp:3019-3127) for every chain that
