@@ -176,6 +176,9 @@ def load_library(path: str | None = None):
     lib.hlala_batch_get_pairs.argtypes = [vp, vp, C.POINTER(PairsOut)]
     lib.hlala_batch_get_stats.argtypes = [vp, vp, C.POINTER(BatchStats)]
     lib.hlala_batch_export_pair_records.argtypes = [vp, vp, vp]
+    lib.hlala_set_gene_intervals.argtypes = [vp, C.c_int32, c_i32p, c_i32p]
+    lib.hlala_postprocess_pairs.argtypes = [vp, vp, c_u8p]
+    lib.hlala_get_coverage.argtypes = [vp, c_i32p, C.c_int]
     lib.hlala_exon_loglik.argtypes = [vp, C.POINTER(ExonIn), c_f64p, c_i32p]
     lib.hlala_pair_loglik.argtypes = [vp, c_f64p, c_i32p, C.c_int32, C.c_int32, c_f64p, c_f64p, c_f64p]
     lib.hlala_kat_phred.argtypes = [vp, C.c_int, c_f64p, c_u8p, c_u8p, c_f64p]
@@ -192,7 +195,7 @@ EXPORTED_SYMBOLS = [
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
     "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
-    "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
+    "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
     "hlala_kat_rand_r", "hlala_abi_sizeof",
 ]
 
@@ -270,6 +273,20 @@ class Context:
                                                *[o.ctypes.data_as(c_f64p) for o in out]), "hlala_pair_loglik")
         return out
 
+    def set_gene_intervals(self, first_level, last_level):
+        """HLATyper::interestingLevels (graphgene_levelBoundaries, hla/HLATyper.cpp:241-252)."""
+        f = np.ascontiguousarray(first_level, np.int32); l = np.ascontiguousarray(last_level, np.int32)
+        assert f.shape == l.shape
+        self._check(self.lib.hlala_set_gene_intervals(self.h, len(f), f.ctypes.data_as(c_i32p), l.ctypes.data_as(c_i32p)), "hlala_set_gene_intervals")
+
+    def coverage(self, reset=False):
+        """bases_per_level accumulated by Batch.postprocess() over all batches of this context (reads_per_level.txt)."""
+        info = GraphInfo()
+        self._check(self.lib.hlala_graph_get_info(self.h, C.byref(info)), "hlala_graph_get_info")
+        out = np.zeros(max(1, info.n_levels - 1), np.int32)
+        self._check(self.lib.hlala_get_coverage(self.h, out.ctypes.data_as(c_i32p), int(reset)), "hlala_get_coverage")
+        return out
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.hlala_destroy(self.h)
@@ -312,6 +329,12 @@ class Batch:
         """Write 8 doubles per pair into a device buffer (e.g. a torch tensor's data_ptr())."""
         self.ctx._check(self.ctx.lib.hlala_batch_export_pair_records(self.ctx.h, self.b, C.c_void_p(device_ptr)),
                         "hlala_batch_export_pair_records")
+
+    def postprocess(self):
+        """Per-pair post-processing (processBAM.cpp:2411-2446): adds to the context's coverage counters, returns includeInHLA per pair."""
+        inc = np.zeros(self.n_pairs, np.uint8)
+        self.ctx._check(self.ctx.lib.hlala_postprocess_pairs(self.ctx.h, self.b, inc.ctypes.data_as(c_u8p)), "hlala_postprocess_pairs")
+        return inc
 
     def stats(self) -> BatchStats:
         st = BatchStats()

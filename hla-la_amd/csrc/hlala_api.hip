@@ -53,6 +53,8 @@ struct hlala_ctx {
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     hipEvent_t ev[9]{};           // start/end per stage; [7] / [6] / [8] = before DpTiny / after DpTiny / after the retry classes
     int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
+    // per-pair post-processing: coverage counters [L-1] and gene intervals
+    int* d_cov = nullptr; int n_cov = 0; int* d_gene_first = nullptr; int* d_gene_last = nullptr; int n_genes = 0;
     std::string err;
 };
 
@@ -620,6 +622,55 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
         }
         done(0);
     }
+    return HLALA_OK;
+}
+
+int hlala_set_gene_intervals(hlala_ctx* c, int32_t n, const int32_t* first_level, const int32_t* last_level)
+{
+    if(!c || n < 0 || (n > 0 && (!first_level || !last_level))) return HLALA_E_ARG;
+    for(int i = 0; i < n; i++) if(first_level[i] < 0 || last_level[i] < first_level[i]) { c->err = "gene interval with first > last or negative level"; return HLALA_E_ARG; }
+    c->n_genes = 0;
+    if(n > 0) {
+        int rc = dev_upload(c, c->allocs, first_level, (size_t)n, &c->d_gene_first); if(rc) return rc;
+        rc = dev_upload(c, c->allocs, last_level, (size_t)n, &c->d_gene_last); if(rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->n_genes = n;
+    return HLALA_OK;
+}
+
+int hlala_postprocess_pairs(hlala_ctx* c, hlala_batch* b, uint8_t* include_in_hla)
+{
+    if(!c || !b) return HLALA_E_ARG;
+    if(!(b->staged & 4)) { c->err = "hlala_postprocess_pairs before hlala_pair_chains"; return HLALA_E_STATE; }
+    DevBatch& B = b->B;
+    if(!c->d_cov) {
+        c->n_cov = c->F.L > 1 ? c->F.L - 1 : 1;
+        int rc = dev_alloc(c, c->allocs, (size_t)c->n_cov, &c->d_cov, true); if(rc) return rc;
+    }
+    if(B.n_pairs <= 0) return HLALA_OK;
+    uint8_t* dInc = nullptr; std::vector<void*> tmp;
+    auto done = [&](int r_) { for(void* p : tmp) if(p) (void)hipFree(p); return r_; };
+    if(include_in_hla) { int rc = dev_alloc(c, tmp, (size_t)B.n_pairs, &dInc, false); if(rc) return done(rc); }
+    hipError_t e = hipMemsetAsync(B.work_counter + 11, 0, sizeof(int), c->stream);
+    if(e != hipSuccess) { c->err = hipGetErrorString(e); return done(HLALA_E_DEVICE); }
+    int grid = B.n_pairs < c->stitch_grid ? B.n_pairs : c->stitch_grid;
+    hipLaunchKernelGGL(k_post_pairs, dim3(grid), dim3(64), 0, c->stream, b->dB, c->d_cov, c->n_cov, c->d_gene_first, c->d_gene_last, c->n_genes, dInc);
+    int rc = check_launch(c, "k_post_pairs"); if(rc) return done(rc);
+    if(include_in_hla) e = hipMemcpyAsync(include_in_hla, dInc, (size_t)B.n_pairs, hipMemcpyDeviceToHost, c->stream);
+    if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if(e != hipSuccess) { c->err = std::string("hlala_postprocess_pairs: ") + hipGetErrorString(e); return done(HLALA_E_DEVICE); }
+    return done(HLALA_OK);
+}
+
+int hlala_get_coverage(hlala_ctx* c, int32_t* bases_per_level, int reset)
+{
+    if(!c || !bases_per_level) return HLALA_E_ARG;
+    const int n = c->F.L > 1 ? c->F.L - 1 : 1;
+    if(!c->d_cov) { memset(bases_per_level, 0, (size_t)n * 4); return HLALA_OK; }
+    HIP_TRY(c, hipMemcpyAsync(bases_per_level, c->d_cov, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if(reset) HIP_TRY(c, hipMemsetAsync(c->d_cov, 0, (size_t)n * 4, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HLALA_OK;
 }
 

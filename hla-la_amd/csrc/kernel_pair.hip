@@ -216,6 +216,46 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
     }
 }
 
+// Per-pair post-processing (processBAM.cpp:2411-2446): coverage counters over the columns of both selected chains and the
+// includeInHLA flag (closed-interval overlap of [first level, last level] of a mate with a gene interval).  One wave per pair.
+__global__ __launch_bounds__(64) void k_post_pairs(const DevBatch* __restrict__ Bp, int* __restrict__ cov, int nCov, const int* __restrict__ geneFirst,
+                                                   const int* __restrict__ geneLast, int nGenes, uint8_t* __restrict__ include)
+{
+    const DevBatch& B = *Bp;
+    const int lane = lane_id();
+    const int stride = B.stride;
+    constexpr int CHUNK = 8;
+    for(;;) {
+        int p0 = 0;
+        if(lane == 0) p0 = atomicAdd(&B.work_counter[11], CHUNK);
+        p0 = __builtin_amdgcn_readfirstlane(p0);
+        if(p0 >= B.n_pairs) break;
+        const int pEnd = min(p0 + CHUNK, B.n_pairs);
+        for(int p = p0; p < pEnd; p++) {
+            bool inc = false;
+            if(uni(B.pair_status[p]) == 0) {
+                for(int m = 0; m < 2; m++) {
+                    const int ch = uni(B.best_chain[2 * p + m]);
+                    if(ch < 0 || ch >= B.n_chains) continue;
+                    const int n = uni(B.ext_ncols[ch]);
+                    const size_t so = (size_t)ch * stride;
+                    for(int j = lane; j < n; j += 64) {
+                        const int lv = B.ext_level[so + j];
+                        if(lv != -1 && B.ext_g[so + j] != '_' && lv >= 0 && lv < nCov) atomicAdd(&cov[lv], 1);          // :2414-2418
+                    }
+                    const int first = uni(B.ext_firstlast[4 * ch + 0]), last = uni(B.ext_firstlast[4 * ch + 2]);          // alignment_firstLevel / _lastLevel
+                    if(first != -1) {
+                        bool hit = false;
+                        for(int g = lane; g < nGenes; g += 64) hit = hit || (geneLast[g] >= first && geneFirst[g] <= last);      // IntervalTree.h:166
+                        if(__ballot(hit)) inc = true;
+                    }
+                }
+            }
+            if(lane == 0 && include) include[p] = inc ? 1 : 0;
+        }
+    }
+}
+
 // Columns of the selected chains, gathered into read-major staging rows for one bulk copy per array
 // (hlala_batch_get_pairs): read r0 + blockIdx.x -> row blockIdx.x; columns beyond n_cols are zero.
 __global__ void k_gather_selected(const DevBatch* __restrict__ Bp, int r0, int nRows, int* __restrict__ oN, int* __restrict__ oLevel, int* __restrict__ oEdge,

@@ -55,3 +55,13 @@ def gather_records(local, dst: int = 0):
     if rank != dst:
         return None
     return [o[:int(s.item())] for o, s in zip(out, sizes)]
+
+
+def reduce_coverage(local, dst: int = 0):
+    """Sum the per-rank coverage counters (bases_per_level, int32[L-1]) on `dst`: the one reduction of the path
+    (the reference sums its per-thread counters the same way, processBAM.cpp:1866-1887).  `local` is a torch tensor
+    on the device the process group works on (cuda for nccl == RCCL, cpu for gloo); returns the total on dst, None elsewhere."""
+    import torch.distributed as dist
+    t = local.clone()
+    dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+    return t if dist.get_rank() == dst else None

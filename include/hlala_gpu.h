@@ -243,6 +243,21 @@ typedef struct {
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-pair post-processing of alignReads_postSeedExtraction_andStoreInto (mapper/processBAM.cpp:2411-2446).
+ *   coverage  : bases_per_level[level]++ for every column of both selected chains whose level is defined and whose graph
+ *               character is not '_' (:2411-2428); the counters live in the context and accumulate over batches
+ *               (they end up in reads_per_level.txt, processBAM.cpp:1902-1913)
+ *   includeInHLA : a mate with a defined first level overlaps one of the gene intervals
+ *               (HLATyper::intervalOverlapsWithGenes, hla/HLATyper.cpp:259-268: closed intervals, stop >= first && start <= last;
+ *               the intervals are graphgene_levelBoundaries, HLATyper.cpp:241-252)
+ * Pairs whose status is not 0 contribute nothing and are not included.
+ * ---------------------------------------------------------------------------------------- */
+int  hlala_set_gene_intervals(hlala_ctx* ctx, int32_t n_genes, const int32_t* first_level, const int32_t* last_level);
+int  hlala_postprocess_pairs(hlala_ctx* ctx, hlala_batch* b, uint8_t* include_in_hla /* [n_pairs], may be NULL */);
+/* bases_per_level[0 .. n_levels-2]; reset != 0 clears the counters afterwards */
+int  hlala_get_coverage(hlala_ctx* ctx, int32_t* bases_per_level, int reset);
+
+/* ------------------------------------------------------------------------------------------
  * HLATyper per-read log-likelihood scoring (hla/HLATyper.cpp).  One locus at a time.
  * Reads are the per-read lists of hla::oneExonPosition (hla/oneExonPosition.h:16-46) that survive the
  * HOST-side filters (mapQ_position >= 0.7, ignored alleles, ignored reads: HLATyper.cpp:2102-2121 --

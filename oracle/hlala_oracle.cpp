@@ -1446,6 +1446,41 @@ int orc_pair_loglik(const double* LL, const int32_t* mism, int C, int R, double*
 /* PRGContigAlignment2Seed over column alignments handed in as seeds_in columns WITHOUT edges
  * (the simulateBAMAlignments route of --action testAlignments2Chains / testChainExtension,
  * HLA-LA.cpp:1622-1861): seq_begin/seq_end play sequence_aligned_{start,stop}InRaw. */
+// Per-pair post-processing of alignReads_postSeedExtraction_andStoreInto (mapper/processBAM.cpp:2411-2446) on the selected
+// chains of a batch: bases_per_level counters (:2411-2428) and includeInHLA (:2430-2446) through
+// HLATyper::intervalOverlapsWithGenes (hla/HLATyper.cpp:259-268) = "some gene interval with stop >= first && start <= last"
+// (IntervalTree::findOverlapping, intervalTree/IntervalTree.h:162-180: the tree only prunes, the test is the closed one at :166).
+int orc_postprocess_pairs(int n_pairs, int stride, const int32_t* pair_status, const int32_t* n_cols /* [2n] */, const int32_t* col_level,
+                          const uint8_t* col_gchar, int n_genes, const int32_t* gene_first, const int32_t* gene_last,
+                          int n_cov, int32_t* bases_per_level /* in/out */, uint8_t* include_in_hla)
+{
+    for(int p = 0; p < n_pairs; p++) {
+        bool includeInHLA = false;
+        if(pair_status[p] == 0) {
+            for(int m = 0; m < 2; m++) {
+                const size_t r = (size_t)2 * p + m;
+                const int32_t* lv = col_level + r * stride; const uint8_t* g = col_gchar + r * stride;
+                const int n = n_cols[r];
+                for(int aI = 0; aI < n; aI++) {
+                    int level = lv[aI];
+                    if((level != -1) && (g[aI] != '_')) { if(level < 0 || level >= n_cov) return -1; bases_per_level[level]++; }
+                }
+                int firstLevel = -1, lastLevel = -1;                       // verboseSeedChain::alignment_firstLevel / alignment_lastLevel, verboseSeedChain.h:122-183
+                for(int i = 0; i < n; i++) if(lv[i] != -1) { firstLevel = lv[i]; break; }
+                for(int i = n - 1; i >= 0; i--) if(lv[i] != -1) { lastLevel = lv[i]; break; }
+                if(firstLevel != -1) {
+                    if(!(firstLevel <= lastLevel)) return -2;              // assert, :2438
+                    bool found = false;
+                    for(int gI = 0; gI < n_genes; gI++) if(gene_last[gI] >= firstLevel && gene_first[gI] <= lastLevel) found = true;
+                    includeInHLA = includeInHLA || found;
+                }
+            }
+        }
+        if(include_in_hla) include_in_hla[p] = includeInHLA ? 1 : 0;
+    }
+    return 0;
+}
+
 int orc_rethread_columns(orc_handle* h, const hlala_seeds_in* in, int restrict_gaps, hlala_chains_out* out)
 {
     try {

@@ -128,3 +128,19 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+
+def postprocess_pairs(pairs, n_pairs, stride, gene_first, gene_last, n_cov, cov=None):
+    """orc_postprocess_pairs on the `pairs` dict of Oracle.align_batch / Batch.pairs(): returns (bases_per_level, includeInHLA)."""
+    l = lib()
+    gf = np.ascontiguousarray(gene_first, np.int32); gl = np.ascontiguousarray(gene_last, np.int32)
+    cov = np.zeros(n_cov, np.int32) if cov is None else cov
+    inc = np.zeros(n_pairs, np.uint8)
+    st = np.ascontiguousarray(pairs["pair_status"], np.int32); nc = np.ascontiguousarray(pairs["n_cols"], np.int32)
+    lv = np.ascontiguousarray(pairs["col_level"], np.int32); g = np.ascontiguousarray(pairs["col_gchar"], np.uint8)
+    l.orc_postprocess_pairs.argtypes = [C.c_int, C.c_int, P.c_i32p, P.c_i32p, P.c_i32p, P.c_u8p, C.c_int, P.c_i32p, P.c_i32p, C.c_int, P.c_i32p, P.c_u8p]
+    rc = l.orc_postprocess_pairs(n_pairs, stride, st.ctypes.data_as(P.c_i32p), nc.ctypes.data_as(P.c_i32p), lv.ctypes.data_as(P.c_i32p),
+                                 g.ctypes.data_as(P.c_u8p), len(gf), gf.ctypes.data_as(P.c_i32p), gl.ctypes.data_as(P.c_i32p), n_cov,
+                                 cov.ctypes.data_as(P.c_i32p), inc.ctypes.data_as(P.c_u8p))
+    assert rc == 0, rc
+    return cov, inc

@@ -40,10 +40,19 @@ def _worker(rank, world, port, n_pairs, tmp):
     rec = _records(pr)
     rec[:, 1:3] += c0                     # chain indices back to the global numbering
     got = D.gather_records(torch.from_numpy(rec), dst=0)
+    # per-pair post-processing: the coverage counters of the shards sum to the counters of the unsharded run
+    import oracle_binding as ob
+    nlev = int(w["graph"]["n_levels"]); genes = (np.array([100, 3000], np.int32), np.array([400, 3300], np.int32))
+    cov, inc = ob.postprocess_pairs(pr, sub["n_pairs"], o.max_columns, genes[0], genes[1], nlev - 1)
+    tot = D.reduce_coverage(torch.from_numpy(cov), dst=0)
+    incs = D.gather_records(torch.from_numpy(inc.astype(np.int64)), dst=0)
     if rank == 0:
-        full = _records(Oracle(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=99).align_batch(b)["pairs"])
+        fullp = Oracle(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=99).align_batch(b)["pairs"]
+        full = _records(fullp)
         cat = torch.cat(got).numpy()
-        np.save(os.path.join(tmp, "ok.npy"), np.array([int(np.array_equal(cat, full)), cat.shape[0]]))
+        cov_full, inc_full = ob.postprocess_pairs(fullp, b["n_pairs"], o.max_columns, genes[0], genes[1], nlev - 1)
+        ok = np.array_equal(cat, full) and np.array_equal(tot.numpy(), cov_full) and np.array_equal(torch.cat(incs).numpy(), inc_full) and cov_full.sum() > 0
+        np.save(os.path.join(tmp, "ok.npy"), np.array([int(ok), cat.shape[0]]))
     dist.barrier()
     dist.destroy_process_group()
 
