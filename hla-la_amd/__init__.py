@@ -83,6 +83,11 @@ class ExonIn(C.Structure):
                 ("pos_use", c_u8p)]
 
 
+class CallOut(C.Structure):
+    _fields_ = [("first_cluster", C.c_int32), ("second_cluster", C.c_int32), ("first_marginal", C.c_double), ("second_p", C.c_double),
+                ("ll_max", C.c_double), ("max_pair", C.c_int32), ("n_sort_ties", C.c_int32)]
+
+
 class BatchStats(C.Structure):
     _fields_ = [("ms_project", C.c_float), ("ms_extend", C.c_float), ("ms_pair", C.c_float),
                 ("n_chains_extended", C.c_int64), ("n_dp_calls", C.c_int64), ("n_dp_iterations", C.c_int64),
@@ -184,6 +189,7 @@ def load_library(path: str | None = None):
     lib.hlala_kat_phred.argtypes = [vp, C.c_int, c_f64p, c_u8p, c_u8p, c_f64p]
     lib.hlala_kat_rand_r.argtypes = [vp, C.c_int, c_u32p, c_i32p]
     lib.hlala_abi_sizeof.argtypes = [C.c_char_p]
+    lib.hlala_call_locus.argtypes = [vp, C.c_int32, c_f64p, c_f64p, c_f64p, c_i32p, c_f64p, c_f64p, C.POINTER(CallOut)]
     lib.hlala_abi_sizeof.restype = C.c_int
     if path is None:
         _lib = lib
@@ -196,7 +202,7 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
-    "hlala_kat_rand_r", "hlala_abi_sizeof",
+    "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus",
 ]
 
 
@@ -272,6 +278,17 @@ class Context:
         self._check(self.lib.hlala_pair_loglik(self.h, LL.ctypes.data_as(c_f64p), mism.ctypes.data_as(c_i32p), Cn, R,
                                                *[o.ctypes.data_as(c_f64p) for o in out]), "hlala_pair_loglik")
         return out
+
+    def call_locus(self, pairLL, misAvg, misMin):
+        """The call of one locus from the all-pairs table (hlala_call_locus; hla/HLATyper.cpp:2366-2541)."""
+        a = [np.ascontiguousarray(x, np.float64) for x in (pairLL, misAvg, misMin)]
+        nP = len(a[0]); Cn = int((np.sqrt(8 * nP + 1) - 1) / 2 + 0.5)
+        assert Cn * (Cn + 1) // 2 == nP
+        order = np.zeros(nP, np.int32); pn = np.zeros(nP, np.float64); marg = np.zeros(Cn, np.float64); out = CallOut()
+        self._check(self.lib.hlala_call_locus(self.h, Cn, *[x.ctypes.data_as(c_f64p) for x in a], order.ctypes.data_as(c_i32p),
+                                              pn.ctypes.data_as(c_f64p), marg.ctypes.data_as(c_f64p), C.byref(out)), "hlala_call_locus")
+        return dict(order=order, p_normalized=pn, cluster_marginal=marg, first_cluster=out.first_cluster, second_cluster=out.second_cluster,
+                    first_marginal=out.first_marginal, second_p=out.second_p, ll_max=out.ll_max, max_pair=out.max_pair, n_sort_ties=out.n_sort_ties)
 
     def set_gene_intervals(self, first_level, last_level):
         """HLATyper::interestingLevels (graphgene_levelBoundaries, hla/HLATyper.cpp:241-252)."""

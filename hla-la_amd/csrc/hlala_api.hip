@@ -17,6 +17,7 @@
 #include "kernel_project.hip"
 #include "kernel_pair.hip"
 #include "kernel_typer.hip"
+#include "kernel_call.hip"
 
 namespace hlala {
 size_t proj_slab_bytes_host(int stride, int maxNodesPerLevel) { return proj_slab_bytes(stride, maxNodesPerLevel); }
@@ -834,13 +835,62 @@ extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uin
     return HLALA_OK;
 }
 
+extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, const double* misAvg, const double* misMin,
+                                int32_t* order, double* p_normalized, double* cluster_marginal, hlala_call_out* out)
+{
+    if(!c || C < 1 || !pairLL || !misAvg || !misMin || !out) return HLALA_E_ARG;
+    if(C > 46000) { c->err = "hlala_call_locus: more than 46000 clusters (pair index exceeds 31 bits)"; return HLALA_E_CAPACITY; }
+    const long long nP = (long long)C * (C + 1) / 2, n2 = 2 * nP;
+    std::vector<void*> tmp;
+    auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };       // scratch is parked for the next locus
+    int rc = 0;
+    double *dLL = nullptr, *dMA = nullptr, *dMM = nullptr, *dP = nullptr, *dPart = nullptr, *dScal = nullptr, *dVal = nullptr, *dVal2 = nullptr, *dMarg = nullptr;
+    u64 *dK1 = nullptr, *dK2 = nullptr, *dCK = nullptr, *dCK2 = nullptr; int *dI1 = nullptr, *dI2 = nullptr, *dC1 = nullptr, *dC2 = nullptr, *dTies = nullptr;
+    long long* dPidx = nullptr; hlala_call_out* dOut = nullptr;
+    const int NB = 1024;
+    if((rc = dev_upload(c, tmp, pairLL, (size_t)nP, &dLL)) || (rc = dev_upload(c, tmp, misAvg, (size_t)nP, &dMA)) || (rc = dev_upload(c, tmp, misMin, (size_t)nP, &dMM)) ||
+       (rc = dev_alloc(c, tmp, (size_t)nP, &dP)) || (rc = dev_alloc(c, tmp, (size_t)NB, &dPart)) || (rc = dev_alloc(c, tmp, (size_t)NB, &dPidx)) || (rc = dev_alloc(c, tmp, 4, &dScal)) ||
+       (rc = dev_alloc(c, tmp, (size_t)nP, &dK1)) || (rc = dev_alloc(c, tmp, (size_t)nP, &dK2)) || (rc = dev_alloc(c, tmp, (size_t)nP, &dI1)) || (rc = dev_alloc(c, tmp, (size_t)nP, &dI2)) ||
+       (rc = dev_alloc(c, tmp, (size_t)nP, &dC1)) || (rc = dev_alloc(c, tmp, (size_t)nP, &dC2)) || (rc = dev_alloc(c, tmp, (size_t)n2, &dCK)) || (rc = dev_alloc(c, tmp, (size_t)n2, &dCK2)) ||
+       (rc = dev_alloc(c, tmp, (size_t)n2, &dVal)) || (rc = dev_alloc(c, tmp, (size_t)n2, &dVal2)) || (rc = dev_alloc(c, tmp, (size_t)C, &dMarg)) || (rc = dev_alloc(c, tmp, 1, &dTies, true)) ||
+       (rc = dev_alloc(c, tmp, 1, &dOut))) return done(rc);
+    long long* dMaxIdx = (long long*)(dScal + 2);      // dScal[0] = LL max, dScal[1] = P sum, dScal[2..3] as one long long = index of the maximum
+    hipStream_t st = c->stream;
+    const int T = 256; const unsigned gP = (unsigned)((nP + T - 1) / T);
+    hipLaunchKernelGGL(k_call_max, dim3(NB), dim3(T), 0, st, dLL, nP, dPart, dPidx);
+    hipLaunchKernelGGL(k_call_max_final, dim3(1), dim3(1), 0, st, dPart, dPidx, NB, dScal, dMaxIdx);
+    hipLaunchKernelGGL(k_call_p, dim3(NB), dim3(T), 0, st, dLL, nP, dScal, dP, dPart);
+    hipLaunchKernelGGL(k_call_psum_final, dim3(1), dim3(1), 0, st, dPart, NB, dScal + 1);
+    hipLaunchKernelGGL(k_call_normalize, dim3(gP), dim3(T), 0, st, dP, nP, dScal + 1);
+    // order: stable sort by Mism_avg ascending, then stable sort by LL descending
+    hipLaunchKernelGGL(k_call_keys_mism, dim3(gP), dim3(T), 0, st, dMA, nP, dK1, dI1);
+    size_t cubBytes = 0, cubBytes2 = 0;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, cubBytes, dK1, dK2, dI1, dI2, (int)nP, 0, 64, st));
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, cubBytes2, dCK, dCK2, dVal, dVal2, (int)n2, 0, 64, st));
+    if(cubBytes2 > cubBytes) cubBytes = cubBytes2;
+    char* dCub = nullptr; if((rc = dev_alloc(c, tmp, cubBytes ? cubBytes : 1, &dCub))) return done(rc);
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(dCub, cubBytes, dK1, dK2, dI1, dI2, (int)nP, 0, 64, st));
+    hipLaunchKernelGGL(k_call_keys_ll, dim3(gP), dim3(T), 0, st, dLL, dI2, nP, dK1);
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(dCub, cubBytes, dK1, dK2, dI2, dI1, (int)nP, 0, 64, st));       // dI1 = order
+    // marginals in the reference's accumulation order
+    hipLaunchKernelGGL(k_call_clusters, dim3((unsigned)C), dim3(128), 0, st, (int)C, dC1, dC2);
+    hipLaunchKernelGGL(k_call_contrib, dim3(gP), dim3(T), 0, st, dI1, dC1, dC2, dP, nP, dCK, dVal, dTies, dLL, dMA);
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(dCub, cubBytes, dCK, dCK2, dVal, dVal2, (int)n2, 0, 64, st));
+    hipLaunchKernelGGL(k_call_marginals, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, dCK2, dVal2, n2, (int)C, dMarg);
+    hipLaunchKernelGGL(k_call_decide, dim3(1), dim3(64), 0, st, (int)C, dMarg, dP, dMM, dScal, dMaxIdx, dTies, dOut);
+    rc = check_launch(c, "hlala_call_locus kernels"); if(rc) return done(rc);
+    if((rc = dl(c, order, dI1, (size_t)nP)) || (rc = dl(c, p_normalized, dP, (size_t)nP)) || (rc = dl(c, cluster_marginal, dMarg, (size_t)C)) || (rc = dl(c, out, dOut, 1))) return done(rc);
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return done(HLALA_OK);
+}
+
 extern "C" int hlala_abi_sizeof(const char* name)
 {
     if(!name) return -1;
     const std::string n(name);
 #define SZ(t) if(n == #t) return (int)sizeof(t);
     SZ(hlala_graph_desc) SZ(hlala_contigs_desc) SZ(hlala_params) SZ(hlala_graph_info) SZ(hlala_batch_in) SZ(hlala_seeds_in)
-    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in)
+    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out)
 #undef SZ
     return -1;
 }

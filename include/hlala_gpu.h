@@ -283,6 +283,25 @@ int  hlala_exon_loglik(hlala_ctx* ctx, const hlala_exon_in* in, double* LL, int3
 int  hlala_pair_loglik(hlala_ctx* ctx, const double* LL, const int32_t* mism, int32_t C, int32_t R,
                        double* pairLL, double* misAvg, double* misMin);
 
+/* The call of one locus from the all-pairs table (hla/HLATyper.cpp:2366-2541).  Pair (c1 <= c2) sits at the index
+ * hlala_pair_loglik uses.  order = pair indices sorted by LL descending, Mism_avg ascending (std::sort + std::reverse, :2381-2403;
+ * the order among pairs equal in both keys is unspecified in the reference too -- n_sort_ties counts adjacent equal keys);
+ * p_normalized = exp(LL - max) / sum (:2411-2448); cluster_marginal = clusterI_overAllPairs, accumulated in `order` (:2459-2486);
+ * first = first maximum of the marginals in cluster order (findIntMapMax, Utilities.cpp:257-272, :2490); second = among the pairs that
+ * contain `first` the maximum P, ties resolved by the smallest Mism_min, then the smallest cluster (:2498-2533). */
+typedef struct {
+    int32_t first_cluster;     /* bestGuess_firstAllele.second                    */
+    int32_t second_cluster;    /* bestGuess_secondAllele.second                   */
+    double  first_marginal;    /* bestGuess_firstAllele.first                     */
+    double  second_p;          /* oneBestGuess_secondAllele.first                 */
+    double  ll_max;            /* findVectorMax(LLs_completeReads).first (:2408)  */
+    int32_t max_pair;          /* ... .second (first maximum)                     */
+    int32_t n_sort_ties;
+} hlala_call_out;
+int  hlala_call_locus(hlala_ctx* ctx, int32_t C, const double* pairLL, const double* misAvg, const double* misMin,
+                      int32_t* order /* [C(C+1)/2] or NULL */, double* p_normalized /* [C(C+1)/2] or NULL */,
+                      double* cluster_marginal /* [C] or NULL */, hlala_call_out* out);
+
 /* Known-answer helpers exported for the parity tests (device implementations of
  * Utilities::PCorrectToPhred / PhredToPCorrect, Utilities.cpp:178-203, 357-377, and of glibc
  * rand_r as used by Utilities::randomNumber_nonCritical, Utilities.cpp:922).                 */

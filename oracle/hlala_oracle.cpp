@@ -1443,6 +1443,83 @@ int orc_pair_loglik(const double* LL, const int32_t* mism, int C, int R, double*
     return 0;
 }
 
+// The call of one locus (hla/HLATyper.cpp:2366-2541) from the all-pairs table; same index convention as orc_pair_loglik
+// (LLs_clusterIs is filled c1-major, c2 >= c1, :2293-2364).  std::sort + std::reverse are the reference's own calls (:2381-2403).
+int orc_call_locus(int C, const double* pairLL, const double* misAvg, const double* misMin, int32_t* order, double* p_normalized,
+                   double* cluster_marginal, hlala_call_out* out)
+{
+    const size_t nP = (size_t)C * (C + 1) / 2;
+    if(C < 1) return -1;
+    std::vector<std::pair<unsigned int, unsigned int>> LLs_clusterIs; LLs_clusterIs.reserve(nP);
+    for(int c1 = 0; c1 < C; c1++) for(int c2 = c1; c2 < C; c2++) LLs_clusterIs.push_back(std::make_pair((unsigned)c1, (unsigned)c2));
+    std::vector<double> LLs_completeReads(pairLL, pairLL + nP), Mismatches_avg(misAvg, misAvg + nP), Mismatches_min(misMin, misMin + nP);
+    std::vector<size_t> LLs_completeReads_indices;
+    for(size_t i = 0; i < LLs_completeReads.size(); i++) LLs_completeReads_indices.push_back(i);
+    std::sort(LLs_completeReads_indices.begin(), LLs_completeReads_indices.end(), [&](unsigned int a, unsigned int b) {
+        if(LLs_completeReads.at(a) == LLs_completeReads.at(b)) return (Mismatches_avg.at(b) < Mismatches_avg.at(a));
+        else return (LLs_completeReads.at(a) < LLs_completeReads.at(b));
+    });
+    std::reverse(LLs_completeReads_indices.begin(), LLs_completeReads_indices.end());
+    // findVectorMax, Utilities.cpp:309-324: first maximum
+    double LL_max = 0; unsigned iMax = 0;
+    for(unsigned int i = 0; i < LLs_completeReads.size(); i++) if((i == 0) || (LLs_completeReads.at(i) > LL_max)) { iMax = i; LL_max = LLs_completeReads.at(i); }
+    std::vector<double> LLs_normalized;
+    double P_sum = 0;
+    for(unsigned int cI = 0; cI < LLs_clusterIs.size(); cI++) P_sum += exp(LLs_completeReads.at(cI) - LL_max);
+    if(P_sum > 0) {
+        for(unsigned int cI = 0; cI < LLs_clusterIs.size(); cI++) {
+            double P_normalized = exp(LLs_completeReads.at(cI) - LL_max) / P_sum;
+            if(!((P_normalized >= 0) && (P_normalized <= 1))) return -2;      // assert, :2438-2439
+            LLs_normalized.push_back(P_normalized);
+        }
+    } else for(unsigned int cI = 0; cI < LLs_clusterIs.size(); cI++) LLs_normalized.push_back(1.0 / (double)LLs_clusterIs.size());
+    std::map<int, double> clusterI_overAllPairs;
+    for(unsigned int cII = 0; cII < LLs_completeReads_indices.size(); cII++) {
+        unsigned int cI = LLs_completeReads_indices.at(cII);
+        std::pair<unsigned int, unsigned int>& clusters = LLs_clusterIs.at(cI);
+        if(clusterI_overAllPairs.count(clusters.first) == 0) clusterI_overAllPairs[clusters.first] = 0;
+        clusterI_overAllPairs[clusters.first] += LLs_normalized.at(cI);
+        if(clusters.second != clusters.first) {
+            if(clusterI_overAllPairs.count(clusters.second) == 0) clusterI_overAllPairs[clusters.second] = 0;
+            clusterI_overAllPairs[clusters.second] += LLs_normalized.at(cI);
+        }
+    }
+    auto findIntMapMax = [](std::map<int, double>& m) {                         // Utilities.cpp:257-272: first maximum in key order
+        double max = 0; int iMaxK = 0;
+        for(std::map<int, double>::iterator mIt = m.begin(); mIt != m.end(); mIt++) if((mIt == m.begin()) || (mIt->second > max)) { max = mIt->second; iMaxK = mIt->first; }
+        return std::pair<double, int>(max, iMaxK);
+    };
+    std::pair<double, int> bestGuess_firstAllele = findIntMapMax(clusterI_overAllPairs);
+    std::map<int, double> bestGuess_secondAllele_alternatives, bestGuess_secondAllele_alternatives_mismatches;
+    for(unsigned int cI = 0; cI < LLs_clusterIs.size(); cI++) {
+        std::pair<unsigned int, unsigned int>& clusters = LLs_clusterIs.at(cI);
+        if((int)clusters.first == bestGuess_firstAllele.second) {
+            bestGuess_secondAllele_alternatives[clusters.second] = LLs_normalized.at(cI);
+            bestGuess_secondAllele_alternatives_mismatches[clusters.second] = Mismatches_min.at(cI);
+        } else if((int)clusters.second == bestGuess_firstAllele.second) {
+            bestGuess_secondAllele_alternatives[clusters.first] = LLs_normalized.at(cI);
+            bestGuess_secondAllele_alternatives_mismatches[clusters.first] = Mismatches_min.at(cI);
+        }
+    }
+    std::pair<double, int> oneBestGuess_secondAllele = findIntMapMax(bestGuess_secondAllele_alternatives);
+    std::map<int, double> mismatches_allBestGuessPairs;
+    for(std::map<int, double>::iterator it = bestGuess_secondAllele_alternatives.begin(); it != bestGuess_secondAllele_alternatives.end(); it++)
+        if(it->second == oneBestGuess_secondAllele.first) mismatches_allBestGuessPairs[it->first] = -1 * bestGuess_secondAllele_alternatives_mismatches.at(it->first);
+    std::pair<double, int> bestGuess_secondAllele = findIntMapMax(mismatches_allBestGuessPairs);
+    if(order) for(size_t i = 0; i < nP; i++) order[i] = (int32_t)LLs_completeReads_indices[i];
+    if(p_normalized) for(size_t i = 0; i < nP; i++) p_normalized[i] = LLs_normalized[i];
+    if(cluster_marginal) for(int c = 0; c < C; c++) cluster_marginal[c] = clusterI_overAllPairs.count(c) ? clusterI_overAllPairs.at(c) : 0.0;
+    if(out) {
+        out->first_cluster = bestGuess_firstAllele.second; out->second_cluster = bestGuess_secondAllele.second;
+        out->first_marginal = bestGuess_firstAllele.first; out->second_p = oneBestGuess_secondAllele.first;
+        out->ll_max = LL_max; out->max_pair = (int32_t)iMax;
+        int ties = 0;
+        for(size_t i = 1; i < nP; i++) { size_t a = LLs_completeReads_indices[i - 1], b = LLs_completeReads_indices[i]; if(pairLL[a] == pairLL[b] && misAvg[a] == misAvg[b]) ties++; }
+        out->n_sort_ties = ties;
+    }
+    return 0;
+}
+
 /* PRGContigAlignment2Seed over column alignments handed in as seeds_in columns WITHOUT edges
  * (the simulateBAMAlignments route of --action testAlignments2Chains / testChainExtension,
  * HLA-LA.cpp:1622-1861): seq_begin/seq_end play sequence_aligned_{start,stop}InRaw. */

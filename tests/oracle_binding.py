@@ -144,3 +144,18 @@ def postprocess_pairs(pairs, n_pairs, stride, gene_first, gene_last, n_cov, cov=
                                  cov.ctypes.data_as(P.c_i32p), inc.ctypes.data_as(P.c_u8p))
     assert rc == 0, rc
     return cov, inc
+
+
+def call_locus(pairLL, misAvg, misMin):
+    """orc_call_locus: the reference's call of one locus (hla/HLATyper.cpp:2366-2541)."""
+    l = lib()
+    a = [np.ascontiguousarray(x, np.float64) for x in (pairLL, misAvg, misMin)]
+    nP = len(a[0]); Cn = int((np.sqrt(8 * nP + 1) - 1) / 2 + 0.5)
+    assert Cn * (Cn + 1) // 2 == nP
+    order = np.zeros(nP, np.int32); pn = np.zeros(nP, np.float64); marg = np.zeros(Cn, np.float64); out = P.CallOut()
+    l.orc_call_locus.argtypes = [C.c_int, P.c_f64p, P.c_f64p, P.c_f64p, P.c_i32p, P.c_f64p, P.c_f64p, C.POINTER(P.CallOut)]
+    rc = l.orc_call_locus(Cn, *[x.ctypes.data_as(P.c_f64p) for x in a], order.ctypes.data_as(P.c_i32p), pn.ctypes.data_as(P.c_f64p),
+                          marg.ctypes.data_as(P.c_f64p), C.byref(out))
+    assert rc == 0, rc
+    return dict(order=order, p_normalized=pn, cluster_marginal=marg, first_cluster=out.first_cluster, second_cluster=out.second_cluster,
+                first_marginal=out.first_marginal, second_p=out.second_p, ll_max=out.ll_max, max_pair=out.max_pair, n_sort_ties=out.n_sort_ties)
