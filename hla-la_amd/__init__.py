@@ -83,6 +83,54 @@ class ExonIn(C.Structure):
                 ("pos_use", c_u8p)]
 
 
+E_CAPACITY = -4      # HLALA_E_CAPACITY
+
+
+class LocusDesc(C.Structure):
+    _fields_ = [("level_min", C.c_int32), ("level_max", C.c_int32), ("level_to_exon", c_i32p), ("insert_mean", C.c_double), ("insert_sd", C.c_double),
+                ("min_mapq", C.c_double), ("min_weighted_ok", C.c_double), ("pair_mask", c_u8p)]
+
+
+class ExonPositionsOut(C.Structure):
+    _fields_ = [("cap_reads", C.c_int32), ("cap_pos", C.c_int32), ("cap_chars", C.c_int32), ("n_reads", C.c_int32), ("n_pos", C.c_int32), ("n_chars", C.c_int32),
+                ("n_pairs_ok", C.c_int32), ("n_pairs_broken", C.c_int32),
+                ("read_pair", c_i32p), ("read_weighted_ok", c_f64p), ("read_fraction_ok", c_f64p), ("read_distance", c_i32p), ("read_cols_nongap", c_i32p),
+                ("pos_off", c_i32p), ("pos_exon", c_i32p), ("pos_level", c_i32p), ("pos_mate", c_u8p), ("pos_mapq", c_u8p), ("pos_novel_gap", c_i32p),
+                ("geno_off", c_i32p), ("geno_chars", c_u8p), ("qual_chars", c_u8p)]
+
+
+def alloc_exon_positions_out(cap_reads, cap_pos, cap_chars):
+    """ExonPositionsOut over fresh numpy arrays; returns (struct, dict of arrays)."""
+    d = dict(read_pair=np.zeros(cap_reads, np.int32), read_weighted_ok=np.zeros(2 * cap_reads), read_fraction_ok=np.zeros(2 * cap_reads),
+             read_distance=np.zeros(cap_reads, np.int32), read_cols_nongap=np.zeros(2 * cap_reads, np.int32), pos_off=np.zeros(cap_reads + 1, np.int32),
+             pos_exon=np.zeros(cap_pos, np.int32), pos_level=np.zeros(cap_pos, np.int32), pos_mate=np.zeros(cap_pos, np.uint8), pos_mapq=np.zeros(cap_pos, np.uint8),
+             pos_novel_gap=np.zeros(cap_pos, np.int32), geno_off=np.zeros(cap_pos + 1, np.int32), geno_chars=np.zeros(cap_chars, np.uint8), qual_chars=np.zeros(cap_chars, np.uint8))
+    o = ExonPositionsOut(); o.cap_reads, o.cap_pos, o.cap_chars = cap_reads, cap_pos, cap_chars
+    for k, v in d.items():
+        setattr(o, k, v.ctypes.data_as(dict(ExonPositionsOut._fields_)[k]))
+    return o, d
+
+
+def trim_exon_positions(o, d):
+    """Cut the arrays of alloc_exon_positions_out to what the call filled in."""
+    nr, npos, nch = o.n_reads, o.n_pos, o.n_chars
+    cut = dict(read_pair=nr, read_weighted_ok=2 * nr, read_fraction_ok=2 * nr, read_distance=nr, read_cols_nongap=2 * nr, pos_off=nr + 1, pos_exon=npos, pos_level=npos,
+               pos_mate=npos, pos_mapq=npos, pos_novel_gap=npos, geno_off=npos + 1, geno_chars=nch, qual_chars=nch)
+    out = {k: d[k][:n].copy() for k, n in cut.items()}
+    out.update(n_reads=nr, n_pos=npos, n_chars=nch, n_pairs_ok=o.n_pairs_ok, n_pairs_broken=o.n_pairs_broken)
+    return out
+
+
+def make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None):
+    l2e = np.ascontiguousarray(level_to_exon, np.int32)
+    L = LocusDesc(); L.level_min = int(level_min); L.level_max = int(level_min) + len(l2e) - 1; L.level_to_exon = l2e.ctypes.data_as(c_i32p)
+    L.insert_mean, L.insert_sd, L.min_mapq, L.min_weighted_ok = float(insert_mean), float(insert_sd), float(min_mapq), float(min_weighted_ok)
+    keep = [l2e]
+    if pair_mask is not None:
+        m = np.ascontiguousarray(pair_mask, np.uint8); L.pair_mask = m.ctypes.data_as(c_u8p); keep.append(m)
+    return L, keep
+
+
 class CallOut(C.Structure):
     _fields_ = [("first_cluster", C.c_int32), ("second_cluster", C.c_int32), ("first_marginal", C.c_double), ("second_p", C.c_double),
                 ("ll_max", C.c_double), ("max_pair", C.c_int32), ("n_sort_ties", C.c_int32)]
@@ -189,6 +237,7 @@ def load_library(path: str | None = None):
     lib.hlala_kat_phred.argtypes = [vp, C.c_int, c_f64p, c_u8p, c_u8p, c_f64p]
     lib.hlala_kat_rand_r.argtypes = [vp, C.c_int, c_u32p, c_i32p]
     lib.hlala_abi_sizeof.argtypes = [C.c_char_p]
+    lib.hlala_exon_positions.argtypes = [vp, vp, C.POINTER(LocusDesc), C.POINTER(ExonPositionsOut)]
     lib.hlala_call_locus.argtypes = [vp, C.c_int32, c_f64p, c_f64p, c_f64p, c_i32p, c_f64p, c_f64p, C.POINTER(CallOut)]
     lib.hlala_abi_sizeof.restype = C.c_int
     if path is None:
@@ -202,7 +251,7 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
-    "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus",
+    "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions",
 ]
 
 
@@ -352,6 +401,17 @@ class Batch:
         inc = np.zeros(self.n_pairs, np.uint8)
         self.ctx._check(self.ctx.lib.hlala_postprocess_pairs(self.ctx.h, self.b, inc.ctypes.data_as(c_u8p)), "hlala_postprocess_pairs")
         return inc
+
+    def exon_positions(self, level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None):
+        """Exon positions of this batch's read pairs for one locus (hlala_exon_positions; hla/HLATyper.cpp:1385-1428)."""
+        L, keep = make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq, min_weighted_ok, pair_mask)
+        o, d = alloc_exon_positions_out(0, 0, 0)
+        rc = self.ctx.lib.hlala_exon_positions(self.ctx.h, self.b, C.byref(L), C.byref(o))          # sizing call
+        if rc not in (0, E_CAPACITY):
+            self.ctx._check(rc, "hlala_exon_positions")
+        o, d = alloc_exon_positions_out(o.n_reads, o.n_pos, o.n_chars)
+        self.ctx._check(self.ctx.lib.hlala_exon_positions(self.ctx.h, self.b, C.byref(L), C.byref(o)), "hlala_exon_positions")
+        return trim_exon_positions(o, d)
 
     def stats(self) -> BatchStats:
         st = BatchStats()

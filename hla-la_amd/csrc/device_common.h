@@ -50,6 +50,7 @@ struct DevTables {
     int    is_dmin, is_n;      // logpdf table covers integer distances [is_dmin, is_dmin + is_n)
     const double* is_logpdf;   // device pointer; entries with pdf <= 0 hold is_penalty
     double phred_thr[256];     // phred_thr[k] = largest pWrong for which PCorrectToPhred gives >= k
+    double pcorrect[256];      // Utilities::PhredToPCorrect(q), Utilities.cpp:357-377 (host libm)
 };
 
 // capacities of the extension DP (one wavefront per chain)

@@ -18,6 +18,7 @@
 #include "kernel_pair.hip"
 #include "kernel_typer.hip"
 #include "kernel_call.hip"
+#include "kernel_exonpos.hip"
 
 namespace hlala {
 size_t proj_slab_bytes_host(int stride, int maxNodesPerLevel) { return proj_slab_bytes(stride, maxNodesPerLevel); }
@@ -169,6 +170,7 @@ static int build_tables(hlala_ctx* c)
         T.ll_match[q] = log(pCorrect);
         double pIncorrect = 1 - pCorrect; pIncorrect *= (1.0 / 3.0);
         T.ll_mismatch[q] = log(pIncorrect);
+        T.pcorrect[q] = host_PhredToPCorrect((unsigned char)q);
     }
     double rate = c->params.long_read_mode ? log(0.075) : log(0.001);
     T.rate_indel = rate;
@@ -884,13 +886,70 @@ extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, c
     return done(HLALA_OK);
 }
 
+extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_locus_desc* L, hlala_exon_positions_out* o)
+{
+    if(!c || !b || !L || !o) return HLALA_E_ARG;
+    if(!(b->staged & 4)) { c->err = "hlala_exon_positions before hlala_pair_chains"; return HLALA_E_STATE; }
+    if(L->level_max < L->level_min || !L->level_to_exon) { c->err = "locus: empty level range or no level_to_exon table"; return HLALA_E_ARG; }
+    DevBatch& B = b->B;
+    const int np = B.n_pairs;
+    o->n_reads = o->n_pos = o->n_chars = 0; o->n_pairs_ok = o->n_pairs_broken = 0;
+    if(np <= 0) { if(o->pos_off && o->cap_reads >= 0) o->pos_off[0] = 0; if(o->geno_off && o->cap_pos >= 0) o->geno_off[0] = 0; return HLALA_OK; }
+    std::vector<void*> tmp;
+    auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
+    int rc = 0;
+    ExonLocus EL; EL.level_min = L->level_min; EL.level_max = L->level_max; EL.insert_mean = L->insert_mean; EL.insert_sd = L->insert_sd;
+    EL.min_mapq = L->min_mapq; EL.min_weighted_ok = L->min_weighted_ok; EL.level_to_exon = nullptr; EL.pair_mask = nullptr;
+    int* dL2E = nullptr; uint8_t* dMask = nullptr; int *dCnt = nullptr, *dOff = nullptr, *dOB = nullptr; char* dCub = nullptr;
+    if((rc = dev_upload(c, tmp, L->level_to_exon, (size_t)(L->level_max - L->level_min + 1), &dL2E))) return done(rc);
+    EL.level_to_exon = dL2E;
+    if(L->pair_mask) { if((rc = dev_upload(c, tmp, L->pair_mask, (size_t)np, &dMask))) return done(rc); EL.pair_mask = dMask; }
+    if((rc = dev_alloc(c, tmp, (size_t)3 * np + 3, &dCnt)) || (rc = dev_alloc(c, tmp, (size_t)3 * np + 3, &dOff)) || (rc = dev_alloc(c, tmp, 2, &dOB, true))) return done(rc);
+    hipStream_t st = c->stream;
+    hlala_exon_positions_out dO; memset(&dO, 0, sizeof(dO));
+    const unsigned grid = (unsigned)((np + 127) / 128);
+    hipLaunchKernelGGL((k_exon_positions<0>), dim3(grid), dim3(128), 0, st, b->dB, c->dT, EL, dCnt, (const int*)nullptr, dOB, dO);
+    if((rc = check_launch(c, "k_exon_positions<0>"))) return done(rc);
+    // interleaved (read, positions, characters) counts -> three exclusive sums in one scan over 3-vectors: scan each column separately
+    // with a strided view is not what the library offers, so the counts are de-interleaved by scanning the flat array three times with
+    // a transform; simpler and still tiny: one scan over the flat array of a struct of three ints
+    struct I3 { int a, b, c; };
+    struct I3Add { __host__ __device__ I3 operator()(const I3& x, const I3& y) const { I3 r; r.a = x.a + y.a; r.b = x.b + y.b; r.c = x.c + y.c; return r; } };
+    size_t cubBytes = 0; I3 zero; zero.a = zero.b = zero.c = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveScan(nullptr, cubBytes, (I3*)dCnt, (I3*)dOff, I3Add(), zero, np + 1, st));
+    if((rc = dev_alloc(c, tmp, cubBytes ? cubBytes : 1, &dCub))) return done(rc);
+    HIP_TRY(c, hipMemsetAsync(dCnt + 3 * (size_t)np, 0, 3 * sizeof(int), st));
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveScan(dCub, cubBytes, (I3*)dCnt, (I3*)dOff, I3Add(), zero, np + 1, st));
+    int totals[3] = {0, 0, 0}, ob[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(totals, dOff + 3 * (size_t)np, sizeof(totals), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(ob, dOB, sizeof(ob), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    o->n_reads = totals[0]; o->n_pos = totals[1]; o->n_chars = totals[2]; o->n_pairs_ok = ob[0]; o->n_pairs_broken = ob[1];
+    if(totals[0] > o->cap_reads || totals[1] > o->cap_pos || totals[2] > o->cap_chars) { c->err = "hlala_exon_positions: output capacity too small (needed sizes are in n_reads / n_pos / n_chars)"; return done(HLALA_E_CAPACITY); }
+    const size_t nR = (size_t)totals[0], nPz = (size_t)totals[1], nC = (size_t)totals[2];
+    if((rc = dev_alloc(c, tmp, nR, &dO.read_pair)) || (rc = dev_alloc(c, tmp, 2 * nR, &dO.read_weighted_ok)) || (rc = dev_alloc(c, tmp, 2 * nR, &dO.read_fraction_ok)) ||
+       (rc = dev_alloc(c, tmp, nR, &dO.read_distance)) || (rc = dev_alloc(c, tmp, 2 * nR, &dO.read_cols_nongap)) || (rc = dev_alloc(c, tmp, nR + 1, &dO.pos_off)) ||
+       (rc = dev_alloc(c, tmp, nPz, &dO.pos_exon)) || (rc = dev_alloc(c, tmp, nPz, &dO.pos_level)) || (rc = dev_alloc(c, tmp, nPz, &dO.pos_mate)) || (rc = dev_alloc(c, tmp, nPz, &dO.pos_mapq)) ||
+       (rc = dev_alloc(c, tmp, nPz, &dO.pos_novel_gap)) || (rc = dev_alloc(c, tmp, nPz + 1, &dO.geno_off)) || (rc = dev_alloc(c, tmp, nC, &dO.geno_chars)) || (rc = dev_alloc(c, tmp, nC, &dO.qual_chars))) return done(rc);
+    hipLaunchKernelGGL((k_exon_positions<1>), dim3(grid), dim3(128), 0, st, b->dB, c->dT, EL, dCnt, (const int*)dOff, dOB, dO);
+    if((rc = check_launch(c, "k_exon_positions<1>"))) return done(rc);
+    if((rc = dl(c, o->read_pair, dO.read_pair, nR)) || (rc = dl(c, o->read_weighted_ok, dO.read_weighted_ok, 2 * nR)) || (rc = dl(c, o->read_fraction_ok, dO.read_fraction_ok, 2 * nR)) ||
+       (rc = dl(c, o->read_distance, dO.read_distance, nR)) || (rc = dl(c, o->read_cols_nongap, dO.read_cols_nongap, 2 * nR)) || (rc = dl(c, o->pos_off, dO.pos_off, nR)) ||
+       (rc = dl(c, o->pos_exon, dO.pos_exon, nPz)) || (rc = dl(c, o->pos_level, dO.pos_level, nPz)) || (rc = dl(c, o->pos_mate, dO.pos_mate, nPz)) || (rc = dl(c, o->pos_mapq, dO.pos_mapq, nPz)) ||
+       (rc = dl(c, o->pos_novel_gap, dO.pos_novel_gap, nPz)) || (rc = dl(c, o->geno_off, dO.geno_off, nPz)) || (rc = dl(c, o->geno_chars, dO.geno_chars, nC)) || (rc = dl(c, o->qual_chars, dO.qual_chars, nC))) return done(rc);
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if(o->pos_off) o->pos_off[nR] = (int32_t)nPz;
+    if(o->geno_off) o->geno_off[nPz] = (int32_t)nC;
+    return done(HLALA_OK);
+}
+
 extern "C" int hlala_abi_sizeof(const char* name)
 {
     if(!name) return -1;
     const std::string n(name);
 #define SZ(t) if(n == #t) return (int)sizeof(t);
     SZ(hlala_graph_desc) SZ(hlala_contigs_desc) SZ(hlala_params) SZ(hlala_graph_info) SZ(hlala_batch_in) SZ(hlala_seeds_in)
-    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out)
+    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out)
 #undef SZ
     return -1;
 }

@@ -283,6 +283,46 @@ int  hlala_exon_loglik(hlala_ctx* ctx, const hlala_exon_in* in, double* LL, int3
 int  hlala_pair_loglik(hlala_ctx* ctx, const double* LL, const int32_t* mism, int32_t C, int32_t R,
                        double* pairLL, double* misAvg, double* misMin);
 
+/* Exon positions of the read pairs of a batch for one locus (hla/HLATyper.cpp:1385-1428 with
+ * oneReadAlignment_2_exonPositions_paired :3192-3565, alignmentFractionOK :3082-3101, alignmentWeightedOKFraction :3933-4018,
+ * alignerBase::alignedReadPair_pairsDistanceInGraphLevels alignerBase.cpp:246-283, removeDoublePositionsFromRead :4020-4083).
+ * A pair yields one entry of exonPositions_fromReads when it passes the pair test (:1404-1410: strands valid, |distance - insert mean|
+ * <= 5 sd, mapQ of mate 1 >= min_mapq, both weighted-OK fractions >= min_weighted_ok) and at least one of its columns lies on an exon
+ * level; positions come out as the reference's std::map order (ascending graph level, one per level: the alternative with the best
+ * worst-quality, first wins).  Reads are taken in alignment orientation (read_bases / read_quals of the batch), which is the base the
+ * reference reaches through its reverse-index arithmetic (:3307-3321).                                                            */
+typedef struct {
+    int32_t        level_min, level_max; /* combined_exon_sequences_graphLevels_min / _max                                  */
+    const int32_t* level_to_exon;        /* [level_max - level_min + 1] graphLevel_2_exonPosition; -1 = not an exon level   */
+    double         insert_mean, insert_sd;
+    double         min_mapq;             /* minimumMappingQuality (0.0, HLATyper.cpp:30)                                    */
+    double         min_weighted_ok;      /* min_bothReads_weightedCharactersOK (0.0, HLATyper.cpp:28)                       */
+    const uint8_t* pair_mask;            /* [n_pairs] or NULL: only pairs with a non-zero entry are looked at (includeInHLA) */
+} hlala_locus_desc;
+
+typedef struct {
+    int32_t  cap_reads, cap_pos, cap_chars;  /* in: capacities of the arrays below                                          */
+    int32_t  n_reads, n_pos, n_chars;        /* out: exonPositions_fromReads.size(), total positions, total genotype chars  */
+    int32_t  n_pairs_ok, n_pairs_broken;     /* out: readPairs_OK / readPairs_broken (:1424, :1462), over the looked-at pairs */
+    int32_t* read_pair;        /* [cap_reads] pair index in the batch                                                        */
+    double*  read_weighted_ok; /* [2*cap_reads] alignmentWeightedOKFraction of mate 1, mate 2                                 */
+    double*  read_fraction_ok; /* [2*cap_reads] alignmentFractionOK of mate 1, mate 2                                         */
+    int32_t* read_distance;    /* [cap_reads] alignedReadPair_pairsDistanceInGraphLevels                                      */
+    int32_t* read_cols_nongap; /* [2*cap_reads] alignmentColumnsWithAtLeastOneNonGap of mate 1, mate 2                        */
+    int32_t* pos_off;          /* [cap_reads+1] positions of read i: [pos_off[i], pos_off[i+1])                               */
+    int32_t* pos_exon;         /* oneExonPosition::positionInExon                                                            */
+    int32_t* pos_level;        /* ::graphLevel                                                                               */
+    uint8_t* pos_mate;         /* 1 / 2: the mate the position comes from (fromFirstRead)                                    */
+    uint8_t* pos_mapq;         /* Phred character of mapQ_perPosition; ::mapQ_position = PhredToPCorrect of it               */
+    int32_t* pos_novel_gap;    /* ::runningNovelGapEitherDirection                                                           */
+    int32_t* geno_off;         /* [cap_pos+1] genotype / qualities of position j: [geno_off[j], geno_off[j+1])               */
+    uint8_t* geno_chars;       /* ::genotype                                                                                 */
+    uint8_t* qual_chars;       /* ::qualities (0 where the genotype is "_" and carries no quality)                            */
+} hlala_exon_positions_out;
+
+/* returns HLALA_E_CAPACITY (with the needed n_* filled in) when an array is too small */
+int  hlala_exon_positions(hlala_ctx* ctx, hlala_batch* b, const hlala_locus_desc* locus, hlala_exon_positions_out* out);
+
 /* The call of one locus from the all-pairs table (hla/HLATyper.cpp:2366-2541).  Pair (c1 <= c2) sits at the index
  * hlala_pair_loglik uses.  order = pair indices sorted by LL descending, Mism_avg ascending (std::sort + std::reverse, :2381-2403;
  * the order among pairs equal in both keys is unspecified in the reference too -- n_sort_ties counts adjacent equal keys);

@@ -1443,6 +1443,213 @@ int orc_pair_loglik(const double* LL, const int32_t* mism, int C, int R, double*
     return 0;
 }
 
+// ---- exon positions of read pairs for one locus -------------------------------------------------------------------------
+// One alignment as the typer sees it: columns of the selected chain + the read in alignment orientation.
+struct TyperAln { int n; const int32_t* lv; const uint8_t* g; const uint8_t* s; const uint8_t* mq; const uint8_t* bases; const uint8_t* quals; int readLen; double mapQ; };
+struct ExonPos { int positionInExon, graphLevel; std::string genotype, alignment_edgelabels, qualities; int mate; unsigned char mapqChar; int novelGap; };
+
+static int aln_firstLevel(const TyperAln& a) { for(int i = 0; i < a.n; i++) if(a.lv[i] != -1) return a.lv[i]; return -1; }      // verboseSeedChain.h:122-135
+static int aln_lastLevel(const TyperAln& a) { for(int i = a.n - 1; i >= 0; i--) if(a.lv[i] != -1) return a.lv[i]; return -1; }  // :157-183
+// HLATyper::alignmentFractionOK, hla/HLATyper.cpp:3082-3101
+static double alignmentFractionOK(const TyperAln& r)
+{
+    int positions_OK = 0, positions_checked = 0;
+    for(int i = 0; i < r.n; i++) {
+        if((r.g[i] == '_') && (r.s[i] == '_')) continue;
+        positions_checked++;
+        if(r.g[i] == r.s[i]) positions_OK++;
+    }
+    return double(positions_OK) / double(positions_checked);
+}
+// HLATyper::alignmentWeightedOKFraction, hla/HLATyper.cpp:3933-4018 (sequence_begin = 0 for extended chains; the reverse-index
+// arithmetic of :3949-3959 lands on the alignment-orientation base, which is what `bases` / `quals` hold)
+static int alignmentWeightedOKFraction(const TyperAln& a, double& out)
+{
+    int indexIntoOriginalReadData = 0 - 1;
+    int totalMismatches = 0; double weightedMismatches = 0;
+    for(int cI = 0; cI < a.n; cI++) {
+        unsigned char sequenceCharacter = a.s[cI], graphCharacter = a.g[cI];
+        if(sequenceCharacter != '_') {
+            indexIntoOriginalReadData++;
+            if(!(indexIntoOriginalReadData >= 0 && indexIntoOriginalReadData < a.readLen)) return -1;
+            if(a.bases[indexIntoOriginalReadData] != sequenceCharacter) return -2;            // assert(underlyingReadCharacter == sequenceCharacter)
+            if(graphCharacter == '_') { totalMismatches++; weightedMismatches++; }
+            else {
+                double pCorrect = PhredToPCorrect(a.quals[indexIntoOriginalReadData]);
+                if(!((pCorrect >= 0) && (pCorrect <= 1))) return -3;
+                if(sequenceCharacter != graphCharacter) { weightedMismatches += pCorrect; totalMismatches++; }
+            }
+        } else {
+            if(graphCharacter == '_') { if(a.lv[cI] == -1) return -4; }
+            else { totalMismatches++; weightedMismatches++; }
+        }
+    }
+    double readLength = a.readLen;
+    out = (1.0 - (weightedMismatches / readLength));
+    return 0;
+}
+// alignerBase::alignedReadPair_pairsDistanceInGraphLevels, mapper/aligner/alignerBase.cpp:246-283
+static int pairsDistanceInGraphLevels(const TyperAln& r1, const TyperAln& r2)
+{
+    if(aln_firstLevel(r1) < aln_firstLevel(r2)) return (aln_firstLevel(r2) - aln_lastLevel(r1) - 1);
+    return (aln_firstLevel(r1) - aln_lastLevel(r2) - 1);
+}
+// HLATyper::oneReadAlignment_2_exonPositions_paired, hla/HLATyper.cpp:3192-3565 (only the fields that differ per position are kept)
+static int oneReadAlignment_2_exonPositions(const TyperAln& alignment, int mate, std::vector<ExonPos>& ret, int levels_min, int levels_max, const int32_t* level_to_exon, int& colsNonGap)
+{
+    int alignment_firstLevel = aln_firstLevel(alignment), alignment_lastLevel = aln_lastLevel(alignment);
+    colsNonGap = 0;
+    if(!(alignment_firstLevel <= alignment_lastLevel)) return -10;
+    if(!intervalsOverlap(alignment_firstLevel, alignment_lastLevel, levels_min, levels_max)) return 0;
+    std::vector<ExonPos> readAlignment_exonPositions;
+    int alignmentColumns_oneNonGap = 0;
+    for(int cI = 0; cI < alignment.n; cI++) if((alignment.s[cI] != '_') || (alignment.s[cI] != '_')) alignmentColumns_oneNonGap++;      // sic, :3236
+    colsNonGap = alignmentColumns_oneNonGap;
+    std::vector<int> runningNovelGaps(alignment.n, 0);
+    {
+        int runningNovelGap = 0;
+        for(int cI = 0; cI < alignment.n; cI++) {
+            unsigned char sc = alignment.s[cI], gc = alignment.g[cI];
+            if((gc != '_') && (sc != '_')) runningNovelGap = 0;
+            else if(!((gc == '_') && (sc == '_'))) runningNovelGap++;
+            if(runningNovelGap > runningNovelGaps.at(cI)) runningNovelGaps.at(cI) = runningNovelGap;
+        }
+        runningNovelGap = 0;
+        for(int cI = alignment.n - 1; cI >= 0; cI--) {
+            unsigned char sc = alignment.s[cI], gc = alignment.g[cI];
+            if((gc != '_') && (sc != '_')) runningNovelGap = 0;
+            else if(!((gc == '_') && (sc == '_'))) runningNovelGap++;
+            if(runningNovelGap > runningNovelGaps.at(cI)) runningNovelGaps.at(cI) = runningNovelGap;
+        }
+    }
+    int indexIntoOriginalReadData = -1;
+    for(int cI = 0; cI < alignment.n; cI++) {
+        unsigned char sequenceCharacter = alignment.s[cI], graphCharacter = alignment.g[cI];
+        int graphLevel = alignment.lv[cI];
+        if(graphLevel == -1) {
+            // insertion relative to the graph - extend the last character, :3299-3340
+            if(!(graphCharacter == '_') || !(sequenceCharacter != '_')) return -11;
+            indexIntoOriginalReadData++;
+            if(!(indexIntoOriginalReadData >= 0 && indexIntoOriginalReadData < alignment.readLen)) return -12;
+            if(alignment.bases[indexIntoOriginalReadData] != sequenceCharacter) return -13;
+            char qualityCharacter = (char)alignment.quals[indexIntoOriginalReadData];
+            if(readAlignment_exonPositions.size() > 0) {
+                ExonPos& bk = readAlignment_exonPositions.back();
+                bk.genotype.push_back((char)sequenceCharacter); bk.alignment_edgelabels.push_back((char)graphCharacter); bk.qualities.push_back(qualityCharacter);
+                if(!(bk.genotype.length() == bk.qualities.length())) {
+                    if(!(bk.genotype.length() == (bk.qualities.length() + 1)) || !(bk.genotype.at(0) == '_')) return -14;
+                    bk.genotype = bk.genotype.substr(1); bk.alignment_edgelabels = bk.alignment_edgelabels.substr(1);
+                }
+                if(bk.genotype.length() != bk.qualities.length()) return -15;
+            }
+        } else {
+            ExonPos thisPosition;
+            thisPosition.graphLevel = graphLevel; thisPosition.positionInExon = -1; thisPosition.mate = mate;
+            thisPosition.mapqChar = alignment.mq[cI]; thisPosition.novelGap = runningNovelGaps.at(cI);
+            thisPosition.alignment_edgelabels = std::string(1, (char)graphCharacter);
+            if(sequenceCharacter != '_') {
+                indexIntoOriginalReadData++;
+                if(!(indexIntoOriginalReadData >= 0 && indexIntoOriginalReadData < alignment.readLen)) return -16;
+                if(alignment.bases[indexIntoOriginalReadData] != sequenceCharacter) return -17;
+                thisPosition.genotype = std::string(1, (char)sequenceCharacter);
+                thisPosition.qualities = std::string(1, (char)alignment.quals[indexIntoOriginalReadData]);       // both branches :3360-3427
+            } else {
+                thisPosition.genotype = "_"; thisPosition.qualities = "";                                         // :3431-3490
+            }
+            readAlignment_exonPositions.push_back(thisPosition);
+        }
+    }
+    int alongReadMode = 0, lastPositionInExon = -1;
+    for(size_t posInAlignment = 0; posInAlignment < readAlignment_exonPositions.size(); posInAlignment++) {
+        ExonPos& thisPosition = readAlignment_exonPositions.at(posInAlignment);
+        bool inExon = thisPosition.graphLevel >= levels_min && thisPosition.graphLevel <= levels_max && level_to_exon[thisPosition.graphLevel - levels_min] >= 0;
+        if(inExon) {
+            if(alongReadMode == 2) lastPositionInExon = -1;
+            thisPosition.positionInExon = level_to_exon[thisPosition.graphLevel - levels_min];
+            if(!((lastPositionInExon == -1) || (thisPosition.positionInExon == (lastPositionInExon + 1)))) return -18;     // assert, :3528
+            lastPositionInExon = thisPosition.positionInExon;
+            alongReadMode = 1;
+            ret.push_back(thisPosition);
+        } else if(alongReadMode == 1) alongReadMode = 2;
+    }
+    return 0;
+}
+// HLATyper::removeDoublePositionsFromRead, hla/HLATyper.cpp:4020-4083
+static int removeDoublePositionsFromRead(const std::vector<ExonPos>& positions, std::vector<ExonPos>& forReturn)
+{
+    std::map<int, std::vector<ExonPos>> positions_per_graphLevel;
+    for(size_t i = 0; i < positions.size(); i++) positions_per_graphLevel[positions[i].graphLevel].push_back(positions[i]);
+    for(auto it = positions_per_graphLevel.begin(); it != positions_per_graphLevel.end(); it++) {
+        const std::vector<ExonPos>& alternatives = it->second;
+        unsigned int bestI = 0; unsigned char bestI_quality = 0;
+        for(unsigned int i = 0; i < alternatives.size(); i++) {
+            const ExonPos& t = alternatives[i];
+            if(!((t.genotype == "_") || (t.qualities.size() > 0))) return -20;
+            unsigned char Q = 0;
+            if(t.genotype != "_") { for(unsigned int k = 0; k < t.qualities.size(); k++) if((k == 0) || ((unsigned char)t.qualities[k] < Q)) Q = (unsigned char)t.qualities[k]; }
+            if((i == 0) || (Q > bestI_quality)) { bestI = i; bestI_quality = Q; }
+        }
+        forReturn.push_back(alternatives.at(bestI));
+    }
+    return 0;
+}
+
+// The paired-read part of the per-locus loop of HLATyper::HLATypeInference, hla/HLATyper.cpp:1385-1428.
+int orc_exon_positions(int n_pairs, int stride, const int32_t* pair_status, const int32_t* n_cols, const int32_t* col_level, const uint8_t* col_gchar,
+                       const uint8_t* col_schar, const uint8_t* col_mapq, const double* mate_mapq, const uint8_t* strands_valid,
+                       const int32_t* read_off, const uint8_t* read_bases, const uint8_t* read_quals,
+                       const hlala_locus_desc* L, hlala_exon_positions_out* o)
+{
+    int nReads = 0, nPos = 0, nChars = 0; bool overflow = false;
+    o->n_pairs_ok = 0; o->n_pairs_broken = 0;
+    for(int p = 0; p < n_pairs; p++) {
+        if(L->pair_mask && !L->pair_mask[p]) continue;
+        if(pair_status[p] != 0) continue;
+        TyperAln a[2];
+        for(int m = 0; m < 2; m++) {
+            size_t r = (size_t)2 * p + m;
+            a[m].n = n_cols[r]; a[m].lv = col_level + r * stride; a[m].g = col_gchar + r * stride; a[m].s = col_schar + r * stride; a[m].mq = col_mapq + r * stride;
+            a[m].bases = read_bases + read_off[r]; a[m].quals = read_quals + read_off[r]; a[m].readLen = read_off[r + 1] - read_off[r]; a[m].mapQ = mate_mapq[r];
+        }
+        std::vector<ExonPos> read1_exonPositions, read2_exonPositions; int cng[2] = {0, 0};
+        int rc = oneReadAlignment_2_exonPositions(a[0], 1, read1_exonPositions, L->level_min, L->level_max, L->level_to_exon, cng[0]); if(rc) return rc;
+        rc = oneReadAlignment_2_exonPositions(a[1], 2, read2_exonPositions, L->level_min, L->level_max, L->level_to_exon, cng[1]); if(rc) return rc;
+        double w[2]; if((rc = alignmentWeightedOKFraction(a[0], w[0])) || (rc = alignmentWeightedOKFraction(a[1], w[1]))) return rc;
+        int dist = pairsDistanceInGraphLevels(a[0], a[1]);
+        double mapQ_thisAlignment = a[0].mapQ;
+        if(!((mapQ_thisAlignment >= 0) && (mapQ_thisAlignment <= 1))) return -30;
+        // `abs` on a double: Utilities.h:20 puts namespace std in scope, so the reference resolves to std::abs(double) (no truncation)
+        if(strands_valid[p] && (std::abs(dist - L->insert_mean) <= (5 * L->insert_sd)) && (mapQ_thisAlignment >= L->min_mapq) && ((w[0] >= L->min_weighted_ok) && (w[1] >= L->min_weighted_ok))) {
+            std::vector<ExonPos> thisRead_exonPositions = read1_exonPositions;
+            thisRead_exonPositions.insert(thisRead_exonPositions.end(), read2_exonPositions.begin(), read2_exonPositions.end());
+            if(thisRead_exonPositions.size() > 0) {
+                std::vector<ExonPos> cleaned; if((rc = removeDoublePositionsFromRead(thisRead_exonPositions, cleaned))) return rc;
+                size_t chars = 0; for(auto& e : cleaned) chars += e.genotype.size();
+                if(nReads + 1 > o->cap_reads || nPos + (int)cleaned.size() > o->cap_pos || nChars + (int)chars > o->cap_chars) overflow = true;
+                if(!overflow) {
+                    o->read_pair[nReads] = p; o->read_weighted_ok[2 * nReads] = w[0]; o->read_weighted_ok[2 * nReads + 1] = w[1];
+                    o->read_fraction_ok[2 * nReads] = alignmentFractionOK(a[0]); o->read_fraction_ok[2 * nReads + 1] = alignmentFractionOK(a[1]);
+                    o->read_distance[nReads] = dist; o->read_cols_nongap[2 * nReads] = cng[0]; o->read_cols_nongap[2 * nReads + 1] = cng[1];
+                    o->pos_off[nReads] = nPos;
+                    int q = nPos, ch = nChars;
+                    for(auto& e : cleaned) {
+                        o->pos_exon[q] = e.positionInExon; o->pos_level[q] = e.graphLevel; o->pos_mate[q] = (uint8_t)e.mate; o->pos_mapq[q] = e.mapqChar; o->pos_novel_gap[q] = e.novelGap;
+                        o->geno_off[q] = ch;
+                        for(size_t k = 0; k < e.genotype.size(); k++) { o->geno_chars[ch] = (uint8_t)e.genotype[k]; o->qual_chars[ch] = k < e.qualities.size() ? (uint8_t)e.qualities[k] : 0; ch++; }
+                        q++;
+                    }
+                }
+                nReads++; nPos += (int)cleaned.size(); nChars += (int)chars;
+            }
+            o->n_pairs_ok++;
+        } else o->n_pairs_broken++;
+    }
+    o->n_reads = nReads; o->n_pos = nPos; o->n_chars = nChars;
+    if(overflow) return -100;
+    o->pos_off[nReads] = nPos; o->geno_off[nPos] = nChars;
+    return 0;
+}
+
 // The call of one locus (hla/HLATyper.cpp:2366-2541) from the all-pairs table; same index convention as orc_pair_loglik
 // (LLs_clusterIs is filled c1-major, c2 >= c1, :2293-2364).  std::sort + std::reverse are the reference's own calls (:2381-2403).
 int orc_call_locus(int C, const double* pairLL, const double* misAvg, const double* misMin, int32_t* order, double* p_normalized,

@@ -159,3 +159,24 @@ def call_locus(pairLL, misAvg, misMin):
     assert rc == 0, rc
     return dict(order=order, p_normalized=pn, cluster_marginal=marg, first_cluster=out.first_cluster, second_cluster=out.second_cluster,
                 first_marginal=out.first_marginal, second_p=out.second_p, ll_max=out.ll_max, max_pair=out.max_pair, n_sort_ties=out.n_sort_ties)
+
+
+def exon_positions(pairs, batch, stride, level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None):
+    """orc_exon_positions on the `pairs` dict of Oracle.align_batch and the reads of `batch` (hla/HLATyper.cpp:1385-1428)."""
+    l = lib()
+    L, keep = P.make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq, min_weighted_ok, pair_mask)
+    n = int(batch["n_pairs"])
+    o, d = P.alloc_exon_positions_out(n, 2 * n * stride, 4 * n * stride)
+    a = dict(st=np.ascontiguousarray(pairs["pair_status"], np.int32), nc=np.ascontiguousarray(pairs["n_cols"], np.int32),
+             lv=np.ascontiguousarray(pairs["col_level"], np.int32), g=np.ascontiguousarray(pairs["col_gchar"], np.uint8),
+             s=np.ascontiguousarray(pairs["col_schar"], np.uint8), mq=np.ascontiguousarray(pairs["col_mapq"], np.uint8),
+             mm=np.ascontiguousarray(pairs["mate_mapq"], np.float64), sv=np.ascontiguousarray(pairs["strands_valid"], np.uint8),
+             ro=np.ascontiguousarray(batch["read_off"], np.int32), rb=np.ascontiguousarray(batch["read_bases"], np.uint8), rq=np.ascontiguousarray(batch["read_quals"], np.uint8))
+    l.orc_exon_positions.argtypes = [C.c_int, C.c_int, P.c_i32p, P.c_i32p, P.c_i32p, P.c_u8p, P.c_u8p, P.c_u8p, P.c_f64p, P.c_u8p, P.c_i32p, P.c_u8p, P.c_u8p,
+                                     C.POINTER(P.LocusDesc), C.POINTER(P.ExonPositionsOut)]
+    rc = l.orc_exon_positions(n, stride, a["st"].ctypes.data_as(P.c_i32p), a["nc"].ctypes.data_as(P.c_i32p), a["lv"].ctypes.data_as(P.c_i32p),
+                              a["g"].ctypes.data_as(P.c_u8p), a["s"].ctypes.data_as(P.c_u8p), a["mq"].ctypes.data_as(P.c_u8p), a["mm"].ctypes.data_as(P.c_f64p),
+                              a["sv"].ctypes.data_as(P.c_u8p), a["ro"].ctypes.data_as(P.c_i32p), a["rb"].ctypes.data_as(P.c_u8p), a["rq"].ctypes.data_as(P.c_u8p),
+                              C.byref(L), C.byref(o))
+    assert rc == 0, rc
+    return P.trim_exon_positions(o, d)
