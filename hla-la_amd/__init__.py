@@ -131,6 +131,62 @@ def make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0
     return L, keep
 
 
+class FilterParams(C.Structure):
+    _fields_ = [("filter_first20", C.c_int32), ("first20_n", C.c_int32), ("first20_min_prop", C.c_double), ("first20_limit_per_read", C.c_int32),
+                ("min_per_position_mapq", C.c_double), ("high_coverage_filter", C.c_int32), ("high_coverage_min_coverage", C.c_int32), ("high_coverage_min_freq", C.c_double)]
+
+
+class FilterStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("considered_positions", "positions_with_removed_alleles", "considered_alleles", "removed_alleles", "reads_kicked_out",
+                                         "reads_kicked_out_robust", "high_coverage_positions", "high_coverage_removed_alleles", "bases_used")]
+
+
+def default_filter_params(**kw):
+    """The reference's settings for short reads (hla/HLATyper.cpp:28-31, 69-75; HLATyper.h:57)."""
+    p = FilterParams(1, 20, 0.1, 2, 0.7, 0, 100, 0.2)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def exon_positions_struct(e):
+    """ExonPositionsOut view over the dict Batch.exon_positions() returns (for hlala_filter_positions)."""
+    o = ExonPositionsOut(); keep = []
+    o.n_reads, o.n_pos, o.n_chars = int(e["n_reads"]), int(e["n_pos"]), int(e["n_chars"])
+    o.cap_reads, o.cap_pos, o.cap_chars = o.n_reads, o.n_pos, o.n_chars
+    types = dict(ExonPositionsOut._fields_)
+    for k in ("read_pair", "read_weighted_ok", "read_fraction_ok", "read_distance", "read_cols_nongap", "pos_off", "pos_exon", "pos_level", "pos_mate", "pos_mapq",
+              "pos_novel_gap", "geno_off", "geno_chars", "qual_chars"):
+        a = np.ascontiguousarray(e[k]); keep.append(a); setattr(o, k, a.ctypes.data_as(types[k]))
+    return o, keep
+
+
+def filter_positions(lib, e, params=None):
+    """hlala_filter_positions on the dict Batch.exon_positions() returns: (pos_use, read_ignored, stats dict)."""
+    o, keep = exon_positions_struct(e)
+    prm = params or default_filter_params()
+    use = np.zeros(max(1, o.n_pos), np.uint8); ign = np.zeros(max(1, o.n_reads), np.uint8); st = FilterStats()
+    lib.hlala_filter_positions.argtypes = [C.POINTER(ExonPositionsOut), C.POINTER(FilterParams), c_u8p, c_u8p, C.POINTER(FilterStats)]
+    rc = lib.hlala_filter_positions(C.byref(o), C.byref(prm), use.ctypes.data_as(c_u8p), ign.ctypes.data_as(c_u8p), C.byref(st))
+    if rc != 0:
+        raise HlalaError(f"hlala_filter_positions failed ({rc})")
+    return use[:o.n_pos], ign[:o.n_reads], {k: int(getattr(st, k)) for k, _ in FilterStats._fields_}
+
+
+def exon_in_from_positions(e, pos_use, cluster_seq, n_clusters, exon_length):
+    """hlala_exon_in (input of hlala_exon_loglik) from the outputs of hlala_exon_positions and hlala_filter_positions: the likelihood loop
+    reads the first genotype character, the genotype length and the first quality of every position (hla/HLATyper.cpp:2080-2277)."""
+    go = np.asarray(e["geno_off"], np.int64)
+    n = int(e["n_pos"])
+    first = go[:n]
+    g0 = np.asarray(e["geno_chars"], np.uint8)[first] if n else np.zeros(0, np.uint8)
+    q0 = np.asarray(e["qual_chars"], np.uint8)[first] if n else np.zeros(0, np.uint8)
+    return dict(n_clusters=int(n_clusters), exon_length=int(exon_length), cluster_seq=np.ascontiguousarray(cluster_seq, np.uint8).reshape(-1),
+                n_reads=int(e["n_reads"]), pos_off=np.ascontiguousarray(e["pos_off"], np.int32), pos_exon=np.ascontiguousarray(e["pos_exon"], np.int32),
+                pos_g0=np.ascontiguousarray(g0), pos_glen=np.ascontiguousarray(go[1:n + 1] - go[:n], np.int32), pos_qual=np.ascontiguousarray(q0),
+                pos_use=np.ascontiguousarray(pos_use, np.uint8))
+
+
 class CallOut(C.Structure):
     _fields_ = [("first_cluster", C.c_int32), ("second_cluster", C.c_int32), ("first_marginal", C.c_double), ("second_p", C.c_double),
                 ("ll_max", C.c_double), ("max_pair", C.c_int32), ("n_sort_ties", C.c_int32)]
@@ -251,7 +307,7 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
-    "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions",
+    "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions",
 ]
 
 

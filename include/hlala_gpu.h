@@ -323,6 +323,31 @@ typedef struct {
 /* returns HLALA_E_CAPACITY (with the needed n_* filled in) when an array is too small */
 int  hlala_exon_positions(hlala_ctx* ctx, hlala_batch* b, const hlala_locus_desc* locus, hlala_exon_positions_out* out);
 
+/* Read / allele filters between the exon positions and the likelihoods (hla/HLATyper.cpp:1496-1720 filterFirst20, :1722-1862
+ * high-coverage allele filter, and the use test of the likelihood loop :2102-2120).  pos_use[j] = 1 iff position j enters the
+ * likelihood: mapQ_position >= min_per_position_mapq, its read is not ignored, its allele is not ignored at its exon position.
+ * This step runs on the HOST: which reads make the "first 20" of a position is decided by std::sort on tied keys (:1557-1565), i.e.
+ * by the C++ library's unspecified tie order; calling the same library routine on the same sequence is the only way to agree with
+ * the reference, and the data is a few hundred thousand small records per locus.  No context is needed.                          */
+typedef struct {
+    int32_t filter_first20;              /* filterFirst20 (true, HLATyper.cpp:73); also the divisor of first20_prop, :1593 (sic)   */
+    int32_t first20_n;                   /* filterFirst20N (20)                                                                     */
+    double  first20_min_prop;            /* filterFirst20MinProp (0.1)                                                              */
+    int32_t first20_limit_per_read;      /* filterFirst20MinProp_limitKickOutPerRead (2, HLATyper.h:57)                              */
+    double  min_per_position_mapq;       /* minimumPerPositionMappingQuality (0.7, HLATyper.cpp:31)                                  */
+    int32_t high_coverage_filter;        /* highCoverage_filter_alleles (false; true with min coverage 1 / freq 0.15 at :944-946)    */
+    int32_t high_coverage_min_coverage;  /* highCoverage_minCoverage (100)                                                          */
+    double  high_coverage_min_freq;      /* highCoverage_minAlleleFreq (0.2)                                                        */
+} hlala_filter_params;
+typedef struct {
+    int64_t considered_positions, positions_with_removed_alleles, considered_alleles, removed_alleles;   /* :1703-1707 */
+    int64_t reads_kicked_out, reads_kicked_out_robust;                                                   /* :1709, :1714 */
+    int64_t high_coverage_positions, high_coverage_removed_alleles;                                      /* :1865-1868 */
+    int64_t bases_used;                                                                                  /* HLATypeInference_thisLocus_bases_used, :2122 */
+} hlala_filter_stats;
+int  hlala_filter_positions(const hlala_exon_positions_out* pos, const hlala_filter_params* prm, uint8_t* pos_use /* [n_pos] */,
+                            uint8_t* read_ignored /* [n_reads] or NULL */, hlala_filter_stats* stats /* or NULL */);
+
 /* The call of one locus from the all-pairs table (hla/HLATyper.cpp:2366-2541).  Pair (c1 <= c2) sits at the index
  * hlala_pair_loglik uses.  order = pair indices sorted by LL descending, Mism_avg ascending (std::sort + std::reverse, :2381-2403;
  * the order among pairs equal in both keys is unspecified in the reference too -- n_sort_ties counts adjacent equal keys);

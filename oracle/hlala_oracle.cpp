@@ -1650,6 +1650,119 @@ int orc_exon_positions(int n_pairs, int stride, const int32_t* pair_status, cons
     return 0;
 }
 
+// Read / allele filters of HLATyper::HLATypeInference: filterFirst20 (hla/HLATyper.cpp:1496-1720), the high-coverage allele filter
+// (:1722-1862, short reads: the strand filter of :1847-1858 needs longReadsMode) and the use test of the likelihood loop (:2102-2120).
+// Reads are the entries of exonPositions_fromReads; a read's ID pair is unique to the entry, so ignore_readIDs is a set of entries.
+int orc_filter_positions(const hlala_exon_positions_out* pos, const hlala_filter_params* prm, uint8_t* pos_use, uint8_t* read_ignored, hlala_filter_stats* st)
+{
+    const int nReads = pos->n_reads;
+    auto genotype = [&](int j) { return std::string((const char*)pos->geno_chars + pos->geno_off[j], (size_t)(pos->geno_off[j + 1] - pos->geno_off[j])); };
+    auto mapQ_position = [&](int j) { return PhredToPCorrect(pos->pos_mapq[j]); };
+    auto weightedOK = [&](int readI) { return (pos->read_weighted_ok[2 * readI] + pos->read_weighted_ok[2 * readI + 1]) / 2.0; };   // commutative: same for both mates
+    std::set<int> ignore_readIDs;
+    std::map<unsigned int, std::set<std::string>> perPosition_ignore_alleles;
+    hlala_filter_stats S; memset(&S, 0, sizeof(S));
+    const bool filterFirst20 = prm->filter_first20 != 0;
+    if(filterFirst20) {
+        std::map<unsigned int, int> perRead_kickedOut, perRead_kickedOut_robust;
+        std::map<unsigned int, std::vector<std::string>> perPosition_alleles;
+        std::map<unsigned int, std::vector<double>> perPosition_weightedOK;
+        std::map<unsigned int, std::vector<unsigned int>> perPosition_readI;
+        for(int readI = 0; readI < nReads; readI++)
+            for(int j = pos->pos_off[readI]; j < pos->pos_off[readI + 1]; j++) {
+                if(!((mapQ_position(j) >= 0) && (mapQ_position(j) <= 1))) return -1;
+                if(mapQ_position(j) < prm->min_per_position_mapq) continue;
+                int position = pos->pos_exon[j];
+                perPosition_alleles[position].push_back(genotype(j));
+                perPosition_weightedOK[position].push_back(weightedOK(readI));
+                perPosition_readI[position].push_back((unsigned)readI);
+            }
+        for(auto position : perPosition_alleles) {
+            int n_alleles = (int)perPosition_alleles.at(position.first).size();
+            if(n_alleles < prm->first20_n) continue;
+            std::vector<unsigned int> allele_indices; allele_indices.reserve(n_alleles);
+            for(unsigned int i = 0; i < (unsigned)n_alleles; i++) allele_indices.push_back(i);
+            std::sort(allele_indices.begin(), allele_indices.end(), [&](unsigned int a, unsigned int b) {
+                return (perPosition_weightedOK.at(position.first).at(a) < perPosition_weightedOK.at(position.first).at(b)); });
+            std::reverse(allele_indices.begin(), allele_indices.end());
+            std::map<std::string, int> alleles_first20;
+            std::set<std::string> kickedOutAlleles;
+            for(unsigned int i = 0; i < (unsigned)prm->first20_n; i++) {
+                std::string allele = perPosition_alleles.at(position.first).at(allele_indices.at(i));
+                if(alleles_first20.count(allele) == 0) alleles_first20[allele] = 0;
+                alleles_first20.at(allele)++;
+            }
+            bool kickedOneOut = false;
+            for(unsigned int i = 0; i < (unsigned)n_alleles; i++) {
+                std::string allele = perPosition_alleles.at(position.first).at(i);
+                unsigned int readI = perPosition_readI.at(position.first).at(i);
+                int first20_alleleCount = alleles_first20.count(allele) ? alleles_first20.at(allele) : 0;
+                double first20_prop = (double)first20_alleleCount / (double)filterFirst20;        // sic: the bool, not filterFirst20N (:1593)
+                S.considered_alleles++;
+                if(first20_prop < prm->first20_min_prop) {
+                    kickedOutAlleles.insert(allele); perPosition_ignore_alleles[position.first].insert(allele);
+                    if(perRead_kickedOut.count(readI) == 0) perRead_kickedOut[readI] = 0;
+                    perRead_kickedOut.at(readI)++; kickedOneOut = true; S.removed_alleles++;
+                }
+            }
+            std::map<std::string, int> allele_kickedOut_howMany;
+            for(unsigned int i = 0; i < (unsigned)n_alleles; i++) {
+                std::string allele = perPosition_alleles.at(position.first).at(i);
+                if(kickedOutAlleles.count(allele)) { if(allele_kickedOut_howMany.count(allele) == 0) allele_kickedOut_howMany[allele] = 0; allele_kickedOut_howMany.at(allele)++; }
+            }
+            for(unsigned int i = 0; i < (unsigned)n_alleles; i++) {
+                std::string allele = perPosition_alleles.at(position.first).at(i);
+                unsigned int readI = perPosition_readI.at(position.first).at(i);
+                if(allele_kickedOut_howMany.count(allele) && (allele_kickedOut_howMany.at(allele) >= 2)) {
+                    if(perRead_kickedOut_robust.count(readI) == 0) perRead_kickedOut_robust[readI] = 0;
+                    perRead_kickedOut_robust.at(readI)++;
+                }
+            }
+            S.considered_positions++;
+            if(kickedOneOut) S.positions_with_removed_alleles++;
+        }
+        for(auto readKickedOut : perRead_kickedOut) if(readKickedOut.second > prm->first20_limit_per_read) S.reads_kicked_out++;     // counted only, :1661-1668
+        for(auto readKickedOut : perRead_kickedOut_robust)
+            if(readKickedOut.second > prm->first20_limit_per_read) { S.reads_kicked_out_robust++; ignore_readIDs.insert((int)readKickedOut.first); }   // :1682-1690
+    }
+    {   // high-coverage allele filter, :1722-1862
+        std::map<unsigned int, std::map<std::string, int>> perPosition_allele_counts;
+        for(int readI = 0; readI < nReads; readI++)
+            for(int j = pos->pos_off[readI]; j < pos->pos_off[readI + 1]; j++) {
+                if(ignore_readIDs.count(readI)) continue;
+                if(mapQ_position(j) < prm->min_per_position_mapq) continue;
+                int position = pos->pos_exon[j]; std::string allele = genotype(j);
+                if(perPosition_ignore_alleles.count(position) && (perPosition_ignore_alleles.at(position).count(allele))) continue;
+                if(perPosition_allele_counts[position].count(allele) == 0) perPosition_allele_counts[position][allele] = 0;
+                perPosition_allele_counts.at(position).at(allele)++;
+            }
+        for(auto position : perPosition_allele_counts) {
+            int count_position = 0;
+            for(auto allele : perPosition_allele_counts.at(position.first)) count_position += allele.second;
+            if(count_position >= prm->high_coverage_min_coverage) {
+                S.high_coverage_positions++;
+                for(auto allele : perPosition_allele_counts.at(position.first)) {
+                    double aF = (double)allele.second / (double)count_position;
+                    if((aF < prm->high_coverage_min_freq) && prm->high_coverage_filter) { perPosition_ignore_alleles[position.first].insert(allele.first); S.high_coverage_removed_alleles += allele.second; }
+                }
+            }
+        }
+    }
+    for(int readI = 0; readI < nReads; readI++) {
+        if(read_ignored) read_ignored[readI] = ignore_readIDs.count(readI) ? 1 : 0;
+        for(int j = pos->pos_off[readI]; j < pos->pos_off[readI + 1]; j++) {
+            bool use = true;                                                                      // :2102-2120
+            if(mapQ_position(j) < prm->min_per_position_mapq) use = false;
+            else if(perPosition_ignore_alleles.count(pos->pos_exon[j]) && (perPosition_ignore_alleles.at(pos->pos_exon[j]).count(genotype(j)))) use = false;
+            else if(ignore_readIDs.count(readI)) use = false;
+            pos_use[j] = use ? 1 : 0;
+            if(use) S.bases_used++;
+        }
+    }
+    if(st) *st = S;
+    return 0;
+}
+
 // The call of one locus (hla/HLATyper.cpp:2366-2541) from the all-pairs table; same index convention as orc_pair_loglik
 // (LLs_clusterIs is filled c1-major, c2 >= c1, :2293-2364).  std::sort + std::reverse are the reference's own calls (:2381-2403).
 int orc_call_locus(int C, const double* pairLL, const double* misAvg, const double* misMin, int32_t* order, double* p_normalized,

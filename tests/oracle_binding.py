@@ -180,3 +180,15 @@ def exon_positions(pairs, batch, stride, level_min, level_to_exon, insert_mean, 
                               C.byref(L), C.byref(o))
     assert rc == 0, rc
     return P.trim_exon_positions(o, d)
+
+
+def filter_positions(e, params=None):
+    """orc_filter_positions on an exon-positions dict: (pos_use, read_ignored, stats dict)."""
+    l = lib()
+    o, keep = P.exon_positions_struct(e)
+    prm = params or P.default_filter_params()
+    use = np.zeros(max(1, o.n_pos), np.uint8); ign = np.zeros(max(1, o.n_reads), np.uint8); st = P.FilterStats()
+    l.orc_filter_positions.argtypes = [C.POINTER(P.ExonPositionsOut), C.POINTER(P.FilterParams), P.c_u8p, P.c_u8p, C.POINTER(P.FilterStats)]
+    rc = l.orc_filter_positions(C.byref(o), C.byref(prm), use.ctypes.data_as(P.c_u8p), ign.ctypes.data_as(P.c_u8p), C.byref(st))
+    assert rc == 0, rc
+    return use[:o.n_pos], ign[:o.n_reads], {k: int(getattr(st, k)) for k, _ in P.FilterStats._fields_}
