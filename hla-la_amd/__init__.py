@@ -187,6 +187,10 @@ def exon_in_from_positions(e, pos_use, cluster_seq, n_clusters, exon_length):
                 pos_use=np.ascontiguousarray(pos_use, np.uint8))
 
 
+class InsertSizeOut(C.Structure):
+    _fields_ = [("mean", C.c_double), ("sd", C.c_double), ("n_used", C.c_int32), ("n_skipped", C.c_int32), ("total_weight", C.c_double)]
+
+
 class CallOut(C.Structure):
     _fields_ = [("first_cluster", C.c_int32), ("second_cluster", C.c_int32), ("first_marginal", C.c_double), ("second_p", C.c_double),
                 ("ll_max", C.c_double), ("max_pair", C.c_int32), ("n_sort_ties", C.c_int32)]
@@ -293,6 +297,7 @@ def load_library(path: str | None = None):
     lib.hlala_kat_phred.argtypes = [vp, C.c_int, c_f64p, c_u8p, c_u8p, c_f64p]
     lib.hlala_kat_rand_r.argtypes = [vp, C.c_int, c_u32p, c_i32p]
     lib.hlala_abi_sizeof.argtypes = [C.c_char_p]
+    lib.hlala_estimate_insert_size.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(InsertSizeOut)]
     lib.hlala_exon_positions.argtypes = [vp, vp, C.POINTER(LocusDesc), C.POINTER(ExonPositionsOut)]
     lib.hlala_call_locus.argtypes = [vp, C.c_int32, c_f64p, c_f64p, c_f64p, c_i32p, c_f64p, c_f64p, C.POINTER(CallOut)]
     lib.hlala_abi_sizeof.restype = C.c_int
@@ -307,7 +312,7 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
-    "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions",
+    "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size",
 ]
 
 
@@ -394,6 +399,13 @@ class Context:
                                               pn.ctypes.data_as(c_f64p), marg.ctypes.data_as(c_f64p), C.byref(out)), "hlala_call_locus")
         return dict(order=order, p_normalized=pn, cluster_marginal=marg, first_cluster=out.first_cluster, second_cluster=out.second_cluster,
                     first_marginal=out.first_marginal, second_p=out.second_p, ll_max=out.ll_max, max_pair=out.max_pair, n_sort_ties=out.n_sort_ties)
+
+    def estimate_insert_size(self, batch_in: dict):
+        """processBAM::estimateInsertSize on the primaries of `batch_in` (hlala_estimate_insert_size)."""
+        s, keep = fill_struct(BatchIn, batch_in)
+        o = InsertSizeOut()
+        self._check(self.lib.hlala_estimate_insert_size(self.h, C.byref(s), C.byref(o)), "hlala_estimate_insert_size")
+        return dict(mean=o.mean, sd=o.sd, n_used=o.n_used, n_skipped=o.n_skipped, total_weight=o.total_weight)
 
     def set_gene_intervals(self, first_level, last_level):
         """HLATyper::interestingLevels (graphgene_levelBoundaries, hla/HLATyper.cpp:241-252)."""

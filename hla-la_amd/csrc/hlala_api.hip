@@ -4,6 +4,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <map>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -628,6 +629,61 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
     return HLALA_OK;
 }
 
+int hlala_estimate_insert_size(hlala_ctx* c, const hlala_batch_in* in, hlala_insert_size_out* out)
+{
+    if(!c || !in || !out) return HLALA_E_ARG;
+    memset(out, 0, sizeof(*out));
+    const int np = in->n_pairs, nr = 2 * np;
+    if(np <= 0) { c->err = "hlala_estimate_insert_size: no pairs"; return HLALA_E_ARG; }
+    // the batch of primaries: one chain per read
+    std::vector<int32_t> chain_off(nr + 1), read_primary(nr), contig(nr), pos(nr), offset(nr), as(nr), cigar_off(nr + 1, 0); std::vector<uint8_t> rev(nr); std::vector<uint32_t> cigar;
+    for(int r = 0; r < nr; r++) {
+        const int ch = in->read_primary[r];
+        if(ch < in->chain_off[r] || ch >= in->chain_off[r + 1]) { c->err = "read_primary outside the read's chains"; return HLALA_E_ARG; }
+        chain_off[r] = r; read_primary[r] = r; contig[r] = in->chain_contig[ch]; pos[r] = in->chain_pos[ch]; offset[r] = in->chain_offset[ch]; as[r] = in->chain_as[ch]; rev[r] = in->chain_reverse[ch];
+        cigar.insert(cigar.end(), in->cigar + in->cigar_off[ch], in->cigar + in->cigar_off[ch + 1]); cigar_off[r + 1] = (int32_t)cigar.size();
+    }
+    chain_off[nr] = nr;
+    hlala_batch_in pb = *in;
+    pb.chain_off = chain_off.data(); pb.read_primary = read_primary.data(); pb.n_chains = nr; pb.chain_contig = contig.data(); pb.chain_pos = pos.data();
+    pb.chain_offset = offset.data(); pb.chain_as = as.data(); pb.chain_reverse = rev.data(); pb.cigar_off = cigar_off.data(); pb.cigar = cigar.data();
+    hlala_batch* b = nullptr;
+    int rc = hlala_batch_create(c, &pb, &b); if(rc) return rc;
+    auto done = [&](int r_) { hlala_batch_destroy(b); return r_; };
+    if((rc = hlala_project_chains(c, b)) || (rc = hlala_extend_chains(c, b))) return done(rc);
+    std::vector<void*> tmp; int *dN = nullptr, *dD = nullptr;
+    auto done2 = [&](int r_) { for(void* p : tmp) pool_release(c, p); return done(r_); };
+    if((rc = dev_alloc(c, tmp, (size_t)np, &dN)) || (rc = dev_alloc(c, tmp, (size_t)np * PAIR_MAXDIST, &dD))) return done2(rc);
+    hipLaunchKernelGGL(k_pair_distances, dim3((unsigned)((np + 127) / 128)), dim3(128), 0, c->stream, c->dG, b->dB, dN, dD);
+    if((rc = check_launch(c, "k_pair_distances"))) return done2(rc);
+    std::vector<int> hN((size_t)np), hD((size_t)np * PAIR_MAXDIST);
+    if((rc = dl(c, hN.data(), dN, (size_t)np)) || (rc = dl(c, hD.data(), dD, (size_t)np * PAIR_MAXDIST))) return done2(rc);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if(e != hipSuccess) { c->err = hipGetErrorString(e); return done2(HLALA_E_DEVICE); }
+    // histogram in pair order (processBAM.cpp:1135-1146), then calculateInsertSizeFromHistogram (:991-1069)
+    std::map<int, double> IS_combined_counts;
+    for(int p = 0; p < np; p++) {
+        if(hN[p] == -1) { out->n_skipped++; continue; }                       // flagged chain: the reference would have asserted
+        out->n_used++;
+        if(hN[p] == -2) { out->n_skipped++; continue; }                       // strands not valid, :1149
+        if(hN[p] > PAIR_MAXDIST) { c->err = "more distinct insert-size distances for one pair than this build holds"; return done2(HLALA_E_CAPACITY); }
+        std::set<int> dist(hD.begin() + (size_t)p * PAIR_MAXDIST, hD.begin() + (size_t)p * PAIR_MAXDIST + hN[p]);
+        for(int IS : dist) { if(IS_combined_counts.count(IS) == 0) IS_combined_counts[IS] = 0; IS_combined_counts[IS] += 1.0 / (double)dist.size(); }
+    }
+    double total = 0; for(auto& kv : IS_combined_counts) total += kv.second;
+    double cum = 0, med = 0, p20 = 0, p80 = 0; bool sm = false, s2 = false, s8 = false;
+    for(auto& kv : IS_combined_counts) {
+        cum += kv.second;
+        if(!sm && cum >= total * 0.5) { med = kv.first; sm = true; }
+        if(!s2 && cum >= total * 0.2) { p20 = kv.first; s2 = true; }
+        if(!s8 && cum >= total * 0.8) { p80 = kv.first; s8 = true; }
+    }
+    if(!(sm && s2 && s8)) { c->err = "hlala_estimate_insert_size: no pair with valid strands and a common underlying sequence"; return done2(HLALA_E_STATE); }
+    const double d20 = std::fabs(med - p20), d80 = std::fabs(med - p80);
+    out->mean = med; out->sd = d20 > d80 ? d20 : d80; out->total_weight = total;
+    return done2(HLALA_OK);
+}
+
 int hlala_set_gene_intervals(hlala_ctx* c, int32_t n, const int32_t* first_level, const int32_t* last_level)
 {
     if(!c || n < 0 || (n > 0 && (!first_level || !last_level))) return HLALA_E_ARG;
@@ -949,7 +1005,7 @@ extern "C" int hlala_abi_sizeof(const char* name)
     const std::string n(name);
 #define SZ(t) if(n == #t) return (int)sizeof(t);
     SZ(hlala_graph_desc) SZ(hlala_contigs_desc) SZ(hlala_params) SZ(hlala_graph_info) SZ(hlala_batch_in) SZ(hlala_seeds_in)
-    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats)
+    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats) SZ(hlala_insert_size_out)
 #undef SZ
     return -1;
 }

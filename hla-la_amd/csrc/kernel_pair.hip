@@ -55,6 +55,50 @@ __device__ inline double pair_insert_ll(const DevGraph& G, const DevTables& T, c
     return have ? best : T.is_penalty;
 }
 
+// Insert-size estimation (processBAM::estimateInsertSize, processBAM.cpp:1071-1165): for a batch that holds ONE chain per read
+// (chain 2p = mate 1, chain 2p + 1 = mate 2 of pair p) the strand test and every distance of
+// alignedReadPair_pairsDistancesUnderlyingSequences (alignerBase.cpp:290-329; same anchors as pair_insert_ll).  One thread per pair.
+// out_n[p] = -1: a chain is flagged; -2: strands not valid; else the number of distances (duplicates possible, the host builds the set).
+constexpr int PAIR_MAXDIST = 32;
+__global__ void k_pair_distances(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, int* __restrict__ out_n, int* __restrict__ out_d)
+{
+    const DevGraph& G = *Gp; const DevBatch& B = *Bp;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= B.n_pairs) return;
+    const int ca = 2 * p, cb = 2 * p + 1;
+    if(B.ext_status[ca] != HLALA_CHAIN_OK || B.ext_status[cb] != HLALA_CHAIN_OK) { out_n[p] = -1; return; }
+    const int* fa = B.ext_firstlast + 4 * ca; const int* fb = B.ext_firstlast + 4 * cb;
+    const bool ra = B.chain_reverse[ca] != 0, rb = B.chain_reverse[cb] != 0;
+    bool valid = false;
+    if(fa[0] != -1 && fb[0] != -1 && ra != rb) valid = (!ra) ? (fa[0] < fb[0]) : (fa[2] > fb[2]);          // alignerBase.cpp:213-244
+    if(!valid) { out_n[p] = -2; return; }
+    const int* fl_up = (fa[0] < fb[0]) ? fa : fb; const int* fl_down = (fa[0] < fb[0]) ? fb : fa;           // alignerBase.cpp:294, 312
+    int upL[2] = {fl_up[2], fl_up[3]}, dnL[2] = {fl_down[0], fl_down[1]};
+    int n = 0;
+    for(int a = 0; a < 2; a++) {
+        if(upL[a] < 0) continue;
+        for(long long ia = G.lp_off[upL[a]]; ia < G.lp_off[upL[a] + 1]; ia++) {
+            int id = G.lp_seqid[ia]; int endPos = G.lp_pos[ia];
+            if(a == 1 && upL[0] >= 0) {
+                bool dup = false;
+                for(long long q = G.lp_off[upL[0]]; q < G.lp_off[upL[0] + 1]; q++) if(G.lp_seqid[q] == id) { dup = true; break; }
+                if(dup) continue;
+            }
+            int beginPos = -1;
+            for(int b = 0; b < 2 && beginPos < 0; b++) {
+                if(dnL[b] < 0) continue;
+                for(long long q = G.lp_off[dnL[b]]; q < G.lp_off[dnL[b] + 1]; q++) if(G.lp_seqid[q] == id) { beginPos = G.lp_pos[q]; break; }
+            }
+            if(beginPos < 0) continue;
+            const int d = beginPos - endPos - 1;
+            bool seen = false;
+            for(int k = 0; k < n && k < PAIR_MAXDIST; k++) if(out_d[(size_t)p * PAIR_MAXDIST + k] == d) seen = true;
+            if(!seen) { if(n < PAIR_MAXDIST) out_d[(size_t)p * PAIR_MAXDIST + n] = d; n++; }
+        }
+    }
+    out_n[p] = n;
+}
+
 __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp)
 {
     const DevGraph& G = *Gp;

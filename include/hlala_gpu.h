@@ -243,6 +243,22 @@ typedef struct {
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 
 /* ------------------------------------------------------------------------------------------
+ * Insert-size estimation (processBAM::estimateInsertSize, mapper/processBAM.cpp:1071-1165, and
+ * calculateInsertSizeFromHistogram :991-1069) on the kernels of stages A and B: for every pair of `in` the PRIMARY
+ * alignment of mate 1 and of mate 2 (read_primary) is projected and extended; if the strands are valid every
+ * distance of alignedReadPair_pairsDistancesUnderlyingSequences gets the weight 1/#distances in a histogram
+ * (accumulated in pair order, as the reference walks its sorted read IDs); mean = weighted median,
+ * sd = max(|median - 20 %|, |median - 80 %|).  The caller passes the first 4000 complete pairs (extractSeeds(4000), :1075).
+ * A pair with a flagged chain (status < 0) is skipped and counted in n_skipped.  insert_mean / insert_sd of the context are
+ * not used (and may be placeholders).                                                                                    */
+typedef struct {
+    double  mean, sd;                 /* calculateInsertSizeFromHistogram: weighted median / max deviation of the 20 % and 80 % points */
+    int32_t n_used, n_skipped;        /* used_proto_seeds / skipped_proto_seeds (:1162)                                                */
+    double  total_weight;             /* IS_total_size                                                                                 */
+} hlala_insert_size_out;
+int  hlala_estimate_insert_size(hlala_ctx* ctx, const hlala_batch_in* in, hlala_insert_size_out* out);
+
+/* ------------------------------------------------------------------------------------------
  * Per-pair post-processing of alignReads_postSeedExtraction_andStoreInto (mapper/processBAM.cpp:2411-2446).
  *   coverage  : bases_per_level[level]++ for every column of both selected chains whose level is defined and whose graph
  *               character is not '_' (:2411-2428); the counters live in the context and accumulate over batches

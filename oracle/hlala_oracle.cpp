@@ -1371,6 +1371,79 @@ int orc_align_batch(orc_handle* h, const hlala_batch_in* in, hlala_chains_out* s
     } catch(std::exception& e) { g_err = e.what(); return -1; }
 }
 
+/* processBAM::calculateInsertSizeFromHistogram, mapper/processBAM.cpp:991-1069 */
+static int calculateInsertSizeFromHistogram(const std::map<int, double>& IS_combined_counts, double& mean, double& sd, double& total)
+{
+    std::set<int> IS_keys; double IS_total_size = 0;
+    for(auto ISentry : IS_combined_counts) { IS_keys.insert(ISentry.first); if(!(ISentry.second >= 0)) return -1; IS_total_size += ISentry.second; }
+    double cumulative_sum = 0, weighted_median = 0, weighted_20 = 0, weighted_80 = 0;
+    bool set_median = false, set_weighted_20 = false, set_weighted_80 = false;
+    for(std::set<int>::iterator ISit = IS_keys.begin(); ISit != IS_keys.end(); ISit++) {
+        int d = *ISit;
+        cumulative_sum += IS_combined_counts.at(d);
+        if((set_median == false) && (cumulative_sum >= (IS_total_size * 0.5))) { weighted_median = d; set_median = true; }
+        if((set_weighted_20 == false) && (cumulative_sum >= (IS_total_size * 0.2))) { weighted_20 = d; set_weighted_20 = true; }
+        if((set_weighted_80 == false) && (cumulative_sum >= (IS_total_size * 0.8))) { weighted_80 = d; set_weighted_80 = true; }
+    }
+    if(!(set_weighted_80 && set_weighted_20 && set_median)) return -2;                  // assert, :1044
+    double f_mean_ret = weighted_median;
+    weighted_20 = std::abs(weighted_median - weighted_20);                               // std::abs(double): Utilities.h:20 brings std into scope
+    weighted_80 = std::abs(weighted_median - weighted_80);
+    double f_sd_ret = (weighted_20 > weighted_80) ? weighted_20 : weighted_80;
+    mean = f_mean_ret; sd = f_sd_ret; total = IS_total_size;
+    return 0;
+}
+
+int orc_insert_size_from_histogram(int n, const int32_t* keys, const double* counts, double* mean, double* sd)
+{
+    std::map<int, double> h; for(int i = 0; i < n; i++) h[keys[i]] = counts[i];
+    double total; return calculateInsertSizeFromHistogram(h, *mean, *sd, total);
+}
+
+/* processBAM::estimateInsertSize, mapper/processBAM.cpp:1071-1165, on the pairs of a batch in their given order: the primary alignment of
+ * each mate (the first primary x primary combination, :1102-1153), alignment2Chain, extendSeedChain, strands, distances, histogram. */
+int orc_estimate_insert_size(orc_handle* h, const hlala_batch_in* in, hlala_insert_size_out* out)
+{
+    try {
+        Processor& P = h->P;
+        Aligner& A = *P.eA;
+        std::map<int, double> IS_combined_counts;
+        int used_proto_seeds = 0, skipped_proto_seeds = 0;
+        for(int p = 0; p < in->n_pairs; p++) {
+            Chain ext[2];
+            for(int m = 0; m < 2; m++) {
+                int r = 2 * p + m;
+                std::string seq((const char*)in->read_bases + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
+                int c = in->read_primary[r];
+                BamRecord al; al.contig = in->chain_contig[c]; al.pos = in->chain_pos[c]; al.offset = in->chain_offset[c];
+                al.as = in->chain_as[c]; al.reverse = in->chain_reverse[c] != 0;
+                al.cigar.assign(in->cigar + in->cigar_off[c], in->cigar + in->cigar_off[c + 1]);
+                ContigAlignment ca;
+                bool ok = P.transformBAMreadToInternalAlignment(al, seq, ca);
+                ORC_CHECK(ok, "alignment consists of insertions only");
+                Chain seed = P.PRGContigAlignment2Seed(ca, true);
+                seed.checkConcordance(seq);
+                // imposed determinism: the DP of mate r draws the seed rng_seed + 2r + side, as if the batch held the primaries only
+                ext[m] = A.extendSeedChain(seq, seed, P.params.rng_seed + 2u * (unsigned)r, P.params.rng_seed + 2u * (unsigned)r + 1u);
+            }
+            used_proto_seeds++;
+            if(Processor::strandsValid(ext[0], ext[1])) {
+                std::set<int> underlyingSequencesDistances = P.pairDistances(ext[0], ext[1]);
+                for(std::set<int>::iterator ISiterator = underlyingSequencesDistances.begin(); ISiterator != underlyingSequencesDistances.end(); ISiterator++) {
+                    int IS = *ISiterator;
+                    if(IS_combined_counts.count(IS) == 0) IS_combined_counts[IS] = 0;
+                    double weight = 1.0 / (double)underlyingSequencesDistances.size();
+                    IS_combined_counts[IS] += weight;
+                }
+            } else skipped_proto_seeds++;
+        }
+        out->n_used = used_proto_seeds; out->n_skipped = skipped_proto_seeds;
+        int rc = calculateInsertSizeFromHistogram(IS_combined_counts, out->mean, out->sd, out->total_weight);
+        if(rc) { g_err = "insert-size histogram is empty"; return rc; }
+        return 0;
+    } catch(std::exception& e) { g_err = e.what(); return -1; }
+}
+
 /* HLATyper per-cluster x per-read log-likelihood and mismatch count, hla/HLATyper.cpp:2067-2277 (parameters :935-959).
  * The position filters of :2102-2121 are cluster-independent and arrive folded into pos_use. */
 int orc_exon_loglik(const hlala_exon_in* in, int long_read_mode, double* LL, int32_t* mism)

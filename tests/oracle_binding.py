@@ -36,6 +36,8 @@ def lib():
         _lib.orc_pair_loglik.argtypes = [P.c_f64p, P.c_i32p, C.c_int, C.c_int, P.c_f64p, P.c_f64p, P.c_f64p]
         _lib.orc_normal_logpdf_penalty.argtypes = [C.c_double, C.c_double]
         _lib.orc_normal_logpdf_penalty.restype = C.c_double
+        _lib.orc_estimate_insert_size.argtypes = [vp, C.POINTER(P.BatchIn), C.POINTER(P.InsertSizeOut)]
+        _lib.orc_insert_size_from_histogram.argtypes = [C.c_int, P.c_i32p, P.c_f64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return _lib
 
 
@@ -117,6 +119,12 @@ class Oracle:
         self._check(lib().orc_align_batch(self.h, C.byref(s), C.byref(so), C.byref(eo), C.byref(po),
                                           int(stop_after_projection), stats.ctypes.data_as(P.c_i64p)))
         return dict(seeds=sd, ext=ed, pairs=pd, stats=stats)
+
+    def estimate_insert_size(self, batch_in):
+        s, keep = P.fill_struct(P.BatchIn, batch_in)
+        o = P.InsertSizeOut()
+        self._check(lib().orc_estimate_insert_size(self.h, C.byref(s), C.byref(o)))
+        return dict(mean=o.mean, sd=o.sd, n_used=o.n_used, n_skipped=o.n_skipped, total_weight=o.total_weight)
 
     def close(self):
         if self.h:
