@@ -88,7 +88,7 @@ E_CAPACITY = -4      # HLALA_E_CAPACITY
 
 class LocusDesc(C.Structure):
     _fields_ = [("level_min", C.c_int32), ("level_max", C.c_int32), ("level_to_exon", c_i32p), ("insert_mean", C.c_double), ("insert_sd", C.c_double),
-                ("min_mapq", C.c_double), ("min_weighted_ok", C.c_double), ("pair_mask", c_u8p)]
+                ("min_mapq", C.c_double), ("min_weighted_ok", C.c_double), ("pair_mask", c_u8p), ("min_alignment_columns", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ExonPositionsOut(C.Structure):
@@ -121,10 +121,11 @@ def trim_exon_positions(o, d):
     return out
 
 
-def make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None):
+def make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None, min_alignment_columns=1000):
     l2e = np.ascontiguousarray(level_to_exon, np.int32)
     L = LocusDesc(); L.level_min = int(level_min); L.level_max = int(level_min) + len(l2e) - 1; L.level_to_exon = l2e.ctypes.data_as(c_i32p)
     L.insert_mean, L.insert_sd, L.min_mapq, L.min_weighted_ok = float(insert_mean), float(insert_sd), float(min_mapq), float(min_weighted_ok)
+    L.min_alignment_columns = int(min_alignment_columns)
     keep = [l2e]
     if pair_mask is not None:
         m = np.ascontiguousarray(pair_mask, np.uint8); L.pair_mask = m.ctypes.data_as(c_u8p); keep.append(m)
@@ -279,6 +280,7 @@ def load_library(path: str | None = None):
     lib.hlala_graph_get_paths.argtypes = [vp, c_i32p, c_i32p, c_i32p]
     lib.hlala_graph_get_gap_stretch.argtypes = [vp, c_u8p]
     lib.hlala_batch_create.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(vp)]
+    lib.hlala_batch_create_unpaired.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(vp)]
     lib.hlala_batch_create_from_seeds.argtypes = [vp, C.POINTER(SeedsIn), C.POINTER(vp)]
     lib.hlala_batch_destroy.argtypes = [vp]
     lib.hlala_batch_destroy.restype = None
@@ -309,7 +311,7 @@ def load_library(path: str | None = None):
 EXPORTED_SYMBOLS = [
     "hlala_create", "hlala_destroy", "hlala_last_error", "hlala_graph_get_info", "hlala_graph_get_nodes",
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
-    "hlala_batch_create_from_seeds", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
+    "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
     "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size",
@@ -363,6 +365,13 @@ class Context:
         s, keep = fill_struct(BatchIn, batch_in)
         b = C.c_void_p()
         self._check(self.lib.hlala_batch_create(self.h, C.byref(s), C.byref(b)), "hlala_batch_create")
+        return Batch(self, b, batch_in["n_chains"], batch_in["n_pairs"])
+
+    def batch_unpaired(self, batch_in: dict) -> "Batch":
+        """Long-read / unpaired mode: batch_in["n_pairs"] is the number of reads (hlala_batch_create_unpaired)."""
+        s, keep = fill_struct(BatchIn, batch_in)
+        b = C.c_void_p()
+        self._check(self.lib.hlala_batch_create_unpaired(self.h, C.byref(s), C.byref(b)), "hlala_batch_create_unpaired")
         return Batch(self, b, batch_in["n_chains"], batch_in["n_pairs"])
 
     def batch_from_seeds(self, seeds_in: dict) -> "Batch":
@@ -470,9 +479,9 @@ class Batch:
         self.ctx._check(self.ctx.lib.hlala_postprocess_pairs(self.ctx.h, self.b, inc.ctypes.data_as(c_u8p)), "hlala_postprocess_pairs")
         return inc
 
-    def exon_positions(self, level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None):
+    def exon_positions(self, level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None, min_alignment_columns=1000):
         """Exon positions of this batch's read pairs for one locus (hlala_exon_positions; hla/HLATyper.cpp:1385-1428)."""
-        L, keep = make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq, min_weighted_ok, pair_mask)
+        L, keep = make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq, min_weighted_ok, pair_mask, min_alignment_columns)
         o, d = alloc_exon_positions_out(0, 0, 0)
         rc = self.ctx.lib.hlala_exon_positions(self.ctx.h, self.b, C.byref(L), C.byref(o))          # sizing call
         if rc not in (0, E_CAPACITY):

@@ -7,6 +7,7 @@ namespace hlala {
 struct DevBatch {
     int n_pairs, n_reads, n_chains, stride;
     int from_seeds;                 // 1: seed chains were uploaded directly (no stage A / C inputs)
+    int unpaired;                   // 1: one read per unit (long-read / unpaired mode): n_reads == n_pairs, no extension DP
     // ---- inputs
     const int* read_off;            // [n_reads+1]
     const uint8_t* read_bases;      // alignment orientation of the primary

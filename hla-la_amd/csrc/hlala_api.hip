@@ -50,6 +50,7 @@ struct hlala_ctx {
     std::unordered_map<void*, size_t> block_bytes;
     std::multimap<size_t, void*> pool;
     size_t pool_bytes = 0;
+    std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
@@ -307,6 +308,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
 void hlala_destroy(hlala_ctx* c)
 {
     if(!c) return;
+    for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(auto& kv : c->pool) (void)hipFree(kv.second);
     for(int i = 0; i < 9; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -373,15 +375,19 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     return 0;
 }
 
-int hlala_batch_create(hlala_ctx* c, const hlala_batch_in* in, hlala_batch** out)
+static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch** out, bool unpaired);
+int hlala_batch_create(hlala_ctx* c, const hlala_batch_in* in, hlala_batch** out) { return batch_create_impl(c, in, out, false); }
+int hlala_batch_create_unpaired(hlala_ctx* c, const hlala_batch_in* in, hlala_batch** out) { return batch_create_impl(c, in, out, true); }
+
+static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch** out, bool unpaired)
 {
     if(!c || !in || !out) return HLALA_E_ARG;
     *out = nullptr;
     if(in->n_pairs < 0 || in->n_chains < 0) { c->err = "negative batch sizes"; return HLALA_E_ARG; }
     if(!c->d_contig_off) { c->err = "hlala_batch_create needs contigs (hlala_create was called without them)"; return HLALA_E_STATE; }
-    hlala_batch* b = new hlala_batch(); b->ctx = c;
+    hlala_batch* b = new hlala_batch(); b->ctx = c; c->batches.insert(b);
     DevBatch& B = b->B;
-    B.n_pairs = in->n_pairs; B.n_reads = 2 * in->n_pairs; B.n_chains = in->n_chains; B.stride = c->params.max_columns; B.from_seeds = 0;
+    B.n_pairs = in->n_pairs; B.n_reads = (unpaired ? 1 : 2) * in->n_pairs; B.n_chains = in->n_chains; B.stride = c->params.max_columns; B.from_seeds = 0; B.unpaired = unpaired ? 1 : 0;
     int nr = B.n_reads, nc = B.n_chains;
     auto fail = [&](int rc) { hlala_batch_destroy(b); return rc; };
     // validation the reference would assert on
@@ -414,7 +420,7 @@ int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_
 {
     if(!c || !in || !out) return HLALA_E_ARG;
     *out = nullptr;
-    hlala_batch* b = new hlala_batch(); b->ctx = c;
+    hlala_batch* b = new hlala_batch(); b->ctx = c; c->batches.insert(b);
     DevBatch& B = b->B;
     B.n_pairs = 0; B.n_reads = in->n_reads; B.n_chains = in->n_chains; B.stride = c->params.max_columns; B.from_seeds = 1;
     int nr = B.n_reads, nc = B.n_chains; int stride = B.stride;
@@ -460,6 +466,7 @@ void hlala_batch_destroy(hlala_batch* b)
     if(!b) return;
     hlala_ctx* c = b->ctx;
     if(c) {
+        c->batches.erase(b);
         (void)hipStreamSynchronize(c->stream);       // nothing of this batch may still be running when its buffers are handed to the next one
         for(void* p : b->allocs) pool_release(c, p);
     } else for(void* p : b->allocs) if(p) (void)hipFree(p);
@@ -539,7 +546,8 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
     HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
     if(B.n_pairs > 0) {
         int grid = B.n_pairs < c->pair_grid ? B.n_pairs : c->pair_grid;
-        hipLaunchKernelGGL(k_pair_chains, dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);
+        if(B.unpaired) hipLaunchKernelGGL((k_pair_chains<true>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);
+        else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);
         int rc = check_launch(c, "k_pair_chains"); if(rc) return rc;
     }
     HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
@@ -955,7 +963,7 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
     auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
     int rc = 0;
     ExonLocus EL; EL.level_min = L->level_min; EL.level_max = L->level_max; EL.insert_mean = L->insert_mean; EL.insert_sd = L->insert_sd;
-    EL.min_mapq = L->min_mapq; EL.min_weighted_ok = L->min_weighted_ok; EL.level_to_exon = nullptr; EL.pair_mask = nullptr;
+    EL.min_mapq = L->min_mapq; EL.min_weighted_ok = L->min_weighted_ok; EL.level_to_exon = nullptr; EL.pair_mask = nullptr; EL.min_alignment_columns = L->min_alignment_columns;
     int* dL2E = nullptr; uint8_t* dMask = nullptr; int *dCnt = nullptr, *dOff = nullptr, *dOB = nullptr; char* dCub = nullptr;
     if((rc = dev_upload(c, tmp, L->level_to_exon, (size_t)(L->level_max - L->level_min + 1), &dL2E))) return done(rc);
     EL.level_to_exon = dL2E;

@@ -978,11 +978,12 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
             if(err) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = 0.0; atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
             else {
                 B.ext_status[c] = EXT_PENDING;
-                if(sBegin != 0) {                                                      // left extension, extensionAligner.cpp:220-268
+                // long-read / unpaired mode: alignOneLongRead only pads the seed chain (extendToFullSequenceLength, processBAM.cpp:3733-3735)
+                if(!B.unpaired && sBegin != 0) {                                                      // left extension, extensionAligner.cpp:220-268
                     int firstNode = G.edge_from_new[e0]; int lvl = G.node_level[firstNode];
                     if(lvl > 0) { needL = true; itL.item = 2 * c; itL.rOff = rOff; itL.seqLen = seqLen; itL.start_seq = sBegin; itL.startLevel = lvl; itL.startNode = firstNode; itL.pad0 = 0; itL.pad1 = 0; }
                 }
-                if(sEnd != seqLen - 1) {                                               // right extension, :271-319
+                if(!B.unpaired && sEnd != seqLen - 1) {                                // right extension, :271-319
                     int lastNode = G.edge_to_new[e1]; int lvl = G.node_level[lastNode];
                     if(lvl < G.L - 1) { needR = true; itR.item = 2 * c + 1; itR.rOff = rOff; itR.seqLen = seqLen; itR.start_seq = sEnd + 1; itR.startLevel = lvl; itR.startNode = lastNode; itR.pad0 = 0; itR.pad1 = 0; }
                 }

@@ -13,7 +13,7 @@
 
 namespace hlala {
 
-struct ExonLocus { int level_min, level_max; const int* level_to_exon; double insert_mean, insert_sd, min_mapq, min_weighted_ok; const uint8_t* pair_mask; };
+struct ExonLocus { int level_min, level_max; const int* level_to_exon; double insert_mean, insert_sd, min_mapq, min_weighted_ok; const uint8_t* pair_mask; int min_alignment_columns; };
 
 // one mate as the typer sees it
 struct MateAln { int n; const int* lv; const uint8_t* g; const uint8_t* s; const uint8_t* mq; const uint8_t* bases; const uint8_t* quals; int readLen; int first, last; };
@@ -112,6 +112,40 @@ __global__ void k_exon_positions(const DevBatch* __restrict__ Bp, const DevTable
     if(PASS == 1 && cnt[3 * p] == 0) return;
     const int stride = B.stride;
     MateAln a[2];
+    if(B.unpaired) {
+        // one read per unit: oneReadAlignment_2_exonPositions_unpaired (:3568-3930) and the test of :1476; no removeDoublePositionsFromRead
+        const int ch = B.best_chain[p];
+        if(ch < 0 || ch >= B.n_chains) return;
+        const size_t so = (size_t)ch * stride;
+        MateAln& u = a[0];
+        u.n = B.ext_ncols[ch]; u.lv = B.ext_level + so; u.g = B.ext_g + so; u.s = B.ext_s + so; u.mq = B.sel_mapq + (size_t)p * stride;
+        u.bases = B.read_bases + B.read_off[p]; u.quals = B.read_quals + B.read_off[p]; u.readLen = B.read_off[p + 1] - B.read_off[p];
+        u.first = B.ext_firstlast[4 * ch + 0]; u.last = B.ext_firstlast[4 * ch + 2];
+        double w0, f0; int cng0;
+        mate_fractions(u, T, w0, f0, cng0);
+        const bool readOK = (B.mate_mapq[p] >= L.min_mapq) && (u.n >= L.min_alignment_columns);
+        if(PASS == 0) atomicAdd(&okBroken[readOK ? 0 : 1], 1);
+        if(!readOK) return;
+        const int x1 = u.first, x2 = u.last, y1 = L.level_min, y2 = L.level_max;
+        const bool use0 = (x1 != -1) && ((x1 >= y1 && x1 <= y2) || (x2 >= y1 && x2 <= y2) || (y1 >= x1 && y1 <= x2) || (y2 >= x1 && y2 <= x2));
+        PosCursor c0; c0.j = 0; c0.seqIdx = 0; c0.runF = 0;
+        bool h0 = use0 && pos_next(u, L, c0);
+        int nPos = 0, nCh = 0;
+        const int slot = PASS == 1 ? off[3 * p] : 0; int q = PASS == 1 ? off[3 * p + 1] : 0, chOff = PASS == 1 ? off[3 * p + 2] : 0;
+        if(PASS == 1) o.pos_off[slot] = q;
+        while(h0) {
+            if(PASS == 1) emit_position(u, c0, 1, q, chOff, o);
+            q++; chOff += c0.nChars; nPos++; nCh += c0.nChars;
+            h0 = pos_next(u, L, c0);
+        }
+        if(PASS == 0) { if(nPos > 0) { cnt[3 * p] = 1; cnt[3 * p + 1] = nPos; cnt[3 * p + 2] = nCh; } }
+        else {
+            o.read_pair[slot] = p; o.read_weighted_ok[2 * slot] = w0; o.read_weighted_ok[2 * slot + 1] = -1;
+            o.read_fraction_ok[2 * slot] = f0; o.read_fraction_ok[2 * slot + 1] = -1; o.read_distance[slot] = -1;
+            o.read_cols_nongap[2 * slot] = use0 ? cng0 : 0; o.read_cols_nongap[2 * slot + 1] = 0;
+        }
+        return;
+    }
     for(int m = 0; m < 2; m++) {
         const int r = 2 * p + m; const int ch = B.best_chain[r];
         if(ch < 0 || ch >= B.n_chains) return;

@@ -99,6 +99,9 @@ __global__ void k_pair_distances(const DevGraph* __restrict__ Gp, const DevBatch
     out_n[p] = n;
 }
 
+// UNPAIRED: one read per unit (processBAM::alignOneLongRead :3618-3838 selects the first maximum of the chains' log likelihoods;
+// assignMappingQualities_unpaired :3900-4059 is the paired computation with a single, neutral second mate).
+template <bool UNPAIRED>
 __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp)
 {
     const DevGraph& G = *Gp;
@@ -119,8 +122,9 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
         for(int p = p0; p < pEnd; p++) {
         // ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains), error propagation
         int bad = 0;
-        for(int m = 0; m < 2; m++) {
-            int r = 2 * p + m; int c0 = B.chain_off[r], c1 = B.chain_off[r + 1];
+        constexpr int NM = UNPAIRED ? 1 : 2;
+        for(int m = 0; m < NM; m++) {
+            int r = UNPAIRED ? p : 2 * p + m; int c0 = B.chain_off[r], c1 = B.chain_off[r + 1];
             int cnt = 0;
             for(int b0 = c0; b0 < c1; b0 += 64) {
                 int c = b0 + lane; int st = c < c1 ? B.ext_status[c] : 1;
@@ -133,17 +137,18 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
             if(cnt < 1 || cnt > PAIR_CHAINS) bad = 1;
         }
         WSYNC();
-        const int n1 = uni(P.nlist[0]), n2 = uni(P.nlist[1]);
+        const int n1 = uni(P.nlist[0]), n2 = UNPAIRED ? 1 : uni(P.nlist[1]);
         bad = uni(bad);
         const long long nCombLL = (long long)n1 * n2;
         if(!bad && nCombLL > PAIR_COMB) bad = 1;
         if(bad) {
-            if(lane == 0) { B.pair_status[p] = -1; B.best_chain[2 * p] = -1; B.best_chain[2 * p + 1] = -1; B.n_comb[p] = 0; }
+            if(lane == 0) { B.pair_status[p] = -1; if(UNPAIRED) B.best_chain[p] = -1; else { B.best_chain[2 * p] = -1; B.best_chain[2 * p + 1] = -1; } B.n_comb[p] = 0; }
         } else {
         const int nComb = (int)nCombLL;
         // ---- combination log likelihoods, row-major (i1, i2) (:3408-3506)
         for(int i = lane; i < nComb; i += 64) {
             int i1 = i / n2, i2 = i % n2;
+            if(UNPAIRED) { P.LL[i] = B.ext_ll[P.list[0][i1]]; continue; }                                             // read1_extendedChains_log_likelihoods, :3743
             int ca = P.list[0][i1], cb = P.list[1][i2];
             const int* fa = B.ext_firstlast + 4 * ca; const int* fb = B.ext_firstlast + 4 * cb;
             bool ra = B.chain_reverse[ca] != 0, rb = B.chain_reverse[cb] != 0;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
         for(int i = lane; i < nComb; i += 64) { double v = P.LL[i]; if(v > mx) { mx = v; mi = i; } }
         for(int o = 32; o; o >>= 1) { double ov = __shfl_xor(mx, o); int oi = __shfl_xor(mi, o); if(ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; } }
         const int bestI = uni(mi), best1 = bestI / n2, best2 = bestI % n2;
-        const int selA = uni(P.list[0][best1]), selB = uni(P.list[1][best2]);
+        const int selA = uni(P.list[0][best1]), selB = UNPAIRED ? selA : uni(P.list[1][best2]);
         // ---- posterior over combinations (:4064-4085): exp(LL - max), normalised by a left-to-right sum
         double mapQ = 1, q1 = 1, q2 = 1;
         if(nComb > 1) {
@@ -185,16 +190,19 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
             mapQ = P.LL[bestI]; q1 = P.red[1]; q2 = P.red[2];
         }
         if(lane == 0) {
-            B.pair_status[p] = 0; B.best_chain[2 * p] = selA; B.best_chain[2 * p + 1] = selB; B.n_comb[p] = nComb;
-            B.pair_ll[p] = mx; B.pair_mapq[p] = mapQ; B.mate_mapq[2 * p] = q1; B.mate_mapq[2 * p + 1] = q2;
+            B.pair_status[p] = 0; B.n_comb[p] = nComb; B.pair_ll[p] = mx; B.pair_mapq[p] = mapQ;
+            if(UNPAIRED) { B.best_chain[p] = selA; B.mate_mapq[p] = mapQ; B.strands_valid[p] = 0; }                       // forReturn.mapQ = mapQ, :3921
+            else {
+            B.best_chain[2 * p] = selA; B.best_chain[2 * p + 1] = selB; B.mate_mapq[2 * p] = q1; B.mate_mapq[2 * p + 1] = q2;
             const int* fa = B.ext_firstlast + 4 * selA; const int* fb = B.ext_firstlast + 4 * selB;
             bool ra = B.chain_reverse[selA] != 0, rb = B.chain_reverse[selB] != 0; bool valid = false;
             if(fa[0] != -1 && fb[0] != -1 && ra != rb) valid = (!ra) ? (fa[0] < fb[0]) : (fa[2] > fb[2]);
             B.strands_valid[p] = valid ? 1 : 0;
+            }
         }
         // ---- per-position mapping quality of the selected chains (:4155-4311)
-        for(int m = 0; m < 2; m++) {
-            const int sel = m ? selB : selA; const int r = 2 * p + m;
+        for(int m = 0; m < NM; m++) {
+            const int sel = m ? selB : selA; const int r = UNPAIRED ? p : 2 * p + m;
             const int nSel = uni(B.ext_ncols[sel]); const size_t sb = (size_t)sel * stride; const size_t ob = (size_t)r * stride;
             if(nComb == 1) {
                 unsigned char ph = phred_from_pcorrect(T, 1.0);
@@ -278,8 +286,9 @@ __global__ __launch_bounds__(64) void k_post_pairs(const DevBatch* __restrict__ 
         for(int p = p0; p < pEnd; p++) {
             bool inc = false;
             if(uni(B.pair_status[p]) == 0) {
-                for(int m = 0; m < 2; m++) {
-                    const int ch = uni(B.best_chain[2 * p + m]);
+                const int nm = B.unpaired ? 1 : 2;
+                for(int m = 0; m < nm; m++) {
+                    const int ch = uni(B.best_chain[B.unpaired ? p : 2 * p + m]);
                     if(ch < 0 || ch >= B.n_chains) continue;
                     const int n = uni(B.ext_ncols[ch]);
                     const size_t so = (size_t)ch * stride;
@@ -329,6 +338,7 @@ __global__ void k_export_pairs(const DevBatch* __restrict__ Bp, double* out)
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if(p >= B.n_pairs) return;
     double* o = out + 8 * (size_t)p;
+    if(B.unpaired) { o[0] = B.pair_status[p]; o[1] = B.best_chain[p]; o[2] = -1; o[3] = B.n_comb[p]; o[4] = B.pair_ll[p]; o[5] = B.pair_mapq[p]; o[6] = B.mate_mapq[p]; o[7] = 0; return; }
     o[0] = B.pair_status[p]; o[1] = B.best_chain[2 * p]; o[2] = B.best_chain[2 * p + 1]; o[3] = B.n_comb[p];
     o[4] = B.pair_ll[p]; o[5] = B.pair_mapq[p]; o[6] = B.mate_mapq[2 * p]; o[7] = B.mate_mapq[2 * p + 1];
 }

@@ -191,9 +191,17 @@ typedef struct {
 
 /* Upload a batch: inputs become resident in HBM; nothing is computed.                       */
 int  hlala_batch_create(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** out);
+/* Long-read / unpaired mode (processBAM::alignOneLongRead, mapper/processBAM.cpp:3618-3838, and
+ * assignMappingQualities_unpaired, :3900-4059): `in->n_pairs` is the number of READS, every array that is per read
+ * has one entry per unit (read_off[n+1], chain_off[n+1], read_primary[n]).  hlala_align_batch then projects every
+ * alignment that passes the strand / duplicate filters, pads it to the full read (no extension DP: :3733-3735),
+ * scores it (long-read rates if params.long_read_mode), selects the first maximum and assigns the unpaired mapping
+ * qualities.  hlala_pairs_out arrays are per unit: [n] where the paired layout has [2n].  The column capacity of this
+ * build (params.max_columns <= 512) bounds the read length; longer reads are flagged HLALA_CHAIN_ERR_COLUMNS.       */
+int  hlala_batch_create_unpaired(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** out);
 /* Upload seed chains directly (stage A is then not available on this batch).                */
 int  hlala_batch_create_from_seeds(hlala_ctx* ctx, const hlala_seeds_in* in, hlala_batch** out);
-/* Destroy batches before their context.  The device buffers are parked in the context and reused by the next batch
+/* The device buffers are parked in the context and reused by the next batch (a batch that outlives its context frees them itself)
  * of similar size (allocating the column arrays of a 1 M-pair batch costs about a second otherwise).                 */
 void hlala_batch_destroy(hlala_batch* b);
 
@@ -306,7 +314,10 @@ int  hlala_pair_loglik(hlala_ctx* ctx, const double* LL, const int32_t* mism, in
  * <= 5 sd, mapQ of mate 1 >= min_mapq, both weighted-OK fractions >= min_weighted_ok) and at least one of its columns lies on an exon
  * level; positions come out as the reference's std::map order (ascending graph level, one per level: the alternative with the best
  * worst-quality, first wins).  Reads are taken in alignment orientation (read_bases / read_quals of the batch), which is the base the
- * reference reaches through its reverse-index arithmetic (:3307-3321).                                                            */
+ * reference reaches through its reverse-index arithmetic (:3307-3321).
+ * On an UNPAIRED batch (hlala_batch_create_unpaired) the unit is a read: oneReadAlignment_2_exonPositions_unpaired (:3568-3930) and the
+ * test of :1476 (mapQ >= min_mapq and at least min_alignment_columns alignment columns); the "mate 2" halves of the per-read arrays
+ * hold -1 (pairedRead_* = -1, :3574-3580) and read_distance is -1.                                                                */
 typedef struct {
     int32_t        level_min, level_max; /* combined_exon_sequences_graphLevels_min / _max                                  */
     const int32_t* level_to_exon;        /* [level_max - level_min + 1] graphLevel_2_exonPosition; -1 = not an exon level   */
@@ -314,6 +325,8 @@ typedef struct {
     double         min_mapq;             /* minimumMappingQuality (0.0, HLATyper.cpp:30)                                    */
     double         min_weighted_ok;      /* min_bothReads_weightedCharactersOK (0.0, HLATyper.cpp:28)                       */
     const uint8_t* pair_mask;            /* [n_pairs] or NULL: only pairs with a non-zero entry are looked at (includeInHLA) */
+    int32_t        min_alignment_columns;/* unpaired batches only: minAlignmentLength_unpaired (1000, HLATyper.cpp:1032, test at :1476) */
+    int32_t        reserved;
 } hlala_locus_desc;
 
 typedef struct {

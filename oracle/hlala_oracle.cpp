@@ -1371,6 +1371,88 @@ int orc_align_batch(orc_handle* h, const hlala_batch_in* in, hlala_chains_out* s
     } catch(std::exception& e) { g_err = e.what(); return -1; }
 }
 
+/* processBAM::alignOneLongRead (mapper/processBAM.cpp:3618-3838) + assignMappingQualities_unpaired (:3900-4059) for a batch of single
+ * reads: in->n_pairs READS, per-read arrays have one entry per read.  pairs_out is filled per read ([n] where the paired layout has [2n]). */
+int orc_align_long_reads(orc_handle* h, const hlala_batch_in* in, hlala_chains_out* seeds_out, hlala_chains_out* ext_out, hlala_pairs_out* pairs_out)
+{
+    try {
+        Processor& P = h->P;
+        Aligner& A = *P.eA;
+        int stride = P.params.max_columns;
+        bool longRead = P.params.long_read_mode != 0;
+        for(int r = 0; r < in->n_pairs; r++) {
+            std::string seq((const char*)in->read_bases + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
+            std::string qual((const char*)in->read_quals + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
+            int prim = in->read_primary[r];
+            bool primReverse = in->chain_reverse[prim] != 0;
+            std::string oseq = primReverse ? invertRead(seq, true) : seq;                        /* r1.invert(), :3636-3639 */
+            std::string oqual = primReverse ? invertRead(qual, false) : qual;
+            std::vector<Chain> read1_extendedChains; std::vector<double> read1_extendedChains_log_likelihoods; std::vector<int> extIdx;
+            std::map<std::string, int> read1_alignments_scores;
+            bool err = false;
+            for(int c = in->chain_off[r]; c < in->chain_off[r + 1]; c++) {
+                BamRecord al; al.contig = in->chain_contig[c]; al.pos = in->chain_pos[c]; al.offset = in->chain_offset[c];
+                al.as = in->chain_as[c]; al.reverse = in->chain_reverse[c] != 0;
+                al.cigar.assign(in->cigar + in->cigar_off[c], in->cigar + in->cigar_off[c + 1]);
+                std::pair<int, int> ss = P.startstop(al);
+                std::string id = std::to_string(ss.first) + "//" + std::to_string(ss.second);
+                int score = al.as;
+                if(al.reverse != primReverse) {                                                     /* :3685 */
+                    storeChain(Chain(), c, stride, seeds_out, HLALA_CHAIN_SKIP_STRAND); storeChain(Chain(), c, stride, ext_out, HLALA_CHAIN_SKIP_STRAND);
+                    continue;
+                }
+                ContigAlignment ca;
+                bool ok = P.transformBAMreadToInternalAlignment(al, seq, ca);
+                ORC_CHECK(ok, "alignment consists of insertions only");
+                Chain al_Chain = P.PRGContigAlignment2Seed(ca, true);                                /* alignment2Chain, :3694 */
+                if(read1_alignments_scores.count(id) && (read1_alignments_scores.at(id) >= score)) {  /* :3705 */
+                    storeChain(Chain(), c, stride, seeds_out, HLALA_CHAIN_SKIP_DUP); storeChain(Chain(), c, stride, ext_out, HLALA_CHAIN_SKIP_DUP);
+                    continue;
+                }
+                al_Chain.checkConcordance(seq);
+                storeChain(al_Chain, c, stride, seeds_out, HLALA_CHAIN_OK);
+                Chain al_Chain_extended = al_Chain;
+                al_Chain_extended.extendToFull(seq);                                                  /* :3734-3735, no extension DP */
+                al_Chain_extended.checkConcordance(seq);
+                al_Chain_extended.ll = A.scoreOneAlignment(al_Chain_extended, oseq, oqual, longRead);
+                storeChain(al_Chain_extended, c, stride, ext_out, HLALA_CHAIN_OK);
+                if((int)al_Chain_extended.size() > stride) err = true;
+                read1_extendedChains.push_back(al_Chain_extended); read1_extendedChains_log_likelihoods.push_back(al_Chain_extended.ll); extIdx.push_back(c);
+                if((read1_alignments_scores.count(id) == 0) || (read1_alignments_scores.at(id) < score)) read1_alignments_scores[id] = score;
+            }
+            if(!pairs_out) continue;
+            ORC_CHECK(read1_extendedChains.size() > 0, "no chains for a read");                      /* :3768 */
+            auto mx = firstMax(read1_extendedChains_log_likelihoods);                               /* findVectorMax, :3770 */
+            /* assignMappingQualities_unpaired == the paired routine with one neutral second mate */
+            std::vector<std::pair<unsigned, unsigned>> idx; for(unsigned i = 0; i < read1_extendedChains.size(); i++) idx.push_back({i, 0u});
+            std::vector<Chain> dummy(1);
+            Processor::PairResult R; R.best1 = mx.second; R.best2 = 0; R.nComb = (int)idx.size(); R.ll = mx.first;
+            R.c1 = read1_extendedChains[mx.second];
+            P.assignMappingQualities(R, idx, read1_extendedChains_log_likelihoods, mx, read1_extendedChains, dummy);
+            if(pairs_out->pair_status) pairs_out->pair_status[r] = err ? -1 : 0;
+            if(pairs_out->best_chain) pairs_out->best_chain[r] = extIdx[R.best1];
+            if(pairs_out->n_combinations) pairs_out->n_combinations[r] = R.nComb;
+            if(pairs_out->pair_ll) pairs_out->pair_ll[r] = R.ll;
+            if(pairs_out->pair_mapq) pairs_out->pair_mapq[r] = R.mapQ;
+            if(pairs_out->mate_mapq) pairs_out->mate_mapq[r] = R.mapQ;                               /* forReturn.mapQ = mapQ, :3921 */
+            if(pairs_out->strands_valid) pairs_out->strands_valid[r] = 0;
+            const Chain& cc = R.c1; int n = (int)cc.size();
+            if(n > stride) { if(pairs_out->n_cols) pairs_out->n_cols[r] = 0; continue; }
+            if(pairs_out->n_cols) pairs_out->n_cols[r] = n;
+            size_t base = (size_t)r * stride;
+            for(int j = 0; j < n; j++) {
+                if(pairs_out->col_level) pairs_out->col_level[base + j] = cc.levels[j];
+                if(pairs_out->col_edge) pairs_out->col_edge[base + j] = cc.edges[j];
+                if(pairs_out->col_gchar) pairs_out->col_gchar[base + j] = (uint8_t)cc.graph_aligned[j];
+                if(pairs_out->col_schar) pairs_out->col_schar[base + j] = (uint8_t)cc.sequence_aligned[j];
+                if(pairs_out->col_fromseed) pairs_out->col_fromseed[base + j] = cc.is_from_BWAseed[j];
+                if(pairs_out->col_mapq) pairs_out->col_mapq[base + j] = (uint8_t)cc.mapQ_perPosition[j];
+            }
+        }
+        return 0;
+    } catch(std::exception& e) { g_err = e.what(); return -1; }
+}
+
 /* processBAM::calculateInsertSizeFromHistogram, mapper/processBAM.cpp:991-1069 */
 static int calculateInsertSizeFromHistogram(const std::map<int, double>& IS_combined_counts, double& mean, double& sd, double& total)
 {
@@ -1713,6 +1795,53 @@ int orc_exon_positions(int n_pairs, int stride, const int32_t* pair_status, cons
                     }
                 }
                 nReads++; nPos += (int)cleaned.size(); nChars += (int)chars;
+            }
+            o->n_pairs_ok++;
+        } else o->n_pairs_broken++;
+    }
+    o->n_reads = nReads; o->n_pos = nPos; o->n_chars = nChars;
+    if(overflow) return -100;
+    o->pos_off[nReads] = nPos; o->geno_off[nPos] = nChars;
+    return 0;
+}
+
+// The unpaired-read part of the per-locus loop, hla/HLATyper.cpp:1470-1493 with oneReadAlignment_2_exonPositions_unpaired (:3568-3930: the paired
+// routine without the mate; pairedRead_* = -1, pairs_strands_distance = -1).  Arrays are per read ([n] where the paired layout has [2n]).
+int orc_exon_positions_unpaired(int n_reads, int stride, const int32_t* pair_status, const int32_t* n_cols, const int32_t* col_level, const uint8_t* col_gchar,
+                                const uint8_t* col_schar, const uint8_t* col_mapq, const double* mate_mapq,
+                                const int32_t* read_off, const uint8_t* read_bases, const uint8_t* read_quals,
+                                const hlala_locus_desc* L, hlala_exon_positions_out* o)
+{
+    int nReads = 0, nPos = 0, nChars = 0; bool overflow = false;
+    o->n_pairs_ok = 0; o->n_pairs_broken = 0;
+    for(int r = 0; r < n_reads; r++) {
+        if(L->pair_mask && !L->pair_mask[r]) continue;
+        if(pair_status[r] != 0) continue;
+        TyperAln a;
+        a.n = n_cols[r]; a.lv = col_level + (size_t)r * stride; a.g = col_gchar + (size_t)r * stride; a.s = col_schar + (size_t)r * stride; a.mq = col_mapq + (size_t)r * stride;
+        a.bases = read_bases + read_off[r]; a.quals = read_quals + read_off[r]; a.readLen = read_off[r + 1] - read_off[r]; a.mapQ = mate_mapq[r];
+        std::vector<ExonPos> read_exonPositions; int cng = 0;
+        int rc = oneReadAlignment_2_exonPositions(a, 1, read_exonPositions, L->level_min, L->level_max, L->level_to_exon, cng); if(rc) return rc;
+        double w; if((rc = alignmentWeightedOKFraction(a, w))) return rc;
+        double mapQ_thisAlignment = a.mapQ;
+        if((mapQ_thisAlignment >= L->min_mapq) && (a.n >= L->min_alignment_columns)) {               // :1476
+            if(read_exonPositions.size() > 0) {                                                       // pushed as they are: no removeDoublePositionsFromRead, :1481-1485
+                size_t chars = 0; for(auto& e : read_exonPositions) chars += e.genotype.size();
+                if(nReads + 1 > o->cap_reads || nPos + (int)read_exonPositions.size() > o->cap_pos || nChars + (int)chars > o->cap_chars) overflow = true;
+                if(!overflow) {
+                    o->read_pair[nReads] = r; o->read_weighted_ok[2 * nReads] = w; o->read_weighted_ok[2 * nReads + 1] = -1;
+                    o->read_fraction_ok[2 * nReads] = alignmentFractionOK(a); o->read_fraction_ok[2 * nReads + 1] = -1;
+                    o->read_distance[nReads] = -1; o->read_cols_nongap[2 * nReads] = cng; o->read_cols_nongap[2 * nReads + 1] = 0;
+                    o->pos_off[nReads] = nPos;
+                    int q = nPos, ch = nChars;
+                    for(auto& e : read_exonPositions) {
+                        o->pos_exon[q] = e.positionInExon; o->pos_level[q] = e.graphLevel; o->pos_mate[q] = 1; o->pos_mapq[q] = e.mapqChar; o->pos_novel_gap[q] = e.novelGap;
+                        o->geno_off[q] = ch;
+                        for(size_t k = 0; k < e.genotype.size(); k++) { o->geno_chars[ch] = (uint8_t)e.genotype[k]; o->qual_chars[ch] = k < e.qualities.size() ? (uint8_t)e.qualities[k] : 0; ch++; }
+                        q++;
+                    }
+                }
+                nReads++; nPos += (int)read_exonPositions.size(); nChars += (int)chars;
             }
             o->n_pairs_ok++;
         } else o->n_pairs_broken++;

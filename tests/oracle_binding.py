@@ -36,6 +36,7 @@ def lib():
         _lib.orc_pair_loglik.argtypes = [P.c_f64p, P.c_i32p, C.c_int, C.c_int, P.c_f64p, P.c_f64p, P.c_f64p]
         _lib.orc_normal_logpdf_penalty.argtypes = [C.c_double, C.c_double]
         _lib.orc_normal_logpdf_penalty.restype = C.c_double
+        _lib.orc_align_long_reads.argtypes = [vp, C.POINTER(P.BatchIn), C.POINTER(P.ChainsOut), C.POINTER(P.ChainsOut), C.POINTER(P.PairsOut)]
         _lib.orc_estimate_insert_size.argtypes = [vp, C.POINTER(P.BatchIn), C.POINTER(P.InsertSizeOut)]
         _lib.orc_insert_size_from_histogram.argtypes = [C.c_int, P.c_i32p, P.c_f64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return _lib
@@ -120,6 +121,15 @@ class Oracle:
                                           int(stop_after_projection), stats.ctypes.data_as(P.c_i64p)))
         return dict(seeds=sd, ext=ed, pairs=pd, stats=stats)
 
+    def align_long_reads(self, batch_in):
+        """alignOneLongRead per read of an unpaired batch (n_pairs = number of reads)."""
+        s, keep = P.fill_struct(P.BatchIn, batch_in)
+        so, sd = P.alloc_chains_out(batch_in["n_chains"], self.max_columns)
+        eo, ed = P.alloc_chains_out(batch_in["n_chains"], self.max_columns)
+        po, pd = P.alloc_pairs_out(batch_in["n_pairs"], self.max_columns)
+        self._check(lib().orc_align_long_reads(self.h, C.byref(s), C.byref(so), C.byref(eo), C.byref(po)))
+        return dict(seeds=sd, ext=ed, pairs=pd)
+
     def estimate_insert_size(self, batch_in):
         s, keep = P.fill_struct(P.BatchIn, batch_in)
         o = P.InsertSizeOut()
@@ -169,10 +179,10 @@ def call_locus(pairLL, misAvg, misMin):
                 first_marginal=out.first_marginal, second_p=out.second_p, ll_max=out.ll_max, max_pair=out.max_pair, n_sort_ties=out.n_sort_ties)
 
 
-def exon_positions(pairs, batch, stride, level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None):
+def exon_positions(pairs, batch, stride, level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None, unpaired=False, min_alignment_columns=1000):
     """orc_exon_positions on the `pairs` dict of Oracle.align_batch and the reads of `batch` (hla/HLATyper.cpp:1385-1428)."""
     l = lib()
-    L, keep = P.make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq, min_weighted_ok, pair_mask)
+    L, keep = P.make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq, min_weighted_ok, pair_mask, min_alignment_columns)
     n = int(batch["n_pairs"])
     o, d = P.alloc_exon_positions_out(n, 2 * n * stride, 4 * n * stride)
     a = dict(st=np.ascontiguousarray(pairs["pair_status"], np.int32), nc=np.ascontiguousarray(pairs["n_cols"], np.int32),
@@ -182,6 +192,14 @@ def exon_positions(pairs, batch, stride, level_min, level_to_exon, insert_mean, 
              ro=np.ascontiguousarray(batch["read_off"], np.int32), rb=np.ascontiguousarray(batch["read_bases"], np.uint8), rq=np.ascontiguousarray(batch["read_quals"], np.uint8))
     l.orc_exon_positions.argtypes = [C.c_int, C.c_int, P.c_i32p, P.c_i32p, P.c_i32p, P.c_u8p, P.c_u8p, P.c_u8p, P.c_f64p, P.c_u8p, P.c_i32p, P.c_u8p, P.c_u8p,
                                      C.POINTER(P.LocusDesc), C.POINTER(P.ExonPositionsOut)]
+    if unpaired:
+        l.orc_exon_positions_unpaired.argtypes = [C.c_int, C.c_int, P.c_i32p, P.c_i32p, P.c_i32p, P.c_u8p, P.c_u8p, P.c_u8p, P.c_f64p, P.c_i32p, P.c_u8p, P.c_u8p,
+                                                  C.POINTER(P.LocusDesc), C.POINTER(P.ExonPositionsOut)]
+        rc = l.orc_exon_positions_unpaired(n, stride, a["st"].ctypes.data_as(P.c_i32p), a["nc"].ctypes.data_as(P.c_i32p), a["lv"].ctypes.data_as(P.c_i32p),
+                                           a["g"].ctypes.data_as(P.c_u8p), a["s"].ctypes.data_as(P.c_u8p), a["mq"].ctypes.data_as(P.c_u8p), a["mm"].ctypes.data_as(P.c_f64p),
+                                           a["ro"].ctypes.data_as(P.c_i32p), a["rb"].ctypes.data_as(P.c_u8p), a["rq"].ctypes.data_as(P.c_u8p), C.byref(L), C.byref(o))
+        assert rc == 0, rc
+        return P.trim_exon_positions(o, d)
     rc = l.orc_exon_positions(n, stride, a["st"].ctypes.data_as(P.c_i32p), a["nc"].ctypes.data_as(P.c_i32p), a["lv"].ctypes.data_as(P.c_i32p),
                               a["g"].ctypes.data_as(P.c_u8p), a["s"].ctypes.data_as(P.c_u8p), a["mq"].ctypes.data_as(P.c_u8p), a["mm"].ctypes.data_as(P.c_f64p),
                               a["sv"].ctypes.data_as(P.c_u8p), a["ro"].ctypes.data_as(P.c_i32p), a["rb"].ctypes.data_as(P.c_u8p), a["rq"].ctypes.data_as(P.c_u8p),

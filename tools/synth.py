@@ -399,3 +399,10 @@ def make_locus(seed=5, n_clusters=200, exon_length=546, n_reads=300, snp_density
                 pos_off=np.asarray(pos_off, np.int32), pos_exon=np.asarray(pe, np.int32), pos_g0=np.asarray(g0, np.uint8),
                 pos_glen=np.asarray(gl, np.int32), pos_qual=np.asarray(q, np.uint8), pos_use=np.asarray(use, np.uint8),
                 truth=truth)
+
+
+def as_unpaired(b):
+    """View a paired batch as 2 n_pairs single reads (long-read / unpaired mode input: n_pairs = number of reads)."""
+    u = dict(b)
+    u["n_pairs"] = 2 * int(b["n_pairs"])
+    return u
