@@ -151,7 +151,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "graph_levels": args.levels, "parallelism": f"shard{world}",
                        "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
-                       "dp_cells_per_s": st.n_dp_cells / ext_s, "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
+                       "dp_cells_per_s": st.n_dp_cells / ((st.ms_dp_main + st.ms_extend_retry) * 1e-3), "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
                        "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "extend_dp_16lane_kernel": st.ms_dp_main,
                                     "extend_dp_retry_classes": st.ms_extend_retry, "pair": st.ms_pair},
                        "dp_calls_retried_wider_class": int(st.n_chains_retried), "dp_calls_retried_large_class": int(st.n_dp_retried_large),
