@@ -174,6 +174,41 @@ def filter_positions(lib, e, params=None):
     return use[:o.n_pos], ign[:o.n_reads], {k: int(getattr(st, k)) for k, _ in FilterStats._fields_}
 
 
+def _graph_from_handle(lib, h):
+    d = GraphDesc()
+    lib.hlala_graph_file_desc.argtypes = [C.c_void_p, C.POINTER(GraphDesc)]
+    if lib.hlala_graph_file_desc(h, C.byref(d)) != 0:
+        raise HlalaError("hlala_graph_file_desc failed")
+    g = dict(n_levels=d.n_levels, n_nodes=d.n_nodes, n_edges=d.n_edges,
+             node_level=np.ctypeslib.as_array(d.node_level, (d.n_nodes,)).copy(), edge_from=np.ctypeslib.as_array(d.edge_from, (max(d.n_edges, 1),))[:d.n_edges].copy(),
+             edge_to=np.ctypeslib.as_array(d.edge_to, (max(d.n_edges, 1),))[:d.n_edges].copy(), edge_label=np.ctypeslib.as_array(d.edge_label, (max(d.n_edges, 1),))[:d.n_edges].copy())
+    lib.hlala_graph_file_free.argtypes = [C.c_void_p]; lib.hlala_graph_file_free.restype = None
+    lib.hlala_graph_file_free(h)
+    return g
+
+
+def load_graph_text(lib, path):
+    """PRG/graph.txt -> graph dict (hlala_graph_load_text)."""
+    h = C.c_void_p(); lib.hlala_graph_load_text.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]; lib.hlala_loader_last_error.restype = C.c_char_p
+    if lib.hlala_graph_load_text(str(path).encode(), C.byref(h)) != 0:
+        raise HlalaError(lib.hlala_loader_last_error().decode())
+    return _graph_from_handle(lib, h)
+
+
+def save_graph_cache(lib, graph, path):
+    s, keep = fill_struct(GraphDesc, graph)
+    lib.hlala_graph_cache_save.argtypes = [C.POINTER(GraphDesc), C.c_char_p]; lib.hlala_loader_last_error.restype = C.c_char_p
+    if lib.hlala_graph_cache_save(C.byref(s), str(path).encode()) != 0:
+        raise HlalaError(lib.hlala_loader_last_error().decode())
+
+
+def load_graph_cache(lib, path):
+    h = C.c_void_p(); lib.hlala_graph_cache_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]; lib.hlala_loader_last_error.restype = C.c_char_p
+    if lib.hlala_graph_cache_load(str(path).encode(), C.byref(h)) != 0:
+        raise HlalaError(lib.hlala_loader_last_error().decode())
+    return _graph_from_handle(lib, h)
+
+
 def exon_in_from_positions(e, pos_use, cluster_seq, n_clusters, exon_length):
     """hlala_exon_in (input of hlala_exon_loglik) from the outputs of hlala_exon_positions and hlala_filter_positions: the likelihood loop
     reads the first genotype character, the genotype length and the first quality of every position (hla/HLATyper.cpp:2080-2277)."""
@@ -314,7 +349,8 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
-    "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size",
+    "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
+    "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
 ]
 
 

@@ -251,6 +251,22 @@ typedef struct {
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 
 /* ------------------------------------------------------------------------------------------
+ * Graph files (host code, no context needed).  hlala_graph_load_text parses PRG/graph.txt in the format of
+ * Graph::writeToFile / Graph::readFromFile (Graph/Graph.cpp:2225-2327 / :2329-2545; allele codes:
+ * Graph/LocusCodeAllocation.cpp:264-312, deCode :32-48); nodes and edges keep their order in the file, node indices are
+ * renumbered 0.. in that order.  hlala_graph_cache_save / _load keep the same arrays in a binary file: loading is a few
+ * reads instead of minutes of text (or Boost archive) parsing.  hlala_graph_file_desc fills a descriptor that points into
+ * the handle (valid until hlala_graph_file_free); hlala_loader_last_error holds the text of the last failure.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hlala_graph_file hlala_graph_file;
+int  hlala_graph_load_text(const char* path, hlala_graph_file** out);
+int  hlala_graph_cache_save(const hlala_graph_desc* graph, const char* path);
+int  hlala_graph_cache_load(const char* path, hlala_graph_file** out);
+int  hlala_graph_file_desc(const hlala_graph_file* g, hlala_graph_desc* desc);
+void hlala_graph_file_free(hlala_graph_file* g);
+const char* hlala_loader_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
  * Insert-size estimation (processBAM::estimateInsertSize, mapper/processBAM.cpp:1071-1165, and
  * calculateInsertSizeFromHistogram :991-1069) on the kernels of stages A and B: for every pair of `in` the PRIMARY
  * alignment of mate 1 and of mate 2 (read_primary) is projected and extended; if the strands are valid every
