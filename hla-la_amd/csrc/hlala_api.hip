@@ -55,6 +55,7 @@ struct hlala_ctx {
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
+    char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
     hipEvent_t ev[9]{};           // start/end per stage; [7] / [6] / [8] = before DpTiny / after DpTiny / after the retry classes
     int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
     // per-pair post-processing: coverage counters [L-1] and gene intervals
@@ -244,7 +245,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     FlatGraph& F = c->F;
     if(F.N >= (1 << 28) || F.L >= (1 << 24)) { c->err = "graph exceeds 2^28 nodes or 2^24 levels (DP cell key layout)"; return fail(HLALA_E_CAPACITY); }
     if(F.max_nodes_per_level > PROJ_NODES) { c->err = "more nodes in one level than this build holds in LDS (PROJ_NODES)"; return fail(HLALA_E_CAPACITY); }
-    if(c->params.max_columns > PROJ_CAP || c->params.max_columns > PAIR_COLS) { c->err = "params.max_columns exceeds the LDS column capacity of this build (512)"; return fail(HLALA_E_ARG); }
+    if(c->params.max_columns > PROJL_CAP) { c->err = "params.max_columns exceeds the column capacity of this build (16384)"; return fail(HLALA_E_ARG); }
     DevGraph& G = c->G;
     G.L = F.L; G.N = F.N; G.E = F.E; G.P = (int)F.path_len.size();
     std::vector<uint8_t> edge_label(graph->edge_label, graph->edge_label + graph->n_edges);
@@ -295,6 +296,12 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->ext_slabs);
     c->proj_grid = cus * 9; c->pair_grid = cus * 14;
+    if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
+        c->proj_grid = cus * 4;
+        c->proj_long_slab_bytes = proj_long_slab_bytes();
+        if(hipMalloc((void**)&c->proj_long_slabs, c->proj_long_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(long-read projection slabs) failed"; return fail(HLALA_E_DEVICE); }
+        c->allocs.push_back(c->proj_long_slabs);
+    }
     c->proj_slab_bytes = proj_slab_bytes_host(c->params.max_columns, F.max_nodes_per_level);
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
@@ -492,8 +499,12 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
         int threads = 256, blocks = (B.n_reads + threads - 1) / threads;
         hipLaunchKernelGGL(k_filter_chains, dim3(blocks), dim3(threads), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_level);
         int grid = B.n_chains < c->proj_grid ? B.n_chains : c->proj_grid;
-        hipLaunchKernelGGL(k_project_chains, dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
-                           c->proj_slabs, c->proj_slab_bytes);
+        if(c->proj_long_slabs)
+            hipLaunchKernelGGL((k_project_chains<ProjLdsLong>), dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
+                               c->proj_slabs, c->proj_slab_bytes, c->proj_long_slabs, c->proj_long_slab_bytes);
+        else
+            hipLaunchKernelGGL((k_project_chains<ProjLds>), dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
+                               c->proj_slabs, c->proj_slab_bytes, (char*)nullptr, (size_t)0);
         int rc = check_launch(c, "k_project_chains"); if(rc) return rc;
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));

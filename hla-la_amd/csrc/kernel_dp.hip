@@ -969,7 +969,7 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
             const size_t cb = (size_t)c * stride;
             const int nSeed = B.seed_ncols[c], sBegin = B.seed_begin[c], sEnd = B.seed_end[c];
             int err = 0;
-            if(seqLen > DP_SEQCAP || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;
+            if((!B.unpaired && seqLen > DP_SEQCAP) || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;     // DP_SEQCAP bounds the DP only
             int e0 = -1, e1 = -1;
             if(!err) {
                 e0 = B.seed_edge[cb]; e1 = B.seed_edge[cb + nSeed - 1];
@@ -1192,44 +1192,49 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
         {
             // phase 1 (parallel): every lane turns its <= 8 consecutive columns into two addends each (an unused addend is +0.0,
             // an exact identity); phase 2 (serial by construction of FP addition): the running sum walks the lanes in order.
-            constexpr int LLPER = 8;                                   // 64 * 8 = 512 >= params.max_columns
-            const int per = (total + 63) / 64;
-            const int j0 = lane * per, j1 = min(total, j0 + per);
-            unsigned char scv[LLPER], gcv[LLPER];
-            int nb = 0;
-#pragma unroll
-            for(int k = 0; k < LLPER; k++) {
-                int j = j0 + k; bool in = k < per && j < j1;
-                scv[k] = in ? B.ext_s[cb + j] : (unsigned char)'_'; gcv[k] = in ? B.ext_g[cb + j] : (unsigned char)'_';
-                if(in && scv[k] != '_') nb++;
-            }
-            int tot; int before = wave_excl_scan(nb, tot);
-            double t1[LLPER], t2[LLPER];
-            {
-                int idx = before;
+            constexpr int LLPER = 8;                                   // 64 lanes * 8 columns per round; long reads take several rounds
+            double carry = 0.0; int baseIdx = 0;                       // running sum / read bases consumed before this round
+            for(int c0 = 0; c0 < total; c0 += 64 * LLPER) {
+                const int chunk = min(64 * LLPER, total - c0);
+                const int per = (chunk + 63) / 64;
+                const int j0 = c0 + lane * per, j1 = min(c0 + chunk, j0 + per);
+                unsigned char scv[LLPER], gcv[LLPER];
+                int nb = 0;
 #pragma unroll
                 for(int k = 0; k < LLPER; k++) {
-                    unsigned char sc = scv[k], gc = gcv[k];
-                    double a1 = 0.0, a2 = 0.0;
-                    if(sc != '_') {
-                        if(gc == '_') a1 = T.rate_ins_quarter;
-                        else { a1 = T.rate_match_mismatch; unsigned char q = B.read_quals[rOff + idx]; a2 = (sc == gc) ? T.ll_match[q] : T.ll_mismatch[q]; }
-                        idx++;
-                    } else if(gc != '_') a1 = T.rate_indel;
-                    t1[k] = a1; t2[k] = a2;
+                    int j = j0 + k; bool in = k < per && j < j1;
+                    scv[k] = in ? B.ext_s[cb + j] : (unsigned char)'_'; gcv[k] = in ? B.ext_g[cb + j] : (unsigned char)'_';
+                    if(in && scv[k] != '_') nb++;
                 }
-            }
-            double acc = 0.0;
-            for(int l = 0; l < 64; l++) {
-                double in = __shfl(acc, l > 0 ? l - 1 : 0);
-                if(lane == l) {
-                    double a = (l == 0) ? 0.0 : in;
+                int tot; int before = baseIdx + wave_excl_scan(nb, tot);
+                double t1[LLPER], t2[LLPER];
+                {
+                    int idx = before;
 #pragma unroll
-                    for(int k = 0; k < LLPER; k++) { a += t1[k]; a += t2[k]; }
-                    acc = a;
+                    for(int k = 0; k < LLPER; k++) {
+                        unsigned char sc = scv[k], gc = gcv[k];
+                        double a1 = 0.0, a2 = 0.0;
+                        if(sc != '_') {
+                            if(gc == '_') a1 = T.rate_ins_quarter;
+                            else { a1 = T.rate_match_mismatch; unsigned char q = B.read_quals[rOff + idx]; a2 = (sc == gc) ? T.ll_match[q] : T.ll_mismatch[q]; }
+                            idx++;
+                        } else if(gc != '_') a1 = T.rate_indel;
+                        t1[k] = a1; t2[k] = a2;
+                    }
                 }
+                double acc = 0.0;
+                for(int l = 0; l < 64; l++) {
+                    double in = __shfl(acc, l > 0 ? l - 1 : 0);
+                    if(lane == l) {
+                        double a = (l == 0) ? carry : in;
+#pragma unroll
+                        for(int k = 0; k < LLPER; k++) { a += t1[k]; a += t2[k]; }
+                        acc = a;
+                    }
+                }
+                carry = __shfl(acc, 63); baseIdx += tot;
             }
-            double ll = __shfl(acc, 63);
+            double ll = carry;
             ST_T(3);
             // first / last two defined levels for the pairing stage (verboseSeedChain.h:134-228)
             if(lane == 0) {

@@ -141,6 +141,12 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
         bad = uni(bad);
         const long long nCombLL = (long long)n1 * n2;
         if(!bad && nCombLL > PAIR_COMB) bad = 1;
+        if(!bad && nCombLL > 1) {
+            // the per-position pass below holds PAIR_COLS columns per chain (long reads come with one alignment each: nComb == 1, any length)
+            int mxc = 0;
+            for(int m = 0; m < NM; m++) { const int nl = m ? n2 : n1; for(int k = lane; k < nl; k += 64) mxc = max(mxc, B.ext_ncols[P.list[m][k]]); }
+            if(wave_max_i32(mxc) > PAIR_COLS) bad = 1;
+        }
         if(bad) {
             if(lane == 0) { B.pair_status[p] = -1; if(UNPAIRED) B.best_chain[p] = -1; else { B.best_chain[2 * p] = -1; B.best_chain[2 * p + 1] = -1; } B.n_comb[p] = 0; }
         } else {

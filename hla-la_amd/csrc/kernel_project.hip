@@ -27,6 +27,7 @@ constexpr int PROJ_SEGMAX = 24;     // longest run of multi-node levels one lane
 struct ChoiceRec { int eid; short fromz; short S; };
 
 struct __align__(16) ProjLds {
+    static constexpr int CAP = PROJ_CAP, SN = PROJ_SN, SE = PROJ_SE; static constexpr bool LONG = false;
     int lvl[2][PROJ_CAP];
     unsigned char g[2][PROJ_CAP], s[2][PROJ_CAP];
     short Srow[2][PROJ_NODES];
@@ -40,7 +41,44 @@ struct __align__(16) ProjLds {
     unsigned short segStart[PROJ_CAP + 2];  // level indices where a DP segment starts (single-node levels, see below)
     u64 mGap[PROJ_CAP / 64], mDef[PROJ_CAP / 64], mSeq[PROJ_CAP / 64];     // column bit masks of the restrict step
     int err, n, startRaw, stopRaw, tmp0, tmp1;
+    __device__ __forceinline__ short* sflat() { return &Srow[0][0]; }        // S per node of the window in the segment-parallel form (SN <= 2 * PROJ_NODES)
 };
+
+// Long reads (params.max_columns > PROJ_CAP): the same kernel with the column / window arrays in the wave's HBM slab; the LDS block
+// only holds the pointers, the per-level score rows and the scalars.  Member names and index syntax match ProjLds.
+constexpr int PROJL_CAP = 16384;    // alignment columns (>= params.max_columns)
+constexpr int PROJL_SN  = 49152;    // nodes of the level window (16-bit offsets: < 65536)
+constexpr int PROJL_SE  = 57344;    // in-edges of the level window
+struct __align__(16) ProjLdsLong {
+    static constexpr int CAP = PROJL_CAP, SN = PROJL_SN, SE = PROJL_SE; static constexpr bool LONG = true;
+    int* lvl[2];
+    unsigned char* g[2]; unsigned char* s[2];
+    short Srow[2][PROJ_NODES];
+    unsigned short* sLev; unsigned short* sIn; unsigned short* sChoice; unsigned short* sFrom; unsigned char* sLab;
+    u32* colInfo; unsigned short* segStart;
+    u64* mGap; u64* mDef; u64* mSeq;
+    short* sflatp;
+    int err, n, startRaw, stopRaw, tmp0, tmp1;
+    __device__ __forceinline__ short* sflat() { return sflatp; }
+};
+__host__ __device__ inline size_t proj_long_slab_bytes()
+{
+    size_t b = 0;
+    b += 2 * (size_t)PROJL_CAP * 4 + 4 * (size_t)PROJL_CAP;                                   // lvl, g, s
+    b += ((size_t)PROJL_CAP + 2) * 2 * 2 + (size_t)PROJL_CAP * 4 + 3 * (size_t)(PROJL_CAP / 64) * 8;     // sLev, segStart, colInfo, masks
+    b += ((size_t)PROJL_SN + 2) * 2 + 2 * (size_t)PROJL_SN * 2 + (size_t)PROJL_SE * 2 + (size_t)PROJL_SE;    // sIn, sChoice, sflat, sFrom, sLab
+    return (b + 4095) & ~(size_t)255;
+}
+__device__ inline void proj_bind(ProjLds&, char*) { }
+__device__ inline void proj_bind(ProjLdsLong& P, char* p)      // 8-byte arrays first, then 4-, 2-, 1-byte ones
+{
+    P.mGap = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8; P.mDef = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8; P.mSeq = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8;
+    P.lvl[0] = (int*)p; p += (size_t)PROJL_CAP * 4; P.lvl[1] = (int*)p; p += (size_t)PROJL_CAP * 4; P.colInfo = (u32*)p; p += (size_t)PROJL_CAP * 4;
+    P.sLev = (unsigned short*)p; p += ((size_t)PROJL_CAP + 2) * 2; P.segStart = (unsigned short*)p; p += ((size_t)PROJL_CAP + 2) * 2;
+    P.sIn = (unsigned short*)p; p += ((size_t)PROJL_SN + 2) * 2; P.sChoice = (unsigned short*)p; p += (size_t)PROJL_SN * 2; P.sflatp = (short*)p; p += (size_t)PROJL_SN * 2; P.sFrom = (unsigned short*)p; p += (size_t)PROJL_SE * 2;
+    P.g[0] = (unsigned char*)p; p += PROJL_CAP; P.g[1] = (unsigned char*)p; p += PROJL_CAP; P.s[0] = (unsigned char*)p; p += PROJL_CAP; P.s[1] = (unsigned char*)p; p += PROJL_CAP;
+    P.sLab = (unsigned char*)p;
+}
 
 __host__ __device__ inline size_t proj_slab_bytes(int stride, int maxNodesPerLevel)
 {
@@ -96,13 +134,15 @@ __global__ void k_filter_chains(const DevGraph* __restrict__ Gp, const DevBatch*
 #define PJ_T(i) do { if(B.dbg) tPh[i] = clock64(); } while(0)      // HLALA_DEBUG phase clocks -> counters[16..23]
 #define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
 
+template <class PL>
 __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
-                                                       const int* contig_level, char* slabs, size_t slabBytes)
+                                                       const int* contig_level, char* slabs, size_t slabBytes, char* longSlabs, size_t longSlabBytes)
 {
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
-    __shared__ ProjLds P;
+    __shared__ PL P;
     const int lane = lane_id();
+    if(PL::LONG) { if(lane == 0) proj_bind(P, longSlabs + (size_t)blockIdx.x * longSlabBytes); WSYNC(); }
     ChoiceRec* slabCh = (ChoiceRec*)(slabs + (size_t)blockIdx.x * slabBytes);
     const int slabEnt = (int)(slabBytes / sizeof(ChoiceRec));
     const int stride = B.stride;
@@ -132,66 +172,88 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         // ---------------- CIGAR walk (transformBAMreadToInternalAlignment, :4794-5337)
         // Columns are the M/=/X/D/I operations in CIGAR order: M -> (ref, read), D -> (ref, '_'), I -> (-1, '_', read);
         // S advances the read index, H only counts at the very start (:4868-4874), P is dropped (:4814-4828), N throws (:5167).
-        if(nOps < 1 || nOps > PROJ_OPS) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+        if(nOps < 1 || (!PL::LONG && nOps > PROJ_OPS)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
         int nCols = 0;
-        // one CIGAR operation per lane; the per-operation starts stay in registers and are broadcast with readlane
-        int opK = 6, opLen = 0, opCol = 0, opRef = 0, opRead = 0;
-        if(nOps >= 1 && nOps <= PROJ_OPS) {
-            u32 cg = lane < nOps ? B.cigar[cg0 + lane] : 0;
-            int op = (int)(cg & 15u), len = (int)(cg >> 4);
-            if(lane >= nOps) { op = 6; len = 0; }                       // behaves like 'P'
-            bool isCol = (op == 0 || op == 7 || op == 8 || op == 2 || op == 1);
-            bool useRef = (op == 0 || op == 7 || op == 8 || op == 2);
-            bool useRead = (op == 0 || op == 7 || op == 8 || op == 1 || op == 4);
-            int leadH = 0;
-            if(lane == 0 && op == 5) leadH = len;                       // leading hard clip offsets the unclipped read index
-            leadH = __shfl(leadH, 0);
-            int tc, tr, tq;
-            int colStart = wave_excl_scan(isCol ? len : 0, tc);
-            int refStart = wave_excl_scan(useRef ? len : 0, tr);
-            int readStart = wave_excl_scan(useRead ? len : 0, tq) + leadH;
-            opK = op; opLen = len; opCol = colStart; opRef = refStart; opRead = readStart;
-            if(lane < nOps) {
-                if(op == 3 || op > 8) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
-                // an insertion must follow a column operation or open the alignment (assert(index_along_read == 0), :5086)
-                if(op == 1 && colStart > 0 && lane > 0) {
-                    int pop = __shfl_up(op, 1);
-                    if(!(pop == 0 || pop == 7 || pop == 8 || pop == 2 || pop == 1)) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
+        // 64 CIGAR operations at a time, one per lane; the per-operation starts stay in registers and are broadcast with readlane.
+        // (Short reads: a single round.  Long reads carry the running column / reference / read offsets from round to round.)
+        if(PJ_OK()) {
+            int baseCol = 0, baseRef = 0, baseRead = 0, leadH = 0, prevOp = -1;
+            int firstStart = -1, lastRS = 0, lastLen = 0, lastUse = 0;
+            // pass 1: totals, validity, first / last column operation (sequence_aligned_{start,stop}InRaw, :5197-5203)
+            for(int ob = 0; ob < nOps; ob += 64) {
+                const int oi = ob + lane;
+                u32 cg = oi < nOps ? B.cigar[cg0 + oi] : 0;
+                int op = (int)(cg & 15u), len = (int)(cg >> 4);
+                if(oi >= nOps) { op = 6; len = 0; }                       // behaves like 'P'
+                bool isCol = (op == 0 || op == 7 || op == 8 || op == 2 || op == 1);
+                bool useRef = (op == 0 || op == 7 || op == 8 || op == 2);
+                bool useRead = (op == 0 || op == 7 || op == 8 || op == 1 || op == 4);
+                if(ob == 0) { int lh = 0; if(lane == 0 && op == 5) lh = len; leadH = __shfl(lh, 0); }     // leading hard clip offsets the unclipped read index
+                int tc, tr, tq;
+                int colStart = baseCol + wave_excl_scan(isCol ? len : 0, tc);
+                int refStart = baseRef + wave_excl_scan(useRef ? len : 0, tr);
+                int readStart = baseRead + wave_excl_scan(useRead ? len : 0, tq) + leadH;
+                int pop = __shfl_up(op, 1); if(lane == 0) pop = prevOp;          // the operation before this one (previous round for lane 0)
+                if(oi < nOps) {
+                    if(op == 3 || op > 8) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
+                    // an insertion must follow a column operation or open the alignment (assert(index_along_read == 0), :5086)
+                    if(op == 1 && colStart > 0 && oi > 0) {
+                        if(!(pop == 0 || pop == 7 || pop == 8 || pop == 2 || pop == 1)) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
+                    }
                 }
+                prevOp = __shfl(op, 63);
+                u64 colMask = __ballot(isCol && len > 0);
+                if(colMask) {
+                    int firstOp = __ffsll((long long)colMask) - 1, lastOp = 63 - __clzll((long long)colMask);
+                    if(firstStart < 0) firstStart = __shfl(readStart, firstOp);
+                    lastRS = __shfl(readStart, lastOp); lastLen = __shfl(len, lastOp); lastUse = __shfl(useRead ? 1 : 0, lastOp);
+                }
+                baseCol += tc; baseRef += tr; baseRead += tq;
             }
-            nCols = tc;
-            // first / last column operation give sequence_aligned_{start,stop}InRaw (:5197-5203)
-            u64 colMask = __ballot(isCol && len > 0);
-            if(colMask == 0) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
-            else {
-                int firstOp = __ffsll((long long)colMask) - 1, lastOp = 63 - __clzll((long long)colMask);
-                int startRaw = __shfl(readStart, firstOp);
-                int lastRS = __shfl(readStart, lastOp), lastLen = __shfl(len, lastOp), lastUse = __shfl(useRead ? 1 : 0, lastOp);
-                if(lane == 0) { P.startRaw = startRaw; P.stopRaw = lastRS + (lastUse ? lastLen : 0) - 1; }
-            }
-            if(nCols > PROJ_CAP || nCols > stride) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); }
+            nCols = baseCol;
+            if(firstStart < 0) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+            else if(lane == 0) { P.startRaw = firstStart; P.stopRaw = lastRS + (lastUse ? lastLen : 0) - 1; }
+            if(nCols > PL::CAP || nCols > stride) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); }
         }
         WSYNC();
         if(PJ_OK()) {
-            for(int o = 0; o < nOps; o++) {
-                const int op = __builtin_amdgcn_readlane(opK, o), olen = __builtin_amdgcn_readlane(opLen, o);
-                if(!(op == 0 || op == 7 || op == 8 || op == 2 || op == 1)) continue;
-                const int ocs = __builtin_amdgcn_readlane(opCol, o), ors = __builtin_amdgcn_readlane(opRef, o), oqs = __builtin_amdgcn_readlane(opRead, o);
-                for(int k = lane; k < olen; k += 64) {
-                    int lv = -1; unsigned char gc = '_', sc = '_';
-                    if(op != 1) {
-                        int refpos = pos + ors + k;
-                        int ti = refpos - tOffset;
-                        if(refpos < 0 || refpos >= cLen || ti < 0 || ti >= cLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
-                        else { gc = contig_seq[cOff + refpos]; lv = contig_level[cOff + ti]; }
+            // pass 2: columns.  M/=/X/D/I operations in CIGAR order: M -> (ref, read), D -> (ref, '_'), I -> (-1, '_', read)
+            int baseCol = 0, baseRef = 0, baseRead = 0, leadH = 0;
+            for(int ob = 0; ob < nOps; ob += 64) {
+                const int oi = ob + lane;
+                u32 cg = oi < nOps ? B.cigar[cg0 + oi] : 0;
+                int opK = (int)(cg & 15u), opLen = (int)(cg >> 4);
+                if(oi >= nOps) { opK = 6; opLen = 0; }
+                bool isCol = (opK == 0 || opK == 7 || opK == 8 || opK == 2 || opK == 1);
+                bool useRef = (opK == 0 || opK == 7 || opK == 8 || opK == 2);
+                bool useRead = (opK == 0 || opK == 7 || opK == 8 || opK == 1 || opK == 4);
+                if(ob == 0) { int lh = 0; if(lane == 0 && opK == 5) lh = opLen; leadH = __shfl(lh, 0); }
+                int tc, tr, tq;
+                int opCol = baseCol + wave_excl_scan(isCol ? opLen : 0, tc);
+                int opRef = baseRef + wave_excl_scan(useRef ? opLen : 0, tr);
+                int opRead = baseRead + wave_excl_scan(useRead ? opLen : 0, tq) + leadH;
+                const int nHere = min(64, nOps - ob);
+                for(int o = 0; o < nHere; o++) {
+                    const int op = __builtin_amdgcn_readlane(opK, o), olen = __builtin_amdgcn_readlane(opLen, o);
+                    if(!(op == 0 || op == 7 || op == 8 || op == 2 || op == 1)) continue;
+                    const int ocs = __builtin_amdgcn_readlane(opCol, o), ors = __builtin_amdgcn_readlane(opRef, o), oqs = __builtin_amdgcn_readlane(opRead, o);
+                    for(int k = lane; k < olen; k += 64) {
+                        int lv = -1; unsigned char gc = '_', sc = '_';
+                        if(op != 1) {
+                            int refpos = pos + ors + k;
+                            int ti = refpos - tOffset;
+                            if(refpos < 0 || refpos >= cLen || ti < 0 || ti >= cLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+                            else { gc = contig_seq[cOff + refpos]; lv = contig_level[cOff + ti]; }
+                        }
+                        if(op != 2) {
+                            int ri = oqs + k;
+                            if(ri < 0 || ri >= readLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); } else sc = B.read_bases[rOff + ri];
+                        }
+                        const int j = ocs + k;
+                        P.lvl[0][j] = lv; P.g[0][j] = gc; P.s[0][j] = sc;
                     }
-                    if(op != 2) {
-                        int ri = oqs + k;
-                        if(ri < 0 || ri >= readLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); } else sc = B.read_bases[rOff + ri];
-                    }
-                    const int j = ocs + k;
-                    P.lvl[0][j] = lv; P.g[0][j] = gc; P.s[0][j] = sc;
                 }
+                baseCol += tc; baseRef += tr; baseRead += tq;
             }
         }
         WSYNC();
@@ -226,7 +288,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                     int tg; int gb = wave_excl_scan(gap, tg);
                     int np = (j - firstCol) + carryGap + gb + gap;
                     if(act) {
-                        if(np >= PROJ_CAP || np >= stride) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS);
+                        if(np >= PL::CAP || np >= stride) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS);
                         else {
                             for(int q = 0; q < gap; q++) { int w = np - gap + q; P.lvl[1][w] = prevExcl + 1 + q; P.g[1][w] = '_'; P.s[1][w] = '_'; }
                             P.lvl[1][np] = lv; P.g[1][np] = P.g[0][j]; P.s[1][np] = P.s[0][j];
@@ -235,7 +297,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                     carryGap += tg; carryPrev = __shfl(prevIncl, 63);
                 }
                 n1 = (lastCol - firstCol + 1) + carryGap;
-                if(n1 > PROJ_CAP || n1 > stride) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); }
+                if(n1 > PL::CAP || n1 > stride) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); }
             }
         }
         WSYNC();
@@ -400,7 +462,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 int v2 = 0; if(lane == 0) v2 = G.in_off[nb]; else if(lane == 1) v2 = G.in_off[nodeEnd];
                 eBase = __builtin_amdgcn_readlane(v2, 0);
                 nEdges = __builtin_amdgcn_readlane(v2, 1) - eBase;
-                staged = (nDef <= PROJ_CAP) && (nodeEnd - nodeBase <= PROJ_SN) && (nEdges <= PROJ_SE);
+                staged = (nDef <= PL::CAP) && (nodeEnd - nodeBase <= PL::SN) && (nEdges <= PL::SE);
                 if(staged) {
                     for(int i = lane; i <= nDef + 1; i += 64) P.sLev[i] = (unsigned short)(G.level_off[level0 + i] - nodeBase);
                     for(int i = lane; i <= chCount; i += 64) P.sIn[i] = (unsigned short)(G.in_off[nb + i] - eBase);
@@ -411,7 +473,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         WSYNC();
         u64 edgesTouched = 0;
         int nSeg = 0;
-        short* const Sflat = &P.Srow[0][0];                                                    // S per node of the window (parallel form)
+        short* const Sflat = P.sflat();                                                    // S per node of the window (parallel form)
         if(PJ_OK() && staged) {
             // level -> (column, read character, seed-is-match); the defined columns must cover level0..lastLevel exactly once
             int defCount = 0;

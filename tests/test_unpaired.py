@@ -72,3 +72,26 @@ def test_unpaired_exon_positions_and_filters(pkg, oracle):
             ug, ig, sg = pkg.filter_positions(C.CDLL(pkg.LIB_PATH), g, prm)
             ue, ie, se = ob.filter_positions(e, prm)
             assert np.array_equal(ug, ue) and np.array_equal(ig, ie) and sg == se
+
+
+@pytest.mark.parametrize("seed,G,k,n_reads,lo,hi", [(7, 30000, 1, 40, 2000, 9000), (8, 20000, 3, 30, 600, 4000)], ids=["long-k1", "long-k3"])
+def test_long_reads_match_oracle(pkg, oracle, seed, G, k, n_reads, lo, hi):
+    """BASELINE config 5 style: kilobase reads with indel-rich CIGARs (thousands of operations), max_columns = 16384:
+    the slab-backed projection kernel, the multi-round log-likelihood sum and the unpaired selection."""
+    w = synth.make_world(seed=seed, G=G, k=k)
+    u = synth.make_long_batch(w, n_reads, seed=seed + 1, len_lo=lo, len_hi=hi)
+    cols = 16384
+    o = oracle(w["graph"], w["contigs"], insert_mean=200.0, insert_sd=35.0, rng_seed=3, long_read_mode=1, max_columns=cols)
+    e = o.align_long_reads(u)
+    ctx = pkg.Context(w["graph"], w["contigs"], insert_mean=200.0, insert_sd=35.0, rng_seed=3, long_read_mode=1, max_columns=cols)
+    gb = ctx.batch_unpaired(u); gb.align()
+    st = gb.stats()
+    assert st.n_errors == 0 and st.n_dp_calls == 0
+    compare_chains(gb.chains(0), e["seeds"], u["n_chains"], check_ll=False, check_dp=False, label="long seeds")
+    compare_chains(gb.chains(1), e["ext"], u["n_chains"], check_dp=False, label="long padded chains")
+    g = gb.pairs(); x = e["pairs"]; n = n_reads
+    for key in PAIR_INT:
+        per = {"pair_status": n, "best_chain": n, "n_combinations": n, "n_cols": n}.get(key, n * cols)
+        assert np.array_equal(np.asarray(g[key])[:per], np.asarray(x[key])[:per]), key
+    assert np.allclose(g["pair_ll"][:n], x["pair_ll"][:n], rtol=1e-12, atol=0)
+    assert int(np.asarray(x["n_cols"])[:n].max()) > 2000 and int(np.diff(u["cigar_off"]).max()) > 64

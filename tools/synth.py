@@ -406,3 +406,64 @@ def as_unpaired(b):
     u = dict(b)
     u["n_pairs"] = 2 * int(b["n_pairs"])
     return u
+
+
+def make_long_batch(world, n_reads, seed=5, len_lo=2000, len_hi=10000, sub=0.05, ins=0.04, dele=0.04, clip_max=60, p_second=0.0):
+    """Single long reads (BASELINE config 5 style: ONT-like substitution / insertion / deletion rates) with one primary alignment each
+    whose CIGAR is derived from the truth (thousands of operations), in the hlala_batch_in layout of an UNPAIRED batch
+    (n_pairs = number of reads).  `p_second`: fraction of reads that also get a clean second alignment on another haplotype."""
+    rng = np.random.default_rng(seed)
+    C = world["contigs"]; nh = C["n_contigs"]; off = C["contig_off"]; clen = np.diff(off); seq = C["contig_seq"]
+    nuc = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads_b, reads_q, read_off, chain_off, read_primary = [], [], [0], [0], []
+    ch = dict(contig=[], pos=[], offset=[], AS=[], rev=[], cig=[])
+    for r in range(n_reads):
+        h = int(rng.integers(0, nh)); L = int(rng.integers(len_lo, len_hi + 1)); L = min(L, int(clen[h]) - 10)
+        s = int(rng.integers(0, clen[h] - L))
+        ref = seq[off[h] + s: off[h] + s + L]
+        # walk the reference segment, emitting read bases and run-length encoded operations
+        ev = rng.random(L)
+        ops = []; rb = []
+
+        def push(o, n=1):
+            if ops and ops[-1][1] == o:
+                ops[-1][0] += n
+            else:
+                ops.append([n, o])
+        for i in range(L):
+            if ev[i] < dele and 0 < i < L - 1:
+                push("D")
+                continue
+            b = ref[i]
+            if ev[i] > 1 - sub:
+                b = nuc[rng.integers(0, 4)]
+            rb.append(b); push("M")
+            if rng.random() < ins and i < L - 1:
+                k = int(rng.integers(1, 3)); rb.extend(nuc[rng.integers(0, 4, k)]); push("I", k)
+        a = int(rng.beta(1, 4) * clip_max); c = int(rng.beta(1, 4) * clip_max)
+        head = nuc[rng.integers(0, 4, a)]; tail = nuc[rng.integers(0, 4, c)]
+        b_all = np.concatenate([head, np.asarray(rb, np.uint8), tail]).astype(np.uint8)
+        cig = [(a, "S")] + [(n, o) for n, o in ops] + [(c, "S")]
+        rev = bool(rng.random() < 0.5)
+        recs = [dict(contig=h, pos=s, AS=int(len(rb)), rev=rev, cig=cig, primary=True)]
+        if rng.random() < p_second and nh > 1:
+            h2 = int((h + 1 + rng.integers(0, nh - 1)) % nh)
+            mlen = min(len(b_all) - a - c, int(clen[h2]) - 5)
+            p2 = int(rng.integers(0, clen[h2] - mlen))
+            recs.append(dict(contig=h2, pos=p2, AS=int(mlen // 2), rev=rev, cig=[(a, "S"), (mlen, "M"), (len(b_all) - a - mlen, "S")], primary=False))
+        c0 = chain_off[-1]
+        for i, rec in enumerate(recs):
+            if rec["primary"]:
+                read_primary.append(c0 + i)
+            ch["contig"].append(rec["contig"]); ch["pos"].append(rec["pos"]); ch["offset"].append(0); ch["AS"].append(rec["AS"])
+            ch["rev"].append(1 if rec["rev"] else 0); ch["cig"].append(_cigar(rec["cig"]))
+        chain_off.append(c0 + len(recs))
+        q = np.clip(20 - rng.geometric(0.3, len(b_all)) + 1, 2, 20).astype(np.uint8)
+        reads_b.append(b_all); reads_q.append(q + 33); read_off.append(read_off[-1] + len(b_all))
+    cigar_off = np.concatenate([[0], np.cumsum([len(c) for c in ch["cig"]])]).astype(np.int32)
+    cigar = np.asarray([x for c in ch["cig"] for x in c], dtype=np.uint32)
+    return dict(n_pairs=n_reads, read_off=np.asarray(read_off, np.int32), read_bases=np.concatenate(reads_b).astype(np.uint8),
+                read_quals=np.concatenate(reads_q).astype(np.uint8), chain_off=np.asarray(chain_off, np.int32), read_primary=np.asarray(read_primary, np.int32),
+                n_chains=len(ch["pos"]), chain_contig=np.asarray(ch["contig"], np.int32), chain_pos=np.asarray(ch["pos"], np.int32),
+                chain_offset=np.asarray(ch["offset"], np.int32), chain_as=np.asarray(ch["AS"], np.int32), chain_reverse=np.asarray(ch["rev"], np.uint8),
+                cigar_off=cigar_off, cigar=cigar)
