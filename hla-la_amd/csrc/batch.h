@@ -65,7 +65,7 @@ struct DevBatch {
                                     //      [1]/[10] left / right items fetched, [12..23] retry lists (count, fetched) per tier 1..3 and direction
     int* retry_list;                // [6*n_chains] DP items that outgrew a capacity class: (tier 1..3) x (left, right) x n_chains
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
-    int* dbg;                       // host-mapped progress words (HLALA_DEBUG=1), else null
+    int* dbg;                       // non-null with HLALA_DEBUG=1: kernels add phase clocks to counters[16..31]
 };
 
 enum {

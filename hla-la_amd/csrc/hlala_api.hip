@@ -57,7 +57,7 @@ struct hlala_ctx {
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
     hipEvent_t ev[9]{};           // start/end per stage; [7] / [6] / [8] = before DpTiny / after DpTiny / after the retry classes
-    int* dbg_host = nullptr;      // hipHostMalloc'ed progress words, device-visible (HLALA_DEBUG=1)
+    int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
     // per-pair post-processing: coverage counters [L-1] and gene intervals
     int* d_cov = nullptr; int n_cov = 0; int* d_gene_first = nullptr; int* d_gene_last = nullptr; int n_genes = 0;
     std::string err;
@@ -880,17 +880,6 @@ extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(out32, b->B.counters, 32 * sizeof(u64), hipMemcpyDeviceToHost));
     return HLALA_OK;
-}
-
-extern "C" int hlala_debug_peek(hlala_ctx* c, int* out64)
-{
-    if(!c || !c->dbg_host) return HLALA_E_STATE;
-    for(int i = 0; i < 8192; i++) out64[i] = ((volatile int*)c->dbg_host)[i];
-    hipError_t q = hipStreamQuery(c->stream);
-    if(q == hipSuccess) return 1;                 // stream idle
-    if(q == hipErrorNotReady) return 0;           // still running
-    c->err = std::string("hipStreamQuery: ") + hipGetErrorString(q);
-    return -100 - (int)q;                          // device error (sticky)
 }
 
 extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uint8_t* phred_out, const uint8_t* phred_in, double* p_out)

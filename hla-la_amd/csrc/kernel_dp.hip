@@ -74,7 +74,7 @@ struct __align__(16) DpLdsT {
     short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
     short tes[C::HC];               // per target: existing / assigned table slot (-1 = none; CELLS <= 32767)
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
-    int nT, nNew, nImp, nKeepF, err, nCompletedAdd;
+    int nNew, nImp, nKeepF, err, nCompletedAdd;
     int btSlot, btM, btX, btY, btGuard, btDone;       // back-pointer chase in progress (lane 0 of the group)
     DpState st;
     u64 accCalls, accIters, accCells, accEdges;       // work counters of the DPs this group finished (flushed once at exit)
