@@ -209,6 +209,39 @@ def load_graph_cache(lib, path):
     return _graph_from_handle(lib, h)
 
 
+class BamInterval(C.Structure):
+    _fields_ = [("ref_name", C.c_char_p), ("start_0based", C.c_int32), ("stop_0based", C.c_int32), ("contig", C.c_int32)]
+
+
+def bam_extract_seeds(lib, path, intervals, long_read_mode=False):
+    """hlala_bam_extract_seeds: intervals = [(ref name, start_0based, stop_0based, contig index)]; returns (batch dict, read names, counts)."""
+    arr = (BamInterval * max(1, len(intervals)))()
+    for i, (nm, a, b, c) in enumerate(intervals):
+        arr[i] = BamInterval(nm.encode(), int(a), int(b), int(c))
+    h = C.c_void_p()
+    lib.hlala_bam_extract_seeds.argtypes = [C.c_char_p, C.c_int32, C.POINTER(BamInterval), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.hlala_bam_last_error.restype = C.c_char_p
+    if lib.hlala_bam_extract_seeds(str(path).encode(), len(intervals), arr, int(bool(long_read_mode)), C.byref(h)) != 0:
+        raise HlalaError(lib.hlala_bam_last_error().decode())
+    d = BatchIn(); cnt = (C.c_int64 * 3)()
+    lib.hlala_seed_batch_desc.argtypes = [C.c_void_p, C.POINTER(BatchIn), C.POINTER(C.c_int64)]
+    lib.hlala_seed_batch_desc(h, C.byref(d), cnt)
+    nu = d.n_pairs; nr = nu * (1 if long_read_mode else 2); nc = d.n_chains
+
+    def arr_of(ptr, n, dt):
+        return np.ctypeslib.as_array(ptr, (max(n, 1),))[:n].astype(dt).copy()
+    ro = arr_of(d.read_off, nr + 1, np.int32); co = arr_of(d.cigar_off, nc + 1, np.int32)
+    b = dict(n_pairs=nu, read_off=ro, read_bases=arr_of(d.read_bases, int(ro[-1]), np.uint8), read_quals=arr_of(d.read_quals, int(ro[-1]), np.uint8),
+             chain_off=arr_of(d.chain_off, nr + 1, np.int32), read_primary=arr_of(d.read_primary, nr, np.int32), n_chains=nc,
+             chain_contig=arr_of(d.chain_contig, nc, np.int32), chain_pos=arr_of(d.chain_pos, nc, np.int32), chain_offset=arr_of(d.chain_offset, nc, np.int32),
+             chain_as=arr_of(d.chain_as, nc, np.int32), chain_reverse=arr_of(d.chain_reverse, nc, np.uint8), cigar_off=co, cigar=arr_of(d.cigar, int(co[-1]), np.uint32))
+    lib.hlala_seed_batch_name.argtypes = [C.c_void_p, C.c_int32]; lib.hlala_seed_batch_name.restype = C.c_char_p
+    names = [lib.hlala_seed_batch_name(h, i).decode() for i in range(nu)]
+    lib.hlala_seed_batch_free.argtypes = [C.c_void_p]; lib.hlala_seed_batch_free.restype = None
+    lib.hlala_seed_batch_free(h)
+    return b, names, dict(examined=int(cnt[0]), seeds=int(cnt[1]), incomplete=int(cnt[2]))
+
+
 def exon_in_from_positions(e, pos_use, cluster_seq, n_clusters, exon_length):
     """hlala_exon_in (input of hlala_exon_loglik) from the outputs of hlala_exon_positions and hlala_filter_positions: the likelihood loop
     reads the first genotype character, the genotype length and the first quality of every position (hla/HLATyper.cpp:2080-2277)."""
@@ -351,6 +384,7 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
     "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
     "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
+    "hlala_bam_extract_seeds", "hlala_seed_batch_desc", "hlala_seed_batch_name", "hlala_seed_batch_free", "hlala_bam_last_error",
 ]
 
 

@@ -269,6 +269,30 @@ void hlala_graph_file_free(hlala_graph_file* g);
 const char* hlala_loader_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
+ * BAM reader + seed extraction (host code, zlib): processBAM::extractSeeds2 (mapper/processBAM.cpp:703-864) with
+ * protoSeeds::takeAlignment / isComplete (mapper/reads/protoSeeds.cpp:23-36, 371-380), sortChainsInSeeds (:1945-1967),
+ * getAlignmentScore (:4314-4334).  A record is used if it is mapped (long-read mode: and not secondary), its reference carries
+ * intervals, it has CIGAR operations and both its start and its end lie inside an interval.  Complete units (pairs with a primary
+ * alignment for both mates; long reads: a primary alignment) come out in read-name order with their alignments sorted by the AS
+ * tag (std::sort + std::reverse as in the reference), positions re-based to the interval start (chain_offset = 0, the contig of a
+ * chain is the interval's `contig`).  long_read_mode != 0 yields the layout of hlala_batch_create_unpaired.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const char* ref_name;       /* BAM reference name (sequences.txt column Chr)                     */
+    int32_t start_0based;       /* Start_1based - 1                                                   */
+    int32_t stop_0based;        /* Stop_1based - 1                                                    */
+    int32_t contig;             /* index into hlala_contigs_desc of the sequence this interval is     */
+} hlala_bam_interval;
+typedef struct hlala_seed_batch hlala_seed_batch;
+int  hlala_bam_extract_seeds(const char* bam_path, int32_t n_intervals, const hlala_bam_interval* intervals, int32_t long_read_mode,
+                             hlala_seed_batch** out);
+/* descriptor pointing into the handle; counts[3] = records examined, seeds (read names), incomplete seeds */
+int  hlala_seed_batch_desc(const hlala_seed_batch* s, hlala_batch_in* in, int64_t* counts);
+const char* hlala_seed_batch_name(const hlala_seed_batch* s, int32_t unit);
+void hlala_seed_batch_free(hlala_seed_batch* s);
+const char* hlala_bam_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
  * Insert-size estimation (processBAM::estimateInsertSize, mapper/processBAM.cpp:1071-1165, and
  * calculateInsertSizeFromHistogram :991-1069) on the kernels of stages A and B: for every pair of `in` the PRIMARY
  * alignment of mate 1 and of mate 2 (read_primary) is projected and extended; if the strands are valid every
