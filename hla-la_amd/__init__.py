@@ -96,7 +96,7 @@ class ExonPositionsOut(C.Structure):
                 ("n_pairs_ok", C.c_int32), ("n_pairs_broken", C.c_int32),
                 ("read_pair", c_i32p), ("read_weighted_ok", c_f64p), ("read_fraction_ok", c_f64p), ("read_distance", c_i32p), ("read_cols_nongap", c_i32p),
                 ("pos_off", c_i32p), ("pos_exon", c_i32p), ("pos_level", c_i32p), ("pos_mate", c_u8p), ("pos_mapq", c_u8p), ("pos_novel_gap", c_i32p),
-                ("geno_off", c_i32p), ("geno_chars", c_u8p), ("qual_chars", c_u8p)]
+                ("geno_off", c_i32p), ("geno_chars", c_u8p), ("qual_chars", c_u8p), ("read_reverse", c_u8p), ("read_mapq", c_f64p)]
 
 
 def alloc_exon_positions_out(cap_reads, cap_pos, cap_chars):
@@ -104,7 +104,8 @@ def alloc_exon_positions_out(cap_reads, cap_pos, cap_chars):
     d = dict(read_pair=np.zeros(cap_reads, np.int32), read_weighted_ok=np.zeros(2 * cap_reads), read_fraction_ok=np.zeros(2 * cap_reads),
              read_distance=np.zeros(cap_reads, np.int32), read_cols_nongap=np.zeros(2 * cap_reads, np.int32), pos_off=np.zeros(cap_reads + 1, np.int32),
              pos_exon=np.zeros(cap_pos, np.int32), pos_level=np.zeros(cap_pos, np.int32), pos_mate=np.zeros(cap_pos, np.uint8), pos_mapq=np.zeros(cap_pos, np.uint8),
-             pos_novel_gap=np.zeros(cap_pos, np.int32), geno_off=np.zeros(cap_pos + 1, np.int32), geno_chars=np.zeros(cap_chars, np.uint8), qual_chars=np.zeros(cap_chars, np.uint8))
+             pos_novel_gap=np.zeros(cap_pos, np.int32), geno_off=np.zeros(cap_pos + 1, np.int32), geno_chars=np.zeros(cap_chars, np.uint8), qual_chars=np.zeros(cap_chars, np.uint8),
+             read_reverse=np.zeros(2 * cap_reads, np.uint8), read_mapq=np.zeros(2 * cap_reads))
     o = ExonPositionsOut(); o.cap_reads, o.cap_pos, o.cap_chars = cap_reads, cap_pos, cap_chars
     for k, v in d.items():
         setattr(o, k, v.ctypes.data_as(dict(ExonPositionsOut._fields_)[k]))
@@ -115,7 +116,7 @@ def trim_exon_positions(o, d):
     """Cut the arrays of alloc_exon_positions_out to what the call filled in."""
     nr, npos, nch = o.n_reads, o.n_pos, o.n_chars
     cut = dict(read_pair=nr, read_weighted_ok=2 * nr, read_fraction_ok=2 * nr, read_distance=nr, read_cols_nongap=2 * nr, pos_off=nr + 1, pos_exon=npos, pos_level=npos,
-               pos_mate=npos, pos_mapq=npos, pos_novel_gap=npos, geno_off=npos + 1, geno_chars=nch, qual_chars=nch)
+               pos_mate=npos, pos_mapq=npos, pos_novel_gap=npos, geno_off=npos + 1, geno_chars=nch, qual_chars=nch, read_reverse=2 * nr, read_mapq=2 * nr)
     out = {k: d[k][:n].copy() for k, n in cut.items()}
     out.update(n_reads=nr, n_pos=npos, n_chars=nch, n_pairs_ok=o.n_pairs_ok, n_pairs_broken=o.n_pairs_broken)
     return out
@@ -134,17 +135,19 @@ def make_locus_desc(level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0
 
 class FilterParams(C.Structure):
     _fields_ = [("filter_first20", C.c_int32), ("first20_n", C.c_int32), ("first20_min_prop", C.c_double), ("first20_limit_per_read", C.c_int32),
-                ("min_per_position_mapq", C.c_double), ("high_coverage_filter", C.c_int32), ("high_coverage_min_coverage", C.c_int32), ("high_coverage_min_freq", C.c_double)]
+                ("min_per_position_mapq", C.c_double), ("high_coverage_filter", C.c_int32), ("high_coverage_min_coverage", C.c_int32), ("high_coverage_min_freq", C.c_double),
+                ("long_read_strand_filter", C.c_int32), ("strand_min_allele_coverage", C.c_int32), ("strand_min_freq", C.c_double)]
 
 
 class FilterStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("considered_positions", "positions_with_removed_alleles", "considered_alleles", "removed_alleles", "reads_kicked_out",
-                                         "reads_kicked_out_robust", "high_coverage_positions", "high_coverage_removed_alleles", "bases_used")]
+                                         "reads_kicked_out_robust", "high_coverage_positions", "high_coverage_removed_alleles", "bases_used",
+                                         "strand_alleles_enough_coverage", "strand_removed_alleles", "strand_positions_with_removed")]
 
 
 def default_filter_params(**kw):
     """The reference's settings for short reads (hla/HLATyper.cpp:28-31, 69-75; HLATyper.h:57)."""
-    p = FilterParams(1, 20, 0.1, 2, 0.7, 0, 100, 0.2)
+    p = FilterParams(1, 20, 0.1, 2, 0.7, 0, 100, 0.2, 0, 100, 0.1)          # long reads: long_read_strand_filter=1
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -157,7 +160,9 @@ def exon_positions_struct(e):
     o.cap_reads, o.cap_pos, o.cap_chars = o.n_reads, o.n_pos, o.n_chars
     types = dict(ExonPositionsOut._fields_)
     for k in ("read_pair", "read_weighted_ok", "read_fraction_ok", "read_distance", "read_cols_nongap", "pos_off", "pos_exon", "pos_level", "pos_mate", "pos_mapq",
-              "pos_novel_gap", "geno_off", "geno_chars", "qual_chars"):
+              "pos_novel_gap", "geno_off", "geno_chars", "qual_chars", "read_reverse", "read_mapq"):
+        if k not in e:
+            continue                                       # optional arrays stay NULL
         a = np.ascontiguousarray(e[k]); keep.append(a); setattr(o, k, a.ctypes.data_as(types[k]))
     return o, keep
 

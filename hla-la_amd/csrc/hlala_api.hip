@@ -994,13 +994,15 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
     if((rc = dev_alloc(c, tmp, nR, &dO.read_pair)) || (rc = dev_alloc(c, tmp, 2 * nR, &dO.read_weighted_ok)) || (rc = dev_alloc(c, tmp, 2 * nR, &dO.read_fraction_ok)) ||
        (rc = dev_alloc(c, tmp, nR, &dO.read_distance)) || (rc = dev_alloc(c, tmp, 2 * nR, &dO.read_cols_nongap)) || (rc = dev_alloc(c, tmp, nR + 1, &dO.pos_off)) ||
        (rc = dev_alloc(c, tmp, nPz, &dO.pos_exon)) || (rc = dev_alloc(c, tmp, nPz, &dO.pos_level)) || (rc = dev_alloc(c, tmp, nPz, &dO.pos_mate)) || (rc = dev_alloc(c, tmp, nPz, &dO.pos_mapq)) ||
-       (rc = dev_alloc(c, tmp, nPz, &dO.pos_novel_gap)) || (rc = dev_alloc(c, tmp, nPz + 1, &dO.geno_off)) || (rc = dev_alloc(c, tmp, nC, &dO.geno_chars)) || (rc = dev_alloc(c, tmp, nC, &dO.qual_chars))) return done(rc);
+       (rc = dev_alloc(c, tmp, nPz, &dO.pos_novel_gap)) || (rc = dev_alloc(c, tmp, nPz + 1, &dO.geno_off)) || (rc = dev_alloc(c, tmp, nC, &dO.geno_chars)) || (rc = dev_alloc(c, tmp, nC, &dO.qual_chars)) ||
+       (rc = dev_alloc(c, tmp, 2 * nR, &dO.read_reverse)) || (rc = dev_alloc(c, tmp, 2 * nR, &dO.read_mapq))) return done(rc);
     hipLaunchKernelGGL((k_exon_positions<1>), dim3(grid), dim3(128), 0, st, b->dB, c->dT, EL, dCnt, (const int*)dOff, dOB, dO);
     if((rc = check_launch(c, "k_exon_positions<1>"))) return done(rc);
     if((rc = dl(c, o->read_pair, dO.read_pair, nR)) || (rc = dl(c, o->read_weighted_ok, dO.read_weighted_ok, 2 * nR)) || (rc = dl(c, o->read_fraction_ok, dO.read_fraction_ok, 2 * nR)) ||
        (rc = dl(c, o->read_distance, dO.read_distance, nR)) || (rc = dl(c, o->read_cols_nongap, dO.read_cols_nongap, 2 * nR)) || (rc = dl(c, o->pos_off, dO.pos_off, nR)) ||
        (rc = dl(c, o->pos_exon, dO.pos_exon, nPz)) || (rc = dl(c, o->pos_level, dO.pos_level, nPz)) || (rc = dl(c, o->pos_mate, dO.pos_mate, nPz)) || (rc = dl(c, o->pos_mapq, dO.pos_mapq, nPz)) ||
-       (rc = dl(c, o->pos_novel_gap, dO.pos_novel_gap, nPz)) || (rc = dl(c, o->geno_off, dO.geno_off, nPz)) || (rc = dl(c, o->geno_chars, dO.geno_chars, nC)) || (rc = dl(c, o->qual_chars, dO.qual_chars, nC))) return done(rc);
+       (rc = dl(c, o->pos_novel_gap, dO.pos_novel_gap, nPz)) || (rc = dl(c, o->geno_off, dO.geno_off, nPz)) || (rc = dl(c, o->geno_chars, dO.geno_chars, nC)) || (rc = dl(c, o->qual_chars, dO.qual_chars, nC)) ||
+       (rc = dl(c, o->read_reverse, dO.read_reverse, 2 * nR)) || (rc = dl(c, o->read_mapq, dO.read_mapq, 2 * nR))) return done(rc);
     HIP_TRY(c, hipStreamSynchronize(st));
     if(o->pos_off) o->pos_off[nR] = (int32_t)nPz;
     if(o->geno_off) o->geno_off[nPz] = (int32_t)nC;

@@ -108,15 +108,21 @@ extern "C" int hlala_filter_positions(const hlala_exon_positions_out* pos, const
             if(kickedRobust[r] > prm->first20_limit_per_read) { S.reads_kicked_out_robust++; ignoreRead[r] = 1; }                // ignore_readIDs, :1686-1690
         }
     }
-    // ---- high-coverage allele filter, :1722-1862
+    // ---- high-coverage allele filter and (long reads) the strand filter, :1722-1862; both look at the counts taken before either
+    if(prm->long_read_strand_filter && nReads > 0 && !pos->read_reverse) return HLALA_E_ARG;
     {
-        std::vector<int> cnt;
+        std::vector<int> cnt, rev; std::vector<std::pair<std::string, int>> byName;
         for(int e = 0; e <= maxExon; e++) {
             const int b0 = bOff[e], n = bOff[(size_t)e + 1] - b0;
             if(n == 0) continue;
             cnt.assign((size_t)nAllelesOf[e], 0);
             int count_position = 0;
-            for(int i = 0; i < n; i++) { const Entry& E = ent[(size_t)b0 + i]; if(ignoreRead[E.read] || ignoreAllele[(size_t)aOff[e] + E.allele]) continue; cnt[E.allele]++; count_position++; }
+            rev.assign((size_t)nAllelesOf[e], 0);
+            for(int i = 0; i < n; i++) {
+                const Entry& E = ent[(size_t)b0 + i]; if(ignoreRead[E.read] || ignoreAllele[(size_t)aOff[e] + E.allele]) continue;
+                cnt[E.allele]++; count_position++;
+                if(prm->long_read_strand_filter && pos->read_reverse[2 * E.read + (pos->pos_mate[E.pos_index] == 2 ? 1 : 0)]) rev[E.allele]++;
+            }
             if(count_position == 0) continue;
             if(count_position >= prm->high_coverage_min_coverage) {
                 S.high_coverage_positions++;
@@ -124,6 +130,22 @@ extern "C" int hlala_filter_positions(const hlala_exon_positions_out* pos, const
                     if(cnt[a] == 0) continue;
                     const double aF = (double)cnt[a] / (double)count_position;
                     if((aF < prm->high_coverage_min_freq) && prm->high_coverage_filter) { ignoreAllele[(size_t)aOff[e] + a] = 1; S.high_coverage_removed_alleles += cnt[a]; }
+                }
+            }
+            if(prm->long_read_strand_filter) {
+                // alleles in std::map<std::string> order: the reference's position counter depends on it (:1857-1860)
+                byName.clear();
+                for(int i = 0; i < n; i++) { const Entry& E = ent[(size_t)b0 + i]; if(cnt[E.allele] > 0) { const int j = E.pos_index; byName.emplace_back(std::string((const char*)pos->geno_chars + pos->geno_off[j], (size_t)(pos->geno_off[j + 1] - pos->geno_off[j])), E.allele); } }
+                std::sort(byName.begin(), byName.end()); byName.erase(std::unique(byName.begin(), byName.end()), byName.end());
+                bool kickedOne = false;
+                for(const auto& an : byName) {
+                    const int a = an.second, total = cnt[a], minStrand = std::min(rev[a], total - rev[a]);
+                    const double minStrandFreq = (double)minStrand / (double)total;
+                    if(total >= prm->strand_min_allele_coverage) {
+                        S.strand_alleles_enough_coverage++;
+                        if(minStrandFreq < prm->strand_min_freq) { ignoreAllele[(size_t)aOff[e] + a] = 1; S.strand_removed_alleles++; kickedOne = true; }
+                    }
+                    if(kickedOne) S.strand_positions_with_removed++;
                 }
             }
         }

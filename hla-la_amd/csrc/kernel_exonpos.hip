@@ -143,6 +143,8 @@ __global__ void k_exon_positions(const DevBatch* __restrict__ Bp, const DevTable
             o.read_pair[slot] = p; o.read_weighted_ok[2 * slot] = w0; o.read_weighted_ok[2 * slot + 1] = -1;
             o.read_fraction_ok[2 * slot] = f0; o.read_fraction_ok[2 * slot + 1] = -1; o.read_distance[slot] = -1;
             o.read_cols_nongap[2 * slot] = use0 ? cng0 : 0; o.read_cols_nongap[2 * slot + 1] = 0;
+            if(o.read_reverse) { o.read_reverse[2 * slot] = B.chain_reverse[ch]; o.read_reverse[2 * slot + 1] = 0; }
+            if(o.read_mapq) { o.read_mapq[2 * slot] = B.mate_mapq[p]; o.read_mapq[2 * slot + 1] = -1; }
         }
         return;
     }
@@ -190,6 +192,8 @@ __global__ void k_exon_positions(const DevBatch* __restrict__ Bp, const DevTable
         o.read_pair[slot] = p; o.read_weighted_ok[2 * slot] = w[0]; o.read_weighted_ok[2 * slot + 1] = w[1];
         o.read_fraction_ok[2 * slot] = f[0]; o.read_fraction_ok[2 * slot + 1] = f[1]; o.read_distance[slot] = dist;
         o.read_cols_nongap[2 * slot] = use[0] ? cng[0] : 0; o.read_cols_nongap[2 * slot + 1] = use[1] ? cng[1] : 0;
+        if(o.read_reverse) { o.read_reverse[2 * slot] = B.chain_reverse[B.best_chain[2 * p]]; o.read_reverse[2 * slot + 1] = B.chain_reverse[B.best_chain[2 * p + 1]]; }
+        if(o.read_mapq) { o.read_mapq[2 * slot] = B.mate_mapq[2 * p]; o.read_mapq[2 * slot + 1] = B.mate_mapq[2 * p + 1]; }
     }
 }
 

@@ -389,6 +389,8 @@ typedef struct {
     int32_t* geno_off;         /* [cap_pos+1] genotype / qualities of position j: [geno_off[j], geno_off[j+1])               */
     uint8_t* geno_chars;       /* ::genotype                                                                                 */
     uint8_t* qual_chars;       /* ::qualities (0 where the genotype is "_" and carries no quality)                            */
+    uint8_t* read_reverse;     /* [2*cap_reads] ::reverse of the positions of mate 1, mate 2 (strand of the chosen alignment); may be NULL */
+    double*  read_mapq;        /* [2*cap_reads] ::mapQ = ::mapQ_genomic of the positions of mate 1, mate 2 (-1: no mate 2); may be NULL     */
 } hlala_exon_positions_out;
 
 /* returns HLALA_E_CAPACITY (with the needed n_* filled in) when an array is too small */
@@ -409,12 +411,16 @@ typedef struct {
     int32_t high_coverage_filter;        /* highCoverage_filter_alleles (false; true with min coverage 1 / freq 0.15 at :944-946)    */
     int32_t high_coverage_min_coverage;  /* highCoverage_minCoverage (100)                                                          */
     double  high_coverage_min_freq;      /* highCoverage_minAlleleFreq (0.2)                                                        */
+    int32_t long_read_strand_filter;     /* longReadsMode set && longReads_filterStrand (true, HLATyper.cpp:77): alleles seen >=      */
+    int32_t strand_min_allele_coverage;  /* longReads_filterStrand_minAlleleCoverage (100) times whose rarer strand is below         */
+    double  strand_min_freq;             /* longReads_filterStrand_minStrandFreq (0.1) are ignored, :1846-1855; needs read_reverse    */
 } hlala_filter_params;
 typedef struct {
     int64_t considered_positions, positions_with_removed_alleles, considered_alleles, removed_alleles;   /* :1703-1707 */
     int64_t reads_kicked_out, reads_kicked_out_robust;                                                   /* :1709, :1714 */
     int64_t high_coverage_positions, high_coverage_removed_alleles;                                      /* :1865-1868 */
     int64_t bases_used;                                                                                  /* HLATypeInference_thisLocus_bases_used, :2122 */
+    int64_t strand_alleles_enough_coverage, strand_removed_alleles, strand_positions_with_removed;      /* :1874-1876 (the last one counts as the reference does: once per allele visited after a removal) */
 } hlala_filter_stats;
 int  hlala_filter_positions(const hlala_exon_positions_out* pos, const hlala_filter_params* prm, uint8_t* pos_use /* [n_pos] */,
                             uint8_t* read_ignored /* [n_reads] or NULL */, hlala_filter_stats* stats /* or NULL */);

@@ -1785,6 +1785,7 @@ int orc_exon_positions(int n_pairs, int stride, const int32_t* pair_status, cons
                     o->read_pair[nReads] = p; o->read_weighted_ok[2 * nReads] = w[0]; o->read_weighted_ok[2 * nReads + 1] = w[1];
                     o->read_fraction_ok[2 * nReads] = alignmentFractionOK(a[0]); o->read_fraction_ok[2 * nReads + 1] = alignmentFractionOK(a[1]);
                     o->read_distance[nReads] = dist; o->read_cols_nongap[2 * nReads] = cng[0]; o->read_cols_nongap[2 * nReads + 1] = cng[1];
+                    if(o->read_mapq) { o->read_mapq[2 * nReads] = a[0].mapQ; o->read_mapq[2 * nReads + 1] = a[1].mapQ; }      /* thisPosition.mapQ = alignment.mapQ, :3387 */
                     o->pos_off[nReads] = nPos;
                     int q = nPos, ch = nChars;
                     for(auto& e : cleaned) {
@@ -1832,6 +1833,7 @@ int orc_exon_positions_unpaired(int n_reads, int stride, const int32_t* pair_sta
                     o->read_pair[nReads] = r; o->read_weighted_ok[2 * nReads] = w; o->read_weighted_ok[2 * nReads + 1] = -1;
                     o->read_fraction_ok[2 * nReads] = alignmentFractionOK(a); o->read_fraction_ok[2 * nReads + 1] = -1;
                     o->read_distance[nReads] = -1; o->read_cols_nongap[2 * nReads] = cng; o->read_cols_nongap[2 * nReads + 1] = 0;
+                    if(o->read_mapq) { o->read_mapq[2 * nReads] = a.mapQ; o->read_mapq[2 * nReads + 1] = -1; }
                     o->pos_off[nReads] = nPos;
                     int q = nPos, ch = nChars;
                     for(auto& e : read_exonPositions) {
@@ -1929,14 +1931,19 @@ int orc_filter_positions(const hlala_exon_positions_out* pos, const hlala_filter
     }
     {   // high-coverage allele filter, :1722-1862
         std::map<unsigned int, std::map<std::string, int>> perPosition_allele_counts;
+        std::map<unsigned int, std::map<std::string, std::pair<int, int>>> perPosition_allele_counts_byStrand;
         for(int readI = 0; readI < nReads; readI++)
             for(int j = pos->pos_off[readI]; j < pos->pos_off[readI + 1]; j++) {
                 if(ignore_readIDs.count(readI)) continue;
                 if(mapQ_position(j) < prm->min_per_position_mapq) continue;
                 int position = pos->pos_exon[j]; std::string allele = genotype(j);
                 if(perPosition_ignore_alleles.count(position) && (perPosition_ignore_alleles.at(position).count(allele))) continue;
-                if(perPosition_allele_counts[position].count(allele) == 0) perPosition_allele_counts[position][allele] = 0;
+                if(perPosition_allele_counts[position].count(allele) == 0) { perPosition_allele_counts[position][allele] = 0; perPosition_allele_counts_byStrand[position][allele] = std::make_pair(0, 0); }
                 perPosition_allele_counts.at(position).at(allele)++;
+                if(pos->read_reverse) {                                                           /* onePositionSpecifier.reverse, :1768-1775 */
+                    bool reverse = pos->read_reverse[2 * readI + (pos->pos_mate[j] == 2 ? 1 : 0)] != 0;
+                    if(reverse) perPosition_allele_counts_byStrand.at(position).at(allele).second++; else perPosition_allele_counts_byStrand.at(position).at(allele).first++;
+                }
             }
         for(auto position : perPosition_allele_counts) {
             int count_position = 0;
@@ -1947,6 +1954,17 @@ int orc_filter_positions(const hlala_exon_positions_out* pos, const hlala_filter
                     double aF = (double)allele.second / (double)count_position;
                     if((aF < prm->high_coverage_min_freq) && prm->high_coverage_filter) { perPosition_ignore_alleles[position.first].insert(allele.first); S.high_coverage_removed_alleles += allele.second; }
                 }
+            }
+            bool kickedOutAtLeastOneAllele_sF = false;                                            /* :1826-1861 */
+            if(pos->read_reverse) for(auto allele : perPosition_allele_counts_byStrand.at(position.first)) {
+                int totalCount = allele.second.first + allele.second.second;
+                int minStrandCount = (allele.second.first < allele.second.second) ? allele.second.first : allele.second.second;
+                double minStrandFreq = (double)minStrandCount / (double)totalCount;
+                if(prm->long_read_strand_filter && (totalCount >= prm->strand_min_allele_coverage)) {
+                    S.strand_alleles_enough_coverage++;
+                    if(minStrandFreq < prm->strand_min_freq) { perPosition_ignore_alleles[position.first].insert(allele.first); S.strand_removed_alleles++; kickedOutAtLeastOneAllele_sF = true; }
+                }
+                if(kickedOutAtLeastOneAllele_sF) S.strand_positions_with_removed++;
             }
         }
     }

@@ -105,5 +105,9 @@ def test_exon_positions_match_oracle(pkg, oracle, seed, G, k, n_pairs):
         # FP64 sums in column order with host-built pCorrect: bit-identical
         assert np.array_equal(g["read_weighted_ok"], e["read_weighted_ok"])
         assert np.array_equal(g["read_fraction_ok"], e["read_fraction_ok"], equal_nan=True)
+        # oneExonPosition::mapQ of either mate (posteriors: device exp(), as in test_gpu_align) and ::reverse = strand of the chosen alignment
+        assert np.allclose(g["read_mapq"], e["read_mapq"], rtol=1e-9, atol=1e-15)
+        best = exp_pairs["best_chain"].reshape(-1, 2)[g["read_pair"]].reshape(-1)
+        assert np.array_equal(g["read_reverse"], b["chain_reverse"][best])
         total += e["n_pos"]
     assert total > 1000

@@ -90,3 +90,28 @@ def test_product_filters_match_oracle(pkg, oracle, seed, n_reads, n_exon):
         assert np.array_equal(ug, ue) and np.array_equal(ig, ie) and sg == se
     if n_reads >= 900:
         assert se["considered_positions"] > 0 and se["removed_alleles"] > 0
+
+
+@pytest.mark.parametrize("seed,n_reads,n_exon", [(11, 1500, 150), (12, 4000, 300)])
+def test_long_read_strand_filter_matches_oracle(pkg, oracle, seed, n_reads, n_exon):
+    """longReads_filterStrand (hla/HLATyper.cpp:1826-1861): alleles seen often enough whose rarer strand is below the minimum are ignored."""
+    rng = np.random.default_rng(seed)
+    e = synth_positions(rng, n_reads, n_exon)
+    # strands: most reads forward with a few reverse, so that common alleles have a thin rarer strand; some reads get balanced strands
+    rev = (rng.random(2 * n_reads) < 0.07).astype(np.uint8)
+    e["read_reverse"] = rev
+    e["read_mapq"] = np.ones(2 * n_reads)
+    lib = C.CDLL(pkg.LIB_PATH)
+    seen = 0
+    for cov, fr in ((100, 0.1), (30, 0.05), (10, 0.2)):
+        prm = pkg.default_filter_params(long_read_strand_filter=1, strand_min_allele_coverage=cov, strand_min_freq=fr)
+        ue, ie, se = ob.filter_positions(e, prm)
+        ug, ig, sg = pkg.filter_positions(lib, e, prm)
+        assert np.array_equal(ug, ue) and np.array_equal(ig, ie) and sg == se
+        seen += se["strand_removed_alleles"]
+        assert se["strand_alleles_enough_coverage"] > 0
+    assert seen > 0
+    # without the strand array the filter cannot run
+    e2 = {k: v for k, v in e.items() if k != "read_reverse"}
+    with pytest.raises(Exception):
+        pkg.filter_positions(lib, e2, pkg.default_filter_params(long_read_strand_filter=1))
