@@ -261,6 +261,147 @@ def exon_in_from_positions(e, pos_use, cluster_seq, n_clusters, exon_length):
                 pos_use=np.ascontiguousarray(pos_use, np.uint8))
 
 
+class LocusInfo(C.Structure):
+    _fields_ = [("n_clusters", C.c_int32), ("n_columns", C.c_int32), ("n_exons", C.c_int32), ("level_min", C.c_int32), ("level_max", C.c_int32), ("n_types", C.c_int32),
+                ("cluster_seq", c_u8p), ("level_to_exon", c_i32p), ("col_level", c_i32p), ("col_exon", c_i32p), ("col_exon_pos", c_i32p), ("exon_length", c_i32p)]
+
+
+class LocusReportIn(C.Structure):
+    _fields_ = [("pos", C.POINTER(ExonPositionsOut)), ("filter", C.POINTER(FilterParams)), ("unit_name_1", C.POINTER(C.c_char_p)), ("unit_name_2", C.POINTER(C.c_char_p)),
+                ("long_read_mode", C.c_int32), ("n_clusters", C.c_int32), ("pair_ll", c_f64p), ("mis_avg", c_f64p), ("mis_min", c_f64p), ("order", c_i32p),
+                ("p_normalized", c_f64p), ("call", C.c_void_p), ("kmers_covered", C.c_double * 2), ("unaccounted_min_coverage", C.c_int32), ("reserved", C.c_int32),
+                ("unaccounted_min_fraction", C.c_double)]
+
+
+class LocusReportOut(C.Structure):
+    _fields_ = [("locus_coverage", C.c_double), ("first_decile_coverage", C.c_double), ("minimum_coverage", C.c_double), ("avg_column_error", C.c_double),
+                ("min_column_p", C.c_double), ("bases_used", C.c_int64), ("n_columns_unaccounted", C.c_int32), ("n_utilized_reads", C.c_int32),
+                ("n_piled_positions", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Typer:
+    """hlala_typer wrapper (host code): graph level names, gene level ranges, exon files and allele clusters of a locus, result files."""
+
+    def __init__(self, lib, graph_dir):
+        self.lib = lib; self.h = C.c_void_p()
+        lib.hlala_typer_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.hlala_typer_last_error.restype = C.c_char_p
+        self._check(lib.hlala_typer_open(str(graph_dir).encode(), C.byref(self.h)))
+        lib.hlala_typer_n_levels.argtypes = [C.c_void_p]; lib.hlala_typer_level_name.argtypes = [C.c_void_p, C.c_int32]; lib.hlala_typer_level_name.restype = C.c_char_p
+        lib.hlala_typer_level_of.argtypes = [C.c_void_p, C.c_char_p]; lib.hlala_typer_n_genes.argtypes = [C.c_void_p]
+        lib.hlala_typer_gene.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), c_i32p, c_i32p]
+        lib.hlala_typer_load_g_groups.argtypes = [C.c_void_p, C.c_char_p]
+        lib.hlala_typer_locus.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+        lib.hlala_typer_close.argtypes = [C.c_void_p]; lib.hlala_typer_close.restype = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HlalaError(self.lib.hlala_typer_last_error().decode())
+
+    def level_names(self):
+        return [self.lib.hlala_typer_level_name(self.h, i).decode() for i in range(self.lib.hlala_typer_n_levels(self.h))]
+
+    def level_of(self, name):
+        return self.lib.hlala_typer_level_of(self.h, name.encode())
+
+    def genes(self):
+        """[(gene, first level, last level)] in name order: the intervals of hlala_set_gene_intervals."""
+        out = []
+        for i in range(self.lib.hlala_typer_n_genes(self.h)):
+            nm = C.c_char_p(); a = C.c_int32(); b = C.c_int32()
+            self._check(self.lib.hlala_typer_gene(self.h, i, C.byref(nm), C.byref(a), C.byref(b)))
+            out.append((nm.value.decode(), a.value, b.value))
+        return out
+
+    def load_g_groups(self, path):
+        self._check(self.lib.hlala_typer_load_g_groups(self.h, str(path).encode()))
+
+    def locus(self, name, exons=None):
+        h = C.c_void_p()
+        if exons is None:
+            arr, n = None, 0
+        else:
+            arr = (C.c_char_p * len(exons))(*[e.encode() for e in exons]); n = len(exons)
+        self._check(self.lib.hlala_typer_locus(self.h, name.encode(), n, arr, C.byref(h)))
+        return Locus(self, h, name)
+
+    def close(self):
+        if self.h:
+            self.lib.hlala_typer_close(self.h); self.h = None
+
+
+class Locus:
+    """hlala_locus wrapper: exon columns and allele clusters of one locus."""
+
+    def __init__(self, typer, h, name):
+        self.typer, self.lib, self.h, self.name = typer, typer.lib, h, name
+        lib = self.lib
+        lib.hlala_locus_get.argtypes = [C.c_void_p, C.POINTER(LocusInfo)]
+        lib.hlala_locus_cluster_id.argtypes = [C.c_void_p, C.c_int32]; lib.hlala_locus_cluster_id.restype = C.c_char_p
+        lib.hlala_locus_type_cluster.argtypes = [C.c_void_p, C.c_char_p]
+        lib.hlala_locus_cluster_kmers.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, c_i32p, c_i32p]
+        lib.hlala_locus_write_files.argtypes = [C.c_void_p, C.POINTER(LocusReportIn), C.c_char_p, C.POINTER(LocusReportOut)]
+        lib.hlala_locus_free.argtypes = [C.c_void_p]; lib.hlala_locus_free.restype = None
+        i = LocusInfo(); typer._check(lib.hlala_locus_get(h, C.byref(i)))
+        nl = i.level_max - i.level_min + 1
+        cp = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, (max(n, 1),))[:n].astype(dt).copy()
+        self.n_clusters, self.n_columns, self.n_exons, self.level_min, self.level_max, self.n_types = i.n_clusters, i.n_columns, i.n_exons, i.level_min, i.level_max, i.n_types
+        self.cluster_seq = cp(i.cluster_seq, i.n_clusters * i.n_columns, np.uint8).reshape(i.n_clusters, i.n_columns)
+        self.level_to_exon = cp(i.level_to_exon, nl, np.int32); self.col_level = cp(i.col_level, i.n_columns, np.int32)
+        self.col_exon = cp(i.col_exon, i.n_columns, np.int32); self.col_exon_pos = cp(i.col_exon_pos, i.n_columns, np.int32); self.exon_length = cp(i.exon_length, i.n_exons, np.int32)
+
+    def cluster_id(self, c):
+        return self.lib.hlala_locus_cluster_id(self.h, c).decode()
+
+    def type_cluster(self, hla_type):
+        return self.lib.hlala_locus_type_cluster(self.h, hla_type.encode())
+
+    def cluster_kmers(self, cluster, k=31):
+        """(query k-mers without '*', total number of k-mers) of a cluster's exon sequences."""
+        nq = C.c_int32(); nt = C.c_int32()
+        self.lib.hlala_locus_cluster_kmers(self.h, cluster, k, None, 0, C.byref(nq), C.byref(nt))
+        buf = C.create_string_buffer(max(1, nq.value * k))
+        self.typer._check(self.lib.hlala_locus_cluster_kmers(self.h, cluster, k, buf, nq.value, C.byref(nq), C.byref(nt)))
+        raw = buf.raw[:nq.value * k].decode()
+        return [raw[i * k:(i + 1) * k] for i in range(nq.value)], nt.value
+
+    def write_files(self, out_dir, e, names1, names2, pair_ll, mis_avg, mis_min, order, p_normalized, call, kmers_covered=(-1.0, -1.0), params=None,
+                    long_read_mode=False, unaccounted_min_coverage=30, unaccounted_min_fraction=0.2):
+        """hlala_locus_write_files; e = dict of Batch.exon_positions(), call = CallOut.  Returns LocusReportOut."""
+        o, keep = exon_positions_struct(e)
+        prm = params or default_filter_params()
+        r = LocusReportIn(); r.pos = C.pointer(o); r.filter = C.pointer(prm)
+        n1 = (C.c_char_p * max(1, len(names1)))(*[n.encode() for n in names1]); r.unit_name_1 = n1
+        if names2 is not None:
+            n2 = (C.c_char_p * max(1, len(names2)))(*[n.encode() for n in names2]); r.unit_name_2 = n2
+        r.long_read_mode = int(bool(long_read_mode)); r.n_clusters = self.n_clusters
+        arrs = [np.ascontiguousarray(pair_ll, np.float64), np.ascontiguousarray(mis_avg, np.float64), np.ascontiguousarray(mis_min, np.float64),
+                np.ascontiguousarray(order, np.int32), np.ascontiguousarray(p_normalized, np.float64)]
+        r.pair_ll, r.mis_avg, r.mis_min = (a.ctypes.data_as(c_f64p) for a in arrs[:3]); r.order = arrs[3].ctypes.data_as(c_i32p); r.p_normalized = arrs[4].ctypes.data_as(c_f64p)
+        r.call = C.cast(C.pointer(call), C.c_void_p); r.kmers_covered[0], r.kmers_covered[1] = float(kmers_covered[0]), float(kmers_covered[1])
+        r.unaccounted_min_coverage = unaccounted_min_coverage; r.unaccounted_min_fraction = unaccounted_min_fraction
+        out = LocusReportOut()
+        self.typer._check(self.lib.hlala_locus_write_files(self.h, C.byref(r), str(out_dir).encode(), C.byref(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            self.lib.hlala_locus_free(self.h); self.h = None
+
+
+def typer_begin_output(lib, out_dir, unaccounted_min_fraction=0.2):
+    lib.hlala_typer_begin_output.argtypes = [C.c_char_p, C.c_double]; lib.hlala_typer_last_error.restype = C.c_char_p
+    if lib.hlala_typer_begin_output(str(out_dir).encode(), unaccounted_min_fraction) != 0:
+        raise HlalaError(lib.hlala_typer_last_error().decode())
+
+
+def typer_end_output(lib, out_dir, loci, very_conservative=False):
+    lib.hlala_typer_end_output.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]; lib.hlala_typer_last_error.restype = C.c_char_p
+    if lib.hlala_typer_end_output(str(out_dir).encode(), ",".join(loci).encode(), int(very_conservative)) != 0:
+        raise HlalaError(lib.hlala_typer_last_error().decode())
+
+
+
 class InsertSizeOut(C.Structure):
     _fields_ = [("mean", C.c_double), ("sd", C.c_double), ("n_used", C.c_int32), ("n_skipped", C.c_int32), ("total_weight", C.c_double)]
 
@@ -390,6 +531,9 @@ EXPORTED_SYMBOLS = [
     "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
     "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
     "hlala_bam_extract_seeds", "hlala_seed_batch_desc", "hlala_seed_batch_name", "hlala_seed_batch_free", "hlala_bam_last_error",
+    "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
+    "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",
+    "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_typer_end_output",
 ]
 
 
@@ -483,6 +627,16 @@ class Context:
                                               pn.ctypes.data_as(c_f64p), marg.ctypes.data_as(c_f64p), C.byref(out)), "hlala_call_locus")
         return dict(order=order, p_normalized=pn, cluster_marginal=marg, first_cluster=out.first_cluster, second_cluster=out.second_cluster,
                     first_marginal=out.first_marginal, second_p=out.second_p, ll_max=out.ll_max, max_pair=out.max_pair, n_sort_ties=out.n_sort_ties)
+
+    def kmer_presence(self, batch, queries, k=31, pair_mask=None):
+        """hlala_kmer_presence: which query k-mers (strings of length k) occur, in canonical form, in the reads of `batch`."""
+        n = len(queries)
+        buf = "".join(queries).encode(); assert len(buf) == n * k
+        present = np.zeros(max(1, n), np.uint8)
+        mask = None if pair_mask is None else np.ascontiguousarray(pair_mask, np.uint8)
+        self.lib.hlala_kmer_presence.argtypes = [C.c_void_p, C.c_void_p, c_u8p, C.c_int32, C.c_int32, C.c_char_p, c_u8p]
+        self._check(self.lib.hlala_kmer_presence(self.h, batch.b, None if mask is None else mask.ctypes.data_as(c_u8p), k, n, buf, present.ctypes.data_as(c_u8p)), "hlala_kmer_presence")
+        return present[:n]
 
     def estimate_insert_size(self, batch_in: dict):
         """processBAM::estimateInsertSize on the primaries of `batch_in` (hlala_estimate_insert_size)."""

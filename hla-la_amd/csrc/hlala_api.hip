@@ -20,6 +20,7 @@
 #include "kernel_typer.hip"
 #include "kernel_call.hip"
 #include "kernel_exonpos.hip"
+#include "kernel_kmer.hip"
 
 namespace hlala {
 size_t proj_slab_bytes_host(int stride, int maxNodesPerLevel) { return proj_slab_bytes(stride, maxNodesPerLevel); }
@@ -1009,13 +1010,51 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
     return done(HLALA_OK);
 }
 
+extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present)
+{
+    if(!c || !b || n_queries < 0 || (n_queries > 0 && (!queries || !present))) return HLALA_E_ARG;
+    if(k < 1 || k > 31) { c->err = "hlala_kmer_presence: k must be in 1..31 (2-bit codes in one 64-bit word)"; return HLALA_E_ARG; }
+    if(n_queries == 0) return HLALA_OK;
+    // canonical codes of the queries; a query with a character outside ACGT cannot occur in a read k-mer over ACGT
+    std::vector<u64> canon((size_t)n_queries, ~0ull);
+    std::vector<u64> uniq;
+    for(int i = 0; i < n_queries; i++) {
+        u64 f = 0, rc = 0; bool ok = true;
+        for(int j = 0; j < k; j++) {
+            const char ch = queries[(size_t)i * k + j];
+            const int cj = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+            if(cj > 3) { ok = false; break; }
+            f = (f << 2) | (u64)cj; rc |= (u64)(3 - cj) << (2 * j);
+        }
+        if(ok) { canon[i] = rc < f ? rc : f; uniq.push_back(canon[i]); }
+    }
+    std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    if(uniq.size() > (size_t)hlala::KMER_QCAP) { c->err = "hlala_kmer_presence: more than 4096 distinct query k-mers in one call"; return HLALA_E_CAPACITY; }
+    memset(present, 0, (size_t)n_queries);
+    if(uniq.empty() || b->B.n_pairs <= 0) return HLALA_OK;
+    std::vector<void*> tmp;
+    auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
+    int rc = 0; u64* dQ = nullptr; uint8_t *dP = nullptr, *dMask = nullptr;
+    if((rc = dev_upload(c, tmp, uniq.data(), uniq.size(), &dQ)) || (rc = dev_alloc(c, tmp, uniq.size(), &dP, true))) return done(rc);
+    if(pair_mask && (rc = dev_upload(c, tmp, pair_mask, (size_t)b->B.n_pairs, &dMask))) return done(rc);
+    const int nReads = b->B.unpaired ? b->B.n_pairs : 2 * b->B.n_pairs;
+    const unsigned grid = (unsigned)std::min<long long>((long long)nReads, (long long)c->stitch_grid);
+    hipLaunchKernelGGL(k_kmer_presence, dim3(grid), dim3(64), 0, c->stream, b->dB, (const uint8_t*)dMask, (int)k, (int)uniq.size(), (const u64*)dQ, dP);
+    if((rc = check_launch(c, "k_kmer_presence"))) return done(rc);
+    std::vector<uint8_t> hp(uniq.size());
+    if((rc = dl(c, hp.data(), dP, uniq.size()))) return done(rc);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for(int i = 0; i < n_queries; i++) if(canon[i] != ~0ull) present[i] = hp[(size_t)(std::lower_bound(uniq.begin(), uniq.end(), canon[i]) - uniq.begin())];
+    return done(HLALA_OK);
+}
+
 extern "C" int hlala_abi_sizeof(const char* name)
 {
     if(!name) return -1;
     const std::string n(name);
 #define SZ(t) if(n == #t) return (int)sizeof(t);
     SZ(hlala_graph_desc) SZ(hlala_contigs_desc) SZ(hlala_params) SZ(hlala_graph_info) SZ(hlala_batch_in) SZ(hlala_seeds_in)
-    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats) SZ(hlala_insert_size_out)
+    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats) SZ(hlala_insert_size_out) SZ(hlala_locus_info) SZ(hlala_locus_report_in) SZ(hlala_locus_report_out)
 #undef SZ
     return -1;
 }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/hlala_gpu.h"
+#include "host_internal.h"
 
 namespace {
 
@@ -29,6 +30,12 @@ struct Entry { int pos_index; int read; int allele; double w; };     // one posi
 }  // namespace
 
 extern "C" int hlala_filter_positions(const hlala_exon_positions_out* pos, const hlala_filter_params* prm, uint8_t* pos_use, uint8_t* read_ignored, hlala_filter_stats* stats)
+{
+    return hlala_host::filter_positions_impl(pos, prm, pos_use, read_ignored, stats, nullptr);
+}
+
+int hlala_host::filter_positions_impl(const hlala_exon_positions_out* pos, const hlala_filter_params* prm, uint8_t* pos_use, uint8_t* read_ignored, hlala_filter_stats* stats,
+                                      std::vector<std::vector<AlleleTally>>* tallies)
 {
     if(!pos || !prm || !pos_use) return HLALA_E_ARG;
     const int nReads = pos->n_reads, nPos = pos->n_pos;
@@ -124,12 +131,27 @@ extern "C" int hlala_filter_positions(const hlala_exon_positions_out* pos, const
                 if(prm->long_read_strand_filter && pos->read_reverse[2 * E.read + (pos->pos_mate[E.pos_index] == 2 ? 1 : 0)]) rev[E.allele]++;
             }
             if(count_position == 0) continue;
+            std::vector<hlala_host::AlleleTally>* tal = nullptr;
+            if(tallies) {
+                // what the reports print per allele of a position (perPosition_allele_counts / _byStrand / _strand1, :1731-1786): the counts of this stage
+                if((int)tallies->size() <= e) tallies->resize((size_t)e + 1);
+                tal = &(*tallies)[e]; tal->assign((size_t)nAllelesOf[e], hlala_host::AlleleTally());
+                for(int i = 0; i < n; i++) {
+                    const Entry& E = ent[(size_t)b0 + i]; if(ignoreRead[E.read] || ignoreAllele[(size_t)aOff[e] + E.allele]) continue;
+                    hlala_host::AlleleTally& t = (*tal)[E.allele]; const int j = E.pos_index;
+                    if(t.count == 0) t.allele.assign((const char*)pos->geno_chars + pos->geno_off[j], (size_t)(pos->geno_off[j + 1] - pos->geno_off[j]));
+                    t.count++;
+                    if(pos->read_reverse && pos->read_reverse[2 * E.read + (pos->pos_mate[j] == 2 ? 1 : 0)]) t.reverse++;
+                    if(pos->pos_mate[j] == 1) t.from_first++;
+                }
+            }
             if(count_position >= prm->high_coverage_min_coverage) {
                 S.high_coverage_positions++;
                 for(int a = 0; a < nAllelesOf[e]; a++) {
                     if(cnt[a] == 0) continue;
                     const double aF = (double)cnt[a] / (double)count_position;
                     if((aF < prm->high_coverage_min_freq) && prm->high_coverage_filter) { ignoreAllele[(size_t)aOff[e] + a] = 1; S.high_coverage_removed_alleles += cnt[a]; }
+                    else if(tal) (*tal)[a].post_filtering = cnt[a];                                    // perPosition_allele_counts_postFiltering, :1821
                 }
             }
             if(prm->long_read_strand_filter) {

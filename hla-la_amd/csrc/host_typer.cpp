@@ -1,0 +1,513 @@
+// host_typer.cpp -- the HLATyper host side around the kernels: which graph levels are which exon column, the allele
+// clusters of a locus, G groups, the pile-up and the per-locus result files of HLATyper::HLATypeInference.
+//
+//   hlala_typer_open        graph loci = column names of the segment files in PRG/segments.txt order (Graph::readGraphLoci,
+//                           Graph/Graph.cpp:2563-2614), gene level boundaries (hla/HLATyper.cpp:104-214), the file list of PRG/
+//   hlala_typer_locus       exon files of one locus -> combined exon columns, allele sequences, clusters of identical alleles
+//                           (hla/HLATyper.cpp:1180-1372; find_file_for_exon :3130-3200; the exon table fill_loci_2_exons :2812-2846)
+//   hlala_locus_write_files pile-up, read IDs, all-pairs table, column incompatibilities, best-guess rows (:1883-2044, :2451-2488,
+//                           :2543-2759; G groups :4086-4207)
+//
+// Text goes through std::ostream with default formatting, exactly the calls the reference makes (Utilities::DtoStr / ItoStr are
+// `stringstream << value`, Utilities.cpp:576-597), so numbers print the same way.  Data is flat: positions are bucketed by exon
+// column with a counting pass, never as maps of maps of structs.
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/hlala_gpu.h"
+#include "host_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& m) { g_err = m; return code; }
+
+// Utilities::split(string, string), Utilities.cpp:531-568 (empty fields are kept)
+std::vector<std::string> split(const std::string& in, const std::string& d)
+{
+    std::vector<std::string> out;
+    if(in.empty()) return out;
+    size_t s = 0, p;
+    while((p = in.find(d, s)) != std::string::npos) { out.push_back(in.substr(s, p - s)); s = p + d.size(); }
+    out.push_back(in.substr(s));
+    return out;
+}
+void erase_nl(std::string& s) { while(!s.empty() && (s.back() == '\r' || s.back() == '\n')) s.pop_back(); }
+std::string join(const std::vector<std::string>& v, const std::string& d)
+{
+    std::string r;
+    for(size_t i = 0; i < v.size(); i++) { if(i) r += d; r += v[i]; }
+    return r;
+}
+template <class T> std::string to_str(T v) { std::stringstream s; s << v; return s.str(); }      // ItoStr / DtoStr
+
+// the reference's reading loop: `while(stream.good()) { getline; eraseNL; push }` -- a final empty line is part of the result
+bool read_lines(const std::string& path, std::vector<std::string>& lines)
+{
+    std::ifstream f(path.c_str());
+    if(!f.is_open()) return false;
+    while(f.good()) { std::string l; std::getline(f, l); erase_nl(l); lines.push_back(l); }
+    return true;
+}
+
+// Utilities::PhredToPCorrect, Utilities.cpp:357-377
+double phred_to_pcorrect(unsigned char q)
+{
+    if(q == 0) return -1;
+    return 1 - exp(log(10.0) * (((double)q - 33) / -10.0));
+}
+
+// HLATyper::simpleChiSq for two classes (hla/HLATyper.cpp:4258-4320): 1 - cdf of chi-squared with ONE degree of freedom.  boost
+// evaluates that cdf as gamma_p(1/2, x/2) = 1 - erfc(sqrt(x/2)) for half-integer shape; the same two subtractions are made here
+double chi_sq_p(const double observed[2], const double expected[2])
+{
+    double statistic = 0;
+    for(int i = 0; i < 2; i++) statistic += pow((observed[i] - expected[i]), 2) / expected[i];
+    const double cdf = 1 - erfc(sqrt(statistic / 2));
+    return 1 - cdf;
+}
+
+}  // namespace
+
+struct hlala_typer {
+    std::string graphDir;
+    std::vector<std::string> levelNames;                       // graphLoci
+    std::unordered_map<std::string, int> levelOf;              // graphLocus_2_levels
+    std::vector<std::string> files;                            // files_in_graphDir
+    std::vector<std::string> geneNames; std::vector<int> geneFirst, geneLast;       // graphgene_levelBoundaries in std::map (name) order
+    std::map<std::string, std::string> alleleToG; std::set<std::string> gLoci;      // read_G_alleles
+};
+
+struct hlala_locus {
+    std::string name;
+    int C = 0, P = 0, levelMin = -1, levelMax = -1, nTypes = 0;
+    std::vector<uint8_t> clusterSeq;                            // [C*P]
+    std::vector<std::vector<std::string>> members;              // HLAtype_clusters (std::set order)
+    std::vector<std::string> clusterId;                         // members joined by ";"
+    std::map<std::string, int> typeCluster;                     // HLAtype_2_clusterID
+    std::vector<int> colLevel, colExon, colExonPos, exonLength, levelToExon;
+    const hlala_typer* typer = nullptr;
+};
+
+extern "C" const char* hlala_typer_last_error(void) { return g_err.c_str(); }
+
+extern "C" int hlala_typer_open(const char* graph_dir, hlala_typer** out)
+{
+    if(!graph_dir || !out) return fail(HLALA_E_ARG, "hlala_typer_open: null argument");
+    std::unique_ptr<hlala_typer> T(new hlala_typer());
+    T->graphDir = graph_dir;
+    const std::string prg = T->graphDir + "/PRG";
+    std::vector<std::string> segLines;
+    if(!read_lines(prg + "/segments.txt", segLines)) return fail(HLALA_E_ARG, "Cannot open segments file: " + prg + "/segments.txt");
+    // graph loci: the column names of every segment file, in file order (Graph::readGraphLoci)
+    std::vector<std::vector<std::string>> firstFields;
+    for(const std::string& l : segLines) {
+        if(l.empty()) { firstFields.emplace_back(); continue; }
+        std::ifstream f((prg + "/" + l).c_str());
+        if(!f.is_open()) return fail(HLALA_E_ARG, "Cannot open one segment file: " + prg + "/" + l);
+        std::string first; std::getline(f, first); erase_nl(first);
+        firstFields.push_back(split(first, " "));
+        for(size_t i = 1; i < firstFields.back().size(); i++) {
+            const std::string& id = firstFields.back()[i];
+            if(T->levelOf.count(id)) return fail(HLALA_E_ARG, "graph locus appears twice: " + id);           // assert, hla/HLATyper.cpp:90
+            T->levelOf[id] = (int)T->levelNames.size(); T->levelNames.push_back(id);
+        }
+    }
+    // gene boundaries, hla/HLATyper.cpp:104-214
+    std::map<std::string, std::pair<int, int>> bounds;
+    for(size_t li = 0; li < segLines.size(); li++) {
+        const std::string& l = segLines[li];
+        if(l.empty()) continue;
+        const std::vector<std::string> us = split(l, "_");
+        if(us.size() < 2) return fail(HLALA_E_ARG, "segments.txt: unexpected entry " + l);
+        if(us[1] != "gene") continue;
+        if(us.size() < 5) return fail(HLALA_E_ARG, "segments.txt: unexpected gene entry " + l);
+        const std::string& gene = us[2];
+        if(firstFields[li].empty() || firstFields[li][0] != "IndividualID") return fail(HLALA_E_ARG, "segment file without IndividualID header: " + l);
+        if(!bounds.count(gene)) bounds[gene] = std::make_pair(-1, -1);
+        for(size_t i = 1; i < firstFields[li].size(); i++) {
+            const int lv = T->levelOf.at(firstFields[li][i]);
+            std::pair<int, int>& b = bounds[gene];
+            if(b.first == -1 || lv < b.first) b.first = lv;
+            if(b.second == -1 || lv > b.second) b.second = lv;
+        }
+    }
+    for(const auto& g : bounds) { T->geneNames.push_back(g.first); T->geneFirst.push_back(g.second.first); T->geneLast.push_back(g.second.second); }
+    // Utilities::filesInDirectory, Utilities.cpp:1337-1366
+    DIR* d = opendir(prg.c_str());
+    if(!d) return fail(HLALA_E_ARG, "Cannot open directory " + prg);
+    while(dirent* e = readdir(d)) { std::string n(e->d_name); if(n == "." || n == "..") continue; T->files.push_back(prg + "/" + n); }
+    closedir(d);
+    *out = T.release();
+    return HLALA_OK;
+}
+extern "C" void hlala_typer_close(hlala_typer* t) { delete t; }
+extern "C" int32_t hlala_typer_n_levels(const hlala_typer* t) { return t ? (int32_t)t->levelNames.size() : -1; }
+extern "C" const char* hlala_typer_level_name(const hlala_typer* t, int32_t level) { return (t && level >= 0 && level < (int)t->levelNames.size()) ? t->levelNames[level].c_str() : nullptr; }
+extern "C" int32_t hlala_typer_level_of(const hlala_typer* t, const char* id) { if(!t || !id) return -1; auto it = t->levelOf.find(id); return it == t->levelOf.end() ? -1 : it->second; }
+extern "C" int32_t hlala_typer_n_genes(const hlala_typer* t) { return t ? (int32_t)t->geneNames.size() : -1; }
+extern "C" int hlala_typer_gene(const hlala_typer* t, int32_t i, const char** name, int32_t* first_level, int32_t* last_level)
+{
+    if(!t || i < 0 || i >= (int)t->geneNames.size()) return HLALA_E_ARG;
+    if(name) *name = t->geneNames[i].c_str();
+    if(first_level) *first_level = t->geneFirst[i];
+    if(last_level) *last_level = t->geneLast[i];
+    return HLALA_OK;
+}
+
+// ---- G groups, hla/HLATyper.cpp:4150-4207
+extern "C" int hlala_typer_load_g_groups(hlala_typer* t, const char* path)
+{
+    if(!t || !path) return fail(HLALA_E_ARG, "hlala_typer_load_g_groups: null argument");
+    std::vector<std::string> lines;
+    if(!read_lines(path, lines)) return fail(HLALA_E_ARG, std::string("Can't open file ") + path);
+    t->alleleToG.clear(); t->gLoci.clear();
+    for(const std::string& line : lines) {
+        if(line.empty() || line[0] == '#') continue;
+        const std::vector<std::string> c = split(line, ";");
+        if(c.size() < 2 || c[0].empty() || c[0].back() != '*') return fail(HLALA_E_ARG, "G group file: unexpected line " + line);
+        const std::string& locusStar = c[0];
+        t->gLoci.insert(locusStar.substr(0, locusStar.size() - 1));
+        std::string code;
+        if(!c.back().empty()) code = c.back();
+        else { if(c.size() != 3) return fail(HLALA_E_ARG, "G group file: unexpected line " + line); code = c[1]; }
+        code = locusStar + code;
+        for(const std::string& a : split(c[1], "/")) t->alleleToG[locusStar + a] = code;
+    }
+    return HLALA_OK;
+}
+
+namespace {
+// translate_allele_list_to_G_allele, hla/HLATyper.cpp:4095-4148
+std::string to_g_group(const hlala_typer& T, const std::vector<std::string>& alleles, bool& perfectly)
+{
+    std::map<std::string, int> groups;
+    for(const std::string& a : alleles) { auto it = T.alleleToG.find(a); if(it == T.alleleToG.end()) continue; groups[it->second]++; }
+    if(groups.empty()) { perfectly = false; return join(alleles, ";"); }
+    if(groups.size() == 1) { perfectly = true; return groups.begin()->first; }
+    perfectly = false;
+    std::vector<std::string> keys;                                                                  // Utilities::get_map_keys_sorted_by_value, Utilities.cpp:1396-1415
+    for(const auto& e : groups) keys.push_back(e.first);
+    std::sort(keys.begin(), keys.end(), [&](const std::string& l, const std::string& r) { return groups.at(l) < groups.at(r); });
+    std::reverse(keys.begin(), keys.end());
+    return keys[0];
+}
+
+const char* const kExonTable[][3] = {      // fill_loci_2_exons, hla/HLATyper.cpp:2812-2846
+    {"A", "exon_2", "exon_3"}, {"B", "exon_2", "exon_3"}, {"C", "exon_2", "exon_3"}, {"DQA1", "exon_2", nullptr}, {"DQB1", "exon_2", nullptr}, {"DRB1", "exon_2", nullptr},
+    {"DPA1", "exon_2", nullptr}, {"DPB1", "exon_2", nullptr}, {"DRA", "exon_2", nullptr}, {"DRB3", "exon_2", nullptr}, {"DRB4", "exon_2", nullptr},
+    {"E", "exon_2", "exon_3"}, {"F", "exon_2", "exon_3"}, {"G", "exon_2", "exon_3"}, {"H", "exon_2", "exon_3"}, {"J", "exon_2", "exon_3"}, {"K", "exon_2", "exon_3"},
+    {"L", "exon_2", "exon_3"}, {"V", "exon_2", "exon_3"}};
+
+// find_file_for_exon, hla/HLATyper.cpp:3130-3200: <n>_gene_<HLA-locus | locus>_<m>_exon_<N>.txt, the last match in directory order
+std::string find_exon_file(const hlala_typer& T, const std::string& locus, const std::string& exon, std::string& err)
+{
+    const std::vector<std::string> parts = split(exon, "_");
+    if(parts.size() != 2 || parts[0] != "exon" || atoi(parts[1].c_str()) <= 0) { err = "exon id must look like exon_2: " + exon; return ""; }
+    const std::string want = to_str(atoi(parts[1].c_str())) + ".txt";
+    std::string found;
+    for(const std::string& f : T.files) {
+        const std::vector<std::string> sl = split(f, "/");
+        if(sl.empty()) continue;
+        const std::vector<std::string> us = split(sl.back(), "_");
+        if(us.size() >= 6 && us[1] == "gene" && (us[2] == "HLA-" + locus || us[2] == locus) && us[4] == "exon" && us[5] == want) found = f;
+    }
+    if(found.empty()) err = "no file for locus " + locus + ", " + exon + " in " + T.graphDir + "/PRG";
+    return found;
+}
+}  // namespace
+
+extern "C" int hlala_typer_locus(const hlala_typer* t, const char* locus, int32_t n_exons, const char* const* exon_ids, hlala_locus** out)
+{
+    if(!t || !locus || !out) return fail(HLALA_E_ARG, "hlala_typer_locus: null argument");
+    std::vector<std::string> exons;
+    if(exon_ids) for(int i = 0; i < n_exons; i++) exons.push_back(exon_ids[i]);
+    else for(const auto& row : kExonTable) if(locus == std::string(row[0])) { exons.push_back(row[1]); if(row[2]) exons.push_back(row[2]); }
+    if(exons.empty()) return fail(HLALA_E_ARG, std::string("no exons known for locus ") + locus);        // assert(loci_2_exons.at(locus).size()), :1180
+    std::unique_ptr<hlala_locus> L(new hlala_locus());
+    L->name = locus; L->typer = t;
+    std::map<std::string, std::string> seqOf;                                                           // combined_exon_sequences
+    for(size_t exonI = 0; exonI < exons.size(); exonI++) {
+        std::string err; const std::string file = find_exon_file(*t, locus, exons[exonI], err);
+        if(file.empty()) return fail(HLALA_E_ARG, err);
+        std::vector<std::string> lines;
+        if(!read_lines(file, lines)) return fail(HLALA_E_ARG, "Can't read file " + file);
+        const std::vector<std::string> head = split(lines[0], " ");
+        if(head.empty() || head[0] != "IndividualID") return fail(HLALA_E_ARG, file + ": first field must be IndividualID");
+        if(head.size() < 2) return fail(HLALA_E_ARG, file + ": no columns");
+        auto f = t->levelOf.find(head[1]), l = t->levelOf.find(head.back());
+        if(f == t->levelOf.end() || l == t->levelOf.end()) return fail(HLALA_E_ARG, file + ": column names are not graph loci");
+        const int first = f->second, last = l->second;
+        if(!(last > first) || (int)head.size() - 1 != last - first + 1) return fail(HLALA_E_ARG, "locus " + L->name + " " + exons[exonI] + " (" + file + "): problem with expected graph length");
+        const int len = last - first + 1;
+        for(int i = 0; i < len; i++) {
+            auto it = t->levelOf.find(head[(size_t)i + 1]);
+            if(it == t->levelOf.end() || it->second != first + i) return fail(HLALA_E_ARG, file + ": columns are not consecutive graph levels");       // assert, :1247
+            L->colLevel.push_back(first + i); L->colExon.push_back((int)exonI); L->colExonPos.push_back(i);
+            if(L->levelMin == -1 || L->levelMin > first + i) L->levelMin = first + i;
+            if(L->levelMax == -1 || L->levelMax < first + i) L->levelMax = first + i;
+        }
+        L->exonLength.push_back(len);
+        for(size_t li = 1; li < lines.size(); li++) {
+            if(lines[li].empty()) continue;
+            const std::vector<std::string> fields = split(lines[li], " ");
+            if(fields.size() != head.size()) return fail(HLALA_E_ARG, file + ": line " + to_str(li + 1) + " has " + to_str(fields.size()) + " fields, header has " + to_str(head.size()));
+            const std::string& type = fields[0];
+            if(type.find(":") == std::string::npos) continue;                                            // :1275
+            std::string s; for(size_t i = 1; i < fields.size(); i++) s += fields[i];
+            if(exonI == 0) { if(seqOf.count(type)) return fail(HLALA_E_ARG, file + ": allele listed twice: " + type); seqOf[type] = s; }
+            else { auto it = seqOf.find(type); if(it == seqOf.end()) return fail(HLALA_E_ARG, file + ": allele missing from the first exon: " + type); it->second += s; }
+        }
+        if(seqOf.empty()) return fail(HLALA_E_ARG, file + ": no alleles");
+    }
+    L->P = (int)L->colLevel.size();
+    L->levelToExon.assign((size_t)(L->levelMax - L->levelMin + 1), -1);
+    for(int pI = 0; pI < L->P; pI++) L->levelToExon[(size_t)(L->colLevel[pI] - L->levelMin)] = pI;      // graphLevel_2_exonPosition (later columns win, as map assignment)
+    // clusters of identical sequences in allele-name order, :1322-1372
+    std::unordered_map<std::string, int> clusterOfSeq;
+    std::vector<std::set<std::string>> clusters;
+    size_t sequenceL = 0; bool firstSeq = true;
+    for(const auto& ts : seqOf) {
+        if(firstSeq) { sequenceL = ts.second.size(); firstSeq = false; }
+        else if(sequenceL != ts.second.size()) return fail(HLALA_E_ARG, "locus " + L->name + ": allele " + ts.first + " has a different sequence length");
+        auto it = clusterOfSeq.find(ts.second);
+        int c;
+        if(it != clusterOfSeq.end()) c = it->second;
+        else { c = (int)clusters.size(); clusters.emplace_back(); clusterOfSeq[ts.second] = c; L->clusterSeq.insert(L->clusterSeq.end(), ts.second.begin(), ts.second.end()); }
+        clusters[c].insert(ts.first); L->typeCluster[ts.first] = c;
+    }
+    if((int)sequenceL != L->P) return fail(HLALA_E_ARG, "locus " + L->name + ": allele sequences have " + to_str(sequenceL) + " characters, the exons have " + to_str(L->P) + " columns (multi-character fields?)");
+    L->C = (int)clusters.size(); L->nTypes = (int)seqOf.size();
+    for(const auto& c : clusters) { L->members.emplace_back(c.begin(), c.end()); L->clusterId.push_back(join(L->members.back(), ";")); }
+    *out = L.release();
+    return HLALA_OK;
+}
+extern "C" void hlala_locus_free(hlala_locus* l) { delete l; }
+extern "C" int hlala_locus_get(const hlala_locus* l, hlala_locus_info* o)
+{
+    if(!l || !o) return HLALA_E_ARG;
+    o->n_clusters = l->C; o->n_columns = l->P; o->n_exons = (int32_t)l->exonLength.size(); o->level_min = l->levelMin; o->level_max = l->levelMax; o->n_types = l->nTypes;
+    o->cluster_seq = l->clusterSeq.data(); o->level_to_exon = l->levelToExon.data(); o->col_level = l->colLevel.data(); o->col_exon = l->colExon.data();
+    o->col_exon_pos = l->colExonPos.data(); o->exon_length = l->exonLength.data();
+    return HLALA_OK;
+}
+extern "C" const char* hlala_locus_cluster_id(const hlala_locus* l, int32_t c) { return (l && c >= 0 && c < l->C) ? l->clusterId[c].c_str() : nullptr; }
+extern "C" int32_t hlala_locus_type_cluster(const hlala_locus* l, const char* type) { if(!l || !type) return -1; auto it = l->typeCluster.find(type); return it == l->typeCluster.end() ? -1 : it->second; }
+
+// k-mers of one cluster's sequence, exon by exon with gaps removed (calculcatekMerPresence, hla/HLATyper.cpp:2652-2688): n_total counts
+// every k-mer, the ones without '*' are written to `queries` (k characters each) for hlala_kmer_presence
+extern "C" int hlala_locus_cluster_kmers(const hlala_locus* l, int32_t cluster, int32_t k, char* queries, int32_t cap_queries, int32_t* n_queries, int32_t* n_total)
+{
+    if(!l || cluster < 0 || cluster >= l->C || k <= 0 || !n_queries || !n_total) return HLALA_E_ARG;
+    int nq = 0, nt = 0; bool overflow = false;
+    const uint8_t* s = l->clusterSeq.data() + (size_t)cluster * l->P;
+    int col = 0;
+    for(size_t e = 0; e < l->exonLength.size(); e++) {
+        std::string ex;
+        for(int i = 0; i < l->exonLength[e]; i++, col++) if(s[col] != '_') ex.push_back((char)s[col]);
+        if((int)ex.size() < k) continue;
+        for(size_t i = 0; i + (size_t)k <= ex.size(); i++) {
+            nt++;
+            if(ex.find('*', i) < i + (size_t)k) continue;
+            if(queries && nq < cap_queries) memcpy(queries + (size_t)nq * k, ex.data() + i, (size_t)k); else if(queries) overflow = true;
+            nq++;
+        }
+    }
+    *n_queries = nq; *n_total = nt;
+    return overflow ? HLALA_E_CAPACITY : HLALA_OK;
+}
+
+// ---- result files ------------------------------------------------------------------------------------------------------------
+extern "C" int hlala_typer_begin_output(const char* out_dir, double unaccounted_min_fraction)
+{
+    if(!out_dir) return fail(HLALA_E_ARG, "hlala_typer_begin_output: null argument");
+    struct stat sb;
+    if(stat(out_dir, &sb) != 0 && mkdir(out_dir, 0775) != 0) return fail(HLALA_E_ARG, std::string("cannot create ") + out_dir);
+    const std::string field = "NColumns_UnaccountedAllele_fGT" + to_str(unaccounted_min_fraction);
+    std::ofstream a((std::string(out_dir) + "/R1_bestguess.txt").c_str()), g((std::string(out_dir) + "/R1_bestguess_G.txt").c_str());
+    if(!a.is_open() || !g.is_open()) return fail(HLALA_E_ARG, std::string("cannot write to ") + out_dir);
+    a << "Locus" << "\t" << "Chromosome" << "\t" << "Allele" << "\t" << "Q1" << "\t" << "Q2" << "\t" << "AverageCoverage" << "\t" << "CoverageFirstDecile" << "\t" << "MinimumCoverage" << "\t" << "proportionkMersCovered" << "\t" << "LocusAvgColumnError" << "\t" << field << "\n";
+    g << "Locus" << "\t" << "Chromosome" << "\t" << "Allele" << "\t" << "Q1" << "\t" << "Q2" << "\t" << "AverageCoverage" << "\t" << "CoverageFirstDecile" << "\t" << "MinimumCoverage" << "\t" << "proportionkMersCovered" << "\t" << "LocusAvgColumnError" << "\t" << field << "\t" << "perfectG" << "\n";
+    return HLALA_OK;
+}
+extern "C" int hlala_typer_end_output(const char* out_dir, const char* loci_comma_separated, int32_t very_conservative_read_likelihoods)
+{
+    if(!out_dir || !loci_comma_separated) return fail(HLALA_E_ARG, "hlala_typer_end_output: null argument");
+    std::ofstream p((std::string(out_dir) + "/R1_parameters.txt").c_str());
+    if(!p.is_open()) return fail(HLALA_E_ARG, std::string("cannot write to ") + out_dir);
+    p << "Loci" << " = " << loci_comma_separated << "\n";
+    p << "veryConservativeReadLikelihoods" << " = " << (very_conservative_read_likelihoods != 0) << "\n";
+    return HLALA_OK;
+}
+
+extern "C" int hlala_locus_write_files(const hlala_locus* L, const hlala_locus_report_in* in, const char* out_dir, hlala_locus_report_out* res)
+{
+    if(!L || !in || !out_dir || !in->pos || !in->filter || !in->call) return fail(HLALA_E_ARG, "hlala_locus_write_files: null argument");
+    const hlala_exon_positions_out* pos = in->pos;
+    const int nReads = pos->n_reads, nPos = pos->n_pos, P = L->P, C = L->C;
+    if(in->n_clusters != C) return fail(HLALA_E_ARG, "hlala_locus_write_files: n_clusters does not match the locus");
+    if(nReads > 0 && (!pos->read_reverse || !pos->read_mapq || !in->unit_name_1)) return fail(HLALA_E_ARG, "hlala_locus_write_files: read_reverse, read_mapq and unit_name_1 are needed");
+    if(!in->pair_ll || !in->mis_avg || !in->mis_min || !in->order || !in->p_normalized) return fail(HLALA_E_ARG, "hlala_locus_write_files: the all-pairs tables are needed");
+    // ---- the filters once more, with the per-allele counts of the stage the reports print
+    std::vector<uint8_t> use((size_t)std::max(nPos, 1), 0), ignored((size_t)std::max(nReads, 1), 0);
+    std::vector<std::vector<hlala_host::AlleleTally>> tallies;
+    hlala_filter_stats fs;
+    int rc = hlala_host::filter_positions_impl(pos, in->filter, use.data(), ignored.data(), &fs, &tallies);
+    if(rc) return fail(rc, "hlala_locus_write_files: filter_positions failed");
+    // ---- pile-up buckets per exon column, entries in (read, position) order, :1883-1931
+    std::vector<int> readOf((size_t)nPos, 0);
+    for(int r = 0; r < nReads; r++) for(int j = pos->pos_off[r]; j < pos->pos_off[r + 1]; j++) readOf[j] = r;
+    std::vector<int> bOff((size_t)P + 1, 0);
+    auto piled = [&](int j) { return use[j] && !(in->long_read_mode && pos->pos_novel_gap[j] >= 2); };
+    for(int j = 0; j < nPos; j++) { if(pos->pos_exon[j] < 0 || pos->pos_exon[j] >= P) return fail(HLALA_E_ARG, "hlala_locus_write_files: exon position outside the locus"); if(piled(j)) bOff[(size_t)pos->pos_exon[j] + 1]++; }
+    for(int c = 0; c < P; c++) bOff[(size_t)c + 1] += bOff[c];
+    std::vector<int> pile((size_t)bOff[P]);
+    { std::vector<int> fill(bOff.begin(), bOff.end() - 1); for(int j = 0; j < nPos; j++) if(piled(j)) pile[(size_t)fill[pos->pos_exon[j]]++] = j; }
+    auto genotype = [&](int j) { return std::string((const char*)pos->geno_chars + pos->geno_off[j], (size_t)(pos->geno_off[j + 1] - pos->geno_off[j])); };
+    auto tally = [&](int col, const std::string& a) -> const hlala_host::AlleleTally* {
+        if(col >= (int)tallies.size()) return nullptr;
+        for(const auto& t : tallies[col]) if(t.count > 0 && t.allele == a) return &t;
+        return nullptr;
+    };
+    const std::string dir(out_dir), locus = L->name;
+    std::set<std::string> utilized;
+    {
+        std::ofstream pu((dir + "/R1_pileup_" + locus + ".txt").c_str());
+        if(!pu.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_pileup_" + locus + ".txt");
+        std::vector<int> exonFirstCol(L->exonLength.size(), 0);
+        for(size_t e = 1; e < L->exonLength.size(); e++) exonFirstCol[e] = exonFirstCol[e - 1] + L->exonLength[e - 1];
+        for(size_t e = 0; e < L->exonLength.size(); e++) {
+            const int c0 = exonFirstCol[e], c1 = c0 + L->exonLength[e];
+            if(bOff[c1] == bOff[c0]) continue;                               // an exon without any piled position is not in pileUpPerPosition: no lines
+            for(int col = c0; col < c1; col++) {
+                const int n = bOff[(size_t)col + 1] - bOff[col];
+                pu << to_str((int)e) << "\t" << to_str(col - c0) << "\t" << to_str(n);
+                if(n == 0) { pu << "\n"; continue; }
+                std::map<std::string, std::vector<int>> alleleCounts;
+                std::string all;
+                for(int i = 0; i < n; i++) {
+                    const int j = pile[(size_t)bOff[col] + i], r = readOf[j], m = pos->pos_mate[j] == 2 ? 1 : 0;
+                    const std::string g = genotype(j);
+                    std::string q;
+                    for(int k = pos->geno_off[j]; k < pos->geno_off[j + 1]; k++) {
+                        if(pos->geno_chars[k] == '_') continue;                                           // a gap carries no quality
+                        if(!q.empty()) q += ", ";
+                        q += to_str((int)(char)pos->qual_chars[k]);
+                    }
+                    const int unit = pos->read_pair[r];
+                    const char* n1 = in->unit_name_1[unit]; const char* n2 = in->unit_name_2 ? in->unit_name_2[unit] : "";
+                    const std::string thisID = m ? n2 : n1, otherID = in->unit_name_2 ? (m ? n1 : n2) : "";
+                    if(i) all += ", ";
+                    all += g + " (" + q + ")" + " [" + "pairsDistance " + to_str((double)pos->read_distance[r]) + " | " + "alignmentLength " + to_str(pos->read_cols_nongap[2 * r + m]) + " | " +
+                           to_str(phred_to_pcorrect(pos->pos_mapq[j])) + " | " + to_str(pos->read_mapq[2 * r + m]) + " " + to_str(pos->read_mapq[2 * r + m]) + " | " +
+                           to_str(pos->read_weighted_ok[2 * r + m]) + " " + to_str(pos->read_weighted_ok[2 * r + (1 - m)]) + " | " + thisID + " " + otherID + "]";
+                    utilized.insert(thisID);
+                    alleleCounts[g].push_back(pos->read_cols_nongap[2 * r + m]);
+                }
+                std::string summary;
+                for(const auto& a : alleleCounts) {
+                    long long sum = 0; for(int l : a.second) sum += l;
+                    const double avgL = (double)sum / (double)a.second.size();
+                    const hlala_host::AlleleTally* t = tally(col, a.first);
+                    if(!t) return fail(HLALA_E_STATE, "hlala_locus_write_files: piled allele without counts");
+                    const int minStrand = std::min(t->reverse, t->count - t->reverse);
+                    summary += a.first + "x" + to_str(a.second.size()) + "[" + to_str(avgL) + ";" + to_str((double)minStrand / (double)t->count) + ";" + to_str((double)t->from_first / (double)t->count) + "]";
+                }
+                pu << "\t" << all << "\t" << summary << "\n";
+            }
+        }
+        std::ofstream ids((dir + "/R1_readIDs_" + locus + ".txt").c_str());
+        if(!ids.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_readIDs_" + locus + ".txt");
+        for(const std::string& id : utilized) ids << id << "\n";
+    }
+    // ---- all pairs, :2451-2488
+    const long long nPairs = (long long)C * (C + 1) / 2;
+    std::vector<int> c1Of((size_t)nPairs), c2Of((size_t)nPairs);
+    { long long i = 0; for(int a = 0; a < C; a++) for(int b = a; b < C; b++, i++) { c1Of[(size_t)i] = a; c2Of[(size_t)i] = b; } }
+    {
+        std::ofstream ap((dir + "/R1_PP_" + locus + "_pairs.txt").c_str());
+        if(!ap.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_PP_" + locus + "_pairs.txt");
+        ap << "ClusterID" << "\t" << "P" << "\t" << "LL" << "\t" << "Mismatches_avg" << "\n";
+        for(long long k = 0; k < nPairs; k++) {
+            const int cI = in->order[k];
+            if(cI < 0 || cI >= nPairs) return fail(HLALA_E_ARG, "hlala_locus_write_files: order[] holds an index outside the pair table");
+            ap << L->clusterId[c1Of[cI]] << "/" << L->clusterId[c2Of[cI]] << "\t" << in->p_normalized[cI] << "\t" << in->pair_ll[cI] << "\t" << in->mis_avg[cI] << "\n";
+        }
+    }
+    // ---- coverage, column incompatibilities, best guesses, :2543-2759
+    const int first = in->call->first_cluster, second = in->call->second_cluster;
+    if(first < 0 || first >= C || second < 0 || second >= C) return fail(HLALA_E_ARG, "hlala_locus_write_files: called clusters outside the locus");
+    const uint8_t* s1 = L->clusterSeq.data() + (size_t)first * P; const uint8_t* s2 = L->clusterSeq.data() + (size_t)second * P;
+    std::vector<double> positionalCoverages((size_t)P);
+    for(int col = 0; col < P; col++) positionalCoverages[col] = bOff[(size_t)col + 1] - bOff[col];
+    std::sort(positionalCoverages.begin(), positionalCoverages.end(), std::less<int>());                // sic: the reference's comparator converts to int
+    size_t allTotal = 0, allIncompatible = 0; int unaccounted = 0;
+    std::vector<int> colTotal((size_t)P), colIncompatible((size_t)P);
+    for(int col = 0; col < P; col++) {
+        const std::string a1(1, (char)s1[col]), a2(1, (char)s2[col]);
+        int total = 0, bad = 0;
+        for(int i = bOff[col]; i < bOff[(size_t)col + 1]; i++) { total++; const std::string g = genotype(pile[i]); if(g != a1 && g != a2) bad++; }
+        allTotal += total; allIncompatible += bad; colTotal[col] = total; colIncompatible[col] = bad;
+        if(col < (int)tallies.size()) {
+            int totalCoverage = 0; bool any = false;
+            for(const auto& t : tallies[col]) if(t.count > 0 && t.post_filtering >= 0) { totalCoverage += t.post_filtering; any = true; }
+            if(any && totalCoverage >= in->unaccounted_min_coverage)
+                for(const auto& t : tallies[col]) if(t.count > 0 && t.post_filtering >= 0) {
+                    if(t.allele == a1 || t.allele == a2) continue;
+                    if((double)t.post_filtering / (double)totalCoverage >= in->unaccounted_min_fraction) unaccounted++;
+                }
+        }
+    }
+    const double avgErr = allTotal > 0 ? (double)allIncompatible / (double)allTotal : 0;
+    double minP = -1;
+    {
+        std::ofstream ce((dir + "/R1_columnIncompatibilities_" + locus + ".txt").c_str());
+        if(!ce.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_columnIncompatibilities_" + locus + ".txt");
+        ce << "Column" << "\t" << "Coverage" << "\t" << "ExpectedIncompatible" << "\t" << "ObservedIncompatible" << "\t" << "p" << "\n";
+        for(int col = 0; col < P; col++) {
+            const int cov = colTotal[col], obs = colIncompatible[col];
+            const double expected = avgErr * cov;
+            double p = 1;
+            if(obs > expected) { const double o[2] = {(double)(cov - obs), (double)obs}, e[2] = {cov - expected, expected}; p = chi_sq_p(o, e); }
+            ce << to_str(col) << "\t" << to_str(cov) << "\t" << to_str(expected) << "\t" << to_str(obs) << "\t" << to_str(p) << "\n";
+            if(minP < 0 || p < minP) minP = p;
+        }
+    }
+    const double locusCoverage = (double)fs.bases_used / (double)P;
+    const double firstDecile = positionalCoverages[(size_t)(int)((double)positionalCoverages.size() / 10.0)], minimumCoverage = positionalCoverages[0];
+    const double q1First = in->call->first_marginal, q1Second = in->call->second_p;
+    const long long fsIdx = (long long)std::min(first, second) * C - (long long)std::min(first, second) * (std::min(first, second) - 1) / 2 + (std::max(first, second) - std::min(first, second));
+    const double q2 = -1 * in->mis_min[fsIdx];                                                          // bestGuess_secondAllele.first, :2527-2533
+    {
+        std::ofstream bg((dir + "/R1_bestguess.txt").c_str(), std::ios::app);
+        if(!bg.is_open()) return fail(HLALA_E_ARG, "cannot append to " + dir + "/R1_bestguess.txt (hlala_typer_begin_output first)");
+        bg << locus << "\t" << 1 << "\t" << L->clusterId[first] << "\t" << q1First << "\t" << q2 << "\t" << locusCoverage << "\t" << firstDecile << "\t" << minimumCoverage << "\t" << in->kmers_covered[0] << "\t" << avgErr << "\t" << unaccounted << "\n";
+        bg << locus << "\t" << 2 << "\t" << L->clusterId[second] << "\t" << q1Second << "\t" << q2 << "\t" << locusCoverage << "\t" << firstDecile << "\t" << minimumCoverage << "\t" << in->kmers_covered[1] << "\t" << avgErr << "\t" << unaccounted << "\n";
+    }
+    if(L->typer && L->typer->gLoci.count(locus)) {                                                      // can_translateToG_locus
+        bool p1 = false, p2 = false;
+        const std::string g1 = to_g_group(*L->typer, L->members[first], p1), g2 = to_g_group(*L->typer, L->members[second], p2);
+        std::ofstream bg((dir + "/R1_bestguess_G.txt").c_str(), std::ios::app);
+        if(!bg.is_open()) return fail(HLALA_E_ARG, "cannot append to " + dir + "/R1_bestguess_G.txt (hlala_typer_begin_output first)");
+        bg << locus << "\t" << 1 << "\t" << g1 << "\t" << q1First << "\t" << q2 << "\t" << locusCoverage << "\t" << firstDecile << "\t" << minimumCoverage << "\t" << in->kmers_covered[0] << "\t" << avgErr << "\t" << unaccounted << "\t" << p1 << "\n";
+        bg << locus << "\t" << 2 << "\t" << g2 << "\t" << q1Second << "\t" << q2 << "\t" << locusCoverage << "\t" << firstDecile << "\t" << minimumCoverage << "\t" << in->kmers_covered[1] << "\t" << avgErr << "\t" << unaccounted << "\t" << p2 << "\n";
+    }
+    if(res) {
+        res->locus_coverage = locusCoverage; res->first_decile_coverage = firstDecile; res->minimum_coverage = minimumCoverage; res->avg_column_error = avgErr;
+        res->min_column_p = minP; res->n_columns_unaccounted = unaccounted; res->n_utilized_reads = (int32_t)utilized.size(); res->bases_used = fs.bases_used;
+        res->n_piled_positions = bOff[P];
+    }
+    return HLALA_OK;
+}

@@ -444,6 +444,84 @@ int  hlala_call_locus(hlala_ctx* ctx, int32_t C, const double* pairLL, const dou
                       int32_t* order /* [C(C+1)/2] or NULL */, double* p_normalized /* [C(C+1)/2] or NULL */,
                       double* cluster_marginal /* [C] or NULL */, hlala_call_out* out);
 
+/* ------------------------------------------------------------------------------------------
+ * HLATyper host side around the kernels (host code; hla/HLATyper.cpp).  hlala_typer_open reads <graph_dir>/PRG/segments.txt and the
+ * first line of every segment file: graph level names (Graph::readGraphLoci, Graph/Graph.cpp:2563-2614 -> graphLocus_2_levels,
+ * HLATyper.cpp:84-92) and the level range of every gene (graphgene_levelBoundaries, :104-214: the intervals of
+ * hlala_set_gene_intervals).  hlala_typer_locus reads the exon files of one locus (find_file_for_exon :3130-3200; exon_ids NULL =
+ * the table of fill_loci_2_exons :2812-2846) and clusters alleles with identical exon sequences (:1180-1372): cluster_seq /
+ * level_min / level_max / level_to_exon are the inputs of hlala_exon_positions and hlala_exon_loglik.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hlala_typer hlala_typer;
+typedef struct hlala_locus hlala_locus;
+int  hlala_typer_open(const char* graph_dir, hlala_typer** out);
+void hlala_typer_close(hlala_typer* t);
+const char* hlala_typer_last_error(void);
+int32_t     hlala_typer_n_levels(const hlala_typer* t);
+const char* hlala_typer_level_name(const hlala_typer* t, int32_t level);
+int32_t     hlala_typer_level_of(const hlala_typer* t, const char* graph_locus_id);              /* -1: unknown */
+int32_t     hlala_typer_n_genes(const hlala_typer* t);                                            /* genes in name order (std::map) */
+int  hlala_typer_gene(const hlala_typer* t, int32_t i, const char** name, int32_t* first_level, int32_t* last_level);
+/* G groups (hla_nom_g.txt; read_G_alleles / translate_allele_list_to_G_allele, HLATyper.cpp:4086-4207) for R1_bestguess_G.txt */
+int  hlala_typer_load_g_groups(hlala_typer* t, const char* hla_nom_g_path);
+int  hlala_typer_locus(const hlala_typer* t, const char* locus, int32_t n_exons, const char* const* exon_ids, hlala_locus** out);
+void hlala_locus_free(hlala_locus* l);
+typedef struct {
+    int32_t n_clusters, n_columns, n_exons, level_min, level_max, n_types;
+    const uint8_t* cluster_seq;       /* [n_clusters * n_columns] cluster_2_sequence                                        */
+    const int32_t* level_to_exon;     /* [level_max - level_min + 1] graphLevel_2_exonPosition, -1 = not an exon level      */
+    const int32_t* col_level;         /* [n_columns] combined_exon_sequences_graphLevels                                    */
+    const int32_t* col_exon;          /* [n_columns] ..._individualExon                                                     */
+    const int32_t* col_exon_pos;      /* [n_columns] ..._individualExonPosition                                             */
+    const int32_t* exon_length;       /* [n_exons] exon_lengths                                                             */
+} hlala_locus_info;
+int  hlala_locus_get(const hlala_locus* l, hlala_locus_info* out);                               /* pointers into the handle */
+const char* hlala_locus_cluster_id(const hlala_locus* l, int32_t cluster);                       /* members joined by ";" (std::set order) */
+int32_t     hlala_locus_type_cluster(const hlala_locus* l, const char* hla_type);                /* HLAtype_2_clusterID, -1: unknown */
+/* k-mers of a cluster's exon sequences (gaps removed, exon by exon): n_total counts all, the ones without '*' go to queries
+ * (k characters each, no terminator) -- the query set of hlala_kmer_presence (calculcatekMerPresence, HLATyper.cpp:2652-2688) */
+int  hlala_locus_cluster_kmers(const hlala_locus* l, int32_t cluster, int32_t k, char* queries, int32_t cap_queries, int32_t* n_queries, int32_t* n_total);
+
+/* Which of the query k-mers occur in the reads of a batch (the k-mer index of HLATypeInference, HLATyper.cpp:999-1027, asked the way
+ * :2652-2688 asks it): present[q] = 1 iff some read of a looked-at unit holds a k-mer whose canonical form
+ * (kMer_canonical_representation :4237-4256: the smaller of the k-mer and its reverse complement) equals the canonical form of query q.
+ * Runs on the GPU over the reads resident in the batch: no index is built, every read k-mer is looked up in the sorted query set.
+ * k <= 31, queries over ACGT (others never match: the reads' N never equals an allele character); pair_mask as in hlala_locus_desc. */
+int  hlala_kmer_presence(hlala_ctx* ctx, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present);
+
+/* Result files of one locus (HLATyper.cpp:1883-2044 pile-up + read IDs, :2451-2488 all pairs, :2543-2759 coverage, column
+ * incompatibilities, best guesses).  hlala_typer_begin_output creates the directory and the headers of R1_bestguess.txt /
+ * R1_bestguess_G.txt, hlala_locus_write_files writes R1_pileup_<locus>.txt, R1_readIDs_<locus>.txt, R1_PP_<locus>_pairs.txt,
+ * R1_columnIncompatibilities_<locus>.txt and appends the two best-guess rows (the G rows if hlala_typer_load_g_groups knows the
+ * locus), hlala_typer_end_output writes R1_parameters.txt.  Numbers are printed by the same iostream calls as the reference.
+ * Not written: summaryStatistics.txt and histogram_matchesPerRead.txt (diagnostics over all pairs, not only exon-overlapping ones). */
+typedef struct {
+    const hlala_exon_positions_out* pos;     /* hlala_exon_positions of this locus, with read_reverse and read_mapq             */
+    const hlala_filter_params* filter;       /* the parameters hlala_filter_positions ran with                                    */
+    const char* const* unit_name_1;          /* [units of the batch] read.name of mate 1 (indexed by pos->read_pair[])            */
+    const char* const* unit_name_2;          /* ... of mate 2; NULL for unpaired batches (pairedRead_ID = "")                     */
+    int32_t long_read_mode;                  /* longReadsMode set: positions with runningNovelGapEitherDirection >= 2 are not piled */
+    int32_t n_clusters;
+    const double*  pair_ll;                  /* hlala_pair_loglik                                                                  */
+    const double*  mis_avg;
+    const double*  mis_min;
+    const int32_t* order;                    /* hlala_call_locus                                                                   */
+    const double*  p_normalized;
+    const hlala_call_out* call;
+    double  kmers_covered[2];                /* proportionkMersCovered of the first / second called allele (-1: no k-mers)         */
+    int32_t unaccounted_min_coverage;        /* threshold_reportColumn_forPresenceOfUnaccountedAlleles_minCoverage (30, :67)        */
+    int32_t reserved;
+    double  unaccounted_min_fraction;        /* ..._minAlleleFraction (0.2, :68)                                                   */
+} hlala_locus_report_in;
+typedef struct {
+    double  locus_coverage, first_decile_coverage, minimum_coverage, avg_column_error, min_column_p;
+    int64_t bases_used;
+    int32_t n_columns_unaccounted, n_utilized_reads, n_piled_positions, reserved;
+} hlala_locus_report_out;
+int  hlala_typer_begin_output(const char* out_dir, double unaccounted_min_fraction);
+int  hlala_locus_write_files(const hlala_locus* l, const hlala_locus_report_in* in, const char* out_dir, hlala_locus_report_out* out);
+int  hlala_typer_end_output(const char* out_dir, const char* loci_comma_separated, int32_t very_conservative_read_likelihoods);
+
 /* Known-answer helpers exported for the parity tests (device implementations of
  * Utilities::PCorrectToPhred / PhredToPCorrect, Utilities.cpp:178-203, 357-377, and of glibc
  * rand_r as used by Utilities::randomNumber_nonCritical, Utilities.cpp:922).                 */
