@@ -60,7 +60,11 @@ def test_unpaired_exon_positions_and_filters(pkg, oracle):
         g = gb.exon_positions(lmin, l2e, 0, 0, min_mapq=0.3, pair_mask=inc, min_alignment_columns=mac)
         e = ob.exon_positions(x, u, stride, lmin, l2e, 0, 0, min_mapq=0.3, pair_mask=inc_e, unpaired=True, min_alignment_columns=mac)
         for key in e:
-            if isinstance(e[key], np.ndarray):
+            if key == "read_reverse":
+                assert np.array_equal(g[key][0::2], u["chain_reverse"][np.asarray(x["best_chain"])[:n][g["read_pair"]]]) and not g[key][1::2].any()
+            elif key == "read_mapq":
+                assert np.allclose(g[key], e[key], rtol=1e-9, atol=1e-15)
+            elif isinstance(e[key], np.ndarray):
                 assert np.array_equal(g[key], e[key], equal_nan=True), key
             else:
                 assert g[key] == e[key], key
