@@ -1,0 +1,98 @@
+"""BAM file + graph directory in, result files out: every stage of the path through the C ABI in the order HLA-LA runs them
+(mapper/processBAM.cpp:1789-1870 alignReads..., hla/HLATyper.cpp:934-2810 HLATypeInference), on a sample simulated from two known alleles."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_bam import batch_records, write_bam
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def write_graph_dir(root, H, exons):
+    """PRG/ for a world whose graph levels are the columns of H: padding segments and one `gene` segment per exon of locus A."""
+    prg = root / "PRG"; prg.mkdir(parents=True)
+    G = H.shape[1]; names = []; cuts = [0]
+    for a, b in exons:
+        cuts += [a, b]
+    cuts.append(G)
+    k = 0
+    for i in range(len(cuts) - 1):
+        a, b = cuts[i], cuts[i + 1]
+        if a == b:
+            continue
+        k += 1
+        is_exon = (a, b) in exons
+        fn = "%d_gene_HLA-A_%d_exon_%d.txt" % (k, k, 2 + exons.index((a, b))) if is_exon else "%d_pad_%d.txt" % (k, k)
+        lines = ["IndividualID " + " ".join("L%d" % x for x in range(a, b))]
+        if is_exon:
+            for h in range(H.shape[0]):
+                lines.append("A*%02d:01 " % (h + 1) + " ".join(chr(c) for c in H[h, a:b]))
+        else:
+            lines.append("ref " + " ".join(chr(c) for c in H[0, a:b]))
+        (prg / fn).write_text("\n".join(lines) + "\n"); names.append(fn)
+    (prg / "segments.txt").write_text("\n".join(names) + "\n")
+
+
+def test_bam_and_graph_dir_to_result_files(pkg, tmp_path):
+    G = 4000; exons = [(1200, 1470), (1900, 2176)]
+    w = synth.make_world(seed=12, G=G, k=1, n_mut=6, mut_density=0.03)
+    H = w["H"]; truth = (2, 5)
+    lib = C.CDLL(pkg.LIB_PATH)
+    write_graph_dir(tmp_path, H, exons)
+    T = pkg.Typer(lib, tmp_path); L = T.locus("A")
+    assert T.level_names() == ["L%d" % i for i in range(G)] and L.n_columns == 270 + 276
+    want = {L.type_cluster("A*%02d:01" % (h + 1)) for h in truth}
+    assert len(want) == 2
+    # ---- reads of a heterozygous sample, as a BAM file against the haplotype contigs
+    b = synth.make_batch(w, 700, seed=77, haps=truth)
+    clen = np.diff(w["contigs"]["contig_off"]); nct = w["contigs"]["n_contigs"]
+    refs = [("hap%d" % i, int(clen[i])) for i in range(nct)]
+    bam = tmp_path / "sample.bam"
+    write_bam(bam, refs, batch_records(b, np.random.default_rng(1)), block=30000)
+    seeds, names, cnt = pkg.bam_extract_seeds(lib, bam, [("hap%d" % i, 0, int(clen[i]) - 1, i) for i in range(nct)])
+    assert seeds["n_pairs"] == 700
+    # ---- insert size from the sample, alignment, post-processing
+    ctx0 = pkg.Context(w["graph"], w["contigs"], insert_mean=200.0, insert_sd=35.0, rng_seed=5)
+    ins = ctx0.estimate_insert_size(seeds)
+    assert abs(ins["mean"] - b["insert_mean"]) < 25
+    ctx = pkg.Context(w["graph"], w["contigs"], insert_mean=ins["mean"], insert_sd=ins["sd"], rng_seed=5)
+    gb = ctx.batch(seeds); gb.align()
+    assert gb.stats().n_errors == 0
+    genes = T.genes(); assert genes == [("HLA-A", 1200, 2175)]
+    ctx.set_gene_intervals([g[1] for g in genes], [g[2] for g in genes])
+    include = gb.postprocess()
+    assert 50 < include.sum() < 700
+    # ---- locus A: exon positions -> filters -> likelihoods -> all pairs -> call
+    e = gb.exon_positions(L.level_min, L.level_to_exon, ins["mean"], ins["sd"], pair_mask=include)
+    prm = pkg.default_filter_params(first20_n=6)
+    use, ignored, fst = pkg.filter_positions(lib, e, prm)
+    xin = pkg.exon_in_from_positions(e, use, L.cluster_seq, L.n_clusters, L.n_columns)
+    LL, M = ctx.exon_loglik(xin)
+    pair_ll, mis_avg, mis_min = ctx.pair_loglik(LL, M)
+    call = ctx.call_locus(pair_ll, mis_avg, mis_min)
+    assert {call["first_cluster"], call["second_cluster"]} == want
+    # ---- k-mer support of the two called alleles in the reads that went into typing
+    kc = []
+    for c in (call["first_cluster"], call["second_cluster"]):
+        q, total = L.cluster_kmers(c, 31)
+        kc.append(-1.0 if total == 0 else float(ctx.kmer_presence(gb, q, 31, include).sum()) / total)
+    assert min(kc) > 0.9
+    # ---- files
+    out = tmp_path / "hla"
+    pkg.typer_begin_output(lib, out)
+    co = pkg.CallOut(call["first_cluster"], call["second_cluster"], call["first_marginal"], call["second_p"], call["ll_max"], call["max_pair"], call["n_sort_ties"])
+    res = L.write_files(out, e, names, names, pair_ll, mis_avg, mis_min, call["order"], call["p_normalized"], co, kmers_covered=kc, params=prm)
+    pkg.typer_end_output(lib, out, ["A"])
+    rows = [r.split("\t") for r in (out / "R1_bestguess.txt").read_text().splitlines()]
+    assert len(rows) == 3 and {rows[1][2], rows[2][2]} == {L.cluster_id(c) for c in want} and rows[1][0] == "A" and rows[1][1] == "1" and rows[2][1] == "2"
+    assert float(rows[1][5]) > 10 and res.locus_coverage > 10 and res.minimum_coverage > 0 and res.avg_column_error < 0.02
+    pile = (out / "R1_pileup_A.txt").read_text().splitlines()
+    assert len(pile) == 546 and pile[0].split("\t")[:2] == ["0", "0"] and pile[270].split("\t")[:2] == ["1", "0"]
+    ids = (out / "R1_readIDs_A.txt").read_text().split()
+    assert len(ids) == res.n_utilized_reads and set(ids) <= set(names)
+    npairs = L.n_clusters * (L.n_clusters + 1) // 2
+    assert len((out / "R1_PP_A_pairs.txt").read_text().splitlines()) == npairs + 1
+    assert len((out / "R1_columnIncompatibilities_A.txt").read_text().splitlines()) == 547

@@ -144,8 +144,8 @@ def _cigar(ops):
 
 def make_batch(world, n_pairs, seed=3, read_len=150, ins_mean=200.0, ins_sd=35.0, clip_max=30,
                p_secondary=0.5, max_secondary=4, p_random_secondary=0.1, indel_read_frac=0.05,
-               qual_lo=2, qual_hi=40, p_no_clip=0.15, hardclip_frac=0.0, p_flip=0.5):
-    """Read pairs with BAM-like alignment records in the hlala_batch_in layout."""
+               qual_lo=2, qual_hi=40, p_no_clip=0.15, hardclip_frac=0.0, p_flip=0.5, haps=None):
+    """Read pairs with BAM-like alignment records in the hlala_batch_in layout (haps: sample the pairs from these haplotypes only)."""
     rng = np.random.default_rng(seed)
     C = world["contigs"]
     nh = C["n_contigs"]
@@ -170,7 +170,7 @@ def make_batch(world, n_pairs, seed=3, read_len=150, ins_mean=200.0, ins_sd=35.0
     # ins_mean/ins_sd describe the INNER distance between the mates (what the reference's pairing
     # step measures: pos_downstream - pos_upstream - 1, alignerBase.cpp:290-329)
     frag = np.maximum(read_len + 10, np.rint(rng.normal(ins_mean, ins_sd, n_pairs)).astype(np.int64) + 2 * read_len)
-    hap = rng.integers(0, nh, n_pairs)
+    hap = rng.integers(0, nh, n_pairs) if haps is None else np.asarray(haps)[rng.integers(0, len(haps), n_pairs)]
     for p in range(n_pairs):
         h = int(hap[p])
         F = int(min(frag[p], clen[h] - 2))
