@@ -214,6 +214,28 @@ def load_graph_cache(lib, path):
     return _graph_from_handle(lib, h)
 
 
+def load_contigs_dir(lib, graph_dir, extended_reference_genome=True):
+    """hlala_contigs_load_dir: (contigs dict for Context, intervals [(ref name, start0, stop0, contig)] for bam_extract_seeds)."""
+    h = C.c_void_p()
+    lib.hlala_contigs_load_dir.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]; lib.hlala_loader_last_error.restype = C.c_char_p
+    if lib.hlala_contigs_load_dir(str(graph_dir).encode(), int(bool(extended_reference_genome)), C.byref(h)) != 0:
+        raise HlalaError(lib.hlala_loader_last_error().decode())
+    d = ContigsDesc()
+    lib.hlala_contigs_file_desc.argtypes = [C.c_void_p, C.POINTER(ContigsDesc)]; lib.hlala_contigs_file_desc(h, C.byref(d))
+    n = d.n_contigs
+    off = np.ctypeslib.as_array(d.contig_off, (n + 1,)).astype(np.int64).copy(); tot = int(off[-1])
+    contigs = dict(n_contigs=n, contig_off=off, contig_seq=np.ctypeslib.as_array(d.contig_seq, (max(tot, 1),))[:tot].astype(np.uint8).copy(),
+                   contig_level=np.ctypeslib.as_array(d.contig_level, (max(tot, 1),))[:tot].astype(np.int32).copy(),
+                   contig_seqid=np.ctypeslib.as_array(d.contig_seqid, (max(n, 1),))[:n].astype(np.int32).copy())
+    iv = (BamInterval * max(1, n))()
+    lib.hlala_contigs_file_intervals.argtypes = [C.c_void_p, C.POINTER(BamInterval), C.c_int32]
+    lib.hlala_contigs_file_intervals(h, iv, n)
+    intervals = [(iv[i].ref_name.decode(), iv[i].start_0based, iv[i].stop_0based, iv[i].contig) for i in range(n)]
+    lib.hlala_contigs_file_free.argtypes = [C.c_void_p]; lib.hlala_contigs_file_free.restype = None
+    lib.hlala_contigs_file_free(h)
+    return contigs, intervals
+
+
 class BamInterval(C.Structure):
     _fields_ = [("ref_name", C.c_char_p), ("start_0based", C.c_int32), ("stop_0based", C.c_int32), ("contig", C.c_int32)]
 
@@ -531,6 +553,7 @@ EXPORTED_SYMBOLS = [
     "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
     "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
     "hlala_bam_extract_seeds", "hlala_seed_batch_desc", "hlala_seed_batch_name", "hlala_seed_batch_free", "hlala_bam_last_error",
+    "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
     "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",
     "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_typer_end_output",

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
+#include <sstream>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -158,3 +160,119 @@ extern "C" int hlala_graph_cache_load(const char* path, hlala_graph_file** out)
     *out = g;
     return HLALA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Reference contigs of a graph directory: sequences.txt + the reference FASTA + translation/<SequenceID>.txt
+// (processBAM::initBAM mapper/processBAM.cpp:1183-1402, the constructor :69-88, processBAM::_loadMapping :4389-4457).
+//
+// One contig per row of sequences.txt = one "interesting interval": its bases are the stretch [Start_1based, Stop_1based] of the
+// BAM reference the row names (column Chr, or PRG_<SequenceID> when Chr is empty; PRG-only mode: the whole sequence), its levels are
+// the lines of translation/<SequenceID>.txt.  The FASTA is streamed and only the named sequences are kept (the extended reference is
+// the whole genome).  Two quirks of the reference are kept because results can depend on them:
+//   * the translation file is read with `while(good) { getline; push(StrtoI(line)) }`, so a file ending in a newline yields one extra
+//     entry 0 (StrtoI("") == 0): level 0 then "lies under" position <length> of that sequence in graphLevel_2_underlyingSequencePositions.
+//     The contig gets one extra position (base 'N', level 0) so that hlala_create builds the same table;
+//   * PRG-only mode defines PRG_5 as "N" (:87-88).
+struct hlala_contigs_file {
+    std::vector<int64_t> off; std::vector<uint8_t> seq; std::vector<int32_t> level, seqid;
+    std::vector<std::string> refName; std::vector<int32_t> start0, stop0;
+};
+
+namespace {
+struct SeqRow { int id; std::string ref; bool hasRange; int start1, stop1; };
+
+bool read_wanted_fasta(const std::string& path, std::map<std::string, std::string>& wanted)
+{
+    std::ifstream f(path.c_str());
+    if(!f.is_open()) return false;
+    std::string line; std::string* cur = nullptr;
+    while(f.good()) {
+        std::getline(f, line);
+        while(!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+        if(!line.empty() && line[0] == '>') {
+            std::string ident = line.substr(1);                                    // readFASTA(file, false): up to the first blank, Utilities.cpp:782-797
+            const size_t sp = ident.find(' '); if(sp != std::string::npos) ident = ident.substr(0, sp);
+            auto it = wanted.find(ident);
+            cur = it == wanted.end() ? nullptr : &it->second;
+            if(cur) cur->assign("\x01");                                            // marks "seen" (removed below): a sequence may be empty
+        } else if(cur) *cur += line;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int hlala_contigs_load_dir(const char* graph_dir, int32_t extended_reference_genome, hlala_contigs_file** out)
+{
+    if(!graph_dir || !out) return HLALA_E_ARG;
+    const std::string dir(graph_dir);
+    std::ifstream sf((dir + "/sequences.txt").c_str());
+    if(!sf.is_open()) return fail("cannot open " + dir + "/sequences.txt");
+    auto chomp = [](std::string& s) { while(!s.empty() && (s.back() == '\r' || s.back() == '\n')) s.pop_back(); };
+    auto split_tab = [](const std::string& s) { std::vector<std::string> v; size_t a = 0, p; if(s.empty()) return v; while((p = s.find('\t', a)) != std::string::npos) { v.push_back(s.substr(a, p - a)); a = p + 1; } v.push_back(s.substr(a)); return v; };
+    std::string header; std::getline(sf, header); chomp(header);
+    const std::vector<std::string> hf = split_tab(header);
+    int cId = -1, cChr = -1, cStart = -1, cStop = -1;
+    for(size_t i = 0; i < hf.size(); i++) { if(hf[i] == "SequenceID") cId = (int)i; else if(hf[i] == "Chr") cChr = (int)i; else if(hf[i] == "Start_1based") cStart = (int)i; else if(hf[i] == "Stop_1based") cStop = (int)i; }
+    if(cId < 0 || cChr < 0 || (extended_reference_genome && (cStart < 0 || cStop < 0))) return fail(dir + "/sequences.txt: columns SequenceID, Chr, Start_1based, Stop_1based expected");
+    std::vector<SeqRow> rows; std::string line;
+    while(sf.good()) {
+        std::getline(sf, line); chomp(line);
+        if(line.empty()) continue;
+        const std::vector<std::string> lf = split_tab(line);
+        if(lf.size() != hf.size()) return fail(dir + "/sequences.txt: a row has " + std::to_string(lf.size()) + " fields, the header " + std::to_string(hf.size()));
+        SeqRow r; r.id = atoi(lf[cId].c_str());
+        const bool chr = !lf[cChr].empty();
+        r.ref = chr ? lf[cChr] : "PRG_" + lf[cId];
+        r.hasRange = chr && extended_reference_genome;
+        r.start1 = r.hasRange ? atoi(lf[cStart].c_str()) : 1; r.stop1 = r.hasRange ? atoi(lf[cStop].c_str()) : -1;
+        rows.push_back(r);
+    }
+    if(rows.empty()) return fail(dir + "/sequences.txt: no sequences");
+    std::string fasta;
+    if(extended_reference_genome) {
+        std::ifstream pf((dir + "/extendedReferenceGenomePath.txt").c_str());
+        if(pf.is_open()) { std::getline(pf, fasta); chomp(fasta); }                                      // Utilities::getFirstLine
+        else fasta = dir + "/extendedReferenceGenome/extendedReferenceGenome.fa";
+    } else fasta = dir + "/mapping_PRGonly/referenceGenome.fa";
+    std::map<std::string, std::string> seqs;
+    for(const SeqRow& r : rows) seqs[r.ref] = "";
+    if(!read_wanted_fasta(fasta, seqs)) return fail("readFASTA(): Cannot open file " + fasta);
+    if(!extended_reference_genome) { auto it = seqs.find("PRG_5"); if(it != seqs.end() && it->second.empty()) it->second = "\x01N"; }      // :87-88
+    std::unique_ptr<hlala_contigs_file> C(new hlala_contigs_file());
+    C->off.push_back(0);
+    for(const SeqRow& r : rows) {
+        std::string& s = seqs[r.ref];
+        if(s.empty()) return fail(r.ref + " cannot be found in the reference genome " + fasta);
+        const long long len = (long long)s.size() - 1;                                                    // without the "seen" mark
+        const long long a = r.start1, b = r.hasRange ? r.stop1 : len;
+        if(a < 1 || b > len || b < a) return fail("sequences.txt: interval " + std::to_string(a) + "-" + std::to_string(b) + " outside " + r.ref + " (length " + std::to_string(len) + ")");
+        const std::string tf = dir + "/translation/" + std::to_string(r.id) + ".txt";
+        std::ifstream ts(tf.c_str());
+        if(!ts.is_open()) return fail("Expected coordinate translation file not found: " + tf);
+        std::vector<int32_t> lv; std::string tl;
+        while(ts.good()) { std::getline(ts, tl); chomp(tl); std::stringstream ss(tl); int v = 0; ss >> v; lv.push_back(ss.fail() ? 0 : v); }     // StrtoI, Utilities.cpp:644-650
+        const long long n = b - a + 1;
+        if((long long)lv.size() < n) return fail(tf + ": " + std::to_string(lv.size()) + " levels for an interval of " + std::to_string(n) + " bases");
+        C->seq.insert(C->seq.end(), s.begin() + a, s.begin() + b + 1);                                    // s[0] is the mark: 1-based start a = index a
+        C->seq.insert(C->seq.end(), lv.size() - (size_t)n, (uint8_t)'N');
+        C->level.insert(C->level.end(), lv.begin(), lv.end());
+        C->off.push_back((int64_t)C->seq.size()); C->seqid.push_back(r.id);
+        C->refName.push_back(r.ref); C->start0.push_back((int32_t)(a - 1)); C->stop0.push_back((int32_t)(b - 1));
+    }
+    *out = C.release();
+    return HLALA_OK;
+}
+extern "C" int hlala_contigs_file_desc(const hlala_contigs_file* c, hlala_contigs_desc* d)
+{
+    if(!c || !d) return HLALA_E_ARG;
+    d->n_contigs = (int32_t)c->seqid.size(); d->contig_off = c->off.data(); d->contig_seq = c->seq.data(); d->contig_level = c->level.data(); d->contig_seqid = c->seqid.data();
+    return HLALA_OK;
+}
+extern "C" int32_t hlala_contigs_file_intervals(const hlala_contigs_file* c, hlala_bam_interval* out, int32_t cap)
+{
+    if(!c) return -1;
+    const int32_t n = (int32_t)c->seqid.size();
+    for(int32_t i = 0; out && i < n && i < cap; i++) { out[i].ref_name = c->refName[i].c_str(); out[i].start_0based = c->start0[i]; out[i].stop_0based = c->stop0[i]; out[i].contig = i; }
+    return n;
+}
+extern "C" void hlala_contigs_file_free(hlala_contigs_file* c) { delete c; }

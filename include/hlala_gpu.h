@@ -444,6 +444,19 @@ int  hlala_call_locus(hlala_ctx* ctx, int32_t C, const double* pairLL, const dou
                       int32_t* order /* [C(C+1)/2] or NULL */, double* p_normalized /* [C(C+1)/2] or NULL */,
                       double* cluster_marginal /* [C] or NULL */, hlala_call_out* out);
 
+/* Reference contigs of a graph directory (host code): one contig per row of <graph_dir>/sequences.txt -- the stretch
+ * [Start_1based, Stop_1based] of the BAM reference it names (column Chr, or PRG_<SequenceID>; extended_reference_genome == 0: the whole
+ * sequence of mapping_PRGonly/referenceGenome.fa) with the levels of translation/<SequenceID>.txt (processBAM::initBAM
+ * mapper/processBAM.cpp:1183-1402, the constructor :69-88, _loadMapping :4389-4457).  hlala_contigs_file_desc is the `contigs` argument
+ * of hlala_create, hlala_contigs_file_intervals the interval list of hlala_bam_extract_seeds (interval i = contig i).  A translation
+ * file that ends in a newline yields one extra level-0 entry in the reference's table; the contig then carries one extra position
+ * (base 'N', level 0) so that the level -> (sequence, position) table comes out the same. */
+typedef struct hlala_contigs_file hlala_contigs_file;
+int     hlala_contigs_load_dir(const char* graph_dir, int32_t extended_reference_genome, hlala_contigs_file** out);   /* errors: hlala_loader_last_error */
+int     hlala_contigs_file_desc(const hlala_contigs_file* c, hlala_contigs_desc* desc);
+int32_t hlala_contigs_file_intervals(const hlala_contigs_file* c, hlala_bam_interval* out, int32_t cap);              /* returns the number of intervals */
+void    hlala_contigs_file_free(hlala_contigs_file* c);
+
 /* ------------------------------------------------------------------------------------------
  * HLATyper host side around the kernels (host code; hla/HLATyper.cpp).  hlala_typer_open reads <graph_dir>/PRG/segments.txt and the
  * first line of every segment file: graph level names (Graph::readGraphLoci, Graph/Graph.cpp:2563-2614 -> graphLocus_2_levels,

@@ -96,3 +96,39 @@ def test_bam_and_graph_dir_to_result_files(pkg, tmp_path):
     npairs = L.n_clusters * (L.n_clusters + 1) // 2
     assert len((out / "R1_PP_A_pairs.txt").read_text().splitlines()) == npairs + 1
     assert len((out / "R1_columnIncompatibilities_A.txt").read_text().splitlines()) == 547
+
+
+def test_graph_directory_files_align_like_the_oracle(pkg, oracle, tmp_path):
+    """PRG/graph.txt, sequences.txt, the reference FASTA, translation files and a BAM -> context and batch built from files only.
+    The contigs carry the extra level-0 position of translation files ending in a newline (mapper/processBAM.cpp:4406-4412 with
+    Utilities::StrtoI("") == 0); product and oracle get the same arrays, and pairs placed away from level 0 come out as for the source arrays."""
+    from test_gpu_align import assert_pairs_equal, run_both
+    from test_graph_files import write_contigs_dir, write_graph_txt
+    from util import compare_chains
+    w = synth.make_world(seed=21, G=3000, k=2)
+    b = synth.make_batch(w, 300, seed=22)
+    lib = C.CDLL(pkg.LIB_PATH)
+    (tmp_path / "PRG").mkdir()
+    write_graph_txt(tmp_path / "PRG" / "graph.txt", w["graph"], np.random.default_rng(2))
+    write_contigs_dir(tmp_path, w["contigs"], np.random.default_rng(3))
+    graph = pkg.load_graph_text(lib, tmp_path / "PRG" / "graph.txt")
+    contigs, intervals = pkg.load_contigs_dir(lib, tmp_path, extended_reference_genome=False)
+    clen = np.diff(w["contigs"]["contig_off"])
+    assert np.array_equal(np.diff(contigs["contig_off"]), clen + 1)                 # every translation file ended in a newline
+    refs = [(iv[0], int(clen[i])) for i, iv in enumerate(intervals)]
+    bam = tmp_path / "s.bam"
+    write_bam(bam, refs, batch_records(b, np.random.default_rng(4)), block=25000)
+    seeds, names, cnt = pkg.bam_extract_seeds(lib, bam, intervals)
+    assert seeds["n_pairs"] == 300 and cnt["incomplete"] == 0
+    seeds["insert_mean"], seeds["insert_sd"] = b["insert_mean"], b["insert_sd"]
+    exp, gb, ctx = run_both(pkg, oracle, dict(graph=graph, contigs=contigs), seeds)
+    compare_chains(gb.chains(1), exp["ext"], seeds["n_chains"], label="from files")
+    assert_pairs_equal(gb.pairs(), exp["pairs"])
+    # the same batch against the source arrays: identical except where the level-0 quirk can reach (pairs next to level 0)
+    exp0, gb0, ctx0 = run_both(pkg, oracle, w, seeds)
+    p1, p0 = gb.pairs(), gb0.pairs()
+    far = (p0["n_cols"].reshape(-1, 2).min(1) > 0) & (p0["col_level"].reshape(300, -1).max(1) > 50)
+    for k in ("best_chain", "n_cols", "col_level", "col_mapq"):
+        a1 = p1[k].reshape(300, -1); a0 = p0[k].reshape(300, -1)
+        assert np.array_equal(a1[far], a0[far]), k
+    assert far.sum() > 250

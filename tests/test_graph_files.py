@@ -74,3 +74,61 @@ def test_graph_text_errors(pkg, tmp_path):
     p = tmp_path / "ok.txt"; p.write_bytes(ok.encode("latin-1"))
     g = pkg.load_graph_text(lib, p)
     assert g["n_levels"] == 2 and g["node_level"].tolist() == [0, 1] and g["edge_from"].tolist() == [0, 0] and bytes(g["edge_label"]) == b"AC"
+
+
+def write_contigs_dir(root, contigs, rng, trailing_newline=True):
+    """sequences.txt / FASTA files / translation files of a graph directory for the contigs of a synthetic world."""
+    n = contigs["n_contigs"]; off = contigs["contig_off"]
+    (root / "translation").mkdir(); (root / "mapping_PRGonly").mkdir(); (root / "extendedReferenceGenome").mkdir()
+    rows = ["SequenceID\tName\tFASTAID\tChr\tStart_1based\tStop_1based"]
+    ext = [">chrUn some description\n" + "ACGTN" * 40 + "\n"]; prg = []
+    chr6 = "".join("ACGT"[x] for x in rng.integers(0, 4, 777)); starts = {}
+    for i in range(n):
+        sid = int(contigs["contig_seqid"][i]); s = bytes(contigs["contig_seq"][off[i]:off[i + 1]]).decode()
+        if i == 0:
+            starts[i] = len(chr6) + 1; chr6 += s + "GATTACA" * 11
+            rows.append("%d\tref\tpgf\tchr6\t%d\t%d" % (sid, starts[i], starts[i] + len(s) - 1))
+            prg.append(">chr6\n" + s + "\n")                            # PRG-only mode: the whole sequence is the interval
+        else:
+            rows.append("%d\talt%d\talt%d\t\t\t" % (sid, i, i))
+            wrapped = "\n".join(s[j:j + 61] for j in range(0, len(s), 61))
+            ext.append(">PRG_%d extra words\n%s\n" % (sid, wrapped)); prg.append(">PRG_%d\n%s\n" % (sid, wrapped))
+        lv = contigs["contig_level"][off[i]:off[i + 1]]
+        (root / "translation" / ("%d.txt" % sid)).write_text("\n".join(str(int(x)) for x in lv) + ("\n" if trailing_newline or i % 2 else ""))
+    ext.insert(1, ">chr6\n" + "\n".join(chr6[j:j + 70] for j in range(0, len(chr6), 70)) + "\n")
+    (root / "sequences.txt").write_text("\n".join(rows) + "\n")
+    (root / "extendedReferenceGenome" / "extendedReferenceGenome.fa").write_text("".join(ext))
+    (root / "mapping_PRGonly" / "referenceGenome.fa").write_text("".join(prg))
+    return starts
+
+
+@pytest.mark.parametrize("extended,trailing", [(True, True), (False, True), (True, False)])
+def test_contigs_directory_loader(pkg, tmp_path, extended, trailing):
+    """sequences.txt + FASTA + translation files -> hlala_contigs_desc (processBAM.cpp:1183-1402, :4389-4457), including the extra level-0
+    entry a translation file ending in a newline produces in the reference."""
+    w = synth.make_world(seed=3, G=1500, k=1)
+    c = w["contigs"]; n = c["n_contigs"]; off = c["contig_off"]
+    rng = np.random.default_rng(1)
+    starts = write_contigs_dir(tmp_path, c, rng, trailing_newline=trailing)
+    lib = C.CDLL(pkg.LIB_PATH)
+    got, intervals = pkg.load_contigs_dir(lib, tmp_path, extended)
+    assert got["n_contigs"] == n and np.array_equal(got["contig_seqid"], c["contig_seqid"])
+    for i in range(n):
+        extra = 1 if (trailing or i % 2) else 0
+        a, b = got["contig_off"][i], got["contig_off"][i + 1]
+        assert b - a == off[i + 1] - off[i] + extra
+        assert np.array_equal(got["contig_seq"][a:b - extra if extra else b], c["contig_seq"][off[i]:off[i + 1]])
+        assert np.array_equal(got["contig_level"][a:b - extra if extra else b], c["contig_level"][off[i]:off[i + 1]])
+        if extra:
+            assert got["contig_seq"][b - 1] == ord("N") and got["contig_level"][b - 1] == 0
+        L = int(off[i + 1] - off[i])
+        if i == 0:
+            assert intervals[i] == (("chr6", starts[0] - 1, starts[0] + L - 2, 0) if extended else ("chr6", 0, L - 1, 0))
+        else:
+            assert intervals[i] == ("PRG_%d" % c["contig_seqid"][i], 0, L - 1, i)
+    # errors
+    (tmp_path / "translation" / ("%d.txt" % c["contig_seqid"][1])).unlink()
+    with pytest.raises(pkg.HlalaError, match="translation"):
+        pkg.load_contigs_dir(lib, tmp_path, extended)
+    with pytest.raises(pkg.HlalaError):
+        pkg.load_contigs_dir(lib, tmp_path / "nowhere", extended)
