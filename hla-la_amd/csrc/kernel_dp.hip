@@ -55,6 +55,7 @@ struct DpState {
     int itemIdx;                                          // index into the item list (kept for a requeue)
     int item, rOff, seqLen, start_seq, startLevel, startNode;
     int d, b1, b2, bn, n1, n2, nCells, nCompleted, curMax, firstMaxSlot, lastInc, earlyInit, itersRun, diagonals;
+    int earlyMaxNat;                                      // largest natural diagonal |dx|+|dy| among the cells that were created ahead of it
     u32 cellsEvaluated;
     int endSlot, endScore, nSteps, nCols;
     int have, sb, se, err;
@@ -328,7 +329,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.item = it.item; st.rOff = it.rOff; st.seqLen = it.seqLen; st.start_seq = it.start_seq; st.startLevel = it.startLevel; st.startNode = it.startNode;
         st.diagonals = it.seqLen + G.L - 1;
         st.d = 1; st.b1 = 0; st.b2 = 1; st.bn = 2; st.n1 = 1; st.n2 = 0; st.nCells = 1; st.nCompleted = 0;
-        st.curMax = 0; st.firstMaxSlot = 0; st.lastInc = 0; st.earlyInit = 0; st.itersRun = 0;
+        st.curMax = 0; st.firstMaxSlot = 0; st.lastInc = 0; st.earlyInit = 0; st.earlyMaxNat = -1; st.itersRun = 0;
         st.cellsEvaluated = 0;
         st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
         st.have = 0; st.sb = 0; st.se = -1; st.err = 0; st.needTier = 0;
@@ -507,6 +508,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     const int nCompleted0 = guni<GW>(st.nCompleted);
     int nCells = guni<GW>(st.nCells);
     int earlyInit = guni<GW>(st.earlyInit);
+    const int earlyMaxNat0 = guni<GW>(st.earlyMaxNat);
     if(gl == 0) { S.nNew = 0; S.nImp = 0; S.nCompletedAdd = 0; }
     WSYNC();
     int itMaxNew = DP_NEG;        // max Dv over kept targets of this iteration
@@ -514,11 +516,15 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     bool anyEqDiff = false, anyOw = false, anyExisting = false;
 
     // Cells reached through a gap-path jump arrive EARLIER than their natural diagonal |dx|+|dy| and can be
-    // reached again later ("scores" merge, :951-979).  From the first such cell on, every kept target is looked up in and, if
-    // new, registered with the DP's cell hash in the slab -- one compare-and-swap round trip does both (cells that are not
-    // early can never be reached again, registering them is merely harmless).  tes[t] = table slot of an existing cell,
-    // or -2 - (hash entry claimed for a new one), or -1.
-    if(earlyInit) {
+    // reached again later ("scores" merge, :951-979).  Every target of iteration d has a natural diagonal >= d, so a target can
+    // only meet an early cell while d <= the largest natural diagonal of the early cells created so far: in those iterations
+    // every kept target is looked up in and, if new, registered with the DP's cell hash in the slab -- one compare-and-swap
+    // round trip does both (registering a cell that is not early is merely harmless).  Once the early lineage has died out and
+    // d has passed its last diagonal, nothing can be met again and the pre-pass is skipped.  tes[t] = table slot of an
+    // existing cell, or -2 - (hash entry claimed for a new one), or -1.
+    const bool prepass = earlyInit && d <= earlyMaxNat0;
+    int earlyNatMax = -1;         // per lane: largest natural diagonal of the early cells this iteration creates
+    if(prepass) {
         for(int t0 = 0; t0 < nT; t0 += GW) {
             int t = t0 + gl; int es = -1;
             if(t < nT) {
@@ -539,7 +545,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     }
     DP_TQ(3);
     const bool slow = anyExisting;
-    const bool hadEarly = earlyInit != 0;      // S.tes[] holds lookups only if the pre-pass ran
+    const bool hadEarly = prepass;             // S.tes[] holds lookups only if the pre-pass ran
     bool failed = false;
 
     for(int pass = 0; pass < (slow ? 2 : 1); pass++) {
@@ -610,7 +616,8 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 int x = key_x(key), y = key_y(key);
                 int natural = (x > startLevel ? x - startLevel : startLevel - x) + (y > start_seq ? y - start_seq : start_seq - y);
                 bool isEarly = isNew && natural > d;
-                if(!hadEarly && grp_ballot<GW>(isEarly)) {       // the first early cells of this DP: start the hash with them
+                if(isEarly && natural > earlyNatMax) earlyNatMax = natural;
+                if(!hadEarly && grp_ballot<GW>(isEarly)) {       // early cells while no pre-pass ran (the first ones of this DP, or of a new early lineage): into the hash
                     if(!earlyInit) {
                         for(int i = gl; i < C::EARLY; i += GW) sl.early_key()[i] = HKEY_EMPTY;
                         earlyInit = 1;
@@ -713,6 +720,8 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         firstMaxSlot = grp_max_i32<GW>(fs);
     }
     if(anyEqDiff || anyOw) lastInc = d;
+    int earlyMaxNat = earlyMaxNat0;
+    if(earlyInit) { const int m = grp_max_i32<GW>(earlyNatMax); if(m > earlyMaxNat) earlyMaxNat = m; }
 
     DP_TQ(1);
     // ================= filter + sort, :1076-1105 ======================================
@@ -780,7 +789,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         st.b2 = b1; st.b1 = bn; st.bn = b2;                                                   // m2 := m1; m1 := this, :1104-1105
         st.n2 = n1; st.n1 = nNew;
         st.d = d + 1; st.itersRun = d;
-        st.nCells = nCells; st.nCompleted = nCompletedNew; st.earlyInit = earlyInit;
+        st.nCells = nCells; st.nCompleted = nCompletedNew; st.earlyInit = earlyInit; st.earlyMaxNat = earlyMaxNat;
         st.curMax = curMax; st.lastInc = lastInc; if(firstMaxSlot >= 0) st.firstMaxSlot = firstMaxSlot;
         st.cellsEvaluated += (u32)nT;
     }
