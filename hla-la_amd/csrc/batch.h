@@ -44,6 +44,8 @@ struct DevBatch {
     int* dp_sb;                     // [2*n_chains] read interval covered by the extension
     int* dp_se;
     int* dp_err;                    // [2*n_chains] 0, kernel line of a capacity failure, or -1000000 - columns
+    int* dp_alias_head;             // [2*n_chains] items whose DP starts from the same cell of the same read as this item's: head of the list (-1: none)
+    int* dp_alias_next;             // [2*n_chains] ... next entry of the list an item is on
     int* ext_level;                 // [n_chains*stride]
     int* ext_edge;
     uint8_t* ext_g;

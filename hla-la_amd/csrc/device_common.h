@@ -115,6 +115,15 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v)
     return ((u64)(~((u32)mh ^ 0x80000000u)) << 32) | (u64)(~((u32)ml ^ 0x80000000u));
 }
 // exclusive prefix sum over the wave; returns the lane's offset, `total` is wave-uniform
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for(int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
 __device__ __forceinline__ int wave_excl_scan(int v, int& total)
 {
     int x = v;

@@ -372,6 +372,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(seed_level, cs, false); AL(seed_edge, cs, false); AL(seed_g, cs, false); AL(seed_s, cs, false);
     AL(ext_status, nc, true); AL(ext_ncols, nc, true); AL(ext_begin, nc, true); AL(ext_end, nc, true); AL(ext_ll, nc, true);
     AL(dp_iters, 2 * nc, true); AL(dp_score, 2 * nc, true); AL(dp_ncols, 2 * nc, true); AL(dp_sb, 2 * nc, true); AL(dp_se, 2 * nc, true); AL(dp_err, 2 * nc, true);
+    AL(dp_alias_head, 2 * nc, false); AL(dp_alias_next, 2 * nc, false);
     AL(ext_level, cs, false); AL(ext_edge, cs, false); AL(ext_g, cs, false); AL(ext_s, cs, false); AL(ext_fromseed, cs, false);
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
@@ -524,20 +525,24 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if(B.n_chains > 0) {
         DpItem* items = (DpItem*)B.dp_items;
+        HIP_TRY(c, hipMemsetAsync(B.dp_alias_head, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->stream));       // -1: k_dp_items links the duplicates of a DP to it
         hipLaunchKernelGGL(k_dp_items, dim3((B.n_chains + 255) / 256), dim3(256), 0, c->stream, c->dG, b->dB, items);
         int rc = check_launch(c, "k_dp_items"); if(rc) return rc;
-        // every DP item first runs in the 16-lane class; the item count lives on the device, idle groups leave at once
-        HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
-        hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-        rc = check_launch(c, "k_dp<tiny>"); if(rc) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
-        // items that outgrew it: two DPs per wave, then one wave per DP, then the large-capacity class (one block per CU)
-        hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-        rc = check_launch(c, "k_dp<mid>"); if(rc) return rc;
-        hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-        rc = check_launch(c, "k_dp<small>"); if(rc) return rc;
-        hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-        rc = check_launch(c, "k_dp<large>"); if(rc) return rc;
+        // every DP item first runs in the 16-lane class; the item count lives on the device, idle groups leave at once.
+        // Items that outgrew it: two DPs per wave, then one wave per DP, then the large-capacity class (one block per CU).
+        auto run_classes = [&](bool first) -> int {
+            if(first) HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
+            hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            int rc_ = check_launch(c, "k_dp<tiny>"); if(rc_) return rc_;
+            if(first) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+            hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            rc_ = check_launch(c, "k_dp<mid>"); if(rc_) return rc_;
+            hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            rc_ = check_launch(c, "k_dp<small>"); if(rc_) return rc_;
+            hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            return check_launch(c, "k_dp<large>");
+        };
+        rc = run_classes(true); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[8], c->stream));
         int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
         hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);

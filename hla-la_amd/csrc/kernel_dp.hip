@@ -59,6 +59,7 @@ struct DpState {
     u32 cellsEvaluated;
     int endSlot, endScore, nSteps, nCols;
     int have, sb, se, err;
+    int isAlias;                                          // the results now being produced are those of a linked duplicate of the DP that ran
     int needTier;                                         // capacity failure: first tier whose class can hold what overflowed (0 = the next one)
 };
 
@@ -76,6 +77,7 @@ struct __align__(16) DpLdsT {
     short tes[C::HC];               // per target: existing / assigned table slot (-1 = none; CELLS <= 32767)
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     int nNew, nImp, nKeepF, err, nCompletedAdd;
+    int nextPhase;                                    // state after PH_DONE: idle, or the end-cell choice of a linked duplicate
     int btSlot, btM, btX, btY, btGuard, btDone;       // back-pointer chase in progress (lane 0 of the group)
     DpState st;
     u64 accCalls, accIters, accCells, accEdges;       // work counters of the DPs this group finished (flushed once at exit)
@@ -332,7 +334,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.curMax = 0; st.firstMaxSlot = 0; st.lastInc = 0; st.earlyInit = 0; st.earlyMaxNat = -1; st.itersRun = 0;
         st.cellsEvaluated = 0;
         st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
-        st.have = 0; st.sb = 0; st.se = -1; st.err = 0; st.needTier = 0;
+        st.have = 0; st.sb = 0; st.se = -1; st.err = 0; st.needTier = 0; st.isAlias = 0;
         S.err = 0;
         CellRec c0; c0.key = mk_key(it.startLevel, it.start_seq, it.startNode);
         c0.sc[0] = 0; c0.sc[1] = (short)DP_NEG; c0.sc[2] = (short)DP_NEG; c0.sc[3] = 0; c0.bt[0] = 0; c0.bt[1] = 0; c0.bt[2] = 0; c0.pad = 0;
@@ -957,6 +959,33 @@ __device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
 // ------------------------------------------------------------------------------------------
 // Input checks of extendSeedChain (extensionAligner.cpp:184-319) per chain and the list of DP items.
 // work_counter[8] / [9] count the left / right items; chains without any usable seed get their final status here.
+// The DP item of chain c in direction d (0 = left, 1 = right), extensionAligner.cpp:220-319; false: no such DP.
+__device__ inline bool dp_item_for(const DevGraph& G, const DevBatch& B, int c, int d, DpItem& it)
+{
+    if(B.unpaired) return false;            // alignOneLongRead only pads the seed chain (extendToFullSequenceLength, processBAM.cpp:3733-3735)
+    if(B.seed_status[c] != HLALA_CHAIN_OK) return false;
+    const int r = B.chain_read[c];
+    const int rOff = B.read_off[r], seqLen = B.read_off[r + 1] - rOff;
+    const int nSeed = B.seed_ncols[c], sBegin = B.seed_begin[c], sEnd = B.seed_end[c];
+    if(seqLen > DP_SEQCAP || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) return false;
+    const size_t cb = (size_t)c * B.stride;
+    const int e0 = B.seed_edge[cb], e1 = B.seed_edge[cb + nSeed - 1];
+    if(e0 < 0 || e1 < 0 || e0 >= G.E || e1 >= G.E) return false;
+    it.rOff = rOff; it.seqLen = seqLen; it.pad0 = 0; it.pad1 = 0; it.item = 2 * c + d;
+    if(d == 0) {                                                                        // left extension, extensionAligner.cpp:220-268
+        if(sBegin == 0) return false;
+        const int firstNode = G.edge_from_new[e0]; const int lvl = G.node_level[firstNode];
+        if(lvl <= 0) return false;
+        it.start_seq = sBegin; it.startLevel = lvl; it.startNode = firstNode;
+    } else {                                                                            // right extension, :271-319
+        if(sEnd == seqLen - 1) return false;
+        const int lastNode = G.edge_to_new[e1]; const int lvl = G.node_level[lastNode];
+        if(lvl >= G.L - 1) return false;
+        it.start_seq = sEnd + 1; it.startLevel = lvl; it.startNode = lastNode;
+    }
+    return true;
+}
+
 __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, DpItem* items)
 {
     const DevGraph& G = *Gp;
@@ -968,6 +997,7 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
         const int st = B.seed_status[c];
         B.dp_iters[2 * c] = 0; B.dp_iters[2 * c + 1] = 0; B.dp_score[2 * c] = INT32_MIN; B.dp_score[2 * c + 1] = INT32_MIN;
         B.dp_ncols[2 * c] = -1; B.dp_ncols[2 * c + 1] = -1; B.dp_err[2 * c] = 0; B.dp_err[2 * c + 1] = 0;
+        B.dp_alias_next[2 * c] = -1; B.dp_alias_next[2 * c + 1] = -1;
         if(st != HLALA_CHAIN_OK) {
             B.ext_status[c] = st; B.ext_ncols[c] = 0;
             if(st < 0) atomicAdd(&B.counters[CNT_ERRORS], 1ull);
@@ -979,22 +1009,25 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
             const int nSeed = B.seed_ncols[c], sBegin = B.seed_begin[c], sEnd = B.seed_end[c];
             int err = 0;
             if((!B.unpaired && seqLen > DP_SEQCAP) || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;     // DP_SEQCAP bounds the DP only
-            int e0 = -1, e1 = -1;
             if(!err) {
-                e0 = B.seed_edge[cb]; e1 = B.seed_edge[cb + nSeed - 1];
+                const int e0 = B.seed_edge[cb], e1 = B.seed_edge[cb + nSeed - 1];
                 if(e0 < 0 || e1 < 0 || e0 >= G.E || e1 >= G.E) err = HLALA_CHAIN_ERR_INPUT;
             }
             if(err) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = 0.0; atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
             else {
                 B.ext_status[c] = EXT_PENDING;
-                // long-read / unpaired mode: alignOneLongRead only pads the seed chain (extendToFullSequenceLength, processBAM.cpp:3733-3735)
-                if(!B.unpaired && sBegin != 0) {                                                      // left extension, extensionAligner.cpp:220-268
-                    int firstNode = G.edge_from_new[e0]; int lvl = G.node_level[firstNode];
-                    if(lvl > 0) { needL = true; itL.item = 2 * c; itL.rOff = rOff; itL.seqLen = seqLen; itL.start_seq = sBegin; itL.startLevel = lvl; itL.startNode = firstNode; itL.pad0 = 0; itL.pad1 = 0; }
-                }
-                if(!B.unpaired && sEnd != seqLen - 1) {                                // right extension, :271-319
-                    int lastNode = G.edge_to_new[e1]; int lvl = G.node_level[lastNode];
-                    if(lvl < G.L - 1) { needR = true; itR.item = 2 * c + 1; itR.rOff = rOff; itR.seqLen = seqLen; itR.start_seq = sEnd + 1; itR.startLevel = lvl; itR.startNode = lastNode; itR.pad0 = 0; itR.pad1 = 0; }
+                needL = dp_item_for(G, B, c, 0, itL);
+                needR = dp_item_for(G, B, c, 1, itR);
+                // The iterations of a DP are a function of (read, direction, start cell); the chain's random seed only enters when the end
+                // cell is drawn among equal ones.  Alignments of one read to homologous contigs project onto the same graph cells all the
+                // time: such a DP runs once, for the lowest chain of the read that needs it, and the group that ran it then repeats the
+                // end-cell choice (with the other chain's seed), the backtrace and the expansion for every chain linked to it here.
+                if(!B.from_seeds && (needL || needR)) {
+                    for(int c2 = B.chain_off[r]; c2 < c && (needL || needR); c2++) {
+                        DpItem o;
+                        if(needL && dp_item_for(G, B, c2, 0, o) && o.start_seq == itL.start_seq && o.startNode == itL.startNode) { B.dp_alias_next[2 * c] = atomicExch(&B.dp_alias_head[2 * c2], 2 * c); needL = false; }
+                        if(needR && dp_item_for(G, B, c2, 1, o) && o.start_seq == itR.start_seq && o.startNode == itR.startNode) { B.dp_alias_next[2 * c + 1] = atomicExch(&B.dp_alias_head[2 * c2 + 1], 2 * c + 1); needR = false; }
+                    }
                 }
             }
         }
@@ -1087,21 +1120,38 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
                 // final bookkeeping of this DP in this class; a DP that outgrew the class is queued for the next one and leaves no trace
                 const int edges = grp_sum_i32<GW>(edgesAcc);
                 if(gl == 0) {
-                    const DpState& st = S.st;
+                    DpState& st = S.st;
+                    S.nextPhase = PH_IDLE;
                     const bool capacity = st.err != 0 && st.err > -1000000;
                     if(capacity && TIER < 3) {
                         // next tier, or straight to the first tier whose class holds what overflowed (no point in failing again on the way)
                         int to = TIER + 1; if(st.needTier > to) to = st.needTier; if(to > 3) to = 3;
                         int* cnt = &B.work_counter[12 + 4 * (to - 1) + 2 * dirPass]; int* lst = B.retry_list + (size_t)(2 * (to - 1) + dirPass) * (size_t)B.n_chains;
+                        // (a linked duplicate whose own backtrace outgrew the class takes over the item entry: the DP that ran is done with it)
+                        if(st.isAlias) ((int*)(items + st.itemIdx))[0] = st.item;
                         int q = atomicAdd(cnt, 1); lst[q] = st.itemIdx;
                     } else {
                         const int item = st.item;
                         B.dp_iters[item] = st.itersRun; B.dp_score[item] = st.have ? st.endScore : INT32_MIN;
                         B.dp_ncols[item] = st.have ? st.nCols : -1; B.dp_sb[item] = st.sb; B.dp_se[item] = st.se; B.dp_err[item] = st.err;
                         S.accCalls++; S.accIters += (u64)st.itersRun; S.accCells += (u64)st.cellsEvaluated; S.accEdges += (u64)edges;
+                        // the chains of the read whose DP starts from the same cell (k_dp_items): same iterations, their own end-cell draw
+                        int nx = B.dp_alias_head[item]; if(nx < 0) nx = B.dp_alias_next[item];     // the DP that ran heads the list, a duplicate is on it
+                        const bool failed = st.err != 0 && st.err > -1000000;       // capacity of the last class: the same for every copy
+                        while(nx >= 0 && failed) {
+                            B.dp_iters[nx] = st.itersRun; B.dp_score[nx] = INT32_MIN; B.dp_ncols[nx] = -1; B.dp_sb[nx] = st.sb; B.dp_se[nx] = st.se; B.dp_err[nx] = st.err;
+                            S.accCalls++; S.accIters += (u64)st.itersRun; S.accCells += (u64)st.cellsEvaluated; S.accEdges += (u64)edges;
+                            nx = B.dp_alias_next[nx];
+                        }
+                        if(nx >= 0) {
+                            st.item = nx; st.isAlias = 1;
+                            st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0; st.have = 0; st.sb = 0; st.se = -1; st.err = 0;
+                            S.nextPhase = PH_SELECT;
+                        }
                     }
                 }
-                phase = PH_IDLE;
+                WSYNC();
+                phase = guni<GW>(S.nextPhase);
             }
             DP_T(1);
             if(phase == PH_EXPAND) phase = dp_expand<C>(S, sl, G, B, fwd);
