@@ -154,7 +154,7 @@ def main():
                        "dp_cells_per_s": st.n_dp_cells / ((st.ms_dp_main + st.ms_extend_retry) * 1e-3), "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
                        "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "extend_dp_16lane_kernel": st.ms_dp_main,
                                     "extend_dp_retry_classes": st.ms_extend_retry, "pair": st.ms_pair},
-                       "dp_calls_retried_wider_class": int(st.n_chains_retried), "dp_calls_retried_large_class": int(st.n_dp_retried_large),
+                       "dp_calls_sharing_a_dp": int(st.n_dp_shared), "dp_calls_retried_wider_class": int(st.n_chains_retried), "dp_calls_retried_large_class": int(st.n_dp_retried_large),
                        "generation_s": t_gen},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "kernel": "k_dp<DpTiny, 0>", "kernel_ms": st.ms_dp_main,

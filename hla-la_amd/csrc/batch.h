@@ -71,7 +71,7 @@ struct DevBatch {
 };
 
 enum {
-    CNT_CHAINS_EXT = 0, CNT_DP_CALLS, CNT_DP_ITERS, CNT_DP_CELLS, CNT_SEED_COLS, CNT_OUT_COLS, CNT_EDGES, CNT_ERRORS
+    CNT_CHAINS_EXT = 0, CNT_DP_CALLS, CNT_DP_ITERS, CNT_DP_CELLS, CNT_SEED_COLS, CNT_OUT_COLS, CNT_EDGES, CNT_ERRORS, CNT_DP_SHARED
 };
 
 }  // namespace hlala

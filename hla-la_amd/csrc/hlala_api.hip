@@ -783,7 +783,7 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];
     out->n_seed_columns = (int64_t)cnt[CNT_SEED_COLS]; out->n_out_columns = (int64_t)cnt[CNT_OUT_COLS];
-    out->n_edges_touched = (int64_t)cnt[CNT_EDGES]; out->n_errors = (int64_t)cnt[CNT_ERRORS];
+    out->n_edges_touched = (int64_t)cnt[CNT_EDGES]; out->n_errors = (int64_t)cnt[CNT_ERRORS]; out->n_dp_shared = (int64_t)cnt[CNT_DP_SHARED];
     return HLALA_OK;
 }
 

@@ -992,6 +992,7 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
     const DevBatch& B = *Bp;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     bool needL = false, needR = false;
+    int nShared = 0;
     DpItem itL, itR;
     if(c < B.n_chains) {
         const int st = B.seed_status[c];
@@ -1025,8 +1026,8 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
                 if(!B.from_seeds && (needL || needR)) {
                     for(int c2 = B.chain_off[r]; c2 < c && (needL || needR); c2++) {
                         DpItem o;
-                        if(needL && dp_item_for(G, B, c2, 0, o) && o.start_seq == itL.start_seq && o.startNode == itL.startNode) { B.dp_alias_next[2 * c] = atomicExch(&B.dp_alias_head[2 * c2], 2 * c); needL = false; }
-                        if(needR && dp_item_for(G, B, c2, 1, o) && o.start_seq == itR.start_seq && o.startNode == itR.startNode) { B.dp_alias_next[2 * c + 1] = atomicExch(&B.dp_alias_head[2 * c2 + 1], 2 * c + 1); needR = false; }
+                        if(needL && dp_item_for(G, B, c2, 0, o) && o.start_seq == itL.start_seq && o.startNode == itL.startNode) { B.dp_alias_next[2 * c] = atomicExch(&B.dp_alias_head[2 * c2], 2 * c); needL = false; nShared++; }
+                        if(needR && dp_item_for(G, B, c2, 1, o) && o.start_seq == itR.start_seq && o.startNode == itR.startNode) { B.dp_alias_next[2 * c + 1] = atomicExch(&B.dp_alias_head[2 * c2 + 1], 2 * c + 1); needR = false; nShared++; }
                     }
                 }
             }
@@ -1034,6 +1035,8 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
     }
     // wave-aggregated append: left extensions fill items[0, n_chains), right extensions items[n_chains, 2 n_chains)
     const int lane = lane_id();
+    nShared = wave_sum_i32(nShared);
+    if(lane == 0 && nShared) atomicAdd(&B.counters[CNT_DP_SHARED], (u64)nShared);
     const u64 mL = __ballot(needL), mR = __ballot(needR);
     const u64 below = (1ull << lane) - 1ull;
     if(mL) {

@@ -249,6 +249,8 @@ typedef struct {
     int32_t n_chains_retried;     /* re-runs of DP calls in a wider capacity class (a call can be re-run twice) */
     float   ms_dp_main;           /* part of ms_extend spent in the 16-lane DP kernel (k_dp<DpTiny>)      */
     int32_t n_dp_retried_large;   /* DP calls that also outgrew the 64-lane small class                  */
+    int64_t n_dp_shared;          /* of n_dp_calls: calls that start from the same cell of the same read as the call of an earlier chain
+                                     and took their iterations from it (own end-cell choice, backtrace and columns)                  */
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 

@@ -75,6 +75,10 @@ def test_filters_and_cigar_variety(pkg, oracle):
     assert (st == 1).sum() > 0 and (st == 2).sum() > 0
     compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="filters")
     assert_pairs_equal(gb.pairs(), exp["pairs"])
+    # identical haplotypes + secondaries everywhere: many DPs start from the same cell of the same read and are run once
+    # (the parity above covers the chains that took their iterations from another chain's DP); counters are per chain as in the reference
+    stt = gb.stats()
+    assert stt.n_dp_shared > 100 and (stt.n_dp_calls, stt.n_dp_iterations, stt.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
 
 
 def test_chain_extension_protocol(pkg, oracle):

@@ -32,3 +32,4 @@ def test_extend_matches_oracle(pkg, oracle, seed, G, k, n_pairs):
     print(f"k={k}: DP calls {st.n_dp_calls}, re-run in a wider class {st.n_chains_retried}, in the large class {st.n_dp_retried_large}")
     if k == 0:
         assert st.n_chains_retried > 0 and st.n_dp_retried_large > 0
+    print(f"k={k}: DP calls sharing the DP of another chain {st.n_dp_shared}")
