@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhlala_gpu.so")
+# HLALA_LIB_PATH: another build of the same library (tools/asan_host.sh points it at a sanitizer build of the host-side sources)
+LIB_PATH = os.environ.get("HLALA_LIB_PATH") or os.path.join(_HERE, "libhlala_gpu.so")
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -196,7 +197,7 @@ def load_graph_text(lib, path):
     """PRG/graph.txt -> graph dict (hlala_graph_load_text)."""
     h = C.c_void_p(); lib.hlala_graph_load_text.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]; lib.hlala_loader_last_error.restype = C.c_char_p
     if lib.hlala_graph_load_text(str(path).encode(), C.byref(h)) != 0:
-        raise HlalaError(lib.hlala_loader_last_error().decode())
+        raise HlalaError(lib.hlala_loader_last_error().decode(errors="replace"))
     return _graph_from_handle(lib, h)
 
 
@@ -204,13 +205,13 @@ def save_graph_cache(lib, graph, path):
     s, keep = fill_struct(GraphDesc, graph)
     lib.hlala_graph_cache_save.argtypes = [C.POINTER(GraphDesc), C.c_char_p]; lib.hlala_loader_last_error.restype = C.c_char_p
     if lib.hlala_graph_cache_save(C.byref(s), str(path).encode()) != 0:
-        raise HlalaError(lib.hlala_loader_last_error().decode())
+        raise HlalaError(lib.hlala_loader_last_error().decode(errors="replace"))
 
 
 def load_graph_cache(lib, path):
     h = C.c_void_p(); lib.hlala_graph_cache_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]; lib.hlala_loader_last_error.restype = C.c_char_p
     if lib.hlala_graph_cache_load(str(path).encode(), C.byref(h)) != 0:
-        raise HlalaError(lib.hlala_loader_last_error().decode())
+        raise HlalaError(lib.hlala_loader_last_error().decode(errors="replace"))
     return _graph_from_handle(lib, h)
 
 
@@ -219,7 +220,7 @@ def load_contigs_dir(lib, graph_dir, extended_reference_genome=True):
     h = C.c_void_p()
     lib.hlala_contigs_load_dir.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]; lib.hlala_loader_last_error.restype = C.c_char_p
     if lib.hlala_contigs_load_dir(str(graph_dir).encode(), int(bool(extended_reference_genome)), C.byref(h)) != 0:
-        raise HlalaError(lib.hlala_loader_last_error().decode())
+        raise HlalaError(lib.hlala_loader_last_error().decode(errors="replace"))
     d = ContigsDesc()
     lib.hlala_contigs_file_desc.argtypes = [C.c_void_p, C.POINTER(ContigsDesc)]; lib.hlala_contigs_file_desc(h, C.byref(d))
     n = d.n_contigs
@@ -249,7 +250,7 @@ def bam_extract_seeds(lib, path, intervals, long_read_mode=False):
     lib.hlala_bam_extract_seeds.argtypes = [C.c_char_p, C.c_int32, C.POINTER(BamInterval), C.c_int32, C.POINTER(C.c_void_p)]
     lib.hlala_bam_last_error.restype = C.c_char_p
     if lib.hlala_bam_extract_seeds(str(path).encode(), len(intervals), arr, int(bool(long_read_mode)), C.byref(h)) != 0:
-        raise HlalaError(lib.hlala_bam_last_error().decode())
+        raise HlalaError(lib.hlala_bam_last_error().decode(errors="replace"))
     d = BatchIn(); cnt = (C.c_int64 * 3)()
     lib.hlala_seed_batch_desc.argtypes = [C.c_void_p, C.POINTER(BatchIn), C.POINTER(C.c_int64)]
     lib.hlala_seed_batch_desc(h, C.byref(d), cnt)
@@ -318,7 +319,7 @@ class Typer:
 
     def _check(self, rc):
         if rc != 0:
-            raise HlalaError(self.lib.hlala_typer_last_error().decode())
+            raise HlalaError(self.lib.hlala_typer_last_error().decode(errors="replace"))
 
     def level_names(self):
         return [self.lib.hlala_typer_level_name(self.h, i).decode() for i in range(self.lib.hlala_typer_n_levels(self.h))]
@@ -414,13 +415,13 @@ class Locus:
 def typer_begin_output(lib, out_dir, unaccounted_min_fraction=0.2):
     lib.hlala_typer_begin_output.argtypes = [C.c_char_p, C.c_double]; lib.hlala_typer_last_error.restype = C.c_char_p
     if lib.hlala_typer_begin_output(str(out_dir).encode(), unaccounted_min_fraction) != 0:
-        raise HlalaError(lib.hlala_typer_last_error().decode())
+        raise HlalaError(lib.hlala_typer_last_error().decode(errors="replace"))
 
 
 def typer_end_output(lib, out_dir, loci, very_conservative=False):
     lib.hlala_typer_end_output.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]; lib.hlala_typer_last_error.restype = C.c_char_p
     if lib.hlala_typer_end_output(str(out_dir).encode(), ",".join(loci).encode(), int(very_conservative)) != 0:
-        raise HlalaError(lib.hlala_typer_last_error().decode())
+        raise HlalaError(lib.hlala_typer_last_error().decode(errors="replace"))
 
 
 

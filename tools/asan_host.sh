@@ -1,0 +1,11 @@
+#!/bin/bash
+# AddressSanitizer / UBSan over the host-side code of the library (parsers, filters, typer files): CPU build only.
+# Builds hla-la_amd/csrc/host_*.cpp + flat_graph.cpp into /tmp/libhlala_host_asan.so and runs the parser robustness tests against it.
+set -e
+cd "$(dirname "$0")/.."
+S=hla-la_amd/csrc
+g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -o /tmp/libhlala_host_asan.so \
+    $S/host_check.cpp $S/flat_graph.cpp $S/host_filters.cpp $S/host_loaders.cpp $S/host_bam.cpp $S/host_typer.cpp -lz
+ASAN_LIB=$(g++ -print-file-name=libasan.so)
+LD_PRELOAD=$ASAN_LIB ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 HLALA_LIB_PATH=/tmp/libhlala_host_asan.so \
+    python -m pytest tests/test_parsers_robust.py tests/test_typer_files.py tests/test_filters.py tests/test_bam.py tests/test_graph_files.py -x -q -m "not gpu" "$@"
