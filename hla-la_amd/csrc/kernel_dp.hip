@@ -1252,50 +1252,54 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
         // The read quality of alignment-orientation base i is read_quals[i] in both strands: the reference indexes the
         // ORIGINAL-orientation read with len-i-1 when the chain is reverse (extensionAligner.cpp:85-88), which is the same base.
         {
-            // phase 1 (parallel): every lane turns its <= 8 consecutive columns into two addends each (an unused addend is +0.0,
+            // phase 1 (parallel): every lane turns its <= LLPER consecutive columns into two addends each (an unused addend is +0.0,
             // an exact identity); phase 2 (serial by construction of FP addition): the running sum walks the lanes in order.
-            constexpr int LLPER = 8;                                   // 64 lanes * 8 columns per round; long reads take several rounds
+            // Chains of up to 192 columns (2x150 bp reads) take 3 columns per lane, longer ones 8 per lane in rounds of 512.
             double carry = 0.0; int baseIdx = 0;                       // running sum / read bases consumed before this round
-            for(int c0 = 0; c0 < total; c0 += 64 * LLPER) {
-                const int chunk = min(64 * LLPER, total - c0);
-                const int per = (chunk + 63) / 64;
-                const int j0 = c0 + lane * per, j1 = min(c0 + chunk, j0 + per);
-                unsigned char scv[LLPER], gcv[LLPER];
-                int nb = 0;
-#pragma unroll
-                for(int k = 0; k < LLPER; k++) {
-                    int j = j0 + k; bool in = k < per && j < j1;
-                    scv[k] = in ? B.ext_s[cb + j] : (unsigned char)'_'; gcv[k] = in ? B.ext_g[cb + j] : (unsigned char)'_';
-                    if(in && scv[k] != '_') nb++;
-                }
-                int tot; int before = baseIdx + wave_excl_scan(nb, tot);
-                double t1[LLPER], t2[LLPER];
-                {
-                    int idx = before;
+            auto ll_rounds = [&](auto perTag) {
+                constexpr int LLPER = decltype(perTag)::value;
+                for(int c0 = 0; c0 < total; c0 += 64 * LLPER) {
+                    const int chunk = min(64 * LLPER, total - c0);
+                    const int per = (chunk + 63) / 64;
+                    const int j0 = c0 + lane * per, j1 = min(c0 + chunk, j0 + per);
+                    unsigned char scv[LLPER], gcv[LLPER];
+                    int nb = 0;
 #pragma unroll
                     for(int k = 0; k < LLPER; k++) {
-                        unsigned char sc = scv[k], gc = gcv[k];
-                        double a1 = 0.0, a2 = 0.0;
-                        if(sc != '_') {
-                            if(gc == '_') a1 = T.rate_ins_quarter;
-                            else { a1 = T.rate_match_mismatch; unsigned char q = B.read_quals[rOff + idx]; a2 = (sc == gc) ? T.ll_match[q] : T.ll_mismatch[q]; }
-                            idx++;
-                        } else if(gc != '_') a1 = T.rate_indel;
-                        t1[k] = a1; t2[k] = a2;
+                        int j = j0 + k; bool in = k < per && j < j1;
+                        scv[k] = in ? B.ext_s[cb + j] : (unsigned char)'_'; gcv[k] = in ? B.ext_g[cb + j] : (unsigned char)'_';
+                        if(in && scv[k] != '_') nb++;
                     }
-                }
-                double acc = 0.0;
-                for(int l = 0; l < 64; l++) {
-                    double in = __shfl(acc, l > 0 ? l - 1 : 0);
-                    if(lane == l) {
-                        double a = (l == 0) ? carry : in;
+                    int tot; int before = baseIdx + wave_excl_scan(nb, tot);
+                    double t1[LLPER], t2[LLPER];
+                    {
+                        int idx = before;
 #pragma unroll
-                        for(int k = 0; k < LLPER; k++) { a += t1[k]; a += t2[k]; }
-                        acc = a;
+                        for(int k = 0; k < LLPER; k++) {
+                            unsigned char sc = scv[k], gc = gcv[k];
+                            double a1 = 0.0, a2 = 0.0;
+                            if(sc != '_') {
+                                if(gc == '_') a1 = T.rate_ins_quarter;
+                                else { a1 = T.rate_match_mismatch; unsigned char q = B.read_quals[rOff + idx]; a2 = (sc == gc) ? T.ll_match[q] : T.ll_mismatch[q]; }
+                                idx++;
+                            } else if(gc != '_') a1 = T.rate_indel;
+                            t1[k] = a1; t2[k] = a2;
+                        }
                     }
+                    double acc = 0.0;
+                    for(int l = 0; l < 64; l++) {
+                        double in = __shfl(acc, l > 0 ? l - 1 : 0);
+                        if(lane == l) {
+                            double a = (l == 0) ? carry : in;
+#pragma unroll
+                            for(int k = 0; k < LLPER; k++) { a += t1[k]; a += t2[k]; }
+                            acc = a;
+                        }
+                    }
+                    carry = __shfl(acc, 63); baseIdx += tot;
                 }
-                carry = __shfl(acc, 63); baseIdx += tot;
-            }
+            };
+            if(total <= 192) ll_rounds(std::integral_constant<int, 3>{}); else ll_rounds(std::integral_constant<int, 8>{});
             double ll = carry;
             ST_T(3);
             // first / last two defined levels for the pairing stage (verboseSeedChain.h:134-228)
