@@ -5,11 +5,14 @@
 //   mapper::aligner::extensionAligner::extendSeedChain           mapper/aligner/extensionAligner.h:30
 //   mapper::aligner::extensionAligner::scoreOneAlignment         mapper/aligner/extensionAligner.h:34
 //   mapper::processBAM::alignOneReadPair (batched here)          mapper/processBAM.h:87
+//   mapper::processBAM (graph directory + BAM -> resident batch) mapper/processBAM.cpp:30-158, 703-864, 1071-1165, 1183-1402
+//   hla::HLATyper::HLATypeInference                              hla/HLATyper.cpp:934-2810
 // Error behaviour: where the reference would `assert` / throw, these throw std::runtime_error with the library's
 // error text (the reference aborts the process; a maintainer can keep that with a catch-all + abort()).
 // Header-only, needs only a C++11 compiler and libhlala_gpu.so -- no HIP headers.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -205,6 +208,153 @@ private:
 };
 
 }  // namespace aligner
+
+// mapper::processBAM as far as the hot path needs it: the graph directory (PRG/graph.txt, sequences.txt, reference FASTA,
+// translation files) becomes a context, a BAM file becomes a batch resident on the GPU, aligned in place.
+class processBAM {
+public:
+    processBAM(const std::string& graphDir, bool extendedReferenceGenome, int max_columns = 384, uint32_t rng_seed = 0, int device = 0)
+        : graphDir_(graphDir), extended_(extendedReferenceGenome), max_columns_(max_columns), rng_seed_(rng_seed), device_(device)
+    {
+        if(hlala_graph_load_text((graphDir + "/PRG/graph.txt").c_str(), &graph_) != HLALA_OK) throw std::runtime_error(std::string("graph.txt: ") + hlala_loader_last_error());
+        if(hlala_contigs_load_dir(graphDir.c_str(), extendedReferenceGenome ? 1 : 0, &contigs_) != HLALA_OK) throw std::runtime_error(std::string("contigs: ") + hlala_loader_last_error());
+        intervals_.resize((size_t)hlala_contigs_file_intervals(contigs_, nullptr, 0));
+        hlala_contigs_file_intervals(contigs_, intervals_.data(), (int32_t)intervals_.size());
+    }
+    ~processBAM() { if(batch_) hlala_batch_destroy(batch_); if(seeds_) hlala_seed_batch_free(seeds_); if(ctx_) hlala_destroy(ctx_); hlala_contigs_file_free(contigs_); hlala_graph_file_free(graph_); }
+    processBAM(const processBAM&) = delete;
+    processBAM& operator=(const processBAM&) = delete;
+
+    // extractSeeds2 + estimateInsertSize + alignReads_postSeedExtraction (mapper/processBAM.cpp:703-864, 1071-1165, 2391-2483)
+    void alignReads(const std::string& BAM, bool longReads = false)
+    {
+        if(hlala_bam_extract_seeds(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, &seeds_) != HLALA_OK) throw std::runtime_error(std::string("BAM: ") + hlala_bam_last_error());
+        hlala_batch_in in; int64_t counts[3]; hlala_seed_batch_desc(seeds_, &in, counts);
+        readIDs.clear();
+        for(int32_t u = 0; u < in.n_pairs; u++) readIDs.push_back(hlala_seed_batch_name(seeds_, u));
+        hlala_graph_desc gd; hlala_graph_file_desc(graph_, &gd);
+        hlala_contigs_desc cd; hlala_contigs_file_desc(contigs_, &cd);
+        hlala_params pr{200.0, 35.0, rng_seed_, longReads ? 1 : 0, max_columns_, 0};
+        if(!longReads) {                                                              // insert size from this sample, then the real context
+            hlala_ctx* c0 = nullptr;
+            if(hlala_create(&c0, device_, nullptr, &gd, &cd, &pr) != HLALA_OK) throw std::runtime_error(std::string("hlala_create: ") + hlala_last_error(nullptr));
+            hlala_insert_size_out is; int rc = hlala_estimate_insert_size(c0, &in, &is);
+            std::string e = rc ? hlala_last_error(c0) : ""; hlala_destroy(c0);
+            if(rc) throw std::runtime_error("estimateInsertSize: " + e);
+            IS_mean = is.mean; IS_sd = is.sd; pr.insert_mean = is.mean; pr.insert_sd = is.sd;
+        }
+        if(hlala_create(&ctx_, device_, nullptr, &gd, &cd, &pr) != HLALA_OK) throw std::runtime_error(std::string("hlala_create: ") + hlala_last_error(nullptr));
+        int rc = longReads ? hlala_batch_create_unpaired(ctx_, &in, &batch_) : hlala_batch_create(ctx_, &in, &batch_);
+        if(rc == HLALA_OK) rc = hlala_align_batch(ctx_, batch_);
+        if(rc != HLALA_OK) throw std::runtime_error(std::string("alignReads: ") + hlala_last_error(ctx_));
+        n_units = in.n_pairs; longReadsMode = longReads;
+    }
+    hlala_ctx* ctx() const { return ctx_; }
+    hlala_batch* batch() const { return batch_; }
+    std::vector<std::string> readIDs;
+    double IS_mean = 200.0, IS_sd = 35.0;
+    int32_t n_units = 0; bool longReadsMode = false;
+
+private:
+    std::string graphDir_; bool extended_; int max_columns_; uint32_t rng_seed_; int device_;
+    hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; std::vector<hlala_bam_interval> intervals_;
+    hlala_seed_batch* seeds_ = nullptr; hlala_ctx* ctx_ = nullptr; hlala_batch* batch_ = nullptr;
+};
 }  // namespace mapper
+
+namespace hla {
+
+// hla::HLATyper: graph loci, exon files and allele clusters from the graph directory; HLATypeInference runs the per-locus chain on the
+// batch a processBAM left on the GPU and writes the reference's result files (hla/HLATyper.cpp:934-2810).
+class HLATyper {
+public:
+    HLATyper(const std::string& graphDir, const std::string& hla_nom_g = "")
+    {
+        if(hlala_typer_open(graphDir.c_str(), &t_) != HLALA_OK) throw std::runtime_error(std::string("HLATyper: ") + hlala_typer_last_error());
+        if(!hla_nom_g.empty() && hlala_typer_load_g_groups(t_, hla_nom_g.c_str()) != HLALA_OK) { std::string e = hlala_typer_last_error(); hlala_typer_close(t_); throw std::runtime_error("HLATyper: " + e); }
+    }
+    ~HLATyper() { hlala_typer_close(t_); }
+    HLATyper(const HLATyper&) = delete;
+    HLATyper& operator=(const HLATyper&) = delete;
+
+    // the reference's defaults (hla/HLATyper.cpp:28-31, 67-79; HLATyper.h:57)
+    hlala_filter_params filterParams{1, 20, 0.1, 2, 0.7, 0, 100, 0.2, 0, 100, 0.1};
+    double minimumMappingQuality = 0.0, min_bothReads_weightedCharactersOK = 0.0;
+    int minAlignmentLength_unpaired = 1000, k_for_kMer_index = 31;
+
+    struct bestGuess { std::string locus, allele1, allele2; double Q1_allele1 = 0, Q1_allele2 = 0; hlala_locus_report_out summary; };
+
+    std::vector<bestGuess> HLATypeInference(mapper::processBAM& pB, const std::string& outputDirectory, const std::vector<std::string>& loci_for_HLAtyping)
+    {
+        hlala_ctx* c = pB.ctx(); hlala_batch* b = pB.batch();
+        auto chk = [&](int rc, const char* what) { if(rc != HLALA_OK) throw std::runtime_error(std::string(what) + ": " + hlala_last_error(c)); };
+        auto tchk = [&](int rc, const char* what) { if(rc != HLALA_OK) throw std::runtime_error(std::string(what) + ": " + hlala_typer_last_error()); };
+        // interestingLevels -> coverage counters and includeInHLA (mapper/processBAM.cpp:2411-2446)
+        std::vector<int32_t> first, last;
+        for(int32_t i = 0; i < hlala_typer_n_genes(t_); i++) { const char* nm; int32_t a, z; hlala_typer_gene(t_, i, &nm, &a, &z); first.push_back(a); last.push_back(z); }
+        chk(hlala_set_gene_intervals(c, (int32_t)first.size(), first.data(), last.data()), "hlala_set_gene_intervals");
+        std::vector<uint8_t> include((size_t)pB.n_units);
+        chk(hlala_postprocess_pairs(c, b, include.data()), "hlala_postprocess_pairs");
+        std::vector<const char*> names; for(const std::string& s : pB.readIDs) names.push_back(s.c_str());
+        tchk(hlala_typer_begin_output(outputDirectory.c_str(), 0.2), "hlala_typer_begin_output");
+        if(pB.longReadsMode) filterParams.long_read_strand_filter = 1;
+        std::vector<bestGuess> out; std::string lociJoined;
+        for(const std::string& locus : loci_for_HLAtyping) {
+            hlala_locus* L = nullptr; tchk(hlala_typer_locus(t_, locus.c_str(), 0, nullptr, &L), "hlala_typer_locus");
+            struct Free { hlala_locus* l; ~Free() { hlala_locus_free(l); } } guard{L};
+            hlala_locus_info li; hlala_locus_get(L, &li);
+            hlala_locus_desc ld{li.level_min, li.level_max, li.level_to_exon, pB.IS_mean, pB.IS_sd, minimumMappingQuality, min_bothReads_weightedCharactersOK, include.data(), minAlignmentLength_unpaired, 0};
+            // exon positions: sizing call, then the real one
+            hlala_exon_positions_out pos; std::memset(&pos, 0, sizeof(pos));
+            int rc = hlala_exon_positions(c, b, &ld, &pos);
+            if(rc != HLALA_OK && rc != HLALA_E_CAPACITY) chk(rc, "hlala_exon_positions");
+            const size_t nR = (size_t)pos.n_reads, nP = (size_t)pos.n_pos, nC = (size_t)pos.n_chars;
+            std::vector<int32_t> read_pair(nR + 1), read_distance(nR + 1), cols(2 * nR + 1), pos_off(nR + 2), pos_exon(nP + 1), pos_level(nP + 1), novel(nP + 1), geno_off(nP + 2);
+            std::vector<double> wok(2 * nR + 1), fok(2 * nR + 1), rmapq(2 * nR + 1); std::vector<uint8_t> mate(nP + 1), pmapq(nP + 1), geno(nC + 1), qual(nC + 1), rrev(2 * nR + 1);
+            pos.cap_reads = (int32_t)nR; pos.cap_pos = (int32_t)nP; pos.cap_chars = (int32_t)nC;
+            pos.read_pair = read_pair.data(); pos.read_weighted_ok = wok.data(); pos.read_fraction_ok = fok.data(); pos.read_distance = read_distance.data(); pos.read_cols_nongap = cols.data();
+            pos.pos_off = pos_off.data(); pos.pos_exon = pos_exon.data(); pos.pos_level = pos_level.data(); pos.pos_mate = mate.data(); pos.pos_mapq = pmapq.data(); pos.pos_novel_gap = novel.data();
+            pos.geno_off = geno_off.data(); pos.geno_chars = geno.data(); pos.qual_chars = qual.data(); pos.read_reverse = rrev.data(); pos.read_mapq = rmapq.data();
+            chk(hlala_exon_positions(c, b, &ld, &pos), "hlala_exon_positions");
+            std::vector<uint8_t> use(nP + 1), ignored(nR + 1); hlala_filter_stats fs;
+            if(hlala_filter_positions(&pos, &filterParams, use.data(), ignored.data(), &fs) != HLALA_OK) throw std::runtime_error("hlala_filter_positions failed");
+            // likelihoods: first genotype character, genotype length and first quality of every position (hla/HLATyper.cpp:2080-2277)
+            std::vector<uint8_t> g0(nP + 1), q0(nP + 1); std::vector<int32_t> glen(nP + 1);
+            for(size_t j = 0; j < nP; j++) { g0[j] = geno[geno_off[j]]; q0[j] = qual[geno_off[j]]; glen[j] = geno_off[j + 1] - geno_off[j]; }
+            hlala_exon_in xin{li.n_clusters, li.n_columns, li.cluster_seq, (int32_t)nR, pos_off.data(), pos_exon.data(), g0.data(), glen.data(), q0.data(), use.data()};
+            const size_t C = (size_t)li.n_clusters, nPairs = C * (C + 1) / 2;
+            std::vector<double> LL(C * nR + 1), pairLL(nPairs), misAvg(nPairs), misMin(nPairs), pNorm(nPairs), marginal(C); std::vector<int32_t> mism(C * nR + 1), order(nPairs);
+            chk(hlala_exon_loglik(c, &xin, LL.data(), mism.data()), "hlala_exon_loglik");
+            chk(hlala_pair_loglik(c, LL.data(), mism.data(), li.n_clusters, (int32_t)nR, pairLL.data(), misAvg.data(), misMin.data()), "hlala_pair_loglik");
+            hlala_call_out call; chk(hlala_call_locus(c, li.n_clusters, pairLL.data(), misAvg.data(), misMin.data(), order.data(), pNorm.data(), marginal.data(), &call), "hlala_call_locus");
+            double covered[2];
+            for(int a = 0; a < 2; a++) {                                              // proportionkMersCovered, :2652-2688
+                const int32_t cl = a ? call.second_cluster : call.first_cluster; int32_t nq = 0, nt = 0;
+                hlala_locus_cluster_kmers(L, cl, k_for_kMer_index, nullptr, 0, &nq, &nt);
+                std::vector<char> q((size_t)nq * k_for_kMer_index + 1); std::vector<uint8_t> present((size_t)nq + 1);
+                tchk(hlala_locus_cluster_kmers(L, cl, k_for_kMer_index, q.data(), nq, &nq, &nt), "hlala_locus_cluster_kmers");
+                chk(hlala_kmer_presence(c, b, include.data(), k_for_kMer_index, nq, q.data(), present.data()), "hlala_kmer_presence");
+                int hit = 0; for(int32_t i = 0; i < nq; i++) hit += present[i];
+                covered[a] = nt ? (double)hit / (double)nt : -1;
+            }
+            hlala_locus_report_in rin; std::memset(&rin, 0, sizeof(rin));
+            rin.pos = &pos; rin.filter = &filterParams; rin.unit_name_1 = names.data(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.data(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
+            rin.n_clusters = li.n_clusters; rin.pair_ll = pairLL.data(); rin.mis_avg = misAvg.data(); rin.mis_min = misMin.data(); rin.order = order.data(); rin.p_normalized = pNorm.data(); rin.call = &call;
+            rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2;
+            bestGuess g; g.locus = locus;
+            tchk(hlala_locus_write_files(L, &rin, outputDirectory.c_str(), &g.summary), "hlala_locus_write_files");
+            g.allele1 = hlala_locus_cluster_id(L, call.first_cluster); g.allele2 = hlala_locus_cluster_id(L, call.second_cluster); g.Q1_allele1 = call.first_marginal; g.Q1_allele2 = call.second_p;
+            out.push_back(g);
+            lociJoined += (lociJoined.empty() ? "" : ",") + locus;
+        }
+        tchk(hlala_typer_end_output(outputDirectory.c_str(), lociJoined.c_str(), 0), "hlala_typer_end_output");
+        return out;
+    }
+
+private:
+    hlala_typer* t_ = nullptr;
+};
+
+}  // namespace hla
 }  // namespace host
 }  // namespace hlala

@@ -132,3 +132,60 @@ def test_graph_directory_files_align_like_the_oracle(pkg, oracle, tmp_path):
         a1 = p1[k].reshape(300, -1); a0 = p0[k].reshape(300, -1)
         assert np.array_equal(a1[far], a0[far]), k
     assert far.sum() > 250
+
+
+def test_cpp_host_mirror_from_files_to_result_files(pkg, tmp_path):
+    """hla-la_amd/host/hlala_host.hpp (processBAM + HLATyper with the reference's names) driven by a C++ program: the files it writes
+    are the files the ctypes path writes from the same inputs."""
+    import os
+    import subprocess
+    from test_graph_files import write_contigs_dir, write_graph_txt
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G = 4000; exons = [(1200, 1470), (1900, 2176)]
+    w = synth.make_world(seed=12, G=G, k=1, n_mut=6, mut_density=0.03)
+    lib = C.CDLL(pkg.LIB_PATH)
+    write_graph_dir(tmp_path, w["H"], exons)
+    write_graph_txt(tmp_path / "PRG" / "graph.txt", w["graph"], np.random.default_rng(2))
+    write_contigs_dir(tmp_path, w["contigs"], np.random.default_rng(3))
+    b = synth.make_batch(w, 700, seed=77, haps=(2, 5))
+    contigs, intervals = pkg.load_contigs_dir(lib, tmp_path, extended_reference_genome=False)
+    clen = np.diff(w["contigs"]["contig_off"])
+    bam = tmp_path / "sample.bam"
+    write_bam(bam, [(iv[0], int(clen[i])) for i, iv in enumerate(intervals)], batch_records(b, np.random.default_rng(1)), block=30000)
+    # ---- C++
+    exe = str(tmp_path / "typer_mirror")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_typer_mirror.cpp"),
+                           "-L", os.path.join(ROOT, "hla-la_amd"), "-lhlala_gpu", "-Wl,-rpath," + os.path.join(ROOT, "hla-la_amd")])
+    out_cpp = tmp_path / "out_cpp"
+    r = subprocess.run([exe, str(tmp_path), str(bam), str(out_cpp), "A"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "TYPED A A*03:01 A*06:01" in r.stdout or "TYPED A A*06:01 A*03:01" in r.stdout, r.stdout + r.stderr
+    # ---- the same through the ctypes binding
+    graph = pkg.load_graph_text(lib, tmp_path / "PRG" / "graph.txt")
+    seeds, names, cnt = pkg.bam_extract_seeds(lib, bam, intervals)
+    ctx0 = pkg.Context(graph, contigs, insert_mean=200.0, insert_sd=35.0, rng_seed=5)
+    ins = ctx0.estimate_insert_size(seeds)
+    ctx = pkg.Context(graph, contigs, insert_mean=ins["mean"], insert_sd=ins["sd"], rng_seed=5)
+    gb = ctx.batch(seeds); gb.align()
+    T = pkg.Typer(lib, tmp_path); L = T.locus("A")
+    genes = T.genes(); ctx.set_gene_intervals([g[1] for g in genes], [g[2] for g in genes])
+    include = gb.postprocess()
+    e = gb.exon_positions(L.level_min, L.level_to_exon, ins["mean"], ins["sd"], pair_mask=include)
+    prm = pkg.default_filter_params(first20_n=6)
+    use, ignored, fst = pkg.filter_positions(lib, e, prm)
+    LL, M = ctx.exon_loglik(pkg.exon_in_from_positions(e, use, L.cluster_seq, L.n_clusters, L.n_columns))
+    pair_ll, mis_avg, mis_min = ctx.pair_loglik(LL, M)
+    call = ctx.call_locus(pair_ll, mis_avg, mis_min)
+    kc = []
+    for c in (call["first_cluster"], call["second_cluster"]):
+        q, total = L.cluster_kmers(c, 31)
+        kc.append(-1.0 if total == 0 else float(ctx.kmer_presence(gb, q, 31, include).sum()) / total)
+    out_py = tmp_path / "out_py"
+    pkg.typer_begin_output(lib, out_py)
+    co = pkg.CallOut(call["first_cluster"], call["second_cluster"], call["first_marginal"], call["second_p"], call["ll_max"], call["max_pair"], call["n_sort_ties"])
+    L.write_files(out_py, e, names, names, pair_ll, mis_avg, mis_min, call["order"], call["p_normalized"], co, kmers_covered=kc, params=prm)
+    pkg.typer_end_output(lib, out_py, ["A"])
+    files = sorted(os.listdir(out_py))
+    assert files == sorted(os.listdir(out_cpp)) and "R1_bestguess.txt" in files and len(files) == 7
+    for fn in files:
+        assert (out_py / fn).read_bytes() == (out_cpp / fn).read_bytes(), fn
+    assert ("insert size %.3f %.3f pairs 700" % (ins["mean"], ins["sd"])) in r.stdout
