@@ -189,3 +189,51 @@ def test_cpp_host_mirror_from_files_to_result_files(pkg, tmp_path):
     for fn in files:
         assert (out_py / fn).read_bytes() == (out_cpp / fn).read_bytes(), fn
     assert ("insert size %.3f %.3f pairs 700" % (ins["mean"], ins["sd"])) in r.stdout
+
+
+def test_long_reads_from_bam_to_result_files(pkg, tmp_path):
+    """BASELINE config 5 style: unpaired kilobase reads with ONT-like errors; BAM (long-read mode: primaries only) -> unpaired batch ->
+    per-read exon positions -> filters incl. the strand filter -> likelihoods -> call -> files."""
+    G = 6000; exons = [(2200, 2470), (3100, 3376)]
+    w = synth.make_world(seed=14, G=G, k=1, n_mut=6, mut_density=0.03)
+    truth = (1, 4)
+    lib = C.CDLL(pkg.LIB_PATH)
+    write_graph_dir(tmp_path, w["H"], exons)
+    T = pkg.Typer(lib, tmp_path); L = T.locus("A")
+    want = {L.type_cluster("A*%02d:01" % (h + 1)) for h in truth}
+    assert len(want) == 2
+    u = synth.make_long_batch(w, 160, seed=31, len_lo=1500, len_hi=3000, haps=truth, p_second=0.3)
+    clen = np.diff(w["contigs"]["contig_off"]); nct = w["contigs"]["n_contigs"]
+    recs = []
+    for r in range(u["n_pairs"]):
+        seq = bytes(u["read_bases"][u["read_off"][r]:u["read_off"][r + 1]]).decode(); qual = (u["read_quals"][u["read_off"][r]:u["read_off"][r + 1]].astype(int) - 33).tolist()
+        for c in range(u["chain_off"][r], u["chain_off"][r + 1]):
+            cig = [(int(x) >> 4, "MIDNSHP=X"[int(x) & 15]) for x in u["cigar"][u["cigar_off"][c]:u["cigar_off"][c + 1]]]
+            recs.append(dict(name="long%05d" % r, flag=(16 if u["chain_reverse"][c] else 0) | (0 if c == u["read_primary"][r] else 256), ref=int(u["chain_contig"][c]),
+                             pos=int(u["chain_pos"][c]), cigar=cig, seq=seq, qual=qual, tags=[("AS", "i", int(u["chain_as"][c]))]))
+    bam = tmp_path / "long.bam"
+    write_bam(bam, [("hap%d" % i, int(clen[i])) for i in range(nct)], recs, block=40000)
+    seeds, names, cnt = pkg.bam_extract_seeds(lib, bam, [("hap%d" % i, 0, int(clen[i]) - 1, i) for i in range(nct)], long_read_mode=True)
+    assert seeds["n_pairs"] == 160 and seeds["n_chains"] == 160                       # secondaries are not taken in long-read mode
+    ctx = pkg.Context(w["graph"], w["contigs"], insert_mean=200.0, insert_sd=35.0, rng_seed=5, long_read_mode=1, max_columns=8192)
+    gb = ctx.batch_unpaired(seeds); gb.align()
+    assert gb.stats().n_errors == 0
+    genes = T.genes(); ctx.set_gene_intervals([g[1] for g in genes], [g[2] for g in genes])
+    include = gb.postprocess()
+    assert 20 < include.sum() <= 160
+    e = gb.exon_positions(L.level_min, L.level_to_exon, 0, 0, pair_mask=include, min_alignment_columns=1000)
+    assert e["n_reads"] > 20 and (e["read_mapq"][1::2] == -1).all()
+    prm = pkg.default_filter_params(first20_n=6, long_read_strand_filter=1, strand_min_allele_coverage=8, strand_min_freq=0.1)
+    use, ignored, fst = pkg.filter_positions(lib, e, prm)
+    LL, M = ctx.exon_loglik(pkg.exon_in_from_positions(e, use, L.cluster_seq, L.n_clusters, L.n_columns))
+    pair_ll, mis_avg, mis_min = ctx.pair_loglik(LL, M)
+    call = ctx.call_locus(pair_ll, mis_avg, mis_min)
+    assert {call["first_cluster"], call["second_cluster"]} == want
+    out = tmp_path / "hla"
+    pkg.typer_begin_output(lib, out)
+    co = pkg.CallOut(call["first_cluster"], call["second_cluster"], call["first_marginal"], call["second_p"], call["ll_max"], call["max_pair"], call["n_sort_ties"])
+    res = L.write_files(out, e, names, None, pair_ll, mis_avg, mis_min, call["order"], call["p_normalized"], co, params=prm, long_read_mode=True)
+    rows = [r.split("\t") for r in (out / "R1_bestguess.txt").read_text().splitlines()]
+    assert {rows[1][2], rows[2][2]} == {L.cluster_id(c) for c in want} and res.n_utilized_reads > 5      # error-rich reads: the first-N filter drops many of them
+    pile = (out / "R1_pileup_A.txt").read_text().splitlines()
+    assert len(pile) == 546 and all(" long" in l for l in pile if int(l.split("\t")[2]) > 0)

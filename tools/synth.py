@@ -408,7 +408,7 @@ def as_unpaired(b):
     return u
 
 
-def make_long_batch(world, n_reads, seed=5, len_lo=2000, len_hi=10000, sub=0.05, ins=0.04, dele=0.04, clip_max=60, p_second=0.0):
+def make_long_batch(world, n_reads, seed=5, len_lo=2000, len_hi=10000, sub=0.05, ins=0.04, dele=0.04, clip_max=60, p_second=0.0, haps=None):
     """Single long reads (BASELINE config 5 style: ONT-like substitution / insertion / deletion rates) with one primary alignment each
     whose CIGAR is derived from the truth (thousands of operations), in the hlala_batch_in layout of an UNPAIRED batch
     (n_pairs = number of reads).  `p_second`: fraction of reads that also get a clean second alignment on another haplotype."""
@@ -418,7 +418,8 @@ def make_long_batch(world, n_reads, seed=5, len_lo=2000, len_hi=10000, sub=0.05,
     reads_b, reads_q, read_off, chain_off, read_primary = [], [], [0], [0], []
     ch = dict(contig=[], pos=[], offset=[], AS=[], rev=[], cig=[])
     for r in range(n_reads):
-        h = int(rng.integers(0, nh)); L = int(rng.integers(len_lo, len_hi + 1)); L = min(L, int(clen[h]) - 10)
+        h = int(rng.integers(0, nh)) if haps is None else int(haps[int(rng.integers(0, len(haps)))])
+        L = int(rng.integers(len_lo, len_hi + 1)); L = min(L, int(clen[h]) - 10)
         s = int(rng.integers(0, clen[h] - L))
         ref = seq[off[h] + s: off[h] + s + L]
         # walk the reference segment, emitting read bases and run-length encoded operations
