@@ -289,11 +289,36 @@ class LocusInfo(C.Structure):
                 ("cluster_seq", c_u8p), ("level_to_exon", c_i32p), ("col_level", c_i32p), ("col_exon", c_i32p), ("col_exon_pos", c_i32p), ("exon_length", c_i32p)]
 
 
+class UnitStatsOut(C.Structure):
+    _fields_ = [("valid", c_u8p), ("strands_valid", c_u8p), ("distance", c_i32p), ("fraction_ok", c_f64p), ("weighted_ok", c_f64p), ("n_columns", c_i32p), ("mate_mapq", c_f64p)]
+
+
+def unit_stats_struct(d):
+    """UnitStatsOut view over a dict of arrays (valid, strands_valid, distance, fraction_ok, weighted_ok, n_columns, mate_mapq)."""
+    o = UnitStatsOut(); keep = []
+    dt = dict(valid=np.uint8, strands_valid=np.uint8, distance=np.int32, fraction_ok=np.float64, weighted_ok=np.float64, n_columns=np.int32, mate_mapq=np.float64)
+    for k, t in UnitStatsOut._fields_:
+        a = np.ascontiguousarray(d[k], dt[k]); keep.append(a); setattr(o, k, a.ctypes.data_as(t))
+    return o, keep
+
+
+def typer_write_summary(lib, out_dir, stats, unpaired=False, unit_mask=None, insert_mean=0.0, insert_sd=0.0, min_alignment_length_unpaired=1000):
+    """summaryStatistics.txt (hlala_typer_write_summary) from the dict Batch.unit_stats() returns."""
+    o, keep = unit_stats_struct(stats)
+    n = len(stats["valid"]); m = None if unit_mask is None else np.ascontiguousarray(unit_mask, np.uint8)
+    lib.hlala_typer_write_summary.argtypes = [C.c_char_p, C.c_int32, C.c_int32, c_u8p, C.POINTER(UnitStatsOut), C.c_double, C.c_double, C.c_int32]
+    lib.hlala_typer_last_error.restype = C.c_char_p
+    if lib.hlala_typer_write_summary(str(out_dir).encode(), n, int(bool(unpaired)), None if m is None else m.ctypes.data_as(c_u8p), C.byref(o), insert_mean, insert_sd,
+                                     min_alignment_length_unpaired) != 0:
+        raise HlalaError(lib.hlala_typer_last_error().decode(errors="replace"))
+
+
 class LocusReportIn(C.Structure):
     _fields_ = [("pos", C.POINTER(ExonPositionsOut)), ("filter", C.POINTER(FilterParams)), ("unit_name_1", C.POINTER(C.c_char_p)), ("unit_name_2", C.POINTER(C.c_char_p)),
                 ("long_read_mode", C.c_int32), ("n_clusters", C.c_int32), ("pair_ll", c_f64p), ("mis_avg", c_f64p), ("mis_min", c_f64p), ("order", c_i32p),
                 ("p_normalized", c_f64p), ("call", C.c_void_p), ("kmers_covered", C.c_double * 2), ("unaccounted_min_coverage", C.c_int32), ("reserved", C.c_int32),
-                ("unaccounted_min_fraction", C.c_double)]
+                ("unaccounted_min_fraction", C.c_double), ("unit_stats", C.POINTER(UnitStatsOut)), ("unit_mask", c_u8p), ("n_units", C.c_int32), ("reserved2", C.c_int32),
+                ("insert_mean", C.c_double), ("insert_sd", C.c_double), ("min_mapq", C.c_double), ("min_weighted_ok", C.c_double)]
 
 
 class LocusReportOut(C.Structure):
@@ -389,8 +414,10 @@ class Locus:
         return [raw[i * k:(i + 1) * k] for i in range(nq.value)], nt.value
 
     def write_files(self, out_dir, e, names1, names2, pair_ll, mis_avg, mis_min, order, p_normalized, call, kmers_covered=(-1.0, -1.0), params=None,
-                    long_read_mode=False, unaccounted_min_coverage=30, unaccounted_min_fraction=0.2):
-        """hlala_locus_write_files; e = dict of Batch.exon_positions(), call = CallOut.  Returns LocusReportOut."""
+                    long_read_mode=False, unaccounted_min_coverage=30, unaccounted_min_fraction=0.2, unit_stats=None, unit_mask=None, insert_mean=0.0, insert_sd=0.0,
+                    min_mapq=0.0, min_weighted_ok=0.0):
+        """hlala_locus_write_files; e = dict of Batch.exon_positions(), call = CallOut, unit_stats = dict of Batch.unit_stats() (histogram lines).
+        Returns LocusReportOut."""
         o, keep = exon_positions_struct(e)
         prm = params or default_filter_params()
         r = LocusReportIn(); r.pos = C.pointer(o); r.filter = C.pointer(prm)
@@ -403,6 +430,11 @@ class Locus:
         r.pair_ll, r.mis_avg, r.mis_min = (a.ctypes.data_as(c_f64p) for a in arrs[:3]); r.order = arrs[3].ctypes.data_as(c_i32p); r.p_normalized = arrs[4].ctypes.data_as(c_f64p)
         r.call = C.cast(C.pointer(call), C.c_void_p); r.kmers_covered[0], r.kmers_covered[1] = float(kmers_covered[0]), float(kmers_covered[1])
         r.unaccounted_min_coverage = unaccounted_min_coverage; r.unaccounted_min_fraction = unaccounted_min_fraction
+        if unit_stats is not None:
+            us, keep_us = unit_stats_struct(unit_stats); r.unit_stats = C.pointer(us); r.n_units = len(unit_stats["valid"])
+            if unit_mask is not None:
+                um = np.ascontiguousarray(unit_mask, np.uint8); r.unit_mask = um.ctypes.data_as(c_u8p)
+            r.insert_mean, r.insert_sd, r.min_mapq, r.min_weighted_ok = insert_mean, insert_sd, min_mapq, min_weighted_ok
         out = LocusReportOut()
         self.typer._check(self.lib.hlala_locus_write_files(self.h, C.byref(r), str(out_dir).encode(), C.byref(out)))
         return out
@@ -557,7 +589,7 @@ EXPORTED_SYMBOLS = [
     "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
     "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",
-    "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_typer_end_output",
+    "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_unit_alignment_stats", "hlala_typer_write_summary", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_typer_end_output",
 ]
 
 
@@ -731,6 +763,17 @@ class Batch:
         inc = np.zeros(self.n_pairs, np.uint8)
         self.ctx._check(self.ctx.lib.hlala_postprocess_pairs(self.ctx.h, self.b, inc.ctypes.data_as(c_u8p)), "hlala_postprocess_pairs")
         return inc
+
+    def unit_stats(self):
+        """hlala_unit_alignment_stats: per pair / read strands, distance, fraction OK, weighted OK, columns and mapping qualities."""
+        n = self.n_pairs
+        d = dict(valid=np.zeros(n, np.uint8), strands_valid=np.zeros(n, np.uint8), distance=np.zeros(n, np.int32), fraction_ok=np.zeros(2 * n), weighted_ok=np.zeros(2 * n),
+                 n_columns=np.zeros(2 * n, np.int32), mate_mapq=np.zeros(2 * n))
+        o, keep = unit_stats_struct(d)
+        d = dict(zip([k for k, _ in UnitStatsOut._fields_], keep))
+        self.ctx.lib.hlala_unit_alignment_stats.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(UnitStatsOut)]
+        self.ctx._check(self.ctx.lib.hlala_unit_alignment_stats(self.ctx.h, self.b, C.byref(o)), "hlala_unit_alignment_stats")
+        return d
 
     def exon_positions(self, level_min, level_to_exon, insert_mean, insert_sd, min_mapq=0.0, min_weighted_ok=0.0, pair_mask=None, min_alignment_columns=1000):
         """Exon positions of this batch's read pairs for one locus (hlala_exon_positions; hla/HLATyper.cpp:1385-1428)."""

@@ -1015,6 +1015,25 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
     return done(HLALA_OK);
 }
 
+extern "C" int hlala_unit_alignment_stats(hlala_ctx* c, hlala_batch* b, hlala_unit_stats_out* o)
+{
+    if(!c || !b || !o || !o->valid || !o->strands_valid || !o->distance || !o->fraction_ok || !o->weighted_ok || !o->n_columns || !o->mate_mapq) return HLALA_E_ARG;
+    if(!(b->staged & 4)) { c->err = "hlala_unit_alignment_stats before hlala_pair_chains"; return HLALA_E_STATE; }
+    const size_t n = (size_t)b->B.n_pairs;
+    if(n == 0) return HLALA_OK;
+    std::vector<void*> tmp;
+    auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
+    int rc = 0; hlala_unit_stats_out d; memset(&d, 0, sizeof(d));
+    if((rc = dev_alloc(c, tmp, n, &d.valid)) || (rc = dev_alloc(c, tmp, n, &d.strands_valid)) || (rc = dev_alloc(c, tmp, n, &d.distance)) || (rc = dev_alloc(c, tmp, 2 * n, &d.fraction_ok)) ||
+       (rc = dev_alloc(c, tmp, 2 * n, &d.weighted_ok)) || (rc = dev_alloc(c, tmp, 2 * n, &d.n_columns)) || (rc = dev_alloc(c, tmp, 2 * n, &d.mate_mapq))) return done(rc);
+    hipLaunchKernelGGL(k_unit_stats, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c->stream, b->dB, c->dT, d);
+    if((rc = check_launch(c, "k_unit_stats"))) return done(rc);
+    if((rc = dl(c, o->valid, d.valid, n)) || (rc = dl(c, o->strands_valid, d.strands_valid, n)) || (rc = dl(c, o->distance, d.distance, n)) || (rc = dl(c, o->fraction_ok, d.fraction_ok, 2 * n)) ||
+       (rc = dl(c, o->weighted_ok, d.weighted_ok, 2 * n)) || (rc = dl(c, o->n_columns, d.n_columns, 2 * n)) || (rc = dl(c, o->mate_mapq, d.mate_mapq, 2 * n))) return done(rc);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return done(HLALA_OK);
+}
+
 extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present)
 {
     if(!c || !b || n_queries < 0 || (n_queries > 0 && (!queries || !present))) return HLALA_E_ARG;
@@ -1059,7 +1078,7 @@ extern "C" int hlala_abi_sizeof(const char* name)
     const std::string n(name);
 #define SZ(t) if(n == #t) return (int)sizeof(t);
     SZ(hlala_graph_desc) SZ(hlala_contigs_desc) SZ(hlala_params) SZ(hlala_graph_info) SZ(hlala_batch_in) SZ(hlala_seeds_in)
-    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats) SZ(hlala_insert_size_out) SZ(hlala_locus_info) SZ(hlala_locus_report_in) SZ(hlala_locus_report_out)
+    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats) SZ(hlala_insert_size_out) SZ(hlala_locus_info) SZ(hlala_locus_report_in) SZ(hlala_locus_report_out) SZ(hlala_unit_stats_out)
 #undef SZ
     return -1;
 }

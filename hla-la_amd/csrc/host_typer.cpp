@@ -340,6 +340,9 @@ extern "C" int hlala_typer_begin_output(const char* out_dir, double unaccounted_
     if(!a.is_open() || !g.is_open()) return fail(HLALA_E_ARG, std::string("cannot write to ") + out_dir);
     a << "Locus" << "\t" << "Chromosome" << "\t" << "Allele" << "\t" << "Q1" << "\t" << "Q2" << "\t" << "AverageCoverage" << "\t" << "CoverageFirstDecile" << "\t" << "MinimumCoverage" << "\t" << "proportionkMersCovered" << "\t" << "LocusAvgColumnError" << "\t" << field << "\n";
     g << "Locus" << "\t" << "Chromosome" << "\t" << "Allele" << "\t" << "Q1" << "\t" << "Q2" << "\t" << "AverageCoverage" << "\t" << "CoverageFirstDecile" << "\t" << "MinimumCoverage" << "\t" << "proportionkMersCovered" << "\t" << "LocusAvgColumnError" << "\t" << field << "\t" << "perfectG" << "\n";
+    std::ofstream hst((std::string(out_dir) + "/histogram_matchesPerRead.txt").c_str());
+    if(!hst.is_open()) return fail(HLALA_E_ARG, std::string("cannot write to ") + out_dir);
+    hst << "Locus" << "\t" << "Level" << "Value" << "\n";                                            // sic, hla/HLATyper.cpp:1145
     return HLALA_OK;
 }
 extern "C" int hlala_typer_end_output(const char* out_dir, const char* loci_comma_separated, int32_t very_conservative_read_likelihoods)
@@ -349,6 +352,61 @@ extern "C" int hlala_typer_end_output(const char* out_dir, const char* loci_comm
     if(!p.is_open()) return fail(HLALA_E_ARG, std::string("cannot write to ") + out_dir);
     p << "Loci" << " = " << loci_comma_separated << "\n";
     p << "veryConservativeReadLikelihoods" << " = " << (very_conservative_read_likelihoods != 0) << "\n";
+    return HLALA_OK;
+}
+
+// summaryStatistics.txt, hla/HLATyper.cpp:1030-1125
+extern "C" int hlala_typer_write_summary(const char* out_dir, int32_t n_units, int32_t unpaired, const uint8_t* unit_mask, const hlala_unit_stats_out* st,
+                                         double insert_mean, double insert_sd, int32_t min_alignment_length_unpaired)
+{
+    if(!out_dir || !st || n_units < 0) return fail(HLALA_E_ARG, "hlala_typer_write_summary: null argument");
+    size_t nPaired = 0, nUnpaired = 0;
+    int strandsValid = 0, pairedPerfect = 0, oneReadPerfect = 0, unpairedPerfect = 0, strandsValidDistanceOK = 0, unpairedLongEnough = 0;
+    std::vector<double> distances; double pairedSum = 0, unpairedSum = 0;
+    for(int32_t u = 0; u < n_units; u++) {
+        if((unit_mask && !unit_mask[u]) || !st->valid[u]) continue;
+        if(!unpaired) {
+            nPaired++;
+            if(st->strands_valid[u]) {
+                strandsValid++;
+                const double d = st->distance[u]; distances.push_back(d);
+                if(std::abs(d - insert_mean) <= (5 * insert_sd)) strandsValidDistanceOK++;
+            }
+            const double f1 = st->fraction_ok[2 * u], f2 = st->fraction_ok[2 * u + 1];
+            if(f1 == 1) pairedPerfect++;
+            if(f2 == 1) pairedPerfect++;
+            if((f1 == 1) || (f2 == 1)) oneReadPerfect++;
+            pairedSum += f1; pairedSum += f2;
+        } else {
+            nUnpaired++;
+            const double f1 = st->fraction_ok[2 * u];
+            if(st->n_columns[2 * u] >= min_alignment_length_unpaired) unpairedLongEnough++;
+            if(f1 == 1) unpairedPerfect++;
+            unpairedSum += f1;
+        }
+    }
+    std::sort(distances.begin(), distances.end());                                                     // meanMedian, :3103-3121
+    double S = 0; for(double d : distances) S += d;
+    const double mean = distances.empty() ? 0 : S / (double)distances.size(), median = distances.empty() ? 0 : distances[distances.size() / 2];
+    const double pairedAvg = nPaired > 0 ? (pairedSum / (2.0 * (double)nPaired)) : 0, unpairedAvg = nUnpaired > 0 ? (unpairedSum / ((double)nUnpaired)) : 0;
+    auto perc = [](double v1, double v2) { return to_str((v1 / v2) * 100); };                         // printPerc, :3124-3128
+    struct stat sb;
+    if(stat(out_dir, &sb) != 0 && mkdir(out_dir, 0775) != 0) return fail(HLALA_E_ARG, std::string("cannot create ") + out_dir);
+    std::ofstream o((std::string(out_dir) + "/summaryStatistics.txt").c_str());
+    if(!o.is_open()) return fail(HLALA_E_ARG, std::string("cannot write to ") + out_dir);
+    o << "\nRead alignment statistics:\n";
+    o << "\t - Total number (paired) alignments:                 " << nPaired << "\n";
+    o << "\t\t - Alignment pairs with strands OK:                  " << strandsValid << " (" << perc(strandsValid, nPaired) << "%)\n";
+    o << "\t\t - Alignment pairs with strands OK && distance OK:   " << strandsValidDistanceOK << " (" << perc(strandsValidDistanceOK, nPaired) << "%)\n";
+    o << "\t\t - Alignment pairs with strands OK, mean distance:   " << mean << "\n";
+    o << "\t\t - Alignment pairs with strands OK, median distance: " << median << "\n";
+    o << "\t\t - Alignment pairs, average fraction alignment OK:   " << pairedAvg << "\n";
+    o << "\t\t - Alignment pairs, at least one alignment perfect:   " << oneReadPerfect << "\n";
+    o << "\t\t - Single alignments, perfect (total):   " << pairedPerfect << " (" << nPaired * 2 << ")\n";
+    o << "\t - Total number (unpaired) alignments:                 " << nUnpaired << "\n";
+    o << "\t\t - Alignment pairs, average fraction alignment OK:   " << unpairedAvg << "\n";
+    o << "\t\t - Single alignments, perfect (total):   " << unpairedPerfect << " (" << nUnpaired * 2 << ")\n";
+    o << "\t\t - Alignments with length >= " << min_alignment_length_unpaired << ":   " << unpairedLongEnough << "\n";
     return HLALA_OK;
 }
 
@@ -383,6 +441,24 @@ extern "C" int hlala_locus_write_files(const hlala_locus* L, const hlala_locus_r
     };
     const std::string dir(out_dir), locus = L->name;
     std::set<std::string> utilized;
+    if(in->unit_stats) {
+        // histogram_matchesPerRead.txt: per pair that passes the pair test of the locus (:1404-1429), then per piled position (:1928)
+        const hlala_unit_stats_out* us = in->unit_stats;
+        std::ofstream hst((dir + "/histogram_matchesPerRead.txt").c_str(), std::ios::app);
+        if(!hst.is_open()) return fail(HLALA_E_ARG, "cannot append to " + dir + "/histogram_matchesPerRead.txt (hlala_typer_begin_output first)");
+        if(!in->long_read_mode && in->unit_name_2)
+            for(int32_t u = 0; u < in->n_units; u++) {
+                if((in->unit_mask && !in->unit_mask[u]) || !us->valid[u]) continue;
+                const double w1 = us->weighted_ok[2 * u], w2 = us->weighted_ok[2 * u + 1];
+                if(us->strands_valid[u] && (std::abs((double)us->distance[u] - in->insert_mean) <= (5 * in->insert_sd)) && (us->mate_mapq[2 * u] >= in->min_mapq) &&
+                   ((w1 >= in->min_weighted_ok) && (w2 >= in->min_weighted_ok))) {
+                    hst << locus << "\t" << "read" << w1 << "\n";
+                    hst << locus << "\t" << "read" << w2 << "\n";
+                    hst << locus << "\t" << "readPair" << (w1 + w2) / 2.0 << "\n";
+                }
+            }
+        for(int j = 0; j < nPos; j++) if(piled(j)) hst << locus << "\t" << "base" << pos->read_weighted_ok[2 * readOf[j] + (pos->pos_mate[j] == 2 ? 1 : 0)] << "\n";
+    }
     {
         std::ofstream pu((dir + "/R1_pileup_" + locus + ".txt").c_str());
         if(!pu.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_pileup_" + locus + ".txt");

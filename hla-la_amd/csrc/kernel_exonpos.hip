@@ -197,4 +197,35 @@ __global__ void k_exon_positions(const DevBatch* __restrict__ Bp, const DevTable
     }
 }
 
+// per-unit alignment statistics (hla/HLATyper.cpp:1043-1097): one thread per pair / read
+__global__ void k_unit_stats(const DevBatch* __restrict__ Bp, const DevTables* __restrict__ Tp, hlala_unit_stats_out o)
+{
+    const DevBatch& B = *Bp; const DevTables& T = *Tp;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= B.n_pairs) return;
+    const int stride = B.stride; const int nm = B.unpaired ? 1 : 2;
+    o.valid[p] = 0; o.strands_valid[p] = 0; o.distance[p] = 0;
+    for(int m = 0; m < 2; m++) { o.fraction_ok[2 * p + m] = 0; o.weighted_ok[2 * p + m] = 0; o.n_columns[2 * p + m] = 0; o.mate_mapq[2 * p + m] = 0; }
+    if(B.pair_status[p] != 0) return;
+    MateAln a[2];
+    for(int m = 0; m < nm; m++) {
+        const int r = B.unpaired ? p : 2 * p + m; const int ch = B.best_chain[r];
+        if(ch < 0 || ch >= B.n_chains) return;
+        const size_t so = (size_t)ch * stride;
+        a[m].n = B.ext_ncols[ch]; a[m].lv = B.ext_level + so; a[m].g = B.ext_g + so; a[m].s = B.ext_s + so; a[m].mq = B.sel_mapq + (size_t)r * stride;
+        a[m].bases = B.read_bases + B.read_off[r]; a[m].quals = B.read_quals + B.read_off[r]; a[m].readLen = B.read_off[r + 1] - B.read_off[r];
+        a[m].first = B.ext_firstlast[4 * ch + 0]; a[m].last = B.ext_firstlast[4 * ch + 2];
+    }
+    for(int m = 0; m < nm; m++) {
+        double w, f; int cng; mate_fractions(a[m], T, w, f, cng);
+        o.fraction_ok[2 * p + m] = f; o.weighted_ok[2 * p + m] = w; o.n_columns[2 * p + m] = a[m].n; o.mate_mapq[2 * p + m] = B.mate_mapq[B.unpaired ? p : 2 * p + m];
+    }
+    if(B.unpaired) { o.fraction_ok[2 * p + 1] = -1; o.weighted_ok[2 * p + 1] = -1; o.mate_mapq[2 * p + 1] = -1; o.distance[p] = -1; }
+    else {
+        o.strands_valid[p] = B.strands_valid[p];
+        o.distance[p] = (a[0].first < a[1].first) ? (a[1].first - a[0].last - 1) : (a[0].first - a[1].last - 1);      // alignerBase.cpp:246-283
+    }
+    o.valid[p] = 1;
+}
+
 }  // namespace hlala

@@ -297,6 +297,12 @@ public:
         chk(hlala_postprocess_pairs(c, b, include.data()), "hlala_postprocess_pairs");
         std::vector<const char*> names; for(const std::string& s : pB.readIDs) names.push_back(s.c_str());
         tchk(hlala_typer_begin_output(outputDirectory.c_str(), 0.2), "hlala_typer_begin_output");
+        // read alignment statistics (hla/HLATyper.cpp:1030-1125) and the per-pair quantities of the histogram lines
+        const size_t nU = (size_t)pB.n_units;
+        std::vector<uint8_t> usValid(nU + 1), usStrands(nU + 1); std::vector<int32_t> usDist(nU + 1), usCols(2 * nU + 1); std::vector<double> usF(2 * nU + 1), usW(2 * nU + 1), usQ(2 * nU + 1);
+        hlala_unit_stats_out us{usValid.data(), usStrands.data(), usDist.data(), usF.data(), usW.data(), usCols.data(), usQ.data()};
+        chk(hlala_unit_alignment_stats(c, b, &us), "hlala_unit_alignment_stats");
+        tchk(hlala_typer_write_summary(outputDirectory.c_str(), pB.n_units, pB.longReadsMode ? 1 : 0, include.data(), &us, pB.IS_mean, pB.IS_sd, minAlignmentLength_unpaired), "hlala_typer_write_summary");
         if(pB.longReadsMode) filterParams.long_read_strand_filter = 1;
         std::vector<bestGuess> out; std::string lociJoined;
         for(const std::string& locus : loci_for_HLAtyping) {
@@ -341,6 +347,8 @@ public:
             rin.pos = &pos; rin.filter = &filterParams; rin.unit_name_1 = names.data(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.data(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
             rin.n_clusters = li.n_clusters; rin.pair_ll = pairLL.data(); rin.mis_avg = misAvg.data(); rin.mis_min = misMin.data(); rin.order = order.data(); rin.p_normalized = pNorm.data(); rin.call = &call;
             rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2;
+            rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
+            rin.min_mapq = minimumMappingQuality; rin.min_weighted_ok = min_bothReads_weightedCharactersOK;
             bestGuess g; g.locus = locus;
             tchk(hlala_locus_write_files(L, &rin, outputDirectory.c_str(), &g.summary), "hlala_locus_write_files");
             g.allele1 = hlala_locus_cluster_id(L, call.first_cluster); g.allele2 = hlala_locus_cluster_id(L, call.second_cluster); g.Q1_allele1 = call.first_marginal; g.Q1_allele2 = call.second_p;

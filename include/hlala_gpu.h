@@ -504,12 +504,35 @@ int  hlala_locus_cluster_kmers(const hlala_locus* l, int32_t cluster, int32_t k,
  * k <= 31, queries over ACGT (others never match: the reads' N never equals an allele character); pair_mask as in hlala_locus_desc. */
 int  hlala_kmer_presence(hlala_ctx* ctx, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present);
 
+/* Per-unit alignment statistics of a batch (the loop of hla/HLATyper.cpp:1043-1097 and the per-pair quantities of the pair test
+ * :1404-1410): alignedReadPair_strandsValid, alignedReadPair_pairsDistanceInGraphLevels (alignerBase.cpp:246-283), alignmentFractionOK
+ * (:3082-3101) and alignmentWeightedOKFraction (:3933-4018) of both mates, alignment columns (graph_aligned.size()) and the mates'
+ * mapping qualities.  valid[u] = 0 for a unit whose chains hit a device capacity (everything else of that unit is 0).  Unpaired
+ * batches fill the mate-1 halves; the mate-2 halves hold -1 and distance is -1. */
+typedef struct {
+    uint8_t* valid;          /* [n_units]                                   */
+    uint8_t* strands_valid;  /* [n_units]                                   */
+    int32_t* distance;       /* [n_units]                                   */
+    double*  fraction_ok;    /* [2*n_units]                                 */
+    double*  weighted_ok;    /* [2*n_units]                                 */
+    int32_t* n_columns;      /* [2*n_units]                                 */
+    double*  mate_mapq;      /* [2*n_units]                                 */
+} hlala_unit_stats_out;
+int  hlala_unit_alignment_stats(hlala_ctx* ctx, hlala_batch* b, hlala_unit_stats_out* out);
+
+/* summaryStatistics.txt (hla/HLATyper.cpp:1030-1125) over the units with a non-zero unit_mask entry (NULL: all): the units of a paired
+ * batch are the paired alignments, those of an unpaired batch the unpaired ones (the other group is empty, as in a run of the reference
+ * on one kind of reads).  Sums run in unit order like the reference's loops. */
+int  hlala_typer_write_summary(const char* out_dir, int32_t n_units, int32_t unpaired, const uint8_t* unit_mask, const hlala_unit_stats_out* stats,
+                               double insert_mean, double insert_sd, int32_t min_alignment_length_unpaired);
+
 /* Result files of one locus (HLATyper.cpp:1883-2044 pile-up + read IDs, :2451-2488 all pairs, :2543-2759 coverage, column
  * incompatibilities, best guesses).  hlala_typer_begin_output creates the directory and the headers of R1_bestguess.txt /
  * R1_bestguess_G.txt, hlala_locus_write_files writes R1_pileup_<locus>.txt, R1_readIDs_<locus>.txt, R1_PP_<locus>_pairs.txt,
  * R1_columnIncompatibilities_<locus>.txt and appends the two best-guess rows (the G rows if hlala_typer_load_g_groups knows the
  * locus), hlala_typer_end_output writes R1_parameters.txt.  Numbers are printed by the same iostream calls as the reference.
- * Not written: summaryStatistics.txt and histogram_matchesPerRead.txt (diagnostics over all pairs, not only exon-overlapping ones). */
+ * With unit_stats given, the lines of histogram_matchesPerRead.txt of the locus are appended too (header: hlala_typer_begin_output):
+ * "read" / "readPair" per pair that passes the pair test of the locus (:1404-1429; paired batches only) and "base" per piled position (:1928). */
 typedef struct {
     const hlala_exon_positions_out* pos;     /* hlala_exon_positions of this locus, with read_reverse and read_mapq             */
     const hlala_filter_params* filter;       /* the parameters hlala_filter_positions ran with                                    */
@@ -527,6 +550,11 @@ typedef struct {
     int32_t unaccounted_min_coverage;        /* threshold_reportColumn_forPresenceOfUnaccountedAlleles_minCoverage (30, :67)        */
     int32_t reserved;
     double  unaccounted_min_fraction;        /* ..._minAlleleFraction (0.2, :68)                                                   */
+    const hlala_unit_stats_out* unit_stats;  /* NULL: no histogram lines                                                           */
+    const uint8_t* unit_mask;                /* [units of the batch] or NULL: the mask hlala_exon_positions ran with (includeInHLA) */
+    int32_t n_units;                         /* units of the batch                                                                 */
+    int32_t reserved2;
+    double  insert_mean, insert_sd, min_mapq, min_weighted_ok;   /* the pair test of hlala_locus_desc                            */
 } hlala_locus_report_in;
 typedef struct {
     double  locus_coverage, first_decile_coverage, minimum_coverage, avg_column_error, min_column_p;

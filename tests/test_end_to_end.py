@@ -84,8 +84,27 @@ def test_bam_and_graph_dir_to_result_files(pkg, tmp_path):
     out = tmp_path / "hla"
     pkg.typer_begin_output(lib, out)
     co = pkg.CallOut(call["first_cluster"], call["second_cluster"], call["first_marginal"], call["second_p"], call["ll_max"], call["max_pair"], call["n_sort_ties"])
-    res = L.write_files(out, e, names, names, pair_ll, mis_avg, mis_min, call["order"], call["p_normalized"], co, kmers_covered=kc, params=prm)
+    # per-pair statistics: against the columns of the chosen alignments (alignmentFractionOK, pairsDistanceInGraphLevels) and the exon positions
+    us = gb.unit_stats(); pr = gb.pairs(); stride = ctx.max_columns
+    assert us["valid"].all()
+    for p in range(0, 700, 7):
+        fl = []
+        for m in range(2):
+            r = 2 * p + m; n = pr["n_cols"][r]; gch = pr["col_gchar"][r * stride:r * stride + n]; sch = pr["col_schar"][r * stride:r * stride + n]
+            both = (gch == ord("_")) & (sch == ord("_"))
+            assert us["fraction_ok"][r] == ((gch == sch) & ~both).sum() / (~both).sum() and us["n_columns"][r] == n
+            lv = pr["col_level"][r * stride:r * stride + n]; lv = lv[lv != -1]; fl.append((int(lv[0]), int(lv[-1])))
+        d = fl[1][0] - fl[0][1] - 1 if fl[0][0] < fl[1][0] else fl[0][0] - fl[1][1] - 1
+        assert us["distance"][p] == d and us["strands_valid"][p] == pr["strands_valid"][p]
+    assert np.array_equal(us["weighted_ok"].reshape(-1, 2)[e["read_pair"]].reshape(-1), e["read_weighted_ok"]) and np.array_equal(us["mate_mapq"], pr["mate_mapq"])
+    pkg.typer_write_summary(lib, out, us, unit_mask=include, insert_mean=ins["mean"], insert_sd=ins["sd"])
+    summ = (out / "summaryStatistics.txt").read_text()
+    assert "Total number (paired) alignments:                 %d\n" % include.sum() in summ and "(unpaired) alignments:                 0\n" in summ
+    res = L.write_files(out, e, names, names, pair_ll, mis_avg, mis_min, call["order"], call["p_normalized"], co, kmers_covered=kc, params=prm,
+                        unit_stats=us, unit_mask=include, insert_mean=ins["mean"], insert_sd=ins["sd"])
     pkg.typer_end_output(lib, out, ["A"])
+    hist = (out / "histogram_matchesPerRead.txt").read_text().splitlines()
+    assert hist[0] == "Locus\tLevelValue" and sum(l.startswith("A\treadPair") for l in hist) == e["n_pairs_ok"] and sum(l.startswith("A\tbase") for l in hist) == res.n_piled_positions
     rows = [r.split("\t") for r in (out / "R1_bestguess.txt").read_text().splitlines()]
     assert len(rows) == 3 and {rows[1][2], rows[2][2]} == {L.cluster_id(c) for c in want} and rows[1][0] == "A" and rows[1][1] == "1" and rows[2][1] == "2"
     assert float(rows[1][5]) > 10 and res.locus_coverage > 10 and res.minimum_coverage > 0 and res.avg_column_error < 0.02
@@ -182,10 +201,13 @@ def test_cpp_host_mirror_from_files_to_result_files(pkg, tmp_path):
     out_py = tmp_path / "out_py"
     pkg.typer_begin_output(lib, out_py)
     co = pkg.CallOut(call["first_cluster"], call["second_cluster"], call["first_marginal"], call["second_p"], call["ll_max"], call["max_pair"], call["n_sort_ties"])
-    L.write_files(out_py, e, names, names, pair_ll, mis_avg, mis_min, call["order"], call["p_normalized"], co, kmers_covered=kc, params=prm)
+    us = gb.unit_stats()
+    pkg.typer_write_summary(lib, out_py, us, unit_mask=include, insert_mean=ins["mean"], insert_sd=ins["sd"])
+    L.write_files(out_py, e, names, names, pair_ll, mis_avg, mis_min, call["order"], call["p_normalized"], co, kmers_covered=kc, params=prm,
+                  unit_stats=us, unit_mask=include, insert_mean=ins["mean"], insert_sd=ins["sd"])
     pkg.typer_end_output(lib, out_py, ["A"])
     files = sorted(os.listdir(out_py))
-    assert files == sorted(os.listdir(out_cpp)) and "R1_bestguess.txt" in files and len(files) == 7
+    assert files == sorted(os.listdir(out_cpp)) and "R1_bestguess.txt" in files and "summaryStatistics.txt" in files and len(files) == 9
     for fn in files:
         assert (out_py / fn).read_bytes() == (out_cpp / fn).read_bytes(), fn
     assert ("insert size %.3f %.3f pairs 700" % (ins["mean"], ins["sd"])) in r.stdout

@@ -334,3 +334,93 @@ def test_kmer_presence_matches_a_hash_of_all_read_kmers(pkg):
             assert want.sum() > 50 and (k < 10 or (want == 0).sum() > 50)
     with pytest.raises(pkg.HlalaError):
         ctx.kmer_presence(gb, ["A" * 32], 32)
+
+
+def synth_unit_stats(rng, n):
+    f = np.where(rng.random(2 * n) < 0.4, 1.0, np.round(1 - rng.random(2 * n) * 0.1, 4))
+    return dict(valid=(rng.random(n) < 0.95).astype(np.uint8), strands_valid=(rng.random(n) < 0.9).astype(np.uint8), distance=rng.integers(-100, 600, n).astype(np.int32),
+                fraction_ok=f, weighted_ok=np.round(1 - rng.random(2 * n) * 0.05, 5), n_columns=rng.integers(140, 2000, 2 * n).astype(np.int32), mate_mapq=np.round(rng.random(2 * n), 3))
+
+
+@pytest.mark.parametrize("unpaired", [False, True])
+def test_summary_statistics_file(pkg, tmp_path, unpaired):
+    """summaryStatistics.txt against hla/HLATyper.cpp:1030-1125 written out in Python."""
+    rng = np.random.default_rng(31); n = 500
+    st = synth_unit_stats(rng, n); mask = (rng.random(n) < 0.8).astype(np.uint8)
+    lib = C.CDLL(pkg.LIB_PATH)
+    out = tmp_path / "o"
+    pkg.typer_write_summary(lib, out, st, unpaired=unpaired, unit_mask=mask, insert_mean=210.5, insert_sd=30.25)
+    units = [u for u in range(n) if mask[u] and st["valid"][u]]
+    if not unpaired:
+        sv = [u for u in units if st["strands_valid"][u]]
+        dist = sorted(float(st["distance"][u]) for u in sv)
+        ok = sum(1 for u in sv if abs(float(st["distance"][u]) - 210.5) <= 5 * 30.25)
+        S = 0.0
+        for u in units:
+            S += st["fraction_ok"][2 * u]; S += st["fraction_ok"][2 * u + 1]
+        perfect = sum(int(st["fraction_ok"][2 * u] == 1) + int(st["fraction_ok"][2 * u + 1] == 1) for u in units)
+        one = sum(1 for u in units if st["fraction_ok"][2 * u] == 1 or st["fraction_ok"][2 * u + 1] == 1)
+        s = 0.0
+        for d in dist:
+            s += d
+        exp = ("\nRead alignment statistics:\n\t - Total number (paired) alignments:                 %d\n" % len(units) +
+               "\t\t - Alignment pairs with strands OK:                  %d (%s%%)\n" % (len(sv), g(len(sv) / len(units) * 100)) +
+               "\t\t - Alignment pairs with strands OK && distance OK:   %d (%s%%)\n" % (ok, g(ok / len(units) * 100)) +
+               "\t\t - Alignment pairs with strands OK, mean distance:   %s\n" % g(s / len(dist)) +
+               "\t\t - Alignment pairs with strands OK, median distance: %s\n" % g(dist[len(dist) // 2]) +
+               "\t\t - Alignment pairs, average fraction alignment OK:   %s\n" % g(S / (2.0 * len(units))) +
+               "\t\t - Alignment pairs, at least one alignment perfect:   %d\n" % one +
+               "\t\t - Single alignments, perfect (total):   %d (%d)\n" % (perfect, 2 * len(units)) +
+               "\t - Total number (unpaired) alignments:                 0\n\t\t - Alignment pairs, average fraction alignment OK:   0\n"
+               "\t\t - Single alignments, perfect (total):   0 (0)\n\t\t - Alignments with length >= 1000:   0\n")
+    else:
+        S = 0.0
+        for u in units:
+            S += st["fraction_ok"][2 * u]
+        exp = ("\nRead alignment statistics:\n\t - Total number (paired) alignments:                 0\n"
+               "\t\t - Alignment pairs with strands OK:                  0 (%s%%)\n\t\t - Alignment pairs with strands OK && distance OK:   0 (%s%%)\n" % ("-nan", "-nan") +
+               "\t\t - Alignment pairs with strands OK, mean distance:   0\n\t\t - Alignment pairs with strands OK, median distance: 0\n"
+               "\t\t - Alignment pairs, average fraction alignment OK:   0\n\t\t - Alignment pairs, at least one alignment perfect:   0\n"
+               "\t\t - Single alignments, perfect (total):   0 (0)\n" +
+               "\t - Total number (unpaired) alignments:                 %d\n" % len(units) +
+               "\t\t - Alignment pairs, average fraction alignment OK:   %s\n" % g(S / len(units)) +
+               "\t\t - Single alignments, perfect (total):   %d (%d)\n" % (sum(1 for u in units if st["fraction_ok"][2 * u] == 1), 2 * len(units)) +
+               "\t\t - Alignments with length >= 1000:   %d\n" % sum(1 for u in units if st["n_columns"][2 * u] >= 1000))
+    got = (out / "summaryStatistics.txt").read_text()
+    assert got.replace("(nan%)", "(-nan%)") == exp          # 0/0 * 100 prints as the C library prints it (sign of the NaN is platform detail)
+
+
+def test_histogram_lines(pkg, oracle, tmp_path):
+    """histogram_matchesPerRead.txt: "read" / "readPair" lines of the pairs passing the pair test of the locus, then a "base" line per piled position."""
+    rng = np.random.default_rng(41)
+    make_graph_dir(tmp_path, rng)
+    lib = C.CDLL(pkg.LIB_PATH)
+    T = pkg.Typer(lib, tmp_path); L = T.locus("A")
+    n_units = 900; n_reads = 300
+    e = synth_positions(rng, n_reads, L.n_columns)
+    e["read_pair"] = np.sort(rng.choice(n_units, n_reads, replace=False)).astype(np.int32)
+    e["read_reverse"] = (rng.random(2 * n_reads) < 0.4).astype(np.uint8); e["read_mapq"] = np.round(rng.random(2 * n_reads), 3)
+    st = synth_unit_stats(rng, n_units); mask = (rng.random(n_units) < 0.7).astype(np.uint8)
+    prm = pkg.default_filter_params()
+    use, ign, fs = ob.filter_positions(e, prm)
+    Cn = L.n_clusters; nP = Cn * (Cn + 1) // 2
+    ll = -np.round(rng.random(nP) * 300, 2); ma = np.round(rng.random(nP) * 3, 3); mm = np.floor(rng.random(nP) * 4)
+    call = ob.call_locus(ll, ma, mm)
+    co = pkg.CallOut(call["first_cluster"], call["second_cluster"], call["first_marginal"], call["second_p"], call["ll_max"], call["max_pair"], call["n_sort_ties"])
+    names = ["u%04d" % i for i in range(n_units)]
+    out = tmp_path / "out"; pkg.typer_begin_output(lib, out)
+    kw = dict(insert_mean=250.0, insert_sd=40.0, min_mapq=0.2, min_weighted_ok=0.96)
+    L.write_files(out, e, names, names, ll, ma, mm, call["order"], call["p_normalized"], co, params=prm, unit_stats=st, unit_mask=mask, **kw)
+    exp = ["Locus\tLevelValue"]
+    for u in range(n_units):
+        if not mask[u] or not st["valid"][u]:
+            continue
+        w1, w2 = st["weighted_ok"][2 * u], st["weighted_ok"][2 * u + 1]
+        if st["strands_valid"][u] and abs(float(st["distance"][u]) - 250.0) <= 5 * 40.0 and st["mate_mapq"][2 * u] >= 0.2 and w1 >= 0.96 and w2 >= 0.96:
+            exp += ["A\tread" + g(w1), "A\tread" + g(w2), "A\treadPair" + g((w1 + w2) / 2.0)]
+    for r in range(n_reads):
+        for j in range(e["pos_off"][r], e["pos_off"][r + 1]):
+            if use[j]:
+                exp.append("A\tbase" + g(e["read_weighted_ok"][2 * r + (1 if e["pos_mate"][j] == 2 else 0)]))
+    got = (out / "histogram_matchesPerRead.txt").read_text().splitlines()
+    assert got == exp and len(exp) > 1000
