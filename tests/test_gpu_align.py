@@ -81,6 +81,24 @@ def test_filters_and_cigar_variety(pkg, oracle):
     assert stt.n_dp_shared > 100 and (stt.n_dp_calls, stt.n_dp_iterations, stt.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
 
 
+@pytest.mark.parametrize("k,seed", [(0, 51), (2, 52)], ids=["k0-ties", "k2"])
+def test_shared_dps_with_random_end_cells(pkg, oracle, k, seed):
+    """Chains of a read that start their DP from the same cell share its iterations, but each draws its end cell with its own seed
+    (extensionAligner.cpp:1427-1472): identical haplotypes make every secondary such a chain, the gap-heavy k = 0 graph makes equal
+    end cells (and with them the draw) frequent, so a wrong seed or a copied end cell would show up in the columns."""
+    w = synth.make_world(seed=seed, G=6000, k=k, extra_identical=3, n_largegap=2)
+    b = synth.make_batch(w, 250, seed=seed + 1, p_secondary=1.0, max_secondary=6, p_random_secondary=0.0, clip_max=45)
+    exp, gb, ctx = run_both(pkg, oracle, w, b)
+    compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="shared DPs")
+    assert_pairs_equal(gb.pairs(), exp["pairs"])
+    st = gb.stats()
+    assert st.n_dp_shared > 300 and (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
+    # different seeds, different draws: the batch is not insensitive to the seed (so the per-chain seeds above were really used)
+    exp2 = oracle(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=4242, max_columns=384).align_batch(b)
+    if k == 0:
+        assert not np.array_equal(exp2["ext"]["col_level"], exp["ext"]["col_level"])
+
+
 def test_chain_extension_protocol(pkg, oracle):
     """`--action testChainExtension` (HLA-LA.cpp:1733-1861): 10 bases stripped from both ends, extended chain must re-spell the read."""
     from test_oracle_properties import _clip_batch
