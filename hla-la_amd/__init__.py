@@ -289,6 +289,11 @@ class LocusInfo(C.Structure):
                 ("cluster_seq", c_u8p), ("level_to_exon", c_i32p), ("col_level", c_i32p), ("col_exon", c_i32p), ("col_exon_pos", c_i32p), ("exon_length", c_i32p)]
 
 
+class PairsPackedOut(C.Structure):
+    _fields_ = [("cap_cols", C.c_int64), ("n_cols_total", C.c_int64), ("col_off", c_i64p), ("col_level", c_i32p), ("col_edge", c_i32p), ("col_gchar", c_u8p),
+                ("col_schar", c_u8p), ("col_fromseed", c_u8p), ("col_mapq", c_u8p)]
+
+
 class UnitStatsOut(C.Structure):
     _fields_ = [("valid", c_u8p), ("strands_valid", c_u8p), ("distance", c_i32p), ("fraction_ok", c_f64p), ("weighted_ok", c_f64p), ("n_columns", c_i32p), ("mate_mapq", c_f64p)]
 
@@ -582,7 +587,7 @@ EXPORTED_SYMBOLS = [
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
     "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
-    "hlala_batch_get_stats", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
+    "hlala_batch_get_stats", "hlala_batch_get_pairs_packed", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
     "hlala_kat_rand_r", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
     "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
     "hlala_bam_extract_seeds", "hlala_seed_batch_desc", "hlala_seed_batch_name", "hlala_seed_batch_free", "hlala_bam_last_error",
@@ -647,7 +652,8 @@ class Context:
         s, keep = fill_struct(BatchIn, batch_in)
         b = C.c_void_p()
         self._check(self.lib.hlala_batch_create_unpaired(self.h, C.byref(s), C.byref(b)), "hlala_batch_create_unpaired")
-        return Batch(self, b, batch_in["n_chains"], batch_in["n_pairs"])
+        bt = Batch(self, b, batch_in["n_chains"], batch_in["n_pairs"]); bt.unpaired = True
+        return bt
 
     def batch_from_seeds(self, seeds_in: dict) -> "Batch":
         s, keep = fill_struct(SeedsIn, seeds_in)
@@ -763,6 +769,26 @@ class Batch:
         inc = np.zeros(self.n_pairs, np.uint8)
         self.ctx._check(self.ctx.lib.hlala_postprocess_pairs(self.ctx.h, self.b, inc.ctypes.data_as(c_u8p)), "hlala_postprocess_pairs")
         return inc
+
+    def pairs_packed(self):
+        """hlala_batch_get_pairs_packed: the columns of the selected alignments without padding (col_off + concatenated arrays)."""
+        nr = self.n_pairs * (1 if getattr(self, "unpaired", False) else 2)
+        off = np.zeros(nr + 1, np.int64)
+        o = PairsPackedOut(); o.cap_cols = 0; o.col_off = off.ctypes.data_as(c_i64p)
+        self.ctx.lib.hlala_batch_get_pairs_packed.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PairsPackedOut)]
+        rc = self.ctx.lib.hlala_batch_get_pairs_packed(self.ctx.h, self.b, C.byref(o))          # sizing call
+        if rc not in (0, -4):
+            self.ctx._check(rc, "hlala_batch_get_pairs_packed")
+        T = int(o.n_cols_total)
+        d = dict(col_level=np.zeros(T, np.int32), col_edge=np.zeros(T, np.int32), col_gchar=np.zeros(T, np.uint8), col_schar=np.zeros(T, np.uint8),
+                 col_fromseed=np.zeros(T, np.uint8), col_mapq=np.zeros(T, np.uint8))
+        o.cap_cols = T
+        types = dict(PairsPackedOut._fields_)
+        for k, v in d.items():
+            setattr(o, k, v.ctypes.data_as(types[k]))
+        self.ctx._check(self.ctx.lib.hlala_batch_get_pairs_packed(self.ctx.h, self.b, C.byref(o)), "hlala_batch_get_pairs_packed")
+        d["col_off"] = off; d["n_cols_total"] = T
+        return d
 
     def unit_stats(self):
         """hlala_unit_alignment_stats: per pair / read strands, distance, fraction OK, weighted OK, columns and mapping qualities."""

@@ -630,7 +630,7 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
     if(wantCols && nr > 0) {
         const size_t CH = nr < 65536 ? nr : 65536;
         std::vector<void*> tmp;
-        auto done = [&](int r_) { for(void* p : tmp) if(p) (void)hipFree(p); return r_; };
+        auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
         int* dN = nullptr; int* dL = nullptr; int* dE = nullptr; uint8_t* dG = nullptr; uint8_t* dS = nullptr; uint8_t* dF = nullptr;
         if((rc = dev_alloc(c, tmp, CH, &dN, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dL, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dE, false)) ||
            (rc = dev_alloc(c, tmp, CH * stride, &dG, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dS, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dF, false))) return done(rc);
@@ -652,6 +652,45 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
         done(0);
     }
     return HLALA_OK;
+}
+
+int hlala_batch_get_pairs_packed(hlala_ctx* c, hlala_batch* b, hlala_pairs_packed_out* o)
+{
+    if(!c || !b || !o || !o->col_off) return HLALA_E_ARG;
+    if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
+    DevBatch& B = b->B;
+    const size_t nr = (size_t)B.n_reads;
+    o->n_cols_total = 0;
+    if(nr == 0) { o->col_off[0] = 0; return HLALA_OK; }
+    std::vector<void*> tmp;
+    auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
+    int rc = 0; long long *dN = nullptr, *dOff = nullptr; char* dCub = nullptr;
+    if((rc = dev_alloc(c, tmp, nr + 1, &dN)) || (rc = dev_alloc(c, tmp, nr + 1, &dOff))) return done(rc);
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(k_selected_ncols, dim3((unsigned)((nr + 1 + 255) / 256)), dim3(256), 0, st, b->dB, (int)nr, dN);
+    if((rc = check_launch(c, "k_selected_ncols"))) return done(rc);
+    size_t cubBytes = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, cubBytes, dN, dOff, (int)(nr + 1), st));
+    if((rc = dev_alloc(c, tmp, cubBytes ? cubBytes : 1, &dCub))) return done(rc);
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(dCub, cubBytes, dN, dOff, (int)(nr + 1), st));
+    long long total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, dOff + nr, sizeof(total), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    o->n_cols_total = total;
+    { std::vector<long long> ho(nr + 1); if((rc = dl(c, ho.data(), dOff, nr + 1))) return done(rc); HIP_TRY(c, hipStreamSynchronize(st)); for(size_t i = 0; i <= nr; i++) o->col_off[i] = ho[i]; }
+    if(total > o->cap_cols) { c->err = "hlala_batch_get_pairs_packed: cap_cols too small (n_cols_total holds the need)"; return done(HLALA_E_CAPACITY); }
+    if(total == 0) return done(HLALA_OK);
+    int *dL = nullptr, *dE = nullptr; uint8_t *dG = nullptr, *dS = nullptr, *dF = nullptr, *dQ = nullptr;
+    const size_t T = (size_t)total;
+    if((o->col_level && (rc = dev_alloc(c, tmp, T, &dL))) || (o->col_edge && (rc = dev_alloc(c, tmp, T, &dE))) || (o->col_gchar && (rc = dev_alloc(c, tmp, T, &dG))) ||
+       (o->col_schar && (rc = dev_alloc(c, tmp, T, &dS))) || (o->col_fromseed && (rc = dev_alloc(c, tmp, T, &dF))) || (o->col_mapq && (rc = dev_alloc(c, tmp, T, &dQ)))) return done(rc);
+    const unsigned grid = (unsigned)std::min<size_t>(nr, (size_t)c->stitch_grid * 4);
+    hipLaunchKernelGGL(k_gather_packed, dim3(grid), dim3(64), 0, st, b->dB, (int)nr, (const long long*)dOff, dL, dE, dG, dS, dF, dQ);
+    if((rc = check_launch(c, "k_gather_packed"))) return done(rc);
+    if((rc = dl(c, o->col_level, dL, T)) || (rc = dl(c, o->col_edge, dE, T)) || (rc = dl(c, o->col_gchar, dG, T)) || (rc = dl(c, o->col_schar, dS, T)) ||
+       (rc = dl(c, o->col_fromseed, dF, T)) || (rc = dl(c, o->col_mapq, dQ, T))) return done(rc);
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return done(HLALA_OK);
 }
 
 int hlala_estimate_insert_size(hlala_ctx* c, const hlala_batch_in* in, hlala_insert_size_out* out)
@@ -734,7 +773,7 @@ int hlala_postprocess_pairs(hlala_ctx* c, hlala_batch* b, uint8_t* include_in_hl
     }
     if(B.n_pairs <= 0) return HLALA_OK;
     uint8_t* dInc = nullptr; std::vector<void*> tmp;
-    auto done = [&](int r_) { for(void* p : tmp) if(p) (void)hipFree(p); return r_; };
+    auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
     if(include_in_hla) { int rc = dev_alloc(c, tmp, (size_t)B.n_pairs, &dInc, false); if(rc) return done(rc); }
     hipError_t e = hipMemsetAsync(B.work_counter + 11, 0, sizeof(int), c->stream);
     if(e != hipSuccess) { c->err = hipGetErrorString(e); return done(HLALA_E_DEVICE); }
@@ -817,7 +856,7 @@ extern "C" int hlala_exon_loglik(hlala_ctx* c, const hlala_exon_in* in, double* 
     const size_t npos = (size_t)in->pos_off[R];
     for(size_t i = 0; i < npos; i++) if(in->pos_exon[i] < 0 || in->pos_exon[i] >= P || in->pos_glen[i] < 1) { c->err = "exon position out of range / empty genotype"; return HLALA_E_ARG; }
     std::vector<void*> tmp; int rc = 0;
-    auto done = [&](int r) { for(void* p : tmp) (void)hipFree(p); return r; };
+    auto done = [&](int r) { for(void* p : tmp) pool_release(c, p); return r; };
     TyperTables* dT = nullptr; if((rc = typer_tables(c, tmp, &dT))) return done(rc);
     // cluster sequences transposed to [P][C] on the host side of the upload (one-time per locus)
     std::vector<uint8_t> seqT((size_t)C * P);
@@ -844,7 +883,7 @@ extern "C" int hlala_pair_loglik(hlala_ctx* c, const double* LL, const int32_t* 
     if(!c || !LL || !mism || !pairLL || !misAvg || !misMin || C < 0 || R < 0) return HLALA_E_ARG;
     if(C == 0) return HLALA_OK;
     std::vector<void*> tmp; int rc = 0;
-    auto done = [&](int r) { for(void* p : tmp) (void)hipFree(p); return r; };
+    auto done = [&](int r) { for(void* p : tmp) pool_release(c, p); return r; };
     const size_t npairs = (size_t)C * (C + 1) / 2, nCR = (size_t)C * R;
     double *dLL, *dLLT, *dP, *dA, *dMn; int *dM, *dMT;
     if((rc = dev_upload(c, tmp, LL, nCR, &dLL))) return done(rc);
@@ -898,7 +937,7 @@ extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uin
         hipLaunchKernelGGL(k_kat_phred, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dT, n, dp, dq);
         HIP_TRY(c, hipMemcpyAsync(phred_out, dq, (size_t)n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        for(void* p : tmp) (void)hipFree(p);
+        for(void* p : tmp) pool_release(c, p);
     }
     if(phred_in && p_out) {
         // PhredToPCorrect feeds the host-built likelihood tables: report the table entries' pre-image
@@ -1078,7 +1117,7 @@ extern "C" int hlala_abi_sizeof(const char* name)
     const std::string n(name);
 #define SZ(t) if(n == #t) return (int)sizeof(t);
     SZ(hlala_graph_desc) SZ(hlala_contigs_desc) SZ(hlala_params) SZ(hlala_graph_info) SZ(hlala_batch_in) SZ(hlala_seeds_in)
-    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats) SZ(hlala_insert_size_out) SZ(hlala_locus_info) SZ(hlala_locus_report_in) SZ(hlala_locus_report_out) SZ(hlala_unit_stats_out)
+    SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats) SZ(hlala_insert_size_out) SZ(hlala_locus_info) SZ(hlala_locus_report_in) SZ(hlala_locus_report_out) SZ(hlala_unit_stats_out) SZ(hlala_pairs_packed_out)
 #undef SZ
     return -1;
 }
@@ -1094,6 +1133,6 @@ extern "C" int hlala_kat_rand_r(hlala_ctx* c, int n, uint32_t* seeds_inout, int3
     HIP_TRY(c, hipMemcpyAsync(seeds_inout, ds, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(values_out, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for(void* p : tmp) (void)hipFree(p);
+    for(void* p : tmp) pool_release(c, p);
     return HLALA_OK;
 }

@@ -338,6 +338,35 @@ __global__ void k_gather_selected(const DevBatch* __restrict__ Bp, int r0, int n
     }
 }
 
+// packed export of the selected alignments: column counts per read, then one block per read copies its columns to its offset
+__global__ void k_selected_ncols(const DevBatch* __restrict__ Bp, int nReads, long long* __restrict__ n)
+{
+    const DevBatch& B = *Bp;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if(r > nReads) return;
+    long long v = 0;
+    if(r < nReads) { const int ch = B.best_chain[r]; if(ch >= 0 && ch < B.n_chains) { const int c = B.ext_ncols[ch]; if(c > 0) v = c; } }
+    n[r] = v;
+}
+__global__ void k_gather_packed(const DevBatch* __restrict__ Bp, int nReads, const long long* __restrict__ off, int* __restrict__ oLevel, int* __restrict__ oEdge,
+                                uint8_t* __restrict__ oG, uint8_t* __restrict__ oS, uint8_t* __restrict__ oFs, uint8_t* __restrict__ oMq)
+{
+    const DevBatch& B = *Bp;
+    for(int r = blockIdx.x; r < nReads; r += gridDim.x) {
+        const long long d0 = off[r]; const int n = (int)(off[r + 1] - d0);
+        if(n <= 0) continue;
+        const size_t so = (size_t)B.best_chain[r] * B.stride, mo = (size_t)r * B.stride;
+        for(int j = threadIdx.x; j < n; j += blockDim.x) {
+            if(oLevel) oLevel[d0 + j] = B.ext_level[so + j];
+            if(oEdge) oEdge[d0 + j] = B.ext_edge[so + j];
+            if(oG) oG[d0 + j] = B.ext_g[so + j];
+            if(oS) oS[d0 + j] = B.ext_s[so + j];
+            if(oFs) oFs[d0 + j] = B.ext_fromseed[so + j];
+            if(oMq) oMq[d0 + j] = B.sel_mapq[mo + j];
+        }
+    }
+}
+
 __global__ void k_export_pairs(const DevBatch* __restrict__ Bp, double* out)
 {
     const DevBatch& B = *Bp;

@@ -227,6 +227,23 @@ int  hlala_align_batch(hlala_ctx* ctx, hlala_batch* b);
 int  hlala_batch_get_chains(hlala_ctx* ctx, hlala_batch* b, int stage, hlala_chains_out* out);
 int  hlala_batch_get_pairs(hlala_ctx* ctx, hlala_batch* b, hlala_pairs_out* out);
 
+/* The same columns without the padding: the selected alignments are 150-odd columns long, the rows above max_columns (384).  Columns of
+ * read r (mate m of pair p: r = 2p + m; unpaired batches: r = p) sit at [col_off[r], col_off[r+1]) of every col_* array; 2.6 times
+ * less data over PCIe for 2x150 bp reads.  Per-pair scalars: hlala_batch_get_pairs with NULL column pointers.  Returns HLALA_E_CAPACITY
+ * with n_cols_total set when cap_cols is too small (call once with cap_cols = 0 to size the arrays). */
+typedef struct {
+    int64_t  cap_cols;       /* in: capacity of the col_* arrays                         */
+    int64_t  n_cols_total;   /* out: columns of all selected alignments                  */
+    int64_t* col_off;        /* [n_reads + 1]                                            */
+    int32_t* col_level;      /* any of the col_* pointers may be NULL                    */
+    int32_t* col_edge;
+    uint8_t* col_gchar;
+    uint8_t* col_schar;
+    uint8_t* col_fromseed;
+    uint8_t* col_mapq;
+} hlala_pairs_packed_out;
+int  hlala_batch_get_pairs_packed(hlala_ctx* ctx, hlala_batch* b, hlala_pairs_packed_out* out);
+
 /* Device-to-device export of one fixed-size record per pair (8 doubles: pair_status, best_chain[0], best_chain[1],
  * n_combinations, pair_ll, pair_mapq, mate_mapq[0], mate_mapq[1]) into a caller-owned DEVICE buffer of
  * 8 * n_pairs doubles -- the payload of the multi-GPU gather of per-pair best-path records to rank 0

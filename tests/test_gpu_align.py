@@ -211,3 +211,25 @@ def test_full_size_properties(pkg, oracle):
     assert np.array_equal(p1["n_combinations"][sl], exp["n_combinations"])
     assert np.allclose(p1["pair_ll"][sl], exp["pair_ll"], rtol=1e-12, atol=0)
     assert np.array_equal(p1["col_mapq"][2 * p0 * stride: 2 * (p0 + sub["n_pairs"]) * stride], exp["col_mapq"])
+
+
+def test_packed_pairs_equal_the_padded_rows(pkg):
+    """hlala_batch_get_pairs_packed: the same columns as hlala_batch_get_pairs, without the padding."""
+    w = synth.make_world(seed=9, G=5000, k=1)
+    b = synth.make_batch(w, 300, seed=19)
+    ctx = pkg.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=1)
+    gb = ctx.batch(b); gb.align()
+    full = gb.pairs(); pk = gb.pairs_packed(); st = ctx.max_columns
+    assert np.array_equal(np.diff(pk["col_off"]), full["n_cols"]) and pk["n_cols_total"] == full["n_cols"].sum() > 50000
+    for r in range(600):
+        a, z = pk["col_off"][r], pk["col_off"][r + 1]
+        for k in ("col_level", "col_edge", "col_gchar", "col_schar", "col_fromseed", "col_mapq"):
+            assert np.array_equal(pk[k][a:z], full[k][r * st:r * st + (z - a)]), (k, r)
+    u = synth.as_unpaired(synth.make_batch(w, 100, seed=20))
+    cu = pkg.Context(w["graph"], w["contigs"], insert_mean=200.0, insert_sd=35.0, rng_seed=1, long_read_mode=1)
+    gu = cu.batch_unpaired(u); gu.align()
+    fu = gu.pairs(); pu = gu.pairs_packed(); n = u["n_pairs"]
+    assert np.array_equal(np.diff(pu["col_off"])[:n], np.asarray(fu["n_cols"])[:n])
+    for r in range(0, n, 7):
+        a, z = pu["col_off"][r], pu["col_off"][r + 1]
+        assert np.array_equal(pu["col_level"][a:z], fu["col_level"][r * st:r * st + (z - a)]) and np.array_equal(pu["col_mapq"][a:z], fu["col_mapq"][r * st:r * st + (z - a)])

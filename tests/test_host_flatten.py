@@ -82,7 +82,7 @@ def test_ctypes_mirror_matches_the_compiled_struct_layout(pkg):
               "hlala_chains_out": pkg.ChainsOut, "hlala_pairs_out": pkg.PairsOut, "hlala_batch_stats": pkg.BatchStats,
               "hlala_exon_in": pkg.ExonIn, "hlala_call_out": pkg.CallOut, "hlala_locus_desc": pkg.LocusDesc,
               "hlala_exon_positions_out": pkg.ExonPositionsOut, "hlala_filter_params": pkg.FilterParams, "hlala_filter_stats": pkg.FilterStats, "hlala_insert_size_out": pkg.InsertSizeOut,
-              "hlala_locus_info": pkg.LocusInfo, "hlala_locus_report_in": pkg.LocusReportIn, "hlala_locus_report_out": pkg.LocusReportOut, "hlala_unit_stats_out": pkg.UnitStatsOut}
+              "hlala_locus_info": pkg.LocusInfo, "hlala_locus_report_in": pkg.LocusReportIn, "hlala_locus_report_out": pkg.LocusReportOut, "hlala_unit_stats_out": pkg.UnitStatsOut, "hlala_pairs_packed_out": pkg.PairsPackedOut}
     for name, cls in mirror.items():
         assert lib.hlala_abi_sizeof(name.encode()) == C.sizeof(cls), name
     assert lib.hlala_abi_sizeof(b"no_such_struct") == -1

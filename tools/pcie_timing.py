@@ -14,3 +14,8 @@ for it in range(3):
     up = sum(v.nbytes for v in b.values() if hasattr(v, 'nbytes')); dn = sum(v.nbytes for v in pr.values() if hasattr(v, 'nbytes'))
     print('run %d: create+upload %.1f ms (%.2f GB), align %.1f ms, get_pairs %.1f ms (%.2f GB) -> %.0f pairs/s host-buffer inclusive' % (it, (t1-t0)*1e3, up/1e9, (t2-t1)*1e3, (t3-t2)*1e3, dn/1e9, n_pairs/(t3-t0)))
     del gb
+for it in range(3):      # the same with the packed download (columns without padding) + the per-pair scalars
+    t0 = time.perf_counter(); gb = ctx.batch(b); t1 = time.perf_counter(); gb.align(); st = gb.stats(); t2 = time.perf_counter(); pk = gb.pairs_packed(); t3 = time.perf_counter()
+    dn = sum(v.nbytes for v in pk.values() if hasattr(v, 'nbytes'))
+    print('packed %d: create+upload %.1f ms, align %.1f ms, get_pairs_packed %.1f ms (%.2f GB) -> %.0f pairs/s host-buffer inclusive' % (it, (t1-t0)*1e3, (t2-t1)*1e3, (t3-t2)*1e3, dn/1e9, n_pairs/(t3-t0)))
+    del gb
