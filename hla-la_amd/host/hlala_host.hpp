@@ -161,16 +161,27 @@ public:
         int rc = hlala_align_batch(ctx_, b);
         std::vector<reads::verboseSeedChainPair> out;
         if(rc == HLALA_OK) {
-            int n = (int)seeds.size(), st = params_.max_columns; size_t n2 = 2 * (size_t)n;
-            std::vector<int32_t> status(n), best(n2), ncomb(n), ncols(n2), lev(n2 * st), edg(n2 * st); std::vector<double> ll(n), mq(n), mmq(n2);
-            std::vector<uint8_t> sv(n), g(n2 * st), s(n2 * st), fs(n2 * st), pq(n2 * st);
-            hlala_pairs_out po{status.data(), best.data(), ncomb.data(), ll.data(), mq.data(), mmq.data(), sv.data(), ncols.data(), lev.data(), edg.data(), g.data(), s.data(), fs.data(), pq.data()};
+            // per-pair scalars from hlala_batch_get_pairs (no column pointers), the columns without padding from hlala_batch_get_pairs_packed
+            int n = (int)seeds.size(); size_t n2 = 2 * (size_t)n;
+            std::vector<int32_t> status(n), best(n2), ncomb(n); std::vector<double> ll(n), mq(n), mmq(n2); std::vector<uint8_t> sv(n);
+            hlala_pairs_out po{status.data(), best.data(), ncomb.data(), ll.data(), mq.data(), mmq.data(), sv.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             rc = hlala_batch_get_pairs(ctx_, b, &po);
+            std::vector<int64_t> off(n2 + 1); std::vector<int32_t> lev, edg; std::vector<uint8_t> g, s, fs, pq;
+            if(rc == HLALA_OK) {
+                hlala_pairs_packed_out pk{}; pk.col_off = off.data(); pk.cap_cols = 0;
+                rc = hlala_batch_get_pairs_packed(ctx_, b, &pk);                          // sizing call
+                if(rc == HLALA_E_CAPACITY || rc == HLALA_OK) {
+                    const size_t T = (size_t)pk.n_cols_total;
+                    lev.resize(T + 1); edg.resize(T + 1); g.resize(T + 1); s.resize(T + 1); fs.resize(T + 1); pq.resize(T + 1);
+                    pk.cap_cols = pk.n_cols_total; pk.col_level = lev.data(); pk.col_edge = edg.data(); pk.col_gchar = g.data(); pk.col_schar = s.data(); pk.col_fromseed = fs.data(); pk.col_mapq = pq.data();
+                    rc = hlala_batch_get_pairs_packed(ctx_, b, &pk);
+                }
+            }
             for(int p = 0; rc == HLALA_OK && p < n; p++) {
                 if(status[p] != 0) { hlala_batch_destroy(b); throw std::runtime_error("alignOneReadPair: a chain of pair " + seeds[p].readID + " exceeded a device capacity"); }
                 reads::verboseSeedChainPair vp; vp.readID = seeds[p].readID; vp.mapQ = mq[p];
                 for(int m = 0; m < 2; m++) {
-                    reads::verboseSeedChain& c = m ? vp.chains.second : vp.chains.first; size_t r = 2 * (size_t)p + m, o = r * st; int k = ncols[r];
+                    reads::verboseSeedChain& c = m ? vp.chains.second : vp.chains.first; size_t r = 2 * (size_t)p + m, o = (size_t)off[r]; size_t k = (size_t)(off[r + 1] - off[r]);
                     c.graph_aligned_levels.assign(lev.begin() + o, lev.begin() + o + k); c.graph_aligned_edges.assign(edg.begin() + o, edg.begin() + o + k);
                     c.graph_aligned.assign(g.begin() + o, g.begin() + o + k); c.sequence_aligned.assign(s.begin() + o, s.begin() + o + k);
                     c.mapQ_perPosition.assign(pq.begin() + o, pq.begin() + o + k); c.is_from_BWAseed.assign(fs.begin() + o, fs.begin() + o + k);
