@@ -115,6 +115,42 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v)
     return ((u64)(~((u32)mh ^ 0x80000000u)) << 32) | (u64)(~((u32)ml ^ 0x80000000u));
 }
 // exclusive prefix sum over the wave; returns the lane's offset, `total` is wave-uniform
+// exp(x) for x <= 0, correctly rounded (double-double evaluation: ln2 in three exact pieces, 24 Taylor terms with double-double
+// coefficients 1/k!).  The posteriors of the pairing step decide integer outputs at the p == 1 boundary (PCorrectToPhred, Utilities.cpp:178-203):
+// the host's libm returns the correctly rounded exponential in all but rare cases, the device library's exp is off by an ulp in one call of
+// ten.  Arguments below -700 (results near the subnormal range, irrelevant to a normalised posterior) take the library exp.
+__device__ inline double exp_cr_nonpos(double x)
+{
+#pragma clang fp contract(off)      // the error-free transformations below must not be fused behind their back
+    if(!(x < 0.0)) return 1.0;
+    if(x < -700.0) return exp(x);
+    const double n = rint(x * 0x1.71547652b82fep+0);
+    // r = x - n ln2, exact in the first two steps (n has 11 bits, the pieces 32)
+    const double r0 = fma(-n, 0x1.62e42fee00000p-1, x);
+    const double t1 = n * 0x1.a39ef35600000p-33;                    // exact
+    double rh = r0 - t1; double bb = rh - r0; double rl = (r0 - (rh - bb)) + (-t1 - bb);
+    const double t2 = n * 0x1.93c7673007e5fp-65;
+    { double s = rh - t2; double b2 = s - rh; double e = (rh - (s - b2)) + (-t2 - b2); e += rl; rh = s + e; rl = e - (rh - s); }
+    const double ch[25] = {0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p-1, 0x1.5555555555555p-3, 0x1.5555555555555p-5, 0x1.1111111111111p-7, 0x1.6c16c16c16c17p-10,
+        0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-16, 0x1.71de3a556c734p-19, 0x1.27e4fb7789f5cp-22, 0x1.ae64567f544e4p-26, 0x1.1eed8eff8d898p-29, 0x1.6124613a86d09p-33,
+        0x1.93974a8c07c9dp-37, 0x1.ae7f3e733b81fp-41, 0x1.ae7f3e733b81fp-45, 0x1.952c77030ad4ap-49, 0x1.6827863b97d97p-53, 0x1.2f49b46814157p-57, 0x1.e542ba4020225p-62,
+        0x1.71b8ef6dcf572p-66, 0x1.0ce396db7f853p-70, 0x1.761b41316381ap-75, 0x1.f2cf01972f578p-80};
+    const double cl[25] = {0.0, 0.0, 0.0, 0x1.5555555555555p-57, 0x1.5555555555555p-59, 0x1.1111111111111p-63, -0x1.f49f49f49f49fp-65, 0x1.a01a01a01a01ap-73, 0x1.a01a01a01a01ap-76,
+        -0x1.c154f8ddc6c00p-73, 0x1.cbbc05b4fa99ap-76, -0x1.c062e06d1f209p-80, -0x1.2aec959e14c06p-83, 0x1.f28e0cc748ebep-87, 0x1.05d6f8a2efd1fp-92, 0x1.1d8656b0ee8cbp-97,
+        0x1.1d8656b0ee8cbp-101, 0x1.ac981465ddc6cp-103, 0x1.eec01221a8b0bp-107, 0x1.2650f61dbdcb4p-112, 0x1.ea72b4afe3c2fp-120, -0x1.d043ae40c4647p-120, -0x1.aebcdbd20331cp-124,
+        -0x1.3423c7d91404fp-130, -0x1.9ada5fcc1ab14p-135};
+    double ph = ch[24], pl = cl[24];
+#pragma unroll
+    for(int k = 23; k >= 0; k--) {
+        // (ph, pl) = (ph, pl) * (rh, rl) + (ch[k], cl[k])
+        const double m = ph * rh; double e = fma(ph, rh, -m); e = fma(ph, rl, e); e = fma(pl, rh, e);
+        double mh = m + e; double ml = e - (mh - m);
+        const double s = mh + ch[k]; const double b2 = s - mh; double e2 = (mh - (s - b2)) + (ch[k] - b2); e2 += ml + cl[k];
+        ph = s + e2; pl = e2 - (ph - s);
+    }
+    return ldexp(ph, (int)n);
+}
+
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
     for(int o = 32; o > 0; o >>= 1) {

@@ -917,6 +917,11 @@ __global__ void k_kat_rand(int n, u32* seeds, int* vals)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n) { unsigned int s = seeds[i]; vals[i] = glibc_rand_r(&s); seeds[i] = s; }
 }
+__global__ void k_kat_exp(int n, const double* x, double* y)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) y[i] = exp_cr_nonpos(x[i]);
+}
 }  // namespace hlala
 
 extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long long* out32)
@@ -1120,6 +1125,20 @@ extern "C" int hlala_abi_sizeof(const char* name)
     SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats) SZ(hlala_insert_size_out) SZ(hlala_locus_info) SZ(hlala_locus_report_in) SZ(hlala_locus_report_out) SZ(hlala_unit_stats_out) SZ(hlala_pairs_packed_out)
 #undef SZ
     return -1;
+}
+
+extern "C" int hlala_kat_exp(hlala_ctx* c, int n, const double* x, double* y)
+{
+    if(!c || n < 0 || !x || !y) return HLALA_E_ARG;
+    if(!n) return HLALA_OK;
+    double *dx = nullptr, *dy = nullptr; std::vector<void*> tmp;
+    int rc = dev_upload(c, tmp, x, (size_t)n, &dx); if(rc) return rc;
+    rc = dev_alloc(c, tmp, (size_t)n, &dy); if(rc) return rc;
+    hipLaunchKernelGGL(k_kat_exp, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, (const double*)dx, dy);
+    HIP_TRY(c, hipMemcpyAsync(y, dy, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for(void* p : tmp) pool_release(c, p);
+    return HLALA_OK;
 }
 
 extern "C" int hlala_kat_rand_r(hlala_ctx* c, int n, uint32_t* seeds_inout, int32_t* values_out)

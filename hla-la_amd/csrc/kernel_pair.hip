@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
         // ---- posterior over combinations (:4064-4085): exp(LL - max), normalised by a left-to-right sum
         double mapQ = 1, q1 = 1, q2 = 1;
         if(nComb > 1) {
-            for(int i = lane; i < nComb; i += 64) P.LL[i] = exp(P.LL[i] - mx);
+            for(int i = lane; i < nComb; i += 64) P.LL[i] = exp_cr_nonpos(P.LL[i] - mx);
             WSYNC();
             if(lane == 0) {
                 double S = 0; for(int i = 0; i < nComb; i++) S += P.LL[i];

@@ -588,6 +588,8 @@ int  hlala_typer_end_output(const char* out_dir, const char* loci_comma_separate
 int  hlala_kat_phred(hlala_ctx* ctx, int n, const double* p_correct, uint8_t* phred_out,
                      const uint8_t* phred_in, double* p_out);
 int  hlala_kat_rand_r(hlala_ctx* ctx, int n, uint32_t* seeds_inout, int32_t* values_out);
+/* the exponential of the posteriors of the pairing step (arguments <= 0): correctly rounded on the device, see device_common.h */
+int  hlala_kat_exp(hlala_ctx* ctx, int n, const double* x, double* exp_x);
 
 /* sizeof() of the structs of this header as the library was compiled, by struct name ("hlala_graph_desc", "hlala_params", ...);
  * -1 for an unknown name.  Lets a foreign-function binding (ctypes, cgo, JNI) check its mirror of the layout at load time. */

@@ -148,6 +148,17 @@ def test_known_answer_kernels(pkg, oracle):
     ctx._check(ctx.lib.hlala_kat_rand_r(ctx.h, len(seeds), s1.ctypes.data_as(pkg.c_u32p), v1.ctypes.data_as(pkg.c_i32p)), "kat_rand_r")
     ob.lib().orc_rand_r(len(seeds), s2.ctypes.data_as(pkg.c_u32p), v2.ctypes.data_as(pkg.c_i32p))
     assert np.array_equal(v1, v2) and np.array_equal(s1, s2)
+    # the exponential of the posteriors: correctly rounded (reference: 60-digit decimal arithmetic, rounded once to double)
+    import decimal, math
+    decimal.getcontext().prec = 60
+    x = np.concatenate([[0.0, -1e-300, -1e-17, -0.5, -1.0, -math.log(2.0), -36.04365338911715, -699.9], -rng.random(6000) * 40, -rng.random(2000) * 700, -10.0 ** (-rng.random(2000) * 12)])
+    y = np.zeros(len(x))
+    ctx._check(ctx.lib.hlala_kat_exp(ctx.h, len(x), x.ctypes.data_as(pkg.c_f64p), y.ctypes.data_as(pkg.c_f64p)), "kat_exp")
+    ref = np.array([float(decimal.Decimal(float(v)).exp()) for v in x])
+    bad = np.nonzero(y != ref)[0]
+    assert len(bad) == 0, [(float(x[i]).hex(), float(y[i]).hex(), float(ref[i]).hex()) for i in bad[:5]]
+    host = np.array([math.exp(v) for v in x])
+    print("host libm exp differs from the correctly rounded value in %d of %d arguments" % (int((host != ref).sum()), len(x)))
 
 
 def test_edge_cases(pkg, oracle):

@@ -1,0 +1,28 @@
+"""One-off stress: larger random batches than the test suite uses, product vs oracle (pairs + extended chains + work counters)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from tools import synth
+from conftest import load_package
+from oracle_binding import Oracle
+from util import compare_chains
+from test_gpu_align import assert_pairs_equal
+P = load_package()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
+for seed, G, k, kw, bk in ((101, 40000, 1, dict(n_mut=3), dict()), (102, 20000, 0, dict(n_largegap=2), dict(p_secondary=0.8, max_secondary=5)),
+                           (103, 30000, 2, dict(extra_identical=2), dict(p_secondary=1.0, max_secondary=6, clip_max=60)), (104, 15000, 5, dict(n_mut=5), dict(indel_read_frac=0.3)),
+                           (105, 25000, 1, dict(n_mut=8, mut_density=0.04), dict(p_random_secondary=0.4))):
+    t0 = time.time()
+    w = synth.make_world(seed=seed, G=G, k=k, **kw)
+    b = synth.make_batch(w, n, seed=seed + 1000, **bk)
+    kwc = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=seed, max_columns=384)
+    exp = Oracle(w["graph"], w["contigs"], **kwc).align_batch(b)
+    ctx = P.Context(w["graph"], w["contigs"], **kwc)
+    gb = ctx.batch(b); gb.align()
+    compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stress %d" % seed)
+    assert_pairs_equal(gb.pairs(), exp["pairs"])
+    st = gb.stats()
+    assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
+    print("seed %d k=%d: %d pairs, %d chains, %d DP calls (%d shared, %d re-run wider, %d large), errors %d, %.0f s" % (seed, k, n, b["n_chains"], st.n_dp_calls, st.n_dp_shared, st.n_chains_retried, st.n_dp_retried_large, st.n_errors, time.time() - t0), flush=True)
+print("STRESS OK")
