@@ -18,7 +18,6 @@
 namespace hlala {
 
 constexpr int PROJ_CAP   = 512;     // alignment columns held in LDS (>= params.max_columns)
-constexpr int PROJ_OPS   = 64;      // CIGAR operations per record
 constexpr int PROJ_NODES = 512;     // nodes per level held in LDS score rows
 constexpr int PROJ_SN    = 640;     // nodes of a chain's level window staged in LDS (CSR offsets + back pointers)
 constexpr int PROJ_SE    = 768;     // in-edges of that window staged in LDS
@@ -172,10 +171,10 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         // ---------------- CIGAR walk (transformBAMreadToInternalAlignment, :4794-5337)
         // Columns are the M/=/X/D/I operations in CIGAR order: M -> (ref, read), D -> (ref, '_'), I -> (-1, '_', read);
         // S advances the read index, H only counts at the very start (:4868-4874), P is dropped (:4814-4828), N throws (:5167).
-        if(nOps < 1 || (!PL::LONG && nOps > PROJ_OPS)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
+        if(nOps < 1) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
         int nCols = 0;
         // 64 CIGAR operations at a time, one per lane; the per-operation starts stay in registers and are broadcast with readlane.
-        // (Short reads: a single round.  Long reads carry the running column / reference / read offsets from round to round.)
+        // (Short reads: a single round.  Records with more operations carry the running column / reference / read offsets from round to round.)
         if(PJ_OK()) {
             int baseCol = 0, baseRef = 0, baseRead = 0, leadH = 0, prevOp = -1;
             int firstStart = -1, lastRS = 0, lastLen = 0, lastUse = 0;

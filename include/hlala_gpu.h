@@ -198,7 +198,7 @@ int  hlala_batch_create(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** 
  * scores it (long-read rates if params.long_read_mode), selects the first maximum and assigns the unpaired mapping
  * qualities.  hlala_pairs_out arrays are per unit: [n] where the paired layout has [2n].  params.max_columns bounds
  * the columns of a chain (up to 16384: kilobase reads; above 512 the projection works out of HBM scratch instead of
- * LDS); longer chains are flagged HLALA_CHAIN_ERR_COLUMNS, as are reads with several alignments AND more than 512
+ * LDS); longer chains (at any stage of the projection: the columns padded in for skipped graph levels count, so leave headroom) are flagged HLALA_CHAIN_ERR_COLUMNS, as are reads with several alignments AND more than 512
  * columns (the reference keeps primaries only in long-read mode, processBAM.cpp:725-738).                            */
 int  hlala_batch_create_unpaired(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** out);
 /* Upload seed chains directly (stage A is then not available on this batch).                */

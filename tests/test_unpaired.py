@@ -99,3 +99,22 @@ def test_long_reads_match_oracle(pkg, oracle, seed, G, k, n_reads, lo, hi):
         assert np.array_equal(np.asarray(g[key])[:per], np.asarray(x[key])[:per]), key
     assert np.allclose(g["pair_ll"][:n], x["pair_ll"][:n], rtol=1e-12, atol=0)
     assert int(np.asarray(x["n_cols"])[:n].max()) > 2000 and int(np.diff(u["cigar_off"]).max()) > 64
+
+
+def test_many_cigar_operations_in_the_512_column_variant(pkg, oracle):
+    """Error-rich reads of a few hundred bases have more than 64 CIGAR operations; the LDS-resident projection variant (max_columns <= 512)
+    walks them in rounds of 64 like the slab-backed one (it used to flag such records as invalid input)."""
+    w = synth.make_world(seed=21, G=8000, k=1)
+    u = synth.make_long_batch(w, 200, seed=22, len_lo=150, len_hi=300)
+    assert int(np.diff(u["cigar_off"]).max()) > 64
+    kw = dict(insert_mean=200.0, insert_sd=35.0, rng_seed=3, long_read_mode=1, max_columns=512)
+    e = oracle(w["graph"], w["contigs"], **kw).align_long_reads(u)
+    ctx = pkg.Context(w["graph"], w["contigs"], **kw)
+    gb = ctx.batch_unpaired(u); gb.align()
+    assert gb.stats().n_errors == 0
+    compare_chains(gb.chains(0), e["seeds"], u["n_chains"], check_ll=False, check_dp=False, label="seeds, > 64 operations")
+    compare_chains(gb.chains(1), e["ext"], u["n_chains"], check_dp=False, label="chains, > 64 operations")
+    g = gb.pairs(); x = e["pairs"]; n = 200
+    for key in PAIR_INT:
+        per = {"pair_status": n, "best_chain": n, "n_combinations": n, "n_cols": n}.get(key, n * 512)
+        assert np.array_equal(np.asarray(g[key])[:per], np.asarray(x[key])[:per]), key
