@@ -10,9 +10,15 @@ from util import compare_chains
 from test_gpu_align import assert_pairs_equal
 P = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
+only = set(int(x) for x in sys.argv[2].split(',')) if len(sys.argv) > 2 else None
 for seed, G, k, kw, bk in ((101, 40000, 1, dict(n_mut=3), dict()), (102, 20000, 0, dict(n_largegap=2), dict(p_secondary=0.8, max_secondary=5)),
                            (103, 30000, 2, dict(extra_identical=2), dict(p_secondary=1.0, max_secondary=6, clip_max=60)), (104, 15000, 5, dict(n_mut=5), dict(indel_read_frac=0.3)),
-                           (105, 25000, 1, dict(n_mut=8, mut_density=0.04), dict(p_random_secondary=0.4))):
+                           (105, 25000, 1, dict(n_mut=8, mut_density=0.04), dict(p_random_secondary=0.4)),
+                           (106, 20000, 1, dict(n_mut=4), dict(read_len=100, ins_mean=150.0, ins_sd=25.0, clip_max=15, indel_read_frac=0.0)),
+                           (107, 30000, 2, dict(n_mut=4, n_largegap=2), dict(read_len=250, ins_mean=350.0, ins_sd=60.0, clip_max=80, indel_read_frac=0.2)),
+                           (108, 15000, 1, dict(n_mut=3, gap_frac=0.6, mut_density=0.05), dict(clip_max=65, p_no_clip=0.0, p_secondary=0.9))):
+    if only and seed not in only:
+        continue
     t0 = time.time()
     w = synth.make_world(seed=seed, G=G, k=k, **kw)
     b = synth.make_batch(w, n, seed=seed + 1000, **bk)
