@@ -244,3 +244,24 @@ def test_packed_pairs_equal_the_padded_rows(pkg):
     for r in range(0, n, 7):
         a, z = pu["col_off"][r], pu["col_off"][r + 1]
         assert np.array_equal(pu["col_level"][a:z], fu["col_level"][r * st:r * st + (z - a)]) and np.array_equal(pu["col_mapq"][a:z], fu["col_mapq"][r * st:r * st + (z - a)])
+
+
+def test_record_the_reference_asserts_on_is_flagged_alone(pkg):
+    """An alignment with a single aligned base trips assert(startInRaw < stopInRaw) in the reference (processBAM.cpp:5252) and takes the
+    process down; here the chain is flagged (HLALA_CHAIN_ERR_INPUT), its pair gets a negative status, every other pair is untouched."""
+    w = synth.make_world(seed=13, G=4000, k=1)
+    b = synth.make_batch(w, 60, seed=14, p_secondary=0.0)
+    ctx = pkg.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=2)
+    gb = ctx.batch(b); gb.align(); good = gb.pairs()
+    bad = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in b.items()}
+    c = int(b["read_primary"][20]); g0, g1 = b["cigar_off"][c], b["cigar_off"][c + 1]
+    new = np.array([(74 << 4) | 4, (1 << 4) | 0, (75 << 4) | 4], np.uint32)
+    bad["cigar"] = np.concatenate([b["cigar"][:g0], new, b["cigar"][g1:]]).astype(np.uint32)
+    off = b["cigar_off"].copy(); off[c + 1:] += len(new) - (g1 - g0); bad["cigar_off"] = off
+    gb2 = ctx.batch(bad); gb2.align(); got = gb2.pairs()
+    assert gb2.chains(0)["status"][c] == -3 and got["pair_status"][10] < 0 and gb2.stats().n_errors >= 1
+    keep = np.arange(60) != 10
+    assert (got["pair_status"][keep] == 0).all()
+    for k in ("best_chain", "n_cols", "col_level", "col_mapq"):
+        a = got[k].reshape(60, -1); z = good[k].reshape(60, -1)
+        assert np.array_equal(a[keep], z[keep]), k
