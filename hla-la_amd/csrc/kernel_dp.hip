@@ -1099,26 +1099,18 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
         bool more = true;
         int edgesAcc = 0;                                  // per-lane partial sum of the edges the current DP touched
 
+        // One trip: every group advances through as many states as it can -- iterate, and on the last iteration straight on to end cell,
+        // backtrace (up to DP_BT_STEPS_PER_TRIP pointers), expansion, bookkeeping and the next item -- so that a group spends its trips
+        // iterating, not changing state (the states used to be visited in the opposite order: one state change per trip).
         for(;;) {
-            if(phase == PH_IDLE && more) {
-                int w = 0;
-                if(gl == 0) w = atomicAdd(fetchCounter, 1);
-                w = (GW == 64) ? __builtin_amdgcn_readfirstlane(w) : grp_bcast<GW>(w, 0);
-                if(w >= nItems) more = false;
-                else {
-                    const int idx = (TIER == 0) ? listBase + w : guni<GW>(srcList[w]);
-                    const int4* ip = (const int4*)(items + idx);
-                    int4 a = ip[0], b = ip[1];
-                    DpItem it; it.item = a.x; it.rOff = a.y; it.seqLen = a.z; it.start_seq = a.w; it.startLevel = b.x; it.startNode = b.y; it.pad0 = 0; it.pad1 = 0;
-                    phase = dp_begin<C>(S, sl, G, it, idx);
-                    edgesAcc = 0;
-                }
-            }
-            DP_T(0);
-            if(!__ballot(phase != PH_IDLE)) break;       // every group is idle and found no more work
-#ifdef HLALA_DP_TIMING
-            trips++; runGroups += __popcll(__ballot(phase == PH_RUN)) / GW;
-#endif
+            if(phase == PH_RUN) phase = dp_iterate<C>(S, sl, G, fwd ? nrecOut : nrecIn, readBases, fwd, edgesAcc);
+            DP_T(5);
+            if(phase == PH_SELECT) phase = dp_select<C>(S, sl, G, rng_seed, fwd);
+            DP_T(4);
+            if(phase == PH_BT) phase = dp_backtrace<C>(S, sl, DP_BT_STEPS_PER_TRIP, fwd);
+            DP_T(3);
+            if(phase == PH_EXPAND) phase = dp_expand<C>(S, sl, G, B, fwd);
+            DP_T(2);
             if(phase == PH_DONE) {
                 // final bookkeeping of this DP in this class; a DP that outgrew the class is queued for the next one and leaves no trace
                 const int edges = grp_sum_i32<GW>(edgesAcc);
@@ -1157,13 +1149,25 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
                 phase = guni<GW>(S.nextPhase);
             }
             DP_T(1);
-            if(phase == PH_EXPAND) phase = dp_expand<C>(S, sl, G, B, fwd);
-            DP_T(2);
-            if(phase == PH_BT) phase = dp_backtrace<C>(S, sl, DP_BT_STEPS_PER_TRIP, fwd);
-            DP_T(3);
-            if(phase == PH_SELECT) phase = dp_select<C>(S, sl, G, rng_seed, fwd);
-            DP_T(4);
-            if(phase == PH_RUN) phase = dp_iterate<C>(S, sl, G, fwd ? nrecOut : nrecIn, readBases, fwd, edgesAcc);
+            if(phase == PH_IDLE && more) {
+                int w = 0;
+                if(gl == 0) w = atomicAdd(fetchCounter, 1);
+                w = (GW == 64) ? __builtin_amdgcn_readfirstlane(w) : grp_bcast<GW>(w, 0);
+                if(w >= nItems) more = false;
+                else {
+                    const int idx = (TIER == 0) ? listBase + w : guni<GW>(srcList[w]);
+                    const int4* ip = (const int4*)(items + idx);
+                    int4 a = ip[0], b = ip[1];
+                    DpItem it; it.item = a.x; it.rOff = a.y; it.seqLen = a.z; it.start_seq = a.w; it.startLevel = b.x; it.startNode = b.y; it.pad0 = 0; it.pad1 = 0;
+                    phase = dp_begin<C>(S, sl, G, it, idx);
+                    edgesAcc = 0;
+                }
+            }
+            DP_T(0);
+            if(!__ballot(phase != PH_IDLE)) break;       // every group is idle and found no more work
+#ifdef HLALA_DP_TIMING
+            trips++; runGroups += __popcll(__ballot(phase == PH_RUN)) / GW;
+#endif
             DP_T(5);
         }
     }
