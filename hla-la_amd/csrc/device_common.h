@@ -61,6 +61,9 @@ constexpr int DP_CELLS     = 16384;  // kept cells per DP call (global slab); < 
 constexpr int DP_EARLY     = 4096;   // hash entries for cells reached early through gap-path jumps
 constexpr int DP_STEPS     = 8192;   // backtrace steps
 constexpr int DP_COMPLETED = 2048;   // sequence-complete cells
+constexpr int DP_CELLS_LARGE     = 65536;  // kept cells per DP call of the large-capacity class (<= 131072: 17-bit slots in the back pointers)
+constexpr int DP_COMPLETED_LARGE = 16384;  // sequence-complete cells, large-capacity class
+constexpr int DP_MAX_DEGREE = 127;   // edges / gap-path jumps of one node in one direction (7-bit push index, kernel_dp.hip)
 constexpr int DP_NEG       = -30000; // minusInfinity (-DBL_MAX in the reference, extensionAligner.cpp:363)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -201,6 +201,7 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
     }
     // ---- node records: everything one DP iteration needs of a frontier node in one 32-byte read
     {
+        std::string recErr;
         auto build = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& to, const std::vector<uint8_t>& lab,
                          const std::vector<int32_t>& joff, const std::vector<int32_t>& jnode, const std::vector<int32_t>& jlvl,
                          std::vector<int32_t>& rec) {
@@ -209,7 +210,8 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
                 const int32_t e0 = off[n], deg = off[n + 1] - e0;
                 const int32_t j0 = joff[n], nj = joff[n + 1] - j0;
                 int32_t* r = &rec[(size_t)8 * n];
-                r[0] = e0; r[1] = (deg & 0xFFFF) | (int32_t)((uint32_t)(nj > 0x7FFF ? 0x7FFF : nj) << 16);
+                if(deg > 0xFFFF || nj > 0x7FFF) { recErr = "node with more than 65535 edges or 32767 gap-path jumps in one direction (node record layout)"; return; }
+                r[0] = e0; r[1] = deg | (int32_t)((uint32_t)nj << 16);
                 r[2] = deg > 0 ? to[e0] : 0; r[3] = deg > 1 ? to[e0 + 1] : 0;
                 r[4] = j0; r[5] = nj > 0 ? jnode[j0] : 0; r[6] = nj > 0 ? jlvl[j0] : 0;
                 r[7] = (deg > 0 ? lab[e0] : 0) | ((deg > 1 ? lab[e0 + 1] : 0) << 8);
@@ -217,6 +219,7 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
         };
         build(F.out_off, F.out_to, F.out_label, F.jf_off, F.jf_node, F.jf_lvl, F.nrec_out);
         build(F.in_off, F.in_from, F.in_label, F.jb_off, F.jb_node, F.jb_lvl, F.nrec_in);
+        if(!recErr.empty()) return recErr;
     }
     return "";
 }

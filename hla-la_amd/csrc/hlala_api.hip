@@ -54,7 +54,7 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
-    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
+    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* large_slabs = nullptr; size_t large_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
     hipEvent_t ev[9]{};           // start/end per stage; [7] / [6] / [8] = before DpTiny / after DpTiny / after the retry classes
@@ -72,6 +72,16 @@ struct hlala_batch {
     int staged = 0;   // bit0 seeds available, bit1 extended, bit2 paired
     float ms[3] = {0, 0, 0};
 };
+
+// Every entry point runs with the context's device current and restores the caller's device on return: several contexts (one per GPU)
+// may live in one process, and the host program (or torch) may switch devices between calls.
+struct DevGuard {
+    int prev = -1, want = -1;
+    explicit DevGuard(int device) : want(device) { if(device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device) (void)hipSetDevice(device); else prev = -1; }
+    ~DevGuard() { if(prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard&) = delete; DevGuard& operator=(const DevGuard&) = delete;
+};
+#define DEV_GUARD(c) DevGuard dev_guard_((c) ? (c)->device : -1)
 
 #define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HLALA_E_DEVICE; } } while(0)
 
@@ -240,11 +250,19 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->device = device; c->stream = (hipStream_t)stream; c->params = *params;
     auto fail = [&](int rc) { g_create_error = c->err; hlala_destroy(c); return rc; };
     if(c->params.max_columns < 16 || c->params.max_columns > 65536) { c->err = "params.max_columns out of range"; return fail(HLALA_E_ARG); }
-    if(hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(HLALA_E_DEVICE); }
+    DevGuard dev_guard_(device);       // the caller's current device is restored on return
+    { int cur_ = -1; if(hipGetDevice(&cur_) != hipSuccess || cur_ != device) { c->err = "hipSetDevice failed"; return fail(HLALA_E_DEVICE); } }
     std::string ferr = flatten_graph(graph, contigs, c->F);
     if(!ferr.empty()) { c->err = ferr; return fail(HLALA_E_GRAPH); }
     FlatGraph& F = c->F;
     if(F.N >= (1 << 28) || F.L >= (1 << 24)) { c->err = "graph exceeds 2^28 nodes or 2^24 levels (DP cell key layout)"; return fail(HLALA_E_CAPACITY); }
+    // the DP packs the push index of a candidate (edge or gap-path jump of a frontier node) into 7 bits: a wider node would fail in
+    // every capacity class, so it is refused here instead of dropping pairs later
+    if(F.max_out_degree > DP_MAX_DEGREE || F.max_in_degree > DP_MAX_DEGREE || F.max_jumps > DP_MAX_DEGREE) {
+        c->err = "graph has a node with more than " + std::to_string(DP_MAX_DEGREE) + " edges or gap-path jumps in one direction (out " + std::to_string(F.max_out_degree) +
+                 ", in " + std::to_string(F.max_in_degree) + ", jumps " + std::to_string(F.max_jumps) + "): beyond the DP's push-index field";
+        return fail(HLALA_E_CAPACITY);
+    }
     if(F.max_nodes_per_level > PROJ_NODES) { c->err = "more nodes in one level than this build holds in LDS (PROJ_NODES)"; return fail(HLALA_E_CAPACITY); }
     if(c->params.max_columns > PROJL_CAP) { c->err = "params.max_columns exceeds the column capacity of this build (16384)"; return fail(HLALA_E_ARG); }
     DevGraph& G = c->G;
@@ -293,7 +311,10 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();      // 2 * mid_grid mid slabs fit the pool of ext_grid small slabs
     c->retry_grid = cus;
     c->stitch_grid = cus * 32;
-    c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpLarge>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpLarge>();
+    c->ext_slab_bytes = dp_slab_bytes<DpSmall>();
+    c->large_slab_bytes = dp_slab_bytes<DpLarge>();       // one block per CU: a few MB each
+    if(hipMalloc((void**)&c->large_slabs, c->large_slab_bytes * (size_t)c->retry_grid) != hipSuccess) { c->err = "hipMalloc(large-class DP slabs) failed"; return fail(HLALA_E_DEVICE); }
+    c->allocs.push_back(c->large_slabs);
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->ext_slabs);
     c->proj_grid = cus * 9; c->pair_grid = cus * 14;
@@ -316,6 +337,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
 void hlala_destroy(hlala_ctx* c)
 {
     if(!c) return;
+    DEV_GUARD(c);
     for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(auto& kv : c->pool) (void)hipFree(kv.second);
@@ -390,6 +412,7 @@ int hlala_batch_create_unpaired(hlala_ctx* c, const hlala_batch_in* in, hlala_ba
 
 static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch** out, bool unpaired)
 {
+    DEV_GUARD(c);
     if(!c || !in || !out) return HLALA_E_ARG;
     *out = nullptr;
     if(in->n_pairs < 0 || in->n_chains < 0) { c->err = "negative batch sizes"; return HLALA_E_ARG; }
@@ -427,6 +450,7 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
 
 int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_batch** out)
 {
+    DEV_GUARD(c);
     if(!c || !in || !out) return HLALA_E_ARG;
     *out = nullptr;
     hlala_batch* b = new hlala_batch(); b->ctx = c; c->batches.insert(b);
@@ -474,6 +498,7 @@ void hlala_batch_destroy(hlala_batch* b)
 {
     if(!b) return;
     hlala_ctx* c = b->ctx;
+    DEV_GUARD(c);
     if(c) {
         c->batches.erase(b);
         (void)hipStreamSynchronize(c->stream);       // nothing of this batch may still be running when its buffers are handed to the next one
@@ -491,6 +516,7 @@ static int check_launch(hlala_ctx* c, const char* what)
 
 int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
 {
+    DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -516,6 +542,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
 
 int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
 {
+    DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -539,7 +566,7 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
             rc_ = check_launch(c, "k_dp<mid>"); if(rc_) return rc_;
             hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             rc_ = check_launch(c, "k_dp<small>"); if(rc_) return rc_;
-            hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             return check_launch(c, "k_dp<large>");
         };
         rc = run_classes(true); if(rc) return rc;
@@ -555,6 +582,7 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
 
 int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
 {
+    DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage C not available"; return HLALA_E_STATE; }
     if(!(b->staged & 2)) { c->err = "hlala_pair_chains before hlala_extend_chains"; return HLALA_E_STATE; }
@@ -581,6 +609,7 @@ int hlala_align_batch(hlala_ctx* c, hlala_batch* b)
 
 int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains_out* o)
 {
+    DEV_GUARD(c);
     if(!c || !b || !o) return HLALA_E_ARG;
     DevBatch& B = b->B;
     size_t nc = (size_t)B.n_chains, cs = nc * (size_t)B.stride;
@@ -613,6 +642,7 @@ int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains
 
 int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
 {
+    DEV_GUARD(c);
     if(!c || !b || !o) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -656,6 +686,7 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
 
 int hlala_batch_get_pairs_packed(hlala_ctx* c, hlala_batch* b, hlala_pairs_packed_out* o)
 {
+    DEV_GUARD(c);
     if(!c || !b || !o || !o->col_off) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -695,6 +726,7 @@ int hlala_batch_get_pairs_packed(hlala_ctx* c, hlala_batch* b, hlala_pairs_packe
 
 int hlala_estimate_insert_size(hlala_ctx* c, const hlala_batch_in* in, hlala_insert_size_out* out)
 {
+    DEV_GUARD(c);
     if(!c || !in || !out) return HLALA_E_ARG;
     memset(out, 0, sizeof(*out));
     const int np = in->n_pairs, nr = 2 * np;
@@ -750,6 +782,7 @@ int hlala_estimate_insert_size(hlala_ctx* c, const hlala_batch_in* in, hlala_ins
 
 int hlala_set_gene_intervals(hlala_ctx* c, int32_t n, const int32_t* first_level, const int32_t* last_level)
 {
+    DEV_GUARD(c);
     if(!c || n < 0 || (n > 0 && (!first_level || !last_level))) return HLALA_E_ARG;
     for(int i = 0; i < n; i++) if(first_level[i] < 0 || last_level[i] < first_level[i]) { c->err = "gene interval with first > last or negative level"; return HLALA_E_ARG; }
     c->n_genes = 0;
@@ -764,6 +797,7 @@ int hlala_set_gene_intervals(hlala_ctx* c, int32_t n, const int32_t* first_level
 
 int hlala_postprocess_pairs(hlala_ctx* c, hlala_batch* b, uint8_t* include_in_hla)
 {
+    DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "hlala_postprocess_pairs before hlala_pair_chains"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -788,6 +822,7 @@ int hlala_postprocess_pairs(hlala_ctx* c, hlala_batch* b, uint8_t* include_in_hl
 
 int hlala_get_coverage(hlala_ctx* c, int32_t* bases_per_level, int reset)
 {
+    DEV_GUARD(c);
     if(!c || !bases_per_level) return HLALA_E_ARG;
     const int n = c->F.L > 1 ? c->F.L - 1 : 1;
     if(!c->d_cov) { memset(bases_per_level, 0, (size_t)n * 4); return HLALA_OK; }
@@ -799,6 +834,7 @@ int hlala_get_coverage(hlala_ctx* c, int32_t* bases_per_level, int reset)
 
 int hlala_batch_export_pair_records(hlala_ctx* c, hlala_batch* b, double* device_out)
 {
+    DEV_GUARD(c);
     if(!c || !b || !device_out) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     if(b->B.n_pairs > 0) {
@@ -810,6 +846,7 @@ int hlala_batch_export_pair_records(hlala_ctx* c, hlala_batch* b, double* device
 
 int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
 {
+    DEV_GUARD(c);
     if(!c || !b || !out) return HLALA_E_ARG;
     memset(out, 0, sizeof(*out));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -817,7 +854,8 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
     if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]); } }
-    { int wc[32]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[12] + wc[14] + wc[16] + wc[18] + wc[20] + wc[22]; out->n_dp_retried_large = wc[20] + wc[22]; }
+    { int wc[32]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[12] + wc[14] + wc[16] + wc[18] + wc[20] + wc[22]; out->n_dp_retried_large = wc[20] + wc[22];
+      out->n_dp_class[0] = wc[8] + wc[9]; out->n_dp_class[1] = wc[12] + wc[14]; out->n_dp_class[2] = wc[16] + wc[18]; out->n_dp_class[3] = wc[20] + wc[22]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];
@@ -849,6 +887,7 @@ static int typer_tables(hlala_ctx* c, std::vector<void*>& tmp, TyperTables** out
 
 extern "C" int hlala_exon_loglik(hlala_ctx* c, const hlala_exon_in* in, double* LL, int32_t* mism)
 {
+    DEV_GUARD(c);
     if(!c || !in || !LL || !mism) return HLALA_E_ARG;
     const int C = in->n_clusters, P = in->exon_length, R = in->n_reads;
     if(C < 0 || P < 0 || R < 0) { c->err = "negative sizes"; return HLALA_E_ARG; }
@@ -880,6 +919,7 @@ extern "C" int hlala_exon_loglik(hlala_ctx* c, const hlala_exon_in* in, double* 
 
 extern "C" int hlala_pair_loglik(hlala_ctx* c, const double* LL, const int32_t* mism, int32_t C, int32_t R, double* pairLL, double* misAvg, double* misMin)
 {
+    DEV_GUARD(c);
     if(!c || !LL || !mism || !pairLL || !misAvg || !misMin || C < 0 || R < 0) return HLALA_E_ARG;
     if(C == 0) return HLALA_OK;
     std::vector<void*> tmp; int rc = 0;
@@ -926,6 +966,7 @@ __global__ void k_kat_exp(int n, const double* x, double* y)
 
 extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long long* out32)
 {
+    DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(out32, b->B.counters, 32 * sizeof(u64), hipMemcpyDeviceToHost));
@@ -934,6 +975,7 @@ extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long 
 
 extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uint8_t* phred_out, const uint8_t* phred_in, double* p_out)
 {
+    DEV_GUARD(c);
     if(!c || n < 0) return HLALA_E_ARG;
     if(p_correct && phred_out && n) {
         double* dp = nullptr; uint8_t* dq = nullptr; std::vector<void*> tmp;
@@ -954,6 +996,7 @@ extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uin
 extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, const double* misAvg, const double* misMin,
                                 int32_t* order, double* p_normalized, double* cluster_marginal, hlala_call_out* out)
 {
+    DEV_GUARD(c);
     if(!c || C < 1 || !pairLL || !misAvg || !misMin || !out) return HLALA_E_ARG;
     if(C > 46000) { c->err = "hlala_call_locus: more than 46000 clusters (pair index exceeds 31 bits)"; return HLALA_E_CAPACITY; }
     const long long nP = (long long)C * (C + 1) / 2, n2 = 2 * nP;
@@ -1002,6 +1045,7 @@ extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, c
 
 extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_locus_desc* L, hlala_exon_positions_out* o)
 {
+    DEV_GUARD(c);
     if(!c || !b || !L || !o) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "hlala_exon_positions before hlala_pair_chains"; return HLALA_E_STATE; }
     if(L->level_max < L->level_min || !L->level_to_exon) { c->err = "locus: empty level range or no level_to_exon table"; return HLALA_E_ARG; }
@@ -1061,6 +1105,7 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
 
 extern "C" int hlala_unit_alignment_stats(hlala_ctx* c, hlala_batch* b, hlala_unit_stats_out* o)
 {
+    DEV_GUARD(c);
     if(!c || !b || !o || !o->valid || !o->strands_valid || !o->distance || !o->fraction_ok || !o->weighted_ok || !o->n_columns || !o->mate_mapq) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "hlala_unit_alignment_stats before hlala_pair_chains"; return HLALA_E_STATE; }
     const size_t n = (size_t)b->B.n_pairs;
@@ -1080,6 +1125,7 @@ extern "C" int hlala_unit_alignment_stats(hlala_ctx* c, hlala_batch* b, hlala_un
 
 extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present)
 {
+    DEV_GUARD(c);
     if(!c || !b || n_queries < 0 || (n_queries > 0 && (!queries || !present))) return HLALA_E_ARG;
     if(k < 1 || k > 31) { c->err = "hlala_kmer_presence: k must be in 1..31 (2-bit codes in one 64-bit word)"; return HLALA_E_ARG; }
     if(n_queries == 0) return HLALA_OK;
@@ -1129,6 +1175,7 @@ extern "C" int hlala_abi_sizeof(const char* name)
 
 extern "C" int hlala_kat_exp(hlala_ctx* c, int n, const double* x, double* y)
 {
+    DEV_GUARD(c);
     if(!c || n < 0 || !x || !y) return HLALA_E_ARG;
     if(!n) return HLALA_OK;
     double *dx = nullptr, *dy = nullptr; std::vector<void*> tmp;
@@ -1143,6 +1190,7 @@ extern "C" int hlala_kat_exp(hlala_ctx* c, int n, const double* x, double* y)
 
 extern "C" int hlala_kat_rand_r(hlala_ctx* c, int n, uint32_t* seeds_inout, int32_t* values_out)
 {
+    DEV_GUARD(c);
     if(!c || n < 0 || !seeds_inout || !values_out) return HLALA_E_ARG;
     if(!n) return HLALA_OK;
     u32* ds = nullptr; int* dv = nullptr; std::vector<void*> tmp;

@@ -42,6 +42,7 @@ struct Bgzf {
         int bsize = -1;
         for(size_t p = 0; p + 4 <= xlen;) { unsigned sl = extra[p + 2] | (extra[p + 3] << 8); if(extra[p] == 66 && extra[p + 1] == 67 && sl == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8); p += 4 + sl; }
         if(bsize < 0) { g_bam_error = "BGZF block without BC field"; return false; }
+        if((size_t)bsize + 1 < (size_t)12 + xlen + 8) { g_bam_error = "BGZF block size smaller than its own header"; return false; }
         const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
         in.resize(cdata + 8);
         if(fread(in.data(), 1, cdata + 8, f) != cdata + 8) { g_bam_error = "truncated BGZF block"; return false; }
@@ -85,7 +86,7 @@ struct hlala_seed_batch {
 extern "C" const char* hlala_bam_last_error() { return g_bam_error.c_str(); }
 
 extern "C" int hlala_bam_extract_seeds(const char* path, int32_t n_intervals, const hlala_bam_interval* iv, int32_t long_read_mode, hlala_seed_batch** out)
-{
+try {
     if(!path || !out || n_intervals < 0 || (n_intervals > 0 && !iv)) return HLALA_E_ARG;
     *out = nullptr; g_bam_error.clear();
     Bgzf z; z.f = fopen(path, "rb");
@@ -93,13 +94,13 @@ extern "C" int hlala_bam_extract_seeds(const char* path, int32_t n_intervals, co
     auto fail = [&](const std::string& m) { if(g_bam_error.empty()) g_bam_error = m; fclose(z.f); return HLALA_E_ARG; };
     char magic[4]; int32_t l_text = 0, n_ref = 0;
     if(!z.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) return fail("not a BAM file");
-    if(!z.read(&l_text, 4) || l_text < 0) return fail("truncated BAM header");
+    if(!z.read(&l_text, 4) || l_text < 0 || l_text > (1 << 30)) return fail("truncated BAM header");
     { std::vector<char> text((size_t)l_text); if(l_text && !z.read(text.data(), (size_t)l_text)) return fail("truncated BAM header text"); }
     if(!z.read(&n_ref, 4) || n_ref < 0) return fail("truncated BAM header");
     std::vector<std::string> refName((size_t)n_ref);
     for(int i = 0; i < n_ref; i++) {
         int32_t l_name = 0, l_ref = 0;
-        if(!z.read(&l_name, 4) || l_name < 1) return fail("truncated BAM reference list");
+        if(!z.read(&l_name, 4) || l_name < 1 || l_name > (1 << 20)) return fail("truncated BAM reference list");
         std::vector<char> nm((size_t)l_name); if(!z.read(nm.data(), (size_t)l_name) || !z.read(&l_ref, 4)) return fail("truncated BAM reference list");
         refName[i] = std::string(nm.data());
     }
@@ -111,7 +112,7 @@ extern "C" int hlala_bam_extract_seeds(const char* path, int32_t n_intervals, co
     static const char SEQ16[] = "=ACMGRSVTWYHKDBN";
     while(!z.at_end()) {
         int32_t block_size = 0;
-        if(!z.read(&block_size, 4) || block_size < 32) return fail("truncated BAM record");
+        if(!z.read(&block_size, 4) || block_size < 32 || block_size > (1 << 28)) return fail("truncated BAM record");
         rec.resize((size_t)block_size);
         if(!z.read(rec.data(), (size_t)block_size)) return fail("truncated BAM record");
         const int32_t refID = (int32_t)rd32(&rec[0]), position = (int32_t)rd32(&rec[4]);
@@ -198,10 +199,10 @@ extern "C" int hlala_bam_extract_seeds(const char* path, int32_t n_intervals, co
     }
     *out = S;
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_bam_error = std::string("hlala_bam_extract_seeds: ") + e_.what(); return HLALA_E_ARG; }
 
 extern "C" int hlala_seed_batch_desc(const hlala_seed_batch* S, hlala_batch_in* in, int64_t* counts /* [3] examined records, seeds, incomplete seeds; or NULL */)
-{
+try {
     if(!S || !in) return HLALA_E_ARG;
     in->n_pairs = S->n_units; in->read_off = S->read_off.data(); in->read_bases = S->read_bases.data(); in->read_quals = S->read_quals.data();
     in->chain_off = S->chain_off.data(); in->read_primary = S->read_primary.data(); in->n_chains = (int32_t)S->chain_contig.size();
@@ -209,7 +210,7 @@ extern "C" int hlala_seed_batch_desc(const hlala_seed_batch* S, hlala_batch_in* 
     in->chain_reverse = S->chain_reverse.data(); in->cigar_off = S->cigar_off.data(); in->cigar = S->cigar.data();
     if(counts) { counts[0] = S->examined; counts[1] = S->n_seeds; counts[2] = S->n_incomplete; }
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_bam_error = std::string("hlala_seed_batch_desc: ") + e_.what(); return HLALA_E_ARG; }
 
 extern "C" const char* hlala_seed_batch_name(const hlala_seed_batch* S, int32_t unit) { return (S && unit >= 0 && unit < S->n_units) ? S->names[(size_t)unit].c_str() : nullptr; }
 extern "C" void hlala_seed_batch_free(hlala_seed_batch* S) { delete S; }

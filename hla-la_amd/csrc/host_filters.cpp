@@ -31,7 +31,8 @@ struct Entry { int pos_index; int read; int allele; double w; };     // one posi
 
 extern "C" int hlala_filter_positions(const hlala_exon_positions_out* pos, const hlala_filter_params* prm, uint8_t* pos_use, uint8_t* read_ignored, hlala_filter_stats* stats)
 {
-    return hlala_host::filter_positions_impl(pos, prm, pos_use, read_ignored, stats, nullptr);
+    try { return hlala_host::filter_positions_impl(pos, prm, pos_use, read_ignored, stats, nullptr); }
+    catch(const std::exception&) { return HLALA_E_ARG; }      // (bad_alloc on absurd sizes: nothing may cross the C boundary)
 }
 
 int hlala_host::filter_positions_impl(const hlala_exon_positions_out* pos, const hlala_filter_params* prm, uint8_t* pos_use, uint8_t* read_ignored, hlala_filter_stats* stats,

@@ -62,7 +62,7 @@ int fail(const std::string& m) { g_loader_error = m; return HLALA_E_ARG; }
 extern "C" const char* hlala_loader_last_error() { return g_loader_error.c_str(); }
 
 extern "C" int hlala_graph_load_text(const char* path, hlala_graph_file** out)
-{
+try {
     if(!path || !out) return HLALA_E_ARG;
     *out = nullptr;
     std::ifstream in(path);
@@ -115,15 +115,15 @@ extern "C" int hlala_graph_load_text(const char* path, hlala_graph_file** out)
     g->n_levels = maxLevel + 1;
     *out = g;
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_loader_error = std::string("hlala_graph_load_text: ") + e_.what(); return HLALA_E_ARG; }
 
 extern "C" int hlala_graph_file_desc(const hlala_graph_file* g, hlala_graph_desc* d)
-{
+try {
     if(!g || !d) return HLALA_E_ARG;
     d->n_levels = g->n_levels; d->n_nodes = (int32_t)g->node_level.size(); d->n_edges = (int32_t)g->edge_from.size();
     d->node_level = g->node_level.data(); d->edge_from = g->edge_from.data(); d->edge_to = g->edge_to.data(); d->edge_label = g->edge_label.data();
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_loader_error = std::string("hlala_graph_file_desc: ") + e_.what(); return HLALA_E_ARG; }
 
 extern "C" void hlala_graph_file_free(hlala_graph_file* g) { delete g; }
 
@@ -131,7 +131,7 @@ extern "C" void hlala_graph_file_free(hlala_graph_file* g) { delete g; }
 static const char CACHE_MAGIC[8] = {'H', 'L', 'A', 'L', 'A', 'G', 'R', '1'};
 
 extern "C" int hlala_graph_cache_save(const hlala_graph_desc* d, const char* path)
-{
+try {
     if(!d || !path) return HLALA_E_ARG;
     FILE* f = fopen(path, "wb");
     if(!f) return fail(std::string("Cannot open cache file for writing: ") + path);
@@ -141,10 +141,10 @@ extern "C" int hlala_graph_cache_save(const hlala_graph_desc* d, const char* pat
               fwrite(d->edge_to, 4, (size_t)d->n_edges, f) == (size_t)d->n_edges && fwrite(d->edge_label, 1, (size_t)d->n_edges, f) == (size_t)d->n_edges;
     ok = (fclose(f) == 0) && ok;
     return ok ? HLALA_OK : fail(std::string("short write to ") + path);
-}
+} catch(const std::exception& e_) { g_loader_error = std::string("hlala_graph_cache_save: ") + e_.what(); return HLALA_E_ARG; }
 
 extern "C" int hlala_graph_cache_load(const char* path, hlala_graph_file** out)
-{
+try {
     if(!path || !out) return HLALA_E_ARG;
     *out = nullptr;
     FILE* f = fopen(path, "rb");
@@ -159,7 +159,7 @@ extern "C" int hlala_graph_cache_load(const char* path, hlala_graph_file** out)
     if(!ok) { delete g; return fail(std::string("truncated graph cache: ") + path); }
     *out = g;
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_loader_error = std::string("hlala_graph_cache_load: ") + e_.what(); return HLALA_E_ARG; }
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Reference contigs of a graph directory: sequences.txt + the reference FASTA + translation/<SequenceID>.txt
@@ -202,7 +202,7 @@ bool read_wanted_fasta(const std::string& path, std::map<std::string, std::strin
 }  // namespace
 
 extern "C" int hlala_contigs_load_dir(const char* graph_dir, int32_t extended_reference_genome, hlala_contigs_file** out)
-{
+try {
     if(!graph_dir || !out) return HLALA_E_ARG;
     const std::string dir(graph_dir);
     std::ifstream sf((dir + "/sequences.txt").c_str());
@@ -261,13 +261,13 @@ extern "C" int hlala_contigs_load_dir(const char* graph_dir, int32_t extended_re
     }
     *out = C.release();
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_loader_error = std::string("hlala_contigs_load_dir: ") + e_.what(); return HLALA_E_ARG; }
 extern "C" int hlala_contigs_file_desc(const hlala_contigs_file* c, hlala_contigs_desc* d)
-{
+try {
     if(!c || !d) return HLALA_E_ARG;
     d->n_contigs = (int32_t)c->seqid.size(); d->contig_off = c->off.data(); d->contig_seq = c->seq.data(); d->contig_level = c->level.data(); d->contig_seqid = c->seqid.data();
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_loader_error = std::string("hlala_contigs_file_desc: ") + e_.what(); return HLALA_E_ARG; }
 extern "C" int32_t hlala_contigs_file_intervals(const hlala_contigs_file* c, hlala_bam_interval* out, int32_t cap)
 {
     if(!c) return -1;

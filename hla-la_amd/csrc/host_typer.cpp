@@ -104,7 +104,7 @@ struct hlala_locus {
 extern "C" const char* hlala_typer_last_error(void) { return g_err.c_str(); }
 
 extern "C" int hlala_typer_open(const char* graph_dir, hlala_typer** out)
-{
+try {
     if(!graph_dir || !out) return fail(HLALA_E_ARG, "hlala_typer_open: null argument");
     std::unique_ptr<hlala_typer> T(new hlala_typer());
     T->graphDir = graph_dir;
@@ -152,24 +152,24 @@ extern "C" int hlala_typer_open(const char* graph_dir, hlala_typer** out)
     closedir(d);
     *out = T.release();
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_typer_open: ") + e_.what(); return HLALA_E_ARG; }
 extern "C" void hlala_typer_close(hlala_typer* t) { delete t; }
 extern "C" int32_t hlala_typer_n_levels(const hlala_typer* t) { return t ? (int32_t)t->levelNames.size() : -1; }
 extern "C" const char* hlala_typer_level_name(const hlala_typer* t, int32_t level) { return (t && level >= 0 && level < (int)t->levelNames.size()) ? t->levelNames[level].c_str() : nullptr; }
 extern "C" int32_t hlala_typer_level_of(const hlala_typer* t, const char* id) { if(!t || !id) return -1; auto it = t->levelOf.find(id); return it == t->levelOf.end() ? -1 : it->second; }
 extern "C" int32_t hlala_typer_n_genes(const hlala_typer* t) { return t ? (int32_t)t->geneNames.size() : -1; }
 extern "C" int hlala_typer_gene(const hlala_typer* t, int32_t i, const char** name, int32_t* first_level, int32_t* last_level)
-{
+try {
     if(!t || i < 0 || i >= (int)t->geneNames.size()) return HLALA_E_ARG;
     if(name) *name = t->geneNames[i].c_str();
     if(first_level) *first_level = t->geneFirst[i];
     if(last_level) *last_level = t->geneLast[i];
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_typer_gene: ") + e_.what(); return HLALA_E_ARG; }
 
 // ---- G groups, hla/HLATyper.cpp:4150-4207
 extern "C" int hlala_typer_load_g_groups(hlala_typer* t, const char* path)
-{
+try {
     if(!t || !path) return fail(HLALA_E_ARG, "hlala_typer_load_g_groups: null argument");
     std::vector<std::string> lines;
     if(!read_lines(path, lines)) return fail(HLALA_E_ARG, std::string("Can't open file ") + path);
@@ -187,7 +187,7 @@ extern "C" int hlala_typer_load_g_groups(hlala_typer* t, const char* path)
         for(const std::string& a : split(c[1], "/")) t->alleleToG[locusStar + a] = code;
     }
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_typer_load_g_groups: ") + e_.what(); return HLALA_E_ARG; }
 
 namespace {
 // translate_allele_list_to_G_allele, hla/HLATyper.cpp:4095-4148
@@ -230,7 +230,7 @@ std::string find_exon_file(const hlala_typer& T, const std::string& locus, const
 }  // namespace
 
 extern "C" int hlala_typer_locus(const hlala_typer* t, const char* locus, int32_t n_exons, const char* const* exon_ids, hlala_locus** out)
-{
+try {
     if(!t || !locus || !out) return fail(HLALA_E_ARG, "hlala_typer_locus: null argument");
     std::vector<std::string> exons;
     if(exon_ids) for(int i = 0; i < n_exons; i++) exons.push_back(exon_ids[i]);
@@ -293,23 +293,23 @@ extern "C" int hlala_typer_locus(const hlala_typer* t, const char* locus, int32_
     for(const auto& c : clusters) { L->members.emplace_back(c.begin(), c.end()); L->clusterId.push_back(join(L->members.back(), ";")); }
     *out = L.release();
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_typer_locus: ") + e_.what(); return HLALA_E_ARG; }
 extern "C" void hlala_locus_free(hlala_locus* l) { delete l; }
 extern "C" int hlala_locus_get(const hlala_locus* l, hlala_locus_info* o)
-{
+try {
     if(!l || !o) return HLALA_E_ARG;
     o->n_clusters = l->C; o->n_columns = l->P; o->n_exons = (int32_t)l->exonLength.size(); o->level_min = l->levelMin; o->level_max = l->levelMax; o->n_types = l->nTypes;
     o->cluster_seq = l->clusterSeq.data(); o->level_to_exon = l->levelToExon.data(); o->col_level = l->colLevel.data(); o->col_exon = l->colExon.data();
     o->col_exon_pos = l->colExonPos.data(); o->exon_length = l->exonLength.data();
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_locus_get: ") + e_.what(); return HLALA_E_ARG; }
 extern "C" const char* hlala_locus_cluster_id(const hlala_locus* l, int32_t c) { return (l && c >= 0 && c < l->C) ? l->clusterId[c].c_str() : nullptr; }
 extern "C" int32_t hlala_locus_type_cluster(const hlala_locus* l, const char* type) { if(!l || !type) return -1; auto it = l->typeCluster.find(type); return it == l->typeCluster.end() ? -1 : it->second; }
 
 // k-mers of one cluster's sequence, exon by exon with gaps removed (calculcatekMerPresence, hla/HLATyper.cpp:2652-2688): n_total counts
 // every k-mer, the ones without '*' are written to `queries` (k characters each) for hlala_kmer_presence
 extern "C" int hlala_locus_cluster_kmers(const hlala_locus* l, int32_t cluster, int32_t k, char* queries, int32_t cap_queries, int32_t* n_queries, int32_t* n_total)
-{
+try {
     if(!l || cluster < 0 || cluster >= l->C || k <= 0 || !n_queries || !n_total) return HLALA_E_ARG;
     int nq = 0, nt = 0; bool overflow = false;
     const uint8_t* s = l->clusterSeq.data() + (size_t)cluster * l->P;
@@ -327,11 +327,11 @@ extern "C" int hlala_locus_cluster_kmers(const hlala_locus* l, int32_t cluster, 
     }
     *n_queries = nq; *n_total = nt;
     return overflow ? HLALA_E_CAPACITY : HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_locus_cluster_kmers: ") + e_.what(); return HLALA_E_ARG; }
 
 // ---- result files ------------------------------------------------------------------------------------------------------------
 extern "C" int hlala_typer_begin_output(const char* out_dir, double unaccounted_min_fraction)
-{
+try {
     if(!out_dir) return fail(HLALA_E_ARG, "hlala_typer_begin_output: null argument");
     struct stat sb;
     if(stat(out_dir, &sb) != 0 && mkdir(out_dir, 0775) != 0) return fail(HLALA_E_ARG, std::string("cannot create ") + out_dir);
@@ -344,21 +344,21 @@ extern "C" int hlala_typer_begin_output(const char* out_dir, double unaccounted_
     if(!hst.is_open()) return fail(HLALA_E_ARG, std::string("cannot write to ") + out_dir);
     hst << "Locus" << "\t" << "Level" << "Value" << "\n";                                            // sic, hla/HLATyper.cpp:1145
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_typer_begin_output: ") + e_.what(); return HLALA_E_ARG; }
 extern "C" int hlala_typer_end_output(const char* out_dir, const char* loci_comma_separated, int32_t very_conservative_read_likelihoods)
-{
+try {
     if(!out_dir || !loci_comma_separated) return fail(HLALA_E_ARG, "hlala_typer_end_output: null argument");
     std::ofstream p((std::string(out_dir) + "/R1_parameters.txt").c_str());
     if(!p.is_open()) return fail(HLALA_E_ARG, std::string("cannot write to ") + out_dir);
     p << "Loci" << " = " << loci_comma_separated << "\n";
     p << "veryConservativeReadLikelihoods" << " = " << (very_conservative_read_likelihoods != 0) << "\n";
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_typer_end_output: ") + e_.what(); return HLALA_E_ARG; }
 
 // summaryStatistics.txt, hla/HLATyper.cpp:1030-1125
 extern "C" int hlala_typer_write_summary(const char* out_dir, int32_t n_units, int32_t unpaired, const uint8_t* unit_mask, const hlala_unit_stats_out* st,
                                          double insert_mean, double insert_sd, int32_t min_alignment_length_unpaired)
-{
+try {
     if(!out_dir || !st || n_units < 0) return fail(HLALA_E_ARG, "hlala_typer_write_summary: null argument");
     size_t nPaired = 0, nUnpaired = 0;
     int strandsValid = 0, pairedPerfect = 0, oneReadPerfect = 0, unpairedPerfect = 0, strandsValidDistanceOK = 0, unpairedLongEnough = 0;
@@ -408,10 +408,10 @@ extern "C" int hlala_typer_write_summary(const char* out_dir, int32_t n_units, i
     o << "\t\t - Single alignments, perfect (total):   " << unpairedPerfect << " (" << nUnpaired * 2 << ")\n";
     o << "\t\t - Alignments with length >= " << min_alignment_length_unpaired << ":   " << unpairedLongEnough << "\n";
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_typer_write_summary: ") + e_.what(); return HLALA_E_ARG; }
 
 extern "C" int hlala_locus_write_files(const hlala_locus* L, const hlala_locus_report_in* in, const char* out_dir, hlala_locus_report_out* res)
-{
+try {
     if(!L || !in || !out_dir || !in->pos || !in->filter || !in->call) return fail(HLALA_E_ARG, "hlala_locus_write_files: null argument");
     const hlala_exon_positions_out* pos = in->pos;
     const int nReads = pos->n_reads, nPos = pos->n_pos, P = L->P, C = L->C;
@@ -586,4 +586,4 @@ extern "C" int hlala_locus_write_files(const hlala_locus* L, const hlala_locus_r
         res->n_piled_positions = bOff[P];
     }
     return HLALA_OK;
-}
+} catch(const std::exception& e_) { g_err = std::string("hlala_locus_write_files: ") + e_.what(); return HLALA_E_ARG; }

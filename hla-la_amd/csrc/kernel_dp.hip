@@ -44,10 +44,12 @@ constexpr u64 HKEY_EMPTY = ~0ull;
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows per trip of the persistent loop (measured: 3 -> 236 ms, 6 -> 231, 12 -> 226, 24 -> 225, 64 -> 224 per 524 k pairs)
 
-struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; };
-struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; };
-struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; };
-struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; };
+struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; };
+struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; };
+struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; };
+// (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and
+//  thousands of sequence-complete cells per DP were measured -- are what the large class is sized for; its table slots are ints)
+struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; };
 
 // State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
 // that only the phase has to stay in registers across the states of the persistent loop.
@@ -72,9 +74,9 @@ struct __align__(16) DpLdsT {
     typename C::Best hbest[3][C::HC];
     typename TlistT<(C::HC <= 256)>::type tlist[C::HC];     // hash entries in use this iteration
     u64 fkey[3][C::WCAP];
-    short fslot[3][C::WCAP];        // table slot of the frontier cell
+    typename C::Slot fslot[3][C::WCAP];        // table slot of the frontier cell
     short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
-    short tes[C::HC];               // per target: existing / assigned table slot (-1 = none; CELLS <= 32767)
+    typename C::Slot tes[C::HC];    // per target: existing / assigned table slot (-1 = none), or -2 - (claimed early-hash entry)
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     int nNew, nImp, nKeepF, err, nCompletedAdd;
     int nextPhase;                                    // state after PH_DONE: idle, or the end-cell choice of a linked duplicate
@@ -207,12 +209,12 @@ __device__ __forceinline__ u32 hash64(u64 k)
     return h ^ (h >> 6) ^ (h >> 12);
 }
 
-// back pointer: previous cell slot (15 bits, CELLS <= 32768) | source matrix (2) | kind (3) | local push index j (8; 0xFF = none)
-__device__ __forceinline__ u32 mk_bt(int prev, int src, int kind, int edge) { return (u32)prev | ((u32)src << 15) | ((u32)kind << 17) | (((u32)edge & 0xFFu) << 20); }
-__device__ __forceinline__ int bt_prev(u32 b) { return (int)(b & 0x7FFF); }
-__device__ __forceinline__ int bt_src(u32 b) { return (int)((b >> 15) & 3); }
-__device__ __forceinline__ int bt_kind(u32 b) { return (int)((b >> 17) & 7); }
-__device__ __forceinline__ int bt_edge(u32 b) { return (int)((b >> 20) & 0xFF); }
+// back pointer: previous cell slot (17 bits, CELLS <= 131072) | source matrix (2) | kind (3) | local push index j (8; 0xFF = none)
+__device__ __forceinline__ u32 mk_bt(int prev, int src, int kind, int edge) { return (u32)prev | ((u32)src << 17) | ((u32)kind << 19) | (((u32)edge & 0xFFu) << 22); }
+__device__ __forceinline__ int bt_prev(u32 b) { return (int)(b & 0x1FFFF); }
+__device__ __forceinline__ int bt_src(u32 b) { return (int)((b >> 17) & 3); }
+__device__ __forceinline__ int bt_kind(u32 b) { return (int)((b >> 19) & 7); }
+__device__ __forceinline__ int bt_edge(u32 b) { return (int)((b >> 22) & 0xFF); }
 
 
 // candidate value: (score, reversed push index) so that an unsigned max = highest score, earliest push
@@ -418,10 +420,8 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         // '_' edge, :738-752); 5 = first gap-path jump (:757-786, jump_length * S_graphGap = 0)
         const int ord0 = (1 << (C::IBITS + 8)) | (i << 8);
         const int nyG = pyB + dir, nxB = pxB + dir;
-        const bool okA = doA && degA <= 127;
-        const bool okB = hasB && degB <= 127 && (j1 - j0) <= 127;
+        const bool okA = doA, okB = hasB;            // (degrees and jump counts fit the push index: checked once in hlala_create, DP_MAX_DEGREE)
         const bool sgB = okB && nxB >= 0 && nxB <= max_levelI;
-        if((doA && !okA) || (hasB && !okB)) S.err = __LINE__;
         typedef typename C::Best BestT;
         {   // batch 1: both edges of the m-2 entry, the graph gap
             bool cv[3]; u64 ck[3]; u32 ch[3]; u64 cold[3];
@@ -539,7 +539,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     else if(found) { es = __hip_atomic_load(&sl.early_val()[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = es; }
                     else v = -2 - pos;
                 }
-                S.tes[t] = (short)v;
+                S.tes[t] = (typename C::Slot)v;
             }
             if(grp_ballot<GW>(es >= 0)) anyExisting = true;
         }
@@ -650,7 +650,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             }
             if(pass == 0 && slow) {
                 // exact diff needs every staged improvement of the iteration: finish in the second pass
-                if(act) { S.tes[t] = (short)slot; S.timp[t] = (unsigned char)(impMask | (isNew ? 0x80 : 0)); }
+                if(act) { S.tes[t] = (typename C::Slot)slot; S.timp[t] = (unsigned char)(impMask | (isNew ? 0x80 : 0)); }
                 continue;
             }
             if(grp_ballot<GW>(impMask != 0)) anyOw = true;
@@ -744,7 +744,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             const u64 m = grp_ballot<GW>(pass);
             const int pos = nNew + __popcll(m & ((1ull << gl) - 1ull));
             if(pass && pos < C::WCAP) {
-                S.fkey[bn][pos] = key; S.fslot[bn][pos] = (short)(int)S.hbest[0][h];
+                S.fkey[bn][pos] = key; S.fslot[bn][pos] = (typename C::Slot)(int)S.hbest[0][h];
                 S.fD[bn][pos] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][pos] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][pos] = (short)((u32)S.hbest[2][h] & 0xFFFF);
             }
             nNew += __popcll(m);
@@ -753,7 +753,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         WSYNC();
         if(nNew > 1) {
             const bool act = gl < nNew;
-            u64 key = 0; short vs = 0, vD = 0, vG = 0, vS = 0; int rank = 0;
+            u64 key = 0; typename C::Slot vs = 0; short vD = 0, vG = 0, vS = 0; int rank = 0;
             if(act) {
                 key = S.fkey[bn][gl]; vs = S.fslot[bn][gl]; vD = S.fD[bn][gl]; vG = S.fG[bn][gl]; vS = S.fS[bn][gl];
                 for(int u = 0; u < nNew; u++) rank += (S.fkey[bn][u] < key) ? 1 : 0;
@@ -776,7 +776,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     if((mx - vu) <= 15 && S.hkey[hu] < key) rank++;
                 }
                 if(rank < C::WCAP) {
-                    S.fkey[bn][rank] = key; S.fslot[bn][rank] = (short)(int)S.hbest[0][h];
+                    S.fkey[bn][rank] = key; S.fslot[bn][rank] = (typename C::Slot)(int)S.hbest[0][h];
                     S.fD[bn][rank] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][rank] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][rank] = (short)((u32)S.hbest[2][h] & 0xFFFF);
                 }
             }

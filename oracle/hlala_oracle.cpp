@@ -310,6 +310,7 @@ struct Aligner {
     /* alignerBase::alignerBase, mapper/aligner/alignerBase.cpp:19-25 */
     double S_match = 2, S_mismatch = -5, S_gap = -2, S_graphGap = 0, S_openGap = -4, S_extendGap = -2;
     long long stat_cells = 0, stat_iters = 0, stat_calls = 0, stat_edges = 0;
+    long long max_frontier = 0, max_targets = 0, max_kept_cells = 0, max_completed = 0;     /* largest per-call sizes seen (capacity planning of the GPU classes) */
     bool h4_hit = false;
 
     explicit Aligner(const Graph* g_) : g(g_) {}
@@ -548,10 +549,14 @@ struct Aligner {
                     if((mx - scores.at(c).D) <= threshold_for_filtering) filtered.push_back(c);
                 m_thisDiagonal = filtered;
             }
+            if((long long)thisDiagonal.size() > max_targets) max_targets = (long long)thisDiagonal.size();
+            if((long long)m_thisDiagonal.size() > max_frontier) max_frontier = (long long)m_thisDiagonal.size();
             m2_diagonal = m1_diagonal;                                               /* :1104-1105 */
             m1_diagonal = m_thisDiagonal;
         }
         stat_iters += itersRun;
+        if((long long)scores_backtrace.size() > max_kept_cells) max_kept_cells = (long long)scores_backtrace.size();
+        if((long long)achieved_complete_sequence_alignments.size() > max_completed) max_completed = (long long)achieved_complete_sequence_alignments.size();
 
         /* backtraceFrom, :1109-1354 */
         auto backtraceFrom = [&](int start_x, int start_y, int start_z, double StartScore) -> Ext {
@@ -1177,6 +1182,15 @@ orc_handle* orc_create(const hlala_graph_desc* graph, const hlala_contigs_desc* 
     } catch(std::exception& e) { g_err = e.what(); return nullptr; }
 }
 void orc_destroy(orc_handle* h) { if(h) { delete h->P.eA; delete h; } }
+
+/* largest frontier / candidate-cell set / kept-cell table / sequence-complete set of any DP call so far; reset != 0 clears them */
+int orc_dp_maxima(orc_handle* h, int64_t* out4, int reset)
+{
+    Aligner& A = *h->P.eA;
+    out4[0] = A.max_frontier; out4[1] = A.max_targets; out4[2] = A.max_kept_cells; out4[3] = A.max_completed;
+    if(reset) A.max_frontier = A.max_targets = A.max_kept_cells = A.max_completed = 0;
+    return 0;
+}
 
 int orc_graph_info(orc_handle* h, hlala_graph_info* info)
 {

@@ -80,6 +80,13 @@ class Oracle:
         if rc != 0:
             raise OracleError(lib().orc_last_error().decode())
 
+    def dp_maxima(self, reset=False):
+        """Largest frontier, candidate-cell set, kept-cell table and sequence-complete set of any DP call so far."""
+        a = np.zeros(4, np.int64)
+        lib().orc_dp_maxima.argtypes = [C.c_void_p, P.c_i64p, C.c_int]
+        lib().orc_dp_maxima(self.h, a.ctypes.data_as(P.c_i64p), int(reset))
+        return dict(frontier=int(a[0]), targets=int(a[1]), kept_cells=int(a[2]), completed=int(a[3]))
+
     def graph_info(self):
         gi = P.GraphInfo()
         lib().orc_graph_info(self.h, C.byref(gi))

@@ -1,0 +1,177 @@
+"""Graph M: the allele-rich regime -- gene windows with hundreds to thousands of allele paths merged by the suffix
+rule of Graph::buildFromHaplotypes (Graph/Graph.cpp:846-1026), levels with >= 50 nodes, node ranks z >= 10 -- on which HLA typing
+actually depends and which the simpleGraphSimulator-style worlds of the other tests (<= 7 haplotypes) never reach.
+
+CPU part: the generator's invariants, the one-time host flatten against the oracle, and the oracle against the TRUTH the simulator
+knows (the reference's own accuracy metric: fraction of read bases placed on their true graph level, simulator/trueReadLevels.cpp:18-196)
+-- an oracle-independent check.  GPU part: bit-exact parity of the product with the oracle on gene-window reads with all four
+DP capacity classes exercised, and the same truth metric for the product.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_host_flatten import hostlib  # noqa: F401  (fixture)
+from tools import synth
+from util import compare_chains
+
+SMALL = dict(seed=7, n_levels=60_000, n_windows=3, alleles=(400, 3000))
+
+
+@pytest.fixture(scope="module")
+def world_m():
+    return synth.make_world_m(**SMALL)
+
+
+def truth_accuracy(b, pairs, stride, mask=None):
+    """Fraction of read bases the chosen alignment puts on their true level (trueReadLevels.cpp: read base i of the alignment vs the
+    level the simulator drew it from; inserted bases have no true level and are not counted).  mask: per-pair selector."""
+    ok = tot = 0
+    for p in range(b["n_pairs"]):
+        if mask is not None and not mask[p]:
+            continue
+        if pairs["pair_status"][p] != 0:
+            continue
+        for m in range(2):
+            r = 2 * p + m; n = int(pairs["n_cols"][r])
+            lv = pairs["col_level"][r * stride:r * stride + n]; sc = pairs["col_schar"][r * stride:r * stride + n]
+            al = lv[sc != ord("_")]
+            tl = b["truth_level"][b["read_off"][r]:b["read_off"][r + 1]]
+            assert len(al) == len(tl)
+            ok += int(((al == tl) & (tl >= 0)).sum()); tot += int((tl >= 0).sum())
+    return ok / max(1, tot)
+
+
+def test_generator_structure(world_m):
+    g = world_m["graph"]; npl = world_m["nodes_per_level"]
+    assert g["n_levels"] == SMALL["n_levels"] + 1
+    # levelled DAG in level-major creation order
+    lf = g["node_level"][g["edge_from"]]; lt = g["node_level"][g["edge_to"]]
+    assert np.all(lt == lf + 1) and np.all(np.diff(g["node_level"]) >= 0) and np.all(np.diff(lf) >= 0)
+    assert npl.sum() == g["n_nodes"] and npl.min() >= 1
+    # every node has an in- and an out-edge (except the two ends)
+    outdeg = np.bincount(g["edge_from"], minlength=g["n_nodes"]); indeg = np.bincount(g["edge_to"], minlength=g["n_nodes"])
+    assert np.all(outdeg[:-1] >= 1) and np.all(indeg[1:] >= 1)
+    # the regime the round-1 tests never saw
+    assert (npl >= 50).sum() >= 100 and npl.max() >= 100, "no allele-rich levels"
+    w = world_m["windows"]
+    for k in range(len(w["first_level"])):
+        assert npl[w["first_level"][k]] == 1 and npl[w["last_level"][k] + 1] == 1          # segments meet in single nodes
+    # contigs spell paths of the graph: levels strictly ascending, bases over ACGT
+    c = world_m["contigs"]
+    for i in (0, 7, c["n_contigs"] - 1):
+        lv = c["contig_level"][c["contig_off"][i]:c["contig_off"][i + 1]]
+        assert np.all(np.diff(lv) > 0)
+    assert set(np.unique(c["contig_seq"]).tolist()) <= set(b"ACGT")
+    # suffix rule, spot check: two alleles of a window share the node at level l+1 if their next 10 symbols agree (and none is a gap)
+    M, ex = synth.window_matrix(world_m, 1)
+    assert M.shape[0] == w["n_alleles"][1] and ex.max() == 2
+    # deterministic
+    w2 = synth.make_world_m(**SMALL)
+    for k in ("node_level", "edge_from", "edge_to", "edge_label"):
+        assert np.array_equal(w2["graph"][k], g[k])
+
+
+def test_batch_generator(world_m):
+    b = synth.make_batch_m(world_m, 500, seed=3, frac_gene=0.5)
+    assert b["n_pairs"] == 500 and len(b["read_primary"]) == 1000 and b["chain_off"][-1] == b["n_chains"]
+    assert (b["read_window"] >= 0).mean() >= 0.45
+    prim = b["read_primary"]
+    assert np.all(prim >= b["chain_off"][:-1]) and np.all(prim < b["chain_off"][1:])
+    # AS-descending per read (processBAM.cpp:1945-1967), CIGARs consume the whole read
+    ops = b["cigar"] & 15; lens = b["cigar"] >> 4
+    for r in range(0, 1000, 37):
+        a = b["chain_as"][b["chain_off"][r]:b["chain_off"][r + 1]]
+        assert np.all(np.diff(a) <= 0)
+        for c in range(b["chain_off"][r], b["chain_off"][r + 1]):
+            o = ops[b["cigar_off"][c]:b["cigar_off"][c + 1]]; l = lens[b["cigar_off"][c]:b["cigar_off"][c + 1]]
+            assert int(l[(o == 0) | (o == 1) | (o == 4)].sum()) == 150
+            assert o[0] in (0, 4) and o[-1] in (0, 4)
+    # qualities come from the empirical matrix: '#' .. 'J'
+    assert b["read_quals"].min() >= ord("#") and b["read_quals"].max() <= ord("J")
+    b2 = synth.make_batch_m(world_m, 500, seed=3, frac_gene=0.5)
+    assert np.array_equal(b2["read_bases"], b["read_bases"]) and np.array_equal(b2["cigar"], b["cigar"])
+
+
+def test_flatten_matches_oracle_on_graph_m(pkg, oracle, hostlib, world_m):  # noqa: F811
+    g, k1 = pkg.fill_struct(pkg.GraphDesc, world_m["graph"]); c, k2 = pkg.fill_struct(pkg.ContigsDesc, world_m["contigs"])
+    F = hostlib.hlala_host_flatten(C.byref(g), C.byref(c))
+    assert F, hostlib.hlala_host_last_error()
+    o = oracle(world_m["graph"], world_m["contigs"])
+    gi = pkg.GraphInfo(); hostlib.hlala_host_info(F, C.byref(gi)); oi = o.graph_info()
+    for f, _ in pkg.GraphInfo._fields_:
+        assert getattr(gi, f) == getattr(oi, f), f
+    assert gi.max_nodes_per_level == world_m["max_nodes_per_level"] >= 100
+    a = [np.zeros(gi.n_paths, np.int32) for _ in range(3)]
+    hostlib.hlala_host_paths(F, *[x.ctypes.data_as(pkg.c_i32p) for x in a])
+    for x, y in zip(a, o.graph_paths()):
+        assert np.array_equal(x, y)
+    gs = np.zeros(gi.n_levels - 1, np.uint8); hostlib.hlala_host_gap_stretch(F, gs.ctypes.data_as(pkg.c_u8p))
+    assert np.array_equal(gs, o.graph_gap_stretch()) and gs.sum() > 0
+    hostlib.hlala_host_free(F)
+
+
+def test_oracle_recovers_true_levels(oracle, world_m):
+    """Oracle-independent evidence: the restatement places >= 99 % of the read bases on the level they were simulated from, in the
+    backbone and inside the gene windows (reads from allele rows that have no contig of their own)."""
+    b = synth.make_batch_m(world_m, 400, seed=11, frac_gene=0.5)
+    r = oracle(world_m["graph"], world_m["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=5).align_batch(b)
+    assert np.all(r["pairs"]["pair_status"] == 0)
+    gene = b["read_window"] >= 0
+    acc_all = truth_accuracy(b, r["pairs"], 384); acc_gene = truth_accuracy(b, r["pairs"], 384, gene)
+    assert acc_all >= 0.99 and acc_gene >= 0.99, (acc_all, acc_gene)
+    # paranoid invariants of the reference on every selected chain: mapQ in [0, 1], mate mapQ >= pair mapQ
+    assert np.all(r["pairs"]["pair_mapq"] <= 1.0 + 1e-12) and np.all(r["pairs"]["mate_mapq"] >= np.repeat(r["pairs"]["pair_mapq"], 2) - 1e-9)
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+
+PAIR_INT = ("pair_status", "best_chain", "n_combinations", "strands_valid", "n_cols", "col_level", "col_edge",
+            "col_gchar", "col_schar", "col_fromseed", "col_mapq")
+
+
+def gpu_vs_oracle(pkg, oracle, w, b, rng_seed=99):
+    kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=rng_seed, max_columns=384)
+    exp = oracle(w["graph"], w["contigs"], **kw).align_batch(b)
+    ctx = pkg.Context(w["graph"], w["contigs"], **kw)
+    gb = ctx.batch(b); gb.align()
+    compare_chains(gb.chains(0), exp["seeds"], b["n_chains"], check_ll=False, check_dp=False, label="stage A")
+    compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stage B")
+    got = gb.pairs(); ep = exp["pairs"]
+    for k in PAIR_INT:
+        assert np.array_equal(got[k], ep[k]), k
+    assert np.allclose(got["pair_ll"], ep["pair_ll"], rtol=1e-12, atol=0)
+    assert np.allclose(got["pair_mapq"], ep["pair_mapq"], rtol=1e-9, atol=1e-15)
+    assert np.allclose(got["mate_mapq"], ep["mate_mapq"], rtol=1e-9, atol=1e-15)
+    st = gb.stats()
+    assert st.n_errors == 0
+    assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
+    return got, st, exp
+
+
+@pytest.mark.gpu
+def test_gene_window_reads_match_oracle(pkg, oracle, world_m):
+    """Reads from allele rows of the gene windows only: levels with >= 50 nodes, ranks z >= 10, every DP class."""
+    b = synth.make_batch_m(world_m, 1500, seed=21, frac_gene=1.0)
+    got, st, exp = gpu_vs_oracle(pkg, oracle, world_m, b)
+    # the selected alignments really sit on allele-rich levels and high ranks
+    npl = world_m["nodes_per_level"]; stride = 384
+    valid = (np.arange(stride)[None, :] < got["n_cols"][:, None]).reshape(-1)
+    lv = got["col_level"][valid]; lv = lv[lv >= 0]
+    assert (npl[lv] >= 50).sum() > 2000, "selected alignments do not touch allele-rich levels"
+    g = world_m["graph"]; level_first = np.concatenate([[0], np.cumsum(npl)])
+    ed = got["col_edge"][valid]; ed = ed[ed >= 0]
+    z = g["edge_to"][ed] - level_first[g["node_level"][g["edge_to"][ed]]]
+    assert z.max() >= 50 and (z >= 10).sum() > 2000
+    cls = list(st.n_dp_class)
+    assert all(c > 0 for c in cls), f"DP classes entered (16-lane, 32-lane, 64-lane, large): {cls}"
+    assert truth_accuracy(b, got, 384) >= 0.99
+
+
+@pytest.mark.gpu
+def test_mixed_reads_match_oracle(pkg, oracle, world_m):
+    b = synth.make_batch_m(world_m, 2000, seed=22, frac_gene=0.3)
+    got, st, exp = gpu_vs_oracle(pkg, oracle, world_m, b, rng_seed=4)
+    gene = b["read_window"] >= 0
+    assert truth_accuracy(b, got, 384, gene) >= 0.99 and truth_accuracy(b, got, 384, ~gene) >= 0.99

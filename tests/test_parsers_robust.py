@@ -47,6 +47,29 @@ def test_damaged_bam_files(pkg, plib, tmp_path):
     assert err > 10          # truncations and broken blocks are noticed (CRC / sizes); harmless flips may pass
 
 
+def test_bgzf_block_size_smaller_than_header(pkg, plib, tmp_path):
+    """A BC field below the size of the block's own header (here BSIZE = 5) used to underflow the payload length and abort the process
+    with an exception thrown across the C boundary; huge header / record lengths must be refused the same way."""
+    import struct
+    rng = np.random.default_rng(5)
+    refs, recs = make_records(rng, n_names=5)
+    good = tmp_path / "g.bam"; write_bam(good, refs, recs, block=900)
+    data = bytearray(good.read_bytes())
+    assert data[12:14] == b"BC"
+    intervals = [("chr6", 10000, 20000, 0), ("HLA-A*01", 0, 3999, 1)]
+    for bsize in (0, 5, 17, 24):
+        m = bytearray(data); m[16:18] = struct.pack("<H", bsize)
+        p = tmp_path / "b.bam"; p.write_bytes(bytes(m))
+        with pytest.raises(pkg.HlalaError):
+            pkg.bam_extract_seeds(plib, p, intervals)
+    # l_text of 2 GB in an otherwise valid first block
+    from test_bam import bgzf_block
+    raw = b"BAM\x01" + struct.pack("<i", 0x7FFFFFF0) + b"x" * 64
+    p = tmp_path / "t.bam"; p.write_bytes(bgzf_block(raw) + bgzf_block(b""))
+    with pytest.raises(pkg.HlalaError):
+        pkg.bam_extract_seeds(plib, p, intervals)
+
+
 def test_damaged_graph_and_contig_files(pkg, plib, tmp_path):
     rng = np.random.default_rng(5)
     w = synth.make_world(seed=2, G=120, k=1)

@@ -468,3 +468,125 @@ def make_long_batch(world, n_reads, seed=5, len_lo=2000, len_hi=10000, sub=0.05,
                 n_chains=len(ch["pos"]), chain_contig=np.asarray(ch["contig"], np.int32), chain_pos=np.asarray(ch["pos"], np.int32),
                 chain_offset=np.asarray(ch["offset"], np.int32), chain_as=np.asarray(ch["AS"], np.int32), chain_reverse=np.asarray(ch["rev"], np.uint8),
                 cigar_off=cigar_off, cigar=cigar)
+
+
+# --------------------------------------------------------------------------- Graph M (tools/graphm/graphm.cpp)
+
+import ctypes as _C
+import os as _os
+import subprocess as _subprocess
+
+_GM = None
+_ROOT = _os.path.dirname(_os.path.abspath(__file__))
+QUALITY_MATRIX = _os.path.join(_ROOT, "data", "I101_NA12878.txt")
+
+
+class _GmParams(_C.Structure):
+    _fields_ = [("seed", _C.c_uint64), ("n_levels", _C.c_longlong), ("n_backbone", _C.c_int), ("backbone_div", _C.c_double),
+                ("gap_stretch_frac", _C.c_double), ("n_windows", _C.c_int), ("win_len_min", _C.c_int), ("win_len_max", _C.c_int),
+                ("alleles_min", _C.c_int), ("alleles_max", _C.c_int), ("exon_site_density", _C.c_double),
+                ("intron_site_density", _C.c_double), ("private_rate", _C.c_double), ("suffix_len", _C.c_int),
+                ("contigs_per_window", _C.c_int), ("threads", _C.c_int), ("hyper_site_density", _C.c_double)]
+
+
+class _GmBatchParams(_C.Structure):
+    _fields_ = [("seed", _C.c_uint64), ("n_pairs", _C.c_int), ("read_len", _C.c_int), ("jump_mean", _C.c_double), ("jump_sd", _C.c_double),
+                ("clip_max", _C.c_int), ("p_no_clip", _C.c_double), ("frac_gene", _C.c_double), ("p_secondary", _C.c_double),
+                ("max_secondary", _C.c_int), ("p_random_secondary", _C.c_double), ("p_wrong_strand", _C.c_double), ("p_flip", _C.c_double),
+                ("gene_candidates", _C.c_int)]
+
+
+def _gm():
+    global _GM
+    if _GM is None:
+        so = _os.path.join(_ROOT, "_build", "libgraphm.so")
+        src = _os.path.join(_ROOT, "graphm", "graphm.cpp")
+        if not _os.path.exists(so) or _os.path.getmtime(so) < _os.path.getmtime(src):
+            _subprocess.check_call(["make", "-s", "-C", _os.path.join(_ROOT, "graphm")])
+        L = _C.CDLL(so)
+        L.gm_world_create.restype = _C.c_void_p; L.gm_world_create.argtypes = [_C.POINTER(_GmParams)]
+        L.gm_world_destroy.argtypes = [_C.c_void_p]
+        L.gm_last_error.restype = _C.c_char_p
+        vp = _C.c_void_p
+        L.gm_world_sizes.argtypes = [vp, vp]; L.gm_world_graph.argtypes = [vp] * 5; L.gm_world_contigs.argtypes = [vp] * 6
+        L.gm_world_windows.argtypes = [vp] * 5; L.gm_world_window_matrix.argtypes = [vp, _C.c_int, vp, vp]; L.gm_world_nodes_per_level.argtypes = [vp, vp]
+        L.gm_batch_create.restype = vp; L.gm_batch_create.argtypes = [vp, _C.POINTER(_GmBatchParams), _C.c_char_p]
+        L.gm_batch_destroy.argtypes = [vp]; L.gm_batch_sizes.argtypes = [vp, vp]; L.gm_batch_get.argtypes = [vp] * 14
+        _GM = L
+    return _GM
+
+
+class _GmWorldHandle:
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                _gm().gm_world_destroy(self.h)
+        except Exception:
+            pass
+
+
+def make_world_m(seed=2, n_levels=5_000_000, n_backbone=8, backbone_div=0.003, gap_stretch_frac=0.02, n_windows=40,
+                 win_len=(3000, 6000), alleles=(500, 5000), exon_site_density=0.35, intron_site_density=0.04, private_rate=0.001,
+                 suffix_len=10, contigs_per_window=24, threads=0, hyper_site_density=0.6):
+    """Graph M of SURVEY.md 8(d): backbone haplotypes + gene windows with hundreds to thousands of allele paths, nodes merged
+    by the suffix rule of Graph::buildFromHaplotypes (tools/graphm/graphm.cpp).  Same dict layout as make_world, plus `windows`
+    (first / last level, alleles, exon columns per window), `nodes_per_level` and the generator handle for make_batch_m."""
+    L = _gm()
+    p = _GmParams(seed, n_levels, n_backbone, backbone_div, gap_stretch_frac, n_windows, win_len[0], win_len[1], alleles[0], alleles[1],
+                  exon_site_density, intron_site_density, private_rate, suffix_len, contigs_per_window, threads, hyper_site_density)
+    h = L.gm_world_create(_C.byref(p))
+    if not h:
+        raise RuntimeError("gm_world_create: " + L.gm_last_error().decode())
+    sz = np.zeros(8, np.int64); L.gm_world_sizes(h, sz.ctypes.data)
+    nL, N, E, nc, tb, nw, mx, nseg = [int(x) for x in sz]
+    node_level = np.zeros(N, np.int32); ef = np.zeros(E, np.int32); et = np.zeros(E, np.int32); el = np.zeros(E, np.uint8)
+    L.gm_world_graph(h, node_level.ctypes.data, ef.ctypes.data, et.ctypes.data, el.ctypes.data)
+    off = np.zeros(nc + 1, np.int64); seq = np.zeros(tb, np.uint8); lvl = np.zeros(tb, np.int32); cw = np.zeros(nc, np.int32); cr = np.zeros(nc, np.int32)
+    L.gm_world_contigs(h, off.ctypes.data, seq.ctypes.data, lvl.ctypes.data, cw.ctypes.data, cr.ctypes.data)
+    wf = np.zeros(nw, np.int32); wl = np.zeros(nw, np.int32); wa = np.zeros(nw, np.int32); we = np.zeros(nw, np.int32)
+    if nw:
+        L.gm_world_windows(h, wf.ctypes.data, wl.ctypes.data, wa.ctypes.data, we.ctypes.data)
+    npl = np.zeros(nL, np.int32); L.gm_world_nodes_per_level(h, npl.ctypes.data)
+    graph = dict(n_levels=nL, n_nodes=N, n_edges=E, node_level=node_level, edge_from=ef, edge_to=et, edge_label=el)
+    contigs = dict(n_contigs=nc, contig_off=off, contig_seq=seq, contig_level=lvl, contig_seqid=np.arange(1, nc + 1, dtype=np.int32))
+    return dict(graph=graph, contigs=contigs, G=nL - 1, windows=dict(first_level=wf, last_level=wl, n_alleles=wa, n_exon_cols=we),
+                contig_window=cw, contig_row=cr, nodes_per_level=npl, max_nodes_per_level=mx, _gm=_GmWorldHandle(h), kind="graph_m")
+
+
+def window_matrix(world, k):
+    """Aligned allele matrix [alleles, columns] of gene window k and its exon mask."""
+    w = world["windows"]; n = int(w["n_alleles"][k]); ln = int(w["last_level"][k] - w["first_level"][k] + 1)
+    M = np.zeros((n, ln), np.uint8); ex = np.zeros(ln, np.uint8)
+    _gm().gm_world_window_matrix(world["_gm"].h, k, M.ctypes.data, ex.ctypes.data)
+    return M, ex
+
+
+def make_batch_m(world, n_pairs, seed=3, read_len=150, jump_mean=350.0, jump_sd=35.0, clip_max=30, p_no_clip=0.15, frac_gene=0.3,
+                 p_secondary=0.5, max_secondary=4, p_random_secondary=0.1, p_wrong_strand=0.01, p_flip=0.5, gene_candidates=6):
+    """Read pairs + bwa-like seeds on a Graph M world (hlala_batch_in layout + truth): qualities / errors from the empirical matrix
+    tools/data/I101_NA12878.txt stretched to read_len, Poisson indels, start-to-start jump ~ N(jump_mean, jump_sd) (so the inner
+    distance the pairing step measures has mean jump_mean - read_len), at least frac_gene of the pairs drawn from allele rows of the
+    gene windows.  Extra keys: truth_level [bases] (level of every read base, -1 = inserted), read_window [pairs] (-1 = backbone only)."""
+    L = _gm()
+    bp = _GmBatchParams(seed, n_pairs, read_len, jump_mean, jump_sd, clip_max, p_no_clip, frac_gene, p_secondary, max_secondary,
+                        p_random_secondary, p_wrong_strand, p_flip, gene_candidates)
+    h = L.gm_batch_create(world["_gm"].h, _C.byref(bp), QUALITY_MATRIX.encode())
+    if not h:
+        raise RuntimeError("gm_batch_create: " + L.gm_last_error().decode())
+    try:
+        sz = np.zeros(4, np.int64); L.gm_batch_sizes(h, sz.ctypes.data)
+        nr, nb, nc, ncig = [int(x) for x in sz]
+        read_off = np.zeros(nr + 1, np.int32); bases = np.zeros(nb, np.uint8); quals = np.zeros(nb, np.uint8); tl = np.zeros(nb, np.int32)
+        rw = np.zeros(n_pairs, np.int32); chain_off = np.zeros(nr + 1, np.int32); prim = np.zeros(nr, np.int32)
+        cc = np.zeros(nc, np.int32); cp = np.zeros(nc, np.int32); cas = np.zeros(nc, np.int32); crev = np.zeros(nc, np.uint8)
+        cigar_off = np.zeros(nc + 1, np.int32); cigar = np.zeros(ncig, np.uint32)
+        L.gm_batch_get(h, read_off.ctypes.data, bases.ctypes.data, quals.ctypes.data, tl.ctypes.data, rw.ctypes.data, chain_off.ctypes.data,
+                       prim.ctypes.data, cc.ctypes.data, cp.ctypes.data, cas.ctypes.data, crev.ctypes.data, cigar_off.ctypes.data, cigar.ctypes.data)
+    finally:
+        L.gm_batch_destroy(h)
+    return dict(n_pairs=n_pairs, read_off=read_off, read_bases=bases, read_quals=quals, chain_off=chain_off, read_primary=prim, n_chains=nc,
+                chain_contig=cc, chain_pos=cp, chain_offset=np.zeros(nc, np.int32), chain_as=cas, chain_reverse=crev, cigar_off=cigar_off,
+                cigar=cigar, truth_level=tl, read_window=rw, insert_mean=float(jump_mean - read_len), insert_sd=float(jump_sd))
