@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- paired reads/s aligned to a PRG on N MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (stages A+B+C = processBAM::alignOneReadPair) over one batch of
-synthetic 2x150 bp pairs that is already resident in HBM.  N > 1: one process per GPU (torchrun), the
-pairs shard embarrassingly (weak scaling: every rank aligns its own batch), and the only exchange is one
-RCCL gather of the fixed-size per-pair records to rank 0, inside the timed region.
+A "step" is one pass of the hot path (stages A+B+C = processBAM::alignOneReadPair) over one batch of synthetic 2x150 bp pairs that
+is already resident in HBM.  N > 1: one process per GPU, the pairs shard embarrassingly (weak scaling: every rank aligns its own
+batch), and the only exchange is one RCCL gather of the fixed-size per-pair records to rank 0, inside the timed region.
+`python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run as a child process, before anything
+touches the GPU); under torchrun (WORLD_SIZE set) it is one of the ranks.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Workload: "Graph M" -- 5 M levels, 8 backbone haplotypes at 0.3 % divergence with 2 % gap stretches, 40 gene windows
+of 3-6 kb carrying 500-5000 allele paths merged by the suffix-10 rule -- and 2x150 bp pairs with qualities / errors from the
+reference's empirical matrix, Poisson indels, start-to-start jump N(350, 35), >= 30 % of the pairs from allele rows of the gene
+windows, bwa-like seeds (soft clips, secondary alignments on other contigs).  `--graph simple` selects the round-1 stand-in.
+
+Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline`.  Rank 0 at N = 1 additionally measures, outside the timed region:
+the host-buffer-inclusive rate (hlala_batch_create -> hlala_align_batch -> hlala_batch_get_pairs_packed), gene-window and backbone
+pairs separately, two-stream batch pipelining (--stream-batches), the typer kernels at C = 3000, and the CPU oracle on a bounded sample.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,13 +46,48 @@ def load_package():
     return mod
 
 
-def algorithmic_bytes_per_pair(read_len, chains_ext_per_pair, edges_per_chain, out_cols_per_mate):
-    """B_pair = 2(Lr/2 + Lr) + sum_chains[32 + 5 Lr + 5 * edges touched] + 2*7*(Lr+G) + 64,
-    with the measured number of extended chains per pair, CSR edge records touched per chain (= e(Lr+E)) and
-    output columns per mate (= Lr + G).  Every byte counted once."""
+def kernel_source_hash():
+    """sha1 over the kernel / API sources: measurements kept under profiles/ are tagged with it and dropped when it differs."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "hla-la_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def algorithmic_bytes_per_pair(read_len, chains_ext_per_pair, mean_out_degree, cols_per_chain, out_cols_per_mate):
+    """B_pair = 2(Lr/2 + Lr) + sum_chains[32 + 5 Lr + 5 e (Lr + E)] + 2*7*(Lr + G) + 64, every byte counted ONCE:
+    a chain touches the CSR edge records (label 1 B + target 4 B) of the levels it spans -- (Lr + E) = its columns -- times the
+    graph's mean out-degree e, however often the DP re-reads them."""
     return (2 * (read_len / 2 + read_len)
-            + chains_ext_per_pair * (32 + 5 * read_len + 5 * edges_per_chain)
+            + chains_ext_per_pair * (32 + 5 * read_len + 5 * mean_out_degree * cols_per_chain)
             + 2 * 7 * out_cols_per_mate + 64)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks as a child process tree (nothing has touched the GPU yet)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def make_workload(args, synth, rank):
+    if args.graph == "m":
+        w = synth.make_world_m(seed=2, n_levels=args.levels)
+        mk = lambda n, seed, **kw: synth.make_batch_m(w, n, seed=seed, **kw)       # noqa: E731
+        desc = (f"{args.pairs} synthetic 2x150bp pairs per GPU (BASELINE config 2) vs Graph M, the SURVEY 8(d) stand-in for PRG_MHC_GRCh38_withIMGT: "
+                f"{args.levels} levels, 8 backbone haplotypes (0.3 % divergence, 2 % gap stretches), 40 gene windows of 3-6 kb with 500-5000 allele paths "
+                f"(suffix-10 node merging, up to {w['max_nodes_per_level']} nodes per level); reads: I101_NA12878 quality matrix stretched to 150, Poisson indels, "
+                f"start-to-start jump N(350,35) = inner distance N(200,35), 30 % of the pairs drawn from allele rows of the gene windows")
+    else:
+        w = synth.make_world(seed=2, G=args.levels, k=1, n_mut=3, n_largegap=1)
+        mk = lambda n, seed, **kw: synth.make_batch_fast(w, n, seed=seed)          # noqa: E731
+        desc = (f"{args.pairs} synthetic 2x150bp pairs per GPU vs the round-1 stand-in: {args.levels} levels, 5 haplotypes "
+                f"(simpleGraphSimulator recipe), geometric qualities, no read indels, inner distance N(200,35)")
+    return w, mk, desc
 
 
 def main():
@@ -50,9 +97,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1_048_576, help="read pairs per GPU per step (BASELINE config 2: 1M)")
     ap.add_argument("--levels", type=int, default=5_000_000, help="levels of the synthetic MHC-scale stand-in graph")
-    ap.add_argument("--cpu-pairs", type=int, default=4096, help="pairs of the same workload timed on the CPU oracle")
+    ap.add_argument("--graph", choices=["m", "simple"], default="m")
+    ap.add_argument("--cpu-pairs", type=int, default=2048, help="pairs of the same workload timed on the CPU oracle (1 thread; 4x as many on all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region (host-inclusive, gene / backbone split, streaming, typer)")
+    ap.add_argument("--stream-batches", type=int, default=6, help="batches pushed through two contexts / streams for the pipelined host-inclusive rate (0 = skip)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -62,6 +115,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one process per GPU; HLALA_BENCH_BACKEND=gloo (+ ranks sharing a device) exists only to dry-run the N > 1 plumbing on a 1-GPU box
     backend = os.environ.get("HLALA_BENCH_BACKEND", "nccl")
     local_rank = local_rank % torch.cuda.device_count()
@@ -71,19 +126,17 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     P = load_package()
     from tools import synth
 
     t0 = time.time()
-    # the real PRG_MHC_GRCh38_withIMGT is not available offline: synthetic stand-in, same on every rank
-    w = synth.make_world(seed=2, G=args.levels, k=1, n_mut=3, n_largegap=1)
-    b = synth.make_batch_fast(w, args.pairs, seed=1000 + rank)
+    w, mk, desc = make_workload(args, synth, rank)
+    b = mk(args.pairs, 1000 + rank)
     t_gen = time.time() - t0
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = P.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"],
-                    rng_seed=12345, max_columns=384, device=local_rank, stream=stream)
+    ckw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=12345, max_columns=384, device=local_rank)
+    ctx = P.Context(w["graph"], w["contigs"], stream=stream, **ckw)
     gb = ctx.batch(b)            # inputs resident in HBM from here on
     rec = torch.empty((args.pairs, 8), dtype=torch.float64, device="cuda")
     gathered = [torch.empty_like(rec) for _ in range(world)] if (world > 1 and rank == 0) else None
@@ -103,14 +156,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t1 = time.perf_counter()
-    ev0.record()
-    ext_ms = []
     for _ in range(args.steps):
         step()
-        ext_ms.append(None)
-    ev1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -126,57 +174,161 @@ def main():
         n_ok = int((rec[:, 0] == 0).sum().item())
         ms_per_step = elapsed / args.steps * 1e3
         value = args.pairs * world * args.steps / elapsed
+        g = w["graph"]
         chains_pp = st.n_chains_extended / args.pairs
-        edges_pc = st.n_edges_touched / max(1, st.n_chains_extended)
-        cols_pm = st.n_out_columns / max(1, st.n_chains_extended)
-        bpp = algorithmic_bytes_per_pair(150, chains_pp, edges_pc, cols_pm)
-        ext_s = st.ms_dp_main * 1e-3      # the dominant kernel alone: k_dp<DpTiny, 0> (HIP events around it on the ctx stream)
-        achieved = bpp * args.pairs / ext_s / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        cols_pc = st.n_out_columns / max(1, st.n_chains_extended)
+        e_mean = g["n_edges"] / max(1, g["n_nodes"] - 1)
+        bpp = algorithmic_bytes_per_pair(150, chains_pp, e_mean, cols_pc, cols_pc)
+        cls_ms = [float(x) for x in st.ms_dp_class]; cls_n = [int(x) for x in st.n_dp_class]
+        names = ["k_dp<DpTiny, 0>", "k_dp<DpMid, 1>", "k_dp<DpSmall, 2>", "k_dp<DpLarge, 3>"]
+        dom = int(np.argmax(cls_ms))
+        dom_ms = cls_ms[dom]
+        achieved = bpp * args.pairs / (dom_ms * 1e-3) / 1e9
+        khash = kernel_source_hash()
+        traffic, traffic_note, secondary = None, "no PMC pass on file for this build", {}
+        tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("pairs") == args.pairs and tj.get("levels") == args.levels:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                same = (tj.get("pairs") == args.pairs and tj.get("levels") == args.levels and tj.get("graph") == args.graph and tj.get("kernel") == names[dom])
+                if same and tj.get("kernel_source_hash") == khash:
+                    traffic = tj.get("hbm_bytes_per_launch"); traffic_note = f"profiles/r02_traffic.json (kernel sources {khash})"
+                elif same:
+                    traffic_note = f"profiles/r02_traffic.json was measured on kernel sources {tj.get('kernel_source_hash')}, this build is {khash}: dropped"
+                if same:
+                    secondary = dict(tj.get("secondary", {})); secondary["measured_on_kernel_source_hash"] = tj.get("kernel_source_hash")
             except Exception:
-                traffic = None
+                pass
+        secondary["dp_cells_per_s"] = st.n_dp_cells / (sum(cls_ms) * 1e-3)
         out = {
             "metric": "paired reads/sec aligned to PRG graph", "value": value, "unit": "read pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": f"{args.pairs} synthetic 2x150bp pairs per GPU (BASELINE config 2) vs a synthetic "
-                                   f"{args.levels}-level PRG stand-in for PRG_MHC_GRCh38_withIMGT",
-                       "pairs_per_gpu": args.pairs, "graph_levels": args.levels, "parallelism": f"shard{world}",
-                       "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
+            "config": {"workload": desc, "graph": args.graph, "pairs_per_gpu": args.pairs, "graph_levels": args.levels, "graph_nodes": int(g["n_nodes"]), "graph_edges": int(g["n_edges"]),
+                       "parallelism": f"shard{world}", "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
+                       "columns_per_chain": cols_pc, "mean_out_degree": e_mean,
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
-                       "dp_cells_per_s": st.n_dp_cells / ((st.ms_dp_main + st.ms_extend_retry) * 1e-3), "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
-                       "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "extend_dp_16lane_kernel": st.ms_dp_main,
-                                    "extend_dp_retry_classes": st.ms_extend_retry, "pair": st.ms_pair},
-                       "dp_calls_sharing_a_dp": int(st.n_dp_shared), "dp_calls_retried_wider_class": int(st.n_chains_retried), "dp_calls_retried_large_class": int(st.n_dp_retried_large),
-                       "generation_s": t_gen},
+                       "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
+                       "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "pair": st.ms_pair,
+                                    "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_large": cls_ms[3]},
+                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "large": cls_n[3]},
+                       "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "kernel": "k_dp<DpTiny, 0>", "kernel_ms": st.ms_dp_main,
-                         "algorithmic_bytes_per_pair": bpp},
+                         "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,
+                         "algorithmic_bytes_per_pair": bpp,
+                         "note": "dominant kernel only (HIP events on the ctx stream); the path is bound by instruction issue and dependent LDS / global "
+                                 "round trips, not by HBM (SURVEY 8(d)): see `secondary`",
+                         "secondary": secondary},
         }
+        if world == 1 and not args.no_extras:
+            try:
+                out["config"].update(extras(args, P, synth, w, mk, b, ctx, gb, ckw))
+            except Exception as e:          # the extras are reports, never a reason to lose the bench line
+                out["config"]["extras_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import subprocess
-            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-            from oracle_binding import Oracle
-            nb = min(args.cpu_pairs, args.pairs)
-            sb = synth.make_batch_fast(w, nb, seed=1000)       # same generator, same seed: a prefix-like sample of rank 0's workload
-            o = Oracle(w["graph"], w["contigs"], insert_mean=sb["insert_mean"], insert_sd=sb["insert_sd"], rng_seed=12345, max_columns=384)
-            tc = time.perf_counter()
-            o.align_batch(sb)
-            dtc = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": nb / dtc, "unit": "read pairs/s", "cores": 1, "kind": "port",
-                                   "sample": f"{nb} pairs of the same synthetic workload, oracle/hlala_oracle.cpp (C++ restatement, "
-                                             f"-O2, single thread as in HLA-LA.cpp:799), {dtc:.1f} s"}
+            out["cpu_baseline"] = cpu_baseline(args, synth, w, mk)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_baseline(args, synth, w, mk):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    from oracle_binding import Oracle
+    nb = min(args.cpu_pairs, args.pairs)
+    sb = mk(nb, 1000)              # same generator, same seed: the first pairs of rank 0's workload
+    o = Oracle(w["graph"], w["contigs"], insert_mean=sb["insert_mean"], insert_sd=sb["insert_sd"], rng_seed=12345, max_columns=384)
+    tc = time.perf_counter(); o.align_batch(sb); dtc = time.perf_counter() - tc
+    nm = min(4 * nb, args.pairs)
+    mb = mk(nm, 1000)
+    tc = time.perf_counter(); r = o.align_batch_mt(mb, 0, pairs_only=True); dtm = time.perf_counter() - tc
+    return {"value": nb / dtc, "unit": "read pairs/s", "cores": 1, "kind": "port",
+            "sample": f"first {nb} pairs of the same synthetic workload, oracle/hlala_oracle.cpp (C++ restatement, -O2, single thread as in HLA-LA.cpp:799), {dtc:.1f} s",
+            "all_cores": {"value": nm / dtm, "unit": "read pairs/s", "cores": int(r["threads"]), "host_cpus": os.cpu_count(),
+                          "sample": f"first {nm} pairs, OpenMP parallel for schedule(dynamic,64) over pairs, {dtm:.1f} s"}}
+
+
+def extras(args, P, synth, w, mk, b, ctx, gb, ckw):
+    """Measurements outside the timed region (rank 0, one GPU)."""
+    import ctypes as C
+    ex = {}
+    lib = ctx.lib
+    # ---- host-buffer inclusive: hlala_batch_create (H2D) -> hlala_align_batch -> hlala_batch_get_pairs_packed (D2H of every column of the
+    # selected alignments + per-pair scalars), caller-owned pageable buffers allocated once, nothing overlapped
+    # (the columns SURVEY 8(d) counts as output: level 4 B + graph char + read char + mapQ char = 7 B per column)
+    nr = 2 * args.pairs; cap = nr * 184
+    off = np.zeros(nr + 1, np.int64)
+    cols = dict(col_level=np.zeros(cap, np.int32), col_gchar=np.zeros(cap, np.uint8), col_schar=np.zeros(cap, np.uint8), col_mapq=np.zeros(cap, np.uint8))
+    lib.hlala_batch_get_pairs_packed.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(P.PairsPackedOut)]
+
+    def host_pass(cx, batch_in, offv, colsv, capv):
+        gbx = cx.batch(batch_in)
+        gbx.align()
+        o = P.PairsPackedOut(); o.cap_cols = capv; o.col_off = offv.ctypes.data_as(P.c_i64p)
+        types = dict(P.PairsPackedOut._fields_)
+        for k, v in colsv.items():
+            setattr(o, k, v.ctypes.data_as(types[k]))
+        cx._check(lib.hlala_batch_get_pairs_packed(cx.h, gbx.b, C.byref(o)), "hlala_batch_get_pairs_packed")
+        n = int(o.n_cols_total)
+        gbx.close()
+        return n
+
+    host_pass(ctx, b, off, cols, cap)                 # warm: first touch of the host buffers, pool blocks
+    reps = 2
+    t = time.perf_counter()
+    for _ in range(reps):
+        ncols = host_pass(ctx, b, off, cols, cap)
+    dt = (time.perf_counter() - t) / reps
+    ex["host_inclusive"] = {"pairs_per_s": args.pairs / dt, "ms_per_batch": dt * 1e3, "columns_returned": ncols,
+                            "what": "hlala_batch_create (H2D) + hlala_align_batch + hlala_batch_get_pairs_packed (D2H), pageable host buffers, one stream, nothing overlapped"}
+    # ---- two contexts on two streams, one host thread each: a batch's transfers overlap the other batch's kernels
+    if args.stream_batches > 0:
+        ctx2 = P.Context(w["graph"], w["contigs"], stream=None, **ckw)
+        off2 = np.zeros(nr + 1, np.int64); cols2 = {k: np.zeros_like(v) for k, v in cols.items()}
+        host_pass(ctx2, b, off2, cols2, cap)
+        nB = args.stream_batches
+
+        def worker(cx, offv, colsv, count):
+            for _ in range(count):
+                host_pass(cx, b, offv, colsv, cap)
+        th = [threading.Thread(target=worker, args=(ctx, off, cols, (nB + 1) // 2)), threading.Thread(target=worker, args=(ctx2, off2, cols2, nB // 2))]
+        t = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t
+        ex["host_inclusive_pipelined"] = {"pairs_per_s": nB * args.pairs / dt, "batches": nB, "ms_total": dt * 1e3,
+                                          "what": "the same per batch, batches alternate between two contexts (two HIP streams, one host thread each): "
+                                                  "uploads / downloads of one batch overlap the kernels of the other"}
+        del ctx2
+    # ---- gene-window and backbone pairs separately (resident, one step each after a warm-up)
+    if args.graph == "m":
+        ns = min(args.pairs, 262144)
+        for name, fg in (("gene_window_pairs", 1.0), ("backbone_pairs", 0.0)):
+            sb = mk(ns, 77, frac_gene=fg)
+            g2 = ctx.batch(sb); g2.align(); g2.stats()
+            t = time.perf_counter(); g2.align(); s2 = g2.stats(); dt = time.perf_counter() - t
+            ex[name] = {"pairs": ns, "pairs_per_s": ns / dt, "chains_per_pair": sb["n_chains"] / ns, "extended_chains_per_pair": s2.n_chains_extended / ns,
+                        "dp_ms_by_class": [float(x) for x in s2.ms_dp_class], "dp_calls_entering_class": [int(x) for x in s2.n_dp_class], "chain_errors": int(s2.n_errors)}
+            g2.close()
+    # ---- typer kernels at the size of a real class-I locus (C = 3000 clusters, R = 400 reads, 546 exon columns)
+    try:
+        loc = synth.make_locus(seed=5, n_clusters=3000, exon_length=546, n_reads=400)
+        Cn, R = 3000, 400
+        ctx.exon_loglik(loc)
+        t = time.perf_counter(); LL, mism = ctx.exon_loglik(loc); t_exon = time.perf_counter() - t
+        ctx.pair_loglik(LL, mism)
+        t = time.perf_counter(); pl = ctx.pair_loglik(LL, mism); t_pair = time.perf_counter() - t
+        ctx.call_locus(*pl)
+        t = time.perf_counter(); ctx.call_locus(*pl); t_call = time.perf_counter() - t
+        ex["typer"] = {"clusters": Cn, "reads": R, "exon_loglik_ms": t_exon * 1e3, "pair_loglik_ms": t_pair * 1e3, "call_locus_ms": t_call * 1e3,
+                       "g_logavg_per_s": Cn * (Cn + 1) / 2 * R / t_pair / 1e9, "what": "host wall clock of the C-ABI calls incl. their transfers"}
+    except Exception as e:      # the typer record is a report, never a reason to lose the bench line
+        ex["typer"] = {"error": str(e)}
+    return ex
 
 
 if __name__ == "__main__":

@@ -57,7 +57,7 @@ struct hlala_ctx {
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* large_slabs = nullptr; size_t large_slab_bytes = 0; int ext_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
-    hipEvent_t ev[9]{};           // start/end per stage; [7] / [6] / [8] = before DpTiny / after DpTiny / after the retry classes
+    hipEvent_t ev[11]{};          // start/end per stage; [7] / [6] / [9] / [10] / [8] = before DpTiny / after DpTiny / after DpMid / after DpSmall / after DpLarge
     int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
     // per-pair post-processing: coverage counters [L-1] and gene intervals
     int* d_cov = nullptr; int n_cov = 0; int* d_gene_first = nullptr; int* d_gene_last = nullptr; int n_genes = 0;
@@ -328,7 +328,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
-    for(int i = 0; i < 9; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    for(int i = 0; i < 11; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;
@@ -341,7 +341,7 @@ void hlala_destroy(hlala_ctx* c)
     for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(auto& kv : c->pool) (void)hipFree(kv.second);
-    for(int i = 0; i < 9; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for(int i = 0; i < 11; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -564,8 +564,10 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
             if(first) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
             hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             rc_ = check_launch(c, "k_dp<mid>"); if(rc_) return rc_;
+            if(first) HIP_TRY(c, hipEventRecord(c->ev[9], c->stream));
             hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             rc_ = check_launch(c, "k_dp<small>"); if(rc_) return rc_;
+            if(first) HIP_TRY(c, hipEventRecord(c->ev[10], c->stream));
             hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             return check_launch(c, "k_dp<large>");
         };
@@ -853,7 +855,9 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     u64 cnt[16];
     HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
-    if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]); } }
+    if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]);
+          (void)hipEventElapsedTime(&out->ms_dp_class[0], c->ev[7], c->ev[6]); (void)hipEventElapsedTime(&out->ms_dp_class[1], c->ev[6], c->ev[9]);
+          (void)hipEventElapsedTime(&out->ms_dp_class[2], c->ev[9], c->ev[10]); (void)hipEventElapsedTime(&out->ms_dp_class[3], c->ev[10], c->ev[8]); } }
     { int wc[32]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[12] + wc[14] + wc[16] + wc[18] + wc[20] + wc[22]; out->n_dp_retried_large = wc[20] + wc[22];
       out->n_dp_class[0] = wc[8] + wc[9]; out->n_dp_class[1] = wc[12] + wc[14]; out->n_dp_class[2] = wc[16] + wc[18]; out->n_dp_class[3] = wc[20] + wc[22]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
@@ -963,6 +967,17 @@ __global__ void k_kat_exp(int n, const double* x, double* y)
     if(i < n) y[i] = exp_cr_nonpos(x[i]);
 }
 }  // namespace hlala
+
+// HLALA_DEBUG=1: the host-mapped debug buffer of the context (8192 ints); clear != 0 zeroes it afterwards
+extern "C" int hlala_debug_buffer(hlala_ctx* c, int* out8192, int clear)
+{
+    if(!c || !c->dbg_host) return HLALA_E_STATE;
+    DEV_GUARD(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if(out8192) memcpy(out8192, c->dbg_host, 8192 * sizeof(int));
+    if(clear) memset(c->dbg_host, 0, 8192 * sizeof(int));
+    return HLALA_OK;
+}
 
 extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long long* out32)
 {

@@ -44,12 +44,12 @@ constexpr u64 HKEY_EMPTY = ~0ull;
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows per trip of the persistent loop (measured: 3 -> 236 ms, 6 -> 231, 12 -> 226, 24 -> 225, 64 -> 224 per 524 k pairs)
 
-struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; };
-struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; };
-struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; };
+struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; };
+struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; };
+struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; };
 // (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and
 //  thousands of sequence-complete cells per DP were measured -- are what the large class is sized for; its table slots are ints)
-struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; };
+struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; };
 
 // State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
 // that only the phase has to stay in registers across the states of the persistent loop.
@@ -78,6 +78,7 @@ struct __align__(16) DpLdsT {
     short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
     typename C::Slot tes[C::HC];    // per target: existing / assigned table slot (-1 = none), or -2 - (claimed early-hash entry)
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
+    typename C::ImpIdx hq[C::HC];   // per hash entry: index of the improvement its cell staged this iteration (all ones = none)
     int nNew, nImp, nKeepF, err, nCompletedAdd;
     int nextPhase;                                    // state after PH_DONE: idle, or the end-cell choice of a linked duplicate
     int btSlot, btM, btX, btY, btGuard, btDone;       // back-pointer chase in progress (lane 0 of the group)
@@ -85,6 +86,9 @@ struct __align__(16) DpLdsT {
     u64 accCalls, accIters, accCells, accEdges;       // work counters of the DPs this group finished (flushed once at exit)
 #ifdef HLALA_DP_TIMING
     long long tPh[8];
+#endif
+#ifdef HLALA_DP_PROFILE
+    long long pfStart; int pfSlow, pfImp, pfPre, pfMaxNT, pfMaxF; long long pfPh[6];
 #endif
 };
 
@@ -107,7 +111,9 @@ struct DpSlabT {
     static constexpr size_t O_COMPLETED = O_EARLY_VAL + (size_t)C::EARLY * 4;         // int  [COMPLETED]
     static constexpr size_t O_IMP_SLOT  = O_COMPLETED + (size_t)C::COMPLETED * 4;     // int  [IMPCAP]
     static constexpr size_t O_IMP_MASK  = O_IMP_SLOT + (size_t)C::IMPCAP * 4;         // int  [IMPCAP]
-    static constexpr size_t BYTES       = (O_IMP_MASK + (size_t)C::IMPCAP * 4 + 255) & ~(size_t)255;
+    static constexpr size_t O_TIE_SLOT  = O_IMP_MASK + (size_t)C::IMPCAP * 4;         // int  [COMPLETED]
+    static constexpr size_t O_TIE_KEY   = (O_TIE_SLOT + (size_t)C::COMPLETED * 4 + 7) & ~(size_t)7;   // u64 [COMPLETED]
+    static constexpr size_t BYTES       = (O_TIE_KEY + (size_t)C::COMPLETED * 8 + 255) & ~(size_t)255;
     __device__ __forceinline__ CellRec* cell() const { return (CellRec*)(base + O_CELL); }
     __device__ __forceinline__ u64* early_key() const { return (u64*)(base + O_EARLY_KEY); }
     __device__ __forceinline__ u32* step_bt() const { return (u32*)(base + O_STEP_BT); }
@@ -119,6 +125,8 @@ struct DpSlabT {
     __device__ __forceinline__ int* completed() const { return (int*)(base + O_COMPLETED); }
     __device__ __forceinline__ int* imp_slot() const { return (int*)(base + O_IMP_SLOT); }
     __device__ __forceinline__ int* imp_mask() const { return (int*)(base + O_IMP_MASK); }
+    __device__ __forceinline__ int* tie_slot() const { return (int*)(base + O_TIE_SLOT); }
+    __device__ __forceinline__ u64* tie_key() const { return (u64*)(base + O_TIE_KEY); }
 };
 
 template <class C>
@@ -209,6 +217,38 @@ __device__ __forceinline__ u32 hash64(u64 k)
     return h ^ (h >> 6) ^ (h >> 12);
 }
 
+// The per-DP cell hash in the slab holds up to every kept cell of a DP (tens of thousands in allele-rich gap regions) and is probed
+// linearly: it needs a hash that scatters.  hash64 maps the cells of one region onto a narrow range of values (fine for the per-iteration
+// LDS hash, whose few hundred keys form short runs), which made the probe chains of this table thousands of entries long -- one DP call
+// of the Graph M workload took 1.3 s in compare-and-swaps.  Two multiplies per call, only in iterations that can meet an early cell.
+__device__ __forceinline__ u32 hash_mix(u64 k)
+{
+    u32 h = (u32)k * 0x9E3779B1u ^ (u32)(k >> 32) * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
+
+// hash of the per-iteration LDS target table: the cheap one for the small classes (a few dozen keys in a table twice that size); the
+// large class fills its 2048 entries half and more on allele-rich levels, where the narrow value range of hash64 turned linear probing
+// into walks of hundreds of compare-and-swaps per claim
+template <class C> __device__ __forceinline__ u32 tgt_hash(u64 k) { return (C::HC > 256 ? hash_mix(k) : hash64(k)) & (u32)(C::HC - 1); }
+
+// entry of a key in the per-iteration target hash, -1 if it is not a target of this iteration (no insertion; entries are never removed
+// while an iteration is evaluated)
+template <class C>
+__device__ inline int dp_find(const DpLdsT<C>& S, u64 key)
+{
+    u32 h = tgt_hash<C>(key);
+#pragma nounroll
+    for(int probe = 0; probe < C::HC; probe++) {
+        const u64 cur = S.hkey[h];
+        if(cur == key) return (int)h;
+        if(cur == HKEY_EMPTY) return -1;
+        h = (h + 1) & (C::HC - 1);
+    }
+    return -1;
+}
+
 // back pointer: previous cell slot (17 bits, CELLS <= 131072) | source matrix (2) | kind (3) | local push index j (8; 0xFF = none)
 __device__ __forceinline__ u32 mk_bt(int prev, int src, int kind, int edge) { return (u32)prev | ((u32)src << 17) | ((u32)kind << 19) | (((u32)edge & 0xFFu) << 22); }
 __device__ __forceinline__ int bt_prev(u32 b) { return (int)(b & 0x1FFFF); }
@@ -230,7 +270,7 @@ __device__ __forceinline__ int best_order(u64 b) { return 0x7FFFFFFF - (int)(b &
 template <class C>
 __device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int order)
 {
-    u32 h = hash64(key) & (C::HC - 1);
+    u32 h = tgt_hash<C>(key);
 #pragma nounroll
     for(int probe = 0; probe < C::HC; probe++) {
         u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
@@ -256,7 +296,7 @@ __device__ inline u32 dp_probe(DpLdsT<C>& S, u64 key, u32 h)
 template <class C>
 __device__ inline int early_lookup(const DpSlabT<C>& sl, u64 key)
 {
-    u32 h = hash64(key) & (C::EARLY - 1);
+    u32 h = hash_mix(key) & (C::EARLY - 1);
     for(int probe = 0; probe < C::EARLY; probe++) {
         // entries are published with L2 atomics: read them past the CU's L1
         u64 cur = __hip_atomic_load(&sl.early_key()[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -270,7 +310,7 @@ __device__ inline int early_lookup(const DpSlabT<C>& sl, u64 key)
 template <class C>
 __device__ inline int early_claim(const DpSlabT<C>& sl, u64 key, bool& found)
 {
-    u32 h = hash64(key) & (C::EARLY - 1);
+    u32 h = hash_mix(key) & (C::EARLY - 1);
     for(int probe = 0; probe < C::EARLY; probe++) {
         u64 old = atomicCAS(&sl.early_key()[h], HKEY_EMPTY, key);
         if(old == HKEY_EMPTY) { found = false; return (int)h; }
@@ -283,7 +323,7 @@ __device__ inline int early_claim(const DpSlabT<C>& sl, u64 key, bool& found)
 template <class C>
 __device__ inline bool early_insert(const DpSlabT<C>& sl, u64 key, int slot)
 {
-    u32 h = hash64(key) & (C::EARLY - 1);
+    u32 h = hash_mix(key) & (C::EARLY - 1);
     for(int probe = 0; probe < C::EARLY; probe++) {
         u64 old = atomicCAS(&sl.early_key()[h], HKEY_EMPTY, key);
         if(old == HKEY_EMPTY || old == key) { __hip_atomic_store(&sl.early_val()[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
@@ -309,6 +349,19 @@ __device__ inline bool xz_less(int x1, int z1, int x2, int z2)
     const int n = la < lb ? la : lb;
     for(int i = 0; i < n; i++) { int ca = xz_char(x1, z1, lx1, lz1, i), cb = xz_char(x2, z2, lx2, lz2, i); if(ca != cb) return ca < cb; }
     return la < lb;
+}
+
+// a number whose unsigned order is the string order of "x/z": symbols end < '/' < '0' .. '9' as digits of a base-12 number of 14 places
+// (x < 2^24: 8 digits, '/', z: at most 5 digits -- ranks within a level stay far below 100 000; 12^14 < 2^51)
+__device__ inline u64 xz_key(int x, int z)
+{
+    const int lx = dec_len(x), lz = dec_len(z);
+    u64 k = 0; int n = 0;
+    for(int i = 0; i < lx; i++, n++) k = k * 12 + (u64)(2 + (x / pow10i(lx - 1 - i)) % 10);
+    k = k * 12 + 1; n++;
+    for(int i = 0; i < lz && n < 14; i++, n++) k = k * 12 + (u64)(2 + (z / pow10i(lz - 1 - i)) % 10);
+    for(; n < 14; n++) k *= 12;
+    return k;
 }
 
 // one DP item as prepared by k_dp_items (32 bytes)
@@ -338,6 +391,9 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
         st.have = 0; st.sb = 0; st.se = -1; st.err = 0; st.needTier = 0; st.isAlias = 0;
         S.err = 0;
+#ifdef HLALA_DP_PROFILE
+        S.pfStart = clock64(); S.pfSlow = 0; S.pfImp = 0; S.pfPre = 0; S.pfMaxNT = 0; S.pfMaxF = 0; for(int i = 0; i < 6; i++) S.pfPh[i] = 0;
+#endif
         CellRec c0; c0.key = mk_key(it.startLevel, it.start_seq, it.startNode);
         c0.sc[0] = 0; c0.sc[1] = (short)DP_NEG; c0.sc[2] = (short)DP_NEG; c0.sc[3] = 0; c0.bt[0] = 0; c0.bt[1] = 0; c0.bt[2] = 0; c0.pad = 0;
         sl.cell()[0] = c0;
@@ -429,7 +485,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             cv[1] = okA && degA > 1; ck[1] = mk_key(nxA, nyA, tnA1);
             cv[2] = hasB && nyG >= 0 && nyG <= max_seqI; ck[2] = mk_key(pxB, nyG, nodeB);
 #pragma unroll
-            for(int q = 0; q < 3; q++) { ch[q] = hash64(ck[q]) & (C::HC - 1); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
+            for(int q = 0; q < 3; q++) { ch[q] = tgt_hash<C>(ck[q]); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
 #pragma unroll
             for(int q = 0; q < 3; q++)
                 if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
@@ -443,7 +499,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             cv[1] = sgB && degB > 1; ck[1] = mk_key(nxB, pyB, tnB1);
             cv[2] = okB && j1 > j0 && jx0 >= 0 && jx0 <= max_levelI; ck[2] = mk_key(jx0, pyB, jn0);
 #pragma unroll
-            for(int q = 0; q < 3; q++) { ch[q] = hash64(ck[q]) & (C::HC - 1); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
+            for(int q = 0; q < 3; q++) { ch[q] = tgt_hash<C>(ck[q]); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
 #pragma unroll
             for(int q = 0; q < 3; q++)
                 if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
@@ -564,6 +620,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             bool keep = act && (Dv >= -16);                                               // :949
             int es = -1; bool isNew; int slot;
             if(pass == 0) {
+                if(hadEarly && act) S.hq[h] = (typename C::ImpIdx)~0u;
                 int claimed = -1;
                 if(hadEarly && keep) { int v = S.tes[t]; if(v >= 0) es = v; else if(v <= -2) claimed = -2 - v; }
                 isNew = keep && es < 0;
@@ -642,6 +699,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 if(impMask && pass == 0) {
                     int p = atomicAdd(&S.nImp, 1);
                     if(p < C::IMPCAP) {
+                        S.hq[h] = (typename C::ImpIdx)p;
                         sl.imp_slot()[p] = es; sl.imp_key()[p] = key; sl.imp_mask()[p] = impMask;
                         sl.imp_new()[4 * p + 0] = (short)mD; sl.imp_new()[4 * p + 1] = (short)mG; sl.imp_new()[4 * p + 2] = (short)mS;
                         sl.imp_bt()[3 * p + 0] = btD; sl.imp_bt()[3 * p + 1] = btG; sl.imp_bt()[3 * p + 2] = btS;
@@ -670,9 +728,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     int ps = bt_prev(b), pm = bt_src(b);
                     int pv = sl.cell()[ps].sc[pm];
                     // a predecessor improved in THIS iteration counts with its new value only if it precedes this cell in map order
-                    int nImp = S.nImp < C::IMPCAP ? S.nImp : C::IMPCAP;
-                    for(int q = 0; q < nImp; q++)
-                        if(sl.imp_slot()[q] == ps && (sl.imp_mask()[q] & (1 << pm)) && sl.imp_key()[q] < key) pv = sl.imp_new()[4 * q + pm];
+                    // (the improved cells of an iteration are targets of it: found through the target hash, not by scanning the staged list)
+                    const u64 pkey = sl.cell()[ps].key;
+                    if(pkey < key) {
+                        const int ph = dp_find<C>(S, pkey);
+                        if(ph >= 0) { const int q = (int)S.hq[ph]; if(q < C::IMPCAP && q < S.nImp && (sl.imp_mask()[q] & (1 << pm))) pv = sl.imp_new()[4 * q + pm]; }
+                    }
                     diff = Dv - pv;
                 }
             }
@@ -706,10 +767,13 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         }
         if(nImp) {
             WSYNC();
-            for(int q = 0; q < nImp; q++) {
-                int es = sl.imp_slot()[q]; short v0 = sl.imp_new()[4 * q + 0], v1 = sl.imp_new()[4 * q + 1], v2 = sl.imp_new()[4 * q + 2];
-                for(int i = gl; i < n1; i += GW) if(S.fslot[b1][i] == es) { S.fD[b1][i] = v0; S.fG[b1][i] = v1; S.fS[b1][i] = v2; }
-                for(int i = gl; i < n2; i += GW) if(S.fslot[b2][i] == es) { S.fD[b2][i] = v0; S.fG[b2][i] = v1; S.fS[b2][i] = v2; }
+            // cached copies of the improved cells in the two frontiers: a frontier cell that was improved is a target of this iteration
+            for(int w = 0; w < 2; w++) {
+                const int bb = w ? b2 : b1, nn = w ? n2 : n1;
+                for(int i = gl; i < nn; i += GW) {
+                    const int ph = dp_find<C>(S, S.fkey[bb][i]);
+                    if(ph >= 0) { const int q = (int)S.hq[ph]; if(q < C::IMPCAP && q < nImp) { S.fD[bb][i] = sl.imp_new()[4 * q + 0]; S.fG[bb][i] = sl.imp_new()[4 * q + 1]; S.fS[bb][i] = sl.imp_new()[4 * q + 2]; } }
+                }
             }
         }
     }
@@ -734,59 +798,63 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         mx = grp_max_i32<GW>(mx);
     }
     int nNew = 0;
-    if(C::WCAP <= GW) {
-        // survivors are first compacted into the new frontier buffer in target-list order, then every survivor counts the
-        // smaller keys among them (its rank = its place in std::map order) and the buffer is rewritten in rank order
-        for(int t0 = 0; t0 < nT; t0 += GW) {
-            int t = t0 + gl;
-            bool pass = false; u64 key = 0; int h = 0;
-            if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
-            const u64 m = grp_ballot<GW>(pass);
-            const int pos = nNew + __popcll(m & ((1ull << gl) - 1ull));
-            if(pass && pos < C::WCAP) {
-                S.fkey[bn][pos] = key; S.fslot[bn][pos] = (typename C::Slot)(int)S.hbest[0][h];
-                S.fD[bn][pos] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][pos] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][pos] = (short)((u32)S.hbest[2][h] & 0xFFFF);
-            }
-            nNew += __popcll(m);
+    // survivors are first compacted into the new frontier buffer in target-list order ...
+    for(int t0 = 0; t0 < nT; t0 += GW) {
+        int t = t0 + gl;
+        bool pass = false; u64 key = 0; int h = 0;
+        if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
+        const u64 m = grp_ballot<GW>(pass);
+        const int pos = nNew + __popcll(m & ((1ull << gl) - 1ull));
+        if(pass && pos < C::WCAP) {
+            S.fkey[bn][pos] = key; S.fslot[bn][pos] = (typename C::Slot)(int)S.hbest[0][h];
+            S.fD[bn][pos] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][pos] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][pos] = (short)((u32)S.hbest[2][h] & 0xFFFF);
         }
-        if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; st.needTier = tier_for_frontier(nNew); } WSYNC(); return PH_DONE; }
+        nNew += __popcll(m);
+    }
+    if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; st.needTier = tier_for_frontier(nNew); } WSYNC(); return PH_DONE; }
+    WSYNC();
+    // reset the hash entries used by this iteration (the survivors live in the frontier buffer now)
+    for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
+    // ... then put into std::map order (x, y, z) = key order
+    if(nNew > 1 && nNew <= GW) {
+        // every survivor counts the smaller keys among them (= its rank) and the buffer is rewritten in rank order
+        const bool act = gl < nNew;
+        u64 key = 0; typename C::Slot vs = 0; short vD = 0, vG = 0, vS = 0; int rank = 0;
+        if(act) {
+            key = S.fkey[bn][gl]; vs = S.fslot[bn][gl]; vD = S.fD[bn][gl]; vG = S.fG[bn][gl]; vS = S.fS[bn][gl];
+            for(int u = 0; u < nNew; u++) rank += (S.fkey[bn][u] < key) ? 1 : 0;
+        }
         WSYNC();
-        if(nNew > 1) {
-            const bool act = gl < nNew;
-            u64 key = 0; typename C::Slot vs = 0; short vD = 0, vG = 0, vS = 0; int rank = 0;
-            if(act) {
-                key = S.fkey[bn][gl]; vs = S.fslot[bn][gl]; vD = S.fD[bn][gl]; vG = S.fG[bn][gl]; vS = S.fS[bn][gl];
-                for(int u = 0; u < nNew; u++) rank += (S.fkey[bn][u] < key) ? 1 : 0;
-            }
-            WSYNC();
-            if(act) { S.fkey[bn][rank] = key; S.fslot[bn][rank] = vs; S.fD[bn][rank] = vD; S.fG[bn][rank] = vG; S.fS[bn][rank] = vS; }
+        if(act) { S.fkey[bn][rank] = key; S.fslot[bn][rank] = vs; S.fD[bn][rank] = vD; S.fG[bn][rank] = vG; S.fS[bn][rank] = vS; }
+    } else if(C::WCAP > GW && nNew > GW) {
+        // frontier wider than the group (allele-rich levels: hundreds of cells): bitonic sort of (key, packed payload) pairs in LDS;
+        // the payload array borrows the hash's third value array, which is idle (all zero) between iterations.  (The rank of every
+        // survivor used to be counted against all targets: quadratic, and 99 % of the time of the widest DPs of the Graph M workload.)
+        WSYNC();
+        int Pn = GW * 2; while(Pn < nNew) Pn <<= 1;              // power of two >= nNew, <= WCAP
+        u64* pay = (u64*)&S.hbest[2][0];
+        for(int i = gl; i < Pn; i += GW) {
+            if(i < nNew) pay[i] = (u64)(u32)(unsigned short)S.fD[bn][i] | ((u64)(u32)(unsigned short)S.fG[bn][i] << 16) | ((u64)(u32)(unsigned short)S.fS[bn][i] << 32) | ((u64)(u32)(int)S.fslot[bn][i] << 48);
+            else { S.fkey[bn][i] = ~0ull; pay[i] = 0; }
         }
-    } else {
-        // frontier larger than the group: rank among all surviving targets straight from the hash
-        for(int t0 = 0; t0 < nT; t0 += GW) {
-            int t = t0 + gl;
-            bool pass = false; u64 key = 0; int h = 0;
-            if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
-            int rank = 0;
-            if(pass) {
-                for(int u = 0; u < nT; u++) {
-                    int hu = S.tlist[u];
-                    if((u32)S.hbest[0][hu] == 0xFFFFFFFFu) continue;
-                    int vu = (short)((u32)S.hbest[1][hu] & 0xFFFF);
-                    if((mx - vu) <= 15 && S.hkey[hu] < key) rank++;
+        WSYNC();
+        for(int k = 2; k <= Pn; k <<= 1)
+            for(int j = k >> 1; j > 0; j >>= 1) {
+                for(int idx = gl; idx < (Pn >> 1); idx += GW) {
+                    const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1)), l = i | j;
+                    const bool up = (i & k) == 0;
+                    const u64 ka = S.fkey[bn][i], kb = S.fkey[bn][l];
+                    if((ka > kb) == up) { const u64 pa = pay[i], pb = pay[l]; S.fkey[bn][i] = kb; S.fkey[bn][l] = ka; pay[i] = pb; pay[l] = pa; }
                 }
-                if(rank < C::WCAP) {
-                    S.fkey[bn][rank] = key; S.fslot[bn][rank] = (typename C::Slot)(int)S.hbest[0][h];
-                    S.fD[bn][rank] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][rank] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][rank] = (short)((u32)S.hbest[2][h] & 0xFFFF);
-                }
+                WSYNC();
             }
-            nNew += __popcll(grp_ballot<GW>(pass));
+        for(int i = gl; i < Pn; i += GW) {
+            const u64 pv = pay[i];
+            if(i < nNew) { S.fD[bn][i] = (short)(pv & 0xFFFF); S.fG[bn][i] = (short)((pv >> 16) & 0xFFFF); S.fS[bn][i] = (short)((pv >> 32) & 0xFFFF); S.fslot[bn][i] = (typename C::Slot)(int)(pv >> 48); }
+            pay[i] = 0;
         }
-        if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; st.needTier = tier_for_frontier(nNew); } WSYNC(); return PH_DONE; }
     }
     WSYNC();
-    // reset the hash entries used by this iteration
-    for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
     if(gl == 0) {
         st.b2 = b1; st.b1 = bn; st.bn = b2;                                                   // m2 := m1; m1 := this, :1104-1105
         st.n2 = n1; st.n1 = nNew;
@@ -794,6 +862,9 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         st.nCells = nCells; st.nCompleted = nCompletedNew; st.earlyInit = earlyInit; st.earlyMaxNat = earlyMaxNat;
         st.curMax = curMax; st.lastInc = lastInc; if(firstMaxSlot >= 0) st.firstMaxSlot = firstMaxSlot;
         st.cellsEvaluated += (u32)nT;
+#ifdef HLALA_DP_PROFILE
+        if(slow) S.pfSlow++; S.pfImp += S.nImp; if(prepass) S.pfPre++; if(nT > S.pfMaxNT) S.pfMaxNT = nT; if(nNew > S.pfMaxF) S.pfMaxF = nNew;
+#endif
     }
     WSYNC();
     DP_TQ(2);
@@ -821,20 +892,42 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
         int selectedIndex = glibc_rand_r(&sd) % nTies;                                      // Utilities.cpp:922-927
         // the tie with exactly `selectedIndex` ties before it in "x/z" string order
         int found = -1;
-        for(int i0 = 0; i0 < nCompleted; i0 += GW) {
-            int i = i0 + gl;
-            if(i < nCompleted) {
-                int s = sl.completed()[i];
-                if(sl.cell()[s].sc[0] == best) {
-                    u64 k = sl.cell()[s].key; int rank = 0;
-                    if(nTies > 1) {
-                        int kz = key_node(k) - G.level_off[key_x(k)];
-                        for(int u = 0; u < nCompleted; u++) { int su = sl.completed()[u]; if(su != s && sl.cell()[su].sc[0] == best) { u64 ku = sl.cell()[su].key;
-                            if(xz_less(key_x(ku), key_node(ku) - G.level_off[key_x(ku)], key_x(k), kz)) rank++; } }
+        if(nTies <= 2 * GW) {
+            for(int i0 = 0; i0 < nCompleted; i0 += GW) {
+                int i = i0 + gl;
+                if(i < nCompleted) {
+                    int s = sl.completed()[i];
+                    if(sl.cell()[s].sc[0] == best) {
+                        u64 k = sl.cell()[s].key; int rank = 0;
+                        if(nTies > 1) {
+                            int kz = key_node(k) - G.level_off[key_x(k)];
+                            for(int u = 0; u < nCompleted; u++) { int su = sl.completed()[u]; if(su != s && sl.cell()[su].sc[0] == best) { u64 ku = sl.cell()[su].key;
+                                if(xz_less(key_x(ku), key_node(ku) - G.level_off[key_x(ku)], key_x(k), kz)) rank++; } }
+                        }
+                        if(rank == selectedIndex) found = s;
                     }
-                    if(rank == selectedIndex) found = s;
                 }
             }
+        } else {
+            // many ties (allele-rich levels: thousands of sequence-complete cells): every tie gets a number whose order is the string
+            // order (xz_key), the ties are compacted into the slab, and the selectedIndex-th smallest number is found bit by bit
+            int nt = 0;
+            for(int i0 = 0; i0 < nCompleted; i0 += GW) {
+                int i = i0 + gl; bool tie = false; int s = 0; u64 kk = 0;
+                if(i < nCompleted) { s = sl.completed()[i]; if(sl.cell()[s].sc[0] == best) { tie = true; u64 k = sl.cell()[s].key; kk = xz_key(key_x(k), key_node(k) - G.level_off[key_x(k)]); } }
+                const u64 m = grp_ballot<GW>(tie);
+                if(tie) { const int pos = nt + __popcll(m & ((1ull << gl) - 1ull)); sl.tie_slot()[pos] = s; sl.tie_key()[pos] = kk; }
+                nt += __popcll(m);
+            }
+            WSYNC();
+            u64 prefix = 0; int k = selectedIndex;
+            for(int bit = 51; bit >= 0; bit--) {
+                int cnt = 0;
+                for(int i = gl; i < nt; i += GW) { const u64 kk = sl.tie_key()[i]; if((kk >> (bit + 1)) == (prefix >> (bit + 1)) && !((kk >> bit) & 1ull)) cnt++; }
+                cnt = grp_sum_i32<GW>(cnt);
+                if(k >= cnt) { k -= cnt; prefix |= 1ull << bit; }
+            }
+            for(int i = gl; i < nt; i += GW) if(sl.tie_key()[i] == prefix) found = sl.tie_slot()[i];
         }
         endSlot = grp_max_i32<GW>(found); endScore = best;
     } else if(curMax > 0) {
@@ -1117,6 +1210,13 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
                 if(gl == 0) {
                     DpState& st = S.st;
                     S.nextPhase = PH_IDLE;
+#ifdef HLALA_DP_PROFILE
+                    if(B.dbg && TIER == HLALA_DP_PROFILE) {
+                        const long long cyc = clock64() - S.pfStart;
+                        if(cyc > (1ll << 18)) { int q = atomicAdd(&B.dbg[0], 1); if(q < 500) { int* r = B.dbg + 16 + 16 * q; r[0] = st.item; r[1] = st.itersRun; r[2] = (int)st.cellsEvaluated; r[3] = st.nCells;
+                            r[4] = S.pfSlow; r[5] = S.pfImp; r[6] = S.pfPre; r[7] = (int)(cyc >> 10); r[8] = S.pfMaxNT; r[9] = S.pfMaxF; r[10] = st.nCompleted; r[11] = st.err; r[12] = st.nSteps; r[13] = st.earlyInit; r[14] = st.seqLen; r[15] = st.start_seq; } }
+                    }
+#endif
                     const bool capacity = st.err != 0 && st.err > -1000000;
                     if(capacity && TIER < 3) {
                         // next tier, or straight to the first tier whose class holds what overflowed (no point in failing again on the way)

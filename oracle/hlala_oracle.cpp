@@ -36,6 +36,7 @@
 #include <string>
 #include <tuple>
 #include <vector>
+#include <omp.h>
 
 namespace orc {
 
@@ -305,13 +306,24 @@ struct Chain {
 
 /* ------------------------------------------------------------------ extension aligner */
 
+/* Work counters of the calling thread (the all-cores variant of orc_align_batch runs pairs on several threads; the aligner itself is
+ * read-only): cells / iterations / calls / edges, and the largest per-call sizes seen (capacity planning of the GPU classes). */
+struct DpStats {
+    long long cells = 0, iters = 0, calls = 0, edges = 0;
+    long long max_frontier = 0, max_targets = 0, max_kept_cells = 0, max_completed = 0;
+    bool h4_hit = false;
+    void add(const DpStats& o) {
+        cells += o.cells; iters += o.iters; calls += o.calls; edges += o.edges;
+        max_frontier = std::max(max_frontier, o.max_frontier); max_targets = std::max(max_targets, o.max_targets);
+        max_kept_cells = std::max(max_kept_cells, o.max_kept_cells); max_completed = std::max(max_completed, o.max_completed); h4_hit = h4_hit || o.h4_hit;
+    }
+};
+static thread_local DpStats t_stats;
+
 struct Aligner {
     const Graph* g;
     /* alignerBase::alignerBase, mapper/aligner/alignerBase.cpp:19-25 */
     double S_match = 2, S_mismatch = -5, S_gap = -2, S_graphGap = 0, S_openGap = -4, S_extendGap = -2;
-    long long stat_cells = 0, stat_iters = 0, stat_calls = 0, stat_edges = 0;
-    long long max_frontier = 0, max_targets = 0, max_kept_cells = 0, max_completed = 0;     /* largest per-call sizes seen (capacity planning of the GPU classes) */
-    bool h4_hit = false;
 
     explicit Aligner(const Graph* g_) : g(g_) {}
 
@@ -354,7 +366,7 @@ struct Aligner {
            int maxLevel_graph, int maxPosition_sequence, int diagonal_stop_threshold, bool directionPositive,
            unsigned int* rng_seed)
     {
-        stat_calls++;
+        t_stats.calls++;
         const double minusInfinity = -1 * DBL_MAX;                                   /* :363 */
         std::map<Key, Cell> scores;                                                    /* :396 */
         std::map<Key, CellBT> scores_backtrace;                                        /* :397 */
@@ -408,7 +420,7 @@ struct Aligner {
                 auto nextZs = neighbours(px, pz, directionPositive);
                 ORC_CHECK(nextZs.size() > 0, "node without neighbours");
                 for(auto& zj : nextZs) {
-                    stat_edges++;
+                    t_stats.edges++;
                     char edgeEmission = (char)g->elabel[zj.second];
                     double s = scores.at(p).D + ((edgeEmission == sequenceEmission) ? S_match : S_mismatch);
                     BT b; b.x = px; b.y = py; b.z = pz; b.edge = zj.second; b.src = 0;
@@ -439,7 +451,7 @@ struct Aligner {
                         auto nextZs = neighbours(px, pz, directionPositive);
                         ORC_CHECK(nextZs.size() > 0, "node without neighbours");
                         for(auto& zj : nextZs) {
-                            stat_edges++;
+                            t_stats.edges++;
                             bool gapEdge = (g->elabel[zj.second] == '_');
                             Alt& a = thisDiagonal[Key(nx, ny, zj.first)];
                             double s_open = pc.D + S_openGap + S_extendGap;
@@ -472,7 +484,7 @@ struct Aligner {
             /* call maxima for this diagonal, :794-1073 */
             std::vector<Key> m_thisDiagonal;
             for(auto& diagIt : thisDiagonal) {
-                stat_cells++;
+                t_stats.cells++;
                 const Key& k = diagIt.first;
                 int levelI = std::get<0>(k), seqI = std::get<1>(k), stateI = std::get<2>(k);
                 Alt& a = diagIt.second;
@@ -519,7 +531,7 @@ struct Aligner {
                         prevD = (oneRealStepBackwards.src == 0) ? pc2.D : (oneRealStepBackwards.src == 1 ? pc2.GG : pc2.SG);
                     }
                     int previousScore;     /* `int previousScore = <double>`: x86 cvttsd2si gives INT_MIN out of range */
-                    if(prevD <= (double)INT_MIN || prevD >= (double)INT_MAX) { previousScore = INT_MIN; h4_hit = true; }
+                    if(prevD <= (double)INT_MIN || prevD >= (double)INT_MAX) { previousScore = INT_MIN; t_stats.h4_hit = true; }
                     else previousScore = (int)prevD;
                     int scoreDifference = (int)(maxD.first - previousScore);
                     if(maxD.first == currentMaximum) {
@@ -549,14 +561,14 @@ struct Aligner {
                     if((mx - scores.at(c).D) <= threshold_for_filtering) filtered.push_back(c);
                 m_thisDiagonal = filtered;
             }
-            if((long long)thisDiagonal.size() > max_targets) max_targets = (long long)thisDiagonal.size();
-            if((long long)m_thisDiagonal.size() > max_frontier) max_frontier = (long long)m_thisDiagonal.size();
+            if((long long)thisDiagonal.size() > t_stats.max_targets) t_stats.max_targets = (long long)thisDiagonal.size();
+            if((long long)m_thisDiagonal.size() > t_stats.max_frontier) t_stats.max_frontier = (long long)m_thisDiagonal.size();
             m2_diagonal = m1_diagonal;                                               /* :1104-1105 */
             m1_diagonal = m_thisDiagonal;
         }
-        stat_iters += itersRun;
-        if((long long)scores_backtrace.size() > max_kept_cells) max_kept_cells = (long long)scores_backtrace.size();
-        if((long long)achieved_complete_sequence_alignments.size() > max_completed) max_completed = (long long)achieved_complete_sequence_alignments.size();
+        t_stats.iters += itersRun;
+        if((long long)scores_backtrace.size() > t_stats.max_kept_cells) t_stats.max_kept_cells = (long long)scores_backtrace.size();
+        if((long long)achieved_complete_sequence_alignments.size() > t_stats.max_completed) t_stats.max_completed = (long long)achieved_complete_sequence_alignments.size();
 
         /* backtraceFrom, :1109-1354 */
         auto backtraceFrom = [&](int start_x, int start_y, int start_z, double StartScore) -> Ext {
@@ -986,7 +998,7 @@ struct Processor {
                 int fromN = nodeIt.first;
                 ORC_CHECK(g.node_level[fromN] == graphLevel, "rethreading level");
                 for(int e : g.out_e[fromN]) {
-                    eA->stat_edges++;
+                    t_stats.edges++;
                     if(seedIsMatch && (char)g.elabel[e] != sequenceCharacter) continue;
                     double S = ((char)g.elabel[e] == sequenceCharacter) ? 1 : 0;
                     int toN = g.eto[e];
@@ -1186,9 +1198,9 @@ void orc_destroy(orc_handle* h) { if(h) { delete h->P.eA; delete h; } }
 /* largest frontier / candidate-cell set / kept-cell table / sequence-complete set of any DP call so far; reset != 0 clears them */
 int orc_dp_maxima(orc_handle* h, int64_t* out4, int reset)
 {
-    Aligner& A = *h->P.eA;
-    out4[0] = A.max_frontier; out4[1] = A.max_targets; out4[2] = A.max_kept_cells; out4[3] = A.max_completed;
-    if(reset) A.max_frontier = A.max_targets = A.max_kept_cells = A.max_completed = 0;
+    (void)h;
+    out4[0] = t_stats.max_frontier; out4[1] = t_stats.max_targets; out4[2] = t_stats.max_kept_cells; out4[3] = t_stats.max_completed;
+    if(reset) t_stats.max_frontier = t_stats.max_targets = t_stats.max_kept_cells = t_stats.max_completed = 0;
     return 0;
 }
 
@@ -1243,7 +1255,7 @@ int orc_extend_seeds(orc_handle* h, const hlala_seeds_in* in, hlala_chains_out* 
     try {
         Processor& P = h->P;
         Aligner& A = *P.eA;
-        A.stat_calls = A.stat_iters = A.stat_cells = A.stat_edges = 0;
+        t_stats.calls = t_stats.iters = t_stats.cells = t_stats.edges = 0;
         int stride = P.params.max_columns;
         for(int c = 0; c < in->n_chains; c++) {
             int r = in->chain_read[c];
@@ -1263,126 +1275,164 @@ int orc_extend_seeds(orc_handle* h, const hlala_seeds_in* in, hlala_chains_out* 
             e.ll = A.scoreOneAlignment(e, oseq, oqual, P.params.long_read_mode != 0);
             storeChain(e, c, stride, out, HLALA_CHAIN_OK);
         }
-        if(stats) { stats[0] = A.stat_calls; stats[1] = A.stat_iters; stats[2] = A.stat_cells; stats[3] = A.stat_edges; }
+        if(stats) { stats[0] = t_stats.calls; stats[1] = t_stats.iters; stats[2] = t_stats.cells; stats[3] = t_stats.edges; }
         return 0;
     } catch(std::exception& e) { g_err = e.what(); return -1; }
 }
 
 /* processBAM::alignOneReadPair (mapper/processBAM.cpp:3129-3616) over a batch; optionally stops after the
  * projection stage.  seeds_out / ext_out / pairs_out may be NULL. */
+/* one pair of processBAM::alignOneReadPair (mapper/processBAM.cpp:3129-3616); pairs are independent, the aligner is read-only */
+static void align_one_pair(Processor& P, const hlala_batch_in* in, int p, hlala_chains_out* seeds_out, hlala_chains_out* ext_out,
+                           hlala_pairs_out* pairs_out, int stop_after_projection)
+{
+    Aligner& A = *P.eA;
+    const int stride = P.params.max_columns;
+    const bool longRead = P.params.long_read_mode != 0;
+    const double IS_mean = P.params.insert_mean, IS_sd = P.params.insert_sd;
+    const double max_insertsize_penalty_log = log(normal_pdf(IS_mean, IS_sd, IS_mean + 8 * IS_sd));   /* processBAM.cpp:2342-2346 */
+    {
+        std::vector<Chain> ext[2]; std::vector<double> ll[2]; std::vector<int> extIdx[2];
+        bool pairErr = false;
+        for(int m = 0; m < 2; m++) {
+            int r = 2 * p + m;
+            std::string seq((const char*)in->read_bases + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
+            std::string qual((const char*)in->read_quals + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
+            int prim = in->read_primary[r];
+            bool primReverse = in->chain_reverse[prim] != 0;
+            /* oneRead in original orientation: invert() if the primary is on the reverse strand (:3147-3166) */
+            std::string oseq = primReverse ? invertRead(seq, true) : seq;
+            std::string oqual = primReverse ? invertRead(qual, false) : qual;
+            std::map<std::string, int> alignments_scores;                                            /* :3198 */
+            for(int c = in->chain_off[r]; c < in->chain_off[r + 1]; c++) {
+                BamRecord al; al.contig = in->chain_contig[c]; al.pos = in->chain_pos[c]; al.offset = in->chain_offset[c];
+                al.as = in->chain_as[c]; al.reverse = in->chain_reverse[c] != 0;
+                al.cigar.assign(in->cigar + in->cigar_off[c], in->cigar + in->cigar_off[c + 1]);
+                std::pair<int, int> ss = P.startstop(al);
+                std::string id = std::to_string(ss.first) + "//" + std::to_string(ss.second);
+                int score = al.as;
+                if(al.reverse != primReverse) {                                                     /* :3216 */
+                    storeChain(Chain(), c, stride, seeds_out, HLALA_CHAIN_SKIP_STRAND);
+                    storeChain(Chain(), c, stride, ext_out, HLALA_CHAIN_SKIP_STRAND);
+                    continue;
+                }
+                /* alignment2Chain (:3019-3127) is evaluated BEFORE the duplicate test in the reference (:3225 vs :3234);
+                 * its result is discarded for duplicates, so only its asserts could matter. */
+                ContigAlignment ca;
+                bool ok = P.transformBAMreadToInternalAlignment(al, seq, ca);
+                ORC_CHECK(ok, "alignment consists of insertions only");
+                Chain seed = P.PRGContigAlignment2Seed(ca, true);
+                if(alignments_scores.count(id) && alignments_scores.at(id) >= score) {               /* :3234 */
+                    storeChain(Chain(), c, stride, seeds_out, HLALA_CHAIN_SKIP_DUP);
+                    storeChain(Chain(), c, stride, ext_out, HLALA_CHAIN_SKIP_DUP);
+                    continue;
+                }
+                seed.checkConcordance(seq);
+                storeChain(seed, c, stride, seeds_out, HLALA_CHAIN_OK);
+                if(stop_after_projection) { if(alignments_scores.count(id) == 0 || alignments_scores.at(id) < score) alignments_scores[id] = score; continue; }
+                Chain e = A.extendSeedChain(seq, seed, P.params.rng_seed + 2u * (unsigned)c, P.params.rng_seed + 2u * (unsigned)c + 1u);
+                e.ll = A.scoreOneAlignment(e, oseq, oqual, longRead);
+                storeChain(e, c, stride, ext_out, HLALA_CHAIN_OK);
+                if((int)e.size() > stride) pairErr = true;
+                ext[m].push_back(e); ll[m].push_back(e.ll); extIdx[m].push_back(c);
+                if(alignments_scores.count(id) == 0 || alignments_scores.at(id) < score) alignments_scores[id] = score;
+            }
+        }
+        if(stop_after_projection || !pairs_out) return;
+        ORC_CHECK(ext[0].size() > 0 && ext[1].size() > 0, "no extended chains for a mate");           /* :3393-3394 */
+        /* pairing loop, :3408-3506 */
+        std::vector<std::pair<unsigned, unsigned>> idx; std::vector<double> LL;
+        for(unsigned i1 = 0; i1 < ext[0].size(); i1++)
+            for(unsigned i2 = 0; i2 < ext[1].size(); i2++) {
+                double combined = ll[0][i1] + ll[1][i2];
+                const Chain& c1 = ext[0][i1]; const Chain& c2 = ext[1][i2];
+                double ll_IS;
+                if(Processor::strandsValid(c1, c2)) {
+                    std::set<int> dist = P.pairDistances(c1, c2);
+                    if(dist.size()) {
+                        std::vector<double> lls;
+                        for(int d : dist) {
+                            double dP = normal_pdf(IS_mean, IS_sd, d);
+                            if(dP <= 0) lls.push_back(max_insertsize_penalty_log); else lls.push_back(log(dP));
+                        }
+                        ll_IS = firstMax(lls).first;
+                    } else ll_IS = max_insertsize_penalty_log;
+                } else ll_IS = max_insertsize_penalty_log;
+                combined += ll_IS;
+                LL.push_back(combined); idx.push_back({i1, i2});
+            }
+        auto mx = firstMax(LL);                                                                    /* :3538 */
+        Processor::PairResult R;
+        R.best1 = idx[mx.second].first; R.best2 = idx[mx.second].second; R.nComb = (int)idx.size(); R.ll = mx.first;
+        R.c1 = ext[0][R.best1]; R.c2 = ext[1][R.best2];
+        P.assignMappingQualities(R, idx, LL, mx, ext[0], ext[1]);
+        R.strandsOK = Processor::strandsValid(R.c1, R.c2);
+        if(pairs_out->pair_status) pairs_out->pair_status[p] = pairErr ? -1 : 0;
+        if(pairs_out->best_chain) { pairs_out->best_chain[2 * p] = extIdx[0][R.best1]; pairs_out->best_chain[2 * p + 1] = extIdx[1][R.best2]; }
+        if(pairs_out->n_combinations) pairs_out->n_combinations[p] = R.nComb;
+        if(pairs_out->pair_ll) pairs_out->pair_ll[p] = R.ll;
+        if(pairs_out->pair_mapq) pairs_out->pair_mapq[p] = R.mapQ;
+        if(pairs_out->mate_mapq) { pairs_out->mate_mapq[2 * p] = R.c1.mapQ; pairs_out->mate_mapq[2 * p + 1] = R.c2.mapQ; }
+        if(pairs_out->strands_valid) pairs_out->strands_valid[p] = R.strandsOK ? 1 : 0;
+        for(int m = 0; m < 2; m++) {
+            const Chain& c = m ? R.c2 : R.c1;
+            int r = 2 * p + m; int n = (int)c.size();
+            if(n > stride) { if(pairs_out->n_cols) pairs_out->n_cols[r] = 0; continue; }
+            if(pairs_out->n_cols) pairs_out->n_cols[r] = n;
+            size_t base = (size_t)r * stride;
+            for(int j = 0; j < n; j++) {
+                if(pairs_out->col_level) pairs_out->col_level[base + j] = c.levels[j];
+                if(pairs_out->col_edge) pairs_out->col_edge[base + j] = c.edges[j];
+                if(pairs_out->col_gchar) pairs_out->col_gchar[base + j] = (uint8_t)c.graph_aligned[j];
+                if(pairs_out->col_schar) pairs_out->col_schar[base + j] = (uint8_t)c.sequence_aligned[j];
+                if(pairs_out->col_fromseed) pairs_out->col_fromseed[base + j] = c.is_from_BWAseed[j];
+                if(pairs_out->col_mapq) pairs_out->col_mapq[base + j] = (uint8_t)c.mapQ_perPosition[j];
+            }
+        }
+    }
+}
+
 int orc_align_batch(orc_handle* h, const hlala_batch_in* in, hlala_chains_out* seeds_out, hlala_chains_out* ext_out,
                     hlala_pairs_out* pairs_out, int stop_after_projection, int64_t* stats)
 {
     try {
         Processor& P = h->P;
-        Aligner& A = *P.eA;
-        A.stat_calls = A.stat_iters = A.stat_cells = A.stat_edges = 0;
-        int stride = P.params.max_columns;
-        bool longRead = P.params.long_read_mode != 0;
-        double IS_mean = P.params.insert_mean, IS_sd = P.params.insert_sd;
-        double max_insertsize_penalty_log = log(normal_pdf(IS_mean, IS_sd, IS_mean + 8 * IS_sd));   /* processBAM.cpp:2342-2346 */
-        for(int p = 0; p < in->n_pairs; p++) {
-            std::vector<Chain> ext[2]; std::vector<double> ll[2]; std::vector<int> extIdx[2];
-            bool pairErr = false;
-            for(int m = 0; m < 2; m++) {
-                int r = 2 * p + m;
-                std::string seq((const char*)in->read_bases + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
-                std::string qual((const char*)in->read_quals + in->read_off[r], in->read_off[r + 1] - in->read_off[r]);
-                int prim = in->read_primary[r];
-                bool primReverse = in->chain_reverse[prim] != 0;
-                /* oneRead in original orientation: invert() if the primary is on the reverse strand (:3147-3166) */
-                std::string oseq = primReverse ? invertRead(seq, true) : seq;
-                std::string oqual = primReverse ? invertRead(qual, false) : qual;
-                std::map<std::string, int> alignments_scores;                                            /* :3198 */
-                for(int c = in->chain_off[r]; c < in->chain_off[r + 1]; c++) {
-                    BamRecord al; al.contig = in->chain_contig[c]; al.pos = in->chain_pos[c]; al.offset = in->chain_offset[c];
-                    al.as = in->chain_as[c]; al.reverse = in->chain_reverse[c] != 0;
-                    al.cigar.assign(in->cigar + in->cigar_off[c], in->cigar + in->cigar_off[c + 1]);
-                    std::pair<int, int> ss = P.startstop(al);
-                    std::string id = std::to_string(ss.first) + "//" + std::to_string(ss.second);
-                    int score = al.as;
-                    if(al.reverse != primReverse) {                                                     /* :3216 */
-                        storeChain(Chain(), c, stride, seeds_out, HLALA_CHAIN_SKIP_STRAND);
-                        storeChain(Chain(), c, stride, ext_out, HLALA_CHAIN_SKIP_STRAND);
-                        continue;
-                    }
-                    /* alignment2Chain (:3019-3127) is evaluated BEFORE the duplicate test in the reference (:3225 vs :3234);
-                     * its result is discarded for duplicates, so only its asserts could matter. */
-                    ContigAlignment ca;
-                    bool ok = P.transformBAMreadToInternalAlignment(al, seq, ca);
-                    ORC_CHECK(ok, "alignment consists of insertions only");
-                    Chain seed = P.PRGContigAlignment2Seed(ca, true);
-                    if(alignments_scores.count(id) && alignments_scores.at(id) >= score) {               /* :3234 */
-                        storeChain(Chain(), c, stride, seeds_out, HLALA_CHAIN_SKIP_DUP);
-                        storeChain(Chain(), c, stride, ext_out, HLALA_CHAIN_SKIP_DUP);
-                        continue;
-                    }
-                    seed.checkConcordance(seq);
-                    storeChain(seed, c, stride, seeds_out, HLALA_CHAIN_OK);
-                    if(stop_after_projection) { if(alignments_scores.count(id) == 0 || alignments_scores.at(id) < score) alignments_scores[id] = score; continue; }
-                    Chain e = A.extendSeedChain(seq, seed, P.params.rng_seed + 2u * (unsigned)c, P.params.rng_seed + 2u * (unsigned)c + 1u);
-                    e.ll = A.scoreOneAlignment(e, oseq, oqual, longRead);
-                    storeChain(e, c, stride, ext_out, HLALA_CHAIN_OK);
-                    if((int)e.size() > stride) pairErr = true;
-                    ext[m].push_back(e); ll[m].push_back(e.ll); extIdx[m].push_back(c);
-                    if(alignments_scores.count(id) == 0 || alignments_scores.at(id) < score) alignments_scores[id] = score;
-                }
-            }
-            if(stop_after_projection || !pairs_out) continue;
-            ORC_CHECK(ext[0].size() > 0 && ext[1].size() > 0, "no extended chains for a mate");           /* :3393-3394 */
-            /* pairing loop, :3408-3506 */
-            std::vector<std::pair<unsigned, unsigned>> idx; std::vector<double> LL;
-            for(unsigned i1 = 0; i1 < ext[0].size(); i1++)
-                for(unsigned i2 = 0; i2 < ext[1].size(); i2++) {
-                    double combined = ll[0][i1] + ll[1][i2];
-                    const Chain& c1 = ext[0][i1]; const Chain& c2 = ext[1][i2];
-                    double ll_IS;
-                    if(Processor::strandsValid(c1, c2)) {
-                        std::set<int> dist = P.pairDistances(c1, c2);
-                        if(dist.size()) {
-                            std::vector<double> lls;
-                            for(int d : dist) {
-                                double dP = normal_pdf(IS_mean, IS_sd, d);
-                                if(dP <= 0) lls.push_back(max_insertsize_penalty_log); else lls.push_back(log(dP));
-                            }
-                            ll_IS = firstMax(lls).first;
-                        } else ll_IS = max_insertsize_penalty_log;
-                    } else ll_IS = max_insertsize_penalty_log;
-                    combined += ll_IS;
-                    LL.push_back(combined); idx.push_back({i1, i2});
-                }
-            auto mx = firstMax(LL);                                                                    /* :3538 */
-            Processor::PairResult R;
-            R.best1 = idx[mx.second].first; R.best2 = idx[mx.second].second; R.nComb = (int)idx.size(); R.ll = mx.first;
-            R.c1 = ext[0][R.best1]; R.c2 = ext[1][R.best2];
-            P.assignMappingQualities(R, idx, LL, mx, ext[0], ext[1]);
-            R.strandsOK = Processor::strandsValid(R.c1, R.c2);
-            if(pairs_out->pair_status) pairs_out->pair_status[p] = pairErr ? -1 : 0;
-            if(pairs_out->best_chain) { pairs_out->best_chain[2 * p] = extIdx[0][R.best1]; pairs_out->best_chain[2 * p + 1] = extIdx[1][R.best2]; }
-            if(pairs_out->n_combinations) pairs_out->n_combinations[p] = R.nComb;
-            if(pairs_out->pair_ll) pairs_out->pair_ll[p] = R.ll;
-            if(pairs_out->pair_mapq) pairs_out->pair_mapq[p] = R.mapQ;
-            if(pairs_out->mate_mapq) { pairs_out->mate_mapq[2 * p] = R.c1.mapQ; pairs_out->mate_mapq[2 * p + 1] = R.c2.mapQ; }
-            if(pairs_out->strands_valid) pairs_out->strands_valid[p] = R.strandsOK ? 1 : 0;
-            for(int m = 0; m < 2; m++) {
-                const Chain& c = m ? R.c2 : R.c1;
-                int r = 2 * p + m; int n = (int)c.size();
-                if(n > stride) { if(pairs_out->n_cols) pairs_out->n_cols[r] = 0; continue; }
-                if(pairs_out->n_cols) pairs_out->n_cols[r] = n;
-                size_t base = (size_t)r * stride;
-                for(int j = 0; j < n; j++) {
-                    if(pairs_out->col_level) pairs_out->col_level[base + j] = c.levels[j];
-                    if(pairs_out->col_edge) pairs_out->col_edge[base + j] = c.edges[j];
-                    if(pairs_out->col_gchar) pairs_out->col_gchar[base + j] = (uint8_t)c.graph_aligned[j];
-                    if(pairs_out->col_schar) pairs_out->col_schar[base + j] = (uint8_t)c.sequence_aligned[j];
-                    if(pairs_out->col_fromseed) pairs_out->col_fromseed[base + j] = c.is_from_BWAseed[j];
-                    if(pairs_out->col_mapq) pairs_out->col_mapq[base + j] = (uint8_t)c.mapQ_perPosition[j];
-                }
-            }
-        }
-        if(stats) { stats[0] = A.stat_calls; stats[1] = A.stat_iters; stats[2] = A.stat_cells; stats[3] = A.stat_edges; }
+        t_stats.calls = t_stats.iters = t_stats.cells = t_stats.edges = 0;
+        for(int p = 0; p < in->n_pairs; p++) align_one_pair(P, in, p, seeds_out, ext_out, pairs_out, stop_after_projection);
+        if(stats) { stats[0] = t_stats.calls; stats[1] = t_stats.iters; stats[2] = t_stats.cells; stats[3] = t_stats.edges; }
         return 0;
     } catch(std::exception& e) { g_err = e.what(); return -1; }
+}
+
+/* The same over all host cores ("OpenMP parallel for schedule(dynamic,64) over pairs -- legal because pairs are
+ * independent"; the reference itself runs this loop on one thread, HLA-LA.cpp:799).  n_threads <= 0: omp_get_max_threads().
+ * Results are identical to orc_align_batch (every pair writes its own output rows; random seeds are per chain). */
+int orc_align_batch_mt(orc_handle* h, const hlala_batch_in* in, hlala_chains_out* seeds_out, hlala_chains_out* ext_out,
+                       hlala_pairs_out* pairs_out, int n_threads, int64_t* stats, int* threads_used)
+{
+    Processor& P = h->P;
+    if(n_threads <= 0) n_threads = omp_get_max_threads();
+    DpStats total; std::string firstErr; int used = 1;
+#pragma omp parallel num_threads(n_threads)
+    {
+        t_stats = DpStats();
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 64)
+        for(int p = 0; p < in->n_pairs; p++) {
+            try { align_one_pair(P, in, p, seeds_out, ext_out, pairs_out, 0); }
+            catch(std::exception& e) {
+#pragma omp critical
+                if(firstErr.empty()) firstErr = e.what();
+            }
+        }
+#pragma omp critical
+        total.add(t_stats);
+    }
+    if(threads_used) *threads_used = used;
+    if(stats) { stats[0] = total.calls; stats[1] = total.iters; stats[2] = total.cells; stats[3] = total.edges; }
+    if(!firstErr.empty()) { g_err = firstErr; return -1; }
+    return 0;
 }
 
 /* processBAM::alignOneLongRead (mapper/processBAM.cpp:3618-3838) + assignMappingQualities_unpaired (:3900-4059) for a batch of single

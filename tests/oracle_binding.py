@@ -128,6 +128,22 @@ class Oracle:
                                           int(stop_after_projection), stats.ctypes.data_as(P.c_i64p)))
         return dict(seeds=sd, ext=ed, pairs=pd, stats=stats)
 
+    def align_batch_mt(self, batch_in, n_threads=0, pairs_only=False):
+        """orc_align_batch_mt: the same result as align_batch, pairs spread over the host cores (OpenMP, dynamic chunks of 64)."""
+        s, keep = P.fill_struct(P.BatchIn, batch_in)
+        l = lib()
+        l.orc_align_batch_mt.argtypes = [C.c_void_p, C.POINTER(P.BatchIn), C.POINTER(P.ChainsOut), C.POINTER(P.ChainsOut), C.POINTER(P.PairsOut),
+                                         C.c_int, P.c_i64p, C.POINTER(C.c_int)]
+        po, pd = P.alloc_pairs_out(batch_in["n_pairs"], self.max_columns)
+        stats = np.zeros(4, np.int64); used = C.c_int(0)
+        if pairs_only:
+            self._check(l.orc_align_batch_mt(self.h, C.byref(s), None, None, C.byref(po), n_threads, stats.ctypes.data_as(P.c_i64p), C.byref(used)))
+            return dict(pairs=pd, stats=stats, threads=used.value)
+        so, sd = P.alloc_chains_out(batch_in["n_chains"], self.max_columns)
+        eo, ed = P.alloc_chains_out(batch_in["n_chains"], self.max_columns)
+        self._check(l.orc_align_batch_mt(self.h, C.byref(s), C.byref(so), C.byref(eo), C.byref(po), n_threads, stats.ctypes.data_as(P.c_i64p), C.byref(used)))
+        return dict(seeds=sd, ext=ed, pairs=pd, stats=stats, threads=used.value)
+
     def align_long_reads(self, batch_in):
         """alignOneLongRead per read of an unpaired batch (n_pairs = number of reads)."""
         s, keep = P.fill_struct(P.BatchIn, batch_in)
