@@ -369,6 +369,13 @@ class Typer:
     def load_g_groups(self, path):
         self._check(self.lib.hlala_typer_load_g_groups(self.h, str(path).encode()))
 
+    def g_translate(self, alleles):
+        """translate_allele_list_to_G_allele for a list of allele names: (G group or joined list, perfectly)."""
+        self.lib.hlala_typer_g_translate.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+        buf = C.create_string_buffer(1 << 16); perf = C.c_int32(0)
+        self._check(self.lib.hlala_typer_g_translate(self.h, ";".join(alleles).encode(), buf, len(buf), C.byref(perf)))
+        return buf.value.decode(), bool(perf.value)
+
     def locus(self, name, exons=None):
         h = C.c_void_p()
         if exons is None:
@@ -586,7 +593,7 @@ def load_library(path: str | None = None):
 EXPORTED_SYMBOLS = [
     "hlala_create", "hlala_destroy", "hlala_last_error", "hlala_graph_get_info", "hlala_graph_get_nodes",
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
-    "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
+    "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_set_first_chain", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_get_pairs_packed", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
     "hlala_kat_rand_r", "hlala_kat_exp", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
@@ -594,7 +601,7 @@ EXPORTED_SYMBOLS = [
     "hlala_bam_extract_seeds", "hlala_seed_batch_desc", "hlala_seed_batch_name", "hlala_seed_batch_free", "hlala_bam_last_error",
     "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
-    "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",
+    "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_g_translate", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",
     "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_unit_alignment_stats", "hlala_typer_write_summary", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_typer_end_output",
 ]
 
@@ -749,6 +756,11 @@ class Batch:
 
     def align(self):
         self.ctx._check(self.ctx.lib.hlala_align_batch(self.ctx.h, self.b), "hlala_align_batch")
+
+    def set_first_chain(self, first_chain: int):
+        """Absolute index of this batch's chain 0 in the caller's numbering: the DPs then draw the random seeds of the unsplit run."""
+        self.ctx.lib.hlala_batch_set_first_chain.argtypes = [C.c_void_p, C.c_uint32]
+        self.ctx._check(self.ctx.lib.hlala_batch_set_first_chain(self.b, first_chain), "hlala_batch_set_first_chain")
 
     def chains(self, stage: int) -> dict:
         s, d = alloc_chains_out(self.n_chains, self.ctx.max_columns)

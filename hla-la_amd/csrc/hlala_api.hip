@@ -70,6 +70,7 @@ struct hlala_batch {
     DevBatch* dB = nullptr;       // device copy of B
     std::vector<void*> allocs;
     int staged = 0;   // bit0 seeds available, bit1 extended, bit2 paired
+    uint32_t first_chain = 0;    // absolute index of the batch's chain 0 in the caller's numbering (hlala_batch_set_first_chain): offsets the random seeds
     float ms[3] = {0, 0, 0};
 };
 
@@ -494,6 +495,13 @@ int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_
     return HLALA_OK;
 }
 
+int hlala_batch_set_first_chain(hlala_batch* b, uint32_t first_chain)
+{
+    if(!b) return HLALA_E_ARG;
+    b->first_chain = first_chain;
+    return HLALA_OK;
+}
+
 void hlala_batch_destroy(hlala_batch* b)
 {
     if(!b) return;
@@ -559,16 +567,16 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
         // Items that outgrew it: two DPs per wave, then one wave per DP, then the large-capacity class (one block per CU).
         auto run_classes = [&](bool first) -> int {
             if(first) HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
-            hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             int rc_ = check_launch(c, "k_dp<tiny>"); if(rc_) return rc_;
             if(first) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
-            hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             rc_ = check_launch(c, "k_dp<mid>"); if(rc_) return rc_;
             if(first) HIP_TRY(c, hipEventRecord(c->ev[9], c->stream));
-            hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             rc_ = check_launch(c, "k_dp<small>"); if(rc_) return rc_;
             if(first) HIP_TRY(c, hipEventRecord(c->ev[10], c->stream));
-            hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            hipLaunchKernelGGL((k_dp<DpLarge, 3>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             return check_launch(c, "k_dp<large>");
         };
         rc = run_classes(true); if(rc) return rc;

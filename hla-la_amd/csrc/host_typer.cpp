@@ -229,6 +229,23 @@ std::string find_exon_file(const hlala_typer& T, const std::string& locus, const
 }
 }  // namespace
 
+// translate_allele_list_to_G_allele (hla/HLATyper.cpp:4095-4148) for a ';'-joined allele list (the members of a cluster): out receives
+// the G group (or the list itself when no member is known), *perfectly whether all known members share it; HLALA_E_STATE when no
+// G table is loaded or the locus (text before '*') is not in it (can_translateToG_locus, :4086-4092)
+extern "C" int hlala_typer_g_translate(const hlala_typer* t, const char* alleles, char* out, int32_t cap, int32_t* perfectly)
+try {
+    if(!t || !alleles || !out || cap < 1) return fail(HLALA_E_ARG, "hlala_typer_g_translate: null argument");
+    const std::vector<std::string> al = split(alleles, ";");
+    if(al.empty() || t->alleleToG.empty()) return fail(HLALA_E_STATE, "hlala_typer_g_translate: no G group table loaded");
+    const size_t star = al[0].find('*');
+    if(star == std::string::npos || !t->gLoci.count(al[0].substr(0, star))) return fail(HLALA_E_STATE, "hlala_typer_g_translate: locus not in the G group table");
+    bool perf = false; const std::string g = to_g_group(*t, al, perf);
+    if((int32_t)g.size() + 1 > cap) return fail(HLALA_E_CAPACITY, "hlala_typer_g_translate: output buffer too small");
+    memcpy(out, g.c_str(), g.size() + 1);
+    if(perfectly) *perfectly = perf ? 1 : 0;
+    return HLALA_OK;
+} catch(const std::exception& e_) { g_err = std::string("hlala_typer_g_translate: ") + e_.what(); return HLALA_E_ARG; }
+
 extern "C" int hlala_typer_locus(const hlala_typer* t, const char* locus, int32_t n_exons, const char* const* exon_ids, hlala_locus** out)
 try {
     if(!t || !locus || !out) return fail(HLALA_E_ARG, "hlala_typer_locus: null argument");

@@ -1,0 +1,229 @@
+// HLA-LA.cpp -- the `HLA-LA` host program of this repository: the process-level contract HLA-LA.pl relies on ("outer
+// contract"), with the read-to-PRG alignment and the HLATyper scoring running on the GPU behind the C ABI of include/hlala_gpu.h.
+//
+//   HLA-LA --action testBinary                                   prints the line the installation check greps for   (HLA-LA.cpp:129-132)
+//   HLA-LA --action prepareGraph --PRG_graph_dir G               leaves G/serializedGRAPH                          (HLA-LA.cpp:1341-1385; HLA-LA.pl:254-257)
+//   HLA-LA --action HLA --maxThreads N --sampleID S --outputDirectory D --PRG_graph_dir G --FASTQU U --FASTQ1 R1 --FASTQ2 R2
+//          --bwa_bin B --samtools_bin T --mapAgainstCompleteGenome 0|1 --longReads 0|ont2d|pacbio                  (HLA-LA.cpp:577-811; HLA-LA.pl:563)
+//
+// Arguments are `--name value` pairs, unknown names are ignored (HLA-LA.cpp:71-79).  Where the reference asserts or throws (abort /
+// terminate), this program prints the message to stderr and exits with a non-zero status -- HLA-LA.pl treats any non-zero status as
+// failure (:567-570).  Extra, optional arguments of this program: --device <gpu index>, --batchPairs <units per GPU batch>,
+// --rngSeed <base of the end-cell draws>, --loci A,B,... (default: the reference's 17 loci, hla/HLATyper.cpp:42).
+// Not rebuilt: the --BAM entry (the Perl driver never uses it: it extracts reads itself and passes FASTQ files), read simulation /
+// validation actions, KIR.
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <dirent.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "hlala_host.hpp"
+
+using namespace hlala::host;
+
+namespace {
+
+bool fileExists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+bool directoryExists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+void makeDir(const std::string& p) { if(mkdir(p.c_str(), 0775) != 0 && !directoryExists(p)) throw std::runtime_error("Cannot create directory " + p); }
+// Utilities::make_or_clearDirectory: the directory exists and holds no regular files afterwards
+void make_or_clearDirectory(const std::string& p)
+{
+    if(!directoryExists(p)) { makeDir(p); return; }
+    DIR* d = opendir(p.c_str()); if(!d) throw std::runtime_error("Cannot open directory " + p);
+    std::vector<std::string> files;
+    while(dirent* e = readdir(d)) { std::string n = e->d_name; if(n != "." && n != ".." && fileExists(p + "/" + n)) files.push_back(p + "/" + n); }
+    closedir(d);
+    for(const std::string& f : files) if(unlink(f.c_str()) != 0) throw std::runtime_error("Cannot delete " + f);
+}
+std::string getFirstLine(const std::string& p) { std::ifstream f(p.c_str()); std::string l; std::getline(f, l); while(!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back(); return l; }
+std::string timestamp() { time_t t = time(nullptr); char b[64]; strftime(b, sizeof b, "[%Y-%m-%d %H:%M:%S] ", localtime(&t)); return b; }
+bool StrtoB(const std::string& s) { return s == "1" || s == "true" || s == "TRUE" || s == "True"; }
+void need(const std::map<std::string, std::string>& a, const char* k) { if(!a.count(k)) throw std::runtime_error(std::string("Missing argument --") + k); }
+bool intervalsOverlap(int x1, int x2, int y1, int y2) { return x1 <= y2 && y1 <= x2; }          // Utilities.cpp:168-176 (closed intervals)
+
+void run(const std::string& cmd)
+{
+    std::cerr << cmd << "\n" << std::flush;
+    int rc = std::system(cmd.c_str());
+    if(rc != 0) throw std::runtime_error("Command " + cmd + " returned code " + std::to_string(rc));
+}
+
+// mapper::bwa::BWAmapper (mapper/bwa/BWAmapper.cpp): the same command lines
+struct BWAmapper {
+    std::string bwa_bin, samtools_bin; int threads;
+    bool ref_is_indexed(const std::string& ref) const { for(const char* s : {".sa", ".ann", ".bwt"}) if(!fileExists(ref + s)) return false; return true; }      // :53-65
+    void make_sure_ref_is_indexed(const std::string& ref) const { if(!ref_is_indexed(ref)) run(bwa_bin + " index " + ref); }
+    void sort_and_index(const std::string& outputBAM, const std::string& outputUnsorted) const
+    {
+        run(samtools_bin + " sort -@ " + std::to_string(threads) + " -o " + outputBAM + " " + outputUnsorted);
+        if(!fileExists(outputBAM)) throw std::runtime_error("samtools sort did not produce " + outputBAM);
+        run(samtools_bin + " index " + outputBAM);
+        if(!fileExists(outputBAM + ".bai")) throw std::runtime_error("samtools index did not produce " + outputBAM + ".bai");
+        unlink(outputUnsorted.c_str());
+    }
+    void prepare(const std::string& ref, const std::string& outputBAM, std::string& outputUnsorted) const
+    {
+        if(!fileExists(bwa_bin)) throw std::runtime_error("bwa binary not found: " + bwa_bin);
+        if(!fileExists(samtools_bin)) throw std::runtime_error("samtools binary not found: " + samtools_bin);
+        make_sure_ref_is_indexed(ref);
+        if(fileExists(outputBAM)) unlink(outputBAM.c_str());
+        outputUnsorted = outputBAM + ".unsorted";
+        if(fileExists(outputUnsorted)) unlink(outputUnsorted.c_str());
+        if(outputBAM.size() < 4 || outputBAM.substr(outputBAM.size() - 4) != ".bam") throw std::runtime_error("output BAM must end in .bam");
+    }
+    // BWAmapper::map, :178-243
+    void map(const std::string& ref, const std::string& FASTQ1, const std::string& FASTQ2, const std::string& outputBAM, bool withA) const
+    {
+        if(!fileExists(FASTQ1) || !fileExists(FASTQ2)) throw std::runtime_error("FASTQ file not found: " + FASTQ1 + " / " + FASTQ2);
+        std::string unsorted; prepare(ref, outputBAM, unsorted);
+        run(bwa_bin + " mem -t" + std::to_string(threads) + " -M " + (withA ? "-a " : "") + ref + " " + FASTQ1 + " " + FASTQ2 + " | " + samtools_bin + " view -@ " +
+            std::to_string(threads - 1) + " -Sb - > " + unsorted);
+        sort_and_index(outputBAM, unsorted);
+    }
+    // BWAmapper::mapLong, :122-176
+    void mapLong(const std::string& ref, const std::string& FASTQ, const std::string& outputBAM, bool withA, const std::string& longMode) const
+    {
+        if(!fileExists(FASTQ)) throw std::runtime_error("FASTQ file not found: " + FASTQ);
+        std::string unsorted; prepare(ref, outputBAM, unsorted);
+        run(bwa_bin + " mem -t" + std::to_string(threads) + " -x " + longMode + " -M " + (withA ? "-a " : "") + ref + " " + FASTQ + " | " + samtools_bin + " view -@ " +
+            std::to_string(threads - 1) + " -Sb - > " + unsorted);
+        sort_and_index(outputBAM, unsorted);
+    }
+};
+
+int action_prepareGraph(const std::map<std::string, std::string>& arguments)
+{
+    need(arguments, "PRG_graph_dir");
+    const std::string G = arguments.at("PRG_graph_dir");
+    std::cout << "prepareGraph\n" << std::flush;
+    std::cout << timestamp() << "Read graph from " << G << "\n" << std::flush;
+    hlala_graph_file* g = nullptr;
+    if(hlala_graph_load_text((G + "/PRG/graph.txt").c_str(), &g) != HLALA_OK) throw std::runtime_error(std::string("graph.txt: ") + hlala_loader_last_error());
+    std::cout << timestamp() << "\tdone\n" << std::flush;
+    hlala_graph_desc gd; hlala_graph_file_desc(g, &gd);
+    // the reference writes two Boost archives, before and after computeGapEdgePaths; here the flattened arrays are the serialisation (the
+    // gap-path index is rebuilt from them in well under a second at start-up), written under both names
+    for(const char* name : {"/serializedGRAPH_preGapPathIndex", "/serializedGRAPH"}) {
+        std::cout << timestamp() << "Now serialize graph to " << G << name << "\n" << std::flush;
+        if(hlala_graph_cache_save(&gd, (G + name).c_str()) != HLALA_OK) { std::string e = hlala_loader_last_error(); hlala_graph_file_free(g); throw std::runtime_error("Cannot write " + G + name + ": " + e); }
+        std::cout << timestamp() << "\tdone\n" << std::flush;
+    }
+    hlala_graph_file_free(g);
+    return 0;
+}
+
+int action_HLA(const std::map<std::string, std::string>& arguments)
+{
+    unsigned int maxThreads = 1;
+    need(arguments, "sampleID"); need(arguments, "outputDirectory"); need(arguments, "PRG_graph_dir");
+    if(!(arguments.count("BAM") || (arguments.count("FASTQ1") && arguments.count("FASTQ2")))) throw std::runtime_error("Please specify --BAM or --FASTQ1 / --FASTQ2");
+    const std::string outputDirectory = arguments.at("outputDirectory"), PRG_graph_dir = arguments.at("PRG_graph_dir");
+    if(arguments.count("FASTQ1")) { need(arguments, "mapAgainstCompleteGenome"); if(arguments.count("BAM")) throw std::runtime_error("--BAM and --FASTQ1 exclude each other"); }
+    if(arguments.count("maxThreads")) { maxThreads = (unsigned)std::atoi(arguments.at("maxThreads").c_str()); if(maxThreads < 1) maxThreads = 1; std::cout << "Set maxThreads to " << maxThreads << "\n" << std::flush; }
+    if(arguments.count("BAM"))
+        throw std::runtime_error("--BAM is not supported by this build: HLA-LA.pl extracts the reads itself and calls --action HLA with --FASTQ1 / --FASTQ2 / --FASTQU");
+    if(!directoryExists(outputDirectory)) makeDir(outputDirectory);
+
+    const std::string BAM_remapped = outputDirectory + "/remapped_with_a.bam";
+    const std::string PRGonlyReferenceGenomePath = PRG_graph_dir + "/mapping_PRGonly/referenceGenome.fa";
+    std::string extendedReferenceGenomePath;
+    if(fileExists(PRG_graph_dir + "/extendedReferenceGenomePath.txt")) extendedReferenceGenomePath = getFirstLine(PRG_graph_dir + "/extendedReferenceGenomePath.txt");
+    else extendedReferenceGenomePath = PRG_graph_dir + "/extendedReferenceGenome/extendedReferenceGenome.fa";
+    BWAmapper bwaMapper{arguments.at("bwa_bin"), arguments.at("samtools_bin"), (int)maxThreads};
+    const bool remap_with_a = arguments.count("remap_with_a") ? StrtoB(arguments.at("remap_with_a")) : true;
+
+    need(arguments, "FASTQ1"); need(arguments, "FASTQ2"); need(arguments, "longReads");
+    std::string longReads = arguments.at("longReads");
+    if(!(longReads == "0" || longReads == "ont2d" || longReads == "pacbio")) throw std::runtime_error("--longReads must be 0, ont2d or pacbio");
+    if(longReads == "0") longReads = "";
+    if(longReads.length()) need(arguments, "FASTQU");
+    const bool mapAgainstCompleteGenome = StrtoB(arguments.at("mapAgainstCompleteGenome"));
+    const std::string referenceGenomeForMapping = mapAgainstCompleteGenome ? extendedReferenceGenomePath : PRGonlyReferenceGenomePath;
+    if(!fileExists(referenceGenomeForMapping)) throw std::runtime_error("Reference genome not found: " + referenceGenomeForMapping);
+    if(longReads.length()) bwaMapper.mapLong(referenceGenomeForMapping, arguments.at("FASTQU"), BAM_remapped, remap_with_a, longReads);
+    else bwaMapper.map(referenceGenomeForMapping, arguments.at("FASTQ1"), arguments.at("FASTQ2"), BAM_remapped, remap_with_a);
+    std::cout << timestamp() << "Remapping done.\n" << std::flush;
+    if(!fileExists(BAM_remapped) || !fileExists(BAM_remapped + ".bai")) throw std::runtime_error("Remapping did not produce " + BAM_remapped + " and its index");
+
+    const int device = arguments.count("device") ? std::atoi(arguments.at("device").c_str()) : 0;
+    const int32_t batchPairs = arguments.count("batchPairs") ? (int32_t)std::atol(arguments.at("batchPairs").c_str()) : (longReads.length() ? 65536 : 1048576);
+    const uint32_t rngSeed = arguments.count("rngSeed") ? (uint32_t)std::strtoul(arguments.at("rngSeed").c_str(), nullptr, 10) : 0u;
+    // long reads: columns of a read incl. the levels it skips (hlala_batch_create_unpaired)
+    mapper::processBAM BAMprocessor(PRG_graph_dir, mapAgainstCompleteGenome, longReads.length() ? 16384 : 384, rngSeed, device);
+    // the G-group table is looked up in the working directory, as the reference does (hla/HLATyper.cpp:4160-4166; HLA-LA.pl chdirs to the source directory)
+    hla::HLATyper HLAtyper(PRG_graph_dir, fileExists("hla_nom_g.txt") ? "hla_nom_g.txt" : "");
+    std::vector<std::string> loci;
+    if(arguments.count("loci")) { const std::string l = arguments.at("loci"); for(size_t p = 0;;) { size_t q = l.find(',', p); loci.push_back(l.substr(p, q == std::string::npos ? q : q - p)); if(q == std::string::npos) break; p = q + 1; } }
+    else for(const char* l : {"A", "B", "C", "DQA1", "DQB1", "DRB1", "DPA1", "DPB1", "DRA", "DRB3", "DRB4", "E", "F", "G", "H", "K", "V"}) {          // hla/HLATyper.cpp:42
+        if(HLAtyper.has_locus(l)) loci.push_back(l); else std::cerr << "HLATypeInference(..): Locus " << l << ": no exon files in " << PRG_graph_dir << "/PRG -- skipped\n";
+    }
+
+    std::cout << timestamp() << "Start seed extraction\n" << std::flush;
+    BAMprocessor.openBAM(BAM_remapped, longReads.length() != 0, batchPairs);
+    if(!longReads.length()) std::cout << "Insert size: mean " << BAMprocessor.IS_mean << ", sd " << BAMprocessor.IS_sd << "\n" << std::flush;
+    const std::string outputDirectory_for_HLA = outputDirectory + "/hla/";
+    make_or_clearDirectory(outputDirectory + "/hla");                                                   // processBAM.cpp:1805-1806
+    std::cout << timestamp() << "Alignment of " << BAMprocessor.n_units << (longReads.length() ? " reads" : " read pairs") << " in " << BAMprocessor.n_batches() << " GPU batch(es)\n" << std::flush;
+    double alignSeconds = 0; int64_t chainErrors = 0;
+    std::vector<hla::HLATyper::bestGuess> calls = HLAtyper.HLATypeInference(BAMprocessor, outputDirectory_for_HLA, loci, &alignSeconds, &chainErrors);
+    const size_t pairs = longReads.length() ? 0 : (size_t)BAMprocessor.n_units, unpaired = longReads.length() ? (size_t)BAMprocessor.n_units : 0;
+    std::cout << timestamp() << "Processed " << pairs << " protoSeeds (read pairs) / " << unpaired << " protoSeeds (unpaired long reads)\n" << std::flush;
+    std::cout << "Speed: " << (alignSeconds > 0 ? (double)(pairs + unpaired) / alignSeconds : 0.0) << " protoSeeds (read pairs) per s" << "\n" << std::flush;      // :1894-1898
+    if(chainErrors) std::cerr << "WARNING: " << chainErrors << " alignments exceeded a device capacity; their read pairs are not used for typing\n";
+    // reads_per_level.txt, processBAM.cpp:1902-1913
+    {
+        std::vector<int32_t> cov((size_t)(BAMprocessor.n_levels > 1 ? BAMprocessor.n_levels - 1 : 1));
+        if(hlala_get_coverage(BAMprocessor.ctx(), cov.data(), 0) != HLALA_OK) throw std::runtime_error(std::string("hlala_get_coverage: ") + hlala_last_error(BAMprocessor.ctx()));
+        std::ofstream levels_stream((outputDirectory + "/reads_per_level.txt").c_str());
+        if(!levels_stream.is_open()) throw std::runtime_error("Cannot open " + outputDirectory + "/reads_per_level.txt");
+        for(size_t lI = 0; lI + 1 < (size_t)BAMprocessor.n_levels; lI++) levels_stream << lI << "\t" << HLAtyper.level_name((int32_t)lI) << "\t" << cov[lI] << "\n";
+    }
+    if(!fileExists(outputDirectory + "/hla/R1_bestguess.txt")) throw std::runtime_error("HLA type inference did not produce " + outputDirectory + "/hla/R1_bestguess.txt");
+    for(const hla::HLATyper::bestGuess& g : calls) std::cout << "Locus " << g.locus << ": " << g.allele1 << " (Q1 " << g.Q1_allele1 << ") / " << g.allele2 << " (Q1 " << g.Q1_allele2 << ")\n";
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[])
+{
+    try {
+        std::vector<std::string> ARG(argv + 1, argv + argc);
+        std::map<std::string, std::string> arguments;
+        for(unsigned int i = 0; i < ARG.size(); i++)
+            if((ARG.at(i).length() > 2) && (ARG.at(i).substr(0, 2) == "--")) {                          // HLA-LA.cpp:71-79 (a trailing name without a value throws there too)
+                if(i + 1 >= ARG.size()) throw std::runtime_error("Argument " + ARG.at(i) + " has no value");
+                arguments[ARG.at(i).substr(2)] = ARG.at(i + 1);
+            }
+        // the start-up self test of the reference, HLA-LA.cpp:94-102
+        if(intervalsOverlap(1, 10, 11, 20) || intervalsOverlap(5, 11, 1, 4) || !intervalsOverlap(5, 11, 8, 11) || !intervalsOverlap(8, 11, 1, 9) || !intervalsOverlap(8, 11, 9, 10) ||
+           !intervalsOverlap(9, 10, 8, 11) || !intervalsOverlap(1, 10, 2, 3) || !intervalsOverlap(2, 3, 1, 10)) throw std::runtime_error("intervalsOverlap self test failed");
+        if(arguments.count("action") == 0) {
+            std::cerr << "\n\nMissing --action parameter. Please don't try calling me directly; use HLA-LA.pl instead (see documentation on GitHub).\n" << std::endl;
+            throw std::runtime_error("Missing arguments -- see above.");
+        }
+        const std::string action = arguments.at("action");
+        const std::set<std::string> noBinariesRequired = {"prepareGraph", "testBinary"};
+        if(noBinariesRequired.count(action) == 0 && !arguments.count("bwa_bin")) throw std::runtime_error("Please specify arguments --bwa_bin");
+        if(noBinariesRequired.count(action) == 0 && !arguments.count("samtools_bin")) throw std::runtime_error("Please specify arguments --samtools_bin");
+        if(!std::system(NULL)) { std::cerr << "\n\nMissing shell - std::system(NULL) has returned a 0 value.\n" << std::endl; throw std::runtime_error("Missing shell"); }
+        if(action == "testBinary") { std::cout << "\nHLA*LA binary functional!\n\n"; return 0; }
+        if(action == "prepareGraph") return action_prepareGraph(arguments);
+        if(action == "HLA") return action_HLA(arguments);
+        throw std::runtime_error("Action " + action + " is not part of this build (available: HLA, prepareGraph, testBinary)");
+    } catch(const std::exception& e) {
+        std::cerr << "HLA-LA: " << e.what() << "\n" << std::flush;
+        return 1;
+    }
+}

@@ -11,6 +11,7 @@
 // error text (the reference aborts the process; a maintainer can keep that with a catch-all + abort()).
 // Header-only, needs only a C++11 compiler and libhlala_gpu.so -- no HIP headers.
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -220,56 +221,104 @@ private:
 
 }  // namespace aligner
 
-// mapper::processBAM as far as the hot path needs it: the graph directory (PRG/graph.txt, sequences.txt, reference FASTA,
-// translation files) becomes a context, a BAM file becomes a batch resident on the GPU, aligned in place.
+// mapper::processBAM as far as the hot path needs it: the graph directory (serializedGRAPH cache or PRG/graph.txt, sequences.txt,
+// reference FASTA, translation files) becomes a context; a BAM file becomes seeds that go through the GPU in batches of at most
+// `batchPairs` units (the reference walks 10 000 read IDs at a time, mapper/processBAM.cpp:1794; BASELINE config 3 is ~10 M pairs).
 class processBAM {
 public:
     processBAM(const std::string& graphDir, bool extendedReferenceGenome, int max_columns = 384, uint32_t rng_seed = 0, int device = 0)
         : graphDir_(graphDir), extended_(extendedReferenceGenome), max_columns_(max_columns), rng_seed_(rng_seed), device_(device)
     {
-        if(hlala_graph_load_text((graphDir + "/PRG/graph.txt").c_str(), &graph_) != HLALA_OK) throw std::runtime_error(std::string("graph.txt: ") + hlala_loader_last_error());
+        // `--action prepareGraph` leaves the flattened arrays in <graphDir>/serializedGRAPH; a file of that name written by the reference
+        // binary (a Boost archive) is not ours and the text graph is parsed instead
+        if(hlala_graph_cache_load((graphDir + "/serializedGRAPH").c_str(), &graph_) != HLALA_OK) {
+            graph_ = nullptr;
+            if(hlala_graph_load_text((graphDir + "/PRG/graph.txt").c_str(), &graph_) != HLALA_OK) throw std::runtime_error(std::string("graph.txt: ") + hlala_loader_last_error());
+        }
         if(hlala_contigs_load_dir(graphDir.c_str(), extendedReferenceGenome ? 1 : 0, &contigs_) != HLALA_OK) throw std::runtime_error(std::string("contigs: ") + hlala_loader_last_error());
         intervals_.resize((size_t)hlala_contigs_file_intervals(contigs_, nullptr, 0));
         hlala_contigs_file_intervals(contigs_, intervals_.data(), (int32_t)intervals_.size());
     }
-    ~processBAM() { if(batch_) hlala_batch_destroy(batch_); if(seeds_) hlala_seed_batch_free(seeds_); if(ctx_) hlala_destroy(ctx_); hlala_contigs_file_free(contigs_); hlala_graph_file_free(graph_); }
+    ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); if(seeds_) hlala_seed_batch_free(seeds_); if(ctx_) hlala_destroy(ctx_); hlala_contigs_file_free(contigs_); hlala_graph_file_free(graph_); }
     processBAM(const processBAM&) = delete;
     processBAM& operator=(const processBAM&) = delete;
 
-    // extractSeeds2 + estimateInsertSize + alignReads_postSeedExtraction (mapper/processBAM.cpp:703-864, 1071-1165, 2391-2483)
-    void alignReads(const std::string& BAM, bool longReads = false)
+    // initBAM + extractSeeds2 + estimateInsertSize (mapper/processBAM.cpp:1183-1402, 703-864, 1071-1165): seeds of all complete units, insert
+    // size from the first 4000 of them (:1075), then the context with that insert size.  batchPairs = 0: one batch.
+    void openBAM(const std::string& BAM, bool longReads = false, int32_t batchPairs = 0)
     {
         if(hlala_bam_extract_seeds(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, &seeds_) != HLALA_OK) throw std::runtime_error(std::string("BAM: ") + hlala_bam_last_error());
-        hlala_batch_in in; int64_t counts[3]; hlala_seed_batch_desc(seeds_, &in, counts);
+        int64_t counts[3]; hlala_seed_batch_desc(seeds_, &in_, counts);
+        n_units = in_.n_pairs; longReadsMode = longReads;
         readIDs.clear();
-        for(int32_t u = 0; u < in.n_pairs; u++) readIDs.push_back(hlala_seed_batch_name(seeds_, u));
+        for(int32_t u = 0; u < in_.n_pairs; u++) readIDs.push_back(hlala_seed_batch_name(seeds_, u));
         hlala_graph_desc gd; hlala_graph_file_desc(graph_, &gd);
         hlala_contigs_desc cd; hlala_contigs_file_desc(contigs_, &cd);
+        n_levels = gd.n_levels;
         hlala_params pr{200.0, 35.0, rng_seed_, longReads ? 1 : 0, max_columns_, 0};
         if(!longReads) {                                                              // insert size from this sample, then the real context
+            if(n_units == 0) throw std::runtime_error("estimateInsertSize: no complete read pair in " + BAM);
             hlala_ctx* c0 = nullptr;
             if(hlala_create(&c0, device_, nullptr, &gd, &cd, &pr) != HLALA_OK) throw std::runtime_error(std::string("hlala_create: ") + hlala_last_error(nullptr));
-            hlala_insert_size_out is; int rc = hlala_estimate_insert_size(c0, &in, &is);
+            Slice first; slice(0, n_units < 4000 ? n_units : 4000, first);
+            hlala_insert_size_out is; int rc = hlala_estimate_insert_size(c0, &first.in, &is);
             std::string e = rc ? hlala_last_error(c0) : ""; hlala_destroy(c0);
             if(rc) throw std::runtime_error("estimateInsertSize: " + e);
             IS_mean = is.mean; IS_sd = is.sd; pr.insert_mean = is.mean; pr.insert_sd = is.sd;
         }
         if(hlala_create(&ctx_, device_, nullptr, &gd, &cd, &pr) != HLALA_OK) throw std::runtime_error(std::string("hlala_create: ") + hlala_last_error(nullptr));
-        int rc = longReads ? hlala_batch_create_unpaired(ctx_, &in, &batch_) : hlala_batch_create(ctx_, &in, &batch_);
-        if(rc == HLALA_OK) rc = hlala_align_batch(ctx_, batch_);
-        if(rc != HLALA_OK) throw std::runtime_error(std::string("alignReads: ") + hlala_last_error(ctx_));
-        n_units = in.n_pairs; longReadsMode = longReads;
+        batchPairs_ = batchPairs > 0 ? batchPairs : (n_units > 0 ? n_units : 1);
+        live_.assign(n_batches(), nullptr);
     }
+    int32_t n_batches() const { return n_units == 0 ? 0 : (n_units + batchPairs_ - 1) / batchPairs_; }
+    int32_t batch_first_unit(int32_t bi) const { return bi * batchPairs_; }
+    int32_t batch_units(int32_t bi) const { int32_t a = bi * batchPairs_, z = a + batchPairs_; return (z > n_units ? n_units : z) - a; }
+    // batch bi resident on the GPU: uploaded and, if `align`, run through alignOneReadPair / alignOneLongRead (:3129 / :3618); the chains
+    // keep their absolute numbers, so every DP draws the random seed it would draw in one big batch
+    hlala_batch* acquire(int32_t bi, bool align)
+    {
+        if(live_.at(bi)) return live_[bi];
+        Slice s; slice(batch_first_unit(bi), batch_units(bi), s);
+        hlala_batch* b = nullptr;
+        int rc = longReadsMode ? hlala_batch_create_unpaired(ctx_, &s.in, &b) : hlala_batch_create(ctx_, &s.in, &b);
+        if(rc == HLALA_OK) rc = hlala_batch_set_first_chain(b, (uint32_t)s.first_chain);
+        if(rc == HLALA_OK && align) rc = hlala_align_batch(ctx_, b);
+        if(rc != HLALA_OK) { std::string e = hlala_last_error(ctx_); if(b) hlala_batch_destroy(b); throw std::runtime_error("alignReads: " + e); }
+        live_[bi] = b;
+        return b;
+    }
+    void release(int32_t bi) { if(live_.at(bi)) { hlala_batch_destroy(live_[bi]); live_[bi] = nullptr; } }
+
+    // extractSeeds2 + estimateInsertSize + alignReads_postSeedExtraction (mapper/processBAM.cpp:703-864, 1071-1165, 2391-2483), one batch
+    void alignReads(const std::string& BAM, bool longReads = false) { openBAM(BAM, longReads, 0); if(n_units > 0) acquire(0, true); }
     hlala_ctx* ctx() const { return ctx_; }
-    hlala_batch* batch() const { return batch_; }
+    hlala_batch* batch() const { return live_.empty() ? nullptr : live_[0]; }
     std::vector<std::string> readIDs;
     double IS_mean = 200.0, IS_sd = 35.0;
-    int32_t n_units = 0; bool longReadsMode = false;
+    int32_t n_units = 0, n_levels = 0; bool longReadsMode = false;
 
 private:
+    // units [u0, u0 + n) of the seeds as a batch descriptor of their own (offset arrays rebased to 0)
+    struct Slice { hlala_batch_in in; std::vector<int32_t> read_off, chain_off, read_primary, cigar_off; int64_t first_chain = 0; };
+    void slice(int32_t u0, int32_t n, Slice& s) const
+    {
+        const int per = longReadsMode ? 1 : 2; const int32_t r0 = per * u0, nr = per * n;
+        const int32_t c0 = in_.chain_off[r0], c1 = in_.chain_off[r0 + nr], b0 = in_.read_off[r0], g0 = in_.cigar_off[c0];
+        s.read_off.resize((size_t)nr + 1); s.chain_off.resize((size_t)nr + 1); s.read_primary.resize((size_t)nr); s.cigar_off.resize((size_t)(c1 - c0) + 1);
+        for(int32_t i = 0; i <= nr; i++) { s.read_off[i] = in_.read_off[r0 + i] - b0; s.chain_off[i] = in_.chain_off[r0 + i] - c0; }
+        for(int32_t i = 0; i < nr; i++) s.read_primary[i] = in_.read_primary[r0 + i] - c0;
+        for(int32_t i = 0; i <= c1 - c0; i++) s.cigar_off[i] = in_.cigar_off[c0 + i] - g0;
+        s.first_chain = c0;
+        s.in = in_;
+        s.in.n_pairs = n; s.in.read_off = s.read_off.data(); s.in.read_bases = in_.read_bases + b0; s.in.read_quals = in_.read_quals + b0;
+        s.in.chain_off = s.chain_off.data(); s.in.read_primary = s.read_primary.data(); s.in.n_chains = c1 - c0;
+        s.in.chain_contig = in_.chain_contig + c0; s.in.chain_pos = in_.chain_pos + c0; s.in.chain_offset = in_.chain_offset + c0; s.in.chain_as = in_.chain_as + c0;
+        s.in.chain_reverse = in_.chain_reverse + c0; s.in.cigar_off = s.cigar_off.data(); s.in.cigar = in_.cigar + g0;
+    }
     std::string graphDir_; bool extended_; int max_columns_; uint32_t rng_seed_; int device_;
     hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; std::vector<hlala_bam_interval> intervals_;
-    hlala_seed_batch* seeds_ = nullptr; hlala_ctx* ctx_ = nullptr; hlala_batch* batch_ = nullptr;
+    hlala_seed_batch* seeds_ = nullptr; hlala_batch_in in_{}; hlala_ctx* ctx_ = nullptr;
+    int32_t batchPairs_ = 1; std::vector<hlala_batch*> live_;
 };
 }  // namespace mapper
 
@@ -295,80 +344,150 @@ public:
 
     struct bestGuess { std::string locus, allele1, allele2; double Q1_allele1 = 0, Q1_allele2 = 0; hlala_locus_report_out summary; };
 
-    std::vector<bestGuess> HLATypeInference(mapper::processBAM& pB, const std::string& outputDirectory, const std::vector<std::string>& loci_for_HLAtyping)
+    // Per-batch part of alignReads_postSeedExtraction_andStoreInto + HLATypeInference, then the per-locus chain.  The sample's units go
+    // through the GPU batch by batch (processBAM::acquire); what the typing needs of a batch -- includeInHLA, the per-unit alignment
+    // statistics and the exon positions of every locus -- is taken while the batch is resident and appended on the host.
+    // align_seconds (optional) receives the time spent in alignment proper (the reference's "Speed:" line, processBAM.cpp:1894-1898).
+    std::vector<bestGuess> HLATypeInference(mapper::processBAM& pB, const std::string& outputDirectory, const std::vector<std::string>& loci_for_HLAtyping,
+                                            double* align_seconds = nullptr, int64_t* chain_errors = nullptr)
     {
-        hlala_ctx* c = pB.ctx(); hlala_batch* b = pB.batch();
+        hlala_ctx* c = pB.ctx();
         auto chk = [&](int rc, const char* what) { if(rc != HLALA_OK) throw std::runtime_error(std::string(what) + ": " + hlala_last_error(c)); };
         auto tchk = [&](int rc, const char* what) { if(rc != HLALA_OK) throw std::runtime_error(std::string(what) + ": " + hlala_typer_last_error()); };
         // interestingLevels -> coverage counters and includeInHLA (mapper/processBAM.cpp:2411-2446)
         std::vector<int32_t> first, last;
         for(int32_t i = 0; i < hlala_typer_n_genes(t_); i++) { const char* nm; int32_t a, z; hlala_typer_gene(t_, i, &nm, &a, &z); first.push_back(a); last.push_back(z); }
         chk(hlala_set_gene_intervals(c, (int32_t)first.size(), first.data(), last.data()), "hlala_set_gene_intervals");
-        std::vector<uint8_t> include((size_t)pB.n_units);
-        chk(hlala_postprocess_pairs(c, b, include.data()), "hlala_postprocess_pairs");
+        const size_t nU = (size_t)pB.n_units;
+        std::vector<uint8_t> include(nU + 1);
         std::vector<const char*> names; for(const std::string& s : pB.readIDs) names.push_back(s.c_str());
         tchk(hlala_typer_begin_output(outputDirectory.c_str(), 0.2), "hlala_typer_begin_output");
-        // read alignment statistics (hla/HLATyper.cpp:1030-1125) and the per-pair quantities of the histogram lines
-        const size_t nU = (size_t)pB.n_units;
         std::vector<uint8_t> usValid(nU + 1), usStrands(nU + 1); std::vector<int32_t> usDist(nU + 1), usCols(2 * nU + 1); std::vector<double> usF(2 * nU + 1), usW(2 * nU + 1), usQ(2 * nU + 1);
-        hlala_unit_stats_out us{usValid.data(), usStrands.data(), usDist.data(), usF.data(), usW.data(), usCols.data(), usQ.data()};
-        chk(hlala_unit_alignment_stats(c, b, &us), "hlala_unit_alignment_stats");
-        tchk(hlala_typer_write_summary(outputDirectory.c_str(), pB.n_units, pB.longReadsMode ? 1 : 0, include.data(), &us, pB.IS_mean, pB.IS_sd, minAlignmentLength_unpaired), "hlala_typer_write_summary");
         if(pB.longReadsMode) filterParams.long_read_strand_filter = 1;
-        std::vector<bestGuess> out; std::string lociJoined;
-        for(const std::string& locus : loci_for_HLAtyping) {
-            hlala_locus* L = nullptr; tchk(hlala_typer_locus(t_, locus.c_str(), 0, nullptr, &L), "hlala_typer_locus");
-            struct Free { hlala_locus* l; ~Free() { hlala_locus_free(l); } } guard{L};
-            hlala_locus_info li; hlala_locus_get(L, &li);
-            hlala_locus_desc ld{li.level_min, li.level_max, li.level_to_exon, pB.IS_mean, pB.IS_sd, minimumMappingQuality, min_bothReads_weightedCharactersOK, include.data(), minAlignmentLength_unpaired, 0};
-            // exon positions: sizing call, then the real one
-            hlala_exon_positions_out pos; std::memset(&pos, 0, sizeof(pos));
-            int rc = hlala_exon_positions(c, b, &ld, &pos);
-            if(rc != HLALA_OK && rc != HLALA_E_CAPACITY) chk(rc, "hlala_exon_positions");
-            const size_t nR = (size_t)pos.n_reads, nP = (size_t)pos.n_pos, nC = (size_t)pos.n_chars;
-            std::vector<int32_t> read_pair(nR + 1), read_distance(nR + 1), cols(2 * nR + 1), pos_off(nR + 2), pos_exon(nP + 1), pos_level(nP + 1), novel(nP + 1), geno_off(nP + 2);
-            std::vector<double> wok(2 * nR + 1), fok(2 * nR + 1), rmapq(2 * nR + 1); std::vector<uint8_t> mate(nP + 1), pmapq(nP + 1), geno(nC + 1), qual(nC + 1), rrev(2 * nR + 1);
-            pos.cap_reads = (int32_t)nR; pos.cap_pos = (int32_t)nP; pos.cap_chars = (int32_t)nC;
-            pos.read_pair = read_pair.data(); pos.read_weighted_ok = wok.data(); pos.read_fraction_ok = fok.data(); pos.read_distance = read_distance.data(); pos.read_cols_nongap = cols.data();
-            pos.pos_off = pos_off.data(); pos.pos_exon = pos_exon.data(); pos.pos_level = pos_level.data(); pos.pos_mate = mate.data(); pos.pos_mapq = pmapq.data(); pos.pos_novel_gap = novel.data();
-            pos.geno_off = geno_off.data(); pos.geno_chars = geno.data(); pos.qual_chars = qual.data(); pos.read_reverse = rrev.data(); pos.read_mapq = rmapq.data();
-            chk(hlala_exon_positions(c, b, &ld, &pos), "hlala_exon_positions");
+        // ---- loci
+        struct Acc {
+            std::string locus; hlala_locus* L = nullptr; hlala_locus_info li;
+            std::vector<int32_t> read_pair, read_distance, cols, pos_off{0}, pos_exon, pos_level, novel, geno_off{0};
+            std::vector<double> wok, fok, rmapq; std::vector<uint8_t> mate, pmapq, geno, qual, rrev; int32_t ok = 0, broken = 0;
+        };
+        std::vector<Acc> acc(loci_for_HLAtyping.size());
+        struct FreeAll { std::vector<Acc>& a; ~FreeAll() { for(Acc& x : a) if(x.L) hlala_locus_free(x.L); } } guard{acc};
+        for(size_t i = 0; i < acc.size(); i++) {
+            acc[i].locus = loci_for_HLAtyping[i];
+            tchk(hlala_typer_locus(t_, acc[i].locus.c_str(), 0, nullptr, &acc[i].L), "hlala_typer_locus");
+            hlala_locus_get(acc[i].L, &acc[i].li);
+        }
+        // ---- batches
+        double alignS = 0; int64_t errors = 0;
+        const int32_t nB = pB.n_batches();
+        for(int32_t bi = 0; bi < nB; bi++) {
+            const size_t u0 = (size_t)pB.batch_first_unit(bi);
+            const auto t0 = std::chrono::steady_clock::now();
+            hlala_batch* b = pB.acquire(bi, true);
+            hlala_batch_stats bs; chk(hlala_batch_get_stats(c, b, &bs), "hlala_batch_get_stats");          // (synchronises: the batch is aligned)
+            alignS += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            errors += bs.n_errors;
+            chk(hlala_postprocess_pairs(c, b, include.data() + u0), "hlala_postprocess_pairs");
+            // read alignment statistics (hla/HLATyper.cpp:1030-1125) and the per-pair quantities of the histogram lines
+            hlala_unit_stats_out usb{usValid.data() + u0, usStrands.data() + u0, usDist.data() + u0, usF.data() + 2 * u0, usW.data() + 2 * u0, usCols.data() + 2 * u0, usQ.data() + 2 * u0};
+            chk(hlala_unit_alignment_stats(c, b, &usb), "hlala_unit_alignment_stats");
+            for(Acc& A : acc) {
+                hlala_locus_desc ld{A.li.level_min, A.li.level_max, A.li.level_to_exon, pB.IS_mean, pB.IS_sd, minimumMappingQuality, min_bothReads_weightedCharactersOK, include.data() + u0, minAlignmentLength_unpaired, 0};
+                hlala_exon_positions_out pos; std::memset(&pos, 0, sizeof(pos));
+                int rc = hlala_exon_positions(c, b, &ld, &pos);                                             // sizing call
+                if(rc != HLALA_OK && rc != HLALA_E_CAPACITY) chk(rc, "hlala_exon_positions");
+                const size_t nR = (size_t)pos.n_reads, nP = (size_t)pos.n_pos, nC = (size_t)pos.n_chars;
+                std::vector<int32_t> read_pair(nR + 1), read_distance(nR + 1), cols(2 * nR + 1), pos_off(nR + 2), pos_exon(nP + 1), pos_level(nP + 1), novel(nP + 1), geno_off(nP + 2);
+                std::vector<double> wok(2 * nR + 1), fok(2 * nR + 1), rmapq(2 * nR + 1); std::vector<uint8_t> mate(nP + 1), pmapq(nP + 1), geno(nC + 1), qual(nC + 1), rrev(2 * nR + 1);
+                pos.cap_reads = (int32_t)nR; pos.cap_pos = (int32_t)nP; pos.cap_chars = (int32_t)nC;
+                pos.read_pair = read_pair.data(); pos.read_weighted_ok = wok.data(); pos.read_fraction_ok = fok.data(); pos.read_distance = read_distance.data(); pos.read_cols_nongap = cols.data();
+                pos.pos_off = pos_off.data(); pos.pos_exon = pos_exon.data(); pos.pos_level = pos_level.data(); pos.pos_mate = mate.data(); pos.pos_mapq = pmapq.data(); pos.pos_novel_gap = novel.data();
+                pos.geno_off = geno_off.data(); pos.geno_chars = geno.data(); pos.qual_chars = qual.data(); pos.read_reverse = rrev.data(); pos.read_mapq = rmapq.data();
+                chk(hlala_exon_positions(c, b, &ld, &pos), "hlala_exon_positions");
+                const int32_t pBase = A.pos_off.back(), gBase = A.geno_off.back();
+                for(size_t r = 0; r < nR; r++) { A.read_pair.push_back(read_pair[r] + (int32_t)u0); A.read_distance.push_back(read_distance[r]); A.pos_off.push_back(pos_off[r + 1] + pBase);
+                    for(int m = 0; m < 2; m++) { A.cols.push_back(cols[2 * r + m]); A.wok.push_back(wok[2 * r + m]); A.fok.push_back(fok[2 * r + m]); A.rmapq.push_back(rmapq[2 * r + m]); A.rrev.push_back(rrev[2 * r + m]); } }
+                for(size_t j = 0; j < nP; j++) { A.pos_exon.push_back(pos_exon[j]); A.pos_level.push_back(pos_level[j]); A.novel.push_back(novel[j]); A.mate.push_back(mate[j]); A.pmapq.push_back(pmapq[j]); A.geno_off.push_back(geno_off[j + 1] + gBase); }
+                A.geno.insert(A.geno.end(), geno.begin(), geno.begin() + nC); A.qual.insert(A.qual.end(), qual.begin(), qual.begin() + nC);
+                A.ok += pos.n_pairs_ok; A.broken += pos.n_pairs_broken;
+            }
+            if(nB > 1) pB.release(bi);
+        }
+        if(align_seconds) *align_seconds = alignS;
+        if(chain_errors) *chain_errors = errors;
+        hlala_unit_stats_out us{usValid.data(), usStrands.data(), usDist.data(), usF.data(), usW.data(), usCols.data(), usQ.data()};
+        tchk(hlala_typer_write_summary(outputDirectory.c_str(), pB.n_units, pB.longReadsMode ? 1 : 0, include.data(), &us, pB.IS_mean, pB.IS_sd, minAlignmentLength_unpaired), "hlala_typer_write_summary");
+        // ---- per locus: filters -> likelihoods -> all pairs -> call
+        struct Res { hlala_exon_positions_out pos; std::vector<double> pairLL, misAvg, misMin, pNorm; std::vector<int32_t> order; hlala_call_out call; std::vector<char> q[2]; int32_t nq[2], nt[2]; std::vector<uint8_t> present[2]; };
+        std::vector<Res> res(acc.size());
+        for(size_t li = 0; li < acc.size(); li++) {
+            Acc& A = acc[li]; Res& R = res[li];
+            const size_t nR = A.read_pair.size(), nP = A.pos_exon.size();
+            // (vectors may be empty: keep the pointers valid)
+            A.read_pair.push_back(0); A.read_distance.push_back(0); A.pos_exon.push_back(0); A.pos_level.push_back(0); A.novel.push_back(0); A.mate.push_back(0); A.pmapq.push_back(0);
+            A.geno.push_back(0); A.qual.push_back(0); for(int m = 0; m < 2; m++) { A.cols.push_back(0); A.wok.push_back(0); A.fok.push_back(0); A.rmapq.push_back(0); A.rrev.push_back(0); }
+            hlala_exon_positions_out& pos = R.pos; std::memset(&pos, 0, sizeof(pos));
+            pos.cap_reads = pos.n_reads = (int32_t)nR; pos.cap_pos = pos.n_pos = (int32_t)nP; pos.cap_chars = pos.n_chars = (int32_t)(A.geno.size() - 1); pos.n_pairs_ok = A.ok; pos.n_pairs_broken = A.broken;
+            pos.read_pair = A.read_pair.data(); pos.read_weighted_ok = A.wok.data(); pos.read_fraction_ok = A.fok.data(); pos.read_distance = A.read_distance.data(); pos.read_cols_nongap = A.cols.data();
+            pos.pos_off = A.pos_off.data(); pos.pos_exon = A.pos_exon.data(); pos.pos_level = A.pos_level.data(); pos.pos_mate = A.mate.data(); pos.pos_mapq = A.pmapq.data(); pos.pos_novel_gap = A.novel.data();
+            pos.geno_off = A.geno_off.data(); pos.geno_chars = A.geno.data(); pos.qual_chars = A.qual.data(); pos.read_reverse = A.rrev.data(); pos.read_mapq = A.rmapq.data();
             std::vector<uint8_t> use(nP + 1), ignored(nR + 1); hlala_filter_stats fs;
             if(hlala_filter_positions(&pos, &filterParams, use.data(), ignored.data(), &fs) != HLALA_OK) throw std::runtime_error("hlala_filter_positions failed");
             // likelihoods: first genotype character, genotype length and first quality of every position (hla/HLATyper.cpp:2080-2277)
             std::vector<uint8_t> g0(nP + 1), q0(nP + 1); std::vector<int32_t> glen(nP + 1);
-            for(size_t j = 0; j < nP; j++) { g0[j] = geno[geno_off[j]]; q0[j] = qual[geno_off[j]]; glen[j] = geno_off[j + 1] - geno_off[j]; }
-            hlala_exon_in xin{li.n_clusters, li.n_columns, li.cluster_seq, (int32_t)nR, pos_off.data(), pos_exon.data(), g0.data(), glen.data(), q0.data(), use.data()};
-            const size_t C = (size_t)li.n_clusters, nPairs = C * (C + 1) / 2;
-            std::vector<double> LL(C * nR + 1), pairLL(nPairs), misAvg(nPairs), misMin(nPairs), pNorm(nPairs), marginal(C); std::vector<int32_t> mism(C * nR + 1), order(nPairs);
+            for(size_t j = 0; j < nP; j++) { g0[j] = A.geno[A.geno_off[j]]; q0[j] = A.qual[A.geno_off[j]]; glen[j] = A.geno_off[j + 1] - A.geno_off[j]; }
+            hlala_exon_in xin{A.li.n_clusters, A.li.n_columns, A.li.cluster_seq, (int32_t)nR, A.pos_off.data(), A.pos_exon.data(), g0.data(), glen.data(), q0.data(), use.data()};
+            const size_t C = (size_t)A.li.n_clusters, nPairs = C * (C + 1) / 2;
+            std::vector<double> LL(C * nR + 1), marginal(C + 1); std::vector<int32_t> mism(C * nR + 1);
+            R.pairLL.assign(nPairs + 1, 0); R.misAvg.assign(nPairs + 1, 0); R.misMin.assign(nPairs + 1, 0); R.pNorm.assign(nPairs + 1, 0); R.order.assign(nPairs + 1, 0);
             chk(hlala_exon_loglik(c, &xin, LL.data(), mism.data()), "hlala_exon_loglik");
-            chk(hlala_pair_loglik(c, LL.data(), mism.data(), li.n_clusters, (int32_t)nR, pairLL.data(), misAvg.data(), misMin.data()), "hlala_pair_loglik");
-            hlala_call_out call; chk(hlala_call_locus(c, li.n_clusters, pairLL.data(), misAvg.data(), misMin.data(), order.data(), pNorm.data(), marginal.data(), &call), "hlala_call_locus");
-            double covered[2];
-            for(int a = 0; a < 2; a++) {                                              // proportionkMersCovered, :2652-2688
-                const int32_t cl = a ? call.second_cluster : call.first_cluster; int32_t nq = 0, nt = 0;
-                hlala_locus_cluster_kmers(L, cl, k_for_kMer_index, nullptr, 0, &nq, &nt);
-                std::vector<char> q((size_t)nq * k_for_kMer_index + 1); std::vector<uint8_t> present((size_t)nq + 1);
-                tchk(hlala_locus_cluster_kmers(L, cl, k_for_kMer_index, q.data(), nq, &nq, &nt), "hlala_locus_cluster_kmers");
-                chk(hlala_kmer_presence(c, b, include.data(), k_for_kMer_index, nq, q.data(), present.data()), "hlala_kmer_presence");
-                int hit = 0; for(int32_t i = 0; i < nq; i++) hit += present[i];
-                covered[a] = nt ? (double)hit / (double)nt : -1;
+            chk(hlala_pair_loglik(c, LL.data(), mism.data(), A.li.n_clusters, (int32_t)nR, R.pairLL.data(), R.misAvg.data(), R.misMin.data()), "hlala_pair_loglik");
+            chk(hlala_call_locus(c, A.li.n_clusters, R.pairLL.data(), R.misAvg.data(), R.misMin.data(), R.order.data(), R.pNorm.data(), marginal.data(), &R.call), "hlala_call_locus");
+            for(int a = 0; a < 2; a++) {                                              // k-mers of the two called alleles, :2652-2688
+                const int32_t cl = a ? R.call.second_cluster : R.call.first_cluster; R.nq[a] = 0; R.nt[a] = 0;
+                hlala_locus_cluster_kmers(A.L, cl, k_for_kMer_index, nullptr, 0, &R.nq[a], &R.nt[a]);
+                R.q[a].assign((size_t)R.nq[a] * k_for_kMer_index + 1, 0); R.present[a].assign((size_t)R.nq[a] + 1, 0);
+                tchk(hlala_locus_cluster_kmers(A.L, cl, k_for_kMer_index, R.q[a].data(), R.nq[a], &R.nq[a], &R.nt[a]), "hlala_locus_cluster_kmers");
             }
+        }
+        // ---- which of those k-mers occur in the reads that went into typing: one more pass over the reads (a batch that was released is
+        // uploaded again, not aligned again)
+        for(int32_t bi = 0; bi < nB; bi++) {
+            const size_t u0 = (size_t)pB.batch_first_unit(bi);
+            hlala_batch* b = pB.acquire(bi, false);
+            for(Res& R : res) for(int a = 0; a < 2; a++) {
+                std::vector<uint8_t> pr((size_t)R.nq[a] + 1);
+                chk(hlala_kmer_presence(c, b, include.data() + u0, k_for_kMer_index, R.nq[a], R.q[a].data(), pr.data()), "hlala_kmer_presence");
+                for(int32_t i = 0; i < R.nq[a]; i++) R.present[a][i] |= pr[i];
+            }
+            if(nB > 1) pB.release(bi);
+        }
+        // ---- files
+        std::vector<bestGuess> out; std::string lociJoined;
+        for(size_t li = 0; li < acc.size(); li++) {
+            Acc& A = acc[li]; Res& R = res[li];
+            double covered[2];
+            for(int a = 0; a < 2; a++) { int hit = 0; for(int32_t i = 0; i < R.nq[a]; i++) hit += R.present[a][i]; covered[a] = R.nt[a] ? (double)hit / (double)R.nt[a] : -1; }
             hlala_locus_report_in rin; std::memset(&rin, 0, sizeof(rin));
-            rin.pos = &pos; rin.filter = &filterParams; rin.unit_name_1 = names.data(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.data(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
-            rin.n_clusters = li.n_clusters; rin.pair_ll = pairLL.data(); rin.mis_avg = misAvg.data(); rin.mis_min = misMin.data(); rin.order = order.data(); rin.p_normalized = pNorm.data(); rin.call = &call;
+            rin.pos = &R.pos; rin.filter = &filterParams; rin.unit_name_1 = names.data(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.data(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
+            rin.n_clusters = A.li.n_clusters; rin.pair_ll = R.pairLL.data(); rin.mis_avg = R.misAvg.data(); rin.mis_min = R.misMin.data(); rin.order = R.order.data(); rin.p_normalized = R.pNorm.data(); rin.call = &R.call;
             rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2;
             rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
             rin.min_mapq = minimumMappingQuality; rin.min_weighted_ok = min_bothReads_weightedCharactersOK;
-            bestGuess g; g.locus = locus;
-            tchk(hlala_locus_write_files(L, &rin, outputDirectory.c_str(), &g.summary), "hlala_locus_write_files");
-            g.allele1 = hlala_locus_cluster_id(L, call.first_cluster); g.allele2 = hlala_locus_cluster_id(L, call.second_cluster); g.Q1_allele1 = call.first_marginal; g.Q1_allele2 = call.second_p;
+            bestGuess g; g.locus = A.locus;
+            tchk(hlala_locus_write_files(A.L, &rin, outputDirectory.c_str(), &g.summary), "hlala_locus_write_files");
+            g.allele1 = hlala_locus_cluster_id(A.L, R.call.first_cluster); g.allele2 = hlala_locus_cluster_id(A.L, R.call.second_cluster); g.Q1_allele1 = R.call.first_marginal; g.Q1_allele2 = R.call.second_p;
             out.push_back(g);
-            lociJoined += (lociJoined.empty() ? "" : ",") + locus;
+            lociJoined += (lociJoined.empty() ? "" : ",") + A.locus;
         }
         tchk(hlala_typer_end_output(outputDirectory.c_str(), lociJoined.c_str(), 0), "hlala_typer_end_output");
         return out;
     }
+
+    // graph level names (Graph::getOneLocusIDforLevel) and the gene list, for the caller's own files (reads_per_level.txt)
+    int32_t n_levels() const { return hlala_typer_n_levels(t_); }
+    std::string level_name(int32_t level) const { const char* n = hlala_typer_level_name(t_, level); return n ? n : ""; }
+    bool has_locus(const std::string& locus) const { hlala_locus* L = nullptr; if(hlala_typer_locus(t_, locus.c_str(), 0, nullptr, &L) != HLALA_OK) return false; hlala_locus_free(L); return true; }
 
 private:
     hlala_typer* t_ = nullptr;

@@ -203,6 +203,11 @@ int  hlala_batch_create(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** 
 int  hlala_batch_create_unpaired(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** out);
 /* Upload seed chains directly (stage A is then not available on this batch).                */
 int  hlala_batch_create_from_seeds(hlala_ctx* ctx, const hlala_seeds_in* in, hlala_batch** out);
+/* A sample that is pushed through the GPU in several batches (BASELINE config 3: ~10 M pairs) keeps ONE numbering of its chains:
+ * `first_chain` is the absolute index of this batch's chain 0, so that the DP of chain c, direction d draws from
+ * rng_seed + 2*(first_chain + c) + d -- the seeds of the unsplit run (params.rng_seed above; the reference's rng_seeds is a public
+ * mutable member the caller sets per call, extensionAligner.h:38).  Default 0.  Call before hlala_extend_chains / hlala_align_batch. */
+int  hlala_batch_set_first_chain(hlala_batch* b, uint32_t first_chain);
 /* The device buffers are parked in the context and reused by the next batch (a batch that outlives its context frees them itself)
  * of similar size (allocating the column arrays of a 1 M-pair batch costs about a second otherwise).                 */
 void hlala_batch_destroy(hlala_batch* b);
@@ -499,6 +504,10 @@ int32_t     hlala_typer_n_genes(const hlala_typer* t);                          
 int  hlala_typer_gene(const hlala_typer* t, int32_t i, const char** name, int32_t* first_level, int32_t* last_level);
 /* G groups (hla_nom_g.txt; read_G_alleles / translate_allele_list_to_G_allele, HLATyper.cpp:4086-4207) for R1_bestguess_G.txt */
 int  hlala_typer_load_g_groups(hlala_typer* t, const char* hla_nom_g_path);
+/* translate_allele_list_to_G_allele (hla/HLATyper.cpp:4095-4148) for a ';'-joined allele list (e.g. hlala_locus_cluster_id): the G group all
+ * known members share (*perfectly = 1), the most frequent one (0), or the list itself when no member is in the table (0).  HLALA_E_STATE
+ * when no table is loaded or the locus is not in it (can_translateToG_locus, :4086-4092).                                            */
+int  hlala_typer_g_translate(const hlala_typer* t, const char* alleles, char* out, int32_t cap, int32_t* perfectly);
 int  hlala_typer_locus(const hlala_typer* t, const char* locus, int32_t n_exons, const char* const* exon_ids, hlala_locus** out);
 void hlala_locus_free(hlala_locus* l);
 typedef struct {

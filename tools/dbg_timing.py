@@ -6,8 +6,13 @@ from tools import synth
 from conftest import load_package
 P = load_package()
 n_pairs = int(sys.argv[1]); G = int(sys.argv[2])
-w = synth.make_world(seed=2, G=G, k=1, n_mut=3)
-b = synth.make_batch_fast(w, n_pairs, seed=1000)
+# usage: dbg_timing.py <pairs> <levels> [m [frac_gene]]   (m: Graph M instead of the round-1 stand-in)
+if len(sys.argv) > 3 and sys.argv[3] == "m":
+    w = synth.make_world_m(seed=2, n_levels=G)
+    b = synth.make_batch_m(w, n_pairs, seed=1000, frac_gene=float(sys.argv[4]) if len(sys.argv) > 4 else 0.3)
+else:
+    w = synth.make_world(seed=2, G=G, k=1, n_mut=3)
+    b = synth.make_batch_fast(w, n_pairs, seed=1000)
 ctx = P.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=12345)
 gb = ctx.batch(b)
 gb.align(); gb.stats()
