@@ -772,6 +772,17 @@ class Batch:
         self.ctx._check(self.ctx.lib.hlala_batch_get_pairs(self.ctx.h, self.b, C.byref(s)), "hlala_batch_get_pairs")
         return d
 
+    def pairs_scalars(self) -> dict:
+        """hlala_batch_get_pairs with NULL column pointers: the per-pair / per-mate scalars only."""
+        n = self.n_pairs; nr = n * (1 if getattr(self, "unpaired", False) else 2)
+        d = dict(pair_status=np.zeros(n, np.int32), best_chain=np.zeros(nr, np.int32), n_combinations=np.zeros(n, np.int32), pair_ll=np.zeros(n), pair_mapq=np.zeros(n),
+                 mate_mapq=np.zeros(nr), strands_valid=np.zeros(n, np.uint8))
+        o = PairsOut(); types = dict(PairsOut._fields_)
+        for k, v in d.items():
+            setattr(o, k, v.ctypes.data_as(types[k]))
+        self.ctx._check(self.ctx.lib.hlala_batch_get_pairs(self.ctx.h, self.b, C.byref(o)), "hlala_batch_get_pairs")
+        return d
+
     def export_pair_records(self, device_ptr: int):
         """Write 8 doubles per pair into a device buffer (e.g. a torch tensor's data_ptr())."""
         self.ctx._check(self.ctx.lib.hlala_batch_export_pair_records(self.ctx.h, self.b, C.c_void_p(device_ptr)),

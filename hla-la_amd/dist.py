@@ -16,8 +16,14 @@ def shard_bounds(n_units: int, rank: int, world: int):
 
 def shard_pairs(batch: dict, rank: int, world: int):
     """Slice a hlala_batch_in dict to this rank's block of pairs.  Returns (sub_batch, first_pair, first_chain);
-    pass rng_seed + 2 * first_chain to the context so every DP draws the seed it would draw in the unsharded run."""
+    pass rng_seed + 2 * first_chain to the context (or first_chain to hlala_batch_set_first_chain) so every DP draws the seed it would
+    draw in the unsharded run."""
     p0, p1 = shard_bounds(batch["n_pairs"], rank, world)
+    return shard_pairs_range(batch, p0, p1)
+
+
+def shard_pairs_range(batch: dict, p0: int, p1: int):
+    """Pairs [p0, p1) of a hlala_batch_in dict as a batch of their own: (sub_batch, first_pair, first_chain)."""
     r0, r1 = 2 * p0, 2 * p1
     c0, c1 = int(batch["chain_off"][r0]), int(batch["chain_off"][r1])
     b0, b1 = int(batch["read_off"][r0]), int(batch["read_off"][r1])

@@ -1,0 +1,98 @@
+"""BASELINE config 2 at FULL size under pytest (1 048 576 synthetic 2x150 bp pairs on the 5 M-level Graph M): the oracle needs ~15 minutes
+per core for this, so parity is carried by the reference's own paranoid invariants and by size-independent properties, checked over every
+one of the ~317 M output columns with numpy:
+  * checkChainConcordanceWithSequence (mapper/reads/verboseSeedChain.cpp:48-77): the read characters of the columns re-spell the read;
+  * checkLevelContiguity (mapper/reads/verboseSeedChain.h:282-315): defined levels ascend by exactly one;
+  * columns against the graph: the edge of a column leaves its level and carries its graph character; level -1 <=> no edge;
+  * mapping qualities: in [0, 1], mate >= pair (processBAM.cpp:4245-4300), per-position Phred chars >= the pair's;
+  * truth (simulator/trueReadLevels.cpp:18-196): >= 99 % of the read bases on the level they were drawn from -- oracle-independent;
+  * idempotence: a second pass over the resident batch gives the same bytes (checksum of all outputs);
+  * sampled bit-exact parity: 3 x 300 pairs spread over the batch, re-run alone with their absolute chain numbers (hlala_batch_set_first_chain),
+    equal their rows of the big run AND the oracle.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+N_PAIRS = 1_048_576
+
+
+def _digest(d):
+    h = hashlib.sha1()
+    for k in sorted(d):
+        if isinstance(d[k], np.ndarray):
+            h.update(np.ascontiguousarray(d[k]).tobytes())
+    return h.hexdigest()
+
+
+def test_one_million_pairs_keep_the_reference_invariants(pkg, oracle):
+    from hla_la_amd import dist as D
+    w = synth.make_world_m(seed=2)
+    b = synth.make_batch_m(w, N_PAIRS, seed=1000)
+    kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=12345, max_columns=384)
+    ctx = pkg.Context(w["graph"], w["contigs"], **kw)
+    gb = ctx.batch(b); gb.align()
+    st = gb.stats()
+    assert st.n_errors <= 64, st.n_errors                      # capacity of the largest DP class (frontier > 1024 cells): flagged, never silent
+    assert all(int(x) > 0 for x in st.n_dp_class)
+    pk = gb.pairs_packed()
+    sc = gb.pairs_scalars()
+    off = pk["col_off"]; T = pk["n_cols_total"]
+    ok_pair = sc["pair_status"] == 0
+    assert ok_pair.sum() >= N_PAIRS - 64 and T > 300 * N_PAIRS
+    ok_read = np.repeat(ok_pair, 2)
+    ncols = np.diff(off)
+    assert np.all(ncols[ok_read] >= 150) and np.all(ncols[~ok_read] == 0)
+    read_of_col = np.repeat(np.arange(2 * N_PAIRS, dtype=np.int32), ncols)
+    # ---- chain concordance: the non-gap read characters of all columns are the reads, in order
+    s = pk["col_schar"]; isbase = s != ord("_")
+    bases_ok = b["read_bases"].reshape(2 * N_PAIRS, 150)[ok_read].reshape(-1)
+    assert isbase.sum() == bases_ok.size and np.array_equal(s[isbase], bases_ok)
+    # ---- level contiguity: consecutive defined levels of a read differ by exactly one
+    lv = pk["col_level"]; d = np.nonzero(lv != -1)[0]
+    same = read_of_col[d[1:]] == read_of_col[d[:-1]]
+    assert np.all((lv[d[1:]] - lv[d[:-1]])[same] == 1)
+    # ---- columns against the graph
+    g = w["graph"]; ed = pk["col_edge"]; gc = pk["col_gchar"]
+    has = ed >= 0
+    assert np.array_equal(has, lv != -1)
+    assert np.array_equal(g["node_level"][g["edge_from"][ed[has]]], lv[has]) and np.array_equal(g["edge_label"][ed[has]], gc[has])
+    assert np.all(gc[~has] == ord("_")) and np.all(s[~has] != ord("_"))                  # level -1: a read base against nothing
+    # ---- mapping qualities
+    assert np.all(sc["pair_mapq"][ok_pair] > 0) and np.all(sc["pair_mapq"] <= 1 + 1e-12)
+    assert np.all(sc["mate_mapq"][ok_read] >= np.repeat(sc["pair_mapq"], 2)[ok_read] - 1e-9) and np.all(sc["mate_mapq"] <= 1 + 1e-12)
+    assert pk["col_mapq"].min() >= 33
+    # ---- truth: read bases on the level they were simulated from
+    tl = b["truth_level"].reshape(2 * N_PAIRS, 150)[ok_read].reshape(-1)
+    al = lv[isbase]
+    known = tl >= 0
+    acc = float((al[known] == tl[known]).mean())
+    gene = np.repeat(np.repeat(b["read_window"] >= 0, 2)[ok_read], 150)
+    acc_gene = float((al[known & gene] == tl[known & gene]).mean())
+    assert acc >= 0.99 and acc_gene >= 0.985, (acc, acc_gene)
+    # ---- idempotence
+    h1 = _digest(pk) + _digest(sc)
+    gb.align()
+    assert _digest(gb.pairs_packed()) + _digest(gb.pairs_scalars()) == h1
+    # ---- sampled bit-exact parity against the oracle (and against the rows of the big run)
+    big = dict(n_pairs=N_PAIRS, **{k: b[k] for k in ("read_off", "read_bases", "read_quals", "chain_off", "read_primary", "n_chains", "cigar_off", "cigar",
+                                                     "chain_contig", "chain_pos", "chain_offset", "chain_as", "chain_reverse", "insert_mean", "insert_sd")})
+    for start in (0, 500_000, N_PAIRS - 300):
+        sub, p0, c0 = D.shard_pairs_range(big, start, start + 300)
+        exp = oracle(w["graph"], w["contigs"], **dict(kw, rng_seed=(12345 + 2 * c0) & 0xFFFFFFFF)).align_batch(sub)["pairs"]
+        gs = ctx.batch(sub); gs.set_first_chain(c0); gs.align()
+        got = gs.pairs()
+        for k in ("pair_status", "n_combinations", "n_cols", "col_level", "col_edge", "col_gchar", "col_schar", "col_mapq"):
+            assert np.array_equal(got[k], exp[k]), (start, k)
+        assert np.array_equal(got["best_chain"], exp["best_chain"]) and np.allclose(got["pair_ll"], exp["pair_ll"], rtol=1e-12, atol=0)
+        r0, r1 = 2 * start, 2 * (start + 300)
+        for r in range(r0, r1, 7):
+            n = int(ncols[r])
+            assert n == got["n_cols"][r - r0] and np.array_equal(lv[off[r]:off[r] + n], got["col_level"][(r - r0) * 384:(r - r0) * 384 + n])
+        assert np.array_equal(sc["best_chain"][r0:r1], got["best_chain"] + c0) and np.array_equal(sc["pair_ll"][start:start + 300], got["pair_ll"])
+        gs.close()
