@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         // segments are a few levels long.  Windows that do not fit the LDS staging, that contain a segment longer than
         // PROJ_SEGMAX levels, or in which a segment hits the "no node reachable" assert, run the column-sequential form below.
         int level0 = -1, nb = 0, chCount = 0; ChoiceRec* ch = slabCh;
-        int nDef = 0, nodeBase = 0, eBase = 0, nEdges = 0; bool staged = false, par = false;
+        int nDef = 0, nodeBase = 0, eBase = 0, nEdges = 0; bool staged = false, par = false, windowed = false, chunked = false; int defCount = 0, nChunks = 0;
         if(PJ_OK()) {
             level0 = uni(P.lvl[cur][0]);
             int lastLevel = uni(P.lvl[cur][n1 - 1]);
@@ -462,8 +462,10 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 eBase = __builtin_amdgcn_readlane(v2, 0);
                 nEdges = __builtin_amdgcn_readlane(v2, 1) - eBase;
                 staged = (nDef <= PL::CAP) && (nodeEnd - nodeBase <= PL::SN) && (nEdges <= PL::SE);
+                // offsets of the window's levels (16-bit, relative to its first node): the segment-parallel and the chunked form both need them
+                windowed = (nDef <= PL::CAP) && (nodeEnd - nodeBase < 65536) && (nEdges < 65536);
+                if(windowed) for(int i = lane; i <= nDef + 1; i += 64) P.sLev[i] = (unsigned short)(G.level_off[level0 + i] - nodeBase);
                 if(staged) {
-                    for(int i = lane; i <= nDef + 1; i += 64) P.sLev[i] = (unsigned short)(G.level_off[level0 + i] - nodeBase);
                     for(int i = lane; i <= chCount; i += 64) P.sIn[i] = (unsigned short)(G.in_off[nb + i] - eBase);
                     for(int e = lane; e < nEdges; e += 64) { P.sFrom[e] = (unsigned short)(G.in_from[eBase + e] - nodeBase); P.sLab[e] = G.in_label[eBase + e]; }
                 }
@@ -473,9 +475,8 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         u64 edgesTouched = 0;
         int nSeg = 0;
         short* const Sflat = P.sflat();                                                    // S per node of the window (parallel form)
-        if(PJ_OK() && staged) {
+        if(PJ_OK() && windowed) {
             // level -> (column, read character, seed-is-match); the defined columns must cover level0..lastLevel exactly once
-            int defCount = 0;
             for(int j0 = 0; j0 < n1; j0 += 64) {
                 int j = j0 + lane; bool d = false;
                 if(j < n1) {
@@ -487,6 +488,9 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 }
                 defCount += __popcll(__ballot(d));
             }
+        }
+        WSYNC();
+        if(PJ_OK() && staged) {
             for(int i0 = 0; i0 < nDef; i0 += 64) {
                 int i = i0 + lane;
                 bool cut = i < nDef && (i == 0 || (P.sLev[i + 1] - P.sLev[i]) == 1);
@@ -542,7 +546,97 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         WSYNC();
         if(PJ_OK()) {
             int rowP = 0;
-            if(!par) {
+            chunked = !par && windowed && defCount == nDef;
+            if(chunked) {
+                // Column-sequential form on LDS-staged CHUNKS of the window.  Allele-rich stretches have no single-node level for
+                // hundreds of levels (no cuts for the segment-parallel form) and tens to hundreds of nodes per level (the whole window
+                // does not fit the staging arrays): walking them level by level against HBM cost two dependent round trips per level,
+                // 13x the time of a backbone chain on the Graph M workload.  Here runs of consecutive levels whose target nodes and
+                // in-edges fit the staging arrays are loaded with coalesced reads (one round trip per chunk) and the levels of a chunk
+                // are solved out of LDS; the back pointers go to the wave's slab as before (window-relative CSR edge index).
+                // segStart[i] = first in-edge (window-relative) of the target nodes of level i, i = 0 .. nDef
+                for(int i = lane; i <= nDef; i += 64) P.segStart[i] = (unsigned short)(G.in_off[nodeBase + P.sLev[i + 1]] - eBase);
+                WSYNC();
+                const int nbR = nb - nodeBase;
+                int a = 0;
+                while(a < nDef && PJ_OK()) {
+                    const int cand = a + lane;
+                    const bool fits = cand < nDef && ((int)P.sLev[cand + 2] - (int)P.sLev[a + 1]) <= PL::SN && ((int)P.segStart[cand + 1] - (int)P.segStart[a]) <= PL::SE;
+                    const u64 fm = __ballot(fits);
+                    const int cnt = (fm == ~0ull) ? 64 : (__ffsll((long long)~fm) - 1);        // levels a .. a + cnt - 1 fit together (a prefix: both sums grow)
+                    if(cnt == 0) {
+                        // one level wider than the staging arrays: straight from HBM
+                        if(lane == 0) P.sChoice[nChunks] = (unsigned short)(a | 0x8000);
+                        nChunks++;
+                        const u32 ci = P.colInfo[a];
+                        const unsigned char sc = (unsigned char)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
+                        const int tb = nodeBase + P.sLev[a + 1], tm = (int)P.sLev[a + 2] - (int)P.sLev[a + 1], fb = nodeBase + P.sLev[a];
+                        if(tm > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); break; }
+                        int anyReached = 0;
+                        for(int z = lane; z < tm; z += 64) {
+                            const int node = tb + z;
+                            int best = -1, bestE = -1, bestFrom = -1;
+                            const int e0 = G.in_off[node], e1 = G.in_off[node + 1];
+                            for(int e = e0; e < e1; e++) {
+                                const int fz = G.in_from[e] - fb; const int sp = P.Srow[rowP][fz];
+                                if(sp < 0) continue;
+                                const unsigned char lab = G.in_label[e];
+                                if(seedIsMatch && lab != sc) continue;
+                                const int cd = sp + (lab == sc ? 1 : 0);
+                                if(cd > best) { best = cd; bestE = e - eBase; bestFrom = fz; }
+                            }
+                            edgesTouched += (u64)(e1 - e0);
+                            P.Srow[1 - rowP][z] = (short)best;
+                            ChoiceRec cr; cr.eid = bestE; cr.fromz = (short)bestFrom; cr.S = (short)best;
+                            ch[node - nb] = cr;
+                            if(best >= 0) anyReached = 1;
+                        }
+                        if(!__ballot(anyReached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); break; }
+                        rowP = 1 - rowP;
+                        WSYNC();
+                        a++;
+                        continue;
+                    }
+                    const int b = a + cnt - 1;
+                    if(lane == 0) P.sChoice[nChunks] = (unsigned short)a;
+                    nChunks++;
+                    const int tBase = P.sLev[a + 1], nT = (int)P.sLev[b + 2] - tBase, eC = P.segStart[a], nE = (int)P.segStart[b + 1] - eC;
+                    for(int t = lane; t <= nT; t += 64) P.sIn[t] = (unsigned short)(G.in_off[nodeBase + tBase + t] - eBase - eC);
+                    for(int e = lane; e < nE; e += 64) { P.sFrom[e] = (unsigned short)(G.in_from[eBase + eC + e] - nodeBase); P.sLab[e] = G.in_label[eBase + eC + e]; }
+                    WSYNC();
+                    bool stop = false;
+                    for(int i = a; i <= b; i++) {
+                        const u32 ci = P.colInfo[i];
+                        const unsigned char sc = (unsigned char)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
+                        const int t0 = (int)P.sLev[i + 1] - tBase, tm = (int)P.sLev[i + 2] - (int)P.sLev[i + 1], fb = P.sLev[i];
+                        if(tm > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); stop = true; break; }
+                        int anyReached = 0;
+                        for(int z = lane; z < tm; z += 64) {
+                            const int t = t0 + z;
+                            int best = -1, bestE = -1, bestFrom = -1;
+                            const int e0 = P.sIn[t], e1 = P.sIn[t + 1];
+                            for(int e = e0; e < e1; e++) {                                   // in-edges in creation order: first maximum = smallest edge
+                                const int fz = (int)P.sFrom[e] - fb; const int sp = P.Srow[rowP][fz];
+                                if(sp < 0) continue;
+                                const unsigned char lab = P.sLab[e];
+                                if(seedIsMatch && lab != sc) continue;                        // :2803-2809
+                                const int cd = sp + (lab == sc ? 1 : 0);
+                                if(cd > best) { best = cd; bestE = eC + e; bestFrom = fz; }
+                            }
+                            edgesTouched += (u64)(e1 - e0);
+                            P.Srow[1 - rowP][z] = (short)best;
+                            ChoiceRec cr; cr.eid = bestE; cr.fromz = (short)bestFrom; cr.S = (short)best;
+                            ch[tBase + t - nbR] = cr;
+                            if(best >= 0) anyReached = 1;
+                        }
+                        if(!__ballot(anyReached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); stop = true; break; }  // assert(seedChain_backtrack_*.size() > 0)
+                        rowP = 1 - rowP;
+                        WSYNC();
+                    }
+                    if(stop) break;
+                    a = b + 1;
+                }
+            } else if(!par) {
                 for(int j = 0; j < n1; j++) {
                     int l = uni(P.lvl[cur][j]);
                     if(l == -1) continue;                                                     // :2710-2714
@@ -606,6 +700,33 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         int e = pick[j];
                         if(e < 0) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
                         else { B.seed_level[cb + j] = P.lvl[cur][j]; B.seed_edge[cb + j] = G.in_eid[eBase + e]; B.seed_g[cb + j] = P.sLab[e]; }
+                        B.seed_s[cb + j] = P.s[cur][j];
+                    }
+                } else if(chunked) {
+                    // the chunks again, last to first: the back pointers of a chunk's nodes are staged into LDS with coalesced reads, lane 0
+                    // follows them there, then all lanes emit
+                    int* pick = P.lvl[1 - cur];
+                    for(int j = lane; j < n1; j += 64) pick[j] = -1;
+                    WSYNC();
+                    const int nbR = nb - nodeBase;
+                    int z = zsel;
+                    for(int k = nChunks - 1; k >= 0; k--) {
+                        const int a = P.sChoice[k] & 0x7FFF; const bool wide = (P.sChoice[k] & 0x8000) != 0;
+                        const int b = (k + 1 < nChunks ? (int)(P.sChoice[k + 1] & 0x7FFF) : nDef) - 1;
+                        if(wide) {
+                            if(lane == 0) { const ChoiceRec cr = ch[(int)P.sLev[a + 1] + z - nbR]; pick[P.colInfo[a] & 0xFFFFu] = cr.eid; z = cr.fromz; }
+                        } else {
+                            const int tBase = P.sLev[a + 1], nT = (int)P.sLev[b + 2] - tBase;
+                            for(int t = lane; t < nT; t += 64) { const ChoiceRec cr = ch[tBase + t - nbR]; P.sIn[t] = (unsigned short)cr.fromz; P.sFrom[t] = (unsigned short)cr.eid; }
+                            WSYNC();
+                            if(lane == 0) for(int i = b; i >= a; i--) { const int t = (int)P.sLev[i + 1] - tBase + z; pick[P.colInfo[i] & 0xFFFFu] = (int)P.sFrom[t]; z = (int)(short)P.sIn[t]; }
+                        }
+                        WSYNC();
+                    }
+                    for(int j = lane; j < n1; j += 64) {
+                        const int e = pick[j];
+                        if(e < 0) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
+                        else { B.seed_level[cb + j] = P.lvl[cur][j]; B.seed_edge[cb + j] = G.in_eid[eBase + e]; B.seed_g[cb + j] = G.in_label[eBase + e]; }
                         B.seed_s[cb + j] = P.s[cur][j];
                     }
                 } else if(lane == 0) {
