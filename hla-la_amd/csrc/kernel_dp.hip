@@ -47,6 +47,9 @@ constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows p
 struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; };
 struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; };
 struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; };
+// frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
+// but a quarter of its LDS, so that five of them share a CU instead of one
+struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; typedef short Slot; typedef unsigned short ImpIdx; };
 // (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and
 //  thousands of sequence-complete cells per DP were measured -- are what the large class is sized for; its table slots are ints)
 struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; };
@@ -368,8 +371,9 @@ __device__ inline u64 xz_key(int x, int z)
 struct __align__(16) DpItem { int item, rOff, seqLen, start_seq, startLevel, startNode, pad0, pad1; };
 
 // first tier (1 = DpMid, 2 = DpSmall, 3 = DpLarge) whose class holds a frontier of n cells / a target set of n cells
-__device__ __forceinline__ int tier_for_frontier(int n) { return n <= DpMid::WCAP ? 1 : (n <= DpSmall::WCAP ? 2 : 3); }
-__device__ __forceinline__ int tier_for_targets(int n) { return n <= (DpMid::HC * 3) / 4 ? 1 : (n <= (DpSmall::HC * 3) / 4 ? 2 : 3); }
+constexpr int DP_LAST_TIER = 4;      // tiers: 0 DpTiny, 1 DpMid, 2 DpSmall, 3 DpWide, 4 DpLarge
+__device__ __forceinline__ int tier_for_frontier(int n) { return n <= DpMid::WCAP ? 1 : (n <= DpSmall::WCAP ? 2 : (n <= DpWide::WCAP ? 3 : 4)); }
+__device__ __forceinline__ int tier_for_targets(int n) { return n <= (DpMid::HC * 3) / 4 ? 1 : (n <= (DpSmall::HC * 3) / 4 ? 2 : (n <= (DpWide::HC * 3) / 4 ? 3 : 4)); }
 
 #define DP_FAIL(code) do { if(gl == 0 && S.err == 0) S.err = (code); } while(0)
 
@@ -1182,7 +1186,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
 
     for(int dirPass = 0; dirPass < 2; dirPass++) {
         // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
-        // retry list of tier k = 1..3 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
+        // retry list of tier k = 1..4 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
         int* fetchCounter = &B.work_counter[TIER == 0 ? (dirPass ? 10 : 1) : 13 + 4 * (TIER - 1) + 2 * dirPass];
         const int nItems = uni(B.work_counter[TIER == 0 ? 8 + dirPass : 12 + 4 * (TIER - 1) + 2 * dirPass]);
         const int listBase = (TIER == 0 && dirPass) ? B.n_chains : 0;
@@ -1218,9 +1222,9 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
                     }
 #endif
                     const bool capacity = st.err != 0 && st.err > -1000000;
-                    if(capacity && TIER < 3) {
+                    if(capacity && TIER < DP_LAST_TIER) {
                         // next tier, or straight to the first tier whose class holds what overflowed (no point in failing again on the way)
-                        int to = TIER + 1; if(st.needTier > to) to = st.needTier; if(to > 3) to = 3;
+                        int to = TIER + 1; if(st.needTier > to) to = st.needTier; if(to > DP_LAST_TIER) to = DP_LAST_TIER;
                         int* cnt = &B.work_counter[12 + 4 * (to - 1) + 2 * dirPass]; int* lst = B.retry_list + (size_t)(2 * (to - 1) + dirPass) * (size_t)B.n_chains;
                         // (a linked duplicate whose own backtrace outgrew the class takes over the item entry: the DP that ran is done with it)
                         if(st.isAlias) ((int*)(items + st.itemIdx))[0] = st.item;

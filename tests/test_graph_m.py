@@ -175,3 +175,4 @@ def test_mixed_reads_match_oracle(pkg, oracle, world_m):
     got, st, exp = gpu_vs_oracle(pkg, oracle, world_m, b, rng_seed=4)
     gene = b["read_window"] >= 0
     assert truth_accuracy(b, got, 384, gene) >= 0.99 and truth_accuracy(b, got, 384, ~gene) >= 0.99
+

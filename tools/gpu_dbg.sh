@@ -5,4 +5,4 @@ set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 make -s -C tools/graphm 2>&1 | tail -1
-HLALA_DEBUG=1 timeout 600 python tools/dbg_timing.py "$@" 2>&1 | tail -6
+HLALA_DEBUG=1 timeout 600 python tools/dbg_timing.py "$@" 2>&1 | tail -7
