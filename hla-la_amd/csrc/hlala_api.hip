@@ -954,7 +954,7 @@ extern "C" int hlala_pair_loglik(hlala_ctx* c, const double* LL, const int32_t* 
         hipLaunchKernelGGL(k_transpose<double>, tg, tb, 0, c->stream, C, R, dLL, dLLT);
         hipLaunchKernelGGL(k_transpose<int>, tg, tb, 0, c->stream, C, R, dM, dMT);
     }
-    hipLaunchKernelGGL(k_pair_loglik, dim3((C + 255) / 256, C), dim3(256), 0, c->stream, C, R, dLL, dLLT, dM, dMT, dP, dA, dMn);
+    hipLaunchKernelGGL(k_pair_loglik, dim3((C + 255) / 256, (C + PAIRLL_ROWS - 1) / PAIRLL_ROWS), dim3(256), 0, c->stream, C, R, dLL, dLLT, dM, dMT, dP, dA, dMn);
     if((rc = check_launch(c, "k_pair_loglik"))) return done(rc);
     if(hipMemcpyAsync(pairLL, dP, npairs * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipMemcpyAsync(misAvg, dA, npairs * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
        hipMemcpyAsync(misMin, dMn, npairs * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "hlala_pair_loglik: download failed"; return done(HLALA_E_DEVICE); }

@@ -56,35 +56,54 @@ __device__ __forceinline__ double log_avg(double a, double b)                   
     return (log(0.5) + (log(1 + exp(a - b)) + b));
 }
 
-// block = one c1 and 256 consecutive c2 >= c1; row c1 staged in LDS, operand c2 read from the transposed matrix (coalesced)
-constexpr int PAIRLL_TILE = 1024;
+// block = PAIRLL_ROWS consecutive c1 and 256 consecutive c2 >= the first of them: the rows are staged in LDS, the operand of column c2 for
+// read r (transposed matrix: coalesced) is loaded ONCE and meets all the rows -- a quarter of the operand traffic of one row per block, and
+// four independent exp / log chains per thread to fill the FP64 pipeline.  Every (c1, c2) sum still runs over the reads left to right, as the
+// reference's loop does (:2312-2345).  Cells below the diagonal (c2 < c1) of the first rows' tile are computed and dropped.
+#ifndef HLALA_PAIRLL_ROWS
+#define HLALA_PAIRLL_ROWS 4
+#endif
+constexpr int PAIRLL_TILE = 512, PAIRLL_ROWS = HLALA_PAIRLL_ROWS;
 __global__ __launch_bounds__(256) void k_pair_loglik(int C, int R, const double* __restrict__ LL, const double* __restrict__ LLT,
                                                      const int* __restrict__ mism, const int* __restrict__ mismT,
                                                      double* __restrict__ pairLL, double* __restrict__ misAvg, double* __restrict__ misMin)
 {
-    __shared__ double rowA[PAIRLL_TILE];
-    __shared__ int rowM[PAIRLL_TILE];
-    const int c1 = blockIdx.y;
-    const int c2 = c1 + blockIdx.x * blockDim.x + threadIdx.x;
-    if(c1 + (int)(blockIdx.x * blockDim.x) >= C) return;
-    double ll = 0, sAvg = 0, sMin = 0;
+    __shared__ double rowA[PAIRLL_ROWS][PAIRLL_TILE];
+    __shared__ int rowM[PAIRLL_ROWS][PAIRLL_TILE];
+    const int c1b = blockIdx.y * PAIRLL_ROWS;
+    const int c2 = c1b + blockIdx.x * blockDim.x + threadIdx.x;
+    if(c1b + (int)(blockIdx.x * blockDim.x) >= C) return;
+    double ll[PAIRLL_ROWS], sAvg[PAIRLL_ROWS], sMin[PAIRLL_ROWS];
+#pragma unroll
+    for(int k = 0; k < PAIRLL_ROWS; k++) { ll[k] = 0; sAvg[k] = 0; sMin[k] = 0; }
     for(int r0 = 0; r0 < R; r0 += PAIRLL_TILE) {
-        int n = min(PAIRLL_TILE, R - r0);
+        const int n = min(PAIRLL_TILE, R - r0);
         __syncthreads();
-        for(int i = threadIdx.x; i < n; i += blockDim.x) { rowA[i] = LL[(size_t)c1 * R + r0 + i]; rowM[i] = mism[(size_t)c1 * R + r0 + i]; }
+        for(int k = 0; k < PAIRLL_ROWS; k++) {
+            const int c1 = min(c1b + k, C - 1);
+            for(int i = threadIdx.x; i < n; i += blockDim.x) { rowA[k][i] = LL[(size_t)c1 * R + r0 + i]; rowM[k][i] = mism[(size_t)c1 * R + r0 + i]; }
+        }
         __syncthreads();
         if(c2 < C)
-            for(int i = 0; i < n; i++) {                                                      // reads in order: the sum is left to right as in :2312-2345
-                double a = rowA[i], b = LLT[(size_t)(r0 + i) * C + c2];
-                int m1 = rowM[i], m2 = mismT[(size_t)(r0 + i) * C + c2];
-                ll += log_avg(a, b);
-                sAvg += ((double)(m1 + m2) / 2.0);
-                sMin += (m1 < m2) ? m1 : m2;
+            for(int i = 0; i < n; i++) {
+                const double b = LLT[(size_t)(r0 + i) * C + c2];
+                const int m2 = mismT[(size_t)(r0 + i) * C + c2];
+#pragma unroll
+                for(int k = 0; k < PAIRLL_ROWS; k++) {
+                    const double a = rowA[k][i]; const int m1 = rowM[k][i];
+                    ll[k] += log_avg(a, b);
+                    sAvg[k] += ((double)(m1 + m2) / 2.0);
+                    sMin[k] += (m1 < m2) ? m1 : m2;
+                }
             }
     }
-    if(c2 < C) {
-        size_t idx = (size_t)c1 * C - (size_t)c1 * (c1 - 1) / 2 + (size_t)(c2 - c1);
-        pairLL[idx] = ll; misAvg[idx] = sAvg; misMin[idx] = sMin;
+#pragma unroll
+    for(int k = 0; k < PAIRLL_ROWS; k++) {
+        const int c1 = c1b + k;
+        if(c1 < C && c2 >= c1 && c2 < C) {
+            const size_t idx = (size_t)c1 * C - (size_t)c1 * (c1 - 1) / 2 + (size_t)(c2 - c1);
+            pairLL[idx] = ll[k]; misAvg[idx] = sAvg[k]; misMin[idx] = sMin[k];
+        }
     }
 }
 
