@@ -54,10 +54,10 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
-    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* large_slabs = nullptr; size_t large_slab_bytes = 0; int ext_grid = 0; int wide_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
+    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* large_slabs = nullptr; size_t large_slab_bytes = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
-    hipEvent_t ev[12]{};          // start/end per stage; [7] / [6] / [9] / [10] / [11] / [8] = before DpTiny / after DpTiny / DpMid / DpSmall / DpWide / DpLarge
+    hipEvent_t ev[13]{};          // start/end per stage; [7] / [6] / [9] / [10] / [11] / [12] / [8] = before DpTiny / after DpTiny / DpMid / DpSmall / DpWide / DpBroad / DpLarge
     int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
     // per-pair post-processing: coverage counters [L-1] and gene intervals
     int* d_cov = nullptr; int n_cov = 0; int* d_gene_first = nullptr; int* d_gene_last = nullptr; int n_genes = 0;
@@ -311,11 +311,12 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->ext_grid = cus * 20;
     c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();      // 2 * mid_grid mid slabs fit the pool of ext_grid small slabs
     c->retry_grid = cus;
+    c->broad_grid = cus * 2;         // two DpBroad blocks per CU, slabs of the large layout
     c->wide_grid = cus * 5;          // LDS: five DpWide blocks per CU; their slabs come from the pool of the 64-lane class (same layout)
     c->stitch_grid = cus * 32;
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>();
-    c->large_slab_bytes = dp_slab_bytes<DpLarge>();       // one block per CU: a few MB each
-    if(hipMalloc((void**)&c->large_slabs, c->large_slab_bytes * (size_t)c->retry_grid) != hipSuccess) { c->err = "hipMalloc(large-class DP slabs) failed"; return fail(HLALA_E_DEVICE); }
+    c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / two blocks per CU: a few MB each
+    if(hipMalloc((void**)&c->large_slabs, c->large_slab_bytes * (size_t)c->broad_grid) != hipSuccess) { c->err = "hipMalloc(large-class DP slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->large_slabs);
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->ext_slabs);
@@ -330,7 +331,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
-    for(int i = 0; i < 12; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    for(int i = 0; i < 13; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;
@@ -343,7 +344,7 @@ void hlala_destroy(hlala_ctx* c)
     for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(auto& kv : c->pool) (void)hipFree(kv.second);
-    for(int i = 0; i < 12; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for(int i = 0; i < 13; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -401,7 +402,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
-    AL(counters, 32, true); AL(work_counter, 32, true); AL(retry_list, 8 * nc, false);
+    AL(counters, 32, true); AL(work_counter, 32, true); AL(retry_list, 10 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
     B.dbg = c->dbg_host;
 #undef AL
@@ -580,7 +581,10 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
             hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             rc_ = check_launch(c, "k_dp<wide>"); if(rc_) return rc_;
             if(first) HIP_TRY(c, hipEventRecord(c->ev[11], c->stream));
-            hipLaunchKernelGGL((k_dp<DpLarge, 4>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            rc_ = check_launch(c, "k_dp<broad>"); if(rc_) return rc_;
+            if(first) HIP_TRY(c, hipEventRecord(c->ev[12], c->stream));
+            hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             return check_launch(c, "k_dp<large>");
         };
         rc = run_classes(true); if(rc) return rc;
@@ -869,9 +873,9 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
     if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]);
           (void)hipEventElapsedTime(&out->ms_dp_class[0], c->ev[7], c->ev[6]); (void)hipEventElapsedTime(&out->ms_dp_class[1], c->ev[6], c->ev[9]);
-          (void)hipEventElapsedTime(&out->ms_dp_class[2], c->ev[9], c->ev[10]); (void)hipEventElapsedTime(&out->ms_dp_class[3], c->ev[10], c->ev[11]); (void)hipEventElapsedTime(&out->ms_dp_class[4], c->ev[11], c->ev[8]); } }
-    { int wc[32]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = wc[12] + wc[14] + wc[16] + wc[18] + wc[20] + wc[22] + wc[24] + wc[26]; out->n_dp_retried_large = wc[24] + wc[26];
-      out->n_dp_class[0] = wc[8] + wc[9]; for(int k = 1; k <= 4; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
+          (void)hipEventElapsedTime(&out->ms_dp_class[2], c->ev[9], c->ev[10]); (void)hipEventElapsedTime(&out->ms_dp_class[3], c->ev[10], c->ev[11]); (void)hipEventElapsedTime(&out->ms_dp_class[4], c->ev[11], c->ev[12]); (void)hipEventElapsedTime(&out->ms_dp_class[5], c->ev[12], c->ev[8]); } }
+    { int wc[32]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = 0; for(int k = 1; k <= 5; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
+      out->n_dp_class[0] = wc[8] + wc[9]; for(int k = 1; k <= 5; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

@@ -44,15 +44,17 @@ constexpr u64 HKEY_EMPTY = ~0ull;
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows per trip of the persistent loop (measured: 3 -> 236 ms, 6 -> 231, 12 -> 226, 24 -> 225, 64 -> 224 per 524 k pairs)
 
-struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; };
-struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; };
-struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; };
+struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr int BLOOM = 512; };
+struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 1024; };
+struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 4096; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
 // but a quarter of its LDS, so that five of them share a CU instead of one
-struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; typedef short Slot; typedef unsigned short ImpIdx; };
+struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 16384; };
+// frontiers of 257 .. 512 cells with the table sizes of the large class (tens of thousands of kept cells): half the LDS of the large class, two per CU
+struct DpBroad { static constexpr int WAVES = 1, GW = 64, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 16384; };
 // (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and
 //  thousands of sequence-complete cells per DP were measured -- are what the large class is sized for; its table slots are ints)
-struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; };
+struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 65536; };
 
 // State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
 // that only the phase has to stay in registers across the states of the persistent loop.
@@ -79,9 +81,10 @@ struct __align__(16) DpLdsT {
     u64 fkey[3][C::WCAP];
     typename C::Slot fslot[3][C::WCAP];        // table slot of the frontier cell
     short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
-    typename C::Slot tes[C::HC];    // per target: existing / assigned table slot (-1 = none), or -2 - (claimed early-hash entry)
+    typename C::Slot tes[C::HC];    // per target: existing / assigned table slot (-1 = none)
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     typename C::ImpIdx hq[C::HC];   // per hash entry: index of the improvement its cell staged this iteration (all ones = none)
+    u32 bloom[C::BLOOM / 32];       // Bloom filter (two bits per key) over the early cells registered in the slab hash: most lookups never leave LDS
     int nNew, nImp, nKeepF, err, nCompletedAdd;
     int nextPhase;                                    // state after PH_DONE: idle, or the end-cell choice of a linked duplicate
     int btSlot, btM, btX, btY, btGuard, btDone;       // back-pointer chase in progress (lane 0 of the group)
@@ -91,7 +94,7 @@ struct __align__(16) DpLdsT {
     long long tPh[8];
 #endif
 #ifdef HLALA_DP_PROFILE
-    long long pfStart; int pfSlow, pfImp, pfPre, pfMaxNT, pfMaxF; long long pfPh[6];
+    long long pfStart; int pfSlow, pfImp, pfPre, pfMaxNT, pfMaxF; long long pfPh[8];
 #endif
 };
 
@@ -296,6 +299,17 @@ __device__ inline u32 dp_probe(DpLdsT<C>& S, u64 key, u32 h)
     return (u32)C::HC;
 }
 
+template <class C> __device__ __forceinline__ bool bloom_maybe(const DpLdsT<C>& S, u64 key)
+{
+    const u32 hm = hash_mix(key), a = hm & (u32)(C::BLOOM - 1), b = (hm >> 16) & (u32)(C::BLOOM - 1);
+    return ((S.bloom[a >> 5] >> (a & 31)) & (S.bloom[b >> 5] >> (b & 31)) & 1u) != 0;
+}
+template <class C> __device__ __forceinline__ void bloom_set(DpLdsT<C>& S, u64 key)
+{
+    const u32 hm = hash_mix(key), a = hm & (u32)(C::BLOOM - 1), b = (hm >> 16) & (u32)(C::BLOOM - 1);
+    atomicOr(&S.bloom[a >> 5], 1u << (a & 31)); atomicOr(&S.bloom[b >> 5], 1u << (b & 31));
+}
+
 template <class C>
 __device__ inline int early_lookup(const DpSlabT<C>& sl, u64 key)
 {
@@ -307,20 +321,6 @@ __device__ inline int early_lookup(const DpSlabT<C>& sl, u64 key)
         if(cur == HKEY_EMPTY) return -1;
         h = (h + 1) & (C::EARLY - 1);
     }
-    return -1;
-}
-// find-or-insert in ONE compare-and-swap round trip per probe: returns the entry (>= 0) and whether the key was already there
-template <class C>
-__device__ inline int early_claim(const DpSlabT<C>& sl, u64 key, bool& found)
-{
-    u32 h = hash_mix(key) & (C::EARLY - 1);
-    for(int probe = 0; probe < C::EARLY; probe++) {
-        u64 old = atomicCAS(&sl.early_key()[h], HKEY_EMPTY, key);
-        if(old == HKEY_EMPTY) { found = false; return (int)h; }
-        if(old == key) { found = true; return (int)h; }
-        h = (h + 1) & (C::EARLY - 1);
-    }
-    found = false;
     return -1;
 }
 template <class C>
@@ -371,9 +371,9 @@ __device__ inline u64 xz_key(int x, int z)
 struct __align__(16) DpItem { int item, rOff, seqLen, start_seq, startLevel, startNode, pad0, pad1; };
 
 // first tier (1 = DpMid, 2 = DpSmall, 3 = DpLarge) whose class holds a frontier of n cells / a target set of n cells
-constexpr int DP_LAST_TIER = 4;      // tiers: 0 DpTiny, 1 DpMid, 2 DpSmall, 3 DpWide, 4 DpLarge
-__device__ __forceinline__ int tier_for_frontier(int n) { return n <= DpMid::WCAP ? 1 : (n <= DpSmall::WCAP ? 2 : (n <= DpWide::WCAP ? 3 : 4)); }
-__device__ __forceinline__ int tier_for_targets(int n) { return n <= (DpMid::HC * 3) / 4 ? 1 : (n <= (DpSmall::HC * 3) / 4 ? 2 : (n <= (DpWide::HC * 3) / 4 ? 3 : 4)); }
+constexpr int DP_LAST_TIER = 5;      // tiers: 0 DpTiny, 1 DpMid, 2 DpSmall, 3 DpWide, 4 DpBroad, 5 DpLarge
+__device__ __forceinline__ int tier_for_frontier(int n) { return n <= DpMid::WCAP ? 1 : (n <= DpSmall::WCAP ? 2 : (n <= DpWide::WCAP ? 3 : (n <= DpBroad::WCAP ? 4 : 5))); }
+__device__ __forceinline__ int tier_for_targets(int n) { return n <= (DpMid::HC * 3) / 4 ? 1 : (n <= (DpSmall::HC * 3) / 4 ? 2 : (n <= (DpWide::HC * 3) / 4 ? 3 : (n <= (DpBroad::HC * 3) / 4 ? 4 : 5))); }
 
 #define DP_FAIL(code) do { if(gl == 0 && S.err == 0) S.err = (code); } while(0)
 
@@ -396,7 +396,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.have = 0; st.sb = 0; st.se = -1; st.err = 0; st.needTier = 0; st.isAlias = 0;
         S.err = 0;
 #ifdef HLALA_DP_PROFILE
-        S.pfStart = clock64(); S.pfSlow = 0; S.pfImp = 0; S.pfPre = 0; S.pfMaxNT = 0; S.pfMaxF = 0; for(int i = 0; i < 6; i++) S.pfPh[i] = 0;
+        S.pfStart = clock64(); S.pfSlow = 0; S.pfImp = 0; S.pfPre = 0; S.pfMaxNT = 0; S.pfMaxF = 0; for(int i = 0; i < 8; i++) S.pfPh[i] = 0;
 #endif
         CellRec c0; c0.key = mk_key(it.startLevel, it.start_seq, it.startNode);
         c0.sc[0] = 0; c0.sc[1] = (short)DP_NEG; c0.sc[2] = (short)DP_NEG; c0.sc[3] = 0; c0.bt[0] = 0; c0.bt[1] = 0; c0.bt[2] = 0; c0.pad = 0;
@@ -438,9 +438,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     }
     if(d > 60000) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }      // watchdog: far beyond any read length + patience
 
-#ifdef HLALA_DP_TIMING
+#if defined(HLALA_DP_TIMING)
     long long tq0 = clock64();
 #define DP_TQ(i) do { __builtin_amdgcn_s_waitcnt(0); long long t_ = clock64(); if(gl == 0) S.tPh[i] += t_ - tq0; tq0 = t_; } while(0)
+#elif defined(HLALA_DP_PROFILE)
+    long long tq0 = clock64();      // phases of the profiled DP: 4 records, 5 pushes, 0 target list, 3 early look-ups, 6 evaluate passes, 1 post-evaluate, 2 filter + sort + reset
+#define DP_TQ(i) do { __builtin_amdgcn_s_waitcnt(0); long long t_ = clock64(); if(gl == 0) S.pfPh[i] += t_ - tq0; tq0 = t_; } while(0)
 #else
 #define DP_TQ(i) do { } while(0)
 #endif
@@ -577,13 +580,13 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     u64 itMaxKey = ~0ull;         // smallest key achieving it (= first such cell in std::map order)
     bool anyEqDiff = false, anyOw = false, anyExisting = false;
 
-    // Cells reached through a gap-path jump arrive EARLIER than their natural diagonal |dx|+|dy| and can be
-    // reached again later ("scores" merge, :951-979).  Every target of iteration d has a natural diagonal >= d, so a target can
-    // only meet an early cell while d <= the largest natural diagonal of the early cells created so far: in those iterations
-    // every kept target is looked up in and, if new, registered with the DP's cell hash in the slab -- one compare-and-swap
-    // round trip does both (registering a cell that is not early is merely harmless).  Once the early lineage has died out and
-    // d has passed its last diagonal, nothing can be met again and the pre-pass is skipped.  tes[t] = table slot of an
-    // existing cell, or -2 - (hash entry claimed for a new one), or -1.
+    // Cells reached through a gap-path jump arrive EARLIER than their natural diagonal |dx|+|dy| and can be reached again later ("scores"
+    // merge, :951-979): they are registered with the DP's cell hash in the slab (HBM).  Every target of iteration d has a natural diagonal
+    // >= d -- a cell created on its natural diagonal is never met again -- so a target can only meet an early cell while d <= the largest
+    // natural diagonal of the early cells created so far: in those iterations every kept target is looked up.  A Bloom filter over the
+    // registered cells sits in LDS: a target it does not know is new without a trip to the slab (on allele-rich, gap-rich levels the early
+    // lineage lives on for hundreds of iterations, and the lookups -- then one global compare-and-swap per kept target and iteration -- were
+    // most of the time of the wide and large classes).  tes[t] = table slot of an existing cell, or -1.
     const bool prepass = earlyInit && d <= earlyMaxNat0;
     int earlyNatMax = -1;         // per lane: largest natural diagonal of the early cells this iteration creates
     if(prepass) {
@@ -592,14 +595,8 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             if(t < nT) {
                 int h = S.tlist[t];
                 int Dv = max(best_score(S.hbest[M_D][h]), max(best_score(S.hbest[M_GG][h]), best_score(S.hbest[M_SG][h])));
-                int v = -1;
-                if(Dv >= -16) {
-                    bool found; int pos = early_claim<C>(sl, S.hkey[h], found);
-                    if(pos < 0) S.err = __LINE__;
-                    else if(found) { es = __hip_atomic_load(&sl.early_val()[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = es; }
-                    else v = -2 - pos;
-                }
-                S.tes[t] = (typename C::Slot)v;
+                if(Dv >= -16) { const u64 key = S.hkey[h]; if(bloom_maybe<C>(S, key)) es = early_lookup<C>(sl, key); }
+                S.tes[t] = (typename C::Slot)es;
             }
             if(grp_ballot<GW>(es >= 0)) anyExisting = true;
         }
@@ -625,14 +622,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             int es = -1; bool isNew; int slot;
             if(pass == 0) {
                 if(hadEarly && act) S.hq[h] = (typename C::ImpIdx)~0u;
-                int claimed = -1;
-                if(hadEarly && keep) { int v = S.tes[t]; if(v >= 0) es = v; else if(v <= -2) claimed = -2 - v; }
+                if(hadEarly && keep) { int v = S.tes[t]; if(v >= 0) es = v; }
                 isNew = keep && es < 0;
                 int total; int off = grp_excl_scan<GW>(isNew ? 1 : 0, total);
                 slot = isNew ? nCells + off : es;
                 if(nCells + total > C::CELLS) { DP_FAIL(__LINE__); failed = true; }
                 nCells += total;
-                if(isNew && claimed >= 0) __hip_atomic_store(&sl.early_val()[claimed], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 slot = keep ? S.tes[t] : -1;
                 isNew = keep && (S.timp[t] & 0x80);
@@ -680,13 +675,14 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 int natural = (x > startLevel ? x - startLevel : startLevel - x) + (y > start_seq ? y - start_seq : start_seq - y);
                 bool isEarly = isNew && natural > d;
                 if(isEarly && natural > earlyNatMax) earlyNatMax = natural;
-                if(!hadEarly && grp_ballot<GW>(isEarly)) {       // early cells while no pre-pass ran (the first ones of this DP, or of a new early lineage): into the hash
+                if(grp_ballot<GW>(isEarly)) {                    // early cells: into the slab hash and the Bloom filter
                     if(!earlyInit) {
                         for(int i = gl; i < C::EARLY; i += GW) sl.early_key()[i] = HKEY_EMPTY;
+                        for(int i = gl; i < C::BLOOM / 32; i += GW) S.bloom[i] = 0;
                         earlyInit = 1;
                         WSYNC();
                     }
-                    if(isEarly) if(!early_insert<C>(sl, key, slot)) S.err = __LINE__;
+                    if(isEarly) { if(!early_insert<C>(sl, key, slot)) S.err = __LINE__; bloom_set<C>(S, key); }
                 }
                 if(isNew && y == limitY) {                                                     // :982-999
                     int pos = atomicAdd(&S.nCompletedAdd, 1);
@@ -1186,7 +1182,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
 
     for(int dirPass = 0; dirPass < 2; dirPass++) {
         // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
-        // retry list of tier k = 1..4 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
+        // retry list of tier k = 1..5 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
         int* fetchCounter = &B.work_counter[TIER == 0 ? (dirPass ? 10 : 1) : 13 + 4 * (TIER - 1) + 2 * dirPass];
         const int nItems = uni(B.work_counter[TIER == 0 ? 8 + dirPass : 12 + 4 * (TIER - 1) + 2 * dirPass]);
         const int listBase = (TIER == 0 && dirPass) ? B.n_chains : 0;
@@ -1218,7 +1214,8 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
                     if(B.dbg && TIER == HLALA_DP_PROFILE) {
                         const long long cyc = clock64() - S.pfStart;
                         if(cyc > (1ll << 18)) { int q = atomicAdd(&B.dbg[0], 1); if(q < 500) { int* r = B.dbg + 16 + 16 * q; r[0] = st.item; r[1] = st.itersRun; r[2] = (int)st.cellsEvaluated; r[3] = st.nCells;
-                            r[4] = S.pfSlow; r[5] = S.pfImp; r[6] = S.pfPre; r[7] = (int)(cyc >> 10); r[8] = S.pfMaxNT; r[9] = S.pfMaxF; r[10] = st.nCompleted; r[11] = st.err; r[12] = st.nSteps; r[13] = st.earlyInit; r[14] = st.seqLen; r[15] = st.start_seq; } }
+                            r[4] = S.pfSlow; r[5] = S.pfImp; r[6] = S.pfPre; r[7] = (int)(cyc >> 10); r[8] = S.pfMaxNT;
+                            r[9] = (int)(S.pfPh[4] >> 10); r[10] = (int)(S.pfPh[5] >> 10); r[11] = (int)(S.pfPh[0] >> 10); r[12] = (int)(S.pfPh[3] >> 10); r[13] = (int)(S.pfPh[6] >> 10); r[14] = (int)(S.pfPh[1] >> 10); r[15] = (int)(S.pfPh[2] >> 10); } }
                     }
 #endif
                     const bool capacity = st.err != 0 && st.err > -1000000;

@@ -28,7 +28,7 @@ def test_extend_matches_oracle(pkg, oracle, seed, G, k, n_pairs):
     assert st.n_dp_iterations == exp["_stats"][1]
     assert st.n_dp_cells == exp["_stats"][2]
     # the gap-heavy graph (k = 0: long runs of parallel gap paths) must have gone through the wider capacity classes,
-    # i.e. the parity above covers DP calls re-run by the 32-lane, 64-lane and wide kernels as well
+    # i.e. the parity above covers DP calls re-run by the 32-lane, 64-lane and wide kernels as well (the broad and large classes: tests/test_graph_m.py)
     print(f"k={k}: DP calls {st.n_dp_calls}, re-run in a wider class {st.n_chains_retried}, in the large class {st.n_dp_retried_large}")
     if k == 0:
         assert st.n_chains_retried > 0 and all(int(x) > 0 for x in list(st.n_dp_class)[:4]), list(st.n_dp_class)

@@ -165,7 +165,20 @@ def test_gene_window_reads_match_oracle(pkg, oracle, world_m):
     z = g["edge_to"][ed] - level_first[g["node_level"][g["edge_to"][ed]]]
     assert z.max() >= 50 and (z >= 10).sum() > 2000
     cls = list(st.n_dp_class)
-    assert all(c > 0 for c in cls), f"DP classes entered (16-lane, 32-lane, 64-lane, large): {cls}"
+    assert all(c > 0 for c in cls[:4]), f"DP classes entered (16-lane, 32-lane, 64-lane, wide, broad, large): {cls}"
+    assert truth_accuracy(b, got, 384) >= 0.99
+
+
+@pytest.mark.gpu
+def test_dense_windows_reach_the_broad_and_large_classes(pkg, oracle):
+    """Windows with 4000-5000 alleles (up to ~400 nodes per level): frontiers of 500-750 cells, 16 000 kept cells and thousands of tied
+    sequence-complete cells per DP -- the two classes with the large table layout, the bitonic frontier sort and the bitwise tie selection."""
+    w = synth.make_world_m(seed=8, n_levels=60_000, n_windows=3, alleles=(4000, 5000))
+    assert w["max_nodes_per_level"] >= 300
+    b = synth.make_batch_m(w, 1500, seed=21, frac_gene=1.0)
+    got, st, exp = gpu_vs_oracle(pkg, oracle, w, b)
+    cls = list(st.n_dp_class)
+    assert cls[4] > 0 and cls[5] > 0, f"DP classes entered (16-lane, 32-lane, 64-lane, wide, broad, large): {cls}"
     assert truth_accuracy(b, got, 384) >= 0.99
 
 

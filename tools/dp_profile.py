@@ -27,7 +27,7 @@ print("rc", rc, "class ms", [round(float(x), 1) for x in st.ms_dp_class], "calls
 nrec = int(buf[0]); print("records over the threshold:", nrec)
 r = buf[16:16 + 16 * min(nrec, 500)].reshape(-1, 16)
 r = r[np.argsort(-r[:, 7])]
-print("item iters cellsEval nCells slowIters sumImp preIters kcycles maxNT maxF nCompl err nSteps early seqLen startSeq")
+print("item iters cellsEval nCells slowIters sumImp preIters kcycles maxNT | kcycles in: records pushes tlist early-lookups evaluate post-evaluate filter+sort+reset")
 for x in r[:40]:
     print(" ".join(str(int(v)) for v in x))
 print("sum kcycles", int(r[:, 7].sum()), "mean", float(r[:, 7].mean()) if len(r) else 0)
