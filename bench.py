@@ -180,7 +180,7 @@ def main():
         e_mean = g["n_edges"] / max(1, g["n_nodes"] - 1)
         bpp = algorithmic_bytes_per_pair(150, chains_pp, e_mean, cols_pc, cols_pc)
         cls_ms = [float(x) for x in st.ms_dp_class]; cls_n = [int(x) for x in st.n_dp_class]
-        names = ["k_dp<DpTiny, 0>", "k_dp<DpMid, 1>", "k_dp<DpSmall, 2>", "k_dp<DpWide, 3>", "k_dp<DpBroad, 4>", "k_dp<DpLarge, 5>"]
+        names = ["k_dp<DpTiny, 0>", "k_dp<DpMid, 1>", "k_dp<DpSmall, 2>", "k_dp<DpWide, 3>", "k_dp<DpBroad, 4>", "k_dp<DpLarge, 5>", "k_dp<DpHuge, 6>"]
         dom = int(np.argmax(cls_ms))
         dom_ms = cls_ms[dom]
         achieved = bpp * args.pairs / (dom_ms * 1e-3) / 1e9
@@ -211,8 +211,8 @@ def main():
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
                        "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
                        "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "pair": st.ms_pair,
-                                    "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5]},
-                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5]},
+                                    "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6]},
+                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6]},
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,

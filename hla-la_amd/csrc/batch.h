@@ -63,9 +63,9 @@ struct DevBatch {
     uint8_t* sel_mapq;              // [n_reads*stride] mapQ_perPosition of the selected chain
     // ---- counters (device): see hlala_batch_stats
     u64* counters;                  // [32]
-    int* work_counter;              // [32] dynamic work distribution: [0] stage A, [2] stage C, [7] chains stitched, [8]/[9] left / right DP items,
-                                    //      [1]/[10] left / right items fetched, [12..31] retry lists (count, fetched) per tier 1..5 and direction
-    int* retry_list;                // [10*n_chains] DP items that outgrew a capacity class: (tier 1..5) x (left, right) x n_chains
+    int* work_counter;              // [48] dynamic work distribution: [0] stage A, [2] stage C, [7] chains stitched, [8]/[9] left / right DP items,
+                                    //      [1]/[10] left / right items fetched, [12..35] retry lists (count, fetched) per tier 1..6 and direction
+    int* retry_list;                // [12*n_chains] DP items that outgrew a capacity class: (tier 1..6) x (left, right) x n_chains
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
     int* dbg;                       // non-null with HLALA_DEBUG=1: kernels add phase clocks to counters[16..31]
 };

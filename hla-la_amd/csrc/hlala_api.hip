@@ -54,10 +54,10 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
-    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* large_slabs = nullptr; size_t large_slab_bytes = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
+    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
-    hipEvent_t ev[13]{};          // start/end per stage; [7] / [6] / [9] / [10] / [11] / [12] / [8] = before DpTiny / after DpTiny / DpMid / DpSmall / DpWide / DpBroad / DpLarge
+    hipEvent_t ev[14]{};          // start/end per stage; [7] / [6] / [9] / [10] / [11] / [12] / [13] / [8] = before DpTiny / after DpTiny / DpMid / DpSmall / DpWide / DpBroad / DpLarge / DpHuge
     int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
     // per-pair post-processing: coverage counters [L-1] and gene intervals
     int* d_cov = nullptr; int n_cov = 0; int* d_gene_first = nullptr; int* d_gene_last = nullptr; int n_genes = 0;
@@ -318,6 +318,10 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / two blocks per CU: a few MB each
     if(hipMalloc((void**)&c->large_slabs, c->large_slab_bytes * (size_t)c->broad_grid) != hipSuccess) { c->err = "hipMalloc(large-class DP slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->large_slabs);
+    c->huge_grid = cus / 4 > 0 ? cus / 4 : 1;      // the in-memory backstop class: a handful of DP calls per million pairs
+    c->huge_slab_bytes = dp_inmemory_bytes<DpHuge>();
+    if(hipMalloc((void**)&c->huge_slabs, c->huge_slab_bytes * (size_t)c->huge_grid) != hipSuccess) { c->err = "hipMalloc(in-memory DP class) failed"; return fail(HLALA_E_DEVICE); }
+    c->allocs.push_back(c->huge_slabs);
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->ext_slabs);
     c->proj_grid = cus * 9; c->pair_grid = cus * 14;
@@ -331,7 +335,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
-    for(int i = 0; i < 13; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    for(int i = 0; i < 14; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;
@@ -344,7 +348,7 @@ void hlala_destroy(hlala_ctx* c)
     for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(auto& kv : c->pool) (void)hipFree(kv.second);
-    for(int i = 0; i < 13; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for(int i = 0; i < 14; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -402,7 +406,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
-    AL(counters, 32, true); AL(work_counter, 32, true); AL(retry_list, 10 * nc, false);
+    AL(counters, 32, true); AL(work_counter, 48, true); AL(retry_list, 12 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
     B.dbg = c->dbg_host;
 #undef AL
@@ -530,7 +534,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     if(!c || !b) return HLALA_E_ARG;
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
-    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 32 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 48 * sizeof(int), c->stream));
     HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if(B.n_chains > 0) {
@@ -557,7 +561,7 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
-    HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, 25 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, 41 * sizeof(int), c->stream));
     if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if(B.n_chains > 0) {
@@ -585,7 +589,10 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
             rc_ = check_launch(c, "k_dp<broad>"); if(rc_) return rc_;
             if(first) HIP_TRY(c, hipEventRecord(c->ev[12], c->stream));
             hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-            return check_launch(c, "k_dp<large>");
+            rc_ = check_launch(c, "k_dp<large>"); if(rc_) return rc_;
+            if(first) HIP_TRY(c, hipEventRecord(c->ev[13], c->stream));
+            hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            return check_launch(c, "k_dp<huge>");
         };
         rc = run_classes(true); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[8], c->stream));
@@ -873,9 +880,9 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
     if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]);
           (void)hipEventElapsedTime(&out->ms_dp_class[0], c->ev[7], c->ev[6]); (void)hipEventElapsedTime(&out->ms_dp_class[1], c->ev[6], c->ev[9]);
-          (void)hipEventElapsedTime(&out->ms_dp_class[2], c->ev[9], c->ev[10]); (void)hipEventElapsedTime(&out->ms_dp_class[3], c->ev[10], c->ev[11]); (void)hipEventElapsedTime(&out->ms_dp_class[4], c->ev[11], c->ev[12]); (void)hipEventElapsedTime(&out->ms_dp_class[5], c->ev[12], c->ev[8]); } }
-    { int wc[32]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = 0; for(int k = 1; k <= 5; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
-      out->n_dp_class[0] = wc[8] + wc[9]; for(int k = 1; k <= 5; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
+          (void)hipEventElapsedTime(&out->ms_dp_class[2], c->ev[9], c->ev[10]); (void)hipEventElapsedTime(&out->ms_dp_class[3], c->ev[10], c->ev[11]); (void)hipEventElapsedTime(&out->ms_dp_class[4], c->ev[11], c->ev[12]); (void)hipEventElapsedTime(&out->ms_dp_class[5], c->ev[12], c->ev[13]); (void)hipEventElapsedTime(&out->ms_dp_class[6], c->ev[13], c->ev[8]); } }
+    { int wc[48]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
+      out->n_dp_class[0] = wc[8] + wc[9]; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

@@ -44,17 +44,25 @@ constexpr u64 HKEY_EMPTY = ~0ull;
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows per trip of the persistent loop (measured: 3 -> 236 ms, 6 -> 231, 12 -> 226, 24 -> 225, 64 -> 224 per 524 k pairs)
 
-struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr int BLOOM = 512; };
-struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 1024; };
-struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 4096; };
+struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr int BLOOM = 512; static constexpr bool IN_MEMORY = false; };
+struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 1024; static constexpr bool IN_MEMORY = false; };
+struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 4096; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
 // but a quarter of its LDS, so that five of them share a CU instead of one
-struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 16384; };
+struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 16384; static constexpr bool IN_MEMORY = false; };
 // frontiers of 257 .. 512 cells with the table sizes of the large class (tens of thousands of kept cells): half the LDS of the large class, two per CU
-struct DpBroad { static constexpr int WAVES = 1, GW = 64, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 16384; };
+struct DpBroad { static constexpr int WAVES = 1, GW = 64, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 16384; static constexpr bool IN_MEMORY = false; };
 // (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and
 //  thousands of sequence-complete cells per DP were measured -- are what the large class is sized for; its table slots are ints)
-struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 65536; };
+struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 65536; static constexpr bool IN_MEMORY = false; };
+
+// The backstop: everything the other classes keep in LDS -- target table, frontiers, DP state -- lives in the block's HBM slab, so the capacities are
+// set by memory, not by the 160 KB of a CU (frontiers of 3000+ cells, 60 000 kept cells and 15 000 tied complete cells per DP occur on the densest
+// levels of the Graph M workload: about 30 DP calls per million pairs).  Same code (one template): the structure reference simply points into
+// the slab, the wave fences become agent-scope fences (plain loads must not hit stale L1 lines of words the atomics changed in L2), and the
+// frontier sort borrows the otherwise unused LDS.  An order of magnitude slower per cell than the LDS classes; nothing is dropped.
+struct DpHuge  { static constexpr int WAVES = 1, GW = 64, WCAP = 8192, HC = 16384, IBITS = 13, CELLS = 131072, EARLY = 131072, IMPCAP = 8192, COMPLETED = 65536, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 65536; static constexpr bool IN_MEMORY = true; };
+constexpr int DP_SORT_SCRATCH = 8192;       // (key, payload) pairs of the in-memory class's frontier sort, in LDS: 128 KB
 
 // State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
 // that only the phase has to stay in registers across the states of the persistent loop.
@@ -137,6 +145,9 @@ struct DpSlabT {
 
 template <class C>
 __host__ __device__ inline size_t dp_slab_bytes() { return DpSlabT<C>::BYTES; }
+// bytes of one block of an in-memory class: the structure the other classes keep in LDS, then the scratch slab
+template <class C>
+__host__ __device__ inline size_t dp_inmemory_bytes() { return ((sizeof(DpLdsT<C>) + 255) & ~(size_t)255) + DpSlabT<C>::BYTES; }
 
 // ------------------------------------------------------------------------------------------ group collectives
 // GW = 64: the wave-wide DPP reductions of device_common.h (results are wave-uniform, in SGPRs).
@@ -207,6 +218,16 @@ template <int GW> __device__ __forceinline__ int grp_bcast(int v, int srcGroupLa
 }
 // a group-uniform value: scalar for full-wave groups, left alone otherwise
 template <int GW> __device__ __forceinline__ int guni(int v) { return GW == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }
+
+// ordering between the lanes of a DP's group: a wavefront-scope fence for state in LDS; for the in-memory class an agent-scope fence (L1
+// invalidate / write-back around the barrier), because its atomics execute in the L2 and plain loads of the same words would otherwise be
+// served from the CU's L1
+template <class C> __device__ __forceinline__ void dp_sync()
+{
+    if constexpr (C::IN_MEMORY) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+    else { WSYNC(); }
+}
+#define DSYNC() dp_sync<C>()
 
 // DP cell key: level x (24 bits) | read offset y (12 bits) | node id (28 bits).  Node ids are level-major and
 // stable in creation order, so unsigned key order == the reference's std::map order (x, then y, then rank z).
@@ -371,9 +392,9 @@ __device__ inline u64 xz_key(int x, int z)
 struct __align__(16) DpItem { int item, rOff, seqLen, start_seq, startLevel, startNode, pad0, pad1; };
 
 // first tier (1 = DpMid, 2 = DpSmall, 3 = DpLarge) whose class holds a frontier of n cells / a target set of n cells
-constexpr int DP_LAST_TIER = 5;      // tiers: 0 DpTiny, 1 DpMid, 2 DpSmall, 3 DpWide, 4 DpBroad, 5 DpLarge
-__device__ __forceinline__ int tier_for_frontier(int n) { return n <= DpMid::WCAP ? 1 : (n <= DpSmall::WCAP ? 2 : (n <= DpWide::WCAP ? 3 : (n <= DpBroad::WCAP ? 4 : 5))); }
-__device__ __forceinline__ int tier_for_targets(int n) { return n <= (DpMid::HC * 3) / 4 ? 1 : (n <= (DpSmall::HC * 3) / 4 ? 2 : (n <= (DpWide::HC * 3) / 4 ? 3 : (n <= (DpBroad::HC * 3) / 4 ? 4 : 5))); }
+constexpr int DP_LAST_TIER = 6;      // tiers: 0 DpTiny, 1 DpMid, 2 DpSmall, 3 DpWide, 4 DpBroad, 5 DpLarge, 6 DpHuge
+__device__ __forceinline__ int tier_for_frontier(int n) { return n <= DpMid::WCAP ? 1 : (n <= DpSmall::WCAP ? 2 : (n <= DpWide::WCAP ? 3 : (n <= DpBroad::WCAP ? 4 : (n <= DpLarge::WCAP ? 5 : 6)))); }
+__device__ __forceinline__ int tier_for_targets(int n) { return n <= (DpMid::HC * 3) / 4 ? 1 : (n <= (DpSmall::HC * 3) / 4 ? 2 : (n <= (DpWide::HC * 3) / 4 ? 3 : (n <= (DpBroad::HC * 3) / 4 ? 4 : (n <= (DpLarge::HC * 3) / 4 ? 5 : 6)))); }
 
 #define DP_FAIL(code) do { if(gl == 0 && S.err == 0) S.err = (code); } while(0)
 
@@ -404,7 +425,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         S.fkey[0][0] = mk_key(it.startLevel, it.start_seq, it.startNode); S.fslot[0][0] = 0;
         S.fD[0][0] = 0; S.fG[0][0] = (short)DP_NEG; S.fS[0][0] = (short)DP_NEG;
     }
-    WSYNC();
+    DSYNC();
     return PH_RUN;
 }
 
@@ -412,7 +433,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
 // returnGlobalScore = false, preferSequenceCompleAlignments = true, empty blockedPathsTable,
 // diagonal_stop_threshold = -16 (the only configuration extendSeedChain uses, :229-241, :281-293).
 template <class C>
-__device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, const int4* nrec, const uint8_t* readBases, const bool fwd, int& edgesAcc)
+__device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, const int4* nrec, const uint8_t* readBases, const bool fwd, int& edgesAcc, u64* sortScratch)
 {
     constexpr int GW = C::GW;
     const int gl = grp_lane<GW>();
@@ -433,10 +454,10 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         // both frontiers empty: the remaining iterations of the reference loop are no-ops
         int last = lastInc0 + 40; if(last > diagonals) last = diagonals;
         if(gl == 0) st.itersRun = last;
-        WSYNC();
+        DSYNC();
         return PH_SELECT;
     }
-    if(d > 60000) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }      // watchdog: far beyond any read length + patience
+    if(d > 60000) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } DSYNC(); return PH_DONE; }      // watchdog: far beyond any read length + patience
 
 #if defined(HLALA_DP_TIMING)
     long long tq0 = clock64();
@@ -551,10 +572,25 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         }
     }
     edgesAcc += edges;
-    WSYNC();
+    DSYNC();
     DP_TQ(5);
     // target list = occupied hash entries, compacted with a ballot per GW entries (no per-push counter, no ordering assumed)
     int nT = 0;
+    if constexpr (C::IN_MEMORY) {
+        // (the table is in HBM: four independent loads per lane and trip instead of one)
+        for(int h0 = 0; h0 < C::HC; h0 += 4 * GW) {
+            u64 kk[4];
+#pragma unroll
+            for(int q = 0; q < 4; q++) kk[q] = __hip_atomic_load(&S.hkey[h0 + q * GW + gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for(int q = 0; q < 4; q++) {
+                const bool occ = kk[q] != HKEY_EMPTY;
+                const u64 m = grp_ballot<GW>(occ);
+                if(occ) S.tlist[nT + __popcll(m & ((1ull << gl) - 1ull))] = (typename TlistT<(C::HC <= 256)>::type)(h0 + q * GW + gl);
+                nT += __popcll(m);
+            }
+        }
+    } else
     for(int h0 = 0; h0 < C::HC; h0 += GW) {
         const int h = h0 + gl;
         const bool occ = S.hkey[h] != HKEY_EMPTY;
@@ -562,9 +598,9 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         if(occ) S.tlist[nT + __popcll(m & ((1ull << gl) - 1ull))] = (typename TlistT<(C::HC <= 256)>::type)h;
         nT += __popcll(m);
     }
-    WSYNC();
+    DSYNC();
     DP_TQ(0);
-    if(nT > (C::HC * 3) / 4 || guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; if(nT > (C::HC * 3) / 4) st.needTier = tier_for_targets(nT); } WSYNC(); return PH_DONE; }
+    if(nT > (C::HC * 3) / 4 || guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; if(nT > (C::HC * 3) / 4) st.needTier = tier_for_targets(nT); } DSYNC(); return PH_DONE; }
 
     // ================= evaluate =====================================================
     // (the part of the DP state that only this phase needs is read here, not at the top: shorter live ranges)
@@ -575,7 +611,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     int earlyInit = guni<GW>(st.earlyInit);
     const int earlyMaxNat0 = guni<GW>(st.earlyMaxNat);
     if(gl == 0) { S.nNew = 0; S.nImp = 0; S.nCompletedAdd = 0; }
-    WSYNC();
+    DSYNC();
     int itMaxNew = DP_NEG;        // max Dv over kept targets of this iteration
     u64 itMaxKey = ~0ull;         // smallest key achieving it (= first such cell in std::map order)
     bool anyEqDiff = false, anyOw = false, anyExisting = false;
@@ -600,7 +636,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             }
             if(grp_ballot<GW>(es >= 0)) anyExisting = true;
         }
-        WSYNC();
+        DSYNC();
     }
     DP_TQ(3);
     const bool slow = anyExisting;
@@ -680,7 +716,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                         for(int i = gl; i < C::EARLY; i += GW) sl.early_key()[i] = HKEY_EMPTY;
                         for(int i = gl; i < C::BLOOM / 32; i += GW) S.bloom[i] = 0;
                         earlyInit = 1;
-                        WSYNC();
+                        DSYNC();
                     }
                     if(isEarly) { if(!early_insert<C>(sl, key, slot)) S.err = __LINE__; bloom_set<C>(S, key); }
                 }
@@ -753,10 +789,10 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 S.hbest[2][h] = (typename C::Best)(u32)(unsigned short)(short)mS;
             }
         }
-        WSYNC();
+        DSYNC();
     }
     DP_TQ(6);
-    if(guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } WSYNC(); return PH_DONE; }
+    if(guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } DSYNC(); return PH_DONE; }
     const int nCompletedNew = nCompleted0 + guni<GW>(S.nCompletedAdd);
     // apply staged improvements of existing cells and patch cached frontier copies
     {
@@ -766,7 +802,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             for(int m = 0; m < 3; m++) if(msk & (1 << m)) { sl.cell()[es].sc[m] = sl.imp_new()[4 * q + m]; sl.cell()[es].bt[m] = sl.imp_bt()[3 * q + m]; }
         }
         if(nImp) {
-            WSYNC();
+            DSYNC();
             // cached copies of the improved cells in the two frontiers: a frontier cell that was improved is a target of this iteration
             for(int w = 0; w < 2; w++) {
                 const int bb = w ? b2 : b1, nn = w ? n2 : n1;
@@ -811,8 +847,8 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         }
         nNew += __popcll(m);
     }
-    if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; st.needTier = tier_for_frontier(nNew); } WSYNC(); return PH_DONE; }
-    WSYNC();
+    if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; st.needTier = tier_for_frontier(nNew); } DSYNC(); return PH_DONE; }
+    DSYNC();
     // reset the hash entries used by this iteration (the survivors live in the frontier buffer now)
     for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
     // ... then put into std::map order (x, y, z) = key order
@@ -824,18 +860,25 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             key = S.fkey[bn][gl]; vs = S.fslot[bn][gl]; vD = S.fD[bn][gl]; vG = S.fG[bn][gl]; vS = S.fS[bn][gl];
             for(int u = 0; u < nNew; u++) rank += (S.fkey[bn][u] < key) ? 1 : 0;
         }
-        WSYNC();
+        DSYNC();
         if(act) { S.fkey[bn][rank] = key; S.fslot[bn][rank] = vs; S.fD[bn][rank] = vD; S.fG[bn][rank] = vG; S.fS[bn][rank] = vS; }
     } else if(C::WCAP > GW && nNew > GW) {
-        // frontier wider than the group (allele-rich levels: hundreds of cells): bitonic sort of (key, packed payload) pairs in LDS;
-        // the payload array borrows the hash's third value array, which is idle (all zero) between iterations.  (The rank of every
-        // survivor used to be counted against all targets: quadratic, and 99 % of the time of the widest DPs of the Graph M workload.)
-        WSYNC();
+        // frontier wider than the group (allele-rich levels: hundreds of cells): bitonic sort of (key, packed payload) pairs in LDS.  The LDS
+        // classes sort the frontier buffer in place and borrow the hash's third value array, idle (all zero) between iterations, for the payload;
+        // the in-memory class sorts in the block's scratch.  (The rank of every survivor used to be counted against all targets: quadratic,
+        // and 99 % of the time of the widest DPs of the Graph M workload.)  Payload: slot (20 bits) and the three scores in 12 bits each
+        // (0 = none, else score + 64: a kept cell's scores are >= -22).
+        DSYNC();
         int Pn = GW * 2; while(Pn < nNew) Pn <<= 1;              // power of two >= nNew, <= WCAP
-        u64* pay = (u64*)&S.hbest[2][0];
+        u64* keys; u64* pay;
+        if constexpr (C::IN_MEMORY) { keys = sortScratch; pay = sortScratch + DP_SORT_SCRATCH; } else { keys = &S.fkey[bn][0]; pay = (u64*)&S.hbest[2][0]; }
+        auto enc = [](int v) -> u64 { return v == DP_NEG ? 0ull : (u64)(u32)(v + 64); };
+        auto dec = [](u64 e) -> short { return e == 0 ? (short)DP_NEG : (short)((int)e - 64); };
         for(int i = gl; i < Pn; i += GW) {
-            if(i < nNew) pay[i] = (u64)(u32)(unsigned short)S.fD[bn][i] | ((u64)(u32)(unsigned short)S.fG[bn][i] << 16) | ((u64)(u32)(unsigned short)S.fS[bn][i] << 32) | ((u64)(u32)(int)S.fslot[bn][i] << 48);
-            else { S.fkey[bn][i] = ~0ull; pay[i] = 0; }
+            if(i < nNew) {
+                pay[i] = ((u64)(u32)(int)S.fslot[bn][i] << 36) | (enc(S.fD[bn][i]) << 24) | (enc(S.fG[bn][i]) << 12) | enc(S.fS[bn][i]);
+                if constexpr (C::IN_MEMORY) keys[i] = S.fkey[bn][i];
+            } else { keys[i] = ~0ull; pay[i] = 0; }
         }
         WSYNC();
         for(int k = 2; k <= Pn; k <<= 1)
@@ -843,18 +886,21 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 for(int idx = gl; idx < (Pn >> 1); idx += GW) {
                     const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1)), l = i | j;
                     const bool up = (i & k) == 0;
-                    const u64 ka = S.fkey[bn][i], kb = S.fkey[bn][l];
-                    if((ka > kb) == up) { const u64 pa = pay[i], pb = pay[l]; S.fkey[bn][i] = kb; S.fkey[bn][l] = ka; pay[i] = pb; pay[l] = pa; }
+                    const u64 ka = keys[i], kb = keys[l];
+                    if((ka > kb) == up) { const u64 pa = pay[i], pb = pay[l]; keys[i] = kb; keys[l] = ka; pay[i] = pb; pay[l] = pa; }
                 }
                 WSYNC();
             }
         for(int i = gl; i < Pn; i += GW) {
             const u64 pv = pay[i];
-            if(i < nNew) { S.fD[bn][i] = (short)(pv & 0xFFFF); S.fG[bn][i] = (short)((pv >> 16) & 0xFFFF); S.fS[bn][i] = (short)((pv >> 32) & 0xFFFF); S.fslot[bn][i] = (typename C::Slot)(int)(pv >> 48); }
-            pay[i] = 0;
+            if(i < nNew) {
+                S.fD[bn][i] = dec((pv >> 24) & 0xFFF); S.fG[bn][i] = dec((pv >> 12) & 0xFFF); S.fS[bn][i] = dec(pv & 0xFFF); S.fslot[bn][i] = (typename C::Slot)(int)(pv >> 36);
+                if constexpr (C::IN_MEMORY) S.fkey[bn][i] = keys[i];
+            }
+            if constexpr (!C::IN_MEMORY) pay[i] = 0;
         }
     }
-    WSYNC();
+    DSYNC();
     if(gl == 0) {
         st.b2 = b1; st.b1 = bn; st.bn = b2;                                                   // m2 := m1; m1 := this, :1104-1105
         st.n2 = n1; st.n1 = nNew;
@@ -866,7 +912,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         if(slow) S.pfSlow++; S.pfImp += S.nImp; if(prepass) S.pfPre++; if(nT > S.pfMaxNT) S.pfMaxNT = nT; if(nNew > S.pfMaxF) S.pfMaxF = nNew;
 #endif
     }
-    WSYNC();
+    DSYNC();
     DP_TQ(2);
     return PH_RUN;
 }
@@ -919,7 +965,7 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
                 if(tie) { const int pos = nt + __popcll(m & ((1ull << gl) - 1ull)); sl.tie_slot()[pos] = s; sl.tie_key()[pos] = kk; }
                 nt += __popcll(m);
             }
-            WSYNC();
+            DSYNC();
             u64 prefix = 0; int k = selectedIndex;
             for(int bit = 51; bit >= 0; bit--) {
                 int cnt = 0;
@@ -942,7 +988,7 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
         else { st.sb = yEnd; st.se = start_seq - 1; }
         S.btSlot = endSlot; S.btM = 0; S.btX = key_x(ek); S.btY = yEnd; S.btGuard = 0; S.btDone = 0; S.nNew = 0; S.nKeepF = 0;
     }
-    WSYNC();
+    DSYNC();
     return PH_BT;
 }
 
@@ -985,7 +1031,7 @@ __device__ inline int dp_backtrace(DpLdsT<C>& S, const DpSlabT<C>& sl, int maxSt
         }
         S.btDone = done;
     }
-    WSYNC();
+    DSYNC();
     if(guni<GW>(S.btDone)) return guni<GW>(st.err) ? PH_DONE : PH_EXPAND;
     return PH_BT;
 }
@@ -1004,10 +1050,10 @@ __device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
     const int max_seqI = guni<GW>(st.seqLen);
     const int sb = guni<GW>(st.sb), se = guni<GW>(st.se);
     const uint8_t* seqp = B.read_bases + guni<GW>(st.rOff);
-    if(nCols > stride) { if(gl == 0) st.err = -1000000 - nCols; WSYNC(); return PH_DONE; }
-    if(sb > se) { if(gl == 0) { st.err = __LINE__; st.have = 0; } WSYNC(); return PH_DONE; }
+    if(nCols > stride) { if(gl == 0) st.err = -1000000 - nCols; DSYNC(); return PH_DONE; }
+    if(sb > se) { if(gl == 0) { st.err = __LINE__; st.have = 0; } DSYNC(); return PH_DONE; }
     if(gl == 0) st.have = 1;
-    WSYNC();
+    DSYNC();
     const int c = guni<GW>(st.item) >> 1;
     const int rowOff = fwd ? stride - nCols : sb;
     if(rowOff + nCols > stride) return PH_DONE;             // the stitched chain cannot fit the row: k_stitch_chains reports the column error
@@ -1162,11 +1208,18 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
     // graph / batch descriptors stay in memory (scalar loads on demand): passing them by value costs ~150 SGPRs
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
-    __shared__ DpLdsT<C> SS[NG];
     const int gl = grp_lane<GW>();
     const int g = (int)((threadIdx.x & 63) / GW);
-    DpLdsT<C>& S = SS[g];
-    DpSlabT<C> sl; sl.base = slabs + ((size_t)blockIdx.x * NG + g) * slabBytes;
+    DpLdsT<C>* Sp; DpSlabT<C> sl; u64* sortScratch = nullptr;
+    if constexpr (C::IN_MEMORY) {
+        __shared__ u64 scratch[2 * DP_SORT_SCRATCH];
+        char* base = slabs + (size_t)blockIdx.x * slabBytes;          // [ structure | scratch slab ]
+        Sp = (DpLdsT<C>*)base; sl.base = base + ((sizeof(DpLdsT<C>) + 255) & ~(size_t)255); sortScratch = scratch;
+    } else {
+        __shared__ DpLdsT<C> SS[NG];
+        Sp = &SS[g]; sl.base = slabs + ((size_t)blockIdx.x * NG + g) * slabBytes;
+    }
+    DpLdsT<C>& S = *Sp;
     const uint8_t* readBases = readBasesArg;
 
     if(gl == 0) { S.accCalls = 0; S.accIters = 0; S.accCells = 0; S.accEdges = 0; }
@@ -1182,7 +1235,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
 
     for(int dirPass = 0; dirPass < 2; dirPass++) {
         // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
-        // retry list of tier k = 1..5 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
+        // retry list of tier k = 1..6 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
         int* fetchCounter = &B.work_counter[TIER == 0 ? (dirPass ? 10 : 1) : 13 + 4 * (TIER - 1) + 2 * dirPass];
         const int nItems = uni(B.work_counter[TIER == 0 ? 8 + dirPass : 12 + 4 * (TIER - 1) + 2 * dirPass]);
         const int listBase = (TIER == 0 && dirPass) ? B.n_chains : 0;
@@ -1196,7 +1249,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
         // backtrace (up to DP_BT_STEPS_PER_TRIP pointers), expansion, bookkeeping and the next item -- so that a group spends its trips
         // iterating, not changing state (the states used to be visited in the opposite order: one state change per trip).
         for(;;) {
-            if(phase == PH_RUN) phase = dp_iterate<C>(S, sl, G, fwd ? nrecOut : nrecIn, readBases, fwd, edgesAcc);
+            if(phase == PH_RUN) phase = dp_iterate<C>(S, sl, G, fwd ? nrecOut : nrecIn, readBases, fwd, edgesAcc, sortScratch);
             DP_T(5);
             if(phase == PH_SELECT) phase = dp_select<C>(S, sl, G, rng_seed, fwd);
             DP_T(4);
@@ -1246,7 +1299,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
                         }
                     }
                 }
-                WSYNC();
+                DSYNC();
                 phase = guni<GW>(S.nextPhase);
             }
             DP_T(1);

@@ -273,9 +273,9 @@ typedef struct {
     int32_t n_dp_retried_large;   /* DP calls that also outgrew the 64-lane small class                  */
     int64_t n_dp_shared;          /* of n_dp_calls: calls that start from the same cell of the same read as the call of an earlier chain
                                      and took their iterations from it (own end-cell choice, backtrace and columns)                  */
-    int32_t n_dp_class[6];        /* DP calls that entered the 16-lane / 32-lane / 64-lane / wide / broad / large-capacity class (a call that outgrows
-                                     a class enters a later one as well)                                                               */
-    float   ms_dp_class[6];       /* time of the DP kernel of each class (HIP events on the ctx stream)                              */
+    int32_t n_dp_class[7];        /* DP calls that entered the 16-lane / 32-lane / 64-lane / wide / broad / large / in-memory class (a call that
+                                     outgrows a class enters a later one as well)                                                               */
+    float   ms_dp_class[7];       /* time of the DP kernel of each class (HIP events on the ctx stream)                              */
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 

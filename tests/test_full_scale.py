@@ -38,13 +38,13 @@ def test_one_million_pairs_keep_the_reference_invariants(pkg, oracle):
     ctx = pkg.Context(w["graph"], w["contigs"], **kw)
     gb = ctx.batch(b); gb.align()
     st = gb.stats()
-    assert st.n_errors <= 64, st.n_errors                      # capacity of the largest DP class (frontier > 1024 cells): flagged, never silent
+    assert st.n_errors == 0, st.n_errors
     assert all(int(x) > 0 for x in st.n_dp_class)
     pk = gb.pairs_packed()
     sc = gb.pairs_scalars()
     off = pk["col_off"]; T = pk["n_cols_total"]
     ok_pair = sc["pair_status"] == 0
-    assert ok_pair.sum() >= N_PAIRS - 64 and T > 300 * N_PAIRS
+    assert ok_pair.all() and T > 300 * N_PAIRS
     ok_read = np.repeat(ok_pair, 2)
     ncols = np.diff(off)
     assert np.all(ncols[ok_read] >= 150) and np.all(ncols[~ok_read] == 0)
@@ -96,3 +96,31 @@ def test_one_million_pairs_keep_the_reference_invariants(pkg, oracle):
             assert n == got["n_cols"][r - r0] and np.array_equal(lv[off[r]:off[r] + n], got["col_level"][(r - r0) * 384:(r - r0) * 384 + n])
         assert np.array_equal(sc["best_chain"][r0:r1], got["best_chain"] + c0) and np.array_equal(sc["pair_ll"][start:start + 300], got["pair_ll"])
         gs.close()
+
+
+def test_densest_pairs_go_through_the_in_memory_class(pkg, oracle):
+    """About 30 DP calls per million gene-window pairs outgrow every LDS class (frontiers of 1100-3200 cells, up to 58 000 kept cells and
+    13 000 tied sequence-complete cells; measured with the oracle's per-call maxima): they run in the in-memory backstop class.  Pairs known
+    to hold such calls (found once with tools/dp_errors.py while that class did not exist yet) against the oracle, bit for bit."""
+    from hla_la_amd import dist as D
+    w = synth.make_world_m(seed=2)
+    b = synth.make_batch_m(w, 262144, seed=77, frac_gene=1.0)
+    kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], max_columns=384)
+    ctx = pkg.Context(w["graph"], w["contigs"], rng_seed=12345, **kw)
+    n_mem = 0
+    for p in (13255, 133574, 155918, 252296):
+        sub, p0, c0 = D.shard_pairs_range(b, p, p + 1)
+        o = oracle(w["graph"], w["contigs"], rng_seed=(12345 + 2 * c0) & 0xFFFFFFFF, **kw)
+        exp = o.align_batch(sub)
+        gs = ctx.batch(sub); gs.set_first_chain(c0); gs.align()
+        st = gs.stats()
+        assert st.n_errors == 0
+        n_mem += int(st.n_dp_class[6])
+        from util import compare_chains
+        compare_chains(gs.chains(1), exp["ext"], sub["n_chains"], label=f"pair {p}")
+        got = gs.pairs(); ep = exp["pairs"]
+        for k in ("pair_status", "best_chain", "n_combinations", "n_cols", "col_level", "col_edge", "col_gchar", "col_schar", "col_mapq"):
+            assert np.array_equal(got[k], ep[k]), (p, k)
+        assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
+        gs.close()
+    assert n_mem >= 3, n_mem

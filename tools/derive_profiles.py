@@ -12,7 +12,7 @@ import collections, csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.getcwd())
 import bench  # noqa: E402
 
-NAMES = (("DpTiny", "k_dp<DpTiny, 0>"), ("DpMid", "k_dp<DpMid, 1>"), ("DpSmall", "k_dp<DpSmall, 2>"), ("DpWide", "k_dp<DpWide, 3>"), ("DpBroad", "k_dp<DpBroad, 4>"), ("DpLarge", "k_dp<DpLarge, 5>"),
+NAMES = (("DpTiny", "k_dp<DpTiny, 0>"), ("DpMid", "k_dp<DpMid, 1>"), ("DpSmall", "k_dp<DpSmall, 2>"), ("DpWide", "k_dp<DpWide, 3>"), ("DpBroad", "k_dp<DpBroad, 4>"), ("DpLarge", "k_dp<DpLarge, 5>"), ("DpHuge", "k_dp<DpHuge, 6>"),
          ("k_stitch", "k_stitch_chains"), ("k_project", "k_project_chains"), ("k_pair_chains", "k_pair_chains"), ("k_dp_items", "k_dp_items"), ("k_filter", "k_filter_chains"))
 
 
