@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1_048_576, help="read pairs per GPU per step (BASELINE config 2: 1M)")
     ap.add_argument("--levels", type=int, default=5_000_000, help="levels of the synthetic MHC-scale stand-in graph")
     ap.add_argument("--graph", choices=["m", "simple"], default="m")
-    ap.add_argument("--cpu-pairs", type=int, default=2048, help="pairs of the same workload timed on the CPU oracle (1 thread; 4x as many on all cores)")
+    ap.add_argument("--cpu-pairs", type=int, default=16384, help="pairs of the same workload timed on the CPU oracle (1 thread; 4x as many on all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region (host-inclusive, gene / backbone split, streaming, typer)")
     ap.add_argument("--stream-batches", type=int, default=6, help="batches pushed through two contexts / streams for the pipelined host-inclusive rate (0 = skip)")

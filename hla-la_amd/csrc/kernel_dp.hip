@@ -44,24 +44,24 @@ constexpr u64 HKEY_EMPTY = ~0ull;
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows per trip of the persistent loop (measured: 3 -> 236 ms, 6 -> 231, 12 -> 226, 24 -> 225, 64 -> 224 per 524 k pairs)
 
-struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr int BLOOM = 512; static constexpr bool IN_MEMORY = false; };
-struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 1024; static constexpr bool IN_MEMORY = false; };
-struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 4096; static constexpr bool IN_MEMORY = false; };
+struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
 // but a quarter of its LDS, so that five of them share a CU instead of one
-struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 16384; static constexpr bool IN_MEMORY = false; };
+struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 257 .. 512 cells with the table sizes of the large class (tens of thousands of kept cells): half the LDS of the large class, two per CU
-struct DpBroad { static constexpr int WAVES = 1, GW = 64, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 16384; static constexpr bool IN_MEMORY = false; };
+struct DpBroad { static constexpr int WAVES = 1, GW = 64, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and
 //  thousands of sequence-complete cells per DP were measured -- are what the large class is sized for; its table slots are ints)
-struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 65536; static constexpr bool IN_MEMORY = false; };
+struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 
 // The backstop: everything the other classes keep in LDS -- target table, frontiers, DP state -- lives in the block's HBM slab, so the capacities are
 // set by memory, not by the 160 KB of a CU (frontiers of 3000+ cells, 60 000 kept cells and 15 000 tied complete cells per DP occur on the densest
 // levels of the Graph M workload: about 30 DP calls per million pairs).  Same code (one template): the structure reference simply points into
 // the slab, the wave fences become agent-scope fences (plain loads must not hit stale L1 lines of words the atomics changed in L2), and the
 // frontier sort borrows the otherwise unused LDS.  An order of magnitude slower per cell than the LDS classes; nothing is dropped.
-struct DpHuge  { static constexpr int WAVES = 1, GW = 64, WCAP = 8192, HC = 16384, IBITS = 13, CELLS = 131072, EARLY = 131072, IMPCAP = 8192, COMPLETED = 65536, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr int BLOOM = 65536; static constexpr bool IN_MEMORY = true; };
+struct DpHuge  { static constexpr int WAVES = 1, GW = 64, WCAP = 8192, HC = 16384, IBITS = 13, CELLS = 131072, EARLY = 131072, IMPCAP = 8192, COMPLETED = 65536, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = true; };
 constexpr int DP_SORT_SCRATCH = 8192;       // (key, payload) pairs of the in-memory class's frontier sort, in LDS: 128 KB
 
 // State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
@@ -92,7 +92,6 @@ struct __align__(16) DpLdsT {
     typename C::Slot tes[C::HC];    // per target: existing / assigned table slot (-1 = none)
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     typename C::ImpIdx hq[C::HC];   // per hash entry: index of the improvement its cell staged this iteration (all ones = none)
-    u32 bloom[C::BLOOM / 32];       // Bloom filter (two bits per key) over the early cells registered in the slab hash: most lookups never leave LDS
     int nNew, nImp, nKeepF, err, nCompletedAdd;
     int nextPhase;                                    // state after PH_DONE: idle, or the end-cell choice of a linked duplicate
     int btSlot, btM, btX, btY, btGuard, btDone;       // back-pointer chase in progress (lane 0 of the group)
@@ -320,21 +319,13 @@ __device__ inline u32 dp_probe(DpLdsT<C>& S, u64 key, u32 h)
     return (u32)C::HC;
 }
 
-template <class C> __device__ __forceinline__ bool bloom_maybe(const DpLdsT<C>& S, u64 key)
-{
-    const u32 hm = hash_mix(key), a = hm & (u32)(C::BLOOM - 1), b = (hm >> 16) & (u32)(C::BLOOM - 1);
-    return ((S.bloom[a >> 5] >> (a & 31)) & (S.bloom[b >> 5] >> (b & 31)) & 1u) != 0;
-}
-template <class C> __device__ __forceinline__ void bloom_set(DpLdsT<C>& S, u64 key)
-{
-    const u32 hm = hash_mix(key), a = hm & (u32)(C::BLOOM - 1), b = (hm >> 16) & (u32)(C::BLOOM - 1);
-    atomicOr(&S.bloom[a >> 5], 1u << (a & 31)); atomicOr(&S.bloom[b >> 5], 1u << (b & 31));
-}
+// (the two smallest classes keep the cheap hash for their slab tables of at most 4096 / 8192 entries: the multiplies cost them 2 % of their time)
+template <class C> __device__ __forceinline__ u32 early_hash(u64 k) { return (C::EARLY > 8192 ? hash_mix(k) : hash64(k)) & (u32)(C::EARLY - 1); }
 
 template <class C>
 __device__ inline int early_lookup(const DpSlabT<C>& sl, u64 key)
 {
-    u32 h = hash_mix(key) & (C::EARLY - 1);
+    u32 h = early_hash<C>(key);
     for(int probe = 0; probe < C::EARLY; probe++) {
         // entries are published with L2 atomics: read them past the CU's L1
         u64 cur = __hip_atomic_load(&sl.early_key()[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -347,7 +338,7 @@ __device__ inline int early_lookup(const DpSlabT<C>& sl, u64 key)
 template <class C>
 __device__ inline bool early_insert(const DpSlabT<C>& sl, u64 key, int slot)
 {
-    u32 h = hash_mix(key) & (C::EARLY - 1);
+    u32 h = early_hash<C>(key);
     for(int probe = 0; probe < C::EARLY; probe++) {
         u64 old = atomicCAS(&sl.early_key()[h], HKEY_EMPTY, key);
         if(old == HKEY_EMPTY || old == key) { __hip_atomic_store(&sl.early_val()[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
@@ -619,10 +610,9 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     // Cells reached through a gap-path jump arrive EARLIER than their natural diagonal |dx|+|dy| and can be reached again later ("scores"
     // merge, :951-979): they are registered with the DP's cell hash in the slab (HBM).  Every target of iteration d has a natural diagonal
     // >= d -- a cell created on its natural diagonal is never met again -- so a target can only meet an early cell while d <= the largest
-    // natural diagonal of the early cells created so far: in those iterations every kept target is looked up.  A Bloom filter over the
-    // registered cells sits in LDS: a target it does not know is new without a trip to the slab (on allele-rich, gap-rich levels the early
-    // lineage lives on for hundreds of iterations, and the lookups -- then one global compare-and-swap per kept target and iteration -- were
-    // most of the time of the wide and large classes).  tes[t] = table slot of an existing cell, or -1.
+    // natural diagonal of the early cells created so far: in those iterations every kept target is looked up (a probing read), and only cells
+    // that are early themselves are inserted.  tes[t] = table slot of an existing cell, or -1.  (Tried: a Bloom filter in LDS in front of
+    // the look-ups -- no gain on Graph M, a loss on gap-heavy small graphs whose filter saturates.)
     const bool prepass = earlyInit && d <= earlyMaxNat0;
     int earlyNatMax = -1;         // per lane: largest natural diagonal of the early cells this iteration creates
     if(prepass) {
@@ -631,7 +621,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             if(t < nT) {
                 int h = S.tlist[t];
                 int Dv = max(best_score(S.hbest[M_D][h]), max(best_score(S.hbest[M_GG][h]), best_score(S.hbest[M_SG][h])));
-                if(Dv >= -16) { const u64 key = S.hkey[h]; if(bloom_maybe<C>(S, key)) es = early_lookup<C>(sl, key); }
+                if(Dv >= -16) es = early_lookup<C>(sl, S.hkey[h]);
                 S.tes[t] = (typename C::Slot)es;
             }
             if(grp_ballot<GW>(es >= 0)) anyExisting = true;
@@ -711,14 +701,13 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 int natural = (x > startLevel ? x - startLevel : startLevel - x) + (y > start_seq ? y - start_seq : start_seq - y);
                 bool isEarly = isNew && natural > d;
                 if(isEarly && natural > earlyNatMax) earlyNatMax = natural;
-                if(grp_ballot<GW>(isEarly)) {                    // early cells: into the slab hash and the Bloom filter
+                if(grp_ballot<GW>(isEarly)) {                    // early cells: into the slab hash
                     if(!earlyInit) {
                         for(int i = gl; i < C::EARLY; i += GW) sl.early_key()[i] = HKEY_EMPTY;
-                        for(int i = gl; i < C::BLOOM / 32; i += GW) S.bloom[i] = 0;
                         earlyInit = 1;
                         DSYNC();
                     }
-                    if(isEarly) { if(!early_insert<C>(sl, key, slot)) S.err = __LINE__; bloom_set<C>(S, key); }
+                    if(isEarly) if(!early_insert<C>(sl, key, slot)) S.err = __LINE__;
                 }
                 if(isNew && y == limitY) {                                                     // :982-999
                     int pos = atomicAdd(&S.nCompletedAdd, 1);
@@ -849,8 +838,10 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     }
     if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; st.needTier = tier_for_frontier(nNew); } DSYNC(); return PH_DONE; }
     DSYNC();
-    // reset the hash entries used by this iteration (the survivors live in the frontier buffer now)
-    for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
+    // reset the hash entries used by this iteration (the survivors live in the frontier buffer now).  A wide frontier's sort borrows the hash's
+    // value array, so it resets first; the narrow case keeps the reset at the end of the iteration, off the path to the sorted frontier
+    const bool wideSort = C::WCAP > GW && nNew > GW;
+    if(wideSort) for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
     // ... then put into std::map order (x, y, z) = key order
     if(nNew > 1 && nNew <= GW) {
         // every survivor counts the smaller keys among them (= its rank) and the buffer is rewritten in rank order
@@ -862,7 +853,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         }
         DSYNC();
         if(act) { S.fkey[bn][rank] = key; S.fslot[bn][rank] = vs; S.fD[bn][rank] = vD; S.fG[bn][rank] = vG; S.fS[bn][rank] = vS; }
-    } else if(C::WCAP > GW && nNew > GW) {
+    } else if(wideSort) {
         // frontier wider than the group (allele-rich levels: hundreds of cells): bitonic sort of (key, packed payload) pairs in LDS.  The LDS
         // classes sort the frontier buffer in place and borrow the hash's third value array, idle (all zero) between iterations, for the payload;
         // the in-memory class sorts in the block's scratch.  (The rank of every survivor used to be counted against all targets: quadratic,
@@ -901,6 +892,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         }
     }
     DSYNC();
+    if(!wideSort) for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
     if(gl == 0) {
         st.b2 = b1; st.b1 = bn; st.bn = b2;                                                   // m2 := m1; m1 := this, :1104-1105
         st.n2 = n1; st.n1 = nNew;
@@ -915,6 +907,35 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     DSYNC();
     DP_TQ(2);
     return PH_RUN;
+}
+
+// many ties (allele-rich levels: thousands of sequence-complete cells): every tie gets a number whose order is the string order (xz_key), the
+// ties are compacted into the slab, and the selectedIndex-th smallest number is found bit by bit.  Register-hungry: only the classes that can hold thousands of complete
+// cells (frontier > 64) carry it; in the 16- / 32- / 64-lane kernels it cost 8 more spilled VGPRs in the persistent loop (+16 % kernel time).
+template <class C>
+__device__ inline int dp_select_many(const DpSlabT<C>& sl, const DevGraph& G, int nCompleted, int best, int selectedIndex)
+{
+    constexpr int GW = C::GW;
+    const int gl = grp_lane<GW>();
+    int found = -1;
+    int nt = 0;
+    for(int i0 = 0; i0 < nCompleted; i0 += GW) {
+        int i = i0 + gl; bool tie = false; int s = 0; u64 kk = 0;
+        if(i < nCompleted) { s = sl.completed()[i]; if(sl.cell()[s].sc[0] == best) { tie = true; u64 k = sl.cell()[s].key; kk = xz_key(key_x(k), key_node(k) - G.level_off[key_x(k)]); } }
+        const u64 m = grp_ballot<GW>(tie);
+        if(tie) { const int pos = nt + __popcll(m & ((1ull << gl) - 1ull)); sl.tie_slot()[pos] = s; sl.tie_key()[pos] = kk; }
+        nt += __popcll(m);
+    }
+    dp_sync<C>();
+    u64 prefix = 0; int k = selectedIndex;
+    for(int bit = 51; bit >= 0; bit--) {
+        int cnt = 0;
+        for(int i = gl; i < nt; i += GW) { const u64 kk = sl.tie_key()[i]; if((kk >> (bit + 1)) == (prefix >> (bit + 1)) && !((kk >> bit) & 1ull)) cnt++; }
+        cnt = grp_sum_i32<GW>(cnt);
+        if(k >= cnt) { k -= cnt; prefix |= 1ull << bit; }
+    }
+    for(int i = gl; i < nt; i += GW) if(sl.tie_key()[i] == prefix) found = sl.tie_slot()[i];
+    return found;
 }
 
 // ---- end cell, :1381-1517
@@ -938,7 +959,7 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
         int selectedIndex = glibc_rand_r(&sd) % nTies;                                      // Utilities.cpp:922-927
         // the tie with exactly `selectedIndex` ties before it in "x/z" string order
         int found = -1;
-        if(nTies <= 2 * GW) {
+        if(C::WCAP <= 64 || nTies <= 2 * GW) {
             for(int i0 = 0; i0 < nCompleted; i0 += GW) {
                 int i = i0 + gl;
                 if(i < nCompleted) {
@@ -954,27 +975,7 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
                     }
                 }
             }
-        } else {
-            // many ties (allele-rich levels: thousands of sequence-complete cells): every tie gets a number whose order is the string
-            // order (xz_key), the ties are compacted into the slab, and the selectedIndex-th smallest number is found bit by bit
-            int nt = 0;
-            for(int i0 = 0; i0 < nCompleted; i0 += GW) {
-                int i = i0 + gl; bool tie = false; int s = 0; u64 kk = 0;
-                if(i < nCompleted) { s = sl.completed()[i]; if(sl.cell()[s].sc[0] == best) { tie = true; u64 k = sl.cell()[s].key; kk = xz_key(key_x(k), key_node(k) - G.level_off[key_x(k)]); } }
-                const u64 m = grp_ballot<GW>(tie);
-                if(tie) { const int pos = nt + __popcll(m & ((1ull << gl) - 1ull)); sl.tie_slot()[pos] = s; sl.tie_key()[pos] = kk; }
-                nt += __popcll(m);
-            }
-            DSYNC();
-            u64 prefix = 0; int k = selectedIndex;
-            for(int bit = 51; bit >= 0; bit--) {
-                int cnt = 0;
-                for(int i = gl; i < nt; i += GW) { const u64 kk = sl.tie_key()[i]; if((kk >> (bit + 1)) == (prefix >> (bit + 1)) && !((kk >> bit) & 1ull)) cnt++; }
-                cnt = grp_sum_i32<GW>(cnt);
-                if(k >= cnt) { k -= cnt; prefix |= 1ull << bit; }
-            }
-            for(int i = gl; i < nt; i += GW) if(sl.tie_key()[i] == prefix) found = sl.tie_slot()[i];
-        }
+        } else if constexpr (C::WCAP > 64) found = dp_select_many<C>(sl, G, nCompleted, best, selectedIndex);
         endSlot = grp_max_i32<GW>(found); endScore = best;
     } else if(curMax > 0) {
         endSlot = firstMaxSlot; endScore = sl.cell()[firstMaxSlot].sc[0];
