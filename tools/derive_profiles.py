@@ -25,7 +25,8 @@ def label(k):
 
 def counters(d):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); launches = collections.defaultdict(set)
-    for f in glob.glob(os.path.join("gpurun_out", d, "*", "*counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join("gpurun_out", d, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:            # (gpurun merges into gpurun_out/: keep the newest pass only)
         for r in csv.DictReader(open(f)):
             n = label(r["Kernel_Name"])
             if n:
@@ -34,7 +35,7 @@ def counters(d):
 
 
 os.makedirs("profiles", exist_ok=True)
-st = glob.glob("gpurun_out/r02_stats/*/*kernel_stats.csv")[0]
+st = sorted(glob.glob("gpurun_out/r02_stats/*/*kernel_stats.csv"), key=os.path.getmtime)[-1]
 shutil.copy(st, "profiles/r02_kernel_stats_1Mpairs.csv")
 avg_ms = {}
 for r in csv.DictReader(open(st)):
