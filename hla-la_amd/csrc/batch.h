@@ -66,6 +66,8 @@ struct DevBatch {
     int* work_counter;              // [48] dynamic work distribution: [0] stage A, [2] stage C, [7] chains stitched, [8]/[9] left / right DP items,
                                     //      [1]/[10] left / right items fetched, [12..35] retry lists (count, fetched) per tier 1..6 and direction
     int* retry_list;                // [12*n_chains] DP items that outgrew a capacity class: (tier 1..6) x (left, right) x n_chains
+    uint8_t* pair_deferred;         // [n_pairs] 1: a DP call of the pair went to the in-memory class; with the fused entry point its chains are stitched and
+                                    //           the pair is scored in a second pass, after that class (which runs on a side stream next to the first pass)
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
     int* dbg;                       // non-null with HLALA_DEBUG=1: kernels add phase clocks to counters[16..31]
 };

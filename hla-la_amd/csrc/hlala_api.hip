@@ -37,6 +37,8 @@ struct DevBuf {
 struct hlala_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;   // the in-memory DP class of the fused entry point runs here, next to the first stitch / pairing pass on `stream`
+    hipEvent_t evSide[4]{};       // large class done (main) / in-memory class start, end (side)
     hlala_params params{};
     FlatGraph F;
     DevGraph G{};
@@ -70,6 +72,8 @@ struct hlala_batch {
     DevBatch* dB = nullptr;       // device copy of B
     std::vector<void*> allocs;
     int staged = 0;   // bit0 seeds available, bit1 extended, bit2 paired
+    bool side_used = false;      // the last extend of this batch ran the in-memory class on the side stream (its time is between evSide[1] and [2])
+    bool side_pending = false;   // the fused entry point left the in-memory class running on the side stream: the second pass is still to come
     uint32_t first_chain = 0;    // absolute index of the batch's chain 0 in the caller's numbering (hlala_batch_set_first_chain): offsets the random seeds
     float ms[3] = {0, 0, 0};
 };
@@ -336,6 +340,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->allocs.push_back(c->proj_slabs);
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
     for(int i = 0; i < 14; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    for(int i = 0; i < 4; i++) if(hipEventCreate(&c->evSide[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    if(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;
@@ -349,6 +355,8 @@ void hlala_destroy(hlala_ctx* c)
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(auto& kv : c->pool) (void)hipFree(kv.second);
     for(int i = 0; i < 14; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for(int i = 0; i < 4; i++) if(c->evSide[i]) (void)hipEventDestroy(c->evSide[i]);
+    if(c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     delete c;
 }
 
@@ -406,7 +414,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
-    AL(counters, 32, true); AL(work_counter, 48, true); AL(retry_list, 12 * nc, false);
+    AL(pair_deferred, np, true); AL(counters, 32, true); AL(work_counter, 48, true); AL(retry_list, 12 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
     B.dbg = c->dbg_host;
 #undef AL
@@ -554,12 +562,19 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     return HLALA_OK;
 }
 
-int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
+static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused);
+int hlala_extend_chains(hlala_ctx* c, hlala_batch* b) { return extend_impl(c, b, false); }
+
+// fused = called from hlala_align_batch on a paired batch: the in-memory class runs on the side stream while the chains and pairs it does not
+// concern are stitched and scored on the main stream; pair_impl then waits for it and finishes the deferred pairs
+static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
 {
     DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
+    if(B.unpaired || B.from_seeds || B.n_pairs <= 0) fused = false;
+    if(B.n_pairs > 0) HIP_TRY(c, hipMemsetAsync(B.pair_deferred, 0, (size_t)B.n_pairs, c->stream));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, 41 * sizeof(int), c->stream));
     if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
@@ -591,14 +606,19 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b)
             hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
             rc_ = check_launch(c, "k_dp<large>"); if(rc_) return rc_;
             if(first) HIP_TRY(c, hipEventRecord(c->ev[13], c->stream));
-            hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-            return check_launch(c, "k_dp<huge>");
+            hipStream_t hs = c->stream;
+            if(fused) { HIP_TRY(c, hipEventRecord(c->evSide[0], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->side, c->evSide[0], 0)); hs = c->side; HIP_TRY(c, hipEventRecord(c->evSide[1], c->side)); }
+            hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(64), 0, hs, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+            rc_ = check_launch(c, "k_dp<huge>"); if(rc_) return rc_;
+            if(fused) HIP_TRY(c, hipEventRecord(c->evSide[2], c->side));
+            return 0;
         };
         rc = run_classes(true); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[8], c->stream));
         int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
-        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);
+        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)(fused ? B.pair_deferred : nullptr));
         rc = check_launch(c, "k_stitch_chains"); if(rc) return rc;
+        b->side_pending = fused; b->side_used = fused;
     }
     HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
     b->staged |= 2;
@@ -612,13 +632,28 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage C not available"; return HLALA_E_STATE; }
     if(!(b->staged & 2)) { c->err = "hlala_pair_chains before hlala_extend_chains"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
+    const bool fused = b->side_pending;
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
-    if(B.n_pairs > 0) {
+    auto launch_pair = [&](int mode) -> int {
         int grid = B.n_pairs < c->pair_grid ? B.n_pairs : c->pair_grid;
-        if(B.unpaired) hipLaunchKernelGGL((k_pair_chains<true>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);
-        else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB);
-        int rc = check_launch(c, "k_pair_chains"); if(rc) return rc;
+        if(B.unpaired) hipLaunchKernelGGL((k_pair_chains<true>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode);
+        else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode);
+        return check_launch(c, "k_pair_chains");
+    };
+    if(B.n_pairs > 0) {
+        int rc = launch_pair(fused ? 1 : 0); if(rc) return rc;
+        if(fused) {
+            // second pass: the in-memory class has finished on the side stream; stitch the chains it left pending, score their pairs
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSide[2], 0));
+            HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, sizeof(int), c->stream));
+            HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->stream));
+            int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
+            hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)nullptr);
+            rc = check_launch(c, "k_stitch_chains (second pass)"); if(rc) return rc;
+            rc = launch_pair(2); if(rc) return rc;
+            b->side_pending = false;
+        }
     }
     HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
     b->staged |= 4;
@@ -628,7 +663,7 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
 int hlala_align_batch(hlala_ctx* c, hlala_batch* b)
 {
     int rc = hlala_project_chains(c, b); if(rc) return rc;
-    rc = hlala_extend_chains(c, b); if(rc) return rc;
+    rc = extend_impl(c, b, true); if(rc) return rc;
     return hlala_pair_chains(c, b);
 }
 
@@ -880,7 +915,8 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
     if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]);
           (void)hipEventElapsedTime(&out->ms_dp_class[0], c->ev[7], c->ev[6]); (void)hipEventElapsedTime(&out->ms_dp_class[1], c->ev[6], c->ev[9]);
-          (void)hipEventElapsedTime(&out->ms_dp_class[2], c->ev[9], c->ev[10]); (void)hipEventElapsedTime(&out->ms_dp_class[3], c->ev[10], c->ev[11]); (void)hipEventElapsedTime(&out->ms_dp_class[4], c->ev[11], c->ev[12]); (void)hipEventElapsedTime(&out->ms_dp_class[5], c->ev[12], c->ev[13]); (void)hipEventElapsedTime(&out->ms_dp_class[6], c->ev[13], c->ev[8]); } }
+          (void)hipEventElapsedTime(&out->ms_dp_class[2], c->ev[9], c->ev[10]); (void)hipEventElapsedTime(&out->ms_dp_class[3], c->ev[10], c->ev[11]); (void)hipEventElapsedTime(&out->ms_dp_class[4], c->ev[11], c->ev[12]); (void)hipEventElapsedTime(&out->ms_dp_class[5], c->ev[12], c->ev[13]);
+          if(b->side_used) (void)hipEventElapsedTime(&out->ms_dp_class[6], c->evSide[1], c->evSide[2]); else (void)hipEventElapsedTime(&out->ms_dp_class[6], c->ev[13], c->ev[8]); } }
     { int wc[48]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
       out->n_dp_class[0] = wc[8] + wc[9]; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);

@@ -1280,6 +1280,8 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
                         // (a linked duplicate whose own backtrace outgrew the class takes over the item entry: the DP that ran is done with it)
                         if(st.isAlias) ((int*)(items + st.itemIdx))[0] = st.item;
                         int q = atomicAdd(cnt, 1); lst[q] = st.itemIdx;
+                        // (all chains that share this DP belong to one read: its pair waits for the in-memory class)
+                        if(to == DP_LAST_TIER && B.n_pairs > 0 && !B.unpaired) B.pair_deferred[B.chain_read[st.item >> 1] >> 1] = 1;
                     } else {
                         const int item = st.item;
                         B.dp_iters[item] = st.itersRun; B.dp_score[item] = st.have ? st.endScore : INT32_MIN;
@@ -1339,7 +1341,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
 // ------------------------------------------------------------------------------------------
 // one wave per chain: stitch left extension + seed + right extension (extendWithOtherSeedChain /
 // extendToFullSequenceLength, verboseSeedChain.cpp:23-136), then scoreOneAlignment (extensionAligner.cpp:52-182).
-__global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp)
+__global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp, const uint8_t* __restrict__ deferPairs)
 {
     const DevBatch& B = *Bp;
     const DevTables& T = *Tp;
@@ -1362,7 +1364,8 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
         const int cEnd = min(c0 + CHUNK, B.n_chains);
         for(int c = c0; c < cEnd; c++) {
         ST_T(0);
-        if(uni(B.ext_status[c]) == EXT_PENDING) {
+        // (first pass of the fused entry point: chains of a pair with a DP call still running in the in-memory class stay pending)
+        if(uni(B.ext_status[c]) == EXT_PENDING && !(deferPairs && uni(deferPairs[uni(B.chain_read[c]) >> 1]))) {
         const int r = uni(B.chain_read[c]);
         const int rOff = uni(B.read_off[r]), seqLen = uni(B.read_off[r + 1]) - rOff;
         const size_t cb = (size_t)c * stride;

@@ -102,7 +102,8 @@ __global__ void k_pair_distances(const DevGraph* __restrict__ Gp, const DevBatch
 // UNPAIRED: one read per unit (processBAM::alignOneLongRead :3618-3838 selects the first maximum of the chains' log likelihoods;
 // assignMappingQualities_unpaired :3900-4059 is the paired computation with a single, neutral second mate).
 template <bool UNPAIRED>
-__global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp)
+__global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
+                                                   const uint8_t* __restrict__ deferPairs, const int deferMode)      // deferMode 1: skip deferred pairs, 2: only those
 {
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
         if(p0 >= B.n_pairs) break;
         const int pEnd = min(p0 + CHUNK, B.n_pairs);
         for(int p = p0; p < pEnd; p++) {
+        if(deferMode) { const bool df = uni(deferPairs[p]) != 0; if(df == (deferMode == 1)) continue; }
         // ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains), error propagation
         int bad = 0;
         constexpr int NM = UNPAIRED ? 1 : 2;
