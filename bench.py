@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--graph", choices=["m", "simple"], default="m")
     ap.add_argument("--cpu-pairs", type=int, default=16384, help="pairs of the same workload timed on the CPU oracle (1 thread; 4x as many on all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="two batches alternate, but each step's export follows its alignment at once (a batch's tail does not run beside the next batch)")
+    ap.add_argument("--single-batch", action="store_true", help="one resident batch, steps strictly one after the other (no overlap of a batch's tail with the next batch)")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region (host-inclusive, gene / backbone split, streaming, typer)")
     ap.add_argument("--stream-batches", type=int, default=6, help="batches pushed through two contexts / streams for the pipelined host-inclusive rate (0 = skip)")
     args = ap.parse_args()
@@ -138,27 +140,41 @@ def main():
     ckw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=12345, max_columns=384, device=local_rank)
     ctx = P.Context(w["graph"], w["contigs"], stream=stream, **ckw)
     gb = ctx.batch(b)            # inputs resident in HBM from here on
-    rec = torch.empty((args.pairs, 8), dtype=torch.float64, device="cuda")
+    # A sample is a stream of batches (BASELINE config 3): two batch objects of this workload alternate, as in the host program.  A step = one batch
+    # through the whole path and its record export (+ the gather to rank 0); the export of step i is issued after the alignment of step i+1, so the
+    # side-stream tail of one batch (the wide DP classes, include/hlala_gpu.h: hlala_align_batch) runs beside the bulk of the next.  K alignments and
+    # K exports lie between the two synchronisations.  --single-batch keeps one batch and no overlap between steps.
+    gbs = [gb] if args.single_batch else [gb, ctx.batch(mk(args.pairs, 5000 + rank))]
+    recs = [torch.empty((args.pairs, 8), dtype=torch.float64, device="cuda") for _ in gbs]
+    rec = recs[0]
     gathered = [torch.empty_like(rec) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    def step():
-        gb.align()
-        gb.export_pair_records(rec.data_ptr())
+    def finish(k):
+        gbs[k].export_pair_records(recs[k].data_ptr())
         if world > 1:
             if backend == "nccl":
-                dist.gather(rec, gathered, dst=0)          # RCCL over xGMI: the one exchange of the path
+                dist.gather(recs[k], gathered, dst=0)          # RCCL over xGMI: the one exchange of the path
             else:
-                dist.gather(rec.cpu(), [g.cpu() for g in gathered] if gathered is not None else None, dst=0)
+                dist.gather(recs[k].cpu(), [g.cpu() for g in gathered] if gathered is not None else None, dst=0)
 
-    for _ in range(args.warmup):
-        step()
+    def run(n):
+        for i in range(n):
+            k = i % len(gbs)
+            gbs[k].align()
+            if len(gbs) == 1 or args.no_overlap:
+                finish(k)
+            elif i > 0:
+                finish((i - 1) % len(gbs))
+        if len(gbs) > 1 and n > 0 and not args.no_overlap:
+            finish((n - 1) % len(gbs))
+
+    run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -206,11 +222,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": desc, "graph": args.graph, "pairs_per_gpu": args.pairs, "graph_levels": args.levels, "graph_nodes": int(g["n_nodes"]), "graph_edges": int(g["n_edges"]),
-                       "parallelism": f"shard{world}", "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
+                       "parallelism": f"shard{world}", "batches_in_flight": len(gbs), "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
                        "columns_per_chain": cols_pc, "mean_out_degree": e_mean,
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
                        "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
-                       "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "pair": st.ms_pair,
+                       "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "pair": st.ms_pair, "side_stream": st.ms_side,
                                     "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6]},
                        "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6]},
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},

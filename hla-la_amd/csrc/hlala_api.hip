@@ -37,8 +37,12 @@ struct DevBuf {
 struct hlala_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;   // the in-memory DP class of the fused entry point runs here, next to the first stitch / pairing pass on `stream`
-    hipEvent_t evSide[4]{};       // large class done (main) / in-memory class start, end (side)
+    // hlala_align_batch (fused, paired batches) runs the DP classes from DP_SIDE_TIER on -- few, long DP calls that leave most of the chip idle --
+    // on this second, low-priority stream, then the second stitch / pairing pass over the pairs that waited for them; the main stream goes on with the
+    // pairs they do not concern and, when the caller has more than one batch in flight, with the next batch
+    hipStream_t side = nullptr;
+    hipEvent_t evSide[8]{};       // [0] fork point on the main stream; [1] first side-stream class starts; [6] second pairing pass done
+    hipEvent_t evC[7][2]{};       // start / end of each DP class on the stream it ran on
     hlala_params params{};
     FlatGraph F;
     DevGraph G{};
@@ -56,7 +60,7 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
-    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
+    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
     hipEvent_t ev[14]{};          // start/end per stage; [7] / [6] / [9] / [10] / [11] / [12] / [13] / [8] = before DpTiny / after DpTiny / DpMid / DpSmall / DpWide / DpBroad / DpLarge / DpHuge
@@ -72,8 +76,10 @@ struct hlala_batch {
     DevBatch* dB = nullptr;       // device copy of B
     std::vector<void*> allocs;
     int staged = 0;   // bit0 seeds available, bit1 extended, bit2 paired
-    bool side_used = false;      // the last extend of this batch ran the in-memory class on the side stream (its time is between evSide[1] and [2])
-    bool side_pending = false;   // the fused entry point left the in-memory class running on the side stream: the second pass is still to come
+    bool side_used = false;      // the last extend of this batch ran its wide classes on the side stream (their times are between the evSide events)
+    bool side_pending = false;   // ... and hlala_pair_chains has yet to enqueue the second pairing pass behind them
+    bool side_inflight = false;  // work of this batch may still be running on the side stream: evDone orders everything that touches the batch after it
+    hipEvent_t evDone = nullptr;
     uint32_t first_chain = 0;    // absolute index of the batch's chain 0 in the caller's numbering (hlala_batch_set_first_chain): offsets the random seeds
     float ms[3] = {0, 0, 0};
 };
@@ -320,7 +326,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->stitch_grid = cus * 32;
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>();
     c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / two blocks per CU: a few MB each
-    if(hipMalloc((void**)&c->large_slabs, c->large_slab_bytes * (size_t)c->broad_grid) != hipSuccess) { c->err = "hipMalloc(large-class DP slabs) failed"; return fail(HLALA_E_DEVICE); }
+    if(hipMalloc((void**)&c->large_slabs, c->large_slab_bytes * (size_t)(c->broad_grid + c->retry_grid)) != hipSuccess) { c->err = "hipMalloc(large-class DP slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->large_slabs);
     c->huge_grid = cus / 4 > 0 ? cus / 4 : 1;      // the in-memory backstop class: a handful of DP calls per million pairs
     c->huge_slab_bytes = dp_inmemory_bytes<DpHuge>();
@@ -328,6 +334,9 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->allocs.push_back(c->huge_slabs);
     if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->ext_slabs);
+    // (the wide class may run on the side stream while the 32- / 64-lane classes of the next batch use the pool above: slabs of its own)
+    if(hipMalloc((void**)&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid) != hipSuccess) { c->err = "hipMalloc(wide-class slabs) failed"; return fail(HLALA_E_DEVICE); }
+    c->allocs.push_back(c->wide_slabs);
     c->proj_grid = cus * 9; c->pair_grid = cus * 14;
     if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
         c->proj_grid = cus * 4;
@@ -340,8 +349,10 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->allocs.push_back(c->proj_slabs);
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
     for(int i = 0; i < 14; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
-    for(int i = 0; i < 4; i++) if(hipEventCreate(&c->evSide[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
-    if(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); }
+    for(int i = 0; i < 8; i++) if(hipEventCreate(&c->evSide[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    for(int i = 0; i < 14; i++) if(hipEventCreate(&c->evC[i / 2][i % 2]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    { int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);       // (numerically greatest = lowest priority)
+      if(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prLow) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); } }
     if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;
@@ -355,7 +366,8 @@ void hlala_destroy(hlala_ctx* c)
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(auto& kv : c->pool) (void)hipFree(kv.second);
     for(int i = 0; i < 14; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for(int i = 0; i < 4; i++) if(c->evSide[i]) (void)hipEventDestroy(c->evSide[i]);
+    for(int i = 0; i < 8; i++) if(c->evSide[i]) (void)hipEventDestroy(c->evSide[i]);
+    for(int i = 0; i < 14; i++) if(c->evC[i / 2][i % 2]) (void)hipEventDestroy(c->evC[i / 2][i % 2]);
     if(c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     delete c;
 }
@@ -523,10 +535,19 @@ void hlala_batch_destroy(hlala_batch* b)
     DEV_GUARD(c);
     if(c) {
         c->batches.erase(b);
+        if(b->side_inflight) (void)hipEventSynchronize(b->evDone);
         (void)hipStreamSynchronize(c->stream);       // nothing of this batch may still be running when its buffers are handed to the next one
         for(void* p : b->allocs) pool_release(c, p);
     } else for(void* p : b->allocs) if(p) (void)hipFree(p);
+    if(b->evDone) (void)hipEventDestroy(b->evDone);
     delete b;
+}
+
+// everything that reads or rewrites a batch goes behind the side-stream work of its last fused alignment
+static int join_side(hlala_ctx* c, hlala_batch* b)
+{
+    if(b->side_inflight) { HIP_TRY(c, hipStreamWaitEvent(c->stream, b->evDone, 0)); b->side_inflight = false; }
+    return HLALA_OK;
 }
 
 static int check_launch(hlala_ctx* c, const char* what)
@@ -540,6 +561,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
 {
     DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
+    { int rj = join_side(c, b); if(rj) return rj; }
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 48 * sizeof(int), c->stream));
@@ -565,15 +587,19 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
 static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused);
 int hlala_extend_chains(hlala_ctx* c, hlala_batch* b) { return extend_impl(c, b, false); }
 
-// fused = called from hlala_align_batch on a paired batch: the in-memory class runs on the side stream while the chains and pairs it does not
-// concern are stitched and scored on the main stream; pair_impl then waits for it and finishes the deferred pairs
+// fused = called from hlala_align_batch on a paired batch.  The 16- / 32- / 64-lane classes hold all but a few percent of the DP calls; the rest (wide,
+// broad, large, in-memory) are few, long calls that cannot fill the chip.  Fused, they run on the side stream, followed there by a second stitch /
+// pairing pass over the pairs that own them (pair_deferred, set by the DP kernels when they hand an item to one of these classes), while the main
+// stream stitches and pairs everything else and is then free for the caller's next batch.  b->evDone orders later users of the batch behind the side work.
 static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
 {
     DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
+    { int rj = join_side(c, b); if(rj) return rj; }
     DevBatch& B = b->B;
-    if(B.unpaired || B.from_seeds || B.n_pairs <= 0) fused = false;
+    if(B.unpaired || B.from_seeds || B.n_pairs <= 0 || B.n_chains <= 0) fused = false;
+    b->side_used = false; b->side_pending = false;
     if(B.n_pairs > 0) HIP_TRY(c, hipMemsetAsync(B.pair_deferred, 0, (size_t)B.n_pairs, c->stream));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, 41 * sizeof(int), c->stream));
@@ -581,44 +607,54 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if(B.n_chains > 0) {
         DpItem* items = (DpItem*)B.dp_items;
+        const u32 seed = c->params.rng_seed + 2u * b->first_chain;
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_head, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->stream));       // -1: k_dp_items links the duplicates of a DP to it
         hipLaunchKernelGGL(k_dp_items, dim3((B.n_chains + 255) / 256), dim3(256), 0, c->stream, c->dG, b->dB, items);
         int rc = check_launch(c, "k_dp_items"); if(rc) return rc;
         // every DP item first runs in the 16-lane class; the item count lives on the device, idle groups leave at once.
-        // Items that outgrew it: two DPs per wave, then one wave per DP, then the large-capacity class (one block per CU).
-        auto run_classes = [&](bool first) -> int {
-            if(first) HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
-            hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-            int rc_ = check_launch(c, "k_dp<tiny>"); if(rc_) return rc_;
-            if(first) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
-            hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-            rc_ = check_launch(c, "k_dp<mid>"); if(rc_) return rc_;
-            if(first) HIP_TRY(c, hipEventRecord(c->ev[9], c->stream));
-            hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-            rc_ = check_launch(c, "k_dp<small>"); if(rc_) return rc_;
-            if(first) HIP_TRY(c, hipEventRecord(c->ev[10], c->stream));
-            hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-            rc_ = check_launch(c, "k_dp<wide>"); if(rc_) return rc_;
-            if(first) HIP_TRY(c, hipEventRecord(c->ev[11], c->stream));
-            hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-            rc_ = check_launch(c, "k_dp<broad>"); if(rc_) return rc_;
-            if(first) HIP_TRY(c, hipEventRecord(c->ev[12], c->stream));
-            hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(64), 0, c->stream, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-            rc_ = check_launch(c, "k_dp<large>"); if(rc_) return rc_;
-            if(first) HIP_TRY(c, hipEventRecord(c->ev[13], c->stream));
-            hipStream_t hs = c->stream;
-            if(fused) { HIP_TRY(c, hipEventRecord(c->evSide[0], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->side, c->evSide[0], 0)); hs = c->side; HIP_TRY(c, hipEventRecord(c->evSide[1], c->side)); }
-            hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(64), 0, hs, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, c->params.rng_seed + 2u * b->first_chain, c->G.nrec_out, c->G.nrec_in, B.read_bases);
-            rc_ = check_launch(c, "k_dp<huge>"); if(rc_) return rc_;
-            if(fused) HIP_TRY(c, hipEventRecord(c->evSide[2], c->side));
+        // Items that outgrew it: two DPs per wave, then one wave per DP, then the classes with wider frontiers (fewer blocks per CU).
+        // Each class is timed with its own pair of events on the stream it runs on (evC); ev[7] / ev[6] / ev[10] keep marking the start of the 16-lane
+        // class, its end and the end of the 64-lane class on the main stream.
+        hipStream_t ws = c->stream;
+        auto run_class = [&](int tier) -> int {
+            if(fused && tier == DP_SIDE_TIER) {
+                if(!b->evDone) HIP_TRY(c, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming));
+                HIP_TRY(c, hipEventRecord(c->evSide[0], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->side, c->evSide[0], 0));
+                ws = c->side;
+                HIP_TRY(c, hipEventRecord(c->evSide[1], c->side));
+            }
+            HIP_TRY(c, hipEventRecord(c->evC[tier][0], ws));
+            switch(tier) {
+            case 0: hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 2: hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 3: hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->wide_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 4: hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 5: hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->large_slabs + c->large_slab_bytes * (size_t)c->broad_grid, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            default: hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            }
+            int rc_ = check_launch(c, "k_dp"); if(rc_) return rc_;
+            HIP_TRY(c, hipEventRecord(c->evC[tier][1], ws));
             return 0;
         };
-        rc = run_classes(true); if(rc) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev[8], c->stream));
-        int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
-        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)(fused ? B.pair_deferred : nullptr));
+        HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
+        rc = run_class(0); if(rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+        for(int tier = 1; tier <= DP_LAST_TIER; tier++) {
+            rc = run_class(tier); if(rc) return rc;
+            if(tier == 2) HIP_TRY(c, hipEventRecord(c->ev[10], c->stream));
+        }
+        if(!fused) HIP_TRY(c, hipEventRecord(c->ev[8], c->stream));
+        const int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
+        if(fused) {
+            // second pass (side): the chains of the deferred pairs, work counter 36; first pass (main): all the others, work counter 7
+            hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->side, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, 2, 36);
+            rc = check_launch(c, "k_stitch_chains (side)"); if(rc) return rc;
+            HIP_TRY(c, hipEventRecord(b->evDone, c->side));
+            b->side_inflight = true; b->side_used = true; b->side_pending = true;
+        }
+        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, fused ? 1 : 0, 7);
         rc = check_launch(c, "k_stitch_chains"); if(rc) return rc;
-        b->side_pending = fused; b->side_used = fused;
     }
     HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
     b->staged |= 2;
@@ -633,26 +669,23 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
     if(!(b->staged & 2)) { c->err = "hlala_pair_chains before hlala_extend_chains"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
     const bool fused = b->side_pending;
+    if(!fused) { int rj = join_side(c, b); if(rj) return rj; }
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
-    auto launch_pair = [&](int mode) -> int {
-        int grid = B.n_pairs < c->pair_grid ? B.n_pairs : c->pair_grid;
-        if(B.unpaired) hipLaunchKernelGGL((k_pair_chains<true>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode);
-        else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode);
-        return check_launch(c, "k_pair_chains");
-    };
     if(B.n_pairs > 0) {
-        int rc = launch_pair(fused ? 1 : 0); if(rc) return rc;
+        const int grid = B.n_pairs < c->pair_grid ? B.n_pairs : c->pair_grid;
+        auto launch_pair = [&](hipStream_t st, int mode, int counterIdx) -> int {
+            if(B.unpaired) hipLaunchKernelGGL((k_pair_chains<true>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx);
+            else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx);
+            return check_launch(c, "k_pair_chains");
+        };
+        int rc = launch_pair(c->stream, fused ? 1 : 0, 2); if(rc) return rc;
         if(fused) {
-            // second pass: the in-memory class has finished on the side stream; stitch the chains it left pending, score their pairs
-            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSide[2], 0));
-            HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, sizeof(int), c->stream));
-            HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->stream));
-            int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
-            hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)nullptr);
-            rc = check_launch(c, "k_stitch_chains (second pass)"); if(rc) return rc;
-            rc = launch_pair(2); if(rc) return rc;
-            b->side_pending = false;
+            // second pass, behind the side-stream classes and the second stitch pass: the deferred pairs (work counter 37)
+            rc = launch_pair(c->side, 2, 37); if(rc) return rc;
+            HIP_TRY(c, hipEventRecord(c->evSide[6], c->side));
+            HIP_TRY(c, hipEventRecord(b->evDone, c->side));
+            b->side_inflight = true; b->side_pending = false;
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
@@ -670,6 +703,7 @@ int hlala_align_batch(hlala_ctx* c, hlala_batch* b)
 int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains_out* o)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b || !o) return HLALA_E_ARG;
     DevBatch& B = b->B;
     size_t nc = (size_t)B.n_chains, cs = nc * (size_t)B.stride;
@@ -703,6 +737,7 @@ int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains
 int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b || !o) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -747,6 +782,7 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
 int hlala_batch_get_pairs_packed(hlala_ctx* c, hlala_batch* b, hlala_pairs_packed_out* o)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b || !o || !o->col_off) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -858,6 +894,7 @@ int hlala_set_gene_intervals(hlala_ctx* c, int32_t n, const int32_t* first_level
 int hlala_postprocess_pairs(hlala_ctx* c, hlala_batch* b, uint8_t* include_in_hla)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "hlala_postprocess_pairs before hlala_pair_chains"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -895,6 +932,7 @@ int hlala_get_coverage(hlala_ctx* c, int32_t* bases_per_level, int reset)
 int hlala_batch_export_pair_records(hlala_ctx* c, hlala_batch* b, double* device_out)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b || !device_out) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     if(b->B.n_pairs > 0) {
@@ -907,16 +945,16 @@ int hlala_batch_export_pair_records(hlala_ctx* c, hlala_batch* b, double* device
 int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b || !out) return HLALA_E_ARG;
     memset(out, 0, sizeof(*out));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     u64 cnt[16];
     HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
-    if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]);
-          (void)hipEventElapsedTime(&out->ms_dp_class[0], c->ev[7], c->ev[6]); (void)hipEventElapsedTime(&out->ms_dp_class[1], c->ev[6], c->ev[9]);
-          (void)hipEventElapsedTime(&out->ms_dp_class[2], c->ev[9], c->ev[10]); (void)hipEventElapsedTime(&out->ms_dp_class[3], c->ev[10], c->ev[11]); (void)hipEventElapsedTime(&out->ms_dp_class[4], c->ev[11], c->ev[12]); (void)hipEventElapsedTime(&out->ms_dp_class[5], c->ev[12], c->ev[13]);
-          if(b->side_used) (void)hipEventElapsedTime(&out->ms_dp_class[6], c->evSide[1], c->evSide[2]); else (void)hipEventElapsedTime(&out->ms_dp_class[6], c->ev[13], c->ev[8]); } }
+    if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], b->side_used ? c->ev[10] : c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]);
+          for(int k = 0; k <= DP_LAST_TIER; k++) (void)hipEventElapsedTime(&out->ms_dp_class[k], c->evC[k][0], c->evC[k][1]);
+          if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, c->evSide[1], c->evSide[6]); } }
     { int wc[48]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
       out->n_dp_class[0] = wc[8] + wc[9]; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
@@ -1041,6 +1079,7 @@ extern "C" int hlala_debug_buffer(hlala_ctx* c, int* out8192, int clear)
 extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long long* out32)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b) return HLALA_E_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(out32, b->B.counters, 32 * sizeof(u64), hipMemcpyDeviceToHost));
@@ -1120,6 +1159,7 @@ extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, c
 extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_locus_desc* L, hlala_exon_positions_out* o)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b || !L || !o) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "hlala_exon_positions before hlala_pair_chains"; return HLALA_E_STATE; }
     if(L->level_max < L->level_min || !L->level_to_exon) { c->err = "locus: empty level range or no level_to_exon table"; return HLALA_E_ARG; }
@@ -1180,6 +1220,7 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
 extern "C" int hlala_unit_alignment_stats(hlala_ctx* c, hlala_batch* b, hlala_unit_stats_out* o)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b || !o || !o->valid || !o->strands_valid || !o->distance || !o->fraction_ok || !o->weighted_ok || !o->n_columns || !o->mate_mapq) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "hlala_unit_alignment_stats before hlala_pair_chains"; return HLALA_E_STATE; }
     const size_t n = (size_t)b->B.n_pairs;
@@ -1200,6 +1241,7 @@ extern "C" int hlala_unit_alignment_stats(hlala_ctx* c, hlala_batch* b, hlala_un
 extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present)
 {
     DEV_GUARD(c);
+    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
     if(!c || !b || n_queries < 0 || (n_queries > 0 && (!queries || !present))) return HLALA_E_ARG;
     if(k < 1 || k > 31) { c->err = "hlala_kmer_presence: k must be in 1..31 (2-bit codes in one 64-bit word)"; return HLALA_E_ARG; }
     if(n_queries == 0) return HLALA_OK;

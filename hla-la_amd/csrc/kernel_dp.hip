@@ -382,8 +382,15 @@ __device__ inline u64 xz_key(int x, int z)
 // one DP item as prepared by k_dp_items (32 bytes)
 struct __align__(16) DpItem { int item, rOff, seqLen, start_seq, startLevel, startNode, pad0, pad1; };
 
-// first tier (1 = DpMid, 2 = DpSmall, 3 = DpLarge) whose class holds a frontier of n cells / a target set of n cells
+// The fused entry point runs the classes from this tier on on its side stream (hlala_api.hip: extend_impl).  Measured on Graph M, 1M pairs per batch
+// (tools/gpu_side_ab.sh), two batches in flight / one batch at a time: tier 3: 369 / 406 ms per batch, 4: 360 / 393, 5: 366 / 391, 6: 372 / 379;
+// the same two batches without any overlap between them: 400.
+#ifndef HLALA_DP_SIDE_TIER
+#define HLALA_DP_SIDE_TIER 4
+#endif
+constexpr int DP_SIDE_TIER = HLALA_DP_SIDE_TIER;
 constexpr int DP_LAST_TIER = 6;      // tiers: 0 DpTiny, 1 DpMid, 2 DpSmall, 3 DpWide, 4 DpBroad, 5 DpLarge, 6 DpHuge
+// first tier whose class holds a frontier of n cells / a target set of n cells
 __device__ __forceinline__ int tier_for_frontier(int n) { return n <= DpMid::WCAP ? 1 : (n <= DpSmall::WCAP ? 2 : (n <= DpWide::WCAP ? 3 : (n <= DpBroad::WCAP ? 4 : (n <= DpLarge::WCAP ? 5 : 6)))); }
 __device__ __forceinline__ int tier_for_targets(int n) { return n <= (DpMid::HC * 3) / 4 ? 1 : (n <= (DpSmall::HC * 3) / 4 ? 2 : (n <= (DpWide::HC * 3) / 4 ? 3 : (n <= (DpBroad::HC * 3) / 4 ? 4 : (n <= (DpLarge::HC * 3) / 4 ? 5 : 6)))); }
 
@@ -1280,8 +1287,8 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
                         // (a linked duplicate whose own backtrace outgrew the class takes over the item entry: the DP that ran is done with it)
                         if(st.isAlias) ((int*)(items + st.itemIdx))[0] = st.item;
                         int q = atomicAdd(cnt, 1); lst[q] = st.itemIdx;
-                        // (all chains that share this DP belong to one read: its pair waits for the in-memory class)
-                        if(to == DP_LAST_TIER && B.n_pairs > 0 && !B.unpaired) B.pair_deferred[B.chain_read[st.item >> 1] >> 1] = 1;
+                        // (all chains that share this DP belong to one read: its pair waits for the side-stream classes)
+                        if(to >= DP_SIDE_TIER && B.n_pairs > 0 && !B.unpaired) B.pair_deferred[B.chain_read[st.item >> 1] >> 1] = 1;
                     } else {
                         const int item = st.item;
                         B.dp_iters[item] = st.itersRun; B.dp_score[item] = st.have ? st.endScore : INT32_MIN;
@@ -1341,7 +1348,8 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
 // ------------------------------------------------------------------------------------------
 // one wave per chain: stitch left extension + seed + right extension (extendWithOtherSeedChain /
 // extendToFullSequenceLength, verboseSeedChain.cpp:23-136), then scoreOneAlignment (extensionAligner.cpp:52-182).
-__global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp, const uint8_t* __restrict__ deferPairs)
+__global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
+                                                        const uint8_t* __restrict__ deferPairs, const int deferMode, const int counterIdx)      // deferMode 1: skip the chains of deferred pairs, 2: only those
 {
     const DevBatch& B = *Bp;
     const DevTables& T = *Tp;
@@ -1358,14 +1366,17 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
 #endif
     for(;;) {
         int c0 = 0;
-        if(lane == 0) c0 = atomicAdd(&B.work_counter[7], CHUNK);
+        if(lane == 0) c0 = atomicAdd(&B.work_counter[counterIdx], CHUNK);
         c0 = __builtin_amdgcn_readfirstlane(c0);
         if(c0 >= B.n_chains) break;
         const int cEnd = min(c0 + CHUNK, B.n_chains);
         for(int c = c0; c < cEnd; c++) {
         ST_T(0);
-        // (first pass of the fused entry point: chains of a pair with a DP call still running in the in-memory class stay pending)
-        if(uni(B.ext_status[c]) == EXT_PENDING && !(deferPairs && uni(deferPairs[uni(B.chain_read[c]) >> 1]))) {
+        // (fused entry point: the chains of a pair with a DP call in one of the side-stream classes stay pending in the first pass; the second
+        // pass, which may run beside the first one, takes exactly those)
+        bool mine = uni(B.ext_status[c]) == EXT_PENDING;
+        if(mine && deferMode) { const bool df = uni(deferPairs[uni(B.chain_read[c]) >> 1]) != 0; mine = df == (deferMode == 2); }
+        if(mine) {
         const int r = uni(B.chain_read[c]);
         const int rOff = uni(B.read_off[r]), seqLen = uni(B.read_off[r + 1]) - rOff;
         const size_t cb = (size_t)c * stride;

@@ -103,7 +103,7 @@ __global__ void k_pair_distances(const DevGraph* __restrict__ Gp, const DevBatch
 // assignMappingQualities_unpaired :3900-4059 is the paired computation with a single, neutral second mate).
 template <bool UNPAIRED>
 __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
-                                                   const uint8_t* __restrict__ deferPairs, const int deferMode)      // deferMode 1: skip deferred pairs, 2: only those
+                                                   const uint8_t* __restrict__ deferPairs, const int deferMode, const int counterIdx)      // deferMode 1: skip deferred pairs, 2: only those
 {
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
     constexpr int CHUNK = 8;
     for(;;) {
         int p0 = 0;
-        if(lane == 0) p0 = atomicAdd(&B.work_counter[2], CHUNK);
+        if(lane == 0) p0 = atomicAdd(&B.work_counter[counterIdx], CHUNK);
         p0 = __builtin_amdgcn_readfirstlane(p0);
         if(p0 >= B.n_pairs) break;
         const int pEnd = min(p0 + CHUNK, B.n_pairs);

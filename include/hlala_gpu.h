@@ -224,7 +224,12 @@ int  hlala_extend_chains(hlala_ctx* ctx, hlala_batch* b);
 /* Stage C -- the pairing loop of processBAM::alignOneReadPair (mapper/processBAM.cpp:3408-3546)
  * and processBAM::assignMappingQualities (:4062-4312).                                       */
 int  hlala_pair_chains(hlala_ctx* ctx, hlala_batch* b);
-/* A + B + C: processBAM::alignOneReadPair (mapper/processBAM.cpp:3129-3616) over the batch.   */
+/* A + B + C: processBAM::alignOneReadPair (mapper/processBAM.cpp:3129-3616) over the batch.
+ * Asynchronous like the stage calls.  On a paired batch the few percent of DP calls with wide frontiers (allele-rich gene levels) and the
+ * pairs that own them finish on a second stream of the context, beside the rest of the batch; every later call that touches THIS batch
+ * (getters, statistics, post-processing, the next alignment of it, its destruction) is ordered behind that work.  A caller with several
+ * batches can therefore keep two in flight -- align A, align B, fetch A, align C, fetch B, ... -- and have the long tail of one batch
+ * run beside the bulk of the next; same results as one batch at a time.                                                     */
 int  hlala_align_batch(hlala_ctx* ctx, hlala_batch* b);
 
 /* Download results (synchronises the stream).  `stage` 0 = seed chains after stage A,
@@ -256,7 +261,8 @@ int  hlala_batch_get_pairs_packed(hlala_ctx* ctx, hlala_batch* b, hlala_pairs_pa
 int  hlala_batch_export_pair_records(hlala_ctx* ctx, hlala_batch* b, double* device_out);
 
 /* Per-stage statistics of the last hlala_align_batch / stage call on this batch, measured
- * with HIP events on the ctx stream (ms) plus work counters reduced on the device.          */
+ * with HIP events (ms) plus work counters reduced on the device.  The events belong to the context: with several
+ * batches in flight the times are those of the stages launched last.                         */
 typedef struct {
     float   ms_project, ms_extend, ms_pair;
     int64_t n_chains_extended;    /* chains with status OK                        */
@@ -275,7 +281,10 @@ typedef struct {
                                      and took their iterations from it (own end-cell choice, backtrace and columns)                  */
     int32_t n_dp_class[7];        /* DP calls that entered the 16-lane / 32-lane / 64-lane / wide / broad / large / in-memory class (a call that
                                      outgrows a class enters a later one as well)                                                               */
-    float   ms_dp_class[7];       /* time of the DP kernel of each class (HIP events on the ctx stream)                              */
+    float   ms_dp_class[7];       /* time of the DP kernel of each class (HIP events on the stream the kernel ran on)                */
+    float   ms_side;              /* hlala_align_batch on a paired batch: span of the work it put on its second stream (wide / broad / large / in-memory
+                                     class, second stitch and pairing pass over the pairs that own those calls), which runs beside the rest of the
+                                     batch and beside the caller's next batch; 0 when the stages were called one by one                          */
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 

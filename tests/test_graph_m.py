@@ -189,3 +189,31 @@ def test_mixed_reads_match_oracle(pkg, oracle, world_m):
     gene = b["read_window"] >= 0
     assert truth_accuracy(b, got, 384, gene) >= 0.99 and truth_accuracy(b, got, 384, ~gene) >= 0.99
 
+
+
+@pytest.mark.gpu
+def test_two_batches_in_flight_equal_one_at_a_time(pkg, oracle):
+    """hlala_align_batch finishes the wide DP classes and the pairs that own them on the context's second stream; a caller may align the next batch
+    before fetching the previous one (include/hlala_gpu.h).  Dense windows, so that a good part of the pairs takes that path: every array of both
+    batches equals the one-at-a-time result (itself compared with the oracle), whatever the order of the calls, and again when the batches are re-aligned."""
+    w = synth.make_world_m(seed=8, n_levels=60_000, n_windows=3, alleles=(4000, 5000))
+    bs = [synth.make_batch_m(w, 1200, seed=31, frac_gene=1.0), synth.make_batch_m(w, 900, seed=32, frac_gene=0.6)]
+    kw = dict(insert_mean=bs[0]["insert_mean"], insert_sd=bs[0]["insert_sd"], rng_seed=99, max_columns=384)
+    ref = []
+    for b in bs:
+        got, st, exp = gpu_vs_oracle(pkg, oracle, w, b)
+        assert sum(list(st.n_dp_class)[4:]) > 0 and st.ms_side > 0
+        ref.append(got)
+    ctx = pkg.Context(w["graph"], w["contigs"], **kw)
+    gbs = [ctx.batch(b) for b in bs]
+    for rnd in range(3):
+        gbs[0].align(); gbs[1].align()                 # B's bulk runs beside A's tail
+        order = (1, 0) if rnd == 1 else (0, 1)
+        for k in order:
+            got = gbs[k].pairs()
+            for name, v in ref[k].items():
+                assert np.array_equal(got[name], v), (rnd, k, name)
+            assert gbs[k].stats().n_errors == 0
+        if rnd == 1:
+            gbs[0].align()                             # re-align a batch whose previous tail may still be running
+            assert all(np.array_equal(gbs[0].pairs()[name], v) for name, v in ref[0].items())
