@@ -322,7 +322,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();      // 2 * mid_grid mid slabs fit the pool of ext_grid small slabs
     c->retry_grid = cus;
     c->broad_grid = cus * 2;         // two DpBroad blocks per CU, slabs of the large layout
-    c->wide_grid = cus * 5;          // LDS: five DpWide blocks per CU; their slabs come from the pool of the 64-lane class (same layout)
+    c->wide_grid = cus * 6;          // LDS: six DpWide blocks per CU (26 KB each); slabs of the 64-lane layout, in a pool of their own
     c->stitch_grid = cus * 32;
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>();
     c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / two blocks per CU: a few MB each

@@ -49,12 +49,12 @@ struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,
 struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
 // but a quarter of its LDS, so that five of them share a CU instead of one
-struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u64 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 257 .. 512 cells with the table sizes of the large class (tens of thousands of kept cells): half the LDS of the large class, two per CU
-struct DpBroad { static constexpr int WAVES = 1, GW = 64, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpBroad { static constexpr int WAVES = 1, GW = 64, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and
 //  thousands of sequence-complete cells per DP were measured -- are what the large class is sized for; its table slots are ints)
-struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 
 // The backstop: everything the other classes keep in LDS -- target table, frontiers, DP state -- lives in the block's HBM slab, so the capacities are
 // set by memory, not by the 160 KB of a CU (frontiers of 3000+ cells, 60 000 kept cells and 15 000 tied complete cells per DP occur on the densest
@@ -283,13 +283,16 @@ __device__ __forceinline__ int bt_kind(u32 b) { return (int)((b >> 19) & 7); }
 __device__ __forceinline__ int bt_edge(u32 b) { return (int)((b >> 22) & 0xFF); }
 
 
-// candidate value: (score, reversed push index) so that an unsigned max = highest score, earliest push
-__device__ __forceinline__ void pack_best(u32& o, int score, int order) { o = ((u32)(score + 64) << 16) | (u32)(0xFFFF - order); }
-__device__ __forceinline__ void pack_best(u64& o, int score, int order) { o = ((u64)(u32)(score + 64) << 32) | (u64)(u32)(0x7FFFFFFF - order); }
-__device__ __forceinline__ int best_score(u32 b) { return b ? (int)(b >> 16) - 64 : DP_NEG; }
-__device__ __forceinline__ int best_score(u64 b) { return b ? (int)(b >> 32) - 64 : DP_NEG; }
-__device__ __forceinline__ int best_order(u32 b) { return 0xFFFF - (int)(b & 0xFFFF); }
-__device__ __forceinline__ int best_order(u64 b) { return 0x7FFFFFFF - (int)(b & 0xFFFFFFFFull); }
+// candidate value: (score, reversed push index) so that an unsigned max = highest score, earliest push.  The push index has IBITS + 9 bits (frontier
+// entry, phase, edge / jump); every LDS class packs it with the score (+64: < 2^13 for reads up to DP_SEQCAP) into 32 bits -- half the LDS of the
+// value arrays and 32-bit ds_max for the wide classes, which used to carry 64-bit values --, the in-memory class keeps 64.
+template <class C> struct BestBits { static constexpr int OB = (C::IBITS + 9 <= 16) ? 16 : C::IBITS + 9; static_assert(sizeof(typename C::Best) == 8 || OB <= 19, "score field too narrow"); };
+template <class C> __device__ __forceinline__ void pack_best(u32& o, int score, int order) { constexpr int OB = BestBits<C>::OB; o = ((u32)(score + 64) << OB) | (u32)(((1 << OB) - 1) - order); }
+template <class C> __device__ __forceinline__ void pack_best(u64& o, int score, int order) { o = ((u64)(u32)(score + 64) << 32) | (u64)(u32)(0x7FFFFFFF - order); }
+template <class C> __device__ __forceinline__ int best_score(u32 b) { return b ? (int)(b >> BestBits<C>::OB) - 64 : DP_NEG; }
+template <class C> __device__ __forceinline__ int best_score(u64 b) { return b ? (int)(b >> 32) - 64 : DP_NEG; }
+template <class C> __device__ __forceinline__ int best_order(u32 b) { constexpr int OB = BestBits<C>::OB; return ((1 << OB) - 1) - (int)(b & (u32)((1 << OB) - 1)); }
+template <class C> __device__ __forceinline__ int best_order(u64 b) { return 0x7FFFFFFF - (int)(b & 0xFFFFFFFFull); }
 
 // push one candidate (Alt::{D,GG,SG}.push_back in the reference) -- returns false on hash overflow.
 // One LDS round trip per probe: the compare-and-swap both claims an empty entry and reports the resident key.
@@ -300,7 +303,7 @@ __device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int or
 #pragma nounroll
     for(int probe = 0; probe < C::HC; probe++) {
         u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
-        if(old == HKEY_EMPTY || old == key) { typename C::Best v; pack_best(v, score, order); atomicMax(&S.hbest[mat][h], v); return true; }
+        if(old == HKEY_EMPTY || old == key) { typename C::Best v; pack_best<C>(v, score, order); atomicMax(&S.hbest[mat][h], v); return true; }
         h = (h + 1) & (C::HC - 1);
     }
     return false;
@@ -515,9 +518,9 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
 #pragma unroll
             for(int q = 0; q < 3; q++)
                 if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
-            if(cv[0]) { BestT v; pack_best(v, pDA + (labA0 == rc ? 2 : -5), (i << 8) | 0); atomicMax(&S.hbest[M_D][ch[0]], v); }
-            if(cv[1]) { BestT v; pack_best(v, pDA + (labA1 == rc ? 2 : -5), (i << 8) | 1); atomicMax(&S.hbest[M_D][ch[1]], v); }
-            if(cv[2]) { BestT v, w; pack_best(v, pD - 6, ord0 | 0); if(pG != DP_NEG) { pack_best(w, pG - 2, ord0 | 1); if(w > v) v = w; } atomicMax(&S.hbest[M_GG][ch[2]], v); }
+            if(cv[0]) { BestT v; pack_best<C>(v, pDA + (labA0 == rc ? 2 : -5), (i << 8) | 0); atomicMax(&S.hbest[M_D][ch[0]], v); }
+            if(cv[1]) { BestT v; pack_best<C>(v, pDA + (labA1 == rc ? 2 : -5), (i << 8) | 1); atomicMax(&S.hbest[M_D][ch[1]], v); }
+            if(cv[2]) { BestT v, w; pack_best<C>(v, pD - 6, ord0 | 0); if(pG != DP_NEG) { pack_best<C>(w, pG - 2, ord0 | 1); if(w > v) v = w; } atomicMax(&S.hbest[M_GG][ch[2]], v); }
         }
         {   // batch 2: both edges of the m-1 entry, the first jump
             bool cv[3]; u64 ck[3]; u32 ch[3]; u64 cold[3];
@@ -535,15 +538,15 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 if(cv[kk]) {
                     BestT v, w;
                     if(lab != '_') {
-                        pack_best(v, pD - 6, ord0 | (2 * kk)); if(pS != DP_NEG) { pack_best(w, pS - 2, ord0 | (2 * kk + 1)); if(w > v) v = w; }
+                        pack_best<C>(v, pD - 6, ord0 | (2 * kk)); if(pS != DP_NEG) { pack_best<C>(w, pS - 2, ord0 | (2 * kk + 1)); if(w > v) v = w; }
                         atomicMax(&S.hbest[M_SG][ch[kk]], v);
                     } else {
-                        if(pS != DP_NEG) { pack_best(w, pS, ord0 | (2 * kk + 1)); atomicMax(&S.hbest[M_SG][ch[kk]], w); }
-                        pack_best(v, pD, ord0 | kk); atomicMax(&S.hbest[M_D][ch[kk]], v);
+                        if(pS != DP_NEG) { pack_best<C>(w, pS, ord0 | (2 * kk + 1)); atomicMax(&S.hbest[M_SG][ch[kk]], w); }
+                        pack_best<C>(v, pD, ord0 | kk); atomicMax(&S.hbest[M_D][ch[kk]], v);
                     }
                 }
             }
-            if(cv[2]) { BestT v; pack_best(v, pD, ord0 | 128); atomicMax(&S.hbest[M_D][ch[2]], v); }
+            if(cv[2]) { BestT v; pack_best<C>(v, pD, ord0 | 128); atomicMax(&S.hbest[M_D][ch[2]], v); }
         }
         if(okA) edges += degA;
         if(sgB) edges += degB;
@@ -627,7 +630,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             int t = t0 + gl; int es = -1;
             if(t < nT) {
                 int h = S.tlist[t];
-                int Dv = max(best_score(S.hbest[M_D][h]), max(best_score(S.hbest[M_GG][h]), best_score(S.hbest[M_SG][h])));
+                int Dv = max(best_score<C>(S.hbest[M_D][h]), max(best_score<C>(S.hbest[M_GG][h]), best_score<C>(S.hbest[M_SG][h])));
                 if(Dv >= -16) es = early_lookup<C>(sl, S.hkey[h]);
                 S.tes[t] = (typename C::Slot)es;
             }
@@ -647,7 +650,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             int h = act ? S.tlist[t] : 0;
             u64 key = act ? S.hkey[h] : 0;
             typename C::Best bD = act ? S.hbest[M_D][h] : 0, bG = act ? S.hbest[M_GG][h] : 0, bS = act ? S.hbest[M_SG][h] : 0;
-            int Dc = best_score(bD), GGv = best_score(bG), SGv = best_score(bS);
+            int Dc = best_score<C>(bD), GGv = best_score<C>(bG), SGv = best_score<C>(bS);
             int Dv = Dc, dsel = 0;                      // D candidates first, then GG, then SG (:840-865); first maximum wins
             if(GGv > Dv) { Dv = GGv; dsel = 1; }
             if(SGv > Dv) { Dv = SGv; dsel = 2; }
@@ -673,12 +676,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             if(keep && ok && slot >= 0 && slot < C::CELLS) {
                 // back pointer = (previous cell slot, source matrix, kind, local push index j); the graph edge / gap path behind j
                 // is resolved only for the cells on the final path, at backtrace time
-                if(bG) { int o = best_order(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                if(bG) { int o = best_order<C>(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                          btG = mk_bt(S.fslot[b1][i], j ? 1 : 0, K_GGAP, -1); }
-                if(bS) { int o = best_order(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                if(bS) { int o = best_order<C>(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                          btS = mk_bt(S.fslot[b1][i], (j & 1) ? 2 : 0, K_SGAP, j >> 1); }
                 if(dsel == 0) {
-                    int o = best_order(bD); int ph = o >> (C::IBITS + 8); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                    int o = best_order<C>(bD); int ph = o >> (C::IBITS + 8); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                     int sb = ph ? b1 : b2;
                     srcScore = S.fD[sb][i];
                     if(!ph) btD = mk_bt(S.fslot[sb][i], 0, K_DIAG, j);
@@ -686,11 +689,11 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     else btD = mk_bt(S.fslot[sb][i], 0, K_JUMP, j - 128);
                 } else if(dsel == 1) {
                     btD = mk_bt(slot, 1, K_HOP, -1);
-                    int o = best_order(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                    int o = best_order<C>(bG); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                     srcScore = j ? S.fG[b1][i] : S.fD[b1][i];
                 } else {
                     btD = mk_bt(slot, 2, K_HOP, -1);
-                    int o = best_order(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
+                    int o = best_order<C>(bS); int i = (o >> 8) & ((1 << C::IBITS) - 1); int j = o & 255;
                     srcScore = (j & 1) ? S.fS[b1][i] : S.fD[b1][i];
                 }
             }

@@ -384,6 +384,7 @@ public:
             const size_t u0 = (size_t)pB.batch_first_unit(bi);
             const auto t0 = std::chrono::steady_clock::now();
             hlala_batch* b = pB.acquire(bi, true);
+            if(bi + 1 < nB) pB.acquire(bi + 1, true);      // two batches in flight: the next one's bulk runs beside this one's tail (hlala_align_batch)
             hlala_batch_stats bs; chk(hlala_batch_get_stats(c, b, &bs), "hlala_batch_get_stats");          // (synchronises: the batch is aligned)
             alignS += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             errors += bs.n_errors;
