@@ -87,6 +87,13 @@ class Oracle:
         lib().orc_dp_maxima(self.h, a.ctypes.data_as(P.c_i64p), int(reset))
         return dict(frontier=int(a[0]), targets=int(a[1]), kept_cells=int(a[2]), completed=int(a[3]))
 
+    def dp_histogram(self, reset=False):
+        """Per DP call of the calling thread: counts by ceil(log2) of the widest frontier / of the largest target set (bucket b = (2^(b-1), 2^b])."""
+        a = np.zeros(32, np.int64)
+        lib().orc_dp_histogram.argtypes = [C.c_void_p, P.c_i64p, C.c_int]
+        lib().orc_dp_histogram(self.h, a.ctypes.data_as(P.c_i64p), int(reset))
+        return dict(frontier=a[:16].copy(), targets=a[16:].copy())
+
     def graph_info(self):
         gi = P.GraphInfo()
         lib().orc_graph_info(self.h, C.byref(gi))
