@@ -60,7 +60,7 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
-    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
+    char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
     hipEvent_t ev[14]{};          // start/end per stage; [7] / [6] / [9] / [10] / [11] / [12] / [13] / [8] = before DpTiny / after DpTiny / DpMid / DpSmall / DpWide / DpBroad / DpLarge / DpHuge
@@ -314,29 +314,32 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, device) != hipSuccess) { c->err = "hipGetDeviceProperties failed"; return fail(HLALA_E_DEVICE); }
     int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // DP slab pools, one per class and zeroed once: a slab's early-cell table is cleared by the first DP call that needs it and kept clean from then on
+    // (kernel_dp.hip: DP_SLAB_READY), which only holds while no other class lays its own arrays over the same memory
+    auto slab_pool = [&](char** out, size_t bytes, const char* what) -> int {
+        if(hipMalloc((void**)out, bytes) != hipSuccess) { c->err = std::string("hipMalloc(") + what + ") failed"; return HLALA_E_DEVICE; }
+        c->allocs.push_back(*out);
+        if(hipMemsetAsync(*out, 0, bytes, c->stream) != hipSuccess) { c->err = std::string("hipMemset(") + what + ") failed"; return HLALA_E_DEVICE; }
+        return 0;
+    };
     c->tiny_grid = cus * 16;
     c->tiny_slab_bytes = dp_slab_bytes<DpTiny>();
-    if(hipMalloc((void**)&c->tiny_slabs, c->tiny_slab_bytes * 4 * (size_t)c->tiny_grid) != hipSuccess) { c->err = "hipMalloc(DP slabs) failed"; return fail(HLALA_E_DEVICE); }
-    c->allocs.push_back(c->tiny_slabs);
     c->ext_grid = cus * 20;
-    c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();      // 2 * mid_grid mid slabs fit the pool of ext_grid small slabs
+    c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();
     c->retry_grid = cus;
     c->broad_grid = cus * 2;         // two DpBroad blocks per CU, slabs of the large layout
-    c->wide_grid = cus * 6;          // LDS: six DpWide blocks per CU (26 KB each); slabs of the 64-lane layout, in a pool of their own
+    c->wide_grid = cus * 6;          // LDS: six DpWide blocks per CU (26 KB each); slabs of the 64-lane layout
     c->stitch_grid = cus * 32;
-    c->ext_slab_bytes = dp_slab_bytes<DpSmall>();
+    c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpWide>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpWide>();
     c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / two blocks per CU: a few MB each
-    if(hipMalloc((void**)&c->large_slabs, c->large_slab_bytes * (size_t)(c->broad_grid + c->retry_grid)) != hipSuccess) { c->err = "hipMalloc(large-class DP slabs) failed"; return fail(HLALA_E_DEVICE); }
-    c->allocs.push_back(c->large_slabs);
     c->huge_grid = cus / 4 > 0 ? cus / 4 : 1;      // the in-memory backstop class: a handful of DP calls per million pairs
     c->huge_slab_bytes = dp_inmemory_bytes<DpHuge>();
-    if(hipMalloc((void**)&c->huge_slabs, c->huge_slab_bytes * (size_t)c->huge_grid) != hipSuccess) { c->err = "hipMalloc(in-memory DP class) failed"; return fail(HLALA_E_DEVICE); }
-    c->allocs.push_back(c->huge_slabs);
-    if(hipMalloc((void**)&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid) != hipSuccess) { c->err = "hipMalloc(extension slabs) failed"; return fail(HLALA_E_DEVICE); }
-    c->allocs.push_back(c->ext_slabs);
-    // (the wide class may run on the side stream while the 32- / 64-lane classes of the next batch use the pool above: slabs of its own)
-    if(hipMalloc((void**)&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid) != hipSuccess) { c->err = "hipMalloc(wide-class slabs) failed"; return fail(HLALA_E_DEVICE); }
-    c->allocs.push_back(c->wide_slabs);
+    if((rc = slab_pool(&c->tiny_slabs, c->tiny_slab_bytes * (size_t)(64 / DpTiny::GW) * (size_t)c->tiny_grid, "16-lane DP slabs"))) return fail(rc);
+    if((rc = slab_pool(&c->mid_slabs, c->mid_slab_bytes * (size_t)(64 / DpMid::GW) * (size_t)c->mid_grid, "32-lane DP slabs"))) return fail(rc);
+    if((rc = slab_pool(&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid, "64-lane DP slabs"))) return fail(rc);
+    if((rc = slab_pool(&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid, "wide-class DP slabs"))) return fail(rc);
+    if((rc = slab_pool(&c->large_slabs, c->large_slab_bytes * (size_t)(c->broad_grid + c->retry_grid), "large-class DP slabs"))) return fail(rc);       // broad blocks first, then the large ones
+    if((rc = slab_pool(&c->huge_slabs, c->huge_slab_bytes * (size_t)c->huge_grid, "in-memory DP class"))) return fail(rc);
     c->proj_grid = cus * 9; c->pair_grid = cus * 14;
     if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
         c->proj_grid = cus * 4;
@@ -626,7 +629,7 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
             HIP_TRY(c, hipEventRecord(c->evC[tier][0], ws));
             switch(tier) {
             case 0: hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->mid_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
             case 2: hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
             case 3: hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->wide_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
             case 4: hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;

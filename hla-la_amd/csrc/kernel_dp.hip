@@ -41,6 +41,7 @@ enum { M_D = 0, M_GG = 1, M_SG = 2 };
 enum { PH_IDLE = 0, PH_RUN, PH_SELECT, PH_BT, PH_EXPAND, PH_DONE };
 
 constexpr u64 HKEY_EMPTY = ~0ull;
+constexpr int DP_EARLY_GEN_MAX = 0xFFFFFE;      // generations of a slab's early table before it is cleared again (24 bits of the entry word)
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows per trip of the persistent loop (measured: 3 -> 236 ms, 6 -> 231, 12 -> 226, 24 -> 225, 64 -> 224 per 524 k pairs)
 
@@ -126,7 +127,8 @@ struct DpSlabT {
     static constexpr size_t O_IMP_MASK  = O_IMP_SLOT + (size_t)C::IMPCAP * 4;         // int  [IMPCAP]
     static constexpr size_t O_TIE_SLOT  = O_IMP_MASK + (size_t)C::IMPCAP * 4;         // int  [COMPLETED]
     static constexpr size_t O_TIE_KEY   = (O_TIE_SLOT + (size_t)C::COMPLETED * 4 + 7) & ~(size_t)7;   // u64 [COMPLETED]
-    static constexpr size_t BYTES       = (O_TIE_KEY + (size_t)C::COMPLETED * 8 + 255) & ~(size_t)255;
+    static constexpr size_t O_EARLY_GEN = O_TIE_KEY + (size_t)C::COMPLETED * 8;         // int: generation of the early table = number of DP calls that used it (pools start zeroed)
+    static constexpr size_t BYTES       = (O_EARLY_GEN + 8 + 255) & ~(size_t)255;
     __device__ __forceinline__ CellRec* cell() const { return (CellRec*)(base + O_CELL); }
     __device__ __forceinline__ u64* early_key() const { return (u64*)(base + O_EARLY_KEY); }
     __device__ __forceinline__ u32* step_bt() const { return (u32*)(base + O_STEP_BT); }
@@ -140,6 +142,7 @@ struct DpSlabT {
     __device__ __forceinline__ int* imp_mask() const { return (int*)(base + O_IMP_MASK); }
     __device__ __forceinline__ int* tie_slot() const { return (int*)(base + O_TIE_SLOT); }
     __device__ __forceinline__ u64* tie_key() const { return (u64*)(base + O_TIE_KEY); }
+    __device__ __forceinline__ int* early_gen() const { return (int*)(base + O_EARLY_GEN); }
 };
 
 template <class C>
@@ -325,26 +328,39 @@ __device__ inline u32 dp_probe(DpLdsT<C>& S, u64 key, u32 h)
 // (the two smallest classes keep the cheap hash for their slab tables of at most 4096 / 8192 entries: the multiplies cost them 2 % of their time)
 template <class C> __device__ __forceinline__ u32 early_hash(u64 k) { return (C::EARLY > 8192 ? hash_mix(k) : hash64(k)) & (u32)(C::EARLY - 1); }
 
+// The early-cell table of a slab is never cleared between DP calls: an entry is the word (generation 24 bits | read offset 12 | node 28) -- the level
+// is implied by the node -- and only entries of the current generation count; anything else reads as empty.  A DP call that gets its first early cell
+// takes the next generation of its slab (dp_iterate).  (Every such call used to clear the whole table first: 32 KB of stores per call in the 16-lane
+// class, about half of the kernel's HBM writes on the Graph M workload.)
+__device__ __forceinline__ u64 early_word(int gen, u64 key) { return ((u64)(u32)gen << 40) | (key & 0xFFFFFFFFFFull); }
+
 template <class C>
-__device__ inline int early_lookup(const DpSlabT<C>& sl, u64 key)
+__device__ inline int early_lookup(const DpSlabT<C>& sl, int gen, u64 key)
 {
     u32 h = early_hash<C>(key);
+    const u64 w = early_word(gen, key);
     for(int probe = 0; probe < C::EARLY; probe++) {
         // entries are published with L2 atomics: read them past the CU's L1
         u64 cur = __hip_atomic_load(&sl.early_key()[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if(cur == key) return __hip_atomic_load(&sl.early_val()[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if(cur == HKEY_EMPTY) return -1;
+        if(cur == w) return __hip_atomic_load(&sl.early_val()[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if((int)(cur >> 40) != gen) return -1;
         h = (h + 1) & (C::EARLY - 1);
     }
     return -1;
 }
 template <class C>
-__device__ inline bool early_insert(const DpSlabT<C>& sl, u64 key, int slot)
+__device__ inline bool early_insert(const DpSlabT<C>& sl, int gen, u64 key, int slot)
 {
     u32 h = early_hash<C>(key);
+    const u64 w = early_word(gen, key);
     for(int probe = 0; probe < C::EARLY; probe++) {
-        u64 old = atomicCAS(&sl.early_key()[h], HKEY_EMPTY, key);
-        if(old == HKEY_EMPTY || old == key) { __hip_atomic_store(&sl.early_val()[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
+        u64 cur = __hip_atomic_load(&sl.early_key()[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while((int)(cur >> 40) != gen) {              // free (an older generation): claim it; a lane of this group that gets there first leaves a current entry
+            const u64 old = atomicCAS(&sl.early_key()[h], cur, w);
+            if(old == cur) { cur = w; break; }
+            cur = old;
+        }
+        if(cur == w) { __hip_atomic_store(&sl.early_val()[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
         h = (h + 1) & (C::EARLY - 1);
     }
     return false;
@@ -631,7 +647,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             if(t < nT) {
                 int h = S.tlist[t];
                 int Dv = max(best_score<C>(S.hbest[M_D][h]), max(best_score<C>(S.hbest[M_GG][h]), best_score<C>(S.hbest[M_SG][h])));
-                if(Dv >= -16) es = early_lookup<C>(sl, S.hkey[h]);
+                if(Dv >= -16) es = early_lookup<C>(sl, earlyInit, S.hkey[h]);
                 S.tes[t] = (typename C::Slot)es;
             }
             if(grp_ballot<GW>(es >= 0)) anyExisting = true;
@@ -713,11 +729,16 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 if(isEarly && natural > earlyNatMax) earlyNatMax = natural;
                 if(grp_ballot<GW>(isEarly)) {                    // early cells: into the slab hash
                     if(!earlyInit) {
-                        for(int i = gl; i < C::EARLY; i += GW) sl.early_key()[i] = HKEY_EMPTY;
-                        earlyInit = 1;
+                        // first early cell of this call: the next generation of the slab's table (early_lookup)
+                        int g = 0;
+                        if(gl == 0) g = __hip_atomic_load(sl.early_gen(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                        g = (GW == 64) ? __builtin_amdgcn_readfirstlane(g) : grp_bcast<GW>(g, 0);
+                        if(g > DP_EARLY_GEN_MAX) { for(int i = gl; i < C::EARLY; i += GW) sl.early_key()[i] = 0; g = 1; }
+                        if(gl == 0) __hip_atomic_store(sl.early_gen(), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        earlyInit = g;
                         DSYNC();
                     }
-                    if(isEarly) if(!early_insert<C>(sl, key, slot)) S.err = __LINE__;
+                    if(isEarly) if(!early_insert<C>(sl, earlyInit, key, slot)) S.err = __LINE__;
                 }
                 if(isNew && y == limitY) {                                                     // :982-999
                     int pos = atomicAdd(&S.nCompletedAdd, 1);
