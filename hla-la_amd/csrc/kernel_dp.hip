@@ -45,7 +45,9 @@ constexpr int DP_EARLY_GEN_MAX = 0xFFFFFE;      // generations of a slab's early
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows per trip of the persistent loop (measured: 3 -> 236 ms, 6 -> 231, 12 -> 226, 24 -> 225, 64 -> 224 per 524 k pairs)
 
-struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 64,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
+// (16-lane class: a target table of 32 entries, i.e. at most 24 targets per iteration, sends 2.6 % more calls on to the 32-lane class than 64 entries did and
+// makes the kernel 10 % faster: half the table to scan, reset and keep in LDS; 8-lane groups were tried for this class -- 8 DPs per wave -- and lost)
+struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 32,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
 struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
