@@ -25,34 +25,47 @@ struct __align__(16) PairLds {
     int ired[8];
 };
 
-// max_d log pdf(d) over the distances of every underlying sequence both chain ends map to (:3436-3495)
+// position of sequence `id` at `level` (the level's entries are sorted by sequence id, flat_graph.cpp), -1 if the sequence does not pass through it
+__device__ inline int lp_find(const DevGraph& G, int level, int id)
+{
+    long long lo = G.lp_off[level], hi = G.lp_off[level + 1];
+    while(lo < hi) {
+        const long long mid = (lo + hi) >> 1; const int v = G.lp_seqid[mid];
+        if(v == id) return G.lp_pos[mid];
+        if(v < id) lo = mid + 1; else hi = mid;
+    }
+    return -1;
+}
+
+// max_d log pdf(d) over the distances of every underlying sequence both chain ends map to (:3436-3495).  Called by the whole wave with wave-uniform
+// arguments: the lanes share the sequences of the upstream level and look each one up in the downstream levels by binary search (a level of a gene
+// window carries dozens to thousands of sequences; one lane walking both lists against each other was most of this kernel's time on Graph M).
+// The maximum does not depend on the order of the candidates.
 __device__ inline double pair_insert_ll(const DevGraph& G, const DevTables& T, const int* fl_up, const int* fl_down)
 {
+    const int lane = lane_id();
     // upstream chain: last two defined levels (scan order: last, second last); downstream: first two
-    int upL[2] = {fl_up[2], fl_up[3]}, dnL[2] = {fl_down[0], fl_down[1]};
-    double best = 0; bool have = false;
+    const int upL[2] = {uni(fl_up[2]), uni(fl_up[3])}, dnL[2] = {uni(fl_down[0]), uni(fl_down[1])};
+    double best = -1.0e300; bool have = false;
     for(int a = 0; a < 2; a++) {
         if(upL[a] < 0) continue;
-        for(long long ia = G.lp_off[upL[a]]; ia < G.lp_off[upL[a] + 1]; ia++) {
-            int id = G.lp_seqid[ia]; int endPos = G.lp_pos[ia];
-            if(a == 1 && upL[0] >= 0) {                       // first found wins: skip ids already anchored by the last level
-                bool dup = false;
-                for(long long q = G.lp_off[upL[0]]; q < G.lp_off[upL[0] + 1]; q++) if(G.lp_seqid[q] == id) { dup = true; break; }
-                if(dup) continue;
-            }
+        const long long lo = G.lp_off[upL[a]], hi = G.lp_off[upL[a] + 1];
+        for(long long ia = lo + lane; ia < hi; ia += 64) {
+            const int id = G.lp_seqid[ia]; const int endPos = G.lp_pos[ia];
+            if(a == 1 && upL[0] >= 0 && lp_find(G, upL[0], id) >= 0) continue;          // first found wins: ids already anchored by the last level
             int beginPos = -1;
-            for(int b = 0; b < 2 && beginPos < 0; b++) {
-                if(dnL[b] < 0) continue;
-                for(long long q = G.lp_off[dnL[b]]; q < G.lp_off[dnL[b] + 1]; q++) if(G.lp_seqid[q] == id) { beginPos = G.lp_pos[q]; break; }
-            }
+            if(dnL[0] >= 0) beginPos = lp_find(G, dnL[0], id);
+            if(beginPos < 0 && dnL[1] >= 0) beginPos = lp_find(G, dnL[1], id);
             if(beginPos < 0) continue;
-            long long d = (long long)beginPos - endPos - 1;
-            long long k = d - T.is_dmin;
-            double v = (k >= 0 && k < T.is_n) ? T.is_logpdf[k] : T.is_penalty;      // pdf <= 0 -> penalty (:3447-3464)
+            const long long d = (long long)beginPos - endPos - 1;
+            const long long k = d - T.is_dmin;
+            const double v = (k >= 0 && k < T.is_n) ? T.is_logpdf[k] : T.is_penalty;      // pdf <= 0 -> penalty (:3447-3464)
             if(!have || v > best) { best = v; have = true; }
         }
     }
-    return have ? best : T.is_penalty;
+    if(!have) best = -1.0e300;
+    for(int o = 32; o; o >>= 1) { const double ov = __shfl_xor(best, o); if(ov > best) best = ov; }
+    return __ballot(have) ? best : T.is_penalty;
 }
 
 // Insert-size estimation (processBAM::estimateInsertSize, processBAM.cpp:1071-1165): for a batch that holds ONE chain per read
@@ -154,19 +167,20 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
         } else {
         const int nComb = (int)nCombLL;
         // ---- combination log likelihoods, row-major (i1, i2) (:3408-3506)
-        for(int i = lane; i < nComb; i += 64) {
-            int i1 = i / n2, i2 = i % n2;
-            if(UNPAIRED) { P.LL[i] = B.ext_ll[P.list[0][i1]]; continue; }                                             // read1_extendedChains_log_likelihoods, :3743
-            int ca = P.list[0][i1], cb = P.list[1][i2];
+        if(UNPAIRED) { for(int i = lane; i < nComb; i += 64) P.LL[i] = B.ext_ll[P.list[0][i]]; }                         // read1_extendedChains_log_likelihoods, :3743
+        else for(int i = 0; i < nComb; i++) {              // one combination at a time, the wave shares the insert-size term
+            const int i1 = i / n2, i2 = i % n2;
+            const int ca = uni(P.list[0][i1]), cb = uni(P.list[1][i2]);
             const int* fa = B.ext_firstlast + 4 * ca; const int* fb = B.ext_firstlast + 4 * cb;
-            bool ra = B.chain_reverse[ca] != 0, rb = B.chain_reverse[cb] != 0;
+            const int fa0 = uni(fa[0]), fb0 = uni(fb[0]);
+            const bool ra = uni(B.chain_reverse[ca]) != 0, rb = uni(B.chain_reverse[cb]) != 0;
             bool valid = false;
-            if(fa[0] != -1 && fb[0] != -1 && ra != rb) valid = (!ra) ? (fa[0] < fb[0]) : (fa[2] > fb[2]);          // alignerBase.cpp:213-244
+            if(fa0 != -1 && fb0 != -1 && ra != rb) valid = (!ra) ? (fa0 < fb0) : (uni(fa[2]) > uni(fb[2]));          // alignerBase.cpp:213-244
             double llIS = T.is_penalty;
-            if(valid) llIS = (fa[0] < fb[0]) ? pair_insert_ll(G, T, fa, fb) : pair_insert_ll(G, T, fb, fa);        // alignerBase.cpp:294, 312
+            if(valid) llIS = (fa0 < fb0) ? pair_insert_ll(G, T, fa, fb) : pair_insert_ll(G, T, fb, fa);        // alignerBase.cpp:294, 312
             double combined = B.ext_ll[ca] + B.ext_ll[cb];
             combined += llIS;
-            P.LL[i] = combined;
+            if(lane == 0) P.LL[i] = combined;
         }
         WSYNC();
         // ---- first maximum (Utilities::findVectorMax, Utilities.cpp:309-323)
@@ -233,8 +247,16 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
                     carry += __popcll(bm);
                 }
             }
+            // level and graph character of the selected chain's columns: read once, not once per other chain
+            int selLv[PER]; unsigned char selG[PER];
+            for(int t = 0; t < PER; t++) { const int j = t * 64 + lane; selLv[t] = -1; selG[t] = 0; if(j < nSel) { selLv[t] = B.ext_level[sb + j]; selG[t] = B.ext_g[sb + j]; } }
             for(int k = 0; k < nl; k++) {
                 const int ck = uni(P.list[m][k]); const int nk = uni(B.ext_ncols[ck]); const size_t kb = (size_t)ck * stride;
+                if(ck == sel) {
+                    // the selected chain agrees with itself in every column (base columns through their read-base ordinal, gap columns through their level)
+                    for(int t = 0; t < PER; t++) if(t * 64 + lane < nSel) mask[t] |= (1ull << k);
+                    continue;
+                }
                 const int firstK = uni(B.ext_firstlast[4 * ck + 0]);
                 WSYNC();
                 for(int i = lane; i < PAIR_COLS; i += 64) { P.basecol[i] = -1; P.levcol[i] = -1; }
@@ -252,7 +274,7 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
                 for(int t = 0; t < PER; t++) {
                     int j = t * 64 + lane;
                     if(j >= nSel) continue;
-                    int lj = B.ext_level[sb + j]; unsigned char gj = B.ext_g[sb + j];
+                    const int lj = selLv[t]; const unsigned char gj = selG[t];
                     bool hit = false;
                     if(myIdx[t] >= 0) { int col = P.basecol[myIdx[t]]; if(col >= 0) hit = (B.ext_level[kb + col] == lj) && (B.ext_g[kb + col] == gj); }
                     else if(lj != -1 && firstK >= 0) { int li = lj - firstK; if(li >= 0 && li < PAIR_COLS) { int col = P.levcol[li]; if(col >= 0) hit = (B.ext_s[kb + col] == '_') && (B.ext_g[kb + col] == gj); } }
