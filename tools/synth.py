@@ -502,7 +502,15 @@ def _gm():
         so = _os.path.join(_ROOT, "_build", "libgraphm.so")
         src = _os.path.join(_ROOT, "graphm", "graphm.cpp")
         if not _os.path.exists(so) or _os.path.getmtime(so) < _os.path.getmtime(src):
-            _subprocess.check_call(["make", "-s", "-C", _os.path.join(_ROOT, "graphm")])
+            # (several ranks of one bench may get here at once: one builds, the others wait)
+            import fcntl
+            _os.makedirs(_os.path.join(_ROOT, "_build"), exist_ok=True)
+            with open(_os.path.join(_ROOT, "_build", ".graphm.lock"), "w") as lk:
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                try:
+                    _subprocess.check_call(["make", "-s", "-C", _os.path.join(_ROOT, "graphm")])
+                finally:
+                    fcntl.flock(lk, fcntl.LOCK_UN)
         L = _C.CDLL(so)
         L.gm_world_create.restype = _C.c_void_p; L.gm_world_create.argtypes = [_C.POINTER(_GmParams)]
         L.gm_world_destroy.argtypes = [_C.c_void_p]
