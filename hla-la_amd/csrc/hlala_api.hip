@@ -95,6 +95,8 @@ struct DevGuard {
 #define DEV_GUARD(c) DevGuard dev_guard_((c) ? (c)->device : -1)
 
 #define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HLALA_E_DEVICE; } } while(0)
+// the same inside a function that owns temporaries or a half-built object: `cleanup` (a lambda int -> int) releases them and passes the code through
+#define HIP_TRY_F(ctx, call, cleanup) do { hipError_t e_ = (call); if(e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return cleanup(HLALA_E_DEVICE); } } while(0)
 
 // hipMalloc, or a block of a destroyed batch that is large enough and wastes at most a quarter
 static int pool_malloc(hlala_ctx* c, void** out, size_t bytes)
@@ -461,6 +463,11 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
         for(int k = in->chain_off[r]; k < in->chain_off[r + 1]; k++) chain_read[k] = r;
     }
     for(int k = 0; k < nc; k++) if(in->chain_contig[k] < 0 || in->chain_contig[k] >= c->n_contigs) { c->err = "chain_contig out of range"; return fail(HLALA_E_ARG); }
+    // the extension DP of paired reads keys its cells with a 12-bit read coordinate (kernel_dp.hip: mk_key): longer reads belong in an unpaired batch
+    if(!unpaired) for(int r = 0; r < nr; r++) if(in->read_off[r + 1] - in->read_off[r] > DP_SEQCAP) {
+        c->err = "paired read of " + std::to_string(in->read_off[r + 1] - in->read_off[r]) + " bases: the paired path holds reads of at most " + std::to_string(DP_SEQCAP) + " (use hlala_batch_create_unpaired for long reads)";
+        return fail(HLALA_E_CAPACITY);
+    }
     size_t nbases = nr ? (size_t)in->read_off[nr] : 0, ncig = nc ? (size_t)in->cigar_off[nc] : 0;
     int rc = 0;
 #define UPB(field, ptr, n) do { rc = dev_upload(c, b->allocs, (ptr), (n), (std::remove_const<std::remove_pointer<decltype(B.field)>::type>::type**)&B.field); if(rc) return fail(rc); } while(0)
@@ -473,7 +480,7 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
 #undef UPB
     rc = batch_alloc_outputs(c, b); if(rc) return fail(rc);
     rc = dev_upload(c, b->allocs, &b->B, 1, &b->dB); if(rc) return fail(rc);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY_F(c, hipStreamSynchronize(c->stream), fail);
     *out = b;
     return HLALA_OK;
 }
@@ -510,15 +517,15 @@ int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_
             lev[o] = in->col_level[i]; edg[o] = in->col_edge[i]; g[o] = in->col_gchar[i]; s[o] = in->col_schar[i];
         }
     }
-    HIP_TRY(c, hipMemcpyAsync(B.seed_status, st.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(B.seed_ncols, ncols.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(B.seed_begin, in->chain_seq_begin, (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(B.seed_end, in->chain_seq_end, (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(B.seed_level, lev.data(), lev.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(B.seed_edge, edg.data(), edg.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(B.seed_g, g.data(), g.size(), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(B.seed_s, s.data(), s.size(), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_status, st.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_ncols, ncols.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_begin, in->chain_seq_begin, (size_t)nc * 4, hipMemcpyHostToDevice, c->stream), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_end, in->chain_seq_end, (size_t)nc * 4, hipMemcpyHostToDevice, c->stream), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_level, lev.data(), lev.size() * 4, hipMemcpyHostToDevice, c->stream), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_edge, edg.data(), edg.size() * 4, hipMemcpyHostToDevice, c->stream), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_g, g.data(), g.size(), hipMemcpyHostToDevice, c->stream), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_s, s.data(), s.size(), hipMemcpyHostToDevice, c->stream), fail);
+    HIP_TRY_F(c, hipStreamSynchronize(c->stream), fail);
     b->staged = 1;
     *out = b;
     return HLALA_OK;
@@ -800,14 +807,14 @@ int hlala_batch_get_pairs_packed(hlala_ctx* c, hlala_batch* b, hlala_pairs_packe
     hipLaunchKernelGGL(k_selected_ncols, dim3((unsigned)((nr + 1 + 255) / 256)), dim3(256), 0, st, b->dB, (int)nr, dN);
     if((rc = check_launch(c, "k_selected_ncols"))) return done(rc);
     size_t cubBytes = 0;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, cubBytes, dN, dOff, (int)(nr + 1), st));
+    HIP_TRY_F(c, hipcub::DeviceScan::ExclusiveSum(nullptr, cubBytes, dN, dOff, (int)(nr + 1), st), done);
     if((rc = dev_alloc(c, tmp, cubBytes ? cubBytes : 1, &dCub))) return done(rc);
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(dCub, cubBytes, dN, dOff, (int)(nr + 1), st));
+    HIP_TRY_F(c, hipcub::DeviceScan::ExclusiveSum(dCub, cubBytes, dN, dOff, (int)(nr + 1), st), done);
     long long total = 0;
-    HIP_TRY(c, hipMemcpyAsync(&total, dOff + nr, sizeof(total), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY_F(c, hipMemcpyAsync(&total, dOff + nr, sizeof(total), hipMemcpyDeviceToHost, st), done);
+    HIP_TRY_F(c, hipStreamSynchronize(st), done);
     o->n_cols_total = total;
-    { std::vector<long long> ho(nr + 1); if((rc = dl(c, ho.data(), dOff, nr + 1))) return done(rc); HIP_TRY(c, hipStreamSynchronize(st)); for(size_t i = 0; i <= nr; i++) o->col_off[i] = ho[i]; }
+    { std::vector<long long> ho(nr + 1); if((rc = dl(c, ho.data(), dOff, nr + 1))) return done(rc); HIP_TRY_F(c, hipStreamSynchronize(st), done); for(size_t i = 0; i <= nr; i++) o->col_off[i] = ho[i]; }
     if(total > o->cap_cols) { c->err = "hlala_batch_get_pairs_packed: cap_cols too small (n_cols_total holds the need)"; return done(HLALA_E_CAPACITY); }
     if(total == 0) return done(HLALA_OK);
     int *dL = nullptr, *dE = nullptr; uint8_t *dG = nullptr, *dS = nullptr, *dF = nullptr, *dQ = nullptr;
@@ -819,7 +826,7 @@ int hlala_batch_get_pairs_packed(hlala_ctx* c, hlala_batch* b, hlala_pairs_packe
     if((rc = check_launch(c, "k_gather_packed"))) return done(rc);
     if((rc = dl(c, o->col_level, dL, T)) || (rc = dl(c, o->col_edge, dE, T)) || (rc = dl(c, o->col_gchar, dG, T)) || (rc = dl(c, o->col_schar, dS, T)) ||
        (rc = dl(c, o->col_fromseed, dF, T)) || (rc = dl(c, o->col_mapq, dQ, T))) return done(rc);
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY_F(c, hipStreamSynchronize(st), done);
     return done(HLALA_OK);
 }
 
@@ -1140,22 +1147,22 @@ extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, c
     // order: stable sort by Mism_avg ascending, then stable sort by LL descending
     hipLaunchKernelGGL(k_call_keys_mism, dim3(gP), dim3(T), 0, st, dMA, nP, dK1, dI1);
     size_t cubBytes = 0, cubBytes2 = 0;
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, cubBytes, dK1, dK2, dI1, dI2, (int)nP, 0, 64, st));
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, cubBytes2, dCK, dCK2, dVal, dVal2, (int)n2, 0, 64, st));
+    HIP_TRY_F(c, hipcub::DeviceRadixSort::SortPairs(nullptr, cubBytes, dK1, dK2, dI1, dI2, (int)nP, 0, 64, st), done);
+    HIP_TRY_F(c, hipcub::DeviceRadixSort::SortPairs(nullptr, cubBytes2, dCK, dCK2, dVal, dVal2, (int)n2, 0, 64, st), done);
     if(cubBytes2 > cubBytes) cubBytes = cubBytes2;
     char* dCub = nullptr; if((rc = dev_alloc(c, tmp, cubBytes ? cubBytes : 1, &dCub))) return done(rc);
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(dCub, cubBytes, dK1, dK2, dI1, dI2, (int)nP, 0, 64, st));
+    HIP_TRY_F(c, hipcub::DeviceRadixSort::SortPairs(dCub, cubBytes, dK1, dK2, dI1, dI2, (int)nP, 0, 64, st), done);
     hipLaunchKernelGGL(k_call_keys_ll, dim3(gP), dim3(T), 0, st, dLL, dI2, nP, dK1);
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(dCub, cubBytes, dK1, dK2, dI2, dI1, (int)nP, 0, 64, st));       // dI1 = order
+    HIP_TRY_F(c, hipcub::DeviceRadixSort::SortPairs(dCub, cubBytes, dK1, dK2, dI2, dI1, (int)nP, 0, 64, st), done);       // dI1 = order
     // marginals in the reference's accumulation order
     hipLaunchKernelGGL(k_call_clusters, dim3((unsigned)C), dim3(128), 0, st, (int)C, dC1, dC2);
     hipLaunchKernelGGL(k_call_contrib, dim3(gP), dim3(T), 0, st, dI1, dC1, dC2, dP, nP, dCK, dVal, dTies, dLL, dMA);
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(dCub, cubBytes, dCK, dCK2, dVal, dVal2, (int)n2, 0, 64, st));
+    HIP_TRY_F(c, hipcub::DeviceRadixSort::SortPairs(dCub, cubBytes, dCK, dCK2, dVal, dVal2, (int)n2, 0, 64, st), done);
     hipLaunchKernelGGL(k_call_marginals, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, dCK2, dVal2, n2, (int)C, dMarg);
     hipLaunchKernelGGL(k_call_decide, dim3(1), dim3(64), 0, st, (int)C, dMarg, dP, dMM, dScal, dMaxIdx, dTies, dOut);
     rc = check_launch(c, "hlala_call_locus kernels"); if(rc) return done(rc);
     if((rc = dl(c, order, dI1, (size_t)nP)) || (rc = dl(c, p_normalized, dP, (size_t)nP)) || (rc = dl(c, cluster_marginal, dMarg, (size_t)C)) || (rc = dl(c, out, dOut, 1))) return done(rc);
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY_F(c, hipStreamSynchronize(st), done);
     return done(HLALA_OK);
 }
 
@@ -1191,14 +1198,14 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
     struct I3 { int a, b, c; };
     struct I3Add { __host__ __device__ I3 operator()(const I3& x, const I3& y) const { I3 r; r.a = x.a + y.a; r.b = x.b + y.b; r.c = x.c + y.c; return r; } };
     size_t cubBytes = 0; I3 zero; zero.a = zero.b = zero.c = 0;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveScan(nullptr, cubBytes, (I3*)dCnt, (I3*)dOff, I3Add(), zero, np + 1, st));
+    HIP_TRY_F(c, hipcub::DeviceScan::ExclusiveScan(nullptr, cubBytes, (I3*)dCnt, (I3*)dOff, I3Add(), zero, np + 1, st), done);
     if((rc = dev_alloc(c, tmp, cubBytes ? cubBytes : 1, &dCub))) return done(rc);
-    HIP_TRY(c, hipMemsetAsync(dCnt + 3 * (size_t)np, 0, 3 * sizeof(int), st));
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveScan(dCub, cubBytes, (I3*)dCnt, (I3*)dOff, I3Add(), zero, np + 1, st));
+    HIP_TRY_F(c, hipMemsetAsync(dCnt + 3 * (size_t)np, 0, 3 * sizeof(int), st), done);
+    HIP_TRY_F(c, hipcub::DeviceScan::ExclusiveScan(dCub, cubBytes, (I3*)dCnt, (I3*)dOff, I3Add(), zero, np + 1, st), done);
     int totals[3] = {0, 0, 0}, ob[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(totals, dOff + 3 * (size_t)np, sizeof(totals), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(ob, dOB, sizeof(ob), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY_F(c, hipMemcpyAsync(totals, dOff + 3 * (size_t)np, sizeof(totals), hipMemcpyDeviceToHost, st), done);
+    HIP_TRY_F(c, hipMemcpyAsync(ob, dOB, sizeof(ob), hipMemcpyDeviceToHost, st), done);
+    HIP_TRY_F(c, hipStreamSynchronize(st), done);
     o->n_reads = totals[0]; o->n_pos = totals[1]; o->n_chars = totals[2]; o->n_pairs_ok = ob[0]; o->n_pairs_broken = ob[1];
     if(totals[0] > o->cap_reads || totals[1] > o->cap_pos || totals[2] > o->cap_chars) { c->err = "hlala_exon_positions: output capacity too small (needed sizes are in n_reads / n_pos / n_chars)"; return done(HLALA_E_CAPACITY); }
     const size_t nR = (size_t)totals[0], nPz = (size_t)totals[1], nC = (size_t)totals[2];
@@ -1214,7 +1221,7 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
        (rc = dl(c, o->pos_exon, dO.pos_exon, nPz)) || (rc = dl(c, o->pos_level, dO.pos_level, nPz)) || (rc = dl(c, o->pos_mate, dO.pos_mate, nPz)) || (rc = dl(c, o->pos_mapq, dO.pos_mapq, nPz)) ||
        (rc = dl(c, o->pos_novel_gap, dO.pos_novel_gap, nPz)) || (rc = dl(c, o->geno_off, dO.geno_off, nPz)) || (rc = dl(c, o->geno_chars, dO.geno_chars, nC)) || (rc = dl(c, o->qual_chars, dO.qual_chars, nC)) ||
        (rc = dl(c, o->read_reverse, dO.read_reverse, 2 * nR)) || (rc = dl(c, o->read_mapq, dO.read_mapq, 2 * nR))) return done(rc);
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY_F(c, hipStreamSynchronize(st), done);
     if(o->pos_off) o->pos_off[nR] = (int32_t)nPz;
     if(o->geno_off) o->geno_off[nPz] = (int32_t)nC;
     return done(HLALA_OK);
@@ -1237,7 +1244,7 @@ extern "C" int hlala_unit_alignment_stats(hlala_ctx* c, hlala_batch* b, hlala_un
     if((rc = check_launch(c, "k_unit_stats"))) return done(rc);
     if((rc = dl(c, o->valid, d.valid, n)) || (rc = dl(c, o->strands_valid, d.strands_valid, n)) || (rc = dl(c, o->distance, d.distance, n)) || (rc = dl(c, o->fraction_ok, d.fraction_ok, 2 * n)) ||
        (rc = dl(c, o->weighted_ok, d.weighted_ok, 2 * n)) || (rc = dl(c, o->n_columns, d.n_columns, 2 * n)) || (rc = dl(c, o->mate_mapq, d.mate_mapq, 2 * n))) return done(rc);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY_F(c, hipStreamSynchronize(c->stream), done);
     return done(HLALA_OK);
 }
 
@@ -1276,7 +1283,7 @@ extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* 
     if((rc = check_launch(c, "k_kmer_presence"))) return done(rc);
     std::vector<uint8_t> hp(uniq.size());
     if((rc = dl(c, hp.data(), dP, uniq.size()))) return done(rc);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY_F(c, hipStreamSynchronize(c->stream), done);
     for(int i = 0; i < n_queries; i++) if(canon[i] != ~0ull) present[i] = hp[(size_t)(std::lower_bound(uniq.begin(), uniq.end(), canon[i]) - uniq.begin())];
     return done(HLALA_OK);
 }

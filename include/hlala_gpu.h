@@ -189,7 +189,8 @@ typedef struct {
     uint8_t* col_mapq;      /* [2n*stride] mapQ_perPosition (Phred char)                     */
 } hlala_pairs_out;
 
-/* Upload a batch: inputs become resident in HBM; nothing is computed.                       */
+/* Upload a batch: inputs become resident in HBM; nothing is computed.  Paired reads of more than 1024 bases are refused
+ * (HLALA_E_CAPACITY): the extension DP keys its cells with a 12-bit read coordinate; long reads go through hlala_batch_create_unpaired. */
 int  hlala_batch_create(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** out);
 /* Long-read / unpaired mode (processBAM::alignOneLongRead, mapper/processBAM.cpp:3618-3838, and
  * assignMappingQualities_unpaired, :3900-4059): `in->n_pairs` is the number of READS, every array that is per read

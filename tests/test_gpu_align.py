@@ -184,6 +184,14 @@ def test_edge_cases(pkg, oracle):
         gb3.extend()
     with pytest.raises(pkg.HlalaError):
         pkg.Context(w["graph"], w["contigs"], max_columns=100000)
+    # a paired read longer than the DP's 12-bit read coordinate is refused when the batch is created, not flagged chain by chain later
+    long_b = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+    extra = 1100 - int(long_b["read_off"][1] - long_b["read_off"][0])
+    long_b["read_bases"] = np.concatenate([long_b["read_bases"][:long_b["read_off"][1]], np.full(extra, ord("A"), np.uint8), long_b["read_bases"][long_b["read_off"][1]:]])
+    long_b["read_quals"] = np.concatenate([long_b["read_quals"][:long_b["read_off"][1]], np.full(extra, ord("I"), np.uint8), long_b["read_quals"][long_b["read_off"][1]:]])
+    long_b["read_off"] = long_b["read_off"].copy(); long_b["read_off"][1:] += extra
+    with pytest.raises(pkg.HlalaError, match="at most 1024"):
+        ctx.batch(long_b)
 
 
 def test_full_size_properties(pkg, oracle):
