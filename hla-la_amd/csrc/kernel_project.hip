@@ -231,24 +231,33 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 int opCol = baseCol + wave_excl_scan(isCol ? opLen : 0, tc);
                 int opRef = baseRef + wave_excl_scan(useRef ? opLen : 0, tr);
                 int opRead = baseRead + wave_excl_scan(useRead ? opLen : 0, tq) + leadH;
+                // one lane per COLUMN (64 at a time): the lane finds its operation among the (wave-uniform) operations that overlap the 64 columns, then
+                // all gathers of the round are in flight together.  (One operation after the other cost a round trip of dependent loads per operation:
+                // gene-window alignments carry a dozen.)
                 const int nHere = min(64, nOps - ob);
-                for(int o = 0; o < nHere; o++) {
-                    const int op = __builtin_amdgcn_readlane(opK, o), olen = __builtin_amdgcn_readlane(opLen, o);
-                    if(!(op == 0 || op == 7 || op == 8 || op == 2 || op == 1)) continue;
-                    const int ocs = __builtin_amdgcn_readlane(opCol, o), ors = __builtin_amdgcn_readlane(opRef, o), oqs = __builtin_amdgcn_readlane(opRead, o);
-                    for(int k = lane; k < olen; k += 64) {
+                for(int j0 = 0; j0 < tc; j0 += 64) {
+                    const int jr = j0 + lane;                       // column within this round of operations
+                    int myOp = -1, myK = 0, myRef = 0, myRead = 0;
+                    for(int o = 0; o < nHere; o++) {
+                        const int op = __builtin_amdgcn_readlane(opK, o), olen = __builtin_amdgcn_readlane(opLen, o);
+                        if(!(op == 0 || op == 7 || op == 8 || op == 2 || op == 1) || olen == 0) continue;
+                        const int ocs = __builtin_amdgcn_readlane(opCol, o) - baseCol;
+                        if(ocs + olen <= j0 || ocs >= j0 + 64) continue;
+                        if(jr >= ocs && jr < ocs + olen) { myOp = op; myK = jr - ocs; myRef = __builtin_amdgcn_readlane(opRef, o); myRead = __builtin_amdgcn_readlane(opRead, o); }
+                    }
+                    if(myOp >= 0) {
                         int lv = -1; unsigned char gc = '_', sc = '_';
-                        if(op != 1) {
-                            int refpos = pos + ors + k;
+                        if(myOp != 1) {
+                            int refpos = pos + myRef + myK;
                             int ti = refpos - tOffset;
                             if(refpos < 0 || refpos >= cLen || ti < 0 || ti >= cLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
                             else { gc = contig_seq[cOff + refpos]; lv = contig_level[cOff + ti]; }
                         }
-                        if(op != 2) {
-                            int ri = oqs + k;
+                        if(myOp != 2) {
+                            int ri = myRead + myK;
                             if(ri < 0 || ri >= readLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); } else sc = B.read_bases[rOff + ri];
                         }
-                        const int j = ocs + k;
+                        const int j = baseCol + jr;
                         P.lvl[0][j] = lv; P.g[0][j] = gc; P.s[0][j] = sc;
                     }
                 }
