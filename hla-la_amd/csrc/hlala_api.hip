@@ -342,7 +342,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if((rc = slab_pool(&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid, "wide-class DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->large_slabs, c->large_slab_bytes * (size_t)(c->broad_grid + c->retry_grid), "large-class DP slabs"))) return fail(rc);       // broad blocks first, then the large ones
     if((rc = slab_pool(&c->huge_slabs, c->huge_slab_bytes * (size_t)c->huge_grid, "in-memory DP class"))) return fail(rc);
-    c->proj_grid = cus * 9; c->pair_grid = cus * 14;
+    c->proj_grid = cus * (c->params.max_columns <= PROJ_CAP_SHORT ? 11 : 9); c->pair_grid = cus * 14;
     if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
         c->proj_grid = cus * 4;
         c->proj_long_slab_bytes = proj_long_slab_bytes();
@@ -585,7 +585,11 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
             hipLaunchKernelGGL((k_project_chains<ProjLdsLong>), dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
                                c->proj_slabs, c->proj_slab_bytes, c->proj_long_slabs, c->proj_long_slab_bytes);
         else
-            hipLaunchKernelGGL((k_project_chains<ProjLds>), dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
+            if(c->params.max_columns <= PROJ_CAP_SHORT)
+                hipLaunchKernelGGL((k_project_chains<ProjLdsShort>), dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
+                                   c->proj_slabs, c->proj_slab_bytes, (char*)nullptr, (size_t)0);
+            else
+                hipLaunchKernelGGL((k_project_chains<ProjLds>), dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
                                c->proj_slabs, c->proj_slab_bytes, (char*)nullptr, (size_t)0);
         int rc = check_launch(c, "k_project_chains"); if(rc) return rc;
     }

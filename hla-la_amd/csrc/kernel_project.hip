@@ -25,23 +25,29 @@ constexpr int PROJ_SEGMAX = 24;     // longest run of multi-node levels one lane
 
 struct ChoiceRec { int eid; short fromz; short S; };
 
-struct __align__(16) ProjLds {
-    static constexpr int CAP = PROJ_CAP, SN = PROJ_SN, SE = PROJ_SE; static constexpr bool LONG = false;
-    int lvl[2][PROJ_CAP];
-    unsigned char g[2][PROJ_CAP], s[2][PROJ_CAP];
+// (CAP_ = columns held; two sizes are instantiated: 512 and -- for params.max_columns <= 384, the default of the paired path -- 384, whose
+// 14.5 KB let 11 waves share a CU's LDS instead of 9: the kernel waits on memory two thirds of its cycles)
+template <int CAP_>
+struct __align__(16) ProjLdsT {
+    static constexpr int CAP = CAP_, SN = PROJ_SN, SE = PROJ_SE; static constexpr bool LONG = false;
+    int lvl[2][CAP_];
+    unsigned char g[2][CAP_], s[2][CAP_];
     short Srow[2][PROJ_NODES];
     // the chain's window of the in-edge CSR, staged once so that the per-column recurrence never leaves LDS
-    unsigned short sLev[PROJ_CAP + 2];      // level_off[level0 + i] - nodeBase
+    unsigned short sLev[CAP_ + 2];          // level_off[level0 + i] - nodeBase
     unsigned short sIn[PROJ_SN + 1];        // in_off[tgtBase + i] - eBase
     unsigned short sChoice[PROJ_SN];        // per target node: chosen in-edge (index into the window), 0xFFFF = unreachable
     unsigned short sFrom[PROJ_SE];          // in_from[eBase + e] - nodeBase
     unsigned char sLab[PROJ_SE];
-    u32 colInfo[PROJ_CAP];                  // per level of the window: column | read char << 16 | seed-is-match << 24
-    unsigned short segStart[PROJ_CAP + 2];  // level indices where a DP segment starts (single-node levels, see below)
-    u64 mGap[PROJ_CAP / 64], mDef[PROJ_CAP / 64], mSeq[PROJ_CAP / 64];     // column bit masks of the restrict step
+    u32 colInfo[CAP_];                      // per level of the window: column | read char << 16 | seed-is-match << 24
+    unsigned short segStart[CAP_ + 2];      // level indices where a DP segment starts (single-node levels, see below)
+    u64 mGap[CAP_ / 64], mDef[CAP_ / 64], mSeq[CAP_ / 64];     // column bit masks of the restrict step
     int err, n, startRaw, stopRaw, tmp0, tmp1;
     __device__ __forceinline__ short* sflat() { return &Srow[0][0]; }        // S per node of the window in the segment-parallel form (SN <= 2 * PROJ_NODES)
 };
+typedef ProjLdsT<PROJ_CAP> ProjLds;
+constexpr int PROJ_CAP_SHORT = 384;
+typedef ProjLdsT<PROJ_CAP_SHORT> ProjLdsShort;
 
 // Long reads (params.max_columns > PROJ_CAP): the same kernel with the column / window arrays in the wave's HBM slab; the LDS block
 // only holds the pointers, the per-level score rows and the scalars.  Member names and index syntax match ProjLds.
@@ -68,7 +74,7 @@ __host__ __device__ inline size_t proj_long_slab_bytes()
     b += ((size_t)PROJL_SN + 2) * 2 + 2 * (size_t)PROJL_SN * 2 + (size_t)PROJL_SE * 2 + (size_t)PROJL_SE;    // sIn, sChoice, sflat, sFrom, sLab
     return (b + 4095) & ~(size_t)255;
 }
-__device__ inline void proj_bind(ProjLds&, char*) { }
+template <int CAP_> __device__ inline void proj_bind(ProjLdsT<CAP_>&, char*) { }
 __device__ inline void proj_bind(ProjLdsLong& P, char* p)      // 8-byte arrays first, then 4-, 2-, 1-byte ones
 {
     P.mGap = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8; P.mDef = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8; P.mSeq = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8;
@@ -155,14 +161,30 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         c0 = __builtin_amdgcn_readfirstlane(c0);
         if(c0 >= B.n_chains) break;
         const int cEnd = min(c0 + CHUNK, B.n_chains);
+        // the descriptors of the chunk's chains: lane q holds chain c0 + q; two round trips for the chunk (the fields, then what they point to)
+        // instead of a chain of dependent wave-uniform loads per chain
+        int hStatus = -1, hRead = 0, hContig = 0, hPos = 0, hOff = 0, hCg0 = 0, hCg1 = 0;
+        if(lane < CHUNK && c0 + lane < cEnd) {
+            const int cq = c0 + lane;
+            hStatus = B.seed_status[cq]; hRead = B.chain_read[cq]; hContig = B.chain_contig[cq]; hPos = B.chain_pos[cq]; hOff = B.chain_offset[cq];
+            hCg0 = B.cigar_off[cq]; hCg1 = B.cigar_off[cq + 1];
+        }
+        int hR0 = 0, hR1 = 0, hC0lo = 0, hC0hi = 0, hC1lo = 0, hC1hi = 0;
+        if(hStatus == HLALA_CHAIN_OK) {
+            hR0 = B.read_off[hRead]; hR1 = B.read_off[hRead + 1];
+            const long long a0 = contig_off[hContig], a1 = contig_off[hContig + 1];
+            hC0lo = (int)(u32)a0; hC0hi = (int)(a0 >> 32); hC1lo = (int)(u32)a1; hC1hi = (int)(a1 >> 32);
+        }
         for(int c = c0; c < cEnd; c++) {
-        if(uni(B.seed_status[c]) == HLALA_CHAIN_OK) {
-        const int r = uni(B.chain_read[c]);
-        const int rOff = uni(B.read_off[r]), readLen = uni(B.read_off[r + 1]) - rOff;
-        const int contig = uni(B.chain_contig[c]);
-        const long long cOff = contig_off[contig]; const long long cLen = contig_off[contig + 1] - cOff;
-        const int pos = uni(B.chain_pos[c]), tOffset = uni(B.chain_offset[c]);
-        const int cg0 = uni(B.cigar_off[c]), nOps = uni(B.cigar_off[c + 1]) - cg0;
+        const int hq = c - c0;
+        if(__builtin_amdgcn_readlane(hStatus, hq) == HLALA_CHAIN_OK) {
+        const int r = __builtin_amdgcn_readlane(hRead, hq);
+        const int rOff = __builtin_amdgcn_readlane(hR0, hq), readLen = __builtin_amdgcn_readlane(hR1, hq) - rOff;
+        const int contig = __builtin_amdgcn_readlane(hContig, hq);
+        const long long cOff = (long long)(((u64)(u32)__builtin_amdgcn_readlane(hC0hi, hq) << 32) | (u64)(u32)__builtin_amdgcn_readlane(hC0lo, hq));
+        const long long cLen = (long long)(((u64)(u32)__builtin_amdgcn_readlane(hC1hi, hq) << 32) | (u64)(u32)__builtin_amdgcn_readlane(hC1lo, hq)) - cOff;
+        const int pos = __builtin_amdgcn_readlane(hPos, hq), tOffset = __builtin_amdgcn_readlane(hOff, hq);
+        const int cg0 = __builtin_amdgcn_readlane(hCg0, hq), nOps = __builtin_amdgcn_readlane(hCg1, hq) - cg0;
         if(lane == 0) { P.err = 0; }
         WSYNC();
         long long tPh[7] = {0, 0, 0, 0, 0, 0, 0};
