@@ -311,12 +311,14 @@ struct Chain {
 struct DpStats {
     long long cells = 0, iters = 0, calls = 0, edges = 0;
     long long max_frontier = 0, max_targets = 0, max_kept_cells = 0, max_completed = 0;
+    long long ovf_calls = 0, ovf_first_iter = 0, ovf_total_iter = 0;   /* calls whose frontier passes 16 cells or whose target set passes 24: the iteration where it first happens, and their iterations in all */
     long long hist_frontier[16] = {0}, hist_targets[16] = {0};   /* per DP call: bucket ceil(log2) of its widest frontier / target set (tools: capacity classes) */
     bool h4_hit = false;
     void add(const DpStats& o) {
         cells += o.cells; iters += o.iters; calls += o.calls; edges += o.edges;
         max_frontier = std::max(max_frontier, o.max_frontier); max_targets = std::max(max_targets, o.max_targets);
         for(int i = 0; i < 16; i++) { hist_frontier[i] += o.hist_frontier[i]; hist_targets[i] += o.hist_targets[i]; }
+        ovf_calls += o.ovf_calls; ovf_first_iter += o.ovf_first_iter; ovf_total_iter += o.ovf_total_iter;
         max_kept_cells = std::max(max_kept_cells, o.max_kept_cells); max_completed = std::max(max_completed, o.max_completed); h4_hit = h4_hit || o.h4_hit;
     }
 };
@@ -369,7 +371,7 @@ struct Aligner {
            unsigned int* rng_seed)
     {
         t_stats.calls++;
-        long long callMaxF = 0, callMaxT = 0;
+        long long callMaxF = 0, callMaxT = 0, callFirstOvf = -1;
         const double minusInfinity = -1 * DBL_MAX;                                   /* :363 */
         std::map<Key, Cell> scores;                                                    /* :396 */
         std::map<Key, CellBT> scores_backtrace;                                        /* :397 */
@@ -566,12 +568,14 @@ struct Aligner {
             }
             if((long long)thisDiagonal.size() > t_stats.max_targets) t_stats.max_targets = (long long)thisDiagonal.size();
             if((long long)m_thisDiagonal.size() > t_stats.max_frontier) t_stats.max_frontier = (long long)m_thisDiagonal.size();
+            if(callFirstOvf < 0 && ((long long)thisDiagonal.size() > 24 || (long long)m_thisDiagonal.size() > 16)) callFirstOvf = itersRun;
             if((long long)thisDiagonal.size() > callMaxT) callMaxT = (long long)thisDiagonal.size();
             if((long long)m_thisDiagonal.size() > callMaxF) callMaxF = (long long)m_thisDiagonal.size();
             m2_diagonal = m1_diagonal;                                               /* :1104-1105 */
             m1_diagonal = m_thisDiagonal;
         }
         t_stats.iters += itersRun;
+        if(callFirstOvf >= 0) { t_stats.ovf_calls++; t_stats.ovf_first_iter += callFirstOvf; t_stats.ovf_total_iter += itersRun; }
         { auto bucket = [](long long v) { int b = 0; while((1ll << b) < v && b < 15) b++; return b; }; t_stats.hist_frontier[bucket(callMaxF)]++; t_stats.hist_targets[bucket(callMaxT)]++; }
         if((long long)scores_backtrace.size() > t_stats.max_kept_cells) t_stats.max_kept_cells = (long long)scores_backtrace.size();
         if((long long)achieved_complete_sequence_alignments.size() > t_stats.max_completed) t_stats.max_completed = (long long)achieved_complete_sequence_alignments.size();
@@ -1215,6 +1219,7 @@ int orc_dp_histogram(orc_handle* h, int64_t* out32, int reset)
 {
     (void)h;
     for(int i = 0; i < 16; i++) { out32[i] = t_stats.hist_frontier[i]; out32[16 + i] = t_stats.hist_targets[i]; }
+    out32[15] = t_stats.ovf_calls; out32[30] = t_stats.ovf_first_iter; out32[31] = t_stats.ovf_total_iter;   /* (the last buckets are never reached: reused) */
     if(reset) for(int i = 0; i < 16; i++) t_stats.hist_frontier[i] = t_stats.hist_targets[i] = 0;
     return 0;
 }

@@ -13,6 +13,10 @@ for fg in (0.0, 1.0):
     o.dp_histogram(reset=True)
     o.align_batch(b)
     h = o.dp_histogram()
-    print("frac_gene", fg, "calls", h["frontier"].sum())
-    print(" frontier buckets (<=1,2,4,8,16,32,64,...):", (h["frontier"]/h["frontier"].sum()).round(3)[:10])
-    print(" targets  buckets:", (h["targets"]/h["targets"].sum()).round(3)[:10])
+    print("frac_gene", fg, "calls", h["frontier"][:15].sum())
+    print(" frontier buckets (<=1,2,4,8,16,32,64,...):", (h["frontier"][:15]/h["frontier"][:15].sum()).round(3)[:10])
+    print(" targets  buckets:", (h["targets"][:14]/h["targets"][:14].sum()).round(3)[:10])
+    # (the last buckets are never reached; the oracle reuses them for the calls that outgrow the 16-lane class: count, sum of the iteration of
+    # the first overflow, sum of their iterations)
+    n = max(1, int(h["frontier"][15]))
+    print(" calls that pass 16 frontier cells or 24 targets: %d, first at iteration %.1f of %.1f on average" % (h["frontier"][15], h["targets"][14] / n, h["targets"][15] / n))
