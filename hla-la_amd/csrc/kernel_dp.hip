@@ -41,7 +41,10 @@ enum { M_D = 0, M_GG = 1, M_SG = 2 };
 enum { PH_IDLE = 0, PH_RUN, PH_SELECT, PH_BT, PH_EXPAND, PH_DONE };
 
 constexpr u64 HKEY_EMPTY = ~0ull;
-constexpr int DP_EARLY_GEN_MAX = 0xFFFFFE;      // generations of a slab's early table before it is cleared again (24 bits of the entry word)
+#ifndef HLALA_EARLY_GEN_MAX
+#define HLALA_EARLY_GEN_MAX 0xFFFFFE      // (tools/gpu_gen_wrap.sh builds with a tiny value to exercise the wrap-around under the parity tests)
+#endif
+constexpr int DP_EARLY_GEN_MAX = HLALA_EARLY_GEN_MAX;      // generations of a slab's early table before it is cleared again (24 bits of the entry word)
 constexpr int EXT_PENDING = 0x7FFFFFFF;     // ext_status of a chain whose DP items are in flight
 constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows per trip of the persistent loop (measured: 3 -> 236 ms, 6 -> 231, 12 -> 226, 24 -> 225, 64 -> 224 per 524 k pairs)
 
