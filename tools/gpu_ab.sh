@@ -1,4 +1,7 @@
+#!/bin/bash
 # A/B of two versions of kernel_dp.hip on the same box: A = gpurun_in_kernel_dp_A.hip (repo root), B = the tree's file
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
 cd $GRAFT_REPO_ROOT
 N=${1:-1048576}
 mkdir -p /tmp/a && cp -r hla-la_amd include tools tests /tmp/a/ && cp gpurun_in_kernel_dp_A.hip /tmp/a/hla-la_amd/csrc/kernel_dp.hip

@@ -1,3 +1,6 @@
+#!/bin/bash
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
 cd $GRAFT_REPO_ROOT
 export HLALA_BENCH_BACKEND=gloo
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 2 --warmup 1 --pairs 65536 --levels 500000 2>&1 | tail -3 | cut -c1-900

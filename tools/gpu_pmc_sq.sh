@@ -1,3 +1,6 @@
+#!/bin/bash
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
