@@ -62,6 +62,7 @@ struct hlala_ctx {
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
+    double* pair_scratch = nullptr;   // [2 * pair_grid][PAIR_COMB]: combination tables of the rare pairs with more than PAIR_COMB_LDS combinations (main- and side-stream pass)
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
     hipEvent_t ev[14]{};          // start/end per stage; [7] / [6] / [9] / [10] / [11] / [12] / [13] / [8] = before DpTiny / after DpTiny / DpMid / DpSmall / DpWide / DpBroad / DpLarge / DpHuge
     int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
@@ -342,7 +343,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if((rc = slab_pool(&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid, "wide-class DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->large_slabs, c->large_slab_bytes * (size_t)(c->broad_grid + c->retry_grid), "large-class DP slabs"))) return fail(rc);       // broad blocks first, then the large ones
     if((rc = slab_pool(&c->huge_slabs, c->huge_slab_bytes * (size_t)c->huge_grid, "in-memory DP class"))) return fail(rc);
-    c->proj_grid = cus * (c->params.max_columns <= PROJ_CAP_SHORT ? 11 : 9); c->pair_grid = cus * 14;
+    c->proj_grid = cus * (c->params.max_columns <= PROJ_CAP_SHORT ? 11 : 9); c->pair_grid = cus * 20;
+    { int rcp = dev_alloc(c, c->allocs, (size_t)2 * c->pair_grid * PAIR_COMB, &c->pair_scratch, false); if(rcp) return fail(rcp); }
     if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
         c->proj_grid = cus * 4;
         c->proj_long_slab_bytes = proj_long_slab_bytes();
@@ -689,8 +691,8 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
     if(B.n_pairs > 0) {
         const int grid = B.n_pairs < c->pair_grid ? B.n_pairs : c->pair_grid;
         auto launch_pair = [&](hipStream_t st, int mode, int counterIdx) -> int {
-            if(B.unpaired) hipLaunchKernelGGL((k_pair_chains<true>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx);
-            else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx);
+            if(B.unpaired) hipLaunchKernelGGL((k_pair_chains<true>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx, c->pair_scratch + (st == c->side ? (size_t)c->pair_grid * PAIR_COMB : 0));
+            else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx, c->pair_scratch + (st == c->side ? (size_t)c->pair_grid * PAIR_COMB : 0));
             return check_launch(c, "k_pair_chains");
         };
         int rc = launch_pair(c->stream, fused ? 1 : 0, 2); if(rc) return rc;

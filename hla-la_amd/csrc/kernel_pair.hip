@@ -13,10 +13,14 @@ namespace hlala {
 
 constexpr int PAIR_CHAINS = 64;     // extended chains per mate
 constexpr int PAIR_COMB   = 1024;   // chain combinations per pair
+#ifndef HLALA_PAIR_COMB_LDS
+#define HLALA_PAIR_COMB_LDS 128      // (tools/gpu_gen_wrap.sh builds with 2 to run the parity tests through the HBM-scratch instance)
+#endif
+constexpr int PAIR_COMB_LDS = HLALA_PAIR_COMB_LDS;  // ... of which the LDS block holds this many; pairs with more keep theirs in the wave's HBM scratch
 constexpr int PAIR_COLS   = 512;    // columns per chain handled by the per-position pass
 
 struct __align__(16) PairLds {
-    double LL[PAIR_COMB];
+    double LL[PAIR_COMB_LDS];
     int list[2][PAIR_CHAINS];
     int nlist[2];
     short basecol[PAIR_COLS];
@@ -112,62 +116,16 @@ __global__ void k_pair_distances(const DevGraph* __restrict__ Gp, const DevBatch
     out_n[p] = n;
 }
 
-// UNPAIRED: one read per unit (processBAM::alignOneLongRead :3618-3838 selects the first maximum of the chains' log likelihoods;
-// assignMappingQualities_unpaired :3900-4059 is the paired computation with a single, neutral second mate).
+// Everything of a pair after its chain lists are known: combination log likelihoods, first maximum, posteriors, mapping qualities, per-position
+// qualities.  LL holds one double per combination: the pair's LDS block for up to PAIR_COMB_LDS combinations (all but a handful of pairs), else the
+// wave's scratch in HBM -- the call sites differ in nothing but that pointer, so each instance addresses its memory directly.
 template <bool UNPAIRED>
-__global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
-                                                   const uint8_t* __restrict__ deferPairs, const int deferMode, const int counterIdx)      // deferMode 1: skip deferred pairs, 2: only those
+__device__ __forceinline__ void pair_finish(const DevGraph& G, const DevTables& T, const DevBatch& B, PairLds& P, double* __restrict__ LL,
+                                            const int p, const int n1, const int n2, const int nComb, const int lane, const int stride)
 {
-    const DevGraph& G = *Gp;
-    const DevBatch& B = *Bp;
-    __shared__ PairLds P;
-    const int lane = lane_id();
-    const DevTables& T = *Tp;
-    const int stride = B.stride;
-
-    // pairs are drawn eight at a time (one same-address atomic per pair serialises the grid at the L2)
-    constexpr int CHUNK = 8;
-    for(;;) {
-        int p0 = 0;
-        if(lane == 0) p0 = atomicAdd(&B.work_counter[counterIdx], CHUNK);
-        p0 = __builtin_amdgcn_readfirstlane(p0);
-        if(p0 >= B.n_pairs) break;
-        const int pEnd = min(p0 + CHUNK, B.n_pairs);
-        for(int p = p0; p < pEnd; p++) {
-        if(deferMode) { const bool df = uni(deferPairs[p]) != 0; if(df == (deferMode == 1)) continue; }
-        // ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains), error propagation
-        int bad = 0;
-        constexpr int NM = UNPAIRED ? 1 : 2;
-        for(int m = 0; m < NM; m++) {
-            int r = UNPAIRED ? p : 2 * p + m; int c0 = B.chain_off[r], c1 = B.chain_off[r + 1];
-            int cnt = 0;
-            for(int b0 = c0; b0 < c1; b0 += 64) {
-                int c = b0 + lane; int st = c < c1 ? B.ext_status[c] : 1;
-                if(__ballot(st < 0)) bad = 1;
-                u64 okm = __ballot(st == HLALA_CHAIN_OK);
-                if(st == HLALA_CHAIN_OK) { int pos = cnt + __popcll(okm & ((1ull << lane) - 1ull)); if(pos < PAIR_CHAINS) P.list[m][pos] = c; }
-                cnt += __popcll(okm);
-            }
-            if(lane == 0) P.nlist[m] = cnt;
-            if(cnt < 1 || cnt > PAIR_CHAINS) bad = 1;
-        }
-        WSYNC();
-        const int n1 = uni(P.nlist[0]), n2 = UNPAIRED ? 1 : uni(P.nlist[1]);
-        bad = uni(bad);
-        const long long nCombLL = (long long)n1 * n2;
-        if(!bad && nCombLL > PAIR_COMB) bad = 1;
-        if(!bad && nCombLL > 1) {
-            // the per-position pass below holds PAIR_COLS columns per chain (long reads come with one alignment each: nComb == 1, any length)
-            int mxc = 0;
-            for(int m = 0; m < NM; m++) { const int nl = m ? n2 : n1; for(int k = lane; k < nl; k += 64) mxc = max(mxc, B.ext_ncols[P.list[m][k]]); }
-            if(wave_max_i32(mxc) > PAIR_COLS) bad = 1;
-        }
-        if(bad) {
-            if(lane == 0) { B.pair_status[p] = -1; if(UNPAIRED) B.best_chain[p] = -1; else { B.best_chain[2 * p] = -1; B.best_chain[2 * p + 1] = -1; } B.n_comb[p] = 0; }
-        } else {
-        const int nComb = (int)nCombLL;
+    constexpr int NM = UNPAIRED ? 1 : 2;
         // ---- combination log likelihoods, row-major (i1, i2) (:3408-3506)
-        if(UNPAIRED) { for(int i = lane; i < nComb; i += 64) P.LL[i] = B.ext_ll[P.list[0][i]]; }                         // read1_extendedChains_log_likelihoods, :3743
+        if(UNPAIRED) { for(int i = lane; i < nComb; i += 64) LL[i] = B.ext_ll[P.list[0][i]]; }                         // read1_extendedChains_log_likelihoods, :3743
         else for(int i = 0; i < nComb; i++) {              // one combination at a time, the wave shares the insert-size term
             const int i1 = i / n2, i2 = i % n2;
             const int ca = uni(P.list[0][i1]), cb = uni(P.list[1][i2]);
@@ -180,36 +138,36 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
             if(valid) llIS = (fa0 < fb0) ? pair_insert_ll(G, T, fa, fb) : pair_insert_ll(G, T, fb, fa);        // alignerBase.cpp:294, 312
             double combined = B.ext_ll[ca] + B.ext_ll[cb];
             combined += llIS;
-            if(lane == 0) P.LL[i] = combined;
+            if(lane == 0) LL[i] = combined;
         }
         WSYNC();
         // ---- first maximum (Utilities::findVectorMax, Utilities.cpp:309-323)
         double mx = -1.0e300; int mi = 0x7FFFFFFF;
-        for(int i = lane; i < nComb; i += 64) { double v = P.LL[i]; if(v > mx) { mx = v; mi = i; } }
+        for(int i = lane; i < nComb; i += 64) { double v = LL[i]; if(v > mx) { mx = v; mi = i; } }
         for(int o = 32; o; o >>= 1) { double ov = __shfl_xor(mx, o); int oi = __shfl_xor(mi, o); if(ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; } }
         const int bestI = uni(mi), best1 = bestI / n2, best2 = bestI % n2;
         const int selA = uni(P.list[0][best1]), selB = UNPAIRED ? selA : uni(P.list[1][best2]);
         // ---- posterior over combinations (:4064-4085): exp(LL - max), normalised by a left-to-right sum
         double mapQ = 1, q1 = 1, q2 = 1;
         if(nComb > 1) {
-            for(int i = lane; i < nComb; i += 64) P.LL[i] = exp_cr_nonpos(P.LL[i] - mx);
+            for(int i = lane; i < nComb; i += 64) LL[i] = exp_cr_nonpos(LL[i] - mx);
             WSYNC();
             if(lane == 0) {
-                double S = 0; for(int i = 0; i < nComb; i++) S += P.LL[i];
+                double S = 0; for(int i = 0; i < nComb; i++) S += LL[i];
                 P.red[0] = S;
             }
             WSYNC();
             double S = P.red[0];
-            for(int i = lane; i < nComb; i += 64) P.LL[i] = P.LL[i] / S;
+            for(int i = lane; i < nComb; i += 64) LL[i] = LL[i] / S;
             WSYNC();
             if(lane == 0) {
                 double a = 0, b = 0;
-                for(int i = 0; i < nComb; i++) { double pp = P.LL[i]; if(i / n2 == best1) a += pp; if(i % n2 == best2) b += pp; }
+                for(int i = 0; i < nComb; i++) { double pp = LL[i]; if(i / n2 == best1) a += pp; if(i % n2 == best2) b += pp; }
                 if(a > 1) a = 1; if(b > 1) b = 1;
                 P.red[1] = a; P.red[2] = b;
             }
             WSYNC();
-            mapQ = P.LL[bestI]; q1 = P.red[1]; q2 = P.red[2];
+            mapQ = LL[bestI]; q1 = P.red[1]; q2 = P.red[2];
         }
         if(lane == 0) {
             B.pair_status[p] = 0; B.n_comb[p] = nComb; B.pair_ll[p] = mx; B.pair_mapq[p] = mapQ;
@@ -286,12 +244,71 @@ __global__ __launch_bounds__(64) void k_pair_chains(const DevGraph* __restrict__
                 int j = t * 64 + lane;
                 if(j >= nSel) continue;
                 double Q = 0;                                   // alignmentPositionConfidences accumulated in combination order
-                if(m == 0) { for(int i1 = 0; i1 < n1; i1++) if(mask[t] & (1ull << i1)) for(int i2 = 0; i2 < n2; i2++) Q += P.LL[i1 * n2 + i2]; }
-                else       { for(int i1 = 0; i1 < n1; i1++) for(int i2 = 0; i2 < n2; i2++) if(mask[t] & (1ull << i2)) Q += P.LL[i1 * n2 + i2]; }
+                if(m == 0) { for(int i1 = 0; i1 < n1; i1++) if(mask[t] & (1ull << i1)) for(int i2 = 0; i2 < n2; i2++) Q += LL[i1 * n2 + i2]; }
+                else       { for(int i1 = 0; i1 < n1; i1++) for(int i2 = 0; i2 < n2; i2++) if(mask[t] & (1ull << i2)) Q += LL[i1 * n2 + i2]; }
                 if(Q > 1) Q = 1;
                 B.sel_mapq[ob + j] = phred_from_pcorrect(T, Q);
             }
         }
+}
+
+// UNPAIRED: one read per unit (processBAM::alignOneLongRead :3618-3838 selects the first maximum of the chains' log likelihoods;
+// assignMappingQualities_unpaired :3900-4059 is the paired computation with a single, neutral second mate).
+template <bool UNPAIRED>
+__global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
+                                                   const uint8_t* __restrict__ deferPairs, const int deferMode, const int counterIdx,      // deferMode 1: skip deferred pairs, 2: only those
+                                                   double* __restrict__ bigLL)                    // [gridDim.x][PAIR_COMB]
+{
+    const DevGraph& G = *Gp;
+    const DevBatch& B = *Bp;
+    __shared__ PairLds P;
+    const int lane = lane_id();
+    const DevTables& T = *Tp;
+    const int stride = B.stride;
+
+    // pairs are drawn eight at a time (one same-address atomic per pair serialises the grid at the L2)
+    constexpr int CHUNK = 8;
+    for(;;) {
+        int p0 = 0;
+        if(lane == 0) p0 = atomicAdd(&B.work_counter[counterIdx], CHUNK);
+        p0 = __builtin_amdgcn_readfirstlane(p0);
+        if(p0 >= B.n_pairs) break;
+        const int pEnd = min(p0 + CHUNK, B.n_pairs);
+        for(int p = p0; p < pEnd; p++) {
+        if(deferMode) { const bool df = uni(deferPairs[p]) != 0; if(df == (deferMode == 1)) continue; }
+        // ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains), error propagation
+        int bad = 0;
+        constexpr int NM = UNPAIRED ? 1 : 2;
+        for(int m = 0; m < NM; m++) {
+            int r = UNPAIRED ? p : 2 * p + m; int c0 = B.chain_off[r], c1 = B.chain_off[r + 1];
+            int cnt = 0;
+            for(int b0 = c0; b0 < c1; b0 += 64) {
+                int c = b0 + lane; int st = c < c1 ? B.ext_status[c] : 1;
+                if(__ballot(st < 0)) bad = 1;
+                u64 okm = __ballot(st == HLALA_CHAIN_OK);
+                if(st == HLALA_CHAIN_OK) { int pos = cnt + __popcll(okm & ((1ull << lane) - 1ull)); if(pos < PAIR_CHAINS) P.list[m][pos] = c; }
+                cnt += __popcll(okm);
+            }
+            if(lane == 0) P.nlist[m] = cnt;
+            if(cnt < 1 || cnt > PAIR_CHAINS) bad = 1;
+        }
+        WSYNC();
+        const int n1 = uni(P.nlist[0]), n2 = UNPAIRED ? 1 : uni(P.nlist[1]);
+        bad = uni(bad);
+        const long long nCombLL = (long long)n1 * n2;
+        if(!bad && nCombLL > PAIR_COMB) bad = 1;
+        if(!bad && nCombLL > 1) {
+            // the per-position pass below holds PAIR_COLS columns per chain (long reads come with one alignment each: nComb == 1, any length)
+            int mxc = 0;
+            for(int m = 0; m < NM; m++) { const int nl = m ? n2 : n1; for(int k = lane; k < nl; k += 64) mxc = max(mxc, B.ext_ncols[P.list[m][k]]); }
+            if(wave_max_i32(mxc) > PAIR_COLS) bad = 1;
+        }
+        if(bad) {
+            if(lane == 0) { B.pair_status[p] = -1; if(UNPAIRED) B.best_chain[p] = -1; else { B.best_chain[2 * p] = -1; B.best_chain[2 * p + 1] = -1; } B.n_comb[p] = 0; }
+        } else {
+        const int nComb = (int)nCombLL;
+        if(nComb <= PAIR_COMB_LDS) pair_finish<UNPAIRED>(G, T, B, P, P.LL, p, n1, n2, nComb, lane, stride);
+        else pair_finish<UNPAIRED>(G, T, B, P, bigLL + (size_t)blockIdx.x * PAIR_COMB, p, n1, n2, nComb, lane, stride);
         }   // !bad
         WSYNC();
         }
