@@ -27,27 +27,29 @@ struct ChoiceRec { int eid; short fromz; short S; };
 
 // (CAP_ = columns held; two sizes are instantiated: 512 and -- for params.max_columns <= 384, the default of the paired path -- 384, whose
 // 14.5 KB let 11 waves share a CU's LDS instead of 9: the kernel waits on memory two thirds of its cycles)
-template <int CAP_>
+template <int CAP_, int SN_, int SE_>
 struct __align__(16) ProjLdsT {
-    static constexpr int CAP = CAP_, SN = PROJ_SN, SE = PROJ_SE; static constexpr bool LONG = false;
+    static constexpr int CAP = CAP_, SN = SN_, SE = SE_; static constexpr bool LONG = false;
     int lvl[2][CAP_];
     unsigned char g[2][CAP_], s[2][CAP_];
     short Srow[2][PROJ_NODES];
     // the chain's window of the in-edge CSR, staged once so that the per-column recurrence never leaves LDS
     unsigned short sLev[CAP_ + 2];          // level_off[level0 + i] - nodeBase
-    unsigned short sIn[PROJ_SN + 1];        // in_off[tgtBase + i] - eBase
-    unsigned short sChoice[PROJ_SN];        // per target node: chosen in-edge (index into the window), 0xFFFF = unreachable
-    unsigned short sFrom[PROJ_SE];          // in_from[eBase + e] - nodeBase
-    unsigned char sLab[PROJ_SE];
+    unsigned short sIn[SN_ + 1];            // in_off[tgtBase + i] - eBase
+    unsigned short sChoice[SN_];            // per target node: chosen in-edge (index into the window), 0xFFFF = unreachable
+    unsigned short sFrom[SE_];              // in_from[eBase + e] - nodeBase
+    unsigned char sLab[SE_];
     u32 colInfo[CAP_];                      // per level of the window: column | read char << 16 | seed-is-match << 24
     unsigned short segStart[CAP_ + 2];      // level indices where a DP segment starts (single-node levels, see below)
     u64 mGap[CAP_ / 64], mDef[CAP_ / 64], mSeq[CAP_ / 64];     // column bit masks of the restrict step
     int err, n, startRaw, stopRaw, tmp0, tmp1;
     __device__ __forceinline__ short* sflat() { return &Srow[0][0]; }        // S per node of the window in the segment-parallel form (SN <= 2 * PROJ_NODES)
 };
-typedef ProjLdsT<PROJ_CAP> ProjLds;
+typedef ProjLdsT<PROJ_CAP, PROJ_SN, PROJ_SE> ProjLds;
+// the layout of the paired path (params.max_columns <= 384): a 2x150 bp chain spans ~170-200 levels, i.e. ~280 nodes / ~300 in-edges on backbone
+// stretches; 448 / 576 keep those in the one-shot staged form and make the block 13.1 KB: 12 waves per CU
 constexpr int PROJ_CAP_SHORT = 384;
-typedef ProjLdsT<PROJ_CAP_SHORT> ProjLdsShort;
+typedef ProjLdsT<PROJ_CAP_SHORT, 448, 576> ProjLdsShort;
 
 // Long reads (params.max_columns > PROJ_CAP): the same kernel with the column / window arrays in the wave's HBM slab; the LDS block
 // only holds the pointers, the per-level score rows and the scalars.  Member names and index syntax match ProjLds.
@@ -74,7 +76,7 @@ __host__ __device__ inline size_t proj_long_slab_bytes()
     b += ((size_t)PROJL_SN + 2) * 2 + 2 * (size_t)PROJL_SN * 2 + (size_t)PROJL_SE * 2 + (size_t)PROJL_SE;    // sIn, sChoice, sflat, sFrom, sLab
     return (b + 4095) & ~(size_t)255;
 }
-template <int CAP_> __device__ inline void proj_bind(ProjLdsT<CAP_>&, char*) { }
+template <int CAP_, int SN_, int SE_> __device__ inline void proj_bind(ProjLdsT<CAP_, SN_, SE_>&, char*) { }
 __device__ inline void proj_bind(ProjLdsLong& P, char* p)      // 8-byte arrays first, then 4-, 2-, 1-byte ones
 {
     P.mGap = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8; P.mDef = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8; P.mSeq = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8;
