@@ -30,7 +30,8 @@ struct ChoiceRec { int eid; short fromz; short S; };
 template <int CAP_, int SN_, int SE_>
 struct __align__(16) ProjLdsT {
     static constexpr int CAP = CAP_, SN = SN_, SE = SE_; static constexpr bool LONG = false;
-    int lvl[2][CAP_];
+    typedef unsigned short LvT;             // a column's level relative to the chain's first level, + 1; 0 = none (LvCodec)
+    LvT lvl[2][CAP_];
     unsigned char g[2][CAP_], s[2][CAP_];
     short Srow[2][PROJ_NODES];
     // the chain's window of the in-edge CSR, staged once so that the per-column recurrence never leaves LDS
@@ -47,9 +48,9 @@ struct __align__(16) ProjLdsT {
 };
 typedef ProjLdsT<PROJ_CAP, PROJ_SN, PROJ_SE> ProjLds;
 // the layout of the paired path (params.max_columns <= 384): a 2x150 bp chain spans ~170-200 levels, i.e. ~280 nodes / ~300 in-edges on backbone
-// stretches; 448 / 576 keep those in the one-shot staged form and make the block 13.1 KB: 12 waves per CU
+// stretches; 416 / 544 keep those in the one-shot staged form and, with 16-bit column levels, make the block 11.4 KB: 14 waves per CU
 constexpr int PROJ_CAP_SHORT = 384;
-typedef ProjLdsT<PROJ_CAP_SHORT, 448, 576> ProjLdsShort;
+typedef ProjLdsT<PROJ_CAP_SHORT, 416, 544> ProjLdsShort;
 
 // Long reads (params.max_columns > PROJ_CAP): the same kernel with the column / window arrays in the wave's HBM slab; the LDS block
 // only holds the pointers, the per-level score rows and the scalars.  Member names and index syntax match ProjLds.
@@ -58,6 +59,7 @@ constexpr int PROJL_SN  = 49152;    // nodes of the level window (16-bit offsets
 constexpr int PROJL_SE  = 57344;    // in-edges of the level window
 struct __align__(16) ProjLdsLong {
     static constexpr int CAP = PROJL_CAP, SN = PROJL_SN, SE = PROJL_SE; static constexpr bool LONG = true;
+    typedef int LvT;                        // absolute levels, -1 = none
     int* lvl[2];
     unsigned char* g[2]; unsigned char* s[2];
     short Srow[2][PROJ_NODES];
@@ -94,6 +96,18 @@ __host__ __device__ inline size_t proj_slab_bytes(int stride, int maxNodesPerLev
     if(ent < 1024) ent = 1024;
     return (ent * sizeof(ChoiceRec) + 255) & ~(size_t)255;
 }
+
+// Column levels in LDS are 16 bits: level - (first level of the chain) + 1, 0 = none (levels never decrease along a chain and a chain spans fewer
+// levels than it has column slots, so anything that does not fit is a chain the int form flags as well).  The long-read layout keeps ints in HBM.
+// The other column buffer doubles as the per-column edge pick of the backtrace: window-relative edge index, all ones = none.
+template <class PL> struct LvCodec {
+    typedef typename PL::LvT T;
+    static constexpr bool SHORT = sizeof(T) == 2;
+    __device__ static __forceinline__ int get(T v, int base) { if constexpr (SHORT) return v ? base + (int)v - 1 : -1; else return (int)v; }
+    __device__ static __forceinline__ T put(int lv, int base) { if constexpr (SHORT) return (T)(lv < 0 ? 0 : lv - base + 1); else return (T)lv; }
+    __device__ static __forceinline__ T pickNone() { if constexpr (SHORT) return (T)0xFFFF; else return (T)-1; }
+    __device__ static __forceinline__ bool pickIsNone(T v) { if constexpr (SHORT) return v == (T)0xFFFF; else return (int)v < 0; }
+};
 
 // BamAlignment::GetEndPosition(false, true) of BamTools 2.5.1 (un-vendored dependency, makefile:3-12):
 // Position + sum of M, =, X, D, N lengths - 1.  Call site processBAM.cpp:3872.
@@ -187,6 +201,9 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         const long long cLen = (long long)(((u64)(u32)__builtin_amdgcn_readlane(hC1hi, hq) << 32) | (u64)(u32)__builtin_amdgcn_readlane(hC1lo, hq)) - cOff;
         const int pos = __builtin_amdgcn_readlane(hPos, hq), tOffset = __builtin_amdgcn_readlane(hOff, hq);
         const int cg0 = __builtin_amdgcn_readlane(hCg0, hq), nOps = __builtin_amdgcn_readlane(hCg1, hq) - cg0;
+        typedef LvCodec<PL> LC;
+        int lvBase = 0;                      // level of the chain's first reference position (16-bit layouts only)
+        if constexpr (LC::SHORT) { const long long t0 = (long long)pos - tOffset; if(t0 >= 0 && t0 < cLen) lvBase = max(0, uni(contig_level[cOff + t0])); }
         if(lane == 0) { P.err = 0; }
         WSYNC();
         long long tPh[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -282,7 +299,8 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                             if(ri < 0 || ri >= readLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); } else sc = B.read_bases[rOff + ri];
                         }
                         const int j = baseCol + jr;
-                        P.lvl[0][j] = lv; P.g[0][j] = gc; P.s[0][j] = sc;
+                        if constexpr (LC::SHORT) { if(lv >= 0 && lv < lvBase) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); lv = -1; } else if(lv - lvBase >= 65534) { PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); lv = -1; } }
+                        P.lvl[0][j] = LC::put(lv, lvBase); P.g[0][j] = gc; P.s[0][j] = sc;
                     }
                 }
                 baseCol += tc; baseRef += tr; baseRead += tq;
@@ -298,7 +316,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         if(PJ_OK()) {
             int firstCol = nCols, lastCol = -1;
             for(int j0 = 0; j0 < nCols; j0 += 64) {
-                int j = j0 + lane; bool def = j < nCols && P.lvl[0][j] != -1;
+                int j = j0 + lane; bool def = j < nCols && LC::get(P.lvl[0][j], lvBase) != -1;
                 u64 m = __ballot(def);
                 if(m) { int f = j0 + __ffsll((long long)m) - 1, l = j0 + 63 - __clzll((long long)m); if(f < firstCol) firstCol = f; if(l > lastCol) lastCol = l; }
             }
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 int carryGap = 0, carryPrev = -1;
                 for(int j0 = firstCol; j0 <= lastCol; j0 += 64) {
                     int j = j0 + lane; bool act = j <= lastCol;
-                    int lv = act ? P.lvl[0][j] : -1;
+                    int lv = act ? LC::get(P.lvl[0][j], lvBase) : -1;
                     // last defined level strictly before j: prefix max (levels increase along the alignment)
                     int pm = lv;
                     for(int o = 1; o < 64; o <<= 1) { int y = __shfl_up(pm, o); if(lane >= o) pm = max(pm, y); }
@@ -322,8 +340,8 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                     if(act) {
                         if(np >= PL::CAP || np >= stride) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS);
                         else {
-                            for(int q = 0; q < gap; q++) { int w = np - gap + q; P.lvl[1][w] = prevExcl + 1 + q; P.g[1][w] = '_'; P.s[1][w] = '_'; }
-                            P.lvl[1][np] = lv; P.g[1][np] = P.g[0][j]; P.s[1][np] = P.s[0][j];
+                            for(int q = 0; q < gap; q++) { int w = np - gap + q; P.lvl[1][w] = LC::put(prevExcl + 1 + q, lvBase); P.g[1][w] = '_'; P.s[1][w] = '_'; }
+                            P.lvl[1][np] = LC::put(lv, lvBase); P.g[1][np] = P.g[0][j]; P.s[1][np] = P.s[0][j];
                         }
                     }
                     carryGap += tg; carryPrev = __shfl(prevIncl, 63);
@@ -364,7 +382,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             const int nW = (n1 + 63) >> 6;
             for(int k = 0; k < nW; k++) {
                 int j = k * 64 + lane; bool ins = false, dg = false;
-                if(j < n1) { ins = P.lvl[cur][j] == -1; dg = P.g[cur][j] == '_' && P.s[cur][j] == '_'; }
+                if(j < n1) { ins = LC::get(P.lvl[cur][j], lvBase) == -1; dg = P.g[cur][j] == '_' && P.s[cur][j] == '_'; }
                 u64 mi = __ballot(ins), md = __ballot(dg);
                 if(mi | md) any = true;
                 if(lane == 0) { P.mGap[k] = mi | md; P.mDef[k] = mi; P.mSeq[k] = md; }
@@ -386,7 +404,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         if(ni != ng || ni != half) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
                         else {
                             cleaned = true;
-                            int* olv = P.lvl[1 - cur]; unsigned char* osa = P.s[1 - cur];      // scratch: gathered in column order
+                            typename PL::LvT* olv = P.lvl[1 - cur]; unsigned char* osa = P.s[1 - cur];      // scratch: gathered in column order
                             for(int q = a + lane; q <= b; q += 64) {
                                 const int r = q > a ? countBits(P.mDef, a, q - 1) : 0;
                                 if(bitOf(P.mDef, q)) osa[r] = P.s[cur][q]; else olv[(q - a) - r] = P.lvl[cur][q];
@@ -395,7 +413,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                             for(int q = a + lane; q <= b; q += 64) {
                                 const int i = q - a;
                                 if(i < half) { P.lvl[cur][q] = olv[i]; P.g[cur][q] = '_'; P.s[cur][q] = osa[i]; }
-                                else { P.lvl[cur][q] = -1; P.g[cur][q] = '_'; P.s[cur][q] = '_'; }
+                                else { P.lvl[cur][q] = LC::put(-1, lvBase); P.g[cur][q] = '_'; P.s[cur][q] = '_'; }
                             }
                             WSYNC();
                         }
@@ -406,9 +424,9 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                     int w = 0;
                     for(int k = 0; k < nW; k++) {
                         int j = k * 64 + lane; bool keep = false; int lv = 0; unsigned char gc = 0, sc = 0;
-                        if(j < n1) { lv = P.lvl[cur][j]; gc = P.g[cur][j]; sc = P.s[cur][j]; keep = !(lv == -1 && gc == '_' && sc == '_'); }
+                        if(j < n1) { lv = LC::get(P.lvl[cur][j], lvBase); gc = P.g[cur][j]; sc = P.s[cur][j]; keep = !(lv == -1 && gc == '_' && sc == '_'); }
                         const u64 m = __ballot(keep);
-                        if(keep) { const int o = w + __popcll(m & ((1ull << lane) - 1ull)); P.lvl[1 - cur][o] = lv; P.g[1 - cur][o] = gc; P.s[1 - cur][o] = sc; }
+                        if(keep) { const int o = w + __popcll(m & ((1ull << lane) - 1ull)); P.lvl[1 - cur][o] = LC::put(lv, lvBase); P.g[1 - cur][o] = gc; P.s[1 - cur][o] = sc; }
                         w += __popcll(m);
                     }
                     WSYNC();
@@ -427,7 +445,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             for(int k = 0; k < nW; k++) {
                 int j = k * 64 + lane; bool in = false, def = false, sq = false;
                 if(j < n1) {
-                    int l = P.lvl[cur][j]; def = (l != -1); sq = (P.s[cur][j] != '_');
+                    int l = LC::get(P.lvl[cur][j], lvBase); def = (l != -1); sq = (P.s[cur][j] != '_');
                     if(def) { if(l < 0 || l >= G.L - 1) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); else in = G.gap_stretch[l] != 0; }
                 }
                 u64 mg = __ballot(in), md = __ballot(def), ms = __ballot(sq);
@@ -481,8 +499,8 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         int level0 = -1, nb = 0, chCount = 0; ChoiceRec* ch = slabCh;
         int nDef = 0, nodeBase = 0, eBase = 0, nEdges = 0; bool staged = false, par = false, windowed = false, chunked = false; int defCount = 0, nChunks = 0;
         if(PJ_OK()) {
-            level0 = uni(P.lvl[cur][0]);
-            int lastLevel = uni(P.lvl[cur][n1 - 1]);
+            level0 = uni(LC::get(P.lvl[cur][0], lvBase));
+            int lastLevel = uni(LC::get(P.lvl[cur][n1 - 1], lvBase));
             if(level0 < 0 || lastLevel < level0 || lastLevel + 1 >= G.L) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
             else {
                 nDef = lastLevel - level0 + 1;
@@ -513,7 +531,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             for(int j0 = 0; j0 < n1; j0 += 64) {
                 int j = j0 + lane; bool d = false;
                 if(j < n1) {
-                    int l = P.lvl[cur][j];
+                    int l = LC::get(P.lvl[cur][j], lvBase);
                     if(l != -1) {
                         d = true; int li = l - level0;
                         if(li >= 0 && li < nDef) { u32 sc = P.s[cur][j], gc = P.g[cur][j]; P.colInfo[li] = (u32)j | (sc << 16) | ((sc == gc ? 1u : 0u) << 24); }
@@ -671,7 +689,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 }
             } else if(!par) {
                 for(int j = 0; j < n1; j++) {
-                    int l = uni(P.lvl[cur][j]);
+                    int l = uni(LC::get(P.lvl[cur][j], lvBase));
                     if(l == -1) continue;                                                     // :2710-2714
                     unsigned char sc = P.s[cur][j], gc = P.g[cur][j];
                     bool seedIsMatch = (sc == gc);
@@ -705,7 +723,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             PJ_T(5);
             // ---------------- backtrace (:2838-3007)
             if(PJ_OK()) {
-                int lastLevel = uni(P.lvl[cur][n1 - 1]);
+                int lastLevel = uni(LC::get(P.lvl[cur][n1 - 1], lvBase));
                 int tb, tm; const short* lastS;
                 if(par) { tb = nodeBase + P.sLev[nDef]; tm = P.sLev[nDef + 1] - P.sLev[nDef]; lastS = Sflat + P.sLev[nDef]; }
                 else { tb = G.level_off[lastLevel + 1]; tm = G.level_off[lastLevel + 2] - tb; lastS = P.Srow[rowP]; }
@@ -719,8 +737,8 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 if(par) {
                     // every segment is traced from its right cut node (the last one from the selected node); the other column
                     // buffer takes the chosen edge per column, then all lanes emit (edge ids are independent HBM reads)
-                    int* pick = P.lvl[1 - cur];
-                    for(int j = lane; j < n1; j += 64) pick[j] = -1;
+                    typename PL::LvT* pick = P.lvl[1 - cur];
+                    for(int j = lane; j < n1; j += 64) pick[j] = LC::pickNone();
                     WSYNC();
                     const int nbR = nb - nodeBase;
                     for(int sg = lane; sg < nSeg; sg += 64) {
@@ -730,16 +748,16 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                     }
                     WSYNC();
                     for(int j = lane; j < n1; j += 64) {
-                        int e = pick[j];
-                        if(e < 0) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
-                        else { B.seed_level[cb + j] = P.lvl[cur][j]; B.seed_edge[cb + j] = G.in_eid[eBase + e]; B.seed_g[cb + j] = P.sLab[e]; }
+                        const typename PL::LvT pe = pick[j]; const int e = (int)pe;
+                        if(LC::pickIsNone(pe)) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
+                        else { B.seed_level[cb + j] = LC::get(P.lvl[cur][j], lvBase); B.seed_edge[cb + j] = G.in_eid[eBase + e]; B.seed_g[cb + j] = P.sLab[e]; }
                         B.seed_s[cb + j] = P.s[cur][j];
                     }
                 } else if(chunked) {
                     // the chunks again, last to first: the back pointers of a chunk's nodes are staged into LDS with coalesced reads, lane 0
                     // follows them there, then all lanes emit
-                    int* pick = P.lvl[1 - cur];
-                    for(int j = lane; j < n1; j += 64) pick[j] = -1;
+                    typename PL::LvT* pick = P.lvl[1 - cur];
+                    for(int j = lane; j < n1; j += 64) pick[j] = LC::pickNone();
                     WSYNC();
                     const int nbR = nb - nodeBase;
                     int z = zsel;
@@ -757,15 +775,15 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         WSYNC();
                     }
                     for(int j = lane; j < n1; j += 64) {
-                        const int e = pick[j];
-                        if(e < 0) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
-                        else { B.seed_level[cb + j] = P.lvl[cur][j]; B.seed_edge[cb + j] = G.in_eid[eBase + e]; B.seed_g[cb + j] = G.in_label[eBase + e]; }
+                        const typename PL::LvT pe = pick[j]; const int e = (int)pe;
+                        if(LC::pickIsNone(pe)) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
+                        else { B.seed_level[cb + j] = LC::get(P.lvl[cur][j], lvBase); B.seed_edge[cb + j] = G.in_eid[eBase + e]; B.seed_g[cb + j] = G.in_label[eBase + e]; }
                         B.seed_s[cb + j] = P.s[cur][j];
                     }
                 } else if(lane == 0) {
                     int node = tb + zsel;
                     for(int j = n1 - 1; j >= 0; j--) {
-                        int l = P.lvl[cur][j];
+                        int l = LC::get(P.lvl[cur][j], lvBase);
                         if(l == -1) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; B.seed_s[cb + j] = P.s[cur][j]; continue; }
                         ChoiceRec cr = ch[node - nb];
                         B.seed_level[cb + j] = l; B.seed_edge[cb + j] = cr.eid; B.seed_g[cb + j] = G.edge_label[cr.eid]; B.seed_s[cb + j] = P.s[cur][j];
