@@ -8,6 +8,7 @@ knows (the reference's own accuracy metric: fraction of read bases placed on the
 DP capacity classes exercised, and the same truth metric for the product.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -217,3 +218,41 @@ def test_two_batches_in_flight_equal_one_at_a_time(pkg, oracle):
         if rnd == 1:
             gbs[0].align()                             # re-align a batch whose previous tail may still be running
             assert all(np.array_equal(gbs[0].pairs()[name], v) for name, v in ref[0].items())
+
+
+@pytest.mark.gpu
+def test_a_sample_streamed_in_batches_equals_the_whole_sample(pkg, oracle, world_m):
+    """BASELINE config 3 in small: one sample goes through ONE context in five batches of different sizes, two in flight, each batch destroyed once it
+    has been fetched (its buffers go back to the context's pool and serve the next one).  With hlala_batch_set_first_chain every batch draws the
+    random seeds of the unsplit run: each slice equals the oracle's result for the whole sample, array by array."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("d", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hla-la_amd", "dist.py"))
+    pkg_dist = importlib.util.module_from_spec(spec); spec.loader.exec_module(pkg_dist)
+    b = synth.make_batch_m(world_m, 2600, seed=41, frac_gene=0.4)
+    kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=7, max_columns=384)
+    exp = oracle(world_m["graph"], world_m["contigs"], **kw).align_batch(b)["pairs"]
+    ctx = pkg.Context(world_m["graph"], world_m["contigs"], **kw)
+    cuts = [0, 700, 1100, 1900, 2050, 2600]
+
+    def start(i):
+        sub, p0, c0 = pkg_dist.shard_pairs_range(b, cuts[i], cuts[i + 1])
+        gb = ctx.batch(sub); gb.set_first_chain(c0); gb.align()
+        return gb, p0, c0
+
+    cur = start(0)
+    for i in range(len(cuts) - 1):
+        nxt = start(i + 1) if i + 2 < len(cuts) else None          # the next batch is aligned before this one is fetched
+        gb, p0, c0 = cur
+        got = gb.pairs(); n = cuts[i + 1] - cuts[i]; stride = 384
+        for k in ("pair_status", "n_combinations", "strands_valid"):
+            assert np.array_equal(got[k], exp[k][p0:p0 + n]), (i, k)
+        bc = exp["best_chain"][2 * p0:2 * (p0 + n)]
+        assert np.array_equal(got["best_chain"], np.where(bc >= 0, bc - c0, bc)), (i, "best_chain")      # chain indices are batch-relative
+        for k in ("n_cols",):
+            assert np.array_equal(got[k], exp[k][2 * p0:2 * (p0 + n)]), (i, k)
+        for k in ("col_level", "col_edge", "col_gchar", "col_schar", "col_mapq"):
+            assert np.array_equal(got[k], exp[k][2 * p0 * stride:2 * (p0 + n) * stride]), (i, k)
+        assert np.allclose(got["pair_ll"], exp["pair_ll"][p0:p0 + n], rtol=1e-12, atol=0)
+        assert gb.stats().n_errors == 0
+        gb.close()
+        cur = nxt
