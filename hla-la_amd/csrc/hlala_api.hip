@@ -330,8 +330,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->ext_grid = cus * 20;
     c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();
     c->retry_grid = cus;
-    c->broad_grid = cus * 2;         // two DpBroad blocks per CU, slabs of the large layout
-    c->wide_grid = cus * 6;          // LDS: six DpWide blocks per CU (26 KB each); slabs of the 64-lane layout
+    c->broad_grid = cus * 3;         // three DpBroad blocks per CU (48 KB of LDS each), slabs of the large layout
+    c->wide_grid = cus * 7;          // LDS: seven DpWide blocks per CU (22 KB each); slabs of the 64-lane layout
     c->stitch_grid = cus * 32;
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpWide>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpWide>();
     c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / two blocks per CU: a few MB each

@@ -75,7 +75,7 @@ constexpr int DP_SORT_SCRATCH = 8192;       // (key, payload) pairs of the in-me
 struct DpState {
     int itemIdx;                                          // index into the item list (kept for a requeue)
     int item, rOff, seqLen, start_seq, startLevel, startNode;
-    int d, b1, b2, bn, n1, n2, nCells, nCompleted, curMax, firstMaxSlot, lastInc, earlyInit, itersRun, diagonals;
+    int d, b1, b2, n1, n2, nCells, nCompleted, curMax, firstMaxSlot, lastInc, earlyInit, itersRun, diagonals;
     int earlyMaxNat;                                      // largest natural diagonal |dx|+|dy| among the cells that were created ahead of it
     u32 cellsEvaluated;
     int endSlot, endScore, nSteps, nCols;
@@ -92,9 +92,11 @@ struct __align__(16) DpLdsT {
     u64 hkey[C::HC];
     typename C::Best hbest[3][C::HC];
     typename TlistT<(C::HC <= 256)>::type tlist[C::HC];     // hash entries in use this iteration
-    u64 fkey[3][C::WCAP];
-    typename C::Slot fslot[3][C::WCAP];        // table slot of the frontier cell
-    short fD[3][C::WCAP], fG[3][C::WCAP], fS[3][C::WCAP];
+    // two frontier buffers: the cells of the last diagonal (b1) and of the one before (b2); the new frontier of an iteration is written over b2, whose
+    // cells no candidate and no cached score needs once the targets are evaluated (a third buffer used to hold it: a third of the frontier LDS)
+    u64 fkey[2][C::WCAP];
+    typename C::Slot fslot[2][C::WCAP];        // table slot of the frontier cell
+    short fD[2][C::WCAP], fG[2][C::WCAP], fS[2][C::WCAP];
     typename C::Slot tes[C::HC];    // per target: existing / assigned table slot (-1 = none)
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     typename C::ImpIdx hq[C::HC];   // per hash entry: index of the improvement its cell staged this iteration (all ones = none)
@@ -432,7 +434,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.itemIdx = itemIdx;
         st.item = it.item; st.rOff = it.rOff; st.seqLen = it.seqLen; st.start_seq = it.start_seq; st.startLevel = it.startLevel; st.startNode = it.startNode;
         st.diagonals = it.seqLen + G.L - 1;
-        st.d = 1; st.b1 = 0; st.b2 = 1; st.bn = 2; st.n1 = 1; st.n2 = 0; st.nCells = 1; st.nCompleted = 0;
+        st.d = 1; st.b1 = 0; st.b2 = 1; st.n1 = 1; st.n2 = 0; st.nCells = 1; st.nCompleted = 0;
         st.curMax = 0; st.firstMaxSlot = 0; st.lastInc = 0; st.earlyInit = 0; st.earlyMaxNat = -1; st.itersRun = 0;
         st.cellsEvaluated = 0;
         st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
@@ -466,7 +468,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     const int limitY = fwd ? seqLen : 0;
     const int d = guni<GW>(st.d);
     const int n1 = guni<GW>(st.n1), n2 = guni<GW>(st.n2);
-    const int b1 = guni<GW>(st.b1), b2 = guni<GW>(st.b2), bn = guni<GW>(st.bn);
+    const int b1 = guni<GW>(st.b1), b2 = guni<GW>(st.b2), bn = b2;       // (bn: where the new frontier goes)
     const int lastInc0 = guni<GW>(st.lastInc), diagonals = guni<GW>(st.diagonals);
     const uint8_t* seqp = readBases + guni<GW>(st.rOff);
 
@@ -828,13 +830,11 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         }
         if(nImp) {
             DSYNC();
-            // cached copies of the improved cells in the two frontiers: a frontier cell that was improved is a target of this iteration
-            for(int w = 0; w < 2; w++) {
-                const int bb = w ? b2 : b1, nn = w ? n2 : n1;
-                for(int i = gl; i < nn; i += GW) {
-                    const int ph = dp_find<C>(S, S.fkey[bb][i]);
-                    if(ph >= 0) { const int q = (int)S.hq[ph]; if(q < C::IMPCAP && q < nImp) { S.fD[bb][i] = sl.imp_new()[4 * q + 0]; S.fG[bb][i] = sl.imp_new()[4 * q + 1]; S.fS[bb][i] = sl.imp_new()[4 * q + 2]; } }
-                }
+            // cached copies of the improved cells in the frontier that lives on (b1; b2 is about to be overwritten): a frontier cell that was improved is
+            // a target of this iteration
+            for(int i = gl; i < n1; i += GW) {
+                const int ph = dp_find<C>(S, S.fkey[b1][i]);
+                if(ph >= 0) { const int q = (int)S.hq[ph]; if(q < C::IMPCAP && q < nImp) { S.fD[b1][i] = sl.imp_new()[4 * q + 0]; S.fG[b1][i] = sl.imp_new()[4 * q + 1]; S.fS[b1][i] = sl.imp_new()[4 * q + 2]; } }
             }
         }
     }
@@ -930,7 +930,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     DSYNC();
     if(!wideSort) for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; S.hkey[h] = HKEY_EMPTY; S.hbest[0][h] = 0; S.hbest[1][h] = 0; S.hbest[2][h] = 0; }
     if(gl == 0) {
-        st.b2 = b1; st.b1 = bn; st.bn = b2;                                                   // m2 := m1; m1 := this, :1104-1105
+        st.b2 = b1; st.b1 = bn;                                                               // m2 := m1; m1 := this, :1104-1105
         st.n2 = n1; st.n1 = nNew;
         st.d = d + 1; st.itersRun = d;
         st.nCells = nCells; st.nCompleted = nCompletedNew; st.earlyInit = earlyInit; st.earlyMaxNat = earlyMaxNat;
