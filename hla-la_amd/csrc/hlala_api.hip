@@ -334,7 +334,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->wide_grid = cus * 7;          // LDS: seven DpWide blocks per CU (22 KB each); slabs of the 64-lane layout
     c->stitch_grid = cus * 32;
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpWide>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpWide>();
-    c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / two blocks per CU: a few MB each
+    c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / three blocks per CU: a few MB each
     c->huge_grid = cus / 4 > 0 ? cus / 4 : 1;      // the in-memory backstop class: a handful of DP calls per million pairs
     c->huge_slab_bytes = dp_inmemory_bytes<DpHuge>();
     if((rc = slab_pool(&c->tiny_slabs, c->tiny_slab_bytes * (size_t)(64 / DpTiny::GW) * (size_t)c->tiny_grid, "16-lane DP slabs"))) return fail(rc);
