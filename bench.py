@@ -47,12 +47,17 @@ def load_package():
 
 
 def kernel_source_hash():
-    """sha1 over the kernel / API sources: measurements kept under profiles/ are tagged with it and dropped when it differs."""
+    """sha1 over the kernel / API sources (line comments and blank lines left out: a reworded comment is not a new kernel): measurements kept
+    under profiles/ are tagged with it and dropped when it differs."""
+    import re
     h = hashlib.sha1()
     d = os.path.join(ROOT, "hla-la_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h", ".hpp")):
-            h.update(open(os.path.join(d, f), "rb").read())
+            for line in open(os.path.join(d, f), "r", errors="replace"):
+                code = re.sub(r"//.*$", "", line).strip()
+                if code:
+                    h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 
