@@ -307,12 +307,13 @@ template <class C> __device__ __forceinline__ int best_order(u64 b) { return 0x7
 // push one candidate (Alt::{D,GG,SG}.push_back in the reference) -- returns false on hash overflow.
 // One LDS round trip per probe: the compare-and-swap both claims an empty entry and reports the resident key.
 template <class C>
-__device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int order)
+__device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int order, int& claimedAt)      // claimedAt: the entry, if this push took a free one
 {
     u32 h = tgt_hash<C>(key);
 #pragma nounroll
     for(int probe = 0; probe < C::HC; probe++) {
         u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
+        if(old == HKEY_EMPTY) claimedAt = (int)h;
         if(old == HKEY_EMPTY || old == key) { typename C::Best v; pack_best<C>(v, score, order); atomicMax(&S.hbest[mat][h], v); return true; }
         h = (h + 1) & (C::HC - 1);
     }
@@ -321,12 +322,13 @@ __device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int or
 
 // continue the probe sequence of a claim that found a different key at its home entry; returns HC when the hash is full
 template <class C>
-__device__ inline u32 dp_probe(DpLdsT<C>& S, u64 key, u32 h)
+__device__ inline u32 dp_probe(DpLdsT<C>& S, u64 key, u32 h, bool& claimed)
 {
 #pragma nounroll
     for(int probe = 1; probe < C::HC; probe++) {
         h = (h + 1) & (C::HC - 1);
         u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
+        if(old == HKEY_EMPTY) claimed = true;
         if(old == HKEY_EMPTY || old == key) return h;
     }
     return (u32)C::HC;
@@ -502,6 +504,18 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     const int* joff = fwd ? G.jf_off : G.jb_off; const int* jnode = fwd ? G.jf_node : G.jb_node; const int* jlvl = fwd ? G.jf_lvl : G.jb_lvl;
     int edges = 0;      // (the direction is wave-uniform: these are scalar selects)
     const int nMax = n1 > n2 ? n1 : n2;
+    // One wave per DP and a table of 512+ entries: the list of this iteration's targets is written as the entries are claimed (wave ballot, running count
+    // in a register) instead of being collected from the table afterwards -- 8 .. 256 rounds over mostly empty entries.  Its order is arbitrary either way.
+    constexpr bool APPEND = (GW == 64) && (C::WCAP > 64);
+    typedef typename TlistT<(C::HC <= 256)>::type TlT;
+    int nTa = 0;
+    auto append = [&](const bool claimed, const u32 h) {
+        if constexpr (APPEND) {
+            const u64 m = __ballot(claimed);
+            if(claimed) S.tlist[nTa + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (TlT)h;
+            nTa += __popcll(m);
+        }
+    };
     for(int i = gl; i < nMax; i += GW) {
         // ---- round 0: frontier entries (LDS)
         const bool hasA = i < n2, hasB = i < n1;
@@ -538,9 +552,14 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             cv[2] = hasB && nyG >= 0 && nyG <= max_seqI; ck[2] = mk_key(pxB, nyG, nodeB);
 #pragma unroll
             for(int q = 0; q < 3; q++) { ch[q] = tgt_hash<C>(ck[q]); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
+            bool cl[3];
 #pragma unroll
-            for(int q = 0; q < 3; q++)
-                if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
+            for(int q = 0; q < 3; q++) {
+                cl[q] = cv[q] && cold[q] == HKEY_EMPTY;
+                if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q], cl[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; cl[q] = false; } }
+            }
+#pragma unroll
+            for(int q = 0; q < 3; q++) append(cl[q], ch[q]);
             if(cv[0]) { BestT v; pack_best<C>(v, pDA + (labA0 == rc ? 2 : -5), (i << 8) | 0); atomicMax(&S.hbest[M_D][ch[0]], v); }
             if(cv[1]) { BestT v; pack_best<C>(v, pDA + (labA1 == rc ? 2 : -5), (i << 8) | 1); atomicMax(&S.hbest[M_D][ch[1]], v); }
             if(cv[2]) { BestT v, w; pack_best<C>(v, pD - 6, ord0 | 0); if(pG != DP_NEG) { pack_best<C>(w, pG - 2, ord0 | 1); if(w > v) v = w; } atomicMax(&S.hbest[M_GG][ch[2]], v); }
@@ -552,9 +571,14 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             cv[2] = okB && j1 > j0 && jx0 >= 0 && jx0 <= max_levelI; ck[2] = mk_key(jx0, pyB, jn0);
 #pragma unroll
             for(int q = 0; q < 3; q++) { ch[q] = tgt_hash<C>(ck[q]); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
+            bool cl[3];
 #pragma unroll
-            for(int q = 0; q < 3; q++)
-                if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
+            for(int q = 0; q < 3; q++) {
+                cl[q] = cv[q] && cold[q] == HKEY_EMPTY;
+                if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q], cl[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; cl[q] = false; } }
+            }
+#pragma unroll
+            for(int q = 0; q < 3; q++) append(cl[q], ch[q]);
 #pragma unroll
             for(int kk = 0; kk < 2; kk++) {
                 const unsigned char lab = kk ? labB1 : labB0;
@@ -573,26 +597,62 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         }
         if(okA) edges += degA;
         if(sgB) edges += degB;
-        // ---- the rest of wide nodes: edges 2.. and jumps 1.., read from the CSR arrays
-        if(okA) for(int k = 2; k < degA; k++) {
-            int tn = eto[a0 + k]; unsigned char lab = elab[a0 + k];
-            if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | k)) S.err = __LINE__;
-        }
-        if(sgB) for(int kk = 2; kk < degB; kk++) {
-            int tn = eto[e0 + kk]; unsigned char lab = elab[e0 + kk];
-            u64 k = mk_key(nxB, pyB, tn);
-            if(lab != '_') {
-                if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
-                if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
-            } else {
-                if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
-                if(!dp_push<C>(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;
+        // ---- the rest of wide nodes: edges 2.. and jumps 1.., read from the CSR arrays.  (With the claim-time target list the loops run to the
+        // largest count among the lanes, so that every lane takes part in the ballots.)
+        if constexpr (APPEND) {
+            for(int k = 2; __ballot(okA && k < degA) != 0; k++) {
+                int at = -1;
+                if(okA && k < degA) {
+                    int tn = eto[a0 + k]; unsigned char lab = elab[a0 + k];
+                    if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | k, at)) S.err = __LINE__;
+                }
+                append(at >= 0, (u32)at);
             }
-        }
-        if(okB) for(int j = j0 + 1; j < j1; j++) {
-            int tn = jnode[j]; int jx = jlvl[j];
-            if(jx < 0 || jx > max_levelI) continue;
-            if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)))) S.err = __LINE__;
+            for(int kk = 2; __ballot(sgB && kk < degB) != 0; kk++) {
+                int at = -1;
+                if(sgB && kk < degB) {
+                    int tn = eto[e0 + kk]; unsigned char lab = elab[e0 + kk];
+                    u64 k = mk_key(nxB, pyB, tn);
+                    if(lab != '_') {
+                        if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk), at)) S.err = __LINE__;
+                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1), at)) S.err = __LINE__;
+                    } else {
+                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1), at)) S.err = __LINE__;
+                        if(!dp_push<C>(S, k, M_D, pD, ord0 | kk, at)) S.err = __LINE__;
+                    }
+                }
+                append(at >= 0, (u32)at);
+            }
+            for(int j = j0 + 1; __ballot(okB && j < j1) != 0; j++) {
+                int at = -1;
+                if(okB && j < j1) {
+                    int tn = jnode[j]; int jx = jlvl[j];
+                    if(!(jx < 0 || jx > max_levelI)) if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)), at)) S.err = __LINE__;
+                }
+                append(at >= 0, (u32)at);
+            }
+        } else {
+            int at = -1;
+            if(okA) for(int k = 2; k < degA; k++) {
+                int tn = eto[a0 + k]; unsigned char lab = elab[a0 + k];
+                if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | k, at)) S.err = __LINE__;
+            }
+            if(sgB) for(int kk = 2; kk < degB; kk++) {
+                int tn = eto[e0 + kk]; unsigned char lab = elab[e0 + kk];
+                u64 k = mk_key(nxB, pyB, tn);
+                if(lab != '_') {
+                    if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk), at)) S.err = __LINE__;
+                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1), at)) S.err = __LINE__;
+                } else {
+                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1), at)) S.err = __LINE__;
+                    if(!dp_push<C>(S, k, M_D, pD, ord0 | kk, at)) S.err = __LINE__;
+                }
+            }
+            if(okB) for(int j = j0 + 1; j < j1; j++) {
+                int tn = jnode[j]; int jx = jlvl[j];
+                if(jx < 0 || jx > max_levelI) continue;
+                if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)), at)) S.err = __LINE__;
+            }
         }
     }
     edgesAcc += edges;
@@ -600,7 +660,8 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     DP_TQ(5);
     // target list = occupied hash entries, compacted with a ballot per GW entries (no per-push counter, no ordering assumed)
     int nT = 0;
-    if constexpr (C::IN_MEMORY) {
+    if constexpr (APPEND) nT = __builtin_amdgcn_readfirstlane(nTa);       // (lane 0 has been through every round of the loop above)
+    else if constexpr (C::IN_MEMORY) {
         // (the table is in HBM: four independent loads per lane and trip instead of one)
         for(int h0 = 0; h0 < C::HC; h0 += 4 * GW) {
             u64 kk[4];
