@@ -320,7 +320,33 @@ __device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int or
     return false;
 }
 
+// (the classes that collect their target list from the table afterwards have no use for the claim)
+template <class C>
+__device__ inline bool dp_push(DpLdsT<C>& S, u64 key, int mat, int score, int order)
+{
+    u32 h = tgt_hash<C>(key);
+#pragma nounroll
+    for(int probe = 0; probe < C::HC; probe++) {
+        u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
+        if(old == HKEY_EMPTY || old == key) { typename C::Best v; pack_best<C>(v, score, order); atomicMax(&S.hbest[mat][h], v); return true; }
+        h = (h + 1) & (C::HC - 1);
+    }
+    return false;
+}
+
 // continue the probe sequence of a claim that found a different key at its home entry; returns HC when the hash is full
+template <class C>
+__device__ inline u32 dp_probe(DpLdsT<C>& S, u64 key, u32 h)
+{
+#pragma nounroll
+    for(int probe = 1; probe < C::HC; probe++) {
+        h = (h + 1) & (C::HC - 1);
+        u64 old = atomicCAS(&S.hkey[h], HKEY_EMPTY, key);
+        if(old == HKEY_EMPTY || old == key) return h;
+    }
+    return (u32)C::HC;
+}
+// ... reporting whether the entry was free (claim-time target list)
 template <class C>
 __device__ inline u32 dp_probe(DpLdsT<C>& S, u64 key, u32 h, bool& claimed)
 {
@@ -552,14 +578,20 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             cv[2] = hasB && nyG >= 0 && nyG <= max_seqI; ck[2] = mk_key(pxB, nyG, nodeB);
 #pragma unroll
             for(int q = 0; q < 3; q++) { ch[q] = tgt_hash<C>(ck[q]); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
-            bool cl[3];
+            if constexpr (APPEND) {
+                bool cl[3];
 #pragma unroll
-            for(int q = 0; q < 3; q++) {
-                cl[q] = cv[q] && cold[q] == HKEY_EMPTY;
-                if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q], cl[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; cl[q] = false; } }
+                for(int q = 0; q < 3; q++) {
+                    cl[q] = cv[q] && cold[q] == HKEY_EMPTY;
+                    if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q], cl[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; cl[q] = false; } }
+                }
+#pragma unroll
+                for(int q = 0; q < 3; q++) append(cl[q], ch[q]);
+            } else {
+#pragma unroll
+                for(int q = 0; q < 3; q++)
+                    if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
             }
-#pragma unroll
-            for(int q = 0; q < 3; q++) append(cl[q], ch[q]);
             if(cv[0]) { BestT v; pack_best<C>(v, pDA + (labA0 == rc ? 2 : -5), (i << 8) | 0); atomicMax(&S.hbest[M_D][ch[0]], v); }
             if(cv[1]) { BestT v; pack_best<C>(v, pDA + (labA1 == rc ? 2 : -5), (i << 8) | 1); atomicMax(&S.hbest[M_D][ch[1]], v); }
             if(cv[2]) { BestT v, w; pack_best<C>(v, pD - 6, ord0 | 0); if(pG != DP_NEG) { pack_best<C>(w, pG - 2, ord0 | 1); if(w > v) v = w; } atomicMax(&S.hbest[M_GG][ch[2]], v); }
@@ -571,14 +603,20 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             cv[2] = okB && j1 > j0 && jx0 >= 0 && jx0 <= max_levelI; ck[2] = mk_key(jx0, pyB, jn0);
 #pragma unroll
             for(int q = 0; q < 3; q++) { ch[q] = tgt_hash<C>(ck[q]); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
-            bool cl[3];
+            if constexpr (APPEND) {
+                bool cl[3];
 #pragma unroll
-            for(int q = 0; q < 3; q++) {
-                cl[q] = cv[q] && cold[q] == HKEY_EMPTY;
-                if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q], cl[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; cl[q] = false; } }
+                for(int q = 0; q < 3; q++) {
+                    cl[q] = cv[q] && cold[q] == HKEY_EMPTY;
+                    if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q], cl[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; cl[q] = false; } }
+                }
+#pragma unroll
+                for(int q = 0; q < 3; q++) append(cl[q], ch[q]);
+            } else {
+#pragma unroll
+                for(int q = 0; q < 3; q++)
+                    if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
             }
-#pragma unroll
-            for(int q = 0; q < 3; q++) append(cl[q], ch[q]);
 #pragma unroll
             for(int kk = 0; kk < 2; kk++) {
                 const unsigned char lab = kk ? labB1 : labB0;
@@ -632,26 +670,25 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 append(at >= 0, (u32)at);
             }
         } else {
-            int at = -1;
             if(okA) for(int k = 2; k < degA; k++) {
                 int tn = eto[a0 + k]; unsigned char lab = elab[a0 + k];
-                if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | k, at)) S.err = __LINE__;
+                if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | k)) S.err = __LINE__;
             }
             if(sgB) for(int kk = 2; kk < degB; kk++) {
                 int tn = eto[e0 + kk]; unsigned char lab = elab[e0 + kk];
                 u64 k = mk_key(nxB, pyB, tn);
                 if(lab != '_') {
-                    if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk), at)) S.err = __LINE__;
-                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1), at)) S.err = __LINE__;
+                    if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
+                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
                 } else {
-                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1), at)) S.err = __LINE__;
-                    if(!dp_push<C>(S, k, M_D, pD, ord0 | kk, at)) S.err = __LINE__;
+                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
+                    if(!dp_push<C>(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;
                 }
             }
             if(okB) for(int j = j0 + 1; j < j1; j++) {
                 int tn = jnode[j]; int jx = jlvl[j];
                 if(jx < 0 || jx > max_levelI) continue;
-                if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)), at)) S.err = __LINE__;
+                if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)))) S.err = __LINE__;
             }
         }
     }
