@@ -51,10 +51,11 @@ class GraphInfo(C.Structure):
 
 
 class BatchIn(C.Structure):
-    _fields_ = [("n_pairs", C.c_int32), ("read_off", c_i32p), ("read_bases", c_u8p), ("read_quals", c_u8p),
-                ("chain_off", c_i32p), ("read_primary", c_i32p), ("n_chains", C.c_int32),
+    # (64-bit offsets: a batch is a window into the arrays of a sample, include/hlala_gpu.h)
+    _fields_ = [("n_pairs", C.c_int32), ("read_off", c_i64p), ("read_bases", c_u8p), ("read_quals", c_u8p),
+                ("chain_off", c_i64p), ("read_primary", c_i32p), ("n_chains", C.c_int32),
                 ("chain_contig", c_i32p), ("chain_pos", c_i32p), ("chain_offset", c_i32p), ("chain_as", c_i32p),
-                ("chain_reverse", c_u8p), ("cigar_off", c_i32p), ("cigar", c_u32p)]
+                ("chain_reverse", c_u8p), ("cigar_off", c_i64p), ("cigar", c_u32p)]
 
 
 class SeedsIn(C.Structure):
@@ -241,33 +242,94 @@ class BamInterval(C.Structure):
     _fields_ = [("ref_name", C.c_char_p), ("start_0based", C.c_int32), ("stop_0based", C.c_int32), ("contig", C.c_int32)]
 
 
-def bam_extract_seeds(lib, path, intervals, long_read_mode=False):
-    """hlala_bam_extract_seeds: intervals = [(ref name, start_0based, stop_0based, contig index)]; returns (batch dict, read names, counts)."""
+class SeedBatch:
+    """hlala_seed_batch handle: the seeds of a whole sample (64-bit offsets) as decoded from a BAM file."""
+
+    def __init__(self, lib, h, long_read_mode):
+        self.lib, self.h, self.long_read_mode = lib, h, bool(long_read_mode)
+        lib.hlala_seed_batch_units.argtypes = [C.c_void_p]; lib.hlala_seed_batch_units.restype = C.c_int64
+        lib.hlala_seed_batch_window.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(BatchIn)]
+        lib.hlala_seed_batch_name.argtypes = [C.c_void_p, C.c_int64]; lib.hlala_seed_batch_name.restype = C.c_char_p
+        lib.hlala_seed_batch_free.argtypes = [C.c_void_p]; lib.hlala_seed_batch_free.restype = None
+        lib.hlala_seed_batch_timing.argtypes = [C.c_void_p, c_f64p, c_i32p]
+        lib.hlala_seed_batch_desc.argtypes = [C.c_void_p, C.POINTER(BatchIn), C.POINTER(C.c_int64)]
+        self.n_units = int(lib.hlala_seed_batch_units(h))
+        cnt = (C.c_int64 * 3)(); d = BatchIn()
+        if self.n_units <= 0x7FFFFFFF:
+            lib.hlala_seed_batch_desc(h, C.byref(d), cnt)
+        self.counts = dict(examined=int(cnt[0]), seeds=int(cnt[1]), incomplete=int(cnt[2]))
+
+    def window(self, first_unit, n_units) -> "BatchIn":
+        """units [first_unit, first_unit + n_units) as a batch descriptor pointing into the handle (no copy; valid while the handle lives)"""
+        d = BatchIn()
+        if self.lib.hlala_seed_batch_window(self.h, int(first_unit), int(n_units), C.byref(d)) != 0:
+            raise HlalaError(self.lib.hlala_bam_last_error().decode(errors="replace"))
+        return d
+
+    def to_dict(self, first_unit=0, n_units=None):
+        """a window copied into numpy arrays with offsets starting at 0 (the layout the tests and the oracle binding use); first_chain = its first absolute chain"""
+        n = self.n_units - first_unit if n_units is None else n_units
+        d = self.window(first_unit, n)
+        nr = n * (1 if self.long_read_mode else 2); nc = d.n_chains
+
+        def arr(ptr, off, cnt, dt):
+            if cnt == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(ptr, (off + cnt,))[off:off + cnt].astype(dt).copy()
+        ro = arr(d.read_off, 0, nr + 1, np.int64); co = arr(d.chain_off, 0, nr + 1, np.int64)
+        r0, c0 = int(ro[0]), int(co[0])
+        go = arr(d.cigar_off, c0, nc + 1, np.int64); g0 = int(go[0])
+        return dict(n_pairs=n, read_off=(ro - r0), read_bases=arr(d.read_bases, r0, int(ro[-1]) - r0, np.uint8), read_quals=arr(d.read_quals, r0, int(ro[-1]) - r0, np.uint8),
+                    chain_off=(co - c0), read_primary=arr(d.read_primary, 0, nr, np.int32) - c0, n_chains=nc,
+                    chain_contig=arr(d.chain_contig, c0, nc, np.int32), chain_pos=arr(d.chain_pos, c0, nc, np.int32), chain_offset=arr(d.chain_offset, c0, nc, np.int32),
+                    chain_as=arr(d.chain_as, c0, nc, np.int32), chain_reverse=arr(d.chain_reverse, c0, nc, np.uint8), cigar_off=(go - g0),
+                    cigar=arr(d.cigar, g0, int(go[-1]) - g0, np.uint32), first_chain=c0)
+
+    def names(self, first_unit=0, n_units=None):
+        n = self.n_units - first_unit if n_units is None else n_units
+        return [self.lib.hlala_seed_batch_name(self.h, first_unit + i).decode() for i in range(n)]
+
+    def timing(self):
+        s = np.zeros(6, np.float64); t = np.zeros(1, np.int32)
+        self.lib.hlala_seed_batch_timing(self.h, s.ctypes.data_as(c_f64p), t.ctypes.data_as(c_i32p))
+        return dict(zip(("index", "inflate", "parse", "group", "name_sort", "layout"), [float(x) for x in s]), threads=int(t[0]))
+
+    def pin(self, on=True):
+        self.lib.hlala_seed_batch_pin.argtypes = [C.c_void_p, C.c_int]
+        return self.lib.hlala_seed_batch_pin(self.h, 1 if on else 0) == 0
+
+    def close(self):
+        if self.h:
+            self.lib.hlala_seed_batch_free(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bam_open_seeds(lib, path, intervals, long_read_mode=False, threads=0) -> SeedBatch:
+    """hlala_bam_extract_seeds_mt: intervals = [(ref name, start_0based, stop_0based, contig index)]; returns the handle of the whole sample."""
     arr = (BamInterval * max(1, len(intervals)))()
     for i, (nm, a, b, c) in enumerate(intervals):
         arr[i] = BamInterval(nm.encode(), int(a), int(b), int(c))
     h = C.c_void_p()
-    lib.hlala_bam_extract_seeds.argtypes = [C.c_char_p, C.c_int32, C.POINTER(BamInterval), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.hlala_bam_extract_seeds_mt.argtypes = [C.c_char_p, C.c_int32, C.POINTER(BamInterval), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     lib.hlala_bam_last_error.restype = C.c_char_p
-    if lib.hlala_bam_extract_seeds(str(path).encode(), len(intervals), arr, int(bool(long_read_mode)), C.byref(h)) != 0:
+    if lib.hlala_bam_extract_seeds_mt(str(path).encode(), len(intervals), arr, int(bool(long_read_mode)), int(threads), C.byref(h)) != 0:
         raise HlalaError(lib.hlala_bam_last_error().decode(errors="replace"))
-    d = BatchIn(); cnt = (C.c_int64 * 3)()
-    lib.hlala_seed_batch_desc.argtypes = [C.c_void_p, C.POINTER(BatchIn), C.POINTER(C.c_int64)]
-    lib.hlala_seed_batch_desc(h, C.byref(d), cnt)
-    nu = d.n_pairs; nr = nu * (1 if long_read_mode else 2); nc = d.n_chains
+    return SeedBatch(lib, h, long_read_mode)
 
-    def arr_of(ptr, n, dt):
-        return np.ctypeslib.as_array(ptr, (max(n, 1),))[:n].astype(dt).copy()
-    ro = arr_of(d.read_off, nr + 1, np.int32); co = arr_of(d.cigar_off, nc + 1, np.int32)
-    b = dict(n_pairs=nu, read_off=ro, read_bases=arr_of(d.read_bases, int(ro[-1]), np.uint8), read_quals=arr_of(d.read_quals, int(ro[-1]), np.uint8),
-             chain_off=arr_of(d.chain_off, nr + 1, np.int32), read_primary=arr_of(d.read_primary, nr, np.int32), n_chains=nc,
-             chain_contig=arr_of(d.chain_contig, nc, np.int32), chain_pos=arr_of(d.chain_pos, nc, np.int32), chain_offset=arr_of(d.chain_offset, nc, np.int32),
-             chain_as=arr_of(d.chain_as, nc, np.int32), chain_reverse=arr_of(d.chain_reverse, nc, np.uint8), cigar_off=co, cigar=arr_of(d.cigar, int(co[-1]), np.uint32))
-    lib.hlala_seed_batch_name.argtypes = [C.c_void_p, C.c_int32]; lib.hlala_seed_batch_name.restype = C.c_char_p
-    names = [lib.hlala_seed_batch_name(h, i).decode() for i in range(nu)]
-    lib.hlala_seed_batch_free.argtypes = [C.c_void_p]; lib.hlala_seed_batch_free.restype = None
-    lib.hlala_seed_batch_free(h)
-    return b, names, dict(examined=int(cnt[0]), seeds=int(cnt[1]), incomplete=int(cnt[2]))
+
+def bam_extract_seeds(lib, path, intervals, long_read_mode=False, threads=0):
+    """The whole sample as one batch dict (offsets from 0), the read names and the counters; for samples that fit one batch."""
+    S = bam_open_seeds(lib, path, intervals, long_read_mode, threads)
+    try:
+        b = S.to_dict(); b.pop("first_chain")
+        return b, S.names(), S.counts
+    finally:
+        S.close()
 
 
 def exon_in_from_positions(e, pos_use, cluster_seq, n_clusters, exon_length):
@@ -598,7 +660,8 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_get_stats", "hlala_batch_get_pairs_packed", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
     "hlala_kat_rand_r", "hlala_kat_exp", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
     "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
-    "hlala_bam_extract_seeds", "hlala_seed_batch_desc", "hlala_seed_batch_name", "hlala_seed_batch_free", "hlala_bam_last_error",
+    "hlala_bam_extract_seeds", "hlala_bam_extract_seeds_mt", "hlala_seed_batch_desc", "hlala_seed_batch_window", "hlala_seed_batch_units", "hlala_seed_batch_name", "hlala_seed_batch_timing",
+    "hlala_seed_batch_free", "hlala_seed_batch_pin", "hlala_bam_last_error", "hlala_pinned_alloc", "hlala_pinned_free", "hlala_host_register", "hlala_host_unregister", "hlala_set_insert_size",
     "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
     "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_g_translate", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",

@@ -12,6 +12,7 @@
 #include "../../include/hlala_gpu.h"
 #include "batch.h"
 #include "flat_graph.hpp"
+#include "host_internal.h"
 
 // unity build: the kernels live in their own files but are compiled in this translation unit
 #include "kernel_dp.hip"
@@ -41,8 +42,11 @@ struct hlala_ctx {
     // on this second, low-priority stream, then the second stitch / pairing pass over the pairs that waited for them; the main stream goes on with the
     // pairs they do not concern and, when the caller has more than one batch in flight, with the next batch
     hipStream_t side = nullptr;
-    hipEvent_t evSide[8]{};       // [0] fork point on the main stream; [1] first side-stream class starts; [6] second pairing pass done
-    hipEvent_t evC[7][2]{};       // start / end of each DP class on the stream it ran on
+    // `up` carries the uploads of hlala_batch_create, `rs` everything that only READS a batch or works on caller data (getters, post-processing, exon
+    // positions, typer scoring): neither waits for alignments of OTHER batches queued on the main stream, so a caller with two batches in flight
+    // uploads the next batch and fetches the previous one while the current one is being aligned.  `active` = the stream the helpers use right now.
+    hipStream_t up = nullptr, rs = nullptr, active = nullptr;
+    hipEvent_t evSideTail = nullptr; bool sideTailValid = false;      // end of the last work queued on the side stream: a non-fused launch of the classes that share its slabs waits for it
     hlala_params params{};
     FlatGraph F;
     DevGraph G{};
@@ -64,7 +68,6 @@ struct hlala_ctx {
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     double* pair_scratch = nullptr;   // [2 * pair_grid][PAIR_COMB]: combination tables of the rare pairs with more than PAIR_COMB_LDS combinations (main- and side-stream pass)
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
-    hipEvent_t ev[14]{};          // start/end per stage; [7] / [6] / [9] / [10] / [11] / [12] / [13] / [8] = before DpTiny / after DpTiny / DpMid / DpSmall / DpWide / DpBroad / DpLarge / DpHuge
     int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
     // per-pair post-processing: coverage counters [L-1] and gene intervals
     int* d_cov = nullptr; int n_cov = 0; int* d_gene_first = nullptr; int* d_gene_last = nullptr; int n_genes = 0;
@@ -81,6 +84,11 @@ struct hlala_batch {
     bool side_pending = false;   // ... and hlala_pair_chains has yet to enqueue the second pairing pass behind them
     bool side_inflight = false;  // work of this batch may still be running on the side stream: evDone orders everything that touches the batch after it
     hipEvent_t evDone = nullptr;
+    hipEvent_t evMain = nullptr; bool mainValid = false;      // end of the last work of this batch on the main stream (readers on `rs` wait for it)
+    // timing events of THIS batch (created with its first stage call): ev = start / end per stage, [7] / [6] / [10] / [8] = before the 16-lane class / after it /
+    // after the 64-lane class / after the last class; evC = start / end of each DP class on the stream it ran on; evSide[0] fork point on the main stream,
+    // [1] first side-stream class starts, [6] second pairing pass done
+    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; bool eventsMade = false;
     uint32_t first_chain = 0;    // absolute index of the batch's chain 0 in the caller's numbering (hlala_batch_set_first_chain): offsets the random seeds
     float ms[3] = {0, 0, 0};
 };
@@ -98,6 +106,50 @@ struct DevGuard {
 #define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HLALA_E_DEVICE; } } while(0)
 // the same inside a function that owns temporaries or a half-built object: `cleanup` (a lambda int -> int) releases them and passes the code through
 #define HIP_TRY_F(ctx, call, cleanup) do { hipError_t e_ = (call); if(e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return cleanup(HLALA_E_DEVICE); } } while(0)
+
+// everything on the main stream that reads or rewrites a batch goes behind the side-stream work of its last fused alignment
+static int join_side(hlala_ctx* c, hlala_batch* b)
+{
+    if(b->side_inflight) { HIP_TRY(c, hipStreamWaitEvent(c->stream, b->evDone, 0)); b->side_inflight = false; }
+    return HLALA_OK;
+}
+static int batch_events(hlala_ctx* c, hlala_batch* b)
+{
+    if(b->eventsMade) return HLALA_OK;
+    for(int i = 0; i < 14; i++) HIP_TRY(c, hipEventCreate(&b->ev[i]));
+    for(int i = 0; i < 8; i++) HIP_TRY(c, hipEventCreate(&b->evSide[i]));
+    for(int i = 0; i < 14; i++) HIP_TRY(c, hipEventCreate(&b->evC[i / 2][i % 2]));
+    HIP_TRY(c, hipEventCreateWithFlags(&b->evMain, hipEventDisableTiming));
+    b->eventsMade = true;
+    return HLALA_OK;
+}
+static int mark_main(hlala_ctx* c, hlala_batch* b)       // end of a stage call: what readers of the batch on the reader stream wait for
+{
+    HIP_TRY(c, hipEventRecord(b->evMain, c->stream)); b->mainValid = true;
+    return HLALA_OK;
+}
+// A call that only reads a batch (or works on caller data) runs on the context's reader stream, behind the batch's own work on the main and the side
+// stream -- not behind whatever the caller queued for other batches since.  (Calls on one context are serialised by the caller: `active` is plain state.)
+struct ReaderScope {
+    hlala_ctx* c; int rc = HLALA_OK;
+    ReaderScope(hlala_ctx* c_, hlala_batch* b) : c(c_)
+    {
+        if(!c) return;
+        c->active = c->rs;
+        hipError_t e = hipSuccess;
+        if(b && b->mainValid) e = hipStreamWaitEvent(c->rs, b->evMain, 0);
+        if(e == hipSuccess && b && b->side_inflight) e = hipStreamWaitEvent(c->rs, b->evDone, 0);
+        if(e != hipSuccess) { c->err = std::string("hipStreamWaitEvent: ") + hipGetErrorString(e); rc = HLALA_E_DEVICE; }
+    }
+    ~ReaderScope() { if(c) c->active = c->stream; }
+    ReaderScope(const ReaderScope&) = delete; ReaderScope& operator=(const ReaderScope&) = delete;
+};
+struct UploadScope {
+    hlala_ctx* c;
+    explicit UploadScope(hlala_ctx* c_) : c(c_) { if(c) c->active = c->up; }
+    ~UploadScope() { if(c) c->active = c->stream; }
+    UploadScope(const UploadScope&) = delete; UploadScope& operator=(const UploadScope&) = delete;
+};
 
 // hipMalloc, or a block of a destroyed batch that is large enough and wastes at most a quarter
 static int pool_malloc(hlala_ctx* c, void** out, size_t bytes)
@@ -138,7 +190,7 @@ static int dev_upload(hlala_ctx* c, std::vector<void*>& allocs, const T* host, s
     void* p = nullptr;
     { int rc_ = pool_malloc(c, &p, bytes); if(rc_) return rc_; }
     allocs.push_back(p);
-    if(n && host) HIP_TRY(c, hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    if(n && host) HIP_TRY(c, hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c->active));
     *out = (T*)p;
     return 0;
 }
@@ -150,7 +202,7 @@ static int dev_alloc(hlala_ctx* c, std::vector<void*>& allocs, size_t n, T** out
     void* p = nullptr;
     { int rc_ = pool_malloc(c, &p, bytes); if(rc_) return rc_; }
     allocs.push_back(p);
-    if(zero) HIP_TRY(c, hipMemsetAsync(p, 0, bytes, c->stream));
+    if(zero) HIP_TRY(c, hipMemsetAsync(p, 0, bytes, c->active));
     *out = (T*)p;
     return 0;
 }
@@ -242,7 +294,7 @@ template <class T>
 static int dl(hlala_ctx* c, T* host, const T* dev, size_t n)
 {
     if(!host || !n) return 0;
-    HIP_TRY(c, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c->active));
     return 0;
 }
 
@@ -261,7 +313,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
         return HLALA_E_DEVICE;
     }
     hlala_ctx* c = new hlala_ctx();
-    c->device = device; c->stream = (hipStream_t)stream; c->params = *params;
+    c->device = device; c->stream = (hipStream_t)stream; c->active = c->stream; c->params = *params;
     auto fail = [&](int rc) { g_create_error = c->err; hlala_destroy(c); return rc; };
     if(c->params.max_columns < 16 || c->params.max_columns > 65536) { c->err = "params.max_columns out of range"; return fail(HLALA_E_ARG); }
     DevGuard dev_guard_(device);       // the caller's current device is restored on return
@@ -322,7 +374,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     auto slab_pool = [&](char** out, size_t bytes, const char* what) -> int {
         if(hipMalloc((void**)out, bytes) != hipSuccess) { c->err = std::string("hipMalloc(") + what + ") failed"; return HLALA_E_DEVICE; }
         c->allocs.push_back(*out);
-        if(hipMemsetAsync(*out, 0, bytes, c->stream) != hipSuccess) { c->err = std::string("hipMemset(") + what + ") failed"; return HLALA_E_DEVICE; }
+        if(hipMemsetAsync(*out, 0, bytes, c->active) != hipSuccess) { c->err = std::string("hipMemset(") + what + ") failed"; return HLALA_E_DEVICE; }
         return 0;
     };
     c->tiny_grid = cus * 16;
@@ -355,12 +407,11 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
-    for(int i = 0; i < 14; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
-    for(int i = 0; i < 8; i++) if(hipEventCreate(&c->evSide[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
-    for(int i = 0; i < 14; i++) if(hipEventCreate(&c->evC[i / 2][i % 2]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    if(hipEventCreateWithFlags(&c->evSideTail, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
+    if(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); }
     { int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);       // (numerically greatest = lowest priority)
       if(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prLow) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); } }
-    if(hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
+    if(hipStreamSynchronize(c->active) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;
 }
@@ -372,10 +423,10 @@ void hlala_destroy(hlala_ctx* c)
     for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(auto& kv : c->pool) (void)hipFree(kv.second);
-    for(int i = 0; i < 14; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for(int i = 0; i < 8; i++) if(c->evSide[i]) (void)hipEventDestroy(c->evSide[i]);
-    for(int i = 0; i < 14; i++) if(c->evC[i / 2][i % 2]) (void)hipEventDestroy(c->evC[i / 2][i % 2]);
     if(c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if(c->up) { (void)hipStreamSynchronize(c->up); (void)hipStreamDestroy(c->up); }
+    if(c->rs) { (void)hipStreamSynchronize(c->rs); (void)hipStreamDestroy(c->rs); }
+    if(c->evSideTail) (void)hipEventDestroy(c->evSideTail);
     delete c;
 }
 
@@ -448,6 +499,7 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
 {
     DEV_GUARD(c);
     if(!c || !in || !out) return HLALA_E_ARG;
+    UploadScope upscope_(c);           // uploads and the zeroing of the outputs run on the upload stream: beside the alignment of an earlier batch
     *out = nullptr;
     if(in->n_pairs < 0 || in->n_chains < 0) { c->err = "negative batch sizes"; return HLALA_E_ARG; }
     if(!c->d_contig_off) { c->err = "hlala_batch_create needs contigs (hlala_create was called without them)"; return HLALA_E_STATE; }
@@ -456,33 +508,52 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
     B.n_pairs = in->n_pairs; B.n_reads = (unpaired ? 1 : 2) * in->n_pairs; B.n_chains = in->n_chains; B.stride = c->params.max_columns; B.from_seeds = 0; B.unpaired = unpaired ? 1 : 0;
     int nr = B.n_reads, nc = B.n_chains;
     auto fail = [&](int rc) { hlala_batch_destroy(b); return rc; };
+    // the batch is a window into the caller's arrays (include/hlala_gpu.h: hlala_batch_in): 64-bit offsets that need not start at 0 are rebased here
+    const int64_t rb0 = nr > 0 ? in->read_off[0] : 0, cb0 = nr > 0 ? in->chain_off[0] : 0;
+    if(nr > 0) {
+        const int64_t nbases64 = in->read_off[nr] - rb0, nc64 = in->chain_off[nr] - cb0;
+        if(nbases64 < 0 || nc64 != (int64_t)nc || cb0 < 0 || rb0 < 0) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
+        if(nbases64 > 0x7FFFFFFFll) { c->err = "batch of " + std::to_string(nbases64) + " read bases: one batch holds at most 2^31 - 1 (cut the sample into more batches: hlala_seed_batch_window)"; return fail(HLALA_E_CAPACITY); }
+    } else if(nc != 0) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
+    const int64_t gb0 = nc > 0 ? in->cigar_off[cb0] : 0;
+    if(nc > 0) { const int64_t ng64 = in->cigar_off[cb0 + nc] - gb0; if(ng64 < 0) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
+                 if(ng64 > 0x7FFFFFFFll) { c->err = "batch of " + std::to_string(ng64) + " CIGAR operations: one batch holds at most 2^31 - 1"; return fail(HLALA_E_CAPACITY); } }
+    b->first_chain = (uint32_t)cb0;
     // validation the reference would assert on
-    if(nr > 0 && (in->read_off[0] != 0 || in->chain_off[0] != 0 || in->chain_off[nr] != nc)) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
-    std::vector<int> chain_read((size_t)nc);
+    std::vector<int> chain_read((size_t)nc), read_off32((size_t)nr + 1), chain_off32((size_t)nr + 1), primary32((size_t)nr), cigar_off32((size_t)nc + 1);
+    for(int r = 0; r < nr; r++) if(in->read_off[r + 1] < in->read_off[r] || in->chain_off[r + 1] < in->chain_off[r]) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
+    for(int r = 0; r <= nr && nr > 0; r++) { read_off32[r] = (int)(in->read_off[r] - rb0); chain_off32[r] = (int)(in->chain_off[r] - cb0); }
     for(int r = 0; r < nr; r++) {
-        if(in->chain_off[r + 1] <= in->chain_off[r]) { c->err = "read without alignments"; return fail(HLALA_E_ARG); }
-        if(in->read_primary[r] < in->chain_off[r] || in->read_primary[r] >= in->chain_off[r + 1]) { c->err = "read_primary outside the read's chains"; return fail(HLALA_E_ARG); }
-        for(int k = in->chain_off[r]; k < in->chain_off[r + 1]; k++) chain_read[k] = r;
+        if(chain_off32[r + 1] <= chain_off32[r]) { c->err = "read without alignments"; return fail(HLALA_E_ARG); }
+        if(read_off32[r + 1] < read_off32[r]) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
+        const int64_t pr = (int64_t)in->read_primary[r] - cb0;
+        if(pr < chain_off32[r] || pr >= chain_off32[r + 1]) { c->err = "read_primary outside the read's chains"; return fail(HLALA_E_ARG); }
+        primary32[r] = (int)pr;
+        for(int k = chain_off32[r]; k < chain_off32[r + 1]; k++) chain_read[k] = r;
     }
-    for(int k = 0; k < nc; k++) if(in->chain_contig[k] < 0 || in->chain_contig[k] >= c->n_contigs) { c->err = "chain_contig out of range"; return fail(HLALA_E_ARG); }
+    for(int k = 0; k < nc; k++) if(in->cigar_off[cb0 + k + 1] < in->cigar_off[cb0 + k]) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
+    for(int k = 0; k <= nc && nc > 0; k++) cigar_off32[k] = (int)(in->cigar_off[cb0 + k] - gb0);
+    const int32_t* w_contig = in->chain_contig + cb0; const int32_t* w_pos = in->chain_pos + cb0; const int32_t* w_offset = in->chain_offset + cb0; const int32_t* w_as = in->chain_as + cb0;
+    const uint8_t* w_rev = in->chain_reverse + cb0;
+    for(int k = 0; k < nc; k++) if(w_contig[k] < 0 || w_contig[k] >= c->n_contigs) { c->err = "chain_contig out of range"; return fail(HLALA_E_ARG); }
     // the extension DP of paired reads keys its cells with a 12-bit read coordinate (kernel_dp.hip: mk_key): longer reads belong in an unpaired batch
-    if(!unpaired) for(int r = 0; r < nr; r++) if(in->read_off[r + 1] - in->read_off[r] > DP_SEQCAP) {
-        c->err = "paired read of " + std::to_string(in->read_off[r + 1] - in->read_off[r]) + " bases: the paired path holds reads of at most " + std::to_string(DP_SEQCAP) + " (use hlala_batch_create_unpaired for long reads)";
+    if(!unpaired) for(int r = 0; r < nr; r++) if(read_off32[r + 1] - read_off32[r] > DP_SEQCAP) {
+        c->err = "paired read of " + std::to_string(read_off32[r + 1] - read_off32[r]) + " bases: the paired path holds reads of at most " + std::to_string(DP_SEQCAP) + " (use hlala_batch_create_unpaired for long reads)";
         return fail(HLALA_E_CAPACITY);
     }
-    size_t nbases = nr ? (size_t)in->read_off[nr] : 0, ncig = nc ? (size_t)in->cigar_off[nc] : 0;
+    size_t nbases = nr ? (size_t)read_off32[nr] : 0, ncig = nc ? (size_t)cigar_off32[nc] : 0;
     int rc = 0;
 #define UPB(field, ptr, n) do { rc = dev_upload(c, b->allocs, (ptr), (n), (std::remove_const<std::remove_pointer<decltype(B.field)>::type>::type**)&B.field); if(rc) return fail(rc); } while(0)
-    UPB(read_off, in->read_off, (size_t)nr + 1); UPB(read_bases, in->read_bases, nbases); UPB(read_quals, in->read_quals, nbases);
-    UPB(chain_off, in->chain_off, (size_t)nr + 1); UPB(read_primary, in->read_primary, (size_t)nr);
+    UPB(read_off, read_off32.data(), (size_t)nr + 1); UPB(read_bases, in->read_bases + rb0, nbases); UPB(read_quals, in->read_quals + rb0, nbases);
+    UPB(chain_off, chain_off32.data(), (size_t)nr + 1); UPB(read_primary, primary32.data(), (size_t)nr);
     UPB(chain_read, chain_read.data(), (size_t)nc);
-    UPB(chain_contig, in->chain_contig, (size_t)nc); UPB(chain_pos, in->chain_pos, (size_t)nc); UPB(chain_offset, in->chain_offset, (size_t)nc);
-    UPB(chain_as, in->chain_as, (size_t)nc); UPB(chain_reverse, in->chain_reverse, (size_t)nc);
-    UPB(cigar_off, in->cigar_off, (size_t)nc + 1); UPB(cigar, in->cigar, ncig);
+    UPB(chain_contig, w_contig, (size_t)nc); UPB(chain_pos, w_pos, (size_t)nc); UPB(chain_offset, w_offset, (size_t)nc);
+    UPB(chain_as, w_as, (size_t)nc); UPB(chain_reverse, w_rev, (size_t)nc);
+    UPB(cigar_off, cigar_off32.data(), (size_t)nc + 1); UPB(cigar, in->cigar + gb0, ncig);
 #undef UPB
     rc = batch_alloc_outputs(c, b); if(rc) return fail(rc);
     rc = dev_upload(c, b->allocs, &b->B, 1, &b->dB); if(rc) return fail(rc);
-    HIP_TRY_F(c, hipStreamSynchronize(c->stream), fail);
+    HIP_TRY_F(c, hipStreamSynchronize(c->active), fail);
     *out = b;
     return HLALA_OK;
 }
@@ -491,6 +562,7 @@ int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_
 {
     DEV_GUARD(c);
     if(!c || !in || !out) return HLALA_E_ARG;
+    UploadScope upscope_(c);
     *out = nullptr;
     hlala_batch* b = new hlala_batch(); b->ctx = c; c->batches.insert(b);
     DevBatch& B = b->B;
@@ -519,15 +591,15 @@ int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_
             lev[o] = in->col_level[i]; edg[o] = in->col_edge[i]; g[o] = in->col_gchar[i]; s[o] = in->col_schar[i];
         }
     }
-    HIP_TRY_F(c, hipMemcpyAsync(B.seed_status, st.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream), fail);
-    HIP_TRY_F(c, hipMemcpyAsync(B.seed_ncols, ncols.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream), fail);
-    HIP_TRY_F(c, hipMemcpyAsync(B.seed_begin, in->chain_seq_begin, (size_t)nc * 4, hipMemcpyHostToDevice, c->stream), fail);
-    HIP_TRY_F(c, hipMemcpyAsync(B.seed_end, in->chain_seq_end, (size_t)nc * 4, hipMemcpyHostToDevice, c->stream), fail);
-    HIP_TRY_F(c, hipMemcpyAsync(B.seed_level, lev.data(), lev.size() * 4, hipMemcpyHostToDevice, c->stream), fail);
-    HIP_TRY_F(c, hipMemcpyAsync(B.seed_edge, edg.data(), edg.size() * 4, hipMemcpyHostToDevice, c->stream), fail);
-    HIP_TRY_F(c, hipMemcpyAsync(B.seed_g, g.data(), g.size(), hipMemcpyHostToDevice, c->stream), fail);
-    HIP_TRY_F(c, hipMemcpyAsync(B.seed_s, s.data(), s.size(), hipMemcpyHostToDevice, c->stream), fail);
-    HIP_TRY_F(c, hipStreamSynchronize(c->stream), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_status, st.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->active), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_ncols, ncols.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->active), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_begin, in->chain_seq_begin, (size_t)nc * 4, hipMemcpyHostToDevice, c->active), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_end, in->chain_seq_end, (size_t)nc * 4, hipMemcpyHostToDevice, c->active), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_level, lev.data(), lev.size() * 4, hipMemcpyHostToDevice, c->active), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_edge, edg.data(), edg.size() * 4, hipMemcpyHostToDevice, c->active), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_g, g.data(), g.size(), hipMemcpyHostToDevice, c->active), fail);
+    HIP_TRY_F(c, hipMemcpyAsync(B.seed_s, s.data(), s.size(), hipMemcpyHostToDevice, c->active), fail);
+    HIP_TRY_F(c, hipStreamSynchronize(c->active), fail);
     b->staged = 1;
     *out = b;
     return HLALA_OK;
@@ -548,18 +620,14 @@ void hlala_batch_destroy(hlala_batch* b)
     if(c) {
         c->batches.erase(b);
         if(b->side_inflight) (void)hipEventSynchronize(b->evDone);
-        (void)hipStreamSynchronize(c->stream);       // nothing of this batch may still be running when its buffers are handed to the next one
+        if(b->mainValid) (void)hipEventSynchronize(b->evMain);       // nothing of this batch may still be running when its buffers are handed to the next one (readers and uploads return synchronised)
         for(void* p : b->allocs) pool_release(c, p);
     } else for(void* p : b->allocs) if(p) (void)hipFree(p);
     if(b->evDone) (void)hipEventDestroy(b->evDone);
+    if(b->evMain) (void)hipEventDestroy(b->evMain);
+    for(int i = 0; i < 14; i++) { if(b->ev[i]) (void)hipEventDestroy(b->ev[i]); if(b->evC[i / 2][i % 2]) (void)hipEventDestroy(b->evC[i / 2][i % 2]); }
+    for(int i = 0; i < 8; i++) if(b->evSide[i]) (void)hipEventDestroy(b->evSide[i]);
     delete b;
-}
-
-// everything that reads or rewrites a batch goes behind the side-stream work of its last fused alignment
-static int join_side(hlala_ctx* c, hlala_batch* b)
-{
-    if(b->side_inflight) { HIP_TRY(c, hipStreamWaitEvent(c->stream, b->evDone, 0)); b->side_inflight = false; }
-    return HLALA_OK;
 }
 
 static int check_launch(hlala_ctx* c, const char* what)
@@ -575,29 +643,30 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     if(!c || !b) return HLALA_E_ARG;
     { int rj = join_side(c, b); if(rj) return rj; }
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
+    { int re = batch_events(c, b); if(re) return re; }
     DevBatch& B = b->B;
-    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 48 * sizeof(int), c->stream));
-    HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 48 * sizeof(int), c->active));
+    HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->active));
+    HIP_TRY(c, hipEventRecord(b->ev[0], c->active));
     if(B.n_chains > 0) {
         int threads = 256, blocks = (B.n_reads + threads - 1) / threads;
-        hipLaunchKernelGGL(k_filter_chains, dim3(blocks), dim3(threads), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_level);
+        hipLaunchKernelGGL(k_filter_chains, dim3(blocks), dim3(threads), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_level);
         int grid = B.n_chains < c->proj_grid ? B.n_chains : c->proj_grid;
         if(c->proj_long_slabs)
-            hipLaunchKernelGGL((k_project_chains<ProjLdsLong>), dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
+            hipLaunchKernelGGL((k_project_chains<ProjLdsLong>), dim3(grid), dim3(64), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
                                c->proj_slabs, c->proj_slab_bytes, c->proj_long_slabs, c->proj_long_slab_bytes);
         else
             if(c->params.max_columns <= PROJ_CAP_SHORT)
-                hipLaunchKernelGGL((k_project_chains<ProjLdsShort>), dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
+                hipLaunchKernelGGL((k_project_chains<ProjLdsShort>), dim3(grid), dim3(64), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
                                    c->proj_slabs, c->proj_slab_bytes, (char*)nullptr, (size_t)0);
             else
-                hipLaunchKernelGGL((k_project_chains<ProjLds>), dim3(grid), dim3(64), 0, c->stream, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
+                hipLaunchKernelGGL((k_project_chains<ProjLds>), dim3(grid), dim3(64), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
                                c->proj_slabs, c->proj_slab_bytes, (char*)nullptr, (size_t)0);
         int rc = check_launch(c, "k_project_chains"); if(rc) return rc;
     }
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipEventRecord(b->ev[1], c->active));
     b->staged |= 1;
-    return HLALA_OK;
+    return mark_main(c, b);
 }
 
 static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused);
@@ -613,33 +682,37 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
     if(!c || !b) return HLALA_E_ARG;
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
     { int rj = join_side(c, b); if(rj) return rj; }
+    { int re = batch_events(c, b); if(re) return re; }
     DevBatch& B = b->B;
     if(B.unpaired || B.from_seeds || B.n_pairs <= 0 || B.n_chains <= 0) fused = false;
     b->side_used = false; b->side_pending = false;
-    if(B.n_pairs > 0) HIP_TRY(c, hipMemsetAsync(B.pair_deferred, 0, (size_t)B.n_pairs, c->stream));
-    HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->stream));
-    HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, 41 * sizeof(int), c->stream));
-    if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if(B.n_pairs > 0) HIP_TRY(c, hipMemsetAsync(B.pair_deferred, 0, (size_t)B.n_pairs, c->active));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->active));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, 41 * sizeof(int), c->active));
+    if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->active));
+    HIP_TRY(c, hipEventRecord(b->ev[2], c->active));
     if(B.n_chains > 0) {
         DpItem* items = (DpItem*)B.dp_items;
         const u32 seed = c->params.rng_seed + 2u * b->first_chain;
-        HIP_TRY(c, hipMemsetAsync(B.dp_alias_head, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->stream));       // -1: k_dp_items links the duplicates of a DP to it
-        hipLaunchKernelGGL(k_dp_items, dim3((B.n_chains + 255) / 256), dim3(256), 0, c->stream, c->dG, b->dB, items);
+        HIP_TRY(c, hipMemsetAsync(B.dp_alias_head, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));       // -1: k_dp_items links the duplicates of a DP to it
+        hipLaunchKernelGGL(k_dp_items, dim3((B.n_chains + 255) / 256), dim3(256), 0, c->active, c->dG, b->dB, items);
         int rc = check_launch(c, "k_dp_items"); if(rc) return rc;
         // every DP item first runs in the 16-lane class; the item count lives on the device, idle groups leave at once.
         // Items that outgrew it: two DPs per wave, then one wave per DP, then the classes with wider frontiers (fewer blocks per CU).
         // Each class is timed with its own pair of events on the stream it runs on (evC); ev[7] / ev[6] / ev[10] keep marking the start of the 16-lane
         // class, its end and the end of the 64-lane class on the main stream.
-        hipStream_t ws = c->stream;
+        hipStream_t ws = c->active;
         auto run_class = [&](int tier) -> int {
             if(fused && tier == DP_SIDE_TIER) {
                 if(!b->evDone) HIP_TRY(c, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming));
-                HIP_TRY(c, hipEventRecord(c->evSide[0], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->side, c->evSide[0], 0));
+                HIP_TRY(c, hipEventRecord(b->evSide[0], c->active)); HIP_TRY(c, hipStreamWaitEvent(c->side, b->evSide[0], 0));
                 ws = c->side;
-                HIP_TRY(c, hipEventRecord(c->evSide[1], c->side));
+                HIP_TRY(c, hipEventRecord(b->evSide[1], c->side));
             }
-            HIP_TRY(c, hipEventRecord(c->evC[tier][0], ws));
+            // the slabs of the classes from DP_SIDE_TIER on belong to the context: a launch on the main stream (stage calls, unpaired and from-seeds batches)
+            // goes behind whatever an earlier fused alignment of ANOTHER batch still has queued on the side stream
+            if(!fused && tier == DP_SIDE_TIER && c->sideTailValid) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSideTail, 0));
+            HIP_TRY(c, hipEventRecord(b->evC[tier][0], ws));
             switch(tier) {
             case 0: hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
             case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->mid_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
@@ -650,31 +723,32 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
             default: hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(64), 0, ws, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
             }
             int rc_ = check_launch(c, "k_dp"); if(rc_) return rc_;
-            HIP_TRY(c, hipEventRecord(c->evC[tier][1], ws));
+            HIP_TRY(c, hipEventRecord(b->evC[tier][1], ws));
             return 0;
         };
-        HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
+        HIP_TRY(c, hipEventRecord(b->ev[7], c->active));
         rc = run_class(0); if(rc) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+        HIP_TRY(c, hipEventRecord(b->ev[6], c->active));
         for(int tier = 1; tier <= DP_LAST_TIER; tier++) {
             rc = run_class(tier); if(rc) return rc;
-            if(tier == 2) HIP_TRY(c, hipEventRecord(c->ev[10], c->stream));
+            if(tier == 2) HIP_TRY(c, hipEventRecord(b->ev[10], c->active));
         }
-        if(!fused) HIP_TRY(c, hipEventRecord(c->ev[8], c->stream));
+        if(!fused) HIP_TRY(c, hipEventRecord(b->ev[8], c->active));
         const int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
         if(fused) {
             // second pass (side): the chains of the deferred pairs, work counter 36; first pass (main): all the others, work counter 7
             hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->side, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, 2, 36);
             rc = check_launch(c, "k_stitch_chains (side)"); if(rc) return rc;
             HIP_TRY(c, hipEventRecord(b->evDone, c->side));
+            HIP_TRY(c, hipEventRecord(c->evSideTail, c->side)); c->sideTailValid = true;
             b->side_inflight = true; b->side_used = true; b->side_pending = true;
         }
-        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->stream, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, fused ? 1 : 0, 7);
+        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->active, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, fused ? 1 : 0, 7);
         rc = check_launch(c, "k_stitch_chains"); if(rc) return rc;
     }
-    HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(c, hipEventRecord(b->ev[3], c->active));
     b->staged |= 2;
-    return HLALA_OK;
+    return mark_main(c, b);
 }
 
 int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
@@ -683,11 +757,12 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
     if(!c || !b) return HLALA_E_ARG;
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage C not available"; return HLALA_E_STATE; }
     if(!(b->staged & 2)) { c->err = "hlala_pair_chains before hlala_extend_chains"; return HLALA_E_STATE; }
+    { int re = batch_events(c, b); if(re) return re; }
     DevBatch& B = b->B;
     const bool fused = b->side_pending;
     if(!fused) { int rj = join_side(c, b); if(rj) return rj; }
-    HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->active));
+    HIP_TRY(c, hipEventRecord(b->ev[4], c->active));
     if(B.n_pairs > 0) {
         const int grid = B.n_pairs < c->pair_grid ? B.n_pairs : c->pair_grid;
         auto launch_pair = [&](hipStream_t st, int mode, int counterIdx) -> int {
@@ -695,18 +770,19 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
             else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx, c->pair_scratch + (st == c->side ? (size_t)c->pair_grid * PAIR_COMB : 0));
             return check_launch(c, "k_pair_chains");
         };
-        int rc = launch_pair(c->stream, fused ? 1 : 0, 2); if(rc) return rc;
+        int rc = launch_pair(c->active, fused ? 1 : 0, 2); if(rc) return rc;
         if(fused) {
             // second pass, behind the side-stream classes and the second stitch pass: the deferred pairs (work counter 37)
             rc = launch_pair(c->side, 2, 37); if(rc) return rc;
-            HIP_TRY(c, hipEventRecord(c->evSide[6], c->side));
+            HIP_TRY(c, hipEventRecord(b->evSide[6], c->side));
             HIP_TRY(c, hipEventRecord(b->evDone, c->side));
+            HIP_TRY(c, hipEventRecord(c->evSideTail, c->side)); c->sideTailValid = true;
             b->side_inflight = true; b->side_pending = false;
         }
     }
-    HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
+    HIP_TRY(c, hipEventRecord(b->ev[5], c->active));
     b->staged |= 4;
-    return HLALA_OK;
+    return mark_main(c, b);
 }
 
 int hlala_align_batch(hlala_ctx* c, hlala_batch* b)
@@ -719,7 +795,7 @@ int hlala_align_batch(hlala_ctx* c, hlala_batch* b)
 int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains_out* o)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b || !o) return HLALA_E_ARG;
     DevBatch& B = b->B;
     size_t nc = (size_t)B.n_chains, cs = nc * (size_t)B.stride;
@@ -731,7 +807,7 @@ int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains
         if((rc = dl(c, o->removed_cols, B.seed_removed, nc))) return rc;
         if((rc = dl(c, o->col_level, B.seed_level, cs))) return rc; if((rc = dl(c, o->col_edge, B.seed_edge, cs))) return rc;
         if((rc = dl(c, o->col_gchar, B.seed_g, cs))) return rc; if((rc = dl(c, o->col_schar, B.seed_s, cs))) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->active));
         if(o->col_fromseed) memset(o->col_fromseed, 1, cs);
         if(o->ll) memset(o->ll, 0, nc * 8);
         if(o->dp_iters) memset(o->dp_iters, 0, nc * 8);
@@ -745,7 +821,7 @@ int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains
         if((rc = dl(c, o->col_level, B.ext_level, cs))) return rc; if((rc = dl(c, o->col_edge, B.ext_edge, cs))) return rc;
         if((rc = dl(c, o->col_gchar, B.ext_g, cs))) return rc; if((rc = dl(c, o->col_schar, B.ext_s, cs))) return rc;
         if((rc = dl(c, o->col_fromseed, B.ext_fromseed, cs))) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->active));
     } else { c->err = "stage must be 0 or 1"; return HLALA_E_ARG; }
     return HLALA_OK;
 }
@@ -753,7 +829,7 @@ int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains
 int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b || !o) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -764,7 +840,7 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
     if((rc = dl(c, o->pair_ll, B.pair_ll, np))) return rc; if((rc = dl(c, o->pair_mapq, B.pair_mapq, np))) return rc;
     if((rc = dl(c, o->mate_mapq, B.mate_mapq, nr))) return rc; if((rc = dl(c, o->strands_valid, B.strands_valid, np))) return rc;
     if((rc = dl(c, o->col_mapq, B.sel_mapq, nr * stride))) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->active));
     // columns of the selected chains: gathered on the device into read-major staging rows, one bulk copy per array and chunk
     // (columns beyond n_cols come back as zero)
     const bool wantCols = o->n_cols || o->col_level || o->col_edge || o->col_gchar || o->col_schar || o->col_fromseed;
@@ -777,17 +853,17 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
            (rc = dev_alloc(c, tmp, CH * stride, &dG, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dS, false)) || (rc = dev_alloc(c, tmp, CH * stride, &dF, false))) return done(rc);
         for(size_t r0 = 0; r0 < nr; r0 += CH) {
             const size_t rows = nr - r0 < CH ? nr - r0 : CH;
-            hipLaunchKernelGGL(k_gather_selected, dim3((unsigned)rows), dim3(128), 0, c->stream, b->dB, (int)r0, (int)rows, dN, dL, dE, dG, dS, dF);
+            hipLaunchKernelGGL(k_gather_selected, dim3((unsigned)rows), dim3(128), 0, c->active, b->dB, (int)r0, (int)rows, dN, dL, dE, dG, dS, dF);
             if((rc = check_launch(c, "k_gather_selected"))) return done(rc);
             const size_t cols = rows * stride, o0 = r0 * stride;
             hipError_t e = hipSuccess;
-            if(o->n_cols && e == hipSuccess) e = hipMemcpyAsync(o->n_cols + r0, dN, rows * 4, hipMemcpyDeviceToHost, c->stream);
-            if(o->col_level && e == hipSuccess) e = hipMemcpyAsync(o->col_level + o0, dL, cols * 4, hipMemcpyDeviceToHost, c->stream);
-            if(o->col_edge && e == hipSuccess) e = hipMemcpyAsync(o->col_edge + o0, dE, cols * 4, hipMemcpyDeviceToHost, c->stream);
-            if(o->col_gchar && e == hipSuccess) e = hipMemcpyAsync(o->col_gchar + o0, dG, cols, hipMemcpyDeviceToHost, c->stream);
-            if(o->col_schar && e == hipSuccess) e = hipMemcpyAsync(o->col_schar + o0, dS, cols, hipMemcpyDeviceToHost, c->stream);
-            if(o->col_fromseed && e == hipSuccess) e = hipMemcpyAsync(o->col_fromseed + o0, dF, cols, hipMemcpyDeviceToHost, c->stream);
-            if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if(o->n_cols && e == hipSuccess) e = hipMemcpyAsync(o->n_cols + r0, dN, rows * 4, hipMemcpyDeviceToHost, c->active);
+            if(o->col_level && e == hipSuccess) e = hipMemcpyAsync(o->col_level + o0, dL, cols * 4, hipMemcpyDeviceToHost, c->active);
+            if(o->col_edge && e == hipSuccess) e = hipMemcpyAsync(o->col_edge + o0, dE, cols * 4, hipMemcpyDeviceToHost, c->active);
+            if(o->col_gchar && e == hipSuccess) e = hipMemcpyAsync(o->col_gchar + o0, dG, cols, hipMemcpyDeviceToHost, c->active);
+            if(o->col_schar && e == hipSuccess) e = hipMemcpyAsync(o->col_schar + o0, dS, cols, hipMemcpyDeviceToHost, c->active);
+            if(o->col_fromseed && e == hipSuccess) e = hipMemcpyAsync(o->col_fromseed + o0, dF, cols, hipMemcpyDeviceToHost, c->active);
+            if(e == hipSuccess) e = hipStreamSynchronize(c->active);
             if(e != hipSuccess) { c->err = std::string("hlala_batch_get_pairs: ") + hipGetErrorString(e); return done(HLALA_E_DEVICE); }
         }
         done(0);
@@ -798,7 +874,7 @@ int hlala_batch_get_pairs(hlala_ctx* c, hlala_batch* b, hlala_pairs_out* o)
 int hlala_batch_get_pairs_packed(hlala_ctx* c, hlala_batch* b, hlala_pairs_packed_out* o)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b || !o || !o->col_off) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -809,7 +885,7 @@ int hlala_batch_get_pairs_packed(hlala_ctx* c, hlala_batch* b, hlala_pairs_packe
     auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
     int rc = 0; long long *dN = nullptr, *dOff = nullptr; char* dCub = nullptr;
     if((rc = dev_alloc(c, tmp, nr + 1, &dN)) || (rc = dev_alloc(c, tmp, nr + 1, &dOff))) return done(rc);
-    hipStream_t st = c->stream;
+    hipStream_t st = c->active;
     hipLaunchKernelGGL(k_selected_ncols, dim3((unsigned)((nr + 1 + 255) / 256)), dim3(256), 0, st, b->dB, (int)nr, dN);
     if((rc = check_launch(c, "k_selected_ncols"))) return done(rc);
     size_t cubBytes = 0;
@@ -843,13 +919,13 @@ int hlala_estimate_insert_size(hlala_ctx* c, const hlala_batch_in* in, hlala_ins
     memset(out, 0, sizeof(*out));
     const int np = in->n_pairs, nr = 2 * np;
     if(np <= 0) { c->err = "hlala_estimate_insert_size: no pairs"; return HLALA_E_ARG; }
-    // the batch of primaries: one chain per read
-    std::vector<int32_t> chain_off(nr + 1), read_primary(nr), contig(nr), pos(nr), offset(nr), as(nr), cigar_off(nr + 1, 0); std::vector<uint8_t> rev(nr); std::vector<uint32_t> cigar;
+    // the batch of primaries: one chain per read (chain indices of `in` are those of the caller's numbering: the window convention of hlala_batch_in)
+    std::vector<int64_t> chain_off(nr + 1), cigar_off(nr + 1, 0); std::vector<int32_t> read_primary(nr), contig(nr), pos(nr), offset(nr), as(nr); std::vector<uint8_t> rev(nr); std::vector<uint32_t> cigar;
     for(int r = 0; r < nr; r++) {
-        const int ch = in->read_primary[r];
+        const int64_t ch = in->read_primary[r];
         if(ch < in->chain_off[r] || ch >= in->chain_off[r + 1]) { c->err = "read_primary outside the read's chains"; return HLALA_E_ARG; }
         chain_off[r] = r; read_primary[r] = r; contig[r] = in->chain_contig[ch]; pos[r] = in->chain_pos[ch]; offset[r] = in->chain_offset[ch]; as[r] = in->chain_as[ch]; rev[r] = in->chain_reverse[ch];
-        cigar.insert(cigar.end(), in->cigar + in->cigar_off[ch], in->cigar + in->cigar_off[ch + 1]); cigar_off[r + 1] = (int32_t)cigar.size();
+        cigar.insert(cigar.end(), in->cigar + in->cigar_off[ch], in->cigar + in->cigar_off[ch + 1]); cigar_off[r + 1] = (int64_t)cigar.size();
     }
     chain_off[nr] = nr;
     hlala_batch_in pb = *in;
@@ -862,11 +938,11 @@ int hlala_estimate_insert_size(hlala_ctx* c, const hlala_batch_in* in, hlala_ins
     std::vector<void*> tmp; int *dN = nullptr, *dD = nullptr;
     auto done2 = [&](int r_) { for(void* p : tmp) pool_release(c, p); return done(r_); };
     if((rc = dev_alloc(c, tmp, (size_t)np, &dN)) || (rc = dev_alloc(c, tmp, (size_t)np * PAIR_MAXDIST, &dD))) return done2(rc);
-    hipLaunchKernelGGL(k_pair_distances, dim3((unsigned)((np + 127) / 128)), dim3(128), 0, c->stream, c->dG, b->dB, dN, dD);
+    hipLaunchKernelGGL(k_pair_distances, dim3((unsigned)((np + 127) / 128)), dim3(128), 0, c->active, c->dG, b->dB, dN, dD);
     if((rc = check_launch(c, "k_pair_distances"))) return done2(rc);
     std::vector<int> hN((size_t)np), hD((size_t)np * PAIR_MAXDIST);
     if((rc = dl(c, hN.data(), dN, (size_t)np)) || (rc = dl(c, hD.data(), dD, (size_t)np * PAIR_MAXDIST))) return done2(rc);
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = hipStreamSynchronize(c->active);
     if(e != hipSuccess) { c->err = hipGetErrorString(e); return done2(HLALA_E_DEVICE); }
     // histogram in pair order (processBAM.cpp:1135-1146), then calculateInsertSizeFromHistogram (:991-1069)
     std::map<int, double> IS_combined_counts;
@@ -892,6 +968,28 @@ int hlala_estimate_insert_size(hlala_ctx* c, const hlala_batch_in* in, hlala_ins
     return done2(HLALA_OK);
 }
 
+int hlala_set_insert_size(hlala_ctx* c, double insert_mean, double insert_sd)
+{
+    DEV_GUARD(c);
+    if(!c) return HLALA_E_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipStreamSynchronize(c->side));
+    const double m0 = c->params.insert_mean, s0 = c->params.insert_sd;
+    double* oldLog = c->d_islog; DevTables* oldT = c->dT;
+    c->params.insert_mean = insert_mean; c->params.insert_sd = insert_sd;
+    // (the kernels read the tables through c->dT, which batches do not cache: the new tables go to the same device address)
+    std::vector<void*> keep; keep.swap(c->allocs);
+    int rc = build_tables(c);
+    std::vector<void*> made; made.swap(c->allocs); c->allocs.swap(keep);
+    if(rc) { for(void* p : made) if(p) pool_release(c, p); c->params.insert_mean = m0; c->params.insert_sd = s0; c->d_islog = oldLog; c->dT = oldT; return rc; }
+    // copy the new table struct over the old one so that every holder of the old pointer sees it; the log-pdf array it points to stays alive in allocs
+    hipError_t e = hipMemcpyAsync(oldT, c->dT, sizeof(DevTables), hipMemcpyDeviceToDevice, c->stream);
+    if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    for(void* p : made) { if(p == (void*)c->dT) pool_release(c, p); else c->allocs.push_back(p); }
+    c->dT = oldT;
+    if(e != hipSuccess) { c->err = std::string("hlala_set_insert_size: ") + hipGetErrorString(e); return HLALA_E_DEVICE; }
+    return HLALA_OK;
+}
+
 int hlala_set_gene_intervals(hlala_ctx* c, int32_t n, const int32_t* first_level, const int32_t* last_level)
 {
     DEV_GUARD(c);
@@ -901,7 +999,7 @@ int hlala_set_gene_intervals(hlala_ctx* c, int32_t n, const int32_t* first_level
     if(n > 0) {
         int rc = dev_upload(c, c->allocs, first_level, (size_t)n, &c->d_gene_first); if(rc) return rc;
         rc = dev_upload(c, c->allocs, last_level, (size_t)n, &c->d_gene_last); if(rc) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->active));
     }
     c->n_genes = n;
     return HLALA_OK;
@@ -910,7 +1008,7 @@ int hlala_set_gene_intervals(hlala_ctx* c, int32_t n, const int32_t* first_level
 int hlala_postprocess_pairs(hlala_ctx* c, hlala_batch* b, uint8_t* include_in_hla)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "hlala_postprocess_pairs before hlala_pair_chains"; return HLALA_E_STATE; }
     DevBatch& B = b->B;
@@ -922,13 +1020,13 @@ int hlala_postprocess_pairs(hlala_ctx* c, hlala_batch* b, uint8_t* include_in_hl
     uint8_t* dInc = nullptr; std::vector<void*> tmp;
     auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
     if(include_in_hla) { int rc = dev_alloc(c, tmp, (size_t)B.n_pairs, &dInc, false); if(rc) return done(rc); }
-    hipError_t e = hipMemsetAsync(B.work_counter + 11, 0, sizeof(int), c->stream);
+    hipError_t e = hipMemsetAsync(B.work_counter + 11, 0, sizeof(int), c->active);
     if(e != hipSuccess) { c->err = hipGetErrorString(e); return done(HLALA_E_DEVICE); }
     int grid = B.n_pairs < c->stitch_grid ? B.n_pairs : c->stitch_grid;
-    hipLaunchKernelGGL(k_post_pairs, dim3(grid), dim3(64), 0, c->stream, b->dB, c->d_cov, c->n_cov, c->d_gene_first, c->d_gene_last, c->n_genes, dInc);
+    hipLaunchKernelGGL(k_post_pairs, dim3(grid), dim3(64), 0, c->active, b->dB, c->d_cov, c->n_cov, c->d_gene_first, c->d_gene_last, c->n_genes, dInc);
     int rc = check_launch(c, "k_post_pairs"); if(rc) return done(rc);
-    if(include_in_hla) e = hipMemcpyAsync(include_in_hla, dInc, (size_t)B.n_pairs, hipMemcpyDeviceToHost, c->stream);
-    if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if(include_in_hla) e = hipMemcpyAsync(include_in_hla, dInc, (size_t)B.n_pairs, hipMemcpyDeviceToHost, c->active);
+    if(e == hipSuccess) e = hipStreamSynchronize(c->active);
     if(e != hipSuccess) { c->err = std::string("hlala_postprocess_pairs: ") + hipGetErrorString(e); return done(HLALA_E_DEVICE); }
     return done(HLALA_OK);
 }
@@ -936,12 +1034,13 @@ int hlala_postprocess_pairs(hlala_ctx* c, hlala_batch* b, uint8_t* include_in_hl
 int hlala_get_coverage(hlala_ctx* c, int32_t* bases_per_level, int reset)
 {
     DEV_GUARD(c);
+    ReaderScope rscope_(c, nullptr);
     if(!c || !bases_per_level) return HLALA_E_ARG;
     const int n = c->F.L > 1 ? c->F.L - 1 : 1;
     if(!c->d_cov) { memset(bases_per_level, 0, (size_t)n * 4); return HLALA_OK; }
-    HIP_TRY(c, hipMemcpyAsync(bases_per_level, c->d_cov, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    if(reset) HIP_TRY(c, hipMemsetAsync(c->d_cov, 0, (size_t)n * 4, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(bases_per_level, c->d_cov, (size_t)n * 4, hipMemcpyDeviceToHost, c->active));
+    if(reset) HIP_TRY(c, hipMemsetAsync(c->d_cov, 0, (size_t)n * 4, c->active));
+    HIP_TRY(c, hipStreamSynchronize(c->active));
     return HLALA_OK;
 }
 
@@ -952,8 +1051,9 @@ int hlala_batch_export_pair_records(hlala_ctx* c, hlala_batch* b, double* device
     if(!c || !b || !device_out) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     if(b->B.n_pairs > 0) {
-        hipLaunchKernelGGL(k_export_pairs, dim3((b->B.n_pairs + 255) / 256), dim3(256), 0, c->stream, b->dB, device_out);
+        hipLaunchKernelGGL(k_export_pairs, dim3((b->B.n_pairs + 255) / 256), dim3(256), 0, c->active, b->dB, device_out);
         int rc = check_launch(c, "k_export_pairs"); if(rc) return rc;
+        return mark_main(c, b);       // (the export reads the batch: its destruction waits for it)
     }
     return HLALA_OK;
 }
@@ -961,19 +1061,19 @@ int hlala_batch_export_pair_records(hlala_ctx* c, hlala_batch* b, double* device
 int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b || !out) return HLALA_E_ARG;
     memset(out, 0, sizeof(*out));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->active));
     u64 cnt[16];
-    HIP_TRY(c, hipMemcpy(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost));
-    if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, c->ev[0], c->ev[1]);
-    if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, c->ev[2], c->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, c->ev[6], b->side_used ? c->ev[10] : c->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, c->ev[7], c->ev[6]);
-          for(int k = 0; k <= DP_LAST_TIER; k++) (void)hipEventElapsedTime(&out->ms_dp_class[k], c->evC[k][0], c->evC[k][1]);
-          if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, c->evSide[1], c->evSide[6]); } }
-    { int wc[48]; HIP_TRY(c, hipMemcpy(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
+    HIP_TRY(c, hipMemcpyAsync(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active));
+    if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, b->ev[0], b->ev[1]);
+    if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, b->ev[2], b->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, b->ev[6], b->side_used ? b->ev[10] : b->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, b->ev[7], b->ev[6]);
+          for(int k = 0; k <= DP_LAST_TIER; k++) (void)hipEventElapsedTime(&out->ms_dp_class[k], b->evC[k][0], b->evC[k][1]);
+          if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, b->evSide[1], b->evSide[6]); } }
+    { int wc[48]; HIP_TRY(c, hipMemcpyAsync(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
       out->n_dp_class[0] = wc[8] + wc[9]; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
-    if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, c->ev[4], c->ev[5]);
+    if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, b->ev[4], b->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];
     out->n_seed_columns = (int64_t)cnt[CNT_SEED_COLS]; out->n_out_columns = (int64_t)cnt[CNT_OUT_COLS];
@@ -1005,6 +1105,7 @@ static int typer_tables(hlala_ctx* c, std::vector<void*>& tmp, TyperTables** out
 extern "C" int hlala_exon_loglik(hlala_ctx* c, const hlala_exon_in* in, double* LL, int32_t* mism)
 {
     DEV_GUARD(c);
+    ReaderScope rscope_(c, nullptr);
     if(!c || !in || !LL || !mism) return HLALA_E_ARG;
     const int C = in->n_clusters, P = in->exon_length, R = in->n_reads;
     if(C < 0 || P < 0 || R < 0) { c->err = "negative sizes"; return HLALA_E_ARG; }
@@ -1027,16 +1128,17 @@ extern "C" int hlala_exon_loglik(hlala_ctx* c, const hlala_exon_in* in, double* 
     if((rc = dev_upload(c, tmp, in->pos_use, npos, &dUse))) return done(rc);
     if((rc = dev_alloc(c, tmp, (size_t)C * R, &dLL))) return done(rc);
     if((rc = dev_alloc(c, tmp, (size_t)C * R, &dM))) return done(rc);
-    hipLaunchKernelGGL(k_exon_loglik, dim3((C + 255) / 256, R), dim3(256), 0, c->stream, dT, C, P, R, dSeq, dOff, dExon, dG0, dGlen, dQ, dUse, dLL, dM);
+    hipLaunchKernelGGL(k_exon_loglik, dim3((C + 255) / 256, R), dim3(256), 0, c->active, dT, C, P, R, dSeq, dOff, dExon, dG0, dGlen, dQ, dUse, dLL, dM);
     if((rc = check_launch(c, "k_exon_loglik"))) return done(rc);
-    if(hipMemcpyAsync(LL, dLL, (size_t)C * R * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipMemcpyAsync(mism, dM, (size_t)C * R * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-       hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "hlala_exon_loglik: download failed"; return done(HLALA_E_DEVICE); }
+    if(hipMemcpyAsync(LL, dLL, (size_t)C * R * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess || hipMemcpyAsync(mism, dM, (size_t)C * R * 4, hipMemcpyDeviceToHost, c->active) != hipSuccess ||
+       hipStreamSynchronize(c->active) != hipSuccess) { c->err = "hlala_exon_loglik: download failed"; return done(HLALA_E_DEVICE); }
     return done(HLALA_OK);
 }
 
 extern "C" int hlala_pair_loglik(hlala_ctx* c, const double* LL, const int32_t* mism, int32_t C, int32_t R, double* pairLL, double* misAvg, double* misMin)
 {
     DEV_GUARD(c);
+    ReaderScope rscope_(c, nullptr);
     if(!c || !LL || !mism || !pairLL || !misAvg || !misMin || C < 0 || R < 0) return HLALA_E_ARG;
     if(C == 0) return HLALA_OK;
     std::vector<void*> tmp; int rc = 0;
@@ -1052,13 +1154,13 @@ extern "C" int hlala_pair_loglik(hlala_ctx* c, const double* LL, const int32_t* 
     if((rc = dev_alloc(c, tmp, npairs, &dMn))) return done(rc);
     if(R > 0) {
         dim3 tb(32, 32), tg((R + 31) / 32, (C + 31) / 32);
-        hipLaunchKernelGGL(k_transpose<double>, tg, tb, 0, c->stream, C, R, dLL, dLLT);
-        hipLaunchKernelGGL(k_transpose<int>, tg, tb, 0, c->stream, C, R, dM, dMT);
+        hipLaunchKernelGGL(k_transpose<double>, tg, tb, 0, c->active, C, R, dLL, dLLT);
+        hipLaunchKernelGGL(k_transpose<int>, tg, tb, 0, c->active, C, R, dM, dMT);
     }
-    hipLaunchKernelGGL(k_pair_loglik, dim3((C + 255) / 256, (C + PAIRLL_ROWS - 1) / PAIRLL_ROWS), dim3(256), 0, c->stream, C, R, dLL, dLLT, dM, dMT, dP, dA, dMn);
+    hipLaunchKernelGGL(k_pair_loglik, dim3((C + 255) / 256, (C + PAIRLL_ROWS - 1) / PAIRLL_ROWS), dim3(256), 0, c->active, C, R, dLL, dLLT, dM, dMT, dP, dA, dMn);
     if((rc = check_launch(c, "k_pair_loglik"))) return done(rc);
-    if(hipMemcpyAsync(pairLL, dP, npairs * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipMemcpyAsync(misAvg, dA, npairs * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-       hipMemcpyAsync(misMin, dMn, npairs * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "hlala_pair_loglik: download failed"; return done(HLALA_E_DEVICE); }
+    if(hipMemcpyAsync(pairLL, dP, npairs * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess || hipMemcpyAsync(misAvg, dA, npairs * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess ||
+       hipMemcpyAsync(misMin, dMn, npairs * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess || hipStreamSynchronize(c->active) != hipSuccess) { c->err = "hlala_pair_loglik: download failed"; return done(HLALA_E_DEVICE); }
     return done(HLALA_OK);
 }
 
@@ -1086,7 +1188,7 @@ extern "C" int hlala_debug_buffer(hlala_ctx* c, int* out8192, int clear)
 {
     if(!c || !c->dbg_host) return HLALA_E_STATE;
     DEV_GUARD(c);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->active));
     if(out8192) memcpy(out8192, c->dbg_host, 8192 * sizeof(int));
     if(clear) memset(c->dbg_host, 0, 8192 * sizeof(int));
     return HLALA_OK;
@@ -1095,10 +1197,10 @@ extern "C" int hlala_debug_buffer(hlala_ctx* c, int* out8192, int clear)
 extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long long* out32)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b) return HLALA_E_ARG;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out32, b->B.counters, 32 * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipStreamSynchronize(c->active));
+    HIP_TRY(c, hipMemcpyAsync(out32, b->B.counters, 32 * sizeof(u64), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active));
     return HLALA_OK;
 }
 
@@ -1110,9 +1212,9 @@ extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uin
         double* dp = nullptr; uint8_t* dq = nullptr; std::vector<void*> tmp;
         int rc = dev_upload(c, tmp, p_correct, (size_t)n, &dp); if(rc) return rc;
         rc = dev_alloc(c, tmp, (size_t)n, &dq); if(rc) return rc;
-        hipLaunchKernelGGL(k_kat_phred, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dT, n, dp, dq);
-        HIP_TRY(c, hipMemcpyAsync(phred_out, dq, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipLaunchKernelGGL(k_kat_phred, dim3((n + 255) / 256), dim3(256), 0, c->active, c->dT, n, dp, dq);
+        HIP_TRY(c, hipMemcpyAsync(phred_out, dq, (size_t)n, hipMemcpyDeviceToHost, c->active));
+        HIP_TRY(c, hipStreamSynchronize(c->active));
         for(void* p : tmp) pool_release(c, p);
     }
     if(phred_in && p_out) {
@@ -1126,6 +1228,7 @@ extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, c
                                 int32_t* order, double* p_normalized, double* cluster_marginal, hlala_call_out* out)
 {
     DEV_GUARD(c);
+    ReaderScope rscope_(c, nullptr);
     if(!c || C < 1 || !pairLL || !misAvg || !misMin || !out) return HLALA_E_ARG;
     if(C > 46000) { c->err = "hlala_call_locus: more than 46000 clusters (pair index exceeds 31 bits)"; return HLALA_E_CAPACITY; }
     const long long nP = (long long)C * (C + 1) / 2, n2 = 2 * nP;
@@ -1143,7 +1246,7 @@ extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, c
        (rc = dev_alloc(c, tmp, (size_t)n2, &dVal)) || (rc = dev_alloc(c, tmp, (size_t)n2, &dVal2)) || (rc = dev_alloc(c, tmp, (size_t)C, &dMarg)) || (rc = dev_alloc(c, tmp, 1, &dTies, true)) ||
        (rc = dev_alloc(c, tmp, 1, &dOut))) return done(rc);
     long long* dMaxIdx = (long long*)(dScal + 2);      // dScal[0] = LL max, dScal[1] = P sum, dScal[2..3] as one long long = index of the maximum
-    hipStream_t st = c->stream;
+    hipStream_t st = c->active;
     const int T = 256; const unsigned gP = (unsigned)((nP + T - 1) / T);
     hipLaunchKernelGGL(k_call_max, dim3(NB), dim3(T), 0, st, dLL, nP, dPart, dPidx);
     hipLaunchKernelGGL(k_call_max_final, dim3(1), dim3(1), 0, st, dPart, dPidx, NB, dScal, dMaxIdx);
@@ -1175,7 +1278,7 @@ extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, c
 extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_locus_desc* L, hlala_exon_positions_out* o)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b || !L || !o) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "hlala_exon_positions before hlala_pair_chains"; return HLALA_E_STATE; }
     if(L->level_max < L->level_min || !L->level_to_exon) { c->err = "locus: empty level range or no level_to_exon table"; return HLALA_E_ARG; }
@@ -1193,7 +1296,7 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
     EL.level_to_exon = dL2E;
     if(L->pair_mask) { if((rc = dev_upload(c, tmp, L->pair_mask, (size_t)np, &dMask))) return done(rc); EL.pair_mask = dMask; }
     if((rc = dev_alloc(c, tmp, (size_t)3 * np + 3, &dCnt)) || (rc = dev_alloc(c, tmp, (size_t)3 * np + 3, &dOff)) || (rc = dev_alloc(c, tmp, 2, &dOB, true))) return done(rc);
-    hipStream_t st = c->stream;
+    hipStream_t st = c->active;
     hlala_exon_positions_out dO; memset(&dO, 0, sizeof(dO));
     const unsigned grid = (unsigned)((np + 127) / 128);
     hipLaunchKernelGGL((k_exon_positions<0>), dim3(grid), dim3(128), 0, st, b->dB, c->dT, EL, dCnt, (const int*)nullptr, dOB, dO);
@@ -1236,7 +1339,7 @@ extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_lo
 extern "C" int hlala_unit_alignment_stats(hlala_ctx* c, hlala_batch* b, hlala_unit_stats_out* o)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b || !o || !o->valid || !o->strands_valid || !o->distance || !o->fraction_ok || !o->weighted_ok || !o->n_columns || !o->mate_mapq) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "hlala_unit_alignment_stats before hlala_pair_chains"; return HLALA_E_STATE; }
     const size_t n = (size_t)b->B.n_pairs;
@@ -1246,18 +1349,18 @@ extern "C" int hlala_unit_alignment_stats(hlala_ctx* c, hlala_batch* b, hlala_un
     int rc = 0; hlala_unit_stats_out d; memset(&d, 0, sizeof(d));
     if((rc = dev_alloc(c, tmp, n, &d.valid)) || (rc = dev_alloc(c, tmp, n, &d.strands_valid)) || (rc = dev_alloc(c, tmp, n, &d.distance)) || (rc = dev_alloc(c, tmp, 2 * n, &d.fraction_ok)) ||
        (rc = dev_alloc(c, tmp, 2 * n, &d.weighted_ok)) || (rc = dev_alloc(c, tmp, 2 * n, &d.n_columns)) || (rc = dev_alloc(c, tmp, 2 * n, &d.mate_mapq))) return done(rc);
-    hipLaunchKernelGGL(k_unit_stats, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c->stream, b->dB, c->dT, d);
+    hipLaunchKernelGGL(k_unit_stats, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c->active, b->dB, c->dT, d);
     if((rc = check_launch(c, "k_unit_stats"))) return done(rc);
     if((rc = dl(c, o->valid, d.valid, n)) || (rc = dl(c, o->strands_valid, d.strands_valid, n)) || (rc = dl(c, o->distance, d.distance, n)) || (rc = dl(c, o->fraction_ok, d.fraction_ok, 2 * n)) ||
        (rc = dl(c, o->weighted_ok, d.weighted_ok, 2 * n)) || (rc = dl(c, o->n_columns, d.n_columns, 2 * n)) || (rc = dl(c, o->mate_mapq, d.mate_mapq, 2 * n))) return done(rc);
-    HIP_TRY_F(c, hipStreamSynchronize(c->stream), done);
+    HIP_TRY_F(c, hipStreamSynchronize(c->active), done);
     return done(HLALA_OK);
 }
 
 extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b || n_queries < 0 || (n_queries > 0 && (!queries || !present))) return HLALA_E_ARG;
     if(k < 1 || k > 31) { c->err = "hlala_kmer_presence: k must be in 1..31 (2-bit codes in one 64-bit word)"; return HLALA_E_ARG; }
     if(n_queries == 0) return HLALA_OK;
@@ -1285,13 +1388,56 @@ extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* 
     if(pair_mask && (rc = dev_upload(c, tmp, pair_mask, (size_t)b->B.n_pairs, &dMask))) return done(rc);
     const int nReads = b->B.unpaired ? b->B.n_pairs : 2 * b->B.n_pairs;
     const unsigned grid = (unsigned)std::min<long long>((long long)nReads, (long long)c->stitch_grid);
-    hipLaunchKernelGGL(k_kmer_presence, dim3(grid), dim3(64), 0, c->stream, b->dB, (const uint8_t*)dMask, (int)k, (int)uniq.size(), (const u64*)dQ, dP);
+    hipLaunchKernelGGL(k_kmer_presence, dim3(grid), dim3(64), 0, c->active, b->dB, (const uint8_t*)dMask, (int)k, (int)uniq.size(), (const u64*)dQ, dP);
     if((rc = check_launch(c, "k_kmer_presence"))) return done(rc);
     std::vector<uint8_t> hp(uniq.size());
     if((rc = dl(c, hp.data(), dP, uniq.size()))) return done(rc);
-    HIP_TRY_F(c, hipStreamSynchronize(c->stream), done);
+    HIP_TRY_F(c, hipStreamSynchronize(c->active), done);
     for(int i = 0; i < n_queries; i++) if(canon[i] != ~0ull) present[i] = hp[(size_t)(std::lower_bound(uniq.begin(), uniq.end(), canon[i]) - uniq.begin())];
     return done(HLALA_OK);
+}
+
+// ---- page-locked host memory (include/hlala_gpu.h)
+extern "C" void* hlala_pinned_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void hlala_pinned_free(void* p) { if(p) (void)hipHostFree(p); }
+extern "C" int hlala_host_register(void* p, size_t bytes)
+{
+    if(!p || !bytes) return HLALA_E_ARG;
+    if(hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return HLALA_E_DEVICE; }
+    return HLALA_OK;
+}
+extern "C" int hlala_host_unregister(void* p)
+{
+    if(!p) return HLALA_E_ARG;
+    if(hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return HLALA_E_DEVICE; }
+    return HLALA_OK;
+}
+static void seed_batch_unpin(hlala_seed_batch* S)
+{
+    std::vector<std::pair<void*, size_t>> arr; hlala_host::seed_batch_bulk_arrays(S, arr);
+    for(auto& a : arr) { if(hipHostUnregister(a.first) != hipSuccess) (void)hipGetLastError(); }
+    hlala_host::seed_batch_pinned_flag(S) = false;
+}
+extern "C" int hlala_seed_batch_pin(hlala_seed_batch* S, int pin)
+{
+    if(!S) return HLALA_E_ARG;
+    bool& flag = hlala_host::seed_batch_pinned_flag(S);
+    if((pin != 0) == flag) return HLALA_OK;
+    if(!pin) { seed_batch_unpin(S); return HLALA_OK; }
+    std::vector<std::pair<void*, size_t>> arr; hlala_host::seed_batch_bulk_arrays(S, arr);
+    for(size_t i = 0; i < arr.size(); i++)
+        if(hipHostRegister(arr[i].first, arr[i].second, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            for(size_t k = 0; k < i; k++) (void)hipHostUnregister(arr[k].first);
+            return HLALA_E_DEVICE;
+        }
+    flag = true; hlala_host::g_seed_batch_unpin = seed_batch_unpin;
+    return HLALA_OK;
 }
 
 extern "C" int hlala_abi_sizeof(const char* name)
@@ -1313,9 +1459,9 @@ extern "C" int hlala_kat_exp(hlala_ctx* c, int n, const double* x, double* y)
     double *dx = nullptr, *dy = nullptr; std::vector<void*> tmp;
     int rc = dev_upload(c, tmp, x, (size_t)n, &dx); if(rc) return rc;
     rc = dev_alloc(c, tmp, (size_t)n, &dy); if(rc) return rc;
-    hipLaunchKernelGGL(k_kat_exp, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, (const double*)dx, dy);
-    HIP_TRY(c, hipMemcpyAsync(y, dy, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_kat_exp, dim3((n + 255) / 256), dim3(256), 0, c->active, n, (const double*)dx, dy);
+    HIP_TRY(c, hipMemcpyAsync(y, dy, (size_t)n * 8, hipMemcpyDeviceToHost, c->active));
+    HIP_TRY(c, hipStreamSynchronize(c->active));
     for(void* p : tmp) pool_release(c, p);
     return HLALA_OK;
 }
@@ -1328,10 +1474,10 @@ extern "C" int hlala_kat_rand_r(hlala_ctx* c, int n, uint32_t* seeds_inout, int3
     u32* ds = nullptr; int* dv = nullptr; std::vector<void*> tmp;
     int rc = dev_upload(c, tmp, seeds_inout, (size_t)n, &ds); if(rc) return rc;
     rc = dev_alloc(c, tmp, (size_t)n, &dv); if(rc) return rc;
-    hipLaunchKernelGGL(k_kat_rand, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, ds, dv);
-    HIP_TRY(c, hipMemcpyAsync(seeds_inout, ds, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(values_out, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_kat_rand, dim3((n + 255) / 256), dim3(256), 0, c->active, n, ds, dv);
+    HIP_TRY(c, hipMemcpyAsync(seeds_inout, ds, (size_t)n * 4, hipMemcpyDeviceToHost, c->active));
+    HIP_TRY(c, hipMemcpyAsync(values_out, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->active));
+    HIP_TRY(c, hipStreamSynchronize(c->active));
     for(void* p : tmp) pool_release(c, p);
     return HLALA_OK;
 }

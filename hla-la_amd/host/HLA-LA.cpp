@@ -8,8 +8,11 @@
 //
 // Arguments are `--name value` pairs, unknown names are ignored (HLA-LA.cpp:71-79).  Where the reference asserts or throws (abort /
 // terminate), this program prints the message to stderr and exits with a non-zero status -- HLA-LA.pl treats any non-zero status as
-// failure (:567-570).  Extra, optional arguments of this program: --device <gpu index>, --batchPairs <units per GPU batch>,
-// --rngSeed <base of the end-cell draws>, --loci A,B,... (default: the reference's 17 loci, hla/HLATyper.cpp:42).
+// failure (:567-570).  Extra, optional arguments of this program: --devices <gpu,gpu,...> (or --device <gpu>): the batches of the sample are
+// dealt round-robin to one context per listed GPU (a GPU may be listed twice: two contexts on it), results do not depend on the list;
+// --decodeThreads <host threads of the BAM decoder, default all>, --batchPairs <units per GPU batch>, --rngSeed <base of the end-cell draws>,
+// --loci A,B,... (default: the reference's 17 loci, hla/HLATyper.cpp:42).  Several samples in one call (BASELINE config 4): comma-separated lists of
+// equal length in --sampleID, --outputDirectory, --FASTQ1, --FASTQ2 (--FASTQU); sample i runs on device i % #devices, all samples side by side.
 // Not rebuilt: the --BAM entry (the Perl driver never uses it: it extracts reads itself and passes FASTQ files), read simulation /
 // validation actions, KIR.
 #include <sys/stat.h>
@@ -19,12 +22,14 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <ctime>
 #include <fstream>
 #include <iostream>
 #include <map>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hlala_host.hpp"
@@ -123,7 +128,14 @@ int action_prepareGraph(const std::map<std::string, std::string>& arguments)
     return 0;
 }
 
-int action_HLA(const std::map<std::string, std::string>& arguments)
+std::vector<std::string> split_list(const std::string& l)
+{
+    std::vector<std::string> out;
+    for(size_t p = 0;;) { size_t q = l.find(',', p); out.push_back(l.substr(p, q == std::string::npos ? q : q - p)); if(q == std::string::npos) break; p = q + 1; }
+    return out;
+}
+
+int action_HLA_one(const std::map<std::string, std::string>& arguments, const std::vector<int>& devices)
 {
     unsigned int maxThreads = 1;
     need(arguments, "sampleID"); need(arguments, "outputDirectory"); need(arguments, "PRG_graph_dir");
@@ -156,41 +168,82 @@ int action_HLA(const std::map<std::string, std::string>& arguments)
     std::cout << timestamp() << "Remapping done.\n" << std::flush;
     if(!fileExists(BAM_remapped) || !fileExists(BAM_remapped + ".bai")) throw std::runtime_error("Remapping did not produce " + BAM_remapped + " and its index");
 
-    const int device = arguments.count("device") ? std::atoi(arguments.at("device").c_str()) : 0;
+    const int decodeThreads = arguments.count("decodeThreads") ? std::atoi(arguments.at("decodeThreads").c_str()) : 0;
+    const auto tStart = std::chrono::steady_clock::now();
     const int32_t batchPairs = arguments.count("batchPairs") ? (int32_t)std::atol(arguments.at("batchPairs").c_str()) : (longReads.length() ? 65536 : 1048576);
     const uint32_t rngSeed = arguments.count("rngSeed") ? (uint32_t)std::strtoul(arguments.at("rngSeed").c_str(), nullptr, 10) : 0u;
     // long reads: columns of a read incl. the levels it skips (hlala_batch_create_unpaired)
-    mapper::processBAM BAMprocessor(PRG_graph_dir, mapAgainstCompleteGenome, longReads.length() ? 16384 : 384, rngSeed, device);
+    mapper::processBAM BAMprocessor(PRG_graph_dir, mapAgainstCompleteGenome, longReads.length() ? 16384 : 384, rngSeed, devices, decodeThreads);
     // the G-group table is looked up in the working directory, as the reference does (hla/HLATyper.cpp:4160-4166; HLA-LA.pl chdirs to the source directory)
     hla::HLATyper HLAtyper(PRG_graph_dir, fileExists("hla_nom_g.txt") ? "hla_nom_g.txt" : "");
     std::vector<std::string> loci;
-    if(arguments.count("loci")) { const std::string l = arguments.at("loci"); for(size_t p = 0;;) { size_t q = l.find(',', p); loci.push_back(l.substr(p, q == std::string::npos ? q : q - p)); if(q == std::string::npos) break; p = q + 1; } }
+    if(arguments.count("loci")) loci = split_list(arguments.at("loci"));
     else for(const char* l : {"A", "B", "C", "DQA1", "DQB1", "DRB1", "DPA1", "DPB1", "DRA", "DRB3", "DRB4", "E", "F", "G", "H", "K", "V"}) {          // hla/HLATyper.cpp:42
         if(HLAtyper.has_locus(l)) loci.push_back(l); else std::cerr << "HLATypeInference(..): Locus " << l << ": no exon files in " << PRG_graph_dir << "/PRG -- skipped\n";
     }
 
     std::cout << timestamp() << "Start seed extraction\n" << std::flush;
+    const auto tOpen = std::chrono::steady_clock::now();
     BAMprocessor.openBAM(BAM_remapped, longReads.length() != 0, batchPairs);
+    const double openSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tOpen).count();
+    std::cout << timestamp() << "Seed extraction: " << BAMprocessor.n_units << " complete units, BAM decoded in " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
+              << " threads (index " << BAMprocessor.decode_phase_seconds[0] << ", inflate " << BAMprocessor.decode_phase_seconds[1] << ", parse " << BAMprocessor.decode_phase_seconds[2] << ", group "
+              << BAMprocessor.decode_phase_seconds[3] << ", name sort " << BAMprocessor.decode_phase_seconds[4] << ", layout " << BAMprocessor.decode_phase_seconds[5] << "); contexts on " << BAMprocessor.n_devices()
+              << " device(s) + insert size: " << openSeconds - BAMprocessor.decode_seconds << " s\n" << std::flush;
     if(!longReads.length()) std::cout << "Insert size: mean " << BAMprocessor.IS_mean << ", sd " << BAMprocessor.IS_sd << "\n" << std::flush;
     const std::string outputDirectory_for_HLA = outputDirectory + "/hla/";
     make_or_clearDirectory(outputDirectory + "/hla");                                                   // processBAM.cpp:1805-1806
-    std::cout << timestamp() << "Alignment of " << BAMprocessor.n_units << (longReads.length() ? " reads" : " read pairs") << " in " << BAMprocessor.n_batches() << " GPU batch(es)\n" << std::flush;
+    std::cout << timestamp() << "Alignment of " << BAMprocessor.n_units << (longReads.length() ? " reads" : " read pairs") << " in " << BAMprocessor.n_batches() << " GPU batch(es) on " << BAMprocessor.n_devices() << " device context(s)\n" << std::flush;
     double alignSeconds = 0; int64_t chainErrors = 0;
+    const auto tInfer = std::chrono::steady_clock::now();
     std::vector<hla::HLATyper::bestGuess> calls = HLAtyper.HLATypeInference(BAMprocessor, outputDirectory_for_HLA, loci, &alignSeconds, &chainErrors);
+    const double inferSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tInfer).count();
     const size_t pairs = longReads.length() ? 0 : (size_t)BAMprocessor.n_units, unpaired = longReads.length() ? (size_t)BAMprocessor.n_units : 0;
     std::cout << timestamp() << "Processed " << pairs << " protoSeeds (read pairs) / " << unpaired << " protoSeeds (unpaired long reads)\n" << std::flush;
     std::cout << "Speed: " << (alignSeconds > 0 ? (double)(pairs + unpaired) / alignSeconds : 0.0) << " protoSeeds (read pairs) per s" << "\n" << std::flush;      // :1894-1898
+    // BAM bytes -> hla/*: seed extraction (decode, contexts, insert size) + alignment + typing (everything after the remapping)
+    { const double e2e = BAMprocessor.decode_seconds + inferSeconds;
+      std::cout << "End-to-end: " << (e2e > 0 ? (double)(pairs + unpaired) / e2e : 0.0) << " units per s (BAM decode " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
+                << " threads + alignment and typing " << inferSeconds << " s; context creation and insert size " << openSeconds - BAMprocessor.decode_seconds << " s and graph loading are per process, not per sample; "
+                << "whole action after the remapping: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s)\n" << std::flush; }
     if(chainErrors) std::cerr << "WARNING: " << chainErrors << " alignments exceeded a device capacity; their read pairs are not used for typing\n";
     // reads_per_level.txt, processBAM.cpp:1902-1913
     {
-        std::vector<int32_t> cov((size_t)(BAMprocessor.n_levels > 1 ? BAMprocessor.n_levels - 1 : 1));
-        if(hlala_get_coverage(BAMprocessor.ctx(), cov.data(), 0) != HLALA_OK) throw std::runtime_error(std::string("hlala_get_coverage: ") + hlala_last_error(BAMprocessor.ctx()));
+        const std::vector<int32_t> cov = BAMprocessor.coverage();
         std::ofstream levels_stream((outputDirectory + "/reads_per_level.txt").c_str());
         if(!levels_stream.is_open()) throw std::runtime_error("Cannot open " + outputDirectory + "/reads_per_level.txt");
         for(size_t lI = 0; lI + 1 < (size_t)BAMprocessor.n_levels; lI++) levels_stream << lI << "\t" << HLAtyper.level_name((int32_t)lI) << "\t" << cov[lI] << "\n";
     }
     if(!fileExists(outputDirectory + "/hla/R1_bestguess.txt")) throw std::runtime_error("HLA type inference did not produce " + outputDirectory + "/hla/R1_bestguess.txt");
     for(const hla::HLATyper::bestGuess& g : calls) std::cout << "Locus " << g.locus << ": " << g.allele1 << " (Q1 " << g.Q1_allele1 << ") / " << g.allele2 << " (Q1 " << g.Q1_allele2 << ")\n";
+    return 0;
+}
+
+// one sample on all listed devices, or several samples side by side, sample i on device i % #devices (BASELINE config 4: one sample per GPU; the
+// result rows of every sample are its own files under its own output directory, as with one call per sample)
+int action_HLA(const std::map<std::string, std::string>& arguments)
+{
+    std::vector<int> devices;
+    if(arguments.count("devices")) for(const std::string& d : split_list(arguments.at("devices"))) devices.push_back(std::atoi(d.c_str()));
+    else devices.push_back(arguments.count("device") ? std::atoi(arguments.at("device").c_str()) : 0);
+    need(arguments, "sampleID");
+    const std::vector<std::string> samples = split_list(arguments.at("sampleID"));
+    if(samples.size() <= 1) return action_HLA_one(arguments, devices);
+    std::vector<std::map<std::string, std::string>> per(samples.size(), arguments);
+    for(const char* k : {"sampleID", "outputDirectory", "FASTQ1", "FASTQ2", "FASTQU"}) {
+        if(!arguments.count(k)) continue;
+        const std::vector<std::string> v = split_list(arguments.at(k));
+        if(v.size() != samples.size()) throw std::runtime_error(std::string("--") + k + " must list one value per sample (" + std::to_string(samples.size()) + " samples)");
+        for(size_t i = 0; i < samples.size(); i++) per[i][k] = v[i];
+    }
+    std::vector<std::string> errs(samples.size());
+    std::vector<std::thread> th;
+    for(size_t i = 0; i < samples.size(); i++) th.emplace_back([&, i]() {
+        try { action_HLA_one(per[i], std::vector<int>(1, devices[i % devices.size()])); } catch(const std::exception& e) { errs[i] = e.what(); }
+    });
+    for(std::thread& t : th) t.join();
+    for(size_t i = 0; i < samples.size(); i++) if(!errs[i].empty()) throw std::runtime_error("sample " + samples[i] + ": " + errs[i]);
+    std::cout << timestamp() << "Processed " << samples.size() << " samples on " << devices.size() << " device(s)\n" << std::flush;
     return 0;
 }
 

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -140,20 +141,20 @@ public:
     // processBAM::alignOneReadPair over a batch of proto seeds (mapper/processBAM.cpp:3129)
     std::vector<reads::verboseSeedChainPair> alignReadPairs(const std::vector<reads::protoSeeds>& seeds) const
     {
-        std::vector<int32_t> read_off{0}, chain_off{0}, read_primary, contig, pos, offs, as, cigar_off{0}; std::vector<uint8_t> bases, quals, rev; std::vector<uint32_t> cigar;
+        std::vector<int64_t> read_off{0}, chain_off{0}, cigar_off{0}; std::vector<int32_t> read_primary, contig, pos, offs, as; std::vector<uint8_t> bases, quals, rev; std::vector<uint32_t> cigar;
         for(const reads::protoSeeds& ps : seeds)
             for(int m = 0; m < 2; m++) {
                 const std::vector<reads::BamRecord>& al = m ? ps.read2_alignments : ps.read1_alignments;
                 const std::string& qb = m ? ps.read2_QueryBases : ps.read1_QueryBases; const std::string& ql = m ? ps.read2_Qualities : ps.read1_Qualities;
-                bases.insert(bases.end(), qb.begin(), qb.end()); quals.insert(quals.end(), ql.begin(), ql.end()); read_off.push_back((int32_t)bases.size());
+                bases.insert(bases.end(), qb.begin(), qb.end()); quals.insert(quals.end(), ql.begin(), ql.end()); read_off.push_back((int64_t)bases.size());
                 int prim = -1;
                 for(const reads::BamRecord& a : al) {
                     if(a.IsPrimaryAlignment) prim = (int)contig.size();
                     contig.push_back(a.contig); pos.push_back(a.Position); offs.push_back(a.reference2level_offset); as.push_back(a.AS); rev.push_back(a.IsReverseStrand ? 1 : 0);
-                    cigar.insert(cigar.end(), a.CigarData.begin(), a.CigarData.end()); cigar_off.push_back((int32_t)cigar.size());
+                    cigar.insert(cigar.end(), a.CigarData.begin(), a.CigarData.end()); cigar_off.push_back((int64_t)cigar.size());
                 }
                 if(prim < 0) throw std::runtime_error("protoSeeds without a primary alignment (protoSeeds.cpp:255-330 asserts)");
-                read_primary.push_back(prim); chain_off.push_back((int32_t)contig.size());
+                read_primary.push_back(prim); chain_off.push_back((int64_t)contig.size());
             }
         hlala_batch_in in{(int32_t)seeds.size(), read_off.data(), bases.data(), quals.data(), chain_off.data(), read_primary.data(), (int32_t)contig.size(), contig.data(),
                           pos.data(), offs.data(), as.data(), rev.data(), cigar_off.data(), cigar.data()};
@@ -186,7 +187,7 @@ public:
                     c.graph_aligned_levels.assign(lev.begin() + o, lev.begin() + o + k); c.graph_aligned_edges.assign(edg.begin() + o, edg.begin() + o + k);
                     c.graph_aligned.assign(g.begin() + o, g.begin() + o + k); c.sequence_aligned.assign(s.begin() + o, s.begin() + o + k);
                     c.mapQ_perPosition.assign(pq.begin() + o, pq.begin() + o + k); c.is_from_BWAseed.assign(fs.begin() + o, fs.begin() + o + k);
-                    c.mapQ = mmq[r]; c.reverse = rev[best[r]] != 0; c.sequence_begin = 0; c.sequence_end = read_off[r + 1] - read_off[r] - 1;
+                    c.mapQ = mmq[r]; c.reverse = rev[best[r]] != 0; c.sequence_begin = 0; c.sequence_end = (int)(read_off[r + 1] - read_off[r]) - 1;
                 }
                 out.push_back(vp);
             }
@@ -222,12 +223,17 @@ private:
 }  // namespace aligner
 
 // mapper::processBAM as far as the hot path needs it: the graph directory (serializedGRAPH cache or PRG/graph.txt, sequences.txt,
-// reference FASTA, translation files) becomes a context; a BAM file becomes seeds that go through the GPU in batches of at most
-// `batchPairs` units (the reference walks 10 000 read IDs at a time, mapper/processBAM.cpp:1794; BASELINE config 3 is ~10 M pairs).
+// reference FASTA, translation files) becomes one context per GPU; a BAM file becomes the seeds of the whole sample (64-bit offsets, decoded on
+// `threads` host threads), which go through the GPUs in batches of at most `batchPairs` units (the reference walks 10 000 read IDs at a time on
+// its threads, mapper/processBAM.cpp:1794, 2391-2483; BASELINE config 3 is ~10 M pairs).  Batch bi runs on device bi % #devices and keeps the
+// absolute numbering of its chains, so every DP draws the random seed it draws in a one-batch, one-GPU run: results do not depend on the
+// batch size or on the number of devices.
 class processBAM {
 public:
     processBAM(const std::string& graphDir, bool extendedReferenceGenome, int max_columns = 384, uint32_t rng_seed = 0, int device = 0)
-        : graphDir_(graphDir), extended_(extendedReferenceGenome), max_columns_(max_columns), rng_seed_(rng_seed), device_(device)
+        : processBAM(graphDir, extendedReferenceGenome, max_columns, rng_seed, std::vector<int>(1, device), 0) {}
+    processBAM(const std::string& graphDir, bool extendedReferenceGenome, int max_columns, uint32_t rng_seed, const std::vector<int>& devices, int threads)
+        : graphDir_(graphDir), extended_(extendedReferenceGenome), max_columns_(max_columns), rng_seed_(rng_seed), devices_(devices.empty() ? std::vector<int>(1, 0) : devices), threads_(threads)
     {
         // `--action prepareGraph` leaves the flattened arrays in <graphDir>/serializedGRAPH; a file of that name written by the reference
         // binary (a Boost archive) is not ours and the text graph is parsed instead
@@ -239,85 +245,88 @@ public:
         intervals_.resize((size_t)hlala_contigs_file_intervals(contigs_, nullptr, 0));
         hlala_contigs_file_intervals(contigs_, intervals_.data(), (int32_t)intervals_.size());
     }
-    ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); if(seeds_) hlala_seed_batch_free(seeds_); if(ctx_) hlala_destroy(ctx_); hlala_contigs_file_free(contigs_); hlala_graph_file_free(graph_); }
+    ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); for(hlala_ctx* c : ctxs_) if(c) hlala_destroy(c); if(seeds_) hlala_seed_batch_free(seeds_); hlala_contigs_file_free(contigs_); hlala_graph_file_free(graph_); }
     processBAM(const processBAM&) = delete;
     processBAM& operator=(const processBAM&) = delete;
 
     // initBAM + extractSeeds2 + estimateInsertSize (mapper/processBAM.cpp:1183-1402, 703-864, 1071-1165): seeds of all complete units, insert
-    // size from the first 4000 of them (:1075), then the context with that insert size.  batchPairs = 0: one batch.
+    // size from the first 4000 of them (:1075) on the first device, then every context gets that insert size.  batchPairs = 0: one batch.
     void openBAM(const std::string& BAM, bool longReads = false, int32_t batchPairs = 0)
     {
-        if(hlala_bam_extract_seeds(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, &seeds_) != HLALA_OK) throw std::runtime_error(std::string("BAM: ") + hlala_bam_last_error());
-        int64_t counts[3]; hlala_seed_batch_desc(seeds_, &in_, counts);
-        n_units = in_.n_pairs; longReadsMode = longReads;
-        readIDs.clear();
-        for(int32_t u = 0; u < in_.n_pairs; u++) readIDs.push_back(hlala_seed_batch_name(seeds_, u));
+        const auto t0 = std::chrono::steady_clock::now();
+        if(hlala_bam_extract_seeds_mt(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, threads_, &seeds_) != HLALA_OK) throw std::runtime_error(std::string("BAM: ") + hlala_bam_last_error());
+        decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        hlala_seed_batch_timing(seeds_, decode_phase_seconds, &decode_threads);
+        n_units = hlala_seed_batch_units(seeds_); longReadsMode = longReads;
+        (void)hlala_seed_batch_pin(seeds_, 1);                                        // page-locked: batch uploads are plain DMA (a refusal only costs speed)
         hlala_graph_desc gd; hlala_graph_file_desc(graph_, &gd);
         hlala_contigs_desc cd; hlala_contigs_file_desc(contigs_, &cd);
         n_levels = gd.n_levels;
         hlala_params pr{200.0, 35.0, rng_seed_, longReads ? 1 : 0, max_columns_, 0};
-        if(!longReads) {                                                              // insert size from this sample, then the real context
-            if(n_units == 0) throw std::runtime_error("estimateInsertSize: no complete read pair in " + BAM);
-            hlala_ctx* c0 = nullptr;
-            if(hlala_create(&c0, device_, nullptr, &gd, &cd, &pr) != HLALA_OK) throw std::runtime_error(std::string("hlala_create: ") + hlala_last_error(nullptr));
-            Slice first; slice(0, n_units < 4000 ? n_units : 4000, first);
-            hlala_insert_size_out is; int rc = hlala_estimate_insert_size(c0, &first.in, &is);
-            std::string e = rc ? hlala_last_error(c0) : ""; hlala_destroy(c0);
-            if(rc) throw std::runtime_error("estimateInsertSize: " + e);
-            IS_mean = is.mean; IS_sd = is.sd; pr.insert_mean = is.mean; pr.insert_sd = is.sd;
+        if(!longReads && n_units == 0) throw std::runtime_error("estimateInsertSize: no complete read pair in " + BAM);
+        // one context per device, created side by side (each flattens and uploads the graph)
+        ctxs_.assign(devices_.size(), nullptr);
+        std::vector<std::string> errs(devices_.size());
+        std::vector<std::thread> th;
+        for(size_t d = 0; d < devices_.size(); d++) th.emplace_back([&, d]() { if(hlala_create(&ctxs_[d], devices_[d], nullptr, &gd, &cd, &pr) != HLALA_OK) errs[d] = std::string("hlala_create: ") + hlala_last_error(nullptr); });
+        for(std::thread& t : th) t.join();
+        for(const std::string& e : errs) if(!e.empty()) throw std::runtime_error(e);
+        if(!longReads) {                                                              // insert size from this sample
+            hlala_batch_in first; window(0, n_units < 4000 ? (int32_t)n_units : 4000, first);
+            hlala_insert_size_out is; int rc = hlala_estimate_insert_size(ctxs_[0], &first, &is);
+            if(rc) throw std::runtime_error(std::string("estimateInsertSize: ") + hlala_last_error(ctxs_[0]));
+            IS_mean = is.mean; IS_sd = is.sd;
+            for(hlala_ctx* c : ctxs_) if(hlala_set_insert_size(c, is.mean, is.sd) != HLALA_OK) throw std::runtime_error(std::string("hlala_set_insert_size: ") + hlala_last_error(c));
         }
-        if(hlala_create(&ctx_, device_, nullptr, &gd, &cd, &pr) != HLALA_OK) throw std::runtime_error(std::string("hlala_create: ") + hlala_last_error(nullptr));
-        batchPairs_ = batchPairs > 0 ? batchPairs : (n_units > 0 ? n_units : 1);
-        live_.assign(n_batches(), nullptr);
+        batchPairs_ = batchPairs > 0 ? batchPairs : (n_units > 0 ? (n_units > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)n_units) : 1);
+        live_.assign((size_t)n_batches(), nullptr);
     }
-    int32_t n_batches() const { return n_units == 0 ? 0 : (n_units + batchPairs_ - 1) / batchPairs_; }
-    int32_t batch_first_unit(int32_t bi) const { return bi * batchPairs_; }
-    int32_t batch_units(int32_t bi) const { int32_t a = bi * batchPairs_, z = a + batchPairs_; return (z > n_units ? n_units : z) - a; }
-    // batch bi resident on the GPU: uploaded and, if `align`, run through alignOneReadPair / alignOneLongRead (:3129 / :3618); the chains
-    // keep their absolute numbers, so every DP draws the random seed it would draw in one big batch
+    int32_t n_batches() const { return n_units == 0 ? 0 : (int32_t)((n_units + batchPairs_ - 1) / batchPairs_); }
+    int64_t batch_first_unit(int32_t bi) const { return (int64_t)bi * batchPairs_; }
+    int32_t batch_units(int32_t bi) const { int64_t a = (int64_t)bi * batchPairs_, z = a + batchPairs_; return (int32_t)((z > n_units ? n_units : z) - a); }
+    int n_devices() const { return (int)ctxs_.size(); }
+    int batch_device(int32_t bi) const { return (int)(bi % (int32_t)ctxs_.size()); }
+    hlala_ctx* batch_ctx(int32_t bi) const { return ctxs_[(size_t)batch_device(bi)]; }
+    // batch bi resident on its GPU: uploaded and, if `align`, run through alignOneReadPair / alignOneLongRead (:3129 / :3618).  Batches of
+    // different devices may be acquired from different host threads (one thread per device).
     hlala_batch* acquire(int32_t bi, bool align)
     {
-        if(live_.at(bi)) return live_[bi];
-        Slice s; slice(batch_first_unit(bi), batch_units(bi), s);
+        if(live_.at((size_t)bi)) return live_[(size_t)bi];
+        hlala_ctx* c = batch_ctx(bi);
+        hlala_batch_in in; window(batch_first_unit(bi), batch_units(bi), in);
         hlala_batch* b = nullptr;
-        int rc = longReadsMode ? hlala_batch_create_unpaired(ctx_, &s.in, &b) : hlala_batch_create(ctx_, &s.in, &b);
-        if(rc == HLALA_OK) rc = hlala_batch_set_first_chain(b, (uint32_t)s.first_chain);
-        if(rc == HLALA_OK && align) rc = hlala_align_batch(ctx_, b);
-        if(rc != HLALA_OK) { std::string e = hlala_last_error(ctx_); if(b) hlala_batch_destroy(b); throw std::runtime_error("alignReads: " + e); }
-        live_[bi] = b;
+        int rc = longReadsMode ? hlala_batch_create_unpaired(c, &in, &b) : hlala_batch_create(c, &in, &b);       // (chain_off[0] of the window is the batch's first absolute chain number)
+        if(rc == HLALA_OK && align) rc = hlala_align_batch(c, b);
+        if(rc != HLALA_OK) { std::string e = hlala_last_error(c); if(b) hlala_batch_destroy(b); throw std::runtime_error("alignReads: " + e); }
+        live_[(size_t)bi] = b;
         return b;
     }
-    void release(int32_t bi) { if(live_.at(bi)) { hlala_batch_destroy(live_[bi]); live_[bi] = nullptr; } }
+    void release(int32_t bi) { if(live_.at((size_t)bi)) { hlala_batch_destroy(live_[(size_t)bi]); live_[(size_t)bi] = nullptr; } }
 
     // extractSeeds2 + estimateInsertSize + alignReads_postSeedExtraction (mapper/processBAM.cpp:703-864, 1071-1165, 2391-2483), one batch
     void alignReads(const std::string& BAM, bool longReads = false) { openBAM(BAM, longReads, 0); if(n_units > 0) acquire(0, true); }
-    hlala_ctx* ctx() const { return ctx_; }
+    hlala_ctx* ctx() const { return ctxs_.empty() ? nullptr : ctxs_[0]; }
     hlala_batch* batch() const { return live_.empty() ? nullptr : live_[0]; }
-    std::vector<std::string> readIDs;
+    const char* readID(int64_t unit) const { return hlala_seed_batch_name(seeds_, unit); }
+    // bases_per_level summed over the devices (reads_per_level.txt, processBAM.cpp:1902-1913: the per-thread counters are added up, :1866-1887)
+    std::vector<int32_t> coverage() const
+    {
+        std::vector<int32_t> cov((size_t)(n_levels > 1 ? n_levels - 1 : 1), 0), one(cov.size());
+        for(hlala_ctx* c : ctxs_) { if(hlala_get_coverage(c, one.data(), 0) != HLALA_OK) throw std::runtime_error(std::string("hlala_get_coverage: ") + hlala_last_error(c)); for(size_t i = 0; i < cov.size(); i++) cov[i] += one[i]; }
+        return cov;
+    }
     double IS_mean = 200.0, IS_sd = 35.0;
-    int32_t n_units = 0, n_levels = 0; bool longReadsMode = false;
+    int64_t n_units = 0; int32_t n_levels = 0; bool longReadsMode = false;
+    double decode_seconds = 0, decode_phase_seconds[6] = {0, 0, 0, 0, 0, 0}; int32_t decode_threads = 0;
 
 private:
-    // units [u0, u0 + n) of the seeds as a batch descriptor of their own (offset arrays rebased to 0)
-    struct Slice { hlala_batch_in in; std::vector<int32_t> read_off, chain_off, read_primary, cigar_off; int64_t first_chain = 0; };
-    void slice(int32_t u0, int32_t n, Slice& s) const
+    void window(int64_t u0, int32_t n, hlala_batch_in& in) const
     {
-        const int per = longReadsMode ? 1 : 2; const int32_t r0 = per * u0, nr = per * n;
-        const int32_t c0 = in_.chain_off[r0], c1 = in_.chain_off[r0 + nr], b0 = in_.read_off[r0], g0 = in_.cigar_off[c0];
-        s.read_off.resize((size_t)nr + 1); s.chain_off.resize((size_t)nr + 1); s.read_primary.resize((size_t)nr); s.cigar_off.resize((size_t)(c1 - c0) + 1);
-        for(int32_t i = 0; i <= nr; i++) { s.read_off[i] = in_.read_off[r0 + i] - b0; s.chain_off[i] = in_.chain_off[r0 + i] - c0; }
-        for(int32_t i = 0; i < nr; i++) s.read_primary[i] = in_.read_primary[r0 + i] - c0;
-        for(int32_t i = 0; i <= c1 - c0; i++) s.cigar_off[i] = in_.cigar_off[c0 + i] - g0;
-        s.first_chain = c0;
-        s.in = in_;
-        s.in.n_pairs = n; s.in.read_off = s.read_off.data(); s.in.read_bases = in_.read_bases + b0; s.in.read_quals = in_.read_quals + b0;
-        s.in.chain_off = s.chain_off.data(); s.in.read_primary = s.read_primary.data(); s.in.n_chains = c1 - c0;
-        s.in.chain_contig = in_.chain_contig + c0; s.in.chain_pos = in_.chain_pos + c0; s.in.chain_offset = in_.chain_offset + c0; s.in.chain_as = in_.chain_as + c0;
-        s.in.chain_reverse = in_.chain_reverse + c0; s.in.cigar_off = s.cigar_off.data(); s.in.cigar = in_.cigar + g0;
+        if(hlala_seed_batch_window(seeds_, u0, n, &in) != HLALA_OK) throw std::runtime_error(std::string("alignReads: ") + hlala_bam_last_error());
     }
-    std::string graphDir_; bool extended_; int max_columns_; uint32_t rng_seed_; int device_;
+    std::string graphDir_; bool extended_; int max_columns_; uint32_t rng_seed_; std::vector<int> devices_; int threads_;
     hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; std::vector<hlala_bam_interval> intervals_;
-    hlala_seed_batch* seeds_ = nullptr; hlala_batch_in in_{}; hlala_ctx* ctx_ = nullptr;
+    hlala_seed_batch* seeds_ = nullptr; std::vector<hlala_ctx*> ctxs_;
     int32_t batchPairs_ = 1; std::vector<hlala_batch*> live_;
 };
 }  // namespace mapper
@@ -351,16 +360,16 @@ public:
     std::vector<bestGuess> HLATypeInference(mapper::processBAM& pB, const std::string& outputDirectory, const std::vector<std::string>& loci_for_HLAtyping,
                                             double* align_seconds = nullptr, int64_t* chain_errors = nullptr)
     {
-        hlala_ctx* c = pB.ctx();
+        hlala_ctx* c = pB.ctx();                          // the per-locus chain (likelihoods, all pairs, call) runs on the first device
         auto chk = [&](int rc, const char* what) { if(rc != HLALA_OK) throw std::runtime_error(std::string(what) + ": " + hlala_last_error(c)); };
         auto tchk = [&](int rc, const char* what) { if(rc != HLALA_OK) throw std::runtime_error(std::string(what) + ": " + hlala_typer_last_error()); };
+        const int nDev = pB.n_devices();
         // interestingLevels -> coverage counters and includeInHLA (mapper/processBAM.cpp:2411-2446)
         std::vector<int32_t> first, last;
         for(int32_t i = 0; i < hlala_typer_n_genes(t_); i++) { const char* nm; int32_t a, z; hlala_typer_gene(t_, i, &nm, &a, &z); first.push_back(a); last.push_back(z); }
-        chk(hlala_set_gene_intervals(c, (int32_t)first.size(), first.data(), last.data()), "hlala_set_gene_intervals");
+        for(int d = 0; d < nDev; d++) { hlala_ctx* cd = pB.batch_ctx(d); if(hlala_set_gene_intervals(cd, (int32_t)first.size(), first.data(), last.data()) != HLALA_OK) throw std::runtime_error(std::string("hlala_set_gene_intervals: ") + hlala_last_error(cd)); }
         const size_t nU = (size_t)pB.n_units;
         std::vector<uint8_t> include(nU + 1);
-        std::vector<const char*> names; for(const std::string& s : pB.readIDs) names.push_back(s.c_str());
         tchk(hlala_typer_begin_output(outputDirectory.c_str(), 0.2), "hlala_typer_begin_output");
         std::vector<uint8_t> usValid(nU + 1), usStrands(nU + 1); std::vector<int32_t> usDist(nU + 1), usCols(2 * nU + 1); std::vector<double> usF(2 * nU + 1), usW(2 * nU + 1), usQ(2 * nU + 1);
         if(pB.longReadsMode) filterParams.long_read_strand_filter = 1;
@@ -377,47 +386,75 @@ public:
             tchk(hlala_typer_locus(t_, acc[i].locus.c_str(), 0, nullptr, &acc[i].L), "hlala_typer_locus");
             hlala_locus_get(acc[i].L, &acc[i].li);
         }
-        // ---- batches
-        double alignS = 0; int64_t errors = 0;
+        // ---- batches.  One host thread per device walks the batches of its device (bi % #devices), two in flight: the next batch is uploaded and its
+        // alignment queued before the current one is read back (the reader calls wait for their own batch only).  What the typing needs of a batch is
+        // kept per batch (exon positions of every locus: a few thousand reads) and appended in batch order afterwards -- the order of one walk over the
+        // sample on one device (the reference adds up its per-thread results in thread order, mapper/processBAM.cpp:1866-1887).
+        struct LocusPart { std::vector<int32_t> read_pair, read_distance, cols, pos_off, pos_exon, pos_level, novel, geno_off; std::vector<double> wok, fok, rmapq; std::vector<uint8_t> mate, pmapq, geno, qual, rrev; int32_t ok = 0, broken = 0; size_t nR = 0, nP = 0, nC = 0; };
         const int32_t nB = pB.n_batches();
+        std::vector<std::vector<LocusPart>> parts((size_t)nB, std::vector<LocusPart>(acc.size()));
+        std::vector<double> devAlign((size_t)nDev, 0.0); std::vector<int64_t> devErrors((size_t)nDev, 0); std::vector<std::string> devErr((size_t)nDev);
+        const auto tAll = std::chrono::steady_clock::now();
+        auto device_walk = [&](int d) {
+            try {
+                hlala_ctx* cd = pB.batch_ctx(d);
+                auto dchk = [&](int rc, const char* what) { if(rc != HLALA_OK) throw std::runtime_error(std::string(what) + ": " + hlala_last_error(cd)); };
+                for(int32_t bi = d; bi < nB; bi += nDev) {
+                    const size_t u0 = (size_t)pB.batch_first_unit(bi);
+                    const auto t0 = std::chrono::steady_clock::now();
+                    hlala_batch* b = pB.acquire(bi, true);
+                    if(bi + nDev < nB) pB.acquire(bi + nDev, true);      // two batches in flight per device
+                    hlala_batch_stats bs; dchk(hlala_batch_get_stats(cd, b, &bs), "hlala_batch_get_stats");          // (waits for this batch only)
+                    devAlign[(size_t)d] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    devErrors[(size_t)d] += bs.n_errors;
+                    dchk(hlala_postprocess_pairs(cd, b, include.data() + u0), "hlala_postprocess_pairs");
+                    // read alignment statistics (hla/HLATyper.cpp:1030-1125) and the per-pair quantities of the histogram lines
+                    hlala_unit_stats_out usb{usValid.data() + u0, usStrands.data() + u0, usDist.data() + u0, usF.data() + 2 * u0, usW.data() + 2 * u0, usCols.data() + 2 * u0, usQ.data() + 2 * u0};
+                    dchk(hlala_unit_alignment_stats(cd, b, &usb), "hlala_unit_alignment_stats");
+                    for(size_t li = 0; li < acc.size(); li++) {
+                        Acc& A = acc[li]; LocusPart& P = parts[(size_t)bi][li];
+                        hlala_locus_desc ld{A.li.level_min, A.li.level_max, A.li.level_to_exon, pB.IS_mean, pB.IS_sd, minimumMappingQuality, min_bothReads_weightedCharactersOK, include.data() + u0, minAlignmentLength_unpaired, 0};
+                        hlala_exon_positions_out pos; std::memset(&pos, 0, sizeof(pos));
+                        int rc = hlala_exon_positions(cd, b, &ld, &pos);                                             // sizing call
+                        if(rc != HLALA_OK && rc != HLALA_E_CAPACITY) dchk(rc, "hlala_exon_positions");
+                        const size_t nR = (size_t)pos.n_reads, nP = (size_t)pos.n_pos, nC = (size_t)pos.n_chars;
+                        P.nR = nR; P.nP = nP; P.nC = nC;
+                        P.read_pair.resize(nR + 1); P.read_distance.resize(nR + 1); P.cols.resize(2 * nR + 1); P.pos_off.resize(nR + 2); P.pos_exon.resize(nP + 1); P.pos_level.resize(nP + 1); P.novel.resize(nP + 1); P.geno_off.resize(nP + 2);
+                        P.wok.resize(2 * nR + 1); P.fok.resize(2 * nR + 1); P.rmapq.resize(2 * nR + 1); P.mate.resize(nP + 1); P.pmapq.resize(nP + 1); P.geno.resize(nC + 1); P.qual.resize(nC + 1); P.rrev.resize(2 * nR + 1);
+                        pos.cap_reads = (int32_t)nR; pos.cap_pos = (int32_t)nP; pos.cap_chars = (int32_t)nC;
+                        pos.read_pair = P.read_pair.data(); pos.read_weighted_ok = P.wok.data(); pos.read_fraction_ok = P.fok.data(); pos.read_distance = P.read_distance.data(); pos.read_cols_nongap = P.cols.data();
+                        pos.pos_off = P.pos_off.data(); pos.pos_exon = P.pos_exon.data(); pos.pos_level = P.pos_level.data(); pos.pos_mate = P.mate.data(); pos.pos_mapq = P.pmapq.data(); pos.pos_novel_gap = P.novel.data();
+                        pos.geno_off = P.geno_off.data(); pos.geno_chars = P.geno.data(); pos.qual_chars = P.qual.data(); pos.read_reverse = P.rrev.data(); pos.read_mapq = P.rmapq.data();
+                        if(nR > 0) dchk(hlala_exon_positions(cd, b, &ld, &pos), "hlala_exon_positions");
+                        P.ok = pos.n_pairs_ok; P.broken = pos.n_pairs_broken;
+                    }
+                    if(nB > 1) pB.release(bi);
+                }
+            } catch(const std::exception& e) { devErr[(size_t)d] = e.what(); }
+        };
+        if(nDev == 1) device_walk(0);
+        else { std::vector<std::thread> th; for(int d = 0; d < nDev; d++) th.emplace_back(device_walk, d); for(std::thread& t : th) t.join(); }
+        for(const std::string& e : devErr) if(!e.empty()) throw std::runtime_error(e);
+        double alignS = nDev == 1 ? devAlign[0] : std::chrono::duration<double>(std::chrono::steady_clock::now() - tAll).count();
+        int64_t errors = 0; for(int64_t e : devErrors) errors += e;
         for(int32_t bi = 0; bi < nB; bi++) {
             const size_t u0 = (size_t)pB.batch_first_unit(bi);
-            const auto t0 = std::chrono::steady_clock::now();
-            hlala_batch* b = pB.acquire(bi, true);
-            if(bi + 1 < nB) pB.acquire(bi + 1, true);      // two batches in flight: the next one's bulk runs beside this one's tail (hlala_align_batch)
-            hlala_batch_stats bs; chk(hlala_batch_get_stats(c, b, &bs), "hlala_batch_get_stats");          // (synchronises: the batch is aligned)
-            alignS += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            errors += bs.n_errors;
-            chk(hlala_postprocess_pairs(c, b, include.data() + u0), "hlala_postprocess_pairs");
-            // read alignment statistics (hla/HLATyper.cpp:1030-1125) and the per-pair quantities of the histogram lines
-            hlala_unit_stats_out usb{usValid.data() + u0, usStrands.data() + u0, usDist.data() + u0, usF.data() + 2 * u0, usW.data() + 2 * u0, usCols.data() + 2 * u0, usQ.data() + 2 * u0};
-            chk(hlala_unit_alignment_stats(c, b, &usb), "hlala_unit_alignment_stats");
-            for(Acc& A : acc) {
-                hlala_locus_desc ld{A.li.level_min, A.li.level_max, A.li.level_to_exon, pB.IS_mean, pB.IS_sd, minimumMappingQuality, min_bothReads_weightedCharactersOK, include.data() + u0, minAlignmentLength_unpaired, 0};
-                hlala_exon_positions_out pos; std::memset(&pos, 0, sizeof(pos));
-                int rc = hlala_exon_positions(c, b, &ld, &pos);                                             // sizing call
-                if(rc != HLALA_OK && rc != HLALA_E_CAPACITY) chk(rc, "hlala_exon_positions");
-                const size_t nR = (size_t)pos.n_reads, nP = (size_t)pos.n_pos, nC = (size_t)pos.n_chars;
-                std::vector<int32_t> read_pair(nR + 1), read_distance(nR + 1), cols(2 * nR + 1), pos_off(nR + 2), pos_exon(nP + 1), pos_level(nP + 1), novel(nP + 1), geno_off(nP + 2);
-                std::vector<double> wok(2 * nR + 1), fok(2 * nR + 1), rmapq(2 * nR + 1); std::vector<uint8_t> mate(nP + 1), pmapq(nP + 1), geno(nC + 1), qual(nC + 1), rrev(2 * nR + 1);
-                pos.cap_reads = (int32_t)nR; pos.cap_pos = (int32_t)nP; pos.cap_chars = (int32_t)nC;
-                pos.read_pair = read_pair.data(); pos.read_weighted_ok = wok.data(); pos.read_fraction_ok = fok.data(); pos.read_distance = read_distance.data(); pos.read_cols_nongap = cols.data();
-                pos.pos_off = pos_off.data(); pos.pos_exon = pos_exon.data(); pos.pos_level = pos_level.data(); pos.pos_mate = mate.data(); pos.pos_mapq = pmapq.data(); pos.pos_novel_gap = novel.data();
-                pos.geno_off = geno_off.data(); pos.geno_chars = geno.data(); pos.qual_chars = qual.data(); pos.read_reverse = rrev.data(); pos.read_mapq = rmapq.data();
-                chk(hlala_exon_positions(c, b, &ld, &pos), "hlala_exon_positions");
+            for(size_t li = 0; li < acc.size(); li++) {
+                Acc& A = acc[li]; LocusPart& P = parts[(size_t)bi][li];
                 const int32_t pBase = A.pos_off.back(), gBase = A.geno_off.back();
-                for(size_t r = 0; r < nR; r++) { A.read_pair.push_back(read_pair[r] + (int32_t)u0); A.read_distance.push_back(read_distance[r]); A.pos_off.push_back(pos_off[r + 1] + pBase);
-                    for(int m = 0; m < 2; m++) { A.cols.push_back(cols[2 * r + m]); A.wok.push_back(wok[2 * r + m]); A.fok.push_back(fok[2 * r + m]); A.rmapq.push_back(rmapq[2 * r + m]); A.rrev.push_back(rrev[2 * r + m]); } }
-                for(size_t j = 0; j < nP; j++) { A.pos_exon.push_back(pos_exon[j]); A.pos_level.push_back(pos_level[j]); A.novel.push_back(novel[j]); A.mate.push_back(mate[j]); A.pmapq.push_back(pmapq[j]); A.geno_off.push_back(geno_off[j + 1] + gBase); }
-                A.geno.insert(A.geno.end(), geno.begin(), geno.begin() + nC); A.qual.insert(A.qual.end(), qual.begin(), qual.begin() + nC);
-                A.ok += pos.n_pairs_ok; A.broken += pos.n_pairs_broken;
+                for(size_t r = 0; r < P.nR; r++) { A.read_pair.push_back(P.read_pair[r] + (int32_t)u0); A.read_distance.push_back(P.read_distance[r]); A.pos_off.push_back(P.pos_off[r + 1] + pBase);
+                    for(int m = 0; m < 2; m++) { A.cols.push_back(P.cols[2 * r + m]); A.wok.push_back(P.wok[2 * r + m]); A.fok.push_back(P.fok[2 * r + m]); A.rmapq.push_back(P.rmapq[2 * r + m]); A.rrev.push_back(P.rrev[2 * r + m]); } }
+                for(size_t j = 0; j < P.nP; j++) { A.pos_exon.push_back(P.pos_exon[j]); A.pos_level.push_back(P.pos_level[j]); A.novel.push_back(P.novel[j]); A.mate.push_back(P.mate[j]); A.pmapq.push_back(P.pmapq[j]); A.geno_off.push_back(P.geno_off[j + 1] + gBase); }
+                A.geno.insert(A.geno.end(), P.geno.begin(), P.geno.begin() + P.nC); A.qual.insert(A.qual.end(), P.qual.begin(), P.qual.begin() + P.nC);
+                A.ok += P.ok; A.broken += P.broken;
+                LocusPart().pos_off.swap(P.pos_off);
             }
-            if(nB > 1) pB.release(bi);
         }
+        { std::vector<std::vector<LocusPart>>().swap(parts); }
         if(align_seconds) *align_seconds = alignS;
         if(chain_errors) *chain_errors = errors;
         hlala_unit_stats_out us{usValid.data(), usStrands.data(), usDist.data(), usF.data(), usW.data(), usCols.data(), usQ.data()};
-        tchk(hlala_typer_write_summary(outputDirectory.c_str(), pB.n_units, pB.longReadsMode ? 1 : 0, include.data(), &us, pB.IS_mean, pB.IS_sd, minAlignmentLength_unpaired), "hlala_typer_write_summary");
+        tchk(hlala_typer_write_summary(outputDirectory.c_str(), (int32_t)pB.n_units, pB.longReadsMode ? 1 : 0, include.data(), &us, pB.IS_mean, pB.IS_sd, minAlignmentLength_unpaired), "hlala_typer_write_summary");
         // ---- per locus: filters -> likelihoods -> all pairs -> call
         struct Res { hlala_exon_positions_out pos; std::vector<double> pairLL, misAvg, misMin, pNorm; std::vector<int32_t> order; hlala_call_out call; std::vector<char> q[2]; int32_t nq[2], nt[2]; std::vector<uint8_t> present[2]; };
         std::vector<Res> res(acc.size());
@@ -452,18 +489,37 @@ public:
             }
         }
         // ---- which of those k-mers occur in the reads that went into typing: one more pass over the reads (a batch that was released is
-        // uploaded again, not aligned again)
-        for(int32_t bi = 0; bi < nB; bi++) {
-            const size_t u0 = (size_t)pB.batch_first_unit(bi);
-            hlala_batch* b = pB.acquire(bi, false);
-            for(Res& R : res) for(int a = 0; a < 2; a++) {
-                std::vector<uint8_t> pr((size_t)R.nq[a] + 1);
-                chk(hlala_kmer_presence(c, b, include.data() + u0, k_for_kMer_index, R.nq[a], R.q[a].data(), pr.data()), "hlala_kmer_presence");
-                for(int32_t i = 0; i < R.nq[a]; i++) R.present[a][i] |= pr[i];
-            }
-            if(nB > 1) pB.release(bi);
+        // uploaded again, not aligned again), every device over its own batches
+        {
+            std::vector<std::string> kErr((size_t)nDev);
+            std::vector<std::vector<std::vector<uint8_t>>> devPresent((size_t)nDev);      // [device][2 * locus + allele][query]
+            auto kmer_walk = [&](int d) {
+                try {
+                    hlala_ctx* cd = pB.batch_ctx(d);
+                    std::vector<std::vector<uint8_t>>& mine = devPresent[(size_t)d];
+                    mine.resize(2 * res.size());
+                    for(size_t li = 0; li < res.size(); li++) for(int a = 0; a < 2; a++) mine[2 * li + (size_t)a].assign((size_t)res[li].nq[a] + 1, 0);
+                    for(int32_t bi = d; bi < nB; bi += nDev) {
+                        const size_t u0 = (size_t)pB.batch_first_unit(bi);
+                        hlala_batch* b = pB.acquire(bi, false);
+                        for(size_t li = 0; li < res.size(); li++) for(int a = 0; a < 2; a++) {
+                            Res& R = res[li];
+                            std::vector<uint8_t> pr((size_t)R.nq[a] + 1);
+                            if(hlala_kmer_presence(cd, b, include.data() + u0, k_for_kMer_index, R.nq[a], R.q[a].data(), pr.data()) != HLALA_OK) throw std::runtime_error(std::string("hlala_kmer_presence: ") + hlala_last_error(cd));
+                            for(int32_t i = 0; i < R.nq[a]; i++) mine[2 * li + (size_t)a][(size_t)i] |= pr[(size_t)i];
+                        }
+                        if(nB > 1) pB.release(bi);
+                    }
+                } catch(const std::exception& e) { kErr[(size_t)d] = e.what(); }
+            };
+            if(nDev == 1) kmer_walk(0);
+            else { std::vector<std::thread> th; for(int d = 0; d < nDev; d++) th.emplace_back(kmer_walk, d); for(std::thread& t : th) t.join(); }
+            for(const std::string& e : kErr) if(!e.empty()) throw std::runtime_error(e);
+            for(int d = 0; d < nDev; d++) for(size_t li = 0; li < res.size(); li++) for(int a = 0; a < 2; a++)
+                for(int32_t i = 0; i < res[li].nq[a]; i++) res[li].present[a][(size_t)i] |= devPresent[(size_t)d][2 * li + (size_t)a][(size_t)i];
         }
         // ---- files
+        std::vector<const char*> names(nU + 1, nullptr); for(size_t u = 0; u < nU; u++) names[u] = pB.readID((int64_t)u);
         std::vector<bestGuess> out; std::string lociJoined;
         for(size_t li = 0; li < acc.size(); li++) {
             Acc& A = acc[li]; Res& R = res[li];
@@ -473,7 +529,7 @@ public:
             rin.pos = &R.pos; rin.filter = &filterParams; rin.unit_name_1 = names.data(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.data(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
             rin.n_clusters = A.li.n_clusters; rin.pair_ll = R.pairLL.data(); rin.mis_avg = R.misAvg.data(); rin.mis_min = R.misMin.data(); rin.order = R.order.data(); rin.p_normalized = R.pNorm.data(); rin.call = &R.call;
             rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2;
-            rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
+            rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = (int32_t)pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
             rin.min_mapq = minimumMappingQuality; rin.min_weighted_ok = min_bothReads_weightedCharactersOK;
             bestGuess g; g.locus = A.locus;
             tchk(hlala_locus_write_files(A.L, &rin, outputDirectory.c_str(), &g.summary), "hlala_locus_write_files");

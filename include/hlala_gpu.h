@@ -20,6 +20,7 @@
 #ifndef HLALA_GPU_H_
 #define HLALA_GPU_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -112,21 +113,30 @@ int hlala_graph_get_gap_stretch(const hlala_ctx* ctx, uint8_t* in_stretch /* [n_
  * read 2p is mate 1 of pair p, read 2p+1 is mate 2.  Bases/qualities are those of the mate's
  * PRIMARY alignment in alignment orientation (processBAM.cpp:3142-3145); chains of a read are
  * its BAM records in AS-descending order (processBAM.cpp:1945).
+ *
+ * A batch is a WINDOW into the arrays of a sample: the three offset arrays are 64-bit and need not start at 0.
+ * Read r of the batch has its bases at read_bases[read_off[r] .. read_off[r+1]) and its chains at index
+ * [chain_off[r], chain_off[r+1]) of every chain_* array (read_primary holds indices of the same numbering, cigar_off is
+ * indexed by it).  A caller that holds a whole sample (BASELINE config 3: ~10 M pairs = 3e9 bases, beyond 32-bit offsets)
+ * passes `read_off + 2*u0`, `chain_off + 2*u0`, `read_primary + 2*u0` and n_pairs = n for the units [u0, u0 + n) and leaves
+ * every other pointer alone (hlala_seed_batch_window does exactly that); the library uploads the window and rebases it.
+ * chain_off[0] is taken as the batch's first absolute chain number (hlala_batch_set_first_chain).  ONE batch is limited to
+ * 2^31-1 bases / chains / CIGAR operations (HLALA_E_CAPACITY beyond that: cut the sample into more batches).
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t         n_pairs;
-    const int32_t*  read_off;      /* [2n+1] offsets into read_bases / read_quals               */
+    const int64_t*  read_off;      /* [2n+1] offsets into read_bases / read_quals               */
     const uint8_t*  read_bases;    /* ASCII                                                     */
     const uint8_t*  read_quals;    /* ASCII Phred+33                                            */
-    const int32_t*  chain_off;     /* [2n+1] chains of read r: [chain_off[r], chain_off[r+1])   */
-    const int32_t*  read_primary;  /* [2n] absolute chain index of the read's primary alignment */
-    int32_t         n_chains;
-    const int32_t*  chain_contig;  /* [n_chains] index into hlala_contigs_desc                  */
-    const int32_t*  chain_pos;     /* [n_chains] BamAlignment::Position (0-based leftmost)      */
-    const int32_t*  chain_offset;  /* [n_chains] reference2level_offset (interval start)        */
-    const int32_t*  chain_as;      /* [n_chains] AS tag                                         */
-    const uint8_t*  chain_reverse; /* [n_chains] IsReverseStrand()                              */
-    const int32_t*  cigar_off;     /* [n_chains+1]                                              */
+    const int64_t*  chain_off;     /* [2n+1] chains of read r: [chain_off[r], chain_off[r+1])   */
+    const int32_t*  read_primary;  /* [2n] chain index (numbering of chain_off) of the read's primary alignment */
+    int32_t         n_chains;      /* chain_off[2n] - chain_off[0]                              */
+    const int32_t*  chain_contig;  /* [chain index] index into hlala_contigs_desc               */
+    const int32_t*  chain_pos;     /* BamAlignment::Position (0-based leftmost)                 */
+    const int32_t*  chain_offset;  /* reference2level_offset (interval start)                   */
+    const int32_t*  chain_as;      /* AS tag                                                    */
+    const uint8_t*  chain_reverse; /* IsReverseStrand()                                         */
+    const int64_t*  cigar_off;     /* [chain index .. +1] offsets into cigar                    */
     const uint32_t* cigar;         /* BAM encoding: len<<4 | op, op index into "MIDNSHP=X"      */
 } hlala_batch_in;
 
@@ -323,11 +333,33 @@ typedef struct {
 typedef struct hlala_seed_batch hlala_seed_batch;
 int  hlala_bam_extract_seeds(const char* bam_path, int32_t n_intervals, const hlala_bam_interval* intervals, int32_t long_read_mode,
                              hlala_seed_batch** out);
-/* descriptor pointing into the handle; counts[3] = records examined, seeds (read names), incomplete seeds */
+/* The same with the number of decoding threads stated (0 = one per hardware thread, at most 64).  BGZF blocks are independent gzip
+ * members: they are inflated, their records parsed and grouped by read name in parallel; one final sort puts the complete units into
+ * read-name order (the reference's std::map order, mapper/processBAM.cpp:712, 2024-2039).  The result does not depend on the thread count. */
+int  hlala_bam_extract_seeds_mt(const char* bam_path, int32_t n_intervals, const hlala_bam_interval* intervals, int32_t long_read_mode,
+                                int32_t n_threads, hlala_seed_batch** out);
+/* The WHOLE sample as one descriptor (64-bit offsets starting at 0) pointing into the handle; counts[3] = records examined, seeds (read
+ * names), incomplete seeds.  A sample beyond the size of one batch goes through the GPU window by window: hlala_seed_batch_window. */
 int  hlala_seed_batch_desc(const hlala_seed_batch* s, hlala_batch_in* in, int64_t* counts);
-const char* hlala_seed_batch_name(const hlala_seed_batch* s, int32_t unit);
+/* Units [first_unit, first_unit + n_units) of the sample as a batch descriptor (no copy: the window convention of hlala_batch_in).
+ * HLALA_E_ARG outside the sample, HLALA_E_CAPACITY when the window itself exceeds the size of one batch. */
+int  hlala_seed_batch_window(const hlala_seed_batch* s, int64_t first_unit, int32_t n_units, hlala_batch_in* in);
+int64_t     hlala_seed_batch_units(const hlala_seed_batch* s);
+const char* hlala_seed_batch_name(const hlala_seed_batch* s, int64_t unit);
+/* decoding record: seconds[0..5] = block index, inflate, parse, group, name sort, layout (wall clock of each phase); threads used */
+int  hlala_seed_batch_timing(const hlala_seed_batch* s, double* seconds6, int32_t* n_threads);
 void hlala_seed_batch_free(hlala_seed_batch* s);
 const char* hlala_bam_last_error(void);
+
+/* Page-locked host memory for the buffers a caller hands to hlala_batch_create / hlala_batch_get_pairs_packed / the getters: transfers from and
+ * to such buffers are true DMA (asynchronous, full PCIe rate); pageable buffers work everywhere, at about a third of the rate.  hlala_host_register
+ * pins an existing allocation in place (e.g. the arrays of a seed batch: hlala_seed_batch_pin), hlala_host_unregister undoes it.  */
+void* hlala_pinned_alloc(size_t bytes);
+void  hlala_pinned_free(void* p);
+int   hlala_host_register(void* p, size_t bytes);
+int   hlala_host_unregister(void* p);
+/* pins (pin != 0) or unpins the bulk arrays of a seed batch: read bases, qualities, chain records, CIGARs */
+int   hlala_seed_batch_pin(hlala_seed_batch* s, int pin);
 
 /* ------------------------------------------------------------------------------------------
  * Insert-size estimation (processBAM::estimateInsertSize, mapper/processBAM.cpp:1071-1165, and
@@ -344,6 +376,10 @@ typedef struct {
     double  total_weight;             /* IS_total_size                                                                                 */
 } hlala_insert_size_out;
 int  hlala_estimate_insert_size(hlala_ctx* ctx, const hlala_batch_in* in, hlala_insert_size_out* out);
+/* Replace insert_mean / insert_sd of a live context (the tables of the pairing step are rebuilt; graph and slabs stay): the context that estimated
+ * the insert size goes on to align the sample (processBAM: estimateInsertSize, then IS_mean / IS_sd are set, mapper/processBAM.cpp:1071-1165).
+ * Batches aligned before the call keep their results; call it with no alignment in flight. */
+int  hlala_set_insert_size(hlala_ctx* ctx, double insert_mean, double insert_sd);
 
 /* ------------------------------------------------------------------------------------------
  * Per-pair post-processing of alignReads_postSeedExtraction_andStoreInto (mapper/processBAM.cpp:2411-2446).

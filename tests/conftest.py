@@ -37,7 +37,7 @@ def oracle():
     """The CPU oracle (test infrastructure).  Built on demand with gcc."""
     so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
     src = os.path.join(ROOT, "oracle", "hlala_oracle.cpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "hlala_gpu.h"))):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     import oracle_binding
     return oracle_binding.Oracle

@@ -501,7 +501,8 @@ def _gm():
     if _GM is None:
         so = _os.path.join(_ROOT, "_build", "libgraphm.so")
         src = _os.path.join(_ROOT, "graphm", "graphm.cpp")
-        if not _os.path.exists(so) or _os.path.getmtime(so) < _os.path.getmtime(src):
+        src2 = _os.path.join(_ROOT, "graphm", "bamwriter.cpp")
+        if not _os.path.exists(so) or _os.path.getmtime(so) < max(_os.path.getmtime(src), _os.path.getmtime(src2)):
             # (several ranks of one bench may get here at once: one builds, the others wait)
             import fcntl
             _os.makedirs(_os.path.join(_ROOT, "_build"), exist_ok=True)
@@ -520,8 +521,89 @@ def _gm():
         L.gm_world_windows.argtypes = [vp] * 5; L.gm_world_window_matrix.argtypes = [vp, _C.c_int, vp, vp]; L.gm_world_nodes_per_level.argtypes = [vp, vp]
         L.gm_batch_create.restype = vp; L.gm_batch_create.argtypes = [vp, _C.POINTER(_GmBatchParams), _C.c_char_p]
         L.gm_batch_destroy.argtypes = [vp]; L.gm_batch_sizes.argtypes = [vp, vp]; L.gm_batch_get.argtypes = [vp] * 14
+        L.bw_open.restype = vp; L.bw_open.argtypes = [_C.c_char_p, _C.c_int, _C.POINTER(_C.c_char_p), vp, _C.c_int, _C.c_int]
+        L.bw_append.argtypes = [vp, _C.c_int64] + [vp] * 11; L.bw_close.argtypes = [vp]; L.bw_close.restype = _C.c_longlong
+        L.bw_last_error.restype = _C.c_char_p
         _GM = L
     return _GM
+
+
+# --------------------------------------------------------------------------- BAM files of synthetic samples (tools/graphm/bamwriter.cpp)
+
+class BamWriter:
+    """Writes records given as flat arrays into a BAM file (parallel deflate).  refs = [(name, length)]."""
+
+    def __init__(self, path, refs, threads=0, level=1):
+        L = _gm()
+        names = (_C.c_char_p * max(1, len(refs)))(*[nm.encode() for nm, _ in refs])
+        lens = np.array([ln for _, ln in refs], np.int32)
+        self.h = L.bw_open(str(path).encode(), len(refs), names, lens.ctypes.data, threads, level)
+        if not self.h:
+            raise RuntimeError("bw_open: " + L.bw_last_error().decode())
+        self.records = 0
+
+    def append(self, name_chars, name_off, flag, ref, pos, cigar_off, cigar, seq_off, bases, quals, as_tag):
+        a = [np.ascontiguousarray(x, dt) for x, dt in ((name_chars, np.uint8), (name_off, np.int64), (flag, np.uint16), (ref, np.int32), (pos, np.int32), (cigar_off, np.int64),
+                                                      (cigar, np.uint32), (seq_off, np.int64), (bases, np.uint8), (quals, np.uint8), (as_tag, np.int32))]
+        n = len(a[2])
+        if _gm().bw_append(self.h, n, *[x.ctypes.data for x in a]) != 0:
+            raise RuntimeError("bw_append: " + _gm().bw_last_error().decode())
+        self.records += n
+
+    def append_batch(self, b, names, order="coordinate", rng=None):
+        """All alignments of a batch dict (hlala_batch_in layout, paired) as BAM records: the primary of a mate carries the read (alignment
+        orientation, as bwa writes it), the others SEQ '*'; `names` = fixed-width name per pair ([n_pairs, width] uint8).
+        order: "coordinate" (reference id, position: what samtools sort leaves), "random" (needs rng) or "given"."""
+        nr = 2 * b["n_pairs"]; nc = b["n_chains"]
+        chain_off = np.asarray(b["chain_off"], np.int64); read_off = np.asarray(b["read_off"], np.int64); cigar_off = np.asarray(b["cigar_off"], np.int64)
+        chain_read = np.repeat(np.arange(nr, dtype=np.int64), np.diff(chain_off))
+        is_prim = np.zeros(nc, bool); is_prim[np.asarray(b["read_primary"], np.int64)] = True
+        flag = (1 | np.where(chain_read % 2 == 0, 64, 128) | np.where(np.asarray(b["chain_reverse"]) != 0, 16, 0) | np.where(is_prim, 0, 256)).astype(np.uint16)
+        pos = (np.asarray(b["chain_pos"], np.int64) + np.asarray(b["chain_offset"], np.int64)).astype(np.int32)
+        ref = np.asarray(b["chain_contig"], np.int32)
+        if order == "coordinate":
+            perm = np.lexsort((pos, ref))
+        elif order == "random":
+            perm = rng.permutation(nc)
+        else:
+            perm = np.arange(nc)
+        names = np.ascontiguousarray(names, np.uint8); width = names.shape[1]
+        pair_of = (chain_read // 2)[perm]
+        name_chars = names[pair_of].reshape(-1); name_off = np.arange(nc + 1, dtype=np.int64) * width
+        # CIGARs and reads gathered in record order
+        clen = np.diff(cigar_off)[perm]; c_off = np.concatenate([[0], np.cumsum(clen)]).astype(np.int64)
+        cig_idx = np.repeat(cigar_off[:-1][perm] - c_off[:-1], clen) + np.arange(int(c_off[-1]), dtype=np.int64)
+        rlen = np.where(is_prim, (read_off[1:] - read_off[:-1])[chain_read], 0)[perm]; s_off = np.concatenate([[0], np.cumsum(rlen)]).astype(np.int64)
+        seq_idx = np.repeat(read_off[:-1][chain_read][perm] - s_off[:-1], rlen) + np.arange(int(s_off[-1]), dtype=np.int64)
+        self.append(name_chars, name_off, flag[perm], ref[perm], pos[perm], c_off, np.asarray(b["cigar"], np.uint32)[cig_idx], s_off,
+                    np.asarray(b["read_bases"], np.uint8)[seq_idx], np.asarray(b["read_quals"], np.uint8)[seq_idx], np.asarray(b["chain_as"], np.int32)[perm])
+
+    def close(self):
+        if self.h:
+            n = _gm().bw_close(self.h); self.h = None
+            if n < 0:
+                raise RuntimeError("bw_close: " + _gm().bw_last_error().decode())
+            return n
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def scrambled_names(chunk, n_pairs, prefix=b"r"):
+    """Fixed-width read names [n_pairs, width] whose byte order is a permutation of the pair order: prefix, two hex digits of the chunk, eight hex
+    digits of (pair index * odd constant mod 2^32).  Returns (names, rank): rank[p] = position of pair p among the chunk's names in name order."""
+    scr = (np.arange(n_pairs, dtype=np.uint64) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    hexd = np.frombuffer(b"0123456789abcdef", np.uint8)
+    cols = [np.full(n_pairs, c, np.uint8) for c in prefix] + [np.full(n_pairs, hexd[(chunk >> 4) & 15], np.uint8), np.full(n_pairs, hexd[chunk & 15], np.uint8)]
+    for sh in range(28, -4, -4):
+        cols.append(hexd[((scr >> np.uint64(sh)) & np.uint64(15)).astype(np.int64)])
+    names = np.stack(cols, axis=1)
+    order = np.argsort(scr, kind="stable")
+    rank = np.empty(n_pairs, np.int64); rank[order] = np.arange(n_pairs)
+    return names, rank
 
 
 class _GmWorldHandle:
