@@ -47,7 +47,7 @@ class GraphInfo(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("n_nodes", C.c_int32), ("n_edges", C.c_int32), ("n_paths", C.c_int32),
                 ("n_jump_entries", C.c_int64), ("n_path_edges", C.c_int64), ("n_levelpos_entries", C.c_int64),
                 ("max_nodes_per_level", C.c_int32), ("max_out_degree", C.c_int32), ("max_in_degree", C.c_int32),
-                ("n_gap_stretch_levels", C.c_int32)]
+                ("n_gap_stretch_levels", C.c_int32), ("max_jumps", C.c_int32), ("max_parallel", C.c_int32)]
 
 
 class BatchIn(C.Structure):
@@ -717,6 +717,18 @@ class Context:
         b = C.c_void_p()
         self._check(self.lib.hlala_batch_create(self.h, C.byref(s), C.byref(b)), "hlala_batch_create")
         return Batch(self, b, batch_in["n_chains"], batch_in["n_pairs"])
+
+    def batch_window(self, seeds: "SeedBatch", first_unit: int, n_units: int) -> "Batch":
+        """units [first_unit, first_unit + n_units) of a decoded sample as a resident batch: the descriptor points into the sample's arrays (no host
+        copy), the batch takes chain_off[0] of the window as its first absolute chain number"""
+        d = seeds.window(first_unit, n_units)
+        b = C.c_void_p()
+        f = self.lib.hlala_batch_create_unpaired if seeds.long_read_mode else self.lib.hlala_batch_create
+        self._check(f(self.h, C.byref(d), C.byref(b)), "hlala_batch_create (window)")
+        bt = Batch(self, b, d.n_chains, n_units)
+        if seeds.long_read_mode:
+            bt.unpaired = True
+        return bt
 
     def batch_unpaired(self, batch_in: dict) -> "Batch":
         """Long-read / unpaired mode: batch_in["n_pairs"] is the number of reads (hlala_batch_create_unpaired)."""

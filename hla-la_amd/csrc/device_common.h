@@ -27,6 +27,7 @@ struct DevGraph {
     const uint8_t* edge_label; // [E] by creation index
     const int* jf_off; const int* jf_node; const int* jf_path; const int* jf_lvl;
     const int* jb_off; const int* jb_node; const int* jb_path; const int* jb_lvl;
+    const uint8_t* out_prank; const uint8_t* in_prank; const uint8_t* jf_prank; const uint8_t* jb_prank;   // rank among the node's earlier entries to the same target (flat_graph.hpp)
     const int4* nrec_out;      // [2*N] 32-byte node records of the extension DP (flat_graph.hpp)
     const int4* nrec_in;
     const int* path_len;       // [P]
@@ -63,7 +64,7 @@ constexpr int DP_STEPS     = 8192;   // backtrace steps
 constexpr int DP_COMPLETED = 2048;   // sequence-complete cells
 constexpr int DP_CELLS_LARGE     = 65536;  // kept cells per DP call of the large-capacity class (<= 131072: 17-bit slots in the back pointers)
 constexpr int DP_COMPLETED_LARGE = 16384;  // sequence-complete cells, large-capacity class
-constexpr int DP_MAX_DEGREE = 127;   // edges / gap-path jumps of one node in one direction (7-bit push index, kernel_dp.hip)
+constexpr int DP_MAX_PARALLEL = 127; // parallel edges (or gap paths) between ONE pair of nodes: what the 7-bit rank in the push index of a DP candidate holds (kernel_dp.hip); a node's degree is not limited
 constexpr int DP_NEG       = -30000; // minusInfinity (-DBL_MAX in the reference, extensionAligner.cpp:363)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -199,6 +199,27 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
                 }
             }
     }
+    // ---- ranks among parallel entries (same node, same target), in entry order
+    {
+        auto ranks = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& to, std::vector<uint8_t>& prank) {
+            prank.assign(to.size(), 0);
+            std::vector<std::pair<int32_t, int32_t>> tmp;      // (target, entry) of one node
+            for(int32_t n = 0; n < N; n++) {
+                const int32_t e0 = off[n], deg = off[n + 1] - e0;
+                if(deg < 2) continue;
+                if(deg <= 8) {                                   // the common case: compare pairwise
+                    for(int32_t a = 1; a < deg; a++) { int r = 0; for(int32_t b = 0; b < a; b++) if(to[e0 + b] == to[e0 + a]) r++; if(r > 255) r = 255; prank[e0 + a] = (uint8_t)r; F.max_parallel = std::max(F.max_parallel, r + 1); }
+                } else {
+                    tmp.clear(); for(int32_t a = 0; a < deg; a++) tmp.emplace_back(to[e0 + a], a);
+                    std::sort(tmp.begin(), tmp.end());
+                    for(size_t i = 0; i < tmp.size();) { size_t j = i; while(j < tmp.size() && tmp[j].first == tmp[i].first) { const int r = (int)(j - i); prank[e0 + tmp[j].second] = (uint8_t)std::min(r, 255); F.max_parallel = std::max(F.max_parallel, r + 1); j++; } i = j; }
+                }
+            }
+        };
+        F.max_parallel = (E > 0) ? 1 : 0;
+        ranks(F.out_off, F.out_to, F.out_prank); ranks(F.in_off, F.in_from, F.in_prank);
+        ranks(F.jf_off, F.jf_node, F.jf_prank); ranks(F.jb_off, F.jb_node, F.jb_prank);
+    }
     // ---- node records: everything one DP iteration needs of a frontier node in one 32-byte read
     {
         std::string recErr;
@@ -214,7 +235,7 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
                 r[0] = e0; r[1] = deg | (int32_t)((uint32_t)nj << 16);
                 r[2] = deg > 0 ? to[e0] : 0; r[3] = deg > 1 ? to[e0 + 1] : 0;
                 r[4] = j0; r[5] = nj > 0 ? jnode[j0] : 0; r[6] = nj > 0 ? jlvl[j0] : 0;
-                r[7] = (deg > 0 ? lab[e0] : 0) | ((deg > 1 ? lab[e0 + 1] : 0) << 8);
+                r[7] = (deg > 0 ? lab[e0] : 0) | ((deg > 1 ? lab[e0 + 1] : 0) << 8) | ((deg > 1 && to[e0 + 1] == to[e0] ? 1 : 0) << 16);
             }
         };
         build(F.out_off, F.out_to, F.out_label, F.jf_off, F.jf_node, F.jf_lvl, F.nrec_out);

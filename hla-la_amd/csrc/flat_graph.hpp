@@ -39,14 +39,18 @@ struct FlatGraph {
     std::vector<int32_t> jf_node, jb_node;       // target node (new id)
     std::vector<int32_t> jf_path, jb_path;       // path index
     std::vector<int32_t> jf_lvl, jb_lvl;         // level of the target node (saves a dependent load on the device)
+    // rank of a CSR edge / jump entry among the EARLIER entries of the same node that lead to the same target node.  It is all the extension DP needs to
+    // order the candidates of one target cell (candidates of different edges of one frontier cell only compete when they reach the same node), so the push
+    // index of a candidate holds this rank -- a few bits -- instead of the edge number, and a node's degree is not limited by the width of that field.
+    std::vector<uint8_t> out_prank, in_prank, jf_prank, jb_prank;
     // one 32-byte record per node and direction for the extension DP: {first CSR edge, degree | jumps << 16, target of edge 0,
-    // target of edge 1, first jump-table entry, node of jump 0, level of jump 0, label 0 | label 1 << 8}
+    // target of edge 1, first jump-table entry, node of jump 0, level of jump 0, label 0 | label 1 << 8 | rank of edge 1 << 16}
     std::vector<int32_t> nrec_out, nrec_in;      // [8*N]
     std::vector<uint8_t> gap_stretch;            // [L-1]
     // level -> (sequence id, position) CSR, entries sorted by sequence id
     std::vector<int64_t> lp_off;                 // [L+1]
     std::vector<int32_t> lp_seqid, lp_pos;
-    int32_t max_nodes_per_level = 0, max_out_degree = 0, max_in_degree = 0, max_jumps = 0;
+    int32_t max_nodes_per_level = 0, max_out_degree = 0, max_in_degree = 0, max_jumps = 0, max_parallel = 0;       // max_parallel: largest rank + 1 above
 };
 
 // Returns "" on success, else the error text (graph invariants the reference asserts).

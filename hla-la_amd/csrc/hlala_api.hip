@@ -322,11 +322,10 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(!ferr.empty()) { c->err = ferr; return fail(HLALA_E_GRAPH); }
     FlatGraph& F = c->F;
     if(F.N >= (1 << 28) || F.L >= (1 << 24)) { c->err = "graph exceeds 2^28 nodes or 2^24 levels (DP cell key layout)"; return fail(HLALA_E_CAPACITY); }
-    // the DP packs the push index of a candidate (edge or gap-path jump of a frontier node) into 7 bits: a wider node would fail in
-    // every capacity class, so it is refused here instead of dropping pairs later
-    if(F.max_out_degree > DP_MAX_DEGREE || F.max_in_degree > DP_MAX_DEGREE || F.max_jumps > DP_MAX_DEGREE) {
-        c->err = "graph has a node with more than " + std::to_string(DP_MAX_DEGREE) + " edges or gap-path jumps in one direction (out " + std::to_string(F.max_out_degree) +
-                 ", in " + std::to_string(F.max_in_degree) + ", jumps " + std::to_string(F.max_jumps) + "): beyond the DP's push-index field";
+    // the push index of a DP candidate holds the rank of its edge among the PARALLEL edges (same two nodes) in 7 bits: a node may have any number of
+    // edges and gap-path jumps, but more than 127 parallel ones between two nodes are refused here instead of dropping pairs later
+    if(F.max_parallel > DP_MAX_PARALLEL) {
+        c->err = "graph has " + std::to_string(F.max_parallel) + " parallel edges or gap paths between one pair of nodes: more than the " + std::to_string(DP_MAX_PARALLEL) + " the DP's push-index field ranks";
         return fail(HLALA_E_CAPACITY);
     }
     if(F.max_nodes_per_level > PROJ_NODES) { c->err = "more nodes in one level than this build holds in LDS (PROJ_NODES)"; return fail(HLALA_E_CAPACITY); }
@@ -343,6 +342,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     UPG(jf_off, F.jf_off); UPG(jf_node, F.jf_node); UPG(jf_path, F.jf_path);
     UPG(jb_off, F.jb_off); UPG(jb_node, F.jb_node); UPG(jb_path, F.jb_path);
     UPG(jf_lvl, F.jf_lvl); UPG(jb_lvl, F.jb_lvl);
+    UPG(out_prank, F.out_prank); UPG(in_prank, F.in_prank); UPG(jf_prank, F.jf_prank); UPG(jb_prank, F.jb_prank);
     { int* p_ = nullptr; rc = dev_upload(c, c->allocs, F.nrec_out.data(), F.nrec_out.size(), &p_); if(rc) return fail(rc); G.nrec_out = (const int4*)p_;
       rc = dev_upload(c, c->allocs, F.nrec_in.data(), F.nrec_in.size(), &p_); if(rc) return fail(rc); G.nrec_in = (const int4*)p_; }
     UPG(path_len, F.path_len); UPG(path_edges, F.path_edges);
@@ -438,7 +438,7 @@ int hlala_graph_get_info(const hlala_ctx* c, hlala_graph_info* info)
     info->n_levels = F.L; info->n_nodes = F.N; info->n_edges = F.E; info->n_paths = (int)F.path_len.size();
     info->n_jump_entries = (int64_t)F.jf_node.size(); info->n_path_edges = (int64_t)F.path_edges.size();
     info->n_levelpos_entries = (int64_t)F.lp_seqid.size();
-    info->max_nodes_per_level = F.max_nodes_per_level; info->max_out_degree = F.max_out_degree; info->max_in_degree = F.max_in_degree;
+    info->max_nodes_per_level = F.max_nodes_per_level; info->max_out_degree = F.max_out_degree; info->max_in_degree = F.max_in_degree; info->max_jumps = F.max_jumps; info->max_parallel = F.max_parallel;
     for(uint8_t b : F.gap_stretch) info->n_gap_stretch_levels += b;
     return HLALA_OK;
 }

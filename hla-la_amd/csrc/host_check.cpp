@@ -25,7 +25,7 @@ int hlala_host_info(const hlala::FlatGraph* F, hlala_graph_info* info)
     info->n_levels = F->L; info->n_nodes = F->N; info->n_edges = F->E; info->n_paths = (int)F->path_len.size();
     info->n_jump_entries = (int64_t)F->jf_node.size(); info->n_path_edges = (int64_t)F->path_edges.size();
     info->n_levelpos_entries = (int64_t)F->lp_seqid.size();
-    info->max_nodes_per_level = F->max_nodes_per_level; info->max_out_degree = F->max_out_degree; info->max_in_degree = F->max_in_degree;
+    info->max_nodes_per_level = F->max_nodes_per_level; info->max_out_degree = F->max_out_degree; info->max_in_degree = F->max_in_degree; info->max_jumps = F->max_jumps; info->max_parallel = F->max_parallel;
     for(uint8_t b : F->gap_stretch) info->n_gap_stretch_levels += b;
     return 0;
 }

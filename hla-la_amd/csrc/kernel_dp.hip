@@ -528,6 +528,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     // execute the pushes is irrelevant.
     const int* eoff = fwd ? G.out_off : G.in_off; const int* eto = fwd ? G.out_to : G.in_from; const uint8_t* elab = fwd ? G.out_label : G.in_label;
     const int* joff = fwd ? G.jf_off : G.jb_off; const int* jnode = fwd ? G.jf_node : G.jb_node; const int* jlvl = fwd ? G.jf_lvl : G.jb_lvl;
+    // The low bits of a push index hold the RANK of the edge (jump) among the node's earlier edges (jumps) to the same target node, not the edge number:
+    // candidates of different edges of one frontier cell compete only when they reach the same cell, i.e. the same node, and among those the rank orders
+    // exactly as the edge number does.  A node may therefore have any number of edges and gap-path jumps (allele-rich levels of a real PRG: hundreds); the
+    // field limits only the parallel edges between ONE pair of nodes (DP_MAX_PARALLEL, checked in hlala_create).  The backtrace resolves (previous node,
+    // this node, rank) to the edge.
+    const uint8_t* eprk = fwd ? G.out_prank : G.in_prank; const uint8_t* jprk = fwd ? G.jf_prank : G.jb_prank;
     int edges = 0;      // (the direction is wave-uniform: these are scalar selects)
     const int nMax = n1 > n2 ? n1 : n2;
     // One wave per DP and a table of 512+ entries: the list of this iteration's targets is written as the entries are claimed (wave ballot, running count
@@ -558,6 +564,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         if(hasB) { rb0 = nrec[2 * (size_t)nodeB]; rb1 = nrec[2 * (size_t)nodeB + 1]; }
         const int a0 = ra0.x, degA = ra0.y & 0xFFFF, tnA0 = ra0.z, tnA1 = ra0.w;
         const unsigned char labA0 = (unsigned char)(ra1.w & 0xFF), labA1 = (unsigned char)((ra1.w >> 8) & 0xFF);
+        const int rkA1 = (ra1.w >> 16) & 1, rkB1 = (rb1.w >> 16) & 1;          // rank of edge 1: 1 iff it leads where edge 0 leads
         const int e0 = rb0.x, degB = rb0.y & 0xFFFF, tnB0 = rb0.z, tnB1 = rb0.w;
         const int j0 = rb1.x, j1 = j0 + (int)((u32)rb0.y >> 16), jn0 = rb1.y, jx0 = rb1.z;
         const unsigned char labB0 = (unsigned char)(rb1.w & 0xFF), labB1 = (unsigned char)((rb1.w >> 8) & 0xFF);
@@ -568,7 +575,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         // '_' edge, :738-752); 5 = first gap-path jump (:757-786, jump_length * S_graphGap = 0)
         const int ord0 = (1 << (C::IBITS + 8)) | (i << 8);
         const int nyG = pyB + dir, nxB = pxB + dir;
-        const bool okA = doA, okB = hasB;            // (degrees and jump counts fit the push index: checked once in hlala_create, DP_MAX_DEGREE)
+        const bool okA = doA, okB = hasB;
         const bool sgB = okB && nxB >= 0 && nxB <= max_levelI;
         typedef typename C::Best BestT;
         {   // batch 1: both edges of the m-2 entry, the graph gap
@@ -593,7 +600,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     if(cv[q] && !(cold[q] == HKEY_EMPTY || cold[q] == ck[q])) { ch[q] = dp_probe<C>(S, ck[q], ch[q]); if(ch[q] >= (u32)C::HC) { S.err = __LINE__; cv[q] = false; } }
             }
             if(cv[0]) { BestT v; pack_best<C>(v, pDA + (labA0 == rc ? 2 : -5), (i << 8) | 0); atomicMax(&S.hbest[M_D][ch[0]], v); }
-            if(cv[1]) { BestT v; pack_best<C>(v, pDA + (labA1 == rc ? 2 : -5), (i << 8) | 1); atomicMax(&S.hbest[M_D][ch[1]], v); }
+            if(cv[1]) { BestT v; pack_best<C>(v, pDA + (labA1 == rc ? 2 : -5), (i << 8) | rkA1); atomicMax(&S.hbest[M_D][ch[1]], v); }
             if(cv[2]) { BestT v, w; pack_best<C>(v, pD - 6, ord0 | 0); if(pG != DP_NEG) { pack_best<C>(w, pG - 2, ord0 | 1); if(w > v) v = w; } atomicMax(&S.hbest[M_GG][ch[2]], v); }
         }
         {   // batch 2: both edges of the m-1 entry, the first jump
@@ -620,14 +627,15 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
 #pragma unroll
             for(int kk = 0; kk < 2; kk++) {
                 const unsigned char lab = kk ? labB1 : labB0;
+                const int rk = kk ? rkB1 : 0;
                 if(cv[kk]) {
                     BestT v, w;
                     if(lab != '_') {
-                        pack_best<C>(v, pD - 6, ord0 | (2 * kk)); if(pS != DP_NEG) { pack_best<C>(w, pS - 2, ord0 | (2 * kk + 1)); if(w > v) v = w; }
+                        pack_best<C>(v, pD - 6, ord0 | (2 * rk)); if(pS != DP_NEG) { pack_best<C>(w, pS - 2, ord0 | (2 * rk + 1)); if(w > v) v = w; }
                         atomicMax(&S.hbest[M_SG][ch[kk]], v);
                     } else {
-                        if(pS != DP_NEG) { pack_best<C>(w, pS, ord0 | (2 * kk + 1)); atomicMax(&S.hbest[M_SG][ch[kk]], w); }
-                        pack_best<C>(v, pD, ord0 | kk); atomicMax(&S.hbest[M_D][ch[kk]], v);
+                        if(pS != DP_NEG) { pack_best<C>(w, pS, ord0 | (2 * rk + 1)); atomicMax(&S.hbest[M_SG][ch[kk]], w); }
+                        pack_best<C>(v, pD, ord0 | rk); atomicMax(&S.hbest[M_D][ch[kk]], v);
                     }
                 }
             }
@@ -642,21 +650,21 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 int at = -1;
                 if(okA && k < degA) {
                     int tn = eto[a0 + k]; unsigned char lab = elab[a0 + k];
-                    if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | k, at)) S.err = __LINE__;
+                    if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | (int)eprk[a0 + k], at)) S.err = __LINE__;
                 }
                 append(at >= 0, (u32)at);
             }
             for(int kk = 2; __ballot(sgB && kk < degB) != 0; kk++) {
                 int at = -1;
                 if(sgB && kk < degB) {
-                    int tn = eto[e0 + kk]; unsigned char lab = elab[e0 + kk];
+                    int tn = eto[e0 + kk]; unsigned char lab = elab[e0 + kk]; const int rk = (int)eprk[e0 + kk];
                     u64 k = mk_key(nxB, pyB, tn);
                     if(lab != '_') {
-                        if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk), at)) S.err = __LINE__;
-                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1), at)) S.err = __LINE__;
+                        if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * rk), at)) S.err = __LINE__;
+                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * rk + 1), at)) S.err = __LINE__;
                     } else {
-                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1), at)) S.err = __LINE__;
-                        if(!dp_push<C>(S, k, M_D, pD, ord0 | kk, at)) S.err = __LINE__;
+                        if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * rk + 1), at)) S.err = __LINE__;
+                        if(!dp_push<C>(S, k, M_D, pD, ord0 | rk, at)) S.err = __LINE__;
                     }
                 }
                 append(at >= 0, (u32)at);
@@ -665,30 +673,30 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 int at = -1;
                 if(okB && j < j1) {
                     int tn = jnode[j]; int jx = jlvl[j];
-                    if(!(jx < 0 || jx > max_levelI)) if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)), at)) S.err = __LINE__;
+                    if(!(jx < 0 || jx > max_levelI)) if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (int)jprk[j]), at)) S.err = __LINE__;
                 }
                 append(at >= 0, (u32)at);
             }
         } else {
             if(okA) for(int k = 2; k < degA; k++) {
                 int tn = eto[a0 + k]; unsigned char lab = elab[a0 + k];
-                if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | k)) S.err = __LINE__;
+                if(!dp_push<C>(S, mk_key(nxA, nyA, tn), M_D, pDA + (lab == rc ? 2 : -5), (i << 8) | (int)eprk[a0 + k])) S.err = __LINE__;
             }
             if(sgB) for(int kk = 2; kk < degB; kk++) {
-                int tn = eto[e0 + kk]; unsigned char lab = elab[e0 + kk];
+                int tn = eto[e0 + kk]; unsigned char lab = elab[e0 + kk]; const int rk = (int)eprk[e0 + kk];
                 u64 k = mk_key(nxB, pyB, tn);
                 if(lab != '_') {
-                    if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * kk))) S.err = __LINE__;
-                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * kk + 1))) S.err = __LINE__;
+                    if(!dp_push<C>(S, k, M_SG, pD - 6, ord0 | (2 * rk))) S.err = __LINE__;
+                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS - 2, ord0 | (2 * rk + 1))) S.err = __LINE__;
                 } else {
-                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * kk + 1))) S.err = __LINE__;
-                    if(!dp_push<C>(S, k, M_D, pD, ord0 | kk)) S.err = __LINE__;
+                    if(pS != DP_NEG) if(!dp_push<C>(S, k, M_SG, pS, ord0 | (2 * rk + 1))) S.err = __LINE__;
+                    if(!dp_push<C>(S, k, M_D, pD, ord0 | rk)) S.err = __LINE__;
                 }
             }
             if(okB) for(int j = j0 + 1; j < j1; j++) {
                 int tn = jnode[j]; int jx = jlvl[j];
                 if(jx < 0 || jx > max_levelI) continue;
-                if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (j - j0)))) S.err = __LINE__;
+                if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (int)jprk[j]))) S.err = __LINE__;
             }
         }
     }
@@ -1142,7 +1150,8 @@ __device__ inline int dp_backtrace(DpLdsT<C>& S, const DpSlabT<C>& sl, int maxSt
         int done = 0;
         for(int it = 0; it < maxSteps; it++) {
             if(!((x != startLevel || y != start_seq) && nSteps < C::STEPS && guardSteps++ < 4 * C::STEPS)) { done = 1; break; }
-            u32 b = sl.cell()[slot].bt[m];
+            const CellRec* cr = sl.cell() + slot;
+            u32 b = cr->bt[m]; const u64 ckey = cr->key;      // (one 32-byte record: both loads are in flight together)
             int kind = bt_kind(b);
             int prev = bt_prev(b);
             int px = 0;
@@ -1150,7 +1159,7 @@ __device__ inline int dp_backtrace(DpLdsT<C>& S, const DpSlabT<C>& sl, int maxSt
             if(kind != K_HOP) {
                 int len = 1;
                 if(kind == K_JUMP) len = px > x ? px - x : x - px;
-                sl.step_bt()[nSteps] = b; sl.step_xy()[nSteps] = ((u64)(u32)x << 32) | ((u64)(u32)y << 8) | 0; nSteps++; nCols += len;
+                sl.step_bt()[nSteps] = b; sl.step_xy()[nSteps] = ckey; nSteps++; nCols += len;       // the cell the step arrives at: x, y and its node
             }
             if(kind == K_DIAG) { x -= dir; y -= dir; }
             else if(kind == K_GGAP) { y -= dir; }
@@ -1199,18 +1208,30 @@ __device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
         int s = s0 + gl; bool act = s < nSteps;
         u32 b = act ? sl.step_bt()[s] : 0; u64 xy = act ? sl.step_xy()[s] : 0;
         int kind = bt_kind(b);
-        // resolve the graph object behind the push index j: edge j of the previous cell's node, or entry j of its jump table
+        // resolve the graph object behind the rank j: the (j+1)-th edge of the previous cell's node that leads to this cell's node, or the (j+1)-th
+        // entry of its jump table that does (degrees beyond two are rare and only the cells of the chosen path come here)
         int pnode = 0, robj = -1;
         if(act && kind != K_GGAP) {
             u64 pkey = sl.cell()[bt_prev(b)].key; pnode = key_node(pkey);
+            const int node = key_node(xy);
             int j = bt_edge(b);
-            if(kind == K_JUMP) robj = (fwd ? G.jf_path : G.jb_path)[(fwd ? G.jf_off : G.jb_off)[pnode] + j];
-            else robj = fwd ? G.out_eid[G.out_off[pnode] + j] : G.in_eid[G.in_off[pnode] + j];
+            if(kind == K_JUMP) {
+                const int* jo = fwd ? G.jf_off : G.jb_off; const int* jn = fwd ? G.jf_node : G.jb_node;
+                const int q1 = jo[pnode + 1]; int q = jo[pnode];
+                for(; q < q1; q++) if(jn[q] == node && j-- == 0) break;
+                if(q < q1) robj = (fwd ? G.jf_path : G.jb_path)[q];
+            } else {
+                const int* eo = fwd ? G.out_off : G.in_off; const int* et = fwd ? G.out_to : G.in_from;
+                const int q1 = eo[pnode + 1]; int q = eo[pnode];
+                for(; q < q1; q++) if(et[q] == node && j-- == 0) break;
+                if(q < q1) robj = (fwd ? G.out_eid : G.in_eid)[q];
+            }
+            if(robj < 0) { st.err = __LINE__; act = false; }        // (cannot happen: the rank was derived from these very arrays)
         }
         int len = act ? (kind == K_JUMP ? G.path_len[robj] : 1) : 0;
         int total; int off = grp_excl_scan<GW>(len, total);
         if(act) {
-            int x = (int)(xy >> 32), y = (int)((xy >> 8) & 0xFFFFFF);
+            int x = key_x(xy), y = key_y(xy);
             int start = fwd ? (nCols - (base + off) - len) : (base + off);     // forward traces are reversed at the end, :1319-1326
             if(kind == K_JUMP) {                                                       // :1282-1307
                 int p = robj; long long po = G.path_off[p];

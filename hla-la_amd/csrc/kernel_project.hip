@@ -202,8 +202,18 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         const int pos = __builtin_amdgcn_readlane(hPos, hq), tOffset = __builtin_amdgcn_readlane(hOff, hq);
         const int cg0 = __builtin_amdgcn_readlane(hCg0, hq), nOps = __builtin_amdgcn_readlane(hCg1, hq) - cg0;
         typedef LvCodec<PL> LC;
-        int lvBase = 0;                      // level of the chain's first reference position (16-bit layouts only)
-        if constexpr (LC::SHORT) { const long long t0 = (long long)pos - tOffset; if(t0 >= 0 && t0 < cLen) lvBase = max(0, uni(contig_level[cOff + t0])); }
+        // 16-bit layouts: column levels are kept as offsets from the first DEFINED level at or after the chain's first reference position (a translation
+        // table holds -1 where a contig base is on no graph level, processBAM.cpp:2519, 5293: the chain may well start on one)
+        int lvBase = 0;
+        if constexpr (LC::SHORT) {
+            const long long t0 = (long long)pos - tOffset;
+            for(long long q0 = t0 > 0 ? t0 : 0, qEnd = q0 + 2 * (long long)PL::CAP; q0 < cLen && q0 < qEnd; q0 += 64) {
+                const long long q = q0 + lane;
+                const int lv = q < cLen ? contig_level[cOff + q] : -1;
+                const int m = -wave_max_i32(lv >= 0 ? -lv : -0x7FFFFFFF);
+                if(m != 0x7FFFFFFF) { lvBase = m; break; }
+            }
+        }
         if(lane == 0) { P.err = 0; }
         WSYNC();
         long long tPh[7] = {0, 0, 0, 0, 0, 0, 0};

@@ -98,6 +98,7 @@ typedef struct {
     int32_t n_levels, n_nodes, n_edges, n_paths;
     int64_t n_jump_entries, n_path_edges, n_levelpos_entries;
     int32_t max_nodes_per_level, max_out_degree, max_in_degree, n_gap_stretch_levels;
+    int32_t max_jumps, max_parallel;   /* most gap-path jumps of a node in one direction; most parallel edges / gap paths between one pair of nodes */
 } hlala_graph_info;
 int hlala_graph_get_info(const hlala_ctx* ctx, hlala_graph_info* info);
 /* node renumbering: device node id -> creation index, [n_nodes]; level offsets [n_levels+1] */

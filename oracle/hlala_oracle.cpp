@@ -1236,6 +1236,10 @@ int orc_graph_info(orc_handle* h, hlala_graph_info* info)
     for(auto& l : g.out_e) info->max_out_degree = std::max(info->max_out_degree, (int)l.size());
     for(auto& l : g.in_e) info->max_in_degree = std::max(info->max_in_degree, (int)l.size());
     for(auto b : g.inGraphGapStretch) info->n_gap_stretch_levels += b;
+    for(auto& a : g.jump_fwd) info->max_jumps = std::max(info->max_jumps, (int)a.second.size());
+    for(auto& a : g.jump_bwd) info->max_jumps = std::max(info->max_jumps, (int)a.second.size());
+    /* most parallel edges between one pair of nodes (a gap path is unique per node pair: "duplicate gap path" above) */
+    for(auto& l : g.out_e) { std::map<int, int> cnt; for(int e : l) info->max_parallel = std::max(info->max_parallel, ++cnt[g.eto[e]]); }
     return 0;
 }
 int orc_graph_get_paths(orc_handle* h, int32_t* first_node, int32_t* last_node, int32_t* length)
@@ -1620,6 +1624,8 @@ int orc_exon_loglik(const hlala_exon_in* in, int long_read_mode, double* LL, int
     double log_likelihood_deletion = log(deletionP);
     double log_likelihood_match_mismatch = log(1 - insertionP - deletionP);
     const int C = in->n_clusters, P = in->exon_length, R = in->n_reads;
+    /* (clusters are independent; every (cluster, read) sum below runs in the reference's order) */
+#pragma omp parallel for schedule(dynamic, 8)
     for(int clusterI = 0; clusterI < C; clusterI++) {
         const unsigned char* clusterSequence = in->cluster_seq + (size_t)clusterI * P;
         for(int readI = 0; readI < R; readI++) {
@@ -1666,9 +1672,12 @@ static double logAvg(double a, double b)
 /* all cluster pairs in single-thread order, hla/HLATyper.cpp:2293-2364 */
 int orc_pair_loglik(const double* LL, const int32_t* mism, int C, int R, double* pairLL, double* misAvg, double* misMin)
 {
-    size_t idx = 0;
+    /* (the reference walks c1, c2 on one thread; rows are independent and every sum below runs over the reads of ONE pair in the reference's order,
+       so the rows may be computed side by side: pair (c1, c2) goes to the index the sequential walk gives it) */
+#pragma omp parallel for schedule(dynamic, 4)
     for(int c1 = 0; c1 < C; c1++)
         for(int c2 = c1; c2 < C; c2++) {
+            const size_t idx = (size_t)c1 * (size_t)C - (size_t)c1 * (size_t)(c1 - 1) / 2 + (size_t)(c2 - c1);
             double mismatches_sum_averages = 0, mismatches_sum_min = 0, pair_log_likelihood = 0;
             for(int readI = 0; readI < R; readI++) {
                 double a = LL[(size_t)c1 * R + readI], b = LL[(size_t)c2 * R + readI];
@@ -1677,7 +1686,7 @@ int orc_pair_loglik(const double* LL, const int32_t* mism, int C, int R, double*
                 mismatches_sum_min += ((m1 < m2) ? m1 : m2);
                 pair_log_likelihood += logAvg(a, b);
             }
-            pairLL[idx] = pair_log_likelihood; misAvg[idx] = mismatches_sum_averages; misMin[idx] = mismatches_sum_min; idx++;
+            pairLL[idx] = pair_log_likelihood; misAvg[idx] = mismatches_sum_averages; misMin[idx] = mismatches_sum_min;
         }
     return 0;
 }

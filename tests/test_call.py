@@ -27,6 +27,21 @@ def table(C, rng, dup=()):
     return pairLL, misAvg, misMin
 
 
+def table_rows(C, rng, dup=(), R=40):
+    """The same table, one row of pairs (c1, c1 .. C-1) at a time: usable at the size of a real locus (C = 3000 .. 5000)."""
+    ll = -rng.random((C, R)) * 30 - 1; mm = rng.integers(0, 4, (C, R))
+    for a, b in dup:
+        ll[a] = ll[b]; mm[a] = mm[b]
+    nP = C * (C + 1) // 2
+    pairLL = np.zeros(nP); misAvg = np.zeros(nP); misMin = np.zeros(nP)
+    for c1 in range(C):
+        i0 = tri(c1, c1, C); n = C - c1
+        hi = np.maximum(ll[c1], ll[c1:]); lo = np.minimum(ll[c1], ll[c1:])
+        pairLL[i0:i0 + n] = np.sum(np.log(0.5) + hi + np.log1p(np.exp(lo - hi)), axis=1)
+        misAvg[i0:i0 + n] = np.sum((mm[c1] + mm[c1:]) / 2.0, axis=1); misMin[i0:i0 + n] = np.sum(np.minimum(mm[c1], mm[c1:]), axis=1)
+    return pairLL, misAvg, misMin
+
+
 def test_oracle_call_hand_derived(oracle):
     # C = 3; pairs in index order: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
     ln = np.log
@@ -57,11 +72,12 @@ def same_up_to_ties(order_a, order_b, LL, MA):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("C,dup", [(1, ()), (2, ()), (37, ()), (200, ()), (120, ((5, 17), (40, 3), (41, 3), (119, 0)))], ids=["C1", "C2", "C37", "C200", "ties"])
+@pytest.mark.parametrize("C,dup", [(1, ()), (2, ()), (37, ()), (200, ()), (120, ((5, 17), (40, 3), (41, 3), (119, 0))), (3000, ((5, 17), (2999, 0), (1500, 1499), (1501, 1499))), (5000, ())],
+                         ids=["C1", "C2", "C37", "C200", "ties", "C3000-ties", "C5000"])
 def test_call_matches_oracle(pkg, oracle, C, dup):
     from tools import synth
     rng = np.random.default_rng(100 + C)
-    LL, MA, MM = table(C, rng, dup)
+    LL, MA, MM = table(C, rng, dup) if C <= 200 else table_rows(C, rng, dup)
     e = ob.call_locus(LL, MA, MM)
     w = synth.make_world(seed=1, G=300, k=1); ctx = pkg.Context(w["graph"], w["contigs"])
     g = ctx.call_locus(LL, MA, MM)

@@ -273,3 +273,42 @@ def test_record_the_reference_asserts_on_is_flagged_alone(pkg):
     for k in ("best_chain", "n_cols", "col_level", "col_mapq"):
         a = got[k].reshape(60, -1); z = good[k].reshape(60, -1)
         assert np.array_equal(a[keep], z[keep]), k
+
+
+def test_chains_far_into_a_graph_of_more_than_65534_levels(pkg, oracle):
+    """The 384-column layout of the projection keeps column levels as 16-bit offsets from the chain's first defined level: chains that start
+    beyond level 65 534 of a 90 000-level graph come out like any other.  A translation table with a negative entry never reaches the kernels:
+    processBAM::_loadMapping asserts thisLevel >= 0 (mapper/processBAM.cpp:4441-4443) and hlala_create refuses it the same way."""
+    w = synth.make_world(seed=9, G=90000, k=1)
+    b = synth.make_batch(w, 260, seed=19)
+    exp, gb, ctx = run_both(pkg, oracle, w, b)
+    lv0 = gb.chains(0)
+    assert (lv0["col_level"].reshape(b["n_chains"], -1)[:, 0] > 66000).sum() > 40
+    compare_chains(lv0, exp["seeds"], b["n_chains"], check_ll=False, check_dp=False, label="stage A")
+    compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stage B")
+    assert_pairs_equal(gb.pairs(), exp["pairs"])
+    bad = dict(w["contigs"]); bad["contig_level"] = bad["contig_level"].copy(); bad["contig_level"][int(bad["contig_off"][1]) + 5] = -1
+    with pytest.raises(pkg.HlalaError, match="translation level out of range"):
+        pkg.Context(w["graph"], bad, insert_mean=200.0, insert_sd=35.0)
+
+
+def test_nodes_with_hundreds_of_edges_and_gap_path_jumps(pkg, oracle):
+    """No limit on a node's degree: one node with 320 out-edges, one with 320 in-edges, one with 150 '_' out-edges and 150 forward gap-path jumps,
+    one with 150 backward jumps (tools/synth.py: make_fan_world) -- what HLA-B / -C / -DRB1 windows of PRG_MHC_GRCh38_withIMGT look like where this
+    build used to refuse the graph (7-bit push index).  Push order semantics kept: alignerBase.cpp:149-195 (edges in set order),
+    extensionAligner.cpp:2694-2742 (jumps in map order), first maximum in push order (Utilities.cpp:379-406)."""
+    w = synth.make_fan_world()
+    b = synth.make_batch(w, 260, seed=23, max_secondary=3)
+    exp, gb, ctx = run_both(pkg, oracle, w, b)
+    gi = ctx.graph_info()
+    assert gi.max_out_degree == 320 and gi.max_in_degree == 320 and gi.max_jumps == 150
+    compare_chains(gb.chains(0), exp["seeds"], b["n_chains"], check_ll=False, check_dp=False, label="stage A")
+    compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stage B")
+    assert_pairs_equal(gb.pairs(), exp["pairs"])
+    st = gb.stats()
+    assert st.n_errors == 0
+    assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
+    assert sum(int(x) for x in st.n_dp_class[3:]) > 0                      # frontiers of hundreds of cells: the wide classes ran
+    lv = gb.chains(1)["col_level"].reshape(b["n_chains"], -1)
+    for lo, hi in ((590, 620), (1190, 1360), (1840, 2010)):                 # alignments through the fan, the deletions that start together, those that end together
+        assert ((lv >= lo) & (lv <= hi)).any(1).sum() > 30

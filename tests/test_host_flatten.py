@@ -29,9 +29,11 @@ def hostlib(pkg):
     return lib
 
 
-@pytest.mark.parametrize("seed,G,k", [(1, 5000, 1), (2, 8000, 0), (3, 8000, 3), (4, 3000, 10), (5, 20000, 2)])
+@pytest.mark.parametrize("seed,G,k", [(1, 5000, 1), (2, 8000, 0), (3, 8000, 3), (4, 3000, 10), (5, 20000, 2), (5, 2400, -1)],
+                         ids=["k1", "k0", "k3", "k10", "k2", "fan-320-edges-150-jumps"])
 def test_flatten_matches_oracle(pkg, oracle, hostlib, seed, G, k):
-    w = synth.make_world(seed=seed, G=G, k=k)
+    # k = -1: nodes with 320 out- / in-edges and 150 gap-path jumps in either direction (allele-rich levels of a real PRG; no degree limit)
+    w = synth.make_world(seed=seed, G=G, k=k) if k >= 0 else synth.make_fan_world(seed=seed, G=G)
     g, k1 = pkg.fill_struct(pkg.GraphDesc, w["graph"]); c, k2 = pkg.fill_struct(pkg.ContigsDesc, w["contigs"])
     F = hostlib.hlala_host_flatten(C.byref(g), C.byref(c))
     assert F, hostlib.hlala_host_last_error()
@@ -48,12 +50,14 @@ def test_flatten_matches_oracle(pkg, oracle, hostlib, seed, G, k):
     assert np.array_equal(gs, o.graph_gap_stretch())
     # jump tables: per first node, targets ascending in creation index (std::map<Node*,Edge*> order)
     first, last, _ = a
+    if k < 0:
+        assert gi.max_out_degree == 320 and gi.max_in_degree == 320 and gi.max_jumps == 150 and gi.max_parallel == 1
     for node in np.unique(first)[:200]:
-        t = np.zeros(64, np.int32); p = np.zeros(64, np.int32)
-        n = hostlib.hlala_host_jumps(F, int(node), 1, 64, t.ctypes.data_as(pkg.c_i32p), p.ctypes.data_as(pkg.c_i32p))
+        t = np.zeros(256, np.int32); p = np.zeros(256, np.int32)
+        n = hostlib.hlala_host_jumps(F, int(node), 1, 256, t.ctypes.data_as(pkg.c_i32p), p.ctypes.data_as(pkg.c_i32p))
         exp = sorted(last[first == node].tolist())
-        assert n == len(exp) and t[:min(n, 64)].tolist() == exp[:64]
-        assert all(first[pp] == node for pp in p[:min(n, 64)])
+        assert n == len(exp) and t[:min(n, 256)].tolist() == exp[:256]
+        assert all(first[pp] == node for pp in p[:min(n, 256)])
     hostlib.hlala_host_free(F)
 
 

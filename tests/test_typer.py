@@ -40,7 +40,9 @@ def test_pair_loglik_by_hand(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("C,R,seed", [(200, 300, 5), (37, 1500, 6), (1, 5, 7), (513, 64, 8)])
+# (3000, 400) and (5000, 1000): the size of a real class-I / class-II locus of PRG_MHC_GRCh38_withIMGT -- 12 and 20 column tiles of the tiled all-pairs kernel,
+# 4.5 M and 12.5 M cluster pairs (the oracle computes its rows on all host cores; each sum keeps the reference's order, hla/HLATyper.cpp:2293-2364)
+@pytest.mark.parametrize("C,R,seed", [(200, 300, 5), (37, 1500, 6), (1, 5, 7), (513, 64, 8), (3000, 400, 9), (5000, 1000, 10)])
 def test_typer_kernels_match_oracle(pkg, oracle, C, R, seed):
     loc = synth.make_locus(seed=seed, n_clusters=C, n_reads=R)
     w = synth.make_world(seed=1, G=300, k=1)

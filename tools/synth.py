@@ -62,10 +62,11 @@ def make_haplotypes(rng, G, n_mut=2, n_largegap=1, mut_density=0.02, gap_frac=0.
     return H
 
 
-def build_graph(H: np.ndarray, k: int = 1):
+def build_graph(H: np.ndarray, k: int = 1, private=None, force_shared=()):
     """Levelled DAG from aligned haplotypes.  Node classes at level l = haplotypes sharing the
     next k symbols (k = 0: one node per level, parallel edges); node / edge creation order =
-    level-major, then first-haplotype order -- this IS the canonical order of the C-ABI."""
+    level-major, then first-haplotype order -- this IS the canonical order of the C-ABI.
+    private [nh, L] bool (optional): where set, the haplotype has a node of its own at that level."""
     nh, G = H.shape
     L = G + 1
     # class key per (hap, level): polynomial hash of symbols [l, l+k)
@@ -75,6 +76,11 @@ def build_graph(H: np.ndarray, k: int = 1):
         for j in range(k):
             key[:, :G] = key[:, :G] * np.uint64(257) + pad[:, j:j + G] + np.uint64(1)
     key[:, G] = 0  # single sink class
+    if private is not None:
+        own = (np.uint64(1) << np.uint64(60)) + np.arange(nh, dtype=np.uint64)[:, None] * np.ones((1, L), np.uint64)
+        key = np.where(private, own, key)
+    for l in force_shared:          # one node at this level whatever the next symbols are
+        key[:, l] = np.uint64(7)
 
     def first_occurrence_rank(keys):
         """keys [nh, N] -> (rank [nh, N] of each hap's class in first-hap order, n_classes [N])"""
@@ -132,6 +138,44 @@ def make_world(seed=1, G=25000, k=1, **kw):
     rng = np.random.default_rng(seed)
     H = make_haplotypes(rng, G, **kw)
     g = build_graph(H, k)
+    c = make_contigs(H)
+    return dict(H=H, graph=g, contigs=c, G=G)
+
+
+def make_fan_world(seed=5, G=2400, nh=320, fan=(600, 612), gaps_out=(1200, 150), gaps_in=(2000, 150)):
+    """A small world whose nodes have HUNDREDS of edges and gap-path jumps, the way allele-rich levels of a real PRG do (thousands of alleles
+    of HLA-B, allele-specific deletions): nh haplotypes with sparse substitutions;
+      * fan: every haplotype runs through nodes of its own between levels fan[0] and fan[1] -- one node with nh out-edges, one with nh in-edges;
+      * gaps_out = (level, n): n haplotypes carry a deletion that STARTS at that level, each of another length -- their common node there has n
+        out-edges labelled '_' and n forward gap-path jumps;
+      * gaps_in = (level, n): n other haplotypes carry deletions of different lengths that all END at that level -- n backward jumps at one node."""
+    rng = np.random.default_rng(seed)
+    nuc = np.frombuffer(b"ACGT", dtype=np.uint8)
+    scaffold = nuc[rng.integers(0, 4, G)]
+    H = np.tile(scaffold, (nh, 1))
+    snp = rng.random((nh, G)) < 0.004
+    H[snp] = nuc[rng.integers(0, 4, int(snp.sum()))]
+    L = G + 1
+    private = np.zeros((nh, L), bool)
+    a0, a1 = fan
+    H[:, a0:a1] = nuc[rng.integers(0, 4, (nh, a1 - a0))]
+    private[:, a0 + 1:a1] = True
+    H[:, a0 - 1] = scaffold[a0 - 1]; H[:, a1] = scaffold[a1]; H[:, a1 + 1] = scaffold[a1 + 1]          # one shared node before and after (k = 1: the next symbol decides)
+    H[:, a0] = nuc[rng.integers(0, 4, nh)]
+    # node(a0) must be ONE node although the haplotypes leave it with different symbols: private=False there and the key of level a0 made equal
+    b0, nb = gaps_out
+    for i in range(nb):
+        ln = 5 + i
+        H[i, b0:b0 + ln] = ord("_"); private[i, b0 + 1:b0 + ln] = True
+        H[i, b0 - 1] = scaffold[b0 - 1]
+    c1, ncg = gaps_in
+    for i in range(ncg):
+        h = nb + i; ln = 5 + i
+        H[h, c1 - ln:c1] = ord("_"); private[h, c1 - ln + 1:c1] = True
+    H[:, c1] = scaffold[c1]
+    H[:, :2] = scaffold[:2]; H[:, -2:] = scaffold[-2:]
+    # shared single nodes at the fan's two ends: the class key of those levels is forced equal for all haplotypes
+    g = build_graph(H, 1, private=private, force_shared=(a0, a1))
     c = make_contigs(H)
     return dict(H=H, graph=g, contigs=c, G=G)
 
