@@ -12,9 +12,14 @@ of 3-6 kb carrying 500-5000 allele paths merged by the suffix-10 rule -- and 2x1
 reference's empirical matrix, Poisson indels, start-to-start jump N(350, 35), >= 30 % of the pairs from allele rows of the gene
 windows, bwa-like seeds (soft clips, secondary alignments on other contigs).  `--graph simple` selects the round-1 stand-in.
 
-Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline`.  Rank 0 at N = 1 additionally measures, outside the timed region:
-the host-buffer-inclusive rate (hlala_batch_create -> hlala_align_batch -> hlala_batch_get_pairs_packed), gene-window and backbone
-pairs separately, two-stream batch pipelining (--stream-batches), the typer kernels at C = 3000, and the CPU oracle on a bounded sample.
+Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline`.  `value` is the resident rate (inputs in HBM when the timed region starts: the
+contract of this bench).  Rank 0 at N = 1 additionally measures, each with its own timed loop:
+  host_inclusive  the boundary of the C ABI -- hlala_batch_create (H2D) -> hlala_align_batch -> hlala_batch_get_pairs_packed (D2H of every column of
+                  the selected alignments) per step, page-locked caller buffers (hlala_pinned_alloc), two batches in flight on ONE context: uploads run
+                  on the context's upload stream, downloads on its reader stream, both beside the alignment of the other batch;
+  end_to_end      BAM bytes -> hla/*: the `HLA-LA --action HLA` host program on a Graph M graph directory and a multi-million-pair BAM (decode on all
+                  host threads, batches through the GPU two in flight, typing of six loci, result files), its own End-to-end line;
+and, as reports: gene-window and backbone pairs separately, the typer kernels at C = 3000, the CPU oracle on a bounded sample.
 """
 from __future__ import annotations
 
@@ -108,7 +113,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="two batches alternate, but each step's export follows its alignment at once (a batch's tail does not run beside the next batch)")
     ap.add_argument("--single-batch", action="store_true", help="one resident batch, steps strictly one after the other (no overlap of a batch's tail with the next batch)")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region (host-inclusive, gene / backbone split, streaming, typer)")
-    ap.add_argument("--stream-batches", type=int, default=6, help="batches pushed through two contexts / streams for the pipelined host-inclusive rate (0 = skip)")
+    ap.add_argument("--host-steps", type=int, default=6, help="steps of the host-inclusive loop (0 = skip)")
+    ap.add_argument("--e2e-pairs", type=int, default=4_194_304, help="pairs of the sample pushed through `HLA-LA --action HLA` for the end-to-end rate (0 = skip)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -149,7 +155,10 @@ def main():
     # through the whole path and its record export (+ the gather to rank 0); the export of step i is issued after the alignment of step i+1, so the
     # side-stream tail of one batch (the wide DP classes, include/hlala_gpu.h: hlala_align_batch) runs beside the bulk of the next.  K alignments and
     # K exports lie between the two synchronisations.  --single-batch keeps one batch and no overlap between steps.
-    gbs = [gb] if args.single_batch else [gb, ctx.batch(mk(args.pairs, 5000 + rank))]
+    b2 = None if args.single_batch else mk(args.pairs, 5000 + rank)
+    gbs = [gb] if args.single_batch else [gb, ctx.batch(b2)]
+    if b2 is not None:
+        gbs[-1].src = b2
     recs = [torch.empty((args.pairs, 8), dtype=torch.float64, device="cuda") for _ in gbs]
     rec = recs[0]
     gathered = [torch.empty_like(rec) for _ in range(world)] if (world > 1 and rank == 0) else None
@@ -190,7 +199,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    st = gb.stats()          # HIP events of the LAST step on the ctx stream + device work counters
+    st = gb.stats()          # HIP events of THIS batch's last alignment (the events belong to the batch) + device work counters
     if rank == 0:
         n_ok = int((rec[:, 0] == 0).sum().item())
         ms_per_step = elapsed / args.steps * 1e3
@@ -202,7 +211,9 @@ def main():
         bpp = algorithmic_bytes_per_pair(150, chains_pp, e_mean, cols_pc, cols_pc)
         cls_ms = [float(x) for x in st.ms_dp_class]; cls_n = [int(x) for x in st.n_dp_class]
         names = ["k_dp<DpTiny, 0>", "k_dp<DpMid, 1>", "k_dp<DpSmall, 2>", "k_dp<DpWide, 3>", "k_dp<DpBroad, 4>", "k_dp<DpLarge, 5>", "k_dp<DpHuge, 6>"]
-        dom = int(np.argmax(cls_ms))
+        # the dominant kernel among the classes of the main stream: the times of the side-stream classes (few hundred long DP calls at low priority beside
+        # the next batch, hlala_align_batch) are waiting times, not work
+        dom = int(np.argmax(cls_ms[:4]))
         dom_ms = cls_ms[dom]
         achieved = bpp * args.pairs / (dom_ms * 1e-3) / 1e9
         khash = kernel_source_hash()
@@ -237,21 +248,194 @@ def main():
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,
-                         "algorithmic_bytes_per_pair": bpp,
+                         "algorithmic_bytes_per_pair": bpp, "whole_step_achieved": bpp * args.pairs / (ms_per_step * 1e-3) / 1e9,
                          "note": "dominant kernel only (HIP events on the ctx stream); the path is bound by instruction issue and dependent LDS / global "
                                  "round trips, not by HBM (SURVEY 8(d)): see `secondary`",
                          "secondary": secondary},
         }
         if world == 1 and not args.no_extras:
             try:
+                if args.host_steps > 0:
+                    out["host_inclusive"] = host_pipeline(args, P, ctx, [b, gbs[-1].src if hasattr(gbs[-1], "src") else b])
                 out["config"].update(extras(args, P, synth, w, mk, b, ctx, gb, ckw))
             except Exception as e:          # the extras are reports, never a reason to lose the bench line
                 out["config"]["extras_error"] = repr(e)
+            for x in gbs:
+                x.close()
+            ctx.close()
+            if args.e2e_pairs > 0 and args.graph == "m":
+                try:
+                    out["end_to_end"] = end_to_end(args, P, synth, w, mk)
+                except Exception as e:
+                    out["end_to_end"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, synth, w, mk)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+class Pinned:
+    """numpy views of page-locked host memory from the library (hlala_pinned_alloc)"""
+
+    def __init__(self, lib):
+        import ctypes as C
+        self.lib = lib; self.ptrs = []
+        lib.hlala_pinned_alloc.restype = C.c_void_p; lib.hlala_pinned_alloc.argtypes = [C.c_size_t]
+        lib.hlala_pinned_free.argtypes = [C.c_void_p]; lib.hlala_pinned_free.restype = None
+
+    def empty(self, n, dtype):
+        import ctypes as C
+        dt = np.dtype(dtype); nb = max(1, int(n)) * dt.itemsize
+        p = self.lib.hlala_pinned_alloc(nb)
+        if not p:
+            raise RuntimeError("hlala_pinned_alloc failed")
+        self.ptrs.append(p)
+        return np.frombuffer((C.c_char * nb).from_address(p), dtype=dt, count=int(n))
+
+    def copy(self, a):
+        o = self.empty(a.size, a.dtype); o[:] = a.reshape(-1)
+        return o
+
+    def free(self):
+        for p in self.ptrs:
+            self.lib.hlala_pinned_free(p)
+        self.ptrs = []
+
+
+def host_pipeline(args, P, ctx, batches):
+    """The boundary in the loop: per step hlala_batch_create (H2D) -> hlala_align_batch -> per-pair scalars + hlala_batch_get_pairs_packed (D2H: level 4 B +
+    graph char + read char + mapQ char of every column of the selected alignments, the 7 B per column SURVEY 8(d) counts as output) -> hlala_batch_destroy,
+    two batches in flight on one context and one host thread, page-locked caller buffers."""
+    import ctypes as C
+    lib = ctx.lib
+    pin = Pinned(lib)
+    try:
+        ins = []
+        dts = dict(read_bases=np.uint8, read_quals=np.uint8, chain_contig=np.int32, chain_pos=np.int32, chain_offset=np.int32, chain_as=np.int32, chain_reverse=np.uint8, cigar=np.uint32,
+                   read_off=np.int64, chain_off=np.int64, cigar_off=np.int64, read_primary=np.int32)
+        for b in batches:
+            d = {k: b[k] for k in ("n_pairs", "n_chains")}
+            for k, dt in dts.items():
+                d[k] = pin.copy(np.ascontiguousarray(b[k], dt))
+            st, keep = P.fill_struct(P.BatchIn, d)
+            ins.append((st, keep, d))
+        n = args.pairs; nr = 2 * n; cap = nr * 184
+        off = pin.empty(nr + 1, np.int64)
+        cols = dict(col_level=pin.empty(cap, np.int32), col_gchar=pin.empty(cap, np.uint8), col_schar=pin.empty(cap, np.uint8), col_mapq=pin.empty(cap, np.uint8))
+        scal = dict(pair_status=pin.empty(n, np.int32), best_chain=pin.empty(nr, np.int32), n_combinations=pin.empty(n, np.int32), pair_ll=pin.empty(n, np.float64),
+                    pair_mapq=pin.empty(n, np.float64), mate_mapq=pin.empty(nr, np.float64), strands_valid=pin.empty(n, np.uint8))
+        po, keep_po = P.fill_struct(P.PairsOut, scal)
+        pk = P.PairsPackedOut(); pk.cap_cols = cap; pk.col_off = off.ctypes.data_as(P.c_i64p)
+        types = dict(P.PairsPackedOut._fields_)
+        for k, v in cols.items():
+            setattr(pk, k, v.ctypes.data_as(types[k]))
+        lib.hlala_batch_get_pairs_packed.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(P.PairsPackedOut)]
+        lib.hlala_batch_get_pairs.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(P.PairsOut)]
+
+        def start(i):
+            h = C.c_void_p()
+            ctx._check(lib.hlala_batch_create(ctx.h, C.byref(ins[i % len(ins)][0]), C.byref(h)), "hlala_batch_create")
+            ctx._check(lib.hlala_align_batch(ctx.h, h), "hlala_align_batch")
+            return h
+
+        def finish(h):
+            ctx._check(lib.hlala_batch_get_pairs(ctx.h, h, C.byref(po)), "hlala_batch_get_pairs")
+            ctx._check(lib.hlala_batch_get_pairs_packed(ctx.h, h, C.byref(pk)), "hlala_batch_get_pairs_packed")
+            lib.hlala_batch_destroy(h)
+            return int(pk.n_cols_total)
+
+        def loop(k):
+            cur = start(0); ncols = 0
+            for i in range(k):
+                nxt = start(i + 1) if i + 1 < k else None      # the next batch is uploaded and queued before this one is read back
+                ncols = finish(cur)
+                cur = nxt
+            return ncols
+
+        loop(2)                                                # warm: pool blocks, first touch
+        t = time.perf_counter(); ncols = loop(args.host_steps); dt = time.perf_counter() - t
+        ok = int((scal["pair_status"] == 0).sum())
+        res = {"value": args.pairs * args.host_steps / dt, "unit": "read pairs/s", "steps": args.host_steps, "ms_per_step": dt / args.host_steps * 1e3, "columns_returned_per_step": ncols,
+               "bytes_down_per_step": 7 * ncols + 8 * (nr + 1) + 37 * n, "bytes_up_per_step": int(sum(ins[0][2][k].nbytes for k in dts)), "pairs_ok_last_step": ok,
+               "what": "hlala_batch_create (H2D) + hlala_align_batch + hlala_batch_get_pairs + hlala_batch_get_pairs_packed (D2H) + hlala_batch_destroy per step; page-locked "
+                       "caller buffers (hlala_pinned_alloc); two batches in flight on one context, one host thread"}
+        # the same with pageable caller buffers (what a caller that does not use hlala_pinned_alloc gets)
+        offp = np.zeros(nr + 1, np.int64); colsp = {k: np.zeros_like(v) for k, v in cols.items()}
+        pk.col_off = offp.ctypes.data_as(P.c_i64p)
+        for k, v in colsp.items():
+            setattr(pk, k, v.ctypes.data_as(types[k]))
+        insp = []
+        for b in batches:
+            st, keep = P.fill_struct(P.BatchIn, {k: b[k] for k in list(dts) + ["n_pairs", "n_chains"]}); insp.append((st, keep, None))
+        ins, insq = insp, ins
+        loop(1)
+        t = time.perf_counter(); loop(3); dtp = time.perf_counter() - t
+        res["pageable"] = {"value": args.pairs * 3 / dtp, "ms_per_step": dtp / 3 * 1e3, "steps": 3}
+        return res
+    finally:
+        pin.free()
+
+
+def end_to_end(args, P, synth, w, mk):
+    """BAM bytes -> hla/*: `HLA-LA --action HLA` (hla-la_amd/host/HLA-LA.cpp) on a Graph M graph directory; bwa / samtools stand-ins hand over the BAM of a
+    synthetic sample (their command lines run unchanged).  The figure is the program's own End-to-end line: units / (BAM decode + alignment and typing)."""
+    import re
+    import shutil
+    import stat
+    import tempfile
+    from tools import graphm_dir
+    exe = os.path.join(ROOT, "hla-la_amd", "bin", "HLA-LA")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "hla-la_amd", "csrc"), "../bin/HLA-LA"])
+    tmp = tempfile.mkdtemp(prefix="hlala_e2e_")
+    try:
+        t0 = time.time()
+        gdir = os.path.join(tmp, "graph"); os.makedirs(gdir)
+        loci = ["A", "B", "C", "DQA1", "DQB1", "DRB1"]
+        graphm_dir.write_graph_dir_m(gdir, w, P, loci=loci)
+        t_dir = time.time() - t0; t0 = time.time()
+        ch = min(args.pairs, 1 << 20); nch = max(1, args.e2e_pairs // ch)
+        clen = np.diff(w["contigs"]["contig_off"])
+        bam = os.path.join(tmp, "sample.bam")
+        bw = synth.BamWriter(bam, [(nm, int(clen[i])) for i, nm in enumerate(graphm_dir.ref_names(w))], threads=0, level=1)
+        for k in range(nch):
+            bk = mk(ch, 3000 + k); names, _ = synth.scrambled_names(k, ch)
+            bw.append_batch(bk, names, order="coordinate"); del bk
+        size = bw.close()
+        t_bam = time.time() - t0
+
+        def stub(path, text):
+            with open(path, "w") as f:
+                f.write(text)
+            os.chmod(path, os.stat(path).st_mode | stat.S_IXUSR | stat.S_IXGRP | stat.S_IXOTH)
+        stub(os.path.join(tmp, "bwa"), "#!/bin/bash\nif [ \"$1\" = index ]; then touch $2.sa $2.ann $2.bwt; fi\nexit 0\n")
+        stub(os.path.join(tmp, "samtools"), f"#!/bin/bash\ncase \"$1\" in\n view) cat > /dev/null ;;\n sort) while [ $# -gt 0 ]; do if [ \"$1\" = -o ]; then ln -f {bam} \"$2\" || cp {bam} \"$2\"; fi; shift; done ;;\n"
+                                             " index) touch \"$2.bai\" ;;\nesac\nexit 0\n")
+        for fq in ("r1.fq", "r2.fq"):
+            with open(os.path.join(tmp, fq), "w") as f:
+                f.write("@r\nA\n+\nI\n")
+        outd = os.path.join(tmp, "out")
+        cmd = [exe, "--action", "HLA", "--maxThreads", "2", "--sampleID", "S", "--outputDirectory", outd, "--PRG_graph_dir", gdir, "--FASTQU", os.path.join(tmp, "r1.fq"),
+               "--FASTQ1", os.path.join(tmp, "r1.fq"), "--FASTQ2", os.path.join(tmp, "r2.fq"), "--bwa_bin", os.path.join(tmp, "bwa"), "--samtools_bin", os.path.join(tmp, "samtools"),
+               "--mapAgainstCompleteGenome", "0", "--longReads", "0", "--loci", ",".join(loci), "--rngSeed", "12345", "--batchPairs", str(ch)]
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp, timeout=1500)
+        t_run = time.time() - t0
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr)[-1500:]}
+        m = re.search(r"End-to-end: ([0-9.e+]+) units per s \(BAM decode ([0-9.e+-]+) s on (\d+) threads \+ alignment and typing ([0-9.e+-]+) s; context creation and insert size ([0-9.e+-]+) s", r.stdout)
+        sp = re.search(r"Speed: ([0-9.e+]+) protoSeeds", r.stdout)
+        files = sorted(os.listdir(os.path.join(outd, "hla")))
+        calls = [ln for ln in r.stdout.splitlines() if ln.startswith("Locus ")]
+        return {"value": float(m.group(1)), "unit": "read pairs/s", "pairs": nch * ch, "bam_bytes": int(size), "decode_s": float(m.group(2)), "decode_threads": int(m.group(3)),
+                "alignment_and_typing_s": float(m.group(4)), "context_and_insert_size_s": float(m.group(5)), "speed_line_pairs_per_s": float(sp.group(1)) if sp else None,
+                "process_wall_s": t_run, "loci": loci, "result_files": len(files), "calls": calls[:6],
+                "setup_s": {"graph_directory": t_dir, "sample_generation_and_bam": t_bam},
+                "what": "HLA-LA --action HLA: BAM bytes -> hla/* (decode on all host threads, batches of %d pairs two in flight on one GPU, typing of %d loci, result files); "
+                        "value = pairs / (decode + alignment and typing), the program's End-to-end line; graph loading and context creation are per process" % (ch, len(loci))}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(args, synth, w, mk):
@@ -273,58 +457,7 @@ def cpu_baseline(args, synth, w, mk):
 
 def extras(args, P, synth, w, mk, b, ctx, gb, ckw):
     """Measurements outside the timed region (rank 0, one GPU)."""
-    import ctypes as C
     ex = {}
-    lib = ctx.lib
-    # ---- host-buffer inclusive: hlala_batch_create (H2D) -> hlala_align_batch -> hlala_batch_get_pairs_packed (D2H of every column of the
-    # selected alignments + per-pair scalars), caller-owned pageable buffers allocated once, nothing overlapped
-    # (the columns SURVEY 8(d) counts as output: level 4 B + graph char + read char + mapQ char = 7 B per column)
-    nr = 2 * args.pairs; cap = nr * 184
-    off = np.zeros(nr + 1, np.int64)
-    cols = dict(col_level=np.zeros(cap, np.int32), col_gchar=np.zeros(cap, np.uint8), col_schar=np.zeros(cap, np.uint8), col_mapq=np.zeros(cap, np.uint8))
-    lib.hlala_batch_get_pairs_packed.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(P.PairsPackedOut)]
-
-    def host_pass(cx, batch_in, offv, colsv, capv):
-        gbx = cx.batch(batch_in)
-        gbx.align()
-        o = P.PairsPackedOut(); o.cap_cols = capv; o.col_off = offv.ctypes.data_as(P.c_i64p)
-        types = dict(P.PairsPackedOut._fields_)
-        for k, v in colsv.items():
-            setattr(o, k, v.ctypes.data_as(types[k]))
-        cx._check(lib.hlala_batch_get_pairs_packed(cx.h, gbx.b, C.byref(o)), "hlala_batch_get_pairs_packed")
-        n = int(o.n_cols_total)
-        gbx.close()
-        return n
-
-    host_pass(ctx, b, off, cols, cap)                 # warm: first touch of the host buffers, pool blocks
-    reps = 2
-    t = time.perf_counter()
-    for _ in range(reps):
-        ncols = host_pass(ctx, b, off, cols, cap)
-    dt = (time.perf_counter() - t) / reps
-    ex["host_inclusive"] = {"pairs_per_s": args.pairs / dt, "ms_per_batch": dt * 1e3, "columns_returned": ncols,
-                            "what": "hlala_batch_create (H2D) + hlala_align_batch + hlala_batch_get_pairs_packed (D2H), pageable host buffers, one stream, nothing overlapped"}
-    # ---- two contexts on two streams, one host thread each: a batch's transfers overlap the other batch's kernels
-    if args.stream_batches > 0:
-        ctx2 = P.Context(w["graph"], w["contigs"], stream=None, **ckw)
-        off2 = np.zeros(nr + 1, np.int64); cols2 = {k: np.zeros_like(v) for k, v in cols.items()}
-        host_pass(ctx2, b, off2, cols2, cap)
-        nB = args.stream_batches
-
-        def worker(cx, offv, colsv, count):
-            for _ in range(count):
-                host_pass(cx, b, offv, colsv, cap)
-        th = [threading.Thread(target=worker, args=(ctx, off, cols, (nB + 1) // 2)), threading.Thread(target=worker, args=(ctx2, off2, cols2, nB // 2))]
-        t = time.perf_counter()
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        dt = time.perf_counter() - t
-        ex["host_inclusive_pipelined"] = {"pairs_per_s": nB * args.pairs / dt, "batches": nB, "ms_total": dt * 1e3,
-                                          "what": "the same per batch, batches alternate between two contexts (two HIP streams, one host thread each): "
-                                                  "uploads / downloads of one batch overlap the kernels of the other"}
-        del ctx2
     # ---- gene-window and backbone pairs separately (resident, one step each after a warm-up)
     if args.graph == "m":
         ns = min(args.pairs, 262144)

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -247,10 +248,30 @@ try {
         const long long a = r.start1, b = r.hasRange ? r.stop1 : len;
         if(a < 1 || b > len || b < a) return fail("sequences.txt: interval " + std::to_string(a) + "-" + std::to_string(b) + " outside " + r.ref + " (length " + std::to_string(len) + ")");
         const std::string tf = dir + "/translation/" + std::to_string(r.id) + ".txt";
-        std::ifstream ts(tf.c_str());
-        if(!ts.is_open()) return fail("Expected coordinate translation file not found: " + tf);
-        std::vector<int32_t> lv; std::string tl;
-        while(ts.good()) { std::getline(ts, tl); chomp(tl); std::stringstream ss(tl); int v = 0; ss >> v; lv.push_back(ss.fail() ? 0 : v); }     // StrtoI, Utilities.cpp:644-650
+        // one level per line, read as the reference's loop does (mapper/processBAM.cpp:4406-4412: getline while good(), Utilities::StrtoI = stringstream >> int,
+        // Utilities.cpp:644-650): a file that ends in a newline yields one more, empty line = level 0; a line without a leading integer yields 0.  Parsed by hand:
+        // the MHC graph has tens of millions of these lines.
+        std::vector<int32_t> lv;
+        {
+            std::ifstream ts(tf.c_str(), std::ios::binary);
+            if(!ts.is_open()) return fail("Expected coordinate translation file not found: " + tf);
+            std::string all((std::istreambuf_iterator<char>(ts)), std::istreambuf_iterator<char>());
+            const char* p = all.data(); const char* end = p + all.size();
+            for(;;) {
+                const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+                const char* le = nl ? nl : end;
+                const char* q = p;
+                while(q < le && (*q == ' ' || *q == '\t' || *q == '\r' || *q == '\v' || *q == '\f')) q++;
+                bool neg = false; if(q < le && (*q == '+' || *q == '-')) { neg = *q == '-'; q++; }
+                long long v = 0; bool digits = false, over = false;
+                while(q < le && *q >= '0' && *q <= '9') { digits = true; v = v * 10 + (*q - '0'); if(v > 4294967296ll) over = true; q++; }
+                if(neg) v = -v;
+                if(!digits || over || v > 2147483647ll || v < -2147483648ll) v = 0;                       // failed extraction: 0
+                lv.push_back((int32_t)v);
+                if(!nl) break;
+                p = nl + 1;
+            }
+        }
         const long long n = b - a + 1;
         if((long long)lv.size() < n) return fail(tf + ": " + std::to_string(lv.size()) + " levels for an interval of " + std::to_string(n) + " bases");
         C->seq.insert(C->seq.end(), s.begin() + a, s.begin() + b + 1);                                    // s[0] is the mark: 1-based start a = index a

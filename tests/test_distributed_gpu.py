@@ -1,4 +1,5 @@
-"""Two ranks (gloo) sharing the one GPU of the box, PRODUCT engine on every rank: pairs sharded in blocks, per-rank alignment with the
+"""Two ranks, PRODUCT engine on every rank -- over RCCL (backend nccl, one device per rank) when the node has two or more GPUs, over gloo with both
+ranks sharing the one GPU of the box otherwise: pairs sharded in blocks, per-rank alignment with the
 random seeds of the unsharded run, one gather of the per-pair records, one ragged gather of the exon positions of the locus, the call on
 rank 0 -- equal to the call of the unsharded product run.  (On an 8-GPU node the same code runs over RCCL; tests/test_distributed_cpu.py
 covers the plumbing with the oracle engine where there is no GPU.)"""
@@ -37,11 +38,18 @@ class ProductEngine:
         return self.ctx.call_locus(a, b, c)
 
 
-def _worker(rank, world, port, n_pairs, tmp):
+def _worker(rank, world, port, n_pairs, tmp, backend):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
+    my_dev = rank if backend == "nccl" else 0
+    dev = torch.device("cuda", my_dev) if backend == "nccl" else None          # where the process group works
+    if backend == "nccl":
+        torch.cuda.set_device(my_dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from conftest import load_package
     from tools import synth
     P = load_package()
@@ -60,7 +68,7 @@ def _worker(rank, world, port, n_pairs, tmp):
     prm = P.default_filter_params(first20_n=6, first20_limit_per_read=0)
 
     def run(batch, rng_seed):
-        ctx = P.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=rng_seed & 0xFFFFFFFF, device=0)
+        ctx = P.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=rng_seed & 0xFFFFFFFF, device=my_dev)
         gb = ctx.batch(batch); gb.align()
         assert gb.stats().n_errors == 0
         ctx.set_gene_intervals(*gene)
@@ -74,13 +82,14 @@ def _worker(rank, world, port, n_pairs, tmp):
     sub, p0, c0 = D.shard_pairs(b, rank, world)
     ctx, local, rec, cov = run(sub, 99 + 2 * c0)
     rec[:, 1:3] += c0
-    got = D.gather_records(torch.from_numpy(rec), dst=0)
-    tot = D.reduce_coverage(torch.from_numpy(cov), dst=0)
-    call = D.call_locus_sharded(ProductEngine(P, ctx), local, p0, seqs, Cn, Pex, prm, dst=0)
+    to_pg = (lambda a: torch.from_numpy(a).to(dev)) if dev is not None else torch.from_numpy
+    got = D.gather_records(to_pg(rec), dst=0)
+    tot = D.reduce_coverage(to_pg(cov), dst=0)
+    call = D.call_locus_sharded(ProductEngine(P, ctx), local, p0, seqs, Cn, Pex, prm, dst=0, device=dev)
     if rank == 0:
         ctxF, full, recF, covF = run(b, 99)
         eng = ProductEngine(P, ctxF)
-        ok = np.array_equal(torch.cat(got).numpy(), recF) and np.array_equal(tot.numpy(), covF)
+        ok = np.array_equal(torch.cat(got).cpu().numpy(), recF) and np.array_equal(tot.cpu().numpy(), covF)
         for k in D._EXON_ARRAYS:
             ok = ok and np.array_equal(np.asarray(call["positions"][k]), np.asarray(full[k]), equal_nan=True)
         use, ign, st = eng.filter_positions(full, prm)
@@ -88,13 +97,16 @@ def _worker(rank, world, port, n_pairs, tmp):
         pl = eng.pair_loglik(LL, Mm); ref = eng.call_locus(*pl)
         ok = ok and np.array_equal(call["pos_use"], use) and np.array_equal(call["pair_ll"], pl[0]) and np.array_equal(call["order"], ref["order"])
         ok = ok and (call["first_cluster"], call["second_cluster"]) == (ref["first_cluster"], ref["second_cluster"])
-        np.save(os.path.join(tmp, "ok.npy"), np.array([int(ok), full["n_reads"], call["positions"]["n_reads"]]))
+        np.save(os.path.join(tmp, "ok.npy"), np.array([int(ok), full["n_reads"], call["positions"]["n_reads"], int(backend == "nccl")]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_reach_the_unsharded_call(tmp_path):
+def test_two_ranks_reach_the_unsharded_call(tmp_path):
+    import torch
+    # (counting devices does not initialise the GPU in this process: the ranks are spawned first)
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     port = 32500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, 1201, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, 1201, str(tmp_path), backend), nprocs=2, join=True)
     ok = np.load(tmp_path / "ok.npy")
-    assert ok[0] == 1 and ok[1] == ok[2] and ok[1] > 50
+    assert ok[0] == 1 and ok[1] == ok[2] and ok[1] > 50 and ok[3] == int(backend == "nccl")

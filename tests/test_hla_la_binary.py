@@ -183,6 +183,24 @@ def test_action_hla_writes_the_files_of_the_ctypes_path(exe, pkg, tmp_path):
     for fn in files:
         assert (out3 / "hla" / fn).read_bytes() == (out1 / "hla" / fn).read_bytes(), fn
     assert (out3 / "reads_per_level.txt").read_bytes() == (out1 / "reads_per_level.txt").read_bytes()
+    # ---- two contexts (listed devices 0,0: the multi-GPU walk of the host program, one host thread per context, batches dealt round-robin,
+    # coverage summed, exon positions merged in batch order, call on the first context) write the same files as one context
+    out2 = tmp_path / "out2"
+    r2 = subprocess.run(base + ["--outputDirectory", str(out2), "--batchPairs", "150", "--devices", "0,0", "--decodeThreads", "3"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r2.returncode == 0 and "in 5 GPU batch(es) on 2 device context(s)" in r2.stdout and "End-to-end: " in r2.stdout, r2.stdout + r2.stderr
+    for fn in files:
+        assert (out2 / "hla" / fn).read_bytes() == (out1 / "hla" / fn).read_bytes(), fn
+    assert (out2 / "reads_per_level.txt").read_bytes() == (out1 / "reads_per_level.txt").read_bytes()
+    # ---- BASELINE config 4 in small: two samples in one call, one per listed device, side by side; each writes what its own call writes
+    ra = [x for x in base]
+    for key, val in (("--sampleID", "S1,S2"), ("--FASTQ1", f"{tmp_path / 'r1.fq'},{tmp_path / 'r1.fq'}"), ("--FASTQ2", f"{tmp_path / 'r2.fq'},{tmp_path / 'r2.fq'}"),
+                     ("--FASTQU", f"{tmp_path / 'r1.fq'},{tmp_path / 'r1.fq'}")):
+        ra[ra.index(key) + 1] = val
+    r4 = subprocess.run(ra + ["--outputDirectory", f"{tmp_path / 'outA'},{tmp_path / 'outB'}", "--devices", "0,0"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r4.returncode == 0 and "Processed 2 samples on 2 device(s)" in r4.stdout, r4.stdout + r4.stderr
+    for o in ("outA", "outB"):
+        for fn in files:
+            assert (tmp_path / o / "hla" / fn).read_bytes() == (out1 / "hla" / fn).read_bytes(), (o, fn)
     # ---- a stale file under hla/ is wiped (processBAM.cpp:1805-1806), a failing mapper ends with a non-zero status
     (out1 / "hla" / "stale.txt").write_text("x")
     r = subprocess.run(base + ["--outputDirectory", str(out1)], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
