@@ -426,11 +426,12 @@ def end_to_end(args, P, synth, w, mk):
             return {"error": (r.stdout + r.stderr)[-1500:]}
         m = re.search(r"End-to-end: ([0-9.e+]+) units per s \(BAM decode ([0-9.e+-]+) s on (\d+) threads \+ alignment and typing ([0-9.e+-]+) s; context creation and insert size ([0-9.e+-]+) s", r.stdout)
         sp = re.search(r"Speed: ([0-9.e+]+) protoSeeds", r.stdout)
+        ph = re.search(r"Typing phases: (.*)", r.stdout)
         files = sorted(os.listdir(os.path.join(outd, "hla")))
         calls = [ln for ln in r.stdout.splitlines() if ln.startswith("Locus ")]
         return {"value": float(m.group(1)), "unit": "read pairs/s", "pairs": nch * ch, "bam_bytes": int(size), "decode_s": float(m.group(2)), "decode_threads": int(m.group(3)),
                 "alignment_and_typing_s": float(m.group(4)), "context_and_insert_size_s": float(m.group(5)), "speed_line_pairs_per_s": float(sp.group(1)) if sp else None,
-                "process_wall_s": t_run, "loci": loci, "result_files": len(files), "calls": calls[:6],
+                "process_wall_s": t_run, "typing_phases": ph.group(1) if ph else None, "loci": loci, "result_files": len(files), "calls": calls[:6],
                 "setup_s": {"graph_directory": t_dir, "sample_generation_and_bam": t_bam},
                 "what": "HLA-LA --action HLA: BAM bytes -> hla/* (decode on all host threads, batches of %d pairs two in flight on one GPU, typing of %d loci, result files); "
                         "value = pairs / (decode + alignment and typing), the program's End-to-end line; graph loading and context creation are per process" % (ch, len(loci))}

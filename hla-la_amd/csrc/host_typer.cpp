@@ -15,6 +15,8 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -533,11 +535,29 @@ try {
         std::ofstream ap((dir + "/R1_PP_" + locus + "_pairs.txt").c_str());
         if(!ap.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_PP_" + locus + "_pairs.txt");
         ap << "ClusterID" << "\t" << "P" << "\t" << "LL" << "\t" << "Mismatches_avg" << "\n";
-        for(long long k = 0; k < nPairs; k++) {
-            const int cI = in->order[k];
-            if(cI < 0 || cI >= nPairs) return fail(HLALA_E_ARG, "hlala_locus_write_files: order[] holds an index outside the pair table");
-            ap << L->clusterId[c1Of[cI]] << "/" << L->clusterId[c2Of[cI]] << "\t" << in->p_normalized[cI] << "\t" << in->pair_ll[cI] << "\t" << in->mis_avg[cI] << "\n";
-        }
+        for(long long k = 0; k < nPairs; k++) if(in->order[k] < 0 || in->order[k] >= nPairs) return fail(HLALA_E_ARG, "hlala_locus_write_files: order[] holds an index outside the pair table");
+        // one line per cluster pair (millions for a class-I locus): the lines are formatted by the same iostream calls as the reference's, chunk by chunk on all
+        // host threads, and written in order
+        const long long CH = 65536; const long long nChunks = (nPairs + CH - 1) / CH;
+        std::vector<std::string> parts((size_t)nChunks);
+        std::atomic<long long> next(0);
+        auto work = [&]() {
+            for(;;) {
+                const long long c = next.fetch_add(1); if(c >= nChunks) break;
+                std::ostringstream os;
+                const long long k1 = std::min(nPairs, (c + 1) * CH);
+                for(long long k = c * CH; k < k1; k++) {
+                    const int cI = in->order[k];
+                    os << L->clusterId[c1Of[cI]] << "/" << L->clusterId[c2Of[cI]] << "\t" << in->p_normalized[cI] << "\t" << in->pair_ll[cI] << "\t" << in->mis_avg[cI] << "\n";
+                }
+                parts[(size_t)c] = os.str();
+            }
+        };
+        unsigned T = std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 64) T = 64; if((long long)T > nChunks) T = (unsigned)nChunks;
+        std::vector<std::thread> th; for(unsigned t = 1; t < T; t++) th.emplace_back(work);
+        work();
+        for(std::thread& x : th) x.join();
+        for(const std::string& pstr : parts) ap.write(pstr.data(), (std::streamsize)pstr.size());
     }
     // ---- coverage, column incompatibilities, best guesses, :2543-2759
     const int first = in->call->first_cluster, second = in->call->second_cluster;

@@ -50,24 +50,44 @@ constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows p
 
 // (16-lane class: a target table of 32 entries, i.e. at most 24 targets per iteration, sends 2.6 % more calls on to the 32-lane class than 64 entries did and
 // makes the kernel 10 % faster: half the table to scan, reset and keep in LDS; 8-lane groups were tried for this class -- 8 DPs per wave -- and lost)
-struct DpTiny  { static constexpr int WAVES = 4, GW = 16, WCAP = 16,   HC = 32,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
-struct DpMid   { static constexpr int WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
-struct DpSmall { static constexpr int WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+// The three classes of the long tail (frontiers of 257 .. 8192 cells: a few thousand DP calls per million pairs, each hundreds of iterations over hundreds of cells)
+// run one DP per BLOCK of several wavefronts: the rounds of an iteration over the frontier / the targets are split across the waves, block barriers take the
+// place of the wave fences and the group collectives exchange one word per wave through LDS.  (One wavefront per DP left most of the chip idle while a few
+// hundred waves walked their frontiers 64 cells at a time: 120 ms of side stream per million pairs.)  HLALA_DP_TAIL_THREADS = 64 restores one wave per DP.
+// Measured on Graph M, 1 M pairs per batch (tools/gpu_tail_variants.sh; ms per step with two batches in flight / one batch at a time; tail alone):
+//   64 threads 281 / 336 (tail 120 ms)   128 threads 280 / 306 (86 ms)   256 threads 299 / 300 (80 ms)   in-memory class at 1024 threads: 315 / 345 (spills)
+// -- four waves per DP shorten the tail most but take issue slots from the main-stream kernels of the next batch (16-lane class 91 -> 118 ms beside them).
+#ifndef HLALA_DP_TAIL_THREADS
+#define HLALA_DP_TAIL_THREADS 128
+#endif
+constexpr int DP_TAIL_THREADS = HLALA_DP_TAIL_THREADS;
+#ifndef HLALA_DP_BROAD_THREADS
+#define HLALA_DP_BROAD_THREADS HLALA_DP_TAIL_THREADS
+#endif
+#ifndef HLALA_DP_LARGE_THREADS
+#define HLALA_DP_LARGE_THREADS HLALA_DP_TAIL_THREADS
+#endif
+#ifndef HLALA_DP_HUGE_THREADS
+#define HLALA_DP_HUGE_THREADS HLALA_DP_TAIL_THREADS
+#endif
+struct DpTiny  { static constexpr int THREADS = 64, WAVES = 4, GW = 16, WCAP = 16,   HC = 32,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpMid   { static constexpr int THREADS = 64, WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpSmall { static constexpr int THREADS = 64, WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
 // but a quarter of its LDS, so that seven of them share a CU instead of one
-struct DpWide  { static constexpr int WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpWide  { static constexpr int THREADS = 64, WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 257 .. 512 cells with the table sizes of the large class (tens of thousands of kept cells): half the LDS of the large class, three per CU
-struct DpBroad { static constexpr int WAVES = 1, GW = 64, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpBroad { static constexpr int THREADS = HLALA_DP_BROAD_THREADS, WAVES = 1, GW = HLALA_DP_BROAD_THREADS, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and
 //  thousands of sequence-complete cells per DP were measured -- are what the large class is sized for; its table slots are ints)
-struct DpLarge { static constexpr int WAVES = 1, GW = 64, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpLarge { static constexpr int THREADS = HLALA_DP_LARGE_THREADS, WAVES = 1, GW = HLALA_DP_LARGE_THREADS, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 
 // The backstop: everything the other classes keep in LDS -- target table, frontiers, DP state -- lives in the block's HBM slab, so the capacities are
 // set by memory, not by the 160 KB of a CU (frontiers of 3000+ cells, 60 000 kept cells and 15 000 tied complete cells per DP occur on the densest
 // levels of the Graph M workload: about 30 DP calls per million pairs).  Same code (one template): the structure reference simply points into
 // the slab, the wave fences become agent-scope fences (plain loads must not hit stale L1 lines of words the atomics changed in L2), and the
 // frontier sort borrows the otherwise unused LDS.  An order of magnitude slower per cell than the LDS classes; nothing is dropped.
-struct DpHuge  { static constexpr int WAVES = 1, GW = 64, WCAP = 8192, HC = 16384, IBITS = 13, CELLS = 131072, EARLY = 131072, IMPCAP = 8192, COMPLETED = 65536, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = true; };
+struct DpHuge  { static constexpr int THREADS = HLALA_DP_HUGE_THREADS, WAVES = 1, GW = HLALA_DP_HUGE_THREADS, WCAP = 8192, HC = 16384, IBITS = 13, CELLS = 131072, EARLY = 131072, IMPCAP = 8192, COMPLETED = 65536, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = true; };
 constexpr int DP_SORT_SCRATCH = 8192;       // (key, payload) pairs of the in-memory class's frontier sort, in LDS: 128 KB
 
 // State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
@@ -101,6 +121,7 @@ struct __align__(16) DpLdsT {
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     typename C::ImpIdx hq[C::HC];   // per hash entry: index of the improvement its cell staged this iteration (all ones = none)
     int nNew, nImp, nKeepF, err, nCompletedAdd;
+    int nTa;                                          // targets claimed so far this iteration (classes of several waves per DP: the waves append to one list)
     int nextPhase;                                    // state after PH_DONE: idle, or the end-cell choice of a linked duplicate
     int btSlot, btM, btX, btY, btGuard, btDone;       // back-pointer chase in progress (lane 0 of the group)
     DpState st;
@@ -174,19 +195,50 @@ template <int GW> __device__ __forceinline__ int grp_base() { return (int)(threa
         t_ = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); v = OP(v, t_);      /* row_mirror */          \
     } while(0)
 
+// GW > 64 (one DP per block of several wavefronts): a block barrier that also orders the block's LDS / global accesses, and an exchange of one word per
+// wave through LDS.  The second barrier of a collective keeps a fast wave from overwriting the words before every wave has read them.
+__device__ __forceinline__ void blk_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <int GW> struct BlkX { static constexpr int NW = GW / 64; };
+template <int GW> __device__ __forceinline__ int* blk_words() { __shared__ int x[BlkX<GW>::NW > 0 ? 2 * BlkX<GW>::NW : 2]; return x; }
+
 template <int GW> __device__ __forceinline__ int grp_max_i32(int v)
 {
     if(GW == 64) return wave_max_i32(v);
+    if constexpr (GW > 64) {
+        const int w = wave_max_i32(v); int* x = blk_words<GW>();
+        if(lane_id() == 0) x[threadIdx.x >> 6] = w;
+        blk_barrier();
+        int r = x[0];
+#pragma unroll
+        for(int i = 1; i < BlkX<GW>::NW; i++) r = op_max_(r, x[i]);
+        blk_barrier();
+        return r;
+    } else {
     HLALA_ROW_ALLREDUCE(v, op_max_);
     if(GW == 32) v = op_max_(v, __shfl_xor(v, 16));     // the partner row of a 32-lane group
     return v;
+    }
 }
 template <int GW> __device__ __forceinline__ int grp_sum_i32(int v)
 {
     if(GW == 64) return wave_sum_i32(v);
+    if constexpr (GW > 64) {
+        const int w = wave_sum_i32(v); int* x = blk_words<GW>();
+        if(lane_id() == 0) x[threadIdx.x >> 6] = w;
+        blk_barrier();
+        int r = x[0];
+#pragma unroll
+        for(int i = 1; i < BlkX<GW>::NW; i++) r += x[i];
+        blk_barrier();
+        return r;
+    } else {
     HLALA_ROW_ALLREDUCE(v, op_add_);
     if(GW == 32) v = op_add_(v, __shfl_xor(v, 16));
     return v;
+    }
 }
 template <int GW> __device__ __forceinline__ u64 grp_min_u64(u64 v)
 {
@@ -201,6 +253,18 @@ template <int GW> __device__ __forceinline__ u64 grp_min_u64(u64 v)
 template <int GW> __device__ __forceinline__ int grp_excl_scan(int v, int& total)
 {
     if(GW == 64) return wave_excl_scan(v, total);
+    if constexpr (GW > 64) {
+        int wt; const int off = wave_excl_scan(v, wt); int* x = blk_words<GW>();
+        const int wv = (int)(threadIdx.x >> 6);
+        if(lane_id() == 0) x[wv] = wt;
+        blk_barrier();
+        int before = 0, tot = 0;
+#pragma unroll
+        for(int i = 0; i < BlkX<GW>::NW; i++) { const int t = x[i]; if(i < wv) before += t; tot += t; }
+        blk_barrier();
+        total = tot;
+        return before + off;
+    } else {
     int x = v, t;
     t = dpp_mov<0x111>(0, x); x += t;       // row_shr:1 (lanes without a source keep 0)
     t = dpp_mov<0x112>(0, x); x += t;
@@ -214,26 +278,73 @@ template <int GW> __device__ __forceinline__ int grp_excl_scan(int v, int& total
     }
     total = m;
     return x - v;
+    }
 }
-template <int GW> __device__ __forceinline__ u64 grp_ballot(bool p)
+template <int GW> __device__ __forceinline__ u64 grp_ballot(bool p)      // groups of at most one wavefront
 {
+    static_assert(GW <= 64, "grp_ballot: one wavefront at most (grp_any / grp_rank for blocks)");
     u64 b = __ballot(p);
     if(GW == 64) return b;
     return (b >> grp_base<GW>()) & ((1ull << (GW & 63)) - 1ull);
 }
-template <int GW> __device__ __forceinline__ int grp_bcast(int v, int srcGroupLane)
+// does the predicate hold for any lane of the group
+template <int GW> __device__ __forceinline__ bool grp_any(bool p)
 {
-    return __shfl(v, grp_base<GW>() + srcGroupLane);
+    if constexpr (GW > 64) {
+        const int w = __ballot(p) != 0 ? 1 : 0; int* x = blk_words<GW>();
+        if(lane_id() == 0) x[threadIdx.x >> 6] = w;
+        blk_barrier();
+        int r = 0;
+#pragma unroll
+        for(int i = 0; i < BlkX<GW>::NW; i++) r |= x[i];
+        blk_barrier();
+        return r != 0;
+    } else return grp_ballot<GW>(p) != 0;
 }
-// a group-uniform value: scalar for full-wave groups, left alone otherwise
-template <int GW> __device__ __forceinline__ int guni(int v) { return GW == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }
+// number of lanes before this one (in group order) for which the predicate holds; `total` = how many in the group (group-uniform)
+template <int GW> __device__ __forceinline__ int grp_rank(bool p, int& total)
+{
+    if constexpr (GW > 64) {
+        const u64 m = __ballot(p);
+        const int off = (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+        int* x = blk_words<GW>(); const int wv = (int)(threadIdx.x >> 6);
+        if(lane_id() == 0) x[wv] = __popcll(m);
+        blk_barrier();
+        int before = 0, tot = 0;
+#pragma unroll
+        for(int i = 0; i < BlkX<GW>::NW; i++) { const int t = x[i]; if(i < wv) before += t; tot += t; }
+        blk_barrier();
+        total = tot;
+        return before + off;
+    } else {
+        const u64 m = grp_ballot<GW>(p);
+        total = __popcll(m);
+        return __popcll(m & ((1ull << grp_lane<GW>()) - 1ull));
+    }
+}
+// the value lane 0 of the group holds, in every lane
+template <int GW> __device__ __forceinline__ int grp_bcast0(int v)
+{
+    if(GW == 64) return __builtin_amdgcn_readfirstlane(v);
+    if constexpr (GW > 64) {
+        int* x = blk_words<GW>();
+        if(threadIdx.x == 0) x[0] = v;
+        blk_barrier();
+        const int r = x[0];
+        blk_barrier();
+        return __builtin_amdgcn_readfirstlane(r);
+    } else return __shfl(v, grp_base<GW>());
+}
+// a group-uniform value: scalar for groups of whole wavefronts, left alone otherwise
+template <int GW> __device__ __forceinline__ int guni(int v) { return GW >= 64 ? __builtin_amdgcn_readfirstlane(v) : v; }
 
 // ordering between the lanes of a DP's group: a wavefront-scope fence for state in LDS; for the in-memory class an agent-scope fence (L1
 // invalidate / write-back around the barrier), because its atomics execute in the L2 and plain loads of the same words would otherwise be
 // served from the CU's L1
 template <class C> __device__ __forceinline__ void dp_sync()
 {
-    if constexpr (C::IN_MEMORY) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+    if constexpr (C::IN_MEMORY) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); if constexpr (C::GW > 64) __builtin_amdgcn_s_barrier(); else __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+    else if constexpr (C::GW > 64) blk_barrier();
     else { WSYNC(); }
 }
 #define DSYNC() dp_sync<C>()
@@ -467,7 +578,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.cellsEvaluated = 0;
         st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
         st.have = 0; st.sb = 0; st.se = -1; st.err = 0; st.needTier = 0; st.isAlias = 0;
-        S.err = 0;
+        S.err = 0; S.nTa = 0;
 #ifdef HLALA_DP_PROFILE
         S.pfStart = clock64(); S.pfSlow = 0; S.pfImp = 0; S.pfPre = 0; S.pfMaxNT = 0; S.pfMaxF = 0; for(int i = 0; i < 8; i++) S.pfPh[i] = 0;
 #endif
@@ -538,14 +649,24 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     const int nMax = n1 > n2 ? n1 : n2;
     // One wave per DP and a table of 512+ entries: the list of this iteration's targets is written as the entries are claimed (wave ballot, running count
     // in a register) instead of being collected from the table afterwards -- 8 .. 256 rounds over mostly empty entries.  Its order is arbitrary either way.
-    constexpr bool APPEND = (GW == 64) && (C::WCAP > 64);
+    constexpr bool APPEND = (GW >= 64) && (C::WCAP > 64);
     typedef typename TlistT<(C::HC <= 256)>::type TlT;
     int nTa = 0;
     auto append = [&](const bool claimed, const u32 h) {
-        if constexpr (APPEND) {
+        if constexpr (APPEND && GW == 64) {
             const u64 m = __ballot(claimed);
             if(claimed) S.tlist[nTa + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (TlT)h;
             nTa += __popcll(m);
+        } else if constexpr (APPEND) {
+            // several waves append to one list: a wave reserves its entries with one atomic on the shared count (the order of the list is arbitrary)
+            const u64 m = __ballot(claimed);
+            if(m) {
+                int base = 0;
+                if(lane_id() == 0) base = atomicAdd(&S.nTa, (int)__popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                if(claimed && pos < C::HC) S.tlist[pos] = (TlT)h;
+            }
         }
     };
     for(int i = gl; i < nMax; i += GW) {
@@ -705,7 +826,8 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     DP_TQ(5);
     // target list = occupied hash entries, compacted with a ballot per GW entries (no per-push counter, no ordering assumed)
     int nT = 0;
-    if constexpr (APPEND) nT = __builtin_amdgcn_readfirstlane(nTa);       // (lane 0 has been through every round of the loop above)
+    if constexpr (APPEND && GW == 64) nT = __builtin_amdgcn_readfirstlane(nTa);       // (lane 0 has been through every round of the loop above)
+    else if constexpr (APPEND) { nT = guni<GW>(S.nTa); if(nT > C::HC) nT = C::HC + 1; }
     else if constexpr (C::IN_MEMORY) {
         // (the table is in HBM: four independent loads per lane and trip instead of one)
         for(int h0 = 0; h0 < C::HC; h0 += 4 * GW) {
@@ -715,18 +837,18 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
 #pragma unroll
             for(int q = 0; q < 4; q++) {
                 const bool occ = kk[q] != HKEY_EMPTY;
-                const u64 m = grp_ballot<GW>(occ);
-                if(occ) S.tlist[nT + __popcll(m & ((1ull << gl) - 1ull))] = (typename TlistT<(C::HC <= 256)>::type)(h0 + q * GW + gl);
-                nT += __popcll(m);
+                int tot; const int rk = grp_rank<GW>(occ, tot);
+                if(occ) S.tlist[nT + rk] = (typename TlistT<(C::HC <= 256)>::type)(h0 + q * GW + gl);
+                nT += tot;
             }
         }
     } else
     for(int h0 = 0; h0 < C::HC; h0 += GW) {
         const int h = h0 + gl;
         const bool occ = S.hkey[h] != HKEY_EMPTY;
-        const u64 m = grp_ballot<GW>(occ);
-        if(occ) S.tlist[nT + __popcll(m & ((1ull << gl) - 1ull))] = (typename TlistT<(C::HC <= 256)>::type)h;
-        nT += __popcll(m);
+        int tot; const int rk = grp_rank<GW>(occ, tot);
+        if(occ) S.tlist[nT + rk] = (typename TlistT<(C::HC <= 256)>::type)h;
+        nT += tot;
     }
     DSYNC();
     DP_TQ(0);
@@ -740,7 +862,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     int nCells = guni<GW>(st.nCells);
     int earlyInit = guni<GW>(st.earlyInit);
     const int earlyMaxNat0 = guni<GW>(st.earlyMaxNat);
-    if(gl == 0) { S.nNew = 0; S.nImp = 0; S.nCompletedAdd = 0; }
+    if(gl == 0) { S.nNew = 0; S.nImp = 0; S.nCompletedAdd = 0; S.nTa = 0; }       // (nTa: read above, counts again from the next generate phase on)
     DSYNC();
     int itMaxNew = DP_NEG;        // max Dv over kept targets of this iteration
     u64 itMaxKey = ~0ull;         // smallest key achieving it (= first such cell in std::map order)
@@ -763,8 +885,9 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 if(Dv >= -16) es = early_lookup<C>(sl, earlyInit, S.hkey[h]);
                 S.tes[t] = (typename C::Slot)es;
             }
-            if(grp_ballot<GW>(es >= 0)) anyExisting = true;
+            if(es >= 0) anyExisting = true;
         }
+        anyExisting = grp_any<GW>(anyExisting);
         DSYNC();
     }
     DP_TQ(3);
@@ -840,12 +963,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 int natural = (x > startLevel ? x - startLevel : startLevel - x) + (y > start_seq ? y - start_seq : start_seq - y);
                 bool isEarly = isNew && natural > d;
                 if(isEarly && natural > earlyNatMax) earlyNatMax = natural;
-                if(grp_ballot<GW>(isEarly)) {                    // early cells: into the slab hash
+                if(grp_any<GW>(isEarly)) {                       // early cells: into the slab hash
                     if(!earlyInit) {
                         // first early cell of this call: the next generation of the slab's table (early_lookup)
                         int g = 0;
                         if(gl == 0) g = __hip_atomic_load(sl.early_gen(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-                        g = (GW == 64) ? __builtin_amdgcn_readfirstlane(g) : grp_bcast<GW>(g, 0);
+                        g = grp_bcast0<GW>(g);
                         if(g > DP_EARLY_GEN_MAX) { for(int i = gl; i < C::EARLY; i += GW) sl.early_key()[i] = 0; g = 1; }
                         if(gl == 0) __hip_atomic_store(sl.early_gen(), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         earlyInit = g;
@@ -880,7 +1003,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 if(act) { S.tes[t] = (typename C::Slot)slot; S.timp[t] = (unsigned char)(impMask | (isNew ? 0x80 : 0)); }
                 continue;
             }
-            if(grp_ballot<GW>(impMask != 0)) anyOw = true;
+            if(impMask != 0) anyOw = true;            // (per lane; combined over the group after the loop)
             // ---- the `diff` rule, :1007-1041: score difference to the real previous step of the MERGED D back pointer
             int diff = 1;
             if(keep && ok) {
@@ -907,14 +1030,9 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 }
             }
             // ---- running maximum bookkeeping, :1043-1062
-            bool eq = keep && Dv == curMax0 && diff != 0;
-            if(grp_ballot<GW>(eq)) anyEqDiff = true;
-            int wm = grp_max_i32<GW>(keep ? Dv : DP_NEG);
-            if(wm > itMaxNew) { itMaxNew = wm; itMaxKey = ~0ull; }
-            if(itMaxNew > curMax0) {       // the first cell of a NEW maximum is only needed when the maximum moves (group-uniform test)
-                u64 mn = grp_min_u64<GW>((keep && Dv == itMaxNew) ? key : ~0ull);
-                if(mn < itMaxKey) itMaxKey = mn;
-            }
+            if(keep && Dv == curMax0 && diff != 0) anyEqDiff = true;
+            // per lane: the largest D among its kept targets and the smallest key that carries it (combined over the group after the loop)
+            if(keep) { if(Dv > itMaxNew) { itMaxNew = Dv; itMaxKey = key; } else if(Dv == itMaxNew && key < itMaxKey) itMaxKey = key; }
             // stash for the filter phase: [0] = slot (or ~0 if dropped), [1] = merged D | GG<<16, [2] = merged SG
             if(act) {
                 S.hbest[0][h] = keep ? (typename C::Best)(u32)slot : (typename C::Best)0xFFFFFFFFu;
@@ -923,6 +1041,14 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             }
         }
         DSYNC();
+    }
+    // the group's view of what its lanes saw: a kept target equal to the running maximum with a real step behind it, an overwritten entry, the iteration's
+    // maximum and -- only needed when the maximum moves -- the first cell in map order that carries it
+    anyEqDiff = grp_any<GW>(anyEqDiff); anyOw = grp_any<GW>(anyOw);
+    {
+        const int mine = itMaxNew;
+        itMaxNew = grp_max_i32<GW>(mine);
+        if(itMaxNew > curMax0) itMaxKey = grp_min_u64<GW>(mine == itMaxNew ? itMaxKey : ~0ull);
     }
     DP_TQ(6);
     if(guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } DSYNC(); return PH_DONE; }
@@ -970,13 +1096,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         int t = t0 + gl;
         bool pass = false; u64 key = 0; int h = 0;
         if(t < nT) { h = S.tlist[t]; key = S.hkey[h]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); pass = (mx - v) <= 15; } }
-        const u64 m = grp_ballot<GW>(pass);
-        const int pos = nNew + __popcll(m & ((1ull << gl) - 1ull));
+        int passTot; const int pos = nNew + grp_rank<GW>(pass, passTot);
         if(pass && pos < C::WCAP) {
             S.fkey[bn][pos] = key; S.fslot[bn][pos] = (typename C::Slot)(int)S.hbest[0][h];
             S.fD[bn][pos] = (short)((u32)S.hbest[1][h] & 0xFFFF); S.fG[bn][pos] = (short)((u32)S.hbest[1][h] >> 16); S.fS[bn][pos] = (short)((u32)S.hbest[2][h] & 0xFFFF);
         }
-        nNew += __popcll(m);
+        nNew += passTot;
     }
     if(nNew > C::WCAP) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; st.needTier = tier_for_frontier(nNew); } DSYNC(); return PH_DONE; }
     DSYNC();
@@ -1013,7 +1138,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 if constexpr (C::IN_MEMORY) keys[i] = S.fkey[bn][i];
             } else { keys[i] = ~0ull; pay[i] = 0; }
         }
-        WSYNC();
+        DSYNC();
         for(int k = 2; k <= Pn; k <<= 1)
             for(int j = k >> 1; j > 0; j >>= 1) {
                 for(int idx = gl; idx < (Pn >> 1); idx += GW) {
@@ -1022,7 +1147,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     const u64 ka = keys[i], kb = keys[l];
                     if((ka > kb) == up) { const u64 pa = pay[i], pb = pay[l]; keys[i] = kb; keys[l] = ka; pay[i] = pb; pay[l] = pa; }
                 }
-                WSYNC();
+                DSYNC();
             }
         for(int i = gl; i < Pn; i += GW) {
             const u64 pv = pay[i];
@@ -1064,9 +1189,9 @@ __device__ inline int dp_select_many(const DpSlabT<C>& sl, const DevGraph& G, in
     for(int i0 = 0; i0 < nCompleted; i0 += GW) {
         int i = i0 + gl; bool tie = false; int s = 0; u64 kk = 0;
         if(i < nCompleted) { s = sl.completed()[i]; if(sl.cell()[s].sc[0] == best) { tie = true; u64 k = sl.cell()[s].key; kk = xz_key(key_x(k), key_node(k) - G.level_off[key_x(k)]); } }
-        const u64 m = grp_ballot<GW>(tie);
-        if(tie) { const int pos = nt + __popcll(m & ((1ull << gl) - 1ull)); sl.tie_slot()[pos] = s; sl.tie_key()[pos] = kk; }
-        nt += __popcll(m);
+        int tieTot; const int rk = grp_rank<GW>(tie, tieTot);
+        if(tie) { const int pos = nt + rk; sl.tie_slot()[pos] = s; sl.tie_key()[pos] = kk; }
+        nt += tieTot;
     }
     dp_sync<C>();
     u64 prefix = 0; int k = selectedIndex;
@@ -1096,7 +1221,8 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
         for(int i = gl; i < nCompleted; i += GW) best = max(best, (int)sl.cell()[sl.completed()[i]].sc[0]);
         best = grp_max_i32<GW>(best);
         int nTies = 0;
-        for(int i0 = 0; i0 < nCompleted; i0 += GW) { int i = i0 + gl; bool tie = i < nCompleted && sl.cell()[sl.completed()[i]].sc[0] == best; nTies += __popcll(grp_ballot<GW>(tie)); }
+        for(int i = gl; i < nCompleted; i += GW) if(sl.cell()[sl.completed()[i]].sc[0] == best) nTies++;
+        nTies = grp_sum_i32<GW>(nTies);
         u32 sd = seed;
         int selectedIndex = glibc_rand_r(&sd) % nTies;                                      // Utilities.cpp:922-927
         // the tie with exactly `selectedIndex` ties before it in "x/z" string order
@@ -1353,14 +1479,15 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
 //         every choice between the out- and the in-edge arrays) is uniform across the four groups of a wavefront;
 // TIER k > 0: items that outgrew the class of tier k-1 (retry list k).
 template <class C, int TIER>
-__global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items,
+__global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items,
                                                         char* slabs, size_t slabBytes, u32 rng_seed,
                                                         // the arrays of the inner loop are passed as kernel arguments: pointers loaded from the descriptors are generic
                                                         // (flat_load, which also ties up the LDS counter), kernel-argument pointers are known to be global
                                                         const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBasesArg)
 {
     constexpr int GW = C::GW;
-    constexpr int NG = 64 / GW;
+    constexpr int NG = GW >= 64 ? 1 : 64 / GW;           // DPs per block: groups of a wavefront, or one DP for the whole block
+    static_assert(C::THREADS == (GW >= 64 ? GW : 64), "block size");
     // graph / batch descriptors stay in memory (scalar loads on demand): passing them by value costs ~150 SGPRs
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
@@ -1464,7 +1591,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_dp(const DevGraph* __restrict_
             if(phase == PH_IDLE && more) {
                 int w = 0;
                 if(gl == 0) w = atomicAdd(fetchCounter, 1);
-                w = (GW == 64) ? __builtin_amdgcn_readfirstlane(w) : grp_bcast<GW>(w, 0);
+                w = grp_bcast0<GW>(w);
                 if(w >= nItems) more = false;
                 else {
                     const int idx = (TIER == 0) ? listBase + w : guni<GW>(srcList[w]);

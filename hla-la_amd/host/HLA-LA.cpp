@@ -206,6 +206,8 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
       std::cout << "End-to-end: " << (e2e > 0 ? (double)(pairs + unpaired) / e2e : 0.0) << " units per s (BAM decode " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
                 << " threads + alignment and typing " << inferSeconds << " s; context creation and insert size " << openSeconds - BAMprocessor.decode_seconds << " s and graph loading are per process, not per sample; "
                 << "whole action after the remapping: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s)\n" << std::flush; }
+    std::cout << "Typing phases: batches (alignment, post-processing, exon positions) " << HLAtyper.timing.batches << " s, summary " << HLAtyper.timing.summary << " s, per-locus likelihoods and calls "
+              << HLAtyper.timing.loci << " s, k-mer pass " << HLAtyper.timing.kmers << " s, result files " << HLAtyper.timing.files << " s\n" << std::flush;
     if(chainErrors) std::cerr << "WARNING: " << chainErrors << " alignments exceeded a device capacity; their read pairs are not used for typing\n";
     // reads_per_level.txt, processBAM.cpp:1902-1913
     {

@@ -352,6 +352,9 @@ public:
     int minAlignmentLength_unpaired = 1000, k_for_kMer_index = 31;
 
     struct bestGuess { std::string locus, allele1, allele2; double Q1_allele1 = 0, Q1_allele2 = 0; hlala_locus_report_out summary; };
+    // wall clock of the phases of the last HLATypeInference: the walk over the batches (alignment + what the typing takes from a resident batch), the summary
+    // file, the per-locus chain (filters, likelihoods, all pairs, call), the k-mer pass over the reads, the result files
+    struct Timing { double batches = 0, summary = 0, loci = 0, kmers = 0, files = 0; } timing;
 
     // Per-batch part of alignReads_postSeedExtraction_andStoreInto + HLATypeInference, then the per-locus chain.  The sample's units go
     // through the GPU batch by batch (processBAM::acquire); what the typing needs of a batch -- includeInHLA, the per-unit alignment
@@ -436,6 +439,9 @@ public:
         else { std::vector<std::thread> th; for(int d = 0; d < nDev; d++) th.emplace_back(device_walk, d); for(std::thread& t : th) t.join(); }
         for(const std::string& e : devErr) if(!e.empty()) throw std::runtime_error(e);
         double alignS = nDev == 1 ? devAlign[0] : std::chrono::duration<double>(std::chrono::steady_clock::now() - tAll).count();
+        auto lap = [](std::chrono::steady_clock::time_point& t) { const auto n = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double>(n - t).count(); t = n; return d; };
+        auto tLap = tAll;
+        timing = Timing();
         int64_t errors = 0; for(int64_t e : devErrors) errors += e;
         for(int32_t bi = 0; bi < nB; bi++) {
             const size_t u0 = (size_t)pB.batch_first_unit(bi);
@@ -451,10 +457,12 @@ public:
             }
         }
         { std::vector<std::vector<LocusPart>>().swap(parts); }
+        timing.batches = lap(tLap);
         if(align_seconds) *align_seconds = alignS;
         if(chain_errors) *chain_errors = errors;
         hlala_unit_stats_out us{usValid.data(), usStrands.data(), usDist.data(), usF.data(), usW.data(), usCols.data(), usQ.data()};
         tchk(hlala_typer_write_summary(outputDirectory.c_str(), (int32_t)pB.n_units, pB.longReadsMode ? 1 : 0, include.data(), &us, pB.IS_mean, pB.IS_sd, minAlignmentLength_unpaired), "hlala_typer_write_summary");
+        timing.summary = lap(tLap);
         // ---- per locus: filters -> likelihoods -> all pairs -> call
         struct Res { hlala_exon_positions_out pos; std::vector<double> pairLL, misAvg, misMin, pNorm; std::vector<int32_t> order; hlala_call_out call; std::vector<char> q[2]; int32_t nq[2], nt[2]; std::vector<uint8_t> present[2]; };
         std::vector<Res> res(acc.size());
@@ -488,6 +496,7 @@ public:
                 tchk(hlala_locus_cluster_kmers(A.L, cl, k_for_kMer_index, R.q[a].data(), R.nq[a], &R.nq[a], &R.nt[a]), "hlala_locus_cluster_kmers");
             }
         }
+        timing.loci = lap(tLap);
         // ---- which of those k-mers occur in the reads that went into typing: one more pass over the reads (a batch that was released is
         // uploaded again, not aligned again), every device over its own batches
         {
@@ -518,6 +527,7 @@ public:
             for(int d = 0; d < nDev; d++) for(size_t li = 0; li < res.size(); li++) for(int a = 0; a < 2; a++)
                 for(int32_t i = 0; i < res[li].nq[a]; i++) res[li].present[a][(size_t)i] |= devPresent[(size_t)d][2 * li + (size_t)a][(size_t)i];
         }
+        timing.kmers = lap(tLap);
         // ---- files
         std::vector<const char*> names(nU + 1, nullptr); for(size_t u = 0; u < nU; u++) names[u] = pB.readID((int64_t)u);
         std::vector<bestGuess> out; std::string lociJoined;
@@ -538,6 +548,7 @@ public:
             lociJoined += (lociJoined.empty() ? "" : ",") + A.locus;
         }
         tchk(hlala_typer_end_output(outputDirectory.c_str(), lociJoined.c_str(), 0), "hlala_typer_end_output");
+        timing.files = lap(tLap);
         return out;
     }
 
