@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region (host-inclusive, gene / backbone split, streaming, typer)")
     ap.add_argument("--host-steps", type=int, default=6, help="steps of the host-inclusive loop (0 = skip)")
     ap.add_argument("--e2e-pairs", type=int, default=4_194_304, help="pairs of the sample pushed through `HLA-LA --action HLA` for the end-to-end rate (0 = skip)")
+    ap.add_argument("--e2e-frac-gene", type=float, default=0.04, help="share of the end-to-end sample drawn from the gene windows: 0.04 = the windows' share of the graph, i.e. the uniform "
+                    "coverage of a whole-genome sample (the resident workload keeps 0.3: its gene-window pairs are the expensive ones; at 0.3 every typed locus would see 2000x coverage)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -243,8 +245,8 @@ def main():
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
                        "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
                        "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "pair": st.ms_pair, "side_stream": st.ms_side,
-                                    "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6]},
-                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6]},
+                                    "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6], "dp_lane": float(st.ms_dp_lane)},
+                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "lane": int(st.n_dp_lane)},
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,
@@ -400,7 +402,7 @@ def end_to_end(args, P, synth, w, mk):
         bam = os.path.join(tmp, "sample.bam")
         bw = synth.BamWriter(bam, [(nm, int(clen[i])) for i, nm in enumerate(graphm_dir.ref_names(w))], threads=0, level=1)
         for k in range(nch):
-            bk = mk(ch, 3000 + k); names, _ = synth.scrambled_names(k, ch)
+            bk = mk(ch, 3000 + k, frac_gene=args.e2e_frac_gene); names, _ = synth.scrambled_names(k, ch)
             bw.append_batch(bk, names, order="coordinate"); del bk
         size = bw.close()
         t_bam = time.time() - t0
@@ -431,7 +433,7 @@ def end_to_end(args, P, synth, w, mk):
         calls = [ln for ln in r.stdout.splitlines() if ln.startswith("Locus ")]
         return {"value": float(m.group(1)), "unit": "read pairs/s", "pairs": nch * ch, "bam_bytes": int(size), "decode_s": float(m.group(2)), "decode_threads": int(m.group(3)),
                 "alignment_and_typing_s": float(m.group(4)), "context_and_insert_size_s": float(m.group(5)), "speed_line_pairs_per_s": float(sp.group(1)) if sp else None,
-                "process_wall_s": t_run, "typing_phases": ph.group(1) if ph else None, "loci": loci, "result_files": len(files), "calls": calls[:6],
+                "process_wall_s": t_run, "typing_phases": ph.group(1) if ph else None, "loci": loci, "result_files": len(files), "calls": calls[:6], "gene_window_share_of_the_sample": args.e2e_frac_gene,
                 "setup_s": {"graph_directory": t_dir, "sample_generation_and_bam": t_bam},
                 "what": "HLA-LA --action HLA: BAM bytes -> hla/* (decode on all host threads, batches of %d pairs two in flight on one GPU, typing of %d loci, result files); "
                         "value = pairs / (decode + alignment and typing), the program's End-to-end line; graph loading and context creation are per process" % (ch, len(loci))}

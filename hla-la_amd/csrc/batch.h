@@ -65,7 +65,8 @@ struct DevBatch {
     u64* counters;                  // [32]
     int* work_counter;              // [48] dynamic work distribution: [0] stage A, [2] stage C, [7] chains stitched, [8]/[9] left / right DP items,
                                     //      [1]/[10] left / right items fetched, [12..35] retry lists (count, fetched) per tier 1..6 and direction
-    int* retry_list;                // [12*n_chains] DP items that outgrew a capacity class: (tier 1..6) x (left, right) x n_chains
+    int* retry_list;                // [14*n_chains] DP items that outgrew a capacity class: (tier 1..6) x (left, right) x n_chains; then (left, right) x n_chains: the
+                                    //      items the lane-per-DP class passed on to the 16-lane class (work_counter[40..45], kernel_dp_lane.hip)
     uint8_t* pair_deferred;         // [n_pairs] 1: a DP call of the pair went to the in-memory class; with the fused entry point its chains are stitched and
                                     //           the pair is scored in a second pass, after that class (which runs on a side stream next to the first pass)
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)

@@ -16,6 +16,7 @@
 
 // unity build: the kernels live in their own files but are compiled in this translation unit
 #include "kernel_dp.hip"
+#include "kernel_dp_lane.hip"
 #include "kernel_project.hip"
 #include "kernel_pair.hip"
 #include "kernel_typer.hip"
@@ -64,6 +65,7 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
+    char* lane_slabs = nullptr; int lane_grid = 0;      // the lane-per-DP class in front of the 16-lane class (kernel_dp_lane.hip); lane_grid 0: not used (HLALA_DP_LANE=0)
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     double* pair_scratch = nullptr;   // [2 * pair_grid][PAIR_COMB]: combination tables of the rare pairs with more than PAIR_COMB_LDS combinations (main- and side-stream pass)
@@ -88,7 +90,7 @@ struct hlala_batch {
     // timing events of THIS batch (created with its first stage call): ev = start / end per stage, [7] / [6] / [10] / [8] = before the 16-lane class / after it /
     // after the 64-lane class / after the last class; evC = start / end of each DP class on the stream it ran on; evSide[0] fork point on the main stream,
     // [1] first side-stream class starts, [6] second pairing pass done
-    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; bool eventsMade = false;
+    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; hipEvent_t evLane[2]{}; bool eventsMade = false; bool lane_used = false;
     uint32_t first_chain = 0;    // absolute index of the batch's chain 0 in the caller's numbering (hlala_batch_set_first_chain): offsets the random seeds
     float ms[3] = {0, 0, 0};
 };
@@ -119,6 +121,7 @@ static int batch_events(hlala_ctx* c, hlala_batch* b)
     for(int i = 0; i < 14; i++) HIP_TRY(c, hipEventCreate(&b->ev[i]));
     for(int i = 0; i < 8; i++) HIP_TRY(c, hipEventCreate(&b->evSide[i]));
     for(int i = 0; i < 14; i++) HIP_TRY(c, hipEventCreate(&b->evC[i / 2][i % 2]));
+    for(int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreate(&b->evLane[i]));
     HIP_TRY(c, hipEventCreateWithFlags(&b->evMain, hipEventDisableTiming));
     b->eventsMade = true;
     return HLALA_OK;
@@ -390,6 +393,9 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->huge_grid = cus / 4 > 0 ? cus / 4 : 1;      // the in-memory backstop class: a handful of DP calls per million pairs
     c->huge_slab_bytes = dp_inmemory_bytes<DpHuge>();
     if((rc = slab_pool(&c->tiny_slabs, c->tiny_slab_bytes * (size_t)(64 / DpTiny::GW) * (size_t)c->tiny_grid, "16-lane DP slabs"))) return fail(rc);
+    // (an experiment that lost, kept switchable and under test: HLALA_DP_LANE=1 puts the lane-per-DP class in front of the 16-lane class -- kernel_dp_lane.hip)
+    { const char* e = getenv("HLALA_DP_LANE"); c->lane_grid = (e && atoi(e) != 0) ? cus * 4 : 0; }          // 36 KB of LDS per wave: four per CU
+    if(c->lane_grid && (rc = slab_pool(&c->lane_slabs, dp_lane_slab_bytes() * (size_t)64 * (size_t)c->lane_grid, "lane-per-DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->mid_slabs, c->mid_slab_bytes * (size_t)(64 / DpMid::GW) * (size_t)c->mid_grid, "32-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid, "64-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid, "wide-class DP slabs"))) return fail(rc);
@@ -484,7 +490,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
-    AL(pair_deferred, np, true); AL(counters, 32, true); AL(work_counter, 48, true); AL(retry_list, 12 * nc, false);
+    AL(pair_deferred, np, true); AL(counters, 32, true); AL(work_counter, 48, true); AL(retry_list, 14 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
     B.dbg = c->dbg_host;
 #undef AL
@@ -627,6 +633,7 @@ void hlala_batch_destroy(hlala_batch* b)
     if(b->evMain) (void)hipEventDestroy(b->evMain);
     for(int i = 0; i < 14; i++) { if(b->ev[i]) (void)hipEventDestroy(b->ev[i]); if(b->evC[i / 2][i % 2]) (void)hipEventDestroy(b->evC[i / 2][i % 2]); }
     for(int i = 0; i < 8; i++) if(b->evSide[i]) (void)hipEventDestroy(b->evSide[i]);
+    for(int i = 0; i < 2; i++) if(b->evLane[i]) (void)hipEventDestroy(b->evLane[i]);
     delete b;
 }
 
@@ -701,6 +708,7 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
         // Items that outgrew it: two DPs per wave, then one wave per DP, then the classes with wider frontiers (fewer blocks per CU).
         // Each class is timed with its own pair of events on the stream it runs on (evC); ev[7] / ev[6] / ev[10] keep marking the start of the 16-lane
         // class, its end and the end of the 64-lane class on the main stream.
+        int* tinyList = nullptr;          // items the lane-per-DP class passes on to the 16-lane class (set below when that class runs)
         hipStream_t ws = c->active;
         auto run_class = [&](int tier) -> int {
             if(fused && tier == DP_SIDE_TIER) {
@@ -714,18 +722,27 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
             if(!fused && tier == DP_SIDE_TIER && c->sideTailValid) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSideTail, 0));
             HIP_TRY(c, hipEventRecord(b->evC[tier][0], ws));
             switch(tier) {
-            case 0: hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(DpTiny::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(DpMid::THREADS), 0, ws, c->dG, b->dB, items, c->mid_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 2: hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(DpSmall::THREADS), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 3: hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(DpWide::THREADS), 0, ws, c->dG, b->dB, items, c->wide_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 4: hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(DpBroad::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 5: hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(DpLarge::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs + c->large_slab_bytes * (size_t)c->broad_grid, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            default: hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(DpHuge::THREADS), 0, ws, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 0: hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(DpTiny::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)tinyList); break;
+            case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(DpMid::THREADS), 0, ws, c->dG, b->dB, items, c->mid_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
+            case 2: hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(DpSmall::THREADS), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
+            case 3: hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(DpWide::THREADS), 0, ws, c->dG, b->dB, items, c->wide_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
+            case 4: hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(DpBroad::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
+            case 5: hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(DpLarge::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs + c->large_slab_bytes * (size_t)c->broad_grid, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
+            default: hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(DpHuge::THREADS), 0, ws, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
             }
             int rc_ = check_launch(c, "k_dp"); if(rc_) return rc_;
             HIP_TRY(c, hipEventRecord(b->evC[tier][1], ws));
             return 0;
         };
+        // the lane-per-DP class first: 64 calls per wavefront; what it cannot finish exactly goes on to the 16-lane class through its list
+        b->lane_used = c->lane_grid > 0;
+        if(b->lane_used) {
+            tinyList = B.retry_list + (size_t)12 * (size_t)B.n_chains;
+            HIP_TRY(c, hipEventRecord(b->evLane[0], c->active));
+            hipLaunchKernelGGL(k_dp_lane, dim3(c->lane_grid), dim3(64), 0, c->active, c->dG, b->dB, items, c->lane_slabs, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, tinyList);
+            rc = check_launch(c, "k_dp_lane"); if(rc) return rc;
+            HIP_TRY(c, hipEventRecord(b->evLane[1], c->active));
+        }
         HIP_TRY(c, hipEventRecord(b->ev[7], c->active));
         rc = run_class(0); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(b->ev[6], c->active));
@@ -1070,9 +1087,10 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, b->ev[0], b->ev[1]);
     if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, b->ev[2], b->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, b->ev[6], b->side_used ? b->ev[10] : b->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, b->ev[7], b->ev[6]);
           for(int k = 0; k <= DP_LAST_TIER; k++) (void)hipEventElapsedTime(&out->ms_dp_class[k], b->evC[k][0], b->evC[k][1]);
+          if(b->lane_used) (void)hipEventElapsedTime(&out->ms_dp_lane, b->evLane[0], b->evLane[1]);
           if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, b->evSide[1], b->evSide[6]); } }
     { int wc[48]; HIP_TRY(c, hipMemcpyAsync(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
-      out->n_dp_class[0] = wc[8] + wc[9]; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
+      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9]; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, b->ev[4], b->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

@@ -1483,7 +1483,8 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
                                                         char* slabs, size_t slabBytes, u32 rng_seed,
                                                         // the arrays of the inner loop are passed as kernel arguments: pointers loaded from the descriptors are generic
                                                         // (flat_load, which also ties up the LDS counter), kernel-argument pointers are known to be global
-                                                        const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBasesArg)
+                                                        const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBasesArg,
+                                                        const int* __restrict__ tinyList)      // TIER 0 with the lane-per-DP class in front (kernel_dp_lane.hip): the items that class passed on; else null
 {
     constexpr int GW = C::GW;
     constexpr int NG = GW >= 64 ? 1 : 64 / GW;           // DPs per block: groups of a wavefront, or one DP for the whole block
@@ -1519,10 +1520,11 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
     for(int dirPass = 0; dirPass < 2; dirPass++) {
         // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
         // retry list of tier k = 1..6 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
-        int* fetchCounter = &B.work_counter[TIER == 0 ? (dirPass ? 10 : 1) : 13 + 4 * (TIER - 1) + 2 * dirPass];
-        const int nItems = uni(B.work_counter[TIER == 0 ? 8 + dirPass : 12 + 4 * (TIER - 1) + 2 * dirPass]);
+        const bool fromLane = TIER == 0 && tinyList != nullptr;         // [40]/[42] counts, [41]/[43] fetched: the list of the lane-per-DP class
+        int* fetchCounter = &B.work_counter[TIER == 0 ? (fromLane ? 41 + 2 * dirPass : (dirPass ? 10 : 1)) : 13 + 4 * (TIER - 1) + 2 * dirPass];
+        const int nItems = uni(B.work_counter[TIER == 0 ? (fromLane ? 40 + 2 * dirPass : 8 + dirPass) : 12 + 4 * (TIER - 1) + 2 * dirPass]);
         const int listBase = (TIER == 0 && dirPass) ? B.n_chains : 0;
-        const int* srcList = B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains;
+        const int* srcList = fromLane ? tinyList + (size_t)dirPass * (size_t)B.n_chains : B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains;
         const bool fwd = dirPass != 0;                     // left extensions run backwards (alignerBase: extensionAligner.cpp:229-241)
         int phase = PH_IDLE;
         bool more = true;
@@ -1594,7 +1596,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
                 w = grp_bcast0<GW>(w);
                 if(w >= nItems) more = false;
                 else {
-                    const int idx = (TIER == 0) ? listBase + w : guni<GW>(srcList[w]);
+                    const int idx = (TIER == 0 && !fromLane) ? listBase + w : guni<GW>(srcList[w]);
                     const int4* ip = (const int4*)(items + idx);
                     int4 a = ip[0], b = ip[1];
                     DpItem it; it.item = a.x; it.rOff = a.y; it.seqLen = a.z; it.start_seq = a.w; it.startLevel = b.x; it.startNode = b.y; it.pad0 = 0; it.pad1 = 0;

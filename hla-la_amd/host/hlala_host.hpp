@@ -11,9 +11,16 @@
 // error text (the reference aborts the process; a maintainer can keep that with a catch-all + abort()).
 // Header-only, needs only a C++11 compiler and libhlala_gpu.so -- no HIP headers.
 #pragma once
+#include <dirent.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -530,22 +537,59 @@ public:
         timing.kmers = lap(tLap);
         // ---- files
         std::vector<const char*> names(nU + 1, nullptr); for(size_t u = 0; u < nU; u++) names[u] = pB.readID((int64_t)u);
-        std::vector<bestGuess> out; std::string lociJoined;
-        for(size_t li = 0; li < acc.size(); li++) {
-            Acc& A = acc[li]; Res& R = res[li];
-            double covered[2];
-            for(int a = 0; a < 2; a++) { int hit = 0; for(int32_t i = 0; i < R.nq[a]; i++) hit += R.present[a][i]; covered[a] = R.nt[a] ? (double)hit / (double)R.nt[a] : -1; }
-            hlala_locus_report_in rin; std::memset(&rin, 0, sizeof(rin));
-            rin.pos = &R.pos; rin.filter = &filterParams; rin.unit_name_1 = names.data(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.data(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
-            rin.n_clusters = A.li.n_clusters; rin.pair_ll = R.pairLL.data(); rin.mis_avg = R.misAvg.data(); rin.mis_min = R.misMin.data(); rin.order = R.order.data(); rin.p_normalized = R.pNorm.data(); rin.call = &R.call;
-            rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2;
-            rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = (int32_t)pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
-            rin.min_mapq = minimumMappingQuality; rin.min_weighted_ok = min_bothReads_weightedCharactersOK;
-            bestGuess g; g.locus = A.locus;
-            tchk(hlala_locus_write_files(A.L, &rin, outputDirectory.c_str(), &g.summary), "hlala_locus_write_files");
-            g.allele1 = hlala_locus_cluster_id(A.L, R.call.first_cluster); g.allele2 = hlala_locus_cluster_id(A.L, R.call.second_cluster); g.Q1_allele1 = R.call.first_marginal; g.Q1_allele2 = R.call.second_p;
-            out.push_back(g);
-            lociJoined += (lociJoined.empty() ? "" : ",") + A.locus;
+        // The loci write their files side by side (the all-pairs table of a class-I locus is millions of lines): every locus into a directory of its own
+        // under the output directory; afterwards, in locus order, the rows it appended to the shared files (best guesses, histogram lines) are appended to
+        // the real ones and its own files are moved up -- the bytes of one locus after the other.
+        std::vector<bestGuess> out(acc.size()); std::string lociJoined;
+        {
+            std::vector<std::string> ferr(acc.size());
+            std::vector<std::string> tmpDir(acc.size());
+            for(size_t li = 0; li < acc.size(); li++) tmpDir[li] = outputDirectory + "/.locus_" + std::to_string(li);
+            auto write_one = [&](size_t li) {
+                try {
+                    Acc& A = acc[li]; Res& R = res[li];
+                    if(::mkdir(tmpDir[li].c_str(), 0775) != 0 && errno != EEXIST) throw std::runtime_error("cannot create " + tmpDir[li]);
+                    double covered[2];
+                    for(int a = 0; a < 2; a++) { int hit = 0; for(int32_t i = 0; i < R.nq[a]; i++) hit += R.present[a][i]; covered[a] = R.nt[a] ? (double)hit / (double)R.nt[a] : -1; }
+                    hlala_locus_report_in rin; std::memset(&rin, 0, sizeof(rin));
+                    rin.pos = &R.pos; rin.filter = &filterParams; rin.unit_name_1 = names.data(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.data(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
+                    rin.n_clusters = A.li.n_clusters; rin.pair_ll = R.pairLL.data(); rin.mis_avg = R.misAvg.data(); rin.mis_min = R.misMin.data(); rin.order = R.order.data(); rin.p_normalized = R.pNorm.data(); rin.call = &R.call;
+                    rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2;
+                    rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = (int32_t)pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
+                    rin.min_mapq = minimumMappingQuality; rin.min_weighted_ok = min_bothReads_weightedCharactersOK;
+                    bestGuess g; g.locus = A.locus;
+                    if(hlala_locus_write_files(A.L, &rin, tmpDir[li].c_str(), &g.summary) != HLALA_OK) throw std::runtime_error(std::string("hlala_locus_write_files: ") + hlala_typer_last_error());
+                    g.allele1 = hlala_locus_cluster_id(A.L, R.call.first_cluster); g.allele2 = hlala_locus_cluster_id(A.L, R.call.second_cluster); g.Q1_allele1 = R.call.first_marginal; g.Q1_allele2 = R.call.second_p;
+                    out[li] = g;
+                } catch(const std::exception& e) { ferr[li] = e.what(); }
+            };
+            const size_t par = acc.size() < 8 ? acc.size() : 8;
+            if(par <= 1) { for(size_t li = 0; li < acc.size(); li++) write_one(li); }
+            else {
+                std::atomic<size_t> nextLocus(0);
+                std::vector<std::thread> th;
+                for(size_t t = 0; t < par; t++) th.emplace_back([&]() { for(;;) { const size_t li = nextLocus.fetch_add(1); if(li >= acc.size()) break; write_one(li); } });
+                for(std::thread& t : th) t.join();
+            }
+            for(const std::string& e : ferr) if(!e.empty()) throw std::runtime_error(e);
+            for(size_t li = 0; li < acc.size(); li++) {
+                DIR* dd = opendir(tmpDir[li].c_str());
+                if(!dd) throw std::runtime_error("cannot open " + tmpDir[li]);
+                std::vector<std::string> ents;
+                while(dirent* e = readdir(dd)) { const std::string n = e->d_name; if(n != "." && n != "..") ents.push_back(n); }
+                closedir(dd);
+                for(const std::string& n : ents) {
+                    const std::string from = tmpDir[li] + "/" + n, to = outputDirectory + "/" + n;
+                    if(n == "R1_bestguess.txt" || n == "R1_bestguess_G.txt" || n == "histogram_matchesPerRead.txt") {
+                        std::ifstream in(from.c_str(), std::ios::binary); std::ofstream app(to.c_str(), std::ios::binary | std::ios::app);
+                        if(!in.is_open() || !app.is_open()) throw std::runtime_error("cannot append " + from + " to " + to);
+                        app << in.rdbuf();
+                        in.close(); ::unlink(from.c_str());
+                    } else if(::rename(from.c_str(), to.c_str()) != 0) throw std::runtime_error("cannot move " + from + " to " + to);
+                }
+                ::rmdir(tmpDir[li].c_str());
+                lociJoined += (lociJoined.empty() ? "" : ",") + acc[li].locus;
+            }
         }
         tchk(hlala_typer_end_output(outputDirectory.c_str(), lociJoined.c_str(), 0), "hlala_typer_end_output");
         timing.files = lap(tLap);

@@ -297,6 +297,9 @@ typedef struct {
     float   ms_side;              /* hlala_align_batch on a paired batch: span of the work it put on its second stream (wide / broad / large / in-memory
                                      class, second stitch and pairing pass over the pairs that own those calls), which runs beside the rest of the
                                      batch and beside the caller's next batch; 0 when the stages were called one by one                          */
+    int32_t n_dp_lane;            /* DP calls that entered the lane-per-DP class (64 calls per wavefront, one per lane: every item starts there); those it passes on
+                                     enter the 16-lane class (n_dp_class[0]); 0 when the class is switched off (HLALA_DP_LANE=0)                                 */
+    float   ms_dp_lane;           /* time of that class's kernel                                                                                              */
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 

@@ -312,3 +312,20 @@ def test_nodes_with_hundreds_of_edges_and_gap_path_jumps(pkg, oracle):
     lv = gb.chains(1)["col_level"].reshape(b["n_chains"], -1)
     for lo, hi in ((590, 620), (1190, 1360), (1840, 2010)):                 # alignments through the fan, the deletions that start together, those that end together
         assert ((lv >= lo) & (lv <= hi)).any(1).sum() > 30
+
+
+def test_lane_per_dp_class_is_bit_exact(pkg, oracle, monkeypatch):
+    """The lane-per-DP class (64 DP calls per wavefront, one per lane; hla-la_amd/csrc/kernel_dp_lane.hip) is switched off by default -- it is slower
+    than the 16-lane class it was meant to relieve -- but stays correct: with HLALA_DP_LANE=1 every DP call starts there, the calls it cannot finish exactly
+    (a node with more than two edges or a gap-path jump, wider frontiers) go on to the 16-lane class, and every output equals the oracle's, counters included."""
+    monkeypatch.setenv("HLALA_DP_LANE", "1")
+    for seed, G, k in ((1, 5000, 1), (2, 8000, 0), (3, 8000, 3)):
+        w = synth.make_world(seed=seed, G=G, k=k)
+        b = synth.make_batch(w, 300, seed=seed + 10)
+        exp, gb, ctx = run_both(pkg, oracle, w, b)
+        compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stage B (lane class)")
+        assert_pairs_equal(gb.pairs(), exp["pairs"])
+        st = gb.stats()
+        assert st.n_errors == 0 and st.n_dp_lane > 0 and st.n_dp_lane >= st.n_dp_class[0]
+        assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
+    assert st.n_dp_lane > st.n_dp_class[0]            # some calls finished in the lane class
