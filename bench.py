@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--single-batch", action="store_true", help="one resident batch, steps strictly one after the other (no overlap of a batch's tail with the next batch)")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region (host-inclusive, gene / backbone split, streaming, typer)")
     ap.add_argument("--host-steps", type=int, default=6, help="steps of the host-inclusive loop (0 = skip)")
-    ap.add_argument("--e2e-pairs", type=int, default=4_194_304, help="pairs of the sample pushed through `HLA-LA --action HLA` for the end-to-end rate (0 = skip)")
+    ap.add_argument("--e2e-pairs", type=int, default=8_388_608, help="pairs of the sample pushed through `HLA-LA --action HLA` for the end-to-end rate (0 = skip)")
     ap.add_argument("--e2e-frac-gene", type=float, default=0.04, help="share of the end-to-end sample drawn from the gene windows: 0.04 = the windows' share of the graph, i.e. the uniform "
                     "coverage of a whole-genome sample (the resident workload keeps 0.3: its gene-window pairs are the expensive ones; at 0.3 every typed locus would see 2000x coverage)")
     args = ap.parse_args()
@@ -220,20 +220,23 @@ def main():
         achieved = bpp * args.pairs / (dom_ms * 1e-3) / 1e9
         khash = kernel_source_hash()
         traffic, traffic_note, secondary = None, "no PMC pass on file for this build", {}
-        tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tfile):
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", t + "_traffic.json") for t in ("r03", "r02")) if os.path.exists(f)), "")
+        tname = os.path.relpath(tfile, ROOT) if tfile else ""
+        if tfile:
             try:
                 tj = json.load(open(tfile))
                 same = (tj.get("pairs") == args.pairs and tj.get("levels") == args.levels and tj.get("graph") == args.graph and tj.get("kernel") == names[dom])
                 if same and tj.get("kernel_source_hash") == khash:
-                    traffic = tj.get("hbm_bytes_per_launch"); traffic_note = f"profiles/r02_traffic.json (kernel sources {khash})"
+                    traffic = tj.get("hbm_bytes_per_launch"); traffic_note = f"{tname} (kernel sources {khash})"
                 elif same:
-                    traffic_note = f"profiles/r02_traffic.json was measured on kernel sources {tj.get('kernel_source_hash')}, this build is {khash}: dropped"
+                    traffic_note = f"{tname} was measured on kernel sources {tj.get('kernel_source_hash')}, this build is {khash}: dropped"
                 if same:
                     secondary = dict(tj.get("secondary", {})); secondary["measured_on_kernel_source_hash"] = tj.get("kernel_source_hash")
             except Exception:
                 pass
         secondary["dp_cells_per_s"] = st.n_dp_cells / (sum(cls_ms) * 1e-3)
+        if secondary.get("valu_insts_all_dp_classes_per_launch"):
+            secondary["valu_wave_insts_per_dp_cell"] = secondary["valu_insts_all_dp_classes_per_launch"] / max(1, st.n_dp_cells)
         out = {
             "metric": "paired reads/sec aligned to PRG graph", "value": value, "unit": "read pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -416,7 +416,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(hipEventCreateWithFlags(&c->evSideTail, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); }
     { int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);       // (numerically greatest = lowest priority)
-      if(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prLow) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); } }
+      int pr = prLow; if(const char* e = getenv("HLALA_SIDE_PRIORITY")) { if(!strcmp(e, "high")) pr = prHigh; else if(!strcmp(e, "normal")) pr = (prLow + prHigh) / 2; }      // (tools/gpu_side_prio.sh)
+      if(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, pr) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); } }
     if(hipStreamSynchronize(c->active) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
     *out = c;
     return HLALA_OK;

@@ -191,8 +191,8 @@ try {
     if(!path || !out || n_intervals < 0 || (n_intervals > 0 && !iv) || n_threads < 0) return HLALA_E_ARG;
     *out = nullptr; g_bam_error.clear();
     int T = n_threads;
-    if(T == 0) { T = (int)std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 64) T = 64; }
-    if(T > 255) T = 255;
+    if(T == 0) { T = (int)std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 128) T = 128; }
+    if(T > 1024) T = 1024;
     std::unique_ptr<hlala_seed_batch> S(new hlala_seed_batch());
     S->threads = T; S->unpaired = long_read_mode ? 1 : 0;
     auto tPhase = Clock::now();

@@ -61,6 +61,9 @@ constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows p
 #define HLALA_DP_TAIL_THREADS 128
 #endif
 constexpr int DP_TAIL_THREADS = HLALA_DP_TAIL_THREADS;
+#ifndef HLALA_DP_WIDE_THREADS
+#define HLALA_DP_WIDE_THREADS 64
+#endif
 #ifndef HLALA_DP_BROAD_THREADS
 #define HLALA_DP_BROAD_THREADS HLALA_DP_TAIL_THREADS
 #endif
@@ -75,7 +78,7 @@ struct DpMid   { static constexpr int THREADS = 64, WAVES = 4, GW = 32, WCAP = 3
 struct DpSmall { static constexpr int THREADS = 64, WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
 // but a quarter of its LDS, so that seven of them share a CU instead of one
-struct DpWide  { static constexpr int THREADS = 64, WAVES = 2, GW = 64, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpWide  { static constexpr int THREADS = HLALA_DP_WIDE_THREADS, WAVES = 2, GW = HLALA_DP_WIDE_THREADS, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 257 .. 512 cells with the table sizes of the large class (tens of thousands of kept cells): half the LDS of the large class, three per CU
 struct DpBroad { static constexpr int THREADS = HLALA_DP_BROAD_THREADS, WAVES = 1, GW = HLALA_DP_BROAD_THREADS, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and

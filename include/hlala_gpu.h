@@ -337,7 +337,7 @@ typedef struct {
 typedef struct hlala_seed_batch hlala_seed_batch;
 int  hlala_bam_extract_seeds(const char* bam_path, int32_t n_intervals, const hlala_bam_interval* intervals, int32_t long_read_mode,
                              hlala_seed_batch** out);
-/* The same with the number of decoding threads stated (0 = one per hardware thread, at most 64).  BGZF blocks are independent gzip
+/* The same with the number of decoding threads stated (0 = one per hardware thread, at most 128).  BGZF blocks are independent gzip
  * members: they are inflated, their records parsed and grouped by read name in parallel; one final sort puts the complete units into
  * read-name order (the reference's std::map order, mapper/processBAM.cpp:712, 2024-2039).  The result does not depend on the thread count. */
 int  hlala_bam_extract_seeds_mt(const char* bam_path, int32_t n_intervals, const hlala_bam_interval* intervals, int32_t long_read_mode,

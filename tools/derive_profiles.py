@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/r02_{stats,fetch,write,sq} (tools/gpu_profile_r02.sh) -> profiles/r02_*:
+"""gpurun_out/<tag>_{stats,fetch,write,sq} (tools/gpu_profile.sh <tag>) -> profiles/<tag>_* (tag = r02, r03, ...: `python tools/derive_profiles.py r03`):
   r02_kernel_stats_1Mpairs.csv   rocprofv3 --kernel-trace --stats summary (bench.py --steps 3 --warmup 1: 4 launches per kernel)
   r02_pmc_hbm_1Mpairs.csv        per kernel FETCH_SIZE / WRITE_SIZE (KB) and (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch -- FETCH_SIZE doubled
                                  for gfx950 as /opt/skills/guides/MI355X_MICROARCH.md prescribes, WRITE_SIZE uncalibrated; separate --pmc passes
@@ -11,6 +11,8 @@ import collections, csv, glob, json, os, shutil, sys
 
 sys.path.insert(0, os.getcwd())
 import bench  # noqa: E402
+
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 NAMES = (("DpTiny", "k_dp<DpTiny, 0>"), ("DpMid", "k_dp<DpMid, 1>"), ("DpSmall", "k_dp<DpSmall, 2>"), ("DpWide", "k_dp<DpWide, 3>"), ("DpBroad", "k_dp<DpBroad, 4>"), ("DpLarge", "k_dp<DpLarge, 5>"), ("DpHuge", "k_dp<DpHuge, 6>"),
          ("k_stitch", "k_stitch_chains"), ("k_project", "k_project_chains"), ("k_pair_chains", "k_pair_chains"), ("k_dp_items", "k_dp_items"), ("k_filter", "k_filter_chains"))
@@ -35,24 +37,24 @@ def counters(d):
 
 
 os.makedirs("profiles", exist_ok=True)
-st = sorted(glob.glob("gpurun_out/r02_stats/*/*kernel_stats.csv"), key=os.path.getmtime)[-1]
-shutil.copy(st, "profiles/r02_kernel_stats_1Mpairs.csv")
+st = sorted(glob.glob("gpurun_out/" + TAG + "_stats/*/*kernel_stats.csv"), key=os.path.getmtime)[-1]
+shutil.copy(st, "profiles/" + TAG + "_kernel_stats_1Mpairs.csv")
 avg_ms = {}
 for r in csv.DictReader(open(st)):
     n = label(r["Name"])
     if n:
         avg_ms[n] = float(r["AverageNs"]) / 1e6
-f, fl = counters("r02_fetch"); w, wl = counters("r02_write"); q, ql = counters("r02_sq")
+f, fl = counters(TAG + "_fetch"); w, wl = counters(TAG + "_write"); q, ql = counters(TAG + "_sq")
 rows = []
 for k in f:
     fk = f[k]["FETCH_SIZE"] / fl[k]; wk = w[k]["WRITE_SIZE"] / max(1, wl.get(k, 1))
     rows.append((k, fk, wk, (2 * fk + wk) * 1024))
-with open("profiles/r02_pmc_hbm_1Mpairs.csv", "w") as o:
+with open("profiles/" + TAG + "_pmc_hbm_1Mpairs.csv", "w") as o:
     o.write("kernel,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch_(2*FETCH+WRITE)*1024,avg_ms_rocprof\n")
     for r in sorted(rows, key=lambda r: -r[3]):
         o.write("%s,%.3f,%.3f,%.0f,%.3f\n" % (r + (avg_ms.get(r[0], 0.0),)))
 cn = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"]
-with open("profiles/r02_pmc_sq_1Mpairs.csv", "w") as o:
+with open("profiles/" + TAG + "_pmc_sq_1Mpairs.csv", "w") as o:
     o.write("kernel," + ",".join(c + "_per_launch" for c in cn) + ",wait_frac,active_frac\n")
     for k in sorted(q, key=lambda k: -q[k]["SQ_WAVE_CYCLES"]):
         v = [q[k][c] / ql[k] for c in cn]
@@ -66,9 +68,10 @@ args = dict(pairs=1048576, levels=5000000, graph="m")
 json.dump(dict(args, kernel=dom, kernel_source_hash=bench.kernel_source_hash(), fetch_size_kb=t[1], write_size_kb=t[2], hbm_bytes_per_launch=t[3], rocprof_avg_ms=avg_ms[dom],
                secondary={"wait_frac": qs["SQ_WAIT_ANY"] / qs["SQ_WAVE_CYCLES"], "active_frac": qs["SQ_ACTIVE_INST_ANY"] / qs["SQ_WAVE_CYCLES"],
                           "valu_insts_per_launch": qs["SQ_INSTS_VALU"], "salu_insts_per_launch": qs["SQ_INSTS_SALU"], "lds_insts_per_launch": qs["SQ_INSTS_LDS"],
-                          "source": "profiles/r02_pmc_sq_1Mpairs.csv (SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES of the dominant kernel)"},
+                          "valu_insts_all_dp_classes_per_launch": sum(q[k]["SQ_INSTS_VALU"] / ql[k] for k in q if k.startswith("k_dp<")),
+                          "source": "profiles/" + TAG + "_pmc_sq_1Mpairs.csv (SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES of the dominant kernel)"},
                note="(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes of `bench.py --steps 1 --warmup 0 --no-extras`; FETCH_SIZE doubled as "
-                    "MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE uncalibrated"), open("profiles/r02_traffic.json", "w"), indent=1)
+                    "MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE uncalibrated"), open("profiles/" + TAG + "_traffic.json", "w"), indent=1)
 print("dominant", dom, avg_ms[dom], "ms; hbm bytes/launch %.4g" % t[3])
 for r in sorted(rows, key=lambda r: -r[3]):
     print("%-20s %8.2f ms  %.4g bytes  wait %.2f" % (r[0], avg_ms.get(r[0], 0), r[3], q[r[0]]["SQ_WAIT_ANY"] / max(1.0, q[r[0]]["SQ_WAVE_CYCLES"])))
