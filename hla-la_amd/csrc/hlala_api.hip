@@ -380,7 +380,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
         if(hipMemsetAsync(*out, 0, bytes, c->active) != hipSuccess) { c->err = std::string("hipMemset(") + what + ") failed"; return HLALA_E_DEVICE; }
         return 0;
     };
-    c->tiny_grid = cus * 16;
+    c->tiny_grid = cus * 4 * DpTiny::WAVES;
     c->tiny_slab_bytes = dp_slab_bytes<DpTiny>();
     c->ext_grid = cus * 20;
     c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();

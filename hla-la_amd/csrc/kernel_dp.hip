@@ -61,6 +61,9 @@ constexpr int DP_BT_STEPS_PER_TRIP = 32;    // back pointers one group follows p
 #define HLALA_DP_TAIL_THREADS 128
 #endif
 constexpr int DP_TAIL_THREADS = HLALA_DP_TAIL_THREADS;
+#ifndef HLALA_DP_TINY_WAVES
+#define HLALA_DP_TINY_WAVES 4          // waves per SIMD the 16-lane kernel is compiled for (registers: 512 / waves)
+#endif
 #ifndef HLALA_DP_WIDE_THREADS
 #define HLALA_DP_WIDE_THREADS 64
 #endif
@@ -73,7 +76,7 @@ constexpr int DP_TAIL_THREADS = HLALA_DP_TAIL_THREADS;
 #ifndef HLALA_DP_HUGE_THREADS
 #define HLALA_DP_HUGE_THREADS HLALA_DP_TAIL_THREADS
 #endif
-struct DpTiny  { static constexpr int THREADS = 64, WAVES = 4, GW = 16, WCAP = 16,   HC = 32,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpTiny  { static constexpr int THREADS = 64, WAVES = HLALA_DP_TINY_WAVES, GW = 16, WCAP = 16,   HC = 32,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
 struct DpMid   { static constexpr int THREADS = 64, WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 struct DpSmall { static constexpr int THREADS = 64, WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
