@@ -85,11 +85,14 @@ struct Block { size_t coff; uint32_t clen, isize; uint64_t uoff; };      // comp
 // one kept alignment (per interval it falls into, as in the reference's loop :746-830)
 struct Rec {
     uint64_t hash, order;          // name hash; sequence number in the file (x 256 + interval rank): the order within a mate before sortChainsInSeeds
-    const uint8_t* aux;            // in the producing thread's arena: [CIGAR operations, 4 bytes each][name, NUL-terminated]
-    const uint8_t* seq;            // ... [bases][qualities] of a primary record
-    int32_t contig, pos, as, l_seq;
-    uint16_t n_cigar, nameLen; uint8_t which, flags, pad0, pad1;       // flags: 1 reverse, 2 primary
-    const char* name() const { return (const char*)aux + 4 * (size_t)n_cigar; }
+    const uint8_t* rec;            // the BAM record (after its length field) in the inflated data, which is kept until the sample is laid out: name, CIGAR, packed bases
+                                   // and qualities are read from there -- nothing is copied at parse time
+    int32_t contig, pos, as, l_seq;        // l_seq: 0 for non-primary records (their bases are never read)
+    uint16_t n_cigar, nameLen; uint8_t which, flags, l_read_name, pad1;       // flags: 1 reverse, 2 primary
+    const char* name() const { return (const char*)rec + 32; }
+    const uint8_t* cigar() const { return rec + 32 + l_read_name; }                       // 4 bytes per operation, little-endian, unaligned
+    const uint8_t* seq4() const { return cigar() + 4 * (size_t)n_cigar; }                 // 4-bit bases, two per byte
+    const uint8_t* qual(int32_t lseq) const { return seq4() + ((size_t)lseq + 1) / 2; }   // Phred values
 };
 // large allocations: page aligned, huge pages where the kernel grants them (first-touch page faults of multi-GB arrays otherwise cost more than the
 // copies that fill them), never cleared
@@ -106,20 +109,8 @@ uint8_t* big_alloc(size_t bytes)
 }
 struct BigFree { void operator()(uint8_t* p) const { free(p); } };
 
-// memory of one decoding thread: blocks that are never moved (records point into them); a request beyond the block size gets a block of its own
-struct Arena {
-    std::vector<std::unique_ptr<uint8_t, BigFree>> blocks; size_t left = 0; uint8_t* at = nullptr;
-    std::vector<std::vector<Rec>> part; int64_t examined = 0;
-    uint8_t* alloc(size_t n)
-    {
-        n = (n + 3) & ~(size_t)3;
-        constexpr size_t BLK = (size_t)16 << 20;
-        if(n > BLK / 4) { blocks.emplace_back(big_alloc(n)); return blocks.back().get(); }
-        if(n > left) { blocks.emplace_back(big_alloc(BLK)); at = blocks.back().get(); left = BLK; }
-        uint8_t* p = at; at += n; left -= n;
-        return p;
-    }
-};
+// what one decoding thread collects: its kept records by name partition
+struct Arena { std::vector<std::vector<Rec>> part; int64_t examined = 0; };
 
 // a big array of the result: allocated without being cleared (the threads that fill it are the first to touch its pages)
 template <class T>
@@ -232,38 +223,45 @@ try {
     // ---------------------------------------------------------------- inflate + parse, segment by segment
     std::unordered_map<std::string, std::vector<int>> intervalsOfRef;                     // interestingIntervals, processBAM.cpp:1226-1400
     for(int i = 0; i < n_intervals; i++) { if(!iv[i].ref_name || iv[i].stop_0based < iv[i].start_0based) throw Fail("bad interval"); intervalsOfRef[iv[i].ref_name].push_back(i); }
-    std::vector<Arena> arenas((size_t)T);
+    // the decoder's working memory (a dozen GB for a 10 M-pair sample) is released on a thread of its own after the result is handed over: unmapping it
+    // costs about a second that the caller need not wait for
+    struct Work { std::vector<Arena> arenas; std::vector<std::vector<Rec>> precs; std::vector<Unit> units; std::vector<int64_t> cigCount;
+                  std::vector<std::unique_ptr<uint8_t, BigFree>> inflated; };       // the inflated rounds: the records the Recs point into
+    std::unique_ptr<Work> W(new Work());
+    std::vector<Arena>& arenas = W->arenas; arenas.resize((size_t)T);
     for(Arena& a : arenas) a.part.resize(NPART);
     std::vector<std::vector<int>> refIntervals;          // per BAM reference id: the intervals it carries
     bool headerDone = false; int32_t n_ref = 0;
     // uncompressed bytes inflated and parsed per round (HLALA_BAM_SEGMENT_BYTES: the tests choose a few blocks per round to exercise records that
-    // straddle rounds; the reference dictionary must fit the first round)
-    size_t SEG_BYTES = (size_t)256 << 20;
+    // straddle rounds; the reference dictionary must fit the first round).  1 GiB per round: threads are started and joined twice per round
+    size_t SEG_BYTES = (size_t)1 << 30;
     if(const char* e = getenv("HLALA_BAM_SEGMENT_BYTES")) { const long long v = atoll(e); if(v >= 65536) SEG_BYTES = (size_t)v; }
-    std::vector<uint8_t> buf;                            // [carry-over of the previous segment | this segment's blocks]
-    size_t carry = 0; uint64_t recSeq = 0;
+    // a round's buffer = [bytes of the record that straddles the previous round | this round's blocks]; buffers are kept (records point into them)
+    const uint8_t* carryFrom = nullptr; size_t carry = 0; uint64_t recSeq = 0;
     double tInflate = 0, tParse = 0;
     static const char SEQ16[] = "=ACMGRSVTWYHKDBN";
     for(size_t b0 = 0; b0 < blocks.size();) {
         size_t b1 = b0; size_t segBytes = 0;
         while(b1 < blocks.size() && (segBytes == 0 || segBytes + blocks[b1].isize <= SEG_BYTES)) { segBytes += blocks[b1].isize; b1++; }
         auto t0 = Clock::now();
-        buf.resize(carry + segBytes);
+        W->inflated.emplace_back(big_alloc(carry + segBytes));
+        uint8_t* const bufp = W->inflated.back().get(); const size_t bufn = carry + segBytes;
+        if(carry) memcpy(bufp, carryFrom, carry);
         const uint64_t u0 = blocks[b0].uoff;
         parallel_for((int64_t)(b1 - b0), T, [&](int64_t k, int) {
             const Block& b = blocks[b0 + (size_t)k];
             z_stream zs; memset(&zs, 0, sizeof(zs));
             if(inflateInit2(&zs, -15) != Z_OK) throw Fail("inflateInit2 failed");
-            zs.next_in = (Bytef*)(mf.p + b.coff); zs.avail_in = b.clen; zs.next_out = buf.data() + carry + (size_t)(b.uoff - u0); zs.avail_out = b.isize;
+            zs.next_in = (Bytef*)(mf.p + b.coff); zs.avail_in = b.clen; zs.next_out = bufp + carry + (size_t)(b.uoff - u0); zs.avail_out = b.isize;
             const int rc = inflate(&zs, Z_FINISH); const uLong got = zs.total_out; inflateEnd(&zs);
             if(rc != Z_STREAM_END || got != b.isize) throw Fail("BGZF inflate failed");
         });
         tInflate += since(t0); t0 = Clock::now();
-        const uint8_t* d = buf.data(); const size_t dn = buf.size();
+        const uint8_t* d = bufp; const size_t dn = bufn;
         size_t o = 0;
         const bool lastSegment = b1 == blocks.size();
         if(!headerDone) {
-            // magic, header text, reference list (needs the whole header inside the first segment: 256 MB holds any reference dictionary)
+            // magic, header text, reference list (needs the whole header inside the first round: 1 GiB holds any reference dictionary)
             auto need = [&](size_t k) { if(dn - o < k) throw Fail("truncated BAM header"); };
             need(4); if(memcmp(d, "BAM\1", 4) != 0) throw Fail("not a BAM file"); o = 4;
             need(4); const int32_t l_text = (int32_t)rd32(d + o); o += 4; if(l_text < 0 || l_text > (1 << 30)) throw Fail("truncated BAM header");
@@ -311,7 +309,7 @@ try {
                 const std::vector<int>& ivs = refIntervals[(size_t)refID];
                 if(ivs.empty()) continue;                                                          // :744
                 int refLen = -1; int as = 0; bool haveAS = false, parsed = false;
-                const uint8_t* aux = nullptr; const uint8_t* seqp = nullptr; uint64_t hash = 0; size_t nameLen = 0;
+                uint64_t hash = 0; size_t nameLen = 0;
                 int rank = 0;
                 for(int ii : ivs) {
                     A.examined++;                                                                  // :757 (per interval, as in the reference)
@@ -348,20 +346,11 @@ try {
                         if(!haveAS) throw Fail("Can't get AS tag!");                               // assert(1 == 0), :4330-4332
                         nameLen = strnlen((const char*)rec + oName, l_read_name);
                         hash = hash_name(rec + oName, nameLen);
-                        { uint8_t* a = A.alloc(4 * (size_t)n_cigar + nameLen + 1); aux = a;
-                          for(unsigned k = 0; k < n_cigar; k++) { const uint32_t cg = rd32(rec + oCigar + 4 * k); memcpy(a + 4 * k, &cg, 4); }
-                          memcpy(a + 4 * (size_t)n_cigar, rec + oName, nameLen); a[4 * (size_t)n_cigar + nameLen] = 0; }
-                        if(primary) {                                                             // QueryBases / Qualities (BuildCharData: Phred + 33), alignment orientation
-                            uint8_t* bs = A.alloc(2 * (size_t)l_seq); uint8_t* qs = bs + l_seq; seqp = bs;
-                            for(int32_t i = 0; i + 1 < l_seq; i += 2) { const unsigned b = rec[oSeq + (size_t)i / 2]; bs[i] = (uint8_t)SEQ16[b >> 4]; bs[i + 1] = (uint8_t)SEQ16[b & 15]; }
-                            if(l_seq & 1) bs[l_seq - 1] = (uint8_t)SEQ16[rec[oSeq + (size_t)(l_seq - 1) / 2] >> 4];
-                            for(int32_t i = 0; i < l_seq; i++) qs[i] = (uint8_t)(rec[oQual + (size_t)i] + 33);
-                        }
                     }
                     Rec r; r.hash = hash; r.order = ((seq0 + ri) << 8) | (uint64_t)(rank < 255 ? rank : 255); rank++;
-                    r.aux = aux; r.seq = seqp; r.contig = iv[ii].contig; r.pos = position - iv[ii].start_0based; r.as = as; r.l_seq = primary ? l_seq : 0;
+                    r.rec = rec; r.contig = iv[ii].contig; r.pos = position - iv[ii].start_0based; r.as = as; r.l_seq = primary ? l_seq : 0;
                     r.n_cigar = (uint16_t)n_cigar; r.nameLen = (uint16_t)nameLen; r.which = (uint8_t)(long_read_mode ? 0 : ((flag & 64) ? 0 : 1));      // IsFirstMate() ? 1 : 2; long reads: 1 (:814-818)
-                    r.flags = (uint8_t)(((flag & 16) ? 1 : 0) | (primary ? 2 : 0)); r.pad0 = 0; r.pad1 = 0;
+                    r.flags = (uint8_t)(((flag & 16) ? 1 : 0) | (primary ? 2 : 0)); r.l_read_name = (uint8_t)l_read_name; r.pad1 = 0;
                     A.part[(size_t)(hash >> 56)].push_back(r);
                 }
             }
@@ -369,19 +358,17 @@ try {
         recSeq += nRec;
         if(recSeq >= (1ull << 55)) throw Fail("more BAM records than the sequence numbers hold");
         // bytes of a record that continues in the next segment move to the front
-        carry = dn - o;
-        if(carry) memmove(buf.data(), buf.data() + o, carry);
+        carry = dn - o; carryFrom = d + o;
         tParse += since(t0);
         b0 = b1;
     }
     if(!headerDone) throw Fail("not a BAM file");
-    { std::vector<uint8_t>().swap(buf); }
     S->seconds[1] = tInflate; S->seconds[2] = tParse;
     for(const Arena& a : arenas) S->examined += a.examined;
 
     // ---------------------------------------------------------------- group: every partition on its own
     tPhase = Clock::now();
-    std::vector<std::vector<Rec>> precs(NPART);           // records of a partition sorted by (hash, name, file order)
+    std::vector<std::vector<Rec>>& precs = W->precs; precs.resize(NPART);       // records of a partition sorted by (hash, name, file order)
     std::vector<std::vector<Unit>> punits(NPART);         // all units of the partition (complete or not)
     std::vector<int64_t> pIncomplete(NPART, 0);
     auto rec_name = [&](const Rec& r) { return r.name(); };
@@ -411,7 +398,7 @@ try {
             i = j;
         }
     });
-    std::vector<Unit> units;
+    std::vector<Unit>& units = W->units;
     { size_t n = 0; for(auto& u : punits) n += u.size(); units.reserve(n); for(auto& u : punits) { units.insert(units.end(), u.begin(), u.end()); std::vector<Unit>().swap(u); } }
     for(int p = 0; p < NPART; p++) S->n_incomplete += pIncomplete[(size_t)p];
     S->n_seeds = (int64_t)units.size() + S->n_incomplete;
@@ -458,7 +445,7 @@ try {
     S->read_primary.assign(nR, 0);
     // sizes per read: bases, chains, cigar operations; the primary of a mate is only known after its sort, so the alignments of every mate are
     // ordered here once (kept as record indices) and reused by the fill pass
-    std::vector<int64_t> cigCount(nR + 1, 0);
+    std::vector<int64_t>& cigCount = W->cigCount; cigCount.assign(nR + 1, 0);
     std::vector<std::vector<uint32_t>> order((size_t)T);
     const int64_t UCH = std::max<int64_t>(16, std::min<int64_t>(8192, (int64_t)nU / ((int64_t)T * 8) + 1)); const int64_t nUChunks = ((int64_t)nU + UCH - 1) / UCH;
     // sortChainsInSeeds (:1952-1961) on the mate's alignments in file order; returns the position of the first primary (read*_getPrimaryAlignmentI)
@@ -503,21 +490,26 @@ try {
                 const size_t prim = sorted_mate(u, m, idx);
                 const size_t r = ui * (size_t)nm + (size_t)m;
                 const Rec& pa = R[idx[prim]];
-                const uint8_t* sq = pa.seq;
-                memcpy(S->read_bases.data() + S->read_off[r], sq, (size_t)pa.l_seq);                // QueryBases / Qualities of the primary, alignment orientation (:3142-3145)
-                memcpy(S->read_quals.data() + S->read_off[r], sq + pa.l_seq, (size_t)pa.l_seq);
+                {   // QueryBases / Qualities of the primary (BuildCharData: 4-bit codes -> characters, Phred + 33), alignment orientation (:3142-3145)
+                    const int32_t ls = pa.l_seq; const uint8_t* s4 = pa.seq4(); const uint8_t* ql = pa.qual(ls);
+                    uint8_t* bs = S->read_bases.data() + S->read_off[r]; uint8_t* qs = S->read_quals.data() + S->read_off[r];
+                    for(int32_t i = 0; i + 1 < ls; i += 2) { const unsigned b = s4[(size_t)i / 2]; bs[i] = (uint8_t)SEQ16[b >> 4]; bs[i + 1] = (uint8_t)SEQ16[b & 15]; }
+                    if(ls & 1) bs[ls - 1] = (uint8_t)SEQ16[s4[(size_t)(ls - 1) / 2] >> 4];
+                    for(int32_t i = 0; i < ls; i++) qs[i] = (uint8_t)(ql[i] + 33);
+                }
                 size_t ch = (size_t)S->chain_off[r]; int64_t cg = cigCount[r];
                 S->read_primary[r] = (int32_t)(ch + prim);
                 for(uint32_t k : idx) {
                     const Rec& x = R[k];
                     S->chain_contig[ch] = x.contig; S->chain_pos[ch] = x.pos; S->chain_offset[ch] = 0; S->chain_as[ch] = x.as; S->chain_reverse[ch] = (uint8_t)(x.flags & 1);
-                    memcpy(S->cigar.data() + cg, x.aux, 4 * (size_t)x.n_cigar);
+                    memcpy(S->cigar.data() + cg, x.cigar(), 4 * (size_t)x.n_cigar);               // (BAM is little-endian like every host this library runs on)
                     cg += x.n_cigar; S->cigar_off[ch + 1] = cg; ch++;
                 }
             }
         }
     });
     S->seconds[5] = since(tPhase);
+    { Work* w = W.release(); try { std::thread([w]() { delete w; }).detach(); } catch(...) { delete w; } }
     *out = S.release();
     return HLALA_OK;
 } catch(const std::exception& e_) { g_bam_error = dynamic_cast<const Fail*>(&e_) ? std::string(e_.what()) : std::string("hlala_bam_extract_seeds: ") + e_.what(); return HLALA_E_ARG; }
