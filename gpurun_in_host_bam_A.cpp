@@ -1,0 +1,570 @@
+// host_bam.cpp -- BAM reader + seed extraction: the records of a bwa-mem BAM that fall into the PRG intervals become the
+// pairs / chains of an hlala_batch_in.  Sized for a whole sample (BASELINE config 3: ~10 M pairs, ~60 M records, > 2^31 read bases):
+// 64-bit offsets, every phase parallel.
+//
+// Reference: processBAM::extractSeeds2 (mapper/processBAM.cpp:703-864), reads::protoSeeds::takeAlignment / isComplete
+// (mapper/reads/protoSeeds.cpp:23-36, 371-380), sortChainsInSeeds (:1945-1967), getAlignmentScore (:4314-4334: the AS tag), the order of
+// completeProtoSeeds (std::map over read names, :2024-2039).  BamTools (un-vendored, "tested with 2.5.1", makefile:3-12) is replaced by
+// a direct reading of the BAM format (SAM/BAM specification v1: BGZF blocks = gzip members with a BC extra field, little-endian records).
+//   * a record is used if it is mapped, (long-read mode: primary,) its reference carries intervals, it has CIGAR operations, and both its
+//     start and its end (Position + reference-consuming length - 1 = GetEndPosition(false, true)) lie inside an interval (:763-768);
+//   * positions are re-based to the interval start (the reference passes the interval start as reference2level_offset_0based and indexes
+//     the translation with position - offset; here chain_pos = position - start and chain_offset = 0, the contig is the interval);
+//   * std::sort + std::reverse on the alignment scores is the reference's own call (:1952-1961): equal scores keep the library's order,
+//     so the alignments of a mate are collected in FILE order first (every kept record carries its sequence number).
+//
+// Phases (wall clock of each in hlala_seed_batch_timing):
+//   index   the file is mapped and the BGZF block headers are walked (block boundaries are only known sequentially; ~16 bytes per 64 KB)
+//   inflate blocks are independent gzip members: a segment of consecutive blocks is inflated by all threads into one buffer
+//   parse   record boundaries of the segment are found by hopping over the 4-byte length fields, then ranges of records are parsed in
+//           parallel: filters, CIGAR, AS tag, name hash; bases / qualities are unpacked for primary records only (the only ones the path
+//           reads, processBAM.cpp:3142-3145); kept records go to one of 256 partitions by name hash
+//   group   every partition is grouped by read name on its own (sort by hash, names compared within equal hashes)
+//   sort    the complete units of all partitions are put into read-name order by a parallel sample sort (byte-wise comparison then
+//           length = std::string's operator<, the order of the reference's std::map)
+//   layout  prefix sums over the units, then the output arrays are filled in parallel
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include "../../include/hlala_gpu.h"
+#include "host_internal.h"
+
+namespace {
+
+thread_local std::string g_bam_error;
+
+typedef std::chrono::steady_clock Clock;
+double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+// run fn(task) for task in [0, n) on up to T threads (dynamic distribution); the first exception is rethrown on the caller's thread
+template <class F>
+void parallel_for(int64_t n, int T, F fn)
+{
+    if(n <= 0) return;
+    if(T > n) T = (int)n;
+    if(T <= 1) { for(int64_t i = 0; i < n; i++) fn(i, 0); return; }
+    std::atomic<int64_t> next(0);
+    std::exception_ptr err; std::mutex em;
+    std::vector<std::thread> th;
+    for(int t = 0; t < T; t++) th.emplace_back([&, t]() {
+        try { for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
+        catch(...) { std::lock_guard<std::mutex> g(em); if(!err) err = std::current_exception(); next.store(n); }
+    });
+    for(auto& x : th) x.join();
+    if(err) std::rethrow_exception(err);
+}
+
+struct Fail : std::runtime_error { using std::runtime_error::runtime_error; };
+
+uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// ---- the mapped file (owning: released on every path out of the extraction)
+struct MappedFile {
+    int fd = -1; const uint8_t* p = nullptr; size_t n = 0;
+    ~MappedFile() { if(p && n) munmap((void*)p, n); if(fd >= 0) close(fd); }
+};
+
+struct Block { size_t coff; uint32_t clen, isize; uint64_t uoff; };      // compressed payload at coff (clen bytes), uncompressed isize bytes at uoff of the stream
+
+// one kept alignment (per interval it falls into, as in the reference's loop :746-830)
+struct Rec {
+    uint64_t hash, order;          // name hash; sequence number in the file (x 256 + interval rank): the order within a mate before sortChainsInSeeds
+    const uint8_t* aux;            // in the producing thread's arena: [CIGAR operations, 4 bytes each][name, NUL-terminated]
+    const uint8_t* seq;            // ... [bases][qualities] of a primary record
+    int32_t contig, pos, as, l_seq;
+    uint16_t n_cigar, nameLen; uint8_t which, flags, pad0, pad1;       // flags: 1 reverse, 2 primary
+    const char* name() const { return (const char*)aux + 4 * (size_t)n_cigar; }
+};
+// large allocations: page aligned, huge pages where the kernel grants them (first-touch page faults of multi-GB arrays otherwise cost more than the
+// copies that fill them), never cleared
+uint8_t* big_alloc(size_t bytes)
+{
+    constexpr size_t HUGE = (size_t)2 << 20;
+    void* p = nullptr;
+    if(bytes >= HUGE) {
+        if(posix_memalign(&p, HUGE, (bytes + HUGE - 1) & ~(HUGE - 1)) != 0) p = nullptr;
+        if(p) (void)madvise(p, (bytes + HUGE - 1) & ~(HUGE - 1), MADV_HUGEPAGE);
+    } else p = malloc(bytes ? bytes : 1);
+    if(!p) throw std::bad_alloc();
+    return (uint8_t*)p;
+}
+struct BigFree { void operator()(uint8_t* p) const { free(p); } };
+
+// memory of one decoding thread: blocks that are never moved (records point into them); a request beyond the block size gets a block of its own
+struct Arena {
+    std::vector<std::unique_ptr<uint8_t, BigFree>> blocks; size_t left = 0; uint8_t* at = nullptr;
+    std::vector<std::vector<Rec>> part; int64_t examined = 0;
+    uint8_t* alloc(size_t n)
+    {
+        n = (n + 3) & ~(size_t)3;
+        constexpr size_t BLK = (size_t)16 << 20;
+        if(n > BLK / 4) { blocks.emplace_back(big_alloc(n)); return blocks.back().get(); }
+        if(n > left) { blocks.emplace_back(big_alloc(BLK)); at = blocks.back().get(); left = BLK; }
+        uint8_t* p = at; at += n; left -= n;
+        return p;
+    }
+};
+
+// a big array of the result: allocated without being cleared (the threads that fill it are the first to touch its pages)
+template <class T>
+struct Buf {
+    T* p = nullptr; size_t n = 0;
+    Buf() {}
+    ~Buf() { free(p); }
+    Buf(const Buf&) = delete; Buf& operator=(const Buf&) = delete;
+    void alloc(size_t k) { free(p); p = nullptr; n = 0; if(k) { p = (T*)big_alloc(k * sizeof(T)); n = k; } }
+    T* data() { return p; } const T* data() const { return p; } size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; }
+};
+
+constexpr int NPART = 256;
+
+uint64_t hash_name(const uint8_t* s, size_t n)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    for(size_t i = 0; i < n; i++) { h ^= s[i]; h *= 0x100000001b3ull; }
+    h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
+    return h;
+}
+
+struct Unit { const char* name; uint32_t nameLen; uint32_t part; uint32_t first, count; };      // recs [first, first + count) of the partition's sorted record list
+
+bool name_less(const Unit& a, const Unit& b)
+{
+    const size_t n = a.nameLen < b.nameLen ? a.nameLen : b.nameLen;
+    const int c = memcmp(a.name, b.name, n);
+    return c != 0 ? c < 0 : a.nameLen < b.nameLen;
+}
+
+}  // namespace
+
+struct hlala_seed_batch {
+    std::vector<int64_t> read_off, chain_off;
+    Buf<int64_t> cigar_off;
+    std::vector<int32_t> read_primary;
+    Buf<int32_t> chain_contig, chain_pos, chain_offset, chain_as;
+    Buf<uint8_t> read_bases, read_quals, chain_reverse; Buf<uint32_t> cigar;
+    Buf<char> name_chars; std::vector<int64_t> name_off;          // names of the units, NUL-terminated
+    int64_t n_units = 0; int32_t unpaired = 0; int64_t examined = 0, n_seeds = 0, n_incomplete = 0;
+    double seconds[6] = {0, 0, 0, 0, 0, 0}; int32_t threads = 1;
+    bool pinned = false;
+};
+
+namespace hlala_host {
+void seed_batch_bulk_arrays(hlala_seed_batch* S, std::vector<std::pair<void*, size_t>>& out)
+{
+    out.clear();
+    auto add = [&](void* p, size_t b) { if(p && b) out.emplace_back(p, b); };
+    add(S->read_bases.data(), S->read_bases.size()); add(S->read_quals.data(), S->read_quals.size());
+    add(S->chain_contig.data(), S->chain_contig.size() * 4); add(S->chain_pos.data(), S->chain_pos.size() * 4); add(S->chain_offset.data(), S->chain_offset.size() * 4);
+    add(S->chain_as.data(), S->chain_as.size() * 4); add(S->chain_reverse.data(), S->chain_reverse.size()); add(S->cigar.data(), S->cigar.size() * 4);
+}
+bool& seed_batch_pinned_flag(hlala_seed_batch* S) { return S->pinned; }
+void (*g_seed_batch_unpin)(hlala_seed_batch*) = nullptr;       // set by the GPU library (hlala_seed_batch_pin): a pinned batch is unpinned before it is freed
+}  // namespace hlala_host
+
+extern "C" const char* hlala_bam_last_error() { return g_bam_error.c_str(); }
+
+extern "C" int hlala_bam_extract_seeds(const char* path, int32_t n_intervals, const hlala_bam_interval* iv, int32_t long_read_mode, hlala_seed_batch** out)
+{
+    return hlala_bam_extract_seeds_mt(path, n_intervals, iv, long_read_mode, 0, out);
+}
+
+extern "C" int hlala_bam_extract_seeds_mt(const char* path, int32_t n_intervals, const hlala_bam_interval* iv, int32_t long_read_mode, int32_t n_threads, hlala_seed_batch** out)
+try {
+    if(!path || !out || n_intervals < 0 || (n_intervals > 0 && !iv) || n_threads < 0) return HLALA_E_ARG;
+    *out = nullptr; g_bam_error.clear();
+    int T = n_threads;
+    if(T == 0) { T = (int)std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 128) T = 128; }
+    if(T > 1024) T = 1024;
+    std::unique_ptr<hlala_seed_batch> S(new hlala_seed_batch());
+    S->threads = T; S->unpaired = long_read_mode ? 1 : 0;
+    auto tPhase = Clock::now();
+
+    // ---------------------------------------------------------------- index: map the file, walk the block headers
+    MappedFile mf;
+    mf.fd = open(path, O_RDONLY);
+    if(mf.fd < 0) throw Fail(std::string("Cannot open BAM file: ") + path);
+    { struct stat st; if(fstat(mf.fd, &st) != 0) throw Fail("Cannot stat BAM file"); mf.n = (size_t)st.st_size; }
+    if(mf.n == 0) throw Fail("not a BAM file");
+    mf.p = (const uint8_t*)mmap(nullptr, mf.n, PROT_READ, MAP_PRIVATE, mf.fd, 0);
+    if(mf.p == MAP_FAILED) { mf.p = nullptr; throw Fail("Cannot map BAM file"); }
+    (void)madvise((void*)mf.p, mf.n, MADV_SEQUENTIAL);
+    std::vector<Block> blocks;
+    {
+        size_t o = 0; uint64_t u = 0;
+        while(o < mf.n) {
+            if(mf.n - o < 18) throw Fail("truncated BGZF header");
+            const uint8_t* h = mf.p + o;
+            if(h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw Fail("not a BGZF block");
+            const size_t xlen = h[10] | (h[11] << 8);
+            if(mf.n - o < 12 + xlen) throw Fail("truncated BGZF header");
+            // the BC subfield holds the block size - 1; it is the first subfield in every BGZF writer, but walk the extra field anyway
+            long bsize = -1;
+            for(size_t p = 0; p + 4 <= xlen;) { const uint8_t* e = h + 12 + p; const size_t sl = e[2] | (e[3] << 8); if(e[0] == 66 && e[1] == 67 && sl == 2 && p + 6 <= xlen) bsize = e[4] | (e[5] << 8); p += 4 + sl; }
+            if(bsize < 0) throw Fail("BGZF block without BC field");
+            if((size_t)bsize + 1 < 12 + xlen + 8) throw Fail("BGZF block size smaller than its own header");
+            if(mf.n - o < (size_t)bsize + 1) throw Fail("truncated BGZF block");
+            Block b; b.coff = o + 12 + xlen; b.clen = (uint32_t)((size_t)bsize + 1 - 12 - xlen - 8); b.isize = rd32(h + bsize + 1 - 4); b.uoff = u;
+            if(b.isize > (1u << 16)) throw Fail("BGZF block with more than 64 KiB of payload");
+            if(b.isize) blocks.push_back(b);                              // (empty blocks: the end-of-file marker)
+            u += b.isize; o += (size_t)bsize + 1;
+        }
+    }
+    S->seconds[0] = since(tPhase);
+
+    // ---------------------------------------------------------------- inflate + parse, segment by segment
+    std::unordered_map<std::string, std::vector<int>> intervalsOfRef;                     // interestingIntervals, processBAM.cpp:1226-1400
+    for(int i = 0; i < n_intervals; i++) { if(!iv[i].ref_name || iv[i].stop_0based < iv[i].start_0based) throw Fail("bad interval"); intervalsOfRef[iv[i].ref_name].push_back(i); }
+    std::vector<Arena> arenas((size_t)T);
+    for(Arena& a : arenas) a.part.resize(NPART);
+    std::vector<std::vector<int>> refIntervals;          // per BAM reference id: the intervals it carries
+    bool headerDone = false; int32_t n_ref = 0;
+    // uncompressed bytes inflated and parsed per round (HLALA_BAM_SEGMENT_BYTES: the tests choose a few blocks per round to exercise records that
+    // straddle rounds; the reference dictionary must fit the first round)
+    size_t SEG_BYTES = (size_t)256 << 20;
+    if(const char* e = getenv("HLALA_BAM_SEGMENT_BYTES")) { const long long v = atoll(e); if(v >= 65536) SEG_BYTES = (size_t)v; }
+    std::vector<uint8_t> buf;                            // [carry-over of the previous segment | this segment's blocks]
+    size_t carry = 0; uint64_t recSeq = 0;
+    double tInflate = 0, tParse = 0;
+    static const char SEQ16[] = "=ACMGRSVTWYHKDBN";
+    for(size_t b0 = 0; b0 < blocks.size();) {
+        size_t b1 = b0; size_t segBytes = 0;
+        while(b1 < blocks.size() && (segBytes == 0 || segBytes + blocks[b1].isize <= SEG_BYTES)) { segBytes += blocks[b1].isize; b1++; }
+        auto t0 = Clock::now();
+        buf.resize(carry + segBytes);
+        const uint64_t u0 = blocks[b0].uoff;
+        parallel_for((int64_t)(b1 - b0), T, [&](int64_t k, int) {
+            const Block& b = blocks[b0 + (size_t)k];
+            z_stream zs; memset(&zs, 0, sizeof(zs));
+            if(inflateInit2(&zs, -15) != Z_OK) throw Fail("inflateInit2 failed");
+            zs.next_in = (Bytef*)(mf.p + b.coff); zs.avail_in = b.clen; zs.next_out = buf.data() + carry + (size_t)(b.uoff - u0); zs.avail_out = b.isize;
+            const int rc = inflate(&zs, Z_FINISH); const uLong got = zs.total_out; inflateEnd(&zs);
+            if(rc != Z_STREAM_END || got != b.isize) throw Fail("BGZF inflate failed");
+        });
+        tInflate += since(t0); t0 = Clock::now();
+        const uint8_t* d = buf.data(); const size_t dn = buf.size();
+        size_t o = 0;
+        const bool lastSegment = b1 == blocks.size();
+        if(!headerDone) {
+            // magic, header text, reference list (needs the whole header inside the first segment: 256 MB holds any reference dictionary)
+            auto need = [&](size_t k) { if(dn - o < k) throw Fail("truncated BAM header"); };
+            need(4); if(memcmp(d, "BAM\1", 4) != 0) throw Fail("not a BAM file"); o = 4;
+            need(4); const int32_t l_text = (int32_t)rd32(d + o); o += 4; if(l_text < 0 || l_text > (1 << 30)) throw Fail("truncated BAM header");
+            need((size_t)l_text); o += (size_t)l_text;
+            need(4); n_ref = (int32_t)rd32(d + o); o += 4; if(n_ref < 0) throw Fail("truncated BAM header");
+            refIntervals.resize((size_t)n_ref);
+            for(int i = 0; i < n_ref; i++) {
+                if(dn - o < 4) throw Fail("truncated BAM reference list");
+                const int32_t l_name = (int32_t)rd32(d + o); o += 4;
+                if(l_name < 1 || l_name > (1 << 20) || dn - o < (size_t)l_name + 4) throw Fail("truncated BAM reference list");
+                const std::string nm((const char*)d + o, strnlen((const char*)d + o, (size_t)l_name));
+                o += (size_t)l_name + 4;
+                auto it = intervalsOfRef.find(nm);
+                if(it != intervalsOfRef.end()) refIntervals[(size_t)i] = it->second;
+            }
+            headerDone = true;
+        }
+        // record boundaries: hop over the length fields
+        std::vector<size_t> recStart;
+        recStart.reserve((dn - o) / 200 + 16);
+        while(dn - o >= 4) {
+            const int32_t bs = (int32_t)rd32(d + o);
+            if(bs < 32 || bs > (1 << 28)) throw Fail("truncated BAM record");
+            if(dn - o - 4 < (size_t)bs) break;
+            recStart.push_back(o); o += 4 + (size_t)bs;
+        }
+        if(lastSegment && o != dn) throw Fail("truncated BAM record");
+        const size_t nRec = recStart.size();
+        const int64_t CH = std::max<int64_t>(16, std::min<int64_t>(4096, (int64_t)nRec / ((int64_t)T * 8) + 1)); const int64_t nTasks = ((int64_t)nRec + CH - 1) / CH;      // (long reads: few, large records per round)
+        const uint64_t seq0 = recSeq;
+        parallel_for(nTasks, T, [&](int64_t task, int t) {
+            Arena& A = arenas[(size_t)t];
+            const size_t r0 = (size_t)(task * CH), r1 = std::min(nRec, r0 + (size_t)CH);
+            for(size_t ri = r0; ri < r1; ri++) {
+                const uint8_t* rec = d + recStart[ri] + 4; const size_t rn = (size_t)rd32(d + recStart[ri]);
+                const int32_t refID = (int32_t)rd32(rec), position = (int32_t)rd32(rec + 4);
+                const unsigned l_read_name = rec[8]; const unsigned n_cigar = rec[12] | (rec[13] << 8); const unsigned flag = rec[14] | (rec[15] << 8);
+                const int32_t l_seq = (int32_t)rd32(rec + 16);
+                if(l_seq < 0) throw Fail("corrupt BAM record");
+                const size_t oName = 32, oCigar = oName + l_read_name, oSeq = oCigar + 4 * (size_t)n_cigar, oQual = oSeq + ((size_t)l_seq + 1) / 2, oTags = oQual + (size_t)l_seq;
+                if(oTags > rn || l_read_name < 1) throw Fail("corrupt BAM record");
+                if(flag & 4) continue;                                                             // ! IsMapped(), :727
+                if(long_read_mode && (flag & 256)) continue;                                       // ! IsPrimaryAlignment(), :732-738 (BamTools 2.5.1: !(AlignmentFlag & 0x100))
+                if(refID < 0 || refID >= n_ref) continue;
+                const std::vector<int>& ivs = refIntervals[(size_t)refID];
+                if(ivs.empty()) continue;                                                          // :744
+                int refLen = -1; int as = 0; bool haveAS = false, parsed = false;
+                const uint8_t* aux = nullptr; const uint8_t* seqp = nullptr; uint64_t hash = 0; size_t nameLen = 0;
+                int rank = 0;
+                for(int ii : ivs) {
+                    A.examined++;                                                                  // :757 (per interval, as in the reference)
+                    if(n_cigar == 0) continue;                                                     // :759-763
+                    if(refLen < 0) { refLen = 0; for(unsigned k = 0; k < n_cigar; k++) { const uint32_t c = rd32(rec + oCigar + 4 * k); const unsigned op = c & 15u; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) refLen += (int)(c >> 4); } }
+                    const int start = position, stop = position + refLen - 1;                      // GetEndPosition(false, true), :766
+                    if(!((start >= iv[ii].start_0based && start <= iv[ii].stop_0based) && (stop >= iv[ii].start_0based && stop <= iv[ii].stop_0based))) continue;
+                    if(!long_read_mode && !(flag & 1)) throw Fail("unpaired record in a paired-end BAM (assert(currentAlignment.IsPaired()), processBAM.cpp:783)");
+                    const bool primary = !(flag & 256);                                            // BamTools IsPrimaryAlignment: !(flag & 0x100)
+                    if(!parsed) {
+                        parsed = true;
+                        // the AS tag (getAlignmentScore, :4314-4334): any integer type
+                        for(size_t p = oTags; p + 3 <= rn;) {
+                            const char t0 = (char)rec[p], t1 = (char)rec[p + 1], ty = (char)rec[p + 2]; p += 3;
+                            size_t sz = 0; long long v = 0; bool isInt = true;
+                            switch(ty) {
+                                case 'c': sz = 1; if(p + 1 <= rn) v = (int8_t)rec[p]; break;
+                                case 'C': sz = 1; if(p + 1 <= rn) v = rec[p]; break;
+                                case 's': sz = 2; if(p + 2 <= rn) v = (int16_t)(rec[p] | (rec[p + 1] << 8)); break;
+                                case 'S': sz = 2; if(p + 2 <= rn) v = (uint16_t)(rec[p] | (rec[p + 1] << 8)); break;
+                                case 'i': sz = 4; if(p + 4 <= rn) v = (int32_t)rd32(rec + p); break;
+                                case 'I': sz = 4; if(p + 4 <= rn) v = rd32(rec + p); break;
+                                case 'A': sz = 1; isInt = false; break;
+                                case 'f': sz = 4; isInt = false; break;
+                                case 'Z': case 'H': { isInt = false; size_t q = p; while(q < rn && rec[q]) q++; sz = q - p + 1; break; }
+                                case 'B': { isInt = false; if(p + 5 > rn) throw Fail("corrupt BAM tag"); const char et = (char)rec[p]; const uint32_t cnt = rd32(rec + p + 1);
+                                            const size_t es = (et == 'c' || et == 'C') ? 1 : (et == 's' || et == 'S') ? 2 : 4; sz = 5 + es * (size_t)cnt; break; }
+                                default: throw Fail("unknown BAM tag type");
+                            }
+                            if(p + sz > rn) throw Fail("corrupt BAM tag");
+                            if(t0 == 'A' && t1 == 'S' && isInt) { as = (int)v; haveAS = true; }
+                            p += sz;
+                        }
+                        if(!haveAS) throw Fail("Can't get AS tag!");                               // assert(1 == 0), :4330-4332
+                        nameLen = strnlen((const char*)rec + oName, l_read_name);
+                        hash = hash_name(rec + oName, nameLen);
+                        { uint8_t* a = A.alloc(4 * (size_t)n_cigar + nameLen + 1); aux = a;
+                          for(unsigned k = 0; k < n_cigar; k++) { const uint32_t cg = rd32(rec + oCigar + 4 * k); memcpy(a + 4 * k, &cg, 4); }
+                          memcpy(a + 4 * (size_t)n_cigar, rec + oName, nameLen); a[4 * (size_t)n_cigar + nameLen] = 0; }
+                        if(primary) {                                                             // QueryBases / Qualities (BuildCharData: Phred + 33), alignment orientation
+                            uint8_t* bs = A.alloc(2 * (size_t)l_seq); uint8_t* qs = bs + l_seq; seqp = bs;
+                            for(int32_t i = 0; i + 1 < l_seq; i += 2) { const unsigned b = rec[oSeq + (size_t)i / 2]; bs[i] = (uint8_t)SEQ16[b >> 4]; bs[i + 1] = (uint8_t)SEQ16[b & 15]; }
+                            if(l_seq & 1) bs[l_seq - 1] = (uint8_t)SEQ16[rec[oSeq + (size_t)(l_seq - 1) / 2] >> 4];
+                            for(int32_t i = 0; i < l_seq; i++) qs[i] = (uint8_t)(rec[oQual + (size_t)i] + 33);
+                        }
+                    }
+                    Rec r; r.hash = hash; r.order = ((seq0 + ri) << 8) | (uint64_t)(rank < 255 ? rank : 255); rank++;
+                    r.aux = aux; r.seq = seqp; r.contig = iv[ii].contig; r.pos = position - iv[ii].start_0based; r.as = as; r.l_seq = primary ? l_seq : 0;
+                    r.n_cigar = (uint16_t)n_cigar; r.nameLen = (uint16_t)nameLen; r.which = (uint8_t)(long_read_mode ? 0 : ((flag & 64) ? 0 : 1));      // IsFirstMate() ? 1 : 2; long reads: 1 (:814-818)
+                    r.flags = (uint8_t)(((flag & 16) ? 1 : 0) | (primary ? 2 : 0)); r.pad0 = 0; r.pad1 = 0;
+                    A.part[(size_t)(hash >> 56)].push_back(r);
+                }
+            }
+        });
+        recSeq += nRec;
+        if(recSeq >= (1ull << 55)) throw Fail("more BAM records than the sequence numbers hold");
+        // bytes of a record that continues in the next segment move to the front
+        carry = dn - o;
+        if(carry) memmove(buf.data(), buf.data() + o, carry);
+        tParse += since(t0);
+        b0 = b1;
+    }
+    if(!headerDone) throw Fail("not a BAM file");
+    { std::vector<uint8_t>().swap(buf); }
+    S->seconds[1] = tInflate; S->seconds[2] = tParse;
+    for(const Arena& a : arenas) S->examined += a.examined;
+
+    // ---------------------------------------------------------------- group: every partition on its own
+    tPhase = Clock::now();
+    std::vector<std::vector<Rec>> precs(NPART);           // records of a partition sorted by (hash, name, file order)
+    std::vector<std::vector<Unit>> punits(NPART);         // all units of the partition (complete or not)
+    std::vector<int64_t> pIncomplete(NPART, 0);
+    auto rec_name = [&](const Rec& r) { return r.name(); };
+    parallel_for(NPART, T, [&](int64_t p, int) {
+        std::vector<Rec>& R = precs[(size_t)p];
+        size_t n = 0; for(const Arena& a : arenas) n += a.part[(size_t)p].size();
+        if(n > 0xFFFFFFFFull) throw Fail("BAM too large: more than 2^32 records in one name partition");
+        R.reserve(n);
+        for(Arena& a : arenas) { std::vector<Rec>& v = a.part[(size_t)p]; R.insert(R.end(), v.begin(), v.end()); std::vector<Rec>().swap(v); }
+        std::sort(R.begin(), R.end(), [&](const Rec& a, const Rec& b) {
+            if(a.hash != b.hash) return a.hash < b.hash;
+            if(a.nameLen != b.nameLen || memcmp(rec_name(a), rec_name(b), a.nameLen) != 0) {          // equal 64-bit hashes of different names: order them by name
+                const size_t m = a.nameLen < b.nameLen ? a.nameLen : b.nameLen; const int c = memcmp(rec_name(a), rec_name(b), m);
+                return c != 0 ? c < 0 : a.nameLen < b.nameLen;
+            }
+            return a.order < b.order;
+        });
+        std::vector<Unit>& U = punits[(size_t)p];
+        for(size_t i = 0; i < R.size();) {
+            size_t j = i + 1;
+            while(j < R.size() && R[j].hash == R[i].hash && R[j].nameLen == R[i].nameLen && memcmp(rec_name(R[j]), rec_name(R[i]), R[i].nameLen) == 0) j++;
+            bool prim[2] = {false, false};
+            for(size_t k = i; k < j; k++) if(R[k].flags & 2) prim[R[k].which] = true;                // takeAlignment, protoSeeds.cpp:23-36
+            const bool complete = long_read_mode ? prim[0] : (prim[0] && prim[1]);                  // isComplete / isComplete_unpaired, protoSeeds.cpp:371-380
+            if(complete) { Unit u; u.name = rec_name(R[i]); u.nameLen = R[i].nameLen; u.part = (uint32_t)p; u.first = (uint32_t)i; u.count = (uint32_t)(j - i); U.push_back(u); }
+            else pIncomplete[(size_t)p]++;
+            i = j;
+        }
+    });
+    std::vector<Unit> units;
+    { size_t n = 0; for(auto& u : punits) n += u.size(); units.reserve(n); for(auto& u : punits) { units.insert(units.end(), u.begin(), u.end()); std::vector<Unit>().swap(u); } }
+    for(int p = 0; p < NPART; p++) S->n_incomplete += pIncomplete[(size_t)p];
+    S->n_seeds = (int64_t)units.size() + S->n_incomplete;
+    S->seconds[3] = since(tPhase);
+
+    // ---------------------------------------------------------------- sort: read-name order (parallel sample sort)
+    tPhase = Clock::now();
+    if(T > 1 && units.size() > 100000) {
+        const int NB = T * 4;
+        std::vector<Unit> sample;
+        const size_t stepS = std::max<size_t>(1, units.size() / (size_t)(NB * 64));
+        for(size_t i = 0; i < units.size(); i += stepS) sample.push_back(units[i]);
+        std::sort(sample.begin(), sample.end(), name_less);
+        std::vector<Unit> split;
+        for(int k = 1; k < NB; k++) split.push_back(sample[sample.size() * (size_t)k / (size_t)NB]);
+        const int64_t CHK = 65536; const int64_t nChunks = ((int64_t)units.size() + CHK - 1) / CHK;
+        std::vector<uint16_t> bucketOf(units.size());
+        std::vector<std::vector<int64_t>> cnt((size_t)nChunks, std::vector<int64_t>((size_t)NB, 0));
+        parallel_for(nChunks, T, [&](int64_t c, int) {
+            const size_t a = (size_t)(c * CHK), z = std::min(units.size(), a + (size_t)CHK);
+            for(size_t i = a; i < z; i++) { const int bk = (int)(std::upper_bound(split.begin(), split.end(), units[i], name_less) - split.begin()); bucketOf[i] = (uint16_t)bk; cnt[(size_t)c][(size_t)bk]++; }
+        });
+        std::vector<int64_t> bstart((size_t)NB + 1, 0);
+        for(int bk = 0; bk < NB; bk++) { int64_t s = 0; for(int64_t c = 0; c < nChunks; c++) s += cnt[(size_t)c][(size_t)bk]; bstart[(size_t)bk + 1] = bstart[(size_t)bk] + s; }
+        // per chunk and bucket: where its units go
+        { std::vector<int64_t> run(bstart.begin(), bstart.end() - 1); for(int64_t c = 0; c < nChunks; c++) for(int bk = 0; bk < NB; bk++) { const int64_t k = cnt[(size_t)c][(size_t)bk]; cnt[(size_t)c][(size_t)bk] = run[(size_t)bk]; run[(size_t)bk] += k; } }
+        std::vector<Unit> sorted(units.size());
+        parallel_for(nChunks, T, [&](int64_t c, int) {
+            const size_t a = (size_t)(c * CHK), z = std::min(units.size(), a + (size_t)CHK);
+            std::vector<int64_t>& at = cnt[(size_t)c];
+            for(size_t i = a; i < z; i++) sorted[(size_t)at[bucketOf[i]]++] = units[i];
+        });
+        parallel_for(NB, T, [&](int64_t bk, int) { std::sort(sorted.begin() + bstart[(size_t)bk], sorted.begin() + bstart[(size_t)bk + 1], name_less); });
+        units.swap(sorted);
+    } else std::sort(units.begin(), units.end(), name_less);
+    S->seconds[4] = since(tPhase);
+
+    // ---------------------------------------------------------------- layout
+    tPhase = Clock::now();
+    const int nm = long_read_mode ? 1 : 2;
+    const size_t nU = units.size(), nR = nU * (size_t)nm;
+    S->n_units = (int64_t)nU;
+    S->read_off.assign(nR + 1, 0); S->chain_off.assign(nR + 1, 0); S->name_off.assign(nU + 1, 0);
+    S->read_primary.assign(nR, 0);
+    // sizes per read: bases, chains, cigar operations; the primary of a mate is only known after its sort, so the alignments of every mate are
+    // ordered here once (kept as record indices) and reused by the fill pass
+    std::vector<int64_t> cigCount(nR + 1, 0);
+    std::vector<std::vector<uint32_t>> order((size_t)T);
+    const int64_t UCH = std::max<int64_t>(16, std::min<int64_t>(8192, (int64_t)nU / ((int64_t)T * 8) + 1)); const int64_t nUChunks = ((int64_t)nU + UCH - 1) / UCH;
+    // sortChainsInSeeds (:1952-1961) on the mate's alignments in file order; returns the position of the first primary (read*_getPrimaryAlignmentI)
+    auto sorted_mate = [&](const Unit& u, int m, std::vector<uint32_t>& idx) -> size_t {
+        const std::vector<Rec>& R = precs[u.part];
+        idx.clear();
+        for(uint32_t k = u.first; k < u.first + u.count; k++) if(R[k].which == m) idx.push_back(k);
+        std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return R[a].as < R[b].as; });
+        std::reverse(idx.begin(), idx.end());
+        for(size_t i = 0; i < idx.size(); i++) if(R[idx[i]].flags & 2) return i;
+        return idx.size();
+    };
+    parallel_for(nUChunks, T, [&](int64_t c, int t) {
+        std::vector<uint32_t>& idx = order[(size_t)t];
+        const size_t a = (size_t)(c * UCH), z = std::min(nU, a + (size_t)UCH);
+        for(size_t ui = a; ui < z; ui++) {
+            const Unit& u = units[ui]; const std::vector<Rec>& R = precs[u.part];
+            S->name_off[ui + 1] = (int64_t)u.nameLen + 1;
+            for(int m = 0; m < nm; m++) {
+                const size_t prim = sorted_mate(u, m, idx);
+                const size_t r = ui * (size_t)nm + (size_t)m;
+                S->read_off[r + 1] = R[idx[prim]].l_seq; S->chain_off[r + 1] = (int64_t)idx.size();
+                int64_t cg = 0; for(uint32_t k : idx) cg += R[k].n_cigar;
+                cigCount[r + 1] = cg;
+            }
+        }
+    });
+    for(size_t r = 0; r < nR; r++) { S->read_off[r + 1] += S->read_off[r]; S->chain_off[r + 1] += S->chain_off[r]; cigCount[r + 1] += cigCount[r]; }
+    for(size_t ui = 0; ui < nU; ui++) S->name_off[ui + 1] += S->name_off[ui];
+    const size_t nBases = (size_t)S->read_off[nR], nChains = (size_t)S->chain_off[nR], nCig = (size_t)cigCount[nR];
+    if(nChains > 0x7FFFFFFFull) throw Fail("more than 2^31 - 1 alignments in one sample: chain numbers are 32-bit");
+    S->read_bases.alloc(nBases); S->read_quals.alloc(nBases);
+    S->chain_contig.alloc(nChains); S->chain_pos.alloc(nChains); S->chain_offset.alloc(nChains); S->chain_as.alloc(nChains); S->chain_reverse.alloc(nChains);
+    S->cigar_off.alloc(nChains + 1); S->cigar_off[0] = 0; S->cigar.alloc(nCig); S->name_chars.alloc((size_t)S->name_off[nU]);
+    parallel_for(nUChunks, T, [&](int64_t c, int t) {
+        std::vector<uint32_t>& idx = order[(size_t)t];
+        const size_t a = (size_t)(c * UCH), z = std::min(nU, a + (size_t)UCH);
+        for(size_t ui = a; ui < z; ui++) {
+            const Unit& u = units[ui]; const std::vector<Rec>& R = precs[u.part];
+            memcpy(S->name_chars.data() + S->name_off[ui], u.name, (size_t)u.nameLen); S->name_chars[(size_t)S->name_off[ui] + u.nameLen] = 0;
+            for(int m = 0; m < nm; m++) {
+                const size_t prim = sorted_mate(u, m, idx);
+                const size_t r = ui * (size_t)nm + (size_t)m;
+                const Rec& pa = R[idx[prim]];
+                const uint8_t* sq = pa.seq;
+                memcpy(S->read_bases.data() + S->read_off[r], sq, (size_t)pa.l_seq);                // QueryBases / Qualities of the primary, alignment orientation (:3142-3145)
+                memcpy(S->read_quals.data() + S->read_off[r], sq + pa.l_seq, (size_t)pa.l_seq);
+                size_t ch = (size_t)S->chain_off[r]; int64_t cg = cigCount[r];
+                S->read_primary[r] = (int32_t)(ch + prim);
+                for(uint32_t k : idx) {
+                    const Rec& x = R[k];
+                    S->chain_contig[ch] = x.contig; S->chain_pos[ch] = x.pos; S->chain_offset[ch] = 0; S->chain_as[ch] = x.as; S->chain_reverse[ch] = (uint8_t)(x.flags & 1);
+                    memcpy(S->cigar.data() + cg, x.aux, 4 * (size_t)x.n_cigar);
+                    cg += x.n_cigar; S->cigar_off[ch + 1] = cg; ch++;
+                }
+            }
+        }
+    });
+    S->seconds[5] = since(tPhase);
+    *out = S.release();
+    return HLALA_OK;
+} catch(const std::exception& e_) { g_bam_error = dynamic_cast<const Fail*>(&e_) ? std::string(e_.what()) : std::string("hlala_bam_extract_seeds: ") + e_.what(); return HLALA_E_ARG; }
+
+extern "C" int hlala_seed_batch_window(const hlala_seed_batch* S, int64_t first_unit, int32_t n_units, hlala_batch_in* in)
+{
+    if(!S || !in || first_unit < 0 || n_units < 0 || first_unit + n_units > S->n_units) { g_bam_error = "hlala_seed_batch_window: units outside the sample"; return HLALA_E_ARG; }
+    const int per = S->unpaired ? 1 : 2;
+    const size_t r0 = (size_t)first_unit * (size_t)per, nr = (size_t)n_units * (size_t)per;
+    const int64_t nb = S->read_off[r0 + nr] - S->read_off[r0], nc = S->chain_off[r0 + nr] - S->chain_off[r0];
+    const int64_t ng = S->cigar_off[(size_t)S->chain_off[r0 + nr]] - S->cigar_off[(size_t)S->chain_off[r0]];
+    if(nb > 0x7FFFFFFFll || nc > 0x7FFFFFFFll || ng > 0x7FFFFFFFll) {
+        g_bam_error = "hlala_seed_batch_window: " + std::to_string(n_units) + " units hold " + std::to_string(nb) + " bases / " + std::to_string(nc) + " alignments: more than one batch holds (2^31 - 1)";
+        return HLALA_E_CAPACITY;
+    }
+    in->n_pairs = n_units; in->read_off = S->read_off.data() + r0; in->read_bases = S->read_bases.data(); in->read_quals = S->read_quals.data();
+    in->chain_off = S->chain_off.data() + r0; in->read_primary = S->read_primary.data() + r0; in->n_chains = (int32_t)nc;
+    in->chain_contig = S->chain_contig.data(); in->chain_pos = S->chain_pos.data(); in->chain_offset = S->chain_offset.data(); in->chain_as = S->chain_as.data();
+    in->chain_reverse = S->chain_reverse.data(); in->cigar_off = S->cigar_off.data(); in->cigar = S->cigar.data();
+    return HLALA_OK;
+}
+
+extern "C" int hlala_seed_batch_desc(const hlala_seed_batch* S, hlala_batch_in* in, int64_t* counts /* [3] examined records, seeds, incomplete seeds; or NULL */)
+{
+    if(!S || !in) return HLALA_E_ARG;
+    if(S->n_units > 0x7FFFFFFFll) { g_bam_error = "hlala_seed_batch_desc: more than 2^31 - 1 units"; return HLALA_E_CAPACITY; }
+    // the whole sample: n_chains saturates when the sample holds more than one batch can (hlala_batch_create refuses such a descriptor;
+    // hlala_seed_batch_window cuts batches)
+    in->n_pairs = (int32_t)S->n_units; in->read_off = S->read_off.data(); in->read_bases = S->read_bases.data(); in->read_quals = S->read_quals.data();
+    in->chain_off = S->chain_off.data(); in->read_primary = S->read_primary.data(); in->n_chains = (int32_t)std::min<size_t>(S->chain_contig.size(), 0x7FFFFFFF);
+    in->chain_contig = S->chain_contig.data(); in->chain_pos = S->chain_pos.data(); in->chain_offset = S->chain_offset.data(); in->chain_as = S->chain_as.data();
+    in->chain_reverse = S->chain_reverse.data(); in->cigar_off = S->cigar_off.data(); in->cigar = S->cigar.data();
+    if(counts) { counts[0] = S->examined; counts[1] = S->n_seeds; counts[2] = S->n_incomplete; }
+    return HLALA_OK;
+}
+
+extern "C" int64_t hlala_seed_batch_units(const hlala_seed_batch* S) { return S ? S->n_units : 0; }
+extern "C" const char* hlala_seed_batch_name(const hlala_seed_batch* S, int64_t unit) { return (S && unit >= 0 && unit < S->n_units) ? S->name_chars.data() + S->name_off[(size_t)unit] : nullptr; }
+extern "C" int hlala_seed_batch_timing(const hlala_seed_batch* S, double* seconds6, int32_t* n_threads)
+{
+    if(!S) return HLALA_E_ARG;
+    if(seconds6) for(int i = 0; i < 6; i++) seconds6[i] = S->seconds[i];
+    if(n_threads) *n_threads = S->threads;
+    return HLALA_OK;
+}
+extern "C" void hlala_seed_batch_free(hlala_seed_batch* S)
+{
+    if(S && S->pinned && hlala_host::g_seed_batch_unpin) hlala_host::g_seed_batch_unpin(S);
+    delete S;
+}
