@@ -5,10 +5,14 @@
 // right extension of one seed chain (extendSeedChain, :220-319).  A frontier of this DP holds a handful of
 // cells (median 3-4 on 2x150 bp pairs), so a DP is run by a GROUP of lanes, not by a whole wavefront:
 //
-//   DpTiny   16 lanes per DP, 4 DPs per wavefront   frontier <= 16 cells, <= 48 candidate targets per iteration
+//   DpTiny   16 lanes per DP, 4 DPs per wavefront   frontier <= 16 cells, <= 24 candidate targets per iteration
 //   DpMid    32 lanes per DP, 2 DPs per wavefront   frontier <= 32, <= 96 targets        (DPs that outgrow DpTiny)
 //   DpSmall  64 lanes per DP                        frontier <= 64, <= 96 targets        (DPs that outgrow DpMid)
-//   DpLarge  64 lanes per DP                        frontier <= 1024, <= 1536 targets    (DPs that outgrow DpSmall)
+//   DpWide   64 lanes per DP                        frontier <= 256, <= 384 targets
+//   DpBroad / DpLarge / DpHuge   one DP per BLOCK of two wavefronts (DP_TAIL_THREADS)   frontier <= 512 / 1024 / 8192 (the last with its state in HBM)
+// A DP that outgrows its class is queued for the first later class that holds what overflowed and runs there again; every class computes identical results
+// (one template).  Groups of up to one wavefront synchronise with wave fences, blocks of several wavefronts with s_barrier, and the group collectives below
+// exchange one word per wave through LDS.
 //
 // Every group is a small state machine (fetch -> iterate ... -> select end cell -> backtrace -> expand -> done);
 // the four groups of a wavefront advance independently inside one persistent loop, so a DP that ends early
@@ -94,7 +98,13 @@ struct DpLarge { static constexpr int THREADS = HLALA_DP_LARGE_THREADS, WAVES = 
 // the slab, the wave fences become agent-scope fences (plain loads must not hit stale L1 lines of words the atomics changed in L2), and the
 // frontier sort borrows the otherwise unused LDS.  An order of magnitude slower per cell than the LDS classes; nothing is dropped.
 struct DpHuge  { static constexpr int THREADS = HLALA_DP_HUGE_THREADS, WAVES = 1, GW = HLALA_DP_HUGE_THREADS, WCAP = 8192, HC = 16384, IBITS = 13, CELLS = 131072, EARLY = 131072, IMPCAP = 8192, COMPLETED = 65536, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = true; };
-constexpr int DP_SORT_SCRATCH = 8192;       // (key, payload) pairs of the in-memory class's frontier sort, in LDS: 128 KB
+// (key, payload) pairs of the in-memory class's frontier sort held in LDS: 64 KB.  (It was 8192 pairs = 128 KB: a block then needed a CU with four fifths of its LDS free,
+// which the persistent main-stream kernels of the next batch rarely leave -- the class took 119 ms beside them and 27 ms alone --, and once resident it left room for five of
+// the sixteen 16-lane blocks.)  Frontiers beyond 4096 cells -- none on the Graph M workload: the widest holds 3200 -- are sorted in the block's slab in HBM.
+#ifndef HLALA_DP_SORT_SCRATCH
+#define HLALA_DP_SORT_SCRATCH 4096
+#endif
+constexpr int DP_SORT_SCRATCH = HLALA_DP_SORT_SCRATCH;
 
 // State of one DP call.  It lives in the group's LDS block (all lanes of the group read the same words, a broadcast), so
 // that only the phase has to stay in registers across the states of the persistent loop.
@@ -162,7 +172,8 @@ struct DpSlabT {
     static constexpr size_t O_TIE_SLOT  = O_IMP_MASK + (size_t)C::IMPCAP * 4;         // int  [COMPLETED]
     static constexpr size_t O_TIE_KEY   = (O_TIE_SLOT + (size_t)C::COMPLETED * 4 + 7) & ~(size_t)7;   // u64 [COMPLETED]
     static constexpr size_t O_EARLY_GEN = O_TIE_KEY + (size_t)C::COMPLETED * 8;         // int: generation of the early table = number of DP calls that used it (pools start zeroed)
-    static constexpr size_t BYTES       = (O_EARLY_GEN + 8 + 255) & ~(size_t)255;
+    static constexpr size_t O_SORT_SPILL = (O_EARLY_GEN + 8 + 15) & ~(size_t)15;        // u64[2 * WCAP], in-memory class only: (key, payload) pairs of a frontier wider than the LDS scratch
+    static constexpr size_t BYTES       = (O_SORT_SPILL + (C::IN_MEMORY ? (size_t)C::WCAP * 16 : 0) + 255) & ~(size_t)255;
     __device__ __forceinline__ CellRec* cell() const { return (CellRec*)(base + O_CELL); }
     __device__ __forceinline__ u64* early_key() const { return (u64*)(base + O_EARLY_KEY); }
     __device__ __forceinline__ u32* step_bt() const { return (u32*)(base + O_STEP_BT); }
@@ -177,6 +188,7 @@ struct DpSlabT {
     __device__ __forceinline__ int* tie_slot() const { return (int*)(base + O_TIE_SLOT); }
     __device__ __forceinline__ u64* tie_key() const { return (u64*)(base + O_TIE_KEY); }
     __device__ __forceinline__ int* early_gen() const { return (int*)(base + O_EARLY_GEN); }
+    __device__ __forceinline__ u64* sort_spill() const { return (u64*)(base + O_SORT_SPILL); }
 };
 
 template <class C>
@@ -1135,7 +1147,10 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
         DSYNC();
         int Pn = GW * 2; while(Pn < nNew) Pn <<= 1;              // power of two >= nNew, <= WCAP
         u64* keys; u64* pay;
-        if constexpr (C::IN_MEMORY) { keys = sortScratch; pay = sortScratch + DP_SORT_SCRATCH; } else { keys = &S.fkey[bn][0]; pay = (u64*)&S.hbest[2][0]; }
+        if constexpr (C::IN_MEMORY) {
+            if(Pn <= DP_SORT_SCRATCH) { keys = sortScratch; pay = sortScratch + DP_SORT_SCRATCH; }
+            else { keys = sl.sort_spill(); pay = keys + C::WCAP; }            // wider than the LDS scratch: in the slab (the group fences of this class order global memory)
+        } else { keys = &S.fkey[bn][0]; pay = (u64*)&S.hbest[2][0]; }
         auto enc = [](int v) -> u64 { return v == DP_NEG ? 0ull : (u64)(u32)(v + 64); };
         auto dec = [](u64 e) -> short { return e == 0 ? (short)DP_NEG : (short)((int)e - 64); };
         for(int i = gl; i < Pn; i += GW) {

@@ -173,24 +173,30 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     const int32_t batchPairs = arguments.count("batchPairs") ? (int32_t)std::atol(arguments.at("batchPairs").c_str()) : (longReads.length() ? 65536 : 1048576);
     const uint32_t rngSeed = arguments.count("rngSeed") ? (uint32_t)std::strtoul(arguments.at("rngSeed").c_str(), nullptr, 10) : 0u;
     // long reads: columns of a read incl. the levels it skips (hlala_batch_create_unpaired)
+    // the typer's view of the graph directory (level names of every segment file: millions of them) is read beside the graph, the contigs and the BAM
+    std::unique_ptr<hla::HLATyper> typerPtr; std::string typerErr;
+    std::thread typerThread([&]() { try { typerPtr.reset(new hla::HLATyper(PRG_graph_dir, fileExists("hla_nom_g.txt") ? "hla_nom_g.txt" : "")); } catch(const std::exception& e) { typerErr = e.what(); } });
+    struct Joiner { std::thread& t; ~Joiner() { if(t.joinable()) t.join(); } } typerJoin{typerThread};
     mapper::processBAM BAMprocessor(PRG_graph_dir, mapAgainstCompleteGenome, longReads.length() ? 16384 : 384, rngSeed, devices, decodeThreads);
-    // the G-group table is looked up in the working directory, as the reference does (hla/HLATyper.cpp:4160-4166; HLA-LA.pl chdirs to the source directory)
-    hla::HLATyper HLAtyper(PRG_graph_dir, fileExists("hla_nom_g.txt") ? "hla_nom_g.txt" : "");
-    std::vector<std::string> loci;
-    if(arguments.count("loci")) loci = split_list(arguments.at("loci"));
-    else for(const char* l : {"A", "B", "C", "DQA1", "DQB1", "DRB1", "DPA1", "DPB1", "DRA", "DRB3", "DRB4", "E", "F", "G", "H", "K", "V"}) {          // hla/HLATyper.cpp:42
-        if(HLAtyper.has_locus(l)) loci.push_back(l); else std::cerr << "HLATypeInference(..): Locus " << l << ": no exon files in " << PRG_graph_dir << "/PRG -- skipped\n";
-    }
-
+    const double loadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count();
     std::cout << timestamp() << "Start seed extraction\n" << std::flush;
     const auto tOpen = std::chrono::steady_clock::now();
     BAMprocessor.openBAM(BAM_remapped, longReads.length() != 0, batchPairs);
     const double openSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tOpen).count();
     std::cout << timestamp() << "Seed extraction: " << BAMprocessor.n_units << " complete units, BAM decoded in " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
               << " threads (index " << BAMprocessor.decode_phase_seconds[0] << ", inflate " << BAMprocessor.decode_phase_seconds[1] << ", parse " << BAMprocessor.decode_phase_seconds[2] << ", group "
-              << BAMprocessor.decode_phase_seconds[3] << ", name sort " << BAMprocessor.decode_phase_seconds[4] << ", layout " << BAMprocessor.decode_phase_seconds[5] << "); contexts on " << BAMprocessor.n_devices()
-              << " device(s) + insert size: " << openSeconds - BAMprocessor.decode_seconds << " s\n" << std::flush;
+              << BAMprocessor.decode_phase_seconds[3] << ", name sort " << BAMprocessor.decode_phase_seconds[4] << ", layout " << BAMprocessor.decode_phase_seconds[5] << "); beside it: contexts on " << BAMprocessor.n_devices()
+              << " device(s) in " << BAMprocessor.context_seconds << " s; graph + contigs loaded in " << loadSeconds << " s (typer files beside them); seed extraction in all " << openSeconds << " s\n" << std::flush;
     if(!longReads.length()) std::cout << "Insert size: mean " << BAMprocessor.IS_mean << ", sd " << BAMprocessor.IS_sd << "\n" << std::flush;
+    // the G-group table is looked up in the working directory, as the reference does (hla/HLATyper.cpp:4160-4166; HLA-LA.pl chdirs to the source directory)
+    typerThread.join();
+    if(!typerErr.empty()) throw std::runtime_error(typerErr);
+    hla::HLATyper& HLAtyper = *typerPtr;
+    std::vector<std::string> loci;
+    if(arguments.count("loci")) loci = split_list(arguments.at("loci"));
+    else for(const char* l : {"A", "B", "C", "DQA1", "DQB1", "DRB1", "DPA1", "DPB1", "DRA", "DRB3", "DRB4", "E", "F", "G", "H", "K", "V"}) {          // hla/HLATyper.cpp:42
+        if(HLAtyper.has_locus(l)) loci.push_back(l); else std::cerr << "HLATypeInference(..): Locus " << l << ": no exon files in " << PRG_graph_dir << "/PRG -- skipped\n";
+    }
     const std::string outputDirectory_for_HLA = outputDirectory + "/hla/";
     make_or_clearDirectory(outputDirectory + "/hla");                                                   // processBAM.cpp:1805-1806
     std::cout << timestamp() << "Alignment of " << BAMprocessor.n_units << (longReads.length() ? " reads" : " read pairs") << " in " << BAMprocessor.n_batches() << " GPU batch(es) on " << BAMprocessor.n_devices() << " device context(s)\n" << std::flush;
@@ -204,7 +210,7 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     // BAM bytes -> hla/*: seed extraction (decode, contexts, insert size) + alignment + typing (everything after the remapping)
     { const double e2e = BAMprocessor.decode_seconds + inferSeconds;
       std::cout << "End-to-end: " << (e2e > 0 ? (double)(pairs + unpaired) / e2e : 0.0) << " units per s (BAM decode " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
-                << " threads + alignment and typing " << inferSeconds << " s; context creation and insert size " << openSeconds - BAMprocessor.decode_seconds << " s and graph loading are per process, not per sample; "
+                << " threads + alignment and typing " << inferSeconds << " s; context creation and insert size " << openSeconds - BAMprocessor.decode_seconds << " s beyond the decode, graph loading " << loadSeconds << " s: per process, not per sample; "
                 << "whole action after the remapping: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s)\n" << std::flush; }
     std::cout << "Typing phases: batches (alignment, post-processing, exon positions) " << HLAtyper.timing.batches << " s, summary " << HLAtyper.timing.summary << " s, per-locus likelihoods and calls "
               << HLAtyper.timing.loci << " s, k-mer pass " << HLAtyper.timing.kmers << " s, result files " << HLAtyper.timing.files << " s\n" << std::flush;

@@ -243,12 +243,21 @@ public:
         : graphDir_(graphDir), extended_(extendedReferenceGenome), max_columns_(max_columns), rng_seed_(rng_seed), devices_(devices.empty() ? std::vector<int>(1, 0) : devices), threads_(threads)
     {
         // `--action prepareGraph` leaves the flattened arrays in <graphDir>/serializedGRAPH; a file of that name written by the reference
-        // binary (a Boost archive) is not ours and the text graph is parsed instead
-        if(hlala_graph_cache_load((graphDir + "/serializedGRAPH").c_str(), &graph_) != HLALA_OK) {
-            graph_ = nullptr;
-            if(hlala_graph_load_text((graphDir + "/PRG/graph.txt").c_str(), &graph_) != HLALA_OK) throw std::runtime_error(std::string("graph.txt: ") + hlala_loader_last_error());
-        }
-        if(hlala_contigs_load_dir(graphDir.c_str(), extendedReferenceGenome ? 1 : 0, &contigs_) != HLALA_OK) throw std::runtime_error(std::string("contigs: ") + hlala_loader_last_error());
+        // binary (a Boost archive) is not ours and the text graph is parsed instead.  The graph and the contigs (tens of millions of translation lines) are
+        // independent files: read side by side.
+        std::string gErr, cErr;
+        std::thread tg([&]() {
+            try {
+                if(hlala_graph_cache_load((graphDir + "/serializedGRAPH").c_str(), &graph_) != HLALA_OK) {
+                    graph_ = nullptr;
+                    if(hlala_graph_load_text((graphDir + "/PRG/graph.txt").c_str(), &graph_) != HLALA_OK) gErr = std::string("graph.txt: ") + hlala_loader_last_error();
+                }
+            } catch(const std::exception& e) { gErr = e.what(); }
+        });
+        try { if(hlala_contigs_load_dir(graphDir.c_str(), extendedReferenceGenome ? 1 : 0, &contigs_) != HLALA_OK) cErr = std::string("contigs: ") + hlala_loader_last_error(); }
+        catch(const std::exception& e) { cErr = e.what(); }
+        tg.join();
+        if(!gErr.empty() || !cErr.empty()) { if(graph_) hlala_graph_file_free(graph_); if(contigs_) hlala_contigs_file_free(contigs_); graph_ = nullptr; contigs_ = nullptr; throw std::runtime_error(gErr.empty() ? cErr : gErr); }
         intervals_.resize((size_t)hlala_contigs_file_intervals(contigs_, nullptr, 0));
         hlala_contigs_file_intervals(contigs_, intervals_.data(), (int32_t)intervals_.size());
     }
@@ -260,24 +269,31 @@ public:
     // size from the first 4000 of them (:1075) on the first device, then every context gets that insert size.  batchPairs = 0: one batch.
     void openBAM(const std::string& BAM, bool longReads = false, int32_t batchPairs = 0)
     {
+        // the BAM is decoded (all host threads) while the contexts are created (one thread per device: each flattens and uploads the graph)
         const auto t0 = std::chrono::steady_clock::now();
-        if(hlala_bam_extract_seeds_mt(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, threads_, &seeds_) != HLALA_OK) throw std::runtime_error(std::string("BAM: ") + hlala_bam_last_error());
-        decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        hlala_seed_batch_timing(seeds_, decode_phase_seconds, &decode_threads);
-        n_units = hlala_seed_batch_units(seeds_); longReadsMode = longReads;
-        (void)hlala_seed_batch_pin(seeds_, 1);                                        // page-locked: batch uploads are plain DMA (a refusal only costs speed)
+        std::string bamErr;
+        std::thread tdec([&]() {
+            try { if(hlala_bam_extract_seeds_mt(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, threads_, &seeds_) != HLALA_OK) bamErr = std::string("BAM: ") + hlala_bam_last_error(); }
+            catch(const std::exception& e) { bamErr = e.what(); }
+            decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
         hlala_graph_desc gd; hlala_graph_file_desc(graph_, &gd);
         hlala_contigs_desc cd; hlala_contigs_file_desc(contigs_, &cd);
         n_levels = gd.n_levels;
         hlala_params pr{200.0, 35.0, rng_seed_, longReads ? 1 : 0, max_columns_, 0};
-        if(!longReads && n_units == 0) throw std::runtime_error("estimateInsertSize: no complete read pair in " + BAM);
-        // one context per device, created side by side (each flattens and uploads the graph)
         ctxs_.assign(devices_.size(), nullptr);
         std::vector<std::string> errs(devices_.size());
         std::vector<std::thread> th;
         for(size_t d = 0; d < devices_.size(); d++) th.emplace_back([&, d]() { if(hlala_create(&ctxs_[d], devices_[d], nullptr, &gd, &cd, &pr) != HLALA_OK) errs[d] = std::string("hlala_create: ") + hlala_last_error(nullptr); });
         for(std::thread& t : th) t.join();
+        context_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        tdec.join();
+        if(!bamErr.empty()) throw std::runtime_error(bamErr);
         for(const std::string& e : errs) if(!e.empty()) throw std::runtime_error(e);
+        hlala_seed_batch_timing(seeds_, decode_phase_seconds, &decode_threads);
+        n_units = hlala_seed_batch_units(seeds_); longReadsMode = longReads;
+        (void)hlala_seed_batch_pin(seeds_, 1);                                        // page-locked: batch uploads are plain DMA (a refusal only costs speed)
+        if(!longReads && n_units == 0) throw std::runtime_error("estimateInsertSize: no complete read pair in " + BAM);
         if(!longReads) {                                                              // insert size from this sample
             hlala_batch_in first; window(0, n_units < 4000 ? (int32_t)n_units : 4000, first);
             hlala_insert_size_out is; int rc = hlala_estimate_insert_size(ctxs_[0], &first, &is);
@@ -325,6 +341,7 @@ public:
     double IS_mean = 200.0, IS_sd = 35.0;
     int64_t n_units = 0; int32_t n_levels = 0; bool longReadsMode = false;
     double decode_seconds = 0, decode_phase_seconds[6] = {0, 0, 0, 0, 0, 0}; int32_t decode_threads = 0;
+    double context_seconds = 0;       // creation of the contexts (beside the decode)
 
 private:
     void window(int64_t u0, int32_t n, hlala_batch_in& in) const
