@@ -164,11 +164,14 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+// inclusive scans over the wave: the DPP sequence above leaves in every lane the reduction of lanes 0 .. lane (row_shr within a row of 16,
+// then the last lane of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2 and 3)
+__device__ __forceinline__ int wave_incl_scan_add(int v) { HLALA_DPP_REDUCE(v, 0, op_add_); return v; }
+__device__ __forceinline__ int wave_incl_scan_max(int v) { HLALA_DPP_REDUCE(v, (int)0x80000000, op_max_); return v; }
 __device__ __forceinline__ int wave_excl_scan(int v, int& total)
 {
-    int x = v;
-    for(int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if(lane_id() >= o) x += y; }
-    total = __shfl(x, 63);
+    const int x = wave_incl_scan_add(v);
+    total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
 

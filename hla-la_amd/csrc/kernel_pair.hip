@@ -45,11 +45,11 @@ __device__ inline int lp_find(const DevGraph& G, int level, int id)
 // arguments: the lanes share the sequences of the upstream level and look each one up in the downstream levels by binary search (a level of a gene
 // window carries dozens to thousands of sequences; one lane walking both lists against each other was most of this kernel's time on Graph M).
 // The maximum does not depend on the order of the candidates.
-__device__ inline double pair_insert_ll(const DevGraph& G, const DevTables& T, const int* fl_up, const int* fl_down)
+__device__ inline double pair_insert_ll(const DevGraph& G, const DevTables& T, const int up0, const int up1, const int dn0, const int dn1)
 {
     const int lane = lane_id();
     // upstream chain: last two defined levels (scan order: last, second last); downstream: first two
-    const int upL[2] = {uni(fl_up[2]), uni(fl_up[3])}, dnL[2] = {uni(fl_down[0]), uni(fl_down[1])};
+    const int upL[2] = {up0, up1}, dnL[2] = {dn0, dn1};
     double best = -1.0e300; bool have = false;
     for(int a = 0; a < 2; a++) {
         if(upL[a] < 0) continue;
@@ -126,19 +126,27 @@ __device__ __forceinline__ void pair_finish(const DevGraph& G, const DevTables& 
     constexpr int NM = UNPAIRED ? 1 : 2;
         // ---- combination log likelihoods, row-major (i1, i2) (:3408-3506)
         if(UNPAIRED) { for(int i = lane; i < nComb; i += 64) LL[i] = B.ext_ll[P.list[0][i]]; }                         // read1_extendedChains_log_likelihoods, :3743
-        else for(int i = 0; i < nComb; i++) {              // one combination at a time, the wave shares the insert-size term
-            const int i1 = i / n2, i2 = i % n2;
-            const int ca = uni(P.list[0][i1]), cb = uni(P.list[1][i2]);
-            const int* fa = B.ext_firstlast + 4 * ca; const int* fb = B.ext_firstlast + 4 * cb;
-            const int fa0 = uni(fa[0]), fb0 = uni(fb[0]);
-            const bool ra = uni(B.chain_reverse[ca]) != 0, rb = uni(B.chain_reverse[cb]) != 0;
-            bool valid = false;
-            if(fa0 != -1 && fb0 != -1 && ra != rb) valid = (!ra) ? (fa0 < fb0) : (uni(fa[2]) > uni(fb[2]));          // alignerBase.cpp:213-244
-            double llIS = T.is_penalty;
-            if(valid) llIS = (fa0 < fb0) ? pair_insert_ll(G, T, fa, fb) : pair_insert_ll(G, T, fb, fa);        // alignerBase.cpp:294, 312
-            double combined = B.ext_ll[ca] + B.ext_ll[cb];
-            combined += llIS;
-            if(lane == 0) LL[i] = combined;
+        else {
+            // what a combination needs of its two chains -- first / last two levels, strand, log likelihood -- is read once per CHAIN, lane k holding the
+            // k-th chain of either mate (one round trip), not once per combination through wave-uniform loads (three dependent round trips each)
+            int4 fA = make_int4(-1, -1, -1, -1), fB = make_int4(-1, -1, -1, -1); int rA = 0, rB = 0; double lA = 0.0, lB = 0.0;
+            if(lane < n1) { const int c = P.list[0][lane]; fA = *(const int4*)(B.ext_firstlast + 4 * (size_t)c); rA = B.chain_reverse[c]; lA = B.ext_ll[c]; }
+            if(lane < n2) { const int c = P.list[1][lane]; fB = *(const int4*)(B.ext_firstlast + 4 * (size_t)c); rB = B.chain_reverse[c]; lB = B.ext_ll[c]; }
+            auto rl64 = [](double v, int l) -> double { const long long b = __double_as_longlong(v);
+                return __longlong_as_double((long long)(((u64)(u32)__builtin_amdgcn_readlane((int)(b >> 32), l) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)b, l))); };
+            for(int i = 0; i < nComb; i++) {              // one combination at a time, the wave shares the insert-size term
+                const int i1 = i / n2, i2 = i % n2;
+                const int fa0 = __builtin_amdgcn_readlane(fA.x, i1), fa1 = __builtin_amdgcn_readlane(fA.y, i1), fa2 = __builtin_amdgcn_readlane(fA.z, i1), fa3 = __builtin_amdgcn_readlane(fA.w, i1);
+                const int fb0 = __builtin_amdgcn_readlane(fB.x, i2), fb1 = __builtin_amdgcn_readlane(fB.y, i2), fb2 = __builtin_amdgcn_readlane(fB.z, i2), fb3 = __builtin_amdgcn_readlane(fB.w, i2);
+                const bool ra = __builtin_amdgcn_readlane(rA, i1) != 0, rb = __builtin_amdgcn_readlane(rB, i2) != 0;
+                bool valid = false;
+                if(fa0 != -1 && fb0 != -1 && ra != rb) valid = (!ra) ? (fa0 < fb0) : (fa2 > fb2);          // alignerBase.cpp:213-244
+                double llIS = T.is_penalty;
+                if(valid) llIS = (fa0 < fb0) ? pair_insert_ll(G, T, fa2, fa3, fb0, fb1) : pair_insert_ll(G, T, fb2, fb3, fa0, fa1);        // alignerBase.cpp:294, 312
+                double combined = rl64(lA, i1) + rl64(lB, i2);
+                combined += llIS;
+                if(lane == 0) LL[i] = combined;
+            }
         }
         WSYNC();
         // ---- first maximum (Utilities::findVectorMax, Utilities.cpp:309-323)
@@ -274,19 +282,39 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
         p0 = __builtin_amdgcn_readfirstlane(p0);
         if(p0 >= B.n_pairs) break;
         const int pEnd = min(p0 + CHUNK, B.n_pairs);
+        // the chunk's deferred flags and chain ranges: lane q holds pair p0 + q (one round trip for the chunk, not two dependent ones per pair)
+        constexpr int NM = UNPAIRED ? 1 : 2;
+        int hDf = 0, hC[NM + 1];
+        #pragma unroll
+        for(int m = 0; m <= NM; m++) hC[m] = 0;
+        if(lane < CHUNK && p0 + lane < pEnd) {
+            const int pq = p0 + lane;
+            if(deferMode) hDf = deferPairs[pq];
+            #pragma unroll
+            for(int m = 0; m <= NM; m++) hC[m] = B.chain_off[NM * pq + m];
+        }
         for(int p = p0; p < pEnd; p++) {
-        if(deferMode) { const bool df = uni(deferPairs[p]) != 0; if(df == (deferMode == 1)) continue; }
+        const int hq = p - p0;
+        if(deferMode) { const bool df = __builtin_amdgcn_readlane(hDf, hq) != 0; if(df == (deferMode == 1)) continue; }
         // ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains), error propagation
         int bad = 0;
-        constexpr int NM = UNPAIRED ? 1 : 2;
+        int cLo[NM], cHi[NM], stF[NM], ncF[NM];
+        #pragma unroll
+        for(int m = 0; m < NM; m++) { cLo[m] = __builtin_amdgcn_readlane(hC[m], hq); cHi[m] = __builtin_amdgcn_readlane(hC[m + 1], hq); }
+        // status and length of the first 64 chains of both mates: one round trip (a pair with more alignments per mate loops on)
+        #pragma unroll
+        for(int m = 0; m < NM; m++) { const int c = cLo[m] + lane; stF[m] = 1; ncF[m] = 0; if(c < cHi[m]) { stF[m] = B.ext_status[c]; ncF[m] = B.ext_ncols[c]; } }
+        int mxc = 0;                 // longest listed chain: the per-position pass below holds PAIR_COLS columns per chain (long reads come with one alignment each: nComb == 1, any length)
+        #pragma unroll
         for(int m = 0; m < NM; m++) {
-            int r = UNPAIRED ? p : 2 * p + m; int c0 = B.chain_off[r], c1 = B.chain_off[r + 1];
+            const int c0 = cLo[m], c1 = cHi[m];
             int cnt = 0;
             for(int b0 = c0; b0 < c1; b0 += 64) {
-                int c = b0 + lane; int st = c < c1 ? B.ext_status[c] : 1;
+                int c = b0 + lane; int st, nc;
+                if(b0 == c0) { st = stF[m]; nc = ncF[m]; } else { st = 1; nc = 0; if(c < c1) { st = B.ext_status[c]; nc = B.ext_ncols[c]; } }
                 if(__ballot(st < 0)) bad = 1;
                 u64 okm = __ballot(st == HLALA_CHAIN_OK);
-                if(st == HLALA_CHAIN_OK) { int pos = cnt + __popcll(okm & ((1ull << lane) - 1ull)); if(pos < PAIR_CHAINS) P.list[m][pos] = c; }
+                if(st == HLALA_CHAIN_OK) { int pos = cnt + __popcll(okm & ((1ull << lane) - 1ull)); if(pos < PAIR_CHAINS) { P.list[m][pos] = c; mxc = max(mxc, nc); } }
                 cnt += __popcll(okm);
             }
             if(lane == 0) P.nlist[m] = cnt;
@@ -297,12 +325,8 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
         bad = uni(bad);
         const long long nCombLL = (long long)n1 * n2;
         if(!bad && nCombLL > PAIR_COMB) bad = 1;
-        if(!bad && nCombLL > 1) {
-            // the per-position pass below holds PAIR_COLS columns per chain (long reads come with one alignment each: nComb == 1, any length)
-            int mxc = 0;
-            for(int m = 0; m < NM; m++) { const int nl = m ? n2 : n1; for(int k = lane; k < nl; k += 64) mxc = max(mxc, B.ext_ncols[P.list[m][k]]); }
-            if(wave_max_i32(mxc) > PAIR_COLS) bad = 1;
-        }
+        mxc = wave_max_i32(mxc);
+        if(!bad && nCombLL > 1 && mxc > PAIR_COLS) bad = 1;
         if(bad) {
             if(lane == 0) { B.pair_status[p] = -1; if(UNPAIRED) B.best_chain[p] = -1; else { B.best_chain[2 * p] = -1; B.best_chain[2 * p + 1] = -1; } B.n_comb[p] = 0; }
         } else {

@@ -25,6 +25,7 @@ constexpr int PROJ_SEGMAX = 24;     // longest run of multi-node levels one lane
 
 struct ChoiceRec { int eid; short fromz; short S; };
 
+
 // (CAP_ = columns held; two sizes are instantiated: 512 and -- for params.max_columns <= 384, the default of the paired path -- 384, whose
 // 14.5 KB let 11 waves share a CU's LDS instead of 9: the kernel waits on memory two thirds of its cycles)
 template <int CAP_, int SN_, int SE_>
@@ -151,6 +152,21 @@ __global__ void k_filter_chains(const DevGraph* __restrict__ Gp, const DevBatch*
     }
 }
 
+// Copy loops global -> LDS (staging a window of the graph): `for(i ...) lds[i] = f(global[i])` waits for every load before its store, one
+// round trip per 64 (or 16) elements.  Here U loads are requested before the first store: one round trip per U rows of lanes.
+template <int U, class LoadF, class StoreF>
+__device__ __forceinline__ void staged_rows(int first, int end, int step, LoadF load, StoreF store)
+{
+    for(int base = first; base < end; base += U * step) {
+        decltype(load(0)) v[U];
+        #pragma unroll
+        for(int u = 0; u < U; u++) { const int i = base + u * step; if(i < end) v[u] = load(i); }
+        #pragma unroll
+        for(int u = 0; u < U; u++) { const int i = base + u * step; if(i < end) store(i, v[u]); }
+    }
+}
+struct FromLab { int from; unsigned char lab; };
+
 #define PJ_FAIL(code) do { if(P.err == 0) P.err = (code); } while(0)
 #define PJ_T(i) do { if(B.dbg) tPh[i] = clock64(); } while(0)      // HLALA_DEBUG phase clocks -> counters[16..23]
 #define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
@@ -204,7 +220,9 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         typedef LvCodec<PL> LC;
         // 16-bit layouts: column levels are kept as offsets from the first DEFINED level at or after the chain's first reference position (a translation
         // table holds -1 where a contig base is on no graph level, processBAM.cpp:2519, 5293: the chain may well start on one)
+        // (the first 64 positions and the first 64 CIGAR operations are requested together: one round trip, not two)
         int lvBase = 0;
+        const u32 cgFirst = lane < nOps ? B.cigar[cg0 + lane] : 0;
         if constexpr (LC::SHORT) {
             const long long t0 = (long long)pos - tOffset;
             for(long long q0 = t0 > 0 ? t0 : 0, qEnd = q0 + 2 * (long long)PL::CAP; q0 < cLen && q0 < qEnd; q0 += 64) {
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             // pass 1: totals, validity, first / last column operation (sequence_aligned_{start,stop}InRaw, :5197-5203)
             for(int ob = 0; ob < nOps; ob += 64) {
                 const int oi = ob + lane;
-                u32 cg = oi < nOps ? B.cigar[cg0 + oi] : 0;
+                u32 cg = ob == 0 ? cgFirst : (oi < nOps ? B.cigar[cg0 + oi] : 0);
                 int op = (int)(cg & 15u), len = (int)(cg >> 4);
                 if(oi >= nOps) { op = 6; len = 0; }                       // behaves like 'P'
                 bool isCol = (op == 0 || op == 7 || op == 8 || op == 2 || op == 1);
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             int baseCol = 0, baseRef = 0, baseRead = 0, leadH = 0;
             for(int ob = 0; ob < nOps; ob += 64) {
                 const int oi = ob + lane;
-                u32 cg = oi < nOps ? B.cigar[cg0 + oi] : 0;
+                u32 cg = ob == 0 ? cgFirst : (oi < nOps ? B.cigar[cg0 + oi] : 0);
                 int opK = (int)(cg & 15u), opLen = (int)(cg >> 4);
                 if(oi >= nOps) { opK = 6; opLen = 0; }
                 bool isCol = (opK == 0 || opK == 7 || opK == 8 || opK == 2 || opK == 1);
@@ -282,35 +300,48 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 int opCol = baseCol + wave_excl_scan(isCol ? opLen : 0, tc);
                 int opRef = baseRef + wave_excl_scan(useRef ? opLen : 0, tr);
                 int opRead = baseRead + wave_excl_scan(useRead ? opLen : 0, tq) + leadH;
-                // one lane per COLUMN (64 at a time): the lane finds its operation among the (wave-uniform) operations that overlap the 64 columns, then
-                // all gathers of the round are in flight together.  (One operation after the other cost a round trip of dependent loads per operation:
-                // gene-window alignments carry a dozen.)
+                // one lane per COLUMN, PJ_U x 64 columns at a time (a 2 x 150 bp chain in one go): the lane finds the operation of each of its columns among
+                // the (wave-uniform) operations that overlap them, then all gathers are in flight together.  (One operation after the other cost a round
+                // trip of dependent loads per operation -- gene-window alignments carry a dozen --, 64 columns at a time one per 64 columns.)
+                constexpr int PJ_U = 6;
                 const int nHere = min(64, nOps - ob);
-                for(int j0 = 0; j0 < tc; j0 += 64) {
-                    const int jr = j0 + lane;                       // column within this round of operations
-                    int myOp = -1, myK = 0, myRef = 0, myRead = 0;
+                for(int j0 = 0; j0 < tc; j0 += 64 * PJ_U) {
+                    int myOp[PJ_U], refB[PJ_U], readB[PJ_U];          // operation of column j0 + 64 u + lane; reference / read offset of the column = base + column
+                    #pragma unroll
+                    for(int u = 0; u < PJ_U; u++) { myOp[u] = -1; refB[u] = 0; readB[u] = 0; }
                     for(int o = 0; o < nHere; o++) {
                         const int op = __builtin_amdgcn_readlane(opK, o), olen = __builtin_amdgcn_readlane(opLen, o);
                         if(!(op == 0 || op == 7 || op == 8 || op == 2 || op == 1) || olen == 0) continue;
                         const int ocs = __builtin_amdgcn_readlane(opCol, o) - baseCol;
-                        if(ocs + olen <= j0 || ocs >= j0 + 64) continue;
-                        if(jr >= ocs && jr < ocs + olen) { myOp = op; myK = jr - ocs; myRef = __builtin_amdgcn_readlane(opRef, o); myRead = __builtin_amdgcn_readlane(opRead, o); }
+                        if(ocs + olen <= j0 || ocs >= j0 + 64 * PJ_U) continue;
+                        const int oref = __builtin_amdgcn_readlane(opRef, o) - ocs, oread = __builtin_amdgcn_readlane(opRead, o) - ocs;
+                        #pragma unroll
+                        for(int u = 0; u < PJ_U; u++) { const int jr = j0 + 64 * u + lane; if(jr >= ocs && jr < ocs + olen) { myOp[u] = op; refB[u] = oref; readB[u] = oread; } }
                     }
-                    if(myOp >= 0) {
-                        int lv = -1; unsigned char gc = '_', sc = '_';
-                        if(myOp != 1) {
-                            int refpos = pos + myRef + myK;
-                            int ti = refpos - tOffset;
-                            if(refpos < 0 || refpos >= cLen || ti < 0 || ti >= cLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
-                            else { gc = contig_seq[cOff + refpos]; lv = contig_level[cOff + ti]; }
+                    int lvv[PJ_U]; unsigned char gcv[PJ_U], scv[PJ_U]; int bad = 0;
+                    #pragma unroll
+                    for(int u = 0; u < PJ_U; u++) {
+                        lvv[u] = -1; gcv[u] = '_'; scv[u] = '_';
+                        const int jr = j0 + 64 * u + lane;
+                        if(myOp[u] >= 0 && myOp[u] != 1) {
+                            const int refpos = pos + refB[u] + jr, ti = refpos - tOffset;
+                            if(refpos < 0 || refpos >= cLen || ti < 0 || ti >= cLen) bad = 1;
+                            else { gcv[u] = contig_seq[cOff + refpos]; lvv[u] = contig_level[cOff + ti]; }
                         }
-                        if(myOp != 2) {
-                            int ri = myRead + myK;
-                            if(ri < 0 || ri >= readLen) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); } else sc = B.read_bases[rOff + ri];
+                        if(myOp[u] >= 0 && myOp[u] != 2) {
+                            const int ri = readB[u] + jr;
+                            if(ri < 0 || ri >= readLen) bad = 1; else scv[u] = B.read_bases[rOff + ri];
                         }
-                        const int j = baseCol + jr;
-                        if constexpr (LC::SHORT) { if(lv >= 0 && lv < lvBase) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); lv = -1; } else if(lv - lvBase >= 65534) { PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); lv = -1; } }
-                        P.lvl[0][j] = LC::put(lv, lvBase); P.g[0][j] = gc; P.s[0][j] = sc;
+                    }
+                    if(bad) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
+                    #pragma unroll
+                    for(int u = 0; u < PJ_U; u++) {
+                        if(myOp[u] >= 0) {
+                            int lv = lvv[u];
+                            const int j = baseCol + j0 + 64 * u + lane;
+                            if constexpr (LC::SHORT) { if(lv >= 0 && lv < lvBase) { PJ_FAIL(HLALA_CHAIN_ERR_INPUT); lv = -1; } else if(lv - lvBase >= 65534) { PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); lv = -1; } }
+                            P.lvl[0][j] = LC::put(lv, lvBase); P.g[0][j] = gcv[u]; P.s[0][j] = scv[u];
+                        }
                     }
                 }
                 baseCol += tc; baseRef += tr; baseRead += tq;
@@ -452,16 +483,29 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             // three bit masks per 64 columns (gap-stretch level / defined level / read character) carry all the step needs
             bool any = false; int seqChars = 0;
             const int nW = (n1 + 63) >> 6;
-            for(int k = 0; k < nW; k++) {
-                int j = k * 64 + lane; bool in = false, def = false, sq = false;
-                if(j < n1) {
-                    int l = LC::get(P.lvl[cur][j], lvBase); def = (l != -1); sq = (P.s[cur][j] != '_');
-                    if(def) { if(l < 0 || l >= G.L - 1) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); else in = G.gap_stretch[l] != 0; }
+            // (the gap-stretch flags of eight words of columns are requested together: the ballots made each word a round trip of its own)
+            constexpr int PJ_W = 8;
+            const int nLevelsG = G.L;
+            for(int k0 = 0; k0 < nW; k0 += PJ_W) {
+                unsigned char gs[PJ_W]; bool defv[PJ_W], sqv[PJ_W]; int bad = 0;
+                #pragma unroll
+                for(int u = 0; u < PJ_W; u++) {
+                    const int j = (k0 + u) * 64 + lane; gs[u] = 0; defv[u] = false; sqv[u] = false;
+                    if(k0 + u < nW && j < n1) {
+                        const int l = LC::get(P.lvl[cur][j], lvBase); defv[u] = (l != -1); sqv[u] = (P.s[cur][j] != '_');
+                        if(defv[u]) { if(l < 0 || l >= nLevelsG - 1) bad = 1; else gs[u] = G.gap_stretch[l]; }
+                    }
                 }
-                u64 mg = __ballot(in), md = __ballot(def), ms = __ballot(sq);
-                if(mg) any = true;
-                seqChars += __popcll(ms);
-                if(lane == 0) { P.mGap[k] = mg; P.mDef[k] = md; P.mSeq[k] = ms; }
+                if(bad) PJ_FAIL(HLALA_CHAIN_ERR_INPUT);
+                #pragma unroll
+                for(int u = 0; u < PJ_W; u++) {
+                    if(k0 + u < nW) {
+                        const u64 mg = __ballot(gs[u] != 0), md = __ballot(defv[u]), ms = __ballot(sqv[u]);
+                        if(mg) any = true;
+                        seqChars += __popcll(ms);
+                        if(lane == 0) { P.mGap[k0 + u] = mg; P.mDef[k0 + u] = md; P.mSeq[k0 + u] = ms; }
+                    }
+                }
             }
             WSYNC();
             if(any && PJ_OK()) {
@@ -525,10 +569,37 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 staged = (nDef <= PL::CAP) && (nodeEnd - nodeBase <= PL::SN) && (nEdges <= PL::SE);
                 // offsets of the window's levels (16-bit, relative to its first node): the segment-parallel and the chunked form both need them
                 windowed = (nDef <= PL::CAP) && (nodeEnd - nodeBase < 65536) && (nEdges < 65536);
-                if(windowed) for(int i = lane; i <= nDef + 1; i += 64) P.sLev[i] = (unsigned short)(G.level_off[level0 + i] - nodeBase);
+                if constexpr (!PL::LONG) {
+                    // level offsets and -- where the window fits the staging arrays -- its in-edge CSR: every load is requested before the first store (one round trip)
+                    constexpr int U1 = (PL::CAP + 2 + 63) / 64, U2 = (PL::SN + 1 + 63) / 64, U3 = (PL::SE + 63) / 64;
+                    int v1[U1], v2[U2]; FromLab v3[U3];
+                    if(windowed) {
+                        #pragma unroll
+                        for(int u = 0; u < U1; u++) { const int i = lane + 64 * u; if(i <= nDef + 1) v1[u] = G.level_off[level0 + i]; }
+                    }
+                    if(staged) {
+                        #pragma unroll
+                        for(int u = 0; u < U2; u++) { const int i = lane + 64 * u; if(i <= chCount) v2[u] = G.in_off[nb + i]; }
+                        #pragma unroll
+                        for(int u = 0; u < U3; u++) { const int e = lane + 64 * u; if(e < nEdges) { v3[u].from = G.in_from[eBase + e]; v3[u].lab = G.in_label[eBase + e]; } }
+                    }
+                    if(windowed) {
+                        #pragma unroll
+                        for(int u = 0; u < U1; u++) { const int i = lane + 64 * u; if(i <= nDef + 1) P.sLev[i] = (unsigned short)(v1[u] - nodeBase); }
+                    }
+                    if(staged) {
+                        #pragma unroll
+                        for(int u = 0; u < U2; u++) { const int i = lane + 64 * u; if(i <= chCount) P.sIn[i] = (unsigned short)(v2[u] - eBase); }
+                        #pragma unroll
+                        for(int u = 0; u < U3; u++) { const int e = lane + 64 * u; if(e < nEdges) { P.sFrom[e] = (unsigned short)(v3[u].from - nodeBase); P.sLab[e] = v3[u].lab; } }
+                    }
+                } else {
+                if(windowed) staged_rows<7>(lane, nDef + 2, 64, [&](int i) { return G.level_off[level0 + i]; }, [&](int i, int v) { P.sLev[i] = (unsigned short)(v - nodeBase); });
                 if(staged) {
-                    for(int i = lane; i <= chCount; i += 64) P.sIn[i] = (unsigned short)(G.in_off[nb + i] - eBase);
-                    for(int e = lane; e < nEdges; e += 64) { P.sFrom[e] = (unsigned short)(G.in_from[eBase + e] - nodeBase); P.sLab[e] = G.in_label[eBase + e]; }
+                    staged_rows<7>(lane, chCount + 1, 64, [&](int i) { return G.in_off[nb + i]; }, [&](int i, int v) { P.sIn[i] = (unsigned short)(v - eBase); });
+                    staged_rows<9>(lane, nEdges, 64, [&](int e) { FromLab r; r.from = G.in_from[eBase + e]; r.lab = G.in_label[eBase + e]; return r; },
+                                   [&](int e, FromLab r) { P.sFrom[e] = (unsigned short)(r.from - nodeBase); P.sLab[e] = r.lab; });
+                }
                 }
             }
         }
@@ -616,7 +687,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 // in-edges fit the staging arrays are loaded with coalesced reads (one round trip per chunk) and the levels of a chunk
                 // are solved out of LDS; the back pointers go to the wave's slab as before (window-relative CSR edge index).
                 // segStart[i] = first in-edge (window-relative) of the target nodes of level i, i = 0 .. nDef
-                for(int i = lane; i <= nDef; i += 64) P.segStart[i] = (unsigned short)(G.in_off[nodeBase + P.sLev[i + 1]] - eBase);
+                staged_rows<7>(lane, nDef + 1, 64, [&](int i) { return G.in_off[nodeBase + P.sLev[i + 1]]; }, [&](int i, int v) { P.segStart[i] = (unsigned short)(v - eBase); });
                 WSYNC();
                 const int nbR = nb - nodeBase;
                 int a = 0;
@@ -662,8 +733,9 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                     if(lane == 0) P.sChoice[nChunks] = (unsigned short)a;
                     nChunks++;
                     const int tBase = P.sLev[a + 1], nT = (int)P.sLev[b + 2] - tBase, eC = P.segStart[a], nE = (int)P.segStart[b + 1] - eC;
-                    for(int t = lane; t <= nT; t += 64) P.sIn[t] = (unsigned short)(G.in_off[nodeBase + tBase + t] - eBase - eC);
-                    for(int e = lane; e < nE; e += 64) { P.sFrom[e] = (unsigned short)(G.in_from[eBase + eC + e] - nodeBase); P.sLab[e] = G.in_label[eBase + eC + e]; }
+                    staged_rows<7>(lane, nT + 1, 64, [&](int t) { return G.in_off[nodeBase + tBase + t]; }, [&](int t, int v) { P.sIn[t] = (unsigned short)(v - eBase - eC); });
+                    staged_rows<9>(lane, nE, 64, [&](int e) { FromLab r; r.from = G.in_from[eBase + eC + e]; r.lab = G.in_label[eBase + eC + e]; return r; },
+                                   [&](int e, FromLab r) { P.sFrom[e] = (unsigned short)(r.from - nodeBase); P.sLab[e] = r.lab; });
                     WSYNC();
                     bool stop = false;
                     for(int i = a; i <= b; i++) {
@@ -757,12 +829,13 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         for(int i = b - 1; i >= a; i--) { int e = P.sChoice[t - nbR]; pick[P.colInfo[i] & 0xFFFFu] = e; t = P.sFrom[e]; }
                     }
                     WSYNC();
-                    for(int j = lane; j < n1; j += 64) {
-                        const typename PL::LvT pe = pick[j]; const int e = (int)pe;
-                        if(LC::pickIsNone(pe)) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
-                        else { B.seed_level[cb + j] = LC::get(P.lvl[cur][j], lvBase); B.seed_edge[cb + j] = G.in_eid[eBase + e]; B.seed_g[cb + j] = P.sLab[e]; }
-                        B.seed_s[cb + j] = P.s[cur][j];
-                    }
+                    staged_rows<6>(lane, n1, 64, [&](int j) { const typename PL::LvT pe = pick[j]; return LC::pickIsNone(pe) ? -1 : G.in_eid[eBase + (int)pe]; },
+                        [&](int j, int eid) {
+                            const typename PL::LvT pe = pick[j];
+                            if(LC::pickIsNone(pe)) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
+                            else { B.seed_level[cb + j] = LC::get(P.lvl[cur][j], lvBase); B.seed_edge[cb + j] = eid; B.seed_g[cb + j] = P.sLab[(int)pe]; }
+                            B.seed_s[cb + j] = P.s[cur][j];
+                        });
                 } else if(chunked) {
                     // the chunks again, last to first: the back pointers of a chunk's nodes are staged into LDS with coalesced reads, lane 0
                     // follows them there, then all lanes emit
@@ -778,18 +851,18 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                             if(lane == 0) { const ChoiceRec cr = ch[(int)P.sLev[a + 1] + z - nbR]; pick[P.colInfo[a] & 0xFFFFu] = cr.eid; z = cr.fromz; }
                         } else {
                             const int tBase = P.sLev[a + 1], nT = (int)P.sLev[b + 2] - tBase;
-                            for(int t = lane; t < nT; t += 64) { const ChoiceRec cr = ch[tBase + t - nbR]; P.sIn[t] = (unsigned short)cr.fromz; P.sFrom[t] = (unsigned short)cr.eid; }
+                            staged_rows<7>(lane, nT, 64, [&](int t) { return ch[tBase + t - nbR]; }, [&](int t, ChoiceRec cr) { P.sIn[t] = (unsigned short)cr.fromz; P.sFrom[t] = (unsigned short)cr.eid; });
                             WSYNC();
                             if(lane == 0) for(int i = b; i >= a; i--) { const int t = (int)P.sLev[i + 1] - tBase + z; pick[P.colInfo[i] & 0xFFFFu] = (int)P.sFrom[t]; z = (int)(short)P.sIn[t]; }
                         }
                         WSYNC();
                     }
-                    for(int j = lane; j < n1; j += 64) {
-                        const typename PL::LvT pe = pick[j]; const int e = (int)pe;
-                        if(LC::pickIsNone(pe)) { B.seed_level[cb + j] = -1; B.seed_edge[cb + j] = -1; B.seed_g[cb + j] = '_'; }
-                        else { B.seed_level[cb + j] = LC::get(P.lvl[cur][j], lvBase); B.seed_edge[cb + j] = G.in_eid[eBase + e]; B.seed_g[cb + j] = G.in_label[eBase + e]; }
-                        B.seed_s[cb + j] = P.s[cur][j];
-                    }
+                    staged_rows<6>(lane, n1, 64, [&](int j) { const typename PL::LvT pe = pick[j]; FromLab r; r.from = -1; r.lab = '_';
+                                                              if(!LC::pickIsNone(pe)) { r.from = G.in_eid[eBase + (int)pe]; r.lab = G.in_label[eBase + (int)pe]; } return r; },
+                        [&](int j, FromLab r) {
+                            B.seed_level[cb + j] = LC::pickIsNone(pick[j]) ? -1 : LC::get(P.lvl[cur][j], lvBase); B.seed_edge[cb + j] = r.from; B.seed_g[cb + j] = r.lab;
+                            B.seed_s[cb + j] = P.s[cur][j];
+                        });
                 } else if(lane == 0) {
                     int node = tb + zsel;
                     for(int j = n1 - 1; j >= 0; j--) {
