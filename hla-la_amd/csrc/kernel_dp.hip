@@ -1237,7 +1237,31 @@ __device__ inline int dp_select(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
     const u32 seed = rng_seed + (u32)guni<GW>(st.item);
     const int curMax = guni<GW>(st.curMax), firstMaxSlot = guni<GW>(st.firstMaxSlot), start_seq = guni<GW>(st.start_seq);
     int endSlot = -1, endScore = 0;
-    if(nCompleted > 0) {
+    if(GW <= 64 && nCompleted > 0 && nCompleted <= GW) {
+        // the common case -- at most one sequence-complete cell per lane: slot, score and key are read once (two dependent round trips; the passes below
+        // read them three times over, the tie ranking once more per pair of cells) and the ties rank each other through lane shuffles
+        int s = -1, sc0 = DP_NEG; u64 k = 0;
+        if(gl < nCompleted) { s = sl.completed()[gl]; const CellRec* cr = sl.cell() + s; sc0 = cr->sc[0]; k = cr->key; }
+        const int best = grp_max_i32<GW>(sc0);
+        const bool tie = gl < nCompleted && sc0 == best;
+        const int nTies = grp_sum_i32<GW>(tie ? 1 : 0);
+        u32 sd = seed;
+        const int selectedIndex = glibc_rand_r(&sd) % nTies;                                // Utilities.cpp:922-927
+        int found = -1;
+        if(nTies == 1) { if(tie) found = s; }
+        else {
+            // the tie with exactly `selectedIndex` ties before it in "x/z" string order
+            const int kx = key_x(k), kz = tie ? key_node(k) - G.level_off[kx] : 0;
+            const int l0 = (int)(lane_id() & ~(u32)(GW - 1));
+            int rank = 0;
+            for(int u = 0; u < nCompleted; u++) {
+                const int ux = __shfl(kx, l0 + u), uz = __shfl(kz, l0 + u), ut = __shfl(tie ? 1 : 0, l0 + u);
+                if(ut && u != gl && xz_less(ux, uz, kx, kz)) rank++;
+            }
+            if(tie && rank == selectedIndex) found = s;
+        }
+        endSlot = grp_max_i32<GW>(found); endScore = best;
+    } else if(nCompleted > 0) {
         int best = DP_NEG;
         for(int i = gl; i < nCompleted; i += GW) best = max(best, (int)sl.cell()[sl.completed()[i]].sc[0]);
         best = grp_max_i32<GW>(best);
@@ -1331,7 +1355,7 @@ __device__ inline int dp_backtrace(DpLdsT<C>& S, const DpSlabT<C>& sl, int maxSt
 // the left extension at its final place [seq_begin, seq_begin + n), the right extension right-aligned in the row
 // (k_stitch_chains moves it next to the seed once the left extension's length is known)
 template <class C>
-__device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, const DevBatch& B, const bool fwd)
+__device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGraph& G, const DevBatch& B, const int4* nrec, const bool fwd)
 {
     constexpr int GW = C::GW;
     const int gl = grp_lane<GW>();
@@ -1357,20 +1381,25 @@ __device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
         int kind = bt_kind(b);
         // resolve the graph object behind the rank j: the (j+1)-th edge of the previous cell's node that leads to this cell's node, or the (j+1)-th
         // entry of its jump table that does (degrees beyond two are rare and only the cells of the chosen path come here)
-        int pnode = 0, robj = -1;
+        // (the previous node's 32-byte record -- first edge, degree, the targets and labels of its first two edges, its first jump -- answers the common case
+        // in one round trip; the CSR offsets, the scan of the targets and the label of the edge were three dependent ones)
+        int pnode = 0, robj = -1, recLab = -1;
         if(act && kind != K_GGAP) {
             u64 pkey = sl.cell()[bt_prev(b)].key; pnode = key_node(pkey);
             const int node = key_node(xy);
             int j = bt_edge(b);
+            const int4 r0 = nrec[2 * (size_t)pnode], r1 = nrec[2 * (size_t)pnode + 1];
             if(kind == K_JUMP) {
-                const int* jo = fwd ? G.jf_off : G.jb_off; const int* jn = fwd ? G.jf_node : G.jb_node;
-                const int q1 = jo[pnode + 1]; int q = jo[pnode];
-                for(; q < q1; q++) if(jn[q] == node && j-- == 0) break;
+                const int* jn = fwd ? G.jf_node : G.jb_node;
+                const int nj = (int)((u32)r0.y >> 16); int q = r1.x; const int q1 = q + nj;
+                if(!(nj > 0 && r1.y == node && j == 0)) for(; q < q1; q++) if(jn[q] == node && j-- == 0) break;
                 if(q < q1) robj = (fwd ? G.jf_path : G.jb_path)[q];
             } else {
-                const int* eo = fwd ? G.out_off : G.in_off; const int* et = fwd ? G.out_to : G.in_from;
-                const int q1 = eo[pnode + 1]; int q = eo[pnode];
-                for(; q < q1; q++) if(et[q] == node && j-- == 0) break;
+                const int* et = fwd ? G.out_to : G.in_from;
+                const int deg = r0.y & 0xFFFF; int q = r0.x; const int q1 = q + deg;
+                if(deg > 0 && r0.z == node && j == 0) recLab = r1.w & 0xFF;
+                else if(deg > 1 && r0.w == node && j == ((r1.w >> 16) & 1)) { q++; recLab = (r1.w >> 8) & 0xFF; }
+                else for(; q < q1; q++) if(et[q] == node && j-- == 0) break;
                 if(q < q1) robj = (fwd ? G.out_eid : G.in_eid)[q];
             }
             if(robj < 0) { st.err = __LINE__; act = false; }        // (cannot happen: the rank was derived from these very arrays)
@@ -1388,9 +1417,10 @@ __device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
                 int eid = robj;
                 unsigned char sc = fwd ? (y >= 1 ? seqp[y - 1] : 0) : (y < max_seqI ? seqp[y] : 0);
                 int lvl = fwd ? x - 1 : x;
-                if(kind == K_DIAG) { oL[start] = lvl; oE[start] = eid; oG[start] = G.edge_label[eid]; oS[start] = sc; }
+                const unsigned char gch = kind == K_GGAP ? (unsigned char)'_' : (recLab >= 0 ? (unsigned char)recLab : G.edge_label[eid]);
+                if(kind == K_DIAG) { oL[start] = lvl; oE[start] = eid; oG[start] = gch; oS[start] = sc; }
                 else if(kind == K_GGAP) { oL[start] = -1; oE[start] = -1; oG[start] = '_'; oS[start] = sc; }
-                else { oL[start] = lvl; oE[start] = eid; oG[start] = G.edge_label[eid]; oS[start] = '_'; }
+                else { oL[start] = lvl; oE[start] = eid; oG[start] = gch; oS[start] = '_'; }
             }
         }
         base += total;
@@ -1561,7 +1591,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
             DP_T(4);
             if(phase == PH_BT) phase = dp_backtrace<C>(S, sl, DP_BT_STEPS_PER_TRIP, fwd);
             DP_T(3);
-            if(phase == PH_EXPAND) phase = dp_expand<C>(S, sl, G, B, fwd);
+            if(phase == PH_EXPAND) phase = dp_expand<C>(S, sl, G, B, fwd ? nrecOut : nrecIn, fwd);
             DP_T(2);
             if(phase == PH_DONE) {
                 // final bookkeeping of this DP in this class; a DP that outgrew the class is queued for the next one and leaves no trace
