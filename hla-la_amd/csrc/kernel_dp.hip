@@ -1698,34 +1698,24 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
         c0 = __builtin_amdgcn_readfirstlane(c0);
         if(c0 >= B.n_chains) break;
         const int cEnd = min(c0 + CHUNK, B.n_chains);
-        // the descriptors of the chunk's chains: lane q holds chain c0 + q -- two round trips for the chunk (the fields, then what the read index points
-        // to) instead of a chain of dependent wave-uniform loads per chain (status -> read -> deferred flag, read -> offsets: 60 % of this kernel's time)
-        int hSt = 0, hRead = 0, hNS = 0, hSB = 0, hSE = 0, hNL = 0, hNR = 0, hEL = 0, hER = 0, hDSB = 0, hDSE = 0, hR0 = 0, hR1 = 0, hDf = 0;
-        if(lane < CHUNK && c0 + lane < cEnd) {
-            const int cq = c0 + lane;
-            hSt = B.ext_status[cq]; hRead = B.chain_read[cq]; hNS = B.seed_ncols[cq]; hSB = B.seed_begin[cq]; hSE = B.seed_end[cq];
-            hNL = B.dp_ncols[2 * cq]; hNR = B.dp_ncols[2 * cq + 1]; hEL = B.dp_err[2 * cq]; hER = B.dp_err[2 * cq + 1]; hDSB = B.dp_sb[2 * cq]; hDSE = B.dp_se[2 * cq + 1];
-            hR0 = B.read_off[hRead]; hR1 = B.read_off[hRead + 1];
-            if(deferMode) hDf = deferPairs[hRead >> 1];
-        }
         for(int c = c0; c < cEnd; c++) {
         ST_T(0);
-        const int hq = c - c0;
         // (fused entry point: the chains of a pair with a DP call in one of the side-stream classes stay pending in the first pass; the second
         // pass, which may run beside the first one, takes exactly those)
-        bool mine = __builtin_amdgcn_readlane(hSt, hq) == EXT_PENDING;
-        if(mine && deferMode) { const bool df = __builtin_amdgcn_readlane(hDf, hq) != 0; mine = df == (deferMode == 2); }
+        bool mine = uni(B.ext_status[c]) == EXT_PENDING;
+        if(mine && deferMode) { const bool df = uni(deferPairs[uni(B.chain_read[c]) >> 1]) != 0; mine = df == (deferMode == 2); }
         if(mine) {
-        const int rOff = __builtin_amdgcn_readlane(hR0, hq), seqLen = __builtin_amdgcn_readlane(hR1, hq) - rOff;
+        const int r = uni(B.chain_read[c]);
+        const int rOff = uni(B.read_off[r]), seqLen = uni(B.read_off[r + 1]) - rOff;
         const size_t cb = (size_t)c * stride;
-        const int nSeed = __builtin_amdgcn_readlane(hNS, hq), sBegin = __builtin_amdgcn_readlane(hSB, hq), sEnd = __builtin_amdgcn_readlane(hSE, hq);
-        const int ncL = __builtin_amdgcn_readlane(hNL, hq), ncR = __builtin_amdgcn_readlane(hNR, hq);
-        const int errL = __builtin_amdgcn_readlane(hEL, hq), errR = __builtin_amdgcn_readlane(hER, hq);
+        const int nSeed = uni(B.seed_ncols[c]), sBegin = uni(B.seed_begin[c]), sEnd = uni(B.seed_end[c]);
+        const int ncL = uni(B.dp_ncols[2 * c]), ncR = uni(B.dp_ncols[2 * c + 1]);
+        const int errL = uni(B.dp_err[2 * c]), errR = uni(B.dp_err[2 * c + 1]);
         int err = 0;
         if(errL || errR) err = ((errL <= -1000000) || (errR <= -1000000)) ? HLALA_CHAIN_ERR_COLUMNS : HLALA_CHAIN_ERR_FRONTIER;
         const bool haveL = ncL >= 0 && !errL, haveR = ncR >= 0 && !errR;
         const int nL = haveL ? ncL : 0, nR = haveR ? ncR : 0;
-        const int newBegin = haveL ? __builtin_amdgcn_readlane(hDSB, hq) : sBegin, newEnd = haveR ? __builtin_amdgcn_readlane(hDSE, hq) : sEnd;
+        const int newBegin = haveL ? uni(B.dp_sb[2 * c]) : sBegin, newEnd = haveR ? uni(B.dp_se[2 * c + 1]) : sEnd;
         const int padL = newBegin, padR = seqLen - 1 - newEnd;
         const int total = padL + nL + nSeed + nR + padR;
         if(!err && total > stride) err = HLALA_CHAIN_ERR_COLUMNS;
@@ -1748,33 +1738,14 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
                 }
             }
         }
-        // (the loads of up to eight rows of 64 columns are requested before the first store: one round trip, not one per row)
-        {
-            struct StCol { int lv, ed; unsigned char g, s, kind; };           // kind 0: extension column, stays; 1: padding; 2: seed column
-            constexpr int ST_U = 8;
-            for(int jb = 0; jb < total; jb += 64 * ST_U) {
-                StCol v[ST_U];
-#pragma unroll
-                for(int u = 0; u < ST_U; u++) {
-                    const int j = jb + 64 * u + lane;
-                    v[u].lv = -1; v[u].ed = -1; v[u].g = '_'; v[u].s = '_'; v[u].kind = 0;
-                    if(j < total) {
-                        if(j < padL) { v[u].kind = 1; v[u].s = B.read_bases[rOff + j]; }
-                        else if(j < padL + nL) { }
-                        else if(j < padL + nL + nSeed) { const int q = j - padL - nL; v[u].kind = 2; v[u].lv = B.seed_level[cb + q]; v[u].ed = B.seed_edge[cb + q]; v[u].g = B.seed_g[cb + q]; v[u].s = B.seed_s[cb + q]; }
-                        else if(j < padL + nL + nSeed + nR) { }
-                        else { const int q = j - (padL + nL + nSeed + nR); v[u].kind = 1; v[u].s = B.read_bases[rOff + newEnd + 1 + q]; }
-                    }
-                }
-#pragma unroll
-                for(int u = 0; u < ST_U; u++) {
-                    const int j = jb + 64 * u + lane;
-                    if(j < total) {
-                        if(v[u].kind) { B.ext_level[cb + j] = v[u].lv; B.ext_edge[cb + j] = v[u].ed; B.ext_g[cb + j] = v[u].g; B.ext_s[cb + j] = v[u].s; }
-                        B.ext_fromseed[cb + j] = v[u].kind == 2 ? 1 : 0;
-                    }
-                }
-            }
+        for(int j = lane; j < total; j += 64) {
+            unsigned char fs = 0;
+            if(j < padL) { B.ext_level[cb + j] = -1; B.ext_edge[cb + j] = -1; B.ext_g[cb + j] = '_'; B.ext_s[cb + j] = B.read_bases[rOff + j]; }
+            else if(j < padL + nL) { }
+            else if(j < padL + nL + nSeed) { int q = j - padL - nL; B.ext_level[cb + j] = B.seed_level[cb + q]; B.ext_edge[cb + j] = B.seed_edge[cb + q]; B.ext_g[cb + j] = B.seed_g[cb + q]; B.ext_s[cb + j] = B.seed_s[cb + q]; fs = 1; }
+            else if(j < padL + nL + nSeed + nR) { }
+            else { int q = j - (padL + nL + nSeed + nR); B.ext_level[cb + j] = -1; B.ext_edge[cb + j] = -1; B.ext_g[cb + j] = '_'; B.ext_s[cb + j] = B.read_bases[rOff + newEnd + 1 + q]; }
+            B.ext_fromseed[cb + j] = fs;
         }
         WSYNC();
         ST_T(2);
@@ -1833,19 +1804,10 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
             double ll = carry;
             ST_T(3);
             // first / last two defined levels for the pairing stage (verboseSeedChain.h:134-228)
-            // (64 columns per round trip from either end; one lane walking the padding columns cost a round trip per column)
-            int f0 = -1, f1 = -1, l0 = -1, l1 = -1;
-            for(int j0 = 0; j0 < total && f1 < 0; j0 += 64) {
-                const int j = j0 + lane; const int lv = j < total ? B.ext_level[cb + j] : -1;
-                u64 m = __ballot(lv != -1);
-                while(m && f1 < 0) { const int v = __builtin_amdgcn_readlane(lv, __ffsll((long long)m) - 1); if(f0 < 0) f0 = v; else f1 = v; m &= m - 1; }
-            }
-            for(int j0 = 0; j0 < total && l1 < 0; j0 += 64) {
-                const int j = total - 1 - j0 - lane; const int lv = j >= 0 ? B.ext_level[cb + j] : -1;
-                u64 m = __ballot(lv != -1);
-                while(m && l1 < 0) { const int v = __builtin_amdgcn_readlane(lv, __ffsll((long long)m) - 1); if(l0 < 0) l0 = v; else l1 = v; m &= m - 1; }
-            }
             if(lane == 0) {
+                int f0 = -1, f1 = -1, l0 = -1, l1 = -1;
+                for(int j = 0; j < total && f1 < 0; j++) { int lv = B.ext_level[cb + j]; if(lv != -1) { if(f0 < 0) f0 = lv; else f1 = lv; } }
+                for(int j = total - 1; j >= 0 && l1 < 0; j--) { int lv = B.ext_level[cb + j]; if(lv != -1) { if(l0 < 0) l0 = lv; else l1 = lv; } }
                 B.ext_firstlast[4 * c + 0] = f0; B.ext_firstlast[4 * c + 1] = f1; B.ext_firstlast[4 * c + 2] = l0; B.ext_firstlast[4 * c + 3] = l1;
                 B.ext_status[c] = HLALA_CHAIN_OK; B.ext_ncols[c] = total; B.ext_begin[c] = 0; B.ext_end[c] = seqLen - 1; B.ext_ll[c] = ll;
                 accChains++; accCols += (u64)total;

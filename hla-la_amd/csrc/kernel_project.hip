@@ -892,7 +892,9 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         }
     }
     if(lane == 0) { if(accCols) atomicAdd(&B.counters[CNT_SEED_COLS], accCols); if(accEdges) atomicAdd(&B.counters[CNT_EDGES], accEdges); }
+#ifndef HLALA_DP_TIMING      // (the timing build of the DP kernels puts k_stitch_chains' clocks into the same counters)
     if(B.dbg && lane == 0) { for(int i = 0; i < 6; i++) atomicAdd(&B.counters[16 + i], (u64)tAcc[i]); atomicAdd(&B.counters[23], (u64)tAcc[6]); }
+#endif
 }
 
 }  // namespace hlala

@@ -27,12 +27,11 @@ print('retry ms', st.ms_extend_retry, 'dp main ms', st.ms_dp_main, 'retried', st
 
 pj = np.array(list(buf)[16:24], dtype=np.float64)
 if pj[7] > 0:
-    print('stitch cycles/chain (timing build): fetch+status %.0f descriptors %.0f stitch %.0f LL %.0f firstlast+out %.0f | chains %d' % tuple(list(pj[:5] / pj[7]) + [int(pj[7])]))
-    print('project cycles/chain: walk %.0f trim+pad %.0f clean %.0f restrict %.0f stage+dp %.0f backtrace %.0f | chains %d' % tuple(list(pj[:6] / pj[7]) + [int(pj[7])]))
+    # counters[16..23]: the projection's phase clocks (HLALA_DEBUG=1, default build) or, in the -DHLALA_DP_TIMING build, k_stitch_chains' (that build leaves the projection's out)
+    if d[6] > 0:
+        print('stitch cycles/chain (timing build): fetch+status %.0f descriptors %.0f stitch %.0f LL %.0f firstlast+out %.0f | chains %d' % tuple(list(pj[:5] / pj[7]) + [int(pj[7])]))
+    else:
+        print('project cycles/chain: walk %.0f trim+pad %.0f clean %.0f restrict %.0f stage+dp %.0f backtrace %.0f | chains %d' % tuple(list(pj[:6] / pj[7]) + [int(pj[7])]))
 hh = np.array(list(buf)[24:32], dtype=np.float64)
-if pj[7] > 0 and hh[4] > 0 and d[6] == 0:
-    print('project, chunked form, cycles/chain (all chains): set-up %.0f chunk staging %.0f node records %.0f level loops %.0f | chunks/chain %.2f' % tuple(list(hh[:4] / pj[7]) + [hh[4] / pj[7]]))
-    print('project, chunked form: %d chunks, %d solved level by level, %.1f levels and %.1f depth steps per chunk' % (hh[4], hh[6], hh[7] / max(hh[4], 1), hh[5] / max(hh[4], 1)))
-    hh[:] = 0
 if hh[0] > 0 and d[6] > 0:
     print('dp_iterate cycles/trip (group 0 of each wave; waitcnt(0) before each clock): header+records %.0f pushes %.0f tlist %.0f early-lookup %.0f evaluate-passes %.0f post-evaluate %.0f filter+writeback %.0f' % (hh[4]/d[6], hh[5]/d[6], hh[0]/d[6], hh[3]/d[6], hh[6]/d[6], hh[1]/d[6], hh[2]/d[6]))
