@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <thread>
 #include <atomic>
+#include <charconv>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -544,13 +545,20 @@ try {
         auto work = [&]() {
             for(;;) {
                 const long long c = next.fetch_add(1); if(c >= nChunks) break;
-                std::ostringstream os;
+                // (a double goes out as the stream's default format -- %g, six significant digits -- through std::to_chars(general, 6), which is defined
+                // as that printf conversion and six times as fast as operator<<; a value that is not finite takes the stream, whose spelling of it is the reference's)
+                std::string& out = parts[(size_t)c];
                 const long long k1 = std::min(nPairs, (c + 1) * CH);
+                out.reserve((size_t)(k1 - c * CH) * 64);
+                auto num = [&](double v) {
+                    if(std::isfinite(v)) { char b[40]; const auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::general, 6); out.append(b, r.ptr); }
+                    else { std::ostringstream os; os << v; out += os.str(); }
+                };
                 for(long long k = c * CH; k < k1; k++) {
                     const int cI = in->order[k];
-                    os << L->clusterId[c1Of[cI]] << "/" << L->clusterId[c2Of[cI]] << "\t" << in->p_normalized[cI] << "\t" << in->pair_ll[cI] << "\t" << in->mis_avg[cI] << "\n";
+                    out += L->clusterId[c1Of[cI]]; out += '/'; out += L->clusterId[c2Of[cI]]; out += '\t';
+                    num(in->p_normalized[cI]); out += '\t'; num(in->pair_ll[cI]); out += '\t'; num(in->mis_avg[cI]); out += '\n';
                 }
-                parts[(size_t)c] = os.str();
             }
         };
         unsigned T = std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 64) T = 64; if((long long)T > nChunks) T = (unsigned)nChunks;
