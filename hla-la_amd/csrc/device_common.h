@@ -22,6 +22,8 @@ struct DevGraph {
     const int* in_from;
     const uint8_t* in_label;
     const int* in_eid;
+    const unsigned int* in_rec; // [E] packed in-edge records of the projection's re-threading DP (flat_graph.hpp)
+    const uint8_t* level_fast;  // [L] the level can be solved edge-parallel (flat_graph.hpp)
     const int* edge_from_new;  // [E] by creation index
     const int* edge_to_new;    // [E]
     const uint8_t* edge_label; // [E] by creation index

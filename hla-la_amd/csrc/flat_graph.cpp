@@ -238,6 +238,30 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
                 r[7] = (deg > 0 ? lab[e0] : 0) | ((deg > 1 ? lab[e0 + 1] : 0) << 8) | ((deg > 1 && to[e0 + 1] == to[e0] ? 1 : 0) << 16);
             }
         };
+        // ---- in-edge records of the projection's re-threading DP (flat_graph.hpp)
+        F.in_rec.assign((size_t)F.E, 0);
+        F.level_fast.assign((size_t)F.L, 0);
+        for(int32_t lv = 1; lv < F.L; lv++) {
+            const int32_t n0 = F.level_off[lv], n1 = F.level_off[lv + 1];
+            if(n1 <= n0) continue;
+            const int32_t eFirst = F.in_off[n0], eEnd = F.in_off[n1];
+            const int32_t pFirst = F.in_off[F.level_off[lv - 1]];                 // first in-edge of the level before (its edge list starts there)
+            bool fast = (n1 - n0) <= 512; int maxd = 1;
+            for(int32_t t = n0; t < n1; t++) {
+                const int32_t e0 = F.in_off[t], e1 = F.in_off[t + 1];
+                if(e1 - e0 < 1 || e1 - e0 > 8) fast = false;
+                if(e1 - e0 > maxd) maxd = e1 - e0;
+                for(int32_t e = e0; e < e1; e++) {
+                    const int32_t from = F.in_from[e], flv = F.node_level[from], fz = from - F.level_off[flv];
+                    if(flv != lv - 1 || fz > 511) fast = false;
+                    const int32_t own = F.in_off[from + 1] - 1 - pFirst;         // (meaningful when the level before is solved in one slice as well: 0 .. 63)
+                    uint32_t r = ((uint32_t)fz & 511u) | (((uint32_t)own & 63u) << 9) | ((uint32_t)std::min(e - e0, 7) << 15) | ((uint32_t)F.in_label[e] << 18);
+                    if(e == e1 - 1) r |= 1u << 28;
+                    F.in_rec[(size_t)e] = r;
+                }
+            }
+            F.level_fast[(size_t)lv] = fast ? (uint8_t)(((eEnd - eFirst) <= 64 ? 1 : 2) | ((maxd - 1) << 2)) : 0;
+        }
         build(F.out_off, F.out_to, F.out_label, F.jf_off, F.jf_node, F.jf_lvl, F.nrec_out);
         build(F.in_off, F.in_from, F.in_label, F.jb_off, F.jb_node, F.jb_lvl, F.nrec_in);
         if(!recErr.empty()) return recErr;

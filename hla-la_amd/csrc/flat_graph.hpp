@@ -43,6 +43,14 @@ struct FlatGraph {
     // order the candidates of one target cell (candidates of different edges of one frontier cell only compete when they reach the same node), so the push
     // index of a candidate holds this rank -- a few bits -- instead of the edge number, and a node's degree is not limited by the width of that field.
     std::vector<uint8_t> out_prank, in_prank, jf_prank, jb_prank;
+    // one word per in-edge (CSR order) for the re-threading DP of the seed projection (kernel_project.hip, chunked form): the lanes of a wavefront take
+    // the in-edges of a level, not its nodes.  bits 0-8 rank of the from-node in its level; 9-14 the place, among the in-edges of the from-node's
+    // level, of the from-node's LAST in-edge (the lane that holds the from-node's score when that level was solved in one slice of 64 edges); 15-17 the
+    // edge's place among the in-edges of its target (0 .. 7); 18-25 label; 28 last in-edge of its target.
+    // level_fast[l]: 0 = the level is solved node by node; else bits 0-1 = 1: edge-parallel in one slice (at most 64 in-edges), 2: in several; bits 2-4 = largest
+    // in-degree - 1.  Edge-parallel needs: every node has one to eight in-edges, all from level l - 1, ranks below 512.
+    std::vector<uint32_t> in_rec;                // [E]
+    std::vector<uint8_t> level_fast;             // [L]
     // one 32-byte record per node and direction for the extension DP: {first CSR edge, degree | jumps << 16, target of edge 0,
     // target of edge 1, first jump-table entry, node of jump 0, level of jump 0, label 0 | label 1 << 8 | rank of edge 1 << 16}
     std::vector<int32_t> nrec_out, nrec_in;      // [8*N]

@@ -340,7 +340,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
 #define UPG(field, vec) do { rc = dev_upload(c, c->allocs, (vec).data(), (vec).size(), (std::remove_const<std::remove_pointer<decltype(G.field)>::type>::type**)&G.field); if(rc) return fail(rc); } while(0)
     UPG(level_off, F.level_off); UPG(node_level, F.node_level); UPG(node_orig, F.node_orig);
     UPG(out_off, F.out_off); UPG(out_to, F.out_to); UPG(out_label, F.out_label); UPG(out_eid, F.out_eid);
-    UPG(in_off, F.in_off); UPG(in_from, F.in_from); UPG(in_label, F.in_label); UPG(in_eid, F.in_eid);
+    UPG(in_off, F.in_off); UPG(in_from, F.in_from); UPG(in_label, F.in_label); UPG(in_eid, F.in_eid); UPG(in_rec, F.in_rec); UPG(level_fast, F.level_fast);
     UPG(edge_from_new, F.edge_from_new); UPG(edge_to_new, F.edge_to_new); UPG(edge_label, edge_label);
     UPG(jf_off, F.jf_off); UPG(jf_node, F.jf_node); UPG(jf_path, F.jf_path);
     UPG(jb_off, F.jb_off); UPG(jb_node, F.jb_node); UPG(jb_path, F.jb_path);
@@ -402,6 +402,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if((rc = slab_pool(&c->large_slabs, c->large_slab_bytes * (size_t)(c->broad_grid + c->retry_grid), "large-class DP slabs"))) return fail(rc);       // broad blocks first, then the large ones
     if((rc = slab_pool(&c->huge_slabs, c->huge_slab_bytes * (size_t)c->huge_grid, "in-memory DP class"))) return fail(rc);
     c->proj_grid = cus * (c->params.max_columns <= PROJ_CAP_SHORT ? 14 : 10); c->pair_grid = cus * 20;
+    if(const char* e = getenv("HLALA_PROJ_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 14) c->proj_grid = cus * w; }      // (experiment: waves of the projection kernel per CU)
     { int rcp = dev_alloc(c, c->allocs, (size_t)2 * c->pair_grid * PAIR_COMB, &c->pair_scratch, false); if(rcp) return fail(rcp); }
     if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
         c->proj_grid = cus * 4;

@@ -39,8 +39,12 @@ struct __align__(16) ProjLdsT {
     unsigned short sLev[CAP_ + 2];          // level_off[level0 + i] - nodeBase
     unsigned short sIn[SN_ + 1];            // in_off[tgtBase + i] - eBase
     unsigned short sChoice[SN_];            // per target node: chosen in-edge (index into the window), 0xFFFF = unreachable
-    unsigned short sFrom[SE_];              // in_from[eBase + e] - nodeBase
-    unsigned char sLab[SE_];
+    static constexpr int CE = (3 * SE_) / 4;        // in-edges of a chunk of the chunked form (its packed records share the bytes of sFrom and sLab)
+    union {
+        struct { unsigned short sFrom[SE_];     // in_from[eBase + e] - nodeBase
+                 unsigned char sLab[SE_]; };
+        u32 eRec[CE];                       // chunked form: DevGraph::in_rec of the chunk's in-edges
+    };
     u32 colInfo[CAP_];                      // per level of the window: column | read char << 16 | seed-is-match << 24
     unsigned short segStart[CAP_ + 2];      // level indices where a DP segment starts (single-node levels, see below)
     u64 mGap[CAP_ / 64], mDef[CAP_ / 64], mSeq[CAP_ / 64];     // column bit masks of the restrict step
@@ -61,6 +65,7 @@ constexpr int PROJL_SE  = 57344;    // in-edges of the level window
 struct __align__(16) ProjLdsLong {
     static constexpr int CAP = PROJL_CAP, SN = PROJL_SN, SE = PROJL_SE; static constexpr bool LONG = true;
     typedef int LvT;                        // absolute levels, -1 = none
+    static constexpr int CE = PROJL_SE;
     int* lvl[2];
     unsigned char* g[2]; unsigned char* s[2];
     short Srow[2][PROJ_NODES];
@@ -167,6 +172,7 @@ __device__ __forceinline__ void staged_rows(int first, int end, int step, LoadF 
 }
 struct FromLab { int from; unsigned char lab; };
 
+// colInfo, chunked form: bits 25-29 = DevGraph::level_fast of the level (25-26: 1 = edge-parallel in one slice of 64 in-edges, 2 = in several, 0 = node by node; 27-29: largest in-degree - 1)
 #define PJ_FAIL(code) do { if(P.err == 0) P.err = (code); } while(0)
 #define PJ_T(i) do { if(B.dbg) tPh[i] = clock64(); } while(0)      // HLALA_DEBUG phase clocks -> counters[16..23]
 #define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
     const int stride = B.stride;
 
     long long tAcc[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long tSub[4] = {0, 0, 0, 0};          // HLALA_DEBUG: chunked form -- chunk staging, level loops, chunks, levels
     u64 accCols = 0, accEdges = 0;           // work counters, flushed once per wave (same-address atomics serialise at the L2)
     constexpr int CHUNK = 4;                 // chains drawn per atomic
     for(;;) {
@@ -687,13 +694,16 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 // in-edges fit the staging arrays are loaded with coalesced reads (one round trip per chunk) and the levels of a chunk
                 // are solved out of LDS; the back pointers go to the wave's slab as before (window-relative CSR edge index).
                 // segStart[i] = first in-edge (window-relative) of the target nodes of level i, i = 0 .. nDef
-                staged_rows<7>(lane, nDef + 1, 64, [&](int i) { return G.in_off[nodeBase + P.sLev[i + 1]]; }, [&](int i, int v) { P.segStart[i] = (unsigned short)(v - eBase); });
+                // (with it, in the same round trip: whether a level can be solved edge-parallel, DevGraph::level_fast -> bit 25 of colInfo)
+                staged_rows<7>(lane, nDef + 1, 64, [&](int i) { int2 r; r.x = G.in_off[nodeBase + P.sLev[i + 1]]; r.y = (!PL::LONG && i < nDef) ? (int)G.level_fast[level0 + i + 1] : 0; return r; },
+                               [&](int i, int2 r) { P.segStart[i] = (unsigned short)(r.x - eBase); if(!PL::LONG && i < nDef && r.y) P.colInfo[i] |= (u32)r.y << 25; });
                 WSYNC();
                 const int nbR = nb - nodeBase;
                 int a = 0;
                 while(a < nDef && PJ_OK()) {
                     const int cand = a + lane;
-                    const bool fits = cand < nDef && ((int)P.sLev[cand + 2] - (int)P.sLev[a + 1]) <= PL::SN && ((int)P.segStart[cand + 1] - (int)P.segStart[a]) <= PL::SE;
+                    // (chunked form of the LDS layouts: at most 62 levels, whose offsets ride in the lanes of a register)
+                    const bool fits = cand < nDef && (PL::LONG || lane < 62) && ((int)P.sLev[cand + 2] - (int)P.sLev[a + 1]) <= PL::SN && ((int)P.segStart[cand + 1] - (int)P.segStart[a]) <= PL::CE;
                     const u64 fm = __ballot(fits);
                     const int cnt = (fm == ~0ull) ? 64 : (__ffsll((long long)~fm) - 1);        // levels a .. a + cnt - 1 fit together (a prefix: both sums grow)
                     if(cnt == 0) {
@@ -729,15 +739,20 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         a++;
                         continue;
                     }
+                    const long long tC0 = B.dbg ? clock64() : 0;
                     const int b = a + cnt - 1;
                     if(lane == 0) P.sChoice[nChunks] = (unsigned short)a;
                     nChunks++;
                     const int tBase = P.sLev[a + 1], nT = (int)P.sLev[b + 2] - tBase, eC = P.segStart[a], nE = (int)P.segStart[b + 1] - eC;
                     staged_rows<7>(lane, nT + 1, 64, [&](int t) { return G.in_off[nodeBase + tBase + t]; }, [&](int t, int v) { P.sIn[t] = (unsigned short)(v - eBase - eC); });
+                    if constexpr (PL::LONG) {
                     staged_rows<9>(lane, nE, 64, [&](int e) { FromLab r; r.from = G.in_from[eBase + eC + e]; r.lab = G.in_label[eBase + eC + e]; return r; },
                                    [&](int e, FromLab r) { P.sFrom[e] = (unsigned short)(r.from - nodeBase); P.sLab[e] = r.lab; });
+                    } else staged_rows<9>(lane, nE, 64, [&](int e) { return G.in_rec[eBase + eC + e]; }, [&](int e, u32 r) { P.eRec[e] = r; });
                     WSYNC();
+                    const long long tC1 = B.dbg ? clock64() : 0;
                     bool stop = false;
+                    if constexpr (PL::LONG) {
                     for(int i = a; i <= b; i++) {
                         const u32 ci = P.colInfo[i];
                         const unsigned char sc = (unsigned char)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
@@ -766,6 +781,119 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         rowP = 1 - rowP;
                         WSYNC();
                     }
+                    } else {
+                    // The levels of the chunk, one after the other, with the lanes on the level's IN-EDGES (DevGraph::in_rec, staged above), not on its nodes.
+                    // What bounds this loop is the latency of ONE wave per level (the time per level does not depend on how many waves share the CU:
+                    // profiles/r03_experiments.txt), i.e. the dependent LDS round trips and branches of a level, so a level is cut down to one:
+                    //   - a lane's edge fetches the score of its from-node from the LANE that computed it one level earlier (ds_bpermute; the place of that
+                    //     lane is a static property of the graph and part of the edge's record) -- from the LDS row only after a level solved the other way;
+                    //   - the candidates of the (at most eight) in-edges of a node sit in neighbouring lanes and are combined with DPP shifts (as many as the level's largest in-degree - 1): the key
+                    //     orders by score, then by the EARLIER edge (first maximum = smallest edge, as the node-by-node loop takes it), and carries the from-node;
+                    //   - the lane of a node's last in-edge holds the node's score, writes it to the row (for whoever needs it there) and the back pointer to the slab;
+                    //   - the level's offsets, first in-edges, read characters and "can be solved this way" flags (DevGraph::level_fast) ride in the lanes
+                    //     of four registers (readlane: no LDS round trip), the next level's records are requested a level ahead.
+                    // A level with more than 64 in-edges takes overlapping slices (below); one with a node without in-edges or with more than eight is solved node by
+                    // node as before (3 % of the levels of Graph M's gene windows).
+                    const int lvReg = lane <= cnt + 1 ? (int)P.sLev[a + lane] : 0;
+                    const int sgReg = lane <= cnt ? (int)P.segStart[a + lane] - eC : 0;
+                    const u32 ciReg = lane < cnt ? P.colInfo[a + lane] : 0u;
+                    bool prevFast = false; int sReg = -1;
+                    u32 recN = 0;
+                    { const int nE0 = __builtin_amdgcn_readlane(sgReg, 1) - __builtin_amdgcn_readlane(sgReg, 0); if(lane < nE0 && nE0 <= 64) recN = P.eRec[__builtin_amdgcn_readlane(sgReg, 0) + lane]; }
+                    for(int k = 0; k < cnt; k++) {
+                        const u32 ci = (u32)__builtin_amdgcn_readlane((int)ciReg, k);
+                        const int sc = (int)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
+                        const int l1 = __builtin_amdgcn_readlane(lvReg, k + 1), tm = __builtin_amdgcn_readlane(lvReg, k + 2) - l1;
+                        const int eL0 = __builtin_amdgcn_readlane(sgReg, k), eL1 = __builtin_amdgcn_readlane(sgReg, k + 1), nEl = eL1 - eL0;
+                        const int mode = (int)((ci >> 25) & 3u), maxd = (int)((ci >> 27) & 7u);
+                        const u32 rec = recN;
+                        if(k + 1 < cnt) { const int nEn = __builtin_amdgcn_readlane(sgReg, k + 2) - eL1; recN = (lane < nEn && nEn <= 64) ? P.eRec[eL1 + lane] : 0u; }
+                        if(tm > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); stop = true; break; }
+                        bool reached = false;
+                        // candidate of the lane's edge -> key; the keys of a node's in-edges (neighbouring lanes) -> the key of its best edge, in the lane of its last one
+                        auto edge_key = [&](const u32 r, const int sp, const bool mine) -> int {
+                            const int m = (int)((r >> 18) & 0xFFu) == sc ? 1 : 0;
+                            const int cand = (mine && sp >= 0 && (m || !seedIsMatch)) ? sp + m + 1 : 0;       // 0: not admitted (:2803-2809) or from-node unreachable; else score + 1
+                            return (cand << 15) | ((63 - lane) << 9) | (int)(r & 511u);
+                        };
+                        auto node_key = [&](const u32 r, const int key) -> int {
+                            const int pos = (int)((r >> 15) & 7u);
+                            int bk = key, kj = key;
+                            for(int j = 1; j <= maxd; j++) { kj = __builtin_amdgcn_update_dpp(0, kj, 0x138, 0xF, 0xF, false); if(pos >= j) bk = max(bk, kj); }      // wave_shr:1 -- the edge j places before
+                            return bk;
+                        };
+                        if(mode == 1) {
+                            const bool mine = lane < nEl;
+                            int sp;
+                            if(prevFast) sp = __builtin_amdgcn_ds_bpermute((int)(((rec >> 9) & 63u) << 2), sReg);
+                            else sp = (int)P.Srow[rowP][rec & 511u];
+                            const int bk = node_key(rec, edge_key(rec, sp, mine));
+                            const bool last = mine && (rec & (1u << 28)) != 0;
+                            const u64 lastMask = __ballot(last);
+                            const int best = (bk >> 15) - 1;
+                            sReg = best;
+                            if(last) {
+                                const int tz = (int)__builtin_amdgcn_mbcnt_hi((u32)(lastMask >> 32), __builtin_amdgcn_mbcnt_lo((u32)lastMask, 0u));      // the node's rank in its level
+                                ChoiceRec cr; cr.eid = best >= 0 ? eC + eL0 + 63 - ((bk >> 9) & 63) : -1; cr.fromz = (short)(best >= 0 ? (bk & 511) : -1); cr.S = (short)best;
+                                P.Srow[1 - rowP][tz] = (short)best;
+                                ch[l1 + tz - nbR] = cr;
+                                reached = best >= 0;
+                            }
+                            if(lane == 0) edgesTouched += (u64)nEl;
+                            prevFast = true;
+                        } else if(mode == 2) {
+                            // more than 64 in-edges: slices of 64 that overlap by seven lanes, so that a node whose last in-edge lies in a slice's lanes 7 .. 63 has all
+                            // its (at most eight) in-edges in that slice; the lanes 0 .. 6 of a later slice only provide them
+                            int nodesDone = 0;
+                            for(int s0 = 0; s0 == 0 || s0 + 7 < nEl; s0 += 57) {
+                                const bool mine = s0 + lane < nEl;
+                                const u32 r = mine ? P.eRec[eL0 + s0 + lane] : 0u;
+                                const int sp = (int)P.Srow[rowP][r & 511u];
+                                const int bk = node_key(r, edge_key(r, sp, mine));
+                                const bool last = mine && (r & (1u << 28)) != 0 && (s0 == 0 || lane >= 7);
+                                const u64 lastMask = __ballot(last);
+                                if(last) {
+                                    const int best = (bk >> 15) - 1;
+                                    const int tz = nodesDone + (int)__builtin_amdgcn_mbcnt_hi((u32)(lastMask >> 32), __builtin_amdgcn_mbcnt_lo((u32)lastMask, 0u));
+                                    ChoiceRec cr; cr.eid = best >= 0 ? eC + eL0 + s0 + 63 - ((bk >> 9) & 63) : -1; cr.fromz = (short)(best >= 0 ? (bk & 511) : -1); cr.S = (short)best;
+                                    P.Srow[1 - rowP][tz] = (short)best;
+                                    ch[l1 + tz - nbR] = cr;
+                                    if(best >= 0) reached = true;
+                                }
+                                nodesDone += (int)__popcll(lastMask);
+                            }
+                            if(lane == 0) edgesTouched += (u64)nEl;
+                            prevFast = false;
+                        } else {
+                            const int t0 = l1 - tBase;
+                            for(int z = lane; z < tm; z += 64) {
+                                const int t = t0 + z;
+                                int best = -1, bestE = -1, bestFrom = -1;
+                                const int e0 = P.sIn[t], e1 = P.sIn[t + 1];
+                                for(int e = e0; e < e1; e++) {                               // in-edges in creation order: first maximum = smallest edge
+                                    const u32 r = P.eRec[e];
+                                    const int fz = (int)(r & 511u);
+                                    const int sp = P.Srow[rowP][fz];
+                                    if(sp < 0) continue;
+                                    const int lab = (int)((r >> 18) & 0xFFu);
+                                    if(seedIsMatch && lab != sc) continue;                    // :2803-2809
+                                    const int cd = sp + (lab == sc ? 1 : 0);
+                                    if(cd > best) { best = cd; bestE = eC + e; bestFrom = fz; }
+                                }
+                                edgesTouched += (u64)(e1 - e0);
+                                P.Srow[1 - rowP][z] = (short)best;
+                                ChoiceRec cr; cr.eid = bestE; cr.fromz = (short)bestFrom; cr.S = (short)best;
+                                ch[tBase + t - nbR] = cr;
+                                if(best >= 0) reached = true;
+                            }
+                            prevFast = false;
+                        }
+                        if(!__ballot(reached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); stop = true; break; }  // assert(seedChain_backtrack_*.size() > 0)
+                        rowP = 1 - rowP;
+                        WSYNC();
+                    }
+                    }
+                    if(B.dbg) { tSub[0] += tC1 - tC0; tSub[1] += clock64() - tC1; tSub[2]++; tSub[3] += cnt; }
                     if(stop) break;
                     a = b + 1;
                 }
@@ -894,6 +1022,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
     if(lane == 0) { if(accCols) atomicAdd(&B.counters[CNT_SEED_COLS], accCols); if(accEdges) atomicAdd(&B.counters[CNT_EDGES], accEdges); }
 #ifndef HLALA_DP_TIMING      // (the timing build of the DP kernels puts k_stitch_chains' clocks into the same counters)
     if(B.dbg && lane == 0) { for(int i = 0; i < 6; i++) atomicAdd(&B.counters[16 + i], (u64)tAcc[i]); atomicAdd(&B.counters[23], (u64)tAcc[6]); }
+    if(B.dbg && lane == 0) for(int i = 0; i < 4; i++) atomicAdd(&B.counters[24 + i], (u64)tSub[i]);
 #endif
 }
 

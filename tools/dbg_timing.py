@@ -33,5 +33,8 @@ if pj[7] > 0:
     else:
         print('project cycles/chain: walk %.0f trim+pad %.0f clean %.0f restrict %.0f stage+dp %.0f backtrace %.0f | chains %d' % tuple(list(pj[:6] / pj[7]) + [int(pj[7])]))
 hh = np.array(list(buf)[24:32], dtype=np.float64)
+if pj[7] > 0 and d[6] == 0 and hh[2] > 0:
+    print('project, chunked form: chunk staging %.0f and level loops %.0f cycles/chain (all chains); %.2f chunks/chain, %.1f levels/chunk, %.0f cycles/level' % (hh[0] / pj[7], hh[1] / pj[7], hh[2] / pj[7], hh[3] / hh[2], hh[1] / hh[3]))
+    hh[:] = 0
 if hh[0] > 0 and d[6] > 0:
     print('dp_iterate cycles/trip (group 0 of each wave; waitcnt(0) before each clock): header+records %.0f pushes %.0f tlist %.0f early-lookup %.0f evaluate-passes %.0f post-evaluate %.0f filter+writeback %.0f' % (hh[4]/d[6], hh[5]/d[6], hh[0]/d[6], hh[3]/d[6], hh[6]/d[6], hh[1]/d[6], hh[2]/d[6]))

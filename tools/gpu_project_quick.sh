@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 L=gpurun_out/r3_project_ab.log
 echo "== $(date) quick ${1:-}" | tee -a $L
-for rg in 1 0; do
+for rg in 1; do
 for cfg in "262144 5000000 m 1.0" "1048576 5000000 m 0.3"; do
   echo "-- HLALA_RETHREAD_GROUPS=$rg $cfg" | tee -a $L
   ( HLALA_RETHREAD_GROUPS=$rg HLALA_DEBUG=1 timeout 900 python tools/dbg_timing.py $cfg 2>&1 | grep -E "^ms |project" ) | tee -a $L
