@@ -68,6 +68,7 @@ struct hlala_ctx {
     char* lane_slabs = nullptr; int lane_grid = 0;      // the lane-per-DP class in front of the 16-lane class (kernel_dp_lane.hip); lane_grid 0: not used (HLALA_DP_LANE=0)
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
+    char* rethread_slabs = nullptr; size_t rethread_slab_bytes = 0; int rethread_grid = 0;      // k_rethread_chains: back pointers of one chain per wave (short reads; HLALA_RETHREAD=0 turns the kernel off)
     double* pair_scratch = nullptr;   // [2 * pair_grid][PAIR_COMB]: combination tables of the rare pairs with more than PAIR_COMB_LDS combinations (main- and side-stream pass)
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
     int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
@@ -413,6 +414,19 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->proj_slab_bytes = proj_slab_bytes_host(c->params.max_columns, F.max_nodes_per_level);
     if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
+    if(!c->proj_long_slabs) {
+        const char* e = getenv("HLALA_RETHREAD");
+        if(!(e && atoi(e) == 0)) {
+            // a chain of that kernel has at most RT_SN nodes per level: its window holds at most max_columns * RT_SN nodes
+            size_t ent = (size_t)c->params.max_columns * (size_t)RT_SN; if(ent < 1024) ent = 1024;
+            c->rethread_slab_bytes = (ent * sizeof(ChoiceRec) + 255) & ~(size_t)255;
+            if(c->rethread_slab_bytes > c->proj_slab_bytes) c->rethread_slab_bytes = c->proj_slab_bytes;
+            int wv = 24; if(const char* w = getenv("HLALA_RETHREAD_WAVES")) { const int v = atoi(w); if(v >= 1 && v <= 24) wv = v; }
+            c->rethread_grid = cus * wv;
+            if(hipMalloc((void**)&c->rethread_slabs, c->rethread_slab_bytes * (size_t)c->rethread_grid) != hipSuccess) { c->err = "hipMalloc(re-threading slabs) failed"; return fail(HLALA_E_DEVICE); }
+            c->allocs.push_back(c->rethread_slabs);
+        }
+    }
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
     if(hipEventCreateWithFlags(&c->evSideTail, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); }
@@ -663,15 +677,19 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
         int grid = B.n_chains < c->proj_grid ? B.n_chains : c->proj_grid;
         if(c->proj_long_slabs)
             hipLaunchKernelGGL((k_project_chains<ProjLdsLong>), dim3(grid), dim3(64), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
-                               c->proj_slabs, c->proj_slab_bytes, c->proj_long_slabs, c->proj_long_slab_bytes);
+                               c->proj_slabs, c->proj_slab_bytes, c->proj_long_slabs, c->proj_long_slab_bytes, 0);
         else
             if(c->params.max_columns <= PROJ_CAP_SHORT)
                 hipLaunchKernelGGL((k_project_chains<ProjLdsShort>), dim3(grid), dim3(64), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
-                                   c->proj_slabs, c->proj_slab_bytes, (char*)nullptr, (size_t)0);
+                                   c->proj_slabs, c->proj_slab_bytes, (char*)nullptr, (size_t)0, c->rethread_slabs ? 1 : 0);
             else
                 hipLaunchKernelGGL((k_project_chains<ProjLds>), dim3(grid), dim3(64), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
-                               c->proj_slabs, c->proj_slab_bytes, (char*)nullptr, (size_t)0);
+                               c->proj_slabs, c->proj_slab_bytes, (char*)nullptr, (size_t)0, c->rethread_slabs ? 1 : 0);
         int rc = check_launch(c, "k_project_chains"); if(rc) return rc;
+        if(c->rethread_slabs) {
+            hipLaunchKernelGGL(k_rethread_chains, dim3(c->rethread_grid), dim3(64), 0, c->active, c->dG, b->dB, c->rethread_slabs, c->rethread_slab_bytes);
+            rc = check_launch(c, "k_rethread_chains"); if(rc) return rc;
+        }
     }
     HIP_TRY(c, hipEventRecord(b->ev[1], c->active));
     b->staged |= 1;

@@ -25,6 +25,11 @@ constexpr int PROJ_SEGMAX = 24;     // longest run of multi-node levels one lane
 
 struct ChoiceRec { int eid; short fromz; short S; };
 
+// k_rethread_chains (below): the chunked form of the re-threading DP in a kernel of its own, with a fraction of the LDS and registers of k_project_chains
+constexpr int RT_SN = 416;          // nodes of a chunk of levels (and of one level)
+constexpr int RT_CE = 512;          // in-edges of a chunk (and of one level)
+constexpr int CHAIN_RETHREAD_PENDING = 64;     // seed_status between the two kernels (never leaves the stage)
+
 
 // (CAP_ = columns held; two sizes are instantiated: 512 and -- for params.max_columns <= 384, the default of the paired path -- 384, whose
 // 14.5 KB let 11 waves share a CU's LDS instead of 9: the kernel waits on memory two thirds of its cycles)
@@ -179,7 +184,8 @@ struct FromLab { int from; unsigned char lab; };
 
 template <class PL>
 __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
-                                                       const int* contig_level, char* slabs, size_t slabBytes, char* longSlabs, size_t longSlabBytes)
+                                                       const int* contig_level, char* slabs, size_t slabBytes, char* longSlabs, size_t longSlabBytes,
+                                                       int deferRethread)      // 1: chains that need the chunked form and fit k_rethread_chains are left to it
 {
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         // segments are a few levels long.  Windows that do not fit the LDS staging, that contain a segment longer than
         // PROJ_SEGMAX levels, or in which a segment hits the "no node reachable" assert, run the column-sequential form below.
         int level0 = -1, nb = 0, chCount = 0; ChoiceRec* ch = slabCh;
-        int nDef = 0, nodeBase = 0, eBase = 0, nEdges = 0; bool staged = false, par = false, windowed = false, chunked = false; int defCount = 0, nChunks = 0;
+        int nDef = 0, nodeBase = 0, eBase = 0, nEdges = 0; bool staged = false, par = false, windowed = false, chunked = false, deferred = false; int defCount = 0, nChunks = 0;
         if(PJ_OK()) {
             level0 = uni(LC::get(P.lvl[cur][0], lvBase));
             int lastLevel = uni(LC::get(P.lvl[cur][n1 - 1], lvBase));
@@ -698,8 +704,32 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 staged_rows<7>(lane, nDef + 1, 64, [&](int i) { int2 r; r.x = G.in_off[nodeBase + P.sLev[i + 1]]; r.y = (!PL::LONG && i < nDef) ? (int)G.level_fast[level0 + i + 1] : 0; return r; },
                                [&](int i, int2 r) { P.segStart[i] = (unsigned short)(r.x - eBase); if(!PL::LONG && i < nDef && r.y) P.colInfo[i] |= (u32)r.y << 25; });
                 WSYNC();
+                if constexpr (!PL::LONG) if(deferRethread) {
+                    // The level loop below is bound by the latency of one wave per level (its time per level does not depend on how many waves share the CU),
+                    // so what it needs is MORE WAVES -- and this kernel's 11.7 KB of LDS and 120 VGPRs allow 14 per CU.  A chain whose levels all fit the
+                    // staging arrays of k_rethread_chains goes there (5 KB, half the registers): its columns go out as they are (the graph character of the seed
+                    // stays in seed_g for now), colInfo rides in its seed_edge slots, the window's level offsets and first in-edges in its (still unused)
+                    // ext_level / ext_edge rows, the window's scalars in its DP item slots.
+                    int mxN = nb - nodeBase, mxE = 0;
+                    for(int i = lane; i < nDef; i += 64) { mxN = max(mxN, (int)P.sLev[i + 2] - (int)P.sLev[i + 1]); mxE = max(mxE, (int)P.segStart[i + 1] - (int)P.segStart[i]); }
+                    mxN = wave_max_i32(mxN); mxE = wave_max_i32(mxE);
+                    if(mxN <= RT_SN && mxE <= RT_CE) {
+                        deferred = true;
+                        const size_t cb = (size_t)c * stride;
+                        for(int j = lane; j < n1; j += 64) { B.seed_level[cb + j] = LC::get(P.lvl[cur][j], lvBase); B.seed_g[cb + j] = P.g[cur][j]; B.seed_s[cb + j] = P.s[cur][j]; }
+                        for(int i = lane; i < nDef; i += 64) B.seed_edge[cb + i] = (int)P.colInfo[i];
+                        unsigned short* lvRow = (unsigned short*)(B.ext_level + cb); unsigned short* sgRow = (unsigned short*)(B.ext_edge + cb);
+                        for(int i = lane; i <= nDef + 1; i += 64) lvRow[i] = P.sLev[i];
+                        for(int i = lane; i <= nDef; i += 64) sgRow[i] = P.segStart[i];
+                        if(lane == 0) {
+                            B.seed_ncols[c] = n1; B.seed_begin[c] = P.startRaw; B.seed_end[c] = P.stopRaw; B.seed_removed[c] = removed; B.seed_status[c] = CHAIN_RETHREAD_PENDING;
+                            int* st = (int*)B.dp_items + (size_t)c * 16;
+                            *(int4*)st = make_int4(level0, nDef, nodeBase, nb); st[4] = eBase; st[5] = n1;
+                        }
+                    }
+                }
                 const int nbR = nb - nodeBase;
-                int a = 0;
+                int a = deferred ? nDef : 0;
                 while(a < nDef && PJ_OK()) {
                     const int cand = a + lane;
                     // (chunked form of the LDS layouts: at most 62 levels, whose offsets ride in the lanes of a register)
@@ -932,7 +962,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             WSYNC();
             PJ_T(5);
             // ---------------- backtrace (:2838-3007)
-            if(PJ_OK()) {
+            if(PJ_OK() && !deferred) {
                 int lastLevel = uni(LC::get(P.lvl[cur][n1 - 1], lvBase));
                 int tb, tm; const short* lastS;
                 if(par) { tb = nodeBase + P.sLev[nDef]; tm = P.sLev[nDef + 1] - P.sLev[nDef]; lastS = Sflat + P.sLev[nDef]; }
@@ -1024,6 +1054,226 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
     if(B.dbg && lane == 0) { for(int i = 0; i < 6; i++) atomicAdd(&B.counters[16 + i], (u64)tAcc[i]); atomicAdd(&B.counters[23], (u64)tAcc[6]); }
     if(B.dbg && lane == 0) for(int i = 0; i < 4; i++) atomicAdd(&B.counters[24 + i], (u64)tSub[i]);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// k_rethread_chains -- the chunked form of the re-threading DP (processBAM.cpp:2676-3007) for the chains k_project_chains left pending.
+// The level loop of that form is bound by the latency of ONE wave per level -- a dependent chain of ~120 instructions; its time per level is the
+// same with 2 and with 14 waves on a CU (profiles/r03_experiments.txt) -- so throughput is waves per CU, and k_project_chains, which carries the
+// whole projection (11.7 KB of LDS, 120 VGPRs), tops out at 14.  This kernel holds only what the loop needs: a chunk's in-edge records and in-edge
+// offsets, two score rows, the picks of the backtrace (5.3 KB); a chunk's level offsets, first in-edges and colInfo ride in the lanes of registers
+// (a chunk has at most 62 levels), read from the rows k_project_chains left in HBM.  Same recurrence, same order of the ties (first maximum = smallest
+// edge), same end node (smallest among the maxima), same chunking rule per chain as the wave-wide form there; see the comments at that loop.
+struct __align__(16) RethreadLds {
+    u32 eRec[RT_CE];                        // DevGraph::in_rec of the chunk's in-edges; backtrace: from-node (low half) | chosen edge (high half) of the chunk's nodes
+    unsigned short sIn[RT_SN + 2];          // in_off of the chunk's nodes (levels solved node by node)
+    short Srow[2][PROJ_NODES];
+    unsigned short pick[PROJ_CAP];          // per column: chosen in-edge (window-relative), 0xFFFF = none
+    u64 chunkStart[PROJ_CAP / 64];          // levels at which a chunk started
+};
+
+__global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, char* slabs, size_t slabBytes)
+{
+    const DevGraph& G = *Gp;
+    const DevBatch& B = *Bp;
+    __shared__ RethreadLds P;
+    const int lane = lane_id();
+    ChoiceRec* const ch = (ChoiceRec*)(slabs + (size_t)blockIdx.x * slabBytes);
+    const int stride = B.stride;
+    u64 accCols = 0, accEdges = 0;
+    for(;;) {
+        // 64 chains per draw: the wave takes the pending ones among them, one after the other
+        int c0 = 0;
+        if(lane == 0) c0 = atomicAdd(&B.work_counter[3], 64);
+        c0 = __builtin_amdgcn_readfirstlane(c0);
+        if(c0 >= B.n_chains) break;
+        u64 pend = __ballot(c0 + lane < B.n_chains && B.seed_status[c0 + lane] == CHAIN_RETHREAD_PENDING);
+        for(; pend; pend &= pend - 1) {
+            const int c = c0 + __ffsll((long long)pend) - 1;
+            const size_t cb = (size_t)c * stride;
+            const int* st = (const int*)B.dp_items + (size_t)c * 16;
+            int sv = lane < 6 ? st[lane] : 0;
+            const int level0 = __builtin_amdgcn_readlane(sv, 0), nDef = __builtin_amdgcn_readlane(sv, 1), nodeBase = __builtin_amdgcn_readlane(sv, 2), nb = __builtin_amdgcn_readlane(sv, 3),
+                      eBase = __builtin_amdgcn_readlane(sv, 4), n1 = __builtin_amdgcn_readlane(sv, 5);
+            (void)level0;
+            const unsigned short* lvRow = (const unsigned short*)(B.ext_level + cb); const unsigned short* sgRow = (const unsigned short*)(B.ext_edge + cb);
+            const int* ciRow = B.seed_edge + cb;
+            const int nbR = nb - nodeBase;
+            for(int z = lane; z < nbR; z += 64) P.Srow[0][z] = 0;                          // all nodes of the first level, S = 0 (:2694-2701)
+            if(lane < PROJ_CAP / 64) P.chunkStart[lane] = 0;
+            WSYNC();
+            int rowP = 0, err = 0;
+            u64 edgesTouched = 0;
+            int a = 0;
+            while(a < nDef && !err) {
+                // the chunk's levels: offsets a .. a + 63 (+ 2), first in-edges a .. a + 63 (+ 1), colInfo -- one round trip
+                const int i0 = a + lane;
+                const int lvA = i0 <= nDef + 1 ? (int)lvRow[i0] : 0, lvC = i0 + 2 <= nDef + 1 ? (int)lvRow[i0 + 2] : 0;
+                const int sgA = i0 <= nDef ? (int)sgRow[i0] : 0, sgB = i0 + 1 <= nDef ? (int)sgRow[i0 + 1] : 0;
+                const u32 ciReg = i0 < nDef ? (u32)ciRow[i0] : 0u;
+                const int lvA1 = __builtin_amdgcn_readlane(lvA, 1), sgA0 = __builtin_amdgcn_readlane(sgA, 0);
+                const bool fits = i0 < nDef && lane < 62 && (lvC - lvA1) <= RT_SN && (sgB - sgA0) <= RT_CE;
+                const u64 fm = __ballot(fits);
+                const int cnt = __ffsll((long long)~fm) - 1;                               // levels a .. a + cnt - 1 fit together (a prefix: both sums grow)
+                if(cnt == 0) { err = HLALA_CHAIN_ERR_FRONTIER; break; }                    // (k_project_chains keeps every chain with a level beyond these arrays)
+                const int b = a + cnt - 1;
+                if(lane == 0) P.chunkStart[a >> 6] |= 1ull << (a & 63);
+                const int tBase = lvA1, nT = __builtin_amdgcn_readlane(lvA, cnt + 1) - tBase, eC = sgA0, nE = __builtin_amdgcn_readlane(sgA, cnt) - eC;
+                const int lvReg = lvA, sgReg = sgA - eC;
+                {   // the chunk's in-edge records and in-edge offsets: one round trip
+                    constexpr int UE = RT_CE / 64, UN = (RT_SN + 1 + 63) / 64;
+                    u32 ve[UE]; int vn[UN];
+                    #pragma unroll
+                    for(int u = 0; u < UE; u++) { const int e = lane + 64 * u; if(e < nE) ve[u] = G.in_rec[eBase + eC + e]; }
+                    #pragma unroll
+                    for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) vn[u] = G.in_off[nodeBase + tBase + t]; }
+                    #pragma unroll
+                    for(int u = 0; u < UE; u++) { const int e = lane + 64 * u; if(e < nE) P.eRec[e] = ve[u]; }
+                    #pragma unroll
+                    for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) P.sIn[t] = (unsigned short)(vn[u] - eBase - eC); }
+                }
+                WSYNC();
+                bool prevFast = false; int sReg = -1;
+                u32 recN = 0;
+                { const int nE0 = __builtin_amdgcn_readlane(sgReg, 1); if(lane < nE0 && nE0 <= 64) recN = P.eRec[lane]; }
+                for(int k = 0; k < cnt; k++) {
+                    const u32 ci = (u32)__builtin_amdgcn_readlane((int)ciReg, k);
+                    const int sc = (int)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
+                    const int l1 = __builtin_amdgcn_readlane(lvReg, k + 1), tm = __builtin_amdgcn_readlane(lvReg, k + 2) - l1;
+                    const int eL0 = __builtin_amdgcn_readlane(sgReg, k), eL1 = __builtin_amdgcn_readlane(sgReg, k + 1), nEl = eL1 - eL0;
+                    const int mode = (int)((ci >> 25) & 3u), maxd = (int)((ci >> 27) & 7u);
+                    const u32 rec = recN;
+                    if(k + 1 < cnt) { const int nEn = __builtin_amdgcn_readlane(sgReg, k + 2) - eL1; recN = (lane < nEn && nEn <= 64) ? P.eRec[eL1 + lane] : 0u; }
+                    bool reached = false;
+                    auto edge_key = [&](const u32 r, const int sp, const bool mine) -> int {
+                        const int m = (int)((r >> 18) & 0xFFu) == sc ? 1 : 0;
+                        const int cand = (mine && sp >= 0 && (m || !seedIsMatch)) ? sp + m + 1 : 0;           // 0: not admitted (:2803-2809) or from-node unreachable; else score + 1
+                        return (cand << 15) | ((63 - lane) << 9) | (int)(r & 511u);
+                    };
+                    auto node_key = [&](const u32 r, const int key) -> int {
+                        const int pos = (int)((r >> 15) & 7u);
+                        int bk = key, kj = key;
+                        for(int j = 1; j <= maxd; j++) { kj = __builtin_amdgcn_update_dpp(0, kj, 0x138, 0xF, 0xF, false); if(pos >= j) bk = max(bk, kj); }          // wave_shr:1 -- the edge j places before
+                        return bk;
+                    };
+                    if(mode == 1) {
+                        const bool mine = lane < nEl;
+                        int sp;
+                        if(prevFast) sp = __builtin_amdgcn_ds_bpermute((int)(((rec >> 9) & 63u) << 2), sReg);
+                        else sp = (int)P.Srow[rowP][rec & 511u];
+                        const int bk = node_key(rec, edge_key(rec, sp, mine));
+                        const bool last = mine && (rec & (1u << 28)) != 0;
+                        const u64 lastMask = __ballot(last);
+                        const int best = (bk >> 15) - 1;
+                        sReg = best;
+                        if(last) {
+                            const int tz = (int)__builtin_amdgcn_mbcnt_hi((u32)(lastMask >> 32), __builtin_amdgcn_mbcnt_lo((u32)lastMask, 0u));
+                            ChoiceRec cr; cr.eid = best >= 0 ? eC + eL0 + 63 - ((bk >> 9) & 63) : -1; cr.fromz = (short)(best >= 0 ? (bk & 511) : -1); cr.S = (short)best;
+                            P.Srow[1 - rowP][tz] = (short)best;
+                            ch[l1 + tz - nbR] = cr;
+                            reached = best >= 0;
+                        }
+                        if(lane == 0) edgesTouched += (u64)nEl;
+                        prevFast = true;
+                    } else if(mode == 2) {
+                        int nodesDone = 0;
+                        for(int s0 = 0; s0 == 0 || s0 + 7 < nEl; s0 += 57) {
+                            const bool mine = s0 + lane < nEl;
+                            const u32 r = mine ? P.eRec[eL0 + s0 + lane] : 0u;
+                            const int sp = (int)P.Srow[rowP][r & 511u];
+                            const int bk = node_key(r, edge_key(r, sp, mine));
+                            const bool last = mine && (r & (1u << 28)) != 0 && (s0 == 0 || lane >= 7);
+                            const u64 lastMask = __ballot(last);
+                            if(last) {
+                                const int best = (bk >> 15) - 1;
+                                const int tz = nodesDone + (int)__builtin_amdgcn_mbcnt_hi((u32)(lastMask >> 32), __builtin_amdgcn_mbcnt_lo((u32)lastMask, 0u));
+                                ChoiceRec cr; cr.eid = best >= 0 ? eC + eL0 + s0 + 63 - ((bk >> 9) & 63) : -1; cr.fromz = (short)(best >= 0 ? (bk & 511) : -1); cr.S = (short)best;
+                                P.Srow[1 - rowP][tz] = (short)best;
+                                ch[l1 + tz - nbR] = cr;
+                                if(best >= 0) reached = true;
+                            }
+                            nodesDone += (int)__popcll(lastMask);
+                        }
+                        if(lane == 0) edgesTouched += (u64)nEl;
+                        prevFast = false;
+                    } else {
+                        const int t0 = l1 - tBase;
+                        for(int z = lane; z < tm; z += 64) {
+                            const int t = t0 + z;
+                            int best = -1, bestE = -1, bestFrom = -1;
+                            const int e0 = P.sIn[t], e1 = P.sIn[t + 1];
+                            for(int e = e0; e < e1; e++) {                                   // in-edges in creation order: first maximum = smallest edge
+                                const u32 r = P.eRec[e];
+                                const int fz = (int)(r & 511u);
+                                const int sp = P.Srow[rowP][fz];
+                                if(sp < 0) continue;
+                                const int lab = (int)((r >> 18) & 0xFFu);
+                                if(seedIsMatch && lab != sc) continue;                        // :2803-2809
+                                const int cd = sp + (lab == sc ? 1 : 0);
+                                if(cd > best) { best = cd; bestE = eC + e; bestFrom = fz; }
+                            }
+                            edgesTouched += (u64)(e1 - e0);
+                            P.Srow[1 - rowP][z] = (short)best;
+                            ChoiceRec cr; cr.eid = bestE; cr.fromz = (short)bestFrom; cr.S = (short)best;
+                            ch[tBase + t - nbR] = cr;
+                            if(best >= 0) reached = true;
+                        }
+                        prevFast = false;
+                    }
+                    if(!__ballot(reached)) { err = HLALA_CHAIN_ERR_INPUT; break; }          // assert(seedChain_backtrack_*.size() > 0)
+                    rowP = 1 - rowP;
+                    WSYNC();
+                }
+                a = b + 1;
+            }
+            // ---- backtrace (:2838-3007)
+            if(!err) {
+                const int lvLast = (int)lvRow[nDef], tmL = (int)lvRow[nDef + 1] - lvLast;
+                const short* lastS = P.Srow[rowP];
+                int bestS = -1;
+                for(int z = lane; z < tmL; z += 64) bestS = max(bestS, (int)lastS[z]);
+                bestS = wave_max_i32(bestS);
+                int zsel = 0x7FFFFFFF;
+                for(int z = lane; z < tmL; z += 64) if(lastS[z] == bestS) zsel = min(zsel, z);
+                zsel = -wave_max_i32(-zsel);                                               // *(runningN.begin()): smallest node among the maxima (:2867)
+                for(int j = lane; j < n1; j += 64) P.pick[j] = 0xFFFF;
+                WSYNC();
+                int z = zsel;
+                for(int bb = nDef - 1; bb >= 0; ) {
+                    int w = bb >> 6; u64 m = P.chunkStart[w] & (~0ull >> (63 - (bb & 63)));
+                    while(m == 0) { w--; m = P.chunkStart[w]; }                            // (level 0 starts a chunk)
+                    const int aa = w * 64 + 63 - __clzll((long long)m);
+                    const int i0 = aa + lane;
+                    const int lvA = i0 <= nDef + 1 ? (int)lvRow[i0] : 0;
+                    const u32 ciReg = i0 <= bb ? (u32)ciRow[i0] : 0u;
+                    const int tBase = __builtin_amdgcn_readlane(lvA, 1), nT = __builtin_amdgcn_readlane(lvA, bb - aa + 2) - tBase;
+                    {   // the back pointers of the chunk's nodes: from-node | chosen edge per node, one round trip
+                        constexpr int UN = (RT_SN + 63) / 64;
+                        ChoiceRec vr[UN];
+                        #pragma unroll
+                        for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t < nT) vr[u] = ch[tBase + t - nbR]; }
+                        #pragma unroll
+                        for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t < nT) P.eRec[t] = (u32)(unsigned short)vr[u].fromz | ((u32)(unsigned short)vr[u].eid << 16); }
+                    }
+                    WSYNC();
+                    for(int i = bb; i >= aa; i--) {
+                        const int col = (int)((u32)__builtin_amdgcn_readlane((int)ciReg, i - aa) & 0xFFFFu), lvI = __builtin_amdgcn_readlane(lvA, i - aa + 1);
+                        if(lane == 0) { const u32 r = P.eRec[lvI - tBase + z]; P.pick[col] = (unsigned short)(r >> 16); z = (int)(short)(r & 0xFFFFu); }
+                    }
+                    WSYNC();
+                    bb = aa - 1;
+                }
+                staged_rows<6>(lane, n1, 64, [&](int j) { const unsigned short pe = P.pick[j]; FromLab r; r.from = -1; r.lab = '_';
+                                                          if(pe != 0xFFFF) { r.from = G.in_eid[eBase + pe]; r.lab = G.in_label[eBase + pe]; } return r; },
+                               [&](int j, FromLab r) { B.seed_edge[cb + j] = r.from; B.seed_g[cb + j] = r.lab; });
+                if(lane == 0) { B.seed_status[c] = HLALA_CHAIN_OK; accCols += (u64)n1; }
+            } else if(lane == 0) { B.seed_status[c] = err; B.seed_ncols[c] = 0; }
+            accEdges += edgesTouched;
+            WSYNC();
+        }
+    }
+    accCols = wave_sum_u64(accCols); accEdges = wave_sum_u64(accEdges);
+    if(lane == 0) { if(accCols) atomicAdd(&B.counters[CNT_SEED_COLS], accCols); if(accEdges) atomicAdd(&B.counters[CNT_EDGES], accEdges); }
 }
 
 }  // namespace hlala
