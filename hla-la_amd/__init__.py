@@ -383,7 +383,7 @@ def typer_write_summary(lib, out_dir, stats, unpaired=False, unit_mask=None, ins
 class LocusReportIn(C.Structure):
     _fields_ = [("pos", C.POINTER(ExonPositionsOut)), ("filter", C.POINTER(FilterParams)), ("unit_name_1", C.POINTER(C.c_char_p)), ("unit_name_2", C.POINTER(C.c_char_p)),
                 ("long_read_mode", C.c_int32), ("n_clusters", C.c_int32), ("pair_ll", c_f64p), ("mis_avg", c_f64p), ("mis_min", c_f64p), ("order", c_i32p),
-                ("p_normalized", c_f64p), ("call", C.c_void_p), ("kmers_covered", C.c_double * 2), ("unaccounted_min_coverage", C.c_int32), ("reserved", C.c_int32),
+                ("p_normalized", c_f64p), ("call", C.c_void_p), ("kmers_covered", C.c_double * 2), ("unaccounted_min_coverage", C.c_int32), ("pairs_file_done", C.c_int32),
                 ("unaccounted_min_fraction", C.c_double), ("unit_stats", C.POINTER(UnitStatsOut)), ("unit_mask", c_u8p), ("n_units", C.c_int32), ("reserved2", C.c_int32),
                 ("insert_mean", C.c_double), ("insert_sd", C.c_double), ("min_mapq", C.c_double), ("min_weighted_ok", C.c_double)]
 
@@ -666,7 +666,7 @@ EXPORTED_SYMBOLS = [
     "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
     "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_g_translate", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",
-    "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_unit_alignment_stats", "hlala_typer_write_summary", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_typer_end_output",
+    "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_unit_alignment_stats", "hlala_typer_write_summary", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_locus_write_pairs_file", "hlala_typer_end_output",
 ]
 
 

@@ -430,6 +430,60 @@ try {
     return HLALA_OK;
 } catch(const std::exception& e_) { g_err = std::string("hlala_typer_write_summary: ") + e_.what(); return HLALA_E_ARG; }
 
+static int write_pairs_table(const hlala_locus* L, const int C, const int32_t* order, const double* p_normalized, const double* pair_ll, const double* mis_avg, const std::string& dir)
+{
+    const std::string& locus = L->name;
+    // ---- all pairs, :2451-2488
+    const long long nPairs = (long long)C * (C + 1) / 2;
+    std::vector<int> c1Of((size_t)nPairs), c2Of((size_t)nPairs);
+    { long long i = 0; for(int a = 0; a < C; a++) for(int b = a; b < C; b++, i++) { c1Of[(size_t)i] = a; c2Of[(size_t)i] = b; } }
+    {
+        std::ofstream ap((dir + "/R1_PP_" + locus + "_pairs.txt").c_str());
+        if(!ap.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_PP_" + locus + "_pairs.txt");
+        ap << "ClusterID" << "\t" << "P" << "\t" << "LL" << "\t" << "Mismatches_avg" << "\n";
+        for(long long k = 0; k < nPairs; k++) if(order[k] < 0 || order[k] >= nPairs) return fail(HLALA_E_ARG, "hlala_locus_write_pairs_file: order[] holds an index outside the pair table");
+        // one line per cluster pair (millions for a class-I locus): the lines are formatted by the same iostream calls as the reference's, chunk by chunk on all
+        // host threads, and written in order
+        const long long CH = 65536; const long long nChunks = (nPairs + CH - 1) / CH;
+        std::vector<std::string> parts((size_t)nChunks);
+        std::atomic<long long> next(0);
+        auto work = [&]() {
+            for(;;) {
+                const long long c = next.fetch_add(1); if(c >= nChunks) break;
+                // (a double goes out as the stream's default format -- %g, six significant digits -- through std::to_chars(general, 6), which is defined
+                // as that printf conversion and six times as fast as operator<<; a value that is not finite takes the stream, whose spelling of it is the reference's)
+                std::string& out = parts[(size_t)c];
+                const long long k1 = std::min(nPairs, (c + 1) * CH);
+                out.reserve((size_t)(k1 - c * CH) * 64);
+                auto num = [&](double v) {
+                    if(std::isfinite(v)) { char b[40]; const auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::general, 6); out.append(b, r.ptr); }
+                    else { std::ostringstream os; os << v; out += os.str(); }
+                };
+                for(long long k = c * CH; k < k1; k++) {
+                    const int cI = order[k];
+                    out += L->clusterId[c1Of[cI]]; out += '/'; out += L->clusterId[c2Of[cI]]; out += '\t';
+                    num(p_normalized[cI]); out += '\t'; num(pair_ll[cI]); out += '\t'; num(mis_avg[cI]); out += '\n';
+                }
+            }
+        };
+        unsigned T = std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 64) T = 64; if((long long)T > nChunks) T = (unsigned)nChunks;
+        std::vector<std::thread> th; for(unsigned t = 1; t < T; t++) th.emplace_back(work);
+        work();
+        for(std::thread& x : th) x.join();
+        for(const std::string& pstr : parts) ap.write(pstr.data(), (std::streamsize)pstr.size());
+    }
+    return HLALA_OK;
+}
+
+extern "C" int hlala_locus_write_pairs_file(const hlala_locus* L, int32_t n_clusters, const int32_t* order, const double* p_normalized, const double* pair_ll,
+                                            const double* mis_avg, const char* out_dir)
+{
+    if(!L || !order || !p_normalized || !pair_ll || !mis_avg || !out_dir) return fail(HLALA_E_ARG, "hlala_locus_write_pairs_file: null argument");
+    if(n_clusters != (int32_t)L->clusterId.size()) return fail(HLALA_E_ARG, "hlala_locus_write_pairs_file: n_clusters does not match the locus");
+    try { return write_pairs_table(L, n_clusters, order, p_normalized, pair_ll, mis_avg, out_dir); }
+    catch(const std::exception& e) { return fail(HLALA_E_ARG, std::string("hlala_locus_write_pairs_file: ") + e.what()); }
+}
+
 extern "C" int hlala_locus_write_files(const hlala_locus* L, const hlala_locus_report_in* in, const char* out_dir, hlala_locus_report_out* res)
 try {
     if(!L || !in || !out_dir || !in->pos || !in->filter || !in->call) return fail(HLALA_E_ARG, "hlala_locus_write_files: null argument");
@@ -529,44 +583,7 @@ try {
         for(const std::string& id : utilized) ids << id << "\n";
     }
     // ---- all pairs, :2451-2488
-    const long long nPairs = (long long)C * (C + 1) / 2;
-    std::vector<int> c1Of((size_t)nPairs), c2Of((size_t)nPairs);
-    { long long i = 0; for(int a = 0; a < C; a++) for(int b = a; b < C; b++, i++) { c1Of[(size_t)i] = a; c2Of[(size_t)i] = b; } }
-    {
-        std::ofstream ap((dir + "/R1_PP_" + locus + "_pairs.txt").c_str());
-        if(!ap.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_PP_" + locus + "_pairs.txt");
-        ap << "ClusterID" << "\t" << "P" << "\t" << "LL" << "\t" << "Mismatches_avg" << "\n";
-        for(long long k = 0; k < nPairs; k++) if(in->order[k] < 0 || in->order[k] >= nPairs) return fail(HLALA_E_ARG, "hlala_locus_write_files: order[] holds an index outside the pair table");
-        // one line per cluster pair (millions for a class-I locus): the lines are formatted by the same iostream calls as the reference's, chunk by chunk on all
-        // host threads, and written in order
-        const long long CH = 65536; const long long nChunks = (nPairs + CH - 1) / CH;
-        std::vector<std::string> parts((size_t)nChunks);
-        std::atomic<long long> next(0);
-        auto work = [&]() {
-            for(;;) {
-                const long long c = next.fetch_add(1); if(c >= nChunks) break;
-                // (a double goes out as the stream's default format -- %g, six significant digits -- through std::to_chars(general, 6), which is defined
-                // as that printf conversion and six times as fast as operator<<; a value that is not finite takes the stream, whose spelling of it is the reference's)
-                std::string& out = parts[(size_t)c];
-                const long long k1 = std::min(nPairs, (c + 1) * CH);
-                out.reserve((size_t)(k1 - c * CH) * 64);
-                auto num = [&](double v) {
-                    if(std::isfinite(v)) { char b[40]; const auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::general, 6); out.append(b, r.ptr); }
-                    else { std::ostringstream os; os << v; out += os.str(); }
-                };
-                for(long long k = c * CH; k < k1; k++) {
-                    const int cI = in->order[k];
-                    out += L->clusterId[c1Of[cI]]; out += '/'; out += L->clusterId[c2Of[cI]]; out += '\t';
-                    num(in->p_normalized[cI]); out += '\t'; num(in->pair_ll[cI]); out += '\t'; num(in->mis_avg[cI]); out += '\n';
-                }
-            }
-        };
-        unsigned T = std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 64) T = 64; if((long long)T > nChunks) T = (unsigned)nChunks;
-        std::vector<std::thread> th; for(unsigned t = 1; t < T; t++) th.emplace_back(work);
-        work();
-        for(std::thread& x : th) x.join();
-        for(const std::string& pstr : parts) ap.write(pstr.data(), (std::streamsize)pstr.size());
-    }
+    if(!in->pairs_file_done) { const int rcp = write_pairs_table(L, C, in->order, in->p_normalized, in->pair_ll, in->mis_avg, dir); if(rcp != HLALA_OK) return rcp; }
     // ---- coverage, column incompatibilities, best guesses, :2543-2759
     const int first = in->call->first_cluster, second = in->call->second_cluster;
     if(first < 0 || first >= C || second < 0 || second >= C) return fail(HLALA_E_ARG, "hlala_locus_write_files: called clusters outside the locus");

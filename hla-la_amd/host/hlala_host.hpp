@@ -490,6 +490,12 @@ public:
         // ---- per locus: filters -> likelihoods -> all pairs -> call
         struct Res { hlala_exon_positions_out pos; std::vector<double> pairLL, misAvg, misMin, pNorm; std::vector<int32_t> order; hlala_call_out call; std::vector<char> q[2]; int32_t nq[2], nt[2]; std::vector<uint8_t> present[2]; };
         std::vector<Res> res(acc.size());
+        // (the all-pairs table of a locus -- millions of lines for class I -- is written by a thread of its own as soon as the locus is called: beside the typing
+        // of the next locus and the k-mer pass; into the locus' directory under the output directory, see "files" below)
+        std::vector<std::string> tmpDir(acc.size());
+        for(size_t li = 0; li < acc.size(); li++) tmpDir[li] = outputDirectory + "/.locus_" + std::to_string(li);
+        std::vector<std::thread> pairWriters; std::vector<std::string> pairErr(acc.size());
+        struct JoinAll { std::vector<std::thread>& t; ~JoinAll() { for(std::thread& x : t) if(x.joinable()) x.join(); } } joinPairWriters{pairWriters};
         for(size_t li = 0; li < acc.size(); li++) {
             Acc& A = acc[li]; Res& R = res[li];
             const size_t nR = A.read_pair.size(), nP = A.pos_exon.size();
@@ -513,6 +519,12 @@ public:
             chk(hlala_exon_loglik(c, &xin, LL.data(), mism.data()), "hlala_exon_loglik");
             chk(hlala_pair_loglik(c, LL.data(), mism.data(), A.li.n_clusters, (int32_t)nR, R.pairLL.data(), R.misAvg.data(), R.misMin.data()), "hlala_pair_loglik");
             chk(hlala_call_locus(c, A.li.n_clusters, R.pairLL.data(), R.misAvg.data(), R.misMin.data(), R.order.data(), R.pNorm.data(), marginal.data(), &R.call), "hlala_call_locus");
+            if(::mkdir(tmpDir[li].c_str(), 0775) != 0 && errno != EEXIST) throw std::runtime_error("cannot create " + tmpDir[li]);
+            pairWriters.emplace_back([&, li]() {
+                const Res& Rr = res[li];
+                if(hlala_locus_write_pairs_file(acc[li].L, acc[li].li.n_clusters, Rr.order.data(), Rr.pNorm.data(), Rr.pairLL.data(), Rr.misAvg.data(), tmpDir[li].c_str()) != HLALA_OK)
+                    pairErr[li] = std::string("hlala_locus_write_pairs_file: ") + hlala_typer_last_error();
+            });
             for(int a = 0; a < 2; a++) {                                              // k-mers of the two called alleles, :2652-2688
                 const int32_t cl = a ? R.call.second_cluster : R.call.first_cluster; R.nq[a] = 0; R.nt[a] = 0;
                 hlala_locus_cluster_kmers(A.L, cl, k_for_kMer_index, nullptr, 0, &R.nq[a], &R.nt[a]);
@@ -560,8 +572,8 @@ public:
         std::vector<bestGuess> out(acc.size()); std::string lociJoined;
         {
             std::vector<std::string> ferr(acc.size());
-            std::vector<std::string> tmpDir(acc.size());
-            for(size_t li = 0; li < acc.size(); li++) tmpDir[li] = outputDirectory + "/.locus_" + std::to_string(li);
+            for(std::thread& x : pairWriters) x.join();
+            for(const std::string& e : pairErr) if(!e.empty()) throw std::runtime_error(e);
             auto write_one = [&](size_t li) {
                 try {
                     Acc& A = acc[li]; Res& R = res[li];
@@ -571,7 +583,7 @@ public:
                     hlala_locus_report_in rin; std::memset(&rin, 0, sizeof(rin));
                     rin.pos = &R.pos; rin.filter = &filterParams; rin.unit_name_1 = names.data(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.data(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
                     rin.n_clusters = A.li.n_clusters; rin.pair_ll = R.pairLL.data(); rin.mis_avg = R.misAvg.data(); rin.mis_min = R.misMin.data(); rin.order = R.order.data(); rin.p_normalized = R.pNorm.data(); rin.call = &R.call;
-                    rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2;
+                    rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2; rin.pairs_file_done = 1;
                     rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = (int32_t)pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
                     rin.min_mapq = minimumMappingQuality; rin.min_weighted_ok = min_bothReads_weightedCharactersOK;
                     bestGuess g; g.locus = A.locus;

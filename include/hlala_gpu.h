@@ -627,7 +627,7 @@ typedef struct {
     const hlala_call_out* call;
     double  kmers_covered[2];                /* proportionkMersCovered of the first / second called allele (-1: no k-mers)         */
     int32_t unaccounted_min_coverage;        /* threshold_reportColumn_forPresenceOfUnaccountedAlleles_minCoverage (30, :67)        */
-    int32_t reserved;
+    int32_t pairs_file_done;                 /* 1: R1_PP_<locus>_pairs.txt is already there (hlala_locus_write_pairs_file); 0: write it  */
     double  unaccounted_min_fraction;        /* ..._minAlleleFraction (0.2, :68)                                                   */
     const hlala_unit_stats_out* unit_stats;  /* NULL: no histogram lines                                                           */
     const uint8_t* unit_mask;                /* [units of the batch] or NULL: the mask hlala_exon_positions ran with (includeInHLA) */
@@ -642,6 +642,10 @@ typedef struct {
 } hlala_locus_report_out;
 int  hlala_typer_begin_output(const char* out_dir, double unaccounted_min_fraction);
 int  hlala_locus_write_files(const hlala_locus* l, const hlala_locus_report_in* in, const char* out_dir, hlala_locus_report_out* out);
+/* The all-pairs table R1_PP_<locus>_pairs.txt alone (HLATyper.cpp:2451-2488; millions of lines for a class-I locus): what it prints is known as soon as
+ * hlala_call_locus returns, so a host program can write it beside the k-mer pass and the typing of the next locus and set pairs_file_done above. */
+int  hlala_locus_write_pairs_file(const hlala_locus* l, int32_t n_clusters, const int32_t* order, const double* p_normalized, const double* pair_ll,
+                                  const double* mis_avg, const char* out_dir);
 int  hlala_typer_end_output(const char* out_dir, const char* loci_comma_separated, int32_t very_conservative_read_likelihoods);
 
 /* Known-answer helpers exported for the parity tests (device implementations of
