@@ -382,6 +382,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
         return 0;
     };
     c->tiny_grid = cus * 4 * DpTiny::WAVES;
+    if(const char* e = getenv("HLALA_TINY_WAVES_PER_CU")) { const int w = atoi(e); if(w >= 1 && w <= 4 * DpTiny::WAVES) c->tiny_grid = cus * w; }      // (experiment: blocks of the 16-lane kernel per CU, tools/gpu_tiny_waves.sh)
     c->tiny_slab_bytes = dp_slab_bytes<DpTiny>();
     c->ext_grid = cus * 20;
     c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();
