@@ -171,6 +171,34 @@ def test_gene_window_reads_match_oracle(pkg, oracle, world_m):
 
 
 @pytest.mark.gpu
+def test_both_forms_of_the_rethreading_dp_match_the_oracle(pkg, oracle, world_m):
+    """Stage A of gene-window chains has two homes: k_rethread_chains (default: the chains k_project_chains leaves pending) and the wave-wide chunked form
+    inside k_project_chains (HLALA_RETHREAD=0, and the chains the other kernel's staging arrays do not hold).  Both against the oracle's seed chains, bit for bit,
+    including the edge counter that both kernels add to."""
+    b = synth.make_batch_m(world_m, 3000, seed=23, frac_gene=1.0)
+    kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=5, max_columns=384)
+    exp = oracle(world_m["graph"], world_m["contigs"], **kw).align_batch(b)
+    edges = []
+    old = os.environ.get("HLALA_RETHREAD")
+    try:
+        for mode in ("1", "0"):
+            os.environ["HLALA_RETHREAD"] = mode                      # read by hlala_create
+            ctx = pkg.Context(world_m["graph"], world_m["contigs"], **kw)
+            gb = ctx.batch(b); gb.project()
+            compare_chains(gb.chains(0), exp["seeds"], b["n_chains"], check_ll=False, check_dp=False, label="stage A, HLALA_RETHREAD=" + mode)
+            gb.extend(); gb.pair()
+            st = gb.stats(); edges.append(int(st.n_edges_touched))
+            assert st.n_errors == 0
+            gb.close(); ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("HLALA_RETHREAD", None)
+        else:
+            os.environ["HLALA_RETHREAD"] = old
+    assert edges[0] == edges[1], edges
+
+
+@pytest.mark.gpu
 def test_dense_windows_reach_the_broad_and_large_classes(pkg, oracle):
     """Windows with 4000-5000 alleles (up to ~400 nodes per level): frontiers of 500-750 cells, 16 000 kept cells and thousands of tied
     sequence-complete cells per DP -- the two classes with the large table layout, the bitonic frontier sort and the bitwise tie selection."""
