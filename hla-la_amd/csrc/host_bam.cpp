@@ -279,65 +279,14 @@ try {
             }
             headerDone = true;
         }
-        // Record boundaries.  Hopping over the length fields is a chain of dependent loads over the whole round -- 30 ns per record on one thread, most of
-        // this phase on a many-core host --, so every BGZF block is hopped on its own, in parallel, on the guess that a record starts where the block starts
-        // (htslib never lets a record straddle two blocks unless it is larger than a block: bam_write1 -> bgzf_flush_try).  The guesses are then checked in
-        // file order: a block whose start the chain of the blocks before it really reaches contributes its list; wherever the chain arrives inside a block
-        // (a writer that cuts blocks anywhere, a record larger than a block, the header), the records are hopped one by one until the chain meets a block
-        // start again.  The result is the list the serial walk gives, for any layout of the file.
+        // record boundaries: hop over the length fields
         std::vector<size_t> recStart;
-        {
-            const size_t nb = b1 - b0;
-            struct Guess { std::vector<size_t> starts; size_t end = 0; int stop = 0; };          // stop: 0 reached the next block, 1 bad length at `end`, 2 record runs beyond the round's bytes
-            std::vector<Guess> guess(nb);
-            auto block_start = [&](size_t j) -> size_t { return j < nb ? carry + (size_t)(blocks[b0 + j].uoff - u0) : dn; };
-            parallel_for((int64_t)nb, T, [&](int64_t jj, int) {
-                const size_t j = (size_t)jj; Guess& g = guess[j];
-                size_t p = block_start(j); const size_t lim = block_start(j + 1);
-                if(p < o) { g.stop = 1; g.end = p; return; }                                        // (the header: the chain tells where the first record starts)
-                g.starts.reserve((lim - p) / 160 + 4);
-                for(;;) {
-                    if(dn - p < 4) { g.stop = 2; break; }
-                    const int32_t bs = (int32_t)rd32(d + p);
-                    if(bs < 32 || bs > (1 << 28)) { g.stop = 1; break; }
-                    if(dn - p - 4 < (size_t)bs) { g.stop = 2; break; }
-                    g.starts.push_back(p); p += 4 + (size_t)bs;
-                    if(p >= lim) break;
-                }
-                g.end = p;
-            });
-            // the chain
-            std::vector<size_t> pieceOff(nb + 1, 0); std::vector<char> taken(nb, 0);
-            std::vector<std::pair<size_t, std::vector<size_t>>> serialRuns;                          // (position in the final list, records hopped one by one)
-            size_t count = 0; size_t j = 0; bool done = false;
-            while(!done) {
-                while(j < nb && block_start(j) < o) j++;
-                if(j < nb && block_start(j) == o) {
-                    Guess& g = guess[j];
-                    pieceOff[j] = count; taken[j] = 1; count += g.starts.size(); o = g.end;
-                    if(g.stop == 1) throw Fail("truncated BAM record");
-                    if(g.stop == 2) done = true;
-                    j++;
-                    continue;
-                }
-                // one record at a time until the chain stands on a block start again
-                std::vector<size_t> run;
-                const size_t at = count;
-                for(;;) {
-                    if(dn - o < 4) { done = true; break; }
-                    const int32_t bs = (int32_t)rd32(d + o);
-                    if(bs < 32 || bs > (1 << 28)) throw Fail("truncated BAM record");
-                    if(dn - o - 4 < (size_t)bs) { done = true; break; }
-                    run.push_back(o); o += 4 + (size_t)bs;
-                    while(j < nb && block_start(j) < o) j++;
-                    if(j < nb && block_start(j) == o) break;
-                }
-                count += run.size();
-                serialRuns.emplace_back(at, std::move(run));
-            }
-            recStart.resize(count);
-            parallel_for((int64_t)nb, T, [&](int64_t jj, int) { if(taken[(size_t)jj]) { const Guess& g = guess[(size_t)jj]; if(!g.starts.empty()) memcpy(recStart.data() + pieceOff[(size_t)jj], g.starts.data(), g.starts.size() * sizeof(size_t)); } });
-            for(const auto& r : serialRuns) if(!r.second.empty()) memcpy(recStart.data() + r.first, r.second.data(), r.second.size() * sizeof(size_t));
+        recStart.reserve((dn - o) / 200 + 16);
+        while(dn - o >= 4) {
+            const int32_t bs = (int32_t)rd32(d + o);
+            if(bs < 32 || bs > (1 << 28)) throw Fail("truncated BAM record");
+            if(dn - o - 4 < (size_t)bs) break;
+            recStart.push_back(o); o += 4 + (size_t)bs;
         }
         if(lastSegment && o != dn) throw Fail("truncated BAM record");
         const size_t nRec = recStart.size();

@@ -18,7 +18,6 @@ namespace {
 struct Writer {
     FILE* f = nullptr; int threads = 1, level = 1; std::string err;
     std::vector<uint8_t> pending;        // uncompressed bytes not yet written (less than one block is kept between appends)
-    std::vector<size_t> bounds;          // offsets in `pending` at which a record (or, first, the header) ends: where a block may end
     long long bytes_out = 0, records = 0;
 };
 
@@ -48,38 +47,23 @@ bool bgzf_block(const uint8_t* p, size_t n, int level, std::vector<uint8_t>& out
     return true;
 }
 
-// compress and write the blocks of `pending` that are complete (everything if `all`).  Like htslib (bam_write1 -> bgzf_flush_try) a block ends where a record
-// ends: a record lies in ONE block unless it is larger than a block.
+// compress and write all complete blocks of `pending` (everything if `all`)
 bool flush(Writer* w, bool all)
 {
     const size_t n = w->pending.size();
-    std::vector<size_t> cut(1, 0);                    // block b = [cut[b], cut[b + 1])
-    size_t bi = 0;
-    for(;;) {
-        const size_t a = cut.back();
-        if(a >= n) break;
-        if(!all && n - a < BLOCK) break;              // the rest waits for more records
-        while(bi < w->bounds.size() && w->bounds[bi] <= a) bi++;
-        size_t z = 0; size_t k = bi;
-        while(k < w->bounds.size() && w->bounds[k] - a <= BLOCK) { z = w->bounds[k]; k++; }
-        if(z == 0) z = std::min(n, a + BLOCK);        // a record larger than a block (or bytes without a boundary): cut anywhere
-        cut.push_back(z);
-    }
-    const size_t nBlocks = cut.size() - 1;
+    const size_t nBlocks = all ? (n + BLOCK - 1) / BLOCK : n / BLOCK;
     if(nBlocks == 0) return true;
     std::vector<std::vector<uint8_t>> outs(nBlocks);
     std::atomic<size_t> next(0); std::atomic<bool> ok(true);
-    auto work = [&]() { for(;;) { size_t b = next.fetch_add(1); if(b >= nBlocks) break; if(!bgzf_block(w->pending.data() + cut[b], cut[b + 1] - cut[b], w->level, outs[b])) ok = false; } };
+    auto work = [&]() { for(;;) { size_t b = next.fetch_add(1); if(b >= nBlocks) break; const size_t a = b * BLOCK, z = std::min(n, a + BLOCK); if(!bgzf_block(w->pending.data() + a, z - a, w->level, outs[b])) ok = false; } };
     std::vector<std::thread> th; const int T = (int)std::min<size_t>((size_t)w->threads, nBlocks);
     for(int t = 1; t < T; t++) th.emplace_back(work);
     work();
     for(auto& x : th) x.join();
     if(!ok) { w->err = "deflate failed"; return false; }
     for(auto& o : outs) { if(fwrite(o.data(), 1, o.size(), w->f) != o.size()) { w->err = "write failed"; return false; } w->bytes_out += (long long)o.size(); }
-    const size_t used = cut.back();
+    const size_t used = std::min(n, nBlocks * BLOCK);
     w->pending.erase(w->pending.begin(), w->pending.begin() + (long)used);
-    std::vector<size_t> rest; for(size_t x : w->bounds) if(x > used) rest.push_back(x - used);
-    w->bounds.swap(rest);
     return true;
 }
 
@@ -98,7 +82,6 @@ void* bw_open(const char* path, int n_refs, const char* const* ref_names, const 
     std::vector<uint8_t>& v = w->pending;
     v.insert(v.end(), {'B', 'A', 'M', 1}); put32(v, 0); put32(v, (uint32_t)n_refs);
     for(int i = 0; i < n_refs; i++) { const size_t l = strlen(ref_names[i]) + 1; put32(v, (uint32_t)l); v.insert(v.end(), ref_names[i], ref_names[i] + l); put32(v, (uint32_t)ref_lengths[i]); }
-    w->bounds.push_back(v.size());
     return w;
 }
 
@@ -148,7 +131,6 @@ int bw_append(void* h, int64_t n, const char* name_chars, const int64_t* name_of
     std::vector<std::thread> th; for(int t = 1; t < w->threads; t++) th.emplace_back(work);
     work();
     for(auto& x : th) x.join();
-    for(int64_t r = 0; r < n; r++) w->bounds.push_back(base + (size_t)off[(size_t)r + 1]);
     w->records += n;
     if(!flush(w, false)) { g_err = w->err; return -1; }
     return 0;
