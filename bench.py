@@ -437,7 +437,7 @@ def end_to_end(args, P, synth, w, mk):
         return {"value": float(m.group(1)), "unit": "read pairs/s", "pairs": nch * ch, "bam_bytes": int(size), "decode_s": float(m.group(2)), "decode_threads": int(m.group(3)),
                 "alignment_and_typing_s": float(m.group(4)), "context_and_insert_size_s": float(m.group(5)), "speed_line_pairs_per_s": float(sp.group(1)) if sp else None,
                 "process_wall_s": t_run, "whole_process_pairs_per_s": nch * ch / t_run, "typing_phases": ph.group(1) if ph else None,
-                "log": [ln[:600] for ln in r.stdout.splitlines() if ("Seed extraction:" in ln or ln.startswith("End-to-end:"))], "loci": loci, "result_files": len(files), "calls": calls[:6], "gene_window_share_of_the_sample": args.e2e_frac_gene,
+                "log": [ln[:600] for ln in r.stdout.splitlines() if ("Seed extraction:" in ln or ln.startswith("End-to-end:"))] + [ln[:300] for ln in r.stderr.splitlines() if ln.startswith("bam-debug:")][:40], "loci": loci, "result_files": len(files), "calls": calls[:6], "gene_window_share_of_the_sample": args.e2e_frac_gene,
                 "setup_s": {"graph_directory": t_dir, "sample_generation_and_bam": t_bam},
                 "what": "HLA-LA --action HLA: BAM bytes -> hla/* (decode on all host threads, batches of %d pairs two in flight on one GPU, typing of %d loci, result files); "
                         "value = pairs / (decode + alignment and typing), the program's End-to-end line; graph loading and context creation are per process" % (ch, len(loci))}

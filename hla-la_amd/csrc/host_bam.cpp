@@ -230,6 +230,13 @@ try {
     std::unique_ptr<Work> W(new Work());
     std::vector<Arena>& arenas = W->arenas; arenas.resize((size_t)T);
     for(Arena& a : arenas) a.part.resize(NPART);
+    {   // The kept records of a thread go to 256 vectors (one per name partition).  Growing 128 x 256 vectors from nothing made the first round take six times as
+        // long as the later ones (reallocation, fresh pages): they are reserved for the share of the file a thread can expect (records of >= 200 bytes, a quarter
+        // on top; the memory is only touched when used).
+        uint64_t payload = 0; for(const Block& b : blocks) payload += b.isize;
+        const size_t each = (size_t)(payload / 200 / ((uint64_t)T * NPART) * 5 / 4) + 32;
+        parallel_for((int64_t)T, T, [&](int64_t t, int) { for(std::vector<Rec>& v : arenas[(size_t)t].part) v.reserve(each); });
+    }
     std::vector<std::vector<int>> refIntervals;          // per BAM reference id: the intervals it carries
     bool headerDone = false; int32_t n_ref = 0;
     // uncompressed bytes inflated and parsed per round (HLALA_BAM_SEGMENT_BYTES: the tests choose a few blocks per round to exercise records that
@@ -355,6 +362,7 @@ try {
                 }
             }
         });
+        if(getenv("HLALA_BAM_DEBUG")) fprintf(stderr, "bam-debug: round of %zu blocks, %zu records: inflate + hop + parse so far %.3f + %.3f s\n", b1 - b0, nRec, tInflate, tParse + since(t0));
         recSeq += nRec;
         if(recSeq >= (1ull << 55)) throw Fail("more BAM records than the sequence numbers hold");
         // bytes of a record that continues in the next segment move to the front
