@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <thread>
+#include <type_traits>
 #include <atomic>
 #include <charconv>
 #include <cmath>
@@ -54,7 +55,19 @@ std::string join(const std::vector<std::string>& v, const std::string& d)
     for(size_t i = 0; i < v.size(); i++) { if(i) r += d; r += v[i]; }
     return r;
 }
-template <class T> std::string to_str(T v) { std::stringstream s; s << v; return s.str(); }      // ItoStr / DtoStr
+// ItoStr / DtoStr: what `stream << v` prints.  Integers and finite floating-point values go through std::to_chars -- for a double the stream's default format is
+// %g with six significant digits = std::chars_format::general, precision 6 (checked against operator<< on 15 M values) -- because a std::stringstream per
+// number was most of the time of the pile-up files; everything else (characters, bool, non-finite values) takes the stream.
+template <class T> typename std::enable_if<!std::is_arithmetic<T>::value || std::is_same<T, bool>::value || std::is_same<T, char>::value || std::is_same<T, signed char>::value || std::is_same<T, unsigned char>::value, std::string>::type
+to_str(T v) { std::stringstream s; s << v; return s.str(); }
+template <class T> typename std::enable_if<std::is_integral<T>::value && !std::is_same<T, bool>::value && !std::is_same<T, char>::value && !std::is_same<T, signed char>::value && !std::is_same<T, unsigned char>::value, std::string>::type
+to_str(T v) { char b[24]; const auto r = std::to_chars(b, b + sizeof b, v); return std::string(b, r.ptr); }
+template <class T> typename std::enable_if<std::is_floating_point<T>::value, std::string>::type
+to_str(T v)
+{
+    if(!std::isfinite(v)) { std::stringstream s; s << v; return s.str(); }
+    char b[48]; const auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::general, 6); return std::string(b, r.ptr);
+}
 
 // the reference's reading loop: `while(stream.good()) { getline; eraseNL; push }` -- a final empty line is part of the result
 bool read_lines(const std::string& path, std::vector<std::string>& lines)
