@@ -481,6 +481,7 @@ try {
             }
         }
     });
+    const bool dbgL = getenv("HLALA_BAM_DEBUG") != nullptr; const double tL1 = since(tPhase);
     for(size_t r = 0; r < nR; r++) { S->read_off[r + 1] += S->read_off[r]; S->chain_off[r + 1] += S->chain_off[r]; cigCount[r + 1] += cigCount[r]; }
     for(size_t ui = 0; ui < nU; ui++) S->name_off[ui + 1] += S->name_off[ui];
     const size_t nBases = (size_t)S->read_off[nR], nChains = (size_t)S->chain_off[nR], nCig = (size_t)cigCount[nR];
@@ -488,6 +489,7 @@ try {
     S->read_bases.alloc(nBases); S->read_quals.alloc(nBases);
     S->chain_contig.alloc(nChains); S->chain_pos.alloc(nChains); S->chain_offset.alloc(nChains); S->chain_as.alloc(nChains); S->chain_reverse.alloc(nChains);
     S->cigar_off.alloc(nChains + 1); S->cigar_off[0] = 0; S->cigar.alloc(nCig); S->name_chars.alloc((size_t)S->name_off[nU]);
+    const double tL2 = since(tPhase);
     parallel_for(nUChunks, T, [&](int64_t c, int t) {
         std::vector<uint32_t>& idx = order[(size_t)t];
         const size_t a = (size_t)(c * UCH), z = std::min(nU, a + (size_t)UCH);
@@ -517,6 +519,7 @@ try {
         }
     });
     S->seconds[5] = since(tPhase);
+    if(dbgL) fprintf(stderr, "bam-debug: layout: sizes %.3f (of which the zeroed offset arrays come first), prefix sums + allocation %.3f, fill %.3f s\n", tL1, tL2 - tL1, S->seconds[5] - tL2);
     { Work* w = W.release(); try { std::thread([w]() { delete w; }).detach(); } catch(...) { delete w; } }
     *out = S.release();
     return HLALA_OK;
