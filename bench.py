@@ -88,16 +88,68 @@ def make_workload(args, synth, rank):
     if args.graph == "m":
         w = synth.make_world_m(seed=2, n_levels=args.levels)
         mk = lambda n, seed, **kw: synth.make_batch_m(w, n, seed=seed, **kw)       # noqa: E731
-        desc = (f"{args.pairs} synthetic 2x150bp pairs per GPU (BASELINE config 2) vs Graph M, the SURVEY 8(d) stand-in for PRG_MHC_GRCh38_withIMGT: "
-                f"{args.levels} levels, 8 backbone haplotypes (0.3 % divergence, 2 % gap stretches), 40 gene windows of 3-6 kb with 500-5000 allele paths "
-                f"(suffix-10 node merging, up to {w['max_nodes_per_level']} nodes per level); reads: I101_NA12878 quality matrix stretched to 150, Poisson indels, "
-                f"start-to-start jump N(350,35) = inner distance N(200,35), 30 % of the pairs drawn from allele rows of the gene windows")
     else:
         w = synth.make_world(seed=2, G=args.levels, k=1, n_mut=3, n_largegap=1)
         mk = lambda n, seed, **kw: synth.make_batch_fast(w, n, seed=seed)          # noqa: E731
-        desc = (f"{args.pairs} synthetic 2x150bp pairs per GPU vs the round-1 stand-in: {args.levels} levels, 5 haplotypes "
-                f"(simpleGraphSimulator recipe), geometric qualities, no read indels, inner distance N(200,35)")
-    return w, mk, desc
+    return w, mk
+
+
+def workload_desc(args, w):
+    if args.graph == "m":
+        return (f"{args.pairs} synthetic 2x150bp pairs per GPU (BASELINE config 2) vs Graph M, the SURVEY 8(d) stand-in for PRG_MHC_GRCh38_withIMGT: "
+                f"{args.levels} levels, 8 backbone haplotypes (0.3 % divergence, 2 % gap stretches), 40 gene windows of 3-6 kb with 500-5000 allele paths "
+                f"(suffix-10 node merging, up to {int(w['max_nodes_per_level'])} nodes per level); reads: I101_NA12878 quality matrix stretched to 150, Poisson indels, "
+                f"start-to-start jump N(350,35) = inner distance N(200,35), 30 % of the pairs drawn from allele rows of the gene windows")
+    return (f"{args.pairs} synthetic 2x150bp pairs per GPU vs the round-1 stand-in: {args.levels} levels, 5 haplotypes "
+            f"(simpleGraphSimulator recipe), geometric qualities, no read indels, inner distance N(200,35)")
+
+
+BATCH_KEYS = ("read_off", "read_bases", "read_quals", "chain_off", "read_primary", "chain_contig", "chain_pos", "chain_offset", "chain_as", "chain_reverse", "cigar_off", "cigar")
+
+
+def shared_workload(args, synth, rank, world, dist):
+    """N > 1: rank 0 generates the world ONCE, and every rank's two batches with it (the generator keeps the allele matrices of the gene windows: eight
+    copies of it side by side are eight 10 s generations and eight working sets); the other ranks read the arrays from a directory in shared memory."""
+    import shutil
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    d = os.path.join(base, "hlala_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+    w = mk = None
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+        w, mk = make_workload(args, synth, rank)
+        for k, v in w["graph"].items():
+            np.save(os.path.join(d, "graph_%s.npy" % k), np.asarray(v))
+        for k, v in w["contigs"].items():
+            np.save(os.path.join(d, "contigs_%s.npy" % k), np.asarray(v))
+        np.save(os.path.join(d, "max_nodes_per_level.npy"), np.asarray(int(w.get("max_nodes_per_level", 0))))
+        for r in range(1, world):
+            for j, seed in enumerate((1000 + r, 5000 + r)):
+                bb = mk(args.pairs, seed)
+                np.save(os.path.join(d, "b%d_%d_scalars.npy" % (r, j)), np.asarray([bb["n_pairs"], bb["n_chains"]], np.int64))
+                np.save(os.path.join(d, "b%d_%d_insert.npy" % (r, j)), np.asarray([bb["insert_mean"], bb["insert_sd"]], np.float64))
+                for k in BATCH_KEYS:
+                    np.save(os.path.join(d, "b%d_%d_%s.npy" % (r, j, k)), bb[k])
+                del bb
+        bs = [mk(args.pairs, 1000), mk(args.pairs, 5000)]
+    dist.barrier()
+    if rank != 0:
+        ld = lambda n: np.load(os.path.join(d, n + ".npy"))          # noqa: E731
+        def unbox(a): return a.item() if a.ndim == 0 else a          # noqa: E704
+        g = {k[6:-4]: unbox(ld(k[:-4])) for k in sorted(os.listdir(d)) if k.startswith("graph_")}
+        c = {k[8:-4]: unbox(ld(k[:-4])) for k in sorted(os.listdir(d)) if k.startswith("contigs_")}
+        w = {"graph": g, "contigs": c, "max_nodes_per_level": int(ld("max_nodes_per_level"))}
+        bs = []
+        for j in range(2):
+            sc = ld("b%d_%d_scalars" % (rank, j)); ins = ld("b%d_%d_insert" % (rank, j))
+            bb = {"n_pairs": int(sc[0]), "n_chains": int(sc[1]), "insert_mean": float(ins[0]), "insert_sd": float(ins[1])}
+            for k in BATCH_KEYS:
+                bb[k] = ld("b%d_%d_%s" % (rank, j, k))
+            bs.append(bb)
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+    return w, mk, bs
 
 
 def main():
@@ -110,13 +162,16 @@ def main():
     ap.add_argument("--graph", choices=["m", "simple"], default="m")
     ap.add_argument("--cpu-pairs", type=int, default=16384, help="pairs of the same workload timed on the CPU oracle (1 thread; 4x as many on all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="two batches alternate, but each step's export follows its alignment at once (a batch's tail does not run beside the next batch)")
-    ap.add_argument("--single-batch", action="store_true", help="one resident batch, steps strictly one after the other (no overlap of a batch's tail with the next batch)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region (host-inclusive, gene / backbone split, streaming, typer)")
-    ap.add_argument("--host-steps", type=int, default=6, help="steps of the host-inclusive loop (0 = skip)")
+    ap.add_argument("--no-overlap", action="store_true", help="resident loop: two batches alternate, but each step's export follows its alignment at once (a batch's tail does not run beside the next batch)")
+    ap.add_argument("--single-batch", action="store_true", help="one batch at a time in both loops: no overlap of a batch's tail / transfers with the next batch")
+    ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region (gene / backbone split, long reads, typer, end to end)")
+    ap.add_argument("--resident-only", action="store_true", help="kernel A/B mode: only the resident loop (inputs already in HBM) is run and timed; `value` is then the RESIDENT rate and the line says so")
+    ap.add_argument("--resident-steps", type=int, default=8, help="steps of the resident loop that follows the timed boundary loop (config.resident; 0 = skip)")
     ap.add_argument("--e2e-pairs", type=int, default=8_388_608, help="pairs of the sample pushed through `HLA-LA --action HLA` for the end-to-end rate (0 = skip)")
     ap.add_argument("--e2e-frac-gene", type=float, default=0.04, help="share of the end-to-end sample drawn from the gene windows: 0.04 = the windows' share of the graph, i.e. the uniform "
                     "coverage of a whole-genome sample (the resident workload keeps 0.3: its gene-window pairs are the expensive ones; at 0.3 every typed locus would see 2000x coverage)")
+    ap.add_argument("--e2e-threads", default="0,32", help="--decodeThreads values of the end-to-end runs (0 = all host threads)")
+    ap.add_argument("--long-reads", type=int, default=50_000, help="reads of the long-read record (BASELINE config 5: 50 000 reads of ~10 kb; 0 = skip)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -146,32 +201,108 @@ def main():
     from tools import synth
 
     t0 = time.time()
-    w, mk, desc = make_workload(args, synth, rank)
-    b = mk(args.pairs, 1000 + rank)
+    if world > 1:
+        w, mk, bsrc = shared_workload(args, synth, rank, world, dist)
+    else:
+        w, mk = make_workload(args, synth, rank)
+        bsrc = [mk(args.pairs, 1000), mk(args.pairs, 5000)]
+    if args.single_batch:
+        bsrc = bsrc[:1]
+    b = bsrc[0]
+    desc = workload_desc(args, w)
     t_gen = time.time() - t0
     stream = torch.cuda.current_stream().cuda_stream
     ckw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=12345, max_columns=384, device=local_rank)
     ctx = P.Context(w["graph"], w["contigs"], stream=stream, **ckw)
-    gb = ctx.batch(b)            # inputs resident in HBM from here on
-    # A sample is a stream of batches (BASELINE config 3): two batch objects of this workload alternate, as in the host program.  A step = one batch
-    # through the whole path and its record export (+ the gather to rank 0); the export of step i is issued after the alignment of step i+1, so the
-    # side-stream tail of one batch (the wide DP classes, include/hlala_gpu.h: hlala_align_batch) runs beside the bulk of the next.  K alignments and
-    # K exports lie between the two synchronisations.  --single-batch keeps one batch and no overlap between steps.
-    b2 = None if args.single_batch else mk(args.pairs, 5000 + rank)
-    gbs = [gb] if args.single_batch else [gb, ctx.batch(b2)]
-    if b2 is not None:
-        gbs[-1].src = b2
-    recs = [torch.empty((args.pairs, 8), dtype=torch.float64, device="cuda") for _ in gbs]
-    rec = recs[0]
-    gathered = [torch.empty_like(rec) for _ in range(world)] if (world > 1 and rank == 0) else None
+    recs = [torch.empty((args.pairs, 8), dtype=torch.float64, device="cuda") for _ in range(2)]
+    gathered = [torch.empty_like(recs[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+    n_gathers = [0]
 
-    def finish(k):
-        gbs[k].export_pair_records(recs[k].data_ptr())
+    # the gather runs on a stream of its own: the library's export returns with the records in place, and the collective must not queue behind the
+    # alignment of the NEXT batch, which the main stream already holds
+    gstream = torch.cuda.Stream() if world > 1 and backend == "nccl" else None
+
+    def before_export():
+        if gstream is not None:
+            gstream.synchronize()          # the previous gathers have read their record buffers
+
+    def gather(k):
+        # the ONE exchange of the path: the fixed-size per-pair records to rank 0 (RCCL over xGMI)
         if world > 1:
             if backend == "nccl":
-                dist.gather(recs[k], gathered, dst=0)          # RCCL over xGMI: the one exchange of the path
+                with torch.cuda.stream(gstream):
+                    dist.gather(recs[k], gathered, dst=0)
             else:
                 dist.gather(recs[k].cpu(), [g.cpu() for g in gathered] if gathered is not None else None, dst=0)
+            n_gathers[0] += 1
+
+    def timed(fn, n):
+        """barrier + synchronize on both sides of n steps, MAX over ranks"""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fn(n)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = mine = time.perf_counter() - t1
+        per_rank = [mine]
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            allt = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            per_rank = [float(x.item()) for x in allt]
+            el = max(per_rank)
+        return el, per_rank
+
+    # ---- the timed region: the boundary of the C ABI.  Per step: hlala_batch_create (H2D from page-locked caller buffers) -> hlala_align_batch ->
+    # export of the per-pair records (+ the gather to rank 0 for N > 1) -> hlala_batch_get_pairs + hlala_batch_get_pairs_packed (D2H of every column
+    # of the selected alignments) -> hlala_batch_destroy; two batches in flight on ONE context and one host thread: the next batch is uploaded and
+    # queued before the current one is read back (uploads on the context's upload stream, downloads on its reader stream).
+    boundary = None
+    if not args.resident_only:
+        bnd = Boundary(args, P, ctx, bsrc)
+        try:
+            def run_boundary(n):
+                if n <= 0:
+                    return
+                if args.single_batch:
+                    for i in range(n):
+                        h = bnd.start(i); before_export()
+                        bnd.finish(h, recs[0], lambda: gather(0))
+                    return
+                cur = bnd.start(0)
+                for i in range(n):
+                    nxt = bnd.start(i + 1) if i + 1 < n else None
+                    before_export()
+                    bnd.finish(cur, recs[i % 2], lambda k=i % 2: gather(k))
+                    cur = nxt
+            run_boundary(max(args.warmup, 1))          # (at least one: pool blocks, first touch of the page-locked buffers)
+            g0 = n_gathers[0]
+            elapsed, per_rank = timed(run_boundary, args.steps)
+            boundary = {"elapsed": elapsed, "per_rank_s": per_rank, "gathers": n_gathers[0] - g0, "pairs_ok": bnd.pairs_ok(), "columns": bnd.last_cols,
+                        "bytes_up": bnd.bytes_up, "bytes_down": bnd.bytes_down()}
+            # the same with pageable caller buffers (what a caller that does not use hlala_pinned_alloc gets): a report
+            if world == 1 and not args.no_extras:
+                bnd.pageable()
+                run_boundary(1)
+                el_p, _ = timed(run_boundary, 3)
+                boundary["pageable"] = {"value": args.pairs * 3 / el_p, "ms_per_step": el_p / 3 * 1e3, "steps": 3}
+        finally:
+            bnd.free()
+
+    # ---- the resident loop: inputs in HBM, two batch objects of the workload alternate, a step = hlala_align_batch + the export of the per-pair records
+    # (+ the gather); the export of step i is issued after the alignment of step i+1, so the side-stream tail of one batch runs beside the bulk of the next.
+    gbs = [ctx.batch(x) for x in bsrc]
+    gb = gbs[0]
+
+    def finish(k):
+        before_export()
+        gbs[k].export_pair_records(recs[k].data_ptr())
+        gather(k)
 
     def run(n):
         for i in range(n):
@@ -184,28 +315,42 @@ def main():
         if len(gbs) > 1 and n > 0 and not args.no_overlap:
             finish((n - 1) % len(gbs))
 
-    run(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t1
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
+    rsteps = args.steps if args.resident_only else args.resident_steps
+    resident = None
+    if rsteps > 0:
+        run(args.warmup if args.resident_only else 2)
+        g0 = n_gathers[0]
+        el_r, per_rank_r = timed(run, rsteps)
+        resident = {"value": args.pairs * world * rsteps / el_r, "unit": "read pairs/s", "steps": rsteps, "ms_per_step": el_r / rsteps * 1e3, "per_rank_s": per_rank_r,
+                    "what": "inputs resident in HBM: hlala_align_batch + device-to-device export of the per-pair records (+ the gather for N > 1) per step, "
+                            + ("one batch at a time" if len(gbs) == 1 else "two resident batches alternate")}
+        if world > 1:
+            assert n_gathers[0] - g0 == rsteps, "every step of the resident loop gathers once"
+    else:
+        gb.align()
     st = gb.stats()          # HIP events of THIS batch's last alignment (the events belong to the batch) + device work counters
+    torch.cuda.synchronize()
+    rec = recs[(rsteps - 1) % len(gbs)] if rsteps > 0 else recs[0]          # the records of the last step (the ones the last gather carried)
+    n_ok_local = int((rec[:, 0] == 0).sum().item())
+    if world > 1:
+        # every rank's share arrived: the gathered records of the last step hold `pairs` valid rows per rank
+        oks = [None] * world
+        dist.all_gather_object(oks, n_ok_local)
+        if rank == 0:
+            assert dist.get_world_size() == world and len(gathered) == world
+            if backend == "nccl":
+                got = [int((g[:, 0] == 0).sum().item()) for g in gathered]
+                assert got == [int(x) for x in oks], f"gathered records differ from the ranks' own counts: {got} vs {oks}"
+    else:
+        oks = [n_ok_local]
+
     if rank == 0:
-        n_ok = int((rec[:, 0] == 0).sum().item())
-        ms_per_step = elapsed / args.steps * 1e3
-        value = args.pairs * world * args.steps / elapsed
+        if boundary is not None:
+            elapsed = boundary["elapsed"]; steps = args.steps
+        else:
+            elapsed = resident["ms_per_step"] * 1e-3 * resident["steps"]; steps = resident["steps"]
+        ms_per_step = elapsed / steps * 1e3
+        value = args.pairs * world * steps / elapsed
         g = w["graph"]
         chains_pp = st.n_chains_extended / args.pairs
         cols_pc = st.n_out_columns / max(1, st.n_chains_extended)
@@ -220,7 +365,7 @@ def main():
         achieved = bpp * args.pairs / (dom_ms * 1e-3) / 1e9
         khash = kernel_source_hash()
         traffic, traffic_note, secondary = None, "no PMC pass on file for this build", {}
-        tfile = next((f for f in (os.path.join(ROOT, "profiles", t + "_traffic.json") for t in ("r03", "r02")) if os.path.exists(f)), "")
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", t + "_traffic.json") for t in ("r04", "r03", "r02")) if os.path.exists(f)), "")
         tname = os.path.relpath(tfile, ROOT) if tfile else ""
         if tfile:
             try:
@@ -237,19 +382,24 @@ def main():
         secondary["dp_cells_per_s"] = st.n_dp_cells / (sum(cls_ms) * 1e-3)
         if secondary.get("valu_insts_all_dp_classes_per_launch"):
             secondary["valu_wave_insts_per_dp_cell"] = secondary["valu_insts_all_dp_classes_per_launch"] / max(1, st.n_dp_cells)
+        headline = ("host-inclusive: hlala_batch_create (H2D, page-locked caller buffers) + hlala_align_batch + export of the per-pair records (+ gather) + hlala_batch_get_pairs + "
+                    "hlala_batch_get_pairs_packed (D2H) + hlala_batch_destroy per step, " + ("one batch at a time" if args.single_batch else "two batches in flight on one context, one host thread")) \
+            if boundary is not None else "RESIDENT rate (--resident-only: kernel A/B mode, the boundary loop was not run)"
         out = {
             "metric": "paired reads/sec aligned to PRG graph", "value": value, "unit": "read pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": desc, "graph": args.graph, "pairs_per_gpu": args.pairs, "graph_levels": args.levels, "graph_nodes": int(g["n_nodes"]), "graph_edges": int(g["n_edges"]),
-                       "parallelism": f"shard{world}", "batches_in_flight": len(gbs), "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
+            "config": {"workload": desc, "timed_region": headline, "graph": args.graph, "pairs_per_gpu": args.pairs, "graph_levels": args.levels, "graph_nodes": int(g["n_nodes"]), "graph_edges": int(g["n_edges"]),
+                       "parallelism": f"shard{world}", "batches_in_flight": 1 if args.single_batch else 2, "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
                        "columns_per_chain": cols_pc, "mean_out_degree": e_mean,
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
-                       "pairs_ok": n_ok, "chain_errors": int(st.n_errors),
+                       "pairs_ok": int(oks[0]), "pairs_ok_per_rank": [int(x) for x in oks], "chain_errors": int(st.n_errors),
+                       "resident": resident,
                        "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "pair": st.ms_pair, "side_stream": st.ms_side,
-                                    "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6], "dp_lane": float(st.ms_dp_lane)},
-                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "lane": int(st.n_dp_lane)},
+                                    "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6]},
+                       "stage_ms_source": "HIP events of one batch of the resident loop, on the streams its kernels ran on (the kernels of the boundary loop are the same)",
+                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6]},
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,
@@ -258,16 +408,26 @@ def main():
                                  "round trips, not by HBM (SURVEY 8(d)): see `secondary`",
                          "secondary": secondary},
         }
-        if world == 1 and not args.no_extras:
+        if boundary is not None:
+            out["host_inclusive"] = {"value": value, "unit": "read pairs/s", "steps": steps, "ms_per_step": ms_per_step, "per_rank_s": boundary["per_rank_s"], "gathers_in_timed_region": boundary["gathers"],
+                                     "columns_returned_per_step": boundary["columns"], "bytes_down_per_step": boundary["bytes_down"], "bytes_up_per_step": boundary["bytes_up"],
+                                     "pairs_ok_last_step": boundary["pairs_ok"], "pageable": boundary.get("pageable"), "what": "this IS the headline: `value` / `ms_per_step` of this line"}
+            if world > 1:
+                assert boundary["gathers"] == args.steps, "every step of the timed region gathers once"
+        if world == 1 and not args.no_extras and not args.resident_only:
             try:
-                if args.host_steps > 0:
-                    out["host_inclusive"] = host_pipeline(args, P, ctx, [b, gbs[-1].src if hasattr(gbs[-1], "src") else b])
                 out["config"].update(extras(args, P, synth, w, mk, b, ctx, gb, ckw))
             except Exception as e:          # the extras are reports, never a reason to lose the bench line
                 out["config"]["extras_error"] = repr(e)
-            for x in gbs:
-                x.close()
-            ctx.close()
+        for x in gbs:
+            x.close()
+        ctx.close()
+        if world == 1 and not args.no_extras and not args.resident_only:
+            if args.long_reads > 0:
+                try:
+                    out["long_reads"] = long_reads(args, P, synth, w)
+                except Exception as e:
+                    out["long_reads"] = {"error": repr(e)}
             if args.e2e_pairs > 0 and args.graph == "m":
                 try:
                     out["end_to_end"] = end_to_end(args, P, synth, w, mk)
@@ -277,6 +437,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, synth, w, mk)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -308,83 +469,85 @@ class Pinned:
         self.ptrs = []
 
 
-def host_pipeline(args, P, ctx, batches):
-    """The boundary in the loop: per step hlala_batch_create (H2D) -> hlala_align_batch -> per-pair scalars + hlala_batch_get_pairs_packed (D2H: level 4 B +
-    graph char + read char + mapQ char of every column of the selected alignments, the 7 B per column SURVEY 8(d) counts as output) -> hlala_batch_destroy,
-    two batches in flight on one context and one host thread, page-locked caller buffers."""
-    import ctypes as C
-    lib = ctx.lib
-    pin = Pinned(lib)
-    try:
-        ins = []
-        dts = dict(read_bases=np.uint8, read_quals=np.uint8, chain_contig=np.int32, chain_pos=np.int32, chain_offset=np.int32, chain_as=np.int32, chain_reverse=np.uint8, cigar=np.uint32,
-                   read_off=np.int64, chain_off=np.int64, cigar_off=np.int64, read_primary=np.int32)
+class Boundary:
+    """The C-ABI boundary of one step: hlala_batch_create (H2D) -> hlala_align_batch | export of the per-pair records (+ gather) -> per-pair scalars +
+    hlala_batch_get_pairs_packed (D2H: level 4 B + graph char + read char + mapQ char of every column of the selected alignments, the 7 B per column
+    SURVEY 8(d) counts as output) -> hlala_batch_destroy.  Caller buffers are page-locked (hlala_pinned_alloc) until pageable() swaps them."""
+
+    DTS = dict(read_bases=np.uint8, read_quals=np.uint8, chain_contig=np.int32, chain_pos=np.int32, chain_offset=np.int32, chain_as=np.int32, chain_reverse=np.uint8, cigar=np.uint32,
+               read_off=np.int64, chain_off=np.int64, cigar_off=np.int64, read_primary=np.int32)
+
+    def __init__(self, args, P, ctx, batches):
+        import ctypes as C
+        self.C = C; self.P = P; self.ctx = ctx; self.lib = lib = ctx.lib; self.batches = batches
+        self.pin = pin = Pinned(lib)
+        self.ins = []
         for b in batches:
             d = {k: b[k] for k in ("n_pairs", "n_chains")}
-            for k, dt in dts.items():
+            for k, dt in self.DTS.items():
                 d[k] = pin.copy(np.ascontiguousarray(b[k], dt))
             st, keep = P.fill_struct(P.BatchIn, d)
-            ins.append((st, keep, d))
-        n = args.pairs; nr = 2 * n; cap = nr * 184
-        off = pin.empty(nr + 1, np.int64)
-        cols = dict(col_level=pin.empty(cap, np.int32), col_gchar=pin.empty(cap, np.uint8), col_schar=pin.empty(cap, np.uint8), col_mapq=pin.empty(cap, np.uint8))
-        scal = dict(pair_status=pin.empty(n, np.int32), best_chain=pin.empty(nr, np.int32), n_combinations=pin.empty(n, np.int32), pair_ll=pin.empty(n, np.float64),
-                    pair_mapq=pin.empty(n, np.float64), mate_mapq=pin.empty(nr, np.float64), strands_valid=pin.empty(n, np.uint8))
-        po, keep_po = P.fill_struct(P.PairsOut, scal)
-        pk = P.PairsPackedOut(); pk.cap_cols = cap; pk.col_off = off.ctypes.data_as(P.c_i64p)
-        types = dict(P.PairsPackedOut._fields_)
-        for k, v in cols.items():
-            setattr(pk, k, v.ctypes.data_as(types[k]))
+            self.ins.append((st, keep, d))
+        self.bytes_up = int(sum(self.ins[0][2][k].nbytes for k in self.DTS))
+        self.n = n = args.pairs; self.nr = nr = 2 * n; self.cap = cap = nr * 184
+        self.off = pin.empty(nr + 1, np.int64)
+        self.cols = dict(col_level=pin.empty(cap, np.int32), col_gchar=pin.empty(cap, np.uint8), col_schar=pin.empty(cap, np.uint8), col_mapq=pin.empty(cap, np.uint8))
+        self.scal = dict(pair_status=pin.empty(n, np.int32), best_chain=pin.empty(nr, np.int32), n_combinations=pin.empty(n, np.int32), pair_ll=pin.empty(n, np.float64),
+                         pair_mapq=pin.empty(n, np.float64), mate_mapq=pin.empty(nr, np.float64), strands_valid=pin.empty(n, np.uint8))
+        self.po, self._keep_po = P.fill_struct(P.PairsOut, self.scal)
+        self.pk = P.PairsPackedOut(); self.pk.cap_cols = cap
+        self._bind(self.off, self.cols)
         lib.hlala_batch_get_pairs_packed.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(P.PairsPackedOut)]
         lib.hlala_batch_get_pairs.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(P.PairsOut)]
+        lib.hlala_batch_export_pair_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.last_cols = 0
 
-        def start(i):
-            h = C.c_void_p()
-            ctx._check(lib.hlala_batch_create(ctx.h, C.byref(ins[i % len(ins)][0]), C.byref(h)), "hlala_batch_create")
-            ctx._check(lib.hlala_align_batch(ctx.h, h), "hlala_align_batch")
-            return h
+    def _bind(self, off, cols):
+        types = dict(self.P.PairsPackedOut._fields_)
+        self.pk.col_off = off.ctypes.data_as(self.P.c_i64p)
+        for k, v in cols.items():
+            setattr(self.pk, k, v.ctypes.data_as(types[k]))
+        self._bound = (off, cols)
 
-        def finish(h):
-            ctx._check(lib.hlala_batch_get_pairs(ctx.h, h, C.byref(po)), "hlala_batch_get_pairs")
-            ctx._check(lib.hlala_batch_get_pairs_packed(ctx.h, h, C.byref(pk)), "hlala_batch_get_pairs_packed")
-            lib.hlala_batch_destroy(h)
-            return int(pk.n_cols_total)
+    def pageable(self):
+        P = self.P
+        self._bind(np.zeros(self.nr + 1, np.int64), {k: np.zeros_like(v) for k, v in self.cols.items()})
+        ins = []
+        for b in self.batches:
+            st, keep = P.fill_struct(P.BatchIn, {k: np.ascontiguousarray(b[k], dt) for k, dt in self.DTS.items()} | {k: b[k] for k in ("n_pairs", "n_chains")})
+            ins.append((st, keep, None))
+        self.ins = ins
 
-        def loop(k):
-            cur = start(0); ncols = 0
-            for i in range(k):
-                nxt = start(i + 1) if i + 1 < k else None      # the next batch is uploaded and queued before this one is read back
-                ncols = finish(cur)
-                cur = nxt
-            return ncols
+    def start(self, i):
+        C = self.C; h = C.c_void_p()
+        self.ctx._check(self.lib.hlala_batch_create(self.ctx.h, C.byref(self.ins[i % len(self.ins)][0]), C.byref(h)), "hlala_batch_create")
+        self.ctx._check(self.lib.hlala_align_batch(self.ctx.h, h), "hlala_align_batch")
+        return h
 
-        loop(2)                                                # warm: pool blocks, first touch
-        t = time.perf_counter(); ncols = loop(args.host_steps); dt = time.perf_counter() - t
-        ok = int((scal["pair_status"] == 0).sum())
-        res = {"value": args.pairs * args.host_steps / dt, "unit": "read pairs/s", "steps": args.host_steps, "ms_per_step": dt / args.host_steps * 1e3, "columns_returned_per_step": ncols,
-               "bytes_down_per_step": 7 * ncols + 8 * (nr + 1) + 37 * n, "bytes_up_per_step": int(sum(ins[0][2][k].nbytes for k in dts)), "pairs_ok_last_step": ok,
-               "what": "hlala_batch_create (H2D) + hlala_align_batch + hlala_batch_get_pairs + hlala_batch_get_pairs_packed (D2H) + hlala_batch_destroy per step; page-locked "
-                       "caller buffers (hlala_pinned_alloc); two batches in flight on one context, one host thread"}
-        # the same with pageable caller buffers (what a caller that does not use hlala_pinned_alloc gets)
-        offp = np.zeros(nr + 1, np.int64); colsp = {k: np.zeros_like(v) for k, v in cols.items()}
-        pk.col_off = offp.ctypes.data_as(P.c_i64p)
-        for k, v in colsp.items():
-            setattr(pk, k, v.ctypes.data_as(types[k]))
-        insp = []
-        for b in batches:
-            st, keep = P.fill_struct(P.BatchIn, {k: b[k] for k in list(dts) + ["n_pairs", "n_chains"]}); insp.append((st, keep, None))
-        ins, insq = insp, ins
-        loop(1)
-        t = time.perf_counter(); loop(3); dtp = time.perf_counter() - t
-        res["pageable"] = {"value": args.pairs * 3 / dtp, "ms_per_step": dtp / 3 * 1e3, "steps": 3}
-        return res
-    finally:
-        pin.free()
+    def finish(self, h, rec, gather):
+        C = self.C
+        self.ctx._check(self.lib.hlala_batch_export_pair_records(self.ctx.h, h, C.c_void_p(rec.data_ptr())), "hlala_batch_export_pair_records")
+        gather()
+        self.ctx._check(self.lib.hlala_batch_get_pairs(self.ctx.h, h, C.byref(self.po)), "hlala_batch_get_pairs")
+        self.ctx._check(self.lib.hlala_batch_get_pairs_packed(self.ctx.h, h, C.byref(self.pk)), "hlala_batch_get_pairs_packed")
+        self.lib.hlala_batch_destroy(h)
+        self.last_cols = int(self.pk.n_cols_total)
+
+    def pairs_ok(self):
+        return int((self.scal["pair_status"] == 0).sum())
+
+    def bytes_down(self):
+        return 7 * self.last_cols + 8 * (self.nr + 1) + 37 * self.n
+
+    def free(self):
+        self.pin.free()
 
 
 def end_to_end(args, P, synth, w, mk):
     """BAM bytes -> hla/*: `HLA-LA --action HLA` (hla-la_amd/host/HLA-LA.cpp) on a Graph M graph directory; bwa / samtools stand-ins hand over the BAM of a
-    synthetic sample (their command lines run unchanged).  The figure is the program's own End-to-end line: units / (BAM decode + alignment and typing)."""
+    synthetic sample (their command lines run unchanged).  The figure is the program's own End-to-end line: units / (BAM decode + page-locking and insert size +
+    alignment and typing).  One sample, one run per --decodeThreads value of --e2e-threads (0 = all host threads; 32 = the share of a 256-thread host one of
+    eight samples gets in BASELINE config 4)."""
     import re
     import shutil
     import stat
@@ -420,29 +583,71 @@ def end_to_end(args, P, synth, w, mk):
         for fq in ("r1.fq", "r2.fq"):
             with open(os.path.join(tmp, fq), "w") as f:
                 f.write("@r\nA\n+\nI\n")
-        outd = os.path.join(tmp, "out")
-        cmd = [exe, "--action", "HLA", "--maxThreads", "2", "--sampleID", "S", "--outputDirectory", outd, "--PRG_graph_dir", gdir, "--FASTQU", os.path.join(tmp, "r1.fq"),
-               "--FASTQ1", os.path.join(tmp, "r1.fq"), "--FASTQ2", os.path.join(tmp, "r2.fq"), "--bwa_bin", os.path.join(tmp, "bwa"), "--samtools_bin", os.path.join(tmp, "samtools"),
-               "--mapAgainstCompleteGenome", "0", "--longReads", "0", "--loci", ",".join(loci), "--rngSeed", "12345", "--batchPairs", str(ch)]
-        t0 = time.time()
-        r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp, timeout=1500)
-        t_run = time.time() - t0
-        if r.returncode != 0:
-            return {"error": (r.stdout + r.stderr)[-1500:]}
-        m = re.search(r"End-to-end: ([0-9.e+]+) units per s \(BAM decode ([0-9.e+-]+) s on (\d+) threads \+ alignment and typing ([0-9.e+-]+) s; context creation and insert size ([0-9.e+-]+) s", r.stdout)
-        sp = re.search(r"Speed: ([0-9.e+]+) protoSeeds", r.stdout)
-        ph = re.search(r"Typing phases: (.*)", r.stdout)
-        files = sorted(os.listdir(os.path.join(outd, "hla")))
-        calls = [ln for ln in r.stdout.splitlines() if ln.startswith("Locus ")]
-        return {"value": float(m.group(1)), "unit": "read pairs/s", "pairs": nch * ch, "bam_bytes": int(size), "decode_s": float(m.group(2)), "decode_threads": int(m.group(3)),
-                "alignment_and_typing_s": float(m.group(4)), "context_and_insert_size_s": float(m.group(5)), "speed_line_pairs_per_s": float(sp.group(1)) if sp else None,
-                "process_wall_s": t_run, "whole_process_pairs_per_s": nch * ch / t_run, "typing_phases": ph.group(1) if ph else None,
-                "log": [ln[:600] for ln in r.stdout.splitlines() if ("Seed extraction:" in ln or ln.startswith("End-to-end:"))] + [ln[:300] for ln in r.stderr.splitlines() if ln.startswith("bam-debug:")][:40], "loci": loci, "result_files": len(files), "calls": calls[:6], "gene_window_share_of_the_sample": args.e2e_frac_gene,
-                "setup_s": {"graph_directory": t_dir, "sample_generation_and_bam": t_bam},
-                "what": "HLA-LA --action HLA: BAM bytes -> hla/* (decode on all host threads, batches of %d pairs two in flight on one GPU, typing of %d loci, result files); "
-                        "value = pairs / (decode + alignment and typing), the program's End-to-end line; graph loading and context creation are per process" % (ch, len(loci))}
+
+        def one(threads):
+            outd = os.path.join(tmp, "out%d" % threads)
+            cmd = [exe, "--action", "HLA", "--maxThreads", "2", "--sampleID", "S", "--outputDirectory", outd, "--PRG_graph_dir", gdir, "--FASTQU", os.path.join(tmp, "r1.fq"),
+                   "--FASTQ1", os.path.join(tmp, "r1.fq"), "--FASTQ2", os.path.join(tmp, "r2.fq"), "--bwa_bin", os.path.join(tmp, "bwa"), "--samtools_bin", os.path.join(tmp, "samtools"),
+                   "--mapAgainstCompleteGenome", "0", "--longReads", "0", "--loci", ",".join(loci), "--rngSeed", "12345", "--batchPairs", str(ch)]
+            if threads > 0:
+                cmd += ["--decodeThreads", str(threads)]
+            t0 = time.time()
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp, timeout=1500)
+            t_run = time.time() - t0
+            if r.returncode != 0:
+                return {"error": (r.stdout + r.stderr)[-1500:]}
+            m = re.search(r"End-to-end: ([0-9.e+]+) units per s \(BAM decode ([0-9.e+-]+) s on (\d+) threads \+ page-locking and insert size ([0-9.e+-]+) s \+ alignment and typing ([0-9.e+-]+) s", r.stdout)
+            sp = re.search(r"Speed: ([0-9.e+]+) protoSeeds", r.stdout)
+            ph = re.search(r"Typing phases: (.*)", r.stdout)
+            files = sorted(os.listdir(os.path.join(outd, "hla")))
+            calls = [ln for ln in r.stdout.splitlines() if ln.startswith("Locus ")]
+            shutil.rmtree(outd, ignore_errors=True)
+            return {"value": float(m.group(1)), "unit": "read pairs/s", "pairs": nch * ch, "bam_bytes": int(size), "decode_s": float(m.group(2)), "decode_threads": int(m.group(3)),
+                    "page_locking_and_insert_size_s": float(m.group(4)), "alignment_and_typing_s": float(m.group(5)), "speed_line_pairs_per_s": float(sp.group(1)) if sp else None,
+                    "process_wall_s": t_run, "whole_process_pairs_per_s": nch * ch / t_run, "typing_phases": ph.group(1) if ph else None,
+                    "log": [ln[:700] for ln in r.stdout.splitlines() if ("Seed extraction:" in ln or ln.startswith("End-to-end:"))] + [ln[:300] for ln in r.stderr.splitlines() if ln.startswith("bam-debug:")][:40],
+                    "loci": loci, "result_files": len(files), "calls": calls[:6]}
+
+        runs = [one(int(t)) for t in str(args.e2e_threads).split(",") if t.strip() != ""]
+        res = runs[0]
+        res.update({"gene_window_share_of_the_sample": args.e2e_frac_gene, "setup_s": {"graph_directory": t_dir, "sample_generation_and_bam": t_bam},
+                    "what": "HLA-LA --action HLA: BAM bytes -> hla/* (decode on the stated host threads, batches of %d pairs two in flight on one GPU, typing of %d loci, result files); "
+                            "value = pairs / (decode + page-locking and insert size + alignment and typing), the program's End-to-end line; graph loading and context creation are per process" % (ch, len(loci))})
+        if len(runs) > 1:
+            res["other_thread_counts"] = [{k: r.get(k) for k in ("value", "decode_s", "decode_threads", "page_locking_and_insert_size_s", "alignment_and_typing_s", "process_wall_s", "whole_process_pairs_per_s", "error") if k in r} for r in runs[1:]]
+        return res
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def long_reads(args, P, synth, w):
+    """BASELINE config 5: long-read mode (processBAM::alignOneLongRead, mapper/processBAM.cpp:3618-3838: projection of the one primary alignment +
+    extendToFullSequenceLength + scoreOneAlignment; the reference runs no extension DP in this mode, :3732-3734).  --long-reads distinct reads over 6-14 kb of
+    reference (mean read length ~10.2 kb) drawn from the backbone haplotypes of the bench's graph -- crossing the gene windows where they lie --, substitutions 5 %, insertions 4 %,
+    deletions 4 %, in batches of 10 000 reads through a context with 16 384-column rows.  Inputs resident; reads/s and bases/s, stage times."""
+    n = args.long_reads; per = 10000
+    ctx = P.Context(w["graph"], w["contigs"], insert_mean=200.0, insert_sd=35.0, rng_seed=12345, long_read_mode=1, max_columns=16384, device=0)
+    try:
+        t0 = time.time()
+        bs = synth.make_long_batches_parallel(w, n, per_batch=per, seed=700, len_lo=6000, len_hi=14000, procs=min(16, max(1, (os.cpu_count() or 8) // 2)))
+        t_gen = time.time() - t0
+        gbs = [ctx.batch_unpaired(x) for x in bs]
+        bases = int(sum(int(x["read_off"][-1]) for x in bs))
+        gbs[0].align(); gbs[0].stats()                       # warm-up (stats() waits for the batch)
+        t = time.perf_counter()
+        for g in gbs:
+            g.align()
+        sts = [g.stats() for g in gbs]                     # (the batches run in order on the context's main stream)
+        dt = time.perf_counter() - t
+        ok = int(sum(int((g.pairs_scalars()["pair_status"] == 0).sum()) for g in gbs))
+        for g in gbs:
+            g.close()
+        return {"reads": n, "bases": bases, "mean_read_length": bases / max(1, n), "reads_per_s": n / dt, "bases_per_s": bases / dt, "seconds": dt, "batches": len(gbs), "reads_ok": ok,
+                "stage_ms_sum": {"project": float(sum(s.ms_project for s in sts)), "pad_and_score": float(sum(s.ms_extend for s in sts)), "select": float(sum(s.ms_pair for s in sts))},
+                "chain_errors": int(sum(int(s.n_errors) for s in sts)), "generation_s": t_gen,
+                "what": "hlala_batch_create_unpaired batches resident in HBM, hlala_align_batch each; distinct reads, one primary alignment each (the reference takes primaries only, processBAM.cpp:732-738)"}
+    finally:
+        ctx.close()
 
 
 def cpu_baseline(args, synth, w, mk):

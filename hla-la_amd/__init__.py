@@ -648,9 +648,18 @@ def load_library(path: str | None = None):
     lib.hlala_exon_positions.argtypes = [vp, vp, C.POINTER(LocusDesc), C.POINTER(ExonPositionsOut)]
     lib.hlala_call_locus.argtypes = [vp, C.c_int32, c_f64p, c_f64p, c_f64p, c_i32p, c_f64p, c_f64p, C.POINTER(CallOut)]
     lib.hlala_abi_sizeof.restype = C.c_int
+    # a library built from another revision of include/hlala_gpu.h may keep every struct size and still mean something else by a field
+    # (round 3: 64-bit window offsets in hlala_batch_in): refuse it instead of uploading garbage
+    if not hasattr(lib, "hlala_abi_version") or lib.hlala_abi_version() != ABI_VERSION:
+        got = lib.hlala_abi_version() if hasattr(lib, "hlala_abi_version") else "none"
+        raise HlalaError(f"{p}: interface version {got}, this binding mirrors version {ABI_VERSION} of include/hlala_gpu.h -- rebuild the library")
     if path is None:
         _lib = lib
     return lib
+
+
+ABI_VERSION = 2              # HLALA_ABI_VERSION of include/hlala_gpu.h
+BUILD_LANE_CLASS = 1         # hlala_build_flags(): the lane-per-DP class is compiled in (make EXTRA=-DHLALA_WITH_LANE_CLASS)
 
 
 EXPORTED_SYMBOLS = [
@@ -659,7 +668,7 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_set_first_chain", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_get_pairs_packed", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
-    "hlala_kat_rand_r", "hlala_kat_exp", "hlala_abi_sizeof", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
+    "hlala_kat_rand_r", "hlala_kat_exp", "hlala_abi_sizeof", "hlala_abi_version", "hlala_build_flags", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
     "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
     "hlala_bam_extract_seeds", "hlala_bam_extract_seeds_mt", "hlala_seed_batch_desc", "hlala_seed_batch_window", "hlala_seed_batch_units", "hlala_seed_batch_name", "hlala_seed_batch_timing",
     "hlala_seed_batch_free", "hlala_seed_batch_pin", "hlala_bam_last_error", "hlala_pinned_alloc", "hlala_pinned_free", "hlala_host_register", "hlala_host_unregister", "hlala_set_insert_size",

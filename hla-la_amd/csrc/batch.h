@@ -69,6 +69,12 @@ struct DevBatch {
                                     //      items the lane-per-DP class passed on to the 16-lane class (work_counter[40..45], kernel_dp_lane.hip)
     uint8_t* pair_deferred;         // [n_pairs] 1: a DP call of the pair went to the in-memory class; with the fused entry point its chains are stitched and
                                     //           the pair is scored in a second pass, after that class (which runs on a side stream next to the first pass)
+    // ---- position order of the chains (kernel_order.hip): the kernels that walk the graph take their chains in this order, so that the work in flight at
+    //      one time sits on neighbouring levels and its share of the graph arrays stays in the L2 (input order = read-name order = random positions)
+    int* chain_order;               // [n_chains] chain numbers sorted by position bucket; null: input order
+    int* chain_bucket;              // [n_chains] position bucket = first level >> order_shift (the last bucket: chains filtered out)
+    int* order_hist;                // [order_nb + 1] bucket counts -> bucket starts -> scatter cursors
+    int order_shift, order_nb;
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
     int* dbg;                       // non-null with HLALA_DEBUG=1: kernels add phase clocks to counters[16..31]
 };

@@ -16,8 +16,11 @@
 
 // unity build: the kernels live in their own files but are compiled in this translation unit
 #include "kernel_dp.hip"
+#ifdef HLALA_WITH_LANE_CLASS      // the lane-per-DP class lost its A/B and is not part of the default library: make EXTRA=-DHLALA_WITH_LANE_CLASS
 #include "kernel_dp_lane.hip"
+#endif
 #include "kernel_project.hip"
+#include "kernel_order.hip"
 #include "kernel_pair.hip"
 #include "kernel_typer.hip"
 #include "kernel_call.hip"
@@ -71,6 +74,7 @@ struct hlala_ctx {
     char* rethread_slabs = nullptr; size_t rethread_slab_bytes = 0; int rethread_grid = 0;      // k_rethread_chains: back pointers of one chain per wave (short reads; HLALA_RETHREAD=0 turns the kernel off)
     double* pair_scratch = nullptr;   // [2 * pair_grid][PAIR_COMB]: combination tables of the rare pairs with more than PAIR_COMB_LDS combinations (main- and side-stream pass)
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
+    int order_shift = 8, order_nb = 0;      // position buckets of a batch's chains (kernel_order.hip); order_nb 0: input order (HLALA_LOCALITY=0)
     int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
     // per-pair post-processing: coverage counters [L-1] and gene intervals
     int* d_cov = nullptr; int n_cov = 0; int* d_gene_first = nullptr; int* d_gene_last = nullptr; int n_genes = 0;
@@ -113,7 +117,12 @@ struct DevGuard {
 // everything on the main stream that reads or rewrites a batch goes behind the side-stream work of its last fused alignment
 static int join_side(hlala_ctx* c, hlala_batch* b)
 {
-    if(b->side_inflight) { HIP_TRY(c, hipStreamWaitEvent(c->stream, b->evDone, 0)); b->side_inflight = false; }
+    if(b->side_inflight) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, b->evDone, 0));
+        // evMain is what hlala_batch_destroy and the readers wait for once side_inflight is cleared: it has to lie BEHIND the wait just queued even if the
+        // stage call that joined returns early (state / launch error) and never reaches its own mark_main
+        if(b->evMain) { HIP_TRY(c, hipEventRecord(b->evMain, c->stream)); b->mainValid = true; b->side_inflight = false; }
+    }
     return HLALA_OK;
 }
 static int batch_events(hlala_ctx* c, hlala_batch* b)
@@ -396,8 +405,10 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->huge_slab_bytes = dp_inmemory_bytes<DpHuge>();
     if((rc = slab_pool(&c->tiny_slabs, c->tiny_slab_bytes * (size_t)(64 / DpTiny::GW) * (size_t)c->tiny_grid, "16-lane DP slabs"))) return fail(rc);
     // (an experiment that lost, kept switchable and under test: HLALA_DP_LANE=1 puts the lane-per-DP class in front of the 16-lane class -- kernel_dp_lane.hip)
+#ifdef HLALA_WITH_LANE_CLASS
     { const char* e = getenv("HLALA_DP_LANE"); c->lane_grid = (e && atoi(e) != 0) ? cus * 4 : 0; }          // 36 KB of LDS per wave: four per CU
     if(c->lane_grid && (rc = slab_pool(&c->lane_slabs, dp_lane_slab_bytes() * (size_t)64 * (size_t)c->lane_grid, "lane-per-DP slabs"))) return fail(rc);
+#endif
     if((rc = slab_pool(&c->mid_slabs, c->mid_slab_bytes * (size_t)(64 / DpMid::GW) * (size_t)c->mid_grid, "32-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid, "64-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid, "wide-class DP slabs"))) return fail(rc);
@@ -428,6 +439,9 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
             c->allocs.push_back(c->rethread_slabs);
         }
     }
+    // position buckets: a few hundred levels each, at most 16 384 of them (the scan is one block)
+    { const char* e = getenv("HLALA_LOCALITY");
+      if(!(e && atoi(e) == 0)) { int sh = 8; if(e && atoi(e) >= 2 && atoi(e) <= 20) sh = atoi(e); while((F.L >> sh) + 2 > 16384) sh++; c->order_shift = sh; c->order_nb = (F.L >> sh) + 2; } }
     if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
     if(hipEventCreateWithFlags(&c->evSideTail, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); }
@@ -509,6 +523,8 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
     AL(pair_deferred, np, true); AL(counters, 32, true); AL(work_counter, 48, true); AL(retry_list, 14 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
+    B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb;
+    if(c->order_nb > 0 && !B.from_seeds && nc > 0) { AL(chain_order, nc, false); AL(chain_bucket, nc, false); AL(order_hist, (size_t)c->order_nb + 1, false); }
     B.dbg = c->dbg_host;
 #undef AL
     return 0;
@@ -674,7 +690,14 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     HIP_TRY(c, hipEventRecord(b->ev[0], c->active));
     if(B.n_chains > 0) {
         int threads = 256, blocks = (B.n_reads + threads - 1) / threads;
+        if(B.order_hist) HIP_TRY(c, hipMemsetAsync(B.order_hist, 0, ((size_t)B.order_nb + 1) * sizeof(int), c->active));
         hipLaunchKernelGGL(k_filter_chains, dim3(blocks), dim3(threads), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_level);
+        if(B.order_hist) {
+            // chains into position order (kernel_order.hip): every later kernel that walks the graph takes them from B.chain_order
+            hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_SCAN_THREADS), 0, c->active, B.order_hist, B.order_nb);
+            hipLaunchKernelGGL(k_order_scatter, dim3((B.n_chains + 255) / 256), dim3(256), 0, c->active, b->dB);
+            int rco = check_launch(c, "k_order_scatter"); if(rco) return rco;
+        }
         int grid = B.n_chains < c->proj_grid ? B.n_chains : c->proj_grid;
         if(c->proj_long_slabs)
             hipLaunchKernelGGL((k_project_chains<ProjLdsLong>), dim3(grid), dim3(64), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
@@ -757,6 +780,7 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
         };
         // the lane-per-DP class first: 64 calls per wavefront; what it cannot finish exactly goes on to the 16-lane class through its list
         b->lane_used = c->lane_grid > 0;
+#ifdef HLALA_WITH_LANE_CLASS
         if(b->lane_used) {
             tinyList = B.retry_list + (size_t)12 * (size_t)B.n_chains;
             HIP_TRY(c, hipEventRecord(b->evLane[0], c->active));
@@ -764,6 +788,7 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
             rc = check_launch(c, "k_dp_lane"); if(rc) return rc;
             HIP_TRY(c, hipEventRecord(b->evLane[1], c->active));
         }
+#endif
         HIP_TRY(c, hipEventRecord(b->ev[7], c->active));
         rc = run_class(0); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(b->ev[6], c->active));
@@ -1085,13 +1110,16 @@ int hlala_get_coverage(hlala_ctx* c, int32_t* bases_per_level, int reset)
 int hlala_batch_export_pair_records(hlala_ctx* c, hlala_batch* b, double* device_out)
 {
     DEV_GUARD(c);
-    if(c && b) { int rj = join_side(c, b); if(rj) return rj; }
+    // a reader like the getters: on the reader stream, behind THIS batch's work on the main and the side stream -- not behind the alignment of the next batch the
+    // caller has queued on the main stream since (it ran there until round 4: with two batches in flight the records of batch i waited for batch i+1) -- and
+    // synchronised on return, so that a collective the caller issues next on any stream of its own finds the records in place
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b || !device_out) return HLALA_E_ARG;
     if(!(b->staged & 4)) { c->err = "pairs not computed"; return HLALA_E_STATE; }
     if(b->B.n_pairs > 0) {
         hipLaunchKernelGGL(k_export_pairs, dim3((b->B.n_pairs + 255) / 256), dim3(256), 0, c->active, b->dB, device_out);
         int rc = check_launch(c, "k_export_pairs"); if(rc) return rc;
-        return mark_main(c, b);       // (the export reads the batch: its destruction waits for it)
+        HIP_TRY(c, hipStreamSynchronize(c->active));
     }
     return HLALA_OK;
 }
@@ -1488,6 +1516,16 @@ extern "C" int hlala_abi_sizeof(const char* name)
     SZ(hlala_chains_out) SZ(hlala_pairs_out) SZ(hlala_batch_stats) SZ(hlala_exon_in) SZ(hlala_call_out) SZ(hlala_locus_desc) SZ(hlala_exon_positions_out) SZ(hlala_filter_params) SZ(hlala_filter_stats) SZ(hlala_insert_size_out) SZ(hlala_locus_info) SZ(hlala_locus_report_in) SZ(hlala_locus_report_out) SZ(hlala_unit_stats_out) SZ(hlala_pairs_packed_out)
 #undef SZ
     return -1;
+}
+
+extern "C" int hlala_abi_version(void) { return HLALA_ABI_VERSION; }
+extern "C" int hlala_build_flags(void)
+{
+    int f = 0;
+#ifdef HLALA_WITH_LANE_CLASS
+    f |= HLALA_BUILD_LANE_CLASS;
+#endif
+    return f;
 }
 
 extern "C" int hlala_kat_exp(hlala_ctx* c, int n, const double* x, double* y)

@@ -1462,7 +1462,10 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
 {
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // thread t takes the t-th chain in position order (kernel_order.hip), so that the item lists, which the waves append to in launch order, come out
+    // (nearly) sorted by graph position: DP calls in flight at one time then read neighbouring node records
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = t < B.n_chains ? (B.chain_order ? B.chain_order[t] : t) : B.n_chains;
     bool needL = false, needR = false;
     int nShared = 0;
     DpItem itL, itR;

@@ -1,0 +1,48 @@
+// kernel_order.hip -- position order of a batch's chains.
+//
+// A batch arrives in read-name order (the reference's std::map of read IDs, mapper/processBAM.cpp:2024-2039), i.e. in RANDOM order of graph
+// position: the persistent kernels of stages A and B, which hand out chains / DP calls from a list, then have a few thousand waves on a few
+// thousand unrelated places of a 0.7 GB graph, and every node record, CSR window and level list they touch comes from HBM (measured, round 3:
+// 43 GB fetched by the 16-lane DP kernel of a 1 M-pair batch against 0.44 GB of node records in the whole graph).  Results do not depend on the order
+// in which chains are processed (every DP call draws its random seed from its chain's absolute number), so the lists are put into position order:
+// a counting sort of the chains by (first level >> shift) -- buckets of a few hundred levels; the order inside a bucket is left to the atomics.
+// The work in flight at one time then covers a window of the graph that fits the 4 MB L2 of an XCD.
+//   k_filter_chains (kernel_project.hip)  bucket of every chain + histogram
+//   k_order_scan                           exclusive scan of the histogram (one block)
+//   k_order_scatter                        chain numbers into their bucket's range
+#include "batch.h"
+
+namespace hlala {
+
+constexpr int ORDER_SCAN_THREADS = 1024;
+
+__global__ __launch_bounds__(ORDER_SCAN_THREADS) void k_order_scan(int* hist, int nb)
+{
+    __shared__ int part[ORDER_SCAN_THREADS];
+    const int t = threadIdx.x;
+    const int per = (nb + ORDER_SCAN_THREADS - 1) / ORDER_SCAN_THREADS;
+    const int a = t * per, z = min(nb, a + per);
+    int s = 0;
+    for(int i = a; i < z; i++) s += hist[i];
+    part[t] = s;
+    __syncthreads();
+    for(int o = 1; o < ORDER_SCAN_THREADS; o <<= 1) {
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;          // exclusive start of this thread's stretch
+    for(int i = a; i < z; i++) { const int h = hist[i]; hist[i] = run; run += h; }
+}
+
+__global__ void k_order_scatter(const DevBatch* __restrict__ Bp)
+{
+    const DevBatch& B = *Bp;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if(c >= B.n_chains) return;
+    const int pos = atomicAdd(&B.order_hist[B.chain_bucket[c]], 1);
+    B.chain_order[pos] = c;
+}
+
+}  // namespace hlala

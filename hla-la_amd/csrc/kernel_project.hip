@@ -159,6 +159,13 @@ __global__ void k_filter_chains(const DevGraph* __restrict__ Gp, const DevBatch*
         }
         B.seed_status[c] = st;
         if(st != HLALA_CHAIN_OK) B.seed_ncols[c] = 0;
+        // position bucket of the chain (kernel_order.hip): the level its first reference base sits on; chains that take no further part go last
+        if(B.chain_bucket) {
+            int bk = B.order_nb - 1;
+            if(st == HLALA_CHAIN_OK) { bk = (idA >= 0 ? idA : (idB >= 0 ? idB : 0)) >> B.order_shift; if(bk > B.order_nb - 2) bk = B.order_nb - 2; }
+            B.chain_bucket[c] = bk;
+            atomicAdd(&B.order_hist[bk], 1);
+        }
     }
 }
 
@@ -208,9 +215,12 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         const int cEnd = min(c0 + CHUNK, B.n_chains);
         // the descriptors of the chunk's chains: lane q holds chain c0 + q; two round trips for the chunk (the fields, then what they point to)
         // instead of a chain of dependent wave-uniform loads per chain
-        int hStatus = -1, hRead = 0, hContig = 0, hPos = 0, hOff = 0, hCg0 = 0, hCg1 = 0;
+        // (chains are taken in the order of their graph position, B.chain_order -- kernel_order.hip: the windows of the chains in flight at one time are
+        //  neighbours in the CSR arrays and stay in the L2)
+        int hStatus = -1, hRead = 0, hContig = 0, hPos = 0, hOff = 0, hCg0 = 0, hCg1 = 0, hChain = 0;
         if(lane < CHUNK && c0 + lane < cEnd) {
-            const int cq = c0 + lane;
+            const int cq = B.chain_order ? B.chain_order[c0 + lane] : c0 + lane;
+            hChain = cq;
             hStatus = B.seed_status[cq]; hRead = B.chain_read[cq]; hContig = B.chain_contig[cq]; hPos = B.chain_pos[cq]; hOff = B.chain_offset[cq];
             hCg0 = B.cigar_off[cq]; hCg1 = B.cigar_off[cq + 1];
         }
@@ -220,8 +230,9 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             const long long a0 = contig_off[hContig], a1 = contig_off[hContig + 1];
             hC0lo = (int)(u32)a0; hC0hi = (int)(a0 >> 32); hC1lo = (int)(u32)a1; hC1hi = (int)(a1 >> 32);
         }
-        for(int c = c0; c < cEnd; c++) {
-        const int hq = c - c0;
+        for(int drawn = c0; drawn < cEnd; drawn++) {
+        const int hq = drawn - c0;
+        const int c = __builtin_amdgcn_readlane(hChain, hq);
         if(__builtin_amdgcn_readlane(hStatus, hq) == HLALA_CHAIN_OK) {
         const int r = __builtin_amdgcn_readlane(hRead, hq);
         const int rOff = __builtin_amdgcn_readlane(hR0, hq), readLen = __builtin_amdgcn_readlane(hR1, hq) - rOff;
@@ -1087,9 +1098,10 @@ __global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __res
         if(lane == 0) c0 = atomicAdd(&B.work_counter[3], 64);
         c0 = __builtin_amdgcn_readfirstlane(c0);
         if(c0 >= B.n_chains) break;
-        u64 pend = __ballot(c0 + lane < B.n_chains && B.seed_status[c0 + lane] == CHAIN_RETHREAD_PENDING);
+        const int cq = c0 + lane < B.n_chains ? (B.chain_order ? B.chain_order[c0 + lane] : c0 + lane) : -1;        // position order, as in k_project_chains
+        u64 pend = __ballot(cq >= 0 && B.seed_status[cq] == CHAIN_RETHREAD_PENDING);
         for(; pend; pend &= pend - 1) {
-            const int c = c0 + __ffsll((long long)pend) - 1;
+            const int c = __builtin_amdgcn_readlane(cq, __ffsll((long long)pend) - 1);
             const size_t cb = (size_t)c * stride;
             const int* st = (const int*)B.dp_items + (size_t)c * 16;
             int sv = lane < 6 ? st[lane] : 0;

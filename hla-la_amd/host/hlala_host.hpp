@@ -32,6 +32,21 @@
 namespace hlala {
 namespace host {
 
+// a libhlala_gpu.so built from another revision of the header can keep every struct size and still mean something else by a field
+inline void check_abi()
+{
+    if(hlala_abi_version() != HLALA_ABI_VERSION)
+        throw std::runtime_error("libhlala_gpu.so implements interface version " + std::to_string(hlala_abi_version()) + ", this program was compiled against version " + std::to_string(HLALA_ABI_VERSION) + " of include/hlala_gpu.h");
+}
+// joins the threads it holds when it goes out of scope: an exception between the start of a thread and its join() must not destroy a joinable
+// std::thread (std::terminate)
+struct ThreadJoiner {
+    std::vector<std::thread> th;
+    template <class F> void start(F&& f) { th.emplace_back(std::forward<F>(f)); }
+    void join() { for(std::thread& t : th) if(t.joinable()) t.join(); }
+    ~ThreadJoiner() { join(); }
+};
+
 struct Graph {                          // Graph::readFromFile result, creation order (Graph/Graph.cpp:2329-2559)
     int32_t n_levels = 0;
     std::vector<int32_t> node_level, edge_from, edge_to;
@@ -97,6 +112,7 @@ public:
         if(contigs) { cd.n_contigs = (int32_t)contigs->contig_seqid.size(); cd.contig_off = contigs->contig_off.data(); cd.contig_seq = contigs->contig_seq.data();
                       cd.contig_level = contigs->contig_level.data(); cd.contig_seqid = contigs->contig_seqid.data(); }
         params_ = hlala_params{IS_mean, IS_sd, rng_seed, 0, max_columns, 0};
+        check_abi();
         if(hlala_create(&ctx_, device, stream, &gd, contigs ? &cd : nullptr, &params_) != HLALA_OK)
             throw std::runtime_error(std::string("hlala_create: ") + hlala_last_error(nullptr));
     }
@@ -272,20 +288,23 @@ public:
         // the BAM is decoded (all host threads) while the contexts are created (one thread per device: each flattens and uploads the graph)
         const auto t0 = std::chrono::steady_clock::now();
         std::string bamErr;
-        std::thread tdec([&]() {
-            try { if(hlala_bam_extract_seeds_mt(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, threads_, &seeds_) != HLALA_OK) bamErr = std::string("BAM: ") + hlala_bam_last_error(); }
-            catch(const std::exception& e) { bamErr = e.what(); }
-            decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        });
+        check_abi();
+        // (the decoder thread and the per-device threads are joined by `tdec` / `th` on every way out of this scope, exceptions included;
+        //  everything they capture is declared before them)
         hlala_graph_desc gd; hlala_graph_file_desc(graph_, &gd);
         hlala_contigs_desc cd; hlala_contigs_file_desc(contigs_, &cd);
         n_levels = gd.n_levels;
         hlala_params pr{200.0, 35.0, rng_seed_, longReads ? 1 : 0, max_columns_, 0};
         ctxs_.assign(devices_.size(), nullptr);
         std::vector<std::string> errs(devices_.size());
-        std::vector<std::thread> th;
-        for(size_t d = 0; d < devices_.size(); d++) th.emplace_back([&, d]() { if(hlala_create(&ctxs_[d], devices_[d], nullptr, &gd, &cd, &pr) != HLALA_OK) errs[d] = std::string("hlala_create: ") + hlala_last_error(nullptr); });
-        for(std::thread& t : th) t.join();
+        ThreadJoiner tdec, th;
+        tdec.start([&]() {
+            try { if(hlala_bam_extract_seeds_mt(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, threads_, &seeds_) != HLALA_OK) bamErr = std::string("BAM: ") + hlala_bam_last_error(); }
+            catch(const std::exception& e) { bamErr = e.what(); }
+            decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+        for(size_t d = 0; d < devices_.size(); d++) th.start([&, d]() { if(hlala_create(&ctxs_[d], devices_[d], nullptr, &gd, &cd, &pr) != HLALA_OK) errs[d] = std::string("hlala_create: ") + hlala_last_error(nullptr); });
+        th.join();
         context_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         tdec.join();
         if(!bamErr.empty()) throw std::runtime_error(bamErr);

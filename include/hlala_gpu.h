@@ -269,12 +269,14 @@ int  hlala_batch_get_pairs_packed(hlala_ctx* ctx, hlala_batch* b, hlala_pairs_pa
 /* Device-to-device export of one fixed-size record per pair (8 doubles: pair_status, best_chain[0], best_chain[1],
  * n_combinations, pair_ll, pair_mapq, mate_mapq[0], mate_mapq[1]) into a caller-owned DEVICE buffer of
  * 8 * n_pairs doubles -- the payload of the multi-GPU gather of per-pair best-path records to rank 0
- * (the host program hands the buffer to RCCL; there is no collective inside this library).        */
+ * (the host program hands the buffer to RCCL; there is no collective inside this library).  Runs like the getters: behind
+ * THIS batch's work only (not behind other batches queued since) and returns when the records are in `device_out`, so the
+ * caller may start its collective on any stream at once.                                             */
 int  hlala_batch_export_pair_records(hlala_ctx* ctx, hlala_batch* b, double* device_out);
 
 /* Per-stage statistics of the last hlala_align_batch / stage call on this batch, measured
- * with HIP events (ms) plus work counters reduced on the device.  The events belong to the context: with several
- * batches in flight the times are those of the stages launched last.                         */
+ * with HIP events (ms) plus work counters reduced on the device.  The events belong to the BATCH (since round 3): with
+ * several batches in flight every batch reports its own stages.                              */
 typedef struct {
     float   ms_project, ms_extend, ms_pair;
     int64_t n_chains_extended;    /* chains with status OK                        */
@@ -660,6 +662,17 @@ int  hlala_kat_exp(hlala_ctx* ctx, int n, const double* x, double* exp_x);
 /* sizeof() of the structs of this header as the library was compiled, by struct name ("hlala_graph_desc", "hlala_params", ...);
  * -1 for an unknown name.  Lets a foreign-function binding (ctypes, cgo, JNI) check its mirror of the layout at load time. */
 int  hlala_abi_sizeof(const char* struct_name);
+
+/* Version of this interface.  It changes whenever the meaning or the type of a field changes WITHOUT changing the size of its struct (which
+ * hlala_abi_sizeof cannot see): 2 = hlala_batch_in carries 64-bit window offsets and an absolute read_primary (round 3).  A caller compares
+ * hlala_abi_version() with the HLALA_ABI_VERSION it was compiled against and refuses to run on a mismatch (hla-la_amd/__init__.py and
+ * hla-la_amd/host/hlala_host.hpp do). */
+#define HLALA_ABI_VERSION 2
+int  hlala_abi_version(void);
+/* bit mask of optional parts compiled into this library: HLALA_BUILD_LANE_CLASS = the lane-per-DP class (kernel_dp_lane.hip, an experiment that
+ * lost its A/B and is left out of the default build: make EXTRA=-DHLALA_WITH_LANE_CLASS) */
+#define HLALA_BUILD_LANE_CLASS 1
+int  hlala_build_flags(void);
 
 #ifdef __cplusplus
 }

@@ -318,6 +318,8 @@ def test_lane_per_dp_class_is_bit_exact(pkg, oracle, monkeypatch):
     """The lane-per-DP class (64 DP calls per wavefront, one per lane; hla-la_amd/csrc/kernel_dp_lane.hip) is switched off by default -- it is slower
     than the 16-lane class it was meant to relieve -- but stays correct: with HLALA_DP_LANE=1 every DP call starts there, the calls it cannot finish exactly
     (a node with more than two edges or a gap-path jump, wider frontiers) go on to the 16-lane class, and every output equals the oracle's, counters included."""
+    if not (pkg.load_library().hlala_build_flags() & pkg.BUILD_LANE_CLASS):
+        pytest.skip("the lane-per-DP class is not part of the default library (tools/gpu_lane_build.sh builds with -DHLALA_WITH_LANE_CLASS and runs this test)")
     monkeypatch.setenv("HLALA_DP_LANE", "1")
     for seed, G, k in ((1, 5000, 1), (2, 8000, 0), (3, 8000, 3)):
         w = synth.make_world(seed=seed, G=G, k=k)
