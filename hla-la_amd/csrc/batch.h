@@ -75,9 +75,17 @@ struct DevBatch {
     int* chain_bucket;              // [n_chains] position bucket = first level >> order_shift (the last bucket: chains filtered out)
     int* order_hist;                // [order_nb + 1] bucket counts -> bucket starts -> scatter cursors
     int order_shift, order_nb;
+    int* dp_blk;                    // [4 * dp_nblk + 1] items per block of k_dp_items and list (jump-free left / right, general left / right); after the scan: where they start
+    int* dp_list;                   // [2*n_chains] the four dense lists of the first DP classes: slots of dp_items in position order (k_dp_lists)
+    int dp_nblk;                    // blocks of k_dp_items
+    int dp_jf;                      // 1: calls that meet no gap-path jump go to the lists of the jump-free instantiation (0: HLALA_DP_JF=0, every call in the general one)
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
     int* dbg;                       // non-null with HLALA_DEBUG=1: kernels add phase clocks to counters[16..31]
 };
+
+// number of entries of B.chain_order: the chains that passed the filters (k_filter_chains); without a position order every chain is listed.
+// (order_hist[order_nb - 1] is the start of a bucket nothing is put into = the end of the last real bucket, before and after the scatter)
+__device__ __forceinline__ int ordered_chains(const DevBatch& B) { return B.chain_order ? __builtin_amdgcn_readfirstlane(B.order_hist[B.order_nb - 1]) : B.n_chains; }
 
 enum {
     CNT_CHAINS_EXT = 0, CNT_DP_CALLS, CNT_DP_ITERS, CNT_DP_CELLS, CNT_SEED_COLS, CNT_OUT_COLS, CNT_EDGES, CNT_ERRORS, CNT_DP_SHARED

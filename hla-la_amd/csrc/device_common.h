@@ -30,6 +30,7 @@ struct DevGraph {
     const int* jf_off; const int* jf_node; const int* jf_path; const int* jf_lvl;
     const int* jb_off; const int* jb_node; const int* jb_path; const int* jb_lvl;
     const uint8_t* out_prank; const uint8_t* in_prank; const uint8_t* jf_prank; const uint8_t* jb_prank;   // rank among the node's earlier entries to the same target (flat_graph.hpp)
+    const uint8_t* jfree_out; const uint8_t* jfree_in;   // [L] levels without a gap-path jump from this level on, in either direction (flat_graph.hpp)
     const int4* nrec_out;      // [2*N] 32-byte node records of the extension DP (flat_graph.hpp)
     const int4* nrec_in;
     const int* path_len;       // [P]

@@ -265,6 +265,17 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
         build(F.out_off, F.out_to, F.out_label, F.jf_off, F.jf_node, F.jf_lvl, F.nrec_out);
         build(F.in_off, F.in_from, F.in_label, F.jb_off, F.jb_node, F.jb_lvl, F.nrec_in);
         if(!recErr.empty()) return recErr;
+        // ---- how far an extension DP can walk from a level without meeting a gap-path jump (flat_graph.hpp): jfree_out[l] = levels l, l + 1, ... whose nodes
+        // have no forward jump, jfree_in[l] = levels l, l - 1, ... without a backward one; capped at 255
+        F.jfree_out.assign((size_t)F.L, 0); F.jfree_in.assign((size_t)F.L, 0);
+        {
+            std::vector<uint8_t> hasF((size_t)F.L, 0), hasB((size_t)F.L, 0);
+            for(int32_t n = 0; n < N; n++) { if(F.jf_off[n + 1] > F.jf_off[n]) hasF[(size_t)F.node_level[n]] = 1; if(F.jb_off[n + 1] > F.jb_off[n]) hasB[(size_t)F.node_level[n]] = 1; }
+            int run = 255;                                   // (beyond the last level there is nothing to meet)
+            for(int32_t l = F.L - 1; l >= 0; l--) { run = hasF[(size_t)l] ? 0 : std::min(255, run + 1); F.jfree_out[(size_t)l] = (uint8_t)run; }
+            run = 255;
+            for(int32_t l = 0; l < F.L; l++) { run = hasB[(size_t)l] ? 0 : std::min(255, run + 1); F.jfree_in[(size_t)l] = (uint8_t)run; }
+        }
     }
     return "";
 }

@@ -54,6 +54,10 @@ struct FlatGraph {
     // one 32-byte record per node and direction for the extension DP: {first CSR edge, degree | jumps << 16, target of edge 0,
     // target of edge 1, first jump-table entry, node of jump 0, level of jump 0, label 0 | label 1 << 8 | rank of edge 1 << 16}
     std::vector<int32_t> nrec_out, nrec_in;      // [8*N]
+    // jfree_out[l]: number of consecutive levels l, l + 1, ... none of whose nodes has a forward gap-path jump (jfree_in: l, l - 1, ..., backward jumps), capped
+    // at 255.  An extension DP that starts at level l and can reach at most r levels is known to meet no jump when jfree > r: such calls run in the
+    // instantiation of the 16-lane class that is compiled without the early-cell machinery (kernel_dp.hip: DpTinyJF; a call that meets one anyway is re-run).
+    std::vector<uint8_t> jfree_out, jfree_in;    // [L]
     std::vector<uint8_t> gap_stretch;            // [L-1]
     // level -> (sequence id, position) CSR, entries sorted by sequence id
     std::vector<int64_t> lp_off;                 // [L+1]

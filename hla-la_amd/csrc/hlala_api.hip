@@ -67,7 +67,7 @@ struct hlala_ctx {
     size_t pool_bytes = 0;
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
-    char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0;
+    char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
     char* lane_slabs = nullptr; int lane_grid = 0;      // the lane-per-DP class in front of the 16-lane class (kernel_dp_lane.hip); lane_grid 0: not used (HLALA_DP_LANE=0)
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
@@ -95,7 +95,7 @@ struct hlala_batch {
     // timing events of THIS batch (created with its first stage call): ev = start / end per stage, [7] / [6] / [10] / [8] = before the 16-lane class / after it /
     // after the 64-lane class / after the last class; evC = start / end of each DP class on the stream it ran on; evSide[0] fork point on the main stream,
     // [1] first side-stream class starts, [6] second pairing pass done
-    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; hipEvent_t evLane[2]{}; bool eventsMade = false; bool lane_used = false;
+    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; hipEvent_t evLane[2]{}; hipEvent_t evJF = nullptr; /* end of the jump-free instantiation of the 16-lane class */ bool eventsMade = false; bool lane_used = false;
     uint32_t first_chain = 0;    // absolute index of the batch's chain 0 in the caller's numbering (hlala_batch_set_first_chain): offsets the random seeds
     float ms[3] = {0, 0, 0};
 };
@@ -132,6 +132,7 @@ static int batch_events(hlala_ctx* c, hlala_batch* b)
     for(int i = 0; i < 8; i++) HIP_TRY(c, hipEventCreate(&b->evSide[i]));
     for(int i = 0; i < 14; i++) HIP_TRY(c, hipEventCreate(&b->evC[i / 2][i % 2]));
     for(int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreate(&b->evLane[i]));
+    HIP_TRY(c, hipEventCreate(&b->evJF));
     HIP_TRY(c, hipEventCreateWithFlags(&b->evMain, hipEventDisableTiming));
     b->eventsMade = true;
     return HLALA_OK;
@@ -355,6 +356,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     UPG(jf_off, F.jf_off); UPG(jf_node, F.jf_node); UPG(jf_path, F.jf_path);
     UPG(jb_off, F.jb_off); UPG(jb_node, F.jb_node); UPG(jb_path, F.jb_path);
     UPG(jf_lvl, F.jf_lvl); UPG(jb_lvl, F.jb_lvl);
+    UPG(jfree_out, F.jfree_out); UPG(jfree_in, F.jfree_in);
     UPG(out_prank, F.out_prank); UPG(in_prank, F.in_prank); UPG(jf_prank, F.jf_prank); UPG(jb_prank, F.jb_prank);
     { int* p_ = nullptr; rc = dev_upload(c, c->allocs, F.nrec_out.data(), F.nrec_out.size(), &p_); if(rc) return fail(rc); G.nrec_out = (const int4*)p_;
       rc = dev_upload(c, c->allocs, F.nrec_in.data(), F.nrec_in.size(), &p_); if(rc) return fail(rc); G.nrec_in = (const int4*)p_; }
@@ -393,17 +395,22 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->tiny_grid = cus * 4 * DpTiny::WAVES;
     if(const char* e = getenv("HLALA_TINY_WAVES_PER_CU")) { const int w = atoi(e); if(w >= 1 && w <= 4 * DpTiny::WAVES) c->tiny_grid = cus * w; }      // (experiment: blocks of the 16-lane kernel per CU, tools/gpu_tiny_waves.sh)
     c->tiny_slab_bytes = dp_slab_bytes<DpTiny>();
+    c->jf_grid = cus * 4 * DpTinyJF::WAVES;
+#ifdef HLALA_WITH_LANE_CLASS
+    if(const char* e = getenv("HLALA_DP_LANE")) { if(atoi(e) != 0) c->jf_grid = 0; }      // (the lane-per-DP class takes every item itself)
+#endif
+    if(const char* e = getenv("HLALA_DP_JF")) { if(atoi(e) == 0) c->jf_grid = 0; }      // (A/B: every call in the general instantiation -- the kernels' lists are built either way)
     c->ext_grid = cus * 20;
     c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();
     c->retry_grid = cus;
     c->broad_grid = cus * 3;         // three DpBroad blocks per CU (48 KB of LDS each), slabs of the large layout
     c->wide_grid = cus * 7;          // LDS: seven DpWide blocks per CU (22 KB each); slabs of the 64-lane layout
-    c->stitch_grid = cus * 32;
+    c->stitch_grid = cus * 20;        // k_stitch_chains: five waves per SIMD (92 VGPRs, nothing spilled)
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpWide>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpWide>();
     c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / three blocks per CU: a few MB each
     c->huge_grid = cus / 4 > 0 ? cus / 4 : 1;      // the in-memory backstop class: a handful of DP calls per million pairs
     c->huge_slab_bytes = dp_inmemory_bytes<DpHuge>();
-    if((rc = slab_pool(&c->tiny_slabs, c->tiny_slab_bytes * (size_t)(64 / DpTiny::GW) * (size_t)c->tiny_grid, "16-lane DP slabs"))) return fail(rc);
+    if((rc = slab_pool(&c->tiny_slabs, c->tiny_slab_bytes * (size_t)(64 / DpTiny::GW) * (size_t)(c->tiny_grid > c->jf_grid ? c->tiny_grid : c->jf_grid), "16-lane DP slabs"))) return fail(rc);
     // (an experiment that lost, kept switchable and under test: HLALA_DP_LANE=1 puts the lane-per-DP class in front of the 16-lane class -- kernel_dp_lane.hip)
 #ifdef HLALA_WITH_LANE_CLASS
     { const char* e = getenv("HLALA_DP_LANE"); c->lane_grid = (e && atoi(e) != 0) ? cus * 4 : 0; }          // 36 KB of LDS per wave: four per CU
@@ -414,7 +421,9 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if((rc = slab_pool(&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid, "wide-class DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->large_slabs, c->large_slab_bytes * (size_t)(c->broad_grid + c->retry_grid), "large-class DP slabs"))) return fail(rc);       // broad blocks first, then the large ones
     if((rc = slab_pool(&c->huge_slabs, c->huge_slab_bytes * (size_t)c->huge_grid, "in-memory DP class"))) return fail(rc);
-    c->proj_grid = cus * (c->params.max_columns <= PROJ_CAP_SHORT ? 14 : 10); c->pair_grid = cus * 20;
+    // k_project_chains<384 columns>: 143 VGPRs = three waves per SIMD = 12 resident blocks per CU (its 11.7 KB of LDS would allow 13); the 512-column
+    // layout: 173 VGPRs = two per SIMD (-Rpass-analysis=kernel-resource-usage; a cap of 128 VGPRs for a fourth wave costs 287 spilled SGPRs and wins one block)
+    c->proj_grid = cus * (c->params.max_columns <= PROJ_CAP_SHORT ? 12 : 8); c->pair_grid = cus * 20;
     if(const char* e = getenv("HLALA_PROJ_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 14) c->proj_grid = cus * w; }      // (experiment: waves of the projection kernel per CU)
     { int rcp = dev_alloc(c, c->allocs, (size_t)2 * c->pair_grid * PAIR_COMB, &c->pair_scratch, false); if(rcp) return fail(rcp); }
     if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
@@ -523,6 +532,9 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
     AL(pair_deferred, np, true); AL(counters, 32, true); AL(work_counter, 48, true); AL(retry_list, 14 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
+    B.dp_nblk = (int)((nc + 255) / 256); if(B.dp_nblk < 1) B.dp_nblk = 1;
+    B.dp_jf = c->jf_grid > 0 ? 1 : 0;
+    AL(dp_blk, (size_t)4 * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
     B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb;
     if(c->order_nb > 0 && !B.from_seeds && nc > 0) { AL(chain_order, nc, false); AL(chain_bucket, nc, false); AL(order_hist, (size_t)c->order_nb + 1, false); }
     B.dbg = c->dbg_host;
@@ -667,6 +679,7 @@ void hlala_batch_destroy(hlala_batch* b)
     for(int i = 0; i < 14; i++) { if(b->ev[i]) (void)hipEventDestroy(b->ev[i]); if(b->evC[i / 2][i % 2]) (void)hipEventDestroy(b->evC[i / 2][i % 2]); }
     for(int i = 0; i < 8; i++) if(b->evSide[i]) (void)hipEventDestroy(b->evSide[i]);
     for(int i = 0; i < 2; i++) if(b->evLane[i]) (void)hipEventDestroy(b->evLane[i]);
+    if(b->evJF) (void)hipEventDestroy(b->evJF);
     delete b;
 }
 
@@ -739,15 +752,21 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
     b->side_used = false; b->side_pending = false;
     if(B.n_pairs > 0) HIP_TRY(c, hipMemsetAsync(B.pair_deferred, 0, (size_t)B.n_pairs, c->active));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->active));
-    HIP_TRY(c, hipMemsetAsync(B.work_counter + 7, 0, 41 * sizeof(int), c->active));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 4, 0, 44 * sizeof(int), c->active));       // [4..6] jump-free lists, [7..] stitch, DP items, retry lists
     if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->active));
     HIP_TRY(c, hipEventRecord(b->ev[2], c->active));
     if(B.n_chains > 0) {
         DpItem* items = (DpItem*)B.dp_items;
         const u32 seed = c->params.rng_seed + 2u * b->first_chain;
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_head, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));       // -1: k_dp_items links the duplicates of a DP to it
-        hipLaunchKernelGGL(k_dp_items, dim3((B.n_chains + 255) / 256), dim3(256), 0, c->active, c->dG, b->dB, items);
+        HIP_TRY(c, hipMemsetAsync(B.dp_alias_next, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));
+        // items, then the four dense lists of the first classes (jump-free / general, left / right) in position order: counts per block, their scan, the slots
+        HIP_TRY(c, hipMemsetAsync(B.dp_blk, 0, ((size_t)4 * B.dp_nblk + 1) * sizeof(int), c->active));
+        hipLaunchKernelGGL(k_dp_items, dim3(B.dp_nblk), dim3(256), 0, c->active, c->dG, b->dB, items);
         int rc = check_launch(c, "k_dp_items"); if(rc) return rc;
+        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_SCAN_THREADS), 0, c->active, B.dp_blk, 4 * B.dp_nblk + 1);
+        hipLaunchKernelGGL(k_dp_lists, dim3(B.dp_nblk), dim3(256), 0, c->active, b->dB, (const DpItem*)items);
+        rc = check_launch(c, "k_dp_lists"); if(rc) return rc;
         // every DP item first runs in the 16-lane class; the item count lives on the device, idle groups leave at once.
         // Items that outgrew it: two DPs per wave, then one wave per DP, then the classes with wider frontiers (fewer blocks per CU).
         // Each class is timed with its own pair of events on the stream it runs on (evC); ev[7] / ev[6] / ev[10] keep marking the start of the 16-lane
@@ -766,7 +785,14 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
             if(!fused && tier == DP_SIDE_TIER && c->sideTailValid) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSideTail, 0));
             HIP_TRY(c, hipEventRecord(b->evC[tier][0], ws));
             switch(tier) {
-            case 0: hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(DpTiny::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)tinyList); break;
+            case 0:
+                // the calls that meet no gap-path jump in the instantiation without the early-cell machinery, then the others (same slabs: one after the other)
+                if(!tinyList && c->jf_grid > 0) {
+                    hipLaunchKernelGGL((k_dp<DpTinyJF, 0>), dim3(c->jf_grid), dim3(DpTinyJF::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr);
+                    int rcj = check_launch(c, "k_dp<DpTinyJF>"); if(rcj) return rcj;
+                    HIP_TRY(c, hipEventRecord(b->evJF, ws));
+                }
+                hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(DpTiny::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)tinyList); break;
             case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(DpMid::THREADS), 0, ws, c->dG, b->dB, items, c->mid_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
             case 2: hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(DpSmall::THREADS), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
             case 3: hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(DpWide::THREADS), 0, ws, c->dG, b->dB, items, c->wide_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
@@ -1137,9 +1163,10 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, b->ev[2], b->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, b->ev[6], b->side_used ? b->ev[10] : b->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, b->ev[7], b->ev[6]);
           for(int k = 0; k <= DP_LAST_TIER; k++) (void)hipEventElapsedTime(&out->ms_dp_class[k], b->evC[k][0], b->evC[k][1]);
           if(b->lane_used) (void)hipEventElapsedTime(&out->ms_dp_lane, b->evLane[0], b->evLane[1]);
+          if(c->jf_grid > 0 && !b->lane_used) (void)hipEventElapsedTime(&out->ms_dp_jump_free, b->evC[0][0], b->evJF);
           if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, b->evSide[1], b->evSide[6]); } }
     { int wc[48]; HIP_TRY(c, hipMemcpyAsync(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
-      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9]; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
+      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9]; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; out->n_dp_jump_free = (c->jf_grid > 0 && !b->lane_used) ? wc[6] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, b->ev[4], b->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

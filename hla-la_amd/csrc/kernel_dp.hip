@@ -80,24 +80,34 @@ constexpr int DP_TAIL_THREADS = HLALA_DP_TAIL_THREADS;
 #ifndef HLALA_DP_HUGE_THREADS
 #define HLALA_DP_HUGE_THREADS HLALA_DP_TAIL_THREADS
 #endif
-struct DpTiny  { static constexpr int THREADS = 64, WAVES = HLALA_DP_TINY_WAVES, GW = 16, WCAP = 16,   HC = 32,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
-struct DpMid   { static constexpr int THREADS = 64, WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
-struct DpSmall { static constexpr int THREADS = 64, WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpTiny  { static constexpr bool JF = false; static constexpr int THREADS = 64, WAVES = HLALA_DP_TINY_WAVES, GW = 16, WCAP = 16,   HC = 32,   IBITS = 4,  CELLS = 2048,     EARLY = 4096,     IMPCAP = 64,   COMPLETED = 256,          STEPS = 1024;     typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
+// The 16-lane class for DP calls that are known to meet no gap-path jump (k_dp_items: FlatGraph::jfree_out / jfree_in beyond the reach of the call -- two
+// thirds of the calls of the Graph M workload).  Without jumps no cell is ever created ahead of its diagonal, so no cell is met twice: the instantiation
+// is compiled WITHOUT the early-cell table, its look-ups, the second evaluate pass, the staged improvements of existing cells and the jump candidates
+// (a fifth fewer instructions, no spilled register at four waves per SIMD), and -- more to the point -- its wavefronts never execute those paths because
+// ONE of their four groups needs them.  A call that meets a jump after all (the bound is a heuristic, not a proof) fails over to the next class like a call that
+// outgrew its capacity and is re-run there: results do not depend on the classification.
+#ifndef HLALA_DP_TINYJF_WAVES
+#define HLALA_DP_TINYJF_WAVES 4
+#endif
+struct DpTinyJF : DpTiny { static constexpr bool JF = true; static constexpr int WAVES = HLALA_DP_TINYJF_WAVES; };
+struct DpMid   { static constexpr bool JF = false; static constexpr int THREADS = 64, WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpSmall { static constexpr bool JF = false; static constexpr int THREADS = 64, WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
 // but a quarter of its LDS, so that seven of them share a CU instead of one
-struct DpWide  { static constexpr int THREADS = HLALA_DP_WIDE_THREADS, WAVES = 2, GW = HLALA_DP_WIDE_THREADS, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpWide  { static constexpr bool JF = false; static constexpr int THREADS = HLALA_DP_WIDE_THREADS, WAVES = 2, GW = HLALA_DP_WIDE_THREADS, WCAP = 256,  HC = 512,  IBITS = 8,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 257 .. 512 cells with the table sizes of the large class (tens of thousands of kept cells): half the LDS of the large class, three per CU
-struct DpBroad { static constexpr int THREADS = HLALA_DP_BROAD_THREADS, WAVES = 1, GW = HLALA_DP_BROAD_THREADS, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpBroad { static constexpr bool JF = false; static constexpr int THREADS = HLALA_DP_BROAD_THREADS, WAVES = 1, GW = HLALA_DP_BROAD_THREADS, WCAP = 512,  HC = 1024, IBITS = 9,  CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // (allele-rich levels of a real PRG -- hundreds of nodes per level, SURVEY.md 8(d) Graph M: frontiers of 700+ cells, 16 000+ kept cells and
 //  thousands of sequence-complete cells per DP were measured -- are what the large class is sized for; its table slots are ints)
-struct DpLarge { static constexpr int THREADS = HLALA_DP_LARGE_THREADS, WAVES = 1, GW = HLALA_DP_LARGE_THREADS, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
+struct DpLarge { static constexpr bool JF = false; static constexpr int THREADS = HLALA_DP_LARGE_THREADS, WAVES = 1, GW = HLALA_DP_LARGE_THREADS, WCAP = 1024, HC = 2048, IBITS = 10, CELLS = DP_CELLS_LARGE, EARLY = DP_CELLS_LARGE, IMPCAP = 4096, COMPLETED = DP_COMPLETED_LARGE, STEPS = DP_STEPS; typedef u32 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 
 // The backstop: everything the other classes keep in LDS -- target table, frontiers, DP state -- lives in the block's HBM slab, so the capacities are
 // set by memory, not by the 160 KB of a CU (frontiers of 3000+ cells, 60 000 kept cells and 15 000 tied complete cells per DP occur on the densest
 // levels of the Graph M workload: about 30 DP calls per million pairs).  Same code (one template): the structure reference simply points into
 // the slab, the wave fences become agent-scope fences (plain loads must not hit stale L1 lines of words the atomics changed in L2), and the
 // frontier sort borrows the otherwise unused LDS.  An order of magnitude slower per cell than the LDS classes; nothing is dropped.
-struct DpHuge  { static constexpr int THREADS = HLALA_DP_HUGE_THREADS, WAVES = 1, GW = HLALA_DP_HUGE_THREADS, WCAP = 8192, HC = 16384, IBITS = 13, CELLS = 131072, EARLY = 131072, IMPCAP = 8192, COMPLETED = 65536, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = true; };
+struct DpHuge  { static constexpr bool JF = false; static constexpr int THREADS = HLALA_DP_HUGE_THREADS, WAVES = 1, GW = HLALA_DP_HUGE_THREADS, WCAP = 8192, HC = 16384, IBITS = 13, CELLS = 131072, EARLY = 131072, IMPCAP = 8192, COMPLETED = 65536, STEPS = DP_STEPS; typedef u64 Best; typedef int Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = true; };
 // (key, payload) pairs of the in-memory class's frontier sort held in LDS: 64 KB.  Frontiers beyond 4096 cells -- none on the Graph M workload: the widest holds 3200 --
 // are sorted in the block's slab in HBM.  (8192 pairs = 128 KB, 4096 and 2048 measured the same within 1 % with two batches in flight and alone,
 // profiles/r03_experiments.txt: beside the next batch's persistent kernels the class is short of issue slots, not of LDS.  64 KB leaves a CU room for other blocks.)
@@ -143,7 +153,7 @@ struct __align__(16) DpLdsT {
     DpState st;
     u64 accCalls, accIters, accCells, accEdges;       // work counters of the DPs this group finished (flushed once at exit)
 #ifdef HLALA_DP_TIMING
-    long long tPh[8];
+    long long tPh[16];
 #endif
 #ifdef HLALA_DP_PROFILE
     long long pfStart; int pfSlow, pfImp, pfPre, pfMaxNT, pfMaxF; long long pfPh[8];
@@ -746,7 +756,8 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             bool cv[3]; u64 ck[3]; u32 ch[3]; u64 cold[3];
             cv[0] = sgB && degB > 0; ck[0] = mk_key(nxB, pyB, tnB0);
             cv[1] = sgB && degB > 1; ck[1] = mk_key(nxB, pyB, tnB1);
-            cv[2] = okB && j1 > j0 && jx0 >= 0 && jx0 <= max_levelI; ck[2] = mk_key(jx0, pyB, jn0);
+            if constexpr (C::JF) { cv[2] = false; ck[2] = 0; if(okB && j1 > j0) S.err = __LINE__; }       // a jump after all: the call is re-run in the next class
+            else { cv[2] = okB && j1 > j0 && jx0 >= 0 && jx0 <= max_levelI; ck[2] = mk_key(jx0, pyB, jn0); }
 #pragma unroll
             for(int q = 0; q < 3; q++) { ch[q] = tgt_hash<C>(ck[q]); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
             if constexpr (APPEND) {
@@ -778,7 +789,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     }
                 }
             }
-            if(cv[2]) { BestT v; pack_best<C>(v, pD, ord0 | 128); atomicMax(&S.hbest[M_D][ch[2]], v); }
+            if constexpr (!C::JF) if(cv[2]) { BestT v; pack_best<C>(v, pD, ord0 | 128); atomicMax(&S.hbest[M_D][ch[2]], v); }
         }
         if(okA) edges += degA;
         if(sgB) edges += degB;
@@ -832,7 +843,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     if(!dp_push<C>(S, k, M_D, pD, ord0 | rk)) S.err = __LINE__;
                 }
             }
-            if(okB) for(int j = j0 + 1; j < j1; j++) {
+            if constexpr (!C::JF) if(okB) for(int j = j0 + 1; j < j1; j++) {
                 int tn = jnode[j]; int jx = jlvl[j];
                 if(jx < 0 || jx > max_levelI) continue;
                 if(!dp_push<C>(S, mk_key(jx, pyB, tn), M_D, pD, ord0 | (128 + (int)jprk[j]))) S.err = __LINE__;
@@ -892,7 +903,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     // natural diagonal of the early cells created so far: in those iterations every kept target is looked up (a probing read), and only cells
     // that are early themselves are inserted.  tes[t] = table slot of an existing cell, or -1.  (Tried: a Bloom filter in LDS in front of
     // the look-ups -- no gain on Graph M, a loss on gap-heavy small graphs whose filter saturates.)
-    const bool prepass = earlyInit && d <= earlyMaxNat0;
+    const bool prepass = !C::JF && earlyInit && d <= earlyMaxNat0;
     int earlyNatMax = -1;         // per lane: largest natural diagonal of the early cells this iteration creates
     if(prepass) {
         for(int t0 = 0; t0 < nT; t0 += GW) {
@@ -925,6 +936,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             if(GGv > Dv) { Dv = GGv; dsel = 1; }
             if(SGv > Dv) { Dv = SGv; dsel = 2; }
             bool keep = act && (Dv >= -16);                                               // :949
+            DP_TQ(8);
             int es = -1; bool isNew; int slot;
             if(pass == 0) {
                 if(hadEarly && act) S.hq[h] = (typename C::ImpIdx)~0u;
@@ -940,6 +952,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 es = isNew ? -1 : slot;
             }
             const bool ok = !failed && S.err == 0;
+            DP_TQ(9);
             // ---- back pointers of the three matrices, decoded from the winning push index
             u32 btD = 0, btG = 0, btS = 0;
             int srcScore = 0;       // score the real previous step came from (fast form of the `diff` rule)
@@ -967,6 +980,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     srcScore = (j & 1) ? S.fS[b1][i] : S.fD[b1][i];
                 }
             }
+            DP_TQ(10);
             int impMask = 0;
             int mD = Dv, mG = GGv, mS = SGv;          // merged values
             u32 mbtD = btD;                            // merged D back pointer
@@ -979,7 +993,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 }
                 int x = key_x(key), y = key_y(key);
                 int natural = (x > startLevel ? x - startLevel : startLevel - x) + (y > start_seq ? y - start_seq : start_seq - y);
-                bool isEarly = isNew && natural > d;
+                bool isEarly = !C::JF && isNew && natural > d;
                 if(isEarly && natural > earlyNatMax) earlyNatMax = natural;
                 if(grp_any<GW>(isEarly)) {                       // early cells: into the slab hash
                     if(!earlyInit) {
@@ -999,8 +1013,9 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     if(nCompleted0 + pos < C::COMPLETED) sl.completed()[nCompleted0 + pos] = slot; else S.err = __LINE__;
                 }
             }
+            DP_TQ(11);
             // ---- existing cells: each matrix independently overwritten iff strictly greater, :951-979 (writes are staged)
-            if(keep && !isNew && ok) {
+            if constexpr (!C::JF) if(keep && !isNew && ok) {
                 const CellRec* er = sl.cell() + es;
                 int oD = er->sc[0], oG = er->sc[1], oS = er->sc[2];
                 if(Dv > oD) impMask |= 1; else { mD = oD; mbtD = er->bt[0]; }
@@ -1021,6 +1036,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 if(act) { S.tes[t] = (typename C::Slot)slot; S.timp[t] = (unsigned char)(impMask | (isNew ? 0x80 : 0)); }
                 continue;
             }
+            DP_TQ(12);
             if(impMask != 0) anyOw = true;            // (per lane; combined over the group after the loop)
             // ---- the `diff` rule, :1007-1041: score difference to the real previous step of the MERGED D back pointer
             int diff = 1;
@@ -1057,6 +1073,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                 S.hbest[1][h] = (typename C::Best)(((u32)(unsigned short)(short)mD) | ((u32)(unsigned short)(short)mG << 16));
                 S.hbest[2][h] = (typename C::Best)(u32)(unsigned short)(short)mS;
             }
+            DP_TQ(13);
         }
         DSYNC();
     }
@@ -1072,7 +1089,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     if(guni<GW>(S.err)) { if(gl == 0) { st.itersRun = d; st.err = __LINE__; } DSYNC(); return PH_DONE; }
     const int nCompletedNew = nCompleted0 + guni<GW>(S.nCompletedAdd);
     // apply staged improvements of existing cells and patch cached frontier copies
-    {
+    if constexpr (!C::JF) {
         int nImp = guni<GW>(S.nImp);
         for(int q = gl; q < nImp; q += GW) {
             int es = sl.imp_slot()[q]; int msk = sl.imp_mask()[q];
@@ -1098,12 +1115,12 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
     }
     if(anyEqDiff || anyOw) lastInc = d;
     int earlyMaxNat = earlyMaxNat0;
-    if(earlyInit) { const int m = grp_max_i32<GW>(earlyNatMax); if(m > earlyMaxNat) earlyMaxNat = m; }
+    if constexpr (!C::JF) if(earlyInit) { const int m = grp_max_i32<GW>(earlyNatMax); if(m > earlyMaxNat) earlyMaxNat = m; }
 
     DP_TQ(1);
     // ================= filter + sort, :1076-1105 ======================================
     int mx = itMaxNew;          // without merges the merged D of a kept target is its new D
-    if(slow) {
+    if constexpr (!C::JF) if(slow) {
         mx = DP_NEG;
         for(int t = gl; t < nT; t += GW) { int h = S.tlist[t]; if((u32)S.hbest[0][h] != 0xFFFFFFFFu) { int v = (short)((u32)S.hbest[1][h] & 0xFFFF); mx = max(mx, v); } }
         mx = grp_max_i32<GW>(mx);
@@ -1462,69 +1479,119 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
 {
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
-    // thread t takes the t-th chain in position order (kernel_order.hip), so that the item lists, which the waves append to in launch order, come out
-    // (nearly) sorted by graph position: DP calls in flight at one time then read neighbouring node records
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = t < B.n_chains ? (B.chain_order ? B.chain_order[t] : t) : B.n_chains;
+    // ---- every chain: DP outputs reset; chains that did not pass stage A get their final status here (dp_alias_head / dp_alias_next: memset by the host)
+    if(t < B.n_chains) {
+        const int st = B.seed_status[t];
+        B.dp_iters[2 * t] = 0; B.dp_iters[2 * t + 1] = 0; B.dp_score[2 * t] = INT32_MIN; B.dp_score[2 * t + 1] = INT32_MIN;
+        B.dp_ncols[2 * t] = -1; B.dp_ncols[2 * t + 1] = -1; B.dp_err[2 * t] = 0; B.dp_err[2 * t + 1] = 0;
+        if(st != HLALA_CHAIN_OK) {
+            B.ext_status[t] = st; B.ext_ncols[t] = 0;
+            if(st < 0) atomicAdd(&B.counters[CNT_ERRORS], 1ull);
+        }
+    }
+    // ---- the item lists: slot t of the left list and slot t of the right list belong to the t-th chain IN POSITION ORDER (kernel_order.hip; input order
+    // without one), a slot without a DP holds item = -1.  The DP classes draw slots in list order, so the DP calls in flight at one time start on
+    // neighbouring levels and read neighbouring node records.  (A dense list appended to by the waves in launch order is sorted only as far as the grid
+    // runs in order: a twelfth of the graph at a time.)
+    const int nOrd = ordered_chains(B);
+    const int c = t < nOrd ? (B.chain_order ? B.chain_order[t] : t) : -1;
     bool needL = false, needR = false;
     int nShared = 0;
     DpItem itL, itR;
-    if(c < B.n_chains) {
-        const int st = B.seed_status[c];
-        B.dp_iters[2 * c] = 0; B.dp_iters[2 * c + 1] = 0; B.dp_score[2 * c] = INT32_MIN; B.dp_score[2 * c + 1] = INT32_MIN;
-        B.dp_ncols[2 * c] = -1; B.dp_ncols[2 * c + 1] = -1; B.dp_err[2 * c] = 0; B.dp_err[2 * c + 1] = 0;
-        B.dp_alias_next[2 * c] = -1; B.dp_alias_next[2 * c + 1] = -1;
-        if(st != HLALA_CHAIN_OK) {
-            B.ext_status[c] = st; B.ext_ncols[c] = 0;
-            if(st < 0) atomicAdd(&B.counters[CNT_ERRORS], 1ull);
-        } else {
-            const int stride = B.stride;
-            const int r = B.chain_read[c];
-            const int rOff = B.read_off[r], seqLen = B.read_off[r + 1] - rOff;
-            const size_t cb = (size_t)c * stride;
-            const int nSeed = B.seed_ncols[c], sBegin = B.seed_begin[c], sEnd = B.seed_end[c];
-            int err = 0;
-            if((!B.unpaired && seqLen > DP_SEQCAP) || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;     // DP_SEQCAP bounds the DP only
-            if(!err) {
-                const int e0 = B.seed_edge[cb], e1 = B.seed_edge[cb + nSeed - 1];
-                if(e0 < 0 || e1 < 0 || e0 >= G.E || e1 >= G.E) err = HLALA_CHAIN_ERR_INPUT;
-            }
-            if(err) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = 0.0; atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
-            else {
-                B.ext_status[c] = EXT_PENDING;
-                needL = dp_item_for(G, B, c, 0, itL);
-                needR = dp_item_for(G, B, c, 1, itR);
-                // The iterations of a DP are a function of (read, direction, start cell); the chain's random seed only enters when the end
-                // cell is drawn among equal ones.  Alignments of one read to homologous contigs project onto the same graph cells all the
-                // time: such a DP runs once, for the lowest chain of the read that needs it, and the group that ran it then repeats the
-                // end-cell choice (with the other chain's seed), the backtrace and the expansion for every chain linked to it here.
-                if(!B.from_seeds && (needL || needR)) {
-                    for(int c2 = B.chain_off[r]; c2 < c && (needL || needR); c2++) {
-                        DpItem o;
-                        if(needL && dp_item_for(G, B, c2, 0, o) && o.start_seq == itL.start_seq && o.startNode == itL.startNode) { B.dp_alias_next[2 * c] = atomicExch(&B.dp_alias_head[2 * c2], 2 * c); needL = false; nShared++; }
-                        if(needR && dp_item_for(G, B, c2, 1, o) && o.start_seq == itR.start_seq && o.startNode == itR.startNode) { B.dp_alias_next[2 * c + 1] = atomicExch(&B.dp_alias_head[2 * c2 + 1], 2 * c + 1); needR = false; nShared++; }
-                    }
+    if(c >= 0 && B.seed_status[c] == HLALA_CHAIN_OK) {
+        const int stride = B.stride;
+        const int r = B.chain_read[c];
+        const int rOff = B.read_off[r], seqLen = B.read_off[r + 1] - rOff;
+        const size_t cb = (size_t)c * stride;
+        const int nSeed = B.seed_ncols[c], sBegin = B.seed_begin[c], sEnd = B.seed_end[c];
+        int err = 0;
+        if((!B.unpaired && seqLen > DP_SEQCAP) || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;     // DP_SEQCAP bounds the DP only
+        if(!err) {
+            const int e0 = B.seed_edge[cb], e1 = B.seed_edge[cb + nSeed - 1];
+            if(e0 < 0 || e1 < 0 || e0 >= G.E || e1 >= G.E) err = HLALA_CHAIN_ERR_INPUT;
+        }
+        if(err) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = 0.0; atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
+        else {
+            B.ext_status[c] = EXT_PENDING;
+            needL = dp_item_for(G, B, c, 0, itL);
+            needR = dp_item_for(G, B, c, 1, itR);
+            // The iterations of a DP are a function of (read, direction, start cell); the chain's random seed only enters when the end
+            // cell is drawn among equal ones.  Alignments of one read to homologous contigs project onto the same graph cells all the
+            // time: such a DP runs once, for the lowest chain of the read that needs it, and the group that ran it then repeats the
+            // end-cell choice (with the other chain's seed), the backtrace and the expansion for every chain linked to it here.
+            if(!B.from_seeds && (needL || needR)) {
+                for(int c2 = B.chain_off[r]; c2 < c && (needL || needR); c2++) {
+                    DpItem o;
+                    if(needL && dp_item_for(G, B, c2, 0, o) && o.start_seq == itL.start_seq && o.startNode == itL.startNode) { B.dp_alias_next[2 * c] = atomicExch(&B.dp_alias_head[2 * c2], 2 * c); needL = false; nShared++; }
+                    if(needR && dp_item_for(G, B, c2, 1, o) && o.start_seq == itR.start_seq && o.startNode == itR.startNode) { B.dp_alias_next[2 * c + 1] = atomicExch(&B.dp_alias_head[2 * c2 + 1], 2 * c + 1); needR = false; nShared++; }
                 }
             }
         }
     }
-    // wave-aggregated append: left extensions fill items[0, n_chains), right extensions items[n_chains, 2 n_chains)
+    // Jump-free calls (DpTinyJF): a call can reach about as many levels as it has read bases left, plus the few columns of gaps the X-drop window admits and the
+    // iterations of patience; no node of those levels has a gap-path jump (FlatGraph::jfree_out / jfree_in).  A heuristic bound: a call that meets a jump
+    // anyway is re-run in the next class.
+    bool jfL = false, jfR = false;
+    if(needL && B.dp_jf) { const int reach = itL.start_seq + 48; jfL = reach < 255 && (int)G.jfree_in[itL.startLevel] > reach; }
+    if(needR && B.dp_jf) { const int reach = itR.seqLen - itR.start_seq + 48; jfR = reach < 255 && (int)G.jfree_out[itR.startLevel] > reach; }
+    if(t < nOrd) {
+        int4* sl = (int4*)(items + t); int4* sr = (int4*)(items + (size_t)B.n_chains + t);
+        if(needL) { sl[0] = make_int4(itL.item, itL.rOff, itL.seqLen, itL.start_seq); sl[1] = make_int4(itL.startLevel, itL.startNode, jfL ? 1 : 0, 0); } else sl[0] = make_int4(-1, 0, 0, 0);
+        if(needR) { sr[0] = make_int4(itR.item, itR.rOff, itR.seqLen, itR.start_seq); sr[1] = make_int4(itR.startLevel, itR.startNode, jfR ? 1 : 0, 0); } else sr[0] = make_int4(-1, 0, 0, 0);
+    }
+    // ---- how many items of each of the four lists (jump-free left / right, general left / right) this block holds: k_order_scan turns the counts of all
+    // blocks into the blocks' places in the dense lists, k_dp_lists writes the slot numbers there -- in position order, nothing is left to the atomics.
+    // work_counter[8] / [9]: left / right DP calls of the batch, [6]: the jump-free ones among them (statistics)
+    __shared__ int blkCnt[4];
+    if(threadIdx.x < 4) blkCnt[threadIdx.x] = 0;
+    __syncthreads();
     const int lane = lane_id();
     nShared = wave_sum_i32(nShared);
     if(lane == 0 && nShared) atomicAdd(&B.counters[CNT_DP_SHARED], (u64)nShared);
-    const u64 mL = __ballot(needL), mR = __ballot(needR);
-    const u64 below = (1ull << lane) - 1ull;
-    if(mL) {
-        int basePos = 0;
-        if(lane == 0) basePos = atomicAdd(&B.work_counter[8], __popcll(mL));
-        basePos = __shfl(basePos, 0);
-        if(needL) items[basePos + __popcll(mL & below)] = itL;
+    const u64 mL = __ballot(needL), mR = __ballot(needR), mJL = __ballot(needL && jfL), mJR = __ballot(needR && jfR);
+    if(lane == 0) {
+        if(mL) atomicAdd(&B.work_counter[8], __popcll(mL));
+        if(mR) atomicAdd(&B.work_counter[9], __popcll(mR));
+        if(mJL | mJR) atomicAdd(&B.work_counter[6], __popcll(mJL) + __popcll(mJR));
+        if(mJL) atomicAdd(&blkCnt[0], __popcll(mJL));
+        if(mJR) atomicAdd(&blkCnt[1], __popcll(mJR));
+        if(mL & ~mJL) atomicAdd(&blkCnt[2], __popcll(mL & ~mJL));
+        if(mR & ~mJR) atomicAdd(&blkCnt[3], __popcll(mR & ~mJR));
     }
-    if(mR) {
-        int basePos = 0;
-        if(lane == 0) basePos = atomicAdd(&B.work_counter[9], __popcll(mR));
-        basePos = __shfl(basePos, 0);
-        if(needR) items[B.n_chains + basePos + __popcll(mR & below)] = itR;
+    __syncthreads();
+    if(threadIdx.x < 4) B.dp_blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = blkCnt[threadIdx.x];
+}
+
+// The four dense item lists of the first DP classes: list k (0 jump-free left, 1 jump-free right, 2 general left, 3 general right) occupies
+// dp_list[dp_blk[k * nBlk] .. dp_blk[(k + 1) * nBlk]) -- dp_blk after its exclusive scan: entry k * nBlk + b = where block b's items of list k start --, its
+// entries are the slots of k_dp_items' item arrays in position order.  Same grid as k_dp_items.
+__global__ void k_dp_lists(const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items)
+{
+    const DevBatch& B = *Bp;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nOrd = ordered_chains(B);
+    int kL = -1, kR = -1;             // list of the left / right item of this slot
+    if(t < nOrd) {
+        const int4* sl = (const int4*)(items + t); const int4* sr = (const int4*)(items + (size_t)B.n_chains + t);
+        if(sl[0].x >= 0) kL = sl[1].z ? 0 : 2;
+        if(sr[0].x >= 0) kR = sr[1].z ? 1 : 3;
+    }
+    __shared__ int waveCnt[4][4];      // [list][wave of the block]
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    u64 m[4]; m[0] = __ballot(kL == 0); m[1] = __ballot(kR == 1); m[2] = __ballot(kL == 2); m[3] = __ballot(kR == 3);
+    if(lane == 0) { waveCnt[0][wv] = (int)__popcll(m[0]); waveCnt[1][wv] = (int)__popcll(m[1]); waveCnt[2][wv] = (int)__popcll(m[2]); waveCnt[3][wv] = (int)__popcll(m[3]); }
+    __syncthreads();
+    const u64 below = (1ull << lane) - 1ull;
+#pragma unroll
+    for(int k = 0; k < 4; k++) {
+        const bool mine = (k & 1) ? kR == k : kL == k;
+        if(mine) {
+            int before = 0;
+            for(int w2 = 0; w2 < wv; w2++) before += waveCnt[k][w2];
+            const int pos = B.dp_blk[(size_t)k * gridDim.x + blockIdx.x] + before + (int)__popcll(m[k] & below);
+            B.dp_list[pos] = (k & 1) ? B.n_chains + t : t;
+        }
     }
 }
 
@@ -1562,7 +1629,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
 
     if(gl == 0) { S.accCalls = 0; S.accIters = 0; S.accCells = 0; S.accEdges = 0; }
 #ifdef HLALA_DP_TIMING
-    if(gl == 0) { for(int i = 0; i < 8; i++) S.tPh[i] = 0; }
+    if(gl == 0) { for(int i = 0; i < 16; i++) S.tPh[i] = 0; }
 #endif
 #ifdef HLALA_DP_TIMING                                     // build-time switch: cycles per state of the persistent loop -> counters[8..15]
     long long tAcc[6] = {0, 0, 0, 0, 0, 0}; long long trips = 0, runGroups = 0; long long tMark = clock64();
@@ -1575,10 +1642,13 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
         // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
         // retry list of tier k = 1..6 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
         const bool fromLane = TIER == 0 && tinyList != nullptr;         // [40]/[42] counts, [41]/[43] fetched: the list of the lane-per-DP class
-        int* fetchCounter = &B.work_counter[TIER == 0 ? (fromLane ? 41 + 2 * dirPass : (dirPass ? 10 : 1)) : 13 + 4 * (TIER - 1) + 2 * dirPass];
-        const int nItems = uni(B.work_counter[TIER == 0 ? (fromLane ? 40 + 2 * dirPass : 8 + dirPass) : 12 + 4 * (TIER - 1) + 2 * dirPass]);
-        const int listBase = (TIER == 0 && dirPass) ? B.n_chains : 0;
-        const int* srcList = fromLane ? tinyList + (size_t)dirPass * (size_t)B.n_chains : B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains;
+        int* fetchCounter = &B.work_counter[TIER == 0 ? (fromLane ? 41 + 2 * dirPass : (C::JF ? 4 + dirPass : (dirPass ? 10 : 1))) : 13 + 4 * (TIER - 1) + 2 * dirPass];        // [4]/[5]: the jump-free lists
+        // (TIER 0 draws from the dense lists of k_dp_lists -- jump-free or general, left or right --, the later tiers from the retry lists)
+        const int seg = (C::JF ? 0 : 2) + dirPass;
+        const int segStart = (TIER == 0 && !fromLane) ? uni(B.dp_blk[(size_t)seg * B.dp_nblk]) : 0;
+        const int nItems = (TIER == 0 && !fromLane) ? uni(B.dp_blk[(size_t)(seg + 1) * B.dp_nblk]) - segStart : uni(B.work_counter[TIER == 0 ? 40 + 2 * dirPass : 12 + 4 * (TIER - 1) + 2 * dirPass]);
+        const int* srcList = (TIER == 0 && !fromLane) ? B.dp_list + segStart
+                           : (fromLane ? tinyList + (size_t)dirPass * (size_t)B.n_chains : B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains);
         const bool fwd = dirPass != 0;                     // left extensions run backwards (alignerBase: extensionAligner.cpp:229-241)
         int phase = PH_IDLE;
         bool more = true;
@@ -1650,7 +1720,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
                 w = grp_bcast0<GW>(w);
                 if(w >= nItems) more = false;
                 else {
-                    const int idx = (TIER == 0 && !fromLane) ? listBase + w : guni<GW>(srcList[w]);
+                    const int idx = guni<GW>(srcList[w]);
                     const int4* ip = (const int4*)(items + idx);
                     int4 a = ip[0], b = ip[1];
                     DpItem it; it.item = a.x; it.rOff = a.y; it.seqLen = a.z; it.start_seq = a.w; it.startLevel = b.x; it.startNode = b.y; it.pad0 = 0; it.pad1 = 0;
@@ -1671,7 +1741,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
         atomicAdd(&B.counters[CNT_DP_CELLS], S.accCells); atomicAdd(&B.counters[CNT_EDGES], S.accEdges);
     }
 #ifdef HLALA_DP_TIMING
-    if(TIER == 0 && (threadIdx.x & 63) == 0) { for(int i = 0; i < 8; i++) atomicAdd(&B.counters[24 + i], (u64)S.tPh[i]);
+    if(TIER == 0 && (threadIdx.x & 63) == 0) { for(int i = 0; i < 8; i++) atomicAdd(&B.counters[24 + i], (u64)S.tPh[i]); for(int i = 0; i < 8; i++) atomicAdd(&B.counters[16 + i], (u64)S.tPh[8 + i]);
         for(int i = 0; i < 6; i++) atomicAdd(&B.counters[8 + i], (u64)tAcc[i]); atomicAdd(&B.counters[14], (u64)trips); atomicAdd(&B.counters[15], (u64)runGroups); }
 #endif
 }
@@ -1679,7 +1749,120 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
 // ------------------------------------------------------------------------------------------
 // one wave per chain: stitch left extension + seed + right extension (extendWithOtherSeedChain /
 // extendToFullSequenceLength, verboseSeedChain.cpp:23-136), then scoreOneAlignment (extensionAligner.cpp:52-182).
-__global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
+//
+// Round 4.  The kernel waits on memory nine tenths of its time: a chain used to cost a dozen DEPENDENT round trips to cold rows (descriptors one after
+// the other, the right extension moved, the seed copied, then the row just written read back for the likelihood, then lane 0 walking the levels for the
+// first / last two).  Now: the descriptors of eight chains arrive together (one per lane, two round trips per eight chains); a lane owns CONSECUTIVE
+// columns of the final row and fetches each from where it lives (pad: the read; left extension: in place; seed row; right extension at the end of the
+// row) -- one round trip for every column of the chain --, writes what has to move, and keeps level / graph character / read character in registers for
+// the likelihood terms and for the first / last levels (ballots, no loads).  The read qualities are the one dependent gather left.
+template <int PER>
+__device__ __forceinline__ void stitch_rounds(const DevBatch& B, const DevTables& T, const size_t cb, const int rOff, const int total, const int padL, const int nL, const int nSeed,
+                                              const int nR, const int newEnd, const int stride, const int lane, double& llOut, int& f0, int& f1, int& l0, int& l1)
+{
+    const int seedAt = padL + nL, rightAt = seedAt + nSeed, padRAt = rightAt + nR;
+    const int srcShift = (stride - nR) - rightAt;          // a column of the right extension sits this far behind its place (>= 0: the row holds the chain)
+    double carry = 0.0; int baseIdx = 0;                   // running sum / read bases consumed before this round
+    f0 = -1; f1 = -1; l0 = -1; l1 = -1;
+    for(int c0 = 0; c0 < total; c0 += 64 * PER) {
+        const int chunk = min(64 * PER, total - c0);
+        const int per = (chunk + 63) / 64;
+        const int j0 = c0 + lane * per, j1 = min(c0 + chunk, j0 + per);
+        int lv[PER], ed[PER]; unsigned char gcv[PER], scv[PER], kind[PER];       // kind: 0 pad, 1 left extension (in place), 2 seed, 3 right extension, 4 none
+        // ---- every column of the round from where it lives: all loads are requested before the first store.  (The right extension moves towards the
+        // front of the row, destination <= source: a store of this round can only hit a source column of this or an earlier round, whose load precedes it
+        // in program order -- and the pads behind it lie behind every source column still to be read.)
+#pragma unroll
+        for(int k = 0; k < PER; k++) {
+            const int j = j0 + k; const bool in = k < per && j < j1;
+            lv[k] = -1; ed[k] = -1; gcv[k] = '_'; scv[k] = '_'; kind[k] = 4;
+            if(in) {
+                if(j < padL) { kind[k] = 0; scv[k] = B.read_bases[rOff + j]; }
+                else if(j < seedAt) { kind[k] = 1; lv[k] = B.ext_level[cb + j]; gcv[k] = B.ext_g[cb + j]; scv[k] = B.ext_s[cb + j]; }
+                else if(j < rightAt) { const int q = j - seedAt; kind[k] = 2; lv[k] = B.seed_level[cb + q]; ed[k] = B.seed_edge[cb + q]; gcv[k] = B.seed_g[cb + q]; scv[k] = B.seed_s[cb + q]; }
+                else if(j < padRAt) { const size_t p = cb + j + srcShift; kind[k] = 3; lv[k] = B.ext_level[p]; ed[k] = B.ext_edge[p]; gcv[k] = B.ext_g[p]; scv[k] = B.ext_s[p]; }
+                else { kind[k] = 0; scv[k] = B.read_bases[rOff + newEnd + 1 + (j - padRAt)]; }
+            }
+        }
+        WSYNC();
+        // ---- read bases before each column -> the index of its quality; the gather of the qualities is requested, then the stores go out beside it
+        int nb = 0;
+#pragma unroll
+        for(int k = 0; k < PER; k++) if(kind[k] != 4 && scv[k] != '_') nb++;
+        int tot; const int before = baseIdx + wave_excl_scan(nb, tot);
+        unsigned char qv[PER];
+        {
+            int idx = before;
+#pragma unroll
+            for(int k = 0; k < PER; k++) {
+                qv[k] = 0;
+                if(kind[k] != 4 && scv[k] != '_') { if(gcv[k] != '_') qv[k] = B.read_quals[rOff + idx]; idx++; }
+            }
+        }
+#pragma unroll
+        for(int k = 0; k < PER; k++) {
+            const size_t o = cb + j0 + k;
+            if(kind[k] == 1) B.ext_fromseed[o] = 0;
+            else if(kind[k] != 4) {
+                if(kind[k] != 3 || srcShift != 0) { B.ext_level[o] = lv[k]; B.ext_edge[o] = ed[k]; B.ext_g[o] = gcv[k]; B.ext_s[o] = scv[k]; }
+                B.ext_fromseed[o] = kind[k] == 2 ? 1 : 0;
+            }
+        }
+        // ---- scoreOneAlignment: terms are added strictly left to right in FP64 (same order as the reference loop).
+        // The read quality of alignment-orientation base i is read_quals[i] in both strands: the reference indexes the
+        // ORIGINAL-orientation read with len-i-1 when the chain is reverse (extensionAligner.cpp:85-88), which is the same base.
+        // Every lane turns its columns into two addends each (an unused addend is +0.0, an exact identity); the running sum then walks the lanes in order.
+        double t1[PER], t2[PER];
+#pragma unroll
+        for(int k = 0; k < PER; k++) {
+            const unsigned char sc = scv[k], gc = gcv[k];
+            double a1 = 0.0, a2 = 0.0;
+            if(kind[k] != 4) {
+                if(sc != '_') {
+                    if(gc == '_') a1 = T.rate_ins_quarter;
+                    else { a1 = T.rate_match_mismatch; a2 = (sc == gc) ? T.ll_match[qv[k]] : T.ll_mismatch[qv[k]]; }
+                } else if(gc != '_') a1 = T.rate_indel;
+            }
+            t1[k] = a1; t2[k] = a2;
+        }
+        const int lanesUsed = (chunk + per - 1) / per;          // lanes beyond hold no column: nothing to add
+        double acc = 0.0;
+        for(int l = 0; l < lanesUsed; l++) {
+            double in = __shfl(acc, l > 0 ? l - 1 : 0);
+            if(lane == l) {
+                double a = (l == 0) ? carry : in;
+#pragma unroll
+                for(int k = 0; k < PER; k++) { a += t1[k]; a += t2[k]; }
+                acc = a;
+            }
+        }
+        carry = __shfl(acc, lanesUsed - 1); baseIdx += tot;
+        // ---- first / last two defined levels (verboseSeedChain.h:134-228) from the registers: per lane the number of defined levels among its columns,
+        // the first two and the last two; lanes hold consecutive columns, so lane order is column order
+        {
+            int cnt = 0, a0 = -1, a1 = -1, z0 = -1, z1 = -1;
+#pragma unroll
+            for(int k = 0; k < PER; k++) if(kind[k] != 4 && lv[k] != -1) { if(cnt == 0) a0 = lv[k]; else if(cnt == 1) a1 = lv[k]; z1 = z0; z0 = lv[k]; cnt++; }
+            const u64 m1 = __ballot(cnt >= 1);
+            if(m1) {
+                const int F = __ffsll((long long)m1) - 1, Lz = 63 - __clzll((long long)m1);
+                if(f1 < 0) {
+                    const int fa0 = __shfl(a0, F), fa1 = __shfl(a1, F);
+                    int nx = -1; { const u64 m2 = m1 & ~(1ull << F); if(m2) nx = __shfl(a0, __ffsll((long long)m2) - 1); }
+                    if(f0 < 0) { f0 = fa0; f1 = fa1 >= 0 ? fa1 : nx; }
+                    else f1 = fa0;
+                }
+                const int lz0 = __shfl(z0, Lz), lz1 = __shfl(z1, Lz);
+                int pv = -1; { const u64 m2 = m1 & ~(1ull << Lz); if(m2) pv = __shfl(z0, 63 - __clzll((long long)m2)); }
+                const int second = lz1 >= 0 ? lz1 : (pv >= 0 ? pv : l0);        // (one defined level in this round: the second-last is the last of the rounds before)
+                l0 = lz0; l1 = second;
+            }
+        }
+    }
+    llOut = carry;
+}
+
+__global__ __launch_bounds__(64, 5) void k_stitch_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
                                                         const uint8_t* __restrict__ deferPairs, const int deferMode, const int counterIdx)      // deferMode 1: skip the chains of deferred pairs, 2: only those
 {
     const DevBatch& B = *Bp;
@@ -1689,146 +1872,61 @@ __global__ __launch_bounds__(64, 8) void k_stitch_chains(const DevGraph* __restr
     // chains are drawn eight at a time: one same-address atomic per chain would serialise the whole grid at the L2
     constexpr int CHUNK = 8;
     u64 accChains = 0, accCols = 0;          // work counters, flushed once per wave (same-address atomics serialise at the L2)
-#ifdef HLALA_DP_TIMING
-    long long tS[6] = {0, 0, 0, 0, 0, 0}, tM = clock64(); long long nCh = 0;
-#define ST_T(i) do { long long t_ = clock64(); tS[i] += t_ - tM; tM = t_; } while(0)
-#else
-#define ST_T(i) do { } while(0)
-#endif
     for(;;) {
         int c0 = 0;
         if(lane == 0) c0 = atomicAdd(&B.work_counter[counterIdx], CHUNK);
         c0 = __builtin_amdgcn_readfirstlane(c0);
         if(c0 >= B.n_chains) break;
-        const int cEnd = min(c0 + CHUNK, B.n_chains);
-        for(int c = c0; c < cEnd; c++) {
-        ST_T(0);
-        // (fused entry point: the chains of a pair with a DP call in one of the side-stream classes stay pending in the first pass; the second
-        // pass, which may run beside the first one, takes exactly those)
-        bool mine = uni(B.ext_status[c]) == EXT_PENDING;
-        if(mine && deferMode) { const bool df = uni(deferPairs[uni(B.chain_read[c]) >> 1]) != 0; mine = df == (deferMode == 2); }
-        if(mine) {
-        const int r = uni(B.chain_read[c]);
-        const int rOff = uni(B.read_off[r]), seqLen = uni(B.read_off[r + 1]) - rOff;
-        const size_t cb = (size_t)c * stride;
-        const int nSeed = uni(B.seed_ncols[c]), sBegin = uni(B.seed_begin[c]), sEnd = uni(B.seed_end[c]);
-        const int ncL = uni(B.dp_ncols[2 * c]), ncR = uni(B.dp_ncols[2 * c + 1]);
-        const int errL = uni(B.dp_err[2 * c]), errR = uni(B.dp_err[2 * c + 1]);
-        int err = 0;
-        if(errL || errR) err = ((errL <= -1000000) || (errR <= -1000000)) ? HLALA_CHAIN_ERR_COLUMNS : HLALA_CHAIN_ERR_FRONTIER;
-        const bool haveL = ncL >= 0 && !errL, haveR = ncR >= 0 && !errR;
-        const int nL = haveL ? ncL : 0, nR = haveR ? ncR : 0;
-        const int newBegin = haveL ? uni(B.dp_sb[2 * c]) : sBegin, newEnd = haveR ? uni(B.dp_se[2 * c + 1]) : sEnd;
-        const int padL = newBegin, padR = seqLen - 1 - newEnd;
-        const int total = padL + nL + nSeed + nR + padR;
-        if(!err && total > stride) err = HLALA_CHAIN_ERR_COLUMNS;
-        ST_T(1);
-        if(err) {
-            if(lane == 0) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(errL ? errL : errR); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
-        } else {
-        // ---- stitch.  The left extension already sits at [padL, padL + nL).  The right extension moves from the end of the row
-        // to its place after the seed: destination <= source, so ascending 64-column chunks (read all, then write all) are safe.
-        {
-            const int src = stride - nR, dst = padL + nL + nSeed;
-            if(nR > 0 && dst != src) {
-                for(int q0 = 0; q0 < nR; q0 += 64) {
-                    int q = q0 + lane; bool in = q < nR;
-                    int lv = 0, ed = 0; unsigned char gg = 0, ss = 0;
-                    if(in) { lv = B.ext_level[cb + src + q]; ed = B.ext_edge[cb + src + q]; gg = B.ext_g[cb + src + q]; ss = B.ext_s[cb + src + q]; }
-                    WSYNC();
-                    if(in) { B.ext_level[cb + dst + q] = lv; B.ext_edge[cb + dst + q] = ed; B.ext_g[cb + dst + q] = gg; B.ext_s[cb + dst + q] = ss; }
-                    WSYNC();
+        // the descriptors of the chunk's chains: lane q holds chain c0 + q (two round trips for the chunk: the fields, then what they point to)
+        const int cq = c0 + lane; const bool has = lane < CHUNK && cq < B.n_chains;
+        int dSt = 0, dRead = 0, dNSeed = 0, dSB = 0, dSE = 0, dNcL = -1, dNcR = -1, dErrL = 0, dErrR = 0, dSbL = 0, dSeR = 0;
+        if(has) dSt = B.ext_status[cq];
+        if(has && dSt == EXT_PENDING) {
+            dRead = B.chain_read[cq]; dNSeed = B.seed_ncols[cq]; dSB = B.seed_begin[cq]; dSE = B.seed_end[cq];
+            const int2 nc = ((const int2*)B.dp_ncols)[cq], er = ((const int2*)B.dp_err)[cq];
+            dNcL = nc.x; dNcR = nc.y; dErrL = er.x; dErrR = er.y; dSbL = B.dp_sb[2 * cq]; dSeR = B.dp_se[2 * cq + 1];
+        }
+        int dR0 = 0, dR1 = 0; bool dMine = has && dSt == EXT_PENDING;
+        if(dMine) {
+            dR0 = B.read_off[dRead]; dR1 = B.read_off[dRead + 1];
+            // (fused entry point: the chains of a pair with a DP call in one of the side-stream classes stay pending in the first pass; the second
+            // pass, which may run beside the first one, takes exactly those)
+            if(deferMode) { const bool df = deferPairs[dRead >> 1] != 0; dMine = df == (deferMode == 2); }
+        }
+        u64 mine = __ballot(dMine);
+        for(; mine; mine &= mine - 1) {
+            const int q = __ffsll((long long)mine) - 1;
+            const int c = c0 + q;
+            const int rOff = __builtin_amdgcn_readlane(dR0, q), seqLen = __builtin_amdgcn_readlane(dR1, q) - rOff;
+            const size_t cb = (size_t)c * stride;
+            const int nSeed = __builtin_amdgcn_readlane(dNSeed, q), sBegin = __builtin_amdgcn_readlane(dSB, q), sEnd = __builtin_amdgcn_readlane(dSE, q);
+            const int ncL = __builtin_amdgcn_readlane(dNcL, q), ncR = __builtin_amdgcn_readlane(dNcR, q);
+            const int errL = __builtin_amdgcn_readlane(dErrL, q), errR = __builtin_amdgcn_readlane(dErrR, q);
+            int err = 0;
+            if(errL || errR) err = ((errL <= -1000000) || (errR <= -1000000)) ? HLALA_CHAIN_ERR_COLUMNS : HLALA_CHAIN_ERR_FRONTIER;
+            const bool haveL = ncL >= 0 && !errL, haveR = ncR >= 0 && !errR;
+            const int nL = haveL ? ncL : 0, nR = haveR ? ncR : 0;
+            const int newBegin = haveL ? __builtin_amdgcn_readlane(dSbL, q) : sBegin, newEnd = haveR ? __builtin_amdgcn_readlane(dSeR, q) : sEnd;
+            const int padL = newBegin, padR = seqLen - 1 - newEnd;
+            const int total = padL + nL + nSeed + nR + padR;
+            if(!err && total > stride) err = HLALA_CHAIN_ERR_COLUMNS;
+            if(err) {
+                if(lane == 0) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(errL ? errL : errR); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
+            } else {
+                double ll; int f0, f1, l0, l1;
+                // chains of up to 192 columns (2x150 bp reads) take 3 columns per lane, longer ones 8 per lane in rounds of 512
+                if(total <= 192) stitch_rounds<3>(B, T, cb, rOff, total, padL, nL, nSeed, nR, newEnd, stride, lane, ll, f0, f1, l0, l1);
+                else stitch_rounds<8>(B, T, cb, rOff, total, padL, nL, nSeed, nR, newEnd, stride, lane, ll, f0, f1, l0, l1);
+                if(lane == 0) {
+                    ((int4*)B.ext_firstlast)[c] = make_int4(f0, f1, l0, l1);
+                    B.ext_status[c] = HLALA_CHAIN_OK; B.ext_ncols[c] = total; B.ext_begin[c] = 0; B.ext_end[c] = seqLen - 1; B.ext_ll[c] = ll;
+                    accChains++; accCols += (u64)total;
                 }
             }
-        }
-        for(int j = lane; j < total; j += 64) {
-            unsigned char fs = 0;
-            if(j < padL) { B.ext_level[cb + j] = -1; B.ext_edge[cb + j] = -1; B.ext_g[cb + j] = '_'; B.ext_s[cb + j] = B.read_bases[rOff + j]; }
-            else if(j < padL + nL) { }
-            else if(j < padL + nL + nSeed) { int q = j - padL - nL; B.ext_level[cb + j] = B.seed_level[cb + q]; B.ext_edge[cb + j] = B.seed_edge[cb + q]; B.ext_g[cb + j] = B.seed_g[cb + q]; B.ext_s[cb + j] = B.seed_s[cb + q]; fs = 1; }
-            else if(j < padL + nL + nSeed + nR) { }
-            else { int q = j - (padL + nL + nSeed + nR); B.ext_level[cb + j] = -1; B.ext_edge[cb + j] = -1; B.ext_g[cb + j] = '_'; B.ext_s[cb + j] = B.read_bases[rOff + newEnd + 1 + q]; }
-            B.ext_fromseed[cb + j] = fs;
-        }
-        WSYNC();
-        ST_T(2);
-        // ---- scoreOneAlignment: terms are added strictly left to right in FP64 (same order as the reference loop).
-        // The read quality of alignment-orientation base i is read_quals[i] in both strands: the reference indexes the
-        // ORIGINAL-orientation read with len-i-1 when the chain is reverse (extensionAligner.cpp:85-88), which is the same base.
-        {
-            // phase 1 (parallel): every lane turns its <= LLPER consecutive columns into two addends each (an unused addend is +0.0,
-            // an exact identity); phase 2 (serial by construction of FP addition): the running sum walks the lanes in order.
-            // Chains of up to 192 columns (2x150 bp reads) take 3 columns per lane, longer ones 8 per lane in rounds of 512.
-            double carry = 0.0; int baseIdx = 0;                       // running sum / read bases consumed before this round
-            auto ll_rounds = [&](auto perTag) {
-                constexpr int LLPER = decltype(perTag)::value;
-                for(int c0 = 0; c0 < total; c0 += 64 * LLPER) {
-                    const int chunk = min(64 * LLPER, total - c0);
-                    const int per = (chunk + 63) / 64;
-                    const int j0 = c0 + lane * per, j1 = min(c0 + chunk, j0 + per);
-                    unsigned char scv[LLPER], gcv[LLPER];
-                    int nb = 0;
-#pragma unroll
-                    for(int k = 0; k < LLPER; k++) {
-                        int j = j0 + k; bool in = k < per && j < j1;
-                        scv[k] = in ? B.ext_s[cb + j] : (unsigned char)'_'; gcv[k] = in ? B.ext_g[cb + j] : (unsigned char)'_';
-                        if(in && scv[k] != '_') nb++;
-                    }
-                    int tot; int before = baseIdx + wave_excl_scan(nb, tot);
-                    double t1[LLPER], t2[LLPER];
-                    {
-                        int idx = before;
-#pragma unroll
-                        for(int k = 0; k < LLPER; k++) {
-                            unsigned char sc = scv[k], gc = gcv[k];
-                            double a1 = 0.0, a2 = 0.0;
-                            if(sc != '_') {
-                                if(gc == '_') a1 = T.rate_ins_quarter;
-                                else { a1 = T.rate_match_mismatch; unsigned char q = B.read_quals[rOff + idx]; a2 = (sc == gc) ? T.ll_match[q] : T.ll_mismatch[q]; }
-                                idx++;
-                            } else if(gc != '_') a1 = T.rate_indel;
-                            t1[k] = a1; t2[k] = a2;
-                        }
-                    }
-                    double acc = 0.0;
-                    for(int l = 0; l < 64; l++) {
-                        double in = __shfl(acc, l > 0 ? l - 1 : 0);
-                        if(lane == l) {
-                            double a = (l == 0) ? carry : in;
-#pragma unroll
-                            for(int k = 0; k < LLPER; k++) { a += t1[k]; a += t2[k]; }
-                            acc = a;
-                        }
-                    }
-                    carry = __shfl(acc, 63); baseIdx += tot;
-                }
-            };
-            if(total <= 192) ll_rounds(std::integral_constant<int, 3>{}); else ll_rounds(std::integral_constant<int, 8>{});
-            double ll = carry;
-            ST_T(3);
-            // first / last two defined levels for the pairing stage (verboseSeedChain.h:134-228)
-            if(lane == 0) {
-                int f0 = -1, f1 = -1, l0 = -1, l1 = -1;
-                for(int j = 0; j < total && f1 < 0; j++) { int lv = B.ext_level[cb + j]; if(lv != -1) { if(f0 < 0) f0 = lv; else f1 = lv; } }
-                for(int j = total - 1; j >= 0 && l1 < 0; j--) { int lv = B.ext_level[cb + j]; if(lv != -1) { if(l0 < 0) l0 = lv; else l1 = lv; } }
-                B.ext_firstlast[4 * c + 0] = f0; B.ext_firstlast[4 * c + 1] = f1; B.ext_firstlast[4 * c + 2] = l0; B.ext_firstlast[4 * c + 3] = l1;
-                B.ext_status[c] = HLALA_CHAIN_OK; B.ext_ncols[c] = total; B.ext_begin[c] = 0; B.ext_end[c] = seqLen - 1; B.ext_ll[c] = ll;
-                accChains++; accCols += (u64)total;
-            }
-            ST_T(4);
-#ifdef HLALA_DP_TIMING
-            nCh++;
-#endif
-        }
-        }   // no error
-        }   // chain pending
-        WSYNC();
+            WSYNC();
         }
     }
     if(lane == 0 && accChains) { atomicAdd(&B.counters[CNT_CHAINS_EXT], accChains); atomicAdd(&B.counters[CNT_OUT_COLS], accCols); }
-#ifdef HLALA_DP_TIMING
-    if(lane == 0) { for(int i = 0; i < 5; i++) atomicAdd(&B.counters[16 + i], (u64)tS[i]); atomicAdd(&B.counters[23], (u64)nCh); }
-#endif
 }
 
 }  // namespace hlala

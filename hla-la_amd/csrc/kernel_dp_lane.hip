@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64, 1) void k_dp_lane(const DevGraph* __restrict__ 
     for(int dirPass = 0; dirPass < 2; dirPass++) {
         const bool fwd = dirPass != 0;
         const int dir = fwd ? 1 : -1;
-        const int nItems = uni(B.work_counter[8 + dirPass]);
+        const int nItems = ordered_chains(B);           // slots of k_dp_items' lists (one per chain in position order; item = -1: no DP)
         const int listBase = dirPass ? B.n_chains : 0;
         int* const fetchCounter = &B.work_counter[WC_LANE_FETCH + dirPass];
         int* const tinyCount = &B.work_counter[WC_TINY_COUNT + 2 * dirPass];
@@ -104,11 +104,12 @@ __global__ __launch_bounds__(64, 1) void k_dp_lane(const DevGraph* __restrict__ 
                     const int avail = poolEnd - poolNext;
                     if(phase == LPH_IDLE && more && rk < avail) {
                         const int w = poolNext + rk;
+                        const int4* ip = (const int4*)(items + listBase + (w < nItems ? w : 0));
+                        const int4 a = ip[0];
                         if(w >= nItems) more = false;
-                        else {
+                        else if(a.x >= 0) {            // (an empty slot: the lane stays idle and draws again in the next round)
                             itemIdx = listBase + w;
-                            const int4* ip = (const int4*)(items + itemIdx);
-                            const int4 a = ip[0], b = ip[1];
+                            const int4 b = ip[1];
                             item = a.x; rOff = a.y; seqLen = a.z; start_seq = a.w; startLevel = b.x; startNode = b.y;
                             diagonals = seqLen + G.L - 1;
                             d = 1; n1 = 1; n2 = 0; nCells = 1; nCompleted = 0; curMax = 0; firstMaxSlot = 0; lastInc = 0; itersRun = 0; edges = 0; cellsEvaluated = 0;

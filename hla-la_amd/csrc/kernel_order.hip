@@ -5,7 +5,8 @@
 // thousand unrelated places of a 0.7 GB graph, and every node record, CSR window and level list they touch comes from HBM (measured, round 3:
 // 43 GB fetched by the 16-lane DP kernel of a 1 M-pair batch against 0.44 GB of node records in the whole graph).  Results do not depend on the order
 // in which chains are processed (every DP call draws its random seed from its chain's absolute number), so the lists are put into position order:
-// a counting sort of the chains by (first level >> shift) -- buckets of a few hundred levels; the order inside a bucket is left to the atomics.
+// a counting sort of the chains that passed the filters by (first level >> shift) -- buckets of a few hundred levels; the order inside a bucket is left to
+// the atomics.
 // The work in flight at one time then covers a window of the graph that fits the 4 MB L2 of an XCD.
 //   k_filter_chains (kernel_project.hip)  bucket of every chain + histogram
 //   k_order_scan                           exclusive scan of the histogram (one block)
@@ -41,7 +42,9 @@ __global__ void k_order_scatter(const DevBatch* __restrict__ Bp)
     const DevBatch& B = *Bp;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if(c >= B.n_chains) return;
-    const int pos = atomicAdd(&B.order_hist[B.chain_bucket[c]], 1);
+    const int bk = B.chain_bucket[c];
+    if(bk < 0) return;                      // filtered out: takes no further part
+    const int pos = atomicAdd(&B.order_hist[bk], 1);
     B.chain_order[pos] = c;
 }
 

@@ -58,7 +58,7 @@ struct __align__(16) ProjLdsT {
 };
 typedef ProjLdsT<PROJ_CAP, PROJ_SN, PROJ_SE> ProjLds;
 // the layout of the paired path (params.max_columns <= 384): a 2x150 bp chain spans ~170-200 levels, i.e. ~280 nodes / ~300 in-edges on backbone
-// stretches; 416 / 544 keep those in the one-shot staged form and, with 16-bit column levels, make the block 11.4 KB: 14 waves per CU
+// stretches; 416 / 544 keep those in the one-shot staged form and, with 16-bit column levels, make the block 11.4 KB: 13 blocks per CU by LDS (12 resident: 143 VGPRs, three waves per SIMD)
 constexpr int PROJ_CAP_SHORT = 384;
 typedef ProjLdsT<PROJ_CAP_SHORT, 416, 544> ProjLdsShort;
 
@@ -160,11 +160,12 @@ __global__ void k_filter_chains(const DevGraph* __restrict__ Gp, const DevBatch*
         B.seed_status[c] = st;
         if(st != HLALA_CHAIN_OK) B.seed_ncols[c] = 0;
         // position bucket of the chain (kernel_order.hip): the level its first reference base sits on; chains that take no further part go last
+        // (one atomic per chain on ONE counter -- all filtered chains in a bucket of their own -- cost 90 ms per million pairs: same-address atomics
+        //  serialise at the L2)
         if(B.chain_bucket) {
-            int bk = B.order_nb - 1;
-            if(st == HLALA_CHAIN_OK) { bk = (idA >= 0 ? idA : (idB >= 0 ? idB : 0)) >> B.order_shift; if(bk > B.order_nb - 2) bk = B.order_nb - 2; }
+            int bk = -1;
+            if(st == HLALA_CHAIN_OK) { bk = (idA >= 0 ? idA : (idB >= 0 ? idB : 0)) >> B.order_shift; if(bk > B.order_nb - 2) bk = B.order_nb - 2; atomicAdd(&B.order_hist[bk], 1); }
             B.chain_bucket[c] = bk;
-            atomicAdd(&B.order_hist[bk], 1);
         }
     }
 }
@@ -207,12 +208,13 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
     long long tSub[4] = {0, 0, 0, 0};          // HLALA_DEBUG: chunked form -- chunk staging, level loops, chunks, levels
     u64 accCols = 0, accEdges = 0;           // work counters, flushed once per wave (same-address atomics serialise at the L2)
     constexpr int CHUNK = 4;                 // chains drawn per atomic
+    const int nWork = ordered_chains(B);     // position order: only the chains that passed the filters are listed
     for(;;) {
         int c0 = 0;
         if(lane == 0) c0 = atomicAdd(&B.work_counter[0], CHUNK);
         c0 = __builtin_amdgcn_readfirstlane(c0);
-        if(c0 >= B.n_chains) break;
-        const int cEnd = min(c0 + CHUNK, B.n_chains);
+        if(c0 >= nWork) break;
+        const int cEnd = min(c0 + CHUNK, nWork);
         // the descriptors of the chunk's chains: lane q holds chain c0 + q; two round trips for the chunk (the fields, then what they point to)
         // instead of a chain of dependent wave-uniform loads per chain
         // (chains are taken in the order of their graph position, B.chain_order -- kernel_order.hip: the windows of the chains in flight at one time are
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 WSYNC();
                 if constexpr (!PL::LONG) if(deferRethread) {
                     // The level loop below is bound by the latency of one wave per level (its time per level does not depend on how many waves share the CU),
-                    // so what it needs is MORE WAVES -- and this kernel's 11.7 KB of LDS and 120 VGPRs allow 14 per CU.  A chain whose levels all fit the
+                    // so what it needs is MORE WAVES -- and this kernel's 11.7 KB of LDS and 143 VGPRs allow 12 per CU.  A chain whose levels all fit the
                     // staging arrays of k_rethread_chains goes there (5 KB, half the registers): its columns go out as they are (the graph character of the seed
                     // stays in seed_g for now), colInfo rides in its seed_edge slots, the window's level offsets and first in-edges in its (still unused)
                     // ext_level / ext_edge rows, the window's scalars in its DP item slots.
@@ -1071,7 +1073,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
 // k_rethread_chains -- the chunked form of the re-threading DP (processBAM.cpp:2676-3007) for the chains k_project_chains left pending.
 // The level loop of that form is bound by the latency of ONE wave per level -- a dependent chain of ~120 instructions; its time per level is the
 // same with 2 and with 14 waves on a CU (profiles/r03_experiments.txt) -- so throughput is waves per CU, and k_project_chains, which carries the
-// whole projection (11.7 KB of LDS, 120 VGPRs), tops out at 14.  This kernel holds only what the loop needs: a chunk's in-edge records and in-edge
+// whole projection (11.7 KB of LDS, 143 VGPRs), tops out at 12.  This kernel holds only what the loop needs: a chunk's in-edge records and in-edge
 // offsets, two score rows, the picks of the backtrace (5.3 KB); a chunk's level offsets, first in-edges and colInfo ride in the lanes of registers
 // (a chunk has at most 62 levels), read from the rows k_project_chains left in HBM.  Same recurrence, same order of the ties (first maximum = smallest
 // edge), same end node (smallest among the maxima), same chunking rule per chain as the wave-wide form there; see the comments at that loop.
@@ -1089,16 +1091,22 @@ __global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __res
     const DevBatch& B = *Bp;
     __shared__ RethreadLds P;
     const int lane = lane_id();
-    ChoiceRec* const ch = (ChoiceRec*)(slabs + (size_t)blockIdx.x * slabBytes);
+    // back pointer of a window node: from-node rank (low half, 0xFFFF = none) | chosen in-edge, window-relative (high half) -- ONE word per node (the 8-byte
+    // ChoiceRec of k_project_chains carries the score as well, which the backtrace never reads: half of this kernel's slab traffic)
+    u32* const ch = (u32*)(slabs + (size_t)blockIdx.x * slabBytes);
     const int stride = B.stride;
     u64 accCols = 0, accEdges = 0;
+    const int nWork = ordered_chains(B);
     for(;;) {
-        // 64 chains per draw: the wave takes the pending ones among them, one after the other
+        // RT_DRAW chains per draw: the wave takes the pending ones among them, one after the other.  (64 per draw until the chains came in position
+        // order: the pending chains -- gene windows -- then sit together in the list, a draw holds up to 64 of them at 300 k cycles each, and the waves
+        // that drew the last full ones finished 10 ms after the others.)
+        constexpr int RT_DRAW = 16;
         int c0 = 0;
-        if(lane == 0) c0 = atomicAdd(&B.work_counter[3], 64);
+        if(lane == 0) c0 = atomicAdd(&B.work_counter[3], RT_DRAW);
         c0 = __builtin_amdgcn_readfirstlane(c0);
-        if(c0 >= B.n_chains) break;
-        const int cq = c0 + lane < B.n_chains ? (B.chain_order ? B.chain_order[c0 + lane] : c0 + lane) : -1;        // position order, as in k_project_chains
+        if(c0 >= nWork) break;
+        const int cq = (lane < RT_DRAW && c0 + lane < nWork) ? (B.chain_order ? B.chain_order[c0 + lane] : c0 + lane) : -1;        // position order, as in k_project_chains
         u64 pend = __ballot(cq >= 0 && B.seed_status[cq] == CHAIN_RETHREAD_PENDING);
         for(; pend; pend &= pend - 1) {
             const int c = __builtin_amdgcn_readlane(cq, __ffsll((long long)pend) - 1);
@@ -1134,15 +1142,21 @@ __global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __res
                 const int lvReg = lvA, sgReg = sgA - eC;
                 {   // the chunk's in-edge records and in-edge offsets: one round trip
                     constexpr int UE = RT_CE / 64, UN = (RT_SN + 1 + 63) / 64;
+                    // (the in-edge offsets of the nodes are only read by the levels that are solved node by node -- mode 0, 3 % of the levels: most chunks have none)
+                    const bool needOff = __ballot(lane < cnt && ((ciReg >> 25) & 3u) == 0u) != 0;
                     u32 ve[UE]; int vn[UN];
                     #pragma unroll
                     for(int u = 0; u < UE; u++) { const int e = lane + 64 * u; if(e < nE) ve[u] = G.in_rec[eBase + eC + e]; }
-                    #pragma unroll
-                    for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) vn[u] = G.in_off[nodeBase + tBase + t]; }
+                    if(needOff) {
+                        #pragma unroll
+                        for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) vn[u] = G.in_off[nodeBase + tBase + t]; }
+                    }
                     #pragma unroll
                     for(int u = 0; u < UE; u++) { const int e = lane + 64 * u; if(e < nE) P.eRec[e] = ve[u]; }
-                    #pragma unroll
-                    for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) P.sIn[t] = (unsigned short)(vn[u] - eBase - eC); }
+                    if(needOff) {
+                        #pragma unroll
+                        for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) P.sIn[t] = (unsigned short)(vn[u] - eBase - eC); }
+                    }
                 }
                 WSYNC();
                 bool prevFast = false; int sReg = -1;
@@ -1180,9 +1194,8 @@ __global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __res
                         sReg = best;
                         if(last) {
                             const int tz = (int)__builtin_amdgcn_mbcnt_hi((u32)(lastMask >> 32), __builtin_amdgcn_mbcnt_lo((u32)lastMask, 0u));
-                            ChoiceRec cr; cr.eid = best >= 0 ? eC + eL0 + 63 - ((bk >> 9) & 63) : -1; cr.fromz = (short)(best >= 0 ? (bk & 511) : -1); cr.S = (short)best;
                             P.Srow[1 - rowP][tz] = (short)best;
-                            ch[l1 + tz - nbR] = cr;
+                            ch[l1 + tz - nbR] = best >= 0 ? ((u32)(bk & 511) | ((u32)(eC + eL0 + 63 - ((bk >> 9) & 63)) << 16)) : 0xFFFFFFFFu;
                             reached = best >= 0;
                         }
                         if(lane == 0) edgesTouched += (u64)nEl;
@@ -1199,9 +1212,8 @@ __global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __res
                             if(last) {
                                 const int best = (bk >> 15) - 1;
                                 const int tz = nodesDone + (int)__builtin_amdgcn_mbcnt_hi((u32)(lastMask >> 32), __builtin_amdgcn_mbcnt_lo((u32)lastMask, 0u));
-                                ChoiceRec cr; cr.eid = best >= 0 ? eC + eL0 + s0 + 63 - ((bk >> 9) & 63) : -1; cr.fromz = (short)(best >= 0 ? (bk & 511) : -1); cr.S = (short)best;
                                 P.Srow[1 - rowP][tz] = (short)best;
-                                ch[l1 + tz - nbR] = cr;
+                                ch[l1 + tz - nbR] = best >= 0 ? ((u32)(bk & 511) | ((u32)(eC + eL0 + s0 + 63 - ((bk >> 9) & 63)) << 16)) : 0xFFFFFFFFu;
                                 if(best >= 0) reached = true;
                             }
                             nodesDone += (int)__popcll(lastMask);
@@ -1226,8 +1238,7 @@ __global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __res
                             }
                             edgesTouched += (u64)(e1 - e0);
                             P.Srow[1 - rowP][z] = (short)best;
-                            ChoiceRec cr; cr.eid = bestE; cr.fromz = (short)bestFrom; cr.S = (short)best;
-                            ch[tBase + t - nbR] = cr;
+                            ch[tBase + t - nbR] = (u32)(unsigned short)(short)bestFrom | ((u32)(unsigned short)bestE << 16);
                             if(best >= 0) reached = true;
                         }
                         prevFast = false;
@@ -1261,11 +1272,11 @@ __global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __res
                     const int tBase = __builtin_amdgcn_readlane(lvA, 1), nT = __builtin_amdgcn_readlane(lvA, bb - aa + 2) - tBase;
                     {   // the back pointers of the chunk's nodes: from-node | chosen edge per node, one round trip
                         constexpr int UN = (RT_SN + 63) / 64;
-                        ChoiceRec vr[UN];
+                        u32 vr[UN];
                         #pragma unroll
                         for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t < nT) vr[u] = ch[tBase + t - nbR]; }
                         #pragma unroll
-                        for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t < nT) P.eRec[t] = (u32)(unsigned short)vr[u].fromz | ((u32)(unsigned short)vr[u].eid << 16); }
+                        for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t < nT) P.eRec[t] = vr[u]; }
                     }
                     WSYNC();
                     for(int i = bb; i >= aa; i--) {

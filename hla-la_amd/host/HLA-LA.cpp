@@ -135,7 +135,10 @@ std::vector<std::string> split_list(const std::string& l)
     return out;
 }
 
-int action_HLA_one(const std::map<std::string, std::string>& arguments, const std::vector<int>& devices)
+// what several samples of one call share: the graph directory as the aligner and as the typer read it (read once, read-only afterwards)
+struct SharedGraph { std::shared_ptr<mapper::GraphDirectory> dir; std::unique_ptr<hla::HLATyper> typer; };
+
+int action_HLA_one(const std::map<std::string, std::string>& arguments, const std::vector<int>& devices, const SharedGraph* shared = nullptr)
 {
     unsigned int maxThreads = 1;
     need(arguments, "sampleID"); need(arguments, "outputDirectory"); need(arguments, "PRG_graph_dir");
@@ -175,9 +178,14 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     // long reads: columns of a read incl. the levels it skips (hlala_batch_create_unpaired)
     // the typer's view of the graph directory (level names of every segment file: millions of them) is read beside the graph, the contigs and the BAM
     std::unique_ptr<hla::HLATyper> typerPtr; std::string typerErr;
-    std::thread typerThread([&]() { try { typerPtr.reset(new hla::HLATyper(PRG_graph_dir, fileExists("hla_nom_g.txt") ? "hla_nom_g.txt" : "")); } catch(const std::exception& e) { typerErr = e.what(); } });
+    std::thread typerThread([&]() {
+        try {
+            if(shared) typerPtr.reset(new hla::HLATyper(*shared->typer, hla::HLATyper::Borrow()));       // (several samples per call: read once by action_HLA)
+            else typerPtr.reset(new hla::HLATyper(PRG_graph_dir, fileExists("hla_nom_g.txt") ? "hla_nom_g.txt" : ""));
+        } catch(const std::exception& e) { typerErr = e.what(); } });
     struct Joiner { std::thread& t; ~Joiner() { if(t.joinable()) t.join(); } } typerJoin{typerThread};
-    mapper::processBAM BAMprocessor(PRG_graph_dir, mapAgainstCompleteGenome, longReads.length() ? 16384 : 384, rngSeed, devices, decodeThreads);
+    const std::shared_ptr<mapper::GraphDirectory> graphDirectory = shared ? shared->dir : std::make_shared<mapper::GraphDirectory>(PRG_graph_dir, mapAgainstCompleteGenome);
+    mapper::processBAM BAMprocessor(graphDirectory, longReads.length() ? 16384 : 384, rngSeed, devices, decodeThreads);
     const double loadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count();
     std::cout << timestamp() << "Start seed extraction\n" << std::flush;
     const auto tOpen = std::chrono::steady_clock::now();
@@ -249,12 +257,27 @@ int action_HLA(const std::map<std::string, std::string>& arguments)
         if(v.size() != samples.size()) throw std::runtime_error(std::string("--") + k + " must list one value per sample (" + std::to_string(samples.size()) + " samples)");
         for(size_t i = 0; i < samples.size(); i++) per[i][k] = v[i];
     }
+    // the graph directory is read ONCE for all samples -- graph and contigs on this thread, the typer's view beside them -- and shared read-only
+    // (eight samples on an eight-GPU node used to mean eight loads of the graph, eight of the 44 M translation lines and eight scans of the segment files)
+    need(arguments, "PRG_graph_dir"); need(arguments, "mapAgainstCompleteGenome");
+    const std::string PRG_graph_dir = arguments.at("PRG_graph_dir");
+    SharedGraph shared; std::string typerErr;
+    {
+        const auto tLoad = std::chrono::steady_clock::now();
+        ThreadJoiner tj;
+        tj.start([&]() { try { shared.typer.reset(new hla::HLATyper(PRG_graph_dir, fileExists("hla_nom_g.txt") ? "hla_nom_g.txt" : "")); } catch(const std::exception& e) { typerErr = e.what(); } });
+        shared.dir = std::make_shared<mapper::GraphDirectory>(PRG_graph_dir, StrtoB(arguments.at("mapAgainstCompleteGenome")));
+        tj.join();
+        if(!typerErr.empty()) throw std::runtime_error(typerErr);
+        std::cout << timestamp() << "Graph directory read once for " << samples.size() << " samples in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tLoad).count() << " s\n" << std::flush;
+    }
     std::vector<std::string> errs(samples.size());
-    std::vector<std::thread> th;
-    for(size_t i = 0; i < samples.size(); i++) th.emplace_back([&, i]() {
-        try { action_HLA_one(per[i], std::vector<int>(1, devices[i % devices.size()])); } catch(const std::exception& e) { errs[i] = e.what(); }
-    });
-    for(std::thread& t : th) t.join();
+    {
+        ThreadJoiner th;
+        for(size_t i = 0; i < samples.size(); i++) th.start([&, i]() {
+            try { action_HLA_one(per[i], std::vector<int>(1, devices[i % devices.size()]), &shared); } catch(const std::exception& e) { errs[i] = e.what(); }
+        });
+    }
     for(size_t i = 0; i < samples.size(); i++) if(!errs[i].empty()) throw std::runtime_error("sample " + samples[i] + ": " + errs[i]);
     std::cout << timestamp() << "Processed " << samples.size() << " samples on " << devices.size() << " device(s)\n" << std::flush;
     return 0;

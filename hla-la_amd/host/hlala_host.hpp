@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -251,12 +252,12 @@ private:
 // its threads, mapper/processBAM.cpp:1794, 2391-2483; BASELINE config 3 is ~10 M pairs).  Batch bi runs on device bi % #devices and keeps the
 // absolute numbering of its chains, so every DP draws the random seed it draws in a one-batch, one-GPU run: results do not depend on the
 // batch size or on the number of devices.
-class processBAM {
+// What a process reads of a graph directory ONCE, however many samples it aligns (BASELINE config 4: eight samples side by side, one per GPU): the graph,
+// the contigs with their translation tables, the reference intervals the BAM decoder keeps.  Read-only after construction; every processBAM of the process
+// holds a reference.
+class GraphDirectory {
 public:
-    processBAM(const std::string& graphDir, bool extendedReferenceGenome, int max_columns = 384, uint32_t rng_seed = 0, int device = 0)
-        : processBAM(graphDir, extendedReferenceGenome, max_columns, rng_seed, std::vector<int>(1, device), 0) {}
-    processBAM(const std::string& graphDir, bool extendedReferenceGenome, int max_columns, uint32_t rng_seed, const std::vector<int>& devices, int threads)
-        : graphDir_(graphDir), extended_(extendedReferenceGenome), max_columns_(max_columns), rng_seed_(rng_seed), devices_(devices.empty() ? std::vector<int>(1, 0) : devices), threads_(threads)
+    GraphDirectory(const std::string& graphDir, bool extendedReferenceGenome) : dir(graphDir), extended(extendedReferenceGenome)
     {
         // `--action prepareGraph` leaves the flattened arrays in <graphDir>/serializedGRAPH; a file of that name written by the reference
         // binary (a Boost archive) is not ours and the text graph is parsed instead.  The graph and the contigs (tens of millions of translation lines) are
@@ -277,7 +278,24 @@ public:
         intervals_.resize((size_t)hlala_contigs_file_intervals(contigs_, nullptr, 0));
         hlala_contigs_file_intervals(contigs_, intervals_.data(), (int32_t)intervals_.size());
     }
-    ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); for(hlala_ctx* c : ctxs_) if(c) hlala_destroy(c); if(seeds_) hlala_seed_batch_free(seeds_); hlala_contigs_file_free(contigs_); hlala_graph_file_free(graph_); }
+    ~GraphDirectory() { hlala_contigs_file_free(contigs_); hlala_graph_file_free(graph_); }
+    GraphDirectory(const GraphDirectory&) = delete;
+    GraphDirectory& operator=(const GraphDirectory&) = delete;
+    const std::string dir; const bool extended;
+    hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; std::vector<hlala_bam_interval> intervals_;
+};
+
+class processBAM {
+public:
+    processBAM(const std::string& graphDir, bool extendedReferenceGenome, int max_columns = 384, uint32_t rng_seed = 0, int device = 0)
+        : processBAM(graphDir, extendedReferenceGenome, max_columns, rng_seed, std::vector<int>(1, device), 0) {}
+    processBAM(const std::string& graphDir, bool extendedReferenceGenome, int max_columns, uint32_t rng_seed, const std::vector<int>& devices, int threads)
+        : processBAM(std::make_shared<GraphDirectory>(graphDir, extendedReferenceGenome), max_columns, rng_seed, devices, threads) {}
+    // a graph directory the process has read already (several samples per process share one)
+    processBAM(const std::shared_ptr<GraphDirectory>& gdir, int max_columns, uint32_t rng_seed, const std::vector<int>& devices, int threads)
+        : gdir_(gdir), graphDir_(gdir->dir), extended_(gdir->extended), max_columns_(max_columns), rng_seed_(rng_seed), devices_(devices.empty() ? std::vector<int>(1, 0) : devices), threads_(threads),
+          graph_(gdir->graph_), contigs_(gdir->contigs_), intervals_(gdir->intervals_) {}
+    ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); for(hlala_ctx* c : ctxs_) if(c) hlala_destroy(c); if(seeds_) hlala_seed_batch_free(seeds_); }
     processBAM(const processBAM&) = delete;
     processBAM& operator=(const processBAM&) = delete;
 
@@ -367,8 +385,9 @@ private:
     {
         if(hlala_seed_batch_window(seeds_, u0, n, &in) != HLALA_OK) throw std::runtime_error(std::string("alignReads: ") + hlala_bam_last_error());
     }
+    std::shared_ptr<GraphDirectory> gdir_;
     std::string graphDir_; bool extended_; int max_columns_; uint32_t rng_seed_; std::vector<int> devices_; int threads_;
-    hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; std::vector<hlala_bam_interval> intervals_;
+    hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; const std::vector<hlala_bam_interval>& intervals_;      // owned by gdir_
     hlala_seed_batch* seeds_ = nullptr; std::vector<hlala_ctx*> ctxs_;
     int32_t batchPairs_ = 1; std::vector<hlala_batch*> live_;
 };
@@ -385,7 +404,11 @@ public:
         if(hlala_typer_open(graphDir.c_str(), &t_) != HLALA_OK) throw std::runtime_error(std::string("HLATyper: ") + hlala_typer_last_error());
         if(!hla_nom_g.empty() && hlala_typer_load_g_groups(t_, hla_nom_g.c_str()) != HLALA_OK) { std::string e = hlala_typer_last_error(); hlala_typer_close(t_); throw std::runtime_error("HLATyper: " + e); }
     }
-    ~HLATyper() { hlala_typer_close(t_); }
+    // the typer's view of a graph directory the process has read already (several samples per process: the handle is read-only, each sample has its own
+    // parameters and timing)
+    struct Borrow {};
+    HLATyper(const HLATyper& loaded, Borrow) : t_(loaded.t_), owns_(false) {}
+    ~HLATyper() { if(owns_) hlala_typer_close(t_); }
     HLATyper(const HLATyper&) = delete;
     HLATyper& operator=(const HLATyper&) = delete;
 
@@ -650,7 +673,7 @@ public:
     bool has_locus(const std::string& locus) const { hlala_locus* L = nullptr; if(hlala_typer_locus(t_, locus.c_str(), 0, nullptr, &L) != HLALA_OK) return false; hlala_locus_free(L); return true; }
 
 private:
-    hlala_typer* t_ = nullptr;
+    hlala_typer* t_ = nullptr; bool owns_ = true;
 };
 
 }  // namespace hla

@@ -302,6 +302,9 @@ typedef struct {
     int32_t n_dp_lane;            /* DP calls that entered the lane-per-DP class (64 calls per wavefront, one per lane: every item starts there); those it passes on
                                      enter the 16-lane class (n_dp_class[0]); 0 when the class is switched off (HLALA_DP_LANE=0)                                 */
     float   ms_dp_lane;           /* time of that class's kernel                                                                                              */
+    int32_t n_dp_jump_free;       /* of n_dp_class[0]: calls that were known to meet no gap-path jump and ran in the instantiation of the 16-lane class that is
+                                     compiled without the early-cell machinery (kernel_dp.hip: DpTinyJF)                                                      */
+    float   ms_dp_jump_free;      /* part of ms_dp_class[0] spent in that instantiation                                                                       */
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 
@@ -664,10 +667,11 @@ int  hlala_kat_exp(hlala_ctx* ctx, int n, const double* x, double* exp_x);
 int  hlala_abi_sizeof(const char* struct_name);
 
 /* Version of this interface.  It changes whenever the meaning or the type of a field changes WITHOUT changing the size of its struct (which
- * hlala_abi_sizeof cannot see): 2 = hlala_batch_in carries 64-bit window offsets and an absolute read_primary (round 3).  A caller compares
+ * hlala_abi_sizeof cannot see) or a struct grows: 2 = hlala_batch_in carries 64-bit window offsets and an absolute read_primary (round 3);
+ * 3 = hlala_batch_stats ends with n_dp_jump_free / ms_dp_jump_free (round 4).  A caller compares
  * hlala_abi_version() with the HLALA_ABI_VERSION it was compiled against and refuses to run on a mismatch (hla-la_amd/__init__.py and
  * hla-la_amd/host/hlala_host.hpp do). */
-#define HLALA_ABI_VERSION 2
+#define HLALA_ABI_VERSION 3
 int  hlala_abi_version(void);
 /* bit mask of optional parts compiled into this library: HLALA_BUILD_LANE_CLASS = the lane-per-DP class (kernel_dp_lane.hip, an experiment that
  * lost its A/B and is left out of the default build: make EXTRA=-DHLALA_WITH_LANE_CLASS) */

@@ -73,3 +73,93 @@ def test_fifty_thousand_ten_kilobase_reads(pkg, oracle):
         for key in ("col_level", "col_edge", "col_gchar", "col_schar", "col_mapq"):
             assert np.array_equal(np.asarray(e[key])[r * stride:r * stride + k0], pk[key][off[r]:off[r] + k0]), (r, key)
     assert np.allclose(sc["pair_ll"][:m], e["pair_ll"][:m], rtol=1e-12, atol=0) and np.array_equal(sc["best_chain"][:m], e["best_chain"][:m])
+
+
+def _sub_reads(u, idx):
+    """The unpaired batch of reads `idx` (one chain per read) of batch u."""
+    idx = np.asarray(idx)
+    ro = np.asarray(u["read_off"], np.int64); co = np.asarray(u["cigar_off"], np.int64)
+    rl = (ro[idx + 1] - ro[idx]); cl = (co[idx + 1] - co[idx])
+    take_b = np.concatenate([np.arange(ro[i], ro[i + 1]) for i in idx]); take_c = np.concatenate([np.arange(co[i], co[i + 1]) for i in idx])
+    n = len(idx); ar = np.arange(n + 1, dtype=np.int32)
+    return dict(n_pairs=n, read_off=np.concatenate([[0], np.cumsum(rl)]).astype(np.int32), read_bases=u["read_bases"][take_b], read_quals=u["read_quals"][take_b],
+                chain_off=ar, read_primary=ar[:-1].copy(), n_chains=n, chain_contig=u["chain_contig"][idx], chain_pos=u["chain_pos"][idx], chain_offset=u["chain_offset"][idx],
+                chain_as=u["chain_as"][idx], chain_reverse=u["chain_reverse"][idx], cigar_off=np.concatenate([[0], np.cumsum(cl)]).astype(np.int32), cigar=u["cigar"][take_c])
+
+
+def test_distinct_long_reads_on_graph_m(pkg, oracle):
+    """Variety instead of copies: 6 000 DISTINCT reads over 6-14 kb of reference on a Graph M world (backbone haplotypes with gap stretches, gene
+    windows with hundreds to thousands of allele paths).  4 000 lie anywhere on the backbone contigs; 1 600 are laid ACROSS a gene window (they enter the
+    allele-rich levels from the backbone and leave them again: the projection's chunked and level-by-level forms, levels with hundreds of nodes); 400 come
+    from allele contigs of the windows.  Every column is checked against the reference's invariants and the graph, and 512 reads -- 256 of them
+    window-crossing or allele reads -- bit for bit against the oracle."""
+    w = synth.make_world_m(seed=9, n_levels=400_000, n_windows=6, alleles=(400, 3000))
+    c = w["contigs"]; off = np.asarray(c["contig_off"], np.int64); clen = np.diff(off); cw = np.asarray(w["contig_window"])
+    backbone = np.nonzero(cw < 0)[0]; allele = np.nonzero(cw >= 0)[0]
+    rng = np.random.default_rng(77)
+    starts = []
+    for _ in range(4000):                                    # anywhere on the backbone
+        h = int(backbone[rng.integers(0, len(backbone))]); starts.append((h, int(rng.integers(0, clen[h] - 14010))))
+    wf = w["windows"]["first_level"]; wl = w["windows"]["last_level"]
+    for i in range(1600):                                    # across a gene window: the read starts 1-5 kb in front of it
+        k = i % len(wf); h = int(backbone[rng.integers(0, len(backbone))])
+        lv = c["contig_level"][off[h]:off[h + 1]]
+        p = int(np.searchsorted(lv, wf[k])) - int(rng.integers(1000, 5000))
+        starts.append((h, max(0, min(p, int(clen[h]) - 14010))))
+    for _ in range(400):                                     # allele contigs (3-6 kb: the whole contig or its tail)
+        h = int(allele[rng.integers(0, len(allele))]); starts.append((h, int(rng.integers(0, max(1, clen[h] // 4)))))
+    bs = synth.make_long_batches_parallel(w, len(starts), per_batch=750, seed=900, len_lo=6000, len_hi=14000, procs=8, starts=starts)
+    # one batch: concatenate the chunks
+    def cat_off(key):
+        out = [np.zeros(1, np.int64)]
+        for b in bs:
+            out.append(np.asarray(b[key][1:], np.int64) + out[-1][-1])
+        return np.concatenate(out)
+    n = sum(b["n_pairs"] for b in bs); ar = np.arange(n + 1, dtype=np.int64)
+    u = dict(n_pairs=n, n_chains=n, read_off=cat_off("read_off"), cigar_off=cat_off("cigar_off"), chain_off=ar, read_primary=ar[:-1].astype(np.int32))
+    for k in ("read_bases", "read_quals", "chain_contig", "chain_pos", "chain_offset", "chain_as", "chain_reverse", "cigar"):
+        u[k] = np.concatenate([b[k] for b in bs])
+    assert n == 6000 and len(np.unique(u["chain_pos"].astype(np.int64) * 1000 + u["chain_contig"])) > 5900          # distinct reads
+    crosses = np.zeros(n, bool); crosses[4000:] = True
+    kw = dict(insert_mean=200.0, insert_sd=35.0, rng_seed=3, long_read_mode=1, max_columns=16384)
+    ctx = pkg.Context(w["graph"], w["contigs"], **kw)
+    gb = ctx.batch_unpaired(u); gb.align()
+    st = gb.stats()
+    assert st.n_dp_calls == 0
+    pk = gb.pairs_packed(); sc = gb.pairs_scalars()
+    okr = sc["pair_status"] == 0
+    assert okr.mean() > 0.995, okr.mean()                    # (a read may exceed the 16 384-column row when it crosses a long gap stretch: flagged, not dropped silently)
+    off_c = pk["col_off"]; ncols = np.diff(off_c)
+    assert np.all(ncols[okr] >= np.diff(u["read_off"])[okr])
+    read_of_col = np.repeat(np.arange(n, dtype=np.int32), ncols)
+    s = pk["col_schar"]; isbase = s != ord("_")
+    # chain concordance of every aligned read
+    nb = np.bincount(read_of_col[isbase], minlength=n)
+    assert np.array_equal(nb[okr], np.diff(u["read_off"])[okr])
+    keep_b = np.repeat(okr, np.diff(u["read_off"]))
+    assert np.array_equal(s[isbase], u["read_bases"][keep_b])
+    # level contiguity, columns against the graph
+    lv = pk["col_level"]; d = np.nonzero(lv != -1)[0]
+    same = read_of_col[d[1:]] == read_of_col[d[:-1]]
+    assert np.all((lv[d[1:]] - lv[d[:-1]])[same] == 1)
+    g = w["graph"]; ed = pk["col_edge"]; gc = pk["col_gchar"]; has = ed >= 0
+    assert np.array_equal(has, lv != -1)
+    assert np.array_equal(g["node_level"][g["edge_from"][ed[has]]], lv[has]) and np.array_equal(g["edge_label"][ed[has]], gc[has])
+    # the window-crossing reads did walk allele-rich levels
+    npl = w["nodes_per_level"]
+    rich = np.zeros(n, bool); rich[np.unique(read_of_col[has][npl[lv[has]] >= 50])] = True
+    assert rich[4000:5600].mean() > 0.9 and rich.sum() > 1500
+    # ---- 512 reads against the oracle: 256 from the backbone, 256 that cross a window or come from an allele contig
+    pick = np.concatenate([np.arange(0, 4000, 4000 // 256)[:256], np.arange(4000, 6000, 2000 // 256)[:256]])
+    sub = _sub_reads(u, pick)
+    e = oracle(w["graph"], w["contigs"], **kw).align_long_reads(sub)["pairs"]
+    stride = 16384
+    for i, r in enumerate(pick):
+        assert int(e["pair_status"][i]) == int(sc["pair_status"][r]), (i, r)
+        if sc["pair_status"][r] != 0:
+            continue
+        k0 = int(e["n_cols"][i])
+        assert k0 == ncols[r], (i, r)
+        for key in ("col_level", "col_edge", "col_gchar", "col_schar", "col_mapq"):
+            assert np.array_equal(np.asarray(e[key])[i * stride:i * stride + k0], pk[key][off_c[r]:off_c[r] + k0]), (r, key)
+    assert np.allclose(sc["pair_ll"][pick], e["pair_ll"][:len(pick)], rtol=1e-12, atol=0) and np.array_equal(sc["best_chain"][pick] - pick, e["best_chain"][:len(pick)] - np.arange(len(pick)))

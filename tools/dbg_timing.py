@@ -28,7 +28,7 @@ print('retry ms', st.ms_extend_retry, 'dp main ms', st.ms_dp_main, 'retried', st
 pj = np.array(list(buf)[16:24], dtype=np.float64)
 if pj[7] > 0:
     # counters[16..23]: the projection's phase clocks (HLALA_DEBUG=1, default build) or, in the -DHLALA_DP_TIMING build, k_stitch_chains' (that build leaves the projection's out)
-    if d[6] > 0:
+    if False:
         print('stitch cycles/chain (timing build): fetch+status %.0f descriptors %.0f stitch %.0f LL %.0f firstlast+out %.0f | chains %d' % tuple(list(pj[:5] / pj[7]) + [int(pj[7])]))
     else:
         print('project cycles/chain: walk %.0f trim+pad %.0f clean %.0f restrict %.0f stage+dp %.0f backtrace %.0f | chains %d' % tuple(list(pj[:6] / pj[7]) + [int(pj[7])]))
@@ -36,5 +36,8 @@ hh = np.array(list(buf)[24:32], dtype=np.float64)
 if pj[7] > 0 and d[6] == 0 and hh[2] > 0:
     print('project, chunked form: chunk staging %.0f and level loops %.0f cycles/chain (all chains); %.2f chunks/chain, %.1f levels/chunk, %.0f cycles/level' % (hh[0] / pj[7], hh[1] / pj[7], hh[2] / pj[7], hh[3] / hh[2], hh[1] / hh[3]))
     hh[:] = 0
+if hh[0] > 0 and d[6] > 0 and pj[0] > 0:
+    # -DHLALA_DP_TIMING, round 4: the evaluate pass in pieces (counters[16..21] = tPh[8..13])
+    print('evaluate pieces, cycles/trip: reads+decode %.0f scan+slot %.0f back pointers %.0f new cell / early / complete %.0f existing %.0f diff+stash %.0f (rest of the pass: loop ends, fences)' % tuple(pj[:6] / d[6]))
 if hh[0] > 0 and d[6] > 0:
     print('dp_iterate cycles/trip (group 0 of each wave; waitcnt(0) before each clock): header+records %.0f pushes %.0f tlist %.0f early-lookup %.0f evaluate-passes %.0f post-evaluate %.0f filter+writeback %.0f' % (hh[4]/d[6], hh[5]/d[6], hh[0]/d[6], hh[3]/d[6], hh[6]/d[6], hh[1]/d[6], hh[2]/d[6]))

@@ -4,13 +4,13 @@
 set -u
 : "${GRAFT_REPO_ROOT:?run through gpurun}"
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$R"
 mkdir -p gpurun_out
 make -s -C tools/graphm 2>&1 | tail -1
 rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_sq
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu-baseline --no-extras --host-steps 0 --e2e-pairs 0"
+B="--no-cpu-baseline --resident-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py $B > $R/gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --single-batch $B > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -- python3 $R/bench.py --steps 1 --warmup 0 --single-batch $B > $R/gpurun_out/${TAG}_write.log 2>&1
