@@ -191,6 +191,13 @@ def test_action_hla_writes_the_files_of_the_ctypes_path(exe, pkg, tmp_path):
     for fn in files:
         assert (out2 / "hla" / fn).read_bytes() == (out1 / "hla" / fn).read_bytes(), fn
     assert (out2 / "reads_per_level.txt").read_bytes() == (out1 / "reads_per_level.txt").read_bytes()
+    # ---- four contexts (what `--devices 0,1,2,3` does on a node with four GPUs), seven batches dealt round-robin
+    out4 = tmp_path / "out4"
+    r24 = subprocess.run(base + ["--outputDirectory", str(out4), "--batchPairs", "100", "--devices", "0,0,0,0"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r24.returncode == 0 and "on 4 device context(s)" in r24.stdout, r24.stdout + r24.stderr
+    for fn in files:
+        assert (out4 / "hla" / fn).read_bytes() == (out1 / "hla" / fn).read_bytes(), fn
+    assert (out4 / "reads_per_level.txt").read_bytes() == (out1 / "reads_per_level.txt").read_bytes()
     # ---- BASELINE config 4 in small: two samples in one call, one per listed device, side by side; each writes what its own call writes
     ra = [x for x in base]
     for key, val in (("--sampleID", "S1,S2"), ("--FASTQ1", f"{tmp_path / 'r1.fq'},{tmp_path / 'r1.fq'}"), ("--FASTQ2", f"{tmp_path / 'r2.fq'},{tmp_path / 'r2.fq'}"),
@@ -198,6 +205,7 @@ def test_action_hla_writes_the_files_of_the_ctypes_path(exe, pkg, tmp_path):
         ra[ra.index(key) + 1] = val
     r4 = subprocess.run(ra + ["--outputDirectory", f"{tmp_path / 'outA'},{tmp_path / 'outB'}", "--devices", "0,0"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r4.returncode == 0 and "Processed 2 samples on 2 device(s)" in r4.stdout, r4.stdout + r4.stderr
+    assert "Graph directory read once for 2 samples" in r4.stdout                    # the samples share one view of the graph directory
     for o in ("outA", "outB"):
         for fn in files:
             assert (tmp_path / o / "hla" / fn).read_bytes() == (out1 / "hla" / fn).read_bytes(), (o, fn)
