@@ -165,12 +165,15 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="resident loop: two batches alternate, but each step's export follows its alignment at once (a batch's tail does not run beside the next batch)")
     ap.add_argument("--single-batch", action="store_true", help="one batch at a time in both loops: no overlap of a batch's tail / transfers with the next batch")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region (gene / backbone split, long reads, typer, end to end)")
+    ap.add_argument("--ascii-bases", action="store_true", help="boundary loop: hand the read bases over as ASCII (1 B per base) instead of 4-bit packed as the BAM decoder has them")
     ap.add_argument("--resident-only", action="store_true", help="kernel A/B mode: only the resident loop (inputs already in HBM) is run and timed; `value` is then the RESIDENT rate and the line says so")
     ap.add_argument("--resident-steps", type=int, default=8, help="steps of the resident loop that follows the timed boundary loop (config.resident; 0 = skip)")
     ap.add_argument("--e2e-pairs", type=int, default=8_388_608, help="pairs of the sample pushed through `HLA-LA --action HLA` for the end-to-end rate (0 = skip)")
     ap.add_argument("--e2e-frac-gene", type=float, default=0.04, help="share of the end-to-end sample drawn from the gene windows: 0.04 = the windows' share of the graph, i.e. the uniform "
                     "coverage of a whole-genome sample (the resident workload keeps 0.3: its gene-window pairs are the expensive ones; at 0.3 every typed locus would see 2000x coverage)")
-    ap.add_argument("--e2e-threads", default="0,32", help="--decodeThreads values of the end-to-end runs (0 = all host threads)")
+    ap.add_argument("--e2e-threads", default="0,128", help="--decodeThreads values of the end-to-end runs (0 = the decoder's default: at most 32 threads)")
+    ap.add_argument("--no-extras-but-e2e", action="store_true", help="of the measurements outside the timed region only the end-to-end run")
+    ap.add_argument("--e2e-variants", default="", help="experiments: further end-to-end runs of the same sample under other environments, 'label:ENV=1 ENV2=x;label2:...'")
     ap.add_argument("--long-reads", type=int, default=50_000, help="reads of the long-read record (BASELINE config 5: 50 000 reads of ~10 kb; 0 = skip)")
     args = ap.parse_args()
 
@@ -274,16 +277,22 @@ def main():
                         h = bnd.start(i); before_export()
                         bnd.finish(h, recs[0], lambda: gather(0))
                     return
-                cur = bnd.start(0)
+                # Two alignments in flight and one upload ahead: while the GPU aligns batches i and i+1 the host thread uploads the INPUTS of batch i+2 (0.9 GB;
+                # hlala_batch_create allocates no outputs), then reads batch i back and destroys it, then queues the alignment of batch i+2, whose output arrays
+                # are the pool blocks batch i just gave back.  (With the upload AFTER the read-back -- round 3's order -- the one host thread was the critical path:
+                # create 63 ms + wait for the batch 127 + read-back 67 = the 258 ms of a step, 30 ms of them with the GPU's main stream idle.)
+                ahead = [bnd.start(k) for k in range(min(2, n))]
                 for i in range(n):
-                    nxt = bnd.start(i + 1) if i + 1 < n else None
+                    up = bnd.upload(i + 2) if i + 2 < n else None
                     before_export()
-                    bnd.finish(cur, recs[i % 2], lambda k=i % 2: gather(k))
-                    cur = nxt
+                    bnd.finish(ahead.pop(0), recs[i % 2], lambda k=i % 2: gather(k))
+                    if up is not None:
+                        ahead.append(bnd.launch(up))
             run_boundary(max(args.warmup, 1))          # (at least one: pool blocks, first touch of the page-locked buffers)
             g0 = n_gathers[0]
+            bnd.host_s = {}; bnd.host_n = {}
             elapsed, per_rank = timed(run_boundary, args.steps)
-            boundary = {"elapsed": elapsed, "per_rank_s": per_rank, "gathers": n_gathers[0] - g0, "pairs_ok": bnd.pairs_ok(), "columns": bnd.last_cols,
+            boundary = {"host_thread_ms_per_call": bnd.host_ms(), "elapsed": elapsed, "per_rank_s": per_rank, "gathers": n_gathers[0] - g0, "pairs_ok": bnd.pairs_ok(), "columns": bnd.last_cols,
                         "bytes_up": bnd.bytes_up, "bytes_down": bnd.bytes_down()}
             # the same with pageable caller buffers (what a caller that does not use hlala_pinned_alloc gets): a report
             if world == 1 and not args.no_extras:
@@ -357,7 +366,8 @@ def main():
         e_mean = g["n_edges"] / max(1, g["n_nodes"] - 1)
         bpp = algorithmic_bytes_per_pair(150, chains_pp, e_mean, cols_pc, cols_pc)
         cls_ms = [float(x) for x in st.ms_dp_class]; cls_n = [int(x) for x in st.n_dp_class]
-        names = ["k_dp<DpTiny, 0>", "k_dp<DpMid, 1>", "k_dp<DpSmall, 2>", "k_dp<DpWide, 3>", "k_dp<DpBroad, 4>", "k_dp<DpLarge, 5>", "k_dp<DpHuge, 6>"]
+        # (the 16-lane class is two kernels launched back to back: the jump-free and the general instantiation of one template; its events span both)
+        names = ["k_dp<DpTinyJF, 0> + k_dp<DpTiny, 0>" if st.n_dp_jump_free > 0 else "k_dp<DpTiny, 0>", "k_dp<DpMid, 1>", "k_dp<DpSmall, 2>", "k_dp<DpWide, 3>", "k_dp<DpBroad, 4>", "k_dp<DpLarge, 5>", "k_dp<DpHuge, 6>"]
         # the dominant kernel among the classes of the main stream: the times of the side-stream classes (few hundred long DP calls at low priority beside
         # the next batch, hlala_align_batch) are waiting times, not work
         dom = int(np.argmax(cls_ms[:4]))
@@ -383,7 +393,7 @@ def main():
         if secondary.get("valu_insts_all_dp_classes_per_launch"):
             secondary["valu_wave_insts_per_dp_cell"] = secondary["valu_insts_all_dp_classes_per_launch"] / max(1, st.n_dp_cells)
         headline = ("host-inclusive: hlala_batch_create (H2D, page-locked caller buffers) + hlala_align_batch + export of the per-pair records (+ gather) + hlala_batch_get_pairs + "
-                    "hlala_batch_get_pairs_packed (D2H) + hlala_batch_destroy per step, " + ("one batch at a time" if args.single_batch else "two batches in flight on one context, one host thread")) \
+                    "hlala_batch_get_pairs_packed (D2H) + hlala_batch_destroy per step, " + ("one batch at a time" if args.single_batch else "two alignments in flight and one upload ahead on one context, one host thread")) \
             if boundary is not None else "RESIDENT rate (--resident-only: kernel A/B mode, the boundary loop was not run)"
         out = {
             "metric": "paired reads/sec aligned to PRG graph", "value": value, "unit": "read pairs/s",
@@ -400,7 +410,7 @@ def main():
                                     "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6],
                                     "dp_16lane_jump_free_part": float(st.ms_dp_jump_free)},
                        "stage_ms_source": "HIP events of one batch of the resident loop, on the streams its kernels ran on (the kernels of the boundary loop are the same)",
-                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "16lane_jump_free": int(st.n_dp_jump_free)},
+                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "16lane_jump_free": int(st.n_dp_jump_free), "jump_free_handed_on_by_the_8lane_instantiation": int(st.n_dp_jump_free_16)},
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,
@@ -412,10 +422,10 @@ def main():
         if boundary is not None:
             out["host_inclusive"] = {"value": value, "unit": "read pairs/s", "steps": steps, "ms_per_step": ms_per_step, "per_rank_s": boundary["per_rank_s"], "gathers_in_timed_region": boundary["gathers"],
                                      "columns_returned_per_step": boundary["columns"], "bytes_down_per_step": boundary["bytes_down"], "bytes_up_per_step": boundary["bytes_up"],
-                                     "pairs_ok_last_step": boundary["pairs_ok"], "pageable": boundary.get("pageable"), "what": "this IS the headline: `value` / `ms_per_step` of this line"}
+                                     "pairs_ok_last_step": boundary["pairs_ok"], "host_thread_ms_per_call": boundary["host_thread_ms_per_call"], "pageable": boundary.get("pageable"), "what": "this IS the headline: `value` / `ms_per_step` of this line"}
             if world > 1:
                 assert boundary["gathers"] == args.steps, "every step of the timed region gathers once"
-        if world == 1 and not args.no_extras and not args.resident_only:
+        if world == 1 and not args.no_extras and not args.resident_only and not args.no_extras_but_e2e:
             try:
                 out["config"].update(extras(args, P, synth, w, mk, b, ctx, gb, ckw))
             except Exception as e:          # the extras are reports, never a reason to lose the bench line
@@ -483,13 +493,21 @@ class Boundary:
         self.C = C; self.P = P; self.ctx = ctx; self.lib = lib = ctx.lib; self.batches = batches
         self.pin = pin = Pinned(lib)
         self.ins = []
+        lib.hlala_pack_bases.argtypes = [P.c_u8p, P.c_i64p, C.c_int64, P.c_u8p]
         for b in batches:
             d = {k: b[k] for k in ("n_pairs", "n_chains")}
             for k, dt in self.DTS.items():
                 d[k] = pin.copy(np.ascontiguousarray(b[k], dt))
+            if not args.ascii_bases:
+                # the bases as a BAM decoder has them (hlala_bam_extract_seeds_opt with HLALA_SEEDS_PACKED: what the host program hands over): 4-bit packed, unpacked on the device
+                ro = d["read_off"]; nr = len(ro) - 1
+                pk = pin.empty((int(ro[-1]) + nr + 1) // 2 + 2, np.uint8)
+                if lib.hlala_pack_bases(d["read_bases"].ctypes.data_as(P.c_u8p), ro.ctypes.data_as(P.c_i64p), nr, pk.ctypes.data_as(P.c_u8p)) != 0:
+                    raise RuntimeError("hlala_pack_bases failed")
+                d["read_bases_packed"] = pk; d["read_bases"] = None; d["first_read"] = 0
             st, keep = P.fill_struct(P.BatchIn, d)
             self.ins.append((st, keep, d))
-        self.bytes_up = int(sum(self.ins[0][2][k].nbytes for k in self.DTS))
+        self.bytes_up = int(sum(v.nbytes for v in self.ins[0][2].values() if isinstance(v, np.ndarray)))
         self.n = n = args.pairs; self.nr = nr = 2 * n; self.cap = cap = nr * 184
         self.off = pin.empty(nr + 1, np.int64)
         self.cols = dict(col_level=pin.empty(cap, np.int32), col_gchar=pin.empty(cap, np.uint8), col_schar=pin.empty(cap, np.uint8), col_mapq=pin.empty(cap, np.uint8))
@@ -502,6 +520,7 @@ class Boundary:
         lib.hlala_batch_get_pairs.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(P.PairsOut)]
         lib.hlala_batch_export_pair_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         self.last_cols = 0
+        self.host_s = {}; self.host_n = {}
 
     def _bind(self, off, cols):
         types = dict(self.P.PairsPackedOut._fields_)
@@ -519,20 +538,43 @@ class Boundary:
             ins.append((st, keep, None))
         self.ins = ins
 
-    def start(self, i):
+    def _t(self, name, t0):
+        t1 = time.perf_counter(); self.host_s[name] = self.host_s.get(name, 0.0) + (t1 - t0); self.host_n[name] = self.host_n.get(name, 0) + 1
+        return t1
+
+    def upload(self, i):
         C = self.C; h = C.c_void_p()
+        t = time.perf_counter()
         self.ctx._check(self.lib.hlala_batch_create(self.ctx.h, C.byref(self.ins[i % len(self.ins)][0]), C.byref(h)), "hlala_batch_create")
-        self.ctx._check(self.lib.hlala_align_batch(self.ctx.h, h), "hlala_align_batch")
+        self._t("create", t)
         return h
+
+    def launch(self, h):
+        t = time.perf_counter()
+        self.ctx._check(self.lib.hlala_align_batch(self.ctx.h, h), "hlala_align_batch")
+        self._t("align_launch", t)
+        return h
+
+    def start(self, i):
+        return self.launch(self.upload(i))
 
     def finish(self, h, rec, gather):
         C = self.C
+        t = time.perf_counter()
         self.ctx._check(self.lib.hlala_batch_export_pair_records(self.ctx.h, h, C.c_void_p(rec.data_ptr())), "hlala_batch_export_pair_records")
         gather()
+        t = self._t("wait_and_export", t)
         self.ctx._check(self.lib.hlala_batch_get_pairs(self.ctx.h, h, C.byref(self.po)), "hlala_batch_get_pairs")
+        t = self._t("get_pairs", t)
         self.ctx._check(self.lib.hlala_batch_get_pairs_packed(self.ctx.h, h, C.byref(self.pk)), "hlala_batch_get_pairs_packed")
+        t = self._t("get_pairs_packed", t)
         self.lib.hlala_batch_destroy(h)
+        self._t("destroy", t)
         self.last_cols = int(self.pk.n_cols_total)
+
+    def host_ms(self):
+        """mean wall clock of the host thread per call (ms): where the one host thread of the boundary loop spends a step"""
+        return {k: 1e3 * self.host_s[k] / max(1, self.host_n[k]) for k in self.host_s}
 
     def pairs_ok(self):
         return int((self.scal["pair_status"] == 0).sum())
@@ -547,8 +589,8 @@ class Boundary:
 def end_to_end(args, P, synth, w, mk):
     """BAM bytes -> hla/*: `HLA-LA --action HLA` (hla-la_amd/host/HLA-LA.cpp) on a Graph M graph directory; bwa / samtools stand-ins hand over the BAM of a
     synthetic sample (their command lines run unchanged).  The figure is the program's own End-to-end line: units / (BAM decode + page-locking and insert size +
-    alignment and typing).  One sample, one run per --decodeThreads value of --e2e-threads (0 = all host threads; 32 = the share of a 256-thread host one of
-    eight samples gets in BASELINE config 4)."""
+    alignment and typing).  One sample, one run per --decodeThreads value of --e2e-threads (0 = the decoder's default, at most 32 threads: the share of a
+    256-thread host one of eight samples gets in BASELINE config 4 and, measured, its best count; 128 beside it)."""
     import re
     import shutil
     import stat
@@ -585,7 +627,7 @@ def end_to_end(args, P, synth, w, mk):
             with open(os.path.join(tmp, fq), "w") as f:
                 f.write("@r\nA\n+\nI\n")
 
-        def one(threads):
+        def one(threads, extra_env=None):
             outd = os.path.join(tmp, "out%d" % threads)
             cmd = [exe, "--action", "HLA", "--maxThreads", "2", "--sampleID", "S", "--outputDirectory", outd, "--PRG_graph_dir", gdir, "--FASTQU", os.path.join(tmp, "r1.fq"),
                    "--FASTQ1", os.path.join(tmp, "r1.fq"), "--FASTQ2", os.path.join(tmp, "r2.fq"), "--bwa_bin", os.path.join(tmp, "bwa"), "--samtools_bin", os.path.join(tmp, "samtools"),
@@ -593,24 +635,30 @@ def end_to_end(args, P, synth, w, mk):
             if threads > 0:
                 cmd += ["--decodeThreads", str(threads)]
             t0 = time.time()
-            r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp, timeout=1500)
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp, timeout=1500, env=dict(os.environ, **(extra_env or {})))
             t_run = time.time() - t0
             if r.returncode != 0:
                 return {"error": (r.stdout + r.stderr)[-1500:]}
-            m = re.search(r"End-to-end: ([0-9.e+]+) units per s \(BAM decode ([0-9.e+-]+) s on (\d+) threads \+ page-locking and insert size ([0-9.e+-]+) s \+ alignment and typing ([0-9.e+-]+) s", r.stdout)
+            m = re.search(r"End-to-end: ([0-9.e+]+) units per s \(BAM decode ([0-9.e+-]+) s on (\d+) threads \+ page-locking and insert size ([0-9.e+-]+) s \+ alignment and typing ([0-9.e+-]+) s, of which the host spent ([0-9.e+-]+) s filling", r.stdout)
             sp = re.search(r"Speed: ([0-9.e+]+) protoSeeds", r.stdout)
             ph = re.search(r"Typing phases: (.*)", r.stdout)
             files = sorted(os.listdir(os.path.join(outd, "hla")))
             calls = [ln for ln in r.stdout.splitlines() if ln.startswith("Locus ")]
             shutil.rmtree(outd, ignore_errors=True)
             return {"value": float(m.group(1)), "unit": "read pairs/s", "pairs": nch * ch, "bam_bytes": int(size), "decode_s": float(m.group(2)), "decode_threads": int(m.group(3)),
-                    "page_locking_and_insert_size_s": float(m.group(4)), "alignment_and_typing_s": float(m.group(5)), "speed_line_pairs_per_s": float(sp.group(1)) if sp else None,
+                    "page_locking_and_insert_size_s": float(m.group(4)), "alignment_and_typing_s": float(m.group(5)), "window_fill_beside_the_gpu_s": float(m.group(6)), "speed_line_pairs_per_s": float(sp.group(1)) if sp else None,
                     "process_wall_s": t_run, "whole_process_pairs_per_s": nch * ch / t_run, "typing_phases": ph.group(1) if ph else None,
                     "log": [ln[:700] for ln in r.stdout.splitlines() if ("Seed extraction:" in ln or ln.startswith("End-to-end:"))] + [ln[:300] for ln in r.stderr.splitlines() if ln.startswith("bam-debug:")][:40],
                     "loci": loci, "result_files": len(files), "calls": calls[:6]}
 
         runs = [one(int(t)) for t in str(args.e2e_threads).split(",") if t.strip() != ""]
         res = runs[0]
+        if args.e2e_variants:          # experiments: the same sample again under other environments ("label:ENV=1 ENV2=x;label2:...")
+            res["variants"] = {}
+            for v in args.e2e_variants.split(";"):
+                label, _, envs = v.partition(":")
+                rv = one(0, dict(kv.split("=", 1) for kv in envs.split()))
+                res["variants"][label] = {k: rv.get(k) for k in ("value", "decode_s", "page_locking_and_insert_size_s", "alignment_and_typing_s", "window_fill_beside_the_gpu_s", "typing_phases", "process_wall_s", "error") if k in rv}
         res.update({"gene_window_share_of_the_sample": args.e2e_frac_gene, "setup_s": {"graph_directory": t_dir, "sample_generation_and_bam": t_bam},
                     "what": "HLA-LA --action HLA: BAM bytes -> hla/* (decode on the stated host threads, batches of %d pairs two in flight on one GPU, typing of %d loci, result files); "
                             "value = pairs / (decode + page-locking and insert size + alignment and typing), the program's End-to-end line; graph loading and context creation are per process" % (ch, len(loci))})

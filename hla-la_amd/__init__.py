@@ -55,7 +55,7 @@ class BatchIn(C.Structure):
     _fields_ = [("n_pairs", C.c_int32), ("read_off", c_i64p), ("read_bases", c_u8p), ("read_quals", c_u8p),
                 ("chain_off", c_i64p), ("read_primary", c_i32p), ("n_chains", C.c_int32),
                 ("chain_contig", c_i32p), ("chain_pos", c_i32p), ("chain_offset", c_i32p), ("chain_as", c_i32p),
-                ("chain_reverse", c_u8p), ("cigar_off", c_i64p), ("cigar", c_u32p)]
+                ("chain_reverse", c_u8p), ("cigar_off", c_i64p), ("cigar", c_u32p), ("read_bases_packed", c_u8p), ("first_read", C.c_int64)]
 
 
 class SeedsIn(C.Structure):
@@ -254,9 +254,9 @@ class SeedBatch:
         lib.hlala_seed_batch_timing.argtypes = [C.c_void_p, c_f64p, c_i32p]
         lib.hlala_seed_batch_desc.argtypes = [C.c_void_p, C.POINTER(BatchIn), C.POINTER(C.c_int64)]
         self.n_units = int(lib.hlala_seed_batch_units(h))
-        cnt = (C.c_int64 * 3)(); d = BatchIn()
-        if self.n_units <= 0x7FFFFFFF:
-            lib.hlala_seed_batch_desc(h, C.byref(d), cnt)
+        cnt = (C.c_int64 * 3)()
+        lib.hlala_seed_batch_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        lib.hlala_seed_batch_counts(h, cnt)          # (hlala_seed_batch_desc would fill in the whole sample: the windows are filled as they are handed out)
         self.counts = dict(examined=int(cnt[0]), seeds=int(cnt[1]), incomplete=int(cnt[2]))
 
     def window(self, first_unit, n_units) -> "BatchIn":
@@ -279,7 +279,17 @@ class SeedBatch:
         ro = arr(d.read_off, 0, nr + 1, np.int64); co = arr(d.chain_off, 0, nr + 1, np.int64)
         r0, c0 = int(ro[0]), int(co[0])
         go = arr(d.cigar_off, c0, nc + 1, np.int64); g0 = int(go[0])
-        return dict(n_pairs=n, read_off=(ro - r0), read_bases=arr(d.read_bases, r0, int(ro[-1]) - r0, np.uint8), read_quals=arr(d.read_quals, r0, int(ro[-1]) - r0, np.uint8),
+        if d.read_bases_packed:        # a sample decoded with HLALA_SEEDS_PACKED: unpacked here for the tests (read R of the sample starts at byte (base offset + R + 1) >> 1)
+            R0 = int(d.first_read); p0 = (r0 + R0 + 1) >> 1; p1 = ((int(ro[-1]) + R0 + nr + 1) >> 1) + 1
+            pk = arr(d.read_bases_packed, p0, p1 - p0, np.uint8); lut = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
+            bases = np.zeros(int(ro[-1]) - r0, np.uint8)
+            for r in range(nr):
+                a, z = int(ro[r]) - r0, int(ro[r + 1]) - r0; at = ((int(ro[r]) + R0 + r + 1) >> 1) - p0
+                by = pk[at:at + (z - a + 1) // 2]; nib = np.empty(2 * len(by), np.uint8); nib[0::2] = by >> 4; nib[1::2] = by & 15
+                bases[a:z] = lut[nib[:z - a]]
+        else:
+            bases = arr(d.read_bases, r0, int(ro[-1]) - r0, np.uint8)
+        return dict(n_pairs=n, read_off=(ro - r0), read_bases=bases, read_quals=arr(d.read_quals, r0, int(ro[-1]) - r0, np.uint8),
                     chain_off=(co - c0), read_primary=arr(d.read_primary, 0, nr, np.int32) - c0, n_chains=nc,
                     chain_contig=arr(d.chain_contig, c0, nc, np.int32), chain_pos=arr(d.chain_pos, c0, nc, np.int32), chain_offset=arr(d.chain_offset, c0, nc, np.int32),
                     chain_as=arr(d.chain_as, c0, nc, np.int32), chain_reverse=arr(d.chain_reverse, c0, nc, np.uint8), cigar_off=(go - g0),
@@ -309,15 +319,18 @@ class SeedBatch:
             pass
 
 
-def bam_open_seeds(lib, path, intervals, long_read_mode=False, threads=0) -> SeedBatch:
-    """hlala_bam_extract_seeds_mt: intervals = [(ref name, start_0based, stop_0based, contig index)]; returns the handle of the whole sample."""
+SEEDS_PACKED = 1          # HLALA_SEEDS_PACKED
+
+
+def bam_open_seeds(lib, path, intervals, long_read_mode=False, threads=0, flags=0) -> SeedBatch:
+    """hlala_bam_extract_seeds_opt: intervals = [(ref name, start_0based, stop_0based, contig index)]; returns the handle of the whole sample."""
     arr = (BamInterval * max(1, len(intervals)))()
     for i, (nm, a, b, c) in enumerate(intervals):
         arr[i] = BamInterval(nm.encode(), int(a), int(b), int(c))
     h = C.c_void_p()
-    lib.hlala_bam_extract_seeds_mt.argtypes = [C.c_char_p, C.c_int32, C.POINTER(BamInterval), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.hlala_bam_extract_seeds_opt.argtypes = [C.c_char_p, C.c_int32, C.POINTER(BamInterval), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     lib.hlala_bam_last_error.restype = C.c_char_p
-    if lib.hlala_bam_extract_seeds_mt(str(path).encode(), len(intervals), arr, int(bool(long_read_mode)), int(threads), C.byref(h)) != 0:
+    if lib.hlala_bam_extract_seeds_opt(str(path).encode(), len(intervals), arr, int(bool(long_read_mode)), int(threads), int(flags), C.byref(h)) != 0:
         raise HlalaError(lib.hlala_bam_last_error().decode(errors="replace"))
     return SeedBatch(lib, h, long_read_mode)
 
@@ -547,7 +560,7 @@ class BatchStats(C.Structure):
                 ("n_edges_touched", C.c_int64), ("n_errors", C.c_int64), ("ms_extend_retry", C.c_float),
                 ("n_chains_retried", C.c_int32), ("ms_dp_main", C.c_float), ("n_dp_retried_large", C.c_int32), ("n_dp_shared", C.c_int64),
                 ("n_dp_class", C.c_int32 * 7), ("ms_dp_class", C.c_float * 7), ("ms_side", C.c_float),
-                ("n_dp_lane", C.c_int32), ("ms_dp_lane", C.c_float), ("n_dp_jump_free", C.c_int32), ("ms_dp_jump_free", C.c_float)]
+                ("n_dp_lane", C.c_int32), ("ms_dp_lane", C.c_float), ("n_dp_jump_free", C.c_int32), ("ms_dp_jump_free", C.c_float), ("n_dp_jump_free_16", C.c_int32)]
 
 
 _DT = {c_i32p: np.int32, c_i64p: np.int64, c_u8p: np.uint8, c_u32p: np.uint32, c_f64p: np.float64}
@@ -668,9 +681,9 @@ EXPORTED_SYMBOLS = [
     "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_set_first_chain", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
     "hlala_batch_get_stats", "hlala_batch_get_pairs_packed", "hlala_batch_export_pair_records", "hlala_set_gene_intervals", "hlala_postprocess_pairs", "hlala_get_coverage", "hlala_exon_loglik", "hlala_pair_loglik", "hlala_kat_phred",
-    "hlala_kat_rand_r", "hlala_kat_exp", "hlala_abi_sizeof", "hlala_abi_version", "hlala_build_flags", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
+    "hlala_kat_rand_r", "hlala_kat_exp", "hlala_abi_sizeof", "hlala_abi_version", "hlala_build_flags", "hlala_pack_bases", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
     "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
-    "hlala_bam_extract_seeds", "hlala_bam_extract_seeds_mt", "hlala_seed_batch_desc", "hlala_seed_batch_window", "hlala_seed_batch_units", "hlala_seed_batch_name", "hlala_seed_batch_timing",
+    "hlala_bam_extract_seeds", "hlala_bam_extract_seeds_mt", "hlala_bam_extract_seeds_opt", "hlala_seed_batch_counts", "hlala_seed_batch_desc", "hlala_seed_batch_window", "hlala_seed_batch_units", "hlala_seed_batch_name", "hlala_seed_batch_timing",
     "hlala_seed_batch_free", "hlala_seed_batch_pin", "hlala_bam_last_error", "hlala_pinned_alloc", "hlala_pinned_free", "hlala_host_register", "hlala_host_unregister", "hlala_set_insert_size",
     "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",

@@ -67,6 +67,7 @@ struct hlala_ctx {
     size_t pool_bytes = 0;
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
+    char* jf8_slabs = nullptr; size_t jf8_slab_bytes = 0; int jf8_grid = 0;      // the 8-lane jump-free instantiation in front of the 16-lane one (0: not used)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
     char* lane_slabs = nullptr; int lane_grid = 0;      // the lane-per-DP class in front of the 16-lane class (kernel_dp_lane.hip); lane_grid 0: not used (HLALA_DP_LANE=0)
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
@@ -87,6 +88,7 @@ struct hlala_batch {
     DevBatch* dB = nullptr;       // device copy of B
     std::vector<void*> allocs;
     int staged = 0;   // bit0 seeds available, bit1 extended, bit2 paired
+    bool outputs_ready = false;      // the output arrays (50 GB for a 1 M-pair batch) exist: allocated by the first stage call, not by hlala_batch_create (ensure_outputs)
     bool side_used = false;      // the last extend of this batch ran its wide classes on the side stream (their times are between the evSide events)
     bool side_pending = false;   // ... and hlala_pair_chains has yet to enqueue the second pairing pass behind them
     bool side_inflight = false;  // work of this batch may still be running on the side stream: evDone orders everything that touches the batch after it
@@ -400,10 +402,13 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_DP_LANE")) { if(atoi(e) != 0) c->jf_grid = 0; }      // (the lane-per-DP class takes every item itself)
 #endif
     if(const char* e = getenv("HLALA_DP_JF")) { if(atoi(e) == 0) c->jf_grid = 0; }      // (A/B: every call in the general instantiation -- the kernels' lists are built either way)
+    c->jf8_grid = c->jf_grid > 0 ? cus * 4 * DpTinyJF8::WAVES : 0; c->jf8_slab_bytes = dp_slab_bytes<DpTinyJF8>();
+    if(const char* e = getenv("HLALA_DP_JF8")) { if(atoi(e) == 0) c->jf8_grid = 0; }     // (A/B: the jump-free calls start in the 16-lane instantiation)
     c->ext_grid = cus * 20;
     c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();
     c->retry_grid = cus;
     c->broad_grid = cus * 3;         // three DpBroad blocks per CU (48 KB of LDS each), slabs of the large layout
+
     c->wide_grid = cus * 7;          // LDS: seven DpWide blocks per CU (22 KB each); slabs of the 64-lane layout
     c->stitch_grid = cus * 20;        // k_stitch_chains: five waves per SIMD (92 VGPRs, nothing spilled)
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpWide>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpWide>();
@@ -416,6 +421,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     { const char* e = getenv("HLALA_DP_LANE"); c->lane_grid = (e && atoi(e) != 0) ? cus * 4 : 0; }          // 36 KB of LDS per wave: four per CU
     if(c->lane_grid && (rc = slab_pool(&c->lane_slabs, dp_lane_slab_bytes() * (size_t)64 * (size_t)c->lane_grid, "lane-per-DP slabs"))) return fail(rc);
 #endif
+    if(c->jf8_grid > 0 && (rc = slab_pool(&c->jf8_slabs, c->jf8_slab_bytes * (size_t)(64 / DpTinyJF8::GW) * (size_t)c->jf8_grid, "8-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->mid_slabs, c->mid_slab_bytes * (size_t)(64 / DpMid::GW) * (size_t)c->mid_grid, "32-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid, "64-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid, "wide-class DP slabs"))) return fail(rc);
@@ -595,17 +601,45 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
     size_t nbases = nr ? (size_t)read_off32[nr] : 0, ncig = nc ? (size_t)cigar_off32[nc] : 0;
     int rc = 0;
 #define UPB(field, ptr, n) do { rc = dev_upload(c, b->allocs, (ptr), (n), (std::remove_const<std::remove_pointer<decltype(B.field)>::type>::type**)&B.field); if(rc) return fail(rc); } while(0)
-    UPB(read_off, read_off32.data(), (size_t)nr + 1); UPB(read_bases, in->read_bases + rb0, nbases); UPB(read_quals, in->read_quals + rb0, nbases);
+    UPB(read_off, read_off32.data(), (size_t)nr + 1); UPB(read_quals, in->read_quals + rb0, nbases);
+    if(in->read_bases_packed && nr > 0) {
+        // 4-bit packed bases (half the upload): read R of the sample starts at byte (base offset + R + 1) >> 1; unpacked on the device into the array the kernels read
+        const int64_t R0 = in->first_read;
+        if(R0 < 0) { c->err = "first_read is negative"; return fail(HLALA_E_ARG); }
+        const int64_t p0 = (rb0 + R0 + 1) >> 1, p1 = ((in->read_off[nr] + R0 + (int64_t)nr + 1) >> 1) + 1;
+        uint8_t* dPacked = nullptr; uint8_t* dBases = nullptr;
+        rc = dev_upload(c, b->allocs, in->read_bases_packed + p0, (size_t)(p1 - p0), &dPacked); if(rc) return fail(rc);
+        rc = dev_alloc(c, b->allocs, nbases, &dBases, false); if(rc) return fail(rc);
+        hipLaunchKernelGGL(k_unpack_bases, dim3((unsigned)nr), dim3(64), 0, c->active, (const uint8_t*)dPacked, B.read_off, nr, (long long)rb0, (long long)R0, (long long)p0, dBases);
+        { hipError_t el = hipGetLastError(); if(el != hipSuccess) { c->err = std::string("k_unpack_bases: ") + hipGetErrorString(el); return fail(HLALA_E_DEVICE); } }
+        B.read_bases = dBases;
+    } else {
+        if(!in->read_bases && nbases > 0) { c->err = "neither read_bases nor read_bases_packed"; return fail(HLALA_E_ARG); }
+        UPB(read_bases, in->read_bases + rb0, nbases);
+    }
     UPB(chain_off, chain_off32.data(), (size_t)nr + 1); UPB(read_primary, primary32.data(), (size_t)nr);
     UPB(chain_read, chain_read.data(), (size_t)nc);
     UPB(chain_contig, w_contig, (size_t)nc); UPB(chain_pos, w_pos, (size_t)nc); UPB(chain_offset, w_offset, (size_t)nc);
     UPB(chain_as, w_as, (size_t)nc); UPB(chain_reverse, w_rev, (size_t)nc);
     UPB(cigar_off, cigar_off32.data(), (size_t)nc + 1); UPB(cigar, in->cigar + gb0, ncig);
 #undef UPB
-    rc = batch_alloc_outputs(c, b); if(rc) return fail(rc);
+    // The OUTPUT arrays are allocated by the first stage call (ensure_outputs): a caller that uploads batch i+2 while batches i and i+1 are aligned and read back
+    // (two alignments in flight, one upload ahead) then holds the inputs of three batches -- 0.9 GB each -- but the outputs of two, and the outputs of the batch it
+    // destroys are the pool blocks the next alignment takes.  Until then the device descriptor holds the inputs only (what hlala_kmer_presence reads).
     rc = dev_upload(c, b->allocs, &b->B, 1, &b->dB); if(rc) return fail(rc);
     HIP_TRY_F(c, hipStreamSynchronize(c->active), fail);
     *out = b;
+    return HLALA_OK;
+}
+
+// output arrays of a batch that came through hlala_batch_create / _unpaired: allocated (pool) and zeroed on the stream of the stage call that needs them first, then the
+// device descriptor is written again with their addresses
+static int ensure_outputs(hlala_ctx* c, hlala_batch* b)
+{
+    if(b->outputs_ready) return HLALA_OK;
+    int rc = batch_alloc_outputs(c, b); if(rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(b->dB, &b->B, sizeof(DevBatch), hipMemcpyHostToDevice, c->active));
+    b->outputs_ready = true;
     return HLALA_OK;
 }
 
@@ -651,7 +685,7 @@ int hlala_batch_create_from_seeds(hlala_ctx* c, const hlala_seeds_in* in, hlala_
     HIP_TRY_F(c, hipMemcpyAsync(B.seed_g, g.data(), g.size(), hipMemcpyHostToDevice, c->active), fail);
     HIP_TRY_F(c, hipMemcpyAsync(B.seed_s, s.data(), s.size(), hipMemcpyHostToDevice, c->active), fail);
     HIP_TRY_F(c, hipStreamSynchronize(c->active), fail);
-    b->staged = 1;
+    b->staged = 1; b->outputs_ready = true;
     *out = b;
     return HLALA_OK;
 }
@@ -697,6 +731,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     { int rj = join_side(c, b); if(rj) return rj; }
     if(b->B.from_seeds) { c->err = "batch was created from seeds: stage A not available"; return HLALA_E_STATE; }
     { int re = batch_events(c, b); if(re) return re; }
+    { int ro = ensure_outputs(c, b); if(ro) return ro; }
     DevBatch& B = b->B;
     HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 48 * sizeof(int), c->active));
     HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->active));
@@ -788,7 +823,14 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
             case 0:
                 // the calls that meet no gap-path jump in the instantiation without the early-cell machinery, then the others (same slabs: one after the other)
                 if(!tinyList && c->jf_grid > 0) {
-                    hipLaunchKernelGGL((k_dp<DpTinyJF, 0>), dim3(c->jf_grid), dim3(DpTinyJF::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr);
+                    const int* jfList = nullptr;
+                    if(c->jf8_grid > 0) {
+                        // eight lanes per call first; what outgrows that goes on to the 16-lane jump-free instantiation through jfList
+                        jfList = B.retry_list + (size_t)12 * (size_t)B.n_chains;
+                        hipLaunchKernelGGL((k_dp<DpTinyJF8, 0>), dim3(c->jf8_grid), dim3(DpTinyJF8::THREADS), 0, ws, c->dG, b->dB, items, c->jf8_slabs, c->jf8_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, jfList);
+                        int rc8 = check_launch(c, "k_dp<DpTinyJF8>"); if(rc8) return rc8;
+                    }
+                    hipLaunchKernelGGL((k_dp<DpTinyJF, 0>), dim3(c->jf_grid), dim3(DpTinyJF::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, jfList);
                     int rcj = check_launch(c, "k_dp<DpTinyJF>"); if(rcj) return rcj;
                     HIP_TRY(c, hipEventRecord(b->evJF, ws));
                 }
@@ -1166,7 +1208,7 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
           if(c->jf_grid > 0 && !b->lane_used) (void)hipEventElapsedTime(&out->ms_dp_jump_free, b->evC[0][0], b->evJF);
           if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, b->evSide[1], b->evSide[6]); } }
     { int wc[48]; HIP_TRY(c, hipMemcpyAsync(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
-      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9]; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; out->n_dp_jump_free = (c->jf_grid > 0 && !b->lane_used) ? wc[6] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
+      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9]; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; out->n_dp_jump_free = (c->jf_grid > 0 && !b->lane_used) ? wc[6] : 0; out->n_dp_jump_free_16 = (c->jf8_grid > 0 && c->jf_grid > 0 && !b->lane_used) ? wc[40] + wc[42] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, b->ev[4], b->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];
@@ -1545,6 +1587,18 @@ extern "C" int hlala_abi_sizeof(const char* name)
     return -1;
 }
 
+extern "C" int hlala_pack_bases(const uint8_t* read_bases, const int64_t* read_off, int64_t n_reads, uint8_t* packed)
+{
+    if(!read_bases || !read_off || !packed || n_reads < 0) return HLALA_E_ARG;
+    static uint8_t code[256]; static bool init = false;
+    if(!init) { memset(code, 15, sizeof(code)); const char* s16 = "=ACMGRSVTWYHKDBN"; for(int i = 0; i < 16; i++) code[(unsigned char)s16[i]] = (uint8_t)i; init = true; }
+    for(int64_t r = 0; r < n_reads; r++) {
+        const int64_t o = read_off[r], len = read_off[r + 1] - o; uint8_t* dst = packed + ((o + r + 1) >> 1);
+        for(int64_t j = 0; j + 1 < len; j += 2) dst[j >> 1] = (uint8_t)((code[read_bases[o + j]] << 4) | code[read_bases[o + j + 1]]);
+        if(len & 1) dst[len >> 1] = (uint8_t)(code[read_bases[o + len - 1]] << 4);
+    }
+    return HLALA_OK;
+}
 extern "C" int hlala_abi_version(void) { return HLALA_ABI_VERSION; }
 extern "C" int hlala_build_flags(void)
 {

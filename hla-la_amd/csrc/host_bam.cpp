@@ -136,6 +136,14 @@ uint64_t hash_name(const uint8_t* s, size_t n)
 
 struct Unit { const char* name; uint32_t nameLen; uint32_t part; uint32_t first, count; };      // recs [first, first + count) of the partition's sorted record list
 
+// The decoder's working memory: the inflated rounds (the records the Recs point into), the kept records by name partition, the units in name order.  It outlives
+// hlala_bam_extract_seeds_mt: the arrays of the result are FILLED per window, when a window is first asked for (fill state below), and released when the last
+// unit has been filled (or with the seed batch).
+struct Work { std::vector<Arena> arenas; std::vector<std::vector<Rec>> precs; std::vector<Unit> units; std::vector<int64_t> cigCount;
+              std::vector<std::unique_ptr<uint8_t, BigFree>> inflated;
+              // ---- fill state: the units are filled in chunks of UCH (chunk c = units [c * UCH, (c + 1) * UCH)), `done` per chunk, under the seed batch's fill_mu
+              int nm = 2, T = 1; int64_t UCH = 1, nUChunks = 0, remaining = 0; std::vector<uint8_t> done; };
+
 bool name_less(const Unit& a, const Unit& b)
 {
     const size_t n = a.nameLen < b.nameLen ? a.nameLen : b.nameLen;
@@ -151,18 +159,114 @@ struct hlala_seed_batch {
     std::vector<int32_t> read_primary;
     Buf<int32_t> chain_contig, chain_pos, chain_offset, chain_as;
     Buf<uint8_t> read_bases, read_quals, chain_reverse; Buf<uint32_t> cigar;
+    Buf<uint8_t> read_bases_packed; bool packed = false;      // HLALA_SEEDS_PACKED: the bases stay 4-bit packed as the BAM records hold them (hlala_batch_in::read_bases_packed), read_bases is empty
     Buf<char> name_chars; std::vector<int64_t> name_off;          // names of the units, NUL-terminated
     int64_t n_units = 0; int32_t unpaired = 0; int64_t examined = 0, n_seeds = 0, n_incomplete = 0;
     double seconds[6] = {0, 0, 0, 0, 0, 0}; int32_t threads = 1;
     bool pinned = false;
+    // the decoder's working memory while units remain to be filled (hlala_seed_batch_window fills what it hands out); null once every unit is filled
+    Work* work = nullptr; double fill_seconds = 0; std::mutex fill_mu;       // (the mutex lives here, not in the working memory it outlives)
+    ~hlala_seed_batch() { if(work) { Work* w = work; work = nullptr; try { std::thread([w]() { delete w; }).detach(); } catch(...) { delete w; } } }
 };
+
+namespace {
+// sortChainsInSeeds (:1952-1961) on the mate's alignments in file order; returns the position of the first primary (read*_getPrimaryAlignmentI)
+size_t sorted_mate(const std::vector<std::vector<Rec>>& precs, const Unit& u, int m, std::vector<uint32_t>& idx)
+{
+    const std::vector<Rec>& R = precs[u.part];
+    idx.clear();
+    for(uint32_t k = u.first; k < u.first + u.count; k++) if(R[k].which == m) idx.push_back(k);
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return R[a].as < R[b].as; });
+    std::reverse(idx.begin(), idx.end());
+    for(size_t i = 0; i < idx.size(); i++) if(R[idx[i]].flags & 2) return i;
+    return idx.size();
+}
+
+// names, bases, qualities, alignments and CIGARs of the units [a, z) into the arrays of the result (offsets and sizes are in place since the decode)
+void fill_units(hlala_seed_batch* S, const Work& W, const size_t a, const size_t z, std::vector<uint32_t>& idx)
+{
+    static const char SEQ16[] = "=ACMGRSVTWYHKDBN";
+    const std::vector<Unit>& units = W.units; const std::vector<std::vector<Rec>>& precs = W.precs; const std::vector<int64_t>& cigCount = W.cigCount; const int nm = W.nm;
+    for(size_t ui = a; ui < z; ui++) {
+        // The fill gathers names, CIGARs and packed bases from records scattered over the whole inflated file (name order against coordinate order: a cache
+        // and TLB miss per record, 6.8 us per read and thread on a 128-thread host).  Two steps ahead of the work: the descriptors of the unit sixteen
+        // ahead, and -- through the descriptors requested eight units ago -- the record bytes of the unit eight ahead (CIGAR; bases and qualities of a primary).
+        if(ui + 16 < z) { const Unit& uf = units[ui + 16]; const Rec* rf = precs[uf.part].data() + uf.first; for(uint32_t k = 0; k < uf.count; k++) __builtin_prefetch(rf + k); }
+        if(ui + 8 < z) {
+            const Unit& un = units[ui + 8]; const Rec* rn = precs[un.part].data() + un.first;
+            __builtin_prefetch(un.name);
+            for(uint32_t k = 0; k < un.count; k++) {
+                const uint8_t* cg = rn[k].cigar(); __builtin_prefetch(cg);
+                if(rn[k].l_seq > 0) { const uint8_t* sq = rn[k].seq4(); const size_t nb = ((size_t)rn[k].l_seq + 1) / 2 + (size_t)rn[k].l_seq; for(size_t o = 0; o < nb + 63; o += 64) __builtin_prefetch(sq + o); }
+            }
+        }
+        const Unit& u = units[ui]; const std::vector<Rec>& R = precs[u.part];
+        memcpy(S->name_chars.data() + S->name_off[ui], u.name, (size_t)u.nameLen); S->name_chars[(size_t)S->name_off[ui] + u.nameLen] = 0;
+        for(int m = 0; m < nm; m++) {
+            const size_t prim = sorted_mate(precs, u, m, idx);
+            const size_t r = ui * (size_t)nm + (size_t)m;
+            const Rec& pa = R[idx[prim]];
+            {   // QueryBases / Qualities of the primary (BuildCharData: 4-bit codes -> characters, Phred + 33), alignment orientation (:3142-3145)
+                const int32_t ls = pa.l_seq; const uint8_t* s4 = pa.seq4(); const uint8_t* ql = pa.qual(ls);
+                uint8_t* qs = S->read_quals.data() + S->read_off[r];
+                if(S->packed) memcpy(S->read_bases_packed.data() + ((S->read_off[r] + (int64_t)r + 1) >> 1), s4, ((size_t)ls + 1) / 2);       // every read on a byte of its own: include/hlala_gpu.h
+                else {
+                    uint8_t* bs = S->read_bases.data() + S->read_off[r];
+                    for(int32_t i = 0; i + 1 < ls; i += 2) { const unsigned b = s4[(size_t)i / 2]; bs[i] = (uint8_t)SEQ16[b >> 4]; bs[i + 1] = (uint8_t)SEQ16[b & 15]; }
+                    if(ls & 1) bs[ls - 1] = (uint8_t)SEQ16[s4[(size_t)(ls - 1) / 2] >> 4];
+                }
+                for(int32_t i = 0; i < ls; i++) qs[i] = (uint8_t)(ql[i] + 33);
+            }
+            size_t ch = (size_t)S->chain_off[r]; int64_t cg = cigCount[r];
+            S->read_primary[r] = (int32_t)(ch + prim);
+            for(uint32_t k : idx) {
+                const Rec& x = R[k];
+                S->chain_contig[ch] = x.contig; S->chain_pos[ch] = x.pos; S->chain_offset[ch] = 0; S->chain_as[ch] = x.as; S->chain_reverse[ch] = (uint8_t)(x.flags & 1);
+                memcpy(S->cigar.data() + cg, x.cigar(), 4 * (size_t)x.n_cigar);               // (BAM is little-endian like every host this library runs on)
+                cg += x.n_cigar; S->cigar_off[ch + 1] = cg; ch++;
+            }
+        }
+    }
+}
+
+// The units [u0, u1) are filled before this returns (whichever thread asks first fills them, on the decoder's thread count; the others wait).  Once no unit is left
+// the working memory is released on a thread of its own (unmapping a dozen GB takes about a second that the caller need not wait for).
+void ensure_filled(const hlala_seed_batch* Sc, int64_t u0, int64_t u1)
+{
+    hlala_seed_batch* S = const_cast<hlala_seed_batch*>(Sc);
+    if(u1 <= u0) return;
+    std::unique_lock<std::mutex> g(S->fill_mu);
+    Work* W = S->work;
+    if(!W) return;
+    const Clock::time_point t0 = Clock::now();
+    std::vector<int64_t> todo;
+    for(int64_t c = u0 / W->UCH; c <= (u1 - 1) / W->UCH && c < W->nUChunks; c++) if(!W->done[(size_t)c]) todo.push_back(c);
+    if(!todo.empty()) {
+        std::vector<std::vector<uint32_t>> order((size_t)W->T);
+        const size_t nU = W->units.size();
+        parallel_for((int64_t)todo.size(), W->T, [&](int64_t i, int t) {
+            const int64_t c = todo[(size_t)i];
+            fill_units(S, *W, (size_t)(c * W->UCH), std::min(nU, (size_t)((c + 1) * W->UCH)), order[(size_t)t]);
+        });
+        for(int64_t c : todo) W->done[(size_t)c] = 1;
+        W->remaining -= (int64_t)todo.size();
+    }
+    const double dt = since(t0);
+    S->fill_seconds += dt; S->seconds[5] += dt;
+    if(W->remaining <= 0) {
+        S->work = nullptr;
+        g.unlock();
+        try { std::thread([W]() { delete W; }).detach(); } catch(...) { delete W; }
+    }
+}
+}  // namespace
 
 namespace hlala_host {
 void seed_batch_bulk_arrays(hlala_seed_batch* S, std::vector<std::pair<void*, size_t>>& out)
 {
     out.clear();
     auto add = [&](void* p, size_t b) { if(p && b) out.emplace_back(p, b); };
-    add(S->read_bases.data(), S->read_bases.size()); add(S->read_quals.data(), S->read_quals.size());
+    add(S->read_bases.data(), S->read_bases.size()); add(S->read_bases_packed.data(), S->read_bases_packed.size()); add(S->read_quals.data(), S->read_quals.size());
     add(S->chain_contig.data(), S->chain_contig.size() * 4); add(S->chain_pos.data(), S->chain_pos.size() * 4); add(S->chain_offset.data(), S->chain_offset.size() * 4);
     add(S->chain_as.data(), S->chain_as.size() * 4); add(S->chain_reverse.data(), S->chain_reverse.size()); add(S->cigar.data(), S->cigar.size() * 4);
 }
@@ -178,14 +282,23 @@ extern "C" int hlala_bam_extract_seeds(const char* path, int32_t n_intervals, co
 }
 
 extern "C" int hlala_bam_extract_seeds_mt(const char* path, int32_t n_intervals, const hlala_bam_interval* iv, int32_t long_read_mode, int32_t n_threads, hlala_seed_batch** out)
+{
+    return hlala_bam_extract_seeds_opt(path, n_intervals, iv, long_read_mode, n_threads, 0, out);
+}
+
+extern "C" int hlala_bam_extract_seeds_opt(const char* path, int32_t n_intervals, const hlala_bam_interval* iv, int32_t long_read_mode, int32_t n_threads, int32_t flags, hlala_seed_batch** out)
 try {
     if(!path || !out || n_intervals < 0 || (n_intervals > 0 && !iv) || n_threads < 0) return HLALA_E_ARG;
     *out = nullptr; g_bam_error.clear();
     int T = n_threads;
-    if(T == 0) { T = (int)std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 128) T = 128; }
+    // Default: at most 32 threads.  Measured on a 256-thread host (tools/gpu_decode_threads.sh, 8.4 M pairs, 2.6 GB of BAM): 5.2 s on 8 threads, 3.5 on 16, 2.85 on 32,
+    // 3.0 on 64, 3.3-3.7 on 128 -- the phases are passes over ~12 GB of inflated records bound by memory latency and by the first touch of their
+    // working memory (4 KB pages fault in at 10 GB/s on that host whatever the number of threads); beyond 32 threads they only get in each other's way.
+    // It is also the share of such a host that one of eight samples gets (BASELINE config 4).
+    if(T == 0) { T = (int)std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 32) T = 32; }
     if(T > 1024) T = 1024;
     std::unique_ptr<hlala_seed_batch> S(new hlala_seed_batch());
-    S->threads = T; S->unpaired = long_read_mode ? 1 : 0;
+    S->threads = T; S->unpaired = long_read_mode ? 1 : 0; S->packed = (flags & HLALA_SEEDS_PACKED) != 0;
     auto tPhase = Clock::now();
 
     // ---------------------------------------------------------------- index: map the file, walk the block headers
@@ -225,8 +338,6 @@ try {
     for(int i = 0; i < n_intervals; i++) { if(!iv[i].ref_name || iv[i].stop_0based < iv[i].start_0based) throw Fail("bad interval"); intervalsOfRef[iv[i].ref_name].push_back(i); }
     // the decoder's working memory (a dozen GB for a 10 M-pair sample) is released on a thread of its own after the result is handed over: unmapping it
     // costs about a second that the caller need not wait for
-    struct Work { std::vector<Arena> arenas; std::vector<std::vector<Rec>> precs; std::vector<Unit> units; std::vector<int64_t> cigCount;
-                  std::vector<std::unique_ptr<uint8_t, BigFree>> inflated; };       // the inflated rounds: the records the Recs point into
     std::unique_ptr<Work> W(new Work());
     std::vector<Arena>& arenas = W->arenas; arenas.resize((size_t)T);
     for(Arena& a : arenas) a.part.resize(NPART);
@@ -456,16 +567,6 @@ try {
     std::vector<int64_t>& cigCount = W->cigCount; cigCount.assign(nR + 1, 0);
     std::vector<std::vector<uint32_t>> order((size_t)T);
     const int64_t UCH = std::max<int64_t>(16, std::min<int64_t>(8192, (int64_t)nU / ((int64_t)T * 8) + 1)); const int64_t nUChunks = ((int64_t)nU + UCH - 1) / UCH;
-    // sortChainsInSeeds (:1952-1961) on the mate's alignments in file order; returns the position of the first primary (read*_getPrimaryAlignmentI)
-    auto sorted_mate = [&](const Unit& u, int m, std::vector<uint32_t>& idx) -> size_t {
-        const std::vector<Rec>& R = precs[u.part];
-        idx.clear();
-        for(uint32_t k = u.first; k < u.first + u.count; k++) if(R[k].which == m) idx.push_back(k);
-        std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return R[a].as < R[b].as; });
-        std::reverse(idx.begin(), idx.end());
-        for(size_t i = 0; i < idx.size(); i++) if(R[idx[i]].flags & 2) return i;
-        return idx.size();
-    };
     parallel_for(nUChunks, T, [&](int64_t c, int t) {
         std::vector<uint32_t>& idx = order[(size_t)t];
         const size_t a = (size_t)(c * UCH), z = std::min(nU, a + (size_t)UCH);
@@ -475,7 +576,7 @@ try {
             const Unit& u = units[ui]; const std::vector<Rec>& R = precs[u.part];
             S->name_off[ui + 1] = (int64_t)u.nameLen + 1;
             for(int m = 0; m < nm; m++) {
-                const size_t prim = sorted_mate(u, m, idx);
+                const size_t prim = sorted_mate(precs, u, m, idx);
                 const size_t r = ui * (size_t)nm + (size_t)m;
                 S->read_off[r + 1] = R[idx[prim]].l_seq; S->chain_off[r + 1] = (int64_t)idx.size();
                 int64_t cg = 0; for(uint32_t k : idx) cg += R[k].n_cigar;
@@ -488,53 +589,20 @@ try {
     for(size_t ui = 0; ui < nU; ui++) S->name_off[ui + 1] += S->name_off[ui];
     const size_t nBases = (size_t)S->read_off[nR], nChains = (size_t)S->chain_off[nR], nCig = (size_t)cigCount[nR];
     if(nChains > 0x7FFFFFFFull) throw Fail("more than 2^31 - 1 alignments in one sample: chain numbers are 32-bit");
-    S->read_bases.alloc(nBases); S->read_quals.alloc(nBases);
+    if(S->packed) S->read_bases_packed.alloc((nBases + nR + 1) / 2 + 2); else S->read_bases.alloc(nBases);
+    S->read_quals.alloc(nBases);
     S->chain_contig.alloc(nChains); S->chain_pos.alloc(nChains); S->chain_offset.alloc(nChains); S->chain_as.alloc(nChains); S->chain_reverse.alloc(nChains);
     S->cigar_off.alloc(nChains + 1); S->cigar_off[0] = 0; S->cigar.alloc(nCig); S->name_chars.alloc((size_t)S->name_off[nU]);
     const double tL2 = since(tPhase);
-    parallel_for(nUChunks, T, [&](int64_t c, int t) {
-        std::vector<uint32_t>& idx = order[(size_t)t];
-        const size_t a = (size_t)(c * UCH), z = std::min(nU, a + (size_t)UCH);
-        for(size_t ui = a; ui < z; ui++) {
-            // The fill gathers names, CIGARs and packed bases from records scattered over the whole inflated file (name order against coordinate order: a cache
-            // and TLB miss per record, 6.8 us per read and thread on a 128-thread host).  Two steps ahead of the work: the descriptors of the unit sixteen
-            // ahead, and -- through the descriptors requested eight units ago -- the record bytes of the unit eight ahead (CIGAR; bases and qualities of a primary).
-            if(ui + 16 < z) { const Unit& uf = units[ui + 16]; const Rec* rf = precs[uf.part].data() + uf.first; for(uint32_t k = 0; k < uf.count; k++) __builtin_prefetch(rf + k); }
-            if(ui + 8 < z) {
-                const Unit& un = units[ui + 8]; const Rec* rn = precs[un.part].data() + un.first;
-                __builtin_prefetch(un.name);
-                for(uint32_t k = 0; k < un.count; k++) {
-                    const uint8_t* cg = rn[k].cigar(); __builtin_prefetch(cg);
-                    if(rn[k].l_seq > 0) { const uint8_t* sq = rn[k].seq4(); const size_t nb = ((size_t)rn[k].l_seq + 1) / 2 + (size_t)rn[k].l_seq; for(size_t o = 0; o < nb + 63; o += 64) __builtin_prefetch(sq + o); }
-                }
-            }
-            const Unit& u = units[ui]; const std::vector<Rec>& R = precs[u.part];
-            memcpy(S->name_chars.data() + S->name_off[ui], u.name, (size_t)u.nameLen); S->name_chars[(size_t)S->name_off[ui] + u.nameLen] = 0;
-            for(int m = 0; m < nm; m++) {
-                const size_t prim = sorted_mate(u, m, idx);
-                const size_t r = ui * (size_t)nm + (size_t)m;
-                const Rec& pa = R[idx[prim]];
-                {   // QueryBases / Qualities of the primary (BuildCharData: 4-bit codes -> characters, Phred + 33), alignment orientation (:3142-3145)
-                    const int32_t ls = pa.l_seq; const uint8_t* s4 = pa.seq4(); const uint8_t* ql = pa.qual(ls);
-                    uint8_t* bs = S->read_bases.data() + S->read_off[r]; uint8_t* qs = S->read_quals.data() + S->read_off[r];
-                    for(int32_t i = 0; i + 1 < ls; i += 2) { const unsigned b = s4[(size_t)i / 2]; bs[i] = (uint8_t)SEQ16[b >> 4]; bs[i + 1] = (uint8_t)SEQ16[b & 15]; }
-                    if(ls & 1) bs[ls - 1] = (uint8_t)SEQ16[s4[(size_t)(ls - 1) / 2] >> 4];
-                    for(int32_t i = 0; i < ls; i++) qs[i] = (uint8_t)(ql[i] + 33);
-                }
-                size_t ch = (size_t)S->chain_off[r]; int64_t cg = cigCount[r];
-                S->read_primary[r] = (int32_t)(ch + prim);
-                for(uint32_t k : idx) {
-                    const Rec& x = R[k];
-                    S->chain_contig[ch] = x.contig; S->chain_pos[ch] = x.pos; S->chain_offset[ch] = 0; S->chain_as[ch] = x.as; S->chain_reverse[ch] = (uint8_t)(x.flags & 1);
-                    memcpy(S->cigar.data() + cg, x.cigar(), 4 * (size_t)x.n_cigar);               // (BAM is little-endian like every host this library runs on)
-                    cg += x.n_cigar; S->cigar_off[ch + 1] = cg; ch++;
-                }
-            }
-        }
-    });
+    // ---- the fill.  Names, bases, qualities, alignments and CIGARs of a unit are written when a window that holds it is first handed out
+    // (hlala_seed_batch_window / _desc / _name -> ensure_filled): a caller that walks the sample batch by batch has the GPU align one batch while the host
+    // fills the next, instead of waiting for the whole sample here (0.6 s of 2.9 for 8.4 M pairs).  HLALA_BAM_EAGER=1 fills everything now.
+    W->nm = nm; W->T = T; W->UCH = UCH; W->nUChunks = nUChunks; W->remaining = nUChunks; W->done.assign((size_t)nUChunks, 0);
     S->seconds[5] = since(tPhase);
-    if(dbgL) fprintf(stderr, "bam-debug: layout: sizes %.3f (of which the zeroed offset arrays come first), prefix sums + allocation %.3f, fill %.3f s\n", tL1, tL2 - tL1, S->seconds[5] - tL2);
-    { Work* w = W.release(); try { std::thread([w]() { delete w; }).detach(); } catch(...) { delete w; } }
+    if(dbgL) fprintf(stderr, "bam-debug: layout: sizes %.3f (of which the zeroed offset arrays come first), prefix sums + allocation %.3f s; the fill runs per window\n", tL1, tL2 - tL1);
+    S->work = W.release();
+    if(nUChunks == 0) { delete S->work; S->work = nullptr; }
+    else if(const char* e = getenv("HLALA_BAM_EAGER")) { if(atoi(e) != 0) ensure_filled(S.get(), 0, (int64_t)nU); }
     *out = S.release();
     return HLALA_OK;
 } catch(const std::exception& e_) { g_bam_error = dynamic_cast<const Fail*>(&e_) ? std::string(e_.what()) : std::string("hlala_bam_extract_seeds: ") + e_.what(); return HLALA_E_ARG; }
@@ -544,6 +612,7 @@ extern "C" int hlala_seed_batch_window(const hlala_seed_batch* S, int64_t first_
     if(!S || !in || first_unit < 0 || n_units < 0 || first_unit + n_units > S->n_units) { g_bam_error = "hlala_seed_batch_window: units outside the sample"; return HLALA_E_ARG; }
     const int per = S->unpaired ? 1 : 2;
     const size_t r0 = (size_t)first_unit * (size_t)per, nr = (size_t)n_units * (size_t)per;
+    try { ensure_filled(S, first_unit, first_unit + n_units); } catch(const std::exception& e_) { g_bam_error = std::string("hlala_seed_batch_window: ") + e_.what(); return HLALA_E_ARG; }
     const int64_t nb = S->read_off[r0 + nr] - S->read_off[r0], nc = S->chain_off[r0 + nr] - S->chain_off[r0];
     const int64_t ng = S->cigar_off[(size_t)S->chain_off[r0 + nr]] - S->cigar_off[(size_t)S->chain_off[r0]];
     if(nb > 0x7FFFFFFFll || nc > 0x7FFFFFFFll || ng > 0x7FFFFFFFll) {
@@ -551,6 +620,7 @@ extern "C" int hlala_seed_batch_window(const hlala_seed_batch* S, int64_t first_
         return HLALA_E_CAPACITY;
     }
     in->n_pairs = n_units; in->read_off = S->read_off.data() + r0; in->read_bases = S->read_bases.data(); in->read_quals = S->read_quals.data();
+    in->read_bases_packed = S->packed ? S->read_bases_packed.data() : nullptr; in->first_read = (int64_t)r0;
     in->chain_off = S->chain_off.data() + r0; in->read_primary = S->read_primary.data() + r0; in->n_chains = (int32_t)nc;
     in->chain_contig = S->chain_contig.data(); in->chain_pos = S->chain_pos.data(); in->chain_offset = S->chain_offset.data(); in->chain_as = S->chain_as.data();
     in->chain_reverse = S->chain_reverse.data(); in->cigar_off = S->cigar_off.data(); in->cigar = S->cigar.data();
@@ -561,9 +631,11 @@ extern "C" int hlala_seed_batch_desc(const hlala_seed_batch* S, hlala_batch_in* 
 {
     if(!S || !in) return HLALA_E_ARG;
     if(S->n_units > 0x7FFFFFFFll) { g_bam_error = "hlala_seed_batch_desc: more than 2^31 - 1 units"; return HLALA_E_CAPACITY; }
+    try { ensure_filled(S, 0, S->n_units); } catch(const std::exception& e_) { g_bam_error = std::string("hlala_seed_batch_desc: ") + e_.what(); return HLALA_E_ARG; }
     // the whole sample: n_chains saturates when the sample holds more than one batch can (hlala_batch_create refuses such a descriptor;
     // hlala_seed_batch_window cuts batches)
     in->n_pairs = (int32_t)S->n_units; in->read_off = S->read_off.data(); in->read_bases = S->read_bases.data(); in->read_quals = S->read_quals.data();
+    in->read_bases_packed = S->packed ? S->read_bases_packed.data() : nullptr; in->first_read = 0;
     in->chain_off = S->chain_off.data(); in->read_primary = S->read_primary.data(); in->n_chains = (int32_t)std::min<size_t>(S->chain_contig.size(), 0x7FFFFFFF);
     in->chain_contig = S->chain_contig.data(); in->chain_pos = S->chain_pos.data(); in->chain_offset = S->chain_offset.data(); in->chain_as = S->chain_as.data();
     in->chain_reverse = S->chain_reverse.data(); in->cigar_off = S->cigar_off.data(); in->cigar = S->cigar.data();
@@ -572,7 +644,18 @@ extern "C" int hlala_seed_batch_desc(const hlala_seed_batch* S, hlala_batch_in* 
 }
 
 extern "C" int64_t hlala_seed_batch_units(const hlala_seed_batch* S) { return S ? S->n_units : 0; }
-extern "C" const char* hlala_seed_batch_name(const hlala_seed_batch* S, int64_t unit) { return (S && unit >= 0 && unit < S->n_units) ? S->name_chars.data() + S->name_off[(size_t)unit] : nullptr; }
+extern "C" int hlala_seed_batch_counts(const hlala_seed_batch* S, int64_t* counts)
+{
+    if(!S || !counts) return HLALA_E_ARG;
+    counts[0] = S->examined; counts[1] = S->n_seeds; counts[2] = S->n_incomplete;
+    return HLALA_OK;
+}
+extern "C" const char* hlala_seed_batch_name(const hlala_seed_batch* S, int64_t unit)
+{
+    if(!S || unit < 0 || unit >= S->n_units) return nullptr;
+    try { ensure_filled(S, unit, unit + 1); } catch(...) { return nullptr; }
+    return S->name_chars.data() + S->name_off[(size_t)unit];
+}
 extern "C" int hlala_seed_batch_timing(const hlala_seed_batch* S, double* seconds6, int32_t* n_threads)
 {
     if(!S) return HLALA_E_ARG;

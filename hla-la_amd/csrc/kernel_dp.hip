@@ -91,6 +91,11 @@ struct DpTiny  { static constexpr bool JF = false; static constexpr int THREADS 
 #define HLALA_DP_TINYJF_WAVES 4
 #endif
 struct DpTinyJF : DpTiny { static constexpr bool JF = true; static constexpr int WAVES = HLALA_DP_TINYJF_WAVES; };
+// ... and in front of it the same instantiation with EIGHT lanes per DP call, eight calls per wavefront: three quarters of the jump-free calls never hold more than eight
+// frontier cells or twelve targets, and a wavefront's trip costs the same whether its lanes serve four calls or eight.  What outgrows it (frontier, targets, 1024 kept cells)
+// or meets a jump goes on to the 16-lane jump-free instantiation through a list of its own (the list the lane-per-DP experiment used: work_counter[40..43]).
+struct DpTinyJF8 { static constexpr bool JF = true; static constexpr int THREADS = 64, WAVES = 4, GW = 8, WCAP = 8, HC = 16, IBITS = 3, CELLS = 1024, EARLY = 16, IMPCAP = 16, COMPLETED = 128, STEPS = 512;
+                   typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
 struct DpMid   { static constexpr bool JF = false; static constexpr int THREADS = 64, WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 struct DpSmall { static constexpr bool JF = false; static constexpr int THREADS = 64, WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
@@ -223,6 +228,15 @@ template <int GW> __device__ __forceinline__ int grp_base() { return (int)(threa
         t_ = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); v = OP(v, t_);      /* row_mirror */          \
     } while(0)
 
+// GW = 8: half a DPP row; quad_perm xor 1 / xor 2, row_half_mirror (3 ops)
+#define HLALA_HALFROW_ALLREDUCE(v, OP)                                                      \
+    do {                                                                                    \
+        int t_;                                                                             \
+        t_ = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); v = OP(v, t_);       /* quad_perm [1,0,3,2] */ \
+        t_ = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false); v = OP(v, t_);       /* quad_perm [2,3,0,1] */ \
+        t_ = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false); v = OP(v, t_);      /* row_half_mirror */     \
+    } while(0)
+
 // GW > 64 (one DP per block of several wavefronts): a block barrier that also orders the block's LDS / global accesses, and an exchange of one word per
 // wave through LDS.  The second barrier of a collective keeps a fast wave from overwriting the words before every wave has read them.
 __device__ __forceinline__ void blk_barrier()
@@ -244,6 +258,9 @@ template <int GW> __device__ __forceinline__ int grp_max_i32(int v)
         for(int i = 1; i < BlkX<GW>::NW; i++) r = op_max_(r, x[i]);
         blk_barrier();
         return r;
+    } else if constexpr (GW == 8) {
+        HLALA_HALFROW_ALLREDUCE(v, op_max_);
+        return v;
     } else {
     HLALA_ROW_ALLREDUCE(v, op_max_);
     if(GW == 32) v = op_max_(v, __shfl_xor(v, 16));     // the partner row of a 32-lane group
@@ -262,6 +279,9 @@ template <int GW> __device__ __forceinline__ int grp_sum_i32(int v)
         for(int i = 1; i < BlkX<GW>::NW; i++) r += x[i];
         blk_barrier();
         return r;
+    } else if constexpr (GW == 8) {
+        HLALA_HALFROW_ALLREDUCE(v, op_add_);
+        return v;
     } else {
     HLALA_ROW_ALLREDUCE(v, op_add_);
     if(GW == 32) v = op_add_(v, __shfl_xor(v, 16));
@@ -292,6 +312,16 @@ template <int GW> __device__ __forceinline__ int grp_excl_scan(int v, int& total
         blk_barrier();
         total = tot;
         return before + off;
+    } else if constexpr (GW == 8) {
+        // row_shr moves within the 16-lane row: what would cross from the group below into this one is dropped
+        const int l8 = (int)(threadIdx.x & 7);
+        int x = v, t;
+        t = dpp_mov<0x111>(0, x); if(l8 < 1) t = 0; x += t;
+        t = dpp_mov<0x112>(0, x); if(l8 < 2) t = 0; x += t;
+        t = dpp_mov<0x114>(0, x); if(l8 < 4) t = 0; x += t;
+        int m = x; HLALA_HALFROW_ALLREDUCE(m, op_max_);
+        total = m;
+        return x - v;
     } else {
     int x = v, t;
     t = dpp_mov<0x111>(0, x); x += t;       // row_shr:1 (lanes without a source keep 0)
@@ -544,19 +574,38 @@ __device__ inline bool early_insert(const DpSlabT<C>& sl, int gen, u64 key, int 
 // (characters are produced on the fly: no per-lane buffers, no scratch memory)
 __device__ inline int dec_len(int v) { int n = 1; while(v >= 10) { v /= 10; n++; } return n; }
 __device__ inline int pow10i(int n) { int p = 1; while(n-- > 0) p *= 10; return p; }
-__device__ inline int xz_char(int x, int z, int lx, int lz, int i)
+// number of decimal digits without a division (the loop of dec_len compiles to one software division per digit)
+__device__ __forceinline__ int dec_len_cmp(int v)
 {
-    if(i < lx) return '0' + (x / pow10i(lx - 1 - i)) % 10;
-    if(i == lx) return '/';
-    return '0' + (z / pow10i(lz - 1 - (i - lx - 1))) % 10;
+    return 1 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) + (v >= 10000000) + (v >= 100000000) + (v >= 1000000000);
 }
-__device__ inline bool xz_less(int x1, int z1, int x2, int z2)
+__device__ __forceinline__ u32 pow10_u32(int k)          // 10^k, k = 0 .. 9
 {
-    const int lx1 = dec_len(x1), lz1 = dec_len(z1), lx2 = dec_len(x2), lz2 = dec_len(z2);
-    const int la = lx1 + 1 + lz1, lb = lx2 + 1 + lz2;
-    const int n = la < lb ? la : lb;
-    for(int i = 0; i < n; i++) { int ca = xz_char(x1, z1, lx1, lz1, i), cb = xz_char(x2, z2, lx2, lz2, i); if(ca != cb) return ca < cb; }
-    return la < lb;
+    u32 p = (k & 1) ? 10u : 1u;
+    if(k & 2) p *= 100u;
+    if(k & 4) p *= 10000u;
+    if(k & 8) p *= 100000000u;
+    return p;
+}
+// order of the decimal strings of a and b, where the character that follows a number ('/' after x, the end of the string after z) sorts before every digit:
+// pad the shorter number with zeros to the length of the longer one -- the first differing character decides as the numbers do; equal after padding, the
+// shorter one is a proper prefix and comes first.  No division.  (The character-by-character comparison it replaces -- two software divisions per character and
+// side -- was a fifth of the 16-lane kernel's instructions in the binary; checked against std::string's operator< on millions of pairs: tools/xz_order_check.py.)
+__device__ __forceinline__ int xz_part(int a, int b)       // -1 / 0 / 1
+{
+    if(a == b) return 0;
+    const int la = dec_len_cmp(a), lb = dec_len_cmp(b);
+    u64 A = (u64)(u32)a, Bv = (u64)(u32)b;
+    if(la < lb) A *= (u64)pow10_u32(lb - la); else if(lb < la) Bv *= (u64)pow10_u32(la - lb);
+    if(A != Bv) return A < Bv ? -1 : 1;
+    return la < lb ? -1 : 1;
+}
+// "x1/z1" < "x2/z2" as strings
+__device__ __forceinline__ bool xz_less(int x1, int z1, int x2, int z2)
+{
+    const int c = xz_part(x1, x2);
+    if(c) return c < 0;
+    return xz_part(z1, z2) < 0;
 }
 
 // a number whose unsigned order is the string order of "x/z": symbols end < '/' < '0' .. '9' as digits of a base-12 number of 14 places
@@ -1641,7 +1690,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
     for(int dirPass = 0; dirPass < 2; dirPass++) {
         // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
         // retry list of tier k = 1..6 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
-        const bool fromLane = TIER == 0 && tinyList != nullptr;         // [40]/[42] counts, [41]/[43] fetched: the list of the lane-per-DP class
+        const bool fromLane = TIER == 0 && tinyList != nullptr && C::GW != 8;         // [40]/[42] counts, [41]/[43] fetched: the list of the class in front (for the 8-lane instantiation `tinyList` is where it hands ON)
         int* fetchCounter = &B.work_counter[TIER == 0 ? (fromLane ? 41 + 2 * dirPass : (C::JF ? 4 + dirPass : (dirPass ? 10 : 1))) : 13 + 4 * (TIER - 1) + 2 * dirPass];        // [4]/[5]: the jump-free lists
         // (TIER 0 draws from the dense lists of k_dp_lists -- jump-free or general, left or right --, the later tiers from the retry lists)
         const int seg = (C::JF ? 0 : 2) + dirPass;
@@ -1681,6 +1730,12 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
                     }
 #endif
                     const bool capacity = st.err != 0 && st.err > -1000000;
+                    if(capacity && C::GW == 8) {
+                        // the 8-lane jump-free instantiation hands on to the 16-lane one (its list: `tinyList`, counts work_counter[40] / [42])
+                        if(st.isAlias) ((int*)(items + st.itemIdx))[0] = st.item;
+                        int q = atomicAdd(&B.work_counter[40 + 2 * dirPass], 1);
+                        ((int*)tinyList)[(size_t)dirPass * (size_t)B.n_chains + q] = st.itemIdx;
+                    } else
                     if(capacity && TIER < DP_LAST_TIER) {
                         // next tier, or straight to the first tier whose class holds what overflowed (no point in failing again on the way)
                         int to = TIER + 1; if(st.needTier > to) to = st.needTier; if(to > DP_LAST_TIER) to = DP_LAST_TIER;

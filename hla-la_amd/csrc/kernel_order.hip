@@ -48,4 +48,25 @@ __global__ void k_order_scatter(const DevBatch* __restrict__ Bp)
     B.chain_order[pos] = c;
 }
 
+// 4-bit packed bases of a window (hlala_batch_in::read_bases_packed: BAM nibble codes, every read on a byte boundary at (base offset + read number + 1) >> 1) ->
+// the ASCII array the kernels read.  One thread per base pair: two characters from one byte.
+__global__ void k_unpack_bases(const uint8_t* __restrict__ packed, const int* __restrict__ read_off, const int n_reads, const long long rb0, const long long firstRead,
+                               const long long p0, uint8_t* __restrict__ out)
+{
+    const int r = blockIdx.x;
+    if(r >= n_reads) return;
+    const int o0 = read_off[r], len = read_off[r + 1] - o0;
+    const long long at = ((rb0 + (long long)o0 + firstRead + (long long)r + 1) >> 1) - p0;
+    // "=ACMGRSVTWYHKDBN" in four words, first character in the low byte
+    auto dec = [](unsigned c) -> uint8_t {
+        const u32 w = c < 4 ? 0x4D43413Du : (c < 8 ? 0x56535247u : (c < 12 ? 0x48595754u : 0x4E42444Bu));
+        return (uint8_t)(w >> (8 * (c & 3)));
+    };
+    for(int j = 2 * (int)threadIdx.x; j < len; j += 2 * (int)blockDim.x) {
+        const unsigned b = packed[at + (j >> 1)];
+        out[o0 + j] = dec(b >> 4);
+        if(j + 1 < len) out[o0 + j + 1] = dec(b & 15u);
+    }
+}
+
 }  // namespace hlala

@@ -19,6 +19,7 @@
 #include <cerrno>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -317,7 +318,9 @@ public:
         std::vector<std::string> errs(devices_.size());
         ThreadJoiner tdec, th;
         tdec.start([&]() {
-            try { if(hlala_bam_extract_seeds_mt(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, threads_, &seeds_) != HLALA_OK) bamErr = std::string("BAM: ") + hlala_bam_last_error(); }
+            // (the bases stay 4-bit packed as the BAM records hold them: a copy instead of an unpacking pass here, half the bytes to upload, unpacked on the device)
+            const int32_t seedFlags = std::getenv("HLALA_SEEDS_ASCII") ? 0 : HLALA_SEEDS_PACKED;          // (HLALA_SEEDS_ASCII=1: the decoder unpacks the bases on the host, as before round 4 -- for A/B runs)
+            try { if(hlala_bam_extract_seeds_opt(BAM.c_str(), (int32_t)intervals_.size(), intervals_.data(), longReads ? 1 : 0, threads_, seedFlags, &seeds_) != HLALA_OK) bamErr = std::string("BAM: ") + hlala_bam_last_error(); }
             catch(const std::exception& e) { bamErr = e.what(); }
             decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         });
@@ -339,8 +342,11 @@ public:
             for(hlala_ctx* c : ctxs_) if(hlala_set_insert_size(c, is.mean, is.sd) != HLALA_OK) throw std::runtime_error(std::string("hlala_set_insert_size: ") + hlala_last_error(c));
         }
         batchPairs_ = batchPairs > 0 ? batchPairs : (n_units > 0 ? (n_units > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)n_units) : 1);
-        live_.assign((size_t)n_batches(), nullptr);
+        live_.assign((size_t)n_batches(), nullptr); aligned_.assign((size_t)n_batches(), 0);
     }
+    // seconds the decoder has spent laying the sample out so far: sizes and offsets at decode time, then the fill of every window handed out since
+    // (hlala_seed_batch_window fills what it hands out, beside the GPU's work on the batch before)
+    double layout_seconds() const { double s[6] = {0, 0, 0, 0, 0, 0}; int32_t t = 0; if(seeds_) hlala_seed_batch_timing(seeds_, s, &t); return s[5]; }
     int32_t n_batches() const { return n_units == 0 ? 0 : (int32_t)((n_units + batchPairs_ - 1) / batchPairs_); }
     int64_t batch_first_unit(int32_t bi) const { return (int64_t)bi * batchPairs_; }
     int32_t batch_units(int32_t bi) const { int64_t a = (int64_t)bi * batchPairs_, z = a + batchPairs_; return (int32_t)((z > n_units ? n_units : z) - a); }
@@ -349,19 +355,26 @@ public:
     hlala_ctx* batch_ctx(int32_t bi) const { return ctxs_[(size_t)batch_device(bi)]; }
     // batch bi resident on its GPU: uploaded and, if `align`, run through alignOneReadPair / alignOneLongRead (:3129 / :3618).  Batches of
     // different devices may be acquired from different host threads (one thread per device).
+    // (A batch acquired without `align` is only uploaded -- its inputs: hlala_batch_create allocates no outputs -- and aligned by a later acquire(bi, true).)
     hlala_batch* acquire(int32_t bi, bool align)
     {
-        if(live_.at((size_t)bi)) return live_[(size_t)bi];
         hlala_ctx* c = batch_ctx(bi);
-        hlala_batch_in in; window(batch_first_unit(bi), batch_units(bi), in);
-        hlala_batch* b = nullptr;
-        int rc = longReadsMode ? hlala_batch_create_unpaired(c, &in, &b) : hlala_batch_create(c, &in, &b);       // (chain_off[0] of the window is the batch's first absolute chain number)
-        if(rc == HLALA_OK && align) rc = hlala_align_batch(c, b);
-        if(rc != HLALA_OK) { std::string e = hlala_last_error(c); if(b) hlala_batch_destroy(b); throw std::runtime_error("alignReads: " + e); }
-        live_[(size_t)bi] = b;
+        hlala_batch* b = live_.at((size_t)bi);
+        int rc = HLALA_OK;
+        if(!b) {
+            hlala_batch_in in; window(batch_first_unit(bi), batch_units(bi), in);            // (fills the window's units if nobody asked for them yet)
+            rc = longReadsMode ? hlala_batch_create_unpaired(c, &in, &b) : hlala_batch_create(c, &in, &b);       // (chain_off[0] of the window is the batch's first absolute chain number)
+            if(rc != HLALA_OK) { std::string e = hlala_last_error(c); if(b) hlala_batch_destroy(b); throw std::runtime_error("alignReads: " + e); }
+            live_[(size_t)bi] = b; aligned_[(size_t)bi] = 0;
+        }
+        if(align && !aligned_[(size_t)bi]) {
+            rc = hlala_align_batch(c, b);
+            if(rc != HLALA_OK) { std::string e = hlala_last_error(c); hlala_batch_destroy(b); live_[(size_t)bi] = nullptr; throw std::runtime_error("alignReads: " + e); }
+            aligned_[(size_t)bi] = 1;
+        }
         return b;
     }
-    void release(int32_t bi) { if(live_.at((size_t)bi)) { hlala_batch_destroy(live_[(size_t)bi]); live_[(size_t)bi] = nullptr; } }
+    void release(int32_t bi) { if(live_.at((size_t)bi)) { hlala_batch_destroy(live_[(size_t)bi]); live_[(size_t)bi] = nullptr; aligned_[(size_t)bi] = 0; } }
 
     // extractSeeds2 + estimateInsertSize + alignReads_postSeedExtraction (mapper/processBAM.cpp:703-864, 1071-1165, 2391-2483), one batch
     void alignReads(const std::string& BAM, bool longReads = false) { openBAM(BAM, longReads, 0); if(n_units > 0) acquire(0, true); }
@@ -389,7 +402,7 @@ private:
     std::string graphDir_; bool extended_; int max_columns_; uint32_t rng_seed_; std::vector<int> devices_; int threads_;
     hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; const std::vector<hlala_bam_interval>& intervals_;      // owned by gdir_
     hlala_seed_batch* seeds_ = nullptr; std::vector<hlala_ctx*> ctxs_;
-    int32_t batchPairs_ = 1; std::vector<hlala_batch*> live_;
+    int32_t batchPairs_ = 1; std::vector<hlala_batch*> live_; std::vector<char> aligned_;       // aligned_[bi]: hlala_align_batch has been queued for live_[bi]
 };
 }  // namespace mapper
 
@@ -472,7 +485,9 @@ public:
                     const size_t u0 = (size_t)pB.batch_first_unit(bi);
                     const auto t0 = std::chrono::steady_clock::now();
                     hlala_batch* b = pB.acquire(bi, true);
-                    if(bi + nDev < nB) pB.acquire(bi + nDev, true);      // two batches in flight per device
+                    if(bi + nDev < nB) pB.acquire(bi + nDev, true);      // two alignments in flight per device ...
+                    if(bi + 2 * nDev < nB) pB.acquire(bi + 2 * nDev, false);      // ... and one upload ahead: the window after next is filled and uploaded (inputs only) while the GPU is busy and before
+                                                                                // this thread waits for batch bi -- the host's 100 ms per batch off the critical path (bench.py's boundary loop does the same)
                     hlala_batch_stats bs; dchk(hlala_batch_get_stats(cd, b, &bs), "hlala_batch_get_stats");          // (waits for this batch only)
                     devAlign[(size_t)d] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     devErrors[(size_t)d] += bs.n_errors;

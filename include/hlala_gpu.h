@@ -139,7 +139,17 @@ typedef struct {
     const uint8_t*  chain_reverse; /* IsReverseStrand()                                         */
     const int64_t*  cigar_off;     /* [chain index .. +1] offsets into cigar                    */
     const uint32_t* cigar;         /* BAM encoding: len<<4 | op, op index into "MIDNSHP=X"      */
+    /* Optional (round 4): the bases 4-bit packed as a BAM record holds them (codes of "=ACMGRSVTWYHKDBN", two per byte, the first base in the high nibble) --
+     * half the bytes to upload, and what a BAM decoder has without unpacking.  When read_bases_packed is not NULL, read_bases is not read.  Every read starts on a
+     * byte: read R of the SAMPLE (R = first_read + r for read r of the window) has its (length + 1) / 2 bytes at read_bases_packed[(read_off[r] + R + 1) >> 1 ...],
+     * a closed form in the 64-bit base offset and the read's number that leaves room for one spare nibble per read (hlala_pack_bases writes this layout,
+     * hlala_seed_batch_window of a sample decoded with HLALA_SEEDS_PACKED hands it out).  The library unpacks on the device.                                       */
+    const uint8_t*  read_bases_packed;
+    int64_t         first_read;    /* number of the window's first read in the sample (0 for a batch that is its own sample) */
 } hlala_batch_in;
+/* ASCII bases of reads [0, n_reads) with offsets read_off (starting at 0) -> the packed layout above; `packed` holds (read_off[n_reads] + n_reads + 1) / 2 + 1 bytes.
+ * Characters outside "=ACMGRSVTWYHKDBN" are packed as N. */
+int  hlala_pack_bases(const uint8_t* read_bases, const int64_t* read_off, int64_t n_reads, uint8_t* packed);
 
 /* Seed chains handed over directly, bypassing the BAM projection: the protocol of
  * `--action testChainExtension` (HLA-LA.cpp:1733-1861) and the input type of
@@ -201,7 +211,9 @@ typedef struct {
 } hlala_pairs_out;
 
 /* Upload a batch: inputs become resident in HBM; nothing is computed.  Paired reads of more than 1024 bases are refused
- * (HLALA_E_CAPACITY): the extension DP keys its cells with a 12-bit read coordinate; long reads go through hlala_batch_create_unpaired. */
+ * (HLALA_E_CAPACITY): the extension DP keys its cells with a 12-bit read coordinate; long reads go through hlala_batch_create_unpaired.
+ * Returns when the caller's buffers have been read.  The OUTPUT arrays of the batch (50 GB per million pairs) are allocated by its first stage call
+ * (hlala_project_chains / hlala_align_batch), not here: a batch that is only uploaded costs its inputs. */
 int  hlala_batch_create(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** out);
 /* Long-read / unpaired mode (processBAM::alignOneLongRead, mapper/processBAM.cpp:3618-3838, and
  * assignMappingQualities_unpaired, :3900-4059): `in->n_pairs` is the number of READS, every array that is per read
@@ -305,6 +317,8 @@ typedef struct {
     int32_t n_dp_jump_free;       /* of n_dp_class[0]: calls that were known to meet no gap-path jump and ran in the instantiation of the 16-lane class that is
                                      compiled without the early-cell machinery (kernel_dp.hip: DpTinyJF)                                                      */
     float   ms_dp_jump_free;      /* part of ms_dp_class[0] spent in that instantiation                                                                       */
+    int32_t n_dp_jump_free_16;    /* of n_dp_jump_free: calls the 8-lane jump-free instantiation (eight calls per wavefront, where every jump-free call starts) handed on to
+                                     the 16-lane one -- frontier beyond 8 cells, more than 12 targets or 1024 kept cells, a jump after all                     */
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 
@@ -342,14 +356,25 @@ typedef struct {
 typedef struct hlala_seed_batch hlala_seed_batch;
 int  hlala_bam_extract_seeds(const char* bam_path, int32_t n_intervals, const hlala_bam_interval* intervals, int32_t long_read_mode,
                              hlala_seed_batch** out);
-/* The same with the number of decoding threads stated (0 = one per hardware thread, at most 128).  BGZF blocks are independent gzip
+/* The same with the number of decoding threads stated (0 = one per hardware thread, at most 32: measured on a 256-thread host the phases -- passes over
+ * ~12 GB of inflated records bound by memory latency -- are fastest there; it is also one sample's share of such a host in BASELINE config 4).  The call returns
+ * once the units, their order and every offset are known; names, bases, qualities, alignments and CIGARs of a unit are FILLED IN when a window that holds it is
+ * first handed out (hlala_seed_batch_window, _desc -- the whole sample --, _name), on the same number of threads: a caller that walks the sample window by
+ * window fills window i + 1 while the GPU aligns window i (HLALA_BAM_EAGER=1: everything at once, as before round 4).  BGZF blocks are independent gzip
  * members: they are inflated, their records parsed and grouped by read name in parallel; one final sort puts the complete units into
  * read-name order (the reference's std::map order, mapper/processBAM.cpp:712, 2024-2039).  The result does not depend on the thread count. */
 int  hlala_bam_extract_seeds_mt(const char* bam_path, int32_t n_intervals, const hlala_bam_interval* intervals, int32_t long_read_mode,
                                 int32_t n_threads, hlala_seed_batch** out);
+/* ... with options.  HLALA_SEEDS_PACKED: the bases of the sample stay 4-bit packed as the BAM records hold them (a copy instead of an unpacking pass on the host, half the
+ * bytes to upload): the descriptors of the sample carry read_bases_packed / first_read and a NULL read_bases (hlala_batch_in). */
+#define HLALA_SEEDS_PACKED 1
+int  hlala_bam_extract_seeds_opt(const char* bam_path, int32_t n_intervals, const hlala_bam_interval* intervals, int32_t long_read_mode,
+                                 int32_t n_threads, int32_t flags, hlala_seed_batch** out);
 /* The WHOLE sample as one descriptor (64-bit offsets starting at 0) pointing into the handle; counts[3] = records examined, seeds (read
  * names), incomplete seeds.  A sample beyond the size of one batch goes through the GPU window by window: hlala_seed_batch_window. */
 int  hlala_seed_batch_desc(const hlala_seed_batch* s, hlala_batch_in* in, int64_t* counts);
+/* the counters alone (nothing is filled in) */
+int  hlala_seed_batch_counts(const hlala_seed_batch* s, int64_t* counts);
 /* Units [first_unit, first_unit + n_units) of the sample as a batch descriptor (no copy: the window convention of hlala_batch_in).
  * HLALA_E_ARG outside the sample, HLALA_E_CAPACITY when the window itself exceeds the size of one batch. */
 int  hlala_seed_batch_window(const hlala_seed_batch* s, int64_t first_unit, int32_t n_units, hlala_batch_in* in);
@@ -668,7 +693,7 @@ int  hlala_abi_sizeof(const char* struct_name);
 
 /* Version of this interface.  It changes whenever the meaning or the type of a field changes WITHOUT changing the size of its struct (which
  * hlala_abi_sizeof cannot see) or a struct grows: 2 = hlala_batch_in carries 64-bit window offsets and an absolute read_primary (round 3);
- * 3 = hlala_batch_stats ends with n_dp_jump_free / ms_dp_jump_free (round 4).  A caller compares
+ * 3 = hlala_batch_stats ends with n_dp_jump_free / ms_dp_jump_free, hlala_batch_in with read_bases_packed / first_read (round 4).  A caller compares
  * hlala_abi_version() with the HLALA_ABI_VERSION it was compiled against and refuses to run on a mismatch (hla-la_amd/__init__.py and
  * hla-la_amd/host/hlala_host.hpp do). */
 #define HLALA_ABI_VERSION 3

@@ -98,7 +98,7 @@ def check(b, names, cnt, units, examined, n_seeds, n_inc, long_mode):
             r += 1
 
 
-def make_records(rng, n_names=60):
+def make_records(rng, n_names=60, lengths=(150,)):
     refs = [("chr6", 50000), ("chrUn", 9000), ("HLA-A*01", 4000)]
     recs = []
     nuc = "ACGT"
@@ -110,7 +110,8 @@ def make_records(rng, n_names=60):
             nal = 1 + int(rng.integers(0, 4))
             for k in range(nal):
                 ref = int(rng.choice([0, 0, 0, 1, 2]))
-                L = 150; clipl = int(rng.integers(0, 20)); clipr = int(rng.integers(0, 20))
+                L = int(rng.choice(lengths)) if len(lengths) > 1 else lengths[0]
+                clipl = int(rng.integers(0, 20)); clipr = int(rng.integers(0, 20))
                 cig = [(clipl, "S")] if clipl else []
                 mid = L - clipl - clipr
                 if rng.random() < 0.3:
@@ -218,6 +219,62 @@ def test_bam_round_trip_of_synthetic_batch(pkg, tmp_path):
     for r in range(2 * b["n_pairs"]):                                        # AS-descending inside every read
         a = got["chain_as"][got["chain_off"][r]:got["chain_off"][r + 1]]
         assert (np.diff(a) <= 0).all()
+
+
+def test_packed_bases_of_the_decoder_and_the_packer(pkg, tmp_path):
+    """HLALA_SEEDS_PACKED: the sample's bases stay 4-bit packed as the BAM records hold them, every read on a byte of its own at (base offset + read number + 1) >> 1
+    (include/hlala_gpu.h: hlala_batch_in::read_bases_packed).  Unpacked, the sample equals the one decoded to ASCII -- as a whole and window by window (odd read
+    lengths, windows that start on odd reads) --, and hlala_pack_bases writes the same bytes from the ASCII bases."""
+    rng = np.random.default_rng(11)
+    refs, recs = make_records(rng, lengths=(149, 150, 151, 97))
+    p = tmp_path / "t.bam"; write_bam(p, refs, recs)
+    lib = C.CDLL(pkg.LIB_PATH)
+    intervals = [("chr6", 10000, 20000, 0), ("HLA-A*01", 0, 3999, 1), ("chr6", 19000, 30000, 2)]
+    for long_mode in (False, True):
+        A = pkg.bam_open_seeds(lib, p, intervals, long_read_mode=long_mode)
+        P = pkg.bam_open_seeds(lib, p, intervals, long_read_mode=long_mode, flags=pkg.SEEDS_PACKED)
+        assert A.n_units == P.n_units and A.n_units > 5
+        a = A.to_dict(); q = P.to_dict()
+        assert len(set(np.diff(a["read_off"]) % 2)) == 2                     # odd and even read lengths
+        for k in a:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(q[k])), k
+        for u0, n in ((1, 3), (2, A.n_units - 2), (A.n_units - 1, 1)):
+            wa = A.to_dict(u0, n); wq = P.to_dict(u0, n)
+            assert P.window(u0, n).read_bases_packed and not P.window(u0, n).read_bases and P.window(u0, n).first_read == u0 * (1 if long_mode else 2)
+            for k in wa:
+                assert np.array_equal(np.asarray(wa[k]), np.asarray(wq[k])), (u0, n, k)
+        # the host packer: same layout
+        ro = a["read_off"].astype(np.int64); nr = len(ro) - 1
+        out = np.zeros((int(ro[-1]) + nr + 1) // 2 + 2, np.uint8)
+        lib.hlala_pack_bases.argtypes = [pkg.c_u8p, pkg.c_i64p, C.c_int64, pkg.c_u8p]
+        assert lib.hlala_pack_bases(np.ascontiguousarray(a["read_bases"]).ctypes.data_as(pkg.c_u8p), ro.ctypes.data_as(pkg.c_i64p), nr, out.ctypes.data_as(pkg.c_u8p)) == 0
+        d = P.window(0, P.n_units)
+        ref = np.ctypeslib.as_array(d.read_bases_packed, (len(out),))
+        for r in range(nr):
+            at = (int(ro[r]) + r + 1) >> 1; nb = (int(ro[r + 1] - ro[r]) + 1) // 2; full = int(ro[r + 1] - ro[r]) // 2
+            assert np.array_equal(out[at:at + full], ref[at:at + full]) and (nb == full or (out[at + full] >> 4) == (ref[at + full] >> 4)), r
+        A.close(); P.close()
+
+
+@pytest.mark.gpu
+def test_packed_batch_aligns_like_the_ascii_batch(pkg, oracle, tmp_path):
+    """A batch handed over with 4-bit packed bases (unpacked on the device) gives the results of the ASCII batch: through the decoder (HLALA_SEEDS_PACKED, whole
+    sample and a window that starts on an odd unit) and through hlala_pack_bases on a synthetic batch."""
+    from test_gpu_align import assert_pairs_equal
+    w, b, p, intervals = world_bam(tmp_path, 6, 250)
+    lib = C.CDLL(pkg.LIB_PATH)
+    A = pkg.bam_open_seeds(lib, p, intervals); P = pkg.bam_open_seeds(lib, p, intervals, flags=pkg.SEEDS_PACKED)
+    ctx = pkg.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=5)
+    for u0, n in ((0, A.n_units), (7, 101)):
+        ga = ctx.batch_window(A, u0, n); ga.align(); gp = ctx.batch_window(P, u0, n); gp.align()
+        assert_pairs_equal(gp.pairs(), ga.pairs())
+        ca, cp = ga.chains(1), gp.chains(1)
+        for k in ca:
+            if isinstance(ca[k], np.ndarray):
+                assert np.array_equal(ca[k], cp[k]), k
+        assert gp.stats().n_errors == 0
+        ga.close(); gp.close()
+    A.close(); P.close()
 
 
 @pytest.mark.gpu
