@@ -410,7 +410,7 @@ def main():
                                     "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6],
                                     "dp_16lane_jump_free_part": float(st.ms_dp_jump_free)},
                        "stage_ms_source": "HIP events of one batch of the resident loop, on the streams its kernels ran on (the kernels of the boundary loop are the same)",
-                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "16lane_jump_free": int(st.n_dp_jump_free), "jump_free_handed_on_by_the_8lane_instantiation": int(st.n_dp_jump_free_16)},
+                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "16lane_jump_free": int(st.n_dp_jump_free)},
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,

@@ -560,7 +560,7 @@ class BatchStats(C.Structure):
                 ("n_edges_touched", C.c_int64), ("n_errors", C.c_int64), ("ms_extend_retry", C.c_float),
                 ("n_chains_retried", C.c_int32), ("ms_dp_main", C.c_float), ("n_dp_retried_large", C.c_int32), ("n_dp_shared", C.c_int64),
                 ("n_dp_class", C.c_int32 * 7), ("ms_dp_class", C.c_float * 7), ("ms_side", C.c_float),
-                ("n_dp_lane", C.c_int32), ("ms_dp_lane", C.c_float), ("n_dp_jump_free", C.c_int32), ("ms_dp_jump_free", C.c_float), ("n_dp_jump_free_16", C.c_int32)]
+                ("n_dp_lane", C.c_int32), ("ms_dp_lane", C.c_float), ("n_dp_jump_free", C.c_int32), ("ms_dp_jump_free", C.c_float)]
 
 
 _DT = {c_i32p: np.int32, c_i64p: np.int64, c_u8p: np.uint8, c_u32p: np.uint32, c_f64p: np.float64}

@@ -78,7 +78,7 @@ struct DevBatch {
     int* dp_blk;                    // [4 * dp_nblk + 1] items per block of k_dp_items and list (jump-free left / right, general left / right); after the scan: where they start
     int* dp_list;                   // [2*n_chains] the four dense lists of the first DP classes: slots of dp_items in position order (k_dp_lists)
     int dp_nblk;                    // blocks of k_dp_items
-    int dp_jf;                      // 1: calls that meet no gap-path jump go to the lists of the jump-free instantiation (0: HLALA_DP_JF=0, every call in the general one)
+    int dp_jf;                      // > 0: calls that meet no gap-path jump go to the lists of the jump-free instantiations, reach = read bases left + dp_jf - 1 levels (0: HLALA_DP_JF=0, every call in the general one)
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
     int* dbg;                       // non-null with HLALA_DEBUG=1: kernels add phase clocks to counters[16..31]
 };

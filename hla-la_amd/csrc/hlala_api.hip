@@ -67,7 +67,7 @@ struct hlala_ctx {
     size_t pool_bytes = 0;
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
-    char* jf8_slabs = nullptr; size_t jf8_slab_bytes = 0; int jf8_grid = 0;      // the 8-lane jump-free instantiation in front of the 16-lane one (0: not used)
+    int jf_margin = 16;      // (measured 4 / 8 / 16 / 48: 16-lane + 32-lane class 105.6 / 104.1 / 103.4 / 104.1 ms -- a tight bound sends more calls to the cheap instantiation and more of them on to the 32-lane class) levels beyond the read bases left that a jump-free call is taken to reach (kernel_dp.hip: k_dp_items)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
     char* lane_slabs = nullptr; int lane_grid = 0;      // the lane-per-DP class in front of the 16-lane class (kernel_dp_lane.hip); lane_grid 0: not used (HLALA_DP_LANE=0)
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
@@ -402,8 +402,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_DP_LANE")) { if(atoi(e) != 0) c->jf_grid = 0; }      // (the lane-per-DP class takes every item itself)
 #endif
     if(const char* e = getenv("HLALA_DP_JF")) { if(atoi(e) == 0) c->jf_grid = 0; }      // (A/B: every call in the general instantiation -- the kernels' lists are built either way)
-    c->jf8_grid = c->jf_grid > 0 ? cus * 4 * DpTinyJF8::WAVES : 0; c->jf8_slab_bytes = dp_slab_bytes<DpTinyJF8>();
-    if(const char* e = getenv("HLALA_DP_JF8")) { if(atoi(e) == 0) c->jf8_grid = 0; }     // (A/B: the jump-free calls start in the 16-lane instantiation)
+    if(const char* e = getenv("HLALA_DP_JF_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 200) c->jf_margin = m; }      // (A/B: levels beyond the read bases left that a jump-free call may reach)
     c->ext_grid = cus * 20;
     c->mid_grid = cus * 16; c->mid_slab_bytes = dp_slab_bytes<DpMid>();
     c->retry_grid = cus;
@@ -421,7 +420,6 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     { const char* e = getenv("HLALA_DP_LANE"); c->lane_grid = (e && atoi(e) != 0) ? cus * 4 : 0; }          // 36 KB of LDS per wave: four per CU
     if(c->lane_grid && (rc = slab_pool(&c->lane_slabs, dp_lane_slab_bytes() * (size_t)64 * (size_t)c->lane_grid, "lane-per-DP slabs"))) return fail(rc);
 #endif
-    if(c->jf8_grid > 0 && (rc = slab_pool(&c->jf8_slabs, c->jf8_slab_bytes * (size_t)(64 / DpTinyJF8::GW) * (size_t)c->jf8_grid, "8-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->mid_slabs, c->mid_slab_bytes * (size_t)(64 / DpMid::GW) * (size_t)c->mid_grid, "32-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid, "64-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid, "wide-class DP slabs"))) return fail(rc);
@@ -539,7 +537,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(pair_deferred, np, true); AL(counters, 32, true); AL(work_counter, 48, true); AL(retry_list, 14 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
     B.dp_nblk = (int)((nc + 255) / 256); if(B.dp_nblk < 1) B.dp_nblk = 1;
-    B.dp_jf = c->jf_grid > 0 ? 1 : 0;
+    B.dp_jf = c->jf_grid > 0 ? c->jf_margin + 1 : 0;
     AL(dp_blk, (size_t)4 * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
     B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb;
     if(c->order_nb > 0 && !B.from_seeds && nc > 0) { AL(chain_order, nc, false); AL(chain_bucket, nc, false); AL(order_hist, (size_t)c->order_nb + 1, false); }
@@ -823,14 +821,7 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
             case 0:
                 // the calls that meet no gap-path jump in the instantiation without the early-cell machinery, then the others (same slabs: one after the other)
                 if(!tinyList && c->jf_grid > 0) {
-                    const int* jfList = nullptr;
-                    if(c->jf8_grid > 0) {
-                        // eight lanes per call first; what outgrows that goes on to the 16-lane jump-free instantiation through jfList
-                        jfList = B.retry_list + (size_t)12 * (size_t)B.n_chains;
-                        hipLaunchKernelGGL((k_dp<DpTinyJF8, 0>), dim3(c->jf8_grid), dim3(DpTinyJF8::THREADS), 0, ws, c->dG, b->dB, items, c->jf8_slabs, c->jf8_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, jfList);
-                        int rc8 = check_launch(c, "k_dp<DpTinyJF8>"); if(rc8) return rc8;
-                    }
-                    hipLaunchKernelGGL((k_dp<DpTinyJF, 0>), dim3(c->jf_grid), dim3(DpTinyJF::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, jfList);
+                    hipLaunchKernelGGL((k_dp<DpTinyJF, 0>), dim3(c->jf_grid), dim3(DpTinyJF::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr);
                     int rcj = check_launch(c, "k_dp<DpTinyJF>"); if(rcj) return rcj;
                     HIP_TRY(c, hipEventRecord(b->evJF, ws));
                 }
@@ -1208,7 +1199,7 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
           if(c->jf_grid > 0 && !b->lane_used) (void)hipEventElapsedTime(&out->ms_dp_jump_free, b->evC[0][0], b->evJF);
           if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, b->evSide[1], b->evSide[6]); } }
     { int wc[48]; HIP_TRY(c, hipMemcpyAsync(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
-      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9]; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; out->n_dp_jump_free = (c->jf_grid > 0 && !b->lane_used) ? wc[6] : 0; out->n_dp_jump_free_16 = (c->jf8_grid > 0 && c->jf_grid > 0 && !b->lane_used) ? wc[40] + wc[42] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
+      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9]; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; out->n_dp_jump_free = (c->jf_grid > 0 && !b->lane_used) ? wc[6] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, b->ev[4], b->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

@@ -31,8 +31,10 @@
 //              iteration pushes in the reference's std::map order.
 // Scores are integers (the reference's doubles only ever hold integers, alignerBase.cpp:19-25).
 //
-// k_dp_items      : per chain, input checks of extendSeedChain and the list of DP items
-// k_dp<C, TIER>   : the DP classes above; extension columns go straight into the chain's output row
+// k_dp_items      : per chain, input checks of extendSeedChain and the DP items, one slot per chain in position order (kernel_order.hip); counts per block and list
+// k_dp_lists      : the four dense item lists of the first class (jump-free / general x left / right) from the scanned counts
+// k_dp<C, TIER>   : the DP classes above (the first one in two instantiations: DpTinyJF for calls that meet no gap-path jump, DpTiny for the rest); extension
+//                   columns go straight into the chain's output row
 // k_stitch_chains : extendWithOtherSeedChain / extendToFullSequenceLength (verboseSeedChain.cpp:23-136) and
 //                   scoreOneAlignment (extensionAligner.cpp:52-182), one wavefront per chain
 #include "batch.h"
@@ -91,11 +93,6 @@ struct DpTiny  { static constexpr bool JF = false; static constexpr int THREADS 
 #define HLALA_DP_TINYJF_WAVES 4
 #endif
 struct DpTinyJF : DpTiny { static constexpr bool JF = true; static constexpr int WAVES = HLALA_DP_TINYJF_WAVES; };
-// ... and in front of it the same instantiation with EIGHT lanes per DP call, eight calls per wavefront: three quarters of the jump-free calls never hold more than eight
-// frontier cells or twelve targets, and a wavefront's trip costs the same whether its lanes serve four calls or eight.  What outgrows it (frontier, targets, 1024 kept cells)
-// or meets a jump goes on to the 16-lane jump-free instantiation through a list of its own (the list the lane-per-DP experiment used: work_counter[40..43]).
-struct DpTinyJF8 { static constexpr bool JF = true; static constexpr int THREADS = 64, WAVES = 4, GW = 8, WCAP = 8, HC = 16, IBITS = 3, CELLS = 1024, EARLY = 16, IMPCAP = 16, COMPLETED = 128, STEPS = 512;
-                   typedef u32 Best; typedef short Slot; typedef unsigned char ImpIdx; static constexpr bool IN_MEMORY = false; };
 struct DpMid   { static constexpr bool JF = false; static constexpr int THREADS = 64, WAVES = 4, GW = 32, WCAP = 32,   HC = 128,  IBITS = 5,  CELLS = 4096,     EARLY = 8192,     IMPCAP = 256,  COMPLETED = 512,          STEPS = 2048;     typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 struct DpSmall { static constexpr bool JF = false; static constexpr int THREADS = 64, WAVES = 5, GW = 64, WCAP = 64,   HC = 128,  IBITS = 7,  CELLS = DP_CELLS, EARLY = DP_CELLS, IMPCAP = 2048, COMPLETED = DP_COMPLETED, STEPS = DP_STEPS; typedef u32 Best; typedef short Slot; typedef unsigned short ImpIdx; static constexpr bool IN_MEMORY = false; };
 // frontiers of 65 .. 256 cells (the bulk of what outgrows the 64-lane class on allele-rich levels): one wavefront per DP like the large class,
@@ -228,15 +225,6 @@ template <int GW> __device__ __forceinline__ int grp_base() { return (int)(threa
         t_ = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); v = OP(v, t_);      /* row_mirror */          \
     } while(0)
 
-// GW = 8: half a DPP row; quad_perm xor 1 / xor 2, row_half_mirror (3 ops)
-#define HLALA_HALFROW_ALLREDUCE(v, OP)                                                      \
-    do {                                                                                    \
-        int t_;                                                                             \
-        t_ = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); v = OP(v, t_);       /* quad_perm [1,0,3,2] */ \
-        t_ = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false); v = OP(v, t_);       /* quad_perm [2,3,0,1] */ \
-        t_ = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false); v = OP(v, t_);      /* row_half_mirror */     \
-    } while(0)
-
 // GW > 64 (one DP per block of several wavefronts): a block barrier that also orders the block's LDS / global accesses, and an exchange of one word per
 // wave through LDS.  The second barrier of a collective keeps a fast wave from overwriting the words before every wave has read them.
 __device__ __forceinline__ void blk_barrier()
@@ -258,9 +246,6 @@ template <int GW> __device__ __forceinline__ int grp_max_i32(int v)
         for(int i = 1; i < BlkX<GW>::NW; i++) r = op_max_(r, x[i]);
         blk_barrier();
         return r;
-    } else if constexpr (GW == 8) {
-        HLALA_HALFROW_ALLREDUCE(v, op_max_);
-        return v;
     } else {
     HLALA_ROW_ALLREDUCE(v, op_max_);
     if(GW == 32) v = op_max_(v, __shfl_xor(v, 16));     // the partner row of a 32-lane group
@@ -279,9 +264,6 @@ template <int GW> __device__ __forceinline__ int grp_sum_i32(int v)
         for(int i = 1; i < BlkX<GW>::NW; i++) r += x[i];
         blk_barrier();
         return r;
-    } else if constexpr (GW == 8) {
-        HLALA_HALFROW_ALLREDUCE(v, op_add_);
-        return v;
     } else {
     HLALA_ROW_ALLREDUCE(v, op_add_);
     if(GW == 32) v = op_add_(v, __shfl_xor(v, 16));
@@ -312,16 +294,6 @@ template <int GW> __device__ __forceinline__ int grp_excl_scan(int v, int& total
         blk_barrier();
         total = tot;
         return before + off;
-    } else if constexpr (GW == 8) {
-        // row_shr moves within the 16-lane row: what would cross from the group below into this one is dropped
-        const int l8 = (int)(threadIdx.x & 7);
-        int x = v, t;
-        t = dpp_mov<0x111>(0, x); if(l8 < 1) t = 0; x += t;
-        t = dpp_mov<0x112>(0, x); if(l8 < 2) t = 0; x += t;
-        t = dpp_mov<0x114>(0, x); if(l8 < 4) t = 0; x += t;
-        int m = x; HLALA_HALFROW_ALLREDUCE(m, op_max_);
-        total = m;
-        return x - v;
     } else {
     int x = v, t;
     t = dpp_mov<0x111>(0, x); x += t;       // row_shr:1 (lanes without a source keep 0)
@@ -1578,12 +1550,13 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
             }
         }
     }
-    // Jump-free calls (DpTinyJF): a call can reach about as many levels as it has read bases left, plus the few columns of gaps the X-drop window admits and the
-    // iterations of patience; no node of those levels has a gap-path jump (FlatGraph::jfree_out / jfree_in).  A heuristic bound: a call that meets a jump
-    // anyway is re-run in the next class.
+    // Jump-free calls (DpTinyJF): no node of the levels a call can reach has a gap-path jump (FlatGraph::jfree_out / jfree_in).  A heuristic bound: a call
+    // that meets a jump anyway is re-run in the next class.
     bool jfL = false, jfR = false;
-    if(needL && B.dp_jf) { const int reach = itL.start_seq + 48; jfL = reach < 255 && (int)G.jfree_in[itL.startLevel] > reach; }
-    if(needR && B.dp_jf) { const int reach = itR.seqLen - itR.start_seq + 48; jfR = reach < 255 && (int)G.jfree_out[itR.startLevel] > reach; }
+    // (reach: a frontier cell lies at most as many levels from the start as the read has bases left, plus the five or six levels of gaps the X-drop window of 15 admits
+    //  at 6 + 2 per level; DP_JF_MARGIN on top.  B.dp_jf = the margin + 1, 0 = off.)
+    if(needL && B.dp_jf) { const int reach = itL.start_seq + B.dp_jf - 1; jfL = reach < 255 && (int)G.jfree_in[itL.startLevel] > reach; }
+    if(needR && B.dp_jf) { const int reach = itR.seqLen - itR.start_seq + B.dp_jf - 1; jfR = reach < 255 && (int)G.jfree_out[itR.startLevel] > reach; }
     if(t < nOrd) {
         int4* sl = (int4*)(items + t); int4* sr = (int4*)(items + (size_t)B.n_chains + t);
         if(needL) { sl[0] = make_int4(itL.item, itL.rOff, itL.seqLen, itL.start_seq); sl[1] = make_int4(itL.startLevel, itL.startNode, jfL ? 1 : 0, 0); } else sl[0] = make_int4(-1, 0, 0, 0);
@@ -1690,7 +1663,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
     for(int dirPass = 0; dirPass < 2; dirPass++) {
         // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
         // retry list of tier k = 1..6 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
-        const bool fromLane = TIER == 0 && tinyList != nullptr && C::GW != 8;         // [40]/[42] counts, [41]/[43] fetched: the list of the class in front (for the 8-lane instantiation `tinyList` is where it hands ON)
+        const bool fromLane = TIER == 0 && tinyList != nullptr;         // [40]/[42] counts, [41]/[43] fetched: the list of the lane-per-DP class
         int* fetchCounter = &B.work_counter[TIER == 0 ? (fromLane ? 41 + 2 * dirPass : (C::JF ? 4 + dirPass : (dirPass ? 10 : 1))) : 13 + 4 * (TIER - 1) + 2 * dirPass];        // [4]/[5]: the jump-free lists
         // (TIER 0 draws from the dense lists of k_dp_lists -- jump-free or general, left or right --, the later tiers from the retry lists)
         const int seg = (C::JF ? 0 : 2) + dirPass;
@@ -1730,12 +1703,6 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
                     }
 #endif
                     const bool capacity = st.err != 0 && st.err > -1000000;
-                    if(capacity && C::GW == 8) {
-                        // the 8-lane jump-free instantiation hands on to the 16-lane one (its list: `tinyList`, counts work_counter[40] / [42])
-                        if(st.isAlias) ((int*)(items + st.itemIdx))[0] = st.item;
-                        int q = atomicAdd(&B.work_counter[40 + 2 * dirPass], 1);
-                        ((int*)tinyList)[(size_t)dirPass * (size_t)B.n_chains + q] = st.itemIdx;
-                    } else
                     if(capacity && TIER < DP_LAST_TIER) {
                         // next tier, or straight to the first tier whose class holds what overflowed (no point in failing again on the way)
                         int to = TIER + 1; if(st.needTier > to) to = st.needTier; if(to > DP_LAST_TIER) to = DP_LAST_TIER;

@@ -317,8 +317,6 @@ typedef struct {
     int32_t n_dp_jump_free;       /* of n_dp_class[0]: calls that were known to meet no gap-path jump and ran in the instantiation of the 16-lane class that is
                                      compiled without the early-cell machinery (kernel_dp.hip: DpTinyJF)                                                      */
     float   ms_dp_jump_free;      /* part of ms_dp_class[0] spent in that instantiation                                                                       */
-    int32_t n_dp_jump_free_16;    /* of n_dp_jump_free: calls the 8-lane jump-free instantiation (eight calls per wavefront, where every jump-free call starts) handed on to
-                                     the 16-lane one -- frontier beyond 8 cells, more than 12 targets or 1024 kept cells, a jump after all                     */
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 
