@@ -5,7 +5,8 @@ copying, two batches in flight -- and every batch keeps the reference's invarian
   * no chain and no pair flagged; checkChainConcordanceWithSequence (verboseSeedChain.cpp:48-77), checkLevelContiguity (verboseSeedChain.h:282-315) and
     the columns against the graph over every output column;
   * truth (simulator/trueReadLevels.cpp:18-196): >= 99 % of the read bases on the level they were drawn from -- oracle-independent;
-  * sampled bit-exact parity: 3 x 64 pairs of the batch re-run alone with their absolute chain numbers equal their rows of the big run and the oracle.
+  * sampled bit-exact parity: 3 x 64 pairs of the batch re-run alone with their absolute chain numbers equal their rows of the big run and the oracle, and (round 4)
+    a block of 8 192 consecutive pairs of the big run itself equals the oracle run on all host cores -- 65 536 + 1 536 pairs of the sample.
 Reference: processBAM::alignReads_and_inferHLA's walk over the sample (mapper/processBAM.cpp:1788-1923), extractSeeds2 (:703-864)."""
 import ctypes as C
 import os
@@ -117,6 +118,22 @@ def test_eight_million_pairs_stream_through_one_context(pkg, oracle, tmp_path):
                 assert m == got["n_cols"][r - r0] and np.array_equal(lv[off[r]:off[r] + m], got["col_level"][(r - r0) * 384:(r - r0) * 384 + m])
             assert np.array_equal(sc["best_chain"][r0:r0 + 128], got["best_chain"] + c0) and np.array_equal(sc["pair_ll"][start:start + 64], got["pair_ll"])
             gs.close()
+        # ---- a block of 8 192 consecutive pairs of the BIG run itself against the oracle on all host cores (orc_align_batch_mt: pairs are independent; every DP
+        # draws its random seed from its chain's absolute number): rows of the big run, not a re-run -- 65 536 pairs of the sample in all
+        BLK = 8192; start = (CHUNK // 3 + 4099 * k) % (CHUNK - BLK)
+        sub, p0, c0 = D.shard_pairs_range(d, start, start + BLK)
+        sub["insert_mean"], sub["insert_sd"] = kw["insert_mean"], kw["insert_sd"]
+        first = d["first_chain"] + c0
+        exp = oracle(w["graph"], w["contigs"], **dict(kw, rng_seed=(12345 + 2 * first) & 0xFFFFFFFF)).align_batch_mt(sub, 0, pairs_only=True)["pairs"]
+        r0 = 2 * start
+        assert np.array_equal(sc["pair_status"][start:start + BLK], exp["pair_status"]) and np.array_equal(sc["n_combinations"][start:start + BLK], exp["n_combinations"])
+        assert np.array_equal(sc["best_chain"][r0:r0 + 2 * BLK], exp["best_chain"] + c0) and np.array_equal(ncols[r0:r0 + 2 * BLK], exp["n_cols"])
+        assert np.allclose(sc["pair_ll"][start:start + BLK], exp["pair_ll"], rtol=1e-12, atol=0) and np.allclose(sc["pair_mapq"][start:start + BLK], exp["pair_mapq"], rtol=1e-9, atol=1e-12)
+        ecols = {key: np.asarray(exp[key]).reshape(2 * BLK, 384) for key in ("col_level", "col_gchar", "col_schar", "col_mapq")}
+        sel = np.arange(384)[None, :] < exp["n_cols"][:, None]
+        a0, a1 = int(off[r0]), int(off[r0 + 2 * BLK])
+        for key in ("col_level", "col_gchar", "col_schar", "col_mapq"):
+            assert np.array_equal(ecols[key][sel], pk[key][a0:a1]), (k, key)
         gb.close(); del pk, sc, b, d
         t_check += time.time() - t1
     tm = S.timing()

@@ -8,7 +8,7 @@ one of the ~317 M output columns with numpy:
   * truth (simulator/trueReadLevels.cpp:18-196): >= 99 % of the read bases on the level they were drawn from -- oracle-independent;
   * idempotence: a second pass over the resident batch gives the same bytes (checksum of all outputs);
   * sampled bit-exact parity: 3 x 300 pairs spread over the batch, re-run alone with their absolute chain numbers (hlala_batch_set_first_chain),
-    equal their rows of the big run AND the oracle.
+    equal their rows of the big run AND the oracle; (round 4) 32 768 consecutive pairs of the big run itself equal the oracle run on all host cores.
 """
 import hashlib
 
@@ -96,6 +96,18 @@ def test_one_million_pairs_keep_the_reference_invariants(pkg, oracle):
             assert n == got["n_cols"][r - r0] and np.array_equal(lv[off[r]:off[r] + n], got["col_level"][(r - r0) * 384:(r - r0) * 384 + n])
         assert np.array_equal(sc["best_chain"][r0:r1], got["best_chain"] + c0) and np.array_equal(sc["pair_ll"][start:start + 300], got["pair_ll"])
         gs.close()
+    # ---- (round 4) 32 768 consecutive pairs of the BIG run itself against the oracle on all host cores (orc_align_batch_mt): every column of every selected alignment
+    BLK = 32768; start = 261_123
+    sub, p0, c0 = D.shard_pairs_range(big, start, start + BLK)
+    exp = oracle(w["graph"], w["contigs"], **dict(kw, rng_seed=(12345 + 2 * c0) & 0xFFFFFFFF)).align_batch_mt(sub, 0, pairs_only=True)["pairs"]
+    r0 = 2 * start
+    assert np.array_equal(sc["pair_status"][start:start + BLK], exp["pair_status"]) and np.array_equal(sc["n_combinations"][start:start + BLK], exp["n_combinations"])
+    assert np.array_equal(sc["best_chain"][r0:r0 + 2 * BLK], exp["best_chain"] + c0) and np.array_equal(ncols[r0:r0 + 2 * BLK], exp["n_cols"])
+    assert np.allclose(sc["pair_ll"][start:start + BLK], exp["pair_ll"], rtol=1e-12, atol=0) and np.allclose(sc["pair_mapq"][start:start + BLK], exp["pair_mapq"], rtol=1e-9, atol=1e-12)
+    sel = np.arange(384)[None, :] < exp["n_cols"][:, None]
+    a0, a1 = int(off[r0]), int(off[r0 + 2 * BLK])
+    for key in ("col_level", "col_edge", "col_gchar", "col_schar", "col_mapq"):
+        assert np.array_equal(np.asarray(exp[key]).reshape(2 * BLK, 384)[sel], pk[key][a0:a1]), key
 
 
 def test_densest_pairs_go_through_the_in_memory_class(pkg, oracle):
