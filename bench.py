@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--e2e-pairs", type=int, default=8_388_608, help="pairs of the sample pushed through `HLA-LA --action HLA` for the end-to-end rate (0 = skip)")
     ap.add_argument("--e2e-frac-gene", type=float, default=0.04, help="share of the end-to-end sample drawn from the gene windows: 0.04 = the windows' share of the graph, i.e. the uniform "
                     "coverage of a whole-genome sample (the resident workload keeps 0.3: its gene-window pairs are the expensive ones; at 0.3 every typed locus would see 2000x coverage)")
-    ap.add_argument("--e2e-threads", default="0,128", help="--decodeThreads values of the end-to-end runs (0 = the decoder's default: at most 32 threads)")
+    ap.add_argument("--e2e-threads", default="0,128", help="--decodeThreads values of the end-to-end runs (0 = the decoder's default: twice the CPUs the process may use, at most 32 threads)")
     ap.add_argument("--no-extras-but-e2e", action="store_true", help="of the measurements outside the timed region only the end-to-end run")
     ap.add_argument("--e2e-variants", default="", help="experiments: further end-to-end runs of the same sample under other environments, 'label:ENV=1 ENV2=x;label2:...'")
     ap.add_argument("--long-reads", type=int, default=50_000, help="reads of the long-read record (BASELINE config 5: 50 000 reads of ~10 kb; 0 = skip)")
@@ -659,7 +659,8 @@ def end_to_end(args, P, synth, w, mk):
                 label, _, envs = v.partition(":")
                 rv = one(0, dict(kv.split("=", 1) for kv in envs.split()))
                 res["variants"][label] = {k: rv.get(k) for k in ("value", "decode_s", "page_locking_and_insert_size_s", "alignment_and_typing_s", "window_fill_beside_the_gpu_s", "typing_phases", "process_wall_s", "error") if k in rv}
-        res.update({"gene_window_share_of_the_sample": args.e2e_frac_gene, "setup_s": {"graph_directory": t_dir, "sample_generation_and_bam": t_bam},
+        res.update({"host_cpus": {"hardware_threads": os.cpu_count(), "cgroup_cpu_quota": host_cpu_quota()},
+                    "gene_window_share_of_the_sample": args.e2e_frac_gene, "setup_s": {"graph_directory": t_dir, "sample_generation_and_bam": t_bam},
                     "what": "HLA-LA --action HLA: BAM bytes -> hla/* (decode on the stated host threads, batches of %d pairs two in flight on one GPU, typing of %d loci, result files); "
                             "value = pairs / (decode + page-locking and insert size + alignment and typing), the program's End-to-end line; graph loading and context creation are per process" % (ch, len(loci))})
         if len(runs) > 1:
@@ -699,6 +700,21 @@ def long_reads(args, P, synth, w):
         ctx.close()
 
 
+def host_cpu_quota():
+    """CPUs the process may keep busy under its control group's CFS quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us); None: no quota.  The GPU boxes of this
+    pool show 256 hardware threads and a quota of 16 CPUs: every host-side figure of this file (decoder, end to end, cpu_baseline) is a 16-CPU figure."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 and per > 0 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, synth, w, mk):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
@@ -708,11 +724,13 @@ def cpu_baseline(args, synth, w, mk):
     o = Oracle(w["graph"], w["contigs"], insert_mean=sb["insert_mean"], insert_sd=sb["insert_sd"], rng_seed=12345, max_columns=384)
     tc = time.perf_counter(); o.align_batch(sb); dtc = time.perf_counter() - tc
     nm = min(4 * nb, args.pairs)
+    quota = host_cpu_quota()
     mb = mk(nm, 1000)
     tc = time.perf_counter(); r = o.align_batch_mt(mb, 0, pairs_only=True); dtm = time.perf_counter() - tc
     return {"value": nb / dtc, "unit": "read pairs/s", "cores": 1, "kind": "port",
             "sample": f"first {nb} pairs of the same synthetic workload, oracle/hlala_oracle.cpp (C++ restatement, -O2, single thread as in HLA-LA.cpp:799), {dtc:.1f} s",
-            "all_cores": {"value": nm / dtm, "unit": "read pairs/s", "cores": int(r["threads"]), "host_cpus": os.cpu_count(),
+            "all_cores": {"value": nm / dtm, "unit": "read pairs/s", "cores": int(min(r["threads"], quota)) if quota else int(r["threads"]), "threads": int(r["threads"]), "host_cpus": os.cpu_count(),
+                          "cgroup_cpu_quota": quota,
                           "sample": f"first {nm} pairs, OpenMP parallel for schedule(dynamic,64) over pairs, {dtm:.1f} s"}}
 
 

@@ -688,7 +688,7 @@ EXPORTED_SYMBOLS = [
     "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
     "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_g_translate", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",
-    "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_unit_alignment_stats", "hlala_typer_write_summary", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_locus_write_pairs_file", "hlala_typer_end_output",
+    "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_kmer_keep_reads", "hlala_kmer_presence_kept", "hlala_kmer_forget_reads", "hlala_unit_alignment_stats", "hlala_typer_write_summary", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_locus_write_pairs_file", "hlala_typer_end_output",
 ]
 
 
@@ -805,6 +805,27 @@ class Context:
         self.lib.hlala_kmer_presence.argtypes = [C.c_void_p, C.c_void_p, c_u8p, C.c_int32, C.c_int32, C.c_char_p, c_u8p]
         self._check(self.lib.hlala_kmer_presence(self.h, batch.b, None if mask is None else mask.ctypes.data_as(c_u8p), k, n, buf, present.ctypes.data_as(c_u8p)), "hlala_kmer_presence")
         return present[:n]
+
+    def kmer_keep_reads(self, batch, pair_mask=None):
+        """hlala_kmer_keep_reads: the looked-at reads of `batch` stay on the device for kmer_presence_kept; returns the number of reads kept."""
+        mask = None if pair_mask is None else np.ascontiguousarray(pair_mask, np.uint8)
+        n = C.c_int64(0)
+        self.lib.hlala_kmer_keep_reads.argtypes = [C.c_void_p, C.c_void_p, c_u8p, C.POINTER(C.c_int64)]
+        self._check(self.lib.hlala_kmer_keep_reads(self.h, batch.b, None if mask is None else mask.ctypes.data_as(c_u8p), C.byref(n)), "hlala_kmer_keep_reads")
+        return n.value
+
+    def kmer_presence_kept(self, queries, k=31):
+        """hlala_kmer_presence_kept: kmer_presence over the union of the reads kept since the last kmer_forget_reads."""
+        n = len(queries)
+        buf = "".join(queries).encode(); assert len(buf) == n * k
+        present = np.zeros(max(1, n), np.uint8)
+        self.lib.hlala_kmer_presence_kept.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, c_u8p]
+        self._check(self.lib.hlala_kmer_presence_kept(self.h, k, n, buf, present.ctypes.data_as(c_u8p)), "hlala_kmer_presence_kept")
+        return present[:n]
+
+    def kmer_forget_reads(self):
+        self.lib.hlala_kmer_forget_reads.argtypes = [C.c_void_p]; self.lib.hlala_kmer_forget_reads.restype = None
+        self.lib.hlala_kmer_forget_reads(self.h)
 
     def estimate_insert_size(self, batch_in: dict):
         """processBAM::estimateInsertSize on the primaries of `batch_in` (hlala_estimate_insert_size)."""

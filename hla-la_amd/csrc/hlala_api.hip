@@ -79,6 +79,9 @@ struct hlala_ctx {
     int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
     // per-pair post-processing: coverage counters [L-1] and gene intervals
     int* d_cov = nullptr; int n_cov = 0; int* d_gene_first = nullptr; int* d_gene_last = nullptr; int n_genes = 0;
+    // reads kept for the k-mer questions (hlala_kmer_keep_reads): one chunk per call, blocks of the pool
+    struct KeptReads { uint8_t* store = nullptr; long long* start = nullptr; int* length = nullptr; int n = 0; };
+    std::vector<KeptReads> kept;
     std::string err;
 };
 
@@ -472,6 +475,7 @@ void hlala_destroy(hlala_ctx* c)
     DEV_GUARD(c);
     for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
+    for(hlala_ctx::KeptReads& kr : c->kept) { (void)hipFree(kr.store); (void)hipFree(kr.start); (void)hipFree(kr.length); }
     for(auto& kv : c->pool) (void)hipFree(kv.second);
     if(c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if(c->up) { (void)hipStreamSynchronize(c->up); (void)hipStreamDestroy(c->up); }
@@ -1484,16 +1488,11 @@ extern "C" int hlala_unit_alignment_stats(hlala_ctx* c, hlala_batch* b, hlala_un
     return done(HLALA_OK);
 }
 
-extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present)
+// canonical codes of the query k-mers and the sorted set of the distinct ones; a query with a character outside ACGT cannot occur in a read k-mer over ACGT
+static int kmer_queries(hlala_ctx* c, const char* who, int32_t k, int32_t n_queries, const char* queries, std::vector<u64>& canon, std::vector<u64>& uniq)
 {
-    DEV_GUARD(c);
-    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
-    if(!c || !b || n_queries < 0 || (n_queries > 0 && (!queries || !present))) return HLALA_E_ARG;
-    if(k < 1 || k > 31) { c->err = "hlala_kmer_presence: k must be in 1..31 (2-bit codes in one 64-bit word)"; return HLALA_E_ARG; }
-    if(n_queries == 0) return HLALA_OK;
-    // canonical codes of the queries; a query with a character outside ACGT cannot occur in a read k-mer over ACGT
-    std::vector<u64> canon((size_t)n_queries, ~0ull);
-    std::vector<u64> uniq;
+    if(k < 1 || k > 31) { c->err = std::string(who) + ": k must be in 1..31 (2-bit codes in one 64-bit word)"; return HLALA_E_ARG; }
+    canon.assign((size_t)n_queries, ~0ull); uniq.clear();
     for(int i = 0; i < n_queries; i++) {
         u64 f = 0, rc = 0; bool ok = true;
         for(int j = 0; j < k; j++) {
@@ -1505,18 +1504,97 @@ extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* 
         if(ok) { canon[i] = rc < f ? rc : f; uniq.push_back(canon[i]); }
     }
     std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-    if(uniq.size() > (size_t)hlala::KMER_QCAP) { c->err = "hlala_kmer_presence: more than 4096 distinct query k-mers in one call"; return HLALA_E_CAPACITY; }
+    if(uniq.size() > (size_t)hlala::KMER_QCAP) { c->err = std::string(who) + ": more than 4096 distinct query k-mers in one call"; return HLALA_E_CAPACITY; }
+    return HLALA_OK;
+}
+
+extern "C" int hlala_kmer_presence(hlala_ctx* c, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present)
+{
+    DEV_GUARD(c);
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
+    if(!c || !b || n_queries < 0 || (n_queries > 0 && (!queries || !present))) return HLALA_E_ARG;
+    std::vector<u64> canon, uniq;
+    int rc = kmer_queries(c, "hlala_kmer_presence", k, n_queries, queries, canon, uniq); if(rc) return rc;
+    if(n_queries == 0) return HLALA_OK;
     memset(present, 0, (size_t)n_queries);
     if(uniq.empty() || b->B.n_pairs <= 0) return HLALA_OK;
     std::vector<void*> tmp;
     auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
-    int rc = 0; u64* dQ = nullptr; uint8_t *dP = nullptr, *dMask = nullptr;
+    u64* dQ = nullptr; uint8_t *dP = nullptr, *dMask = nullptr;
     if((rc = dev_upload(c, tmp, uniq.data(), uniq.size(), &dQ)) || (rc = dev_alloc(c, tmp, uniq.size(), &dP, true))) return done(rc);
     if(pair_mask && (rc = dev_upload(c, tmp, pair_mask, (size_t)b->B.n_pairs, &dMask))) return done(rc);
     const int nReads = b->B.unpaired ? b->B.n_pairs : 2 * b->B.n_pairs;
     const unsigned grid = (unsigned)std::min<long long>((long long)nReads, (long long)c->stitch_grid);
     hipLaunchKernelGGL(k_kmer_presence, dim3(grid), dim3(64), 0, c->active, b->dB, (const uint8_t*)dMask, (int)k, (int)uniq.size(), (const u64*)dQ, dP);
     if((rc = check_launch(c, "k_kmer_presence"))) return done(rc);
+    std::vector<uint8_t> hp(uniq.size());
+    if((rc = dl(c, hp.data(), dP, uniq.size()))) return done(rc);
+    HIP_TRY_F(c, hipStreamSynchronize(c->active), done);
+    for(int i = 0; i < n_queries; i++) if(canon[i] != ~0ull) present[i] = hp[(size_t)(std::lower_bound(uniq.begin(), uniq.end(), canon[i]) - uniq.begin())];
+    return done(HLALA_OK);
+}
+
+extern "C" void hlala_kmer_forget_reads(hlala_ctx* c)
+{
+    if(!c) return;
+    DEV_GUARD(c);
+    if(!c->kept.empty() && c->rs) (void)hipStreamSynchronize(c->rs);
+    for(hlala_ctx::KeptReads& kr : c->kept) { pool_release(c, kr.store); pool_release(c, kr.start); pool_release(c, kr.length); }
+    c->kept.clear();
+}
+
+extern "C" int hlala_kmer_keep_reads(hlala_ctx* c, hlala_batch* b, const uint8_t* pair_mask, int64_t* n_reads_kept)
+{
+    DEV_GUARD(c);
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
+    if(!c || !b) return HLALA_E_ARG;
+    if(n_reads_kept) *n_reads_kept = 0;
+    if(b->B.n_pairs <= 0) return HLALA_OK;
+    std::vector<void*> tmp;
+    auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
+    int rc = 0; uint8_t* dMask = nullptr; unsigned long long* dTot = nullptr;
+    if((rc = dev_alloc(c, tmp, 4, &dTot, true))) return done(rc);
+    if(pair_mask && (rc = dev_upload(c, tmp, pair_mask, (size_t)b->B.n_pairs, &dMask))) return done(rc);
+    const int nReads = b->B.unpaired ? b->B.n_pairs : 2 * b->B.n_pairs;
+    hipLaunchKernelGGL(k_kmer_count_kept, dim3((unsigned)std::min<long long>(((long long)nReads + 255) / 256, 4096)), dim3(256), 0, c->active, b->dB, (const uint8_t*)dMask, dTot);
+    if((rc = check_launch(c, "k_kmer_count_kept"))) return done(rc);
+    unsigned long long tot[2] = {0, 0};
+    if((rc = dl(c, tot, dTot, 2))) return done(rc);
+    HIP_TRY_F(c, hipStreamSynchronize(c->active), done);
+    if(tot[0] == 0) return done(HLALA_OK);
+    hlala_ctx::KeptReads kr; kr.n = (int)tot[0];
+    void* p = nullptr;
+    if((rc = pool_malloc(c, &p, (size_t)tot[1] + 64))) return done(rc); kr.store = (uint8_t*)p;
+    if((rc = pool_malloc(c, &p, (size_t)tot[0] * sizeof(long long)))) { pool_release(c, kr.store); return done(rc); } kr.start = (long long*)p;
+    if((rc = pool_malloc(c, &p, (size_t)tot[0] * sizeof(int)))) { pool_release(c, kr.store); pool_release(c, kr.start); return done(rc); } kr.length = (int*)p;
+    c->kept.push_back(kr);                                                          // (owned by the context from here on)
+    const unsigned grid = (unsigned)std::min<long long>((long long)nReads, (long long)c->stitch_grid);
+    hipLaunchKernelGGL(k_kmer_keep, dim3(grid), dim3(64), 0, c->active, b->dB, (const uint8_t*)dMask, dTot + 2, kr.start, kr.length, kr.store);
+    if((rc = check_launch(c, "k_kmer_keep"))) return done(rc);
+    HIP_TRY_F(c, hipStreamSynchronize(c->active), done);                            // (the mask and the cursors go back to the pool)
+    if(n_reads_kept) *n_reads_kept = (int64_t)tot[0];
+    return done(HLALA_OK);
+}
+
+extern "C" int hlala_kmer_presence_kept(hlala_ctx* c, int32_t k, int32_t n_queries, const char* queries, uint8_t* present)
+{
+    DEV_GUARD(c);
+    ReaderScope rscope_(c, nullptr); if(rscope_.rc) return rscope_.rc;
+    if(!c || n_queries < 0 || (n_queries > 0 && (!queries || !present))) return HLALA_E_ARG;
+    std::vector<u64> canon, uniq;
+    int rc = kmer_queries(c, "hlala_kmer_presence_kept", k, n_queries, queries, canon, uniq); if(rc) return rc;
+    if(n_queries == 0) return HLALA_OK;
+    memset(present, 0, (size_t)n_queries);
+    if(uniq.empty() || c->kept.empty()) return HLALA_OK;
+    std::vector<void*> tmp;
+    auto done = [&](int r_) { for(void* p : tmp) pool_release(c, p); return r_; };
+    u64* dQ = nullptr; uint8_t* dP = nullptr;
+    if((rc = dev_upload(c, tmp, uniq.data(), uniq.size(), &dQ)) || (rc = dev_alloc(c, tmp, uniq.size(), &dP, true))) return done(rc);
+    for(const hlala_ctx::KeptReads& kr : c->kept) {
+        const unsigned grid = (unsigned)std::min<long long>((long long)kr.n, (long long)c->stitch_grid);
+        hipLaunchKernelGGL(k_kmer_presence_kept, dim3(grid), dim3(64), 0, c->active, (const long long*)kr.start, (const int*)kr.length, (const uint8_t*)kr.store, kr.n, (int)k, (int)uniq.size(), (const u64*)dQ, dP);
+        if((rc = check_launch(c, "k_kmer_presence_kept"))) return done(rc);
+    }
     std::vector<uint8_t> hp(uniq.size());
     if((rc = dl(c, hp.data(), dP, uniq.size()))) return done(rc);
     HIP_TRY_F(c, hipStreamSynchronize(c->active), done);
@@ -1546,16 +1624,46 @@ extern "C" int hlala_host_unregister(void* p)
 }
 static void seed_batch_unpin(hlala_seed_batch* S)
 {
-    std::vector<std::pair<void*, size_t>> arr; hlala_host::seed_batch_bulk_arrays(S, arr);
-    for(auto& a : arr) { if(hipHostUnregister(a.first) != hipSuccess) (void)hipGetLastError(); }
+    if(hlala_host::seed_batch_pin_lazy(S)) {
+        std::lock_guard<std::mutex> g(hlala_host::seed_batch_pin_mutex(S));
+        for(auto& r : hlala_host::seed_batch_pin_regions(S)) { if(hipHostUnregister(r.first) != hipSuccess) (void)hipGetLastError(); }
+        hlala_host::seed_batch_pin_regions(S).clear(); hlala_host::seed_batch_pin_cursor(S).clear();
+        hlala_host::seed_batch_pin_lazy(S) = false;
+    } else {
+        std::vector<std::pair<void*, size_t>> arr; hlala_host::seed_batch_bulk_arrays(S, arr);
+        for(auto& a : arr) { if(hipHostUnregister(a.first) != hipSuccess) (void)hipGetLastError(); }
+    }
     hlala_host::seed_batch_pinned_flag(S) = false;
+}
+// window by window (pin = 2): what the units before unit_end occupy of every bulk array, rounded up to 2 MB, beyond what is locked already.  Called by
+// hlala_seed_batch_window after it has filled the window; a refusal only costs speed (the upload of that window goes through the driver's staging buffer).
+static void seed_batch_pin_upto(hlala_seed_batch* S, int64_t unit_end)
+{
+    std::lock_guard<std::mutex> g(hlala_host::seed_batch_pin_mutex(S));
+    std::vector<std::pair<void*, size_t>> arr; std::vector<size_t> upto;
+    hlala_host::seed_batch_bulk_arrays(S, arr, unit_end, &upto);
+    std::vector<size_t>& cur = hlala_host::seed_batch_pin_cursor(S);
+    if(cur.size() != arr.size()) cur.assign(arr.size(), 0);
+    const size_t G = (size_t)2 << 20;
+    for(size_t i = 0; i < arr.size(); i++) {
+        const size_t target = std::min(arr[i].second, (upto[i] + G - 1) / G * G);
+        if(target <= cur[i]) continue;
+        void* p = (char*)arr[i].first + cur[i];
+        if(hipHostRegister(p, target - cur[i], hipHostRegisterDefault) == hipSuccess) hlala_host::seed_batch_pin_regions(S).emplace_back(p, target - cur[i]);
+        else (void)hipGetLastError();
+        cur[i] = target;
+    }
 }
 extern "C" int hlala_seed_batch_pin(hlala_seed_batch* S, int pin)
 {
-    if(!S) return HLALA_E_ARG;
+    if(!S || pin < 0 || pin > 2) return HLALA_E_ARG;
     bool& flag = hlala_host::seed_batch_pinned_flag(S);
-    if((pin != 0) == flag) return HLALA_OK;
-    if(!pin) { seed_batch_unpin(S); return HLALA_OK; }
+    const int now = !flag ? 0 : hlala_host::seed_batch_pin_lazy(S) ? 2 : 1;
+    if(pin == now) return HLALA_OK;
+    if(flag) seed_batch_unpin(S);
+    if(!pin) return HLALA_OK;
+    hlala_host::g_seed_batch_unpin = seed_batch_unpin;
+    if(pin == 2) { hlala_host::g_seed_batch_pin_upto = seed_batch_pin_upto; hlala_host::seed_batch_pin_lazy(S) = true; flag = true; return HLALA_OK; }
     std::vector<std::pair<void*, size_t>> arr; hlala_host::seed_batch_bulk_arrays(S, arr);
     for(size_t i = 0; i < arr.size(); i++)
         if(hipHostRegister(arr[i].first, arr[i].second, hipHostRegisterDefault) != hipSuccess) {
@@ -1563,7 +1671,7 @@ extern "C" int hlala_seed_batch_pin(hlala_seed_batch* S, int pin)
             for(size_t k = 0; k < i; k++) (void)hipHostUnregister(arr[k].first);
             return HLALA_E_DEVICE;
         }
-    flag = true; hlala_host::g_seed_batch_unpin = seed_batch_unpin;
+    flag = true;
     return HLALA_OK;
 }
 

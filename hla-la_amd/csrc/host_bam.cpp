@@ -70,6 +70,27 @@ void parallel_for(int64_t n, int T, F fn)
     if(err) std::rethrow_exception(err);
 }
 
+// fn(i, t) for i = 0 .. n-1 on T threads, the items handed out in ascending order, and beside() on the calling thread while they run.  beside(stop) follows
+// the items (it watches flags fn sets) and must return when `stop` turns true: a worker has failed and the remaining items will never be done.
+template <class F, class M>
+void parallel_for_beside(int64_t n, int T, F fn, M beside)
+{
+    std::atomic<bool> stop(false);
+    if(n <= 0 || T <= 1) { for(int64_t i = 0; i < n; i++) fn(i, 0); beside(stop); return; }
+    if(T > n) T = (int)n;
+    std::atomic<int64_t> next(0);
+    std::exception_ptr err, errMain; std::mutex em;
+    std::vector<std::thread> th;
+    for(int t = 0; t < T; t++) th.emplace_back([&, t]() {
+        try { for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
+        catch(...) { std::lock_guard<std::mutex> g(em); if(!err) err = std::current_exception(); next.store(n); stop.store(true); }
+    });
+    try { beside(stop); } catch(...) { errMain = std::current_exception(); next.store(n); }
+    for(auto& x : th) x.join();
+    if(err) std::rethrow_exception(err);
+    if(errMain) std::rethrow_exception(errMain);
+}
+
 struct Fail : std::runtime_error { using std::runtime_error::runtime_error; };
 
 uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -164,6 +185,8 @@ struct hlala_seed_batch {
     int64_t n_units = 0; int32_t unpaired = 0; int64_t examined = 0, n_seeds = 0, n_incomplete = 0;
     double seconds[6] = {0, 0, 0, 0, 0, 0}; int32_t threads = 1;
     bool pinned = false;
+    // page-locking window by window (hlala_seed_batch_pin(S, 2)): per bulk array the bytes locked so far, and the regions to unlock
+    bool pin_lazy = false; std::mutex pin_mu; std::vector<size_t> pin_cursor; std::vector<std::pair<void*, size_t>> pin_regions;
     // the decoder's working memory while units remain to be filled (hlala_seed_batch_window fills what it hands out); null once every unit is filled
     Work* work = nullptr; double fill_seconds = 0; std::mutex fill_mu;       // (the mutex lives here, not in the working memory it outlives)
     ~hlala_seed_batch() { if(work) { Work* w = work; work = nullptr; try { std::thread([w]() { delete w; }).detach(); } catch(...) { delete w; } } }
@@ -262,14 +285,43 @@ void ensure_filled(const hlala_seed_batch* Sc, int64_t u0, int64_t u1)
 }  // namespace
 
 namespace hlala_host {
-void seed_batch_bulk_arrays(hlala_seed_batch* S, std::vector<std::pair<void*, size_t>>& out)
+int host_cpu_budget()
 {
-    out.clear();
-    auto add = [&](void* p, size_t b) { if(p && b) out.emplace_back(p, b); };
-    add(S->read_bases.data(), S->read_bases.size()); add(S->read_bases_packed.data(), S->read_bases_packed.size()); add(S->read_quals.data(), S->read_quals.size());
-    add(S->chain_contig.data(), S->chain_contig.size() * 4); add(S->chain_pos.data(), S->chain_pos.size() * 4); add(S->chain_offset.data(), S->chain_offset.size() * 4);
-    add(S->chain_as.data(), S->chain_as.size() * 4); add(S->chain_reverse.data(), S->chain_reverse.size()); add(S->cigar.data(), S->cigar.size() * 4);
+    int hw = (int)std::thread::hardware_concurrency(); if(hw < 1) hw = 1;
+    double quota = 0;
+    if(FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                              // cgroup v2: "<quota|max> <period>"
+        char q[64]; double per = 0;
+        if(fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / per;
+        fclose(f);
+    } else {
+        double q = 0, per = 0;
+        if(FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if(fscanf(g, "%lf", &q) != 1) q = 0; fclose(g); }
+        if(FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if(fscanf(g, "%lf", &per) != 1) per = 0; fclose(g); }
+        if(q > 0 && per > 0) quota = q / per;
+    }
+    if(quota > 0) { const int c = (int)(quota + 0.999); if(c >= 1 && c < hw) hw = c; }
+    return hw;
 }
+// the bulk arrays of a seed batch (what a batch upload reads most of its bytes from) and, with `upto`, how many bytes of each the units before unit_end occupy
+void seed_batch_bulk_arrays(hlala_seed_batch* S, std::vector<std::pair<void*, size_t>>& out, int64_t unit_end, std::vector<size_t>* upto)
+{
+    out.clear(); if(upto) upto->clear();
+    size_t nBases = 0, nPacked = 0, nChains = 0, nCigar = 0;
+    if(upto) {
+        const size_t r = (size_t)std::max<int64_t>(0, std::min(unit_end, S->n_units)) * (size_t)(S->unpaired ? 1 : 2);
+        nBases = (size_t)S->read_off[r]; nPacked = (nBases + r + 1) >> 1; nChains = (size_t)S->chain_off[r]; nCigar = (size_t)S->cigar_off[nChains];
+    }
+    auto add = [&](void* p, size_t b, size_t u) { if(p && b) { out.emplace_back(p, b); if(upto) upto->push_back(std::min(u, b)); } };
+    add(S->read_bases.data(), S->read_bases.size(), nBases); add(S->read_bases_packed.data(), S->read_bases_packed.size(), nPacked); add(S->read_quals.data(), S->read_quals.size(), nBases);
+    add(S->chain_contig.data(), S->chain_contig.size() * 4, nChains * 4); add(S->chain_pos.data(), S->chain_pos.size() * 4, nChains * 4); add(S->chain_offset.data(), S->chain_offset.size() * 4, nChains * 4);
+    add(S->chain_as.data(), S->chain_as.size() * 4, nChains * 4); add(S->chain_reverse.data(), S->chain_reverse.size(), nChains); add(S->cigar.data(), S->cigar.size() * 4, nCigar * 4);
+}
+void seed_batch_bulk_arrays(hlala_seed_batch* S, std::vector<std::pair<void*, size_t>>& out) { seed_batch_bulk_arrays(S, out, 0, nullptr); }
+bool& seed_batch_pin_lazy(hlala_seed_batch* S) { return S->pin_lazy; }
+std::mutex& seed_batch_pin_mutex(hlala_seed_batch* S) { return S->pin_mu; }
+std::vector<size_t>& seed_batch_pin_cursor(hlala_seed_batch* S) { return S->pin_cursor; }
+std::vector<std::pair<void*, size_t>>& seed_batch_pin_regions(hlala_seed_batch* S) { return S->pin_regions; }
+void (*g_seed_batch_pin_upto)(hlala_seed_batch*, int64_t) = nullptr;      // set by the GPU library: page-locks what the units before unit_end occupy and is not locked yet
 bool& seed_batch_pinned_flag(hlala_seed_batch* S) { return S->pinned; }
 void (*g_seed_batch_unpin)(hlala_seed_batch*) = nullptr;       // set by the GPU library (hlala_seed_batch_pin): a pinned batch is unpinned before it is freed
 }  // namespace hlala_host
@@ -295,7 +347,7 @@ try {
     // 3.0 on 64, 3.3-3.7 on 128 -- the phases are passes over ~12 GB of inflated records bound by memory latency and by the first touch of their
     // working memory (4 KB pages fault in at 10 GB/s on that host whatever the number of threads); beyond 32 threads they only get in each other's way.
     // It is also the share of such a host that one of eight samples gets (BASELINE config 4).
-    if(T == 0) { T = (int)std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 32) T = 32; }
+    if(T == 0) { T = 2 * hlala_host::host_cpu_budget(); if(T > 32) T = 32; }      // (twice the CPUs: the phases wait on memory as much as they compute; beyond 32 threads they only get in each other's way)
     if(T > 1024) T = 1024;
     std::unique_ptr<hlala_seed_batch> S(new hlala_seed_batch());
     S->threads = T; S->unpaired = long_read_mode ? 1 : 0; S->packed = (flags & HLALA_SEEDS_PACKED) != 0;
@@ -357,7 +409,6 @@ try {
     // a round's buffer = [bytes of the record that straddles the previous round | this round's blocks]; buffers are kept (records point into them)
     const uint8_t* carryFrom = nullptr; size_t carry = 0; uint64_t recSeq = 0;
     double tInflate = 0, tParse = 0;
-    static const char SEQ16[] = "=ACMGRSVTWYHKDBN";
     for(size_t b0 = 0; b0 < blocks.size();) {
         size_t b1 = b0; size_t segBytes = 0;
         while(b1 < blocks.size() && (segBytes == 0 || segBytes + blocks[b1].isize <= SEG_BYTES)) { segBytes += blocks[b1].isize; b1++; }
@@ -366,46 +417,65 @@ try {
         uint8_t* const bufp = W->inflated.back().get(); const size_t bufn = carry + segBytes;
         if(carry) memcpy(bufp, carryFrom, carry);
         const uint64_t u0 = blocks[b0].uoff;
-        parallel_for((int64_t)(b1 - b0), T, [&](int64_t k, int) {
+        // The records of a round are found by hopping over their 4-byte length fields, one after the other from the round's first byte: the calling thread does
+        // that BESIDE the threads that inflate the round's blocks (handed out in ascending order), right behind the block they have completed last -- on its own
+        // after the inflate the hop was half of the parse phase, the one part of it that no thread count shortens.
+        const size_t nBlk = b1 - b0;
+        std::unique_ptr<std::atomic<uint8_t>[]> blockDone(new std::atomic<uint8_t>[nBlk]);
+        for(size_t k = 0; k < nBlk; k++) blockDone[k].store(0, std::memory_order_relaxed);
+        const uint8_t* d = bufp; const size_t dn = bufn;
+        size_t o = 0;
+        const bool lastSegment = b1 == blocks.size();
+        std::vector<size_t> recStart;
+        recStart.reserve(dn / 200 + 16);
+        parallel_for_beside((int64_t)nBlk, T, [&](int64_t k, int) {
             const Block& b = blocks[b0 + (size_t)k];
             z_stream zs; memset(&zs, 0, sizeof(zs));
             if(inflateInit2(&zs, -15) != Z_OK) throw Fail("inflateInit2 failed");
             zs.next_in = (Bytef*)(mf.p + b.coff); zs.avail_in = b.clen; zs.next_out = bufp + carry + (size_t)(b.uoff - u0); zs.avail_out = b.isize;
             const int rc = inflate(&zs, Z_FINISH); const uLong got = zs.total_out; inflateEnd(&zs);
             if(rc != Z_STREAM_END || got != b.isize) throw Fail("BGZF inflate failed");
+            blockDone[(size_t)k].store(1, std::memory_order_release);
+        }, [&](const std::atomic<bool>& stop) {
+            size_t ready = carry, kReady = 0;                   // bytes [0, ready) of the buffer are final: the carried bytes + the blocks before kReady
+            // true when bytes [o, o + k) are there to be read (waits for the blocks that hold them); false: the round ends before o + k, or a worker failed
+            auto avail = [&](size_t k) -> bool {
+                if(dn - o < k) return false;
+                while(ready < o + k) {
+                    if(kReady < nBlk && blockDone[kReady].load(std::memory_order_acquire)) { ready += blocks[b0 + kReady].isize; kReady++; continue; }
+                    if(stop.load()) return false;
+                    std::this_thread::yield();
+                }
+                return true;
+            };
+            if(!headerDone) {
+                // magic, header text, reference list (needs the whole header inside the first round: 1 GiB holds any reference dictionary)
+                auto need = [&](size_t k) { if(!avail(k)) throw Fail("truncated BAM header"); };
+                need(4); if(memcmp(d, "BAM\1", 4) != 0) throw Fail("not a BAM file"); o = 4;
+                need(4); const int32_t l_text = (int32_t)rd32(d + o); o += 4; if(l_text < 0 || l_text > (1 << 30)) throw Fail("truncated BAM header");
+                need((size_t)l_text); o += (size_t)l_text;
+                need(4); n_ref = (int32_t)rd32(d + o); o += 4; if(n_ref < 0) throw Fail("truncated BAM header");
+                refIntervals.resize((size_t)n_ref);
+                for(int i = 0; i < n_ref; i++) {
+                    if(!avail(4)) throw Fail("truncated BAM reference list");
+                    const int32_t l_name = (int32_t)rd32(d + o); o += 4;
+                    if(l_name < 1 || l_name > (1 << 20) || !avail((size_t)l_name + 4)) throw Fail("truncated BAM reference list");
+                    const std::string nm((const char*)d + o, strnlen((const char*)d + o, (size_t)l_name));
+                    o += (size_t)l_name + 4;
+                    auto it = intervalsOfRef.find(nm);
+                    if(it != intervalsOfRef.end()) refIntervals[(size_t)i] = it->second;
+                }
+                headerDone = true;
+            }
+            // record boundaries: hop over the length fields
+            while(avail(4)) {
+                const int32_t bs = (int32_t)rd32(d + o);
+                if(bs < 32 || bs > (1 << 28)) throw Fail("truncated BAM record");
+                if(dn - o - 4 < (size_t)bs) break;
+                recStart.push_back(o); o += 4 + (size_t)bs;
+            }
         });
         tInflate += since(t0); t0 = Clock::now();
-        const uint8_t* d = bufp; const size_t dn = bufn;
-        size_t o = 0;
-        const bool lastSegment = b1 == blocks.size();
-        if(!headerDone) {
-            // magic, header text, reference list (needs the whole header inside the first round: 1 GiB holds any reference dictionary)
-            auto need = [&](size_t k) { if(dn - o < k) throw Fail("truncated BAM header"); };
-            need(4); if(memcmp(d, "BAM\1", 4) != 0) throw Fail("not a BAM file"); o = 4;
-            need(4); const int32_t l_text = (int32_t)rd32(d + o); o += 4; if(l_text < 0 || l_text > (1 << 30)) throw Fail("truncated BAM header");
-            need((size_t)l_text); o += (size_t)l_text;
-            need(4); n_ref = (int32_t)rd32(d + o); o += 4; if(n_ref < 0) throw Fail("truncated BAM header");
-            refIntervals.resize((size_t)n_ref);
-            for(int i = 0; i < n_ref; i++) {
-                if(dn - o < 4) throw Fail("truncated BAM reference list");
-                const int32_t l_name = (int32_t)rd32(d + o); o += 4;
-                if(l_name < 1 || l_name > (1 << 20) || dn - o < (size_t)l_name + 4) throw Fail("truncated BAM reference list");
-                const std::string nm((const char*)d + o, strnlen((const char*)d + o, (size_t)l_name));
-                o += (size_t)l_name + 4;
-                auto it = intervalsOfRef.find(nm);
-                if(it != intervalsOfRef.end()) refIntervals[(size_t)i] = it->second;
-            }
-            headerDone = true;
-        }
-        // record boundaries: hop over the length fields
-        std::vector<size_t> recStart;
-        recStart.reserve((dn - o) / 200 + 16);
-        while(dn - o >= 4) {
-            const int32_t bs = (int32_t)rd32(d + o);
-            if(bs < 32 || bs > (1 << 28)) throw Fail("truncated BAM record");
-            if(dn - o - 4 < (size_t)bs) break;
-            recStart.push_back(o); o += 4 + (size_t)bs;
-        }
         if(lastSegment && o != dn) throw Fail("truncated BAM record");
         const size_t nRec = recStart.size();
         const int64_t CH = std::max<int64_t>(16, std::min<int64_t>(4096, (int64_t)nRec / ((int64_t)T * 8) + 1)); const int64_t nTasks = ((int64_t)nRec + CH - 1) / CH;      // (long reads: few, large records per round)
@@ -473,7 +543,7 @@ try {
                 }
             }
         });
-        if(getenv("HLALA_BAM_DEBUG")) fprintf(stderr, "bam-debug: round of %zu blocks, %zu records: inflate + hop + parse so far %.3f + %.3f s\n", b1 - b0, nRec, tInflate, tParse + since(t0));
+        if(getenv("HLALA_BAM_DEBUG")) fprintf(stderr, "bam-debug: round of %zu blocks, %zu records: inflate (the hop beside it) + parse so far %.3f + %.3f s\n", b1 - b0, nRec, tInflate, tParse + since(t0));
         recSeq += nRec;
         if(recSeq >= (1ull << 55)) throw Fail("more BAM records than the sequence numbers hold");
         // bytes of a record that continues in the next segment move to the front
@@ -613,6 +683,7 @@ extern "C" int hlala_seed_batch_window(const hlala_seed_batch* S, int64_t first_
     const int per = S->unpaired ? 1 : 2;
     const size_t r0 = (size_t)first_unit * (size_t)per, nr = (size_t)n_units * (size_t)per;
     try { ensure_filled(S, first_unit, first_unit + n_units); } catch(const std::exception& e_) { g_bam_error = std::string("hlala_seed_batch_window: ") + e_.what(); return HLALA_E_ARG; }
+    if(S->pin_lazy && hlala_host::g_seed_batch_pin_upto) hlala_host::g_seed_batch_pin_upto(const_cast<hlala_seed_batch*>(S), first_unit + n_units);      // (filled first: the pages exist when they are locked)
     const int64_t nb = S->read_off[r0 + nr] - S->read_off[r0], nc = S->chain_off[r0 + nr] - S->chain_off[r0];
     const int64_t ng = S->cigar_off[(size_t)S->chain_off[r0 + nr]] - S->cigar_off[(size_t)S->chain_off[r0]];
     if(nb > 0x7FFFFFFFll || nc > 0x7FFFFFFFll || ng > 0x7FFFFFFFll) {

@@ -479,7 +479,7 @@ static int write_pairs_table(const hlala_locus* L, const int C, const int32_t* o
                 }
             }
         };
-        unsigned T = std::thread::hardware_concurrency(); if(T < 1) T = 1; if(T > 64) T = 64; if((long long)T > nChunks) T = (unsigned)nChunks;
+        unsigned T = (unsigned)hlala_host::host_cpu_budget(); if(T > 64) T = 64; if((long long)T > nChunks) T = (unsigned)nChunks;
         std::vector<std::thread> th; for(unsigned t = 1; t < T; t++) th.emplace_back(work);
         work();
         for(std::thread& x : th) x.join();

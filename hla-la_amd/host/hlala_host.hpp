@@ -332,7 +332,9 @@ public:
         for(const std::string& e : errs) if(!e.empty()) throw std::runtime_error(e);
         hlala_seed_batch_timing(seeds_, decode_phase_seconds, &decode_threads);
         n_units = hlala_seed_batch_units(seeds_); longReadsMode = longReads;
-        (void)hlala_seed_batch_pin(seeds_, 1);                                        // page-locked: batch uploads are plain DMA (a refusal only costs speed)
+        // page-locked: batch uploads are plain DMA (a refusal only costs speed).  Window by window, when a window is handed out (filled, then locked): the 0.2 s that
+        // locking the whole sample took lay between the decode and the first batch; HLALA_PIN_WHOLE=1 locks everything here as before round 4
+        (void)hlala_seed_batch_pin(seeds_, std::getenv("HLALA_PIN_WHOLE") ? 1 : 2);
         if(!longReads && n_units == 0) throw std::runtime_error("estimateInsertSize: no complete read pair in " + BAM);
         if(!longReads) {                                                              // insert size from this sample
             hlala_batch_in first; window(0, n_units < 4000 ? (int32_t)n_units : 4000, first);
@@ -476,6 +478,7 @@ public:
         const int32_t nB = pB.n_batches();
         std::vector<std::vector<LocusPart>> parts((size_t)nB, std::vector<LocusPart>(acc.size()));
         std::vector<double> devAlign((size_t)nDev, 0.0); std::vector<int64_t> devErrors((size_t)nDev, 0); std::vector<std::string> devErr((size_t)nDev);
+        for(int d = 0; d < nDev; d++) hlala_kmer_forget_reads(pB.batch_ctx(d));
         const auto tAll = std::chrono::steady_clock::now();
         auto device_walk = [&](int d) {
             try {
@@ -492,6 +495,9 @@ public:
                     devAlign[(size_t)d] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     devErrors[(size_t)d] += bs.n_errors;
                     dchk(hlala_postprocess_pairs(cd, b, include.data() + u0), "hlala_postprocess_pairs");
+                    // the reads of the looked-at units stay on the device for the k-mer questions that follow the calls (HLATyper.cpp:999-1027 builds its index of
+                    // read k-mers in this walk too): a few per cent of a batch, copied device to device -- no batch is uploaded a second time
+                    dchk(hlala_kmer_keep_reads(cd, b, include.data() + u0, nullptr), "hlala_kmer_keep_reads");
                     // read alignment statistics (hla/HLATyper.cpp:1030-1125) and the per-pair quantities of the histogram lines
                     hlala_unit_stats_out usb{usValid.data() + u0, usStrands.data() + u0, usDist.data() + u0, usF.data() + 2 * u0, usW.data() + 2 * u0, usCols.data() + 2 * u0, usQ.data() + 2 * u0};
                     dchk(hlala_unit_alignment_stats(cd, b, &usb), "hlala_unit_alignment_stats");
@@ -590,35 +596,18 @@ public:
             }
         }
         timing.loci = lap(tLap);
-        // ---- which of those k-mers occur in the reads that went into typing: one more pass over the reads (a batch that was released is
-        // uploaded again, not aligned again), every device over its own batches
+        // ---- which of those k-mers occur in the reads that went into typing: asked of the reads every device kept while it walked its batches
         {
-            std::vector<std::string> kErr((size_t)nDev);
-            std::vector<std::vector<std::vector<uint8_t>>> devPresent((size_t)nDev);      // [device][2 * locus + allele][query]
-            auto kmer_walk = [&](int d) {
-                try {
-                    hlala_ctx* cd = pB.batch_ctx(d);
-                    std::vector<std::vector<uint8_t>>& mine = devPresent[(size_t)d];
-                    mine.resize(2 * res.size());
-                    for(size_t li = 0; li < res.size(); li++) for(int a = 0; a < 2; a++) mine[2 * li + (size_t)a].assign((size_t)res[li].nq[a] + 1, 0);
-                    for(int32_t bi = d; bi < nB; bi += nDev) {
-                        const size_t u0 = (size_t)pB.batch_first_unit(bi);
-                        hlala_batch* b = pB.acquire(bi, false);
-                        for(size_t li = 0; li < res.size(); li++) for(int a = 0; a < 2; a++) {
-                            Res& R = res[li];
-                            std::vector<uint8_t> pr((size_t)R.nq[a] + 1);
-                            if(hlala_kmer_presence(cd, b, include.data() + u0, k_for_kMer_index, R.nq[a], R.q[a].data(), pr.data()) != HLALA_OK) throw std::runtime_error(std::string("hlala_kmer_presence: ") + hlala_last_error(cd));
-                            for(int32_t i = 0; i < R.nq[a]; i++) mine[2 * li + (size_t)a][(size_t)i] |= pr[(size_t)i];
-                        }
-                        if(nB > 1) pB.release(bi);
-                    }
-                } catch(const std::exception& e) { kErr[(size_t)d] = e.what(); }
-            };
-            if(nDev == 1) kmer_walk(0);
-            else { std::vector<std::thread> th; for(int d = 0; d < nDev; d++) th.emplace_back(kmer_walk, d); for(std::thread& t : th) t.join(); }
-            for(const std::string& e : kErr) if(!e.empty()) throw std::runtime_error(e);
-            for(int d = 0; d < nDev; d++) for(size_t li = 0; li < res.size(); li++) for(int a = 0; a < 2; a++)
-                for(int32_t i = 0; i < res[li].nq[a]; i++) res[li].present[a][(size_t)i] |= devPresent[(size_t)d][2 * li + (size_t)a][(size_t)i];
+            struct Forget { mapper::processBAM& p; int n; ~Forget() { for(int d = 0; d < n; d++) hlala_kmer_forget_reads(p.batch_ctx(d)); } } forget{pB, nDev};
+            for(int d = 0; d < nDev; d++) {
+                hlala_ctx* cd = pB.batch_ctx(d);
+                for(size_t li = 0; li < res.size(); li++) for(int a = 0; a < 2; a++) {
+                    Res& R = res[li];
+                    std::vector<uint8_t> pr((size_t)R.nq[a] + 1);
+                    if(hlala_kmer_presence_kept(cd, k_for_kMer_index, R.nq[a], R.q[a].data(), pr.data()) != HLALA_OK) throw std::runtime_error(std::string("hlala_kmer_presence_kept: ") + hlala_last_error(cd));
+                    for(int32_t i = 0; i < R.nq[a]; i++) R.present[a][(size_t)i] |= pr[(size_t)i];
+                }
+            }
         }
         timing.kmers = lap(tLap);
         // ---- files

@@ -390,7 +390,10 @@ void* hlala_pinned_alloc(size_t bytes);
 void  hlala_pinned_free(void* p);
 int   hlala_host_register(void* p, size_t bytes);
 int   hlala_host_unregister(void* p);
-/* pins (pin != 0) or unpins the bulk arrays of a seed batch: read bases, qualities, chain records, CIGARs */
+/* pins or unpins (pin = 0) the bulk arrays of a seed batch: read bases, qualities, chain records, CIGARs.  pin = 1: everything now (touches every page
+ * of a sample whose windows are still unfilled); pin = 2: window by window -- hlala_seed_batch_window locks what the units up to the end of the window it
+ * hands out occupy (2 MB granules, after filling them), so that a caller who walks the sample in ascending windows pays for the locking beside the GPU's
+ * work on the batch before, not up front.  hlala_seed_batch_free unpins. */
 int   hlala_seed_batch_pin(hlala_seed_batch* s, int pin);
 
 /* ------------------------------------------------------------------------------------------
@@ -610,6 +613,14 @@ int  hlala_locus_cluster_kmers(const hlala_locus* l, int32_t cluster, int32_t k,
  * Runs on the GPU over the reads resident in the batch: no index is built, every read k-mer is looked up in the sorted query set.
  * k <= 31, queries over ACGT (others never match: the reads' N never equals an allele character); pair_mask as in hlala_locus_desc. */
 int  hlala_kmer_presence(hlala_ctx* ctx, hlala_batch* b, const uint8_t* pair_mask, int32_t k, int32_t n_queries, const char* queries, uint8_t* present);
+/* The same questions asked of reads that were KEPT on the device while their batches were resident: the reference builds its k-mer index while it walks
+ * the reads (HLATyper.cpp:999-1027) and asks after the calls (:2652-2688); a sample that goes through the GPU in batches has released most of them by
+ * then.  hlala_kmer_keep_reads appends the bases of the looked-at units of `b` (pair_mask as above; null: all) to the context's store -- a device-to-device
+ * copy of the few per cent of the reads that overlap the loci -- and hlala_kmer_presence_kept answers for the union of everything kept since the last
+ * hlala_kmer_forget_reads (also called by hlala_destroy).  present[q] equals the OR over the batches of what hlala_kmer_presence would return. */
+int  hlala_kmer_keep_reads(hlala_ctx* ctx, hlala_batch* b, const uint8_t* pair_mask, int64_t* n_reads_kept /* may be null */);
+int  hlala_kmer_presence_kept(hlala_ctx* ctx, int32_t k, int32_t n_queries, const char* queries, uint8_t* present);
+void hlala_kmer_forget_reads(hlala_ctx* ctx);
 
 /* Per-unit alignment statistics of a batch (the loop of hla/HLATyper.cpp:1043-1097 and the per-pair quantities of the pair test
  * :1404-1410): alignedReadPair_strandsValid, alignedReadPair_pairsDistanceInGraphLevels (alignerBase.cpp:246-283), alignmentFractionOK

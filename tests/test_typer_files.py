@@ -336,6 +336,44 @@ def test_kmer_presence_matches_a_hash_of_all_read_kmers(pkg):
         ctx.kmer_presence(gb, ["A" * 32], 32)
 
 
+@pytest.mark.gpu
+def test_kmer_presence_of_kept_reads_is_the_union_over_the_batches(pkg):
+    """hlala_kmer_keep_reads / hlala_kmer_presence_kept: the questions of HLATyper.cpp:2652-2688 asked after the batches were released --
+    equal to the OR of hlala_kmer_presence over the batches (paired batches with and without a mask, an unpaired one, an empty selection)."""
+    from tools import synth
+    rng = np.random.default_rng(18)
+    w = synth.make_world(seed=3, G=3000, k=1)
+    ctx = pkg.Context(w["graph"], w["contigs"], insert_mean=200.0, insert_sd=35.0)
+    assert np.array_equal(ctx.kmer_presence_kept(["A" * 31, "C" * 31]), [0, 0])                   # nothing kept yet
+    batches, masks = [], []
+    for i, n in enumerate((300, 170, 64)):
+        b = synth.make_batch(w, n, seed=20 + i)
+        b["read_bases"] = b["read_bases"].copy(); b["read_bases"][rng.integers(0, len(b["read_bases"]), 50)] = ord("N")
+        batches.append(b); masks.append([(np.arange(n) % 3 != 0).astype(np.uint8), None, np.zeros(n, np.uint8)][i])
+    for k in (31, 12):
+        ctx.kmer_forget_reads()
+        q = []
+        for b in batches:
+            for r in rng.integers(0, len(b["read_off"]) - 1, 60):
+                s = bytes(b["read_bases"][b["read_off"][r]:b["read_off"][r + 1]]).decode()
+                i = int(rng.integers(0, len(s) - k + 1)); q.append(s[i:i + k])
+        q += ["".join(rng.choice(list("ACGT"), k)) for _ in range(100)] + ["N" * k]
+        want = np.zeros(len(q), np.uint8); kept = []
+        for b, m in zip(batches, masks):
+            gb = ctx.batch(b)
+            want |= ctx.kmer_presence(gb, q, k, m)
+            kept.append(ctx.kmer_keep_reads(gb, m))
+            del gb                                                          # the batch is gone when the questions are asked
+        assert kept == [2 * int(masks[0].sum()), 2 * 170, 0]
+        got = ctx.kmer_presence_kept(q, k)
+        assert np.array_equal(got, want), k
+        assert 50 < want.sum() < len(q) - (50 if k > 20 else 0)
+    ctx.kmer_forget_reads()
+    assert ctx.kmer_presence_kept(q, 12).sum() == 0
+    with pytest.raises(pkg.HlalaError):
+        ctx.kmer_presence_kept(["A" * 32], 32)
+
+
 def synth_unit_stats(rng, n):
     f = np.where(rng.random(2 * n) < 0.4, 1.0, np.round(1 - rng.random(2 * n) * 0.1, 4))
     return dict(valid=(rng.random(n) < 0.95).astype(np.uint8), strands_valid=(rng.random(n) < 0.9).astype(np.uint8), distance=rng.integers(-100, 600, n).astype(np.int32),
