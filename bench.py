@@ -648,7 +648,7 @@ def end_to_end(args, P, synth, w, mk):
             return {"value": float(m.group(1)), "unit": "read pairs/s", "pairs": nch * ch, "bam_bytes": int(size), "decode_s": float(m.group(2)), "decode_threads": int(m.group(3)),
                     "page_locking_and_insert_size_s": float(m.group(4)), "alignment_and_typing_s": float(m.group(5)), "window_fill_beside_the_gpu_s": float(m.group(6)), "speed_line_pairs_per_s": float(sp.group(1)) if sp else None,
                     "process_wall_s": t_run, "whole_process_pairs_per_s": nch * ch / t_run, "typing_phases": ph.group(1) if ph else None,
-                    "log": [ln[:700] for ln in r.stdout.splitlines() if ("Seed extraction:" in ln or ln.startswith("End-to-end:"))] + [ln[:300] for ln in r.stderr.splitlines() if ln.startswith("bam-debug:")][:40],
+                    "log": [ln[:700] for ln in r.stdout.splitlines() if ("Seed extraction:" in ln or ln.startswith("End-to-end:"))] + [ln[:300] for ln in r.stderr.splitlines() if ln.startswith(("bam-debug:", "host-debug:"))][:60],
                     "loci": loci, "result_files": len(files), "calls": calls[:6]}
 
         runs = [one(int(t)) for t in str(args.e2e_threads).split(",") if t.strip() != ""]

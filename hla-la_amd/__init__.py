@@ -684,7 +684,7 @@ EXPORTED_SYMBOLS = [
     "hlala_kat_rand_r", "hlala_kat_exp", "hlala_abi_sizeof", "hlala_abi_version", "hlala_build_flags", "hlala_pack_bases", "hlala_call_locus", "hlala_exon_positions", "hlala_filter_positions", "hlala_estimate_insert_size", "hlala_graph_load_text", "hlala_graph_cache_save",
     "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
     "hlala_bam_extract_seeds", "hlala_bam_extract_seeds_mt", "hlala_bam_extract_seeds_opt", "hlala_seed_batch_counts", "hlala_seed_batch_desc", "hlala_seed_batch_window", "hlala_seed_batch_units", "hlala_seed_batch_name", "hlala_seed_batch_timing",
-    "hlala_seed_batch_free", "hlala_seed_batch_pin", "hlala_bam_last_error", "hlala_pinned_alloc", "hlala_pinned_free", "hlala_host_register", "hlala_host_unregister", "hlala_set_insert_size",
+    "hlala_seed_batch_free", "hlala_seed_batch_pin", "hlala_bam_last_error", "hlala_bam_inflate_engine", "hlala_pinned_alloc", "hlala_pinned_free", "hlala_host_register", "hlala_host_unregister", "hlala_set_insert_size",
     "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
     "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_g_translate", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",

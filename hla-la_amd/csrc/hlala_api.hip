@@ -201,6 +201,7 @@ static void pool_release(hlala_ctx* c, void* p)
     c->pool.emplace(it->second, p); c->pool_bytes += it->second;
 }
 
+constexpr size_t PIN_GRANULE = (size_t)64 << 20;
 template <class T>
 static int dev_upload(hlala_ctx* c, std::vector<void*>& allocs, const T* host, size_t n, T** out)
 {
@@ -209,7 +210,16 @@ static int dev_upload(hlala_ctx* c, std::vector<void*>& allocs, const T* host, s
     void* p = nullptr;
     { int rc_ = pool_malloc(c, &p, bytes); if(rc_) return rc_; }
     allocs.push_back(p);
-    if(n && host) HIP_TRY(c, hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c->active));
+    // A caller's array may be page-locked piece by piece (hlala_seed_batch_pin(S, 2): pieces that begin and end on multiples of PIN_GRANULE bytes of address); the
+    // runtime refuses a copy whose source straddles two registrations, so no copy crosses such an address -- a dozen copies per GB instead of one.
+    if(n && host) {
+        const char* src = (const char*)host; char* dst = (char*)p; size_t left = n * sizeof(T);
+        while(left) {
+            const size_t toEdge = PIN_GRANULE - (size_t)((uintptr_t)src & (PIN_GRANULE - 1)), k = left < toEdge ? left : toEdge;
+            HIP_TRY(c, hipMemcpyAsync(dst, src, k, hipMemcpyHostToDevice, c->active));
+            src += k; dst += k; left -= k;
+        }
+    }
     *out = (T*)p;
     return 0;
 }
@@ -1635,7 +1645,7 @@ static void seed_batch_unpin(hlala_seed_batch* S)
     }
     hlala_host::seed_batch_pinned_flag(S) = false;
 }
-// window by window (pin = 2): what the units before unit_end occupy of every bulk array, rounded up to 2 MB, beyond what is locked already.  Called by
+// window by window (pin = 2): what the units before unit_end occupy of every bulk array, rounded up to the next multiple of 64 MB, beyond what is locked already.  Called by
 // hlala_seed_batch_window after it has filled the window; a refusal only costs speed (the upload of that window goes through the driver's staging buffer).
 static void seed_batch_pin_upto(hlala_seed_batch* S, int64_t unit_end)
 {
@@ -1644,9 +1654,10 @@ static void seed_batch_pin_upto(hlala_seed_batch* S, int64_t unit_end)
     hlala_host::seed_batch_bulk_arrays(S, arr, unit_end, &upto);
     std::vector<size_t>& cur = hlala_host::seed_batch_pin_cursor(S);
     if(cur.size() != arr.size()) cur.assign(arr.size(), 0);
-    const size_t G = (size_t)2 << 20;
+    // pieces begin and end on multiples of PIN_GRANULE bytes of ADDRESS (the array's own start and end excepted): dev_upload cuts its copies there
     for(size_t i = 0; i < arr.size(); i++) {
-        const size_t target = std::min(arr[i].second, (upto[i] + G - 1) / G * G);
+        const uintptr_t base = (uintptr_t)arr[i].first;
+        const size_t target = std::min(arr[i].second, (size_t)(((base + upto[i] + PIN_GRANULE - 1) & ~(uintptr_t)(PIN_GRANULE - 1)) - base));
         if(target <= cur[i]) continue;
         void* p = (char*)arr[i].first + cur[i];
         if(hipHostRegister(p, target - cur[i], hipHostRegisterDefault) == hipSuccess) hlala_host::seed_batch_pin_regions(S).emplace_back(p, target - cur[i]);

@@ -41,6 +41,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <dlfcn.h>
 
 #include "../../include/hlala_gpu.h"
 #include "host_internal.h"
@@ -92,6 +93,38 @@ void parallel_for_beside(int64_t n, int T, F fn, M beside)
 }
 
 struct Fail : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// Raw DEFLATE of one BGZF block.  zlib's inflate is what the image links against; libdeflate (whole-buffer decoder, about twice as fast on BGZF blocks) is used
+// instead when the machine has its shared library -- looked up at run time, its three entry points declared here (the image ships the library without a header).
+// Both produce the same bytes; HLALA_BAM_ZLIB=1 keeps zlib (tests/test_bam.py decodes one file both ways).
+struct Inflater {
+    typedef void* (*AllocFn)(void); typedef int (*RunFn)(void*, const void*, size_t, void*, size_t, size_t*); typedef void (*FreeFn)(void*);
+    static AllocFn ld_alloc; static RunFn ld_run; static FreeFn ld_free; static std::once_flag once;
+    static void look()
+    {
+        if(getenv("HLALA_BAM_ZLIB")) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if(!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if(!h) return;
+        AllocFn a = (AllocFn)dlsym(h, "libdeflate_alloc_decompressor"); RunFn r = (RunFn)dlsym(h, "libdeflate_deflate_decompress"); FreeFn f = (FreeFn)dlsym(h, "libdeflate_free_decompressor");
+        if(a && r && f) { ld_alloc = a; ld_run = r; ld_free = f; }
+    }
+    void* d = nullptr;
+    Inflater() { std::call_once(once, look); if(ld_alloc) d = ld_alloc(); }
+    ~Inflater() { if(d) ld_free(d); }
+    Inflater(const Inflater&) = delete; Inflater& operator=(const Inflater&) = delete;
+    static const char* engine() { std::call_once(once, look); return ld_alloc ? "libdeflate" : "zlib"; }
+    void run(const uint8_t* in, size_t nin, uint8_t* out, size_t nout)
+    {
+        if(d) { size_t got = 0; if(ld_run(d, in, nin, out, nout, &got) != 0 || got != nout) throw Fail("BGZF inflate failed"); return; }
+        z_stream zs; memset(&zs, 0, sizeof(zs));
+        if(inflateInit2(&zs, -15) != Z_OK) throw Fail("inflateInit2 failed");
+        zs.next_in = (Bytef*)in; zs.avail_in = (uInt)nin; zs.next_out = out; zs.avail_out = (uInt)nout;
+        const int rc = inflate(&zs, Z_FINISH); const uLong got = zs.total_out; inflateEnd(&zs);
+        if(rc != Z_STREAM_END || got != nout) throw Fail("BGZF inflate failed");
+    }
+};
+Inflater::AllocFn Inflater::ld_alloc = nullptr; Inflater::RunFn Inflater::ld_run = nullptr; Inflater::FreeFn Inflater::ld_free = nullptr; std::once_flag Inflater::once;
 
 uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 
@@ -327,6 +360,7 @@ void (*g_seed_batch_unpin)(hlala_seed_batch*) = nullptr;       // set by the GPU
 }  // namespace hlala_host
 
 extern "C" const char* hlala_bam_last_error() { return g_bam_error.c_str(); }
+extern "C" const char* hlala_bam_inflate_engine() { return Inflater::engine(); }
 
 extern "C" int hlala_bam_extract_seeds(const char* path, int32_t n_intervals, const hlala_bam_interval* iv, int32_t long_read_mode, hlala_seed_batch** out)
 {
@@ -409,6 +443,10 @@ try {
     // a round's buffer = [bytes of the record that straddles the previous round | this round's blocks]; buffers are kept (records point into them)
     const uint8_t* carryFrom = nullptr; size_t carry = 0; uint64_t recSeq = 0;
     double tInflate = 0, tParse = 0;
+    std::vector<Inflater> inflaters((size_t)std::max(1, T));
+    // (tests: HLALA_BAM_TEST_HASH_BITS=k keeps the partition byte and k low bits of the name hashes -- many names per hash, the path that real samples never take)
+    uint64_t hashMask = ~0ull;
+    if(const char* e = getenv("HLALA_BAM_TEST_HASH_BITS")) { const int k = atoi(e); if(k >= 0 && k < 56) hashMask = (0xFFull << 56) | ((1ull << k) - 1); }
     for(size_t b0 = 0; b0 < blocks.size();) {
         size_t b1 = b0; size_t segBytes = 0;
         while(b1 < blocks.size() && (segBytes == 0 || segBytes + blocks[b1].isize <= SEG_BYTES)) { segBytes += blocks[b1].isize; b1++; }
@@ -428,13 +466,9 @@ try {
         const bool lastSegment = b1 == blocks.size();
         std::vector<size_t> recStart;
         recStart.reserve(dn / 200 + 16);
-        parallel_for_beside((int64_t)nBlk, T, [&](int64_t k, int) {
+        parallel_for_beside((int64_t)nBlk, T, [&](int64_t k, int t) {
             const Block& b = blocks[b0 + (size_t)k];
-            z_stream zs; memset(&zs, 0, sizeof(zs));
-            if(inflateInit2(&zs, -15) != Z_OK) throw Fail("inflateInit2 failed");
-            zs.next_in = (Bytef*)(mf.p + b.coff); zs.avail_in = b.clen; zs.next_out = bufp + carry + (size_t)(b.uoff - u0); zs.avail_out = b.isize;
-            const int rc = inflate(&zs, Z_FINISH); const uLong got = zs.total_out; inflateEnd(&zs);
-            if(rc != Z_STREAM_END || got != b.isize) throw Fail("BGZF inflate failed");
+            inflaters[(size_t)t].run(mf.p + b.coff, b.clen, bufp + carry + (size_t)(b.uoff - u0), b.isize);
             blockDone[(size_t)k].store(1, std::memory_order_release);
         }, [&](const std::atomic<bool>& stop) {
             size_t ready = carry, kReady = 0;                   // bytes [0, ready) of the buffer are final: the carried bytes + the blocks before kReady
@@ -444,7 +478,7 @@ try {
                 while(ready < o + k) {
                     if(kReady < nBlk && blockDone[kReady].load(std::memory_order_acquire)) { ready += blocks[b0 + kReady].isize; kReady++; continue; }
                     if(stop.load()) return false;
-                    std::this_thread::yield();
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));      // (asleep, not spinning: under a CPU quota a spinning thread is paid for by the inflate threads)
                 }
                 return true;
             };
@@ -533,7 +567,7 @@ try {
                         }
                         if(!haveAS) throw Fail("Can't get AS tag!");                               // assert(1 == 0), :4330-4332
                         nameLen = strnlen((const char*)rec + oName, l_read_name);
-                        hash = hash_name(rec + oName, nameLen);
+                        hash = hash_name(rec + oName, nameLen) & hashMask;
                     }
                     Rec r; r.hash = hash; r.order = ((seq0 + ri) << 8) | (uint64_t)(rank < 255 ? rank : 255); rank++;
                     r.rec = rec; r.contig = iv[ii].contig; r.pos = position - iv[ii].start_0based; r.as = as; r.l_seq = primary ? l_seq : 0;
@@ -543,7 +577,7 @@ try {
                 }
             }
         });
-        if(getenv("HLALA_BAM_DEBUG")) fprintf(stderr, "bam-debug: round of %zu blocks, %zu records: inflate (the hop beside it) + parse so far %.3f + %.3f s\n", b1 - b0, nRec, tInflate, tParse + since(t0));
+        if(getenv("HLALA_BAM_DEBUG")) fprintf(stderr, "bam-debug: round of %zu blocks, %zu records: inflate (%s; the hop beside it) + parse so far %.3f + %.3f s\n", b1 - b0, nRec, Inflater::engine(), tInflate, tParse + since(t0));
         recSeq += nRec;
         if(recSeq >= (1ull << 55)) throw Fail("more BAM records than the sequence numbers hold");
         // bytes of a record that continues in the next segment move to the front
@@ -561,24 +595,46 @@ try {
     std::vector<std::vector<Unit>> punits(NPART);         // all units of the partition (complete or not)
     std::vector<int64_t> pIncomplete(NPART, 0);
     auto rec_name = [&](const Rec& r) { return r.name(); };
+    // Sorted by (hash, file order) on 24-byte integer keys; the NAMES are looked at once per record afterwards, in sorted order and prefetched (they lie in the
+    // inflated file, a cache miss each: inside the sort's comparator they cost several misses per record).  Different names with one 64-bit hash -- never seen,
+    // possible -- put the run they share into (name, file order) order, as before.
+    struct Key { uint64_t hash, order; uint32_t idx; };
     parallel_for(NPART, T, [&](int64_t p, int) {
         std::vector<Rec>& R = precs[(size_t)p];
         size_t n = 0; for(const Arena& a : arenas) n += a.part[(size_t)p].size();
         if(n > 0xFFFFFFFFull) throw Fail("BAM too large: more than 2^32 records in one name partition");
-        R.reserve(n);
-        for(Arena& a : arenas) { std::vector<Rec>& v = a.part[(size_t)p]; R.insert(R.end(), v.begin(), v.end()); std::vector<Rec>().swap(v); }
-        std::sort(R.begin(), R.end(), [&](const Rec& a, const Rec& b) {
-            if(a.hash != b.hash) return a.hash < b.hash;
-            if(a.nameLen != b.nameLen || memcmp(rec_name(a), rec_name(b), a.nameLen) != 0) {          // equal 64-bit hashes of different names: order them by name
-                const size_t m = a.nameLen < b.nameLen ? a.nameLen : b.nameLen; const int c = memcmp(rec_name(a), rec_name(b), m);
-                return c != 0 ? c < 0 : a.nameLen < b.nameLen;
-            }
-            return a.order < b.order;
-        });
-        std::vector<Unit>& U = punits[(size_t)p];
-        for(size_t i = 0; i < R.size();) {
+        std::vector<Rec> in; in.reserve(n);
+        for(Arena& a : arenas) { std::vector<Rec>& v = a.part[(size_t)p]; in.insert(in.end(), v.begin(), v.end()); std::vector<Rec>().swap(v); }
+        std::vector<Key> keys(n);
+        for(size_t i = 0; i < n; i++) { keys[i].hash = in[i].hash; keys[i].order = in[i].order; keys[i].idx = (uint32_t)i; }
+        std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.hash != b.hash ? a.hash < b.hash : a.order < b.order; });
+        auto same_name = [&](const Rec& a, const Rec& b) { return a.nameLen == b.nameLen && memcmp(rec_name(a), rec_name(b), a.nameLen) == 0; };
+        std::vector<uint8_t> starts(n + 1, 0);              // starts[i]: record i of the sorted partition is the first of its name
+        for(size_t i = 0; i < n;) {
             size_t j = i + 1;
-            while(j < R.size() && R[j].hash == R[i].hash && R[j].nameLen == R[i].nameLen && memcmp(rec_name(R[j]), rec_name(R[i]), R[i].nameLen) == 0) j++;
+            while(j < n && keys[j].hash == keys[i].hash) j++;
+            if(j + 16 < n) __builtin_prefetch(&in[keys[j + 16].idx]);
+            if(j + 4 < n) __builtin_prefetch(rec_name(in[keys[j + 4].idx]));
+            bool oneName = true;
+            for(size_t k = i + 1; k < j && oneName; k++) oneName = same_name(in[keys[k].idx], in[keys[i].idx]);
+            starts[i] = 1;
+            if(!oneName) {
+                std::sort(keys.begin() + (ptrdiff_t)i, keys.begin() + (ptrdiff_t)j, [&](const Key& ka, const Key& kb) {
+                    const Rec& a = in[ka.idx]; const Rec& b = in[kb.idx];
+                    if(!same_name(a, b)) { const size_t m = a.nameLen < b.nameLen ? a.nameLen : b.nameLen; const int c = memcmp(rec_name(a), rec_name(b), m); return c != 0 ? c < 0 : a.nameLen < b.nameLen; }
+                    return ka.order < kb.order;
+                });
+                for(size_t k = i + 1; k < j; k++) starts[k] = same_name(in[keys[k].idx], in[keys[k - 1].idx]) ? 0 : 1;
+            }
+            i = j;
+        }
+        starts[n] = 1;
+        R.resize(n);
+        for(size_t i = 0; i < n; i++) R[i] = in[keys[i].idx];
+        std::vector<Unit>& U = punits[(size_t)p];
+        for(size_t i = 0; i < n;) {
+            size_t j = i + 1;
+            while(!starts[j]) j++;
             bool prim[2] = {false, false};
             for(size_t k = i; k < j; k++) if(R[k].flags & 2) prim[R[k].which] = true;                // takeAlignment, protoSeeds.cpp:23-36
             const bool complete = long_read_mode ? prim[0] : (prim[0] && prim[1]);                  // isComplete / isComplete_unpaired, protoSeeds.cpp:371-380

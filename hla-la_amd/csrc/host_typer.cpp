@@ -551,23 +551,38 @@ try {
         if(!pu.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_pileup_" + locus + ".txt");
         std::vector<int> exonFirstCol(L->exonLength.size(), 0);
         for(size_t e = 1; e < L->exonLength.size(); e++) exonFirstCol[e] = exonFirstCol[e - 1] + L->exonLength[e - 1];
+        // the columns that get a line, in the order of the file; their lines are formatted side by side (a class-I locus at 30x piles half a million positions,
+        // a dozen numbers each) in runs of columns of about equal numbers of piled positions, written one run after the other
+        struct ColRef { int e, col, c0; };
+        std::vector<ColRef> cols;
         for(size_t e = 0; e < L->exonLength.size(); e++) {
             const int c0 = exonFirstCol[e], c1 = c0 + L->exonLength[e];
             if(bOff[c1] == bOff[c0]) continue;                               // an exon without any piled position is not in pileUpPerPosition: no lines
-            for(int col = c0; col < c1; col++) {
+            for(int col = c0; col < c1; col++) cols.push_back(ColRef{(int)e, col, c0});
+        }
+        long long piledTotal = 0; for(const ColRef& cr : cols) piledTotal += bOff[(size_t)cr.col + 1] - bOff[cr.col];
+        long long perRun = 20000; if(const char* ev = getenv("HLALA_PILEUP_RUN")) { const long long v = atoll(ev); if(v > 0) perRun = v; }       // (tests: small runs)
+        const int K = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(8, std::max(2, hlala_host::host_cpu_budget())), piledTotal / perRun));
+        std::vector<size_t> cut((size_t)K + 1, cols.size()); cut[0] = 0;
+        { long long run = 0; int k = 1; for(size_t i = 0; i < cols.size() && k < K; i++) { run += bOff[(size_t)cols[i].col + 1] - bOff[cols[i].col]; if(run >= piledTotal * k / K) cut[(size_t)k++] = i + 1; } }
+        std::vector<std::string> text((size_t)K); std::vector<std::set<std::string>> used((size_t)K); std::vector<int> bad((size_t)K, 0);
+        auto format_run = [&](int k) {
+            std::string& out = text[(size_t)k];
+            for(size_t ci = cut[(size_t)k]; ci < cut[(size_t)k + 1]; ci++) {
+                const int e = cols[ci].e, col = cols[ci].col, c0 = cols[ci].c0;
                 const int n = bOff[(size_t)col + 1] - bOff[col];
-                pu << to_str((int)e) << "\t" << to_str(col - c0) << "\t" << to_str(n);
-                if(n == 0) { pu << "\n"; continue; }
+                out += to_str(e); out += '\t'; out += to_str(col - c0); out += '\t'; out += to_str(n);
+                if(n == 0) { out += '\n'; continue; }
                 std::map<std::string, std::vector<int>> alleleCounts;
                 std::string all;
                 for(int i = 0; i < n; i++) {
                     const int j = pile[(size_t)bOff[col] + i], r = readOf[j], m = pos->pos_mate[j] == 2 ? 1 : 0;
                     const std::string g = genotype(j);
                     std::string q;
-                    for(int k = pos->geno_off[j]; k < pos->geno_off[j + 1]; k++) {
-                        if(pos->geno_chars[k] == '_') continue;                                           // a gap carries no quality
+                    for(int k2 = pos->geno_off[j]; k2 < pos->geno_off[j + 1]; k2++) {
+                        if(pos->geno_chars[k2] == '_') continue;                                          // a gap carries no quality
                         if(!q.empty()) q += ", ";
-                        q += to_str((int)(char)pos->qual_chars[k]);
+                        q += to_str((int)(char)pos->qual_chars[k2]);
                     }
                     const int unit = pos->read_pair[r];
                     const char* n1 = in->unit_name_1[unit]; const char* n2 = in->unit_name_2 ? in->unit_name_2[unit] : "";
@@ -576,7 +591,7 @@ try {
                     all += g + " (" + q + ")" + " [" + "pairsDistance " + to_str((double)pos->read_distance[r]) + " | " + "alignmentLength " + to_str(pos->read_cols_nongap[2 * r + m]) + " | " +
                            to_str(phred_to_pcorrect(pos->pos_mapq[j])) + " | " + to_str(pos->read_mapq[2 * r + m]) + " " + to_str(pos->read_mapq[2 * r + m]) + " | " +
                            to_str(pos->read_weighted_ok[2 * r + m]) + " " + to_str(pos->read_weighted_ok[2 * r + (1 - m)]) + " | " + thisID + " " + otherID + "]";
-                    utilized.insert(thisID);
+                    used[(size_t)k].insert(thisID);
                     alleleCounts[g].push_back(pos->read_cols_nongap[2 * r + m]);
                 }
                 std::string summary;
@@ -584,12 +599,24 @@ try {
                     long long sum = 0; for(int l : a.second) sum += l;
                     const double avgL = (double)sum / (double)a.second.size();
                     const hlala_host::AlleleTally* t = tally(col, a.first);
-                    if(!t) return fail(HLALA_E_STATE, "hlala_locus_write_files: piled allele without counts");
+                    if(!t) { bad[(size_t)k] = 1; return; }
                     const int minStrand = std::min(t->reverse, t->count - t->reverse);
                     summary += a.first + "x" + to_str(a.second.size()) + "[" + to_str(avgL) + ";" + to_str((double)minStrand / (double)t->count) + ";" + to_str((double)t->from_first / (double)t->count) + "]";
                 }
-                pu << "\t" << all << "\t" << summary << "\n";
+                out += '\t'; out += all; out += '\t'; out += summary; out += '\n';
             }
+        };
+        if(K == 1) format_run(0);
+        else {
+            std::vector<std::thread> th; std::vector<std::exception_ptr> ex((size_t)K);
+            for(int k = 0; k < K; k++) th.emplace_back([&, k]() { try { format_run(k); } catch(...) { ex[(size_t)k] = std::current_exception(); } });
+            for(std::thread& t : th) t.join();
+            for(const std::exception_ptr& e : ex) if(e) std::rethrow_exception(e);
+        }
+        for(int k = 0; k < K; k++) {
+            if(bad[(size_t)k]) return fail(HLALA_E_STATE, "hlala_locus_write_files: piled allele without counts");
+            pu.write(text[(size_t)k].data(), (std::streamsize)text[(size_t)k].size());
+            utilized.insert(used[(size_t)k].begin(), used[(size_t)k].end());
         }
         std::ofstream ids((dir + "/R1_readIDs_" + locus + ".txt").c_str());
         if(!ids.is_open()) return fail(HLALA_E_ARG, "cannot write " + dir + "/R1_readIDs_" + locus + ".txt");

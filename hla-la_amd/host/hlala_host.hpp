@@ -12,6 +12,7 @@
 // Header-only, needs only a C++11 compiler and libhlala_gpu.so -- no HIP headers.
 #pragma once
 #include <dirent.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -22,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iostream>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -408,6 +410,26 @@ private:
 };
 }  // namespace mapper
 
+// Result tables that a GPU call fills completely (millions of doubles per locus): page-aligned, huge pages where the kernel grants them, NOT cleared -- a
+// std::vector zero-fills what the download overwrites a moment later, one 4 KB page fault after the other.
+template <class T>
+struct RawBuf {
+    T* p = nullptr; size_t n = 0;
+    RawBuf() {}
+    ~RawBuf() { std::free(p); }
+    RawBuf(const RawBuf&) = delete; RawBuf& operator=(const RawBuf&) = delete;
+    void alloc(size_t count)
+    {
+        std::free(p); p = nullptr; n = count;
+        const size_t H = (size_t)2 << 20, bytes = ((count ? count : 1) * sizeof(T) + H - 1) / H * H;
+        void* q = nullptr;
+        if(posix_memalign(&q, H, bytes) != 0 || !q) throw std::bad_alloc();
+        (void)madvise(q, bytes, MADV_HUGEPAGE);
+        p = (T*)q; p[0] = T();
+    }
+    T* data() { return p; } const T* data() const { return p; }
+};
+
 namespace hla {
 
 // hla::HLATyper: graph loci, exon files and allele clusters from the graph directory; HLATypeInference runs the per-locus chain on the
@@ -551,7 +573,7 @@ public:
         tchk(hlala_typer_write_summary(outputDirectory.c_str(), (int32_t)pB.n_units, pB.longReadsMode ? 1 : 0, include.data(), &us, pB.IS_mean, pB.IS_sd, minAlignmentLength_unpaired), "hlala_typer_write_summary");
         timing.summary = lap(tLap);
         // ---- per locus: filters -> likelihoods -> all pairs -> call
-        struct Res { hlala_exon_positions_out pos; std::vector<double> pairLL, misAvg, misMin, pNorm; std::vector<int32_t> order; hlala_call_out call; std::vector<char> q[2]; int32_t nq[2], nt[2]; std::vector<uint8_t> present[2]; };
+        struct Res { hlala_exon_positions_out pos; RawBuf<double> pairLL, misAvg, misMin, pNorm; RawBuf<int32_t> order; hlala_call_out call; std::vector<char> q[2]; int32_t nq[2], nt[2]; std::vector<uint8_t> present[2]; };
         std::vector<Res> res(acc.size());
         // (the all-pairs table of a locus -- millions of lines for class I -- is written by a thread of its own as soon as the locus is called: beside the typing
         // of the next locus and the k-mer pass; into the locus' directory under the output directory, see "files" below)
@@ -559,9 +581,12 @@ public:
         for(size_t li = 0; li < acc.size(); li++) tmpDir[li] = outputDirectory + "/.locus_" + std::to_string(li);
         std::vector<std::thread> pairWriters; std::vector<std::string> pairErr(acc.size());
         struct JoinAll { std::vector<std::thread>& t; ~JoinAll() { for(std::thread& x : t) if(x.joinable()) x.join(); } } joinPairWriters{pairWriters};
+        double lociClock[6] = {0, 0, 0, 0, 0, 0};      // filters, buffers, likelihoods, all pairs, call, k-mer lists (HLALA_HOST_DEBUG=1 prints them)
+        auto tL = std::chrono::steady_clock::now();
         for(size_t li = 0; li < acc.size(); li++) {
             Acc& A = acc[li]; Res& R = res[li];
             const size_t nR = A.read_pair.size(), nP = A.pos_exon.size();
+            tL = std::chrono::steady_clock::now();
             // (vectors may be empty: keep the pointers valid)
             A.read_pair.push_back(0); A.read_distance.push_back(0); A.pos_exon.push_back(0); A.pos_level.push_back(0); A.novel.push_back(0); A.mate.push_back(0); A.pmapq.push_back(0);
             A.geno.push_back(0); A.qual.push_back(0); for(int m = 0; m < 2; m++) { A.cols.push_back(0); A.wok.push_back(0); A.fok.push_back(0); A.rmapq.push_back(0); A.rrev.push_back(0); }
@@ -572,16 +597,22 @@ public:
             pos.geno_off = A.geno_off.data(); pos.geno_chars = A.geno.data(); pos.qual_chars = A.qual.data(); pos.read_reverse = A.rrev.data(); pos.read_mapq = A.rmapq.data();
             std::vector<uint8_t> use(nP + 1), ignored(nR + 1); hlala_filter_stats fs;
             if(hlala_filter_positions(&pos, &filterParams, use.data(), ignored.data(), &fs) != HLALA_OK) throw std::runtime_error("hlala_filter_positions failed");
+            lociClock[0] += lap(tL);
             // likelihoods: first genotype character, genotype length and first quality of every position (hla/HLATyper.cpp:2080-2277)
             std::vector<uint8_t> g0(nP + 1), q0(nP + 1); std::vector<int32_t> glen(nP + 1);
             for(size_t j = 0; j < nP; j++) { g0[j] = A.geno[A.geno_off[j]]; q0[j] = A.qual[A.geno_off[j]]; glen[j] = A.geno_off[j + 1] - A.geno_off[j]; }
             hlala_exon_in xin{A.li.n_clusters, A.li.n_columns, A.li.cluster_seq, (int32_t)nR, A.pos_off.data(), A.pos_exon.data(), g0.data(), glen.data(), q0.data(), use.data()};
             const size_t C = (size_t)A.li.n_clusters, nPairs = C * (C + 1) / 2;
-            std::vector<double> LL(C * nR + 1), marginal(C + 1); std::vector<int32_t> mism(C * nR + 1);
-            R.pairLL.assign(nPairs + 1, 0); R.misAvg.assign(nPairs + 1, 0); R.misMin.assign(nPairs + 1, 0); R.pNorm.assign(nPairs + 1, 0); R.order.assign(nPairs + 1, 0);
+            std::vector<double> marginal(C + 1); RawBuf<double> LL; RawBuf<int32_t> mism; LL.alloc(C * nR + 1); mism.alloc(C * nR + 1);
+            R.pairLL.alloc(nPairs + 1); R.misAvg.alloc(nPairs + 1); R.misMin.alloc(nPairs + 1); R.pNorm.alloc(nPairs + 1); R.order.alloc(nPairs + 1);
+            lociClock[1] += lap(tL);
             chk(hlala_exon_loglik(c, &xin, LL.data(), mism.data()), "hlala_exon_loglik");
+            lociClock[2] += lap(tL);
             chk(hlala_pair_loglik(c, LL.data(), mism.data(), A.li.n_clusters, (int32_t)nR, R.pairLL.data(), R.misAvg.data(), R.misMin.data()), "hlala_pair_loglik");
+            lociClock[3] += lap(tL);
             chk(hlala_call_locus(c, A.li.n_clusters, R.pairLL.data(), R.misAvg.data(), R.misMin.data(), R.order.data(), R.pNorm.data(), marginal.data(), &R.call), "hlala_call_locus");
+            lociClock[4] += lap(tL);
+            if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: locus " << A.locus << ": " << C << " clusters, " << nR << " reads, " << nP << " positions\n";
             if(::mkdir(tmpDir[li].c_str(), 0775) != 0 && errno != EEXIST) throw std::runtime_error("cannot create " + tmpDir[li]);
             pairWriters.emplace_back([&, li]() {
                 const Res& Rr = res[li];
@@ -594,8 +625,11 @@ public:
                 R.q[a].assign((size_t)R.nq[a] * k_for_kMer_index + 1, 0); R.present[a].assign((size_t)R.nq[a] + 1, 0);
                 tchk(hlala_locus_cluster_kmers(A.L, cl, k_for_kMer_index, R.q[a].data(), R.nq[a], &R.nq[a], &R.nt[a]), "hlala_locus_cluster_kmers");
             }
+            lociClock[5] += lap(tL);
         }
         timing.loci = lap(tLap);
+        if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: per-locus chain: filters " << lociClock[0] << ", buffers " << lociClock[1] << ", likelihoods " << lociClock[2] << ", all pairs " << lociClock[3]
+                                                       << ", call " << lociClock[4] << ", pair writer + k-mer lists " << lociClock[5] << " s\n";
         // ---- which of those k-mers occur in the reads that went into typing: asked of the reads every device kept while it walked its batches
         {
             struct Forget { mapper::processBAM& p; int n; ~Forget() { for(int d = 0; d < n; d++) hlala_kmer_forget_reads(p.batch_ctx(d)); } } forget{pB, nDev};
@@ -611,15 +645,21 @@ public:
         }
         timing.kmers = lap(tLap);
         // ---- files
-        std::vector<const char*> names(nU + 1, nullptr); for(size_t u = 0; u < nU; u++) names[u] = pB.readID((int64_t)u);
+        // (read names: the report looks up the units of the reads at the locus only -- a few thousand of the sample's millions; zero pages of the table that nobody touches stay unmapped)
+        struct Free { void operator()(const char** p) const { std::free((void*)p); } };
+        std::unique_ptr<const char*[], Free> names((const char**)std::calloc(nU + 1, sizeof(const char*)));
+        if(!names) throw std::bad_alloc();
+        for(const Acc& A : acc) for(int32_t u : A.read_pair) if(u >= 0 && (size_t)u < nU && !names[(size_t)u]) names[(size_t)u] = pB.readID((int64_t)u);
         // The loci write their files side by side (the all-pairs table of a class-I locus is millions of lines): every locus into a directory of its own
         // under the output directory; afterwards, in locus order, the rows it appended to the shared files (best guesses, histogram lines) are appended to
         // the real ones and its own files are moved up -- the bytes of one locus after the other.
         std::vector<bestGuess> out(acc.size()); std::string lociJoined;
         {
             std::vector<std::string> ferr(acc.size());
+            auto tF = std::chrono::steady_clock::now();
             for(std::thread& x : pairWriters) x.join();
             for(const std::string& e : pairErr) if(!e.empty()) throw std::runtime_error(e);
+            if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: files: names " << std::chrono::duration<double>(tF - tLap).count() << ", waiting for the all-pairs writers " << lap(tF) << " s\n";
             auto write_one = [&](size_t li) {
                 try {
                     Acc& A = acc[li]; Res& R = res[li];
@@ -627,7 +667,7 @@ public:
                     double covered[2];
                     for(int a = 0; a < 2; a++) { int hit = 0; for(int32_t i = 0; i < R.nq[a]; i++) hit += R.present[a][i]; covered[a] = R.nt[a] ? (double)hit / (double)R.nt[a] : -1; }
                     hlala_locus_report_in rin; std::memset(&rin, 0, sizeof(rin));
-                    rin.pos = &R.pos; rin.filter = &filterParams; rin.unit_name_1 = names.data(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.data(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
+                    rin.pos = &R.pos; rin.filter = &filterParams; rin.unit_name_1 = names.get(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.get(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
                     rin.n_clusters = A.li.n_clusters; rin.pair_ll = R.pairLL.data(); rin.mis_avg = R.misAvg.data(); rin.mis_min = R.misMin.data(); rin.order = R.order.data(); rin.p_normalized = R.pNorm.data(); rin.call = &R.call;
                     rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2; rin.pairs_file_done = 1;
                     rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = (int32_t)pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
@@ -647,6 +687,7 @@ public:
                 for(std::thread& t : th) t.join();
             }
             for(const std::string& e : ferr) if(!e.empty()) throw std::runtime_error(e);
+            if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: files: per-locus files " << lap(tF) << " s\n";
             for(size_t li = 0; li < acc.size(); li++) {
                 DIR* dd = opendir(tmpDir[li].c_str());
                 if(!dd) throw std::runtime_error("cannot open " + tmpDir[li]);

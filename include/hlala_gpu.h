@@ -382,6 +382,9 @@ const char* hlala_seed_batch_name(const hlala_seed_batch* s, int64_t unit);
 int  hlala_seed_batch_timing(const hlala_seed_batch* s, double* seconds6, int32_t* n_threads);
 void hlala_seed_batch_free(hlala_seed_batch* s);
 const char* hlala_bam_last_error(void);
+/* "libdeflate" or "zlib": what inflates the BGZF blocks in this process (libdeflate's shared library if the machine has it, looked up at run time; HLALA_BAM_ZLIB=1
+ * keeps zlib).  The decoded sample does not depend on it. */
+const char* hlala_bam_inflate_engine(void);
 
 /* Page-locked host memory for the buffers a caller hands to hlala_batch_create / hlala_batch_get_pairs_packed / the getters: transfers from and
  * to such buffers are true DMA (asynchronous, full PCIe rate); pageable buffers work everywhere, at about a third of the rate.  hlala_host_register
@@ -392,7 +395,7 @@ int   hlala_host_register(void* p, size_t bytes);
 int   hlala_host_unregister(void* p);
 /* pins or unpins (pin = 0) the bulk arrays of a seed batch: read bases, qualities, chain records, CIGARs.  pin = 1: everything now (touches every page
  * of a sample whose windows are still unfilled); pin = 2: window by window -- hlala_seed_batch_window locks what the units up to the end of the window it
- * hands out occupy (2 MB granules, after filling them), so that a caller who walks the sample in ascending windows pays for the locking beside the GPU's
+ * hands out occupy (64 MB granules, after filling them), so that a caller who walks the sample in ascending windows pays for the locking beside the GPU's
  * work on the batch before, not up front.  hlala_seed_batch_free unpins. */
 int   hlala_seed_batch_pin(hlala_seed_batch* s, int pin);
 

@@ -1,6 +1,7 @@
 """BAM reader + seed extraction (mapper/processBAM.cpp:703-864, 1945-1967, 4314-4334; protoSeeds.cpp:23-36, 371-380).
 The BAM file is written here following the SAM/BAM specification (BGZF blocks, little-endian records); the expected batch is derived
 from the same record list with the reference's rules written out in Python."""
+import os
 import ctypes as C
 import struct
 import zlib
@@ -219,6 +220,57 @@ def test_bam_round_trip_of_synthetic_batch(pkg, tmp_path):
     for r in range(2 * b["n_pairs"]):                                        # AS-descending inside every read
         a = got["chain_as"][got["chain_off"][r]:got["chain_off"][r + 1]]
         assert (np.diff(a) <= 0).all()
+
+
+def test_names_that_share_a_hash_are_told_apart(pkg, tmp_path, monkeypatch):
+    """The decoder groups the records of a read by a 64-bit hash of its name and looks at the names once per record; different names with one hash (forced here:
+    HLALA_BAM_TEST_HASH_BITS=0 keeps the partition byte only: 400 names on 256 hashes) are ordered by name within their run: the same sample as with full hashes."""
+    rng = np.random.default_rng(77)
+    refs, recs = make_records(rng, n_names=400)
+    p = tmp_path / "t.bam"; write_bam(p, refs, recs)
+    lib = C.CDLL(pkg.LIB_PATH)
+    intervals = [("chr6", 10000, 20000, 0), ("HLA-A*01", 0, 3999, 1), ("chr6", 19000, 30000, 2)]
+    for long_mode in (False, True):
+        monkeypatch.delenv("HLALA_BAM_TEST_HASH_BITS", raising=False)
+        want = pkg.bam_extract_seeds(lib, p, intervals, long_read_mode=long_mode, threads=3)
+        monkeypatch.setenv("HLALA_BAM_TEST_HASH_BITS", "0")
+        got = pkg.bam_extract_seeds(lib, p, intervals, long_read_mode=long_mode, threads=3)
+        assert got[1] == want[1] and got[2] == want[2] and len(want[1]) > 100
+        assert sorted(got[0]) == sorted(want[0])
+        for k in want[0]:
+            assert np.array_equal(np.asarray(got[0][k]), np.asarray(want[0][k])), k
+
+
+def test_inflate_engines_decode_the_same_sample(pkg, tmp_path):
+    """The BGZF blocks go through libdeflate where the machine has it and through zlib otherwise (HLALA_BAM_ZLIB=1: always): the same sample either way.
+    The other engine runs in a process of its own (the choice is made once per process)."""
+    import hashlib, subprocess, sys, textwrap
+    w, b, p, intervals = world_bam(tmp_path, 5, 300)
+    prog = textwrap.dedent("""
+        import sys, ctypes as C, hashlib, importlib, json
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module("hla-la_amd")
+        lib = C.CDLL(pkg.LIB_PATH)
+        lib.hlala_bam_inflate_engine.restype = C.c_char_p
+        got, names, cnt = pkg.bam_extract_seeds(lib, %r, %r, threads=3)
+        h = hashlib.sha256()
+        for k in sorted(got):
+            v = got[k]
+            h.update(k.encode()); h.update(v.tobytes() if hasattr(v, "tobytes") else repr(v).encode())
+        h.update(repr(names).encode()); h.update(repr(sorted(cnt.items())).encode())
+        print(json.dumps([lib.hlala_bam_inflate_engine().decode(), h.hexdigest()]))
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(p), [tuple(i) for i in intervals])
+    import json
+    out = {}
+    for label, env in (("default", {}), ("zlib", {"HLALA_BAM_ZLIB": "1"})):
+        e = dict(os.environ); e.pop("HLALA_BAM_ZLIB", None); e.update(env)
+        r = subprocess.run([sys.executable, "-c", prog], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[label] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["zlib"][0] == "zlib" and out["default"][0] in ("libdeflate", "zlib")
+    assert out["zlib"][1] == out["default"][1]
+    lib = C.CDLL(pkg.LIB_PATH); lib.hlala_bam_inflate_engine.restype = C.c_char_p
+    assert lib.hlala_bam_inflate_engine().decode() in ("libdeflate", "zlib")
 
 
 def test_packed_bases_of_the_decoder_and_the_packer(pkg, tmp_path):

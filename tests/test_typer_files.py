@@ -248,7 +248,9 @@ def tallies_of(e, prm, oracle_use_before_hc, long_mode):
 
 
 @pytest.mark.parametrize("seed,n_reads,long_mode,hc", [(21, 400, False, False), (22, 3000, False, True), (23, 1500, True, False)])
-def test_locus_files_match_reference_rules(pkg, oracle, tmp_path, seed, n_reads, long_mode, hc):
+def test_locus_files_match_reference_rules(pkg, oracle, tmp_path, seed, n_reads, long_mode, hc, monkeypatch):
+    if seed != 21:
+        monkeypatch.setenv("HLALA_PILEUP_RUN", "700")                     # the pile-up lines in several runs of columns formatted side by side, as for a real locus
     rng = np.random.default_rng(seed)
     segs, types, content, base, n_levels = make_graph_dir(tmp_path, rng)
     lib = C.CDLL(pkg.LIB_PATH)
