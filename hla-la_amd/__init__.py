@@ -688,7 +688,7 @@ EXPORTED_SYMBOLS = [
     "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
     "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_g_translate", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",
-    "hlala_locus_cluster_kmers", "hlala_kmer_presence", "hlala_kmer_keep_reads", "hlala_kmer_presence_kept", "hlala_kmer_forget_reads", "hlala_unit_alignment_stats", "hlala_typer_write_summary", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_locus_write_pairs_file", "hlala_typer_end_output",
+    "hlala_locus_cluster_kmers", "hlala_type_locus", "hlala_kmer_presence", "hlala_kmer_keep_reads", "hlala_kmer_presence_kept", "hlala_kmer_forget_reads", "hlala_unit_alignment_stats", "hlala_typer_write_summary", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_locus_write_pairs_file", "hlala_typer_end_output",
 ]
 
 
@@ -795,6 +795,20 @@ class Context:
                                               pn.ctypes.data_as(c_f64p), marg.ctypes.data_as(c_f64p), C.byref(out)), "hlala_call_locus")
         return dict(order=order, p_normalized=pn, cluster_marginal=marg, first_cluster=out.first_cluster, second_cluster=out.second_cluster,
                     first_marginal=out.first_marginal, second_p=out.second_p, ll_max=out.ll_max, max_pair=out.max_pair, n_sort_ties=out.n_sort_ties)
+
+    def type_locus(self, exon_in: dict, want_reads_table=True):
+        """hlala_type_locus: exon_loglik -> pair_loglik -> call_locus with the tables left on the device in between."""
+        s, keep = fill_struct(ExonIn, exon_in)
+        Cn, R = exon_in["n_clusters"], exon_in["n_reads"]
+        nP = Cn * (Cn + 1) // 2
+        LL = np.zeros(Cn * R, np.float64) if want_reads_table else None; mism = np.zeros(Cn * R, np.int32) if want_reads_table else None
+        pl, ma, mm, pn = [np.zeros(nP, np.float64) for _ in range(4)]; order = np.zeros(nP, np.int32); marg = np.zeros(Cn, np.float64); out = CallOut()
+        self.lib.hlala_type_locus.argtypes = [C.c_void_p, C.c_void_p, c_f64p, c_i32p, c_f64p, c_f64p, c_f64p, c_i32p, c_f64p, c_f64p, C.c_void_p]
+        self._check(self.lib.hlala_type_locus(self.h, C.byref(s), None if LL is None else LL.ctypes.data_as(c_f64p), None if mism is None else mism.ctypes.data_as(c_i32p),
+                                              pl.ctypes.data_as(c_f64p), ma.ctypes.data_as(c_f64p), mm.ctypes.data_as(c_f64p), order.ctypes.data_as(c_i32p),
+                                              pn.ctypes.data_as(c_f64p), marg.ctypes.data_as(c_f64p), C.byref(out)), "hlala_type_locus")
+        return dict(LL=None if LL is None else LL.reshape(Cn, R), mism=None if mism is None else mism.reshape(Cn, R), pairLL=pl, misAvg=ma, misMin=mm, order=order, p_normalized=pn, cluster_marginal=marg,
+                    first_cluster=out.first_cluster, second_cluster=out.second_cluster, first_marginal=out.first_marginal, second_p=out.second_p, ll_max=out.ll_max, max_pair=out.max_pair, n_sort_ties=out.n_sort_ties)
 
     def kmer_presence(self, batch, queries, k=31, pair_mask=None):
         """hlala_kmer_presence: which query k-mers (strings of length k) occur, in canonical form, in the reads of `batch`."""

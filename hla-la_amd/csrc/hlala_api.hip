@@ -1243,11 +1243,16 @@ static int typer_tables(hlala_ctx* c, std::vector<void*>& tmp, TyperTables** out
     return dev_upload(c, tmp, &T, 1, out);
 }
 
-extern "C" int hlala_exon_loglik(hlala_ctx* c, const hlala_exon_in* in, double* LL, int32_t* mism)
+// The three steps of a locus (hla/HLATyper.cpp:2067-2541) on tables that may stay on the device between them: `keep` (non-null) receives the device tables
+// of a step instead of the pool, and a step whose device inputs are given uploads nothing (hlala_type_locus).  Host outputs that are null are not downloaded.
+static void hand_over(std::vector<void*>& from, std::vector<void*>* to, void* p)
 {
-    DEV_GUARD(c);
-    ReaderScope rscope_(c, nullptr);
-    if(!c || !in || !LL || !mism) return HLALA_E_ARG;
+    for(size_t i = 0; i < from.size(); i++) if(from[i] == p) { from.erase(from.begin() + (ptrdiff_t)i); break; }
+    to->push_back(p);
+}
+static int exon_loglik_impl(hlala_ctx* c, const hlala_exon_in* in, double* LL, int32_t* mism, std::vector<void*>* keep, double** dLLout, int** dMout)
+{
+    if(!c || !in || (!keep && (!LL || !mism))) return HLALA_E_ARG;
     const int C = in->n_clusters, P = in->exon_length, R = in->n_reads;
     if(C < 0 || P < 0 || R < 0) { c->err = "negative sizes"; return HLALA_E_ARG; }
     if(C == 0 || R == 0) return HLALA_OK;
@@ -1271,23 +1276,33 @@ extern "C" int hlala_exon_loglik(hlala_ctx* c, const hlala_exon_in* in, double* 
     if((rc = dev_alloc(c, tmp, (size_t)C * R, &dM))) return done(rc);
     hipLaunchKernelGGL(k_exon_loglik, dim3((C + 255) / 256, R), dim3(256), 0, c->active, dT, C, P, R, dSeq, dOff, dExon, dG0, dGlen, dQ, dUse, dLL, dM);
     if((rc = check_launch(c, "k_exon_loglik"))) return done(rc);
-    if(hipMemcpyAsync(LL, dLL, (size_t)C * R * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess || hipMemcpyAsync(mism, dM, (size_t)C * R * 4, hipMemcpyDeviceToHost, c->active) != hipSuccess ||
-       hipStreamSynchronize(c->active) != hipSuccess) { c->err = "hlala_exon_loglik: download failed"; return done(HLALA_E_DEVICE); }
+    if((LL && hipMemcpyAsync(LL, dLL, (size_t)C * R * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess) || (mism && hipMemcpyAsync(mism, dM, (size_t)C * R * 4, hipMemcpyDeviceToHost, c->active) != hipSuccess) ||
+       hipStreamSynchronize(c->active) != hipSuccess) { c->err = "hlala_exon_loglik: download failed"; return done(HLALA_E_DEVICE); }       // (synchronised either way: the host arrays uploaded above are the caller's)
+    if(keep) { hand_over(tmp, keep, dLL); hand_over(tmp, keep, dM); *dLLout = dLL; *dMout = dM; }
     return done(HLALA_OK);
 }
-
-extern "C" int hlala_pair_loglik(hlala_ctx* c, const double* LL, const int32_t* mism, int32_t C, int32_t R, double* pairLL, double* misAvg, double* misMin)
+extern "C" int hlala_exon_loglik(hlala_ctx* c, const hlala_exon_in* in, double* LL, int32_t* mism)
 {
     DEV_GUARD(c);
     ReaderScope rscope_(c, nullptr);
-    if(!c || !LL || !mism || !pairLL || !misAvg || !misMin || C < 0 || R < 0) return HLALA_E_ARG;
+    if(!c || !in || !LL || !mism) return HLALA_E_ARG;
+    return exon_loglik_impl(c, in, LL, mism, nullptr, nullptr, nullptr);
+}
+
+static int pair_loglik_impl(hlala_ctx* c, const double* LL, const int32_t* mism, const double* dLLin, const int* dMin, int32_t C, int32_t R, double* pairLL, double* misAvg, double* misMin,
+                           std::vector<void*>* keep, double** dPout, double** dAout, double** dMnout)
+{
+    if(!c || (!dLLin && (!LL || !mism)) || !pairLL || !misAvg || !misMin || C < 0 || R < 0) return HLALA_E_ARG;
     if(C == 0) return HLALA_OK;
     std::vector<void*> tmp; int rc = 0;
     auto done = [&](int r) { for(void* p : tmp) pool_release(c, p); return r; };
     const size_t npairs = (size_t)C * (C + 1) / 2, nCR = (size_t)C * R;
     double *dLL, *dLLT, *dP, *dA, *dMn; int *dM, *dMT;
-    if((rc = dev_upload(c, tmp, LL, nCR, &dLL))) return done(rc);
-    if((rc = dev_upload(c, tmp, mism, nCR, &dM))) return done(rc);
+    if(dLLin) { dLL = const_cast<double*>(dLLin); dM = const_cast<int*>(dMin); }
+    else {
+        if((rc = dev_upload(c, tmp, LL, nCR, &dLL))) return done(rc);
+        if((rc = dev_upload(c, tmp, mism, nCR, &dM))) return done(rc);
+    }
     if((rc = dev_alloc(c, tmp, nCR, &dLLT))) return done(rc);
     if((rc = dev_alloc(c, tmp, nCR, &dMT))) return done(rc);
     if((rc = dev_alloc(c, tmp, npairs, &dP))) return done(rc);
@@ -1301,8 +1316,17 @@ extern "C" int hlala_pair_loglik(hlala_ctx* c, const double* LL, const int32_t* 
     hipLaunchKernelGGL(k_pair_loglik, dim3((C + 255) / 256, (C + PAIRLL_ROWS - 1) / PAIRLL_ROWS), dim3(256), 0, c->active, C, R, dLL, dLLT, dM, dMT, dP, dA, dMn);
     if((rc = check_launch(c, "k_pair_loglik"))) return done(rc);
     if(hipMemcpyAsync(pairLL, dP, npairs * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess || hipMemcpyAsync(misAvg, dA, npairs * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess ||
-       hipMemcpyAsync(misMin, dMn, npairs * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess || hipStreamSynchronize(c->active) != hipSuccess) { c->err = "hlala_pair_loglik: download failed"; return done(HLALA_E_DEVICE); }
+       hipMemcpyAsync(misMin, dMn, npairs * 8, hipMemcpyDeviceToHost, c->active) != hipSuccess || (!keep && hipStreamSynchronize(c->active) != hipSuccess)) { c->err = "hlala_pair_loglik: download failed"; return done(HLALA_E_DEVICE); }
+    if(keep) { hand_over(tmp, keep, dP); hand_over(tmp, keep, dA); hand_over(tmp, keep, dMn); *dPout = dP; *dAout = dA; *dMnout = dMn;
+               hand_over(tmp, keep, dLLT); hand_over(tmp, keep, dMT); }      // (not synchronised: the caller's next step runs behind this one on the same stream; its scratch stays allocated until then)
     return done(HLALA_OK);
+}
+extern "C" int hlala_pair_loglik(hlala_ctx* c, const double* LL, const int32_t* mism, int32_t C, int32_t R, double* pairLL, double* misAvg, double* misMin)
+{
+    DEV_GUARD(c);
+    ReaderScope rscope_(c, nullptr);
+    if(!c || !LL || !mism) return HLALA_E_ARG;
+    return pair_loglik_impl(c, LL, mism, nullptr, nullptr, C, R, pairLL, misAvg, misMin, nullptr, nullptr, nullptr, nullptr);
 }
 
 // ---- known-answer kernels
@@ -1365,12 +1389,10 @@ extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uin
     return HLALA_OK;
 }
 
-extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, const double* misAvg, const double* misMin,
-                                int32_t* order, double* p_normalized, double* cluster_marginal, hlala_call_out* out)
+static int call_locus_impl(hlala_ctx* c, int32_t C, const double* pairLL, const double* misAvg, const double* misMin, const double* dLLin, const double* dMAin, const double* dMMin,
+                          int32_t* order, double* p_normalized, double* cluster_marginal, hlala_call_out* out)
 {
-    DEV_GUARD(c);
-    ReaderScope rscope_(c, nullptr);
-    if(!c || C < 1 || !pairLL || !misAvg || !misMin || !out) return HLALA_E_ARG;
+    if(!c || C < 1 || (!dLLin && (!pairLL || !misAvg || !misMin)) || !out) return HLALA_E_ARG;
     if(C > 46000) { c->err = "hlala_call_locus: more than 46000 clusters (pair index exceeds 31 bits)"; return HLALA_E_CAPACITY; }
     const long long nP = (long long)C * (C + 1) / 2, n2 = 2 * nP;
     std::vector<void*> tmp;
@@ -1380,8 +1402,9 @@ extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, c
     u64 *dK1 = nullptr, *dK2 = nullptr, *dCK = nullptr, *dCK2 = nullptr; int *dI1 = nullptr, *dI2 = nullptr, *dC1 = nullptr, *dC2 = nullptr, *dTies = nullptr;
     long long* dPidx = nullptr; hlala_call_out* dOut = nullptr;
     const int NB = 1024;
-    if((rc = dev_upload(c, tmp, pairLL, (size_t)nP, &dLL)) || (rc = dev_upload(c, tmp, misAvg, (size_t)nP, &dMA)) || (rc = dev_upload(c, tmp, misMin, (size_t)nP, &dMM)) ||
-       (rc = dev_alloc(c, tmp, (size_t)nP, &dP)) || (rc = dev_alloc(c, tmp, (size_t)NB, &dPart)) || (rc = dev_alloc(c, tmp, (size_t)NB, &dPidx)) || (rc = dev_alloc(c, tmp, 4, &dScal)) ||
+    if(dLLin) { dLL = const_cast<double*>(dLLin); dMA = const_cast<double*>(dMAin); dMM = const_cast<double*>(dMMin); }
+    else if((rc = dev_upload(c, tmp, pairLL, (size_t)nP, &dLL)) || (rc = dev_upload(c, tmp, misAvg, (size_t)nP, &dMA)) || (rc = dev_upload(c, tmp, misMin, (size_t)nP, &dMM))) return done(rc);
+    if((rc = dev_alloc(c, tmp, (size_t)nP, &dP)) || (rc = dev_alloc(c, tmp, (size_t)NB, &dPart)) || (rc = dev_alloc(c, tmp, (size_t)NB, &dPidx)) || (rc = dev_alloc(c, tmp, 4, &dScal)) ||
        (rc = dev_alloc(c, tmp, (size_t)nP, &dK1)) || (rc = dev_alloc(c, tmp, (size_t)nP, &dK2)) || (rc = dev_alloc(c, tmp, (size_t)nP, &dI1)) || (rc = dev_alloc(c, tmp, (size_t)nP, &dI2)) ||
        (rc = dev_alloc(c, tmp, (size_t)nP, &dC1)) || (rc = dev_alloc(c, tmp, (size_t)nP, &dC2)) || (rc = dev_alloc(c, tmp, (size_t)n2, &dCK)) || (rc = dev_alloc(c, tmp, (size_t)n2, &dCK2)) ||
        (rc = dev_alloc(c, tmp, (size_t)n2, &dVal)) || (rc = dev_alloc(c, tmp, (size_t)n2, &dVal2)) || (rc = dev_alloc(c, tmp, (size_t)C, &dMarg)) || (rc = dev_alloc(c, tmp, 1, &dTies, true)) ||
@@ -1414,6 +1437,37 @@ extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, c
     if((rc = dl(c, order, dI1, (size_t)nP)) || (rc = dl(c, p_normalized, dP, (size_t)nP)) || (rc = dl(c, cluster_marginal, dMarg, (size_t)C)) || (rc = dl(c, out, dOut, 1))) return done(rc);
     HIP_TRY_F(c, hipStreamSynchronize(st), done);
     return done(HLALA_OK);
+}
+extern "C" int hlala_call_locus(hlala_ctx* c, int32_t C, const double* pairLL, const double* misAvg, const double* misMin,
+                                int32_t* order, double* p_normalized, double* cluster_marginal, hlala_call_out* out)
+{
+    DEV_GUARD(c);
+    ReaderScope rscope_(c, nullptr);
+    if(!c || !pairLL || !misAvg || !misMin) return HLALA_E_ARG;
+    return call_locus_impl(c, C, pairLL, misAvg, misMin, nullptr, nullptr, nullptr, order, p_normalized, cluster_marginal, out);
+}
+
+// hlala_exon_loglik -> hlala_pair_loglik -> hlala_call_locus with the tables left on the device in between: the per-read table (clusters x reads) is neither
+// downloaded nor uploaded again, the all-pairs tables go down once (the caller's files need them) and are not uploaded for the call.
+extern "C" int hlala_type_locus(hlala_ctx* c, const hlala_exon_in* in, double* LL, int32_t* mism, double* pairLL, double* misAvg, double* misMin,
+                                int32_t* order, double* p_normalized, double* cluster_marginal, hlala_call_out* out)
+{
+    DEV_GUARD(c);
+    ReaderScope rscope_(c, nullptr);
+    if(!c || !in || !pairLL || !misAvg || !misMin || !order || !p_normalized || !cluster_marginal || !out) return HLALA_E_ARG;
+    if(in->n_clusters < 1) { c->err = "hlala_type_locus: no clusters"; return HLALA_E_ARG; }
+    std::vector<void*> keep;
+    auto done = [&](int r_) { for(void* p : keep) pool_release(c, p); return r_; };
+    const int C = in->n_clusters, R = in->n_reads < 0 ? 0 : in->n_reads;
+    double *dLL = nullptr, *dP = nullptr, *dA = nullptr, *dMn = nullptr; int* dM = nullptr;
+    int rc = exon_loglik_impl(c, in, LL, mism, &keep, &dLL, &dM); if(rc) return done(rc);
+    if(!dLL) {                                                     // no reads at the locus: empty per-read tables (hlala_exon_loglik writes nothing either)
+        if((rc = dev_alloc(c, keep, 1, &dLL)) || (rc = dev_alloc(c, keep, 1, &dM))) return done(rc);
+    }
+    if((rc = pair_loglik_impl(c, nullptr, nullptr, dLL, dM, C, R, pairLL, misAvg, misMin, &keep, &dP, &dA, &dMn))) return done(rc);
+    rc = call_locus_impl(c, C, nullptr, nullptr, nullptr, dP, dA, dMn, order, p_normalized, cluster_marginal, out);       // (ends synchronised)
+    if(rc) (void)hipStreamSynchronize(c->active);
+    return done(rc);
 }
 
 extern "C" int hlala_exon_positions(hlala_ctx* c, hlala_batch* b, const hlala_locus_desc* L, hlala_exon_positions_out* o)

@@ -474,6 +474,8 @@ static int write_pairs_table(const hlala_locus* L, const int C, const int32_t* o
                 };
                 for(long long k = c * CH; k < k1; k++) {
                     const int cI = order[k];
+                    // (the lines come in `order`, their values lie at the pair's own index: five cache misses per line, asked for sixteen lines ahead)
+                    if(k + 16 < k1) { const int cF = order[k + 16]; __builtin_prefetch(&c1Of[cF]); __builtin_prefetch(&c2Of[cF]); __builtin_prefetch(&p_normalized[cF]); __builtin_prefetch(&pair_ll[cF]); __builtin_prefetch(&mis_avg[cF]); }
                     out += L->clusterId[c1Of[cI]]; out += '/'; out += L->clusterId[c2Of[cI]]; out += '\t';
                     num(p_normalized[cI]); out += '\t'; num(pair_ll[cI]); out += '\t'; num(mis_avg[cI]); out += '\n';
                 }

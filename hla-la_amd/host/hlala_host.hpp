@@ -603,15 +603,12 @@ public:
             for(size_t j = 0; j < nP; j++) { g0[j] = A.geno[A.geno_off[j]]; q0[j] = A.qual[A.geno_off[j]]; glen[j] = A.geno_off[j + 1] - A.geno_off[j]; }
             hlala_exon_in xin{A.li.n_clusters, A.li.n_columns, A.li.cluster_seq, (int32_t)nR, A.pos_off.data(), A.pos_exon.data(), g0.data(), glen.data(), q0.data(), use.data()};
             const size_t C = (size_t)A.li.n_clusters, nPairs = C * (C + 1) / 2;
-            std::vector<double> marginal(C + 1); RawBuf<double> LL; RawBuf<int32_t> mism; LL.alloc(C * nR + 1); mism.alloc(C * nR + 1);
+            std::vector<double> marginal(C + 1);
             R.pairLL.alloc(nPairs + 1); R.misAvg.alloc(nPairs + 1); R.misMin.alloc(nPairs + 1); R.pNorm.alloc(nPairs + 1); R.order.alloc(nPairs + 1);
             lociClock[1] += lap(tL);
-            chk(hlala_exon_loglik(c, &xin, LL.data(), mism.data()), "hlala_exon_loglik");
+            // per-read likelihoods -> all pairs -> call, the tables left on the device in between (the per-read table of a class-I locus is 100 MB that nobody on the host reads)
+            chk(hlala_type_locus(c, &xin, nullptr, nullptr, R.pairLL.data(), R.misAvg.data(), R.misMin.data(), R.order.data(), R.pNorm.data(), marginal.data(), &R.call), "hlala_type_locus");
             lociClock[2] += lap(tL);
-            chk(hlala_pair_loglik(c, LL.data(), mism.data(), A.li.n_clusters, (int32_t)nR, R.pairLL.data(), R.misAvg.data(), R.misMin.data()), "hlala_pair_loglik");
-            lociClock[3] += lap(tL);
-            chk(hlala_call_locus(c, A.li.n_clusters, R.pairLL.data(), R.misAvg.data(), R.misMin.data(), R.order.data(), R.pNorm.data(), marginal.data(), &R.call), "hlala_call_locus");
-            lociClock[4] += lap(tL);
             if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: locus " << A.locus << ": " << C << " clusters, " << nR << " reads, " << nP << " positions\n";
             if(::mkdir(tmpDir[li].c_str(), 0775) != 0 && errno != EEXIST) throw std::runtime_error("cannot create " + tmpDir[li]);
             pairWriters.emplace_back([&, li]() {
@@ -628,8 +625,7 @@ public:
             lociClock[5] += lap(tL);
         }
         timing.loci = lap(tLap);
-        if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: per-locus chain: filters " << lociClock[0] << ", buffers " << lociClock[1] << ", likelihoods " << lociClock[2] << ", all pairs " << lociClock[3]
-                                                       << ", call " << lociClock[4] << ", pair writer + k-mer lists " << lociClock[5] << " s\n";
+        if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: per-locus chain: filters " << lociClock[0] << ", buffers " << lociClock[1] << ", likelihoods + all pairs + call " << lociClock[2] << ", pair writer + k-mer lists " << lociClock[5] << " s\n";
         // ---- which of those k-mers occur in the reads that went into typing: asked of the reads every device kept while it walked its batches
         {
             struct Forget { mapper::processBAM& p; int n; ~Forget() { for(int d = 0; d < n; d++) hlala_kmer_forget_reads(p.batch_ctx(d)); } } forget{pB, nDev};
@@ -649,6 +645,7 @@ public:
         struct Free { void operator()(const char** p) const { std::free((void*)p); } };
         std::unique_ptr<const char*[], Free> names((const char**)std::calloc(nU + 1, sizeof(const char*)));
         if(!names) throw std::bad_alloc();
+        const auto tNames0 = std::chrono::steady_clock::now();
         for(const Acc& A : acc) for(int32_t u : A.read_pair) if(u >= 0 && (size_t)u < nU && !names[(size_t)u]) names[(size_t)u] = pB.readID((int64_t)u);
         // The loci write their files side by side (the all-pairs table of a class-I locus is millions of lines): every locus into a directory of its own
         // under the output directory; afterwards, in locus order, the rows it appended to the shared files (best guesses, histogram lines) are appended to
@@ -659,7 +656,7 @@ public:
             auto tF = std::chrono::steady_clock::now();
             for(std::thread& x : pairWriters) x.join();
             for(const std::string& e : pairErr) if(!e.empty()) throw std::runtime_error(e);
-            if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: files: names " << std::chrono::duration<double>(tF - tLap).count() << ", waiting for the all-pairs writers " << lap(tF) << " s\n";
+            if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: files: names " << std::chrono::duration<double>(tF - tLap).count() << " (of which after the table was allocated " << std::chrono::duration<double>(tF - tNames0).count() << "), waiting for the all-pairs writers " << lap(tF) << " s\n";
             auto write_one = [&](size_t li) {
                 try {
                     Acc& A = acc[li]; Res& R = res[li];

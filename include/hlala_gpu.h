@@ -555,6 +555,12 @@ int  hlala_call_locus(hlala_ctx* ctx, int32_t C, const double* pairLL, const dou
                       int32_t* order /* [C(C+1)/2] or NULL */, double* p_normalized /* [C(C+1)/2] or NULL */,
                       double* cluster_marginal /* [C] or NULL */, hlala_call_out* out);
 
+/* The three steps of a locus in one call -- hlala_exon_loglik, hlala_pair_loglik, hlala_call_locus (HLATyper.cpp:2067-2541) -- with the tables left on the
+ * device in between: the per-read table (clusters x reads; LL / mism may be NULL: not downloaded) is not moved at all, the all-pairs tables come down once and
+ * are not uploaded again for the call.  Every output equals, bit for bit, what the three calls return one after the other. */
+int  hlala_type_locus(hlala_ctx* ctx, const hlala_exon_in* in, double* LL /* [C*R] or NULL */, int32_t* mism /* [C*R] or NULL */,
+                      double* pairLL, double* misAvg, double* misMin /* [C(C+1)/2] each */, int32_t* order, double* p_normalized, double* cluster_marginal, hlala_call_out* out);
+
 /* Reference contigs of a graph directory (host code): one contig per row of <graph_dir>/sequences.txt -- the stretch
  * [Start_1based, Stop_1based] of the BAM reference it names (column Chr, or PRG_<SequenceID>; extended_reference_genome == 0: the whole
  * sequence of mapping_PRGonly/referenceGenome.fa) with the levels of translation/<SequenceID>.txt (processBAM::initBAM

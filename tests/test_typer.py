@@ -57,3 +57,39 @@ def test_typer_kernels_match_oracle(pkg, oracle, C, R, seed):
     assert np.allclose(gpl, epl, rtol=1e-9, atol=0)                                   # north star: summed log-likelihoods within 1e-6 relative
     # the best pair is the same
     assert int(np.argmax(gpl)) == int(np.argmax(epl))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,R,seed", [(200, 300, 5), (1, 5, 7), (513, 64, 8), (3000, 400, 9)])
+def test_type_locus_equals_the_three_calls(pkg, C, R, seed):
+    """hlala_type_locus (the per-read and all-pairs tables stay on the device between the steps) returns, bit for bit, what hlala_exon_loglik ->
+    hlala_pair_loglik -> hlala_call_locus return one after the other (hla/HLATyper.cpp:2067-2541)."""
+    loc = synth.make_locus(seed=seed, n_clusters=C, n_reads=R)
+    w = synth.make_world(seed=1, G=300, k=1)
+    ctx = pkg.Context(w["graph"], w["contigs"])
+    LL, mism = ctx.exon_loglik(loc)
+    pl, ma, mn = ctx.pair_loglik(LL, mism)
+    call = ctx.call_locus(pl, ma, mn)
+    for want_table in (True, False):
+        got = ctx.type_locus(loc, want_reads_table=want_table)
+        if want_table:
+            assert np.array_equal(got["LL"], LL) and np.array_equal(got["mism"], mism)
+        else:
+            assert got["LL"] is None
+        assert np.array_equal(got["pairLL"], pl) and np.array_equal(got["misAvg"], ma) and np.array_equal(got["misMin"], mn)
+        for k in ("order", "p_normalized", "cluster_marginal"):
+            assert np.array_equal(got[k], call[k]), k
+        for k in ("first_cluster", "second_cluster", "first_marginal", "second_p", "ll_max", "max_pair", "n_sort_ties"):
+            assert got[k] == call[k], k
+
+
+@pytest.mark.gpu
+def test_type_locus_without_reads(pkg):
+    loc = synth.make_locus(seed=3, n_clusters=40, n_reads=0)
+    w = synth.make_world(seed=1, G=300, k=1)
+    ctx = pkg.Context(w["graph"], w["contigs"])
+    LL, mism = ctx.exon_loglik(loc)
+    pl, ma, mn = ctx.pair_loglik(LL, mism)
+    call = ctx.call_locus(pl, ma, mn)
+    got = ctx.type_locus(loc)
+    assert np.array_equal(got["pairLL"], pl) and np.array_equal(got["order"], call["order"]) and got["first_cluster"] == call["first_cluster"] and got["second_cluster"] == call["second_cluster"]

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 make -s -C oracle 2>&1 | tail -1; make -s -C tools/graphm 2>&1 | tail -1
-timeout 1500 python -m pytest tests/test_typer_files.py tests/test_end_to_end.py tests/test_hla_la_binary.py tests/test_bam.py tests/test_bam_scale.py tests/test_insert_size.py -m gpu -q -x > gpurun_out/r4_host_tests.log 2>&1
+timeout 1500 python -m pytest tests/test_typer.py tests/test_typer_files.py tests/test_end_to_end.py tests/test_hla_la_binary.py tests/test_bam.py tests/test_bam_scale.py tests/test_insert_size.py -m gpu -q -x > gpurun_out/r4_host_tests.log 2>&1
 echo "host tests rc=$?"; tail -4 gpurun_out/r4_host_tests.log
 HLALA_HOST_DEBUG=1 HLALA_BAM_DEBUG=1 timeout 1500 python bench.py --steps 6 --warmup 2 --resident-steps 0 --long-reads 0 --no-cpu-baseline --no-extras-but-e2e --e2e-threads 0,16 --e2e-variants "zlib:HLALA_BAM_ZLIB=1;again:HLALA_X=1" > gpurun_out/r4_e2e_host.log 2> gpurun_out/r4_e2e_host.err
 echo "bench rc=$?"
