@@ -193,7 +193,7 @@ struct Unit { const char* name; uint32_t nameLen; uint32_t part; uint32_t first,
 // The decoder's working memory: the inflated rounds (the records the Recs point into), the kept records by name partition, the units in name order.  It outlives
 // hlala_bam_extract_seeds_mt: the arrays of the result are FILLED per window, when a window is first asked for (fill state below), and released when the last
 // unit has been filled (or with the seed batch).
-struct Work { std::vector<Arena> arenas; std::vector<std::vector<Rec>> precs; std::vector<Unit> units; std::vector<int64_t> cigCount;
+struct Work { std::vector<Arena> arenas; std::vector<std::vector<Rec>> precs; std::vector<Unit> units; Buf<int64_t> cigCount;
               std::vector<std::unique_ptr<uint8_t, BigFree>> inflated;
               // ---- fill state: the units are filled in chunks of UCH (chunk c = units [c * UCH, (c + 1) * UCH)), `done` per chunk, under the seed batch's fill_mu
               int nm = 2, T = 1; int64_t UCH = 1, nUChunks = 0, remaining = 0; std::vector<uint8_t> done; };
@@ -208,13 +208,13 @@ bool name_less(const Unit& a, const Unit& b)
 }  // namespace
 
 struct hlala_seed_batch {
-    std::vector<int64_t> read_off, chain_off;
+    Buf<int64_t> read_off, chain_off;
     Buf<int64_t> cigar_off;
-    std::vector<int32_t> read_primary;
+    Buf<int32_t> read_primary;
     Buf<int32_t> chain_contig, chain_pos, chain_offset, chain_as;
     Buf<uint8_t> read_bases, read_quals, chain_reverse; Buf<uint32_t> cigar;
     Buf<uint8_t> read_bases_packed; bool packed = false;      // HLALA_SEEDS_PACKED: the bases stay 4-bit packed as the BAM records hold them (hlala_batch_in::read_bases_packed), read_bases is empty
-    Buf<char> name_chars; std::vector<int64_t> name_off;          // names of the units, NUL-terminated
+    Buf<char> name_chars; Buf<int64_t> name_off;          // names of the units, NUL-terminated
     int64_t n_units = 0; int32_t unpaired = 0; int64_t examined = 0, n_seeds = 0, n_incomplete = 0;
     double seconds[6] = {0, 0, 0, 0, 0, 0}; int32_t threads = 1;
     bool pinned = false;
@@ -242,7 +242,7 @@ size_t sorted_mate(const std::vector<std::vector<Rec>>& precs, const Unit& u, in
 void fill_units(hlala_seed_batch* S, const Work& W, const size_t a, const size_t z, std::vector<uint32_t>& idx)
 {
     static const char SEQ16[] = "=ACMGRSVTWYHKDBN";
-    const std::vector<Unit>& units = W.units; const std::vector<std::vector<Rec>>& precs = W.precs; const std::vector<int64_t>& cigCount = W.cigCount; const int nm = W.nm;
+    const std::vector<Unit>& units = W.units; const std::vector<std::vector<Rec>>& precs = W.precs; const Buf<int64_t>& cigCount = W.cigCount; const int nm = W.nm;
     for(size_t ui = a; ui < z; ui++) {
         // The fill gathers names, CIGARs and packed bases from records scattered over the whole inflated file (name order against coordinate order: a cache
         // and TLB miss per record, 6.8 us per read and thread on a 128-thread host).  Two steps ahead of the work: the descriptors of the unit sixteen
@@ -686,11 +686,12 @@ try {
     const int nm = long_read_mode ? 1 : 2;
     const size_t nU = units.size(), nR = nU * (size_t)nm;
     S->n_units = (int64_t)nU;
-    S->read_off.assign(nR + 1, 0); S->chain_off.assign(nR + 1, 0); S->name_off.assign(nU + 1, 0);
-    S->read_primary.assign(nR, 0);
+    // (offset arrays of 8 bytes per read: not cleared -- every entry but the first is written by the pass below, read_primary by the fill)
+    S->read_off.alloc(nR + 1); S->chain_off.alloc(nR + 1); S->name_off.alloc(nU + 1); S->read_off[0] = 0; S->chain_off[0] = 0; S->name_off[0] = 0;
+    S->read_primary.alloc(nR + 1);
     // sizes per read: bases, chains, cigar operations; the primary of a mate is only known after its sort, so the alignments of every mate are
     // ordered here once (kept as record indices) and reused by the fill pass
-    std::vector<int64_t>& cigCount = W->cigCount; cigCount.assign(nR + 1, 0);
+    Buf<int64_t>& cigCount = W->cigCount; cigCount.alloc(nR + 1); cigCount[0] = 0;
     std::vector<std::vector<uint32_t>> order((size_t)T);
     const int64_t UCH = std::max<int64_t>(16, std::min<int64_t>(8192, (int64_t)nU / ((int64_t)T * 8) + 1)); const int64_t nUChunks = ((int64_t)nU + UCH - 1) / UCH;
     parallel_for(nUChunks, T, [&](int64_t c, int t) {
@@ -725,7 +726,7 @@ try {
     // fills the next, instead of waiting for the whole sample here (0.6 s of 2.9 for 8.4 M pairs).  HLALA_BAM_EAGER=1 fills everything now.
     W->nm = nm; W->T = T; W->UCH = UCH; W->nUChunks = nUChunks; W->remaining = nUChunks; W->done.assign((size_t)nUChunks, 0);
     S->seconds[5] = since(tPhase);
-    if(dbgL) fprintf(stderr, "bam-debug: layout: sizes %.3f (of which the zeroed offset arrays come first), prefix sums + allocation %.3f s; the fill runs per window\n", tL1, tL2 - tL1);
+    if(dbgL) fprintf(stderr, "bam-debug: layout: sizes %.3f, prefix sums + allocation %.3f s; the fill runs per window\n", tL1, tL2 - tL1);
     S->work = W.release();
     if(nUChunks == 0) { delete S->work; S->work = nullptr; }
     else if(const char* e = getenv("HLALA_BAM_EAGER")) { if(atoi(e) != 0) ensure_filled(S.get(), 0, (int64_t)nU); }
