@@ -685,7 +685,7 @@ EXPORTED_SYMBOLS = [
     "hlala_graph_cache_load", "hlala_graph_file_desc", "hlala_graph_file_free", "hlala_loader_last_error",
     "hlala_bam_extract_seeds", "hlala_bam_extract_seeds_mt", "hlala_bam_extract_seeds_opt", "hlala_seed_batch_counts", "hlala_seed_batch_desc", "hlala_seed_batch_window", "hlala_seed_batch_units", "hlala_seed_batch_name", "hlala_seed_batch_timing",
     "hlala_seed_batch_free", "hlala_seed_batch_pin", "hlala_bam_last_error", "hlala_bam_inflate_engine", "hlala_pinned_alloc", "hlala_pinned_free", "hlala_host_register", "hlala_host_unregister", "hlala_set_insert_size",
-    "hlala_contigs_load_dir", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
+    "hlala_contigs_load_dir", "hlala_contigs_open_dir", "hlala_contigs_load_translations", "hlala_contigs_file_desc", "hlala_contigs_file_intervals", "hlala_contigs_file_free",
     "hlala_typer_open", "hlala_typer_close", "hlala_typer_last_error", "hlala_typer_n_levels", "hlala_typer_level_name", "hlala_typer_level_of", "hlala_typer_n_genes",
     "hlala_typer_gene", "hlala_typer_load_g_groups", "hlala_typer_g_translate", "hlala_typer_locus", "hlala_locus_free", "hlala_locus_get", "hlala_locus_cluster_id", "hlala_locus_type_cluster",
     "hlala_locus_cluster_kmers", "hlala_type_locus", "hlala_kmer_presence", "hlala_kmer_keep_reads", "hlala_kmer_presence_kept", "hlala_kmer_forget_reads", "hlala_unit_alignment_stats", "hlala_typer_write_summary", "hlala_typer_begin_output", "hlala_locus_write_files", "hlala_locus_write_pairs_file", "hlala_typer_end_output",

@@ -1751,18 +1751,6 @@ extern "C" int hlala_abi_sizeof(const char* name)
     return -1;
 }
 
-extern "C" int hlala_pack_bases(const uint8_t* read_bases, const int64_t* read_off, int64_t n_reads, uint8_t* packed)
-{
-    if(!read_bases || !read_off || !packed || n_reads < 0) return HLALA_E_ARG;
-    static uint8_t code[256]; static bool init = false;
-    if(!init) { memset(code, 15, sizeof(code)); const char* s16 = "=ACMGRSVTWYHKDBN"; for(int i = 0; i < 16; i++) code[(unsigned char)s16[i]] = (uint8_t)i; init = true; }
-    for(int64_t r = 0; r < n_reads; r++) {
-        const int64_t o = read_off[r], len = read_off[r + 1] - o; uint8_t* dst = packed + ((o + r + 1) >> 1);
-        for(int64_t j = 0; j + 1 < len; j += 2) dst[j >> 1] = (uint8_t)((code[read_bases[o + j]] << 4) | code[read_bases[o + j + 1]]);
-        if(len & 1) dst[len >> 1] = (uint8_t)(code[read_bases[o + len - 1]] << 4);
-    }
-    return HLALA_OK;
-}
 extern "C" int hlala_abi_version(void) { return HLALA_ABI_VERSION; }
 extern "C" int hlala_build_flags(void)
 {

@@ -9,6 +9,9 @@
 // of the file are arbitrary integers and are renumbered 0.. in line order.  An emission byte equal to '|' appears as "|||||||" and is
 // handled the way the reference does (:2338-2365, :2450-2453).
 #include <algorithm>
+#include <atomic>
+#include <exception>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -174,13 +177,17 @@ try {
 //     entry 0 (StrtoI("") == 0): level 0 then "lies under" position <length> of that sequence in graphLevel_2_underlyingSequencePositions.
 //     The contig gets one extra position (base 'N', level 0) so that hlala_create builds the same table;
 //   * PRG-only mode defines PRG_5 as "N" (:87-88).
+namespace {
+struct SeqRow { int id; std::string ref; bool hasRange; int start1, stop1; };
+}
 struct hlala_contigs_file {
     std::vector<int64_t> off; std::vector<uint8_t> seq; std::vector<int32_t> level, seqid;
     std::vector<std::string> refName; std::vector<int32_t> start0, stop0;
+    // between hlala_contigs_open_dir and hlala_contigs_load_translations: the rows of sequences.txt and the reference sequences they name
+    bool complete = false; std::string dir; std::vector<SeqRow> rows; std::map<std::string, std::string> seqs;
 };
 
 namespace {
-struct SeqRow { int id; std::string ref; bool hasRange; int start1, stop1; };
 
 bool read_wanted_fasta(const std::string& path, std::map<std::string, std::string>& wanted)
 {
@@ -202,7 +209,7 @@ bool read_wanted_fasta(const std::string& path, std::map<std::string, std::strin
 }
 }  // namespace
 
-extern "C" int hlala_contigs_load_dir(const char* graph_dir, int32_t extended_reference_genome, hlala_contigs_file** out)
+extern "C" int hlala_contigs_open_dir(const char* graph_dir, int32_t extended_reference_genome, hlala_contigs_file** out)
 try {
     if(!graph_dir || !out) return HLALA_E_ARG;
     const std::string dir(graph_dir);
@@ -240,52 +247,95 @@ try {
     if(!read_wanted_fasta(fasta, seqs)) return fail("readFASTA(): Cannot open file " + fasta);
     if(!extended_reference_genome) { auto it = seqs.find("PRG_5"); if(it != seqs.end() && it->second.empty()) it->second = "\x01N"; }      // :87-88
     std::unique_ptr<hlala_contigs_file> C(new hlala_contigs_file());
-    C->off.push_back(0);
     for(const SeqRow& r : rows) {
-        std::string& s = seqs[r.ref];
+        const std::string& s = seqs[r.ref];
         if(s.empty()) return fail(r.ref + " cannot be found in the reference genome " + fasta);
         const long long len = (long long)s.size() - 1;                                                    // without the "seen" mark
         const long long a = r.start1, b = r.hasRange ? r.stop1 : len;
         if(a < 1 || b > len || b < a) return fail("sequences.txt: interval " + std::to_string(a) + "-" + std::to_string(b) + " outside " + r.ref + " (length " + std::to_string(len) + ")");
+        C->seqid.push_back(r.id); C->refName.push_back(r.ref); C->start0.push_back((int32_t)(a - 1)); C->stop0.push_back((int32_t)(b - 1));
+    }
+    C->dir = dir; C->rows.swap(rows); C->seqs.swap(seqs);
+    *out = C.release();
+    return HLALA_OK;
+} catch(const std::exception& e_) { g_loader_error = std::string("hlala_contigs_open_dir: ") + e_.what(); return HLALA_E_ARG; }
+
+// the translation tables (tens of millions of lines for the MHC graph: the bulk of the directory's reading time): the files are parsed side by side on a few
+// threads and appended in the order of sequences.txt
+extern "C" int hlala_contigs_load_translations(hlala_contigs_file* C)
+try {
+    if(!C) return HLALA_E_ARG;
+    if(C->complete) return HLALA_OK;
+    const std::string& dir = C->dir; const std::vector<SeqRow>& rows = C->rows;
+    std::vector<std::vector<int32_t>> levels(rows.size()); std::vector<std::string> errs(rows.size());
+    auto parse_one = [&](size_t ri) {
+        const SeqRow& r = rows[ri];
         const std::string tf = dir + "/translation/" + std::to_string(r.id) + ".txt";
         // one level per line, read as the reference's loop does (mapper/processBAM.cpp:4406-4412: getline while good(), Utilities::StrtoI = stringstream >> int,
         // Utilities.cpp:644-650): a file that ends in a newline yields one more, empty line = level 0; a line without a leading integer yields 0.  Parsed by hand:
         // the MHC graph has tens of millions of these lines.
-        std::vector<int32_t> lv;
-        {
-            std::ifstream ts(tf.c_str(), std::ios::binary);
-            if(!ts.is_open()) return fail("Expected coordinate translation file not found: " + tf);
-            std::string all((std::istreambuf_iterator<char>(ts)), std::istreambuf_iterator<char>());
-            const char* p = all.data(); const char* end = p + all.size();
-            for(;;) {
-                const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-                const char* le = nl ? nl : end;
-                const char* q = p;
-                while(q < le && (*q == ' ' || *q == '\t' || *q == '\r' || *q == '\v' || *q == '\f')) q++;
-                bool neg = false; if(q < le && (*q == '+' || *q == '-')) { neg = *q == '-'; q++; }
-                long long v = 0; bool digits = false, over = false;
-                while(q < le && *q >= '0' && *q <= '9') { digits = true; v = v * 10 + (*q - '0'); if(v > 4294967296ll) over = true; q++; }
-                if(neg) v = -v;
-                if(!digits || over || v > 2147483647ll || v < -2147483648ll) v = 0;                       // failed extraction: 0
-                lv.push_back((int32_t)v);
-                if(!nl) break;
-                p = nl + 1;
-            }
+        std::vector<int32_t>& lv = levels[ri];
+        std::ifstream ts(tf.c_str(), std::ios::binary);
+        if(!ts.is_open()) { errs[ri] = "Expected coordinate translation file not found: " + tf; return; }
+        std::string all((std::istreambuf_iterator<char>(ts)), std::istreambuf_iterator<char>());
+        const char* p = all.data(); const char* end = p + all.size();
+        for(;;) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* le = nl ? nl : end;
+            const char* q = p;
+            while(q < le && (*q == ' ' || *q == '\t' || *q == '\r' || *q == '\v' || *q == '\f')) q++;
+            bool neg = false; if(q < le && (*q == '+' || *q == '-')) { neg = *q == '-'; q++; }
+            long long v = 0; bool digits = false, over = false;
+            while(q < le && *q >= '0' && *q <= '9') { digits = true; v = v * 10 + (*q - '0'); if(v > 4294967296ll) over = true; q++; }
+            if(neg) v = -v;
+            if(!digits || over || v > 2147483647ll || v < -2147483648ll) v = 0;                       // failed extraction: 0
+            lv.push_back((int32_t)v);
+            if(!nl) break;
+            p = nl + 1;
         }
+    };
+    {
+        const size_t T = std::min<size_t>(rows.size(), 8);
+        std::atomic<size_t> next(0); std::vector<std::thread> th; std::vector<std::exception_ptr> ex(T);
+        for(size_t t = 0; t < T; t++) th.emplace_back([&, t]() { try { for(;;) { const size_t ri = next.fetch_add(1); if(ri >= rows.size()) break; parse_one(ri); } } catch(...) { ex[t] = std::current_exception(); } });
+        for(std::thread& x : th) x.join();
+        for(const std::exception_ptr& e : ex) if(e) std::rethrow_exception(e);
+    }
+    C->off.assign(1, 0); C->seq.clear(); C->level.clear();
+    for(size_t ri = 0; ri < rows.size(); ri++) {
+        if(!errs[ri].empty()) return fail(errs[ri]);
+        const SeqRow& r = rows[ri];
+        const std::string& s = C->seqs[r.ref];
+        const std::vector<int32_t>& lv = levels[ri];
+        const std::string tf = dir + "/translation/" + std::to_string(r.id) + ".txt";
+        const long long a = (long long)C->start0[ri] + 1, b = (long long)C->stop0[ri] + 1;
         const long long n = b - a + 1;
         if((long long)lv.size() < n) return fail(tf + ": " + std::to_string(lv.size()) + " levels for an interval of " + std::to_string(n) + " bases");
         C->seq.insert(C->seq.end(), s.begin() + a, s.begin() + b + 1);                                    // s[0] is the mark: 1-based start a = index a
         C->seq.insert(C->seq.end(), lv.size() - (size_t)n, (uint8_t)'N');
         C->level.insert(C->level.end(), lv.begin(), lv.end());
-        C->off.push_back((int64_t)C->seq.size()); C->seqid.push_back(r.id);
-        C->refName.push_back(r.ref); C->start0.push_back((int32_t)(a - 1)); C->stop0.push_back((int32_t)(b - 1));
+        C->off.push_back((int64_t)C->seq.size());
+        std::vector<int32_t>().swap(levels[ri]);
     }
-    *out = C.release();
+    C->complete = true; std::vector<SeqRow>().swap(C->rows); std::map<std::string, std::string>().swap(C->seqs);
     return HLALA_OK;
-} catch(const std::exception& e_) { g_loader_error = std::string("hlala_contigs_load_dir: ") + e_.what(); return HLALA_E_ARG; }
+} catch(const std::exception& e_) { g_loader_error = std::string("hlala_contigs_load_translations: ") + e_.what(); return HLALA_E_ARG; }
+
+extern "C" int hlala_contigs_load_dir(const char* graph_dir, int32_t extended_reference_genome, hlala_contigs_file** out)
+{
+    if(!out) return HLALA_E_ARG;
+    hlala_contigs_file* C = nullptr;
+    int rc = hlala_contigs_open_dir(graph_dir, extended_reference_genome, &C);
+    if(rc != HLALA_OK) return rc;
+    rc = hlala_contigs_load_translations(C);
+    if(rc != HLALA_OK) { delete C; return rc; }
+    *out = C;
+    return HLALA_OK;
+}
 extern "C" int hlala_contigs_file_desc(const hlala_contigs_file* c, hlala_contigs_desc* d)
 try {
     if(!c || !d) return HLALA_E_ARG;
+    if(!c->complete) { g_loader_error = "hlala_contigs_file_desc before hlala_contigs_load_translations"; return HLALA_E_STATE; }
     d->n_contigs = (int32_t)c->seqid.size(); d->contig_off = c->off.data(); d->contig_seq = c->seq.data(); d->contig_level = c->level.data(); d->contig_seqid = c->seqid.data();
     return HLALA_OK;
 } catch(const std::exception& e_) { g_loader_error = std::string("hlala_contigs_file_desc: ") + e_.what(); return HLALA_E_ARG; }

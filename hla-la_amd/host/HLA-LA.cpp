@@ -194,7 +194,8 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     std::cout << timestamp() << "Seed extraction: " << BAMprocessor.n_units << " complete units, BAM decoded in " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
               << " threads (index " << BAMprocessor.decode_phase_seconds[0] << ", inflate " << BAMprocessor.decode_phase_seconds[1] << ", parse " << BAMprocessor.decode_phase_seconds[2] << ", group "
               << BAMprocessor.decode_phase_seconds[3] << ", name sort " << BAMprocessor.decode_phase_seconds[4] << ", layout (sizes and offsets; the windows are filled batch by batch beside the GPU) " << BAMprocessor.decode_phase_seconds[5] << "); beside it: contexts on " << BAMprocessor.n_devices()
-              << " device(s) in " << BAMprocessor.context_seconds << " s; graph + contigs loaded in " << loadSeconds << " s (typer files beside them); seed extraction in all " << openSeconds << " s\n" << std::flush;
+              << " device(s) ready after " << BAMprocessor.context_seconds << " s (of which " << BAMprocessor.directory_wait_seconds << " s waiting for the graph directory: reference intervals after " << graphDirectory->intervals_seconds
+              << " s -- the decoder starts with them --, graph read after " << graphDirectory->graph_seconds << " s, translation tables after " << graphDirectory->contigs_seconds << " s, typer files beside them); seed extraction in all " << openSeconds << " s\n" << std::flush;
     if(!longReads.length()) std::cout << "Insert size: mean " << BAMprocessor.IS_mean << ", sd " << BAMprocessor.IS_sd << "\n" << std::flush;
     // the G-group table is looked up in the working directory, as the reference does (hla/HLATyper.cpp:4160-4166; HLA-LA.pl chdirs to the source directory)
     typerThread.join();
@@ -223,8 +224,8 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
       const double e2e = openSample + inferSeconds;
       std::cout << "End-to-end: " << (e2e > 0 ? (double)(pairs + unpaired) / e2e : 0.0) << " units per s (BAM decode " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
                 << " threads + page-locking and insert size " << openSample - BAMprocessor.decode_seconds << " s + alignment and typing " << inferSeconds << " s, of which the host spent " << BAMprocessor.layout_seconds() - BAMprocessor.decode_phase_seconds[5]
-                << " s filling the windows of the batches beside the GPU; per process, not per sample: context creation beyond the decode "
-                << ctxBeyond << " s, graph loading " << loadSeconds << " s; "
+                << " s filling the windows of the batches beside the GPU; per process, not per sample: graph directory + context creation beyond the decode "
+                << ctxBeyond << " s, reference intervals before it " << loadSeconds << " s; "
                 << "whole action after the remapping: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s)\n" << std::flush; }
     std::cout << "Typing phases: batches (alignment, post-processing, exon positions) " << HLAtyper.timing.batches << " s, summary " << HLAtyper.timing.summary << " s, per-locus likelihoods and calls "
               << HLAtyper.timing.loci << " s, k-mer pass " << HLAtyper.timing.kmers << " s, result files " << HLAtyper.timing.files << " s\n" << std::flush;

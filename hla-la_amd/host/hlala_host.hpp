@@ -25,6 +25,7 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -260,32 +261,53 @@ private:
 // holds a reference.
 class GraphDirectory {
 public:
+    // Returns once the reference intervals are known (sequences.txt + the reference sequences it names: what the BAM decoder needs); the graph and the
+    // translation tables -- the bulk of the directory -- are read on two threads behind it.  graph() / contigs() wait for them.
     GraphDirectory(const std::string& graphDir, bool extendedReferenceGenome) : dir(graphDir), extended(extendedReferenceGenome)
     {
-        // `--action prepareGraph` leaves the flattened arrays in <graphDir>/serializedGRAPH; a file of that name written by the reference
-        // binary (a Boost archive) is not ours and the text graph is parsed instead.  The graph and the contigs (tens of millions of translation lines) are
-        // independent files: read side by side.
-        std::string gErr, cErr;
-        std::thread tg([&]() {
-            try {
-                if(hlala_graph_cache_load((graphDir + "/serializedGRAPH").c_str(), &graph_) != HLALA_OK) {
-                    graph_ = nullptr;
-                    if(hlala_graph_load_text((graphDir + "/PRG/graph.txt").c_str(), &graph_) != HLALA_OK) gErr = std::string("graph.txt: ") + hlala_loader_last_error();
-                }
-            } catch(const std::exception& e) { gErr = e.what(); }
-        });
-        try { if(hlala_contigs_load_dir(graphDir.c_str(), extendedReferenceGenome ? 1 : 0, &contigs_) != HLALA_OK) cErr = std::string("contigs: ") + hlala_loader_last_error(); }
-        catch(const std::exception& e) { cErr = e.what(); }
-        tg.join();
-        if(!gErr.empty() || !cErr.empty()) { if(graph_) hlala_graph_file_free(graph_); if(contigs_) hlala_contigs_file_free(contigs_); graph_ = nullptr; contigs_ = nullptr; throw std::runtime_error(gErr.empty() ? cErr : gErr); }
+        const auto t0 = std::chrono::steady_clock::now();
+        if(hlala_contigs_open_dir(graphDir.c_str(), extendedReferenceGenome ? 1 : 0, &contigs_) != HLALA_OK) throw std::runtime_error(std::string("contigs: ") + hlala_loader_last_error());
         intervals_.resize((size_t)hlala_contigs_file_intervals(contigs_, nullptr, 0));
         hlala_contigs_file_intervals(contigs_, intervals_.data(), (int32_t)intervals_.size());
+        intervals_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // `--action prepareGraph` leaves the flattened arrays in <graphDir>/serializedGRAPH; a file of that name written by the reference
+        // binary (a Boost archive) is not ours and the text graph is parsed instead.  The graph and the translation tables (tens of millions of lines) are
+        // independent files: read side by side.
+        try {
+            loaders_.start([this, graphDir, t0]() {
+                try {
+                    if(hlala_graph_cache_load((graphDir + "/serializedGRAPH").c_str(), &graph_) != HLALA_OK) {
+                        graph_ = nullptr;
+                        if(hlala_graph_load_text((graphDir + "/PRG/graph.txt").c_str(), &graph_) != HLALA_OK) gErr_ = std::string("graph.txt: ") + hlala_loader_last_error();
+                    }
+                } catch(const std::exception& e) { gErr_ = e.what(); }
+                graph_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            });
+            loaders_.start([this, t0]() {
+                try { if(hlala_contigs_load_translations(contigs_) != HLALA_OK) cErr_ = std::string("contigs: ") + hlala_loader_last_error(); }
+                catch(const std::exception& e) { cErr_ = e.what(); }
+                contigs_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            });
+        } catch(...) { loaders_.join(); hlala_contigs_file_free(contigs_); if(graph_) hlala_graph_file_free(graph_); throw; }
     }
-    ~GraphDirectory() { hlala_contigs_file_free(contigs_); hlala_graph_file_free(graph_); }
+    ~GraphDirectory() { loaders_.join(); hlala_contigs_file_free(contigs_); if(graph_) hlala_graph_file_free(graph_); }
     GraphDirectory(const GraphDirectory&) = delete;
     GraphDirectory& operator=(const GraphDirectory&) = delete;
+    // the graph and the complete contigs (several threads may ask)
+    void wait()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        loaders_.join();
+        if(!gErr_.empty() || !cErr_.empty()) throw std::runtime_error(gErr_.empty() ? cErr_ : gErr_);
+    }
+    hlala_graph_file* graph() { wait(); return graph_; }
+    hlala_contigs_file* contigs() { wait(); return contigs_; }
+    const std::vector<hlala_bam_interval>& intervals() const { return intervals_; }
     const std::string dir; const bool extended;
+    double intervals_seconds = 0, graph_seconds = 0, contigs_seconds = 0;      // since the constructor began: intervals known, graph read, translation tables read
+private:
     hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; std::vector<hlala_bam_interval> intervals_;
+    std::string gErr_, cErr_; std::mutex mu_; ThreadJoiner loaders_;
 };
 
 class processBAM {
@@ -297,7 +319,7 @@ public:
     // a graph directory the process has read already (several samples per process share one)
     processBAM(const std::shared_ptr<GraphDirectory>& gdir, int max_columns, uint32_t rng_seed, const std::vector<int>& devices, int threads)
         : gdir_(gdir), graphDir_(gdir->dir), extended_(gdir->extended), max_columns_(max_columns), rng_seed_(rng_seed), devices_(devices.empty() ? std::vector<int>(1, 0) : devices), threads_(threads),
-          graph_(gdir->graph_), contigs_(gdir->contigs_), intervals_(gdir->intervals_) {}
+          intervals_(gdir->intervals()) {}
     ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); for(hlala_ctx* c : ctxs_) if(c) hlala_destroy(c); if(seeds_) hlala_seed_batch_free(seeds_); }
     processBAM(const processBAM&) = delete;
     processBAM& operator=(const processBAM&) = delete;
@@ -312,13 +334,12 @@ public:
         check_abi();
         // (the decoder thread and the per-device threads are joined by `tdec` / `th` on every way out of this scope, exceptions included;
         //  everything they capture is declared before them)
-        hlala_graph_desc gd; hlala_graph_file_desc(graph_, &gd);
-        hlala_contigs_desc cd; hlala_contigs_file_desc(contigs_, &cd);
-        n_levels = gd.n_levels;
+        hlala_graph_desc gd; hlala_contigs_desc cd;
         hlala_params pr{200.0, 35.0, rng_seed_, longReads ? 1 : 0, max_columns_, 0};
         ctxs_.assign(devices_.size(), nullptr);
         std::vector<std::string> errs(devices_.size());
         ThreadJoiner tdec, th;
+        // (the decoder needs the reference intervals only: it starts while the graph directory may still be reading its graph and translation tables)
         tdec.start([&]() {
             // (the bases stay 4-bit packed as the BAM records hold them: a copy instead of an unpacking pass here, half the bytes to upload, unpacked on the device)
             const int32_t seedFlags = std::getenv("HLALA_SEEDS_ASCII") ? 0 : HLALA_SEEDS_PACKED;          // (HLALA_SEEDS_ASCII=1: the decoder unpacks the bases on the host, as before round 4 -- for A/B runs)
@@ -326,6 +347,11 @@ public:
             catch(const std::exception& e) { bamErr = e.what(); }
             decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         });
+        graph_ = gdir_->graph(); contigs_ = gdir_->contigs();                       // (waits for the directory; throws what its readers reported: tdec is joined on the way out)
+        directory_wait_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        hlala_graph_file_desc(graph_, &gd);
+        if(hlala_contigs_file_desc(contigs_, &cd) != HLALA_OK) throw std::runtime_error(std::string("contigs: ") + hlala_loader_last_error());
+        n_levels = gd.n_levels;
         for(size_t d = 0; d < devices_.size(); d++) th.start([&, d]() { if(hlala_create(&ctxs_[d], devices_[d], nullptr, &gd, &cd, &pr) != HLALA_OK) errs[d] = std::string("hlala_create: ") + hlala_last_error(nullptr); });
         th.join();
         context_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -395,7 +421,8 @@ public:
     double IS_mean = 200.0, IS_sd = 35.0;
     int64_t n_units = 0; int32_t n_levels = 0; bool longReadsMode = false;
     double decode_seconds = 0, decode_phase_seconds[6] = {0, 0, 0, 0, 0, 0}; int32_t decode_threads = 0;
-    double context_seconds = 0;       // creation of the contexts (beside the decode)
+    double context_seconds = 0;       // until the contexts exist (beside the decode): the wait for the graph directory + their creation
+    double directory_wait_seconds = 0;      // ... of which waiting for the graph directory's readers
 
 private:
     void window(int64_t u0, int32_t n, hlala_batch_in& in) const

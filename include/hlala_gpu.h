@@ -570,6 +570,11 @@ int  hlala_type_locus(hlala_ctx* ctx, const hlala_exon_in* in, double* LL /* [C*
  * (base 'N', level 0) so that the level -> (sequence, position) table comes out the same. */
 typedef struct hlala_contigs_file hlala_contigs_file;
 int     hlala_contigs_load_dir(const char* graph_dir, int32_t extended_reference_genome, hlala_contigs_file** out);   /* errors: hlala_loader_last_error */
+/* The same in two steps, for a caller that wants the BAM decoder running while the bulk of the directory is still being read: hlala_contigs_open_dir reads
+ * sequences.txt and the reference sequences it names -- enough for hlala_contigs_file_intervals --, hlala_contigs_load_translations the translation tables
+ * (tens of millions of lines; parsed side by side) that hlala_contigs_file_desc / hlala_create need.  hlala_contigs_load_dir = both. */
+int     hlala_contigs_open_dir(const char* graph_dir, int32_t extended_reference_genome, hlala_contigs_file** out);
+int     hlala_contigs_load_translations(hlala_contigs_file* c);
 int     hlala_contigs_file_desc(const hlala_contigs_file* c, hlala_contigs_desc* desc);
 int32_t hlala_contigs_file_intervals(const hlala_contigs_file* c, hlala_bam_interval* out, int32_t cap);              /* returns the number of intervals */
 void    hlala_contigs_file_free(hlala_contigs_file* c);
