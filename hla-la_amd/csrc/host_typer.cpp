@@ -15,6 +15,9 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <exception>
+#include <string_view>
+#include <functional>
 #include <thread>
 #include <type_traits>
 #include <atomic>
@@ -97,10 +100,46 @@ double chi_sq_p(const double observed[2], const double expected[2])
 
 }  // namespace
 
+// graphLocus_2_levels: level of a name.  An open-addressing table of level numbers over the names themselves (no node, no second copy of five million
+// strings: building a std::unordered_map<std::string, int> of the MHC graph's level names took four seconds, longer than the BAM decoder runs); filled from
+// several threads (a slot is claimed by compare-and-swap), read-only afterwards.
+struct LevelIndex {
+    const std::vector<std::string>* names = nullptr;
+    std::unique_ptr<std::atomic<int32_t>[]> slot; size_t mask = 0;
+    static size_t hash(const char* p, size_t n) { return std::hash<std::string_view>()(std::string_view(p, n)); }
+    void reset(const std::vector<std::string>* nm)
+    {
+        names = nm; size_t cap = 16; while(cap < 2 * nm->size() + 2) cap <<= 1;
+        slot.reset(new std::atomic<int32_t>[cap]); mask = cap - 1;
+        for(size_t i = 0; i < cap; i++) slot[i].store(-1, std::memory_order_relaxed);
+    }
+    // false: another level carries the same name
+    bool insert(int32_t level)
+    {
+        const std::string& s = (*names)[(size_t)level];
+        for(size_t h = hash(s.data(), s.size()) & mask;; h = (h + 1) & mask) {
+            int32_t cur = slot[h].load(std::memory_order_acquire);
+            if(cur == -1) { if(slot[h].compare_exchange_strong(cur, level, std::memory_order_acq_rel)) return true; }
+            if((*names)[(size_t)cur] == s) return false;
+        }
+    }
+    int find(const char* p, size_t n) const
+    {
+        if(!names || !slot) return -1;
+        for(size_t h = hash(p, n) & mask;; h = (h + 1) & mask) {
+            const int32_t cur = slot[h].load(std::memory_order_relaxed);
+            if(cur == -1) return -1;
+            const std::string& s = (*names)[(size_t)cur];
+            if(s.size() == n && memcmp(s.data(), p, n) == 0) return cur;
+        }
+    }
+    int find(const std::string& s) const { return find(s.data(), s.size()); }
+};
+
 struct hlala_typer {
     std::string graphDir;
     std::vector<std::string> levelNames;                       // graphLoci
-    std::unordered_map<std::string, int> levelOf;              // graphLocus_2_levels
+    LevelIndex levelOf;                                        // graphLocus_2_levels
     std::vector<std::string> files;                            // files_in_graphDir
     std::vector<std::string> geneNames; std::vector<int> geneFirst, geneLast;       // graphgene_levelBoundaries in std::map (name) order
     std::map<std::string, std::string> alleleToG; std::set<std::string> gLoci;      // read_G_alleles
@@ -127,23 +166,46 @@ try {
     const std::string prg = T->graphDir + "/PRG";
     std::vector<std::string> segLines;
     if(!read_lines(prg + "/segments.txt", segLines)) return fail(HLALA_E_ARG, "Cannot open segments file: " + prg + "/segments.txt");
-    // graph loci: the column names of every segment file, in file order (Graph::readGraphLoci)
-    std::vector<std::vector<std::string>> firstFields;
-    for(const std::string& l : segLines) {
-        if(l.empty()) { firstFields.emplace_back(); continue; }
+    // graph loci: the column names of every segment file, in file order (Graph::readGraphLoci).  The first lines are read and cut into names side by side
+    // (millions of names for the MHC graph), every segment's names land at the segment's place in the list of levels.
+    const size_t nSeg = segLines.size();
+    std::vector<std::vector<std::string>> firstFields(nSeg); std::vector<std::string> segErr(nSeg);
+    auto in_parallel = [&](size_t n, const std::function<void(size_t)>& fn) {
+        const size_t Tn = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n, 16), (size_t)hlala_host::host_cpu_budget()));
+        std::atomic<size_t> next(0); std::vector<std::exception_ptr> ex(Tn); std::vector<std::thread> th;
+        auto work = [&](size_t t) { try { for(;;) { const size_t i = next.fetch_add(1); if(i >= n) break; fn(i); } } catch(...) { ex[t] = std::current_exception(); } };
+        for(size_t t = 1; t < Tn; t++) th.emplace_back(work, t);
+        work(0);
+        for(std::thread& x : th) x.join();
+        for(const std::exception_ptr& e : ex) if(e) std::rethrow_exception(e);
+    };
+    in_parallel(nSeg, [&](size_t li) {
+        const std::string& l = segLines[li];
+        if(l.empty()) return;
         std::ifstream f((prg + "/" + l).c_str());
-        if(!f.is_open()) return fail(HLALA_E_ARG, "Cannot open one segment file: " + prg + "/" + l);
+        if(!f.is_open()) { segErr[li] = "Cannot open one segment file: " + prg + "/" + l; return; }
         std::string first; std::getline(f, first); erase_nl(first);
-        firstFields.push_back(split(first, " "));
-        for(size_t i = 1; i < firstFields.back().size(); i++) {
-            const std::string& id = firstFields.back()[i];
-            if(T->levelOf.count(id)) return fail(HLALA_E_ARG, "graph locus appears twice: " + id);           // assert, hla/HLATyper.cpp:90
-            T->levelOf[id] = (int)T->levelNames.size(); T->levelNames.push_back(id);
-        }
-    }
-    // gene boundaries, hla/HLATyper.cpp:104-214
+        firstFields[li] = split(first, " ");
+    });
+    for(const std::string& e : segErr) if(!e.empty()) return fail(HLALA_E_ARG, e);
+    std::vector<size_t> base(nSeg + 1, 0);
+    for(size_t li = 0; li < nSeg; li++) base[li + 1] = base[li] + (firstFields[li].size() > 1 ? firstFields[li].size() - 1 : 0);
+    if(base[nSeg] > 0x7FFFFFF0ull) return fail(HLALA_E_CAPACITY, "more than 2^31 graph levels");
+    T->levelNames.resize(base[nSeg]);
+    std::vector<std::string> keepFirst(nSeg);                                 // the first field of every segment file ("IndividualID" for a gene segment)
+    in_parallel(nSeg, [&](size_t li) {
+        std::vector<std::string>& ff = firstFields[li];
+        if(!ff.empty()) keepFirst[li] = ff[0];
+        for(size_t i = 1; i < ff.size(); i++) T->levelNames[base[li] + i - 1] = std::move(ff[i]);
+        std::vector<std::string>().swap(ff);
+    });
+    T->levelOf.reset(&T->levelNames);
+    std::vector<long long> dup(nSeg, -1);
+    in_parallel(nSeg, [&](size_t li) { for(size_t k = base[li]; k < base[li + 1]; k++) if(!T->levelOf.insert((int32_t)k)) { dup[li] = (long long)k; return; } });
+    for(size_t li = 0; li < nSeg; li++) if(dup[li] >= 0) return fail(HLALA_E_ARG, "graph locus appears twice: " + T->levelNames[(size_t)dup[li]]);           // assert, hla/HLATyper.cpp:90
+    // gene boundaries, hla/HLATyper.cpp:104-214 (the level of a segment's i-th name is its place in the list: the names are distinct)
     std::map<std::string, std::pair<int, int>> bounds;
-    for(size_t li = 0; li < segLines.size(); li++) {
+    for(size_t li = 0; li < nSeg; li++) {
         const std::string& l = segLines[li];
         if(l.empty()) continue;
         const std::vector<std::string> us = split(l, "_");
@@ -151,13 +213,13 @@ try {
         if(us[1] != "gene") continue;
         if(us.size() < 5) return fail(HLALA_E_ARG, "segments.txt: unexpected gene entry " + l);
         const std::string& gene = us[2];
-        if(firstFields[li].empty() || firstFields[li][0] != "IndividualID") return fail(HLALA_E_ARG, "segment file without IndividualID header: " + l);
+        if(keepFirst[li] != "IndividualID") return fail(HLALA_E_ARG, "segment file without IndividualID header: " + l);
         if(!bounds.count(gene)) bounds[gene] = std::make_pair(-1, -1);
-        for(size_t i = 1; i < firstFields[li].size(); i++) {
-            const int lv = T->levelOf.at(firstFields[li][i]);
-            std::pair<int, int>& b = bounds[gene];
-            if(b.first == -1 || lv < b.first) b.first = lv;
-            if(b.second == -1 || lv > b.second) b.second = lv;
+        if(base[li + 1] > base[li]) {
+            std::pair<int, int>& bd = bounds[gene];
+            const int lo = (int)base[li], hi = (int)base[li + 1] - 1;
+            if(bd.first == -1 || lo < bd.first) bd.first = lo;
+            if(bd.second == -1 || hi > bd.second) bd.second = hi;
         }
     }
     for(const auto& g : bounds) { T->geneNames.push_back(g.first); T->geneFirst.push_back(g.second.first); T->geneLast.push_back(g.second.second); }
@@ -172,7 +234,7 @@ try {
 extern "C" void hlala_typer_close(hlala_typer* t) { delete t; }
 extern "C" int32_t hlala_typer_n_levels(const hlala_typer* t) { return t ? (int32_t)t->levelNames.size() : -1; }
 extern "C" const char* hlala_typer_level_name(const hlala_typer* t, int32_t level) { return (t && level >= 0 && level < (int)t->levelNames.size()) ? t->levelNames[level].c_str() : nullptr; }
-extern "C" int32_t hlala_typer_level_of(const hlala_typer* t, const char* id) { if(!t || !id) return -1; auto it = t->levelOf.find(id); return it == t->levelOf.end() ? -1 : it->second; }
+extern "C" int32_t hlala_typer_level_of(const hlala_typer* t, const char* id) { if(!t || !id) return -1; return t->levelOf.find(id, strlen(id)); }
 extern "C" int32_t hlala_typer_n_genes(const hlala_typer* t) { return t ? (int32_t)t->geneNames.size() : -1; }
 extern "C" int hlala_typer_gene(const hlala_typer* t, int32_t i, const char** name, int32_t* first_level, int32_t* last_level)
 try {
@@ -280,14 +342,12 @@ try {
         const std::vector<std::string> head = split(lines[0], " ");
         if(head.empty() || head[0] != "IndividualID") return fail(HLALA_E_ARG, file + ": first field must be IndividualID");
         if(head.size() < 2) return fail(HLALA_E_ARG, file + ": no columns");
-        auto f = t->levelOf.find(head[1]), l = t->levelOf.find(head.back());
-        if(f == t->levelOf.end() || l == t->levelOf.end()) return fail(HLALA_E_ARG, file + ": column names are not graph loci");
-        const int first = f->second, last = l->second;
+        const int first = t->levelOf.find(head[1]), last = t->levelOf.find(head.back());
+        if(first < 0 || last < 0) return fail(HLALA_E_ARG, file + ": column names are not graph loci");
         if(!(last > first) || (int)head.size() - 1 != last - first + 1) return fail(HLALA_E_ARG, "locus " + L->name + " " + exons[exonI] + " (" + file + "): problem with expected graph length");
         const int len = last - first + 1;
         for(int i = 0; i < len; i++) {
-            auto it = t->levelOf.find(head[(size_t)i + 1]);
-            if(it == t->levelOf.end() || it->second != first + i) return fail(HLALA_E_ARG, file + ": columns are not consecutive graph levels");       // assert, :1247
+            if(t->levelOf.find(head[(size_t)i + 1]) != first + i) return fail(HLALA_E_ARG, file + ": columns are not consecutive graph levels");       // assert, :1247
             L->colLevel.push_back(first + i); L->colExon.push_back((int)exonI); L->colExonPos.push_back(i);
             if(L->levelMin == -1 || L->levelMin > first + i) L->levelMin = first + i;
             if(L->levelMax == -1 || L->levelMax < first + i) L->levelMax = first + i;

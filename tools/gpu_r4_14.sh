@@ -21,3 +21,16 @@ if l:
 else:
     print(open('gpurun_out/r4_e2e_host.err').read()[-2000:])
 PY
+# the same program on a sample with 30 % of its pairs in the gene windows
+HLALA_HOST_DEBUG=1 timeout 1500 python bench.py --steps 2 --warmup 1 --resident-steps 0 --long-reads 0 --no-cpu-baseline --no-extras-but-e2e --e2e-threads 0 --e2e-frac-gene 0.3 > gpurun_out/r4_e2e_gene30.log 2> gpurun_out/r4_e2e_gene30.err
+python3 - <<'PY'
+import json
+l = [x for x in open('gpurun_out/r4_e2e_gene30.log') if x.startswith('{')]
+if l:
+    e = json.loads(l[-1]).get("end_to_end", {})
+    print("e2e 30% gene share", {k: e.get(k) for k in ("value", "decode_s", "alignment_and_typing_s", "typing_phases", "process_wall_s", "error")})
+    for ln in e.get("log", []):
+        if "host-debug: locus" in ln or "whole action" in ln: print("   ", ln[-300:])
+else:
+    print(open('gpurun_out/r4_e2e_gene30.err').read()[-1500:])
+PY
