@@ -608,27 +608,42 @@ public:
         for(size_t li = 0; li < acc.size(); li++) tmpDir[li] = outputDirectory + "/.locus_" + std::to_string(li);
         std::vector<std::thread> pairWriters; std::vector<std::string> pairErr(acc.size());
         struct JoinAll { std::vector<std::thread>& t; ~JoinAll() { for(std::thread& x : t) if(x.joinable()) x.join(); } } joinPairWriters{pairWriters};
-        double lociClock[6] = {0, 0, 0, 0, 0, 0};      // filters, buffers, likelihoods, all pairs, call, k-mer lists (HLALA_HOST_DEBUG=1 prints them)
+        double lociClock[6] = {0, 0, 0, 0, 0, 0};      // filters (all loci side by side), buffers, likelihoods + all pairs + call, k-mer lists (HLALA_HOST_DEBUG=1 prints them)
         auto tL = std::chrono::steady_clock::now();
+        // the host part of every locus first, the loci side by side: the read / allele filters (hla/HLATyper.cpp:1509-1880; host code by design: libstdc++'s tie order)
+        // and what the likelihood kernel reads of a position -- first genotype character, genotype length, first quality (hla/HLATyper.cpp:2080-2277)
+        struct Prep { std::vector<uint8_t> use, ignored, g0, q0; std::vector<int32_t> glen; hlala_filter_stats fs; size_t nR = 0, nP = 0; std::string err; };
+        std::vector<Prep> prep(acc.size());
+        {
+            auto prepare = [&](size_t li) {
+                try {
+                    Acc& A = acc[li]; Res& R = res[li]; Prep& Q = prep[li];
+                    const size_t nR = A.read_pair.size(), nP = A.pos_exon.size();
+                    Q.nR = nR; Q.nP = nP;
+                    // (vectors may be empty: keep the pointers valid)
+                    A.read_pair.push_back(0); A.read_distance.push_back(0); A.pos_exon.push_back(0); A.pos_level.push_back(0); A.novel.push_back(0); A.mate.push_back(0); A.pmapq.push_back(0);
+                    A.geno.push_back(0); A.qual.push_back(0); for(int m = 0; m < 2; m++) { A.cols.push_back(0); A.wok.push_back(0); A.fok.push_back(0); A.rmapq.push_back(0); A.rrev.push_back(0); }
+                    hlala_exon_positions_out& pos = R.pos; std::memset(&pos, 0, sizeof(pos));
+                    pos.cap_reads = pos.n_reads = (int32_t)nR; pos.cap_pos = pos.n_pos = (int32_t)nP; pos.cap_chars = pos.n_chars = (int32_t)(A.geno.size() - 1); pos.n_pairs_ok = A.ok; pos.n_pairs_broken = A.broken;
+                    pos.read_pair = A.read_pair.data(); pos.read_weighted_ok = A.wok.data(); pos.read_fraction_ok = A.fok.data(); pos.read_distance = A.read_distance.data(); pos.read_cols_nongap = A.cols.data();
+                    pos.pos_off = A.pos_off.data(); pos.pos_exon = A.pos_exon.data(); pos.pos_level = A.pos_level.data(); pos.pos_mate = A.mate.data(); pos.pos_mapq = A.pmapq.data(); pos.pos_novel_gap = A.novel.data();
+                    pos.geno_off = A.geno_off.data(); pos.geno_chars = A.geno.data(); pos.qual_chars = A.qual.data(); pos.read_reverse = A.rrev.data(); pos.read_mapq = A.rmapq.data();
+                    Q.use.assign(nP + 1, 0); Q.ignored.assign(nR + 1, 0);
+                    if(hlala_filter_positions(&pos, &filterParams, Q.use.data(), Q.ignored.data(), &Q.fs) != HLALA_OK) throw std::runtime_error("hlala_filter_positions failed");
+                    Q.g0.assign(nP + 1, 0); Q.q0.assign(nP + 1, 0); Q.glen.assign(nP + 1, 0);
+                    for(size_t j = 0; j < nP; j++) { Q.g0[j] = A.geno[A.geno_off[j]]; Q.q0[j] = A.qual[A.geno_off[j]]; Q.glen[j] = A.geno_off[j + 1] - A.geno_off[j]; }
+                } catch(const std::exception& e) { prep[li].err = e.what(); }
+            };
+            if(acc.size() <= 1) { for(size_t li = 0; li < acc.size(); li++) prepare(li); }
+            else { ThreadJoiner th; for(size_t li = 0; li < acc.size(); li++) th.start([&, li]() { prepare(li); }); th.join(); }
+            for(const Prep& Q : prep) if(!Q.err.empty()) throw std::runtime_error(Q.err);
+        }
+        lociClock[0] += lap(tL);
         for(size_t li = 0; li < acc.size(); li++) {
-            Acc& A = acc[li]; Res& R = res[li];
-            const size_t nR = A.read_pair.size(), nP = A.pos_exon.size();
+            Acc& A = acc[li]; Res& R = res[li]; Prep& Q = prep[li];
+            const size_t nR = Q.nR, nP = Q.nP;
             tL = std::chrono::steady_clock::now();
-            // (vectors may be empty: keep the pointers valid)
-            A.read_pair.push_back(0); A.read_distance.push_back(0); A.pos_exon.push_back(0); A.pos_level.push_back(0); A.novel.push_back(0); A.mate.push_back(0); A.pmapq.push_back(0);
-            A.geno.push_back(0); A.qual.push_back(0); for(int m = 0; m < 2; m++) { A.cols.push_back(0); A.wok.push_back(0); A.fok.push_back(0); A.rmapq.push_back(0); A.rrev.push_back(0); }
-            hlala_exon_positions_out& pos = R.pos; std::memset(&pos, 0, sizeof(pos));
-            pos.cap_reads = pos.n_reads = (int32_t)nR; pos.cap_pos = pos.n_pos = (int32_t)nP; pos.cap_chars = pos.n_chars = (int32_t)(A.geno.size() - 1); pos.n_pairs_ok = A.ok; pos.n_pairs_broken = A.broken;
-            pos.read_pair = A.read_pair.data(); pos.read_weighted_ok = A.wok.data(); pos.read_fraction_ok = A.fok.data(); pos.read_distance = A.read_distance.data(); pos.read_cols_nongap = A.cols.data();
-            pos.pos_off = A.pos_off.data(); pos.pos_exon = A.pos_exon.data(); pos.pos_level = A.pos_level.data(); pos.pos_mate = A.mate.data(); pos.pos_mapq = A.pmapq.data(); pos.pos_novel_gap = A.novel.data();
-            pos.geno_off = A.geno_off.data(); pos.geno_chars = A.geno.data(); pos.qual_chars = A.qual.data(); pos.read_reverse = A.rrev.data(); pos.read_mapq = A.rmapq.data();
-            std::vector<uint8_t> use(nP + 1), ignored(nR + 1); hlala_filter_stats fs;
-            if(hlala_filter_positions(&pos, &filterParams, use.data(), ignored.data(), &fs) != HLALA_OK) throw std::runtime_error("hlala_filter_positions failed");
-            lociClock[0] += lap(tL);
-            // likelihoods: first genotype character, genotype length and first quality of every position (hla/HLATyper.cpp:2080-2277)
-            std::vector<uint8_t> g0(nP + 1), q0(nP + 1); std::vector<int32_t> glen(nP + 1);
-            for(size_t j = 0; j < nP; j++) { g0[j] = A.geno[A.geno_off[j]]; q0[j] = A.qual[A.geno_off[j]]; glen[j] = A.geno_off[j + 1] - A.geno_off[j]; }
-            hlala_exon_in xin{A.li.n_clusters, A.li.n_columns, A.li.cluster_seq, (int32_t)nR, A.pos_off.data(), A.pos_exon.data(), g0.data(), glen.data(), q0.data(), use.data()};
+            hlala_exon_in xin{A.li.n_clusters, A.li.n_columns, A.li.cluster_seq, (int32_t)nR, A.pos_off.data(), A.pos_exon.data(), Q.g0.data(), Q.glen.data(), Q.q0.data(), Q.use.data()};
             const size_t C = (size_t)A.li.n_clusters, nPairs = C * (C + 1) / 2;
             std::vector<double> marginal(C + 1);
             R.pairLL.alloc(nPairs + 1); R.misAvg.alloc(nPairs + 1); R.misMin.alloc(nPairs + 1); R.pNorm.alloc(nPairs + 1); R.order.alloc(nPairs + 1);
