@@ -126,9 +126,30 @@ def test_contigs_directory_loader(pkg, tmp_path, extended, trailing):
             assert intervals[i] == (("chr6", starts[0] - 1, starts[0] + L - 2, 0) if extended else ("chr6", 0, L - 1, 0))
         else:
             assert intervals[i] == ("PRG_%d" % c["contig_seqid"][i], 0, L - 1, i)
+    # the same in two steps (what the host program does: the BAM decoder starts on the intervals while the translation tables are still being read)
+    h = C.c_void_p()
+    lib.hlala_contigs_open_dir.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.hlala_contigs_load_translations.argtypes = [C.c_void_p]; lib.hlala_contigs_file_free.argtypes = [C.c_void_p]; lib.hlala_contigs_file_free.restype = None
+    lib.hlala_contigs_file_desc.argtypes = [C.c_void_p, C.POINTER(pkg.ContigsDesc)]; lib.hlala_contigs_file_intervals.argtypes = [C.c_void_p, C.POINTER(pkg.BamInterval), C.c_int32]
+    assert lib.hlala_contigs_open_dir(str(tmp_path).encode(), int(extended), C.byref(h)) == 0
+    iv = (pkg.BamInterval * n)()
+    assert lib.hlala_contigs_file_intervals(h, iv, n) == n
+    assert [(iv[i].ref_name.decode(), iv[i].start_0based, iv[i].stop_0based, iv[i].contig) for i in range(n)] == intervals
+    d = pkg.ContigsDesc()
+    assert lib.hlala_contigs_file_desc(h, C.byref(d)) != 0                 # not before the translation tables are in
+    assert lib.hlala_contigs_load_translations(h) == 0 and lib.hlala_contigs_load_translations(h) == 0
+    assert lib.hlala_contigs_file_desc(h, C.byref(d)) == 0 and d.n_contigs == n
+    tot = int(got["contig_off"][-1])
+    assert np.array_equal(np.ctypeslib.as_array(d.contig_off, (n + 1,)), got["contig_off"])
+    assert np.array_equal(np.ctypeslib.as_array(d.contig_level, (tot,)), got["contig_level"]) and np.array_equal(np.ctypeslib.as_array(d.contig_seq, (tot,)), got["contig_seq"])
+    lib.hlala_contigs_file_free(h)
     # errors
     (tmp_path / "translation" / ("%d.txt" % c["contig_seqid"][1])).unlink()
     with pytest.raises(pkg.HlalaError, match="translation"):
         pkg.load_contigs_dir(lib, tmp_path, extended)
+    h = C.c_void_p()
+    assert lib.hlala_contigs_open_dir(str(tmp_path).encode(), int(extended), C.byref(h)) == 0       # (the intervals do not need the tables)
+    assert lib.hlala_contigs_load_translations(h) != 0
+    lib.hlala_contigs_file_free(h)
     with pytest.raises(pkg.HlalaError):
         pkg.load_contigs_dir(lib, tmp_path / "nowhere", extended)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, session 15: boundary loop with the alignment of batch i+2 queued before batch i is read back (three sets of output arrays alive), pool caps
+# (bench.py --launch-first and HLALA_POOL_GB existed for this session only: the order lost, profiles/r04_experiments.txt 15)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 run() {
