@@ -228,7 +228,7 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
                 << ctxBeyond << " s, reference intervals before it " << loadSeconds << " s; "
                 << "whole action after the remapping: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s)\n" << std::flush; }
     std::cout << "Typing phases: batches (alignment, post-processing, exon positions) " << HLAtyper.timing.batches << " s, summary " << HLAtyper.timing.summary << " s, per-locus likelihoods and calls "
-              << HLAtyper.timing.loci << " s, k-mer pass " << HLAtyper.timing.kmers << " s, result files " << HLAtyper.timing.files << " s\n" << std::flush;
+              << HLAtyper.timing.loci << " s (with the k-mer questions; the files of a locus are written beside the next locus), result files after the last locus " << HLAtyper.timing.files << " s\n" << std::flush;
     if(chainErrors) std::cerr << "WARNING: " << chainErrors << " alignments exceeded a device capacity; their read pairs are not used for typing\n";
     // reads_per_level.txt, processBAM.cpp:1902-1913
     {

@@ -483,7 +483,7 @@ public:
 
     struct bestGuess { std::string locus, allele1, allele2; double Q1_allele1 = 0, Q1_allele2 = 0; hlala_locus_report_out summary; };
     // wall clock of the phases of the last HLATypeInference: the walk over the batches (alignment + what the typing takes from a resident batch), the summary
-    // file, the per-locus chain (filters, likelihoods, all pairs, call), the k-mer pass over the reads, the result files
+    // file, the per-locus chain (filters, likelihoods, all pairs, call, k-mer questions), the result files after the last locus (kmers: 0 since the reads are kept on the device)
     struct Timing { double batches = 0, summary = 0, loci = 0, kmers = 0, files = 0; } timing;
 
     // Per-batch part of alignReads_postSeedExtraction_andStoreInto + HLATypeInference, then the per-locus chain.  The sample's units go
@@ -603,7 +603,7 @@ public:
         struct Res { hlala_exon_positions_out pos; RawBuf<double> pairLL, misAvg, misMin, pNorm; RawBuf<int32_t> order; hlala_call_out call; std::vector<char> q[2]; int32_t nq[2], nt[2]; std::vector<uint8_t> present[2]; };
         std::vector<Res> res(acc.size());
         // (the all-pairs table of a locus -- millions of lines for class I -- is written by a thread of its own as soon as the locus is called: beside the typing
-        // of the next locus and the k-mer pass; into the locus' directory under the output directory, see "files" below)
+        // of the next locus; into the locus' directory under the output directory, see "files" below)
         std::vector<std::string> tmpDir(acc.size());
         for(size_t li = 0; li < acc.size(); li++) tmpDir[li] = outputDirectory + "/.locus_" + std::to_string(li);
         std::vector<std::thread> pairWriters; std::vector<std::string> pairErr(acc.size());
@@ -639,6 +639,37 @@ public:
             for(const Prep& Q : prep) if(!Q.err.empty()) throw std::runtime_error(Q.err);
         }
         lociClock[0] += lap(tL);
+        // (read names: the report looks up the units of the reads at the locus only -- a few thousand of the sample's millions; zero pages of the table that nobody touches stay unmapped)
+        struct Free { void operator()(const char** p) const { std::free((void*)p); } };
+        std::unique_ptr<const char*[], Free> names((const char**)std::calloc(nU + 1, sizeof(const char*)));
+        if(!names) throw std::bad_alloc();
+        for(const Acc& A : acc) for(int32_t u : A.read_pair) if(u >= 0 && (size_t)u < nU && !names[(size_t)u]) names[(size_t)u] = pB.readID((int64_t)u);
+        // The files of a locus are written by a thread of its own as soon as the locus is called and its k-mer questions are answered -- the all-pairs table (millions
+        // of lines for class I), then pile-up, read IDs, column incompatibilities, best guesses -- beside the typing of the next locus: every locus into a directory of
+        // its own under the output directory; afterwards, in locus order, the rows it appended to the shared files (best guesses, histogram lines) are appended to the
+        // real ones and its own files are moved up -- the bytes of one locus after the other.
+        std::vector<bestGuess> out(acc.size()); std::string lociJoined;
+        std::vector<std::string> ferr(acc.size());
+        auto write_one = [&](size_t li) {
+            try {
+                Acc& A = acc[li]; Res& R = res[li];
+                if(::mkdir(tmpDir[li].c_str(), 0775) != 0 && errno != EEXIST) throw std::runtime_error("cannot create " + tmpDir[li]);
+                double covered[2];
+                for(int a = 0; a < 2; a++) { int hit = 0; for(int32_t i = 0; i < R.nq[a]; i++) hit += R.present[a][i]; covered[a] = R.nt[a] ? (double)hit / (double)R.nt[a] : -1; }
+                hlala_locus_report_in rin; std::memset(&rin, 0, sizeof(rin));
+                rin.pos = &R.pos; rin.filter = &filterParams; rin.unit_name_1 = names.get(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.get(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
+                rin.n_clusters = A.li.n_clusters; rin.pair_ll = R.pairLL.data(); rin.mis_avg = R.misAvg.data(); rin.mis_min = R.misMin.data(); rin.order = R.order.data(); rin.p_normalized = R.pNorm.data(); rin.call = &R.call;
+                rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2; rin.pairs_file_done = 1;
+                rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = (int32_t)pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
+                rin.min_mapq = minimumMappingQuality; rin.min_weighted_ok = min_bothReads_weightedCharactersOK;
+                bestGuess g; g.locus = A.locus;
+                if(hlala_locus_write_files(A.L, &rin, tmpDir[li].c_str(), &g.summary) != HLALA_OK) throw std::runtime_error(std::string("hlala_locus_write_files: ") + hlala_typer_last_error());
+                g.allele1 = hlala_locus_cluster_id(A.L, R.call.first_cluster); g.allele2 = hlala_locus_cluster_id(A.L, R.call.second_cluster); g.Q1_allele1 = R.call.first_marginal; g.Q1_allele2 = R.call.second_p;
+                out[li] = g;
+            } catch(const std::exception& e) { ferr[li] = e.what(); }
+        };
+        JoinAll joinWritersFirst{pairWriters};       // (declared after everything the writers touch: on the way out of an exception they are joined before any of it goes)
+        struct Forget { mapper::processBAM& p; int n; ~Forget() { for(int d = 0; d < n; d++) hlala_kmer_forget_reads(p.batch_ctx(d)); } } forget{pB, nDev};
         for(size_t li = 0; li < acc.size(); li++) {
             Acc& A = acc[li]; Res& R = res[li]; Prep& Q = prep[li];
             const size_t nR = Q.nR, nP = Q.nP;
@@ -652,81 +683,38 @@ public:
             chk(hlala_type_locus(c, &xin, nullptr, nullptr, R.pairLL.data(), R.misAvg.data(), R.misMin.data(), R.order.data(), R.pNorm.data(), marginal.data(), &R.call), "hlala_type_locus");
             lociClock[2] += lap(tL);
             if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: locus " << A.locus << ": " << C << " clusters, " << nR << " reads, " << nP << " positions\n";
-            if(::mkdir(tmpDir[li].c_str(), 0775) != 0 && errno != EEXIST) throw std::runtime_error("cannot create " + tmpDir[li]);
-            pairWriters.emplace_back([&, li]() {
-                const Res& Rr = res[li];
-                if(hlala_locus_write_pairs_file(acc[li].L, acc[li].li.n_clusters, Rr.order.data(), Rr.pNorm.data(), Rr.pairLL.data(), Rr.misAvg.data(), tmpDir[li].c_str()) != HLALA_OK)
-                    pairErr[li] = std::string("hlala_locus_write_pairs_file: ") + hlala_typer_last_error();
-            });
-            for(int a = 0; a < 2; a++) {                                              // k-mers of the two called alleles, :2652-2688
+            for(int a = 0; a < 2; a++) {                                              // k-mers of the two called alleles, :2652-2688 ...
                 const int32_t cl = a ? R.call.second_cluster : R.call.first_cluster; R.nq[a] = 0; R.nt[a] = 0;
                 hlala_locus_cluster_kmers(A.L, cl, k_for_kMer_index, nullptr, 0, &R.nq[a], &R.nt[a]);
                 R.q[a].assign((size_t)R.nq[a] * k_for_kMer_index + 1, 0); R.present[a].assign((size_t)R.nq[a] + 1, 0);
                 tchk(hlala_locus_cluster_kmers(A.L, cl, k_for_kMer_index, R.q[a].data(), R.nq[a], &R.nq[a], &R.nt[a]), "hlala_locus_cluster_kmers");
-            }
-            lociClock[5] += lap(tL);
-        }
-        timing.loci = lap(tLap);
-        if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: per-locus chain: filters " << lociClock[0] << ", buffers " << lociClock[1] << ", likelihoods + all pairs + call " << lociClock[2] << ", pair writer + k-mer lists " << lociClock[5] << " s\n";
-        // ---- which of those k-mers occur in the reads that went into typing: asked of the reads every device kept while it walked its batches
-        {
-            struct Forget { mapper::processBAM& p; int n; ~Forget() { for(int d = 0; d < n; d++) hlala_kmer_forget_reads(p.batch_ctx(d)); } } forget{pB, nDev};
-            for(int d = 0; d < nDev; d++) {
-                hlala_ctx* cd = pB.batch_ctx(d);
-                for(size_t li = 0; li < res.size(); li++) for(int a = 0; a < 2; a++) {
-                    Res& R = res[li];
+                // ... and which of them occur in the reads that went into typing: asked of the reads every device kept while it walked its batches
+                for(int d = 0; d < nDev; d++) {
+                    hlala_ctx* cd = pB.batch_ctx(d);
                     std::vector<uint8_t> pr((size_t)R.nq[a] + 1);
                     if(hlala_kmer_presence_kept(cd, k_for_kMer_index, R.nq[a], R.q[a].data(), pr.data()) != HLALA_OK) throw std::runtime_error(std::string("hlala_kmer_presence_kept: ") + hlala_last_error(cd));
                     for(int32_t i = 0; i < R.nq[a]; i++) R.present[a][(size_t)i] |= pr[(size_t)i];
                 }
             }
+            if(::mkdir(tmpDir[li].c_str(), 0775) != 0 && errno != EEXIST) throw std::runtime_error("cannot create " + tmpDir[li]);
+            pairWriters.emplace_back([&, li]() {
+                const Res& Rr = res[li];
+                if(hlala_locus_write_pairs_file(acc[li].L, acc[li].li.n_clusters, Rr.order.data(), Rr.pNorm.data(), Rr.pairLL.data(), Rr.misAvg.data(), tmpDir[li].c_str()) != HLALA_OK)
+                    { pairErr[li] = std::string("hlala_locus_write_pairs_file: ") + hlala_typer_last_error(); return; }
+                write_one(li);
+            });
+            lociClock[5] += lap(tL);
         }
-        timing.kmers = lap(tLap);
-        // ---- files
-        // (read names: the report looks up the units of the reads at the locus only -- a few thousand of the sample's millions; zero pages of the table that nobody touches stay unmapped)
-        struct Free { void operator()(const char** p) const { std::free((void*)p); } };
-        std::unique_ptr<const char*[], Free> names((const char**)std::calloc(nU + 1, sizeof(const char*)));
-        if(!names) throw std::bad_alloc();
-        const auto tNames0 = std::chrono::steady_clock::now();
-        for(const Acc& A : acc) for(int32_t u : A.read_pair) if(u >= 0 && (size_t)u < nU && !names[(size_t)u]) names[(size_t)u] = pB.readID((int64_t)u);
-        // The loci write their files side by side (the all-pairs table of a class-I locus is millions of lines): every locus into a directory of its own
-        // under the output directory; afterwards, in locus order, the rows it appended to the shared files (best guesses, histogram lines) are appended to
-        // the real ones and its own files are moved up -- the bytes of one locus after the other.
-        std::vector<bestGuess> out(acc.size()); std::string lociJoined;
+        timing.loci = lap(tLap);
+        if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: per-locus chain: filters " << lociClock[0] << ", buffers " << lociClock[1] << ", likelihoods + all pairs + call " << lociClock[2] << ", pair writer + k-mer lists " << lociClock[5] << " s\n";
+        timing.kmers = 0;                                                          // (the k-mer questions are part of the per-locus chain since the reads are kept on the device)
+        // ---- files: the writers of the loci finish; their directories are merged in locus order
         {
-            std::vector<std::string> ferr(acc.size());
             auto tF = std::chrono::steady_clock::now();
             for(std::thread& x : pairWriters) x.join();
             for(const std::string& e : pairErr) if(!e.empty()) throw std::runtime_error(e);
-            if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: files: names " << std::chrono::duration<double>(tF - tLap).count() << " (of which after the table was allocated " << std::chrono::duration<double>(tF - tNames0).count() << "), waiting for the all-pairs writers " << lap(tF) << " s\n";
-            auto write_one = [&](size_t li) {
-                try {
-                    Acc& A = acc[li]; Res& R = res[li];
-                    if(::mkdir(tmpDir[li].c_str(), 0775) != 0 && errno != EEXIST) throw std::runtime_error("cannot create " + tmpDir[li]);
-                    double covered[2];
-                    for(int a = 0; a < 2; a++) { int hit = 0; for(int32_t i = 0; i < R.nq[a]; i++) hit += R.present[a][i]; covered[a] = R.nt[a] ? (double)hit / (double)R.nt[a] : -1; }
-                    hlala_locus_report_in rin; std::memset(&rin, 0, sizeof(rin));
-                    rin.pos = &R.pos; rin.filter = &filterParams; rin.unit_name_1 = names.get(); rin.unit_name_2 = pB.longReadsMode ? nullptr : names.get(); rin.long_read_mode = pB.longReadsMode ? 1 : 0;
-                    rin.n_clusters = A.li.n_clusters; rin.pair_ll = R.pairLL.data(); rin.mis_avg = R.misAvg.data(); rin.mis_min = R.misMin.data(); rin.order = R.order.data(); rin.p_normalized = R.pNorm.data(); rin.call = &R.call;
-                    rin.kmers_covered[0] = covered[0]; rin.kmers_covered[1] = covered[1]; rin.unaccounted_min_coverage = 30; rin.unaccounted_min_fraction = 0.2; rin.pairs_file_done = 1;
-                    rin.unit_stats = &us; rin.unit_mask = include.data(); rin.n_units = (int32_t)pB.n_units; rin.insert_mean = pB.IS_mean; rin.insert_sd = pB.IS_sd;
-                    rin.min_mapq = minimumMappingQuality; rin.min_weighted_ok = min_bothReads_weightedCharactersOK;
-                    bestGuess g; g.locus = A.locus;
-                    if(hlala_locus_write_files(A.L, &rin, tmpDir[li].c_str(), &g.summary) != HLALA_OK) throw std::runtime_error(std::string("hlala_locus_write_files: ") + hlala_typer_last_error());
-                    g.allele1 = hlala_locus_cluster_id(A.L, R.call.first_cluster); g.allele2 = hlala_locus_cluster_id(A.L, R.call.second_cluster); g.Q1_allele1 = R.call.first_marginal; g.Q1_allele2 = R.call.second_p;
-                    out[li] = g;
-                } catch(const std::exception& e) { ferr[li] = e.what(); }
-            };
-            const size_t par = acc.size() < 8 ? acc.size() : 8;
-            if(par <= 1) { for(size_t li = 0; li < acc.size(); li++) write_one(li); }
-            else {
-                std::atomic<size_t> nextLocus(0);
-                std::vector<std::thread> th;
-                for(size_t t = 0; t < par; t++) th.emplace_back([&]() { for(;;) { const size_t li = nextLocus.fetch_add(1); if(li >= acc.size()) break; write_one(li); } });
-                for(std::thread& t : th) t.join();
-            }
             for(const std::string& e : ferr) if(!e.empty()) throw std::runtime_error(e);
-            if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: files: per-locus files " << lap(tF) << " s\n";
+            if(std::getenv("HLALA_HOST_DEBUG")) std::cerr << "host-debug: files: waiting for the writers of the loci " << lap(tF) << " s\n";
             for(size_t li = 0; li < acc.size(); li++) {
                 DIR* dd = opendir(tmpDir[li].c_str());
                 if(!dd) throw std::runtime_error("cannot open " + tmpDir[li]);
