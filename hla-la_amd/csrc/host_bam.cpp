@@ -63,10 +63,12 @@ void parallel_for(int64_t n, int T, F fn)
     std::atomic<int64_t> next(0);
     std::exception_ptr err; std::mutex em;
     std::vector<std::thread> th;
-    for(int t = 0; t < T; t++) th.emplace_back([&, t]() {
-        try { for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
-        catch(...) { std::lock_guard<std::mutex> g(em); if(!err) err = std::current_exception(); next.store(n); }
-    });
+    try {
+        for(int t = 0; t < T; t++) th.emplace_back([&, t]() {
+            try { for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
+            catch(...) { std::lock_guard<std::mutex> g(em); if(!err) err = std::current_exception(); next.store(n); }
+        });
+    } catch(...) { next.store(n); for(auto& x : th) x.join(); throw; }       // (a thread that cannot be started: the ones running are joined, not destroyed joinable)
     for(auto& x : th) x.join();
     if(err) std::rethrow_exception(err);
 }
@@ -82,10 +84,12 @@ void parallel_for_beside(int64_t n, int T, F fn, M beside)
     std::atomic<int64_t> next(0);
     std::exception_ptr err, errMain; std::mutex em;
     std::vector<std::thread> th;
-    for(int t = 0; t < T; t++) th.emplace_back([&, t]() {
-        try { for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
-        catch(...) { std::lock_guard<std::mutex> g(em); if(!err) err = std::current_exception(); next.store(n); stop.store(true); }
-    });
+    try {
+        for(int t = 0; t < T; t++) th.emplace_back([&, t]() {
+            try { for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
+            catch(...) { std::lock_guard<std::mutex> g(em); if(!err) err = std::current_exception(); next.store(n); stop.store(true); }
+        });
+    } catch(...) { next.store(n); stop.store(true); for(auto& x : th) x.join(); throw; }
     try { beside(stop); } catch(...) { errMain = std::current_exception(); next.store(n); }
     for(auto& x : th) x.join();
     if(err) std::rethrow_exception(err);

@@ -297,7 +297,8 @@ try {
     {
         const size_t T = std::min<size_t>(rows.size(), 8);
         std::atomic<size_t> next(0); std::vector<std::thread> th; std::vector<std::exception_ptr> ex(T);
-        for(size_t t = 0; t < T; t++) th.emplace_back([&, t]() { try { for(;;) { const size_t ri = next.fetch_add(1); if(ri >= rows.size()) break; parse_one(ri); } } catch(...) { ex[t] = std::current_exception(); } });
+        try { for(size_t t = 0; t < T; t++) th.emplace_back([&, t]() { try { for(;;) { const size_t ri = next.fetch_add(1); if(ri >= rows.size()) break; parse_one(ri); } } catch(...) { ex[t] = std::current_exception(); } }); }
+        catch(...) { next.store(rows.size()); for(std::thread& x : th) x.join(); throw; }
         for(std::thread& x : th) x.join();
         for(const std::exception_ptr& e : ex) if(e) std::rethrow_exception(e);
     }

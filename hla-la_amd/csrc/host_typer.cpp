@@ -15,6 +15,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <mutex>
 #include <exception>
 #include <string_view>
 #include <functional>
@@ -174,7 +175,7 @@ try {
         const size_t Tn = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n, 16), (size_t)hlala_host::host_cpu_budget()));
         std::atomic<size_t> next(0); std::vector<std::exception_ptr> ex(Tn); std::vector<std::thread> th;
         auto work = [&](size_t t) { try { for(;;) { const size_t i = next.fetch_add(1); if(i >= n) break; fn(i); } } catch(...) { ex[t] = std::current_exception(); } };
-        for(size_t t = 1; t < Tn; t++) th.emplace_back(work, t);
+        try { for(size_t t = 1; t < Tn; t++) th.emplace_back(work, t); } catch(...) { next.store(n); for(std::thread& x : th) x.join(); throw; }
         work(0);
         for(std::thread& x : th) x.join();
         for(const std::exception_ptr& e : ex) if(e) std::rethrow_exception(e);
@@ -542,9 +543,13 @@ static int write_pairs_table(const hlala_locus* L, const int C, const int32_t* o
             }
         };
         unsigned T = (unsigned)hlala_host::host_cpu_budget(); if(T > 64) T = 64; if((long long)T > nChunks) T = (unsigned)nChunks;
-        std::vector<std::thread> th; for(unsigned t = 1; t < T; t++) th.emplace_back(work);
-        work();
+        std::exception_ptr werr; std::mutex wm;
+        auto guarded = [&]() { try { work(); } catch(...) { std::lock_guard<std::mutex> g(wm); if(!werr) werr = std::current_exception(); next.store(nChunks); } };
+        std::vector<std::thread> th;
+        try { for(unsigned t = 1; t < T; t++) th.emplace_back(guarded); } catch(...) { next.store(nChunks); for(std::thread& x : th) x.join(); throw; }
+        guarded();
         for(std::thread& x : th) x.join();
+        if(werr) std::rethrow_exception(werr);
         for(const std::string& pstr : parts) ap.write(pstr.data(), (std::streamsize)pstr.size());
     }
     return HLALA_OK;
@@ -671,7 +676,8 @@ try {
         if(K == 1) format_run(0);
         else {
             std::vector<std::thread> th; std::vector<std::exception_ptr> ex((size_t)K);
-            for(int k = 0; k < K; k++) th.emplace_back([&, k]() { try { format_run(k); } catch(...) { ex[(size_t)k] = std::current_exception(); } });
+            try { for(int k = 0; k < K; k++) th.emplace_back([&, k]() { try { format_run(k); } catch(...) { ex[(size_t)k] = std::current_exception(); } }); }
+            catch(...) { for(std::thread& t : th) t.join(); throw; }
             for(std::thread& t : th) t.join();
             for(const std::exception_ptr& e : ex) if(e) std::rethrow_exception(e);
         }
