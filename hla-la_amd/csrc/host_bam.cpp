@@ -579,7 +579,7 @@ try {
                                 default: throw Fail("unknown BAM tag type");
                             }
                             if(p + sz > rn) throw Fail("corrupt BAM tag");
-                            if(t0 == 'A' && t1 == 'S' && isInt) { as = (int)v; haveAS = true; }
+                            if(t0 == 'A' && t1 == 'S' && isInt) { as = (int)v; haveAS = true; break; }      // (the first one, as BamTools' GetTag; what follows -- XS, SA, XA: hundreds of bytes with bwa -a -- is not walked)
                             p += sz;
                         }
                         if(!haveAS) throw Fail("Can't get AS tag!");                               // assert(1 == 0), :4330-4332
