@@ -171,7 +171,6 @@ def main():
     ap.add_argument("--e2e-pairs", type=int, default=8_388_608, help="pairs of the sample pushed through `HLA-LA --action HLA` for the end-to-end rate (0 = skip)")
     ap.add_argument("--e2e-frac-gene", type=float, default=0.04, help="share of the end-to-end sample drawn from the gene windows: 0.04 = the windows' share of the graph, i.e. the uniform "
                     "coverage of a whole-genome sample (the resident workload keeps 0.3: its gene-window pairs are the expensive ones; at 0.3 every typed locus would see 2000x coverage)")
-    ap.add_argument("--e2e-samples", type=int, default=2, help="end to end: also this many copies of the sample in ONE HLA-LA call on one device (they take turns: decode beside alignment); 1 = off")
     ap.add_argument("--e2e-threads", default="0,128", help="--decodeThreads values of the end-to-end runs (0 = the decoder's default: twice the CPUs the process may use, at most 32 threads)")
     ap.add_argument("--no-extras-but-e2e", action="store_true", help="of the measurements outside the timed region only the end-to-end run")
     ap.add_argument("--e2e-variants", default="", help="experiments: further end-to-end runs of the same sample under other environments, 'label:ENV=1 ENV2=x;label2:...'")
@@ -652,30 +651,8 @@ def end_to_end(args, P, synth, w, mk):
                     "log": [ln[:700] for ln in r.stdout.splitlines() if ("Seed extraction:" in ln or ln.startswith("End-to-end:"))] + [ln[:300] for ln in r.stderr.splitlines() if ln.startswith(("bam-debug:", "host-debug:"))][:60],
                     "loci": loci, "result_files": len(files), "calls": calls[:6]}
 
-        def several(ns):
-            """ns samples in ONE call on ONE device (HLA-LA --sampleID a,b --devices 0): the samples take turns -- a sample decodes while the one before it aligns, and aligns
-            while that one is typed and written.  The figure is pairs of all samples / wall clock of the whole process (graph directory read once, contexts, stand-in remapping included)."""
-            outs = [os.path.join(tmp, "outS%d" % k) for k in range(ns)]
-            cmd = [exe, "--action", "HLA", "--maxThreads", "2", "--sampleID", ",".join("S%d" % k for k in range(ns)), "--outputDirectory", ",".join(outs), "--PRG_graph_dir", gdir,
-                   "--FASTQU", ",".join([os.path.join(tmp, "r1.fq")] * ns), "--FASTQ1", ",".join([os.path.join(tmp, "r1.fq")] * ns), "--FASTQ2", ",".join([os.path.join(tmp, "r2.fq")] * ns),
-                   "--bwa_bin", os.path.join(tmp, "bwa"), "--samtools_bin", os.path.join(tmp, "samtools"), "--mapAgainstCompleteGenome", "0", "--longReads", "0", "--loci", ",".join(loci),
-                   "--rngSeed", "12345", "--batchPairs", str(ch), "--devices", "0"]
-            t0 = time.time()
-            r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp, timeout=2400, env=dict(os.environ))
-            t_run = time.time() - t0
-            if r.returncode != 0:
-                return {"samples": ns, "error": (r.stdout + r.stderr)[-1500:]}
-            per = [float(x) for x in re.findall(r"End-to-end: ([0-9.e+]+) units per s", r.stdout)]
-            same = all(sorted(os.listdir(os.path.join(o, "hla"))) == sorted(os.listdir(os.path.join(outs[0], "hla"))) for o in outs)
-            for o in outs:
-                shutil.rmtree(o, ignore_errors=True)
-            return {"samples": ns, "pairs": ns * nch * ch, "process_wall_s": t_run, "pairs_per_s_whole_process": ns * nch * ch / t_run, "per_sample_end_to_end_lines": per, "same_result_files": bool(same),
-                    "what": "HLA-LA --sampleID a,b,... --devices 0: the samples of one call take turns on the device (decode of sample k+1 beside the alignment of sample k)"}
-
         runs = [one(int(t)) for t in str(args.e2e_threads).split(",") if t.strip() != ""]
         res = runs[0]
-        if args.e2e_samples > 1:
-            res["several_samples_one_gpu"] = several(args.e2e_samples)
         if args.e2e_variants:          # experiments: the same sample again under other environments ("label:ENV=1 ENV2=x;label2:...")
             res["variants"] = {}
             for v in args.e2e_variants.split(";"):

@@ -676,7 +676,7 @@ BUILD_LANE_CLASS = 1         # hlala_build_flags(): the lane-per-DP class is com
 
 
 EXPORTED_SYMBOLS = [
-    "hlala_create", "hlala_destroy", "hlala_trim_pool", "hlala_last_error", "hlala_graph_get_info", "hlala_graph_get_nodes",
+    "hlala_create", "hlala_destroy", "hlala_last_error", "hlala_graph_get_info", "hlala_graph_get_nodes",
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
     "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_set_first_chain", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
     "hlala_pair_chains", "hlala_align_batch", "hlala_batch_get_chains", "hlala_batch_get_pairs",
@@ -861,13 +861,6 @@ class Context:
         out = np.zeros(max(1, info.n_levels - 1), np.int32)
         self._check(self.lib.hlala_get_coverage(self.h, out.ctypes.data_as(c_i32p), int(reset)), "hlala_get_coverage")
         return out
-
-    def trim_pool(self):
-        """hlala_trim_pool: the device memory of destroyed batches the context keeps for its next batch goes back to the device; returns the bytes freed."""
-        n = C.c_int64(0)
-        self.lib.hlala_trim_pool.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
-        self._check(self.lib.hlala_trim_pool(self.h, C.byref(n)), "hlala_trim_pool")
-        return n.value
 
     def close(self):
         if getattr(self, "h", None):

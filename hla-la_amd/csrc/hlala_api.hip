@@ -494,21 +494,6 @@ void hlala_destroy(hlala_ctx* c)
     delete c;
 }
 
-// the device memory of destroyed batches that the context keeps for its next batch goes back to the device (another context on the same GPU is about to need it)
-extern "C" int hlala_trim_pool(hlala_ctx* c, int64_t* bytes_freed)
-{
-    if(!c) return HLALA_E_ARG;
-    DEV_GUARD(c);
-    if(bytes_freed) *bytes_freed = 0;
-    // (a parked block may still be read by work queued before its batch was destroyed: everything the context queued has to be through)
-    for(hipStream_t st : {c->stream, c->side, c->up, c->rs}) if(st) HIP_TRY(c, hipStreamSynchronize(st));
-    int64_t freed = 0;
-    for(auto& kv : c->pool) { freed += (int64_t)kv.first; c->block_bytes.erase(kv.second); (void)hipFree(kv.second); }
-    c->pool.clear(); c->pool_bytes = 0;
-    if(bytes_freed) *bytes_freed = freed;
-    return HLALA_OK;
-}
-
 int hlala_graph_get_info(const hlala_ctx* c, hlala_graph_info* info)
 {
     if(!c || !info) return HLALA_E_ARG;

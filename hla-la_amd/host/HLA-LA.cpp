@@ -137,12 +137,9 @@ std::vector<std::string> split_list(const std::string& l)
 
 // what several samples of one call share: the graph directory as the aligner and as the typer read it (read once, read-only afterwards)
 struct SharedGraph { std::shared_ptr<mapper::GraphDirectory> dir; std::unique_ptr<hla::HLATyper> typer; };
-// (samples of one call that share a device: the lane they take turns on, and how many come before this one)
-struct LanePlace { mapper::DeviceLane* lane = nullptr; int k = 0; };
 
-int action_HLA_one(const std::map<std::string, std::string>& arguments, const std::vector<int>& devices, const SharedGraph* shared = nullptr, LanePlace place = LanePlace())
+int action_HLA_one(const std::map<std::string, std::string>& arguments, const std::vector<int>& devices, const SharedGraph* shared = nullptr)
 {
-    mapper::LaneTurn turn(place.lane, place.k);
     unsigned int maxThreads = 1;
     need(arguments, "sampleID"); need(arguments, "outputDirectory"); need(arguments, "PRG_graph_dir");
     if(!(arguments.count("BAM") || (arguments.count("FASTQ1") && arguments.count("FASTQ2")))) throw std::runtime_error("Please specify --BAM or --FASTQ1 / --FASTQ2");
@@ -191,10 +188,8 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     mapper::processBAM BAMprocessor(graphDirectory, longReads.length() ? 16384 : 384, rngSeed, devices, decodeThreads);
     const double loadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count();
     std::cout << timestamp() << "Start seed extraction\n" << std::flush;
-    turn.wait_decode();                                                      // (a sample before this one on the same device is still decoding: the host's threads are its)
     const auto tOpen = std::chrono::steady_clock::now();
     BAMprocessor.openBAM(BAM_remapped, longReads.length() != 0, batchPairs);
-    turn.decode_done();
     const double openSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tOpen).count();
     std::cout << timestamp() << "Seed extraction: " << BAMprocessor.n_units << " complete units, BAM decoded in " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
               << " threads (index " << BAMprocessor.decode_phase_seconds[0] << ", inflate " << BAMprocessor.decode_phase_seconds[1] << ", parse " << BAMprocessor.decode_phase_seconds[2] << ", group "
@@ -215,10 +210,8 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     make_or_clearDirectory(outputDirectory + "/hla");                                                   // processBAM.cpp:1805-1806
     std::cout << timestamp() << "Alignment of " << BAMprocessor.n_units << (longReads.length() ? " reads" : " read pairs") << " in " << BAMprocessor.n_batches() << " GPU batch(es) on " << BAMprocessor.n_devices() << " device context(s)\n" << std::flush;
     double alignSeconds = 0; int64_t chainErrors = 0;
-    turn.wait_align();                                                       // (... is still aligning: the device is its)
     const auto tInfer = std::chrono::steady_clock::now();
-    std::vector<hla::HLATyper::bestGuess> calls = HLAtyper.HLATypeInference(BAMprocessor, outputDirectory_for_HLA, loci, &alignSeconds, &chainErrors,
-        [&]() { if(turn.shared()) { BAMprocessor.trim_pools(); turn.align_done(); } });
+    std::vector<hla::HLATyper::bestGuess> calls = HLAtyper.HLATypeInference(BAMprocessor, outputDirectory_for_HLA, loci, &alignSeconds, &chainErrors);
     const double inferSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tInfer).count();
     const size_t pairs = longReads.length() ? 0 : (size_t)BAMprocessor.n_units, unpaired = longReads.length() ? (size_t)BAMprocessor.n_units : 0;
     std::cout << timestamp() << "Processed " << pairs << " protoSeeds (read pairs) / " << unpaired << " protoSeeds (unpaired long reads)\n" << std::flush;
@@ -281,19 +274,10 @@ int action_HLA(const std::map<std::string, std::string>& arguments)
         std::cout << timestamp() << "Graph directory read once for " << samples.size() << " samples in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tLoad).count() << " s\n" << std::flush;
     }
     std::vector<std::string> errs(samples.size());
-    // Sample i runs on device i mod #devices.  Samples that share a device take turns on it (mapper::DeviceLane): the next one decodes while this one aligns, and
-    // aligns while this one is typed and its files are written.
-    std::vector<std::unique_ptr<mapper::DeviceLane>> lanes(devices.size());
-    std::vector<LanePlace> place(samples.size());
-    if(samples.size() > devices.size()) {
-        for(size_t d = 0; d < devices.size(); d++) lanes[d].reset(new mapper::DeviceLane());
-        for(size_t i = 0; i < samples.size(); i++) { place[i].lane = lanes[i % devices.size()].get(); place[i].k = (int)(i / devices.size()); }
-        std::cout << timestamp() << samples.size() << " samples take turns on " << devices.size() << " device(s): a sample decodes while the one before it on its device aligns\n" << std::flush;
-    }
     {
         ThreadJoiner th;
         for(size_t i = 0; i < samples.size(); i++) th.start([&, i]() {
-            try { action_HLA_one(per[i], std::vector<int>(1, devices[i % devices.size()]), &shared, place[i]); } catch(const std::exception& e) { errs[i] = e.what(); }
+            try { action_HLA_one(per[i], std::vector<int>(1, devices[i % devices.size()]), &shared); } catch(const std::exception& e) { errs[i] = e.what(); }
         });
     }
     for(size_t i = 0; i < samples.size(); i++) if(!errs[i].empty()) throw std::runtime_error("sample " + samples[i] + ": " + errs[i]);

@@ -19,12 +19,10 @@
 #include <atomic>
 #include <cerrno>
 #include <chrono>
-#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
-#include <functional>
 #include <iostream>
 #include <memory>
 #include <mutex>
@@ -261,26 +259,6 @@ private:
 // What a process reads of a graph directory ONCE, however many samples it aligns (BASELINE config 4: eight samples side by side, one per GPU): the graph,
 // the contigs with their translation tables, the reference intervals the BAM decoder keeps.  Read-only after construction; every processBAM of the process
 // holds a reference.
-// Samples of one call that share a GPU take turns (HLA-LA --sampleID a,b,... with fewer devices than samples): sample k + 1 decodes its BAM -- host work --
-// while sample k aligns, and aligns while sample k is typed and written, so that the device sees one sample's batches after the other's without the gap of
-// a decode in between.  A turn is a count of finished phases; a sample that fails gives its turns up on the way out (LaneTurn), nobody waits for it.
-struct DeviceLane {
-    std::mutex m; std::condition_variable cv; int decoded = 0, aligned = 0;
-    void wait(const int& counter, int k) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&]() { return counter >= k; }); }
-    void done(int& counter, int k) { { std::lock_guard<std::mutex> l(m); if(counter < k + 1) counter = k + 1; } cv.notify_all(); }
-};
-struct LaneTurn {
-    DeviceLane* lane; int k;                   // k: how many samples of the lane come before this one
-    LaneTurn(DeviceLane* l, int k_) : lane(l), k(k_) {}
-    ~LaneTurn() { decode_done(); align_done(); }
-    LaneTurn(const LaneTurn&) = delete; LaneTurn& operator=(const LaneTurn&) = delete;
-    void wait_decode() { if(lane) lane->wait(lane->decoded, k); }
-    void decode_done() { if(lane) lane->done(lane->decoded, k); }
-    void wait_align() { if(lane) lane->wait(lane->aligned, k); }
-    void align_done() { if(lane) lane->done(lane->aligned, k); }
-    bool shared() const { return lane != nullptr; }
-};
-
 class GraphDirectory {
 public:
     // Returns once the reference intervals are known (sequences.txt + the reference sequences it names: what the BAM decoder needs); the graph and the
@@ -426,8 +404,6 @@ public:
         }
         return b;
     }
-    // the contexts give the device memory they keep for their next batch back (hlala_trim_pool): no batch of this sample follows
-    void trim_pools() { for(hlala_ctx* c : ctxs_) if(c) (void)hlala_trim_pool(c, nullptr); }
     void release(int32_t bi) { if(live_.at((size_t)bi)) { hlala_batch_destroy(live_[(size_t)bi]); live_[(size_t)bi] = nullptr; aligned_[(size_t)bi] = 0; } }
 
     // extractSeeds2 + estimateInsertSize + alignReads_postSeedExtraction (mapper/processBAM.cpp:703-864, 1071-1165, 2391-2483), one batch
@@ -515,7 +491,7 @@ public:
     // statistics and the exon positions of every locus -- is taken while the batch is resident and appended on the host.
     // align_seconds (optional) receives the time spent in alignment proper (the reference's "Speed:" line, processBAM.cpp:1894-1898).
     std::vector<bestGuess> HLATypeInference(mapper::processBAM& pB, const std::string& outputDirectory, const std::vector<std::string>& loci_for_HLAtyping,
-                                            double* align_seconds = nullptr, int64_t* chain_errors = nullptr, const std::function<void()>& after_batches = std::function<void()>())
+                                            double* align_seconds = nullptr, int64_t* chain_errors = nullptr)
     {
         hlala_ctx* c = pB.ctx();                          // the per-locus chain (likelihoods, all pairs, call) runs on the first device
         auto chk = [&](int rc, const char* what) { if(rc != HLALA_OK) throw std::runtime_error(std::string(what) + ": " + hlala_last_error(c)); };
@@ -598,7 +574,6 @@ public:
         if(nDev == 1) device_walk(0);
         else { std::vector<std::thread> th; for(int d = 0; d < nDev; d++) th.emplace_back(device_walk, d); for(std::thread& t : th) t.join(); }
         for(const std::string& e : devErr) if(!e.empty()) throw std::runtime_error(e);
-        if(after_batches) after_batches();                // (the last batch is read back and released: a caller with another sample waiting for the device lets it go now)
         double alignS = nDev == 1 ? devAlign[0] : std::chrono::duration<double>(std::chrono::steady_clock::now() - tAll).count();
         auto lap = [](std::chrono::steady_clock::time_point& t) { const auto n = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double>(n - t).count(); t = n; return d; };
         auto tLap = tAll;

@@ -91,10 +91,6 @@ int  hlala_create(hlala_ctx** out, int device, void* stream,
                   const hlala_graph_desc* graph, const hlala_contigs_desc* contigs,
                   const hlala_params* params);
 void hlala_destroy(hlala_ctx* ctx);
-/* A context keeps the device memory of destroyed batches (tens of GB for million-pair batches) for its next batch.  hlala_trim_pool gives it back to the
- * device -- for a caller whose next batches run on ANOTHER context of the same GPU (HLA-LA with several samples per device: the next sample aligns while
- * this one is typed).  Waits for everything the context has queued.  bytes_freed may be NULL. */
-int  hlala_trim_pool(hlala_ctx* ctx, int64_t* bytes_freed);
 const char* hlala_last_error(const hlala_ctx* ctx);   /* ctx may be NULL: create-time errors */
 
 /* Flattened-graph introspection (parity of the one-time host pass with the oracle).          */

@@ -209,15 +209,6 @@ def test_action_hla_writes_the_files_of_the_ctypes_path(exe, pkg, tmp_path):
     for o in ("outA", "outB"):
         for fn in files:
             assert (tmp_path / o / "hla" / fn).read_bytes() == (out1 / "hla" / fn).read_bytes(), (o, fn)
-    # ---- three samples on ONE listed device take turns on it (a sample decodes while the one before it aligns, and aligns while that one is typed): the same files again
-    rb = [x for x in base]
-    for key, val in (("--sampleID", "S1,S2,S3"), ("--FASTQ1", ",".join([str(tmp_path / "r1.fq")] * 3)), ("--FASTQ2", ",".join([str(tmp_path / "r2.fq")] * 3)), ("--FASTQU", ",".join([str(tmp_path / "r1.fq")] * 3))):
-        rb[rb.index(key) + 1] = val
-    r5 = subprocess.run(rb + ["--outputDirectory", ",".join(str(tmp_path / o) for o in ("outC", "outD", "outE")), "--devices", "0", "--batchPairs", "200"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
-    assert r5.returncode == 0 and "3 samples take turns on 1 device(s)" in r5.stdout and "Processed 3 samples on 1 device(s)" in r5.stdout, r5.stdout + r5.stderr
-    for o in ("outC", "outD", "outE"):
-        for fn in files:
-            assert (tmp_path / o / "hla" / fn).read_bytes() == (out1 / "hla" / fn).read_bytes(), (o, fn)
     # ---- a stale file under hla/ is wiped (processBAM.cpp:1805-1806), a failing mapper ends with a non-zero status
     (out1 / "hla" / "stale.txt").write_text("x")
     r = subprocess.run(base + ["--outputDirectory", str(out1)], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
