@@ -4,7 +4,7 @@
 // oracle and the other classes, it finishes 68 % of the DP calls of the Graph M workload (3.77 M calls per million pairs; 1.19 M go on to the 16-lane class),
 // but takes 69-78 ms for them where the 16-lane class takes 33 ms (90 ms for all calls, 57 ms for the 1.19 M that are left): a lane walks the candidates
 // of its few cells one after the other, the wavefront executes the longest lane's loops, and at one wave per SIMD (36 KB of LDS per wave) every vector
-// instruction costs its four cycles: ~9 k wave instructions per trip for 64 calls = 140 per call and iteration, against 357 / 4 = 89 in the 16-lane class,
+// instruction costs its two cycles of the SIMD-32: ~9 k wave instructions per trip for 64 calls = 140 per call and iteration, against 357 / 4 = 89 in the 16-lane class,
 // whose 16 lanes share the work of a call's cells.  Requesting the node records of four frontier entries at a time and writing the columns during the
 // backtrace did not change that (the class is bound by issue, not by its chain of loads).  See DESIGN.md, section 4B.
 //
