@@ -52,7 +52,25 @@ for s in range(s0, s0 + N):
     assert_pairs_equal(gb.pairs(), exp["pairs"])
     st = gb.stats()
     assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3]), s
+    extra = ""
+    if s % 3 != 2 and s % 2 == 0:
+        # the same reads once more as UNPAIRED reads in long-read mode (alignOneLongRead, mapper/processBAM.cpp:3618-3838: projection, padding, scoring, selection; no extension DP)
+        u = synth.as_unpaired(b); nu = u["n_pairs"]
+        ko = dict(insert_mean=200.0, insert_sd=35.0, rng_seed=s, long_read_mode=1)
+        eo = Oracle(w["graph"], w["contigs"], **ko); e = eo.align_long_reads(u)
+        cu = P.Context(w["graph"], w["contigs"], **ko)
+        gu = cu.batch_unpaired(u); gu.align()
+        assert gu.stats().n_dp_calls == 0
+        compare_chains(gu.chains(0), e["seeds"], u["n_chains"], check_ll=False, check_dp=False, label="sweep %d unpaired seeds" % s)
+        compare_chains(gu.chains(1), e["ext"], u["n_chains"], check_dp=False, label="sweep %d unpaired padded chains" % s)
+        g = gu.pairs(); x = e["pairs"]; stride = eo.max_columns
+        for key in ("pair_status", "best_chain", "n_combinations", "n_cols", "col_level", "col_edge", "col_gchar", "col_schar", "col_fromseed", "col_mapq"):
+            per = {"pair_status": nu, "best_chain": nu, "n_combinations": nu, "n_cols": nu}.get(key, nu * stride)
+            assert np.array_equal(np.asarray(g[key])[:per], np.asarray(x[key])[:per]), (s, key)
+        assert np.allclose(g["pair_ll"][:nu], x["pair_ll"][:nu], rtol=1e-12, atol=0)
+        extra = "; + %d unpaired reads in long-read mode" % nu
+        gu.close(); cu.close()
     ok += 1
-    print("seed %d ok (%s; reads of %d): %d pairs, %d chains, %d DP calls by class %s, flagged %d, %.0f s" % (s, what, read_len, n, b["n_chains"], st.n_dp_calls, list(st.n_dp_class), st.n_errors, time.time() - t0), flush=True)
+    print("seed %d ok (%s; reads of %d): %d pairs, %d chains, %d DP calls by class %s, flagged %d%s, %.0f s" % (s, what, read_len, n, b["n_chains"], st.n_dp_calls, list(st.n_dp_class), st.n_errors, extra, time.time() - t0), flush=True)
     gb.close(); ctx.close()
 print("PARITY SWEEP OK %d/%d worlds bit-exact (chains, pairs, work counters); skipped %s" % (ok, N, skipped))
