@@ -171,9 +171,21 @@ struct UploadScope {
 };
 
 // hipMalloc, or a block of a destroyed batch that is large enough and wastes at most a quarter
-static int pool_malloc(hlala_ctx* c, void** out, size_t bytes)
+// Sizes are rounded up to classes a sixteenth of a power of two apart (at most 6 % more than asked for): the arrays of consecutive batches differ by a fraction of a
+// per cent in size, and with exact sizes a batch kept finding the blocks of the batch before it a little too small for some of its arrays -- a few hipMalloc and
+// hipFree of gigabyte blocks in every step, 8-16 ms per hlala_align_batch in the first process on a freshly booted device (0.4 ms once the driver has handed the
+// memory out before), which is the step the next batch's kernels are launched from.
+static size_t pool_class(size_t bytes)
 {
     bytes = (bytes + 255) & ~(size_t)255;
+    if(bytes <= 4096) return bytes;
+    const int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t g = (size_t)1 << (lg - 4);
+    return (bytes + g - 1) & ~(g - 1);
+}
+static int pool_malloc(hlala_ctx* c, void** out, size_t bytes)
+{
+    bytes = pool_class(bytes);
     auto it = c->pool.lower_bound(bytes);
     if(it != c->pool.end() && it->first <= bytes + bytes / 4 + 4096) {
         *out = it->second; c->pool_bytes -= it->first; c->pool.erase(it);
