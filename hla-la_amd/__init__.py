@@ -560,7 +560,8 @@ class BatchStats(C.Structure):
                 ("n_edges_touched", C.c_int64), ("n_errors", C.c_int64), ("ms_extend_retry", C.c_float),
                 ("n_chains_retried", C.c_int32), ("ms_dp_main", C.c_float), ("n_dp_retried_large", C.c_int32), ("n_dp_shared", C.c_int64),
                 ("n_dp_class", C.c_int32 * 7), ("ms_dp_class", C.c_float * 7), ("ms_side", C.c_float),
-                ("n_dp_lane", C.c_int32), ("ms_dp_lane", C.c_float), ("n_dp_jump_free", C.c_int32), ("ms_dp_jump_free", C.c_float)]
+                ("n_dp_lane", C.c_int32), ("ms_dp_lane", C.c_float), ("n_dp_jump_free", C.c_int32), ("ms_dp_jump_free", C.c_float),
+                ("n_dp_band", C.c_int32), ("n_dp_band_failed", C.c_int32), ("n_dp_jump_free_failed", C.c_int32), ("ms_dp_band", C.c_float)]
 
 
 _DT = {c_i32p: np.int32, c_i64p: np.int64, c_u8p: np.uint8, c_u32p: np.uint32, c_f64p: np.float64}
@@ -671,7 +672,7 @@ def load_library(path: str | None = None):
     return lib
 
 
-ABI_VERSION = 3              # HLALA_ABI_VERSION of include/hlala_gpu.h
+ABI_VERSION = 4              # HLALA_ABI_VERSION of include/hlala_gpu.h
 BUILD_LANE_CLASS = 1         # hlala_build_flags(): the lane-per-DP class is compiled in (make EXTRA=-DHLALA_WITH_LANE_CLASS)
 
 

@@ -63,9 +63,9 @@ struct DevBatch {
     uint8_t* sel_mapq;              // [n_reads*stride] mapQ_perPosition of the selected chain
     // ---- counters (device): see hlala_batch_stats
     u64* counters;                  // [32]
-    int* work_counter;              // [48] dynamic work distribution: [0] stage A, [2] stage C, [7] chains stitched, [8]/[9] left / right DP items,
+    int* work_counter;              // [WC_N] dynamic work distribution: [0] stage A, [2] stage C, [7] chains stitched, [8]/[9] left / right DP items,
                                     //      [1]/[10] left / right items fetched, [12..35] retry lists (count, fetched) per tier 1..6 and direction
-    int* retry_list;                // [14*n_chains] DP items that outgrew a capacity class: (tier 1..6) x (left, right) x n_chains; then (left, right) x n_chains: the
+    int* retry_list;                // [16*n_chains] DP items that outgrew a capacity class: (tier 1..6) x (left, right) x n_chains; then (left, right) x n_chains: the
                                     //      items the lane-per-DP class passed on to the 16-lane class (work_counter[40..45], kernel_dp_lane.hip)
     uint8_t* pair_deferred;         // [n_pairs] 1: a DP call of the pair went to the in-memory class; with the fused entry point its chains are stitched and
                                     //           the pair is scored in a second pass, after that class (which runs on a side stream next to the first pass)
@@ -75,9 +75,10 @@ struct DevBatch {
     int* chain_bucket;              // [n_chains] position bucket = first level >> order_shift (the last bucket: chains filtered out)
     int* order_hist;                // [order_nb + 1] bucket counts -> bucket starts -> scatter cursors
     int order_shift, order_nb;
-    int* dp_blk;                    // [4 * dp_nblk + 1] items per block of k_dp_items and list (jump-free left / right, general left / right); after the scan: where they start
-    int* dp_list;                   // [2*n_chains] the four dense lists of the first DP classes: slots of dp_items in position order (k_dp_lists)
+    int* dp_blk;                    // [DPL_N * dp_nblk + 1] items per block of k_dp_items and list (band left / right, jump-free left / right, general left / right); after the scan: where they start
+    int* dp_list;                   // [2*n_chains] the six dense lists of the first DP classes: slots of dp_items in position order (k_dp_lists)
     int dp_nblk;                    // blocks of k_dp_items
+    int dp_band;                    // > 0: calls whose reach (read bases left + dp_band - 1 levels) stays inside a linear run of the graph go to the band kernel's lists (kernel_dp_band.hip); 0: HLALA_DP_BAND=0
     int dp_jf;                      // > 0: calls that meet no gap-path jump go to the lists of the jump-free instantiations, reach = read bases left + dp_jf - 1 levels (0: HLALA_DP_JF=0, every call in the general one)
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
     int* dbg;                       // non-null with HLALA_DEBUG=1: kernels add phase clocks to counters[16..31]
@@ -86,6 +87,18 @@ struct DevBatch {
 // number of entries of B.chain_order: the chains that passed the filters (k_filter_chains); without a position order every chain is listed.
 // (order_hist[order_nb - 1] is the start of a bucket nothing is put into = the end of the last real bucket, before and after the scatter)
 __device__ __forceinline__ int ordered_chains(const DevBatch& B) { return B.chain_order ? __builtin_amdgcn_readfirstlane(B.order_hist[B.order_nb - 1]) : B.n_chains; }
+
+// ---- the first DP classes' dense item lists (k_dp_items / k_dp_lists): list k occupies dp_list[dp_blk[k * dp_nblk] .. dp_blk[(k + 1) * dp_nblk])
+enum { DPL_BAND = 0 /* +1: right */, DPL_JF = 2, DPL_GEN = 4, DPL_N = 6 };
+// ---- B.work_counter (WC_N ints): [0] stage A, [1] / [10] left / right general items fetched, [2] stage C, [4] / [5] jump-free items fetched, [6] jump-free calls (statistics),
+// [7] chains stitched, [8] / [9] left / right DP calls, [12..35] retry lists of tiers 1..6 (count, fetched) x (left, right), [36] / [37] second stitch / pairing pass,
+// [40..45] lists of the lane-per-DP class; round 5:
+enum { WC_BAND_FETCH = 48 /* +1: right */, WC_FO_COUNT = 50 /* +1 */, WC_FO_FETCH = 52 /* +1 */, WC_BAND_FAILED = 54, WC_BAND_CALLS = 55, WC_JF_FAILED = 56, WC_N = 64 };
+// the fail-over list of the first classes: calls the band kernel (kernel_dp_band.hip) or the jump-free instantiation could not finish; k_dp<DpTiny, 0> draws it after
+// its own lists.  Entries (slots of dp_items) at retry_list[(14 + direction) * n_chains ...], counts in work_counter[WC_FO_COUNT + direction].
+// ---- capacities of the band kernel (kernel_dp_band.hip); k_dp_items lists a call for it when it has at most BAND_MAXJ read bases left and a linear run of at least
+// bases left + margin <= BAND_REACH levels ahead
+constexpr int BAND_MAXJ = 48, BAND_REACH = 64, BAND_MAXD = 160;
 
 enum {
     CNT_CHAINS_EXT = 0, CNT_DP_CALLS, CNT_DP_ITERS, CNT_DP_CELLS, CNT_SEED_COLS, CNT_OUT_COLS, CNT_EDGES, CNT_ERRORS, CNT_DP_SHARED

@@ -275,6 +275,21 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
             for(int32_t l = F.L - 1; l >= 0; l--) { run = hasF[(size_t)l] ? 0 : std::min(255, run + 1); F.jfree_out[(size_t)l] = (uint8_t)run; }
             run = 255;
             for(int32_t l = 0; l < F.L; l++) { run = hasB[(size_t)l] ? 0 : std::min(255, run + 1); F.jfree_in[(size_t)l] = (uint8_t)run; }
+            // ---- linear steps (flat_graph.hpp): one node on either side, one edge between them, a real label, no gap-path jump along the step
+            F.lin_label.assign((size_t)F.L, 0); F.lin_eid.assign((size_t)F.L, -1); F.lin_out.assign((size_t)F.L, 0); F.lin_in.assign((size_t)F.L, 0);
+            for(int32_t l = 0; l + 1 < F.L; l++) {
+                const int32_t n = F.level_off[l];
+                if(F.level_off[l + 1] - n != 1 || F.level_off[l + 2] - F.level_off[l + 1] != 1) continue;
+                if(F.out_off[n + 1] - F.out_off[n] != 1 || F.in_off[n + 2] - F.in_off[n + 1] != 1) continue;
+                const int32_t e = F.out_off[n];
+                if(F.out_to[e] != n + 1 || F.out_label[e] == '_' || F.out_label[e] == 0) continue;
+                if(hasF[(size_t)l] || hasB[(size_t)l + 1]) continue;
+                F.lin_label[(size_t)l] = F.out_label[e]; F.lin_eid[(size_t)l] = F.out_eid[e];
+            }
+            run = 0;
+            for(int32_t l = F.L - 1; l >= 0; l--) { run = F.lin_label[(size_t)l] ? std::min(255, run + 1) : 0; F.lin_out[(size_t)l] = (uint8_t)run; }
+            run = 0;
+            for(int32_t l = 0; l < F.L; l++) { run = (l > 0 && F.lin_label[(size_t)l - 1]) ? std::min(255, run + 1) : 0; F.lin_in[(size_t)l] = (uint8_t)run; }
         }
     }
     return "";

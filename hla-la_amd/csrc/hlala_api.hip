@@ -26,6 +26,7 @@
 #include "kernel_call.hip"
 #include "kernel_exonpos.hip"
 #include "kernel_kmer.hip"
+#include "kernel_dp_band.hip"
 
 namespace hlala {
 size_t proj_slab_bytes_host(int stride, int maxNodesPerLevel) { return proj_slab_bytes(stride, maxNodesPerLevel); }
@@ -68,6 +69,7 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     int jf_margin = 16;      // (measured 4 / 8 / 16 / 48: 16-lane + 32-lane class 105.6 / 104.1 / 103.4 / 104.1 ms -- a tight bound sends more calls to the cheap instantiation and more of them on to the 32-lane class) levels beyond the read bases left that a jump-free call is taken to reach (kernel_dp.hip: k_dp_items)
+    int band_grid = 0, band_margin = 8;      // the band kernel in front of the 16-lane class (kernel_dp_band.hip): blocks (0: HLALA_DP_BAND=0) and the levels beyond the read bases left a call is taken to reach (HLALA_DP_BAND_MARGIN)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
     char* lane_slabs = nullptr; int lane_grid = 0;      // the lane-per-DP class in front of the 16-lane class (kernel_dp_lane.hip); lane_grid 0: not used (HLALA_DP_LANE=0)
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
@@ -100,7 +102,7 @@ struct hlala_batch {
     // timing events of THIS batch (created with its first stage call): ev = start / end per stage, [7] / [6] / [10] / [8] = before the 16-lane class / after it /
     // after the 64-lane class / after the last class; evC = start / end of each DP class on the stream it ran on; evSide[0] fork point on the main stream,
     // [1] first side-stream class starts, [6] second pairing pass done
-    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; hipEvent_t evLane[2]{}; hipEvent_t evJF = nullptr; /* end of the jump-free instantiation of the 16-lane class */ bool eventsMade = false; bool lane_used = false;
+    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; hipEvent_t evLane[2]{}; hipEvent_t evJF = nullptr; /* end of the jump-free instantiation of the 16-lane class */ hipEvent_t evBand[2]{}; /* the band kernel */ bool band_used = false; bool eventsMade = false; bool lane_used = false;
     uint32_t first_chain = 0;    // absolute index of the batch's chain 0 in the caller's numbering (hlala_batch_set_first_chain): offsets the random seeds
     float ms[3] = {0, 0, 0};
 };
@@ -138,6 +140,7 @@ static int batch_events(hlala_ctx* c, hlala_batch* b)
     for(int i = 0; i < 14; i++) HIP_TRY(c, hipEventCreate(&b->evC[i / 2][i % 2]));
     for(int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreate(&b->evLane[i]));
     HIP_TRY(c, hipEventCreate(&b->evJF));
+    for(int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreate(&b->evBand[i]));
     HIP_TRY(c, hipEventCreateWithFlags(&b->evMain, hipEventDisableTiming));
     b->eventsMade = true;
     return HLALA_OK;
@@ -384,6 +387,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     UPG(jb_off, F.jb_off); UPG(jb_node, F.jb_node); UPG(jb_path, F.jb_path);
     UPG(jf_lvl, F.jf_lvl); UPG(jb_lvl, F.jb_lvl);
     UPG(jfree_out, F.jfree_out); UPG(jfree_in, F.jfree_in);
+    UPG(lin_label, F.lin_label); UPG(lin_out, F.lin_out); UPG(lin_in, F.lin_in); UPG(lin_eid, F.lin_eid);
     UPG(out_prank, F.out_prank); UPG(in_prank, F.in_prank); UPG(jf_prank, F.jf_prank); UPG(jb_prank, F.jb_prank);
     { int* p_ = nullptr; rc = dev_upload(c, c->allocs, F.nrec_out.data(), F.nrec_out.size(), &p_); if(rc) return fail(rc); G.nrec_out = (const int4*)p_;
       rc = dev_upload(c, c->allocs, F.nrec_in.data(), F.nrec_in.size(), &p_); if(rc) return fail(rc); G.nrec_in = (const int4*)p_; }
@@ -426,6 +430,10 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
 #ifdef HLALA_WITH_LANE_CLASS
     if(const char* e = getenv("HLALA_DP_LANE")) { if(atoi(e) != 0) c->jf_grid = 0; }      // (the lane-per-DP class takes every item itself)
 #endif
+    c->band_grid = cus * 20;          // 6.8 KB of LDS per block, five waves per SIMD
+    if(const char* e = getenv("HLALA_DP_BAND")) { if(atoi(e) == 0) c->band_grid = 0; }      // (A/B and parity: every call in the hashed-frontier classes)
+    if(const char* e = getenv("HLALA_DP_BAND_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= BAND_REACH - BAND_MAXJ) c->band_margin = m; }
+    if(const char* e = getenv("HLALA_DP_BAND_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 24 && c->band_grid) c->band_grid = cus * w; }
     if(const char* e = getenv("HLALA_DP_JF")) { if(atoi(e) == 0) c->jf_grid = 0; }      // (A/B: every call in the general instantiation -- the kernels' lists are built either way)
     if(const char* e = getenv("HLALA_DP_JF_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 200) c->jf_margin = m; }      // (A/B: levels beyond the read bases left that a jump-free call may reach)
     c->ext_grid = cus * 20;
@@ -560,11 +568,12 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
-    AL(pair_deferred, np, true); AL(counters, 32, true); AL(work_counter, 48, true); AL(retry_list, 14 * nc, false);
+    AL(pair_deferred, np, true); AL(counters, 32, true); AL(work_counter, WC_N, true); AL(retry_list, 16 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
     B.dp_nblk = (int)((nc + 255) / 256); if(B.dp_nblk < 1) B.dp_nblk = 1;
     B.dp_jf = c->jf_grid > 0 ? c->jf_margin + 1 : 0;
-    AL(dp_blk, (size_t)4 * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
+    B.dp_band = c->band_grid > 0 ? c->band_margin + 1 : 0;
+    AL(dp_blk, (size_t)DPL_N * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
     B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb;
     if(c->order_nb > 0 && !B.from_seeds && nc > 0) { AL(chain_order, nc, false); AL(chain_bucket, nc, false); AL(order_hist, (size_t)c->order_nb + 1, false); }
     B.dbg = c->dbg_host;
@@ -738,6 +747,7 @@ void hlala_batch_destroy(hlala_batch* b)
     for(int i = 0; i < 8; i++) if(b->evSide[i]) (void)hipEventDestroy(b->evSide[i]);
     for(int i = 0; i < 2; i++) if(b->evLane[i]) (void)hipEventDestroy(b->evLane[i]);
     if(b->evJF) (void)hipEventDestroy(b->evJF);
+    for(int i = 0; i < 2; i++) if(b->evBand[i]) (void)hipEventDestroy(b->evBand[i]);
     delete b;
 }
 
@@ -757,7 +767,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     { int re = batch_events(c, b); if(re) return re; }
     { int ro = ensure_outputs(c, b); if(ro) return ro; }
     DevBatch& B = b->B;
-    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, 48 * sizeof(int), c->active));
+    HIP_TRY(c, hipMemsetAsync(B.work_counter, 0, WC_N * sizeof(int), c->active));
     HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->active));
     HIP_TRY(c, hipEventRecord(b->ev[0], c->active));
     if(B.n_chains > 0) {
@@ -811,7 +821,7 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
     b->side_used = false; b->side_pending = false;
     if(B.n_pairs > 0) HIP_TRY(c, hipMemsetAsync(B.pair_deferred, 0, (size_t)B.n_pairs, c->active));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->active));
-    HIP_TRY(c, hipMemsetAsync(B.work_counter + 4, 0, 44 * sizeof(int), c->active));       // [4..6] jump-free lists, [7..] stitch, DP items, retry lists
+    HIP_TRY(c, hipMemsetAsync(B.work_counter + 4, 0, (WC_N - 4) * sizeof(int), c->active));       // [4..6] jump-free lists, [7..] stitch, DP items, retry lists, band / fail-over lists
     if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->active));
     HIP_TRY(c, hipEventRecord(b->ev[2], c->active));
     if(B.n_chains > 0) {
@@ -820,10 +830,10 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_head, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));       // -1: k_dp_items links the duplicates of a DP to it
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_next, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));
         // items, then the four dense lists of the first classes (jump-free / general, left / right) in position order: counts per block, their scan, the slots
-        HIP_TRY(c, hipMemsetAsync(B.dp_blk, 0, ((size_t)4 * B.dp_nblk + 1) * sizeof(int), c->active));
+        HIP_TRY(c, hipMemsetAsync(B.dp_blk, 0, ((size_t)DPL_N * B.dp_nblk + 1) * sizeof(int), c->active));
         hipLaunchKernelGGL(k_dp_items, dim3(B.dp_nblk), dim3(256), 0, c->active, c->dG, b->dB, items);
         int rc = check_launch(c, "k_dp_items"); if(rc) return rc;
-        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_SCAN_THREADS), 0, c->active, B.dp_blk, 4 * B.dp_nblk + 1);
+        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_SCAN_THREADS), 0, c->active, B.dp_blk, DPL_N * B.dp_nblk + 1);
         hipLaunchKernelGGL(k_dp_lists, dim3(B.dp_nblk), dim3(256), 0, c->active, b->dB, (const DpItem*)items);
         rc = check_launch(c, "k_dp_lists"); if(rc) return rc;
         // every DP item first runs in the 16-lane class; the item count lives on the device, idle groups leave at once.
@@ -874,6 +884,15 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
             HIP_TRY(c, hipEventRecord(b->evLane[1], c->active));
         }
 #endif
+        // calls on linear stretches of the graph first: anti-diagonals in registers, four calls per wavefront (kernel_dp_band.hip); what it cannot finish is on the
+        // fail-over list the general 16-lane instantiation draws after its own
+        b->band_used = c->band_grid > 0 && !tinyList;
+        if(b->band_used) {
+            HIP_TRY(c, hipEventRecord(b->evBand[0], c->active));
+            hipLaunchKernelGGL(k_dp_band, dim3(c->band_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->G.lin_label, c->G.lin_eid);
+            rc = check_launch(c, "k_dp_band"); if(rc) return rc;
+            HIP_TRY(c, hipEventRecord(b->evBand[1], c->active));
+        }
         HIP_TRY(c, hipEventRecord(b->ev[7], c->active));
         rc = run_class(0); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(b->ev[6], c->active));
@@ -1215,6 +1234,7 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b || !out) return HLALA_E_ARG;
     memset(out, 0, sizeof(*out));
+    if(!b->outputs_ready) return HLALA_OK;       // only uploaded so far: no stage has run, the counters do not exist yet (zeros, as before the outputs were allocated lazily)
     HIP_TRY(c, hipStreamSynchronize(c->active));
     u64 cnt[16];
     HIP_TRY(c, hipMemcpyAsync(cnt, b->B.counters, sizeof(cnt), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active));
@@ -1223,9 +1243,11 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
           for(int k = 0; k <= DP_LAST_TIER; k++) (void)hipEventElapsedTime(&out->ms_dp_class[k], b->evC[k][0], b->evC[k][1]);
           if(b->lane_used) (void)hipEventElapsedTime(&out->ms_dp_lane, b->evLane[0], b->evLane[1]);
           if(c->jf_grid > 0 && !b->lane_used) (void)hipEventElapsedTime(&out->ms_dp_jump_free, b->evC[0][0], b->evJF);
+          if(b->band_used) (void)hipEventElapsedTime(&out->ms_dp_band, b->evBand[0], b->evBand[1]);
           if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, b->evSide[1], b->evSide[6]); } }
-    { int wc[48]; HIP_TRY(c, hipMemcpyAsync(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
-      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9]; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; out->n_dp_jump_free = (c->jf_grid > 0 && !b->lane_used) ? wc[6] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
+    { int wc[WC_N]; HIP_TRY(c, hipMemcpyAsync(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
+      out->n_dp_band = b->band_used ? wc[WC_BAND_CALLS] : 0; out->n_dp_band_failed = b->band_used ? wc[WC_BAND_FAILED] : 0; out->n_dp_jump_free_failed = wc[WC_JF_FAILED];
+      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9] - out->n_dp_band + out->n_dp_band_failed; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; out->n_dp_jump_free = (c->jf_grid > 0 && !b->lane_used) ? wc[6] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, b->ev[4], b->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];
@@ -1375,7 +1397,8 @@ extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long 
 {
     DEV_GUARD(c);
     ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
-    if(!c || !b) return HLALA_E_ARG;
+    if(!c || !b || !out32) return HLALA_E_ARG;
+    if(!b->outputs_ready) { memset(out32, 0, 32 * sizeof(u64)); return HLALA_OK; }      // only uploaded so far: the counters do not exist yet
     HIP_TRY(c, hipStreamSynchronize(c->active));
     HIP_TRY(c, hipMemcpyAsync(out32, b->B.counters, 32 * sizeof(u64), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active));
     return HLALA_OK;

@@ -149,6 +149,7 @@ struct __align__(16) DpLdsT {
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     typename C::ImpIdx hq[C::HC];   // per hash entry: index of the improvement its cell staged this iteration (all ones = none)
     int nNew, nImp, nKeepF, err, nCompletedAdd;
+    int jumpMet;                                      // jump-free instantiation: the call met a gap-path jump after all (it goes on to the general 16-lane list)
     int nTa;                                          // targets claimed so far this iteration (classes of several waves per DP: the waves append to one list)
     int nextPhase;                                    // state after PH_DONE: idle, or the end-cell choice of a linked duplicate
     int btSlot, btM, btX, btY, btGuard, btDone;       // back-pointer chase in progress (lane 0 of the group)
@@ -627,7 +628,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.cellsEvaluated = 0;
         st.endSlot = -1; st.endScore = 0; st.nSteps = 0; st.nCols = 0;
         st.have = 0; st.sb = 0; st.se = -1; st.err = 0; st.needTier = 0; st.isAlias = 0;
-        S.err = 0; S.nTa = 0;
+        S.err = 0; S.nTa = 0; S.jumpMet = 0;
 #ifdef HLALA_DP_PROFILE
         S.pfStart = clock64(); S.pfSlow = 0; S.pfImp = 0; S.pfPre = 0; S.pfMaxNT = 0; S.pfMaxF = 0; for(int i = 0; i < 8; i++) S.pfPh[i] = 0;
 #endif
@@ -777,7 +778,7 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
             bool cv[3]; u64 ck[3]; u32 ch[3]; u64 cold[3];
             cv[0] = sgB && degB > 0; ck[0] = mk_key(nxB, pyB, tnB0);
             cv[1] = sgB && degB > 1; ck[1] = mk_key(nxB, pyB, tnB1);
-            if constexpr (C::JF) { cv[2] = false; ck[2] = 0; if(okB && j1 > j0) S.err = __LINE__; }       // a jump after all: the call is re-run in the next class
+            if constexpr (C::JF) { cv[2] = false; ck[2] = 0; if(okB && j1 > j0) { S.err = __LINE__; S.jumpMet = 1; } }       // a jump after all: the call is re-run in the general instantiation
             else { cv[2] = okB && j1 > j0 && jx0 >= 0 && jx0 <= max_levelI; ck[2] = mk_key(jx0, pyB, jn0); }
 #pragma unroll
             for(int q = 0; q < 3; q++) { ch[q] = tgt_hash<C>(ck[q]); cold[q] = HKEY_EMPTY; if(cv[q]) cold[q] = atomicCAS(&S.hkey[ch[q]], HKEY_EMPTY, ck[q]); }
@@ -1557,35 +1558,45 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
     //  at 6 + 2 per level; DP_JF_MARGIN on top.  B.dp_jf = the margin + 1, 0 = off.)
     if(needL && B.dp_jf) { const int reach = itL.start_seq + B.dp_jf - 1; jfL = reach < 255 && (int)G.jfree_in[itL.startLevel] > reach; }
     if(needR && B.dp_jf) { const int reach = itR.seqLen - itR.start_seq + B.dp_jf - 1; jfR = reach < 255 && (int)G.jfree_out[itR.startLevel] > reach; }
+    // Band calls (kernel_dp_band.hip): the levels the call can reach -- read bases left + dp_band - 1 -- are a run of LINEAR steps (FlatGraph::lin_out / lin_in: one
+    // node per level, one edge per step, no '_' label, no jump).  A call that walks further anyway fails over to the general list.
+    bool bdL = false, bdR = false;
+    if(needL && B.dp_band) { const int jm = itL.start_seq, reach = jm + B.dp_band - 1; bdL = jm <= BAND_MAXJ && reach <= BAND_REACH && (int)G.lin_in[itL.startLevel] >= reach; }
+    if(needR && B.dp_band) { const int jm = itR.seqLen - itR.start_seq, reach = jm + B.dp_band - 1; bdR = jm <= BAND_MAXJ && reach <= BAND_REACH && (int)G.lin_out[itR.startLevel] >= reach; }
+    const int clsL = bdL ? 2 : (jfL ? 1 : 0), clsR = bdR ? 2 : (jfR ? 1 : 0);       // the list an item goes to: 2 band, 1 jump-free, 0 general
     if(t < nOrd) {
         int4* sl = (int4*)(items + t); int4* sr = (int4*)(items + (size_t)B.n_chains + t);
-        if(needL) { sl[0] = make_int4(itL.item, itL.rOff, itL.seqLen, itL.start_seq); sl[1] = make_int4(itL.startLevel, itL.startNode, jfL ? 1 : 0, 0); } else sl[0] = make_int4(-1, 0, 0, 0);
-        if(needR) { sr[0] = make_int4(itR.item, itR.rOff, itR.seqLen, itR.start_seq); sr[1] = make_int4(itR.startLevel, itR.startNode, jfR ? 1 : 0, 0); } else sr[0] = make_int4(-1, 0, 0, 0);
+        if(needL) { sl[0] = make_int4(itL.item, itL.rOff, itL.seqLen, itL.start_seq); sl[1] = make_int4(itL.startLevel, itL.startNode, clsL, 0); } else sl[0] = make_int4(-1, 0, 0, 0);
+        if(needR) { sr[0] = make_int4(itR.item, itR.rOff, itR.seqLen, itR.start_seq); sr[1] = make_int4(itR.startLevel, itR.startNode, clsR, 0); } else sr[0] = make_int4(-1, 0, 0, 0);
     }
-    // ---- how many items of each of the four lists (jump-free left / right, general left / right) this block holds: k_order_scan turns the counts of all
+    // ---- how many items of each of the six lists (band left / right, jump-free left / right, general left / right) this block holds: k_order_scan turns the counts of all
     // blocks into the blocks' places in the dense lists, k_dp_lists writes the slot numbers there -- in position order, nothing is left to the atomics.
-    // work_counter[8] / [9]: left / right DP calls of the batch, [6]: the jump-free ones among them (statistics)
-    __shared__ int blkCnt[4];
-    if(threadIdx.x < 4) blkCnt[threadIdx.x] = 0;
+    // work_counter[8] / [9]: left / right DP calls of the batch, [6]: the jump-free ones among them, [WC_BAND_CALLS]: the band ones (statistics)
+    __shared__ int blkCnt[DPL_N];
+    if(threadIdx.x < DPL_N) blkCnt[threadIdx.x] = 0;
     __syncthreads();
     const int lane = lane_id();
     nShared = wave_sum_i32(nShared);
     if(lane == 0 && nShared) atomicAdd(&B.counters[CNT_DP_SHARED], (u64)nShared);
-    const u64 mL = __ballot(needL), mR = __ballot(needR), mJL = __ballot(needL && jfL), mJR = __ballot(needR && jfR);
+    const u64 mL = __ballot(needL), mR = __ballot(needR);
+    const u64 mBL = __ballot(needL && clsL == 2), mBR = __ballot(needR && clsR == 2), mJL = __ballot(needL && clsL == 1), mJR = __ballot(needR && clsR == 1);
     if(lane == 0) {
         if(mL) atomicAdd(&B.work_counter[8], __popcll(mL));
         if(mR) atomicAdd(&B.work_counter[9], __popcll(mR));
         if(mJL | mJR) atomicAdd(&B.work_counter[6], __popcll(mJL) + __popcll(mJR));
-        if(mJL) atomicAdd(&blkCnt[0], __popcll(mJL));
-        if(mJR) atomicAdd(&blkCnt[1], __popcll(mJR));
-        if(mL & ~mJL) atomicAdd(&blkCnt[2], __popcll(mL & ~mJL));
-        if(mR & ~mJR) atomicAdd(&blkCnt[3], __popcll(mR & ~mJR));
+        if(mBL | mBR) atomicAdd(&B.work_counter[WC_BAND_CALLS], __popcll(mBL) + __popcll(mBR));
+        if(mBL) atomicAdd(&blkCnt[DPL_BAND], __popcll(mBL));
+        if(mBR) atomicAdd(&blkCnt[DPL_BAND + 1], __popcll(mBR));
+        if(mJL) atomicAdd(&blkCnt[DPL_JF], __popcll(mJL));
+        if(mJR) atomicAdd(&blkCnt[DPL_JF + 1], __popcll(mJR));
+        if(mL & ~mJL & ~mBL) atomicAdd(&blkCnt[DPL_GEN], __popcll(mL & ~mJL & ~mBL));
+        if(mR & ~mJR & ~mBR) atomicAdd(&blkCnt[DPL_GEN + 1], __popcll(mR & ~mJR & ~mBR));
     }
     __syncthreads();
-    if(threadIdx.x < 4) B.dp_blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = blkCnt[threadIdx.x];
+    if(threadIdx.x < DPL_N) B.dp_blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = blkCnt[threadIdx.x];
 }
 
-// The four dense item lists of the first DP classes: list k (0 jump-free left, 1 jump-free right, 2 general left, 3 general right) occupies
+// The six dense item lists of the first DP classes: list k (DPL_BAND / DPL_JF / DPL_GEN, + 1 for the right extensions) occupies
 // dp_list[dp_blk[k * nBlk] .. dp_blk[(k + 1) * nBlk]) -- dp_blk after its exclusive scan: entry k * nBlk + b = where block b's items of list k start --, its
 // entries are the slots of k_dp_items' item arrays in position order.  Same grid as k_dp_items.
 __global__ void k_dp_lists(const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items)
@@ -1596,17 +1607,22 @@ __global__ void k_dp_lists(const DevBatch* __restrict__ Bp, const DpItem* __rest
     int kL = -1, kR = -1;             // list of the left / right item of this slot
     if(t < nOrd) {
         const int4* sl = (const int4*)(items + t); const int4* sr = (const int4*)(items + (size_t)B.n_chains + t);
-        if(sl[0].x >= 0) kL = sl[1].z ? 0 : 2;
-        if(sr[0].x >= 0) kR = sr[1].z ? 1 : 3;
+        if(sl[0].x >= 0) { const int cls = sl[1].z; kL = cls == 2 ? DPL_BAND : (cls == 1 ? DPL_JF : DPL_GEN); }
+        if(sr[0].x >= 0) { const int cls = sr[1].z; kR = (cls == 2 ? DPL_BAND : (cls == 1 ? DPL_JF : DPL_GEN)) + 1; }
     }
-    __shared__ int waveCnt[4][4];      // [list][wave of the block]
+    __shared__ int waveCnt[DPL_N][4];      // [list][wave of the block]
     const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
-    u64 m[4]; m[0] = __ballot(kL == 0); m[1] = __ballot(kR == 1); m[2] = __ballot(kL == 2); m[3] = __ballot(kR == 3);
-    if(lane == 0) { waveCnt[0][wv] = (int)__popcll(m[0]); waveCnt[1][wv] = (int)__popcll(m[1]); waveCnt[2][wv] = (int)__popcll(m[2]); waveCnt[3][wv] = (int)__popcll(m[3]); }
+    u64 m[DPL_N];
+#pragma unroll
+    for(int k = 0; k < DPL_N; k++) m[k] = __ballot((k & 1) ? kR == k : kL == k);
+    if(lane == 0) {
+#pragma unroll
+        for(int k = 0; k < DPL_N; k++) waveCnt[k][wv] = (int)__popcll(m[k]);
+    }
     __syncthreads();
     const u64 below = (1ull << lane) - 1ull;
 #pragma unroll
-    for(int k = 0; k < 4; k++) {
+    for(int k = 0; k < DPL_N; k++) {
         const bool mine = (k & 1) ? kR == k : kL == k;
         if(mine) {
             int before = 0;
@@ -1660,17 +1676,26 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
 #define DP_T(i) do { } while(0)
 #endif
 
-    for(int dirPass = 0; dirPass < 2; dirPass++) {
+    // TIER 0, general instantiation: after its own two lists the fail-over lists of the band kernel and of the jump-free instantiation (passes 2 and 3)
+    constexpr int NPASS = (TIER == 0 && !C::JF) ? 4 : 2;
+    for(int pass = 0; pass < NPASS; pass++) {
+        const int dirPass = pass & 1;
+        const bool foPass = pass >= 2;
         // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
         // retry list of tier k = 1..6 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
         const bool fromLane = TIER == 0 && tinyList != nullptr;         // [40]/[42] counts, [41]/[43] fetched: the list of the lane-per-DP class
-        int* fetchCounter = &B.work_counter[TIER == 0 ? (fromLane ? 41 + 2 * dirPass : (C::JF ? 4 + dirPass : (dirPass ? 10 : 1))) : 13 + 4 * (TIER - 1) + 2 * dirPass];        // [4]/[5]: the jump-free lists
+        if(foPass && fromLane) break;
+        int* fetchCounter = foPass ? &B.work_counter[WC_FO_FETCH + dirPass]
+                          : &B.work_counter[TIER == 0 ? (fromLane ? 41 + 2 * dirPass : (C::JF ? 4 + dirPass : (dirPass ? 10 : 1))) : 13 + 4 * (TIER - 1) + 2 * dirPass];        // [4]/[5]: the jump-free lists
         // (TIER 0 draws from the dense lists of k_dp_lists -- jump-free or general, left or right --, the later tiers from the retry lists)
-        const int seg = (C::JF ? 0 : 2) + dirPass;
-        const int segStart = (TIER == 0 && !fromLane) ? uni(B.dp_blk[(size_t)seg * B.dp_nblk]) : 0;
-        const int nItems = (TIER == 0 && !fromLane) ? uni(B.dp_blk[(size_t)(seg + 1) * B.dp_nblk]) - segStart : uni(B.work_counter[TIER == 0 ? 40 + 2 * dirPass : 12 + 4 * (TIER - 1) + 2 * dirPass]);
-        const int* srcList = (TIER == 0 && !fromLane) ? B.dp_list + segStart
-                           : (fromLane ? tinyList + (size_t)dirPass * (size_t)B.n_chains : B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains);
+        const int seg = (C::JF ? DPL_JF : DPL_GEN) + dirPass;
+        const bool dense = TIER == 0 && !fromLane && !foPass;
+        const int segStart = dense ? uni(B.dp_blk[(size_t)seg * B.dp_nblk]) : 0;
+        const int nItems = dense ? uni(B.dp_blk[(size_t)(seg + 1) * B.dp_nblk]) - segStart
+                         : (foPass ? uni(B.work_counter[WC_FO_COUNT + dirPass]) : uni(B.work_counter[TIER == 0 ? 40 + 2 * dirPass : 12 + 4 * (TIER - 1) + 2 * dirPass]));
+        const int* srcList = dense ? B.dp_list + segStart
+                           : (foPass ? B.retry_list + (size_t)(14 + dirPass) * (size_t)B.n_chains
+                           : (fromLane ? tinyList + (size_t)dirPass * (size_t)B.n_chains : B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains));
         const bool fwd = dirPass != 0;                     // left extensions run backwards (alignerBase: extensionAligner.cpp:229-241)
         int phase = PH_IDLE;
         bool more = true;
@@ -1703,7 +1728,16 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
                     }
 #endif
                     const bool capacity = st.err != 0 && st.err > -1000000;
-                    if(capacity && TIER < DP_LAST_TIER) {
+                    bool handed = false;
+                    if constexpr (C::JF && TIER == 0) if(capacity && S.jumpMet) {
+                        // the jump-free instantiation met a gap-path jump: the call goes to the fail-over list of the GENERAL 16-lane instantiation, not to the 32-lane class
+                        if(st.isAlias) ((int*)(items + st.itemIdx))[0] = st.item;
+                        const int q = atomicAdd(&B.work_counter[WC_FO_COUNT + dirPass], 1); B.retry_list[(size_t)(14 + dirPass) * (size_t)B.n_chains + q] = st.itemIdx;
+                        atomicAdd(&B.work_counter[WC_JF_FAILED], 1);
+                        handed = true;
+                    }
+                    if(handed) { }
+                    else if(capacity && TIER < DP_LAST_TIER) {
                         // next tier, or straight to the first tier whose class holds what overflowed (no point in failing again on the way)
                         int to = TIER + 1; if(st.needTier > to) to = st.needTier; if(to > DP_LAST_TIER) to = DP_LAST_TIER;
                         int* cnt = &B.work_counter[12 + 4 * (to - 1) + 2 * dirPass]; int* lst = B.retry_list + (size_t)(2 * (to - 1) + dirPass) * (size_t)B.n_chains;

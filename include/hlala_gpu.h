@@ -317,6 +317,12 @@ typedef struct {
     int32_t n_dp_jump_free;       /* of n_dp_class[0]: calls that were known to meet no gap-path jump and ran in the instantiation of the 16-lane class that is
                                      compiled without the early-cell machinery (kernel_dp.hip: DpTinyJF)                                                      */
     float   ms_dp_jump_free;      /* part of ms_dp_class[0] spent in that instantiation                                                                       */
+    int32_t n_dp_band;            /* DP calls listed for the band kernel (kernel_dp_band.hip: the levels within reach are a linear stretch of the graph -- one node per
+                                     level, one edge per step --, anti-diagonals held in registers, no cell table); they do not enter the 16-lane class ...          */
+    int32_t n_dp_band_failed;     /* ... except these: calls that left the band or the staged levels and were re-run in the general 16-lane instantiation (counted in
+                                     n_dp_class[0])                                                                                                                */
+    int32_t n_dp_jump_free_failed;/* of n_dp_jump_free: calls that met a gap-path jump after all and were re-run in the general 16-lane instantiation                  */
+    float   ms_dp_band;           /* time of the band kernel (before the 16-lane class on the main stream; not part of ms_dp_class[0])                                 */
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 
@@ -716,10 +722,11 @@ int  hlala_abi_sizeof(const char* struct_name);
 
 /* Version of this interface.  It changes whenever the meaning or the type of a field changes WITHOUT changing the size of its struct (which
  * hlala_abi_sizeof cannot see) or a struct grows: 2 = hlala_batch_in carries 64-bit window offsets and an absolute read_primary (round 3);
- * 3 = hlala_batch_stats ends with n_dp_jump_free / ms_dp_jump_free, hlala_batch_in with read_bases_packed / first_read (round 4).  A caller compares
+ * 3 = hlala_batch_stats ends with n_dp_jump_free / ms_dp_jump_free, hlala_batch_in with read_bases_packed / first_read (round 4);
+ * 4 = hlala_batch_stats ends with n_dp_band / n_dp_band_failed / n_dp_jump_free_failed / ms_dp_band (round 5).  A caller compares
  * hlala_abi_version() with the HLALA_ABI_VERSION it was compiled against and refuses to run on a mismatch (hla-la_amd/__init__.py and
  * hla-la_amd/host/hlala_host.hpp do). */
-#define HLALA_ABI_VERSION 3
+#define HLALA_ABI_VERSION 4
 int  hlala_abi_version(void);
 /* bit mask of optional parts compiled into this library: HLALA_BUILD_LANE_CLASS = the lane-per-DP class (kernel_dp_lane.hip, an experiment that
  * lost its A/B and is left out of the default build: make EXTRA=-DHLALA_WITH_LANE_CLASS) */

@@ -61,6 +61,53 @@ def test_flatten_matches_oracle(pkg, oracle, hostlib, seed, G, k):
     hostlib.hlala_host_free(F)
 
 
+@pytest.mark.parametrize("kind", ["simple", "k0-identical", "graph_m"])
+def test_linear_steps_and_run_lengths(pkg, hostlib, kind):
+    """FlatGraph::lin_label / lin_eid / lin_out / lin_in (what decides which DP calls the band kernel takes) against a definition written down independently
+    in numpy: a step l -> l + 1 is linear when both levels hold one node, exactly one edge joins them, its label is not '_' and no gap-path jump leaves or
+    enters along it; the run lengths count consecutive linear steps ahead / behind, capped at 255."""
+    if kind == "simple":
+        w = synth.make_world(seed=7, G=6000, k=2)
+    elif kind == "k0-identical":
+        w = synth.make_world(seed=8, G=3000, k=0, n_mut=0, n_largegap=0)
+    else:
+        w = synth.make_world_m(seed=4, n_levels=60000, n_windows=2, alleles=(50, 200))
+    gd = w["graph"]
+    g, k1 = pkg.fill_struct(pkg.GraphDesc, gd); c, k2 = pkg.fill_struct(pkg.ContigsDesc, w["contigs"])
+    F = hostlib.hlala_host_flatten(C.byref(g), C.byref(c))
+    assert F, hostlib.hlala_host_last_error()
+    L = gd["n_levels"]
+    lab = np.zeros(L, np.uint8); eid = np.zeros(L, np.int32); lo = np.zeros(L, np.uint8); li = np.zeros(L, np.uint8)
+    hostlib.hlala_host_linear.argtypes = [C.c_void_p, pkg.c_u8p, pkg.c_i32p, pkg.c_u8p, pkg.c_u8p]
+    hostlib.hlala_host_linear(F, lab.ctypes.data_as(pkg.c_u8p), eid.ctypes.data_as(pkg.c_i32p), lo.ctypes.data_as(pkg.c_u8p), li.ctypes.data_as(pkg.c_u8p))
+    nl = gd["node_level"]; ef = gd["edge_from"]; el = gd["edge_label"]
+    npl = np.bincount(nl, minlength=L); elv = nl[ef]; epl = np.bincount(elv, minlength=L)
+    # levels with a '_' edge start or carry gap paths; a single non-gap edge out of a single node has none (checked against the jump tables below)
+    exp_lab = np.zeros(L, np.uint8); exp_eid = np.full(L, -1, np.int32)
+    first = np.zeros(L, np.int64); first[elv] = np.arange(len(ef))
+    one = np.zeros(L, bool); one[:-1] = (npl[:-1] == 1) & (npl[1:] == 1) & (epl[:-1] == 1)
+    one &= el[first] != ord('_')
+    exp_lab[one] = el[first[one]]; exp_eid[one] = first[one]
+    assert np.array_equal(lab, exp_lab) and np.array_equal(eid, exp_eid)
+    # no gap-path jump at either end of a linear step
+    gi = pkg.GraphInfo(); hostlib.hlala_host_info(F, C.byref(gi))
+    if gi.n_paths:
+        a = [np.zeros(gi.n_paths, np.int32) for _ in range(3)]
+        hostlib.hlala_host_paths(F, *[x.ctypes.data_as(pkg.c_i32p) for x in a])
+        assert not one[nl[a[0]]].any()                       # first node of a path: a level whose step ahead is linear has no forward jump
+        lastl = nl[a[1]]; assert not one[lastl[lastl > 0] - 1].any()
+    exp_out = np.zeros(L, np.int64); exp_in = np.zeros(L, np.int64); run = 0
+    for x in range(L - 1, -1, -1):
+        run = min(255, run + 1) if one[x] else 0; exp_out[x] = run
+    run = 0
+    for x in range(L):
+        run = min(255, run + 1) if (x > 0 and one[x - 1]) else 0; exp_in[x] = run
+    assert np.array_equal(lo, exp_out) and np.array_equal(li, exp_in)
+    if kind != "graph_m":
+        assert one.mean() > 0.5          # (the stand-in graphs are mostly linear between their variants)
+    hostlib.hlala_host_free(F)
+
+
 def test_flatten_rejects_bad_graphs(pkg, hostlib):
     w = synth.make_world(seed=1, G=100, k=1)
     bad = dict(w["graph"]); bad["edge_to"] = bad["edge_to"].copy(); bad["edge_to"][0] = bad["edge_from"][0]      # same level
