@@ -79,6 +79,7 @@ struct DevBatch {
     int* dp_list;                   // [2*n_chains] the six dense lists of the first DP classes: slots of dp_items in position order (k_dp_lists)
     int dp_nblk;                    // blocks of k_dp_items
     int dp_band;                    // > 0: calls whose reach (read bases left + dp_band - 1 levels) stays inside a linear run of the graph go to the band kernel's lists (kernel_dp_band.hip); 0: HLALA_DP_BAND=0
+    int dp_band_risky;              // tests (HLALA_DP_BAND_RISKY=1): a call is listed for the band kernel as soon as the linear run covers its read bases -- many then walk past it and exercise the fail-over
     int dp_jf;                      // > 0: calls that meet no gap-path jump go to the lists of the jump-free instantiations, reach = read bases left + dp_jf - 1 levels (0: HLALA_DP_JF=0, every call in the general one)
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
     int* dbg;                       // non-null with HLALA_DEBUG=1: kernels add phase clocks to counters[16..31]
@@ -88,17 +89,21 @@ struct DevBatch {
 // (order_hist[order_nb - 1] is the start of a bucket nothing is put into = the end of the last real bucket, before and after the scatter)
 __device__ __forceinline__ int ordered_chains(const DevBatch& B) { return B.chain_order ? __builtin_amdgcn_readfirstlane(B.order_hist[B.order_nb - 1]) : B.n_chains; }
 
-// ---- the first DP classes' dense item lists (k_dp_items / k_dp_lists): list k occupies dp_list[dp_blk[k * dp_nblk] .. dp_blk[(k + 1) * dp_nblk])
-enum { DPL_BAND = 0 /* +1: right */, DPL_JF = 2, DPL_GEN = 4, DPL_N = 6 };
+// ---- the first DP classes' dense item lists (k_dp_items / k_dp_lists): list k occupies dp_list[dp_blk[k * dp_nblk] .. dp_blk[(k + 1) * dp_nblk]); k + 1: the right extensions
+enum { DPL_BAND16 = 0, DPL_BAND32 = 2, DPL_BAND64 = 4, DPL_JF = 6, DPL_GEN = 8, DPL_N = 10 };
+// the list an item is put on, by the class k_dp_items gives it (0 general, 1 jump-free, 2 / 3 / 4 band kernel with 16 / 32 / 64 lanes per call); + 1 for a right extension
+__host__ __device__ inline int dpl_of_class(int cls) { return cls == 0 ? DPL_GEN : (cls == 1 ? DPL_JF : (cls == 2 ? DPL_BAND16 : (cls == 3 ? DPL_BAND32 : DPL_BAND64))); }
 // ---- B.work_counter (WC_N ints): [0] stage A, [1] / [10] left / right general items fetched, [2] stage C, [4] / [5] jump-free items fetched, [6] jump-free calls (statistics),
 // [7] chains stitched, [8] / [9] left / right DP calls, [12..35] retry lists of tiers 1..6 (count, fetched) x (left, right), [36] / [37] second stitch / pairing pass,
-// [40..45] lists of the lane-per-DP class; round 5:
-enum { WC_BAND_FETCH = 48 /* +1: right */, WC_FO_COUNT = 50 /* +1 */, WC_FO_FETCH = 52 /* +1 */, WC_BAND_FAILED = 54, WC_BAND_CALLS = 55, WC_JF_FAILED = 56, WC_N = 64 };
+// [40..45] lists of the lane-per-DP class; round 5: items fetched by the three band kernels (left, right each), the fail-over list's counts and fetch counters, band calls that
+// failed over, band calls listed, jump-free calls that met a jump, and why band calls failed ([WC_BAND_WHY + 2 .. + 5]: past the staged levels, past the linear run, too
+// many iterations, too many tied end cells)
+enum { WC_BAND_FETCH = 48, WC_FO_COUNT = 54, WC_FO_FETCH = 56, WC_BAND_FAILED = 58, WC_BAND_CALLS = 59, WC_JF_FAILED = 60, WC_BAND_WHY = 62, WC_N = 72 };
 // the fail-over list of the first classes: calls the band kernel (kernel_dp_band.hip) or the jump-free instantiation could not finish; k_dp<DpTiny, 0> draws it after
 // its own lists.  Entries (slots of dp_items) at retry_list[(14 + direction) * n_chains ...], counts in work_counter[WC_FO_COUNT + direction].
-// ---- capacities of the band kernel (kernel_dp_band.hip); k_dp_items lists a call for it when it has at most BAND_MAXJ read bases left and a linear run of at least
-// bases left + margin <= BAND_REACH levels ahead
-constexpr int BAND_MAXJ = 48, BAND_REACH = 64, BAND_MAXD = 160;
+// ---- capacities of the band kernels (kernel_dp_band.hip): read bases a call may have left for the instantiation with 16 / 32 / 64 lanes per call; k_dp_items lists a call
+// for one of them when the linear run ahead of its start level covers bases left + margin + min(bases left + 6, 40) levels
+constexpr int BAND_MAXJ16 = 15, BAND_MAXJ32 = 31, BAND_MAXJ64 = 48;
 
 enum {
     CNT_CHAINS_EXT = 0, CNT_DP_CALLS, CNT_DP_ITERS, CNT_DP_CELLS, CNT_SEED_COLS, CNT_OUT_COLS, CNT_EDGES, CNT_ERRORS, CNT_DP_SHARED

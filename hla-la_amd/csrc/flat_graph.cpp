@@ -11,7 +11,7 @@ namespace {
 struct TrieEnt { int32_t parent; int32_t edge; int32_t len; };
 }
 
-std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c, FlatGraph& F)
+std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c, FlatGraph& F, bool keep_unit_jumps)
 {
     if(!g || g->n_levels < 2 || g->n_nodes < 2 || g->n_edges < 1) return "graph needs >= 2 levels, nodes and >= 1 edge";
     const int32_t L = g->n_levels, N = g->n_nodes, E = g->n_edges;
@@ -159,6 +159,18 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
         if(!build(F.path_last, F.path_first, F.jb_off, F.jb_node, F.jb_path)) return "duplicate gap-edge path between two nodes";
         F.jf_lvl.resize(P); F.jb_lvl.resize(P);
         for(int32_t i = 0; i < P; i++) { F.jf_lvl[i] = F.node_level[F.jf_node[i]]; F.jb_lvl[i] = F.node_level[F.jb_node[i]]; }
+        // the tables the device walks: without the one-edge paths (flat_graph.hpp)
+        auto filt = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& node, const std::vector<int32_t>& path, const std::vector<int32_t>& lvl,
+                        std::vector<int32_t>& doff, std::vector<int32_t>& dnode, std::vector<int32_t>& dpath, std::vector<int32_t>& dlvl) {
+            doff.assign(N + 1, 0); dnode.clear(); dpath.clear(); dlvl.clear();
+            for(int32_t n = 0; n < N; n++) {
+                for(int32_t i = off[n]; i < off[n + 1]; i++)
+                    if(keep_unit_jumps || F.path_len[path[i]] >= 2) { dnode.push_back(node[i]); dpath.push_back(path[i]); dlvl.push_back(lvl[i]); }
+                doff[n + 1] = (int32_t)dnode.size();
+            }
+        };
+        filt(F.jf_off, F.jf_node, F.jf_path, F.jf_lvl, F.djf_off, F.djf_node, F.djf_path, F.djf_lvl);
+        filt(F.jb_off, F.jb_node, F.jb_path, F.jb_lvl, F.djb_off, F.djb_node, F.djb_path, F.djb_lvl);
     }
 
     // ---- level -> (sequence id, position), last writer wins (processBAM.cpp:4455)
@@ -218,7 +230,7 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
         };
         F.max_parallel = (E > 0) ? 1 : 0;
         ranks(F.out_off, F.out_to, F.out_prank); ranks(F.in_off, F.in_from, F.in_prank);
-        ranks(F.jf_off, F.jf_node, F.jf_prank); ranks(F.jb_off, F.jb_node, F.jb_prank);
+        ranks(F.djf_off, F.djf_node, F.jf_prank); ranks(F.djb_off, F.djb_node, F.jb_prank);
     }
     // ---- node records: everything one DP iteration needs of a frontier node in one 32-byte read
     {
@@ -262,15 +274,15 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
             }
             F.level_fast[(size_t)lv] = fast ? (uint8_t)(((eEnd - eFirst) <= 64 ? 1 : 2) | ((maxd - 1) << 2)) : 0;
         }
-        build(F.out_off, F.out_to, F.out_label, F.jf_off, F.jf_node, F.jf_lvl, F.nrec_out);
-        build(F.in_off, F.in_from, F.in_label, F.jb_off, F.jb_node, F.jb_lvl, F.nrec_in);
+        build(F.out_off, F.out_to, F.out_label, F.djf_off, F.djf_node, F.djf_lvl, F.nrec_out);
+        build(F.in_off, F.in_from, F.in_label, F.djb_off, F.djb_node, F.djb_lvl, F.nrec_in);
         if(!recErr.empty()) return recErr;
         // ---- how far an extension DP can walk from a level without meeting a gap-path jump (flat_graph.hpp): jfree_out[l] = levels l, l + 1, ... whose nodes
         // have no forward jump, jfree_in[l] = levels l, l - 1, ... without a backward one; capped at 255
         F.jfree_out.assign((size_t)F.L, 0); F.jfree_in.assign((size_t)F.L, 0);
         {
             std::vector<uint8_t> hasF((size_t)F.L, 0), hasB((size_t)F.L, 0);
-            for(int32_t n = 0; n < N; n++) { if(F.jf_off[n + 1] > F.jf_off[n]) hasF[(size_t)F.node_level[n]] = 1; if(F.jb_off[n + 1] > F.jb_off[n]) hasB[(size_t)F.node_level[n]] = 1; }
+            for(int32_t n = 0; n < N; n++) { if(F.djf_off[n + 1] > F.djf_off[n]) hasF[(size_t)F.node_level[n]] = 1; if(F.djb_off[n + 1] > F.djb_off[n]) hasB[(size_t)F.node_level[n]] = 1; }
             int run = 255;                                   // (beyond the last level there is nothing to meet)
             for(int32_t l = F.L - 1; l >= 0; l--) { run = hasF[(size_t)l] ? 0 : std::min(255, run + 1); F.jfree_out[(size_t)l] = (uint8_t)run; }
             run = 255;

@@ -39,10 +39,16 @@ struct FlatGraph {
     std::vector<int32_t> jf_node, jb_node;       // target node (new id)
     std::vector<int32_t> jf_path, jb_path;       // path index
     std::vector<int32_t> jf_lvl, jb_lvl;         // level of the target node (saves a dependent load on the device)
+    // The jump tables the DEVICE walks (round 5): the entries above without the paths of ONE edge.  A gap path that consists of a single '_' edge p -> q is a no-op
+    // for the extension DP: its candidate -- D[p] + 1 * S_graphGap into cell (level(q), y, q), extensionAligner.cpp:757-786 -- has the value of the candidate the
+    // '_' edge itself pushed into the same cell a moment earlier (the non-affine sequence gap D[p] + S_graphGap, :738-752, in the same pass over p), and "first maximum
+    // in push order" (Utilities.cpp:379-406) never picks the later of two equal candidates; the cell exists either way.  Dropping them changes no result, and a
+    // call that only ever meets such paths (every single-level deletion of a haplotype is one) counts as jump-free (DpTinyJF).  keep_unit_jumps = true keeps all.
+    std::vector<int32_t> djf_off, djb_off, djf_node, djb_node, djf_path, djb_path, djf_lvl, djb_lvl;
     // rank of a CSR edge / jump entry among the EARLIER entries of the same node that lead to the same target node.  It is all the extension DP needs to
     // order the candidates of one target cell (candidates of different edges of one frontier cell only compete when they reach the same node), so the push
     // index of a candidate holds this rank -- a few bits -- instead of the edge number, and a node's degree is not limited by the width of that field.
-    std::vector<uint8_t> out_prank, in_prank, jf_prank, jb_prank;
+    std::vector<uint8_t> out_prank, in_prank, jf_prank, jb_prank;       // (jf_prank / jb_prank: over the device's tables djf_* / djb_*)
     // one word per in-edge (CSR order) for the re-threading DP of the seed projection (kernel_project.hip, chunked form): the lanes of a wavefront take
     // the in-edges of a level, not its nodes.  bits 0-8 rank of the from-node in its level; 9-14 the place, among the in-edges of the from-node's
     // level, of the from-node's LAST in-edge (the lane that holds the from-node's score when that level was solved in one slice of 64 edges); 15-17 the
@@ -73,6 +79,6 @@ struct FlatGraph {
 };
 
 // Returns "" on success, else the error text (graph invariants the reference asserts).
-std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c, FlatGraph& out);
+std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c, FlatGraph& out, bool keep_unit_jumps = false);
 
 }  // namespace hlala

@@ -69,6 +69,7 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     int jf_margin = 16;      // (measured 4 / 8 / 16 / 48: 16-lane + 32-lane class 105.6 / 104.1 / 103.4 / 104.1 ms -- a tight bound sends more calls to the cheap instantiation and more of them on to the 32-lane class) levels beyond the read bases left that a jump-free call is taken to reach (kernel_dp.hip: k_dp_items)
+    bool band_risky = false;      // HLALA_DP_BAND_RISKY=1 (tests: force fail-overs of the band kernel)
     int band_grid = 0, band_margin = 8;      // the band kernel in front of the 16-lane class (kernel_dp_band.hip): blocks (0: HLALA_DP_BAND=0) and the levels beyond the read bases left a call is taken to reach (HLALA_DP_BAND_MARGIN)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
     char* lane_slabs = nullptr; int lane_grid = 0;      // the lane-per-DP class in front of the 16-lane class (kernel_dp_lane.hip); lane_grid 0: not used (HLALA_DP_LANE=0)
@@ -362,7 +363,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(c->params.max_columns < 16 || c->params.max_columns > 65536) { c->err = "params.max_columns out of range"; return fail(HLALA_E_ARG); }
     DevGuard dev_guard_(device);       // the caller's current device is restored on return
     { int cur_ = -1; if(hipGetDevice(&cur_) != hipSuccess || cur_ != device) { c->err = "hipSetDevice failed"; return fail(HLALA_E_DEVICE); } }
-    std::string ferr = flatten_graph(graph, contigs, c->F);
+    const bool keepUnitJumps = [] { const char* e = getenv("HLALA_UNIT_JUMPS"); return e && atoi(e) != 0; }();       // (A/B and parity: the one-edge gap paths stay in the device's jump tables)
+    std::string ferr = flatten_graph(graph, contigs, c->F, keepUnitJumps);
     if(!ferr.empty()) { c->err = ferr; return fail(HLALA_E_GRAPH); }
     FlatGraph& F = c->F;
     if(F.N >= (1 << 28) || F.L >= (1 << 24)) { c->err = "graph exceeds 2^28 nodes or 2^24 levels (DP cell key layout)"; return fail(HLALA_E_CAPACITY); }
@@ -383,9 +385,10 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     UPG(out_off, F.out_off); UPG(out_to, F.out_to); UPG(out_label, F.out_label); UPG(out_eid, F.out_eid);
     UPG(in_off, F.in_off); UPG(in_from, F.in_from); UPG(in_label, F.in_label); UPG(in_eid, F.in_eid); UPG(in_rec, F.in_rec); UPG(level_fast, F.level_fast);
     UPG(edge_from_new, F.edge_from_new); UPG(edge_to_new, F.edge_to_new); UPG(edge_label, edge_label);
-    UPG(jf_off, F.jf_off); UPG(jf_node, F.jf_node); UPG(jf_path, F.jf_path);
-    UPG(jb_off, F.jb_off); UPG(jb_node, F.jb_node); UPG(jb_path, F.jb_path);
-    UPG(jf_lvl, F.jf_lvl); UPG(jb_lvl, F.jb_lvl);
+    // (the device's jump tables hold the gap paths of two and more edges only: a one-edge path is a no-op for the DP, flat_graph.hpp)
+    UPG(jf_off, F.djf_off); UPG(jf_node, F.djf_node); UPG(jf_path, F.djf_path);
+    UPG(jb_off, F.djb_off); UPG(jb_node, F.djb_node); UPG(jb_path, F.djb_path);
+    UPG(jf_lvl, F.djf_lvl); UPG(jb_lvl, F.djb_lvl);
     UPG(jfree_out, F.jfree_out); UPG(jfree_in, F.jfree_in);
     UPG(lin_label, F.lin_label); UPG(lin_out, F.lin_out); UPG(lin_in, F.lin_in); UPG(lin_eid, F.lin_eid);
     UPG(out_prank, F.out_prank); UPG(in_prank, F.in_prank); UPG(jf_prank, F.jf_prank); UPG(jb_prank, F.jb_prank);
@@ -430,10 +433,11 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
 #ifdef HLALA_WITH_LANE_CLASS
     if(const char* e = getenv("HLALA_DP_LANE")) { if(atoi(e) != 0) c->jf_grid = 0; }      // (the lane-per-DP class takes every item itself)
 #endif
-    c->band_grid = cus * 20;          // 6.8 KB of LDS per block, five waves per SIMD
+    c->band_grid = cus * 24;          // a few KB of LDS per block, six waves per SIMD (80 VGPRs)
     if(const char* e = getenv("HLALA_DP_BAND")) { if(atoi(e) == 0) c->band_grid = 0; }      // (A/B and parity: every call in the hashed-frontier classes)
-    if(const char* e = getenv("HLALA_DP_BAND_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= BAND_REACH - BAND_MAXJ) c->band_margin = m; }
-    if(const char* e = getenv("HLALA_DP_BAND_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 24 && c->band_grid) c->band_grid = cus * w; }
+    if(const char* e = getenv("HLALA_DP_BAND_RISKY")) c->band_risky = atoi(e) != 0;
+    if(const char* e = getenv("HLALA_DP_BAND_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 24) c->band_margin = m; }
+    if(const char* e = getenv("HLALA_DP_BAND_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 32 && c->band_grid) c->band_grid = cus * w; }
     if(const char* e = getenv("HLALA_DP_JF")) { if(atoi(e) == 0) c->jf_grid = 0; }      // (A/B: every call in the general instantiation -- the kernels' lists are built either way)
     if(const char* e = getenv("HLALA_DP_JF_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 200) c->jf_margin = m; }      // (A/B: levels beyond the read bases left that a jump-free call may reach)
     c->ext_grid = cus * 20;
@@ -573,6 +577,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     B.dp_nblk = (int)((nc + 255) / 256); if(B.dp_nblk < 1) B.dp_nblk = 1;
     B.dp_jf = c->jf_grid > 0 ? c->jf_margin + 1 : 0;
     B.dp_band = c->band_grid > 0 ? c->band_margin + 1 : 0;
+    B.dp_band_risky = c->band_risky ? 1 : 0;
     AL(dp_blk, (size_t)DPL_N * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
     B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb;
     if(c->order_nb > 0 && !B.from_seeds && nc > 0) { AL(chain_order, nc, false); AL(chain_bucket, nc, false); AL(order_hist, (size_t)c->order_nb + 1, false); }
@@ -889,7 +894,9 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
         b->band_used = c->band_grid > 0 && !tinyList;
         if(b->band_used) {
             HIP_TRY(c, hipEventRecord(b->evBand[0], c->active));
-            hipLaunchKernelGGL(k_dp_band, dim3(c->band_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->G.lin_label, c->G.lin_eid);
+            hipLaunchKernelGGL((k_dp_band<16>), dim3(c->band_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->G.lin_label, c->G.lin_eid);
+            hipLaunchKernelGGL((k_dp_band<32>), dim3(c->band_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->G.lin_label, c->G.lin_eid);
+            hipLaunchKernelGGL((k_dp_band<64>), dim3(c->band_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->G.lin_label, c->G.lin_eid);
             rc = check_launch(c, "k_dp_band"); if(rc) return rc;
             HIP_TRY(c, hipEventRecord(b->evBand[1], c->active));
         }
@@ -1401,6 +1408,18 @@ extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long 
     if(!b->outputs_ready) { memset(out32, 0, 32 * sizeof(u64)); return HLALA_OK; }      // only uploaded so far: the counters do not exist yet
     HIP_TRY(c, hipStreamSynchronize(c->active));
     HIP_TRY(c, hipMemcpyAsync(out32, b->B.counters, 32 * sizeof(u64), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active));
+    return HLALA_OK;
+}
+
+// the batch's work counters (diagnostics: item counts of the lists, fail-over reasons of the band kernel -- batch.h)
+extern "C" int hlala_debug_work_counters(hlala_ctx* c, hlala_batch* b, int* out64)
+{
+    DEV_GUARD(c);
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
+    if(!c || !b || !out64) return HLALA_E_ARG;
+    if(!b->outputs_ready) { memset(out64, 0, WC_N * sizeof(int)); return HLALA_OK; }
+    HIP_TRY(c, hipStreamSynchronize(c->active));
+    HIP_TRY(c, hipMemcpyAsync(out64, b->B.work_counter, WC_N * sizeof(int), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active));
     return HLALA_OK;
 }
 

@@ -149,6 +149,7 @@ struct __align__(16) DpLdsT {
     unsigned char timp[C::HC];      // per target: improved-matrix mask | 0x80 = new cell
     typename C::ImpIdx hq[C::HC];   // per hash entry: index of the improvement its cell staged this iteration (all ones = none)
     int nNew, nImp, nKeepF, err, nCompletedAdd;
+    int chunkNext, chunkEnd;                          // items of the group's current draw from the item list (several per atomic: k_dp)
     int jumpMet;                                      // jump-free instantiation: the call met a gap-path jump after all (it goes on to the general 16-lane list)
     int nTa;                                          // targets claimed so far this iteration (classes of several waves per DP: the waves append to one list)
     int nextPhase;                                    // state after PH_DONE: idle, or the end-cell choice of a linked duplicate
@@ -159,7 +160,7 @@ struct __align__(16) DpLdsT {
     long long tPh[16];
 #endif
 #ifdef HLALA_DP_PROFILE
-    long long pfStart; int pfSlow, pfImp, pfPre, pfMaxNT, pfMaxF; long long pfPh[8];
+    long long pfStart; int pfSlow, pfImp, pfPre, pfMaxNT, pfMaxF; long long pfPh[16];
 #endif
 };
 
@@ -630,7 +631,7 @@ __device__ inline int dp_begin(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGrap
         st.have = 0; st.sb = 0; st.se = -1; st.err = 0; st.needTier = 0; st.isAlias = 0;
         S.err = 0; S.nTa = 0; S.jumpMet = 0;
 #ifdef HLALA_DP_PROFILE
-        S.pfStart = clock64(); S.pfSlow = 0; S.pfImp = 0; S.pfPre = 0; S.pfMaxNT = 0; S.pfMaxF = 0; for(int i = 0; i < 8; i++) S.pfPh[i] = 0;
+        S.pfStart = clock64(); S.pfSlow = 0; S.pfImp = 0; S.pfPre = 0; S.pfMaxNT = 0; S.pfMaxF = 0; for(int i = 0; i < 16; i++) S.pfPh[i] = 0;
 #endif
         CellRec c0; c0.key = mk_key(it.startLevel, it.start_seq, it.startNode);
         c0.sc[0] = 0; c0.sc[1] = (short)DP_NEG; c0.sc[2] = (short)DP_NEG; c0.sc[3] = 0; c0.bt[0] = 0; c0.bt[1] = 0; c0.bt[2] = 0; c0.pad = 0;
@@ -1561,13 +1562,16 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
     // Band calls (kernel_dp_band.hip): the levels the call can reach -- read bases left + dp_band - 1 -- are a run of LINEAR steps (FlatGraph::lin_out / lin_in: one
     // node per level, one edge per step, no '_' label, no jump).  A call that walks further anyway fails over to the general list.
     bool bdL = false, bdR = false;
-    if(needL && B.dp_band) { const int jm = itL.start_seq, reach = jm + B.dp_band - 1; bdL = jm <= BAND_MAXJ && reach <= BAND_REACH && (int)G.lin_in[itL.startLevel] >= reach; }
-    if(needR && B.dp_band) { const int jm = itR.seqLen - itR.start_seq, reach = jm + B.dp_band - 1; bdR = jm <= BAND_MAXJ && reach <= BAND_REACH && (int)G.lin_out[itR.startLevel] >= reach; }
-    const int clsL = bdL ? 2 : (jfL ? 1 : 0), clsR = bdR ? 2 : (jfR ? 1 : 0);       // the list an item goes to: 2 band, 1 jump-free, 0 general
+    int runL = 0, runR = 0;
+    int clsL = jfL ? 1 : 0, clsR = jfR ? 1 : 0;       // the list an item goes to: 0 general, 1 jump-free, 2 / 3 / 4 band kernel with 16 / 32 / 64 lanes per call
+    // (levels a call is taken to reach: while it has read bases left a cell sits at most dp_band - 1 levels beyond them; afterwards the tail -- one sequence gap per
+    //  iteration from the best complete cell, score <= 2 * bases, -6 then -2 per level down to the threshold of -16, at most 40 iterations -- walks up to bases + 6 more)
+    if(needL && B.dp_band) { const int jm = itL.start_seq, reach = jm + B.dp_band - 1; runL = (int)G.lin_in[itL.startLevel]; bdL = jm <= BAND_MAXJ64 && runL >= (B.dp_band_risky ? jm : reach + min(jm + 6, 40)); if(bdL) clsL = jm <= BAND_MAXJ16 ? 2 : (jm <= BAND_MAXJ32 ? 3 : 4); }
+    if(needR && B.dp_band) { const int jm = itR.seqLen - itR.start_seq, reach = jm + B.dp_band - 1; runR = (int)G.lin_out[itR.startLevel]; bdR = jm <= BAND_MAXJ64 && runR >= (B.dp_band_risky ? jm : reach + min(jm + 6, 40)); if(bdR) clsR = jm <= BAND_MAXJ16 ? 2 : (jm <= BAND_MAXJ32 ? 3 : 4); }
     if(t < nOrd) {
         int4* sl = (int4*)(items + t); int4* sr = (int4*)(items + (size_t)B.n_chains + t);
-        if(needL) { sl[0] = make_int4(itL.item, itL.rOff, itL.seqLen, itL.start_seq); sl[1] = make_int4(itL.startLevel, itL.startNode, clsL, 0); } else sl[0] = make_int4(-1, 0, 0, 0);
-        if(needR) { sr[0] = make_int4(itR.item, itR.rOff, itR.seqLen, itR.start_seq); sr[1] = make_int4(itR.startLevel, itR.startNode, clsR, 0); } else sr[0] = make_int4(-1, 0, 0, 0);
+        if(needL) { sl[0] = make_int4(itL.item, itL.rOff, itL.seqLen, itL.start_seq); sl[1] = make_int4(itL.startLevel, itL.startNode, clsL, runL); } else sl[0] = make_int4(-1, 0, 0, 0);
+        if(needR) { sr[0] = make_int4(itR.item, itR.rOff, itR.seqLen, itR.start_seq); sr[1] = make_int4(itR.startLevel, itR.startNode, clsR, runR); } else sr[0] = make_int4(-1, 0, 0, 0);
     }
     // ---- how many items of each of the six lists (band left / right, jump-free left / right, general left / right) this block holds: k_order_scan turns the counts of all
     // blocks into the blocks' places in the dense lists, k_dp_lists writes the slot numbers there -- in position order, nothing is left to the atomics.
@@ -1579,18 +1583,18 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
     nShared = wave_sum_i32(nShared);
     if(lane == 0 && nShared) atomicAdd(&B.counters[CNT_DP_SHARED], (u64)nShared);
     const u64 mL = __ballot(needL), mR = __ballot(needR);
-    const u64 mBL = __ballot(needL && clsL == 2), mBR = __ballot(needR && clsR == 2), mJL = __ballot(needL && clsL == 1), mJR = __ballot(needR && clsR == 1);
+    const int kL = needL ? dpl_of_class(clsL) : -1, kR = needR ? dpl_of_class(clsR) + 1 : -1;
+    const u64 mJL = __ballot(needL && clsL == 1), mJR = __ballot(needR && clsR == 1), mBL = __ballot(needL && clsL >= 2), mBR = __ballot(needR && clsR >= 2);
     if(lane == 0) {
         if(mL) atomicAdd(&B.work_counter[8], __popcll(mL));
         if(mR) atomicAdd(&B.work_counter[9], __popcll(mR));
         if(mJL | mJR) atomicAdd(&B.work_counter[6], __popcll(mJL) + __popcll(mJR));
         if(mBL | mBR) atomicAdd(&B.work_counter[WC_BAND_CALLS], __popcll(mBL) + __popcll(mBR));
-        if(mBL) atomicAdd(&blkCnt[DPL_BAND], __popcll(mBL));
-        if(mBR) atomicAdd(&blkCnt[DPL_BAND + 1], __popcll(mBR));
-        if(mJL) atomicAdd(&blkCnt[DPL_JF], __popcll(mJL));
-        if(mJR) atomicAdd(&blkCnt[DPL_JF + 1], __popcll(mJR));
-        if(mL & ~mJL & ~mBL) atomicAdd(&blkCnt[DPL_GEN], __popcll(mL & ~mJL & ~mBL));
-        if(mR & ~mJR & ~mBR) atomicAdd(&blkCnt[DPL_GEN + 1], __popcll(mR & ~mJR & ~mBR));
+    }
+#pragma unroll
+    for(int k = 0; k < DPL_N; k++) {
+        const u64 mk = __ballot((k & 1) ? kR == k : kL == k);
+        if(lane == 0 && mk) atomicAdd(&blkCnt[k], __popcll(mk));
     }
     __syncthreads();
     if(threadIdx.x < DPL_N) B.dp_blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = blkCnt[threadIdx.x];
@@ -1607,8 +1611,8 @@ __global__ void k_dp_lists(const DevBatch* __restrict__ Bp, const DpItem* __rest
     int kL = -1, kR = -1;             // list of the left / right item of this slot
     if(t < nOrd) {
         const int4* sl = (const int4*)(items + t); const int4* sr = (const int4*)(items + (size_t)B.n_chains + t);
-        if(sl[0].x >= 0) { const int cls = sl[1].z; kL = cls == 2 ? DPL_BAND : (cls == 1 ? DPL_JF : DPL_GEN); }
-        if(sr[0].x >= 0) { const int cls = sr[1].z; kR = (cls == 2 ? DPL_BAND : (cls == 1 ? DPL_JF : DPL_GEN)) + 1; }
+        if(sl[0].x >= 0) kL = dpl_of_class(sl[1].z);
+        if(sr[0].x >= 0) kR = dpl_of_class(sr[1].z) + 1;
     }
     __shared__ int waveCnt[DPL_N][4];      // [list][wave of the block]
     const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
@@ -1647,6 +1651,11 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
 {
     constexpr int GW = C::GW;
     constexpr int NG = GW >= 64 ? 1 : 64 / GW;           // DPs per block: groups of a wavefront, or one DP for the whole block
+#ifndef HLALA_DP_DRAW0
+#define HLALA_DP_DRAW0 8
+#endif
+    constexpr int DRAW = (TIER == 0 && C::JF) ? HLALA_DP_DRAW0 : 1;      // items a group draws per atomic: several for the short, even calls of the jump-free list (36.7 -> 32.5 ms at 3 M calls); the general list and the later
+                                                                          // classes hold long calls that sit together in position order -- draws of 8 there cost 9 ms of tail (profiles/r05_experiments.txt)
     static_assert(C::THREADS == (GW >= 64 ? GW : 64), "block size");
     // graph / batch descriptors stay in memory (scalar loads on demand): passing them by value costs ~150 SGPRs
     const DevGraph& G = *Gp;
@@ -1697,6 +1706,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
                            : (foPass ? B.retry_list + (size_t)(14 + dirPass) * (size_t)B.n_chains
                            : (fromLane ? tinyList + (size_t)dirPass * (size_t)B.n_chains : B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains));
         const bool fwd = dirPass != 0;                     // left extensions run backwards (alignerBase: extensionAligner.cpp:229-241)
+        if constexpr (DRAW > 1) { if(gl == 0) { S.chunkNext = 0; S.chunkEnd = 0; } DSYNC(); }
         int phase = PH_IDLE;
         bool more = true;
         int edgesAcc = 0;                                  // per-lane partial sum of the edges the current DP touched
@@ -1771,8 +1781,17 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
             }
             DP_T(1);
             if(phase == PH_IDLE && more) {
+                // items are drawn DRAW at a time: one word hands out ~88 draws per microsecond (MI355X_MICROARCH.md: dequeue), and the first class asks for
+                // 3.8 M items per million pairs -- with one atomic per item the jump-free instantiation ran at exactly that rate (79-83 calls per microsecond
+                // whatever the mix of calls: profiles/r05_experiments.txt)
                 int w = 0;
-                if(gl == 0) w = atomicAdd(fetchCounter, 1);
+                if(gl == 0) {
+                    if constexpr (DRAW > 1) {
+                        int nx = S.chunkNext;
+                        if(nx >= S.chunkEnd) { nx = atomicAdd(fetchCounter, DRAW); S.chunkEnd = nx + DRAW; }
+                        S.chunkNext = nx + 1; w = nx;
+                    } else w = atomicAdd(fetchCounter, 1);
+                }
                 w = grp_bcast0<GW>(w);
                 if(w >= nItems) more = false;
                 else {

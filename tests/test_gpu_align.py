@@ -331,3 +331,46 @@ def test_lane_per_dp_class_is_bit_exact(pkg, oracle, monkeypatch):
         assert st.n_errors == 0 and st.n_dp_lane > 0 and st.n_dp_lane >= st.n_dp_class[0]
         assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
     assert st.n_dp_lane > st.n_dp_class[0]            # some calls finished in the lane class
+
+
+BAND_WORLDS = [("simple k1", dict(seed=31, G=9000, k=1), dict(seed=41)),
+               ("identical haplotypes: all linear", dict(seed=32, G=6000, k=0, n_mut=0, n_largegap=0), dict(seed=42, indel_read_frac=0.3)),
+               ("long clips", dict(seed=33, G=12000, k=2, mut_density=0.004), dict(seed=43, clip_max=48, p_no_clip=0.0)),
+               ("low qualities, many indels", dict(seed=34, G=8000, k=1, mut_density=0.01), dict(seed=44, indel_read_frac=0.5, qual_hi=12))]
+
+
+_BAND_EDGES = {}
+
+
+@pytest.mark.parametrize("env", [dict(), dict(HLALA_DP_BAND="0"), dict(HLALA_DP_BAND_RISKY="1"), dict(HLALA_UNIT_JUMPS="1"), dict(HLALA_DP_BAND_MARGIN="0", HLALA_DP_JF_MARGIN="2")],
+                         ids=["default", "band-off", "band-risky", "unit-jumps-kept", "tight-margins"])
+def test_band_kernel_and_its_fail_over_are_bit_exact(pkg, oracle, monkeypatch, env):
+    """The band kernel (kernel_dp_band.hip: extension DP calls on linear stretches of the graph, anti-diagonals in registers, 16 / 32 / 64 lanes per call by the
+    read bases left) against the oracle -- columns, DP scores, iteration / cell / edge counters -- on worlds that are mostly linear, with clips up to 48 bases (all
+    three instantiations) and indel-rich reads (graph-gap and sequence-gap back pointers, tied end cells).  The same worlds with the kernel switched off, with
+    calls listed for it as soon as the linear run covers their read bases (RISKY: many walk past the run and go through the fail-over list of the general
+    16-lane instantiation), with the one-edge gap paths kept in the device's jump tables (flat_graph.hpp: they are no-ops) and with tight reach margins: results
+    never depend on which kernel ran a call (extensionAligner.cpp:335-1556)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tot_band = tot_failed = tot_calls = 0
+    for name, wk, bk in BAND_WORLDS:
+        w = synth.make_world(**wk)
+        b = synth.make_batch(w, 400, **bk)
+        exp, gb, ctx = run_both(pkg, oracle, w, b)
+        compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stage B (%s)" % name)
+        assert_pairs_equal(gb.pairs(), exp["pairs"])
+        st = gb.stats()
+        assert st.n_errors == 0
+        assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3]), name
+        # (n_edges_touched also counts stage A's edges: the same number whichever kernels ran the DP calls)
+        assert _BAND_EDGES.setdefault(name, int(st.n_edges_touched)) == int(st.n_edges_touched), name
+        tot_band += st.n_dp_band; tot_failed += st.n_dp_band_failed; tot_calls += st.n_dp_calls
+    if env.get("HLALA_DP_BAND") == "0":
+        assert tot_band == 0
+    else:
+        assert tot_band > 0.25 * tot_calls                   # these worlds are mostly linear: the band kernel is what runs
+        if env.get("HLALA_DP_BAND_RISKY"):
+            assert tot_failed > 0.02 * tot_band              # the fail-over path is exercised ...
+        elif not env:
+            assert tot_failed <= 0.01 * tot_band             # ... and is not the common path
