@@ -69,6 +69,7 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     int jf_margin = 16;      // (measured 4 / 8 / 16 / 48: 16-lane + 32-lane class 105.6 / 104.1 / 103.4 / 104.1 ms -- a tight bound sends more calls to the cheap instantiation and more of them on to the 32-lane class) levels beyond the read bases left that a jump-free call is taken to reach (kernel_dp.hip: k_dp_items)
+    int stitch_draw = 12;      // chains per draw of k_stitch_chains (8: 9.1 ms per million pairs, the rate of the draws themselves; 12 / 16: 6.7 / 6.6 ms; 64: 15 ms -- kernel_dp.hip)
     bool band_risky = false;      // HLALA_DP_BAND_RISKY=1 (tests: force fail-overs of the band kernel)
     int band_grid = 0, band_margin = 8;      // the band kernel in front of the 16-lane class (kernel_dp_band.hip): blocks (0: HLALA_DP_BAND=0) and the levels beyond the read bases left a call is taken to reach (HLALA_DP_BAND_MARGIN)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
@@ -447,6 +448,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
 
     c->wide_grid = cus * 7;          // LDS: seven DpWide blocks per CU (22 KB each); slabs of the 64-lane layout
     c->stitch_grid = cus * 20;        // k_stitch_chains: five waves per SIMD (92 VGPRs, nothing spilled)
+    if(const char* e = getenv("HLALA_STITCH_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 20) c->stitch_grid = cus * w; }      // (experiments: waves per CU and chains per wave and round of k_stitch_chains)
+    if(const char* e = getenv("HLALA_STITCH_DRAW")) { const int d = atoi(e); if(d >= 1 && d <= 64) c->stitch_draw = d; }
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpWide>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpWide>();
     c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / three blocks per CU: a few MB each
     c->huge_grid = cus / 4 > 0 ? cus / 4 : 1;      // the in-memory backstop class: a handful of DP calls per million pairs
@@ -911,13 +914,14 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
         const int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
         if(fused) {
             // second pass (side): the chains of the deferred pairs, work counter 36; first pass (main): all the others, work counter 7
-            hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->side, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, 2, 36);
+            { const int pgrid = (B.n_pairs + 63) / 64, cap = c->stitch_grid / 20;       // the second pass sweeps the pairs' flags, 64 per wave and round: one wave per CU finds room beside the next batch's persistent kernels
+              hipLaunchKernelGGL(k_stitch_chains, dim3(pgrid < cap ? (pgrid > 0 ? pgrid : 1) : cap), dim3(64), 0, c->side, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, 2, 0); }
             rc = check_launch(c, "k_stitch_chains (side)"); if(rc) return rc;
             HIP_TRY(c, hipEventRecord(b->evDone, c->side));
             HIP_TRY(c, hipEventRecord(c->evSideTail, c->side)); c->sideTailValid = true;
             b->side_inflight = true; b->side_used = true; b->side_pending = true;
         }
-        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->active, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, fused ? 1 : 0, 7);
+        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->active, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, fused ? 1 : 0, c->stitch_draw);
         rc = check_launch(c, "k_stitch_chains"); if(rc) return rc;
     }
     HIP_TRY(c, hipEventRecord(b->ev[3], c->active));

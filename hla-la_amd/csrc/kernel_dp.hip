@@ -1937,68 +1937,98 @@ __device__ __forceinline__ void stitch_rounds(const DevBatch& B, const DevTables
     llOut = carry;
 }
 
+// The chains of one draw: lane q holds chain cq (-1: none).  Descriptors of all of them in two round trips (the fields, then what they point to), then one
+// chain after the other.  deferMode 1: the chains of deferred pairs stay pending (the second pass takes them), 0 / 2: every pending chain given.
+__device__ __forceinline__ void stitch_draw(const DevBatch& B, const DevTables& T, const uint8_t* __restrict__ deferPairs, const int deferMode, const int lane, const int cq,
+                                            u64& accChains, u64& accCols)
+{
+    const int stride = B.stride;
+    const bool has = cq >= 0;
+    int dSt = 0, dRead = 0, dNSeed = 0, dSB = 0, dSE = 0, dNcL = -1, dNcR = -1, dErrL = 0, dErrR = 0, dSbL = 0, dSeR = 0;
+    if(has) dSt = B.ext_status[cq];
+    if(has && dSt == EXT_PENDING) {
+        dRead = B.chain_read[cq]; dNSeed = B.seed_ncols[cq]; dSB = B.seed_begin[cq]; dSE = B.seed_end[cq];
+        const int2 nc = ((const int2*)B.dp_ncols)[cq], er = ((const int2*)B.dp_err)[cq];
+        dNcL = nc.x; dNcR = nc.y; dErrL = er.x; dErrR = er.y; dSbL = B.dp_sb[2 * cq]; dSeR = B.dp_se[2 * cq + 1];
+    }
+    int dR0 = 0, dR1 = 0; bool dMine = has && dSt == EXT_PENDING;
+    if(dMine) {
+        dR0 = B.read_off[dRead]; dR1 = B.read_off[dRead + 1];
+        // (fused entry point: the chains of a pair with a DP call in one of the side-stream classes stay pending in the first pass; the second
+        // pass, which may run beside the first one, takes exactly those)
+        if(deferMode == 1) dMine = deferPairs[dRead >> 1] == 0;
+    }
+    u64 mine = __ballot(dMine);
+    for(; mine; mine &= mine - 1) {
+        const int q = __ffsll((long long)mine) - 1;
+        const int c = __builtin_amdgcn_readlane(cq, q);
+        const int rOff = __builtin_amdgcn_readlane(dR0, q), seqLen = __builtin_amdgcn_readlane(dR1, q) - rOff;
+        const size_t cb = (size_t)c * stride;
+        const int nSeed = __builtin_amdgcn_readlane(dNSeed, q), sBegin = __builtin_amdgcn_readlane(dSB, q), sEnd = __builtin_amdgcn_readlane(dSE, q);
+        const int ncL = __builtin_amdgcn_readlane(dNcL, q), ncR = __builtin_amdgcn_readlane(dNcR, q);
+        const int errL = __builtin_amdgcn_readlane(dErrL, q), errR = __builtin_amdgcn_readlane(dErrR, q);
+        int err = 0;
+        if(errL || errR) err = ((errL <= -1000000) || (errR <= -1000000)) ? HLALA_CHAIN_ERR_COLUMNS : HLALA_CHAIN_ERR_FRONTIER;
+        const bool haveL = ncL >= 0 && !errL, haveR = ncR >= 0 && !errR;
+        const int nL = haveL ? ncL : 0, nR = haveR ? ncR : 0;
+        const int newBegin = haveL ? __builtin_amdgcn_readlane(dSbL, q) : sBegin, newEnd = haveR ? __builtin_amdgcn_readlane(dSeR, q) : sEnd;
+        const int padL = newBegin, padR = seqLen - 1 - newEnd;
+        const int total = padL + nL + nSeed + nR + padR;
+        if(!err && total > stride) err = HLALA_CHAIN_ERR_COLUMNS;
+        if(err) {
+            if(lane == 0) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(errL ? errL : errR); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
+        } else {
+            double ll; int f0, f1, l0, l1;
+            // chains of up to 192 columns (2x150 bp reads) take 3 columns per lane, longer ones 8 per lane in rounds of 512
+            if(total <= 192) stitch_rounds<3>(B, T, cb, rOff, total, padL, nL, nSeed, nR, newEnd, stride, lane, ll, f0, f1, l0, l1);
+            else stitch_rounds<8>(B, T, cb, rOff, total, padL, nL, nSeed, nR, newEnd, stride, lane, ll, f0, f1, l0, l1);
+            if(lane == 0) {
+                ((int4*)B.ext_firstlast)[c] = make_int4(f0, f1, l0, l1);
+                B.ext_status[c] = HLALA_CHAIN_OK; B.ext_ncols[c] = total; B.ext_begin[c] = 0; B.ext_end[c] = seqLen - 1; B.ext_ll[c] = ll;
+                accChains++; accCols += (u64)total;
+            }
+        }
+        WSYNC();
+    }
+}
+
+// deferMode 0: every pending chain; 1: all but the chains of deferred pairs (first pass of the fused entry point); 2: only those (second pass).
+// Passes 0 / 1 draw `draw` consecutive chain NUMBERS per atomic (work_counter[7]), lane q of a draw looking at chain first + q: a third of the chains are pending, the
+// others got their final status from k_dp_items.  Round 5, measured (profiles/r05_experiments.txt): with 8 chains per draw the kernel runs at the rate ONE L2 word
+// hands out draws -- 762 k draws in 8.7 ms = 88 per microsecond (MI355X_MICROARCH.md: dequeue) -- but every way around the atomic cost more than it: draws of 64
+// chains, or the dense position-ordered list of the pending chains, 15 ms; a static deal of 2 / 4 / 8 / 16 chains per wave and round 13 / 17 / 15 / 10 ms; draws of 12 or
+// 16 chains are the optimum: 6.7 / 6.6 ms (the default: 12).  What
+// the draws keep small is the WINDOW of 4 KB rows, out of 30 GB of column arrays, that the 5 120 waves touch at one time.
+// Pass 2 does not look at chains at all: the waves take the PAIRS 64 at a time (no atomic), and the chains of the few deferred ones -- ~2.5 k pairs per million --
+// are stitched; it used to test all 6.1 M chains beside the next batch's kernels (25 ms on the side stream for a few thousand chains; 0.15 ms now).
 __global__ __launch_bounds__(64, 5) void k_stitch_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
-                                                        const uint8_t* __restrict__ deferPairs, const int deferMode, const int counterIdx)      // deferMode 1: skip the chains of deferred pairs, 2: only those
+                                                        const uint8_t* __restrict__ deferPairs, const int deferMode, const int draw)      // draw: chains per wave and round (1 .. 64)
 {
     const DevBatch& B = *Bp;
     const DevTables& T = *Tp;
     const int lane = lane_id();
-    const int stride = B.stride;
-    // chains are drawn eight at a time: one same-address atomic per chain would serialise the whole grid at the L2
-    constexpr int CHUNK = 8;
     u64 accChains = 0, accCols = 0;          // work counters, flushed once per wave (same-address atomics serialise at the L2)
-    for(;;) {
-        int c0 = 0;
-        if(lane == 0) c0 = atomicAdd(&B.work_counter[counterIdx], CHUNK);
-        c0 = __builtin_amdgcn_readfirstlane(c0);
-        if(c0 >= B.n_chains) break;
-        // the descriptors of the chunk's chains: lane q holds chain c0 + q (two round trips for the chunk: the fields, then what they point to)
-        const int cq = c0 + lane; const bool has = lane < CHUNK && cq < B.n_chains;
-        int dSt = 0, dRead = 0, dNSeed = 0, dSB = 0, dSE = 0, dNcL = -1, dNcR = -1, dErrL = 0, dErrR = 0, dSbL = 0, dSeR = 0;
-        if(has) dSt = B.ext_status[cq];
-        if(has && dSt == EXT_PENDING) {
-            dRead = B.chain_read[cq]; dNSeed = B.seed_ncols[cq]; dSB = B.seed_begin[cq]; dSE = B.seed_end[cq];
-            const int2 nc = ((const int2*)B.dp_ncols)[cq], er = ((const int2*)B.dp_err)[cq];
-            dNcL = nc.x; dNcR = nc.y; dErrL = er.x; dErrR = er.y; dSbL = B.dp_sb[2 * cq]; dSeR = B.dp_se[2 * cq + 1];
-        }
-        int dR0 = 0, dR1 = 0; bool dMine = has && dSt == EXT_PENDING;
-        if(dMine) {
-            dR0 = B.read_off[dRead]; dR1 = B.read_off[dRead + 1];
-            // (fused entry point: the chains of a pair with a DP call in one of the side-stream classes stay pending in the first pass; the second
-            // pass, which may run beside the first one, takes exactly those)
-            if(deferMode) { const bool df = deferPairs[dRead >> 1] != 0; dMine = df == (deferMode == 2); }
-        }
-        u64 mine = __ballot(dMine);
-        for(; mine; mine &= mine - 1) {
-            const int q = __ffsll((long long)mine) - 1;
-            const int c = c0 + q;
-            const int rOff = __builtin_amdgcn_readlane(dR0, q), seqLen = __builtin_amdgcn_readlane(dR1, q) - rOff;
-            const size_t cb = (size_t)c * stride;
-            const int nSeed = __builtin_amdgcn_readlane(dNSeed, q), sBegin = __builtin_amdgcn_readlane(dSB, q), sEnd = __builtin_amdgcn_readlane(dSE, q);
-            const int ncL = __builtin_amdgcn_readlane(dNcL, q), ncR = __builtin_amdgcn_readlane(dNcR, q);
-            const int errL = __builtin_amdgcn_readlane(dErrL, q), errR = __builtin_amdgcn_readlane(dErrR, q);
-            int err = 0;
-            if(errL || errR) err = ((errL <= -1000000) || (errR <= -1000000)) ? HLALA_CHAIN_ERR_COLUMNS : HLALA_CHAIN_ERR_FRONTIER;
-            const bool haveL = ncL >= 0 && !errL, haveR = ncR >= 0 && !errR;
-            const int nL = haveL ? ncL : 0, nR = haveR ? ncR : 0;
-            const int newBegin = haveL ? __builtin_amdgcn_readlane(dSbL, q) : sBegin, newEnd = haveR ? __builtin_amdgcn_readlane(dSeR, q) : sEnd;
-            const int padL = newBegin, padR = seqLen - 1 - newEnd;
-            const int total = padL + nL + nSeed + nR + padR;
-            if(!err && total > stride) err = HLALA_CHAIN_ERR_COLUMNS;
-            if(err) {
-                if(lane == 0) { B.ext_status[c] = err; B.ext_ncols[c] = 0; B.ext_ll[c] = (double)(errL ? errL : errR); atomicAdd(&B.counters[CNT_ERRORS], 1ull); }
-            } else {
-                double ll; int f0, f1, l0, l1;
-                // chains of up to 192 columns (2x150 bp reads) take 3 columns per lane, longer ones 8 per lane in rounds of 512
-                if(total <= 192) stitch_rounds<3>(B, T, cb, rOff, total, padL, nL, nSeed, nR, newEnd, stride, lane, ll, f0, f1, l0, l1);
-                else stitch_rounds<8>(B, T, cb, rOff, total, padL, nL, nSeed, nR, newEnd, stride, lane, ll, f0, f1, l0, l1);
-                if(lane == 0) {
-                    ((int4*)B.ext_firstlast)[c] = make_int4(f0, f1, l0, l1);
-                    B.ext_status[c] = HLALA_CHAIN_OK; B.ext_ncols[c] = total; B.ext_begin[c] = 0; B.ext_end[c] = seqLen - 1; B.ext_ll[c] = ll;
-                    accChains++; accCols += (u64)total;
-                }
+    if(deferMode == 2) {
+        const int nP = B.n_pairs;
+        for(int p0 = (int)blockIdx.x * 64; p0 < nP; p0 += (int)gridDim.x * 64) {
+            const int p = p0 + lane;
+            u64 dm = __ballot(p < nP && deferPairs[p] != 0);
+            for(; dm; dm &= dm - 1) {
+                const int q = __ffsll((long long)dm) - 1;
+                const int pp = p0 + q;
+                const int c0 = uni(B.chain_off[2 * pp]), c1 = uni(B.chain_off[2 * pp + 2]);
+                for(int cb = c0; cb < c1; cb += 64) stitch_draw(B, T, deferPairs, 0, lane, cb + lane < c1 ? cb + lane : -1, accChains, accCols);
             }
-            WSYNC();
+        }
+    } else {
+        const int nList = B.n_chains;
+        for(;;) {
+            int w0 = 0;
+            if(lane == 0) w0 = atomicAdd(&B.work_counter[7], draw);
+            w0 = __builtin_amdgcn_readfirstlane(w0);
+            if(w0 >= nList) break;
+            const int wq = w0 + lane;
+            stitch_draw(B, T, deferPairs, deferMode, lane, (lane < draw && wq < nList) ? wq : -1, accChains, accCols);
         }
     }
     if(lane == 0 && accChains) { atomicAdd(&B.counters[CNT_CHAINS_EXT], accChains); atomicAdd(&B.counters[CNT_OUT_COLS], accCols); }

@@ -276,10 +276,14 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
 
     // pairs are drawn eight at a time (one same-address atomic per pair serialises the grid at the L2)
     constexpr int CHUNK = 8;
+    int sweep = 0;
     for(;;) {
         int p0 = 0;
-        if(lane == 0) p0 = atomicAdd(&B.work_counter[counterIdx], CHUNK);
-        p0 = __builtin_amdgcn_readfirstlane(p0);
+        if(deferMode == 2) { p0 = ((int)blockIdx.x + sweep * (int)gridDim.x) * CHUNK; sweep++; }      // second pass (a few thousand pairs of a million): the waves sweep the flags, no draws
+        else {
+            if(lane == 0) p0 = atomicAdd(&B.work_counter[counterIdx], CHUNK);
+            p0 = __builtin_amdgcn_readfirstlane(p0);
+        }
         if(p0 >= B.n_pairs) break;
         const int pEnd = min(p0 + CHUNK, B.n_pairs);
         // the chunk's deferred flags and chain ranges: lane q holds pair p0 + q (one round trip for the chunk, not two dependent ones per pair)

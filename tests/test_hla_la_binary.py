@@ -218,3 +218,56 @@ def test_action_hla_writes_the_files_of_the_ctypes_path(exe, pkg, tmp_path):
     bad = [x if x != str(tmp_path / "samtools") else str(tmp_path / "samtools_fail") for x in base]
     r = subprocess.run(bad + ["--outputDirectory", str(tmp_path / "outbad")], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode != 0 and "returned code" in r.stderr
+
+
+@pytest.mark.gpu
+def test_eight_samples_on_eight_contexts_in_one_call(exe, pkg, tmp_path):
+    """BASELINE config 4 in its own shape on a one-GPU box: EIGHT DIFFERENT samples in one `HLA-LA --action HLA` call on `--devices 0,0,0,0,0,0,0,0` -- eight contexts
+    (eight sets of DP slabs and pools) in one process, eight sample threads side by side, three GPU batches per sample, the graph directory read once -- and every
+    sample's hla/* and reads_per_level.txt are the bytes of its own single-sample call.  The reference adds up the parts of its per-thread runs the same way
+    (mapper/processBAM.cpp:1866-1887); on an eight-GPU node the only difference is the device numbers."""
+    from test_bam import batch_records, write_bam
+    from test_end_to_end import write_graph_dir
+    from test_graph_files import write_contigs_dir, write_graph_txt
+    gdir = tmp_path / "graph"; gdir.mkdir()
+    G = 4000; exons = [(1200, 1470), (1900, 2176)]
+    w = synth.make_world(seed=12, G=G, k=1, n_mut=6, mut_density=0.03)
+    lib = C.CDLL(pkg.LIB_PATH)
+    write_graph_dir(gdir, w["H"], exons)
+    write_graph_txt(gdir / "PRG" / "graph.txt", w["graph"], np.random.default_rng(2))
+    write_contigs_dir(gdir, w["contigs"], np.random.default_rng(3))
+    contigs, intervals = pkg.load_contigs_dir(lib, gdir, extended_reference_genome=False)
+    clen = np.diff(w["contigs"]["contig_off"])
+    NS = 8
+    names = [f"s{i}" for i in range(NS)]
+    for i, nm in enumerate(names):       # eight samples drawn from different haplotype pairs, different sizes
+        b = synth.make_batch(w, 220 + 20 * i, seed=500 + i, haps=(i % 5, (i + 2) % 5 + 1))
+        write_bam(tmp_path / f"premade_{nm}.bam", [(iv[0], int(clen[k])) for k, iv in enumerate(intervals)], batch_records(b, np.random.default_rng(10 + i)), block=30000)
+    # stand-ins for bwa and samtools: `samtools sort -o <outdir>/remapped_with_a.bam` receives the BAM made for the sample whose output directory it is
+    _stub(tmp_path / "bwa", "#!/bin/bash\nif [ \"$1\" = index ]; then touch $2.sa $2.ann $2.bwt; fi\nexit 0\n")
+    _stub(tmp_path / "samtools", f"#!/bin/bash\ncase \"$1\" in\n view) cat > /dev/null ;;\n sort) while [ $# -gt 0 ]; do if [ \"$1\" = -o ]; then d=$(basename $(dirname \"$2\")); cp {tmp_path}/premade_${{d#*_}}.bam \"$2\"; fi; shift; done ;;\n"
+                                  " index) touch \"$2.bai\" ;;\nesac\nexit 0\n")
+    (tmp_path / "r1.fq").write_text("@r\nA\n+\nI\n"); (tmp_path / "r2.fq").write_text("@r\nA\n+\nI\n")
+    fq1 = str(tmp_path / "r1.fq"); fq2 = str(tmp_path / "r2.fq")
+
+    def args(sample_ids, outs):
+        n = len(sample_ids)
+        return [exe, "--action", "HLA", "--maxThreads", "2", "--sampleID", ",".join(sample_ids), "--PRG_graph_dir", str(gdir), "--FASTQU", ",".join([fq1] * n), "--FASTQ1", ",".join([fq1] * n),
+                "--FASTQ2", ",".join([fq2] * n), "--bwa_bin", str(tmp_path / "bwa"), "--samtools_bin", str(tmp_path / "samtools"), "--mapAgainstCompleteGenome", "0", "--longReads", "0",
+                "--loci", "A", "--rngSeed", "5", "--batchPairs", "100", "--outputDirectory", ",".join(str(o) for o in outs)]
+    outs8 = [tmp_path / f"all_{nm}" for nm in names]
+    r8 = subprocess.run(args(names, outs8) + ["--devices", ",".join(["0"] * NS)], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r8.returncode == 0, r8.stdout[-3000:] + r8.stderr[-3000:]
+    assert f"Processed {NS} samples on {NS} device(s)" in r8.stdout and f"Graph directory read once for {NS} samples" in r8.stdout
+    seen = set()
+    for nm, o8 in zip(names, outs8):
+        o1 = tmp_path / f"one_{nm}"
+        r1 = subprocess.run(args([nm], [o1]), capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+        assert r1.returncode == 0 and "in 3 GPU batch(es)" in r1.stdout, r1.stdout[-2000:] + r1.stderr[-2000:]
+        files = sorted(os.listdir(o1 / "hla"))
+        assert files == sorted(os.listdir(o8 / "hla")) and "R1_bestguess.txt" in files and len(files) == 9
+        for fn in files:
+            assert (o8 / "hla" / fn).read_bytes() == (o1 / "hla" / fn).read_bytes(), (nm, fn)
+        assert (o8 / "reads_per_level.txt").read_bytes() == (o1 / "reads_per_level.txt").read_bytes(), nm
+        seen.add((o1 / "hla" / "R1_PP_A_pairs.txt").read_bytes() if (o1 / "hla" / "R1_PP_A_pairs.txt").exists() else (o1 / "reads_per_level.txt").read_bytes())
+    assert len(seen) == NS          # eight different samples, not one sample eight times
