@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--no-extras-but-e2e", action="store_true", help="of the measurements outside the timed region only the end-to-end run")
     ap.add_argument("--e2e-variants", default="", help="experiments: further end-to-end runs of the same sample under other environments, 'label:ENV=1 ENV2=x;label2:...'")
     ap.add_argument("--long-reads", type=int, default=50_000, help="reads of the long-read record (BASELINE config 5: 50 000 reads of ~10 kb; 0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=2, choices=(2, 3), help="alignments in flight on the one context in the boundary loop (plus one upload ahead)")
     ap.add_argument("--long-reads-check", type=int, default=256, help="reads of the long-read record compared with the CPU oracle after the clock has stopped (0 = none)")
     args = ap.parse_args()
 
@@ -282,11 +283,20 @@ def main():
                 # hlala_batch_create allocates no outputs), then reads batch i back and destroys it, then queues the alignment of batch i+2, whose output arrays
                 # are the pool blocks batch i just gave back.  (With the upload AFTER the read-back -- round 3's order -- the one host thread was the critical path:
                 # create 63 ms + wait for the batch 127 + read-back 67 = the 258 ms of a step, 30 ms of them with the GPU's main stream idle.)
+                # --in-flight 3 (round 5): a batch is complete when its tail classes have run on the side stream, beside the main-stream kernels of the NEXT batch;
+                # with main-stream steps of ~205 ms the chain [tail of batch i: ~135 ms] -> [read-back of batch i: 62 ms] -> [launch of batch i+2] ends where the main
+                # stream runs dry.  With 3, the alignment of batch i+2 is queued as soon as batch i is COMPLETE, before it is read back: three batches' outputs are
+                # live at that moment (a third set of pool blocks, 50 GB), two alignments are queued on the GPU as before.  (Queueing a third alignment AHEAD instead
+                # made hlala_align_batch block for a whole step: profiles/r05_experiments.txt.)
                 ahead = [bnd.start(k) for k in range(min(2, n))]
                 for i in range(n):
                     up = bnd.upload(i + 2) if i + 2 < n else None
                     before_export()
-                    bnd.finish(ahead.pop(0), recs[i % 2], lambda k=i % 2: gather(k))
+                    h = ahead.pop(0)
+                    bnd.wait_export(h, recs[i % 2], lambda k=i % 2: gather(k))
+                    if args.in_flight == 3 and up is not None:
+                        ahead.append(bnd.launch(up)); up = None
+                    bnd.readback(h)
                     if up is not None:
                         ahead.append(bnd.launch(up))
             run_boundary(max(args.warmup, 1))          # (at least one: pool blocks, first touch of the page-locked buffers)
@@ -367,16 +377,20 @@ def main():
         e_mean = g["n_edges"] / max(1, g["n_nodes"] - 1)
         bpp = algorithmic_bytes_per_pair(150, chains_pp, e_mean, cols_pc, cols_pc)
         cls_ms = [float(x) for x in st.ms_dp_class]; cls_n = [int(x) for x in st.n_dp_class]
-        # (the 16-lane class is two kernels launched back to back: the jump-free and the general instantiation of one template; its events span both)
-        names = ["k_dp<DpTinyJF, 0> + k_dp<DpTiny, 0>" if st.n_dp_jump_free > 0 else "k_dp<DpTiny, 0>", "k_dp<DpMid, 1>", "k_dp<DpSmall, 2>", "k_dp<DpWide, 3>", "k_dp<DpBroad, 4>", "k_dp<DpLarge, 5>", "k_dp<DpHuge, 6>"]
-        # the dominant kernel among the classes of the main stream: the times of the side-stream classes (few hundred long DP calls at low priority beside
-        # the next batch, hlala_align_batch) are waiting times, not work
-        dom = int(np.argmax(cls_ms[:4]))
-        dom_ms = cls_ms[dom]
+        # The first DP class is five kernels launched back to back (round 5): the band kernels (k_dp_band<16 / 32 / 64>: calls on linear stretches of the graph), then the
+        # jump-free and the general instantiation of the 16-lane template, whose events span both.  Every kernel is named on its own; the single dominant kernel among
+        # the classes of the main stream is what `roofline` prices (the times of the side-stream classes -- a few hundred long DP calls at low priority beside the next
+        # batch, hlala_align_batch -- are waiting times, not work), and `roofline.first_class` holds the sum of the five.
+        ms_band = float(st.ms_dp_band); ms_jf = float(st.ms_dp_jump_free); ms_gen = max(0.0, cls_ms[0] - ms_jf)
+        kern = [("k_dp_band<16> + <32> + <64>", ms_band), ("k_dp<DpTinyJF, 0>", ms_jf), ("k_dp<DpTiny, 0>", ms_gen), ("k_dp<DpMid, 1>", cls_ms[1]), ("k_dp<DpSmall, 2>", cls_ms[2]), ("k_dp<DpWide, 3>", cls_ms[3])]
+        names = [k for k, _ in kern]
+        dom = int(np.argmax([m for _, m in kern]))
+        dom_ms = kern[dom][1]
         achieved = bpp * args.pairs / (dom_ms * 1e-3) / 1e9
+        first_class_ms = ms_band + cls_ms[0]
         khash = kernel_source_hash()
         traffic, traffic_note, secondary = None, "no PMC pass on file for this build", {}
-        tfile = next((f for f in (os.path.join(ROOT, "profiles", t + "_traffic.json") for t in ("r04", "r03", "r02")) if os.path.exists(f)), "")
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", t + "_traffic.json") for t in ("r05", "r04", "r03", "r02")) if os.path.exists(f)), "")
         tname = os.path.relpath(tfile, ROOT) if tfile else ""
         if tfile:
             try:
@@ -390,11 +404,11 @@ def main():
                     secondary = dict(tj.get("secondary", {})); secondary["measured_on_kernel_source_hash"] = tj.get("kernel_source_hash")
             except Exception:
                 pass
-        secondary["dp_cells_per_s"] = st.n_dp_cells / (sum(cls_ms) * 1e-3)
+        secondary["dp_cells_per_s"] = st.n_dp_cells / ((sum(cls_ms) + ms_band) * 1e-3)
         if secondary.get("valu_insts_all_dp_classes_per_launch"):
             secondary["valu_wave_insts_per_dp_cell"] = secondary["valu_insts_all_dp_classes_per_launch"] / max(1, st.n_dp_cells)
         headline = ("host-inclusive: hlala_batch_create (H2D, page-locked caller buffers) + hlala_align_batch + export of the per-pair records (+ gather) + hlala_batch_get_pairs + "
-                    "hlala_batch_get_pairs_packed (D2H) + hlala_batch_destroy per step, " + ("one batch at a time" if args.single_batch else "two alignments in flight and one upload ahead on one context, one host thread")) \
+                    "hlala_batch_get_pairs_packed (D2H) + hlala_batch_destroy per step, " + ("one batch at a time" if args.single_batch else f"{args.in_flight} alignments in flight and one upload ahead on one context, one host thread")) \
             if boundary is not None else "RESIDENT rate (--resident-only: kernel A/B mode, the boundary loop was not run)"
         out = {
             "metric": "paired reads/sec aligned to PRG graph", "value": value, "unit": "read pairs/s",
@@ -402,19 +416,22 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": desc, "timed_region": headline, "graph": args.graph, "pairs_per_gpu": args.pairs, "graph_levels": args.levels, "graph_nodes": int(g["n_nodes"]), "graph_edges": int(g["n_edges"]),
-                       "parallelism": f"shard{world}", "batches_in_flight": 1 if args.single_batch else 2, "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
+                       "parallelism": f"shard{world}", "batches_in_flight": 1 if args.single_batch else (args.in_flight if boundary is not None else 2), "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
                        "columns_per_chain": cols_pc, "mean_out_degree": e_mean,
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
                        "pairs_ok": int(oks[0]), "pairs_ok_per_rank": [int(x) for x in oks], "chain_errors": int(st.n_errors),
                        "resident": resident,
                        "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "pair": st.ms_pair, "side_stream": st.ms_side,
                                     "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6],
-                                    "dp_16lane_jump_free_part": float(st.ms_dp_jump_free)},
+                                    "dp_16lane_jump_free_part": ms_jf, "dp_16lane_general_part": ms_gen, "dp_band": ms_band},
                        "stage_ms_source": "HIP events of one batch of the resident loop, on the streams its kernels ran on (the kernels of the boundary loop are the same)",
-                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "16lane_jump_free": int(st.n_dp_jump_free)},
+                       "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "16lane_jump_free": int(st.n_dp_jump_free),
+                                                   "band": int(st.n_dp_band), "band_failed_over_to_16lane": int(st.n_dp_band_failed), "jump_free_met_a_jump_and_went_to_the_general_list": int(st.n_dp_jump_free_failed)},
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,
+                         "first_class": {"kernels": "k_dp_band<16> + <32> + <64> + k_dp<DpTinyJF, 0> + k_dp<DpTiny, 0>", "ms": first_class_ms, "achieved": bpp * args.pairs / (first_class_ms * 1e-3) / 1e9,
+                                         "by_kernel_ms": {k: m for k, m in kern[:3]}},
                          "algorithmic_bytes_per_pair": bpp, "whole_step_achieved": bpp * args.pairs / (ms_per_step * 1e-3) / 1e9,
                          "note": "dominant kernel only (HIP events on the ctx stream); the path is bound by instruction issue and dependent LDS / global "
                                  "round trips, not by HBM (SURVEY 8(d)): see `secondary`",
@@ -559,12 +576,16 @@ class Boundary:
     def start(self, i):
         return self.launch(self.upload(i))
 
-    def finish(self, h, rec, gather):
+    def wait_export(self, h, rec, gather):
         C = self.C
         t = time.perf_counter()
         self.ctx._check(self.lib.hlala_batch_export_pair_records(self.ctx.h, h, C.c_void_p(rec.data_ptr())), "hlala_batch_export_pair_records")
         gather()
-        t = self._t("wait_and_export", t)
+        self._t("wait_and_export", t)
+
+    def readback(self, h):
+        C = self.C
+        t = time.perf_counter()
         self.ctx._check(self.lib.hlala_batch_get_pairs(self.ctx.h, h, C.byref(self.po)), "hlala_batch_get_pairs")
         t = self._t("get_pairs", t)
         self.ctx._check(self.lib.hlala_batch_get_pairs_packed(self.ctx.h, h, C.byref(self.pk)), "hlala_batch_get_pairs_packed")
@@ -572,6 +593,10 @@ class Boundary:
         self.lib.hlala_batch_destroy(h)
         self._t("destroy", t)
         self.last_cols = int(self.pk.n_cols_total)
+
+    def finish(self, h, rec, gather):
+        self.wait_export(h, rec, gather)
+        self.readback(h)
 
     def host_ms(self):
         """mean wall clock of the host thread per call (ms): where the one host thread of the boundary loop spends a step"""

@@ -214,7 +214,7 @@ static void pool_release(hlala_ctx* c, void* p)
     if(!p) return;
     auto it = c->block_bytes.find(p);
     if(it == c->block_bytes.end()) { (void)hipFree(p); return; }
-    if(c->pool_bytes + it->second > ((size_t)96 << 30)) { c->block_bytes.erase(it); (void)hipFree(p); return; }      // keep at most 96 GB parked
+    if(c->pool_bytes + it->second > ((size_t)176 << 30)) { c->block_bytes.erase(it); (void)hipFree(p); return; }      // keep at most 176 GB parked (three 1 M-pair batches' arrays: a caller with three sets of outputs live gives them all back between two runs)
     c->pool.emplace(it->second, p); c->pool_bytes += it->second;
 }
 

@@ -263,7 +263,7 @@ def test_eight_samples_on_eight_contexts_in_one_call(exe, pkg, tmp_path):
     for nm, o8 in zip(names, outs8):
         o1 = tmp_path / f"one_{nm}"
         r1 = subprocess.run(args([nm], [o1]), capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
-        assert r1.returncode == 0 and "in 3 GPU batch(es)" in r1.stdout, r1.stdout[-2000:] + r1.stderr[-2000:]
+        assert r1.returncode == 0 and ("in 3 GPU batch(es)" in r1.stdout or "in 4 GPU batch(es)" in r1.stdout), r1.stdout[-2000:] + r1.stderr[-2000:]       # 220 .. 360 pairs in batches of 100
         files = sorted(os.listdir(o1 / "hla"))
         assert files == sorted(os.listdir(o8 / "hla")) and "R1_bestguess.txt" in files and len(files) == 9
         for fn in files:

@@ -14,7 +14,7 @@ import bench  # noqa: E402
 
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
-NAMES = (("DpTinyJF", "k_dp<DpTinyJF, 0>"), ("DpTiny", "k_dp<DpTiny, 0>"), ("DpMid", "k_dp<DpMid, 1>"), ("DpSmall", "k_dp<DpSmall, 2>"), ("DpWide", "k_dp<DpWide, 3>"), ("DpBroad", "k_dp<DpBroad, 4>"), ("DpLarge", "k_dp<DpLarge, 5>"), ("DpHuge", "k_dp<DpHuge, 6>"),
+NAMES = (("k_dp_band<16>", "k_dp_band<16>"), ("k_dp_band<32>", "k_dp_band<32>"), ("k_dp_band<64>", "k_dp_band<64>"), ("DpTinyJF", "k_dp<DpTinyJF, 0>"), ("DpTiny", "k_dp<DpTiny, 0>"), ("DpMid", "k_dp<DpMid, 1>"), ("DpSmall", "k_dp<DpSmall, 2>"), ("DpWide", "k_dp<DpWide, 3>"), ("DpBroad", "k_dp<DpBroad, 4>"), ("DpLarge", "k_dp<DpLarge, 5>"), ("DpHuge", "k_dp<DpHuge, 6>"),
          ("k_stitch", "k_stitch_chains"), ("k_project", "k_project_chains"), ("k_rethread", "k_rethread_chains"), ("k_pair_chains", "k_pair_chains"), ("k_dp_items", "k_dp_items"), ("k_filter", "k_filter_chains"))
 
 
@@ -59,28 +59,36 @@ with open("profiles/" + TAG + "_pmc_sq_1Mpairs.csv", "w") as o:
     for k in sorted(q, key=lambda k: -q[k]["SQ_WAVE_CYCLES"]):
         v = [q[k][c] / ql[k] for c in cn]
         o.write(k + "," + ",".join("%.0f" % x for x in v) + ",%.4f,%.4f\n" % (v[2] / max(1.0, v[0]), v[4] / max(1.0, v[0])))
-# the 16-lane class is two kernels launched back to back since round 4 (jump-free + general instantiation of one template): a class-level row = their sum
-CLS = "k_dp<DpTinyJF, 0> + k_dp<DpTiny, 0>"
-if "k_dp<DpTinyJF, 0>" in q and "k_dp<DpTiny, 0>" in q:
-    a, b_ = "k_dp<DpTinyJF, 0>", "k_dp<DpTiny, 0>"
+# the first DP class is five kernels launched back to back since round 5 (three band kernels, the jump-free and the general instantiation of the 16-lane template): a
+# class-level row = their sum; the DOMINANT kernel is a single kernel (bench.py: roofline.kernel), chosen as the DP kernel that keeps the chip busy longest when it
+# runs alone (SQ_BUSY_CYCLES of the single-batch PMC pass) -- the rocprof averages of the default run include the stretch of the side-stream classes beside the next batch
+BAND = "k_dp_band<16> + <32> + <64>"
+parts = [k for k in ("k_dp_band<16>", "k_dp_band<32>", "k_dp_band<64>") if k in q]
+if parts:
     for c in cn:
-        q[CLS][c] = q[a][c] / ql[a] + q[b_][c] / ql[b_]
-    ql[CLS] = 1
-    ra = [r for r in rows if r[0] == a][0]; rb = [r for r in rows if r[0] == b_][0]
-    rows.append((CLS, ra[1] + rb[1], ra[2] + rb[2], ra[3] + rb[3]))
-    avg_ms[CLS] = avg_ms[a] + avg_ms[b_]
-    for k in (a, b_):          # (the class row stands for them when the dominant kernel is chosen)
-        q[k]["SQ_BUSY_CYCLES"] = 0
-# dominant kernel: the DP class that keeps the chip busy longest when it runs alone (SQ_BUSY_CYCLES of the single-batch PMC pass) -- the rocprof averages of
-# the default run include the stretch of the side-stream classes beside the next batch and would name the in-memory class on some boxes
-dom = max((k for k in q if k.startswith("k_dp")), key=lambda k: q[k]["SQ_BUSY_CYCLES"] / ql[k])
+        q[BAND][c] = sum(q[k][c] / ql[k] for k in parts)
+    ql[BAND] = 1
+    rp = [r for r in rows if r[0] in parts]
+    rows.append((BAND, sum(r[1] for r in rp), sum(r[2] for r in rp), sum(r[3] for r in rp)))
+    avg_ms[BAND] = sum(avg_ms.get(k, 0.0) for k in parts)
+CLS = "first DP class: " + BAND + " + k_dp<DpTinyJF, 0> + k_dp<DpTiny, 0>"
+members = [k for k in (BAND, "k_dp<DpTinyJF, 0>", "k_dp<DpTiny, 0>") if k in q]
+for c in cn:
+    q[CLS][c] = sum(q[k][c] / ql[k] for k in members)
+ql[CLS] = 1
+rm = [r for r in rows if r[0] in members]
+rows.append((CLS, sum(r[1] for r in rm), sum(r[2] for r in rm), sum(r[3] for r in rm)))
+avg_ms[CLS] = sum(avg_ms.get(k, 0.0) for k in members)
+single = [k for k in q if (k.startswith("k_dp<") or k == BAND) and k in ("k_dp<DpTinyJF, 0>", "k_dp<DpTiny, 0>", "k_dp<DpMid, 1>", "k_dp<DpSmall, 2>", "k_dp<DpWide, 3>", BAND)]
+dom = max(single, key=lambda k: q[k]["SQ_BUSY_CYCLES"] / ql[k])
 t = [r for r in rows if r[0] == dom][0]
 qs = {c: q[dom][c] / ql[dom] for c in cn}
 args = dict(pairs=1048576, levels=5000000, graph="m")
 json.dump(dict(args, kernel=dom, kernel_source_hash=bench.kernel_source_hash(), fetch_size_kb=t[1], write_size_kb=t[2], hbm_bytes_per_launch=t[3], rocprof_avg_ms=avg_ms[dom],
                secondary={"wait_frac": qs["SQ_WAIT_ANY"] / qs["SQ_WAVE_CYCLES"], "active_frac": qs["SQ_ACTIVE_INST_ANY"] / qs["SQ_WAVE_CYCLES"],
                           "valu_insts_per_launch": qs["SQ_INSTS_VALU"], "salu_insts_per_launch": qs["SQ_INSTS_SALU"], "lds_insts_per_launch": qs["SQ_INSTS_LDS"],
-                          "valu_insts_all_dp_classes_per_launch": sum(q[k]["SQ_INSTS_VALU"] / ql[k] for k in q if k.startswith("k_dp<") and k != CLS),
+                          "valu_insts_all_dp_classes_per_launch": sum(q[k]["SQ_INSTS_VALU"] / ql[k] for k in q if (k.startswith("k_dp<") or k.startswith("k_dp_band<")) and k not in (CLS, BAND)),
+                          "first_class": {"kernels": CLS, "hbm_bytes_per_launch": [r for r in rows if r[0] == CLS][0][3], "valu_insts_per_launch": q[CLS]["SQ_INSTS_VALU"], "rocprof_avg_ms": avg_ms[CLS]},
                           "source": "profiles/" + TAG + "_pmc_sq_1Mpairs.csv (SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES of the dominant kernel)"},
                note="(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes of `bench.py --steps 1 --warmup 0 --no-extras`; FETCH_SIZE doubled as "
                     "MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE uncalibrated"), open("profiles/" + TAG + "_traffic.json", "w"), indent=1)
