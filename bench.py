@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--e2e-variants", default="", help="experiments: further end-to-end runs of the same sample under other environments, 'label:ENV=1 ENV2=x;label2:...'")
     ap.add_argument("--long-reads", type=int, default=50_000, help="reads of the long-read record (BASELINE config 5: 50 000 reads of ~10 kb; 0 = skip)")
     ap.add_argument("--in-flight", type=int, default=2, choices=(2, 3), help="alignments in flight on the one context in the boundary loop (plus one upload ahead)")
+    ap.add_argument("--long-reads-batch", type=int, default=50000, help="reads per batch of the long-read record (16 384-column rows: 17 GB of column arrays for 50 000 reads; five batches of 10 000 take 2.5 times as long -- every batch ends on its slowest wavefronts)")
     ap.add_argument("--long-reads-check", type=int, default=256, help="reads of the long-read record compared with the CPU oracle after the clock has stopped (0 = none)")
     args = ap.parse_args()
 
@@ -701,7 +702,7 @@ def long_reads(args, P, synth, w):
     extendToFullSequenceLength + scoreOneAlignment; the reference runs no extension DP in this mode, :3732-3734).  --long-reads distinct reads over 6-14 kb of
     reference (mean read length ~10.2 kb) drawn from the backbone haplotypes of the bench's graph -- crossing the gene windows where they lie --, substitutions 5 %, insertions 4 %,
     deletions 4 %, in batches of 10 000 reads through a context with 16 384-column rows.  Inputs resident; reads/s and bases/s, stage times."""
-    n = args.long_reads; per = 10000
+    n = args.long_reads; per = getattr(args, "long_reads_batch", 50000)
     ctx = P.Context(w["graph"], w["contigs"], insert_mean=200.0, insert_sd=35.0, rng_seed=12345, long_read_mode=1, max_columns=16384, device=0)
     try:
         t0 = time.time()
@@ -725,7 +726,23 @@ def long_reads(args, P, synth, w):
             checked = {"error": repr(e)}
         for g in gbs:
             g.close()
-        return {"reads": n, "bases": bases, "parity_checked": checked, "mean_read_length": bases / max(1, n), "reads_per_s": n / dt, "bases_per_s": bases / dt, "seconds": dt, "batches": len(gbs), "reads_ok": ok,
+        # roofline of the leg: SURVEY 8(d)'s per-unit bytes for ONE read and ONE chain (packed bases + qualities, the record, translation + reference base per column, the
+        # CSR edges of the levels the chain spans counted once, the output columns) over the time of the dominant kernel, k_project_chains<ProjLdsLong>
+        cols = float(sum(int(s_.n_out_columns) for s_ in sts)) / max(1, n); rl = bases / max(1, n)
+        e_mean = w["graph"]["n_edges"] / max(1, w["graph"]["n_nodes"] - 1)
+        b_read = (rl / 2 + rl) + (32 + 5 * rl + 5 * e_mean * cols) + 7 * cols + 64
+        proj_s = float(sum(s_.ms_project for s_ in sts)) * 1e-3
+        ach = b_read * n / max(proj_s, 1e-9) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_project_chains<ProjLdsLong>", "kernel_ms_sum": proj_s * 1e3, "algorithmic_bytes_per_read": b_read, "columns_per_read": cols, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                "frac": ach / 8000.0, "traffic": None, "note": "HIP events of the batches' projection stage; the measured HBM traffic and the SQ counters of the kernel: profiles/r05_long_*"}
+        tl = os.path.join(ROOT, "profiles", "r05_long_traffic.json")
+        if os.path.exists(tl):
+            try:
+                tj = json.load(open(tl)); roof["traffic_per_read"] = tj.get("hbm_bytes_per_read"); roof["traffic"] = tj.get("hbm_bytes_per_read", 0) * n / max(1, len(gbs)); roof["secondary"] = tj.get("secondary")
+                roof["traffic_source"] = "profiles/r05_long_traffic.json (kernel sources %s)" % tj.get("kernel_source_hash")
+            except Exception:
+                pass
+        return {"reads": n, "bases": bases, "parity_checked": checked, "reads_per_batch": per, "roofline": roof, "mean_read_length": bases / max(1, n), "reads_per_s": n / dt, "bases_per_s": bases / dt, "seconds": dt, "batches": len(gbs), "reads_ok": ok,
                 "stage_ms_sum": {"project": float(sum(s.ms_project for s in sts)), "pad_and_score": float(sum(s.ms_extend for s in sts)), "select": float(sum(s.ms_pair for s in sts))},
                 "chain_errors": int(sum(int(s.n_errors) for s in sts)), "generation_s": t_gen,
                 "what": "hlala_batch_create_unpaired batches resident in HBM, hlala_align_batch each; distinct reads, one primary alignment each (the reference takes primaries only, processBAM.cpp:732-738)"}
