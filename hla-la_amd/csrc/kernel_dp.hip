@@ -47,6 +47,9 @@ enum { M_D = 0, M_GG = 1, M_SG = 2 };
 enum { PH_IDLE = 0, PH_RUN, PH_SELECT, PH_BT, PH_EXPAND, PH_DONE };
 
 constexpr u64 HKEY_EMPTY = ~0ull;
+#ifndef HLALA_DP_PROFILE_LOG2
+#define HLALA_DP_PROFILE_LOG2 18      // (profile build: calls of more than 2^this cycles are recorded)
+#endif
 #ifndef HLALA_EARLY_GEN_MAX
 #define HLALA_EARLY_GEN_MAX 0xFFFFFE      // (tools/gpu_gen_wrap.sh builds with a tiny value to exercise the wrap-around under the parity tests)
 #endif
@@ -1730,9 +1733,9 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
                     DpState& st = S.st;
                     S.nextPhase = PH_IDLE;
 #ifdef HLALA_DP_PROFILE
-                    if(B.dbg && TIER == HLALA_DP_PROFILE) {
+                    if(B.dbg && TIER == HLALA_DP_PROFILE && !C::JF) {
                         const long long cyc = clock64() - S.pfStart;
-                        if(cyc > (1ll << 18)) { int q = atomicAdd(&B.dbg[0], 1); if(q < 500) { int* r = B.dbg + 16 + 16 * q; r[0] = st.item; r[1] = st.itersRun; r[2] = (int)st.cellsEvaluated; r[3] = st.nCells;
+                        if(cyc > (1ll << HLALA_DP_PROFILE_LOG2) && (HLALA_DP_PROFILE_LOG2 >= 12 || (((u32)st.item * 2654435761u) >> 24) == 0)) { int q = atomicAdd(&B.dbg[0], 1); if(q < 500) { int* r = B.dbg + 16 + 16 * q; r[0] = st.item; r[1] = st.itersRun; r[2] = (int)st.cellsEvaluated; r[3] = st.nCells;
                             r[4] = S.pfSlow; r[5] = S.pfImp; r[6] = S.pfPre; r[7] = (int)(cyc >> 10); r[8] = S.pfMaxNT;
                             r[9] = (int)(S.pfPh[4] >> 10); r[10] = (int)(S.pfPh[5] >> 10); r[11] = (int)(S.pfPh[0] >> 10); r[12] = (int)(S.pfPh[3] >> 10); r[13] = (int)(S.pfPh[6] >> 10); r[14] = (int)(S.pfPh[1] >> 10); r[15] = (int)(S.pfPh[2] >> 10); } }
                     }

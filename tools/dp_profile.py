@@ -31,3 +31,12 @@ print("item iters cellsEval nCells slowIters sumImp preIters kcycles maxNT | kcy
 for x in r[:40]:
     print(" ".join(str(int(v)) for v in x))
 print("sum kcycles", int(r[:, 7].sum()), "mean", float(r[:, 7].mean()) if len(r) else 0)
+
+# groups: by whether the call looked up early cells (preIters > 0) and whether it met one again (slowIters > 0)
+if len(r):
+    pre = r[:, 6] > 0; slow = r[:, 4] > 0
+    for name, m in (("no early cell", ~pre), ("early-cell look-ups, none met again", pre & ~slow), ("met an early cell again (two-pass iterations)", slow)):
+        if m.any():
+            x = r[m]
+            print("%-48s %4d calls: mean kcycles %7.1f, iterations %5.1f, cells %6.1f, slow iters %4.1f, pre iters %4.1f | records %5.1f pushes %5.1f tlist %4.1f early %5.1f evaluate %5.1f post %5.1f filter %5.1f" % (
+                name, int(m.sum()), x[:, 7].mean(), x[:, 1].mean(), x[:, 2].mean(), x[:, 4].mean(), x[:, 6].mean(), x[:, 9].mean(), x[:, 10].mean(), x[:, 11].mean(), x[:, 12].mean(), x[:, 13].mean(), x[:, 14].mean(), x[:, 15].mean()))
