@@ -1516,7 +1516,9 @@ extern "C" int hlala_type_locus(hlala_ctx* c, const hlala_exon_in* in, double* L
     if(!c || !in || !pairLL || !misAvg || !misMin || !order || !p_normalized || !cluster_marginal || !out) return HLALA_E_ARG;
     if(in->n_clusters < 1) { c->err = "hlala_type_locus: no clusters"; return HLALA_E_ARG; }
     std::vector<void*> keep;
-    auto done = [&](int r_) { for(void* p : keep) pool_release(c, p); return r_; };
+    // (the steps run unsynchronised in keep mode: on ANY failure the stream is drained before the kept device blocks go back to the pool and before the caller, who
+    //  sees the error, may free the host buffers the queued copies write to)
+    auto done = [&](int r_) { if(r_) (void)hipStreamSynchronize(c->active); for(void* p : keep) pool_release(c, p); return r_; };
     const int C = in->n_clusters, R = in->n_reads < 0 ? 0 : in->n_reads;
     double *dLL = nullptr, *dP = nullptr, *dA = nullptr, *dMn = nullptr; int* dM = nullptr;
     int rc = exon_loglik_impl(c, in, LL, mism, &keep, &dLL, &dM); if(rc) return done(rc);
@@ -1525,7 +1527,6 @@ extern "C" int hlala_type_locus(hlala_ctx* c, const hlala_exon_in* in, double* L
     }
     if((rc = pair_loglik_impl(c, nullptr, nullptr, dLL, dM, C, R, pairLL, misAvg, misMin, &keep, &dP, &dA, &dMn))) return done(rc);
     rc = call_locus_impl(c, C, nullptr, nullptr, nullptr, dP, dA, dMn, order, p_normalized, cluster_marginal, out);       // (ends synchronised)
-    if(rc) (void)hipStreamSynchronize(c->active);
     return done(rc);
 }
 
@@ -1690,11 +1691,14 @@ extern "C" int hlala_kmer_keep_reads(hlala_ctx* c, hlala_batch* b, const uint8_t
     if((rc = pool_malloc(c, &p, (size_t)tot[1] + 64))) return done(rc); kr.store = (uint8_t*)p;
     if((rc = pool_malloc(c, &p, (size_t)tot[0] * sizeof(long long)))) { pool_release(c, kr.store); return done(rc); } kr.start = (long long*)p;
     if((rc = pool_malloc(c, &p, (size_t)tot[0] * sizeof(int)))) { pool_release(c, kr.store); pool_release(c, kr.start); return done(rc); } kr.length = (int*)p;
-    c->kept.push_back(kr);                                                          // (owned by the context from here on)
+    // (the chunk joins the context's list only once it is filled: a failed launch or copy must not leave an entry with undefined start[] / length[] behind,
+    //  which hlala_kmer_presence_kept would index the store with)
+    auto drop = [&](int r_) { (void)hipStreamSynchronize(c->active); pool_release(c, kr.store); pool_release(c, kr.start); pool_release(c, kr.length); return done(r_); };
     const unsigned grid = (unsigned)std::min<long long>((long long)nReads, (long long)c->stitch_grid);
     hipLaunchKernelGGL(k_kmer_keep, dim3(grid), dim3(64), 0, c->active, b->dB, (const uint8_t*)dMask, dTot + 2, kr.start, kr.length, kr.store);
-    if((rc = check_launch(c, "k_kmer_keep"))) return done(rc);
-    HIP_TRY_F(c, hipStreamSynchronize(c->active), done);                            // (the mask and the cursors go back to the pool)
+    if((rc = check_launch(c, "k_kmer_keep"))) return drop(rc);
+    if(hipStreamSynchronize(c->active) != hipSuccess) { c->err = "hlala_kmer_keep_reads: the device reported an error"; return drop(HLALA_E_DEVICE); }      // (the mask and the cursors go back to the pool)
+    c->kept.push_back(kr);                                                          // (owned by the context from here on)
     if(n_reads_kept) *n_reads_kept = (int64_t)tot[0];
     return done(HLALA_OK);
 }

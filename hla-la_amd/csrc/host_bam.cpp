@@ -367,8 +367,10 @@ void (*g_seed_batch_unpin)(hlala_seed_batch*) = nullptr;       // set by the GPU
 extern "C" int hlala_pack_bases(const uint8_t* read_bases, const int64_t* read_off, int64_t n_reads, uint8_t* packed)
 {
     if(!read_bases || !read_off || !packed || n_reads < 0) return HLALA_E_ARG;
-    static uint8_t code[256]; static bool init = false;
-    if(!init) { memset(code, 15, sizeof(code)); const char* s16 = "=ACMGRSVTWYHKDBN"; for(int i = 0; i < 16; i++) code[(unsigned char)s16[i]] = (uint8_t)i; init = true; }
+    // (a function-local static initialised by a lambda: thread-safe by the language; two callers making the first call at once used to race on a plain flag)
+    struct Table { uint8_t v[256]; };
+    static const Table table = [] { Table t; memset(t.v, 15, sizeof(t.v)); const char* s16 = "=ACMGRSVTWYHKDBN"; for(int i = 0; i < 16; i++) t.v[(unsigned char)s16[i]] = (uint8_t)i; return t; }();
+    const uint8_t* code = table.v;
     for(int64_t r = 0; r < n_reads; r++) {
         const int64_t o = read_off[r], len = read_off[r + 1] - o; uint8_t* dst = packed + ((o + r + 1) >> 1);
         for(int64_t j = 0; j + 1 < len; j += 2) dst[j >> 1] = (uint8_t)((code[read_bases[o + j]] << 4) | code[read_bases[o + j + 1]]);

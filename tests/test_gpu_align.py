@@ -374,3 +374,18 @@ def test_band_kernel_and_its_fail_over_are_bit_exact(pkg, oracle, monkeypatch, e
             assert tot_failed > 0.02 * tot_band              # the fail-over path is exercised ...
         elif not env:
             assert tot_failed <= 0.01 * tot_band             # ... and is not the common path
+
+
+def test_stats_of_a_batch_that_was_only_uploaded(pkg):
+    """hlala_batch_create allocates no outputs (the first stage call does): hlala_batch_get_stats and the debug counters of a batch that was only uploaded -- what
+    the host program's walk holds one step ahead -- return zeros instead of reading counters that do not exist yet."""
+    w = synth.make_world(seed=5, G=3000, k=1)
+    b = synth.make_batch(w, 50, seed=6)
+    ctx = pkg.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=1)
+    gb = ctx.batch(b)
+    st = gb.stats()
+    assert st.n_dp_calls == 0 and st.n_chains_extended == 0 and st.n_errors == 0 and st.ms_extend == 0.0
+    gb.align()
+    st = gb.stats()
+    assert st.n_dp_calls > 0 and st.n_chains_extended > 0
+    gb.close(); ctx.close()
