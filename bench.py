@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--no-extras-but-e2e", action="store_true", help="of the measurements outside the timed region only the end-to-end run")
     ap.add_argument("--e2e-variants", default="", help="experiments: further end-to-end runs of the same sample under other environments, 'label:ENV=1 ENV2=x;label2:...'")
     ap.add_argument("--long-reads", type=int, default=50_000, help="reads of the long-read record (BASELINE config 5: 50 000 reads of ~10 kb; 0 = skip)")
-    ap.add_argument("--in-flight", type=int, default=2, choices=(2, 3), help="alignments in flight on the one context in the boundary loop (plus one upload ahead)")
+    ap.add_argument("--in-flight", type=int, default=3, choices=(2, 3), help="batches whose outputs are live at one time in the boundary loop: 2 = the alignment of batch i+2 is queued after batch i has been read back and destroyed; 3 (default) = as soon as batch i is COMPLETE, before its read-back (two alignments queued on the GPU either way, plus one upload ahead)")
     ap.add_argument("--long-reads-batch", type=int, default=50000, help="reads per batch of the long-read record (16 384-column rows: 17 GB of column arrays for 50 000 reads; five batches of 10 000 take 2.5 times as long -- every batch ends on its slowest wavefronts)")
     ap.add_argument("--long-reads-check", type=int, default=256, help="reads of the long-read record compared with the CPU oracle after the clock has stopped (0 = none)")
     args = ap.parse_args()

@@ -604,8 +604,10 @@ struct __align__(16) DpItem { int item, rOff, seqLen, start_seq, startLevel, sta
 // The fused entry point runs the classes from this tier on on its side stream (hlala_api.hip: extend_impl).  Measured on Graph M, 1M pairs per batch
 // (tools/gpu_side_ab.sh), two batches in flight / one batch at a time: tier 3: 369 / 406 ms per batch, 4: 360 / 393, 5: 366 / 391, 6: 372 / 379;
 // the same two batches without any overlap between them: 400.
+// Round 5 (the main stream's kernels take 200 ms of a step, the side stream's 135): with the wide class on the side stream as well, resident step 205.2 -> 199.8 / 200.4 ms (side span 163 ms);
+// with the 64-lane class too 211.1 ms (side span 203 ms: the side stream becomes the longer one).  profiles/r05_experiments.txt 10.
 #ifndef HLALA_DP_SIDE_TIER
-#define HLALA_DP_SIDE_TIER 4
+#define HLALA_DP_SIDE_TIER 3
 #endif
 constexpr int DP_SIDE_TIER = HLALA_DP_SIDE_TIER;
 constexpr int DP_LAST_TIER = 6;      // tiers: 0 DpTiny, 1 DpMid, 2 DpSmall, 3 DpWide, 4 DpBroad, 5 DpLarge, 6 DpHuge
