@@ -98,7 +98,7 @@ __host__ __device__ inline int dpl_of_class(int cls) { return cls == 0 ? DPL_GEN
 // [40..45] lists of the lane-per-DP class; round 5: items fetched by the three band kernels (left, right each), the fail-over list's counts and fetch counters, band calls that
 // failed over, band calls listed, jump-free calls that met a jump, and why band calls failed ([WC_BAND_WHY + 2 .. + 5]: past the staged levels, past the linear run, too
 // many iterations, too many tied end cells)
-enum { WC_BAND_FETCH = 48, WC_FO_COUNT = 54, WC_FO_FETCH = 56, WC_BAND_FAILED = 58, WC_BAND_CALLS = 59, WC_JF_FAILED = 60, WC_BAND_WHY = 62, WC_N = 72 };
+enum { WC_BAND_FETCH = 48, WC_FO_COUNT = 54, WC_FO_FETCH = 56, WC_BAND_FAILED = 58, WC_BAND_CALLS = 59, WC_JF_FAILED = 60, WC_BAND_WHY = 62, WC_BAND_TIED = 68, WC_N = 72 };
 // the fail-over list of the first classes: calls the band kernel (kernel_dp_band.hip) or the jump-free instantiation could not finish; k_dp<DpTiny, 0> draws it after
 // its own lists.  Entries (slots of dp_items) at retry_list[(14 + direction) * n_chains ...], counts in work_counter[WC_FO_COUNT + direction].
 // ---- capacities of the band kernels (kernel_dp_band.hip): read bases a call may have left for the instantiation with 16 / 32 / 64 lanes per call; k_dp_items lists a call

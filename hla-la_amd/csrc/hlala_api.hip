@@ -458,6 +458,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     // (an experiment that lost, kept switchable and under test: HLALA_DP_LANE=1 puts the lane-per-DP class in front of the 16-lane class -- kernel_dp_lane.hip)
 #ifdef HLALA_WITH_LANE_CLASS
     { const char* e = getenv("HLALA_DP_LANE"); c->lane_grid = (e && atoi(e) != 0) ? cus * 4 : 0; }          // 36 KB of LDS per wave: four per CU
+    if(c->lane_grid) c->band_grid = 0;          // (the lane-per-DP class draws every item itself: no band lists beside it)
     if(c->lane_grid && (rc = slab_pool(&c->lane_slabs, dp_lane_slab_bytes() * (size_t)64 * (size_t)c->lane_grid, "lane-per-DP slabs"))) return fail(rc);
 #endif
     if((rc = slab_pool(&c->mid_slabs, c->mid_slab_bytes * (size_t)(64 / DpMid::GW) * (size_t)c->mid_grid, "32-lane DP slabs"))) return fail(rc);

@@ -180,6 +180,7 @@ __device__ __forceinline__ void band_pass(const DevGraph& G, const DevBatch& B, 
         const int best = __shfl(cBest, srcLane), nTies = __shfl(cCount, srcLane), tie0 = __shfl(cFirstD, srcLane);
         if(nTies > BAND_TIES) fail = 5;
         bool live = has && !fail;           // groups still serving an item
+        if(live && gl == 0 && nTies > 1) atomicAdd(&B.work_counter[WC_BAND_TIED], 1);       // (statistics: calls whose end cell was drawn among equal ones -- the tests want that path taken)
         int item = item0;
         int endPos = -1, nSteps = 0;
         bool first = true;

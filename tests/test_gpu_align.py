@@ -4,6 +4,8 @@ Bar: bit-exact for every integer / byte / index output (levels, edges, character
 iteration counts, Phred strings); log-likelihoods within 1e-12 relative (the terms come from host-built tables and are
 summed in the reference's order, so they are in practice bit-identical); posteriors within 1e-9 (device exp()).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -353,7 +355,7 @@ def test_band_kernel_and_its_fail_over_are_bit_exact(pkg, oracle, monkeypatch, e
     never depend on which kernel ran a call (extensionAligner.cpp:335-1556)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    tot_band = tot_failed = tot_calls = 0
+    tot_band = tot_failed = tot_calls = tot_tied = 0
     for name, wk, bk in BAND_WORLDS:
         w = synth.make_world(**wk)
         b = synth.make_batch(w, 400, **bk)
@@ -366,10 +368,13 @@ def test_band_kernel_and_its_fail_over_are_bit_exact(pkg, oracle, monkeypatch, e
         # (n_edges_touched also counts stage A's edges: the same number whichever kernels ran the DP calls)
         assert _BAND_EDGES.setdefault(name, int(st.n_edges_touched)) == int(st.n_edges_touched), name
         tot_band += st.n_dp_band; tot_failed += st.n_dp_band_failed; tot_calls += st.n_dp_calls
+        wc = (C.c_int * 72)(); ctx.lib.hlala_debug_work_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]; ctx.lib.hlala_debug_work_counters(ctx.h, gb.b, wc)
+        tot_tied += int(wc[68])               # band calls whose end cell was drawn among equal sequence-complete cells (rand_r + "x/z" string order, extensionAligner.cpp:1427-1472)
     if env.get("HLALA_DP_BAND") == "0":
         assert tot_band == 0
     else:
         assert tot_band > 0.25 * tot_calls                   # these worlds are mostly linear: the band kernel is what runs
+        assert tot_tied > 0                                  # ... and some of its calls drew their end cell among tied ones
         if env.get("HLALA_DP_BAND_RISKY"):
             assert tot_failed > 0.02 * tot_band              # the fail-over path is exercised ...
         elif not env:
