@@ -1429,6 +1429,21 @@ extern "C" int hlala_debug_work_counters(hlala_ctx* c, hlala_batch* b, int* out6
     return HLALA_OK;
 }
 
+// diagnostics (tools/tier_predict.py): the DP items of the batch's last extension stage ([2 * n_chains] records of 8 ints: item, read offset, read length, start offset,
+// start level, start node, class, linear run; item < 0: no call) and its retry lists ([16 * n_chains] slots of dp_items; counts in the work counters)
+extern "C" int hlala_debug_dp_items(hlala_ctx* c, hlala_batch* b, int* items_out, int* retry_out)
+{
+    DEV_GUARD(c);
+    ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
+    if(!c || !b) return HLALA_E_ARG;
+    if(!b->outputs_ready || !(b->staged & 2)) { c->err = "hlala_debug_dp_items before the extension stage"; return HLALA_E_STATE; }
+    const size_t nc = (size_t)b->B.n_chains;
+    if(items_out) HIP_TRY(c, hipMemcpyAsync(items_out, b->B.dp_items, 2 * nc * 32, hipMemcpyDeviceToHost, c->active));
+    if(retry_out) HIP_TRY(c, hipMemcpyAsync(retry_out, b->B.retry_list, 16 * nc * sizeof(int), hipMemcpyDeviceToHost, c->active));
+    HIP_TRY(c, hipStreamSynchronize(c->active));
+    return HLALA_OK;
+}
+
 extern "C" int hlala_kat_phred(hlala_ctx* c, int n, const double* p_correct, uint8_t* phred_out, const uint8_t* phred_in, double* p_out)
 {
     DEV_GUARD(c);
