@@ -300,7 +300,7 @@ def main():
                     bnd.readback(h)
                     if up is not None:
                         ahead.append(bnd.launch(up))
-            run_boundary(max(args.warmup, 1))          # (at least one: pool blocks, first touch of the page-locked buffers)
+            run_boundary(max(args.warmup, 3 if args.in_flight == 3 else 1))          # (at least one: pool blocks, first touch of the page-locked buffers; three with three sets of outputs live, so that the third set exists before the clock starts)
             g0 = n_gathers[0]
             bnd.host_s = {}; bnd.host_n = {}
             elapsed, per_rank = timed(run_boundary, args.steps)

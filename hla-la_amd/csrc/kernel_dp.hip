@@ -1213,7 +1213,10 @@ __device__ inline int dp_iterate(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGr
                     const u64 ka = keys[i], kb = keys[l];
                     if((ka > kb) == up) { const u64 pa = pay[i], pb = pay[l]; keys[i] = kb; keys[l] = ka; pay[i] = pb; pay[l] = pa; }
                 }
-                DSYNC();
+                // (in-memory class: the pairs being sorted sit in LDS unless the frontier is wider than the scratch -- a workgroup barrier orders them; the agent-scope
+                //  fences of DSYNC, an L2 write-back and an L1 invalidate per pass, 66 passes for 2 048 pairs, are for state in HBM)
+                if constexpr (C::IN_MEMORY) { if(Pn <= DP_SORT_SCRATCH) { if constexpr (GW > 64) blk_barrier(); else { WSYNC(); } } else DSYNC(); }
+                else DSYNC();
             }
         for(int i = gl; i < Pn; i += GW) {
             const u64 pv = pay[i];
