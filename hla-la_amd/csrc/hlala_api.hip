@@ -447,6 +447,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->broad_grid = cus * 3;         // three DpBroad blocks per CU (48 KB of LDS each), slabs of the large layout
 
     c->wide_grid = cus * 7;          // LDS: seven DpWide blocks per CU (22 KB each); slabs of the 64-lane layout
+    if(const char* e = getenv("HLALA_DP_WIDE_BLOCKS")) { const int w = atoi(e); if(w >= 1 && w <= 7) c->wide_grid = cus * w; }      // (experiment: the class runs on the side stream since round 5 -- how much LDS it may hold beside the main stream's kernels)
     c->stitch_grid = cus * 20;        // k_stitch_chains: five waves per SIMD (92 VGPRs, nothing spilled)
     if(const char* e = getenv("HLALA_STITCH_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 20) c->stitch_grid = cus * w; }      // (experiments: waves per CU and chains per wave and round of k_stitch_chains)
     if(const char* e = getenv("HLALA_STITCH_DRAW")) { const int d = atoi(e); if(d >= 1 && d <= 64) c->stitch_draw = d; }

@@ -378,7 +378,11 @@ template <int GW> __device__ __forceinline__ int guni(int v) { return GW >= 64 ?
 // served from the CU's L1
 template <class C> __device__ __forceinline__ void dp_sync()
 {
-    if constexpr (C::IN_MEMORY) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); if constexpr (C::GW > 64) __builtin_amdgcn_s_barrier(); else __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+    // (round 5: the RELEASE is workgroup-scope.  A DP call's state is written and read by the wavefronts of ONE block, i.e. one CU: its stores are through the CU's L1 and in the
+    //  XCD's L2 once they are counted done, which is all a reader on the same CU needs -- what it must not do is hit a stale L1 line of a word an L2 atomic changed, hence the
+    //  agent-scope ACQUIRE (L1 invalidate).  The agent-scope release this used to be is an L2 WRITE-BACK of the whole XCD's dirty lines, a dozen times per iteration of a call:
+    //  it slowed the class and every kernel beside it -- profiles/r05_experiments.txt 12, 13.)
+    if constexpr (C::IN_MEMORY) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if constexpr (C::GW > 64) __builtin_amdgcn_s_barrier(); else __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
     else if constexpr (C::GW > 64) blk_barrier();
     else { WSYNC(); }
 }
