@@ -76,7 +76,7 @@ struct DevBatch {
     int* order_hist;                // [order_nb + 1] bucket counts -> bucket starts -> scatter cursors
     int order_shift, order_nb;
     int* dp_blk;                    // [DPL_N * dp_nblk + 1] items per block of k_dp_items and list (band left / right, jump-free left / right, general left / right); after the scan: where they start
-    int* dp_list;                   // [2*n_chains] the six dense lists of the first DP classes: slots of dp_items in position order (k_dp_lists)
+    int* dp_list;                   // [2*n_chains] the ten dense lists of the first DP classes: slots of dp_items in position order (k_dp_lists)
     int dp_nblk;                    // blocks of k_dp_items
     int dp_band;                    // > 0: calls whose reach (read bases left + dp_band - 1 levels) stays inside a linear run of the graph go to the band kernel's lists (kernel_dp_band.hip); 0: HLALA_DP_BAND=0
     int dp_band_risky;              // tests (HLALA_DP_BAND_RISKY=1): a call is listed for the band kernel as soon as the linear run covers its read bases -- many then walk past it and exercise the fail-over

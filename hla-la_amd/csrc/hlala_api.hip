@@ -840,7 +840,7 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
         const u32 seed = c->params.rng_seed + 2u * b->first_chain;
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_head, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));       // -1: k_dp_items links the duplicates of a DP to it
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_next, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));
-        // items, then the four dense lists of the first classes (jump-free / general, left / right) in position order: counts per block, their scan, the slots
+        // items, then the ten dense lists of the first classes (three band lists, jump-free, general; left / right each) in position order: counts per block, their scan, the slots
         HIP_TRY(c, hipMemsetAsync(B.dp_blk, 0, ((size_t)DPL_N * B.dp_nblk + 1) * sizeof(int), c->active));
         hipLaunchKernelGGL(k_dp_items, dim3(B.dp_nblk), dim3(256), 0, c->active, c->dG, b->dB, items);
         int rc = check_launch(c, "k_dp_items"); if(rc) return rc;

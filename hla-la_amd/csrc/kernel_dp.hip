@@ -32,7 +32,7 @@
 // Scores are integers (the reference's doubles only ever hold integers, alignerBase.cpp:19-25).
 //
 // k_dp_items      : per chain, input checks of extendSeedChain and the DP items, one slot per chain in position order (kernel_order.hip); counts per block and list
-// k_dp_lists      : the four dense item lists of the first class (jump-free / general x left / right) from the scanned counts
+// k_dp_lists      : the ten dense item lists of the first class (band x 3, jump-free, general; left / right each) from the scanned counts
 // k_dp<C, TIER>   : the DP classes above (the first one in two instantiations: DpTinyJF for calls that meet no gap-path jump, DpTiny for the rest); extension
 //                   columns go straight into the chain's output row
 // k_stitch_chains : extendWithOtherSeedChain / extendToFullSequenceLength (verboseSeedChain.cpp:23-136) and
@@ -1585,7 +1585,7 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
         if(needL) { sl[0] = make_int4(itL.item, itL.rOff, itL.seqLen, itL.start_seq); sl[1] = make_int4(itL.startLevel, itL.startNode, clsL, runL); } else sl[0] = make_int4(-1, 0, 0, 0);
         if(needR) { sr[0] = make_int4(itR.item, itR.rOff, itR.seqLen, itR.start_seq); sr[1] = make_int4(itR.startLevel, itR.startNode, clsR, runR); } else sr[0] = make_int4(-1, 0, 0, 0);
     }
-    // ---- how many items of each of the six lists (band left / right, jump-free left / right, general left / right) this block holds: k_order_scan turns the counts of all
+    // ---- how many items of each of the ten lists (three band lists, jump-free, general; left / right each) this block holds: k_order_scan turns the counts of all
     // blocks into the blocks' places in the dense lists, k_dp_lists writes the slot numbers there -- in position order, nothing is left to the atomics.
     // work_counter[8] / [9]: left / right DP calls of the batch, [6]: the jump-free ones among them, [WC_BAND_CALLS]: the band ones (statistics)
     __shared__ int blkCnt[DPL_N];
@@ -1612,7 +1612,7 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
     if(threadIdx.x < DPL_N) B.dp_blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = blkCnt[threadIdx.x];
 }
 
-// The six dense item lists of the first DP classes: list k (DPL_BAND / DPL_JF / DPL_GEN, + 1 for the right extensions) occupies
+// The ten dense item lists of the first DP classes: list k (DPL_BAND16 / DPL_BAND32 / DPL_BAND64 / DPL_JF / DPL_GEN, + 1 for the right extensions) occupies
 // dp_list[dp_blk[k * nBlk] .. dp_blk[(k + 1) * nBlk]) -- dp_blk after its exclusive scan: entry k * nBlk + b = where block b's items of list k start --, its
 // entries are the slots of k_dp_items' item arrays in position order.  Same grid as k_dp_items.
 __global__ void k_dp_lists(const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items)
