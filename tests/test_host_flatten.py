@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def hostlib(pkg):
-    so = os.path.join(ROOT, "hla-la_amd", "libhlala_host.so")
+    so = os.environ.get("HLALA_HOST_LIB") or os.path.join(ROOT, "hla-la_amd", "libhlala_host.so")       # (tools/asan_host.sh points it at the sanitizer build)
     if not os.path.exists(so):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "hla-la_amd", "csrc"), "../libhlala_host.so"])
