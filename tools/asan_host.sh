@@ -10,6 +10,6 @@ ASAN_LIB=$(g++ -print-file-name=libasan.so)
 # (libstdc++ is preloaded too: the sanitizer resolves __cxa_throw at start-up, before Python loads the library that throws)
 STDCXX=$(g++ -print-file-name=libstdc++.so)
 LD_PRELOAD="$ASAN_LIB $STDCXX" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 HLALA_LIB_PATH=/tmp/libhlala_host_asan.so HLALA_HOST_LIB=/tmp/libhlala_host_asan.so \
-    python -m pytest tests/test_host_flatten.py -k "flatten or linear" -x -q -m "not gpu"       # (the graph flatten incl. the linear steps and the device's jump tables; the ABI tests need the GPU library)
+    python -m pytest tests/test_host_flatten.py -k "matches_oracle or linear_steps or rejects_bad" -x -q -m "not gpu"       # (the graph flatten incl. the linear steps and the device's jump tables; the ABI tests need the GPU library)
 LD_PRELOAD="$ASAN_LIB $STDCXX" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 HLALA_LIB_PATH=/tmp/libhlala_host_asan.so \
     python -m pytest tests/test_parsers_robust.py tests/test_typer_files.py tests/test_filters.py tests/test_bam.py tests/test_bam_scale.py tests/test_graph_files.py -x -q -m "not gpu" "$@"
