@@ -136,3 +136,37 @@ def test_densest_pairs_go_through_the_in_memory_class(pkg, oracle):
         assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3])
         gs.close()
     assert n_mem >= 3, n_mem
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_which_kernel_ran_a_dp_call_at_scale(pkg, monkeypatch):
+    """An oracle-free cross-check at size: 262 144 pairs on a 5 M-level Graph M world -- 0.95 M DP calls, 0.39 M of them in the band kernels -- aligned three times: with the
+    default build, with the band kernels switched off (every call in the hashed-frontier classes, extensionAligner.cpp:335-1556 as kernel_dp.hip runs it) and with the one-edge gap
+    paths kept in the device's jump tables (flat_graph.hpp).  Every pair record, every column of every selected alignment, the per-position qualities and the work counters
+    (DP calls, iterations, candidate cells, edges) are identical; the log likelihoods are bit-identical too (the same terms in the same order)."""
+    w = synth.make_world_m(seed=2, n_levels=5_000_000)
+    b = synth.make_batch_m(w, 262144, seed=4242, frac_gene=0.3)
+    kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=2024, max_columns=384)
+    results = []
+    for env in (dict(), dict(HLALA_DP_BAND="0"), dict(HLALA_UNIT_JUMPS="1")):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            ctx = pkg.Context(w["graph"], w["contigs"], **kw)
+        gb = ctx.batch(b); gb.align()
+        st = gb.stats()
+        assert st.n_errors == 0
+        pk = gb.pairs_packed(); sc = gb.pairs_scalars()
+        results.append((env, st, {k: np.array(v, copy=True) for k, v in pk.items() if isinstance(v, np.ndarray)}, {k: np.array(v, copy=True) for k, v in sc.items() if isinstance(v, np.ndarray)}))
+        gb.close(); ctx.close()
+    (_, st0, pk0, sc0) = results[0]
+    assert st0.n_dp_band > 0.3 * st0.n_dp_calls and st0.n_dp_band_failed == 0
+    assert results[1][1].n_dp_band == 0
+    for env, st, pk, sc in results[1:]:
+        assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells, st.n_edges_touched, st.n_chains_extended, st.n_out_columns) == \
+               (st0.n_dp_calls, st0.n_dp_iterations, st0.n_dp_cells, st0.n_edges_touched, st0.n_chains_extended, st0.n_out_columns), env
+        assert pk.keys() == pk0.keys() and sc.keys() == sc0.keys()
+        for k in pk0:
+            assert np.array_equal(pk[k], pk0[k]), (env, k)
+        for k in sc0:
+            assert np.array_equal(sc[k], sc0[k]), (env, k)
