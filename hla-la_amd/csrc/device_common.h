@@ -31,7 +31,7 @@ struct DevGraph {
     const int* jb_off; const int* jb_node; const int* jb_path; const int* jb_lvl;
     const uint8_t* out_prank; const uint8_t* in_prank; const uint8_t* jf_prank; const uint8_t* jb_prank;   // rank among the node's earlier entries to the same target (flat_graph.hpp)
     const uint8_t* jfree_out; const uint8_t* jfree_in;   // [L] levels without a gap-path jump from this level on, in either direction (flat_graph.hpp)
-    const uint8_t* lin_label; const uint8_t* lin_out; const uint8_t* lin_in; const int* lin_eid;   // [L] linear steps and their run lengths (flat_graph.hpp; kernel_dp_band.hip)
+    const u32* lin_label; const uint8_t* lin_out; const uint8_t* lin_in; const int* lin_eid;   // [L] linear steps and their run lengths (flat_graph.hpp; kernel_dp_band.hip)
     const int4* nrec_out;      // [2*N] 32-byte node records of the extension DP (flat_graph.hpp)
     const int4* nrec_in;
     const int* path_len;       // [P]

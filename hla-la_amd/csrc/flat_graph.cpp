@@ -287,16 +287,22 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
             for(int32_t l = F.L - 1; l >= 0; l--) { run = hasF[(size_t)l] ? 0 : std::min(255, run + 1); F.jfree_out[(size_t)l] = (uint8_t)run; }
             run = 255;
             for(int32_t l = 0; l < F.L; l++) { run = hasB[(size_t)l] ? 0 : std::min(255, run + 1); F.jfree_in[(size_t)l] = (uint8_t)run; }
-            // ---- linear steps (flat_graph.hpp): one node on either side, one edge between them, a real label, no gap-path jump along the step
+            // ---- linear steps (flat_graph.hpp): one node on either side, one to four parallel edges between them, real labels, no gap-path jump along the step
             F.lin_label.assign((size_t)F.L, 0); F.lin_eid.assign((size_t)F.L, -1); F.lin_out.assign((size_t)F.L, 0); F.lin_in.assign((size_t)F.L, 0);
             for(int32_t l = 0; l + 1 < F.L; l++) {
                 const int32_t n = F.level_off[l];
                 if(F.level_off[l + 1] - n != 1 || F.level_off[l + 2] - F.level_off[l + 1] != 1) continue;
-                if(F.out_off[n + 1] - F.out_off[n] != 1 || F.in_off[n + 2] - F.in_off[n + 1] != 1) continue;
-                const int32_t e = F.out_off[n];
-                if(F.out_to[e] != n + 1 || F.out_label[e] == '_' || F.out_label[e] == 0) continue;
+                const int32_t e0 = F.out_off[n], K = F.out_off[n + 1] - e0, i0 = F.in_off[n + 1];
+                if(K < 1 || K > 4 || F.in_off[n + 2] - i0 != K) continue;
                 if(hasF[(size_t)l] || hasB[(size_t)l + 1]) continue;
-                F.lin_label[(size_t)l] = F.out_label[e]; F.lin_eid[(size_t)l] = F.out_eid[e];
+                uint32_t w = 0; bool ok = true;
+                for(int32_t k = 0; k < K && ok; k++) {
+                    // the same edges in the same order from either end: a backward call visits them through the in-CSR of the upper node
+                    ok = F.out_to[e0 + k] == n + 1 && F.out_label[e0 + k] != '_' && F.out_label[e0 + k] != 0 && F.in_eid[i0 + k] == F.out_eid[e0 + k];
+                    w |= (uint32_t)F.out_label[e0 + k] << (8 * k);
+                }
+                if(!ok) continue;
+                F.lin_label[(size_t)l] = w; F.lin_eid[(size_t)l] = F.out_eid[e0];
             }
             run = 0;
             for(int32_t l = F.L - 1; l >= 0; l--) { run = F.lin_label[(size_t)l] ? std::min(255, run + 1) : 0; F.lin_out[(size_t)l] = (uint8_t)run; }

@@ -64,12 +64,14 @@ struct FlatGraph {
     // at 255.  An extension DP that starts at level l and can reach at most r levels is known to meet no jump when jfree > r: such calls run in the
     // instantiation of the 16-lane class that is compiled without the early-cell machinery (kernel_dp.hip: DpTinyJF; a call that meets one anyway is re-run).
     std::vector<uint8_t> jfree_out, jfree_in;    // [L]
-    // LINEAR steps (round 5, kernel_dp_band.hip): lin_label[l] = label of the ONLY edge between levels l and l + 1 when both levels hold exactly one node, the
-    // label is not '_' and neither end has a gap-path jump along it; 0 otherwise.  lin_eid[l] = creation index of that edge (-1: none).  lin_out[l] = number of
+    // LINEAR steps (round 5, kernel_dp_band.hip): a step l -> l + 1 is linear when both levels hold exactly one node, one to four PARALLEL edges join them (the
+    // SNPs of a merged backbone are such edges), no label is '_' and neither end has a gap-path jump along it.  lin_label[l] = the labels of those edges in CSR
+    // (= creation) order, one per byte from the low byte up (0: not linear); lin_eid[l] = creation index of the first (-1: none).  lin_out[l] = number of
     // consecutive linear steps l -> l + 1, l + 1 -> l + 2, ...; lin_in[l] = steps l -> l - 1, l - 1 -> l - 2, ... (capped at 255).  Inside such a run the node rank
     // z is 0 everywhere, the frontier of an extension DP is a plain band of cells (level, read offset) and no cell is ever met twice: calls whose reach stays
     // inside a run take the register-resident anti-diagonal kernel instead of the hashed-frontier machine.
-    std::vector<uint8_t> lin_label, lin_out, lin_in;   // [L]
+    std::vector<uint32_t> lin_label;                   // [L]
+    std::vector<uint8_t> lin_out, lin_in;              // [L]
     std::vector<int32_t> lin_eid;                      // [L]
     std::vector<uint8_t> gap_stretch;            // [L-1]
     // level -> (sequence id, position) CSR, entries sorted by sequence id

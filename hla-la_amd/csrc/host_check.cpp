@@ -45,9 +45,9 @@ int hlala_host_jumps(const hlala::FlatGraph* F, int node, int forward, int cap, 
     return off[n + 1] - off[n];
 }
 // linear steps and their run lengths (flat_graph.hpp; kernel_dp_band.hip), [L] each
-int hlala_host_linear(const hlala::FlatGraph* F, uint8_t* lin_label, int32_t* lin_eid, uint8_t* lin_out, uint8_t* lin_in)
+int hlala_host_linear(const hlala::FlatGraph* F, uint32_t* lin_label, int32_t* lin_eid, uint8_t* lin_out, uint8_t* lin_in)
 {
-    memcpy(lin_label, F->lin_label.data(), F->lin_label.size()); memcpy(lin_eid, F->lin_eid.data(), F->lin_eid.size() * 4);
+    memcpy(lin_label, F->lin_label.data(), F->lin_label.size() * 4); memcpy(lin_eid, F->lin_eid.data(), F->lin_eid.size() * 4);
     memcpy(lin_out, F->lin_out.data(), F->lin_out.size()); memcpy(lin_in, F->lin_in.data(), F->lin_in.size());
     return 0;
 }

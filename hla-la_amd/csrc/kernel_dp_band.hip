@@ -43,7 +43,7 @@ struct __align__(16) BandLds {
     u32 bt[C::MAXD / 8][C::GW];           // back pointers: 4 bits per (iteration, lane)
     unsigned short steps[C::MAXD];        // steps of the chosen path: kind | i << 2 | j << 9
     unsigned short tieD[BAND_TIES];       // iterations of the sequence-complete cells that equal the best one (entry 0 lives in a register)
-    unsigned char ls[C::REACH];           // ls[t] = label of the t-th step away from the start level (lin_label)
+    u32 ls[C::REACH];                     // ls[t] = labels of the (one to four parallel) edges of the t-th step away from the start level (lin_label)
 };
 
 // the value lane l - 1 of the call's group holds (DP_NEG for its first lane)
@@ -63,7 +63,7 @@ template <int GW> __device__ __forceinline__ int band_prev(int v, int gl)
 
 template <class C, bool FWD>
 __device__ __forceinline__ void band_pass(const DevGraph& G, const DevBatch& B, const DpItem* __restrict__ items, const u32 rng_seed, const uint8_t* __restrict__ readBases,
-                                          const uint8_t* __restrict__ linLabel, const int* __restrict__ linEid, BandLds<C>& S,
+                                          const u32* __restrict__ linLabel, const int* __restrict__ linEid, BandLds<C>& S,
                                           u64& accCalls, u64& accIters, u64& accCells, u64& accEdges)
 {
     constexpr int GW = C::GW, NG = 64 / GW;
@@ -106,6 +106,7 @@ __device__ __forceinline__ void band_pass(const DevGraph& G, const DevBatch& B, 
             for(int t = gl; t < reach; t += GW) S.ls[t] = linLabel[FWD ? x0 + t : x0 - 1 - t];
             if(gl >= 1 && gl <= jmax) myRc = readBases[rOff + (FWD ? y0 + gl - 1 : y0 - gl)];
         }
+        const u32 rcRep = (u32)myRc * 0x01010101u;
         WSYNC();
         BAND_T(0);
 
@@ -128,7 +129,11 @@ __device__ __forceinline__ void band_pass(const DevGraph& G, const DevBatch& B, 
             }
             if(__ballot(running) == 0) break;
             const int i = d - gl;
-            const int m = (S.ls[min(max(i - 1, 0), C::REACH - 1)] == (unsigned char)myRc) ? 2 : -5;                  // :582-590
+            // the step's parallel edges push their D candidates in CSR order (:565-607): the first maximum is +2 through the first edge whose label is the
+            // read base, else -5 through the first edge -- "some byte of the word equals the base" decides the score, the edge is looked up at the backtrace
+            const u32 lw = S.ls[min(max(i - 1, 0), C::REACH - 1)], lx = lw ^ rcRep;
+            const int m = ((lx - 0x01010101u) & ~lx & 0x80808080u) ? 2 : -5;                                      // :582-590
+            const int nPar = 4 - (__clz((int)lw) >> 3);                                                           // edges of the step (0 when it is not staged)
             const int Dd = band_prev<GW>(D2, gl), Dg = band_prev<GW>(D1, gl), Gg = band_prev<GW>(G1, gl);         // the cell one read base back: two / one iteration ago
             const int Ds = D1, Ss = S1;                                                                           // the cell one level back, one iteration ago
             const int cD = Dd + m;
@@ -147,7 +152,7 @@ __device__ __forceinline__ void band_pass(const DevGraph& G, const DevBatch& B, 
             if(running) {
                 itersRun = d;
                 cellsAcc += exists ? 1 : 0;                                                                       // :492
-                edgesAcc += ((Dd > BAND_ABSENT && inRead) ? 1 : 0) + ((Ds > BAND_ABSENT) ? 1 : 0);                 // :428, :459
+                edgesAcc += ((Dd > BAND_ABSENT && inRead) ? nPar : 0) + ((Ds > BAND_ABSENT) ? nPar : 0);           // :428, :459: every edge of a source cell counts
                 if(mk != 0) {                                                                                     // :1043-1062
                     if(mx >= curMax) lastInc = d;
                     if(mx > curMax) { curMax = mx; firstPos = (d << 6) | (FWD ? (mk & 63) : GW - 1 - (mk & 63)); }
@@ -253,9 +258,17 @@ __device__ __forceinline__ void band_pass(const DevGraph& G, const DevBatch& B, 
                             const int st = S.steps[s]; const int kind = st & 3, i_ = (st >> 2) & 127, j_ = st >> 9;
                             const int lvl = FWD ? x0 + i_ - 1 : x0 - i_;
                             const int at = FWD ? nCols - 1 - s : s;                        // forward traces are reversed at the end, :1319-1326
-                            const unsigned char sc = j_ > 0 ? readBases[rOff + (FWD ? y0 + j_ - 1 : y0 - j_)] : (unsigned char)0, gc = S.ls[i_ > 0 ? i_ - 1 : 0];
+                            const unsigned char sc = j_ > 0 ? readBases[rOff + (FWD ? y0 + j_ - 1 : y0 - j_)] : (unsigned char)0;
+                            const u32 lw = S.ls[i_ > 0 ? i_ - 1 : 0];
+                            // the edge of the step: a diagonal step took the first edge that carries the read base (else the first), a sequence gap the first --
+                            // its open / extend candidates are equal over the parallel edges and the first of equal candidates wins (:664-754, Utilities.cpp:379-406)
+                            int par = 0;
+                            if(kind == K_DIAG) { if(((lw >> 8) & 255u) == sc) par = 1; if(((lw >> 16) & 255u) == sc && par == 0) par = 2; if((lw >> 24) == sc && par == 0) par = 3; if((lw & 255u) == sc) par = 0; }
                             if(kind == K_GGAP) { oL[at] = -1; oE[at] = -1; oG[at] = '_'; oS[at] = sc; }
-                            else { oL[at] = lvl; oE[at] = linEid[lvl]; oG[at] = gc; oS[at] = (kind == K_DIAG) ? sc : (unsigned char)'_'; }
+                            else {
+                                oL[at] = lvl; oE[at] = par == 0 ? linEid[lvl] : G.out_eid[G.out_off[G.level_off[lvl]] + par];
+                                oG[at] = (unsigned char)((lw >> (8 * par)) & 255u); oS[at] = (kind == K_DIAG) ? sc : (unsigned char)'_';
+                            }
                         }
                     }
                 }
@@ -292,7 +305,7 @@ __device__ __forceinline__ void band_pass(const DevGraph& G, const DevBatch& B, 
 
 template <int GW>
 __global__ __launch_bounds__(64, BandCfg<GW>::WAVES) void k_dp_band(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items, const u32 rng_seed,
-                                                                    const uint8_t* __restrict__ readBases, const uint8_t* __restrict__ linLabel, const int* __restrict__ linEid)
+                                                                    const uint8_t* __restrict__ readBases, const u32* __restrict__ linLabel, const int* __restrict__ linEid)
 {
     typedef BandCfg<GW> C;
     const DevGraph& G = *Gp;

@@ -338,7 +338,10 @@ def test_lane_per_dp_class_is_bit_exact(pkg, oracle, monkeypatch):
 BAND_WORLDS = [("simple k1", dict(seed=31, G=9000, k=1), dict(seed=41)),
                ("identical haplotypes: all linear", dict(seed=32, G=6000, k=0, n_mut=0, n_largegap=0), dict(seed=42, indel_read_frac=0.3)),
                ("long clips", dict(seed=33, G=12000, k=2, mut_density=0.004), dict(seed=43, clip_max=48, p_no_clip=0.0)),
-               ("low qualities, many indels", dict(seed=34, G=8000, k=1, mut_density=0.01), dict(seed=44, indel_read_frac=0.5, qual_hi=12))]
+               ("low qualities, many indels", dict(seed=34, G=8000, k=1, mut_density=0.01), dict(seed=44, indel_read_frac=0.5, qual_hi=12)),
+               # k = 0 merges the haplotypes at every level: their SNPs are PARALLEL edges between single nodes, which a linear step may carry (flat_graph.hpp)
+               ("k0: SNPs are parallel edges", dict(seed=35, G=8000, k=0, mut_density=0.01), dict(seed=45, indel_read_frac=0.2)),
+               ("k0, dense SNPs, long clips", dict(seed=36, G=8000, k=0, mut_density=0.03), dict(seed=46, clip_max=40, p_no_clip=0.2))]
 
 
 _BAND_EDGES = {}

@@ -64,8 +64,8 @@ def test_flatten_matches_oracle(pkg, oracle, hostlib, seed, G, k):
 @pytest.mark.parametrize("kind", ["simple", "k0-identical", "graph_m"])
 def test_linear_steps_and_run_lengths(pkg, hostlib, kind):
     """FlatGraph::lin_label / lin_eid / lin_out / lin_in (what decides which DP calls the band kernel takes) against a definition written down independently
-    in numpy: a step l -> l + 1 is linear when both levels hold one node, exactly one edge joins them, its label is not '_' and no gap-path jump leaves or
-    enters along it; the run lengths count consecutive linear steps ahead / behind, capped at 255."""
+    in numpy: a step l -> l + 1 is linear when both levels hold one node, one to four parallel edges join them, no label is '_' and no gap-path jump leaves or
+    enters along it; lin_label packs the labels in creation order, one per byte; the run lengths count consecutive linear steps ahead / behind, capped at 255."""
     if kind == "simple":
         w = synth.make_world(seed=7, G=6000, k=2)
     elif kind == "k0-identical":
@@ -77,18 +77,26 @@ def test_linear_steps_and_run_lengths(pkg, hostlib, kind):
     F = hostlib.hlala_host_flatten(C.byref(g), C.byref(c))
     assert F, hostlib.hlala_host_last_error()
     L = gd["n_levels"]
-    lab = np.zeros(L, np.uint8); eid = np.zeros(L, np.int32); lo = np.zeros(L, np.uint8); li = np.zeros(L, np.uint8)
-    hostlib.hlala_host_linear.argtypes = [C.c_void_p, pkg.c_u8p, pkg.c_i32p, pkg.c_u8p, pkg.c_u8p]
-    hostlib.hlala_host_linear(F, lab.ctypes.data_as(pkg.c_u8p), eid.ctypes.data_as(pkg.c_i32p), lo.ctypes.data_as(pkg.c_u8p), li.ctypes.data_as(pkg.c_u8p))
+    lab = np.zeros(L, np.uint32); eid = np.zeros(L, np.int32); lo = np.zeros(L, np.uint8); li = np.zeros(L, np.uint8)
+    c_u32p = C.POINTER(C.c_uint32)
+    hostlib.hlala_host_linear.argtypes = [C.c_void_p, c_u32p, pkg.c_i32p, pkg.c_u8p, pkg.c_u8p]
+    hostlib.hlala_host_linear(F, lab.ctypes.data_as(c_u32p), eid.ctypes.data_as(pkg.c_i32p), lo.ctypes.data_as(pkg.c_u8p), li.ctypes.data_as(pkg.c_u8p))
     nl = gd["node_level"]; ef = gd["edge_from"]; el = gd["edge_label"]
     npl = np.bincount(nl, minlength=L); elv = nl[ef]; epl = np.bincount(elv, minlength=L)
-    # levels with a '_' edge start or carry gap paths; a single non-gap edge out of a single node has none (checked against the jump tables below)
-    exp_lab = np.zeros(L, np.uint8); exp_eid = np.full(L, -1, np.int32)
-    first = np.zeros(L, np.int64); first[elv] = np.arange(len(ef))
-    one = np.zeros(L, bool); one[:-1] = (npl[:-1] == 1) & (npl[1:] == 1) & (epl[:-1] == 1)
-    one &= el[first] != ord('_')
-    exp_lab[one] = el[first[one]]; exp_eid[one] = first[one]
+    gapl = np.bincount(elv, weights=(el == ord('_')), minlength=L) > 0
+    # levels with a '_' edge start or carry gap paths; non-gap edges out of a single node have none (checked against the jump tables below)
+    one = np.zeros(L, bool); one[:-1] = (npl[:-1] == 1) & (npl[1:] == 1) & (epl[:-1] >= 1) & (epl[:-1] <= 4)
+    one &= ~gapl
+    exp_lab = np.zeros(L, np.uint32); exp_eid = np.full(L, -1, np.int32)
+    order = np.argsort(elv, kind="stable")                      # edges by level, creation order inside a level
+    start = np.concatenate([[0], np.cumsum(epl)])
+    for k in range(4):
+        has = one & (epl > k)
+        exp_lab[has] |= el[order[start[:-1][has] + k]].astype(np.uint32) << (8 * k)
+    exp_eid[one] = order[start[:-1][one]]
     assert np.array_equal(lab, exp_lab) and np.array_equal(eid, exp_eid)
+    if kind == "graph_m":
+        assert (one & (epl > 1)).sum() > 50          # (the SNPs of the merged backbone are parallel edges between single nodes)
     # no gap-path jump at either end of a linear step
     gi = pkg.GraphInfo(); hostlib.hlala_host_info(F, C.byref(gi))
     if gi.n_paths:
