@@ -336,6 +336,18 @@ def main():
         if len(gbs) > 1 and n > 0 and not args.no_overlap:
             finish((n - 1) % len(gbs))
 
+    def device_memory(batch):
+        """bytes of one batch's device blocks and of the whole context (hlala_debug_memory), chains with column rows"""
+        import ctypes as C_
+        out = (C_.c_ulonglong * 4)()
+        try:
+            ctx.lib.hlala_debug_memory.argtypes = [C_.c_void_p, C_.c_void_p, C_.POINTER(C_.c_ulonglong)]
+            ctx.lib.hlala_debug_memory(ctx.h, batch.b, out)
+        except AttributeError:
+            return None
+        return {"batch_bytes": int(out[0]), "chains": int(bsrc[0]["n_chains"]), "chains_with_column_rows": int(out[1]), "context_bytes_with_two_resident_batches": int(out[3]),
+                "what": "device blocks of one aligned 1 M-pair batch (inputs + outputs); column rows exist for the chains that passed the filters (batch.h: chain_row)"}
+
     rsteps = args.steps if args.resident_only else args.resident_steps
     resident = None
     if rsteps > 0:
@@ -421,7 +433,7 @@ def main():
                        "columns_per_chain": cols_pc, "mean_out_degree": e_mean,
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
                        "pairs_ok": int(oks[0]), "pairs_ok_per_rank": [int(x) for x in oks], "chain_errors": int(st.n_errors),
-                       "resident": resident,
+                       "resident": resident, "device_memory": device_memory(gbs[0]),
                        "stage_ms": {"project": st.ms_project, "extend": st.ms_extend, "pair": st.ms_pair, "side_stream": st.ms_side,
                                     "dp_16lane": cls_ms[0], "dp_32lane": cls_ms[1], "dp_64lane": cls_ms[2], "dp_wide": cls_ms[3], "dp_broad": cls_ms[4], "dp_large": cls_ms[5], "dp_in_memory": cls_ms[6],
                                     "dp_16lane_jump_free_part": ms_jf, "dp_16lane_general_part": ms_gen, "dp_band": ms_band},

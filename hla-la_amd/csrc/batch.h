@@ -28,7 +28,7 @@ struct DevBatch {
     int* seed_begin;
     int* seed_end;
     int* seed_removed;
-    int* seed_level;                // [n_chains*stride]
+    int* seed_level;                // [n_rows*stride]: the column rows of a chain start at row_base(B, chain)
     int* seed_edge;
     uint8_t* seed_g;
     uint8_t* seed_s;
@@ -46,7 +46,7 @@ struct DevBatch {
     int* dp_err;                    // [2*n_chains] 0, kernel line of a capacity failure, or -1000000 - columns
     int* dp_alias_head;             // [2*n_chains] items whose DP starts from the same cell of the same read as this item's: head of the list (-1: none)
     int* dp_alias_next;             // [2*n_chains] ... next entry of the list an item is on
-    int* ext_level;                 // [n_chains*stride]
+    int* ext_level;                 // [n_rows*stride]
     int* ext_edge;
     uint8_t* ext_g;
     uint8_t* ext_s;
@@ -75,6 +75,12 @@ struct DevBatch {
     int* chain_bucket;              // [n_chains] position bucket = first level >> order_shift (the last bucket: chains filtered out)
     int* order_hist;                // [order_nb + 1] bucket counts -> bucket starts -> scatter cursors
     int order_shift, order_nb;
+    // ---- column rows only for the chains that passed the filters (round 5): two thirds of a batch's chains end at k_filter_chains (strand, duplicate coordinates,
+    //      processBAM.cpp:3200-3240) and never hold a column.  The filter and the position order run when the batch is CREATED (they read inputs only), the count of the
+    //      ordered chains comes back with the upload's synchronisation, and the column arrays (seed_* / ext_*: 20 bytes per column slot) are sized by it: row k belongs to
+    //      chain_order[k] -- rows are in position order -- and chain_row is the inverse (-1: no row).  null: row = chain number (batches made from seeds, no position order).
+    int* chain_row;                 // [n_chains]
+    int n_rows;
     int* dp_blk;                    // [DPL_N * dp_nblk + 1] items per block of k_dp_items and list (band left / right, jump-free left / right, general left / right); after the scan: where they start
     int* dp_list;                   // [2*n_chains] the ten dense lists of the first DP classes: slots of dp_items in position order (k_dp_lists)
     int dp_nblk;                    // blocks of k_dp_items
@@ -88,6 +94,9 @@ struct DevBatch {
 // number of entries of B.chain_order: the chains that passed the filters (k_filter_chains); without a position order every chain is listed.
 // (order_hist[order_nb - 1] is the start of a bucket nothing is put into = the end of the last real bucket, before and after the scatter)
 __device__ __forceinline__ int ordered_chains(const DevBatch& B) { return B.chain_order ? __builtin_amdgcn_readfirstlane(B.order_hist[B.order_nb - 1]) : B.n_chains; }
+
+// first column slot of a chain's rows in seed_* / ext_* (only chains that passed the filters have rows: callers look at the chain's status first)
+__device__ __forceinline__ size_t row_base(const DevBatch& B, int c) { return (size_t)(B.chain_row ? B.chain_row[c] : c) * (size_t)B.stride; }
 
 // ---- the first DP classes' dense item lists (k_dp_items / k_dp_lists): list k occupies dp_list[dp_blk[k * dp_nblk] .. dp_blk[(k + 1) * dp_nblk]); k + 1: the right extensions
 enum { DPL_BAND16 = 0, DPL_BAND32 = 2, DPL_BAND64 = 4, DPL_JF = 6, DPL_GEN = 8, DPL_N = 10 };

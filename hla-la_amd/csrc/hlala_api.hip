@@ -69,7 +69,10 @@ struct hlala_ctx {
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     int jf_margin = 16;      // (measured 4 / 8 / 16 / 48: 16-lane + 32-lane class 105.6 / 104.1 / 103.4 / 104.1 ms -- a tight bound sends more calls to the cheap instantiation and more of them on to the 32-lane class) levels beyond the read bases left that a jump-free call is taken to reach (kernel_dp.hip: k_dp_items)
+    int stitch_by_row = 1;     // k_stitch_chains draws column rows (position order, only chains that hold one) instead of chain numbers (HLALA_STITCH_BY_ROW=0; 6.9 -> 6.65 ms)
     int stitch_draw = 12;      // chains per draw of k_stitch_chains (8: 9.1 ms per million pairs, the rate of the draws themselves; 12 / 16: 6.7 / 6.6 ms; 64: 15 ms -- kernel_dp.hip)
+    bool side_after_pair = false; // HLALA_SIDE_AFTER_PAIR=1: the side-stream classes are queued behind the main stream's stitch and pairing passes instead of beside them (measured: the pairing pass 20.9 -> 4.1 ms, but the next batch's projection 35.5 -> 54.8 ms beside the wide class instead; step 183.4 -> 185.5 ms)
+    bool rows_all = false;        // HLALA_ROWS_ALL=1: column rows for every chain of a batch, the filters run with the projection (rounds 1-4)
     bool band_risky = false;      // HLALA_DP_BAND_RISKY=1 (tests: force fail-overs of the band kernel)
     int band_grid = 0, band_margin = 8;      // the band kernel in front of the 16-lane class (kernel_dp_band.hip): blocks (0: HLALA_DP_BAND=0) and the levels beyond the read bases left a call is taken to reach (HLALA_DP_BAND_MARGIN)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
@@ -95,6 +98,8 @@ struct hlala_batch {
     DevBatch* dB = nullptr;       // device copy of B
     std::vector<void*> allocs;
     int staged = 0;   // bit0 seeds available, bit1 extended, bit2 paired
+    bool prepared = false;           // the filters and the position order ran when the batch was created; B.n_rows = chains that hold column rows (batch.h: chain_row)
+    int n_rows_host = 0;             // ... read back with the upload's synchronisation
     bool outputs_ready = false;      // the output arrays (50 GB for a 1 M-pair batch) exist: allocated by the first stage call, not by hlala_batch_create (ensure_outputs)
     bool side_used = false;      // the last extend of this batch ran its wide classes on the side stream (their times are between the evSide events)
     bool side_pending = false;   // ... and hlala_pair_chains has yet to enqueue the second pairing pass behind them
@@ -437,6 +442,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->band_grid = cus * 24;          // a few KB of LDS per block, six waves per SIMD (80 VGPRs)
     if(const char* e = getenv("HLALA_DP_BAND")) { if(atoi(e) == 0) c->band_grid = 0; }      // (A/B and parity: every call in the hashed-frontier classes)
     if(const char* e = getenv("HLALA_DP_BAND_RISKY")) c->band_risky = atoi(e) != 0;
+    if(const char* e = getenv("HLALA_ROWS_ALL")) c->rows_all = atoi(e) != 0;
+    if(const char* e = getenv("HLALA_SIDE_AFTER_PAIR")) c->side_after_pair = atoi(e) != 0;
     if(const char* e = getenv("HLALA_DP_BAND_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 24) c->band_margin = m; }
     if(const char* e = getenv("HLALA_DP_BAND_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 32 && c->band_grid) c->band_grid = cus * w; }
     if(const char* e = getenv("HLALA_DP_JF")) { if(atoi(e) == 0) c->jf_grid = 0; }      // (A/B: every call in the general instantiation -- the kernels' lists are built either way)
@@ -450,6 +457,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_DP_WIDE_BLOCKS")) { const int w = atoi(e); if(w >= 1 && w <= 7) c->wide_grid = cus * w; }      // (experiment: the class runs on the side stream since round 5 -- how much LDS it may hold beside the main stream's kernels)
     c->stitch_grid = cus * 20;        // k_stitch_chains: five waves per SIMD (92 VGPRs, nothing spilled)
     if(const char* e = getenv("HLALA_STITCH_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 20) c->stitch_grid = cus * w; }      // (experiments: waves per CU and chains per wave and round of k_stitch_chains)
+    if(const char* e = getenv("HLALA_STITCH_BY_ROW")) c->stitch_by_row = atoi(e) != 0;
     if(const char* e = getenv("HLALA_STITCH_DRAW")) { const int d = atoi(e); if(d >= 1 && d <= 64) c->stitch_draw = d; }
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpWide>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpWide>();
     c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / three blocks per CU: a few MB each
@@ -470,6 +478,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     // k_project_chains<384 columns>: 143 VGPRs = three waves per SIMD = 12 resident blocks per CU (its 11.7 KB of LDS would allow 13); the 512-column
     // layout: 173 VGPRs = two per SIMD (-Rpass-analysis=kernel-resource-usage; a cap of 128 VGPRs for a fourth wave costs 287 spilled SGPRs and wins one block)
     c->proj_grid = cus * (c->params.max_columns <= PROJ_CAP_SHORT ? 12 : 8); c->pair_grid = cus * 20;
+    if(const char* e = getenv("HLALA_PAIR_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 32) c->pair_grid = cus * w; }      // (experiments)
     if(const char* e = getenv("HLALA_PROJ_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 14) c->proj_grid = cus * w; }      // (experiment: waves of the projection kernel per CU)
     { int rcp = dev_alloc(c, c->allocs, (size_t)2 * c->pair_grid * PAIR_COMB, &c->pair_scratch, false); if(rcp) return fail(rcp); }
     if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
@@ -566,10 +575,14 @@ int hlala_graph_get_gap_stretch(const hlala_ctx* c, uint8_t* in_stretch)
 static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
 {
     DevBatch& B = b->B;
-    size_t nc = (size_t)B.n_chains, cs = nc * (size_t)B.stride, nr = (size_t)B.n_reads, np = (size_t)B.n_pairs;
+    size_t nc = (size_t)B.n_chains, nr = (size_t)B.n_reads, np = (size_t)B.n_pairs;
+    // column rows: one per chain that passed the filters when they ran at creation (batch.h: chain_row), else one per chain
+    if(!b->prepared) { B.n_rows = B.n_chains; B.chain_row = nullptr; }
+    const size_t cs = (size_t)(B.n_rows > 0 ? B.n_rows : 1) * (size_t)B.stride;
     int rc = 0;
 #define AL(field, n, zero) do { rc = dev_alloc(c, b->allocs, (n), &B.field, zero); if(rc) return rc; } while(0)
-    AL(seed_status, nc, true); AL(seed_ncols, nc, true); AL(seed_begin, nc, true); AL(seed_end, nc, true); AL(seed_removed, nc, true);
+    if(!b->prepared) { AL(seed_status, nc, true); AL(seed_ncols, nc, true); }
+    AL(seed_begin, nc, true); AL(seed_end, nc, true); AL(seed_removed, nc, true);
     AL(seed_level, cs, false); AL(seed_edge, cs, false); AL(seed_g, cs, false); AL(seed_s, cs, false);
     AL(ext_status, nc, true); AL(ext_ncols, nc, true); AL(ext_begin, nc, true); AL(ext_end, nc, true); AL(ext_ll, nc, true);
     AL(dp_iters, 2 * nc, true); AL(dp_score, 2 * nc, true); AL(dp_ncols, 2 * nc, true); AL(dp_sb, 2 * nc, true); AL(dp_se, 2 * nc, true); AL(dp_err, 2 * nc, true);
@@ -585,8 +598,10 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     B.dp_band = c->band_grid > 0 ? c->band_margin + 1 : 0;
     B.dp_band_risky = c->band_risky ? 1 : 0;
     AL(dp_blk, (size_t)DPL_N * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
-    B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb;
-    if(c->order_nb > 0 && !B.from_seeds && nc > 0) { AL(chain_order, nc, false); AL(chain_bucket, nc, false); AL(order_hist, (size_t)c->order_nb + 1, false); }
+    if(!b->prepared) {
+        B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb;
+        if(c->order_nb > 0 && !B.from_seeds && nc > 0) { AL(chain_order, nc, false); AL(chain_bucket, nc, false); AL(order_hist, (size_t)c->order_nb + 1, false); }
+    }
     B.dbg = c->dbg_host;
 #undef AL
     return 0;
@@ -670,8 +685,30 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
     // The OUTPUT arrays are allocated by the first stage call (ensure_outputs): a caller that uploads batch i+2 while batches i and i+1 are aligned and read back
     // (two alignments in flight, one upload ahead) then holds the inputs of three batches -- 0.9 GB each -- but the outputs of two, and the outputs of the batch it
     // destroys are the pool blocks the next alignment takes.  Until then the device descriptor holds the inputs only (what hlala_kmer_presence reads).
+    // ... except the few per-chain arrays of the FILTERS and the POSITION ORDER, which read inputs only and run here, on the upload stream: the number of chains that
+    // passed -- a third of them on an MHC-scale graph -- comes back with the synchronisation this function ends on anyway, and the column arrays (20 bytes per column slot:
+    // 47 GB for the 6.1 M chains of a 1 M-pair batch) are then sized for those chains alone (batch.h: chain_row; HLALA_ROWS_ALL=1: a row per chain, filters at the stage call)
+    if(c->order_nb > 0 && nc > 0 && !c->rows_all) {
+#define AL(field, n, zero) do { rc = dev_alloc(c, b->allocs, (n), &B.field, zero); if(rc) return fail(rc); } while(0)
+        AL(seed_status, (size_t)nc, true); AL(seed_ncols, (size_t)nc, true);
+        AL(chain_order, (size_t)nc, false); AL(chain_bucket, (size_t)nc, false); AL(chain_row, (size_t)nc, false); AL(order_hist, (size_t)c->order_nb + 1, true);
+#undef AL
+        B.order_shift = c->order_shift; B.order_nb = c->order_nb;
+        b->prepared = true;
+    }
     rc = dev_upload(c, b->allocs, &b->B, 1, &b->dB); if(rc) return fail(rc);
+    if(b->prepared) {
+        hipLaunchKernelGGL(k_filter_chains, dim3((nr + 255) / 256), dim3(256), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_level);
+        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_SCAN_THREADS), 0, c->active, B.order_hist, B.order_nb);
+        hipLaunchKernelGGL(k_order_scatter, dim3((nc + 255) / 256), dim3(256), 0, c->active, b->dB);
+        { hipError_t el = hipGetLastError(); if(el != hipSuccess) { c->err = std::string("k_order_scatter: ") + hipGetErrorString(el); return fail(HLALA_E_DEVICE); } }
+        HIP_TRY_F(c, hipMemcpyAsync(&b->n_rows_host, B.order_hist + (B.order_nb - 1), sizeof(int), hipMemcpyDeviceToHost, c->active), fail);
+    }
     HIP_TRY_F(c, hipStreamSynchronize(c->active), fail);
+    if(b->prepared) {
+        if(b->n_rows_host < 0 || b->n_rows_host > nc) { c->err = "position order counted " + std::to_string(b->n_rows_host) + " chains of " + std::to_string(nc); return fail(HLALA_E_DEVICE); }
+        B.n_rows = b->n_rows_host;        // (the device descriptor gets it with the output arrays: ensure_outputs)
+    }
     *out = b;
     return HLALA_OK;
 }
@@ -783,9 +820,10 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     HIP_TRY(c, hipEventRecord(b->ev[0], c->active));
     if(B.n_chains > 0) {
         int threads = 256, blocks = (B.n_reads + threads - 1) / threads;
-        if(B.order_hist) HIP_TRY(c, hipMemsetAsync(B.order_hist, 0, ((size_t)B.order_nb + 1) * sizeof(int), c->active));
-        hipLaunchKernelGGL(k_filter_chains, dim3(blocks), dim3(threads), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_level);
-        if(B.order_hist) {
+        // (the filters and the position order of a batch ran when it was created, hlala_batch_create: they read inputs only)
+        if(!b->prepared && B.order_hist) HIP_TRY(c, hipMemsetAsync(B.order_hist, 0, ((size_t)B.order_nb + 1) * sizeof(int), c->active));
+        if(!b->prepared) hipLaunchKernelGGL(k_filter_chains, dim3(blocks), dim3(threads), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_level);
+        if(!b->prepared && B.order_hist) {
             // chains into position order (kernel_order.hip): every later kernel that walks the graph takes them from B.chain_order
             hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_SCAN_THREADS), 0, c->active, B.order_hist, B.order_nb);
             hipLaunchKernelGGL(k_order_scatter, dim3((B.n_chains + 255) / 256), dim3(256), 0, c->active, b->dB);
@@ -813,40 +851,49 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
     return mark_main(c, b);
 }
 
-static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused);
+static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase = 0);
 int hlala_extend_chains(hlala_ctx* c, hlala_batch* b) { return extend_impl(c, b, false); }
 
 // fused = called from hlala_align_batch on a paired batch.  The 16- / 32- / 64-lane classes hold all but a few percent of the DP calls; the rest (wide,
 // broad, large, in-memory) are few, long calls that cannot fill the chip.  Fused, they run on the side stream, followed there by a second stitch /
 // pairing pass over the pairs that own them (pair_deferred, set by the DP kernels when they hand an item to one of these classes), while the main
 // stream stitches and pairs everything else and is then free for the caller's next batch.  b->evDone orders later users of the batch behind the side work.
-static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
+// phase (fused only; hlala_align_batch): 0 = the whole stage, the side-stream classes forked off as soon as the 64-lane class is done; 1 = the main-stream part alone (classes
+// before DP_SIDE_TIER, first stitch pass), 2 = the side-stream part alone (the later classes, second stitch pass) -- queued by hlala_align_batch AFTER the main stream's
+// pairing pass: k_stitch_chains and k_pair_chains are short, latency-bound kernels, and beside the wide class (seven blocks of four wavefronts per CU: 28 of a CU's 32
+// wavefront slots) they ran on one wavefront per SIMD: 20.9 ms for a pairing pass that takes 4.1 ms alone (profiles/r05_experiments.txt).
+static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
 {
     DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
-    { int rj = join_side(c, b); if(rj) return rj; }
+    if(phase != 2) { int rj = join_side(c, b); if(rj) return rj; }
     { int re = batch_events(c, b); if(re) return re; }
     DevBatch& B = b->B;
-    if(B.unpaired || B.from_seeds || B.n_pairs <= 0 || B.n_chains <= 0) fused = false;
+    if(B.unpaired || B.from_seeds || B.n_pairs <= 0 || B.n_chains <= 0) { fused = false; if(phase == 2) return HLALA_OK; phase = 0; }
+    if(phase != 2) {
     b->side_used = false; b->side_pending = false;
     if(B.n_pairs > 0) HIP_TRY(c, hipMemsetAsync(B.pair_deferred, 0, (size_t)B.n_pairs, c->active));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->active));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 4, 0, (WC_N - 4) * sizeof(int), c->active));       // [4..6] jump-free lists, [7..] stitch, DP items, retry lists, band / fail-over lists
     if(B.from_seeds) HIP_TRY(c, hipMemsetAsync(B.counters, 0, 32 * sizeof(u64), c->active));
     HIP_TRY(c, hipEventRecord(b->ev[2], c->active));
+    }
     if(B.n_chains > 0) {
         DpItem* items = (DpItem*)B.dp_items;
         const u32 seed = c->params.rng_seed + 2u * b->first_chain;
+        int rc = 0;
+        if(phase != 2) {
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_head, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));       // -1: k_dp_items links the duplicates of a DP to it
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_next, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));
         // items, then the ten dense lists of the first classes (three band lists, jump-free, general; left / right each) in position order: counts per block, their scan, the slots
         HIP_TRY(c, hipMemsetAsync(B.dp_blk, 0, ((size_t)DPL_N * B.dp_nblk + 1) * sizeof(int), c->active));
         hipLaunchKernelGGL(k_dp_items, dim3(B.dp_nblk), dim3(256), 0, c->active, c->dG, b->dB, items);
-        int rc = check_launch(c, "k_dp_items"); if(rc) return rc;
+        rc = check_launch(c, "k_dp_items"); if(rc) return rc;
         hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_SCAN_THREADS), 0, c->active, B.dp_blk, DPL_N * B.dp_nblk + 1);
         hipLaunchKernelGGL(k_dp_lists, dim3(B.dp_nblk), dim3(256), 0, c->active, b->dB, (const DpItem*)items);
         rc = check_launch(c, "k_dp_lists"); if(rc) return rc;
+        }
         // every DP item first runs in the 16-lane class; the item count lives on the device, idle groups leave at once.
         // Items that outgrew it: two DPs per wave, then one wave per DP, then the classes with wider frontiers (fewer blocks per CU).
         // Each class is timed with its own pair of events on the stream it runs on (evC); ev[7] / ev[6] / ev[10] keep marking the start of the 16-lane
@@ -884,6 +931,7 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
             HIP_TRY(c, hipEventRecord(b->evC[tier][1], ws));
             return 0;
         };
+        if(phase != 2) {
         // the lane-per-DP class first: 64 calls per wavefront; what it cannot finish exactly goes on to the 16-lane class through its list
         b->lane_used = c->lane_grid > 0;
 #ifdef HLALA_WITH_LANE_CLASS
@@ -909,30 +957,40 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused)
         HIP_TRY(c, hipEventRecord(b->ev[7], c->active));
         rc = run_class(0); if(rc) return rc;
         HIP_TRY(c, hipEventRecord(b->ev[6], c->active));
+        }
         for(int tier = 1; tier <= DP_LAST_TIER; tier++) {
+            if(phase == 1 && tier >= DP_SIDE_TIER) break;
+            if(phase == 2 && tier < DP_SIDE_TIER) continue;
             rc = run_class(tier); if(rc) return rc;
             if(tier == 2) HIP_TRY(c, hipEventRecord(b->ev[10], c->active));
         }
         if(!fused) HIP_TRY(c, hipEventRecord(b->ev[8], c->active));
         const int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
-        if(fused) {
+        if(fused && phase == 1) b->side_pending = true;
+        if(fused && phase != 1) {
             // second pass (side): the chains of the deferred pairs, work counter 36; first pass (main): all the others, work counter 7
             { const int pgrid = (B.n_pairs + 63) / 64, cap = c->stitch_grid / 20;       // the second pass sweeps the pairs' flags, 64 per wave and round: one wave per CU finds room beside the next batch's persistent kernels
-              hipLaunchKernelGGL(k_stitch_chains, dim3(pgrid < cap ? (pgrid > 0 ? pgrid : 1) : cap), dim3(64), 0, c->side, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, 2, 0); }
+              hipLaunchKernelGGL(k_stitch_chains, dim3(pgrid < cap ? (pgrid > 0 ? pgrid : 1) : cap), dim3(64), 0, c->side, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, 2, 0, 0); }
             rc = check_launch(c, "k_stitch_chains (side)"); if(rc) return rc;
             HIP_TRY(c, hipEventRecord(b->evDone, c->side));
             HIP_TRY(c, hipEventRecord(c->evSideTail, c->side)); c->sideTailValid = true;
             b->side_inflight = true; b->side_used = true; b->side_pending = true;
         }
-        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->active, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, fused ? 1 : 0, c->stitch_draw);
+        if(phase != 2) {
+        hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->active, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, fused ? 1 : 0, c->stitch_draw, c->stitch_by_row);
         rc = check_launch(c, "k_stitch_chains"); if(rc) return rc;
+        }
     }
+    if(phase == 2) return HLALA_OK;
     HIP_TRY(c, hipEventRecord(b->ev[3], c->active));
     b->staged |= 2;
     return mark_main(c, b);
 }
 
-int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
+static int pair_impl(hlala_ctx* c, hlala_batch* b, int phase);
+int hlala_pair_chains(hlala_ctx* c, hlala_batch* b) { return pair_impl(c, b, 0); }
+// phase: 0 = the whole stage; 1 = the main-stream pass alone, 2 = the side-stream pass alone (hlala_align_batch: extend_impl)
+static int pair_impl(hlala_ctx* c, hlala_batch* b, int phase)
 {
     DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
@@ -941,9 +999,12 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
     { int re = batch_events(c, b); if(re) return re; }
     DevBatch& B = b->B;
     const bool fused = b->side_pending;
+    if(!fused) { if(phase == 2) return HLALA_OK; phase = 0; }
     if(!fused) { int rj = join_side(c, b); if(rj) return rj; }
+    if(phase != 2) {
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 2, 0, sizeof(int), c->active));
     HIP_TRY(c, hipEventRecord(b->ev[4], c->active));
+    }
     if(B.n_pairs > 0) {
         const int grid = B.n_pairs < c->pair_grid ? B.n_pairs : c->pair_grid;
         auto launch_pair = [&](hipStream_t st, int mode, int counterIdx) -> int {
@@ -951,8 +1012,9 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
             else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx, c->pair_scratch + (st == c->side ? (size_t)c->pair_grid * PAIR_COMB : 0));
             return check_launch(c, "k_pair_chains");
         };
-        int rc = launch_pair(c->active, fused ? 1 : 0, 2); if(rc) return rc;
-        if(fused) {
+        int rc = 0;
+        if(phase != 2) { rc = launch_pair(c->active, fused ? 1 : 0, 2); if(rc) return rc; }
+        if(fused && phase != 1) {
             // second pass, behind the side-stream classes and the second stitch pass: the deferred pairs (work counter 37)
             rc = launch_pair(c->side, 2, 37); if(rc) return rc;
             HIP_TRY(c, hipEventRecord(b->evSide[6], c->side));
@@ -961,6 +1023,7 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
             b->side_inflight = true; b->side_pending = false;
         }
     }
+    if(phase == 2) return HLALA_OK;
     HIP_TRY(c, hipEventRecord(b->ev[5], c->active));
     b->staged |= 4;
     return mark_main(c, b);
@@ -969,8 +1032,16 @@ int hlala_pair_chains(hlala_ctx* c, hlala_batch* b)
 int hlala_align_batch(hlala_ctx* c, hlala_batch* b)
 {
     int rc = hlala_project_chains(c, b); if(rc) return rc;
-    rc = extend_impl(c, b, true); if(rc) return rc;
-    return hlala_pair_chains(c, b);
+    if(!c->side_after_pair) {
+        rc = extend_impl(c, b, true); if(rc) return rc;
+        return hlala_pair_chains(c, b);
+    }
+    // the main stream's part of the batch first -- DP classes up to the 64-lane one, stitch, pairing --, then the side stream's classes and its second stitch / pairing pass
+    // are queued behind it (extend_impl): the main stream's short kernels do not share the CUs with the wide class
+    rc = extend_impl(c, b, true, 1); if(rc) return rc;
+    rc = pair_impl(c, b, 1); if(rc) return rc;
+    rc = extend_impl(c, b, true, 2); if(rc) return rc;
+    return pair_impl(c, b, 2);
 }
 
 int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains_out* o)
@@ -981,13 +1052,30 @@ int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains
     DevBatch& B = b->B;
     size_t nc = (size_t)B.n_chains, cs = nc * (size_t)B.stride;
     int rc = 0;
+    // the column arrays hold a row per chain that passed the filters (batch.h: chain_row); the caller's arrays hold one per chain: rows are copied to their chains'
+    // places on the host (chains without a row: zeros)
+    std::vector<int> rowOf;
+    if(B.chain_row && nc > 0) { rowOf.resize(nc); HIP_TRY(c, hipMemcpyAsync(rowOf.data(), B.chain_row, nc * sizeof(int), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); }
+    auto dlRows = [&](auto* host, const auto* dev) -> int {
+        typedef typename std::remove_pointer<decltype(host)>::type T;
+        if(!host || !cs) return 0;
+        if(rowOf.empty()) return dl(c, host, dev, cs);
+        const size_t stride = (size_t)B.stride, nrows = (size_t)B.n_rows;
+        std::vector<T> tmp(nrows * stride + 1);
+        if(nrows) { HIP_TRY(c, hipMemcpyAsync(tmp.data(), dev, nrows * stride * sizeof(T), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); }
+        for(size_t k = 0; k < nc; k++) {
+            const int r = rowOf[k];
+            if(r >= 0 && (size_t)r < nrows) memcpy(host + k * stride, tmp.data() + (size_t)r * stride, stride * sizeof(T)); else memset(host + k * stride, 0, stride * sizeof(T));
+        }
+        return 0;
+    };
     if(stage == 0) {
         if(!(b->staged & 1)) { c->err = "seed chains not computed"; return HLALA_E_STATE; }
         if((rc = dl(c, o->status, B.seed_status, nc))) return rc; if((rc = dl(c, o->n_cols, B.seed_ncols, nc))) return rc;
         if((rc = dl(c, o->seq_begin, B.seed_begin, nc))) return rc; if((rc = dl(c, o->seq_end, B.seed_end, nc))) return rc;
         if((rc = dl(c, o->removed_cols, B.seed_removed, nc))) return rc;
-        if((rc = dl(c, o->col_level, B.seed_level, cs))) return rc; if((rc = dl(c, o->col_edge, B.seed_edge, cs))) return rc;
-        if((rc = dl(c, o->col_gchar, B.seed_g, cs))) return rc; if((rc = dl(c, o->col_schar, B.seed_s, cs))) return rc;
+        if((rc = dlRows(o->col_level, (const int*)B.seed_level))) return rc; if((rc = dlRows(o->col_edge, (const int*)B.seed_edge))) return rc;
+        if((rc = dlRows(o->col_gchar, (const uint8_t*)B.seed_g))) return rc; if((rc = dlRows(o->col_schar, (const uint8_t*)B.seed_s))) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->active));
         if(o->col_fromseed) memset(o->col_fromseed, 1, cs);
         if(o->ll) memset(o->ll, 0, nc * 8);
@@ -999,9 +1087,9 @@ int hlala_batch_get_chains(hlala_ctx* c, hlala_batch* b, int stage, hlala_chains
         if((rc = dl(c, o->seq_begin, B.ext_begin, nc))) return rc; if((rc = dl(c, o->seq_end, B.ext_end, nc))) return rc;
         if((rc = dl(c, o->removed_cols, B.seed_removed, nc))) return rc; if((rc = dl(c, o->ll, B.ext_ll, nc))) return rc;
         if((rc = dl(c, o->dp_iters, B.dp_iters, 2 * nc))) return rc; if((rc = dl(c, o->dp_score, B.dp_score, 2 * nc))) return rc;
-        if((rc = dl(c, o->col_level, B.ext_level, cs))) return rc; if((rc = dl(c, o->col_edge, B.ext_edge, cs))) return rc;
-        if((rc = dl(c, o->col_gchar, B.ext_g, cs))) return rc; if((rc = dl(c, o->col_schar, B.ext_s, cs))) return rc;
-        if((rc = dl(c, o->col_fromseed, B.ext_fromseed, cs))) return rc;
+        if((rc = dlRows(o->col_level, (const int*)B.ext_level))) return rc; if((rc = dlRows(o->col_edge, (const int*)B.ext_edge))) return rc;
+        if((rc = dlRows(o->col_gchar, (const uint8_t*)B.ext_g))) return rc; if((rc = dlRows(o->col_schar, (const uint8_t*)B.ext_s))) return rc;
+        if((rc = dlRows(o->col_fromseed, (const uint8_t*)B.ext_fromseed))) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->active));
     } else { c->err = "stage must be 0 or 1"; return HLALA_E_ARG; }
     return HLALA_OK;
@@ -1415,6 +1503,22 @@ extern "C" int hlala_debug_counters(hlala_ctx* c, hlala_batch* b, unsigned long 
     if(!b->outputs_ready) { memset(out32, 0, 32 * sizeof(u64)); return HLALA_OK; }      // only uploaded so far: the counters do not exist yet
     HIP_TRY(c, hipStreamSynchronize(c->active));
     HIP_TRY(c, hipMemcpyAsync(out32, b->B.counters, 32 * sizeof(u64), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active));
+    return HLALA_OK;
+}
+
+// device memory of a batch and of its context (diagnostics; bench.py reports them): out[0] = bytes of the batch's blocks (inputs + outputs, pool size classes included),
+// out[1] = chains that hold column rows (batch.h: chain_row; n_chains when every chain does), out[2] = bytes parked in the context's pool, out[3] = bytes of every block the
+// context has handed out or parked (graph, tables, slabs, batches)
+extern "C" int hlala_debug_memory(hlala_ctx* c, hlala_batch* b, unsigned long long* out4)
+{
+    if(!c || !out4) return HLALA_E_ARG;
+    out4[0] = out4[1] = 0;
+    if(b) {
+        for(void* p : b->allocs) { auto it = c->block_bytes.find(p); if(it != c->block_bytes.end()) out4[0] += it->second; }
+        out4[1] = (unsigned long long)(b->prepared ? b->B.n_rows : b->B.n_chains);
+    }
+    out4[2] = c->pool_bytes; out4[3] = 0;
+    for(auto& kv : c->block_bytes) out4[3] += kv.second;
     return HLALA_OK;
 }
 

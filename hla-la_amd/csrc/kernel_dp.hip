@@ -1424,7 +1424,7 @@ __device__ inline int dp_expand(DpLdsT<C>& S, const DpSlabT<C>& sl, const DevGra
     const int c = guni<GW>(st.item) >> 1;
     const int rowOff = fwd ? stride - nCols : sb;
     if(rowOff + nCols > stride) return PH_DONE;             // the stitched chain cannot fit the row: k_stitch_chains reports the column error
-    const size_t cb = (size_t)c * stride + rowOff;
+    const size_t cb = row_base(B, c) + rowOff;
     int* oL = B.ext_level + cb; int* oE = B.ext_edge + cb; uint8_t* oG = B.ext_g + cb; uint8_t* oS = B.ext_s + cb;
     int base = 0;
     for(int s0 = 0; s0 < nSteps; s0 += GW) {
@@ -1492,7 +1492,7 @@ __device__ inline bool dp_item_for(const DevGraph& G, const DevBatch& B, int c, 
     const int rOff = B.read_off[r], seqLen = B.read_off[r + 1] - rOff;
     const int nSeed = B.seed_ncols[c], sBegin = B.seed_begin[c], sEnd = B.seed_end[c];
     if(seqLen > DP_SEQCAP || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) return false;
-    const size_t cb = (size_t)c * B.stride;
+    const size_t cb = row_base(B, c);
     const int e0 = B.seed_edge[cb], e1 = B.seed_edge[cb + nSeed - 1];
     if(e0 < 0 || e1 < 0 || e0 >= G.E || e1 >= G.E) return false;
     it.rOff = rOff; it.seqLen = seqLen; it.pad0 = 0; it.pad1 = 0; it.item = 2 * c + d;
@@ -1538,7 +1538,7 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
         const int stride = B.stride;
         const int r = B.chain_read[c];
         const int rOff = B.read_off[r], seqLen = B.read_off[r + 1] - rOff;
-        const size_t cb = (size_t)c * stride;
+        const size_t cb = row_base(B, c);
         const int nSeed = B.seed_ncols[c], sBegin = B.seed_begin[c], sEnd = B.seed_end[c];
         int err = 0;
         if((!B.unpaired && seqLen > DP_SEQCAP) || seqLen < 1 || nSeed < 1 || sBegin < 0 || sEnd >= seqLen || sBegin > sEnd) err = HLALA_CHAIN_ERR_INPUT;     // DP_SEQCAP bounds the DP only
@@ -1975,7 +1975,7 @@ __device__ __forceinline__ void stitch_draw(const DevBatch& B, const DevTables& 
         const int q = __ffsll((long long)mine) - 1;
         const int c = __builtin_amdgcn_readlane(cq, q);
         const int rOff = __builtin_amdgcn_readlane(dR0, q), seqLen = __builtin_amdgcn_readlane(dR1, q) - rOff;
-        const size_t cb = (size_t)c * stride;
+        const size_t cb = row_base(B, c);
         const int nSeed = __builtin_amdgcn_readlane(dNSeed, q), sBegin = __builtin_amdgcn_readlane(dSB, q), sEnd = __builtin_amdgcn_readlane(dSE, q);
         const int ncL = __builtin_amdgcn_readlane(dNcL, q), ncR = __builtin_amdgcn_readlane(dNcR, q);
         const int errL = __builtin_amdgcn_readlane(dErrL, q), errR = __builtin_amdgcn_readlane(dErrR, q);
@@ -2014,7 +2014,7 @@ __device__ __forceinline__ void stitch_draw(const DevBatch& B, const DevTables& 
 // Pass 2 does not look at chains at all: the waves take the PAIRS 64 at a time (no atomic), and the chains of the few deferred ones -- ~2.5 k pairs per million --
 // are stitched; it used to test all 6.1 M chains beside the next batch's kernels (25 ms on the side stream for a few thousand chains; 0.15 ms now).
 __global__ __launch_bounds__(64, 5) void k_stitch_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
-                                                        const uint8_t* __restrict__ deferPairs, const int deferMode, const int draw)      // draw: chains per wave and round (1 .. 64)
+                                                        const uint8_t* __restrict__ deferPairs, const int deferMode, const int draw, const int byRow)      // draw: chains per wave and round (1 .. 64)
 {
     const DevBatch& B = *Bp;
     const DevTables& T = *Tp;
@@ -2033,14 +2033,18 @@ __global__ __launch_bounds__(64, 5) void k_stitch_chains(const DevGraph* __restr
             }
         }
     } else {
-        const int nList = B.n_chains;
+        // byRow: the draws walk the COLUMN ROWS (batch.h: chain_row -- only the chains that passed the filters hold one, in position order), not the chain numbers
+        const bool rows = byRow && B.chain_order && B.chain_row;
+        const int nList = rows ? ordered_chains(B) : B.n_chains;
         for(;;) {
             int w0 = 0;
             if(lane == 0) w0 = atomicAdd(&B.work_counter[7], draw);
             w0 = __builtin_amdgcn_readfirstlane(w0);
             if(w0 >= nList) break;
             const int wq = w0 + lane;
-            stitch_draw(B, T, deferPairs, deferMode, lane, (lane < draw && wq < nList) ? wq : -1, accChains, accCols);
+            int cq = (lane < draw && wq < nList) ? wq : -1;
+            if(rows && cq >= 0) cq = B.chain_order[cq];
+            stitch_draw(B, T, deferPairs, deferMode, lane, cq, accChains, accCols);
         }
     }
     if(lane == 0 && accChains) { atomicAdd(&B.counters[CNT_CHAINS_EXT], accChains); atomicAdd(&B.counters[CNT_OUT_COLS], accCols); }

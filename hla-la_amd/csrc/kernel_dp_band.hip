@@ -252,7 +252,7 @@ __device__ __forceinline__ void band_pass(const DevGraph& G, const DevBatch& B, 
 #else
                     if(live && rowOff + nCols <= stride) {
 #endif
-                        const size_t cb = (size_t)(item >> 1) * stride + rowOff;
+                        const size_t cb = row_base(B, item >> 1) + rowOff;
                         int* oL = B.ext_level + cb; int* oE = B.ext_edge + cb; uint8_t* oG = B.ext_g + cb; uint8_t* oS = B.ext_s + cb;
                         for(int s = gl; s < nCols; s += GW) {
                             const int st = S.steps[s]; const int kind = st & 3, i_ = (st >> 2) & 127, j_ = st >> 9;

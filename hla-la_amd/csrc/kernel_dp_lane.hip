@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64, 1) void k_dp_lane(const DevGraph* __restrict__ 
                                 // this cell's node), which the chase loads next anyway -- so step k's column is written while step k + 1's cell is on its way.  The left
                                 // extension is written at its final place [sb, sb + n); the right extension right-aligned in the row, i.e. step s at stride - 1 - s, which
                                 // is where the reversal of a forward trace (:1319-1326) puts it whatever its length (k_stitch_chains moves it next to the seed).
-                                const int c = cur >> 1; const size_t rowBase = (size_t)c * stride;
+                                const int c = cur >> 1; const size_t rowBase = row_base(B, c);
                                 int* oL = B.ext_level + rowBase; int* oE = B.ext_edge + rowBase; uint8_t* oG = B.ext_g + rowBase; uint8_t* oS = B.ext_s + rowBase;
                                 const int* eo = fwd ? G.out_off : G.in_off; const int* et = fwd ? G.out_to : G.in_from; const int* ee = fwd ? G.out_eid : G.in_eid;
                                 int slot = endSlot, m = 0, x = key_x(ek), y = yEnd, nSteps = 0, guard = 0;

@@ -116,7 +116,7 @@ __global__ void k_exon_positions(const DevBatch* __restrict__ Bp, const DevTable
         // one read per unit: oneReadAlignment_2_exonPositions_unpaired (:3568-3930) and the test of :1476; no removeDoublePositionsFromRead
         const int ch = B.best_chain[p];
         if(ch < 0 || ch >= B.n_chains) return;
-        const size_t so = (size_t)ch * stride;
+        const size_t so = row_base(B, ch);
         MateAln& u = a[0];
         u.n = B.ext_ncols[ch]; u.lv = B.ext_level + so; u.g = B.ext_g + so; u.s = B.ext_s + so; u.mq = B.sel_mapq + (size_t)p * stride;
         u.bases = B.read_bases + B.read_off[p]; u.quals = B.read_quals + B.read_off[p]; u.readLen = B.read_off[p + 1] - B.read_off[p];
@@ -151,7 +151,7 @@ __global__ void k_exon_positions(const DevBatch* __restrict__ Bp, const DevTable
     for(int m = 0; m < 2; m++) {
         const int r = 2 * p + m; const int ch = B.best_chain[r];
         if(ch < 0 || ch >= B.n_chains) return;
-        const size_t so = (size_t)ch * stride;
+        const size_t so = row_base(B, ch);
         a[m].n = B.ext_ncols[ch]; a[m].lv = B.ext_level + so; a[m].g = B.ext_g + so; a[m].s = B.ext_s + so; a[m].mq = B.sel_mapq + (size_t)r * stride;
         a[m].bases = B.read_bases + B.read_off[r]; a[m].quals = B.read_quals + B.read_off[r]; a[m].readLen = B.read_off[r + 1] - B.read_off[r];
         a[m].first = B.ext_firstlast[4 * ch + 0]; a[m].last = B.ext_firstlast[4 * ch + 2];
@@ -211,7 +211,7 @@ __global__ void k_unit_stats(const DevBatch* __restrict__ Bp, const DevTables* _
     for(int m = 0; m < nm; m++) {
         const int r = B.unpaired ? p : 2 * p + m; const int ch = B.best_chain[r];
         if(ch < 0 || ch >= B.n_chains) return;
-        const size_t so = (size_t)ch * stride;
+        const size_t so = row_base(B, ch);
         a[m].n = B.ext_ncols[ch]; a[m].lv = B.ext_level + so; a[m].g = B.ext_g + so; a[m].s = B.ext_s + so; a[m].mq = B.sel_mapq + (size_t)r * stride;
         a[m].bases = B.read_bases + B.read_off[r]; a[m].quals = B.read_quals + B.read_off[r]; a[m].readLen = B.read_off[r + 1] - B.read_off[r];
         a[m].first = B.ext_firstlast[4 * ch + 0]; a[m].last = B.ext_firstlast[4 * ch + 2];

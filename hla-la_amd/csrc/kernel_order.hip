@@ -43,9 +43,10 @@ __global__ void k_order_scatter(const DevBatch* __restrict__ Bp)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if(c >= B.n_chains) return;
     const int bk = B.chain_bucket[c];
-    if(bk < 0) return;                      // filtered out: takes no further part
+    if(bk < 0) { if(B.chain_row) B.chain_row[c] = -1; return; }                      // filtered out: takes no further part, holds no column row
     const int pos = atomicAdd(&B.order_hist[bk], 1);
     B.chain_order[pos] = c;
+    if(B.chain_row) B.chain_row[c] = pos;   // column rows are in position order (batch.h: row_base)
 }
 
 // 4-bit packed bases of a window (hlala_batch_in::read_bases_packed: BAM nibble codes, every read on a byte boundary at (base offset + read number + 1) >> 1) ->

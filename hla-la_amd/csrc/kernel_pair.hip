@@ -19,15 +19,33 @@ constexpr int PAIR_COMB   = 1024;   // chain combinations per pair
 constexpr int PAIR_COMB_LDS = HLALA_PAIR_COMB_LDS;  // ... of which the LDS block holds this many; pairs with more keep theirs in the wave's HBM scratch
 constexpr int PAIR_COLS   = 512;    // columns per chain handled by the per-position pass
 
+// Per-position pass: what the columns of the chain under comparison look like from the selected chain's side -- by read-base ordinal and by level
+// (level - the chain's first level; a chain's defined levels rise by one per column, so 512 columns span fewer than 512 levels)
+constexpr short PAIR_NOCOL = -32768;     // no base column with this ordinal
+constexpr short PAIR_NOLEVEL = -32767;   // the column carries no level (-1: a base the read inserts)
 struct __align__(16) PairLds {
     double LL[PAIR_COMB_LDS];
+    double phredThr[256];                // DevTables::phred_thr: the binary search of PCorrectToPhred runs on this copy (eight dependent loads per column otherwise)
     int list[2][PAIR_CHAINS];
     int nlist[2];
-    short basecol[PAIR_COLS];
-    short levcol[PAIR_COLS];
+    unsigned char src[2][PAIR_CHAINS];   // the lane that loaded the facts of list entry k (PairChain)
+    short baseLev[PAIR_COLS];            // [read-base ordinal] relative level of that base's column (PAIR_NOCOL / PAIR_NOLEVEL)
+    unsigned char baseG[PAIR_COLS];      // ... its graph character
+    unsigned char levS[PAIR_COLS];       // [relative level] read character of the column on that level (0: none)
+    unsigned char levG[PAIR_COLS];       // ... its graph character
     double red[4];
     int ired[8];
 };
+
+// Utilities::PCorrectToPhred (Utilities.cpp:178-203), device_common.h: phred_from_pcorrect on the block's copy of the threshold table
+__device__ __forceinline__ unsigned char pair_phred(const PairLds& P, double pCorrect)
+{
+    double pWrong = 1 - pCorrect;
+    if(pWrong == 0) pWrong = 1e-100;
+    int lo = 0, hi = 255;
+    while(lo < hi) { const int mid = (lo + hi + 1) >> 1; if(pWrong <= P.phredThr[mid]) lo = mid; else hi = mid - 1; }
+    return (unsigned char)lo;
+}
 
 // position of sequence `id` at `level` (the level's entries are sorted by sequence id, flat_graph.cpp), -1 if the sequence does not pass through it
 __device__ inline int lp_find(const DevGraph& G, int level, int id)
@@ -48,6 +66,43 @@ __device__ inline int lp_find(const DevGraph& G, int level, int id)
 __device__ inline double pair_insert_ll(const DevGraph& G, const DevTables& T, const int up0, const int up1, const int dn0, const int dn1)
 {
     const int lane = lane_id();
+    // Levels of the backbone carry a handful of sequences.  When none of the four levels has more than 16, a quarter of the wave takes each level: the four
+    // (offset, count) pairs in one round trip, every (sequence, position) entry in a second, the look-ups between the quarters through lane reads, the table value
+    // in a third -- the general form below spends a dependent load per step of every binary search (twenty round trips per combination).
+    {
+        const int g = lane >> 4, e = lane & 15;
+        const int lvl = g == 0 ? up0 : (g == 1 ? up1 : (g == 2 ? dn0 : dn1));
+        long long lo = 0; int n = 0;
+        if(lvl >= 0) { lo = G.lp_off[lvl]; n = (int)(G.lp_off[lvl + 1] - lo); }
+        if(__ballot(n > 16) == 0) {
+            int id = -1, pos = -1;
+            if(e < n) { id = G.lp_seqid[lo + e]; pos = G.lp_pos[lo + e]; }
+            const int nU0 = __builtin_amdgcn_readlane(n, 0), nD0 = __builtin_amdgcn_readlane(n, 32), nD1 = __builtin_amdgcn_readlane(n, 48);
+            bool cand = g < 2 && e < n;
+            for(int u = 0; u < nU0; u++) {          // first found wins: ids already anchored by the last level
+                const int oid = __builtin_amdgcn_readlane(id, u), op = __builtin_amdgcn_readlane(pos, u);
+                if(g == 1 && oid == id && op >= 0) cand = false;
+            }
+            int beginPos = -1;
+            for(int u = 0; u < nD0; u++) {
+                const int oid = __builtin_amdgcn_readlane(id, 32 + u), op = __builtin_amdgcn_readlane(pos, 32 + u);
+                if(oid == id && beginPos < 0) beginPos = op;
+            }
+            for(int u = 0; u < nD1; u++) {
+                const int oid = __builtin_amdgcn_readlane(id, 48 + u), op = __builtin_amdgcn_readlane(pos, 48 + u);
+                if(oid == id && beginPos < 0) beginPos = op;
+            }
+            const bool have = cand && beginPos >= 0;
+            double best = -1.0e300;
+            if(have) {
+                const long long d = (long long)beginPos - pos - 1;
+                const long long k = d - T.is_dmin;
+                best = (k >= 0 && k < T.is_n) ? T.is_logpdf[k] : T.is_penalty;      // pdf <= 0 -> penalty (:3447-3464)
+            }
+            for(int o = 32; o; o >>= 1) { const double ov = __shfl_xor(best, o); if(ov > best) best = ov; }
+            return __ballot(have) ? best : T.is_penalty;
+        }
+    }
     // upstream chain: last two defined levels (scan order: last, second last); downstream: first two
     const int upL[2] = {up0, up1}, dnL[2] = {dn0, dn1};
     double best = -1.0e300; bool have = false;
@@ -119,19 +174,153 @@ __global__ void k_pair_distances(const DevGraph* __restrict__ Gp, const DevBatch
 // Everything of a pair after its chain lists are known: combination log likelihoods, first maximum, posteriors, mapping qualities, per-position
 // qualities.  LL holds one double per combination: the pair's LDS block for up to PAIR_COMB_LDS combinations (all but a handful of pairs), else the
 // wave's scratch in HBM -- the call sites differ in nothing but that pointer, so each instance addresses its memory directly.
+// What the pairing needs of one extended chain -- first / last two levels, strand, log likelihood, length, column row --, lane k holding the k-th chain of a
+// mate's list.  Every field of every candidate chain of the pair is requested in ONE round trip, beside the status that decides whether the chain is listed at
+// all, and moved to the list's lane order through lane permutes: each dependent load of this kernel is a random 64-byte access into arrays of tens of megabytes
+// (1-2 us with the TLB miss), and there used to be four in a row before the first combination was scored (status -> list -> levels / strand / likelihood;
+// later length / row / first level again for the per-position pass, and the selected chains' levels once more for the pair's outputs).
+struct PairChain { int4 fl; int rev, nk, row; double ll; };
+__device__ __forceinline__ PairChain pair_chain_load(const DevBatch& B, const int c)
+{
+    PairChain x;
+    x.fl = *(const int4*)(B.ext_firstlast + 4 * (size_t)c); x.rev = B.chain_reverse[c]; x.ll = B.ext_ll[c]; x.nk = B.ext_ncols[c]; x.row = B.chain_row ? B.chain_row[c] : c;
+    return x;
+}
+__device__ __forceinline__ PairChain pair_chain_from_lane(const PairChain& x, const int srcLane)
+{
+    PairChain y;
+    y.fl.x = __shfl(x.fl.x, srcLane); y.fl.y = __shfl(x.fl.y, srcLane); y.fl.z = __shfl(x.fl.z, srcLane); y.fl.w = __shfl(x.fl.w, srcLane);
+    y.rev = __shfl(x.rev, srcLane); y.nk = __shfl(x.nk, srcLane); y.row = __shfl(x.row, srcLane);
+    const long long b = __double_as_longlong(x.ll);
+    y.ll = __longlong_as_double((long long)(((u64)(u32)__shfl((int)(b >> 32), srcLane) << 32) | (u64)(u32)__shfl((int)b, srcLane)));
+    return y;
+}
+
+// Per-position mapping quality of the selected chains (:4155-4311).  PER: columns per lane (3: chains of up to 192 columns -- 2x150 bp reads --, 8: up to PAIR_COLS).
+// ---- per-position mapping quality of the selected chains (:4155-4311)
+// A column of the selected chain is "shared" by another chain of the mate when that chain aligns the same read base to the same level and graph character
+// (base columns, matched through their read-base ordinal) or carries a gap with the same graph character on the same level (gap columns, matched through
+// the level).  Per other chain: its columns in ONE round trip (up to 256 per lane round), turned into two LDS tables -- by base ordinal and by relative
+// level -- that hold what the comparison needs, so the comparison itself reads LDS only.  (Rounds 1-4: column numbers in LDS, the compared fields read back
+// from HBM per column, the chain's length / row / first level through three dependent wave-uniform loads, and PCorrectToPhred's binary search on the
+// table in global memory: ~75 dependent round trips for a pair of two chains per mate, 85 k cycles.)
+template <bool UNPAIRED, int PER>
+__device__ __forceinline__ void pair_positions(const DevBatch& B, PairLds& P, const double* __restrict__ LL, const int p, const int n1, const int n2, const int nComb,
+                                               const int best1, const int best2, const PairChain& cA, const PairChain& cB, const int lane, const int stride)
+{
+    constexpr int NM = UNPAIRED ? 1 : 2;
+    for(int m = 0; m < NM; m++) {
+        const int r = UNPAIRED ? p : 2 * p + m;
+        const int nl = m ? n2 : n1;
+        // length, column row and first level of every chain of the mate's list: lane k holds chain k (PairChain)
+        const int nkL = m ? cB.nk : cA.nk, rowL = m ? cB.row : cA.row, f0L = m ? cB.fl.x : cA.fl.x;
+        const int kSel = m ? best2 : best1;
+        const int nSel = __builtin_amdgcn_readlane(nkL, kSel); const size_t sb = (size_t)__builtin_amdgcn_readlane(rowL, kSel) * (size_t)stride; const size_t ob = (size_t)r * stride;
+        if(nComb == 1) {
+            const unsigned char ph = (unsigned char)P.ired[7];          // PCorrectToPhred(1), set when the block started
+            for(int j = lane; j < nSel; j += 64) B.sel_mapq[ob + j] = ph;
+            continue;
+        }
+        // columns of the selected chain handled by this lane: j = lane + 64*t
+        u64 mask[PER];
+        int selLv[PER], selInfo[PER];          // selInfo: graph character | base ordinal << 8 (0xFFFF: a gap column) | read character << 24 (until the ordinals are known)
+        #pragma unroll
+        for(int t = 0; t < PER; t++) { const int j = t * 64 + lane; mask[t] = 0; selLv[t] = -1; selInfo[t] = (int)((u32)'_' << 24); if(j < nSel) { selLv[t] = B.ext_level[sb + j]; selInfo[t] = (int)((u32)B.ext_g[sb + j] | ((u32)B.ext_s[sb + j] << 24)); } }
+        // read-base ordinal of each selected column (alignment orientation; strand is shared by all chains of the mate)
+        {
+            int carry = 0;
+            #pragma unroll
+            for(int t = 0; t < PER; t++) {
+                if(t * 64 >= nSel) break;
+                const int j = t * 64 + lane; const bool isBase = j < nSel && ((u32)selInfo[t] >> 24) != (u32)'_';
+                const u64 bm = __ballot(isBase);
+                const int ord = isBase ? carry + __popcll(bm & ((1ull << lane) - 1ull)) : 0xFFFF;
+                selInfo[t] = (int)(((u32)selInfo[t] & 255u) | ((u32)ord << 8));
+                carry += __popcll(bm);
+            }
+            #pragma unroll
+            for(int t = 0; t < PER; t++) if(t * 64 >= nSel) selInfo[t] = (int)(((u32)selInfo[t] & 255u) | (0xFFFFu << 8));
+        }
+        for(int k = 0; k < nl; k++) {
+            if(k == kSel) {
+                // the selected chain agrees with itself in every column (base columns through their read-base ordinal, gap columns through their level)
+                #pragma unroll
+                for(int t = 0; t < PER; t++) if(t * 64 + lane < nSel) mask[t] |= (1ull << k);
+                continue;
+            }
+            const int nk = __builtin_amdgcn_readlane(nkL, k), firstK = __builtin_amdgcn_readlane(f0L, k);
+            const size_t kb = (size_t)__builtin_amdgcn_readlane(rowL, k) * (size_t)stride;
+            WSYNC();
+            for(int i = lane; i < PAIR_COLS / 4; i += 64) { ((unsigned long long*)P.baseLev)[i] = 0x8000800080008000ull; }          // PAIR_NOCOL everywhere
+            for(int i = lane; i < PAIR_COLS / 8; i += 64) { ((unsigned long long*)P.levS)[i] = 0ull; }
+            WSYNC();
+            int carry = 0;
+            for(int t0 = 0; t0 * 64 < nk; t0 += 4) {
+                unsigned char ks[4], kg[4]; int kl[4];
+                #pragma unroll
+                for(int u = 0; u < 4; u++) { const int j = (t0 + u) * 64 + lane; ks[u] = 0; kg[u] = 0; kl[u] = -1; if(j < nk) { ks[u] = B.ext_s[kb + j]; kg[u] = B.ext_g[kb + j]; kl[u] = B.ext_level[kb + j]; } }
+                #pragma unroll
+                for(int u = 0; u < 4; u++) {
+                    if((t0 + u) * 64 >= nk) break;
+                    const int j = (t0 + u) * 64 + lane; const bool act = j < nk;
+                    const bool isBase = act && ks[u] != '_';
+                    const u64 bm = __ballot(isBase);
+                    const int rel = kl[u] == -1 ? (int)PAIR_NOLEVEL : kl[u] - firstK;          // (firstK is the first defined level: rel >= 0 for a defined level)
+                    if(isBase) { const int bi = carry + __popcll(bm & ((1ull << lane) - 1ull)); if(bi < PAIR_COLS) { P.baseLev[bi] = (short)(rel > 32767 ? 32767 : rel); P.baseG[bi] = kg[u]; } }
+                    carry += __popcll(bm);
+                    if(act && kl[u] != -1 && firstK >= 0 && rel >= 0 && rel < PAIR_COLS) { P.levS[rel] = ks[u]; P.levG[rel] = kg[u]; }
+                }
+            }
+            WSYNC();
+            #pragma unroll
+            for(int t = 0; t < PER; t++) {
+                const int j = t * 64 + lane;
+                if(j >= nSel) continue;
+                const int lj = selLv[t]; const unsigned char gj = (unsigned char)(selInfo[t] & 255); const int myIdx = (int)(((u32)selInfo[t] >> 8) & 0xFFFFu);
+                bool hit = false;
+                if(myIdx != 0xFFFF) {
+                    // the other chain's column of the same read base: same level (or both none) and same graph character
+                    const short bl = myIdx < PAIR_COLS ? P.baseLev[myIdx] : PAIR_NOCOL;
+                    if(bl != PAIR_NOCOL) {
+                        int want = lj == -1 ? (int)PAIR_NOLEVEL : lj - firstK;
+                        if(lj != -1 && (want > 32767 || want < -32766)) want = 32766;          // out of a chain's span: never stored (stored levels are below PAIR_COLS; a clipped one is 32767)
+                        hit = ((int)bl == want) && (P.baseG[myIdx] == gj);
+                    }
+                }
+                else if(lj != -1 && firstK >= 0) { const int li = lj - firstK; if(li >= 0 && li < PAIR_COLS) hit = (P.levS[li] == '_') && (P.levG[li] == gj); }
+                if(hit) mask[t] |= (1ull << k);
+            }
+        }
+        WSYNC();
+        #pragma unroll
+        for(int t = 0; t < PER; t++) {
+            const int j = t * 64 + lane;
+            if(j >= nSel) continue;
+            double Q = 0;                                   // alignmentPositionConfidences accumulated in combination order
+            if(m == 0) { for(int i1 = 0; i1 < n1; i1++) if(mask[t] & (1ull << i1)) for(int i2 = 0; i2 < n2; i2++) Q += LL[i1 * n2 + i2]; }
+            else       { for(int i1 = 0; i1 < n1; i1++) for(int i2 = 0; i2 < n2; i2++) if(mask[t] & (1ull << i2)) Q += LL[i1 * n2 + i2]; }
+            if(Q > 1) Q = 1;
+            B.sel_mapq[ob + j] = pair_phred(P, Q);
+        }
+    }
+}
+
+#ifdef HLALA_PAIR_TIMING      // build-time switch: cycles per phase of a wavefront (lists, combinations, maximum + posterior, per-position pass) -> counters[24..31]
+#define PAIR_T(i) do { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); tAcc[i] += t_ - tMark; tMark = t_; } while(0)
+#else
+#define PAIR_T(i) do { } while(0)
+#endif
+
 template <bool UNPAIRED>
 __device__ __forceinline__ void pair_finish(const DevGraph& G, const DevTables& T, const DevBatch& B, PairLds& P, double* __restrict__ LL,
-                                            const int p, const int n1, const int n2, const int nComb, const int lane, const int stride)
+                                            const int p, const int n1, const int n2, const int nComb, const int mxc, const PairChain& cA, const PairChain& cB, const int lane, const int stride, long long* tAcc, long long& tMark)
 {
     constexpr int NM = UNPAIRED ? 1 : 2;
         // ---- combination log likelihoods, row-major (i1, i2) (:3408-3506)
-        if(UNPAIRED) { for(int i = lane; i < nComb; i += 64) LL[i] = B.ext_ll[P.list[0][i]]; }                         // read1_extendedChains_log_likelihoods, :3743
+        if(UNPAIRED) { if(lane < nComb) LL[lane] = cA.ll; }                         // read1_extendedChains_log_likelihoods, :3743 (one chain list: nComb = n1 <= PAIR_CHAINS)
         else {
-            // what a combination needs of its two chains -- first / last two levels, strand, log likelihood -- is read once per CHAIN, lane k holding the
-            // k-th chain of either mate (one round trip), not once per combination through wave-uniform loads (three dependent round trips each)
-            int4 fA = make_int4(-1, -1, -1, -1), fB = make_int4(-1, -1, -1, -1); int rA = 0, rB = 0; double lA = 0.0, lB = 0.0;
-            if(lane < n1) { const int c = P.list[0][lane]; fA = *(const int4*)(B.ext_firstlast + 4 * (size_t)c); rA = B.chain_reverse[c]; lA = B.ext_ll[c]; }
-            if(lane < n2) { const int c = P.list[1][lane]; fB = *(const int4*)(B.ext_firstlast + 4 * (size_t)c); rB = B.chain_reverse[c]; lB = B.ext_ll[c]; }
+            // what a combination needs of its two chains -- first / last two levels, strand, log likelihood -- sits in lane k for the k-th chain of either mate (PairChain)
+            const int4 fA = cA.fl, fB = cB.fl; const int rA = cA.rev, rB = cB.rev; const double lA = cA.ll, lB = cB.ll;
             auto rl64 = [](double v, int l) -> double { const long long b = __double_as_longlong(v);
                 return __longlong_as_double((long long)(((u64)(u32)__builtin_amdgcn_readlane((int)(b >> 32), l) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)b, l))); };
             for(int i = 0; i < nComb; i++) {              // one combination at a time, the wave shares the insert-size term
@@ -142,13 +331,16 @@ __device__ __forceinline__ void pair_finish(const DevGraph& G, const DevTables& 
                 bool valid = false;
                 if(fa0 != -1 && fb0 != -1 && ra != rb) valid = (!ra) ? (fa0 < fb0) : (fa2 > fb2);          // alignerBase.cpp:213-244
                 double llIS = T.is_penalty;
+#ifndef PAIR_X_NOINSERT
                 if(valid) llIS = (fa0 < fb0) ? pair_insert_ll(G, T, fa2, fa3, fb0, fb1) : pair_insert_ll(G, T, fb2, fb3, fa0, fa1);        // alignerBase.cpp:294, 312
+#endif
                 double combined = rl64(lA, i1) + rl64(lB, i2);
                 combined += llIS;
                 if(lane == 0) LL[i] = combined;
             }
         }
         WSYNC();
+        PAIR_T(1);
         // ---- first maximum (Utilities::findVectorMax, Utilities.cpp:309-323)
         double mx = -1.0e300; int mi = 0x7FFFFFFF;
         for(int i = lane; i < nComb; i += 64) { double v = LL[i]; if(v > mx) { mx = v; mi = i; } }
@@ -177,87 +369,29 @@ __device__ __forceinline__ void pair_finish(const DevGraph& G, const DevTables& 
             WSYNC();
             mapQ = LL[bestI]; q1 = P.red[1]; q2 = P.red[2];
         }
+        bool svalid = false;
+        if(!UNPAIRED) {          // alignedReadPair_strandsValid of the selected chains (alignerBase.cpp:213-244)
+            const int fa0 = __builtin_amdgcn_readlane(cA.fl.x, best1), fa2 = __builtin_amdgcn_readlane(cA.fl.z, best1), fb0 = __builtin_amdgcn_readlane(cB.fl.x, best2), fb2 = __builtin_amdgcn_readlane(cB.fl.z, best2);
+            const bool ra = __builtin_amdgcn_readlane(cA.rev, best1) != 0, rb = __builtin_amdgcn_readlane(cB.rev, best2) != 0;
+            if(fa0 != -1 && fb0 != -1 && ra != rb) svalid = (!ra) ? (fa0 < fb0) : (fa2 > fb2);
+        }
         if(lane == 0) {
             B.pair_status[p] = 0; B.n_comb[p] = nComb; B.pair_ll[p] = mx; B.pair_mapq[p] = mapQ;
             if(UNPAIRED) { B.best_chain[p] = selA; B.mate_mapq[p] = mapQ; B.strands_valid[p] = 0; }                       // forReturn.mapQ = mapQ, :3921
             else {
             B.best_chain[2 * p] = selA; B.best_chain[2 * p + 1] = selB; B.mate_mapq[2 * p] = q1; B.mate_mapq[2 * p + 1] = q2;
-            const int* fa = B.ext_firstlast + 4 * selA; const int* fb = B.ext_firstlast + 4 * selB;
-            bool ra = B.chain_reverse[selA] != 0, rb = B.chain_reverse[selB] != 0; bool valid = false;
-            if(fa[0] != -1 && fb[0] != -1 && ra != rb) valid = (!ra) ? (fa[0] < fb[0]) : (fa[2] > fb[2]);
-            B.strands_valid[p] = valid ? 1 : 0;
+            B.strands_valid[p] = svalid ? 1 : 0;
             }
         }
-        // ---- per-position mapping quality of the selected chains (:4155-4311)
-        for(int m = 0; m < NM; m++) {
-            const int sel = m ? selB : selA; const int r = UNPAIRED ? p : 2 * p + m;
-            const int nSel = uni(B.ext_ncols[sel]); const size_t sb = (size_t)sel * stride; const size_t ob = (size_t)r * stride;
-            if(nComb == 1) {
-                unsigned char ph = phred_from_pcorrect(T, 1.0);
-                for(int j = lane; j < nSel; j += 64) B.sel_mapq[ob + j] = ph;
-                continue;
-            }
-            const int nl = m ? n2 : n1;
-            // columns of the selected chain handled by this lane: j = lane + 64*t
-            constexpr int PER = PAIR_COLS / 64;
-            u64 mask[PER];
-            int myIdx[PER];
-            for(int t = 0; t < PER; t++) { mask[t] = 0; myIdx[t] = -1; }
-            // read-base ordinal of each selected column (alignment orientation; strand is shared by all chains of the mate)
-            {
-                int carry = 0;
-                for(int t = 0; t < PER; t++) {
-                    int j = t * 64 + lane; bool isBase = j < nSel && B.ext_s[sb + j] != '_';
-                    u64 bm = __ballot(isBase);
-                    if(isBase) myIdx[t] = carry + __popcll(bm & ((1ull << lane) - 1ull));
-                    carry += __popcll(bm);
-                }
-            }
-            // level and graph character of the selected chain's columns: read once, not once per other chain
-            int selLv[PER]; unsigned char selG[PER];
-            for(int t = 0; t < PER; t++) { const int j = t * 64 + lane; selLv[t] = -1; selG[t] = 0; if(j < nSel) { selLv[t] = B.ext_level[sb + j]; selG[t] = B.ext_g[sb + j]; } }
-            for(int k = 0; k < nl; k++) {
-                const int ck = uni(P.list[m][k]); const int nk = uni(B.ext_ncols[ck]); const size_t kb = (size_t)ck * stride;
-                if(ck == sel) {
-                    // the selected chain agrees with itself in every column (base columns through their read-base ordinal, gap columns through their level)
-                    for(int t = 0; t < PER; t++) if(t * 64 + lane < nSel) mask[t] |= (1ull << k);
-                    continue;
-                }
-                const int firstK = uni(B.ext_firstlast[4 * ck + 0]);
-                WSYNC();
-                for(int i = lane; i < PAIR_COLS; i += 64) { P.basecol[i] = -1; P.levcol[i] = -1; }
-                WSYNC();
-                int carry = 0;
-                for(int j0 = 0; j0 < nk; j0 += 64) {
-                    int j = j0 + lane; bool act = j < nk;
-                    bool isBase = act && B.ext_s[kb + j] != '_';
-                    u64 bm = __ballot(isBase);
-                    if(isBase) { int bi = carry + __popcll(bm & ((1ull << lane) - 1ull)); if(bi < PAIR_COLS) P.basecol[bi] = (short)j; }
-                    carry += __popcll(bm);
-                    if(act) { int l = B.ext_level[kb + j]; if(l != -1 && firstK >= 0) { int li = l - firstK; if(li >= 0 && li < PAIR_COLS) P.levcol[li] = (short)j; } }
-                }
-                WSYNC();
-                for(int t = 0; t < PER; t++) {
-                    int j = t * 64 + lane;
-                    if(j >= nSel) continue;
-                    const int lj = selLv[t]; const unsigned char gj = selG[t];
-                    bool hit = false;
-                    if(myIdx[t] >= 0) { int col = P.basecol[myIdx[t]]; if(col >= 0) hit = (B.ext_level[kb + col] == lj) && (B.ext_g[kb + col] == gj); }
-                    else if(lj != -1 && firstK >= 0) { int li = lj - firstK; if(li >= 0 && li < PAIR_COLS) { int col = P.levcol[li]; if(col >= 0) hit = (B.ext_s[kb + col] == '_') && (B.ext_g[kb + col] == gj); } }
-                    if(hit) mask[t] |= (1ull << k);
-                }
-            }
-            WSYNC();
-            for(int t = 0; t < PER; t++) {
-                int j = t * 64 + lane;
-                if(j >= nSel) continue;
-                double Q = 0;                                   // alignmentPositionConfidences accumulated in combination order
-                if(m == 0) { for(int i1 = 0; i1 < n1; i1++) if(mask[t] & (1ull << i1)) for(int i2 = 0; i2 < n2; i2++) Q += LL[i1 * n2 + i2]; }
-                else       { for(int i1 = 0; i1 < n1; i1++) for(int i2 = 0; i2 < n2; i2++) if(mask[t] & (1ull << i2)) Q += LL[i1 * n2 + i2]; }
-                if(Q > 1) Q = 1;
-                B.sel_mapq[ob + j] = phred_from_pcorrect(T, Q);
-            }
-        }
+        PAIR_T(2);
+#ifndef PAIR_X_NOPOS
+        if(mxc <= 192) pair_positions<UNPAIRED, 3>(B, P, LL, p, n1, n2, nComb, best1, best2, cA, cB, lane, stride);
+        else pair_positions<UNPAIRED, PAIR_COLS / 64>(B, P, LL, p, n1, n2, nComb, best1, best2, cA, cB, lane, stride);
+#endif
+        PAIR_T(nComb == 1 ? 3 : 4);
+#ifdef HLALA_PAIR_TIMING
+        tAcc[nComb == 1 ? 5 : 6] += 1;
+#endif
 }
 
 // UNPAIRED: one read per unit (processBAM::alignOneLongRead :3618-3838 selects the first maximum of the chains' log likelihoods;
@@ -277,6 +411,11 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
     // pairs are drawn eight at a time (one same-address atomic per pair serialises the grid at the L2)
     constexpr int CHUNK = 8;
     int sweep = 0;
+    for(int i = lane; i < 256; i += 64) P.phredThr[i] = T.phred_thr[i];
+    WSYNC();
+    if(lane == 0) P.ired[7] = (int)pair_phred(P, 1.0);
+    WSYNC();
+    long long tAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tMark = clock64();
     for(;;) {
         int p0 = 0;
         if(deferMode == 2) { p0 = ((int)blockIdx.x + sweep * (int)gridDim.x) * CHUNK; sweep++; }      // second pass (a few thousand pairs of a million): the waves sweep the flags, no draws
@@ -300,6 +439,10 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
         for(int p = p0; p < pEnd; p++) {
         const int hq = p - p0;
         if(deferMode) { const bool df = __builtin_amdgcn_readlane(hDf, hq) != 0; if(df == (deferMode == 1)) continue; }
+#if defined(PAIR_X_LEVEL) && PAIR_X_LEVEL == 1
+        if(lane == 0) B.pair_status[p] = __builtin_amdgcn_readlane(hC[0], hq) & 0;
+        continue;
+#endif
         // ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains), error propagation
         int bad = 0;
         int cLo[NM], cHi[NM], stF[NM], ncF[NM];
@@ -308,6 +451,10 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
         // status and length of the first 64 chains of both mates: one round trip (a pair with more alignments per mate loops on)
         #pragma unroll
         for(int m = 0; m < NM; m++) { const int c = cLo[m] + lane; stF[m] = 1; ncF[m] = 0; if(c < cHi[m]) { stF[m] = B.ext_status[c]; ncF[m] = B.ext_ncols[c]; } }
+        // ... and, in the same round trip, everything else the pairing reads of these chains (PairChain; chains that turn out not to be listed cost a few unused loads)
+        PairChain cF[NM];
+        #pragma unroll
+        for(int m = 0; m < NM; m++) { const int c = cLo[m] + lane; cF[m].fl = make_int4(-1, -1, -1, -1); cF[m].rev = 0; cF[m].nk = 0; cF[m].row = 0; cF[m].ll = 0.0; if(c < cHi[m]) { cF[m] = pair_chain_load(B, c); } }
         int mxc = 0;                 // longest listed chain: the per-position pass below holds PAIR_COLS columns per chain (long reads come with one alignment each: nComb == 1, any length)
         #pragma unroll
         for(int m = 0; m < NM; m++) {
@@ -318,7 +465,7 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
                 if(b0 == c0) { st = stF[m]; nc = ncF[m]; } else { st = 1; nc = 0; if(c < c1) { st = B.ext_status[c]; nc = B.ext_ncols[c]; } }
                 if(__ballot(st < 0)) bad = 1;
                 u64 okm = __ballot(st == HLALA_CHAIN_OK);
-                if(st == HLALA_CHAIN_OK) { int pos = cnt + __popcll(okm & ((1ull << lane) - 1ull)); if(pos < PAIR_CHAINS) { P.list[m][pos] = c; mxc = max(mxc, nc); } }
+                if(st == HLALA_CHAIN_OK) { int pos = cnt + __popcll(okm & ((1ull << lane) - 1ull)); if(pos < PAIR_CHAINS) { P.list[m][pos] = c; P.src[m][pos] = (unsigned char)lane; mxc = max(mxc, nc); } }
                 cnt += __popcll(okm);
             }
             if(lane == 0) P.nlist[m] = cnt;
@@ -331,16 +478,33 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
         if(!bad && nCombLL > PAIR_COMB) bad = 1;
         mxc = wave_max_i32(mxc);
         if(!bad && nCombLL > 1 && mxc > PAIR_COLS) bad = 1;
+#if defined(PAIR_X_LEVEL) && PAIR_X_LEVEL == 2
+        { PairChain z = pair_chain_from_lane(cF[0], P.src[0][lane & 1]); if(lane == 0) B.pair_status[p] = (z.fl.x + z.rev + z.nk + z.row + (int)z.ll + cF[NM - 1].fl.y + n1 + n2) & 0; }
+        continue;
+#endif
         if(bad) {
             if(lane == 0) { B.pair_status[p] = -1; if(UNPAIRED) B.best_chain[p] = -1; else { B.best_chain[2 * p] = -1; B.best_chain[2 * p + 1] = -1; } B.n_comb[p] = 0; }
         } else {
         const int nComb = (int)nCombLL;
-        if(nComb <= PAIR_COMB_LDS) pair_finish<UNPAIRED>(G, T, B, P, P.LL, p, n1, n2, nComb, lane, stride);
-        else pair_finish<UNPAIRED>(G, T, B, P, bigLL + (size_t)blockIdx.x * PAIR_COMB, p, n1, n2, nComb, lane, stride);
+        // the listed chains' facts into list order: lane k <- the lane that loaded chain list[k] (a mate with more than 64 alignments: loaded again through the list)
+        PairChain cL[2];
+        #pragma unroll
+        for(int m = 0; m < NM; m++) {
+            const int nl = m ? n2 : n1;
+            if(cHi[m] - cLo[m] <= 64) cL[m] = pair_chain_from_lane(cF[m], lane < nl ? (int)P.src[m][lane] : lane);
+            else { cL[m].fl = make_int4(-1, -1, -1, -1); cL[m].rev = 0; cL[m].nk = 0; cL[m].row = 0; cL[m].ll = 0.0; if(lane < nl) cL[m] = pair_chain_load(B, P.list[m][lane]); }
+        }
+        if(UNPAIRED) cL[1] = cL[0];
+        PAIR_T(0);
+        if(nComb <= PAIR_COMB_LDS) pair_finish<UNPAIRED>(G, T, B, P, P.LL, p, n1, n2, nComb, mxc, cL[0], cL[1], lane, stride, tAcc, tMark);
+        else pair_finish<UNPAIRED>(G, T, B, P, bigLL + (size_t)blockIdx.x * PAIR_COMB, p, n1, n2, nComb, mxc, cL[0], cL[1], lane, stride, tAcc, tMark);
         }   // !bad
         WSYNC();
         }
     }
+#ifdef HLALA_PAIR_TIMING
+    if(lane == 0 && deferMode != 2) for(int i = 0; i < 7; i++) atomicAdd(&B.counters[24 + i], (u64)tAcc[i]);
+#endif
 }
 
 // Per-pair post-processing (processBAM.cpp:2411-2446): coverage counters over the columns of both selected chains and the
@@ -366,7 +530,7 @@ __global__ __launch_bounds__(64) void k_post_pairs(const DevBatch* __restrict__ 
                     const int ch = uni(B.best_chain[B.unpaired ? p : 2 * p + m]);
                     if(ch < 0 || ch >= B.n_chains) continue;
                     const int n = uni(B.ext_ncols[ch]);
-                    const size_t so = (size_t)ch * stride;
+                    const size_t so = row_base(B, ch);
                     for(int j = lane; j < n; j += 64) {
                         const int lv = B.ext_level[so + j];
                         if(lv != -1 && B.ext_g[so + j] != '_' && lv >= 0 && lv < nCov) atomicAdd(&cov[lv], 1);          // :2414-2418
@@ -399,7 +563,7 @@ __global__ void k_gather_selected(const DevBatch* __restrict__ Bp, int r0, int n
     if(ch >= 0 && ch < B.n_chains) n = B.ext_ncols[ch];
     if(n < 0) n = 0;
     if(threadIdx.x == 0) oN[row] = n;
-    const size_t so = (size_t)(ch >= 0 ? ch : 0) * stride, dofs = (size_t)row * stride;
+    const size_t so = (n > 0 ? row_base(B, ch) : (size_t)0), dofs = (size_t)row * stride;
     for(int j = threadIdx.x; j < stride; j += blockDim.x) {
         const bool in = j < n;
         oLevel[dofs + j] = in ? B.ext_level[so + j] : 0; oEdge[dofs + j] = in ? B.ext_edge[so + j] : 0;
@@ -424,7 +588,7 @@ __global__ void k_gather_packed(const DevBatch* __restrict__ Bp, int nReads, con
     for(int r = blockIdx.x; r < nReads; r += gridDim.x) {
         const long long d0 = off[r]; const int n = (int)(off[r + 1] - d0);
         if(n <= 0) continue;
-        const size_t so = (size_t)B.best_chain[r] * B.stride, mo = (size_t)r * B.stride;
+        const size_t so = row_base(B, B.best_chain[r]), mo = (size_t)r * B.stride;
         for(int j = threadIdx.x; j < n; j += blockDim.x) {
             if(oLevel) oLevel[d0 + j] = B.ext_level[so + j];
             if(oEdge) oEdge[d0 + j] = B.ext_edge[so + j];

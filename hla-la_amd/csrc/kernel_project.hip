@@ -728,7 +728,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                     mxN = wave_max_i32(mxN); mxE = wave_max_i32(mxE);
                     if(mxN <= RT_SN && mxE <= RT_CE) {
                         deferred = true;
-                        const size_t cb = (size_t)c * stride;
+                        const size_t cb = row_base(B, c);
                         for(int j = lane; j < n1; j += 64) { B.seed_level[cb + j] = LC::get(P.lvl[cur][j], lvBase); B.seed_g[cb + j] = P.g[cur][j]; B.seed_s[cb + j] = P.s[cur][j]; }
                         for(int i = lane; i < nDef; i += 64) B.seed_edge[cb + i] = (int)P.colInfo[i];
                         unsigned short* lvRow = (unsigned short*)(B.ext_level + cb); unsigned short* sgRow = (unsigned short*)(B.ext_edge + cb);
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 int zsel = 0x7FFFFFFF;
                 for(int z = lane; z < tm; z += 64) if(lastS[z] == bestS) { zsel = min(zsel, z); }
                 zsel = -wave_max_i32(-zsel);                                                   // *(runningN.begin()): smallest node among the maxima (:2867)
-                const size_t cb = (size_t)c * stride;
+                const size_t cb = row_base(B, c);
                 if(par) {
                     // every segment is traced from its right cut node (the last one from the selected node); the other column
                     // buffer takes the chosen edge per column, then all lanes emit (edge ids are independent HBM reads)
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __res
         u64 pend = __ballot(cq >= 0 && B.seed_status[cq] == CHAIN_RETHREAD_PENDING);
         for(; pend; pend &= pend - 1) {
             const int c = __builtin_amdgcn_readlane(cq, __ffsll((long long)pend) - 1);
-            const size_t cb = (size_t)c * stride;
+            const size_t cb = row_base(B, c);
             const int* st = (const int*)B.dp_items + (size_t)c * 16;
             int sv = lane < 6 ? st[lane] : 0;
             const int level0 = __builtin_amdgcn_readlane(sv, 0), nDef = __builtin_amdgcn_readlane(sv, 1), nodeBase = __builtin_amdgcn_readlane(sv, 2), nb = __builtin_amdgcn_readlane(sv, 3),

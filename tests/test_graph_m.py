@@ -221,6 +221,43 @@ def test_mixed_reads_match_oracle(pkg, oracle, world_m):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(), dict(HLALA_ROWS_ALL="1"), dict(HLALA_STITCH_BY_ROW="0"), dict(HLALA_SIDE_AFTER_PAIR="1")],
+                         ids=["rows-for-filtered-chains", "a-row-per-chain", "stitch-by-chain-number", "side-classes-after-pairing"])
+def test_column_rows_only_for_chains_that_pass_the_filters(pkg, oracle, world_m, monkeypatch, env):
+    """The column arrays of a batch (seed_* / ext_*: 20 bytes per column slot) hold a row per chain that passed the strand / duplicate-coordinate filters
+    (processBAM.cpp:3200-3240), in position order; the filters and the position order run when the batch is created (batch.h: chain_row).  Seed chains,
+    extended chains and pairs against the oracle with that layout, with a row per chain (HLALA_ROWS_ALL=1: rounds 1-4), with the stitch pass walking chain numbers
+    instead of rows, and with the side-stream classes queued behind the main stream's pairing pass; the device memory of the batch shrinks with the rows."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    b = synth.make_batch_m(world_m, 1500, seed=23, frac_gene=0.5)
+    kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=9, max_columns=384)
+    exp = oracle(world_m["graph"], world_m["contigs"], **kw).align_batch(b)
+    ctx = pkg.Context(world_m["graph"], world_m["contigs"], **kw)
+    gb = ctx.batch(b)
+    gb.align()
+    compare_chains(gb.chains(0), exp["seeds"], b["n_chains"], check_ll=False, check_dp=False, label="stage A")
+    compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stage B")
+    got = gb.pairs()
+    for k in PAIR_INT:
+        assert np.array_equal(got[k], exp["pairs"][k]), k
+    assert np.allclose(got["pair_ll"], exp["pairs"]["pair_ll"], rtol=1e-12, atol=0)
+    assert np.allclose(got["mate_mapq"], exp["pairs"]["mate_mapq"], rtol=1e-9, atol=1e-15)
+    gb.align()                                   # a second alignment of the same batch (the filters ran once, at creation)
+    got2 = gb.pairs()
+    assert np.array_equal(got2["best_chain"], got["best_chain"]) and np.array_equal(got2["col_level"], got["col_level"])
+    mem = (C.c_ulonglong * 4)()
+    ctx.lib.hlala_debug_memory.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_ulonglong)]
+    assert ctx.lib.hlala_debug_memory(ctx.h, gb.b, mem) == 0
+    n_ok = int((exp["seeds"]["status"] != 1).sum() - (exp["seeds"]["status"] == 2).sum())          # chains the filters let through (1: wrong strand, 2: duplicate coordinates)
+    if env.get("HLALA_ROWS_ALL") == "1":
+        assert int(mem[1]) == b["n_chains"]
+    else:
+        assert int(mem[1]) == n_ok < 0.7 * b["n_chains"]
+        assert int(mem[0]) < 0.6 * (b["n_chains"] * 384 * 21)          # (a row per chain would be 21 bytes x 384 columns x chains)
+
+
+@pytest.mark.gpu
 def test_two_batches_in_flight_equal_one_at_a_time(pkg, oracle):
     """hlala_align_batch finishes the wide DP classes and the pairs that own them on the context's second stream; a caller may align the next batch
     before fetching the previous one (include/hlala_gpu.h).  Dense windows, so that a good part of the pairs takes that path: every array of both
