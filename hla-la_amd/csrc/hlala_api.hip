@@ -860,8 +860,9 @@ int hlala_extend_chains(hlala_ctx* c, hlala_batch* b) { return extend_impl(c, b,
 // stream stitches and pairs everything else and is then free for the caller's next batch.  b->evDone orders later users of the batch behind the side work.
 // phase (fused only; hlala_align_batch): 0 = the whole stage, the side-stream classes forked off as soon as the 64-lane class is done; 1 = the main-stream part alone (classes
 // before DP_SIDE_TIER, first stitch pass), 2 = the side-stream part alone (the later classes, second stitch pass) -- queued by hlala_align_batch AFTER the main stream's
-// pairing pass: k_stitch_chains and k_pair_chains are short, latency-bound kernels, and beside the wide class (seven blocks of four wavefronts per CU: 28 of a CU's 32
-// wavefront slots) they ran on one wavefront per SIMD: 20.9 ms for a pairing pass that takes 4.1 ms alone (profiles/r05_experiments.txt).
+// pairing pass: k_pair_chains is a short, latency-bound kernel that needs 6 KB of LDS per wavefront, and beside the wide class (seven blocks of 22 KB per CU: 154 of a
+// CU's 160 KB) hardly a block of it fits: 20.9 ms for a pairing pass that takes 4.1 ms alone (profiles/r05_experiments.txt, 19).  Not the default: the next batch's
+// projection (11.7 KB per block) then meets the wide class instead.
 static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
 {
     DEV_GUARD(c);
