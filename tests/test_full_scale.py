@@ -140,15 +140,16 @@ def test_densest_pairs_go_through_the_in_memory_class(pkg, oracle):
 
 @pytest.mark.gpu
 def test_results_do_not_depend_on_which_kernel_ran_a_dp_call_at_scale(pkg, monkeypatch):
-    """An oracle-free cross-check at size: 262 144 pairs on a 5 M-level Graph M world -- 0.95 M DP calls, 0.39 M of them in the band kernels -- aligned three times: with the
-    default build, with the band kernels switched off (every call in the hashed-frontier classes, extensionAligner.cpp:335-1556 as kernel_dp.hip runs it) and with the one-edge gap
-    paths kept in the device's jump tables (flat_graph.hpp).  Every pair record, every column of every selected alignment, the per-position qualities and the work counters
+    """An oracle-free cross-check at size: 262 144 pairs on a 5 M-level Graph M world -- 0.95 M DP calls, 0.39 M of them in the band kernels -- aligned four times: with the
+    default build, with the band kernels switched off (every call in the hashed-frontier classes, extensionAligner.cpp:335-1556 as kernel_dp.hip runs it), with the one-edge gap
+    paths kept in the device's jump tables (flat_graph.hpp), and with a column row for every chain instead of one per chain that passed the filters (batch.h: chain_row; the
+    stitch pass then walks chain numbers, the side-stream classes are queued behind the pairing pass).  Every pair record, every column of every selected alignment, the per-position qualities and the work counters
     (DP calls, iterations, candidate cells, edges) are identical; the log likelihoods are bit-identical too (the same terms in the same order)."""
     w = synth.make_world_m(seed=2, n_levels=5_000_000)
     b = synth.make_batch_m(w, 262144, seed=4242, frac_gene=0.3)
     kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=2024, max_columns=384)
     results = []
-    for env in (dict(), dict(HLALA_DP_BAND="0"), dict(HLALA_UNIT_JUMPS="1")):
+    for env in (dict(), dict(HLALA_DP_BAND="0"), dict(HLALA_UNIT_JUMPS="1"), dict(HLALA_ROWS_ALL="1", HLALA_SIDE_AFTER_PAIR="1")):
         with monkeypatch.context() as m:
             for k, v in env.items():
                 m.setenv(k, v)
