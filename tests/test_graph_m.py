@@ -228,6 +228,8 @@ def test_column_rows_only_for_chains_that_pass_the_filters(pkg, oracle, world_m,
     (processBAM.cpp:3200-3240), in position order; the filters and the position order run when the batch is created (batch.h: chain_row).  Seed chains,
     extended chains and pairs against the oracle with that layout, with a row per chain (HLALA_ROWS_ALL=1: rounds 1-4), with the stitch pass walking chain numbers
     instead of rows, and with the side-stream classes queued behind the main stream's pairing pass; the device memory of the batch shrinks with the rows."""
+    for k in ("HLALA_ROWS_ALL", "HLALA_STITCH_BY_ROW", "HLALA_SIDE_AFTER_PAIR"):
+        monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     b = synth.make_batch_m(world_m, 1500, seed=23, frac_gene=0.5)
