@@ -221,14 +221,14 @@ def test_mixed_reads_match_oracle(pkg, oracle, world_m):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [dict(), dict(HLALA_ROWS_ALL="1"), dict(HLALA_STITCH_BY_ROW="0"), dict(HLALA_SIDE_AFTER_PAIR="1")],
-                         ids=["rows-for-filtered-chains", "a-row-per-chain", "stitch-by-chain-number", "side-classes-after-pairing"])
+@pytest.mark.parametrize("env", [dict(), dict(HLALA_ROWS_ALL="1"), dict(HLALA_STITCH_BY_ROW="0"), dict(HLALA_SIDE_AFTER_PAIR="1"), dict(HLALA_LOCALITY="0")],
+                         ids=["rows-for-filtered-chains", "a-row-per-chain", "stitch-by-chain-number", "side-classes-after-pairing", "no-position-order"])
 def test_column_rows_only_for_chains_that_pass_the_filters(pkg, oracle, world_m, monkeypatch, env):
     """The column arrays of a batch (seed_* / ext_*: 20 bytes per column slot) hold a row per chain that passed the strand / duplicate-coordinate filters
     (processBAM.cpp:3200-3240), in position order; the filters and the position order run when the batch is created (batch.h: chain_row).  Seed chains,
     extended chains and pairs against the oracle with that layout, with a row per chain (HLALA_ROWS_ALL=1: rounds 1-4), with the stitch pass walking chain numbers
-    instead of rows, and with the side-stream classes queued behind the main stream's pairing pass; the device memory of the batch shrinks with the rows."""
-    for k in ("HLALA_ROWS_ALL", "HLALA_STITCH_BY_ROW", "HLALA_SIDE_AFTER_PAIR"):
+    instead of rows, with the side-stream classes queued behind the main stream's pairing pass, and without the position order (HLALA_LOCALITY=0: input order, a row per chain); the device memory of the batch shrinks with the rows."""
+    for k in ("HLALA_ROWS_ALL", "HLALA_STITCH_BY_ROW", "HLALA_SIDE_AFTER_PAIR", "HLALA_LOCALITY"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -252,7 +252,7 @@ def test_column_rows_only_for_chains_that_pass_the_filters(pkg, oracle, world_m,
     ctx.lib.hlala_debug_memory.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_ulonglong)]
     assert ctx.lib.hlala_debug_memory(ctx.h, gb.b, mem) == 0
     n_ok = int((exp["seeds"]["status"] != 1).sum() - (exp["seeds"]["status"] == 2).sum())          # chains the filters let through (1: wrong strand, 2: duplicate coordinates)
-    if env.get("HLALA_ROWS_ALL") == "1":
+    if env.get("HLALA_ROWS_ALL") == "1" or env.get("HLALA_LOCALITY") == "0":          # (without a position order the chains keep their input order and a row each)
         assert int(mem[1]) == b["n_chains"]
     else:
         assert int(mem[1]) == n_ok < 0.7 * b["n_chains"]
