@@ -441,7 +441,7 @@ def main():
                        "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "16lane_jump_free": int(st.n_dp_jump_free),
                                                    "band": int(st.n_dp_band), "band_failed_over_to_16lane": int(st.n_dp_band_failed), "jump_free_met_a_jump_and_went_to_the_general_list": int(st.n_dp_jump_free_failed)},
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "roofline": {"bound": "latency", "bound_note": "instruction issue + dependent LDS / L2 round trips of an integer frontier DP (HBM is 1-2 % busy); achieved / peak / frac are the HBM figures the metric asks for, not the binding resource", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,
                          "first_class": {"kernels": "k_dp_band<16> + <32> + <64> + k_dp<DpTinyJF, 0> + k_dp<DpTiny, 0>", "ms": first_class_ms, "achieved": bpp * args.pairs / (first_class_ms * 1e-3) / 1e9,
                                          "by_kernel_ms": {k: m for k, m in kern[:3]}},
@@ -468,6 +468,8 @@ def main():
             if args.long_reads > 0:
                 try:
                     out["long_reads"] = long_reads(args, P, synth, w)
+                except AssertionError:          # the timed reads differ from the oracle: a throughput of wrong results is not reported
+                    raise
                 except Exception as e:
                     out["long_reads"] = {"error": repr(e)}
             if args.e2e_pairs > 0 and args.graph == "m":
@@ -734,8 +736,8 @@ def long_reads(args, P, synth, w):
         checked = 0
         try:
             checked = long_reads_parity(args, gbs[0], bs[0], w, min(args.long_reads_check, bs[0]["n_pairs"]))
-        except Exception as e:
-            checked = {"error": repr(e)}
+        except (OSError, ImportError, subprocess.CalledProcessError) as e:      # no oracle on this machine (not built / no compiler): the check is skipped and says so;
+            checked = {"skipped": repr(e)}                                      # a DIFFERENCE from the oracle (AssertionError) is not caught: the bench fails, no line is printed
         for g in gbs:
             g.close()
         # roofline of the leg: SURVEY 8(d)'s per-unit bytes for ONE read and ONE chain (packed bases + qualities, the record, translation + reference base per column, the
@@ -745,7 +747,7 @@ def long_reads(args, P, synth, w):
         b_read = (rl / 2 + rl) + (32 + 5 * rl + 5 * e_mean * cols) + 7 * cols + 64
         proj_s = float(sum(s_.ms_project for s_ in sts)) * 1e-3
         ach = b_read * n / max(proj_s, 1e-9) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_project_chains<ProjLdsLong>", "kernel_ms_sum": proj_s * 1e3, "algorithmic_bytes_per_read": b_read, "columns_per_read": cols, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+        roof = {"bound": "latency", "bound_note": "the level loop of one wavefront per read (waits most of its cycles); achieved / peak / frac are the HBM figures the metric asks for", "kernel": "k_project_chains<ProjLdsLong>", "kernel_ms_sum": proj_s * 1e3, "algorithmic_bytes_per_read": b_read, "columns_per_read": cols, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                 "frac": ach / 8000.0, "traffic": None, "note": "HIP events of the batches' projection stage; the measured HBM traffic and the SQ counters of the kernel: profiles/r05_long_*"}
         tl = os.path.join(ROOT, "profiles", "r05_long_traffic.json")
         if os.path.exists(tl):

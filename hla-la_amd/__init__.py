@@ -673,10 +673,12 @@ def load_library(path: str | None = None):
 
 
 ABI_VERSION = 4              # HLALA_ABI_VERSION of include/hlala_gpu.h
-BUILD_LANE_CLASS = 1         # hlala_build_flags(): the lane-per-DP class is compiled in (make EXTRA=-DHLALA_WITH_LANE_CLASS)
+DEBUG_WC_N, DEBUG_WC_BAND_FETCH, DEBUG_WC_BAND_WHY, DEBUG_WC_BAND_TIED = 72, 48, 62, 68      # include/hlala_gpu.h: debug section
+BUILD_AGENT_RELEASE = 2      # hlala_build_flags(): the in-memory DP class releases at agent scope (make EXTRA=-DHLALA_DP_AGENT_RELEASE)
 
 
 EXPORTED_SYMBOLS = [
+    "hlala_debug_work_counters", "hlala_debug_dp_items", "hlala_debug_counters", "hlala_debug_buffer", "hlala_debug_memory",
     "hlala_create", "hlala_destroy", "hlala_last_error", "hlala_graph_get_info", "hlala_graph_get_nodes",
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
     "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_set_first_chain", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
@@ -969,6 +971,21 @@ class Batch:
         o, d = alloc_exon_positions_out(o.n_reads, o.n_pos, o.n_chars)
         self.ctx._check(self.ctx.lib.hlala_exon_positions(self.ctx.h, self.b, C.byref(L), C.byref(o)), "hlala_exon_positions")
         return trim_exon_positions(o, d)
+
+    def work_counters(self):
+        """B.work_counter of the batch's last stages (diagnostics; indices: DEBUG_WC_* = include/hlala_gpu.h's HLALA_DEBUG_WC_*)."""
+        wc = (C.c_int * DEBUG_WC_N)()
+        self.ctx.lib.hlala_debug_work_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        self.ctx._check(self.ctx.lib.hlala_debug_work_counters(self.ctx.h, self.b, wc, DEBUG_WC_N), "hlala_debug_work_counters")
+        return np.array(wc[:], np.int64)
+
+    def dp_items(self):
+        """(items [2 * n_chains, 8], retry lists [16 * n_chains]) of the batch's last extension stage (hlala_debug_dp_items)."""
+        nc = int(self.n_chains)
+        items = np.zeros((2 * nc, 8), np.int32); retry = np.zeros(16 * nc, np.int32)
+        self.ctx.lib.hlala_debug_dp_items.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
+        self.ctx._check(self.ctx.lib.hlala_debug_dp_items(self.ctx.h, self.b, items.ctypes.data, items.nbytes, retry.ctypes.data, retry.nbytes), "hlala_debug_dp_items")
+        return items, retry
 
     def stats(self) -> BatchStats:
         st = BatchStats()

@@ -65,8 +65,8 @@ struct DevBatch {
     u64* counters;                  // [32]
     int* work_counter;              // [WC_N] dynamic work distribution: [0] stage A, [2] stage C, [7] chains stitched, [8]/[9] left / right DP items,
                                     //      [1]/[10] left / right items fetched, [12..35] retry lists (count, fetched) per tier 1..6 and direction
-    int* retry_list;                // [16*n_chains] DP items that outgrew a capacity class: (tier 1..6) x (left, right) x n_chains; then (left, right) x n_chains: the
-                                    //      items the lane-per-DP class passed on to the 16-lane class (work_counter[40..45], kernel_dp_lane.hip)
+    int* retry_list;                // [16*n_chains] DP items that outgrew a capacity class: (tier 1..6) x (left, right) x n_chains; rows 14 / 15: the fail-over lists of the band kernels and the
+                                    //      jump-free instantiation (WC_FO_COUNT)
     uint8_t* pair_deferred;         // [n_pairs] 1: a DP call of the pair went to the in-memory class; with the fused entry point its chains are stitched and
                                     //           the pair is scored in a second pass, after that class (which runs on a side stream next to the first pass)
     // ---- position order of the chains (kernel_order.hip): the kernels that walk the graph take their chains in this order, so that the work in flight at
@@ -104,7 +104,7 @@ enum { DPL_BAND16 = 0, DPL_BAND32 = 2, DPL_BAND64 = 4, DPL_JF = 6, DPL_GEN = 8, 
 __host__ __device__ inline int dpl_of_class(int cls) { return cls == 0 ? DPL_GEN : (cls == 1 ? DPL_JF : (cls == 2 ? DPL_BAND16 : (cls == 3 ? DPL_BAND32 : DPL_BAND64))); }
 // ---- B.work_counter (WC_N ints): [0] stage A, [1] / [10] left / right general items fetched, [2] stage C, [4] / [5] jump-free items fetched, [6] jump-free calls (statistics),
 // [7] chains stitched, [8] / [9] left / right DP calls, [12..35] retry lists of tiers 1..6 (count, fetched) x (left, right), [36] / [37] second stitch / pairing pass,
-// [40..45] lists of the lane-per-DP class; round 5: items fetched by the three band kernels (left, right each), the fail-over list's counts and fetch counters, band calls that
+// [40..45] unused (the lane-per-DP class of round 3); round 5: items fetched by the three band kernels (left, right each), the fail-over list's counts and fetch counters, band calls that
 // failed over, band calls listed, jump-free calls that met a jump, and why band calls failed ([WC_BAND_WHY + 2 .. + 5]: past the staged levels, past the linear run, too
 // many iterations, too many tied end cells)
 enum { WC_BAND_FETCH = 48, WC_FO_COUNT = 54, WC_FO_FETCH = 56, WC_BAND_FAILED = 58, WC_BAND_CALLS = 59, WC_JF_FAILED = 60, WC_BAND_WHY = 62, WC_BAND_TIED = 68, WC_N = 72 };

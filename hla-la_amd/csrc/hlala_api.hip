@@ -3,7 +3,9 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <algorithm>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <unordered_map>
@@ -16,9 +18,6 @@
 
 // unity build: the kernels live in their own files but are compiled in this translation unit
 #include "kernel_dp.hip"
-#ifdef HLALA_WITH_LANE_CLASS      // the lane-per-DP class lost its A/B and is not part of the default library: make EXTRA=-DHLALA_WITH_LANE_CLASS
-#include "kernel_dp_lane.hip"
-#endif
 #include "kernel_project.hip"
 #include "kernel_order.hip"
 #include "kernel_pair.hip"
@@ -66,6 +65,7 @@ struct hlala_ctx {
     std::unordered_map<void*, size_t> block_bytes;
     std::multimap<size_t, void*> pool;
     size_t pool_bytes = 0;
+    std::mutex pool_mu;              // the pool and block_bytes: this context's thread, and any thread that meets an out-of-memory error on the device (device_malloc_retry)
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
     int jf_margin = 16;      // (measured 4 / 8 / 16 / 48: 16-lane + 32-lane class 105.6 / 104.1 / 103.4 / 104.1 ms -- a tight bound sends more calls to the cheap instantiation and more of them on to the 32-lane class) levels beyond the read bases left that a jump-free call is taken to reach (kernel_dp.hip: k_dp_items)
@@ -76,7 +76,6 @@ struct hlala_ctx {
     bool band_risky = false;      // HLALA_DP_BAND_RISKY=1 (tests: force fail-overs of the band kernel)
     int band_grid = 0, band_margin = 8;      // the band kernel in front of the 16-lane class (kernel_dp_band.hip): blocks (0: HLALA_DP_BAND=0) and the levels beyond the read bases left a call is taken to reach (HLALA_DP_BAND_MARGIN)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
-    char* lane_slabs = nullptr; int lane_grid = 0;      // the lane-per-DP class in front of the 16-lane class (kernel_dp_lane.hip); lane_grid 0: not used (HLALA_DP_LANE=0)
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
     char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
     char* rethread_slabs = nullptr; size_t rethread_slab_bytes = 0; int rethread_grid = 0;      // k_rethread_chains: back pointers of one chain per wave (short reads; HLALA_RETHREAD=0 turns the kernel off)
@@ -109,7 +108,7 @@ struct hlala_batch {
     // timing events of THIS batch (created with its first stage call): ev = start / end per stage, [7] / [6] / [10] / [8] = before the 16-lane class / after it /
     // after the 64-lane class / after the last class; evC = start / end of each DP class on the stream it ran on; evSide[0] fork point on the main stream,
     // [1] first side-stream class starts, [6] second pairing pass done
-    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; hipEvent_t evLane[2]{}; hipEvent_t evJF = nullptr; /* end of the jump-free instantiation of the 16-lane class */ hipEvent_t evBand[2]{}; /* the band kernel */ bool band_used = false; bool eventsMade = false; bool lane_used = false;
+    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; hipEvent_t evJF = nullptr; /* end of the jump-free instantiation of the 16-lane class */ hipEvent_t evBand[2]{}; /* the band kernel */ bool band_used = false; bool eventsMade = false;
     uint32_t first_chain = 0;    // absolute index of the batch's chain 0 in the caller's numbering (hlala_batch_set_first_chain): offsets the random seeds
     float ms[3] = {0, 0, 0};
 };
@@ -145,7 +144,6 @@ static int batch_events(hlala_ctx* c, hlala_batch* b)
     for(int i = 0; i < 14; i++) HIP_TRY(c, hipEventCreate(&b->ev[i]));
     for(int i = 0; i < 8; i++) HIP_TRY(c, hipEventCreate(&b->evSide[i]));
     for(int i = 0; i < 14; i++) HIP_TRY(c, hipEventCreate(&b->evC[i / 2][i % 2]));
-    for(int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreate(&b->evLane[i]));
     HIP_TRY(c, hipEventCreate(&b->evJF));
     for(int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreate(&b->evBand[i]));
     HIP_TRY(c, hipEventCreateWithFlags(&b->evMain, hipEventDisableTiming));
@@ -193,22 +191,47 @@ static size_t pool_class(size_t bytes)
     const size_t g = (size_t)1 << (lg - 4);
     return (bytes + g - 1) & ~(g - 1);
 }
+// Every live context is registered: a context parks up to 176 GB of a 288 GB device, and an allocation of ANOTHER context on the same device (a second hlala_create,
+// its slabs, its batches) must be able to get that memory back.  A context's pool is touched by its own thread (pool_malloc / pool_release) and, on an out-of-memory
+// error anywhere on the device, by the thread that met the error: pool_mu orders the two.
+static std::mutex g_ctx_mu;
+static std::vector<hlala_ctx*> g_ctxs;
+static void pool_trim_locked(hlala_ctx* c)
+{
+    for(auto& kv : c->pool) { c->block_bytes.erase(kv.second); (void)hipFree(kv.second); }
+    c->pool.clear(); c->pool_bytes = 0;
+}
+// hipMalloc; on failure the blocks parked by every context of this device are released and the call is tried once more (`self`: the caller's context when it
+// already holds its own pool_mu, else null)
+static hipError_t device_malloc_retry(int device, hlala_ctx* self, void** p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if(e == hipSuccess) return e;
+    (void)hipGetLastError();
+    bool freed = false;
+    {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        for(hlala_ctx* o : g_ctxs) {
+            if(o->device != device) continue;
+            if(o == self) { if(!o->pool.empty()) { pool_trim_locked(o); freed = true; } continue; }
+            std::lock_guard<std::mutex> g2(o->pool_mu);
+            if(!o->pool.empty()) { pool_trim_locked(o); freed = true; }
+        }
+    }
+    if(!freed) return e;
+    return hipMalloc(p, bytes);
+}
 static int pool_malloc(hlala_ctx* c, void** out, size_t bytes)
 {
     bytes = pool_class(bytes);
+    std::lock_guard<std::mutex> g(c->pool_mu);
     auto it = c->pool.lower_bound(bytes);
     if(it != c->pool.end() && it->first <= bytes + bytes / 4 + 4096) {
         *out = it->second; c->pool_bytes -= it->first; c->pool.erase(it);
         return 0;
     }
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if(e != hipSuccess && !c->pool.empty()) {       // out of memory with blocks parked in the pool: release them and retry
-        for(auto& kv : c->pool) { c->block_bytes.erase(kv.second); (void)hipFree(kv.second); }
-        c->pool.clear(); c->pool_bytes = 0;
-        (void)hipGetLastError();
-        e = hipMalloc(&p, bytes);
-    }
+    hipError_t e = device_malloc_retry(c->device, c, &p, bytes);       // out of memory with blocks parked (here or in another context of the device): released, then retried
     if(e != hipSuccess) { c->err = std::string("hipMalloc: ") + hipGetErrorString(e); return HLALA_E_DEVICE; }
     c->block_bytes[p] = bytes;
     *out = p;
@@ -217,6 +240,7 @@ static int pool_malloc(hlala_ctx* c, void** out, size_t bytes)
 static void pool_release(hlala_ctx* c, void* p)
 {
     if(!p) return;
+    std::lock_guard<std::mutex> g(c->pool_mu);
     auto it = c->block_bytes.find(p);
     if(it == c->block_bytes.end()) { (void)hipFree(p); return; }
     if(c->pool_bytes + it->second > ((size_t)176 << 30)) { c->block_bytes.erase(it); (void)hipFree(p); return; }      // keep at most 176 GB parked (three 1 M-pair batches' arrays: a caller with three sets of outputs live gives them all back between two runs)
@@ -427,7 +451,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     // DP slab pools, one per class and zeroed once: a slab's early-cell table is cleared by the first DP call that needs it and kept clean from then on
     // (kernel_dp.hip: DP_SLAB_READY), which only holds while no other class lays its own arrays over the same memory
     auto slab_pool = [&](char** out, size_t bytes, const char* what) -> int {
-        if(hipMalloc((void**)out, bytes) != hipSuccess) { c->err = std::string("hipMalloc(") + what + ") failed"; return HLALA_E_DEVICE; }
+        if(device_malloc_retry(c->device, nullptr, (void**)out, bytes) != hipSuccess) { c->err = std::string("hipMalloc(") + what + ") failed"; return HLALA_E_DEVICE; }
         c->allocs.push_back(*out);
         if(hipMemsetAsync(*out, 0, bytes, c->active) != hipSuccess) { c->err = std::string("hipMemset(") + what + ") failed"; return HLALA_E_DEVICE; }
         return 0;
@@ -436,9 +460,6 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_TINY_WAVES_PER_CU")) { const int w = atoi(e); if(w >= 1 && w <= 4 * DpTiny::WAVES) c->tiny_grid = cus * w; }      // (experiment: blocks of the 16-lane kernel per CU, tools/gpu_tiny_waves.sh)
     c->tiny_slab_bytes = dp_slab_bytes<DpTiny>();
     c->jf_grid = cus * 4 * DpTinyJF::WAVES;
-#ifdef HLALA_WITH_LANE_CLASS
-    if(const char* e = getenv("HLALA_DP_LANE")) { if(atoi(e) != 0) c->jf_grid = 0; }      // (the lane-per-DP class takes every item itself)
-#endif
     c->band_grid = cus * 24;          // a few KB of LDS per block, six waves per SIMD (80 VGPRs)
     if(const char* e = getenv("HLALA_DP_BAND")) { if(atoi(e) == 0) c->band_grid = 0; }      // (A/B and parity: every call in the hashed-frontier classes)
     if(const char* e = getenv("HLALA_DP_BAND_RISKY")) c->band_risky = atoi(e) != 0;
@@ -464,12 +485,6 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->huge_grid = cus / 4 > 0 ? cus / 4 : 1;      // the in-memory backstop class: a handful of DP calls per million pairs
     c->huge_slab_bytes = dp_inmemory_bytes<DpHuge>();
     if((rc = slab_pool(&c->tiny_slabs, c->tiny_slab_bytes * (size_t)(64 / DpTiny::GW) * (size_t)(c->tiny_grid > c->jf_grid ? c->tiny_grid : c->jf_grid), "16-lane DP slabs"))) return fail(rc);
-    // (an experiment that lost, kept switchable and under test: HLALA_DP_LANE=1 puts the lane-per-DP class in front of the 16-lane class -- kernel_dp_lane.hip)
-#ifdef HLALA_WITH_LANE_CLASS
-    { const char* e = getenv("HLALA_DP_LANE"); c->lane_grid = (e && atoi(e) != 0) ? cus * 4 : 0; }          // 36 KB of LDS per wave: four per CU
-    if(c->lane_grid) c->band_grid = 0;          // (the lane-per-DP class draws every item itself: no band lists beside it)
-    if(c->lane_grid && (rc = slab_pool(&c->lane_slabs, dp_lane_slab_bytes() * (size_t)64 * (size_t)c->lane_grid, "lane-per-DP slabs"))) return fail(rc);
-#endif
     if((rc = slab_pool(&c->mid_slabs, c->mid_slab_bytes * (size_t)(64 / DpMid::GW) * (size_t)c->mid_grid, "32-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->ext_slabs, c->ext_slab_bytes * (size_t)c->ext_grid, "64-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->wide_slabs, c->ext_slab_bytes * (size_t)c->wide_grid, "wide-class DP slabs"))) return fail(rc);
@@ -485,11 +500,11 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
         c->proj_grid = cus * 16;       // (round 5: 16 waves per CU -- 103 VGPRs, four per SIMD; with 4 per CU the kernel ran one wave per SIMD, waiting 72 % of its cycles: 71 k -> 82 k reads/s in batches of 10 000, 223 k in one batch of 50 000)
         if(const char* e = getenv("HLALA_PROJ_LONG_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 16) c->proj_grid = cus * w; }      // (experiment: waves of the long-read projection per CU)
         c->proj_long_slab_bytes = proj_long_slab_bytes();
-        if(hipMalloc((void**)&c->proj_long_slabs, c->proj_long_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(long-read projection slabs) failed"; return fail(HLALA_E_DEVICE); }
+        if(device_malloc_retry(c->device, nullptr, (void**)&c->proj_long_slabs, c->proj_long_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(long-read projection slabs) failed"; return fail(HLALA_E_DEVICE); }
         c->allocs.push_back(c->proj_long_slabs);
     }
     c->proj_slab_bytes = proj_slab_bytes_host(c->params.max_columns, F.max_nodes_per_level);
-    if(hipMalloc((void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
+    if(device_malloc_retry(c->device, nullptr, (void**)&c->proj_slabs, c->proj_slab_bytes * (size_t)c->proj_grid) != hipSuccess) { c->err = "hipMalloc(projection slabs) failed"; return fail(HLALA_E_DEVICE); }
     c->allocs.push_back(c->proj_slabs);
     if(!c->proj_long_slabs) {
         const char* e = getenv("HLALA_RETHREAD");
@@ -500,7 +515,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
             if(c->rethread_slab_bytes > c->proj_slab_bytes) c->rethread_slab_bytes = c->proj_slab_bytes;
             int wv = 24; if(const char* w = getenv("HLALA_RETHREAD_WAVES")) { const int v = atoi(w); if(v >= 1 && v <= 24) wv = v; }
             c->rethread_grid = cus * wv;
-            if(hipMalloc((void**)&c->rethread_slabs, c->rethread_slab_bytes * (size_t)c->rethread_grid) != hipSuccess) { c->err = "hipMalloc(re-threading slabs) failed"; return fail(HLALA_E_DEVICE); }
+            if(device_malloc_retry(c->device, nullptr, (void**)&c->rethread_slabs, c->rethread_slab_bytes * (size_t)c->rethread_grid) != hipSuccess) { c->err = "hipMalloc(re-threading slabs) failed"; return fail(HLALA_E_DEVICE); }
             c->allocs.push_back(c->rethread_slabs);
         }
     }
@@ -514,6 +529,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
       int pr = prLow; if(const char* e = getenv("HLALA_SIDE_PRIORITY")) { if(!strcmp(e, "high")) pr = prHigh; else if(!strcmp(e, "normal")) pr = (prLow + prHigh) / 2; }      // (tools/gpu_side_prio.sh)
       if(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, pr) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); } }
     if(hipStreamSynchronize(c->active) != hipSuccess) { c->err = "upload failed"; return fail(HLALA_E_DEVICE); }
+    { std::lock_guard<std::mutex> g(g_ctx_mu); g_ctxs.push_back(c); }
     *out = c;
     return HLALA_OK;
 }
@@ -522,6 +538,7 @@ void hlala_destroy(hlala_ctx* c)
 {
     if(!c) return;
     DEV_GUARD(c);
+    { std::lock_guard<std::mutex> g(g_ctx_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end()); }
     for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(hlala_ctx::KeptReads& kr : c->kept) { (void)hipFree(kr.store); (void)hipFree(kr.start); (void)hipFree(kr.length); }
@@ -578,7 +595,12 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     size_t nc = (size_t)B.n_chains, nr = (size_t)B.n_reads, np = (size_t)B.n_pairs;
     // column rows: one per chain that passed the filters when they ran at creation (batch.h: chain_row), else one per chain
     if(!b->prepared) { B.n_rows = B.n_chains; B.chain_row = nullptr; }
-    const size_t cs = (size_t)(B.n_rows > 0 ? B.n_rows : 1) * (size_t)B.stride;
+    // (the column arrays are sized for the row count rounded up to a 64th of the chain count: consecutive batches of a sample differ by a per cent in the chains that
+    //  pass the filters, and with exact sizes their arrays fell into different size classes of the pool every few batches -- a hipMalloc / hipFree pair of gigabytes, each a
+    //  device-wide synchronisation, in front of the next launch)
+    size_t rowsAlloc = (size_t)(B.n_rows > 0 ? B.n_rows : 1);
+    if(b->prepared && nc >= 4096) { const size_t gran = nc / 64; rowsAlloc = (rowsAlloc + gran - 1) / gran * gran; if(rowsAlloc > nc) rowsAlloc = nc; }
+    const size_t cs = rowsAlloc * (size_t)B.stride;
     int rc = 0;
 #define AL(field, n, zero) do { rc = dev_alloc(c, b->allocs, (n), &B.field, zero); if(rc) return rc; } while(0)
     if(!b->prepared) { AL(seed_status, nc, true); AL(seed_ncols, nc, true); }
@@ -793,7 +815,6 @@ void hlala_batch_destroy(hlala_batch* b)
     if(b->evMain) (void)hipEventDestroy(b->evMain);
     for(int i = 0; i < 14; i++) { if(b->ev[i]) (void)hipEventDestroy(b->ev[i]); if(b->evC[i / 2][i % 2]) (void)hipEventDestroy(b->evC[i / 2][i % 2]); }
     for(int i = 0; i < 8; i++) if(b->evSide[i]) (void)hipEventDestroy(b->evSide[i]);
-    for(int i = 0; i < 2; i++) if(b->evLane[i]) (void)hipEventDestroy(b->evLane[i]);
     if(b->evJF) (void)hipEventDestroy(b->evJF);
     for(int i = 0; i < 2; i++) if(b->evBand[i]) (void)hipEventDestroy(b->evBand[i]);
     delete b;
@@ -899,7 +920,6 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
         // Items that outgrew it: two DPs per wave, then one wave per DP, then the classes with wider frontiers (fewer blocks per CU).
         // Each class is timed with its own pair of events on the stream it runs on (evC); ev[7] / ev[6] / ev[10] keep marking the start of the 16-lane
         // class, its end and the end of the 64-lane class on the main stream.
-        int* tinyList = nullptr;          // items the lane-per-DP class passes on to the 16-lane class (set below when that class runs)
         hipStream_t ws = c->active;
         auto run_class = [&](int tier) -> int {
             if(fused && tier == DP_SIDE_TIER) {
@@ -915,38 +935,27 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
             switch(tier) {
             case 0:
                 // the calls that meet no gap-path jump in the instantiation without the early-cell machinery, then the others (same slabs: one after the other)
-                if(!tinyList && c->jf_grid > 0) {
-                    hipLaunchKernelGGL((k_dp<DpTinyJF, 0>), dim3(c->jf_grid), dim3(DpTinyJF::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr);
+                if(c->jf_grid > 0) {
+                    hipLaunchKernelGGL((k_dp<DpTinyJF, 0>), dim3(c->jf_grid), dim3(DpTinyJF::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
                     int rcj = check_launch(c, "k_dp<DpTinyJF>"); if(rcj) return rcj;
                     HIP_TRY(c, hipEventRecord(b->evJF, ws));
                 }
-                hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(DpTiny::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)tinyList); break;
-            case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(DpMid::THREADS), 0, ws, c->dG, b->dB, items, c->mid_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
-            case 2: hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(DpSmall::THREADS), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
-            case 3: hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(DpWide::THREADS), 0, ws, c->dG, b->dB, items, c->wide_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
-            case 4: hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(DpBroad::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
-            case 5: hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(DpLarge::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs + c->large_slab_bytes * (size_t)c->broad_grid, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
-            default: hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(DpHuge::THREADS), 0, ws, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, (const int*)nullptr); break;
+                hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(DpTiny::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(DpMid::THREADS), 0, ws, c->dG, b->dB, items, c->mid_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 2: hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(DpSmall::THREADS), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 3: hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(DpWide::THREADS), 0, ws, c->dG, b->dB, items, c->wide_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 4: hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(DpBroad::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            case 5: hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(DpLarge::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs + c->large_slab_bytes * (size_t)c->broad_grid, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+            default: hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(DpHuge::THREADS), 0, ws, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
             }
             int rc_ = check_launch(c, "k_dp"); if(rc_) return rc_;
             HIP_TRY(c, hipEventRecord(b->evC[tier][1], ws));
             return 0;
         };
         if(phase != 2) {
-        // the lane-per-DP class first: 64 calls per wavefront; what it cannot finish exactly goes on to the 16-lane class through its list
-        b->lane_used = c->lane_grid > 0;
-#ifdef HLALA_WITH_LANE_CLASS
-        if(b->lane_used) {
-            tinyList = B.retry_list + (size_t)12 * (size_t)B.n_chains;
-            HIP_TRY(c, hipEventRecord(b->evLane[0], c->active));
-            hipLaunchKernelGGL(k_dp_lane, dim3(c->lane_grid), dim3(64), 0, c->active, c->dG, b->dB, items, c->lane_slabs, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, tinyList);
-            rc = check_launch(c, "k_dp_lane"); if(rc) return rc;
-            HIP_TRY(c, hipEventRecord(b->evLane[1], c->active));
-        }
-#endif
         // calls on linear stretches of the graph first: anti-diagonals in registers, four calls per wavefront (kernel_dp_band.hip); what it cannot finish is on the
         // fail-over list the general 16-lane instantiation draws after its own
-        b->band_used = c->band_grid > 0 && !tinyList;
+        b->band_used = c->band_grid > 0;
         if(b->band_used) {
             HIP_TRY(c, hipEventRecord(b->evBand[0], c->active));
             hipLaunchKernelGGL((k_dp_band<16>), dim3(c->band_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->G.lin_label, c->G.lin_eid);
@@ -1344,13 +1353,12 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
     if((b->staged & 1) && !b->B.from_seeds) (void)hipEventElapsedTime(&out->ms_project, b->ev[0], b->ev[1]);
     if(b->staged & 2) { (void)hipEventElapsedTime(&out->ms_extend, b->ev[2], b->ev[3]); if(b->B.n_chains > 0) { (void)hipEventElapsedTime(&out->ms_extend_retry, b->ev[6], b->side_used ? b->ev[10] : b->ev[8]); (void)hipEventElapsedTime(&out->ms_dp_main, b->ev[7], b->ev[6]);
           for(int k = 0; k <= DP_LAST_TIER; k++) (void)hipEventElapsedTime(&out->ms_dp_class[k], b->evC[k][0], b->evC[k][1]);
-          if(b->lane_used) (void)hipEventElapsedTime(&out->ms_dp_lane, b->evLane[0], b->evLane[1]);
-          if(c->jf_grid > 0 && !b->lane_used) (void)hipEventElapsedTime(&out->ms_dp_jump_free, b->evC[0][0], b->evJF);
+          if(c->jf_grid > 0) (void)hipEventElapsedTime(&out->ms_dp_jump_free, b->evC[0][0], b->evJF);
           if(b->band_used) (void)hipEventElapsedTime(&out->ms_dp_band, b->evBand[0], b->evBand[1]);
           if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, b->evSide[1], b->evSide[6]); } }
     { int wc[WC_N]; HIP_TRY(c, hipMemcpyAsync(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
       out->n_dp_band = b->band_used ? wc[WC_BAND_CALLS] : 0; out->n_dp_band_failed = b->band_used ? wc[WC_BAND_FAILED] : 0; out->n_dp_jump_free_failed = wc[WC_JF_FAILED];
-      out->n_dp_class[0] = b->lane_used ? wc[40] + wc[42] : wc[8] + wc[9] - out->n_dp_band + out->n_dp_band_failed; out->n_dp_lane = b->lane_used ? wc[8] + wc[9] : 0; out->n_dp_jump_free = (c->jf_grid > 0 && !b->lane_used) ? wc[6] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
+      out->n_dp_class[0] = wc[8] + wc[9] - out->n_dp_band + out->n_dp_band_failed; out->n_dp_jump_free = c->jf_grid > 0 ? wc[6] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, b->ev[4], b->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];
@@ -1524,26 +1532,30 @@ extern "C" int hlala_debug_memory(hlala_ctx* c, hlala_batch* b, unsigned long lo
 }
 
 // the batch's work counters (diagnostics: item counts of the lists, fail-over reasons of the band kernel -- batch.h)
-extern "C" int hlala_debug_work_counters(hlala_ctx* c, hlala_batch* b, int* out64)
+extern "C" int hlala_debug_work_counters(hlala_ctx* c, hlala_batch* b, int* out, int capacity)
 {
+    static_assert(WC_N == HLALA_DEBUG_WC_N && WC_BAND_FETCH == HLALA_DEBUG_WC_BAND_FETCH && WC_BAND_WHY == HLALA_DEBUG_WC_BAND_WHY && WC_BAND_TIED == HLALA_DEBUG_WC_BAND_TIED, "include/hlala_gpu.h: debug section");
     DEV_GUARD(c);
     ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
-    if(!c || !b || !out64) return HLALA_E_ARG;
-    if(!b->outputs_ready) { memset(out64, 0, WC_N * sizeof(int)); return HLALA_OK; }
+    if(!c || !b || !out || capacity < 0) return HLALA_E_ARG;
+    const int n = capacity < WC_N ? capacity : WC_N;          // (a caller built against an older header gets the counters it has room for)
+    if(!b->outputs_ready) { memset(out, 0, (size_t)n * sizeof(int)); return HLALA_OK; }
     HIP_TRY(c, hipStreamSynchronize(c->active));
-    HIP_TRY(c, hipMemcpyAsync(out64, b->B.work_counter, WC_N * sizeof(int), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active));
+    HIP_TRY(c, hipMemcpyAsync(out, b->B.work_counter, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active));
     return HLALA_OK;
 }
 
 // diagnostics (tools/tier_predict.py): the DP items of the batch's last extension stage ([2 * n_chains] records of 8 ints: item, read offset, read length, start offset,
 // start level, start node, class, linear run; item < 0: no call) and its retry lists ([16 * n_chains] slots of dp_items; counts in the work counters)
-extern "C" int hlala_debug_dp_items(hlala_ctx* c, hlala_batch* b, int* items_out, int* retry_out)
+extern "C" int hlala_debug_dp_items(hlala_ctx* c, hlala_batch* b, int* items_out, long long items_capacity_bytes, int* retry_out, long long retry_capacity_bytes)
 {
     DEV_GUARD(c);
     ReaderScope rscope_(c, b); if(rscope_.rc) return rscope_.rc;
     if(!c || !b) return HLALA_E_ARG;
     if(!b->outputs_ready || !(b->staged & 2)) { c->err = "hlala_debug_dp_items before the extension stage"; return HLALA_E_STATE; }
     const size_t nc = (size_t)b->B.n_chains;
+    if((items_out && items_capacity_bytes < (long long)(2 * nc * 32)) || (retry_out && retry_capacity_bytes < (long long)(16 * nc * sizeof(int)))) {
+        c->err = "hlala_debug_dp_items: buffer too small (items 64 bytes per chain, retry lists 64 bytes per chain)"; return HLALA_E_ARG; }
     if(items_out) HIP_TRY(c, hipMemcpyAsync(items_out, b->B.dp_items, 2 * nc * 32, hipMemcpyDeviceToHost, c->active));
     if(retry_out) HIP_TRY(c, hipMemcpyAsync(retry_out, b->B.retry_list, 16 * nc * sizeof(int), hipMemcpyDeviceToHost, c->active));
     HIP_TRY(c, hipStreamSynchronize(c->active));
@@ -1940,8 +1952,8 @@ extern "C" int hlala_abi_version(void) { return HLALA_ABI_VERSION; }
 extern "C" int hlala_build_flags(void)
 {
     int f = 0;
-#ifdef HLALA_WITH_LANE_CLASS
-    f |= HLALA_BUILD_LANE_CLASS;
+#ifdef HLALA_DP_AGENT_RELEASE
+    f |= HLALA_BUILD_AGENT_RELEASE;
 #endif
     return f;
 }

@@ -382,7 +382,17 @@ template <class C> __device__ __forceinline__ void dp_sync()
     //  XCD's L2 once they are counted done, which is all a reader on the same CU needs -- what it must not do is hit a stale L1 line of a word an L2 atomic changed, hence the
     //  agent-scope ACQUIRE (L1 invalidate).  The agent-scope release this used to be is an L2 WRITE-BACK of the whole XCD's dirty lines, a dozen times per iteration of a call:
     //  it slowed the class and every kernel beside it -- profiles/r05_experiments.txt 12, 13.)
-    if constexpr (C::IN_MEMORY) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if constexpr (C::GW > 64) __builtin_amdgcn_s_barrier(); else __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+    //  The workgroup-scope release is only enough while the wavefronts of a block share one L1, i.e. NOT in threadgroup-split mode (-mtgsplit): refuse that build;
+    //  make EXTRA=-DHLALA_DP_AGENT_RELEASE keeps the agent-scope release of rounds 2-4 (hlala_build_flags() reports it; tools/gpu_r6_agentrel.sh runs the parity suite on it).
+#if defined(__AMDGCN_TGSPLIT__) || defined(__gfx950_tgsplit__)
+#error "kernel_dp.hip: dp_sync releases at workgroup scope -- build with -DHLALA_DP_AGENT_RELEASE for threadgroup-split mode"
+#endif
+#ifdef HLALA_DP_AGENT_RELEASE
+#define DP_RELEASE_SCOPE "agent"
+#else
+#define DP_RELEASE_SCOPE "workgroup"
+#endif
+    if constexpr (C::IN_MEMORY) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, DP_RELEASE_SCOPE); if constexpr (C::GW > 64) __builtin_amdgcn_s_barrier(); else __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
     else if constexpr (C::GW > 64) blk_barrier();
     else { WSYNC(); }
 }
@@ -1658,8 +1668,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
                                                         char* slabs, size_t slabBytes, u32 rng_seed,
                                                         // the arrays of the inner loop are passed as kernel arguments: pointers loaded from the descriptors are generic
                                                         // (flat_load, which also ties up the LDS counter), kernel-argument pointers are known to be global
-                                                        const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBasesArg,
-                                                        const int* __restrict__ tinyList)      // TIER 0 with the lane-per-DP class in front (kernel_dp_lane.hip): the items that class passed on; else null
+                                                        const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBasesArg)
 {
     constexpr int GW = C::GW;
     constexpr int NG = GW >= 64 ? 1 : 64 / GW;           // DPs per block: groups of a wavefront, or one DP for the whole block
@@ -1704,19 +1713,17 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
         const bool foPass = pass >= 2;
         // work_counter: [8]/[9] left / right item counts, [1]/[10] their fetch counters;
         // retry list of tier k = 1..6 and direction p: count [12 + 4(k-1) + 2p], fetched [13 + 4(k-1) + 2p], entries retry_list[(2(k-1) + p) n_chains ...]
-        const bool fromLane = TIER == 0 && tinyList != nullptr;         // [40]/[42] counts, [41]/[43] fetched: the list of the lane-per-DP class
-        if(foPass && fromLane) break;
         int* fetchCounter = foPass ? &B.work_counter[WC_FO_FETCH + dirPass]
-                          : &B.work_counter[TIER == 0 ? (fromLane ? 41 + 2 * dirPass : (C::JF ? 4 + dirPass : (dirPass ? 10 : 1))) : 13 + 4 * (TIER - 1) + 2 * dirPass];        // [4]/[5]: the jump-free lists
+                          : &B.work_counter[TIER == 0 ? (C::JF ? 4 + dirPass : (dirPass ? 10 : 1)) : 13 + 4 * (TIER - 1) + 2 * dirPass];        // [4]/[5]: the jump-free lists
         // (TIER 0 draws from the dense lists of k_dp_lists -- jump-free or general, left or right --, the later tiers from the retry lists)
         const int seg = (C::JF ? DPL_JF : DPL_GEN) + dirPass;
-        const bool dense = TIER == 0 && !fromLane && !foPass;
+        const bool dense = TIER == 0 && !foPass;
         const int segStart = dense ? uni(B.dp_blk[(size_t)seg * B.dp_nblk]) : 0;
         const int nItems = dense ? uni(B.dp_blk[(size_t)(seg + 1) * B.dp_nblk]) - segStart
-                         : (foPass ? uni(B.work_counter[WC_FO_COUNT + dirPass]) : uni(B.work_counter[TIER == 0 ? 40 + 2 * dirPass : 12 + 4 * (TIER - 1) + 2 * dirPass]));
+                         : (foPass ? uni(B.work_counter[WC_FO_COUNT + dirPass]) : uni(B.work_counter[12 + 4 * (TIER > 0 ? TIER - 1 : 0) + 2 * dirPass]));
         const int* srcList = dense ? B.dp_list + segStart
                            : (foPass ? B.retry_list + (size_t)(14 + dirPass) * (size_t)B.n_chains
-                           : (fromLane ? tinyList + (size_t)dirPass * (size_t)B.n_chains : B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains));
+                           : B.retry_list + (size_t)(2 * (TIER > 0 ? TIER - 1 : 0) + dirPass) * (size_t)B.n_chains);
         const bool fwd = dirPass != 0;                     // left extensions run backwards (alignerBase: extensionAligner.cpp:229-241)
         if constexpr (DRAW > 1) { if(gl == 0) { S.chunkNext = 0; S.chunkEnd = 0; } DSYNC(); }
         int phase = PH_IDLE;

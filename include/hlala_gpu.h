@@ -311,9 +311,8 @@ typedef struct {
     float   ms_side;              /* hlala_align_batch on a paired batch: span of the work it put on its second stream (wide / broad / large / in-memory
                                      class, second stitch and pairing pass over the pairs that own those calls), which runs beside the rest of the
                                      batch and beside the caller's next batch; 0 when the stages were called one by one                          */
-    int32_t n_dp_lane;            /* DP calls that entered the lane-per-DP class (64 calls per wavefront, one per lane: every item starts there); those it passes on
-                                     enter the 16-lane class (n_dp_class[0]); 0 when the class is switched off (HLALA_DP_LANE=0)                                 */
-    float   ms_dp_lane;           /* time of that class's kernel                                                                                              */
+    int32_t n_dp_lane;            /* always 0 (the lane-per-DP class of round 3 lost its A/B and was removed in round 6; the two fields keep the layout)       */
+    float   ms_dp_lane;           /* always 0                                                                                                                 */
     int32_t n_dp_jump_free;       /* of n_dp_class[0]: calls that were known to meet no gap-path jump and ran in the instantiation of the 16-lane class that is
                                      compiled without the early-cell machinery (kernel_dp.hip: DpTinyJF)                                                      */
     float   ms_dp_jump_free;      /* part of ms_dp_class[0] spent in that instantiation                                                                       */
@@ -728,9 +727,25 @@ int  hlala_abi_sizeof(const char* struct_name);
  * hla-la_amd/host/hlala_host.hpp do). */
 #define HLALA_ABI_VERSION 4
 int  hlala_abi_version(void);
-/* bit mask of optional parts compiled into this library: HLALA_BUILD_LANE_CLASS = the lane-per-DP class (kernel_dp_lane.hip, an experiment that
- * lost its A/B and is left out of the default build: make EXTRA=-DHLALA_WITH_LANE_CLASS) */
-#define HLALA_BUILD_LANE_CLASS 1
+/* ---- debug / diagnostics section (tests and tools only; not part of the path the reference calls).  Layouts may change between rounds: the constants below are
+ * checked against the library's own at compile time (hlala_api.hip). */
+#define HLALA_DEBUG_WC_N           72     /* work counters of a batch (csrc/batch.h: B.work_counter)                                                   */
+#define HLALA_DEBUG_WC_BAND_FETCH  48     /* [+0..5] items fetched by the 16 / 32 / 64-lane band kernels, left and right                               */
+#define HLALA_DEBUG_WC_BAND_WHY    62     /* [+2..5] band calls that failed over: past the staged levels, past the linear run, too many iterations, ties */
+#define HLALA_DEBUG_WC_BAND_TIED   68     /* band calls whose end cell was drawn among equal sequence-complete cells                                   */
+/* the first min(capacity, HLALA_DEBUG_WC_N) work counters of the batch's last stages */
+int  hlala_debug_work_counters(hlala_ctx* ctx, hlala_batch* batch, int* out, int capacity);
+/* the DP items of the batch's last extension stage ([2 * n_chains] records of 8 ints: item, read offset, read length, start offset, start level, start node, class,
+ * linear run; item < 0: no call) and its retry / fail-over lists ([16 * n_chains] slots); either pointer may be NULL; capacities in bytes are checked */
+int  hlala_debug_dp_items(hlala_ctx* ctx, hlala_batch* batch, int* items_out, long long items_capacity_bytes, int* retry_out, long long retry_capacity_bytes);
+/* counters[32] of a batch (stage statistics, timing builds), the phase-clock buffer of profile builds (8192 ints), device memory of a batch / its context (4 values) */
+int  hlala_debug_counters(hlala_ctx* ctx, hlala_batch* batch, unsigned long long* out32);
+int  hlala_debug_buffer(hlala_ctx* ctx, int* out8192, int clear);
+int  hlala_debug_memory(hlala_ctx* ctx, hlala_batch* batch, unsigned long long* out4);
+
+/* bit mask of build-time variants compiled into this library: HLALA_BUILD_AGENT_RELEASE = the in-memory DP class releases at agent scope
+ * (make EXTRA=-DHLALA_DP_AGENT_RELEASE: the fences of rounds 2-4, kept as a switch for a device in threadgroup-split mode, kernel_dp.hip dp_sync) */
+#define HLALA_BUILD_AGENT_RELEASE 2
 int  hlala_build_flags(void);
 
 #ifdef __cplusplus

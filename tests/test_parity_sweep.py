@@ -14,6 +14,10 @@ sys.path.insert(0, ROOT)
 SEEDS = list(range(9000, 9048))          # seeds with s % 3 == 2 are Graph M worlds (16 of the 48); even seeds of the others add the unpaired pass (16 more)
 
 
+RAN = []                                 # seeds whose world was compared (a world is skipped when the oracle raises on a generated record)
+MIN_WORLDS = 44                          # of the 48: a change of the generator must not turn the sweep into skips without anybody noticing
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_world_is_bit_exact(pkg, oracle, seed):
@@ -22,3 +26,14 @@ def test_random_world_is_bit_exact(pkg, oracle, seed):
     if st is None:
         pytest.skip("the generator produced a record the reference asserts on (the oracle raised)")
     assert st.n_errors == 0 and st.n_dp_calls > 0
+    RAN.append(seed)
+
+
+@pytest.mark.gpu
+def test_the_sweep_compared_enough_worlds(request):
+    """Runs after the parametrized test (definition order): at least 44 of the 48 worlds were compared with the oracle.  Only checked when the whole sweep was
+    selected (a `-k` run of single seeds, or pytest -x stopping early, says nothing about the sweep)."""
+    selected = [it for it in request.session.items if it.name.startswith("test_random_world_is_bit_exact[")]
+    if len(selected) < len(SEEDS):
+        pytest.skip("only part of the sweep was selected")
+    assert len(RAN) >= MIN_WORLDS, f"only {len(RAN)} of {len(SEEDS)} random worlds were compared with the oracle (the others were skipped)"

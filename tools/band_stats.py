@@ -17,15 +17,10 @@ gb.align(); st = gb.stats()
 print("pairs %d levels %d frac_gene %.2f: DP calls %d (shared %d), iterations %d, cells %d, errors %d" % (n_pairs, G, fg, st.n_dp_calls, st.n_dp_shared, st.n_dp_iterations, st.n_dp_cells, st.n_errors))
 print(" band: %d calls (%.1f %% of the calls that run), failed over %d (%.2f %%), %.2f ms" % (st.n_dp_band, 100.0 * st.n_dp_band / max(1, st.n_dp_band + st.n_dp_class[0] - st.n_dp_band_failed), st.n_dp_band_failed, 100.0 * st.n_dp_band_failed / max(1, st.n_dp_band), st.ms_dp_band))
 import ctypes as C
-wc = (C.c_int * 72)()
-try:
-    ctx.lib.hlala_debug_work_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
-    ctx.lib.hlala_debug_work_counters(ctx.h, gb.b, wc)
-    print("  fail-over reasons: past the staged levels %d, past the linear run %d, too many iterations %d, too many ties %d" % (wc[64], wc[65], wc[66], wc[67]))
-    ls = [wc[48 + k] for k in range(6)]
-    print("  items fetched (>= listed) by the 16 / 32 / 64-lane band kernels, left + right:", ls[0] + ls[1], ls[2] + ls[3], ls[4] + ls[5])
-except AttributeError:
-    pass
+wc = gb.work_counters(); why = P.DEBUG_WC_BAND_WHY
+print("  fail-over reasons: past the staged levels %d, past the linear run %d, too many iterations %d, too many ties %d" % (wc[why + 2], wc[why + 3], wc[why + 4], wc[why + 5]))
+ls = [wc[P.DEBUG_WC_BAND_FETCH + k] for k in range(6)]
+print("  items fetched (>= listed) by the 16 / 32 / 64-lane band kernels, left + right:", ls[0] + ls[1], ls[2] + ls[3], ls[4] + ls[5])
 print(" 16-lane class: %d calls, %.2f ms (jump-free part: %d calls, %d met a jump, %.2f ms)" % (st.n_dp_class[0], st.ms_dp_class[0], st.n_dp_jump_free, st.n_dp_jump_free_failed, st.ms_dp_jump_free))
 print(" later classes: calls", list(st.n_dp_class)[1:], "ms", [round(x, 2) for x in list(st.ms_dp_class)[1:]])
 print(" stages ms: project %.2f extend %.2f pair %.2f -> %.0f pairs/s (one batch alone)" % (st.ms_project, st.ms_extend, st.ms_pair, n_pairs / ((st.ms_project + st.ms_extend + st.ms_pair) * 1e-3)))

@@ -14,10 +14,7 @@ b = synth.make_batch_m(w, n_pairs, seed=77, frac_gene=fg)
 ctx = P.Context(w["graph"], w["contigs"], insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=12345)
 gb = ctx.batch(b); gb.align(); st = gb.stats()
 nc = b["n_chains"]
-items = np.zeros((2 * nc, 8), np.int32); retry = np.zeros(16 * nc, np.int32); wc = (C.c_int * 72)()
-ctx.lib.hlala_debug_dp_items.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-assert ctx.lib.hlala_debug_dp_items(ctx.h, gb.b, items.ctypes.data, retry.ctypes.data) == 0
-ctx.lib.hlala_debug_work_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]; ctx.lib.hlala_debug_work_counters(ctx.h, gb.b, wc)
+items, retry = gb.dp_items(); wc = gb.work_counters()
 npl = np.bincount(w["graph"]["node_level"], minlength=w["graph"]["n_levels"]).astype(np.int64)
 L = len(npl)
 # widest level within R levels ahead / behind: sliding maximum
