@@ -679,6 +679,7 @@ BUILD_AGENT_RELEASE = 2      # hlala_build_flags(): the in-memory DP class relea
 
 EXPORTED_SYMBOLS = [
     "hlala_debug_work_counters", "hlala_debug_dp_items", "hlala_debug_counters", "hlala_debug_buffer", "hlala_debug_memory",
+    "hlala_set_tail_pool", "hlala_flush",
     "hlala_create", "hlala_destroy", "hlala_last_error", "hlala_graph_get_info", "hlala_graph_get_nodes",
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
     "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_set_first_chain", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
@@ -843,6 +844,15 @@ class Context:
     def kmer_forget_reads(self):
         self.lib.hlala_kmer_forget_reads.argtypes = [C.c_void_p]; self.lib.hlala_kmer_forget_reads.restype = None
         self.lib.hlala_kmer_forget_reads(self.h)
+
+    def set_tail_pool(self, k: int):
+        """hlala_set_tail_pool: the broad / large / in-memory DP classes of up to k consecutive alignments run in one launch per class."""
+        self.lib.hlala_set_tail_pool.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.hlala_set_tail_pool(self.h, int(k)), "hlala_set_tail_pool")
+
+    def flush(self):
+        self.lib.hlala_flush.argtypes = [C.c_void_p]
+        self._check(self.lib.hlala_flush(self.h), "hlala_flush")
 
     def estimate_insert_size(self, batch_in: dict):
         """processBAM::estimateInsertSize on the primaries of `batch_in` (hlala_estimate_insert_size)."""

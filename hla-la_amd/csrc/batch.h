@@ -67,6 +67,7 @@ struct DevBatch {
                                     //      [1]/[10] left / right items fetched, [12..35] retry lists (count, fetched) per tier 1..6 and direction
     int* retry_list;                // [16*n_chains] DP items that outgrew a capacity class: (tier 1..6) x (left, right) x n_chains; rows 14 / 15: the fail-over lists of the band kernels and the
                                     //      jump-free instantiation (WC_FO_COUNT)
+    int* pair_multi;                // [2 passes][2 classes][n_pairs] pairs with several combinations, listed by k_pair_chains for k_pair_multi (kernel_pair.hip; counts in work_counter[WC_PAIR_MULTI ...])
     uint8_t* pair_deferred;         // [n_pairs] 1: a DP call of the pair went to the in-memory class; with the fused entry point its chains are stitched and
                                     //           the pair is scored in a second pass, after that class (which runs on a side stream next to the first pass)
     // ---- position order of the chains (kernel_order.hip): the kernels that walk the graph take their chains in this order, so that the work in flight at
@@ -104,10 +105,10 @@ enum { DPL_BAND16 = 0, DPL_BAND32 = 2, DPL_BAND64 = 4, DPL_JF = 6, DPL_GEN = 8, 
 __host__ __device__ inline int dpl_of_class(int cls) { return cls == 0 ? DPL_GEN : (cls == 1 ? DPL_JF : (cls == 2 ? DPL_BAND16 : (cls == 3 ? DPL_BAND32 : DPL_BAND64))); }
 // ---- B.work_counter (WC_N ints): [0] stage A, [1] / [10] left / right general items fetched, [2] stage C, [4] / [5] jump-free items fetched, [6] jump-free calls (statistics),
 // [7] chains stitched, [8] / [9] left / right DP calls, [12..35] retry lists of tiers 1..6 (count, fetched) x (left, right), [36] / [37] second stitch / pairing pass,
-// [40..45] unused (the lane-per-DP class of round 3); round 5: items fetched by the three band kernels (left, right each), the fail-over list's counts and fetch counters, band calls that
+// [40..47] round 6: the lists of the pairs with several combinations (k_pair_chains -> k_pair_multi): per pass (main / side stream) count and fetched of class 0, of class 1; round 5: items fetched by the three band kernels (left, right each), the fail-over list's counts and fetch counters, band calls that
 // failed over, band calls listed, jump-free calls that met a jump, and why band calls failed ([WC_BAND_WHY + 2 .. + 5]: past the staged levels, past the linear run, too
 // many iterations, too many tied end cells)
-enum { WC_BAND_FETCH = 48, WC_FO_COUNT = 54, WC_FO_FETCH = 56, WC_BAND_FAILED = 58, WC_BAND_CALLS = 59, WC_JF_FAILED = 60, WC_BAND_WHY = 62, WC_BAND_TIED = 68, WC_N = 72 };
+enum { WC_PAIR_MULTI = 40, WC_BAND_FETCH = 48, WC_FO_COUNT = 54, WC_FO_FETCH = 56, WC_BAND_FAILED = 58, WC_BAND_CALLS = 59, WC_JF_FAILED = 60, WC_BAND_WHY = 62, WC_BAND_TIED = 68, WC_N = 72 };
 // the fail-over list of the first classes: calls the band kernel (kernel_dp_band.hip) or the jump-free instantiation could not finish; k_dp<DpTiny, 0> draws it after
 // its own lists.  Entries (slots of dp_items) at retry_list[(14 + direction) * n_chains ...], counts in work_counter[WC_FO_COUNT + direction].
 // ---- capacities of the band kernels (kernel_dp_band.hip): read bases a call may have left for the instantiation with 16 / 32 / 64 lanes per call; k_dp_items lists a call

@@ -50,6 +50,8 @@ struct hlala_ctx {
     // positions, typer scoring): neither waits for alignments of OTHER batches queued on the main stream, so a caller with two batches in flight
     // uploads the next batch and fetches the previous one while the current one is being aligned.  `active` = the stream the helpers use right now.
     hipStream_t up = nullptr, rs = nullptr, active = nullptr;
+    // tail pool (round 6, hlala_set_tail_pool): fused alignments leave their broad / large / in-memory DP classes pending; flush_tail runs them ONCE for the pooled batches
+    int tail_pool_k = 1; std::vector<hlala_batch*> tail;
     hipEvent_t evSideTail = nullptr; bool sideTailValid = false;      // end of the last work queued on the side stream: a non-fused launch of the classes that share its slabs waits for it
     hlala_params params{};
     FlatGraph F;
@@ -77,7 +79,7 @@ struct hlala_ctx {
     int band_grid = 0, band_margin = 8;      // the band kernel in front of the 16-lane class (kernel_dp_band.hip): blocks (0: HLALA_DP_BAND=0) and the levels beyond the read bases left a call is taken to reach (HLALA_DP_BAND_MARGIN)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
-    char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0;
+    char* proj_slabs = nullptr; size_t proj_slab_bytes = 0; int proj_grid = 0, pair_grid = 0, pair_lean_grid = 0;
     char* rethread_slabs = nullptr; size_t rethread_slab_bytes = 0; int rethread_grid = 0;      // k_rethread_chains: back pointers of one chain per wave (short reads; HLALA_RETHREAD=0 turns the kernel off)
     double* pair_scratch = nullptr;   // [2 * pair_grid][PAIR_COMB]: combination tables of the rare pairs with more than PAIR_COMB_LDS combinations (main- and side-stream pass)
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
@@ -102,6 +104,7 @@ struct hlala_batch {
     bool outputs_ready = false;      // the output arrays (50 GB for a 1 M-pair batch) exist: allocated by the first stage call, not by hlala_batch_create (ensure_outputs)
     bool side_used = false;      // the last extend of this batch ran its wide classes on the side stream (their times are between the evSide events)
     bool side_pending = false;   // ... and hlala_pair_chains has yet to enqueue the second pairing pass behind them
+    bool tail_pooled = false;    // the batch waits in its context's tail pool: its deferred pairs are complete after flush_tail (readers and stage calls flush first)
     bool side_inflight = false;  // work of this batch may still be running on the side stream: evDone orders everything that touches the batch after it
     hipEvent_t evDone = nullptr;
     hipEvent_t evMain = nullptr; bool mainValid = false;      // end of the last work of this batch on the main stream (readers on `rs` wait for it)
@@ -128,8 +131,10 @@ struct DevGuard {
 #define HIP_TRY_F(ctx, call, cleanup) do { hipError_t e_ = (call); if(e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return cleanup(HLALA_E_DEVICE); } } while(0)
 
 // everything on the main stream that reads or rewrites a batch goes behind the side-stream work of its last fused alignment
+static int flush_tail(hlala_ctx* c);
 static int join_side(hlala_ctx* c, hlala_batch* b)
 {
+    if(b->tail_pooled) { int rf = flush_tail(c); if(rf) return rf; }
     if(b->side_inflight) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream, b->evDone, 0));
         // evMain is what hlala_batch_destroy and the readers wait for once side_inflight is cleared: it has to lie BEHIND the wait just queued even if the
@@ -162,6 +167,7 @@ struct ReaderScope {
     ReaderScope(hlala_ctx* c_, hlala_batch* b) : c(c_)
     {
         if(!c) return;
+        if(b && b->tail_pooled) { rc = flush_tail(c); if(rc) return; }          // the batch's tail classes are still pooled: run them now (with whatever the pool holds)
         c->active = c->rs;
         hipError_t e = hipSuccess;
         if(b && b->mainValid) e = hipStreamWaitEvent(c->rs, b->evMain, 0);
@@ -460,11 +466,12 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_TINY_WAVES_PER_CU")) { const int w = atoi(e); if(w >= 1 && w <= 4 * DpTiny::WAVES) c->tiny_grid = cus * w; }      // (experiment: blocks of the 16-lane kernel per CU, tools/gpu_tiny_waves.sh)
     c->tiny_slab_bytes = dp_slab_bytes<DpTiny>();
     c->jf_grid = cus * 4 * DpTinyJF::WAVES;
-    c->band_grid = cus * 24;          // a few KB of LDS per block, six waves per SIMD (80 VGPRs)
+    c->band_grid = cus * 20;          // a few KB of LDS per block, five waves per SIMD (96 VGPRs, nothing spilled)
     if(const char* e = getenv("HLALA_DP_BAND")) { if(atoi(e) == 0) c->band_grid = 0; }      // (A/B and parity: every call in the hashed-frontier classes)
     if(const char* e = getenv("HLALA_DP_BAND_RISKY")) c->band_risky = atoi(e) != 0;
     if(const char* e = getenv("HLALA_ROWS_ALL")) c->rows_all = atoi(e) != 0;
     if(const char* e = getenv("HLALA_SIDE_AFTER_PAIR")) c->side_after_pair = atoi(e) != 0;
+    if(const char* e = getenv("HLALA_TAIL_POOL")) { const int k = atoi(e); if(k >= 1 && k <= DP_POOL_MAX) c->tail_pool_k = k; }      // (experiments and the parity suite: hlala_set_tail_pool without touching the caller)
     if(const char* e = getenv("HLALA_DP_BAND_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 24) c->band_margin = m; }
     if(const char* e = getenv("HLALA_DP_BAND_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 32 && c->band_grid) c->band_grid = cus * w; }
     if(const char* e = getenv("HLALA_DP_JF")) { if(atoi(e) == 0) c->jf_grid = 0; }      // (A/B: every call in the general instantiation -- the kernels' lists are built either way)
@@ -492,7 +499,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if((rc = slab_pool(&c->huge_slabs, c->huge_slab_bytes * (size_t)c->huge_grid, "in-memory DP class"))) return fail(rc);
     // k_project_chains<384 columns>: 143 VGPRs = three waves per SIMD = 12 resident blocks per CU (its 11.7 KB of LDS would allow 13); the 512-column
     // layout: 173 VGPRs = two per SIMD (-Rpass-analysis=kernel-resource-usage; a cap of 128 VGPRs for a fourth wave costs 287 spilled SGPRs and wins one block)
-    c->proj_grid = cus * (c->params.max_columns <= PROJ_CAP_SHORT ? 12 : 8); c->pair_grid = cus * 20;
+    c->proj_grid = cus * (c->params.max_columns <= PROJ_CAP_SHORT ? 12 : 8); c->pair_grid = cus * 16; c->pair_lean_grid = cus * 24;      // k_pair_multi<., false>: four waves per SIMD (125 registers, nothing spilled); k_pair_chains (0.7 KB of LDS, 80 registers): six
     if(const char* e = getenv("HLALA_PAIR_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 32) c->pair_grid = cus * w; }      // (experiments)
     if(const char* e = getenv("HLALA_PROJ_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 14) c->proj_grid = cus * w; }      // (experiment: waves of the projection kernel per CU)
     { int rcp = dev_alloc(c, c->allocs, (size_t)2 * c->pair_grid * PAIR_COMB, &c->pair_scratch, false); if(rcp) return fail(rcp); }
@@ -539,6 +546,7 @@ void hlala_destroy(hlala_ctx* c)
     if(!c) return;
     DEV_GUARD(c);
     { std::lock_guard<std::mutex> g(g_ctx_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end()); }
+    if(!c->tail.empty()) (void)flush_tail(c);
     for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
     for(hlala_ctx::KeptReads& kr : c->kept) { (void)hipFree(kr.store); (void)hipFree(kr.start); (void)hipFree(kr.length); }
@@ -613,7 +621,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     AL(ext_firstlast, 4 * nc, true);
     AL(pair_status, np, true); AL(best_chain, nr, true); AL(n_comb, np, true); AL(pair_ll, np, true); AL(pair_mapq, np, true);
     AL(mate_mapq, nr, true); AL(strands_valid, np, true); AL(sel_mapq, nr * (size_t)B.stride, true);
-    AL(pair_deferred, np, true); AL(counters, 32, true); AL(work_counter, WC_N, true); AL(retry_list, 16 * nc, false);
+    AL(pair_deferred, np, true); AL(pair_multi, 4 * np, false); AL(counters, 32, true); AL(work_counter, WC_N, true); AL(retry_list, 16 * nc, false);
     { DpItem* it = nullptr; rc = dev_alloc(c, b->allocs, 2 * nc, &it, false); if(rc) return rc; B.dp_items = it; }
     B.dp_nblk = (int)((nc + 255) / 256); if(B.dp_nblk < 1) B.dp_nblk = 1;
     B.dp_jf = c->jf_grid > 0 ? c->jf_margin + 1 : 0;
@@ -806,6 +814,8 @@ void hlala_batch_destroy(hlala_batch* b)
     hlala_ctx* c = b->ctx;
     DEV_GUARD(c);
     if(c) {
+        if(b->tail_pooled) (void)flush_tail(c);       // (its pending classes run with whatever the pool holds; should that fail, the batch leaves the pool below)
+        c->tail.erase(std::remove(c->tail.begin(), c->tail.end(), b), c->tail.end());
         c->batches.erase(b);
         if(b->side_inflight) (void)hipEventSynchronize(b->evDone);
         if(b->mainValid) (void)hipEventSynchronize(b->evMain);       // nothing of this batch may still be running when its buffers are handed to the next one (readers and uploads return synchronised)
@@ -889,11 +899,15 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
     DEV_GUARD(c);
     if(!c || !b) return HLALA_E_ARG;
     if(!(b->staged & 1)) { c->err = "hlala_extend_chains before seed chains exist"; return HLALA_E_STATE; }
-    if(phase != 2) { int rj = join_side(c, b); if(rj) return rj; }
+    // phases 3 / 4 (round 6, tail pool): 3 = the main-stream part + the first side-stream class (wide) of THIS batch, the later classes left pending; 4 = the second stitch
+    // pass alone, queued by flush_tail behind the pooled launches of those classes
+    const bool sidePartOnly = phase == 2 || phase == 4;
+    if(!sidePartOnly) { int rj = join_side(c, b); if(rj) return rj; }
     { int re = batch_events(c, b); if(re) return re; }
     DevBatch& B = b->B;
-    if(B.unpaired || B.from_seeds || B.n_pairs <= 0 || B.n_chains <= 0) { fused = false; if(phase == 2) return HLALA_OK; phase = 0; }
-    if(phase != 2) {
+    if(B.unpaired || B.from_seeds || B.n_pairs <= 0 || B.n_chains <= 0) { fused = false; if(sidePartOnly) return HLALA_OK; phase = 0; }
+    const bool mainPart = !sidePartOnly;
+    if(mainPart) {
     b->side_used = false; b->side_pending = false;
     if(B.n_pairs > 0) HIP_TRY(c, hipMemsetAsync(B.pair_deferred, 0, (size_t)B.n_pairs, c->active));
     HIP_TRY(c, hipMemsetAsync(B.work_counter + 1, 0, sizeof(int), c->active));
@@ -905,7 +919,7 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
         DpItem* items = (DpItem*)B.dp_items;
         const u32 seed = c->params.rng_seed + 2u * b->first_chain;
         int rc = 0;
-        if(phase != 2) {
+        if(mainPart) {
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_head, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));       // -1: k_dp_items links the duplicates of a DP to it
         HIP_TRY(c, hipMemsetAsync(B.dp_alias_next, 0xFF, (size_t)2 * B.n_chains * sizeof(int), c->active));
         // items, then the ten dense lists of the first classes (three band lists, jump-free, general; left / right each) in position order: counts per block, their scan, the slots
@@ -921,6 +935,8 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
         // Each class is timed with its own pair of events on the stream it runs on (evC); ev[7] / ev[6] / ev[10] keep marking the start of the 16-lane
         // class, its end and the end of the 64-lane class on the main stream.
         hipStream_t ws = c->active;
+        const DpPoolArgs noPool{};                                   // classes before DP_POOL_TIER take the batch of their plain arguments
+        DpPoolArgs one{}; one.n = 1; one.seed[0] = seed; one.B[0] = b->dB; one.items[0] = items; one.bases[0] = (const uint8_t*)B.read_bases;      // the later ones a list of batches: this one
         auto run_class = [&](int tier) -> int {
             if(fused && tier == DP_SIDE_TIER) {
                 if(!b->evDone) HIP_TRY(c, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming));
@@ -936,23 +952,23 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
             case 0:
                 // the calls that meet no gap-path jump in the instantiation without the early-cell machinery, then the others (same slabs: one after the other)
                 if(c->jf_grid > 0) {
-                    hipLaunchKernelGGL((k_dp<DpTinyJF, 0>), dim3(c->jf_grid), dim3(DpTinyJF::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases);
+                    hipLaunchKernelGGL((k_dp<DpTinyJF, 0>), dim3(c->jf_grid), dim3(DpTinyJF::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, noPool);
                     int rcj = check_launch(c, "k_dp<DpTinyJF>"); if(rcj) return rcj;
                     HIP_TRY(c, hipEventRecord(b->evJF, ws));
                 }
-                hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(DpTiny::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(DpMid::THREADS), 0, ws, c->dG, b->dB, items, c->mid_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 2: hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(DpSmall::THREADS), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 3: hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(DpWide::THREADS), 0, ws, c->dG, b->dB, items, c->wide_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 4: hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(DpBroad::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            case 5: hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(DpLarge::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs + c->large_slab_bytes * (size_t)c->broad_grid, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
-            default: hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(DpHuge::THREADS), 0, ws, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases); break;
+                hipLaunchKernelGGL((k_dp<DpTiny, 0>), dim3(c->tiny_grid), dim3(DpTiny::THREADS), 0, ws, c->dG, b->dB, items, c->tiny_slabs, c->tiny_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, noPool); break;
+            case 1: hipLaunchKernelGGL((k_dp<DpMid, 1>), dim3(c->mid_grid), dim3(DpMid::THREADS), 0, ws, c->dG, b->dB, items, c->mid_slabs, c->mid_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, noPool); break;
+            case 2: hipLaunchKernelGGL((k_dp<DpSmall, 2>), dim3(c->ext_grid), dim3(DpSmall::THREADS), 0, ws, c->dG, b->dB, items, c->ext_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, noPool); break;
+            case 3: hipLaunchKernelGGL((k_dp<DpWide, 3>), dim3(c->wide_grid), dim3(DpWide::THREADS), 0, ws, c->dG, b->dB, items, c->wide_slabs, c->ext_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, noPool); break;
+            case 4: hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(DpBroad::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, one); break;
+            case 5: hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(DpLarge::THREADS), 0, ws, c->dG, b->dB, items, c->large_slabs + c->large_slab_bytes * (size_t)c->broad_grid, c->large_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, one); break;
+            default: hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(DpHuge::THREADS), 0, ws, c->dG, b->dB, items, c->huge_slabs, c->huge_slab_bytes, seed, c->G.nrec_out, c->G.nrec_in, B.read_bases, one); break;
             }
             int rc_ = check_launch(c, "k_dp"); if(rc_) return rc_;
             HIP_TRY(c, hipEventRecord(b->evC[tier][1], ws));
             return 0;
         };
-        if(phase != 2) {
+        if(mainPart) {
         // calls on linear stretches of the graph first: anti-diagonals in registers, four calls per wavefront (kernel_dp_band.hip); what it cannot finish is on the
         // fail-over list the general 16-lane instantiation draws after its own
         b->band_used = c->band_grid > 0;
@@ -969,15 +985,18 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
         HIP_TRY(c, hipEventRecord(b->ev[6], c->active));
         }
         for(int tier = 1; tier <= DP_LAST_TIER; tier++) {
+            if(phase == 4) break;
             if(phase == 1 && tier >= DP_SIDE_TIER) break;
             if(phase == 2 && tier < DP_SIDE_TIER) continue;
+            if(phase == 3 && tier >= DP_POOL_TIER) break;
             rc = run_class(tier); if(rc) return rc;
             if(tier == 2) HIP_TRY(c, hipEventRecord(b->ev[10], c->active));
         }
         if(!fused) HIP_TRY(c, hipEventRecord(b->ev[8], c->active));
         const int sgrid = B.n_chains < c->stitch_grid ? B.n_chains : c->stitch_grid;
         if(fused && phase == 1) b->side_pending = true;
-        if(fused && phase != 1) {
+        if(fused && phase == 3) { b->side_pending = true; b->side_used = true; }
+        if(fused && phase != 1 && phase != 3) {
             // second pass (side): the chains of the deferred pairs, work counter 36; first pass (main): all the others, work counter 7
             { const int pgrid = (B.n_pairs + 63) / 64, cap = c->stitch_grid / 20;       // the second pass sweeps the pairs' flags, 64 per wave and round: one wave per CU finds room beside the next batch's persistent kernels
               hipLaunchKernelGGL(k_stitch_chains, dim3(pgrid < cap ? (pgrid > 0 ? pgrid : 1) : cap), dim3(64), 0, c->side, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, 2, 0, 0); }
@@ -986,12 +1005,12 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
             HIP_TRY(c, hipEventRecord(c->evSideTail, c->side)); c->sideTailValid = true;
             b->side_inflight = true; b->side_used = true; b->side_pending = true;
         }
-        if(phase != 2) {
+        if(mainPart) {
         hipLaunchKernelGGL(k_stitch_chains, dim3(sgrid), dim3(64), 0, c->active, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, fused ? 1 : 0, c->stitch_draw, c->stitch_by_row);
         rc = check_launch(c, "k_stitch_chains"); if(rc) return rc;
         }
     }
-    if(phase == 2) return HLALA_OK;
+    if(sidePartOnly) return HLALA_OK;
     HIP_TRY(c, hipEventRecord(b->ev[3], c->active));
     b->staged |= 2;
     return mark_main(c, b);
@@ -1017,10 +1036,25 @@ static int pair_impl(hlala_ctx* c, hlala_batch* b, int phase)
     }
     if(B.n_pairs > 0) {
         const int grid = B.n_pairs < c->pair_grid ? B.n_pairs : c->pair_grid;
+        // k_pair_chains finishes the pairs with one combination and lists the others, k_pair_multi<., false / true> runs the two lists (kernel_pair.hip); the main-
+        // and the side-stream pass have their own lists, counters and combination scratch
         auto launch_pair = [&](hipStream_t st, int mode, int counterIdx) -> int {
-            if(B.unpaired) hipLaunchKernelGGL((k_pair_chains<true>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx, c->pair_scratch + (st == c->side ? (size_t)c->pair_grid * PAIR_COMB : 0));
-            else hipLaunchKernelGGL((k_pair_chains<false>), dim3(grid), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx, c->pair_scratch + (st == c->side ? (size_t)c->pair_grid * PAIR_COMB : 0));
-            return check_launch(c, "k_pair_chains");
+            const int pass = st == c->side ? 1 : 0, multiBase = WC_PAIR_MULTI + 4 * pass;
+            int* multiList = B.pair_multi + (size_t)pass * 2 * (size_t)B.n_pairs;
+            double* scratch = c->pair_scratch + (pass ? (size_t)c->pair_grid * PAIR_COMB : 0);
+            HIP_TRY(c, hipMemsetAsync(B.work_counter + multiBase, 0, 4 * sizeof(int), st));
+            const int lean = B.n_pairs < c->pair_lean_grid ? B.n_pairs : c->pair_lean_grid;
+            const int g0 = mode == 2 ? (grid < c->pair_grid / 5 ? grid : c->pair_grid / 5) : grid, g1 = grid < c->pair_grid / 5 ? grid : c->pair_grid / 5;      // (the second pass and the general class hold a few thousand pairs at most)
+            if(B.unpaired) {
+                hipLaunchKernelGGL((k_pair_chains<true>), dim3(lean), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx, multiList, multiBase);
+                hipLaunchKernelGGL((k_pair_multi<true, false>), dim3(g0), dim3(64), 0, st, c->dG, c->dT, b->dB, (const int*)multiList, multiBase, scratch);
+                hipLaunchKernelGGL((k_pair_multi<true, true>), dim3(g1), dim3(64), 0, st, c->dG, c->dT, b->dB, (const int*)multiList, multiBase, scratch);
+            } else {
+                hipLaunchKernelGGL((k_pair_chains<false>), dim3(lean), dim3(64), 0, st, c->dG, c->dT, b->dB, (const uint8_t*)B.pair_deferred, mode, counterIdx, multiList, multiBase);
+                hipLaunchKernelGGL((k_pair_multi<false, false>), dim3(g0), dim3(64), 0, st, c->dG, c->dT, b->dB, (const int*)multiList, multiBase, scratch);
+                hipLaunchKernelGGL((k_pair_multi<false, true>), dim3(g1), dim3(64), 0, st, c->dG, c->dT, b->dB, (const int*)multiList, multiBase, scratch);
+            }
+            return check_launch(c, "k_pair_chains / k_pair_multi");
         };
         int rc = 0;
         if(phase != 2) { rc = launch_pair(c->active, fused ? 1 : 0, 2); if(rc) return rc; }
@@ -1039,9 +1073,62 @@ static int pair_impl(hlala_ctx* c, hlala_batch* b, int phase)
     return mark_main(c, b);
 }
 
+// The tail pool (round 6).  The broad, large and in-memory DP classes hold 0.07 % of a batch's DP calls and took 100 ms of side stream per batch: their cost is the
+// latency of their slowest calls, paid per launch, while their blocks hold most of every CU's LDS beside the next batch's kernels.  With hlala_set_tail_pool(ctx, k)
+// a fused alignment runs its main-stream part and its wide class as before and leaves those three classes PENDING; the k-th pending batch (or hlala_flush, or any
+// call that reads or re-runs a pending batch) launches each of them once over all pending batches (k_dp: DpPoolArgs), then the second stitch / pairing pass of every
+// batch.  Results do not depend on k (tests/test_graph_m.py).
+static int flush_tail(hlala_ctx* c)
+{
+    if(c->tail.empty()) return HLALA_OK;
+    DEV_GUARD(c);
+    std::vector<hlala_batch*> pool; pool.swap(c->tail);
+    for(hlala_batch* b : pool) b->tail_pooled = false;           // (whatever happens below, nobody waits for this flush again)
+    DpPoolArgs a{}; a.n = (int)pool.size();
+    for(int i = 0; i < a.n; i++) { hlala_batch* b = pool[i]; a.seed[i] = c->params.rng_seed + 2u * b->first_chain; a.B[i] = b->dB; a.items[i] = (const DpItem*)b->B.dp_items; a.bases[i] = (const uint8_t*)b->B.read_bases; }
+    const hipStream_t ws = c->side;
+    for(int tier = DP_POOL_TIER; tier <= DP_LAST_TIER; tier++) {
+        for(hlala_batch* b : pool) HIP_TRY(c, hipEventRecord(b->evC[tier][0], ws));
+        hlala_batch* b0 = pool[0];
+        switch(tier) {
+        case 4: hipLaunchKernelGGL((k_dp<DpBroad, 4>), dim3(c->broad_grid), dim3(DpBroad::THREADS), 0, ws, c->dG, b0->dB, (DpItem*)b0->B.dp_items, c->large_slabs, c->large_slab_bytes, a.seed[0], c->G.nrec_out, c->G.nrec_in, b0->B.read_bases, a); break;
+        case 5: hipLaunchKernelGGL((k_dp<DpLarge, 5>), dim3(c->retry_grid), dim3(DpLarge::THREADS), 0, ws, c->dG, b0->dB, (DpItem*)b0->B.dp_items, c->large_slabs + c->large_slab_bytes * (size_t)c->broad_grid, c->large_slab_bytes, a.seed[0], c->G.nrec_out, c->G.nrec_in, b0->B.read_bases, a); break;
+        default: hipLaunchKernelGGL((k_dp<DpHuge, 6>), dim3(c->huge_grid), dim3(DpHuge::THREADS), 0, ws, c->dG, b0->dB, (DpItem*)b0->B.dp_items, c->huge_slabs, c->huge_slab_bytes, a.seed[0], c->G.nrec_out, c->G.nrec_in, b0->B.read_bases, a); break;
+        }
+        int rc_ = check_launch(c, "k_dp (pooled)"); if(rc_) return rc_;
+        for(hlala_batch* b : pool) HIP_TRY(c, hipEventRecord(b->evC[tier][1], ws));
+    }
+    for(hlala_batch* b : pool) {
+        int rc = extend_impl(c, b, true, 4); if(rc) return rc;      // second stitch pass over the deferred pairs
+        rc = pair_impl(c, b, 2); if(rc) return rc;                   // second pairing pass; records evDone
+    }
+    return HLALA_OK;
+}
+
+int hlala_set_tail_pool(hlala_ctx* c, int k)
+{
+    if(!c || k < 1 || k > DP_POOL_MAX) { if(c) c->err = "hlala_set_tail_pool: k must be 1 .. " + std::to_string(DP_POOL_MAX); return HLALA_E_ARG; }
+    if(k < (int)c->tail.size() || k == 1) { int rf = flush_tail(c); if(rf) return rf; }
+    c->tail_pool_k = k;
+    return HLALA_OK;
+}
+int hlala_flush(hlala_ctx* c)
+{
+    if(!c) return HLALA_E_ARG;
+    return flush_tail(c);
+}
+
 int hlala_align_batch(hlala_ctx* c, hlala_batch* b)
 {
     int rc = hlala_project_chains(c, b); if(rc) return rc;
+    if(c->tail_pool_k > 1 && DP_POOL_TIER > DP_SIDE_TIER) {
+        rc = extend_impl(c, b, true, 3); if(rc) return rc;
+        if(!b->side_pending) return hlala_pair_chains(c, b);          // not a fused alignment (unpaired, from seeds, empty): nothing to pool
+        rc = pair_impl(c, b, 1); if(rc) return rc;
+        c->tail.push_back(b); b->tail_pooled = true;
+        if((int)c->tail.size() >= c->tail_pool_k) return flush_tail(c);
+        return HLALA_OK;
+    }
     if(!c->side_after_pair) {
         rc = extend_impl(c, b, true); if(rc) return rc;
         return hlala_pair_chains(c, b);

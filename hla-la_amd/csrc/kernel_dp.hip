@@ -625,6 +625,8 @@ struct __align__(16) DpItem { int item, rOff, seqLen, start_seq, startLevel, sta
 #endif
 constexpr int DP_SIDE_TIER = HLALA_DP_SIDE_TIER;
 constexpr int DP_LAST_TIER = 6;      // tiers: 0 DpTiny, 1 DpMid, 2 DpSmall, 3 DpWide, 4 DpBroad, 5 DpLarge, 6 DpHuge
+constexpr int DP_POOL_TIER = DP_SIDE_TIER > 4 ? DP_SIDE_TIER : 4;      // first class that a tail pool defers and runs once for several batches (k_dp: DpPoolArgs)
+constexpr int DP_POOL_MAX = 8;       // batches per pooled launch
 // first tier whose class holds a frontier of n cells / a target set of n cells
 __device__ __forceinline__ int tier_for_frontier(int n) { return n <= DpMid::WCAP ? 1 : (n <= DpSmall::WCAP ? 2 : (n <= DpWide::WCAP ? 3 : (n <= DpBroad::WCAP ? 4 : (n <= DpLarge::WCAP ? 5 : 6)))); }
 __device__ __forceinline__ int tier_for_targets(int n) { return n <= (DpMid::HC * 3) / 4 ? 1 : (n <= (DpSmall::HC * 3) / 4 ? 2 : (n <= (DpWide::HC * 3) / 4 ? 3 : (n <= (DpBroad::HC * 3) / 4 ? 4 : (n <= (DpLarge::HC * 3) / 4 ? 5 : 6)))); }
@@ -1663,25 +1665,34 @@ __global__ void k_dp_lists(const DevBatch* __restrict__ Bp, const DpItem* __rest
 // TIER 0: items of k_dp_items, the left extensions first and then the right extensions, so that the direction (and with it
 //         every choice between the out- and the in-edge arrays) is uniform across the four groups of a wavefront;
 // TIER k > 0: items that outgrew the class of tier k-1 (retry list k).
+// Round 6: the classes from DP_POOL_TIER on (broad, large, in-memory: a few hundred long calls per batch whose cost is the latency of their slowest call, paid per
+// LAUNCH) take the lists of SEVERAL batches in one launch -- hlala_align_batch with a tail pool (hlala_set_tail_pool) leaves them pending and runs them once for up to
+// DP_POOL_MAX consecutive batches of a sample.  The kernel walks the batches one after the other: every list has its own fetch counter, a block that finds a list
+// drained goes on to the next batch's.
+struct DpPoolArgs {
+    int n;                                      // batches of this launch (1: the batch of the plain arguments)
+    u32 seed[DP_POOL_MAX];                      // rng_seed + 2 * first chain of the batch
+    const DevBatch* B[DP_POOL_MAX];
+    const DpItem* items[DP_POOL_MAX];
+    const uint8_t* bases[DP_POOL_MAX];
+};
+
+template <class C, int TIER>
+__device__ __forceinline__ void dp_class_run(const DevGraph& G, const DevBatch& B, const DpItem* __restrict__ items, DpLdsT<C>& S, DpSlabT<C> sl, u64* sortScratch, const u32 rng_seed,
+                                             const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBases);
+
 template <class C, int TIER>
 __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const DpItem* __restrict__ items,
                                                         char* slabs, size_t slabBytes, u32 rng_seed,
                                                         // the arrays of the inner loop are passed as kernel arguments: pointers loaded from the descriptors are generic
                                                         // (flat_load, which also ties up the LDS counter), kernel-argument pointers are known to be global
-                                                        const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBasesArg)
+                                                        const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBasesArg, const DpPoolArgs pool)
 {
     constexpr int GW = C::GW;
     constexpr int NG = GW >= 64 ? 1 : 64 / GW;           // DPs per block: groups of a wavefront, or one DP for the whole block
-#ifndef HLALA_DP_DRAW0
-#define HLALA_DP_DRAW0 8
-#endif
-    constexpr int DRAW = (TIER == 0 && C::JF) ? HLALA_DP_DRAW0 : 1;      // items a group draws per atomic: several for the short, even calls of the jump-free list (36.7 -> 32.5 ms at 3 M calls); the general list and the later
-                                                                          // classes hold long calls that sit together in position order -- draws of 8 there cost 9 ms of tail (profiles/r05_experiments.txt)
     static_assert(C::THREADS == (GW >= 64 ? GW : 64), "block size");
     // graph / batch descriptors stay in memory (scalar loads on demand): passing them by value costs ~150 SGPRs
     const DevGraph& G = *Gp;
-    const DevBatch& B = *Bp;
-    const int gl = grp_lane<GW>();
     const int g = (int)((threadIdx.x & 63) / GW);
     DpLdsT<C>* Sp; DpSlabT<C> sl; u64* sortScratch = nullptr;
     if constexpr (C::IN_MEMORY) {
@@ -1692,8 +1703,28 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES) void k_dp(const DevGraph* __r
         __shared__ DpLdsT<C> SS[NG];
         Sp = &SS[g]; sl.base = slabs + ((size_t)blockIdx.x * NG + g) * slabBytes;
     }
-    DpLdsT<C>& S = *Sp;
-    const uint8_t* readBases = readBasesArg;
+    if constexpr (TIER >= DP_POOL_TIER) {
+        const int nB = __builtin_amdgcn_readfirstlane(pool.n);
+        for(int bi = 0; bi < nB; bi++) {
+            dp_class_run<C, TIER>(G, *pool.B[bi], pool.items[bi], *Sp, sl, sortScratch, pool.seed[bi], nrecOut, nrecIn, pool.bases[bi]);
+            DSYNC();
+        }
+    } else dp_class_run<C, TIER>(G, *Bp, items, *Sp, sl, sortScratch, rng_seed, nrecOut, nrecIn, readBasesArg);
+}
+
+// one class over the lists of one batch (the body of k_dp)
+template <class C, int TIER>
+__device__ __forceinline__ void dp_class_run(const DevGraph& G, const DevBatch& B, const DpItem* __restrict__ items, DpLdsT<C>& S, DpSlabT<C> sl, u64* sortScratch, const u32 rng_seed,
+                                             const int4* __restrict__ nrecOut, const int4* __restrict__ nrecIn, const uint8_t* __restrict__ readBases)
+{
+    constexpr int GW = C::GW;
+    constexpr int NG = GW >= 64 ? 1 : 64 / GW;           // DPs per block: groups of a wavefront, or one DP for the whole block
+#ifndef HLALA_DP_DRAW0
+#define HLALA_DP_DRAW0 8
+#endif
+    constexpr int DRAW = (TIER == 0 && C::JF) ? HLALA_DP_DRAW0 : 1;      // items a group draws per atomic: several for the short, even calls of the jump-free list (36.7 -> 32.5 ms at 3 M calls); the general list and the later
+                                                                          // classes hold long calls that sit together in position order -- draws of 8 there cost 9 ms of tail (profiles/r05_experiments.txt)
+    const int gl = grp_lane<GW>();
 
     if(gl == 0) { S.accCalls = 0; S.accIters = 0; S.accCells = 0; S.accEdges = 0; }
 #ifdef HLALA_DP_TIMING

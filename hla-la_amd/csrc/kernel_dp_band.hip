@@ -33,10 +33,12 @@ constexpr int BAND_ABSENT = -20000;       // any value below: no cell / no candi
 constexpr int BAND_DRAW = 16;             // tasks of a wavefront per draw from the item list
 constexpr int BAND_TIES = 16;             // equal best sequence-complete cells a call may hold (more: fail-over)
 
+// WAVES: five per SIMD (96 registers, nothing spilled).  Six (80 registers) spilled 8 registers of the 16- and 32-lane instantiations into scratch inside the iteration
+// loop and bought nothing: the kernels take the same time with 12, 16 or 24 waves on a CU (profiles/r05_experiments.txt 4).
 template <int GW_> struct BandCfg;
-template <> struct BandCfg<16> { static constexpr int GW = 16, MAXJ = BAND_MAXJ16, REACH = 64, MAXD = 96, WAVES = 6; };
-template <> struct BandCfg<32> { static constexpr int GW = 32, MAXJ = BAND_MAXJ32, REACH = 96, MAXD = 128, WAVES = 6; };
-template <> struct BandCfg<64> { static constexpr int GW = 64, MAXJ = BAND_MAXJ64, REACH = 112, MAXD = 160, WAVES = 6; };
+template <> struct BandCfg<16> { static constexpr int GW = 16, MAXJ = BAND_MAXJ16, REACH = 64, MAXD = 96, WAVES = 5; };
+template <> struct BandCfg<32> { static constexpr int GW = 32, MAXJ = BAND_MAXJ32, REACH = 96, MAXD = 128, WAVES = 5; };
+template <> struct BandCfg<64> { static constexpr int GW = 64, MAXJ = BAND_MAXJ64, REACH = 112, MAXD = 160, WAVES = 5; };
 
 template <class C>
 struct __align__(16) BandLds {

@@ -17,18 +17,28 @@ constexpr int PAIR_COMB   = 1024;   // chain combinations per pair
 #define HLALA_PAIR_COMB_LDS 128      // (tools/gpu_gen_wrap.sh builds with 2 to run the parity tests through the HBM-scratch instance)
 #endif
 constexpr int PAIR_COMB_LDS = HLALA_PAIR_COMB_LDS;  // ... of which the LDS block holds this many; pairs with more keep theirs in the wave's HBM scratch
+#ifndef PAIR_LEAN_WAVES
+#define PAIR_LEAN_WAVES 6           // waves per SIMD k_pair_chains / k_pair_multi<., false> are compiled for (tools/gpu_r6_pair.sh measures the alternatives)
+#endif
+#ifndef PAIR_MULTI_WAVES
+#define PAIR_MULTI_WAVES 4
+#endif
 constexpr int PAIR_COLS   = 512;    // columns per chain handled by the per-position pass
 
 // Per-position pass: what the columns of the chain under comparison look like from the selected chain's side -- by read-base ordinal and by level
 // (level - the chain's first level; a chain's defined levels rise by one per column, so 512 columns span fewer than 512 levels)
 constexpr short PAIR_NOCOL = -32768;     // no base column with this ordinal
 constexpr short PAIR_NOLEVEL = -32767;   // the column carries no level (-1: a base the read inserts)
-struct __align__(16) PairLds {
-    double LL[PAIR_COMB_LDS];
-    double phredThr[256];                // DevTables::phred_thr: the binary search of PCorrectToPhred runs on this copy (eight dependent loads per column otherwise)
+// the chain lists of a pair: all that k_pair_chains itself keeps in LDS (0.7 KB per wavefront; round 6 -- the tables of the multi-combination pairs live in k_pair_multi)
+struct __align__(16) PairListLds {
     int list[2][PAIR_CHAINS];
     int nlist[2];
     unsigned char src[2][PAIR_CHAINS];   // the lane that loaded the facts of list entry k (PairChain)
+};
+struct __align__(16) PairLds {
+    PairListLds L;
+    double LL[PAIR_COMB_LDS];
+    double phredThr[256];                // DevTables::phred_thr: the binary search of PCorrectToPhred runs on this copy (eight dependent loads per column otherwise)
     short baseLev[PAIR_COLS];            // [read-base ordinal] relative level of that base's column (PAIR_NOCOL / PAIR_NOLEVEL)
     unsigned char baseG[PAIR_COLS];      // ... its graph character
     unsigned char levS[PAIR_COLS];       // [relative level] read character of the column on that level (0: none)
@@ -311,7 +321,7 @@ __device__ __forceinline__ void pair_positions(const DevBatch& B, PairLds& P, co
 #define PAIR_T(i) do { } while(0)
 #endif
 
-template <bool UNPAIRED>
+template <bool UNPAIRED, bool BIG>
 __device__ __forceinline__ void pair_finish(const DevGraph& G, const DevTables& T, const DevBatch& B, PairLds& P, double* __restrict__ LL,
                                             const int p, const int n1, const int n2, const int nComb, const int mxc, const PairChain& cA, const PairChain& cB, const int lane, const int stride, long long* tAcc, long long& tMark)
 {
@@ -346,7 +356,7 @@ __device__ __forceinline__ void pair_finish(const DevGraph& G, const DevTables& 
         for(int i = lane; i < nComb; i += 64) { double v = LL[i]; if(v > mx) { mx = v; mi = i; } }
         for(int o = 32; o; o >>= 1) { double ov = __shfl_xor(mx, o); int oi = __shfl_xor(mi, o); if(ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; } }
         const int bestI = uni(mi), best1 = bestI / n2, best2 = bestI % n2;
-        const int selA = uni(P.list[0][best1]), selB = UNPAIRED ? selA : uni(P.list[1][best2]);
+        const int selA = uni(P.L.list[0][best1]), selB = UNPAIRED ? selA : uni(P.L.list[1][best2]);
         // ---- posterior over combinations (:4064-4085): exp(LL - max), normalised by a left-to-right sum
         double mapQ = 1, q1 = 1, q2 = 1;
         if(nComb > 1) {
@@ -385,7 +395,7 @@ __device__ __forceinline__ void pair_finish(const DevGraph& G, const DevTables& 
         }
         PAIR_T(2);
 #ifndef PAIR_X_NOPOS
-        if(mxc <= 192) pair_positions<UNPAIRED, 3>(B, P, LL, p, n1, n2, nComb, best1, best2, cA, cB, lane, stride);
+        if(!BIG || mxc <= 192) pair_positions<UNPAIRED, 3>(B, P, LL, p, n1, n2, nComb, best1, best2, cA, cB, lane, stride);
         else pair_positions<UNPAIRED, PAIR_COLS / 64>(B, P, LL, p, n1, n2, nComb, best1, best2, cA, cB, lane, stride);
 #endif
         PAIR_T(nComb == 1 ? 3 : 4);
@@ -394,16 +404,74 @@ __device__ __forceinline__ void pair_finish(const DevGraph& G, const DevTables& 
 #endif
 }
 
+// ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains, :3408-3420), error propagation, and the facts of the listed chains in list
+// order (PairChain: lane k holds the k-th chain of either mate's list).  cLo / cHi: the chain ranges of the pair's mates (wave-uniform).
+// Returns 1 when the pair cannot be scored (a flagged chain, an empty list, more chains / combinations / columns than the tables hold).
+template <bool UNPAIRED>
+__device__ __forceinline__ int pair_lists(const DevBatch& B, PairListLds& L, const int* cLo, const int* cHi, const int lane, int& n1, int& n2, int& mxcOut, PairChain* cL)
+{
+    constexpr int NM = UNPAIRED ? 1 : 2;
+    int bad = 0;
+    int stF[NM], ncF[NM];
+    // status and length of the first 64 chains of both mates: one round trip (a pair with more alignments per mate loops on)
+    #pragma unroll
+    for(int m = 0; m < NM; m++) { const int c = cLo[m] + lane; stF[m] = 1; ncF[m] = 0; if(c < cHi[m]) { stF[m] = B.ext_status[c]; ncF[m] = B.ext_ncols[c]; } }
+    // ... and, in the same round trip, everything else the pairing reads of these chains (PairChain; chains that turn out not to be listed cost a few unused loads)
+    PairChain cF[NM];
+    #pragma unroll
+    for(int m = 0; m < NM; m++) { const int c = cLo[m] + lane; cF[m].fl = make_int4(-1, -1, -1, -1); cF[m].rev = 0; cF[m].nk = 0; cF[m].row = 0; cF[m].ll = 0.0; if(c < cHi[m]) { cF[m] = pair_chain_load(B, c); } }
+    int mxc = 0;                 // longest listed chain: the per-position pass holds PAIR_COLS columns per chain (long reads come with one alignment each: nComb == 1, any length)
+    #pragma unroll
+    for(int m = 0; m < NM; m++) {
+        const int c0 = cLo[m], c1 = cHi[m];
+        int cnt = 0;
+        for(int b0 = c0; b0 < c1; b0 += 64) {
+            int c = b0 + lane; int st, nc;
+            if(b0 == c0) { st = stF[m]; nc = ncF[m]; } else { st = 1; nc = 0; if(c < c1) { st = B.ext_status[c]; nc = B.ext_ncols[c]; } }
+            if(__ballot(st < 0)) bad = 1;
+            u64 okm = __ballot(st == HLALA_CHAIN_OK);
+            if(st == HLALA_CHAIN_OK) { int pos = cnt + __popcll(okm & ((1ull << lane) - 1ull)); if(pos < PAIR_CHAINS) { L.list[m][pos] = c; L.src[m][pos] = (unsigned char)lane; mxc = max(mxc, nc); } }
+            cnt += __popcll(okm);
+        }
+        if(lane == 0) L.nlist[m] = cnt;
+        if(cnt < 1 || cnt > PAIR_CHAINS) bad = 1;
+    }
+    WSYNC();
+    n1 = uni(L.nlist[0]); n2 = UNPAIRED ? 1 : uni(L.nlist[1]);
+    bad = uni(bad);
+    const long long nCombLL = (long long)n1 * n2;
+    if(!bad && nCombLL > PAIR_COMB) bad = 1;
+    mxc = wave_max_i32(mxc);
+    if(!bad && nCombLL > 1 && mxc > PAIR_COLS) bad = 1;
+    mxcOut = mxc;
+    if(bad) return 1;
+    // the listed chains' facts into list order: lane k <- the lane that loaded chain list[k] (a mate with more than 64 alignments: loaded again through the list)
+    #pragma unroll
+    for(int m = 0; m < NM; m++) {
+        const int nl = m ? n2 : n1;
+        if(cHi[m] - cLo[m] <= 64) cL[m] = pair_chain_from_lane(cF[m], lane < nl ? (int)L.src[m][lane] : lane);
+        else { cL[m].fl = make_int4(-1, -1, -1, -1); cL[m].rev = 0; cL[m].nk = 0; cL[m].row = 0; cL[m].ll = 0.0; if(lane < nl) cL[m] = pair_chain_load(B, L.list[m][lane]); }
+    }
+    if(UNPAIRED) cL[1] = cL[0];
+    return 0;
+}
+
+// Round 6: the pairing stage is two kinds of pairs.  74 % of a Graph M batch's pairs have ONE combination: one insert-size term, mapQ 1, a constant per-position
+// quality -- 2.6 k cycles, no table.  The others run the posterior and the per-position pass (43 k cycles; LL table, Phred thresholds and the column tables: 6.3 KB of
+// LDS, and, compiled into one kernel with the first kind, 63 spilled registers for everybody).  k_pair_chains now finishes the first kind and LISTS the second
+// (multiList / work_counter[WC_PAIR_MULTI ...]: class 0 = up to PAIR_COMB_LDS combinations and chains of up to 192 columns, class 1 = the rest), k_pair_multi<., BIG>
+// runs a class from its list.  With 0.7 KB of LDS a block of k_pair_chains finds room beside the wide DP class of its batch (seven blocks of 22 KB on a CU).
 // UNPAIRED: one read per unit (processBAM::alignOneLongRead :3618-3838 selects the first maximum of the chains' log likelihoods;
 // assignMappingQualities_unpaired :3900-4059 is the paired computation with a single, neutral second mate).
+// multiBase: first of the four work counters of this pass's lists (count / fetched of class 0, count / fetched of class 1); multiList: [2][n_pairs] pair numbers.
 template <bool UNPAIRED>
-__global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
+__global__ __launch_bounds__(64, PAIR_LEAN_WAVES) void k_pair_chains(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
                                                    const uint8_t* __restrict__ deferPairs, const int deferMode, const int counterIdx,      // deferMode 1: skip deferred pairs, 2: only those
-                                                   double* __restrict__ bigLL)                    // [gridDim.x][PAIR_COMB]
+                                                   int* __restrict__ multiList, const int multiBase)
 {
     const DevGraph& G = *Gp;
     const DevBatch& B = *Bp;
-    __shared__ PairLds P;
+    __shared__ PairListLds L;
     const int lane = lane_id();
     const DevTables& T = *Tp;
     const int stride = B.stride;
@@ -411,11 +479,10 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
     // pairs are drawn eight at a time (one same-address atomic per pair serialises the grid at the L2)
     constexpr int CHUNK = 8;
     int sweep = 0;
-    for(int i = lane; i < 256; i += 64) P.phredThr[i] = T.phred_thr[i];
-    WSYNC();
-    if(lane == 0) P.ired[7] = (int)pair_phred(P, 1.0);
-    WSYNC();
-    long long tAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tMark = clock64();
+    // PCorrectToPhred(1): the per-position quality of a pair with one combination (Utilities.cpp:178-203; once per block on the table in global memory)
+    int ph1 = 0;
+    if(lane == 0) { double pWrong = 1e-100; int lo = 0, hi = 255; while(lo < hi) { const int mid = (lo + hi + 1) >> 1; if(pWrong <= T.phred_thr[mid]) lo = mid; else hi = mid - 1; } ph1 = lo; }
+    ph1 = __builtin_amdgcn_readfirstlane(ph1);
     for(;;) {
         int p0 = 0;
         if(deferMode == 2) { p0 = ((int)blockIdx.x + sweep * (int)gridDim.x) * CHUNK; sweep++; }      // second pass (a few thousand pairs of a million): the waves sweep the flags, no draws
@@ -439,71 +506,105 @@ __global__ __launch_bounds__(64, 5) void k_pair_chains(const DevGraph* __restric
         for(int p = p0; p < pEnd; p++) {
         const int hq = p - p0;
         if(deferMode) { const bool df = __builtin_amdgcn_readlane(hDf, hq) != 0; if(df == (deferMode == 1)) continue; }
-#if defined(PAIR_X_LEVEL) && PAIR_X_LEVEL == 1
-        if(lane == 0) B.pair_status[p] = __builtin_amdgcn_readlane(hC[0], hq) & 0;
-        continue;
-#endif
-        // ---- lists of extended chains per mate (read1_extendedChains / read2_extendedChains), error propagation
-        int bad = 0;
-        int cLo[NM], cHi[NM], stF[NM], ncF[NM];
+        int cLo[NM], cHi[NM];
         #pragma unroll
         for(int m = 0; m < NM; m++) { cLo[m] = __builtin_amdgcn_readlane(hC[m], hq); cHi[m] = __builtin_amdgcn_readlane(hC[m + 1], hq); }
-        // status and length of the first 64 chains of both mates: one round trip (a pair with more alignments per mate loops on)
-        #pragma unroll
-        for(int m = 0; m < NM; m++) { const int c = cLo[m] + lane; stF[m] = 1; ncF[m] = 0; if(c < cHi[m]) { stF[m] = B.ext_status[c]; ncF[m] = B.ext_ncols[c]; } }
-        // ... and, in the same round trip, everything else the pairing reads of these chains (PairChain; chains that turn out not to be listed cost a few unused loads)
-        PairChain cF[NM];
-        #pragma unroll
-        for(int m = 0; m < NM; m++) { const int c = cLo[m] + lane; cF[m].fl = make_int4(-1, -1, -1, -1); cF[m].rev = 0; cF[m].nk = 0; cF[m].row = 0; cF[m].ll = 0.0; if(c < cHi[m]) { cF[m] = pair_chain_load(B, c); } }
-        int mxc = 0;                 // longest listed chain: the per-position pass below holds PAIR_COLS columns per chain (long reads come with one alignment each: nComb == 1, any length)
-        #pragma unroll
-        for(int m = 0; m < NM; m++) {
-            const int c0 = cLo[m], c1 = cHi[m];
-            int cnt = 0;
-            for(int b0 = c0; b0 < c1; b0 += 64) {
-                int c = b0 + lane; int st, nc;
-                if(b0 == c0) { st = stF[m]; nc = ncF[m]; } else { st = 1; nc = 0; if(c < c1) { st = B.ext_status[c]; nc = B.ext_ncols[c]; } }
-                if(__ballot(st < 0)) bad = 1;
-                u64 okm = __ballot(st == HLALA_CHAIN_OK);
-                if(st == HLALA_CHAIN_OK) { int pos = cnt + __popcll(okm & ((1ull << lane) - 1ull)); if(pos < PAIR_CHAINS) { P.list[m][pos] = c; P.src[m][pos] = (unsigned char)lane; mxc = max(mxc, nc); } }
-                cnt += __popcll(okm);
-            }
-            if(lane == 0) P.nlist[m] = cnt;
-            if(cnt < 1 || cnt > PAIR_CHAINS) bad = 1;
-        }
-        WSYNC();
-        const int n1 = uni(P.nlist[0]), n2 = UNPAIRED ? 1 : uni(P.nlist[1]);
-        bad = uni(bad);
-        const long long nCombLL = (long long)n1 * n2;
-        if(!bad && nCombLL > PAIR_COMB) bad = 1;
-        mxc = wave_max_i32(mxc);
-        if(!bad && nCombLL > 1 && mxc > PAIR_COLS) bad = 1;
-#if defined(PAIR_X_LEVEL) && PAIR_X_LEVEL == 2
-        { PairChain z = pair_chain_from_lane(cF[0], P.src[0][lane & 1]); if(lane == 0) B.pair_status[p] = (z.fl.x + z.rev + z.nk + z.row + (int)z.ll + cF[NM - 1].fl.y + n1 + n2) & 0; }
-        continue;
-#endif
+        int n1 = 0, n2 = 0, mxc = 0; PairChain cL[2];
+        const int bad = pair_lists<UNPAIRED>(B, L, cLo, cHi, lane, n1, n2, mxc, cL);
         if(bad) {
             if(lane == 0) { B.pair_status[p] = -1; if(UNPAIRED) B.best_chain[p] = -1; else { B.best_chain[2 * p] = -1; B.best_chain[2 * p + 1] = -1; } B.n_comb[p] = 0; }
+        } else if(n1 * n2 > 1) {
+            // posterior over several combinations + per-position pass: k_pair_multi, from this pass's list of the pair's class
+            if(lane == 0) { const int cls = (n1 * n2 <= PAIR_COMB_LDS && mxc <= 192) ? 0 : 1; const int q = atomicAdd(&B.work_counter[multiBase + 2 * cls], 1); multiList[(size_t)cls * (size_t)B.n_pairs + q] = p; }
         } else {
-        const int nComb = (int)nCombLL;
-        // the listed chains' facts into list order: lane k <- the lane that loaded chain list[k] (a mate with more than 64 alignments: loaded again through the list)
-        PairChain cL[2];
-        #pragma unroll
-        for(int m = 0; m < NM; m++) {
-            const int nl = m ? n2 : n1;
-            if(cHi[m] - cLo[m] <= 64) cL[m] = pair_chain_from_lane(cF[m], lane < nl ? (int)P.src[m][lane] : lane);
-            else { cL[m].fl = make_int4(-1, -1, -1, -1); cL[m].rev = 0; cL[m].nk = 0; cL[m].row = 0; cL[m].ll = 0.0; if(lane < nl) cL[m] = pair_chain_load(B, P.list[m][lane]); }
+            // ---- one combination (:3408-3506): its log likelihood is the maximum, the posterior 1 (:4064-4085), every position's confidence 1 (:4155-4311)
+            double combined = cL[0].ll;                               // (lane 0 holds the one listed chain of either mate)
+            bool svalid = false;
+            if(!UNPAIRED) {
+                const int fa0 = __builtin_amdgcn_readlane(cL[0].fl.x, 0), fa1 = __builtin_amdgcn_readlane(cL[0].fl.y, 0), fa2 = __builtin_amdgcn_readlane(cL[0].fl.z, 0), fa3 = __builtin_amdgcn_readlane(cL[0].fl.w, 0);
+                const int fb0 = __builtin_amdgcn_readlane(cL[1].fl.x, 0), fb1 = __builtin_amdgcn_readlane(cL[1].fl.y, 0), fb2 = __builtin_amdgcn_readlane(cL[1].fl.z, 0), fb3 = __builtin_amdgcn_readlane(cL[1].fl.w, 0);
+                const bool ra = __builtin_amdgcn_readlane(cL[0].rev, 0) != 0, rb = __builtin_amdgcn_readlane(cL[1].rev, 0) != 0;
+                if(fa0 != -1 && fb0 != -1 && ra != rb) svalid = (!ra) ? (fa0 < fb0) : (fa2 > fb2);          // alignerBase.cpp:213-244
+                double llIS = T.is_penalty;
+                if(svalid) llIS = (fa0 < fb0) ? pair_insert_ll(G, T, fa2, fa3, fb0, fb1) : pair_insert_ll(G, T, fb2, fb3, fa0, fa1);        // alignerBase.cpp:294, 312
+                combined = cL[0].ll + cL[1].ll;
+                combined += llIS;
+            }
+            const int selA = uni(L.list[0][0]), selB = UNPAIRED ? selA : uni(L.list[1][0]);
+            if(lane == 0) {
+                B.pair_status[p] = 0; B.n_comb[p] = 1; B.pair_ll[p] = combined; B.pair_mapq[p] = 1.0;
+                if(UNPAIRED) { B.best_chain[p] = selA; B.mate_mapq[p] = 1.0; B.strands_valid[p] = 0; }
+                else { B.best_chain[2 * p] = selA; B.best_chain[2 * p + 1] = selB; B.mate_mapq[2 * p] = 1.0; B.mate_mapq[2 * p + 1] = 1.0; B.strands_valid[p] = svalid ? 1 : 0; }
+            }
+            #pragma unroll
+            for(int m = 0; m < NM; m++) {
+                const int nSel = __builtin_amdgcn_readlane(cL[m].nk, 0); const size_t ob = (size_t)(UNPAIRED ? p : 2 * p + m) * stride;
+                for(int j = lane; j < nSel; j += 64) B.sel_mapq[ob + j] = (unsigned char)ph1;
+            }
         }
-        if(UNPAIRED) cL[1] = cL[0];
-        PAIR_T(0);
-        if(nComb <= PAIR_COMB_LDS) pair_finish<UNPAIRED>(G, T, B, P, P.LL, p, n1, n2, nComb, mxc, cL[0], cL[1], lane, stride, tAcc, tMark);
-        else pair_finish<UNPAIRED>(G, T, B, P, bigLL + (size_t)blockIdx.x * PAIR_COMB, p, n1, n2, nComb, mxc, cL[0], cL[1], lane, stride, tAcc, tMark);
-        }   // !bad
         WSYNC();
         }
     }
+}
+
+// The pairs with several combinations, from the list k_pair_chains wrote (class BIG ? 1 : 0 of the pass whose counters start at multiBase): lists again (one round
+// trip), then combinations, first maximum, posteriors, per-position pass.  BIG = false: up to PAIR_COMB_LDS combinations in LDS and chains of up to 192 columns
+// (three columns per lane); BIG = true: the general form (combination table in the wave's HBM scratch when it does not fit, eight columns per lane).
+template <bool UNPAIRED, bool BIG>
+__global__ __launch_bounds__(64, BIG ? 3 : PAIR_MULTI_WAVES) void k_pair_multi(const DevGraph* __restrict__ Gp, const DevTables* __restrict__ Tp, const DevBatch* __restrict__ Bp,
+                                                  const int* __restrict__ multiList, const int multiBase, double* __restrict__ bigLL)                    // bigLL: [gridDim.x][PAIR_COMB]
+{
+    const DevGraph& G = *Gp;
+    const DevBatch& B = *Bp;
+    __shared__ PairLds P;
+    const int lane = lane_id();
+    const DevTables& T = *Tp;
+    const int stride = B.stride;
+    constexpr int CHUNK = 4;
+    constexpr int NM = UNPAIRED ? 1 : 2;
+    const int* list = multiList + (BIG ? (size_t)B.n_pairs : (size_t)0);
+    const int nList = uni(B.work_counter[multiBase + (BIG ? 2 : 0)]);
+    int* fetch = &B.work_counter[multiBase + (BIG ? 3 : 1)];
+    if(nList <= 0) return;
+    for(int i = lane; i < 256; i += 64) P.phredThr[i] = T.phred_thr[i];
+    WSYNC();
+    if(lane == 0) P.ired[7] = (int)pair_phred(P, 1.0);
+    WSYNC();
+    long long tAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tMark = clock64();
+    for(;;) {
+        int q0 = 0;
+        if(lane == 0) q0 = atomicAdd(fetch, CHUNK);
+        q0 = __builtin_amdgcn_readfirstlane(q0);
+        if(q0 >= nList) break;
+        const int qEnd = min(q0 + CHUNK, nList);
+        // the chunk's pairs and chain ranges: lane q holds entry q0 + q
+        int hP = 0, hC[NM + 1];
+        #pragma unroll
+        for(int m = 0; m <= NM; m++) hC[m] = 0;
+        if(lane < CHUNK && q0 + lane < qEnd) {
+            hP = list[q0 + lane];
+            #pragma unroll
+            for(int m = 0; m <= NM; m++) hC[m] = B.chain_off[NM * hP + m];
+        }
+        for(int q = q0; q < qEnd; q++) {
+            const int hq = q - q0;
+            const int p = __builtin_amdgcn_readlane(hP, hq);
+            int cLo[NM], cHi[NM];
+            #pragma unroll
+            for(int m = 0; m < NM; m++) { cLo[m] = __builtin_amdgcn_readlane(hC[m], hq); cHi[m] = __builtin_amdgcn_readlane(hC[m + 1], hq); }
+            int n1 = 0, n2 = 0, mxc = 0; PairChain cL[2];
+            const int bad = pair_lists<UNPAIRED>(B, P.L, cLo, cHi, lane, n1, n2, mxc, cL);
+            if(!bad) {                                          // (k_pair_chains listed the pair because its lists were good)
+                const int nComb = n1 * n2;
+                PAIR_T(0);
+                if(!BIG || nComb <= PAIR_COMB_LDS) pair_finish<UNPAIRED, BIG>(G, T, B, P, P.LL, p, n1, n2, nComb, mxc, cL[0], cL[1], lane, stride, tAcc, tMark);
+                else pair_finish<UNPAIRED, BIG>(G, T, B, P, bigLL + (size_t)blockIdx.x * PAIR_COMB, p, n1, n2, nComb, mxc, cL[0], cL[1], lane, stride, tAcc, tMark);
+            }
+            WSYNC();
+        }
+    }
 #ifdef HLALA_PAIR_TIMING
-    if(lane == 0 && deferMode != 2) for(int i = 0; i < 7; i++) atomicAdd(&B.counters[24 + i], (u64)tAcc[i]);
+    if(lane == 0) for(int i = 0; i < 7; i++) atomicAdd(&B.counters[24 + i], (u64)tAcc[i]);
 #endif
 }
 

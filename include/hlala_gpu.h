@@ -255,6 +255,15 @@ int  hlala_pair_chains(hlala_ctx* ctx, hlala_batch* b);
  * batches can therefore keep two in flight -- align A, align B, fetch A, align C, fetch B, ... -- and have the long tail of one batch
  * run beside the bulk of the next; same results as one batch at a time.                                                     */
 int  hlala_align_batch(hlala_ctx* ctx, hlala_batch* b);
+/* The tail pool (round 6).  0.07 % of a batch's DP calls -- frontiers of hundreds to thousands of cells on allele-rich levels -- run in three capacity classes
+ * whose cost is the latency of their slowest calls, paid once per LAUNCH.  With k > 1, hlala_align_batch on a paired batch leaves those classes and the pairs that
+ * wait for them PENDING; when k batches are pending (or on hlala_flush, or as soon as a call reads, re-runs or destroys a pending batch) each class is launched once
+ * over all pending batches, then every batch's deferred pairs are completed.  A caller that walks a sample (mapper/processBAM.cpp:2024-2039: the loop over
+ * the read pairs of a sample) keeps k + 1 batches in flight -- align i .. i + k, fetch i, align i + k + 1, ... -- and pays that latency once per k batches.
+ * Results do not depend on k.  k = 1 (default): every alignment runs its own tail, as in rounds 2-5.  1 <= k <= 8.  The replaced reference code has no
+ * counterpart: extensionAligner.cpp:335-1556 runs one DP call at a time on one thread.                                          */
+int  hlala_set_tail_pool(hlala_ctx* ctx, int k);
+int  hlala_flush(hlala_ctx* ctx);
 
 /* Download results (synchronises the stream).  `stage` 0 = seed chains after stage A,
  * 1 = extended chains after stage B.                                                         */
