@@ -37,6 +37,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+TAIL_POOL_DEFAULT = 1          # hlala_set_tail_pool of the bench's loops (--tail-pool)
 sys.path.insert(0, ROOT)
 
 
@@ -176,6 +177,9 @@ def main():
     ap.add_argument("--e2e-variants", default="", help="experiments: further end-to-end runs of the same sample under other environments, 'label:ENV=1 ENV2=x;label2:...'")
     ap.add_argument("--long-reads", type=int, default=50_000, help="reads of the long-read record (BASELINE config 5: 50 000 reads of ~10 kb; 0 = skip)")
     ap.add_argument("--in-flight", type=int, default=3, choices=(2, 3), help="batches whose outputs are live at one time in the boundary loop: 2 = the alignment of batch i+2 is queued after batch i has been read back and destroyed; 3 (default) = as soon as batch i is COMPLETE, before its read-back (two alignments queued on the GPU either way, plus one upload ahead)")
+    ap.add_argument("--tail-pool", type=int, default=TAIL_POOL_DEFAULT, help="hlala_set_tail_pool(k): the broad / large / in-memory DP classes of k consecutive alignments run in one launch per class "
+                                                                             "(1 = every alignment runs its own tail, as in rounds 2-5); the loops keep k alignments queued ahead and k + 1 batches' outputs live")
+    ap.add_argument("--resident-lag", type=int, default=0, help="resident loop with a tail pool: the export of step i follows the alignment of step i + lag (default: tail pool + 1); lag + 1 resident batches")
     ap.add_argument("--long-reads-batch", type=int, default=50000, help="reads per batch of the long-read record (16 384-column rows: 17 GB of column arrays for 50 000 reads; five batches of 10 000 take 2.5 times as long -- every batch ends on its slowest wavefronts)")
     ap.add_argument("--long-reads-check", type=int, default=256, help="reads of the long-read record compared with the CPU oracle after the clock has stopped (0 = none)")
     args = ap.parse_args()
@@ -220,6 +224,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ckw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=12345, max_columns=384, device=local_rank)
     ctx = P.Context(w["graph"], w["contigs"], stream=stream, **ckw)
+    if args.tail_pool > 1:
+        ctx.set_tail_pool(args.tail_pool)
     recs = [torch.empty((args.pairs, 8), dtype=torch.float64, device="cuda") for _ in range(2)]
     gathered = [torch.empty_like(recs[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
     n_gathers = [0]
@@ -289,9 +295,12 @@ def main():
                 # stream runs dry.  With 3, the alignment of batch i+2 is queued as soon as batch i is COMPLETE, before it is read back: three batches' outputs are
                 # live at that moment (a third set of pool blocks, 50 GB), two alignments are queued on the GPU as before.  (Queueing a third alignment AHEAD instead
                 # made hlala_align_batch block for a whole step: profiles/r05_experiments.txt.)
-                ahead = [bnd.start(k) for k in range(min(2, n))]
+                # --tail-pool k (round 6): k alignments are queued ahead instead of two -- batch i is complete once the pooled tail of ITS group of k has run, and the
+                # library launches that tail with the k-th alignment of the group; k + 1 batches' outputs are live.
+                na = max(2, args.tail_pool)
+                ahead = [bnd.start(k) for k in range(min(na, n))]
                 for i in range(n):
-                    up = bnd.upload(i + 2) if i + 2 < n else None
+                    up = bnd.upload(i + na) if i + na < n else None
                     before_export()
                     h = ahead.pop(0)
                     bnd.wait_export(h, recs[i % 2], lambda k=i % 2: gather(k))
@@ -300,7 +309,7 @@ def main():
                     bnd.readback(h)
                     if up is not None:
                         ahead.append(bnd.launch(up))
-            run_boundary(max(args.warmup, 3 if args.in_flight == 3 else 1))          # (at least one: pool blocks, first touch of the page-locked buffers; three with three sets of outputs live, so that the third set exists before the clock starts)
+            run_boundary(max(args.warmup, (max(2, args.tail_pool) + 1) if args.in_flight == 3 else 1))          # (at least one: pool blocks, first touch of the page-locked buffers; three with three sets of outputs live, so that the third set exists before the clock starts)
             g0 = n_gathers[0]
             bnd.host_s = {}; bnd.host_n = {}
             elapsed, per_rank = timed(run_boundary, args.steps)
@@ -317,13 +326,16 @@ def main():
 
     # ---- the resident loop: inputs in HBM, two batch objects of the workload alternate, a step = hlala_align_batch + the export of the per-pair records
     # (+ the gather); the export of step i is issued after the alignment of step i+1, so the side-stream tail of one batch runs beside the bulk of the next.
-    gbs = [ctx.batch(x) for x in bsrc]
+    # --tail-pool k > 1: k + 2 resident batch objects of the two source batches take turns, the export of step i follows the alignment of step i + k (the tail of a
+    # group of k runs with the group's last alignment; one more alignment is queued before the host waits for it)
+    lag = 1 if args.tail_pool <= 1 else (args.resident_lag if args.resident_lag > 0 else args.tail_pool + 1)
+    gbs = [ctx.batch(x) for x in bsrc] if lag == 1 else [ctx.batch(bsrc[i % len(bsrc)]) for i in range(lag + 1)]
     gb = gbs[0]
 
     def finish(k):
         before_export()
-        gbs[k].export_pair_records(recs[k].data_ptr())
-        gather(k)
+        gbs[k].export_pair_records(recs[k % len(recs)].data_ptr())
+        gather(k % len(recs))
 
     def run(n):
         for i in range(n):
@@ -331,10 +343,11 @@ def main():
             gbs[k].align()
             if len(gbs) == 1 or args.no_overlap:
                 finish(k)
-            elif i > 0:
-                finish((i - 1) % len(gbs))
+            elif i >= lag:
+                finish((i - lag) % len(gbs))
         if len(gbs) > 1 and n > 0 and not args.no_overlap:
-            finish((n - 1) % len(gbs))
+            for j in range(max(0, n - lag), n):
+                finish(j % len(gbs))
 
     def device_memory(batch):
         """bytes of one batch's device blocks and of the whole context (hlala_debug_memory), chains with column rows"""
@@ -351,19 +364,19 @@ def main():
     rsteps = args.steps if args.resident_only else args.resident_steps
     resident = None
     if rsteps > 0:
-        run(args.warmup if args.resident_only else 2)
+        run(max(args.warmup if args.resident_only else 2, len(gbs) if lag > 1 else 0))
         g0 = n_gathers[0]
         el_r, per_rank_r = timed(run, rsteps)
         resident = {"value": args.pairs * world * rsteps / el_r, "unit": "read pairs/s", "steps": rsteps, "ms_per_step": el_r / rsteps * 1e3, "per_rank_s": per_rank_r,
                     "what": "inputs resident in HBM: hlala_align_batch + device-to-device export of the per-pair records (+ the gather for N > 1) per step, "
-                            + ("one batch at a time" if len(gbs) == 1 else "two resident batches alternate")}
+                            + ("one batch at a time" if len(gbs) == 1 else ("two resident batches alternate" if lag == 1 else f"tail pool of {lag}: {len(gbs)} resident batches take turns, the export of a step follows the alignment {lag} steps later"))}
         if world > 1:
             assert n_gathers[0] - g0 == rsteps, "every step of the resident loop gathers once"
     else:
         gb.align()
     st = gb.stats()          # HIP events of THIS batch's last alignment (the events belong to the batch) + device work counters
     torch.cuda.synchronize()
-    rec = recs[(rsteps - 1) % len(gbs)] if rsteps > 0 else recs[0]          # the records of the last step (the ones the last gather carried)
+    rec = recs[((rsteps - 1) % len(gbs)) % len(recs)] if rsteps > 0 else recs[0]          # the records of the last step (the ones the last gather carried)
     n_ok_local = int((rec[:, 0] == 0).sum().item())
     if world > 1:
         # every rank's share arrived: the gathered records of the last step hold `pairs` valid rows per rank
@@ -429,7 +442,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": desc, "timed_region": headline, "graph": args.graph, "pairs_per_gpu": args.pairs, "graph_levels": args.levels, "graph_nodes": int(g["n_nodes"]), "graph_edges": int(g["n_edges"]),
-                       "parallelism": f"shard{world}", "batches_in_flight": 1 if args.single_batch else (args.in_flight if boundary is not None else 2), "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
+                       "parallelism": f"shard{world}", "tail_pool": args.tail_pool, "batches_in_flight": 1 if args.single_batch else (args.in_flight if boundary is not None else 2), "chains_per_pair": b["n_chains"] / args.pairs, "extended_chains_per_pair": chains_pp,
                        "columns_per_chain": cols_pc, "mean_out_degree": e_mean,
                        "dp_calls_per_pair": st.n_dp_calls / args.pairs, "dp_iterations_per_call": st.n_dp_iterations / max(1, st.n_dp_calls),
                        "pairs_ok": int(oks[0]), "pairs_ok_per_rank": [int(x) for x in oks], "chain_errors": int(st.n_errors),

@@ -680,6 +680,7 @@ BUILD_AGENT_RELEASE = 2      # hlala_build_flags(): the in-memory DP class relea
 EXPORTED_SYMBOLS = [
     "hlala_debug_work_counters", "hlala_debug_dp_items", "hlala_debug_counters", "hlala_debug_buffer", "hlala_debug_memory",
     "hlala_set_tail_pool", "hlala_flush",
+    "hlala_comm_create", "hlala_comm_destroy", "hlala_comm_uses_rccl", "hlala_comm_last_error", "hlala_gather_pair_records", "hlala_reduce_coverage",
     "hlala_create", "hlala_destroy", "hlala_last_error", "hlala_graph_get_info", "hlala_graph_get_nodes",
     "hlala_graph_get_paths", "hlala_graph_get_gap_stretch", "hlala_batch_create",
     "hlala_batch_create_from_seeds", "hlala_batch_create_unpaired", "hlala_batch_set_first_chain", "hlala_batch_destroy", "hlala_project_chains", "hlala_extend_chains",
@@ -879,6 +880,58 @@ class Context:
         if getattr(self, "h", None):
             self.lib.hlala_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """hlala_comm: the contexts of one process (one per GPU) with the exchange steps of the path -- gather of the per-pair records, sum of the coverage
+    counters -- over RCCL when they sit on different devices (include/hlala_gpu.h)."""
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs); self.lib = lib = self.ctxs[0].lib
+        lib.hlala_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+        lib.hlala_comm_last_error.restype = C.c_char_p; lib.hlala_comm_last_error.argtypes = [C.c_void_p]
+        lib.hlala_comm_destroy.argtypes = [C.c_void_p]; lib.hlala_comm_destroy.restype = None
+        lib.hlala_comm_uses_rccl.argtypes = [C.c_void_p]
+        lib.hlala_gather_pair_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_void_p]
+        lib.hlala_reduce_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        hs = (C.c_void_p * len(self.ctxs))(*[c.h for c in self.ctxs]); h = C.c_void_p()
+        if lib.hlala_comm_create(hs, len(self.ctxs), C.byref(h)) != 0:
+            raise RuntimeError("hlala_comm_create: " + (lib.hlala_comm_last_error(None) or b"").decode())
+        self.h = h
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: " + (self.lib.hlala_comm_last_error(self.h) or b"").decode())
+
+    @property
+    def uses_rccl(self):
+        return bool(self.lib.hlala_comm_uses_rccl(self.h))
+
+    def gather_pair_records(self, batches):
+        """batches[i]: the Batch of context i or None.  Returns (records [sum of pairs, 8], counts [contexts])."""
+        n = len(self.ctxs)
+        bs = (C.c_void_p * n)(*[(b.b if b is not None else None) for b in batches])
+        total = int(sum(b.n_pairs for b in batches if b is not None))
+        out = np.zeros((max(1, total), 8), np.float64); counts = np.zeros(n, np.int64)
+        self._check(self.lib.hlala_gather_pair_records(self.h, bs, out.ctypes.data, total, counts.ctypes.data), "hlala_gather_pair_records")
+        return out[:total], counts
+
+    def reduce_coverage(self, reset=False):
+        info = GraphInfo()
+        self.ctxs[0]._check(self.lib.hlala_graph_get_info(self.ctxs[0].h, C.byref(info)), "hlala_graph_get_info")
+        out = np.zeros(max(1, info.n_levels - 1), np.int32)
+        self._check(self.lib.hlala_reduce_coverage(self.h, out.ctypes.data, int(reset)), "hlala_reduce_coverage")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hlala_comm_destroy(self.h); self.h = None
 
     def __del__(self):
         try:

@@ -1427,6 +1427,181 @@ int hlala_batch_export_pair_records(hlala_ctx* c, hlala_batch* b, double* device
     return HLALA_OK;
 }
 
+// ---- several GPUs in ONE process (the host program's --devices: one context per GPU): the exchange steps of the path over RCCL.
+// The reference merges its per-thread results on the host (mapper/processBAM.cpp:1866-1887: the per-thread alignment vectors are appended, the per-level read
+// counters added up); with one context per GPU the same two steps are a gather of the per-pair records and a sum-reduce of the coverage counters to the first
+// context's device.  RCCL is looked up at run time (dlopen: a one-GPU run never loads it) and used when the communicator's contexts sit on different devices;
+// contexts that share a device (tests on a one-GPU box) or a communicator of one take device-to-device copies on the same arrays.
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+namespace {
+struct RcclApi {
+    void* lib = nullptr; bool tried = false; std::string err;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr; ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load()
+    {
+        if(tried) return lib != nullptr;
+        tried = true;
+        for(const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if(lib) break; }
+        if(!lib) { err = std::string("librccl.so not found: ") + dlerror(); return false; }
+#define RSYM(field, sym) do { *(void**)(&field) = dlsym(lib, sym); if(!field) { err = std::string("librccl.so lacks ") + sym; dlclose(lib); lib = nullptr; return false; } } while(0)
+        RSYM(CommInitAll, "ncclCommInitAll"); RSYM(CommDestroy, "ncclCommDestroy"); RSYM(GroupStart, "ncclGroupStart"); RSYM(GroupEnd, "ncclGroupEnd");
+        RSYM(Send, "ncclSend"); RSYM(Recv, "ncclRecv"); RSYM(Reduce, "ncclReduce"); RSYM(GetErrorString, "ncclGetErrorString");
+#undef RSYM
+        return true;
+    }
+};
+RcclApi g_rccl; std::mutex g_rccl_mu;
+}
+struct hlala_comm {
+    std::vector<hlala_ctx*> ctxs;
+    std::vector<ncclComm_t> comms;            // empty: device-to-device copies (one context, or contexts that share a device)
+    std::vector<hipStream_t> streams;         // one per context, for the collectives
+    std::vector<double*> send; std::vector<size_t> sendCap;      // per context: its batch's records
+    double* recv = nullptr; size_t recvCap = 0;                  // on the first context's device: every context's records, in context order
+    int* covAcc = nullptr; size_t covN = 0;                      // ... and the summed coverage counters
+    std::string err;
+};
+static thread_local std::string g_comm_error;
+const char* hlala_comm_last_error(const hlala_comm* m) { return m ? m->err.c_str() : g_comm_error.c_str(); }
+int hlala_comm_uses_rccl(const hlala_comm* m) { return m && !m->comms.empty() ? 1 : 0; }
+
+void hlala_comm_destroy(hlala_comm* m)
+{
+    if(!m) return;
+    for(size_t i = 0; i < m->ctxs.size(); i++) {
+        DevGuard g(m->ctxs[i]->device);
+        if(i < m->streams.size() && m->streams[i]) { (void)hipStreamSynchronize(m->streams[i]); (void)hipStreamDestroy(m->streams[i]); }
+        if(i < m->send.size() && m->send[i]) (void)hipFree(m->send[i]);
+        if(i == 0) { if(m->recv) (void)hipFree(m->recv); if(m->covAcc) (void)hipFree(m->covAcc); }
+    }
+    for(ncclComm_t q : m->comms) if(q) (void)g_rccl.CommDestroy(q);
+    delete m;
+}
+
+int hlala_comm_create(hlala_ctx* const* ctxs, int n, hlala_comm** out)
+{
+    if(out) *out = nullptr;
+    if(!ctxs || n < 1 || !out) { g_comm_error = "hlala_comm_create: no contexts"; return HLALA_E_ARG; }
+    for(int i = 0; i < n; i++) if(!ctxs[i]) { g_comm_error = "hlala_comm_create: null context"; return HLALA_E_ARG; }
+    hlala_comm* m = new hlala_comm;
+    m->ctxs.assign(ctxs, ctxs + n); m->streams.assign((size_t)n, nullptr); m->send.assign((size_t)n, nullptr); m->sendCap.assign((size_t)n, 0);
+    auto fail = [&](int rc, const std::string& e) { g_comm_error = e; hlala_comm_destroy(m); return rc; };
+    for(int i = 0; i < n; i++) { DevGuard g(ctxs[i]->device); if(hipStreamCreateWithFlags(&m->streams[(size_t)i], hipStreamNonBlocking) != hipSuccess) return fail(HLALA_E_DEVICE, "hlala_comm_create: hipStreamCreate failed"); }
+    std::set<int> distinct; for(int i = 0; i < n; i++) distinct.insert(ctxs[i]->device);
+    const char* force = getenv("HLALA_COMM_RCCL");          // 1: RCCL even for a communicator of one (tests); 0: never
+    const bool want = force ? atoi(force) != 0 : n > 1;
+    if(want && (int)distinct.size() == n) {
+        std::lock_guard<std::mutex> g(g_rccl_mu);
+        if(!g_rccl.load()) return fail(HLALA_E_DEVICE, "hlala_comm_create: " + g_rccl.err);
+        std::vector<int> devs((size_t)n); for(int i = 0; i < n; i++) devs[(size_t)i] = ctxs[i]->device;
+        m->comms.assign((size_t)n, nullptr);
+        const ncclResult_t r = g_rccl.CommInitAll(m->comms.data(), n, devs.data());
+        if(r != ncclSuccess) { m->comms.clear(); return fail(HLALA_E_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); }
+    }
+    *out = m;
+    return HLALA_OK;
+}
+
+static int comm_buf(hlala_comm* m, int device, double** p, size_t* cap, size_t need)
+{
+    if(*cap >= need && *p) return HLALA_OK;
+    DevGuard g(device);
+    if(*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    if(device_malloc_retry(device, nullptr, (void**)p, (need ? need : 1) * sizeof(double)) != hipSuccess) { m->err = "hipMalloc (gather buffers) failed"; return HLALA_E_DEVICE; }
+    *cap = need;
+    return HLALA_OK;
+}
+
+// The per-pair records (8 doubles per pair: hlala_batch_export_pair_records) of one batch per context -- batches[i] belongs to context i of the communicator, NULL:
+// that context has none this round -- gathered to the first context's device and copied to host_out in context order; counts_out[i] = pairs of context i.
+// The counts are known on the host (the batches live in this process: the "counts first" step of the multi-process protocol in hla-la_amd/dist.py needs no
+// collective here); the payload is ONE grouped exchange: every context sends its records, the first one posts a receive per peer at that peer's offset.
+int hlala_gather_pair_records(hlala_comm* m, hlala_batch* const* batches, double* host_out, int64_t host_capacity_pairs, int64_t* counts_out)
+{
+    if(!m || !batches || !host_out) return HLALA_E_ARG;
+    const int n = (int)m->ctxs.size();
+    std::vector<size_t> cnt((size_t)n, 0), off((size_t)n + 1, 0);
+    for(int i = 0; i < n; i++) { if(batches[i]) { if(batches[i]->ctx != m->ctxs[(size_t)i]) { m->err = "hlala_gather_pair_records: batch " + std::to_string(i) + " does not belong to context " + std::to_string(i); return HLALA_E_ARG; } cnt[(size_t)i] = (size_t)batches[i]->B.n_pairs; } off[(size_t)i + 1] = off[(size_t)i] + cnt[(size_t)i]; if(counts_out) counts_out[i] = (int64_t)cnt[(size_t)i]; }
+    const size_t total = off[(size_t)n];
+    if((int64_t)total > host_capacity_pairs) { m->err = "hlala_gather_pair_records: " + std::to_string(total) + " pairs, room for " + std::to_string(host_capacity_pairs); return HLALA_E_CAPACITY; }
+    if(total == 0) return HLALA_OK;
+    int rc = comm_buf(m, m->ctxs[0]->device, &m->recv, &m->recvCap, 8 * total); if(rc) return rc;
+    const bool rccl = !m->comms.empty();
+    // every context's records into its send buffer (the first context's straight into its place in the receive buffer when no RCCL exchange follows)
+    for(int i = 0; i < n; i++) {
+        if(!cnt[(size_t)i]) continue;
+        double* dst = nullptr;
+        if(!rccl && m->ctxs[(size_t)i]->device == m->ctxs[0]->device) dst = m->recv + 8 * off[(size_t)i];
+        else { rc = comm_buf(m, m->ctxs[(size_t)i]->device, &m->send[(size_t)i], &m->sendCap[(size_t)i], 8 * cnt[(size_t)i]); if(rc) return rc; dst = m->send[(size_t)i]; }
+        rc = hlala_batch_export_pair_records(m->ctxs[(size_t)i], batches[i], dst);      // (returns synchronised: the records are in place)
+        if(rc) { m->err = std::string("hlala_batch_export_pair_records: ") + m->ctxs[(size_t)i]->err; return rc; }
+    }
+    if(rccl) {
+        ncclResult_t r = g_rccl.GroupStart();
+        for(int i = 0; i < n && r == ncclSuccess; i++) {
+            if(!cnt[(size_t)i]) continue;
+            r = g_rccl.Send(m->send[(size_t)i], 8 * cnt[(size_t)i], ncclDouble, 0, m->comms[(size_t)i], m->streams[(size_t)i]);
+            if(r == ncclSuccess) r = g_rccl.Recv(m->recv + 8 * off[(size_t)i], 8 * cnt[(size_t)i], ncclDouble, i, m->comms[0], m->streams[0]);
+        }
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if(r == ncclSuccess) r = re;
+        if(r != ncclSuccess) { m->err = std::string("RCCL gather: ") + g_rccl.GetErrorString(r); return HLALA_E_DEVICE; }
+        for(int i = 1; i < n; i++) if(cnt[(size_t)i]) { DevGuard g(m->ctxs[(size_t)i]->device); if(hipStreamSynchronize(m->streams[(size_t)i]) != hipSuccess) { m->err = "RCCL gather: send stream failed"; return HLALA_E_DEVICE; } }
+    } else {
+        // contexts on other devices without RCCL (HLALA_COMM_RCCL=0): peer copies into the receive buffer
+        for(int i = 0; i < n; i++) if(cnt[(size_t)i] && m->ctxs[(size_t)i]->device != m->ctxs[0]->device) {
+            DevGuard g(m->ctxs[0]->device);
+            if(hipMemcpyPeerAsync(m->recv + 8 * off[(size_t)i], m->ctxs[0]->device, m->send[(size_t)i], m->ctxs[(size_t)i]->device, 8 * cnt[(size_t)i] * sizeof(double), m->streams[0]) != hipSuccess) { m->err = "hipMemcpyPeerAsync failed"; return HLALA_E_DEVICE; }
+        }
+    }
+    DevGuard g0(m->ctxs[0]->device);
+    if(hipMemcpyAsync(host_out, m->recv, 8 * total * sizeof(double), hipMemcpyDeviceToHost, m->streams[0]) != hipSuccess || hipStreamSynchronize(m->streams[0]) != hipSuccess) { m->err = "gather: copy to the host failed"; return HLALA_E_DEVICE; }
+    return HLALA_OK;
+}
+
+// bases_per_level of every context of the communicator added up on the first context's device (ncclReduce, sum of int32 -- integer sums do not depend on the
+// order) and copied to bases_per_level; reset: the contexts' counters are cleared afterwards (hlala_get_coverage).  processBAM.cpp:1866-1887, :1902-1913.
+int hlala_reduce_coverage(hlala_comm* m, int32_t* bases_per_level, int reset)
+{
+    if(!m || !bases_per_level) return HLALA_E_ARG;
+    const int n = (int)m->ctxs.size();
+    hlala_ctx* c0 = m->ctxs[0];
+    const size_t nl = (size_t)(c0->F.L > 1 ? c0->F.L - 1 : 1);
+    for(int i = 0; i < n; i++) if(m->ctxs[(size_t)i]->F.L != c0->F.L) { m->err = "hlala_reduce_coverage: the contexts hold different graphs"; return HLALA_E_ARG; }
+    if(m->comms.empty() || n == 1) {
+        // one context, or contexts sharing a device: the host adds the counters up
+        std::vector<int32_t> one(nl);
+        std::fill(bases_per_level, bases_per_level + nl, 0);
+        for(int i = 0; i < n; i++) { int rc = hlala_get_coverage(m->ctxs[(size_t)i], one.data(), reset); if(rc) { m->err = m->ctxs[(size_t)i]->err; return rc; } for(size_t k = 0; k < nl; k++) bases_per_level[k] += one[k]; }
+        return HLALA_OK;
+    }
+    { DevGuard g(c0->device); if(m->covN < nl) { if(m->covAcc) (void)hipFree(m->covAcc); m->covAcc = nullptr; if(device_malloc_retry(c0->device, nullptr, (void**)&m->covAcc, nl * sizeof(int)) != hipSuccess) { m->err = "hipMalloc (coverage) failed"; return HLALA_E_DEVICE; } m->covN = nl; } }
+    // every context's counters exist and are final: its queued work is waited for first (post-processing adds to them on the reader stream)
+    for(int i = 0; i < n; i++) { hlala_ctx* c = m->ctxs[(size_t)i]; DevGuard g(c->device);
+        if(!c->d_cov) { c->n_cov = (int)nl; int rc = dev_alloc(c, c->allocs, nl, &c->d_cov, true); if(rc) { m->err = c->err; return rc; } }
+        if(hipStreamSynchronize(c->rs) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { m->err = "hlala_reduce_coverage: a context's stream failed"; return HLALA_E_DEVICE; } }
+    ncclResult_t r = g_rccl.GroupStart();
+    for(int i = 0; i < n && r == ncclSuccess; i++) r = g_rccl.Reduce(m->ctxs[(size_t)i]->d_cov, i == 0 ? (void*)m->covAcc : nullptr, nl, ncclInt32, ncclSum, 0, m->comms[(size_t)i], m->streams[(size_t)i]);
+    const ncclResult_t re = g_rccl.GroupEnd();
+    if(r == ncclSuccess) r = re;
+    if(r != ncclSuccess) { m->err = std::string("RCCL reduce: ") + g_rccl.GetErrorString(r); return HLALA_E_DEVICE; }
+    for(int i = 0; i < n; i++) { hlala_ctx* c = m->ctxs[(size_t)i]; DevGuard g(c->device);
+        if(hipStreamSynchronize(m->streams[(size_t)i]) != hipSuccess) { m->err = "RCCL reduce: stream failed"; return HLALA_E_DEVICE; }
+        if(reset && hipMemset(c->d_cov, 0, nl * sizeof(int)) != hipSuccess) { m->err = "hipMemset failed"; return HLALA_E_DEVICE; } }
+    DevGuard g0(c0->device);
+    if(hipMemcpy(bases_per_level, m->covAcc, nl * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { m->err = "coverage: copy to the host failed"; return HLALA_E_DEVICE; }
+    return HLALA_OK;
+}
+
+
 int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
 {
     DEV_GUARD(c);

@@ -10,11 +10,14 @@
 // terminate), this program prints the message to stderr and exits with a non-zero status -- HLA-LA.pl treats any non-zero status as
 // failure (:567-570).  Extra, optional arguments of this program: --devices <gpu,gpu,...> (or --device <gpu>): the batches of the sample are
 // dealt round-robin to one context per listed GPU (a GPU may be listed twice: two contexts on it), results do not depend on the list;
-// --decodeThreads <host threads of the BAM decoder, default all>, --batchPairs <units per GPU batch>, --rngSeed <base of the end-cell draws>,
+// --tailPool <k: GPU batches per launch of the widest DP classes>, --decodeThreads <host threads of the BAM decoder, default all>, --batchPairs <units per GPU batch>, --rngSeed <base of the end-cell draws>,
 // --loci A,B,... (default: the reference's 17 loci, hla/HLATyper.cpp:42).  Several samples in one call (BASELINE config 4): comma-separated lists of
 // equal length in --sampleID, --outputDirectory, --FASTQ1, --FASTQ2 (--FASTQU); sample i runs on device i % #devices, all samples side by side.
 // Not rebuilt: the --BAM entry (the Perl driver never uses it: it extracts reads itself and passes FASTQ files), read simulation /
 // validation actions, KIR.
+#ifndef HLALA_HOST_TAIL_POOL_DEFAULT
+#define HLALA_HOST_TAIL_POOL_DEFAULT 1
+#endif
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <dirent.h>
@@ -172,6 +175,9 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     if(!fileExists(BAM_remapped) || !fileExists(BAM_remapped + ".bai")) throw std::runtime_error("Remapping did not produce " + BAM_remapped + " and its index");
 
     const int decodeThreads = arguments.count("decodeThreads") ? std::atoi(arguments.at("decodeThreads").c_str()) : 0;
+    // --tailPool k: the broad / large / in-memory DP classes of k consecutive GPU batches of the sample run in one launch per class (include/hlala_gpu.h: hlala_set_tail_pool);
+    // k + 1 batches are in flight per device.  Default HLALA_HOST_TAIL_POOL_DEFAULT; 1 = every batch runs its own tail (rounds 2-5)
+    const int tailPool = arguments.count("tailPool") ? std::atoi(arguments.at("tailPool").c_str()) : HLALA_HOST_TAIL_POOL_DEFAULT;
     const auto tStart = std::chrono::steady_clock::now();
     const int32_t batchPairs = arguments.count("batchPairs") ? (int32_t)std::atol(arguments.at("batchPairs").c_str()) : (longReads.length() ? 65536 : 1048576);
     const uint32_t rngSeed = arguments.count("rngSeed") ? (uint32_t)std::strtoul(arguments.at("rngSeed").c_str(), nullptr, 10) : 0u;
@@ -190,6 +196,7 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     std::cout << timestamp() << "Start seed extraction\n" << std::flush;
     const auto tOpen = std::chrono::steady_clock::now();
     BAMprocessor.openBAM(BAM_remapped, longReads.length() != 0, batchPairs);
+    BAMprocessor.set_tail_pool(tailPool);
     const double openSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tOpen).count();
     std::cout << timestamp() << "Seed extraction: " << BAMprocessor.n_units << " complete units, BAM decoded in " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
               << " threads (index " << BAMprocessor.decode_phase_seconds[0] << ", inflate " << BAMprocessor.decode_phase_seconds[1] << ", parse " << BAMprocessor.decode_phase_seconds[2] << ", group "

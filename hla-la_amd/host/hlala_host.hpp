@@ -320,7 +320,7 @@ public:
     processBAM(const std::shared_ptr<GraphDirectory>& gdir, int max_columns, uint32_t rng_seed, const std::vector<int>& devices, int threads)
         : gdir_(gdir), graphDir_(gdir->dir), extended_(gdir->extended), max_columns_(max_columns), rng_seed_(rng_seed), devices_(devices.empty() ? std::vector<int>(1, 0) : devices), threads_(threads),
           intervals_(gdir->intervals()) {}
-    ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); for(hlala_ctx* c : ctxs_) if(c) hlala_destroy(c); if(seeds_) hlala_seed_batch_free(seeds_); }
+    ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); if(comm_) hlala_comm_destroy(comm_); for(hlala_ctx* c : ctxs_) if(c) hlala_destroy(c); if(seeds_) hlala_seed_batch_free(seeds_); }
     processBAM(const processBAM&) = delete;
     processBAM& operator=(const processBAM&) = delete;
 
@@ -358,6 +358,9 @@ public:
         tdec.join();
         if(!bamErr.empty()) throw std::runtime_error(bamErr);
         for(const std::string& e : errs) if(!e.empty()) throw std::runtime_error(e);
+        // several devices: the merge steps of the sample's results that live on the devices (the per-level read counters; the per-pair records for callers that want
+        // them) go over RCCL between the contexts (include/hlala_gpu.h: hlala_comm_*; contexts that share a device are served by copies)
+        if(ctxs_.size() > 1 && hlala_comm_create(ctxs_.data(), (int)ctxs_.size(), &comm_) != HLALA_OK) throw std::runtime_error(std::string("hlala_comm_create: ") + hlala_comm_last_error(nullptr));
         hlala_seed_batch_timing(seeds_, decode_phase_seconds, &decode_threads);
         n_units = hlala_seed_batch_units(seeds_); longReadsMode = longReads;
         // page-locked: batch uploads are plain DMA (a refusal only costs speed).  Window by window, when a window is handed out (filled, then locked): the 0.2 s that
@@ -409,12 +412,17 @@ public:
     // extractSeeds2 + estimateInsertSize + alignReads_postSeedExtraction (mapper/processBAM.cpp:703-864, 1071-1165, 2391-2483), one batch
     void alignReads(const std::string& BAM, bool longReads = false) { openBAM(BAM, longReads, 0); if(n_units > 0) acquire(0, true); }
     hlala_ctx* ctx() const { return ctxs_.empty() ? nullptr : ctxs_[0]; }
+    // hlala_set_tail_pool on every context (1: off).  Memory: k + 1 batches' outputs live per device.
+    void set_tail_pool(int k) { tail_pool_ = k < 1 ? 1 : k; for(hlala_ctx* c : ctxs_) if(c && hlala_set_tail_pool(c, tail_pool_) != HLALA_OK) throw std::runtime_error(std::string("hlala_set_tail_pool: ") + hlala_last_error(c)); }
+    int tail_pool() const { return tail_pool_; }
+    bool uses_rccl() const { return comm_ && hlala_comm_uses_rccl(comm_); }          // the contexts sit on different GPUs and exchange over RCCL
     hlala_batch* batch() const { return live_.empty() ? nullptr : live_[0]; }
     const char* readID(int64_t unit) const { return hlala_seed_batch_name(seeds_, unit); }
     // bases_per_level summed over the devices (reads_per_level.txt, processBAM.cpp:1902-1913: the per-thread counters are added up, :1866-1887)
     std::vector<int32_t> coverage() const
     {
         std::vector<int32_t> cov((size_t)(n_levels > 1 ? n_levels - 1 : 1), 0), one(cov.size());
+        if(comm_) { if(hlala_reduce_coverage(comm_, cov.data(), 0) != HLALA_OK) throw std::runtime_error(std::string("hlala_reduce_coverage: ") + hlala_comm_last_error(comm_)); return cov; }
         for(hlala_ctx* c : ctxs_) { if(hlala_get_coverage(c, one.data(), 0) != HLALA_OK) throw std::runtime_error(std::string("hlala_get_coverage: ") + hlala_last_error(c)); for(size_t i = 0; i < cov.size(); i++) cov[i] += one[i]; }
         return cov;
     }
@@ -432,7 +440,7 @@ private:
     std::shared_ptr<GraphDirectory> gdir_;
     std::string graphDir_; bool extended_; int max_columns_; uint32_t rng_seed_; std::vector<int> devices_; int threads_;
     hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; const std::vector<hlala_bam_interval>& intervals_;      // owned by gdir_
-    hlala_seed_batch* seeds_ = nullptr; std::vector<hlala_ctx*> ctxs_;
+    hlala_seed_batch* seeds_ = nullptr; std::vector<hlala_ctx*> ctxs_; hlala_comm* comm_ = nullptr; int tail_pool_ = 1;
     int32_t batchPairs_ = 1; std::vector<hlala_batch*> live_; std::vector<char> aligned_;       // aligned_[bi]: hlala_align_batch has been queued for live_[bi]
 };
 }  // namespace mapper
@@ -537,8 +545,11 @@ public:
                     const size_t u0 = (size_t)pB.batch_first_unit(bi);
                     const auto t0 = std::chrono::steady_clock::now();
                     hlala_batch* b = pB.acquire(bi, true);
-                    if(bi + nDev < nB) pB.acquire(bi + nDev, true);      // two alignments in flight per device ...
-                    if(bi + 2 * nDev < nB) pB.acquire(bi + 2 * nDev, false);      // ... and one upload ahead: the window after next is filled and uploaded (inputs only) while the GPU is busy and before
+                    // two alignments in flight per device -- with a tail pool of k (round 6: hlala_set_tail_pool, the broad / large / in-memory DP classes of k consecutive batches
+                    // in one launch per class) k more than the one being read, so that a whole group is queued before its first batch is waited for ...
+                    const int32_t ahead = pB.tail_pool() > 1 ? pB.tail_pool() : 1;
+                    for(int32_t j = 1; j <= ahead; j++) if(bi + j * nDev < nB) pB.acquire(bi + j * nDev, true);
+                    if(bi + (ahead + 1) * nDev < nB) pB.acquire(bi + (ahead + 1) * nDev, false);      // ... and one upload ahead: the window after those is filled and uploaded (inputs only) while the GPU is busy and before
                                                                                 // this thread waits for batch bi -- the host's 100 ms per batch off the critical path (bench.py's boundary loop does the same)
                     hlala_batch_stats bs; dchk(hlala_batch_get_stats(cd, b, &bs), "hlala_batch_get_stats");          // (waits for this batch only)
                     devAlign[(size_t)d] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

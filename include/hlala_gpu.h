@@ -295,6 +295,25 @@ int  hlala_batch_get_pairs_packed(hlala_ctx* ctx, hlala_batch* b, hlala_pairs_pa
  * caller may start its collective on any stream at once.                                             */
 int  hlala_batch_export_pair_records(hlala_ctx* ctx, hlala_batch* b, double* device_out);
 
+/* ---- several GPUs in ONE process (the host program's --devices 0,1,...: one context per GPU).  The reference merges the results of its threads on the host
+ * (mapper/processBAM.cpp:1866-1887: the per-thread vectors of aligned pairs appended, the per-level read counters added up, written out at :1902-1913); with one
+ * context per GPU these are the two exchange steps of the path, over RCCL (xGMI): hlala_gather_pair_records = one grouped send / receive of the per-pair records
+ * to the first context's device (the counts are known to the host, which holds every batch), hlala_reduce_coverage = ncclReduce (sum) of bases_per_level.
+ * hlala_comm_create runs ncclCommInitAll over the contexts' devices when there are several, all different (librccl.so is looked up at run time); a communicator
+ * of one context, or of contexts that share a device, copies device to device instead -- same results, hlala_comm_uses_rccl() says which.
+ * HLALA_COMM_RCCL=1 forces RCCL for a communicator of one (tests), =0 forbids it.  The multi-PROCESS form of the same steps (one rank per GPU, torch.distributed
+ * over RCCL) is hla-la_amd/dist.py. */
+typedef struct hlala_comm hlala_comm;
+int  hlala_comm_create(hlala_ctx* const* ctxs, int n, hlala_comm** out);
+void hlala_comm_destroy(hlala_comm* comm);
+int  hlala_comm_uses_rccl(const hlala_comm* comm);
+const char* hlala_comm_last_error(const hlala_comm* comm);      /* NULL: the error of the last failed hlala_comm_create of this thread */
+/* batches[i]: the batch of context i (NULL: none this round); host_out: [sum of pairs][8] doubles in context order (hlala_batch_export_pair_records' layout);
+ * counts_out[i] (may be NULL) = pairs of context i.  Returns when host_out is filled. */
+int  hlala_gather_pair_records(hlala_comm* comm, hlala_batch* const* batches, double* host_out, int64_t host_capacity_pairs, int64_t* counts_out);
+/* bases_per_level[n_levels - 1] summed over the communicator's contexts (hlala_get_coverage of each, added up on the first context's device) */
+int  hlala_reduce_coverage(hlala_comm* comm, int32_t* bases_per_level, int reset);
+
 /* Per-stage statistics of the last hlala_align_batch / stage call on this batch, measured
  * with HIP events (ms) plus work counters reduced on the device.  The events belong to the BATCH (since round 3): with
  * several batches in flight every batch reports its own stages.                              */

@@ -288,8 +288,51 @@ def test_two_batches_in_flight_equal_one_at_a_time(pkg, oracle):
 
 
 @pytest.mark.gpu
-def test_a_sample_streamed_in_batches_equals_the_whole_sample(pkg, oracle, world_m):
-    """BASELINE config 3 in small: one sample goes through ONE context in five batches of different sizes, two in flight, each batch destroyed once it
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_tail_pool_gives_the_results_of_one_batch_at_a_time(pkg, oracle, k):
+    """Round 6, hlala_set_tail_pool(k): the broad / large / in-memory DP classes of up to k consecutive alignments run in ONE launch per class, then every batch's
+    deferred pairs are completed.  Four different batches on dense windows (a good part of the pairs waits for those classes): every array of every batch equals
+    the one-at-a-time result (itself compared with the oracle) -- with the pool filled exactly (k batches), flushed early by a reader, by hlala_flush, by a
+    re-alignment of a pending batch and by the destruction of one; the work counters (DP calls, iterations, cells) do not change either."""
+    w = synth.make_world_m(seed=8, n_levels=60_000, n_windows=3, alleles=(4000, 5000))
+    bs = [synth.make_batch_m(w, n, seed=sd, frac_gene=fg) for n, sd, fg in ((1200, 31, 1.0), (900, 32, 0.6), (700, 33, 1.0), (1000, 34, 0.8))]
+    kw = dict(insert_mean=bs[0]["insert_mean"], insert_sd=bs[0]["insert_sd"], rng_seed=99, max_columns=384)
+    ref, refst = [], []
+    for b in bs:
+        got, st, exp = gpu_vs_oracle(pkg, oracle, w, b)
+        assert st.ms_side > 0
+        ref.append(got); refst.append((st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells, tuple(st.n_dp_class)))
+    assert sum(sum(x[3][4:]) for x in refst) > 0          # the pooled classes have work
+    ctx = pkg.Context(w["graph"], w["contigs"], **kw)
+    ctx.set_tail_pool(k)
+    gbs = [ctx.batch(b) for b in bs]
+
+    def check(i):
+        got = gbs[i].pairs()
+        for name, v in ref[i].items():
+            assert np.array_equal(got[name], v), (k, i, name)
+        st = gbs[i].stats()
+        assert st.n_errors == 0 and (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells, tuple(st.n_dp_class)) == refst[i], (k, i)
+
+    # (1) all four aligned, then read in reverse order: pools of k fill and flush by themselves, the rest is flushed by the first reader
+    for g in gbs:
+        g.align()
+    for i in (3, 2, 1, 0):
+        check(i)
+    # (2) a reader flushes a pool of one; hlala_flush a pool of two; a re-alignment of a pending batch flushes, then the batch is pooled again
+    gbs[0].align(); check(0)
+    gbs[1].align(); gbs[2].align(); ctx.flush(); check(2); check(1)
+    gbs[3].align(); gbs[3].align(); gbs[0].align(); check(0); check(3)
+    # (3) a pending batch is destroyed: the others of its pool are completed
+    extra = ctx.batch(bs[1]); gbs[2].align(); extra.align(); extra.close(); check(2)
+    # (4) back to k = 1: pending batches are flushed, later alignments run their own tails
+    gbs[1].align(); ctx.set_tail_pool(1); check(1); gbs[0].align(); check(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pool", [1, 3])
+def test_a_sample_streamed_in_batches_equals_the_whole_sample(pkg, oracle, world_m, pool):
+    """BASELINE config 3 in small (pool 3: with a tail pool of three and four batches in flight -- round 6): one sample goes through ONE context in five batches of different sizes, two in flight, each batch destroyed once it
     has been fetched (its buffers go back to the context's pool and serve the next one).  With hlala_batch_set_first_chain every batch draws the
     random seeds of the unsplit run: each slice equals the oracle's result for the whole sample, array by array."""
     import importlib.util
@@ -299,6 +342,7 @@ def test_a_sample_streamed_in_batches_equals_the_whole_sample(pkg, oracle, world
     kw = dict(insert_mean=b["insert_mean"], insert_sd=b["insert_sd"], rng_seed=7, max_columns=384)
     exp = oracle(world_m["graph"], world_m["contigs"], **kw).align_batch(b)["pairs"]
     ctx = pkg.Context(world_m["graph"], world_m["contigs"], **kw)
+    ctx.set_tail_pool(pool)
     cuts = [0, 700, 1100, 1900, 2050, 2600]
 
     def start(i):
@@ -306,10 +350,12 @@ def test_a_sample_streamed_in_batches_equals_the_whole_sample(pkg, oracle, world
         gb = ctx.batch(sub); gb.set_first_chain(c0); gb.align()
         return gb, p0, c0
 
-    cur = start(0)
-    for i in range(len(cuts) - 1):
-        nxt = start(i + 1) if i + 2 < len(cuts) else None          # the next batch is aligned before this one is fetched
-        gb, p0, c0 = cur
+    nb = len(cuts) - 1
+    ahead = [start(i) for i in range(min(pool, nb))]               # `pool` batches aligned before the first one is fetched (1: the next batch is aligned before this one is fetched)
+    for i in range(nb):
+        if i + len(ahead) < nb:
+            ahead.append(start(i + len(ahead)))
+        gb, p0, c0 = ahead.pop(0)
         got = gb.pairs(); n = cuts[i + 1] - cuts[i]; stride = 384
         for k in ("pair_status", "n_combinations", "strands_valid"):
             assert np.array_equal(got[k], exp[k][p0:p0 + n]), (i, k)
@@ -322,4 +368,3 @@ def test_a_sample_streamed_in_batches_equals_the_whole_sample(pkg, oracle, world
         assert np.allclose(got["pair_ll"], exp["pair_ll"][p0:p0 + n], rtol=1e-12, atol=0)
         assert gb.stats().n_errors == 0
         gb.close()
-        cur = nxt
