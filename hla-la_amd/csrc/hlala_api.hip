@@ -1042,7 +1042,9 @@ static int pair_impl(hlala_ctx* c, hlala_batch* b, int phase)
             const int pass = st == c->side ? 1 : 0, multiBase = WC_PAIR_MULTI + 4 * pass;
             int* multiList = B.pair_multi + (size_t)pass * 2 * (size_t)B.n_pairs;
             double* scratch = c->pair_scratch + (pass ? (size_t)c->pair_grid * PAIR_COMB : 0);
-            HIP_TRY(c, hipMemsetAsync(B.work_counter + multiBase, 0, 4 * sizeof(int), st));
+            // (the lists' counters are among those the extension stage clears; a pairing stage called again on its own clears them here.  Not on the side stream: a fill
+            //  kernel queued there waits 13-36 ms for a wave slot beside the persistent kernels -- profiles/r06_experiments.txt)
+            if(!fused) HIP_TRY(c, hipMemsetAsync(B.work_counter + multiBase, 0, 4 * sizeof(int), st));
             const int lean = B.n_pairs < c->pair_lean_grid ? B.n_pairs : c->pair_lean_grid;
             const int g0 = mode == 2 ? (grid < c->pair_grid / 5 ? grid : c->pair_grid / 5) : grid, g1 = grid < c->pair_grid / 5 ? grid : c->pair_grid / 5;      // (the second pass and the general class hold a few thousand pairs at most)
             if(B.unpaired) {
