@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--e2e-frac-gene", type=float, default=0.04, help="share of the end-to-end sample drawn from the gene windows: 0.04 = the windows' share of the graph, i.e. the uniform "
                     "coverage of a whole-genome sample (the resident workload keeps 0.3: its gene-window pairs are the expensive ones; at 0.3 every typed locus would see 2000x coverage)")
     ap.add_argument("--e2e-threads", default="0,128", help="--decodeThreads values of the end-to-end runs (0 = the decoder's default: twice the CPUs the process may use, at most 32 threads)")
+    ap.add_argument("--e2e-samples", default="2,4", help="end to end: further runs with this many samples (the same BAM; 'n:threads' = with --decodeThreads threads) in ONE call on one device, the decode of sample k + 1 beside the alignment of sample k ('' = none)")
     ap.add_argument("--no-extras-but-e2e", action="store_true", help="of the measurements outside the timed region only the end-to-end run")
     ap.add_argument("--e2e-variants", default="", help="experiments: further end-to-end runs of the same sample under other environments, 'label:ENV=1 ENV2=x;label2:...'")
     ap.add_argument("--long-reads", type=int, default=50_000, help="reads of the long-read record (BASELINE config 5: 50 000 reads of ~10 kb; 0 = skip)")
@@ -705,8 +706,42 @@ def end_to_end(args, P, synth, w, mk):
                     "log": [ln[:700] for ln in r.stdout.splitlines() if ("Seed extraction:" in ln or ln.startswith("End-to-end:"))] + [ln[:300] for ln in r.stderr.splitlines() if ln.startswith(("bam-debug:", "host-debug:"))][:60],
                     "loci": loci, "result_files": len(files), "calls": calls[:6]}
 
+        def several(ns, threads=0):
+            """ns samples (the same BAM) in ONE call on one device: the decode of sample k + 1 runs on the host threads while the GPU aligns sample k (round 6: HLA-LA.cpp
+            SampleSchedule).  pairs / wall of the program's `Samples:` line (from the end of the graph directory's load to the last sample's result files), every sample's
+            hla/* compared byte for byte with the first one's."""
+            import hashlib
+            outs = [os.path.join(tmp, "outs%d_%d" % (ns, i)) for i in range(ns)]
+            rep_ = lambda x: ",".join([x] * ns)
+            cmd = [exe, "--action", "HLA", "--maxThreads", "2", "--sampleID", ",".join("S%d" % i for i in range(ns)), "--outputDirectory", ",".join(outs), "--PRG_graph_dir", gdir,
+                   "--FASTQU", rep_(os.path.join(tmp, "r1.fq")), "--FASTQ1", rep_(os.path.join(tmp, "r1.fq")), "--FASTQ2", rep_(os.path.join(tmp, "r2.fq")), "--bwa_bin", os.path.join(tmp, "bwa"),
+                   "--samtools_bin", os.path.join(tmp, "samtools"), "--mapAgainstCompleteGenome", "0", "--longReads", "0", "--loci", ",".join(loci), "--rngSeed", "12345", "--batchPairs", str(ch)]
+            if threads > 0:
+                cmd += ["--decodeThreads", str(threads)]
+            t0 = time.time()
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp, timeout=3000)
+            t_run = time.time() - t0
+            if r.returncode != 0:
+                return {"error": (r.stdout + r.stderr)[-1500:]}
+            m = re.search(r"Samples: (\d+) on (\d+) device\(s\), (\d+) decoding at a time, in ([0-9.e+-]+) s", r.stdout)
+            def digest(d):
+                h = hashlib.sha256()
+                for fn in sorted(os.listdir(os.path.join(d, "hla"))):
+                    h.update(fn.encode()); h.update(open(os.path.join(d, "hla", fn), "rb").read())
+                return h.hexdigest()
+            dg = [digest(o) for o in outs]
+            for o in outs:
+                shutil.rmtree(o, ignore_errors=True)
+            wall = float(m.group(4))
+            return {"samples": ns, "decode_threads_asked": threads, "pairs": ns * nch * ch, "wall_s": wall, "value": ns * nch * ch / wall, "unit": "read pairs/s", "decoding_at_a_time": int(m.group(3)), "process_wall_s": t_run,
+                    "whole_process_pairs_per_s": ns * nch * ch / t_run, "hla_files_identical_across_samples": len(set(dg)) == 1,
+                    "per_sample_lines": [ln[:260] for ln in r.stdout.splitlines() if ln.startswith("End-to-end:")],
+                    "what": "one HLA-LA call, %d samples on one device: sample k + 1 is decoded while sample k is aligned and typed; pairs of all samples / seconds from the loaded graph directory to the last result file" % ns}
+
         runs = [one(int(t)) for t in str(args.e2e_threads).split(",") if t.strip() != ""]
         res = runs[0]
+        if args.e2e_samples:
+            res["several_samples"] = [several(int(x.split(":")[0]), int(x.split(":")[1]) if ":" in x else 0) for x in str(args.e2e_samples).split(",") if x.strip() != ""]
         if args.e2e_variants:          # experiments: the same sample again under other environments ("label:ENV=1 ENV2=x;label2:...")
             res["variants"] = {}
             for v in args.e2e_variants.split(";"):

@@ -10,7 +10,7 @@
 // terminate), this program prints the message to stderr and exits with a non-zero status -- HLA-LA.pl treats any non-zero status as
 // failure (:567-570).  Extra, optional arguments of this program: --devices <gpu,gpu,...> (or --device <gpu>): the batches of the sample are
 // dealt round-robin to one context per listed GPU (a GPU may be listed twice: two contexts on it), results do not depend on the list;
-// --tailPool <k: GPU batches per launch of the widest DP classes>, --decodeThreads <host threads of the BAM decoder, default all>, --batchPairs <units per GPU batch>, --rngSeed <base of the end-cell draws>,
+// --decodeSlots <samples that decode at one time, default CPUs / 16>, --tailPool <k: GPU batches per launch of the widest DP classes>, --decodeThreads <host threads of the BAM decoder, default all>, --batchPairs <units per GPU batch>, --rngSeed <base of the end-cell draws>,
 // --loci A,B,... (default: the reference's 17 loci, hla/HLATyper.cpp:42).  Several samples in one call (BASELINE config 4): comma-separated lists of
 // equal length in --sampleID, --outputDirectory, --FASTQ1, --FASTQ2 (--FASTQU); sample i runs on device i % #devices, all samples side by side.
 // Not rebuilt: the --BAM entry (the Perl driver never uses it: it extracts reads itself and passes FASTQ files), read simulation /
@@ -26,6 +26,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <ctime>
 #include <fstream>
 #include <iostream>
@@ -141,8 +143,47 @@ std::vector<std::string> split_list(const std::string& l)
 // what several samples of one call share: the graph directory as the aligner and as the typer read it (read once, read-only afterwards)
 struct SharedGraph { std::shared_ptr<mapper::GraphDirectory> dir; std::unique_ptr<hla::HLATyper> typer; };
 
-int action_HLA_one(const std::map<std::string, std::string>& arguments, const std::vector<int>& devices, const SharedGraph* shared = nullptr)
+// Several samples in one call (round 6): who decodes and who holds a device when.  Within a sample the decode must be complete before the first batch is cut (a chain's
+// random seed is its number in read-NAME order, mapper/processBAM.cpp:2024-2039); ACROSS samples nothing forbids decoding sample k + 1 on the host threads while the
+// GPU aligns sample k.  Decodes start in sample order, as many at a time as the host has CPUs for (a decode keeps up to 32 threads busy); a device runs the alignment and
+// typing of one sample at a time, in the order of the samples it was dealt.
+struct SampleSchedule {
+    std::mutex m; std::condition_variable cv;
+    int decodeSlots = 1, decoding = 0; size_t nextDecode = 0;
+    std::vector<size_t> nextOnDevice;
+    void begin_decode(size_t sample) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return nextDecode == sample && decoding < decodeSlots; }); decoding++; nextDecode++; cv.notify_all(); }
+    void end_decode() { std::lock_guard<std::mutex> l(m); decoding--; cv.notify_all(); }
+    void begin_device(size_t slot, size_t rank) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return nextOnDevice[slot] == rank; }); }
+    void end_device(size_t slot) { std::lock_guard<std::mutex> l(m); nextOnDevice[slot]++; cv.notify_all(); }
+    // a sample that fails before its turn must not block the others
+    void skip(size_t sample, size_t slot, size_t rank, bool decoded, bool onDevice) {
+        std::unique_lock<std::mutex> l(m);
+        if(!decoded) { cv.wait(l, [&] { return nextDecode >= sample; }); if(nextDecode == sample) nextDecode++; }
+        if(!onDevice) { cv.wait(l, [&] { return nextOnDevice[slot] >= rank; }); if(nextOnDevice[slot] == rank) nextOnDevice[slot]++; }
+        cv.notify_all();
+    }
+};
+struct SampleTurn { SampleSchedule* sched; size_t sample, slot, rank; SampleTurn() : sched(nullptr), sample(0), slot(0), rank(0) {} SampleTurn(SampleSchedule* s, size_t a, size_t b, size_t c) : sched(s), sample(a), slot(b), rank(c) {} };
+
+// CPUs this process may keep busy: the control group's quota when there is one (cgroup v2 cpu.max), else the hardware threads
+static int cpu_budget()
 {
+    int n = (int)std::thread::hardware_concurrency(); if(n < 1) n = 1;
+    std::ifstream f("/sys/fs/cgroup/cpu.max"); std::string q; long long per = 0;
+    if(f.is_open() && (f >> q >> per) && q != "max" && per > 0) { const long long quota = std::atoll(q.c_str()); if(quota > 0) { const int c = (int)((quota + per - 1) / per); if(c >= 1 && c < n) n = c; } }
+    return n;
+}
+
+int action_HLA_one(const std::map<std::string, std::string>& arguments, const std::vector<int>& devices, const SharedGraph* shared = nullptr, const SampleTurn* turn = nullptr)
+{
+    // (several samples per call: this sample's turns at the decoder and at its device; released on every way out)
+    struct TurnGuard { const SampleTurn* t; bool decoding, decoded, onDevice, deviceDone;
+        explicit TurnGuard(const SampleTurn* t_) : t(t_), decoding(false), decoded(false), onDevice(false), deviceDone(false) {}
+        void begin_decode() { if(t) { t->sched->begin_decode(t->sample); decoding = true; } }
+        void end_decode() { if(t && decoding) { t->sched->end_decode(); decoding = false; decoded = true; } }
+        void begin_device() { if(t) { t->sched->begin_device(t->slot, t->rank); onDevice = true; } }
+        void end_device() { if(t && onDevice && !deviceDone) { t->sched->end_device(t->slot); deviceDone = true; } }
+        ~TurnGuard() { if(!t) return; if(decoding) { t->sched->end_decode(); decoded = true; } if(onDevice && !deviceDone) { t->sched->end_device(t->slot); deviceDone = true; } if(!decoded || !onDevice) t->sched->skip(t->sample, t->slot, t->rank, decoded, onDevice); } } turnGuard(turn);
     unsigned int maxThreads = 1;
     need(arguments, "sampleID"); need(arguments, "outputDirectory"); need(arguments, "PRG_graph_dir");
     if(!(arguments.count("BAM") || (arguments.count("FASTQ1") && arguments.count("FASTQ2")))) throw std::runtime_error("Please specify --BAM or --FASTQ1 / --FASTQ2");
@@ -193,10 +234,12 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     const std::shared_ptr<mapper::GraphDirectory> graphDirectory = shared ? shared->dir : std::make_shared<mapper::GraphDirectory>(PRG_graph_dir, mapAgainstCompleteGenome);
     mapper::processBAM BAMprocessor(graphDirectory, longReads.length() ? 16384 : 384, rngSeed, devices, decodeThreads);
     const double loadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count();
+    turnGuard.begin_decode();
     std::cout << timestamp() << "Start seed extraction\n" << std::flush;
     const auto tOpen = std::chrono::steady_clock::now();
     BAMprocessor.openBAM(BAM_remapped, longReads.length() != 0, batchPairs);
     BAMprocessor.set_tail_pool(tailPool);
+    turnGuard.end_decode();
     const double openSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tOpen).count();
     std::cout << timestamp() << "Seed extraction: " << BAMprocessor.n_units << " complete units, BAM decoded in " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
               << " threads (index " << BAMprocessor.decode_phase_seconds[0] << ", inflate " << BAMprocessor.decode_phase_seconds[1] << ", parse " << BAMprocessor.decode_phase_seconds[2] << ", group "
@@ -217,6 +260,7 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     make_or_clearDirectory(outputDirectory + "/hla");                                                   // processBAM.cpp:1805-1806
     std::cout << timestamp() << "Alignment of " << BAMprocessor.n_units << (longReads.length() ? " reads" : " read pairs") << " in " << BAMprocessor.n_batches() << " GPU batch(es) on " << BAMprocessor.n_devices() << " device context(s)\n" << std::flush;
     double alignSeconds = 0; int64_t chainErrors = 0;
+    turnGuard.begin_device();          // (the device may still be aligning the sample before this one; this sample's decode ran beside it)
     const auto tInfer = std::chrono::steady_clock::now();
     std::vector<hla::HLATyper::bestGuess> calls = HLAtyper.HLATypeInference(BAMprocessor, outputDirectory_for_HLA, loci, &alignSeconds, &chainErrors);
     const double inferSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tInfer).count();
@@ -244,6 +288,7 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
         if(!levels_stream.is_open()) throw std::runtime_error("Cannot open " + outputDirectory + "/reads_per_level.txt");
         for(size_t lI = 0; lI + 1 < (size_t)BAMprocessor.n_levels; lI++) levels_stream << lI << "\t" << HLAtyper.level_name((int32_t)lI) << "\t" << cov[lI] << "\n";
     }
+    turnGuard.end_device();
     if(!fileExists(outputDirectory + "/hla/R1_bestguess.txt")) throw std::runtime_error("HLA type inference did not produce " + outputDirectory + "/hla/R1_bestguess.txt");
     for(const hla::HLATyper::bestGuess& g : calls) std::cout << "Locus " << g.locus << ": " << g.allele1 << " (Q1 " << g.Q1_allele1 << ") / " << g.allele2 << " (Q1 " << g.Q1_allele2 << ")\n";
     return 0;
@@ -281,14 +326,22 @@ int action_HLA(const std::map<std::string, std::string>& arguments)
         std::cout << timestamp() << "Graph directory read once for " << samples.size() << " samples in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tLoad).count() << " s\n" << std::flush;
     }
     std::vector<std::string> errs(samples.size());
+    SampleSchedule sched;
+    sched.nextOnDevice.assign(devices.size(), 0);
+    { const int cpus = cpu_budget(); sched.decodeSlots = cpus / 16 > 0 ? cpus / 16 : 1; if(arguments.count("decodeSlots")) { const int v = std::atoi(arguments.at("decodeSlots").c_str()); if(v >= 1) sched.decodeSlots = v; } }
+    std::vector<SampleTurn> turns(samples.size());
+    for(size_t i = 0; i < samples.size(); i++) turns[i] = SampleTurn(&sched, i, i % devices.size(), i / devices.size());
+    const auto tSamples = std::chrono::steady_clock::now();
     {
         ThreadJoiner th;
         for(size_t i = 0; i < samples.size(); i++) th.start([&, i]() {
-            try { action_HLA_one(per[i], std::vector<int>(1, devices[i % devices.size()]), &shared); } catch(const std::exception& e) { errs[i] = e.what(); }
+            try { action_HLA_one(per[i], std::vector<int>(1, devices[i % devices.size()]), &shared, &turns[i]); } catch(const std::exception& e) { errs[i] = e.what(); }
         });
     }
     for(size_t i = 0; i < samples.size(); i++) if(!errs[i].empty()) throw std::runtime_error("sample " + samples[i] + ": " + errs[i]);
     std::cout << timestamp() << "Processed " << samples.size() << " samples on " << devices.size() << " device(s)\n" << std::flush;
+    std::cout << "Samples: " << samples.size() << " on " << devices.size() << " device(s), " << sched.decodeSlots << " decoding at a time, in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tSamples).count()
+              << " s after the graph directory (remapping, decode of sample k + 1 beside the alignment of sample k, contexts, alignment, typing, result files)\n" << std::flush;
     return 0;
 }
 

@@ -271,3 +271,13 @@ def test_eight_samples_on_eight_contexts_in_one_call(exe, pkg, tmp_path):
         assert (o8 / "reads_per_level.txt").read_bytes() == (o1 / "reads_per_level.txt").read_bytes(), nm
         seen.add((o1 / "hla" / "R1_PP_A_pairs.txt").read_bytes() if (o1 / "hla" / "R1_PP_A_pairs.txt").exists() else (o1 / "reads_per_level.txt").read_bytes())
     assert len(seen) == NS          # eight different samples, not one sample eight times
+    # ---- round 6: the same eight samples on ONE listed device -- they take turns on it in sample order, sample k + 1 is decoded on the host while sample k is aligned and
+    # typed (HLA-LA.cpp: SampleSchedule) --, with a tail pool of two (hlala_set_tail_pool: three batches in flight per sample): the same bytes again
+    outsT = [tmp_path / f"turn_{nm}" for nm in names]
+    rt = subprocess.run(args(names, outsT) + ["--devices", "0", "--tailPool", "2"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert rt.returncode == 0, rt.stdout[-3000:] + rt.stderr[-3000:]
+    assert f"Samples: {NS} on 1 device(s)" in rt.stdout and f"Processed {NS} samples on 1 device(s)" in rt.stdout
+    for o8, oT in zip(outs8, outsT):
+        for fn in sorted(os.listdir(o8 / "hla")):
+            assert (oT / "hla" / fn).read_bytes() == (o8 / "hla" / fn).read_bytes(), (str(oT), fn)
+        assert (oT / "reads_per_level.txt").read_bytes() == (o8 / "reads_per_level.txt").read_bytes()
