@@ -561,7 +561,8 @@ class BatchStats(C.Structure):
                 ("n_chains_retried", C.c_int32), ("ms_dp_main", C.c_float), ("n_dp_retried_large", C.c_int32), ("n_dp_shared", C.c_int64),
                 ("n_dp_class", C.c_int32 * 7), ("ms_dp_class", C.c_float * 7), ("ms_side", C.c_float),
                 ("n_dp_lane", C.c_int32), ("ms_dp_lane", C.c_float), ("n_dp_jump_free", C.c_int32), ("ms_dp_jump_free", C.c_float),
-                ("n_dp_band", C.c_int32), ("n_dp_band_failed", C.c_int32), ("n_dp_jump_free_failed", C.c_int32), ("ms_dp_band", C.c_float)]
+                ("n_dp_band", C.c_int32), ("n_dp_band_failed", C.c_int32), ("n_dp_jump_free_failed", C.c_int32), ("ms_dp_band", C.c_float),
+                ("n_dp_band2", C.c_int32), ("n_dp_band2_failed", C.c_int32), ("ms_dp_band2", C.c_float), ("reserved_stats", C.c_int32)]
 
 
 _DT = {c_i32p: np.int32, c_i64p: np.int64, c_u8p: np.uint8, c_u32p: np.uint32, c_f64p: np.float64}
@@ -672,8 +673,8 @@ def load_library(path: str | None = None):
     return lib
 
 
-ABI_VERSION = 4              # HLALA_ABI_VERSION of include/hlala_gpu.h
-DEBUG_WC_N, DEBUG_WC_BAND_FETCH, DEBUG_WC_BAND_WHY, DEBUG_WC_BAND_TIED = 72, 48, 62, 68      # include/hlala_gpu.h: debug section
+ABI_VERSION = 5              # HLALA_ABI_VERSION of include/hlala_gpu.h
+DEBUG_WC_N, DEBUG_WC_BAND_FETCH, DEBUG_WC_BAND_WHY, DEBUG_WC_BAND_TIED = 88, 48, 62, 68      # include/hlala_gpu.h: debug section
 BUILD_AGENT_RELEASE = 2      # hlala_build_flags(): the in-memory DP class releases at agent scope (make EXTRA=-DHLALA_DP_AGENT_RELEASE)
 
 

@@ -86,6 +86,7 @@ struct DevBatch {
     int* dp_list;                   // [2*n_chains] the ten dense lists of the first DP classes: slots of dp_items in position order (k_dp_lists)
     int dp_nblk;                    // blocks of k_dp_items
     int dp_band;                    // > 0: calls whose reach (read bases left + dp_band - 1 levels) stays inside a linear run of the graph go to the band kernel's lists (kernel_dp_band.hip); 0: HLALA_DP_BAND=0
+    int dp_band2;                   // > 0: calls whose track run (FlatGraph::trk_out / trk_in: levels of one or two nodes) covers read bases left + dp_band2 - 1 levels go to the two-track band kernels (kernel_dp_band2.hip); 0: HLALA_DP_BAND2=0
     int dp_band_risky;              // tests (HLALA_DP_BAND_RISKY=1): a call is listed for the band kernel as soon as the linear run covers its read bases -- many then walk past it and exercise the fail-over
     int dp_jf;                      // > 0: calls that meet no gap-path jump go to the lists of the jump-free instantiations, reach = read bases left + dp_jf - 1 levels (0: HLALA_DP_JF=0, every call in the general one)
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)
@@ -100,20 +101,25 @@ __device__ __forceinline__ int ordered_chains(const DevBatch& B) { return B.chai
 __device__ __forceinline__ size_t row_base(const DevBatch& B, int c) { return (size_t)(B.chain_row ? B.chain_row[c] : c) * (size_t)B.stride; }
 
 // ---- the first DP classes' dense item lists (k_dp_items / k_dp_lists): list k occupies dp_list[dp_blk[k * dp_nblk] .. dp_blk[(k + 1) * dp_nblk]); k + 1: the right extensions
-enum { DPL_BAND16 = 0, DPL_BAND32 = 2, DPL_BAND64 = 4, DPL_JF = 6, DPL_GEN = 8, DPL_N = 10 };
-// the list an item is put on, by the class k_dp_items gives it (0 general, 1 jump-free, 2 / 3 / 4 band kernel with 16 / 32 / 64 lanes per call); + 1 for a right extension
-__host__ __device__ inline int dpl_of_class(int cls) { return cls == 0 ? DPL_GEN : (cls == 1 ? DPL_JF : (cls == 2 ? DPL_BAND16 : (cls == 3 ? DPL_BAND32 : DPL_BAND64))); }
+enum { DPL_BAND16 = 0, DPL_BAND32 = 2, DPL_BAND64 = 4, DPL_JF = 6, DPL_GEN = 8, DPL_B2_16 = 10, DPL_B2_32 = 12, DPL_B2_64 = 14, DPL_N = 16 };
+// the list an item is put on, by the class k_dp_items gives it (0 general, 1 jump-free, 2 / 3 / 4 band kernel with 16 / 32 / 64 lanes per call, 5 / 6 / 7 two-track band kernel); + 1 for a right extension
+__host__ __device__ inline int dpl_of_class(int cls) { return cls == 0 ? DPL_GEN : (cls == 1 ? DPL_JF : (cls == 2 ? DPL_BAND16 : (cls == 3 ? DPL_BAND32 : (cls == 4 ? DPL_BAND64 : (cls == 5 ? DPL_B2_16 : (cls == 6 ? DPL_B2_32 : DPL_B2_64)))))); }
 // ---- B.work_counter (WC_N ints): [0] stage A, [1] / [10] left / right general items fetched, [2] stage C, [4] / [5] jump-free items fetched, [6] jump-free calls (statistics),
 // [7] chains stitched, [8] / [9] left / right DP calls, [12..35] retry lists of tiers 1..6 (count, fetched) x (left, right), [36] / [37] second stitch / pairing pass,
 // [40..47] round 6: the lists of the pairs with several combinations (k_pair_chains -> k_pair_multi): per pass (main / side stream) count and fetched of class 0, of class 1; round 5: items fetched by the three band kernels (left, right each), the fail-over list's counts and fetch counters, band calls that
 // failed over, band calls listed, jump-free calls that met a jump, and why band calls failed ([WC_BAND_WHY + 2 .. + 5]: past the staged levels, past the linear run, too
 // many iterations, too many tied end cells)
-enum { WC_PAIR_MULTI = 40, WC_BAND_FETCH = 48, WC_FO_COUNT = 54, WC_FO_FETCH = 56, WC_BAND_FAILED = 58, WC_BAND_CALLS = 59, WC_JF_FAILED = 60, WC_BAND_WHY = 62, WC_BAND_TIED = 68, WC_N = 72 };
+// round 6: [72..77] items fetched by the three two-track band kernels (left, right each), [78] calls listed for them, [79] those that failed over, [80..87] why (2 end of the
+// staged track steps, 4 too many iterations, 5 too many tied end cells, 6-8 internal)
+enum { WC_PAIR_MULTI = 40, WC_BAND_FETCH = 48, WC_FO_COUNT = 54, WC_FO_FETCH = 56, WC_BAND_FAILED = 58, WC_BAND_CALLS = 59, WC_JF_FAILED = 60, WC_BAND_WHY = 62, WC_BAND_TIED = 68,
+       WC_B2_FETCH = 72, WC_B2_CALLS = 78, WC_B2_FAILED = 79, WC_B2_WHY = 80, WC_N = 88 };
 // the fail-over list of the first classes: calls the band kernel (kernel_dp_band.hip) or the jump-free instantiation could not finish; k_dp<DpTiny, 0> draws it after
 // its own lists.  Entries (slots of dp_items) at retry_list[(14 + direction) * n_chains ...], counts in work_counter[WC_FO_COUNT + direction].
 // ---- capacities of the band kernels (kernel_dp_band.hip): read bases a call may have left for the instantiation with 16 / 32 / 64 lanes per call; k_dp_items lists a call
 // for one of them when the linear run ahead of its start level covers bases left + margin + min(bases left + 6, 40) levels
 constexpr int BAND_MAXJ16 = 15, BAND_MAXJ32 = 31, BAND_MAXJ64 = 48;
+// ... of the two-track band kernels (kernel_dp_band2.hip): read bases per instantiation, iterations a call may run (rows of a wavefront's back-pointer slab)
+constexpr int B2_MAXJ16 = 15, B2_MAXJ32 = 31, B2_MAXJ64 = 63, B2_MAXD = 256;
 
 enum {
     CNT_CHAINS_EXT = 0, CNT_DP_CALLS, CNT_DP_ITERS, CNT_DP_CELLS, CNT_SEED_COLS, CNT_OUT_COLS, CNT_EDGES, CNT_ERRORS, CNT_DP_SHARED

@@ -32,6 +32,7 @@ struct DevGraph {
     const uint8_t* out_prank; const uint8_t* in_prank; const uint8_t* jf_prank; const uint8_t* jb_prank;   // rank among the node's earlier entries to the same target (flat_graph.hpp)
     const uint8_t* jfree_out; const uint8_t* jfree_in;   // [L] levels without a gap-path jump from this level on, in either direction (flat_graph.hpp)
     const u32* lin_label; const uint8_t* lin_out; const uint8_t* lin_in; const int* lin_eid;   // [L] linear steps and their run lengths (flat_graph.hpp; kernel_dp_band.hip)
+    const u64* trk_w_out; const u64* trk_w_in; const uint8_t* trk_out; const uint8_t* trk_in; const u32* trk_j_out; const u32* trk_j_in; const int* trk_jp_out; const int* trk_jp_in;   // [L] track steps (flat_graph.hpp; kernel_dp_band2.hip)
     const int4* nrec_out;      // [2*N] 32-byte node records of the extension DP (flat_graph.hpp)
     const int4* nrec_in;
     const int* path_len;       // [P]

@@ -309,6 +309,56 @@ std::string flatten_graph(const hlala_graph_desc* g, const hlala_contigs_desc* c
             run = 0;
             for(int32_t l = 0; l < F.L; l++) { run = (l > 0 && F.lin_label[(size_t)l - 1]) ? std::min(255, run + 1) : 0; F.lin_in[(size_t)l] = (uint8_t)run; }
         }
+        // ---- track steps and the jumps along them (flat_graph.hpp; the model of the kernel that uses them: tools/band2/band2_model.cpp build_window / step_word)
+        {
+            const size_t Lz = (size_t)F.L;
+            F.trk_w_out.assign(Lz, 0); F.trk_w_in.assign(Lz, 0); F.trk_out.assign(Lz, 0); F.trk_in.assign(Lz, 0);
+            F.trk_j_out.assign(Lz, 0); F.trk_j_in.assign(Lz, 0); F.trk_jp_out.assign(Lz, -1); F.trk_jp_in.assign(Lz, -1);
+            auto code = [](uint8_t c) -> int { return c == 'A' ? 0 : (c == 'C' ? 1 : (c == 'G' ? 2 : (c == 'T' ? 3 : (c == 'N' ? 4 : (c == '_' ? 5 : -1))))); };
+            auto word = [&](int32_t l, int32_t other, const std::vector<int32_t>& off, const std::vector<int32_t>& to, const std::vector<uint8_t>& lab) -> uint64_t {
+                if(other < 0 || other >= F.L) return 0;
+                const int32_t n0 = F.level_off[l], nn = F.level_off[l + 1] - n0, o0 = F.level_off[other], on = F.level_off[other + 1] - o0;
+                if(nn < 1 || nn > 2 || on < 1 || on > 2) return 0;
+                uint64_t w = 0;
+                for(int32_t zs = 0; zs < nn; zs++) {
+                    const int32_t e0 = off[n0 + zs], deg = off[n0 + zs + 1] - e0;
+                    if(deg < 1 || deg > 4) return 0;
+                    uint32_t pr[2] = {0, 0}; int firstReal[2] = {-1, -1}, firstGap[2] = {-1, -1};
+                    for(int32_t k = 0; k < deg; k++) {
+                        const int32_t z = to[e0 + k] - o0; const int cd = code(lab[e0 + k]);
+                        if(z < 0 || z > 1 || cd < 0) return 0;
+                        pr[z] |= 1u;
+                        if(cd == 5) { pr[z] |= 4u; if(firstGap[z] < 0) firstGap[z] = k; }
+                        else { pr[z] |= 2u | (1u << (4 + cd)); if(firstReal[z] < 0) firstReal[z] = k; }
+                    }
+                    for(int z = 0; z < 2; z++) if(firstGap[z] >= 0 && (firstReal[z] < 0 || firstGap[z] < firstReal[z])) pr[z] |= 8u;
+                    pr[0] |= (uint32_t)deg << 9;
+                    w |= (uint64_t)pr[0] << (16 * (2 * zs)); w |= (uint64_t)pr[1] << (16 * (2 * zs + 1));
+                }
+                return w;
+            };
+            auto jumps = [&](int32_t l, const std::vector<int32_t>& off, const std::vector<int32_t>& node, const std::vector<int32_t>& path, uint32_t& jw, int32_t& jp) {
+                const int32_t n0 = F.level_off[l], nn = F.level_off[l + 1] - n0;
+                int nLong = 0, zA = 0, other = -1, p = -1;
+                for(int32_t zs = 0; zs < nn; zs++)
+                    for(int32_t i = off[n0 + zs]; i < off[n0 + zs + 1]; i++) if(F.path_len[path[i]] >= 2) { nLong++; zA = zs; other = node[i]; p = path[i]; }
+                if(nLong == 0) return;
+                const int len = F.path_len[p];
+                const int32_t zB = other - F.level_off[F.node_level[other]];
+                if(nLong > 1 || len < 4 || len > 29 || zA > 1 || zB > 1) { jw = 2u; return; }
+                jw = 1u | ((uint32_t)zA << 2) | ((uint32_t)zB << 3) | ((uint32_t)len << 8); jp = p;
+            };
+            for(int32_t l = 0; l < F.L; l++) {
+                F.trk_w_out[(size_t)l] = word(l, l + 1, F.out_off, F.out_to, F.out_label);
+                F.trk_w_in[(size_t)l] = word(l, l - 1, F.in_off, F.in_from, F.in_label);
+                jumps(l, F.jf_off, F.jf_node, F.jf_path, F.trk_j_out[(size_t)l], F.trk_jp_out[(size_t)l]);
+                jumps(l, F.jb_off, F.jb_node, F.jb_path, F.trk_j_in[(size_t)l], F.trk_jp_in[(size_t)l]);
+            }
+            int run = 0;
+            for(int32_t l = F.L - 1; l >= 0; l--) { run = F.trk_w_out[(size_t)l] ? std::min(255, run + 1) : 0; F.trk_out[(size_t)l] = (uint8_t)run; }
+            run = 0;
+            for(int32_t l = 0; l < F.L; l++) { run = F.trk_w_in[(size_t)l] ? std::min(255, run + 1) : 0; F.trk_in[(size_t)l] = (uint8_t)run; }
+        }
     }
     return "";
 }

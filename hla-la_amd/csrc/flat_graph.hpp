@@ -73,6 +73,19 @@ struct FlatGraph {
     std::vector<uint32_t> lin_label;                   // [L]
     std::vector<uint8_t> lin_out, lin_in;              // [L]
     std::vector<int32_t> lin_eid;                      // [L]
+    // TRACK steps (round 6, kernel_dp_band2.hip): the neighbourhood of a gap stretch of the backbone is two nodes per level -- a base track and a '_' track, or two base
+    // tracks until a SNP merges them -- with at most one gap-path jump across.  A step in the walking direction (out: level l -> l + 1 through the out-edges of the nodes
+    // of l; in: level l -> l - 1 through the in-edges of the nodes of l) is a track step when both levels hold one or two nodes, every source node has one to four edges
+    // and every label is one of A C G T N _.  trk_w_*[l] = its 64-bit word (0: not a track step): 16 bits per (source rank z', target rank z) pair at bits 16 (2 z' + z):
+    // bit 0 some edge, 1 an edge with a real label, 2 a '_' edge, 3 the '_' edge precedes the first real edge of the pair in CSR order, 4..8 which of A C G T N label
+    // the pair's real edges, 9..11 (pairs (z', 0)) the number of edges of source node z'.  trk_out / trk_in[l] = consecutive track steps from level l on (capped at 255).
+    // trk_j_*[l]: the gap-path jumps of MORE than one edge that start at the nodes of level l in that direction (paths of one edge are no-ops, see above): 0 none;
+    // bit 0 exactly one, and the kernel can take it (4 to 29 edges); bit 1 anything else (several, shorter, longer: a call that stands there fails over); bit 2 rank of
+    // the source node, bit 3 rank of the target node, bits 8..15 edges of the path; trk_jp_*[l] = the path (index into path_len / path_off).
+    std::vector<unsigned long long> trk_w_out, trk_w_in;         // [L]
+    std::vector<uint8_t> trk_out, trk_in;              // [L]
+    std::vector<uint32_t> trk_j_out, trk_j_in;         // [L]
+    std::vector<int32_t> trk_jp_out, trk_jp_in;        // [L]
     std::vector<uint8_t> gap_stretch;            // [L-1]
     // level -> (sequence id, position) CSR, entries sorted by sequence id
     std::vector<int64_t> lp_off;                 // [L+1]

@@ -26,6 +26,7 @@
 #include "kernel_exonpos.hip"
 #include "kernel_kmer.hip"
 #include "kernel_dp_band.hip"
+#include "kernel_dp_band2.hip"
 
 namespace hlala {
 size_t proj_slab_bytes_host(int stride, int maxNodesPerLevel) { return proj_slab_bytes(stride, maxNodesPerLevel); }
@@ -76,6 +77,7 @@ struct hlala_ctx {
     bool side_after_pair = false; // HLALA_SIDE_AFTER_PAIR=1: the side-stream classes are queued behind the main stream's stitch and pairing passes instead of beside them (measured: the pairing pass 20.9 -> 4.1 ms, but the next batch's projection 35.5 -> 54.8 ms beside the wide class instead; step 183.4 -> 185.5 ms)
     bool rows_all = false;        // HLALA_ROWS_ALL=1: column rows for every chain of a batch, the filters run with the projection (rounds 1-4)
     bool band_risky = false;      // HLALA_DP_BAND_RISKY=1 (tests: force fail-overs of the band kernel)
+    int band2_grid = 0, band2_margin = 12; u64* band2_slabs = nullptr;      // the two-track band kernels (kernel_dp_band2.hip): blocks (0: HLALA_DP_BAND2=0), levels beyond the read bases left that the track run must cover (HLALA_DP_BAND2_MARGIN), back-pointer slabs
     int band_grid = 0, band_margin = 8;      // the band kernel in front of the 16-lane class (kernel_dp_band.hip): blocks (0: HLALA_DP_BAND=0) and the levels beyond the read bases left a call is taken to reach (HLALA_DP_BAND_MARGIN)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
     char* ext_slabs = nullptr; size_t ext_slab_bytes = 0; char* wide_slabs = nullptr; char* mid_slabs = nullptr; char* large_slabs = nullptr; size_t large_slab_bytes = 0; char* huge_slabs = nullptr; size_t huge_slab_bytes = 0; int huge_grid = 0; int ext_grid = 0; int wide_grid = 0; int broad_grid = 0; int retry_grid = 0; int stitch_grid = 0; int mid_grid = 0; size_t mid_slab_bytes = 0;
@@ -111,7 +113,7 @@ struct hlala_batch {
     // timing events of THIS batch (created with its first stage call): ev = start / end per stage, [7] / [6] / [10] / [8] = before the 16-lane class / after it /
     // after the 64-lane class / after the last class; evC = start / end of each DP class on the stream it ran on; evSide[0] fork point on the main stream,
     // [1] first side-stream class starts, [6] second pairing pass done
-    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; hipEvent_t evJF = nullptr; /* end of the jump-free instantiation of the 16-lane class */ hipEvent_t evBand[2]{}; /* the band kernel */ bool band_used = false; bool eventsMade = false;
+    hipEvent_t ev[14]{}; hipEvent_t evC[7][2]{}; hipEvent_t evSide[8]{}; hipEvent_t evJF = nullptr; /* end of the jump-free instantiation of the 16-lane class */ hipEvent_t evBand[2]{}; /* the band kernel */ bool band_used = false; hipEvent_t evBand2[2]{}; bool band2_used = false; bool eventsMade = false;
     uint32_t first_chain = 0;    // absolute index of the batch's chain 0 in the caller's numbering (hlala_batch_set_first_chain): offsets the random seeds
     float ms[3] = {0, 0, 0};
 };
@@ -151,6 +153,7 @@ static int batch_events(hlala_ctx* c, hlala_batch* b)
     for(int i = 0; i < 14; i++) HIP_TRY(c, hipEventCreate(&b->evC[i / 2][i % 2]));
     HIP_TRY(c, hipEventCreate(&b->evJF));
     for(int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreate(&b->evBand[i]));
+    for(int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreate(&b->evBand2[i]));
     HIP_TRY(c, hipEventCreateWithFlags(&b->evMain, hipEventDisableTiming));
     b->eventsMade = true;
     return HLALA_OK;
@@ -427,6 +430,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     UPG(jf_lvl, F.djf_lvl); UPG(jb_lvl, F.djb_lvl);
     UPG(jfree_out, F.jfree_out); UPG(jfree_in, F.jfree_in);
     UPG(lin_label, F.lin_label); UPG(lin_out, F.lin_out); UPG(lin_in, F.lin_in); UPG(lin_eid, F.lin_eid);
+    UPG(trk_w_out, F.trk_w_out); UPG(trk_w_in, F.trk_w_in); UPG(trk_out, F.trk_out); UPG(trk_in, F.trk_in); UPG(trk_j_out, F.trk_j_out); UPG(trk_j_in, F.trk_j_in); UPG(trk_jp_out, F.trk_jp_out); UPG(trk_jp_in, F.trk_jp_in);
     UPG(out_prank, F.out_prank); UPG(in_prank, F.in_prank); UPG(jf_prank, F.jf_prank); UPG(jb_prank, F.jb_prank);
     { int* p_ = nullptr; rc = dev_upload(c, c->allocs, F.nrec_out.data(), F.nrec_out.size(), &p_); if(rc) return fail(rc); G.nrec_out = (const int4*)p_;
       rc = dev_upload(c, c->allocs, F.nrec_in.data(), F.nrec_in.size(), &p_); if(rc) return fail(rc); G.nrec_in = (const int4*)p_; }
@@ -473,6 +477,11 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_SIDE_AFTER_PAIR")) c->side_after_pair = atoi(e) != 0;
     if(const char* e = getenv("HLALA_TAIL_POOL")) { const int k = atoi(e); if(k >= 1 && k <= DP_POOL_MAX) c->tail_pool_k = k; }      // (experiments and the parity suite: hlala_set_tail_pool without touching the caller)
     if(const char* e = getenv("HLALA_DP_BAND_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 24) c->band_margin = m; }
+    c->band2_grid = cus * 6;          // 19-25 KB of LDS per block (the ring of the early band's cells)
+    if(const char* e = getenv("HLALA_DP_BAND2")) { if(atoi(e) == 0) c->band2_grid = 0; }      // (A/B and parity: those calls in the hashed-frontier classes)
+    if(const char* e = getenv("HLALA_DP_BAND2_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 200) c->band2_margin = m; }
+    if(const char* e = getenv("HLALA_DP_BAND2_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 16 && c->band2_grid) c->band2_grid = cus * w; }
+    if(c->band2_grid) { char* p_ = nullptr; if((rc = slab_pool(&p_, (size_t)c->band2_grid * (size_t)B2_MAXD * 64 * sizeof(u64), "two-track band slabs"))) return fail(rc); c->band2_slabs = (u64*)p_; }
     if(const char* e = getenv("HLALA_DP_BAND_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 32 && c->band_grid) c->band_grid = cus * w; }
     if(const char* e = getenv("HLALA_DP_JF")) { if(atoi(e) == 0) c->jf_grid = 0; }      // (A/B: every call in the general instantiation -- the kernels' lists are built either way)
     if(const char* e = getenv("HLALA_DP_JF_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 200) c->jf_margin = m; }      // (A/B: levels beyond the read bases left that a jump-free call may reach)
@@ -626,6 +635,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     B.dp_nblk = (int)((nc + 255) / 256); if(B.dp_nblk < 1) B.dp_nblk = 1;
     B.dp_jf = c->jf_grid > 0 ? c->jf_margin + 1 : 0;
     B.dp_band = c->band_grid > 0 ? c->band_margin + 1 : 0;
+    B.dp_band2 = c->band2_grid > 0 ? c->band2_margin + 1 : 0;
     B.dp_band_risky = c->band_risky ? 1 : 0;
     AL(dp_blk, (size_t)DPL_N * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
     if(!b->prepared) {
@@ -827,6 +837,7 @@ void hlala_batch_destroy(hlala_batch* b)
     for(int i = 0; i < 8; i++) if(b->evSide[i]) (void)hipEventDestroy(b->evSide[i]);
     if(b->evJF) (void)hipEventDestroy(b->evJF);
     for(int i = 0; i < 2; i++) if(b->evBand[i]) (void)hipEventDestroy(b->evBand[i]);
+    for(int i = 0; i < 2; i++) if(b->evBand2[i]) (void)hipEventDestroy(b->evBand2[i]);
     delete b;
 }
 
@@ -979,6 +990,16 @@ static int extend_impl(hlala_ctx* c, hlala_batch* b, bool fused, int phase)
             hipLaunchKernelGGL((k_dp_band<64>), dim3(c->band_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->G.lin_label, c->G.lin_eid);
             rc = check_launch(c, "k_dp_band"); if(rc) return rc;
             HIP_TRY(c, hipEventRecord(b->evBand[1], c->active));
+        }
+        // calls beside gap stretches next: two tracks and one gap-path jump in registers (kernel_dp_band2.hip); same fail-over list
+        b->band2_used = c->band2_grid > 0;
+        if(b->band2_used) {
+            HIP_TRY(c, hipEventRecord(b->evBand2[0], c->active));
+            hipLaunchKernelGGL((k_dp_band2<16>), dim3(c->band2_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->band2_slabs);
+            hipLaunchKernelGGL((k_dp_band2<32>), dim3(c->band2_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->band2_slabs);
+            hipLaunchKernelGGL((k_dp_band2<64>), dim3(c->band2_grid), dim3(64), 0, c->active, c->dG, b->dB, (const DpItem*)items, seed, (const uint8_t*)B.read_bases, c->band2_slabs);
+            rc = check_launch(c, "k_dp_band2"); if(rc) return rc;
+            HIP_TRY(c, hipEventRecord(b->evBand2[1], c->active));
         }
         HIP_TRY(c, hipEventRecord(b->ev[7], c->active));
         rc = run_class(0); if(rc) return rc;
@@ -1619,10 +1640,12 @@ int hlala_batch_get_stats(hlala_ctx* c, hlala_batch* b, hlala_batch_stats* out)
           for(int k = 0; k <= DP_LAST_TIER; k++) (void)hipEventElapsedTime(&out->ms_dp_class[k], b->evC[k][0], b->evC[k][1]);
           if(c->jf_grid > 0) (void)hipEventElapsedTime(&out->ms_dp_jump_free, b->evC[0][0], b->evJF);
           if(b->band_used) (void)hipEventElapsedTime(&out->ms_dp_band, b->evBand[0], b->evBand[1]);
+          if(b->band2_used) (void)hipEventElapsedTime(&out->ms_dp_band2, b->evBand2[0], b->evBand2[1]);
           if(b->side_used) (void)hipEventElapsedTime(&out->ms_side, b->evSide[1], b->evSide[6]); } }
     { int wc[WC_N]; HIP_TRY(c, hipMemcpyAsync(wc, b->B.work_counter, sizeof(wc), hipMemcpyDeviceToHost, c->active)); HIP_TRY(c, hipStreamSynchronize(c->active)); out->n_chains_retried = 0; for(int k = 1; k <= 6; k++) out->n_chains_retried += wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; out->n_dp_retried_large = wc[28] + wc[30];
       out->n_dp_band = b->band_used ? wc[WC_BAND_CALLS] : 0; out->n_dp_band_failed = b->band_used ? wc[WC_BAND_FAILED] : 0; out->n_dp_jump_free_failed = wc[WC_JF_FAILED];
-      out->n_dp_class[0] = wc[8] + wc[9] - out->n_dp_band + out->n_dp_band_failed; out->n_dp_jump_free = c->jf_grid > 0 ? wc[6] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
+      out->n_dp_band2 = b->band2_used ? wc[WC_B2_CALLS] : 0; out->n_dp_band2_failed = b->band2_used ? wc[WC_B2_FAILED] : 0;
+      out->n_dp_class[0] = wc[8] + wc[9] - out->n_dp_band + out->n_dp_band_failed - out->n_dp_band2 + out->n_dp_band2_failed; out->n_dp_jump_free = c->jf_grid > 0 ? wc[6] : 0; for(int k = 1; k <= 6; k++) out->n_dp_class[k] = wc[12 + 4 * (k - 1)] + wc[14 + 4 * (k - 1)]; }
     if(b->staged & 4) (void)hipEventElapsedTime(&out->ms_pair, b->ev[4], b->ev[5]);
     out->n_chains_extended = (int64_t)cnt[CNT_CHAINS_EXT]; out->n_dp_calls = (int64_t)cnt[CNT_DP_CALLS];
     out->n_dp_iterations = (int64_t)cnt[CNT_DP_ITERS]; out->n_dp_cells = (int64_t)cnt[CNT_DP_CELLS];

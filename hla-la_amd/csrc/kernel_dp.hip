@@ -1592,6 +1592,10 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
     //  iteration from the best complete cell, score <= 2 * bases, -6 then -2 per level down to the threshold of -16, at most 40 iterations -- walks up to bases + 6 more)
     if(needL && B.dp_band) { const int jm = itL.start_seq, reach = jm + B.dp_band - 1; runL = (int)G.lin_in[itL.startLevel]; bdL = jm <= BAND_MAXJ64 && runL >= (B.dp_band_risky ? jm : reach + min(jm + 6, 40)); if(bdL) clsL = jm <= BAND_MAXJ16 ? 2 : (jm <= BAND_MAXJ32 ? 3 : 4); }
     if(needR && B.dp_band) { const int jm = itR.seqLen - itR.start_seq, reach = jm + B.dp_band - 1; runR = (int)G.lin_out[itR.startLevel]; bdR = jm <= BAND_MAXJ64 && runR >= (B.dp_band_risky ? jm : reach + min(jm + 6, 40)); if(bdR) clsR = jm <= BAND_MAXJ16 ? 2 : (jm <= BAND_MAXJ32 ? 3 : 4); }
+    // Two-track band calls (kernel_dp_band2.hip, round 6): not linear, but every level the call is taken to reach -- read bases left + dp_band2 - 1 -- holds one or two nodes
+    // of at most four edges (FlatGraph::trk_out / trk_in); the kernel itself finds the one gap-path jump it can take among them.  A call that walks further fails over.
+    if(needL && !bdL && B.dp_band2) { const int jm = itL.start_seq, run = (int)G.trk_in[itL.startLevel]; if(jm <= B2_MAXJ64 && run >= min(jm + B.dp_band2 - 1, 255)) { clsL = jm <= B2_MAXJ16 ? 5 : (jm <= B2_MAXJ32 ? 6 : 7); runL = run; } }
+    if(needR && !bdR && B.dp_band2) { const int jm = itR.seqLen - itR.start_seq, run = (int)G.trk_out[itR.startLevel]; if(jm <= B2_MAXJ64 && run >= min(jm + B.dp_band2 - 1, 255)) { clsR = jm <= B2_MAXJ16 ? 5 : (jm <= B2_MAXJ32 ? 6 : 7); runR = run; } }
     if(t < nOrd) {
         int4* sl = (int4*)(items + t); int4* sr = (int4*)(items + (size_t)B.n_chains + t);
         if(needL) { sl[0] = make_int4(itL.item, itL.rOff, itL.seqLen, itL.start_seq); sl[1] = make_int4(itL.startLevel, itL.startNode, clsL, runL); } else sl[0] = make_int4(-1, 0, 0, 0);
@@ -1608,12 +1612,14 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
     if(lane == 0 && nShared) atomicAdd(&B.counters[CNT_DP_SHARED], (u64)nShared);
     const u64 mL = __ballot(needL), mR = __ballot(needR);
     const int kL = needL ? dpl_of_class(clsL) : -1, kR = needR ? dpl_of_class(clsR) + 1 : -1;
-    const u64 mJL = __ballot(needL && clsL == 1), mJR = __ballot(needR && clsR == 1), mBL = __ballot(needL && clsL >= 2), mBR = __ballot(needR && clsR >= 2);
+    const u64 mJL = __ballot(needL && clsL == 1), mJR = __ballot(needR && clsR == 1), mBL = __ballot(needL && clsL >= 2 && clsL <= 4), mBR = __ballot(needR && clsR >= 2 && clsR <= 4);
+    const u64 m2L = __ballot(needL && clsL >= 5), m2R = __ballot(needR && clsR >= 5);
     if(lane == 0) {
         if(mL) atomicAdd(&B.work_counter[8], __popcll(mL));
         if(mR) atomicAdd(&B.work_counter[9], __popcll(mR));
         if(mJL | mJR) atomicAdd(&B.work_counter[6], __popcll(mJL) + __popcll(mJR));
         if(mBL | mBR) atomicAdd(&B.work_counter[WC_BAND_CALLS], __popcll(mBL) + __popcll(mBR));
+        if(m2L | m2R) atomicAdd(&B.work_counter[WC_B2_CALLS], __popcll(m2L) + __popcll(m2R));
     }
 #pragma unroll
     for(int k = 0; k < DPL_N; k++) {

@@ -350,6 +350,11 @@ typedef struct {
                                      n_dp_class[0])                                                                                                                */
     int32_t n_dp_jump_free_failed;/* of n_dp_jump_free: calls that met a gap-path jump after all and were re-run in the general 16-lane instantiation                  */
     float   ms_dp_band;           /* time of the band kernel (before the 16-lane class on the main stream; not part of ms_dp_class[0])                                 */
+    int32_t n_dp_band2;           /* round 6: DP calls listed for the two-track band kernels (kernel_dp_band2.hip: one or two nodes per level within reach, at most one
+                                     gap-path jump -- the neighbourhood of a gap stretch); they do not enter the 16-lane class ...                                     */
+    int32_t n_dp_band2_failed;    /* ... except these: calls that reached the end of their track steps and were re-run in the general 16-lane instantiation            */
+    float   ms_dp_band2;          /* time of those kernels (after the band kernels, before the 16-lane class; not part of ms_dp_class[0])                              */
+    int32_t reserved_stats;
 } hlala_batch_stats;
 int  hlala_batch_get_stats(hlala_ctx* ctx, hlala_batch* b, hlala_batch_stats* out);
 
@@ -750,14 +755,15 @@ int  hlala_abi_sizeof(const char* struct_name);
 /* Version of this interface.  It changes whenever the meaning or the type of a field changes WITHOUT changing the size of its struct (which
  * hlala_abi_sizeof cannot see) or a struct grows: 2 = hlala_batch_in carries 64-bit window offsets and an absolute read_primary (round 3);
  * 3 = hlala_batch_stats ends with n_dp_jump_free / ms_dp_jump_free, hlala_batch_in with read_bases_packed / first_read (round 4);
- * 4 = hlala_batch_stats ends with n_dp_band / n_dp_band_failed / n_dp_jump_free_failed / ms_dp_band (round 5).  A caller compares
+ * 4 = hlala_batch_stats ends with n_dp_band / n_dp_band_failed / n_dp_jump_free_failed / ms_dp_band (round 5);
+ * 5 = ... with n_dp_band2 / n_dp_band2_failed / ms_dp_band2, hlala_set_tail_pool / hlala_flush / hlala_comm_* exist (round 6).  A caller compares
  * hlala_abi_version() with the HLALA_ABI_VERSION it was compiled against and refuses to run on a mismatch (hla-la_amd/__init__.py and
  * hla-la_amd/host/hlala_host.hpp do). */
-#define HLALA_ABI_VERSION 4
+#define HLALA_ABI_VERSION 5
 int  hlala_abi_version(void);
 /* ---- debug / diagnostics section (tests and tools only; not part of the path the reference calls).  Layouts may change between rounds: the constants below are
  * checked against the library's own at compile time (hlala_api.hip). */
-#define HLALA_DEBUG_WC_N           72     /* work counters of a batch (csrc/batch.h: B.work_counter)                                                   */
+#define HLALA_DEBUG_WC_N           88     /* work counters of a batch (csrc/batch.h: B.work_counter)                                                   */
 #define HLALA_DEBUG_WC_BAND_FETCH  48     /* [+0..5] items fetched by the 16 / 32 / 64-lane band kernels, left and right                               */
 #define HLALA_DEBUG_WC_BAND_WHY    62     /* [+2..5] band calls that failed over: past the staged levels, past the linear run, too many iterations, ties */
 #define HLALA_DEBUG_WC_BAND_TIED   68     /* band calls whose end cell was drawn among equal sequence-complete cells                                   */

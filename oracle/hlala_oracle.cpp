@@ -363,7 +363,7 @@ struct Aligner {
 
     struct Ext { bool have = false; Chain chain; int iters = 0; int score = INT_MIN; };
     /* test instrumentation (tools/band2: the CPU model of a GPU kernel is run on the arguments of every DP call and compared with its result): no part of the restatement */
-    struct DpObserver { virtual ~DpObserver() {} virtual void seen(const Aligner& A, const std::string& sequence, int start_sequence, int startLevel, int startZ, bool fwd, unsigned int seedBefore, const Ext& result) = 0; };
+    struct DpObserver { virtual ~DpObserver() {} virtual void seen(const Aligner& A, const std::string& sequence, int start_sequence, int startLevel, int startZ, bool fwd, unsigned int seedBefore, const Ext& result, long long cells, long long edges) = 0; };
     static DpObserver*& observer() { static thread_local DpObserver* o = nullptr; return o; }
 
     /* extensionAligner::fullNeedleman_diagonal_extension_gapJumper, extensionAligner.cpp:335-1556,
@@ -374,7 +374,7 @@ struct Aligner {
            unsigned int* rng_seed)
     {
         t_stats.calls++;
-        const unsigned int seedBefore_ = *rng_seed;
+        const unsigned int seedBefore_ = *rng_seed; const long long cells0_ = t_stats.cells, edges0_ = t_stats.edges;
         long long callMaxF = 0, callMaxT = 0, callFirstOvf = -1;
         const double minusInfinity = -1 * DBL_MAX;                                   /* :363 */
         std::map<Key, Cell> scores;                                                    /* :396 */
@@ -674,7 +674,7 @@ struct Aligner {
             }
         }
         result.iters = itersRun;
-        if(observer()) observer()->seen(*this, sequence, start_sequence, startLevel_graph, startZ_graph, directionPositive, seedBefore_, result);
+        if(observer()) observer()->seen(*this, sequence, start_sequence, startLevel_graph, startZ_graph, directionPositive, seedBefore_, result, t_stats.cells - cells0_, t_stats.edges - edges0_);
         return result;
     }
 

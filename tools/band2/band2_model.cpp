@@ -173,7 +173,7 @@ struct Model {
                     for(int zs = 0; zs < 2; zs++) {
                         const int src = D2[b][j - 1][zs];
                         if(src <= ABSENT) continue;
-                        R.edges += deg[zs];
+                        if(z == 0) R.edges += deg[zs];
                         if(pr[zs] & 1u) { const int v = src + ((bc < 5 && ((pr[zs] >> (4 + bc)) & 1u)) ? 2 : -5); if(v > best) { best = v; dsel = zs; } }
                     }
                 }
@@ -201,7 +201,7 @@ struct Model {
                 for(int zs = 0; zs < 2; zs++) {
                     const int sD = D1[b][j][zs], sS = S1[b][j][zs];
                     if(sD <= ABSENT || !sw) continue;
-                    R.edges += deg[zs];
+                    if(z == 0) R.edges += deg[zs];
                     const unsigned p = pr[zs];
                     if(!(p & 1u)) continue;
                     const bool real = p & 2u, gap = p & 4u, gapFirst = p & 8u;
@@ -382,8 +382,8 @@ struct Model {
 struct Stats { long long withEarly = 0, withRemet = 0, withOverwritten = 0, withDiffPtr = 0; long long calls = 0, bases_ok = 0, eligible = 0, done = 0, mismatch = 0, fail[8] = {0}, withJump = 0, iters_done = 0; long long firstBad[8] = {0}; };
 
 struct Observer : Aligner::DpObserver {
-    Stats st; int wantReach = 0;
-    void seen(const Aligner& A, const std::string& sequence, int start_sequence, int startLevel, int startZ, bool fwd, unsigned int seedBefore, const Aligner::Ext& r) override
+    Stats st; int wantReach = 0; long long prevCells = 0, prevEdges = 0; long long badCounters = 0;
+    void seen(const Aligner& A, const std::string& sequence, int start_sequence, int startLevel, int startZ, bool fwd, unsigned int seedBefore, const Aligner::Ext& r, long long oCells, long long oEdges) override
     {
         st.calls++;
         const int jmax = fwd ? (int)sequence.size() - start_sequence : start_sequence;
@@ -399,6 +399,7 @@ struct Observer : Aligner::DpObserver {
         st.done++; st.iters_done += m.iters; if(m.earlyKept) st.withEarly++; if(m.remet) st.withRemet++; if(m.overwritten) st.withOverwritten++; if(m.diffViaPointer) st.withDiffPtr++;
         bool same = (m.have == r.have) && (m.iters == r.iters);
         if(same && m.have) same = m.score == r.score && m.levels == r.chain.levels && m.edges_used == r.chain.edges && m.gchars == r.chain.graph_aligned && m.schars == r.chain.sequence_aligned && m.sb == r.chain.sequence_begin && m.se == r.chain.sequence_end;
+        if(same && (m.cells != oCells || m.edges != oEdges)) { same = false; if(getenv("B2_VERBOSE") && badCounters++ < 3) fprintf(stderr, "band2 counters: cells %lld vs %lld, edges %lld vs %lld (x0 %d y0 %d fwd %d)\n", m.cells, oCells, m.edges, oEdges, startLevel, start_sequence, (int)fwd); }
         if(!same) {
             if(st.mismatch < 1) {
                 st.firstBad[0] = startLevel; st.firstBad[1] = start_sequence; st.firstBad[2] = startZ; st.firstBad[3] = fwd; st.firstBad[4] = m.iters; st.firstBad[5] = r.iters; st.firstBad[6] = m.have ? m.score : -999; st.firstBad[7] = r.have ? r.score : -999;

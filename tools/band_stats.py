@@ -21,6 +21,9 @@ wc = gb.work_counters(); why = P.DEBUG_WC_BAND_WHY
 print("  fail-over reasons: past the staged levels %d, past the linear run %d, too many iterations %d, too many ties %d" % (wc[why + 2], wc[why + 3], wc[why + 4], wc[why + 5]))
 ls = [wc[P.DEBUG_WC_BAND_FETCH + k] for k in range(6)]
 print("  items fetched (>= listed) by the 16 / 32 / 64-lane band kernels, left + right:", ls[0] + ls[1], ls[2] + ls[3], ls[4] + ls[5])
+why2 = P.DEBUG_WC_N - 8
+print(" two-track band: %d calls (%.1f %% of the calls that run), failed over %d (%.2f %%): end of the track steps %d, iterations %d, ties %d, other %d; %.2f ms" % (st.n_dp_band2, 100.0 * st.n_dp_band2 / max(1, st.n_dp_band + st.n_dp_band2 + st.n_dp_class[0] - st.n_dp_band_failed - st.n_dp_band2_failed),
+      st.n_dp_band2_failed, 100.0 * st.n_dp_band2_failed / max(1, st.n_dp_band2), wc[why2 + 2], wc[why2 + 4], wc[why2 + 5], wc[why2 + 6] + wc[why2 + 7], st.ms_dp_band2))
 print(" 16-lane class: %d calls, %.2f ms (jump-free part: %d calls, %d met a jump, %.2f ms)" % (st.n_dp_class[0], st.ms_dp_class[0], st.n_dp_jump_free, st.n_dp_jump_free_failed, st.ms_dp_jump_free))
 print(" later classes: calls", list(st.n_dp_class)[1:], "ms", [round(x, 2) for x in list(st.ms_dp_class)[1:]])
 print(" stages ms: project %.2f extend %.2f pair %.2f -> %.0f pairs/s (one batch alone)" % (st.ms_project, st.ms_extend, st.ms_pair, n_pairs / ((st.ms_project + st.ms_extend + st.ms_pair) * 1e-3)))
