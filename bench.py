@@ -95,6 +95,27 @@ def make_workload(args, synth, rank):
     return w, mk
 
 
+def write_batch(d, r, j, bb):
+    np.save(os.path.join(d, "b%d_%d_scalars.npy" % (r, j)), np.asarray([bb["n_pairs"], bb["n_chains"]], np.int64))
+    np.save(os.path.join(d, "b%d_%d_insert.npy" % (r, j)), np.asarray([bb["insert_mean"], bb["insert_sd"]], np.float64))
+    for k in BATCH_KEYS:
+        np.save(os.path.join(d, "b%d_%d_%s.npy" % (r, j, k)), bb[k])
+
+
+def gen_worker(argv):
+    """`bench.py --gen-worker <dir> <ranks> --pairs P --levels L --graph g`: the two batches of each listed rank, written where shared_workload's readers expect them
+    (no torch, no GPU: a child of rank 0)."""
+    d = argv[0]; ranks = [int(x) for x in argv[1].split(",") if x]
+    ap = argparse.ArgumentParser(); ap.add_argument("--pairs", type=int); ap.add_argument("--levels", type=int); ap.add_argument("--graph")
+    a = ap.parse_args(argv[2:])
+    sys.path.insert(0, ROOT)
+    from tools import synth
+    w, mk = make_workload(a, synth, 0)
+    for r in ranks:
+        for j, seed in enumerate((1000 + r, 5000 + r)):
+            write_batch(d, r, j, mk(a.pairs, seed))
+
+
 def workload_desc(args, w):
     if args.graph == "m":
         return (f"{args.pairs} synthetic 2x150bp pairs per GPU (BASELINE config 2) vs Graph M, the SURVEY 8(d) stand-in for PRG_MHC_GRCh38_withIMGT: "
@@ -124,15 +145,16 @@ def shared_workload(args, synth, rank, world, dist):
         for k, v in w["contigs"].items():
             np.save(os.path.join(d, "contigs_%s.npy" % k), np.asarray(v))
         np.save(os.path.join(d, "max_nodes_per_level.npy"), np.asarray(int(w.get("max_nodes_per_level", 0))))
-        for r in range(1, world):
-            for j, seed in enumerate((1000 + r, 5000 + r)):
-                bb = mk(args.pairs, seed)
-                np.save(os.path.join(d, "b%d_%d_scalars.npy" % (r, j)), np.asarray([bb["n_pairs"], bb["n_chains"]], np.int64))
-                np.save(os.path.join(d, "b%d_%d_insert.npy" % (r, j)), np.asarray([bb["insert_mean"], bb["insert_sd"]], np.float64))
-                for k in BATCH_KEYS:
-                    np.save(os.path.join(d, "b%d_%d_%s.npy" % (r, j, k)), bb[k])
-                del bb
+        # the other ranks' batches: generated side by side by child processes that never touch the GPU (round 6: sixteen generations one after the other were
+        # 3.5 minutes at N = 8 before the first timed step); every worker builds the same world again (deterministic, ~10 s) and writes its ranks' batches
+        nw = min(world - 1, max(1, (os.cpu_count() or 8) // 2), 7)
+        shares = [[r for r in range(1, world) if (r - 1) % nw == k] for k in range(nw)]
+        workers = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gen-worker", d, ",".join(str(r) for r in sh), "--pairs", str(args.pairs), "--levels", str(args.levels), "--graph", args.graph])
+                   for sh in shares if sh]
         bs = [mk(args.pairs, 1000), mk(args.pairs, 5000)]
+        for wk in workers:
+            if wk.wait() != 0:
+                raise SystemExit("bench.py: a workload generator process failed")
     dist.barrier()
     if rank != 0:
         ld = lambda n: np.load(os.path.join(d, n + ".npy"))          # noqa: E731
@@ -904,4 +926,6 @@ def extras(args, P, synth, w, mk, b, ctx, gb, ckw):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--gen-worker":
+        gen_worker(sys.argv[2:]); sys.exit(0)
     main()

@@ -87,6 +87,7 @@ struct DevBatch {
     int dp_nblk;                    // blocks of k_dp_items
     int dp_band;                    // > 0: calls whose reach (read bases left + dp_band - 1 levels) stays inside a linear run of the graph go to the band kernel's lists (kernel_dp_band.hip); 0: HLALA_DP_BAND=0
     int dp_band2;                   // > 0: calls whose track run (FlatGraph::trk_out / trk_in: levels of one or two nodes) covers read bases left + dp_band2 - 1 levels go to the two-track band kernels (kernel_dp_band2.hip); 0: HLALA_DP_BAND2=0
+    int dp_band2_maxj;              // ... and whose read bases left do not exceed this (HLALA_DP_BAND2_MAXJ: 15 / 31 / 63 = the 16- / 32- / 64-lane instantiation and below)
     int dp_band_risky;              // tests (HLALA_DP_BAND_RISKY=1): a call is listed for the band kernel as soon as the linear run covers its read bases -- many then walk past it and exercise the fail-over
     int dp_jf;                      // > 0: calls that meet no gap-path jump go to the lists of the jump-free instantiations, reach = read bases left + dp_jf - 1 levels (0: HLALA_DP_JF=0, every call in the general one)
     void* dp_items;                 // [2*n_chains] DpItem (kernel_dp.hip)

@@ -77,6 +77,7 @@ struct hlala_ctx {
     bool side_after_pair = false; // HLALA_SIDE_AFTER_PAIR=1: the side-stream classes are queued behind the main stream's stitch and pairing passes instead of beside them (measured: the pairing pass 20.9 -> 4.1 ms, but the next batch's projection 35.5 -> 54.8 ms beside the wide class instead; step 183.4 -> 185.5 ms)
     bool rows_all = false;        // HLALA_ROWS_ALL=1: column rows for every chain of a batch, the filters run with the projection (rounds 1-4)
     bool band_risky = false;      // HLALA_DP_BAND_RISKY=1 (tests: force fail-overs of the band kernel)
+    int band2_maxj = B2_MAXJ64;
     int band2_grid = 0, band2_margin = 12; u64* band2_slabs = nullptr;      // the two-track band kernels (kernel_dp_band2.hip): blocks (0: HLALA_DP_BAND2=0), levels beyond the read bases left that the track run must cover (HLALA_DP_BAND2_MARGIN), back-pointer slabs
     int band_grid = 0, band_margin = 8;      // the band kernel in front of the 16-lane class (kernel_dp_band.hip): blocks (0: HLALA_DP_BAND=0) and the levels beyond the read bases left a call is taken to reach (HLALA_DP_BAND_MARGIN)
     char* tiny_slabs = nullptr; size_t tiny_slab_bytes = 0; int tiny_grid = 0; int jf_grid = 0;      // jf_grid: blocks of the jump-free instantiation of the 16-lane class (0: not used)
@@ -477,8 +478,12 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_SIDE_AFTER_PAIR")) c->side_after_pair = atoi(e) != 0;
     if(const char* e = getenv("HLALA_TAIL_POOL")) { const int k = atoi(e); if(k >= 1 && k <= DP_POOL_MAX) c->tail_pool_k = k; }      // (experiments and the parity suite: hlala_set_tail_pool without touching the caller)
     if(const char* e = getenv("HLALA_DP_BAND_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 24) c->band_margin = m; }
-    c->band2_grid = cus * 6;          // 19-25 KB of LDS per block (the ring of the early band's cells)
-    if(const char* e = getenv("HLALA_DP_BAND2")) { if(atoi(e) == 0) c->band2_grid = 0; }      // (A/B and parity: those calls in the hashed-frontier classes)
+    // The two-track band kernels are bit-exact and SLOWER than the hashed-frontier classes they would relieve (profiles/r06_experiments.txt 6: 1 000 vector instructions
+    // per iteration for two bands of two tracks -- the per-call cost of the hashed machine): not part of the default path.  HLALA_DP_BAND2=1 switches them on (the parity
+    // suite runs them: tests/test_gpu_align.py); the slabs are only allocated then.
+    c->band2_grid = 0;
+    if(const char* e = getenv("HLALA_DP_BAND2")) { if(atoi(e) != 0) c->band2_grid = cus * 6; }      // 19-25 KB of LDS per block (the ring of the early band's cells)
+    if(const char* e = getenv("HLALA_DP_BAND2_MAXJ")) { const int m = atoi(e); if(m >= 1 && m <= B2_MAXJ64) c->band2_maxj = m; }
     if(const char* e = getenv("HLALA_DP_BAND2_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 200) c->band2_margin = m; }
     if(const char* e = getenv("HLALA_DP_BAND2_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 16 && c->band2_grid) c->band2_grid = cus * w; }
     if(c->band2_grid) { char* p_ = nullptr; if((rc = slab_pool(&p_, (size_t)c->band2_grid * (size_t)B2_MAXD * 64 * sizeof(u64), "two-track band slabs"))) return fail(rc); c->band2_slabs = (u64*)p_; }
@@ -636,6 +641,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     B.dp_jf = c->jf_grid > 0 ? c->jf_margin + 1 : 0;
     B.dp_band = c->band_grid > 0 ? c->band_margin + 1 : 0;
     B.dp_band2 = c->band2_grid > 0 ? c->band2_margin + 1 : 0;
+    B.dp_band2_maxj = c->band2_maxj;
     B.dp_band_risky = c->band_risky ? 1 : 0;
     AL(dp_blk, (size_t)DPL_N * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
     if(!b->prepared) {

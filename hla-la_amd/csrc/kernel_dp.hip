@@ -1594,8 +1594,8 @@ __global__ void k_dp_items(const DevGraph* __restrict__ Gp, const DevBatch* __re
     if(needR && B.dp_band) { const int jm = itR.seqLen - itR.start_seq, reach = jm + B.dp_band - 1; runR = (int)G.lin_out[itR.startLevel]; bdR = jm <= BAND_MAXJ64 && runR >= (B.dp_band_risky ? jm : reach + min(jm + 6, 40)); if(bdR) clsR = jm <= BAND_MAXJ16 ? 2 : (jm <= BAND_MAXJ32 ? 3 : 4); }
     // Two-track band calls (kernel_dp_band2.hip, round 6): not linear, but every level the call is taken to reach -- read bases left + dp_band2 - 1 -- holds one or two nodes
     // of at most four edges (FlatGraph::trk_out / trk_in); the kernel itself finds the one gap-path jump it can take among them.  A call that walks further fails over.
-    if(needL && !bdL && B.dp_band2) { const int jm = itL.start_seq, run = (int)G.trk_in[itL.startLevel]; if(jm <= B2_MAXJ64 && run >= min(jm + B.dp_band2 - 1, 255)) { clsL = jm <= B2_MAXJ16 ? 5 : (jm <= B2_MAXJ32 ? 6 : 7); runL = run; } }
-    if(needR && !bdR && B.dp_band2) { const int jm = itR.seqLen - itR.start_seq, run = (int)G.trk_out[itR.startLevel]; if(jm <= B2_MAXJ64 && run >= min(jm + B.dp_band2 - 1, 255)) { clsR = jm <= B2_MAXJ16 ? 5 : (jm <= B2_MAXJ32 ? 6 : 7); runR = run; } }
+    if(needL && !bdL && B.dp_band2) { const int jm = itL.start_seq, run = (int)G.trk_in[itL.startLevel]; if(jm <= B.dp_band2_maxj && run >= min(jm + B.dp_band2 - 1, 255)) { clsL = jm <= B2_MAXJ16 ? 5 : (jm <= B2_MAXJ32 ? 6 : 7); runL = run; } }
+    if(needR && !bdR && B.dp_band2) { const int jm = itR.seqLen - itR.start_seq, run = (int)G.trk_out[itR.startLevel]; if(jm <= B.dp_band2_maxj && run >= min(jm + B.dp_band2 - 1, 255)) { clsR = jm <= B2_MAXJ16 ? 5 : (jm <= B2_MAXJ32 ? 6 : 7); runR = run; } }
     if(t < nOrd) {
         int4* sl = (int4*)(items + t); int4* sr = (int4*)(items + (size_t)B.n_chains + t);
         if(needL) { sl[0] = make_int4(itL.item, itL.rOff, itL.seqLen, itL.start_seq); sl[1] = make_int4(itL.startLevel, itL.startNode, clsL, runL); } else sl[0] = make_int4(-1, 0, 0, 0);

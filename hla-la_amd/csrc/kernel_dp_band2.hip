@@ -53,24 +53,25 @@ __device__ __forceinline__ int b2_dec(u32 b) { return b ? (int)b - 32 : DP_NEG; 
 // D2p / D1p / G1p: the lane of read offset j - 1 (cells (i - 1, j - 1) of two iterations ago, (i, j - 1) of the last one); D1o / S1o: this lane's cells (i - 1, j) of
 // the last iteration; jv / jz: the jump's candidate and target rank (jz < 0: none).  Per cell: newD, dsel (0 / 1 diagonal from rank 0 / 1, 2 / 3 '_' edge from rank
 // 0 / 1, 4 jump, 5 GG, 6 SG), GGv + gbit, SGv + ssel (ssrc | sext << 1 | sgap << 2).
-template <bool FWD>
+template <bool FWD, bool T1>      // T1 = false: no rank-1 cell and no second track anywhere in the wavefront this iteration -- only the pair (0, 0)
 __device__ __forceinline__ void b2_eval(const u64 sw, const bool hasPrev, const int bc, const int* D2p, const int* D1p, const int* G1p, const int* D1o, const int* S1o, const int jv, const int jz,
                                         int* newD, int* dsel, int* GGv, int* gbit, int* SGv, int* ssel, int& edges)
 {
     constexpr int ABS = -20000;
     const int deg0 = (int)((sw >> 9) & 7ull), deg1 = (int)((sw >> 41) & 7ull);
     if(sw) {
-        if(hasPrev) { if(D2p[0] > ABS) edges += deg0; if(D2p[1] > ABS) edges += deg1; }       // :428: every edge of a source cell of the m-2 diagonal
-        if(D1o[0] > ABS) edges += deg0; if(D1o[1] > ABS) edges += deg1;                        // :459: ... and of the m-1 diagonal
+        if(hasPrev) { if(D2p[0] > ABS) edges += deg0; if(T1 && D2p[1] > ABS) edges += deg1; }       // :428: every edge of a source cell of the m-2 diagonal
+        if(D1o[0] > ABS) edges += deg0; if(T1 && D1o[1] > ABS) edges += deg1;                        // :459: ... and of the m-1 diagonal
     }
+    constexpr int NZ = T1 ? 2 : 1;
 #pragma unroll
-    for(int z = 0; z < 2; z++) {
+    for(int z = 0; z < NZ; z++) {
         const u32 pr[2] = {(u32)((sw >> (16 * z)) & 0xFFFFull), (u32)((sw >> (32 + 16 * z)) & 0xFFFFull)};
         int best = DP_NEG, ds = 0;
         // m-2 diagonal (:565-607): +2 when a real edge of the pair carries the read base, else -5
         if(hasPrev) {
 #pragma unroll
-            for(int zs = 0; zs < 2; zs++) {
+            for(int zs = 0; zs < NZ; zs++) {
                 const int src = D2p[zs];
                 if(src > ABS && (pr[zs] & 1u)) { const int v = src + ((bc < 5 && ((pr[zs] >> (4 + bc)) & 1u)) ? 2 : -5); if(v > best) { best = v; ds = zs; } }
             }
@@ -78,7 +79,7 @@ __device__ __forceinline__ void b2_eval(const u64 sw, const bool hasPrev, const 
         // m-1 diagonal, D candidates: '_' edges (:738-752) and the jump (:757-786) in map order of their sources -- the jump's source has the lower level: first forward, last backward
         if(FWD) { if(jz == z && jv > ABS && jv > best) { best = jv; ds = 4; } }
 #pragma unroll
-        for(int zs = 0; zs < 2; zs++) { const int src = D1o[zs]; if(src > ABS && (pr[zs] & 4u) && src > best) { best = src; ds = 2 + zs; } }
+        for(int zs = 0; zs < NZ; zs++) { const int src = D1o[zs]; if(src > ABS && (pr[zs] & 4u) && src > best) { best = src; ds = 2 + zs; } }
         if(!FWD) { if(jz == z && jv > ABS && jv > best) { best = jv; ds = 4; } }
         // gap in graph (:621-661): open before extend
         int gg = DP_NEG, gb = 0;
@@ -86,7 +87,7 @@ __device__ __forceinline__ void b2_eval(const u64 sw, const bool hasPrev, const 
         // gap in sequence (:664-754), sources in rank order, per pair: [the '_' edge's free extension if it comes first,] open through the first real edge, extend through it, [the '_' edge's extension]
         int sg = DP_NEG, ss = 0;
 #pragma unroll
-        for(int zs = 0; zs < 2; zs++) {
+        for(int zs = 0; zs < NZ; zs++) {
             const int sD = D1o[zs], sS = S1o[zs]; const u32 p = pr[zs];
             if(sD > ABS && (p & 1u)) {
                 const bool real = p & 2u, gap = p & 4u, gapFirst = p & 8u;
@@ -106,6 +107,12 @@ __device__ __forceinline__ void b2_eval(const u64 sw, const bool hasPrev, const 
 // 11-bit back-pointer record of one cell: kept | useD << 1 | useG << 2 | useS << 3 | dsel << 4 | gbit << 7 | ssel << 8
 __device__ __forceinline__ u32 b2_rec(bool useD, bool useG, bool useS, int dsel, int gbit, int ssel) { return 1u | (useD ? 2u : 0u) | (useG ? 4u : 0u) | (useS ? 8u : 0u) | ((u32)dsel << 4) | ((u32)gbit << 7) | ((u32)ssel << 8); }
 
+#ifdef HLALA_B2_TIMING       // build-time switch: cycles per phase of a wavefront's task (draw + stage, iterations, end cell + backtrace, columns + outputs) -> counters[16..23]
+#define B2_T(i) do { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); tAcc[i] += t_ - tMark; tMark = t_; } while(0)
+#else
+#define B2_T(i) do { } while(0)
+#endif
+
 template <class C, bool FWD>
 __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B, const DpItem* __restrict__ items, const u32 rng_seed, const uint8_t* __restrict__ readBases,
                                            Band2Lds<C>& S, u64* __restrict__ slab, u64& accCalls, u64& accIters, u64& accCells, u64& accEdges)
@@ -122,7 +129,11 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
     const u32* __restrict__ trkJ = FWD ? G.trk_j_out : G.trk_j_in;
     const int* __restrict__ trkJP = FWD ? G.trk_jp_out : G.trk_jp_in;
     const int stride = B.stride, levelsL = G.L;
+#ifdef HLALA_B2_TIMING
+    long long tAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tMark = clock64();
+#endif
     for(;;) {
+        B2_T(4);
         int w0 = 0;
         if(lane == 0) w0 = atomicAdd(fetchCounter, NG);
         w0 = __builtin_amdgcn_readfirstlane(w0);
@@ -164,9 +175,11 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
             if(haveJump && ja >= reach) haveJump = false;
         }
         const int Delta = haveJump ? jlen - 1 : 0;
+        const bool wJump = __ballot(haveJump) != 0;                       // (wave-uniform: some call of this wavefront has a jump)
         int myBc = 5;                                                     // the read base this lane's cells consume last, as a code (A C G T N = 0 .. 4)
         if(has && gl >= 1 && gl <= jmax) myBc = b2_base_code(readBases[rOff + (FWD ? y0 + gl - 1 : y0 - gl)]);
         WSYNC();
+        B2_T(0);
 
         // ---- state: [band][rank]; band 0 = main, 1 = early.  D1 / G1 / S1: the lane's cells of the last iteration after the filter, D2: of the one before (frontier values);
         // P*: what `scores` holds for the main band's cells of the last two iterations, frontier or not (the diff rule of cells met again)
@@ -199,68 +212,88 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
                 else if(d > C::MAXD - 1) { running = false; fail = 4; }
             }
             if(__ballot(running) == 0) break;
-            // ---- candidates
+            // ---- candidates.  Two wave-uniform switches keep the common iteration short (the loop is bound by instruction issue: ~1 000 vector instructions with everything on):
+            // eOn -- some lane of the wavefront holds an early cell or is about to get one through the jump; t1 -- some lane has a rank-1 cell or a step with a second track.
             const int iM = d - gl, iE = d - gl + Delta;
             const u64 swM = (inRead && iM >= 1 && iM <= reach) ? S.sw[iM] : 0ull;
-            const u64 swE = (inRead && haveJump && iE >= max(jb, 1) && iE <= reach) ? S.sw[iE] : 0ull;
+            const bool okM = inRead && iM >= 0 && iM <= reach, okE = inRead && haveJump && iE >= jb && iE <= reach;
+            const int jv = (okE && iE == jb) ? (jzA ? D1[0][1] : D1[0][0]) : DP_NEG;       // the jump's candidate: the main band's cell of the last iteration IS the jump's source then (level a, rank zA)
+            const bool eOn = wJump && __ballot(haveJump && (D1[1][0] > ABS || D1[1][1] > ABS || D2[1][0] > ABS || D2[1][1] > ABS || jv > ABS)) != 0;
+            const u64 swE = (eOn && inRead && haveJump && iE >= max(jb, 1) && iE <= reach) ? S.sw[iE] : 0ull;
+            const bool t1 = __ballot(((swM | swE) >> 16) != 0ull || D1[0][1] > ABS || D2[0][1] > ABS || D1[1][1] > ABS || D2[1][1] > ABS || (jv > ABS && jzB == 1)) != 0;
             int nD[2][2], ds[2][2], gv[2][2], gb[2][2], sv[2][2], ss[2][2];
-            int D2p[2][2], D1p[2][2], G1p[2][2];
 #pragma unroll
             for(int b = 0; b < 2; b++)
 #pragma unroll
-                for(int z = 0; z < 2; z++) { D2p[b][z] = band_prev<GW>(D2[b][z], gl); D1p[b][z] = band_prev<GW>(D1[b][z], gl); G1p[b][z] = band_prev<GW>(G1[b][z], gl); }
-            const bool okM = inRead && iM >= 0 && iM <= reach, okE = inRead && haveJump && iE >= jb && iE <= reach;
+                for(int z = 0; z < 2; z++) { nD[b][z] = DP_NEG; ds[b][z] = 0; gv[b][z] = DP_NEG; gb[b][z] = 0; sv[b][z] = DP_NEG; ss[b][z] = 0; }
             int edgesIt = 0;
-            b2_eval<FWD>(swM, gl >= 1, myBc, D2p[0], D1p[0], G1p[0], D1[0], S1[0], DP_NEG, -1, nD[0], ds[0], gv[0], gb[0], sv[0], ss[0], edgesIt);
-            // the jump's candidate: the main band's cell of the last iteration when that cell is the jump's source (level a, rank zA)
-            const int jv = (okE && iE == jb && (d - 1 - gl) == ja) ? (jzA ? D1[0][1] : D1[0][0]) : DP_NEG;
-            b2_eval<FWD>(swE, gl >= 1, myBc, D2p[1], D1p[1], G1p[1], D1[1], S1[1], jv, (okE && iE == jb) ? jzB : -1, nD[1], ds[1], gv[1], gb[1], sv[1], ss[1], edgesIt);
+            {
+                int D2p[2] = {band_prev<GW>(D2[0][0], gl), DP_NEG}, D1p[2] = {band_prev<GW>(D1[0][0], gl), DP_NEG}, G1p[2] = {band_prev<GW>(G1[0][0], gl), DP_NEG};
+                if(t1) { D2p[1] = band_prev<GW>(D2[0][1], gl); D1p[1] = band_prev<GW>(D1[0][1], gl); G1p[1] = band_prev<GW>(G1[0][1], gl);
+                         b2_eval<FWD, true>(swM, gl >= 1, myBc, D2p, D1p, G1p, D1[0], S1[0], DP_NEG, -1, nD[0], ds[0], gv[0], gb[0], sv[0], ss[0], edgesIt); }
+                else b2_eval<FWD, false>(swM, gl >= 1, myBc, D2p, D1p, G1p, D1[0], S1[0], DP_NEG, -1, nD[0], ds[0], gv[0], gb[0], sv[0], ss[0], edgesIt);
+            }
+            if(eOn) {
+                int D2p[2] = {band_prev<GW>(D2[1][0], gl), DP_NEG}, D1p[2] = {band_prev<GW>(D1[1][0], gl), DP_NEG}, G1p[2] = {band_prev<GW>(G1[1][0], gl), DP_NEG};
+                const int jz = (okE && iE == jb) ? jzB : -1;
+                if(t1) { D2p[1] = band_prev<GW>(D2[1][1], gl); D1p[1] = band_prev<GW>(D1[1][1], gl); G1p[1] = band_prev<GW>(G1[1][1], gl);
+                         b2_eval<FWD, true>(swE, gl >= 1, myBc, D2p, D1p, G1p, D1[1], S1[1], jv, jz, nD[1], ds[1], gv[1], gb[1], sv[1], ss[1], edgesIt); }
+                else b2_eval<FWD, false>(swE, gl >= 1, myBc, D2p, D1p, G1p, D1[1], S1[1], jv, jz, nD[1], ds[1], gv[1], gb[1], sv[1], ss[1], edgesIt);
+            }
             if(!okM) { nD[0][0] = DP_NEG; nD[0][1] = DP_NEG; }
             if(!okE) { nD[1][0] = DP_NEG; nD[1][1] = DP_NEG; }
             // ---- call maxima (:794-1073)
             // what the early band left in `scores` for the main band's cells of this iteration
             u32 eb[2] = {0, 0};
-            const bool ringValid = haveJump && iM >= jb && d - Delta >= 1;
-            if(ringValid) { const u64 e = S.ring[(d - Delta) & (B2_RING - 1)][gl]; eb[0] = (u32)e; eb[1] = (u32)(e >> 32); }
+            if(wJump) {
+                const bool ringValid = haveJump && iM >= jb && d - Delta >= 1;
+                if(ringValid) { const u64 e = S.ring[(d - Delta) & (B2_RING - 1)][gl]; eb[0] = (u32)e; eb[1] = (u32)(e >> 32); }
+            }
             int stD[2][2], stG[2][2], stS[2][2]; bool kept[2][2]; u32 rec[2][2];
             int mxStoredL = DP_NEG, packL = 0; bool anyOv = false, eqNZ = false, needPtr = false;
             bool useDm[2] = {true, true}, useGm[2] = {true, true}, useSm[2] = {true, true};
 #pragma unroll
             for(int b = 0; b < 2; b++)
 #pragma unroll
-                for(int z = 0; z < 2; z++) {
-                    const int v = nD[b][z];
-                    const bool k = v >= -16;                                                                      // :949
-                    kept[b][z] = k; rec[b][z] = 0; stD[b][z] = DP_NEG; stG[b][z] = DP_NEG; stS[b][z] = DP_NEG;
-                    if(v > ABS) cellsAcc += running ? 1 : 0;                                                        // :492
-                    if(k) {
-                        int sD = v, sG = gv[b][z], sS = sv[b][z];
-                        bool uD = true, uG = true, uS = true;
-                        const bool E = b == 0 && ((eb[z] >> 24) & 1u);
-                        if(E) {                                                                                     // :951-979
-                            const int eD = b2_dec(eb[z] & 255u), eG = b2_dec((eb[z] >> 8) & 255u), eS = b2_dec((eb[z] >> 16) & 255u);
-                            uD = v > eD; uG = sG > eG; uS = sS > eS;
-                            if(uD || uG || uS) anyOv = true;
-                            if(!uD) sD = eD; if(!uG) sG = eG; if(!uS) sS = eS;
-                            useDm[z] = uD; useGm[z] = uG; useSm[z] = uS;
-                        }
-                        stD[b][z] = sD; stG[b][z] = sG; stS[b][z] = sS;
-                        if(sD > mxStoredL) mxStoredL = sD;
-                        const int i = b ? iE : iM;
-                        const int ord = FWD ? ((i << 7) | (gl << 1) | z) : (((511 - i) << 7) | ((63 - gl) << 1) | z);
-                        const int pk = ((v + 64) << 16) | (0xFFFF - ord);
-                        if(pk > packL) packL = pk;
-                        if(v == curMax) {                                                                           // :1007-1041
-                            if(!E || uD) {
-                                const int sse = (E && !uS) ? (int)((eb[z] >> 29) & 7u) : ss[b][z];                 // (the SG pointer behind a D that came from SG: the stored one)
-                                const bool zero = (ds[b][z] >= 2 && ds[b][z] <= 4) || (ds[b][z] == 6 && (sse & 2) && (sse & 4));
-                                if(!zero) eqNZ = true;
-                            } else needPtr = true;
-                        }
-                        rec[b][z] = b2_rec(uD, uG, uS, ds[b][z], gb[b][z], ss[b][z]);
-                    }
-                }
-            if(__ballot(needPtr) != 0) {
+                for(int z = 0; z < 2; z++) { kept[b][z] = false; rec[b][z] = 0; stD[b][z] = DP_NEG; stG[b][z] = DP_NEG; stS[b][z] = DP_NEG; }
+            // one cell (band b, rank z) through :949-1062 (tools/band2/band2_model.cpp, "call maxima")
+#define B2_CELL(b, z) do {                                                                                                                        \
+                    const int v = nD[b][z];                                                                                                        \
+                    const bool k = v >= -16;                                                                      /* :949 */                       \
+                    kept[b][z] = k;                                                                                                                \
+                    if(v > ABS) cellsAcc += running ? 1 : 0;                                                      /* :492 */                       \
+                    if(k) {                                                                                                                        \
+                        int sD = v, sG = gv[b][z], sS = sv[b][z];                                                                                  \
+                        bool uD = true, uG = true, uS = true;                                                                                      \
+                        const bool E = b == 0 && ((eb[z] >> 24) & 1u);                                                                             \
+                        if(E) {                                                                                   /* :951-979 */                   \
+                            const int eD = b2_dec(eb[z] & 255u), eG = b2_dec((eb[z] >> 8) & 255u), eS = b2_dec((eb[z] >> 16) & 255u);              \
+                            uD = v > eD; uG = sG > eG; uS = sS > eS;                                                                               \
+                            if(uD || uG || uS) anyOv = true;                                                                                       \
+                            if(!uD) sD = eD; if(!uG) sG = eG; if(!uS) sS = eS;                                                                     \
+                            useDm[z] = uD; useGm[z] = uG; useSm[z] = uS;                                                                           \
+                        }                                                                                                                          \
+                        stD[b][z] = sD; stG[b][z] = sG; stS[b][z] = sS;                                                                            \
+                        if(sD > mxStoredL) mxStoredL = sD;                                                                                         \
+                        const int i_ = b ? iE : iM;                                                                                                \
+                        const int ord = FWD ? ((i_ << 7) | (gl << 1) | z) : (((511 - i_) << 7) | ((63 - gl) << 1) | z);                            \
+                        const int pk = ((v + 64) << 16) | (0xFFFF - ord);                                                                          \
+                        if(pk > packL) packL = pk;                                                                                                 \
+                        if(v == curMax) {                                                                         /* :1007-1041 */                 \
+                            if(!E || uD) {                                                                                                         \
+                                const int sse = (E && !uS) ? (int)((eb[z] >> 29) & 7u) : ss[b][z];                /* (the SG pointer behind a D that came from SG: the stored one) */ \
+                                const bool zero = (ds[b][z] >= 2 && ds[b][z] <= 4) || (ds[b][z] == 6 && (sse & 2) && (sse & 4));                   \
+                                if(!zero) eqNZ = true;                                                                                             \
+                            } else needPtr = true;                                                                                                 \
+                        }                                                                                                                          \
+                        rec[b][z] = b2_rec(uD, uG, uS, ds[b][z], gb[b][z], ss[b][z]);                                                              \
+                    }                                                                                                                              \
+                } while(0)
+            B2_CELL(0, 0);
+            if(t1) B2_CELL(0, 1);
+            if(eOn) { B2_CELL(1, 0); if(t1) B2_CELL(1, 1); }
+#undef B2_CELL
+            if(wJump && __ballot(needPtr) != 0) {
                 // cells met again and not improved in D that equal the running maximum: the early band's pointer, followed through the merged GG / SG pointers of the same cell;
                 // the predecessor's CURRENT value (the lanes' P registers: the cells of the last two iterations)
                 const int PD2p0 = band_prev<GW>(PD2[0], gl), PD2p1 = band_prev<GW>(PD2[1], gl), PD1p0 = band_prev<GW>(PD1[0], gl), PD1p1 = band_prev<GW>(PD1[1], gl);
@@ -282,7 +315,7 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
             }
             const int mk = grp_max_i32<GW>(packL);
             const int mxStored = grp_max_i32<GW>(mxStoredL);
-            const bool gOv = grp_ballot<GW>(anyOv) != 0, gEq = grp_ballot<GW>(eqNZ) != 0;
+            const bool gOv = wJump && grp_ballot<GW>(anyOv) != 0, gEq = grp_ballot<GW>(eqNZ) != 0;
             if(running) {
                 itersRun = d; dLast = d;
                 edgesAcc += edgesIt;
@@ -296,8 +329,10 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
                         fp = (d << 8) | (fj << 2) | (fz << 1) | ((fi + fj == d) ? 0 : 1);
                     } else if(gEq) lastInc = d;
                 }
-                // sequence-complete cells (:982-999): lane jmax
-                if(gl == jmax) {
+            }
+            // sequence-complete cells (:982-999): lane jmax
+            if(__ballot(running && gl == jmax && (kept[0][0] || kept[0][1] || kept[1][0] || kept[1][1])) != 0) {
+                if(running && gl == jmax) {
 #pragma unroll
                     for(int b = 0; b < 2; b++)
 #pragma unroll
@@ -310,21 +345,24 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
                             }
                         }
                 }
-                // the main band's lanes remember what `scores` holds for their cells of this iteration
+            }
+            if(running) {
+                // the main band's lanes remember what `scores` holds for their cells of this iteration; the early band's cells go into the ring
+                if(wJump) {
 #pragma unroll
-                for(int z = 0; z < 2; z++) {
-                    PD2[z] = PD1[z];
-                    int pD = DP_NEG, pG = DP_NEG, pS = DP_NEG;
-                    if(kept[0][z]) { pD = stD[0][z]; pG = stG[0][z]; pS = stS[0][z]; }
-                    else if((eb[z] >> 24) & 1u) { pD = b2_dec(eb[z] & 255u); pG = b2_dec((eb[z] >> 8) & 255u); pS = b2_dec((eb[z] >> 16) & 255u); }
-                    PD1[z] = pD; PG1[z] = pG; PS1[z] = pS;
-                }
-                // the early band's cells into the ring, the back pointers into the slab
-                if(haveJump) {
-                    u32 e[2];
+                    for(int z = 0; z < 2; z++) {
+                        PD2[z] = PD1[z];
+                        int pD = DP_NEG, pG = DP_NEG, pS = DP_NEG;
+                        if(kept[0][z]) { pD = stD[0][z]; pG = stG[0][z]; pS = stS[0][z]; }
+                        else if((eb[z] >> 24) & 1u) { pD = b2_dec(eb[z] & 255u); pG = b2_dec((eb[z] >> 8) & 255u); pS = b2_dec((eb[z] >> 16) & 255u); }
+                        PD1[z] = pD; PG1[z] = pG; PS1[z] = pS;
+                    }
+                    if(haveJump) {
+                        u32 e[2];
 #pragma unroll
-                    for(int z = 0; z < 2; z++) e[z] = kept[1][z] ? (b2_enc(stD[1][z]) | (b2_enc(stG[1][z]) << 8) | (b2_enc(stS[1][z]) << 16) | (1u << 24) | ((u32)ds[1][z] << 25) | ((u32)gb[1][z] << 28) | ((u32)ss[1][z] << 29)) : 0u;
-                    S.ring[d & (B2_RING - 1)][gl] = (u64)e[0] | ((u64)e[1] << 32);
+                        for(int z = 0; z < 2; z++) e[z] = kept[1][z] ? (b2_enc(stD[1][z]) | (b2_enc(stG[1][z]) << 8) | (b2_enc(stS[1][z]) << 16) | (1u << 24) | ((u32)ds[1][z] << 25) | ((u32)gb[1][z] << 28) | ((u32)ss[1][z] << 29)) : 0u;
+                        S.ring[d & (B2_RING - 1)][gl] = (u64)e[0] | ((u64)e[1] << 32);
+                    }
                 }
                 slab[(size_t)d * 64 + lane] = (u64)(rec[0][0] | (rec[0][1] << 11)) | ((u64)(rec[1][0] | (rec[1][1] << 11)) << 32);
                 // filtering (:1076-1102) and the next frontiers (:1104-1105)
@@ -338,11 +376,16 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
                         if(survive && (b ? iE : iM) >= reach) fail = 2;           // the next iteration would walk a step that is not staged
                     }
             }
-            WSYNC();                                    // (the ring: written by this iteration, read Delta iterations later by the same lane -- ordering only)
+            // (no fence here: a lane reads only its OWN column of the ring, Delta iterations after it wrote it -- program order --, and a fence would wait for the
+            //  iteration's store into the HBM slab: a microsecond per iteration, measured)
             fail = grp_max_i32<GW>(fail);
             if(fail) running = false;
         }
         WSYNC();
+        B2_T(1);
+#ifdef HLALA_B2_TIMING
+        tAcc[5] += d - 1; tAcc[6] += 1;
+#endif
         const int nCells = grp_sum_i32<GW>(cellsAcc), nEdges = grp_sum_i32<GW>(edgesAcc);
 
         // ---- end cell, backtrace, columns -- once for the call and once more for every linked duplicate (k_dp_items: same iterations, own random seed)
@@ -384,11 +427,24 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
             if(liveG && (first || newKey != endKey)) {
                 endKey = newKey; endJ = ej;
                 int ci = haveEnd ? (FWD ? ex - x0 : x0 - ex) : 0, cj = haveEnd ? ej : 0, cz = ez, cm = 0, n = 0, cols = 0, guard = 0;
+                // The pointers live in HBM: a dependent load per step would be a microsecond per step.  Most steps are diagonal -- (iteration - 2, lane - 1) --, so lane q of the
+                // group fetches the words of the q-th cell DOWN THE DIAGONAL from an anchor cell in one round trip; a step that stays on the diagonal takes its words from
+                // there, one that leaves it (a gap, the jump) moves the anchor.
+                int pfT = -1, pfL = -1; u64 pfM = 0, pfE = 0;
                 while(!(ci == 0 && cj == 0) && guard < 4 * C::MAXD && !fail) {
                     guard++;
                     const int tm = ci + cj, te = tm - Delta;
-                    const u64 wm = (tm >= 1 && tm <= dLast) ? slab[(size_t)tm * 64 + rowBase + cj] : 0ull;
-                    const u64 we = (haveJump && ci >= jb && te >= 1 && te <= dLast) ? slab[(size_t)te * 64 + rowBase + cj] : 0ull;
+                    int q = (pfT >= 0 && ((pfT - tm) & 1) == 0) ? (pfT - tm) >> 1 : -1;
+                    if(!(q >= 0 && q < GW && pfL - q == cj)) {
+                        pfT = tm; pfL = cj; q = 0;
+                        const int t_ = tm - 2 * gl, l_ = cj - gl, te_ = t_ - Delta;
+                        pfM = (l_ >= 0 && t_ >= 1 && t_ <= dLast) ? slab[(size_t)t_ * 64 + rowBase + l_] : 0ull;
+                        pfE = (haveJump && l_ >= 0 && te_ >= 1 && te_ <= dLast) ? slab[(size_t)te_ * 64 + rowBase + l_] : 0ull;
+                    }
+                    const u64 wmq = ((u64)(u32)__shfl((int)(pfM >> 32), rowBase + q) << 32) | (u64)(u32)__shfl((int)pfM, rowBase + q);
+                    const u64 weq = ((u64)(u32)__shfl((int)(pfE >> 32), rowBase + q) << 32) | (u64)(u32)__shfl((int)pfE, rowBase + q);
+                    const u64 wm = (tm >= 1 && tm <= dLast) ? wmq : 0ull;
+                    const u64 we = (haveJump && ci >= jb && te >= 1 && te <= dLast) ? weq : 0ull;
                     const u32 rm = (u32)(wm >> (11 * cz)) & 0x7FFu, re = (u32)(we >> (32 + 11 * cz)) & 0x7FFu;
                     const int bit = cm == 0 ? 1 : (cm == 1 ? 2 : 3);
                     const u32 r = ((rm & 1u) && ((rm >> bit) & 1u)) ? rm : ((re & 1u) ? re : rm);
@@ -415,6 +471,7 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
             }
             fail = grp_max_i32<GW>(fail);
             if(fail) liveG = false;
+            B2_T(2);
             const int endScore = nT >= 1 ? best : curMax;
             bool have = endKey >= 0 && liveG;
             // -- toVerboseSeedChain (VirtualNWUnique.cpp:28-29) and the columns, written into the chain's output row as k_dp does (dp_expand)
@@ -470,6 +527,7 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
             nx = __shfl(nx, rowBase);
             if(nx < 0) liveG = false; else item = nx;
             first = false;
+            B2_T(3);
         }
         // ---- a call that left the class goes to the general 16-lane list (with its linked duplicates: that kernel serves them)
         if(has && fail && gl == 0) {
@@ -479,6 +537,9 @@ __device__ __forceinline__ void band2_pass(const DevGraph& G, const DevBatch& B,
         }
         WSYNC();
     }
+#ifdef HLALA_B2_TIMING
+    if(lane == 0) { const int base = GW == 16 ? 0 : (GW == 32 ? 8 : 16); for(int i = 0; i < 7; i++) atomicAdd(&B.counters[8 + base + i], (u64)tAcc[i]); }
+#endif
 }
 
 template <int GW>

@@ -141,7 +141,11 @@ std::vector<std::string> split_list(const std::string& l)
 }
 
 // what several samples of one call share: the graph directory as the aligner and as the typer read it (read once, read-only afterwards)
-struct SharedGraph { std::shared_ptr<mapper::GraphDirectory> dir; std::unique_ptr<hla::HLATyper> typer; };
+struct SharedGraph { std::shared_ptr<mapper::GraphDirectory> dir; std::unique_ptr<hla::HLATyper> typer;
+                     // round 6: the device contexts of a call with several samples, one per listed device slot, created beside the first decodes and used by the samples in turn
+                     std::vector<hlala_ctx*> ctx; std::vector<std::string> ctxErr; std::vector<std::thread> ctxThreads; std::mutex ctxMu; std::vector<char> ctxJoined;
+                     hlala_ctx* context(size_t slot) { std::lock_guard<std::mutex> l(ctxMu); if(!ctxJoined[slot]) { if(ctxThreads[slot].joinable()) ctxThreads[slot].join(); ctxJoined[slot] = 1; } if(!ctxErr[slot].empty()) throw std::runtime_error(ctxErr[slot]); return ctx[slot]; }
+                     ~SharedGraph() { for(std::thread& t : ctxThreads) if(t.joinable()) t.join(); for(hlala_ctx* c : ctx) if(c) hlala_destroy(c); } };
 
 // Several samples in one call (round 6): who decodes and who holds a device when.  Within a sample the decode must be complete before the first batch is cut (a chain's
 // random seed is its number in read-NAME order, mapper/processBAM.cpp:2024-2039); ACROSS samples nothing forbids decoding sample k + 1 on the host threads while the
@@ -237,8 +241,9 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     turnGuard.begin_decode();
     std::cout << timestamp() << "Start seed extraction\n" << std::flush;
     const auto tOpen = std::chrono::steady_clock::now();
-    BAMprocessor.openBAM(BAM_remapped, longReads.length() != 0, batchPairs);
-    BAMprocessor.set_tail_pool(tailPool);
+    const bool borrowed = turn && shared && !shared->ctx.empty();          // several samples: the call's contexts, taken when this sample's turn at the device comes
+    BAMprocessor.openBAM(BAM_remapped, longReads.length() != 0, batchPairs, borrowed);
+    if(!borrowed) BAMprocessor.set_tail_pool(tailPool);
     turnGuard.end_decode();
     const double openSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tOpen).count();
     std::cout << timestamp() << "Seed extraction: " << BAMprocessor.n_units << " complete units, BAM decoded in " << BAMprocessor.decode_seconds << " s on " << BAMprocessor.decode_threads
@@ -246,7 +251,7 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
               << BAMprocessor.decode_phase_seconds[3] << ", name sort " << BAMprocessor.decode_phase_seconds[4] << ", layout (sizes and offsets; the windows are filled batch by batch beside the GPU) " << BAMprocessor.decode_phase_seconds[5] << "); beside it: contexts on " << BAMprocessor.n_devices()
               << " device(s) ready after " << BAMprocessor.context_seconds << " s (of which " << BAMprocessor.directory_wait_seconds << " s waiting for the graph directory: reference intervals after " << graphDirectory->intervals_seconds
               << " s -- the decoder starts with them --, graph read after " << graphDirectory->graph_seconds << " s, translation tables after " << graphDirectory->contigs_seconds << " s, typer files beside them); seed extraction in all " << openSeconds << " s\n" << std::flush;
-    if(!longReads.length()) std::cout << "Insert size: mean " << BAMprocessor.IS_mean << ", sd " << BAMprocessor.IS_sd << "\n" << std::flush;
+    if(!longReads.length() && !borrowed) std::cout << "Insert size: mean " << BAMprocessor.IS_mean << ", sd " << BAMprocessor.IS_sd << "\n" << std::flush;
     // the G-group table is looked up in the working directory, as the reference does (hla/HLATyper.cpp:4160-4166; HLA-LA.pl chdirs to the source directory)
     typerThread.join();
     if(!typerErr.empty()) throw std::runtime_error(typerErr);
@@ -261,6 +266,8 @@ int action_HLA_one(const std::map<std::string, std::string>& arguments, const st
     std::cout << timestamp() << "Alignment of " << BAMprocessor.n_units << (longReads.length() ? " reads" : " read pairs") << " in " << BAMprocessor.n_batches() << " GPU batch(es) on " << BAMprocessor.n_devices() << " device context(s)\n" << std::flush;
     double alignSeconds = 0; int64_t chainErrors = 0;
     turnGuard.begin_device();          // (the device may still be aligning the sample before this one; this sample's decode ran beside it)
+    if(borrowed) { BAMprocessor.use_contexts(std::vector<hlala_ctx*>(1, const_cast<SharedGraph*>(shared)->context(turn->slot))); BAMprocessor.set_tail_pool(tailPool);
+                   if(!longReads.length()) std::cout << "Insert size: mean " << BAMprocessor.IS_mean << ", sd " << BAMprocessor.IS_sd << "\n" << std::flush; }
     const auto tInfer = std::chrono::steady_clock::now();
     std::vector<hla::HLATyper::bestGuess> calls = HLAtyper.HLATypeInference(BAMprocessor, outputDirectory_for_HLA, loci, &alignSeconds, &chainErrors);
     const double inferSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tInfer).count();
@@ -329,6 +336,21 @@ int action_HLA(const std::map<std::string, std::string>& arguments)
     SampleSchedule sched;
     sched.nextOnDevice.assign(devices.size(), 0);
     { const int cpus = cpu_budget(); sched.decodeSlots = cpus / 16 > 0 ? cpus / 16 : 1; if(arguments.count("decodeSlots")) { const int v = std::atoi(arguments.at("decodeSlots").c_str()); if(v >= 1) sched.decodeSlots = v; } }
+    // one context per device slot for the whole call, created on threads of their own while the first samples decode (hlala_host.hpp: processBAM::use_contexts)
+    {
+        const bool longR = arguments.count("longReads") && arguments.at("longReads") != "0";
+        const uint32_t rngSeed = arguments.count("rngSeed") ? (uint32_t)std::strtoul(arguments.at("rngSeed").c_str(), nullptr, 10) : 0u;
+        shared.ctx.assign(devices.size(), nullptr); shared.ctxErr.assign(devices.size(), ""); shared.ctxJoined.assign(devices.size(), 0);
+        for(size_t d = 0; d < devices.size(); d++) shared.ctxThreads.emplace_back([&shared, &devices, d, longR, rngSeed]() {
+            try {
+                hlala_graph_desc gd; hlala_contigs_desc cd;
+                hlala_graph_file_desc(shared.dir->graph(), &gd);
+                if(hlala_contigs_file_desc(shared.dir->contigs(), &cd) != HLALA_OK) throw std::runtime_error(std::string("contigs: ") + hlala_loader_last_error());
+                hlala_params pr{200.0, 35.0, rngSeed, longR ? 1 : 0, longR ? 16384 : 384, 0};
+                if(hlala_create(&shared.ctx[d], devices[d], nullptr, &gd, &cd, &pr) != HLALA_OK) throw std::runtime_error(std::string("hlala_create: ") + hlala_last_error(nullptr));
+            } catch(const std::exception& e) { shared.ctxErr[d] = e.what(); }
+        });
+    }
     std::vector<SampleTurn> turns(samples.size());
     for(size_t i = 0; i < samples.size(); i++) turns[i] = SampleTurn(&sched, i, i % devices.size(), i / devices.size());
     const auto tSamples = std::chrono::steady_clock::now();

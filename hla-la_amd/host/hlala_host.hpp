@@ -320,13 +320,26 @@ public:
     processBAM(const std::shared_ptr<GraphDirectory>& gdir, int max_columns, uint32_t rng_seed, const std::vector<int>& devices, int threads)
         : gdir_(gdir), graphDir_(gdir->dir), extended_(gdir->extended), max_columns_(max_columns), rng_seed_(rng_seed), devices_(devices.empty() ? std::vector<int>(1, 0) : devices), threads_(threads),
           intervals_(gdir->intervals()) {}
-    ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); if(comm_) hlala_comm_destroy(comm_); for(hlala_ctx* c : ctxs_) if(c) hlala_destroy(c); if(seeds_) hlala_seed_batch_free(seeds_); }
+    ~processBAM() { for(hlala_batch* b : live_) if(b) hlala_batch_destroy(b); if(comm_) hlala_comm_destroy(comm_); if(owns_ctx_) for(hlala_ctx* c : ctxs_) if(c) hlala_destroy(c); if(seeds_) hlala_seed_batch_free(seeds_); }
     processBAM(const processBAM&) = delete;
     processBAM& operator=(const processBAM&) = delete;
 
     // initBAM + extractSeeds2 + estimateInsertSize (mapper/processBAM.cpp:1183-1402, 703-864, 1071-1165): seeds of all complete units, insert
     // size from the first 4000 of them (:1075) on the first device, then every context gets that insert size.  batchPairs = 0: one batch.
-    void openBAM(const std::string& BAM, bool longReads = false, int32_t batchPairs = 0)
+    // Round 6, several samples taking turns on a device (HLA-LA.cpp: SampleSchedule): the contexts belong to the CALL, not to the sample -- created once per device (flatten
+    // + upload + 12 GB of DP slabs: 2 s, and a dozen device-wide synchronisations that the sample before would feel in its kernels), their pools of device blocks warm from
+    // the sample before.  Such a sample opens its BAM with borrowed = true (decode only: nothing here touches a GPU while another sample may be using the contexts) and
+    // calls use_contexts() when its turn at the device has come: insert-size estimate (:1071-1165) on the first context, insert size and cleared read counters on all.
+    void use_contexts(const std::vector<hlala_ctx*>& ctxs)
+    {
+        if(ctxs.size() != devices_.size()) throw std::runtime_error("use_contexts: one context per listed device");
+        ctxs_ = ctxs; owns_ctx_ = false;
+        std::vector<int32_t> scratch((size_t)(n_levels > 1 ? n_levels - 1 : 1));
+        for(hlala_ctx* c : ctxs_) if(hlala_get_coverage(c, scratch.data(), 1) != HLALA_OK) throw std::runtime_error(std::string("hlala_get_coverage: ") + hlala_last_error(c));      // (the sample before has read its counters)
+        if(ctxs_.size() > 1 && !comm_ && hlala_comm_create(ctxs_.data(), (int)ctxs_.size(), &comm_) != HLALA_OK) throw std::runtime_error(std::string("hlala_comm_create: ") + hlala_comm_last_error(nullptr));
+        finish_open();
+    }
+    void openBAM(const std::string& BAM, bool longReads = false, int32_t batchPairs = 0, bool borrowed = false)
     {
         // the BAM is decoded (all host threads) while the contexts are created (one thread per device: each flattens and uploads the graph)
         const auto t0 = std::chrono::steady_clock::now();
@@ -336,7 +349,7 @@ public:
         //  everything they capture is declared before them)
         hlala_graph_desc gd; hlala_contigs_desc cd;
         hlala_params pr{200.0, 35.0, rng_seed_, longReads ? 1 : 0, max_columns_, 0};
-        ctxs_.assign(devices_.size(), nullptr);
+        if(!borrowed) ctxs_.assign(devices_.size(), nullptr);
         std::vector<std::string> errs(devices_.size());
         ThreadJoiner tdec, th;
         // (the decoder needs the reference intervals only: it starts while the graph directory may still be reading its graph and translation tables)
@@ -352,7 +365,7 @@ public:
         hlala_graph_file_desc(graph_, &gd);
         if(hlala_contigs_file_desc(contigs_, &cd) != HLALA_OK) throw std::runtime_error(std::string("contigs: ") + hlala_loader_last_error());
         n_levels = gd.n_levels;
-        for(size_t d = 0; d < devices_.size(); d++) th.start([&, d]() { if(hlala_create(&ctxs_[d], devices_[d], nullptr, &gd, &cd, &pr) != HLALA_OK) errs[d] = std::string("hlala_create: ") + hlala_last_error(nullptr); });
+        for(size_t d = 0; d < devices_.size() && !borrowed; d++) th.start([&, d]() { if(hlala_create(&ctxs_[d], devices_[d], nullptr, &gd, &cd, &pr) != HLALA_OK) errs[d] = std::string("hlala_create: ") + hlala_last_error(nullptr); });
         th.join();
         context_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         tdec.join();
@@ -360,9 +373,17 @@ public:
         for(const std::string& e : errs) if(!e.empty()) throw std::runtime_error(e);
         // several devices: the merge steps of the sample's results that live on the devices (the per-level read counters; the per-pair records for callers that want
         // them) go over RCCL between the contexts (include/hlala_gpu.h: hlala_comm_*; contexts that share a device are served by copies)
-        if(ctxs_.size() > 1 && hlala_comm_create(ctxs_.data(), (int)ctxs_.size(), &comm_) != HLALA_OK) throw std::runtime_error(std::string("hlala_comm_create: ") + hlala_comm_last_error(nullptr));
+        if(!borrowed && ctxs_.size() > 1 && hlala_comm_create(ctxs_.data(), (int)ctxs_.size(), &comm_) != HLALA_OK) throw std::runtime_error(std::string("hlala_comm_create: ") + hlala_comm_last_error(nullptr));
         hlala_seed_batch_timing(seeds_, decode_phase_seconds, &decode_threads);
-        n_units = hlala_seed_batch_units(seeds_); longReadsMode = longReads;
+        n_units = hlala_seed_batch_units(seeds_); longReadsMode = longReads; BAM_ = BAM;
+        batchPairs_ = batchPairs > 0 ? batchPairs : (n_units > 0 ? (n_units > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)n_units) : 1);
+        live_.assign((size_t)n_batches(), nullptr); aligned_.assign((size_t)n_batches(), 0);
+        if(!borrowed) finish_open();
+    }
+    // what openBAM does on the contexts once they are this sample's: page-locking mode, insert size
+    void finish_open()
+    {
+        const bool longReads = longReadsMode; const std::string& BAM = BAM_;
         // page-locked: batch uploads are plain DMA (a refusal only costs speed).  Window by window, when a window is handed out (filled, then locked): the 0.2 s that
         // locking the whole sample took lay between the decode and the first batch; HLALA_PIN_WHOLE=1 locks everything here as before round 4
         (void)hlala_seed_batch_pin(seeds_, std::getenv("HLALA_PIN_WHOLE") ? 1 : 2);
@@ -374,8 +395,6 @@ public:
             IS_mean = is.mean; IS_sd = is.sd;
             for(hlala_ctx* c : ctxs_) if(hlala_set_insert_size(c, is.mean, is.sd) != HLALA_OK) throw std::runtime_error(std::string("hlala_set_insert_size: ") + hlala_last_error(c));
         }
-        batchPairs_ = batchPairs > 0 ? batchPairs : (n_units > 0 ? (n_units > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)n_units) : 1);
-        live_.assign((size_t)n_batches(), nullptr); aligned_.assign((size_t)n_batches(), 0);
     }
     // seconds the decoder has spent laying the sample out so far: sizes and offsets at decode time, then the fill of every window handed out since
     // (hlala_seed_batch_window fills what it hands out, beside the GPU's work on the batch before)
@@ -440,7 +459,7 @@ private:
     std::shared_ptr<GraphDirectory> gdir_;
     std::string graphDir_; bool extended_; int max_columns_; uint32_t rng_seed_; std::vector<int> devices_; int threads_;
     hlala_graph_file* graph_ = nullptr; hlala_contigs_file* contigs_ = nullptr; const std::vector<hlala_bam_interval>& intervals_;      // owned by gdir_
-    hlala_seed_batch* seeds_ = nullptr; std::vector<hlala_ctx*> ctxs_; hlala_comm* comm_ = nullptr; int tail_pool_ = 1;
+    hlala_seed_batch* seeds_ = nullptr; std::vector<hlala_ctx*> ctxs_; hlala_comm* comm_ = nullptr; int tail_pool_ = 1; bool owns_ctx_ = true; std::string BAM_;
     int32_t batchPairs_ = 1; std::vector<hlala_batch*> live_; std::vector<char> aligned_;       // aligned_[bi]: hlala_align_batch has been queued for live_[bi]
 };
 }  // namespace mapper

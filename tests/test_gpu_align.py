@@ -387,6 +387,40 @@ def test_band_kernel_and_its_fail_over_are_bit_exact(pkg, oracle, monkeypatch, e
             assert tot_failed <= 0.01 * tot_band             # ... and is not the common path
 
 
+BAND2_WORLDS = [("k1, large gaps", dict(seed=51, G=12000, k=1, n_largegap=3, gap_frac=0.2), dict(seed=61)),
+                ("k3, gap-heavy", dict(seed=52, G=12000, k=3, n_mut=8, mut_density=0.01, gap_frac=0.6), dict(seed=62, clip_max=48, p_no_clip=0.0)),
+                ("k5, identical copies", dict(seed=53, G=10000, k=5, n_mut=4, extra_identical=2), dict(seed=63, indel_read_frac=0.3)),
+                ("k2, long clips", dict(seed=54, G=14000, k=2, n_mut=2, mut_density=0.01), dict(seed=64, clip_max=60, p_no_clip=0.0))]
+
+
+@pytest.mark.parametrize("env", [dict(HLALA_DP_BAND2="1"), dict(HLALA_DP_BAND2="1", HLALA_DP_BAND2_MARGIN="0"), dict(HLALA_DP_BAND2="1", HLALA_DP_BAND2_MAXJ="15", HLALA_DP_BAND="0")],
+                         ids=["band2", "band2-tight-margin", "band2-16-lanes-no-band"])
+def test_two_track_band_kernels_are_bit_exact(pkg, oracle, monkeypatch, env):
+    """Round 6, kernel_dp_band2.hip (switched on with HLALA_DP_BAND2=1; not part of the default path: it is slower than the classes it relieves): extension DP calls
+    beside gap stretches -- one or two nodes per level, one gap-path jump -- with two bands of two tracks in registers: the early band a jump creates
+    (extensionAligner.cpp:757-786), the merge when the main band meets its cells again (:951-979), the patience resets of overwritten entries and the diff rule
+    through stored pointers (:1007-1062).  Gap-heavy stand-in worlds against the oracle: columns, DP scores, iteration / cell counters; with a track run that just
+    covers the read (most calls then walk to the end of their staged steps and fail over) and with the 16-lane instantiation alone and the linear band kernels off (it
+    then takes their calls too).  The algorithm's CPU model: tools/band2/band2_model.cpp (tests/test_band2_model.py)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tot2 = tot2f = tot_calls = 0
+    for name, wk, bk in BAND2_WORLDS:
+        w = synth.make_world(**wk)
+        b = synth.make_batch(w, 400, **bk)
+        exp, gb, ctx = run_both(pkg, oracle, w, b)
+        compare_chains(gb.chains(1), exp["ext"], b["n_chains"], label="stage B (%s)" % name)
+        assert_pairs_equal(gb.pairs(), exp["pairs"])
+        st = gb.stats()
+        assert st.n_errors == 0
+        assert (st.n_dp_calls, st.n_dp_iterations, st.n_dp_cells) == tuple(int(x) for x in exp["stats"][:3]), name
+        tot2 += st.n_dp_band2; tot2f += st.n_dp_band2_failed; tot_calls += st.n_dp_calls
+    assert tot2 > 0.1 * tot_calls                            # these worlds are full of gap stretches: the two-track kernels take a good part of the calls
+    assert tot2f < tot2
+    if env.get("HLALA_DP_BAND2_MARGIN") == "0":
+        assert tot2f > 0.02 * tot2                           # the fail-over path is exercised
+
+
 def test_stats_of_a_batch_that_was_only_uploaded(pkg):
     """hlala_batch_create allocates no outputs (the first stage call does): hlala_batch_get_stats and the debug counters of a batch that was only uploaded -- what
     the host program's walk holds one step ahead -- return zeros instead of reading counters that do not exist yet."""

@@ -30,6 +30,10 @@ print(" stages ms: project %.2f extend %.2f pair %.2f -> %.0f pairs/s (one batch
 buf = (C.c_ulonglong * 32)()
 ctx.lib.hlala_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_ulonglong)]
 ctx.lib.hlala_debug_counters(ctx.h, gb.b, buf)
+for nm, o in (("16", 8), ("32", 16), ("64", 24)):
+    t2 = np.array(list(buf)[o:o + 7], dtype=np.float64)
+    if os.environ.get("B2_TIMING") and t2[6] > 0:
+        print(" two-track band kernel (%s lanes per call), cycles per task of a wavefront (-DHLALA_B2_TIMING): draw + stage %.0f, iterations %.0f (%.1f per task, %.0f cycles each), end cell + backtrace %.0f, columns + outputs %.0f, between tasks %.0f | %d tasks" % (nm, t2[0] / t2[6], t2[1] / t2[6], t2[5] / t2[6], t2[1] / max(1, t2[5]), t2[2] / t2[6], t2[3] / t2[6], t2[4] / t2[6], int(t2[6])))
 t = np.array(list(buf)[16:23], dtype=np.float64)
 if t[6] > 0:
     print(" band kernel (16 lanes), cycles per task of a wavefront (-DHLALA_BAND_TIMING): draw + stage %.0f, iterations %.0f (%.1f per task, %.0f cycles each), end cell + backtrace %.0f, columns + outputs %.0f, between tasks %.0f | %d tasks (all three kernels)" % (t[0] / t[6], t[1] / t[6], t[5] / t[6], t[1] / max(1, t[5]), t[2] / t[6], t[3] / t[6], t[4] / t[6], int(t[6])))
