@@ -204,7 +204,7 @@ def main():
                                                                              "(1 = every alignment runs its own tail, as in rounds 2-5); the loops keep k alignments queued ahead and k + 1 batches' outputs live")
     ap.add_argument("--resident-lag", type=int, default=0, help="resident loop with a tail pool: the export of step i follows the alignment of step i + lag (default: tail pool + 1); lag + 1 resident batches")
     ap.add_argument("--long-reads-batch", type=int, default=50000, help="reads per batch of the long-read record (16 384-column rows: 17 GB of column arrays for 50 000 reads; five batches of 10 000 take 2.5 times as long -- every batch ends on its slowest wavefronts)")
-    ap.add_argument("--long-reads-check", type=int, default=256, help="reads of the long-read record compared with the CPU oracle after the clock has stopped (0 = none)")
+    ap.add_argument("--long-reads-check", type=int, default=2048, help="reads of the long-read record compared with the CPU oracle after the clock has stopped (0 = none)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -439,7 +439,7 @@ def main():
         first_class_ms = ms_band + cls_ms[0]
         khash = kernel_source_hash()
         traffic, traffic_note, secondary = None, "no PMC pass on file for this build", {}
-        tfile = next((f for f in (os.path.join(ROOT, "profiles", t + "_traffic.json") for t in ("r05", "r04", "r03", "r02")) if os.path.exists(f)), "")
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", t + "_traffic.json") for t in ("r06", "r05", "r04", "r03", "r02")) if os.path.exists(f)), "")
         tname = os.path.relpath(tfile, ROOT) if tfile else ""
         if tfile:
             try:
@@ -818,12 +818,12 @@ def long_reads(args, P, synth, w):
         proj_s = float(sum(s_.ms_project for s_ in sts)) * 1e-3
         ach = b_read * n / max(proj_s, 1e-9) / 1e9
         roof = {"bound": "latency", "bound_note": "the level loop of one wavefront per read (waits most of its cycles); achieved / peak / frac are the HBM figures the metric asks for", "kernel": "k_project_chains<ProjLdsLong>", "kernel_ms_sum": proj_s * 1e3, "algorithmic_bytes_per_read": b_read, "columns_per_read": cols, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                "frac": ach / 8000.0, "traffic": None, "note": "HIP events of the batches' projection stage; the measured HBM traffic and the SQ counters of the kernel: profiles/r05_long_*"}
-        tl = os.path.join(ROOT, "profiles", "r05_long_traffic.json")
-        if os.path.exists(tl):
+                "frac": ach / 8000.0, "traffic": None, "note": "HIP events of the batches' projection stage; the measured HBM traffic and the SQ counters of the kernel: profiles/r0N_long_*"}
+        tl = next((f for f in (os.path.join(ROOT, "profiles", t + "_long_traffic.json") for t in ("r06", "r05")) if os.path.exists(f)), "")
+        if tl:
             try:
                 tj = json.load(open(tl)); roof["traffic_per_read"] = tj.get("hbm_bytes_per_read"); roof["traffic"] = tj.get("hbm_bytes_per_read", 0) * n / max(1, len(gbs)); roof["secondary"] = tj.get("secondary")
-                roof["traffic_source"] = "profiles/r05_long_traffic.json (kernel sources %s)" % tj.get("kernel_source_hash")
+                roof["traffic_source"] = "%s (kernel sources %s)" % (os.path.relpath(tl, ROOT), tj.get("kernel_source_hash"))
             except Exception:
                 pass
         return {"reads": n, "bases": bases, "parity_checked": checked, "reads_per_batch": per, "roofline": roof, "mean_read_length": bases / max(1, n), "reads_per_s": n / dt, "bases_per_s": bases / dt, "seconds": dt, "batches": len(gbs), "reads_ok": ok,

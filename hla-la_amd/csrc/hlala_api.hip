@@ -68,6 +68,7 @@ struct hlala_ctx {
     std::unordered_map<void*, size_t> block_bytes;
     std::multimap<size_t, void*> pool;
     size_t pool_bytes = 0;
+    size_t pool_cap = (size_t)176 << 30;      // bytes the pool may keep parked (HLALA_POOL_CAP_GB: several processes sharing one device, e.g. the N-rank dry runs on a one-GPU box)
     std::mutex pool_mu;              // the pool and block_bytes: this context's thread, and any thread that meets an out-of-memory error on the device (device_malloc_retry)
     std::set<struct hlala_batch*> batches;     // live batches: detached (not dangling) if the context is destroyed first
     // DP scratch slabs: one per DpTiny group (4 per wave), one per DpSmall / DpLarge wave (same pool, same layout size)
@@ -253,7 +254,7 @@ static void pool_release(hlala_ctx* c, void* p)
     std::lock_guard<std::mutex> g(c->pool_mu);
     auto it = c->block_bytes.find(p);
     if(it == c->block_bytes.end()) { (void)hipFree(p); return; }
-    if(c->pool_bytes + it->second > ((size_t)176 << 30)) { c->block_bytes.erase(it); (void)hipFree(p); return; }      // keep at most 176 GB parked (three 1 M-pair batches' arrays: a caller with three sets of outputs live gives them all back between two runs)
+    if(c->pool_bytes + it->second > c->pool_cap) { c->block_bytes.erase(it); (void)hipFree(p); return; }      // keep at most 176 GB parked (three 1 M-pair batches' arrays: a caller with three sets of outputs live gives them all back between two runs)
     c->pool.emplace(it->second, p); c->pool_bytes += it->second;
 }
 
@@ -476,6 +477,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_DP_BAND_RISKY")) c->band_risky = atoi(e) != 0;
     if(const char* e = getenv("HLALA_ROWS_ALL")) c->rows_all = atoi(e) != 0;
     if(const char* e = getenv("HLALA_SIDE_AFTER_PAIR")) c->side_after_pair = atoi(e) != 0;
+    if(const char* e = getenv("HLALA_POOL_CAP_GB")) { const long g = atol(e); if(g >= 0 && g <= 1024) c->pool_cap = (size_t)g << 30; }
     if(const char* e = getenv("HLALA_TAIL_POOL")) { const int k = atoi(e); if(k >= 1 && k <= DP_POOL_MAX) c->tail_pool_k = k; }      // (experiments and the parity suite: hlala_set_tail_pool without touching the caller)
     if(const char* e = getenv("HLALA_DP_BAND_MARGIN")) { const int m = atoi(e); if(m >= 0 && m <= 24) c->band_margin = m; }
     // The two-track band kernels are bit-exact and SLOWER than the hashed-frontier classes they would relieve (profiles/r06_experiments.txt 6: 1 000 vector instructions

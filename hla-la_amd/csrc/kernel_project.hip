@@ -188,6 +188,10 @@ struct FromLab { int from; unsigned char lab; };
 // colInfo, chunked form: bits 25-29 = DevGraph::level_fast of the level (25-26: 1 = edge-parallel in one slice of 64 in-edges, 2 = in several, 0 = node by node; 27-29: largest in-degree - 1)
 #define PJ_FAIL(code) do { if(P.err == 0) P.err = (code); } while(0)
 #define PJ_T(i) do { if(B.dbg) tPh[i] = clock64(); } while(0)      // HLALA_DEBUG phase clocks -> counters[16..23]
+// Ordering between the lanes of the wavefront for LDS ONLY: the LDS instructions of a wavefront execute in order, so waiting for the LDS counter and keeping the compiler from
+// moving accesses across is enough.  WSYNC() is a release / acquire fence and also waits for every store to HBM in flight -- a microsecond -- which the level loops of
+// the long-read layout paid once per level (their stores of back pointers into the slab are not read before the backtrace): 10 000 levels, 5 k cycles each (round 6).
+#define LSYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while(0)
 #define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
 
 template <class PL>
@@ -661,12 +665,18 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             int mx = 0;
             for(int sg = lane; sg < nSeg; sg += 64) mx = max(mx, (int)P.segStart[sg + 1] - (int)P.segStart[sg]);
             mx = wave_max_i32(mx);
-            par = (defCount == nDef) && (mx <= PROJ_SEGMAX);
+            // Long reads (round 6): a read that crosses a gene window has ONE segment of thousands of levels between its hundreds of short ones, and used to take the
+            // column-sequential form for all of its 10 000 levels (the slowest wavefronts of a batch, 50 M cycles each).  Its short segments are solved one per lane as
+            // in every other read; the long ones afterwards by the whole wavefront, level by level, the lanes on the level's nodes and the scores of the last level in
+            // LDS -- into the same per-node choices (P.sChoice), so the backtrace below is the segment-parallel one.
+            const bool hybrid = PL::LONG && mx > PROJ_SEGMAX;
+            par = (defCount == nDef) && (mx <= PROJ_SEGMAX || PL::LONG);
             if(par) {
                 const int nbR = nb - nodeBase;
                 int fail = 0;
                 for(int sg = lane; sg < nSeg; sg += 64) {
                     const int a = P.segStart[sg], b = P.segStart[sg + 1];
+                    if(hybrid && b - a > PROJ_SEGMAX) continue;
                     for(int i = a; i < b && !fail; i++) {
                         const u32 ci = P.colInfo[i];
                         const unsigned char sc = (unsigned char)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
@@ -688,6 +698,40 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                             if(best >= 0) anyReached = 1;
                         }
                         if(!anyReached) fail = 1;
+                    }
+                }
+                if(PL::LONG && hybrid && !__ballot(fail)) {
+                    for(int sg = 0; sg < nSeg && !fail; sg++) {
+                        const int a = uni(P.segStart[sg]), b = uni(P.segStart[sg + 1]);
+                        if(b - a <= PROJ_SEGMAX) continue;
+                        int rowQ = 0;
+                        for(int i = a; i < b; i++) {
+                            const u32 ci = P.colInfo[i];
+                            const unsigned char sc = (unsigned char)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
+                            const int t0 = P.sLev[i + 1], tm = (int)P.sLev[i + 2] - t0, fb = P.sLev[i];
+                            if(tm > PROJ_NODES) { fail = 1; break; }                          // (wider than the score rows: the column-sequential form decides)
+                            int anyReached = 0;
+                            for(int z = lane; z < tm; z += 64) {
+                                const int t = t0 + z;
+                                int best = -1, bestE = 0xFFFF;
+                                const int e0 = P.sIn[t - nbR], e1 = P.sIn[t - nbR + 1];
+                                for(int e = e0; e < e1; e++) {                               // in-edges in creation order: first maximum = smallest edge
+                                    const int sp = (i == a) ? 0 : (int)P.Srow[rowQ][(int)P.sFrom[e] - fb];
+                                    if(sp < 0) continue;
+                                    const unsigned char lab = P.sLab[e];
+                                    if(seedIsMatch && lab != sc) continue;                    // :2803-2809
+                                    const int cand = sp + (lab == sc ? 1 : 0);
+                                    if(cand > best) { best = cand; bestE = e; }
+                                }
+                                P.Srow[1 - rowQ][z] = (short)best;
+                                Sflat[t] = (short)best;
+                                P.sChoice[t - nbR] = (unsigned short)bestE;
+                                if(best >= 0) anyReached = 1;
+                            }
+                            if(!__ballot(anyReached)) { fail = 1; break; }
+                            rowQ = 1 - rowQ;
+                            LSYNC();
+                        }
                     }
                 }
                 if(__ballot(fail)) par = false;                                               // let the sequential form raise the reference's assert
@@ -778,7 +822,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         }
                         if(!__ballot(anyReached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); break; }
                         rowP = 1 - rowP;
-                        WSYNC();
+                        LSYNC();
                         a++;
                         continue;
                     }
@@ -822,8 +866,9 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         }
                         if(!__ballot(anyReached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); stop = true; break; }  // assert(seedChain_backtrack_*.size() > 0)
                         rowP = 1 - rowP;
-                        WSYNC();
+                        LSYNC();
                     }
+                    WSYNC();
                     } else {
                     // The levels of the chunk, one after the other, with the lanes on the level's IN-EDGES (DevGraph::in_rec, staged above), not on its nodes.
                     // What bounds this loop is the latency of ONE wave per level (the time per level does not depend on how many waves share the CU:
@@ -933,8 +978,9 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         }
                         if(!__ballot(reached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); stop = true; break; }  // assert(seedChain_backtrack_*.size() > 0)
                         rowP = 1 - rowP;
-                        WSYNC();
+                        LSYNC();
                     }
+                    WSYNC();
                     }
                     if(B.dbg) { tSub[0] += tC1 - tC0; tSub[1] += clock64() - tC1; tSub[2]++; tSub[3] += cnt; }
                     if(stop) break;
@@ -969,7 +1015,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                     }
                     if(!__ballot(anyReached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); break; }  // assert(seedChain_backtrack_*.size() > 0)
                     rowP = 1 - rowP;
-                    WSYNC();
+                    LSYNC();                      // (the score rows are LDS; the back pointers go to HBM and are not read before the backtrace)
                 }
             }
             WSYNC();
@@ -1245,8 +1291,9 @@ __global__ __launch_bounds__(64, 6) void k_rethread_chains(const DevGraph* __res
                     }
                     if(!__ballot(reached)) { err = HLALA_CHAIN_ERR_INPUT; break; }          // assert(seedChain_backtrack_*.size() > 0)
                     rowP = 1 - rowP;
-                    WSYNC();
+                    LSYNC();          // (round 6: the lanes exchange scores through LDS and lane permutes only; WSYNC() also waited for the level's back-pointer stores to reach HBM)
                 }
+                WSYNC();
                 a = b + 1;
             }
             // ---- backtrace (:2838-3007)
