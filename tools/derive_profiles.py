@@ -15,7 +15,7 @@ import bench  # noqa: E402
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 NAMES = (("k_dp_band<16>", "k_dp_band<16>"), ("k_dp_band<32>", "k_dp_band<32>"), ("k_dp_band<64>", "k_dp_band<64>"), ("DpTinyJF", "k_dp<DpTinyJF, 0>"), ("DpTiny", "k_dp<DpTiny, 0>"), ("DpMid", "k_dp<DpMid, 1>"), ("DpSmall", "k_dp<DpSmall, 2>"), ("DpWide", "k_dp<DpWide, 3>"), ("DpBroad", "k_dp<DpBroad, 4>"), ("DpLarge", "k_dp<DpLarge, 5>"), ("DpHuge", "k_dp<DpHuge, 6>"),
-         ("k_stitch", "k_stitch_chains"), ("k_project", "k_project_chains"), ("k_rethread", "k_rethread_chains"), ("k_pair_chains", "k_pair_chains"), ("k_dp_items", "k_dp_items"), ("k_filter", "k_filter_chains"))
+         ("k_stitch", "k_stitch_chains"), ("k_project", "k_project_chains"), ("k_rethread", "k_rethread_chains"), ("k_pair_chains", "k_pair_chains"), ("k_pair_multi", "k_pair_multi"), ("k_dp_band2", "k_dp_band2"), ("k_dp_items", "k_dp_items"), ("k_filter", "k_filter_chains"))
 
 
 def label(k):
