@@ -76,6 +76,8 @@ struct DevBatch {
     int* chain_bucket;              // [n_chains] position bucket = first level >> order_shift (the last bucket: chains filtered out)
     int* order_hist;                // [order_nb + 1] bucket counts -> bucket starts -> scatter cursors
     int order_shift, order_nb;
+    int order_cost;                 // long-read layout: buckets by DESCENDING size of the chain's window (nodes between its first and last level) instead of position -- the reads that
+                                    // cross a gene window take a hundred times a backbone read's time and must not be the last ones a wavefront draws (kernel_project.hip: k_filter_chains)
     // ---- column rows only for the chains that passed the filters (round 5): two thirds of a batch's chains end at k_filter_chains (strand, duplicate coordinates,
     //      processBAM.cpp:3200-3240) and never hold a column.  The filter and the position order run when the batch is CREATED (they read inputs only), the count of the
     //      ordered chains comes back with the upload's synchronisation, and the column arrays (seed_* / ext_*: 20 bytes per column slot) are sized by it: row k belongs to

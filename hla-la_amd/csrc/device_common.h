@@ -73,6 +73,23 @@ constexpr int DP_MAX_PARALLEL = 127; // parallel edges (or gap paths) between ON
 constexpr int DP_NEG       = -30000; // minusInfinity (-DBL_MAX in the reference, extensionAligner.cpp:363)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// A pointer that is KNOWN to point into HBM.  A pointer the compiler cannot trace back to a kernel argument -- one read from a descriptor struct or from LDS -- is
+// 'generic': every access through it is a FLAT instruction, which goes to the LDS queue as well as to the vector-memory path, counts in both wait counters and can
+// only be waited for with 'everything outstanding' (round 6: 286 of the 310 loads of the long-read projection were flat_load).  glob() casts to the global address
+// space (the result is a pointer TYPE of that address space: `auto`, not `T*`, receives it); GPtr<T> is a pointer member whose accesses are global.
+#define HLALA_AS_GLOBAL __attribute__((address_space(1)))
+template <class T> struct GPtr {
+    typedef HLALA_AS_GLOBAL T GT;
+    T* p;
+    __device__ __forceinline__ GPtr& operator=(T* q) { p = q; return *this; }
+    __device__ __forceinline__ GT* g() const { return (GT*)p; }
+    __device__ __forceinline__ GT& operator[](int i) const { return g()[i]; }
+    __device__ __forceinline__ GT& operator[](unsigned i) const { return g()[i]; }
+    __device__ __forceinline__ GT& operator[](long long i) const { return g()[i]; }
+    __device__ __forceinline__ GT& operator[](size_t i) const { return g()[i]; }
+    __device__ __forceinline__ operator GT*() const { return g(); }
+};
+template <class T> __device__ __forceinline__ HLALA_AS_GLOBAL T* glob(T* p) { return (HLALA_AS_GLOBAL T*)p; }
 // All kernels run ONE wavefront per block, so a block barrier is only a memory-ordering point between lanes of the
 // same wave.  __syncthreads() is not used: hipcc (ROCm 7.2) miscompiled persistent work loops that `continue` / `break`
 // around it (kernels never terminated); a wavefront-scope fence + scheduling barrier gives the ordering without the

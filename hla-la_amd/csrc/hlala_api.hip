@@ -87,8 +87,10 @@ struct hlala_ctx {
     char* rethread_slabs = nullptr; size_t rethread_slab_bytes = 0; int rethread_grid = 0;      // k_rethread_chains: back pointers of one chain per wave (short reads; HLALA_RETHREAD=0 turns the kernel off)
     double* pair_scratch = nullptr;   // [2 * pair_grid][PAIR_COMB]: combination tables of the rare pairs with more than PAIR_COMB_LDS combinations (main- and side-stream pass)
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
+    int proj_long_stagger = 0;              // long-read projection: wavefront w starts (w mod 64) x this many cycles after the kernel does (HLALA_PROJ_LONG_STAGGER; k_project_chains)
+    int order_cost = 0;                     // long-read layout: heaviest windows first (batch.h: order_cost; HLALA_LONG_ORDER=0: position order)
     int order_shift = 8, order_nb = 0;      // position buckets of a batch's chains (kernel_order.hip); order_nb 0: input order (HLALA_LOCALITY=0)
-    int* dbg_host = nullptr;      // non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
+    int* dbg_host = nullptr;      // (device memory) non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
     // per-pair post-processing: coverage counters [L-1] and gene intervals
     int* d_cov = nullptr; int n_cov = 0; int* d_gene_first = nullptr; int* d_gene_last = nullptr; int n_genes = 0;
     // reads kept for the k-mer questions (hlala_kmer_keep_reads): one chunk per call, blocks of the pool
@@ -545,7 +547,11 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     // position buckets: a few hundred levels each, at most 16 384 of them (the scan is one block)
     { const char* e = getenv("HLALA_LOCALITY");
       if(!(e && atoi(e) == 0)) { int sh = 8; if(e && atoi(e) >= 2 && atoi(e) <= 20) sh = atoi(e); while((F.L >> sh) + 2 > 16384) sh++; c->order_shift = sh; c->order_nb = (F.L >> sh) + 2; } }
-    if(getenv("HLALA_DEBUG")) { if(hipHostMalloc((void**)&c->dbg_host, 8192 * sizeof(int), hipHostMallocMapped) != hipSuccess) c->dbg_host = nullptr; else memset(c->dbg_host, 0, 8192 * sizeof(int)); }
+    if(const char* e = getenv("HLALA_PROJ_LONG_STAGGER")) c->proj_long_stagger = atoi(e);
+    if(c->proj_long_slabs && c->order_nb > 0) { const char* e = getenv("HLALA_LONG_ORDER"); c->order_cost = (e && atoi(e) == 0) ? 0 : 1; }
+    // (the debug buffer is DEVICE memory since round 6: host-mapped, every counter a kernel added to it was an atomic over PCIe -- the wavefronts of the long-read projection queued
+    //  behind each other's, and the clocks they were meant to read showed that queue)
+    if(getenv("HLALA_DEBUG")) { if(hipMalloc((void**)&c->dbg_host, 8192 * sizeof(int)) != hipSuccess) c->dbg_host = nullptr; else { (void)hipMemset(c->dbg_host, 0, 8192 * sizeof(int)); c->allocs.push_back(c->dbg_host); } }
     if(hipEventCreateWithFlags(&c->evSideTail, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
     if(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); }
     { int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);       // (numerically greatest = lowest priority)
@@ -647,7 +653,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     B.dp_band_risky = c->band_risky ? 1 : 0;
     AL(dp_blk, (size_t)DPL_N * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
     if(!b->prepared) {
-        B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb;
+        B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb; B.order_cost = c->order_cost;
         if(c->order_nb > 0 && !B.from_seeds && nc > 0) { AL(chain_order, nc, false); AL(chain_bucket, nc, false); AL(order_hist, (size_t)c->order_nb + 1, false); }
     }
     B.dbg = c->dbg_host;
@@ -741,7 +747,7 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
         AL(seed_status, (size_t)nc, true); AL(seed_ncols, (size_t)nc, true);
         AL(chain_order, (size_t)nc, false); AL(chain_bucket, (size_t)nc, false); AL(chain_row, (size_t)nc, false); AL(order_hist, (size_t)c->order_nb + 1, true);
 #undef AL
-        B.order_shift = c->order_shift; B.order_nb = c->order_nb;
+        B.order_shift = c->order_shift; B.order_nb = c->order_nb; B.order_cost = c->order_cost;
         b->prepared = true;
     }
     rc = dev_upload(c, b->allocs, &b->B, 1, &b->dB); if(rc) return fail(rc);
@@ -882,7 +888,7 @@ int hlala_project_chains(hlala_ctx* c, hlala_batch* b)
         int grid = B.n_chains < c->proj_grid ? B.n_chains : c->proj_grid;
         if(c->proj_long_slabs)
             hipLaunchKernelGGL((k_project_chains<ProjLdsLong>), dim3(grid), dim3(64), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
-                               c->proj_slabs, c->proj_slab_bytes, c->proj_long_slabs, c->proj_long_slab_bytes, 0);
+                               c->proj_slabs, c->proj_slab_bytes, c->proj_long_slabs, c->proj_long_slab_bytes, c->proj_long_stagger);      // (long layout: the last argument staggers the wavefronts' starts)
         else
             if(c->params.max_columns <= PROJ_CAP_SHORT)
                 hipLaunchKernelGGL((k_project_chains<ProjLdsShort>), dim3(grid), dim3(64), 0, c->active, c->dG, b->dB, c->d_contig_off, c->d_contig_seq, c->d_contig_level,
@@ -1788,14 +1794,14 @@ __global__ void k_kat_exp(int n, const double* x, double* y)
 }
 }  // namespace hlala
 
-// HLALA_DEBUG=1: the host-mapped debug buffer of the context (8192 ints); clear != 0 zeroes it afterwards
+// HLALA_DEBUG=1: the debug buffer of the context (8192 ints in device memory, copied out here); clear != 0 zeroes it afterwards
 extern "C" int hlala_debug_buffer(hlala_ctx* c, int* out8192, int clear)
 {
     if(!c || !c->dbg_host) return HLALA_E_STATE;
     DEV_GUARD(c);
     HIP_TRY(c, hipStreamSynchronize(c->active));
-    if(out8192) memcpy(out8192, c->dbg_host, 8192 * sizeof(int));
-    if(clear) memset(c->dbg_host, 0, 8192 * sizeof(int));
+    if(out8192) HIP_TRY(c, hipMemcpy(out8192, c->dbg_host, 8192 * sizeof(int), hipMemcpyDeviceToHost));
+    if(clear) HIP_TRY(c, hipMemset(c->dbg_host, 0, 8192 * sizeof(int)));
     return HLALA_OK;
 }
 

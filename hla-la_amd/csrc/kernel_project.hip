@@ -67,19 +67,26 @@ typedef ProjLdsT<PROJ_CAP_SHORT, 416, 544> ProjLdsShort;
 constexpr int PROJL_CAP = 16384;    // alignment columns (>= params.max_columns)
 constexpr int PROJL_SN  = 49152;    // nodes of the level window (16-bit offsets: < 65536)
 constexpr int PROJL_SE  = 57344;    // in-edges of the level window
+constexpr int PROJL_LONGSEG = 32;   // long segments (more than PROJ_SEGMAX levels without a cut) of one read that are solved level by level beside its short ones; a read with more takes that form as a whole
 struct __align__(16) ProjLdsLong {
     static constexpr int CAP = PROJL_CAP, SN = PROJL_SN, SE = PROJL_SE; static constexpr bool LONG = true;
     typedef int LvT;                        // absolute levels, -1 = none
     static constexpr int CE = PROJL_SE;
-    int* lvl[2];
-    unsigned char* g[2]; unsigned char* s[2];
+    GPtr<int> lvl[2];                       // (GPtr: device_common.h -- accesses are global_load / global_store, not flat)
+    GPtr<unsigned char> g[2], s[2];
     short Srow[2][PROJ_NODES];
-    unsigned short* sLev; unsigned short* sIn; unsigned short* sChoice; unsigned short* sFrom; unsigned char* sLab;
-    u32* colInfo; unsigned short* segStart;
-    u64* mGap; u64* mDef; u64* mSeq;
+    GPtr<unsigned short> sLev, sIn, sChoice, sFrom; GPtr<unsigned char> sLab;
+    GPtr<u32> colInfo; GPtr<unsigned short> segStart;
+    union {
+        struct { u64 mGap[PROJL_CAP / 64], mDef[PROJL_CAP / 64], mSeq[PROJL_CAP / 64]; };      // column bit masks of the clean / restrict steps: in LDS (6 KB) -- the scalar walks over them are chains of dependent reads (round 6: they were in the slab)
+        // the level-by-level form of the re-threading DP (reads that cross a gene window; the masks are dead by then): where its chunks of levels start, a chunk's in-edge
+        // records and in-edge offsets -- as in k_rethread_chains
+        struct { u64 chunkStart[PROJL_CAP / 64]; u32 cRec[RT_CE]; unsigned short cIn[RT_SN + 2]; };
+    };
     short* sflatp;
+    int longSeg[2 * PROJL_LONGSEG];          // level ranges that go through the level-by-level form: the long segments of a read, or the whole read
     int err, n, startRaw, stopRaw, tmp0, tmp1;
-    __device__ __forceinline__ short* sflat() { return sflatp; }
+    __device__ __forceinline__ HLALA_AS_GLOBAL short* sflat() { return glob(sflatp); }
 };
 __host__ __device__ inline size_t proj_long_slab_bytes()
 {
@@ -92,7 +99,7 @@ __host__ __device__ inline size_t proj_long_slab_bytes()
 template <int CAP_, int SN_, int SE_> __device__ inline void proj_bind(ProjLdsT<CAP_, SN_, SE_>&, char*) { }
 __device__ inline void proj_bind(ProjLdsLong& P, char* p)      // 8-byte arrays first, then 4-, 2-, 1-byte ones
 {
-    P.mGap = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8; P.mDef = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8; P.mSeq = (u64*)p; p += (size_t)(PROJL_CAP / 64) * 8;
+    p += 3 * (size_t)(PROJL_CAP / 64) * 8;       // (the masks lived here until round 6)
     P.lvl[0] = (int*)p; p += (size_t)PROJL_CAP * 4; P.lvl[1] = (int*)p; p += (size_t)PROJL_CAP * 4; P.colInfo = (u32*)p; p += (size_t)PROJL_CAP * 4;
     P.sLev = (unsigned short*)p; p += ((size_t)PROJL_CAP + 2) * 2; P.segStart = (unsigned short*)p; p += ((size_t)PROJL_CAP + 2) * 2;
     P.sIn = (unsigned short*)p; p += ((size_t)PROJL_SN + 2) * 2; P.sChoice = (unsigned short*)p; p += (size_t)PROJL_SN * 2; P.sflatp = (short*)p; p += (size_t)PROJL_SN * 2; P.sFrom = (unsigned short*)p; p += (size_t)PROJL_SE * 2;
@@ -164,7 +171,15 @@ __global__ void k_filter_chains(const DevGraph* __restrict__ Gp, const DevBatch*
         //  serialise at the L2)
         if(B.chain_bucket) {
             int bk = -1;
-            if(st == HLALA_CHAIN_OK) { bk = (idA >= 0 ? idA : (idB >= 0 ? idB : 0)) >> B.order_shift; if(bk > B.order_nb - 2) bk = B.order_nb - 2; atomicAdd(&B.order_hist[bk], 1); }
+            if(st == HLALA_CHAIN_OK) {
+                if(B.order_cost) {
+                    // long reads: heaviest window first (32 nodes per bucket; a 10 kb backbone read has ~11 k nodes in its window, one across a gene window 100 k and more)
+                    const int la = idA < idB ? idA : idB, lb = idA < idB ? idB : idA;
+                    const int cost = (Gp->level_off[lb + 1] - Gp->level_off[la]) >> 5;
+                    bk = B.order_nb - 2 - cost; if(bk < 0) bk = 0;
+                } else { bk = (idA >= 0 ? idA : (idB >= 0 ? idB : 0)) >> B.order_shift; if(bk > B.order_nb - 2) bk = B.order_nb - 2; }
+                atomicAdd(&B.order_hist[bk], 1);
+            }
             B.chain_bucket[c] = bk;
         }
     }
@@ -187,6 +202,11 @@ struct FromLab { int from; unsigned char lab; };
 
 // colInfo, chunked form: bits 25-29 = DevGraph::level_fast of the level (25-26: 1 = edge-parallel in one slice of 64 in-edges, 2 = in several, 0 = node by node; 27-29: largest in-degree - 1)
 #define PJ_FAIL(code) do { if(P.err == 0) P.err = (code); } while(0)
+#ifdef HLALA_PROJ_TIMING       // build-time switch (make EXTRA=-DHLALA_PROJ_TIMING; tools/long_phase.py): the long-read projection in pieces, per-read histograms, the heaviest reads on their own
+constexpr bool PJ_FINE = true;
+#else
+constexpr bool PJ_FINE = false;
+#endif
 #define PJ_T(i) do { if(B.dbg) tPh[i] = clock64(); } while(0)      // HLALA_DEBUG phase clocks -> counters[16..23]
 // Ordering between the lanes of the wavefront for LDS ONLY: the LDS instructions of a wavefront execute in order, so waiting for the LDS counter and keeping the compiler from
 // moving accesses across is enough.  WSYNC() is a release / acquire fence and also waits for every store to HBM in flight -- a microsecond -- which the level loops of
@@ -204,12 +224,16 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
     __shared__ PL P;
     const int lane = lane_id();
     if(PL::LONG) { if(lane == 0) proj_bind(P, longSlabs + (size_t)blockIdx.x * longSlabBytes); WSYNC(); }
+    if(PL::LONG && deferRethread > 0) { const long long tGo = clock64() + (long long)(blockIdx.x & 63) * (long long)deferRethread; while(clock64() < tGo) __builtin_amdgcn_s_sleep(64); }      // (experiment: staggered starts)
     ChoiceRec* slabCh = (ChoiceRec*)(slabs + (size_t)blockIdx.x * slabBytes);
     const int slabEnt = (int)(slabBytes / sizeof(ChoiceRec));
     const int stride = B.stride;
 
     long long tAcc[7] = {0, 0, 0, 0, 0, 0, 0};
+    int readOrd = -1;                          // HLALA_DEBUG: how many chains this wavefront has finished
     long long tSub[4] = {0, 0, 0, 0};          // HLALA_DEBUG: chunked form -- chunk staging, level loops, chunks, levels
+    long long tFine[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tFineLast = 0;      // HLALA_DEBUG: pieces of the re-threading DP and of the backtrace (dbg[4300 ..], cycles >> 12; tools/long_phase.py)
+#define PJ_F(i) do { if constexpr (PL::LONG && PJ_FINE) if(B.dbg) { const long long t_ = clock64(); if((i) >= 0) tFine[(i) < 0 ? 0 : (i)] += t_ - tFineLast; tFineLast = t_; } } while(0)
     u64 accCols = 0, accEdges = 0;           // work counters, flushed once per wave (same-address atomics serialise at the L2)
     constexpr int CHUNK = 4;                 // chains drawn per atomic
     const int nWork = ordered_chains(B);     // position order: only the chains that passed the filters are listed
@@ -265,6 +289,8 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         if(lane == 0) { P.err = 0; }
         WSYNC();
         long long tPh[7] = {0, 0, 0, 0, 0, 0, 0};
+        long long tFine0[12], tSub0[4]; int dbgN[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (HLALA_DEBUG) what a heavy read looked like: operations, columns, padded columns, levels, window nodes, segments, long ranges, form
+        if constexpr (PL::LONG && PJ_FINE) if(B.dbg) { for(int i = 0; i < 12; i++) tFine0[i] = tFine[i]; for(int i = 0; i < 4; i++) tSub0[i] = tSub[i]; }
 
         PJ_T(0);
         // ---------------- CIGAR walk (transformBAMreadToInternalAlignment, :4794-5337)
@@ -381,6 +407,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         if(PJ_OK() && !(uni(P.startRaw) < uni(P.stopRaw))) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }        // :5252
         WSYNC();
 
+        if constexpr (PL::LONG && PJ_FINE) if(B.dbg) { dbgN[0] = nOps; dbgN[1] = nCols; }
         PJ_T(1);
         // ---------------- trim leading / trailing insertion columns, pad skipped levels (:2518-2579)
         int n1 = 0;
@@ -475,7 +502,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         if(ni != ng || ni != half) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); }
                         else {
                             cleaned = true;
-                            typename PL::LvT* olv = P.lvl[1 - cur]; unsigned char* osa = P.s[1 - cur];      // scratch: gathered in column order
+                            auto olv = P.lvl[1 - cur]; auto osa = P.s[1 - cur];      // scratch: gathered in column order
                             for(int q = a + lane; q <= b; q += 64) {
                                 const int r = q > a ? countBits(P.mDef, a, q - 1) : 0;
                                 if(bitOf(P.mDef, q)) osa[r] = P.s[cur][q]; else olv[(q - a) - r] = P.lvl[cur][q];
@@ -568,7 +595,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         }
         WSYNC();
 
-        PJ_T(4);
+        PJ_T(4); PJ_F(-1);
         // ---------------- re-threading DP, sequence variant (:2676-2835)
         // state of column i = best number of edge labels equal to the read character over all graph paths that respect
         // the seed's matches, per node of the column's target level; ties keep the smallest edge (std::set<Edge*> order).
@@ -582,6 +609,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         // PROJ_SEGMAX levels, or in which a segment hits the "no node reachable" assert, run the column-sequential form below.
         int level0 = -1, nb = 0, chCount = 0; ChoiceRec* ch = slabCh;
         int nDef = 0, nodeBase = 0, eBase = 0, nEdges = 0; bool staged = false, par = false, windowed = false, chunked = false, deferred = false; int defCount = 0, nChunks = 0;
+        int nLong = 0; bool lastLong = false;      // (long reads) level ranges solved level by level; the last of them ends the window
         if(PJ_OK()) {
             level0 = uni(LC::get(P.lvl[cur][0], lvBase));
             int lastLevel = uni(LC::get(P.lvl[cur][n1 - 1], lvBase));
@@ -633,11 +661,12 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 }
             }
         }
-        WSYNC();
+        WSYNC(); PJ_F(0);
         u64 edgesTouched = 0;
         int nSeg = 0;
-        short* const Sflat = P.sflat();                                                    // S per node of the window (parallel form)
-        if(PJ_OK() && windowed) {
+        auto const Sflat = P.sflat();                                                    // S per node of the window (parallel form)
+        const bool haveCols = windowed || (PL::LONG && nDef <= PL::CAP);      // (long reads: the level-by-level form needs the table whatever the size of the window)
+        if(PJ_OK() && haveCols) {
             // level -> (column, read character, seed-is-match); the defined columns must cover level0..lastLevel exactly once
             for(int j0 = 0; j0 < n1; j0 += 64) {
                 int j = j0 + lane; bool d = false;
@@ -651,7 +680,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 defCount += __popcll(__ballot(d));
             }
         }
-        WSYNC();
+        WSYNC(); PJ_F(1);
         if(PJ_OK() && staged) {
             for(int i0 = 0; i0 < nDef; i0 += 64) {
                 int i = i0 + lane;
@@ -665,18 +694,27 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
             int mx = 0;
             for(int sg = lane; sg < nSeg; sg += 64) mx = max(mx, (int)P.segStart[sg + 1] - (int)P.segStart[sg]);
             mx = wave_max_i32(mx);
-            // Long reads (round 6): a read that crosses a gene window has ONE segment of thousands of levels between its hundreds of short ones, and used to take the
-            // column-sequential form for all of its 10 000 levels (the slowest wavefronts of a batch, 50 M cycles each).  Its short segments are solved one per lane as
-            // in every other read; the long ones afterwards by the whole wavefront, level by level, the lanes on the level's nodes and the scores of the last level in
-            // LDS -- into the same per-node choices (P.sChoice), so the backtrace below is the segment-parallel one.
-            const bool hybrid = PL::LONG && mx > PROJ_SEGMAX;
-            par = (defCount == nDef) && (mx <= PROJ_SEGMAX || PL::LONG);
+            // Long reads (round 6): a read that crosses a gene window has a segment of thousands of levels between its thousands of short ones.  The short ones are solved one per lane
+            // as in every other read, the long ones (listed here) level by level further down -- the whole read only when the list overflows or its window is not staged.
+            if constexpr (PL::LONG) if(mx > PROJ_SEGMAX) {
+                for(int sg0 = 0; sg0 < nSeg; sg0 += 64) {
+                    const int sgl = sg0 + lane;
+                    const int sa = sgl < nSeg ? (int)P.segStart[sgl] : 0, sb = sgl < nSeg ? (int)P.segStart[sgl + 1] : 0;
+                    const bool isLong = sb - sa > PROJ_SEGMAX;
+                    const u64 lm = __ballot(isLong);
+                    const int pos = nLong + (int)__popcll(lm & ((1ull << lane) - 1ull));
+                    if(isLong && pos < PROJL_LONGSEG) { P.longSeg[2 * pos] = sa; P.longSeg[2 * pos + 1] = sb; }
+                    nLong += (int)__popcll(lm);
+                }
+            }
+            par = (defCount == nDef) && (mx <= PROJ_SEGMAX || (PL::LONG && nLong <= PROJL_LONGSEG));
+            PJ_F(2);
             if(par) {
                 const int nbR = nb - nodeBase;
                 int fail = 0;
                 for(int sg = lane; sg < nSeg; sg += 64) {
                     const int a = P.segStart[sg], b = P.segStart[sg + 1];
-                    if(hybrid && b - a > PROJ_SEGMAX) continue;
+                    if(PL::LONG && b - a > PROJ_SEGMAX) continue;
                     for(int i = a; i < b && !fail; i++) {
                         const u32 ci = P.colInfo[i];
                         const unsigned char sc = (unsigned char)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
@@ -700,40 +738,8 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                         if(!anyReached) fail = 1;
                     }
                 }
-                if(PL::LONG && hybrid && !__ballot(fail)) {
-                    for(int sg = 0; sg < nSeg && !fail; sg++) {
-                        const int a = uni(P.segStart[sg]), b = uni(P.segStart[sg + 1]);
-                        if(b - a <= PROJ_SEGMAX) continue;
-                        int rowQ = 0;
-                        for(int i = a; i < b; i++) {
-                            const u32 ci = P.colInfo[i];
-                            const unsigned char sc = (unsigned char)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
-                            const int t0 = P.sLev[i + 1], tm = (int)P.sLev[i + 2] - t0, fb = P.sLev[i];
-                            if(tm > PROJ_NODES) { fail = 1; break; }                          // (wider than the score rows: the column-sequential form decides)
-                            int anyReached = 0;
-                            for(int z = lane; z < tm; z += 64) {
-                                const int t = t0 + z;
-                                int best = -1, bestE = 0xFFFF;
-                                const int e0 = P.sIn[t - nbR], e1 = P.sIn[t - nbR + 1];
-                                for(int e = e0; e < e1; e++) {                               // in-edges in creation order: first maximum = smallest edge
-                                    const int sp = (i == a) ? 0 : (int)P.Srow[rowQ][(int)P.sFrom[e] - fb];
-                                    if(sp < 0) continue;
-                                    const unsigned char lab = P.sLab[e];
-                                    if(seedIsMatch && lab != sc) continue;                    // :2803-2809
-                                    const int cand = sp + (lab == sc ? 1 : 0);
-                                    if(cand > best) { best = cand; bestE = e; }
-                                }
-                                P.Srow[1 - rowQ][z] = (short)best;
-                                Sflat[t] = (short)best;
-                                P.sChoice[t - nbR] = (unsigned short)bestE;
-                                if(best >= 0) anyReached = 1;
-                            }
-                            if(!__ballot(anyReached)) { fail = 1; break; }
-                            rowQ = 1 - rowQ;
-                            LSYNC();
-                        }
-                    }
-                }
+                PJ_F(3);
+                PJ_F(4);
                 if(__ballot(fail)) par = false;                                               // let the sequential form raise the reference's assert
                 else if(lane == 0) edgesTouched += (u64)nEdges;
             }
@@ -748,8 +754,201 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
         WSYNC();
         if(PJ_OK()) {
             int rowP = 0;
-            chunked = !par && windowed && defCount == nDef;
-            if(chunked) {
+            bool fastLong = false;       // (long reads) the whole read level by level
+            bool runLevels = false;
+            if constexpr (PL::LONG) {
+                if(!par) nLong = 0;
+                if(par) runLevels = nLong > 0;
+                else if(haveCols && defCount == nDef) { runLevels = true; fastLong = true; nLong = 1; if(lane == 0) { P.longSeg[0] = 0; P.longSeg[1] = nDef; } }
+            }
+            if constexpr (PL::LONG) if(runLevels) {
+                // Long reads, level-by-level form (round 6).  A read that crosses a gene window has no cut for thousands of levels; it used to walk ALL its 10 000 levels one by one
+                // against HBM -- two dependent round trips per level, 150 M cycles for a read that spans a whole window: the LAST wavefront of every batch (12 500 reads took
+                // 135 ms, 50 000 took 160).  Now such levels go through the machinery of k_rethread_chains: chunks of up to 62 consecutive levels whose target nodes and
+                // in-edges fit the LDS staging arrays (one round trip per chunk, straight from the graph's arrays: absolute offsets, no window tables), the lanes on a level's
+                // IN-EDGES (DevGraph::in_rec), scores handed from lane to lane, one 32-bit back pointer per node (from-node rank | in-edge within its level) in the wave's slab.
+                u32* const chw = (u32*)slabCh;
+                if(chCount > 2 * slabEnt) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); }
+                for(int i = lane; i < PROJL_CAP / 64; i += 64) P.chunkStart[i] = 0;
+                WSYNC();
+                for(int rq = 0; rq < nLong && PJ_OK(); rq++) {
+                const int ra = uni(P.longSeg[2 * rq]), rb = uni(P.longSeg[2 * rq + 1]);
+                {   // S = 0 on the nodes of the range's first level (:2694-2701; a cut has one)
+                    int v = 0; if(lane < 2) v = G.level_off[level0 + ra + lane];
+                    const int fromCnt = __builtin_amdgcn_readlane(v, 1) - __builtin_amdgcn_readlane(v, 0);
+                    if(fromCnt > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); }
+                    else for(int z = lane; z < fromCnt; z += 64) P.Srow[rowP][z] = 0;
+                    WSYNC();
+                }
+                lastLong = rb == nDef;
+                int a = ra;
+                while(a < rb && PJ_OK()) {
+                    const long long tC0 = (PJ_FINE && B.dbg) ? clock64() : 0;
+                    const int i0 = a + lane;
+                    // offsets of levels a .. a + 63 (+ 2), colInfo + level_fast: one round trip; the first in-edges of the levels' target nodes: a second one
+                    const int lvA = i0 <= nDef + 1 ? G.level_off[level0 + i0] : 0;
+                    const int lvB = i0 + 1 <= nDef + 1 ? G.level_off[level0 + i0 + 1] : 0;
+                    const int lvC = i0 + 2 <= nDef + 1 ? G.level_off[level0 + i0 + 2] : 0;
+                    const u32 ciReg = i0 < nDef ? ((u32)P.colInfo[i0] | ((u32)G.level_fast[level0 + i0 + 1] << 25)) : 0u;
+                    const int sgA = i0 <= nDef ? G.in_off[lvB] : 0;
+                    const int sgB = __shfl_down(sgA, 1);
+                    const int lvA1 = __builtin_amdgcn_readlane(lvA, 1), sgA0 = __builtin_amdgcn_readlane(sgA, 0);
+                    const bool fits = i0 < rb && lane < 62 && (lvC - lvA1) <= RT_SN && (sgB - sgA0) <= RT_CE;
+                    const u64 fm = __ballot(fits);
+                    const int cnt = __ffsll((long long)~fm) - 1;                               // levels a .. a + cnt - 1 fit together (a prefix: both sums grow)
+                    if(lane == 0) P.chunkStart[a >> 6] |= 1ull << (a & 63);
+                    if(cnt == 0) {
+                        // one level wider than the staging arrays: node by node, straight from HBM
+                        const u32 ci = (u32)__builtin_amdgcn_readlane((int)ciReg, 0);
+                        const unsigned char sc = (unsigned char)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
+                        const int fb = __builtin_amdgcn_readlane(lvA, 0), tb = lvA1, tm = __builtin_amdgcn_readlane(lvA, 2) - lvA1;
+                        if(tm > PROJ_NODES) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); break; }
+                        int anyReached = 0;
+                        for(int z = lane; z < tm; z += 64) {
+                            const int node = tb + z;
+                            int best = -1, bestE = 0, bestFrom = -1;
+                            const int e0 = G.in_off[node], e1 = G.in_off[node + 1];
+                            for(int e = e0; e < e1; e++) {
+                                const int fz = G.in_from[e] - fb; const int sp = P.Srow[rowP][fz];
+                                if(sp < 0) continue;
+                                const unsigned char lab = G.in_label[e];
+                                if(seedIsMatch && lab != sc) continue;
+                                const int cd = sp + (lab == sc ? 1 : 0);
+                                if(cd > best) { best = cd; bestE = e - sgA0; bestFrom = fz; }
+                            }
+                            if(!par) edgesTouched += (u64)(e1 - e0);
+                            if(bestE > 0xFFFF) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER);
+                            P.Srow[1 - rowP][z] = (short)best;
+                            chw[node - nb] = best >= 0 ? ((u32)bestFrom | ((u32)bestE << 16)) : 0xFFFFFFFFu;
+                            if(best >= 0) anyReached = 1;
+                        }
+                        if(!__ballot(anyReached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); break; }
+                        rowP = 1 - rowP;
+                        WSYNC();
+                        a++;
+                        continue;
+                    }
+                    const int b = a + cnt - 1;
+                    const int tBase = lvA1, nT = __builtin_amdgcn_readlane(lvA, cnt + 1) - tBase, eC = sgA0, nE = __builtin_amdgcn_readlane(sgA, cnt) - eC;
+                    const int lvReg = lvA, sgReg = sgA - eC;
+                    {   // the chunk's in-edge records and in-edge offsets: one round trip
+                        constexpr int UE = RT_CE / 64, UN = (RT_SN + 1 + 63) / 64;
+                        // (the in-edge offsets of the nodes are only read by the levels that are solved node by node -- mode 0: most chunks have none)
+                        const bool needOff = __ballot(lane < cnt && ((ciReg >> 25) & 3u) == 0u) != 0;
+                        u32 ve[UE]; int vn[UN];
+                        #pragma unroll
+                        for(int u = 0; u < UE; u++) { const int e = lane + 64 * u; if(e < nE) ve[u] = G.in_rec[eC + e]; }
+                        if(needOff) {
+                            #pragma unroll
+                            for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) vn[u] = G.in_off[tBase + t]; }
+                        }
+                        #pragma unroll
+                        for(int u = 0; u < UE; u++) { const int e = lane + 64 * u; if(e < nE) P.cRec[e] = ve[u]; }
+                        if(needOff) {
+                            #pragma unroll
+                            for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) P.cIn[t] = (unsigned short)(vn[u] - eC); }
+                        }
+                    }
+                    WSYNC();
+                    const long long tC1 = (PJ_FINE && B.dbg) ? clock64() : 0;
+                    bool prevFast = false, stop = false; int sReg = -1;
+                    u32 recN = 0;
+                    { const int nE0 = __builtin_amdgcn_readlane(sgReg, 1); if(lane < nE0 && nE0 <= 64) recN = P.cRec[lane]; }
+                    for(int k = 0; k < cnt; k++) {
+                        const u32 ci = (u32)__builtin_amdgcn_readlane((int)ciReg, k);
+                        const int sc = (int)((ci >> 16) & 0xFFu); const bool seedIsMatch = ((ci >> 24) & 1u) != 0;
+                        const int l1 = __builtin_amdgcn_readlane(lvReg, k + 1), tm = __builtin_amdgcn_readlane(lvReg, k + 2) - l1;
+                        const int eL0 = __builtin_amdgcn_readlane(sgReg, k), eL1 = __builtin_amdgcn_readlane(sgReg, k + 1), nEl = eL1 - eL0;
+                        const int mode = (int)((ci >> 25) & 3u), maxd = (int)((ci >> 27) & 7u);
+                        const u32 rec = recN;
+                        if(k + 1 < cnt) { const int nEn = __builtin_amdgcn_readlane(sgReg, k + 2) - eL1; recN = (lane < nEn && nEn <= 64) ? P.cRec[eL1 + lane] : 0u; }
+                        bool reached = false;
+                        auto edge_key = [&](const u32 r, const int sp, const bool mine) -> int {
+                            const int m = (int)((r >> 18) & 0xFFu) == sc ? 1 : 0;
+                            const int cand = (mine && sp >= 0 && (m || !seedIsMatch)) ? sp + m + 1 : 0;           // 0: not admitted (:2803-2809) or from-node unreachable; else score + 1
+                            return (cand << 15) | ((63 - lane) << 9) | (int)(r & 511u);
+                        };
+                        auto node_key = [&](const u32 r, const int key) -> int {
+                            const int pos = (int)((r >> 15) & 7u);
+                            int bk = key, kj = key;
+                            for(int j = 1; j <= maxd; j++) { kj = __builtin_amdgcn_update_dpp(0, kj, 0x138, 0xF, 0xF, false); if(pos >= j) bk = max(bk, kj); }          // wave_shr:1 -- the edge j places before
+                            return bk;
+                        };
+                        if(mode == 1) {
+                            const bool mine = lane < nEl;
+                            int sp;
+                            if(prevFast) sp = __builtin_amdgcn_ds_bpermute((int)(((rec >> 9) & 63u) << 2), sReg);
+                            else sp = (int)P.Srow[rowP][rec & 511u];
+                            const int bk = node_key(rec, edge_key(rec, sp, mine));
+                            const bool last = mine && (rec & (1u << 28)) != 0;
+                            const u64 lastMask = __ballot(last);
+                            const int best = (bk >> 15) - 1;
+                            sReg = best;
+                            if(last) {
+                                const int tz = (int)__builtin_amdgcn_mbcnt_hi((u32)(lastMask >> 32), __builtin_amdgcn_mbcnt_lo((u32)lastMask, 0u));
+                                P.Srow[1 - rowP][tz] = (short)best;
+                                chw[l1 + tz - nb] = best >= 0 ? ((u32)(bk & 511) | ((u32)(63 - ((bk >> 9) & 63)) << 16)) : 0xFFFFFFFFu;
+                                reached = best >= 0;
+                            }
+                            if(lane == 0 && !par) edgesTouched += (u64)nEl;
+                            prevFast = true;
+                        } else if(mode == 2) {
+                            int nodesDone = 0;
+                            for(int s0 = 0; s0 == 0 || s0 + 7 < nEl; s0 += 57) {
+                                const bool mine = s0 + lane < nEl;
+                                const u32 r = mine ? P.cRec[eL0 + s0 + lane] : 0u;
+                                const int sp = (int)P.Srow[rowP][r & 511u];
+                                const int bk = node_key(r, edge_key(r, sp, mine));
+                                const bool last = mine && (r & (1u << 28)) != 0 && (s0 == 0 || lane >= 7);
+                                const u64 lastMask = __ballot(last);
+                                if(last) {
+                                    const int best = (bk >> 15) - 1;
+                                    const int tz = nodesDone + (int)__builtin_amdgcn_mbcnt_hi((u32)(lastMask >> 32), __builtin_amdgcn_mbcnt_lo((u32)lastMask, 0u));
+                                    P.Srow[1 - rowP][tz] = (short)best;
+                                    chw[l1 + tz - nb] = best >= 0 ? ((u32)(bk & 511) | ((u32)(s0 + 63 - ((bk >> 9) & 63)) << 16)) : 0xFFFFFFFFu;
+                                    if(best >= 0) reached = true;
+                                }
+                                nodesDone += (int)__popcll(lastMask);
+                            }
+                            if(lane == 0 && !par) edgesTouched += (u64)nEl;
+                            prevFast = false;
+                        } else {
+                            const int t0 = l1 - tBase;
+                            for(int z = lane; z < tm; z += 64) {
+                                const int t = t0 + z;
+                                int best = -1, bestE = 0, bestFrom = -1;
+                                const int e0 = P.cIn[t], e1 = P.cIn[t + 1];
+                                for(int e = e0; e < e1; e++) {                                   // in-edges in creation order: first maximum = smallest edge
+                                    const u32 r = P.cRec[e];
+                                    const int fz = (int)(r & 511u);
+                                    const int sp = P.Srow[rowP][fz];
+                                    if(sp < 0) continue;
+                                    const int lab = (int)((r >> 18) & 0xFFu);
+                                    if(seedIsMatch && lab != sc) continue;                        // :2803-2809
+                                    const int cd = sp + (lab == sc ? 1 : 0);
+                                    if(cd > best) { best = cd; bestE = e - eL0; bestFrom = fz; }
+                                }
+                                if(!par) edgesTouched += (u64)(e1 - e0);
+                                P.Srow[1 - rowP][z] = (short)best;
+                                chw[tBase + t - nb] = best >= 0 ? ((u32)bestFrom | ((u32)bestE << 16)) : 0xFFFFFFFFu;
+                                if(best >= 0) reached = true;
+                            }
+                            prevFast = false;
+                        }
+                        if(!__ballot(reached)) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_INPUT); stop = true; break; }      // assert(seedChain_backtrack_*.size() > 0)
+                        rowP = 1 - rowP;
+                        LSYNC();
+                    }
+                    WSYNC();
+                    if(PJ_FINE && B.dbg) { tSub[0] += tC1 - tC0; tSub[1] += clock64() - tC1; tSub[2]++; tSub[3] += cnt; }
+                    if(stop) break;
+                    a = b + 1;
+                }
+                }
+            }
+            chunked = !PL::LONG && !par && windowed && defCount == nDef;
+            if(runLevels) { }
+            else if(chunked) {
                 // Column-sequential form on LDS-staged CHUNKS of the window.  Allele-rich stretches have no single-node level for
                 // hundreds of levels (no cuts for the segment-parallel form) and tens to hundreds of nodes per level (the whole window
                 // does not fit the staging arrays): walking them level by level against HBM cost two dependent round trips per level,
@@ -1019,12 +1218,13 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 }
             }
             WSYNC();
-            PJ_T(5);
+            if constexpr (PL::LONG && PJ_FINE) if(B.dbg) { dbgN[2] = n1; dbgN[3] = nDef; dbgN[4] = chCount; dbgN[5] = nSeg; dbgN[6] = nLong; dbgN[7] = (par ? 1 : 0) | (fastLong ? 2 : 0) | (staged ? 4 : 0) | (windowed ? 8 : 0); }
+            PJ_T(5); PJ_F(5);
             // ---------------- backtrace (:2838-3007)
             if(PJ_OK() && !deferred) {
                 int lastLevel = uni(LC::get(P.lvl[cur][n1 - 1], lvBase));
                 int tb, tm; const short* lastS;
-                if(par) { tb = nodeBase + P.sLev[nDef]; tm = P.sLev[nDef + 1] - P.sLev[nDef]; lastS = Sflat + P.sLev[nDef]; }
+                if(par && !lastLong) { tb = nodeBase + P.sLev[nDef]; tm = P.sLev[nDef + 1] - P.sLev[nDef]; lastS = (const short*)(Sflat + P.sLev[nDef]); }      // (lastLong: the window's last levels were solved level by level -- their scores are in the row)
                 else { tb = G.level_off[lastLevel + 1]; tm = G.level_off[lastLevel + 2] - tb; lastS = P.Srow[rowP]; }
                 int bestS = -1;
                 for(int z = lane; z < tm; z += 64) bestS = max(bestS, (int)lastS[z]);
@@ -1033,19 +1233,63 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 for(int z = lane; z < tm; z += 64) if(lastS[z] == bestS) { zsel = min(zsel, z); }
                 zsel = -wave_max_i32(-zsel);                                                   // *(runningN.begin()): smallest node among the maxima (:2867)
                 const size_t cb = row_base(B, c);
-                if(par) {
+                if(par || fastLong) {
                     // every segment is traced from its right cut node (the last one from the selected node); the other column
-                    // buffer takes the chosen edge per column, then all lanes emit (edge ids are independent HBM reads)
-                    typename PL::LvT* pick = P.lvl[1 - cur];
+                    // buffer takes the chosen edge per column (window-relative: CSR in-edge - eBase), then all lanes emit (edge ids are independent HBM reads)
+                    auto pick = P.lvl[1 - cur];
                     for(int j = lane; j < n1; j += 64) pick[j] = LC::pickNone();
-                    WSYNC();
+                    WSYNC(); PJ_F(6);
                     const int nbR = nb - nodeBase;
-                    for(int sg = lane; sg < nSeg; sg += 64) {
+                    if(par) for(int sg = lane; sg < nSeg; sg += 64) {
                         const int a = P.segStart[sg], b = P.segStart[sg + 1];
+                        if(PL::LONG && b - a > PROJ_SEGMAX) continue;
                         int t = (b == nDef) ? (int)P.sLev[nDef] + zsel : (int)P.sLev[b];
                         for(int i = b - 1; i >= a; i--) { int e = P.sChoice[t - nbR]; pick[P.colInfo[i] & 0xFFFFu] = e; t = P.sFrom[e]; }
                     }
-                    WSYNC();
+                    if constexpr (PL::LONG) {
+                    // the ranges solved level by level: their chunks again, last to first (P.chunkStart) -- the back pointers of a chunk's nodes are staged into LDS with coalesced
+                    // reads and lane 0 follows them there.  A range that ends the window starts from the selected node, any other from its cut node.
+                    const u32* const chw = (const u32*)slabCh;
+                    for(int rq = nLong - 1; rq >= 0; rq--) {
+                    const int ra = uni(P.longSeg[2 * rq]), rb = uni(P.longSeg[2 * rq + 1]);
+                    int z = rb == nDef ? zsel : 0;
+                    for(int bb = rb - 1; bb >= ra; ) {
+                        int w = bb >> 6; u64 m = P.chunkStart[w] & (~0ull >> (63 - (bb & 63)));
+                        while(m == 0) { w--; m = P.chunkStart[w]; }                            // (the range's first level starts a chunk)
+                        const int aa = w * 64 + 63 - __clzll((long long)m);
+                        const int i0 = aa + lane;
+                        const int lvA = i0 <= nDef + 1 ? G.level_off[level0 + i0] : 0;
+                        const int lvB = (i0 <= bb && i0 + 1 <= nDef + 1) ? G.level_off[level0 + i0 + 1] : 0;
+                        const u32 ciReg = i0 <= bb ? (u32)P.colInfo[i0] : 0u;
+                        const int sgA = i0 <= bb ? G.in_off[lvB] - eBase : 0;
+                        const int tBase = __builtin_amdgcn_readlane(lvA, 1), nT = __builtin_amdgcn_readlane(lvA, bb - aa + 2) - tBase;
+                        {
+                            constexpr int UN = RT_CE / 64;          // (a chunk holds at most RT_SN nodes, a level on its own at most PROJ_NODES = RT_CE)
+                            u32 vr[UN];
+                            #pragma unroll
+                            for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t < nT) vr[u] = chw[tBase + t - nb]; }
+                            #pragma unroll
+                            for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t < nT) P.cRec[t] = vr[u]; }
+                        }
+                        WSYNC();
+                        for(int i = bb; i >= aa; i--) {
+                            const int col = (int)((u32)__builtin_amdgcn_readlane((int)ciReg, i - aa) & 0xFFFFu), lvI = __builtin_amdgcn_readlane(lvA, i - aa + 1), sgI = __builtin_amdgcn_readlane(sgA, i - aa);
+                            if(lane == 0) { const u32 r = P.cRec[lvI - tBase + z]; pick[col] = sgI + (int)(r >> 16); z = (int)(short)(r & 0xFFFFu); }
+                        }
+                        WSYNC();
+                        bb = aa - 1;
+                    }
+                    }
+                    }
+                    WSYNC(); PJ_F(7);
+                    if constexpr (PL::LONG) {
+                    staged_rows<6>(lane, n1, 64, [&](int j) { const int pe = pick[j]; FromLab r; r.from = -1; r.lab = '_';
+                                                              if(pe >= 0) { r.from = G.in_eid[eBase + pe]; r.lab = G.in_label[eBase + pe]; } return r; },
+                        [&](int j, FromLab r) {
+                            B.seed_level[cb + j] = r.from < 0 ? -1 : LC::get(P.lvl[cur][j], lvBase); B.seed_edge[cb + j] = r.from; B.seed_g[cb + j] = r.lab;
+                            B.seed_s[cb + j] = P.s[cur][j];
+                        });
+                    } else {
                     staged_rows<6>(lane, n1, 64, [&](int j) { const typename PL::LvT pe = pick[j]; return LC::pickIsNone(pe) ? -1 : G.in_eid[eBase + (int)pe]; },
                         [&](int j, int eid) {
                             const typename PL::LvT pe = pick[j];
@@ -1053,10 +1297,11 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                             else { B.seed_level[cb + j] = LC::get(P.lvl[cur][j], lvBase); B.seed_edge[cb + j] = eid; B.seed_g[cb + j] = P.sLab[(int)pe]; }
                             B.seed_s[cb + j] = P.s[cur][j];
                         });
+                    }
                 } else if(chunked) {
                     // the chunks again, last to first: the back pointers of a chunk's nodes are staged into LDS with coalesced reads, lane 0
                     // follows them there, then all lanes emit
-                    typename PL::LvT* pick = P.lvl[1 - cur];
+                    auto pick = P.lvl[1 - cur];
                     for(int j = lane; j < n1; j += 64) pick[j] = LC::pickNone();
                     WSYNC();
                     const int nbR = nb - nodeBase;
@@ -1096,8 +1341,21 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
                 }
             }
         }
-        PJ_T(6);
+        PJ_T(6); PJ_F(8);
+        if constexpr (PL::LONG && PJ_FINE) readOrd++;
         if(B.dbg) { for(int i = 0; i < 6; i++) if(tPh[i + 1] && tPh[i]) tAcc[i] += tPh[i + 1] - tPh[i]; tAcc[6]++; }
+        if constexpr (PL::LONG && PJ_FINE) if(B.dbg && lane == 0 && tPh[6] && tPh[0]) {       // (HLALA_DEBUG=1) histogram of a chain's cycles by their binary logarithm: counts at dbg[4096 ..], sums (cycles >> 16) at dbg[4160 ..] -- tools/long_phase.py
+            const long long cyc = tPh[6] - tPh[0]; int k = 0; while(k < 47 && (cyc >> (k + 1)) != 0) k++;
+            atomicAdd(&B.dbg[4096 + k], 1); atomicAdd(&B.dbg[4160 + k], (int)(cyc >> 16));
+            { const int o = readOrd < 31 ? readOrd : 31; atomicAdd(&B.dbg[4400 + o], (int)(cyc >> 16)); atomicAdd(&B.dbg[4432 + o], 1); atomicAdd(&B.dbg[4464 + o], dbgN[2] >> 4); }      // by the read's ordinal on its wavefront
+            if(k >= 25) {       // the heaviest reads on their own: phases at dbg[4320 ..], the pieces of tFine at dbg[4330 ..] (cycles >> 12), their number at dbg[4319]
+                { const int q = atomicAdd(&B.dbg[4318], 1); if(q < 300) { int* r = B.dbg + 5000 + 10 * q; r[0] = c; r[1] = dbgN[0]; r[2] = dbgN[1]; r[3] = dbgN[2]; r[4] = dbgN[3]; r[5] = dbgN[4]; r[6] = dbgN[5]; r[7] = dbgN[6]; r[8] = (int)(cyc >> 16); r[9] = dbgN[7] | ((int)((tPh[0] >> 20) & 0x7FFFF) << 8); } }
+                atomicAdd(&B.dbg[4319], 1);
+                for(int i = 0; i < 6; i++) atomicAdd(&B.dbg[4320 + i], (int)((tPh[i + 1] - tPh[i]) >> 12));
+                for(int i = 0; i < 12; i++) atomicAdd(&B.dbg[4330 + i], (int)((tFine[i] - tFine0[i]) >> 12));
+                for(int i = 0; i < 4; i++) atomicAdd(&B.dbg[4344 + i], (int)((tSub[i] - tSub0[i]) >> (i < 2 ? 12 : 0)));
+            }
+        }
         {
             int e = wave_sum_i32((int)edgesTouched);
             accEdges += (u64)e;
@@ -1112,6 +1370,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
 #ifndef HLALA_DP_TIMING      // (the timing build of the DP kernels puts k_stitch_chains' clocks into the same counters)
     if(B.dbg && lane == 0) { for(int i = 0; i < 6; i++) atomicAdd(&B.counters[16 + i], (u64)tAcc[i]); atomicAdd(&B.counters[23], (u64)tAcc[6]); }
     if(B.dbg && lane == 0) for(int i = 0; i < 4; i++) atomicAdd(&B.counters[24 + i], (u64)tSub[i]);
+    if constexpr (PL::LONG && PJ_FINE) if(B.dbg && lane == 0) for(int i = 0; i < 12; i++) atomicAdd(&B.dbg[4300 + i], (int)(tFine[i] >> 12));
 #endif
 }
 
