@@ -215,7 +215,7 @@ constexpr bool PJ_FINE = false;
 #define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
 
 template <class PL>
-__global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
+__global__ __launch_bounds__(64, PL::LONG ? 4 : 2) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
                                                        const int* contig_level, char* slabs, size_t slabBytes, char* longSlabs, size_t longSlabBytes,
                                                        int deferRethread)      // 1: chains that need the chunked form and fit k_rethread_chains are left to it
 {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64, 2) void k_project_chains(const DevGraph* __rest
     long long tFine[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tFineLast = 0;      // HLALA_DEBUG: pieces of the re-threading DP and of the backtrace (dbg[4300 ..], cycles >> 12; tools/long_phase.py)
 #define PJ_F(i) do { if constexpr (PL::LONG && PJ_FINE) if(B.dbg) { const long long t_ = clock64(); if((i) >= 0) tFine[(i) < 0 ? 0 : (i)] += t_ - tFineLast; tFineLast = t_; } } while(0)
     u64 accCols = 0, accEdges = 0;           // work counters, flushed once per wave (same-address atomics serialise at the L2)
-    constexpr int CHUNK = 4;                 // chains drawn per atomic
+    constexpr int CHUNK = PL::LONG ? 1 : 4;  // chains drawn per atomic (long reads, heaviest first: one -- a draw of four gave the first wavefronts the four heaviest reads of the batch each)
     const int nWork = ordered_chains(B);     // position order: only the chains that passed the filters are listed
     for(;;) {
         int c0 = 0;
