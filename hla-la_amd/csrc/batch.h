@@ -76,6 +76,8 @@ struct DevBatch {
     int* chain_bucket;              // [n_chains] position bucket = first level >> order_shift (the last bucket: chains filtered out)
     int* order_hist;                // [order_nb + 1] bucket counts -> bucket starts -> scatter cursors
     int order_shift, order_nb;
+    int long_chunk_nodes, long_max_segs;      // long-read layout, level-by-level form of the re-threading DP (kernel_project.hip): nodes a chunk of levels may hold (<= RT_SN) and long segments a read may
+                                    // have beside its short ones (<= PROJL_LONGSEG); HLALA_LONG_CHUNK_NODES / HLALA_LONG_MAXSEGS shrink them so that small tests walk every branch
     int order_cost;                 // long-read layout: buckets by DESCENDING size of the chain's window (nodes between its first and last level) instead of position -- the reads that
                                     // cross a gene window take a hundred times a backbone read's time and must not be the last ones a wavefront draws (kernel_project.hip: k_filter_chains)
     // ---- column rows only for the chains that passed the filters (round 5): two thirds of a batch's chains end at k_filter_chains (strand, duplicate coordinates,

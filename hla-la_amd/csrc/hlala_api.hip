@@ -88,6 +88,7 @@ struct hlala_ctx {
     double* pair_scratch = nullptr;   // [2 * pair_grid][PAIR_COMB]: combination tables of the rare pairs with more than PAIR_COMB_LDS combinations (main- and side-stream pass)
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
     int proj_long_stagger = 0;              // long-read projection: wavefront w starts (w mod 64) x this many cycles after the kernel does (HLALA_PROJ_LONG_STAGGER; k_project_chains)
+    int long_chunk_nodes = 1 << 20, long_max_segs = 1 << 20;      // (batch.h; the kernel clamps them to its array sizes)
     int order_cost = 0;                     // long-read layout: heaviest windows first (batch.h: order_cost; HLALA_LONG_ORDER=0: position order)
     int order_shift = 8, order_nb = 0;      // position buckets of a batch's chains (kernel_order.hip); order_nb 0: input order (HLALA_LOCALITY=0)
     int* dbg_host = nullptr;      // (device memory) non-null with HLALA_DEBUG=1: kernels accumulate phase clocks into the batch counters (hlala_debug_counters)
@@ -548,6 +549,8 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     { const char* e = getenv("HLALA_LOCALITY");
       if(!(e && atoi(e) == 0)) { int sh = 8; if(e && atoi(e) >= 2 && atoi(e) <= 20) sh = atoi(e); while((F.L >> sh) + 2 > 16384) sh++; c->order_shift = sh; c->order_nb = (F.L >> sh) + 2; } }
     if(const char* e = getenv("HLALA_PROJ_LONG_STAGGER")) c->proj_long_stagger = atoi(e);
+    if(const char* e = getenv("HLALA_LONG_CHUNK_NODES")) { const int v = atoi(e); if(v >= 1) c->long_chunk_nodes = v; }
+    if(const char* e = getenv("HLALA_LONG_MAXSEGS")) { const int v = atoi(e); if(v >= 0) c->long_max_segs = v; }
     if(c->proj_long_slabs && c->order_nb > 0) { const char* e = getenv("HLALA_LONG_ORDER"); c->order_cost = (e && atoi(e) == 0) ? 0 : 1; }
     // (the debug buffer is DEVICE memory since round 6: host-mapped, every counter a kernel added to it was an atomic over PCIe -- the wavefronts of the long-read projection queued
     //  behind each other's, and the clocks they were meant to read showed that queue)
@@ -653,7 +656,7 @@ static int batch_alloc_outputs(hlala_ctx* c, hlala_batch* b)
     B.dp_band_risky = c->band_risky ? 1 : 0;
     AL(dp_blk, (size_t)DPL_N * B.dp_nblk + 1, false); AL(dp_list, 2 * nc, false);
     if(!b->prepared) {
-        B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb; B.order_cost = c->order_cost;
+        B.chain_order = nullptr; B.chain_bucket = nullptr; B.order_hist = nullptr; B.order_shift = c->order_shift; B.order_nb = c->order_nb; B.order_cost = c->order_cost; B.long_chunk_nodes = c->long_chunk_nodes; B.long_max_segs = c->long_max_segs;
         if(c->order_nb > 0 && !B.from_seeds && nc > 0) { AL(chain_order, nc, false); AL(chain_bucket, nc, false); AL(order_hist, (size_t)c->order_nb + 1, false); }
     }
     B.dbg = c->dbg_host;
@@ -747,7 +750,7 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
         AL(seed_status, (size_t)nc, true); AL(seed_ncols, (size_t)nc, true);
         AL(chain_order, (size_t)nc, false); AL(chain_bucket, (size_t)nc, false); AL(chain_row, (size_t)nc, false); AL(order_hist, (size_t)c->order_nb + 1, true);
 #undef AL
-        B.order_shift = c->order_shift; B.order_nb = c->order_nb; B.order_cost = c->order_cost;
+        B.order_shift = c->order_shift; B.order_nb = c->order_nb; B.order_cost = c->order_cost; B.long_chunk_nodes = c->long_chunk_nodes; B.long_max_segs = c->long_max_segs;
         b->prepared = true;
     }
     rc = dev_upload(c, b->allocs, &b->B, 1, &b->dB); if(rc) return fail(rc);

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(64, PL::LONG ? 4 : 2) void k_project_chains(const D
                     nLong += (int)__popcll(lm);
                 }
             }
-            par = (defCount == nDef) && (mx <= PROJ_SEGMAX || (PL::LONG && nLong <= PROJL_LONGSEG));
+            par = (defCount == nDef) && (mx <= PROJ_SEGMAX || (PL::LONG && nLong <= min(PROJL_LONGSEG, B.long_max_segs)));
             PJ_F(2);
             if(par) {
                 const int nbR = nb - nodeBase;
@@ -768,6 +768,7 @@ __global__ __launch_bounds__(64, PL::LONG ? 4 : 2) void k_project_chains(const D
                 // in-edges fit the LDS staging arrays (one round trip per chunk, straight from the graph's arrays: absolute offsets, no window tables), the lanes on a level's
                 // IN-EDGES (DevGraph::in_rec), scores handed from lane to lane, one 32-bit back pointer per node (from-node rank | in-edge within its level) in the wave's slab.
                 u32* const chw = (u32*)slabCh;
+                const int chunkNodes = B.long_chunk_nodes > 0 ? min(RT_SN, B.long_chunk_nodes) : RT_SN;
                 if(chCount > 2 * slabEnt) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); }
                 for(int i = lane; i < PROJL_CAP / 64; i += 64) P.chunkStart[i] = 0;
                 WSYNC();
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(64, PL::LONG ? 4 : 2) void k_project_chains(const D
                     const int sgA = i0 <= nDef ? G.in_off[lvB] : 0;
                     const int sgB = __shfl_down(sgA, 1);
                     const int lvA1 = __builtin_amdgcn_readlane(lvA, 1), sgA0 = __builtin_amdgcn_readlane(sgA, 0);
-                    const bool fits = i0 < rb && lane < 62 && (lvC - lvA1) <= RT_SN && (sgB - sgA0) <= RT_CE;
+                    const bool fits = i0 < rb && lane < 62 && (lvC - lvA1) <= chunkNodes && (sgB - sgA0) <= RT_CE;
                     const u64 fm = __ballot(fits);
                     const int cnt = __ffsll((long long)~fm) - 1;                               // levels a .. a + cnt - 1 fit together (a prefix: both sums grow)
                     if(lane == 0) P.chunkStart[a >> 6] |= 1ull << (a & 63);

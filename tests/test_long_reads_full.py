@@ -91,7 +91,7 @@ def test_distinct_long_reads_on_graph_m(pkg, oracle):
     """Variety instead of copies: 6 000 DISTINCT reads over 6-14 kb of reference on a Graph M world (backbone haplotypes with gap stretches, gene
     windows with hundreds to thousands of allele paths).  4 000 lie anywhere on the backbone contigs; 1 600 are laid ACROSS a gene window (they enter the
     allele-rich levels from the backbone and leave them again: the projection's chunked and level-by-level forms, levels with hundreds of nodes); 400 come
-    from allele contigs of the windows.  Every column is checked against the reference's invariants and the graph, and 512 reads -- 256 of them
+    from allele contigs of the windows.  Every column is checked against the reference's invariants and the graph, and 2 048 reads -- 1 024 of them
     window-crossing or allele reads -- bit for bit against the oracle."""
     w = synth.make_world_m(seed=9, n_levels=400_000, n_windows=6, alleles=(400, 3000))
     c = w["contigs"]; off = np.asarray(c["contig_off"], np.int64); clen = np.diff(off); cw = np.asarray(w["contig_window"])
@@ -149,8 +149,8 @@ def test_distinct_long_reads_on_graph_m(pkg, oracle):
     npl = w["nodes_per_level"]
     rich = np.zeros(n, bool); rich[np.unique(read_of_col[has][npl[lv[has]] >= 50])] = True
     assert rich[4000:5600].mean() > 0.9 and rich.sum() > 1500
-    # ---- 512 reads against the oracle: 256 from the backbone, 256 that cross a window or come from an allele contig
-    pick = np.concatenate([np.arange(0, 4000, 4000 // 256)[:256], np.arange(4000, 6000, 2000 // 256)[:256]])
+    # ---- 2 048 reads against the oracle (round 6; 512 before): 1 024 from the backbone, 1 024 that cross a window or come from an allele contig
+    pick = np.concatenate([np.arange(0, 4000, 3)[:1024], np.arange(4000, 6000, 1)[:1024]])
     sub = _sub_reads(u, pick)
     e = oracle(w["graph"], w["contigs"], **kw).align_long_reads(sub)["pairs"]
     stride = 16384
@@ -163,3 +163,48 @@ def test_distinct_long_reads_on_graph_m(pkg, oracle):
         for key in ("col_level", "col_edge", "col_gchar", "col_schar", "col_mapq"):
             assert np.array_equal(np.asarray(e[key])[i * stride:i * stride + k0], pk[key][off_c[r]:off_c[r] + k0]), (r, key)
     assert np.allclose(sc["pair_ll"][pick], e["pair_ll"][:len(pick)], rtol=1e-12, atol=0) and np.array_equal(sc["best_chain"][pick] - pick, e["best_chain"][:len(pick)] - np.arange(len(pick)))
+
+
+def _long_world_and_reads(n_back=300, n_cross=500):
+    w = synth.make_world_m(seed=11, n_levels=200_000, n_windows=4, alleles=(200, 900))
+    c = w["contigs"]; off = np.asarray(c["contig_off"], np.int64); clen = np.diff(off); cw = np.asarray(w["contig_window"])
+    backbone = np.nonzero(cw < 0)[0]
+    rng = np.random.default_rng(5)
+    starts = []
+    for _ in range(n_back):
+        h = int(backbone[rng.integers(0, len(backbone))]); starts.append((h, int(rng.integers(0, clen[h] - 14010))))
+    wf = w["windows"]["first_level"]
+    for i in range(n_cross):
+        k = i % len(wf); h = int(backbone[rng.integers(0, len(backbone))])
+        lv = c["contig_level"][off[h]:off[h + 1]]
+        p = int(np.searchsorted(lv, wf[k])) - int(rng.integers(500, 9000))
+        starts.append((h, max(0, min(p, int(clen[h]) - 14010))))
+    bs = synth.make_long_batches_parallel(w, len(starts), per_batch=len(starts), seed=901, len_lo=6000, len_hi=14000, procs=8, starts=starts)
+    return w, bs[0]
+
+
+def test_forms_of_the_long_read_projection_agree(pkg, monkeypatch):
+    """The re-threading DP of a long read runs in one of several forms (kernel_project.hip): segments one per lane; long segments level by level in chunks of up to 62
+    levels / 416 nodes, a level beyond that node by node; the whole read level by level when it has more long segments than its list holds or its window is not staged.
+    The switches HLALA_LONG_CHUNK_NODES / HLALA_LONG_MAXSEGS / HLALA_LONG_ORDER move reads between the forms; the results must not move.  (The default form against
+    the oracle: test_distinct_long_reads_on_graph_m.)"""
+    w, u = _long_world_and_reads()
+    kw = dict(insert_mean=200.0, insert_sd=35.0, rng_seed=3, long_read_mode=1, max_columns=16384)
+    def run(env):
+        for k in ("HLALA_LONG_CHUNK_NODES", "HLALA_LONG_MAXSEGS", "HLALA_LONG_ORDER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = pkg.Context(w["graph"], w["contigs"], **kw)
+        gb = ctx.batch_unpaired(u); gb.align()
+        st = gb.stats(); pk = gb.pairs_packed(); sc = gb.pairs_scalars()
+        return st, pk, sc
+    st0, pk0, sc0 = run({})
+    assert (sc0["pair_status"] == 0).mean() > 0.99
+    for env in ({"HLALA_LONG_MAXSEGS": "0"}, {"HLALA_LONG_CHUNK_NODES": "8"}, {"HLALA_LONG_CHUNK_NODES": "1", "HLALA_LONG_MAXSEGS": "1"}, {"HLALA_LONG_ORDER": "0"}):
+        st, pk, sc = run(env)
+        assert np.array_equal(sc["pair_status"], sc0["pair_status"]), env
+        for k in ("col_off", "col_level", "col_edge", "col_gchar", "col_schar", "col_mapq"):
+            assert np.array_equal(pk[k], pk0[k]), (env, k)
+        assert np.array_equal(sc["pair_ll"], sc0["pair_ll"]) and np.array_equal(sc["best_chain"], sc0["best_chain"]), env
+        assert st.n_edges_touched == st0.n_edges_touched and st.n_seed_columns == st0.n_seed_columns, env
