@@ -477,7 +477,7 @@ def main():
                        "dp_calls_entering_class": {"16lane": cls_n[0], "32lane": cls_n[1], "64lane": cls_n[2], "wide": cls_n[3], "broad": cls_n[4], "large": cls_n[5], "in_memory": cls_n[6], "16lane_jump_free": int(st.n_dp_jump_free),
                                                    "band": int(st.n_dp_band), "band_failed_over_to_16lane": int(st.n_dp_band_failed), "jump_free_met_a_jump_and_went_to_the_general_list": int(st.n_dp_jump_free_failed)},
                        "dp_calls_sharing_a_dp": int(st.n_dp_shared), "generation_s": t_gen, "kernel_source_hash": khash},
-            "roofline": {"bound": "latency", "bound_note": "instruction issue + dependent LDS / L2 round trips of an integer frontier DP (HBM is 1-2 % busy); achieved / peak / frac are the HBM figures the metric asks for, not the binding resource", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "roofline": {"bound": "latency", "bound_note": "dependent LDS / L2 round trips inside one iteration of an integer frontier DP, which four wavefronts per SIMD do not cover: the kernel's SIMDs issue vector instructions 28 % of the time (profiles/r06_experiments.txt 11), HBM is 1-2 % busy -- achieved / peak / frac are the HBM figures the metric asks for, not the binding resource", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": names[dom], "kernel_ms": dom_ms,
                          "first_class": {"kernels": "k_dp_band<16> + <32> + <64> + k_dp<DpTinyJF, 0> + k_dp<DpTiny, 0>", "ms": first_class_ms, "achieved": bpp * args.pairs / (first_class_ms * 1e-3) / 1e9,
                                          "by_kernel_ms": {k: m for k, m in kern[:3]}},
@@ -817,7 +817,7 @@ def long_reads(args, P, synth, w):
         b_read = (rl / 2 + rl) + (32 + 5 * rl + 5 * e_mean * cols) + 7 * cols + 64
         proj_s = float(sum(s_.ms_project for s_ in sts)) * 1e-3
         ach = b_read * n / max(proj_s, 1e-9) / 1e9
-        roof = {"bound": "latency", "bound_note": "the level loop of one wavefront per read (waits most of its cycles); achieved / peak / frac are the HBM figures the metric asks for", "kernel": "k_project_chains<ProjLdsLong>", "kernel_ms_sum": proj_s * 1e3, "algorithmic_bytes_per_read": b_read, "columns_per_read": cols, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+        roof = {"bound": "latency", "bound_note": "one wavefront per read: column passes against its HBM slab and the level loops of the re-threading DP (round 6: long segments level by level out of LDS-staged chunks); achieved / peak / frac are the HBM figures the metric asks for", "kernel": "k_project_chains<ProjLdsLong>", "kernel_ms_sum": proj_s * 1e3, "algorithmic_bytes_per_read": b_read, "columns_per_read": cols, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                 "frac": ach / 8000.0, "traffic": None, "note": "HIP events of the batches' projection stage; the measured HBM traffic and the SQ counters of the kernel: profiles/r0N_long_*"}
         tl = next((f for f in (os.path.join(ROOT, "profiles", t + "_long_traffic.json") for t in ("r06", "r05")) if os.path.exists(f)), "")
         if tl:
