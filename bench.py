@@ -907,6 +907,21 @@ def extras(args, P, synth, w, mk, b, ctx, gb, ckw):
             t = time.perf_counter(); g2.align(); s2 = g2.stats(); dt = time.perf_counter() - t
             ex[name] = {"pairs": ns, "pairs_per_s": ns / dt, "chains_per_pair": sb["n_chains"] / ns, "extended_chains_per_pair": s2.n_chains_extended / ns,
                         "dp_ms_by_class": [float(x) for x in s2.ms_dp_class], "dp_calls_entering_class": [int(x) for x in s2.n_dp_class], "chain_errors": int(s2.n_errors)}
+            # the same batch as the headline's loops run theirs: two resident batch objects alternate, a batch's side-stream tail beside the next one's main stream
+            # (`pairs_per_s` above is ONE batch alone: main stream, then its tail classes one after the other with nothing beside them)
+            try:
+                g3 = ctx.batch(sb); g3.align(); g3.stats()
+                pr = [g2, g3]; nst = 8
+                t = time.perf_counter()
+                for i in range(nst):
+                    pr[i % 2].align()
+                    if i >= 1: pr[(i - 1) % 2].stats()
+                pr[(nst - 1) % 2].stats()
+                dt2 = time.perf_counter() - t
+                ex[name]["pairs_per_s_two_in_flight"] = ns * nst / dt2; ex[name]["steps_two_in_flight"] = nst
+                g3.close()
+            except Exception as e:
+                ex[name]["pairs_per_s_two_in_flight"] = None; ex[name]["two_in_flight_error"] = repr(e)
             g2.close()
     # ---- typer kernels at the size of a real class-I locus (C = 3000 clusters, R = 400 reads, 546 exon columns)
     try:
