@@ -214,8 +214,11 @@ constexpr bool PJ_FINE = false;
 #define LSYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while(0)
 #define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
 
+#ifndef HLALA_PROJ_LONG_WPS
+#define HLALA_PROJ_LONG_WPS 4      // wavefronts per SIMD the long-read instantiation is compiled for (4: 123 registers, nothing spilled)
+#endif
 template <class PL>
-__global__ __launch_bounds__(64, PL::LONG ? 4 : 2) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
+__global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : 2) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
                                                        const int* contig_level, char* slabs, size_t slabBytes, char* longSlabs, size_t longSlabBytes,
                                                        int deferRethread)      // 1: chains that need the chunked form and fit k_rethread_chains are left to it
 {
