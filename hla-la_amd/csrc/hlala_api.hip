@@ -523,7 +523,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_PROJ_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 14) c->proj_grid = cus * w; }      // (experiment: waves of the projection kernel per CU)
     { int rcp = dev_alloc(c, c->allocs, (size_t)2 * c->pair_grid * PAIR_COMB, &c->pair_scratch, false); if(rcp) return fail(rcp); }
     if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
-        c->proj_grid = cus * 16;       // (round 5: 16 waves per CU -- 103 VGPRs, four per SIMD; with 4 per CU the kernel ran one wave per SIMD, waiting 72 % of its cycles: 71 k -> 82 k reads/s in batches of 10 000, 223 k in one batch of 50 000)
+        c->proj_grid = cus * 18;       // (round 6: 18 waves per CU -- 95 VGPRs, five per SIMD, 8.6 KB of LDS each; round 5: 16 waves per CU -- 103 VGPRs, four per SIMD; with 4 per CU the kernel ran one wave per SIMD, waiting 72 % of its cycles: 71 k -> 82 k reads/s in batches of 10 000, 223 k in one batch of 50 000)
         if(const char* e = getenv("HLALA_PROJ_LONG_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 20) c->proj_grid = cus * w; }      // (experiment: waves of the long-read projection per CU)
         c->proj_long_slab_bytes = proj_long_slab_bytes();
         if(!getenv("HLALA_STITCH_DRAW")) c->stitch_draw = 1;       // rows of 16 384 columns: one chain per draw (12: 11.0 ms per 50 000 reads, 1: 8.8; a batch of 12 500: 7.9 -> 4.0 ms)

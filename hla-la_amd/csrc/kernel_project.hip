@@ -214,8 +214,9 @@ constexpr bool PJ_FINE = false;
 #define LSYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while(0)
 #define PJ_OK() (uni(P.err) == 0)      // read at points where every lane has passed a barrier: wave-uniform
 
+constexpr int PJL_U = 4;            // rows of lanes the copy loops of the long-read instantiation keep in flight (registers: the kernel is compiled for five wavefronts per SIMD)
 #ifndef HLALA_PROJ_LONG_WPS
-#define HLALA_PROJ_LONG_WPS 4      // wavefronts per SIMD the long-read instantiation is compiled for (4: 123 registers, nothing spilled)
+#define HLALA_PROJ_LONG_WPS 5      // wavefronts per SIMD the long-read instantiation is compiled for (5: 95 registers, 2 spilled -- with 8.6 KB of LDS 18 blocks per CU; 4: 123 registers, 16 blocks: 50.0 against 46.5 ms per 50 000 reads)
 #endif
 template <class PL>
 __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : 2) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : 2) void k_proj
                 // one lane per COLUMN, PJ_U x 64 columns at a time (a 2 x 150 bp chain in one go): the lane finds the operation of each of its columns among
                 // the (wave-uniform) operations that overlap them, then all gathers are in flight together.  (One operation after the other cost a round
                 // trip of dependent loads per operation -- gene-window alignments carry a dozen --, 64 columns at a time one per 64 columns.)
-                constexpr int PJ_U = 6;
+                constexpr int PJ_U = PL::LONG ? 4 : 6;
                 const int nHere = min(64, nOps - ob);
                 for(int j0 = 0; j0 < tc; j0 += 64 * PJ_U) {
                     int myOp[PJ_U], refB[PJ_U], readB[PJ_U];          // operation of column j0 + 64 u + lane; reference / read offset of the column = base + column
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : 2) void k_proj
             bool any = false; int seqChars = 0;
             const int nW = (n1 + 63) >> 6;
             // (the gap-stretch flags of eight words of columns are requested together: the ballots made each word a round trip of its own)
-            constexpr int PJ_W = 8;
+            constexpr int PJ_W = PL::LONG ? 4 : 8;
             const int nLevelsG = G.L;
             for(int k0 = 0; k0 < nW; k0 += PJ_W) {
                 unsigned char gs[PJ_W]; bool defv[PJ_W], sqv[PJ_W]; int bad = 0;
@@ -655,10 +656,10 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : 2) void k_proj
                         for(int u = 0; u < U3; u++) { const int e = lane + 64 * u; if(e < nEdges) { P.sFrom[e] = (unsigned short)(v3[u].from - nodeBase); P.sLab[e] = v3[u].lab; } }
                     }
                 } else {
-                if(windowed) staged_rows<7>(lane, nDef + 2, 64, [&](int i) { return G.level_off[level0 + i]; }, [&](int i, int v) { P.sLev[i] = (unsigned short)(v - nodeBase); });
+                if(windowed) staged_rows<PJL_U>(lane, nDef + 2, 64, [&](int i) { return G.level_off[level0 + i]; }, [&](int i, int v) { P.sLev[i] = (unsigned short)(v - nodeBase); });
                 if(staged) {
-                    staged_rows<7>(lane, chCount + 1, 64, [&](int i) { return G.in_off[nb + i]; }, [&](int i, int v) { P.sIn[i] = (unsigned short)(v - eBase); });
-                    staged_rows<9>(lane, nEdges, 64, [&](int e) { FromLab r; r.from = G.in_from[eBase + e]; r.lab = G.in_label[eBase + e]; return r; },
+                    staged_rows<PJL_U>(lane, chCount + 1, 64, [&](int i) { return G.in_off[nb + i]; }, [&](int i, int v) { P.sIn[i] = (unsigned short)(v - eBase); });
+                    staged_rows<PJL_U>(lane, nEdges, 64, [&](int e) { FromLab r; r.from = G.in_from[eBase + e]; r.lab = G.in_label[eBase + e]; return r; },
                                    [&](int e, FromLab r) { P.sFrom[e] = (unsigned short)(r.from - nodeBase); P.sLab[e] = r.lab; });
                 }
                 }
@@ -836,21 +837,22 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : 2) void k_proj
                     const int tBase = lvA1, nT = __builtin_amdgcn_readlane(lvA, cnt + 1) - tBase, eC = sgA0, nE = __builtin_amdgcn_readlane(sgA, cnt) - eC;
                     const int lvReg = lvA, sgReg = sgA - eC;
                     {   // the chunk's in-edge records and in-edge offsets: one round trip
-                        constexpr int UE = RT_CE / 64, UN = (RT_SN + 1 + 63) / 64;
                         // (the in-edge offsets of the nodes are only read by the levels that are solved node by node -- mode 0: most chunks have none)
                         const bool needOff = __ballot(lane < cnt && ((ciReg >> 25) & 3u) == 0u) != 0;
-                        u32 ve[UE]; int vn[UN];
-                        #pragma unroll
-                        for(int u = 0; u < UE; u++) { const int e = lane + 64 * u; if(e < nE) ve[u] = G.in_rec[eC + e]; }
-                        if(needOff) {
+                        // (four rows of lanes per round trip: a chunk of backbone levels has one, a chunk in a gene window up to eight)
+                        for(int e0 = 0; e0 < nE; e0 += 4 * 64) {
+                            u32 ve[4];
                             #pragma unroll
-                            for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) vn[u] = G.in_off[tBase + t]; }
+                            for(int u = 0; u < 4; u++) { const int e = e0 + lane + 64 * u; if(e < nE) ve[u] = G.in_rec[eC + e]; }
+                            #pragma unroll
+                            for(int u = 0; u < 4; u++) { const int e = e0 + lane + 64 * u; if(e < nE) P.cRec[e] = ve[u]; }
                         }
-                        #pragma unroll
-                        for(int u = 0; u < UE; u++) { const int e = lane + 64 * u; if(e < nE) P.cRec[e] = ve[u]; }
-                        if(needOff) {
+                        if(needOff) for(int t0 = 0; t0 <= nT; t0 += 4 * 64) {
+                            int vn[4];
                             #pragma unroll
-                            for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t <= nT) P.cIn[t] = (unsigned short)(vn[u] - eC); }
+                            for(int u = 0; u < 4; u++) { const int t = t0 + lane + 64 * u; if(t <= nT) vn[u] = G.in_off[tBase + t]; }
+                            #pragma unroll
+                            for(int u = 0; u < 4; u++) { const int t = t0 + lane + 64 * u; if(t <= nT) P.cIn[t] = (unsigned short)(vn[u] - eC); }
                         }
                     }
                     WSYNC();
@@ -1268,12 +1270,14 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : 2) void k_proj
                         const int sgA = i0 <= bb ? G.in_off[lvB] - eBase : 0;
                         const int tBase = __builtin_amdgcn_readlane(lvA, 1), nT = __builtin_amdgcn_readlane(lvA, bb - aa + 2) - tBase;
                         {
-                            constexpr int UN = RT_CE / 64;          // (a chunk holds at most RT_SN nodes, a level on its own at most PROJ_NODES = RT_CE)
-                            u32 vr[UN];
-                            #pragma unroll
-                            for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t < nT) vr[u] = chw[tBase + t - nb]; }
-                            #pragma unroll
-                            for(int u = 0; u < UN; u++) { const int t = lane + 64 * u; if(t < nT) P.cRec[t] = vr[u]; }
+                            // (a chunk holds at most RT_SN nodes, a level on its own at most PROJ_NODES = RT_CE)
+                            for(int t0 = 0; t0 < nT; t0 += 4 * 64) {
+                                u32 vr[4];
+                                #pragma unroll
+                                for(int u = 0; u < 4; u++) { const int t = t0 + lane + 64 * u; if(t < nT) vr[u] = chw[tBase + t - nb]; }
+                                #pragma unroll
+                                for(int u = 0; u < 4; u++) { const int t = t0 + lane + 64 * u; if(t < nT) P.cRec[t] = vr[u]; }
+                            }
                         }
                         WSYNC();
                         for(int i = bb; i >= aa; i--) {
@@ -1287,7 +1291,7 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : 2) void k_proj
                     }
                     WSYNC(); PJ_F(7);
                     if constexpr (PL::LONG) {
-                    staged_rows<6>(lane, n1, 64, [&](int j) { const int pe = pick[j]; FromLab r; r.from = -1; r.lab = '_';
+                    staged_rows<PJL_U>(lane, n1, 64, [&](int j) { const int pe = pick[j]; FromLab r; r.from = -1; r.lab = '_';
                                                               if(pe >= 0) { r.from = G.in_eid[eBase + pe]; r.lab = G.in_label[eBase + pe]; } return r; },
                         [&](int j, FromLab r) {
                             B.seed_level[cb + j] = r.from < 0 ? -1 : LC::get(P.lvl[cur][j], lvBase); B.seed_edge[cb + j] = r.from; B.seed_g[cb + j] = r.lab;
