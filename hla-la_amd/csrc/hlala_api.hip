@@ -509,6 +509,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     c->ext_slab_bytes = dp_slab_bytes<DpSmall>() > dp_slab_bytes<DpWide>() ? dp_slab_bytes<DpSmall>() : dp_slab_bytes<DpWide>();
     c->large_slab_bytes = dp_slab_bytes<DpLarge>() > dp_slab_bytes<DpBroad>() ? dp_slab_bytes<DpLarge>() : dp_slab_bytes<DpBroad>();       // one / three blocks per CU: a few MB each
     c->huge_grid = cus / 4 > 0 ? cus / 4 : 1;      // the in-memory backstop class: a handful of DP calls per million pairs
+    if(const char* e = getenv("HLALA_DP_HUGE_BLOCKS")) { const int v = atoi(e); if(v >= 1 && v <= 2 * cus) c->huge_grid = v; }      // (experiment: blocks of the in-memory class -- 128 calls per million pairs on 64 blocks run in two rounds)
     c->huge_slab_bytes = dp_inmemory_bytes<DpHuge>();
     if((rc = slab_pool(&c->tiny_slabs, c->tiny_slab_bytes * (size_t)(64 / DpTiny::GW) * (size_t)(c->tiny_grid > c->jf_grid ? c->tiny_grid : c->jf_grid), "16-lane DP slabs"))) return fail(rc);
     if((rc = slab_pool(&c->mid_slabs, c->mid_slab_bytes * (size_t)(64 / DpMid::GW) * (size_t)c->mid_grid, "32-lane DP slabs"))) return fail(rc);

@@ -218,8 +218,11 @@ constexpr int PJL_U = 4;            // rows of lanes the copy loops of the long-
 #ifndef HLALA_PROJ_LONG_WPS
 #define HLALA_PROJ_LONG_WPS 5      // wavefronts per SIMD the long-read instantiation is compiled for (5: 95 registers, 2 spilled -- with 8.6 KB of LDS 18 blocks per CU; 4: 123 registers, 16 blocks: 50.0 against 46.5 ms per 50 000 reads)
 #endif
+#ifndef HLALA_PROJ_WPS
+#define HLALA_PROJ_WPS 2           // the LDS layouts: the compiler's own choice (153 registers = three wavefronts per SIMD; their 11.7 KB of LDS allow 13 blocks per CU)
+#endif
 template <class PL>
-__global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : 2) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
+__global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : HLALA_PROJ_WPS) void k_project_chains(const DevGraph* __restrict__ Gp, const DevBatch* __restrict__ Bp, const long long* contig_off, const uint8_t* contig_seq,
                                                        const int* contig_level, char* slabs, size_t slabBytes, char* longSlabs, size_t longSlabBytes,
                                                        int deferRethread)      // 1: chains that need the chunked form and fit k_rethread_chains are left to it
 {
