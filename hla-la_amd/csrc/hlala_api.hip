@@ -524,7 +524,7 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     if(const char* e = getenv("HLALA_PROJ_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 14) c->proj_grid = cus * w; }      // (experiment: waves of the projection kernel per CU)
     { int rcp = dev_alloc(c, c->allocs, (size_t)2 * c->pair_grid * PAIR_COMB, &c->pair_scratch, false); if(rcp) return fail(rcp); }
     if(c->params.max_columns > PROJ_CAP) {       // long reads: the projection keeps its column / window arrays in HBM, fewer and bigger blocks
-        c->proj_grid = cus * 18;       // (round 6: 18 waves per CU -- 95 VGPRs, five per SIMD, 8.6 KB of LDS each; round 5: 16 waves per CU -- 103 VGPRs, four per SIMD; with 4 per CU the kernel ran one wave per SIMD, waiting 72 % of its cycles: 71 k -> 82 k reads/s in batches of 10 000, 223 k in one batch of 50 000)
+        c->proj_grid = cus * 20;       // (round 6: 20 waves per CU -- 95 VGPRs, five per SIMD, 6.3 KB of LDS each; round 5: 16 waves per CU -- 103 VGPRs, four per SIMD; with 4 per CU the kernel ran one wave per SIMD, waiting 72 % of its cycles: 71 k -> 82 k reads/s in batches of 10 000, 223 k in one batch of 50 000)
         if(const char* e = getenv("HLALA_PROJ_LONG_WAVES")) { const int w = atoi(e); if(w >= 1 && w <= 20) c->proj_grid = cus * w; }      // (experiment: waves of the long-read projection per CU)
         c->proj_long_slab_bytes = proj_long_slab_bytes();
         if(!getenv("HLALA_STITCH_DRAW")) c->stitch_draw = 1;       // rows of 16 384 columns: one chain per draw (12: 11.0 ms per 50 000 reads, 1: 8.8; a batch of 12 500: 7.9 -> 4.0 ms)
@@ -558,7 +558,11 @@ int hlala_create(hlala_ctx** out, int device, void* stream, const hlala_graph_de
     //  behind each other's, and the clocks they were meant to read showed that queue)
     if(getenv("HLALA_DEBUG")) { if(hipMalloc((void**)&c->dbg_host, 8192 * sizeof(int)) != hipSuccess) c->dbg_host = nullptr; else { (void)hipMemset(c->dbg_host, 0, 8192 * sizeof(int)); c->allocs.push_back(c->dbg_host); } }
     if(hipEventCreateWithFlags(&c->evSideTail, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(HLALA_E_DEVICE); }
-    if(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); }
+    { int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);       // (numerically greatest = lowest priority)
+      // the upload and the reader stream carry copies and a few small kernels (filters, position order, unpacking; export, packing) that the host WAITS for beside the
+      // persistent kernels of the alignment streams: highest priority, so that they get the first wave slots that come free (HLALA_IO_PRIORITY=normal: as before round 6)
+      int prIo = prHigh; if(const char* e = getenv("HLALA_IO_PRIORITY")) { if(!strcmp(e, "normal")) prIo = (prLow + prHigh) / 2; else if(!strcmp(e, "low")) prIo = prLow; }
+      if(hipStreamCreateWithPriority(&c->up, hipStreamNonBlocking, prIo) != hipSuccess || hipStreamCreateWithPriority(&c->rs, hipStreamNonBlocking, prIo) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); } }
     { int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);       // (numerically greatest = lowest priority)
       int pr = prLow; if(const char* e = getenv("HLALA_SIDE_PRIORITY")) { if(!strcmp(e, "high")) pr = prHigh; else if(!strcmp(e, "normal")) pr = (prLow + prHigh) / 2; }      // (tools/gpu_side_prio.sh)
       if(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, pr) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(HLALA_E_DEVICE); } }

@@ -74,17 +74,16 @@ struct __align__(16) ProjLdsLong {
     static constexpr int CE = PROJL_SE;
     GPtr<int> lvl[2];                       // (GPtr: device_common.h -- accesses are global_load / global_store, not flat)
     GPtr<unsigned char> g[2], s[2];
-    short Srow[2][PROJ_NODES];
     GPtr<unsigned short> sLev, sIn, sChoice, sFrom; GPtr<unsigned char> sLab;
     GPtr<u32> colInfo; GPtr<unsigned short> segStart;
+    GPtr<unsigned long long> chunkStart;     // [CAP / 64] bitmap of the levels at which a chunk of the level-by-level form started: bits set with atomics, read with atomic loads (the L1 may hold the last read's words)
     union {
         struct { u64 mGap[PROJL_CAP / 64], mDef[PROJL_CAP / 64], mSeq[PROJL_CAP / 64]; };      // column bit masks of the clean / restrict steps: in LDS (6 KB) -- the scalar walks over them are chains of dependent reads (round 6: they were in the slab)
-        // the level-by-level form of the re-threading DP (reads that cross a gene window; the masks are dead by then): where its chunks of levels start, a chunk's in-edge
-        // records and in-edge offsets -- as in k_rethread_chains
-        struct { u64 chunkStart[PROJL_CAP / 64]; u32 cRec[RT_CE]; unsigned short cIn[RT_SN + 2]; };
+        // the re-threading DP (the masks are dead by then): the score rows of the level loops, a chunk's in-edge records and in-edge offsets -- as in k_rethread_chains --, and the
+        // level ranges that go through the level-by-level form (the long segments of a read, or the whole read).  6.3 KB of LDS per block in all: 20 blocks per CU at five per SIMD.
+        struct { short Srow[2][PROJ_NODES]; u32 cRec[RT_CE]; unsigned short cIn[RT_SN + 2]; int longSeg[2 * PROJL_LONGSEG]; };
     };
     short* sflatp;
-    int longSeg[2 * PROJL_LONGSEG];          // level ranges that go through the level-by-level form: the long segments of a read, or the whole read
     int err, n, startRaw, stopRaw, tmp0, tmp1;
     __device__ __forceinline__ HLALA_AS_GLOBAL short* sflat() { return glob(sflatp); }
 };
@@ -99,7 +98,7 @@ __host__ __device__ inline size_t proj_long_slab_bytes()
 template <int CAP_, int SN_, int SE_> __device__ inline void proj_bind(ProjLdsT<CAP_, SN_, SE_>&, char*) { }
 __device__ inline void proj_bind(ProjLdsLong& P, char* p)      // 8-byte arrays first, then 4-, 2-, 1-byte ones
 {
-    p += 3 * (size_t)(PROJL_CAP / 64) * 8;       // (the masks lived here until round 6)
+    P.chunkStart = (unsigned long long*)p; p += 3 * (size_t)(PROJL_CAP / 64) * 8;       // (the masks lived here until round 6: the first third is the chunk bitmap now)
     P.lvl[0] = (int*)p; p += (size_t)PROJL_CAP * 4; P.lvl[1] = (int*)p; p += (size_t)PROJL_CAP * 4; P.colInfo = (u32*)p; p += (size_t)PROJL_CAP * 4;
     P.sLev = (unsigned short*)p; p += ((size_t)PROJL_CAP + 2) * 2; P.segStart = (unsigned short*)p; p += ((size_t)PROJL_CAP + 2) * 2;
     P.sIn = (unsigned short*)p; p += ((size_t)PROJL_SN + 2) * 2; P.sChoice = (unsigned short*)p; p += (size_t)PROJL_SN * 2; P.sflatp = (short*)p; p += (size_t)PROJL_SN * 2; P.sFrom = (unsigned short*)p; p += (size_t)PROJL_SE * 2;
@@ -778,6 +777,7 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : HLALA_PROJ_WPS
                 const int chunkNodes = B.long_chunk_nodes > 0 ? min(RT_SN, B.long_chunk_nodes) : RT_SN;
                 if(chCount > 2 * slabEnt) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_FRONTIER); }
                 for(int i = lane; i < PROJL_CAP / 64; i += 64) P.chunkStart[i] = 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the bits are set with atomics at the L2: the zeroes must be there first)
                 WSYNC();
                 for(int rq = 0; rq < nLong && PJ_OK(); rq++) {
                 const int ra = uni(P.longSeg[2 * rq]), rb = uni(P.longSeg[2 * rq + 1]);
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : HLALA_PROJ_WPS
                     const bool fits = i0 < rb && lane < 62 && (lvC - lvA1) <= chunkNodes && (sgB - sgA0) <= RT_CE;
                     const u64 fm = __ballot(fits);
                     const int cnt = __ffsll((long long)~fm) - 1;                               // levels a .. a + cnt - 1 fit together (a prefix: both sums grow)
-                    if(lane == 0) P.chunkStart[a >> 6] |= 1ull << (a & 63);
+                    if(lane == 0) atomicOr(P.chunkStart.p + (a >> 6), 1ull << (a & 63));
                     if(cnt == 0) {
                         // one level wider than the staging arrays: node by node, straight from HBM
                         const u32 ci = (u32)__builtin_amdgcn_readlane((int)ciReg, 0);
@@ -1263,8 +1263,8 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : HLALA_PROJ_WPS
                     const int ra = uni(P.longSeg[2 * rq]), rb = uni(P.longSeg[2 * rq + 1]);
                     int z = rb == nDef ? zsel : 0;
                     for(int bb = rb - 1; bb >= ra; ) {
-                        int w = bb >> 6; u64 m = P.chunkStart[w] & (~0ull >> (63 - (bb & 63)));
-                        while(m == 0) { w--; m = P.chunkStart[w]; }                            // (the range's first level starts a chunk)
+                        int w = bb >> 6; u64 m = __hip_atomic_load(P.chunkStart.p + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (~0ull >> (63 - (bb & 63)));
+                        while(m == 0) { w--; m = __hip_atomic_load(P.chunkStart.p + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // (the range's first level starts a chunk)
                         const int aa = w * 64 + 63 - __clzll((long long)m);
                         const int i0 = aa + lane;
                         const int lvA = i0 <= nDef + 1 ? G.level_off[level0 + i0] : 0;
