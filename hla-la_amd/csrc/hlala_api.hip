@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <chrono>
+#include <thread>
 #include <set>
 #include <string>
 #include <unordered_map>
@@ -87,6 +89,7 @@ struct hlala_ctx {
     char* rethread_slabs = nullptr; size_t rethread_slab_bytes = 0; int rethread_grid = 0;      // k_rethread_chains: back pointers of one chain per wave (short reads; HLALA_RETHREAD=0 turns the kernel off)
     double* pair_scratch = nullptr;   // [2 * pair_grid][PAIR_COMB]: combination tables of the rare pairs with more than PAIR_COMB_LDS combinations (main- and side-stream pass)
     char* proj_long_slabs = nullptr; size_t proj_long_slab_bytes = 0;      // long reads only (max_columns > 512): column / window arrays of k_project_chains<ProjLdsLong>
+    void* create_scratch = nullptr; size_t create_scratch_bytes = 0; bool create_scratch_pinned = false;      // host scratch of hlala_batch_create (page-locked when the runtime grants it; one caller thread per context)
     int proj_long_stagger = 0;              // long-read projection: wavefront w starts (w mod 64) x this many cycles after the kernel does (HLALA_PROJ_LONG_STAGGER; k_project_chains)
     int long_chunk_nodes = 1 << 20, long_max_segs = 1 << 20;      // (batch.h; the kernel clamps them to its array sizes)
     int order_cost = 0;                     // long-read layout: heaviest windows first (batch.h: order_cost; HLALA_LONG_ORDER=0: position order)
@@ -580,6 +583,7 @@ void hlala_destroy(hlala_ctx* c)
     if(!c->tail.empty()) (void)flush_tail(c);
     for(hlala_batch* b : c->batches) b->ctx = nullptr;       // a batch that outlives its context frees its own buffers
     for(void* p : c->allocs) if(p) (void)hipFree(p);
+    if(c->create_scratch) { if(c->create_scratch_pinned) (void)hipHostFree(c->create_scratch); else free(c->create_scratch); }
     for(hlala_ctx::KeptReads& kr : c->kept) { (void)hipFree(kr.store); (void)hipFree(kr.start); (void)hipFree(kr.length); }
     for(auto& kv : c->pool) (void)hipFree(kv.second);
     if(c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
@@ -682,11 +686,13 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
     *out = nullptr;
     if(in->n_pairs < 0 || in->n_chains < 0) { c->err = "negative batch sizes"; return HLALA_E_ARG; }
     if(!c->d_contig_off) { c->err = "hlala_batch_create needs contigs (hlala_create was called without them)"; return HLALA_E_STATE; }
+    static const bool hostTiming = getenv("HLALA_HOST_TIMING") != nullptr;       // (stderr: where hlala_batch_create spends the host thread's time)
+    const auto tc0 = std::chrono::steady_clock::now(); auto tc1 = tc0, tc2 = tc0;
     hlala_batch* b = new hlala_batch(); b->ctx = c; c->batches.insert(b);
     DevBatch& B = b->B;
     B.n_pairs = in->n_pairs; B.n_reads = (unpaired ? 1 : 2) * in->n_pairs; B.n_chains = in->n_chains; B.stride = c->params.max_columns; B.from_seeds = 0; B.unpaired = unpaired ? 1 : 0;
     int nr = B.n_reads, nc = B.n_chains;
-    auto fail = [&](int rc) { hlala_batch_destroy(b); return rc; };
+    auto fail = [&](int rc) { (void)hipStreamSynchronize(c->active); hlala_batch_destroy(b); return rc; };      // (uploads already queued -- from the caller's arrays, from the context's scratch -- end before their blocks go back to the pool)
     // the batch is a window into the caller's arrays (include/hlala_gpu.h: hlala_batch_in): 64-bit offsets that need not start at 0 are rebased here
     const int64_t rb0 = nr > 0 ? in->read_off[0] : 0, cb0 = nr > 0 ? in->chain_off[0] : 0;
     if(nr > 0) {
@@ -698,32 +704,80 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
     if(nc > 0) { const int64_t ng64 = in->cigar_off[cb0 + nc] - gb0; if(ng64 < 0) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
                  if(ng64 > 0x7FFFFFFFll) { c->err = "batch of " + std::to_string(ng64) + " CIGAR operations: one batch holds at most 2^31 - 1"; return fail(HLALA_E_CAPACITY); } }
     b->first_chain = (uint32_t)cb0;
-    // validation the reference would assert on
-    std::vector<int> chain_read((size_t)nc), read_off32((size_t)nr + 1), chain_off32((size_t)nr + 1), primary32((size_t)nr), cigar_off32((size_t)nc + 1);
-    for(int r = 0; r < nr; r++) if(in->read_off[r + 1] < in->read_off[r] || in->chain_off[r + 1] < in->chain_off[r]) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
-    for(int r = 0; r <= nr && nr > 0; r++) { read_off32[r] = (int)(in->read_off[r] - rb0); chain_off32[r] = (int)(in->chain_off[r] - cb0); }
-    for(int r = 0; r < nr; r++) {
-        if(chain_off32[r + 1] <= chain_off32[r]) { c->err = "read without alignments"; return fail(HLALA_E_ARG); }
-        if(read_off32[r + 1] < read_off32[r]) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
-        const int64_t pr = (int64_t)in->read_primary[r] - cb0;
-        if(pr < chain_off32[r] || pr >= chain_off32[r + 1]) { c->err = "read_primary outside the read's chains"; return fail(HLALA_E_ARG); }
-        primary32[r] = (int)pr;
-        for(int k = chain_off32[r]; k < chain_off32[r + 1]; k++) chain_read[k] = r;
+    // validation the reference would assert on, and the 32-bit arrays of the window (offsets rebased, the read of every chain).  Round 6: two fused passes -- one over the reads, one over
+    // the chains -- on a few host threads into page-locked scratch of the context (five passes on the calling thread into fresh vectors before: 30 ms of hlala_batch_create's 75 for a
+    // 1 M-pair batch, and their uploads from pageable memory were staged copies the caller waited for).  The FIRST violation in the order of the old passes is the one reported.
+    int* chain_read = nullptr; int* read_off32 = nullptr; int* chain_off32 = nullptr; int* primary32 = nullptr; int* cigar_off32 = nullptr;
+    {
+        const size_t need = ((size_t)nc + (size_t)nr + 1 + (size_t)nr + 1 + (size_t)nr + (size_t)nc + 1 + 16) * sizeof(int);
+        if(need > c->create_scratch_bytes) {
+            if(c->create_scratch) { if(c->create_scratch_pinned) (void)hipHostFree(c->create_scratch); else free(c->create_scratch); c->create_scratch = nullptr; c->create_scratch_bytes = 0; }
+            const size_t want = need + need / 8;
+            void* p = nullptr;
+            if(hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess) c->create_scratch_pinned = true;
+            else { (void)hipGetLastError(); p = malloc(want); c->create_scratch_pinned = false; }
+            if(!p) { c->err = "out of host memory (batch scratch)"; return fail(HLALA_E_ARG); }
+            c->create_scratch = p; c->create_scratch_bytes = want;
+        }
+        int* q = (int*)c->create_scratch;
+        chain_read = q; q += nc; read_off32 = q; q += (size_t)nr + 1; chain_off32 = q; q += (size_t)nr + 1; primary32 = q; q += nr; cigar_off32 = q;
     }
-    for(int k = 0; k < nc; k++) if(in->cigar_off[cb0 + k + 1] < in->cigar_off[cb0 + k]) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
-    for(int k = 0; k <= nc && nc > 0; k++) cigar_off32[k] = (int)(in->cigar_off[cb0 + k] - gb0);
     const int32_t* w_contig = in->chain_contig + cb0; const int32_t* w_pos = in->chain_pos + cb0; const int32_t* w_offset = in->chain_offset + cb0; const int32_t* w_as = in->chain_as + cb0;
     const uint8_t* w_rev = in->chain_reverse + cb0;
-    for(int k = 0; k < nc; k++) if(w_contig[k] < 0 || w_contig[k] >= c->n_contigs) { c->err = "chain_contig out of range"; return fail(HLALA_E_ARG); }
-    // the extension DP of paired reads keys its cells with a 12-bit read coordinate (kernel_dp.hip: mk_key): longer reads belong in an unpaired batch
-    if(!unpaired) for(int r = 0; r < nr; r++) if(read_off32[r + 1] - read_off32[r] > DP_SEQCAP) {
-        c->err = "paired read of " + std::to_string(read_off32[r + 1] - read_off32[r]) + " bases: the paired path holds reads of at most " + std::to_string(DP_SEQCAP) + " (use hlala_batch_create_unpaired for long reads)";
-        return fail(HLALA_E_CAPACITY);
+    {
+        // violations by the pass that used to find them: 0 offsets of a read not ascending, 1 per-read checks (the smallest read decides, then the order of the checks within it),
+        // 2 CIGAR offsets not ascending, 3 contig out of range, 4 paired read too long
+        struct Viol { long long at[5]; int kind1; };
+        const int nt = (nr + nc) >= (1 << 18) ? 4 : 1;
+        std::vector<Viol> viol((size_t)nt);
+        const int n_contigs = c->n_contigs;
+        auto work = [&](int t) {
+            Viol v; for(int i = 0; i < 5; i++) v.at[i] = -1; v.kind1 = 0;
+            const int r0 = (int)((long long)nr * t / nt), r1 = (int)((long long)nr * (t + 1) / nt);
+            for(int r = r0; r < r1; r++) {
+                const int64_t ro0 = in->read_off[r] - rb0, ro1 = in->read_off[r + 1] - rb0, co0 = in->chain_off[r] - cb0, co1 = in->chain_off[r + 1] - cb0;
+                if((ro1 < ro0 || co1 < co0) && v.at[0] < 0) v.at[0] = r;
+                read_off32[r] = (int)ro0; chain_off32[r] = (int)co0;
+                int kind = 0;
+                if((int)co1 <= (int)co0) kind = 1;                         // read without alignments
+                else if((int)ro1 < (int)ro0) kind = 2;                     // inconsistent batch offsets
+                const int64_t pr = (int64_t)in->read_primary[r] - cb0;
+                if(!kind && (pr < (int)co0 || pr >= (int)co1)) kind = 3;    // read_primary outside the read's chains
+                if(kind && v.at[1] < 0) { v.at[1] = r; v.kind1 = kind; }
+                primary32[r] = (int)pr;
+                if(co0 >= 0 && co1 <= (int64_t)nc) for(int64_t k = co0; k < co1; k++) chain_read[k] = r;
+                if(!unpaired && (int)ro1 - (int)ro0 > DP_SEQCAP && v.at[4] < 0) v.at[4] = r;
+            }
+            const int k0 = (int)((long long)nc * t / nt), k1 = (int)((long long)nc * (t + 1) / nt);
+            for(int k = k0; k < k1; k++) {
+                if(in->cigar_off[cb0 + k + 1] < in->cigar_off[cb0 + k] && v.at[2] < 0) v.at[2] = k;
+                cigar_off32[k] = (int)(in->cigar_off[cb0 + k] - gb0);
+                if((w_contig[k] < 0 || w_contig[k] >= n_contigs) && v.at[3] < 0) v.at[3] = k;
+            }
+            viol[(size_t)t] = v;
+        };
+        if(nt == 1) work(0);
+        else { std::vector<std::thread> th; for(int t = 1; t < nt; t++) th.emplace_back(work, t); work(0); for(std::thread& x : th) x.join(); }
+        if(nr > 0) { read_off32[nr] = (int)(in->read_off[nr] - rb0); chain_off32[nr] = (int)(in->chain_off[nr] - cb0); }
+        if(nc > 0) cigar_off32[nc] = (int)(in->cigar_off[cb0 + nc] - gb0);
+        long long first[5] = {-1, -1, -1, -1, -1}; int kind1 = 0;
+        for(int t = 0; t < nt; t++) for(int i = 0; i < 5; i++) if(viol[(size_t)t].at[i] >= 0 && (first[i] < 0 || viol[(size_t)t].at[i] < first[i])) { first[i] = viol[(size_t)t].at[i]; if(i == 1) kind1 = viol[(size_t)t].kind1; }
+        if(first[0] >= 0) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
+        if(first[1] >= 0) { c->err = kind1 == 1 ? "read without alignments" : (kind1 == 2 ? "inconsistent batch offsets" : "read_primary outside the read's chains"); return fail(HLALA_E_ARG); }
+        if(first[2] >= 0) { c->err = "inconsistent batch offsets"; return fail(HLALA_E_ARG); }
+        if(first[3] >= 0) { c->err = "chain_contig out of range"; return fail(HLALA_E_ARG); }
+        // the extension DP of paired reads keys its cells with a 12-bit read coordinate (kernel_dp.hip: mk_key): longer reads belong in an unpaired batch
+        if(first[4] >= 0) {
+            const int r = (int)first[4];
+            c->err = "paired read of " + std::to_string(read_off32[r + 1] - read_off32[r]) + " bases: the paired path holds reads of at most " + std::to_string(DP_SEQCAP) + " (use hlala_batch_create_unpaired for long reads)";
+            return fail(HLALA_E_CAPACITY);
+        }
     }
     size_t nbases = nr ? (size_t)read_off32[nr] : 0, ncig = nc ? (size_t)cigar_off32[nc] : 0;
     int rc = 0;
+    tc1 = std::chrono::steady_clock::now();
 #define UPB(field, ptr, n) do { rc = dev_upload(c, b->allocs, (ptr), (n), (std::remove_const<std::remove_pointer<decltype(B.field)>::type>::type**)&B.field); if(rc) return fail(rc); } while(0)
-    UPB(read_off, read_off32.data(), (size_t)nr + 1); UPB(read_quals, in->read_quals + rb0, nbases);
+    UPB(read_off, read_off32, (size_t)nr + 1); UPB(read_quals, in->read_quals + rb0, nbases);
     if(in->read_bases_packed && nr > 0) {
         // 4-bit packed bases (half the upload): read R of the sample starts at byte (base offset + R + 1) >> 1; unpacked on the device into the array the kernels read
         const int64_t R0 = in->first_read;
@@ -739,11 +793,11 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
         if(!in->read_bases && nbases > 0) { c->err = "neither read_bases nor read_bases_packed"; return fail(HLALA_E_ARG); }
         UPB(read_bases, in->read_bases + rb0, nbases);
     }
-    UPB(chain_off, chain_off32.data(), (size_t)nr + 1); UPB(read_primary, primary32.data(), (size_t)nr);
-    UPB(chain_read, chain_read.data(), (size_t)nc);
+    UPB(chain_off, chain_off32, (size_t)nr + 1); UPB(read_primary, primary32, (size_t)nr);
+    UPB(chain_read, chain_read, (size_t)nc);
     UPB(chain_contig, w_contig, (size_t)nc); UPB(chain_pos, w_pos, (size_t)nc); UPB(chain_offset, w_offset, (size_t)nc);
     UPB(chain_as, w_as, (size_t)nc); UPB(chain_reverse, w_rev, (size_t)nc);
-    UPB(cigar_off, cigar_off32.data(), (size_t)nc + 1); UPB(cigar, in->cigar + gb0, ncig);
+    UPB(cigar_off, cigar_off32, (size_t)nc + 1); UPB(cigar, in->cigar + gb0, ncig);
 #undef UPB
     // The OUTPUT arrays are allocated by the first stage call (ensure_outputs): a caller that uploads batch i+2 while batches i and i+1 are aligned and read back
     // (two alignments in flight, one upload ahead) then holds the inputs of three batches -- 0.9 GB each -- but the outputs of two, and the outputs of the batch it
@@ -767,7 +821,10 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
         { hipError_t el = hipGetLastError(); if(el != hipSuccess) { c->err = std::string("k_order_scatter: ") + hipGetErrorString(el); return fail(HLALA_E_DEVICE); } }
         HIP_TRY_F(c, hipMemcpyAsync(&b->n_rows_host, B.order_hist + (B.order_nb - 1), sizeof(int), hipMemcpyDeviceToHost, c->active), fail);
     }
+    tc2 = std::chrono::steady_clock::now();
     HIP_TRY_F(c, hipStreamSynchronize(c->active), fail);
+    if(hostTiming) { const auto tc3 = std::chrono::steady_clock::now(); auto ms = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
+                     fprintf(stderr, "hlala_batch_create: checks and rebasing %.1f ms, allocations + uploads + kernels queued %.1f ms, waiting for the upload stream %.1f ms\n", ms(tc1 - tc0), ms(tc2 - tc1), ms(tc3 - tc2)); }
     if(b->prepared) {
         if(b->n_rows_host < 0 || b->n_rows_host > nc) { c->err = "position order counted " + std::to_string(b->n_rows_host) + " chains of " + std::to_string(nc); return fail(HLALA_E_DEVICE); }
         B.n_rows = b->n_rows_host;        // (the device descriptor gets it with the output arrays: ensure_outputs)
