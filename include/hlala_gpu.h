@@ -213,7 +213,9 @@ typedef struct {
 /* Upload a batch: inputs become resident in HBM; nothing is computed.  Paired reads of more than 1024 bases are refused
  * (HLALA_E_CAPACITY): the extension DP keys its cells with a 12-bit read coordinate; long reads go through hlala_batch_create_unpaired.
  * Returns when the caller's buffers have been read.  The OUTPUT arrays of the batch (50 GB per million pairs) are allocated by its first stage call
- * (hlala_project_chains / hlala_align_batch), not here: a batch that is only uploaded costs its inputs. */
+ * (hlala_project_chains / hlala_align_batch), not here: a batch that is only uploaded costs its inputs.
+ * The checks of the offsets (the reference's asserts) and their rebasing run on up to four host threads into page-locked scratch of the context: 5 ms for a batch of a million pairs
+ * (round 6; 30 ms on the calling thread before).  One caller thread per context at a time. */
 int  hlala_batch_create(hlala_ctx* ctx, const hlala_batch_in* in, hlala_batch** out);
 /* Long-read / unpaired mode (processBAM::alignOneLongRead, mapper/processBAM.cpp:3618-3838, and
  * assignMappingQualities_unpaired, :3900-4059): `in->n_pairs` is the number of READS, every array that is per read
