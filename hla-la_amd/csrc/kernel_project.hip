@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : HLALA_PROJ_WPS
         long long tFine0[12], tSub0[4]; int dbgN[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (HLALA_DEBUG) what a heavy read looked like: operations, columns, padded columns, levels, window nodes, segments, long ranges, form
         if constexpr (PL::LONG && PJ_FINE) if(B.dbg) { for(int i = 0; i < 12; i++) tFine0[i] = tFine[i]; for(int i = 0; i < 4; i++) tSub0[i] = tSub[i]; }
 
-        PJ_T(0);
+        PJ_T(0); PJ_F(-1);
         // ---------------- CIGAR walk (transformBAMreadToInternalAlignment, :4794-5337)
         // Columns are the M/=/X/D/I operations in CIGAR order: M -> (ref, read), D -> (ref, '_'), I -> (-1, '_', read);
         // S advances the read index, H only counts at the very start (:4868-4874), P is dropped (:4814-4828), N throws (:5167).
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : HLALA_PROJ_WPS
             else if(lane == 0) { P.startRaw = firstStart; P.stopRaw = lastRS + (lastUse ? lastLen : 0) - 1; }
             if(nCols > PL::CAP || nCols > stride) { if(lane == 0) PJ_FAIL(HLALA_CHAIN_ERR_COLUMNS); }
         }
-        WSYNC();
+        WSYNC(); PJ_F(9);
         if(PJ_OK()) {
             // pass 2: columns.  M/=/X/D/I operations in CIGAR order: M -> (ref, read), D -> (ref, '_'), I -> (-1, '_', read)
             int baseCol = 0, baseRef = 0, baseRead = 0, leadH = 0;
@@ -371,6 +371,23 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : HLALA_PROJ_WPS
                     int myOp[PJ_U], refB[PJ_U], readB[PJ_U];          // operation of column j0 + 64 u + lane; reference / read offset of the column = base + column
                     #pragma unroll
                     for(int u = 0; u < PJ_U; u++) { myOp[u] = -1; refB[u] = 0; readB[u] = 0; }
+                    if constexpr (PL::LONG) {
+                        // Long reads carry thousands of operations: every round of 64 walked all of them once per block of columns, a chain of scalar reads and branches
+                        // (1.8 M of a read's 10 M cycles).  The operations' first columns ascend over the lanes, so each lane finds the operation of its column by bisection --
+                        // six lane permutes -- and fetches its fields with four more.  (An operation without columns shares its first column with the next one: the LAST
+                        // operation that starts at or before a column is the one that holds it.)
+                        const int colRel = opCol - baseCol;
+                        #pragma unroll
+                        for(int u = 0; u < PJ_U; u++) {
+                            const int jr = j0 + 64 * u + lane;
+                            int lo = 0;
+                            #pragma unroll
+                            for(int step = 32; step >= 1; step >>= 1) { const int cand = lo + step; const int v = __builtin_amdgcn_ds_bpermute(cand << 2, colRel); if(v <= jr) lo = cand; }
+                            const int op = __builtin_amdgcn_ds_bpermute(lo << 2, opK), olen = __builtin_amdgcn_ds_bpermute(lo << 2, opLen), ocs = __builtin_amdgcn_ds_bpermute(lo << 2, colRel);
+                            const int orf = __builtin_amdgcn_ds_bpermute(lo << 2, opRef), ord = __builtin_amdgcn_ds_bpermute(lo << 2, opRead);
+                            if(jr < tc && (op == 0 || op == 7 || op == 8 || op == 2 || op == 1) && jr >= ocs && jr < ocs + olen) { myOp[u] = op; refB[u] = orf - ocs; readB[u] = ord - ocs; }
+                        }
+                    } else
                     for(int o = 0; o < nHere; o++) {
                         const int op = __builtin_amdgcn_readlane(opK, o), olen = __builtin_amdgcn_readlane(opLen, o);
                         if(!(op == 0 || op == 7 || op == 8 || op == 2 || op == 1) || olen == 0) continue;
@@ -414,6 +431,7 @@ __global__ __launch_bounds__(64, PL::LONG ? HLALA_PROJ_LONG_WPS : HLALA_PROJ_WPS
         WSYNC();
 
         if constexpr (PL::LONG && PJ_FINE) if(B.dbg) { dbgN[0] = nOps; dbgN[1] = nCols; }
+        PJ_F(10);
         PJ_T(1);
         // ---------------- trim leading / trailing insertion columns, pad skipped levels (:2518-2579)
         int n1 = 0;

@@ -37,8 +37,8 @@ if os.environ.get('HLALA_DEBUG'):
             if cnt[k]: print("  2^%d: %d reads, mean %.2f M cycles, %.1f %% of the cycles" % (k, cnt[k], sm[k] / cnt[k] / 1e6, 100.0 * sm[k] / sm.sum()))
     fine = np.array(dbg[4300:4312], dtype=np.float64) * 4096
     if fine.sum() > 0 and t[7] > 0:
-        nm = ["window staging", "level -> column table", "segment list", "short segments, one per lane", "long segments, wave-wide", "chunked / sequential form", "pick reset", "segment backtrace", "outputs"]
-        print("pieces, k cycles per read: " + "; ".join("%s %.0f" % (nm[i], fine[i] / t[7] / 1e3) for i in range(9)))
+        nm = ["window staging", "level -> column table", "segment list", "short segments, one per lane", "long segments, wave-wide", "chunked / sequential form", "pick reset", "segment backtrace", "outputs", "CIGAR pass 1", "CIGAR pass 2"]
+        print("pieces, k cycles per read: " + "; ".join("%s %.0f" % (nm[i], fine[i] / t[7] / 1e3) for i in range(11)))
     hh = np.array(list(buf)[24:28], dtype=np.float64)
     if hh[2] > 0:
         print("level-by-level form: %.0f chunks per read (all reads), %.1f levels per chunk; per chunk %.0f cycles of staging + %.0f of level loops (%.0f per level)" % (hh[2] / t[7], hh[3] / hh[2], hh[0] / hh[2], hh[1] / hh[2], hh[1] / hh[3]))
