@@ -215,7 +215,7 @@ constexpr bool PJ_FINE = false;
 
 constexpr int PJL_U = 4;            // rows of lanes the copy loops of the long-read instantiation keep in flight (registers: the kernel is compiled for five wavefronts per SIMD)
 #ifndef HLALA_PROJ_LONG_WPS
-#define HLALA_PROJ_LONG_WPS 5      // wavefronts per SIMD the long-read instantiation is compiled for (5: 95 registers, 2 spilled -- with 8.6 KB of LDS 18 blocks per CU; 4: 123 registers, 16 blocks: 50.0 against 46.5 ms per 50 000 reads)
+#define HLALA_PROJ_LONG_WPS 5      // wavefronts per SIMD the long-read instantiation is compiled for (5: 96 registers, 3 spilled, 20 blocks of 6.3 KB of LDS per CU; 4: 123 registers, 16 blocks -- 50.0 against 43.5 ms per 50 000 reads)
 #endif
 #ifndef HLALA_PROJ_WPS
 #define HLALA_PROJ_WPS 2           // the LDS layouts: the compiler's own choice (153 registers = three wavefronts per SIMD; their 11.7 KB of LDS allow 13 blocks per CU)
