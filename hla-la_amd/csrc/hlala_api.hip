@@ -757,7 +757,14 @@ static int batch_create_impl(hlala_ctx* c, const hlala_batch_in* in, hlala_batch
             viol[(size_t)t] = v;
         };
         if(nt == 1) work(0);
-        else { std::vector<std::thread> th; for(int t = 1; t < nt; t++) th.emplace_back(work, t); work(0); for(std::thread& x : th) x.join(); }
+        else {
+            // (no exception may leave a C entry point: a thread that cannot be started -- a process at its thread limit -- leaves its share to the calling thread)
+            std::vector<std::thread> th; int started = 0;
+            try { th.reserve((size_t)nt); for(int t = 1; t < nt; t++) { th.emplace_back(work, t); started++; } } catch(...) { }
+            work(0);
+            for(int t = started + 1; t < nt; t++) work(t);
+            for(std::thread& x : th) x.join();
+        }
         if(nr > 0) { read_off32[nr] = (int)(in->read_off[nr] - rb0); chain_off32[nr] = (int)(in->chain_off[nr] - cb0); }
         if(nc > 0) cigar_off32[nc] = (int)(in->cigar_off[cb0 + nc] - gb0);
         long long first[5] = {-1, -1, -1, -1, -1}; int kind1 = 0;
