@@ -23,6 +23,9 @@
 //   sort    the complete units of all partitions are put into read-name order by a parallel sample sort (byte-wise comparison then
 //           length = std::string's operator<, the order of the reference's std::map)
 //   layout  prefix sums over the units, then the output arrays are filled in parallel
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -53,6 +56,14 @@ thread_local std::string g_bam_error;
 typedef std::chrono::steady_clock Clock;
 double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
 
+// HLALA_BAM_NICE=n: the decoder's worker threads lower their own priority by n (setpriority on the thread).  A host program that decodes one sample while it aligns another
+// keeps the threads that feed the GPU ahead of the decoder's -- there are twice as many of those as the control group grants CPUs (experiment: tools/gpu_r6_e2e2.sh).
+static void worker_nice()
+{
+    static const int n = []() { const char* e = getenv("HLALA_BAM_NICE"); return e ? atoi(e) : 0; }();
+    if(n > 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), n);
+}
+
 // run fn(task) for task in [0, n) on up to T threads (dynamic distribution); the first exception is rethrown on the caller's thread
 template <class F>
 void parallel_for(int64_t n, int T, F fn)
@@ -65,7 +76,7 @@ void parallel_for(int64_t n, int T, F fn)
     std::vector<std::thread> th;
     try {
         for(int t = 0; t < T; t++) th.emplace_back([&, t]() {
-            try { for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
+            try { worker_nice(); for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
             catch(...) { std::lock_guard<std::mutex> g(em); if(!err) err = std::current_exception(); next.store(n); }
         });
     } catch(...) { next.store(n); for(auto& x : th) x.join(); throw; }       // (a thread that cannot be started: the ones running are joined, not destroyed joinable)
@@ -86,7 +97,7 @@ void parallel_for_beside(int64_t n, int T, F fn, M beside)
     std::vector<std::thread> th;
     try {
         for(int t = 0; t < T; t++) th.emplace_back([&, t]() {
-            try { for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
+            try { worker_nice(); for(;;) { int64_t i = next.fetch_add(1); if(i >= n) break; fn(i, t); } }
             catch(...) { std::lock_guard<std::mutex> g(em); if(!err) err = std::current_exception(); next.store(n); stop.store(true); }
         });
     } catch(...) { next.store(n); stop.store(true); for(auto& x : th) x.join(); throw; }
